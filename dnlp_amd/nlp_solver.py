@@ -1,0 +1,270 @@
+"""NLP standard form, device oracles and the HIP solver interface.
+
+Mirror of the reference's `NLPsolver` / `Bounds` / `Oracles`
+(reductions/solvers/nlp_solvers/nlp_solver.py:34-427) and of the `IPOPT` solver interface
+(nlp_solvers/ipopt_nlpif.py:25-184) for the MI355X path:
+
+* `Bounds` reproduces cl/cu per constraint kind, lb/ub from `bounds` ∩ nonneg/nonpos and the
+  initial point rule (value, else midpoint / bound±1 / 0) — nlp_solver.py:81-178.
+* `DeviceOracles` has the reference's seven callback names (`objective`, `gradient`,
+  `constraints`, `jacobian`, `jacobianstructure`, `hessian`, `hessianstructure`,
+  `intermediate`), but every evaluation is one call into libdnlp_hip.so (HIP kernels over
+  the tape lowered once by `lowering.lower_problem`), not a Python tree walk.
+* `HIPNLP.solve_via_data / invert` keep the reference's signatures, option names, returned
+  record (`status`, `obj_val`, `x`, `iterations`, plus cyipopt's `g`, `mult_g`,
+  `mult_x_L`, `mult_x_U`) and IPOPT status integers; the interior-point loop itself runs
+  on the device (`dnlp_solve`).
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+
+from . import settings as s
+from .constraints import (Equality, Inequality, NonPos, lower_equality,
+                          lower_ineq_to_nonneg, nonpos2nonneg)
+from .lowering import lower_problem
+from .tape import serialize, tape_arrays
+
+
+class Bounds:
+    """reference nlp_solver.py:81-178 (including its two variable orders: bounds and x0
+    follow the pre-lowering problem's variable order, oracles the lowered problem's)."""
+
+    def __init__(self, problem):
+        self.problem = problem
+        self.main_var = problem.variables()
+        self.get_constraint_bounds()
+        self.get_variable_bounds()
+        self.construct_initial_point()
+
+    def get_constraint_bounds(self):
+        lower, upper, new_constr = [], [], []
+        for constraint in self.problem.constraints:
+            if isinstance(constraint, Equality):
+                lower.extend([0.0] * constraint.size)
+                upper.extend([0.0] * constraint.size)
+                new_constr.append(lower_equality(constraint))
+            elif isinstance(constraint, Inequality):
+                lower.extend([0.0] * constraint.size)
+                upper.extend([np.inf] * constraint.size)
+                new_constr.append(lower_ineq_to_nonneg(constraint))
+            elif isinstance(constraint, NonPos):
+                lower.extend([0.0] * constraint.size)
+                upper.extend([np.inf] * constraint.size)
+                new_constr.append(nonpos2nonneg(constraint))
+            else:
+                raise ValueError("Constraint type %s is not supported on the NLP path."
+                                 % type(constraint).__name__)
+        self.new_problem = self.problem.copy([self.problem.objective, new_constr])
+        self.cl = np.array(lower, dtype=float)
+        self.cu = np.array(upper, dtype=float)
+
+    def get_variable_bounds(self):
+        var_lower, var_upper = [], []
+        for var in self.main_var:
+            size = var.size
+            if var.bounds:
+                lb = var.bounds[0].flatten(order="F")
+                ub = var.bounds[1].flatten(order="F")
+                if var.attributes["nonneg"]:
+                    lb = np.maximum(lb, 0)
+                if var.attributes["nonpos"]:
+                    ub = np.minimum(ub, 0)
+                var_lower.extend(lb)
+                var_upper.extend(ub)
+            else:
+                var_lower.extend([0.0] * size if var.is_nonneg() else [-np.inf] * size)
+                var_upper.extend([0.0] * size if var.is_nonpos() else [np.inf] * size)
+        self.lb = np.array(var_lower, dtype=float)
+        self.ub = np.array(var_upper, dtype=float)
+
+    def construct_initial_point(self):
+        initial_values = []
+        offset = 0
+        for var in self.problem.variables():
+            if var.value is not None:
+                initial_values.append(np.atleast_1d(var.value).flatten(order="F"))
+            else:
+                lb = self.lb[offset:offset + var.size]
+                ub = self.ub[offset:offset + var.size]
+                lb_finite = np.isfinite(lb)
+                ub_finite = np.isfinite(ub)
+                lb0 = np.where(lb_finite, lb, 0.0)
+                ub0 = np.where(ub_finite, ub, 0.0)
+                init = (lb_finite * ub_finite * 0.5 * (lb0 + ub0) +
+                        lb_finite * (~ub_finite) * (lb0 + 1.0) +
+                        (~lb_finite) * ub_finite * (ub0 - 1.0))
+                initial_values.append(init)
+            offset += var.size
+        self.x0 = np.concatenate(initial_values, axis=0) if initial_values else np.zeros(0)
+
+
+class InverseData:
+    """Variable offsets/shapes of the lowered problem (reference inverse_data.py)."""
+
+    def __init__(self, problem):
+        self.var_offsets, self.var_shapes = {}, {}
+        off = 0
+        for v in problem.variables():
+            self.var_offsets[v.id] = off
+            self.var_shapes[v.id] = v.shape
+            off += v.size
+        self.x_length = off
+        self.offset = 0.0
+
+
+def build_nlp_data(problem):
+    """Bounds + tape lowering for a smooth-canonical problem.  Returns the data dict without
+    touching the device (used by CPU tests and by `HIPNLP.apply`)."""
+    bounds = Bounds(problem)
+    new_problem = bounds.new_problem
+    variables = new_problem.variables()
+    if [id(v) for v in variables] != [id(v) for v in bounds.main_var]:
+        warnings.warn("Variable order of the lowered constraints differs from the canonical "
+                      "problem's; bounds and x0 follow the reference's ordering quirk "
+                      "(nlp_solver.py:84,116,163 vs :200).")
+    tape = lower_problem(new_problem.objective.expr,
+                         [c.args[0] for c in new_problem.constraints], variables)
+    inverse_data = InverseData(new_problem)
+    data = {
+        "problem": new_problem,
+        "cl": bounds.cl, "cu": bounds.cu, "lb": bounds.lb, "ub": bounds.ub, "x0": bounds.x0,
+        "tape": tape,
+    }
+    data["tape_arrays"] = tape_arrays(tape, bounds.x0, bounds.lb, bounds.ub, bounds.cl, bounds.cu)
+    return data, inverse_data
+
+
+class DeviceOracles:
+    """The reference's `Oracles` protocol (nlp_solver.py:181-427) over the device tape."""
+
+    def __init__(self, handle, n, m):
+        self._h = handle
+        self.n, self.m = n, m
+        self.iterations = 0
+        self._jac_struct = None
+        self._hess_struct = None
+
+    def objective(self, x):
+        return self._h.eval_f(x)
+
+    def gradient(self, x):
+        return self._h.eval_grad_f(x)
+
+    def constraints(self, x):
+        return self._h.eval_g(x)
+
+    def jacobianstructure(self):
+        if self._jac_struct is None:
+            self._jac_struct = self._h.jac_structure()
+        return self._jac_struct
+
+    def jacobian(self, x):
+        return self._h.eval_jac_g(x)
+
+    def hessianstructure(self):
+        if self._hess_struct is None:
+            self._hess_struct = self._h.hess_structure()
+        return self._hess_struct
+
+    def hessian(self, x, duals, obj_factor):
+        return self._h.eval_h(x, duals, obj_factor)
+
+    def intermediate(self, alg_mod, iter_count, obj_value, inf_pr, inf_du, mu, d_norm,
+                     regularization_size, alpha_du, alpha_pr, ls_trials):
+        self.iterations = iter_count
+
+
+class HIPNLP:
+    """NLP solver interface for the on-device interior-point method.  Same role, method
+    names and record layout as the reference's `IPOPT(NLPsolver)` (ipopt_nlpif.py:25-184)."""
+
+    # IPOPT ApplicationReturnStatus -> status string (reference ipopt_nlpif.py:31-61)
+    STATUS_MAP = {
+        0: s.OPTIMAL, 1: s.OPTIMAL_INACCURATE, 6: s.OPTIMAL,
+        2: s.INFEASIBLE, 4: s.UNBOUNDED,
+        3: s.SOLVER_ERROR, -2: s.SOLVER_ERROR, -3: s.SOLVER_ERROR, -13: s.SOLVER_ERROR,
+        -100: s.SOLVER_ERROR, -101: s.SOLVER_ERROR, -199: s.SOLVER_ERROR,
+        5: s.USER_LIMIT, -1: s.USER_LIMIT, -4: s.USER_LIMIT, -5: s.USER_LIMIT,
+        -102: s.USER_LIMIT,
+        -10: s.SOLVER_ERROR, -11: s.SOLVER_ERROR, -12: s.SOLVER_ERROR,
+    }
+
+    # defaults of the reference (ipopt_nlpif.py:153-160)
+    DEFAULT_OPTIONS = {
+        "mu_strategy": "adaptive",
+        "tol": 1e-7,
+        "bound_relax_factor": 0.0,
+        "hessian_approximation": "exact",
+        "derivative_test": "none",
+        "least_square_init_duals": "yes",
+    }
+
+    def name(self):
+        return s.IPOPT
+
+    def import_solver(self):
+        from . import _capi
+        _capi.load()
+
+    def accepts(self, problem):
+        return problem.is_dnlp()
+
+    def apply(self, problem):
+        """reference nlp_solver.py:47-79: builds the data dict incl. the oracles."""
+        from . import _capi
+        data, inverse_data = build_nlp_data(problem)
+        blob = serialize(data["tape_arrays"])
+        handle = _capi.DeviceProblem(blob, data["tape"])
+        oracles = DeviceOracles(handle, len(data["x0"]), len(data["cl"]))
+        data["handle"] = handle
+        data["oracles"] = oracles
+        for k in ("objective", "gradient", "constraints", "jacobian", "jacobianstructure",
+                  "hessian", "hessianstructure"):
+            data[k] = getattr(oracles, k)
+        return data, inverse_data
+
+    def solve_via_data(self, data, warm_start: bool, verbose: bool, solver_opts,
+                       solver_cache=None):
+        """reference ipopt_nlpif.py:104-174.  `warm_start` is accepted and unused there too."""
+        options = dict(self.DEFAULT_OPTIONS)
+        if solver_opts:
+            options.update(solver_opts)
+        if not verbose and "print_level" not in options:
+            options["print_level"] = 3 if False else 0
+        if verbose and "print_level" not in options:
+            options["print_level"] = 5
+        handle = data["handle"]
+        for k, v in options.items():
+            handle.set_option(k, v)
+        info = handle.solve(data["x0"])
+        data["oracles"].iterations = info["iterations"]
+        return info
+
+    def invert(self, solution, inverse_data):
+        """reference ipopt_nlpif.py:75-102 (duals are not surfaced there either)."""
+        attr = {s.NUM_ITERS: solution["iterations"]}
+        if "solve_time" in solution:
+            attr[s.SOLVE_TIME] = solution["solve_time"]
+        if "all_objs_from_best_of" in solution:
+            attr[s.EXTRA_STATS] = {"all_objs_from_best_of": solution["all_objs_from_best_of"]}
+        status = self.STATUS_MAP[solution["status"]]
+        if status in s.SOLUTION_PRESENT:
+            opt_val = solution["obj_val"] + inverse_data.offset
+            primal_vars = {}
+            x_opt = solution["x"]
+            for vid, offset in inverse_data.var_offsets.items():
+                shape = inverse_data.var_shapes[vid]
+                size = int(np.prod(shape, dtype=int))
+                primal_vars[vid] = np.reshape(x_opt[offset:offset + size], shape, order="F")
+            return {"status": status, "opt_val": opt_val, "primal_vars": primal_vars,
+                    "dual_vars": {}, "attr": attr}
+        opt_val = {s.INFEASIBLE: np.inf, s.UNBOUNDED: -np.inf}.get(status)
+        return {"status": status, "opt_val": opt_val, "primal_vars": {}, "dual_vars": {},
+                "attr": attr}
+
+    def cite(self, data):
+        return ("Interior-point filter line-search algorithm of Waechter & Biegler, Math. "
+                "Prog. 106(1), 2006 (IPOPT), re-implemented on-device for MI355X.")
