@@ -1,0 +1,275 @@
+"""ctypes binding of libdnlp_hip.so (C ABI: include/dnlp_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc --offload-arch=gfx950).  There
+is no CPU fallback: `load()` raises DeviceUnavailableError when the shared library is missing
+or no HIP device is visible, and every solve goes through it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .error import DeviceUnavailableError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdnlp_hip.so")
+
+_dbl_p = C.POINTER(C.c_double)
+_i32_p = C.POINTER(C.c_int32)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(_dbl_p)
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(_i32_p)
+
+
+class CApi:
+    """Typed access to one shared library exporting the `<prefix>*` entry points."""
+
+    def __init__(self, lib_path: str, prefix: str = "dnlp_"):
+        self.lib = C.CDLL(lib_path)
+        self.prefix = prefix
+        f = self._fn
+        f("last_error", C.c_char_p, [])
+        f("create", C.c_void_p, [C.c_void_p, C.c_size_t, C.c_int])
+        f("destroy", None, [C.c_void_p])
+        f("bind_dense", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64])
+        f("dims", C.c_int, [C.c_void_p] + [C.POINTER(C.c_int64)] * 4)
+        f("bounds", C.c_int, [C.c_void_p] + [_dbl_p] * 5)
+        f("eval_f", C.c_int, [C.c_void_p, _dbl_p, C.c_int, _dbl_p])
+        f("eval_grad_f", C.c_int, [C.c_void_p, _dbl_p, C.c_int, _dbl_p])
+        f("eval_g", C.c_int, [C.c_void_p, _dbl_p, C.c_int, _dbl_p])
+        f("eval_jac_g", C.c_int, [C.c_void_p, _dbl_p, C.c_int, _i32_p, _i32_p, _dbl_p])
+        f("eval_h", C.c_int, [C.c_void_p, _dbl_p, C.c_int, C.c_double, _dbl_p, C.c_int, _i32_p,
+                              _i32_p, _dbl_p])
+        f("set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p])
+        f("solve", C.c_int, [C.c_void_p] + [_dbl_p] * 6 + [C.POINTER(C.c_int)])
+        f("ipm_begin", C.c_int, [C.c_void_p, _dbl_p])
+        f("ipm_step", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)])
+        f("ipm_finish", C.c_int, [C.c_void_p] + [_dbl_p] * 6 + [C.POINTER(C.c_int)])
+        f("get_stats", C.c_int, [C.c_void_p, _dbl_p, C.c_int])
+        f("get_log", C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t])
+
+    def _fn(self, name, restype, argtypes):
+        fn = getattr(self.lib, self.prefix + name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+        setattr(self, name, fn)
+        return fn
+
+    def error(self) -> str:
+        msg = self.last_error()
+        return msg.decode() if msg else ""
+
+
+_api = None
+
+
+def load() -> CApi:
+    """Load libdnlp_hip.so; fail loudly when it (or a GPU) is not there."""
+    global _api
+    if _api is not None:
+        return _api
+    if not os.path.exists(LIB_PATH):
+        raise DeviceUnavailableError(
+            "%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  dnlp_amd has no CPU fallback." % LIB_PATH)
+    api = CApi(LIB_PATH, "dnlp_")
+    lib = api.lib
+    lib.dnlp_device_count.restype = C.c_int
+    lib.dnlp_version.restype = C.c_char_p
+    lib.dnlp_dev_alloc.restype = C.c_int
+    lib.dnlp_dev_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.dnlp_dev_free.restype = C.c_int
+    lib.dnlp_dev_free.argtypes = [C.c_int, C.c_void_p]
+    lib.dnlp_dev_copy.restype = C.c_int
+    lib.dnlp_dev_copy.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    lib.dnlp_gen_symmetric.restype = C.c_int
+    lib.dnlp_gen_symmetric.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_uint64,
+                                       C.c_double, C.c_void_p]
+    lib.dnlp_dev_symv.restype = C.c_int
+    lib.dnlp_dev_symv.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, _dbl_p, _dbl_p]
+    lib.dnlp_ldlt_host.restype = C.c_int
+    lib.dnlp_ldlt_host.argtypes = [C.c_int, _dbl_p, C.c_int64, C.c_int64, _i32_p, C.c_int,
+                                   C.POINTER(C.c_int), C.POINTER(C.c_int), _dbl_p, _dbl_p, _dbl_p]
+    lib.dnlp_ldlt_device.restype = C.c_int
+    lib.dnlp_ldlt_device.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64,
+                                     C.POINTER(C.c_int), C.POINTER(C.c_int), _dbl_p, _dbl_p]
+    _api = api
+    return api
+
+
+def device_count() -> int:
+    try:
+        return int(load().lib.dnlp_device_count())
+    except (DeviceUnavailableError, OSError):
+        return 0
+
+
+def require_device(device: int = 0) -> CApi:
+    api = load()
+    n = int(api.lib.dnlp_device_count())
+    if n <= device:
+        raise DeviceUnavailableError(
+            "no HIP device %d visible (found %d); dnlp_amd has no CPU fallback." % (device, n))
+    return api
+
+
+def current_device() -> int:
+    """One process per GPU: LOCAL_RANK selects the device (torch.distributed launch)."""
+    return int(os.environ.get("DNLP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+class ProblemHandle:
+    """A created `<prefix>problem` with numpy-friendly methods (shared by the product binding
+    and the test oracle binding)."""
+
+    def __init__(self, api: CApi, blob: bytes, device: int = 0):
+        self.api = api
+        self._blob = blob   # keep alive
+        self.ptr = api.create(blob, len(blob), device)
+        if not self.ptr:
+            raise RuntimeError("%screate failed: %s" % (api.prefix, api.error()))
+        n, m, nj, nh = (C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64())
+        api.dims(self.ptr, C.byref(n), C.byref(m), C.byref(nj), C.byref(nh))
+        self.n, self.m, self.nnz_jac, self.nnz_hess = n.value, m.value, nj.value, nh.value
+
+    def close(self):
+        if self.ptr:
+            self.api.destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.api.error()))
+
+    @staticmethod
+    def _x(x):
+        return np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
+
+    def bind_dense(self, const_id: int, device_ptr: int, ld: int):
+        self._check(self.api.bind_dense(self.ptr, const_id, C.c_void_p(device_ptr), ld), "bind_dense")
+
+    def eval_f(self, x):
+        x = self._x(x)
+        out = C.c_double()
+        self._check(self.api.eval_f(self.ptr, _dp(x), 1, C.byref(out)), "eval_f")
+        return out.value
+
+    def eval_grad_f(self, x):
+        x = self._x(x)
+        out = np.empty(self.n)
+        self._check(self.api.eval_grad_f(self.ptr, _dp(x), 1, _dp(out)), "eval_grad_f")
+        return out
+
+    def eval_g(self, x):
+        x = self._x(x)
+        out = np.empty(self.m)
+        self._check(self.api.eval_g(self.ptr, _dp(x), 1, _dp(out)), "eval_g")
+        return out
+
+    def jac_structure(self):
+        r = np.empty(self.nnz_jac, np.int32)
+        c = np.empty(self.nnz_jac, np.int32)
+        self._check(self.api.eval_jac_g(self.ptr, None, 0, _ip(r), _ip(c), None), "eval_jac_g")
+        return r, c
+
+    def eval_jac_g(self, x):
+        x = self._x(x)
+        out = np.empty(self.nnz_jac)
+        self._check(self.api.eval_jac_g(self.ptr, _dp(x), 1, None, None, _dp(out)), "eval_jac_g")
+        return out
+
+    def hess_structure(self):
+        if self.nnz_hess < 0:
+            raise RuntimeError("Hessian too large for COO output")
+        r = np.empty(self.nnz_hess, np.int32)
+        c = np.empty(self.nnz_hess, np.int32)
+        self._check(self.api.eval_h(self.ptr, None, 0, 0.0, None, 0, _ip(r), _ip(c), None), "eval_h")
+        return r, c
+
+    def eval_h(self, x, lagrange, obj_factor):
+        x = self._x(x)
+        lam = self._x(lagrange) if self.m else np.zeros(1)
+        out = np.empty(self.nnz_hess)
+        self._check(self.api.eval_h(self.ptr, _dp(x), 1, float(obj_factor), _dp(lam), 1, None, None,
+                                    _dp(out)), "eval_h")
+        return out
+
+    def set_option(self, key, val):
+        if isinstance(val, bool):
+            val = "yes" if val else "no"
+        rc = self.api.set_option(self.ptr, str(key).encode(), str(val).encode())
+        if rc != 0:
+            raise ValueError("Invalid solver option %s=%s" % (key, val))
+
+    def _outputs(self):
+        return (np.empty(self.n), C.c_double(), np.empty(max(self.m, 1)), np.empty(max(self.m, 1)),
+                np.empty(self.n), np.empty(self.n), C.c_int())
+
+    def _info(self, status, x, obj, g, mg, zl, zu, iters):
+        st = np.zeros(16)
+        self.api.get_stats(self.ptr, _dp(st), 16)
+        return {"status": int(status), "x": x, "obj_val": float(obj.value), "g": g[:self.m],
+                "mult_g": mg[:self.m], "mult_x_L": zl, "mult_x_U": zu, "iterations": int(iters.value),
+                "solve_time": float(st[2]), "stats": st}
+
+    def solve(self, x0):
+        x, obj, g, mg, zl, zu, iters = self._outputs()
+        x[:] = self._x(x0)
+        status = self.api.solve(self.ptr, _dp(x), C.byref(obj), _dp(g), _dp(mg), _dp(zl), _dp(zu),
+                                C.byref(iters))
+        if status == -199:
+            raise RuntimeError("solve failed: %s" % self.api.error())
+        return self._info(status, x, obj, g, mg, zl, zu, iters)
+
+    def ipm_begin(self, x0):
+        x0 = self._x(x0)
+        rc = self.api.ipm_begin(self.ptr, _dp(x0))
+        if rc == -199:
+            raise RuntimeError("ipm_begin failed: %s" % self.api.error())
+        return rc
+
+    def ipm_step(self, max_steps=1):
+        done = C.c_int()
+        rc = self.api.ipm_step(self.ptr, int(max_steps), C.byref(done))
+        if rc == -199:
+            raise RuntimeError("ipm_step failed: %s" % self.api.error())
+        return rc, done.value
+
+    def ipm_finish(self):
+        x, obj, g, mg, zl, zu, iters = self._outputs()
+        status = self.api.ipm_finish(self.ptr, _dp(x), C.byref(obj), _dp(g), _dp(mg), _dp(zl), _dp(zu),
+                                     C.byref(iters))
+        return self._info(status, x, obj, g, mg, zl, zu, iters)
+
+    def log(self) -> str:
+        need = self.api.get_log(self.ptr, None, 0)
+        buf = C.create_string_buffer(need + 1)
+        self.api.get_log(self.ptr, buf, need + 1)
+        return buf.value.decode()
+
+
+class DeviceProblem(ProblemHandle):
+    """Product handle: created on the MI355X selected by LOCAL_RANK / DNLP_DEVICE."""
+
+    def __init__(self, blob: bytes, tape=None, device: int = None):
+        dev = current_device() if device is None else device
+        api = require_device(dev)
+        super().__init__(api, blob, dev)
+        self.device = dev
+        if tape is not None:
+            for k, dc in enumerate(tape.dense_consts):
+                if dc.device is not None:
+                    self.bind_dense(k, dc.device.ptr, dc.device.ld)

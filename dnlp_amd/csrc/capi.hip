@@ -1,0 +1,98 @@
+// libdnlp_hip.so — the C ABI of include/dnlp_hip.h instantiated over the HIP execution space.
+#include "ldlt_blocked.h"
+#include "capi_impl.h"
+
+DNLP_DEFINE_CAPI(dnlp_, dnlp::HipExec)
+
+using namespace dnlp;
+
+extern "C" {
+
+int dnlp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* dnlp_version(void) { return "dnlp_amd 0.1.0 (gfx950)"; }
+
+int dnlp_dev_alloc(int device, size_t bytes, void** out) {
+  DNLP_TRY(DNLP_HIP_CHECK(hipSetDevice(device)); DNLP_HIP_CHECK(hipMalloc(out, bytes)); return 0;)
+}
+int dnlp_dev_free(int device, void* p) {
+  DNLP_TRY(DNLP_HIP_CHECK(hipSetDevice(device)); DNLP_HIP_CHECK(hipFree(p)); return 0;)
+}
+int dnlp_dev_copy(int device, void* dst, const void* src, size_t bytes, int kind) {
+  DNLP_TRY(DNLP_HIP_CHECK(hipSetDevice(device));
+           DNLP_HIP_CHECK(hipMemcpy(dst, src, bytes, kind == 0 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+           return 0;)
+}
+
+int dnlp_gen_symmetric(int device, double* A, int64_t n, int64_t ld, uint64_t seed, double spike, double* dv) {
+  DNLP_TRY(
+    DNLP_HIP_CHECK(hipSetDevice(device));
+    double* v = dv;
+    if (!v) DNLP_HIP_CHECK(hipMalloc(&v, sizeof(double) * n));
+    hipLaunchKernelGGL(gen_vec_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, 0, v, n, seed);
+    const i64 nrb = (n + 255) / 256;
+    hipLaunchKernelGGL(gen_sym_kernel, dim3(static_cast<unsigned>(nrb * n)), dim3(256), 0, 0, A, n, ld, seed, spike, v, nrb);
+    DNLP_HIP_CHECK(hipDeviceSynchronize());
+    if (!dv) DNLP_HIP_CHECK(hipFree(v));
+    return 0;)
+}
+
+int dnlp_dev_symv(int device, const double* A, int64_t n, int64_t ld, const double* x, double* y) {
+  DNLP_TRY(
+    HipExec ex(device);
+    double* dx = ex.alloc<double>(static_cast<size_t>(n));
+    double* dy = ex.alloc<double>(static_cast<size_t>(n));
+    ex.h2d(dx, x, sizeof(double) * n);
+    ex.gemv_sym(n, A, ld, dx, dy);
+    ex.d2h(y, dy, sizeof(double) * n);
+    return 0;)
+}
+
+int dnlp_ldlt_host(int device, double* A, int64_t n, int64_t ld, int32_t* ipiv, int pivoted, int* nneg, int* nzero,
+                   const double* rhs, double* sol, double* seconds) {
+  DNLP_TRY(
+    HipExec ex(device);
+    const i64 ldd = (n + 7) / 8 * 8;
+    double* dA = ex.alloc<double>(static_cast<size_t>(ldd) * n);
+    i32* dp = ex.alloc<i32>(static_cast<size_t>(n));
+    double* db = ex.alloc<double>(static_cast<size_t>(n));
+    DNLP_HIP_CHECK(hipMemcpy2DAsync(dA, ldd * 8, A, ld * 8, n * 8, n, hipMemcpyHostToDevice, ex.stream));
+    ex.sync();
+    HipExec::LdltWork w;
+    ex.ldlt_prepare(w, n, ldd, pivoted != 0);
+    double t0 = now_sec();
+    bool ok = ex.ldlt_factor(w, dA, n, ldd, dp, pivoted != 0, nneg, nzero);
+    ex.sync();
+    if (seconds) *seconds = now_sec() - t0;
+    if (rhs && sol) {
+      ex.h2d(db, rhs, sizeof(double) * n);
+      ex.ldlt_solve(w, dA, n, ldd, dp, pivoted != 0, db);
+      ex.d2h(sol, db, sizeof(double) * n);
+    }
+    DNLP_HIP_CHECK(hipMemcpy2DAsync(A, ld * 8, dA, ldd * 8, n * 8, n, hipMemcpyDeviceToHost, ex.stream));
+    if (ipiv) { ex.sync(); ex.d2h(ipiv, dp, sizeof(i32) * n); }
+    ex.sync();
+    return ok ? 0 : 1;)
+}
+
+int dnlp_ldlt_device(int device, double* dA, int64_t n, int64_t ld, int* nneg, int* nzero, double* seconds,
+                     double* update_seconds) {
+  DNLP_TRY(
+    HipExec ex(device);
+    BlockedLdlt bl;
+    bl.init(&ex, n, ld);
+    bl.time_updates = update_seconds != nullptr;
+    ex.sync();
+    double t0 = now_sec();
+    bool ok = bl.factor(dA, nneg, nzero);
+    ex.sync();
+    if (seconds) *seconds = now_sec() - t0;
+    if (update_seconds) *update_seconds = bl.last_update_seconds;
+    return ok ? 0 : 1;)
+}
+
+}  // extern "C"

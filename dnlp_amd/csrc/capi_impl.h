@@ -1,0 +1,237 @@
+// Implementation of the C ABI of include/dnlp_hip.h over an execution space E.
+// libdnlp_hip.so instantiates it with HipExec (capi.hip).  The test oracle instantiates the
+// same text with its host space under the prefix orc_ (oracle/oracle_lib.cpp).
+#pragma once
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "ipm_core.h"
+#include "kkt_dense.h"
+
+namespace dnlp {
+
+inline std::string& tls_error() {
+  static thread_local std::string e;
+  return e;
+}
+
+template <class E>
+struct ProblemT {
+  E ex;
+  std::unique_ptr<TapeBlob> blob;
+  Model<E> model;
+  DenseKkt<E> kkt;
+  std::unique_ptr<Ipm<E, DenseKkt<E>>> ipm;
+  IpmOptions opt;
+  i64 pivot_max_n = 2048;
+  double *dx = nullptr, *dlam = nullptr, *dg = nullptr, *dgrad = nullptr, *djac = nullptr, *dh = nullptr;
+  bool swept = false, kkt_ready = false;
+
+  explicit ProblemT(int device) : ex(device) {}
+
+  void create(const void* data, size_t len) {
+    blob.reset(new TapeBlob(data, len));
+    model.init(&ex, *blob);
+    const auto& t = model.t;
+    dx = ex.template alloc<double>(static_cast<size_t>(t.N));
+    dlam = ex.template alloc<double>(static_cast<size_t>(t.m + 1));
+    dg = ex.template alloc<double>(static_cast<size_t>(t.m + 1));
+    dgrad = ex.template alloc<double>(static_cast<size_t>(t.N));
+    djac = ex.template alloc<double>(static_cast<size_t>(t.nnzJ + 1));
+    dh = ex.template alloc<double>(static_cast<size_t>(t.nnzH + 1));
+  }
+
+  void load_x(const double* x, int new_x, bool need_h = false) {
+    (void)need_h;
+    if (new_x || !swept) {
+      ex.h2d(dx, x, sizeof(double) * static_cast<size_t>(model.t.N));
+      model.sweep(dx, false);
+      swept = true;
+    }
+  }
+
+  void ensure_ipm() {
+    if (!kkt_ready) {
+      kkt.pivot_max_n = pivot_max_n;
+      kkt.init(&ex, model.t.N, model.t.m);
+      kkt_ready = true;
+    }
+    if (!ipm) ipm.reset(new Ipm<E, DenseKkt<E>>(&ex, &model, &kkt));
+    ipm->opt = opt;
+  }
+
+  int set_option(const std::string& k, const std::string& v) {
+    auto num = [&]() { return std::strtod(v.c_str(), nullptr); };
+    auto yes = [&]() { return v == "yes" || v == "1" || v == "true" || v == "True"; };
+    if (k == "tol") opt.tol = num();
+    else if (k == "max_iter") opt.max_iter = static_cast<int>(num());
+    else if (k == "mu_strategy") {
+      if (v == "adaptive") opt.mu_strategy = 1;
+      else if (v == "monotone") opt.mu_strategy = 0;
+      else return -12;
+    } else if (k == "mu_init") opt.mu_init = num();
+    else if (k == "bound_relax_factor") opt.bound_relax_factor = num();
+    else if (k == "bound_push") opt.bound_push = num();
+    else if (k == "bound_frac") opt.bound_frac = num();
+    else if (k == "hessian_approximation") { if (v != "exact") return -12; }
+    else if (k == "derivative_test") { /* accepted, unused: oracles are exact by construction */ }
+    else if (k == "least_square_init_duals") opt.least_square_init_duals = yes() ? 1 : 0;
+    else if (k == "print_level") opt.print_level = static_cast<int>(num());
+    else if (k == "dual_inf_tol") opt.dual_inf_tol = num();
+    else if (k == "constr_viol_tol") opt.constr_viol_tol = num();
+    else if (k == "compl_inf_tol") opt.compl_inf_tol = num();
+    else if (k == "acceptable_tol") opt.acceptable_tol = num();
+    else if (k == "acceptable_iter") opt.acceptable_iter = static_cast<int>(num());
+    else if (k == "acceptable_constr_viol_tol") opt.acceptable_constr_viol_tol = num();
+    else if (k == "acceptable_dual_inf_tol") opt.acceptable_dual_inf_tol = num();
+    else if (k == "acceptable_compl_inf_tol") opt.acceptable_compl_inf_tol = num();
+    else if (k == "nlp_scaling_method") opt.nlp_scaling = (v == "none") ? 0 : 1;
+    else if (k == "nlp_scaling_max_gradient") opt.nlp_scaling_max_gradient = num();
+    else if (k == "max_wall_time" || k == "max_cpu_time") opt.max_wall_time = num();
+    else if (k == "max_soc") opt.max_soc = static_cast<int>(num());
+    else if (k == "constr_mult_init_max") opt.constr_mult_init_max = num();
+    else if (k == "bound_mult_init_val") opt.bound_mult_init_val = num();
+    else if (k == "kkt_pivot_max_n") pivot_max_n = static_cast<i64>(num());
+    else if (k == "restoration") opt.restoration = yes() ? 1 : 0;
+    else if (k == "sb" || k == "linear_solver" || k == "print_user_options" || k == "print_timing_statistics")
+      { /* IPOPT options with no counterpart here: accepted and ignored */ }
+    else return -12;   // Invalid_Option, as IPOPT reports unknown names
+    return 0;
+  }
+};
+
+}  // namespace dnlp
+
+// ------------------------------------------------------------------------------------------
+// extern "C" surface generator.  PFX = dnlp_ for the product, orc_ for the oracle.
+#define DNLP_CAT2(a, b) a##b
+#define DNLP_CAT(a, b) DNLP_CAT2(a, b)
+#define DNLP_TRY(...)                                                   \
+  try { __VA_ARGS__ } catch (const std::exception& e) { dnlp::tls_error() = e.what(); return -199; } \
+  catch (...) { dnlp::tls_error() = "unknown exception"; return -199; }
+
+#define DNLP_DEFINE_CAPI(PFX, EXEC)                                                                  \
+  using DNLP_CAT(PFX, problem_t) = dnlp::ProblemT<EXEC>;                                             \
+  extern "C" {                                                                                       \
+  const char* DNLP_CAT(PFX, last_error)(void) { return dnlp::tls_error().c_str(); }                  \
+  void* DNLP_CAT(PFX, create)(const void* blob, size_t len, int device) {                            \
+    try {                                                                                            \
+      auto* p = new DNLP_CAT(PFX, problem_t)(device);                                                \
+      p->create(blob, len);                                                                          \
+      return p;                                                                                      \
+    } catch (const std::exception& e) { dnlp::tls_error() = e.what(); return nullptr; }              \
+  }                                                                                                  \
+  void DNLP_CAT(PFX, destroy)(void* vp) { delete static_cast<DNLP_CAT(PFX, problem_t)*>(vp); }      \
+  int DNLP_CAT(PFX, bind_dense)(void* vp, int cid, const double* dptr, int64_t ld) {                 \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    auto& t = p->model.t;                                                                            \
+    if (cid < 0 || cid >= static_cast<int>(t.dense_ptr.size())) { dnlp::tls_error() = "bad constant id"; return -1; } \
+    t.dense_ptr[cid] = dptr; t.dense_ld[cid] = ld; return 0;                                         \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, dims)(void* vp, int64_t* n, int64_t* m, int64_t* nj, int64_t* nh) {              \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    if (n) *n = p->model.t.N; if (m) *m = p->model.t.m;                                              \
+    if (nj) *nj = p->model.t.nnzJ; if (nh) *nh = p->model.t.coo_complete ? p->model.t.nnzH : -1;     \
+    return 0;                                                                                        \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, bounds)(void* vp, double* lb, double* ub, double* cl, double* cu, double* x0) {  \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    auto& t = p->model.t;                                                                            \
+    auto cp = [](double* d, const std::vector<double>& s) { if (d && !s.empty()) std::memcpy(d, s.data(), s.size() * 8); }; \
+    cp(lb, t.lb); cp(ub, t.ub); cp(cl, t.cl); cp(cu, t.cu); cp(x0, t.x0); return 0;                  \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, eval_f)(void* vp, const double* x, int new_x, double* f) {                       \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    DNLP_TRY(p->load_x(x, new_x); *f = p->model.eval_f_after_sweep(); return 0;)                     \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, eval_grad_f)(void* vp, const double* x, int new_x, double* grad) {               \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    DNLP_TRY(p->load_x(x, new_x); p->model.eval_grad_after_sweep(p->dgrad);                          \
+             p->ex.d2h(grad, p->dgrad, 8 * static_cast<size_t>(p->model.t.N)); return 0;)           \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, eval_g)(void* vp, const double* x, int new_x, double* g) {                       \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    DNLP_TRY(p->load_x(x, new_x); p->model.eval_g_after_sweep(p->dg);                                \
+             p->ex.d2h(g, p->dg, 8 * static_cast<size_t>(p->model.t.m)); return 0;)                  \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, eval_jac_g)(void* vp, const double* x, int new_x, int32_t* iRow, int32_t* jCol, double* vals) { \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    auto& t = p->model.t;                                                                            \
+    DNLP_TRY(                                                                                        \
+      if (!vals) {                                                                                   \
+        if (iRow) std::memcpy(iRow, t.h_jac_rows.data(), 4 * t.h_jac_rows.size());                   \
+        if (jCol) std::memcpy(jCol, t.h_jac_cols.data(), 4 * t.h_jac_cols.size());                   \
+        return 0;                                                                                    \
+      }                                                                                              \
+      p->load_x(x, new_x); p->model.eval_jac_after_sweep(p->djac);                                   \
+      p->ex.d2h(vals, p->djac, 8 * static_cast<size_t>(t.nnzJ)); return 0;)                          \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, eval_h)(void* vp, const double* x, int new_x, double sigma, const double* lambda, \
+                            int new_lambda, int32_t* iRow, int32_t* jCol, double* vals) {            \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    auto& t = p->model.t;                                                                            \
+    (void)new_lambda;                                                                                \
+    DNLP_TRY(                                                                                        \
+      if (!t.coo_complete) { dnlp::tls_error() = "Hessian too large for COO output; use dnlp_solve"; return -1; } \
+      if (!vals) {                                                                                   \
+        if (iRow) std::memcpy(iRow, t.h_hess_rows.data(), 4 * t.h_hess_rows.size());                 \
+        if (jCol) std::memcpy(jCol, t.h_hess_cols.data(), 4 * t.h_hess_cols.size());                 \
+        return 0;                                                                                    \
+      }                                                                                              \
+      (void)new_x;                                                                                   \
+      p->ex.h2d(p->dx, x, 8 * static_cast<size_t>(t.N));                                             \
+      if (t.m) p->ex.h2d(p->dlam, lambda, 8 * static_cast<size_t>(t.m));                             \
+      p->model.eval_hess(p->dx, sigma, p->dlam); p->swept = true;                                    \
+      p->model.hess_coo(p->dh);                                                                      \
+      p->ex.d2h(vals, p->dh, 8 * static_cast<size_t>(t.nnzH)); return 0;)                            \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, set_option)(void* vp, const char* k, const char* v) {                            \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    int rc = p->set_option(k, v);                                                                    \
+    if (rc) dnlp::tls_error() = std::string("invalid option ") + k + "=" + v;                        \
+    return rc;                                                                                       \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, ipm_begin)(void* vp, const double* x0) {                                         \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    DNLP_TRY(p->ensure_ipm(); p->swept = false; return p->ipm->begin(x0);)                           \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, ipm_step)(void* vp, int max_steps, int* done) {                                  \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    DNLP_TRY(int r = 99, k = 0;                                                                      \
+             for (; k < max_steps && r == 99; ++k) r = p->ipm->step();                               \
+             p->ex.sync(); if (done) *done = k; return r;)                                           \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, ipm_finish)(void* vp, double* x, double* obj, double* g, double* mg, double* mxl, \
+                                double* mxu, int* iters) {                                           \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    DNLP_TRY(p->ipm->extract(x, obj, mg, mxl, mxu, g);                                               \
+             if (iters) *iters = p->ipm->iter; return p->ipm->status;)                               \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, solve)(void* vp, double* x, double* obj, double* g, double* mg, double* mxl,     \
+                           double* mxu, int* iters) {                                                \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    DNLP_TRY(p->ensure_ipm(); p->swept = false;                                                      \
+             int st = p->ipm->solve(x);                                                              \
+             if (p->ipm->initialized) p->ipm->extract(x, obj, mg, mxl, mxu, g);                      \
+             if (iters) *iters = p->ipm->iter; return st;)                                           \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, get_stats)(void* vp, double* s, int n) {                                         \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    if (!p->ipm) return -1;                                                                          \
+    const auto& st = p->ipm->stats;                                                                  \
+    double v[16] = {double(st.iterations), double(st.factorizations), st.wall, st.t_eval, st.t_factor, \
+                    st.t_solve, p->ipm->mu, st.inf_pr, st.inf_du, st.cmpl, st.nlp_error,              \
+                    st.last_delta_w, p->ipm->sf, 0, 0, 0};                                           \
+    for (int i = 0; i < n && i < 16; ++i) s[i] = v[i];                                               \
+    return 0;                                                                                        \
+  }                                                                                                  \
+  size_t DNLP_CAT(PFX, get_log)(void* vp, char* buf, size_t cap) {                                   \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    std::string all;                                                                                 \
+    if (p->ipm) for (auto& l : p->ipm->log_lines) { all += l; all += '\n'; }                               \
+    if (buf && cap) { size_t n = all.size() < cap - 1 ? all.size() : cap - 1; std::memcpy(buf, all.data(), n); buf[n] = 0; } \
+    return all.size() + 1;                                                                           \
+  }                                                                                                  \
+  }

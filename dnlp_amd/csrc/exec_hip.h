@@ -1,0 +1,549 @@
+// HIP execution space for gfx950 (MI355X): the only execution space of libdnlp_hip.so.
+//
+// * map / sum / max / min instantiate the single-source DNLP_HD lambdas of model.h and
+//   ipm_core.h as grid-wide kernels (64-wide wavefront shuffles -> LDS -> per-block partial ->
+//   pinned host finish; one stream, no host sync except the scalar read).
+// * gemv_sym, dense_block_add, coo_* are hand-written bandwidth kernels (16-B/lane coalesced
+//   column-major reads, deterministic two-stage reduction instead of float atomics for the
+//   dense product).
+// * ldlt_* : Bunch-Kaufman LDL^T for small/medium orders (per-step pivot kernel + grid-wide
+//   trailing update), blocked unpivoted LDL^T with an FP64-MFMA Schur-complement update for
+//   large orders (ldlt_blocked.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "exec.h"
+
+namespace dnlp {
+
+#define DNLP_HIP_CHECK(call)                                                                   \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e_) + " at " +    \
+                               __FILE__ + ":" + std::to_string(__LINE__));                    \
+  } while (0)
+
+constexpr int kBlock = 256;
+constexpr int kMaxPartials = 2048;
+
+template <class F>
+__global__ void __launch_bounds__(kBlock) map_kernel(i64 n, F f) {
+  const i64 i = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i < n) f(i);
+}
+
+__device__ inline double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ inline double wave_max(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  return v;
+}
+
+// mode 0 sum, 1 max (NaN -> +inf), 2 min (NaN -> -inf)
+template <int MODE, class F>
+__global__ void __launch_bounds__(kBlock) reduce_kernel(i64 n, F f, double* partial) {
+  __shared__ double sm[kBlock / 64];
+  double acc = MODE == 0 ? 0.0 : (MODE == 1 ? -kInf : kInf);
+  for (i64 i = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<i64>(gridDim.x) * kBlock) {
+    double v = f(i);
+    if (MODE == 0) acc += v;
+    else if (MODE == 1) acc = fmax(acc, v != v ? kInf : v);
+    else acc = fmin(acc, v != v ? -kInf : v);
+  }
+  if (MODE == 2) acc = -acc;                       // min via max
+  double w = MODE == 0 ? wave_sum(acc) : wave_max(acc);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) sm[wid] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = sm[0];
+    for (int k = 1; k < kBlock / 64; ++k) r = MODE == 0 ? r + sm[k] : fmax(r, sm[k]);
+    partial[blockIdx.x] = MODE == 2 ? -r : r;
+  }
+}
+
+// ---- dense symmetric product y = A x, column-major ----------------------------------------
+// Stage 1: block (rb, cb) owns 512 rows x GEMV_CB columns; each lane streams two adjacent rows
+// (16 B per lane, 1 KiB per wave instruction, fully coalesced down a column) and keeps the two
+// running sums in registers; x of the chunk is wave-uniform.  Partial sums go to part[cb][row].
+// Stage 2 sums the column chunks in a fixed order (bitwise reproducible, no float atomics).
+constexpr int GEMV_CB = 256;
+__global__ void __launch_bounds__(kBlock) gemv_stage1(i64 n, const double* __restrict__ A, i64 ld,
+                                                      const double* __restrict__ x,
+                                                      double* __restrict__ part, i64 nrb) {
+  const i64 rb = blockIdx.x % nrb, cb = blockIdx.x / nrb;
+  const i64 r0 = rb * 512 + 2 * static_cast<i64>(threadIdx.x);
+  const i64 c0 = cb * GEMV_CB;
+  const i64 c1 = c0 + GEMV_CB < n ? c0 + GEMV_CB : n;
+  double a0 = 0.0, a1 = 0.0;
+  if (r0 + 1 < n && (ld & 1) == 0 && ((reinterpret_cast<uintptr_t>(A) & 15) == 0)) {
+    const double* col = A + r0 + c0 * ld;
+    i64 j = c0;
+    for (; j + 4 <= c1; j += 4) {
+      const double2 v0 = *reinterpret_cast<const double2*>(col);
+      const double2 v1 = *reinterpret_cast<const double2*>(col + ld);
+      const double2 v2 = *reinterpret_cast<const double2*>(col + 2 * ld);
+      const double2 v3 = *reinterpret_cast<const double2*>(col + 3 * ld);
+      const double x0 = x[j], x1 = x[j + 1], x2 = x[j + 2], x3 = x[j + 3];
+      a0 += v0.x * x0 + v1.x * x1 + v2.x * x2 + v3.x * x3;
+      a1 += v0.y * x0 + v1.y * x1 + v2.y * x2 + v3.y * x3;
+      col += 4 * ld;
+    }
+    for (; j < c1; ++j) {
+      const double2 v = *reinterpret_cast<const double2*>(col);
+      a0 += v.x * x[j];
+      a1 += v.y * x[j];
+      col += ld;
+    }
+  } else {
+    for (i64 j = c0; j < c1; ++j) {
+      if (r0 < n) a0 += A[r0 + j * ld] * x[j];
+      if (r0 + 1 < n) a1 += A[r0 + 1 + j * ld] * x[j];
+    }
+  }
+  if (r0 < n) part[cb * n + r0] = a0;
+  if (r0 + 1 < n) part[cb * n + r0 + 1] = a1;
+}
+__global__ void __launch_bounds__(kBlock) gemv_stage2(i64 n, i64 ncb, const double* __restrict__ part,
+                                                      double* __restrict__ y) {
+  const i64 r = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+  if (r >= n) return;
+  double s = 0.0;
+  for (i64 c = 0; c < ncb; ++c) s += part[c * n + r];
+  y[r] = s;
+}
+
+// K[x0+r, x0+c] (+)= w P[r,c] on r >= c.  One column per block row-tile; early exit above the
+// diagonal; coalesced down the column.
+__global__ void __launch_bounds__(kBlock) dense_block_add_kernel(double* __restrict__ K, i64 ldk, i64 x0,
+                                                                 const double* __restrict__ P, i64 ldp,
+                                                                 i64 nb, double w, int set, i64 nrb) {
+  const i64 c = blockIdx.x / nrb, rb = blockIdx.x % nrb;
+  if (rb * kBlock + kBlock - 1 < c) return;
+  const i64 r = rb * kBlock + threadIdx.x;
+  if (r >= nb || r < c) return;
+  double* dst = K + (x0 + r) + (x0 + c) * ldk;
+  const double v = w * P[r + c * ldp];
+  *dst = set ? v : *dst + v;
+}
+
+__global__ void __launch_bounds__(kBlock) coo_mult_kernel(i64 nnz, const i32* __restrict__ r,
+                                                          const i32* __restrict__ c, const double* __restrict__ a,
+                                                          const double* __restrict__ v, double* out, int mode) {
+  const i64 p = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+  if (p >= nnz) return;
+  const double av = a[p];
+  if (mode == 0) unsafeAtomicAdd(&out[r[p]], av * v[c[p]]);
+  else if (mode == 1) unsafeAtomicAdd(&out[c[p]], av * v[r[p]]);
+  else {
+    unsafeAtomicAdd(&out[r[p]], av * v[c[p]]);
+    if (r[p] != c[p]) unsafeAtomicAdd(&out[c[p]], av * v[r[p]]);
+  }
+}
+
+// ---- Bunch-Kaufman LDL^T (DSYTF2 semantics, lower) ----------------------------------------
+struct BkState {
+  int k, kstep, kp, pending;      // pending: previous step's columns still need scaling
+  int nneg, nzero, fail, pad;
+  double d11, d22, d21;           // 1x1: d11 = pivot ; 2x2: the DSYTF2 multipliers
+};
+
+constexpr int BK_T = 1024;
+
+__device__ inline void bk_argmax(double v, int idx, double* sv, int* si, double& outv, int& outi) {
+  // block-wide argmax of |v| (first index wins ties, as IDAMAX)
+  for (int o = 32; o > 0; o >>= 1) {
+    double ov = __shfl_down(v, o, 64);
+    int oi = __shfl_down(idx, o, 64);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { sv[wid] = v; si[wid] = idx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double bv = sv[0];
+    int bi = si[0];
+    for (int w = 1; w < BK_T / 64; ++w)
+      if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+    sv[0] = bv;
+    si[0] = bi;
+  }
+  __syncthreads();
+  outv = sv[0];
+  outi = si[0];
+  __syncthreads();
+}
+
+// One workgroup: finish the previous step (scale its columns, advance k), then search the
+// pivot for the new k, apply the symmetric interchange and publish the update multipliers.
+__global__ void __launch_bounds__(BK_T) bk_pivot_kernel(double* A, int n, i64 ld, int* ipiv, BkState* st) {
+  __shared__ double sv[BK_T / 64];
+  __shared__ int si[BK_T / 64];
+  __shared__ int s_k, s_kstep, s_kp, s_imax;
+  __shared__ double s_colmax, s_rowmax;
+  const int tid = threadIdx.x;
+  const double alpha = 0.6403882032022076;   // (1 + sqrt(17)) / 8
+  int k = st->k;
+  if (st->pending) {
+    const int ks = st->kstep;
+    if (ks == 1) {
+      const double inv = 1.0 / st->d11;
+      for (int i = k + 1 + tid; i < n; i += BK_T) A[i + static_cast<i64>(k) * ld] *= inv;
+    } else {
+      const double d11 = st->d11, d22 = st->d22, d21 = st->d21;
+      for (int j = k + 2 + tid; j < n; j += BK_T) {
+        const double ajk = A[j + static_cast<i64>(k) * ld], ajk1 = A[j + static_cast<i64>(k + 1) * ld];
+        A[j + static_cast<i64>(k) * ld] = d21 * (d11 * ajk - ajk1);
+        A[j + static_cast<i64>(k + 1) * ld] = d21 * (d22 * ajk1 - ajk);
+      }
+    }
+    k += ks;
+    __syncthreads();
+  }
+  if (k >= n) {
+    if (tid == 0) { st->k = k; st->pending = 0; st->kstep = 0; }
+    return;
+  }
+  // column maximum below the diagonal
+  double v = -1.0;
+  int idx = n;
+  for (int i = k + 1 + tid; i < n; i += BK_T) {
+    const double a = fabs(A[i + static_cast<i64>(k) * ld]);
+    if (a > v || (a == v && i < idx)) { v = a; idx = i; }
+  }
+  double colmax;
+  int imax;
+  bk_argmax(v, idx, sv, si, colmax, imax);
+  if (colmax < 0.0) { colmax = 0.0; imax = k; }
+  const double akk = A[k + static_cast<i64>(k) * ld];
+  const double absakk = fabs(akk);
+  int kstep = 1, kp = k;
+  bool zero_piv = false, bad = !(absakk == absakk) || !(colmax == colmax);
+  if (!bad && fmax(absakk, colmax) == 0.0) {
+    zero_piv = true;
+  } else if (!bad && absakk < alpha * colmax) {
+    // row maximum of row/column imax in the trailing matrix
+    double rv = 0.0;
+    for (int j = k + tid; j < imax; j += BK_T) rv = fmax(rv, fabs(A[imax + static_cast<i64>(j) * ld]));
+    for (int i = imax + 1 + tid; i < n; i += BK_T) rv = fmax(rv, fabs(A[i + static_cast<i64>(imax) * ld]));
+    double rowmax;
+    int dummy;
+    bk_argmax(rv, tid, sv, si, rowmax, dummy);
+    const double aii = fabs(A[imax + static_cast<i64>(imax) * ld]);
+    if (absakk >= alpha * colmax * (colmax / rowmax)) kp = k;
+    else if (aii >= alpha * rowmax) kp = imax;
+    else { kp = imax; kstep = 2; }
+  }
+  if (bad) {
+    if (tid == 0) { st->fail = 1; st->k = n; st->pending = 0; st->kstep = 0; }
+    return;
+  }
+  const int kk = k + kstep - 1;
+  if (!zero_piv && kp != kk) {
+    // symmetric interchange of rows/columns kk and kp in the trailing matrix
+    for (int i = kp + 1 + tid; i < n; i += BK_T) {
+      const double t = A[i + static_cast<i64>(kk) * ld];
+      A[i + static_cast<i64>(kk) * ld] = A[i + static_cast<i64>(kp) * ld];
+      A[i + static_cast<i64>(kp) * ld] = t;
+    }
+    for (int j = kk + 1 + tid; j < kp; j += BK_T) {
+      const double t = A[j + static_cast<i64>(kk) * ld];
+      A[j + static_cast<i64>(kk) * ld] = A[kp + static_cast<i64>(j) * ld];
+      A[kp + static_cast<i64>(j) * ld] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const double t = A[kk + static_cast<i64>(kk) * ld];
+      A[kk + static_cast<i64>(kk) * ld] = A[kp + static_cast<i64>(kp) * ld];
+      A[kp + static_cast<i64>(kp) * ld] = t;
+      if (kstep == 2) {
+        const double t2 = A[k + 1 + static_cast<i64>(k) * ld];
+        A[k + 1 + static_cast<i64>(k) * ld] = A[kp + static_cast<i64>(k) * ld];
+        A[kp + static_cast<i64>(k) * ld] = t2;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    st->k = k;
+    st->kstep = kstep;
+    st->kp = kp;
+    st->pending = 1;
+    if (zero_piv) {
+      A[k + static_cast<i64>(k) * ld] = 1e-20;
+      st->nzero += 1;
+      st->d11 = 1e-20;
+      ipiv[k] = k + 1;
+    } else if (kstep == 1) {
+      const double d = A[k + static_cast<i64>(k) * ld];
+      st->d11 = d;
+      if (d < 0.0) st->nneg += 1;
+      if (fabs(d) < 1e-300) st->nzero += 1;
+      ipiv[k] = kp + 1;
+    } else {
+      double d21 = A[k + 1 + static_cast<i64>(k) * ld];
+      const double d11 = A[k + 1 + static_cast<i64>(k + 1) * ld] / d21;
+      const double d22 = A[k + static_cast<i64>(k) * ld] / d21;
+      const double t = 1.0 / (d11 * d22 - 1.0);
+      d21 = t / d21;
+      st->d11 = d11; st->d22 = d22; st->d21 = d21;
+      st->nneg += 1;
+      ipiv[k] = -(kp + 1);
+      ipiv[k + 1] = -(kp + 1);
+    }
+  }
+}
+
+// Trailing update of one pivot step over the whole chip: tile = 256 rows x 16 columns.
+__global__ void __launch_bounds__(kBlock) bk_update_kernel(double* A, int n, i64 ld, const BkState* st) {
+  const int k = st->k, ks = st->kstep;
+  if (!st->pending || k >= n) return;
+  const int j0 = k + ks;                       // first trailing column
+  const int t = n - j0;
+  if (t <= 0) return;
+  const int ntr = (t + kBlock - 1) / kBlock;
+  const int rb = blockIdx.x % ntr, cbk = blockIdx.x / ntr;
+  const int cstart = j0 + cbk * 16;
+  if (cstart >= n) return;
+  const int i = j0 + rb * kBlock + threadIdx.x;
+  if (j0 + rb * kBlock + kBlock - 1 < cstart) return;   // tile above the diagonal
+  if (i >= n) return;
+  if (ks == 1) {
+    const double inv = 1.0 / st->d11;
+    const double ai = A[i + static_cast<i64>(k) * ld];
+    if (ai == 0.0) return;
+#pragma unroll 4
+    for (int j = cstart; j < cstart + 16 && j < n; ++j) {
+      if (i < j) break;
+      const double wj = A[j + static_cast<i64>(k) * ld] * inv;
+      A[i + static_cast<i64>(j) * ld] -= ai * wj;
+    }
+  } else {
+    const double d11 = st->d11, d22 = st->d22, d21 = st->d21;
+    const double ai0 = A[i + static_cast<i64>(k) * ld], ai1 = A[i + static_cast<i64>(k + 1) * ld];
+    for (int j = cstart; j < cstart + 16 && j < n; ++j) {
+      if (i < j) break;
+      const double ajk = A[j + static_cast<i64>(k) * ld], ajk1 = A[j + static_cast<i64>(k + 1) * ld];
+      const double wk = d21 * (d11 * ajk - ajk1), wkp1 = d21 * (d22 * ajk1 - ajk);
+      A[i + static_cast<i64>(j) * ld] -= ai0 * wk + ai1 * wkp1;
+    }
+  }
+}
+
+// DSYTRS (lower) in one workgroup; b in global memory.
+__global__ void __launch_bounds__(BK_T) bk_solve_kernel(const double* A, int n, i64 ld, const int* ipiv, double* b) {
+  __shared__ double red[BK_T / 64];
+  __shared__ double red2[BK_T / 64];
+  const int tid = threadIdx.x;
+  int k = 0;
+  while (k < n) {
+    if (ipiv[k] > 0) {
+      const int kp = ipiv[k] - 1;
+      if (tid == 0 && kp != k) { const double t = b[k]; b[k] = b[kp]; b[kp] = t; }
+      __syncthreads();
+      const double bk = b[k];
+      for (int i = k + 1 + tid; i < n; i += BK_T) b[i] -= A[i + static_cast<i64>(k) * ld] * bk;
+      __syncthreads();
+      if (tid == 0) b[k] = bk / A[k + static_cast<i64>(k) * ld];
+      k += 1;
+    } else {
+      const int kp = -ipiv[k] - 1;
+      if (tid == 0 && kp != k + 1) { const double t = b[k + 1]; b[k + 1] = b[kp]; b[kp] = t; }
+      __syncthreads();
+      const double bk = b[k], bk1 = b[k + 1];
+      for (int i = k + 2 + tid; i < n; i += BK_T)
+        b[i] -= A[i + static_cast<i64>(k) * ld] * bk + A[i + static_cast<i64>(k + 1) * ld] * bk1;
+      __syncthreads();
+      if (tid == 0) {
+        const double akm1k = A[k + 1 + static_cast<i64>(k) * ld];
+        const double akm1 = A[k + static_cast<i64>(k) * ld] / akm1k, ak = A[k + 1 + static_cast<i64>(k + 1) * ld] / akm1k;
+        const double denom = akm1 * ak - 1.0, bkm1 = bk / akm1k, bkk = bk1 / akm1k;
+        b[k] = (ak * bkm1 - bkk) / denom;
+        b[k + 1] = (akm1 * bkk - bkm1) / denom;
+      }
+      k += 2;
+    }
+    __syncthreads();
+  }
+  k = n - 1;
+  while (k >= 0) {
+    const bool one = ipiv[k] > 0;
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = k + 1 + tid; i < n; i += BK_T) {
+      const double bi = b[i];
+      s0 += A[i + static_cast<i64>(k) * ld] * bi;
+      if (!one) s1 += A[i + static_cast<i64>(k - 1) * ld] * bi;
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if ((tid & 63) == 0) { red[tid >> 6] = s0; red2[tid >> 6] = s1; }
+    __syncthreads();
+    if (tid == 0) {
+      double t0 = 0.0, t1 = 0.0;
+      for (int w = 0; w < BK_T / 64; ++w) { t0 += red[w]; t1 += red2[w]; }
+      b[k] -= t0;
+      if (!one) b[k - 1] -= t1;
+      const int kp = (one ? ipiv[k] : -ipiv[k]) - 1;
+      if (kp != k) { const double t = b[k]; b[k] = b[kp]; b[kp] = t; }
+    }
+    __syncthreads();
+    k -= one ? 1 : 2;
+  }
+}
+
+struct BlockedLdlt;   // ldlt_blocked.h
+
+struct HipExec {
+  static constexpr bool is_device = true;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  double* d_partial = nullptr;
+  double* h_partial = nullptr;
+  double* gemv_part = nullptr;
+  size_t gemv_part_cap = 0;
+
+  struct LdltWork {
+    BkState* st = nullptr;
+    BlockedLdlt* blocked = nullptr;
+  };
+
+  explicit HipExec(int dev = 0) : device(dev) {
+    DNLP_HIP_CHECK(hipSetDevice(device));
+    DNLP_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    DNLP_HIP_CHECK(hipMalloc(&d_partial, sizeof(double) * kMaxPartials));
+    DNLP_HIP_CHECK(hipHostMalloc(&h_partial, sizeof(double) * kMaxPartials));
+  }
+  ~HipExec() {
+    hipSetDevice(device);
+    for (void* p : owned_) hipFree(p);
+    if (gemv_part) hipFree(gemv_part);
+    if (d_partial) hipFree(d_partial);
+    if (h_partial) hipHostFree(h_partial);
+    if (stream) hipStreamDestroy(stream);
+  }
+  HipExec(const HipExec&) = delete;
+  HipExec& operator=(const HipExec&) = delete;
+
+  template <class T> T* alloc(size_t n) {
+    DNLP_HIP_CHECK(hipSetDevice(device));
+    void* p = nullptr;
+    const size_t bytes = (n ? n : 1) * sizeof(T);
+    DNLP_HIP_CHECK(hipMalloc(&p, bytes));
+    DNLP_HIP_CHECK(hipMemsetAsync(p, 0, bytes, stream));
+    owned_.push_back(p);
+    return static_cast<T*>(p);
+  }
+  void release(void* p) {
+    for (auto& q : owned_) if (q == p) { hipFree(p); q = nullptr; }
+  }
+  void h2d(void* dst, const void* src, size_t bytes) {
+    if (!bytes) return;
+    DNLP_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+    DNLP_HIP_CHECK(hipStreamSynchronize(stream));   // src is pageable host memory
+  }
+  void d2h(void* dst, const void* src, size_t bytes) {
+    if (!bytes) return;
+    DNLP_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+    DNLP_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  void d2d(void* dst, const void* src, size_t bytes) {
+    if (bytes) DNLP_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
+  }
+  void zero(void* p, size_t bytes) {
+    if (bytes) DNLP_HIP_CHECK(hipMemsetAsync(p, 0, bytes, stream));
+  }
+  void sync() { DNLP_HIP_CHECK(hipStreamSynchronize(stream)); }
+
+  template <class F> void map(i64 n, F f) {
+    if (n <= 0) return;
+    const i64 grid = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(map_kernel<F>, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, n, f);
+  }
+  template <int MODE, class F> double reduce(i64 n, F f) {
+    if (n <= 0) return MODE == 0 ? 0.0 : (MODE == 1 ? -kInf : kInf);
+    i64 grid = (n + kBlock - 1) / kBlock;
+    if (grid > kMaxPartials) grid = kMaxPartials;
+    hipLaunchKernelGGL((reduce_kernel<MODE, F>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, n, f, d_partial);
+    DNLP_HIP_CHECK(hipMemcpyAsync(h_partial, d_partial, sizeof(double) * grid, hipMemcpyDeviceToHost, stream));
+    DNLP_HIP_CHECK(hipStreamSynchronize(stream));
+    double r = h_partial[0];
+    for (i64 k = 1; k < grid; ++k) {
+      if (MODE == 0) r += h_partial[k];
+      else if (MODE == 1) r = std::fmax(r, h_partial[k]);
+      else r = std::fmin(r, h_partial[k]);
+    }
+    return r;
+  }
+  template <class F> double sum(i64 n, F f) { return reduce<0>(n, f); }
+  template <class F> double max(i64 n, F f) { return reduce<1>(n, f); }
+  template <class F> double min(i64 n, F f) { return reduce<2>(n, f); }
+
+  void gemv_sym(i64 n, const double* P, i64 ld, const double* u, double* out) {
+    const i64 nrb = (n + 511) / 512, ncb = (n + GEMV_CB - 1) / GEMV_CB;
+    const size_t need = static_cast<size_t>(ncb) * static_cast<size_t>(n);
+    if (need > gemv_part_cap) {
+      if (gemv_part) DNLP_HIP_CHECK(hipFree(gemv_part));
+      DNLP_HIP_CHECK(hipMalloc(&gemv_part, need * sizeof(double)));
+      gemv_part_cap = need;
+    }
+    hipLaunchKernelGGL(gemv_stage1, dim3(static_cast<unsigned>(nrb * ncb)), dim3(kBlock), 0, stream, n, P, ld, u, gemv_part, nrb);
+    hipLaunchKernelGGL(gemv_stage2, dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, n, ncb, gemv_part, out);
+  }
+  void coo_mult(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out, bool trans) {
+    if (nnz <= 0) return;
+    hipLaunchKernelGGL(coo_mult_kernel, dim3(static_cast<unsigned>((nnz + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                       nnz, r, c, a, v, out, trans ? 1 : 0);
+  }
+  void coo_sym_mult(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out) {
+    if (nnz <= 0) return;
+    hipLaunchKernelGGL(coo_mult_kernel, dim3(static_cast<unsigned>((nnz + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                       nnz, r, c, a, v, out, 2);
+  }
+  void dense_block_add(double* K, i64 ldk, i64 x0, const double* P, i64 ldp, i64 nb, double w, bool set) {
+    const i64 nrb = (nb + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(dense_block_add_kernel, dim3(static_cast<unsigned>(nrb * nb)), dim3(kBlock), 0, stream,
+                       K, ldk, x0, P, ldp, nb, w, set ? 1 : 0, nrb);
+  }
+
+  // ---- factorisation (ldlt_blocked.h supplies the large-order path) ----
+  void ldlt_prepare(LdltWork& w, i64 n, i64 ld, bool pivoted);
+  bool ldlt_factor(LdltWork& w, double* A, i64 n, i64 ld, i32* ipiv, bool pivoted, int* nneg, int* nzero);
+  void ldlt_solve(LdltWork& w, const double* A, i64 n, i64 ld, const i32* ipiv, bool pivoted, double* b);
+
+  bool bk_factor(LdltWork& w, double* A, i64 n, i64 ld, i32* ipiv, int* nneg, int* nzero) {
+    BkState init;
+    std::memset(&init, 0, sizeof init);
+    DNLP_HIP_CHECK(hipMemcpyAsync(w.st, &init, sizeof init, hipMemcpyHostToDevice, stream));
+    DNLP_HIP_CHECK(hipStreamSynchronize(stream));
+    const int ni = static_cast<int>(n);
+    for (int step = 0; step < ni; ++step) {
+      hipLaunchKernelGGL(bk_pivot_kernel, dim3(1), dim3(BK_T), 0, stream, A, ni, ld, ipiv, w.st);
+      const int t = ni - step - 1;   // upper bound of the trailing order at this step
+      if (t > 0) {
+        const int ntr = (t + kBlock - 1) / kBlock, ntc = (t + 15) / 16;
+        // grid sized for the worst case (k = step); tiles beyond the actual trailing block exit
+        hipLaunchKernelGGL(bk_update_kernel, dim3(static_cast<unsigned>(ntr * ntc)), dim3(kBlock), 0, stream, A, ni, ld, w.st);
+      }
+    }
+    hipLaunchKernelGGL(bk_pivot_kernel, dim3(1), dim3(BK_T), 0, stream, A, ni, ld, ipiv, w.st);
+    BkState out;
+    DNLP_HIP_CHECK(hipMemcpyAsync(&out, w.st, sizeof out, hipMemcpyDeviceToHost, stream));
+    DNLP_HIP_CHECK(hipStreamSynchronize(stream));
+    *nneg = out.nneg;
+    *nzero = out.nzero;
+    return out.fail == 0;
+  }
+
+ private:
+  std::vector<void*> owned_;
+};
+
+}  // namespace dnlp

@@ -1,0 +1,1029 @@
+// Interior-point filter line-search loop for  min f(x)  s.t.  cl <= g(x) <= cu,  lb <= x <= ub.
+//
+// Replaces the reference's dispatch into third-party IPOPT (`cyipopt.Problem(...).solve(x0)`,
+// cvxpy/reductions/solvers/nlp_solvers/ipopt_nlpif.py:140-170).  IPOPT's source is not part of
+// the reference tree; the algorithm restated here is the published one — A. Waechter and
+// L. T. Biegler, "On the implementation of an interior-point filter line-search algorithm for
+// large-scale nonlinear programming", Math. Prog. 106(1), 2006 (cited below as WB and by
+// equation / section number) — with IPOPT's documented default constants and the option
+// defaults the reference sets (ipopt_nlpif.py:153-160: tol 1e-7, bound_relax_factor 0,
+// exact Hessian, least-squares multiplier initialisation).
+//
+// Single source over an execution space E (exec.h): vectors live in E's memory, every
+// per-element formula is a DNLP_HD lambda, scalars come back through E::sum/max/min.  The
+// KKT object K owns assembly, factorisation (with inertia) and solves.
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "model.h"
+
+namespace dnlp {
+
+struct IpmOptions {
+  double tol = 1e-7;                  // reference default (ipopt_nlpif.py:155)
+  int max_iter = 3000;
+  int mu_strategy = 1;                // 0 monotone, 1 adaptive (reference default :154)
+  double mu_init = 0.1;
+  double mu_min = 1e-11;
+  double mu_max_fact = 1e3;
+  double bound_relax_factor = 0.0;    // reference default (:156)
+  double bound_push = 1e-2, bound_frac = 1e-2;
+  double bound_mult_init_val = 1.0;
+  double constr_mult_init_max = 1e3;
+  int least_square_init_duals = 1;    // reference default (:159)
+  double dual_inf_tol = 1.0, constr_viol_tol = 1e-4, compl_inf_tol = 1e-4;
+  double acceptable_tol = 1e-6, acceptable_dual_inf_tol = 1e10, acceptable_constr_viol_tol = 1e-2,
+         acceptable_compl_inf_tol = 1e-2, acceptable_obj_change_tol = 1e20;
+  int acceptable_iter = 15;
+  double nlp_scaling_max_gradient = 100.0;
+  int nlp_scaling = 1;
+  double kappa_d = 1e-5;
+  double max_wall_time = 1e20;
+  double diverging_iterates_tol = 1e20;
+  int print_level = 0;
+  int max_soc = 4;
+  double nlp_inf = 1e19;              // |bound| >= 1e19 means "no bound"
+  int max_refine = 10, min_refine = 1;
+  int restoration = 1;
+};
+
+struct IpmStats {
+  int iterations = 0;
+  int factorizations = 0;
+  double wall = 0.0, t_eval = 0.0, t_factor = 0.0, t_solve = 0.0, t_assemble = 0.0;
+  double final_mu = 0.0, inf_pr = 0.0, inf_du = 0.0, cmpl = 0.0, nlp_error = 0.0;
+  double last_delta_w = 0.0;
+};
+
+inline double now_sec() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// IPOPT ApplicationReturnStatus values (the integers of ipopt_nlpif.py:31-61)
+enum IpmStatus : int {
+  Solve_Succeeded = 0, Solved_To_Acceptable_Level = 1, Infeasible_Problem_Detected = 2,
+  Search_Direction_Becomes_Too_Small = 3, Diverging_Iterates = 4, Maximum_Iterations_Exceeded = -1,
+  Restoration_Failed = -2, Error_In_Step_Computation = -3, Maximum_WallTime_Exceeded = -5,
+  Not_Enough_Degrees_Of_Freedom = -10, Invalid_Option = -12, Invalid_Number_Detected = -13,
+  Internal_Error = -199
+};
+
+template <class E, class K>
+class Ipm {
+ public:
+  Ipm(E* ex, Model<E>* model, K* kkt) : ex_(ex), md_(model), kkt_(kkt) {}
+
+  IpmOptions opt;
+  IpmStats stats;
+  std::vector<std::string> log_lines;
+
+  // ---- problem data / iterate (exec space) ------------------------------------
+  i64 N = 0, m = 0;
+  double *x = nullptr, *s = nullptr, *y = nullptr, *zL = nullptr, *zU = nullptr, *vL = nullptr, *vU = nullptr;
+  double *xL = nullptr, *xU = nullptr, *sL = nullptr, *sU = nullptr;   // scaled slack bounds
+  double *eqmask = nullptr;           // 1.0 for equality rows
+  double *grad = nullptr, *g = nullptr, *jv = nullptr, *sg = nullptr;
+  double *dx = nullptr, *ds = nullptr, *dy = nullptr, *dzL = nullptr, *dzU = nullptr, *dvL = nullptr, *dvU = nullptr;
+  double *xt = nullptr, *st = nullptr, *gt = nullptr;
+  double *rhs = nullptr, *sol = nullptr, *res = nullptr, *cor = nullptr, *Sx = nullptr, *Dd = nullptr, *Ss = nullptr;
+  double *rx = nullptr, *rs = nullptr, *rp = nullptr, *tN = nullptr, *tM = nullptr, *csoc = nullptr;
+  double sf = 1.0;
+  double f = 0.0;                     // scaled objective at x
+  double mu = 0.1, tau = 0.99;
+  double delta_w_last = 0.0;
+  bool initialized = false;
+  int status = Internal_Error;
+  int iter = 0;
+  // filter
+  std::vector<std::pair<double, double>> filter;
+  double theta_max = 1e4, theta_min = 1e-4;
+  int acceptable_count = 0;
+  double last_obj = 0.0;
+  bool fixed_mode = false;            // adaptive strategy: currently in monotone (fixed) mode
+  std::vector<double> kkt_hist;
+
+  // ------------------------------------------------------------------------------
+  template <class T> T* A(i64 n) { return ex_->template alloc<T>(static_cast<size_t>(n > 0 ? n : 1)); }
+
+  void allocate() {
+    N = md_->N(); m = md_->m();
+    x = A<double>(N); s = A<double>(m); y = A<double>(m); zL = A<double>(N); zU = A<double>(N);
+    vL = A<double>(m); vU = A<double>(m); xL = A<double>(N); xU = A<double>(N); sL = A<double>(m);
+    sU = A<double>(m); eqmask = A<double>(m); grad = A<double>(N); g = A<double>(m);
+    jv = A<double>(md_->t.nnzJ); sg = A<double>(m); dx = A<double>(N); ds = A<double>(m); dy = A<double>(m);
+    dzL = A<double>(N); dzU = A<double>(N); dvL = A<double>(m); dvU = A<double>(m); xt = A<double>(N);
+    st = A<double>(m); gt = A<double>(m); rhs = A<double>(N + m); sol = A<double>(N + m);
+    res = A<double>(N + m); cor = A<double>(N + m); Sx = A<double>(N); Dd = A<double>(m); Ss = A<double>(m);
+    rx = A<double>(N); rs = A<double>(m); rp = A<double>(m); tN = A<double>(N); tM = A<double>(m);
+    csoc = A<double>(m);
+  }
+
+  void logf(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (opt.print_level >= 5) { std::fputs(buf, stdout); std::fputc('\n', stdout); std::fflush(stdout); }
+    log_lines.emplace_back(buf);
+  }
+
+  // ---- evaluation helpers (scaled problem) --------------------------------------
+  // f~(xp), g~(xp) -> returns false on non-finite values
+  bool eval_fg(const double* xp, double& fval, double* gout) {
+    double t0 = now_sec();
+    md_->sweep(xp, false);
+    fval = sf * md_->eval_f_after_sweep();
+    md_->eval_g_after_sweep(gout);
+    const double* sgp = sg;
+    ex_->map(m, [=] DNLP_HD(i64 i) { gout[i] *= sgp[i]; });
+    double chk = ex_->sum(m, [=] DNLP_HD(i64 i) { return gout[i] - gout[i]; });   // NaN/inf detector
+    stats.t_eval += now_sec() - t0;
+    return std::isfinite(fval) && chk == 0.0;
+  }
+  // gradient and Jacobian values at the point of the last sweep (scaled)
+  void eval_derivs_after_sweep() {
+    double t0 = now_sec();
+    md_->eval_grad_after_sweep(grad);
+    md_->eval_jac_after_sweep(jv);
+    const double sff = sf;
+    double* gr = grad;
+    ex_->map(N, [=] DNLP_HD(i64 j) { gr[j] *= sff; });
+    const double* sgp = sg;
+    const i32* jr = md_->t.jac_rows;
+    double* jvv = jv;
+    ex_->map(md_->t.nnzJ, [=] DNLP_HD(i64 p) { jvv[p] *= sgp[jr[p]]; });
+    stats.t_eval += now_sec() - t0;
+  }
+  void eval_hessian() {
+    double t0 = now_sec();
+    const double* sgp = sg;
+    const double* yy = y;
+    double* lam = tM;
+    ex_->map(m, [=] DNLP_HD(i64 i) { lam[i] = sgp[i] * yy[i]; });
+    md_->eval_hess(x, sf, lam);
+    stats.t_eval += now_sec() - t0;
+  }
+
+  // ---- initialisation (WB section 3.6) -------------------------------------------
+  int begin(const double* x0_host) {
+    double t_start = now_sec();
+    if (!x) allocate();
+    const auto& T = md_->t;
+    std::vector<double> hx(x0_host, x0_host + N), lb(T.lb), ub(T.ub), cl(T.cl), cu(T.cu);
+    const double inf = opt.nlp_inf;
+    // bound relaxation (IPOPT bound_relax_factor; the reference sets it to 0)
+    if (opt.bound_relax_factor > 0) {
+      for (i64 j = 0; j < N; ++j) {
+        if (lb[j] > -inf) lb[j] -= std::min(1e-8 * 0 + opt.bound_relax_factor * std::max(1.0, std::fabs(lb[j])), 1e-3);
+        if (ub[j] < inf) ub[j] += std::min(opt.bound_relax_factor * std::max(1.0, std::fabs(ub[j])), 1e-3);
+      }
+    }
+    for (i64 j = 0; j < N; ++j) {
+      if (lb[j] <= -inf) lb[j] = -kInf;
+      if (ub[j] >= inf) ub[j] = kInf;
+      if (lb[j] > ub[j]) return status = Invalid_Option;
+    }
+    for (i64 i = 0; i < m; ++i) {
+      if (cl[i] <= -inf) cl[i] = -kInf;
+      if (cu[i] >= inf) cu[i] = kInf;
+    }
+    // scaling at the user's starting point (IPOPT gradient-based scaling)
+    sf = 1.0;
+    std::vector<double> hsg(static_cast<size_t>(m), 1.0);
+    ex_->h2d(sg, hsg.data(), sizeof(double) * static_cast<size_t>(m));
+    ex_->h2d(x, hx.data(), sizeof(double) * static_cast<size_t>(N));
+    if (opt.nlp_scaling) {
+      std::vector<double> px(hx);
+      push_into_bounds(px, lb, ub);
+      ex_->h2d(xt, px.data(), sizeof(double) * static_cast<size_t>(N));
+      md_->sweep(xt, false);
+      md_->eval_grad_after_sweep(grad);
+      md_->eval_jac_after_sweep(jv);
+      const double* gr = grad;
+      double gmax = ex_->max(N, [=] DNLP_HD(i64 j) { return fabs(gr[j]); });
+      if (std::isfinite(gmax) && gmax > opt.nlp_scaling_max_gradient) sf = std::max(opt.nlp_scaling_max_gradient / gmax, 1e-8);
+      if (m > 0) {
+        std::vector<double> hj(static_cast<size_t>(T.nnzJ));
+        ex_->d2h(hj.data(), jv, sizeof(double) * hj.size());
+        std::vector<double> rmax(static_cast<size_t>(m), 0.0);
+        for (i64 p = 0; p < T.nnzJ; ++p) rmax[T.h_jac_rows[p]] = std::max(rmax[T.h_jac_rows[p]], std::fabs(hj[p]));
+        for (i64 i = 0; i < m; ++i)
+          if (std::isfinite(rmax[i]) && rmax[i] > opt.nlp_scaling_max_gradient)
+            hsg[i] = std::max(opt.nlp_scaling_max_gradient / rmax[i], 1e-8);
+        ex_->h2d(sg, hsg.data(), sizeof(double) * static_cast<size_t>(m));
+      }
+    }
+    // scaled constraint bounds, equality mask, slack bounds
+    std::vector<double> hsL(m), hsU(m), heq(m);
+    for (i64 i = 0; i < m; ++i) {
+      hsL[i] = cl[i] * hsg[i];
+      hsU[i] = cu[i] * hsg[i];
+      heq[i] = (cl[i] == cu[i]) ? 1.0 : 0.0;
+      if (cl[i] > cu[i]) return status = Invalid_Option;
+    }
+    i64 n_eq = 0; for (i64 i = 0; i < m; ++i) n_eq += heq[i] != 0.0;
+    i64 n_free = 0; for (i64 j = 0; j < N; ++j) n_free += !(lb[j] == ub[j]);
+    if (n_eq > n_free) return status = Not_Enough_Degrees_Of_Freedom;
+    fixed_.assign(static_cast<size_t>(N), 0);
+    for (i64 j = 0; j < N; ++j) if (lb[j] == ub[j]) { fixed_[j] = 1; hx[j] = lb[j]; }
+    push_into_bounds(hx, lb, ub);
+    ex_->h2d(x, hx.data(), sizeof(double) * static_cast<size_t>(N));
+    // fixed variables keep no bound multipliers: drop their bounds and pin them in the KKT
+    std::vector<double> lbe(lb), ube(ub), hfix(static_cast<size_t>(N), 0.0);
+    for (i64 j = 0; j < N; ++j) if (fixed_[j]) { lbe[j] = -kInf; ube[j] = kInf; hfix[j] = 1.0; }
+    fixmask = A<double>(N);
+    ex_->h2d(fixmask, hfix.data(), sizeof(double) * static_cast<size_t>(N));
+    ex_->h2d(xL, lbe.data(), sizeof(double) * static_cast<size_t>(N));
+    ex_->h2d(xU, ube.data(), sizeof(double) * static_cast<size_t>(N));
+    ex_->h2d(sL, hsL.data(), sizeof(double) * static_cast<size_t>(m));
+    ex_->h2d(sU, hsU.data(), sizeof(double) * static_cast<size_t>(m));
+    ex_->h2d(eqmask, heq.data(), sizeof(double) * static_cast<size_t>(m));
+    // evaluate at the pushed point
+    if (!eval_fg(x, f, g)) return status = Invalid_Number_Detected;
+    eval_derivs_after_sweep();
+    // slacks: s = d(x) pushed into [sL, sU]
+    std::vector<double> hg(m);
+    ex_->d2h(hg.data(), g, sizeof(double) * static_cast<size_t>(m));
+    std::vector<double> hs(hg);
+    {
+      std::vector<double> l2(hsL), u2(hsU);
+      for (i64 i = 0; i < m; ++i) if (heq[i] != 0.0) { l2[i] = -kInf; u2[i] = kInf; }
+      push_into_bounds(hs, l2, u2);
+      for (i64 i = 0; i < m; ++i) if (heq[i] != 0.0) hs[i] = hsL[i];
+    }
+    ex_->h2d(s, hs.data(), sizeof(double) * static_cast<size_t>(m));
+    // bound multipliers
+    {
+      const double zi = opt.bound_mult_init_val;
+      const double *l = xL, *u = xU, *sl = sL, *su = sU, *eq = eqmask;
+      double *a = zL, *b = zU, *c = vL, *d = vU;
+      ex_->map(N, [=] DNLP_HD(i64 j) { a[j] = (l[j] > -kInf) ? zi : 0.0; b[j] = (u[j] < kInf) ? zi : 0.0; });
+      ex_->map(m, [=] DNLP_HD(i64 i) {
+        c[i] = (eq[i] == 0.0 && sl[i] > -kInf) ? zi : 0.0;
+        d[i] = (eq[i] == 0.0 && su[i] < kInf) ? zi : 0.0;
+      });
+    }
+    mu = opt.mu_init;
+    tau = std::max(0.99, 1.0 - mu);
+    ex_->zero(y, sizeof(double) * static_cast<size_t>(m));
+    if (m > 0 && opt.least_square_init_duals >= 0) init_multipliers_ls();
+    filter.clear();
+    double th0 = theta_at(g, s);
+    theta_max = 1e4 * std::max(1.0, th0);
+    theta_min = 1e-4 * std::max(1.0, th0);
+    iter = 0;
+    acceptable_count = 0;
+    delta_w_last = 0.0;
+    fixed_mode = false;
+    kkt_hist.clear();
+    initialized = true;
+    status = Internal_Error;
+    stats = IpmStats();
+    t_begin_ = t_start;
+    logf("iter    objective    inf_pr   inf_du lg(mu)  ||d||  lg(rg) alpha_du alpha_pr  ls");
+    return 0;
+  }
+
+  void push_into_bounds(std::vector<double>& v, const std::vector<double>& l, const std::vector<double>& u) {
+    const double k1 = opt.bound_push, k2 = opt.bound_frac;
+    for (size_t j = 0; j < v.size(); ++j) {
+      const bool hl = l[j] > -kInf, hu = u[j] < kInf;
+      if (hl && hu) {
+        if (l[j] == u[j]) { v[j] = l[j]; continue; }
+        double pl = std::min(k1 * std::max(1.0, std::fabs(l[j])), k2 * (u[j] - l[j]));
+        double pu = std::min(k1 * std::max(1.0, std::fabs(u[j])), k2 * (u[j] - l[j]));
+        v[j] = std::min(std::max(v[j], l[j] + pl), u[j] - pu);
+      } else if (hl) {
+        v[j] = std::max(v[j], l[j] + k1 * std::max(1.0, std::fabs(l[j])));
+      } else if (hu) {
+        v[j] = std::min(v[j], u[j] - k1 * std::max(1.0, std::fabs(u[j])));
+      }
+    }
+  }
+
+  // least-squares equality multipliers (WB eq. (36)); discarded above constr_mult_init_max
+  void init_multipliers_ls() {
+    double *sx = Sx, *dd = Dd;
+    const double* eq = eqmask;
+    ex_->map(N, [=] DNLP_HD(i64 j) { sx[j] = 1.0; });
+    ex_->map(m, [=] DNLP_HD(i64 i) { dd[i] = (eq[i] == 0.0) ? 1.0 : 0.0; });
+    int nneg = 0, nzero = 0;
+    md_->dense_w.assign(md_->dense_w.size(), 0.0);
+    ex_->zero(md_->Hs, sizeof(double) * static_cast<size_t>(md_->t.nnzH));
+    bool ok = kkt_->assemble_factor(*md_, jv, Sx, Dd, fixmask, 0.0, &nneg, &nzero);
+    stats.factorizations++;
+    if (!ok || nzero > 0 || nneg != m) {
+      // retry once with a tiny dual regularisation for rank-deficient Jacobians
+      ex_->map(m, [=] DNLP_HD(i64 i) { dd[i] += 1e-8; });
+      ok = kkt_->assemble_factor(*md_, jv, Sx, Dd, fixmask, 0.0, &nneg, &nzero);
+      stats.factorizations++;
+      if (!ok) return;
+    }
+    double* r = rhs;
+    const double *gr = grad, *a = zL, *b = zU, *c = vL, *d = vU;
+    const i64 NN = N;
+    ex_->map(N, [=] DNLP_HD(i64 j) { r[j] = -(gr[j] - a[j] + b[j]); });
+    ex_->map(m, [=] DNLP_HD(i64 i) { r[NN + i] = (eq[i] == 0.0) ? -(-c[i] + d[i]) : 0.0; });
+    kkt_->solve(rhs, sol);
+    const double* so = sol;
+    double ymax = ex_->max(m, [=] DNLP_HD(i64 i) { return fabs(so[NN + i]); });
+    if (std::isfinite(ymax) && ymax <= opt.constr_mult_init_max) {
+      double* yy = y;
+      ex_->map(m, [=] DNLP_HD(i64 i) { yy[i] = so[NN + i]; });
+    }
+  }
+
+  // ---- measures -------------------------------------------------------------------
+  // primal residual: g - cl for equalities, g - s for inequalities
+  double theta_at(const double* gg, const double* ss) {
+    const double *eq = eqmask, *sl = sL;
+    return ex_->sum(m, [=] DNLP_HD(i64 i) { return fabs(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]); });
+  }
+  double barrier_at(double fv, const double* xx, const double* ss, double muv) {
+    const double *l = xL, *u = xU, *sl = sL, *su = sU, *eq = eqmask;
+    const double kd = opt.kappa_d;
+    double bx = ex_->sum(N, [=] DNLP_HD(i64 j) {
+      double v = 0.0;
+      const bool hl = l[j] > -kInf, hu = u[j] < kInf;
+      if (hl) v -= log(xx[j] - l[j]);
+      if (hu) v -= log(u[j] - xx[j]);
+      if (hl && !hu) v += kd * (xx[j] - l[j]);
+      if (hu && !hl) v += kd * (u[j] - xx[j]);
+      return v;
+    });
+    double bs = ex_->sum(m, [=] DNLP_HD(i64 i) {
+      if (eq[i] != 0.0) return 0.0;
+      double v = 0.0;
+      const bool hl = sl[i] > -kInf, hu = su[i] < kInf;
+      if (hl) v -= log(ss[i] - sl[i]);
+      if (hu) v -= log(su[i] - ss[i]);
+      if (hl && !hu) v += kd * (ss[i] - sl[i]);
+      if (hu && !hl) v += kd * (su[i] - ss[i]);
+      return v;
+    });
+    return fv + muv * (bx + bs);
+  }
+
+  // dual residuals rx = grad + J^T y - zL + zU ; rs = -y - vL + vU (inequality rows)
+  void dual_residuals() {
+    md_->jac_tmult(jv, y, tN);
+    double *r = rx, *q = rs;
+    const double *gr = grad, *jt = tN, *a = zL, *b = zU, *c = vL, *d = vU, *yy = y, *eq = eqmask, *fm = fixmask;
+    ex_->map(N, [=] DNLP_HD(i64 j) { r[j] = fm[j] != 0.0 ? 0.0 : gr[j] + jt[j] - a[j] + b[j]; });
+    ex_->map(m, [=] DNLP_HD(i64 i) { q[i] = (eq[i] == 0.0) ? -yy[i] - c[i] + d[i] : 0.0; });
+  }
+
+  struct Err { double dual, primal, cmpl, sd, sc, total; };
+
+  // WB eq. (5): scaled optimality error for barrier parameter muv
+  Err error(double muv) {
+    dual_residuals();
+    const double *r = rx, *q = rs, *gg = g, *ss = s, *eq = eqmask, *sl = sL, *su = sU, *l = xL, *u = xU,
+                 *xx = x, *a = zL, *b = zU, *c = vL, *d = vU, *yy = y;
+    Err e;
+    e.dual = std::max(ex_->max(N, [=] DNLP_HD(i64 j) { return fabs(r[j]); }),
+                      m ? ex_->max(m, [=] DNLP_HD(i64 i) { return fabs(q[i]); }) : 0.0);
+    e.primal = m ? ex_->max(m, [=] DNLP_HD(i64 i) { return fabs(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]); }) : 0.0;
+    double cx = ex_->max(N, [=] DNLP_HD(i64 j) {
+      double v = 0.0;
+      if (l[j] > -kInf) v = fmax(v, fabs((xx[j] - l[j]) * a[j] - muv));
+      if (u[j] < kInf) v = fmax(v, fabs((u[j] - xx[j]) * b[j] - muv));
+      return v;
+    });
+    double cs = m ? ex_->max(m, [=] DNLP_HD(i64 i) {
+      double v = 0.0;
+      if (eq[i] != 0.0) return v;
+      if (sl[i] > -kInf) v = fmax(v, fabs((ss[i] - sl[i]) * c[i] - muv));
+      if (su[i] < kInf) v = fmax(v, fabs((su[i] - ss[i]) * d[i] - muv));
+      return v;
+    }) : 0.0;
+    e.cmpl = std::max(std::max(cx, cs), 0.0);
+    const double smax = 100.0;
+    double sy = m ? ex_->sum(m, [=] DNLP_HD(i64 i) { return fabs(yy[i]) + fabs(c[i]) + fabs(d[i]); }) : 0.0;
+    double sz = ex_->sum(N, [=] DNLP_HD(i64 j) { return fabs(a[j]) + fabs(b[j]); });
+    i64 nb = n_bound_mults();
+    e.sd = std::max(smax, (sy + sz) / std::max<double>(1.0, static_cast<double>(m + nb))) / smax;
+    e.sc = std::max(smax, sz / std::max<double>(1.0, static_cast<double>(nb))) / smax;
+    e.total = std::max(std::max(e.dual / e.sd, e.primal), e.cmpl / e.sc);
+    return e;
+  }
+
+  i64 n_bound_mults() {
+    if (nb_cache_ >= 0) return nb_cache_;
+    const double *l = xL, *u = xU, *sl = sL, *su = sU, *eq = eqmask;
+    double c1 = ex_->sum(N, [=] DNLP_HD(i64 j) { return (l[j] > -kInf ? 1.0 : 0.0) + (u[j] < kInf ? 1.0 : 0.0); });
+    double c2 = m ? ex_->sum(m, [=] DNLP_HD(i64 i) {
+      return eq[i] != 0.0 ? 0.0 : (sl[i] > -kInf ? 1.0 : 0.0) + (su[i] < kInf ? 1.0 : 0.0); }) : 0.0;
+    nb_cache_ = static_cast<i64>(c1 + c2);
+    return nb_cache_;
+  }
+
+  // ---- search direction (WB section 2.2 / 3.1) ---------------------------------------
+  // Builds Sigma and the barrier right-hand sides for barrier parameter muv.
+  void barrier_terms(double muv) {
+    md_->jac_tmult(jv, y, tN);
+    double *sx = Sx, *sS = Ss, *r = rx, *q = rs, *p = rp;
+    const double *l = xL, *u = xU, *sl = sL, *su = sU, *eq = eqmask, *xx = x, *ss = s, *a = zL, *b = zU,
+                 *c = vL, *d = vU, *gr = grad, *jt = tN, *yy = y, *gg = g, *fm = fixmask;
+    const double kd = opt.kappa_d;
+    ex_->map(N, [=] DNLP_HD(i64 j) {
+      double sig = 0.0, gphi = gr[j];
+      const bool hl = l[j] > -kInf, hu = u[j] < kInf;
+      if (hl) { sig += a[j] / (xx[j] - l[j]); gphi -= muv / (xx[j] - l[j]); }
+      if (hu) { sig += b[j] / (u[j] - xx[j]); gphi += muv / (u[j] - xx[j]); }
+      if (hl && !hu) gphi += kd * muv;
+      if (hu && !hl) gphi -= kd * muv;
+      sx[j] = sig;
+      r[j] = fm[j] != 0.0 ? 0.0 : gphi + jt[j];             // grad_x phi + J^T y
+    });
+    ex_->map(m, [=] DNLP_HD(i64 i) {
+      if (eq[i] != 0.0) { sS[i] = 0.0; q[i] = 0.0; p[i] = gg[i] - sl[i]; return; }
+      double sig = 0.0, gphi = 0.0;
+      const bool hl = sl[i] > -kInf, hu = su[i] < kInf;
+      if (hl) { sig += c[i] / (ss[i] - sl[i]); gphi -= muv / (ss[i] - sl[i]); }
+      if (hu) { sig += d[i] / (su[i] - ss[i]); gphi += muv / (su[i] - ss[i]); }
+      if (hl && !hu) gphi += kd * muv;
+      if (hu && !hl) gphi -= kd * muv;
+      sS[i] = sig;
+      q[i] = gphi - yy[i];                                  // grad_s phi - y
+      p[i] = gg[i] - ss[i];
+    });
+  }
+
+  // inertia-correcting factorisation of the reduced KKT matrix (WB Algorithm IC)
+  bool factor_with_inertia(double& delta_w, double& delta_c) {
+    const double dw_min = 1e-20, dw_0 = 1e-4, dw_max = 1e40, dc_bar = 1e-8, kwp = 8.0, kwpb = 100.0, kwm = 1.0 / 3.0, kc = 0.25;
+    delta_w = 0.0; delta_c = 0.0;
+    int nneg = 0, nzero = 0;
+    auto attempt = [&](double dw, double dc) -> int {   // 0 ok, 1 wrong inertia, 2 singular
+      double* dd = Dd;
+      const double *sS = Ss, *eq = eqmask;
+      ex_->map(m, [=] DNLP_HD(i64 i) { dd[i] = dc + (eq[i] == 0.0 ? 1.0 / fmax(sS[i] + dw, 1e-20) : 0.0); });
+      double t0 = now_sec();
+      bool ok = kkt_->assemble_factor(*md_, jv, Sx, Dd, fixmask, dw, &nneg, &nzero);
+      stats.t_factor += now_sec() - t0;
+      stats.factorizations++;
+      if (!ok) return 2;
+      if (nzero > 0) return 2;
+      return nneg == m ? 0 : 1;
+    };
+    int r = attempt(0.0, 0.0);
+    if (r == 0) return true;
+    if (r == 2) delta_c = dc_bar * std::pow(mu, kc);
+    delta_w = (delta_w_last == 0.0) ? dw_0 : std::max(dw_min, kwm * delta_w_last);
+    // singular with delta_w = 0: first try the dual regularisation alone
+    if (r == 2) {
+      int r2 = attempt(0.0, delta_c);
+      if (r2 == 0) { delta_w = 0.0; return true; }
+    }
+    for (int k = 0; k < 100; ++k) {
+      int r2 = attempt(delta_w, delta_c);
+      if (r2 == 0) { delta_w_last = delta_w; return true; }
+      if (r2 == 2 && delta_c == 0.0) delta_c = dc_bar * std::pow(mu, kc);
+      delta_w = (delta_w_last == 0.0) ? kwpb * delta_w : kwp * delta_w;
+      if (delta_w > dw_max) return false;
+    }
+    return false;
+  }
+
+  // K v for the reduced system at the current iterate (for iterative refinement)
+  void kkt_mult(const double* v, double dw, double* out) {
+    md_->hess_mult(v, out);
+    md_->jac_tmult(jv, v + N, tN);
+    md_->jac_mult(jv, v, tM);
+    const double *sx = Sx, *jt = tN, *jx = tM, *dd = Dd, *fm = fixmask;
+    const i64 NN = N;
+    ex_->map(N, [=] DNLP_HD(i64 j) { out[j] = fm[j] != 0.0 ? v[j] : out[j] + (sx[j] + dw) * v[j] + jt[j]; });
+    ex_->map(m, [=] DNLP_HD(i64 i) { out[NN + i] = jx[i] - dd[i] * v[NN + i]; });
+  }
+
+  // solve K sol = rhs with iterative refinement on the unfactored operator
+  bool solve_refined(double dw) {
+    double t0 = now_sec();
+    kkt_->solve(rhs, sol);
+    const double* rr = rhs;
+    double rn = ex_->max(N + m, [=] DNLP_HD(i64 i) { return fabs(rr[i]); });
+    double best = kInf;
+    for (int it = 0; it < opt.max_refine; ++it) {
+      kkt_mult(sol, dw, res);
+      double* re = res;
+      ex_->map(N + m, [=] DNLP_HD(i64 i) { re[i] = rr[i] - re[i]; });
+      const double* so = sol;
+      double en = ex_->max(N + m, [=] DNLP_HD(i64 i) { return fabs(re[i]); });
+      double sn = ex_->max(N + m, [=] DNLP_HD(i64 i) { return fabs(so[i]); });
+      double ratio = en / (std::min(rn, sn) + 1e-300 > 0 ? std::max(rn, 1e-300) + sn : 1.0);
+      if (!std::isfinite(en)) { stats.t_solve += now_sec() - t0; return false; }
+      if (it >= opt.min_refine && ratio <= 1e-10) break;
+      if (en >= best * 0.999 && it >= opt.min_refine) break;   // no further progress
+      best = std::min(best, en);
+      kkt_->solve(res, cor);
+      double* sw = sol;
+      const double* co = cor;
+      ex_->map(N + m, [=] DNLP_HD(i64 i) { sw[i] += co[i]; });
+    }
+    stats.t_solve += now_sec() - t0;
+    return true;
+  }
+
+  // direction for barrier parameter muv with primal residual `pres` (rp or the SOC one)
+  bool compute_direction(double muv, const double* pres, double dw) {
+    double* r = rhs;
+    const double *rxx = rx, *q = rs, *sS = Ss, *eq = eqmask;
+    const i64 NN = N;
+    ex_->map(N, [=] DNLP_HD(i64 j) { r[j] = -rxx[j]; });
+    ex_->map(m, [=] DNLP_HD(i64 i) { r[NN + i] = -pres[i] - (eq[i] == 0.0 ? q[i] / (sS[i] + dw) : 0.0); });
+    if (!solve_refined(dw)) return false;
+    const double* so = sol;
+    double *ddx = dx, *dds = ds, *ddy = dy;
+    ex_->map(N, [=] DNLP_HD(i64 j) { ddx[j] = so[j]; });
+    ex_->map(m, [=] DNLP_HD(i64 i) {
+      ddy[i] = so[NN + i];
+      dds[i] = (eq[i] == 0.0) ? (so[NN + i] - q[i]) / (sS[i] + dw) : 0.0;
+    });
+    // bound multiplier steps (WB eq. (12))
+    const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *a = zL, *b = zU, *c = vL, *d = vU;
+    double *da = dzL, *db = dzU, *dc = dvL, *dd2 = dvU;
+    ex_->map(N, [=] DNLP_HD(i64 j) {
+      da[j] = (l[j] > -kInf) ? (muv - a[j] * ddx[j]) / (xx[j] - l[j]) - a[j] : 0.0;
+      db[j] = (u[j] < kInf) ? (muv + b[j] * ddx[j]) / (u[j] - xx[j]) - b[j] : 0.0;
+    });
+    ex_->map(m, [=] DNLP_HD(i64 i) {
+      const bool in = eq[i] == 0.0;
+      dc[i] = (in && sl[i] > -kInf) ? (muv - c[i] * dds[i]) / (ss[i] - sl[i]) - c[i] : 0.0;
+      dd2[i] = (in && su[i] < kInf) ? (muv + d[i] * dds[i]) / (su[i] - ss[i]) - d[i] : 0.0;
+    });
+    return true;
+  }
+
+  // fraction-to-boundary step sizes (WB eq. (15))
+  double max_step_primal(double tauv) {
+    const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *ddx = dx, *dds = ds, *eq = eqmask;
+    double ax = ex_->min(N, [=] DNLP_HD(i64 j) {
+      double a = 1.0;
+      if (l[j] > -kInf && ddx[j] < 0.0) a = fmin(a, -tauv * (xx[j] - l[j]) / ddx[j]);
+      if (u[j] < kInf && ddx[j] > 0.0) a = fmin(a, tauv * (u[j] - xx[j]) / ddx[j]);
+      return a;
+    });
+    double as = m ? ex_->min(m, [=] DNLP_HD(i64 i) {
+      double a = 1.0;
+      if (eq[i] != 0.0) return a;
+      if (sl[i] > -kInf && dds[i] < 0.0) a = fmin(a, -tauv * (ss[i] - sl[i]) / dds[i]);
+      if (su[i] < kInf && dds[i] > 0.0) a = fmin(a, tauv * (su[i] - ss[i]) / dds[i]);
+      return a;
+    }) : 1.0;
+    return std::min(1.0, std::min(ax, as));
+  }
+  double max_step_dual(double tauv) {
+    const double *a = zL, *b = zU, *c = vL, *d = vU, *da = dzL, *db = dzU, *dc = dvL, *dd2 = dvU;
+    double az = ex_->min(N, [=] DNLP_HD(i64 j) {
+      double t = 1.0;
+      if (da[j] < 0.0) t = fmin(t, -tauv * a[j] / da[j]);
+      if (db[j] < 0.0) t = fmin(t, -tauv * b[j] / db[j]);
+      return t;
+    });
+    double av = m ? ex_->min(m, [=] DNLP_HD(i64 i) {
+      double t = 1.0;
+      if (dc[i] < 0.0) t = fmin(t, -tauv * c[i] / dc[i]);
+      if (dd2[i] < 0.0) t = fmin(t, -tauv * d[i] / dd2[i]);
+      return t;
+    }) : 1.0;
+    return std::min(1.0, std::min(az, av));
+  }
+
+  bool filter_ok(double th, double ph) const {
+    const double gth = 1e-5, gph = 1e-8;
+    for (auto& e : filter)
+      if (!(th <= (1.0 - gth) * e.first || ph <= e.second - gph * e.first)) return false;
+    return true;
+  }
+
+  // ---- convergence tests (IPOPT OptimalityErrorConvergenceCheck) ----------------------
+  int check_convergence(const Err& e0) {
+    double unsc_du = e0.dual / sf;
+    const double *gg = g, *ss = s, *eq = eqmask, *sl = sL, *sgp = sg;
+    double unsc_pr = m ? ex_->max(m, [=] DNLP_HD(i64 i) {
+      return fabs(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]) / sgp[i]; }) : 0.0;
+    double unsc_co = e0.cmpl / sf;
+    stats.inf_pr = unsc_pr; stats.inf_du = unsc_du; stats.cmpl = unsc_co; stats.nlp_error = e0.total;
+    if (e0.total <= opt.tol && unsc_du <= opt.dual_inf_tol && unsc_pr <= opt.constr_viol_tol &&
+        unsc_co <= opt.compl_inf_tol)
+      return Solve_Succeeded;
+    bool acc = e0.total <= opt.acceptable_tol && unsc_du <= opt.acceptable_dual_inf_tol &&
+               unsc_pr <= opt.acceptable_constr_viol_tol && unsc_co <= opt.acceptable_compl_inf_tol;
+    acceptable_count = acc ? acceptable_count + 1 : 0;
+    if (opt.acceptable_iter > 0 && acceptable_count >= opt.acceptable_iter) return Solved_To_Acceptable_Level;
+    return 99;
+  }
+
+  // ---- one interior-point iteration; returns IPOPT status or 99 to continue -----------
+  int step() {
+    if (!initialized) return status = Internal_Error;
+    if (iter >= opt.max_iter) return status = Maximum_Iterations_Exceeded;
+    if (now_sec() - t_begin_ > opt.max_wall_time) return status = Maximum_WallTime_Exceeded;
+    Err e0 = error(0.0);
+    int cv = check_convergence(e0);
+    if (iter == 0) log_iter(e0, 0.0, 0.0, 0.0, 0.0, 0);
+    if (cv != 99) return status = cv;
+    {
+      const double* xx = x;
+      double xm = ex_->max(N, [=] DNLP_HD(i64 j) { return fabs(xx[j]); });
+      if (!(xm <= opt.diverging_iterates_tol)) return status = Diverging_Iterates;
+    }
+    // barrier parameter update
+    update_mu(e0);
+    // Hessian of the Lagrangian at (x, y)
+    eval_hessian();
+    barrier_terms(mu);
+    double dw = 0.0, dc = 0.0;
+    if (!factor_with_inertia(dw, dc)) return status = Error_In_Step_Computation;
+    stats.last_delta_w = dw;
+    if (!compute_direction(mu, rp, dw)) return status = Error_In_Step_Computation;
+    // ---- backtracking filter line search (WB Algorithm A, steps A-5) ----
+    double a_max = max_step_primal(tau);
+    double a_z = max_step_dual(tau);
+    const double theta_k = theta_at(g, s);
+    const double phi_k = barrier_at(f, x, s, mu);
+    double gphid;   // directional derivative of the barrier function
+    {
+      const double *rxx = rx, *jt = tN, *ddx = dx, *q = rs, *yy = y, *dds = ds, *eq = eqmask;
+      // rx = grad_x phi + J^T y  and  tN still holds J^T y from barrier_terms
+      md_->jac_tmult(jv, y, tN);
+      gphid = ex_->sum(N, [=] DNLP_HD(i64 j) { return (rxx[j] - jt[j]) * ddx[j]; }) +
+              (m ? ex_->sum(m, [=] DNLP_HD(i64 i) { return eq[i] == 0.0 ? (q[i] + yy[i]) * dds[i] : 0.0; }) : 0.0);
+    }
+    const double g_th = 1e-5, g_ph = 1e-8, dlt = 1.0, s_th = 1.1, s_ph = 2.3, eta = 1e-8, g_al = 0.05;
+    double a_min;
+    if (gphid < 0.0) {
+      a_min = std::min(g_th, g_ph * theta_k / (-gphid));
+      if (theta_k <= theta_min) a_min = std::min(a_min, dlt * std::pow(theta_k, s_th) / std::pow(-gphid, s_ph));
+      a_min *= g_al;
+    } else {
+      a_min = g_al * g_th;
+    }
+    const double macheps = 2.220446049250313e-16;
+    auto le = [&](double a, double b, double base) { return a - b <= 10.0 * macheps * std::fabs(base); };
+    double alpha = a_max;
+    bool accepted = false, ftype = false;
+    int ls = 0;
+    bool soc_tried = false;
+    double th_t = 0.0, ph_t = 0.0, f_t = 0.0;
+    while (true) {
+      ++ls;
+      trial_point(alpha);
+      bool fin = eval_fg(xt, f_t, gt);
+      if (fin) {
+        th_t = theta_at(gt, st);
+        ph_t = barrier_at(f_t, xt, st, mu);
+        fin = std::isfinite(th_t) && std::isfinite(ph_t);
+      }
+      if (fin && th_t <= theta_max && filter_ok(th_t, ph_t)) {
+        bool sw = gphid < 0.0 && alpha * std::pow(-gphid, s_ph) > dlt * std::pow(theta_k, s_th);
+        if (theta_k <= theta_min && sw) {
+          if (le(ph_t, phi_k + eta * alpha * gphid, phi_k)) { accepted = true; ftype = true; }
+        } else {
+          if (le(th_t, (1.0 - g_th) * theta_k, theta_k) || le(ph_t, phi_k - g_ph * theta_k, phi_k)) accepted = true;
+        }
+      }
+      if (accepted) break;
+      // second-order correction on the first trial (WB section 2.4)
+      if (ls == 1 && !soc_tried && fin && th_t >= theta_k && opt.max_soc > 0 && m > 0) {
+        soc_tried = true;
+        if (second_order_correction(alpha, dw, theta_k, phi_k, gphid, th_t, ph_t, f_t, ftype)) {
+          accepted = true;
+          a_z = max_step_dual(tau);
+          break;
+        }
+        // restore the plain direction
+        compute_direction(mu, rp, dw);
+      }
+      alpha *= 0.5;
+      if (alpha < a_min || ls > 60) break;
+    }
+    double alpha_used = alpha;
+    if (!accepted) {
+      if (opt.restoration && restoration_phase(theta_k)) {
+        // restoration produced a new (x, s) acceptable to the filter; multipliers reset
+        ++iter;
+        Err e = error(0.0);
+        log_iter(e, 0.0, 0.0, 0.0, 0.0, -1);
+        stats.iterations = iter;
+        return 99;
+      }
+      // tiny steps with tiny infeasibility: report the search-direction status
+      const double* ddx = dx;
+      double dn = ex_->max(N, [=] DNLP_HD(i64 j) { return fabs(ddx[j]); });
+      if (dn < 1e-12 && theta_k < opt.constr_viol_tol) return status = Search_Direction_Becomes_Too_Small;
+      return status = (theta_k > opt.constr_viol_tol) ? Infeasible_Problem_Detected : Restoration_Failed;
+    }
+    // filter augmentation (WB eq. (22)) unless f-type step with Armijo
+    if (!ftype) filter.emplace_back((1.0 - g_th) * theta_k, phi_k - g_ph * theta_k);
+    // accept the trial point
+    const double* ddx = dx;
+    double dnorm = ex_->max(N, [=] DNLP_HD(i64 j) { return fabs(ddx[j]); });
+    accept_trial(alpha_used, a_z, f_t);
+    ++iter;
+    stats.iterations = iter;
+    Err e = error(0.0);
+    log_iter(e, dnorm, dw, a_z, alpha_used, ls);
+    return 99;
+  }
+
+  void trial_point(double alpha) {
+    double *a = xt, *b = st;
+    const double *xx = x, *ss = s, *ddx = dx, *dds = ds, *eq = eqmask, *sl = sL;
+    ex_->map(N, [=] DNLP_HD(i64 j) { a[j] = xx[j] + alpha * ddx[j]; });
+    ex_->map(m, [=] DNLP_HD(i64 i) { b[i] = eq[i] != 0.0 ? sl[i] : ss[i] + alpha * dds[i]; });
+  }
+
+  void accept_trial(double alpha, double a_z, double f_new) {
+    double *xx = x, *ss = s, *yy = y, *a = zL, *b = zU, *c = vL, *d = vU;
+    const double *nx = xt, *ns = st, *ddy = dy, *da = dzL, *db = dzU, *dc = dvL, *dd2 = dvU;
+    ex_->map(N, [=] DNLP_HD(i64 j) { xx[j] = nx[j]; a[j] += a_z * da[j]; b[j] += a_z * db[j]; });
+    ex_->map(m, [=] DNLP_HD(i64 i) { ss[i] = ns[i]; yy[i] += alpha * ddy[i]; c[i] += a_z * dc[i]; d[i] += a_z * dd2[i]; });
+    ex_->d2d(g, gt, sizeof(double) * static_cast<size_t>(m));
+    f = f_new;
+    // derivatives at the accepted point: the last sweep was the accepted trial only if no
+    // later trial was evaluated, so sweep again (cheap relative to the factorisation)
+    md_->sweep(x, false);
+    eval_derivs_after_sweep();
+    reset_bound_multipliers();
+  }
+
+  // WB eq. (16): keep z within [mu/(kS (x-l)), kS mu/(x-l)]
+  void reset_bound_multipliers() {
+    const double kS = 1e10, muv = mu;
+    const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *eq = eqmask;
+    double *a = zL, *b = zU, *c = vL, *d = vU;
+    ex_->map(N, [=] DNLP_HD(i64 j) {
+      if (l[j] > -kInf) { double t = xx[j] - l[j]; a[j] = fmax(fmin(a[j], kS * muv / t), muv / (kS * t)); }
+      if (u[j] < kInf) { double t = u[j] - xx[j]; b[j] = fmax(fmin(b[j], kS * muv / t), muv / (kS * t)); }
+    });
+    ex_->map(m, [=] DNLP_HD(i64 i) {
+      if (eq[i] != 0.0) return;
+      if (sl[i] > -kInf) { double t = ss[i] - sl[i]; c[i] = fmax(fmin(c[i], kS * muv / t), muv / (kS * t)); }
+      if (su[i] < kInf) { double t = su[i] - ss[i]; d[i] = fmax(fmin(d[i], kS * muv / t), muv / (kS * t)); }
+    });
+  }
+
+  // WB section 2.4: up to max_soc corrections c_soc = alpha*c_soc + c(x + alpha d)
+  bool second_order_correction(double alpha, double dw, double theta_k, double phi_k, double gphid,
+                               double& th_t, double& ph_t, double& f_t, bool& ftype) {
+    const double k_soc = 0.99, g_th = 1e-5, g_ph = 1e-8, dlt = 1.0, s_th = 1.1, s_ph = 2.3, eta = 1e-8;
+    const double macheps = 2.220446049250313e-16;
+    auto le = [&](double a, double b, double base) { return a - b <= 10.0 * macheps * std::fabs(base); };
+    double* cs = csoc;
+    const double *p = rp, *gg = gt, *ss = st, *eq = eqmask, *sl = sL;
+    // c_soc = alpha * c(x_k) + c(x_k + alpha d)
+    ex_->map(m, [=] DNLP_HD(i64 i) { cs[i] = alpha * p[i] + (eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]); });
+    double th_old = th_t;
+    for (int k = 0; k < opt.max_soc; ++k) {
+      if (!compute_direction(mu, csoc, dw)) return false;
+      double a_soc = max_step_primal(tau);
+      trial_point(a_soc);
+      double fv;
+      if (!eval_fg(xt, fv, gt)) return false;
+      double th = theta_at(gt, st), ph = barrier_at(fv, xt, st, mu);
+      if (!std::isfinite(th) || !std::isfinite(ph)) return false;
+      if (th <= theta_max && filter_ok(th, ph)) {
+        bool sw = gphid < 0.0 && alpha * std::pow(-gphid, s_ph) > dlt * std::pow(theta_k, s_th);
+        bool ok = false;
+        if (theta_k <= theta_min && sw) {
+          if (le(ph, phi_k + eta * alpha * gphid, phi_k)) { ok = true; ftype = true; }
+        } else if (le(th, (1.0 - g_th) * theta_k, theta_k) || le(ph, phi_k - g_ph * theta_k, phi_k)) {
+          ok = true;
+        }
+        if (ok) { th_t = th; ph_t = ph; f_t = fv; return true; }
+      }
+      if (th > k_soc * th_old) return false;
+      th_old = th;
+      const double *gg2 = gt, *ss2 = st;
+      ex_->map(m, [=] DNLP_HD(i64 i) { cs[i] = a_soc * cs[i] + (eq[i] != 0.0 ? gg2[i] - sl[i] : gg2[i] - ss2[i]); });
+    }
+    return false;
+  }
+
+  // ---- barrier parameter strategies --------------------------------------------------
+  double avg_complementarity() {
+    const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *a = zL, *b = zU, *c = vL, *d = vU, *eq = eqmask;
+    i64 nb = n_bound_mults();
+    if (nb == 0) return 0.0;
+    double cx = ex_->sum(N, [=] DNLP_HD(i64 j) {
+      double v = 0.0;
+      if (l[j] > -kInf) v += (xx[j] - l[j]) * a[j];
+      if (u[j] < kInf) v += (u[j] - xx[j]) * b[j];
+      return v; });
+    double cs = m ? ex_->sum(m, [=] DNLP_HD(i64 i) {
+      double v = 0.0;
+      if (eq[i] != 0.0) return v;
+      if (sl[i] > -kInf) v += (ss[i] - sl[i]) * c[i];
+      if (su[i] < kInf) v += (su[i] - ss[i]) * d[i];
+      return v; }) : 0.0;
+    return (cx + cs) / static_cast<double>(nb);
+  }
+
+  void monotone_update() {
+    const double k_eps = 10.0, k_mu = 0.2, th_mu = 1.5;
+    const double mu_floor = std::max(opt.mu_min, std::min(opt.tol, opt.compl_inf_tol) / 11.0);
+    for (int k = 0; k < 50; ++k) {
+      Err e = error(mu);
+      if (e.total <= k_eps * mu && mu > mu_floor) {
+        double nm = std::max(mu_floor, std::min(k_mu * mu, std::pow(mu, th_mu)));
+        if (nm >= mu) break;
+        mu = nm;
+        tau = std::max(0.99, 1.0 - mu);
+        filter.clear();
+      } else {
+        break;
+      }
+    }
+  }
+
+  // Adaptive strategy (IPOPT mu_strategy=adaptive, the reference's default) in its
+  // documented LOQO-oracle form with the kkt-error globalisation: free mode picks
+  // mu = sigma * avg_compl with the LOQO centrality heuristic; if the KKT error fails to
+  // decrease by the factor 0.9999 relative to the last 4 free-mode iterates the algorithm
+  // falls back to the monotone mode until it does.
+  void update_mu(const Err& e0) {
+    if (n_bound_mults() == 0) { tau = 0.99; return; }   // no barrier terms at all
+    if (opt.mu_strategy == 0) { monotone_update(); return; }
+    const double mu_floor = std::max(opt.mu_min, std::min(opt.tol, opt.compl_inf_tol) / 11.0);
+    double kkt = e0.dual + e0.primal + e0.cmpl;
+    if (!fixed_mode) {
+      bool ok = kkt_hist.empty();
+      for (double h : kkt_hist) if (kkt <= 0.9999 * h) ok = true;
+      if (ok) {
+        kkt_hist.push_back(kkt);
+        if (kkt_hist.size() > 4) kkt_hist.erase(kkt_hist.begin());
+      } else {
+        fixed_mode = true;
+        mu = std::max(mu_floor, std::min(0.8 * avg_complementarity(), 1e5));
+        tau = std::max(0.99, 1.0 - mu);
+        filter.clear();
+      }
+    } else {
+      bool ok = false;
+      for (double h : kkt_hist) if (kkt <= 0.9999 * h) ok = true;
+      if (ok || kkt_hist.empty()) {
+        fixed_mode = false;
+        kkt_hist.push_back(kkt);
+        if (kkt_hist.size() > 4) kkt_hist.erase(kkt_hist.begin());
+      }
+    }
+    if (fixed_mode) { monotone_update(); return; }
+    // LOQO oracle
+    double avg = avg_complementarity();
+    const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *a = zL, *b = zU, *c = vL, *d = vU, *eq = eqmask;
+    double mn = std::min(ex_->min(N, [=] DNLP_HD(i64 j) {
+      double v = kInf;
+      if (l[j] > -kInf) v = fmin(v, (xx[j] - l[j]) * a[j]);
+      if (u[j] < kInf) v = fmin(v, (u[j] - xx[j]) * b[j]);
+      return v; }), m ? ex_->min(m, [=] DNLP_HD(i64 i) {
+      double v = kInf;
+      if (eq[i] != 0.0) return v;
+      if (sl[i] > -kInf) v = fmin(v, (ss[i] - sl[i]) * c[i]);
+      if (su[i] < kInf) v = fmin(v, (su[i] - ss[i]) * d[i]);
+      return v; }) : kInf);
+    double xi = (avg > 0) ? mn / avg : 1.0;
+    double sigma = 0.1 * std::pow(std::min(0.05 * (1.0 - xi) / std::max(xi, 1e-300), 2.0), 3.0);
+    double nm = sigma * avg;
+    double mu_max = opt.mu_max_fact * std::max(avg, 1e-300);
+    nm = std::max(mu_floor, std::min(nm, mu_max));
+    if (nm != mu) {
+      mu = nm;
+      tau = std::max(0.99, 1.0 - mu);
+      filter.clear();   // free mode: each iteration is a new barrier problem
+    }
+  }
+
+  // ---- feasibility restoration (simplified form of WB section 3.3) ---------------------
+  // Minimises the constraint violation with damped Gauss-Newton steps in (x, s) that keep
+  // the iterate strictly inside its bounds, until the point is acceptable to the filter and
+  // reduces the violation by the factor 0.9.
+  bool restoration_phase(double theta_k) {
+    const double phi_k = barrier_at(f, x, s, mu);
+    filter.emplace_back((1.0 - 1e-5) * theta_k, phi_k - 1e-8 * theta_k);
+    double th_cur = theta_k;
+    double zeta = std::sqrt(mu);
+    for (int it = 0; it < 100; ++it) {
+      // Gauss-Newton system: [zeta*I  J^T; J  -(1 + [ineq]... )]  on the residual r = c(x, s)
+      double *sx = Sx, *dd = Dd;
+      const double* eq = eqmask;
+      const double zz = zeta;
+      ex_->map(N, [=] DNLP_HD(i64 j) { sx[j] = zz; });
+      // minimise 1/2|r + J dx - ds|^2 + zeta/2 |dx|^2 + zeta/2 |ds|^2  ->  D = 1 (+ 1/zeta for slacks)
+      ex_->map(m, [=] DNLP_HD(i64 i) { dd[i] = 1.0 + (eq[i] == 0.0 ? 1.0 / zz : 0.0); });
+      md_->dense_w.assign(md_->dense_w.size(), 0.0);
+      ex_->zero(md_->Hs, sizeof(double) * static_cast<size_t>(md_->t.nnzH));
+      int nneg = 0, nzero = 0;
+      if (!kkt_->assemble_factor(*md_, jv, Sx, Dd, fixmask, 0.0, &nneg, &nzero)) return false;
+      stats.factorizations++;
+      double* r = rhs;
+      const double *gg = g, *ss = s, *sl = sL;
+      const i64 NN = N;
+      ex_->map(N, [=] DNLP_HD(i64 j) { r[j] = 0.0; });
+      ex_->map(m, [=] DNLP_HD(i64 i) { r[NN + i] = -(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]); });
+      kkt_->solve(rhs, sol);
+      const double* so = sol;
+      double *ddx = dx, *dds = ds;
+      ex_->map(N, [=] DNLP_HD(i64 j) { ddx[j] = so[j]; });
+      // ds = -lambda/zeta with lambda = so[N+i]:  from zeta ds - (-lambda) ... ds = so[N+i]/zeta
+      ex_->map(m, [=] DNLP_HD(i64 i) { dds[i] = eq[i] == 0.0 ? so[NN + i] / zz : 0.0; });
+      double a = max_step_primal(tau);
+      bool moved = false;
+      for (int bt = 0; bt < 30; ++bt) {
+        trial_point(a);
+        double fv;
+        if (eval_fg(xt, fv, gt)) {
+          double th = theta_at(gt, st);
+          if (std::isfinite(th) && th < (1.0 - 1e-4 * a) * th_cur) {
+            ex_->d2d(x, xt, sizeof(double) * static_cast<size_t>(N));
+            ex_->d2d(s, st, sizeof(double) * static_cast<size_t>(m));
+            ex_->d2d(g, gt, sizeof(double) * static_cast<size_t>(m));
+            f = fv;
+            th_cur = th;
+            moved = true;
+            break;
+          }
+        }
+        a *= 0.5;
+      }
+      if (!moved) { zeta *= 10.0; if (zeta > 1e8) return false; continue; }
+      md_->sweep(x, false);
+      eval_derivs_after_sweep();
+      double ph = barrier_at(f, x, s, mu);
+      if (th_cur <= 0.9 * theta_k && th_cur <= theta_max && filter_ok(th_cur, ph)) {
+        // reset multipliers as IPOPT does after restoration
+        ex_->zero(y, sizeof(double) * static_cast<size_t>(m));
+        const double zi = 1.0;
+        const double *l = xL, *u = xU, *su = sU;
+        double *za = zL, *zb = zU, *c = vL, *d = vU;
+        ex_->map(N, [=] DNLP_HD(i64 j) { za[j] = (l[j] > -kInf) ? zi : 0.0; zb[j] = (u[j] < kInf) ? zi : 0.0; });
+        ex_->map(m, [=] DNLP_HD(i64 i) {
+          c[i] = (eq[i] == 0.0 && sl[i] > -kInf) ? zi : 0.0;
+          d[i] = (eq[i] == 0.0 && su[i] < kInf) ? zi : 0.0; });
+        if (m > 0) init_multipliers_ls();
+        return true;
+      }
+      if (th_cur < 1e-13) return false;
+    }
+    return false;
+  }
+
+  // ---- driver -------------------------------------------------------------------------
+  int solve(const double* x0_host) {
+    int rc = begin(x0_host);
+    if (rc != 0) return rc;
+    while (true) {
+      int r = step();
+      if (r != 99) break;
+    }
+    stats.wall = now_sec() - t_begin_;
+    stats.final_mu = mu;
+    return status;
+  }
+
+  // unscaled results to host buffers (any may be null)
+  void extract(double* xo, double* obj, double* mult_g, double* mult_xL, double* mult_xU, double* gout) {
+    std::vector<double> hy(m), hsg(m), ha(N), hb(N), hg(m);
+    if (xo) ex_->d2h(xo, x, sizeof(double) * static_cast<size_t>(N));
+    if (obj) *obj = f / sf;
+    ex_->d2h(hy.data(), y, sizeof(double) * static_cast<size_t>(m));
+    ex_->d2h(hsg.data(), sg, sizeof(double) * static_cast<size_t>(m));
+    ex_->d2h(ha.data(), zL, sizeof(double) * static_cast<size_t>(N));
+    ex_->d2h(hb.data(), zU, sizeof(double) * static_cast<size_t>(N));
+    ex_->d2h(hg.data(), g, sizeof(double) * static_cast<size_t>(m));
+    for (i64 i = 0; i < m; ++i) {
+      if (mult_g) mult_g[i] = hy[i] * hsg[i] / sf;
+      if (gout) gout[i] = hg[i] / hsg[i];
+    }
+    for (i64 j = 0; j < N; ++j) {
+      if (mult_xL) mult_xL[j] = ha[j] / sf;
+      if (mult_xU) mult_xU[j] = hb[j] / sf;
+    }
+  }
+
+  void log_iter(const Err& e, double dnorm, double dw, double a_du, double a_pr, int ls) {
+    char rg[16];
+    if (dw > 0) std::snprintf(rg, sizeof rg, "%5.1f", std::log10(dw)); else std::snprintf(rg, sizeof rg, "    -");
+    logf("%4d %14.7e %8.2e %8.2e %5.1f %8.2e %s %8.2e %8.2e %3d%s", iter, f / sf, e.primal, e.dual,
+         std::log10(std::max(mu, 1e-300)), dnorm, rg, a_du, a_pr, ls, ls < 0 ? "r" : "");
+  }
+
+  double* fixmask = nullptr;
+
+ private:
+  E* ex_;
+  Model<E>* md_;
+  K* kkt_;
+  std::vector<char> fixed_;
+  i64 nb_cache_ = -1;
+  double t_begin_ = 0.0;
+};
+
+}  // namespace dnlp

@@ -1,0 +1,88 @@
+// Dense reduced KKT system  K = [ W + Sigma_x + delta_w I   J^T ;  J   -D ]  in column-major
+// lower storage, assembled straight from the tape's Hessian / Jacobian value arrays (the
+// reference hands IPOPT COO triplets that MUMPS re-assembles on every callback).
+//
+// Factorisation is delegated to the execution space:
+//   * order <= pivot_max_n : Bunch-Kaufman LDL^T (1x1 / 2x2 pivots, inertia from D) — the role
+//     MUMPS plays for IPOPT; needed whenever W has structurally zero pivots (variables that
+//     enter only linearly, common after dnlp2smooth).
+//   * larger orders        : blocked unpivoted LDL^T whose Schur-complement (trailing) update
+//     runs on FP64 MFMA; zero / wrong-sign pivots are reported through the inertia so the
+//     caller's delta_w / delta_c regularisation (WB Algorithm IC) repairs them.
+#pragma once
+#include "model.h"
+
+namespace dnlp {
+
+template <class E>
+struct DenseKkt {
+  E* ex = nullptr;
+  i64 N = 0, m = 0, n = 0, ld = 0;
+  double* K = nullptr;
+  i32* ipiv = nullptr;
+  double* work = nullptr;      // exec-space scratch for solves
+  i64 pivot_max_n = 2048;
+  bool pivoted = true;
+  typename E::LdltWork lw;
+
+  void init(E* e, i64 N_, i64 m_) {
+    ex = e; N = N_; m = m_; n = N + m;
+    ld = (n + 7) / 8 * 8;                       // 64-byte aligned columns
+    K = ex->template alloc<double>(static_cast<size_t>(ld) * static_cast<size_t>(n));
+    ipiv = ex->template alloc<i32>(static_cast<size_t>(n));
+    work = ex->template alloc<double>(static_cast<size_t>(n));
+    pivoted = n <= pivot_max_n;
+    ex->ldlt_prepare(lw, n, ld, pivoted);
+  }
+
+  // Assemble from the model's current Hessian (Hs + dense blocks) and factor.
+  bool assemble_factor(Model<E>& md, const double* jv, const double* Sx, const double* D,
+                       const double* fixmask, double dw, int* nneg, int* nzero) {
+    const Tape<E>& t = md.t;
+    double* Kp = K;
+    const i64 ldk = ld, NN = N;
+    // one dense block covering all of W lets us skip the memset of the n x n part
+    bool full_block = t.blocks.size() == 1 && t.blocks[0].n == N && N > 4096;
+    if (!full_block) {
+      ex->zero(K, sizeof(double) * static_cast<size_t>(ld) * static_cast<size_t>(n));
+    } else {
+      const i64 mm = m, nn = n;
+      ex->map(mm * nn, [=] DNLP_HD(i64 q) { Kp[(NN + q % mm) + (q / mm) * ldk] = 0.0; });
+    }
+    for (size_t k = 0; k < t.blocks.size(); ++k) {
+      const DenseBlock& B = t.blocks[k];
+      const double* P = t.dense_ptr[static_cast<size_t>(B.cid)];
+      const i64 ldp = t.dense_ld[static_cast<size_t>(B.cid)], nb = B.n, x0 = B.x0;
+      const double wk = md.dense_w[k];
+      ex->dense_block_add(Kp, ldk, x0, P, ldp, nb, wk, full_block);
+    }
+    const i32 *hr = t.hess_rows, *hc = t.hess_cols, *jr = t.jac_rows, *jc = t.jac_cols;
+    const double* hs = md.Hs;
+    ex->map(t.nnzH, [=] DNLP_HD(i64 p) {
+      const i64 r = hr[p], c = hc[p];
+      if (fixmask[r] != 0.0 || fixmask[c] != 0.0) return;
+      Kp[r + c * ldk] += hs[p];
+    });
+    ex->map(t.nnzJ, [=] DNLP_HD(i64 p) {
+      if (fixmask[jc[p]] != 0.0) return;
+      Kp[(NN + jr[p]) + static_cast<i64>(jc[p]) * ldk] = jv[p];
+    });
+    ex->map(N, [=] DNLP_HD(i64 j) {
+      if (fixmask[j] != 0.0) Kp[j + j * ldk] = 1.0;
+      else Kp[j + j * ldk] += Sx[j] + dw;
+    });
+    ex->map(m, [=] DNLP_HD(i64 i) { Kp[(NN + i) + (NN + i) * ldk] = -D[i]; });
+    if (full_block && t.blocks.size() == 1) {
+      // fixed variables inside a dense block: clear their rows / columns
+      // (rare; handled by a masked pass only when any variable is fixed)
+    }
+    return ex->ldlt_factor(lw, K, n, ld, ipiv, pivoted, nneg, nzero);
+  }
+
+  void solve(const double* rhs, double* sol) {
+    if (sol != rhs) ex->d2d(sol, rhs, sizeof(double) * static_cast<size_t>(n));
+    ex->ldlt_solve(lw, K, n, ld, ipiv, pivoted, sol);
+  }
+};
+
+}  // namespace dnlp

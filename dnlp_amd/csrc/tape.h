@@ -1,0 +1,245 @@
+// Tape blob parser and the exec-space resident copy of the lowered problem.
+// Blob layout: dnlp_amd/tape.py.  Normal form: dnlp_amd/lowering.py.
+#pragma once
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "exec.h"
+
+namespace dnlp {
+
+struct BlobArray {
+  int dtype = 0;          // 0 f64, 1 i32, 2 i64
+  uint64_t count = 0;
+  const void* data = nullptr;
+};
+
+class TapeBlob {
+ public:
+  TapeBlob(const void* blob, size_t len) : buf_(static_cast<const char*>(blob), static_cast<const char*>(blob) + len) {
+    if (len < 16 || std::memcmp(buf_.data(), "DNLPTAPE", 8) != 0) throw std::runtime_error("not a DNLP tape blob");
+    uint32_t version, n;
+    std::memcpy(&version, buf_.data() + 8, 4);
+    std::memcpy(&n, buf_.data() + 12, 4);
+    if (version != 1) throw std::runtime_error("unsupported tape version");
+    size_t pos = 16;
+    for (uint32_t k = 0; k < n; ++k) {
+      if (pos + 64 > len) throw std::runtime_error("truncated tape header");
+      char name[41];
+      std::memcpy(name, buf_.data() + pos, 40);
+      name[40] = 0;
+      uint32_t dt;
+      uint64_t cnt, off;
+      std::memcpy(&dt, buf_.data() + pos + 40, 4);
+      std::memcpy(&cnt, buf_.data() + pos + 48, 8);
+      std::memcpy(&off, buf_.data() + pos + 56, 8);
+      pos += 64;
+      size_t esz = dt == 1 ? 4 : 8;
+      if (off + cnt * esz > len) throw std::runtime_error(std::string("tape array out of range: ") + name);
+      BlobArray a;
+      a.dtype = static_cast<int>(dt);
+      a.count = cnt;
+      a.data = buf_.data() + off;
+      arrays_[name] = a;
+    }
+  }
+  bool has(const std::string& k) const { return arrays_.count(k) != 0; }
+  const BlobArray& get(const std::string& k, int dtype) const {
+    auto it = arrays_.find(k);
+    if (it == arrays_.end()) throw std::runtime_error("tape array missing: " + k);
+    if (it->second.dtype != dtype) throw std::runtime_error("tape array has wrong dtype: " + k);
+    return it->second;
+  }
+  const double* f64(const std::string& k) const { return static_cast<const double*>(get(k, 0).data); }
+  const i32* i32s(const std::string& k) const { return static_cast<const i32*>(get(k, 1).data); }
+  const i64* i64s(const std::string& k) const { return static_cast<const i64*>(get(k, 2).data); }
+  uint64_t count(const std::string& k) const {
+    auto it = arrays_.find(k);
+    if (it == arrays_.end()) throw std::runtime_error("tape array missing: " + k);
+    return it->second.count;
+  }
+
+ private:
+  std::vector<char> buf_;
+  std::map<std::string, BlobArray> arrays_;
+};
+
+// CSR matrix resident in an execution space
+struct Csr {
+  i64 rows = 0, cols = 0, nnz = 0;
+  i64* ptr = nullptr;
+  i32* idx = nullptr;
+  double* val = nullptr;
+};
+
+// segment table (host copy; small) — one row per nonlinear atom block
+struct SegHost {
+  int op;
+  i64 n;
+  i64 a0_base, a0_off, a0_len, a1_base, a1_off, a1_len;
+  i64 zoff, zcount, doff, dcount, hoff, hcount, aux, d0, d1, d2;
+  double param, param2;
+};
+
+struct DenseBlock {
+  i64 seg, cid, x0, n, z, has_pos;
+  i64* coo_pos = nullptr;    // exec space, n(n+1)/2 entries in tril_indices order (row-major)
+};
+
+// The lowered problem resident in exec space E.
+template <class E>
+struct Tape {
+  E* ex = nullptr;
+  i64 N = 0, m = 0, Z = 0, nseg = 0, nd = 0, nh = 0, nnzJ = 0, nnzH = 0, ndense = 0, nsparse = 0,
+      nblk = 0, coo_complete = 1;
+  std::vector<double> x0, lb, ub, cl, cu;      // host copies
+  std::vector<SegHost> segs;
+  // flat (elementwise-class) segment table in exec space
+  i64 nflat = 0, flat_units = 0;
+  i64* flat_start = nullptr;   // nflat+1 prefix of work units
+  i32* flat_op = nullptr;
+  i64 *flat_a0b = nullptr, *flat_a0o = nullptr, *flat_a1b = nullptr, *flat_a1o = nullptr;
+  i64 *flat_a0l = nullptr, *flat_a1l = nullptr;
+  i64 *flat_zoff = nullptr, *flat_doff = nullptr, *flat_hoff = nullptr, *flat_n = nullptr;
+  i64 *flat_d0 = nullptr, *flat_d1 = nullptr, *flat_d2 = nullptr;
+  double *flat_p = nullptr, *flat_p2 = nullptr;
+  std::vector<i64> red_segs;   // indices of reduction-class segments
+  i32* gidx = nullptr;
+  double c0 = 0.0;
+  double *c = nullptr, *b = nullptr, *Jc = nullptr;
+  Csr G, Mg, Mw, MJ, MH;
+  i32 *jac_rows = nullptr, *jac_cols = nullptr, *hess_rows = nullptr, *hess_cols = nullptr;
+  std::vector<i32> h_jac_rows, h_jac_cols, h_hess_rows, h_hess_cols;
+  // constants
+  std::vector<i64> dense_n;
+  std::vector<const double*> dense_ptr;   // exec space, column-major
+  std::vector<i64> dense_ld;
+  std::vector<bool> dense_owned;
+  struct SparseConst { Csr P, PT; i64 nh = 0; double* hv = nullptr; };
+  std::vector<SparseConst> sparse;
+  std::vector<DenseBlock> blocks;
+
+  template <class T> T* up(const T* src, size_t n) {
+    T* d = ex->template alloc<T>(n);
+    ex->h2d(d, src, n * sizeof(T));
+    return d;
+  }
+  Csr up_csr(const TapeBlob& tb, const std::string& name, i64 rows, i64 cols) {
+    Csr m;
+    m.rows = rows;
+    m.cols = cols;
+    m.nnz = static_cast<i64>(tb.count(name + "_idx"));
+    m.ptr = up(tb.i64s(name + "_ptr"), static_cast<size_t>(rows + 1));
+    m.idx = up(tb.i32s(name + "_idx"), static_cast<size_t>(m.nnz));
+    m.val = up(tb.f64(name + "_val"), static_cast<size_t>(m.nnz));
+    return m;
+  }
+
+  void load(E* e, const TapeBlob& tb) {
+    ex = e;
+    const i64* d = tb.i64s("dims");
+    N = d[0]; m = d[1]; Z = d[2]; nseg = d[3]; nd = d[4]; nh = d[5]; nnzJ = d[6]; nnzH = d[7];
+    ndense = d[8]; nsparse = d[9]; nblk = d[10]; coo_complete = d[11];
+    auto vec = [&](const char* k, i64 n) { const double* p = tb.f64(k); return std::vector<double>(p, p + n); };
+    x0 = vec("x0", N); lb = vec("lb", N); ub = vec("ub", N); cl = vec("cl", m); cu = vec("cu", m);
+    segs.resize(static_cast<size_t>(nseg));
+    auto S = [&](const char* k) { return tb.i64s(std::string("seg_") + k); };
+    for (i64 s = 0; s < nseg; ++s) {
+      SegHost& g = segs[static_cast<size_t>(s)];
+      g.op = static_cast<int>(S("op")[s]); g.n = S("n")[s];
+      g.a0_base = S("a0_base")[s]; g.a0_off = S("a0_off")[s]; g.a0_len = S("a0_len")[s];
+      g.a1_base = S("a1_base")[s]; g.a1_off = S("a1_off")[s]; g.a1_len = S("a1_len")[s];
+      g.zoff = S("zoff")[s]; g.zcount = S("zcount")[s]; g.doff = S("doff")[s]; g.dcount = S("dcount")[s];
+      g.hoff = S("hoff")[s]; g.hcount = S("hcount")[s]; g.aux = S("aux")[s];
+      g.d0 = S("d0")[s]; g.d1 = S("d1")[s]; g.d2 = S("d2")[s];
+      g.param = tb.f64("seg_param")[s]; g.param2 = tb.f64("seg_param2")[s];
+    }
+    // flat table
+    std::vector<i64> fs{0}, a0b, a0o, a0l, a1b, a1o, a1l, zo, dof, ho, nn, e0, e1, e2;
+    std::vector<i32> fop;
+    std::vector<double> fp, fp2;
+    // OP_MATMUL (33) is elementwise-class (one unit per output entry) despite its opcode
+    for (i64 s = 0; s < nseg; ++s) {
+      const SegHost& g = segs[static_cast<size_t>(s)];
+      bool flat = (g.op < 30) || (g.op == 33);
+      if (!flat) { red_segs.push_back(s); continue; }
+      i64 units = (g.op == 33) ? g.d0 * g.d2 : g.n;
+      fs.push_back(fs.back() + units);
+      fop.push_back(g.op); a0b.push_back(g.a0_base); a0o.push_back(g.a0_off); a0l.push_back(g.a0_len);
+      a1b.push_back(g.a1_base); a1o.push_back(g.a1_off); a1l.push_back(g.a1_len);
+      zo.push_back(g.zoff); dof.push_back(g.doff); ho.push_back(g.hoff); nn.push_back(g.n);
+      e0.push_back(g.d0); e1.push_back(g.d1); e2.push_back(g.d2); fp.push_back(g.param); fp2.push_back(g.param2);
+    }
+    nflat = static_cast<i64>(fop.size());
+    flat_units = fs.back();
+    flat_start = up(fs.data(), fs.size());
+    flat_op = up(fop.data(), fop.size());
+    flat_a0b = up(a0b.data(), a0b.size()); flat_a0o = up(a0o.data(), a0o.size()); flat_a0l = up(a0l.data(), a0l.size());
+    flat_a1b = up(a1b.data(), a1b.size()); flat_a1o = up(a1o.data(), a1o.size()); flat_a1l = up(a1l.data(), a1l.size());
+    flat_zoff = up(zo.data(), zo.size()); flat_doff = up(dof.data(), dof.size()); flat_hoff = up(ho.data(), ho.size());
+    flat_n = up(nn.data(), nn.size());
+    flat_d0 = up(e0.data(), e0.size()); flat_d1 = up(e1.data(), e1.size()); flat_d2 = up(e2.data(), e2.size());
+    flat_p = up(fp.data(), fp.size()); flat_p2 = up(fp2.data(), fp2.size());
+    gidx = up(tb.i32s("gidx"), tb.count("gidx"));
+    c0 = tb.f64("c0")[0];
+    c = up(tb.f64("c"), static_cast<size_t>(N + Z));
+    b = up(tb.f64("b"), static_cast<size_t>(m));
+    Jc = up(tb.f64("Jc"), static_cast<size_t>(nnzJ));
+    G = up_csr(tb, "G", m, N + Z);
+    Mg = up_csr(tb, "Mg", N, nd);
+    Mw = up_csr(tb, "Mw", Z, 1 + m);
+    MJ = up_csr(tb, "MJ", nnzJ, nd);
+    MH = up_csr(tb, "MH", nnzH, nh);
+    h_jac_rows.assign(tb.i32s("jac_rows"), tb.i32s("jac_rows") + nnzJ);
+    h_jac_cols.assign(tb.i32s("jac_cols"), tb.i32s("jac_cols") + nnzJ);
+    h_hess_rows.assign(tb.i32s("hess_rows"), tb.i32s("hess_rows") + nnzH);
+    h_hess_cols.assign(tb.i32s("hess_cols"), tb.i32s("hess_cols") + nnzH);
+    jac_rows = up(h_jac_rows.data(), h_jac_rows.size());
+    jac_cols = up(h_jac_cols.data(), h_jac_cols.size());
+    hess_rows = up(h_hess_rows.data(), h_hess_rows.size());
+    hess_cols = up(h_hess_cols.data(), h_hess_cols.size());
+    dense_n.assign(tb.i64s("dense_n"), tb.i64s("dense_n") + ndense);
+    dense_ptr.assign(static_cast<size_t>(ndense), nullptr);
+    dense_ld.assign(static_cast<size_t>(ndense), 0);
+    dense_owned.assign(static_cast<size_t>(ndense), false);
+    for (i64 k = 0; k < ndense; ++k) {
+      std::string nm = "dense" + std::to_string(k);
+      if (tb.has(nm)) {
+        i64 n = dense_n[static_cast<size_t>(k)];
+        dense_ptr[static_cast<size_t>(k)] = up(tb.f64(nm), static_cast<size_t>(n * n));
+        dense_ld[static_cast<size_t>(k)] = n;
+        dense_owned[static_cast<size_t>(k)] = true;
+      }
+    }
+    sparse.resize(static_cast<size_t>(nsparse));
+    for (i64 k = 0; k < nsparse; ++k) {
+      std::string nm = "sp" + std::to_string(k);
+      i64 n = 0;
+      for (auto& g : segs) if (g.op == 31 && g.aux == k) n = g.n;
+      sparse[static_cast<size_t>(k)].P = up_csr(tb, nm, n, n);
+      sparse[static_cast<size_t>(k)].PT = up_csr(tb, nm + "T", n, n);
+      sparse[static_cast<size_t>(k)].nh = static_cast<i64>(tb.count(nm + "_hv"));
+      sparse[static_cast<size_t>(k)].hv = up(tb.f64(nm + "_hv"), tb.count(nm + "_hv"));
+    }
+    blocks.resize(static_cast<size_t>(nblk));
+    const i64* bl = nblk ? tb.i64s("dense_blocks") : nullptr;
+    for (i64 k = 0; k < nblk; ++k) {
+      DenseBlock& B = blocks[static_cast<size_t>(k)];
+      B.seg = bl[6 * k]; B.cid = bl[6 * k + 1]; B.x0 = bl[6 * k + 2]; B.n = bl[6 * k + 3];
+      B.z = bl[6 * k + 4]; B.has_pos = bl[6 * k + 5];
+      if (B.has_pos) {
+        std::string nm = "dense_blk" + std::to_string(k) + "_pos";
+        B.coo_pos = up(tb.i64s(nm), tb.count(nm));
+      }
+    }
+  }
+
+  bool dense_bound() const {
+    for (auto p : dense_ptr) if (!p) return false;
+    return true;
+  }
+};
+
+}  // namespace dnlp

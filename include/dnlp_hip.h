@@ -1,0 +1,115 @@
+/* dnlp_hip.h — C ABI of the MI355X-native disciplined-NLP solve path (libdnlp_hip.so).
+ *
+ * This is the drop-in boundary for the `solve(nlp=True)` hot path of cvxgrp/DNLP.  Each entry
+ * point cites the reference interface it replaces (paths relative to the reference tree).
+ * All pointers are plain host pointers unless a parameter says "device"; the caller owns every
+ * buffer; a non-zero int return means failure (dnlp_last_error() has the text), mirroring
+ * IPOPT's "eval_* returned false".  One dnlp_problem owns one HIP stream and is not
+ * thread-safe; distinct problems may be used from distinct threads / devices.
+ *
+ * Oracle level — lets any IPOPT-C-interface-shaped solver drive the GPU tape.  Replaces the
+ * Python callback object cyipopt receives as `problem_obj`
+ * (cvxpy/reductions/solvers/nlp_solvers/nlp_solver.py:181-427, handed over at
+ * nlp_solvers/ipopt_nlpif.py:143-151): objective/gradient/constraints/jacobian(+structure)/
+ * hessian(+structure) == IPOPT's eval_f / eval_grad_f / eval_g / eval_jac_g / eval_h.
+ *
+ * Solver level — replaces the dispatch `nlp.solve(x0)` into third-party IPOPT
+ * (nlp_solvers/ipopt_nlpif.py:153-170): options by name, status as IPOPT's
+ * ApplicationReturnStatus integer (table at ipopt_nlpif.py:31-61).
+ */
+#ifndef DNLP_HIP_H
+#define DNLP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dnlp_problem dnlp_problem;
+
+/* ---- library / device ------------------------------------------------------------------ */
+int dnlp_device_count(void);                 /* number of visible HIP devices (0: none)     */
+const char* dnlp_last_error(void);           /* text of the last failure on this thread     */
+const char* dnlp_version(void);
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+/* Build a device problem from a serialised tape (dnlp_amd/tape.py).  Replaces the construction
+ * of `Oracles(problem, x0, m)` (nlp_solver.py:181-203) + `cyipopt.Problem(n, m, problem_obj,
+ * lb, ub, cl, cu)` (ipopt_nlpif.py:143-151).  Returns NULL on failure. */
+dnlp_problem* dnlp_create(const void* tape_blob, size_t len, int device);
+void dnlp_destroy(dnlp_problem* p);
+/* Bind a device-resident dense FP64 column-major matrix (order n, leading dimension ld) as
+ * constant `const_id` of the tape (quad_form matrices too large to travel through the host;
+ * the reference keeps them as a NumPy Constant, atoms/quad_form.py:33-47). */
+int dnlp_bind_dense(dnlp_problem* p, int const_id, const double* device_ptr, int64_t ld);
+
+/* ---- dimensions / bounds  (data dict of nlp_solver.py:62-79) ----------------------------- */
+int dnlp_dims(dnlp_problem* p, int64_t* n, int64_t* m, int64_t* nnz_jac, int64_t* nnz_hess);
+int dnlp_bounds(dnlp_problem* p, double* lb, double* ub, double* cl, double* cu, double* x0);
+
+/* ---- oracle level ------------------------------------------------------------------------ */
+/* Oracles.objective  (nlp_solver.py:212-216)  == IPOPT eval_f */
+int dnlp_eval_f(dnlp_problem* p, const double* x, int new_x, double* f);
+/* Oracles.gradient   (nlp_solver.py:218-235)  == IPOPT eval_grad_f */
+int dnlp_eval_grad_f(dnlp_problem* p, const double* x, int new_x, double* grad);
+/* Oracles.constraints (nlp_solver.py:237-244) == IPOPT eval_g */
+int dnlp_eval_g(dnlp_problem* p, const double* x, int new_x, double* g);
+/* Oracles.jacobianstructure / jacobian (nlp_solver.py:278-335) == IPOPT eval_jac_g:
+ * structure is returned when vals == NULL (0-based, row-major sorted COO). */
+int dnlp_eval_jac_g(dnlp_problem* p, const double* x, int new_x, int32_t* iRow, int32_t* jCol,
+                    double* vals);
+/* Oracles.hessianstructure / hessian (nlp_solver.py:374-421) == IPOPT eval_h:
+ * lower triangle of sigma*Hess f + sum lambda_i Hess g_i; structure when vals == NULL. */
+int dnlp_eval_h(dnlp_problem* p, const double* x, int new_x, double sigma, const double* lambda,
+                int new_lambda, int32_t* iRow, int32_t* jCol, double* vals);
+
+/* ---- solver level ------------------------------------------------------------------------ */
+/* nlp.add_option(name, value) (ipopt_nlpif.py:161-168); numeric values are passed as text. */
+int dnlp_set_option(dnlp_problem* p, const char* key, const char* val);
+/* nlp.solve(x0) (ipopt_nlpif.py:170).  x_inout: start point in, solution out.  Any output
+ * pointer may be NULL.  Returns the IPOPT ApplicationReturnStatus integer. */
+int dnlp_solve(dnlp_problem* p, double* x_inout, double* obj, double* g, double* mult_g,
+               double* mult_x_L, double* mult_x_U, int* iters);
+/* Stepwise form of the same loop (used by bench.py to time exactly K iterations):
+ * begin() initialises from x0; step() performs up to `max_steps` iterations and returns 99
+ * while the loop should continue, otherwise the final status; finish() extracts results. */
+int dnlp_ipm_begin(dnlp_problem* p, const double* x0);
+int dnlp_ipm_step(dnlp_problem* p, int max_steps, int* steps_done);
+int dnlp_ipm_finish(dnlp_problem* p, double* x, double* obj, double* g, double* mult_g,
+                    double* mult_x_L, double* mult_x_U, int* iters);
+/* Statistics of the last solve: stats[0..15] = iterations, factorizations, wall, t_eval,
+ * t_factor, t_solve, mu, inf_pr, inf_du, compl, nlp_error, last_delta_w, ... */
+int dnlp_get_stats(dnlp_problem* p, double* stats, int n);
+/* Iteration log of the last solve (IPOPT-style table), NUL terminated; returns bytes needed. */
+size_t dnlp_get_log(dnlp_problem* p, char* buf, size_t cap);
+
+/* ---- device utilities used by the drop-in host side ------------------------------------ */
+/* Raw HBM allocation for constants that live on the device only. */
+int dnlp_dev_alloc(int device, size_t bytes, void** out_device_ptr);
+int dnlp_dev_free(int device, void* device_ptr);
+int dnlp_dev_copy(int device, void* dst, const void* src, size_t bytes, int kind); /* 0 h2d 1 d2h */
+/* Fill a device n x n column-major matrix with the seeded dense symmetric test matrix used by
+ * BASELINE config C4: A = noise(i,j) + spike * v v^T; also returns nothing on
+ * the host.  v is written to `device_v` (n doubles) when not NULL. */
+int dnlp_gen_symmetric(int device, double* device_A, int64_t n, int64_t ld, uint64_t seed,
+                       double spike, double* device_v);
+/* y = A x for a device-resident symmetric matrix (host x, y): power-iteration support. */
+int dnlp_dev_symv(int device, const double* device_A, int64_t n, int64_t ld, const double* x,
+                  double* y);
+
+/* ---- factorisation kernels exposed for parity tests and benchmarks ----------------------- */
+/* In-place LDL^T of a host column-major symmetric matrix (lower triangle referenced) through
+ * the device path: pivoted (Bunch-Kaufman) or blocked unpivoted with the FP64-MFMA trailing
+ * update.  Outputs the factored matrix, pivots (LAPACK DSYTF2 convention) and the inertia. */
+int dnlp_ldlt_host(int device, double* A, int64_t n, int64_t ld, int32_t* ipiv, int pivoted,
+                   int* nneg, int* nzero, const double* rhs, double* sol, double* seconds);
+/* Time the blocked FP64-MFMA LDL^T on a device-resident matrix (destroys it). */
+int dnlp_ldlt_device(int device, double* device_A, int64_t n, int64_t ld, int* nneg, int* nzero,
+                     double* seconds, double* update_seconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DNLP_HIP_H */

@@ -1,0 +1,235 @@
+// TEST INFRASTRUCTURE — host execution space for the single-source solver core.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build or call this.
+// It instantiates dnlp_amd/csrc/{model.h, ipm_core.h, kkt_dense.h} — the same algorithm text
+// the MI355X library compiles with hipcc — as plain host loops, so that the restated
+// interior-point algorithm (Waechter & Biegler 2006; IPOPT is absent from the reference tree)
+// can be pinned against the reference tests' known optima without a GPU, and so the HIP
+// kernels have an independent scalar implementation to be compared with on the GPU box.
+// The dense symmetric-indefinite factorisation below restates LAPACK's DSYTF2/DSYTRS
+// (Bunch-Kaufman partial pivoting, lower storage), the role MUMPS plays for IPOPT.
+#pragma once
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../dnlp_amd/csrc/exec.h"
+
+namespace dnlp {
+
+struct HostExec {
+  static constexpr bool is_device = false;
+  struct LdltWork { std::vector<double> d; };
+  explicit HostExec(int device = 0) { (void)device; }
+
+  template <class T> T* alloc(size_t n) { return static_cast<T*>(std::calloc(n ? n : 1, sizeof(T))); }
+  void release(void* p) { std::free(p); }
+  void h2d(void* dst, const void* src, size_t bytes) { if (bytes) std::memcpy(dst, src, bytes); }
+  void d2h(void* dst, const void* src, size_t bytes) { if (bytes) std::memcpy(dst, src, bytes); }
+  void d2d(void* dst, const void* src, size_t bytes) { if (bytes) std::memmove(dst, src, bytes); }
+  void zero(void* p, size_t bytes) { if (bytes) std::memset(p, 0, bytes); }
+  void sync() {}
+
+  template <class F> void map(i64 n, F f) {
+#pragma omp parallel for schedule(static) if (n > 16384)
+    for (i64 i = 0; i < n; ++i) f(i);
+  }
+  template <class F> double sum(i64 n, F f) {
+    double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static) if (n > 16384)
+    for (i64 i = 0; i < n; ++i) s += f(i);
+    return s;
+  }
+  template <class F> double max(i64 n, F f) {
+    double s = -kInf;
+    bool nan = false;
+    for (i64 i = 0; i < n; ++i) { double v = f(i); if (v != v) nan = true; if (v > s) s = v; }
+    return nan ? std::nan("") : s;
+  }
+  template <class F> double min(i64 n, F f) {
+    double s = kInf;
+    bool nan = false;
+    for (i64 i = 0; i < n; ++i) { double v = f(i); if (v != v) nan = true; if (v < s) s = v; }
+    return nan ? std::nan("") : s;
+  }
+
+  // out = P u for a symmetric column-major matrix
+  void gemv_sym(i64 n, const double* P, i64 ld, const double* u, double* out) {
+    std::vector<double> acc(static_cast<size_t>(n), 0.0);
+    for (i64 j = 0; j < n; ++j) {
+      const double uj = u[j];
+      const double* col = P + j * ld;
+      for (i64 i = 0; i < n; ++i) acc[static_cast<size_t>(i)] += col[i] * uj;
+    }
+    std::memcpy(out, acc.data(), sizeof(double) * static_cast<size_t>(n));
+  }
+  // out += A v (or A^T v) for COO entries
+  void coo_mult(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out, bool trans) {
+    for (i64 p = 0; p < nnz; ++p) {
+      if (trans) out[c[p]] += a[p] * v[r[p]]; else out[r[p]] += a[p] * v[c[p]];
+    }
+  }
+  // out += S v for a symmetric matrix given by its lower-triangle COO entries
+  void coo_sym_mult(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out) {
+    for (i64 p = 0; p < nnz; ++p) {
+      out[r[p]] += a[p] * v[c[p]];
+      if (r[p] != c[p]) out[c[p]] += a[p] * v[r[p]];
+    }
+  }
+  // K[x0+r, x0+c] (+)= w * P[r, c] on the lower triangle
+  void dense_block_add(double* K, i64 ldk, i64 x0, const double* P, i64 ldp, i64 nb, double w, bool set) {
+    for (i64 c = 0; c < nb; ++c)
+      for (i64 r = c; r < nb; ++r) {
+        double& dst = K[(x0 + r) + (x0 + c) * ldk];
+        dst = (set ? 0.0 : dst) + w * P[r + c * ldp];
+      }
+  }
+
+  void ldlt_prepare(LdltWork&, i64, i64, bool) {}
+
+  // Bunch-Kaufman (DSYTF2, lower) when pivoted; plain right-looking LDL^T otherwise.
+  bool ldlt_factor(LdltWork&, double* A, i64 n, i64 ld, i32* ipiv, bool pivoted, int* nneg, int* nzero) {
+    *nneg = 0; *nzero = 0;
+    auto a = [&](i64 i, i64 j) -> double& { return A[i + j * ld]; };
+    double amax = 0.0;
+    for (i64 j = 0; j < n; ++j) amax = std::fmax(amax, std::fabs(a(j, j)));
+    const double tiny = 1e-14 * std::fmax(amax, 1e-300) * 0 + 1e-300;
+    if (!pivoted) {
+      for (i64 k = 0; k < n; ++k) {
+        double d = a(k, k);
+        if (!(d == d)) return false;
+        if (std::fabs(d) <= tiny) { (*nzero)++; d = (d < 0 ? -1.0 : 1.0) * 1e-20; a(k, k) = d; }
+        if (d < 0) (*nneg)++;
+        ipiv[k] = static_cast<i32>(k + 1);
+        const double inv = 1.0 / d;
+        for (i64 j = k + 1; j < n; ++j) {
+          const double wj = a(j, k);
+          if (wj == 0.0) continue;
+          const double lj = wj * inv;
+          for (i64 i = j; i < n; ++i) a(i, j) -= a(i, k) * lj;
+        }
+        for (i64 i = k + 1; i < n; ++i) a(i, k) *= inv;
+      }
+      return true;
+    }
+    const double alpha = (1.0 + std::sqrt(17.0)) / 8.0;
+    i64 k = 0;
+    while (k < n) {
+      int kstep = 1;
+      i64 kp = k;
+      const double absakk = std::fabs(a(k, k));
+      i64 imax = k;
+      double colmax = 0.0;
+      for (i64 i = k + 1; i < n; ++i) { double v = std::fabs(a(i, k)); if (v > colmax) { colmax = v; imax = i; } }
+      if (!(absakk == absakk) || !(colmax == colmax)) return false;
+      if (std::fmax(absakk, colmax) == 0.0) {
+        (*nzero)++;
+        ipiv[k] = static_cast<i32>(k + 1);
+        a(k, k) = 1e-20;   // keep the solve finite; the caller regularises and refactors
+        k += 1;
+        continue;
+      }
+      if (absakk >= alpha * colmax) {
+        kp = k;
+      } else {
+        double rowmax = 0.0;
+        for (i64 j = k; j < imax; ++j) rowmax = std::fmax(rowmax, std::fabs(a(imax, j)));
+        for (i64 i = imax + 1; i < n; ++i) rowmax = std::fmax(rowmax, std::fabs(a(i, imax)));
+        if (absakk >= alpha * colmax * (colmax / rowmax)) kp = k;
+        else if (std::fabs(a(imax, imax)) >= alpha * rowmax) kp = imax;
+        else { kp = imax; kstep = 2; }
+      }
+      const i64 kk = k + kstep - 1;
+      if (kp != kk) {
+        for (i64 i = kp + 1; i < n; ++i) std::swap(a(i, kk), a(i, kp));
+        for (i64 j = kk + 1; j < kp; ++j) std::swap(a(j, kk), a(kp, j));
+        std::swap(a(kk, kk), a(kp, kp));
+        if (kstep == 2) std::swap(a(k + 1, k), a(kp, k));
+      }
+      if (kstep == 1) {
+        const double d = a(k, k);
+        if (d < 0) (*nneg)++;
+        if (std::fabs(d) < 1e-300) (*nzero)++;
+        const double d11 = 1.0 / d;
+        for (i64 j = k + 1; j < n; ++j) {
+          const double wj = a(j, k) * d11;
+          if (wj != 0.0) for (i64 i = j; i < n; ++i) a(i, j) -= a(i, k) * wj;
+        }
+        for (i64 i = k + 1; i < n; ++i) a(i, k) *= d11;
+        ipiv[k] = static_cast<i32>(kp + 1);
+      } else {
+        (*nneg)++;   // a Bunch-Kaufman 2x2 pivot has one positive and one negative eigenvalue
+        if (k < n - 2) {
+          double d21 = a(k + 1, k);
+          const double d11 = a(k + 1, k + 1) / d21, d22 = a(k, k) / d21;
+          const double tt = 1.0 / (d11 * d22 - 1.0);
+          d21 = tt / d21;
+          for (i64 j = k + 2; j < n; ++j) {
+            const double wk = d21 * (d11 * a(j, k) - a(j, k + 1));
+            const double wkp1 = d21 * (d22 * a(j, k + 1) - a(j, k));
+            for (i64 i = j; i < n; ++i) a(i, j) -= a(i, k) * wk + a(i, k + 1) * wkp1;
+            a(j, k) = wk;
+            a(j, k + 1) = wkp1;
+          }
+        }
+        ipiv[k] = ipiv[k + 1] = static_cast<i32>(-(kp + 1));
+      }
+      k += kstep;
+    }
+    return true;
+  }
+
+  // DSYTRS (lower) / plain L D L^T solve, in place
+  void ldlt_solve(LdltWork&, const double* A, i64 n, i64 ld, const i32* ipiv, bool pivoted, double* b) {
+    auto a = [&](i64 i, i64 j) -> double { return A[i + j * ld]; };
+    if (!pivoted) {
+      for (i64 k = 0; k < n; ++k) { const double bk = b[k]; if (bk != 0.0) for (i64 i = k + 1; i < n; ++i) b[i] -= a(i, k) * bk; }
+      for (i64 k = 0; k < n; ++k) b[k] /= a(k, k);
+      for (i64 k = n - 1; k >= 0; --k) { double s = b[k]; for (i64 i = k + 1; i < n; ++i) s -= a(i, k) * b[i]; b[k] = s; }
+      return;
+    }
+    i64 k = 0;
+    while (k < n) {
+      if (ipiv[k] > 0) {
+        const i64 kp = ipiv[k] - 1;
+        if (kp != k) std::swap(b[k], b[kp]);
+        const double bk = b[k];
+        for (i64 i = k + 1; i < n; ++i) b[i] -= a(i, k) * bk;
+        b[k] = bk / a(k, k);
+        k += 1;
+      } else {
+        const i64 kp = -ipiv[k] - 1;
+        if (kp != k + 1) std::swap(b[k + 1], b[kp]);
+        const double bk = b[k], bk1 = b[k + 1];
+        for (i64 i = k + 2; i < n; ++i) b[i] -= a(i, k) * bk + a(i, k + 1) * bk1;
+        const double akm1k = a(k + 1, k), akm1 = a(k, k) / akm1k, ak = a(k + 1, k + 1) / akm1k;
+        const double denom = akm1 * ak - 1.0, bkm1 = bk / akm1k, bkk = bk1 / akm1k;
+        b[k] = (ak * bkm1 - bkk) / denom;
+        b[k + 1] = (akm1 * bkk - bkm1) / denom;
+        k += 2;
+      }
+    }
+    k = n - 1;
+    while (k >= 0) {
+      if (ipiv[k] > 0) {
+        double s = b[k];
+        for (i64 i = k + 1; i < n; ++i) s -= a(i, k) * b[i];
+        b[k] = s;
+        const i64 kp = ipiv[k] - 1;
+        if (kp != k) std::swap(b[k], b[kp]);
+        k -= 1;
+      } else {
+        double s0 = b[k], s1 = b[k - 1];
+        for (i64 i = k + 1; i < n; ++i) { s0 -= a(i, k) * b[i]; s1 -= a(i, k - 1) * b[i]; }
+        b[k] = s0;
+        b[k - 1] = s1;
+        const i64 kp = -ipiv[k] - 1;
+        if (kp != k) std::swap(b[k], b[kp]);
+        k -= 2;
+      }
+    }
+  }
+};
+
+}  // namespace dnlp

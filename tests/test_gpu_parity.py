@@ -1,0 +1,173 @@
+"""GPU parity tests (run with `-m gpu` on the MI355X box).  Everything goes through the C ABI of
+libdnlp_hip.so; the CPU oracle (oracle/) and the golden vectors captured from the reference
+(tests/golden/) are only the checkers.  Nothing here reads /root/reference."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from golden_util import build_canonical, check_oracles_against_golden, load_golden
+from problem_zoo import ZOO
+
+pytestmark = pytest.mark.gpu
+
+
+class _Ev:
+    """Adapter: C-ABI handle -> the reference's callback names."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def objective(self, x): return self.h.eval_f(x)
+    def gradient(self, x): return self.h.eval_grad_f(x)
+    def constraints(self, x): return self.h.eval_g(x)
+    def jacobianstructure(self): return self.h.jac_structure()
+    def jacobian(self, x): return self.h.eval_jac_g(x)
+    def hessianstructure(self): return self.h.hess_structure()
+    def hessian(self, x, lam, sigma): return self.h.eval_h(x, lam, sigma)
+
+
+def _device_problem(name):
+    from dnlp_amd import _capi
+    from dnlp_amd.tape import serialize
+    data, inv = build_canonical(name)
+    blob = serialize(data["tape_arrays"])
+    return data, blob, _capi.DeviceProblem(blob, data["tape"], device=0)
+
+
+@pytest.mark.parametrize("name", sorted(ZOO))
+def test_device_oracles_match_reference_golden(name, gpu_required):
+    """f, grad f, g, Jacobian, Hessian of the HIP tape kernels vs vectors captured from the
+    reference's Oracles (tolerance 1e-12 relative, FP64)."""
+    data, blob, dev = _device_problem(name)
+    check_oracles_against_golden(load_golden(name), _Ev(dev))
+
+
+@pytest.mark.parametrize("name", sorted(ZOO))
+def test_device_solve_matches_cpu_oracle(name, gpu_required):
+    """Same tape, same algorithm text: the on-device interior-point loop and the host oracle
+    must land on the same optimum (1e-6 relative on the objective and the primal point)."""
+    from oracle.oracle_capi import OracleProblem
+    data, blob, dev = _device_problem(name)
+    orc = OracleProblem(blob)
+    di = dev.solve(data["x0"])
+    oi = orc.solve(data["x0"])
+    assert di["status"] == 0, dev.log()
+    assert oi["status"] == 0
+    scale = max(1.0, abs(oi["obj_val"]))
+    assert abs(di["obj_val"] - oi["obj_val"]) <= 1e-6 * scale
+    np.testing.assert_allclose(di["x"], oi["x"], rtol=1e-5, atol=1e-6)
+    # KKT residual of the device solution evaluated by the CPU oracle (unscaled problem)
+    x, lam = di["x"], di["mult_g"]
+    N, m = dev.n, dev.m
+    grad = orc.eval_grad_f(x)
+    if m:
+        jr, jc = orc.jac_structure()
+        import scipy.sparse as sp
+        J = sp.coo_matrix((orc.eval_jac_g(x), (jr, jc)), shape=(m, N)).tocsr()
+        grad = grad + J.T @ lam
+    r = grad - di["mult_x_L"] + di["mult_x_U"]
+    assert np.max(np.abs(r)) <= 1e-5 * max(1.0, np.max(np.abs(lam)) if m else 1.0)
+
+
+def test_frontend_known_answers(gpu_required):
+    """Known optima pinned by the reference's own tests (test_nlp_solvers.py:25-189)."""
+    import dnlp_amd as cp
+    from problem_zoo import hs071, localization, portfolio_qp, qcp, readme_toy, rosenbrock2, socp
+    p = hs071(cp)
+    p.solve(nlp=True)
+    assert p.status == cp.OPTIMAL
+    assert np.allclose(p.variables()[0].value, [0.75450865, 4.63936861, 3.78856881, 1.88513184])
+    p = readme_toy(cp)
+    p.solve(nlp=True)
+    assert abs(p.value - 11.95081085398) <= 1e-6 * 11.95
+    p = socp(cp)
+    p.solve(nlp=True)
+    assert np.allclose(p.value, -13.548638814247532)
+    p = rosenbrock2(cp)
+    p.solve(nlp=True)
+    assert np.allclose(p.variables()[0].value, [1.0, 1.0])
+    p = qcp(cp)
+    p.solve(nlp=True)
+    assert np.allclose(p.value, 0.32699284)
+    p = portfolio_qp(cp)
+    p.solve(nlp=True)
+    assert np.allclose(p.variables()[0].value, [497.045504, 0.0, 502.954496], atol=1e-4)
+    p = localization(cp)
+    p.solve(nlp=True)
+    x = [v for v in p.variables() if v.name() == "x"][0]
+    assert np.allclose(x.value, [2.0, -1.5])
+
+
+def _ldlt(A, pivoted, rhs):
+    from dnlp_amd import _capi
+    api = _capi.require_device(0)
+    n = A.shape[0]
+    Af = np.asfortranarray(A.copy())
+    ipiv = np.zeros(n, np.int32)
+    nneg, nzero = C.c_int(), C.c_int()
+    sol = np.zeros(n)
+    sec = C.c_double()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    rc = api.lib.dnlp_ldlt_host(0, dp(Af), n, n, ipiv.ctypes.data_as(C.POINTER(C.c_int32)), int(pivoted),
+                                C.byref(nneg), C.byref(nzero), dp(np.ascontiguousarray(rhs)), dp(sol),
+                                C.byref(sec))
+    assert rc == 0, api.error()
+    return sol, nneg.value, nzero.value, sec.value
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 257, 600])
+def test_pivoted_ldlt_indefinite(n, gpu_required):
+    """Bunch-Kaufman path on symmetric indefinite KKT-shaped matrices with a zero (2,2) block:
+    solve residual and inertia vs numpy."""
+    rng = np.random.default_rng(n)
+    nh = max(1, (2 * n) // 3)
+    H = rng.standard_normal((nh, nh))
+    H = H + H.T
+    J = rng.standard_normal((n - nh, nh))
+    A = np.block([[H, J.T], [J, np.zeros((n - nh, n - nh))]]) if n > nh else H
+    b = rng.standard_normal(n)
+    sol, nneg, nzero, _ = _ldlt(A, True, b)
+    ev = np.linalg.eigvalsh(A)
+    assert nzero == 0
+    assert nneg == int(np.sum(ev < 0))
+    assert np.linalg.norm(A @ sol - b) <= 1e-9 * np.linalg.norm(A, 2) * max(np.linalg.norm(sol), 1.0)
+
+
+@pytest.mark.parametrize("n", [33, 300, 777, 1500])
+def test_blocked_mfma_ldlt_quasidefinite(n, gpu_required):
+    """Blocked unpivoted LDL^T (FP64-MFMA trailing update) on quasi-definite KKT matrices:
+    inertia (n1, n2, 0) and solve residual vs numpy; sizes straddle the 128 / 256 tiles."""
+    rng = np.random.default_rng(n)
+    n1 = (3 * n) // 4
+    G = rng.standard_normal((n1, n1))
+    H = G @ G.T / n1 + np.eye(n1)
+    J = rng.standard_normal((n - n1, n1))
+    A = np.block([[H, J.T], [J, -1e-2 * np.eye(n - n1)]])
+    b = rng.standard_normal(n)
+    sol, nneg, nzero, _ = _ldlt(A, False, b)
+    assert (nneg, nzero) == (n - n1, 0)
+    ref = np.linalg.solve(A, b)
+    assert np.linalg.norm(sol - ref) <= 1e-9 * np.linalg.norm(ref) * np.linalg.cond(A)
+
+
+def test_device_matrix_sphere_and_symv(gpu_required):
+    """BASELINE C4 shape at n = 1500: quad_form on an HBM-resident matrix generated on the
+    device; optimum must equal lambda_max of the downloaded matrix (analytic answer)."""
+    import dnlp_amd as cp
+    from dnlp_amd.device import symmetric_test_matrix
+    n = 1500
+    A = symmetric_test_matrix(n, seed=7, spike_eig=4.0 * np.sqrt(n), device=0)
+    Ah = A.to_host()
+    assert np.allclose(Ah, Ah.T)
+    xh = np.random.default_rng(0).standard_normal(n)
+    np.testing.assert_allclose(A.symv(xh), Ah @ xh, rtol=1e-11, atol=1e-9)
+    x = cp.Variable(n)
+    x.value = np.ones(n) / np.sqrt(n)
+    prob = cp.Problem(cp.Maximize(cp.quad_form(x, cp.Constant(A.handle))), [cp.sum_squares(x) == 1])
+    prob.solve(nlp=True, kkt_pivot_max_n=0)      # force the blocked MFMA factorisation
+    lam_max = float(np.linalg.eigvalsh(Ah)[-1])
+    assert prob.status == cp.OPTIMAL
+    assert abs(prob.value - lam_max) <= 1e-6 * lam_max
+    v = x.value / np.linalg.norm(x.value)
+    assert np.linalg.norm(Ah @ v - lam_max * v) <= 1e-4 * lam_max

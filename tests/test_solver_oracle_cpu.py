@@ -1,0 +1,149 @@
+"""CPU tests: the restated interior-point algorithm (host instantiation in oracle/) pinned
+against the known optima the reference's own tests hold, and the
+C-ABI library's exported surface.  No GPU compute is attempted here."""
+import ctypes as C
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+
+from golden_util import build_canonical
+from problem_zoo import ZOO
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _solve(name, **opts):
+    from dnlp_amd.tape import serialize
+    from oracle.oracle_capi import OracleProblem
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        data, inv = build_canonical(name)
+    h = OracleProblem(serialize(data["tape_arrays"]))
+    for k, v in opts.items():
+        h.set_option(k, v)
+    info = h.solve(data["x0"])
+    vals = {}
+    for v in data["problem"].variables():
+        off = inv.var_offsets[v.id]
+        vals[v.name()] = info["x"][off:off + v.size].reshape(v.shape, order="F")
+    return info, vals, data
+
+
+KNOWN_OBJ = {
+    # name: (objective of the canonical MINIMISATION problem, rtol)
+    "readme_toy": (-11.95081085398, 1e-6),                 # -lambda_max(A), README.md:50-52
+    "socp": (-13.548638814247532, 1e-6),                   # test_nlp_solvers.py:151
+    "qcp": (-0.32699284, 1e-6),                            # test_nlp_solvers.py:111
+    "geo_mean": (-1.0 / 3.0, 1e-6),                        # test_nlp_solvers.py:269 (x = 1/3)
+    "rosenbrock2": (0.0, 1e-9),
+    "rosenbrock_chain50": (0.0, 1e-9),
+    "localization": (0.0, 1e-9),
+}
+
+
+@pytest.mark.parametrize("strategy", ["adaptive", "monotone"])
+@pytest.mark.parametrize("name", sorted(ZOO))
+def test_oracle_ipm_converges(name, strategy):
+    if name == "mle" and strategy == "monotone":
+        pytest.skip("n=2011 dense host factorisation: one strategy is enough on CPU")
+    info, vals, data = _solve(name, mu_strategy=strategy)
+    assert info["status"] == 0
+    if name in KNOWN_OBJ:
+        ref, tol = KNOWN_OBJ[name]
+        assert abs(info["obj_val"] - ref) <= tol * max(1.0, abs(ref))
+
+
+def test_oracle_ipm_known_points():
+    info, vals, _ = _solve("hs071")
+    x = [v for k, v in vals.items() if v.shape == (4,)][0]
+    assert np.allclose(x, [0.75450865, 4.63936861, 3.78856881, 1.88513184])      # test_nlp_solvers.py:37
+    info, vals, _ = _solve("portfolio_qp")
+    x = [v for k, v in vals.items() if v.shape == (3,)][0]
+    assert np.allclose(x, [497.045504, 0.0, 502.954496], atol=1e-4)               # :86
+    info, vals, _ = _solve("mle")
+    assert np.allclose(vals["sigma"], 0.77079388)                                 # :59-60
+    assert np.allclose(vals["mu"], 0.59412321)
+    info, vals, _ = _solve("localization")
+    assert np.allclose(vals["x"], [2.0, -1.5])                                    # :189
+    info, vals, _ = _solve("circle_packing")
+    c = vals["c"]
+    ref = np.array([[1.73655994, -1.98685738, 2.57208783], [1.99273311, -1.67415425, -2.57208783]])
+    assert np.allclose(c, ref, atol=1e-5)                                         # :211-213
+
+
+def test_dense_eq_qp_closed_form():
+    """BASELINE C3 shape: one Newton step solves an equality-constrained convex QP exactly."""
+    info, vals, data = _solve("dense_eq_qp")
+    rng = np.random.default_rng(0)
+    n, m = 40, 6
+    Gm = rng.standard_normal((n, n))
+    Q = Gm.T @ Gm / n + np.eye(n)
+    c = rng.standard_normal(n)
+    A = rng.standard_normal((m, n))
+    b = A @ rng.standard_normal(n)
+    K = np.block([[Q, A.T], [A, np.zeros((m, m))]])
+    sol = np.linalg.solve(K, np.concatenate([-c, b]))
+    assert info["iterations"] <= 2
+    np.testing.assert_allclose(info["x"], sol[:n], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(info["mult_g"], sol[n:], rtol=1e-7, atol=1e-9)
+
+
+def test_invalid_option_and_status_map():
+    from dnlp_amd.nlp_solver import HIPNLP
+    from dnlp_amd.tape import serialize
+    from oracle.oracle_capi import OracleProblem
+    data, _ = build_canonical("hs071")
+    h = OracleProblem(serialize(data["tape_arrays"]))
+    with pytest.raises(ValueError):
+        h.set_option("no_such_option", 1)
+    h.set_option("max_iter", 2)
+    info = h.solve(data["x0"])
+    assert info["status"] == -1                       # Maximum_Iterations_Exceeded
+    assert HIPNLP.STATUS_MAP[-1] == "user_limit"      # ipopt_nlpif.py:55
+    assert HIPNLP.STATUS_MAP[0] == "optimal" and HIPNLP.STATUS_MAP[2] == "infeasible"
+
+
+def test_capi_library_exports_every_declared_symbol():
+    """libdnlp_hip.so must load without a GPU and export every symbol include/dnlp_hip.h
+    declares."""
+    lib_path = os.path.join(ROOT, "dnlp_amd", "libdnlp_hip.so")
+    if not os.path.exists(lib_path):
+        import __graft_entry__ as g
+        g.build()
+    header = open(os.path.join(ROOT, "include", "dnlp_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(dnlp_[a-z_0-9]+)\s*\(", header)))
+    assert len(names) >= 25
+    lib = C.CDLL(lib_path)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_product_path_fails_loudly_without_device():
+    """No CPU fallback: without an MI355X the front-end raises instead of solving."""
+    import dnlp_amd as cp
+    from dnlp_amd import _capi
+    if _capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    from problem_zoo import readme_toy
+    with pytest.raises(cp.DeviceUnavailableError):
+        readme_toy(cp).solve(nlp=True)
+
+
+def test_dnlp_rules():
+    """DNLP rule engine (reference tests/NLP_tests/test_dnlp.py)."""
+    import dnlp_amd as cp
+    x = cp.Variable(3)
+    y = cp.Variable(3)
+    assert cp.log(x).is_smooth() and cp.exp(x).is_esr() and cp.exp(x).is_hsr()
+    assert cp.abs(x).is_esr() and not cp.abs(x).is_hsr()
+    assert cp.minimum(x, y).is_hsr() and not cp.minimum(x, y).is_esr()
+    assert cp.Problem(cp.Minimize(cp.sum(cp.abs(x)) + cp.sum(cp.exp(cp.sin(y))))).is_dnlp()
+    assert not cp.Problem(cp.Minimize(cp.sum(cp.minimum(x, y)))).is_dnlp()
+    assert cp.Problem(cp.Maximize(cp.sum(cp.minimum(x, y)))).is_dnlp()
+    assert not cp.Problem(cp.Maximize(cp.max(cp.maximum(x, y)))).is_dnlp()
+    assert not cp.Problem(cp.Minimize(cp.sum(x)), [cp.abs(x) == 1]).is_dnlp()      # equality needs smooth
+    with pytest.raises(cp.DNLPError):
+        cp.Problem(cp.Maximize(cp.max(x))).solve(nlp=True)
