@@ -35,7 +35,9 @@ int dnlp_gen_symmetric(int device, double* A, int64_t n, int64_t ld, uint64_t se
     if (!v) DNLP_HIP_CHECK(hipMalloc(&v, sizeof(double) * n));
     hipLaunchKernelGGL(gen_vec_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, 0, v, n, seed);
     const i64 nrb = (n + 255) / 256;
-    hipLaunchKernelGGL(gen_sym_kernel, dim3(static_cast<unsigned>(nrb * n)), dim3(256), 0, 0, A, n, ld, seed, spike, v, nrb);
+    hipLaunchKernelGGL(gen_sym_kernel, dim3(static_cast<unsigned>(nrb), static_cast<unsigned>(n < 16384 ? n : 16384)),
+                       dim3(256), 0, 0, A, n, ld, seed, spike, v);
+    DNLP_HIP_CHECK(hipGetLastError());
     DNLP_HIP_CHECK(hipDeviceSynchronize());
     if (!dv) DNLP_HIP_CHECK(hipFree(v));
     return 0;)

@@ -27,7 +27,7 @@ struct ProblemT {
   IpmOptions opt;
   i64 pivot_max_n = 2048;
   double *dx = nullptr, *dlam = nullptr, *dg = nullptr, *dgrad = nullptr, *djac = nullptr, *dh = nullptr;
-  bool swept = false, kkt_ready = false;
+  bool swept = false, kkt_ready = false, time_kernels = false;
 
   explicit ProblemT(int device) : ex(device) {}
 
@@ -58,6 +58,7 @@ struct ProblemT {
       kkt.init(&ex, model.t.N, model.t.m);
       kkt_ready = true;
     }
+    kkt.lw.time_updates = time_kernels;
     if (!ipm) ipm.reset(new Ipm<E, DenseKkt<E>>(&ex, &model, &kkt));
     ipm->opt = opt;
   }
@@ -95,6 +96,7 @@ struct ProblemT {
     else if (k == "bound_mult_init_val") opt.bound_mult_init_val = num();
     else if (k == "kkt_pivot_max_n") pivot_max_n = static_cast<i64>(num());
     else if (k == "restoration") opt.restoration = yes() ? 1 : 0;
+    else if (k == "time_kernels") time_kernels = yes();
     else if (k == "sb" || k == "linear_solver" || k == "print_user_options" || k == "print_timing_statistics")
       { /* IPOPT options with no counterpart here: accepted and ignored */ }
     else return -12;   // Invalid_Option, as IPOPT reports unknown names
@@ -221,9 +223,10 @@ struct ProblemT {
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     if (!p->ipm) return -1;                                                                          \
     const auto& st = p->ipm->stats;                                                                  \
+    double k3[3]; p->ex.ldlt_stats(p->kkt.lw, k3);                                                   \
     double v[16] = {double(st.iterations), double(st.factorizations), st.wall, st.t_eval, st.t_factor, \
                     st.t_solve, p->ipm->mu, st.inf_pr, st.inf_du, st.cmpl, st.nlp_error,              \
-                    st.last_delta_w, p->ipm->sf, 0, 0, 0};                                           \
+                    st.last_delta_w, p->ipm->sf, k3[0], k3[1], k3[2]};                               \
     for (int i = 0; i < n && i < 16; ++i) s[i] = v[i];                                               \
     return 0;                                                                                        \
   }                                                                                                  \

@@ -31,9 +31,15 @@ namespace dnlp {
 constexpr int kBlock = 256;
 constexpr int kMaxPartials = 2048;
 
+// HIP caps gridDim.x * blockDim.x below 2^32 threads per launch: large index spaces are
+// covered by several launches with an element offset.
+constexpr i64 kMaxLaunchElems = (static_cast<i64>(1) << 31);
+
+#define DNLP_LAUNCH_CHECK() DNLP_HIP_CHECK(hipGetLastError())
+
 template <class F>
-__global__ void __launch_bounds__(kBlock) map_kernel(i64 n, F f) {
-  const i64 i = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+__global__ void __launch_bounds__(kBlock) map_kernel(i64 off, i64 n, F f) {
+  const i64 i = off + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
   if (i < n) f(i);
 }
 
@@ -121,18 +127,29 @@ __global__ void __launch_bounds__(kBlock) gemv_stage2(i64 n, i64 ncb, const doub
   y[r] = s;
 }
 
-// K[x0+r, x0+c] (+)= w P[r,c] on r >= c.  One column per block row-tile; early exit above the
-// diagonal; coalesced down the column.
+// K[x0+r, x0+c] (+)= w P[r,c] on r >= c.  grid.x walks 512-row tiles (two rows per lane, 16-B
+// accesses down the column), grid.y strides over columns; tiles above the diagonal exit.
 __global__ void __launch_bounds__(kBlock) dense_block_add_kernel(double* __restrict__ K, i64 ldk, i64 x0,
                                                                  const double* __restrict__ P, i64 ldp,
-                                                                 i64 nb, double w, int set, i64 nrb) {
-  const i64 c = blockIdx.x / nrb, rb = blockIdx.x % nrb;
-  if (rb * kBlock + kBlock - 1 < c) return;
-  const i64 r = rb * kBlock + threadIdx.x;
-  if (r >= nb || r < c) return;
-  double* dst = K + (x0 + r) + (x0 + c) * ldk;
-  const double v = w * P[r + c * ldp];
-  *dst = set ? v : *dst + v;
+                                                                 i64 nb, double w, int set) {
+  const i64 r = static_cast<i64>(blockIdx.x) * 512 + 2 * static_cast<i64>(threadIdx.x);
+  const bool vec = ((ldk | ldp | x0) & 1) == 0 && ((reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(P)) & 15) == 0;
+  for (i64 c = blockIdx.y; c < nb; c += gridDim.y) {
+    if (static_cast<i64>(blockIdx.x) * 512 + 511 < c) continue;
+    if (r >= nb) continue;
+    double* dst = K + (x0 + r) + (x0 + c) * ldk;
+    const double* src = P + r + c * ldp;
+    if (vec && r >= c && r + 1 < nb) {
+      const double2 pv = *reinterpret_cast<const double2*>(src);
+      double2 kv = set ? double2{0.0, 0.0} : *reinterpret_cast<const double2*>(dst);
+      kv.x += w * pv.x;
+      kv.y += w * pv.y;
+      *reinterpret_cast<double2*>(dst) = kv;
+    } else {
+      if (r >= c) dst[0] = (set ? 0.0 : dst[0]) + w * src[0];
+      if (r + 1 >= c && r + 1 < nb) dst[1] = (set ? 0.0 : dst[1]) + w * src[1];
+    }
+  }
 }
 
 __global__ void __launch_bounds__(kBlock) coo_mult_kernel(i64 nnz, const i32* __restrict__ r,
@@ -413,7 +430,11 @@ struct HipExec {
   struct LdltWork {
     BkState* st = nullptr;
     BlockedLdlt* blocked = nullptr;
+    int expect_neg = -1;         // inertia the caller needs (early exit of hopeless attempts)
+    bool time_updates = false;
   };
+  // kernel statistics of the dominant (MFMA Schur update) kernel: seconds, flops, launches
+  void ldlt_stats(LdltWork& w, double* out3);
 
   explicit HipExec(int dev = 0) : device(dev) {
     DNLP_HIP_CHECK(hipSetDevice(device));
@@ -463,15 +484,19 @@ struct HipExec {
   void sync() { DNLP_HIP_CHECK(hipStreamSynchronize(stream)); }
 
   template <class F> void map(i64 n, F f) {
-    if (n <= 0) return;
-    const i64 grid = (n + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(map_kernel<F>, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, n, f);
+    for (i64 off = 0; off < n; off += kMaxLaunchElems) {
+      const i64 cnt = (n - off < kMaxLaunchElems) ? n - off : kMaxLaunchElems;
+      const i64 grid = (cnt + kBlock - 1) / kBlock;
+      hipLaunchKernelGGL(map_kernel<F>, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, off, n, f);
+    }
+    DNLP_LAUNCH_CHECK();
   }
   template <int MODE, class F> double reduce(i64 n, F f) {
     if (n <= 0) return MODE == 0 ? 0.0 : (MODE == 1 ? -kInf : kInf);
     i64 grid = (n + kBlock - 1) / kBlock;
     if (grid > kMaxPartials) grid = kMaxPartials;
     hipLaunchKernelGGL((reduce_kernel<MODE, F>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, n, f, d_partial);
+    DNLP_LAUNCH_CHECK();
     DNLP_HIP_CHECK(hipMemcpyAsync(h_partial, d_partial, sizeof(double) * grid, hipMemcpyDeviceToHost, stream));
     DNLP_HIP_CHECK(hipStreamSynchronize(stream));
     double r = h_partial[0];
@@ -496,6 +521,7 @@ struct HipExec {
     }
     hipLaunchKernelGGL(gemv_stage1, dim3(static_cast<unsigned>(nrb * ncb)), dim3(kBlock), 0, stream, n, P, ld, u, gemv_part, nrb);
     hipLaunchKernelGGL(gemv_stage2, dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, n, ncb, gemv_part, out);
+    DNLP_LAUNCH_CHECK();
   }
   void coo_mult(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out, bool trans) {
     if (nnz <= 0) return;
@@ -508,9 +534,11 @@ struct HipExec {
                        nnz, r, c, a, v, out, 2);
   }
   void dense_block_add(double* K, i64 ldk, i64 x0, const double* P, i64 ldp, i64 nb, double w, bool set) {
-    const i64 nrb = (nb + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(dense_block_add_kernel, dim3(static_cast<unsigned>(nrb * nb)), dim3(kBlock), 0, stream,
-                       K, ldk, x0, P, ldp, nb, w, set ? 1 : 0, nrb);
+    const i64 nrb = (nb + 511) / 512;
+    const unsigned gy = static_cast<unsigned>(nb < 16384 ? nb : 16384);
+    hipLaunchKernelGGL(dense_block_add_kernel, dim3(static_cast<unsigned>(nrb), gy), dim3(kBlock), 0, stream,
+                       K, ldk, x0, P, ldp, nb, w, set ? 1 : 0);
+    DNLP_LAUNCH_CHECK();
   }
 
   // ---- factorisation (ldlt_blocked.h supplies the large-order path) ----

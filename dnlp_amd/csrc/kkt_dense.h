@@ -76,6 +76,7 @@ struct DenseKkt {
       // fixed variables inside a dense block: clear their rows / columns
       // (rare; handled by a masked pass only when any variable is fixed)
     }
+    lw.expect_neg = static_cast<int>(m);
     return ex->ldlt_factor(lw, K, n, ld, ipiv, pivoted, nneg, nzero);
   }
 

@@ -26,7 +26,8 @@ namespace dnlp {
 
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
-constexpr int LD_NB = 256;     // outer panel width
+constexpr int LD_NB_MAX = 1024; // largest outer panel width (workspace)
+
 constexpr int LD_nb = 32;      // inner block
 constexpr int GM_BM = 128, GM_BN = 128, GM_BK = 16, GM_PAD = 16;
 
@@ -106,14 +107,16 @@ __global__ void __launch_bounds__(256) ldlt_trsm_kernel(double* A, i64 ld, int j
 }
 
 // ---- C -= W L^T on FP64 MFMA ---------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) gemm_nt_update(double* __restrict__ C, i64 ldc,
-                                                         const double* __restrict__ W, i64 ldw,
-                                                         const double* __restrict__ L, i64 ldl, int M,
-                                                         int Nc, int Kd, int lower, int ntm, int vec_ok) {
-  const int tm = blockIdx.x % ntm, tn = blockIdx.x / ntm;
-  if (lower && (tm * GM_BM + GM_BM - 1 < tn * GM_BN)) return;
-  __shared__ double Ws[GM_BK][GM_BM + GM_PAD];
-  __shared__ double Ls[GM_BK][GM_BN + GM_PAD];
+// Interior tiles (full 128x128, strictly below the diagonal, K a multiple of 16, 16-B aligned
+// operands) take the fast body: the C tile is loaded straight into the MFMA accumulators
+// (D = (-L) W^T + C, so the epilogue is a plain store), operands move global -> registers ->
+// LDS as 16-B lanes with two LDS buffers and ONE barrier per 16-deep k-tile.  Edge / diagonal
+// tiles take the guarded body.
+__device__ inline void gemm_body_guarded(double* __restrict__ C, i64 ldc, const double* __restrict__ W, i64 ldw,
+                                         const double* __restrict__ L, i64 ldl, int M, int Nc, int Kd, int lower,
+                                         int tm, int tn, int vec_ok, double* smem) {
+  double (*Ws)[GM_BM + GM_PAD] = reinterpret_cast<double (*)[GM_BM + GM_PAD]>(smem);
+  double (*Ls)[GM_BN + GM_PAD] = reinterpret_cast<double (*)[GM_BN + GM_PAD]>(smem + GM_BK * (GM_BM + GM_PAD));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   mfma_d4 acc[4][4];
@@ -121,10 +124,9 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_update(double* __restrict__ C,
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-  // staging map: this thread moves rows (2*(tid&63), +1) of k-rows (tid>>6) + 4q, q = 0..3
   const int srow = 2 * (tid & 63), sk = tid >> 6;
-  const i64 gi = static_cast<i64>(tm) * GM_BM + srow;      // W row
-  const i64 gj = static_cast<i64>(tn) * GM_BN + srow;      // L row
+  const i64 gi = static_cast<i64>(tm) * GM_BM + srow;
+  const i64 gj = static_cast<i64>(tn) * GM_BN + srow;
   double2 rw[4], rl[4];
   auto load_tile = [&](int kt) {
 #pragma unroll
@@ -170,7 +172,6 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_update(double* __restrict__ C,
     }
     __syncthreads();
   }
-  // epilogue: D[row = j][col = i]; lane&15 walks i (contiguous), (lane>>4) + 4r walks j
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -184,73 +185,223 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_update(double* __restrict__ C,
     }
 }
 
-// ---- triangular solves with the unit-lower factor (blocks of LD_nb) --------------------------
-// forward, diagonal block: one wave; lane t owns b[j0+t]
-__global__ void __launch_bounds__(64) ldlt_fwd_diag(const double* A, i64 ld, int j0, int jb, double* b) {
+// 512 threads = 8 waves; wave (wm, wn) owns rows wm*64..+64 (i) x cols wn*32..+32 (j):
+// 2 x 4 MFMA tiles = 64 accumulator VGPRs, so four waves fit per SIMD.  Operand tiles go
+// global -> LDS directly (global_load_lds_dwordx4: one 1-KiB k-row per wave instruction, no
+// staging registers), double buffered, one barrier per 16-deep k-tile.  The accumulators
+// start at -C and the result is stored negated (D = L W^T - C), so no operand needs a sign.
+#define DNLP_GLDS(src, dst)                                                                         \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
+                                   (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+__device__ inline void gemm_body_fast(double* __restrict__ C, i64 ldc, const double* __restrict__ W, i64 ldw,
+                                      const double* __restrict__ L, i64 ldl, int Kd, int tm, int tn, double* smem) {
+  constexpr int LDT = GM_BM + GM_PAD;                 // padded LDS row (doubles)
+  constexpr int TILE = GM_BK * LDT;                    // doubles per operand tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  // this wave moves k-rows `wave` and `wave + 8` of both operand tiles
+  const double* pw = W + static_cast<i64>(tm) * GM_BM + 2 * lane + static_cast<i64>(wave) * ldw;
+  const double* pl = L + static_cast<i64>(tn) * GM_BN + 2 * lane + static_cast<i64>(wave) * ldl;
+  mfma_d4 acc[2][4];
+  double* cbase = C + static_cast<i64>(tm) * GM_BM + wm * 64 + (lane & 15) +
+                  (static_cast<i64>(tn) * GM_BN + wn * 32 + (lane >> 4)) * ldc;
+  {
+    const double* cp = cbase;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[ni][mi][r] = -cp[mi * 16];
+        cp += 4 * ldc;
+      }
+  }
+  const int nkt = Kd / GM_BK;
+  {
+    double* ws = smem;
+    double* ls = smem + TILE;
+    DNLP_GLDS(pw, ws + wave * LDT);
+    DNLP_GLDS(pw + 8 * ldw, ws + (wave + 8) * LDT);
+    DNLP_GLDS(pl, ls + wave * LDT);
+    DNLP_GLDS(pl + 8 * ldl, ls + (wave + 8) * LDT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const double* ws = smem + (kt & 1) * 2 * TILE;
+    const double* ls = ws + TILE;
+    if (kt + 1 < nkt) {
+      double* wd = smem + ((kt + 1) & 1) * 2 * TILE;
+      double* ldst = wd + TILE;
+      const i64 ko = static_cast<i64>(kt + 1) * GM_BK;
+      DNLP_GLDS(pw + ko * ldw, wd + wave * LDT);
+      DNLP_GLDS(pw + (ko + 8) * ldw, wd + (wave + 8) * LDT);
+      DNLP_GLDS(pl + ko * ldl, ldst + wave * LDT);
+      DNLP_GLDS(pl + (ko + 8) * ldl, ldst + (wave + 8) * LDT);
+    }
+#pragma unroll
+    for (int kk = 0; kk < GM_BK; kk += 4) {
+      double a[2], b[4];
+      const int kr = kk + (lane >> 4), lc = lane & 15;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) a[t] = ls[kr * LDT + wn * 32 + t * 16 + lc];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) b[t] = ws[kr * LDT + wm * 64 + t * 16 + lc];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ni], b[mi], acc[ni][mi], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  {
+    double* cp = cbase;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) cp[mi * 16] = -acc[ni][mi][r];
+        cp += 4 * ldc;
+      }
+  }
+}
+
+__device__ inline bool gemm_tile_interior(int tm, int tn, int M, int Nc, int Kd, int lower, int vec_ok,
+                                          const double* C, i64 ldc) {
+  return vec_ok && (Kd % GM_BK == 0) && (tm + 1) * GM_BM <= M && (tn + 1) * GM_BN <= Nc &&
+         (!lower || tm * GM_BM >= (tn + 1) * GM_BN) && ((ldc & 1) == 0) &&
+         ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+}
+
+// interior tiles only
+__global__ void __launch_bounds__(512, 4) gemm_nt_update_fast(double* __restrict__ C, i64 ldc,
+                                                              const double* __restrict__ W, i64 ldw,
+                                                              const double* __restrict__ L, i64 ldl, int M,
+                                                              int Nc, int Kd, int lower, int ntm, int vec_ok) {
+  const int tm = blockIdx.x % ntm, tn = blockIdx.x / ntm;
+  if (!gemm_tile_interior(tm, tn, M, Nc, Kd, lower, vec_ok, C, ldc)) return;
+  __shared__ __attribute__((aligned(16))) double smem[4 * GM_BK * (GM_BM + GM_PAD)];
+  gemm_body_fast(C, ldc, W, ldw, L, ldl, Kd, tm, tn, smem);
+}
+
+// edge / diagonal tiles only
+__global__ void __launch_bounds__(256, 2) gemm_nt_update(double* __restrict__ C, i64 ldc,
+                                                         const double* __restrict__ W, i64 ldw,
+                                                         const double* __restrict__ L, i64 ldl, int M,
+                                                         int Nc, int Kd, int lower, int ntm, int vec_ok) {
+  const int tm = blockIdx.x % ntm, tn = blockIdx.x / ntm;
+  if (lower && (tm * GM_BM + GM_BM - 1 < tn * GM_BN)) return;
+  if (gemm_tile_interior(tm, tn, M, Nc, Kd, lower, vec_ok, C, ldc)) return;
+  __shared__ __attribute__((aligned(16))) double smem[2 * GM_BK * (GM_BM + GM_PAD)];
+  gemm_body_guarded(C, ldc, W, ldw, L, ldl, M, Nc, Kd, lower, tm, tn, vec_ok, smem);
+}
+
+// ---- triangular solves with the unit-lower factor ---------------------------------------------
+// Blocks of SV_B = 256 columns: the diagonal block is solved by one workgroup (32-wide
+// wave-shuffle substitutions, no barrier inside a sub-block), the panel below / the panel
+// transposed are bandwidth kernels that stream the factor once per solve (n^2/2 doubles).
+constexpr int SV_B = 256;
+
+__global__ void __launch_bounds__(SV_B) ldlt_fwd_diag(const double* __restrict__ A, i64 ld, int j0, int jb,
+                                                      double* __restrict__ b) {
+  __shared__ double y[SV_B];
   const int t = threadIdx.x;
   double v = (t < jb) ? b[j0 + t] : 0.0;
-  for (int k = 0; k < jb; ++k) {
-    const double yk = __shfl(v, k, 64);
-    if (t > k && t < jb) v -= A[(j0 + t) + static_cast<i64>(j0 + k) * ld] * yk;
+  for (int s0 = 0; s0 < jb; s0 += 32) {
+    const int s1 = (s0 + 32 < jb) ? s0 + 32 : jb;
+    if ((t >> 6) == (s0 >> 6)) {
+      for (int k = s0; k < s1; ++k) {
+        const double yk = __shfl(v, k & 63, 64);
+        if (t > k && t < s1) v -= A[(j0 + t) + static_cast<i64>(j0 + k) * ld] * yk;
+      }
+      if (t >= s0 && t < s1) y[t] = v;
+    }
+    __syncthreads();
+    if (t >= s1 && t < jb) {
+      double s = 0.0;
+      for (int k = s0; k < s1; ++k) s += A[(j0 + t) + static_cast<i64>(j0 + k) * ld] * y[k];
+      v -= s;
+    }
   }
   if (t < jb) b[j0 + t] = v;
 }
-// forward, rows below the block: b[r] -= sum_t A[r, j0+t] y[t]
+// rows below the block: b[r] -= sum_t A[r, j0+t] y[t]  (one row per lane, coalesced columns)
 __global__ void __launch_bounds__(256) ldlt_fwd_update(const double* __restrict__ A, i64 ld, int j0, int jb,
                                                        int n, double* __restrict__ b) {
-  __shared__ double y[LD_nb];
+  __shared__ double y[SV_B];
   if (threadIdx.x < jb) y[threadIdx.x] = b[j0 + threadIdx.x];
   __syncthreads();
   const i64 r = static_cast<i64>(j0) + jb + static_cast<i64>(blockIdx.x) * 256 + threadIdx.x;
   if (r >= n) return;
-  double s = 0.0;
-#pragma unroll 8
-  for (int t = 0; t < jb; ++t) s += A[r + static_cast<i64>(j0 + t) * ld] * y[t];
-  b[r] -= s;
+  const double* row = A + r + static_cast<i64>(j0) * ld;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int t = 0;
+  for (; t + 4 <= jb; t += 4) {
+    s0 += row[static_cast<i64>(t) * ld] * y[t];
+    s1 += row[static_cast<i64>(t + 1) * ld] * y[t + 1];
+    s2 += row[static_cast<i64>(t + 2) * ld] * y[t + 2];
+    s3 += row[static_cast<i64>(t + 3) * ld] * y[t + 3];
+  }
+  for (; t < jb; ++t) s0 += row[static_cast<i64>(t) * ld] * y[t];
+  b[r] -= (s0 + s1) + (s2 + s3);
 }
 __global__ void __launch_bounds__(256) ldlt_diag_scale(const double* A, i64 ld, int n, double* b) {
   const i64 i = static_cast<i64>(blockIdx.x) * 256 + threadIdx.x;
   if (i < n) b[i] /= A[i + i * ld];
 }
-// backward, rows below the block: acc[t] += sum_r A[r, j0+t] x[r]   (acc zeroed by the caller)
+// transposed panel: acc[t] += sum_{r in chunk} A[r, j0+t] x[r]; one wave per column, lanes
+// walk the rows (coalesced), grid.y walks row chunks.  acc is zeroed by the diagonal kernel.
 __global__ void __launch_bounds__(256) ldlt_bwd_update(const double* __restrict__ A, i64 ld, int j0, int jb,
-                                                       int n, const double* __restrict__ b, double* acc,
-                                                       int rows_per_block) {
-  __shared__ double red[4][LD_nb];
-  const i64 rbeg = static_cast<i64>(j0) + jb + static_cast<i64>(blockIdx.x) * rows_per_block;
-  i64 rend = rbeg + rows_per_block;
-  if (rend > n) rend = n;
-  double s[LD_nb];
-#pragma unroll
-  for (int t = 0; t < LD_nb; ++t) s[t] = 0.0;
-  for (i64 r = rbeg + threadIdx.x; r < rend; r += 256) {
-    const double xr = b[r];
-#pragma unroll
-    for (int t = 0; t < LD_nb; ++t)
-      if (t < jb) s[t] += A[r + static_cast<i64>(j0 + t) * ld] * xr;
-  }
+                                                       int n, const double* __restrict__ b,
+                                                       double* __restrict__ acc, int rows_per_chunk) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-  for (int t = 0; t < LD_nb; ++t) {
-    const double w = wave_sum(s[t]);
-    if (lane == 0) red[wid][t] = w;
+  const int t = blockIdx.x * 4 + wid;
+  if (t >= jb) return;
+  const i64 rbeg = static_cast<i64>(j0) + jb + static_cast<i64>(blockIdx.y) * rows_per_chunk;
+  i64 rend = rbeg + rows_per_chunk;
+  if (rend > n) rend = n;
+  const double* col = A + static_cast<i64>(j0 + t) * ld;
+  double s0 = 0.0, s1 = 0.0;
+  i64 r = rbeg + lane;
+  for (; r + 64 < rend; r += 128) {
+    s0 += col[r] * b[r];
+    s1 += col[r + 64] * b[r + 64];
   }
-  __syncthreads();
-  if (threadIdx.x < jb) {
-    const double tot = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    unsafeAtomicAdd(&acc[threadIdx.x], tot);
-  }
+  if (r < rend) s0 += col[r] * b[r];
+  const double w = wave_sum(s0 + s1);
+  if (lane == 0) unsafeAtomicAdd(&acc[t], w);
 }
-// backward, diagonal block: x_t = (b_t - acc_t) - sum_{t' > t} L[t', t] x_t'
-__global__ void __launch_bounds__(64) ldlt_bwd_diag(const double* A, i64 ld, int j0, int jb, double* b,
-                                                    double* acc) {
+// diagonal block, transposed: x = L11^-T (b1 - acc); clears acc for the next block
+__global__ void __launch_bounds__(SV_B) ldlt_bwd_diag(const double* __restrict__ A, i64 ld, int j0, int jb,
+                                                      double* __restrict__ b, double* __restrict__ acc) {
+  __shared__ double xs[SV_B];
   const int t = threadIdx.x;
   double v = (t < jb) ? b[j0 + t] - acc[t] : 0.0;
-  for (int k = jb - 1; k >= 0; --k) {
-    const double xk = __shfl(v, k, 64);
-    if (t < k) v -= A[(j0 + k) + static_cast<i64>(j0 + t) * ld] * xk;
+  if (t < SV_B) acc[t] = 0.0;
+  const int nsb = (jb + 31) / 32;
+  for (int sbk = nsb - 1; sbk >= 0; --sbk) {
+    const int s0 = sbk * 32, s1 = (s0 + 32 < jb) ? s0 + 32 : jb;
+    if ((t >> 6) == (s0 >> 6)) {
+      for (int k = s1 - 1; k >= s0; --k) {
+        const double xk = __shfl(v, k & 63, 64);
+        if (t < k && t >= s0) v -= A[(j0 + k) + static_cast<i64>(j0 + t) * ld] * xk;
+      }
+      if (t >= s0 && t < s1) xs[t] = v;
+    }
+    __syncthreads();
+    if (t < s0) {
+      const double* colt = A + j0 + static_cast<i64>(j0 + t) * ld;
+      double s = 0.0;
+      for (int k = s0; k < s1; ++k) s += colt[k] * xs[k];
+      v -= s;
+    }
   }
-  if (t < jb) { b[j0 + t] = v; acc[t] = 0.0; }
+  if (t < jb) b[j0 + t] = v;
 }
 
 struct BlockedLdlt {
@@ -260,15 +411,23 @@ struct BlockedLdlt {
   LdltInfo* info = nullptr;
   double* acc = nullptr;
   double last_update_seconds = 0.0;
+  double total_update_seconds = 0.0, total_update_flops = 0.0;   // outer (Schur) updates, timed
+  i64 total_update_launches = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool time_updates = false;
+  int NB = 512;                // outer panel width (K of the MFMA Schur update)
+  int max_neg = -1;            // >= 0: give up as soon as more negative pivots than this appear
 
   void init(HipExec* e, i64 n_, i64 ld_) {
     ex = e; n = n_; ld = ld_;
     ldw = (n + 7) / 8 * 8;
-    Wp = ex->alloc<double>(static_cast<size_t>(ldw) * LD_NB);
+    if (const char* e = std::getenv("DNLP_LDLT_NB")) NB = std::atoi(e);
+    if (NB < LD_nb) NB = LD_nb;
+    if (NB > LD_NB_MAX) NB = LD_NB_MAX;
+    NB = NB / LD_nb * LD_nb;
+    Wp = ex->alloc<double>(static_cast<size_t>(ldw) * NB);
     info = ex->alloc<LdltInfo>(1);
-    acc = ex->alloc<double>(LD_nb);
+    acc = ex->alloc<double>(SV_B);
     DNLP_HIP_CHECK(hipEventCreate(&ev0));
     DNLP_HIP_CHECK(hipEventCreate(&ev1));
   }
@@ -278,8 +437,11 @@ struct BlockedLdlt {
     const int ntm = (M + GM_BM - 1) / GM_BM, ntn = (Nc + GM_BN - 1) / GM_BN;
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const int vec_ok = al(W) && al(L) && (ldw % 2 == 0) && (ldl % 2 == 0);
+    hipLaunchKernelGGL(gemm_nt_update_fast, dim3(static_cast<unsigned>(ntm) * ntn), dim3(512), 0, ex->stream, C, ld, W,
+                       ldw, L, ldl, M, Nc, Kd, lower, ntm, vec_ok);
     hipLaunchKernelGGL(gemm_nt_update, dim3(static_cast<unsigned>(ntm) * ntn), dim3(256), 0, ex->stream, C, ld, W, ldw,
                        L, ldl, M, Nc, Kd, lower, ntm, vec_ok);
+    DNLP_LAUNCH_CHECK();
   }
 
   bool factor(double* A, int* nneg, int* nzero) {
@@ -290,8 +452,8 @@ struct BlockedLdlt {
     const double tiny = 1e-300;
     float upd_ms = 0.f;
     const int ni = static_cast<int>(n);
-    for (int K0 = 0; K0 < ni; K0 += LD_NB) {
-      const int KB = std::min(LD_NB, ni - K0);
+    for (int K0 = 0; K0 < ni; K0 += NB) {
+      const int KB = std::min(NB, ni - K0);
       for (int j0 = K0; j0 < K0 + KB; j0 += LD_nb) {
         const int jb = std::min(LD_nb, K0 + KB - j0);
         hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(256), 0, ex->stream, A, ld, j0, jb, info, tiny);
@@ -306,6 +468,14 @@ struct BlockedLdlt {
                A + r0 + static_cast<i64>(j0) * ld, ld, rows, nc, jb, 1);
       }
       const int r1 = K0 + KB;
+      if (max_neg >= 0) {
+        // wrong inertia is known as soon as too many negative pivots have appeared: the rest
+        // of the factorisation would be thrown away by the caller's regularisation loop
+        LdltInfo cur;
+        DNLP_HIP_CHECK(hipMemcpyAsync(&cur, info, sizeof cur, hipMemcpyDeviceToHost, ex->stream));
+        DNLP_HIP_CHECK(hipStreamSynchronize(ex->stream));
+        if (cur.nneg > max_neg || cur.fail) { *nneg = cur.nneg + 1000000; *nzero = cur.nzero; return cur.fail == 0; }
+      }
       if (r1 < ni) {
         if (time_updates) DNLP_HIP_CHECK(hipEventRecord(ev0, ex->stream));
         gemm(A + r1 + static_cast<i64>(r1) * ld, Wp + r1, A + r1 + static_cast<i64>(K0) * ld, ld, ni - r1, ni - r1, KB, 1);
@@ -315,6 +485,11 @@ struct BlockedLdlt {
           float ms = 0.f;
           DNLP_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
           upd_ms += ms;
+          total_update_seconds += ms * 1e-3;
+          // algorithmic flops of this launch: lower triangle of an (n-r1)^2 rank-KB update
+          const double tr = static_cast<double>(ni - r1);
+          total_update_flops += tr * (tr + 1.0) * static_cast<double>(KB);
+          total_update_launches += 1;
         }
       }
     }
@@ -329,26 +504,27 @@ struct BlockedLdlt {
 
   void solve(const double* A, double* b) {
     const int ni = static_cast<int>(n);
-    for (int j0 = 0; j0 < ni; j0 += LD_nb) {
-      const int jb = std::min(LD_nb, ni - j0);
-      hipLaunchKernelGGL(ldlt_fwd_diag, dim3(1), dim3(64), 0, ex->stream, A, ld, j0, jb, b);
+    for (int j0 = 0; j0 < ni; j0 += SV_B) {
+      const int jb = std::min(SV_B, ni - j0);
+      hipLaunchKernelGGL(ldlt_fwd_diag, dim3(1), dim3(SV_B), 0, ex->stream, A, ld, j0, jb, b);
       const int rows = ni - j0 - jb;
       if (rows > 0)
         hipLaunchKernelGGL(ldlt_fwd_update, dim3((rows + 255) / 256), dim3(256), 0, ex->stream, A, ld, j0, jb, ni, b);
     }
     hipLaunchKernelGGL(ldlt_diag_scale, dim3((ni + 255) / 256), dim3(256), 0, ex->stream, A, ld, ni, b);
-    ex->zero(acc, sizeof(double) * LD_nb);
-    const int nblk = (ni + LD_nb - 1) / LD_nb;
+    ex->zero(acc, sizeof(double) * SV_B);
+    const int nblk = (ni + SV_B - 1) / SV_B;
     for (int bi = nblk - 1; bi >= 0; --bi) {
-      const int j0 = bi * LD_nb, jb = std::min(LD_nb, ni - j0);
+      const int j0 = bi * SV_B, jb = std::min(SV_B, ni - j0);
       const int rows = ni - j0 - jb;
       if (rows > 0) {
-        const int rpb = 4096;
-        hipLaunchKernelGGL(ldlt_bwd_update, dim3((rows + rpb - 1) / rpb), dim3(256), 0, ex->stream, A, ld, j0, jb, ni, b,
-                           acc, rpb);
+        const int rpc = 4096;
+        hipLaunchKernelGGL(ldlt_bwd_update, dim3((jb + 3) / 4, (rows + rpc - 1) / rpc), dim3(256), 0, ex->stream, A, ld,
+                           j0, jb, ni, b, acc, rpc);
       }
-      hipLaunchKernelGGL(ldlt_bwd_diag, dim3(1), dim3(64), 0, ex->stream, A, ld, j0, jb, b, acc);
+      hipLaunchKernelGGL(ldlt_bwd_diag, dim3(1), dim3(SV_B), 0, ex->stream, A, ld, j0, jb, b, acc);
     }
+    DNLP_LAUNCH_CHECK();
   }
 };
 
@@ -362,7 +538,17 @@ inline void HipExec::ldlt_prepare(LdltWork& w, i64 n, i64 ld, bool pivoted) {
 }
 inline bool HipExec::ldlt_factor(LdltWork& w, double* A, i64 n, i64 ld, i32* ipiv, bool pivoted, int* nneg, int* nzero) {
   if (pivoted) return bk_factor(w, A, n, ld, ipiv, nneg, nzero);
+  w.blocked->max_neg = w.expect_neg;
+  w.blocked->time_updates = w.time_updates;
   return w.blocked->factor(A, nneg, nzero);
+}
+inline void HipExec::ldlt_stats(LdltWork& w, double* out3) {
+  out3[0] = out3[1] = out3[2] = 0.0;
+  if (w.blocked) {
+    out3[0] = w.blocked->total_update_seconds;
+    out3[1] = w.blocked->total_update_flops;
+    out3[2] = static_cast<double>(w.blocked->total_update_launches);
+  }
 }
 inline void HipExec::ldlt_solve(LdltWork& w, const double* A, i64 n, i64 ld, const i32* ipiv, bool pivoted, double* b) {
   if (pivoted) {
@@ -387,13 +573,14 @@ __global__ void __launch_bounds__(256) gen_vec_kernel(double* v, i64 n, uint64_t
 }
 // A[i,j] = noise(min(i,j), max(i,j)) in [-1,1) + spike * v_i v_j
 __global__ void __launch_bounds__(256) gen_sym_kernel(double* A, i64 n, i64 ld, uint64_t seed, double spike,
-                                                      const double* v, i64 nrb) {
-  const i64 c = blockIdx.x / nrb, rb = blockIdx.x % nrb;
-  const i64 r = rb * 256 + threadIdx.x;
+                                                      const double* v) {
+  const i64 r = static_cast<i64>(blockIdx.x) * 256 + threadIdx.x;
   if (r >= n) return;
-  const uint64_t lo = static_cast<uint64_t>(r < c ? r : c), hi = static_cast<uint64_t>(r < c ? c : r);
-  const double noise = 2.0 * u01(splitmix64(seed + lo * 0x9E3779B97F4A7C15ull + splitmix64(hi))) - 1.0;
-  A[r + c * ld] = noise + spike * v[r] * v[c];
+  for (i64 c = blockIdx.y; c < n; c += gridDim.y) {
+    const uint64_t lo = static_cast<uint64_t>(r < c ? r : c), hi = static_cast<uint64_t>(r < c ? c : r);
+    const double noise = 2.0 * u01(splitmix64(seed + lo * 0x9E3779B97F4A7C15ull + splitmix64(hi))) - 1.0;
+    A[r + c * ld] = noise + spike * v[r] * v[c];
+  }
 }
 
 }  // namespace dnlp

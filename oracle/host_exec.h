@@ -20,7 +20,8 @@ namespace dnlp {
 
 struct HostExec {
   static constexpr bool is_device = false;
-  struct LdltWork { std::vector<double> d; };
+  struct LdltWork { std::vector<double> d; int expect_neg = -1; bool time_updates = false; };
+  void ldlt_stats(LdltWork&, double* out3) { out3[0] = out3[1] = out3[2] = 0.0; }
   explicit HostExec(int device = 0) { (void)device; }
 
   template <class T> T* alloc(size_t n) { return static_cast<T*>(std::calloc(n ? n : 1, sizeof(T))); }
