@@ -315,17 +315,29 @@ __global__ void __launch_bounds__(SV_B) ldlt_fwd_diag(const double* __restrict__
   for (int s0 = 0; s0 < jb; s0 += 32) {
     const int s1 = (s0 + 32 < jb) ? s0 + 32 : jb;
     if ((t >> 6) == (s0 >> 6)) {
-      for (int k = s0; k < s1; ++k) {
-        const double yk = __shfl(v, k & 63, 64);
-        if (t > k && t < s1) v -= A[(j0 + t) + static_cast<i64>(j0 + k) * ld] * yk;
+      // this lane's row of the 32 x 32 sub-block, fetched up front (independent loads) so the
+      // substitution loop below is register-only
+      double lr[32];
+#pragma unroll
+      for (int kk = 0; kk < 32; ++kk)
+        lr[kk] = (s0 + kk < t && t < s1) ? A[(j0 + t) + static_cast<i64>(j0 + s0 + kk) * ld] : 0.0;
+#pragma unroll
+      for (int kk = 0; kk < 32; ++kk) {
+        const double yk = __shfl(v, (s0 + kk) & 63, 64);
+        v -= lr[kk] * yk;
       }
       if (t >= s0 && t < s1) y[t] = v;
     }
     __syncthreads();
     if (t >= s1 && t < jb) {
-      double s = 0.0;
-      for (int k = s0; k < s1; ++k) s += A[(j0 + t) + static_cast<i64>(j0 + k) * ld] * y[k];
-      v -= s;
+      double sa = 0.0, sb = 0.0;
+      const double* row = A + (j0 + t) + static_cast<i64>(j0 + s0) * ld;
+#pragma unroll 8
+      for (int kk = 0; kk < 32; kk += 2) {
+        if (s0 + kk < s1) sa += row[static_cast<i64>(kk) * ld] * y[s0 + kk];
+        if (s0 + kk + 1 < s1) sb += row[static_cast<i64>(kk + 1) * ld] * y[s0 + kk + 1];
+      }
+      v -= sa + sb;
     }
   }
   if (t < jb) b[j0 + t] = v;
@@ -387,9 +399,15 @@ __global__ void __launch_bounds__(SV_B) ldlt_bwd_diag(const double* __restrict__
   for (int sbk = nsb - 1; sbk >= 0; --sbk) {
     const int s0 = sbk * 32, s1 = (s0 + 32 < jb) ? s0 + 32 : jb;
     if ((t >> 6) == (s0 >> 6)) {
-      for (int k = s1 - 1; k >= s0; --k) {
-        const double xk = __shfl(v, k & 63, 64);
-        if (t < k && t >= s0) v -= A[(j0 + k) + static_cast<i64>(j0 + t) * ld] * xk;
+      double lr[32];
+      const double* colt = A + (j0 + s0) + static_cast<i64>(j0 + t) * ld;
+#pragma unroll
+      for (int kk = 0; kk < 32; ++kk)
+        lr[kk] = (s0 + kk > t && s0 + kk < s1 && t >= s0) ? colt[kk] : 0.0;
+#pragma unroll
+      for (int kk = 31; kk >= 0; --kk) {
+        const double xk = __shfl(v, (s0 + kk) & 63, 64);
+        v -= lr[kk] * xk;
       }
       if (t >= s0 && t < s1) xs[t] = v;
     }
