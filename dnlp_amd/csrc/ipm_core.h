@@ -50,6 +50,7 @@ struct IpmOptions {
   double nlp_inf = 1e19;              // |bound| >= 1e19 means "no bound"
   int max_refine = 10, min_refine = 1;
   int restoration = 1;
+  int adaptive_fallback = 1;
 };
 
 struct IpmStats {
@@ -92,6 +93,7 @@ class Ipm {
   double *xt = nullptr, *st = nullptr, *gt = nullptr;
   double *rhs = nullptr, *sol = nullptr, *res = nullptr, *cor = nullptr, *Sx = nullptr, *Dd = nullptr, *Ss = nullptr;
   double *rx = nullptr, *rs = nullptr, *rp = nullptr, *tN = nullptr, *tM = nullptr, *csoc = nullptr;
+  double *aff[7] = {nullptr}, *cen[7] = {nullptr}, *zeroM = nullptr;   // mu-oracle directions
   double sf = 1.0;
   double f = 0.0;                     // scaled objective at x
   double mu = 0.1, tau = 0.99;
@@ -121,6 +123,9 @@ class Ipm {
     res = A<double>(N + m); cor = A<double>(N + m); Sx = A<double>(N); Dd = A<double>(m); Ss = A<double>(m);
     rx = A<double>(N); rs = A<double>(m); rp = A<double>(m); tN = A<double>(N); tM = A<double>(m);
     csoc = A<double>(m);
+    zeroM = A<double>(m);
+    const i64 sz[7] = {N, m, m, N, N, m, m};
+    for (int k = 0; k < 7; ++k) { aff[k] = A<double>(sz[k]); cen[k] = A<double>(sz[k]); }
   }
 
   void logf(const char* fmt, ...) {
@@ -532,7 +537,7 @@ class Ipm {
   }
 
   // direction for barrier parameter muv with primal residual `pres` (rp or the SOC one)
-  bool compute_direction(double muv, const double* pres, double dw) {
+  bool compute_direction(double muv, const double* pres, double dw, bool centering = false) {
     double* r = rhs;
     const double *rxx = rx, *q = rs, *sS = Ss, *eq = eqmask;
     const i64 NN = N;
@@ -549,14 +554,15 @@ class Ipm {
     // bound multiplier steps (WB eq. (12))
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *a = zL, *b = zU, *c = vL, *d = vU;
     double *da = dzL, *db = dzU, *dc = dvL, *dd2 = dvU;
+    const double keep = centering ? 0.0 : 1.0;   // the centering direction has no "- z" term
     ex_->map(N, [=] DNLP_HD(i64 j) {
-      da[j] = (l[j] > -kInf) ? (muv - a[j] * ddx[j]) / (xx[j] - l[j]) - a[j] : 0.0;
-      db[j] = (u[j] < kInf) ? (muv + b[j] * ddx[j]) / (u[j] - xx[j]) - b[j] : 0.0;
+      da[j] = (l[j] > -kInf) ? (muv - a[j] * ddx[j]) / (xx[j] - l[j]) - keep * a[j] : 0.0;
+      db[j] = (u[j] < kInf) ? (muv + b[j] * ddx[j]) / (u[j] - xx[j]) - keep * b[j] : 0.0;
     });
     ex_->map(m, [=] DNLP_HD(i64 i) {
       const bool in = eq[i] == 0.0;
-      dc[i] = (in && sl[i] > -kInf) ? (muv - c[i] * dds[i]) / (ss[i] - sl[i]) - c[i] : 0.0;
-      dd2[i] = (in && su[i] < kInf) ? (muv + d[i] * dds[i]) / (su[i] - ss[i]) - d[i] : 0.0;
+      dc[i] = (in && sl[i] > -kInf) ? (muv - c[i] * dds[i]) / (ss[i] - sl[i]) - keep * c[i] : 0.0;
+      dd2[i] = (in && su[i] < kInf) ? (muv + d[i] * dds[i]) / (su[i] - ss[i]) - keep * d[i] : 0.0;
     });
     return true;
   }
@@ -635,15 +641,21 @@ class Ipm {
       double xm = ex_->max(N, [=] DNLP_HD(i64 j) { return fabs(xx[j]); });
       if (!(xm <= opt.diverging_iterates_tol)) return status = Diverging_Iterates;
     }
-    // barrier parameter update
-    update_mu(e0);
+    // barrier parameter update: monotone / fixed-mode decisions need no linear algebra;
+    // the free-mode oracle needs the factorisation and runs after it
+    const bool want_oracle = update_mu(e0);
     // Hessian of the Lagrangian at (x, y)
     eval_hessian();
     barrier_terms(mu);
     double dw = 0.0, dc = 0.0;
     if (!factor_with_inertia(dw, dc)) return status = Error_In_Step_Computation;
     stats.last_delta_w = dw;
-    if (!compute_direction(mu, rp, dw)) return status = Error_In_Step_Computation;
+    bool have_dir = false;
+    if (want_oracle) have_dir = quality_function_mu(dw);
+    if (!have_dir) {
+      barrier_terms(mu);
+      if (!compute_direction(mu, rp, dw)) return status = Error_In_Step_Computation;
+    }
     // ---- backtracking filter line search (WB Algorithm A, steps A-5) ----
     double a_max = max_step_primal(tau);
     double a_z = max_step_dual(tau);
@@ -849,9 +861,16 @@ class Ipm {
   // mu = sigma * avg_compl with the LOQO centrality heuristic; if the KKT error fails to
   // decrease by the factor 0.9999 relative to the last 4 free-mode iterates the algorithm
   // falls back to the monotone mode until it does.
-  void update_mu(const Err& e0) {
-    if (n_bound_mults() == 0) { tau = 0.99; return; }   // no barrier terms at all
-    if (opt.mu_strategy == 0) { monotone_update(); return; }
+  // Adaptive strategy (IPOPT mu_strategy=adaptive, the reference's default): free mode chooses
+  // mu with the quality-function oracle (IPOPT's default mu_oracle; Nocedal, Waechter, Waltz,
+  // "Adaptive barrier update strategies for nonlinear interior methods", SIOPT 19(4), 2009);
+  // globalisation = kkt-error: if the KKT error fails to decrease by the factor 0.9999
+  // relative to the last 4 free-mode iterates the algorithm runs the monotone (fixed) mode,
+  // started at 0.8 * average complementarity, until it does.
+  // Returns true when the free-mode oracle must be run after the factorisation.
+  bool update_mu(const Err& e0) {
+    if (n_bound_mults() == 0) { tau = 0.99; return false; }   // no barrier terms at all
+    if (opt.mu_strategy == 0) { monotone_update(); return false; }
     const double mu_floor = std::max(opt.mu_min, std::min(opt.tol, opt.compl_inf_tol) / 11.0);
     double kkt = e0.dual + e0.primal + e0.cmpl;
     if (!fixed_mode) {
@@ -875,30 +894,149 @@ class Ipm {
         if (kkt_hist.size() > 4) kkt_hist.erase(kkt_hist.begin());
       }
     }
-    if (fixed_mode) { monotone_update(); return; }
-    // LOQO oracle
-    double avg = avg_complementarity();
-    const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *a = zL, *b = zU, *c = vL, *d = vU, *eq = eqmask;
-    double mn = std::min(ex_->min(N, [=] DNLP_HD(i64 j) {
-      double v = kInf;
-      if (l[j] > -kInf) v = fmin(v, (xx[j] - l[j]) * a[j]);
-      if (u[j] < kInf) v = fmin(v, (u[j] - xx[j]) * b[j]);
-      return v; }), m ? ex_->min(m, [=] DNLP_HD(i64 i) {
-      double v = kInf;
-      if (eq[i] != 0.0) return v;
-      if (sl[i] > -kInf) v = fmin(v, (ss[i] - sl[i]) * c[i]);
-      if (su[i] < kInf) v = fmin(v, (su[i] - ss[i]) * d[i]);
-      return v; }) : kInf);
-    double xi = (avg > 0) ? mn / avg : 1.0;
-    double sigma = 0.1 * std::pow(std::min(0.05 * (1.0 - xi) / std::max(xi, 1e-300), 2.0), 3.0);
-    double nm = sigma * avg;
-    double mu_max = opt.mu_max_fact * std::max(avg, 1e-300);
-    nm = std::max(mu_floor, std::min(nm, mu_max));
-    if (nm != mu) {
-      mu = nm;
-      tau = std::max(0.99, 1.0 - mu);
-      filter.clear();   // free mode: each iteration is a new barrier problem
+    if (fixed_mode) { monotone_update(); return false; }
+    return true;
+  }
+
+  // Quality-function oracle.  With the KKT matrix factored: affine-scaling direction (mu = 0)
+  // and centering direction (unit mu) -> direction(mu) = aff + mu * cen; the quality function
+  // is the linearised KKT error after the fraction-to-boundary step; golden section in
+  // log(sigma), mu = sigma * average complementarity.  On success the search direction for the
+  // chosen mu is already in dx..dvU and rx/rs hold the residuals for that mu.
+  bool quality_function_mu(double dw) {
+    const double avg = avg_complementarity();
+    const i64 nb = n_bound_mults();
+    if (!(avg > 0.0) || nb == 0) return false;
+    const double mu_floor = std::max(opt.mu_min, std::min(opt.tol, opt.compl_inf_tol) / 11.0);
+    double* cur[7] = {dx, ds, dy, dzL, dzU, dvL, dvU};
+    const i64 sz[7] = {N, m, m, N, N, m, m};
+    barrier_terms(0.0);
+    const double *rxx = rx, *rss = rs, *rpp = rp;
+    const double nd2 = ex_->sum(N, [=] DNLP_HD(i64 j) { return rxx[j] * rxx[j]; }) +
+                       (m ? ex_->sum(m, [=] DNLP_HD(i64 i) { return rss[i] * rss[i]; }) : 0.0);
+    const double np2 = m ? ex_->sum(m, [=] DNLP_HD(i64 i) { return rpp[i] * rpp[i]; }) : 0.0;
+    if (!compute_direction(0.0, rp, dw)) return false;
+    for (int k = 0; k < 7; ++k) ex_->d2d(aff[k], cur[k], sizeof(double) * static_cast<size_t>(sz[k]));
+    {
+      // centering right-hand side: derivative of the barrier terms w.r.t. mu
+      double *r = rx, *q = rs;
+      const double *l = xL, *u = xU, *sl = sL, *su = sU, *eq = eqmask, *xx = x, *ss = s, *fm = fixmask;
+      const double kd = opt.kappa_d;
+      ex_->map(N, [=] DNLP_HD(i64 j) {
+        double c = 0.0;
+        const bool hl = l[j] > -kInf, hu = u[j] < kInf;
+        if (hl) c -= 1.0 / (xx[j] - l[j]);
+        if (hu) c += 1.0 / (u[j] - xx[j]);
+        if (hl && !hu) c += kd;
+        if (hu && !hl) c -= kd;
+        r[j] = fm[j] != 0.0 ? 0.0 : c;
+      });
+      ex_->map(m, [=] DNLP_HD(i64 i) {
+        double c = 0.0;
+        if (eq[i] == 0.0) {
+          const bool hl = sl[i] > -kInf, hu = su[i] < kInf;
+          if (hl) c -= 1.0 / (ss[i] - sl[i]);
+          if (hu) c += 1.0 / (su[i] - ss[i]);
+          if (hl && !hu) c += kd;
+          if (hu && !hl) c -= kd;
+        }
+        q[i] = c;
+      });
     }
+    if (!compute_direction(1.0, zeroM, dw, true)) return false;
+    for (int k = 0; k < 7; ++k) ex_->d2d(cen[k], cur[k], sizeof(double) * static_cast<size_t>(sz[k]));
+    i64 n_ineq = static_cast<i64>(m - (m ? ex_->sum(m, [=, eq = eqmask] DNLP_HD(i64 i) { return eq[i]; }) : 0.0));
+    const double n_dual = static_cast<double>(N + n_ineq), n_pri = static_cast<double>(m > 0 ? m : 1);
+    const double *ax = aff[0], *as = aff[1], *aa = aff[3], *ab = aff[4], *ac = aff[5], *ad = aff[6];
+    const double *cx = cen[0], *cs = cen[1], *ca = cen[3], *cb = cen[4], *cc = cen[5], *cd = cen[6];
+    const double *l = xL, *u = xU, *sl = sL, *su = sU, *eq = eqmask, *xx = x, *ss = s, *a = zL, *b = zU,
+                 *c = vL, *d = vU;
+    auto qf = [&](double sigma) -> double {
+      const double mus = sigma * avg;
+      const double tv = std::max(0.99, 1.0 - mus);
+      double ap = ex_->min(N, [=] DNLP_HD(i64 j) {
+        const double dxx = ax[j] + mus * cx[j];
+        double t = 1.0;
+        if (l[j] > -kInf && dxx < 0.0) t = fmin(t, -tv * (xx[j] - l[j]) / dxx);
+        if (u[j] < kInf && dxx > 0.0) t = fmin(t, tv * (u[j] - xx[j]) / dxx);
+        return t; });
+      double ad_ = ex_->min(N, [=] DNLP_HD(i64 j) {
+        const double da = aa[j] + mus * ca[j], db = ab[j] + mus * cb[j];
+        double t = 1.0;
+        if (da < 0.0) t = fmin(t, -tv * a[j] / da);
+        if (db < 0.0) t = fmin(t, -tv * b[j] / db);
+        return t; });
+      if (m) {
+        ap = std::min(ap, ex_->min(m, [=] DNLP_HD(i64 i) {
+          double t = 1.0;
+          if (eq[i] != 0.0) return t;
+          const double dss = as[i] + mus * cs[i];
+          if (sl[i] > -kInf && dss < 0.0) t = fmin(t, -tv * (ss[i] - sl[i]) / dss);
+          if (su[i] < kInf && dss > 0.0) t = fmin(t, tv * (su[i] - ss[i]) / dss);
+          return t; }));
+        ad_ = std::min(ad_, ex_->min(m, [=] DNLP_HD(i64 i) {
+          const double dc = ac[i] + mus * cc[i], dd2 = ad[i] + mus * cd[i];
+          double t = 1.0;
+          if (dc < 0.0) t = fmin(t, -tv * c[i] / dc);
+          if (dd2 < 0.0) t = fmin(t, -tv * d[i] / dd2);
+          return t; }));
+      }
+      ap = std::min(1.0, ap); ad_ = std::min(1.0, ad_);
+      const double apv = ap, adv = ad_;
+      double comp = ex_->sum(N, [=] DNLP_HD(i64 j) {
+        double v = 0.0;
+        const double dxx = ax[j] + mus * cx[j];
+        if (l[j] > -kInf) { const double t = (xx[j] - l[j] + apv * dxx) * (a[j] + adv * (aa[j] + mus * ca[j])); v += t * t; }
+        if (u[j] < kInf) { const double t = (u[j] - xx[j] - apv * dxx) * (b[j] + adv * (ab[j] + mus * cb[j])); v += t * t; }
+        return v; });
+      if (m) comp += ex_->sum(m, [=] DNLP_HD(i64 i) {
+        double v = 0.0;
+        if (eq[i] != 0.0) return v;
+        const double dss = as[i] + mus * cs[i];
+        if (sl[i] > -kInf) { const double t = (ss[i] - sl[i] + apv * dss) * (c[i] + adv * (ac[i] + mus * cc[i])); v += t * t; }
+        if (su[i] < kInf) { const double t = (su[i] - ss[i] - apv * dss) * (d[i] + adv * (ad[i] + mus * cd[i])); v += t * t; }
+        return v; });
+      return (1.0 - adv) * (1.0 - adv) * nd2 / n_dual + (1.0 - apv) * (1.0 - apv) * np2 / n_pri +
+             comp / static_cast<double>(nb);
+    };
+    // search interval (IPOPT: sigma_min 1e-6, sigma_max 1e2, 8 section steps, tol 1e-2)
+    const double mu_max = opt.mu_max_fact * avg;
+    double s_lo = std::max(1e-6, mu_floor / avg), s_up = std::min(1e2, mu_max / avg);
+    double sigma;
+    if (s_lo >= s_up) {
+      sigma = s_lo;
+    } else {
+      const double q1 = qf(1.0), s1m = 1.0 - 1e-2, q1m = qf(std::max(s_lo, s1m));
+      double lo, up;
+      if (q1m > q1 && s_up > 1.0) { lo = 1.0; up = s_up; } else { lo = s_lo; up = std::min(std::max(s_lo, s1m), s_up); }
+      // golden section in log(sigma)
+      const double gr = 0.5 * (3.0 - std::sqrt(5.0));
+      double la = std::log(lo), lb = std::log(std::max(up, lo * (1 + 1e-12)));
+      double m1 = la + gr * (lb - la), m2 = lb - gr * (lb - la);
+      double f1 = qf(std::exp(m1)), f2 = qf(std::exp(m2));
+      for (int it = 0; it < 8 && (lb - la) > 1e-2 * std::fabs(lb) + 1e-12; ++it) {
+        if (f1 > f2) { la = m1; m1 = m2; f1 = f2; m2 = lb - gr * (lb - la); f2 = qf(std::exp(m2)); }
+        else { lb = m2; m2 = m1; f2 = f1; m1 = la + gr * (lb - la); f1 = qf(std::exp(m1)); }
+      }
+      sigma = std::exp(f1 < f2 ? m1 : m2);
+      const double fbest = std::min(f1, f2);
+      const double qlo = qf(lo), qup = qf(up);
+      if (qlo < fbest && qlo <= qup) sigma = lo;
+      else if (qup < fbest) sigma = up;
+    }
+    double nm = std::max(mu_floor, std::min(sigma * avg, mu_max));
+    if (!std::isfinite(nm)) return false;
+    mu = nm;
+    tau = std::max(0.99, 1.0 - mu);
+    filter.clear();                   // free mode: every iteration is a new barrier problem
+    barrier_terms(mu);                // residuals for the chosen mu (line search, SOC)
+    const double muv = mu;
+    for (int k = 0; k < 7; ++k) {
+      double* o = cur[k];
+      const double *p1 = aff[k], *p2 = cen[k];
+      ex_->map(sz[k], [=] DNLP_HD(i64 i) { o[i] = p1[i] + muv * p2[i]; });
+    }
+    return true;
   }
 
   // ---- feasibility restoration (simplified form of WB section 3.3) ---------------------
@@ -977,13 +1115,36 @@ class Ipm {
 
   // ---- driver -------------------------------------------------------------------------
   int solve(const double* x0_host) {
+    const double t_all = now_sec();
     int rc = begin(x0_host);
     if (rc != 0) return rc;
     while (true) {
       int r = step();
       if (r != 99) break;
     }
-    stats.wall = now_sec() - t_begin_;
+    // Robustness device (documented deviation): when the adaptive strategy ends in a step /
+    // restoration failure, the solve is repeated once from the same start in monotone mode.
+    if (opt.mu_strategy == 1 && opt.adaptive_fallback &&
+        (status == Infeasible_Problem_Detected || status == Restoration_Failed ||
+         status == Error_In_Step_Computation || status == Search_Direction_Becomes_Too_Small)) {
+      const int it_first = iter;
+      logf("adaptive barrier strategy ended with status %d after %d iterations: restarting in monotone mode", status, iter);
+      std::vector<std::string> keep = log_lines;
+      opt.mu_strategy = 0;
+      rc = begin(x0_host);
+      if (rc == 0) {
+        while (true) {
+          int r = step();
+          if (r != 99) break;
+        }
+      }
+      opt.mu_strategy = 1;
+      iter += it_first;
+      stats.iterations = iter;
+      keep.insert(keep.end(), log_lines.begin(), log_lines.end());
+      log_lines = keep;
+    }
+    stats.wall = now_sec() - t_all;
     stats.final_mu = mu;
     return status;
   }

@@ -1,0 +1,52 @@
+"""Parametrised paper NLPs for the batch path (BASELINE config C5): instance i draws its data
+from default_rng(i).  `oracle_solver` solves with the CPU oracle (tests only)."""
+import numpy as np
+
+
+def build_localization(i, m=10):
+    """Sensor localization (examples/nlp_examples/localization.ipynb; test_nlp_solvers.py:175-189)
+    with anchors and true position drawn per instance."""
+    import dnlp_amd as cp
+    rng = np.random.default_rng(i)
+    x_true = rng.uniform(-3, 3, 2)
+    a = rng.uniform(-5, 5, (m, 2))
+    rho = np.linalg.norm(a - x_true, axis=1)
+    x = cp.Variable(2, name="x")
+    t = cp.Variable(m, name="t")
+    prob = cp.Problem(cp.Minimize(cp.sum_squares(t - rho)),
+                      [t == cp.sqrt(cp.sum(cp.square(x - a), axis=1))])
+    prob._x_true = x_true
+    return prob
+
+
+def build_circle_packing(i, n=4):
+    """Circle packing (examples/nlp_examples/circle_packing.ipynb) with radii per instance."""
+    import dnlp_amd as cp
+    rng = np.random.default_rng(i)
+    radius = rng.uniform(1.0, 3.0, n)
+    centers = cp.Variable((2, n), name="c")
+    cons = []
+    for a in range(n - 1):
+        for b in range(a + 1, n):
+            cons += [cp.sum(cp.square(centers[:, a] - centers[:, b])) >= (radius[a] + radius[b]) ** 2]
+    centers.value = rng.uniform(-5.0, 5.0, (2, n))
+    return cp.Problem(cp.Minimize(cp.max(cp.norm_inf(centers, axis=0) + radius)), cons)
+
+
+def oracle_solver(problem, **opts):
+    from dnlp_amd.dnlp2smooth import Dnlp2Smooth
+    from dnlp_amd.nlp_solver import build_nlp_data
+    from dnlp_amd.tape import serialize
+    from oracle.oracle_capi import OracleProblem
+    import dnlp_amd as cp
+    flip = isinstance(problem.objective, cp.Maximize)
+    if flip:
+        problem = cp.Problem(cp.Minimize(-problem.objective.expr), problem.constraints)
+    smooth, _ = Dnlp2Smooth().apply(problem)
+    data, _ = build_nlp_data(smooth)
+    h = OracleProblem(serialize(data["tape_arrays"]))
+    for k, v in opts.items():
+        h.set_option(k, v)
+    info = h.solve(data["x0"])
+    obj = -info["obj_val"] if flip else info["obj_val"]
+    return obj, info["status"], info["iterations"], info["x"]

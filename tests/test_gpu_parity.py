@@ -171,3 +171,27 @@ def test_device_matrix_sphere_and_symv(gpu_required):
     assert abs(prob.value - lam_max) <= 1e-6 * lam_max
     v = x.value / np.linalg.norm(x.value)
     assert np.linalg.norm(Ah @ v - lam_max * v) <= 1e-4 * lam_max
+
+
+def test_dense_eq_qp_blocked_kkt_closed_form(gpu_required):
+    """BASELINE C3 shape (dense equality-constrained QP) at n=2400, m=240: KKT order 2640 goes
+    through the blocked FP64-MFMA LDL^T; one Newton step must reproduce the closed-form KKT
+    solution (primal and dual)."""
+    import dnlp_amd as cp
+    n, m = 2400, 240
+    rng = np.random.default_rng(0)
+    Gm = rng.standard_normal((n, n))
+    Q = Gm.T @ Gm / n + np.eye(n)
+    c = rng.standard_normal(n)
+    A = rng.standard_normal((m, n))
+    b = A @ rng.standard_normal(n)
+    x = cp.Variable(n)
+    prob = cp.Problem(cp.Minimize(0.5 * cp.quad_form(x, Q) + c @ x), [A @ x == b])
+    chain = prob._build_chain(None)
+    data, inv = chain.apply(prob)
+    info = chain.solver.solve_via_data(data, True, False, {})
+    K = np.block([[Q, A.T], [A, np.zeros((m, m))]])
+    sol = np.linalg.solve(K, np.concatenate([-c, b]))
+    assert info["status"] == 0 and info["iterations"] <= 2
+    np.testing.assert_allclose(info["x"], sol[:n], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(info["mult_g"], sol[n:], rtol=1e-6, atol=1e-8)
