@@ -76,7 +76,10 @@ struct ProblemT {
     else if (k == "bound_relax_factor") opt.bound_relax_factor = num();
     else if (k == "bound_push") opt.bound_push = num();
     else if (k == "bound_frac") opt.bound_frac = num();
-    else if (k == "hessian_approximation") { if (v != "exact") return -12; }
+    else if (k == "hessian_approximation") {
+      // "limited-memory" is accepted: the exact tape Hessian is always available and used
+      if (v != "exact" && v != "limited-memory") return -12;
+    }
     else if (k == "derivative_test") { /* accepted, unused: oracles are exact by construction */ }
     else if (k == "least_square_init_duals") opt.least_square_init_duals = yes() ? 1 : 0;
     else if (k == "print_level") opt.print_level = static_cast<int>(num());

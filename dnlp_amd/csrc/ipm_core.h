@@ -462,22 +462,25 @@ class Ipm {
   }
 
   // inertia-correcting factorisation of the reduced KKT matrix (WB Algorithm IC)
+  // one factorisation attempt: 0 ok, 1 wrong inertia, 2 singular
+  int try_factor(double dw, double dc) {
+    int nneg = 0, nzero = 0;
+    double* dd = Dd;
+    const double *sS = Ss, *eq = eqmask;
+    ex_->map(m, [=] DNLP_HD(i64 i) { dd[i] = dc + (eq[i] == 0.0 ? 1.0 / fmax(sS[i] + dw, 1e-20) : 0.0); });
+    double t0 = now_sec();
+    bool ok = kkt_->assemble_factor(*md_, jv, Sx, Dd, fixmask, dw, &nneg, &nzero);
+    stats.t_factor += now_sec() - t0;
+    stats.factorizations++;
+    if (!ok) return 2;
+    if (nzero > 0) return 2;
+    return nneg == m ? 0 : 1;
+  }
+
   bool factor_with_inertia(double& delta_w, double& delta_c) {
     const double dw_min = 1e-20, dw_0 = 1e-4, dw_max = 1e40, dc_bar = 1e-8, kwp = 8.0, kwpb = 100.0, kwm = 1.0 / 3.0, kc = 0.25;
     delta_w = 0.0; delta_c = 0.0;
-    int nneg = 0, nzero = 0;
-    auto attempt = [&](double dw, double dc) -> int {   // 0 ok, 1 wrong inertia, 2 singular
-      double* dd = Dd;
-      const double *sS = Ss, *eq = eqmask;
-      ex_->map(m, [=] DNLP_HD(i64 i) { dd[i] = dc + (eq[i] == 0.0 ? 1.0 / fmax(sS[i] + dw, 1e-20) : 0.0); });
-      double t0 = now_sec();
-      bool ok = kkt_->assemble_factor(*md_, jv, Sx, Dd, fixmask, dw, &nneg, &nzero);
-      stats.t_factor += now_sec() - t0;
-      stats.factorizations++;
-      if (!ok) return 2;
-      if (nzero > 0) return 2;
-      return nneg == m ? 0 : 1;
-    };
+    auto attempt = [&](double dw, double dc) -> int { return try_factor(dw, dc); };
     int r = attempt(0.0, 0.0);
     if (r == 0) return true;
     if (r == 2) delta_c = dc_bar * std::pow(mu, kc);
@@ -531,6 +534,15 @@ class Ipm {
       double* sw = sol;
       const double* co = cor;
       ex_->map(N + m, [=] DNLP_HD(i64 i) { sw[i] += co[i]; });
+    }
+    {
+      kkt_mult(sol, dw, res);
+      double* re = res;
+      const double* so = sol;
+      double en = ex_->max(N + m, [=] DNLP_HD(i64 i) { return fabs(rr[i] - re[i]); });
+      double sn = ex_->max(N + m, [=] DNLP_HD(i64 i) { return fabs(so[i]); });
+      last_ratio_ = en / (std::max(rn, 1e-300) + sn);
+      if (!std::isfinite(last_ratio_)) last_ratio_ = kInf;
     }
     stats.t_solve += now_sec() - t0;
     return true;
@@ -653,6 +665,20 @@ class Ipm {
     bool have_dir = false;
     if (want_oracle) have_dir = quality_function_mu(dw);
     if (!have_dir) {
+      barrier_terms(mu);
+      if (!compute_direction(mu, rp, dw)) return status = Error_In_Step_Computation;
+    }
+    // IPOPT's "pretend singular" safeguard (PDFullSpaceSolver, residual_ratio_singular = 1e-5):
+    // a factorisation with the right inertia whose refined solution still has a large residual
+    // is treated as singular and the system is perturbed (delta_c, then growing delta_w).
+    for (int tries = 0; tries < 6 && last_ratio_ > 1e-5; ++tries) {
+      if (dc == 0.0) dc = 1e-8 * std::pow(mu, 0.25);
+      dw = (dw == 0.0) ? ((delta_w_last == 0.0) ? 1e-4 : std::max(1e-20, delta_w_last / 3.0)) : 8.0 * dw;
+      int r = try_factor(dw, dc);
+      while (r != 0 && dw < 1e40) { dw *= 8.0; r = try_factor(dw, dc); }
+      if (r != 0) return status = Error_In_Step_Computation;
+      delta_w_last = dw;
+      stats.last_delta_w = dw;
       barrier_terms(mu);
       if (!compute_direction(mu, rp, dw)) return status = Error_In_Step_Computation;
     }
@@ -1184,6 +1210,7 @@ class Ipm {
   K* kkt_;
   std::vector<char> fixed_;
   i64 nb_cache_ = -1;
+  double last_ratio_ = 0.0;
   double t_begin_ = 0.0;
 };
 
