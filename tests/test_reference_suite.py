@@ -33,7 +33,7 @@ KNOWN_GAPS = {"test_risk_parity.py::TestRiskParity::test_vanilla_risk_parity_for
 
 def test_reference_nlp_suite_passes_on_this_solver():
     cmd = [sys.executable, os.path.join(ROOT, "tools", "run_reference_tests.py"), REF_TESTS,
-           "-k", "not Knitro and not KNITRO and not knitro", "-rf", "-x" if False else "-q"]
+           "-k", "not Knitro and not KNITRO and not knitro", "-rf"]
     env = dict(os.environ, DNLP_SHIM_BACKEND="oracle")
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500).stdout
     failed = set(re.findall(r"^FAILED (\S+)", out, flags=re.M))
