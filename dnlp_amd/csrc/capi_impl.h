@@ -101,6 +101,8 @@ struct ProblemT {
     else if (k == "restoration") opt.restoration = yes() ? 1 : 0;
     else if (k == "time_kernels") time_kernels = yes();
     else if (k == "adaptive_fallback") opt.adaptive_fallback = yes() ? 1 : 0;
+    else if (k == "lanczos_inertia_bound") opt.lanczos_inertia_bound = yes() ? 1 : 0;
+    else if (k == "lanczos_min_n") opt.lanczos_min_n = static_cast<int>(num());
     else if (k == "sb" || k == "linear_solver" || k == "print_user_options" || k == "print_timing_statistics")
       { /* IPOPT options with no counterpart here: accepted and ignored */ }
     else return -12;   // Invalid_Option, as IPOPT reports unknown names

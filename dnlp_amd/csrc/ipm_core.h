@@ -51,11 +51,14 @@ struct IpmOptions {
   int max_refine = 10, min_refine = 1;
   int restoration = 1;
   int adaptive_fallback = 1;
+  int lanczos_inertia_bound = 1;
+  int lanczos_min_n = 4096;
 };
 
 struct IpmStats {
   int iterations = 0;
   int factorizations = 0;
+  int skipped_factorizations = 0;
   double wall = 0.0, t_eval = 0.0, t_factor = 0.0, t_solve = 0.0, t_assemble = 0.0;
   double final_mu = 0.0, inf_pr = 0.0, inf_du = 0.0, cmpl = 0.0, nlp_error = 0.0;
   double last_delta_w = 0.0;
@@ -462,6 +465,111 @@ class Ipm {
   }
 
   // inertia-correcting factorisation of the reduced KKT matrix (WB Algorithm IC)
+  // Provable lower bound on the primal regularisation delta_w (large unpivoted systems).
+  //
+  // All-equality case with few rows (BASELINE C4: m = 1): K = [H~ + dw I, J^T; J, 0] has inertia
+  // (N, m, 0) iff the reduced Hessian Z^T (H~ + dw I) Z is positive definite, i.e. iff
+  // dw > -lambda_min(P H~ P | range P), P the orthogonal projector onto null(J).  Ritz values of
+  // a k-step Lanczos run on P H~ P (full reorthogonalisation; the Krylov space is independent of
+  // the shift dw) bound lambda_min from above, so every dw < -theta_1 is certain to fail.
+  // General case: H~ is a principal submatrix of K, so by Cauchy interlacing dw < -theta_(m+1)
+  // of H~ itself is certain to fail.  Either way the doomed O(n^3) factorisations are skipped at
+  // the price of k Hessian-vector products (k HBM sweeps).  Returns (lower bound, spectral width).
+  std::pair<double, double> lanczos_delta_lower_bound() {
+    const int kmax = 24, qmax = 8;
+    if (N < 4 * kmax) return {0.0, 0.0};
+    const double* eqm = eqmask;
+    const bool all_eq = m > 0 && ex_->sum(m, [=] DNLP_HD(i64 i) { return eqm[i]; }) == static_cast<double>(m);
+    const bool projected = all_eq && m <= qmax;
+    if (!projected && m + 1 > kmax - 2) return {0.0, 0.0};
+    if (!lanV) { lanV = A<double>(static_cast<i64>(kmax + 1) * N); lanW = A<double>(N); lanQ = A<double>(static_cast<i64>(qmax) * N); }
+    int nq = 0;
+    if (projected) {
+      // orthonormal basis of the row space of J (modified Gram-Schmidt on J^T e_i)
+      for (i64 i = 0; i < m; ++i) {
+        double* e = tM;
+        ex_->map(m, [=] DNLP_HD(i64 r) { e[r] = (r == i) ? 1.0 : 0.0; });
+        double* q = lanQ + static_cast<i64>(nq) * N;
+        md_->jac_tmult(jv, tM, q);
+        for (int pass = 0; pass < 2; ++pass)
+          for (int c = 0; c < nq; ++c) {
+            const double* qc = lanQ + static_cast<i64>(c) * N;
+            const double d = ex_->sum(N, [=] DNLP_HD(i64 j) { return q[j] * qc[j]; });
+            ex_->map(N, [=] DNLP_HD(i64 j) { q[j] -= d * qc[j]; });
+          }
+        const double nr = std::sqrt(ex_->sum(N, [=] DNLP_HD(i64 j) { return q[j] * q[j]; }));
+        if (nr > 1e-14) { ex_->map(N, [=] DNLP_HD(i64 j) { q[j] /= nr; }); ++nq; }
+      }
+    }
+    auto project = [&](double* v) {
+      for (int c = 0; c < nq; ++c) {
+        const double* qc = lanQ + static_cast<i64>(c) * N;
+        const double d = ex_->sum(N, [=] DNLP_HD(i64 j) { return v[j] * qc[j]; });
+        ex_->map(N, [=] DNLP_HD(i64 j) { v[j] -= d * qc[j]; });
+      }
+    };
+    std::vector<double> al, be;
+    double* v0 = lanV;
+    {
+      // deterministic start vector with components in every direction
+      ex_->map(N, [=] DNLP_HD(i64 j) { v0[j] = 1.0 + 0.5 * sin(1.0 + 0.37 * static_cast<double>(j % 1009)); });
+      project(v0);
+      const double nrm = std::sqrt(ex_->sum(N, [=] DNLP_HD(i64 j) { return v0[j] * v0[j]; }));
+      if (!(nrm > 0.0)) return {0.0, 0.0};
+      ex_->map(N, [=] DNLP_HD(i64 j) { v0[j] /= nrm; });
+    }
+    for (int k = 0; k < kmax; ++k) {
+      double* vk = lanV + static_cast<i64>(k) * N;
+      double* w = lanW;
+      md_->hess_mult(vk, w);
+      const double *sx = Sx, *fm = fixmask;
+      ex_->map(N, [=] DNLP_HD(i64 j) { w[j] = fm[j] != 0.0 ? 0.0 : w[j] + sx[j] * vk[j]; });
+      project(w);
+      const double a = ex_->sum(N, [=] DNLP_HD(i64 j) { return w[j] * vk[j]; });
+      al.push_back(a);
+      // full reorthogonalisation against all previous vectors (twice is enough)
+      for (int pass = 0; pass < 2; ++pass)
+        for (int q = 0; q <= k; ++q) {
+          const double* vq = lanV + static_cast<i64>(q) * N;
+          const double c = ex_->sum(N, [=] DNLP_HD(i64 j) { return w[j] * vq[j]; });
+          ex_->map(N, [=] DNLP_HD(i64 j) { w[j] -= c * vq[j]; });
+        }
+      const double b = std::sqrt(ex_->sum(N, [=] DNLP_HD(i64 j) { return w[j] * w[j]; }));
+      if (!(b > 1e-12 * (std::fabs(a) + 1.0)) || k + 1 == kmax) break;
+      be.push_back(b);
+      double* vn = lanV + static_cast<i64>(k + 1) * N;
+      ex_->map(N, [=] DNLP_HD(i64 j) { vn[j] = w[j] / b; });
+    }
+    // wanted-th smallest eigenvalue of the k x k tridiagonal T by Sturm bisection
+    const int kk = static_cast<int>(al.size());
+    const int want = projected ? 1 : static_cast<int>(m) + 1;
+    if (kk < want) return {0.0, 0.0};
+    double lo = al[0], hi = al[0];
+    for (int i = 0; i < kk; ++i) {
+      const double r = (i > 0 ? std::fabs(be[i - 1]) : 0.0) + (i < static_cast<int>(be.size()) ? std::fabs(be[i]) : 0.0);
+      lo = std::min(lo, al[i] - r);
+      hi = std::max(hi, al[i] + r);
+    }
+    const double width = hi - lo;
+    auto count_below = [&](double t) {
+      int c = 0;
+      double d = 1.0;
+      for (int i = 0; i < kk; ++i) {
+        const double b2 = (i > 0) ? be[i - 1] * be[i - 1] : 0.0;
+        d = (al[i] - t) - (i > 0 ? b2 / d : 0.0);
+        if (d == 0.0) d = 1e-300;
+        if (d < 0.0) ++c;
+      }
+      return c;
+    };
+    for (int it = 0; it < 100; ++it) {
+      const double mid = 0.5 * (lo + hi);
+      if (count_below(mid) >= want) hi = mid; else lo = mid;
+    }
+    const double theta = hi;
+    return {theta < 0.0 ? -theta : 0.0, width};
+  }
+
   // one factorisation attempt: 0 ok, 1 wrong inertia, 2 singular
   int try_factor(double dw, double dc) {
     int nneg = 0, nzero = 0;
@@ -480,11 +588,33 @@ class Ipm {
   bool factor_with_inertia(double& delta_w, double& delta_c) {
     const double dw_min = 1e-20, dw_0 = 1e-4, dw_max = 1e40, dc_bar = 1e-8, kwp = 8.0, kwpb = 100.0, kwm = 1.0 / 3.0, kc = 0.25;
     delta_w = 0.0; delta_c = 0.0;
-    auto attempt = [&](double dw, double dc) -> int { return try_factor(dw, dc); };
+    // large unpivoted systems: skip regularisation values that are provably too small
+    double dw_lb = 0.0, dw_first = 0.0;
+    bool have_lb = false;
+    auto get_lb = [&]() {
+      auto lbw = lanczos_delta_lower_bound();
+      dw_lb = lbw.first;
+      // first trial above the bound: Ritz values converge from above, so add 5% and 2% of the
+      // spectral width (an over-regularisation of that size is harmless, a failed attempt is not)
+      dw_first = dw_lb > 0.0 ? 1.05 * dw_lb + 0.02 * lbw.second : 0.0;
+      have_lb = true;
+    };
+    const bool use_lb = opt.lanczos_inertia_bound && !kkt_->pivoted && (N + m) >= opt.lanczos_min_n;
+    auto attempt = [&](double dw, double dc) -> int {
+      if (use_lb && have_lb && dw < dw_lb) { stats.skipped_factorizations++; return 1; }
+      double t0 = now_sec();
+      int r = try_factor(dw, dc);
+      if (opt.print_level >= 6) logf("   factor attempt delta_w=%.4e delta_c=%.2e -> %d (%.2fs) lanczos_lb=%.4e", dw, dc, r, now_sec() - t0, dw_lb);
+      return r;
+    };
+    if (use_lb && (iter == 0 || delta_w_used_last_iter_)) get_lb();
     int r = attempt(0.0, 0.0);
-    if (r == 0) return true;
+    if (r == 0) { delta_w_used_last_iter_ = false; return true; }
+    if (use_lb && !have_lb) get_lb();
+    delta_w_used_last_iter_ = true;
     if (r == 2) delta_c = dc_bar * std::pow(mu, kc);
     delta_w = (delta_w_last == 0.0) ? dw_0 : std::max(dw_min, kwm * delta_w_last);
+    if (have_lb && delta_w < dw_first) delta_w = dw_first;   // first value not provably hopeless
     // singular with delta_w = 0: first try the dual regularisation alone
     if (r == 2) {
       int r2 = attempt(0.0, delta_c);
@@ -494,7 +624,9 @@ class Ipm {
       int r2 = attempt(delta_w, delta_c);
       if (r2 == 0) { delta_w_last = delta_w; return true; }
       if (r2 == 2 && delta_c == 0.0) delta_c = dc_bar * std::pow(mu, kc);
-      delta_w = (delta_w_last == 0.0) ? kwpb * delta_w : kwp * delta_w;
+      // with a certified lower bound in hand the trial is already in the right decade: grow gently
+      if (have_lb && dw_lb > 0.0 && delta_w <= 64.0 * dw_lb) delta_w *= 2.0;
+      else delta_w = (delta_w_last == 0.0) ? kwpb * delta_w : kwp * delta_w;
       if (delta_w > dw_max) return false;
     }
     return false;
@@ -1211,6 +1343,8 @@ class Ipm {
   std::vector<char> fixed_;
   i64 nb_cache_ = -1;
   double last_ratio_ = 0.0;
+  bool delta_w_used_last_iter_ = false;
+  double *lanV = nullptr, *lanW = nullptr, *lanQ = nullptr;
   double t_begin_ = 0.0;
 };
 
