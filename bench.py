@@ -82,10 +82,14 @@ def cpu_baseline(n_cpu, seed, device, steps):
     t0 = time.time()
     rc, k = orc.ipm_step(steps)
     dt = time.time() - t0
-    return {"value": k / dt, "unit": "iters/s", "cores": 1, "kind": "port",
-            "sample": "same generator/front-end at n=%d (dense KKT order %d), %d iterations, "
-                      "scalar host LDL^T; work per iteration scales as n^3/3, so n=1e5 is "
-                      "%.3g x this sample per iteration" % (n_cpu, n_cpu + 1, k, (1e5 / n_cpu) ** 3)}
+    import ctypes.util
+    cores = os.cpu_count() or 1
+    return {"value": k / dt, "unit": "iters/s", "cores": cores, "kind": "port",
+            "sample": "same generator/front-end at n=%d (dense KKT order %d), %d iterations of the "
+                      "host build of the same algorithm (OpenMP LDL^T on %d threads); work per "
+                      "iteration scales as n^3/3, so n=1e5 is %.3g x this sample per iteration; "
+                      "libipopt on this box: %s" % (n_cpu, n_cpu + 1, k, cores, (1e5 / n_cpu) ** 3,
+                                                    ctypes.util.find_library("ipopt") or "not found")}
 
 
 def main():
@@ -94,7 +98,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=100000, help="order of the dense NLP (BASELINE: 1e5)")
-    ap.add_argument("--cpu-n", type=int, default=1200)
+    ap.add_argument("--cpu-n", type=int, default=3000)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -173,7 +177,7 @@ def main():
         }
         if not args.no_cpu:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_n, 0, local, 2)
+                out["cpu_baseline"] = cpu_baseline(args.cpu_n, 0, local, 3)
             except Exception as e:   # the baseline is reported, never required for the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": 1, "kind": "port",
                                        "sample": "failed: %s" % e}

@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "atom_math.h"
 #include "exec.h"
 
 namespace dnlp {
@@ -416,10 +417,123 @@ __global__ void __launch_bounds__(BK_T) bk_solve_kernel(const double* A, int n, 
   }
 }
 
+// ---- tape sweep over the elementwise-class segments (hand-written form of Model::sweep_flat) ---
+// 512 work units per workgroup, two consecutive units per lane.  The segment of the block's
+// first unit is found once (binary search by lane 0, broadcast through LDS); lanes advance from
+// there.  When both units of a lane sit in one unary segment with a contiguous, 16-B aligned
+// argument the lane moves double2's (x read, z / dvals / hvals written): fully coalesced 1-KiB
+// wave transactions.  Everything else takes the scalar path with identical arithmetic.
+struct FlatTable {
+  i64 nflat, total;
+  const i64* start;
+  const i32* op;
+  const i64 *a0b, *a0o, *a1b, *a1o, *zoff, *doff, *hoff, *n, *d0, *d1, *d2;
+  const double *p, *p2;
+  const i32* gidx;
+};
+
+__device__ inline void sweep_one_unit(const FlatTable& t, i64 s, i64 i, const double* __restrict__ x,
+                                      double* __restrict__ z, double* __restrict__ dv, double* __restrict__ hv,
+                                      const double* __restrict__ ww, bool with_h) {
+  const int op = t.op[s];
+  const i64 n = t.n[s];
+  if (op < OP_MUL) {
+    const i64 xi = t.a0b[s] >= 0 ? t.a0b[s] + i : t.gidx[t.a0o[s] + i];
+    double val, g1, g2;
+    unary_rules(op, x[xi], t.p[s], t.p2[s], val, g1, g2);
+    z[t.zoff[s] + i] = val;
+    dv[t.doff[s] + i] = g1;
+    if (with_h) hv[t.hoff[s] + i] = ww[t.zoff[s] + i] * g2;
+  } else if (op == OP_MUL) {
+    const i64 xi = t.a0b[s] >= 0 ? t.a0b[s] + i : t.gidx[t.a0o[s] + i];
+    const i64 yi = t.a1b[s] >= 0 ? t.a1b[s] + i : t.gidx[t.a1o[s] + i];
+    const double u = x[xi], v = x[yi];
+    z[t.zoff[s] + i] = u * v;
+    dv[t.doff[s] + i] = v;
+    dv[t.doff[s] + n + i] = u;
+    if (with_h) hv[t.hoff[s] + i] = ww[t.zoff[s] + i];
+  } else if (op == OP_REL_ENTR) {
+    const i64 xi = t.a0b[s] >= 0 ? t.a0b[s] + i : t.gidx[t.a0o[s] + i];
+    const i64 yi = t.a1b[s] >= 0 ? t.a1b[s] + i : t.gidx[t.a1o[s] + i];
+    const double u = x[xi], v = x[yi];
+    const double lr = log(u / v);
+    z[t.zoff[s] + i] = u * lr;
+    dv[t.doff[s] + i] = lr + 1.0;
+    dv[t.doff[s] + n + i] = -u / v;
+    if (with_h) {
+      const double wi = ww[t.zoff[s] + i];
+      hv[t.hoff[s] + i] = wi / u;
+      hv[t.hoff[s] + n + i] = wi * u / (v * v);
+      hv[t.hoff[s] + 2 * n + i] = -wi / v;
+    }
+  } else {   // OP_MATMUL
+    const i64 mm = t.d0[s], kk = t.d1[s];
+    const i64 r = i % mm, cidx = i / mm;
+    double acc = 0.0;
+    const i64 dbase = t.doff[s] + i * kk, cnt = mm * t.d2[s] * kk;
+    for (i64 l = 0; l < kk; ++l) {
+      const double u = x[t.gidx[t.a0o[s] + r + l * mm]], v = x[t.gidx[t.a1o[s] + l + cidx * kk]];
+      acc += u * v;
+      dv[dbase + l] = v;
+      dv[dbase + cnt + l] = u;
+      if (with_h) hv[t.hoff[s] + i * kk + l] = ww[t.zoff[s] + i];
+    }
+    z[t.zoff[s] + i] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) sweep_flat_kernel(FlatTable t, const double* __restrict__ x,
+                                                            double* __restrict__ z, double* __restrict__ dv,
+                                                            double* __restrict__ hv, const double* __restrict__ ww,
+                                                            int with_h) {
+  __shared__ i64 s_first;
+  const i64 e_blk = static_cast<i64>(blockIdx.x) * (2 * kBlock);
+  if (threadIdx.x == 0) {
+    i64 lo = 0, hi = t.nflat;
+    while (hi - lo > 1) {
+      const i64 mid = (lo + hi) >> 1;
+      if (t.start[mid] <= e_blk) lo = mid; else hi = mid;
+    }
+    s_first = lo;
+  }
+  __syncthreads();
+  const i64 e0 = e_blk + 2 * static_cast<i64>(threadIdx.x);
+  if (e0 >= t.total) return;
+  i64 s = s_first;
+  while (t.start[s + 1] <= e0) ++s;
+  const i64 i = e0 - t.start[s];
+  const bool pair = (e0 + 1 < t.start[s + 1]);
+  const int op = t.op[s];
+  if (pair && op < OP_MUL && t.a0b[s] >= 0) {
+    const i64 xi = t.a0b[s] + i, zi = t.zoff[s] + i, di = t.doff[s] + i, hi2 = t.hoff[s] + i;
+    if (((xi | zi | di | (with_h ? hi2 : 0)) & 1) == 0) {
+      const double2 u = *reinterpret_cast<const double2*>(x + xi);
+      double2 val, g1, g2;
+      const double p = t.p[s], p2 = t.p2[s];
+      unary_rules(op, u.x, p, p2, val.x, g1.x, g2.x);
+      unary_rules(op, u.y, p, p2, val.y, g1.y, g2.y);
+      *reinterpret_cast<double2*>(z + zi) = val;
+      *reinterpret_cast<double2*>(dv + di) = g1;
+      if (with_h) {
+        const double2 w2 = *reinterpret_cast<const double2*>(ww + zi);
+        *reinterpret_cast<double2*>(hv + hi2) = double2{w2.x * g2.x, w2.y * g2.y};
+      }
+      return;
+    }
+  }
+  sweep_one_unit(t, s, i, x, z, dv, hv, ww, with_h != 0);
+  if (e0 + 1 < t.total) {
+    i64 s1 = s;
+    while (t.start[s1 + 1] <= e0 + 1) ++s1;
+    sweep_one_unit(t, s1, e0 + 1 - t.start[s1], x, z, dv, hv, ww, with_h != 0);
+  }
+}
+
 struct BlockedLdlt;   // ldlt_blocked.h
 
 struct HipExec {
   static constexpr bool is_device = true;
+  using FlatTableT = FlatTable;
   int device = 0;
   hipStream_t stream = nullptr;
   double* d_partial = nullptr;
@@ -521,6 +635,13 @@ struct HipExec {
     }
     hipLaunchKernelGGL(gemv_stage1, dim3(static_cast<unsigned>(nrb * ncb)), dim3(kBlock), 0, stream, n, P, ld, u, gemv_part, nrb);
     hipLaunchKernelGGL(gemv_stage2, dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, n, ncb, gemv_part, out);
+    DNLP_LAUNCH_CHECK();
+  }
+  void sweep_flat(const FlatTable& t, const double* x, double* z, double* dv, double* hv, const double* w, bool with_h) {
+    if (t.total <= 0) return;
+    const i64 grid = (t.total + 2 * kBlock - 1) / (2 * kBlock);
+    hipLaunchKernelGGL(sweep_flat_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, t, x, z, dv, hv, w,
+                       with_h ? 1 : 0);
     DNLP_LAUNCH_CHECK();
   }
   void coo_mult(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out, bool trans) {

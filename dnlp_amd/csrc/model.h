@@ -65,6 +65,14 @@ struct Model {
   // flat (elementwise-class) sweep: one work unit per output element
   void sweep_flat(const double* x, bool with_h) {
     if (t.flat_units == 0) return;
+    if constexpr (E::is_device) {
+      // hand-written gfx950 kernel (exec_hip.h); the lambda below is the same arithmetic
+      typename E::FlatTableT ft{t.nflat, t.flat_units, t.flat_start, t.flat_op, t.flat_a0b, t.flat_a0o, t.flat_a1b,
+                                t.flat_a1o, t.flat_zoff, t.flat_doff, t.flat_hoff, t.flat_n, t.flat_d0, t.flat_d1,
+                                t.flat_d2, t.flat_p, t.flat_p2, t.gidx};
+      ex->sweep_flat(ft, x, xz + t.N, dvals, hvals, w, with_h);
+      return;
+    }
     const i64 nflat = t.nflat;
     const i64* fstart = t.flat_start;
     const i32* fop = t.flat_op;

@@ -20,6 +20,7 @@ namespace dnlp {
 
 struct HostExec {
   static constexpr bool is_device = false;
+  struct FlatTableT {};
   struct LdltWork { std::vector<double> d; int expect_neg = -1; bool time_updates = false; };
   void ldlt_stats(LdltWork&, double* out3) { out3[0] = out3[1] = out3[2] = 0.0; }
   explicit HostExec(int device = 0) { (void)device; }
@@ -57,11 +58,14 @@ struct HostExec {
 
   // out = P u for a symmetric column-major matrix
   void gemv_sym(i64 n, const double* P, i64 ld, const double* u, double* out) {
+    // P symmetric: row i of P u is the dot product of column i with u (contiguous reads)
     std::vector<double> acc(static_cast<size_t>(n), 0.0);
-    for (i64 j = 0; j < n; ++j) {
-      const double uj = u[j];
-      const double* col = P + j * ld;
-      for (i64 i = 0; i < n; ++i) acc[static_cast<size_t>(i)] += col[i] * uj;
+#pragma omp parallel for schedule(static) if (n > 512)
+    for (i64 i = 0; i < n; ++i) {
+      const double* col = P + i * ld;
+      double s = 0.0;
+      for (i64 j = 0; j < n; ++j) s += col[j] * u[j];
+      acc[static_cast<size_t>(i)] = s;
     }
     std::memcpy(out, acc.data(), sizeof(double) * static_cast<size_t>(n));
   }
@@ -104,11 +108,14 @@ struct HostExec {
         if (d < 0) (*nneg)++;
         ipiv[k] = static_cast<i32>(k + 1);
         const double inv = 1.0 / d;
+#pragma omp parallel for schedule(dynamic, 16) if (n - k > 256)
         for (i64 j = k + 1; j < n; ++j) {
-          const double wj = a(j, k);
+          const double wj = A[j + k * ld];
           if (wj == 0.0) continue;
           const double lj = wj * inv;
-          for (i64 i = j; i < n; ++i) a(i, j) -= a(i, k) * lj;
+          double* cj = A + j * ld;
+          const double* ck = A + k * ld;
+          for (i64 i = j; i < n; ++i) cj[i] -= ck[i] * lj;
         }
         for (i64 i = k + 1; i < n; ++i) a(i, k) *= inv;
       }
