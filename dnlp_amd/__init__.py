@@ -14,7 +14,7 @@ from .settings import (  # noqa: F401
     UNBOUNDED, USER_LIMIT,
 )
 from .error import DeviceUnavailableError, DNLPError, SolverError  # noqa: F401
-from .expressions import Constant, DeviceMatrix, Expression, Variable  # noqa: F401
+from .expressions import Constant, DeviceMatrix, Expression, Parameter, Variable  # noqa: F401
 from .atoms import (  # noqa: F401
     AddExpression, DivExpression, MulExpression, NegExpression, Pnorm, Promote, QuadForm, Sum,
     abs, asinh, atanh, broadcast_to, cos, entr, exp, geo_mean, hstack, huber, index, kl_div,

@@ -239,7 +239,9 @@ class Ipm {
     i64 n_free = 0; for (i64 j = 0; j < N; ++j) n_free += !(lb[j] == ub[j]);
     if (n_eq > n_free) return status = Not_Enough_Degrees_Of_Freedom;
     fixed_.assign(static_cast<size_t>(N), 0);
-    for (i64 j = 0; j < N; ++j) if (lb[j] == ub[j]) { fixed_[j] = 1; hx[j] = lb[j]; }
+    i64 nfix = 0;
+    for (i64 j = 0; j < N; ++j) if (lb[j] == ub[j]) { fixed_[j] = 1; hx[j] = lb[j]; ++nfix; }
+    kkt_->n_fixed = nfix;
     push_into_bounds(hx, lb, ub);
     ex_->h2d(x, hx.data(), sizeof(double) * static_cast<size_t>(N));
     // fixed variables keep no bound multipliers: drop their bounds and pin them in the KKT

@@ -22,6 +22,7 @@ struct DenseKkt {
   i32* ipiv = nullptr;
   double* work = nullptr;      // exec-space scratch for solves
   i64 pivot_max_n = 2048;
+  i64 n_fixed = 0;             // number of fixed variables (set by the interior-point driver)
   bool pivoted = true;
   typename E::LdltWork lw;
 
@@ -72,9 +73,16 @@ struct DenseKkt {
       else Kp[j + j * ldk] += Sx[j] + dw;
     });
     ex->map(m, [=] DNLP_HD(i64 i) { Kp[(NN + i) + (NN + i) * ldk] = -D[i]; });
-    if (full_block && t.blocks.size() == 1) {
-      // fixed variables inside a dense block: clear their rows / columns
-      // (rare; handled by a masked pass only when any variable is fixed)
+    if (n_fixed > 0 && !t.blocks.empty()) {
+      // fixed variables (lb == ub) inside a dense block: pin them (unit row / column)
+      for (const DenseBlock& B : t.blocks) {
+        const i64 nb = B.n, x0 = B.x0;
+        ex->map(nb * nb, [=] DNLP_HD(i64 q) {
+          const i64 r = x0 + q % nb, c = x0 + q / nb;
+          if (r <= c) return;
+          if (fixmask[r] != 0.0 || fixmask[c] != 0.0) Kp[r + c * ldk] = 0.0;
+        });
+      }
     }
     lw.expect_neg = static_cast<int>(m);
     return ex->ldlt_factor(lw, K, n, ld, ipiv, pivoted, nneg, nzero);

@@ -425,99 +425,154 @@ __global__ void __launch_bounds__(SV_B) ldlt_bwd_diag(const double* __restrict__
 struct BlockedLdlt {
   HipExec* ex = nullptr;
   i64 n = 0, ld = 0, ldw = 0;
-  double* Wp = nullptr;
+  double* Wp2[2] = {nullptr, nullptr};     // panel workspaces W = L D (double buffered for look-ahead)
   LdltInfo* info = nullptr;
   double* acc = nullptr;
   double last_update_seconds = 0.0;
   double total_update_seconds = 0.0, total_update_flops = 0.0;   // outer (Schur) updates, timed
   i64 total_update_launches = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> tev0, tev1;      // timing events of the Schur updates of one factorisation
+  hipEvent_t evPanel = nullptr, evUpd = nullptr;
+  hipStream_t s1 = nullptr;                // stream of the big trailing updates
   bool time_updates = false;
+  bool lookahead = true;
   int NB = 512;                // outer panel width (K of the MFMA Schur update)
   int max_neg = -1;            // >= 0: give up as soon as more negative pivots than this appear
 
   void init(HipExec* e, i64 n_, i64 ld_) {
     ex = e; n = n_; ld = ld_;
     ldw = (n + 7) / 8 * 8;
-    if (const char* e = std::getenv("DNLP_LDLT_NB")) NB = std::atoi(e);
+    if (const char* ev = std::getenv("DNLP_LDLT_NB")) NB = std::atoi(ev);
+    if (const char* ev = std::getenv("DNLP_LDLT_LOOKAHEAD")) lookahead = std::atoi(ev) != 0;
     if (NB < LD_nb) NB = LD_nb;
     if (NB > LD_NB_MAX) NB = LD_NB_MAX;
     NB = NB / LD_nb * LD_nb;
-    Wp = ex->alloc<double>(static_cast<size_t>(ldw) * NB);
+    Wp2[0] = ex->alloc<double>(static_cast<size_t>(ldw) * NB);
+    Wp2[1] = lookahead ? ex->alloc<double>(static_cast<size_t>(ldw) * NB) : Wp2[0];
     info = ex->alloc<LdltInfo>(1);
     acc = ex->alloc<double>(SV_B);
-    DNLP_HIP_CHECK(hipEventCreate(&ev0));
-    DNLP_HIP_CHECK(hipEventCreate(&ev1));
+    DNLP_HIP_CHECK(hipEventCreateWithFlags(&evPanel, hipEventDisableTiming));
+    DNLP_HIP_CHECK(hipEventCreateWithFlags(&evUpd, hipEventDisableTiming));
+    // the trailing updates run on their own (lower-priority) stream so that the next panel's
+    // latency-bound factorisation kernels overlap with the previous panel's MFMA update
+    int lo_p = 0, hi_p = 0;
+    DNLP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+    DNLP_HIP_CHECK(hipStreamCreateWithPriority(&s1, hipStreamNonBlocking, lo_p));
   }
 
-  void gemm(double* C, const double* W, const double* L, i64 ldl, int M, int Nc, int Kd, int lower) {
+  void gemm(hipStream_t st, double* C, const double* W, const double* L, i64 ldl, int M, int Nc, int Kd, int lower) {
     if (M <= 0 || Nc <= 0 || Kd <= 0) return;
     const int ntm = (M + GM_BM - 1) / GM_BM, ntn = (Nc + GM_BN - 1) / GM_BN;
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const int vec_ok = al(W) && al(L) && (ldw % 2 == 0) && (ldl % 2 == 0);
-    hipLaunchKernelGGL(gemm_nt_update_fast, dim3(static_cast<unsigned>(ntm) * ntn), dim3(512), 0, ex->stream, C, ld, W,
+    hipLaunchKernelGGL(gemm_nt_update_fast, dim3(static_cast<unsigned>(ntm) * ntn), dim3(512), 0, st, C, ld, W,
                        ldw, L, ldl, M, Nc, Kd, lower, ntm, vec_ok);
-    hipLaunchKernelGGL(gemm_nt_update, dim3(static_cast<unsigned>(ntm) * ntn), dim3(256), 0, ex->stream, C, ld, W, ldw,
+    hipLaunchKernelGGL(gemm_nt_update, dim3(static_cast<unsigned>(ntm) * ntn), dim3(256), 0, st, C, ld, W, ldw,
                        L, ldl, M, Nc, Kd, lower, ntm, vec_ok);
     DNLP_LAUNCH_CHECK();
   }
 
+  // Right-looking blocked LDL^T with one panel of look-ahead:
+  //   stream s0: factor panel p | wait(update p-1) | update the NEXT panel's columns with panel p
+  //   stream s1: wait(panel p)  | update everything right of the next panel with panel p
+  // so the small panel kernels of p+1 run underneath the big MFMA update of p.
   bool factor(double* A, int* nneg, int* nzero) {
+    hipStream_t s0 = ex->stream;
     LdltInfo z;
     std::memset(&z, 0, sizeof z);
-    DNLP_HIP_CHECK(hipMemcpyAsync(info, &z, sizeof z, hipMemcpyHostToDevice, ex->stream));
-    DNLP_HIP_CHECK(hipStreamSynchronize(ex->stream));
+    DNLP_HIP_CHECK(hipMemcpyAsync(info, &z, sizeof z, hipMemcpyHostToDevice, s0));
+    DNLP_HIP_CHECK(hipStreamSynchronize(s0));
     const double tiny = 1e-300;
-    float upd_ms = 0.f;
     const int ni = static_cast<int>(n);
-    for (int K0 = 0; K0 < ni; K0 += NB) {
+    const int npanels = (ni + NB - 1) / NB;
+    if (time_updates && static_cast<int>(tev0.size()) < npanels) {
+      const size_t old = tev0.size();
+      tev0.resize(static_cast<size_t>(npanels));
+      tev1.resize(static_cast<size_t>(npanels));
+      for (size_t k = old; k < tev0.size(); ++k) {
+        DNLP_HIP_CHECK(hipEventCreate(&tev0[k]));
+        DNLP_HIP_CHECK(hipEventCreate(&tev1[k]));
+      }
+    }
+    std::vector<double> upd_flops;
+    bool upd_pending = false, bailed = false;
+    LdltInfo cur;
+    std::memset(&cur, 0, sizeof cur);
+    int p = 0;
+    for (int K0 = 0; K0 < ni; K0 += NB, ++p) {
       const int KB = std::min(NB, ni - K0);
+      double* Wp = Wp2[p & 1];
       for (int j0 = K0; j0 < K0 + KB; j0 += LD_nb) {
         const int jb = std::min(LD_nb, K0 + KB - j0);
-        hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(256), 0, ex->stream, A, ld, j0, jb, info, tiny);
+        hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(256), 0, s0, A, ld, j0, jb, info, tiny);
         const int r0 = j0 + jb;
         if (r0 >= ni) continue;
         const int rows = ni - r0;
-        hipLaunchKernelGGL(ldlt_trsm_kernel, dim3((rows + 255) / 256), dim3(256), 0, ex->stream, A, ld, j0, jb, ni, Wp,
+        hipLaunchKernelGGL(ldlt_trsm_kernel, dim3((rows + 255) / 256), dim3(256), 0, s0, A, ld, j0, jb, ni, Wp,
                            ldw, j0 - K0);
         const int nc = K0 + KB - r0;
         if (nc > 0)
-          gemm(A + r0 + static_cast<i64>(r0) * ld, Wp + r0 + static_cast<i64>(j0 - K0) * ldw,
+          gemm(s0, A + r0 + static_cast<i64>(r0) * ld, Wp + r0 + static_cast<i64>(j0 - K0) * ldw,
                A + r0 + static_cast<i64>(j0) * ld, ld, rows, nc, jb, 1);
       }
       const int r1 = K0 + KB;
       if (max_neg >= 0) {
         // wrong inertia is known as soon as too many negative pivots have appeared: the rest
         // of the factorisation would be thrown away by the caller's regularisation loop
-        LdltInfo cur;
-        DNLP_HIP_CHECK(hipMemcpyAsync(&cur, info, sizeof cur, hipMemcpyDeviceToHost, ex->stream));
-        DNLP_HIP_CHECK(hipStreamSynchronize(ex->stream));
-        if (cur.nneg > max_neg || cur.fail) { *nneg = cur.nneg + 1000000; *nzero = cur.nzero; return cur.fail == 0; }
+        DNLP_HIP_CHECK(hipMemcpyAsync(&cur, info, sizeof cur, hipMemcpyDeviceToHost, s0));
+        DNLP_HIP_CHECK(hipStreamSynchronize(s0));
+        if (cur.nneg > max_neg || cur.fail) { bailed = true; break; }
       }
-      if (r1 < ni) {
-        if (time_updates) DNLP_HIP_CHECK(hipEventRecord(ev0, ex->stream));
-        gemm(A + r1 + static_cast<i64>(r1) * ld, Wp + r1, A + r1 + static_cast<i64>(K0) * ld, ld, ni - r1, ni - r1, KB, 1);
-        if (time_updates) {
-          DNLP_HIP_CHECK(hipEventRecord(ev1, ex->stream));
-          DNLP_HIP_CHECK(hipEventSynchronize(ev1));
-          float ms = 0.f;
-          DNLP_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
-          upd_ms += ms;
-          total_update_seconds += ms * 1e-3;
-          // algorithmic flops of this launch: lower triangle of an (n-r1)^2 rank-KB update
-          const double tr = static_cast<double>(ni - r1);
-          total_update_flops += tr * (tr + 1.0) * static_cast<double>(KB);
-          total_update_launches += 1;
-        }
+      if (r1 >= ni) break;
+      const double* Lp = A + r1 + static_cast<i64>(K0) * ld;
+      if (!lookahead) {
+        if (time_updates) DNLP_HIP_CHECK(hipEventRecord(tev0[static_cast<size_t>(p)], s0));
+        gemm(s0, A + r1 + static_cast<i64>(r1) * ld, Wp + r1, Lp, ld, ni - r1, ni - r1, KB, 1);
+        if (time_updates) DNLP_HIP_CHECK(hipEventRecord(tev1[static_cast<size_t>(p)], s0));
+        const double tr = static_cast<double>(ni - r1);
+        upd_flops.push_back(tr * (tr + 1.0) * static_cast<double>(KB));
+        continue;
+      }
+      const int r2 = std::min(r1 + NB, ni);
+      DNLP_HIP_CHECK(hipEventRecord(evPanel, s0));
+      // the previous big update wrote the next panel's columns too: s0 waits for it
+      if (upd_pending) DNLP_HIP_CHECK(hipStreamWaitEvent(s0, evUpd, 0));
+      gemm(s0, A + r1 + static_cast<i64>(r1) * ld, Wp + r1, Lp, ld, ni - r1, r2 - r1, KB, 1);
+      if (r2 < ni) {
+        DNLP_HIP_CHECK(hipStreamWaitEvent(s1, evPanel, 0));
+        if (time_updates) DNLP_HIP_CHECK(hipEventRecord(tev0[static_cast<size_t>(p)], s1));
+        gemm(s1, A + r2 + static_cast<i64>(r2) * ld, Wp + r2, A + r2 + static_cast<i64>(K0) * ld, ld, ni - r2, ni - r2, KB, 1);
+        if (time_updates) DNLP_HIP_CHECK(hipEventRecord(tev1[static_cast<size_t>(p)], s1));
+        DNLP_HIP_CHECK(hipEventRecord(evUpd, s1));
+        upd_pending = true;
+        const double tr = static_cast<double>(ni - r2);
+        upd_flops.push_back(tr * (tr + 1.0) * static_cast<double>(KB));
+      } else {
+        upd_flops.push_back(-1.0);
       }
     }
-    LdltInfo out;
-    DNLP_HIP_CHECK(hipMemcpyAsync(&out, info, sizeof out, hipMemcpyDeviceToHost, ex->stream));
-    DNLP_HIP_CHECK(hipStreamSynchronize(ex->stream));
-    *nneg = out.nneg;
-    *nzero = out.nzero;
+    if (lookahead) DNLP_HIP_CHECK(hipStreamSynchronize(s1));
+    if (!bailed) {
+      DNLP_HIP_CHECK(hipMemcpyAsync(&cur, info, sizeof cur, hipMemcpyDeviceToHost, s0));
+    }
+    DNLP_HIP_CHECK(hipStreamSynchronize(s0));
+    float upd_ms = 0.f;
+    if (time_updates) {
+      for (size_t k = 0; k < upd_flops.size(); ++k) {
+        if (upd_flops[k] < 0.0) continue;
+        float ms = 0.f;
+        DNLP_HIP_CHECK(hipEventElapsedTime(&ms, tev0[k], tev1[k]));
+        upd_ms += ms;
+        total_update_seconds += ms * 1e-3;
+        total_update_flops += upd_flops[k];
+        total_update_launches += 1;
+      }
+    }
     last_update_seconds = upd_ms * 1e-3;
-    return out.fail == 0;
+    if (bailed) { *nneg = cur.nneg + 1000000; *nzero = cur.nzero; return cur.fail == 0; }
+    *nneg = cur.nneg;
+    *nzero = cur.nzero;
+    return cur.fail == 0;
   }
 
   void solve(const double* A, double* b) {

@@ -551,6 +551,34 @@ class Constant(Leaf):
         return "Constant(%s, %s)" % (self.sign, self.shape)
 
 
+class Parameter(Leaf):
+    """Named constant whose value may change between solves (reference
+    expressions/constants/parameter.py).  On the nlp=True path a parameter is a constant at
+    lowering time: re-solving after `p.value = ...` re-lowers the tape with the new value, which
+    is what the reference does too (it re-canonicalises on every solve, problem.py:1243)."""
+
+    def __init__(self, shape=(), name: Optional[str] = None, value=None, nonneg=False, nonpos=False):
+        self.id = get_id()
+        self._name = name if name is not None else "param%d" % self.id
+        super().__init__(shape, value=value, nonneg=nonneg, nonpos=nonpos)
+
+    def name(self):
+        return self._name
+
+    def parameters(self):
+        return [self]
+
+    def is_constant(self):
+        return True
+
+    @property
+    def is_device(self):
+        return False
+
+    def __repr__(self):
+        return "Parameter(%s, %s)" % (self.shape, self._name)
+
+
 class DeviceMatrix:
     """Handle to a dense FP64 column-major matrix resident in MI355X HBM.
 

@@ -35,7 +35,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import atoms as at
-from .expressions import Constant, Expression, Variable
+from .expressions import Constant, Expression, Parameter, Variable
 
 # ---- opcodes (shared with csrc/tape.h) ---------------------------------------------------
 OP_EXP, OP_LOG, OP_ENTR, OP_LOGISTIC, OP_POWER = 1, 2, 3, 4, 5
@@ -223,6 +223,10 @@ class Lowerer:
     def _lower(self, e):
         if isinstance(e, Variable):
             return self._var_form(e)
+        if isinstance(e, Parameter):
+            if e.value is None:
+                raise ValueError("Parameter %s has no value." % e.name())
+            return self._const_form(e.value, e.size)
         if isinstance(e, Constant):
             if e.is_device:
                 raise ValueError("A device-resident constant can only be the matrix of quad_form.")

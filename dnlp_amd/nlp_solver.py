@@ -232,10 +232,10 @@ class HIPNLP:
         options = dict(self.DEFAULT_OPTIONS)
         if solver_opts:
             options.update(solver_opts)
-        if not verbose and "print_level" not in options:
-            options["print_level"] = 3 if False else 0
-        if verbose and "print_level" not in options:
-            options["print_level"] = 5
+        if "print_level" not in options:
+            # the reference forces print_level 3 when not verbose (ipopt_nlpif.py:164-165); here
+            # 0 is silent and 5 prints the IPOPT-style iteration table
+            options["print_level"] = 5 if verbose else 0
         handle = data["handle"]
         for k, v in options.items():
             handle.set_option(k, v)

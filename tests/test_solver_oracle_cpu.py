@@ -147,3 +147,49 @@ def test_dnlp_rules():
     assert not cp.Problem(cp.Minimize(cp.sum(x)), [cp.abs(x) == 1]).is_dnlp()      # equality needs smooth
     with pytest.raises(cp.DNLPError):
         cp.Problem(cp.Maximize(cp.max(x))).solve(nlp=True)
+
+
+def _oracle_solve_problem(prob, **opts):
+    import dnlp_amd as cp
+    from dnlp_amd.dnlp2smooth import Dnlp2Smooth
+    from dnlp_amd.nlp_solver import build_nlp_data
+    from dnlp_amd.tape import serialize
+    from oracle.oracle_capi import OracleProblem
+    flip = isinstance(prob.objective, cp.Maximize)
+    p = cp.Problem(cp.Minimize(-prob.objective.expr), prob.constraints) if flip else prob
+    smooth, _ = Dnlp2Smooth().apply(p)
+    data, inv = build_nlp_data(smooth)
+    h = OracleProblem(serialize(data["tape_arrays"]))
+    for k, v in opts.items():
+        h.set_option(k, v)
+    info = h.solve(data["x0"])
+    vals = {}
+    for v in data["problem"].variables():
+        off = inv.var_offsets[v.id]
+        vals[v.name()] = info["x"][off:off + v.size].reshape(v.shape, order="F")
+    return info, vals
+
+
+def test_parameter_and_fixed_variable():
+    """Parameters are constants at lowering time; a variable with lb == ub is pinned."""
+    import dnlp_amd as cp
+    a = cp.Parameter(3, value=np.array([1.0, 2.0, 3.0]))
+    x = cp.Variable(3, name="x")
+    y = cp.Variable(name="y", bounds=[2.0, 2.0])          # fixed
+    prob = cp.Problem(cp.Minimize(cp.sum(cp.square(x - a)) + cp.square(y - 5) + cp.sum(cp.exp(x)) * 0.0),
+                      [cp.sum(x) == y])
+    info, vals = _oracle_solve_problem(prob)
+    assert info["status"] == 0
+    assert abs(vals["y"] - 2.0) < 1e-12
+    np.testing.assert_allclose(vals["x"], np.array([1.0, 2.0, 3.0]) - 4.0 / 3.0, atol=1e-6)
+    a.value = np.array([0.0, 0.0, 6.0])
+    info, vals = _oracle_solve_problem(prob)
+    np.testing.assert_allclose(vals["x"], np.array([0.0, 0.0, 6.0]) - 4.0 / 3.0, atol=1e-6)
+
+
+def test_infeasible_problem_reports_infeasible_or_restoration_failure():
+    import dnlp_amd as cp
+    x = cp.Variable(2, bounds=[0, 1])
+    prob = cp.Problem(cp.Minimize(cp.sum(cp.square(x))), [cp.sum(x) == 5])
+    info, _ = _oracle_solve_problem(prob)
+    assert info["status"] in (2, -2)       # Infeasible_Problem_Detected / Restoration_Failed
