@@ -61,6 +61,10 @@ def run_steps(handle, x0, n_steps):
 def cpu_baseline(n_cpu, seed, device, steps):
     """The CPU port (oracle/, host instantiation of the same algorithm) on a bounded sample of
     the same workload: same generator and front-end at order n_cpu, `steps` iterations."""
+    # the scalar OpenMP LDL^T of the port scales to a few dozen threads, not to every core of
+    # the box: pin the thread count before libgomp starts and report exactly that number
+    threads = min(os.cpu_count() or 1, 32)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     from dnlp_amd.tape import serialize
     from oracle.oracle_capi import OracleProblem
     import dnlp_amd as cp
@@ -83,7 +87,7 @@ def cpu_baseline(n_cpu, seed, device, steps):
     rc, k = orc.ipm_step(steps)
     dt = time.time() - t0
     import ctypes.util
-    cores = os.cpu_count() or 1
+    cores = threads
     return {"value": k / dt, "unit": "iters/s", "cores": cores, "kind": "port",
             "sample": "same generator/front-end at n=%d (dense KKT order %d), %d iterations of the "
                       "host build of the same algorithm (OpenMP LDL^T on %d threads); work per "

@@ -319,8 +319,65 @@ class Ipm {
 
   // least-squares equality multipliers (WB eq. (36)); discarded above constr_mult_init_max
   void init_multipliers_ls() {
-    double *sx = Sx, *dd = Dd;
     const double* eq = eqmask;
+    if (!kkt_->pivoted && m <= 8) {
+      // Few rows on a large system: the (1,1) block of the least-squares system is the identity,
+      // so it condenses to the m x m system (J J^T + D) y = J r_x - r_y — no O(n^3) work.
+      double* r = rhs;
+      const double *gr = grad, *a = zL, *b = zU, *c = vL, *d = vU, *fm = fixmask;
+      ex_->map(N, [=] DNLP_HD(i64 j) { r[j] = fm[j] != 0.0 ? 0.0 : -(gr[j] - a[j] + b[j]); });
+      std::vector<double> G(static_cast<size_t>(m * m), 0.0), bb(static_cast<size_t>(m), 0.0), heq(static_cast<size_t>(m));
+      std::vector<double> hc(static_cast<size_t>(m)), hd(static_cast<size_t>(m));
+      ex_->d2h(heq.data(), eqmask, sizeof(double) * static_cast<size_t>(m));
+      ex_->d2h(hc.data(), vL, sizeof(double) * static_cast<size_t>(m));
+      ex_->d2h(hd.data(), vU, sizeof(double) * static_cast<size_t>(m));
+      if (!lanQ) { lanQ = A<double>(static_cast<i64>(8) * N); }
+      for (i64 i = 0; i < m; ++i) {
+        double* e = tM;
+        ex_->map(m, [=] DNLP_HD(i64 q) { e[q] = (q == i) ? 1.0 : 0.0; });
+        double* qi = lanQ + i * N;
+        md_->jac_tmult(jv, tM, qi);
+        ex_->map(N, [=] DNLP_HD(i64 j) { if (fm[j] != 0.0) qi[j] = 0.0; });
+      }
+      for (i64 i = 0; i < m; ++i) {
+        const double* qi = lanQ + i * N;
+        for (i64 k = 0; k <= i; ++k) {
+          const double* qk = lanQ + k * N;
+          const double v = ex_->sum(N, [=] DNLP_HD(i64 j) { return qi[j] * qk[j]; });
+          G[static_cast<size_t>(i * m + k)] = G[static_cast<size_t>(k * m + i)] = v;
+        }
+        const double ry = (heq[static_cast<size_t>(i)] == 0.0) ? -(-hc[static_cast<size_t>(i)] + hd[static_cast<size_t>(i)]) : 0.0;
+        bb[static_cast<size_t>(i)] = ex_->sum(N, [=] DNLP_HD(i64 j) { return qi[j] * r[j]; }) - ry;
+        G[static_cast<size_t>(i * m + i)] += (heq[static_cast<size_t>(i)] == 0.0) ? 1.0 : 0.0;
+      }
+      // dense Gaussian elimination with partial pivoting on the m x m system
+      bool ok = true;
+      const int mm = static_cast<int>(m);
+      for (int k = 0; k < mm && ok; ++k) {
+        int piv = k;
+        for (int i = k + 1; i < mm; ++i) if (std::fabs(G[i * mm + k]) > std::fabs(G[piv * mm + k])) piv = i;
+        if (std::fabs(G[piv * mm + k]) < 1e-14) { ok = false; break; }
+        if (piv != k) { for (int j = 0; j < mm; ++j) std::swap(G[k * mm + j], G[piv * mm + j]); std::swap(bb[k], bb[piv]); }
+        for (int i = k + 1; i < mm; ++i) {
+          const double f = G[i * mm + k] / G[k * mm + k];
+          for (int j = k; j < mm; ++j) G[i * mm + j] -= f * G[k * mm + j];
+          bb[i] -= f * bb[k];
+        }
+      }
+      if (ok) {
+        double ymax = 0.0;
+        for (int i = mm - 1; i >= 0; --i) {
+          double v = bb[i];
+          for (int j = i + 1; j < mm; ++j) v -= G[i * mm + j] * bb[j];
+          bb[i] = v / G[i * mm + i];
+          ymax = std::fmax(ymax, std::fabs(bb[i]));
+        }
+        if (std::isfinite(ymax) && ymax <= opt.constr_mult_init_max)
+          ex_->h2d(y, bb.data(), sizeof(double) * static_cast<size_t>(m));
+        return;
+      }
+    }
+    double *sx = Sx, *dd = Dd;
     ex_->map(N, [=] DNLP_HD(i64 j) { sx[j] = 1.0; });
     ex_->map(m, [=] DNLP_HD(i64 i) { dd[i] = (eq[i] == 0.0) ? 1.0 : 0.0; });
     int nneg = 0, nzero = 0;
