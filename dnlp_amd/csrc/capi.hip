@@ -59,12 +59,13 @@ int dnlp_ldlt_host(int device, double* A, int64_t n, int64_t ld, int32_t* ipiv, 
   DNLP_TRY(
     HipExec ex(device);
     const i64 ldd = (n + 7) / 8 * 8;
-    double* dA = ex.alloc<double>(static_cast<size_t>(ldd) * n);
+    double* dA = ex.alloc<double>(static_cast<size_t>(ldd) * n + 256);
     i32* dp = ex.alloc<i32>(static_cast<size_t>(n));
     double* db = ex.alloc<double>(static_cast<size_t>(n));
     DNLP_HIP_CHECK(hipMemcpy2DAsync(dA, ldd * 8, A, ld * 8, n * 8, n, hipMemcpyHostToDevice, ex.stream));
     ex.sync();
     HipExec::LdltWork w;
+    w.padded = true;
     ex.ldlt_prepare(w, n, ldd, pivoted != 0);
     double t0 = now_sec();
     bool ok = ex.ldlt_factor(w, dA, n, ldd, dp, pivoted != 0, nneg, nzero);
@@ -87,6 +88,7 @@ int dnlp_ldlt_device(int device, double* dA, int64_t n, int64_t ld, int* nneg, i
     HipExec ex(device);
     BlockedLdlt bl;
     bl.init(&ex, n, ld);
+    bl.padded = true;   // contract of this entry point: >= 1 KiB of slack behind the matrix
     bl.time_updates = update_seconds != nullptr;
     ex.sync();
     double t0 = now_sec();

@@ -546,6 +546,7 @@ struct HipExec {
     BlockedLdlt* blocked = nullptr;
     int expect_neg = -1;         // inertia the caller needs (early exit of hopeless attempts)
     bool time_updates = false;
+    bool padded = false;         // matrix allocation carries >= 128 doubles of slack
   };
   // kernel statistics of the dominant (MFMA Schur update) kernel: seconds, flops, launches
   void ldlt_stats(LdltWork& w, double* out3);

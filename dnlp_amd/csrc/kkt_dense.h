@@ -29,10 +29,11 @@ struct DenseKkt {
   void init(E* e, i64 N_, i64 m_) {
     ex = e; N = N_; m = m_; n = N + m;
     ld = (n + 7) / 8 * 8;                       // 64-byte aligned columns
-    K = ex->template alloc<double>(static_cast<size_t>(ld) * static_cast<size_t>(n));
+    K = ex->template alloc<double>(static_cast<size_t>(ld) * static_cast<size_t>(n) + 256);   // +slack: tile reads past the last row
     ipiv = ex->template alloc<i32>(static_cast<size_t>(n));
     work = ex->template alloc<double>(static_cast<size_t>(n));
     pivoted = n <= pivot_max_n;
+    lw.padded = true;
     ex->ldlt_prepare(lw, n, ld, pivoted);
   }
 

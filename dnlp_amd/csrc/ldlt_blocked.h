@@ -194,8 +194,13 @@ __device__ inline void gemm_body_guarded(double* __restrict__ C, i64 ldc, const 
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),            \
                                    (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
+// MASKED = tile on the diagonal or on the last (partial) tile row / column: C accesses are
+// predicated; operand rows past M / Nc are read from the (padded) allocations and only feed
+// accumulators that are never stored.
+template <bool MASKED>
 __device__ inline void gemm_body_fast(double* __restrict__ C, i64 ldc, const double* __restrict__ W, i64 ldw,
-                                      const double* __restrict__ L, i64 ldl, int Kd, int tm, int tn, double* smem) {
+                                      const double* __restrict__ L, i64 ldl, int Kd, int tm, int tn, double* smem,
+                                      int M, int Nc, int lower) {
   constexpr int LDT = GM_BM + GM_PAD;                 // padded LDS row (doubles)
   constexpr int TILE = GM_BK * LDT;                    // doubles per operand tile
   const int tid = threadIdx.x, lane = tid & 63;
@@ -207,6 +212,8 @@ __device__ inline void gemm_body_fast(double* __restrict__ C, i64 ldc, const dou
   mfma_d4 acc[2][4];
   double* cbase = C + static_cast<i64>(tm) * GM_BM + wm * 64 + (lane & 15) +
                   (static_cast<i64>(tn) * GM_BN + wn * 32 + (lane >> 4)) * ldc;
+  const int i_base = tm * GM_BM + wm * 64 + (lane & 15);      // + mi*16
+  const int j_base = tn * GM_BN + wn * 32 + (lane >> 4);      // + ni*16 + 4r
   {
     const double* cp = cbase;
 #pragma unroll
@@ -214,7 +221,14 @@ __device__ inline void gemm_body_fast(double* __restrict__ C, i64 ldc, const dou
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) acc[ni][mi][r] = -cp[mi * 16];
+        for (int mi = 0; mi < 4; ++mi) {
+          if (MASKED) {
+            const int i = i_base + mi * 16, j = j_base + ni * 16 + 4 * r;
+            acc[ni][mi][r] = (i < M && j < Nc && (!lower || i >= j)) ? -cp[mi * 16] : 0.0;
+          } else {
+            acc[ni][mi][r] = -cp[mi * 16];
+          }
+        }
         cp += 4 * ldc;
       }
   }
@@ -265,7 +279,14 @@ __device__ inline void gemm_body_fast(double* __restrict__ C, i64 ldc, const dou
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) cp[mi * 16] = -acc[ni][mi][r];
+        for (int mi = 0; mi < 4; ++mi) {
+          if (MASKED) {
+            const int i = i_base + mi * 16, j = j_base + ni * 16 + 4 * r;
+            if (i < M && j < Nc && (!lower || i >= j)) cp[mi * 16] = -acc[ni][mi][r];
+          } else {
+            cp[mi * 16] = -acc[ni][mi][r];
+          }
+        }
         cp += 4 * ldc;
       }
   }
@@ -278,25 +299,27 @@ __device__ inline bool gemm_tile_interior(int tm, int tn, int M, int Nc, int Kd,
          ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
 }
 
-// interior tiles only
+// all tiles when the operands are 16-B aligned and K is a multiple of 16 (host-side check)
 __global__ void __launch_bounds__(512, 4) gemm_nt_update_fast(double* __restrict__ C, i64 ldc,
                                                               const double* __restrict__ W, i64 ldw,
                                                               const double* __restrict__ L, i64 ldl, int M,
                                                               int Nc, int Kd, int lower, int ntm, int vec_ok) {
   const int tm = blockIdx.x % ntm, tn = blockIdx.x / ntm;
-  if (!gemm_tile_interior(tm, tn, M, Nc, Kd, lower, vec_ok, C, ldc)) return;
+  if (lower && (tm * GM_BM + GM_BM - 1 < tn * GM_BN)) return;
   __shared__ __attribute__((aligned(16))) double smem[4 * GM_BK * (GM_BM + GM_PAD)];
-  gemm_body_fast(C, ldc, W, ldw, L, ldl, Kd, tm, tn, smem);
+  if (gemm_tile_interior(tm, tn, M, Nc, Kd, lower, vec_ok, C, ldc))
+    gemm_body_fast<false>(C, ldc, W, ldw, L, ldl, Kd, tm, tn, smem, M, Nc, lower);
+  else
+    gemm_body_fast<true>(C, ldc, W, ldw, L, ldl, Kd, tm, tn, smem, M, Nc, lower);
 }
 
-// edge / diagonal tiles only
+// every tile through the guarded path (unaligned operands or K not a multiple of 16)
 __global__ void __launch_bounds__(256, 2) gemm_nt_update(double* __restrict__ C, i64 ldc,
                                                          const double* __restrict__ W, i64 ldw,
                                                          const double* __restrict__ L, i64 ldl, int M,
                                                          int Nc, int Kd, int lower, int ntm, int vec_ok) {
   const int tm = blockIdx.x % ntm, tn = blockIdx.x / ntm;
   if (lower && (tm * GM_BM + GM_BM - 1 < tn * GM_BN)) return;
-  if (gemm_tile_interior(tm, tn, M, Nc, Kd, lower, vec_ok, C, ldc)) return;
   __shared__ __attribute__((aligned(16))) double smem[2 * GM_BK * (GM_BM + GM_PAD)];
   gemm_body_guarded(C, ldc, W, ldw, L, ldl, M, Nc, Kd, lower, tm, tn, vec_ok, smem);
 }
@@ -436,6 +459,7 @@ struct BlockedLdlt {
   hipStream_t s1 = nullptr;                // stream of the big trailing updates
   bool time_updates = false;
   bool lookahead = true;
+  bool padded = false;         // the matrix allocation has >= 128 doubles of slack behind it
   int NB = 512;                // outer panel width (K of the MFMA Schur update)
   int max_neg = -1;            // >= 0: give up as soon as more negative pivots than this appear
 
@@ -447,8 +471,8 @@ struct BlockedLdlt {
     if (NB < LD_nb) NB = LD_nb;
     if (NB > LD_NB_MAX) NB = LD_NB_MAX;
     NB = NB / LD_nb * LD_nb;
-    Wp2[0] = ex->alloc<double>(static_cast<size_t>(ldw) * NB);
-    Wp2[1] = lookahead ? ex->alloc<double>(static_cast<size_t>(ldw) * NB) : Wp2[0];
+    Wp2[0] = ex->alloc<double>(static_cast<size_t>(ldw) * NB + 256);
+    Wp2[1] = lookahead ? ex->alloc<double>(static_cast<size_t>(ldw) * NB + 256) : Wp2[0];
     info = ex->alloc<LdltInfo>(1);
     acc = ex->alloc<double>(SV_B);
     DNLP_HIP_CHECK(hipEventCreateWithFlags(&evPanel, hipEventDisableTiming));
@@ -465,10 +489,14 @@ struct BlockedLdlt {
     const int ntm = (M + GM_BM - 1) / GM_BM, ntn = (Nc + GM_BN - 1) / GM_BN;
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const int vec_ok = al(W) && al(L) && (ldw % 2 == 0) && (ldl % 2 == 0);
-    hipLaunchKernelGGL(gemm_nt_update_fast, dim3(static_cast<unsigned>(ntm) * ntn), dim3(512), 0, st, C, ld, W,
-                       ldw, L, ldl, M, Nc, Kd, lower, ntm, vec_ok);
-    hipLaunchKernelGGL(gemm_nt_update, dim3(static_cast<unsigned>(ntm) * ntn), dim3(256), 0, st, C, ld, W, ldw,
-                       L, ldl, M, Nc, Kd, lower, ntm, vec_ok);
+    // operands may be read up to 127 rows past M / Nc: both allocations carry that padding
+    const bool fast_ok = vec_ok && (Kd % GM_BK == 0) && padded;
+    if (fast_ok)
+      hipLaunchKernelGGL(gemm_nt_update_fast, dim3(static_cast<unsigned>(ntm) * ntn), dim3(512), 0, st, C, ld, W,
+                         ldw, L, ldl, M, Nc, Kd, lower, ntm, vec_ok);
+    else
+      hipLaunchKernelGGL(gemm_nt_update, dim3(static_cast<unsigned>(ntm) * ntn), dim3(256), 0, st, C, ld, W, ldw,
+                         L, ldl, M, Nc, Kd, lower, ntm, vec_ok);
     DNLP_LAUNCH_CHECK();
   }
 
@@ -613,6 +641,7 @@ inline bool HipExec::ldlt_factor(LdltWork& w, double* A, i64 n, i64 ld, i32* ipi
   if (pivoted) return bk_factor(w, A, n, ld, ipiv, nneg, nzero);
   w.blocked->max_neg = w.expect_neg;
   w.blocked->time_updates = w.time_updates;
+  w.blocked->padded = w.padded;
   return w.blocked->factor(A, nneg, nzero);
 }
 inline void HipExec::ldlt_stats(LdltWork& w, double* out3) {

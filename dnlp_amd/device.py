@@ -19,7 +19,7 @@ class DeviceDense:
         self.n = int(n)
         self.ld = (self.n + 7) // 8 * 8
         ptr = C.c_void_p()
-        rc = self.api.lib.dnlp_dev_alloc(self.device, C.c_size_t(self.ld * self.n * 8), C.byref(ptr))
+        rc = self.api.lib.dnlp_dev_alloc(self.device, C.c_size_t(self.ld * self.n * 8 + 2048), C.byref(ptr))   # +2 KiB slack (tile over-reads)
         if rc != 0:
             raise MemoryError("dnlp_dev_alloc failed: %s" % self.api.error())
         self.ptr = ptr.value

@@ -105,7 +105,8 @@ int dnlp_dev_symv(int device, const double* device_A, int64_t n, int64_t ld, con
  * update.  Outputs the factored matrix, pivots (LAPACK DSYTF2 convention) and the inertia. */
 int dnlp_ldlt_host(int device, double* A, int64_t n, int64_t ld, int32_t* ipiv, int pivoted,
                    int* nneg, int* nzero, const double* rhs, double* sol, double* seconds);
-/* Time the blocked FP64-MFMA LDL^T on a device-resident matrix (destroys it). */
+/* Time the blocked FP64-MFMA LDL^T on a device-resident matrix (destroys it).  The allocation
+ * must extend at least 1 KiB past the last matrix element (128-row tiles over-read). */
 int dnlp_ldlt_device(int device, double* device_A, int64_t n, int64_t ld, int* nneg, int* nzero,
                      double* seconds, double* update_seconds);
 

@@ -21,7 +21,7 @@ namespace dnlp {
 struct HostExec {
   static constexpr bool is_device = false;
   struct FlatTableT {};
-  struct LdltWork { std::vector<double> d; int expect_neg = -1; bool time_updates = false; };
+  struct LdltWork { std::vector<double> d; int expect_neg = -1; bool time_updates = false; bool padded = false; };
   void ldlt_stats(LdltWork&, double* out3) { out3[0] = out3[1] = out3[2] = 0.0; }
   explicit HostExec(int device = 0) { (void)device; }
 
