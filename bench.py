@@ -101,25 +101,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=100000, help="order of the dense NLP (BASELINE: 1e5)")
+    ap.add_argument("--order", type=int, default=100000, help="order n of the dense NLP (BASELINE: 1e5)")
     ap.add_argument("--cpu-n", type=int, default=3000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    os.environ.setdefault("DNLP_DEVICE", str(local))
     import torch
+    ndev = max(torch.cuda.device_count(), 1)
+    local = local % ndev            # one process per GPU; wraps only in single-GPU debugging runs
+    os.environ["DNLP_DEVICE"] = str(local)
     dist = None
+    tdev = "cpu"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            tdev = "cuda"
+        else:
+            dist.init_process_group(args.backend)
 
     from dnlp_amd import _capi
     _capi.require_device(local)
-    n = args.n
+    n = args.order
     prob, A = build_problem(n, seed=rank, device=local)
     chain, data, inv = lower(prob)
     h = data["handle"]
@@ -146,12 +154,12 @@ def main():
     info = h.ipm_finish()
     st1 = info["stats"]
     if dist is not None:
-        tmax = torch.tensor([dt], device="cuda")
+        tmax = torch.tensor([dt], device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt_all = float(tmax.item())
         # the one exchange of the path: gather per-rank results (objective, iterations, status)
         mine = torch.tensor([info["obj_val"], float(info["iterations"]), float(info["status"])],
-                            device="cuda", dtype=torch.float64)
+                            device=tdev, dtype=torch.float64)
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
     else:

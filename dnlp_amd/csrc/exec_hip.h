@@ -529,6 +529,44 @@ __global__ void __launch_bounds__(kBlock) sweep_flat_kernel(FlatTable t, const d
   }
 }
 
+// out[q] += sum_i V[q*N + i] * w[i] for q < k (k <= 32): all k dot products in one sweep of w
+__global__ void __launch_bounds__(kBlock) vt_dot_kernel(int k, const double* __restrict__ V, i64 N,
+                                                        const double* __restrict__ w, double* out) {
+  __shared__ double red[kBlock / 64][32];
+  double acc[32];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) acc[q] = 0.0;
+  for (i64 i = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x; i < N; i += static_cast<i64>(gridDim.x) * kBlock) {
+    const double wi = w[i];
+#pragma unroll
+    for (int q = 0; q < 32; ++q)
+      if (q < k) acc[q] += V[static_cast<i64>(q) * N + i] * wi;
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    if (q < k) {
+      const double s = wave_sum(acc[q]);
+      if (lane == 0) red[wid][q] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < k) {
+    double t = 0.0;
+    for (int w2 = 0; w2 < kBlock / 64; ++w2) t += red[w2][threadIdx.x];
+    unsafeAtomicAdd(&out[threadIdx.x], t);
+  }
+}
+// w[i] -= sum_q c[q] V[q*N + i]
+__global__ void __launch_bounds__(kBlock) v_axpy_kernel(int k, const double* __restrict__ V, i64 N,
+                                                        const double* __restrict__ c, double* __restrict__ w) {
+  const i64 i = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= N) return;
+  double s = 0.0;
+  for (int q = 0; q < k; ++q) s += c[q] * V[static_cast<i64>(q) * N + i];
+  w[i] -= s;
+}
+
 struct BlockedLdlt;   // ldlt_blocked.h
 
 struct HipExec {
@@ -636,6 +674,19 @@ struct HipExec {
     }
     hipLaunchKernelGGL(gemv_stage1, dim3(static_cast<unsigned>(nrb * ncb)), dim3(kBlock), 0, stream, n, P, ld, u, gemv_part, nrb);
     hipLaunchKernelGGL(gemv_stage2, dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, n, ncb, gemv_part, out);
+    DNLP_LAUNCH_CHECK();
+  }
+  // Gram-Schmidt step against k stored vectors: c = V^T w (returned on the host), w -= V c
+  void orthogonalize(int k, const double* V, i64 N, double* w, double* c_host) {
+    if (k <= 0) return;
+    double* dc = d_partial;      // k <= 32 doubles of the reduction scratch
+    DNLP_HIP_CHECK(hipMemsetAsync(dc, 0, sizeof(double) * 32, stream));
+    i64 grid = (N + kBlock - 1) / kBlock;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(vt_dot_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, k, V, N, w, dc);
+    hipLaunchKernelGGL(v_axpy_kernel, dim3(static_cast<unsigned>((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, k, V, N, dc, w);
+    DNLP_HIP_CHECK(hipMemcpyAsync(c_host, dc, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
+    DNLP_HIP_CHECK(hipStreamSynchronize(stream));
     DNLP_LAUNCH_CHECK();
   }
   void sweep_flat(const FlatTable& t, const double* x, double* z, double* dv, double* hv, const double* w, bool with_h) {

@@ -52,7 +52,7 @@ struct IpmOptions {
   int restoration = 1;
   int adaptive_fallback = 1;
   int lanczos_inertia_bound = 1;
-  int lanczos_min_n = 4096;
+  int lanczos_min_n = 12000;
 };
 
 struct IpmStats {
@@ -560,13 +560,8 @@ class Ipm {
         if (nr > 1e-14) { ex_->map(N, [=] DNLP_HD(i64 j) { q[j] /= nr; }); ++nq; }
       }
     }
-    auto project = [&](double* v) {
-      for (int c = 0; c < nq; ++c) {
-        const double* qc = lanQ + static_cast<i64>(c) * N;
-        const double d = ex_->sum(N, [=] DNLP_HD(i64 j) { return v[j] * qc[j]; });
-        ex_->map(N, [=] DNLP_HD(i64 j) { v[j] -= d * qc[j]; });
-      }
-    };
+    double cbuf[32];
+    auto project = [&](double* v) { ex_->orthogonalize(nq, lanQ, N, v, cbuf); };
     std::vector<double> al, be;
     double* v0 = lanV;
     {
@@ -586,13 +581,9 @@ class Ipm {
       project(w);
       const double a = ex_->sum(N, [=] DNLP_HD(i64 j) { return w[j] * vk[j]; });
       al.push_back(a);
-      // full reorthogonalisation against all previous vectors (twice is enough)
-      for (int pass = 0; pass < 2; ++pass)
-        for (int q = 0; q <= k; ++q) {
-          const double* vq = lanV + static_cast<i64>(q) * N;
-          const double c = ex_->sum(N, [=] DNLP_HD(i64 j) { return w[j] * vq[j]; });
-          ex_->map(N, [=] DNLP_HD(i64 j) { w[j] -= c * vq[j]; });
-        }
+      // full reorthogonalisation against all previous vectors (classical Gram-Schmidt, twice):
+      // two sweeps of w per pass instead of one reduction per stored vector
+      for (int pass = 0; pass < 2; ++pass) ex_->orthogonalize(k + 1, lanV, N, w, cbuf);
       const double b = std::sqrt(ex_->sum(N, [=] DNLP_HD(i64 j) { return w[j] * w[j]; }));
       if (!(b > 1e-12 * (std::fabs(a) + 1.0)) || k + 1 == kmax) break;
       be.push_back(b);

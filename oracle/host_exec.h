@@ -56,6 +56,16 @@ struct HostExec {
     return nan ? std::nan("") : s;
   }
 
+  // Gram-Schmidt step against k stored vectors: c = V^T w, w -= V c
+  void orthogonalize(int k, const double* V, i64 N, double* w, double* c_host) {
+    for (int q = 0; q < k; ++q) {
+      double s = 0.0;
+      for (i64 i = 0; i < N; ++i) s += V[static_cast<i64>(q) * N + i] * w[i];
+      c_host[q] = s;
+    }
+    for (int q = 0; q < k; ++q)
+      for (i64 i = 0; i < N; ++i) w[i] -= c_host[q] * V[static_cast<i64>(q) * N + i];
+  }
   // out = P u for a symmetric column-major matrix
   void gemv_sym(i64 n, const double* P, i64 ld, const double* u, double* out) {
     // P symmetric: row i of P u is the dot product of column i with u (contiguous reads)
