@@ -165,6 +165,17 @@ def main():
     else:
         dt_all = dt
     if rank == 0:
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same
+        # command (FETCH_SIZE and WRITE_SIZE cannot share a pass); the committed summary is quoted
+        # only when it was taken at the same order n
+        traffic, traffic_src = None, None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench_traffic.json")))
+            if int(pj["n"]) == n:
+                traffic = pj["avg_traffic_bytes_per_launch"]
+                traffic_src = "profiles/r01_pmc_bench_traffic.json (" + pj["command"] + ")"
+        except (OSError, KeyError, ValueError):
+            pass
         upd_s, upd_f, upd_l = st1[13] - st0[13], st1[14] - st0[14], st1[15] - st0[15]
         achieved = upd_f / upd_s / 1e12 if upd_s > 0 else None
         out = {
@@ -185,7 +196,8 @@ def main():
                          "frac": (achieved / PEAK_FP64_MFMA_TFLOPS) if achieved else None,
                          "launches": int(upd_l), "avg_launch_ms": 1e3 * upd_s / upd_l if upd_l else None,
                          "avg_launch_gflop": upd_f / upd_l / 1e9 if upd_l else None,
-                         "traffic": None},
+                         "traffic": traffic, "traffic_unit": "bytes per launch (FETCH x2-corrected + WRITE)",
+                         "traffic_source": traffic_src},
         }
         if not args.no_cpu:
             try:

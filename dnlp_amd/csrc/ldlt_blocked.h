@@ -304,7 +304,22 @@ __global__ void __launch_bounds__(512, 4) gemm_nt_update_fast(double* __restrict
                                                               const double* __restrict__ W, i64 ldw,
                                                               const double* __restrict__ L, i64 ldl, int M,
                                                               int Nc, int Kd, int lower, int ntm, int vec_ok) {
-  const int tm = blockIdx.x % ntm, tn = blockIdx.x / ntm;
+  int tm, tn;
+  if (vec_ok & 2) {
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so the 64
+    // workgroups resident on one XCD (equal id % 8, consecutive id / 8) are mapped onto one
+    // 8 x 8 super-tile and share its 8 W strips and 8 L strips through that XCD's L2 instead
+    // of each streaming its own 512-KB W strip from HBM (speed only; any placement is correct)
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int within = seq & 63, super = (seq >> 6) * 8 + xcd;
+    const int nsm = (ntm + 7) >> 3;
+    tm = (super % nsm) * 8 + (within & 7);
+    tn = (super / nsm) * 8 + (within >> 3);
+    if (tm >= ntm || tn * GM_BN >= Nc) return;
+  } else {
+    tm = blockIdx.x % ntm;
+    tn = blockIdx.x / ntm;
+  }
   if (lower && (tm * GM_BM + GM_BM - 1 < tn * GM_BN)) return;
   __shared__ __attribute__((aligned(16))) double smem[4 * GM_BK * (GM_BM + GM_PAD)];
   if (gemm_tile_interior(tm, tn, M, Nc, Kd, lower, vec_ok, C, ldc))
@@ -459,6 +474,7 @@ struct BlockedLdlt {
   hipStream_t s1 = nullptr;                // stream of the big trailing updates
   bool time_updates = false;
   bool lookahead = true;
+  bool xcd_swizzle = false;    // 8 x 8 super-tiles per XCD: cuts the W-strip re-reads ~5x but measured 1.5-3% slower (MFMA-bound), so off; DNLP_LDLT_XCD=1 enables
   bool padded = false;         // the matrix allocation has >= 128 doubles of slack behind it
   int NB = 512;                // outer panel width (K of the MFMA Schur update)
   int max_neg = -1;            // >= 0: give up as soon as more negative pivots than this appear
@@ -468,6 +484,7 @@ struct BlockedLdlt {
     ldw = (n + 7) / 8 * 8;
     if (const char* ev = std::getenv("DNLP_LDLT_NB")) NB = std::atoi(ev);
     if (const char* ev = std::getenv("DNLP_LDLT_LOOKAHEAD")) lookahead = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("DNLP_LDLT_XCD")) xcd_swizzle = std::atoi(ev) != 0;
     if (NB < LD_nb) NB = LD_nb;
     if (NB > LD_NB_MAX) NB = LD_NB_MAX;
     NB = NB / LD_nb * LD_nb;
@@ -491,7 +508,11 @@ struct BlockedLdlt {
     const int vec_ok = al(W) && al(L) && (ldw % 2 == 0) && (ldl % 2 == 0);
     // operands may be read up to 127 rows past M / Nc: both allocations carry that padding
     const bool fast_ok = vec_ok && (Kd % GM_BK == 0) && padded;
-    if (fast_ok)
+    if (fast_ok && xcd_swizzle && ntm >= 16 && ntn >= 16) {
+      const unsigned nsuper = static_cast<unsigned>((ntm + 7) / 8) * static_cast<unsigned>((ntn + 7) / 8);
+      hipLaunchKernelGGL(gemm_nt_update_fast, dim3(((nsuper + 7) / 8) * 8 * 64), dim3(512), 0, st, C, ld, W,
+                         ldw, L, ldl, M, Nc, Kd, lower, ntm, vec_ok | 2);
+    } else if (fast_ok)
       hipLaunchKernelGGL(gemm_nt_update_fast, dim3(static_cast<unsigned>(ntm) * ntn), dim3(512), 0, st, C, ld, W,
                          ldw, L, ldl, M, Nc, Kd, lower, ntm, vec_ok);
     else
