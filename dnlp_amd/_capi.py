@@ -49,6 +49,7 @@ class CApi:
                               _i32_p, _dbl_p])
         f("set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p])
         f("solve", C.c_int, [C.c_void_p] + [_dbl_p] * 6 + [C.POINTER(C.c_int)])
+        f("solve_reduced", C.c_int, [C.c_void_p, _dbl_p, _dbl_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _dbl_p])
         f("ipm_begin", C.c_int, [C.c_void_p, _dbl_p])
         f("ipm_step", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)])
         f("ipm_finish", C.c_int, [C.c_void_p] + [_dbl_p] * 6 + [C.POINTER(C.c_int)])
@@ -233,6 +234,22 @@ class ProblemHandle:
         if status == -199:
             raise RuntimeError("solve failed: %s" % self.api.error())
         return self._info(status, x, obj, g, mg, zl, zu, iters)
+
+    def solve_reduced(self, x0):
+        """Reduced-space L-BFGS (tape f / grad f + line search only; BASELINE config C2)."""
+        import time
+        x = np.array(self._x(x0))
+        obj, gn = C.c_double(), C.c_double()
+        iters, evals = C.c_int(), C.c_int()
+        t0 = time.time()
+        st = self.api.solve_reduced(self.ptr, _dp(x), C.byref(obj), C.byref(iters), C.byref(evals), C.byref(gn))
+        if st == -199:
+            raise RuntimeError("solve_reduced failed: %s" % self.api.error())
+        status = {0: 0, -1: -1, 3: 3}.get(st, st)
+        return {"status": status, "x": x, "obj_val": obj.value, "iterations": iters.value,
+                "evaluations": evals.value, "grad_inf_norm": gn.value, "solve_time": time.time() - t0,
+                "g": np.zeros(self.m), "mult_g": np.zeros(self.m), "mult_x_L": np.zeros(self.n),
+                "mult_x_U": np.zeros(self.n), "stats": np.zeros(16)}
 
     def ipm_begin(self, x0):
         x0 = self._x(x0)

@@ -9,6 +9,7 @@
 
 #include "ipm_core.h"
 #include "kkt_dense.h"
+#include "lbfgs_core.h"
 
 namespace dnlp {
 
@@ -24,6 +25,8 @@ struct ProblemT {
   Model<E> model;
   DenseKkt<E> kkt;
   std::unique_ptr<Ipm<E, DenseKkt<E>>> ipm;
+  std::unique_ptr<ReducedLbfgs<E>> lbfgs;
+  int lbfgs_history = 10;
   IpmOptions opt;
   i64 pivot_max_n = 2048;
   double *dx = nullptr, *dlam = nullptr, *dg = nullptr, *dgrad = nullptr, *djac = nullptr, *dh = nullptr;
@@ -100,6 +103,7 @@ struct ProblemT {
     else if (k == "kkt_pivot_max_n") pivot_max_n = static_cast<i64>(num());
     else if (k == "restoration") opt.restoration = yes() ? 1 : 0;
     else if (k == "time_kernels") time_kernels = yes();
+    else if (k == "lbfgs_history" || k == "limited_memory_max_history") lbfgs_history = static_cast<int>(num());
     else if (k == "adaptive_fallback") opt.adaptive_fallback = yes() ? 1 : 0;
     else if (k == "lanczos_inertia_bound") opt.lanczos_inertia_bound = yes() ? 1 : 0;
     else if (k == "lanczos_min_n") opt.lanczos_min_n = static_cast<int>(num());
@@ -224,6 +228,17 @@ struct ProblemT {
              int st = p->ipm->solve(x);                                                              \
              if (p->ipm->initialized) p->ipm->extract(x, obj, mg, mxl, mxu, g);                      \
              if (iters) *iters = p->ipm->iter; return st;)                                           \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, solve_reduced)(void* vp, double* x, double* obj, int* iters, int* evals, double* gnorm) { \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    DNLP_TRY(if (!p->lbfgs) p->lbfgs.reset(new dnlp::ReducedLbfgs<EXEC>(&p->ex, &p->model));           \
+             p->lbfgs->tol = p->opt.tol; p->lbfgs->max_iter = p->opt.max_iter > 3000 ? p->opt.max_iter : 20000; \
+             p->lbfgs->history = p->lbfgs_history; p->lbfgs->print_level = p->opt.print_level;         \
+             p->swept = false;                                                                       \
+             int st = p->lbfgs->solve(x);                                                            \
+             p->lbfgs->extract(x, obj);                                                              \
+             if (iters) *iters = p->lbfgs->iterations; if (evals) *evals = p->lbfgs->evaluations;    \
+             if (gnorm) *gnorm = p->lbfgs->gnorm_final; return st;)                                  \
   }                                                                                                  \
   int DNLP_CAT(PFX, get_stats)(void* vp, double* s, int n) {                                         \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \

@@ -1,0 +1,193 @@
+// Reduced-space L-BFGS for canonical problems whose constraints only define auxiliary variables
+// (BASELINE config C2: unconstrained NLP, "tape f / grad f evaluation + line search only").
+//
+// The reference solves such problems through IPOPT on the canonical form (aux variables +
+// equalities, dnlp2smooth.py:42-111).  Here the user's variables x_f are the only unknowns:
+//   forward :  t <- t - g(x_f, t)   repeated `depth` times  (every row of g is  t_k - expr_k,
+//              so the fixed point is the exact forward substitution; depth = nesting depth)
+//   adjoint :  lambda <- lambda + (grad_t f - (J^T lambda)_t)   repeated `depth` times
+//   reduced gradient = grad_f f - (J^T lambda)_f
+// built from the same tape kernels as the interior-point path (sweep, G spmv, Mg/MJ maps, COO
+// J^T product).  The optimiser is limited-memory BFGS (two-loop recursion, history 10) with an
+// Armijo backtracking line search; no linear system is ever formed.
+#pragma once
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "ipm_core.h"
+
+namespace dnlp {
+
+template <class E>
+class ReducedLbfgs {
+ public:
+  ReducedLbfgs(E* ex, Model<E>* md) : ex_(ex), md_(md) {}
+
+  double tol = 1e-7;
+  int max_iter = 20000;
+  int history = 10;
+  int print_level = 0;
+  int iterations = 0, evaluations = 0;
+  double f_final = 0.0, gnorm_final = 0.0, wall = 0.0;
+  std::vector<std::string> log_lines;
+
+  // canonical full vector x (N); g (m); grad (N); jv (nnzJ); lam (m); jt (N)
+  double *x = nullptr, *g = nullptr, *grad = nullptr, *jv = nullptr, *lam = nullptr, *jt = nullptr;
+  double *xf = nullptr, *gf = nullptr, *xt = nullptr, *gt = nullptr, *dir = nullptr, *S = nullptr, *Y = nullptr;
+
+  template <class T> T* A(i64 n) { return ex_->template alloc<T>(static_cast<size_t>(n > 0 ? n : 1)); }
+
+  // f and reduced gradient at the free variables xfree (exec space, nfree); returns false on NaN
+  bool eval(const double* xfree, double& fval, double* gred) {
+    const Tape<E>& t = md_->t;
+    const i64 N = t.N, m = t.m, nf = t.nfree;
+    const i32 *fi = t.free_idx, *dv = t.def_var;
+    double* xx = x;
+    ex_->map(nf, [=] DNLP_HD(i64 k) { xx[fi[k]] = xfree[k]; });
+    double* gg = g;
+    for (i64 pass = 0; pass < t.red_depth; ++pass) {
+      md_->sweep(x, false);
+      md_->eval_g_after_sweep(g);
+      ex_->map(m, [=] DNLP_HD(i64 i) { xx[dv[i]] -= gg[i]; });
+    }
+    md_->sweep(x, false);
+    fval = md_->eval_f_after_sweep();
+    md_->eval_grad_after_sweep(grad);
+    ++evaluations;
+    if (m > 0) {
+      md_->eval_jac_after_sweep(jv);
+      ex_->zero(lam, sizeof(double) * static_cast<size_t>(m));
+      ex_->zero(jt, sizeof(double) * static_cast<size_t>(N));
+      double* ll = lam;
+      const double *gr = grad, *jtt = jt;
+      for (i64 pass = 0; pass <= t.red_depth; ++pass) {
+        ex_->map(m, [=] DNLP_HD(i64 i) { ll[i] += gr[dv[i]] - jtt[dv[i]]; });
+        md_->jac_tmult(jv, lam, jt);
+      }
+      ex_->map(nf, [=] DNLP_HD(i64 k) { gred[k] = gr[fi[k]] - jtt[fi[k]]; });
+    } else {
+      const double* gr = grad;
+      ex_->map(nf, [=] DNLP_HD(i64 k) { gred[k] = gr[fi[k]]; });
+    }
+    const double chk = ex_->sum(nf, [=] DNLP_HD(i64 k) { return gred[k] - gred[k]; });
+    return std::isfinite(fval) && chk == 0.0;
+  }
+
+  // returns 0 converged, -1 iteration limit, -13 invalid number at the start, 3 line search stuck
+  int solve(const double* x0_host) {
+    const double t0 = now_sec();
+    const Tape<E>& t = md_->t;
+    if (!t.reducible) return -11;
+    const i64 N = t.N, m = t.m, nf = t.nfree;
+    if (!x) {
+      x = A<double>(N); g = A<double>(m); grad = A<double>(N); jv = A<double>(t.nnzJ); lam = A<double>(m);
+      jt = A<double>(N); xf = A<double>(nf); gf = A<double>(nf); xt = A<double>(nf); gt = A<double>(nf);
+      dir = A<double>(nf); S = A<double>(static_cast<i64>(history) * nf); Y = A<double>(static_cast<i64>(history) * nf);
+    }
+    ex_->h2d(x, x0_host, sizeof(double) * static_cast<size_t>(N));
+    {
+      const i32* fi = t.free_idx;
+      double* a = xf;
+      const double* xx = x;
+      ex_->map(nf, [=] DNLP_HD(i64 k) { a[k] = xx[fi[k]]; });
+    }
+    double f = 0.0;
+    if (!eval(xf, f, gf)) return -13;
+    std::vector<double> rho(static_cast<size_t>(history), 0.0), alpha(static_cast<size_t>(history), 0.0);
+    int stored = 0, head = 0;
+    iterations = 0;
+    int status = -1;
+    char buf[160];
+    for (int it = 0; it < max_iter; ++it) {
+      const double* gp = gf;
+      const double gn = ex_->max(nf, [=] DNLP_HD(i64 k) { return fabs(gp[k]); });
+      gnorm_final = gn;
+      f_final = f;
+      if (print_level >= 5 && (it % 10 == 0)) {
+        std::snprintf(buf, sizeof buf, "%6d  f=%.10e  |g|_inf=%.3e  evals=%d", it, f, gn, evaluations);
+        log_lines.emplace_back(buf);
+      }
+      if (gn <= tol * std::fmax(1.0, std::fabs(f))) { status = 0; break; }
+      // two-loop recursion: dir = -H grad
+      double* d = dir;
+      ex_->map(nf, [=] DNLP_HD(i64 k) { d[k] = gp[k]; });
+      for (int j = 0; j < stored; ++j) {
+        const int idx = (head - 1 - j + 2 * history) % history;
+        const double *sj = S + static_cast<i64>(idx) * nf, *yj = Y + static_cast<i64>(idx) * nf;
+        const double a = rho[idx] * ex_->sum(nf, [=] DNLP_HD(i64 k) { return sj[k] * d[k]; });
+        alpha[idx] = a;
+        ex_->map(nf, [=] DNLP_HD(i64 k) { d[k] -= a * yj[k]; });
+      }
+      if (stored > 0) {
+        const int idx = (head - 1 + history) % history;
+        const double *sj = S + static_cast<i64>(idx) * nf, *yj = Y + static_cast<i64>(idx) * nf;
+        const double sy = ex_->sum(nf, [=] DNLP_HD(i64 k) { return sj[k] * yj[k]; });
+        const double yy = ex_->sum(nf, [=] DNLP_HD(i64 k) { return yj[k] * yj[k]; });
+        const double gam = sy / yy;
+        ex_->map(nf, [=] DNLP_HD(i64 k) { d[k] *= gam; });
+      }
+      for (int j = stored - 1; j >= 0; --j) {
+        const int idx = (head - 1 - j + 2 * history) % history;
+        const double *sj = S + static_cast<i64>(idx) * nf, *yj = Y + static_cast<i64>(idx) * nf;
+        const double b = rho[idx] * ex_->sum(nf, [=] DNLP_HD(i64 k) { return yj[k] * d[k]; });
+        const double a = alpha[idx];
+        ex_->map(nf, [=] DNLP_HD(i64 k) { d[k] += (a - b) * sj[k]; });
+      }
+      ex_->map(nf, [=] DNLP_HD(i64 k) { d[k] = -d[k]; });
+      double gd = ex_->sum(nf, [=] DNLP_HD(i64 k) { return gp[k] * d[k]; });
+      if (!(gd < 0.0)) {   // not a descent direction: restart from steepest descent
+        stored = 0;
+        ex_->map(nf, [=] DNLP_HD(i64 k) { d[k] = -gp[k]; });
+        gd = -ex_->sum(nf, [=] DNLP_HD(i64 k) { return gp[k] * gp[k]; });
+      }
+      // Armijo backtracking (first iteration starts at 1/|g|)
+      double step = (it == 0 && stored == 0) ? std::fmin(1.0, 1.0 / std::fmax(gn, 1e-300)) : 1.0;
+      double fn = 0.0;
+      bool ok = false;
+      for (int ls = 0; ls < 60; ++ls) {
+        double* xn = xt;
+        const double* xc = xf;
+        const double st = step;
+        ex_->map(nf, [=] DNLP_HD(i64 k) { xn[k] = xc[k] + st * d[k]; });
+        if (eval(xt, fn, gt) && fn <= f + 1e-4 * step * gd) { ok = true; break; }
+        step *= 0.5;
+      }
+      if (!ok) { status = 3; break; }
+      // history update
+      double* sn = S + static_cast<i64>(head) * nf;
+      double* yn = Y + static_cast<i64>(head) * nf;
+      const double *xn = xt, *xc = xf, *gnew = gt;
+      ex_->map(nf, [=] DNLP_HD(i64 k) { sn[k] = xn[k] - xc[k]; yn[k] = gnew[k] - gp[k]; });
+      const double sy = ex_->sum(nf, [=] DNLP_HD(i64 k) { return sn[k] * yn[k]; });
+      const double ss = ex_->sum(nf, [=] DNLP_HD(i64 k) { return sn[k] * sn[k]; });
+      const double yy = ex_->sum(nf, [=] DNLP_HD(i64 k) { return yn[k] * yn[k]; });
+      if (sy > 1e-10 * std::sqrt(ss) * std::sqrt(yy)) {
+        rho[head] = 1.0 / sy;
+        head = (head + 1) % history;
+        if (stored < history) ++stored;
+      }
+      ex_->d2d(xf, xt, sizeof(double) * static_cast<size_t>(nf));
+      ex_->d2d(gf, gt, sizeof(double) * static_cast<size_t>(nf));
+      f = fn;
+      iterations = it + 1;
+    }
+    // leave the canonical vector consistent with the final free variables
+    double fl;
+    eval(xf, fl, gf);
+    f_final = fl;
+    wall = now_sec() - t0;
+    return status;
+  }
+
+  void extract(double* x_host, double* obj) {
+    if (x_host) ex_->d2h(x_host, x, sizeof(double) * static_cast<size_t>(md_->t.N));
+    if (obj) *obj = f_final;
+  }
+
+ private:
+  E* ex_;
+  Model<E>* md_;
+};
+
+}  // namespace dnlp

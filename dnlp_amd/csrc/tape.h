@@ -120,6 +120,10 @@ struct Tape {
   struct SparseConst { Csr P, PT; i64 nh = 0; double* hv = nullptr; };
   std::vector<SparseConst> sparse;
   std::vector<DenseBlock> blocks;
+  // reduced-space structure (dnlp_amd/reduced.py): every constraint row defines one auxiliary variable
+  bool reducible = false;
+  i64 nfree = 0, red_depth = 0;
+  i32 *def_var = nullptr, *free_idx = nullptr;
 
   template <class T> T* up(const T* src, size_t n) {
     T* d = ex->template alloc<T>(n);
@@ -234,6 +238,16 @@ struct Tape {
         B.coo_pos = up(tb.i64s(nm), tb.count(nm));
       }
     }
+    load_reduction(tb);
+  }
+
+  void load_reduction(const TapeBlob& tb) {
+    if (!tb.has("def_var") || !tb.has("free_idx") || !tb.has("red_depth")) return;
+    reducible = true;
+    nfree = static_cast<i64>(tb.count("free_idx"));
+    red_depth = tb.i64s("red_depth")[0];
+    def_var = up(tb.i32s("def_var"), tb.count("def_var"));
+    free_idx = up(tb.i32s("free_idx"), tb.count("free_idx"));
   }
 
   bool dense_bound() const {

@@ -115,9 +115,10 @@ class InverseData:
         self.offset = 0.0
 
 
-def build_nlp_data(problem):
+def build_nlp_data(problem, user_variables=None):
     """Bounds + tape lowering for a smooth-canonical problem.  Returns the data dict without
-    touching the device (used by CPU tests and by `HIPNLP.apply`)."""
+    touching the device (used by CPU tests and by `HIPNLP.apply`).  `user_variables` (the
+    variables of the problem as the user wrote it) enables the reduced-space arrays."""
     bounds = Bounds(problem)
     new_problem = bounds.new_problem
     variables = new_problem.variables()
@@ -134,6 +135,12 @@ def build_nlp_data(problem):
         "tape": tape,
     }
     data["tape_arrays"] = tape_arrays(tape, bounds.x0, bounds.lb, bounds.ub, bounds.cl, bounds.cu)
+    if user_variables is not None:
+        from .reduced import reduction_arrays
+        red = reduction_arrays(new_problem, tape, {id(v) for v in user_variables})
+        if red is not None:
+            data["tape_arrays"].update(red)
+        data["reducible"] = red is not None
     return data, inverse_data
 
 
@@ -212,10 +219,10 @@ class HIPNLP:
     def accepts(self, problem):
         return problem.is_dnlp()
 
-    def apply(self, problem):
+    def apply(self, problem, user_variables=None):
         """reference nlp_solver.py:47-79: builds the data dict incl. the oracles."""
         from . import _capi
-        data, inverse_data = build_nlp_data(problem)
+        data, inverse_data = build_nlp_data(problem, user_variables)
         blob = serialize(data["tape_arrays"])
         handle = _capi.DeviceProblem(blob, data["tape"])
         oracles = DeviceOracles(handle, len(data["x0"]), len(data["cl"]))
@@ -237,9 +244,16 @@ class HIPNLP:
             # 0 is silent and 5 prints the IPOPT-style iteration table
             options["print_level"] = 5 if verbose else 0
         handle = data["handle"]
+        algorithm = options.pop("algorithm", "interior-point")
         for k, v in options.items():
             handle.set_option(k, v)
-        info = handle.solve(data["x0"])
+        if algorithm in ("lbfgs", "reduced-lbfgs"):
+            if not data.get("reducible"):
+                raise ValueError("algorithm='lbfgs' needs an unconstrained smooth problem whose "
+                                 "canonical constraints only define auxiliary variables")
+            info = handle.solve_reduced(data["x0"])
+        else:
+            info = handle.solve(data["x0"])
         data["oracles"].iterations = info["iterations"]
         return info
 

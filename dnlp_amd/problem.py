@@ -271,7 +271,7 @@ class NLPChain:
         if self.flip:
             problem = Problem(Minimize(-problem.objective.expr), problem.constraints)
         smooth, _ = Dnlp2Smooth().apply(problem)
-        data, inverse_data = self.solver.apply(smooth)
+        data, inverse_data = self.solver.apply(smooth, user_variables=problem.variables())
         return data, inverse_data
 
     def invert(self, solution, inverse_data):

@@ -79,6 +79,13 @@ int dnlp_ipm_begin(dnlp_problem* p, const double* x0);
 int dnlp_ipm_step(dnlp_problem* p, int max_steps, int* steps_done);
 int dnlp_ipm_finish(dnlp_problem* p, double* x, double* obj, double* g, double* mult_g,
                     double* mult_x_L, double* mult_x_U, int* iters);
+/* Unconstrained problems whose canonical constraints only define auxiliary variables
+ * (BASELINE config C2): reduced-space L-BFGS on the user's variables, built from tape f / grad f
+ * evaluations and a line search only — no KKT system.  Same role as nlp.solve(x0) for such
+ * problems (ipopt_nlpif.py:170).  Returns 0 converged, -1 iteration limit, 3 line search
+ * failure, -11 when the tape has no reduced-space structure. */
+int dnlp_solve_reduced(dnlp_problem* p, double* x_inout, double* obj, int* iters, int* evals,
+                       double* gnorm);
 /* Statistics of the last solve: stats[0..15] = iterations, factorizations, wall, t_eval,
  * t_factor, t_solve, mu, inf_pr, inf_du, compl, nlp_error, last_delta_w, ... */
 int dnlp_get_stats(dnlp_problem* p, double* stats, int n);

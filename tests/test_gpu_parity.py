@@ -239,3 +239,36 @@ def test_c4_full_size_n1e5_lambda_max(gpu_required):
     reference cannot run this size at all; parity is certified through the
     eigenvalue property, to the 1e-6 relative tolerance the north star states."""
     _c4_solve_and_check(100000, 1e-6)
+
+
+def test_c2_rosenbrock_chain_full_size_lbfgs(gpu_required):
+    """BASELINE config C2 at its full size (n = 1e5, canonical N = 399,997): unconstrained
+    Rosenbrock chain, tape f / grad f evaluation + line search only (reduced-space L-BFGS);
+    analytic optimum x* = 1, f* = 0."""
+    import dnlp_amd as cp
+    from problem_zoo import rosenbrock_chain
+    n = 100000
+    p = rosenbrock_chain(cp, n)
+    p.solve(nlp=True, algorithm="lbfgs")
+    x = p.variables()[0]
+    assert p.status == cp.OPTIMAL
+    assert np.max(np.abs(x.value - 1.0)) <= 1e-6
+    assert abs(p.value) <= 1e-10
+
+
+def test_c2_lbfgs_matches_cpu_oracle(gpu_required):
+    from dnlp_amd import _capi
+    from dnlp_amd.dnlp2smooth import Dnlp2Smooth
+    from dnlp_amd.nlp_solver import build_nlp_data
+    from dnlp_amd.tape import serialize
+    from oracle.oracle_capi import OracleProblem
+    import dnlp_amd as cp
+    from problem_zoo import rosenbrock_chain
+    p = rosenbrock_chain(cp, 500)
+    smooth, _ = Dnlp2Smooth().apply(p)
+    data, _ = build_nlp_data(smooth, p.variables())
+    blob = serialize(data["tape_arrays"])
+    d = _capi.DeviceProblem(blob, data["tape"], device=0).solve_reduced(data["x0"])
+    o = OracleProblem(blob).solve_reduced(data["x0"])
+    assert d["status"] == 0 and o["status"] == 0
+    np.testing.assert_allclose(d["x"], o["x"], atol=1e-6)

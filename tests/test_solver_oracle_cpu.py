@@ -193,3 +193,43 @@ def test_infeasible_problem_reports_infeasible_or_restoration_failure():
     prob = cp.Problem(cp.Minimize(cp.sum(cp.square(x))), [cp.sum(x) == 5])
     info, _ = _oracle_solve_problem(prob)
     assert info["status"] in (2, -2)       # Infeasible_Problem_Detected / Restoration_Failed
+
+
+@pytest.mark.parametrize("n", [2, 50, 3000])
+def test_reduced_lbfgs_rosenbrock_chain(n):
+    """BASELINE config C2 (scaled): unconstrained Rosenbrock chain through the reduced-space
+    path — tape f / grad f evaluations and a line search only; optimum x* = 1, f* = 0."""
+    import dnlp_amd as cp
+    from dnlp_amd.dnlp2smooth import Dnlp2Smooth
+    from dnlp_amd.nlp_solver import build_nlp_data
+    from dnlp_amd.tape import serialize
+    from oracle.oracle_capi import OracleProblem
+    from problem_zoo import rosenbrock_chain
+    p = rosenbrock_chain(cp, n)
+    smooth, _ = Dnlp2Smooth().apply(p)
+    data, inv = build_nlp_data(smooth, p.variables())
+    assert data["reducible"]
+    h = OracleProblem(serialize(data["tape_arrays"]))
+    info = h.solve_reduced(data["x0"])
+    assert info["status"] == 0
+    xv = [v for v in data["problem"].variables() if v.size == n][0]
+    off = inv.var_offsets[xv.id]
+    assert np.max(np.abs(info["x"][off:off + n] - 1.0)) <= 1e-6
+    assert abs(info["obj_val"]) <= 1e-10
+    if n <= 50:
+        # the reduced-space optimum must agree with the interior-point solution of the canonical form
+        ip = h.solve(data["x0"])
+        assert ip["status"] == 0
+        np.testing.assert_allclose(ip["x"][off:off + n], info["x"][off:off + n], atol=1e-6)
+
+
+def test_reduction_structure_rejects_constrained_problems():
+    import dnlp_amd as cp
+    from dnlp_amd.dnlp2smooth import Dnlp2Smooth
+    from dnlp_amd.nlp_solver import build_nlp_data
+    from problem_zoo import hs071, socp
+    for f in (hs071, socp):
+        p = f(cp)
+        smooth, _ = Dnlp2Smooth().apply(p)
+        data, _ = build_nlp_data(smooth, p.variables())
+        assert data["reducible"] is False and "def_var" not in data["tape_arrays"]
