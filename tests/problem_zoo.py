@@ -235,3 +235,9 @@ ZOO = {
     "nonsmooth_zoo": nonsmooth_zoo,
     "broadcast_div": broadcast_div,
 }
+
+# golden-vector coverage = the zoo above + the paper's examples at notebook size
+from paper_examples import PAPER  # noqa: E402
+
+GOLDEN_ZOO = dict(ZOO)
+GOLDEN_ZOO.update(PAPER)

@@ -4,10 +4,10 @@ import numpy as np
 import pytest
 
 from golden_util import build_canonical, check_oracles_against_golden, load_golden
-from problem_zoo import ZOO
+from problem_zoo import GOLDEN_ZOO
 
 
-@pytest.mark.parametrize("name", sorted(ZOO))
+@pytest.mark.parametrize("name", sorted(GOLDEN_ZOO))
 def test_standard_form_matches_reference(name):
     g = load_golden(name)
     data, inv = build_canonical(name)
@@ -22,7 +22,7 @@ def test_standard_form_matches_reference(name):
     np.testing.assert_array_equal(data["cu"], g["cu"])
 
 
-@pytest.mark.parametrize("name", sorted(ZOO))
+@pytest.mark.parametrize("name", sorted(GOLDEN_ZOO))
 def test_tape_oracles_match_reference(name):
     from oracle.tape_eval import TapeEvaluator
     g = load_golden(name)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from golden_util import build_canonical, check_oracles_against_golden, load_golden
-from problem_zoo import ZOO
+from problem_zoo import GOLDEN_ZOO, ZOO
 
 pytestmark = pytest.mark.gpu
 
@@ -35,7 +35,7 @@ def _device_problem(name):
     return data, blob, _capi.DeviceProblem(blob, data["tape"], device=0)
 
 
-@pytest.mark.parametrize("name", sorted(ZOO))
+@pytest.mark.parametrize("name", sorted(GOLDEN_ZOO))
 def test_device_oracles_match_reference_golden(name, gpu_required):
     """f, grad f, g, Jacobian, Hessian of the HIP tape kernels vs vectors captured from the
     reference's Oracles (tolerance 1e-12 relative, FP64)."""

@@ -8,6 +8,7 @@ at K seeded points inside the bounds, f, grad f, g, Jacobian values, Hessian val
 seeded (lambda, sigma).  The fixtures are data only; no reference source travels.
 
     python tools/make_golden.py            # rewrites tests/golden/
+    python tools/make_golden.py nb_power_flow nb_path_planning    # only these
 """
 import os
 import sys
@@ -36,10 +37,13 @@ def sample_point(rng, x0, lb, ub):
 
 def main():
     cp = import_reference()
-    from problem_zoo import ZOO
+    from problem_zoo import GOLDEN_ZOO
     out_dir = os.path.join(HERE, "..", "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
-    for name, builder in ZOO.items():
+    only = set(sys.argv[1:])
+    for name, builder in GOLDEN_ZOO.items():
+        if only and name not in only:
+            continue
         prob = builder(cp)
         data, inv, chain = ref_chain_apply(cp, prob)
         o = data["oracles"]
