@@ -55,6 +55,11 @@ class CApi:
         f("ipm_finish", C.c_int, [C.c_void_p] + [_dbl_p] * 6 + [C.POINTER(C.c_int)])
         f("get_stats", C.c_int, [C.c_void_p, _dbl_p, C.c_int])
         f("get_log", C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t])
+        if hasattr(self.lib, prefix + "solve_batch"):      # product library only (no oracle batch path)
+            _int_p = C.POINTER(C.c_int)
+            f("batch_stride", C.c_int64, [C.c_void_p])
+            f("solve_batch", C.c_int, [C.c_void_p, C.c_int, _dbl_p, C.c_int64] + [_dbl_p] * 5 +
+              [_int_p] * 3 + [_dbl_p])
 
     def _fn(self, name, restype, argtypes):
         fn = getattr(self.lib, self.prefix + name)
@@ -270,6 +275,40 @@ class ProblemHandle:
         status = self.api.ipm_finish(self.ptr, _dp(x), C.byref(obj), _dp(g), _dp(mg), _dp(zl), _dp(zu),
                                      C.byref(iters))
         return self._info(status, x, obj, g, mg, zl, zu, iters)
+
+    def solve_batch(self, data, want_duals: bool = False):
+        """Solve `data.shape[0]` instances that share this handle's tape structure in ONE kernel
+        launch (one workgroup per instance, csrc/batch.h).  `data`: (B, stride) float64, rows laid
+        out as dnlp_amd.batch.BATCH_DATA_KEYS.  Returns arrays over the batch."""
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        B, stride = data.shape
+        need = int(self.api.batch_stride(self.ptr))
+        if need < 0:
+            raise RuntimeError("solve_batch: %s" % self.api.error())
+        if stride != need:
+            raise ValueError("solve_batch: rows have %d values, the tape needs %d" % (stride, need))
+        x = np.empty((B, self.n))
+        obj = np.empty(B)
+        mg = np.empty((B, max(self.m, 1))) if want_duals else None
+        zl = np.empty((B, self.n)) if want_duals else None
+        zu = np.empty((B, self.n)) if want_duals else None
+        status = np.empty(B, dtype=np.int32)
+        iters = np.empty(B, dtype=np.int32)
+        nfact = np.empty(B, dtype=np.int32)
+        sec = C.c_double()
+        _int_p = C.POINTER(C.c_int)
+        ip = lambda a: a.ctypes.data_as(_int_p)
+        rc = self.api.solve_batch(self.ptr, B, _dp(data), stride, _dp(x), _dp(obj),
+                                  _dp(mg) if want_duals else None, _dp(zl) if want_duals else None,
+                                  _dp(zu) if want_duals else None, ip(status), ip(iters), ip(nfact),
+                                  C.cast(C.byref(sec), _dbl_p))
+        if rc != 0:
+            raise RuntimeError("solve_batch failed: %s" % self.api.error())
+        out = {"x": x, "obj_val": obj, "status": status, "iterations": iters, "factorizations": nfact,
+               "kernel_seconds": float(sec.value)}
+        if want_duals:
+            out.update({"mult_g": mg[:, :self.m], "mult_x_L": zl, "mult_x_U": zu})
+        return out
 
     def log(self) -> str:
         need = self.api.get_log(self.ptr, None, 0)

@@ -16,6 +16,199 @@ from typing import Callable, List, Sequence, Tuple
 import numpy as np
 
 
+# ---- batched device solve: shared tape structure, per-instance data (csrc/batch.h) -------------
+# Order of the per-instance data vector handed to dnlp_solve_batch.
+BATCH_DATA_KEYS = ("c0", "c", "b", "Jc", "G_val", "Mg_val", "Mw_val", "MJ_val", "MH_val",
+                   "seg_param", "seg_param2", "x0", "lb", "ub", "cl", "cu")
+
+
+def lower_arrays(problem):
+    """Front-end only (no device): Problem -> (tape arrays, data dict, inverse data, flipped)."""
+    from .dnlp2smooth import Dnlp2Smooth
+    from .nlp_solver import build_nlp_data
+    from .problem import Maximize, Minimize, Problem
+    flip = isinstance(problem.objective, Maximize)
+    if flip:
+        problem_min = Problem(Minimize(-problem.objective.expr), problem.constraints)
+    else:
+        problem_min = problem
+    smooth, _ = Dnlp2Smooth().apply(problem_min)
+    data, inv = build_nlp_data(smooth, user_variables=problem.variables())
+    return data["tape_arrays"], data, inv, flip
+
+
+def instance_data(arrays) -> np.ndarray:
+    return np.concatenate([np.asarray(arrays[k], dtype=np.float64).ravel() for k in BATCH_DATA_KEYS])
+
+
+def same_structure(a0, a) -> bool:
+    """Everything that is not per-instance data (index arrays, segment table, constants of
+    quad_forms) must be identical for instances to share one tape."""
+    if set(a0) != set(a):
+        return False
+    for k in a0:
+        if k in BATCH_DATA_KEYS:
+            if a0[k].shape != a[k].shape:
+                return False
+        elif not np.array_equal(a0[k], a[k]):
+            return False
+    return True
+
+
+def arrays_with_data(arrays0, vec):
+    """Inverse of instance_data on the structure of `arrays0` (tests: rebuild an instance's tape)."""
+    out = dict(arrays0)
+    o = 0
+    for k in BATCH_DATA_KEYS:
+        n = arrays0[k].size
+        out[k] = np.asarray(vec[o:o + n], dtype=np.float64).reshape(arrays0[k].shape)
+        o += n
+    return out
+
+
+class BatchResult:
+    """Arrays over the batch plus per-variable access in the user's variable shapes."""
+
+    def __init__(self, raw, inv, flip):
+        self.x = raw["x"]
+        self.obj_val = -raw["obj_val"] if flip else raw["obj_val"]
+        self.status = raw["status"]
+        self.iterations = raw["iterations"]
+        self.factorizations = raw.get("factorizations")
+        self.kernel_seconds = raw.get("kernel_seconds")
+        self.raw = raw
+        self._inv = inv
+
+    def value_of(self, var) -> np.ndarray:
+        off = self._inv.var_offsets[var.id]
+        flat = self.x[:, off:off + var.size]
+        return np.stack([r.reshape(var.shape, order="F") for r in flat]) if var.shape else flat[:, 0]
+
+
+def _device_handle(arrays, tape, device, opts):
+    from . import _capi
+    from .nlp_solver import HIPNLP
+    from .tape import serialize
+    h = _capi.DeviceProblem(serialize(arrays), tape, device=device)
+    options = dict(HIPNLP.DEFAULT_OPTIONS)
+    options.update(opts)
+    options.pop("algorithm", None)
+    for k, v in options.items():
+        h.set_option(k, v)
+    return h
+
+
+def solve_batch(problems: Sequence, device=None, want_duals=False, **opts) -> BatchResult:
+    """Solve independent Problems that lower to the same tape structure in one kernel launch.
+    Every problem is lowered on the host (the generic path; ParametricBatch avoids that)."""
+    lowered = [lower_arrays(p) for p in problems]
+    a0, data0, inv0, flip0 = lowered[0]
+    for a, _, _, flip in lowered[1:]:
+        if flip != flip0 or not same_structure(a0, a):
+            raise ValueError("solve_batch: the problems do not share one tape structure")
+    mat = np.stack([instance_data(a) for a, _, _, _ in lowered])
+    h = _device_handle(a0, data0["tape"], device, opts)
+    try:
+        raw = h.solve_batch(mat, want_duals=want_duals)
+    finally:
+        h.close()
+    return BatchResult(raw, inv0, flip0)
+
+
+class ParametricBatch:
+    """One Problem written with `Parameter` leaves, many parameter values.
+
+    The tape data of a parametrised DNLP problem is (in all the paper's examples) an affine
+    function of the parameter vector: the map is recovered by P + 1 host lowerings (one per
+    parameter entry) and CHECKED on a random probe; instances are then generated as one sparse
+    matrix product instead of B Python lowerings.  A problem whose data is not affine in its
+    parameters (e.g. a product of two parameters) falls back to per-instance lowering."""
+
+    def __init__(self, problem, parameters: Sequence, seed: int = 0):
+        import scipy.sparse as sp
+        self.problem = problem
+        self.params = list(parameters)
+        self.sizes = [int(p.size) for p in self.params]
+        self.P = int(sum(self.sizes))
+        for p in self.params:
+            if p.value is None:
+                raise ValueError("ParametricBatch: every parameter needs a value (the base point)")
+        self.theta0 = self._get()
+        self.arrays0, self.data0, self.inv, self.flip = lower_arrays(problem)
+        self.d0 = instance_data(self.arrays0)
+        cols, rows, vals = [], [], []
+        self.affine = True
+        for k in range(self.P):
+            th = self.theta0.copy()
+            th[k] += 1.0
+            dk = self._lower_at(th)
+            if dk is None:
+                self.affine = False
+                break
+            fin = np.isfinite(dk) & np.isfinite(self.d0)
+            if not np.array_equal(dk[~fin], self.d0[~fin]):     # an infinite bound that moves
+                self.affine = False
+                break
+            diff = np.where(fin, dk, 0.0) - np.where(fin, self.d0, 0.0)
+            nz = np.flatnonzero(diff)
+            rows.extend(nz.tolist())
+            cols.extend([k] * nz.size)
+            vals.extend(diff[nz].tolist())
+        if self.affine:
+            self.D = sp.csr_matrix((vals, (rows, cols)), shape=(self.d0.size, self.P))
+            rng = np.random.default_rng(seed)
+            th = self.theta0 + rng.uniform(-1.0, 1.0, self.P)
+            probe = self._lower_at(th)
+            pred = self.d0 + self.D @ (th - self.theta0)
+            scale = 1.0 + np.abs(probe[np.isfinite(probe)]).max() if probe is not None and probe.size else 1.0
+            if probe is None or not np.allclose(pred, probe, rtol=1e-10, atol=1e-10 * scale):
+                self.affine = False
+        self._set(self.theta0)
+
+    def _get(self):
+        return np.concatenate([np.asarray(p.value, dtype=float).reshape(-1, order="F") for p in self.params]) \
+            if self.params else np.zeros(0)
+
+    def _set(self, theta):
+        o = 0
+        for p, n in zip(self.params, self.sizes):
+            p.value = np.asarray(theta[o:o + n], dtype=float).reshape(p.shape, order="F")
+            o += n
+
+    def _lower_at(self, theta):
+        self._set(theta)
+        a, _, _, flip = lower_arrays(self.problem)
+        if flip != self.flip or not same_structure(self.arrays0, a):
+            return None
+        return instance_data(a)
+
+    def data(self, thetas) -> np.ndarray:
+        """(B, P) parameter values (each row: the parameters flattened F-order, concatenated in
+        the order given to the constructor) -> (B, stride) instance data."""
+        thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
+        if thetas.shape[1] != self.P:
+            raise ValueError("expected %d parameter values per instance" % self.P)
+        if self.affine:
+            return self.d0[None, :] + (self.D @ (thetas - self.theta0[None, :]).T).T
+        rows = []
+        for th in thetas:
+            d = self._lower_at(th)
+            if d is None:
+                raise ValueError("ParametricBatch: an instance changes the tape structure")
+            rows.append(d)
+        self._set(self.theta0)
+        return np.stack(rows)
+
+    def solve(self, thetas, device=None, want_duals=False, **opts) -> BatchResult:
+        mat = self.data(thetas)
+        h = _device_handle(self.arrays0, self.data0["tape"], device, opts)
+        try:
+            raw = h.solve_batch(mat, want_duals=want_duals)
+        finally:
+            h.close()
+        return BatchResult(raw, self.inv, self.flip)
+
+
 def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     per = math.ceil(n_items / world) if world > 0 else n_items
     lo = min(rank * per, n_items)

@@ -1,0 +1,207 @@
+// Batched solve: B instances of one tape structure, one workgroup per instance, the whole
+// interior-point loop inside one kernel (exec_block.h).  BASELINE config C5 / SURVEY.md §8e.
+//
+// Instance data layout handed over by the host language (dnlp_amd/batch.py), `stride` doubles
+// per instance, in this order:
+//   c0(1) c(N+Z) b(m) Jc(nnzJ) G_val Mg_val Mw_val MJ_val MH_val seg_param(nseg) seg_param2(nseg)
+//   x0(N) lb(N) ub(N) cl(m) cu(m)
+// Everything else (index arrays, segment table, sparse quad_form constants) is shared and comes
+// from the tape the problem handle was created with.
+#pragma once
+#include <algorithm>
+#include <vector>
+
+#include "exec_block.h"
+#include "exec_hip.h"
+#include "ipm_core.h"
+#include "kkt_dense.h"
+
+namespace dnlp {
+
+struct BatchLayout {
+  i64 c0 = 0, c = 0, b = 0, Jc = 0, G = 0, Mg = 0, Mw = 0, MJ = 0, MH = 0, fp = 0, fp2 = 0, x0 = 0, lb = 0, ub = 0,
+      cl = 0, cu = 0, total = 0;
+};
+
+struct BatchArgs {
+  TapeView base;
+  BatchLayout lay;
+  double* slabs = nullptr;       // batch x lay.total
+  int batch = 0;
+  char* ws = nullptr;            // gridDim.x x ws_per_block
+  size_t ws_per_block = 0;
+  unsigned lds_bytes = 0;        // dynamic LDS pool for the KKT matrix (0: keep it in global memory)
+  IpmOptions opt;
+  double *x_out = nullptr, *obj_out = nullptr, *multg_out = nullptr, *zl_out = nullptr, *zu_out = nullptr;
+  int *status_out = nullptr, *iters_out = nullptr, *nfact_out = nullptr;
+};
+
+__global__ void __launch_bounds__(kBatchThreads) batch_solve_kernel(BatchArgs a) {
+  extern __shared__ __align__(64) char lds_dyn[];
+  __shared__ double s_red[8];
+  __shared__ int s_redi[8];
+  using KktT = DenseKkt<BlockExec>;
+  for (int inst = blockIdx.x; inst < a.batch; inst += gridDim.x) {
+    BlockExec ex(a.ws + static_cast<size_t>(blockIdx.x) * a.ws_per_block, a.ws_per_block, lds_dyn, a.lds_bytes, s_red, s_redi);
+    double* sl = a.slabs + static_cast<i64>(inst) * a.lay.total;
+    TapeView t = a.base;
+    t.c0 = sl[a.lay.c0];
+    t.c = sl + a.lay.c; t.b = sl + a.lay.b; t.Jc = sl + a.lay.Jc;
+    t.G.val = sl + a.lay.G; t.Mg.val = sl + a.lay.Mg; t.Mw.val = sl + a.lay.Mw; t.MJ.val = sl + a.lay.MJ;
+    t.MH.val = sl + a.lay.MH; t.flat_p = sl + a.lay.fp; t.flat_p2 = sl + a.lay.fp2;
+    t.d_x0 = sl + a.lay.x0; t.d_lb = sl + a.lay.lb; t.d_ub = sl + a.lay.ub; t.d_cl = sl + a.lay.cl; t.d_cu = sl + a.lay.cu;
+    Model<BlockExec> md;
+    md.init_view(&ex, t);
+    KktT kkt;
+    kkt.pivot_max_n = static_cast<i64>(1) << 40;   // always the pivoted (Bunch-Kaufman) factorisation
+    kkt.init(&ex, t.N, t.m);
+    Ipm<BlockExec, KktT> ipm(&ex, &md, &kkt);
+    ipm.opt = a.opt;
+    ipm.allocate();
+    int st = Internal_Error;
+    if (!ex.overflow) {
+      st = ipm.solve(t.d_x0);
+      if (ipm.initialized)
+        ipm.extract_exec(a.x_out + static_cast<i64>(inst) * t.N, a.multg_out ? a.multg_out + static_cast<i64>(inst) * t.m : nullptr,
+                         a.zl_out ? a.zl_out + static_cast<i64>(inst) * t.N : nullptr,
+                         a.zu_out ? a.zu_out + static_cast<i64>(inst) * t.N : nullptr, nullptr);
+    }
+    if (threadIdx.x == 0) {
+      a.status_out[inst] = st;
+      a.iters_out[inst] = ipm.iter;
+      a.obj_out[inst] = ipm.initialized ? ipm.objective_unscaled() : 0.0;
+      if (a.nfact_out) a.nfact_out[inst] = ipm.stats.factorizations;
+    }
+    __syncthreads();
+  }
+}
+
+// Host side: tables uploaded once per problem handle, slabs per call.
+struct BatchRunner {
+  HipExec* ex = nullptr;
+  Tape<HipExec>* tape = nullptr;
+  SegHost* d_segs = nullptr;
+  i64* d_red = nullptr;
+  SparseConst* d_sparse = nullptr;
+  BatchLayout lay;
+  i64 in_stride = 0;
+  std::vector<void*> scratch;
+
+  ~BatchRunner() { release(); if (d_segs) hipFree(d_segs); if (d_red) hipFree(d_red); if (d_sparse) hipFree(d_sparse); }
+  void release() { for (void* p : scratch) hipFree(p); scratch.clear(); }
+  template <class T> T* dalloc(size_t n) {
+    void* p = nullptr;
+    DNLP_HIP_CHECK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+    scratch.push_back(p);
+    return static_cast<T*>(p);
+  }
+
+  void init(HipExec* e, Tape<HipExec>* t) {
+    ex = e; tape = t;
+    if (t->nblk > 0 || t->ndense > 0)
+      throw std::runtime_error("batched solve: tapes with dense quad_form blocks are solved one at a time (dnlp_solve)");
+    auto up = [&](auto** dst, const auto* src, size_t n) {
+      using T = std::remove_pointer_t<std::remove_pointer_t<decltype(dst)>>;
+      DNLP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(dst), (n ? n : 1) * sizeof(T)));
+      if (n) DNLP_HIP_CHECK(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    };
+    up(&d_segs, t->h_segs.data(), t->h_segs.size());
+    up(&d_red, t->h_red_segs.data(), t->h_red_segs.size());
+    up(&d_sparse, t->h_sparse.data(), t->h_sparse.size());
+    i64 o = 0;
+    auto take = [&](i64& f, i64 n) { f = o; o += n; };
+    take(lay.c0, 1); take(lay.c, t->N + t->Z); take(lay.b, t->m); take(lay.Jc, t->nnzJ);
+    take(lay.G, t->G.nnz); take(lay.Mg, t->Mg.nnz); take(lay.Mw, t->Mw.nnz); take(lay.MJ, t->MJ.nnz); take(lay.MH, t->MH.nnz);
+    take(lay.fp, t->nflat); take(lay.fp2, t->nflat);
+    take(lay.x0, t->N); take(lay.lb, t->N); take(lay.ub, t->N); take(lay.cl, t->m); take(lay.cu, t->m);
+    lay.total = o;
+    in_stride = 1 + (t->N + t->Z) + t->m + t->nnzJ + t->G.nnz + t->Mg.nnz + t->Mw.nnz + t->MJ.nnz + t->MH.nnz +
+                2 * t->nseg + 3 * t->N + 2 * t->m;
+  }
+
+  // data: batch x stride (host).  Outputs: host arrays (mult_g / zl / zu may be null).
+  void solve(int batch, const double* data, i64 stride, const IpmOptions& opt, double* x_out, double* obj_out,
+             double* multg_out, double* zl_out, double* zu_out, int* status_out, int* iters_out, int* nfact_out,
+             double* seconds) {
+    if (stride != in_stride) throw std::runtime_error("batched solve: instance stride does not match the tape");
+    const Tape<HipExec>& t = *tape;
+    DNLP_HIP_CHECK(hipSetDevice(ex->device));
+    // host gather: the per-segment parameters become per-flat-row parameters
+    std::vector<double> slab(static_cast<size_t>(batch) * static_cast<size_t>(lay.total));
+    const i64 head = 1 + (t.N + t.Z) + t.m + t.nnzJ + t.G.nnz + t.Mg.nnz + t.Mw.nnz + t.MJ.nnz + t.MH.nnz;
+    const i64 tail = 3 * t.N + 2 * t.m;
+    for (int k = 0; k < batch; ++k) {
+      const double* src = data + static_cast<i64>(k) * stride;
+      double* dst = slab.data() + static_cast<i64>(k) * lay.total;
+      std::copy(src, src + head, dst);
+      const double *sp = src + head, *sp2 = sp + t.nseg;
+      for (i64 f = 0; f < t.nflat; ++f) {
+        dst[lay.fp + f] = sp[t.h_flat_seg[static_cast<size_t>(f)]];
+        dst[lay.fp2 + f] = sp2[t.h_flat_seg[static_cast<size_t>(f)]];
+      }
+      std::copy(sp2 + t.nseg, sp2 + t.nseg + tail, dst + lay.x0);
+    }
+    release();
+    BatchArgs a;
+    a.base = t;           // slice: the view with the shared exec-space index arrays
+    a.base.segs = d_segs; a.base.red_segs = d_red; a.base.sparse = d_sparse;
+    a.base.dense_ptr = nullptr; a.base.dense_ld = nullptr; a.base.blocks = nullptr;
+    a.lay = lay;
+    a.batch = batch;
+    a.opt = opt;
+    a.slabs = dalloc<double>(slab.size());
+    DNLP_HIP_CHECK(hipMemcpy(a.slabs, slab.data(), slab.size() * sizeof(double), hipMemcpyHostToDevice));
+    const i64 n = t.N + t.m, ld = (n + 7) / 8 * 8;
+    // KKT matrix in LDS when it fits beside the static reduction scratch (160 KB per workgroup)
+    const size_t kbytes = ((static_cast<size_t>(ld) * n + 256) * 8 + 63) & ~static_cast<size_t>(63);
+    const size_t lds_max = 160 * 1024 - 1024;
+    a.lds_bytes = kbytes <= lds_max ? static_cast<unsigned>(kbytes) : 0u;
+    const size_t wdoubles = static_cast<size_t>(40 * t.N + 48 * t.m + 2 * t.Z + t.nd + t.nh + t.nnzH + t.nnzJ + 2 * n + 512) +
+                            (a.lds_bytes ? 0 : static_cast<size_t>(ld) * n + 256);
+    a.ws_per_block = (wdoubles * 8 + 160 * 64 + 255) & ~static_cast<size_t>(255);
+    DNLP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(batch_solve_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(a.lds_bytes)));
+    int per_cu = 1, ncu = 256;
+    DNLP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, batch_solve_kernel, kBatchThreads, a.lds_bytes));
+    hipDeviceProp_t prop;
+    DNLP_HIP_CHECK(hipGetDeviceProperties(&prop, ex->device));
+    ncu = prop.multiProcessorCount;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 4) per_cu = 4;
+    const int grid = std::min(batch, ncu * per_cu);
+    a.ws = dalloc<char>(static_cast<size_t>(grid) * a.ws_per_block);
+    a.x_out = dalloc<double>(static_cast<size_t>(batch) * t.N);
+    a.obj_out = dalloc<double>(static_cast<size_t>(batch));
+    a.multg_out = multg_out ? dalloc<double>(static_cast<size_t>(batch) * t.m) : nullptr;
+    a.zl_out = zl_out ? dalloc<double>(static_cast<size_t>(batch) * t.N) : nullptr;
+    a.zu_out = zu_out ? dalloc<double>(static_cast<size_t>(batch) * t.N) : nullptr;
+    a.status_out = dalloc<int>(static_cast<size_t>(batch));
+    a.iters_out = dalloc<int>(static_cast<size_t>(batch));
+    a.nfact_out = dalloc<int>(static_cast<size_t>(batch));
+    hipEvent_t e0, e1;
+    DNLP_HIP_CHECK(hipEventCreate(&e0));
+    DNLP_HIP_CHECK(hipEventCreate(&e1));
+    DNLP_HIP_CHECK(hipEventRecord(e0, ex->stream));
+    hipLaunchKernelGGL(batch_solve_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBatchThreads), a.lds_bytes, ex->stream, a);
+    DNLP_LAUNCH_CHECK();
+    DNLP_HIP_CHECK(hipEventRecord(e1, ex->stream));
+    DNLP_HIP_CHECK(hipStreamSynchronize(ex->stream));
+    float ms = 0.f;
+    DNLP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (seconds) *seconds = 1e-3 * ms;
+    auto down = [&](void* h, const void* d, size_t bytes) { if (h && bytes) DNLP_HIP_CHECK(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost)); };
+    down(x_out, a.x_out, sizeof(double) * static_cast<size_t>(batch) * t.N);
+    down(obj_out, a.obj_out, sizeof(double) * batch);
+    down(multg_out, a.multg_out, sizeof(double) * static_cast<size_t>(batch) * t.m);
+    down(zl_out, a.zl_out, sizeof(double) * static_cast<size_t>(batch) * t.N);
+    down(zu_out, a.zu_out, sizeof(double) * static_cast<size_t>(batch) * t.N);
+    down(status_out, a.status_out, sizeof(int) * batch);
+    down(iters_out, a.iters_out, sizeof(int) * batch);
+    down(nfact_out, a.nfact_out, sizeof(int) * batch);
+    release();
+  }
+};
+
+}  // namespace dnlp

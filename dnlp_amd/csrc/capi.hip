@@ -1,6 +1,7 @@
 // libdnlp_hip.so — the C ABI of include/dnlp_hip.h instantiated over the HIP execution space.
 #include "ldlt_blocked.h"
 #include "capi_impl.h"
+#include "batch.h"
 
 DNLP_DEFINE_CAPI(dnlp_, dnlp::HipExec)
 
@@ -12,6 +13,24 @@ int dnlp_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+// Batched solve (BASELINE C5): `batch` instances sharing the structure of p's tape; see batch.h
+// for the per-instance data layout.  One kernel launch, one workgroup per instance.
+int64_t dnlp_batch_stride(void* vp) {
+  auto* p = static_cast<dnlp_problem_t*>(vp);
+  BatchRunner r;
+  DNLP_TRY(r.init(&p->ex, p->model.owner); return r.in_stride;)
+}
+int dnlp_solve_batch(void* vp, int batch, const double* data, int64_t stride, double* x, double* obj, double* mult_g,
+                     double* mult_x_L, double* mult_x_U, int* status, int* iters, int* factorizations, double* seconds) {
+  auto* p = static_cast<dnlp_problem_t*>(vp);
+  DNLP_TRY(
+    BatchRunner r;
+    r.init(&p->ex, p->model.owner);
+    p->ex.sync();
+    r.solve(batch, data, stride, p->opt, x, obj, mult_g, mult_x_L, mult_x_U, status, iters, factorizations, seconds);
+    return 0;)
 }
 
 const char* dnlp_version(void) { return "dnlp_amd 0.1.0 (gfx950)"; }

@@ -33,6 +33,7 @@ struct ProblemT {
   bool swept = false, kkt_ready = false, time_kernels = false;
 
   explicit ProblemT(int device) : ex(device) {}
+  ~ProblemT() { model.destroy(); }
 
   void create(const void* data, size_t len) {
     blob.reset(new TapeBlob(data, len));
@@ -138,9 +139,9 @@ struct ProblemT {
   void DNLP_CAT(PFX, destroy)(void* vp) { delete static_cast<DNLP_CAT(PFX, problem_t)*>(vp); }      \
   int DNLP_CAT(PFX, bind_dense)(void* vp, int cid, const double* dptr, int64_t ld) {                 \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
-    auto& t = p->model.t;                                                                            \
-    if (cid < 0 || cid >= static_cast<int>(t.dense_ptr.size())) { dnlp::tls_error() = "bad constant id"; return -1; } \
-    t.dense_ptr[cid] = dptr; t.dense_ld[cid] = ld; return 0;                                         \
+    auto& t = *p->model.owner;                                                                       \
+    if (cid < 0 || cid >= static_cast<int>(t.h_dense_ptr.size())) { dnlp::tls_error() = "bad constant id"; return -1; } \
+    t.h_dense_ptr[cid] = dptr; t.h_dense_ld[cid] = ld; return 0;                                     \
   }                                                                                                  \
   int DNLP_CAT(PFX, dims)(void* vp, int64_t* n, int64_t* m, int64_t* nj, int64_t* nh) {              \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
@@ -150,9 +151,9 @@ struct ProblemT {
   }                                                                                                  \
   int DNLP_CAT(PFX, bounds)(void* vp, double* lb, double* ub, double* cl, double* cu, double* x0) {  \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
-    auto& t = p->model.t;                                                                            \
+    auto& t = *p->model.owner;                                                                       \
     auto cp = [](double* d, const std::vector<double>& s) { if (d && !s.empty()) std::memcpy(d, s.data(), s.size() * 8); }; \
-    cp(lb, t.lb); cp(ub, t.ub); cp(cl, t.cl); cp(cu, t.cu); cp(x0, t.x0); return 0;                  \
+    cp(lb, t.h_lb); cp(ub, t.h_ub); cp(cl, t.h_cl); cp(cu, t.h_cu); cp(x0, t.h_x0); return 0;        \
   }                                                                                                  \
   int DNLP_CAT(PFX, eval_f)(void* vp, const double* x, int new_x, double* f) {                       \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
@@ -170,7 +171,7 @@ struct ProblemT {
   }                                                                                                  \
   int DNLP_CAT(PFX, eval_jac_g)(void* vp, const double* x, int new_x, int32_t* iRow, int32_t* jCol, double* vals) { \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
-    auto& t = p->model.t;                                                                            \
+    auto& t = *p->model.owner;                                                                       \
     DNLP_TRY(                                                                                        \
       if (!vals) {                                                                                   \
         if (iRow) std::memcpy(iRow, t.h_jac_rows.data(), 4 * t.h_jac_rows.size());                   \
@@ -183,7 +184,7 @@ struct ProblemT {
   int DNLP_CAT(PFX, eval_h)(void* vp, const double* x, int new_x, double sigma, const double* lambda, \
                             int new_lambda, int32_t* iRow, int32_t* jCol, double* vals) {            \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
-    auto& t = p->model.t;                                                                            \
+    auto& t = *p->model.owner;                                                                       \
     (void)new_lambda;                                                                                \
     DNLP_TRY(                                                                                        \
       if (!t.coo_complete) { dnlp::tls_error() = "Hessian too large for COO output; use dnlp_solve"; return -1; } \
@@ -254,7 +255,7 @@ struct ProblemT {
   size_t DNLP_CAT(PFX, get_log)(void* vp, char* buf, size_t cap) {                                   \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     std::string all;                                                                                 \
-    if (p->ipm) for (auto& l : p->ipm->log_lines) { all += l; all += '\n'; }                               \
+    if (p->ipm) for (auto& l : p->ipm->iterlog.lines) { all += l; all += '\n'; }                               \
     if (buf && cap) { size_t n = all.size() < cap - 1 ? all.size() : cap - 1; std::memcpy(buf, all.data(), n); buf[n] = 0; } \
     return all.size() + 1;                                                                           \
   }                                                                                                  \

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <stdexcept>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -20,11 +21,44 @@
 #define DNLP_HD
 #endif
 
+// DNLP_DEVICE_PASS is 1 while hipcc compiles the gfx950 side of a translation unit.  The
+// single-source classes are __host__ __device__ so that the batched solver (exec_block.h) can
+// run the whole interior-point loop inside one kernel, one workgroup per problem instance;
+// host-only facilities (exceptions, clocks, stdio) are compiled out of that pass.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DNLP_DEVICE_PASS 1
+#define DNLP_FAIL(msg) __builtin_trap()
+#else
+#define DNLP_DEVICE_PASS 0
+#define DNLP_FAIL(msg) throw std::runtime_error(msg)
+#endif
+
 namespace dnlp {
 
 using i64 = int64_t;
 using i32 = int32_t;
 
 constexpr double kInf = std::numeric_limits<double>::infinity();
+
+}  // namespace dnlp
+
+#include <string>
+#include <vector>
+
+namespace dnlp {
+
+// Traits shared by the execution spaces that are driven from the host (HostExec in oracle/,
+// HipExec in exec_hip.h): an iteration log, host-side control memory, host-only algorithm
+// variants (Lanczos bound, condensed multiplier start).
+struct HostControlled {
+  static constexpr bool has_log = true;
+  static constexpr bool has_host_control = true;
+  static constexpr int kFilterCap = 1024;
+  struct Log {
+    std::vector<std::string> lines;
+    void append(const Log& o) { lines.insert(lines.end(), o.lines.begin(), o.lines.end()); }
+  };
+  template <class T> T* ctl_alloc(size_t n) { return static_cast<T*>(std::calloc(n ? n : 1, sizeof(T))); }
+};
 
 }  // namespace dnlp

@@ -569,7 +569,7 @@ __global__ void __launch_bounds__(kBlock) v_axpy_kernel(int k, const double* __r
 
 struct BlockedLdlt;   // ldlt_blocked.h
 
-struct HipExec {
+struct HipExec : HostControlled {
   static constexpr bool is_device = true;
   using FlatTableT = FlatTable;
   int device = 0;

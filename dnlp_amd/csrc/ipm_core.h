@@ -64,9 +64,29 @@ struct IpmStats {
   double last_delta_w = 0.0;
 };
 
-inline double now_sec() {
+DNLP_HD inline double now_sec() {
+#if DNLP_DEVICE_PASS
+  return 0.0;     // no wall clock inside the batch kernel (max_wall_time is a host-side option)
+#else
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+#endif
 }
+
+// bound_push / bound_frac projection of one value into (l, u) (WB section 3.6)
+DNLP_HD inline double push_into_bounds1(double v, double l, double u, double k1, double k2) {
+  const bool hl = l > -kInf, hu = u < kInf;
+  if (hl && hu) {
+    if (l == u) return l;
+    const double pl = fmin(k1 * fmax(1.0, fabs(l)), k2 * (u - l));
+    const double pu = fmin(k1 * fmax(1.0, fabs(u)), k2 * (u - l));
+    return fmin(fmax(v, l + pl), u - pu);
+  }
+  if (hl) return fmax(v, l + k1 * fmax(1.0, fabs(l)));
+  if (hu) return fmin(v, u - k1 * fmax(1.0, fabs(u)));
+  return v;
+}
+
+struct D2 { double first, second; };
 
 // IPOPT ApplicationReturnStatus values (the integers of ipopt_nlpif.py:31-61)
 enum IpmStatus : int {
@@ -80,11 +100,11 @@ enum IpmStatus : int {
 template <class E, class K>
 class Ipm {
  public:
-  Ipm(E* ex, Model<E>* model, K* kkt) : ex_(ex), md_(model), kkt_(kkt) {}
+  DNLP_HD Ipm(E* ex, Model<E>* model, K* kkt) : ex_(ex), md_(model), kkt_(kkt) {}
 
   IpmOptions opt;
   IpmStats stats;
-  std::vector<std::string> log_lines;
+  typename E::Log iterlog;              // iteration table (host / HIP spaces); empty in the batch kernel
 
   // ---- problem data / iterate (exec space) ------------------------------------
   i64 N = 0, m = 0;
@@ -104,18 +124,21 @@ class Ipm {
   bool initialized = false;
   int status = Internal_Error;
   int iter = 0;
-  // filter
-  std::vector<std::pair<double, double>> filter;
+  // filter (WB section 2.3): fixed capacity, the oldest entry is evicted when full
+  static constexpr int kFilterCap = E::kFilterCap;
+  double filt_th[kFilterCap], filt_ph[kFilterCap];
+  int nfilt = 0;
   double theta_max = 1e4, theta_min = 1e-4;
   int acceptable_count = 0;
   double last_obj = 0.0;
   bool fixed_mode = false;            // adaptive strategy: currently in monotone (fixed) mode
-  std::vector<double> kkt_hist;
+  double kkt_hist[4];                 // kkt-error globalisation: last 4 free-mode values
+  int n_hist = 0;
 
   // ------------------------------------------------------------------------------
-  template <class T> T* A(i64 n) { return ex_->template alloc<T>(static_cast<size_t>(n > 0 ? n : 1)); }
+  template <class T> DNLP_HD T* A(i64 n) { return ex_->template alloc<T>(static_cast<size_t>(n > 0 ? n : 1)); }
 
-  void allocate() {
+  DNLP_HD void allocate() {
     N = md_->N(); m = md_->m();
     x = A<double>(N); s = A<double>(m); y = A<double>(m); zL = A<double>(N); zU = A<double>(N);
     vL = A<double>(m); vU = A<double>(m); xL = A<double>(N); xU = A<double>(N); sL = A<double>(m);
@@ -127,23 +150,34 @@ class Ipm {
     rx = A<double>(N); rs = A<double>(m); rp = A<double>(m); tN = A<double>(N); tM = A<double>(m);
     csoc = A<double>(m);
     zeroM = A<double>(m);
+    fixmask = A<double>(N);
+    ex_->zero(zeroM, sizeof(double) * static_cast<size_t>(m));
     const i64 sz[7] = {N, m, m, N, N, m, m};
     for (int k = 0; k < 7; ++k) { aff[k] = A<double>(sz[k]); cen[k] = A<double>(sz[k]); }
   }
 
-  void logf(const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    if (opt.print_level >= 5) { std::fputs(buf, stdout); std::fputc('\n', stdout); std::fflush(stdout); }
-    log_lines.emplace_back(buf);
+  template <class... Args> DNLP_HD void logf(const char* fmt, Args... args) {
+#if !DNLP_DEVICE_PASS
+    if constexpr (E::has_log) {
+      char buf[512];
+      std::snprintf(buf, sizeof buf, fmt, args...);
+      if (opt.print_level >= 5) { std::fputs(buf, stdout); std::fputc('\n', stdout); std::fflush(stdout); }
+      iterlog.lines.emplace_back(buf);
+    }
+#endif
+  }
+  DNLP_HD void filter_clear() { nfilt = 0; }
+  DNLP_HD void filter_add(double th, double ph) {
+    if (nfilt == kFilterCap) {
+      for (int k = 1; k < nfilt; ++k) { filt_th[k - 1] = filt_th[k]; filt_ph[k - 1] = filt_ph[k]; }
+      --nfilt;
+    }
+    filt_th[nfilt] = th; filt_ph[nfilt] = ph; ++nfilt;
   }
 
   // ---- evaluation helpers (scaled problem) --------------------------------------
   // f~(xp), g~(xp) -> returns false on non-finite values
-  bool eval_fg(const double* xp, double& fval, double* gout) {
+  DNLP_HD bool eval_fg(const double* xp, double& fval, double* gout) {
     double t0 = now_sec();
     md_->sweep(xp, false);
     fval = sf * md_->eval_f_after_sweep();
@@ -155,7 +189,7 @@ class Ipm {
     return std::isfinite(fval) && chk == 0.0;
   }
   // gradient and Jacobian values at the point of the last sweep (scaled)
-  void eval_derivs_after_sweep() {
+  DNLP_HD void eval_derivs_after_sweep() {
     double t0 = now_sec();
     md_->eval_grad_after_sweep(grad);
     md_->eval_jac_after_sweep(jv);
@@ -168,7 +202,7 @@ class Ipm {
     ex_->map(md_->t.nnzJ, [=] DNLP_HD(i64 p) { jvv[p] *= sgp[jr[p]]; });
     stats.t_eval += now_sec() - t0;
   }
-  void eval_hessian() {
+  DNLP_HD void eval_hessian() {
     double t0 = now_sec();
     const double* sgp = sg;
     const double* yy = y;
@@ -179,95 +213,102 @@ class Ipm {
   }
 
   // ---- initialisation (WB section 3.6) -------------------------------------------
-  int begin(const double* x0_host) {
+  // x0_ctl: control-space pointer (host memory for the host / HIP spaces)
+  DNLP_HD int begin(const double* x0_ctl) {
     double t_start = now_sec();
     if (!x) allocate();
-    const auto& T = md_->t;
-    std::vector<double> hx(x0_host, x0_host + N), lb(T.lb), ub(T.ub), cl(T.cl), cu(T.cu);
-    const double inf = opt.nlp_inf;
-    // bound relaxation (IPOPT bound_relax_factor; the reference sets it to 0)
-    if (opt.bound_relax_factor > 0) {
-      for (i64 j = 0; j < N; ++j) {
-        if (lb[j] > -inf) lb[j] -= std::min(1e-8 * 0 + opt.bound_relax_factor * std::max(1.0, std::fabs(lb[j])), 1e-3);
-        if (ub[j] < inf) ub[j] += std::min(opt.bound_relax_factor * std::max(1.0, std::fabs(ub[j])), 1e-3);
-      }
-    }
-    for (i64 j = 0; j < N; ++j) {
-      if (lb[j] <= -inf) lb[j] = -kInf;
-      if (ub[j] >= inf) ub[j] = kInf;
-      if (lb[j] > ub[j]) return status = Invalid_Option;
-    }
-    for (i64 i = 0; i < m; ++i) {
-      if (cl[i] <= -inf) cl[i] = -kInf;
-      if (cu[i] >= inf) cu[i] = kInf;
+    const TapeView& T = md_->t;
+    const double inf = opt.nlp_inf, brf = opt.bound_relax_factor;
+    const double k1 = opt.bound_push, k2 = opt.bound_frac;
+    const i64 NN = N;
+    // variable bounds: optional relaxation (IPOPT bound_relax_factor; the reference sets it to 0),
+    // |bound| >= nlp_inf means "no bound"
+    {
+      const double *lb = T.d_lb, *ub = T.d_ub, *cl = T.d_cl, *cu = T.d_cu;
+      double *l = xL, *u = xU, *sl = sL, *su = sU;
+      ex_->map(N, [=] DNLP_HD(i64 j) {
+        double a = lb[j], b = ub[j];
+        if (brf > 0) {
+          if (a > -inf) a -= fmin(brf * fmax(1.0, fabs(a)), 1e-3);
+          if (b < inf) b += fmin(brf * fmax(1.0, fabs(b)), 1e-3);
+        }
+        l[j] = a <= -inf ? -kInf : a;
+        u[j] = b >= inf ? kInf : b;
+      });
+      ex_->map(m, [=] DNLP_HD(i64 i) {
+        sl[i] = cl[i] <= -inf ? -kInf : cl[i];
+        su[i] = cu[i] >= inf ? kInf : cu[i];
+      });
+      const double badx = ex_->max(N, [=] DNLP_HD(i64 j) { return l[j] > u[j] ? 1.0 : 0.0; });
+      const double badc = m ? ex_->max(m, [=] DNLP_HD(i64 i) { return sl[i] > su[i] ? 1.0 : 0.0; }) : 0.0;
+      if (badx > 0.0 || badc > 0.0) return status = Invalid_Option;
     }
     // scaling at the user's starting point (IPOPT gradient-based scaling)
     sf = 1.0;
-    std::vector<double> hsg(static_cast<size_t>(m), 1.0);
-    ex_->h2d(sg, hsg.data(), sizeof(double) * static_cast<size_t>(m));
-    ex_->h2d(x, hx.data(), sizeof(double) * static_cast<size_t>(N));
+    {
+      double* sgp = sg;
+      ex_->map(m, [=] DNLP_HD(i64 i) { sgp[i] = 1.0; });
+    }
+    ex_->h2d(x, x0_ctl, sizeof(double) * static_cast<size_t>(N));
     if (opt.nlp_scaling) {
-      std::vector<double> px(hx);
-      push_into_bounds(px, lb, ub);
-      ex_->h2d(xt, px.data(), sizeof(double) * static_cast<size_t>(N));
+      const double *xx = x, *l = xL, *u = xU;
+      double* px = xt;
+      ex_->map(N, [=] DNLP_HD(i64 j) { px[j] = push_into_bounds1(xx[j], l[j], u[j], k1, k2); });
       md_->sweep(xt, false);
       md_->eval_grad_after_sweep(grad);
       md_->eval_jac_after_sweep(jv);
       const double* gr = grad;
-      double gmax = ex_->max(N, [=] DNLP_HD(i64 j) { return fabs(gr[j]); });
-      if (std::isfinite(gmax) && gmax > opt.nlp_scaling_max_gradient) sf = std::max(opt.nlp_scaling_max_gradient / gmax, 1e-8);
+      const double gmax = ex_->max(N, [=] DNLP_HD(i64 j) { return fabs(gr[j]); });
+      const double smax = opt.nlp_scaling_max_gradient;
+      if (std::isfinite(gmax) && gmax > smax) sf = std::max(smax / gmax, 1e-8);
       if (m > 0) {
-        std::vector<double> hj(static_cast<size_t>(T.nnzJ));
-        ex_->d2h(hj.data(), jv, sizeof(double) * hj.size());
-        std::vector<double> rmax(static_cast<size_t>(m), 0.0);
-        for (i64 p = 0; p < T.nnzJ; ++p) rmax[T.h_jac_rows[p]] = std::max(rmax[T.h_jac_rows[p]], std::fabs(hj[p]));
-        for (i64 i = 0; i < m; ++i)
-          if (std::isfinite(rmax[i]) && rmax[i] > opt.nlp_scaling_max_gradient)
-            hsg[i] = std::max(opt.nlp_scaling_max_gradient / rmax[i], 1e-8);
-        ex_->h2d(sg, hsg.data(), sizeof(double) * static_cast<size_t>(m));
+        const i64* rp_ = T.jac_rowptr;
+        const double* jvv = jv;
+        double* sgp = sg;
+        ex_->map(m, [=] DNLP_HD(i64 i) {
+          double rmax = 0.0;
+          bool fin = true;
+          for (i64 p = rp_[i]; p < rp_[i + 1]; ++p) { const double a = fabs(jvv[p]); if (!(a <= kInf) || a == kInf) fin = false; if (a > rmax) rmax = a; }
+          sgp[i] = (fin && rmax > smax) ? fmax(smax / rmax, 1e-8) : 1.0;
+        });
       }
     }
-    // scaled constraint bounds, equality mask, slack bounds
-    std::vector<double> hsL(m), hsU(m), heq(m);
-    for (i64 i = 0; i < m; ++i) {
-      hsL[i] = cl[i] * hsg[i];
-      hsU[i] = cu[i] * hsg[i];
-      heq[i] = (cl[i] == cu[i]) ? 1.0 : 0.0;
-      if (cl[i] > cu[i]) return status = Invalid_Option;
+    // scaled constraint bounds, equality mask, counts
+    {
+      double *sl = sL, *su = sU, *eq = eqmask;
+      const double* sgp = sg;
+      ex_->map(m, [=] DNLP_HD(i64 i) {
+        eq[i] = (sl[i] == su[i]) ? 1.0 : 0.0;
+        sl[i] *= sgp[i];
+        su[i] *= sgp[i];
+      });
+      const double *l = xL, *u = xU;
+      const i64 n_eq = m ? static_cast<i64>(ex_->sum(m, [=] DNLP_HD(i64 i) { return eq[i]; })) : 0;
+      const i64 n_free = static_cast<i64>(ex_->sum(N, [=] DNLP_HD(i64 j) { return l[j] == u[j] ? 0.0 : 1.0; }));
+      if (n_eq > n_free) return status = Not_Enough_Degrees_Of_Freedom;
+      kkt_->n_fixed = N - n_free;
     }
-    i64 n_eq = 0; for (i64 i = 0; i < m; ++i) n_eq += heq[i] != 0.0;
-    i64 n_free = 0; for (i64 j = 0; j < N; ++j) n_free += !(lb[j] == ub[j]);
-    if (n_eq > n_free) return status = Not_Enough_Degrees_Of_Freedom;
-    fixed_.assign(static_cast<size_t>(N), 0);
-    i64 nfix = 0;
-    for (i64 j = 0; j < N; ++j) if (lb[j] == ub[j]) { fixed_[j] = 1; hx[j] = lb[j]; ++nfix; }
-    kkt_->n_fixed = nfix;
-    push_into_bounds(hx, lb, ub);
-    ex_->h2d(x, hx.data(), sizeof(double) * static_cast<size_t>(N));
-    // fixed variables keep no bound multipliers: drop their bounds and pin them in the KKT
-    std::vector<double> lbe(lb), ube(ub), hfix(static_cast<size_t>(N), 0.0);
-    for (i64 j = 0; j < N; ++j) if (fixed_[j]) { lbe[j] = -kInf; ube[j] = kInf; hfix[j] = 1.0; }
-    fixmask = A<double>(N);
-    ex_->h2d(fixmask, hfix.data(), sizeof(double) * static_cast<size_t>(N));
-    ex_->h2d(xL, lbe.data(), sizeof(double) * static_cast<size_t>(N));
-    ex_->h2d(xU, ube.data(), sizeof(double) * static_cast<size_t>(N));
-    ex_->h2d(sL, hsL.data(), sizeof(double) * static_cast<size_t>(m));
-    ex_->h2d(sU, hsU.data(), sizeof(double) * static_cast<size_t>(m));
-    ex_->h2d(eqmask, heq.data(), sizeof(double) * static_cast<size_t>(m));
+    // start point pushed into the bounds; fixed variables (lb == ub) sit on their value, keep no
+    // bound multipliers (their bounds are dropped) and are pinned in the KKT system
+    {
+      double *xx = x, *l = xL, *u = xU, *fm = fixmask;
+      ex_->map(N, [=] DNLP_HD(i64 j) {
+        const bool fx = l[j] == u[j];
+        xx[j] = fx ? l[j] : push_into_bounds1(xx[j], l[j], u[j], k1, k2);
+        fm[j] = fx ? 1.0 : 0.0;
+        if (fx) { l[j] = -kInf; u[j] = kInf; }
+      });
+    }
+    nb_cache_ = -1;
     // evaluate at the pushed point
     if (!eval_fg(x, f, g)) return status = Invalid_Number_Detected;
     eval_derivs_after_sweep();
-    // slacks: s = d(x) pushed into [sL, sU]
-    std::vector<double> hg(m);
-    ex_->d2h(hg.data(), g, sizeof(double) * static_cast<size_t>(m));
-    std::vector<double> hs(hg);
+    // slacks: s = d(x) pushed into [sL, sU]; equality rows carry their right-hand side
     {
-      std::vector<double> l2(hsL), u2(hsU);
-      for (i64 i = 0; i < m; ++i) if (heq[i] != 0.0) { l2[i] = -kInf; u2[i] = kInf; }
-      push_into_bounds(hs, l2, u2);
-      for (i64 i = 0; i < m; ++i) if (heq[i] != 0.0) hs[i] = hsL[i];
+      double* ss = s;
+      const double *gg = g, *sl = sL, *su = sU, *eq = eqmask;
+      ex_->map(m, [=] DNLP_HD(i64 i) { ss[i] = eq[i] != 0.0 ? sl[i] : push_into_bounds1(gg[i], sl[i], su[i], k1, k2); });
     }
-    ex_->h2d(s, hs.data(), sizeof(double) * static_cast<size_t>(m));
     // bound multipliers
     {
       const double zi = opt.bound_mult_init_val;
@@ -279,11 +320,12 @@ class Ipm {
         d[i] = (eq[i] == 0.0 && su[i] < kInf) ? zi : 0.0;
       });
     }
+    (void)NN;
     mu = opt.mu_init;
     tau = std::max(0.99, 1.0 - mu);
     ex_->zero(y, sizeof(double) * static_cast<size_t>(m));
     if (m > 0 && opt.least_square_init_duals >= 0) init_multipliers_ls();
-    filter.clear();
+    filter_clear();
     double th0 = theta_at(g, s);
     theta_max = 1e4 * std::max(1.0, th0);
     theta_min = 1e-4 * std::max(1.0, th0);
@@ -291,7 +333,7 @@ class Ipm {
     acceptable_count = 0;
     delta_w_last = 0.0;
     fixed_mode = false;
-    kkt_hist.clear();
+    n_hist = 0;
     initialized = true;
     status = Internal_Error;
     stats = IpmStats();
@@ -300,37 +342,19 @@ class Ipm {
     return 0;
   }
 
-  void push_into_bounds(std::vector<double>& v, const std::vector<double>& l, const std::vector<double>& u) {
-    const double k1 = opt.bound_push, k2 = opt.bound_frac;
-    for (size_t j = 0; j < v.size(); ++j) {
-      const bool hl = l[j] > -kInf, hu = u[j] < kInf;
-      if (hl && hu) {
-        if (l[j] == u[j]) { v[j] = l[j]; continue; }
-        double pl = std::min(k1 * std::max(1.0, std::fabs(l[j])), k2 * (u[j] - l[j]));
-        double pu = std::min(k1 * std::max(1.0, std::fabs(u[j])), k2 * (u[j] - l[j]));
-        v[j] = std::min(std::max(v[j], l[j] + pl), u[j] - pu);
-      } else if (hl) {
-        v[j] = std::max(v[j], l[j] + k1 * std::max(1.0, std::fabs(l[j])));
-      } else if (hu) {
-        v[j] = std::min(v[j], u[j] - k1 * std::max(1.0, std::fabs(u[j])));
-      }
-    }
-  }
-
   // least-squares equality multipliers (WB eq. (36)); discarded above constr_mult_init_max
-  void init_multipliers_ls() {
+  DNLP_HD void init_multipliers_ls() {
     const double* eq = eqmask;
-    if (!kkt_->pivoted && m <= 8) {
+    if constexpr (E::has_host_control) if (!kkt_->pivoted && m <= 8) {
       // Few rows on a large system: the (1,1) block of the least-squares system is the identity,
       // so it condenses to the m x m system (J J^T + D) y = J r_x - r_y — no O(n^3) work.
       double* r = rhs;
       const double *gr = grad, *a = zL, *b = zU, *c = vL, *d = vU, *fm = fixmask;
       ex_->map(N, [=] DNLP_HD(i64 j) { r[j] = fm[j] != 0.0 ? 0.0 : -(gr[j] - a[j] + b[j]); });
-      std::vector<double> G(static_cast<size_t>(m * m), 0.0), bb(static_cast<size_t>(m), 0.0), heq(static_cast<size_t>(m));
-      std::vector<double> hc(static_cast<size_t>(m)), hd(static_cast<size_t>(m));
-      ex_->d2h(heq.data(), eqmask, sizeof(double) * static_cast<size_t>(m));
-      ex_->d2h(hc.data(), vL, sizeof(double) * static_cast<size_t>(m));
-      ex_->d2h(hd.data(), vU, sizeof(double) * static_cast<size_t>(m));
+      double G[64] = {0.0}, bb[8] = {0.0}, heq[8], hc[8], hd[8];
+      ex_->d2h(heq, eqmask, sizeof(double) * static_cast<size_t>(m));
+      ex_->d2h(hc, vL, sizeof(double) * static_cast<size_t>(m));
+      ex_->d2h(hd, vU, sizeof(double) * static_cast<size_t>(m));
       if (!lanQ) { lanQ = A<double>(static_cast<i64>(8) * N); }
       for (i64 i = 0; i < m; ++i) {
         double* e = tM;
@@ -373,7 +397,7 @@ class Ipm {
           ymax = std::fmax(ymax, std::fabs(bb[i]));
         }
         if (std::isfinite(ymax) && ymax <= opt.constr_mult_init_max)
-          ex_->h2d(y, bb.data(), sizeof(double) * static_cast<size_t>(m));
+          ex_->h2d(y, bb, sizeof(double) * static_cast<size_t>(m));
         return;
       }
     }
@@ -381,7 +405,7 @@ class Ipm {
     ex_->map(N, [=] DNLP_HD(i64 j) { sx[j] = 1.0; });
     ex_->map(m, [=] DNLP_HD(i64 i) { dd[i] = (eq[i] == 0.0) ? 1.0 : 0.0; });
     int nneg = 0, nzero = 0;
-    md_->dense_w.assign(md_->dense_w.size(), 0.0);
+    md_->clear_dense_w();
     ex_->zero(md_->Hs, sizeof(double) * static_cast<size_t>(md_->t.nnzH));
     bool ok = kkt_->assemble_factor(*md_, jv, Sx, Dd, fixmask, 0.0, &nneg, &nzero);
     stats.factorizations++;
@@ -408,11 +432,11 @@ class Ipm {
 
   // ---- measures -------------------------------------------------------------------
   // primal residual: g - cl for equalities, g - s for inequalities
-  double theta_at(const double* gg, const double* ss) {
+  DNLP_HD double theta_at(const double* gg, const double* ss) {
     const double *eq = eqmask, *sl = sL;
     return ex_->sum(m, [=] DNLP_HD(i64 i) { return fabs(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]); });
   }
-  double barrier_at(double fv, const double* xx, const double* ss, double muv) {
+  DNLP_HD double barrier_at(double fv, const double* xx, const double* ss, double muv) {
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *eq = eqmask;
     const double kd = opt.kappa_d;
     double bx = ex_->sum(N, [=] DNLP_HD(i64 j) {
@@ -438,7 +462,7 @@ class Ipm {
   }
 
   // dual residuals rx = grad + J^T y - zL + zU ; rs = -y - vL + vU (inequality rows)
-  void dual_residuals() {
+  DNLP_HD void dual_residuals() {
     md_->jac_tmult(jv, y, tN);
     double *r = rx, *q = rs;
     const double *gr = grad, *jt = tN, *a = zL, *b = zU, *c = vL, *d = vU, *yy = y, *eq = eqmask, *fm = fixmask;
@@ -449,7 +473,7 @@ class Ipm {
   struct Err { double dual, primal, cmpl, sd, sc, total; };
 
   // WB eq. (5): scaled optimality error for barrier parameter muv
-  Err error(double muv) {
+  DNLP_HD Err error(double muv) {
     dual_residuals();
     const double *r = rx, *q = rs, *gg = g, *ss = s, *eq = eqmask, *sl = sL, *su = sU, *l = xL, *u = xU,
                  *xx = x, *a = zL, *b = zU, *c = vL, *d = vU, *yy = y;
@@ -481,7 +505,7 @@ class Ipm {
     return e;
   }
 
-  i64 n_bound_mults() {
+  DNLP_HD i64 n_bound_mults() {
     if (nb_cache_ >= 0) return nb_cache_;
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *eq = eqmask;
     double c1 = ex_->sum(N, [=] DNLP_HD(i64 j) { return (l[j] > -kInf ? 1.0 : 0.0) + (u[j] < kInf ? 1.0 : 0.0); });
@@ -493,7 +517,7 @@ class Ipm {
 
   // ---- search direction (WB section 2.2 / 3.1) ---------------------------------------
   // Builds Sigma and the barrier right-hand sides for barrier parameter muv.
-  void barrier_terms(double muv) {
+  DNLP_HD void barrier_terms(double muv) {
     md_->jac_tmult(jv, y, tN);
     double *sx = Sx, *sS = Ss, *r = rx, *q = rs, *p = rp;
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *eq = eqmask, *xx = x, *ss = s, *a = zL, *b = zU,
@@ -534,7 +558,10 @@ class Ipm {
   // General case: H~ is a principal submatrix of K, so by Cauchy interlacing dw < -theta_(m+1)
   // of H~ itself is certain to fail.  Either way the doomed O(n^3) factorisations are skipped at
   // the price of k Hessian-vector products (k HBM sweeps).  Returns (lower bound, spectral width).
-  std::pair<double, double> lanczos_delta_lower_bound() {
+  DNLP_HD D2 lanczos_delta_lower_bound() {
+    if constexpr (!E::has_host_control) {
+      return {0.0, 0.0};
+    } else {
     const int kmax = 24, qmax = 8;
     if (N < 4 * kmax) return {0.0, 0.0};
     const double* eqm = eqmask;
@@ -562,7 +589,8 @@ class Ipm {
     }
     double cbuf[32];
     auto project = [&](double* v) { ex_->orthogonalize(nq, lanQ, N, v, cbuf); };
-    std::vector<double> al, be;
+    double al[24], be[24];
+    int nal = 0, nbe = 0;
     double* v0 = lanV;
     {
       // deterministic start vector with components in every direction
@@ -580,23 +608,23 @@ class Ipm {
       ex_->map(N, [=] DNLP_HD(i64 j) { w[j] = fm[j] != 0.0 ? 0.0 : w[j] + sx[j] * vk[j]; });
       project(w);
       const double a = ex_->sum(N, [=] DNLP_HD(i64 j) { return w[j] * vk[j]; });
-      al.push_back(a);
+      al[nal++] = a;
       // full reorthogonalisation against all previous vectors (classical Gram-Schmidt, twice):
       // two sweeps of w per pass instead of one reduction per stored vector
       for (int pass = 0; pass < 2; ++pass) ex_->orthogonalize(k + 1, lanV, N, w, cbuf);
       const double b = std::sqrt(ex_->sum(N, [=] DNLP_HD(i64 j) { return w[j] * w[j]; }));
       if (!(b > 1e-12 * (std::fabs(a) + 1.0)) || k + 1 == kmax) break;
-      be.push_back(b);
+      be[nbe++] = b;
       double* vn = lanV + static_cast<i64>(k + 1) * N;
       ex_->map(N, [=] DNLP_HD(i64 j) { vn[j] = w[j] / b; });
     }
     // wanted-th smallest eigenvalue of the k x k tridiagonal T by Sturm bisection
-    const int kk = static_cast<int>(al.size());
+    const int kk = nal;
     const int want = projected ? 1 : static_cast<int>(m) + 1;
     if (kk < want) return {0.0, 0.0};
     double lo = al[0], hi = al[0];
     for (int i = 0; i < kk; ++i) {
-      const double r = (i > 0 ? std::fabs(be[i - 1]) : 0.0) + (i < static_cast<int>(be.size()) ? std::fabs(be[i]) : 0.0);
+      const double r = (i > 0 ? std::fabs(be[i - 1]) : 0.0) + (i < nbe ? std::fabs(be[i]) : 0.0);
       lo = std::min(lo, al[i] - r);
       hi = std::max(hi, al[i] + r);
     }
@@ -618,10 +646,11 @@ class Ipm {
     }
     const double theta = hi;
     return {theta < 0.0 ? -theta : 0.0, width};
+    }
   }
 
   // one factorisation attempt: 0 ok, 1 wrong inertia, 2 singular
-  int try_factor(double dw, double dc) {
+  DNLP_HD int try_factor(double dw, double dc) {
     int nneg = 0, nzero = 0;
     double* dd = Dd;
     const double *sS = Ss, *eq = eqmask;
@@ -635,14 +664,14 @@ class Ipm {
     return nneg == m ? 0 : 1;
   }
 
-  bool factor_with_inertia(double& delta_w, double& delta_c) {
+  DNLP_HD bool factor_with_inertia(double& delta_w, double& delta_c) {
     const double dw_min = 1e-20, dw_0 = 1e-4, dw_max = 1e40, dc_bar = 1e-8, kwp = 8.0, kwpb = 100.0, kwm = 1.0 / 3.0, kc = 0.25;
     delta_w = 0.0; delta_c = 0.0;
     // large unpivoted systems: skip regularisation values that are provably too small
     double dw_lb = 0.0, dw_first = 0.0;
     bool have_lb = false;
     auto get_lb = [&]() {
-      auto lbw = lanczos_delta_lower_bound();
+      const D2 lbw = lanczos_delta_lower_bound();
       dw_lb = lbw.first;
       // first trial above the bound: Ritz values converge from above, so add 5% and 2% of the
       // spectral width (an over-regularisation of that size is harmless, a failed attempt is not)
@@ -683,7 +712,7 @@ class Ipm {
   }
 
   // K v for the reduced system at the current iterate (for iterative refinement)
-  void kkt_mult(const double* v, double dw, double* out) {
+  DNLP_HD void kkt_mult(const double* v, double dw, double* out) {
     md_->hess_mult(v, out);
     md_->jac_tmult(jv, v + N, tN);
     md_->jac_mult(jv, v, tM);
@@ -694,7 +723,7 @@ class Ipm {
   }
 
   // solve K sol = rhs with iterative refinement on the unfactored operator
-  bool solve_refined(double dw) {
+  DNLP_HD bool solve_refined(double dw) {
     double t0 = now_sec();
     kkt_->solve(rhs, sol);
     const double* rr = rhs;
@@ -731,7 +760,7 @@ class Ipm {
   }
 
   // direction for barrier parameter muv with primal residual `pres` (rp or the SOC one)
-  bool compute_direction(double muv, const double* pres, double dw, bool centering = false) {
+  DNLP_HD bool compute_direction(double muv, const double* pres, double dw, bool centering = false) {
     double* r = rhs;
     const double *rxx = rx, *q = rs, *sS = Ss, *eq = eqmask;
     const i64 NN = N;
@@ -762,7 +791,7 @@ class Ipm {
   }
 
   // fraction-to-boundary step sizes (WB eq. (15))
-  double max_step_primal(double tauv) {
+  DNLP_HD double max_step_primal(double tauv) {
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *ddx = dx, *dds = ds, *eq = eqmask;
     double ax = ex_->min(N, [=] DNLP_HD(i64 j) {
       double a = 1.0;
@@ -779,7 +808,7 @@ class Ipm {
     }) : 1.0;
     return std::min(1.0, std::min(ax, as));
   }
-  double max_step_dual(double tauv) {
+  DNLP_HD double max_step_dual(double tauv) {
     const double *a = zL, *b = zU, *c = vL, *d = vU, *da = dzL, *db = dzU, *dc = dvL, *dd2 = dvU;
     double az = ex_->min(N, [=] DNLP_HD(i64 j) {
       double t = 1.0;
@@ -796,15 +825,15 @@ class Ipm {
     return std::min(1.0, std::min(az, av));
   }
 
-  bool filter_ok(double th, double ph) const {
+  DNLP_HD bool filter_ok(double th, double ph) const {
     const double gth = 1e-5, gph = 1e-8;
-    for (auto& e : filter)
-      if (!(th <= (1.0 - gth) * e.first || ph <= e.second - gph * e.first)) return false;
+    for (int k = 0; k < nfilt; ++k)
+      if (!(th <= (1.0 - gth) * filt_th[k] || ph <= filt_ph[k] - gph * filt_th[k])) return false;
     return true;
   }
 
   // ---- convergence tests (IPOPT OptimalityErrorConvergenceCheck) ----------------------
-  int check_convergence(const Err& e0) {
+  DNLP_HD int check_convergence(const Err& e0) {
     double unsc_du = e0.dual / sf;
     const double *gg = g, *ss = s, *eq = eqmask, *sl = sL, *sgp = sg;
     double unsc_pr = m ? ex_->max(m, [=] DNLP_HD(i64 i) {
@@ -822,7 +851,7 @@ class Ipm {
   }
 
   // ---- one interior-point iteration; returns IPOPT status or 99 to continue -----------
-  int step() {
+  DNLP_HD int step() {
     if (!initialized) return status = Internal_Error;
     if (iter >= opt.max_iter) return status = Maximum_Iterations_Exceeded;
     if (now_sec() - t_begin_ > opt.max_wall_time) return status = Maximum_WallTime_Exceeded;
@@ -942,7 +971,7 @@ class Ipm {
       return status = (theta_k > opt.constr_viol_tol) ? Infeasible_Problem_Detected : Restoration_Failed;
     }
     // filter augmentation (WB eq. (22)) unless f-type step with Armijo
-    if (!ftype) filter.emplace_back((1.0 - g_th) * theta_k, phi_k - g_ph * theta_k);
+    if (!ftype) filter_add((1.0 - g_th) * theta_k, phi_k - g_ph * theta_k);
     // accept the trial point
     const double* ddx = dx;
     double dnorm = ex_->max(N, [=] DNLP_HD(i64 j) { return fabs(ddx[j]); });
@@ -954,14 +983,14 @@ class Ipm {
     return 99;
   }
 
-  void trial_point(double alpha) {
+  DNLP_HD void trial_point(double alpha) {
     double *a = xt, *b = st;
     const double *xx = x, *ss = s, *ddx = dx, *dds = ds, *eq = eqmask, *sl = sL;
     ex_->map(N, [=] DNLP_HD(i64 j) { a[j] = xx[j] + alpha * ddx[j]; });
     ex_->map(m, [=] DNLP_HD(i64 i) { b[i] = eq[i] != 0.0 ? sl[i] : ss[i] + alpha * dds[i]; });
   }
 
-  void accept_trial(double alpha, double a_z, double f_new) {
+  DNLP_HD void accept_trial(double alpha, double a_z, double f_new) {
     double *xx = x, *ss = s, *yy = y, *a = zL, *b = zU, *c = vL, *d = vU;
     const double *nx = xt, *ns = st, *ddy = dy, *da = dzL, *db = dzU, *dc = dvL, *dd2 = dvU;
     ex_->map(N, [=] DNLP_HD(i64 j) { xx[j] = nx[j]; a[j] += a_z * da[j]; b[j] += a_z * db[j]; });
@@ -976,7 +1005,7 @@ class Ipm {
   }
 
   // WB eq. (16): keep z within [mu/(kS (x-l)), kS mu/(x-l)]
-  void reset_bound_multipliers() {
+  DNLP_HD void reset_bound_multipliers() {
     const double kS = 1e10, muv = mu;
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *eq = eqmask;
     double *a = zL, *b = zU, *c = vL, *d = vU;
@@ -992,7 +1021,7 @@ class Ipm {
   }
 
   // WB section 2.4: up to max_soc corrections c_soc = alpha*c_soc + c(x + alpha d)
-  bool second_order_correction(double alpha, double dw, double theta_k, double phi_k, double gphid,
+  DNLP_HD bool second_order_correction(double alpha, double dw, double theta_k, double phi_k, double gphid,
                                double& th_t, double& ph_t, double& f_t, bool& ftype) {
     const double k_soc = 0.99, g_th = 1e-5, g_ph = 1e-8, dlt = 1.0, s_th = 1.1, s_ph = 2.3, eta = 1e-8;
     const double macheps = 2.220446049250313e-16;
@@ -1029,7 +1058,7 @@ class Ipm {
   }
 
   // ---- barrier parameter strategies --------------------------------------------------
-  double avg_complementarity() {
+  DNLP_HD double avg_complementarity() {
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *a = zL, *b = zU, *c = vL, *d = vU, *eq = eqmask;
     i64 nb = n_bound_mults();
     if (nb == 0) return 0.0;
@@ -1047,7 +1076,7 @@ class Ipm {
     return (cx + cs) / static_cast<double>(nb);
   }
 
-  void monotone_update() {
+  DNLP_HD void monotone_update() {
     const double k_eps = 10.0, k_mu = 0.2, th_mu = 1.5;
     const double mu_floor = std::max(opt.mu_min, std::min(opt.tol, opt.compl_inf_tol) / 11.0);
     for (int k = 0; k < 50; ++k) {
@@ -1057,7 +1086,7 @@ class Ipm {
         if (nm >= mu) break;
         mu = nm;
         tau = std::max(0.99, 1.0 - mu);
-        filter.clear();
+        filter_clear();
       } else {
         break;
       }
@@ -1076,30 +1105,32 @@ class Ipm {
   // relative to the last 4 free-mode iterates the algorithm runs the monotone (fixed) mode,
   // started at 0.8 * average complementarity, until it does.
   // Returns true when the free-mode oracle must be run after the factorisation.
-  bool update_mu(const Err& e0) {
+  DNLP_HD void hist_push(double v) {
+    if (n_hist == 4) { for (int k = 1; k < 4; ++k) kkt_hist[k - 1] = kkt_hist[k]; --n_hist; }
+    kkt_hist[n_hist++] = v;
+  }
+  DNLP_HD bool update_mu(const Err& e0) {
     if (n_bound_mults() == 0) { tau = 0.99; return false; }   // no barrier terms at all
     if (opt.mu_strategy == 0) { monotone_update(); return false; }
     const double mu_floor = std::max(opt.mu_min, std::min(opt.tol, opt.compl_inf_tol) / 11.0);
     double kkt = e0.dual + e0.primal + e0.cmpl;
     if (!fixed_mode) {
-      bool ok = kkt_hist.empty();
-      for (double h : kkt_hist) if (kkt <= 0.9999 * h) ok = true;
+      bool ok = n_hist == 0;
+      for (int k = 0; k < n_hist; ++k) if (kkt <= 0.9999 * kkt_hist[k]) ok = true;
       if (ok) {
-        kkt_hist.push_back(kkt);
-        if (kkt_hist.size() > 4) kkt_hist.erase(kkt_hist.begin());
+        hist_push(kkt);
       } else {
         fixed_mode = true;
         mu = std::max(mu_floor, std::min(0.8 * avg_complementarity(), 1e5));
         tau = std::max(0.99, 1.0 - mu);
-        filter.clear();
+        filter_clear();
       }
     } else {
       bool ok = false;
-      for (double h : kkt_hist) if (kkt <= 0.9999 * h) ok = true;
-      if (ok || kkt_hist.empty()) {
+      for (int k = 0; k < n_hist; ++k) if (kkt <= 0.9999 * kkt_hist[k]) ok = true;
+      if (ok || n_hist == 0) {
         fixed_mode = false;
-        kkt_hist.push_back(kkt);
-        if (kkt_hist.size() > 4) kkt_hist.erase(kkt_hist.begin());
+        hist_push(kkt);
       }
     }
     if (fixed_mode) { monotone_update(); return false; }
@@ -1111,7 +1142,7 @@ class Ipm {
   // is the linearised KKT error after the fraction-to-boundary step; golden section in
   // log(sigma), mu = sigma * average complementarity.  On success the search direction for the
   // chosen mu is already in dx..dvU and rx/rs hold the residuals for that mu.
-  bool quality_function_mu(double dw) {
+  DNLP_HD bool quality_function_mu(double dw) {
     const double avg = avg_complementarity();
     const i64 nb = n_bound_mults();
     if (!(avg > 0.0) || nb == 0) return false;
@@ -1236,7 +1267,7 @@ class Ipm {
     if (!std::isfinite(nm)) return false;
     mu = nm;
     tau = std::max(0.99, 1.0 - mu);
-    filter.clear();                   // free mode: every iteration is a new barrier problem
+    filter_clear();                   // free mode: every iteration is a new barrier problem
     barrier_terms(mu);                // residuals for the chosen mu (line search, SOC)
     const double muv = mu;
     for (int k = 0; k < 7; ++k) {
@@ -1251,9 +1282,9 @@ class Ipm {
   // Minimises the constraint violation with damped Gauss-Newton steps in (x, s) that keep
   // the iterate strictly inside its bounds, until the point is acceptable to the filter and
   // reduces the violation by the factor 0.9.
-  bool restoration_phase(double theta_k) {
+  DNLP_HD bool restoration_phase(double theta_k) {
     const double phi_k = barrier_at(f, x, s, mu);
-    filter.emplace_back((1.0 - 1e-5) * theta_k, phi_k - 1e-8 * theta_k);
+    filter_add((1.0 - 1e-5) * theta_k, phi_k - 1e-8 * theta_k);
     double th_cur = theta_k;
     double zeta = std::sqrt(mu);
     for (int it = 0; it < 100; ++it) {
@@ -1264,7 +1295,7 @@ class Ipm {
       ex_->map(N, [=] DNLP_HD(i64 j) { sx[j] = zz; });
       // minimise 1/2|r + J dx - ds|^2 + zeta/2 |dx|^2 + zeta/2 |ds|^2  ->  D = 1 (+ 1/zeta for slacks)
       ex_->map(m, [=] DNLP_HD(i64 i) { dd[i] = 1.0 + (eq[i] == 0.0 ? 1.0 / zz : 0.0); });
-      md_->dense_w.assign(md_->dense_w.size(), 0.0);
+      md_->clear_dense_w();
       ex_->zero(md_->Hs, sizeof(double) * static_cast<size_t>(md_->t.nnzH));
       int nneg = 0, nzero = 0;
       if (!kkt_->assemble_factor(*md_, jv, Sx, Dd, fixmask, 0.0, &nneg, &nzero)) return false;
@@ -1322,9 +1353,9 @@ class Ipm {
   }
 
   // ---- driver -------------------------------------------------------------------------
-  int solve(const double* x0_host) {
+  DNLP_HD int solve(const double* x0_ctl) {
     const double t_all = now_sec();
-    int rc = begin(x0_host);
+    int rc = begin(x0_ctl);
     if (rc != 0) return rc;
     while (true) {
       int r = step();
@@ -1337,9 +1368,9 @@ class Ipm {
          status == Error_In_Step_Computation || status == Search_Direction_Becomes_Too_Small)) {
       const int it_first = iter;
       logf("adaptive barrier strategy ended with status %d after %d iterations: restarting in monotone mode", status, iter);
-      std::vector<std::string> keep = log_lines;
+      typename E::Log keep = iterlog;
       opt.mu_strategy = 0;
-      rc = begin(x0_host);
+      rc = begin(x0_ctl);
       if (rc == 0) {
         while (true) {
           int r = step();
@@ -1349,39 +1380,51 @@ class Ipm {
       opt.mu_strategy = 1;
       iter += it_first;
       stats.iterations = iter;
-      keep.insert(keep.end(), log_lines.begin(), log_lines.end());
-      log_lines = keep;
+      keep.append(iterlog);
+      iterlog = keep;
     }
     stats.wall = now_sec() - t_all;
     stats.final_mu = mu;
     return status;
   }
 
-  // unscaled results to host buffers (any may be null)
-  void extract(double* xo, double* obj, double* mult_g, double* mult_xL, double* mult_xU, double* gout) {
-    std::vector<double> hy(m), hsg(m), ha(N), hb(N), hg(m);
+  // unscaled results into exec-space arrays (any may be null); `res` / `cor` are free between steps
+  DNLP_HD void extract_exec(double* xo, double* mult_g, double* mult_xL, double* mult_xU, double* gout) {
+    const double sff = sf;
+    const double *xx = x, *yy = y, *sgp = sg, *a = zL, *b = zU, *gg = g;
+    if (xo) ex_->map(N, [=] DNLP_HD(i64 j) { xo[j] = xx[j]; });
+    if (mult_g) ex_->map(m, [=] DNLP_HD(i64 i) { mult_g[i] = yy[i] * sgp[i] / sff; });
+    if (gout) ex_->map(m, [=] DNLP_HD(i64 i) { gout[i] = gg[i] / sgp[i]; });
+    if (mult_xL) ex_->map(N, [=] DNLP_HD(i64 j) { mult_xL[j] = a[j] / sff; });
+    if (mult_xU) ex_->map(N, [=] DNLP_HD(i64 j) { mult_xU[j] = b[j] / sff; });
+  }
+  DNLP_HD double objective_unscaled() const { return f / sf; }
+
+  // unscaled results to control-space buffers (any may be null)
+  DNLP_HD void extract(double* xo, double* obj, double* mult_g, double* mult_xL, double* mult_xU, double* gout) {
     if (xo) ex_->d2h(xo, x, sizeof(double) * static_cast<size_t>(N));
-    if (obj) *obj = f / sf;
-    ex_->d2h(hy.data(), y, sizeof(double) * static_cast<size_t>(m));
-    ex_->d2h(hsg.data(), sg, sizeof(double) * static_cast<size_t>(m));
-    ex_->d2h(ha.data(), zL, sizeof(double) * static_cast<size_t>(N));
-    ex_->d2h(hb.data(), zU, sizeof(double) * static_cast<size_t>(N));
-    ex_->d2h(hg.data(), g, sizeof(double) * static_cast<size_t>(m));
-    for (i64 i = 0; i < m; ++i) {
-      if (mult_g) mult_g[i] = hy[i] * hsg[i] / sf;
-      if (gout) gout[i] = hg[i] / hsg[i];
-    }
-    for (i64 j = 0; j < N; ++j) {
-      if (mult_xL) mult_xL[j] = ha[j] / sf;
-      if (mult_xU) mult_xU[j] = hb[j] / sf;
+    if (obj) *obj = objective_unscaled();
+    extract_exec(nullptr, mult_g ? res : nullptr, mult_xL ? cor : nullptr, nullptr, gout ? cor + N : nullptr);
+    if (mult_g) ex_->d2h(mult_g, res, sizeof(double) * static_cast<size_t>(m));
+    if (gout) ex_->d2h(gout, cor + N, sizeof(double) * static_cast<size_t>(m));
+    if (mult_xL) ex_->d2h(mult_xL, cor, sizeof(double) * static_cast<size_t>(N));
+    if (mult_xU) {
+      extract_exec(nullptr, nullptr, nullptr, cor, nullptr);
+      ex_->d2h(mult_xU, cor, sizeof(double) * static_cast<size_t>(N));
     }
   }
 
-  void log_iter(const Err& e, double dnorm, double dw, double a_du, double a_pr, int ls) {
-    char rg[16];
-    if (dw > 0) std::snprintf(rg, sizeof rg, "%5.1f", std::log10(dw)); else std::snprintf(rg, sizeof rg, "    -");
-    logf("%4d %14.7e %8.2e %8.2e %5.1f %8.2e %s %8.2e %8.2e %3d%s", iter, f / sf, e.primal, e.dual,
-         std::log10(std::max(mu, 1e-300)), dnorm, rg, a_du, a_pr, ls, ls < 0 ? "r" : "");
+  DNLP_HD void log_iter(const Err& e, double dnorm, double dw, double a_du, double a_pr, int ls) {
+#if !DNLP_DEVICE_PASS
+    if constexpr (E::has_log) {
+      char rg[16];
+      if (dw > 0) std::snprintf(rg, sizeof rg, "%5.1f", std::log10(dw)); else std::snprintf(rg, sizeof rg, "    -");
+      logf("%4d %14.7e %8.2e %8.2e %5.1f %8.2e %s %8.2e %8.2e %3d%s", iter, f / sf, e.primal, e.dual,
+           std::log10(std::max(mu, 1e-300)), dnorm, rg, a_du, a_pr, ls, ls < 0 ? "r" : "");
+    }
+#else
+    (void)e; (void)dnorm; (void)dw; (void)a_du; (void)a_pr; (void)ls;
+#endif
   }
 
   double* fixmask = nullptr;
@@ -1390,7 +1433,6 @@ class Ipm {
   E* ex_;
   Model<E>* md_;
   K* kkt_;
-  std::vector<char> fixed_;
   i64 nb_cache_ = -1;
   double last_ratio_ = 0.0;
   bool delta_w_used_last_iter_ = false;

@@ -26,7 +26,7 @@ struct DenseKkt {
   bool pivoted = true;
   typename E::LdltWork lw;
 
-  void init(E* e, i64 N_, i64 m_) {
+  DNLP_HD void init(E* e, i64 N_, i64 m_) {
     ex = e; N = N_; m = m_; n = N + m;
     ld = (n + 7) / 8 * 8;                       // 64-byte aligned columns
     K = ex->template alloc<double>(static_cast<size_t>(ld) * static_cast<size_t>(n) + 256);   // +slack: tile reads past the last row
@@ -38,23 +38,23 @@ struct DenseKkt {
   }
 
   // Assemble from the model's current Hessian (Hs + dense blocks) and factor.
-  bool assemble_factor(Model<E>& md, const double* jv, const double* Sx, const double* D,
+  DNLP_HD bool assemble_factor(Model<E>& md, const double* jv, const double* Sx, const double* D,
                        const double* fixmask, double dw, int* nneg, int* nzero) {
-    const Tape<E>& t = md.t;
+    const TapeView& t = md.t;
     double* Kp = K;
     const i64 ldk = ld, NN = N;
     // one dense block covering all of W lets us skip the memset of the n x n part
-    bool full_block = t.blocks.size() == 1 && t.blocks[0].n == N && N > 4096;
+    bool full_block = t.nblk == 1 && t.blocks[0].n == N && N > 4096;
     if (!full_block) {
       ex->zero(K, sizeof(double) * static_cast<size_t>(ld) * static_cast<size_t>(n));
     } else {
       const i64 mm = m, nn = n;
       ex->map(mm * nn, [=] DNLP_HD(i64 q) { Kp[(NN + q % mm) + (q / mm) * ldk] = 0.0; });
     }
-    for (size_t k = 0; k < t.blocks.size(); ++k) {
+    for (i64 k = 0; k < t.nblk; ++k) {
       const DenseBlock& B = t.blocks[k];
-      const double* P = t.dense_ptr[static_cast<size_t>(B.cid)];
-      const i64 ldp = t.dense_ld[static_cast<size_t>(B.cid)], nb = B.n, x0 = B.x0;
+      const double* P = t.dense_ptr[B.cid];
+      const i64 ldp = t.dense_ld[B.cid], nb = B.n, x0 = B.x0;
       const double wk = md.dense_w[k];
       ex->dense_block_add(Kp, ldk, x0, P, ldp, nb, wk, full_block);
     }
@@ -74,9 +74,10 @@ struct DenseKkt {
       else Kp[j + j * ldk] += Sx[j] + dw;
     });
     ex->map(m, [=] DNLP_HD(i64 i) { Kp[(NN + i) + (NN + i) * ldk] = -D[i]; });
-    if (n_fixed > 0 && !t.blocks.empty()) {
+    if (n_fixed > 0 && t.nblk > 0) {
       // fixed variables (lb == ub) inside a dense block: pin them (unit row / column)
-      for (const DenseBlock& B : t.blocks) {
+      for (i64 kb = 0; kb < t.nblk; ++kb) {
+        const DenseBlock& B = t.blocks[kb];
         const i64 nb = B.n, x0 = B.x0;
         ex->map(nb * nb, [=] DNLP_HD(i64 q) {
           const i64 r = x0 + q % nb, c = x0 + q / nb;
@@ -89,7 +90,7 @@ struct DenseKkt {
     return ex->ldlt_factor(lw, K, n, ld, ipiv, pivoted, nneg, nzero);
   }
 
-  void solve(const double* rhs, double* sol) {
+  DNLP_HD void solve(const double* rhs, double* sol) {
     if (sol != rhs) ex->d2d(sol, rhs, sizeof(double) * static_cast<size_t>(n));
     ex->ldlt_solve(lw, K, n, ld, ipiv, pivoted, sol);
   }

@@ -40,7 +40,7 @@ class ReducedLbfgs {
 
   // f and reduced gradient at the free variables xfree (exec space, nfree); returns false on NaN
   bool eval(const double* xfree, double& fval, double* gred) {
-    const Tape<E>& t = md_->t;
+    const TapeView& t = md_->t;
     const i64 N = t.N, m = t.m, nf = t.nfree;
     const i32 *fi = t.free_idx, *dv = t.def_var;
     double* xx = x;
@@ -77,7 +77,7 @@ class ReducedLbfgs {
   // returns 0 converged, -1 iteration limit, -13 invalid number at the start, 3 line search stuck
   int solve(const double* x0_host) {
     const double t0 = now_sec();
-    const Tape<E>& t = md_->t;
+    const TapeView& t = md_->t;
     if (!t.reducible) return -11;
     const i64 N = t.N, m = t.m, nf = t.nfree;
     if (!x) {

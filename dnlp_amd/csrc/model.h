@@ -23,7 +23,8 @@ namespace dnlp {
 template <class E>
 struct Model {
   E* ex = nullptr;
-  Tape<E> t;
+  TapeView t;                 // what the evaluators read (tape.h)
+  Tape<E>* owner = nullptr;   // the loaded tape behind `t` (host / HIP spaces); null inside the batch kernel
   // work arrays (exec space)
   double* xz = nullptr;     // [x; z]
   double* dvals = nullptr;
@@ -32,14 +33,21 @@ struct Model {
   double* sl = nullptr;     // [sigma; lambda]
   double* Hs = nullptr;     // nnzH sparse-part Hessian values
   double* tmpN = nullptr;   // N scratch (dense quad_form products)
-  std::vector<double> dense_w;   // host: current weight 2*w_z of every dense block
+  double* dense_w = nullptr;   // control space: current weight 2*w_z of every dense block
 
-  i64 N() const { return t.N; }
-  i64 m() const { return t.m; }
+  DNLP_HD i64 N() const { return t.N; }
+  DNLP_HD i64 m() const { return t.m; }
 
   void init(E* e, const TapeBlob& tb) {
+    owner = new Tape<E>();
+    owner->load(e, tb);
+    init_view(e, *owner);
+  }
+  void destroy() { delete owner; owner = nullptr; }
+
+  DNLP_HD void init_view(E* e, const TapeView& v) {
     ex = e;
-    t.load(e, tb);
+    t = v;
     xz = ex->template alloc<double>(static_cast<size_t>(t.N + t.Z));
     dvals = ex->template alloc<double>(static_cast<size_t>(t.nd));
     hvals = ex->template alloc<double>(static_cast<size_t>(t.nh));
@@ -47,11 +55,12 @@ struct Model {
     sl = ex->template alloc<double>(static_cast<size_t>(1 + t.m));
     Hs = ex->template alloc<double>(static_cast<size_t>(t.nnzH));
     tmpN = ex->template alloc<double>(static_cast<size_t>(t.N));
-    dense_w.assign(t.blocks.size(), 0.0);
+    dense_w = ex->template ctl_alloc<double>(static_cast<size_t>(t.nblk));
   }
+  DNLP_HD void clear_dense_w() { for (i64 k = 0; k < t.nblk; ++k) dense_w[k] = 0.0; }
 
   // y = base + M v   (base may be null)
-  void spmv(const Csr& M, const double* v, const double* base, double* y) {
+  DNLP_HD void spmv(const Csr& M, const double* v, const double* base, double* y) {
     const i64* ptr = M.ptr;
     const i32* idx = M.idx;
     const double* val = M.val;
@@ -63,7 +72,7 @@ struct Model {
   }
 
   // flat (elementwise-class) sweep: one work unit per output element
-  void sweep_flat(const double* x, bool with_h) {
+  DNLP_HD void sweep_flat(const double* x, bool with_h) {
     if (t.flat_units == 0) return;
     if constexpr (E::is_device) {
       // hand-written gfx950 kernel (exec_hip.h); the lambda below is the same arithmetic
@@ -147,9 +156,9 @@ struct Model {
   }
 
   // reduction-class segments: quad_form (dense / sparse), quad_over_lin
-  void sweep_reductions(const double* x, bool with_h) {
-    for (i64 sidx : t.red_segs) {
-      const SegHost& g = t.segs[static_cast<size_t>(sidx)];
+  DNLP_HD void sweep_reductions(const double* x, bool with_h) {
+    for (i64 rk = 0; rk < t.nred; ++rk) {
+      const SegHost& g = t.segs[t.red_segs[rk]];
       double* z = xz + t.N;
       const i32* gidx = t.gidx;
       const i64 n = g.n, a0b = g.a0_base, a0o = g.a0_off;
@@ -159,16 +168,16 @@ struct Model {
       const i64 zo = g.zoff;
       if (g.op == OP_QUAD_FORM_DENSE) {
         // quad_form.py:41-47 (x'Px), :154-160 (2Px); Hessian block 2wP stays dense
-        const double* P = t.dense_ptr[static_cast<size_t>(g.aux)];
-        if (!P) throw std::runtime_error("dense quad_form matrix not bound (dnlp_bind_dense)");
-        const i64 ld = t.dense_ld[static_cast<size_t>(g.aux)];
+        const double* P = t.dense_ptr[g.aux];
+        if (!P) DNLP_FAIL("dense quad_form matrix not bound (dnlp_bind_dense)");
+        const i64 ld = t.dense_ld[g.aux];
         const double* u = x + a0b;
         ex->gemv_sym(n, P, ld, u, tmpN);            // tmpN = P u
         const double* pu = tmpN;
         double val = ex->sum(n, [=] DNLP_HD(i64 i) { return u[i] * pu[i]; });
         ex->map(n, [=] DNLP_HD(i64 i) { dv[i] = 2.0 * pu[i]; if (i == 0) z[zo] = val; });
       } else if (g.op == OP_QUAD_FORM_SPARSE) {
-        const auto& sc = t.sparse[static_cast<size_t>(g.aux)];
+        const SparseConst& sc = t.sparse[g.aux];
         const Csr P = sc.P, PT = sc.PT;
         const double* hvc = sc.hv;
         const i64 nhv = sc.nh;
@@ -214,27 +223,27 @@ struct Model {
     }
   }
 
-  void set_x(const double* x) { ex->d2d(xz, x, static_cast<size_t>(t.N) * sizeof(double)); }
+  DNLP_HD void set_x(const double* x) { ex->d2d(xz, x, static_cast<size_t>(t.N) * sizeof(double)); }
 
   // values + first-derivative element arrays at x (x: exec space, N)
-  void sweep(const double* x, bool with_h) {
+  DNLP_HD void sweep(const double* x, bool with_h) {
     set_x(x);
     sweep_flat(xz, with_h);
     sweep_reductions(xz, with_h);
   }
 
   // ---- reference callback set (all pointers exec space) ------------------------
-  double eval_f_after_sweep() {
+  DNLP_HD double eval_f_after_sweep() {
     const double* cc = t.c;
     const double* v = xz;
     return t.c0 + ex->sum(t.N + t.Z, [=] DNLP_HD(i64 i) { return cc[i] * v[i]; });
   }
-  void eval_g_after_sweep(double* g) { spmv(t.G, xz, t.b, g); }
-  void eval_grad_after_sweep(double* grad) { spmv(t.Mg, dvals, t.c, grad); }
-  void eval_jac_after_sweep(double* jv) { spmv(t.MJ, dvals, t.Jc, jv); }
+  DNLP_HD void eval_g_after_sweep(double* g) { spmv(t.G, xz, t.b, g); }
+  DNLP_HD void eval_grad_after_sweep(double* grad) { spmv(t.Mg, dvals, t.c, grad); }
+  DNLP_HD void eval_jac_after_sweep(double* jv) { spmv(t.MJ, dvals, t.Jc, jv); }
 
   // Hessian of sigma f + lambda.g at x; sparse part -> Hs, dense block weights -> dense_w
-  void eval_hess(const double* x, double sigma, const double* lambda) {
+  DNLP_HD void eval_hess(const double* x, double sigma, const double* lambda) {
     double* s = sl;
     const i64 mm = t.m;
     ex->map(1 + mm, [=] DNLP_HD(i64 i) { s[i] = (i == 0) ? sigma : lambda[i - 1]; });
@@ -243,7 +252,7 @@ struct Model {
     spmv(t.MH, hvals, nullptr, Hs);
     {
       // only the block weights are needed on the host (one scalar per dense block)
-      for (size_t k = 0; k < t.blocks.size(); ++k) {
+      for (i64 k = 0; k < t.nblk; ++k) {
         double wz;
         ex->d2h(&wz, w + t.blocks[k].z, sizeof(double));
         dense_w[k] = 2.0 * wz;
@@ -252,13 +261,13 @@ struct Model {
   }
 
   // COO Hessian values (lower triangle, fixed pattern) into `out` (exec space, nnzH)
-  void hess_coo(double* out) {
-    if (!t.coo_complete) throw std::runtime_error("dense quad_form block too large for a COO Hessian; use the solver-level entry points");
+  DNLP_HD void hess_coo(double* out) {
+    if (!t.coo_complete) DNLP_FAIL("dense quad_form block too large for a COO Hessian; use the solver-level entry points");
     ex->d2d(out, Hs, static_cast<size_t>(t.nnzH) * sizeof(double));
-    for (size_t k = 0; k < t.blocks.size(); ++k) {
+    for (i64 k = 0; k < t.nblk; ++k) {
       const DenseBlock& B = t.blocks[k];
-      const double* P = t.dense_ptr[static_cast<size_t>(B.cid)];
-      const i64 ld = t.dense_ld[static_cast<size_t>(B.cid)];
+      const double* P = t.dense_ptr[B.cid];
+      const i64 ld = t.dense_ld[B.cid];
       const i64* pos = B.coo_pos;
       const double wk = dense_w[k];
       const i64 n = B.n;
@@ -274,7 +283,7 @@ struct Model {
   }
 
   // out = W v  (W = current Lagrangian Hessian, symmetric) ; v, out: exec space N
-  void hess_mult(const double* v, double* out) {
+  DNLP_HD void hess_mult(const double* v, double* out) {
     const i64 NN = t.N;
     ex->zero(out, static_cast<size_t>(NN) * sizeof(double));
     // sparse part: serial-safe scatter through a row-wise pass is not available in COO
@@ -283,10 +292,10 @@ struct Model {
     const i32 *hr = t.hess_rows, *hc = t.hess_cols;
     const double* hs = Hs;
     ex->coo_sym_mult(t.nnzH, hr, hc, hs, v, out);
-    for (size_t k = 0; k < t.blocks.size(); ++k) {
+    for (i64 k = 0; k < t.nblk; ++k) {
       const DenseBlock& B = t.blocks[k];
-      const double* P = t.dense_ptr[static_cast<size_t>(B.cid)];
-      const i64 ld = t.dense_ld[static_cast<size_t>(B.cid)];
+      const double* P = t.dense_ptr[B.cid];
+      const i64 ld = t.dense_ld[B.cid];
       ex->gemv_sym(B.n, P, ld, v + B.x0, tmpN);
       const double wk = dense_w[k];
       const double* pv = tmpN;
@@ -296,11 +305,11 @@ struct Model {
   }
 
   // out(m) = J v ; out(N) = J^T v with COO values jv on the fixed pattern
-  void jac_mult(const double* jv, const double* v, double* out) {
+  DNLP_HD void jac_mult(const double* jv, const double* v, double* out) {
     ex->zero(out, static_cast<size_t>(t.m) * sizeof(double));
     ex->coo_mult(t.nnzJ, t.jac_rows, t.jac_cols, jv, v, out, false);
   }
-  void jac_tmult(const double* jv, const double* v, double* out) {
+  DNLP_HD void jac_tmult(const double* jv, const double* v, double* out) {
     ex->zero(out, static_cast<size_t>(t.N) * sizeof(double));
     ex->coo_mult(t.nnzJ, t.jac_rows, t.jac_cols, jv, v, out, true);
   }

@@ -88,14 +88,18 @@ struct DenseBlock {
   i64* coo_pos = nullptr;    // exec space, n(n+1)/2 entries in tril_indices order (row-major)
 };
 
-// The lowered problem resident in exec space E.
-template <class E>
-struct Tape {
-  E* ex = nullptr;
+struct SparseConst { Csr P, PT; i64 nh = 0; double* hv = nullptr; };
+
+// Everything the evaluators (model.h) and the interior-point loop (ipm_core.h) read, as plain
+// pointers and counts: the same struct describes a tape loaded by Tape<E>::load below and one
+// instance of a batch inside the batched-solve kernel (exec_block.h).  "exec space" arrays live
+// where E::map runs; "control space" arrays are read by the code that drives E (host memory for
+// the host / HIP spaces, device memory inside the batch kernel).
+struct TapeView {
   i64 N = 0, m = 0, Z = 0, nseg = 0, nd = 0, nh = 0, nnzJ = 0, nnzH = 0, ndense = 0, nsparse = 0,
       nblk = 0, coo_complete = 1;
-  std::vector<double> x0, lb, ub, cl, cu;      // host copies
-  std::vector<SegHost> segs;
+  // exec space: bounds and start of the canonical problem
+  double *d_x0 = nullptr, *d_lb = nullptr, *d_ub = nullptr, *d_cl = nullptr, *d_cu = nullptr;
   // flat (elementwise-class) segment table in exec space
   i64 nflat = 0, flat_units = 0;
   i64* flat_start = nullptr;   // nflat+1 prefix of work units
@@ -105,25 +109,47 @@ struct Tape {
   i64 *flat_zoff = nullptr, *flat_doff = nullptr, *flat_hoff = nullptr, *flat_n = nullptr;
   i64 *flat_d0 = nullptr, *flat_d1 = nullptr, *flat_d2 = nullptr;
   double *flat_p = nullptr, *flat_p2 = nullptr;
-  std::vector<i64> red_segs;   // indices of reduction-class segments
   i32* gidx = nullptr;
   double c0 = 0.0;
   double *c = nullptr, *b = nullptr, *Jc = nullptr;
   Csr G, Mg, Mw, MJ, MH;
   i32 *jac_rows = nullptr, *jac_cols = nullptr, *hess_rows = nullptr, *hess_cols = nullptr;
-  std::vector<i32> h_jac_rows, h_jac_cols, h_hess_rows, h_hess_cols;
-  // constants
-  std::vector<i64> dense_n;
-  std::vector<const double*> dense_ptr;   // exec space, column-major
-  std::vector<i64> dense_ld;
-  std::vector<bool> dense_owned;
-  struct SparseConst { Csr P, PT; i64 nh = 0; double* hv = nullptr; };
-  std::vector<SparseConst> sparse;
-  std::vector<DenseBlock> blocks;
+  i64* jac_rowptr = nullptr;   // m+1: the Jacobian COO is row-major sorted
+  // control space: reduction-class segments, constants, dense Hessian blocks
+  const SegHost* segs = nullptr;
+  const i64* red_segs = nullptr;
+  i64 nred = 0;
+  const double** dense_ptr = nullptr;   // per dense constant: exec-space column-major matrix (or null until bound)
+  i64* dense_ld = nullptr;
+  const SparseConst* sparse = nullptr;
+  const DenseBlock* blocks = nullptr;
   // reduced-space structure (dnlp_amd/reduced.py): every constraint row defines one auxiliary variable
   bool reducible = false;
   i64 nfree = 0, red_depth = 0;
   i32 *def_var = nullptr, *free_idx = nullptr;
+
+  DNLP_HD bool dense_bound() const {
+    for (i64 k = 0; k < ndense; ++k) if (!dense_ptr[k]) return false;
+    return true;
+  }
+};
+
+// The lowered problem resident in exec space E: owner of the arrays behind a TapeView.
+template <class E>
+struct Tape : TapeView {
+  E* ex = nullptr;
+  std::vector<double> h_x0, h_lb, h_ub, h_cl, h_cu;      // host copies
+  std::vector<SegHost> h_segs;
+  std::vector<i64> h_red_segs;   // indices of reduction-class segments
+  std::vector<i64> h_flat_seg;   // segment index of every flat-table row
+  std::vector<i32> h_jac_rows, h_jac_cols, h_hess_rows, h_hess_cols;
+  // constants
+  std::vector<i64> dense_n;
+  std::vector<const double*> h_dense_ptr;   // exec space, column-major
+  std::vector<i64> h_dense_ld;
+  std::vector<bool> dense_owned;
+  std::vector<SparseConst> h_sparse;
+  std::vector<DenseBlock> h_blocks;
 
   template <class T> T* up(const T* src, size_t n) {
     T* d = ex->template alloc<T>(n);
@@ -147,11 +173,13 @@ struct Tape {
     N = d[0]; m = d[1]; Z = d[2]; nseg = d[3]; nd = d[4]; nh = d[5]; nnzJ = d[6]; nnzH = d[7];
     ndense = d[8]; nsparse = d[9]; nblk = d[10]; coo_complete = d[11];
     auto vec = [&](const char* k, i64 n) { const double* p = tb.f64(k); return std::vector<double>(p, p + n); };
-    x0 = vec("x0", N); lb = vec("lb", N); ub = vec("ub", N); cl = vec("cl", m); cu = vec("cu", m);
-    segs.resize(static_cast<size_t>(nseg));
+    h_x0 = vec("x0", N); h_lb = vec("lb", N); h_ub = vec("ub", N); h_cl = vec("cl", m); h_cu = vec("cu", m);
+    d_x0 = up(h_x0.data(), h_x0.size()); d_lb = up(h_lb.data(), h_lb.size()); d_ub = up(h_ub.data(), h_ub.size());
+    d_cl = up(h_cl.data(), h_cl.size()); d_cu = up(h_cu.data(), h_cu.size());
+    h_segs.resize(static_cast<size_t>(nseg));
     auto S = [&](const char* k) { return tb.i64s(std::string("seg_") + k); };
     for (i64 s = 0; s < nseg; ++s) {
-      SegHost& g = segs[static_cast<size_t>(s)];
+      SegHost& g = h_segs[static_cast<size_t>(s)];
       g.op = static_cast<int>(S("op")[s]); g.n = S("n")[s];
       g.a0_base = S("a0_base")[s]; g.a0_off = S("a0_off")[s]; g.a0_len = S("a0_len")[s];
       g.a1_base = S("a1_base")[s]; g.a1_off = S("a1_off")[s]; g.a1_len = S("a1_len")[s];
@@ -166,11 +194,12 @@ struct Tape {
     std::vector<double> fp, fp2;
     // OP_MATMUL (33) is elementwise-class (one unit per output entry) despite its opcode
     for (i64 s = 0; s < nseg; ++s) {
-      const SegHost& g = segs[static_cast<size_t>(s)];
+      const SegHost& g = h_segs[static_cast<size_t>(s)];
       bool flat = (g.op < 30) || (g.op == 33);
-      if (!flat) { red_segs.push_back(s); continue; }
+      if (!flat) { h_red_segs.push_back(s); continue; }
       i64 units = (g.op == 33) ? g.d0 * g.d2 : g.n;
       fs.push_back(fs.back() + units);
+      h_flat_seg.push_back(s);
       fop.push_back(g.op); a0b.push_back(g.a0_base); a0o.push_back(g.a0_off); a0l.push_back(g.a0_len);
       a1b.push_back(g.a1_base); a1o.push_back(g.a1_off); a1l.push_back(g.a1_len);
       zo.push_back(g.zoff); dof.push_back(g.doff); ho.push_back(g.hoff); nn.push_back(g.n);
@@ -200,37 +229,45 @@ struct Tape {
     h_jac_cols.assign(tb.i32s("jac_cols"), tb.i32s("jac_cols") + nnzJ);
     h_hess_rows.assign(tb.i32s("hess_rows"), tb.i32s("hess_rows") + nnzH);
     h_hess_cols.assign(tb.i32s("hess_cols"), tb.i32s("hess_cols") + nnzH);
+    {
+      std::vector<i64> rp(static_cast<size_t>(m + 1), 0);
+      for (i32 r : h_jac_rows) rp[static_cast<size_t>(r) + 1]++;
+      for (i64 i = 0; i < m; ++i) rp[static_cast<size_t>(i + 1)] += rp[static_cast<size_t>(i)];
+      for (i64 p = 1; p < nnzJ; ++p)
+        if (h_jac_rows[static_cast<size_t>(p)] < h_jac_rows[static_cast<size_t>(p - 1)]) throw std::runtime_error("tape Jacobian pattern is not row-major sorted");
+      jac_rowptr = up(rp.data(), rp.size());
+    }
     jac_rows = up(h_jac_rows.data(), h_jac_rows.size());
     jac_cols = up(h_jac_cols.data(), h_jac_cols.size());
     hess_rows = up(h_hess_rows.data(), h_hess_rows.size());
     hess_cols = up(h_hess_cols.data(), h_hess_cols.size());
     dense_n.assign(tb.i64s("dense_n"), tb.i64s("dense_n") + ndense);
-    dense_ptr.assign(static_cast<size_t>(ndense), nullptr);
-    dense_ld.assign(static_cast<size_t>(ndense), 0);
+    h_dense_ptr.assign(static_cast<size_t>(ndense), nullptr);
+    h_dense_ld.assign(static_cast<size_t>(ndense), 0);
     dense_owned.assign(static_cast<size_t>(ndense), false);
     for (i64 k = 0; k < ndense; ++k) {
       std::string nm = "dense" + std::to_string(k);
       if (tb.has(nm)) {
         i64 n = dense_n[static_cast<size_t>(k)];
-        dense_ptr[static_cast<size_t>(k)] = up(tb.f64(nm), static_cast<size_t>(n * n));
-        dense_ld[static_cast<size_t>(k)] = n;
+        h_dense_ptr[static_cast<size_t>(k)] = up(tb.f64(nm), static_cast<size_t>(n * n));
+        h_dense_ld[static_cast<size_t>(k)] = n;
         dense_owned[static_cast<size_t>(k)] = true;
       }
     }
-    sparse.resize(static_cast<size_t>(nsparse));
+    h_sparse.resize(static_cast<size_t>(nsparse));
     for (i64 k = 0; k < nsparse; ++k) {
       std::string nm = "sp" + std::to_string(k);
       i64 n = 0;
-      for (auto& g : segs) if (g.op == 31 && g.aux == k) n = g.n;
-      sparse[static_cast<size_t>(k)].P = up_csr(tb, nm, n, n);
-      sparse[static_cast<size_t>(k)].PT = up_csr(tb, nm + "T", n, n);
-      sparse[static_cast<size_t>(k)].nh = static_cast<i64>(tb.count(nm + "_hv"));
-      sparse[static_cast<size_t>(k)].hv = up(tb.f64(nm + "_hv"), tb.count(nm + "_hv"));
+      for (auto& g : h_segs) if (g.op == 31 && g.aux == k) n = g.n;
+      h_sparse[static_cast<size_t>(k)].P = up_csr(tb, nm, n, n);
+      h_sparse[static_cast<size_t>(k)].PT = up_csr(tb, nm + "T", n, n);
+      h_sparse[static_cast<size_t>(k)].nh = static_cast<i64>(tb.count(nm + "_hv"));
+      h_sparse[static_cast<size_t>(k)].hv = up(tb.f64(nm + "_hv"), tb.count(nm + "_hv"));
     }
-    blocks.resize(static_cast<size_t>(nblk));
+    h_blocks.resize(static_cast<size_t>(nblk));
     const i64* bl = nblk ? tb.i64s("dense_blocks") : nullptr;
     for (i64 k = 0; k < nblk; ++k) {
-      DenseBlock& B = blocks[static_cast<size_t>(k)];
+      DenseBlock& B = h_blocks[static_cast<size_t>(k)];
       B.seg = bl[6 * k]; B.cid = bl[6 * k + 1]; B.x0 = bl[6 * k + 2]; B.n = bl[6 * k + 3];
       B.z = bl[6 * k + 4]; B.has_pos = bl[6 * k + 5];
       if (B.has_pos) {
@@ -238,6 +275,10 @@ struct Tape {
         B.coo_pos = up(tb.i64s(nm), tb.count(nm));
       }
     }
+    // control-space views of the small host tables
+    segs = h_segs.data(); red_segs = h_red_segs.data(); nred = static_cast<i64>(h_red_segs.size());
+    dense_ptr = h_dense_ptr.data(); dense_ld = h_dense_ld.data();
+    sparse = h_sparse.data(); blocks = h_blocks.data();
     load_reduction(tb);
   }
 
@@ -250,10 +291,6 @@ struct Tape {
     free_idx = up(tb.i32s("free_idx"), tb.count("free_idx"));
   }
 
-  bool dense_bound() const {
-    for (auto p : dense_ptr) if (!p) return false;
-    return true;
-  }
 };
 
 }  // namespace dnlp

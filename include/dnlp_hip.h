@@ -86,6 +86,20 @@ int dnlp_ipm_finish(dnlp_problem* p, double* x, double* obj, double* g, double* 
  * failure, -11 when the tape has no reduced-space structure. */
 int dnlp_solve_reduced(dnlp_problem* p, double* x_inout, double* obj, int* iters, int* evals,
                        double* gnorm);
+/* Batched variant (SURVEY.md 8b "dnlp_solve_batch"; BASELINE config C5): `batch` independent
+ * instances that share the structure of p's tape and differ in data — the role of the
+ * reference's serial best_of / re-solve loop (problems/problem.py:1256-1269, which
+ * re-canonicalises and calls nlp.solve once per instance).  ONE kernel launch: one workgroup
+ * per instance runs the whole interior-point loop on the device (csrc/batch.h).
+ * data: batch x stride doubles, row layout
+ *   c0(1) c(N+Z) b(m) Jc(nnzJ) G_val Mg_val Mw_val MJ_val MH_val seg_param(nseg) seg_param2(nseg)
+ *   x0(N) lb(N) ub(N) cl(m) cu(m)            (stride = dnlp_batch_stride(p))
+ * Outputs are batch-major host arrays; mult_* may be NULL.  status[i] is the IPOPT status
+ * integer of instance i.  Options are the ones set with dnlp_set_option. */
+int64_t dnlp_batch_stride(dnlp_problem* p);
+int dnlp_solve_batch(dnlp_problem* p, int batch, const double* data, int64_t stride, double* x,
+                     double* obj, double* mult_g, double* mult_x_L, double* mult_x_U, int* status,
+                     int* iters, int* factorizations, double* kernel_seconds);
 /* Statistics of the last solve: stats[0..15] = iterations, factorizations, wall, t_eval,
  * t_factor, t_solve, mu, inf_pr, inf_du, compl, nlp_error, last_delta_w, ... */
 int dnlp_get_stats(dnlp_problem* p, double* stats, int n);

@@ -18,7 +18,7 @@
 
 namespace dnlp {
 
-struct HostExec {
+struct HostExec : HostControlled {
   static constexpr bool is_device = false;
   struct FlatTableT {};
   struct LdltWork { std::vector<double> d; int expect_neg = -1; bool time_updates = false; bool padded = false; };

@@ -50,3 +50,47 @@ def oracle_solver(problem, **opts):
     info = h.solve(data["x0"])
     obj = -info["obj_val"] if flip else info["obj_val"]
     return obj, info["status"], info["iterations"], info["x"]
+
+
+# ---- parametrised templates for the single-launch batch path (dnlp_amd.batch.ParametricBatch) ----
+def template_localization(m=10):
+    """Localization with anchors `a` (m x 2) and ranges `rho` (m) as Parameters.
+    Returns (problem, [a, rho], sample) with sample(i) -> flattened parameter row of instance i
+    (same draws as build_localization(i))."""
+    import dnlp_amd as cp
+    a = cp.Parameter((m, 2), name="a", value=np.zeros((m, 2)))
+    rho = cp.Parameter(m, name="rho", value=np.ones(m))
+    x = cp.Variable(2, name="x")
+    t = cp.Variable(m, name="t")
+    prob = cp.Problem(cp.Minimize(cp.sum_squares(t - rho)),
+                      [t == cp.sqrt(cp.sum(cp.square(x - a), axis=1))])
+
+    def sample(i):
+        rng = np.random.default_rng(i)
+        x_true = rng.uniform(-3, 3, 2)
+        av = rng.uniform(-5, 5, (m, 2))
+        rv = np.linalg.norm(av - x_true, axis=1)
+        return np.concatenate([av.reshape(-1, order="F"), rv])
+
+    return prob, [a, rho], sample, x
+
+
+def template_circle_packing(n=4):
+    """Circle packing with the squared centre distances' lower bounds R2[a,b] = (r_a + r_b)^2 and
+    the radii as Parameters (the tape data is affine in both)."""
+    import dnlp_amd as cp
+    pairs = [(a, b) for a in range(n - 1) for b in range(a + 1, n)]
+    R2 = cp.Parameter(len(pairs), name="R2", value=np.full(len(pairs), 4.0))
+    rad = cp.Parameter(n, name="rad", value=np.ones(n))
+    centers = cp.Variable((2, n), name="c")
+    cons = [cp.sum(cp.square(centers[:, a] - centers[:, b])) >= R2[k] for k, (a, b) in enumerate(pairs)]
+    centers.value = np.random.default_rng(0).uniform(-5.0, 5.0, (2, n))
+    prob = cp.Problem(cp.Minimize(cp.max(cp.norm_inf(centers, axis=0) + rad)), cons)
+
+    def sample(i):
+        rng = np.random.default_rng(i)
+        radius = rng.uniform(1.0, 3.0, n)
+        r2 = np.array([(radius[a] + radius[b]) ** 2 for a, b in pairs])
+        return np.concatenate([r2, radius])
+
+    return prob, [R2, rad], sample, centers

@@ -1,0 +1,136 @@
+"""Single-launch batch path (csrc/batch.h, dnlp_amd.batch.ParametricBatch / solve_batch):
+BASELINE config C5.  CPU: the affine parameter -> tape-data map against direct lowering.
+GPU: every instance of a batch against the CPU oracle solving that instance's own tape."""
+import numpy as np
+import pytest
+
+import batch_problems as bp
+from dnlp_amd.batch import (BATCH_DATA_KEYS, ParametricBatch, arrays_with_data, instance_data,
+                            lower_arrays, same_structure)
+
+TEMPLATES = {"localization": bp.template_localization, "circle_packing": bp.template_circle_packing}
+
+
+@pytest.mark.parametrize("name", sorted(TEMPLATES))
+def test_parameter_to_tape_data_map_is_affine_and_exact(name):
+    prob, params, sample, _ = TEMPLATES[name]()
+    pb = ParametricBatch(prob, params)
+    assert pb.affine
+    thetas = np.stack([sample(i) for i in range(12)])
+    mat = pb.data(thetas)
+    assert mat.shape == (12, pb.d0.size)
+    for i in (0, 5, 11):
+        pb._set(thetas[i])
+        a, _, _, _ = lower_arrays(prob)
+        assert same_structure(pb.arrays0, a)
+        d = instance_data(a)
+        fin = np.isfinite(d)
+        assert np.array_equal(d[~fin], mat[i][~fin])
+        np.testing.assert_allclose(mat[i][fin], d[fin], rtol=1e-13, atol=1e-13)
+        back = arrays_with_data(pb.arrays0, mat[i])
+        for k in BATCH_DATA_KEYS:
+            assert back[k].shape == a[k].shape
+
+
+def test_non_affine_parameter_use_falls_back_to_lowering():
+    import dnlp_amd as cp
+    p = cp.Parameter(2, name="p", value=np.array([1.0, 2.0]))
+    x = cp.Variable(2)
+    prob = cp.Problem(cp.Minimize(cp.sum_squares(x - cp.multiply(p, p))), [cp.sum(cp.exp(x)) <= 50])
+    pb = ParametricBatch(prob, [p])
+    assert not pb.affine
+    mat = pb.data(np.array([[1.0, 2.0], [3.0, 0.5]]))
+    p.value = np.array([3.0, 0.5])
+    a, _, _, _ = lower_arrays(prob)
+    np.testing.assert_allclose(mat[1][np.isfinite(mat[1])], instance_data(a)[np.isfinite(mat[1])])
+
+
+def _oracle(arrays, opts=None):
+    from dnlp_amd.nlp_solver import HIPNLP
+    from dnlp_amd.tape import serialize
+    from oracle.oracle_capi import OracleProblem
+    orc = OracleProblem(serialize(arrays))
+    o = dict(HIPNLP.DEFAULT_OPTIONS)
+    o.update(opts or {})
+    for k, v in o.items():
+        orc.set_option(k, v)
+    return orc.solve(arrays["x0"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,batch", [("localization", 96), ("circle_packing", 64)])
+def test_batch_kernel_matches_cpu_oracle_per_instance(name, batch, gpu_required):
+    """Same algorithm text in both execution spaces: every instance must land on the oracle's
+    optimum (1e-6 relative objective, 1e-5 primal point) with the oracle's status, and (up to
+    reduction order) in the same number of iterations."""
+    prob, params, sample, var = TEMPLATES[name]()
+    pb = ParametricBatch(prob, params)
+    thetas = np.stack([sample(i) for i in range(batch)])
+    res = pb.solve(thetas, want_duals=True)
+    mat = pb.data(thetas)
+    assert res.x.shape == (batch, pb.arrays0["dims"][0])
+    same_iters = 0
+    for i in range(batch):
+        oi = _oracle(arrays_with_data(pb.arrays0, mat[i]))
+        assert res.status[i] == oi["status"]
+        if oi["status"] != 0:
+            continue
+        assert abs(res.raw["obj_val"][i] - oi["obj_val"]) <= 1e-6 * max(1.0, abs(oi["obj_val"]))
+        np.testing.assert_allclose(res.x[i], oi["x"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(res.raw["mult_g"][i], oi["mult_g"], rtol=1e-4, atol=1e-5)
+        same_iters += int(res.iterations[i] == oi["iterations"])
+    assert same_iters >= int(0.9 * batch)
+    assert np.sum(res.status == 0) >= batch - 1
+    vals = res.value_of(var)
+    assert vals.shape == (batch,) + tuple(var.shape)
+
+
+@pytest.mark.gpu
+def test_localization_batch_recovers_true_positions(gpu_required):
+    """Noise-free ranges: the optimum is the true position (test_nlp_solvers.py:175-189 analogue)."""
+    prob, params, sample, x = bp.template_localization()
+    pb = ParametricBatch(prob, params)
+    ids = np.arange(200)
+    res = pb.solve(np.stack([sample(i) for i in ids]))
+    ok = res.status == 0
+    assert ok.sum() >= 198
+    truth = np.stack([np.random.default_rng(i).uniform(-3, 3, 2) for i in ids])
+    got = res.value_of(x)
+    # a few instances end in a different local minimum of the non-convex range fit
+    good = np.linalg.norm(got - truth, axis=1) < 1e-4
+    assert good[ok].mean() > 0.8
+    assert np.all(np.abs(res.obj_val[ok & good]) < 1e-8)
+
+
+@pytest.mark.gpu
+def test_solve_batch_generic_path_equals_template_path(gpu_required):
+    from dnlp_amd.batch import solve_batch
+    ids = list(range(24))
+    res_g = solve_batch([bp.build_localization(i) for i in ids])
+    prob, params, sample, x = bp.template_localization()
+    res_t = ParametricBatch(prob, params).solve(np.stack([sample(i) for i in ids]))
+    assert np.array_equal(res_g.status, res_t.status)
+    np.testing.assert_allclose(res_g.obj_val, res_t.obj_val, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(res_g.x, res_t.x, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_batch_rejects_wrong_stride_and_dense_blocks(gpu_required):
+    import dnlp_amd as cp
+    from dnlp_amd.batch import _device_handle
+    prob, params, sample, _ = bp.template_localization()
+    pb = ParametricBatch(prob, params)
+    h = _device_handle(pb.arrays0, pb.data0["tape"], 0, {})
+    with pytest.raises(ValueError):
+        h.solve_batch(np.zeros((2, pb.d0.size + 1)))
+    h.close()
+    n = 60                                                   # dense quad_form block (n > 48)
+    A = np.random.default_rng(0).standard_normal((n, n))
+    xq = cp.Variable(n)
+    xq.value = np.ones(n) / np.sqrt(n)
+    q = cp.Problem(cp.Minimize(-cp.quad_form(xq, A @ A.T)), [cp.sum_squares(xq) == 1])
+    arrays, data, _, _ = lower_arrays(q)
+    hq = _device_handle(arrays, data["tape"], 0, {})
+    with pytest.raises(RuntimeError):
+        hq.solve_batch(instance_data(arrays)[None, :])
+    hq.close()
