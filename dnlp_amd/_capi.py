@@ -55,11 +55,11 @@ class CApi:
         f("ipm_finish", C.c_int, [C.c_void_p] + [_dbl_p] * 6 + [C.POINTER(C.c_int)])
         f("get_stats", C.c_int, [C.c_void_p, _dbl_p, C.c_int])
         f("get_log", C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t])
-        if hasattr(self.lib, prefix + "solve_batch"):      # product library only (no oracle batch path)
+        if hasattr(self.lib, prefix + "solve_batch_timed"):      # product library only (no oracle batch path)
             _int_p = C.POINTER(C.c_int)
             f("batch_stride", C.c_int64, [C.c_void_p])
-            f("solve_batch", C.c_int, [C.c_void_p, C.c_int, _dbl_p, C.c_int64] + [_dbl_p] * 5 +
-              [_int_p] * 3 + [_dbl_p])
+            f("solve_batch_timed", C.c_int, [C.c_void_p, C.c_int, _dbl_p, C.c_int64] + [_dbl_p] * 5 +
+              [_int_p] * 3 + [_dbl_p, _dbl_p])
 
     def _fn(self, name, restype, argtypes):
         fn = getattr(self.lib, self.prefix + name)
@@ -298,14 +298,15 @@ class ProblemHandle:
         sec = C.c_double()
         _int_p = C.POINTER(C.c_int)
         ip = lambda a: a.ctypes.data_as(_int_p)
-        rc = self.api.solve_batch(self.ptr, B, _dp(data), stride, _dp(x), _dp(obj),
+        times = np.zeros((B, 4))
+        rc = self.api.solve_batch_timed(self.ptr, B, _dp(data), stride, _dp(x), _dp(obj),
                                   _dp(mg) if want_duals else None, _dp(zl) if want_duals else None,
                                   _dp(zu) if want_duals else None, ip(status), ip(iters), ip(nfact),
-                                  C.cast(C.byref(sec), _dbl_p))
+                                        C.cast(C.byref(sec), _dbl_p), _dp(times))
         if rc != 0:
             raise RuntimeError("solve_batch failed: %s" % self.api.error())
         out = {"x": x, "obj_val": obj, "status": status, "iterations": iters, "factorizations": nfact,
-               "kernel_seconds": float(sec.value)}
+               "kernel_seconds": float(sec.value), "phase_seconds": times}
         if want_duals:
             out.update({"mult_g": mg[:, :self.m], "mult_x_L": zl, "mult_x_U": zu})
         return out

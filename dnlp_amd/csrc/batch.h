@@ -34,15 +34,18 @@ struct BatchArgs {
   IpmOptions opt;
   double *x_out = nullptr, *obj_out = nullptr, *multg_out = nullptr, *zl_out = nullptr, *zu_out = nullptr;
   int *status_out = nullptr, *iters_out = nullptr, *nfact_out = nullptr;
+  double* times_out = nullptr;   // batch x 4: wall, t_eval, t_factor, t_solve (seconds, device clock)
 };
 
 __global__ void __launch_bounds__(kBatchThreads) batch_solve_kernel(BatchArgs a) {
   extern __shared__ __align__(64) char lds_dyn[];
   __shared__ double s_red[8];
   __shared__ int s_redi[8];
+  __shared__ double s_vec[BlockExec::kWaveSolveMax];
+  __shared__ int s_piv[BlockExec::kWaveSolveMax];
   using KktT = DenseKkt<BlockExec>;
   for (int inst = blockIdx.x; inst < a.batch; inst += gridDim.x) {
-    BlockExec ex(a.ws + static_cast<size_t>(blockIdx.x) * a.ws_per_block, a.ws_per_block, lds_dyn, a.lds_bytes, s_red, s_redi);
+    BlockExec ex(a.ws + static_cast<size_t>(blockIdx.x) * a.ws_per_block, a.ws_per_block, lds_dyn, a.lds_bytes, s_red, s_redi, s_vec, s_piv);
     double* sl = a.slabs + static_cast<i64>(inst) * a.lay.total;
     TapeView t = a.base;
     t.c0 = sl[a.lay.c0];
@@ -71,6 +74,10 @@ __global__ void __launch_bounds__(kBatchThreads) batch_solve_kernel(BatchArgs a)
       a.iters_out[inst] = ipm.iter;
       a.obj_out[inst] = ipm.initialized ? ipm.objective_unscaled() : 0.0;
       if (a.nfact_out) a.nfact_out[inst] = ipm.stats.factorizations;
+      if (a.times_out) {
+        double* to = a.times_out + 4 * static_cast<i64>(inst);
+        to[0] = ipm.stats.wall; to[1] = ipm.stats.t_eval; to[2] = ipm.stats.t_factor; to[3] = ipm.stats.t_solve;
+      }
     }
     __syncthreads();
   }
@@ -122,7 +129,7 @@ struct BatchRunner {
   // data: batch x stride (host).  Outputs: host arrays (mult_g / zl / zu may be null).
   void solve(int batch, const double* data, i64 stride, const IpmOptions& opt, double* x_out, double* obj_out,
              double* multg_out, double* zl_out, double* zu_out, int* status_out, int* iters_out, int* nfact_out,
-             double* seconds) {
+             double* seconds, double* times_out = nullptr) {
     if (stride != in_stride) throw std::runtime_error("batched solve: instance stride does not match the tape");
     const Tape<HipExec>& t = *tape;
     DNLP_HIP_CHECK(hipSetDevice(ex->device));
@@ -154,7 +161,7 @@ struct BatchRunner {
     const i64 n = t.N + t.m, ld = (n + 7) / 8 * 8;
     // KKT matrix in LDS when it fits beside the static reduction scratch (160 KB per workgroup)
     const size_t kbytes = ((static_cast<size_t>(ld) * n + 256) * 8 + 63) & ~static_cast<size_t>(63);
-    const size_t lds_max = 160 * 1024 - 1024;
+    const size_t lds_max = 160 * 1024 - 8192;   // static LDS: reduction scratch + solve staging
     a.lds_bytes = kbytes <= lds_max ? static_cast<unsigned>(kbytes) : 0u;
     const size_t wdoubles = static_cast<size_t>(40 * t.N + 48 * t.m + 2 * t.Z + t.nd + t.nh + t.nnzH + t.nnzJ + 2 * n + 512) +
                             (a.lds_bytes ? 0 : static_cast<size_t>(ld) * n + 256);
@@ -178,6 +185,7 @@ struct BatchRunner {
     a.status_out = dalloc<int>(static_cast<size_t>(batch));
     a.iters_out = dalloc<int>(static_cast<size_t>(batch));
     a.nfact_out = dalloc<int>(static_cast<size_t>(batch));
+    a.times_out = times_out ? dalloc<double>(4 * static_cast<size_t>(batch)) : nullptr;
     hipEvent_t e0, e1;
     DNLP_HIP_CHECK(hipEventCreate(&e0));
     DNLP_HIP_CHECK(hipEventCreate(&e1));
@@ -200,6 +208,7 @@ struct BatchRunner {
     down(status_out, a.status_out, sizeof(int) * batch);
     down(iters_out, a.iters_out, sizeof(int) * batch);
     down(nfact_out, a.nfact_out, sizeof(int) * batch);
+    down(times_out, a.times_out, sizeof(double) * 4 * batch);
     release();
   }
 };

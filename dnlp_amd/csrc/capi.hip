@@ -17,6 +17,9 @@ int dnlp_device_count(void) {
 
 // Batched solve (BASELINE C5): `batch` instances sharing the structure of p's tape; see batch.h
 // for the per-instance data layout.  One kernel launch, one workgroup per instance.
+int dnlp_solve_batch_timed(void* vp, int batch, const double* data, int64_t stride, double* x, double* obj, double* mult_g,
+                           double* mult_x_L, double* mult_x_U, int* status, int* iters, int* factorizations, double* seconds,
+                           double* times);
 int64_t dnlp_batch_stride(void* vp) {
   auto* p = static_cast<dnlp_problem_t*>(vp);
   BatchRunner r;
@@ -24,12 +27,19 @@ int64_t dnlp_batch_stride(void* vp) {
 }
 int dnlp_solve_batch(void* vp, int batch, const double* data, int64_t stride, double* x, double* obj, double* mult_g,
                      double* mult_x_L, double* mult_x_U, int* status, int* iters, int* factorizations, double* seconds) {
+  return dnlp_solve_batch_timed(vp, batch, data, stride, x, obj, mult_g, mult_x_L, mult_x_U, status, iters, factorizations,
+                                seconds, nullptr);
+}
+/* same, plus per-instance device-clock phase times: times[4*i..] = wall, t_eval, t_factor, t_solve */
+int dnlp_solve_batch_timed(void* vp, int batch, const double* data, int64_t stride, double* x, double* obj, double* mult_g,
+                           double* mult_x_L, double* mult_x_U, int* status, int* iters, int* factorizations, double* seconds,
+                           double* times) {
   auto* p = static_cast<dnlp_problem_t*>(vp);
   DNLP_TRY(
     BatchRunner r;
     r.init(&p->ex, p->model.owner);
     p->ex.sync();
-    r.solve(batch, data, stride, p->opt, x, obj, mult_g, mult_x_L, mult_x_U, status, iters, factorizations, seconds);
+    r.solve(batch, data, stride, p->opt, x, obj, mult_g, mult_x_L, mult_x_U, status, iters, factorizations, seconds, times);
     return 0;)
 }
 

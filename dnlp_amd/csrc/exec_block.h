@@ -27,6 +27,260 @@ namespace dnlp {
 
 constexpr int kBatchThreads = 256;
 
+// LDS-address-space pointer: ds_read / ds_write instead of flat accesses when the KKT matrix of
+// the instance sits in LDS
+typedef __attribute__((address_space(3))) double lds_double;
+
+__device__ inline void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Bunch-Kaufman LDL^T (DSYTF2 semantics, lower) by ONE wavefront, no workgroup barrier: the
+// pivot column is cached in registers (R rows per lane, n <= 64 R), the trailing update walks
+// the columns with the multiplier broadcast from LDS, all-zero multipliers (sparse KKT
+// systems) skip their column.  AP is `double*` or `lds_double*`; piv is the pivot vector in LDS.
+template <int R, class AP>
+__device__ bool bk_factor_wave(AP A, int n, int ld, int* piv, int* nneg_out, int* nzero_out) {
+  const int lane = threadIdx.x & 63;
+  const double alpha = 0.6403882032022076;   // (1 + sqrt(17)) / 8
+  int k = 0, nneg = 0, nzero = 0;
+  while (k < n) {
+    AP Ak = A + k * ld;
+    double v = -1.0;
+    int idx = n;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = lane + 64 * r;
+      if (i > k && i < n) { const double a = fabs(Ak[i]); if (a > v) { v = a; idx = i; } }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(idx, o, 64);
+      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    double colmax = v;
+    int imax = idx;
+    if (colmax < 0.0) { colmax = 0.0; imax = k; }
+    const double absakk = fabs(Ak[k]);
+    if (!(absakk == absakk) || !(colmax == colmax)) return false;
+    int kstep = 1, kp = k;
+    bool zero_piv = false;
+    if (fmax(absakk, colmax) == 0.0) {
+      zero_piv = true;
+    } else if (absakk < alpha * colmax) {
+      double rv = 0.0;
+      for (int j = k + lane; j < imax; j += 64) rv = fmax(rv, fabs(A[imax + j * ld]));
+      for (int i = imax + 1 + lane; i < n; i += 64) rv = fmax(rv, fabs(A[i + imax * ld]));
+      for (int o = 32; o > 0; o >>= 1) rv = fmax(rv, __shfl_xor(rv, o, 64));
+      const double rowmax = rv;
+      const double aii = fabs(A[imax + imax * ld]);
+      if (absakk >= alpha * colmax * (colmax / rowmax)) kp = k;
+      else if (aii >= alpha * rowmax) kp = imax;
+      else { kp = imax; kstep = 2; }
+    }
+    const int kk = k + kstep - 1;
+    if (!zero_piv && kp != kk) {
+      AP Akk = A + kk * ld;
+      AP Akp = A + kp * ld;
+      for (int i = kp + 1 + lane; i < n; i += 64) { const double t = Akk[i]; Akk[i] = Akp[i]; Akp[i] = t; }
+      for (int j = kk + 1 + lane; j < kp; j += 64) { const double t = Akk[j]; Akk[j] = A[kp + j * ld]; A[kp + j * ld] = t; }
+      wave_sync();
+      if (lane == 0) {
+        const double t = Akk[kk];
+        Akk[kk] = Akp[kp];
+        Akp[kp] = t;
+        if (kstep == 2) { const double t2 = Ak[k + 1]; Ak[k + 1] = Ak[kp]; Ak[kp] = t2; }
+      }
+      wave_sync();
+    }
+    if (zero_piv) {
+      if (lane == 0) { Ak[k] = 1e-20; piv[k] = k + 1; }
+      ++nzero;
+      wave_sync();
+      k += 1;
+      continue;
+    }
+    if (kstep == 1) {
+      const double d = Ak[k];
+      if (d < 0.0) ++nneg;
+      if (fabs(d) < 1e-300) ++nzero;
+      if (lane == 0) piv[k] = kp + 1;
+      const double inv = 1.0 / d;
+      double ak[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) { const int i = lane + 64 * r; ak[r] = (i > k && i < n) ? Ak[i] : 0.0; }
+      // trailing update, four columns in flight: the columns with a non-zero multiplier are
+      // enumerated from ballot masks (scalar unit), the multiplier comes from the owning lane's
+      // register — no LDS access steers the control flow
+#pragma unroll
+      for (int r2 = 0; r2 < R; ++r2) {
+        unsigned long long mask = __ballot(ak[r2] != 0.0);
+        while (mask) {
+          int jj[4];
+          double w[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (mask) {
+              const int b = __builtin_ctzll(mask);
+              mask &= mask - 1;
+              jj[u] = b + 64 * r2;
+              w[u] = __shfl(ak[r2], b, 64) * inv;
+            } else {
+              jj[u] = n;            // sentinel: no row satisfies i >= n
+              w[u] = 0.0;
+            }
+          }
+          double t[4][R];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const int i = lane + 64 * r;
+              t[u][r] = (i >= jj[u] && i < n) ? A[i + jj[u] * ld] : 0.0;
+            }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const int i = lane + 64 * r;
+              if (i >= jj[u] && i < n) A[i + jj[u] * ld] = t[u][r] - ak[r] * w[u];
+            }
+        }
+      }
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < R; ++r) { const int i = lane + 64 * r; if (i > k && i < n) Ak[i] = ak[r] * inv; }
+      wave_sync();
+    } else {
+      AP Ak1 = Ak + ld;
+      double d21 = Ak[k + 1];
+      const double d11 = Ak1[k + 1] / d21, d22 = Ak[k] / d21;
+      const double tt = 1.0 / (d11 * d22 - 1.0);
+      d21 = tt / d21;
+      ++nneg;
+      if (lane == 0) { piv[k] = -(kp + 1); piv[k + 1] = -(kp + 1); }
+      double a0[R], a1[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int i = lane + 64 * r;
+        const bool in = i > k + 1 && i < n;
+        a0[r] = in ? Ak[i] : 0.0;
+        a1[r] = in ? Ak1[i] : 0.0;
+      }
+#pragma unroll
+      for (int r2 = 0; r2 < R; ++r2) {
+        unsigned long long mask = __ballot(a0[r2] != 0.0 || a1[r2] != 0.0);
+        while (mask) {
+          int jj[2];
+          double w0[2], w1[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (mask) {
+              const int b = __builtin_ctzll(mask);
+              mask &= mask - 1;
+              jj[u] = b + 64 * r2;
+              const double ajk = __shfl(a0[r2], b, 64), ajk1 = __shfl(a1[r2], b, 64);
+              w0[u] = d21 * (d11 * ajk - ajk1);
+              w1[u] = d21 * (d22 * ajk1 - ajk);
+            } else {
+              jj[u] = n;
+              w0[u] = w1[u] = 0.0;
+            }
+          }
+          double t[2][R];
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const int i = lane + 64 * r;
+              t[u][r] = (i >= jj[u] && i < n) ? A[i + jj[u] * ld] : 0.0;
+            }
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const int i = lane + 64 * r;
+              if (i >= jj[u] && i < n) A[i + jj[u] * ld] = t[u][r] - (a0[r] * w0[u] + a1[r] * w1[u]);
+            }
+        }
+      }
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int i = lane + 64 * r;
+        if (i > k + 1 && i < n) {
+          Ak[i] = d21 * (d11 * a0[r] - a1[r]);
+          Ak1[i] = d21 * (d22 * a1[r] - a0[r]);
+        }
+      }
+      wave_sync();
+    }
+    k += kstep;
+  }
+  *nneg_out = nneg;
+  *nzero_out = nzero;
+  return true;
+}
+
+// DSYTRS (lower) by ONE wavefront; right-hand side v and pivots piv in LDS.
+template <class AP>
+__device__ void bk_solve_wave(AP A, int n, int ld, const int* piv, double* v) {
+  const int lane = threadIdx.x & 63;
+  int k = 0;
+  while (k < n) {
+    AP Ak = A + k * ld;
+    const int p = piv[k];
+    if (p > 0) {
+      const int kp = p - 1;
+      if (lane == 0 && kp != k) { const double t = v[k]; v[k] = v[kp]; v[kp] = t; }
+      wave_sync();
+      const double bk = v[k];
+      if (bk != 0.0)
+        for (int i = k + 1 + lane; i < n; i += 64) v[i] -= Ak[i] * bk;
+      if (lane == 0) v[k] = bk / Ak[k];
+      k += 1;
+    } else {
+      AP Ak1 = Ak + ld;
+      const int kp = -p - 1;
+      if (lane == 0 && kp != k + 1) { const double t = v[k + 1]; v[k + 1] = v[kp]; v[kp] = t; }
+      wave_sync();
+      const double bk = v[k], bk1 = v[k + 1];
+      for (int i = k + 2 + lane; i < n; i += 64) v[i] -= Ak[i] * bk + Ak1[i] * bk1;
+      if (lane == 0) {
+        const double akm1k = Ak[k + 1];
+        const double akm1 = Ak[k] / akm1k, ak = Ak1[k + 1] / akm1k;
+        const double denom = akm1 * ak - 1.0, bkm1 = bk / akm1k, bkk = bk1 / akm1k;
+        v[k] = (ak * bkm1 - bkk) / denom;
+        v[k + 1] = (akm1 * bkk - bkm1) / denom;
+      }
+      k += 2;
+    }
+    wave_sync();
+  }
+  k = n - 1;
+  while (k >= 0) {
+    const bool one = piv[k] > 0;
+    AP Ak = A + k * ld;
+    AP Akm = one ? Ak : Ak - ld;
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = k + 1 + lane; i < n; i += 64) {
+      const double bi = v[i];
+      s0 += Ak[i] * bi;
+      if (!one) s1 += Akm[i] * bi;
+    }
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+    if (lane == 0) {
+      v[k] -= s0;
+      if (!one) v[k - 1] -= s1;
+      const int kp = (one ? piv[k] : -piv[k]) - 1;
+      if (kp != k) { const double t = v[k]; v[k] = v[kp]; v[kp] = t; }
+    }
+    wave_sync();
+    k -= one ? 1 : 2;
+  }
+}
+
 struct BlockExec {
   static constexpr bool is_device = false;          // model.h: generic lambda form of the flat sweep
   static constexpr bool has_log = false;
@@ -46,9 +300,13 @@ struct BlockExec {
   double* red = nullptr;     // 2 x 4 doubles
   int* redi = nullptr;       // 2 x 4 ints
   int parity = 0;
+  // LDS staging of the right-hand side and the pivot vector for the single-wavefront solve
+  double* vec = nullptr;     // kWaveSolveMax doubles
+  int* piv = nullptr;        // kWaveSolveMax ints
+  static constexpr int kWaveSolveMax = 512;
 
-  __device__ BlockExec(char* slab, size_t cap, char* lds, size_t ldscap, double* r, int* ri)
-      : ws(slab), ws_cap(cap), lds_pool(lds), lds_cap(ldscap), red(r), redi(ri) {}
+  __device__ BlockExec(char* slab, size_t cap, char* lds, size_t ldscap, double* r, int* ri, double* v, int* pv)
+      : ws(slab), ws_cap(cap), lds_pool(lds), lds_cap(ldscap), red(r), redi(ri), vec(v), piv(pv) {}
 
   __device__ void barrier() { __syncthreads(); }
 
@@ -175,6 +433,26 @@ struct BlockExec {
   // bk_update_kernel of exec_hip.h and as the DSYTF2 restatement of the test oracle.
   __device__ bool ldlt_factor(LdltWork&, double* A, i64 nn, i64 ld, i32* ipiv, bool, int* nneg_out, int* nzero_out) {
     const int n = static_cast<int>(nn), tid = threadIdx.x;
+    if (n <= 256 && in_lds(A)) {
+      // LDS-resident matrix of a small instance: one wavefront, no workgroup barrier inside
+      if (tid < 64) {
+        lds_double* L = (lds_double*)A;
+        int nn_ = 0, nz_ = 0;
+        bool ok;
+        if (n <= 64) ok = bk_factor_wave<1>(L, n, static_cast<int>(ld), piv, &nn_, &nz_);
+        else if (n <= 128) ok = bk_factor_wave<2>(L, n, static_cast<int>(ld), piv, &nn_, &nz_);
+        else ok = bk_factor_wave<4>(L, n, static_cast<int>(ld), piv, &nn_, &nz_);
+        if (tid == 0) { redi[0] = ok ? 1 : 0; redi[1] = nn_; redi[2] = nz_; }
+      }
+      __syncthreads();
+      const bool ok = redi[0] != 0;
+      *nneg_out = redi[1];
+      *nzero_out = redi[2];
+      for (int i = tid; i < n; i += kBatchThreads) ipiv[i] = piv[i];
+      __syncthreads();
+      parity = 0;     // redi[0..2] were used outside the alternating scheme: restart it
+      return ok;
+    }
     const int lane = tid & 63, wv = tid >> 6;
     const double alpha = 0.6403882032022076;   // (1 + sqrt(17)) / 8
     int k = 0, nneg = 0, nzero = 0;
@@ -281,9 +559,32 @@ struct BlockExec {
     return true;
   }
 
+  __device__ bool in_lds(const void* p) const {
+    const char* c = static_cast<const char*>(p);
+    return lds_cap > 0 && c >= lds_pool && c < lds_pool + lds_cap;
+  }
+
+  // Small orders: the substitution is a chain of n dependent steps, so workgroup barriers (two
+  // to three per column) are the whole cost of the block form.  The right-hand side and the
+  // pivot vector are staged in LDS, wavefront 0 walks the columns (bk_solve_wave) and the other
+  // wavefronts wait at one barrier.
+  __device__ void ldlt_solve_wave(const double* A, int n, i64 ld, const i32* ipiv, double* b) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += kBatchThreads) { vec[i] = b[i]; piv[i] = ipiv[i]; }
+    __syncthreads();
+    if (tid < 64) {
+      if (in_lds(A)) bk_solve_wave((const lds_double*)A, n, static_cast<int>(ld), piv, vec);
+      else bk_solve_wave(A, n, static_cast<int>(ld), piv, vec);
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += kBatchThreads) b[i] = vec[i];
+    __syncthreads();
+  }
+
   // DSYTRS (lower) by one workgroup; b in exec-space memory
   __device__ void ldlt_solve(LdltWork&, const double* A, i64 nn, i64 ld, const i32* ipiv, bool, double* b) {
     const int n = static_cast<int>(nn), tid = threadIdx.x;
+    if (n <= kWaveSolveMax) { ldlt_solve_wave(A, n, ld, ipiv, b); return; }
     int k = 0;
     while (k < n) {
       const double* Ak = A + static_cast<i64>(k) * ld;

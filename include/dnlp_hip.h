@@ -100,6 +100,12 @@ int64_t dnlp_batch_stride(dnlp_problem* p);
 int dnlp_solve_batch(dnlp_problem* p, int batch, const double* data, int64_t stride, double* x,
                      double* obj, double* mult_g, double* mult_x_L, double* mult_x_U, int* status,
                      int* iters, int* factorizations, double* kernel_seconds);
+/* Same, plus per-instance phase times on the device clock:
+ * times[4*i + 0..3] = whole solve, tape evaluations, KKT factorisations, KKT solves (seconds). */
+int dnlp_solve_batch_timed(dnlp_problem* p, int batch, const double* data, int64_t stride, double* x,
+                           double* obj, double* mult_g, double* mult_x_L, double* mult_x_U,
+                           int* status, int* iters, int* factorizations, double* kernel_seconds,
+                           double* times);
 /* Statistics of the last solve: stats[0..15] = iterations, factorizations, wall, t_eval,
  * t_factor, t_solve, mu, inf_pr, inf_du, compl, nlp_error, last_delta_w, ... */
 int dnlp_get_stats(dnlp_problem* p, double* stats, int n);

@@ -49,7 +49,9 @@ for which in args.which.split(","):
            "optimal": int(np.sum(res.status == 0)), "acceptable": int(np.sum(res.status == 1)),
            "iters_mean": float(res.iterations.mean()), "iters_max": int(res.iterations.max()),
            "iters_per_sec_kernel": float(res.iterations.sum() / res.kernel_seconds),
-           "factorizations_mean": float(res.factorizations.mean())}
+           "factorizations_mean": float(res.factorizations.mean()),
+           "phase_ms_per_iter": dict(zip(("wall", "eval", "factor", "solve"),
+                                         (1e3 * res.raw["phase_seconds"].sum(axis=0) / res.iterations.sum()).tolist()))}
     if args.check:
         from dnlp_amd.nlp_solver import HIPNLP
         from dnlp_amd.tape import serialize
