@@ -9,6 +9,8 @@
 // from the tape the problem handle was created with.
 #pragma once
 #include <algorithm>
+#include <cstdlib>
+#include <new>
 #include <vector>
 
 #include "exec_block.h"
@@ -30,22 +32,49 @@ struct BatchArgs {
   int batch = 0;
   char* ws = nullptr;            // gridDim.x x ws_per_block
   size_t ws_per_block = 0;
-  unsigned lds_bytes = 0;        // dynamic LDS pool for the KKT matrix (0: keep it in global memory)
+  unsigned lds_bytes = 0;        // dynamic LDS pool (0: everything in global memory)
+  int lds_mode = 0;              // what the pool holds: 0 nothing, 1 KKT matrix, 2 vectors, 3 both
   IpmOptions opt;
   double *x_out = nullptr, *obj_out = nullptr, *multg_out = nullptr, *zl_out = nullptr, *zu_out = nullptr;
   int *status_out = nullptr, *iters_out = nullptr, *nfact_out = nullptr;
   double* times_out = nullptr;   // batch x 4: wall, t_eval, t_factor, t_solve (seconds, device clock)
+  int* next = nullptr;           // work queue head: instances are claimed dynamically (iteration counts vary 10x)
 };
 
-__global__ void __launch_bounds__(kBatchThreads) batch_solve_kernel(BatchArgs a) {
+// The solver objects of an instance (exec space, model, KKT, interior-point state) live in LDS,
+// one private copy per wavefront: every wavefront runs the control flow redundantly, and a field
+// read is an LDS access (~0.1 us) instead of a scratch-memory round trip through L2 (~0.5 us)
+// on the critical path of each of the several hundred maps / reductions of an iteration.
+template <int NT>
+__global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
   extern __shared__ __align__(64) char lds_dyn[];
+  using EX = BlockExecT<NT>;
+  using KktT = DenseKkt<EX>;
+  using ModelT = Model<EX>;
+  using IpmT = Ipm<EX, KktT>;
+  constexpr int NW = NT / 64;
+  struct alignas(16) Objs {
+    alignas(16) char ex[sizeof(EX)];
+    alignas(16) char md[sizeof(ModelT)];
+    alignas(16) char kkt[sizeof(KktT)];
+    alignas(16) char ipm[sizeof(IpmT)];
+  };
+  __shared__ Objs s_objs[NW];
   __shared__ double s_red[8];
   __shared__ int s_redi[8];
-  __shared__ double s_vec[BlockExec::kWaveSolveMax];
-  __shared__ int s_piv[BlockExec::kWaveSolveMax];
-  using KktT = DenseKkt<BlockExec>;
-  for (int inst = blockIdx.x; inst < a.batch; inst += gridDim.x) {
-    BlockExec ex(a.ws + static_cast<size_t>(blockIdx.x) * a.ws_per_block, a.ws_per_block, lds_dyn, a.lds_bytes, s_red, s_redi, s_vec, s_piv);
+  __shared__ double s_vec[EX::kWaveSolveMax];
+  __shared__ int s_piv[EX::kWaveSolveMax];
+  __shared__ int s_inst;
+  Objs& o = s_objs[threadIdx.x >> 6];
+  while (true) {
+    if (threadIdx.x == 0) s_inst = atomicAdd(a.next, 1);
+    __syncthreads();
+    const int inst = s_inst;
+    __syncthreads();
+    if (inst >= a.batch) break;
+    EX* ex = new (o.ex) EX(a.ws + static_cast<size_t>(blockIdx.x) * a.ws_per_block, a.ws_per_block, lds_dyn, a.lds_bytes,
+                           s_red, s_redi, s_vec, s_piv);
+    ex->lds_mode = a.lds_mode;
     double* sl = a.slabs + static_cast<i64>(inst) * a.lay.total;
     TapeView t = a.base;
     t.c0 = sl[a.lay.c0];
@@ -53,30 +82,30 @@ __global__ void __launch_bounds__(kBatchThreads) batch_solve_kernel(BatchArgs a)
     t.G.val = sl + a.lay.G; t.Mg.val = sl + a.lay.Mg; t.Mw.val = sl + a.lay.Mw; t.MJ.val = sl + a.lay.MJ;
     t.MH.val = sl + a.lay.MH; t.flat_p = sl + a.lay.fp; t.flat_p2 = sl + a.lay.fp2;
     t.d_x0 = sl + a.lay.x0; t.d_lb = sl + a.lay.lb; t.d_ub = sl + a.lay.ub; t.d_cl = sl + a.lay.cl; t.d_cu = sl + a.lay.cu;
-    Model<BlockExec> md;
-    md.init_view(&ex, t);
-    KktT kkt;
-    kkt.pivot_max_n = static_cast<i64>(1) << 40;   // always the pivoted (Bunch-Kaufman) factorisation
-    kkt.init(&ex, t.N, t.m);
-    Ipm<BlockExec, KktT> ipm(&ex, &md, &kkt);
-    ipm.opt = a.opt;
-    ipm.allocate();
+    ModelT* md = new (o.md) ModelT();
+    md->init_view(ex, t);
+    KktT* kkt = new (o.kkt) KktT();
+    kkt->pivot_max_n = static_cast<i64>(1) << 40;   // always the pivoted (Bunch-Kaufman) factorisation
+    kkt->init(ex, t.N, t.m);
+    IpmT* ipm = new (o.ipm) IpmT(ex, md, kkt);
+    ipm->opt = a.opt;
+    ipm->allocate();
     int st = Internal_Error;
-    if (!ex.overflow) {
-      st = ipm.solve(t.d_x0);
-      if (ipm.initialized)
-        ipm.extract_exec(a.x_out + static_cast<i64>(inst) * t.N, a.multg_out ? a.multg_out + static_cast<i64>(inst) * t.m : nullptr,
-                         a.zl_out ? a.zl_out + static_cast<i64>(inst) * t.N : nullptr,
-                         a.zu_out ? a.zu_out + static_cast<i64>(inst) * t.N : nullptr, nullptr);
+    if (!ex->overflow) {
+      st = ipm->solve(t.d_x0);
+      if (ipm->initialized)
+        ipm->extract_exec(a.x_out + static_cast<i64>(inst) * t.N, a.multg_out ? a.multg_out + static_cast<i64>(inst) * t.m : nullptr,
+                          a.zl_out ? a.zl_out + static_cast<i64>(inst) * t.N : nullptr,
+                          a.zu_out ? a.zu_out + static_cast<i64>(inst) * t.N : nullptr, nullptr);
     }
     if (threadIdx.x == 0) {
       a.status_out[inst] = st;
-      a.iters_out[inst] = ipm.iter;
-      a.obj_out[inst] = ipm.initialized ? ipm.objective_unscaled() : 0.0;
-      if (a.nfact_out) a.nfact_out[inst] = ipm.stats.factorizations;
+      a.iters_out[inst] = ipm->iter;
+      a.obj_out[inst] = ipm->initialized ? ipm->objective_unscaled() : 0.0;
+      if (a.nfact_out) a.nfact_out[inst] = ipm->stats.factorizations;
       if (a.times_out) {
         double* to = a.times_out + 4 * static_cast<i64>(inst);
-        to[0] = ipm.stats.wall; to[1] = ipm.stats.t_eval; to[2] = ipm.stats.t_factor; to[3] = ipm.stats.t_solve;
+        to[0] = ipm->stats.wall; to[1] = ipm->stats.t_eval; to[2] = ipm->stats.t_factor; to[3] = ipm->stats.t_solve;
       }
     }
     __syncthreads();
@@ -92,6 +121,7 @@ struct BatchRunner {
   SparseConst* d_sparse = nullptr;
   BatchLayout lay;
   i64 in_stride = 0;
+  int last_grid = 0, last_threads = 0, last_lds_mode = 0, last_per_cu = 0;   // launch plan of the last solve
   std::vector<void*> scratch;
 
   ~BatchRunner() { release(); if (d_segs) hipFree(d_segs); if (d_red) hipFree(d_red); if (d_sparse) hipFree(d_sparse); }
@@ -161,21 +191,50 @@ struct BatchRunner {
     const i64 n = t.N + t.m, ld = (n + 7) / 8 * 8;
     // KKT matrix in LDS when it fits beside the static reduction scratch (160 KB per workgroup)
     const size_t kbytes = ((static_cast<size_t>(ld) * n + 256) * 8 + 63) & ~static_cast<size_t>(63);
-    const size_t lds_max = 160 * 1024 - 8192;   // static LDS: reduction scratch + solve staging
-    a.lds_bytes = kbytes <= lds_max ? static_cast<unsigned>(kbytes) : 0u;
-    const size_t wdoubles = static_cast<size_t>(40 * t.N + 48 * t.m + 2 * t.Z + t.nd + t.nh + t.nnzH + t.nnzJ + 2 * n + 512) +
-                            (a.lds_bytes ? 0 : static_cast<size_t>(ld) * n + 256);
-    a.ws_per_block = (wdoubles * 8 + 160 * 64 + 255) & ~static_cast<size_t>(255);
-    DNLP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(batch_solve_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(a.lds_bytes)));
+    const size_t vdoubles = static_cast<size_t>(40 * t.N + 48 * t.m + 2 * t.Z + t.nd + t.nh + t.nnzH + t.nnzJ + 2 * n + 512);
+    const size_t vbytes = (vdoubles * 8 + 160 * 64 + 255) & ~static_cast<size_t>(255);
+    // lanes per instance: one wavefront up to order 256 (factorisation and solves are
+    // single-wavefront there, vectors are at most a few hundred long), four above
+    const bool wave = n <= 256;
+    const void* kern = wave ? reinterpret_cast<const void*>(batch_solve_kernel<64>)
+                            : reinterpret_cast<const void*>(batch_solve_kernel<256>);
+    const int nthreads = wave ? 64 : 256;
+    hipFuncAttributes fa;
+    DNLP_HIP_CHECK(hipFuncGetAttributes(&fa, kern));
+    const size_t lds_max = 160 * 1024 - fa.sharedSizeBytes - 512;
+    // LDS plan.  Measured on MI355X (profiles/r01_c5_batch_lds_modes.json): throughput follows the
+    // number of instances resident per CU first (one wavefront each, at most one per SIMD with
+    // this kernel's register budget), the per-iteration latency second (both in LDS < matrix in
+    // LDS < vectors in LDS < nothing).  So: the richest plan among those with the most instances
+    // per CU.  DNLP_BATCH_LDS=0..3 overrides, for experiments.
+    const int slots_max = wave ? 4 : 1;
+    auto slots = [&](int md_) {
+      const size_t dyn = (md_ & 1 ? kbytes : 0) + (md_ & 2 ? vbytes : 0);
+      if (dyn > lds_max) return 0;
+      const size_t per = dyn + fa.sharedSizeBytes + 256;
+      return static_cast<int>(std::min<size_t>(slots_max, (160 * 1024) / per));
+    };
+    int mode = 0, best_slots = slots(0);
+    for (int cand : {2, 1, 3}) if (slots(cand) >= best_slots && slots(cand) > 0) { best_slots = slots(cand); mode = cand; }
+    if (const char* e = std::getenv("DNLP_BATCH_LDS")) {
+      const int want = std::atoi(e);
+      if (want >= 0 && want <= 3 && slots(want) > 0) mode = want;
+    }
+    a.lds_mode = mode;
+    a.lds_bytes = static_cast<unsigned>((mode & 1 ? kbytes : 0) + (mode & 2 ? vbytes : 0));
+    a.ws_per_block = 256 + (mode & 2 ? 0 : vbytes) + (mode & 1 ? 0 : kbytes);
+    DNLP_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(a.lds_bytes)));
     int per_cu = 1, ncu = 256;
-    DNLP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, batch_solve_kernel, kBatchThreads, a.lds_bytes));
+    if (wave) DNLP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, batch_solve_kernel<64>, nthreads, a.lds_bytes));
+    else DNLP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, batch_solve_kernel<256>, nthreads, a.lds_bytes));
     hipDeviceProp_t prop;
     DNLP_HIP_CHECK(hipGetDeviceProperties(&prop, ex->device));
     ncu = prop.multiProcessorCount;
     if (per_cu < 1) per_cu = 1;
-    if (per_cu > 4) per_cu = 4;
+    if (per_cu > 8) per_cu = 8;
+    if (const char* e = std::getenv("DNLP_BATCH_PER_CU")) { const int w = std::atoi(e); if (w >= 1 && w <= 8) per_cu = w; }
     const int grid = std::min(batch, ncu * per_cu);
+    last_grid = grid; last_threads = nthreads; last_lds_mode = mode; last_per_cu = per_cu;
     a.ws = dalloc<char>(static_cast<size_t>(grid) * a.ws_per_block);
     a.x_out = dalloc<double>(static_cast<size_t>(batch) * t.N);
     a.obj_out = dalloc<double>(static_cast<size_t>(batch));
@@ -186,11 +245,14 @@ struct BatchRunner {
     a.iters_out = dalloc<int>(static_cast<size_t>(batch));
     a.nfact_out = dalloc<int>(static_cast<size_t>(batch));
     a.times_out = times_out ? dalloc<double>(4 * static_cast<size_t>(batch)) : nullptr;
+    a.next = dalloc<int>(1);
+    DNLP_HIP_CHECK(hipMemsetAsync(a.next, 0, sizeof(int), ex->stream));
     hipEvent_t e0, e1;
     DNLP_HIP_CHECK(hipEventCreate(&e0));
     DNLP_HIP_CHECK(hipEventCreate(&e1));
     DNLP_HIP_CHECK(hipEventRecord(e0, ex->stream));
-    hipLaunchKernelGGL(batch_solve_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBatchThreads), a.lds_bytes, ex->stream, a);
+    if (wave) hipLaunchKernelGGL(batch_solve_kernel<64>, dim3(static_cast<unsigned>(grid)), dim3(64), a.lds_bytes, ex->stream, a);
+    else hipLaunchKernelGGL(batch_solve_kernel<256>, dim3(static_cast<unsigned>(grid)), dim3(256), a.lds_bytes, ex->stream, a);
     DNLP_LAUNCH_CHECK();
     DNLP_HIP_CHECK(hipEventRecord(e1, ex->stream));
     DNLP_HIP_CHECK(hipStreamSynchronize(ex->stream));

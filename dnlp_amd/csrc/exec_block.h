@@ -25,7 +25,6 @@
 
 namespace dnlp {
 
-constexpr int kBatchThreads = 256;
 
 // LDS-address-space pointer: ds_read / ds_write instead of flat accesses when the KKT matrix of
 // the instance sits in LDS
@@ -85,6 +84,9 @@ __device__ bool bk_factor_wave(AP A, int n, int ld, int* piv, int* nneg_out, int
       AP Akp = A + kp * ld;
       for (int i = kp + 1 + lane; i < n; i += 64) { const double t = Akk[i]; Akk[i] = Akp[i]; Akp[i] = t; }
       for (int j = kk + 1 + lane; j < kp; j += 64) { const double t = Akk[j]; Akk[j] = A[kp + j * ld]; A[kp + j * ld] = t; }
+      // standard form: the interchange also moves the rows of the columns already factored,
+      // so that P A P^T = L D L^T with one permutation applied before / after the solves
+      for (int c = lane; c < k; c += 64) { const double t = A[kk + c * ld]; A[kk + c * ld] = A[kp + c * ld]; A[kp + c * ld] = t; }
       wave_sync();
       if (lane == 0) {
         const double t = Akk[kk];
@@ -223,6 +225,136 @@ __device__ bool bk_factor_wave(AP A, int n, int ld, int* piv, int* nneg_out, int
   return true;
 }
 
+// ---- solves with a standard-form factor (bk_factor_wave), right-hand side in registers -------
+__device__ inline double readlane_d(double v, int l) {
+  l = __builtin_amdgcn_readfirstlane(l);
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+template <int R> __device__ inline double lane_get(const double (&x)[R], int idx) {
+  double o = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) { const double t = readlane_d(x[r], idx & 63); if ((idx >> 6) == r) o = t; }
+  return o;
+}
+template <int R> __device__ inline int lane_geti(const int (&x)[R], int idx) {
+  int o = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int t = __builtin_amdgcn_readlane(x[r], __builtin_amdgcn_readfirstlane(idx & 63));
+    if ((idx >> 6) == r) o = t;
+  }
+  return o;
+}
+template <int R> __device__ inline void lane_set(double (&x)[R], int idx, double val, int lane) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) if ((idx >> 6) == r && lane == (idx & 63)) x[r] = val;
+}
+template <int R> __device__ inline void lane_swap(double (&x)[R], int a, int b, int lane) {
+  const double va = lane_get<R>(x, a), vb = lane_get<R>(x, b);
+  lane_set<R>(x, a, vb, lane);
+  lane_set<R>(x, b, va, lane);
+}
+
+// x = A^-1 b for P A P^T = L D L^T (unit lower L in standard form, D with 1x1 / 2x2 blocks,
+// piv as DSYTF2 records it).  One wavefront; lane l holds entries l, l+64, ...; the chain of n
+// dependent steps is readlane -> fma, the columns (forward) and rows (backward) of L stream
+// from memory one step ahead of their use.
+template <int R, class AP>
+__device__ void bk_solve_reg(AP A, int n, int ld, const int* piv, double* v) {
+  const int lane = threadIdx.x & 63;
+  double x[R], dg[R], sd[R];
+  int pr[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = lane + 64 * r;
+    x[r] = i < n ? v[i] : 0.0;
+    pr[r] = i < n ? piv[i] : 1;
+    dg[r] = i < n ? A[i + i * ld] : 1.0;                 // D diagonal
+    sd[r] = (i + 1 < n) ? A[i + 1 + i * ld] : 0.0;       // D sub-diagonal (2x2 blocks)
+  }
+  // P b
+  for (int k = 0; k < n;) {
+    const int p = lane_geti<R>(pr, k);
+    if (p > 0) { if (p - 1 != k) lane_swap<R>(x, k, p - 1, lane); k += 1; }
+    else { if (-p - 1 != k + 1) lane_swap<R>(x, k + 1, -p - 1, lane); k += 2; }
+  }
+  // L y = P b, then z = D^-1 y on the fly
+  {
+    double cur[R], nxt[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const int i = lane + 64 * r; cur[r] = (i > 0 && i < n) ? A[i] : 0.0; }
+    for (int k = 0; k < n;) {
+      const int p = lane_geti<R>(pr, k);
+#pragma unroll
+      for (int r = 0; r < R; ++r) { const int i = lane + 64 * r; nxt[r] = (k + 1 < n && i > k + 1 && i < n) ? A[i + (k + 1) * ld] : 0.0; }
+      if (p > 0) {
+        const double yk = lane_get<R>(x, k);
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[r] -= cur[r] * yk;          // cur is zero on rows <= k
+        lane_set<R>(x, k, yk / lane_get<R>(dg, k), lane);
+#pragma unroll
+        for (int r = 0; r < R; ++r) cur[r] = nxt[r];
+        k += 1;
+      } else {
+        const double yk = lane_get<R>(x, k), yk1 = lane_get<R>(x, k + 1);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int i = lane + 64 * r;
+          if (i > k + 1) x[r] -= cur[r] * yk + nxt[r] * yk1;      // cur holds the sub-diagonal at row k+1: skip it
+        }
+        const double akm1k = lane_get<R>(sd, k);
+        const double akm1 = lane_get<R>(dg, k) / akm1k, ak = lane_get<R>(dg, k + 1) / akm1k;
+        const double denom = akm1 * ak - 1.0, bkm1 = yk / akm1k, bkk = yk1 / akm1k;
+        lane_set<R>(x, k, (ak * bkm1 - bkk) / denom, lane);
+        lane_set<R>(x, k + 1, (akm1 * bkk - bkm1) / denom, lane);
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const int i = lane + 64 * r; cur[r] = (k + 2 < n && i > k + 2 && i < n) ? A[i + (k + 2) * ld] : 0.0; }
+        k += 2;
+      }
+    }
+  }
+  // L^T w = z in axpy form: row k of L streams in, entries c < k of x are updated
+  {
+    double cur[R], nxt[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const int c = lane + 64 * r; cur[r] = (c < n - 1) ? A[(n - 1) + c * ld] : 0.0; }
+    for (int k = n - 1; k >= 0;) {
+      const int p = lane_geti<R>(pr, k);
+#pragma unroll
+      for (int r = 0; r < R; ++r) { const int c = lane + 64 * r; nxt[r] = (k >= 1 && c < k - 1) ? A[(k - 1) + c * ld] : 0.0; }
+      if (p > 0) {
+        const double xk = lane_get<R>(x, k);
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[r] -= cur[r] * xk;          // cur is zero on entries >= k
+#pragma unroll
+        for (int r = 0; r < R; ++r) cur[r] = nxt[r];
+        k -= 1;
+      } else {
+        // block (k-1, k): nxt was loaded for c < k-1, cur for c < k (its entry k-1 is the D sub-diagonal)
+        const double xk = lane_get<R>(x, k), xk1 = lane_get<R>(x, k - 1);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int c = lane + 64 * r;
+          if (c < k - 1) x[r] -= cur[r] * xk + nxt[r] * xk1;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const int c = lane + 64 * r; cur[r] = (k >= 2 && c < k - 2) ? A[(k - 2) + c * ld] : 0.0; }
+        k -= 2;
+      }
+    }
+  }
+  // P^T w: the interchanges in reverse order
+  for (int k = n - 1; k >= 0;) {
+    const int p = lane_geti<R>(pr, k);
+    if (p > 0) { if (p - 1 != k) lane_swap<R>(x, k, p - 1, lane); k -= 1; }
+    else { if (-p - 1 != k) lane_swap<R>(x, k, -p - 1, lane); k -= 2; }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) { const int i = lane + 64 * r; if (i < n) v[i] = x[r]; }
+}
+
 // DSYTRS (lower) by ONE wavefront; right-hand side v and pivots piv in LDS.
 template <class AP>
 __device__ void bk_solve_wave(AP A, int n, int ld, const int* piv, double* v) {
@@ -281,14 +413,17 @@ __device__ void bk_solve_wave(AP A, int n, int ld, const int* piv, double* v) {
   }
 }
 
-struct BlockExec {
+// NT lanes work on one instance: 64 (one wavefront; small instances, several per CU) or 256.
+template <int NT>
+struct BlockExecT {
+  static constexpr int kBatchThreads = NT;
   static constexpr bool is_device = false;          // model.h: generic lambda form of the flat sweep
   static constexpr bool has_log = false;
   static constexpr bool has_host_control = false;
   static constexpr int kFilterCap = 32;
   struct Log { __device__ void append(const Log&) {} };
   struct FlatTableT {};
-  struct LdltWork { int expect_neg = -1; bool time_updates = false; bool padded = false; };
+  struct LdltWork { int expect_neg = -1; bool time_updates = false; bool padded = false; bool standard = false; };
 
   // per-workgroup bump allocators: global slab and (for the KKT matrix) LDS
   char* ws = nullptr;
@@ -296,6 +431,7 @@ struct BlockExec {
   char* lds_pool = nullptr;
   size_t lds_cap = 0, lds_off = 0;
   int overflow = 0;
+  int lds_mode = 0;          // 0: nothing in LDS, 1: the KKT matrix, 2: the vectors, 3: both
   // reduction scratch in LDS: two alternating buffers (one barrier per reduction)
   double* red = nullptr;     // 2 x 4 doubles
   int* redi = nullptr;       // 2 x 4 ints
@@ -305,7 +441,7 @@ struct BlockExec {
   int* piv = nullptr;        // kWaveSolveMax ints
   static constexpr int kWaveSolveMax = 512;
 
-  __device__ BlockExec(char* slab, size_t cap, char* lds, size_t ldscap, double* r, int* ri, double* v, int* pv)
+  __device__ BlockExecT(char* slab, size_t cap, char* lds, size_t ldscap, double* r, int* ri, double* v, int* pv)
       : ws(slab), ws_cap(cap), lds_pool(lds), lds_cap(ldscap), red(r), redi(ri), vec(v), piv(pv) {}
 
   __device__ void barrier() { __syncthreads(); }
@@ -313,8 +449,11 @@ struct BlockExec {
   template <class T> __device__ T* alloc(size_t n) {
     size_t bytes = ((n ? n : 1) * sizeof(T) + 63) & ~static_cast<size_t>(63);
     char* p;
-    if (bytes >= 16384 && lds_off + bytes <= lds_cap) {
-      // the one large block of a small instance is its KKT matrix: keep it in LDS
+    const bool big = bytes >= 16384;
+    if ((big ? (lds_mode & 1) : (lds_mode & 2)) && lds_off + bytes <= lds_cap) {
+      // LDS first: every map / reduction of the interior-point loop is one dependent memory
+      // round trip, ~0.1 us in LDS against ~1 us in L2.  With lds_all the whole working set of
+      // a small instance (vectors + KKT matrix) lives in LDS; otherwise only the KKT matrix does.
       p = lds_pool + lds_off;
       lds_off += bytes;
     } else {
@@ -374,6 +513,7 @@ struct BlockExec {
       const double other = __shfl_xor(acc, o, 64);
       acc = MODE == 0 ? acc + other : fmax(acc, other);
     }
+    if constexpr (NT == 64) return MODE == 2 ? -acc : acc;     // the butterfly left the result in every lane
     double* buf = red + 4 * parity;
     parity ^= 1;
     if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = acc;
@@ -393,6 +533,7 @@ struct BlockExec {
       const int oi = __shfl_xor(idx, o, 64);
       if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
     }
+    if constexpr (NT == 64) { outv = v; outi = idx; return; }
     double* bv = red + 4 * parity;
     int* bi = redi + 4 * parity;
     parity ^= 1;
@@ -431,17 +572,26 @@ struct BlockExec {
   // ---- Bunch-Kaufman LDL^T by one workgroup (DSYTF2 semantics, lower storage) -------------
   // Same pivot rule, interchanges, multipliers and inertia count as bk_pivot_kernel /
   // bk_update_kernel of exec_hip.h and as the DSYTF2 restatement of the test oracle.
-  __device__ bool ldlt_factor(LdltWork&, double* A, i64 nn, i64 ld, i32* ipiv, bool, int* nneg_out, int* nzero_out) {
+  __device__ bool ldlt_factor(LdltWork& lw, double* A, i64 nn, i64 ld, i32* ipiv, bool, int* nneg_out, int* nzero_out) {
     const int n = static_cast<int>(nn), tid = threadIdx.x;
-    if (n <= 256 && in_lds(A)) {
-      // LDS-resident matrix of a small instance: one wavefront, no workgroup barrier inside
+    lw.standard = false;
+    if (n <= 256) {
+      // small instance: one wavefront, no workgroup barrier inside; L comes out in standard form
+      lw.standard = true;
       if (tid < 64) {
-        lds_double* L = (lds_double*)A;
         int nn_ = 0, nz_ = 0;
         bool ok;
-        if (n <= 64) ok = bk_factor_wave<1>(L, n, static_cast<int>(ld), piv, &nn_, &nz_);
-        else if (n <= 128) ok = bk_factor_wave<2>(L, n, static_cast<int>(ld), piv, &nn_, &nz_);
-        else ok = bk_factor_wave<4>(L, n, static_cast<int>(ld), piv, &nn_, &nz_);
+        const int ldi = static_cast<int>(ld);
+        if (in_lds(A)) {
+          lds_double* L = (lds_double*)A;
+          if (n <= 64) ok = bk_factor_wave<1>(L, n, ldi, piv, &nn_, &nz_);
+          else if (n <= 128) ok = bk_factor_wave<2>(L, n, ldi, piv, &nn_, &nz_);
+          else ok = bk_factor_wave<4>(L, n, ldi, piv, &nn_, &nz_);
+        } else {
+          if (n <= 64) ok = bk_factor_wave<1>(A, n, ldi, piv, &nn_, &nz_);
+          else if (n <= 128) ok = bk_factor_wave<2>(A, n, ldi, piv, &nn_, &nz_);
+          else ok = bk_factor_wave<4>(A, n, ldi, piv, &nn_, &nz_);
+        }
         if (tid == 0) { redi[0] = ok ? 1 : 0; redi[1] = nn_; redi[2] = nz_; }
       }
       __syncthreads();
@@ -568,13 +718,28 @@ struct BlockExec {
   // to three per column) are the whole cost of the block form.  The right-hand side and the
   // pivot vector are staged in LDS, wavefront 0 walks the columns (bk_solve_wave) and the other
   // wavefronts wait at one barrier.
-  __device__ void ldlt_solve_wave(const double* A, int n, i64 ld, const i32* ipiv, double* b) {
+  __device__ void ldlt_solve_wave(const double* A, int n, i64 ld, const i32* ipiv, double* b, bool standard) {
     const int tid = threadIdx.x;
     for (int i = tid; i < n; i += kBatchThreads) { vec[i] = b[i]; piv[i] = ipiv[i]; }
     __syncthreads();
     if (tid < 64) {
-      if (in_lds(A)) bk_solve_wave((const lds_double*)A, n, static_cast<int>(ld), piv, vec);
-      else bk_solve_wave(A, n, static_cast<int>(ld), piv, vec);
+      const int ldi = static_cast<int>(ld);
+      if (standard) {
+        if (in_lds(A)) {
+          const lds_double* L = (const lds_double*)A;
+          if (n <= 64) bk_solve_reg<1>(L, n, ldi, piv, vec);
+          else if (n <= 128) bk_solve_reg<2>(L, n, ldi, piv, vec);
+          else bk_solve_reg<4>(L, n, ldi, piv, vec);
+        } else {
+          if (n <= 64) bk_solve_reg<1>(A, n, ldi, piv, vec);
+          else if (n <= 128) bk_solve_reg<2>(A, n, ldi, piv, vec);
+          else bk_solve_reg<4>(A, n, ldi, piv, vec);
+        }
+      } else if (in_lds(A)) {
+        bk_solve_wave((const lds_double*)A, n, ldi, piv, vec);
+      } else {
+        bk_solve_wave(A, n, ldi, piv, vec);
+      }
     }
     __syncthreads();
     for (int i = tid; i < n; i += kBatchThreads) b[i] = vec[i];
@@ -582,9 +747,9 @@ struct BlockExec {
   }
 
   // DSYTRS (lower) by one workgroup; b in exec-space memory
-  __device__ void ldlt_solve(LdltWork&, const double* A, i64 nn, i64 ld, const i32* ipiv, bool, double* b) {
+  __device__ void ldlt_solve(LdltWork& lw, const double* A, i64 nn, i64 ld, const i32* ipiv, bool, double* b) {
     const int n = static_cast<int>(nn), tid = threadIdx.x;
-    if (n <= kWaveSolveMax) { ldlt_solve_wave(A, n, ld, ipiv, b); return; }
+    if (n <= kWaveSolveMax) { ldlt_solve_wave(A, n, ld, ipiv, b, lw.standard); return; }
     int k = 0;
     while (k < n) {
       const double* Ak = A + static_cast<i64>(k) * ld;

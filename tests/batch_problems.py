@@ -94,3 +94,32 @@ def template_circle_packing(n=4):
         return np.concatenate([r2, radius])
 
     return prob, [R2, rad], sample, centers
+
+
+def template_path_planning(n=50):
+    """Path planning (examples/nlp_examples/path_planning.ipynb) with the obstacle centres `p`
+    (5 x 2) and squared radii `r2` (5) as Parameters: KKT order 1636, the 256-lane batch path."""
+    import dnlp_amd as cp
+    l, d = 10, 2
+    a = np.array([[1.25, 1.25]])
+    b = np.array([[l, l]])
+    p0 = np.array([[2, 4.5, 6, 7, 8.5], [2.2, 5, 8, 6, 9]]).T
+    r0 = np.array([1, 0.8, 0.4, 1.4, 0.5])
+    p = cp.Parameter((5, 2), name="p", value=p0)
+    r2 = cp.Parameter(5, name="r2", value=r0 ** 2)
+    x = cp.Variable((d, n + 1), name="x")
+    L = cp.Variable(name="L")
+    cons = [x[:, 0] == a, x[:, n] == b]
+    cons += [cp.sum(cp.square(x[:, 1:] - x[:, :-1]), axis=0) <= (L / n) ** 2]
+    for i in range(n + 1):
+        cons += [cp.sum(cp.square(x[:, i] - p), axis=1) >= r2]
+    x.value = (b.T - a.T) / n * np.arange(n + 1) + a.T
+    prob = cp.Problem(cp.Minimize(L), cons)
+
+    def sample(i):
+        rng = np.random.default_rng(i)
+        pv = p0 + (rng.uniform(-0.15, 0.15, p0.shape) if i else 0.0)
+        rv = r0 * (rng.uniform(0.9, 1.1, 5) if i else 1.0)
+        return np.concatenate([pv.reshape(-1, order="F"), rv ** 2])
+
+    return prob, [p, r2], sample, x

@@ -86,6 +86,23 @@ def test_batch_kernel_matches_cpu_oracle_per_instance(name, batch, gpu_required)
 
 
 @pytest.mark.gpu
+def test_batch_kernel_large_instances_four_wavefronts(gpu_required):
+    """KKT order 1636 (path planning): the 256-lane form of the kernel (workgroup Bunch-Kaufman,
+    matrix in global memory).  Instance 0 is the notebook's problem: published optimum."""
+    prob, params, sample, x = bp.template_path_planning()
+    pb = ParametricBatch(prob, params)
+    assert pb.affine
+    thetas = np.stack([sample(i) for i in range(3)])
+    res = pb.solve(thetas)
+    assert np.all(res.status == 0)
+    assert abs(res.obj_val[0] - 1.3136882319337619e+01) <= 1e-6 * 13.14      # path_planning.ipynb:103
+    oi = _oracle(arrays_with_data(pb.arrays0, pb.data(thetas)[2]))
+    assert oi["status"] == 0
+    assert abs(res.raw["obj_val"][2] - oi["obj_val"]) <= 1e-6 * abs(oi["obj_val"])
+    np.testing.assert_allclose(res.x[2], oi["x"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
 def test_localization_batch_recovers_true_positions(gpu_required):
     """Noise-free ranges: the optimum is the true position (test_nlp_solvers.py:175-189 analogue)."""
     prob, params, sample, x = bp.template_localization()
