@@ -219,10 +219,12 @@ class HIPNLP:
     def accepts(self, problem):
         return problem.is_dnlp()
 
-    def apply(self, problem, user_variables=None):
+    def apply(self, problem, user_variables=None, make_handle=True):
         """reference nlp_solver.py:47-79: builds the data dict incl. the oracles."""
         from . import _capi
         data, inverse_data = build_nlp_data(problem, user_variables)
+        if not make_handle:          # front-end only: the batched multistart needs just the tape arrays
+            return data, inverse_data
         blob = serialize(data["tape_arrays"])
         handle = _capi.DeviceProblem(blob, data["tape"])
         oracles = DeviceOracles(handle, len(data["x0"]), len(data["cl"]))
@@ -256,6 +258,22 @@ class HIPNLP:
             info = handle.solve(data["x0"])
         data["oracles"].iterations = info["iterations"]
         return info
+
+    def solve_batch_via_data(self, data0, rows, solver_opts):
+        """`rows[k]` = instance data (dnlp_amd.batch.BATCH_DATA_KEYS) of run k on data0's tape:
+        one dnlp_solve_batch launch, one info dict per run (same keys as solve_via_data)."""
+        from .batch import _device_handle
+        opts = dict(solver_opts or {})
+        opts.setdefault("print_level", 0)
+        h = _device_handle(data0["tape_arrays"], data0["tape"], None, opts)
+        try:
+            raw = h.solve_batch(rows, want_duals=True)
+        finally:
+            h.close()
+        return [{"status": int(raw["status"][k]), "x": raw["x"][k], "obj_val": float(raw["obj_val"][k]),
+                 "mult_g": raw["mult_g"][k], "mult_x_L": raw["mult_x_L"][k], "mult_x_U": raw["mult_x_U"][k],
+                 "iterations": int(raw["iterations"][k]), "solve_time": raw["kernel_seconds"] / len(rows),
+                 "stats": np.zeros(16)} for k in range(len(rows))]
 
     def invert(self, solution, inverse_data):
         """reference ipopt_nlpif.py:75-102 (duals are not surfaced there either)."""

@@ -183,12 +183,19 @@ class Problem:
             return self.value
         best_obj, best_solution, all_objs = float("inf"), None, np.zeros(best_of)
         best_inv = None
+        # Multistart as a batch dimension: the runs differ only in the start
+        # point, so on the device path all of them are solved by ONE kernel launch
+        # (dnlp_solve_batch); ranking and bookkeeping stay exactly the reference's.
+        batched = self._best_of_batched(chain, best_of, kwargs) if kwargs.pop("batch", True) else None
         for run in range(best_of):
-            print("Starting NLP solve %d of %d" % (run + 1, best_of))
-            self.set_random_NLP_initial_point(run)
-            canon_problem, inverse_data = chain.apply(self)
-            solution = chain.solver.solve_via_data(canon_problem, warm_start, verbose,
-                                                   solver_opts=kwargs)
+            if batched is None:
+                print("Starting NLP solve %d of %d" % (run + 1, best_of))
+                self.set_random_NLP_initial_point(run)
+                canon_problem, inverse_data = chain.apply(self)
+                solution = chain.solver.solve_via_data(canon_problem, warm_start, verbose,
+                                                       solver_opts=kwargs)
+            else:
+                solution, inverse_data = batched[run]
             # the reference ranks runs by the ORIGINAL objective at the unpacked point
             self.unpack_results(solution, chain, inverse_data, raise_on_error=False)
             obj_value = self.objective.value
@@ -204,6 +211,27 @@ class Problem:
         best_solution["all_objs_from_best_of"] = all_objs
         self.unpack_results(best_solution, chain, best_inv)
         return self.value
+
+    def _best_of_batched(self, chain, best_of, opts):
+        """All `best_of` runs in one device launch; None when the chain's solver has no batch
+        entry point or the lowered runs do not share one tape (then the serial loop runs)."""
+        solve_rows = getattr(chain.solver, "solve_batch_via_data", None)
+        if solve_rows is None:
+            return None
+        from .batch import instance_data, same_structure
+        lowered = []
+        for run in range(best_of):
+            self.set_random_NLP_initial_point(run)
+            data, inv = chain.apply(self, make_handle=False)
+            if lowered and not same_structure(lowered[0][0]["tape_arrays"], data["tape_arrays"]):
+                return None
+            lowered.append((data, inv))
+        if lowered[0][0]["tape"].dense_blocks:
+            return None
+        rows = np.stack([instance_data(d["tape_arrays"]) for d, _ in lowered])
+        print("Solving %d NLP starts in one batched launch" % best_of)
+        infos = solve_rows(lowered[0][0], rows, opts)
+        return [(infos[k], lowered[k][1]) for k in range(best_of)]
 
     def set_random_NLP_initial_point(self, run):
         """Uniform sample inside sample_bounds / finite bounds for variables the user did
@@ -266,13 +294,14 @@ class NLPChain:
         self.flip = flip
         self.solver = solver
 
-    def apply(self, problem):
+    def apply(self, problem, make_handle=True):
         from .dnlp2smooth import Dnlp2Smooth
         if self.flip:
             problem = Problem(Minimize(-problem.objective.expr), problem.constraints)
         smooth, _ = Dnlp2Smooth().apply(problem)
-        data, inverse_data = self.solver.apply(smooth, user_variables=problem.variables())
-        return data, inverse_data
+        if make_handle:
+            return self.solver.apply(smooth, user_variables=problem.variables())
+        return self.solver.apply(smooth, user_variables=problem.variables(), make_handle=False)
 
     def invert(self, solution, inverse_data):
         sol = self.solver.invert(solution, inverse_data)

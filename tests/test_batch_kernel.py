@@ -151,3 +151,39 @@ def test_batch_rejects_wrong_stride_and_dense_blocks(gpu_required):
     with pytest.raises(RuntimeError):
         hq.solve_batch(instance_data(arrays)[None, :])
     hq.close()
+
+
+@pytest.mark.gpu
+def test_best_of_multistart_is_one_batched_launch(gpu_required):
+    """Problem.solve(nlp=True, best_of=N) (reference problem.py:1256-1269): the N starts go through
+    dnlp_solve_batch; per-start objectives and the selected optimum equal the serial loop's."""
+    import dnlp_amd as cp
+
+    def build():
+        rng = np.random.default_rng(3)
+        n = 4
+        radius = rng.uniform(1.0, 3.0, n)
+        centers = cp.Variable((n, 2), name="c")
+        cons = []
+        for i in range(n - 1):
+            cons += [cp.sum((centers[i, :] - centers[i + 1:, :]) ** 2, axis=1) >= (radius[i] + radius[i + 1:]) ** 2]
+        centers.sample_bounds = [-5.0, 5.0]
+        return cp.Problem(cp.Minimize(cp.max(cp.norm_inf(centers, axis=1) + radius)), cons), centers
+
+    # a solved variable counts as user-initialised in later best_of calls (reference
+    # problem.py:1650-1656), so each mode gets a fresh problem
+    prob, centers = build()
+    np.random.seed(0)
+    prob.solve(nlp=True, best_of=12)
+    objs_b = np.array(prob.solver_stats.extra_stats["all_objs_from_best_of"])
+    val_b, c_b = prob.value, centers.value.copy()
+    prob, centers = build()
+    np.random.seed(0)
+    prob.solve(nlp=True, best_of=12, batch=False)
+    objs_s = np.array(prob.solver_stats.extra_stats["all_objs_from_best_of"])
+    assert len(set(np.round(objs_s, 6))) > 1                 # the starts really differ
+    np.testing.assert_allclose(objs_b, objs_s, rtol=1e-6, atol=1e-8)
+    assert abs(val_b - prob.value) <= 1e-6 * abs(val_b)
+    np.testing.assert_allclose(c_b, centers.value, rtol=1e-5, atol=1e-5)
+    # prob.value is the solver's (epigraph) objective, all_objs the original objective at the point
+    assert abs(val_b - objs_b.min()) <= 1e-6 * abs(val_b)

@@ -1,6 +1,15 @@
 """BASELINE config C5 through the single-launch batch path (csrc/batch.h): B parametrised
-localization / circle-packing instances, one workgroup per instance, the whole interior-point
-loop on the device.  Prints problems/s and checks a sample of instances against the CPU oracle."""
+localization / circle-packing / path-planning instances, one wavefront (or workgroup) per
+instance, the whole interior-point loop on the device.  Prints problems/s and checks a sample of
+instances against the CPU oracle.
+
+Multi-GPU: launched under torch.distributed.run, rank r solves the contiguous
+block shard_bounds(B, r, W) on its own GPU; the only exchange is ONE all_gather of
+{id, objective, status, iterations, x*} at the end (RCCL over xGMI with --backend nccl):
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29511 tools/run_c5_batch.py --batch 8192
+"""
 import argparse
 import json
 import os
@@ -20,32 +29,74 @@ ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--check", type=int, default=16)
 ap.add_argument("--which", default="localization,circle_packing")
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--backend", default="nccl")
 args = ap.parse_args()
+
+rank = int(os.environ.get("RANK", "0"))
+world = int(os.environ.get("WORLD_SIZE", "1"))
+local = int(os.environ.get("LOCAL_RANK", "0"))
+dist = None
+if world > 1:
+    import torch
+    import torch.distributed as dist
+    ndev = max(torch.cuda.device_count(), 1)
+    os.environ["DNLP_DEVICE"] = str(local % ndev)
+    if args.backend == "nccl":
+        torch.cuda.set_device(local % ndev)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local % ndev))
+    else:
+        dist.init_process_group(args.backend)
+from dnlp_amd.batch import gather_rows, shard_bounds  # noqa: E402
 
 rows = []
 for which in args.which.split(","):
-    tmpl = {"localization": bp.template_localization, "circle_packing": bp.template_circle_packing}[which]
+    tmpl = {"localization": bp.template_localization, "circle_packing": bp.template_circle_packing,
+            "path_planning": bp.template_path_planning}[which]
     prob, params, sample, var = tmpl()
     t0 = time.time()
     pb = ParametricBatch(prob, params)
     t_template = time.time() - t0
-    thetas = np.stack([sample(i) for i in range(args.batch)])
+    lo, hi = shard_bounds(args.batch, rank, world)
+    thetas = np.stack([sample(i) for i in range(lo, hi)])
     t0 = time.time()
     mat = pb.data(thetas)
     t_data = time.time() - t0
     best = None
     for rep in range(args.reps):
+        if dist is not None:
+            dist.barrier()
         t0 = time.time()
         res = pb.solve(thetas)
         wall = time.time() - t0
         if best is None or wall < best[0]:
             best = (wall, res)
     wall, res = best
-    row = {"problem": which, "batch": args.batch, "N": int(pb.arrays0["dims"][0]), "m": int(pb.arrays0["dims"][1]),
+    if dist is not None:
+        import torch
+        # the one exchange of the path: rows {id, obj, status, iters, x*}
+        local_rows = np.concatenate([np.arange(lo, hi)[:, None], res.raw["obj_val"][:, None],
+                                     res.status[:, None].astype(float), res.iterations[:, None].astype(float),
+                                     res.x], axis=1)
+        t0 = time.time()
+        allrows = gather_rows(local_rows, args.batch)
+        t_gather = time.time() - t0
+        tw = torch.tensor([wall, res.kernel_seconds], dtype=torch.float64,
+                          device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        if rank != 0:
+            continue
+        assert allrows.shape[0] == args.batch and np.array_equal(allrows[:, 0], np.arange(args.batch))
+        print(json.dumps({"problem": which, "n_gpus": world, "batch_total": args.batch,
+                          "problems_per_sec_wall_all_ranks": args.batch / float(tw[0]),
+                          "problems_per_sec_kernel_all_ranks": args.batch / float(tw[1]),
+                          "gather_sec": t_gather, "gather_bytes": int(allrows.size * 8),
+                          "optimal": int(np.sum(allrows[:, 2] == 0))}))
+    nb = hi - lo
+    row = {"problem": which, "batch": nb, "N": int(pb.arrays0["dims"][0]), "m": int(pb.arrays0["dims"][1]),
            "affine_template": bool(pb.affine), "template_sec": t_template, "data_sec": t_data,
            "kernel_sec": res.kernel_seconds, "wall_sec": wall,
-           "problems_per_sec_kernel": args.batch / res.kernel_seconds,
-           "problems_per_sec_wall": args.batch / wall,
+           "problems_per_sec_kernel": nb / res.kernel_seconds,
+           "problems_per_sec_wall": nb / wall,
            "optimal": int(np.sum(res.status == 0)), "acceptable": int(np.sum(res.status == 1)),
            "iters_mean": float(res.iterations.mean()), "iters_max": int(res.iterations.max()),
            "iters_per_sec_kernel": float(res.iterations.sum() / res.kernel_seconds),
@@ -58,7 +109,7 @@ for which in args.which.split(","):
         from oracle.oracle_capi import OracleProblem
         worst_obj, worst_x, same_iters = 0.0, 0.0, 0
         t0 = time.time()
-        for i in range(min(args.check, args.batch)):
+        for i in range(min(args.check, nb)):
             orc = OracleProblem(serialize(arrays_with_data(pb.arrays0, mat[i])))
             for k, v in HIPNLP.DEFAULT_OPTIONS.items():
                 orc.set_option(k, v)
@@ -66,10 +117,13 @@ for which in args.which.split(","):
             worst_obj = max(worst_obj, abs(oi["obj_val"] - res.raw["obj_val"][i]) / max(1.0, abs(oi["obj_val"])))
             worst_x = max(worst_x, float(np.max(np.abs(oi["x"] - res.x[i]))))
             same_iters += int(oi["iterations"] == res.iterations[i])
-        row.update({"checked": min(args.check, args.batch), "max_rel_obj_diff_vs_oracle": worst_obj,
+        row.update({"checked": min(args.check, nb), "max_rel_obj_diff_vs_oracle": worst_obj,
                     "max_abs_x_diff_vs_oracle": worst_x, "same_iteration_count": same_iters,
-                    "oracle_sec_per_problem": (time.time() - t0) / min(args.check, args.batch)})
+                    "oracle_sec_per_problem": (time.time() - t0) / min(args.check, nb)})
     rows.append(row)
     print(json.dumps(row))
-os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "c5_batch.json"), "w"), indent=1)
+if rank == 0:
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "c5_batch.json"), "w"), indent=1)
+if dist is not None:
+    dist.destroy_process_group()
