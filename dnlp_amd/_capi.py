@@ -53,8 +53,11 @@ class CApi:
         f("ipm_begin", C.c_int, [C.c_void_p, _dbl_p])
         f("ipm_step", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)])
         f("ipm_finish", C.c_int, [C.c_void_p] + [_dbl_p] * 6 + [C.POINTER(C.c_int)])
+        f("eval_fused", C.c_int, [C.c_void_p, _dbl_p, _dbl_p, _dbl_p])
         f("get_stats", C.c_int, [C.c_void_p, _dbl_p, C.c_int])
         f("get_log", C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t])
+        if hasattr(self.lib, prefix + "time_fused"):
+            f("time_fused", C.c_int, [C.c_void_p, _dbl_p, C.c_int, _dbl_p])
         if hasattr(self.lib, prefix + "solve_batch_timed"):      # product library only (no oracle batch path)
             _int_p = C.POINTER(C.c_int)
             f("batch_stride", C.c_int64, [C.c_void_p])
@@ -212,6 +215,24 @@ class ProblemHandle:
         self._check(self.api.eval_h(self.ptr, _dp(x), 1, float(obj_factor), _dp(lam), 1, None, None,
                                     _dp(out)), "eval_h")
         return out
+
+    def eval_fused(self, xfree):
+        """f and grad f of the user's variables from the fused element program (one kernel)."""
+        xfree = np.ascontiguousarray(xfree, dtype=np.float64)
+        f = C.c_double()
+        grad = np.empty_like(xfree)
+        rc = self.api.eval_fused(self.ptr, _dp(xfree), C.cast(C.byref(f), _dbl_p), _dp(grad))
+        if rc != 0:
+            raise RuntimeError("eval_fused failed: %s" % self.api.error())
+        return float(f.value), grad
+
+    def time_fused(self, xfree, reps=10) -> float:
+        xfree = np.ascontiguousarray(xfree, dtype=np.float64)
+        sec = C.c_double()
+        rc = self.api.time_fused(self.ptr, _dp(xfree), int(reps), C.cast(C.byref(sec), _dbl_p))
+        if rc != 0:
+            raise RuntimeError("time_fused failed: %s" % self.api.error())
+        return float(sec.value)
 
     def set_option(self, key, val):
         if isinstance(val, bool):

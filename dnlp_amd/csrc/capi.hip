@@ -43,6 +43,33 @@ int dnlp_solve_batch_timed(void* vp, int batch, const double* data, int64_t stri
     return 0;)
 }
 
+// Average seconds of one fused f + grad f evaluation with x resident in HBM (HIP events around
+// `reps` back-to-back evaluations on the problem's stream): the measurement behind the C2 roofline
+// line (tools/run_c2.py).
+int dnlp_time_fused(void* vp, const double* xfree, int reps, double* seconds) {
+  auto* p = static_cast<dnlp_problem_t*>(vp);
+  DNLP_TRY(
+    if (!p->fused.present) { dnlp::tls_error() = "no fused objective program in this tape"; return -11; }
+    const size_t nf = static_cast<size_t>(p->fused.nfree);
+    double* dx = p->ex.alloc<double>(nf);
+    double* dg = p->ex.alloc<double>(nf);
+    p->ex.h2d(dx, xfree, 8 * nf);
+    p->fused.eval(dx, dg);
+    hipEvent_t e0, e1;
+    DNLP_HIP_CHECK(hipEventCreate(&e0));
+    DNLP_HIP_CHECK(hipEventCreate(&e1));
+    DNLP_HIP_CHECK(hipEventRecord(e0, p->ex.stream));
+    for (int r = 0; r < reps; ++r) p->fused.eval(dx, dg);
+    DNLP_HIP_CHECK(hipEventRecord(e1, p->ex.stream));
+    DNLP_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    DNLP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    p->ex.release(dx); p->ex.release(dg);
+    *seconds = 1e-3 * ms / (reps > 0 ? reps : 1);
+    return 0;)
+}
+
 const char* dnlp_version(void) { return "dnlp_amd 0.1.0 (gfx950)"; }
 
 int dnlp_dev_alloc(int device, size_t bytes, void** out) {

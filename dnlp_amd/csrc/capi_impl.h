@@ -26,6 +26,8 @@ struct ProblemT {
   DenseKkt<E> kkt;
   std::unique_ptr<Ipm<E, DenseKkt<E>>> ipm;
   std::unique_ptr<ReducedLbfgs<E>> lbfgs;
+  FusedObjective<E> fused;
+  bool use_fused = true;
   int lbfgs_history = 10;
   IpmOptions opt;
   i64 pivot_max_n = 2048;
@@ -38,6 +40,7 @@ struct ProblemT {
   void create(const void* data, size_t len) {
     blob.reset(new TapeBlob(data, len));
     model.init(&ex, *blob);
+    fused.load(&ex, *blob);
     const auto& t = model.t;
     dx = ex.template alloc<double>(static_cast<size_t>(t.N));
     dlam = ex.template alloc<double>(static_cast<size_t>(t.m + 1));
@@ -105,6 +108,7 @@ struct ProblemT {
     else if (k == "restoration") opt.restoration = yes() ? 1 : 0;
     else if (k == "time_kernels") time_kernels = yes();
     else if (k == "lbfgs_history" || k == "limited_memory_max_history") lbfgs_history = static_cast<int>(num());
+    else if (k == "fused_objective") use_fused = yes();
     else if (k == "adaptive_fallback") opt.adaptive_fallback = yes() ? 1 : 0;
     else if (k == "lanczos_inertia_bound") opt.lanczos_inertia_bound = yes() ? 1 : 0;
     else if (k == "lanczos_min_n") opt.lanczos_min_n = static_cast<int>(num());
@@ -235,11 +239,20 @@ struct ProblemT {
     DNLP_TRY(if (!p->lbfgs) p->lbfgs.reset(new dnlp::ReducedLbfgs<EXEC>(&p->ex, &p->model));           \
              p->lbfgs->tol = p->opt.tol; p->lbfgs->max_iter = p->opt.max_iter > 3000 ? p->opt.max_iter : 20000; \
              p->lbfgs->history = p->lbfgs_history; p->lbfgs->print_level = p->opt.print_level;         \
+             p->lbfgs->fused = &p->fused; p->lbfgs->use_fused = p->use_fused;                        \
              p->swept = false;                                                                       \
              int st = p->lbfgs->solve(x);                                                            \
              p->lbfgs->extract(x, obj);                                                              \
              if (iters) *iters = p->lbfgs->iterations; if (evals) *evals = p->lbfgs->evaluations;    \
              if (gnorm) *gnorm = p->lbfgs->gnorm_final; return st;)                                  \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, eval_fused)(void* vp, const double* xfree, double* f, double* grad) {            \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    DNLP_TRY(if (!p->fused.present) { dnlp::tls_error() = "no fused objective program in this tape"; return -11; } \
+             const size_t nf = static_cast<size_t>(p->fused.nfree);                                   \
+             double* dxf = p->ex.template alloc<double>(nf); double* dgf = p->ex.template alloc<double>(nf); \
+             p->ex.h2d(dxf, xfree, 8 * nf); *f = p->fused.eval(dxf, dgf); p->ex.d2h(grad, dgf, 8 * nf); \
+             p->ex.release(dxf); p->ex.release(dgf); return 0;)                                      \
   }                                                                                                  \
   int DNLP_CAT(PFX, get_stats)(void* vp, double* s, int n) {                                         \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \

@@ -1,0 +1,141 @@
+// Fused native-form objective: f and grad f of an unconstrained elementwise-sum problem in ONE
+// pass over the user's variables (BASELINE config C2, SURVEY.md §8d: "kernel = fused f + grad f,
+// algorithmic bytes 16 n").  The per-element register program comes from dnlp_amd/fused.py
+// (tape arrays fz_*); it is data, not generated code.
+//
+// Per element i: forward sweep over the instructions (values into the element's slots), the
+// last value is the element's contribution to f; reverse sweep turns every slot into the adjoint
+// of its value (each value has exactly one consumer: the programs are trees) and scatters the
+// adjoints of the loads into grad.  The arithmetic of the unary atoms is `unary_rules`
+// (atom_math.h) — the same rules the tape kernels use (reference cvxpy/atoms/elementwise/*.py).
+//
+// fused_elements() is the single source: HipExec runs it with the slots in LDS
+// (slot[k][lane]: conflict-free, register file of the interpreter) and atomic adds into grad;
+// the host space of the test oracle runs the same function with a local array.
+#pragma once
+#include "atom_math.h"
+#include "tape.h"
+
+namespace dnlp {
+
+constexpr int kFusedMaxInstr = 32;
+enum FusedOp : int { F_LOADV = 0, F_LOADC, F_UNARY, F_ADD, F_SUB, F_MUL, F_SCALE, F_ADDC, F_DIV };
+
+// one program, passed by value to the kernel (scalar loads, uniform control flow)
+struct FusedProg {
+  int n = 0;
+  i64 nelem = 0;
+  int op[kFusedMaxInstr], a[kFusedMaxInstr], b[kFusedMaxInstr];
+  i64 off[kFusedMaxInstr], stride[kFusedMaxInstr];
+  double p[kFusedMaxInstr], p2[kFusedMaxInstr];
+};
+
+// NE elements per call (instruction-major: one opcode decode serves NE independent element
+// chains).  S: slot accessor  double& S(int k, int e);  G: scatter  void G(i64 index, double value).
+// Elements i0 + e * estride, e < NE; elements >= P.nelem are skipped by the caller's `valid` mask.
+template <int NE, class S, class G>
+DNLP_HD inline double fused_elements(const FusedProg& P, i64 i0, i64 estride, const bool (&valid)[NE],
+                                     const double* __restrict__ x, const double* __restrict__ consts,
+                                     S slot, G scatter) {
+  const int n = P.n;
+  for (int k = 0; k < n; ++k) {
+    const int op = P.op[k], a = P.a[k], b = P.b[k];
+    const i64 off = P.off[k], st = P.stride[k];
+    const double p = P.p[k], p2 = P.p2[k];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      if (!valid[e]) continue;
+      const i64 i = i0 + e * estride;
+      double v;
+      switch (op) {
+        case F_LOADV: v = x[off + st * i]; break;
+        case F_LOADC: v = consts[off + st * i]; break;
+        case F_UNARY: { double g1, g2; unary_rules(b, slot(a, e), p, p2, v, g1, g2); break; }
+        case F_ADD: v = slot(a, e) + slot(b, e); break;
+        case F_SUB: v = slot(a, e) - slot(b, e); break;
+        case F_MUL: v = slot(a, e) * slot(b, e); break;
+        case F_SCALE: v = p * slot(a, e); break;
+        case F_ADDC: v = slot(a, e) + p; break;
+        default: v = slot(a, e) / slot(b, e); break;   // F_DIV
+      }
+      slot(k, e) = v;
+    }
+  }
+  double fsum = 0.0;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) if (valid[e]) { fsum += slot(n - 1, e); slot(n - 1, e) = 1.0; }
+  for (int k = n - 1; k >= 0; --k) {
+    const int op = P.op[k], a = P.a[k], b = P.b[k];
+    const i64 off = P.off[k], st = P.stride[k];
+    const double p = P.p[k], p2 = P.p2[k];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      if (!valid[e]) continue;
+      const i64 i = i0 + e * estride;
+      const double g = slot(k, e);
+      switch (op) {
+        case F_LOADV: scatter(off + st * i, g); break;
+        case F_LOADC: break;
+        case F_UNARY: { double v, g1, g2; unary_rules(b, slot(a, e), p, p2, v, g1, g2); slot(a, e) = g * g1; break; }
+        case F_ADD: slot(a, e) = g; slot(b, e) = g; break;
+        case F_SUB: slot(a, e) = g; slot(b, e) = -g; break;
+        case F_MUL: { const double va = slot(a, e), vb = slot(b, e); slot(a, e) = g * vb; slot(b, e) = g * va; break; }
+        case F_SCALE: slot(a, e) = g * p; break;
+        case F_ADDC: slot(a, e) = g; break;
+        default: { const double va = slot(a, e), vb = slot(b, e); slot(a, e) = g / vb; slot(b, e) = -g * va / (vb * vb); break; }
+      }
+    }
+  }
+  return fsum;
+}
+
+template <class E>
+struct FusedObjective {
+  E* ex = nullptr;
+  std::vector<FusedProg> progs;
+  double* consts = nullptr;   // exec space
+  double c0 = 0.0;
+  i64 nfree = 0;
+  bool present = false;
+
+  void load(E* e, const TapeBlob& tb) {
+    ex = e;
+    if (!tb.has("fz_dims")) return;
+    const i64* d = tb.i64s("fz_dims");
+    const i64 nprog = d[0], ninstr = d[1], nconst = d[2];
+    nfree = d[3];
+    const i64* ps = tb.i64s("fz_prog_start");
+    const i64* pn = tb.i64s("fz_prog_nelem");
+    for (i64 q = 0; q < nprog; ++q) {
+      FusedProg P;
+      P.n = static_cast<int>(ps[q + 1] - ps[q]);
+      P.nelem = pn[q];
+      if (P.n < 1 || P.n > kFusedMaxInstr || ps[q + 1] > ninstr) throw std::runtime_error("bad fused program");
+      for (int k = 0; k < P.n; ++k) {
+        const i64 s = ps[q] + k;
+        P.op[k] = tb.i32s("fz_op")[s]; P.a[k] = tb.i32s("fz_a")[s]; P.b[k] = tb.i32s("fz_b")[s];
+        P.off[k] = tb.i64s("fz_off")[s]; P.stride[k] = tb.i64s("fz_stride")[s];
+        P.p[k] = tb.f64("fz_p")[s]; P.p2[k] = tb.f64("fz_p2")[s];
+        // every value must have exactly one consumer that comes later (tree programs)
+        if (P.op[k] >= F_UNARY && (P.a[k] < 0 || P.a[k] >= k)) throw std::runtime_error("bad fused operand");
+        if ((P.op[k] == F_ADD || P.op[k] == F_SUB || P.op[k] == F_MUL || P.op[k] == F_DIV) && (P.b[k] < 0 || P.b[k] >= k))
+          throw std::runtime_error("bad fused operand");
+      }
+      progs.push_back(P);
+    }
+    consts = ex->template alloc<double>(static_cast<size_t>(nconst > 0 ? nconst : 1));
+    if (nconst > 0) ex->h2d(consts, tb.f64("fz_consts"), sizeof(double) * static_cast<size_t>(nconst));
+    c0 = tb.f64("fz_c0")[0];
+    present = true;
+  }
+
+  // x, grad: exec space, nfree entries.  Returns f.
+  double eval(const double* x, double* grad) {
+    ex->zero(grad, sizeof(double) * static_cast<size_t>(nfree));
+    double f = c0;
+    for (const FusedProg& P : progs) f += ex->fused_eval(P, x, consts, grad);
+    return f;
+  }
+};
+
+}  // namespace dnlp

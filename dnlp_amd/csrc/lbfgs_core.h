@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "fused_obj.h"
 #include "ipm_core.h"
 
 namespace dnlp {
@@ -23,6 +24,12 @@ template <class E>
 class ReducedLbfgs {
  public:
   ReducedLbfgs(E* ex, Model<E>* md) : ex_(ex), md_(md) {}
+
+  // optional fused native-form evaluator (fused_obj.h); when present and enabled, f / grad f of
+  // the user's variables come from ONE kernel instead of the canonical tape's fixed-point passes
+  FusedObjective<E>* fused = nullptr;
+  bool use_fused = true;
+  bool fused_used = false;
 
   double tol = 1e-7;
   int max_iter = 20000;
@@ -40,6 +47,13 @@ class ReducedLbfgs {
 
   // f and reduced gradient at the free variables xfree (exec space, nfree); returns false on NaN
   bool eval(const double* xfree, double& fval, double* gred) {
+    if (fused && fused->present && use_fused) {
+      fval = fused->eval(xfree, gred);
+      ++evaluations;
+      fused_used = true;
+      const double chk = ex_->sum(fused->nfree, [=] DNLP_HD(i64 k) { return gred[k] - gred[k]; });
+      return std::isfinite(fval) && chk == 0.0;
+    }
     const TapeView& t = md_->t;
     const i64 N = t.N, m = t.m, nf = t.nfree;
     const i32 *fi = t.free_idx, *dv = t.def_var;
@@ -172,9 +186,13 @@ class ReducedLbfgs {
       f = fn;
       iterations = it + 1;
     }
-    // leave the canonical vector consistent with the final free variables
+    // leave the canonical vector consistent with the final free variables (tape pass: it also
+    // fills the auxiliary variables the fused evaluator never forms)
     double fl;
+    const bool keep = use_fused;
+    use_fused = false;
     eval(xf, fl, gf);
+    use_fused = keep;
     f_final = fl;
     wall = now_sec() - t0;
     return status;

@@ -115,7 +115,7 @@ class InverseData:
         self.offset = 0.0
 
 
-def build_nlp_data(problem, user_variables=None):
+def build_nlp_data(problem, user_variables=None, fused_spec=None):
     """Bounds + tape lowering for a smooth-canonical problem.  Returns the data dict without
     touching the device (used by CPU tests and by `HIPNLP.apply`).  `user_variables` (the
     variables of the problem as the user wrote it) enables the reduced-space arrays."""
@@ -140,7 +140,19 @@ def build_nlp_data(problem, user_variables=None):
         red = reduction_arrays(new_problem, tape, {id(v) for v in user_variables})
         if red is not None:
             data["tape_arrays"].update(red)
+            if fused_spec is not None:
+                # fused native-form objective (dnlp_amd/fused.py): variable references become
+                # positions in the free-variable vector of the reduced-space solve
+                from .fused import fused_arrays
+                free = np.asarray(red["free_idx"], dtype=np.int64)
+                off, base = 0, {}
+                for v in new_problem.variables():
+                    if any(v is u for u in user_variables):
+                        base[v.id] = int(np.searchsorted(free, off))
+                    off += v.size
+                data["tape_arrays"].update(fused_arrays(fused_spec, base, free.size))
         data["reducible"] = red is not None
+        data["fused"] = red is not None and fused_spec is not None
     return data, inverse_data
 
 
@@ -219,10 +231,10 @@ class HIPNLP:
     def accepts(self, problem):
         return problem.is_dnlp()
 
-    def apply(self, problem, user_variables=None, make_handle=True):
+    def apply(self, problem, user_variables=None, make_handle=True, fused_spec=None):
         """reference nlp_solver.py:47-79: builds the data dict incl. the oracles."""
         from . import _capi
-        data, inverse_data = build_nlp_data(problem, user_variables)
+        data, inverse_data = build_nlp_data(problem, user_variables, fused_spec)
         if not make_handle:          # front-end only: the batched multistart needs just the tape arrays
             return data, inverse_data
         blob = serialize(data["tape_arrays"])

@@ -300,7 +300,12 @@ class NLPChain:
             problem = Problem(Minimize(-problem.objective.expr), problem.constraints)
         smooth, _ = Dnlp2Smooth().apply(problem)
         if make_handle:
-            return self.solver.apply(smooth, user_variables=problem.variables())
+            from .fused import build_fused_spec
+            try:
+                return self.solver.apply(smooth, user_variables=problem.variables(),
+                                         fused_spec=build_fused_spec(problem))
+            except TypeError:      # a solver interface without the fused-objective hook
+                return self.solver.apply(smooth, user_variables=problem.variables())
         return self.solver.apply(smooth, user_variables=problem.variables(), make_handle=False)
 
     def invert(self, solution, inverse_data):

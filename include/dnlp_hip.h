@@ -106,6 +106,14 @@ int dnlp_solve_batch_timed(dnlp_problem* p, int batch, const double* data, int64
                            double* obj, double* mult_g, double* mult_x_L, double* mult_x_U,
                            int* status, int* iters, int* factorizations, double* kernel_seconds,
                            double* times);
+/* f and grad f of the USER's variables from the fused element program of an unconstrained
+ * elementwise-sum objective (tape arrays fz_*, dnlp_amd/fused.py; BASELINE config C2): one kernel,
+ * x read once, grad accumulated once — eval_f + eval_grad_f of nlp_solver.py:212-235 on the
+ * problem as written, without the auxiliary variables of dnlp2smooth.  xfree / grad hold the
+ * user's variables in canonical order.  -11 when the tape carries no such program. */
+int dnlp_eval_fused(dnlp_problem* p, const double* xfree, double* f, double* grad);
+/* Average seconds of one fused evaluation with x resident in HBM (HIP events, `reps` evaluations). */
+int dnlp_time_fused(dnlp_problem* p, const double* xfree, int reps, double* seconds);
 /* Statistics of the last solve: stats[0..15] = iterations, factorizations, wall, t_eval,
  * t_factor, t_solve, mu, inf_pr, inf_du, compl, nlp_error, last_delta_w, ... */
 int dnlp_get_stats(dnlp_problem* p, double* stats, int n);

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../dnlp_amd/csrc/exec.h"
+#include "../dnlp_amd/csrc/fused_obj.h"
 
 namespace dnlp {
 
@@ -54,6 +55,16 @@ struct HostExec : HostControlled {
     bool nan = false;
     for (i64 i = 0; i < n; ++i) { double v = f(i); if (v != v) nan = true; if (v < s) s = v; }
     return nan ? std::nan("") : s;
+  }
+
+  // fused element program (csrc/fused_obj.h): sequential host loop, local slots
+  double fused_eval(const FusedProg& P, const double* x, const double* consts, double* grad) {
+    double f = 0.0, slots[kFusedMaxInstr];
+    const bool valid[1] = {true};
+    for (i64 i = 0; i < P.nelem; ++i)
+      f += fused_elements<1>(P, i, 0, valid, x, consts, [&](int k, int) -> double& { return slots[k]; },
+                             [&](i64 idx, double v) { grad[idx] += v; });
+    return f;
   }
 
   // Gram-Schmidt step against k stored vectors: c = V^T w, w -= V c

@@ -1,0 +1,128 @@
+"""Fused native-form objective programs (dnlp_amd/fused.py, csrc/fused_obj.h): BASELINE config C2.
+CPU: program builder + numpy interpreter + host instantiation against closed forms, finite
+differences and the canonical-tape reduced gradient.  GPU: the LDS-register-file kernel."""
+import numpy as np
+import pytest
+
+import dnlp_amd as cp
+from dnlp_amd.dnlp2smooth import Dnlp2Smooth
+from dnlp_amd.fused import build_fused_spec
+from dnlp_amd.nlp_solver import build_nlp_data
+from dnlp_amd.tape import serialize
+from problem_zoo import rosenbrock_chain
+
+
+def _data(prob):
+    smooth, _ = Dnlp2Smooth().apply(prob)
+    data, _ = build_nlp_data(smooth, user_variables=prob.variables(), fused_spec=build_fused_spec(prob))
+    return data
+
+
+def _rosenbrock(x):
+    f = np.sum((1 - x[:-1]) ** 2) + 100 * np.sum((x[1:] - x[:-1] ** 2) ** 2)
+    g = np.zeros_like(x)
+    g[:-1] += -2 * (1 - x[:-1]) - 400 * (x[1:] - x[:-1] ** 2) * x[:-1]
+    g[1:] += 200 * (x[1:] - x[:-1] ** 2)
+    return f, g
+
+
+def _mixed(n=40):
+    rng = np.random.default_rng(5)
+    c = rng.standard_normal(n)
+    w = rng.uniform(0.5, 1.5, n)
+    x = cp.Variable(n)
+    y = cp.Variable(n)
+    x.value = rng.uniform(0.5, 1.5, n)
+    y.value = rng.uniform(0.5, 1.5, n)
+    f = (cp.sum(cp.exp(cp.multiply(w, x))) + 0.5 * cp.sum_squares(x - c) + 0.3 * cp.sum(cp.multiply(x[:-1], y[1:]))
+         + 2 * cp.sum(cp.logistic(y)) + (1.0 / 3) * cp.sum(cp.sin(x[::2])) + 0.25 * cp.sum_squares(y) + 7.0)
+    return cp.Problem(cp.Minimize(f), []), (x, y), (c, w)
+
+
+def test_builder_accepts_elementwise_sums_and_rejects_the_rest():
+    assert build_fused_spec(rosenbrock_chain(cp, 30)) is not None
+    prob, _, _ = _mixed()
+    fb = build_fused_spec(prob)
+    assert fb is not None and abs(fb.c0 - 7.0) < 1e-15
+    x = cp.Variable(5)
+    assert build_fused_spec(cp.Problem(cp.Minimize(cp.sum(cp.exp(x))), [cp.sum(x) == 1])) is None      # constraints
+    A = np.random.default_rng(0).standard_normal((5, 5))
+    assert build_fused_spec(cp.Problem(cp.Minimize(cp.quad_form(x, A @ A.T)), [])) is None              # not elementwise
+    assert build_fused_spec(cp.Problem(cp.Minimize(cp.sum(cp.exp(A @ x))), [])) is None                 # matrix product
+    xb = cp.Variable(5, nonneg=True)
+    assert build_fused_spec(cp.Problem(cp.Minimize(cp.sum(cp.exp(xb))), [])) is None                    # bounds -> IPM
+
+
+def test_program_interpreters_match_closed_form_and_tape():
+    from oracle.fused_eval import numpy_eval
+    from oracle.oracle_capi import OracleProblem
+    n = 300
+    data = _data(rosenbrock_chain(cp, n))
+    assert data["fused"]
+    ta = data["tape_arrays"]
+    xv = np.random.default_rng(1).standard_normal(n)
+    f0, g0 = _rosenbrock(xv)
+    f1, g1 = numpy_eval(ta, xv)
+    orc = OracleProblem(serialize(ta))
+    f2, g2 = orc.eval_fused(xv)
+    np.testing.assert_allclose([f1, f2], f0, rtol=1e-13)
+    np.testing.assert_allclose(g1, g0, rtol=1e-12, atol=1e-10)
+    np.testing.assert_allclose(g2, g1, rtol=1e-14, atol=1e-12)
+
+
+def test_mixed_objective_against_finite_differences_and_reduced_tape_solve():
+    from oracle.oracle_capi import OracleProblem
+    prob, (x, y), _ = _mixed()
+    data = _data(prob)
+    assert data["fused"]
+    ta = data["tape_arrays"]
+    orc = OracleProblem(serialize(ta))
+    free = np.asarray(ta["free_idx"])
+    z = np.asarray(data["x0"])[free]
+    f, g = orc.eval_fused(z)
+    for k in (0, 7, 41, 79):
+        e = np.zeros_like(z)
+        e[k] = 1e-6
+        fp, _ = orc.eval_fused(z + e)
+        fm, _ = orc.eval_fused(z - e)
+        assert abs((fp - fm) / 2e-6 - g[k]) <= 1e-6 * max(1.0, abs(g[k]))
+    res = {}
+    for mode in ("yes", "no"):
+        o = OracleProblem(serialize(ta))
+        o.set_option("fused_objective", mode)
+        o.set_option("tol", 1e-6)
+        res[mode] = o.solve_reduced(data["x0"])
+        assert res[mode]["status"] == 0
+    assert abs(res["yes"]["obj_val"] - res["no"]["obj_val"]) <= 1e-9 * abs(res["no"]["obj_val"])
+    np.testing.assert_allclose(res["yes"]["x"], res["no"]["x"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_device_fused_kernel_matches_interpreters(gpu_required):
+    from dnlp_amd import _capi
+    from oracle.fused_eval import numpy_eval
+    for prob in (rosenbrock_chain(cp, 5000), _mixed(1000)[0]):
+        data = _data(prob)
+        ta = data["tape_arrays"]
+        dev = _capi.DeviceProblem(serialize(ta), data["tape"], device=0)
+        z = np.asarray(data["x0"])[np.asarray(ta["free_idx"])] + 0.1
+        f, g = dev.eval_fused(z)
+        f1, g1 = numpy_eval(ta, z)
+        assert abs(f - f1) <= 1e-12 * max(1.0, abs(f1))
+        np.testing.assert_allclose(g, g1, rtol=1e-12, atol=1e-10)
+        dev.close()
+
+
+@pytest.mark.gpu
+def test_c2_full_size_fused_lbfgs(gpu_required):
+    """BASELINE config C2 at n = 1e5 through the front-end with the fused evaluator: x* = 1."""
+    n = 100000
+    prob = rosenbrock_chain(cp, n)
+    prob.solve(nlp=True, algorithm="lbfgs", tol=1e-9)
+    assert prob.status == "optimal"
+    assert np.max(np.abs(prob.variables()[0].value - 1.0)) <= 1e-6
+    assert prob.value <= 1e-10
+    # same answer without the fused evaluator (canonical-tape reduced gradient)
+    prob2 = rosenbrock_chain(cp, n)
+    prob2.solve(nlp=True, algorithm="lbfgs", tol=1e-9, fused_objective="no")
+    assert np.max(np.abs(prob2.variables()[0].value - prob.variables()[0].value)) <= 1e-6
