@@ -259,6 +259,7 @@ class HIPNLP:
             options["print_level"] = 5 if verbose else 0
         handle = data["handle"]
         algorithm = options.pop("algorithm", "interior-point")
+        device_loop = options.pop("device_loop", "auto")
         for k, v in options.items():
             handle.set_option(k, v)
         if algorithm in ("lbfgs", "reduced-lbfgs"):
@@ -266,10 +267,34 @@ class HIPNLP:
                 raise ValueError("algorithm='lbfgs' needs an unconstrained smooth problem whose "
                                  "canonical constraints only define auxiliary variables")
             info = handle.solve_reduced(data["x0"])
+        elif self._use_device_loop(data, options, device_loop):
+            # Small problem, nothing to print: the whole interior-point loop runs inside one kernel
+            # (the batch path with a batch of one, csrc/batch.h) instead of being driven from the
+            # host with a stream synchronisation per scalar.  Same algorithm text, same result.
+            from .batch import instance_data
+            raw = handle.solve_batch(instance_data(data["tape_arrays"])[None, :], want_duals=True)
+            info = {"status": int(raw["status"][0]), "x": raw["x"][0], "obj_val": float(raw["obj_val"][0]),
+                    "g": np.zeros(handle.m), "mult_g": raw["mult_g"][0], "mult_x_L": raw["mult_x_L"][0],
+                    "mult_x_U": raw["mult_x_U"][0], "iterations": int(raw["iterations"][0]),
+                    "solve_time": raw["kernel_seconds"], "stats": np.zeros(16), "device_loop": True}
         else:
             info = handle.solve(data["x0"])
         data["oracles"].iterations = info["iterations"]
         return info
+
+    DEVICE_LOOP_MAX_ORDER = 256        # KKT order N + m up to which one wavefront runs the whole solve
+
+    def _use_device_loop(self, data, options, mode) -> bool:
+        if mode in (False, "no", "host"):
+            return False
+        tape = data["tape"]
+        small = len(data["x0"]) + len(data["cl"]) <= self.DEVICE_LOOP_MAX_ORDER
+        fits = small and not tape.dense_blocks and not tape.dense_consts
+        if mode in (True, "yes", "device"):
+            if tape.dense_blocks or tape.dense_consts:
+                raise ValueError("device_loop='yes' needs a tape without dense quad_form blocks")
+            return True
+        return fits and int(options.get("print_level", 0)) == 0
 
     def solve_batch_via_data(self, data0, rows, solver_opts):
         """`rows[k]` = instance data (dnlp_amd.batch.BATCH_DATA_KEYS) of run k on data0's tape:

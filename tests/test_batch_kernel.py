@@ -187,3 +187,38 @@ def test_best_of_multistart_is_one_batched_launch(gpu_required):
     np.testing.assert_allclose(c_b, centers.value, rtol=1e-5, atol=1e-5)
     # prob.value is the solver's (epigraph) objective, all_objs the original objective at the point
     assert abs(val_b - objs_b.min()) <= 1e-6 * abs(val_b)
+
+
+@pytest.mark.gpu
+def test_small_silent_solves_run_the_loop_on_the_device(gpu_required):
+    """Problem.solve(nlp=True) of a small problem = batch of one (no host round trips); the host-
+    driven loop (device_loop='host', or verbose) gives the same answer."""
+    import dnlp_amd as cp
+    from problem_zoo import hs071, localization
+    for build in (hs071, localization):
+        pa, pb_ = build(cp), build(cp)
+        pa.solve(nlp=True)
+        pb_.solve(nlp=True, device_loop="host")
+        assert pa.status == pb_.status == "optimal"
+        assert abs(pa.value - pb_.value) <= 1e-7 * max(1.0, abs(pb_.value))
+        for va, vb in zip(pa.variables(), pb_.variables()):
+            np.testing.assert_allclose(va.value, vb.value, rtol=1e-5, atol=1e-6)
+        assert pa.solver_stats.num_iters == pb_.solver_stats.num_iters
+
+
+@pytest.mark.gpu
+def test_batch_status_codes_and_options(gpu_required):
+    """IPOPT status integers per instance: an infeasible instance and an iteration limit."""
+    import dnlp_amd as cp
+    from dnlp_amd.batch import solve_batch
+    def make(ub):
+        x = cp.Variable(2)
+        x.value = np.array([0.5, 0.5])
+        return cp.Problem(cp.Minimize(cp.sum(cp.exp(x))), [cp.sum(cp.square(x)) >= 4.0, x <= ub, x >= -ub])
+    res = solve_batch([make(3.0), make(0.5), make(2.5)])
+    assert res.status[0] == 0 and res.status[2] == 0
+    assert res.status[1] in (2, -2)                      # Infeasible_Problem_Detected / Restoration_Failed
+    res2 = solve_batch([make(3.0), make(2.5)], max_iter=2)
+    assert np.all(res2.status == -1) and np.all(res2.iterations == 2)
+    res3 = solve_batch([make(3.0)], mu_strategy="monotone")
+    assert res3.status[0] == 0 and abs(res3.obj_val[0] - res.obj_val[0]) <= 1e-6
