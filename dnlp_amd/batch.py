@@ -189,7 +189,15 @@ class ParametricBatch:
         if thetas.shape[1] != self.P:
             raise ValueError("expected %d parameter values per instance" % self.P)
         if self.affine:
-            return self.d0[None, :] + (self.D @ (thetas - self.theta0[None, :]).T).T
+            delta = thetas - self.theta0[None, :]
+            if self.D.shape[0] * self.D.shape[1] <= 8_000_000:
+                # small map: one dense GEMM, result already row-major (what the C entry point takes)
+                if getattr(self, "_DT_dense", None) is None:
+                    self._DT_dense = np.ascontiguousarray(self.D.toarray().T)
+                out = delta @ self._DT_dense
+                out += self.d0[None, :]
+                return out
+            return np.ascontiguousarray(self.d0[None, :] + (self.D @ delta.T).T)
         rows = []
         for th in thetas:
             d = self._lower_at(th)
@@ -200,13 +208,35 @@ class ParametricBatch:
         return np.stack(rows)
 
     def solve(self, thetas, device=None, want_duals=False, **opts) -> BatchResult:
+        """One kernel launch for all rows of `thetas`.  The device handle (tape structure resident
+        in HBM) is created on first use and kept for later calls with the same device/options."""
+        import time as _t
+        t0 = _t.time()
         mat = self.data(thetas)
-        h = _device_handle(self.arrays0, self.data0["tape"], device, opts)
-        try:
-            raw = h.solve_batch(mat, want_duals=want_duals)
-        finally:
-            h.close()
+        t1 = _t.time()
+        key = (device, tuple(sorted((k, str(v)) for k, v in opts.items())))
+        if getattr(self, "_handle_key", None) != key:
+            self.close()
+            self._handle = _device_handle(self.arrays0, self.data0["tape"], device, opts)
+            self._handle_key = key
+        t2 = _t.time()
+        raw = self._handle.solve_batch(mat, want_duals=want_duals)
+        t3 = _t.time()
+        if os.environ.get("DNLP_BATCH_DEBUG"):
+            print("[batch.py] data %.4f handle %.4f solve_batch %.4f" % (t1 - t0, t2 - t1, t3 - t2), flush=True)
         return BatchResult(raw, self.inv, self.flip)
+
+    def close(self):
+        h = getattr(self, "_handle", None)
+        if h is not None:
+            h.close()
+        self._handle, self._handle_key = None, None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:

@@ -122,15 +122,31 @@ struct BatchRunner {
   BatchLayout lay;
   i64 in_stride = 0;
   int last_grid = 0, last_threads = 0, last_lds_mode = 0, last_per_cu = 0;   // launch plan of the last solve
-  std::vector<void*> scratch;
+  // device buffers kept across calls (grow-only): a call is then one H2D copy, one launch and the
+  // result copies — no allocation on the steady-state path
+  struct Buf { void* p = nullptr; size_t cap = 0; };
+  Buf bufs[12];
+  int nbuf_used = 0;
+  int ncu = 0;
+  std::vector<double> slab;
 
-  ~BatchRunner() { release(); if (d_segs) hipFree(d_segs); if (d_red) hipFree(d_red); if (d_sparse) hipFree(d_sparse); }
-  void release() { for (void* p : scratch) hipFree(p); scratch.clear(); }
+  ~BatchRunner() {
+    for (Buf& b : bufs) if (b.p) hipFree(b.p);
+    if (d_segs) hipFree(d_segs);
+    if (d_red) hipFree(d_red);
+    if (d_sparse) hipFree(d_sparse);
+  }
+  void release() { nbuf_used = 0; }
   template <class T> T* dalloc(size_t n) {
-    void* p = nullptr;
-    DNLP_HIP_CHECK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
-    scratch.push_back(p);
-    return static_cast<T*>(p);
+    Buf& b = bufs[nbuf_used++];
+    const size_t bytes = (n ? n : 1) * sizeof(T);
+    if (bytes > b.cap) {
+      if (b.p) DNLP_HIP_CHECK(hipFree(b.p));
+      b.p = nullptr;
+      DNLP_HIP_CHECK(hipMalloc(&b.p, bytes));
+      b.cap = bytes;
+    }
+    return static_cast<T*>(b.p);
   }
 
   void init(HipExec* e, Tape<HipExec>* t) {
@@ -161,10 +177,13 @@ struct BatchRunner {
              double* multg_out, double* zl_out, double* zu_out, int* status_out, int* iters_out, int* nfact_out,
              double* seconds, double* times_out = nullptr) {
     if (stride != in_stride) throw std::runtime_error("batched solve: instance stride does not match the tape");
+    const bool dbg = std::getenv("DNLP_BATCH_DEBUG") != nullptr;
+    const double tdbg0 = now_sec();
+    auto mark = [&](const char* what) { if (dbg) std::fprintf(stderr, "[batch] %-22s %.4f s\n", what, now_sec() - tdbg0); };
     const Tape<HipExec>& t = *tape;
     DNLP_HIP_CHECK(hipSetDevice(ex->device));
     // host gather: the per-segment parameters become per-flat-row parameters
-    std::vector<double> slab(static_cast<size_t>(batch) * static_cast<size_t>(lay.total));
+    slab.resize(static_cast<size_t>(batch) * static_cast<size_t>(lay.total));
     const i64 head = 1 + (t.N + t.Z) + t.m + t.nnzJ + t.G.nnz + t.Mg.nnz + t.Mw.nnz + t.MJ.nnz + t.MH.nnz;
     const i64 tail = 3 * t.N + 2 * t.m;
     for (int k = 0; k < batch; ++k) {
@@ -178,6 +197,7 @@ struct BatchRunner {
       }
       std::copy(sp2 + t.nseg, sp2 + t.nseg + tail, dst + lay.x0);
     }
+    mark("slab built");
     release();
     BatchArgs a;
     a.base = t;           // slice: the view with the shared exec-space index arrays
@@ -188,6 +208,7 @@ struct BatchRunner {
     a.opt = opt;
     a.slabs = dalloc<double>(slab.size());
     DNLP_HIP_CHECK(hipMemcpy(a.slabs, slab.data(), slab.size() * sizeof(double), hipMemcpyHostToDevice));
+    mark("slab uploaded");
     const i64 n = t.N + t.m, ld = (n + 7) / 8 * 8;
     // KKT matrix in LDS when it fits beside the static reduction scratch (160 KB per workgroup)
     const size_t kbytes = ((static_cast<size_t>(ld) * n + 256) * 8 + 63) & ~static_cast<size_t>(63);
@@ -227,9 +248,12 @@ struct BatchRunner {
     int per_cu = 1, ncu = 256;
     if (wave) DNLP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, batch_solve_kernel<64>, nthreads, a.lds_bytes));
     else DNLP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, batch_solve_kernel<256>, nthreads, a.lds_bytes));
-    hipDeviceProp_t prop;
-    DNLP_HIP_CHECK(hipGetDeviceProperties(&prop, ex->device));
-    ncu = prop.multiProcessorCount;
+    if (this->ncu == 0) {
+      int v = 0;
+      DNLP_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ex->device));
+      this->ncu = v;
+    }
+    ncu = this->ncu;
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     if (const char* e = std::getenv("DNLP_BATCH_PER_CU")) { const int w = std::atoi(e); if (w >= 1 && w <= 8) per_cu = w; }
@@ -247,6 +271,7 @@ struct BatchRunner {
     a.times_out = times_out ? dalloc<double>(4 * static_cast<size_t>(batch)) : nullptr;
     a.next = dalloc<int>(1);
     DNLP_HIP_CHECK(hipMemsetAsync(a.next, 0, sizeof(int), ex->stream));
+    mark("plan + buffers");
     hipEvent_t e0, e1;
     DNLP_HIP_CHECK(hipEventCreate(&e0));
     DNLP_HIP_CHECK(hipEventCreate(&e1));
@@ -260,6 +285,7 @@ struct BatchRunner {
     DNLP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0);
     hipEventDestroy(e1);
+    mark("kernel done");
     if (seconds) *seconds = 1e-3 * ms;
     auto down = [&](void* h, const void* d, size_t bytes) { if (h && bytes) DNLP_HIP_CHECK(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost)); };
     down(x_out, a.x_out, sizeof(double) * static_cast<size_t>(batch) * t.N);
@@ -272,6 +298,7 @@ struct BatchRunner {
     down(nfact_out, a.nfact_out, sizeof(int) * batch);
     down(times_out, a.times_out, sizeof(double) * 4 * batch);
     release();
+    mark("results copied");
   }
 };
 

@@ -20,10 +20,18 @@ int dnlp_device_count(void) {
 int dnlp_solve_batch_timed(void* vp, int batch, const double* data, int64_t stride, double* x, double* obj, double* mult_g,
                            double* mult_x_L, double* mult_x_U, int* status, int* iters, int* factorizations, double* seconds,
                            double* times);
+static BatchRunner* batch_runner(dnlp_problem_t* p) {
+  if (!p->batch_state) {
+    auto* r = new BatchRunner();
+    std::shared_ptr<void> hold(r, [](void* q) { delete static_cast<BatchRunner*>(q); });
+    r->init(&p->ex, p->model.owner);
+    p->batch_state = hold;
+  }
+  return static_cast<BatchRunner*>(p->batch_state.get());
+}
 int64_t dnlp_batch_stride(void* vp) {
   auto* p = static_cast<dnlp_problem_t*>(vp);
-  BatchRunner r;
-  DNLP_TRY(r.init(&p->ex, p->model.owner); return r.in_stride;)
+  DNLP_TRY(return batch_runner(p)->in_stride;)
 }
 int dnlp_solve_batch(void* vp, int batch, const double* data, int64_t stride, double* x, double* obj, double* mult_g,
                      double* mult_x_L, double* mult_x_U, int* status, int* iters, int* factorizations, double* seconds) {
@@ -36,8 +44,7 @@ int dnlp_solve_batch_timed(void* vp, int batch, const double* data, int64_t stri
                            double* times) {
   auto* p = static_cast<dnlp_problem_t*>(vp);
   DNLP_TRY(
-    BatchRunner r;
-    r.init(&p->ex, p->model.owner);
+    BatchRunner& r = *batch_runner(p);
     p->ex.sync();
     r.solve(batch, data, stride, p->opt, x, obj, mult_g, mult_x_L, mult_x_U, status, iters, factorizations, seconds, times);
     return 0;)

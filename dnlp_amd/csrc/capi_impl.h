@@ -27,6 +27,7 @@ struct ProblemT {
   std::unique_ptr<Ipm<E, DenseKkt<E>>> ipm;
   std::unique_ptr<ReducedLbfgs<E>> lbfgs;
   FusedObjective<E> fused;
+  std::shared_ptr<void> batch_state;   // exec-space specific batched-solve state (capi.hip)
   bool use_fused = true;
   int lbfgs_history = 10;
   IpmOptions opt;
