@@ -54,6 +54,7 @@ class CApi:
         f("ipm_step", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)])
         f("ipm_finish", C.c_int, [C.c_void_p] + [_dbl_p] * 6 + [C.POINTER(C.c_int)])
         f("eval_fused", C.c_int, [C.c_void_p, _dbl_p, _dbl_p, _dbl_p])
+        f("kkt_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)])
         f("get_stats", C.c_int, [C.c_void_p, _dbl_p, C.c_int])
         f("get_log", C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t])
         if hasattr(self.lib, prefix + "time_fused"):
@@ -233,6 +234,15 @@ class ProblemHandle:
         if rc != 0:
             raise RuntimeError("time_fused failed: %s" % self.api.error())
         return float(sec.value)
+
+    def kkt_info(self):
+        """Linear-solver plan of this handle: sparse static-pattern LDL^T or dense."""
+        out = (C.c_int64 * 6)()
+        rc = self.api.kkt_info(self.ptr, out)
+        if rc != 0:
+            raise RuntimeError("kkt_info failed: %s" % self.api.error())
+        return {"sparse": bool(out[0]), "factor_values": int(out[1]), "pivot_blocks": int(out[2]),
+                "max_struct": int(out[3]), "pairs_2x2": int(out[4]), "update_triples": int(out[5])}
 
     def set_option(self, key, val):
         if isinstance(val, bool):

@@ -38,6 +38,8 @@ struct BatchArgs {
   double *x_out = nullptr, *obj_out = nullptr, *multg_out = nullptr, *zl_out = nullptr, *zu_out = nullptr;
   int *status_out = nullptr, *iters_out = nullptr, *nfact_out = nullptr;
   double* times_out = nullptr;   // batch x 4: wall, t_eval, t_factor, t_solve (seconds, device clock)
+  SparsePlan sp;                 // static-pattern sparse KKT plan (shared by all instances)
+  int use_sparse = 0;
   int* next = nullptr;           // work queue head: instances are claimed dynamically (iteration counts vary 10x)
 };
 
@@ -85,8 +87,12 @@ __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
     ModelT* md = new (o.md) ModelT();
     md->init_view(ex, t);
     KktT* kkt = new (o.kkt) KktT();
-    kkt->pivot_max_n = static_cast<i64>(1) << 40;   // always the pivoted (Bunch-Kaufman) factorisation
-    kkt->init(ex, t.N, t.m);
+    if (a.use_sparse) {
+      kkt->init_sparse(ex, t.N, t.m, a.sp);
+    } else {
+      kkt->pivot_max_n = static_cast<i64>(1) << 40;   // always the pivoted (Bunch-Kaufman) factorisation
+      kkt->init(ex, t.N, t.m);
+    }
     IpmT* ipm = new (o.ipm) IpmT(ex, md, kkt);
     ipm->opt = a.opt;
     ipm->allocate();
@@ -122,6 +128,9 @@ struct BatchRunner {
   BatchLayout lay;
   i64 in_stride = 0;
   int last_grid = 0, last_threads = 0, last_lds_mode = 0, last_per_cu = 0;   // launch plan of the last solve
+  bool have_sparse = false;
+  SparsePlan dev_plan;
+  void set_sparse_plan(const SparsePlanHost& hp) { dev_plan = hp.upload(ex); have_sparse = true; }
   // device buffers kept across calls (grow-only): a call is then one H2D copy, one launch and the
   // result copies — no allocation on the steady-state path
   struct Buf { void* p = nullptr; size_t cap = 0; };
@@ -211,12 +220,20 @@ struct BatchRunner {
     mark("slab uploaded");
     const i64 n = t.N + t.m, ld = (n + 7) / 8 * 8;
     // KKT matrix in LDS when it fits beside the static reduction scratch (160 KB per workgroup)
-    const size_t kbytes = ((static_cast<size_t>(ld) * n + 256) * 8 + 63) & ~static_cast<size_t>(63);
-    const size_t vdoubles = static_cast<size_t>(40 * t.N + 48 * t.m + 2 * t.Z + t.nd + t.nh + t.nnzH + t.nnzJ + 2 * n + 512);
-    const size_t vbytes = (vdoubles * 8 + 160 * 64 + 255) & ~static_cast<size_t>(255);
+    a.use_sparse = have_sparse ? 1 : 0;
+    a.sp = dev_plan;
+    // working set of one instance: the "matrix" (dense KKT, or the sparse factor when it is large)
+    // and the vectors (model + interior-point state; counts follow Model::init_view / Ipm::allocate)
+    const size_t sparse_vals = have_sparse ? static_cast<size_t>(dev_plan.nvals + 2 * dev_plan.maxs + 16) : 0;
+    const bool sparse_big = sparse_vals * 8 >= 16384;
+    const size_t kbytes = have_sparse ? (sparse_big ? ((sparse_vals * 8 + 63) & ~static_cast<size_t>(63)) : 0)
+                                      : (((static_cast<size_t>(ld) * n + 256) * 8 + 63) & ~static_cast<size_t>(63));
+    const size_t vdoubles = static_cast<size_t>(26 * t.N + 36 * t.m + 2 * t.Z + t.nd + t.nh + t.nnzH + t.nnzJ + 2 * n + 64) +
+                            (have_sparse && !sparse_big ? sparse_vals : 0);
+    const size_t vbytes = ((vdoubles * 8 * 21 / 20) + 96 * 64 + 255) & ~static_cast<size_t>(255);
     // lanes per instance: one wavefront up to order 256 (factorisation and solves are
     // single-wavefront there, vectors are at most a few hundred long), four above
-    const bool wave = n <= 256;
+    const bool wave = n <= 256 || have_sparse;
     const void* kern = wave ? reinterpret_cast<const void*>(batch_solve_kernel<64>)
                             : reinterpret_cast<const void*>(batch_solve_kernel<256>);
     const int nthreads = wave ? 64 : 256;

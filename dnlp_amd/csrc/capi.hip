@@ -25,6 +25,8 @@ static BatchRunner* batch_runner(dnlp_problem_t* p) {
     auto* r = new BatchRunner();
     std::shared_ptr<void> hold(r, [](void* q) { delete static_cast<BatchRunner*>(q); });
     r->init(&p->ex, p->model.owner);
+    p->plan_linear_solver();
+    if (p->use_sparse) r->set_sparse_plan(p->sparse_plan);
     p->batch_state = hold;
   }
   return static_cast<BatchRunner*>(p->batch_state.get());

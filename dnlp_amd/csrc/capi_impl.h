@@ -34,6 +34,9 @@ struct ProblemT {
   i64 pivot_max_n = 2048;
   double *dx = nullptr, *dlam = nullptr, *dg = nullptr, *dgrad = nullptr, *djac = nullptr, *dh = nullptr;
   bool swept = false, kkt_ready = false, time_kernels = false;
+  int linear_solver = 0;            // 0 auto, 1 dense, 2 sparse (static-pattern LDL^T)
+  SparsePlanHost sparse_plan;
+  bool sparse_planned = false, use_sparse = false;
 
   explicit ProblemT(int device) : ex(device) {}
   ~ProblemT() { model.destroy(); }
@@ -60,10 +63,27 @@ struct ProblemT {
     }
   }
 
+  // Decide dense vs sparse KKT once per handle: the plan is built when the pattern is sparse enough
+  // to be worth it, and used when its factor is a small fraction of the dense triangle.
+  void plan_linear_solver() {
+    if (sparse_planned) return;
+    sparse_planned = true;
+    use_sparse = false;
+    const auto& t = *model.owner;
+    const double n = static_cast<double>(t.N + t.m);
+    if (linear_solver == 1 || t.nblk > 0 || t.ndense > 0 || n < 2) return;
+    const double pattern = static_cast<double>(t.nnzH + t.nnzJ) + n;
+    if (linear_solver == 0 && pattern > 0.1 * 0.5 * n * n) return;        // already dense
+    build_sparse_plan(t, sparse_plan, opt.bound_relax_factor > 0.0);
+    use_sparse = linear_solver == 2 || sparse_plan.fill_ratio <= 0.3;
+  }
+
   void ensure_ipm() {
     if (!kkt_ready) {
+      plan_linear_solver();
       kkt.pivot_max_n = pivot_max_n;
-      kkt.init(&ex, model.t.N, model.t.m);
+      if (use_sparse) kkt.init_sparse(&ex, model.t.N, model.t.m, sparse_plan.upload(&ex));
+      else kkt.init(&ex, model.t.N, model.t.m);
       kkt_ready = true;
     }
     kkt.lw.time_updates = time_kernels;
@@ -113,7 +133,12 @@ struct ProblemT {
     else if (k == "adaptive_fallback") opt.adaptive_fallback = yes() ? 1 : 0;
     else if (k == "lanczos_inertia_bound") opt.lanczos_inertia_bound = yes() ? 1 : 0;
     else if (k == "lanczos_min_n") opt.lanczos_min_n = static_cast<int>(num());
-    else if (k == "sb" || k == "linear_solver" || k == "print_user_options" || k == "print_timing_statistics")
+    else if (k == "linear_solver") {
+      // IPOPT's names (mumps, ma27, ...) are accepted and mean "your choice"; dense / sparse force a path
+      linear_solver = (v == "dense") ? 1 : (v == "sparse") ? 2 : 0;
+      if (kkt_ready) return -12;      // fixed once the KKT object exists
+    }
+    else if (k == "sb" || k == "print_user_options" || k == "print_timing_statistics")
       { /* IPOPT options with no counterpart here: accepted and ignored */ }
     else return -12;   // Invalid_Option, as IPOPT reports unknown names
     return 0;
@@ -254,6 +279,13 @@ struct ProblemT {
              double* dxf = p->ex.template alloc<double>(nf); double* dgf = p->ex.template alloc<double>(nf); \
              p->ex.h2d(dxf, xfree, 8 * nf); *f = p->fused.eval(dxf, dgf); p->ex.d2h(grad, dgf, 8 * nf); \
              p->ex.release(dxf); p->ex.release(dgf); return 0;)                                      \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, kkt_info)(void* vp, int64_t* out) {                                               \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    DNLP_TRY(p->plan_linear_solver();                                                                \
+             out[0] = p->use_sparse ? 1 : 0; out[1] = p->sparse_plan.nnzL; out[2] = p->sparse_plan.nblk(); \
+             out[3] = p->sparse_plan.maxs; out[4] = p->sparse_plan.n_pairs;                          \
+             out[5] = static_cast<int64_t>(p->sparse_plan.tdst.size()); return 0;)                    \
   }                                                                                                  \
   int DNLP_CAT(PFX, get_stats)(void* vp, double* s, int n) {                                         \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \

@@ -22,6 +22,7 @@
 
 #include "atom_math.h"
 #include "exec.h"
+#include "sparse_ldl.h"
 
 namespace dnlp {
 
@@ -544,6 +545,29 @@ struct BlockExecT {
     for (int k = 1; k < kBatchThreads / 64; ++k)
       if (bv[k] > outv || (bv[k] == outv && bi[k] < outi)) { outv = bv[k]; outi = bi[k]; }
   }
+
+  // static-pattern sparse LDL^T (sparse_ldl.h): the lanes of this instance are the policy
+  struct Par {
+    BlockExecT* ex;
+    __device__ int lanes() const { return NT; }
+    __device__ int lane() const { return static_cast<int>(threadIdx.x); }
+    __device__ void sync() const { __syncthreads(); }
+    __device__ double sum(double v) const {
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if constexpr (NT == 64) return v;
+      double* buf = ex->red + 4 * ex->parity;
+      ex->parity ^= 1;
+      if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
+      __syncthreads();
+      double r = buf[0];
+      for (int k = 1; k < NT / 64; ++k) r += buf[k];
+      return r;
+    }
+  };
+  __device__ bool sparse_factor(const SparsePlan& pl, double* vals, double* w, int* nneg, int* nzero) {
+    return sparse_ldl_factor(pl, vals, w, nneg, nzero, Par{this});
+  }
+  __device__ void sparse_solve(const SparsePlan& pl, const double* vals, double* x) { sparse_ldl_solve(pl, vals, x, Par{this}); }
 
   // facilities of the large dense path that a batch instance never uses (the host rejects
   // tapes with dense quad_form blocks before launching)

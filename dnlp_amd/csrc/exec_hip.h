@@ -19,6 +19,7 @@
 #include "atom_math.h"
 #include "exec.h"
 #include "fused_obj.h"
+#include "sparse_ldl.h"
 
 namespace dnlp {
 
@@ -604,6 +605,35 @@ fused_eval_kernel(FusedProg P, const double* __restrict__ x, const double* __res
   }
 }
 
+// ---- static-pattern sparse LDL^T (sparse_ldl.h) driven from the host: one workgroup walks the
+// pivot blocks in order (the update triples of a block are spread over the 256 lanes).
+struct WgPar {
+  double* red;
+  __device__ int lanes() const { return kBlock; }
+  __device__ int lane() const { return static_cast<int>(threadIdx.x); }
+  __device__ void sync() const { __syncthreads(); }
+  __device__ double sum(double v) const {
+    v = wave_sum(v);
+    __syncthreads();                      // red may still be read from the previous call
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = red[0];
+    for (int k = 1; k < kBlock / 64; ++k) r += red[k];
+    return r;
+  }
+};
+struct SparseInfo { int ok, nneg, nzero, pad; };
+__global__ void __launch_bounds__(kBlock) sparse_factor_kernel(SparsePlan pl, double* vals, double* w, SparseInfo* info) {
+  __shared__ double red[kBlock / 64];
+  int nneg = 0, nzero = 0;
+  const bool ok = sparse_ldl_factor(pl, vals, w, &nneg, &nzero, WgPar{red});
+  if (threadIdx.x == 0) { info->ok = ok ? 1 : 0; info->nneg = nneg; info->nzero = nzero; }
+}
+__global__ void __launch_bounds__(kBlock) sparse_solve_kernel(SparsePlan pl, const double* vals, double* x) {
+  __shared__ double red[kBlock / 64];
+  sparse_ldl_solve(pl, vals, x, WgPar{red});
+}
+
 struct BlockedLdlt;   // ldlt_blocked.h
 
 struct HipExec : HostControlled {
@@ -614,6 +644,7 @@ struct HipExec : HostControlled {
   double* d_partial = nullptr;
   double* h_partial = nullptr;
   double* gemv_part = nullptr;
+  struct SparseInfo* sparse_info = nullptr;
   size_t gemv_part_cap = 0;
 
   struct LdltWork {
@@ -731,6 +762,21 @@ struct HipExec : HostControlled {
     const i64 grid = (t.total + 2 * kBlock - 1) / (2 * kBlock);
     hipLaunchKernelGGL(sweep_flat_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, t, x, z, dv, hv, w,
                        with_h ? 1 : 0);
+    DNLP_LAUNCH_CHECK();
+  }
+  bool sparse_factor(const SparsePlan& pl, double* vals, double* w, int* nneg, int* nzero) {
+    if (!sparse_info) { sparse_info = alloc<SparseInfo>(1); }
+    hipLaunchKernelGGL(sparse_factor_kernel, dim3(1), dim3(kBlock), 0, stream, pl, vals, w, sparse_info);
+    DNLP_LAUNCH_CHECK();
+    SparseInfo h;
+    DNLP_HIP_CHECK(hipMemcpyAsync(&h, sparse_info, sizeof h, hipMemcpyDeviceToHost, stream));
+    DNLP_HIP_CHECK(hipStreamSynchronize(stream));
+    *nneg = h.nneg;
+    *nzero = h.nzero;
+    return h.ok != 0;
+  }
+  void sparse_solve(const SparsePlan& pl, const double* vals, double* x) {
+    hipLaunchKernelGGL(sparse_solve_kernel, dim3(1), dim3(kBlock), 0, stream, pl, vals, x);
     DNLP_LAUNCH_CHECK();
   }
   double fused_eval(const FusedProg& P, const double* x, const double* consts, double* grad) {

@@ -11,6 +11,7 @@
 //     caller's delta_w / delta_c regularisation (WB Algorithm IC) repairs them.
 #pragma once
 #include "model.h"
+#include "sparse_ldl.h"
 
 namespace dnlp {
 
@@ -25,6 +26,20 @@ struct DenseKkt {
   i64 n_fixed = 0;             // number of fixed variables (set by the interior-point driver)
   bool pivoted = true;
   typename E::LdltWork lw;
+  // sparse mode (sparse_plan.h / sparse_ldl.h): static-pattern LDL^T instead of the dense matrix
+  bool sparse = false;
+  SparsePlan sp;
+  double* svals = nullptr;     // plan-layout values: assembled matrix, then (D, L)
+  double* swork = nullptr;     // 2 * maxs scratch of the numeric phase
+
+  DNLP_HD void init_sparse(E* e, i64 N_, i64 m_, const SparsePlan& plan) {
+    ex = e; N = N_; m = m_; n = N + m; ld = 0;
+    sparse = true;
+    pivoted = true;            // (static 2x2 blocks) keeps the large-dense-only code paths of the IP loop off
+    sp = plan;
+    svals = ex->template alloc<double>(static_cast<size_t>(sp.nvals > 0 ? sp.nvals : 1));
+    swork = ex->template alloc<double>(static_cast<size_t>(2 * sp.maxs + 2));
+  }
 
   DNLP_HD void init(E* e, i64 N_, i64 m_) {
     ex = e; N = N_; m = m_; n = N + m;
@@ -41,6 +56,28 @@ struct DenseKkt {
   DNLP_HD bool assemble_factor(Model<E>& md, const double* jv, const double* Sx, const double* D,
                        const double* fixmask, double dw, int* nneg, int* nzero) {
     const TapeView& t = md.t;
+    if (sparse) {
+      double* V = svals;
+      const i32 *hp = sp.hpos, *jp = sp.jpos, *dp = sp.dpos;
+      const i32 *hr = t.hess_rows, *hc = t.hess_cols, *jc = t.jac_cols;
+      const double* hs = md.Hs;
+      const i64 NN = N;
+      ex->zero(svals, sizeof(double) * static_cast<size_t>(sp.nvals));
+      ex->map(t.nnzH, [=] DNLP_HD(i64 p) {
+        if (fixmask[hr[p]] != 0.0 || fixmask[hc[p]] != 0.0 || hp[p] < 0) return;
+        V[hp[p]] += hs[p];
+      });
+      ex->map(t.nnzJ, [=] DNLP_HD(i64 p) {
+        if (fixmask[jc[p]] != 0.0 || jp[p] < 0) return;
+        V[jp[p]] = jv[p];
+      });
+      ex->map(N, [=] DNLP_HD(i64 j) {
+        if (fixmask[j] != 0.0) V[dp[j]] = 1.0;
+        else V[dp[j]] += Sx[j] + dw;
+      });
+      ex->map(m, [=] DNLP_HD(i64 i) { V[dp[NN + i]] = -D[i]; });
+      return ex->sparse_factor(sp, svals, swork, nneg, nzero);
+    }
     double* Kp = K;
     const i64 ldk = ld, NN = N;
     // one dense block covering all of W lets us skip the memset of the n x n part
@@ -92,6 +129,7 @@ struct DenseKkt {
 
   DNLP_HD void solve(const double* rhs, double* sol) {
     if (sol != rhs) ex->d2d(sol, rhs, sizeof(double) * static_cast<size_t>(n));
+    if (sparse) { ex->sparse_solve(sp, svals, sol); return; }
     ex->ldlt_solve(lw, K, n, ld, ipiv, pivoted, sol);
   }
 };

@@ -1,0 +1,351 @@
+// Static-pattern sparse LDL^T of the reduced KKT matrix
+//
+//     K = [ W + Sigma_x + delta_w I    J^T ]      (order n = N + m)
+//         [ J                          -D  ]
+//
+// for problems whose KKT matrix is sparse (every example of the paper: nnz(L) is 0.4 % of the
+// dense triangle for path planning / power flow, 5 % for localization).  The role
+// MUMPS plays for IPOPT in the reference (ipopt_nlpif.py:140-170).
+//
+// Everything that depends only on the sparsity pattern is computed ONCE per tape on the host
+// (this file):
+//   * static pivot blocks.  dnlp2smooth introduces auxiliary variables that enter linearly and
+//     are defined by equality rows, so both their diagonal and the row's diagonal are
+//     structurally zero: no 1x1 pivot order exists without regularisation.  Every equality row
+//     is therefore paired, when possible, with one adjacent variable into a 2x2 pivot block
+//     [[w, a], [a, -d]] (det = -w d - a^2 < 0 for a != 0), preferring structurally-zero-diagonal
+//     variables and constant Jacobian coefficients (the defining rows `t - expr == 0` have a = 1);
+//   * a minimum-degree elimination order of the blocks, the fill pattern, the address of every
+//     entry of the reduced matrices, and the UPDATE PROGRAM: for every pivot block the list of
+//     (target address, row i, row j) triples of its Schur-complement update.
+// The numeric phase (sparse_ldl.h) is then branch-free index arithmetic over flat arrays: the
+// same single-source routine runs as host loops (test oracle), as one wavefront / workgroup per
+// instance inside the batch kernel, and as a kernel of the HIP space.
+//
+// Pivoting is static: a zero or wrong-sign pivot is reported through the inertia (nzero /
+// nneg), and the interior-point loop's delta_w / delta_c regularisation (WB Algorithm IC)
+// repairs it, exactly as for the unpivoted blocked dense path.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <queue>
+#include <vector>
+
+#include "tape.h"
+
+namespace dnlp {
+
+// exec-space view of the plan (plain pointers)
+struct SparsePlan {
+  i64 n = 0, N = 0, m = 0, nblk = 0, nvals = 0, ntrip = 0, maxs = 0, nlev = 0;
+  i32* bnode = nullptr;   // 2 per block: pivot nodes (second = -1 for a 1x1 block)
+  i64* soff = nullptr;    // nblk + 1: offsets into sidx
+  i32* sidx = nullptr;    // struct of every block: node ids (0..N-1 variables, N.. constraint rows)
+  i64* doff = nullptr;    // per block: D values (1x1: d ; 2x2: d11, d21, d22)
+  i64* loff = nullptr;    // per block: L values, s_k rows x b_k, row-major
+  i64* toff = nullptr;    // nblk + 1: offsets into the triples
+  i32* tdst = nullptr;    // target value index
+  i32* tiu = nullptr;     // row indices (within the block's struct) of the two factors
+  i32* tiv = nullptr;
+  i32* hpos = nullptr;    // value index of every Hessian COO entry (lower triangle)
+  i32* jpos = nullptr;    // value index of every Jacobian COO entry
+  i32* dpos = nullptr;    // value index of the diagonal of every node
+};
+
+struct SparsePlanHost {
+  i64 n = 0, N = 0, m = 0, nvals = 0, maxs = 0;
+  std::vector<i32> bnode, sidx, tdst, tiu, tiv, hpos, jpos, dpos;
+  std::vector<i64> soff, doff, loff, toff;
+  i64 nnzL = 0, n_delayed = 0, n_pairs = 0;
+  double fill_ratio = 0.0;    // factor values / dense lower triangle
+
+  i64 nblk() const { return static_cast<i64>(doff.size()); }
+
+  // zero_diag_var[j]: no Hessian diagonal entry and no finite bound; eq_row[i]: cl == cu;
+  // jac_const[p]: |constant coefficient| of Jacobian entry p, or 0 when the entry is not constant
+  void build(i64 N_, i64 m_, const std::vector<i32>& hr, const std::vector<i32>& hc, const std::vector<i32>& jr,
+             const std::vector<i32>& jc, const std::vector<char>& zero_diag_var, const std::vector<char>& eq_row,
+             const std::vector<double>& jac_const, const std::vector<char>& fixed_var) {
+    N = N_; m = m_; n = N + m;
+    const i64 nn = n;
+    // fixed variables (lb == ub) are pinned by the interior-point loop: unit diagonal, all their
+    // couplings masked.  They are isolated nodes of the pattern and never pivot partners.
+    auto is_fixed = [&](i32 u) { return u < N && fixed_var[static_cast<size_t>(u)] != 0; };
+    // ---- symmetric adjacency (no diagonal) ----
+    std::vector<std::vector<i32>> adj(static_cast<size_t>(nn));
+    auto edge = [&](i32 a, i32 b) { if (a != b && !is_fixed(a) && !is_fixed(b)) { adj[static_cast<size_t>(a)].push_back(b); adj[static_cast<size_t>(b)].push_back(a); } };
+    for (size_t p = 0; p < hr.size(); ++p) edge(hr[p], hc[p]);
+    for (size_t p = 0; p < jr.size(); ++p) edge(static_cast<i32>(N + jr[p]), jc[p]);
+    for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+    // ---- static 2x2 blocks: equality row <-> one adjacent variable ----
+    std::vector<i32> partner(static_cast<size_t>(nn), -1);
+    {
+      // best coefficient per (row, var): from the Jacobian COO
+      std::vector<std::vector<std::pair<i32, double>>> rowvars(static_cast<size_t>(m));
+      for (size_t p = 0; p < jr.size(); ++p)
+        if (!is_fixed(jc[p])) rowvars[static_cast<size_t>(jr[p])].push_back({jc[p], jac_const[p]});
+      // rows with the fewest candidates first (they have the least choice)
+      std::vector<i32> rows;
+      for (i64 i = 0; i < m; ++i) if (eq_row[static_cast<size_t>(i)]) rows.push_back(static_cast<i32>(i));
+      std::stable_sort(rows.begin(), rows.end(), [&](i32 a, i32 b) { return rowvars[static_cast<size_t>(a)].size() < rowvars[static_cast<size_t>(b)].size(); });
+      for (i32 i : rows) {
+        i32 best = -1;
+        double best_score = -1.0;
+        for (auto& vc : rowvars[static_cast<size_t>(i)]) {
+          const i32 v = vc.first;
+          if (partner[static_cast<size_t>(v)] >= 0) continue;
+          // constant coefficient > structurally zero diagonal > low degree
+          double score = (vc.second > 0.0 ? 4.0 + std::min(vc.second, 1.0) : 0.0) + (zero_diag_var[static_cast<size_t>(v)] ? 2.0 : 0.0) +
+                         1.0 / (1.0 + static_cast<double>(adj[static_cast<size_t>(v)].size()));
+          if (score > best_score) { best_score = score; best = v; }
+        }
+        if (best >= 0) { partner[static_cast<size_t>(best)] = static_cast<i32>(N + i); partner[static_cast<size_t>(N + i)] = best; }
+      }
+      // Rows the greedy pass left without a partner: augmenting paths (Kuhn's algorithm, iterative
+      // DFS).  An unpaired equality row is a structurally zero 1x1 pivot whose fill from a
+      // neighbouring [[w, a], [a, 0]] block is -l^T D^-1 l = 0 when w = 0, so a maximum matching is
+      // what makes the static pivot sequence non-singular whenever J has full structural row rank.
+      // Constant coefficients are tried first.
+      std::vector<i64> visit_mark(static_cast<size_t>(N), -1);
+      std::vector<i32> from_row(static_cast<size_t>(N), -1);
+      for (int pass = 0; pass < 2; ++pass) {
+        for (i32 i : rows) {
+          if (partner[static_cast<size_t>(N + i)] >= 0) continue;
+          // BFS over alternating paths: row -> candidate variable -> the row it is matched to -> ...
+          const i64 stamp = static_cast<i64>(pass) * (m + 1) + i;     // unique per (pass, root)
+          std::vector<i32> queue{i};
+          i32 end_var = -1;
+          for (size_t qh = 0; qh < queue.size() && end_var < 0; ++qh) {
+            const i32 r = queue[qh];
+            for (auto& vc : rowvars[static_cast<size_t>(r)]) {
+              const i32 v = vc.first;
+              if (pass == 0 && !(vc.second > 0.0)) continue;
+              if (visit_mark[static_cast<size_t>(v)] == stamp) continue;
+              visit_mark[static_cast<size_t>(v)] = stamp;
+              from_row[static_cast<size_t>(v)] = r;
+              const i32 pr = partner[static_cast<size_t>(v)];
+              if (pr < 0) { end_var = v; break; }
+              queue.push_back(static_cast<i32>(pr - N));
+            }
+          }
+          // flip the path
+          i32 v = end_var;
+          while (v >= 0) {
+            const i32 r = from_row[static_cast<size_t>(v)];
+            const i32 prev = partner[static_cast<size_t>(N + r)];     // variable r was matched to (-1 for the root)
+            partner[static_cast<size_t>(v)] = static_cast<i32>(N + r);
+            partner[static_cast<size_t>(N + r)] = v;
+            v = prev;
+            if (r == i) break;
+          }
+        }
+      }
+    }
+    if (std::getenv("DNLP_SPARSE_DEBUG")) {
+      i64 un = 0, tot = 0;
+      for (i64 i = 0; i < m; ++i) if (eq_row[static_cast<size_t>(i)]) { ++tot; if (partner[static_cast<size_t>(N + i)] < 0) { ++un; if (un <= 5) std::fprintf(stderr, "[plan] unmatched eq row %lld\n", (long long)i); } }
+      std::fprintf(stderr, "[plan] equality rows %lld, unmatched %lld\n", (long long)tot, (long long)un);
+    }
+    // ---- blocks ----
+    std::vector<i32> blk_of(static_cast<size_t>(nn), -1);
+    std::vector<std::array<i32, 2>> bn;
+    for (i64 u = 0; u < nn; ++u) {
+      if (blk_of[static_cast<size_t>(u)] >= 0) continue;
+      const i32 p = partner[static_cast<size_t>(u)];
+      const i32 id = static_cast<i32>(bn.size());
+      if (p >= 0) { bn.push_back({static_cast<i32>(std::min<i64>(u, p)), static_cast<i32>(std::max<i64>(u, p))}); blk_of[static_cast<size_t>(p)] = id; }
+      else bn.push_back({static_cast<i32>(u), -1});
+      blk_of[static_cast<size_t>(u)] = id;
+    }
+    const i64 nb = static_cast<i64>(bn.size());
+    n_pairs = nn - nb;
+    auto bsize = [&](i32 b) { return bn[static_cast<size_t>(b)][1] >= 0 ? 2 : 1; };
+    // block adjacency
+    std::vector<std::vector<i32>> badj(static_cast<size_t>(nb));
+    for (i64 u = 0; u < nn; ++u)
+      for (i32 v : adj[static_cast<size_t>(u)])
+        if (blk_of[static_cast<size_t>(u)] != blk_of[static_cast<size_t>(v)]) badj[static_cast<size_t>(blk_of[static_cast<size_t>(u)])].push_back(blk_of[static_cast<size_t>(v)]);
+    for (auto& a : badj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+    // ---- minimum (external) degree elimination of the blocks, explicit fill ----
+    // A 1x1 block whose diagonal is structurally zero (unpaired equality row, unpaired linear
+    // free variable) is not eligible until one of its neighbours has been eliminated: the
+    // neighbour's update puts -l^2/d on its diagonal, so the static pivot is non-zero.
+    std::vector<char> gone(static_cast<size_t>(nb), 0), ready(static_cast<size_t>(nb), 1);
+    for (i64 b = 0; b < nb; ++b) {
+      if (bsize(static_cast<i32>(b)) == 2) continue;
+      const i32 u = bn[static_cast<size_t>(b)][0];
+      const bool zd = (u < N) ? zero_diag_var[static_cast<size_t>(u)] != 0 : eq_row[static_cast<size_t>(u - N)] != 0;
+      if (zd && !badj[static_cast<size_t>(b)].empty()) ready[static_cast<size_t>(b)] = 0;
+    }
+    n_delayed = 0;
+    for (char r : ready) n_delayed += r ? 0 : 1;
+    std::vector<i64> deg(static_cast<size_t>(nb), 0);
+    auto degree = [&](i32 b) { i64 d = 0; for (i32 c : badj[static_cast<size_t>(b)]) d += bsize(c); return d; };
+    using QE = std::pair<i64, i32>;
+    std::priority_queue<QE, std::vector<QE>, std::greater<QE>> pq;
+    for (i64 b = 0; b < nb; ++b) {
+      deg[static_cast<size_t>(b)] = degree(static_cast<i32>(b));
+      if (ready[static_cast<size_t>(b)]) pq.push({deg[static_cast<size_t>(b)], static_cast<i32>(b)});
+    }
+    std::vector<i32> order;
+    std::vector<std::vector<i32>> bstruct(static_cast<size_t>(nb));   // neighbour blocks at elimination time
+    order.reserve(static_cast<size_t>(nb));
+    std::vector<i32> merged;
+    i64 remaining = nb;
+    while (remaining > 0) {
+      if (pq.empty()) {
+        // only not-ready blocks are left (a component made of zero-diagonal nodes): release them
+        for (i64 b = 0; b < nb; ++b)
+          if (!gone[static_cast<size_t>(b)] && !ready[static_cast<size_t>(b)]) { ready[static_cast<size_t>(b)] = 1; pq.push({deg[static_cast<size_t>(b)], static_cast<i32>(b)}); }
+        continue;
+      }
+      const QE top = pq.top();
+      pq.pop();
+      const i32 b = top.second;
+      if (gone[static_cast<size_t>(b)] || top.first != deg[static_cast<size_t>(b)]) continue;
+      gone[static_cast<size_t>(b)] = 1;
+      --remaining;
+      order.push_back(b);
+      std::vector<i32>& nb_ = badj[static_cast<size_t>(b)];
+      bstruct[static_cast<size_t>(b)] = nb_;
+      // clique among the neighbours, b removed
+      for (i32 c : nb_) {
+        std::vector<i32>& ac = badj[static_cast<size_t>(c)];
+        merged.clear();
+        std::set_union(ac.begin(), ac.end(), nb_.begin(), nb_.end(), std::back_inserter(merged));
+        ac.clear();
+        for (i32 x : merged) if (x != c && x != b) ac.push_back(x);
+        deg[static_cast<size_t>(c)] = degree(c);
+        ready[static_cast<size_t>(c)] = 1;
+        pq.push({deg[static_cast<size_t>(c)], c});
+      }
+      nb_.clear();
+      nb_.shrink_to_fit();
+    }
+    // ---- layout: values = [D blocks | L blocks], in elimination order ----
+    std::vector<i64> pos(static_cast<size_t>(nb));          // elimination position of every block
+    for (i64 k = 0; k < nb; ++k) pos[static_cast<size_t>(order[static_cast<size_t>(k)])] = k;
+    bnode.assign(static_cast<size_t>(2 * nb), -1);
+    soff.assign(static_cast<size_t>(nb + 1), 0);
+    doff.assign(static_cast<size_t>(nb), 0);
+    loff.assign(static_cast<size_t>(nb), 0);
+    i64 v = 0;
+    maxs = 0;
+    for (i64 k = 0; k < nb; ++k) {
+      const i32 b = order[static_cast<size_t>(k)];
+      bnode[static_cast<size_t>(2 * k)] = bn[static_cast<size_t>(b)][0];
+      bnode[static_cast<size_t>(2 * k + 1)] = bn[static_cast<size_t>(b)][1];
+      doff[static_cast<size_t>(k)] = v;
+      v += bsize(b) == 2 ? 3 : 1;
+    }
+    for (i64 k = 0; k < nb; ++k) {
+      const i32 b = order[static_cast<size_t>(k)];
+      // struct nodes sorted by (elimination position of their block, node)
+      std::vector<std::pair<i64, i32>> sn;
+      for (i32 c : bstruct[static_cast<size_t>(b)]) {
+        sn.push_back({pos[static_cast<size_t>(c)], bn[static_cast<size_t>(c)][0]});
+        if (bn[static_cast<size_t>(c)][1] >= 0) sn.push_back({pos[static_cast<size_t>(c)], bn[static_cast<size_t>(c)][1]});
+      }
+      std::sort(sn.begin(), sn.end());
+      soff[static_cast<size_t>(k + 1)] = soff[static_cast<size_t>(k)] + static_cast<i64>(sn.size());
+      for (auto& e : sn) sidx.push_back(e.second);
+      loff[static_cast<size_t>(k)] = v;
+      v += static_cast<i64>(sn.size()) * bsize(b);
+      maxs = std::max<i64>(maxs, static_cast<i64>(sn.size()));
+    }
+    nvals = v;
+    nnzL = v;
+    fill_ratio = static_cast<double>(v) / (0.5 * static_cast<double>(nn) * static_cast<double>(nn + 1));
+    // position of a node inside its block, elimination position of its block
+    std::vector<i64> npos(static_cast<size_t>(nn));
+    std::vector<i32> ncol(static_cast<size_t>(nn));
+    for (i64 k = 0; k < nb; ++k)
+      for (int c = 0; c < 2; ++c) {
+        const i32 u = bnode[static_cast<size_t>(2 * k + c)];
+        if (u >= 0) { npos[static_cast<size_t>(u)] = k; ncol[static_cast<size_t>(u)] = c; }
+      }
+    // address of the entry (u, v) of the (reduced) matrix
+    auto addr = [&](i32 u, i32 w) -> i64 {
+      i64 ku = npos[static_cast<size_t>(u)], kw = npos[static_cast<size_t>(w)];
+      if (ku == kw) {
+        if (u == w) return doff[static_cast<size_t>(ku)] + (ncol[static_cast<size_t>(u)] == 0 ? 0 : 2);
+        return doff[static_cast<size_t>(ku)] + 1;
+      }
+      if (ku > kw) { std::swap(ku, kw); std::swap(u, w); }
+      // u's block is eliminated first: row of w in its struct
+      const i64 s0 = soff[static_cast<size_t>(ku)], s1 = soff[static_cast<size_t>(ku + 1)];
+      const int bk = bnode[static_cast<size_t>(2 * ku + 1)] >= 0 ? 2 : 1;
+      // struct is sorted by (block position, node): linear search is fine for the small structs,
+      // binary search on the pair key for the large ones
+      i64 lo = s0, hi = s1;
+      while (lo < hi) {
+        const i64 mid = (lo + hi) / 2;
+        const i32 x = sidx[static_cast<size_t>(mid)];
+        const bool less = npos[static_cast<size_t>(x)] < kw || (npos[static_cast<size_t>(x)] == kw && x < w);
+        if (less) lo = mid + 1; else hi = mid;
+      }
+      if (lo >= s1 || sidx[static_cast<size_t>(lo)] != w) return -1;
+      return loff[static_cast<size_t>(ku)] + (lo - s0) * bk + ncol[static_cast<size_t>(u)];
+    };
+    // ---- assembly maps ----
+    hpos.resize(hr.size());
+    for (size_t p = 0; p < hr.size(); ++p) hpos[p] = static_cast<i32>(addr(hr[p], hc[p]));
+    jpos.resize(jr.size());
+    for (size_t p = 0; p < jr.size(); ++p) jpos[p] = static_cast<i32>(addr(static_cast<i32>(N + jr[p]), jc[p]));
+    dpos.resize(static_cast<size_t>(nn));
+    for (i64 u = 0; u < nn; ++u) dpos[static_cast<size_t>(u)] = static_cast<i32>(addr(static_cast<i32>(u), static_cast<i32>(u)));
+    // entries that touch a fixed variable have no address (-1): the assembly masks them anyway
+    for (size_t p = 0; p < hr.size(); ++p)
+      if (hpos[p] < 0 && !is_fixed(hr[p]) && !is_fixed(hc[p])) throw std::runtime_error("sparse KKT plan: Hessian entry outside the pattern");
+    for (size_t p = 0; p < jr.size(); ++p)
+      if (jpos[p] < 0 && !is_fixed(jc[p])) throw std::runtime_error("sparse KKT plan: Jacobian entry outside the pattern");
+    // ---- update program ----
+    toff.assign(static_cast<size_t>(nb + 1), 0);
+    for (i64 k = 0; k < nb; ++k) {
+      const i64 s0 = soff[static_cast<size_t>(k)], s = soff[static_cast<size_t>(k + 1)] - s0;
+      for (i64 iu = 0; iu < s; ++iu)
+        for (i64 iv = 0; iv <= iu; ++iv) {
+          const i64 a = addr(sidx[static_cast<size_t>(s0 + iu)], sidx[static_cast<size_t>(s0 + iv)]);
+          if (a < 0) throw std::runtime_error("sparse KKT plan: fill entry outside the pattern");
+          tdst.push_back(static_cast<i32>(a));
+          tiu.push_back(static_cast<i32>(iu));
+          tiv.push_back(static_cast<i32>(iv));
+        }
+      toff[static_cast<size_t>(k + 1)] = static_cast<i64>(tdst.size());
+    }
+    if (nvals >= (static_cast<i64>(1) << 31)) throw std::runtime_error("sparse KKT plan: factor too large for 32-bit addresses");
+  }
+
+  template <class E> SparsePlan upload(E* ex) const {
+    SparsePlan p;
+    p.n = n; p.N = N; p.m = m; p.nblk = nblk(); p.nvals = nvals; p.ntrip = static_cast<i64>(tdst.size()); p.maxs = maxs;
+    auto up = [&](auto*& dst, const auto& src) {
+      using T = std::remove_pointer_t<std::remove_reference_t<decltype(dst)>>;
+      dst = ex->template alloc<T>(src.size());
+      if (!src.empty()) ex->h2d(dst, src.data(), src.size() * sizeof(T));
+    };
+    up(p.bnode, bnode); up(p.soff, soff); up(p.sidx, sidx); up(p.doff, doff); up(p.loff, loff); up(p.toff, toff);
+    up(p.tdst, tdst); up(p.tiu, tiu); up(p.tiv, tiv); up(p.hpos, hpos); up(p.jpos, jpos); up(p.dpos, dpos);
+    return p;
+  }
+};
+
+// Plan of a loaded tape: structural information from the host copies.
+template <class E>
+inline void build_sparse_plan(const Tape<E>& t, SparsePlanHost& plan, bool bounds_relaxed) {
+  std::vector<char> zero_diag(static_cast<size_t>(t.N), 1), eq(static_cast<size_t>(t.m), 0), fixed(static_cast<size_t>(t.N), 0);
+  if (!bounds_relaxed)
+    for (i64 j = 0; j < t.N; ++j) fixed[static_cast<size_t>(j)] = t.h_lb[static_cast<size_t>(j)] == t.h_ub[static_cast<size_t>(j)];
+  // a Hessian diagonal entry is not a safe pivot: entries weighted by multipliers vanish when
+  // the multiplier does (iteration 0 with y = 0).  Only bound terms (Sigma > 0) are relied upon.
+  for (i64 j = 0; j < t.N; ++j)
+    if (t.h_lb[static_cast<size_t>(j)] > -1e19 || t.h_ub[static_cast<size_t>(j)] < 1e19) zero_diag[static_cast<size_t>(j)] = 0;
+  for (i64 i = 0; i < t.m; ++i) eq[static_cast<size_t>(i)] = t.h_cl[static_cast<size_t>(i)] == t.h_cu[static_cast<size_t>(i)];
+  plan.build(t.N, t.m, t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, zero_diag, eq, t.h_jac_const, fixed);
+}
+
+}  // namespace dnlp

@@ -1,6 +1,7 @@
 // Tape blob parser and the exec-space resident copy of the lowered problem.
 // Blob layout: dnlp_amd/tape.py.  Normal form: dnlp_amd/lowering.py.
 #pragma once
+#include <cmath>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -143,6 +144,7 @@ struct Tape : TapeView {
   std::vector<i64> h_red_segs;   // indices of reduction-class segments
   std::vector<i64> h_flat_seg;   // segment index of every flat-table row
   std::vector<i32> h_jac_rows, h_jac_cols, h_hess_rows, h_hess_cols;
+  std::vector<double> h_jac_const;   // |coefficient| of Jacobian entries that are constant (affine rows), else 0
   // constants
   std::vector<i64> dense_n;
   std::vector<const double*> h_dense_ptr;   // exec space, column-major
@@ -227,6 +229,13 @@ struct Tape : TapeView {
     MH = up_csr(tb, "MH", nnzH, nh);
     h_jac_rows.assign(tb.i32s("jac_rows"), tb.i32s("jac_rows") + nnzJ);
     h_jac_cols.assign(tb.i32s("jac_cols"), tb.i32s("jac_cols") + nnzJ);
+    {
+      const i64* mjp = tb.i64s("MJ_ptr");
+      const double* jc0 = tb.f64("Jc");
+      h_jac_const.assign(static_cast<size_t>(nnzJ), 0.0);
+      for (i64 p = 0; p < nnzJ; ++p)
+        if (mjp[p + 1] == mjp[p]) h_jac_const[static_cast<size_t>(p)] = std::fabs(jc0[p]);
+    }
     h_hess_rows.assign(tb.i32s("hess_rows"), tb.i32s("hess_rows") + nnzH);
     h_hess_cols.assign(tb.i32s("hess_cols"), tb.i32s("hess_cols") + nnzH);
     {

@@ -282,14 +282,17 @@ class HIPNLP:
         data["oracles"].iterations = info["iterations"]
         return info
 
-    DEVICE_LOOP_MAX_ORDER = 256        # KKT order N + m up to which one wavefront runs the whole solve
+    DEVICE_LOOP_MAX_ORDER = 256          # dense KKT: order up to which one wavefront runs the whole solve
+    DEVICE_LOOP_MAX_ORDER_SPARSE = 20000  # sparse static-pattern KKT (csrc/sparse_plan.h)
 
     def _use_device_loop(self, data, options, mode) -> bool:
         if mode in (False, "no", "host"):
             return False
         tape = data["tape"]
-        small = len(data["x0"]) + len(data["cl"]) <= self.DEVICE_LOOP_MAX_ORDER
-        fits = small and not tape.dense_blocks and not tape.dense_consts
+        order = len(data["x0"]) + len(data["cl"])
+        fits = not tape.dense_blocks and not tape.dense_consts
+        if fits and order > self.DEVICE_LOOP_MAX_ORDER:
+            fits = order <= self.DEVICE_LOOP_MAX_ORDER_SPARSE and data["handle"].kkt_info()["sparse"]
         if mode in (True, "yes", "device"):
             if tape.dense_blocks or tape.dense_consts:
                 raise ValueError("device_loop='yes' needs a tape without dense quad_form blocks")

@@ -16,6 +16,7 @@
 
 #include "../dnlp_amd/csrc/exec.h"
 #include "../dnlp_amd/csrc/fused_obj.h"
+#include "../dnlp_amd/csrc/sparse_ldl.h"
 
 namespace dnlp {
 
@@ -56,6 +57,12 @@ struct HostExec : HostControlled {
     for (i64 i = 0; i < n; ++i) { double v = f(i); if (v != v) nan = true; if (v < s) s = v; }
     return nan ? std::nan("") : s;
   }
+
+  // static-pattern sparse LDL^T (csrc/sparse_ldl.h): the single-source routine with one lane
+  bool sparse_factor(const SparsePlan& pl, double* vals, double* w, int* nneg, int* nzero) {
+    return sparse_ldl_factor(pl, vals, w, nneg, nzero, SeqPar());
+  }
+  void sparse_solve(const SparsePlan& pl, const double* vals, double* x) { sparse_ldl_solve(pl, vals, x, SeqPar()); }
 
   // fused element program (csrc/fused_obj.h): sequential host loop, local slots
   double fused_eval(const FusedProg& P, const double* x, const double* consts, double* grad) {
