@@ -237,12 +237,13 @@ class ProblemHandle:
 
     def kkt_info(self):
         """Linear-solver plan of this handle: sparse static-pattern LDL^T or dense."""
-        out = (C.c_int64 * 6)()
+        out = (C.c_int64 * 8)()
         rc = self.api.kkt_info(self.ptr, out)
         if rc != 0:
             raise RuntimeError("kkt_info failed: %s" % self.api.error())
         return {"sparse": bool(out[0]), "factor_values": int(out[1]), "pivot_blocks": int(out[2]),
-                "max_struct": int(out[3]), "pairs_2x2": int(out[4]), "update_triples": int(out[5])}
+                "max_struct": int(out[3]), "pairs_2x2": int(out[4]), "update_triples": int(out[5]),
+                "levels": int(out[6])}
 
     def set_option(self, key, val):
         if isinstance(val, bool):

@@ -224,7 +224,7 @@ struct BatchRunner {
     a.sp = dev_plan;
     // working set of one instance: the "matrix" (dense KKT, or the sparse factor when it is large)
     // and the vectors (model + interior-point state; counts follow Model::init_view / Ipm::allocate)
-    const size_t sparse_vals = have_sparse ? static_cast<size_t>(dev_plan.nvals + 2 * dev_plan.maxs + 16) : 0;
+    const size_t sparse_vals = have_sparse ? static_cast<size_t>(2 * dev_plan.nvals + 3 * dev_plan.nblk + 32) : 0;
     const bool sparse_big = sparse_vals * 8 >= 16384;
     const size_t kbytes = have_sparse ? (sparse_big ? ((sparse_vals * 8 + 63) & ~static_cast<size_t>(63)) : 0)
                                       : (((static_cast<size_t>(ld) * n + 256) * 8 + 63) & ~static_cast<size_t>(63));

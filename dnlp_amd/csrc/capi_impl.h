@@ -75,7 +75,9 @@ struct ProblemT {
     const double pattern = static_cast<double>(t.nnzH + t.nnzJ) + n;
     if (linear_solver == 0 && pattern > 0.1 * 0.5 * n * n) return;        // already dense
     build_sparse_plan(t, sparse_plan, opt.bound_relax_factor > 0.0);
-    use_sparse = linear_solver == 2 || sparse_plan.fill_ratio <= 0.3;
+    // a long update program (dense-ish fill) is walked by one workgroup: beyond ~4e5 triples the
+    // chip-wide dense factorisation is the faster choice (phase retrieval: 3.6e6 triples)
+    use_sparse = linear_solver == 2 || (sparse_plan.fill_ratio <= 0.3 && sparse_plan.tdst.size() <= 400000);
   }
 
   void ensure_ipm() {
@@ -285,7 +287,8 @@ struct ProblemT {
     DNLP_TRY(p->plan_linear_solver();                                                                \
              out[0] = p->use_sparse ? 1 : 0; out[1] = p->sparse_plan.nnzL; out[2] = p->sparse_plan.nblk(); \
              out[3] = p->sparse_plan.maxs; out[4] = p->sparse_plan.n_pairs;                          \
-             out[5] = static_cast<int64_t>(p->sparse_plan.tdst.size()); return 0;)                    \
+             out[5] = static_cast<int64_t>(p->sparse_plan.tdst.size());                                 \
+             out[6] = static_cast<int64_t>(p->sparse_plan.lev_off.size()) - 1; return 0;)                    \
   }                                                                                                  \
   int DNLP_CAT(PFX, get_stats)(void* vp, double* s, int n) {                                         \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \

@@ -552,6 +552,7 @@ struct BlockExecT {
     __device__ int lanes() const { return NT; }
     __device__ int lane() const { return static_cast<int>(threadIdx.x); }
     __device__ void sync() const { __syncthreads(); }
+    __device__ void add(double* p, double v) const { unsafeAtomicAdd(p, v); }
     __device__ double sum(double v) const {
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
       if constexpr (NT == 64) return v;

@@ -612,6 +612,7 @@ struct WgPar {
   __device__ int lanes() const { return kBlock; }
   __device__ int lane() const { return static_cast<int>(threadIdx.x); }
   __device__ void sync() const { __syncthreads(); }
+  __device__ void add(double* p, double v) const { unsafeAtomicAdd(p, v); }
   __device__ double sum(double v) const {
     v = wave_sum(v);
     __syncthreads();                      // red may still be read from the previous call

@@ -30,7 +30,7 @@ struct DenseKkt {
   bool sparse = false;
   SparsePlan sp;
   double* svals = nullptr;     // plan-layout values: assembled matrix, then (D, L)
-  double* swork = nullptr;     // 2 * maxs scratch of the numeric phase
+  double* swork = nullptr;     // scratch of the numeric phase (sparse_ldl_work_doubles)
 
   DNLP_HD void init_sparse(E* e, i64 N_, i64 m_, const SparsePlan& plan) {
     ex = e; N = N_; m = m_; n = N + m; ld = 0;
@@ -38,7 +38,7 @@ struct DenseKkt {
     pivoted = true;            // (static 2x2 blocks) keeps the large-dense-only code paths of the IP loop off
     sp = plan;
     svals = ex->template alloc<double>(static_cast<size_t>(sp.nvals > 0 ? sp.nvals : 1));
-    swork = ex->template alloc<double>(static_cast<size_t>(2 * sp.maxs + 2));
+    swork = ex->template alloc<double>(static_cast<size_t>(sparse_ldl_work_doubles(sp)));
   }
 
   DNLP_HD void init(E* e, i64 N_, i64 m_) {

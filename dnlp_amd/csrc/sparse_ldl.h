@@ -18,83 +18,113 @@ struct SeqPar {
   DNLP_HD int lane() const { return 0; }
   DNLP_HD void sync() const {}
   DNLP_HD double sum(double v) const { return v; }
+  DNLP_HD void add(double* p, double v) const { *p += v; }
 };
 
-// vals: assembled matrix in plan layout, overwritten by (D, L).  w: 2 * maxs scratch.
+// work: nvals (w, laid out like the L values) + 3 * nblk (inverse pivot blocks)
+DNLP_HD inline i64 sparse_ldl_work_doubles(const SparsePlan& pl) { return pl.nvals + 3 * pl.nblk + 8; }
+
+// vals: assembled matrix in plan layout, overwritten by (D, L).  Level by level: the blocks of an
+// elimination-tree level are independent, so their pivots are inverted together, their rows scaled
+// together and their update triples applied together (sums into common ancestors through
+// par.add: an atomic add on the device, a plain add on the host).
 template <class P>
-DNLP_HD inline bool sparse_ldl_factor(const SparsePlan& pl, double* vals, double* w, int* nneg_out, int* nzero_out, P par) {
+DNLP_HD inline bool sparse_ldl_factor(const SparsePlan& pl, double* vals, double* work, int* nneg_out, int* nzero_out, P par) {
   const int L = par.lanes(), me = par.lane();
-  int nneg = 0, nzero = 0;
-  bool ok = true;
-  for (i64 k = 0; k < pl.nblk; ++k) {
-    const i64 s = pl.soff[k + 1] - pl.soff[k];
-    const bool two = pl.bnode[2 * k + 1] >= 0;
-    double* Lk = vals + pl.loff[k];
-    double* Dk = vals + pl.doff[k];
-    const i64 t0 = pl.toff[k], t1 = pl.toff[k + 1];
-    if (!two) {
-      double d = Dk[0];
-      if (!(d == d)) ok = false;
-      if (fabs(d) < 1e-300) {
+  double* w = work;
+  double* dinv = work + pl.nvals;
+  double nneg = 0.0, nzero = 0.0, bad = 0.0;
+  for (i64 lev = 0; lev < pl.nlev; ++lev) {
+    const i64 b0 = pl.lev_off[lev], b1 = pl.lev_off[lev + 1];
+    // A: pivot blocks
+    for (i64 k = b0 + me; k < b1; k += L) {
+      double* Dk = vals + pl.doff[k];
+      double* di = dinv + 3 * k;
+      if (pl.bnode[2 * k + 1] < 0) {
+        double d = Dk[0];
+        if (!(d == d)) bad += 1.0;
+        if (fabs(d) < 1e-300) {
 #if !DNLP_DEVICE_PASS
-        if (std::getenv("DNLP_SPARSE_DEBUG")) std::fprintf(stderr, "[sparse] zero 1x1 pivot: block %lld node %d (N=%lld) struct %lld\n", (long long)k, pl.bnode[2 * k], (long long)pl.N, (long long)s);
+          if (std::getenv("DNLP_SPARSE_DEBUG")) std::fprintf(stderr, "[sparse] zero 1x1 pivot: block %lld node %d (N=%lld)\n", (long long)k, pl.bnode[2 * k], (long long)pl.N);
 #endif
-        ++nzero; d = 1e-20; }
-      if (d < 0.0) ++nneg;
-      const double inv = 1.0 / d;
-      for (i64 i = me; i < s; i += L) w[i] = Lk[i] * inv;
-      par.sync();
-      if (me == 0) Dk[0] = d;
-      for (i64 q = t0 + me; q < t1; q += L) vals[pl.tdst[q]] -= Lk[pl.tiu[q]] * w[pl.tiv[q]];
-      par.sync();
-      for (i64 i = me; i < s; i += L) Lk[i] = w[i];
-    } else {
-      const double a = Dk[0], c = Dk[1], e = Dk[2];
-      double det = a * e - c * c;
-      if (!(det == det)) ok = false;
-      if (fabs(det) < 1e-300) {
+          nzero += 1.0; d = 1e-20; Dk[0] = d;
+        }
+        if (d < 0.0) nneg += 1.0;
+        di[0] = 1.0 / d;
+      } else {
+        const double a = Dk[0], c = Dk[1], e = Dk[2];
+        double det = a * e - c * c;
+        if (!(det == det)) bad += 1.0;
+        if (fabs(det) < 1e-300) {
 #if !DNLP_DEVICE_PASS
-        if (std::getenv("DNLP_SPARSE_DEBUG")) std::fprintf(stderr, "[sparse] singular 2x2 pivot: block %lld nodes %d %d (N=%lld) a=%g c=%g e=%g\n", (long long)k, pl.bnode[2 * k], pl.bnode[2 * k + 1], (long long)pl.N, a, c, e);
+          if (std::getenv("DNLP_SPARSE_DEBUG")) std::fprintf(stderr, "[sparse] singular 2x2 pivot: block %lld nodes %d %d (N=%lld) a=%g c=%g e=%g\n", (long long)k, pl.bnode[2 * k], pl.bnode[2 * k + 1], (long long)pl.N, a, c, e);
 #endif
-        ++nzero; det = -1e-20; }
-      if (det < 0.0) nneg += 1;
-      else if (a < 0.0 || (a == 0.0 && e < 0.0)) nneg += 2;
-      const double i11 = e / det, i21 = -c / det, i22 = a / det;
-      for (i64 i = me; i < s; i += L) {
-        const double l1 = Lk[2 * i], l2 = Lk[2 * i + 1];
-        w[2 * i] = i11 * l1 + i21 * l2;
-        w[2 * i + 1] = i21 * l1 + i22 * l2;
+          nzero += 1.0; det = -1e-20;
+        }
+        if (det < 0.0) nneg += 1.0;
+        else if (a < 0.0 || (a == 0.0 && e < 0.0)) nneg += 2.0;
+        di[0] = e / det; di[1] = -c / det; di[2] = a / det;
       }
-      par.sync();
-      for (i64 q = t0 + me; q < t1; q += L) {
-        const i64 iu = pl.tiu[q], iv = pl.tiv[q];
-        vals[pl.tdst[q]] -= Lk[2 * iu] * w[2 * iv] + Lk[2 * iu + 1] * w[2 * iv + 1];
-      }
-      par.sync();
-      for (i64 i = me; i < 2 * s; i += L) Lk[i] = w[i];
     }
     par.sync();
+    // B: w = L D^-1 for every struct row of the level
+    const i64 r0 = pl.soff[b0], r1 = pl.soff[b1];
+    for (i64 r = r0 + me; r < r1; r += L) {
+      const i64 k = pl.sblk[r], i = r - pl.soff[k];
+      const double* di = dinv + 3 * k;
+      if (pl.bnode[2 * k + 1] < 0) {
+        const i64 a = pl.loff[k] + i;
+        w[a] = vals[a] * di[0];
+      } else {
+        const i64 a = pl.loff[k] + 2 * i;
+        const double l1 = vals[a], l2 = vals[a + 1];
+        w[a] = di[0] * l1 + di[1] * l2;
+        w[a + 1] = di[1] * l1 + di[2] * l2;
+      }
+    }
+    par.sync();
+    // C: Schur-complement updates of the level
+    const i64 t0 = pl.toff[b0], t1 = pl.toff[b1];
+    for (i64 q = t0 + me; q < t1; q += L) {
+      const i64 k = pl.tblk[q], iu = pl.tiu[q], iv = pl.tiv[q];
+      double u;
+      if (pl.bnode[2 * k + 1] < 0) {
+        u = vals[pl.loff[k] + iu] * w[pl.loff[k] + iv];
+      } else {
+        const i64 au = pl.loff[k] + 2 * iu, av = pl.loff[k] + 2 * iv;
+        u = vals[au] * w[av] + vals[au + 1] * w[av + 1];
+      }
+      par.add(&vals[pl.tdst[q]], -u);
+    }
+    par.sync();
+    // D: keep L = l D^-1
+    const i64 v0 = pl.loff[b0], v1 = (b1 < pl.nblk) ? pl.loff[b1] : pl.nvals;
+    for (i64 a = v0 + me; a < v1; a += L) vals[a] = w[a];
+    par.sync();
   }
-  *nneg_out = nneg;
-  *nzero_out = nzero;
-  return ok;
+  nneg = par.sum(nneg);
+  nzero = par.sum(nzero);
+  bad = par.sum(bad);
+  *nneg_out = static_cast<int>(nneg);
+  *nzero_out = static_cast<int>(nzero);
+  return bad == 0.0;
 }
 
 // x (n entries, node numbering of the KKT system: variables then constraint rows) <- K^-1 x
 template <class P>
 DNLP_HD inline void sparse_ldl_solve(const SparsePlan& pl, const double* vals, double* x, P par) {
   const int L = par.lanes(), me = par.lane();
-  for (i64 k = 0; k < pl.nblk; ++k) {
-    const i64 s0 = pl.soff[k], s = pl.soff[k + 1] - s0;
-    const i32 u0 = pl.bnode[2 * k], u1 = pl.bnode[2 * k + 1];
-    const double* Lk = vals + pl.loff[k];
-    if (u1 < 0) {
-      const double xp = x[u0];
-      if (xp != 0.0)
-        for (i64 i = me; i < s; i += L) x[pl.sidx[s0 + i]] -= Lk[i] * xp;
-    } else {
-      const double x0 = x[u0], x1 = x[u1];
-      for (i64 i = me; i < s; i += L) x[pl.sidx[s0 + i]] -= Lk[2 * i] * x0 + Lk[2 * i + 1] * x1;
+  // forward, level by level: every struct row pushes its contribution into an ancestor entry
+  for (i64 lev = 0; lev < pl.nlev; ++lev) {
+    const i64 b0 = pl.lev_off[lev], b1 = pl.lev_off[lev + 1];
+    const i64 r0 = pl.soff[b0], r1 = pl.soff[b1];
+    for (i64 r = r0 + me; r < r1; r += L) {
+      const i64 k = pl.sblk[r], i = r - pl.soff[k];
+      const i32 u0 = pl.bnode[2 * k], u1 = pl.bnode[2 * k + 1];
+      double c;
+      if (u1 < 0) c = vals[pl.loff[k] + i] * x[u0];
+      else c = vals[pl.loff[k] + 2 * i] * x[u0] + vals[pl.loff[k] + 2 * i + 1] * x[u1];
+      if (c != 0.0) par.add(&x[pl.sidx[r]], -c);
     }
     par.sync();
   }
@@ -113,21 +143,40 @@ DNLP_HD inline void sparse_ldl_solve(const SparsePlan& pl, const double* vals, d
     }
   }
   par.sync();
-  for (i64 k = pl.nblk - 1; k >= 0; --k) {
-    const i64 s0 = pl.soff[k], s = pl.soff[k + 1] - s0;
-    if (s == 0) continue;
-    const i32 u0 = pl.bnode[2 * k], u1 = pl.bnode[2 * k + 1];
-    const double* Lk = vals + pl.loff[k];
-    double a0 = 0.0, a1 = 0.0;
-    if (u1 < 0) {
-      for (i64 i = me; i < s; i += L) a0 += Lk[i] * x[pl.sidx[s0 + i]];
-      a0 = par.sum(a0);
-      if (me == 0) x[u0] -= a0;
+  // backward, levels descending: a block gathers from its (already final) ancestors.  Wide levels:
+  // one lane per block; narrow levels near the root (few blocks, long structs): all lanes per block.
+  for (i64 lev = pl.nlev - 1; lev >= 0; --lev) {
+    const i64 b0 = pl.lev_off[lev], b1 = pl.lev_off[lev + 1];
+    if ((b1 - b0) * 4 >= L) {
+      for (i64 k = b0 + me; k < b1; k += L) {
+        const i64 s0 = pl.soff[k], s = pl.soff[k + 1] - s0;
+        const i32 u0 = pl.bnode[2 * k], u1 = pl.bnode[2 * k + 1];
+        const double* Lk = vals + pl.loff[k];
+        double a0 = 0.0, a1 = 0.0;
+        if (u1 < 0) { for (i64 i = 0; i < s; ++i) a0 += Lk[i] * x[pl.sidx[s0 + i]]; x[u0] -= a0; }
+        else {
+          for (i64 i = 0; i < s; ++i) { const double xi = x[pl.sidx[s0 + i]]; a0 += Lk[2 * i] * xi; a1 += Lk[2 * i + 1] * xi; }
+          x[u0] -= a0; x[u1] -= a1;
+        }
+      }
     } else {
-      for (i64 i = me; i < s; i += L) { const double xi = x[pl.sidx[s0 + i]]; a0 += Lk[2 * i] * xi; a1 += Lk[2 * i + 1] * xi; }
-      a0 = par.sum(a0);
-      a1 = par.sum(a1);
-      if (me == 0) { x[u0] -= a0; x[u1] -= a1; }
+      for (i64 k = b0; k < b1; ++k) {
+        const i64 s0 = pl.soff[k], s = pl.soff[k + 1] - s0;
+        if (s == 0) continue;
+        const i32 u0 = pl.bnode[2 * k], u1 = pl.bnode[2 * k + 1];
+        const double* Lk = vals + pl.loff[k];
+        double a0 = 0.0, a1 = 0.0;
+        if (u1 < 0) {
+          for (i64 i = me; i < s; i += L) a0 += Lk[i] * x[pl.sidx[s0 + i]];
+          a0 = par.sum(a0);
+          if (me == 0) x[u0] -= a0;
+        } else {
+          for (i64 i = me; i < s; i += L) { const double xi = x[pl.sidx[s0 + i]]; a0 += Lk[2 * i] * xi; a1 += Lk[2 * i + 1] * xi; }
+          a0 = par.sum(a0);
+          a1 = par.sum(a1);
+          if (me == 0) { x[u0] -= a0; x[u1] -= a1; }
+        }
+      }
     }
     par.sync();
   }

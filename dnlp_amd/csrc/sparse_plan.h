@@ -54,12 +54,18 @@ struct SparsePlan {
   i32* hpos = nullptr;    // value index of every Hessian COO entry (lower triangle)
   i32* jpos = nullptr;    // value index of every Jacobian COO entry
   i32* dpos = nullptr;    // value index of the diagonal of every node
+  // level schedule: blocks are stored level-major (elimination-tree levels); blocks of one level
+  // are independent and are processed together
+  i64* lev_off = nullptr; // nlev + 1 offsets into the block order
+  i32* sblk = nullptr;    // block of every struct row (soff-indexed)
+  i32* tblk = nullptr;    // block of every update triple
 };
 
 struct SparsePlanHost {
   i64 n = 0, N = 0, m = 0, nvals = 0, maxs = 0;
   std::vector<i32> bnode, sidx, tdst, tiu, tiv, hpos, jpos, dpos;
-  std::vector<i64> soff, doff, loff, toff;
+  std::vector<i64> soff, doff, loff, toff, lev_off;
+  std::vector<i32> sblk, tblk;
   i64 nnzL = 0, n_delayed = 0, n_pairs = 0;
   double fill_ratio = 0.0;    // factor values / dense lower triangle
 
@@ -226,6 +232,26 @@ struct SparsePlanHost {
       nb_.clear();
       nb_.shrink_to_fit();
     }
+    // ---- elimination-tree levels: level-major order is a topological order of the same tree ----
+    {
+      std::vector<i64> pos0(static_cast<size_t>(nb));
+      for (i64 k = 0; k < nb; ++k) pos0[static_cast<size_t>(order[static_cast<size_t>(k)])] = k;
+      std::vector<i64> level(static_cast<size_t>(nb), 0);
+      for (i64 k = 0; k < nb; ++k) {
+        const i32 b = order[static_cast<size_t>(k)];
+        i64 par = -1;
+        for (i32 c : bstruct[static_cast<size_t>(b)]) if (par < 0 || pos0[static_cast<size_t>(c)] < par) par = pos0[static_cast<size_t>(c)];
+        if (par >= 0) {
+          const i32 pb = order[static_cast<size_t>(par)];
+          level[static_cast<size_t>(pb)] = std::max(level[static_cast<size_t>(pb)], level[static_cast<size_t>(b)] + 1);
+        }
+      }
+      std::stable_sort(order.begin(), order.end(), [&](i32 a, i32 b) { return level[static_cast<size_t>(a)] < level[static_cast<size_t>(b)]; });
+      lev_off.assign(1, 0);
+      for (i64 k = 1; k <= nb; ++k)
+        if (k == nb || level[static_cast<size_t>(order[static_cast<size_t>(k)])] != level[static_cast<size_t>(order[static_cast<size_t>(k - 1)])]) lev_off.push_back(k);
+      if (nb == 0) lev_off.assign(1, 0);
+    }
     // ---- layout: values = [D blocks | L blocks], in elimination order ----
     std::vector<i64> pos(static_cast<size_t>(nb));          // elimination position of every block
     for (i64 k = 0; k < nb; ++k) pos[static_cast<size_t>(order[static_cast<size_t>(k)])] = k;
@@ -252,7 +278,7 @@ struct SparsePlanHost {
       }
       std::sort(sn.begin(), sn.end());
       soff[static_cast<size_t>(k + 1)] = soff[static_cast<size_t>(k)] + static_cast<i64>(sn.size());
-      for (auto& e : sn) sidx.push_back(e.second);
+      for (auto& e : sn) { sidx.push_back(e.second); sblk.push_back(static_cast<i32>(k)); }
       loff[static_cast<size_t>(k)] = v;
       v += static_cast<i64>(sn.size()) * bsize(b);
       maxs = std::max<i64>(maxs, static_cast<i64>(sn.size()));
@@ -314,6 +340,7 @@ struct SparsePlanHost {
           tdst.push_back(static_cast<i32>(a));
           tiu.push_back(static_cast<i32>(iu));
           tiv.push_back(static_cast<i32>(iv));
+          tblk.push_back(static_cast<i32>(k));
         }
       toff[static_cast<size_t>(k + 1)] = static_cast<i64>(tdst.size());
     }
@@ -330,6 +357,8 @@ struct SparsePlanHost {
     };
     up(p.bnode, bnode); up(p.soff, soff); up(p.sidx, sidx); up(p.doff, doff); up(p.loff, loff); up(p.toff, toff);
     up(p.tdst, tdst); up(p.tiu, tiu); up(p.tiv, tiv); up(p.hpos, hpos); up(p.jpos, jpos); up(p.dpos, dpos);
+    up(p.lev_off, lev_off); up(p.sblk, sblk); up(p.tblk, tblk);
+    p.nlev = static_cast<i64>(lev_off.size()) - 1;
     return p;
   }
 };

@@ -116,9 +116,10 @@ int dnlp_eval_fused(dnlp_problem* p, const double* xfree, double* f, double* gra
 int dnlp_time_fused(dnlp_problem* p, const double* xfree, int reps, double* seconds);
 /* Linear-solver plan of the handle (decided once, from the sparsity pattern of the tape):
  * out[0] = 1 static-pattern sparse LDL^T / 0 dense, out[1] = factor values, out[2] = pivot blocks,
- * out[3] = largest block struct, out[4] = static 2x2 pivot pairs, out[5] = update triples.
+ * out[3] = largest block struct, out[4] = static 2x2 pivot pairs, out[5] = update triples,
+ * out[6] = elimination-tree levels (out has room for 8 values).
  * `dnlp_set_option(p, "linear_solver", "dense" | "sparse")` forces a path before the first solve. */
-int dnlp_kkt_info(dnlp_problem* p, int64_t* out6);
+int dnlp_kkt_info(dnlp_problem* p, int64_t* out8);
 /* Statistics of the last solve: stats[0..15] = iterations, factorizations, wall, t_eval,
  * t_factor, t_solve, mu, inf_pr, inf_du, compl, nlp_error, last_delta_w, ... */
 int dnlp_get_stats(dnlp_problem* p, double* stats, int n);
