@@ -40,6 +40,7 @@ struct BatchArgs {
   double* times_out = nullptr;   // batch x 4: wall, t_eval, t_factor, t_solve (seconds, device clock)
   SparsePlan sp;                 // static-pattern sparse KKT plan (shared by all instances)
   int use_sparse = 0;
+  i64 fallback_max_n = 0;        // sparse instances up to this order may switch to in-kernel Bunch-Kaufman
   int* next = nullptr;           // work queue head: instances are claimed dynamically (iteration counts vary 10x)
 };
 
@@ -89,6 +90,8 @@ __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
     KktT* kkt = new (o.kkt) KktT();
     if (a.use_sparse) {
       kkt->init_sparse(ex, t.N, t.m, a.sp);
+      kkt->pivot_max_n = static_cast<i64>(1) << 40;
+      kkt->fallback_max_n = a.fallback_max_n;
     } else {
       kkt->pivot_max_n = static_cast<i64>(1) << 40;   // always the pivoted (Bunch-Kaufman) factorisation
       kkt->init(ex, t.N, t.m);
@@ -128,7 +131,7 @@ struct BatchRunner {
   BatchLayout lay;
   i64 in_stride = 0;
   int last_grid = 0, last_threads = 0, last_lds_mode = 0, last_per_cu = 0;   // launch plan of the last solve
-  bool have_sparse = false;
+  bool have_sparse = false, force_sparse = false;
   SparsePlan dev_plan;
   void set_sparse_plan(const SparsePlanHost& hp) { dev_plan = hp.upload(ex); have_sparse = true; }
   // device buffers kept across calls (grow-only): a call is then one H2D copy, one launch and the
@@ -260,7 +263,11 @@ struct BatchRunner {
     }
     a.lds_mode = mode;
     a.lds_bytes = static_cast<unsigned>((mode & 1 ? kbytes : 0) + (mode & 2 ? vbytes : 0));
-    a.ws_per_block = 256 + (mode & 2 ? 0 : vbytes) + (mode & 1 ? 0 : kbytes);
+    // room for the dense matrix of an instance that falls back from the sparse path (global memory)
+    const bool fb = have_sparse && n <= 512 && !force_sparse;
+    a.fallback_max_n = fb ? 512 : 0;
+    const size_t fbbytes = fb ? (((static_cast<size_t>(ld) * n + 256) * 8 + 2 * static_cast<size_t>(n) * 8 + 4096 + 63) & ~static_cast<size_t>(63)) : 0;
+    a.ws_per_block = 256 + (mode & 2 ? 0 : vbytes) + (mode & 1 ? 0 : kbytes) + fbbytes;
     DNLP_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(a.lds_bytes)));
     int per_cu = 1, ncu = 256;
     if (wave) DNLP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, batch_solve_kernel<64>, nthreads, a.lds_bytes));

@@ -26,7 +26,7 @@ static BatchRunner* batch_runner(dnlp_problem_t* p) {
     std::shared_ptr<void> hold(r, [](void* q) { delete static_cast<BatchRunner*>(q); });
     r->init(&p->ex, p->model.owner);
     p->plan_linear_solver();
-    if (p->use_sparse) r->set_sparse_plan(p->sparse_plan);
+    if (p->use_sparse) { r->set_sparse_plan(p->sparse_plan); r->force_sparse = p->linear_solver == 2; }
     p->batch_state = hold;
   }
   return static_cast<BatchRunner*>(p->batch_state.get());

@@ -74,17 +74,34 @@ struct ProblemT {
     if (linear_solver == 1 || t.nblk > 0 || t.ndense > 0 || n < 2) return;
     const double pattern = static_cast<double>(t.nnzH + t.nnzJ) + n;
     if (linear_solver == 0 && pattern > 0.1 * 0.5 * n * n) return;        // already dense
-    build_sparse_plan(t, sparse_plan, opt.bound_relax_factor > 0.0);
-    // a long update program (dense-ish fill) is walked by one workgroup: beyond ~4e5 triples the
-    // chip-wide dense factorisation is the faster choice (phase retrieval: 3.6e6 triples)
-    use_sparse = linear_solver == 2 || (sparse_plan.fill_ratio <= 0.3 && sparse_plan.tdst.size() <= 400000);
+    // Jacobian magnitudes at the tape's start point steer the static 2x2 pairing away from
+    // couplings that vanish there
+    std::vector<double> jabs(static_cast<size_t>(t.nnzJ), 0.0);
+    if (t.nnzJ > 0) {
+      ex.h2d(dx, t.h_x0.data(), sizeof(double) * static_cast<size_t>(t.N));
+      model.sweep(dx, false);
+      model.eval_jac_after_sweep(djac);
+      ex.d2h(jabs.data(), djac, sizeof(double) * static_cast<size_t>(t.nnzJ));
+      for (double& v : jabs) v = std::isfinite(v) ? std::fabs(v) : 0.0;
+      swept = false;
+    }
+    build_sparse_plan(t, sparse_plan, opt.bound_relax_factor > 0.0, &jabs);
+    // a long update program (dense-ish fill) is walked by one workgroup: it must be clearly cheaper
+    // than the chip-wide dense factorisation (n^3/3 flops at MFMA rate; phase retrieval, order
+    // 1472 with 3.6e6 triples, stays dense — a 7e5-order chain with 8e5 triples is sparse)
+    const double triples = static_cast<double>(sparse_plan.tdst.size());
+    use_sparse = linear_solver == 2 ||
+                 (sparse_plan.fill_ratio <= 0.3 && (triples <= 4e5 || triples * 1000.0 <= n * n * n / 3.0));
   }
 
   void ensure_ipm() {
     if (!kkt_ready) {
       plan_linear_solver();
       kkt.pivot_max_n = pivot_max_n;
-      if (use_sparse) kkt.init_sparse(&ex, model.t.N, model.t.m, sparse_plan.upload(&ex));
+      if (use_sparse) {
+        kkt.init_sparse(&ex, model.t.N, model.t.m, sparse_plan.upload(&ex));
+        kkt.fallback_max_n = linear_solver == 2 ? 0 : 2048;      // forced sparse never falls back
+      }
       else kkt.init(&ex, model.t.N, model.t.m);
       kkt_ready = true;
     }

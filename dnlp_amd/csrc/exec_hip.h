@@ -634,6 +634,57 @@ __global__ void __launch_bounds__(kBlock) sparse_solve_kernel(SparsePlan pl, con
   __shared__ double red[kBlock / 64];
   sparse_ldl_solve(pl, vals, x, WgPar{red});
 }
+// Wide levels (large sparse systems: 7e5-order chains have levels of 1e5 independent pivot
+// blocks): one grid-wide kernel per level phase instead of one workgroup walking everything.
+__global__ void __launch_bounds__(kBlock) sp_pivot_kernel(SparsePlan pl, double* vals, double* dinv, i64 b0, i64 b1, SparseInfo* info) {
+  const i64 k = b0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+  if (k >= b1) return;
+  double nneg = 0.0, nzero = 0.0, bad = 0.0;
+  sp_pivot(pl, vals, dinv, k, nneg, nzero, bad);
+  if (nneg != 0.0) atomicAdd(&info->nneg, static_cast<int>(nneg));
+  if (nzero != 0.0) atomicAdd(&info->nzero, static_cast<int>(nzero));
+  if (bad != 0.0) atomicExch(&info->ok, 0);
+}
+__global__ void __launch_bounds__(kBlock) sp_scale_kernel(SparsePlan pl, const double* vals, double* w, const double* dinv, i64 r0, i64 r1) {
+  const i64 r = r0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+  if (r < r1) sp_scale(pl, vals, w, dinv, r);
+}
+__global__ void __launch_bounds__(kBlock) sp_update_kernel(SparsePlan pl, double* vals, const double* w, i64 t0, i64 t1) {
+  const i64 q = t0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+  if (q < t1) unsafeAtomicAdd(&vals[pl.tdst[q]], -sp_update(pl, vals, w, q));
+}
+__global__ void __launch_bounds__(kBlock) sp_store_kernel(double* vals, const double* w, i64 v0, i64 v1) {
+  const i64 a = v0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+  if (a < v1) vals[a] = w[a];
+}
+__global__ void __launch_bounds__(kBlock) sp_fwd_kernel(SparsePlan pl, const double* vals, double* x, i64 r0, i64 r1) {
+  const i64 r = r0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+  if (r >= r1) return;
+  const double c = sp_fwd(pl, vals, x, r);
+  if (c != 0.0) unsafeAtomicAdd(&x[pl.sidx[r]], -c);
+}
+__global__ void __launch_bounds__(kBlock) sp_dsolve_kernel(SparsePlan pl, const double* vals, double* x) {
+  const i64 k = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+  if (k < pl.nblk) sp_dsolve(pl, vals, x, k);
+}
+// backward: one wavefront per block of the level (shuffle reduction over the block's struct)
+__global__ void __launch_bounds__(kBlock) sp_bwd_kernel(SparsePlan pl, const double* vals, double* x, i64 b0, i64 b1) {
+  const i64 k = b0 + static_cast<i64>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  if (k >= b1) return;
+  const int lane = threadIdx.x & 63;
+  const i64 s0 = pl.soff[k], s = pl.soff[k + 1] - s0;
+  const i32 u0 = pl.bnode[2 * k], u1 = pl.bnode[2 * k + 1];
+  const double* Lk = vals + pl.loff[k];
+  double a0 = 0.0, a1 = 0.0;
+  if (u1 < 0) {
+    for (i64 i = lane; i < s; i += 64) a0 += Lk[i] * x[pl.sidx[s0 + i]];
+  } else {
+    for (i64 i = lane; i < s; i += 64) { const double xi = x[pl.sidx[s0 + i]]; a0 += Lk[2 * i] * xi; a1 += Lk[2 * i + 1] * xi; }
+  }
+  a0 = wave_sum(a0);
+  a1 = wave_sum(a1);
+  if (lane == 0) { x[u0] -= a0; if (u1 >= 0) x[u1] -= a1; }
+}
 
 struct BlockedLdlt;   // ldlt_blocked.h
 
@@ -765,10 +816,29 @@ struct HipExec : HostControlled {
                        with_h ? 1 : 0);
     DNLP_LAUNCH_CHECK();
   }
+  // Small systems: one workgroup walks all levels (one launch).  Large ones (>= 8192 pivot
+  // blocks): one grid-wide kernel per level phase, sized by that level's blocks / rows / triples.
+  static constexpr i64 kSparseGridMin = 8192;
   bool sparse_factor(const SparsePlan& pl, double* vals, double* w, int* nneg, int* nzero) {
     if (!sparse_info) { sparse_info = alloc<SparseInfo>(1); }
-    hipLaunchKernelGGL(sparse_factor_kernel, dim3(1), dim3(kBlock), 0, stream, pl, vals, w, sparse_info);
-    DNLP_LAUNCH_CHECK();
+    auto grid = [](i64 items) { return dim3(static_cast<unsigned>((items + kBlock - 1) / kBlock)); };
+    if (pl.nblk < kSparseGridMin || !pl.h_lev_blk) {
+      hipLaunchKernelGGL(sparse_factor_kernel, dim3(1), dim3(kBlock), 0, stream, pl, vals, w, sparse_info);
+      DNLP_LAUNCH_CHECK();
+    } else {
+      const SparseInfo init{1, 0, 0, 0};
+      DNLP_HIP_CHECK(hipMemcpyAsync(sparse_info, &init, sizeof init, hipMemcpyHostToDevice, stream));
+      double* dinv = w + pl.nvals;
+      for (i64 lev = 0; lev < pl.nlev; ++lev) {
+        const i64 b0 = pl.h_lev_blk[lev], b1 = pl.h_lev_blk[lev + 1], r0 = pl.h_lev_row[lev], r1 = pl.h_lev_row[lev + 1];
+        const i64 t0 = pl.h_lev_trip[lev], t1 = pl.h_lev_trip[lev + 1], v0 = pl.h_lev_val[lev], v1 = pl.h_lev_val[lev + 1];
+        hipLaunchKernelGGL(sp_pivot_kernel, grid(b1 - b0), dim3(kBlock), 0, stream, pl, vals, dinv, b0, b1, sparse_info);
+        if (r1 > r0) hipLaunchKernelGGL(sp_scale_kernel, grid(r1 - r0), dim3(kBlock), 0, stream, pl, vals, w, dinv, r0, r1);
+        if (t1 > t0) hipLaunchKernelGGL(sp_update_kernel, grid(t1 - t0), dim3(kBlock), 0, stream, pl, vals, w, t0, t1);
+        if (v1 > v0) hipLaunchKernelGGL(sp_store_kernel, grid(v1 - v0), dim3(kBlock), 0, stream, vals, w, v0, v1);
+      }
+      DNLP_LAUNCH_CHECK();
+    }
     SparseInfo h;
     DNLP_HIP_CHECK(hipMemcpyAsync(&h, sparse_info, sizeof h, hipMemcpyDeviceToHost, stream));
     DNLP_HIP_CHECK(hipStreamSynchronize(stream));
@@ -777,7 +847,22 @@ struct HipExec : HostControlled {
     return h.ok != 0;
   }
   void sparse_solve(const SparsePlan& pl, const double* vals, double* x) {
-    hipLaunchKernelGGL(sparse_solve_kernel, dim3(1), dim3(kBlock), 0, stream, pl, vals, x);
+    auto grid = [](i64 items) { return dim3(static_cast<unsigned>((items + kBlock - 1) / kBlock)); };
+    if (pl.nblk < kSparseGridMin || !pl.h_lev_blk) {
+      hipLaunchKernelGGL(sparse_solve_kernel, dim3(1), dim3(kBlock), 0, stream, pl, vals, x);
+    } else {
+      for (i64 lev = 0; lev < pl.nlev; ++lev) {
+        const i64 r0 = pl.h_lev_row[lev], r1 = pl.h_lev_row[lev + 1];
+        if (r1 > r0) hipLaunchKernelGGL(sp_fwd_kernel, grid(r1 - r0), dim3(kBlock), 0, stream, pl, vals, x, r0, r1);
+      }
+      hipLaunchKernelGGL(sp_dsolve_kernel, grid(pl.nblk), dim3(kBlock), 0, stream, pl, vals, x);
+      for (i64 lev = pl.nlev - 1; lev >= 0; --lev) {
+        const i64 b0 = pl.h_lev_blk[lev], b1 = pl.h_lev_blk[lev + 1];
+        if (pl.h_lev_row[lev + 1] == pl.h_lev_row[lev]) continue;       // root blocks: empty structs
+        hipLaunchKernelGGL(sp_bwd_kernel, dim3(static_cast<unsigned>((b1 - b0 + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
+                           stream, pl, vals, x, b0, b1);
+      }
+    }
     DNLP_LAUNCH_CHECK();
   }
   double fused_eval(const FusedProg& P, const double* x, const double* consts, double* grad) {

@@ -688,6 +688,22 @@ class Ipm {
     };
     if (use_lb && (iter == 0 || delta_w_used_last_iter_)) get_lb();
     int r = attempt(0.0, 0.0);
+    // Static pivots (sparse KKT) that are singular without any regularisation in consecutive
+    // iterations are structural (free variables without curvature next to unregularised equality
+    // rows): where the dense matrix is affordable the instance switches to Bunch-Kaufman pivoting
+    // for good instead of regularising every step.
+    if (r == 2 && kkt_->can_fallback()) {
+      ++sparse_singular_streak_;
+      // small systems switch at once (the dense factorisation costs nothing there); larger ones only
+      // when the singularity persists beyond the first iteration (multipliers start at zero)
+      if ((N + m) <= 512 || (iter >= 1 && sparse_singular_streak_ >= 2)) {
+        kkt_->fallback_to_dense();
+        logf("   static pivot sequence singular in consecutive iterations: Bunch-Kaufman from here on");
+        r = attempt(0.0, 0.0);
+      }
+    } else {
+      sparse_singular_streak_ = 0;
+    }
     if (r == 0) { delta_w_used_last_iter_ = false; return true; }
     if (use_lb && !have_lb) get_lb();
     delta_w_used_last_iter_ = true;
@@ -1436,6 +1452,7 @@ class Ipm {
   i64 nb_cache_ = -1;
   double last_ratio_ = 0.0;
   bool delta_w_used_last_iter_ = false;
+  int sparse_singular_streak_ = 0;
   double *lanV = nullptr, *lanW = nullptr, *lanQ = nullptr;
   double t_begin_ = 0.0;
 };

@@ -31,6 +31,17 @@ struct DenseKkt {
   SparsePlan sp;
   double* svals = nullptr;     // plan-layout values: assembled matrix, then (D, L)
   double* swork = nullptr;     // scratch of the numeric phase (sparse_ldl_work_doubles)
+  i64 fallback_max_n = 0;      // orders up to which a structurally singular static pivot sequence
+                               // makes the instance switch to the dense Bunch-Kaufman path
+  DNLP_HD bool can_fallback() const { return sparse && n <= fallback_max_n; }
+  DNLP_HD void fallback_to_dense() {
+    sparse = false;
+    const i64 keep = pivot_max_n;
+    if (pivot_max_n < n) pivot_max_n = n;      // the fallback is the pivoted factorisation
+    init(ex, N, m);
+    pivot_max_n = keep;
+    pivoted = true;
+  }
 
   DNLP_HD void init_sparse(E* e, i64 N_, i64 m_, const SparsePlan& plan) {
     ex = e; N = N_; m = m_; n = N + m; ld = 0;

@@ -24,6 +24,82 @@ struct SeqPar {
 // work: nvals (w, laid out like the L values) + 3 * nblk (inverse pivot blocks)
 DNLP_HD inline i64 sparse_ldl_work_doubles(const SparsePlan& pl) { return pl.nvals + 3 * pl.nblk + 8; }
 
+// ---- per-item bodies of the level phases (shared by the cooperative routine below and by the
+// grid-wide level kernels of the HIP space) ------------------------------------------------------
+// A: invert the pivot block k; returns inertia contribution through the three counters
+DNLP_HD inline void sp_pivot(const SparsePlan& pl, double* vals, double* dinv, i64 k, double& nneg, double& nzero, double& bad) {
+  double* Dk = vals + pl.doff[k];
+  double* di = dinv + 3 * k;
+  if (pl.bnode[2 * k + 1] < 0) {
+    double d = Dk[0];
+    if (!(d == d)) bad += 1.0;
+    if (fabs(d) < 1e-300) {
+#if !DNLP_DEVICE_PASS
+      if (std::getenv("DNLP_SPARSE_DEBUG")) std::fprintf(stderr, "[sparse] zero 1x1 pivot: block %lld node %d (N=%lld)\n", (long long)k, pl.bnode[2 * k], (long long)pl.N);
+#endif
+      nzero += 1.0; d = 1e-20; Dk[0] = d;
+    }
+    if (d < 0.0) nneg += 1.0;
+    di[0] = 1.0 / d;
+  } else {
+    const double a = Dk[0], c = Dk[1], e = Dk[2];
+    double det = a * e - c * c;
+    if (!(det == det)) bad += 1.0;
+    if (fabs(det) < 1e-300) {
+#if !DNLP_DEVICE_PASS
+      if (std::getenv("DNLP_SPARSE_DEBUG")) std::fprintf(stderr, "[sparse] singular 2x2 pivot: block %lld nodes %d %d (N=%lld) a=%g c=%g e=%g\n", (long long)k, pl.bnode[2 * k], pl.bnode[2 * k + 1], (long long)pl.N, a, c, e);
+#endif
+      nzero += 1.0; det = -1e-20;
+    }
+    if (det < 0.0) nneg += 1.0;
+    else if (a < 0.0 || (a == 0.0 && e < 0.0)) nneg += 2.0;
+    di[0] = e / det; di[1] = -c / det; di[2] = a / det;
+  }
+}
+// B: w = l D^-1 for struct row r
+DNLP_HD inline void sp_scale(const SparsePlan& pl, const double* vals, double* w, const double* dinv, i64 r) {
+  const i64 k = pl.sblk[r], i = r - pl.soff[k];
+  const double* di = dinv + 3 * k;
+  if (pl.bnode[2 * k + 1] < 0) {
+    const i64 a = pl.loff[k] + i;
+    w[a] = vals[a] * di[0];
+  } else {
+    const i64 a = pl.loff[k] + 2 * i;
+    const double l1 = vals[a], l2 = vals[a + 1];
+    w[a] = di[0] * l1 + di[1] * l2;
+    w[a + 1] = di[1] * l1 + di[2] * l2;
+  }
+}
+// C: value of update triple q
+DNLP_HD inline double sp_update(const SparsePlan& pl, const double* vals, const double* w, i64 q) {
+  const i64 k = pl.tblk[q], iu = pl.tiu[q], iv = pl.tiv[q];
+  if (pl.bnode[2 * k + 1] < 0) return vals[pl.loff[k] + iu] * w[pl.loff[k] + iv];
+  const i64 au = pl.loff[k] + 2 * iu, av = pl.loff[k] + 2 * iv;
+  return vals[au] * w[av] + vals[au + 1] * w[av + 1];
+}
+// forward substitution: contribution of struct row r
+DNLP_HD inline double sp_fwd(const SparsePlan& pl, const double* vals, const double* x, i64 r) {
+  const i64 k = pl.sblk[r], i = r - pl.soff[k];
+  const i32 u0 = pl.bnode[2 * k], u1 = pl.bnode[2 * k + 1];
+  if (u1 < 0) return vals[pl.loff[k] + i] * x[u0];
+  return vals[pl.loff[k] + 2 * i] * x[u0] + vals[pl.loff[k] + 2 * i + 1] * x[u1];
+}
+// D^-1 on block k
+DNLP_HD inline void sp_dsolve(const SparsePlan& pl, const double* vals, double* x, i64 k) {
+  const i32 u0 = pl.bnode[2 * k], u1 = pl.bnode[2 * k + 1];
+  const double* Dk = vals + pl.doff[k];
+  if (u1 < 0) {
+    x[u0] /= Dk[0];
+  } else {
+    const double a = Dk[0], c = Dk[1], e = Dk[2];
+    double det = a * e - c * c;
+    if (fabs(det) < 1e-300) det = -1e-20;
+    const double x0 = x[u0], x1 = x[u1];
+    x[u0] = (e * x0 - c * x1) / det;
+    x[u1] = (a * x1 - c * x0) / det;
+  }
+}
+
 // vals: assembled matrix in plan layout, overwritten by (D, L).  Level by level: the blocks of an
 // elimination-tree level are independent, so their pivots are inverted together, their rows scaled
 // together and their update triples applied together (sums into common ancestors through
@@ -37,65 +113,15 @@ DNLP_HD inline bool sparse_ldl_factor(const SparsePlan& pl, double* vals, double
   for (i64 lev = 0; lev < pl.nlev; ++lev) {
     const i64 b0 = pl.lev_off[lev], b1 = pl.lev_off[lev + 1];
     // A: pivot blocks
-    for (i64 k = b0 + me; k < b1; k += L) {
-      double* Dk = vals + pl.doff[k];
-      double* di = dinv + 3 * k;
-      if (pl.bnode[2 * k + 1] < 0) {
-        double d = Dk[0];
-        if (!(d == d)) bad += 1.0;
-        if (fabs(d) < 1e-300) {
-#if !DNLP_DEVICE_PASS
-          if (std::getenv("DNLP_SPARSE_DEBUG")) std::fprintf(stderr, "[sparse] zero 1x1 pivot: block %lld node %d (N=%lld)\n", (long long)k, pl.bnode[2 * k], (long long)pl.N);
-#endif
-          nzero += 1.0; d = 1e-20; Dk[0] = d;
-        }
-        if (d < 0.0) nneg += 1.0;
-        di[0] = 1.0 / d;
-      } else {
-        const double a = Dk[0], c = Dk[1], e = Dk[2];
-        double det = a * e - c * c;
-        if (!(det == det)) bad += 1.0;
-        if (fabs(det) < 1e-300) {
-#if !DNLP_DEVICE_PASS
-          if (std::getenv("DNLP_SPARSE_DEBUG")) std::fprintf(stderr, "[sparse] singular 2x2 pivot: block %lld nodes %d %d (N=%lld) a=%g c=%g e=%g\n", (long long)k, pl.bnode[2 * k], pl.bnode[2 * k + 1], (long long)pl.N, a, c, e);
-#endif
-          nzero += 1.0; det = -1e-20;
-        }
-        if (det < 0.0) nneg += 1.0;
-        else if (a < 0.0 || (a == 0.0 && e < 0.0)) nneg += 2.0;
-        di[0] = e / det; di[1] = -c / det; di[2] = a / det;
-      }
-    }
+    for (i64 k = b0 + me; k < b1; k += L) sp_pivot(pl, vals, dinv, k, nneg, nzero, bad);
     par.sync();
     // B: w = L D^-1 for every struct row of the level
     const i64 r0 = pl.soff[b0], r1 = pl.soff[b1];
-    for (i64 r = r0 + me; r < r1; r += L) {
-      const i64 k = pl.sblk[r], i = r - pl.soff[k];
-      const double* di = dinv + 3 * k;
-      if (pl.bnode[2 * k + 1] < 0) {
-        const i64 a = pl.loff[k] + i;
-        w[a] = vals[a] * di[0];
-      } else {
-        const i64 a = pl.loff[k] + 2 * i;
-        const double l1 = vals[a], l2 = vals[a + 1];
-        w[a] = di[0] * l1 + di[1] * l2;
-        w[a + 1] = di[1] * l1 + di[2] * l2;
-      }
-    }
+    for (i64 r = r0 + me; r < r1; r += L) sp_scale(pl, vals, w, dinv, r);
     par.sync();
     // C: Schur-complement updates of the level
     const i64 t0 = pl.toff[b0], t1 = pl.toff[b1];
-    for (i64 q = t0 + me; q < t1; q += L) {
-      const i64 k = pl.tblk[q], iu = pl.tiu[q], iv = pl.tiv[q];
-      double u;
-      if (pl.bnode[2 * k + 1] < 0) {
-        u = vals[pl.loff[k] + iu] * w[pl.loff[k] + iv];
-      } else {
-        const i64 au = pl.loff[k] + 2 * iu, av = pl.loff[k] + 2 * iv;
-        u = vals[au] * w[av] + vals[au + 1] * w[av + 1];
-      }
-      par.add(&vals[pl.tdst[q]], -u);
-    }
+    for (i64 q = t0 + me; q < t1; q += L) par.add(&vals[pl.tdst[q]], -sp_update(pl, vals, w, q));
     par.sync();
     // D: keep L = l D^-1
     const i64 v0 = pl.loff[b0], v1 = (b1 < pl.nblk) ? pl.loff[b1] : pl.nvals;
@@ -119,29 +145,12 @@ DNLP_HD inline void sparse_ldl_solve(const SparsePlan& pl, const double* vals, d
     const i64 b0 = pl.lev_off[lev], b1 = pl.lev_off[lev + 1];
     const i64 r0 = pl.soff[b0], r1 = pl.soff[b1];
     for (i64 r = r0 + me; r < r1; r += L) {
-      const i64 k = pl.sblk[r], i = r - pl.soff[k];
-      const i32 u0 = pl.bnode[2 * k], u1 = pl.bnode[2 * k + 1];
-      double c;
-      if (u1 < 0) c = vals[pl.loff[k] + i] * x[u0];
-      else c = vals[pl.loff[k] + 2 * i] * x[u0] + vals[pl.loff[k] + 2 * i + 1] * x[u1];
+      const double c = sp_fwd(pl, vals, x, r);
       if (c != 0.0) par.add(&x[pl.sidx[r]], -c);
     }
     par.sync();
   }
-  for (i64 k = me; k < pl.nblk; k += L) {
-    const i32 u0 = pl.bnode[2 * k], u1 = pl.bnode[2 * k + 1];
-    const double* Dk = vals + pl.doff[k];
-    if (u1 < 0) {
-      x[u0] /= Dk[0];
-    } else {
-      const double a = Dk[0], c = Dk[1], e = Dk[2];
-      double det = a * e - c * c;
-      if (fabs(det) < 1e-300) det = -1e-20;
-      const double x0 = x[u0], x1 = x[u1];
-      x[u0] = (e * x0 - c * x1) / det;
-      x[u1] = (a * x1 - c * x0) / det;
-    }
-  }
+  for (i64 k = me; k < pl.nblk; k += L) sp_dsolve(pl, vals, x, k);
   par.sync();
   // backward, levels descending: a block gathers from its (already final) ancestors.  Wide levels:
   // one lane per block; narrow levels near the root (few blocks, long structs): all lanes per block.

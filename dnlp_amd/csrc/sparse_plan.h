@@ -59,23 +59,31 @@ struct SparsePlan {
   i64* lev_off = nullptr; // nlev + 1 offsets into the block order
   i32* sblk = nullptr;    // block of every struct row (soff-indexed)
   i32* tblk = nullptr;    // block of every update triple
+  // host copies of the level boundaries (blocks / struct rows / triples / values), for the space
+  // that launches one kernel per level phase; unused inside kernels
+  const i64 *h_lev_blk = nullptr, *h_lev_row = nullptr, *h_lev_trip = nullptr, *h_lev_val = nullptr;
 };
 
 struct SparsePlanHost {
   i64 n = 0, N = 0, m = 0, nvals = 0, maxs = 0;
   std::vector<i32> bnode, sidx, tdst, tiu, tiv, hpos, jpos, dpos;
   std::vector<i64> soff, doff, loff, toff, lev_off;
+  std::vector<i64> lev_row, lev_trip, lev_val;     // per-level boundaries in rows / triples / values
   std::vector<i32> sblk, tblk;
   i64 nnzL = 0, n_delayed = 0, n_pairs = 0;
   double fill_ratio = 0.0;    // factor values / dense lower triangle
 
   i64 nblk() const { return static_cast<i64>(doff.size()); }
 
-  // zero_diag_var[j]: no Hessian diagonal entry and no finite bound; eq_row[i]: cl == cu;
-  // jac_const[p]: |constant coefficient| of Jacobian entry p, or 0 when the entry is not constant
+  // zero_diag_var[j]: no finite bound; eq_row[i]: cl == cu;
+  // jac_const[p]: |constant coefficient| of Jacobian entry p, or 0 when the entry is not constant;
+  // jac_abs0[p] (optional): |value| of entry p at the start point — a coupling that is numerically
+  // zero there makes a singular 2x2 block, so such entries are the last resort of the matching
   void build(i64 N_, i64 m_, const std::vector<i32>& hr, const std::vector<i32>& hc, const std::vector<i32>& jr,
              const std::vector<i32>& jc, const std::vector<char>& zero_diag_var, const std::vector<char>& eq_row,
-             const std::vector<double>& jac_const, const std::vector<char>& fixed_var) {
+             const std::vector<double>& jac_const, const std::vector<char>& fixed_var, int relax = 0,
+             const std::vector<double>* jac_abs0 = nullptr) {
+    *this = SparsePlanHost();
     N = N_; m = m_; n = N + m;
     const i64 nn = n;
     // fixed variables (lb == ub) are pinned by the interior-point loop: unit diagonal, all their
@@ -91,9 +99,17 @@ struct SparsePlanHost {
     std::vector<i32> partner(static_cast<size_t>(nn), -1);
     {
       // best coefficient per (row, var): from the Jacobian COO
+      // candidate weight: > 1 constant coefficient, (0, 1] varying coefficient that is non-zero at the
+      // start point, 0 varying coefficient that vanishes there
       std::vector<std::vector<std::pair<i32, double>>> rowvars(static_cast<size_t>(m));
-      for (size_t p = 0; p < jr.size(); ++p)
-        if (!is_fixed(jc[p])) rowvars[static_cast<size_t>(jr[p])].push_back({jc[p], jac_const[p]});
+      for (size_t p = 0; p < jr.size(); ++p) {
+        if (is_fixed(jc[p])) continue;
+        double wgt;
+        if (jac_const[p] > 0.0) wgt = 1.0 + std::min(jac_const[p], 1.0);
+        else if (jac_abs0) wgt = std::min((*jac_abs0)[p], 1.0) * 0.999;
+        else wgt = 0.5;
+        rowvars[static_cast<size_t>(jr[p])].push_back({jc[p], wgt});
+      }
       // rows with the fewest candidates first (they have the least choice)
       std::vector<i32> rows;
       for (i64 i = 0; i < m; ++i) if (eq_row[static_cast<size_t>(i)]) rows.push_back(static_cast<i32>(i));
@@ -103,9 +119,9 @@ struct SparsePlanHost {
         double best_score = -1.0;
         for (auto& vc : rowvars[static_cast<size_t>(i)]) {
           const i32 v = vc.first;
-          if (partner[static_cast<size_t>(v)] >= 0) continue;
-          // constant coefficient > structurally zero diagonal > low degree
-          double score = (vc.second > 0.0 ? 4.0 + std::min(vc.second, 1.0) : 0.0) + (zero_diag_var[static_cast<size_t>(v)] ? 2.0 : 0.0) +
+          if (partner[static_cast<size_t>(v)] >= 0 || !(vc.second > 0.0)) continue;
+          // constant coefficient > large coefficient > structurally zero diagonal > low degree
+          double score = 4.0 * vc.second + (zero_diag_var[static_cast<size_t>(v)] ? 2.0 : 0.0) +
                          1.0 / (1.0 + static_cast<double>(adj[static_cast<size_t>(v)].size()));
           if (score > best_score) { best_score = score; best = v; }
         }
@@ -118,7 +134,7 @@ struct SparsePlanHost {
       // Constant coefficients are tried first.
       std::vector<i64> visit_mark(static_cast<size_t>(N), -1);
       std::vector<i32> from_row(static_cast<size_t>(N), -1);
-      for (int pass = 0; pass < 2; ++pass) {
+      for (int pass = 0; pass < 3; ++pass) {
         for (i32 i : rows) {
           if (partner[static_cast<size_t>(N + i)] >= 0) continue;
           // BFS over alternating paths: row -> candidate variable -> the row it is matched to -> ...
@@ -129,7 +145,8 @@ struct SparsePlanHost {
             const i32 r = queue[qh];
             for (auto& vc : rowvars[static_cast<size_t>(r)]) {
               const i32 v = vc.first;
-              if (pass == 0 && !(vc.second > 0.0)) continue;
+              if (pass == 0 && !(vc.second > 1.0)) continue;       // constant coefficients only
+              if (pass == 1 && !(vc.second > 0.0)) continue;       // non-zero at the start point
               if (visit_mark[static_cast<size_t>(v)] == stamp) continue;
               visit_mark[static_cast<size_t>(v)] = stamp;
               from_row[static_cast<size_t>(v)] = r;
@@ -202,23 +219,21 @@ struct SparsePlanHost {
     order.reserve(static_cast<size_t>(nb));
     std::vector<i32> merged;
     i64 remaining = nb;
-    while (remaining > 0) {
-      if (pq.empty()) {
-        // only not-ready blocks are left (a component made of zero-diagonal nodes): release them
-        for (i64 b = 0; b < nb; ++b)
-          if (!gone[static_cast<size_t>(b)] && !ready[static_cast<size_t>(b)]) { ready[static_cast<size_t>(b)] = 1; pq.push({deg[static_cast<size_t>(b)], static_cast<i32>(b)}); }
-        continue;
-      }
-      const QE top = pq.top();
-      pq.pop();
-      const i32 b = top.second;
-      if (gone[static_cast<size_t>(b)] || top.first != deg[static_cast<size_t>(b)]) continue;
+    // Multiple elimination with a relaxed threshold (`relax`): in one round, a maximal independent
+    // set of the blocks whose degree is within `relax` of the minimum is eliminated; neighbours of
+    // an eliminated block wait for the next round.  relax = 0 is plain minimum degree.  On
+    // chain-like patterns (Rosenbrock chain, path planning) relax = 1 removes every other interior
+    // block per round, so the elimination tree is logarithmically shallow instead of n/2 deep —
+    // the depth is the number of sequential steps of the level-parallel numeric phase.
+    std::vector<i64> mark(static_cast<size_t>(nb), -1);
+    std::vector<i32> cand;
+    i64 round = 0;
+    auto eliminate = [&](i32 b) {
       gone[static_cast<size_t>(b)] = 1;
       --remaining;
       order.push_back(b);
       std::vector<i32>& nb_ = badj[static_cast<size_t>(b)];
       bstruct[static_cast<size_t>(b)] = nb_;
-      // clique among the neighbours, b removed
       for (i32 c : nb_) {
         std::vector<i32>& ac = badj[static_cast<size_t>(c)];
         merged.clear();
@@ -227,10 +242,35 @@ struct SparsePlanHost {
         for (i32 x : merged) if (x != c && x != b) ac.push_back(x);
         deg[static_cast<size_t>(c)] = degree(c);
         ready[static_cast<size_t>(c)] = 1;
+        mark[static_cast<size_t>(c)] = round;
         pq.push({deg[static_cast<size_t>(c)], c});
       }
       nb_.clear();
       nb_.shrink_to_fit();
+    };
+    while (remaining > 0) {
+      // drop stale heads
+      while (!pq.empty() && (gone[static_cast<size_t>(pq.top().second)] || pq.top().first != deg[static_cast<size_t>(pq.top().second)])) pq.pop();
+      if (pq.empty()) {
+        // only not-ready blocks are left (a component made of zero-diagonal nodes): release them
+        for (i64 b = 0; b < nb; ++b)
+          if (!gone[static_cast<size_t>(b)] && !ready[static_cast<size_t>(b)]) { ready[static_cast<size_t>(b)] = 1; pq.push({deg[static_cast<size_t>(b)], static_cast<i32>(b)}); }
+        continue;
+      }
+      ++round;
+      const i64 thresh = pq.top().first + relax;
+      cand.clear();
+      while (!pq.empty() && pq.top().first <= thresh) {
+        const QE top = pq.top();
+        pq.pop();
+        if (gone[static_cast<size_t>(top.second)] || top.first != deg[static_cast<size_t>(top.second)]) continue;
+        cand.push_back(top.second);
+      }
+      for (i32 b : cand) {
+        if (gone[static_cast<size_t>(b)]) continue;
+        if (mark[static_cast<size_t>(b)] == round) continue;     // a neighbour went this round (it was re-queued by eliminate)
+        eliminate(b);
+      }
     }
     // ---- elimination-tree levels: level-major order is a topological order of the same tree ----
     {
@@ -344,6 +384,12 @@ struct SparsePlanHost {
         }
       toff[static_cast<size_t>(k + 1)] = static_cast<i64>(tdst.size());
     }
+    lev_row.clear(); lev_trip.clear(); lev_val.clear();
+    for (i64 b : lev_off) {
+      lev_row.push_back(soff[static_cast<size_t>(b)]);
+      lev_trip.push_back(toff[static_cast<size_t>(b)]);
+      lev_val.push_back(b < nb ? loff[static_cast<size_t>(b)] : nvals);
+    }
     if (nvals >= (static_cast<i64>(1) << 31)) throw std::runtime_error("sparse KKT plan: factor too large for 32-bit addresses");
   }
 
@@ -359,13 +405,14 @@ struct SparsePlanHost {
     up(p.tdst, tdst); up(p.tiu, tiu); up(p.tiv, tiv); up(p.hpos, hpos); up(p.jpos, jpos); up(p.dpos, dpos);
     up(p.lev_off, lev_off); up(p.sblk, sblk); up(p.tblk, tblk);
     p.nlev = static_cast<i64>(lev_off.size()) - 1;
+    p.h_lev_blk = lev_off.data(); p.h_lev_row = lev_row.data(); p.h_lev_trip = lev_trip.data(); p.h_lev_val = lev_val.data();
     return p;
   }
 };
 
 // Plan of a loaded tape: structural information from the host copies.
 template <class E>
-inline void build_sparse_plan(const Tape<E>& t, SparsePlanHost& plan, bool bounds_relaxed) {
+inline void build_sparse_plan(const Tape<E>& t, SparsePlanHost& plan, bool bounds_relaxed, const std::vector<double>* jac_abs0 = nullptr) {
   std::vector<char> zero_diag(static_cast<size_t>(t.N), 1), eq(static_cast<size_t>(t.m), 0), fixed(static_cast<size_t>(t.N), 0);
   if (!bounds_relaxed)
     for (i64 j = 0; j < t.N; ++j) fixed[static_cast<size_t>(j)] = t.h_lb[static_cast<size_t>(j)] == t.h_ub[static_cast<size_t>(j)];
@@ -374,7 +421,17 @@ inline void build_sparse_plan(const Tape<E>& t, SparsePlanHost& plan, bool bound
   for (i64 j = 0; j < t.N; ++j)
     if (t.h_lb[static_cast<size_t>(j)] > -1e19 || t.h_ub[static_cast<size_t>(j)] < 1e19) zero_diag[static_cast<size_t>(j)] = 0;
   for (i64 i = 0; i < t.m; ++i) eq[static_cast<size_t>(i)] = t.h_cl[static_cast<size_t>(i)] == t.h_cu[static_cast<size_t>(i)];
-  plan.build(t.N, t.m, t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, zero_diag, eq, t.h_jac_const, fixed);
+  // two candidate orders: plain minimum degree, and the relaxed multiple elimination that gives
+  // shallow trees on chain-like patterns; the relaxed one is kept unless it costs noticeably more
+  SparsePlanHost strict;
+  strict.build(t.N, t.m, t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, zero_diag, eq, t.h_jac_const, fixed, 0, jac_abs0);
+  plan.build(t.N, t.m, t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, zero_diag, eq, t.h_jac_const, fixed, 1, jac_abs0);
+  // cost model of the level-parallel numeric phase: a level costs a few barriers, a triple a
+  // fraction of that per lane — halving the depth is worth up to 3x the update work
+  const double tr = static_cast<double>(plan.tdst.size()), ts = static_cast<double>(strict.tdst.size());
+  const double lr = static_cast<double>(plan.lev_off.size()), ls = static_cast<double>(strict.lev_off.size());
+  const bool relaxed_ok = (lr <= 0.5 * ls && tr <= 3.0 * ts + 64.0) || (lr <= ls && tr <= 1.2 * ts + 64.0);
+  if (!relaxed_ok) plan = strict;
 }
 
 }  // namespace dnlp

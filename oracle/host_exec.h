@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "../dnlp_amd/csrc/exec.h"
@@ -27,7 +28,11 @@ struct HostExec : HostControlled {
   void ldlt_stats(LdltWork&, double* out3) { out3[0] = out3[1] = out3[2] = 0.0; }
   explicit HostExec(int device = 0) { (void)device; }
 
-  template <class T> T* alloc(size_t n) { return static_cast<T*>(std::calloc(n ? n : 1, sizeof(T))); }
+  template <class T> T* alloc(size_t n) {
+    T* p = static_cast<T*>(std::calloc(n ? n : 1, sizeof(T)));
+    if (!p) throw std::bad_alloc();
+    return p;
+  }
   void release(void* p) { std::free(p); }
   void h2d(void* dst, const void* src, size_t bytes) { if (bytes) std::memcpy(dst, src, bytes); }
   void d2h(void* dst, const void* src, size_t bytes) { if (bytes) std::memcpy(dst, src, bytes); }
