@@ -70,3 +70,46 @@ def test_dense_patterns_keep_the_dense_path():
     assert not OracleProblem(serialize(data["tape_arrays"])).kkt_info()["sparse"]
     data, _ = build_canonical("dense_eq_qp")      # dense Hessian as COO: pattern above 10 % of the triangle
     assert not OracleProblem(serialize(data["tape_arrays"])).kkt_info()["sparse"]
+
+
+def _device_solve(name, linear_solver, device_loop):
+    import dnlp_amd as cp
+    from paper_examples import PAPER, PUBLISHED
+    from problem_zoo import GOLDEN_ZOO as Z
+    prob = Z[name](cp)
+    opts = dict(PUBLISHED.get(name, {}).get("options", {}))
+    prob.solve(nlp=True, linear_solver=linear_solver, device_loop=device_loop, **opts)
+    return prob
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["hs071", "localization", "nb_circle_packing", "nb_path_planning", "nb_power_flow"])
+def test_device_sparse_paths_agree_with_dense(name, gpu_required):
+    """The three ways a sparse-pattern problem can run on the device — in-kernel loop with the
+    sparse factorisation (default), host-driven loop with the sparse kernels, host-driven loop with
+    the chip-wide Bunch-Kaufman — land on the same optimum."""
+    a = _device_solve(name, "mumps", "auto")      # IPOPT's option value: "your choice" -> sparse, in-kernel
+    b = _device_solve(name, "sparse", "host")
+    c = _device_solve(name, "dense", "host")
+    assert a.status == b.status == c.status == "optimal"
+    for p in (a, b):
+        assert abs(p.value - c.value) <= 1e-6 * max(1.0, abs(c.value))
+
+
+@pytest.mark.gpu
+def test_c2_canonical_form_through_the_interior_point_loop(gpu_required):
+    """BASELINE C2 in the form the reference hands to IPOPT: n = 1e5 -> N = 399 997, m = 299 997,
+    KKT order 699 994.  Sparse factor: 2.4e6 values, 22 elimination-tree levels."""
+    import dnlp_amd as cp
+    from problem_zoo import rosenbrock_chain
+    n = 100000
+    prob = rosenbrock_chain(cp, n)
+    chain = prob._build_chain(None)
+    data, inv = chain.apply(prob)
+    info_k = data["handle"].kkt_info()
+    assert info_k["sparse"] and info_k["levels"] <= 64 and info_k["pairs_2x2"] == 3 * n - 3
+    info = chain.solver.solve_via_data(data, True, False, {})
+    prob.unpack_results(info, chain, inv)
+    assert prob.status == "optimal"
+    assert np.max(np.abs(prob.variables()[0].value - 1.0)) <= 1e-6
+    assert info["iterations"] <= 60
