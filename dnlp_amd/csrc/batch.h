@@ -34,6 +34,7 @@ struct BatchArgs {
   size_t ws_per_block = 0;
   unsigned lds_bytes = 0;        // dynamic LDS pool (0: everything in global memory)
   int lds_mode = 0;              // what the pool holds: 0 nothing, 1 KKT matrix, 2 vectors, 3 both
+  unsigned lds_stage_bytes = 0;  // front of the pool: staging arrays of the dense wavefront solves
   IpmOptions opt;
   double *x_out = nullptr, *obj_out = nullptr, *multg_out = nullptr, *zl_out = nullptr, *zu_out = nullptr;
   int *status_out = nullptr, *iters_out = nullptr, *nfact_out = nullptr;
@@ -65,8 +66,11 @@ __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
   __shared__ Objs s_objs[NW];
   __shared__ double s_red[8];
   __shared__ int s_redi[8];
-  __shared__ double s_vec[EX::kWaveSolveMax];
-  __shared__ int s_piv[EX::kWaveSolveMax];
+  // staging of the dense single-wavefront solves: carved from the front of the dynamic pool, and
+  // only when the dense path can be taken (sparse instances without a fallback do not pay for it)
+  double* s_vec = reinterpret_cast<double*>(lds_dyn);
+  int* s_piv = reinterpret_cast<int*>(lds_dyn + sizeof(double) * EX::kWaveSolveMax);
+  const unsigned stage = a.lds_stage_bytes;
   __shared__ int s_inst;
   Objs& o = s_objs[threadIdx.x >> 6];
   while (true) {
@@ -75,8 +79,8 @@ __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
     const int inst = s_inst;
     __syncthreads();
     if (inst >= a.batch) break;
-    EX* ex = new (o.ex) EX(a.ws + static_cast<size_t>(blockIdx.x) * a.ws_per_block, a.ws_per_block, lds_dyn, a.lds_bytes,
-                           s_red, s_redi, s_vec, s_piv);
+    EX* ex = new (o.ex) EX(a.ws + static_cast<size_t>(blockIdx.x) * a.ws_per_block, a.ws_per_block, lds_dyn + stage,
+                           a.lds_bytes - stage, s_red, s_redi, stage ? s_vec : nullptr, stage ? s_piv : nullptr);
     ex->lds_mode = a.lds_mode;
     double* sl = a.slabs + static_cast<i64>(inst) * a.lay.total;
     TapeView t = a.base;
@@ -234,6 +238,10 @@ struct BatchRunner {
     const size_t vdoubles = static_cast<size_t>(26 * t.N + 36 * t.m + 2 * t.Z + t.nd + t.nh + t.nnzH + t.nnzJ + 2 * n + 64) +
                             (have_sparse && !sparse_big ? sparse_vals : 0);
     const size_t vbytes = ((vdoubles * 8 * 21 / 20) + 96 * 64 + 255) & ~static_cast<size_t>(255);
+    // LDS reservation for the vectors: tight (the allocator spills to the global slab, which always
+    // has room for the whole working set, so an underestimate costs latency on a few arrays only)
+    const size_t vdoubles_lds = vdoubles - static_cast<size_t>(have_sparse ? 2 * n : 0);
+    const size_t vbytes_lds = (vdoubles_lds * 8 + 80 * 32 + 63) & ~static_cast<size_t>(63);
     // lanes per instance: one wavefront up to order 256 (factorisation and solves are
     // single-wavefront there, vectors are at most a few hundred long), four above
     const bool wave = n <= 256 || have_sparse;
@@ -248,26 +256,38 @@ struct BatchRunner {
     // this kernel's register budget), the per-iteration latency second (both in LDS < matrix in
     // LDS < vectors in LDS < nothing).  So: the richest plan among those with the most instances
     // per CU.  DNLP_BATCH_LDS=0..3 overrides, for experiments.
+    // staging for the dense single-wavefront solves is needed whenever the dense path can run
+    const bool dense_possible = !have_sparse || (n <= 512 && !force_sparse);
+    const size_t stage_bytes = dense_possible ? static_cast<size_t>(BlockExecT<64>::kWaveSolveMax) * 12 : 0;
     const int slots_max = wave ? 4 : 1;
     auto slots = [&](int md_) {
-      const size_t dyn = (md_ & 1 ? kbytes : 0) + (md_ & 2 ? vbytes : 0);
+      const size_t dyn = stage_bytes + (md_ & 1 ? kbytes : 0) + (md_ & 2 ? vbytes_lds : 0);
       if (dyn > lds_max) return 0;
       const size_t per = dyn + fa.sharedSizeBytes + 256;
       return static_cast<int>(std::min<size_t>(slots_max, (160 * 1024) / per));
     };
-    int mode = 0, best_slots = slots(0);
-    for (int cand : {2, 1, 3}) if (slots(cand) >= best_slots && slots(cand) > 0) { best_slots = slots(cand); mode = cand; }
+    // measured per-iteration latency relative to "nothing in LDS" (profiles/r01_c5_batch_lds_modes.json
+    // and the sparse re-measurement): throughput ~ resident instances / latency
+    const double lat[4] = {1.0, 0.65, 0.53, 0.5};
+    int mode = 0;
+    double best = slots(0) / lat[0];
+    for (int cand : {1, 2, 3}) {
+      if (have_sparse && !sparse_big && (cand & 1)) continue;      // no separate "matrix" to place
+      const double sc = slots(cand) / lat[cand];
+      if (sc > best * 1.02) { best = sc; mode = cand; }
+    }
     if (const char* e = std::getenv("DNLP_BATCH_LDS")) {
       const int want = std::atoi(e);
       if (want >= 0 && want <= 3 && slots(want) > 0) mode = want;
     }
     a.lds_mode = mode;
-    a.lds_bytes = static_cast<unsigned>((mode & 1 ? kbytes : 0) + (mode & 2 ? vbytes : 0));
+    a.lds_stage_bytes = static_cast<unsigned>((stage_bytes + 63) & ~static_cast<size_t>(63));
+    a.lds_bytes = static_cast<unsigned>(a.lds_stage_bytes + (mode & 1 ? kbytes : 0) + (mode & 2 ? vbytes_lds : 0));
     // room for the dense matrix of an instance that falls back from the sparse path (global memory)
     const bool fb = have_sparse && n <= 512 && !force_sparse;
     a.fallback_max_n = fb ? 512 : 0;
     const size_t fbbytes = fb ? (((static_cast<size_t>(ld) * n + 256) * 8 + 2 * static_cast<size_t>(n) * 8 + 4096 + 63) & ~static_cast<size_t>(63)) : 0;
-    a.ws_per_block = 256 + (mode & 2 ? 0 : vbytes) + (mode & 1 ? 0 : kbytes) + fbbytes;
+    a.ws_per_block = 256 + vbytes + (mode & 1 ? 0 : kbytes) + fbbytes;
     DNLP_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(a.lds_bytes)));
     int per_cu = 1, ncu = 256;
     if (wave) DNLP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, batch_solve_kernel<64>, nthreads, a.lds_bytes));
