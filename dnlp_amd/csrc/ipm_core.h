@@ -715,10 +715,20 @@ class Ipm {
       int r2 = attempt(0.0, delta_c);
       if (r2 == 0) { delta_w = 0.0; return true; }
     }
+    const double dw_start = delta_w;
     for (int k = 0; k < 100; ++k) {
       int r2 = attempt(delta_w, delta_c);
       if (r2 == 0) { delta_w_last = delta_w; return true; }
       if (r2 == 2 && delta_c == 0.0) delta_c = dc_bar * std::pow(mu, kc);
+      // A rank-deficient Jacobian can show up as a persistently wrong inertia instead of an exact
+      // zero pivot (static pivots: the equality-row pivots shrink like a^2 / delta_w but never
+      // vanish).  Once delta_w has passed 1e20 without the right inertia the dual
+      // regularisation is switched on and delta_w starts over.
+      if (r2 == 1 && delta_c == 0.0 && delta_w > 1e20) {
+        delta_c = dc_bar * std::pow(mu, kc);
+        delta_w = dw_start;
+        continue;
+      }
       // with a certified lower bound in hand the trial is already in the right decade: grow gently
       if (have_lb && dw_lb > 0.0 && delta_w <= 64.0 * dw_lb) delta_w *= 2.0;
       else delta_w = (delta_w_last == 0.0) ? kwpb * delta_w : kwp * delta_w;

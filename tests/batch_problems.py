@@ -123,3 +123,42 @@ def template_path_planning(n=50):
         return np.concatenate([pv.reshape(-1, order="F"), rv ** 2])
 
     return prob, [p, r2], sample, x
+
+
+def template_power_flow():
+    """AC optimal power flow on the IEEE 9-bus case (examples/nlp_examples/power_flow.ipynb) with the
+    active / reactive loads of buses 4, 6, 8 as Parameters (the notebook fixes them through equal
+    lower and upper bounds; here they are equality rows so that they can vary per instance)."""
+    import dnlp_amd as cp
+    from paper_examples import ieee9_admittance
+    N = 9
+    gen, load = [0, 1, 2], [4, 6, 8]
+    p_min, p_max, q_min, q_max = np.zeros(N), np.zeros(N), np.zeros(N), np.zeros(N)
+    p_min[gen] = [10, 10, 10]
+    p_max[gen] = [250, 300, 270]
+    q_min[gen] = [-5, -5, -5]
+    p_min[load] = q_min[load] = -1e3          # loads are set by the equality rows below
+    G, B = ieee9_admittance()
+    Pl = cp.Parameter(3, name="Pload", value=np.array([54.0, 60.0, 75.0]))
+    Ql = cp.Parameter(3, name="Qload", value=np.array([18.0, 21.0, 30.0]))
+    theta, P, Q = cp.Variable((N, 1)), cp.Variable((N, N)), cp.Variable((N, N))
+    v = cp.Variable((N, 1), bounds=[0.9, 1.1])
+    p = cp.Variable(N, bounds=[p_min, p_max])
+    q = cp.Variable(N, bounds=[q_min, q_max])
+    C, S = cp.cos(theta - theta.T), cp.sin(theta - theta.T)
+    cons = [theta[0] == 0, p == cp.sum(P, axis=1), q == cp.sum(Q, axis=1),
+            p[load] == -Pl, q[load] == -Ql,
+            P == cp.multiply(v @ v.T, cp.multiply(G, C) + cp.multiply(B, S)),
+            Q == cp.multiply(v @ v.T, cp.multiply(G, S) - cp.multiply(B, C))]
+    cost = (0.11 * p[0] ** 2 + 5 * p[0] + 150 + 0.085 * p[1] ** 2 + 1.2 * p[1] + 600
+            + 0.1225 * p[2] ** 2 + p[2] + 335)
+    v.value = np.ones((N, 1))
+    theta.value = np.zeros((N, 1))
+    prob = cp.Problem(cp.Minimize(cost), cons)
+
+    def sample(i):
+        rng = np.random.default_rng(i)
+        scale = rng.uniform(0.8, 1.2, 3) if i else np.ones(3)
+        return np.concatenate([np.array([54.0, 60.0, 75.0]) * scale, np.array([18.0, 21.0, 30.0]) * scale])
+
+    return prob, [Pl, Ql], sample, p

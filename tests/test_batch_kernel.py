@@ -103,6 +103,25 @@ def test_batch_kernel_large_instances_four_wavefronts(gpu_required):
 
 
 @pytest.mark.gpu
+def test_power_flow_batch_base_case_is_the_published_optimum(gpu_required):
+    """9-bus OPF with the loads as parameters: instance 0 carries the notebook's loads and must reach
+    the published IPOPT objective (power_flow.ipynb:101); scaled-load instances match the oracle."""
+    prob, params, sample, p = bp.template_power_flow()
+    pb = ParametricBatch(prob, params)
+    assert pb.affine
+    thetas = np.stack([sample(i) for i in range(16)])
+    res = pb.solve(thetas, least_square_init_duals="no")
+    assert np.all(res.status == 0)
+    assert abs(res.obj_val[0] - 3.0878422284732592e+03) <= 1e-6 * 3.0878e3
+    mat = pb.data(thetas)
+    oi = _oracle(arrays_with_data(pb.arrays0, mat[5]), {"least_square_init_duals": "no"})
+    assert oi["status"] == 0 and abs(res.raw["obj_val"][5] - oi["obj_val"]) <= 1e-6 * abs(oi["obj_val"])
+    # heavier load -> higher generation cost
+    order = np.argsort(thetas[:, :3].sum(axis=1))
+    assert res.obj_val[order[-1]] > res.obj_val[order[0]]
+
+
+@pytest.mark.gpu
 def test_localization_batch_recovers_true_positions(gpu_required):
     """Noise-free ranges: the optimum is the true position (test_nlp_solvers.py:175-189 analogue)."""
     prob, params, sample, x = bp.template_localization()
