@@ -244,7 +244,10 @@ struct BatchRunner {
     const size_t vbytes_lds = (vdoubles_lds * 8 + 80 * 32 + 63) & ~static_cast<size_t>(63);
     // lanes per instance: one wavefront up to order 256 (factorisation and solves are
     // single-wavefront there, vectors are at most a few hundred long), four above
-    const bool wave = n <= 256 || have_sparse;
+    // sparse instances have no dense matrix to factor, so one wavefront suffices at any order;
+    // when the batch does not even fill the CUs, large instances get four wavefronts each instead
+    // (a one-off solve of order ~2000 is then ~3x faster)
+    const bool wave = n <= 256 || (have_sparse && !(n > 512 && batch <= 256));
     const void* kern = wave ? reinterpret_cast<const void*>(batch_solve_kernel<64>)
                             : reinterpret_cast<const void*>(batch_solve_kernel<256>);
     const int nthreads = wave ? 64 : 256;
