@@ -54,6 +54,7 @@ class CApi:
         f("ipm_step", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)])
         f("ipm_finish", C.c_int, [C.c_void_p] + [_dbl_p] * 6 + [C.POINTER(C.c_int)])
         f("eval_fused", C.c_int, [C.c_void_p, _dbl_p, _dbl_p, _dbl_p])
+        f("set_warm_start", C.c_int, [C.c_void_p, _dbl_p, _dbl_p, _dbl_p])
         f("kkt_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)])
         f("get_stats", C.c_int, [C.c_void_p, _dbl_p, C.c_int])
         f("get_log", C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t])
@@ -62,6 +63,7 @@ class CApi:
         if hasattr(self.lib, prefix + "solve_batch_timed"):      # product library only (no oracle batch path)
             _int_p = C.POINTER(C.c_int)
             f("batch_stride", C.c_int64, [C.c_void_p])
+            f("batch_warm_start", C.c_int, [C.c_void_p, C.c_int, _dbl_p, _dbl_p, _dbl_p])
             f("solve_batch_timed", C.c_int, [C.c_void_p, C.c_int, _dbl_p, C.c_int64] + [_dbl_p] * 5 +
               [_int_p] * 3 + [_dbl_p, _dbl_p])
 
@@ -235,6 +237,20 @@ class ProblemHandle:
             raise RuntimeError("time_fused failed: %s" % self.api.error())
         return float(sec.value)
 
+    def set_warm_start(self, mult_g, mult_x_L, mult_x_U):
+        """Multipliers of a previous solution for `warm_start_init_point=yes` (None clears them)."""
+        if mult_g is None:
+            self.api.set_warm_start(self.ptr, None, None, None)
+            return
+        mg = np.ascontiguousarray(mult_g, dtype=np.float64) if self.m else np.zeros(1)
+        zl = np.ascontiguousarray(mult_x_L, dtype=np.float64)
+        zu = np.ascontiguousarray(mult_x_U, dtype=np.float64)
+        if (self.m and mg.size != self.m) or zl.size != self.n or zu.size != self.n:
+            raise ValueError("warm-start multipliers have the wrong size")
+        rc = self.api.set_warm_start(self.ptr, _dp(mg), _dp(zl), _dp(zu))
+        if rc != 0:
+            raise RuntimeError("set_warm_start failed: %s" % self.api.error())
+
     def kkt_info(self):
         """Linear-solver plan of this handle: sparse static-pattern LDL^T or dense."""
         out = (C.c_int64 * 8)()
@@ -308,7 +324,7 @@ class ProblemHandle:
                                      C.byref(iters))
         return self._info(status, x, obj, g, mg, zl, zu, iters)
 
-    def solve_batch(self, data, want_duals: bool = False):
+    def solve_batch(self, data, want_duals: bool = False, warm=None):
         """Solve `data.shape[0]` instances that share this handle's tape structure in ONE kernel
         launch (one workgroup per instance, csrc/batch.h).  `data`: (B, stride) float64, rows laid
         out as dnlp_amd.batch.BATCH_DATA_KEYS.  Returns arrays over the batch."""
@@ -319,6 +335,12 @@ class ProblemHandle:
             raise RuntimeError("solve_batch: %s" % self.api.error())
         if stride != need:
             raise ValueError("solve_batch: rows have %d values, the tape needs %d" % (stride, need))
+        if warm is not None:
+            mg, wl, wu = (np.ascontiguousarray(a, dtype=np.float64) for a in warm)
+            if mg.shape != (B, self.m) or wl.shape != (B, self.n) or wu.shape != (B, self.n):
+                raise ValueError("solve_batch: warm-start multipliers must be (B, m), (B, N), (B, N)")
+            if self.api.batch_warm_start(self.ptr, B, _dp(mg if self.m else np.zeros(1)), _dp(wl), _dp(wu)) != 0:
+                raise RuntimeError("batch_warm_start failed: %s" % self.api.error())
         x = np.empty((B, self.n))
         obj = np.empty(B)
         mg = np.empty((B, max(self.m, 1))) if want_duals else None

@@ -207,20 +207,33 @@ class ParametricBatch:
         self._set(self.theta0)
         return np.stack(rows)
 
-    def solve(self, thetas, device=None, want_duals=False, **opts) -> BatchResult:
+    def solve(self, thetas, device=None, want_duals=False, warm_from=None, **opts) -> BatchResult:
         """One kernel launch for all rows of `thetas`.  The device handle (tape structure resident
-        in HBM) is created on first use and kept for later calls with the same device/options."""
+        in HBM) is created on first use and kept for later calls with the same device/options.
+
+        `warm_from`: a BatchResult of the same batch size solved with want_duals=True — every
+        instance then starts from that result's primal point and multipliers (IPOPT's
+        warm_start_init_point; pass mu_init small, e.g. 1e-6, as with IPOPT)."""
         import time as _t
         t0 = _t.time()
         mat = self.data(thetas)
         t1 = _t.time()
+        if warm_from is not None:
+            opts.setdefault("warm_start_init_point", "yes")
         key = (device, tuple(sorted((k, str(v)) for k, v in opts.items())))
         if getattr(self, "_handle_key", None) != key:
             self.close()
             self._handle = _device_handle(self.arrays0, self.data0["tape"], device, opts)
             self._handle_key = key
+        warm = None
+        if warm_from is not None:
+            if "mult_g" not in warm_from.raw:
+                raise ValueError("warm_from needs a result solved with want_duals=True")
+            o = len(self.d0) - sum(self.arrays0[k].size for k in ("x0", "lb", "ub", "cl", "cu"))
+            mat[:, o:o + warm_from.x.shape[1]] = warm_from.x          # the rows' x0 block
+            warm = (warm_from.raw["mult_g"], warm_from.raw["mult_x_L"], warm_from.raw["mult_x_U"])
         t2 = _t.time()
-        raw = self._handle.solve_batch(mat, want_duals=want_duals)
+        raw = self._handle.solve_batch(mat, want_duals=want_duals, warm=warm)
         t3 = _t.time()
         if os.environ.get("DNLP_BATCH_DEBUG"):
             print("[batch.py] data %.4f handle %.4f solve_batch %.4f" % (t1 - t0, t2 - t1, t3 - t2), flush=True)

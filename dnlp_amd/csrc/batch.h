@@ -42,6 +42,7 @@ struct BatchArgs {
   SparsePlan sp;                 // static-pattern sparse KKT plan (shared by all instances)
   int use_sparse = 0;
   i64 fallback_max_n = 0;        // sparse instances up to this order may switch to in-kernel Bunch-Kaufman
+  const double *ws_g = nullptr, *ws_l = nullptr, *ws_u = nullptr;   // per-instance warm-start multipliers (batch-major) or null
   int* next = nullptr;           // work queue head: instances are claimed dynamically (iteration counts vary 10x)
 };
 
@@ -102,6 +103,11 @@ __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
     }
     IpmT* ipm = new (o.ipm) IpmT(ex, md, kkt);
     ipm->opt = a.opt;
+    if (a.ws_g) {
+      ipm->ws_mult_g = a.ws_g + static_cast<i64>(inst) * t.m;
+      ipm->ws_mult_xL = a.ws_l + static_cast<i64>(inst) * t.N;
+      ipm->ws_mult_xU = a.ws_u + static_cast<i64>(inst) * t.N;
+    }
     ipm->allocate();
     int st = Internal_Error;
     if (!ex->overflow) {
@@ -136,12 +142,20 @@ struct BatchRunner {
   i64 in_stride = 0;
   int last_grid = 0, last_threads = 0, last_lds_mode = 0, last_per_cu = 0;   // launch plan of the last solve
   bool have_sparse = false, force_sparse = false;
+  // warm-start multipliers for the NEXT solve (consumed by it)
+  std::vector<double> h_ws_g, h_ws_l, h_ws_u;
+  int ws_batch = 0;
+  void set_warm_start(int batch, const double* mg, const double* mxl, const double* mxu) {
+    const size_t m = static_cast<size_t>(tape->m), N = static_cast<size_t>(tape->N), B = static_cast<size_t>(batch);
+    h_ws_g.assign(mg, mg + B * m); h_ws_l.assign(mxl, mxl + B * N); h_ws_u.assign(mxu, mxu + B * N);
+    ws_batch = batch;
+  }
   SparsePlan dev_plan;
   void set_sparse_plan(const SparsePlanHost& hp) { dev_plan = hp.upload(ex); have_sparse = true; }
   // device buffers kept across calls (grow-only): a call is then one H2D copy, one launch and the
   // result copies — no allocation on the steady-state path
   struct Buf { void* p = nullptr; size_t cap = 0; };
-  Buf bufs[12];
+  Buf bufs[16];
   int nbuf_used = 0;
   int ncu = 0;
   std::vector<double> slab;
@@ -316,6 +330,16 @@ struct BatchRunner {
     a.iters_out = dalloc<int>(static_cast<size_t>(batch));
     a.nfact_out = dalloc<int>(static_cast<size_t>(batch));
     a.times_out = times_out ? dalloc<double>(4 * static_cast<size_t>(batch)) : nullptr;
+    if (ws_batch == batch && opt.warm_start) {
+      double* g = dalloc<double>(h_ws_g.size());
+      double* l = dalloc<double>(h_ws_l.size());
+      double* u = dalloc<double>(h_ws_u.size());
+      if (!h_ws_g.empty()) DNLP_HIP_CHECK(hipMemcpy(g, h_ws_g.data(), h_ws_g.size() * 8, hipMemcpyHostToDevice));
+      DNLP_HIP_CHECK(hipMemcpy(l, h_ws_l.data(), h_ws_l.size() * 8, hipMemcpyHostToDevice));
+      DNLP_HIP_CHECK(hipMemcpy(u, h_ws_u.data(), h_ws_u.size() * 8, hipMemcpyHostToDevice));
+      a.ws_g = g; a.ws_l = l; a.ws_u = u;
+    }
+    ws_batch = 0;
     a.next = dalloc<int>(1);
     DNLP_HIP_CHECK(hipMemsetAsync(a.next, 0, sizeof(int), ex->stream));
     mark("plan + buffers");

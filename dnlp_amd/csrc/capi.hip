@@ -35,6 +35,11 @@ int64_t dnlp_batch_stride(void* vp) {
   auto* p = static_cast<dnlp_problem_t*>(vp);
   DNLP_TRY(return batch_runner(p)->in_stride;)
 }
+/* per-instance multipliers (batch-major) for the next dnlp_solve_batch with warm_start_init_point=yes */
+int dnlp_batch_warm_start(void* vp, int batch, const double* mult_g, const double* mult_x_L, const double* mult_x_U) {
+  auto* p = static_cast<dnlp_problem_t*>(vp);
+  DNLP_TRY(batch_runner(p)->set_warm_start(batch, mult_g, mult_x_L, mult_x_U); return 0;)
+}
 int dnlp_solve_batch(void* vp, int batch, const double* data, int64_t stride, double* x, double* obj, double* mult_g,
                      double* mult_x_L, double* mult_x_U, int* status, int* iters, int* factorizations, double* seconds) {
   return dnlp_solve_batch_timed(vp, batch, data, stride, x, obj, mult_g, mult_x_L, mult_x_U, status, iters, factorizations,

@@ -34,6 +34,8 @@ struct ProblemT {
   i64 pivot_max_n = 2048;
   double *dx = nullptr, *dlam = nullptr, *dg = nullptr, *dgrad = nullptr, *djac = nullptr, *dh = nullptr;
   bool swept = false, kkt_ready = false, time_kernels = false;
+  double *ws_g = nullptr, *ws_l = nullptr, *ws_u = nullptr;     // warm-start multipliers (exec space)
+  double *ws_buf_g = nullptr, *ws_buf_l = nullptr, *ws_buf_u = nullptr;
   int linear_solver = 0;            // 0 auto, 1 dense, 2 sparse (static-pattern LDL^T)
   SparsePlanHost sparse_plan;
   bool sparse_planned = false, use_sparse = false;
@@ -108,6 +110,7 @@ struct ProblemT {
     kkt.lw.time_updates = time_kernels;
     if (!ipm) ipm.reset(new Ipm<E, DenseKkt<E>>(&ex, &model, &kkt));
     ipm->opt = opt;
+    ipm->ws_mult_g = ws_g; ipm->ws_mult_xL = ws_l; ipm->ws_mult_xU = ws_u;
   }
 
   int set_option(const std::string& k, const std::string& v) {
@@ -144,6 +147,10 @@ struct ProblemT {
     else if (k == "max_soc") opt.max_soc = static_cast<int>(num());
     else if (k == "constr_mult_init_max") opt.constr_mult_init_max = num();
     else if (k == "bound_mult_init_val") opt.bound_mult_init_val = num();
+    else if (k == "warm_start_init_point") opt.warm_start = yes() ? 1 : 0;
+    else if (k == "warm_start_bound_push") opt.warm_start_bound_push = num();
+    else if (k == "warm_start_bound_frac") opt.warm_start_bound_frac = num();
+    else if (k == "warm_start_mult_bound_push") opt.warm_start_mult_bound_push = num();
     else if (k == "kkt_pivot_max_n") pivot_max_n = static_cast<i64>(num());
     else if (k == "restoration") opt.restoration = yes() ? 1 : 0;
     else if (k == "time_kernels") time_kernels = yes();
@@ -298,6 +305,15 @@ struct ProblemT {
              double* dxf = p->ex.template alloc<double>(nf); double* dgf = p->ex.template alloc<double>(nf); \
              p->ex.h2d(dxf, xfree, 8 * nf); *f = p->fused.eval(dxf, dgf); p->ex.d2h(grad, dgf, 8 * nf); \
              p->ex.release(dxf); p->ex.release(dgf); return 0;)                                      \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, set_warm_start)(void* vp, const double* mg, const double* mxl, const double* mxu) { \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    DNLP_TRY(const size_t N = static_cast<size_t>(p->model.t.N), m = static_cast<size_t>(p->model.t.m); \
+             if (!mg || !mxl || !mxu) { p->ws_g = p->ws_l = p->ws_u = nullptr; return 0; }            \
+             if (!p->ws_buf_g) { p->ws_buf_g = p->ex.template alloc<double>(m ? m : 1);               \
+               p->ws_buf_l = p->ex.template alloc<double>(N); p->ws_buf_u = p->ex.template alloc<double>(N); } \
+             p->ex.h2d(p->ws_buf_g, mg, 8 * m); p->ex.h2d(p->ws_buf_l, mxl, 8 * N); p->ex.h2d(p->ws_buf_u, mxu, 8 * N); \
+             p->ws_g = p->ws_buf_g; p->ws_l = p->ws_buf_l; p->ws_u = p->ws_buf_u; return 0;)            \
   }                                                                                                  \
   int DNLP_CAT(PFX, kkt_info)(void* vp, int64_t* out) {                                               \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \

@@ -53,6 +53,10 @@ struct IpmOptions {
   int adaptive_fallback = 1;
   int lanczos_inertia_bound = 1;
   int lanczos_min_n = 12000;
+  // IPOPT's warm start (warm_start_init_point = yes): start from given primal AND dual values,
+  // pushed only slightly into the interior
+  int warm_start = 0;
+  double warm_start_bound_push = 1e-3, warm_start_bound_frac = 1e-3, warm_start_mult_bound_push = 1e-3;
 };
 
 struct IpmStats {
@@ -121,6 +125,8 @@ class Ipm {
   double f = 0.0;                     // scaled objective at x
   double mu = 0.1, tau = 0.99;
   double delta_w_last = 0.0;
+  // warm-start multipliers in the user's (unscaled) units, exec space; null = not provided
+  const double *ws_mult_g = nullptr, *ws_mult_xL = nullptr, *ws_mult_xU = nullptr;
   bool initialized = false;
   int status = Internal_Error;
   int iter = 0;
@@ -219,7 +225,8 @@ class Ipm {
     if (!x) allocate();
     const TapeView& T = md_->t;
     const double inf = opt.nlp_inf, brf = opt.bound_relax_factor;
-    const double k1 = opt.bound_push, k2 = opt.bound_frac;
+    const bool warm = opt.warm_start != 0 && ws_mult_g != nullptr && ws_mult_xL != nullptr && ws_mult_xU != nullptr;
+    const double k1 = warm ? opt.warm_start_bound_push : opt.bound_push, k2 = warm ? opt.warm_start_bound_frac : opt.bound_frac;
     const i64 NN = N;
     // variable bounds: optional relaxation (IPOPT bound_relax_factor; the reference sets it to 0),
     // |bound| >= nlp_inf means "no bound"
@@ -324,7 +331,27 @@ class Ipm {
     mu = opt.mu_init;
     tau = std::max(0.99, 1.0 - mu);
     ex_->zero(y, sizeof(double) * static_cast<size_t>(m));
-    if (m > 0 && opt.least_square_init_duals >= 0) init_multipliers_ls();
+    if (warm) {
+      // given multipliers -> scaled problem: y~ = y sf / sg, z~ = z sf; bound multipliers of the
+      // inequality slacks from the sign convention  -y - vL + vU = 0; all kept >= mult_bound_push
+      const double sff = sf, mp = opt.warm_start_mult_bound_push;
+      const double *wy = ws_mult_g, *wl = ws_mult_xL, *wu = ws_mult_xU, *sgp = sg;
+      const double *l = xL, *u = xU, *sl = sL, *su = sU, *eq = eqmask;
+      double *yy = y, *a = zL, *b = zU, *c = vL, *d = vU;
+      ex_->map(m, [=] DNLP_HD(i64 i) {
+        const double yi = wy[i] * sff / sgp[i];
+        yy[i] = yi;
+        const bool in = eq[i] == 0.0;
+        c[i] = (in && sl[i] > -kInf) ? fmax(-yi, mp) : 0.0;
+        d[i] = (in && su[i] < kInf) ? fmax(yi, mp) : 0.0;
+      });
+      ex_->map(N, [=] DNLP_HD(i64 j) {
+        a[j] = (l[j] > -kInf) ? fmax(wl[j] * sff, mp) : 0.0;
+        b[j] = (u[j] < kInf) ? fmax(wu[j] * sff, mp) : 0.0;
+      });
+    } else if (m > 0 && opt.least_square_init_duals >= 0) {
+      init_multipliers_ls();
+    }
     filter_clear();
     double th0 = theta_at(g, s);
     theta_max = 1e4 * std::max(1.0, th0);

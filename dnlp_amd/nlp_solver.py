@@ -267,12 +267,23 @@ class HIPNLP:
                 raise ValueError("algorithm='lbfgs' needs an unconstrained smooth problem whose "
                                  "canonical constraints only define auxiliary variables")
             info = handle.solve_reduced(data["x0"])
+        elif data.get("warm_duals") is not None and str(options.get("warm_start_init_point", "no")) in ("yes", "True", "1") \
+                and not self._use_device_loop(data, options, device_loop):
+            handle.set_warm_start(*data["warm_duals"])
+            info = handle.solve(data["x0"])
+            handle.set_warm_start(None, None, None)
         elif self._use_device_loop(data, options, device_loop):
             # Small problem, nothing to print: the whole interior-point loop runs inside one kernel
             # (the batch path with a batch of one, csrc/batch.h) instead of being driven from the
             # host with a stream synchronisation per scalar.  Same algorithm text, same result.
             from .batch import instance_data
-            raw = handle.solve_batch(instance_data(data["tape_arrays"])[None, :], want_duals=True)
+            row = instance_data(data["tape_arrays"])
+            o = row.size - sum(data["tape_arrays"][k].size for k in ("x0", "lb", "ub", "cl", "cu"))
+            row[o:o + len(data["x0"])] = data["x0"]                     # a warm start replaces x0
+            wd = data.get("warm_duals")
+            warm = tuple(np.asarray(a, dtype=float)[None, :] for a in wd) \
+                if wd is not None and str(options.get("warm_start_init_point", "no")) in ("yes", "True", "1") else None
+            raw = handle.solve_batch(row[None, :], want_duals=True, warm=warm)
             info = {"status": int(raw["status"][0]), "x": raw["x"][0], "obj_val": float(raw["obj_val"][0]),
                     "g": np.zeros(handle.m), "mult_g": raw["mult_g"][0], "mult_x_L": raw["mult_x_L"][0],
                     "mult_x_U": raw["mult_x_U"][0], "iterations": int(raw["iterations"][0]),

@@ -177,8 +177,18 @@ class Problem:
             raise ValueError("best_of must be a positive integer.")
         if best_of == 1:
             canon_problem, inverse_data = chain.apply(self)
+            # Dual warm start (IPOPT warm_start_init_point=yes; the reference accepts `warm_start` and
+            # drops it, ipopt_nlpif.py:126-127): the previous solve's canonical point and multipliers
+            # are reused when the canonical dimensions are unchanged.
+            prev = getattr(self, "_nlp_last", None)
+            if str(kwargs.get("warm_start_init_point", "no")) in ("yes", "True", "1") and prev is not None \
+                    and prev["x"].size == len(canon_problem["x0"]) and prev["mult_g"].size == len(canon_problem["cl"]):
+                canon_problem["x0"] = prev["x"]
+                canon_problem["warm_duals"] = (prev["mult_g"], prev["mult_x_L"], prev["mult_x_U"])
             solution = chain.solver.solve_via_data(canon_problem, warm_start, verbose,
                                                    solver_opts=kwargs)
+            if "mult_g" in solution:
+                self._nlp_last = {k: np.array(solution[k], dtype=float) for k in ("x", "mult_g", "mult_x_L", "mult_x_U")}
             self.unpack_results(solution, chain, inverse_data)
             return self.value
         best_obj, best_solution, all_objs = float("inf"), None, np.zeros(best_of)

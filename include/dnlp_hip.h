@@ -100,6 +100,11 @@ int64_t dnlp_batch_stride(dnlp_problem* p);
 int dnlp_solve_batch(dnlp_problem* p, int batch, const double* data, int64_t stride, double* x,
                      double* obj, double* mult_g, double* mult_x_L, double* mult_x_U, int* status,
                      int* iters, int* factorizations, double* kernel_seconds);
+/* Per-instance multipliers (batch-major: batch x m, batch x N, batch x N) consumed by the next
+ * dnlp_solve_batch when the option warm_start_init_point=yes is set (the rows' x0 carry the primal
+ * start). */
+int dnlp_batch_warm_start(dnlp_problem* p, int batch, const double* mult_g, const double* mult_x_L,
+                          const double* mult_x_U);
 /* Same, plus per-instance phase times on the device clock:
  * times[4*i + 0..3] = whole solve, tape evaluations, KKT factorisations, KKT solves (seconds). */
 int dnlp_solve_batch_timed(dnlp_problem* p, int batch, const double* data, int64_t stride, double* x,
@@ -114,6 +119,13 @@ int dnlp_solve_batch_timed(dnlp_problem* p, int batch, const double* data, int64
 int dnlp_eval_fused(dnlp_problem* p, const double* xfree, double* f, double* grad);
 /* Average seconds of one fused evaluation with x resident in HBM (HIP events, `reps` evaluations). */
 int dnlp_time_fused(dnlp_problem* p, const double* xfree, int reps, double* seconds);
+/* Dual warm start (IPOPT `warm_start_init_point`; SURVEY.md 8f-4.  The reference accepts
+ * `warm_start` and ignores it, ipopt_nlpif.py:126-127): with the option
+ * `warm_start_init_point=yes`, the next dnlp_solve / dnlp_ipm_begin starts from x_inout AND these
+ * multipliers (user units, as dnlp_solve returns them), pushed into the interior by
+ * warm_start_bound_push / _bound_frac / _mult_bound_push (default 1e-3); no least-squares
+ * multiplier estimate is computed.  NULL pointers clear the stored multipliers. */
+int dnlp_set_warm_start(dnlp_problem* p, const double* mult_g, const double* mult_x_L, const double* mult_x_U);
 /* Linear-solver plan of the handle (decided once, from the sparsity pattern of the tape):
  * out[0] = 1 static-pattern sparse LDL^T / 0 dense, out[1] = factor values, out[2] = pivot blocks,
  * out[3] = largest block struct, out[4] = static 2x2 pivot pairs, out[5] = update triples,
