@@ -72,6 +72,48 @@ def test_dense_patterns_keep_the_dense_path():
     assert not OracleProblem(serialize(data["tape_arrays"])).kkt_info()["sparse"]
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_small_nlps_sparse_equals_dense(seed):
+    """Random sparse NLPs (smooth objective, sparse equalities, bounds, a quadratic inequality, an
+    abs-epigraph): the static-pivot sparse factorisation — forced, i.e. without the Bunch-Kaufman
+    fallback — and the dense path reach the same optimum."""
+    import dnlp_amd as cp
+    from dnlp_amd.dnlp2smooth import Dnlp2Smooth
+    from dnlp_amd.nlp_solver import HIPNLP, build_nlp_data
+    from dnlp_amd.tape import serialize
+    from oracle.oracle_capi import OracleProblem
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(3, 30))
+    k = int(rng.integers(0, max(1, n // 2)))
+    kind = seed % 4
+    x = cp.Variable(n)
+    c = rng.standard_normal(n)
+    obj = (cp.sum_squares(x - c) + 0.1 * cp.sum(cp.exp(0.3 * x))) if kind != 2 \
+        else (cp.sum(cp.logistic(x)) + 0.05 * cp.sum_squares(x))
+    cons = []
+    if k > 0:
+        A = rng.standard_normal((k, n)) * (rng.random((k, n)) < 0.4)
+        A[np.arange(k), rng.integers(0, n, k)] += 1.0
+        cons.append(A @ x == A @ rng.standard_normal(n))
+    if kind in (1, 3):
+        cons += [x >= -1.0, cp.sum(cp.square(x)) <= 2.0 * n]
+    if kind == 3:
+        cons.append(cp.sum(cp.abs(x)) <= 0.8 * n)
+    smooth, _ = Dnlp2Smooth().apply(cp.Problem(cp.Minimize(obj), cons))
+    data, _ = build_nlp_data(smooth)
+    out = {}
+    for ls in ("sparse", "dense"):
+        o = OracleProblem(serialize(data["tape_arrays"]))
+        for kk, v in HIPNLP.DEFAULT_OPTIONS.items():
+            o.set_option(kk, v)
+        o.set_option("linear_solver", ls)
+        out[ls] = o.solve(data["x0"])
+    s_, d_ = out["sparse"], out["dense"]
+    assert s_["status"] == d_["status"] == 0
+    assert abs(s_["obj_val"] - d_["obj_val"]) <= 1e-6 * max(1.0, abs(d_["obj_val"]))
+    np.testing.assert_allclose(s_["x"], d_["x"], rtol=1e-4, atol=1e-5)
+
+
 def _device_solve(name, linear_solver, device_loop):
     import dnlp_amd as cp
     from paper_examples import PAPER, PUBLISHED
