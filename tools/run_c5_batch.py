@@ -51,6 +51,7 @@ from dnlp_amd.batch import gather_rows, shard_bounds  # noqa: E402
 rows = []
 for which in args.which.split(","):
     tmpl = {"localization": bp.template_localization, "circle_packing": bp.template_circle_packing,
+            "circle_packing10": lambda: bp.template_circle_packing(10),
             "path_planning": bp.template_path_planning, "power_flow": bp.template_power_flow}[which]
     prob, params, sample, var = tmpl()
     t0 = time.time()
