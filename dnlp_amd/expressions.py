@@ -8,8 +8,8 @@ numeric forward values (F-order everywhere) and the tree structure that
 `dnlp_amd.dnlp2smooth` rewrites and `dnlp_amd.lowering` flattens into the device tape.
 
 Derivatives are NOT computed on these objects at solve time; they are lowered once to the
-device tape (see lowering.py).  The per-call numeric `jacobian()/hess_vec()` protocol of the
-reference lives in `oracle/tree_oracle.py` as test infrastructure.
+device tape (see lowering.py); the tape's numpy restatement used by the tests is
+`oracle/tape_eval.py` (test infrastructure, never imported from this package).
 """
 from __future__ import annotations
 
