@@ -560,6 +560,14 @@ __global__ void __launch_bounds__(kBlock) vt_dot_kernel(int k, const double* __r
   }
 }
 // w[i] -= sum_q c[q] V[q*N + i]
+__global__ void __launch_bounds__(kBlock) v_comb_kernel(int k, const double* __restrict__ V, i64 N,
+                                                        const double* __restrict__ c, double* __restrict__ out) {
+  const i64 i = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= N) return;
+  double s = 0.0;
+  for (int q = 0; q < k; ++q) s += c[q] * V[static_cast<i64>(q) * N + i];
+  out[i] = s;
+}
 __global__ void __launch_bounds__(kBlock) v_axpy_kernel(int k, const double* __restrict__ V, i64 N,
                                                         const double* __restrict__ c, double* __restrict__ w) {
   const i64 i = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
@@ -797,6 +805,26 @@ struct HipExec : HostControlled {
     DNLP_LAUNCH_CHECK();
   }
   // Gram-Schmidt step against k stored vectors: c = V^T w (returned on the host), w -= V c
+  // c = V^T w (k <= 32 vectors, one fused pass over w and V, one scalar read-back)
+  void vt_dot(int k, const double* V, i64 N, const double* w, double* c_host) {
+    if (k <= 0) return;
+    double* dc = d_partial;
+    DNLP_HIP_CHECK(hipMemsetAsync(dc, 0, sizeof(double) * 32, stream));
+    i64 grid = (N + kBlock - 1) / kBlock;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(vt_dot_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, k, V, N, w, dc);
+    DNLP_HIP_CHECK(hipMemcpyAsync(c_host, dc, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
+    DNLP_HIP_CHECK(hipStreamSynchronize(stream));
+    DNLP_LAUNCH_CHECK();
+  }
+  // out = sum_q c_q V_q (coefficients from the host, no read-back)
+  void v_comb(int k, const double* V, i64 N, const double* c_host, double* out) {
+    double* dc = d_partial + 64;
+    DNLP_HIP_CHECK(hipMemcpyAsync(dc, c_host, sizeof(double) * k, hipMemcpyHostToDevice, stream));
+    DNLP_HIP_CHECK(hipStreamSynchronize(stream));      // c_host is pageable and may be reused by the caller
+    hipLaunchKernelGGL(v_comb_kernel, dim3(static_cast<unsigned>((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, k, V, N, dc, out);
+    DNLP_LAUNCH_CHECK();
+  }
   void orthogonalize(int k, const double* V, i64 N, double* w, double* c_host) {
     if (k <= 0) return;
     double* dc = d_partial;      // k <= 32 doubles of the reduction scratch

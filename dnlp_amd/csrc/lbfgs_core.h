@@ -41,7 +41,7 @@ class ReducedLbfgs {
 
   // canonical full vector x (N); g (m); grad (N); jv (nnzJ); lam (m); jt (N)
   double *x = nullptr, *g = nullptr, *grad = nullptr, *jv = nullptr, *lam = nullptr, *jt = nullptr;
-  double *xf = nullptr, *gf = nullptr, *xt = nullptr, *gt = nullptr, *dir = nullptr, *S = nullptr, *Y = nullptr;
+  double *xf = nullptr, *gf = nullptr, *xt = nullptr, *gt = nullptr, *dir = nullptr, *BV = nullptr;
 
   template <class T> T* A(i64 n) { return ex_->template alloc<T>(static_cast<size_t>(n > 0 ? n : 1)); }
 
@@ -97,7 +97,7 @@ class ReducedLbfgs {
     if (!x) {
       x = A<double>(N); g = A<double>(m); grad = A<double>(N); jv = A<double>(t.nnzJ); lam = A<double>(m);
       jt = A<double>(N); xf = A<double>(nf); gf = A<double>(nf); xt = A<double>(nf); gt = A<double>(nf);
-      dir = A<double>(nf); S = A<double>(static_cast<i64>(history) * nf); Y = A<double>(static_cast<i64>(history) * nf);
+      dir = A<double>(nf);
     }
     ex_->h2d(x, x0_host, sizeof(double) * static_cast<size_t>(N));
     {
@@ -106,15 +106,33 @@ class ReducedLbfgs {
       const double* xx = x;
       ex_->map(nf, [=] DNLP_HD(i64 k) { a[k] = xx[fi[k]]; });
     }
+    // Vector-free form of the two-loop recursion (Chen, Wang, Zhou: "Large-scale L-BFGS using
+    // MapReduce", 2014): the basis B = [s_0..s_{M-1}, y_0..y_{M-1}, g] lives in one contiguous
+    // buffer, its Gram matrix on the host.  Per iteration THREE fused multi-dot kernels (new s, new
+    // y, new g against the whole basis: one scalar read-back each) replace the ~4M dependent
+    // reductions of the textbook loop, the recursion runs on 2M+1 coefficients on the host, and the
+    // direction is one fused linear combination.  Same mathematics, a handful of host round trips.
+    const int M = history < 1 ? 1 : (history > 15 ? 15 : history);
+    const int nb = 2 * M + 1, GR = 2 * M;              // GR: row of the current gradient
+    if (!BV) BV = A<double>(static_cast<i64>(nb) * nf);
+    ex_->zero(BV, sizeof(double) * static_cast<size_t>(nb) * static_cast<size_t>(nf));
+    auto row = [&](int r) { return BV + static_cast<i64>(r) * nf; };
+    std::vector<double> G(static_cast<size_t>(nb) * nb, 0.0), coef(static_cast<size_t>(nb)), tmp(static_cast<size_t>(nb));
+    std::vector<double> rho(static_cast<size_t>(M), 0.0), alpha(static_cast<size_t>(M), 0.0);
+    auto gram_row = [&](int r) {
+      ex_->vt_dot(nb, BV, nf, row(r), tmp.data());
+      for (int j = 0; j < nb; ++j) G[static_cast<size_t>(r) * nb + j] = G[static_cast<size_t>(j) * nb + r] = tmp[static_cast<size_t>(j)];
+    };
     double f = 0.0;
     if (!eval(xf, f, gf)) return -13;
-    std::vector<double> rho(static_cast<size_t>(history), 0.0), alpha(static_cast<size_t>(history), 0.0);
+    ex_->d2d(row(GR), gf, sizeof(double) * static_cast<size_t>(nf));
+    gram_row(GR);
     int stored = 0, head = 0;
     iterations = 0;
     int status = -1;
     char buf[160];
     for (int it = 0; it < max_iter; ++it) {
-      const double* gp = gf;
+      const double* gp = row(GR);
       const double gn = ex_->max(nf, [=] DNLP_HD(i64 k) { return fabs(gp[k]); });
       gnorm_final = gn;
       f_final = f;
@@ -123,38 +141,36 @@ class ReducedLbfgs {
         log_lines.emplace_back(buf);
       }
       if (gn <= tol * std::fmax(1.0, std::fabs(f))) { status = 0; break; }
-      // two-loop recursion: dir = -H grad
-      double* d = dir;
-      ex_->map(nf, [=] DNLP_HD(i64 k) { d[k] = gp[k]; });
+      // two-loop recursion on the coefficients of q in the basis
+      auto Gd = [&](int r, const std::vector<double>& c) { double v = 0.0; for (int j = 0; j < nb; ++j) v += c[static_cast<size_t>(j)] * G[static_cast<size_t>(r) * nb + j]; return v; };
+      std::fill(coef.begin(), coef.end(), 0.0);
+      coef[static_cast<size_t>(GR)] = 1.0;
       for (int j = 0; j < stored; ++j) {
-        const int idx = (head - 1 - j + 2 * history) % history;
-        const double *sj = S + static_cast<i64>(idx) * nf, *yj = Y + static_cast<i64>(idx) * nf;
-        const double a = rho[idx] * ex_->sum(nf, [=] DNLP_HD(i64 k) { return sj[k] * d[k]; });
-        alpha[idx] = a;
-        ex_->map(nf, [=] DNLP_HD(i64 k) { d[k] -= a * yj[k]; });
+        const int idx = (head - 1 - j + 2 * M) % M;
+        const double a = rho[static_cast<size_t>(idx)] * Gd(idx, coef);
+        alpha[static_cast<size_t>(idx)] = a;
+        coef[static_cast<size_t>(M + idx)] -= a;
       }
       if (stored > 0) {
-        const int idx = (head - 1 + history) % history;
-        const double *sj = S + static_cast<i64>(idx) * nf, *yj = Y + static_cast<i64>(idx) * nf;
-        const double sy = ex_->sum(nf, [=] DNLP_HD(i64 k) { return sj[k] * yj[k]; });
-        const double yy = ex_->sum(nf, [=] DNLP_HD(i64 k) { return yj[k] * yj[k]; });
-        const double gam = sy / yy;
-        ex_->map(nf, [=] DNLP_HD(i64 k) { d[k] *= gam; });
+        const int idx = (head - 1 + M) % M;
+        const double gam = G[static_cast<size_t>(idx) * nb + (M + idx)] / G[static_cast<size_t>(M + idx) * nb + (M + idx)];
+        for (double& c : coef) c *= gam;
       }
       for (int j = stored - 1; j >= 0; --j) {
-        const int idx = (head - 1 - j + 2 * history) % history;
-        const double *sj = S + static_cast<i64>(idx) * nf, *yj = Y + static_cast<i64>(idx) * nf;
-        const double b = rho[idx] * ex_->sum(nf, [=] DNLP_HD(i64 k) { return yj[k] * d[k]; });
-        const double a = alpha[idx];
-        ex_->map(nf, [=] DNLP_HD(i64 k) { d[k] += (a - b) * sj[k]; });
+        const int idx = (head - 1 - j + 2 * M) % M;
+        const double bta = rho[static_cast<size_t>(idx)] * Gd(M + idx, coef);
+        coef[static_cast<size_t>(idx)] += alpha[static_cast<size_t>(idx)] - bta;
       }
-      ex_->map(nf, [=] DNLP_HD(i64 k) { d[k] = -d[k]; });
-      double gd = ex_->sum(nf, [=] DNLP_HD(i64 k) { return gp[k] * d[k]; });
+      for (double& c : coef) c = -c;
+      double gd = Gd(GR, coef);
       if (!(gd < 0.0)) {   // not a descent direction: restart from steepest descent
         stored = 0;
-        ex_->map(nf, [=] DNLP_HD(i64 k) { d[k] = -gp[k]; });
-        gd = -ex_->sum(nf, [=] DNLP_HD(i64 k) { return gp[k] * gp[k]; });
+        std::fill(coef.begin(), coef.end(), 0.0);
+        coef[static_cast<size_t>(GR)] = -1.0;
+        gd = -G[static_cast<size_t>(GR) * nb + GR];
       }
+      double* d = dir;
+      ex_->v_comb(nb, BV, nf, coef.data(), dir);
       // Armijo backtracking (first iteration starts at 1/|g|)
       double step = (it == 0 && stored == 0) ? std::fmin(1.0, 1.0 / std::fmax(gn, 1e-300)) : 1.0;
       double fn = 0.0;
@@ -168,24 +184,28 @@ class ReducedLbfgs {
         step *= 0.5;
       }
       if (!ok) { status = 3; break; }
-      // history update
-      double* sn = S + static_cast<i64>(head) * nf;
-      double* yn = Y + static_cast<i64>(head) * nf;
+      // history update: s, y into slot `head`, the new gradient into the g row, three Gram rows
+      double* sn = row(head);
+      double* yn = row(M + head);
+      double* gr = row(GR);
       const double *xn = xt, *xc = xf, *gnew = gt;
-      ex_->map(nf, [=] DNLP_HD(i64 k) { sn[k] = xn[k] - xc[k]; yn[k] = gnew[k] - gp[k]; });
-      const double sy = ex_->sum(nf, [=] DNLP_HD(i64 k) { return sn[k] * yn[k]; });
-      const double ss = ex_->sum(nf, [=] DNLP_HD(i64 k) { return sn[k] * sn[k]; });
-      const double yy = ex_->sum(nf, [=] DNLP_HD(i64 k) { return yn[k] * yn[k]; });
+      ex_->map(nf, [=] DNLP_HD(i64 k) { sn[k] = xn[k] - xc[k]; yn[k] = gnew[k] - gr[k]; });
+      ex_->d2d(gr, gt, sizeof(double) * static_cast<size_t>(nf));
+      gram_row(head);
+      gram_row(M + head);
+      gram_row(GR);
+      const double sy = G[static_cast<size_t>(head) * nb + (M + head)];
+      const double ss = G[static_cast<size_t>(head) * nb + head], yy = G[static_cast<size_t>(M + head) * nb + (M + head)];
       if (sy > 1e-10 * std::sqrt(ss) * std::sqrt(yy)) {
-        rho[head] = 1.0 / sy;
-        head = (head + 1) % history;
-        if (stored < history) ++stored;
+        rho[static_cast<size_t>(head)] = 1.0 / sy;
+        head = (head + 1) % M;
+        if (stored < M) ++stored;
       }
       ex_->d2d(xf, xt, sizeof(double) * static_cast<size_t>(nf));
-      ex_->d2d(gf, gt, sizeof(double) * static_cast<size_t>(nf));
       f = fn;
       iterations = it + 1;
     }
+    ex_->d2d(gf, row(GR), sizeof(double) * static_cast<size_t>(nf));
     // leave the canonical vector consistent with the final free variables (tape pass: it also
     // fills the auxiliary variables the fused evaluator never forms)
     double fl;

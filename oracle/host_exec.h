@@ -79,6 +79,21 @@ struct HostExec : HostControlled {
     return f;
   }
 
+  // c = V^T w for k stored vectors; out = sum_q c_q V_q
+  void vt_dot(int k, const double* V, i64 N, const double* w, double* c_host) {
+    for (int q = 0; q < k; ++q) {
+      double s = 0.0;
+      for (i64 i = 0; i < N; ++i) s += V[static_cast<i64>(q) * N + i] * w[i];
+      c_host[q] = s;
+    }
+  }
+  void v_comb(int k, const double* V, i64 N, const double* c_host, double* out) {
+    for (i64 i = 0; i < N; ++i) {
+      double s = 0.0;
+      for (int q = 0; q < k; ++q) s += c_host[q] * V[static_cast<i64>(q) * N + i];
+      out[i] = s;
+    }
+  }
   // Gram-Schmidt step against k stored vectors: c = V^T w, w -= V c
   void orthogonalize(int k, const double* V, i64 N, double* w, double* c_host) {
     for (int q = 0; q < k; ++q) {
