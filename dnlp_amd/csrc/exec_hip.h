@@ -895,8 +895,9 @@ struct HipExec : HostControlled {
   }
   double fused_eval(const FusedProg& P, const double* x, const double* consts, double* grad) {
     if (P.nelem <= 0) return 0.0;
-    // one element per lane, register budget capped for 6 wavefronts per SIMD: measured best of
-    // {1 elem / 3 waves: 447, 1 / 6: 553, 2 / 4: 451, 1 / 8: 559} GB/s on the 16 n measure at n = 1e8
+    // one element per lane, register budget capped for 6 wavefronts per SIMD.  Measured on the 16 n
+    // measure at n = 1e8: {1 element / 3 wavefronts: 447, 1 / 6: 553, 1 / 8: 559, 2 / 3: 490, 4 / 2: 309}
+    // GB/s — the interpreter is bound by LDS / atomic latency, not by opcode decode.
     constexpr int NE = 1;
     const i64 tile = static_cast<i64>(kBlock) * NE;
     i64 blocks = (P.nelem + tile - 1) / tile;

@@ -38,54 +38,95 @@ DNLP_HD inline double fused_elements(const FusedProg& P, i64 i0, i64 estride, co
                                      const double* __restrict__ x, const double* __restrict__ consts,
                                      S slot, G scatter) {
   const int n = P.n;
+  // opcode dispatch OUTSIDE the element loop: one decode serves NE independent element chains
+#define DNLP_FZ_EACH for (int e = 0; e < NE; ++e) if (valid[e])
   for (int k = 0; k < n; ++k) {
     const int op = P.op[k], a = P.a[k], b = P.b[k];
     const i64 off = P.off[k], st = P.stride[k];
     const double p = P.p[k], p2 = P.p2[k];
+    switch (op) {
+      case F_LOADV:
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      if (!valid[e]) continue;
-      const i64 i = i0 + e * estride;
-      double v;
-      switch (op) {
-        case F_LOADV: v = x[off + st * i]; break;
-        case F_LOADC: v = consts[off + st * i]; break;
-        case F_UNARY: { double g1, g2; unary_rules(b, slot(a, e), p, p2, v, g1, g2); break; }
-        case F_ADD: v = slot(a, e) + slot(b, e); break;
-        case F_SUB: v = slot(a, e) - slot(b, e); break;
-        case F_MUL: v = slot(a, e) * slot(b, e); break;
-        case F_SCALE: v = p * slot(a, e); break;
-        case F_ADDC: v = slot(a, e) + p; break;
-        default: v = slot(a, e) / slot(b, e); break;   // F_DIV
-      }
-      slot(k, e) = v;
+        DNLP_FZ_EACH slot(k, e) = x[off + st * (i0 + e * estride)];
+        break;
+      case F_LOADC:
+#pragma unroll
+        DNLP_FZ_EACH slot(k, e) = consts[off + st * (i0 + e * estride)];
+        break;
+      case F_UNARY:
+#pragma unroll
+        DNLP_FZ_EACH { double v, g1, g2; unary_rules(b, slot(a, e), p, p2, v, g1, g2); slot(k, e) = v; }
+        break;
+      case F_ADD:
+#pragma unroll
+        DNLP_FZ_EACH slot(k, e) = slot(a, e) + slot(b, e);
+        break;
+      case F_SUB:
+#pragma unroll
+        DNLP_FZ_EACH slot(k, e) = slot(a, e) - slot(b, e);
+        break;
+      case F_MUL:
+#pragma unroll
+        DNLP_FZ_EACH slot(k, e) = slot(a, e) * slot(b, e);
+        break;
+      case F_SCALE:
+#pragma unroll
+        DNLP_FZ_EACH slot(k, e) = p * slot(a, e);
+        break;
+      case F_ADDC:
+#pragma unroll
+        DNLP_FZ_EACH slot(k, e) = slot(a, e) + p;
+        break;
+      default:
+#pragma unroll
+        DNLP_FZ_EACH slot(k, e) = slot(a, e) / slot(b, e);
+        break;
     }
   }
   double fsum = 0.0;
 #pragma unroll
-  for (int e = 0; e < NE; ++e) if (valid[e]) { fsum += slot(n - 1, e); slot(n - 1, e) = 1.0; }
+  DNLP_FZ_EACH { fsum += slot(n - 1, e); slot(n - 1, e) = 1.0; }
   for (int k = n - 1; k >= 0; --k) {
     const int op = P.op[k], a = P.a[k], b = P.b[k];
     const i64 off = P.off[k], st = P.stride[k];
     const double p = P.p[k], p2 = P.p2[k];
+    switch (op) {
+      case F_LOADV:
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      if (!valid[e]) continue;
-      const i64 i = i0 + e * estride;
-      const double g = slot(k, e);
-      switch (op) {
-        case F_LOADV: scatter(off + st * i, g); break;
-        case F_LOADC: break;
-        case F_UNARY: { double v, g1, g2; unary_rules(b, slot(a, e), p, p2, v, g1, g2); slot(a, e) = g * g1; break; }
-        case F_ADD: slot(a, e) = g; slot(b, e) = g; break;
-        case F_SUB: slot(a, e) = g; slot(b, e) = -g; break;
-        case F_MUL: { const double va = slot(a, e), vb = slot(b, e); slot(a, e) = g * vb; slot(b, e) = g * va; break; }
-        case F_SCALE: slot(a, e) = g * p; break;
-        case F_ADDC: slot(a, e) = g; break;
-        default: { const double va = slot(a, e), vb = slot(b, e); slot(a, e) = g / vb; slot(b, e) = -g * va / (vb * vb); break; }
-      }
+        DNLP_FZ_EACH scatter(off + st * (i0 + e * estride), slot(k, e));
+        break;
+      case F_LOADC: break;
+      case F_UNARY:
+#pragma unroll
+        DNLP_FZ_EACH { double v, g1, g2; unary_rules(b, slot(a, e), p, p2, v, g1, g2); slot(a, e) = slot(k, e) * g1; }
+        break;
+      case F_ADD:
+#pragma unroll
+        DNLP_FZ_EACH { const double g = slot(k, e); slot(a, e) = g; slot(b, e) = g; }
+        break;
+      case F_SUB:
+#pragma unroll
+        DNLP_FZ_EACH { const double g = slot(k, e); slot(a, e) = g; slot(b, e) = -g; }
+        break;
+      case F_MUL:
+#pragma unroll
+        DNLP_FZ_EACH { const double g = slot(k, e), va = slot(a, e), vb = slot(b, e); slot(a, e) = g * vb; slot(b, e) = g * va; }
+        break;
+      case F_SCALE:
+#pragma unroll
+        DNLP_FZ_EACH slot(a, e) = slot(k, e) * p;
+        break;
+      case F_ADDC:
+#pragma unroll
+        DNLP_FZ_EACH slot(a, e) = slot(k, e);
+        break;
+      default:
+#pragma unroll
+        DNLP_FZ_EACH { const double g = slot(k, e), va = slot(a, e), vb = slot(b, e); slot(a, e) = g / vb; slot(b, e) = -g * va / (vb * vb); }
+        break;
     }
   }
+#undef DNLP_FZ_EACH
   return fsum;
 }
 
