@@ -143,8 +143,9 @@ class ProblemHandle:
 
     def __init__(self, api: CApi, blob: bytes, device: int = 0):
         self.api = api
-        self._blob = blob   # keep alive
-        self.ptr = api.create(blob, len(blob), device)
+        # the library copies the blob while parsing it; bytes and bytearray are both accepted
+        buf = (C.c_char * len(blob)).from_buffer(blob) if isinstance(blob, bytearray) else blob
+        self.ptr = api.create(buf, len(blob), device)
         if not self.ptr:
             raise RuntimeError("%screate failed: %s" % (api.prefix, api.error()))
         n, m, nj, nh = (C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64())

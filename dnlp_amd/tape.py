@@ -132,31 +132,36 @@ def tape_arrays(t: Tape, x0, lb, ub, cl, cu) -> Dict[str, np.ndarray]:
     return a
 
 
-def serialize(arrays: Dict[str, np.ndarray]) -> bytes:
+def serialize(arrays: Dict[str, np.ndarray]):
+    """Named arrays -> one contiguous blob (a bytearray: every array is copied exactly once into
+    its 64-byte aligned place; an 800 MB tape used to cost five copies)."""
     names = list(arrays.keys())
     header_size = 16 + len(names) * (40 + 4 + 4 + 8 + 8)
     off = (header_size + 63) // 64 * 64
     entries = []
-    chunks = []
+    flat = []
     for name in names:
         arr = np.ascontiguousarray(arrays[name])
         if arr.dtype not in _DT:
             raise TypeError("array %s has unsupported dtype %s" % (name, arr.dtype))
-        raw = arr.tobytes()
-        entries.append((name.encode(), _DT[arr.dtype], arr.size, off))
-        pad = (-len(raw)) % 64
-        chunks.append(raw + b"\0" * pad)
-        off += len(raw) + pad
-    out = bytearray()
-    out += MAGIC + struct.pack("<II", VERSION, len(names))
-    for nm, dt, cnt, o in entries:
+        nm = name.encode()
         if len(nm) > 39:
             raise ValueError("array name too long: %s" % nm)
-        out += nm.ljust(40, b"\0") + struct.pack("<IIQQ", dt, 0, cnt, o)
-    out += b"\0" * ((-len(out)) % 64)
-    for ch in chunks:
-        out += ch
-    return bytes(out)
+        nbytes = arr.size * arr.dtype.itemsize
+        entries.append((nm, _DT[arr.dtype], arr.size, off))
+        flat.append((off, arr.reshape(-1)))
+        off += (nbytes + 63) // 64 * 64
+    out = bytearray(off)
+    struct.pack_into("<8sII", out, 0, MAGIC, VERSION, len(names))
+    pos = 16
+    for nm, dt, cnt, o in entries:
+        struct.pack_into("<40sIIQQ", out, pos, nm, dt, 0, cnt, o)
+        pos += 64
+    view = np.frombuffer(out, dtype=np.uint8)
+    for o, arr in flat:
+        if arr.size:
+            view[o:o + arr.size * arr.dtype.itemsize] = arr.view(np.uint8)
+    return out
 
 
 def deserialize(blob: bytes) -> Dict[str, np.ndarray]:
