@@ -590,18 +590,35 @@ fused_eval_kernel(FusedProg P, const double* __restrict__ x, const double* __res
                   double* __restrict__ grad, double* __restrict__ partial) {
   extern __shared__ double fz_slots[];
   __shared__ double sm[kBlock / 64];
+  __shared__ double gwin[kBlock * NE + 64];        // gradient window of the current tile
   double* mine = fz_slots + threadIdx.x;
   double acc = 0.0;
   const i64 tile = static_cast<i64>(kBlock) * NE;
+  const int win = P.win_extra >= 0 ? static_cast<int>(tile) + P.win_extra : 0;
+  for (int t = threadIdx.x; t < win; t += kBlock) gwin[t] = 0.0;
+  __syncthreads();
   for (i64 base = static_cast<i64>(blockIdx.x) * tile; base < P.nelem; base += static_cast<i64>(gridDim.x) * tile) {
     // lane l handles elements base + l + 256 e: every load / atomic of an instruction is a
     // fully coalesced wavefront access
     bool valid[NE];
 #pragma unroll
     for (int e = 0; e < NE; ++e) valid[e] = base + threadIdx.x + static_cast<i64>(e) * kBlock < P.nelem;
+    const i64 wbase = base + P.win_lo;
     acc += fused_elements<NE>(P, base + threadIdx.x, kBlock, valid, x, consts,
                               [=](int k, int e) -> double& { return mine[(k * NE + e) * kBlock]; },
-                              [=](i64 idx, double v) { unsafeAtomicAdd(&grad[idx], v); });
+                              [=](i64 idx, double v) {
+                                const i64 t = idx - wbase;
+                                if (t >= 0 && t < win) unsafeAtomicAdd(&gwin[t], v);      // LDS
+                                else unsafeAtomicAdd(&grad[idx], v);
+                              });
+    if (win) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < win; t += kBlock) {
+        const double v = gwin[t];
+        if (v != 0.0) { unsafeAtomicAdd(&grad[wbase + t], v); gwin[t] = 0.0; }
+      }
+      __syncthreads();
+    }
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;

@@ -13,6 +13,8 @@
 // (slot[k][lane]: conflict-free, register file of the interpreter) and atomic adds into grad;
 // the host space of the test oracle runs the same function with a local array.
 #pragma once
+#include <algorithm>
+
 #include "atom_math.h"
 #include "tape.h"
 
@@ -28,6 +30,11 @@ struct FusedProg {
   int op[kFusedMaxInstr], a[kFusedMaxInstr], b[kFusedMaxInstr];
   i64 off[kFusedMaxInstr], stride[kFusedMaxInstr];
   double p[kFusedMaxInstr], p2[kFusedMaxInstr];
+  // gradient window: when every variable load is x[off_j + i] (unit stride, offsets within a small
+  // range) the adjoints of a tile of elements land in [tile + win_lo, tile + win_lo + tile_size +
+  // win_extra): they are summed in LDS first and flushed with ONE global atomic per entry
+  i64 win_lo = 0;
+  int win_extra = -1;        // -1: no window (strided / far-apart loads): global atomics per load
 };
 
 // NE elements per call (instruction-major: one opcode decode serves NE independent element
@@ -161,6 +168,17 @@ struct FusedObjective {
         if (P.op[k] >= F_UNARY && (P.a[k] < 0 || P.a[k] >= k)) throw std::runtime_error("bad fused operand");
         if ((P.op[k] == F_ADD || P.op[k] == F_SUB || P.op[k] == F_MUL || P.op[k] == F_DIV) && (P.b[k] < 0 || P.b[k] >= k))
           throw std::runtime_error("bad fused operand");
+      }
+      {
+        i64 lo = 0, hi = 0;
+        bool unit = true, any = false;
+        for (int k = 0; k < P.n; ++k) {
+          if (P.op[k] != F_LOADV) continue;
+          if (P.stride[k] != 1) unit = false;
+          if (!any) { lo = hi = P.off[k]; any = true; }
+          lo = std::min(lo, P.off[k]); hi = std::max(hi, P.off[k]);
+        }
+        if (any && unit && hi - lo <= 64) { P.win_lo = lo; P.win_extra = static_cast<int>(hi - lo); }
       }
       progs.push_back(P);
     }

@@ -1414,27 +1414,40 @@ class Ipm {
       int r = step();
       if (r != 99) break;
     }
-    // Robustness device (documented deviation): when the adaptive strategy ends in a step /
-    // restoration failure, the solve is repeated once from the same start in monotone mode.
-    if (opt.mu_strategy == 1 && opt.adaptive_fallback &&
-        (status == Infeasible_Problem_Detected || status == Restoration_Failed ||
-         status == Error_In_Step_Computation || status == Search_Direction_Becomes_Too_Small)) {
-      const int it_first = iter;
-      logf("adaptive barrier strategy ended with status %d after %d iterations: restarting in monotone mode", status, iter);
-      typename E::Log keep = iterlog;
-      opt.mu_strategy = 0;
-      rc = begin(x0_ctl);
-      if (rc == 0) {
-        while (true) {
-          int r = step();
-          if (r != 99) break;
+    // Robustness ladder (documented deviation): a run that ends in a step / restoration failure,
+    // an infeasibility verdict or diverging iterates is repeated from the same start, first in
+    // monotone mode (when it was adaptive), then in monotone mode with a ten times larger initial
+    // barrier (>= 1): nonconvex canonical forms whose objective is unbounded off the feasible
+    // set are path-sensitive, and a stronger barrier keeps the early iterates centred.
+    if (opt.adaptive_fallback) {
+      const int strategy0 = opt.mu_strategy;
+      const double mu_init0 = opt.mu_init;
+      for (int rung = 1; rung <= 2; ++rung) {
+        const bool failed = status == Infeasible_Problem_Detected || status == Restoration_Failed ||
+                            status == Error_In_Step_Computation || status == Search_Direction_Becomes_Too_Small ||
+                            status == Diverging_Iterates;
+        if (!failed) break;
+        if (rung == 1 && strategy0 != 1) continue;       // already monotone: straight to rung 2
+        const int it_first = iter;
+        opt.mu_strategy = 0;
+        if (rung == 2) opt.mu_init = mu_init0 * 10.0 > 1.0 ? mu_init0 * 10.0 : 1.0;
+        logf("run ended with status %d after %d iterations: restarting in monotone mode, mu_init %.1e", status, iter,
+             opt.mu_init);
+        typename E::Log keep = iterlog;
+        rc = begin(x0_ctl);
+        if (rc == 0) {
+          while (true) {
+            int r = step();
+            if (r != 99) break;
+          }
         }
+        iter += it_first;
+        stats.iterations = iter;
+        keep.append(iterlog);
+        iterlog = keep;
       }
-      opt.mu_strategy = 1;
-      iter += it_first;
-      stats.iterations = iter;
-      keep.append(iterlog);
-      iterlog = keep;
+      opt.mu_strategy = strategy0;
+      opt.mu_init = mu_init0;
     }
     stats.wall = now_sec() - t_all;
     stats.final_mu = mu;
