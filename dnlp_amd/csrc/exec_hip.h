@@ -155,17 +155,38 @@ __global__ void __launch_bounds__(kBlock) dense_block_add_kernel(double* __restr
   }
 }
 
+// COO products on the row-major sorted patterns of the tape (Jacobian, lower Hessian): the
+// contributions to out[r] of one wavefront are contiguous runs of equal rows, so they are summed
+// with a segmented shuffle scan and leave as ONE atomic per run (a dense 1e4-entry Jacobian row
+// would otherwise serialise 64 same-address atomics per wavefront); the out[c] side (transpose,
+// symmetric mirror) has distinct neighbouring columns and goes out as plain atomics.
+__device__ inline void coo_row_add(double* out, i32 row, double val, bool active) {
+  const int lane = threadIdx.x & 63;
+  if (!active) row = -1 - lane;                 // unique, never merged, never written
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double tv = __shfl_up(val, o, 64);
+    const i32 tr = __shfl_up(row, o, 64);
+    if (lane >= o && tr == row) val += tv;
+  }
+  const i32 nxt = __shfl_down(row, 1, 64);
+  if (active && (lane == 63 || nxt != row)) unsafeAtomicAdd(&out[row], val);
+}
+
 __global__ void __launch_bounds__(kBlock) coo_mult_kernel(i64 nnz, const i32* __restrict__ r,
                                                           const i32* __restrict__ c, const double* __restrict__ a,
                                                           const double* __restrict__ v, double* out, int mode) {
   const i64 p = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
-  if (p >= nnz) return;
-  const double av = a[p];
-  if (mode == 0) unsafeAtomicAdd(&out[r[p]], av * v[c[p]]);
-  else if (mode == 1) unsafeAtomicAdd(&out[c[p]], av * v[r[p]]);
-  else {
-    unsafeAtomicAdd(&out[r[p]], av * v[c[p]]);
-    if (r[p] != c[p]) unsafeAtomicAdd(&out[c[p]], av * v[r[p]]);
+  const bool active = p < nnz;
+  const double av = active ? a[p] : 0.0;
+  const i32 rp = active ? r[p] : 0, cp = active ? c[p] : 0;
+  if (mode == 0) {
+    coo_row_add(out, rp, active ? av * v[cp] : 0.0, active);
+  } else if (mode == 1) {
+    if (active) unsafeAtomicAdd(&out[cp], av * v[rp]);
+  } else {
+    coo_row_add(out, rp, active ? av * v[cp] : 0.0, active);
+    if (active && rp != cp) unsafeAtomicAdd(&out[cp], av * v[rp]);
   }
 }
 

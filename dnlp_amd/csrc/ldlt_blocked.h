@@ -34,40 +34,53 @@ constexpr int GM_BM = 128, GM_BN = 128, GM_BK = 16, GM_PAD = 16;
 struct LdltInfo { int nneg, nzero, fail, pad; double dmax; };
 
 // ---- diagonal block ----------------------------------------------------------------------
-__global__ void __launch_bounds__(256) ldlt_diag_kernel(double* A, i64 ld, int j0, int jb, LdltInfo* info,
-                                                        double tiny) {
-  __shared__ double S[LD_nb][LD_nb + 1];
-  __shared__ double dinv;
-  const int tid = threadIdx.x;
-  for (int e = tid; e < jb * jb; e += 256) {
-    const int r = e % jb, c = e / jb;
-    S[r][c] = (r >= c) ? A[(j0 + r) + static_cast<i64>(j0 + c) * ld] : 0.0;
+// One wavefront, lane = row, the row's 32 entries in registers (fully unrolled: static register
+// indices); pivots and the multipliers of the pivot column travel by v_readlane, so a step is a
+// handful of scalar broadcasts and FMAs with no LDS, no barrier and no global access: ~3 us per
+// block against ~30 us for the LDS / barrier form it replaces (the panel chain is latency-bound:
+// n / 32 dependent diag -> trsm -> update rounds).
+__device__ inline double ldlt_bcast(double v, int srclane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(64) ldlt_diag_kernel(double* A, i64 ld, int j0, int jb, LdltInfo* info,
+                                                       double tiny) {
+  const int lane = threadIdx.x;
+  const int row = lane < jb ? lane : jb - 1;            // clamped: loads stay inside the block
+  double S[LD_nb];
+#pragma unroll
+  for (int c = 0; c < LD_nb; ++c) {
+    const int cc = c < jb ? c : jb - 1;
+    const double v = A[(j0 + row) + static_cast<i64>(j0 + cc) * ld];
+    // rows / columns beyond jb: identity padding (never stored, never counted)
+    S[c] = (lane < jb && c < jb) ? (lane >= c ? v : 0.0) : (lane == c ? 1.0 : 0.0);
   }
-  __syncthreads();
-  for (int k = 0; k < jb; ++k) {
-    if (tid == 0) {
-      double d = S[k][k];
-      if (!(d == d)) { info->fail = 1; d = 1.0; }
-      if (fabs(d) <= tiny) { info->nzero += 1; d = (d < 0.0 ? -tiny : tiny); if (d == 0.0) d = 1e-300; }
-      if (d < 0.0) info->nneg += 1;
-      S[k][k] = d;
-      dinv = 1.0 / d;
+  int nneg = 0, nzero = 0, fail = 0;
+#pragma unroll
+  for (int k = 0; k < LD_nb; ++k) {
+    double d = ldlt_bcast(S[k], k);
+    if (k < jb) {
+      if (!(d == d)) { fail = 1; d = 1.0; }
+      if (fabs(d) <= tiny) { nzero += 1; d = (d < 0.0 ? -tiny : tiny); if (d == 0.0) d = 1e-300; }
+      if (d < 0.0) nneg += 1;
     }
-    __syncthreads();
-    const double di = dinv;
-    // trailing update of the block with the unscaled column, then scale the column
-    const int t = jb - k - 1;
-    for (int e = tid; e < t * t; e += 256) {
-      const int r = k + 1 + e % t, c = k + 1 + e / t;
-      if (r >= c) S[r][c] -= S[r][k] * S[c][k] * di;
-    }
-    __syncthreads();
-    for (int r = k + 1 + tid; r < jb; r += 256) S[r][k] *= di;
-    __syncthreads();
+    const double di = 1.0 / d;
+    const double mine = S[k];                            // unscaled pivot-column entry of this row
+#pragma unroll
+    for (int c = k + 1; c < LD_nb; ++c) S[c] -= mine * (ldlt_bcast(S[k], c) * di);
+    S[k] = lane == k ? d : mine * di;
   }
-  for (int e = tid; e < jb * jb; e += 256) {
-    const int r = e % jb, c = e / jb;
-    if (r >= c) A[(j0 + r) + static_cast<i64>(j0 + c) * ld] = S[r][c];
+  if (lane < jb) {
+#pragma unroll
+    for (int c = 0; c < LD_nb; ++c)
+      if (c < jb && lane >= c) A[(j0 + lane) + static_cast<i64>(j0 + c) * ld] = S[c];
+  }
+  if (lane == 0 && (nneg | nzero | fail)) {
+    info->nneg += nneg;
+    info->nzero += nzero;
+    if (fail) info->fail = 1;
   }
 }
 
@@ -345,38 +358,47 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_update(double* __restrict__ C,
 // transposed are bandwidth kernels that stream the factor once per solve (n^2/2 doubles).
 constexpr int SV_B = 256;
 
+// Every round s0 needs, for row t >= s0, the 32 entries L[t, s0 .. s0+32): the diagonal sub-block
+// rows use them in a shuffle substitution, the rows below in a 32-term update.  They are fetched one
+// round AHEAD (unconditional, clamped addresses, so the compiler issues them back to back), which
+// takes the global round trip out of the 8-round dependency chain.
 __global__ void __launch_bounds__(SV_B) ldlt_fwd_diag(const double* __restrict__ A, i64 ld, int j0, int jb,
                                                       double* __restrict__ b) {
   __shared__ double y[SV_B];
   const int t = threadIdx.x;
+  const int tr = t < jb ? t : jb - 1;
   double v = (t < jb) ? b[j0 + t] : 0.0;
+  double cur[32], nxt[32];
+  const double* row = A + (j0 + tr) + static_cast<i64>(j0) * ld;
+#pragma unroll
+  for (int kk = 0; kk < 32; ++kk) cur[kk] = row[static_cast<i64>(kk < jb ? kk : jb - 1) * ld];
   for (int s0 = 0; s0 < jb; s0 += 32) {
     const int s1 = (s0 + 32 < jb) ? s0 + 32 : jb;
-    if ((t >> 6) == (s0 >> 6)) {
-      // this lane's row of the 32 x 32 sub-block, fetched up front (independent loads) so the
-      // substitution loop below is register-only
-      double lr[32];
+    if (s1 < jb) {
 #pragma unroll
-      for (int kk = 0; kk < 32; ++kk)
-        lr[kk] = (s0 + kk < t && t < s1) ? A[(j0 + t) + static_cast<i64>(j0 + s0 + kk) * ld] : 0.0;
+      for (int kk = 0; kk < 32; ++kk) nxt[kk] = row[static_cast<i64>(s1 + kk < jb ? s1 + kk : jb - 1) * ld];
+    }
+    if ((t >> 6) == (s0 >> 6)) {
+      const bool mine = t >= s0 && t < s1;
 #pragma unroll
       for (int kk = 0; kk < 32; ++kk) {
         const double yk = __shfl(v, (s0 + kk) & 63, 64);
-        v -= lr[kk] * yk;
+        v -= (mine && s0 + kk < t) ? cur[kk] * yk : 0.0;
       }
-      if (t >= s0 && t < s1) y[t] = v;
+      if (mine) y[t] = v;
     }
     __syncthreads();
     if (t >= s1 && t < jb) {
       double sa = 0.0, sb = 0.0;
-      const double* row = A + (j0 + t) + static_cast<i64>(j0 + s0) * ld;
-#pragma unroll 8
+#pragma unroll
       for (int kk = 0; kk < 32; kk += 2) {
-        if (s0 + kk < s1) sa += row[static_cast<i64>(kk) * ld] * y[s0 + kk];
-        if (s0 + kk + 1 < s1) sb += row[static_cast<i64>(kk + 1) * ld] * y[s0 + kk + 1];
+        sa += (s0 + kk < s1) ? cur[kk] * y[s0 + kk] : 0.0;
+        sb += (s0 + kk + 1 < s1) ? cur[kk + 1] * y[s0 + kk + 1] : 0.0;
       }
       v -= sa + sb;
     }
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) cur[kk] = nxt[kk];
   }
   if (t < jb) b[j0 + t] = v;
 }
@@ -431,31 +453,45 @@ __global__ void __launch_bounds__(SV_B) ldlt_bwd_diag(const double* __restrict__
                                                       double* __restrict__ b, double* __restrict__ acc) {
   __shared__ double xs[SV_B];
   const int t = threadIdx.x;
+  const int tc = t < jb ? t : jb - 1;
   double v = (t < jb) ? b[j0 + t] - acc[t] : 0.0;
   if (t < SV_B) acc[t] = 0.0;
   const int nsb = (jb + 31) / 32;
+  // column t of the block, rows s0 .. s0+32 of every round, fetched one round ahead (see ldlt_fwd_diag)
+  const double* colt = A + j0 + static_cast<i64>(j0 + tc) * ld;
+  double cur[32], nxt[32];
+  {
+    const int s0 = (nsb - 1) * 32;
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) cur[kk] = colt[s0 + kk < jb ? s0 + kk : jb - 1];
+  }
   for (int sbk = nsb - 1; sbk >= 0; --sbk) {
     const int s0 = sbk * 32, s1 = (s0 + 32 < jb) ? s0 + 32 : jb;
-    if ((t >> 6) == (s0 >> 6)) {
-      double lr[32];
-      const double* colt = A + (j0 + s0) + static_cast<i64>(j0 + t) * ld;
+    if (sbk > 0) {
 #pragma unroll
-      for (int kk = 0; kk < 32; ++kk)
-        lr[kk] = (s0 + kk > t && s0 + kk < s1 && t >= s0) ? colt[kk] : 0.0;
+      for (int kk = 0; kk < 32; ++kk) nxt[kk] = colt[s0 - 32 + kk];
+    }
+    if ((t >> 6) == (s0 >> 6)) {
+      const bool mine = t >= s0 && t < s1;
 #pragma unroll
       for (int kk = 31; kk >= 0; --kk) {
         const double xk = __shfl(v, (s0 + kk) & 63, 64);
-        v -= lr[kk] * xk;
+        v -= (mine && s0 + kk > t && s0 + kk < s1) ? cur[kk] * xk : 0.0;
       }
-      if (t >= s0 && t < s1) xs[t] = v;
+      if (mine) xs[t] = v;
     }
     __syncthreads();
     if (t < s0) {
-      const double* colt = A + j0 + static_cast<i64>(j0 + t) * ld;
-      double s = 0.0;
-      for (int k = s0; k < s1; ++k) s += colt[k] * xs[k];
-      v -= s;
+      double sa = 0.0, sb = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < 32; kk += 2) {
+        sa += (s0 + kk < s1) ? cur[kk] * xs[s0 + kk] : 0.0;
+        sb += (s0 + kk + 1 < s1) ? cur[kk + 1] * xs[s0 + kk + 1] : 0.0;
+      }
+      v -= sa + sb;
     }
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) cur[kk] = nxt[kk];
   }
   if (t < jb) b[j0 + t] = v;
 }
@@ -553,7 +589,7 @@ struct BlockedLdlt {
       double* Wp = Wp2[p & 1];
       for (int j0 = K0; j0 < K0 + KB; j0 += LD_nb) {
         const int jb = std::min(LD_nb, K0 + KB - j0);
-        hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(256), 0, s0, A, ld, j0, jb, info, tiny);
+        hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(64), 0, s0, A, ld, j0, jb, info, tiny);
         const int r0 = j0 + jb;
         if (r0 >= ni) continue;
         const int rows = ni - r0;

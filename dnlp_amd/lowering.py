@@ -313,15 +313,13 @@ class Lowerer:
         m, k, p = self._matmul_dims(X, Y)
         if X.is_constant():
             C = X.value
-            C = sp.csr_matrix(C) if sp.issparse(C) else \
-                sp.csr_matrix(np.asarray(C, dtype=float).reshape(m, k))
-            S = sp.kron(sp.identity(p, format="csr"), C, format="csr")
+            C = sp.csr_matrix(C) if sp.issparse(C) else _dense_csr(np.asarray(C, dtype=float).reshape(m, k))
+            S = C if p == 1 else sp.kron(sp.identity(p, format="csr"), C, format="csr")
             return self.lower(Y).apply(S)
         if Y.is_constant():
             C = Y.value
-            C = sp.csr_matrix(C) if sp.issparse(C) else \
-                sp.csr_matrix(np.asarray(C, dtype=float).reshape(k, p))
-            S = sp.kron(C.T, sp.identity(m, format="csr"), format="csr")
+            C = sp.csr_matrix(C) if sp.issparse(C) else _dense_csr(np.asarray(C, dtype=float).reshape(k, p))
+            S = sp.csr_matrix(C.T) if m == 1 else sp.kron(C.T, sp.identity(m, format="csr"), format="csr")
             return self.lower(X).apply(S)
         return self._lower_bilinear_matmul(e, m, k, p)
 
@@ -508,7 +506,11 @@ class Lowerer:
                 dense = n > DENSE_EXPAND_MAX_N
                 if dense:
                     cid = len(self.dense_consts)
-                    self.dense_consts.append(DenseConst(n=n, host=np.asfortranarray(Pm)))
+                    # quad_form's P is symmetric: the transposed view of a C-ordered P is the
+                    # column-major matrix itself, no 8 n^2-byte copy
+                    Pf = Pm.T if (Pm.flags.c_contiguous and not Pm.flags.f_contiguous
+                                  and _is_symmetric(Pm)) else np.asfortranarray(Pm)
+                    self.dense_consts.append(DenseConst(n=n, host=Pf))
                 else:
                     Pm = sp.csr_matrix(Pm)
                     # keep explicit zeros out but make sure the pattern is symmetric
@@ -547,8 +549,33 @@ class Lowerer:
         return self._z_form(seg.zoff, 1)
 
 
+def _is_symmetric(P: np.ndarray) -> bool:
+    """Exact symmetry test, tile against mirrored tile (cache-sized, no n x n temporary)."""
+    n, b = P.shape[0], 256
+    for i in range(0, n, b):
+        for j in range(0, i + 1, b):
+            if not np.array_equal(P[i:i + b, j:j + b], P[j:j + b, i:i + b].T):
+                return False
+    return True
+
+
+def _dense_csr(C: np.ndarray) -> sp.csr_matrix:
+    """CSR of a dense constant; a matrix without zero entries is wrapped without a search."""
+    C = np.ascontiguousarray(C, dtype=float)
+    r, k = C.shape
+    if C.size and np.count_nonzero(C) == C.size:
+        idx_t = np.int32 if C.size < 2 ** 31 - 1 else np.int64
+        return sp.csr_matrix((C.reshape(-1), np.tile(np.arange(k, dtype=idx_t), r),
+                              np.arange(0, C.size + 1, k, dtype=idx_t)), shape=(r, k))
+    return sp.csr_matrix(C)
+
+
 def _coo_unique(keys):
     """Sorted unique keys and the position of every input key among them."""
+    keys = np.asarray(keys)
+    if keys.size < 2 or bool(np.all(keys[1:] > keys[:-1])):
+        # already strictly increasing (pure CSR / dense lower-triangle patterns): nothing to merge
+        return keys, np.arange(keys.size, dtype=np.int64)
     uniq, inv = np.unique(keys, return_inverse=True)
     return uniq, inv.astype(np.int64)
 

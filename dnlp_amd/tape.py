@@ -33,9 +33,9 @@ _DT = {np.dtype("float64"): 0, np.dtype("int32"): 1, np.dtype("int64"): 2}
 def _csr(arrs: Dict[str, np.ndarray], name: str, M):
     M = sp.csr_matrix(M)
     M.sort_indices()
-    arrs[name + "_ptr"] = M.indptr.astype(np.int64)
-    arrs[name + "_idx"] = M.indices.astype(np.int32)
-    arrs[name + "_val"] = M.data.astype(np.float64)
+    arrs[name + "_ptr"] = M.indptr.astype(np.int64, copy=False)
+    arrs[name + "_idx"] = M.indices.astype(np.int32, copy=False)
+    arrs[name + "_val"] = M.data.astype(np.float64, copy=False)
 
 
 def tape_arrays(t: Tape, x0, lb, ub, cl, cu) -> Dict[str, np.ndarray]:
@@ -69,7 +69,7 @@ def tape_arrays(t: Tape, x0, lb, ub, cl, cu) -> Dict[str, np.ndarray]:
         seg[prefix + "_base"].append(int(idx[0]) if contiguous else -1)
         seg[prefix + "_off"].append(goff)
         seg[prefix + "_len"].append(int(idx.size))
-        gidx.append(idx.astype(np.int32))
+        gidx.append(idx.astype(np.int32, copy=False))
         goff += idx.size
 
     for s in t.segments:
@@ -88,40 +88,40 @@ def tape_arrays(t: Tape, x0, lb, ub, cl, cu) -> Dict[str, np.ndarray]:
         a["seg_" + k] = np.asarray(v, dtype=np.int64)
     a["seg_param"] = np.asarray(par, dtype=np.float64)
     a["seg_param2"] = np.asarray(par2, dtype=np.float64)
-    a["gidx"] = np.concatenate(gidx).astype(np.int32) if gidx else np.zeros(0, np.int32)
+    a["gidx"] = np.concatenate(gidx).astype(np.int32, copy=False) if gidx else np.zeros(0, np.int32)
     # linear parts
     a["c0"] = np.array([t.c0])
-    a["c"] = t.c.astype(np.float64)
+    a["c"] = t.c.astype(np.float64, copy=False)
     _csr(a, "G", t.G)
-    a["b"] = t.b.astype(np.float64)
+    a["b"] = t.b.astype(np.float64, copy=False)
     # derivative maps
-    a["drow"] = t.drow.astype(np.int32)
-    a["dcol"] = t.dcol.astype(np.int32)
-    a["hrow"] = t.hrow.astype(np.int32)
-    a["hcol"] = t.hcol.astype(np.int32)
-    a["hz"] = t.hz.astype(np.int32)
+    a["drow"] = t.drow.astype(np.int32, copy=False)
+    a["dcol"] = t.dcol.astype(np.int32, copy=False)
+    a["hrow"] = t.hrow.astype(np.int32, copy=False)
+    a["hcol"] = t.hcol.astype(np.int32, copy=False)
+    a["hz"] = t.hz.astype(np.int32, copy=False)
     _csr(a, "Mg", t.Mg)
     _csr(a, "Mw", t.Mw)
     _csr(a, "MJ", t.MJ)
-    a["Jc"] = t.Jc.astype(np.float64)
-    a["jac_rows"] = t.jac_rows.astype(np.int32)
-    a["jac_cols"] = t.jac_cols.astype(np.int32)
+    a["Jc"] = t.Jc.astype(np.float64, copy=False)
+    a["jac_rows"] = t.jac_rows.astype(np.int32, copy=False)
+    a["jac_cols"] = t.jac_cols.astype(np.int32, copy=False)
     _csr(a, "MH", t.MH)
-    a["hess_rows"] = t.hess_rows.astype(np.int32)
-    a["hess_cols"] = t.hess_cols.astype(np.int32)
+    a["hess_rows"] = t.hess_rows.astype(np.int32, copy=False)
+    a["hess_cols"] = t.hess_cols.astype(np.int32, copy=False)
     # constants
     dn = []
     for k, dc in enumerate(t.dense_consts):
         dn.append(dc.n)
         if dc.host is not None:
-            a["dense%d" % k] = np.asfortranarray(dc.host).reshape(-1, order="F").astype(np.float64)
+            a["dense%d" % k] = np.asfortranarray(dc.host).reshape(-1, order="F").astype(np.float64, copy=False)
     a["dense_n"] = np.asarray(dn, dtype=np.int64)
     for k, (P, r, c, v) in enumerate(t.sparse_consts):
         _csr(a, "sp%d" % k, P)
         _csr(a, "sp%dT" % k, sp.csr_matrix(P).T)
-        a["sp%d_hr" % k] = r.astype(np.int32)
-        a["sp%d_hc" % k] = c.astype(np.int32)
-        a["sp%d_hv" % k] = v.astype(np.float64)
+        a["sp%d_hr" % k] = r.astype(np.int32, copy=False)
+        a["sp%d_hc" % k] = c.astype(np.int32, copy=False)
+        a["sp%d_hv" % k] = v.astype(np.float64, copy=False)
     blk = np.array([[b["seg"], b["const"], b["x0"], b["n"], b["z"],
                      1 if b.get("coo_pos") is not None else 0] for b in t.dense_blocks],
                    dtype=np.int64).reshape(-1)
