@@ -32,6 +32,7 @@ struct ProblemT {
   int lbfgs_history = 10;
   IpmOptions opt;
   i64 pivot_max_n = 2048;
+  i64 optimistic_min_n = static_cast<i64>(1) << 40;   // option kkt_optimistic_min_n: dense orders above it start unpivoted (kkt_dense.h); default off
   double *dx = nullptr, *dlam = nullptr, *dg = nullptr, *dgrad = nullptr, *djac = nullptr, *dh = nullptr;
   bool swept = false, kkt_ready = false, time_kernels = false;
   double *ws_g = nullptr, *ws_l = nullptr, *ws_u = nullptr;     // warm-start multipliers (exec space)
@@ -100,6 +101,7 @@ struct ProblemT {
     if (!kkt_ready) {
       plan_linear_solver();
       kkt.pivot_max_n = pivot_max_n;
+      kkt.optimistic_min_n = optimistic_min_n;
       if (use_sparse) {
         kkt.init_sparse(&ex, model.t.N, model.t.m, sparse_plan.upload(&ex));
         kkt.fallback_max_n = linear_solver == 2 ? 0 : 2048;      // forced sparse never falls back
@@ -152,6 +154,7 @@ struct ProblemT {
     else if (k == "warm_start_bound_frac") opt.warm_start_bound_frac = num();
     else if (k == "warm_start_mult_bound_push") opt.warm_start_mult_bound_push = num();
     else if (k == "kkt_pivot_max_n") pivot_max_n = static_cast<i64>(num());
+    else if (k == "kkt_optimistic_min_n") optimistic_min_n = static_cast<i64>(num());
     else if (k == "restoration") opt.restoration = yes() ? 1 : 0;
     else if (k == "time_kernels") time_kernels = yes();
     else if (k == "lbfgs_history" || k == "limited_memory_max_history") lbfgs_history = static_cast<int>(num());

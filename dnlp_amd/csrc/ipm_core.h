@@ -359,6 +359,7 @@ class Ipm {
     iter = 0;
     acceptable_count = 0;
     delta_w_last = 0.0;
+    dc_fixed_count_ = 0; dc_fixed_last_ = false; always_dc_ = false;
     fixed_mode = false;
     n_hist = 0;
     initialized = true;
@@ -714,12 +715,25 @@ class Ipm {
       return r;
     };
     if (use_lb && (iter == 0 || delta_w_used_last_iter_)) get_lb();
-    int r = attempt(0.0, 0.0);
+    // Degenerate Jacobian (IPOPT's PDPerturbationHandler heuristic): a rank-deficient J shows up as
+    // a zero pivot or — with static pivots, where the equality-row pivots shrink like a^2 / delta_w
+    // but never vanish — as an inertia that no delta_w repairs, while the dual regularisation
+    // delta_c alone does.  After three such iterations delta_c is applied from the first attempt on.
+    const double dc_val = dc_bar * std::pow(mu, kc);
+    auto dc_fixed = [&]() {
+      dc_fixed_last_ = true;
+      if (++dc_fixed_count_ >= 3 && !always_dc_) {
+        always_dc_ = true;
+        logf("   Jacobian treated as degenerate: delta_c is applied in every factorisation from here on");
+      }
+    };
+    int r = attempt(0.0, always_dc_ ? dc_val : 0.0);
+    if (always_dc_) delta_c = dc_val;
     // Static pivots (sparse KKT) that are singular without any regularisation in consecutive
     // iterations are structural (free variables without curvature next to unregularised equality
     // rows): where the dense matrix is affordable the instance switches to Bunch-Kaufman pivoting
     // for good instead of regularising every step.
-    if (r == 2 && kkt_->can_fallback()) {
+    if (r == 2 && !always_dc_ && kkt_->can_fallback()) {
       ++sparse_singular_streak_;
       // small systems switch at once (the dense factorisation costs nothing there); larger ones only
       // when the singularity persists beyond the first iteration (multipliers start at zero)
@@ -731,30 +745,32 @@ class Ipm {
     } else {
       sparse_singular_streak_ = 0;
     }
-    if (r == 0) { delta_w_used_last_iter_ = false; return true; }
+    if (r == 0) { delta_w_used_last_iter_ = false; if (!always_dc_) dc_fixed_last_ = false; return true; }
     if (use_lb && !have_lb) get_lb();
     delta_w_used_last_iter_ = true;
-    if (r == 2) delta_c = dc_bar * std::pow(mu, kc);
+    if (r == 2) delta_c = dc_val;
     delta_w = (delta_w_last == 0.0) ? dw_0 : std::max(dw_min, kwm * delta_w_last);
     if (have_lb && delta_w < dw_first) delta_w = dw_first;   // first value not provably hopeless
-    // singular with delta_w = 0: first try the dual regularisation alone
-    if (r == 2) {
-      int r2 = attempt(0.0, delta_c);
-      if (r2 == 0) { delta_w = 0.0; return true; }
+    // singular with delta_w = 0 (or the wrong inertia that delta_c repaired in the previous
+    // iteration): first try the dual regularisation alone
+    if (delta_c == 0.0 ? (r == 2 || (r == 1 && dc_fixed_last_)) : (r == 2 && !always_dc_)) {
+      int r2 = attempt(0.0, dc_val);
+      if (r2 == 0) { delta_c = dc_val; delta_w = 0.0; if (r == 1) dc_fixed(); return true; }
+      if (r == 1) dc_fixed_last_ = false;
     }
     const double dw_start = delta_w;
+    int wrong_no_dc = 0;
     for (int k = 0; k < 100; ++k) {
       int r2 = attempt(delta_w, delta_c);
-      if (r2 == 0) { delta_w_last = delta_w; return true; }
-      if (r2 == 2 && delta_c == 0.0) delta_c = dc_bar * std::pow(mu, kc);
-      // A rank-deficient Jacobian can show up as a persistently wrong inertia instead of an exact
-      // zero pivot (static pivots: the equality-row pivots shrink like a^2 / delta_w but never
-      // vanish).  Once delta_w has passed 1e20 without the right inertia the dual
-      // regularisation is switched on and delta_w starts over.
-      if (r2 == 1 && delta_c == 0.0 && delta_w > 1e20) {
-        delta_c = dc_bar * std::pow(mu, kc);
-        delta_w = dw_start;
-        continue;
+      if (r2 == 0) { delta_w_last = delta_w; if (!always_dc_) dc_fixed_last_ = false; return true; }
+      if (r2 == 2 && delta_c == 0.0) delta_c = dc_val;
+      // three growing delta_w without the right inertia and without delta_c: suspect the Jacobian
+      if (r2 == 1 && delta_c == 0.0 && ++wrong_no_dc >= 3) {
+        int r3 = attempt(0.0, dc_val);
+        if (r3 == 0) { delta_c = dc_val; delta_w = 0.0; dc_fixed(); return true; }
+        r3 = attempt(dw_start, dc_val);
+        if (r3 == 0) { delta_c = dc_val; delta_w = delta_w_last = dw_start; dc_fixed(); return true; }
+        delta_c = dc_val;                       // keep it and go on growing delta_w
       }
       // with a certified lower bound in hand the trial is already in the right decade: grow gently
       if (have_lb && dw_lb > 0.0 && delta_w <= 64.0 * dw_lb) delta_w *= 2.0;
@@ -1301,20 +1317,49 @@ class Ipm {
       const double q1 = qf(1.0), s1m = 1.0 - 1e-2, q1m = qf(std::max(s_lo, s1m));
       double lo, up;
       if (q1m > q1 && s_up > 1.0) { lo = 1.0; up = s_up; } else { lo = s_lo; up = std::min(std::max(s_lo, s1m), s_up); }
-      // golden section in log(sigma)
+      // golden section in log(sigma) over [lo, up] (IPOPT's search), then IPOPT's end-point check
       const double gr = 0.5 * (3.0 - std::sqrt(5.0));
-      double la = std::log(lo), lb = std::log(std::max(up, lo * (1 + 1e-12)));
-      double m1 = la + gr * (lb - la), m2 = lb - gr * (lb - la);
-      double f1 = qf(std::exp(m1)), f2 = qf(std::exp(m2));
-      for (int it = 0; it < 8 && (lb - la) > 1e-2 * std::fabs(lb) + 1e-12; ++it) {
-        if (f1 > f2) { la = m1; m1 = m2; f1 = f2; m2 = lb - gr * (lb - la); f2 = qf(std::exp(m2)); }
-        else { lb = m2; m2 = m1; f2 = f1; m1 = la + gr * (lb - la); f1 = qf(std::exp(m1)); }
+      double fsel = 0.0;
+      bool endpoint = false;
+      auto section = [&](double slo, double sup) {
+        double la = std::log(slo), lb = std::log(std::max(sup, slo * (1 + 1e-12)));
+        double m1 = la + gr * (lb - la), m2 = lb - gr * (lb - la);
+        double f1 = qf(std::exp(m1)), f2 = qf(std::exp(m2));
+        for (int it = 0; it < 8 && (lb - la) > 1e-2 * std::fabs(lb) + 1e-12; ++it) {
+          if (f1 > f2) { la = m1; m1 = m2; f1 = f2; m2 = lb - gr * (lb - la); f2 = qf(std::exp(m2)); }
+          else { lb = m2; m2 = m1; f2 = f1; m1 = la + gr * (lb - la); f1 = qf(std::exp(m1)); }
+        }
+        double sg = std::exp(f1 < f2 ? m1 : m2);
+        fsel = std::min(f1, f2);
+        const double qlo = qf(slo), qup = qf(sup);
+        endpoint = false;
+        if (qlo < fsel && qlo <= qup) { sg = slo; fsel = qlo; endpoint = true; }
+        else if (qup < fsel) { sg = sup; fsel = qup; endpoint = true; }
+        return sg;
+      };
+      sigma = section(lo, up);
+      // An end point that beats the section's interior result means the quality function is not
+      // unimodal on [lo, up] (observed on AC power flow: q(1e-6) = 655, q(1e-3) = 837, q(0.1) = 5.9,
+      // q(0.99) = 309: the section settles in the left basin, the check returns sigma = 0.99 and mu
+      // shrinks by 1 % per iteration for hundreds of iterations).  Only then (deviation from IPOPT's
+      // search, which stops here): a coarse log-spaced scan brackets the best basin and the section
+      // is repeated inside that bracket.
+      if (endpoint && up > lo * 10.0) {
+        const double grid[6] = {lo, 1e-4, 1e-2, 1e-1, 0.5, up};
+        double gs[6], gq[6];
+        int ng = 0;
+        for (int k = 0; k < 6; ++k) {
+          if (grid[k] < lo || grid[k] > up || (ng > 0 && grid[k] <= gs[ng - 1])) continue;
+          gs[ng] = grid[k]; gq[ng] = qf(grid[k]); ++ng;
+        }
+        int best = 0;
+        for (int k = 1; k < ng; ++k) if (gq[k] < gq[best]) best = k;
+        if (gq[best] < fsel && best > 0 && best + 1 < ng) {
+          const double f0 = fsel, s0 = sigma;
+          sigma = section(gs[best - 1], gs[best + 1]);
+          if (!(fsel < f0)) sigma = s0;
+        }
       }
-      sigma = std::exp(f1 < f2 ? m1 : m2);
-      const double fbest = std::min(f1, f2);
-      const double qlo = qf(lo), qup = qf(up);
-      if (qlo < fbest && qlo <= qup) sigma = lo;
-      else if (qup < fbest) sigma = up;
     }
     double nm = std::max(mu_floor, std::min(sigma * avg, mu_max));
     if (!std::isfinite(nm)) return false;
@@ -1503,6 +1548,8 @@ class Ipm {
   double last_ratio_ = 0.0;
   bool delta_w_used_last_iter_ = false;
   int sparse_singular_streak_ = 0;
+  int dc_fixed_count_ = 0;          // iterations whose wrong inertia the dual regularisation alone repaired
+  bool dc_fixed_last_ = false, always_dc_ = false;
   double *lanV = nullptr, *lanW = nullptr, *lanQ = nullptr;
   double t_begin_ = 0.0;
 };

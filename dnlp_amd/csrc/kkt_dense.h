@@ -25,6 +25,14 @@ struct DenseKkt {
   i64 pivot_max_n = 2048;
   i64 n_fixed = 0;             // number of fixed variables (set by the interior-point driver)
   bool pivoted = true;
+  // Orders between optimistic_min_n and pivot_max_n on a host-driven space start WITHOUT pivoting
+  // (blocked LDL^T, ~50 launches per 512 columns instead of two per column: 17 -> 2 ms at order
+  // 1472) and switch to Bunch-Kaufman for good at the first zero pivot met with delta_w = 0
+  // (variables without curvature, as dnlp2smooth leaves them).
+  bool optimistic = false;
+  int optimistic_zero_streak = 0;   // consecutive delta_w = 0 attempts that met a zero pivot
+  i64 optimistic_min_n = static_cast<i64>(1) << 40;   // off unless the option kkt_optimistic_min_n lowers it:
+                                                      // nonconvex problems can reach another local optimum
   typename E::LdltWork lw;
   // sparse mode (sparse_plan.h / sparse_ldl.h): static-pattern LDL^T instead of the dense matrix
   bool sparse = false;
@@ -59,6 +67,11 @@ struct DenseKkt {
     ipiv = ex->template alloc<i32>(static_cast<size_t>(n));
     work = ex->template alloc<double>(static_cast<size_t>(n));
     pivoted = n <= pivot_max_n;
+    optimistic = false;
+    optimistic_zero_streak = 0;
+    if constexpr (E::has_host_control) {
+      if (pivoted && n > optimistic_min_n) { optimistic = true; pivoted = false; }
+    }
     lw.padded = true;
     ex->ldlt_prepare(lw, n, ld, pivoted);
   }
@@ -135,7 +148,19 @@ struct DenseKkt {
       }
     }
     lw.expect_neg = static_cast<int>(m);
-    return ex->ldlt_factor(lw, K, n, ld, ipiv, pivoted, nneg, nzero);
+    const bool ok = ex->ldlt_factor(lw, K, n, ld, ipiv, pivoted, nneg, nzero);
+    if constexpr (E::has_host_control) {
+      // one such attempt is tolerated (at the start the multipliers are zero and variables that only
+      // occur in nonlinear constraints have no curvature yet: delta_w handles that iteration)
+      if (optimistic && dw == 0.0) optimistic_zero_streak = (!ok || *nzero > 0) ? optimistic_zero_streak + 1 : 0;
+      if (optimistic && dw == 0.0 && optimistic_zero_streak >= 2) {
+        optimistic = false;
+        pivoted = true;
+        ex->ldlt_prepare(lw, n, ld, true);
+        return assemble_factor(md, jv, Sx, D, fixmask, dw, nneg, nzero);
+      }
+    }
+    return ok;
   }
 
   DNLP_HD void solve(const double* rhs, double* sol) {

@@ -67,6 +67,7 @@ def test_cpu_power_flow_iteration_count_equals_ipopt():
     opts = dict(HIPNLP.DEFAULT_OPTIONS)
     opts["least_square_init_duals"] = "no"
     opts["linear_solver"] = "dense"            # Bunch-Kaufman pivoting, the analogue of IPOPT's MA27 / MUMPS
+    opts["kkt_optimistic_min_n"] = 1 << 30     # ... from the first factorisation on (no unpivoted attempt)
     for k, v in opts.items():
         h.set_option(k, v)
     info = h.solve(data["x0"])
