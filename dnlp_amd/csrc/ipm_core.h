@@ -687,6 +687,7 @@ class Ipm {
     bool ok = kkt_->assemble_factor(*md_, jv, Sx, Dd, fixmask, dw, &nneg, &nzero);
     stats.t_factor += now_sec() - t0;
     stats.factorizations++;
+    last_nneg_ = nneg;
     if (!ok) return 2;
     if (nzero > 0) return 2;
     return nneg == m ? 0 : 1;
@@ -759,18 +760,28 @@ class Ipm {
       if (r == 1) dc_fixed_last_ = false;
     }
     const double dw_start = delta_w;
-    int wrong_no_dc = 0;
+    int wrong_no_dc = 0, nneg_seen = -1;
     for (int k = 0; k < 100; ++k) {
       int r2 = attempt(delta_w, delta_c);
       if (r2 == 0) { delta_w_last = delta_w; if (!always_dc_) dc_fixed_last_ = false; return true; }
       if (r2 == 2 && delta_c == 0.0) delta_c = dc_val;
-      // three growing delta_w without the right inertia and without delta_c: suspect the Jacobian
-      if (r2 == 1 && delta_c == 0.0 && ++wrong_no_dc >= 3) {
-        int r3 = attempt(0.0, dc_val);
-        if (r3 == 0) { delta_c = dc_val; delta_w = 0.0; dc_fixed(); return true; }
-        r3 = attempt(dw_start, dc_val);
-        if (r3 == 0) { delta_c = dc_val; delta_w = delta_w_last = dw_start; dc_fixed(); return true; }
-        delta_c = dc_val;                       // keep it and go on growing delta_w
+      // Three growing delta_w that leave the SAME wrong number of negative pivots (negative curvature
+      // would shed them one by one as delta_w grows; an abandoned attempt reports no usable count):
+      // suspect the Jacobian and try the dual regularisation.
+      if (r2 == 1 && delta_c == 0.0) {
+        if (last_nneg_ < 1000000 && (nneg_seen < 0 || last_nneg_ == nneg_seen)) ++wrong_no_dc; else wrong_no_dc = 0;
+        nneg_seen = last_nneg_ < 1000000 ? last_nneg_ : -1;
+        if (wrong_no_dc >= 3) {
+          int r3 = attempt(0.0, dc_val);
+          if (r3 == 0) { delta_c = dc_val; delta_w = 0.0; dc_fixed(); return true; }
+          r3 = attempt(dw_start, dc_val);
+          if (r3 == 0) { delta_c = dc_val; delta_w = delta_w_last = dw_start; dc_fixed(); return true; }
+          delta_c = dc_val;                       // keep it and go on growing delta_w
+        } else if (delta_w > 1e20) {
+          delta_c = dc_val;                       // backstop: nothing helped up to 1e20
+          delta_w = dw_start;
+          continue;
+        }
       }
       // with a certified lower bound in hand the trial is already in the right decade: grow gently
       if (have_lb && dw_lb > 0.0 && delta_w <= 64.0 * dw_lb) delta_w *= 2.0;
@@ -1548,6 +1559,7 @@ class Ipm {
   double last_ratio_ = 0.0;
   bool delta_w_used_last_iter_ = false;
   int sparse_singular_streak_ = 0;
+  int last_nneg_ = 0;               // negative pivots reported by the last factorisation attempt
   int dc_fixed_count_ = 0;          // iterations whose wrong inertia the dual regularisation alone repaired
   bool dc_fixed_last_ = false, always_dc_ = false;
   double *lanV = nullptr, *lanW = nullptr, *lanQ = nullptr;
