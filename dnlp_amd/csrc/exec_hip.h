@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(kBlock) v_axpy_kernel(int k, const double* __r
 // instruction), so resident wavefronts matter more than registers for the libm paths.
 template <int NE, int WPE>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-fused_eval_kernel(FusedProg P, const double* __restrict__ x, const double* __restrict__ consts,
+fused_eval_kernel(FusedSlotProg P, const double* __restrict__ x, const double* __restrict__ consts,
                   double* __restrict__ grad, double* __restrict__ partial) {
   extern __shared__ double fz_slots[];
   __shared__ double sm[kBlock / 64];
@@ -626,7 +626,7 @@ fused_eval_kernel(FusedProg P, const double* __restrict__ x, const double* __res
     for (int e = 0; e < NE; ++e) valid[e] = base + threadIdx.x + static_cast<i64>(e) * kBlock < P.nelem;
     const i64 wbase = base + P.win_lo;
     acc += fused_elements<NE>(P, base + threadIdx.x, kBlock, valid, x, consts,
-                              [=](int k, int e) -> double& { return mine[(k * NE + e) * kBlock]; },
+                              [=](int k, int e) -> double& { return mine[(k * NE + e) * kBlock]; },   // slot-major: conflict-free
                               [=](i64 idx, double v) {
                                 const i64 t = idx - wbase;
                                 if (t >= 0 && t < win) unsafeAtomicAdd(&gwin[t], v);      // LDS
@@ -760,6 +760,7 @@ struct HipExec : HostControlled {
     DNLP_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     DNLP_HIP_CHECK(hipMalloc(&d_partial, sizeof(double) * kMaxPartials));
     DNLP_HIP_CHECK(hipHostMalloc(&h_partial, sizeof(double) * kMaxPartials));
+    if (const char* v = std::getenv("DNLP_FUSED_NE")) fused_ne_override = std::atoi(v);
   }
   ~HipExec() {
     hipSetDevice(device);
@@ -931,18 +932,32 @@ struct HipExec : HostControlled {
     }
     DNLP_LAUNCH_CHECK();
   }
-  double fused_eval(const FusedProg& P, const double* x, const double* consts, double* grad) {
+  template <int NE, int WPE>
+  void fused_launch(const FusedSlotProg& P, const double* x, const double* consts, double* grad, i64 blocks) {
+    const size_t lds = static_cast<size_t>(P.nslots) * NE * kBlock * sizeof(double);
+    hipLaunchKernelGGL((fused_eval_kernel<NE, WPE>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), lds, stream, P, x,
+                       consts, grad, d_partial);
+  }
+  double fused_eval(const FusedSlotProg& P, const double* x, const double* consts, double* grad) {
     if (P.nelem <= 0) return 0.0;
-    // one element per lane, register budget capped for 6 wavefronts per SIMD.  Measured on the 16 n
-    // measure at n = 1e8: {1 element / 3 wavefronts: 447, 1 / 6: 553, 1 / 8: 559, 2 / 3: 490, 4 / 2: 309}
-    // GB/s — the interpreter is bound by LDS / atomic latency, not by opcode decode.
-    constexpr int NE = 1;
-    const i64 tile = static_cast<i64>(kBlock) * NE;
+    // Elements per lane: the interpreter is bound by its per-op decode / branch / LDS round trip,
+    // which NE independent element chains share; the slot form keeps the register file small
+    // enough (slots x NE x 2 KB per workgroup) for that without giving up resident wavefronts.
+    // Small problems keep one element per lane (more workgroups than CUs matters more there).
+    // Measured at n = 1e8 (Rosenbrock, 22 ops over 5 slots, 16 n measure): NE 1: 442, 2: 507,
+    // 4: 702 (4 wavefronts/SIMD; 6: 556, 3: 694), 8: 398 GB/s; the same interpreter with its slots in
+    // VGPRs (s_set_gpr_idx relative addressing, 162-214 registers) reached 284-324 GB/s.
+    int ne = 1;
+    if (P.nelem >= (static_cast<i64>(1) << 19) && P.nslots * 4 * kBlock * 8 <= 48 * 1024) ne = 4;
+    else if (P.nelem >= (static_cast<i64>(1) << 18) && P.nslots * 2 * kBlock * 8 <= 48 * 1024) ne = 2;
+    if (fused_ne_override == 1 || fused_ne_override == 2 || (fused_ne_override == 4 && P.nslots * 4 * kBlock * 8 <= 64 * 1024))
+      ne = fused_ne_override;
+    const i64 tile = static_cast<i64>(kBlock) * ne;
     i64 blocks = (P.nelem + tile - 1) / tile;
     if (blocks > kMaxPartials) blocks = kMaxPartials;
-    const size_t lds = static_cast<size_t>(P.n) * NE * kBlock * sizeof(double);
-    hipLaunchKernelGGL((fused_eval_kernel<NE, 6>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), lds, stream, P, x, consts,
-                       grad, d_partial);
+    if (ne == 4) fused_launch<4, 4>(P, x, consts, grad, blocks);
+    else if (ne == 2) fused_launch<2, 6>(P, x, consts, grad, blocks);
+    else fused_launch<1, 6>(P, x, consts, grad, blocks);
     DNLP_LAUNCH_CHECK();
     DNLP_HIP_CHECK(hipMemcpyAsync(h_partial, d_partial, sizeof(double) * static_cast<size_t>(blocks), hipMemcpyDeviceToHost, stream));
     DNLP_HIP_CHECK(hipStreamSynchronize(stream));
@@ -950,6 +965,7 @@ struct HipExec : HostControlled {
     for (i64 k = 0; k < blocks; ++k) f += h_partial[k];
     return f;
   }
+  int fused_ne_override = 0;     // DNLP_FUSED_NE = 1 | 2 | 4 (measurement sweeps)
   void coo_mult(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out, bool trans) {
     if (nnz <= 0) return;
     hipLaunchKernelGGL(coo_mult_kernel, dim3(static_cast<unsigned>((nnz + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,

@@ -14,6 +14,8 @@
 // the host space of the test oracle runs the same function with a local array.
 #pragma once
 #include <algorithm>
+#include <stdexcept>
+#include <vector>
 
 #include "atom_math.h"
 #include "tape.h"
@@ -37,100 +39,210 @@ struct FusedProg {
   int win_extra = -1;        // -1: no window (strided / far-apart loads): global atomics per load
 };
 
-// NE elements per call (instruction-major: one opcode decode serves NE independent element
-// chains).  S: slot accessor  double& S(int k, int e);  G: scatter  void G(i64 index, double value).
-// Elements i0 + e * estride, e < NE; elements >= P.nelem are skipped by the caller's `valid` mask.
-template <int NE, class S, class G>
-DNLP_HD inline double fused_elements(const FusedProg& P, i64 i0, i64 estride, const bool (&valid)[NE],
-                                     const double* __restrict__ x, const double* __restrict__ consts,
-                                     S slot, G scatter) {
-  const int n = P.n;
-  // opcode dispatch OUTSIDE the element loop: one decode serves NE independent element chains
-#define DNLP_FZ_EACH for (int e = 0; e < NE; ++e) if (valid[e])
+// ---- slot program ---------------------------------------------------------------------------
+// The tree program is differentiated ON THE HOST, once: forward ops, then the reverse sweep written
+// out as ordinary three-address ops (adjoint of a unary = adjoint * stored derivative, of a product =
+// adjoint * the other factor, ...).  A linear-scan register allocation over that straight-line code
+// maps every value / derivative / adjoint to a physical slot; a slot is reused as soon as its last
+// reader has run (in place when the reader is the writer).  Rosenbrock: 11 tree instructions ->
+// 21 ops over 4 slots instead of 11 slots, which is what lets the device kernel keep FOUR elements
+// per lane in LDS and amortise one opcode decode over four independent element chains.
+constexpr int kFusedMaxOps = 112, kFusedMaxRefs = 32;
+enum FusedSlotOp : unsigned char {
+  S_LOADV = 0, S_LOADC, S_UNARY, S_ADD, S_SUB, S_MUL, S_DIV, S_SCALE, S_ADDC, S_SET, S_ACCF, S_SCATTER
+};
+
+struct FusedSlotProg {
+  int nops = 0, nslots = 0;
+  i64 nelem = 0;
+  // d: destination slot; s1, s2: source slots (S_UNARY: s2 = slot of the derivative);
+  // u: unary opcode (S_UNARY) or reference index (S_LOADV / S_LOADC / S_SCATTER)
+  unsigned char op[kFusedMaxOps], d[kFusedMaxOps], s1[kFusedMaxOps], s2[kFusedMaxOps], u[kFusedMaxOps];
+  double p[kFusedMaxOps], p2[kFusedMaxOps];
+  i64 roff[kFusedMaxRefs], rstride[kFusedMaxRefs];
+  i64 win_lo = 0;            // gradient window (see FusedProg)
+  int win_extra = -1;
+};
+
+// Host: tree program -> slot program.  Throws when the expansion exceeds the fixed capacities.
+inline FusedSlotProg fused_compile(const FusedProg& T) {
+  const int n = T.n;
+  struct VOp { int op, d, d2, s1, s2, u; double p, p2; };
+  std::vector<VOp> ops;
+  std::vector<i64> roff, rstride;
+  auto ref = [&](i64 off, i64 st) {
+    for (size_t k = 0; k < roff.size(); ++k) if (roff[k] == off && rstride[k] == st) return static_cast<int>(k);
+    roff.push_back(off); rstride.push_back(st);
+    return static_cast<int>(roff.size() - 1);
+  };
+  // virtual registers: value k, derivative n + k, adjoint 2n + k, temporary 3n + k
+  auto V = [&](int k) { return k; };
+  auto G = [&](int k) { return n + k; };
+  std::vector<int> adj(static_cast<size_t>(n), -1);       // resolved adjoint register of instruction k
   for (int k = 0; k < n; ++k) {
-    const int op = P.op[k], a = P.a[k], b = P.b[k];
-    const i64 off = P.off[k], st = P.stride[k];
-    const double p = P.p[k], p2 = P.p2[k];
-    switch (op) {
-      case F_LOADV:
-#pragma unroll
-        DNLP_FZ_EACH slot(k, e) = x[off + st * (i0 + e * estride)];
-        break;
-      case F_LOADC:
-#pragma unroll
-        DNLP_FZ_EACH slot(k, e) = consts[off + st * (i0 + e * estride)];
-        break;
-      case F_UNARY:
-#pragma unroll
-        DNLP_FZ_EACH { double v, g1, g2; unary_rules(b, slot(a, e), p, p2, v, g1, g2); slot(k, e) = v; }
-        break;
-      case F_ADD:
-#pragma unroll
-        DNLP_FZ_EACH slot(k, e) = slot(a, e) + slot(b, e);
-        break;
-      case F_SUB:
-#pragma unroll
-        DNLP_FZ_EACH slot(k, e) = slot(a, e) - slot(b, e);
-        break;
-      case F_MUL:
-#pragma unroll
-        DNLP_FZ_EACH slot(k, e) = slot(a, e) * slot(b, e);
-        break;
-      case F_SCALE:
-#pragma unroll
-        DNLP_FZ_EACH slot(k, e) = p * slot(a, e);
-        break;
-      case F_ADDC:
-#pragma unroll
-        DNLP_FZ_EACH slot(k, e) = slot(a, e) + p;
-        break;
-      default:
-#pragma unroll
-        DNLP_FZ_EACH slot(k, e) = slot(a, e) / slot(b, e);
-        break;
+    const int o = T.op[k], a = T.a[k], b = T.b[k];
+    switch (o) {
+      case F_LOADV: ops.push_back({S_LOADV, V(k), -1, -1, -1, ref(T.off[k], T.stride[k]), 0, 0}); break;
+      case F_LOADC: ops.push_back({S_LOADC, V(k), -1, -1, -1, ref(T.off[k], T.stride[k]), 0, 0}); break;
+      case F_UNARY: ops.push_back({S_UNARY, V(k), G(k), V(a), -1, b, T.p[k], T.p2[k]}); break;
+      case F_ADD: ops.push_back({S_ADD, V(k), -1, V(a), V(b), 0, 0, 0}); break;
+      case F_SUB: ops.push_back({S_SUB, V(k), -1, V(a), V(b), 0, 0, 0}); break;
+      case F_MUL: ops.push_back({S_MUL, V(k), -1, V(a), V(b), 0, 0, 0}); break;
+      case F_DIV: ops.push_back({S_DIV, V(k), -1, V(a), V(b), 0, 0, 0}); break;
+      case F_SCALE: ops.push_back({S_SCALE, V(k), -1, V(a), -1, 0, T.p[k], 0}); break;
+      case F_ADDC: ops.push_back({S_ADDC, V(k), -1, V(a), -1, 0, T.p[k], 0}); break;
+      default: throw std::runtime_error("bad fused opcode");
     }
   }
-  double fsum = 0.0;
-#pragma unroll
-  DNLP_FZ_EACH { fsum += slot(n - 1, e); slot(n - 1, e) = 1.0; }
+  ops.push_back({S_ACCF, -1, -1, V(n - 1), -1, 0, 0, 0});
+  adj[static_cast<size_t>(n - 1)] = 2 * n + (n - 1);
+  ops.push_back({S_SET, adj[static_cast<size_t>(n - 1)], -1, -1, -1, 0, 1.0, 0});
   for (int k = n - 1; k >= 0; --k) {
-    const int op = P.op[k], a = P.a[k], b = P.b[k];
-    const i64 off = P.off[k], st = P.stride[k];
-    const double p = P.p[k], p2 = P.p2[k];
-    switch (op) {
-      case F_LOADV:
-#pragma unroll
-        DNLP_FZ_EACH scatter(off + st * (i0 + e * estride), slot(k, e));
-        break;
+    const int o = T.op[k], a = T.a[k], b = T.b[k], ak = adj[static_cast<size_t>(k)];
+    if (ak < 0) throw std::runtime_error("fused program is not a tree");
+    const int Aa = 2 * n + a, Ab = 2 * n + b;
+    switch (o) {
+      case F_LOADV: ops.push_back({S_SCATTER, -1, -1, ak, -1, ref(T.off[k], T.stride[k]), 0, 0}); break;
       case F_LOADC: break;
-      case F_UNARY:
-#pragma unroll
-        DNLP_FZ_EACH { double v, g1, g2; unary_rules(b, slot(a, e), p, p2, v, g1, g2); slot(a, e) = slot(k, e) * g1; }
-        break;
-      case F_ADD:
-#pragma unroll
-        DNLP_FZ_EACH { const double g = slot(k, e); slot(a, e) = g; slot(b, e) = g; }
-        break;
+      case F_UNARY: ops.push_back({S_MUL, Aa, -1, ak, G(k), 0, 0, 0}); adj[static_cast<size_t>(a)] = Aa; break;
+      case F_ADD: adj[static_cast<size_t>(a)] = ak; adj[static_cast<size_t>(b)] = ak; break;
       case F_SUB:
-#pragma unroll
-        DNLP_FZ_EACH { const double g = slot(k, e); slot(a, e) = g; slot(b, e) = -g; }
-        break;
+        adj[static_cast<size_t>(a)] = ak;
+        ops.push_back({S_SCALE, Ab, -1, ak, -1, 0, -1.0, 0}); adj[static_cast<size_t>(b)] = Ab; break;
       case F_MUL:
+        ops.push_back({S_MUL, Aa, -1, ak, V(b), 0, 0, 0}); adj[static_cast<size_t>(a)] = Aa;
+        ops.push_back({S_MUL, Ab, -1, ak, V(a), 0, 0, 0}); adj[static_cast<size_t>(b)] = Ab; break;
+      case F_SCALE: ops.push_back({S_SCALE, Aa, -1, ak, -1, 0, T.p[k], 0}); adj[static_cast<size_t>(a)] = Aa; break;
+      case F_ADDC: adj[static_cast<size_t>(a)] = ak; break;
+      default: {   // k = a / b:  adj_a = adj_k / b ;  adj_b = -adj_a * k
+        const int Tm = 3 * n + k;
+        ops.push_back({S_DIV, Aa, -1, ak, V(b), 0, 0, 0}); adj[static_cast<size_t>(a)] = Aa;
+        ops.push_back({S_MUL, Tm, -1, Aa, V(k), 0, 0, 0});
+        ops.push_back({S_SCALE, Ab, -1, Tm, -1, 0, -1.0, 0}); adj[static_cast<size_t>(b)] = Ab; break; }
+    }
+  }
+  if (ops.size() > static_cast<size_t>(kFusedMaxOps) || roff.size() > static_cast<size_t>(kFusedMaxRefs))
+    throw std::runtime_error("fused program too long for the slot form");
+  // liveness: last op that reads each virtual register
+  const int nv = 4 * n;
+  std::vector<int> last(static_cast<size_t>(nv), -1), slot(static_cast<size_t>(nv), -1);
+  for (size_t i = 0; i < ops.size(); ++i) {
+    if (ops[i].s1 >= 0) last[static_cast<size_t>(ops[i].s1)] = static_cast<int>(i);
+    if (ops[i].s2 >= 0) last[static_cast<size_t>(ops[i].s2)] = static_cast<int>(i);
+  }
+  std::vector<int> free_slots;
+  int nslots = 0;
+  auto take = [&]() {
+    if (!free_slots.empty()) {
+      auto it = std::min_element(free_slots.begin(), free_slots.end());
+      const int sl = *it; free_slots.erase(it); return sl;
+    }
+    return nslots++;
+  };
+  FusedSlotProg S;
+  for (size_t i = 0; i < ops.size(); ++i) {
+    const VOp& o = ops[i];
+    const int ps1 = o.s1 >= 0 ? slot[static_cast<size_t>(o.s1)] : 0, ps2 = o.s2 >= 0 ? slot[static_cast<size_t>(o.s2)] : 0;
+    // sources read for the last time here give their slots back BEFORE the destinations are placed
+    // (every op reads all its sources into registers before it writes)
+    if (o.s1 >= 0 && last[static_cast<size_t>(o.s1)] == static_cast<int>(i)) free_slots.push_back(ps1);
+    if (o.s2 >= 0 && o.s2 != o.s1 && last[static_cast<size_t>(o.s2)] == static_cast<int>(i)) free_slots.push_back(ps2);
+    int pd = 0, pd2 = 0;
+    if (o.d >= 0) { pd = take(); slot[static_cast<size_t>(o.d)] = pd; }
+    if (o.d2 >= 0) { pd2 = take(); slot[static_cast<size_t>(o.d2)] = pd2; }
+    // a destination nobody reads (adjoint of a constant branch) is released at once
+    if (o.d >= 0 && last[static_cast<size_t>(o.d)] < 0) free_slots.push_back(pd);
+    if (o.d2 >= 0 && last[static_cast<size_t>(o.d2)] < 0) free_slots.push_back(pd2);
+    S.op[i] = static_cast<unsigned char>(o.op);
+    S.d[i] = static_cast<unsigned char>(pd);
+    S.s1[i] = static_cast<unsigned char>(ps1);
+    S.s2[i] = static_cast<unsigned char>(o.op == S_UNARY ? pd2 : ps2);
+    S.u[i] = static_cast<unsigned char>(o.u);
+    S.p[i] = o.p; S.p2[i] = o.p2;
+  }
+  if (nslots > 255) throw std::runtime_error("fused program needs too many slots");
+  S.nops = static_cast<int>(ops.size());
+  S.nslots = nslots;
+  S.nelem = T.nelem;
+  for (size_t k = 0; k < roff.size(); ++k) { S.roff[k] = roff[k]; S.rstride[k] = rstride[k]; }
+  S.win_lo = T.win_lo;
+  S.win_extra = T.win_extra;
+  return S;
+}
+
+// NE elements per call (op-major: one opcode decode serves NE independent element chains).
+// S: slot accessor  double& S(int slot, int e);  G: scatter  void G(i64 index, double value).
+// Elements i0 + e * estride, e < NE; elements >= P.nelem are skipped through `valid`.
+template <int NE, class S, class G>
+DNLP_HD inline double fused_elements(const FusedSlotProg& P, i64 i0, i64 estride, const bool (&valid)[NE],
+                                     const double* __restrict__ x, const double* __restrict__ consts,
+                                     S slot, G scatter) {
+  double fsum = 0.0;
+  const int nops = P.nops;
+#define DNLP_FZ_EACH for (int e = 0; e < NE; ++e) if (valid[e])
+  for (int i = 0; i < nops; ++i) {
+    const int op = P.op[i], d = P.d[i], s1 = P.s1[i], s2 = P.s2[i], u = P.u[i];
+    switch (op) {
+      case S_LOADV: {
+        const i64 off = P.roff[u], st = P.rstride[u];
 #pragma unroll
-        DNLP_FZ_EACH { const double g = slot(k, e), va = slot(a, e), vb = slot(b, e); slot(a, e) = g * vb; slot(b, e) = g * va; }
-        break;
-      case F_SCALE:
+        DNLP_FZ_EACH slot(d, e) = x[off + st * (i0 + e * estride)];
+        break; }
+      case S_LOADC: {
+        const i64 off = P.roff[u], st = P.rstride[u];
 #pragma unroll
-        DNLP_FZ_EACH slot(a, e) = slot(k, e) * p;
-        break;
-      case F_ADDC:
+        DNLP_FZ_EACH slot(d, e) = consts[off + st * (i0 + e * estride)];
+        break; }
+      case S_UNARY: {
+        const double p = P.p[i], p2 = P.p2[i];
+        if (u == OP_POWER && p == 2.0 && p2 == 2.0) {          // squares: no libm, no compare chain
 #pragma unroll
-        DNLP_FZ_EACH slot(a, e) = slot(k, e);
-        break;
-      default:
+          DNLP_FZ_EACH { const double w = slot(s1, e); slot(d, e) = w * w; slot(s2, e) = 2.0 * w; }
+        } else {
 #pragma unroll
-        DNLP_FZ_EACH { const double g = slot(k, e), va = slot(a, e), vb = slot(b, e); slot(a, e) = g / vb; slot(b, e) = -g * va / (vb * vb); }
+          DNLP_FZ_EACH { double v, g1, g2; unary_rules(u, slot(s1, e), p, p2, v, g1, g2); slot(d, e) = v; slot(s2, e) = g1; }
+        }
+        break; }
+      case S_ADD:
+#pragma unroll
+        DNLP_FZ_EACH { const double a = slot(s1, e), b = slot(s2, e); slot(d, e) = a + b; }
         break;
+      case S_SUB:
+#pragma unroll
+        DNLP_FZ_EACH { const double a = slot(s1, e), b = slot(s2, e); slot(d, e) = a - b; }
+        break;
+      case S_MUL:
+#pragma unroll
+        DNLP_FZ_EACH { const double a = slot(s1, e), b = slot(s2, e); slot(d, e) = a * b; }
+        break;
+      case S_DIV:
+#pragma unroll
+        DNLP_FZ_EACH { const double a = slot(s1, e), b = slot(s2, e); slot(d, e) = a / b; }
+        break;
+      case S_SCALE: {
+        const double p = P.p[i];
+#pragma unroll
+        DNLP_FZ_EACH slot(d, e) = p * slot(s1, e);
+        break; }
+      case S_ADDC: {
+        const double p = P.p[i];
+#pragma unroll
+        DNLP_FZ_EACH slot(d, e) = slot(s1, e) + p;
+        break; }
+      case S_SET: {
+        const double p = P.p[i];
+#pragma unroll
+        DNLP_FZ_EACH slot(d, e) = p;
+        break; }
+      case S_ACCF:
+#pragma unroll
+        DNLP_FZ_EACH fsum += slot(s1, e);
+        break;
+      default: {   // S_SCATTER
+        const i64 off = P.roff[u], st = P.rstride[u];
+#pragma unroll
+        DNLP_FZ_EACH scatter(off + st * (i0 + e * estride), slot(s1, e));
+        break; }
     }
   }
 #undef DNLP_FZ_EACH
@@ -140,7 +252,7 @@ DNLP_HD inline double fused_elements(const FusedProg& P, i64 i0, i64 estride, co
 template <class E>
 struct FusedObjective {
   E* ex = nullptr;
-  std::vector<FusedProg> progs;
+  std::vector<FusedSlotProg> progs;
   double* consts = nullptr;   // exec space
   double c0 = 0.0;
   i64 nfree = 0;
@@ -180,7 +292,7 @@ struct FusedObjective {
         }
         if (any && unit && hi - lo <= 64) { P.win_lo = lo; P.win_extra = static_cast<int>(hi - lo); }
       }
-      progs.push_back(P);
+      progs.push_back(fused_compile(P));
     }
     consts = ex->template alloc<double>(static_cast<size_t>(nconst > 0 ? nconst : 1));
     if (nconst > 0) ex->h2d(consts, tb.f64("fz_consts"), sizeof(double) * static_cast<size_t>(nconst));
@@ -192,7 +304,7 @@ struct FusedObjective {
   double eval(const double* x, double* grad) {
     ex->zero(grad, sizeof(double) * static_cast<size_t>(nfree));
     double f = c0;
-    for (const FusedProg& P : progs) f += ex->fused_eval(P, x, consts, grad);
+    for (const FusedSlotProg& P : progs) f += ex->fused_eval(P, x, consts, grad);
     return f;
   }
 };

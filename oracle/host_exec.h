@@ -70,8 +70,8 @@ struct HostExec : HostControlled {
   void sparse_solve(const SparsePlan& pl, const double* vals, double* x) { sparse_ldl_solve(pl, vals, x, SeqPar()); }
 
   // fused element program (csrc/fused_obj.h): sequential host loop, local slots
-  double fused_eval(const FusedProg& P, const double* x, const double* consts, double* grad) {
-    double f = 0.0, slots[kFusedMaxInstr];
+  double fused_eval(const FusedSlotProg& P, const double* x, const double* consts, double* grad) {
+    double f = 0.0, slots[256];
     const bool valid[1] = {true};
     for (i64 i = 0; i < P.nelem; ++i)
       f += fused_elements<1>(P, i, 0, valid, x, consts, [&](int k, int) -> double& { return slots[k]; },
