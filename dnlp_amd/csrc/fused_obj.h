@@ -15,6 +15,7 @@
 #pragma once
 #include <algorithm>
 #include <stdexcept>
+#include <utility>
 #include <vector>
 
 #include "atom_math.h"
@@ -49,7 +50,7 @@ struct FusedProg {
 // per lane in LDS and amortise one opcode decode over four independent element chains.
 constexpr int kFusedMaxOps = 112, kFusedMaxRefs = 32;
 enum FusedSlotOp : unsigned char {
-  S_LOADV = 0, S_LOADC, S_UNARY, S_ADD, S_SUB, S_MUL, S_DIV, S_SCALE, S_ADDC, S_SET, S_ACCF, S_SCATTER
+  S_LOADV = 0, S_LOADC, S_UNARY, S_ADD, S_SUB, S_MUL, S_DIV, S_SCALE, S_ADDC, S_SET, S_ACCF, S_SCATTER, S_AXPB
 };
 
 struct FusedSlotProg {
@@ -78,9 +79,51 @@ inline FusedSlotProg fused_compile(const FusedProg& T) {
   // virtual registers: value k, derivative n + k, adjoint 2n + k, temporary 3n + k
   auto V = [&](int k) { return k; };
   auto G = [&](int k) { return n + k; };
-  std::vector<int> adj(static_cast<size_t>(n), -1);       // resolved adjoint register of instruction k
+  std::vector<int> adj(static_cast<size_t>(n), -1);       // adjoint register of instruction k (-1: a constant)
+  // forward peephole: scale followed by shift (or shift followed by scale) is one op  d = p s + q
+  std::vector<int> cons(static_cast<size_t>(n), -1);
+  for (int k = 0; k < n; ++k) {
+    if (T.op[k] >= F_UNARY) cons[static_cast<size_t>(T.a[k])] = k;
+    if (T.op[k] == F_ADD || T.op[k] == F_SUB || T.op[k] == F_MUL || T.op[k] == F_DIV) cons[static_cast<size_t>(T.b[k])] = k;
+  }
+  std::vector<char> deferred(static_cast<size_t>(n), 0);
+  // the root's add / sub / scale chain is never evaluated: its leaves are summed into f with
+  // weights (S_ACCF carries the weight), and their adjoints are the weights
+  std::vector<char> peeled(static_cast<size_t>(n), 0);
+  std::vector<std::pair<int, double>> roots;
+  {
+    std::vector<std::pair<int, double>> st{{n - 1, 1.0}};
+    while (!st.empty()) {
+      const auto [k, w] = st.back();
+      st.pop_back();
+      const int o = T.op[k];
+      if (o == F_ADD || o == F_SUB) {
+        peeled[static_cast<size_t>(k)] = 1;
+        st.push_back({T.b[k], o == F_SUB ? -w : w});
+        st.push_back({T.a[k], w});
+      } else if (o == F_SCALE) {
+        peeled[static_cast<size_t>(k)] = 1;
+        st.push_back({T.a[k], w * T.p[k]});
+      } else {
+        roots.push_back({k, w});
+      }
+    }
+  }
   for (int k = 0; k < n; ++k) {
     const int o = T.op[k], a = T.a[k], b = T.b[k];
+    const int ck = cons[static_cast<size_t>(k)];
+    if (peeled[static_cast<size_t>(k)]) continue;
+    if ((o == F_SCALE || o == F_ADDC) && ck >= 0 && T.op[ck] == (o == F_SCALE ? F_ADDC : F_SCALE) &&
+        !peeled[static_cast<size_t>(ck)] && !deferred[static_cast<size_t>(a)]) {
+      deferred[static_cast<size_t>(k)] = 1;       // emitted together with its consumer
+      continue;
+    }
+    if ((o == F_SCALE || o == F_ADDC) && deferred[static_cast<size_t>(a)]) {
+      const int src = V(T.a[a]);
+      if (o == F_ADDC) ops.push_back({S_AXPB, V(k), -1, src, -1, 0, T.p[a], T.p[k]});            // p_a x + q_k
+      else ops.push_back({S_AXPB, V(k), -1, src, -1, 0, T.p[k], T.p[k] * T.p[a]});                // p_k (x + q_a)
+      continue;
+    }
     switch (o) {
       case F_LOADV: ops.push_back({S_LOADV, V(k), -1, -1, -1, ref(T.off[k], T.stride[k]), 0, 0}); break;
       case F_LOADC: ops.push_back({S_LOADC, V(k), -1, -1, -1, ref(T.off[k], T.stride[k]), 0, 0}); break;
@@ -94,31 +137,50 @@ inline FusedSlotProg fused_compile(const FusedProg& T) {
       default: throw std::runtime_error("bad fused opcode");
     }
   }
-  ops.push_back({S_ACCF, -1, -1, V(n - 1), -1, 0, 0, 0});
-  adj[static_cast<size_t>(n - 1)] = 2 * n + (n - 1);
-  ops.push_back({S_SET, adj[static_cast<size_t>(n - 1)], -1, -1, -1, 0, 1.0, 0});
+  for (const auto& rw : roots) ops.push_back({S_ACCF, -1, -1, V(rw.first), -1, 0, rw.second, 0});
+  // Reverse sweep.  The adjoint of instruction k is carried as  fac[k] * (register adj[k]), with
+  // adj[k] = -1 meaning the pure constant fac[k]: constant factors (the root's 1, scales, signs of
+  // subtractions) never cost an op — they travel to the scatter, which applies them (S_SCATTER
+  // carries the weight); a product rule whose incoming adjoint is a pure constant is just an alias
+  // to the stored derivative / other factor.  Rosenbrock: 11 tree instructions -> 14 ops, 5 slots.
+  std::vector<double> fac(static_cast<size_t>(n), 0.0);
+  std::vector<char> seen(static_cast<size_t>(n), 0);
+  auto give = [&](int i, int reg, double c) { adj[static_cast<size_t>(i)] = reg; fac[static_cast<size_t>(i)] = c; seen[static_cast<size_t>(i)] = 1; };
+  give(n - 1, -1, 1.0);
   for (int k = n - 1; k >= 0; --k) {
-    const int o = T.op[k], a = T.a[k], b = T.b[k], ak = adj[static_cast<size_t>(k)];
-    if (ak < 0) throw std::runtime_error("fused program is not a tree");
-    const int Aa = 2 * n + a, Ab = 2 * n + b;
+    const int o = T.op[k], a = T.a[k], b = T.b[k];
+    if (!seen[static_cast<size_t>(k)]) throw std::runtime_error("fused program is not a tree");
+    int ak = adj[static_cast<size_t>(k)];
+    double c = fac[static_cast<size_t>(k)];
+    // adjoint register holding exactly the adjoint (factor folded in), for the rules that need it
+    auto materialise = [&]() {
+      if (ak < 0) { ak = 2 * n + k; ops.push_back({S_SET, ak, -1, -1, -1, 0, c, 0}); }
+      else if (c != 1.0) { ops.push_back({S_SCALE, 2 * n + k, -1, ak, -1, 0, c, 0}); ak = 2 * n + k; }
+      c = 1.0;
+    };
+    // child adjoint = c * ak * (register other)
+    auto times = [&](int child, int other) {
+      if (ak < 0) { give(child, other, c); return; }
+      ops.push_back({S_MUL, 2 * n + child, -1, ak, other, 0, 0, 0});
+      give(child, 2 * n + child, c);
+    };
     switch (o) {
-      case F_LOADV: ops.push_back({S_SCATTER, -1, -1, ak, -1, ref(T.off[k], T.stride[k]), 0, 0}); break;
+      case F_LOADV:
+        if (ak < 0) materialise();
+        ops.push_back({S_SCATTER, -1, -1, ak, -1, ref(T.off[k], T.stride[k]), c, 0});
+        break;
       case F_LOADC: break;
-      case F_UNARY: ops.push_back({S_MUL, Aa, -1, ak, G(k), 0, 0, 0}); adj[static_cast<size_t>(a)] = Aa; break;
-      case F_ADD: adj[static_cast<size_t>(a)] = ak; adj[static_cast<size_t>(b)] = ak; break;
-      case F_SUB:
-        adj[static_cast<size_t>(a)] = ak;
-        ops.push_back({S_SCALE, Ab, -1, ak, -1, 0, -1.0, 0}); adj[static_cast<size_t>(b)] = Ab; break;
-      case F_MUL:
-        ops.push_back({S_MUL, Aa, -1, ak, V(b), 0, 0, 0}); adj[static_cast<size_t>(a)] = Aa;
-        ops.push_back({S_MUL, Ab, -1, ak, V(a), 0, 0, 0}); adj[static_cast<size_t>(b)] = Ab; break;
-      case F_SCALE: ops.push_back({S_SCALE, Aa, -1, ak, -1, 0, T.p[k], 0}); adj[static_cast<size_t>(a)] = Aa; break;
-      case F_ADDC: adj[static_cast<size_t>(a)] = ak; break;
+      case F_UNARY: times(a, G(k)); break;
+      case F_ADD: give(a, ak, c); give(b, ak, c); break;
+      case F_SUB: give(a, ak, c); give(b, ak, -c); break;
+      case F_MUL: times(a, V(b)); times(b, V(a)); break;
+      case F_SCALE: give(a, ak, c * T.p[k]); break;
+      case F_ADDC: give(a, ak, c); break;
       default: {   // k = a / b:  adj_a = adj_k / b ;  adj_b = -adj_a * k
-        const int Tm = 3 * n + k;
-        ops.push_back({S_DIV, Aa, -1, ak, V(b), 0, 0, 0}); adj[static_cast<size_t>(a)] = Aa;
-        ops.push_back({S_MUL, Tm, -1, Aa, V(k), 0, 0, 0});
-        ops.push_back({S_SCALE, Ab, -1, Tm, -1, 0, -1.0, 0}); adj[static_cast<size_t>(b)] = Ab; break; }
+        materialise();
+        const int Aa = 2 * n + a, Tm = 3 * n + k;
+        ops.push_back({S_DIV, Aa, -1, ak, V(b), 0, 0, 0}); give(a, Aa, 1.0);
+        ops.push_back({S_MUL, Tm, -1, Aa, V(k), 0, 0, 0}); give(b, Tm, -1.0); break; }
     }
   }
   if (ops.size() > static_cast<size_t>(kFusedMaxOps) || roff.size() > static_cast<size_t>(kFusedMaxRefs))
@@ -234,14 +296,21 @@ DNLP_HD inline double fused_elements(const FusedSlotProg& P, i64 i0, i64 estride
 #pragma unroll
         DNLP_FZ_EACH slot(d, e) = p;
         break; }
-      case S_ACCF:
+      case S_AXPB: {
+        const double p = P.p[i], q = P.p2[i];
 #pragma unroll
-        DNLP_FZ_EACH fsum += slot(s1, e);
-        break;
+        DNLP_FZ_EACH slot(d, e) = p * slot(s1, e) + q;
+        break; }
+      case S_ACCF: {
+        const double p = P.p[i];
+#pragma unroll
+        DNLP_FZ_EACH fsum += p * slot(s1, e);
+        break; }
       default: {   // S_SCATTER
         const i64 off = P.roff[u], st = P.rstride[u];
+        const double p = P.p[i];
 #pragma unroll
-        DNLP_FZ_EACH scatter(off + st * (i0 + e * estride), slot(s1, e));
+        DNLP_FZ_EACH scatter(off + st * (i0 + e * estride), p * slot(s1, e));
         break; }
     }
   }

@@ -97,6 +97,70 @@ def test_mixed_objective_against_finite_differences_and_reduced_tape_solve():
     np.testing.assert_allclose(res["yes"]["x"], res["no"]["x"], rtol=1e-4, atol=1e-5)
 
 
+def _random_objective(seed, n=24):
+    """Random sums of elementwise trees over slices of two variables: exercises every rule of the
+    host-side reverse sweep (products, quotients, sub / scale / shift chains, constant adjoints)."""
+    rng = np.random.default_rng(seed)
+    x = cp.Variable(n)
+    y = cp.Variable(n)
+    x.value = rng.uniform(0.6, 1.4, n)
+    y.value = rng.uniform(0.6, 1.4, n)
+    m = n - 2
+
+    def leaf():
+        v = x if rng.random() < 0.5 else y
+        o = int(rng.integers(0, 3))
+        return v[o:o + m]
+
+    def tree(depth):
+        r = rng.random()
+        if depth == 0 or r < 0.15:
+            return leaf()
+        if r < 0.30:
+            return cp.multiply(tree(depth - 1), tree(depth - 1))
+        if r < 0.40:
+            return tree(depth - 1) / (1.5 + cp.square(tree(depth - 1)))
+        if r < 0.50:
+            return float(rng.uniform(-2, 2)) * tree(depth - 1) + float(rng.uniform(-1, 1))
+        if r < 0.60:
+            return float(rng.uniform(0.5, 2)) - tree(depth - 1)
+        if r < 0.70:
+            return tree(depth - 1) - tree(depth - 1)
+        if r < 0.78:
+            return cp.multiply(rng.uniform(0.5, 1.5, m), tree(depth - 1))
+        if r < 0.86:
+            return cp.square(tree(depth - 1))
+        if r < 0.93:
+            return cp.exp(0.3 * tree(depth - 1))
+        return cp.sin(tree(depth - 1))
+
+    f = 0
+    for _ in range(int(rng.integers(1, 4))):
+        f = f + float(rng.uniform(-2, 2)) * cp.sum(tree(3))
+    return cp.Problem(cp.Minimize(f + 0.1 * cp.sum_squares(x) + 0.1 * cp.sum_squares(y)), [])
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_slot_program_matches_tree_interpreter_on_random_trees(seed):
+    """csrc/fused_obj.h differentiates the tree on the host and reallocates its registers; the numpy
+    interpreter (oracle/fused_eval.py) walks the tree itself: same f and gradient."""
+    from oracle.fused_eval import numpy_eval
+    from oracle.oracle_capi import OracleProblem
+    prob = _random_objective(seed)
+    if build_fused_spec(prob) is None:
+        pytest.skip("tree outside the fused grammar")
+    data = _data(prob)
+    ta = data["tape_arrays"]
+    if not data.get("fused") or "free_idx" not in ta:
+        pytest.skip("program beyond the fused capacities")
+    free = np.asarray(ta["free_idx"])
+    z = np.asarray(data["x0"])[free]
+    f1, g1 = numpy_eval(ta, z)
+    f2, g2 = OracleProblem(serialize(ta)).eval_fused(z)
+    assert abs(f1 - f2) <= 1e-12 * max(1.0, abs(f1))
+    np.testing.assert_allclose(g2, g1, rtol=1e-11, atol=1e-11)
+
+
 @pytest.mark.gpu
 def test_device_fused_kernel_matches_interpreters(gpu_required):
     from dnlp_amd import _capi
