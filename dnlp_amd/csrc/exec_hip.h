@@ -625,13 +625,14 @@ fused_eval_kernel(FusedSlotProg P, const double* __restrict__ x, const double* _
 #pragma unroll
     for (int e = 0; e < NE; ++e) valid[e] = base + threadIdx.x + static_cast<i64>(e) * kBlock < P.nelem;
     const i64 wbase = base + P.win_lo;
-    acc += fused_elements<NE>(P, base + threadIdx.x, kBlock, valid, x, consts,
-                              [=](int k, int e) -> double& { return mine[(k * NE + e) * kBlock]; },   // slot-major: conflict-free
-                              [=](i64 idx, double v) {
-                                const i64 t = idx - wbase;
-                                if (t >= 0 && t < win) unsafeAtomicAdd(&gwin[t], v);      // LDS
-                                else unsafeAtomicAdd(&grad[idx], v);
-                              });
+    auto slots = [=](int k, int e) -> double& { return mine[(k * NE + e) * kBlock]; };   // slot-major: conflict-free
+    auto scat = [=](i64 idx, double v) {
+      const i64 t = idx - wbase;
+      if (t >= 0 && t < win) unsafeAtomicAdd(&gwin[t], v);      // LDS
+      else unsafeAtomicAdd(&grad[idx], v);
+    };
+    if (base + tile <= P.nelem) acc += fused_elements<NE, true>(P, base + threadIdx.x, kBlock, valid, x, consts, slots, scat);
+    else acc += fused_elements<NE, false>(P, base + threadIdx.x, kBlock, valid, x, consts, slots, scat);
     if (win) {
       __syncthreads();
       for (int t = threadIdx.x; t < win; t += kBlock) {
@@ -946,7 +947,9 @@ struct HipExec : HostControlled {
     // Small problems keep one element per lane (more workgroups than CUs matters more there).
     // Measured at n = 1e8 (Rosenbrock, 22 ops over 5 slots, 16 n measure): NE 1: 442, 2: 507,
     // 4: 702 (4 wavefronts/SIMD; 6: 556, 3: 694), 8: 398 GB/s; the same interpreter with its slots in
-    // VGPRs (s_set_gpr_idx relative addressing, 162-214 registers) reached 284-324 GB/s.
+    // VGPRs (s_set_gpr_idx relative addressing, 162-214 registers) reached 284-324 GB/s.  With the
+    // 14-op program and the predicate-free full-tile body: NE 4 at 3 / 4 / 5 wavefronts per SIMD 1025 /
+    // 1082 / 1042, NE 2: 937, NE 8: 697 GB/s.
     int ne = 1;
     if (P.nelem >= (static_cast<i64>(1) << 19) && P.nslots * 4 * kBlock * 8 <= 48 * 1024) ne = 4;
     else if (P.nelem >= (static_cast<i64>(1) << 18) && P.nslots * 2 * kBlock * 8 <= 48 * 1024) ne = 2;

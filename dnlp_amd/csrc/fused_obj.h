@@ -235,13 +235,15 @@ inline FusedSlotProg fused_compile(const FusedProg& T) {
 // NE elements per call (op-major: one opcode decode serves NE independent element chains).
 // S: slot accessor  double& S(int slot, int e);  G: scatter  void G(i64 index, double value).
 // Elements i0 + e * estride, e < NE; elements >= P.nelem are skipped through `valid`.
-template <int NE, class S, class G>
+// ALL: every element of the tile is valid (all tiles but the last): no per-element predicate, so the
+// NE element chains of an op stay in ONE basic block and their LDS / global accesses overlap.
+template <int NE, bool ALL = false, class S, class G>
 DNLP_HD inline double fused_elements(const FusedSlotProg& P, i64 i0, i64 estride, const bool (&valid)[NE],
                                      const double* __restrict__ x, const double* __restrict__ consts,
                                      S slot, G scatter) {
   double fsum = 0.0;
   const int nops = P.nops;
-#define DNLP_FZ_EACH for (int e = 0; e < NE; ++e) if (valid[e])
+#define DNLP_FZ_EACH for (int e = 0; e < NE; ++e) if (ALL || valid[e])
   for (int i = 0; i < nops; ++i) {
     const int op = P.op[i], d = P.d[i], s1 = P.s1[i], s2 = P.s2[i], u = P.u[i];
     switch (op) {
