@@ -609,13 +609,16 @@ template <int NE, int WPE>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 fused_eval_kernel(FusedSlotProg P, const double* __restrict__ x, const double* __restrict__ consts,
                   double* __restrict__ grad, double* __restrict__ partial) {
+  // dynamic LDS: [slots: nslots x NE x 256 doubles][gradient window of the current tile: 256 NE doubles]
+  // — nothing static, so that 4 slots x 4 elements + window = exactly 40 KB = four workgroups per CU
   extern __shared__ double fz_slots[];
-  __shared__ double sm[kBlock / 64];
-  __shared__ double gwin[kBlock * NE + 64];        // gradient window of the current tile
   double* mine = fz_slots + threadIdx.x;
-  double acc = 0.0;
   const i64 tile = static_cast<i64>(kBlock) * NE;
-  const int win = P.win_extra >= 0 ? static_cast<int>(tile) + P.win_extra : 0;
+  double* gwin = fz_slots + static_cast<size_t>(P.nslots) * tile;
+  double acc = 0.0;
+  // adjoints that land in [tile start + win_lo, + tile) are summed in LDS; the few beyond (offsets
+  // reach win_extra entries further) go out as global atomics
+  const int win = P.win_extra >= 0 ? static_cast<int>(tile) : 0;
   for (int t = threadIdx.x; t < win; t += kBlock) gwin[t] = 0.0;
   __syncthreads();
   for (i64 base = static_cast<i64>(blockIdx.x) * tile; base < P.nelem; base += static_cast<i64>(gridDim.x) * tile) {
@@ -643,13 +646,7 @@ fused_eval_kernel(FusedSlotProg P, const double* __restrict__ x, const double* _
     }
   }
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double r = sm[0];
-    for (int k = 1; k < kBlock / 64; ++k) r += sm[k];
-    partial[blockIdx.x] = r;
-  }
+  if ((threadIdx.x & 63) == 0) partial[blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)] = acc;
 }
 
 // ---- static-pattern sparse LDL^T (sparse_ldl.h) driven from the host: one workgroup walks the
@@ -759,8 +756,9 @@ struct HipExec : HostControlled {
   explicit HipExec(int dev = 0) : device(dev) {
     DNLP_HIP_CHECK(hipSetDevice(device));
     DNLP_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    DNLP_HIP_CHECK(hipMalloc(&d_partial, sizeof(double) * kMaxPartials));
-    DNLP_HIP_CHECK(hipHostMalloc(&h_partial, sizeof(double) * kMaxPartials));
+    // (the fused objective kernel writes one partial per wavefront: 4 per workgroup)
+    DNLP_HIP_CHECK(hipMalloc(&d_partial, sizeof(double) * kMaxPartials * 4));
+    DNLP_HIP_CHECK(hipHostMalloc(&h_partial, sizeof(double) * kMaxPartials * 4));
     if (const char* v = std::getenv("DNLP_FUSED_NE")) fused_ne_override = std::atoi(v);
   }
   ~HipExec() {
@@ -935,7 +933,7 @@ struct HipExec : HostControlled {
   }
   template <int NE, int WPE>
   void fused_launch(const FusedSlotProg& P, const double* x, const double* consts, double* grad, i64 blocks) {
-    const size_t lds = static_cast<size_t>(P.nslots) * NE * kBlock * sizeof(double);
+    const size_t lds = static_cast<size_t>(P.nslots + 1) * NE * kBlock * sizeof(double);      // slots + gradient window
     hipLaunchKernelGGL((fused_eval_kernel<NE, WPE>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), lds, stream, P, x,
                        consts, grad, d_partial);
   }
@@ -951,21 +949,22 @@ struct HipExec : HostControlled {
     // 14-op program and the predicate-free full-tile body: NE 4 at 3 / 4 / 5 wavefronts per SIMD 1025 /
     // 1082 / 1042, NE 2: 937, NE 8: 697 GB/s.
     int ne = 1;
-    if (P.nelem >= (static_cast<i64>(1) << 19) && P.nslots * 4 * kBlock * 8 <= 48 * 1024) ne = 4;
-    else if (P.nelem >= (static_cast<i64>(1) << 18) && P.nslots * 2 * kBlock * 8 <= 48 * 1024) ne = 2;
-    if (fused_ne_override == 1 || fused_ne_override == 2 || (fused_ne_override == 4 && P.nslots * 4 * kBlock * 8 <= 64 * 1024))
+    if (P.nelem >= (static_cast<i64>(1) << 19) && (P.nslots + 1) * 4 * kBlock * 8 <= 56 * 1024) ne = 4;
+    else if (P.nelem >= (static_cast<i64>(1) << 18) && (P.nslots + 1) * 2 * kBlock * 8 <= 56 * 1024) ne = 2;
+    if (fused_ne_override == 1 || fused_ne_override == 2 || (fused_ne_override == 4 && (P.nslots + 1) * 4 * kBlock * 8 <= 64 * 1024))
       ne = fused_ne_override;
     const i64 tile = static_cast<i64>(kBlock) * ne;
     i64 blocks = (P.nelem + tile - 1) / tile;
     if (blocks > kMaxPartials) blocks = kMaxPartials;
     if (ne == 4) fused_launch<4, 4>(P, x, consts, grad, blocks);
-    else if (ne == 2) fused_launch<2, 6>(P, x, consts, grad, blocks);
+    else if (ne == 2) fused_launch<2, 8>(P, x, consts, grad, blocks);
     else fused_launch<1, 6>(P, x, consts, grad, blocks);
     DNLP_LAUNCH_CHECK();
-    DNLP_HIP_CHECK(hipMemcpyAsync(h_partial, d_partial, sizeof(double) * static_cast<size_t>(blocks), hipMemcpyDeviceToHost, stream));
+    const i64 np = blocks * (kBlock / 64);
+    DNLP_HIP_CHECK(hipMemcpyAsync(h_partial, d_partial, sizeof(double) * static_cast<size_t>(np), hipMemcpyDeviceToHost, stream));
     DNLP_HIP_CHECK(hipStreamSynchronize(stream));
     double f = 0.0;
-    for (i64 k = 0; k < blocks; ++k) f += h_partial[k];
+    for (i64 k = 0; k < np; ++k) f += h_partial[k];
     return f;
   }
   int fused_ne_override = 0;     // DNLP_FUSED_NE = 1 | 2 | 4 (measurement sweeps)

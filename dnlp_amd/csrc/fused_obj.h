@@ -109,6 +109,10 @@ inline FusedSlotProg fused_compile(const FusedProg& T) {
       }
     }
   }
+  // a root leaf goes into f as soon as it exists: its slot is free for the rest of the program
+  auto accf = [&](int k) {
+    for (const auto& rw : roots) if (rw.first == k) ops.push_back({S_ACCF, -1, -1, k, -1, 0, rw.second, 0});
+  };
   for (int k = 0; k < n; ++k) {
     const int o = T.op[k], a = T.a[k], b = T.b[k];
     const int ck = cons[static_cast<size_t>(k)];
@@ -122,6 +126,7 @@ inline FusedSlotProg fused_compile(const FusedProg& T) {
       const int src = V(T.a[a]);
       if (o == F_ADDC) ops.push_back({S_AXPB, V(k), -1, src, -1, 0, T.p[a], T.p[k]});            // p_a x + q_k
       else ops.push_back({S_AXPB, V(k), -1, src, -1, 0, T.p[k], T.p[k] * T.p[a]});                // p_k (x + q_a)
+      accf(k);
       continue;
     }
     switch (o) {
@@ -136,8 +141,8 @@ inline FusedSlotProg fused_compile(const FusedProg& T) {
       case F_ADDC: ops.push_back({S_ADDC, V(k), -1, V(a), -1, 0, T.p[k], 0}); break;
       default: throw std::runtime_error("bad fused opcode");
     }
+    accf(k);
   }
-  for (const auto& rw : roots) ops.push_back({S_ACCF, -1, -1, V(rw.first), -1, 0, rw.second, 0});
   // Reverse sweep.  The adjoint of instruction k is carried as  fac[k] * (register adj[k]), with
   // adj[k] = -1 meaning the pure constant fac[k]: constant factors (the root's 1, scales, signs of
   // subtractions) never cost an op — they travel to the scatter, which applies them (S_SCATTER
