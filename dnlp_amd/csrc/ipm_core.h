@@ -360,6 +360,7 @@ class Ipm {
     acceptable_count = 0;
     delta_w_last = 0.0;
     dc_fixed_count_ = 0; dc_fixed_last_ = false; always_dc_ = false;
+    lan_warm_ = false; lan_width_ = 0.0;
     fixed_mode = false;
     n_hist = 0;
     initialized = true;
@@ -596,7 +597,7 @@ class Ipm {
     const bool all_eq = m > 0 && ex_->sum(m, [=] DNLP_HD(i64 i) { return eqm[i]; }) == static_cast<double>(m);
     const bool projected = all_eq && m <= qmax;
     if (!projected && m + 1 > kmax - 2) return {0.0, 0.0};
-    if (!lanV) { lanV = A<double>(static_cast<i64>(kmax + 1) * N); lanW = A<double>(N); lanQ = A<double>(static_cast<i64>(qmax) * N); }
+    if (!lanV) { lanV = A<double>(static_cast<i64>(kmax + 1) * N); lanW = A<double>(N); lanQ = A<double>(static_cast<i64>(qmax) * N); lanY = A<double>(N); }
     int nq = 0;
     if (projected) {
       // orthonormal basis of the row space of J (modified Gram-Schmidt on J^T e_i)
@@ -619,15 +620,53 @@ class Ipm {
     auto project = [&](double* v) { ex_->orthogonalize(nq, lanQ, N, v, cbuf); };
     double al[24], be[24];
     int nal = 0, nbe = 0;
+    // wanted-th smallest eigenvalue of the leading kk x kk part of the tridiagonal T by Sturm bisection
+    const int want = projected ? 1 : static_cast<int>(m) + 1;
+    double width = 0.0;
+    auto ritz = [&](int kk) {
+      double lo = al[0], hi = al[0];
+      for (int i = 0; i < kk; ++i) {
+        const double r = (i > 0 ? std::fabs(be[i - 1]) : 0.0) + (i < nbe && i + 1 < kk ? std::fabs(be[i]) : 0.0);
+        lo = std::min(lo, al[i] - r);
+        hi = std::max(hi, al[i] + r);
+      }
+      width = hi - lo;
+      auto count_below = [&](double t) {
+        int c = 0;
+        double d = 1.0;
+        for (int i = 0; i < kk; ++i) {
+          const double b2 = (i > 0) ? be[i - 1] * be[i - 1] : 0.0;
+          d = (al[i] - t) - (i > 0 ? b2 / d : 0.0);
+          if (d == 0.0) d = 1e-300;
+          if (d < 0.0) ++c;
+        }
+        return c;
+      };
+      for (int it = 0; it < 100; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (count_below(mid) >= want) hi = mid; else lo = mid;
+      }
+      return hi;
+    };
+    // Warm start (projected case): the previous call's Ritz vector of the smallest eigenvalue —
+    // between interior-point iterations the extreme eigenvector barely moves, so the Krylov space
+    // built on it contains the new one after a few steps instead of 24 (every Ritz value is an
+    // upper bound of lambda_min whatever the start vector, so the bound stays certified).  The run
+    // stops when the Ritz value has settled to 1e-4 of the spectral width seen by the first, cold run.
+    const bool warm = projected && lan_warm_;
     double* v0 = lanV;
     {
-      // deterministic start vector with components in every direction
-      ex_->map(N, [=] DNLP_HD(i64 j) { v0[j] = 1.0 + 0.5 * sin(1.0 + 0.37 * static_cast<double>(j % 1009)); });
+      // deterministic vector with components in every direction (cold start; small admixture when warm)
+      const double* yw = lanY;
+      const double mix = (warm ? 1e-3 : 1.0) / std::sqrt(static_cast<double>(N)), wy = warm ? 1.0 : 0.0;   // (no member access inside the lambda)
+      ex_->map(N, [=] DNLP_HD(i64 j) {
+        v0[j] = mix * (1.0 + 0.5 * sin(1.0 + 0.37 * static_cast<double>(j % 1009))) + (wy != 0.0 ? wy * yw[j] : 0.0); });
       project(v0);
       const double nrm = std::sqrt(ex_->sum(N, [=] DNLP_HD(i64 j) { return v0[j] * v0[j]; }));
       if (!(nrm > 0.0)) return {0.0, 0.0};
       ex_->map(N, [=] DNLP_HD(i64 j) { v0[j] /= nrm; });
     }
+    double theta_prev = 0.0;
     for (int k = 0; k < kmax; ++k) {
       double* vk = lanV + static_cast<i64>(k) * N;
       double* w = lanW;
@@ -642,37 +681,42 @@ class Ipm {
       for (int pass = 0; pass < 2; ++pass) ex_->orthogonalize(k + 1, lanV, N, w, cbuf);
       const double b = std::sqrt(ex_->sum(N, [=] DNLP_HD(i64 j) { return w[j] * w[j]; }));
       if (!(b > 1e-12 * (std::fabs(a) + 1.0)) || k + 1 == kmax) break;
+      if (warm && nal >= 3) {
+        const double th = ritz(nal);
+        if (std::fabs(th - theta_prev) <= 1e-4 * lan_width_) break;
+        theta_prev = th;
+      } else if (warm) {
+        theta_prev = ritz(nal);
+      }
       be[nbe++] = b;
       double* vn = lanV + static_cast<i64>(k + 1) * N;
       ex_->map(N, [=] DNLP_HD(i64 j) { vn[j] = w[j] / b; });
     }
-    // wanted-th smallest eigenvalue of the k x k tridiagonal T by Sturm bisection
     const int kk = nal;
-    const int want = projected ? 1 : static_cast<int>(m) + 1;
     if (kk < want) return {0.0, 0.0};
-    double lo = al[0], hi = al[0];
-    for (int i = 0; i < kk; ++i) {
-      const double r = (i > 0 ? std::fabs(be[i - 1]) : 0.0) + (i < nbe ? std::fabs(be[i]) : 0.0);
-      lo = std::min(lo, al[i] - r);
-      hi = std::max(hi, al[i] + r);
-    }
-    const double width = hi - lo;
-    auto count_below = [&](double t) {
-      int c = 0;
-      double d = 1.0;
-      for (int i = 0; i < kk; ++i) {
-        const double b2 = (i > 0) ? be[i - 1] * be[i - 1] : 0.0;
-        d = (al[i] - t) - (i > 0 ? b2 / d : 0.0);
-        if (d == 0.0) d = 1e-300;
-        if (d < 0.0) ++c;
+    const double theta = ritz(kk);
+    if (!warm) lan_width_ = width;
+    width = std::max(width, lan_width_);
+    if (projected) {
+      // Ritz vector for the next call: s from the three-term recurrence of (T - theta I) s = 0
+      double sv[24];
+      sv[0] = 1.0;
+      for (int i = 0; i + 1 < kk; ++i) {
+        const double bi = (i < nbe && be[i] != 0.0) ? be[i] : 1e-300;
+        sv[i + 1] = ((theta - al[i]) * sv[i] - (i > 0 ? be[i - 1] * sv[i - 1] : 0.0)) / bi;
       }
-      return c;
-    };
-    for (int it = 0; it < 100; ++it) {
-      const double mid = 0.5 * (lo + hi);
-      if (count_below(mid) >= want) hi = mid; else lo = mid;
+      double nn = 0.0;
+      for (int i = 0; i < kk; ++i) nn += sv[i] * sv[i];
+      nn = std::sqrt(nn);
+      bool fin = nn > 0.0 && std::isfinite(nn);
+      if (fin) {
+        for (int i = 0; i < kk; ++i) sv[i] /= nn;
+        ex_->v_comb(kk, lanV, N, sv, lanY);
+        lan_warm_ = true;
+      } else {
+        lan_warm_ = false;
+      }
     }
-    const double theta = hi;
     return {theta < 0.0 ? -theta : 0.0, width};
     }
   }
@@ -1562,7 +1606,9 @@ class Ipm {
   int last_nneg_ = 0;               // negative pivots reported by the last factorisation attempt
   int dc_fixed_count_ = 0;          // iterations whose wrong inertia the dual regularisation alone repaired
   bool dc_fixed_last_ = false, always_dc_ = false;
-  double *lanV = nullptr, *lanW = nullptr, *lanQ = nullptr;
+  double *lanV = nullptr, *lanW = nullptr, *lanQ = nullptr, *lanY = nullptr;
+  bool lan_warm_ = false;           // lanY holds the previous call's smallest Ritz vector
+  double lan_width_ = 0.0;          // spectral width seen by the last cold Lanczos run
   double t_begin_ = 0.0;
 };
 
