@@ -320,6 +320,8 @@ struct BatchRunner {
     if (const char* e = std::getenv("DNLP_BATCH_PER_CU")) { const int w = std::atoi(e); if (w >= 1 && w <= 8) per_cu = w; }
     const int grid = std::min(batch, ncu * per_cu);
     last_grid = grid; last_threads = nthreads; last_lds_mode = mode; last_per_cu = per_cu;
+    if (dbg) std::fprintf(stderr, "[batch] plan: threads %d lds_mode %d static LDS %zu B dynamic %u B -> %d per CU, grid %d\n", nthreads, mode,
+                          static_cast<size_t>(fa.sharedSizeBytes), a.lds_bytes, per_cu, grid);
     a.ws = dalloc<char>(static_cast<size_t>(grid) * a.ws_per_block);
     a.x_out = dalloc<double>(static_cast<size_t>(batch) * t.N);
     a.obj_out = dalloc<double>(static_cast<size_t>(batch));

@@ -51,6 +51,7 @@ struct IpmOptions {
   int max_refine = 10, min_refine = 1;
   int restoration = 1;
   int adaptive_fallback = 1;
+  int lazy_dense_fallback = 0;       // small sparse systems: switch to Bunch-Kaufman only after repeated singular pivots
   int lanczos_inertia_bound = 1;
   int lanczos_min_n = 12000;
   // IPOPT's warm start (warm_start_init_point = yes): start from given primal AND dual values,
@@ -782,7 +783,7 @@ class Ipm {
       ++sparse_singular_streak_;
       // small systems switch at once (the dense factorisation costs nothing there); larger ones only
       // when the singularity persists beyond the first iteration (multipliers start at zero)
-      if ((N + m) <= 512 || (iter >= 1 && sparse_singular_streak_ >= 2)) {
+      if (((N + m) <= 512 && !opt.lazy_dense_fallback) || (iter >= 1 && sparse_singular_streak_ >= 2)) {
         kkt_->fallback_to_dense();
         logf("   static pivot sequence singular in consecutive iterations: Bunch-Kaufman from here on");
         r = attempt(0.0, 0.0);

@@ -30,6 +30,7 @@ ap.add_argument("--check", type=int, default=16)
 ap.add_argument("--which", default="localization,circle_packing")
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--backend", default="nccl")
+ap.add_argument("--opt", action="append", default=[], help="solver option key=value (e.g. max_iter=150)")
 args = ap.parse_args()
 
 rank = int(os.environ.get("RANK", "0"))
@@ -67,7 +68,7 @@ for which in args.which.split(","):
         if dist is not None:
             dist.barrier()
         t0 = time.time()
-        res = pb.solve(thetas)
+        res = pb.solve(thetas, **dict(kv.split("=") for kv in args.opt))
         wall = time.time() - t0
         if best is None or wall < best[0]:
             best = (wall, res)
