@@ -1506,6 +1506,31 @@ class Ipm {
     return false;
   }
 
+  // A rung of the retry ladder that converged did so in monotone mode, whose barrier floor (tol / 10)
+  // leaves the point a factor ~1e3 less accurate than the free mode normally ends (its last Newton
+  // steps overshoot the tolerance).  A few more iterations toward tol / 1000 make up for that; if they
+  // do not get there the better of the two points that satisfies the requested tolerance is kept.
+  DNLP_HD void polish() {
+    double* sv[7] = {x, s, y, zL, zU, vL, vU};
+    const i64 sz[7] = {N, m, m, N, N, m, m};
+    for (int k = 0; k < 7; ++k) ex_->d2d(aff[k], sv[k], sizeof(double) * static_cast<size_t>(sz[k]));   // aff: free in monotone mode
+    const double tol0 = opt.tol, mu0 = mu, tau0 = tau;
+    const int maxit0 = opt.max_iter;
+    opt.tol = tol0 * 1e-3;
+    opt.max_iter = iter + 12;
+    while (step() == 99) {}
+    opt.tol = tol0;
+    opt.max_iter = maxit0;
+    if (status == Solve_Succeeded) return;
+    const Err e = error(0.0);
+    if (check_convergence(e) == Solve_Succeeded) { status = Solve_Succeeded; return; }
+    for (int k = 0; k < 7; ++k) ex_->d2d(sv[k], aff[k], sizeof(double) * static_cast<size_t>(sz[k]));
+    mu = mu0; tau = tau0;
+    md_->sweep(x, false);
+    eval_derivs_after_sweep();
+    status = Solve_Succeeded;
+  }
+
   // ---- driver -------------------------------------------------------------------------
   DNLP_HD int solve(const double* x0_ctl) {
     const double t_all = now_sec();
@@ -1543,6 +1568,7 @@ class Ipm {
           }
         }
         iter += it_first;
+        if (status == Solve_Succeeded) polish();
         stats.iterations = iter;
         keep.append(iterlog);
         iterlog = keep;

@@ -28,7 +28,7 @@ NEEDS_OTHER_SOLVER = {
     "test_huber_sum_largest.py::TestNonsmoothNontrivial::test_sum_smallest",
 }
 # ... and the known gap of this round (diverges from the all-default start)
-KNOWN_GAPS = {"test_risk_parity.py::TestRiskParity::test_vanilla_risk_parity_formulation_one"}
+KNOWN_GAPS = set()          # every reference test that only needs the NLP path passes
 
 
 def test_reference_nlp_suite_passes_on_this_solver():
@@ -42,4 +42,4 @@ def test_reference_nlp_suite_passes_on_this_solver():
     passed = int(m.group(1))
     unexpected = failed - NEEDS_OTHER_SOLVER - KNOWN_GAPS
     assert not unexpected, sorted(unexpected)
-    assert passed >= 200, passed
+    assert passed >= 205, passed
