@@ -91,6 +91,10 @@ def _device_handle(arrays, tape, device, opts):
     from .tape import serialize
     h = _capi.DeviceProblem(serialize(arrays), tape, device=device)
     options = dict(HIPNLP.DEFAULT_OPTIONS)
+    # batches: an instance whose static sparse pivots turn singular keeps the sparse factorisation
+    # (delta_c) in its first run and may switch to in-kernel Bunch-Kaufman only in the retry rungs —
+    # the dense path is ~6x slower per iteration and a few such instances were the tail of a launch
+    options["lazy_dense_fallback"] = "yes"
     options.update(opts)
     options.pop("algorithm", None)
     for k, v in options.items():

@@ -51,7 +51,8 @@ struct IpmOptions {
   int max_refine = 10, min_refine = 1;
   int restoration = 1;
   int adaptive_fallback = 1;
-  int lazy_dense_fallback = 0;       // small sparse systems: switch to Bunch-Kaufman only after repeated singular pivots
+  int lazy_dense_fallback = 0;       // 1: a sparse instance switches to Bunch-Kaufman only in the rungs of the retry
+                                     // ladder (the first run handles singular static pivots with delta_c alone)
   int lanczos_inertia_bound = 1;
   int lanczos_min_n = 12000;
   // IPOPT's warm start (warm_start_init_point = yes): start from given primal AND dual values,
@@ -779,11 +780,11 @@ class Ipm {
     // iterations are structural (free variables without curvature next to unregularised equality
     // rows): where the dense matrix is affordable the instance switches to Bunch-Kaufman pivoting
     // for good instead of regularising every step.
-    if (r == 2 && !always_dc_ && kkt_->can_fallback()) {
+    if (r == 2 && !always_dc_ && kkt_->can_fallback() && (!opt.lazy_dense_fallback || ladder_rung_ > 0)) {
       ++sparse_singular_streak_;
       // small systems switch at once (the dense factorisation costs nothing there); larger ones only
       // when the singularity persists beyond the first iteration (multipliers start at zero)
-      if (((N + m) <= 512 && !opt.lazy_dense_fallback) || (iter >= 1 && sparse_singular_streak_ >= 2)) {
+      if ((N + m) <= 512 || (iter >= 1 && sparse_singular_streak_ >= 2)) {
         kkt_->fallback_to_dense();
         logf("   static pivot sequence singular in consecutive iterations: Bunch-Kaufman from here on");
         r = attempt(0.0, 0.0);
@@ -1555,6 +1556,7 @@ class Ipm {
         if (!failed) break;
         if (rung == 1 && strategy0 != 1) continue;       // already monotone: straight to rung 2
         const int it_first = iter;
+        ladder_rung_ = rung;
         opt.mu_strategy = 0;
         if (rung == 2) opt.mu_init = mu_init0 * 10.0 > 1.0 ? mu_init0 * 10.0 : 1.0;
         logf("run ended with status %d after %d iterations: restarting in monotone mode, mu_init %.1e", status, iter,
@@ -1575,6 +1577,7 @@ class Ipm {
       }
       opt.mu_strategy = strategy0;
       opt.mu_init = mu_init0;
+      ladder_rung_ = 0;
     }
     stats.wall = now_sec() - t_all;
     stats.final_mu = mu;
@@ -1631,6 +1634,7 @@ class Ipm {
   bool delta_w_used_last_iter_ = false;
   int sparse_singular_streak_ = 0;
   int last_nneg_ = 0;               // negative pivots reported by the last factorisation attempt
+  int ladder_rung_ = 0;             // 0: first run; 1, 2: rungs of the retry ladder
   int dc_fixed_count_ = 0;          // iterations whose wrong inertia the dual regularisation alone repaired
   bool dc_fixed_last_ = false, always_dc_ = false;
   double *lanV = nullptr, *lanW = nullptr, *lanQ = nullptr, *lanY = nullptr;
