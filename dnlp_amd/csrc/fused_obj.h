@@ -48,21 +48,28 @@ struct FusedProg {
 // reader has run (in place when the reader is the writer).  Rosenbrock: 11 tree instructions ->
 // 21 ops over 4 slots instead of 11 slots, which is what lets the device kernel keep FOUR elements
 // per lane in LDS and amortise one opcode decode over four independent element chains.
-constexpr int kFusedMaxOps = 112, kFusedMaxRefs = 32;
+constexpr int kFusedMaxOps = 112;     // 112 x 32 B of records + header stay below the 4 KB kernel-argument limit
 enum FusedSlotOp : unsigned char {
   S_LOADV = 0, S_LOADC, S_UNARY, S_ADD, S_SUB, S_MUL, S_DIV, S_SCALE, S_ADDC, S_SET, S_ACCF, S_SCATTER, S_AXPB
+};
+
+// One op = one 32-byte record, so the interpreter's decode is a single scalar load:
+// code = op | d << 8 | s1 << 16 | s2 << 24 (S_UNARY: s2 = slot of the derivative); u = unary opcode;
+// p = scale / shift / weight / exponent; q = second parameter (S_UNARY exponent of the derivative,
+// S_AXPB shift) or, for S_LOADV / S_LOADC / S_SCATTER, the index offset; stride = index stride.
+struct alignas(32) FusedOpRec {
+  unsigned code, u;
+  double p;
+  union { double q; i64 off; };
+  i64 stride;
 };
 
 struct FusedSlotProg {
   int nops = 0, nslots = 0;
   i64 nelem = 0;
-  // d: destination slot; s1, s2: source slots (S_UNARY: s2 = slot of the derivative);
-  // u: unary opcode (S_UNARY) or reference index (S_LOADV / S_LOADC / S_SCATTER)
-  unsigned char op[kFusedMaxOps], d[kFusedMaxOps], s1[kFusedMaxOps], s2[kFusedMaxOps], u[kFusedMaxOps];
-  double p[kFusedMaxOps], p2[kFusedMaxOps];
-  i64 roff[kFusedMaxRefs], rstride[kFusedMaxRefs];
   i64 win_lo = 0;            // gradient window (see FusedProg)
   int win_extra = -1;
+  FusedOpRec rec[kFusedMaxOps];
 };
 
 // Host: tree program -> slot program.  Throws when the expansion exceeds the fixed capacities.
@@ -188,7 +195,7 @@ inline FusedSlotProg fused_compile(const FusedProg& T) {
         ops.push_back({S_MUL, Tm, -1, Aa, V(k), 0, 0, 0}); give(b, Tm, -1.0); break; }
     }
   }
-  if (ops.size() > static_cast<size_t>(kFusedMaxOps) || roff.size() > static_cast<size_t>(kFusedMaxRefs))
+  if (ops.size() > static_cast<size_t>(kFusedMaxOps))
     throw std::runtime_error("fused program too long for the slot form");
   // liveness: last op that reads each virtual register
   const int nv = 4 * n;
@@ -220,18 +227,23 @@ inline FusedSlotProg fused_compile(const FusedProg& T) {
     // a destination nobody reads (adjoint of a constant branch) is released at once
     if (o.d >= 0 && last[static_cast<size_t>(o.d)] < 0) free_slots.push_back(pd);
     if (o.d2 >= 0 && last[static_cast<size_t>(o.d2)] < 0) free_slots.push_back(pd2);
-    S.op[i] = static_cast<unsigned char>(o.op);
-    S.d[i] = static_cast<unsigned char>(pd);
-    S.s1[i] = static_cast<unsigned char>(ps1);
-    S.s2[i] = static_cast<unsigned char>(o.op == S_UNARY ? pd2 : ps2);
-    S.u[i] = static_cast<unsigned char>(o.u);
-    S.p[i] = o.p; S.p2[i] = o.p2;
+    FusedOpRec& R = S.rec[i];
+    const unsigned ps2f = static_cast<unsigned>(o.op == S_UNARY ? pd2 : ps2);
+    R.code = static_cast<unsigned>(o.op) | static_cast<unsigned>(pd) << 8 | static_cast<unsigned>(ps1) << 16 | ps2f << 24;
+    R.u = static_cast<unsigned>(o.op == S_UNARY ? o.u : 0);
+    R.p = o.p;
+    R.stride = 0;
+    if (o.op == S_LOADV || o.op == S_LOADC || o.op == S_SCATTER) {
+      R.off = roff[static_cast<size_t>(o.u)];
+      R.stride = rstride[static_cast<size_t>(o.u)];
+    } else {
+      R.q = o.p2;
+    }
   }
   if (nslots > 255) throw std::runtime_error("fused program needs too many slots");
   S.nops = static_cast<int>(ops.size());
   S.nslots = nslots;
   S.nelem = T.nelem;
-  for (size_t k = 0; k < roff.size(); ++k) { S.roff[k] = roff[k]; S.rstride[k] = rstride[k]; }
   S.win_lo = T.win_lo;
   S.win_extra = T.win_extra;
   return S;
@@ -250,20 +262,24 @@ DNLP_HD inline double fused_elements(const FusedSlotProg& P, i64 i0, i64 estride
   const int nops = P.nops;
 #define DNLP_FZ_EACH for (int e = 0; e < NE; ++e) if (ALL || valid[e])
   for (int i = 0; i < nops; ++i) {
-    const int op = P.op[i], d = P.d[i], s1 = P.s1[i], s2 = P.s2[i], u = P.u[i];
+    const FusedOpRec R = P.rec[i];      // (fetching record i + 1 ahead was measured: 1.02 -> 1.09 ms)
+    const int op = static_cast<int>(R.code & 0xffu), d = static_cast<int>((R.code >> 8) & 0xffu),
+              s1 = static_cast<int>((R.code >> 16) & 0xffu), s2 = static_cast<int>(R.code >> 24);
+    const double p = R.p;
     switch (op) {
       case S_LOADV: {
-        const i64 off = P.roff[u], st = P.rstride[u];
+        const i64 off = R.off, st = R.stride;
 #pragma unroll
         DNLP_FZ_EACH slot(d, e) = x[off + st * (i0 + e * estride)];
         break; }
       case S_LOADC: {
-        const i64 off = P.roff[u], st = P.rstride[u];
+        const i64 off = R.off, st = R.stride;
 #pragma unroll
         DNLP_FZ_EACH slot(d, e) = consts[off + st * (i0 + e * estride)];
         break; }
       case S_UNARY: {
-        const double p = P.p[i], p2 = P.p2[i];
+        const int u = static_cast<int>(R.u);
+        const double p2 = R.q;
         if (u == OP_POWER && p == 2.0 && p2 == 2.0) {          // squares: no libm, no compare chain
 #pragma unroll
           DNLP_FZ_EACH { const double w = slot(s1, e); slot(d, e) = w * w; slot(s2, e) = 2.0 * w; }
@@ -288,34 +304,29 @@ DNLP_HD inline double fused_elements(const FusedSlotProg& P, i64 i0, i64 estride
 #pragma unroll
         DNLP_FZ_EACH { const double a = slot(s1, e), b = slot(s2, e); slot(d, e) = a / b; }
         break;
-      case S_SCALE: {
-        const double p = P.p[i];
+      case S_SCALE:
 #pragma unroll
         DNLP_FZ_EACH slot(d, e) = p * slot(s1, e);
-        break; }
-      case S_ADDC: {
-        const double p = P.p[i];
+        break;
+      case S_ADDC:
 #pragma unroll
         DNLP_FZ_EACH slot(d, e) = slot(s1, e) + p;
-        break; }
-      case S_SET: {
-        const double p = P.p[i];
+        break;
+      case S_SET:
 #pragma unroll
         DNLP_FZ_EACH slot(d, e) = p;
-        break; }
+        break;
       case S_AXPB: {
-        const double p = P.p[i], q = P.p2[i];
+        const double q = R.q;
 #pragma unroll
         DNLP_FZ_EACH slot(d, e) = p * slot(s1, e) + q;
         break; }
-      case S_ACCF: {
-        const double p = P.p[i];
+      case S_ACCF:
 #pragma unroll
         DNLP_FZ_EACH fsum += p * slot(s1, e);
-        break; }
+        break;
       default: {   // S_SCATTER
-        const i64 off = P.roff[u], st = P.rstride[u];
-        const double p = P.p[i];
+        const i64 off = R.off, st = R.stride;
 #pragma unroll
         DNLP_FZ_EACH scatter(off + st * (i0 + e * estride), p * slot(s1, e));
         break; }
