@@ -855,6 +855,7 @@ class Ipm {
     const double* rr = rhs;
     double rn = ex_->max(N + m, [=] DNLP_HD(i64 i) { return fabs(rr[i]); });
     double best = kInf;
+    bool fresh = false;          // last_ratio_ already belongs to the current sol (loop left right after its residual)
     for (int it = 0; it < opt.max_refine; ++it) {
       kkt_mult(sol, dw, res);
       double* re = res;
@@ -862,8 +863,10 @@ class Ipm {
       const double* so = sol;
       double en = ex_->max(N + m, [=] DNLP_HD(i64 i) { return fabs(re[i]); });
       double sn = ex_->max(N + m, [=] DNLP_HD(i64 i) { return fabs(so[i]); });
-      double ratio = en / (std::min(rn, sn) + 1e-300 > 0 ? std::max(rn, 1e-300) + sn : 1.0);
+      double ratio = en / (std::max(rn, 1e-300) + sn);
       if (!std::isfinite(en)) { stats.t_solve += now_sec() - t0; return false; }
+      last_ratio_ = std::isfinite(ratio) ? ratio : kInf;
+      fresh = true;
       if (it >= opt.min_refine && ratio <= 1e-10) break;
       if (en >= best * 0.999 && it >= opt.min_refine) break;   // no further progress
       best = std::min(best, en);
@@ -871,8 +874,9 @@ class Ipm {
       double* sw = sol;
       const double* co = cor;
       ex_->map(N + m, [=] DNLP_HD(i64 i) { sw[i] += co[i]; });
+      fresh = false;
     }
-    {
+    if (!fresh) {
       kkt_mult(sol, dw, res);
       double* re = res;
       const double* so = sol;
