@@ -39,6 +39,7 @@ using i64 = int64_t;
 using i32 = int32_t;
 
 constexpr double kInf = std::numeric_limits<double>::infinity();
+struct D2 { double first, second; };     // pair of reduction results (E::min2)
 
 }  // namespace dnlp
 

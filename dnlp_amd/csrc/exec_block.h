@@ -526,6 +526,33 @@ struct BlockExecT {
   template <class F> __device__ double sum(i64 n, F f) { return reduce<0>(n, f); }
   template <class F> __device__ double max(i64 n, F f) { return reduce<1>(n, f); }
   template <class F> __device__ double min(i64 n, F f) { return reduce<2>(n, f); }
+  // two minima in one pass (NaN -> -inf, as min)
+  template <class F> __device__ D2 min2(i64 n, F f) {
+    double a0 = -kInf, a1 = -kInf;                   // min via max of the negatives
+    for (i64 i = threadIdx.x; i < n; i += kBatchThreads) {
+      const D2 v = f(i);
+      a0 = fmax(a0, v.first != v.first ? kInf : -v.first);
+      a1 = fmax(a1, v.second != v.second ? kInf : -v.second);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      a0 = fmax(a0, __shfl_xor(a0, o, 64));
+      a1 = fmax(a1, __shfl_xor(a1, o, 64));
+    }
+    if constexpr (NT == 64) return D2{-a0, -a1};
+    double* buf = red + 4 * parity;
+    parity ^= 1;
+    if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = a0;
+    __syncthreads();
+    double r0 = buf[0];
+    for (int k = 1; k < kBatchThreads / 64; ++k) r0 = fmax(r0, buf[k]);
+    double* buf1 = red + 4 * parity;
+    parity ^= 1;
+    if ((threadIdx.x & 63) == 0) buf1[threadIdx.x >> 6] = a1;
+    __syncthreads();
+    double r1 = buf1[0];
+    for (int k = 1; k < kBatchThreads / 64; ++k) r1 = fmax(r1, buf1[k]);
+    return D2{-r0, -r1};
+  }
 
   // block-wide argmax of v (first index wins ties, as IDAMAX); every lane gets the result
   __device__ void argmax(double v, int idx, double& outv, int& outi) {

@@ -79,6 +79,29 @@ __global__ void __launch_bounds__(kBlock) reduce_kernel(i64 n, F f, double* part
   }
 }
 
+// two minima in one pass (NaN -> -inf, as mode 2 above); partial[2 b], partial[2 b + 1]
+template <class F>
+__global__ void __launch_bounds__(kBlock) reduce_min2_kernel(i64 n, F f, double* partial) {
+  __shared__ double sm[2 * (kBlock / 64)];
+  double a0 = -kInf, a1 = -kInf;
+  for (i64 i = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<i64>(gridDim.x) * kBlock) {
+    const D2 v = f(i);
+    a0 = fmax(a0, v.first != v.first ? kInf : -v.first);
+    a1 = fmax(a1, v.second != v.second ? kInf : -v.second);
+  }
+  a0 = wave_max(a0);
+  a1 = wave_max(a1);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { sm[2 * wid] = a0; sm[2 * wid + 1] = a1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r0 = sm[0], r1 = sm[1];
+    for (int k = 1; k < kBlock / 64; ++k) { r0 = fmax(r0, sm[2 * k]); r1 = fmax(r1, sm[2 * k + 1]); }
+    partial[2 * blockIdx.x] = -r0;
+    partial[2 * blockIdx.x + 1] = -r1;
+  }
+}
+
 // ---- dense symmetric product y = A x, column-major ----------------------------------------
 // Stage 1: block (rb, cb) owns 512 rows x GEMV_CB columns; each lane streams two adjacent rows
 // (16 B per lane, 1 KiB per wave instruction, fully coalesced down a column) and keeps the two
@@ -829,6 +852,18 @@ struct HipExec : HostControlled {
   template <class F> double sum(i64 n, F f) { return reduce<0>(n, f); }
   template <class F> double max(i64 n, F f) { return reduce<1>(n, f); }
   template <class F> double min(i64 n, F f) { return reduce<2>(n, f); }
+  template <class F> D2 min2(i64 n, F f) {
+    if (n <= 0) return D2{kInf, kInf};
+    i64 grid = (n + kBlock - 1) / kBlock;
+    if (grid > kMaxPartials) grid = kMaxPartials;
+    hipLaunchKernelGGL((reduce_min2_kernel<F>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, n, f, d_partial);
+    DNLP_LAUNCH_CHECK();
+    DNLP_HIP_CHECK(hipMemcpyAsync(h_partial, d_partial, sizeof(double) * 2 * grid, hipMemcpyDeviceToHost, stream));
+    DNLP_HIP_CHECK(hipStreamSynchronize(stream));
+    D2 r{h_partial[0], h_partial[1]};
+    for (i64 k = 1; k < grid; ++k) { r.first = std::fmin(r.first, h_partial[2 * k]); r.second = std::fmin(r.second, h_partial[2 * k + 1]); }
+    return r;
+  }
 
   void gemv_sym(i64 n, const double* P, i64 ld, const double* u, double* out) {
     const i64 nrb = (n + 511) / 512, ncb = (n + GEMV_CB - 1) / GEMV_CB;

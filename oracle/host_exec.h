@@ -63,6 +63,18 @@ struct HostExec : HostControlled {
     return nan ? std::nan("") : s;
   }
 
+  template <class F> D2 min2(i64 n, F f) {
+    D2 s{kInf, kInf};
+    bool nan = false;
+    for (i64 i = 0; i < n; ++i) {
+      const D2 v = f(i);
+      if (v.first != v.first || v.second != v.second) nan = true;
+      if (v.first < s.first) s.first = v.first;
+      if (v.second < s.second) s.second = v.second;
+    }
+    return nan ? D2{std::nan(""), std::nan("")} : s;
+  }
+
   // static-pattern sparse LDL^T (csrc/sparse_ldl.h): the single-source routine with one lane
   bool sparse_factor(const SparsePlan& pl, double* vals, double* w, int* nneg, int* nzero) {
     return sparse_ldl_factor(pl, vals, w, nneg, nzero, SeqPar());
