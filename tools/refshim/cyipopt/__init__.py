@@ -49,7 +49,11 @@ class Problem:
             from dnlp_amd._capi import DeviceProblem
             h = DeviceProblem(blob, tape)
         else:
-            from oracle.oracle_capi import OracleProblem
+            import sys
+            _t = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))), "tests")
+            if _t not in sys.path:
+                sys.path.insert(0, _t)
+            from oracle_check import OracleProblem          # tests/oracle_check.py
             h = OracleProblem(blob)
         for k, v in self.opts.items():
             if k in ("print_level",):

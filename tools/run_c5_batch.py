@@ -106,16 +106,11 @@ for which in args.which.split(","):
            "phase_ms_per_iter": dict(zip(("wall", "eval", "factor", "solve"),
                                          (1e3 * res.raw["phase_seconds"].sum(axis=0) / res.iterations.sum()).tolist()))}
     if args.check:
-        from dnlp_amd.nlp_solver import HIPNLP
-        from dnlp_amd.tape import serialize
-        from oracle.oracle_capi import OracleProblem
+        from oracle_check import oracle_solve          # tests/oracle_check.py: the checker lives under tests/
         worst_obj, worst_x, same_iters = 0.0, 0.0, 0
         t0 = time.time()
         for i in range(min(args.check, nb)):
-            orc = OracleProblem(serialize(arrays_with_data(pb.arrays0, mat[i])))
-            for k, v in HIPNLP.DEFAULT_OPTIONS.items():
-                orc.set_option(k, v)
-            oi = orc.solve(mat[i][-0:][pb.d0.size - 0:] if False else arrays_with_data(pb.arrays0, mat[i])["x0"])
+            oi = oracle_solve(arrays_with_data(pb.arrays0, mat[i]))
             worst_obj = max(worst_obj, abs(oi["obj_val"] - res.raw["obj_val"][i]) / max(1.0, abs(oi["obj_val"])))
             worst_x = max(worst_x, float(np.max(np.abs(oi["x"] - res.x[i]))))
             same_iters += int(oi["iterations"] == res.iterations[i])
