@@ -269,6 +269,7 @@ struct Model {
       const double* P = t.dense_ptr[B.cid];
       const i64 ld = t.dense_ld[B.cid];
       const i64* pos = B.coo_pos;
+      const i64 base = B.coo_base;
       const double wk = dense_w[k];
       const i64 n = B.n;
       // tril_indices order: row-major over the lower triangle
@@ -277,7 +278,7 @@ struct Model {
         while (r * (r + 1) / 2 > q) --r;
         while ((r + 1) * (r + 2) / 2 <= q) ++r;
         const i64 cidx = q - r * (r + 1) / 2;
-        out[pos[q]] += wk * P[r + cidx * ld];
+        out[pos ? pos[q] : base + q] += wk * P[r + cidx * ld];
       });
     }
   }

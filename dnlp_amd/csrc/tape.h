@@ -87,6 +87,7 @@ struct SegHost {
 struct DenseBlock {
   i64 seg, cid, x0, n, z, has_pos;
   i64* coo_pos = nullptr;    // exec space, n(n+1)/2 entries in tril_indices order (row-major)
+  i64 coo_base = 0;          // has_pos == 2: the positions are coo_base + q (contiguous run), no table
 };
 
 struct SparseConst { Csr P, PT; i64 nh = 0; double* hv = nullptr; };
@@ -279,7 +280,9 @@ struct Tape : TapeView {
       DenseBlock& B = h_blocks[static_cast<size_t>(k)];
       B.seg = bl[6 * k]; B.cid = bl[6 * k + 1]; B.x0 = bl[6 * k + 2]; B.n = bl[6 * k + 3];
       B.z = bl[6 * k + 4]; B.has_pos = bl[6 * k + 5];
-      if (B.has_pos) {
+      if (B.has_pos == 2) {
+        B.coo_base = tb.i64s("dense_blk" + std::to_string(k) + "_pos")[0];
+      } else if (B.has_pos) {
         std::string nm = "dense_blk" + std::to_string(k) + "_pos";
         B.coo_pos = up(tb.i64s(nm), tb.count(nm));
       }

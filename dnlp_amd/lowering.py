@@ -663,7 +663,14 @@ def lower_problem(objective_expr: Expression, constraint_exprs: List[Expression]
         nb = blk["n"]
         if nb <= DENSE_COO_MAX_N:
             cnt = nb * (nb + 1) // 2
-            blk["coo_pos"] = hinv[off:off + cnt].astype(np.int64)   # tril_indices order
+            pos = hinv[off:off + cnt]                               # tril_indices order
+            if cnt and int(pos[-1]) - int(pos[0]) == cnt - 1 and bool(np.all(pos[1:] > pos[:-1])):
+                # the block's entries are a contiguous run of the sorted pattern (the usual case: the
+                # quad_form block is the only Hessian contribution of its rows): base + q, no table
+                blk["coo_pos"] = np.array([int(pos[0])], dtype=np.int64)
+                blk["coo_pos_identity"] = True
+            else:
+                blk["coo_pos"] = pos.astype(np.int64)
             off += cnt
         else:
             blk["coo_pos"] = None

@@ -123,7 +123,7 @@ def tape_arrays(t: Tape, x0, lb, ub, cl, cu) -> Dict[str, np.ndarray]:
         a["sp%d_hc" % k] = c.astype(np.int32, copy=False)
         a["sp%d_hv" % k] = v.astype(np.float64, copy=False)
     blk = np.array([[b["seg"], b["const"], b["x0"], b["n"], b["z"],
-                     1 if b.get("coo_pos") is not None else 0] for b in t.dense_blocks],
+                     (2 if b.get("coo_pos_identity") else 1) if b.get("coo_pos") is not None else 0] for b in t.dense_blocks],
                    dtype=np.int64).reshape(-1)
     a["dense_blocks"] = blk
     for k, b in enumerate(t.dense_blocks):

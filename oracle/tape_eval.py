@@ -224,6 +224,8 @@ class TapeEvaluator:
             P = self.dense[int(cid)]
             ii, jj = np.tril_indices(int(n))
             pos = self.a["dense_blk%d_pos" % k]
+            if int(has_pos) == 2:                     # contiguous run: base + q
+                pos = int(pos[0]) + np.arange(ii.size)
             np.add.at(H, pos, 2.0 * w[int(zi)] * P[ii, jj])
         return H
 
