@@ -97,7 +97,7 @@ def test_mixed_objective_against_finite_differences_and_reduced_tape_solve():
     np.testing.assert_allclose(res["yes"]["x"], res["no"]["x"], rtol=1e-4, atol=1e-5)
 
 
-def _random_objective(seed, n=24):
+def _random_objective(seed, n=24, vector_constants=True):
     """Random sums of elementwise trees over slices of two variables: exercises every rule of the
     host-side reverse sweep (products, quotients, sub / scale / shift chains, constant adjoints)."""
     rng = np.random.default_rng(seed)
@@ -126,7 +126,7 @@ def _random_objective(seed, n=24):
             return float(rng.uniform(0.5, 2)) - tree(depth - 1)
         if r < 0.70:
             return tree(depth - 1) - tree(depth - 1)
-        if r < 0.78:
+        if r < 0.78 and vector_constants:
             return cp.multiply(rng.uniform(0.5, 1.5, m), tree(depth - 1))
         if r < 0.86:
             return cp.square(tree(depth - 1))
@@ -190,3 +190,34 @@ def test_c2_full_size_fused_lbfgs(gpu_required):
     prob2 = rosenbrock_chain(cp, n)
     prob2.solve(nlp=True, algorithm="lbfgs", tol=1e-9, fused_objective="no")
     assert np.max(np.abs(prob2.variables()[0].value - prob.variables()[0].value)) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_device_slot_kernel_on_random_trees_at_scale(gpu_required, seed):
+    """The device kernel on random slot programs at a size that takes the four-elements-per-lane
+    body, the LDS gradient window and a partial last tile: the programs are index-affine, so the
+    ones lowered at n = 24 are re-targeted to 700 003 elements by patching the element counts (the
+    variables then alias one flat vector — the same function for both interpreters)."""
+    from dnlp_amd import _capi
+    from oracle.fused_eval import numpy_eval
+    prob = _random_objective(seed, vector_constants=False)
+    if build_fused_spec(prob) is None:
+        pytest.skip("tree outside the fused grammar")
+    data = _data(prob)
+    ta = dict(data["tape_arrays"])
+    if not data.get("fused") or "free_idx" not in ta:
+        pytest.skip("program beyond the fused capacities")
+    data["handle"].close() if data.get("handle") is not None else None
+    E = 700003
+    ta["fz_prog_nelem"] = np.full_like(ta["fz_prog_nelem"], E)
+    dims = ta["fz_dims"].copy()
+    dims[3] = E + 128
+    ta["fz_dims"] = dims
+    z = np.random.default_rng(seed).uniform(0.6, 1.4, E + 128)
+    dev = _capi.DeviceProblem(serialize(ta), data["tape"], device=0)
+    f, g = dev.eval_fused(z)
+    dev.close()
+    f1, g1 = numpy_eval(ta, z)
+    assert abs(f - f1) <= 1e-10 * max(1.0, abs(f1))
+    np.testing.assert_allclose(g, g1, rtol=1e-10, atol=1e-10)
