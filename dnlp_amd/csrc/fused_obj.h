@@ -61,7 +61,7 @@ struct alignas(32) FusedOpRec {
   unsigned code, u;
   double p;
   union { double q; i64 off; };
-  i64 stride;
+  union { i64 stride; double w; };     // S_UNARY: w != 0 -> the value goes straight into f with weight w
 };
 
 struct FusedSlotProg {
@@ -77,6 +77,7 @@ inline FusedSlotProg fused_compile(const FusedProg& T) {
   const int n = T.n;
   struct VOp { int op, d, d2, s1, s2, u; double p, p2; };
   std::vector<VOp> ops;
+  std::vector<double> accw;          // per final op: weight of the fused f accumulation (S_UNARY), else 0
   std::vector<i64> roff, rstride;
   auto ref = [&](i64 off, i64 st) {
     for (size_t k = 0; k < roff.size(); ++k) if (roff[k] == off && rstride[k] == st) return static_cast<int>(k);
@@ -195,6 +196,24 @@ inline FusedSlotProg fused_compile(const FusedProg& T) {
         ops.push_back({S_MUL, Tm, -1, Aa, V(k), 0, 0, 0}); give(b, Tm, -1.0); break; }
     }
   }
+  // a unary root leaf is summed into f by the op itself (no separate S_ACCF decode, no value slot)
+  {
+    std::vector<VOp> fusedops;
+    for (size_t i = 0; i < ops.size(); ++i) {
+      if (ops[i].op == S_UNARY && i + 1 < ops.size() && ops[i + 1].op == S_ACCF && ops[i + 1].s1 == ops[i].d && ops[i + 1].p != 0.0) {
+        VOp u = ops[i];
+        u.s2 = -2;                    // marker: accumulate (weight in `w`)
+        fusedops.push_back(u);
+        fusedops.back().d = -1;       // value is not stored
+        accw.push_back(ops[i + 1].p);
+        ++i;
+      } else {
+        fusedops.push_back(ops[i]);
+        accw.push_back(0.0);
+      }
+    }
+    ops.swap(fusedops);
+  }
   if (ops.size() > static_cast<size_t>(kFusedMaxOps))
     throw std::runtime_error("fused program too long for the slot form");
   // liveness: last op that reads each virtual register
@@ -233,6 +252,7 @@ inline FusedSlotProg fused_compile(const FusedProg& T) {
     R.u = static_cast<unsigned>(o.op == S_UNARY ? o.u : 0);
     R.p = o.p;
     R.stride = 0;
+    if (o.op == S_UNARY) R.w = accw[i];
     if (o.op == S_LOADV || o.op == S_LOADC || o.op == S_SCATTER) {
       R.off = roff[static_cast<size_t>(o.u)];
       R.stride = rstride[static_cast<size_t>(o.u)];
@@ -279,10 +299,19 @@ DNLP_HD inline double fused_elements(const FusedSlotProg& P, i64 i0, i64 estride
         break; }
       case S_UNARY: {
         const int u = static_cast<int>(R.u);
-        const double p2 = R.q;
-        if (u == OP_POWER && p == 2.0 && p2 == 2.0) {          // squares: no libm, no compare chain
+        const double p2 = R.q, w = R.w;
+        const bool sq = u == OP_POWER && p == 2.0 && p2 == 2.0;      // squares: no libm, no compare chain
+        if (w != 0.0) {                                              // root leaf: value straight into f
+          if (sq) {
 #pragma unroll
-          DNLP_FZ_EACH { const double w = slot(s1, e); slot(d, e) = w * w; slot(s2, e) = 2.0 * w; }
+            DNLP_FZ_EACH { const double t = slot(s1, e); fsum += w * (t * t); slot(s2, e) = 2.0 * t; }
+          } else {
+#pragma unroll
+            DNLP_FZ_EACH { double v, g1, g2; unary_rules(u, slot(s1, e), p, p2, v, g1, g2); fsum += w * v; slot(s2, e) = g1; }
+          }
+        } else if (sq) {
+#pragma unroll
+          DNLP_FZ_EACH { const double t = slot(s1, e); slot(d, e) = t * t; slot(s2, e) = 2.0 * t; }
         } else {
 #pragma unroll
           DNLP_FZ_EACH { double v, g1, g2; unary_rules(u, slot(s1, e), p, p2, v, g1, g2); slot(d, e) = v; slot(s2, e) = g1; }
