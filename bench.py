@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--order", type=int, default=100000, help="order n of the dense NLP (BASELINE: 1e5)")
-    ap.add_argument("--cpu-n", type=int, default=3000)
+    ap.add_argument("--cpu-n", type=int, default=2400)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     args = ap.parse_args()
