@@ -201,10 +201,8 @@ inline FusedSlotProg fused_compile(const FusedProg& T) {
     std::vector<VOp> fusedops;
     for (size_t i = 0; i < ops.size(); ++i) {
       if (ops[i].op == S_UNARY && i + 1 < ops.size() && ops[i + 1].op == S_ACCF && ops[i + 1].s1 == ops[i].d && ops[i + 1].p != 0.0) {
-        VOp u = ops[i];
-        u.s2 = -2;                    // marker: accumulate (weight in `w`)
-        fusedops.push_back(u);
-        fusedops.back().d = -1;       // value is not stored
+        fusedops.push_back(ops[i]);
+        fusedops.back().d = -1;       // the value is not stored: it goes into f with the weight kept in accw
         accw.push_back(ops[i + 1].p);
         ++i;
       } else {
