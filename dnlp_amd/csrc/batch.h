@@ -13,6 +13,8 @@
 #include <new>
 #include <vector>
 
+#include <type_traits>
+
 #include "exec_block.h"
 #include "exec_hip.h"
 #include "ipm_core.h"
@@ -35,6 +37,9 @@ struct BatchArgs {
   unsigned lds_bytes = 0;        // dynamic LDS pool (0: everything in global memory)
   int lds_mode = 0;              // what the pool holds: 0 nothing, 1 KKT matrix, 2 vectors, 3 both
   unsigned lds_stage_bytes = 0;  // front of the pool: staging arrays of the dense wavefront solves
+  unsigned plan_stage_bytes = 0; // then: LDS copy of the sparse plan's solve-phase index arrays (0: read from global)
+  int plan_stage_factor = 0;     // ... and of the factor-phase / assembly arrays (update triples, value positions)
+  i64 plan_rows = 0;             // struct rows of the plan (length of sidx / sblk)
   IpmOptions opt;
   double *x_out = nullptr, *obj_out = nullptr, *multg_out = nullptr, *zl_out = nullptr, *zu_out = nullptr;
   int *status_out = nullptr, *iters_out = nullptr, *nfact_out = nullptr;
@@ -72,6 +77,41 @@ __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
   double* s_vec = reinterpret_cast<double*>(lds_dyn);
   int* s_piv = reinterpret_cast<int*>(lds_dyn + sizeof(double) * EX::kWaveSolveMax);
   const unsigned stage = a.lds_stage_bytes;
+  // The triangular solves walk small index arrays of the plan (block nodes, struct offsets, row ->
+  // block, row -> node) in chains of dependent loads, ~11 level phases per solve and ~4 solves per
+  // iteration: from L2 that chain is the largest single cost of an iteration.  The arrays are the same
+  // for every instance, so the workgroup copies them into LDS once and every instance it solves
+  // reads them through a patched view of the plan.
+  SparsePlan spl = a.sp;
+  const unsigned pstage = a.use_sparse ? a.plan_stage_bytes : 0u;
+  if (pstage) {
+    char* p = lds_dyn + stage;
+    auto put = [&](auto*& field, i64 count) {
+      using T = typename std::remove_pointer<typename std::remove_reference<decltype(field)>::type>::type;
+      T* dst = reinterpret_cast<T*>(p);
+      for (i64 i = threadIdx.x; i < count; i += NT) dst[i] = field[i];
+      field = dst;
+      p += (static_cast<size_t>(count) * sizeof(T) + 7) & ~static_cast<size_t>(7);
+    };
+    put(spl.bnode, 2 * spl.nblk);
+    put(spl.soff, spl.nblk + 1);
+    put(spl.loff, spl.nblk);
+    put(spl.doff, spl.nblk);
+    put(spl.lev_off, spl.nlev + 1);
+    put(spl.sblk, a.plan_rows);
+    put(spl.sidx, a.plan_rows);
+    if (a.plan_stage_factor) {
+      put(spl.toff, spl.nblk + 1);
+      put(spl.tdst, spl.ntrip);
+      put(spl.tiu, spl.ntrip);
+      put(spl.tiv, spl.ntrip);
+      put(spl.tblk, spl.ntrip);
+      put(spl.hpos, a.base.nnzH);
+      put(spl.jpos, a.base.nnzJ);
+      put(spl.dpos, spl.n);
+    }
+    __syncthreads();
+  }
   __shared__ int s_inst;
   Objs& o = s_objs[threadIdx.x >> 6];
   while (true) {
@@ -80,8 +120,8 @@ __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
     const int inst = s_inst;
     __syncthreads();
     if (inst >= a.batch) break;
-    EX* ex = new (o.ex) EX(a.ws + static_cast<size_t>(blockIdx.x) * a.ws_per_block, a.ws_per_block, lds_dyn + stage,
-                           a.lds_bytes - stage, s_red, s_redi, stage ? s_vec : nullptr, stage ? s_piv : nullptr);
+    EX* ex = new (o.ex) EX(a.ws + static_cast<size_t>(blockIdx.x) * a.ws_per_block, a.ws_per_block, lds_dyn + stage + pstage,
+                           a.lds_bytes - stage - pstage, s_red, s_redi, stage ? s_vec : nullptr, stage ? s_piv : nullptr);
     ex->lds_mode = a.lds_mode;
     double* sl = a.slabs + static_cast<i64>(inst) * a.lay.total;
     TapeView t = a.base;
@@ -94,7 +134,7 @@ __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
     md->init_view(ex, t);
     KktT* kkt = new (o.kkt) KktT();
     if (a.use_sparse) {
-      kkt->init_sparse(ex, t.N, t.m, a.sp);
+      kkt->init_sparse(ex, t.N, t.m, spl);
       kkt->pivot_max_n = static_cast<i64>(1) << 40;
       kkt->fallback_max_n = a.fallback_max_n;
     } else {
@@ -151,7 +191,8 @@ struct BatchRunner {
     ws_batch = batch;
   }
   SparsePlan dev_plan;
-  void set_sparse_plan(const SparsePlanHost& hp) { dev_plan = hp.upload(ex); have_sparse = true; }
+  i64 plan_rows = 0;
+  void set_sparse_plan(const SparsePlanHost& hp) { dev_plan = hp.upload(ex); have_sparse = true; plan_rows = static_cast<i64>(hp.sidx.size()); }
   // device buffers kept across calls (grow-only): a call is then one H2D copy, one launch and the
   // result copies — no allocation on the steady-state path
   struct Buf { void* p = nullptr; size_t cap = 0; };
@@ -300,6 +341,30 @@ struct BatchRunner {
     a.lds_mode = mode;
     a.lds_stage_bytes = static_cast<unsigned>((stage_bytes + 63) & ~static_cast<size_t>(63));
     a.lds_bytes = static_cast<unsigned>(a.lds_stage_bytes + (mode & 1 ? kbytes : 0) + (mode & 2 ? vbytes_lds : 0));
+    // LDS copy of the plan's solve-phase index arrays — when it does not cost a resident instance
+    a.plan_stage_bytes = 0;
+    a.plan_rows = plan_rows;
+    if (have_sparse && !std::getenv("DNLP_BATCH_NO_PLAN_LDS")) {
+      auto pad8 = [](size_t b) { return (b + 7) & ~static_cast<size_t>(7); };
+      const size_t nb = static_cast<size_t>(dev_plan.nblk), nl = static_cast<size_t>(dev_plan.nlev), nr = static_cast<size_t>(plan_rows);
+      const size_t pbytes = (pad8(8 * nb) + pad8(8 * (nb + 1)) + 2 * pad8(8 * nb) + pad8(8 * (nl + 1)) + 2 * pad8(4 * nr) + 63) & ~static_cast<size_t>(63);
+      const size_t per0 = a.lds_bytes + fa.sharedSizeBytes + 256, per1 = per0 + pbytes;
+      const size_t cap = 160 * 1024;
+      const size_t nt = static_cast<size_t>(dev_plan.ntrip);
+      const size_t fbytes2 = (pad8(8 * (nb + 1)) + 4 * pad8(4 * nt) + pad8(4 * static_cast<size_t>(t.nnzH)) +
+                              pad8(4 * static_cast<size_t>(t.nnzJ)) + pad8(4 * static_cast<size_t>(dev_plan.n)) + 63) & ~static_cast<size_t>(63);
+      const size_t per2 = per1 + fbytes2;
+      const size_t s0 = std::min<size_t>(slots_max, cap / per0);
+      a.plan_stage_factor = 0;
+      if (per2 <= cap && std::min<size_t>(slots_max, cap / per2) == s0) {
+        a.plan_stage_bytes = static_cast<unsigned>(pbytes + fbytes2);
+        a.plan_stage_factor = 1;
+        a.lds_bytes += a.plan_stage_bytes;
+      } else if (per1 <= cap && std::min<size_t>(slots_max, cap / per1) == s0) {
+        a.plan_stage_bytes = static_cast<unsigned>(pbytes);
+        a.lds_bytes += a.plan_stage_bytes;
+      }
+    }
     // room for the dense matrix of an instance that falls back from the sparse path (global memory)
     const bool fb = have_sparse && n <= 512 && !force_sparse;
     a.fallback_max_n = fb ? 512 : 0;
@@ -320,8 +385,8 @@ struct BatchRunner {
     if (const char* e = std::getenv("DNLP_BATCH_PER_CU")) { const int w = std::atoi(e); if (w >= 1 && w <= 8) per_cu = w; }
     const int grid = std::min(batch, ncu * per_cu);
     last_grid = grid; last_threads = nthreads; last_lds_mode = mode; last_per_cu = per_cu;
-    if (dbg) std::fprintf(stderr, "[batch] plan: threads %d lds_mode %d static LDS %zu B dynamic %u B -> %d per CU, grid %d\n", nthreads, mode,
-                          static_cast<size_t>(fa.sharedSizeBytes), a.lds_bytes, per_cu, grid);
+    if (dbg) std::fprintf(stderr, "[batch] plan: threads %d lds_mode %d static LDS %zu B dynamic %u B (plan arrays %u B) -> %d per CU, grid %d\n", nthreads, mode,
+                          static_cast<size_t>(fa.sharedSizeBytes), a.lds_bytes, a.plan_stage_bytes, per_cu, grid);
     a.ws = dalloc<char>(static_cast<size_t>(grid) * a.ws_per_block);
     a.x_out = dalloc<double>(static_cast<size_t>(batch) * t.N);
     a.obj_out = dalloc<double>(static_cast<size_t>(batch));
