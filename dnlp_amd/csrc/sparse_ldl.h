@@ -156,7 +156,11 @@ DNLP_HD inline void sparse_ldl_solve(const SparsePlan& pl, const double* vals, d
   // one lane per block; narrow levels near the root (few blocks, long structs): all lanes per block.
   for (i64 lev = pl.nlev - 1; lev >= 0; --lev) {
     const i64 b0 = pl.lev_off[lev], b1 = pl.lev_off[lev + 1];
-    if ((b1 - b0) * 4 >= L) {
+    // (a narrow level only pays for the all-lanes-per-block form when its structs are long compared
+    // with the number of blocks: a lane-wide reduction per block costs about as much as two serial
+    // struct entries, and the blocks of the level are then handled one after the other)
+    const i64 nbl = b1 - b0, nrw = pl.soff[b1] - pl.soff[b0];
+    if (nbl * 4 >= L || nrw <= 3 * nbl * nbl) {
       for (i64 k = b0 + me; k < b1; k += L) {
         const i64 s0 = pl.soff[k], s = pl.soff[k + 1] - s0;
         const i32 u0 = pl.bnode[2 * k], u1 = pl.bnode[2 * k + 1];
