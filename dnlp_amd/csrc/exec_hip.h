@@ -753,6 +753,24 @@ __global__ void __launch_bounds__(kBlock) sp_bwd_kernel(SparsePlan pl, const dou
   if (lane == 0) { x[u0] -= a0; if (u1 >= 0) x[u1] -= a1; }
 }
 
+// levels whose structs are short (a few entries: chain-like problems): one lane per block, serial dot
+__global__ void __launch_bounds__(kBlock) sp_bwd_thread_kernel(SparsePlan pl, const double* vals, double* x, i64 b0, i64 b1) {
+  const i64 k = b0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+  if (k >= b1) return;
+  const i64 s0 = pl.soff[k], s = pl.soff[k + 1] - s0;
+  if (s == 0) return;
+  const i32 u0 = pl.bnode[2 * k], u1 = pl.bnode[2 * k + 1];
+  const double* Lk = vals + pl.loff[k];
+  double a0 = 0.0, a1 = 0.0;
+  if (u1 < 0) {
+    for (i64 i = 0; i < s; ++i) a0 += Lk[i] * x[pl.sidx[s0 + i]];
+    x[u0] -= a0;
+  } else {
+    for (i64 i = 0; i < s; ++i) { const double xi = x[pl.sidx[s0 + i]]; a0 += Lk[2 * i] * xi; a1 += Lk[2 * i + 1] * xi; }
+    x[u0] -= a0; x[u1] -= a1;
+  }
+}
+
 struct BlockedLdlt;   // ldlt_blocked.h
 
 struct HipExec : HostControlled {
@@ -960,8 +978,12 @@ struct HipExec : HostControlled {
       for (i64 lev = pl.nlev - 1; lev >= 0; --lev) {
         const i64 b0 = pl.h_lev_blk[lev], b1 = pl.h_lev_blk[lev + 1];
         if (pl.h_lev_row[lev + 1] == pl.h_lev_row[lev]) continue;       // root blocks: empty structs
-        hipLaunchKernelGGL(sp_bwd_kernel, dim3(static_cast<unsigned>((b1 - b0 + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
-                           stream, pl, vals, x, b0, b1);
+        // average struct length of the level decides: a wavefront per block only pays for long structs
+        if ((pl.h_lev_row[lev + 1] - pl.h_lev_row[lev]) < 16 * (b1 - b0))
+          hipLaunchKernelGGL(sp_bwd_thread_kernel, grid(b1 - b0), dim3(kBlock), 0, stream, pl, vals, x, b0, b1);
+        else
+          hipLaunchKernelGGL(sp_bwd_kernel, dim3(static_cast<unsigned>((b1 - b0 + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
+                             stream, pl, vals, x, b0, b1);
       }
     }
     DNLP_LAUNCH_CHECK();
