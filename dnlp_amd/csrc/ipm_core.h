@@ -954,6 +954,32 @@ class Ipm {
     return std::min(1.0, std::min(az, av));
   }
 
+  // both fraction-to-boundary step sizes in one pass over [variables | constraint rows]
+  DNLP_HD D2 max_steps(double tauv) {
+    const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *ddx = dx, *dds = ds, *eq = eqmask;
+    const double *a = zL, *b = zU, *c = vL, *d = vU, *da = dzL, *db = dzU, *dc = dvL, *dd2 = dvU;
+    const i64 NN = N;
+    const D2 r = ex_->min2(N + m, [=] DNLP_HD(i64 k) -> D2 {
+      double tp = 1.0, td = 1.0;
+      if (k < NN) {
+        const i64 j = k;
+        if (l[j] > -kInf && ddx[j] < 0.0) tp = fmin(tp, -tauv * (xx[j] - l[j]) / ddx[j]);
+        if (u[j] < kInf && ddx[j] > 0.0) tp = fmin(tp, tauv * (u[j] - xx[j]) / ddx[j]);
+        if (da[j] < 0.0) td = fmin(td, -tauv * a[j] / da[j]);
+        if (db[j] < 0.0) td = fmin(td, -tauv * b[j] / db[j]);
+      } else {
+        const i64 i = k - NN;
+        if (eq[i] == 0.0) {
+          if (sl[i] > -kInf && dds[i] < 0.0) tp = fmin(tp, -tauv * (ss[i] - sl[i]) / dds[i]);
+          if (su[i] < kInf && dds[i] > 0.0) tp = fmin(tp, tauv * (su[i] - ss[i]) / dds[i]);
+        }
+        if (dc[i] < 0.0) td = fmin(td, -tauv * c[i] / dc[i]);
+        if (dd2[i] < 0.0) td = fmin(td, -tauv * d[i] / dd2[i]);
+      }
+      return D2{tp, td}; });
+    return D2{std::min(1.0, r.first), std::min(1.0, r.second)};
+  }
+
   DNLP_HD bool filter_ok(double th, double ph) const {
     const double gth = 1e-5, gph = 1e-8;
     for (int k = 0; k < nfilt; ++k)
@@ -1026,8 +1052,9 @@ class Ipm {
       if (!compute_direction(mu, rp, dw)) return status = Error_In_Step_Computation;
     }
     // ---- backtracking filter line search (WB Algorithm A, steps A-5) ----
-    double a_max = max_step_primal(tau);
-    double a_z = max_step_dual(tau);
+    const D2 steps = max_steps(tau);
+    double a_max = steps.first;
+    double a_z = steps.second;
     const double theta_k = theta_at(g, s);
     const double phi_k = barrier_at(f, x, s, mu);
     double gphid;   // directional derivative of the barrier function
