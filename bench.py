@@ -22,6 +22,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+TRAFFIC_PROFILE = "r01_pmc_bench_traffic.json"   # rocprofv3 --pmc passes of this command (refreshed per round)
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X datasheet FP64 matrix peak (dense); see DESIGN.md §5
 
 
@@ -44,8 +45,11 @@ def lower(prob):
 
 
 def run_steps(handle, x0, n_steps):
-    """Exactly n_steps interior-point iterations; restarts from a perturbed point if the
-    solve converges before the count is reached (counted iterations are all real ones)."""
+    """Exactly n_steps interior-point iterations that were carried out (dnlp_ipm_step counts an
+    iteration only when the iterate advanced; the call that merely detects convergence adds
+    nothing).  When the solve converges before the count is reached it restarts from a perturbed
+    point; the restart's dnlp_ipm_begin (one tape sweep + multiplier start, no O(n^3) work) stays
+    inside the timed region and is reported separately (stats[19])."""
     done = 0
     restarts = 0
     while done < n_steps:
@@ -58,42 +62,69 @@ def run_steps(handle, x0, n_steps):
     return restarts
 
 
-def cpu_baseline(n_cpu, seed, device, steps):
-    """The CPU port (oracle/, host instantiation of the same algorithm) on a bounded sample of
-    the same workload: same generator and front-end at order n_cpu, `steps` iterations."""
-    # the scalar OpenMP LDL^T of the port scales to a few dozen threads, not to every core of
-    # the box: pin the thread count before libgomp starts and report exactly that number
-    threads = min(os.cpu_count() or 1, 32)
-    os.environ["OMP_NUM_THREADS"] = str(threads)
+CPU_SWEEP = ((1000, 3), (2000, 3), (4000, 2), (10000, 1))   # (order n, timed iterations) — BASELINE.md §3
+
+
+def cpu_baseline(seed, device, sweep=CPU_SWEEP):
+    """IPOPT-class CPU baseline on the box's host cores, same run: the host build of the same
+    interior-point algorithm (oracle/, test infrastructure) with its dense KKT factorisation routed
+    through LAPACK DSYTRF / DSYTRS (blocked Bunch-Kaufman of the OpenBLAS inside the image's scipy
+    wheel — the dense counterpart of the MA27 / MUMPS factorisation IPOPT calls), on the same
+    generator and front-end at the orders of BASELINE.md §3.  n = 1e5 itself is out of reach of any
+    host factorisation in bench time (n^3/3 = 3.3e14 flop per attempt), so the sweep and its fitted
+    scaling law are reported, never an extrapolated figure as if measured."""
+    import ctypes.util
+    threads = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(threads, 32)))
     from dnlp_amd.tape import serialize
-    from oracle.oracle_capi import OracleProblem
+    from oracle.oracle_capi import OracleProblem, use_lapack
     import dnlp_amd as cp
     from dnlp_amd.device import symmetric_test_matrix
     from dnlp_amd.dnlp2smooth import Dnlp2Smooth
-    from dnlp_amd.nlp_solver import build_nlp_data
-    A = symmetric_test_matrix(n_cpu, seed=seed, spike_eig=4.0 * np.sqrt(n_cpu), device=device)
-    Ah = A.to_host()
-    A.free()
-    x = cp.Variable(n_cpu)
-    rng = np.random.default_rng(seed)
-    x.value = np.ones(n_cpu) / np.sqrt(n_cpu) + 0.1 * rng.standard_normal(n_cpu) / np.sqrt(n_cpu)
-    prob = cp.Problem(cp.Minimize(-cp.quad_form(x, Ah)), [cp.sum_squares(x) == 1])
-    smooth, _ = Dnlp2Smooth().apply(prob)
-    data, _ = build_nlp_data(smooth)
-    orc = OracleProblem(serialize(data["tape_arrays"]))
-    orc.set_option("kkt_pivot_max_n", 0)      # same unpivoted LDL^T path as the GPU run
-    orc.ipm_begin(data["x0"])
-    t0 = time.time()
-    rc, k = orc.ipm_step(steps)
-    dt = time.time() - t0
-    import ctypes.util
-    cores = threads
-    return {"value": k / dt, "unit": "iters/s", "cores": cores, "kind": "port",
-            "sample": "same generator/front-end at n=%d (dense KKT order %d), %d iterations of the "
-                      "host build of the same algorithm (OpenMP LDL^T on %d threads); work per "
-                      "iteration scales as n^3/3, so n=1e5 is %.3g x this sample per iteration; "
-                      "libipopt on this box: %s" % (n_cpu, n_cpu + 1, k, cores, (1e5 / n_cpu) ** 3,
-                                                    ctypes.util.find_library("ipopt") or "not found")}
+    from dnlp_amd.nlp_solver import HIPNLP, build_nlp_data
+    blas_threads = use_lapack(0)
+    kind = "LAPACK dsytrf/dsytrs (scipy OpenBLAS, %d threads)" % blas_threads if blas_threads else \
+        "restated DSYTF2 (no LAPACK found)"
+    table = []
+    for n_cpu, steps in sweep:
+        A = symmetric_test_matrix(n_cpu, seed=seed, spike_eig=4.0 * np.sqrt(n_cpu), device=device)
+        Ah = A.to_host()
+        A.free()
+        x = cp.Variable(n_cpu)
+        rng = np.random.default_rng(seed)
+        x.value = np.ones(n_cpu) / np.sqrt(n_cpu) + 0.1 * rng.standard_normal(n_cpu) / np.sqrt(n_cpu)
+        prob = cp.Problem(cp.Minimize(-cp.quad_form(x, Ah)), [cp.sum_squares(x) == 1])
+        smooth, _ = Dnlp2Smooth().apply(prob)
+        data, _ = build_nlp_data(smooth)
+        orc = OracleProblem(serialize(data["tape_arrays"]))
+        for k, v in HIPNLP.DEFAULT_OPTIONS.items():
+            orc.set_option(k, v)
+        orc.set_option("kkt_pivot_max_n", 10 ** 9)      # pivoted (Bunch-Kaufman) at every order, as IPOPT's solvers are
+        orc.ipm_begin(data["x0"])
+        t0 = time.time()
+        rc, k = orc.ipm_step(steps)
+        dt = time.time() - t0
+        st = orc.stats()
+        nf = max(int(st[1]), 1)
+        table.append({"n": n_cpu, "iterations": k, "factorizations": int(st[1]), "seconds": dt,
+                      "iters_per_s": k / dt if dt > 0 else None,
+                      "s_per_factorization": float(st[4]) / nf,
+                      "factorization_gflops": (n_cpu + 1) ** 3 / 3.0 / (float(st[4]) / nf) / 1e9 if st[4] > 0 else None})
+        orc.close()
+        del Ah, data, smooth, prob
+    ln = np.log([r["n"] for r in table])
+    lt = np.log([max(r["s_per_factorization"], 1e-12) for r in table])
+    expo = float(np.polyfit(ln, lt, 1)[0]) if len(table) >= 2 else None
+    last = table[-1]
+    return {"value": last["iters_per_s"], "unit": "iters/s", "cores": blas_threads or threads, "kind": "port",
+            "n": last["n"], "sweep": table, "factorization_time_exponent": expo,
+            "sample": "host build of the same interior-point algorithm, dense KKT through %s, same generator / "
+                      "front-end at n in %s with %s timed iterations; value = iters/s at n=%d; seconds per "
+                      "factorisation scale as n^%.2f over the sweep (n^3 asymptotically: n=1e5 is %.3g x the "
+                      "n=%d flops per factorisation); libipopt on this box: %s"
+                      % (kind, [r["n"] for r in table], [r["iterations"] for r in table], last["n"],
+                         expo if expo is not None else float("nan"), (1e5 / last["n"]) ** 3, last["n"],
+                         ctypes.util.find_library("ipopt") or "not found")}
 
 
 def main():
@@ -102,7 +133,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--order", type=int, default=100000, help="order n of the dense NLP (BASELINE: 1e5)")
-    ap.add_argument("--cpu-n", type=int, default=2400)
+    ap.add_argument("--cpu-sweep", default="", help="CPU baseline orders as n:iters,... (default: 1000:3,2000:3,4000:2,10000:1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     args = ap.parse_args()
@@ -138,7 +169,7 @@ def main():
     x0 = data["x0"]
     h.ipm_begin(x0)
     run_steps(h, x0, args.warmup)
-    st0 = h.ipm_finish()["stats"].copy()
+    st0 = h.stats()
 
     def barrier():
         if dist is not None:
@@ -152,7 +183,8 @@ def main():
     barrier()
     dt = time.time() - t0
     info = h.ipm_finish()
-    st1 = info["stats"]
+    st1 = h.stats()
+    gathered_ranks, gathered_bytes, backend_name = 1, 0, None
     if dist is not None:
         tmax = torch.tensor([dt], device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -162,6 +194,10 @@ def main():
                             device=tdev, dtype=torch.float64)
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
+        # evidence for the scaling run: how many ranks the collective saw and what it moved
+        gathered_ranks = dist.get_world_size()
+        gathered_bytes = int(sum(g.numel() * g.element_size() for g in gathered))
+        backend_name = "%s (RCCL)" % dist.get_backend() if dist.get_backend() == "nccl" else dist.get_backend()
     else:
         dt_all = dt
     if rank == 0:
@@ -170,38 +206,60 @@ def main():
         # only when it was taken at the same order n
         traffic, traffic_src = None, None
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench_traffic.json")))
+            pj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)))
             if int(pj["n"]) == n:
                 traffic = pj["avg_traffic_bytes_per_launch"]
-                traffic_src = "profiles/r01_pmc_bench_traffic.json (" + pj["command"] + ")"
+                traffic_src = "profiles/" + TRAFFIC_PROFILE + " (" + pj["command"] + ")"
         except (OSError, KeyError, ValueError):
             pass
         upd_s, upd_f, upd_l = st1[13] - st0[13], st1[14] - st0[14], st1[15] - st0[15]
         achieved = upd_f / upd_s / 1e12 if upd_s > 0 else None
+        # counters that survive restarts (stats[16..19]); every one is a delta over the timed region
+        iters_done = int(st1[16] - st0[16])
+        factorizations = int(st1[17] - st0[17])
+        begin_calls, begin_s = int(st1[18] - st0[18]), float(st1[19] - st0[19])
+        per_fact, bailed = int(st1[21]), int(st1[22] - st0[22])
+        # every complete blocked factorisation of this order issues the same number of outer Schur
+        # updates; restarts add begin() factorisations, early-abandoned attempts launch fewer
+        consistent = bailed > 0 or int(upd_l) == per_fact * factorizations
+        if iters_done != args.steps or not consistent:
+            sys.stderr.write("bench: counter mismatch: iterations %d (asked %d), update launches %d, "
+                             "factorizations %d x %d outer updates, abandoned %d\n"
+                             % (iters_done, args.steps, int(upd_l), factorizations, per_fact, bailed))
+        assert iters_done == args.steps, "timed region must hold exactly --steps carried-out iterations"
+        assert consistent, "Schur-update launches do not match the factorisation count"
         out = {
             "metric": "interior-point iters/sec, n=%d dense NLP (sphere quad_form max), 1 replica per GPU" % n,
-            "value": world * args.steps / dt_all,
+            "value": world * iters_done / dt_all,
             "unit": "iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt_all / args.steps,
+            "ms_per_step": 1e3 * dt_all / iters_done,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C4: max x'Ax s.t. ||x||^2=1, dense symmetric A generated in HBM, "
                                    "n=%d (KKT order %d), full Jac_g / Hess_L callbacks" % (n, n + 1),
                        "kkt": "blocked unpivoted LDL^T, FP64-MFMA Schur update", "replicas": world,
+                       "iterations_in_timed_region": iters_done,
+                       "factorizations_in_timed_region": factorizations,
+                       "outer_updates_per_factorization": per_fact,
                        "restarts_in_timed_region": restarts,
-                       "factorizations_in_timed_region": int(st1[1] - st0[1])},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_update (Schur-complement update)",
+                       "restart_begin_seconds_in_timed_region": begin_s if begin_calls else 0.0,
+                       "gathered_ranks": gathered_ranks, "gathered_bytes": gathered_bytes,
+                       "collective_backend": backend_name},
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_update_fast (Schur-complement update)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / PEAK_FP64_MFMA_TFLOPS) if achieved else None,
                          "launches": int(upd_l), "avg_launch_ms": 1e3 * upd_s / upd_l if upd_l else None,
                          "avg_launch_gflop": upd_f / upd_l / 1e9 if upd_l else None,
+                         "whole_iteration_tflops": (n + 1.0) ** 3 / 3.0 * factorizations / dt / 1e12,
                          "traffic": traffic, "traffic_unit": "bytes per launch (FETCH x2-corrected + WRITE)",
                          "traffic_source": traffic_src},
         }
         if not args.no_cpu:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_n, 0, local, 3)
+                sweep = tuple(tuple(int(v) for v in kv.split(":")) for kv in args.cpu_sweep.split(",")) \
+                    if args.cpu_sweep else CPU_SWEEP
+                out["cpu_baseline"] = cpu_baseline(0, local, sweep)
             except Exception as e:   # the baseline is reported, never required for the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": 1, "kind": "port",
                                        "sample": "failed: %s" % e}

@@ -28,6 +28,14 @@ def _ip(a):
     return None if a is None else a.ctypes.data_as(_i32_p)
 
 
+# int cb(alg_mod, iter_count, obj_value, inf_pr, inf_du, mu, d_norm, regularization_size, alpha_du,
+#        alpha_pr, ls_trials, user_data)  -- include/dnlp_hip.h dnlp_intermediate_cb
+INTERMEDIATE_CB = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                              C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p)
+
+N_STATS = 24
+
+
 class CApi:
     """Typed access to one shared library exporting the `<prefix>*` entry points."""
 
@@ -58,6 +66,7 @@ class CApi:
         f("kkt_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)])
         f("get_stats", C.c_int, [C.c_void_p, _dbl_p, C.c_int])
         f("get_log", C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t])
+        f("set_intermediate_cb", C.c_int, [C.c_void_p, INTERMEDIATE_CB, C.c_void_p])
         if hasattr(self.lib, prefix + "time_fused"):
             f("time_fused", C.c_int, [C.c_void_p, _dbl_p, C.c_int, _dbl_p])
         if hasattr(self.lib, prefix + "solve_batch_timed"):      # product library only (no oracle batch path)
@@ -252,6 +261,32 @@ class ProblemHandle:
         if rc != 0:
             raise RuntimeError("set_warm_start failed: %s" % self.api.error())
 
+    def stats(self):
+        st = np.zeros(N_STATS)
+        self.api.get_stats(self.ptr, _dp(st), N_STATS)
+        return st
+
+    def set_intermediate(self, fn):
+        """Per-iteration callback `fn(alg_mod, iter_count, obj_value, inf_pr, inf_du, mu, d_norm,
+        regularization_size, alpha_du, alpha_pr, ls_trials)` (the reference's Oracles.intermediate,
+        nlp_solver.py:423-427).  A return value of False stops the solve with status 5
+        (User_Requested_Stop); None / True continue.  `None` removes the callback."""
+        if fn is None:
+            self._cb_keep = None
+            self.api.set_intermediate_cb(self.ptr, C.cast(None, INTERMEDIATE_CB), None)
+            return
+
+        def tramp(alg, it, obj, ipr, idu, mu, dn, reg, adu, apr, ls, _user):
+            try:
+                r = fn(alg, it, obj, ipr, idu, mu, dn, reg, adu, apr, ls)
+            except Exception:            # an exception inside a C callback cannot propagate: stop the solve
+                import traceback
+                traceback.print_exc()
+                return 0
+            return 0 if r is False else 1
+        self._cb_keep = INTERMEDIATE_CB(tramp)       # keep the thunk alive as long as the handle uses it
+        self.api.set_intermediate_cb(self.ptr, self._cb_keep, None)
+
     def kkt_info(self):
         """Linear-solver plan of this handle: sparse static-pattern LDL^T or dense."""
         out = (C.c_int64 * 8)()
@@ -274,8 +309,8 @@ class ProblemHandle:
                 np.empty(self.n), np.empty(self.n), C.c_int())
 
     def _info(self, status, x, obj, g, mg, zl, zu, iters):
-        st = np.zeros(16)
-        self.api.get_stats(self.ptr, _dp(st), 16)
+        st = np.zeros(N_STATS)
+        self.api.get_stats(self.ptr, _dp(st), N_STATS)
         return {"status": int(status), "x": x, "obj_val": float(obj.value), "g": g[:self.m],
                 "mult_g": mg[:self.m], "mult_x_L": zl, "mult_x_U": zu, "iterations": int(iters.value),
                 "solve_time": float(st[2]), "stats": st}
@@ -303,7 +338,7 @@ class ProblemHandle:
         return {"status": status, "x": x, "obj_val": obj.value, "iterations": iters.value,
                 "evaluations": evals.value, "grad_inf_norm": gn.value, "solve_time": time.time() - t0,
                 "g": np.zeros(self.m), "mult_g": np.zeros(self.m), "mult_x_L": np.zeros(self.n),
-                "mult_x_U": np.zeros(self.n), "stats": np.zeros(16)}
+                "mult_x_U": np.zeros(self.n), "stats": np.zeros(N_STATS)}
 
     def ipm_begin(self, x0):
         x0 = self._x(x0)

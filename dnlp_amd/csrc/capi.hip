@@ -1,9 +1,14 @@
 // libdnlp_hip.so — the C ABI of include/dnlp_hip.h instantiated over the HIP execution space.
+// The public header is included FIRST: every definition below must agree with its prototype (a
+// drifted signature is a compile error — conflicting types for a C-linkage function).
+#include "../../include/dnlp_hip.h"
+
 #include "ldlt_blocked.h"
 #include "capi_impl.h"
 #include "batch.h"
 
-DNLP_DEFINE_CAPI(dnlp_, dnlp::HipExec)
+// struct dnlp_problem (the opaque handle of the header) IS the problem object over the HIP space
+DNLP_DEFINE_CAPI(dnlp_, dnlp::HipExec, dnlp_problem)
 
 using namespace dnlp;
 
@@ -17,7 +22,7 @@ int dnlp_device_count(void) {
 
 // Batched solve (BASELINE C5): `batch` instances sharing the structure of p's tape; see batch.h
 // for the per-instance data layout.  One kernel launch, one workgroup per instance.
-int dnlp_solve_batch_timed(void* vp, int batch, const double* data, int64_t stride, double* x, double* obj, double* mult_g,
+int dnlp_solve_batch_timed(dnlp_problem* vp, int batch, const double* data, int64_t stride, double* x, double* obj, double* mult_g,
                            double* mult_x_L, double* mult_x_U, int* status, int* iters, int* factorizations, double* seconds,
                            double* times);
 static BatchRunner* batch_runner(dnlp_problem_t* p) {
@@ -31,25 +36,25 @@ static BatchRunner* batch_runner(dnlp_problem_t* p) {
   }
   return static_cast<BatchRunner*>(p->batch_state.get());
 }
-int64_t dnlp_batch_stride(void* vp) {
-  auto* p = static_cast<dnlp_problem_t*>(vp);
+int64_t dnlp_batch_stride(dnlp_problem* vp) {
+  dnlp_problem_t* p = vp;
   DNLP_TRY(return batch_runner(p)->in_stride;)
 }
 /* per-instance multipliers (batch-major) for the next dnlp_solve_batch with warm_start_init_point=yes */
-int dnlp_batch_warm_start(void* vp, int batch, const double* mult_g, const double* mult_x_L, const double* mult_x_U) {
-  auto* p = static_cast<dnlp_problem_t*>(vp);
+int dnlp_batch_warm_start(dnlp_problem* vp, int batch, const double* mult_g, const double* mult_x_L, const double* mult_x_U) {
+  dnlp_problem_t* p = vp;
   DNLP_TRY(batch_runner(p)->set_warm_start(batch, mult_g, mult_x_L, mult_x_U); return 0;)
 }
-int dnlp_solve_batch(void* vp, int batch, const double* data, int64_t stride, double* x, double* obj, double* mult_g,
+int dnlp_solve_batch(dnlp_problem* vp, int batch, const double* data, int64_t stride, double* x, double* obj, double* mult_g,
                      double* mult_x_L, double* mult_x_U, int* status, int* iters, int* factorizations, double* seconds) {
   return dnlp_solve_batch_timed(vp, batch, data, stride, x, obj, mult_g, mult_x_L, mult_x_U, status, iters, factorizations,
                                 seconds, nullptr);
 }
 /* same, plus per-instance device-clock phase times: times[4*i..] = wall, t_eval, t_factor, t_solve */
-int dnlp_solve_batch_timed(void* vp, int batch, const double* data, int64_t stride, double* x, double* obj, double* mult_g,
+int dnlp_solve_batch_timed(dnlp_problem* vp, int batch, const double* data, int64_t stride, double* x, double* obj, double* mult_g,
                            double* mult_x_L, double* mult_x_U, int* status, int* iters, int* factorizations, double* seconds,
                            double* times) {
-  auto* p = static_cast<dnlp_problem_t*>(vp);
+  dnlp_problem_t* p = vp;
   DNLP_TRY(
     BatchRunner& r = *batch_runner(p);
     p->ex.sync();
@@ -60,8 +65,8 @@ int dnlp_solve_batch_timed(void* vp, int batch, const double* data, int64_t stri
 // Average seconds of one fused f + grad f evaluation with x resident in HBM (HIP events around
 // `reps` back-to-back evaluations on the problem's stream): the measurement behind the C2 roofline
 // line (tools/run_c2.py).
-int dnlp_time_fused(void* vp, const double* xfree, int reps, double* seconds) {
-  auto* p = static_cast<dnlp_problem_t*>(vp);
+int dnlp_time_fused(dnlp_problem* vp, const double* xfree, int reps, double* seconds) {
+  dnlp_problem_t* p = vp;
   DNLP_TRY(
     if (!p->fused.present) { dnlp::tls_error() = "no fused objective program in this tape"; return -11; }
     const size_t nf = static_cast<size_t>(p->fused.nfree);

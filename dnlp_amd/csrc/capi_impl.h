@@ -29,6 +29,7 @@ struct ProblemT {
   FusedObjective<E> fused;
   std::shared_ptr<void> batch_state;   // exec-space specific batched-solve state (capi.hip)
   bool use_fused = true;
+  bool exact_hessian_substituted = false;   // hessian_approximation=limited-memory was requested
   int lbfgs_history = 10;
   IpmOptions opt;
   i64 pivot_max_n = 2048;
@@ -38,6 +39,12 @@ struct ProblemT {
   double *ws_g = nullptr, *ws_l = nullptr, *ws_u = nullptr;     // warm-start multipliers (exec space)
   double *ws_buf_g = nullptr, *ws_buf_l = nullptr, *ws_buf_u = nullptr;
   int linear_solver = 0;            // 0 auto, 1 dense, 2 sparse (static-pattern LDL^T)
+  // totals over every dnlp_ipm_begin / dnlp_ipm_step of this handle (bench.py: a timed region may
+  // span restarts, and begin() resets the per-solve statistics)
+  long cum_iterations = 0, cum_factorizations = 0, cum_begins = 0;
+  double cum_begin_seconds = 0.0;
+  IntermediateCb intermediate_cb = nullptr;   // dnlp_set_intermediate_cb
+  void* intermediate_user = nullptr;
   SparsePlanHost sparse_plan;
   bool sparse_planned = false, use_sparse = false;
 
@@ -113,6 +120,7 @@ struct ProblemT {
     if (!ipm) ipm.reset(new Ipm<E, DenseKkt<E>>(&ex, &model, &kkt));
     ipm->opt = opt;
     ipm->ws_mult_g = ws_g; ipm->ws_mult_xL = ws_l; ipm->ws_mult_xU = ws_u;
+    ipm->intermediate_cb = intermediate_cb; ipm->intermediate_user = intermediate_user;
   }
 
   int set_option(const std::string& k, const std::string& v) {
@@ -129,8 +137,10 @@ struct ProblemT {
     else if (k == "bound_push") opt.bound_push = num();
     else if (k == "bound_frac") opt.bound_frac = num();
     else if (k == "hessian_approximation") {
-      // "limited-memory" is accepted: the exact tape Hessian is always available and used
+      // "limited-memory" asks IPOPT to do WITHOUT second derivatives; here the exact tape Hessian is
+      // always available, so it is used — the choice is recorded (get_log, stats[22]) rather than hidden
       if (v != "exact" && v != "limited-memory") return -12;
+      exact_hessian_substituted = (v == "limited-memory");
     }
     else if (k == "derivative_test") { /* accepted, unused: oracles are exact by construction */ }
     else if (k == "least_square_init_duals") opt.least_square_init_duals = yes() ? 1 : 0;
@@ -185,51 +195,52 @@ struct ProblemT {
   try { __VA_ARGS__ } catch (const std::exception& e) { dnlp::tls_error() = e.what(); return -199; } \
   catch (...) { dnlp::tls_error() = "unknown exception"; return -199; }
 
-#define DNLP_DEFINE_CAPI(PFX, EXEC)                                                                  \
+#define DNLP_DEFINE_CAPI(PFX, EXEC, HANDLE)                                                          \
+  struct HANDLE : dnlp::ProblemT<EXEC> { using dnlp::ProblemT<EXEC>::ProblemT; };                    \
   using DNLP_CAT(PFX, problem_t) = dnlp::ProblemT<EXEC>;                                             \
   extern "C" {                                                                                       \
   const char* DNLP_CAT(PFX, last_error)(void) { return dnlp::tls_error().c_str(); }                  \
-  void* DNLP_CAT(PFX, create)(const void* blob, size_t len, int device) {                            \
+  HANDLE* DNLP_CAT(PFX, create)(const void* blob, size_t len, int device) {                            \
     try {                                                                                            \
-      auto* p = new DNLP_CAT(PFX, problem_t)(device);                                                \
+      auto* p = new HANDLE(device);                                                \
       p->create(blob, len);                                                                          \
       return p;                                                                                      \
     } catch (const std::exception& e) { dnlp::tls_error() = e.what(); return nullptr; }              \
   }                                                                                                  \
-  void DNLP_CAT(PFX, destroy)(void* vp) { delete static_cast<DNLP_CAT(PFX, problem_t)*>(vp); }      \
-  int DNLP_CAT(PFX, bind_dense)(void* vp, int cid, const double* dptr, int64_t ld) {                 \
+  void DNLP_CAT(PFX, destroy)(HANDLE* vp) { delete vp; }                                                \
+  int DNLP_CAT(PFX, bind_dense)(HANDLE* vp, int cid, const double* dptr, int64_t ld) {                 \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     auto& t = *p->model.owner;                                                                       \
     if (cid < 0 || cid >= static_cast<int>(t.h_dense_ptr.size())) { dnlp::tls_error() = "bad constant id"; return -1; } \
     t.h_dense_ptr[cid] = dptr; t.h_dense_ld[cid] = ld; return 0;                                     \
   }                                                                                                  \
-  int DNLP_CAT(PFX, dims)(void* vp, int64_t* n, int64_t* m, int64_t* nj, int64_t* nh) {              \
+  int DNLP_CAT(PFX, dims)(HANDLE* vp, int64_t* n, int64_t* m, int64_t* nj, int64_t* nh) {              \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     if (n) *n = p->model.t.N; if (m) *m = p->model.t.m;                                              \
     if (nj) *nj = p->model.t.nnzJ; if (nh) *nh = p->model.t.coo_complete ? p->model.t.nnzH : -1;     \
     return 0;                                                                                        \
   }                                                                                                  \
-  int DNLP_CAT(PFX, bounds)(void* vp, double* lb, double* ub, double* cl, double* cu, double* x0) {  \
+  int DNLP_CAT(PFX, bounds)(HANDLE* vp, double* lb, double* ub, double* cl, double* cu, double* x0) {  \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     auto& t = *p->model.owner;                                                                       \
     auto cp = [](double* d, const std::vector<double>& s) { if (d && !s.empty()) std::memcpy(d, s.data(), s.size() * 8); }; \
     cp(lb, t.h_lb); cp(ub, t.h_ub); cp(cl, t.h_cl); cp(cu, t.h_cu); cp(x0, t.h_x0); return 0;        \
   }                                                                                                  \
-  int DNLP_CAT(PFX, eval_f)(void* vp, const double* x, int new_x, double* f) {                       \
+  int DNLP_CAT(PFX, eval_f)(HANDLE* vp, const double* x, int new_x, double* f) {                       \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     DNLP_TRY(p->load_x(x, new_x); *f = p->model.eval_f_after_sweep(); return 0;)                     \
   }                                                                                                  \
-  int DNLP_CAT(PFX, eval_grad_f)(void* vp, const double* x, int new_x, double* grad) {               \
+  int DNLP_CAT(PFX, eval_grad_f)(HANDLE* vp, const double* x, int new_x, double* grad) {               \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     DNLP_TRY(p->load_x(x, new_x); p->model.eval_grad_after_sweep(p->dgrad);                          \
              p->ex.d2h(grad, p->dgrad, 8 * static_cast<size_t>(p->model.t.N)); return 0;)           \
   }                                                                                                  \
-  int DNLP_CAT(PFX, eval_g)(void* vp, const double* x, int new_x, double* g) {                       \
+  int DNLP_CAT(PFX, eval_g)(HANDLE* vp, const double* x, int new_x, double* g) {                       \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     DNLP_TRY(p->load_x(x, new_x); p->model.eval_g_after_sweep(p->dg);                                \
              p->ex.d2h(g, p->dg, 8 * static_cast<size_t>(p->model.t.m)); return 0;)                  \
   }                                                                                                  \
-  int DNLP_CAT(PFX, eval_jac_g)(void* vp, const double* x, int new_x, int32_t* iRow, int32_t* jCol, double* vals) { \
+  int DNLP_CAT(PFX, eval_jac_g)(HANDLE* vp, const double* x, int new_x, int32_t* iRow, int32_t* jCol, double* vals) { \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     auto& t = *p->model.owner;                                                                       \
     DNLP_TRY(                                                                                        \
@@ -241,7 +252,7 @@ struct ProblemT {
       p->load_x(x, new_x); p->model.eval_jac_after_sweep(p->djac);                                   \
       p->ex.d2h(vals, p->djac, 8 * static_cast<size_t>(t.nnzJ)); return 0;)                          \
   }                                                                                                  \
-  int DNLP_CAT(PFX, eval_h)(void* vp, const double* x, int new_x, double sigma, const double* lambda, \
+  int DNLP_CAT(PFX, eval_h)(HANDLE* vp, const double* x, int new_x, double sigma, const double* lambda, \
                             int new_lambda, int32_t* iRow, int32_t* jCol, double* vals) {            \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     auto& t = *p->model.owner;                                                                       \
@@ -260,29 +271,42 @@ struct ProblemT {
       p->model.hess_coo(p->dh);                                                                      \
       p->ex.d2h(vals, p->dh, 8 * static_cast<size_t>(t.nnzH)); return 0;)                            \
   }                                                                                                  \
-  int DNLP_CAT(PFX, set_option)(void* vp, const char* k, const char* v) {                            \
+  int DNLP_CAT(PFX, set_option)(HANDLE* vp, const char* k, const char* v) {                            \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     int rc = p->set_option(k, v);                                                                    \
     if (rc) dnlp::tls_error() = std::string("invalid option ") + k + "=" + v;                        \
     return rc;                                                                                       \
   }                                                                                                  \
-  int DNLP_CAT(PFX, ipm_begin)(void* vp, const double* x0) {                                         \
+  int DNLP_CAT(PFX, set_intermediate_cb)(HANDLE* vp, dnlp::IntermediateCb cb, void* user) {          \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
-    DNLP_TRY(p->ensure_ipm(); p->swept = false; return p->ipm->begin(x0);)                           \
+    p->intermediate_cb = cb; p->intermediate_user = user;                                            \
+    if (p->ipm) { p->ipm->intermediate_cb = cb; p->ipm->intermediate_user = user; }                  \
+    return 0;                                                                                        \
   }                                                                                                  \
-  int DNLP_CAT(PFX, ipm_step)(void* vp, int max_steps, int* done) {                                  \
+  int DNLP_CAT(PFX, ipm_begin)(HANDLE* vp, const double* x0) {                                         \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
-    DNLP_TRY(int r = 99, k = 0;                                                                      \
-             for (; k < max_steps && r == 99; ++k) r = p->ipm->step();                               \
-             p->ex.sync(); if (done) *done = k; return r;)                                           \
+    DNLP_TRY(p->ensure_ipm(); p->swept = false; const double t0 = dnlp::now_sec();                   \
+             const int rc = p->ipm->begin(x0); p->ex.sync();                                         \
+             p->cum_factorizations += p->ipm->stats.factorizations;                                  \
+             p->cum_begin_seconds += dnlp::now_sec() - t0; p->cum_begins += 1; return rc;)           \
   }                                                                                                  \
-  int DNLP_CAT(PFX, ipm_finish)(void* vp, double* x, double* obj, double* g, double* mg, double* mxl, \
+  int DNLP_CAT(PFX, ipm_step)(HANDLE* vp, int max_steps, int* done) {                                  \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    /* counts interior-point iterations that were actually carried out (ipm->iter advanced): the  \
+       step() call that only detects convergence / a limit and returns does not count */            \
+    DNLP_TRY(int r = 99; const int it0 = p->ipm->iter, f0 = p->ipm->stats.factorizations;            \
+             while (r == 99 && p->ipm->iter - it0 < max_steps) r = p->ipm->step();                   \
+             p->ex.sync(); const int k = p->ipm->iter - it0;                                         \
+             p->cum_iterations += k; p->cum_factorizations += p->ipm->stats.factorizations - f0;     \
+             if (done) *done = k; return r;)                                                         \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, ipm_finish)(HANDLE* vp, double* x, double* obj, double* g, double* mg, double* mxl, \
                                 double* mxu, int* iters) {                                           \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     DNLP_TRY(p->ipm->extract(x, obj, mg, mxl, mxu, g);                                               \
              if (iters) *iters = p->ipm->iter; return p->ipm->status;)                               \
   }                                                                                                  \
-  int DNLP_CAT(PFX, solve)(void* vp, double* x, double* obj, double* g, double* mg, double* mxl,     \
+  int DNLP_CAT(PFX, solve)(HANDLE* vp, double* x, double* obj, double* g, double* mg, double* mxl,     \
                            double* mxu, int* iters) {                                                \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     DNLP_TRY(p->ensure_ipm(); p->swept = false;                                                      \
@@ -290,7 +314,7 @@ struct ProblemT {
              if (p->ipm->initialized) p->ipm->extract(x, obj, mg, mxl, mxu, g);                      \
              if (iters) *iters = p->ipm->iter; return st;)                                           \
   }                                                                                                  \
-  int DNLP_CAT(PFX, solve_reduced)(void* vp, double* x, double* obj, int* iters, int* evals, double* gnorm) { \
+  int DNLP_CAT(PFX, solve_reduced)(HANDLE* vp, double* x, double* obj, int* iters, int* evals, double* gnorm) { \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     DNLP_TRY(if (!p->lbfgs) p->lbfgs.reset(new dnlp::ReducedLbfgs<EXEC>(&p->ex, &p->model));           \
              p->lbfgs->tol = p->opt.tol; p->lbfgs->max_iter = p->opt.max_iter > 3000 ? p->opt.max_iter : 20000; \
@@ -302,7 +326,7 @@ struct ProblemT {
              if (iters) *iters = p->lbfgs->iterations; if (evals) *evals = p->lbfgs->evaluations;    \
              if (gnorm) *gnorm = p->lbfgs->gnorm_final; return st;)                                  \
   }                                                                                                  \
-  int DNLP_CAT(PFX, eval_fused)(void* vp, const double* xfree, double* f, double* grad) {            \
+  int DNLP_CAT(PFX, eval_fused)(HANDLE* vp, const double* xfree, double* f, double* grad) {            \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     DNLP_TRY(if (!p->fused.present) { dnlp::tls_error() = "no fused objective program in this tape"; return -11; } \
              const size_t nf = static_cast<size_t>(p->fused.nfree);                                   \
@@ -310,7 +334,7 @@ struct ProblemT {
              p->ex.h2d(dxf, xfree, 8 * nf); *f = p->fused.eval(dxf, dgf); p->ex.d2h(grad, dgf, 8 * nf); \
              p->ex.release(dxf); p->ex.release(dgf); return 0;)                                      \
   }                                                                                                  \
-  int DNLP_CAT(PFX, set_warm_start)(void* vp, const double* mg, const double* mxl, const double* mxu) { \
+  int DNLP_CAT(PFX, set_warm_start)(HANDLE* vp, const double* mg, const double* mxl, const double* mxu) { \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     DNLP_TRY(const size_t N = static_cast<size_t>(p->model.t.N), m = static_cast<size_t>(p->model.t.m); \
              if (!mg || !mxl || !mxu) { p->ws_g = p->ws_l = p->ws_u = nullptr; return 0; }            \
@@ -319,7 +343,7 @@ struct ProblemT {
              p->ex.h2d(p->ws_buf_g, mg, 8 * m); p->ex.h2d(p->ws_buf_l, mxl, 8 * N); p->ex.h2d(p->ws_buf_u, mxu, 8 * N); \
              p->ws_g = p->ws_buf_g; p->ws_l = p->ws_buf_l; p->ws_u = p->ws_buf_u; return 0;)            \
   }                                                                                                  \
-  int DNLP_CAT(PFX, kkt_info)(void* vp, int64_t* out) {                                               \
+  int DNLP_CAT(PFX, kkt_info)(HANDLE* vp, int64_t* out) {                                               \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     DNLP_TRY(p->plan_linear_solver();                                                                \
              out[0] = p->use_sparse ? 1 : 0; out[1] = p->sparse_plan.nnzL; out[2] = p->sparse_plan.nblk(); \
@@ -327,18 +351,21 @@ struct ProblemT {
              out[5] = static_cast<int64_t>(p->sparse_plan.tdst.size());                                 \
              out[6] = static_cast<int64_t>(p->sparse_plan.lev_off.size()) - 1; return 0;)                    \
   }                                                                                                  \
-  int DNLP_CAT(PFX, get_stats)(void* vp, double* s, int n) {                                         \
+  int DNLP_CAT(PFX, get_stats)(HANDLE* vp, double* s, int n) {                                         \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     if (!p->ipm) return -1;                                                                          \
     const auto& st = p->ipm->stats;                                                                  \
-    double k3[3]; p->ex.ldlt_stats(p->kkt.lw, k3);                                                   \
-    double v[16] = {double(st.iterations), double(st.factorizations), st.wall, st.t_eval, st.t_factor, \
+    double k3[5] = {0, 0, 0, 0, 0}; p->ex.ldlt_stats(p->kkt.lw, k3);                                                   \
+    double v[24] = {double(st.iterations), double(st.factorizations), st.wall, st.t_eval, st.t_factor, \
                     st.t_solve, p->ipm->mu, st.inf_pr, st.inf_du, st.cmpl, st.nlp_error,              \
-                    st.last_delta_w, p->ipm->sf, k3[0], k3[1], k3[2]};                               \
-    for (int i = 0; i < n && i < 16; ++i) s[i] = v[i];                                               \
+                    st.last_delta_w, p->ipm->sf, k3[0], k3[1], k3[2],                                \
+                    double(p->cum_iterations), double(p->cum_factorizations), double(p->cum_begins), \
+                    p->cum_begin_seconds, double(st.skipped_factorizations), k3[3], k3[4],                  \
+                    p->exact_hessian_substituted ? 1.0 : 0.0};       \
+    for (int i = 0; i < n && i < 24; ++i) s[i] = v[i];                                               \
     return 0;                                                                                        \
   }                                                                                                  \
-  size_t DNLP_CAT(PFX, get_log)(void* vp, char* buf, size_t cap) {                                   \
+  size_t DNLP_CAT(PFX, get_log)(HANDLE* vp, char* buf, size_t cap) {                                   \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     std::string all;                                                                                 \
     if (p->ipm) for (auto& l : p->ipm->iterlog.lines) { all += l; all += '\n'; }                               \

@@ -95,15 +95,25 @@ DNLP_HD inline double push_into_bounds1(double v, double l, double u, double k1,
 // IPOPT ApplicationReturnStatus values (the integers of ipopt_nlpif.py:31-61)
 enum IpmStatus : int {
   Solve_Succeeded = 0, Solved_To_Acceptable_Level = 1, Infeasible_Problem_Detected = 2,
-  Search_Direction_Becomes_Too_Small = 3, Diverging_Iterates = 4, Maximum_Iterations_Exceeded = -1,
+  Search_Direction_Becomes_Too_Small = 3, Diverging_Iterates = 4, User_Requested_Stop = 5,
+  Maximum_Iterations_Exceeded = -1,
   Restoration_Failed = -2, Error_In_Step_Computation = -3, Maximum_WallTime_Exceeded = -5,
   Not_Enough_Degrees_Of_Freedom = -10, Invalid_Option = -12, Invalid_Number_Detected = -13,
   Internal_Error = -199
 };
 
+// Per-iteration callback, the role of Oracles.intermediate (nlp_solver.py:423-427; cyipopt calls it
+// once per iteration with IPOPT's eleven intermediate_callback values).  A zero return stops the
+// solve with User_Requested_Stop, as IPOPT does for `false`.
+typedef int (*IntermediateCb)(int alg_mod, int iter_count, double obj_value, double inf_pr, double inf_du, double mu,
+                              double d_norm, double regularization_size, double alpha_du, double alpha_pr,
+                              int ls_trials, void* user_data);
+
 template <class E, class K>
 class Ipm {
  public:
+  IntermediateCb intermediate_cb = nullptr;   // host-driven spaces only
+  void* intermediate_user = nullptr;
   DNLP_HD Ipm(E* ex, Model<E>* model, K* kkt) : ex_(ex), md_(model), kkt_(kkt) {}
 
   IpmOptions opt;
@@ -361,6 +371,7 @@ class Ipm {
     delta_w_last = 0.0;
     dc_fixed_count_ = 0; dc_fixed_last_ = false; always_dc_ = false;
     lan_warm_ = false; lan_width_ = 0.0;
+    resto_stationary_ = false; resto_theta_ = 0.0;
     e_cached_valid_ = false;
     fixed_mode = false;
     n_hist = 0;
@@ -1008,15 +1019,17 @@ class Ipm {
   // ---- one interior-point iteration; returns IPOPT status or 99 to continue -----------
   DNLP_HD int step() {
     if (!initialized) return status = Internal_Error;
-    if (iter >= opt.max_iter) return status = Maximum_Iterations_Exceeded;
-    if (now_sec() - t_begin_ > opt.max_wall_time) return status = Maximum_WallTime_Exceeded;
     // (the optimality error of this point was already computed for the log line that closed the
     // previous iteration: nine reductions saved per iteration)
     Err e0 = e_cached_valid_ ? e_cached_ : error(0.0);
     e_cached_valid_ = false;
+    // convergence is tested before the limits, as IPOPT does: a point that converges exactly at
+    // max_iter is a success
     int cv = check_convergence(e0);
-    if (iter == 0) log_iter(e0, 0.0, 0.0, 0.0, 0.0, 0);
+    if (iter == 0 && !notify(e0, 0.0, 0.0, 0.0, 0.0, 0)) return status = User_Requested_Stop;
     if (cv != 99) return status = cv;
+    if (iter >= opt.max_iter) return status = Maximum_Iterations_Exceeded;
+    if (now_sec() - t_begin_ > opt.max_wall_time) return status = Maximum_WallTime_Exceeded;
     {
       const double* xx = x;
       double xm = ex_->max(N, [=] DNLP_HD(i64 j) { return fabs(xx[j]); });
@@ -1119,15 +1132,19 @@ class Ipm {
         // restoration produced a new (x, s) acceptable to the filter; multipliers reset
         ++iter;
         Err e = error(0.0);
-        log_iter(e, 0.0, 0.0, 0.0, 0.0, -1);
         stats.iterations = iter;
+        if (!notify(e, 0.0, 0.0, 0.0, 0.0, -1)) return status = User_Requested_Stop;
         return 99;
       }
       // tiny steps with tiny infeasibility: report the search-direction status
       const double* ddx = dx;
       double dn = ex_->max(N, [=] DNLP_HD(i64 j) { return fabs(ddx[j]); });
       if (dn < 1e-12 && theta_k < opt.constr_viol_tol) return status = Search_Direction_Becomes_Too_Small;
-      return status = (theta_k > opt.constr_viol_tol) ? Infeasible_Problem_Detected : Restoration_Failed;
+      // "infeasible" needs evidence: the restoration must have ended at a (numerically) stationary
+      // point of the constraint violation that is still above constr_viol_tol; anything else is a
+      // failure of the restoration itself, as IPOPT reports it
+      return status = (resto_stationary_ && resto_theta_ > opt.constr_viol_tol) ? Infeasible_Problem_Detected
+                                                                               : Restoration_Failed;
     }
     // filter augmentation (WB eq. (22)) unless f-type step with Armijo
     if (!ftype) filter_add((1.0 - g_th) * theta_k, phi_k - g_ph * theta_k);
@@ -1140,7 +1157,7 @@ class Ipm {
     Err e = error(0.0);
     e_cached_ = e;
     e_cached_valid_ = true;
-    log_iter(e, dnorm, dw, a_z, alpha_used, ls);
+    if (!notify(e, dnorm, dw, a_z, alpha_used, ls)) return status = User_Requested_Stop;
     return 99;
   }
 
@@ -1478,6 +1495,8 @@ class Ipm {
     filter_add((1.0 - 1e-5) * theta_k, phi_k - 1e-8 * theta_k);
     double th_cur = theta_k;
     double zeta = std::sqrt(mu);
+    resto_stationary_ = false;
+    resto_theta_ = theta_k;
     for (int it = 0; it < 100; ++it) {
       // Gauss-Newton system: [zeta*I  J^T; J  -(1 + [ineq]... )]  on the residual r = c(x, s)
       double *sx = Sx, *dd = Dd;
@@ -1521,7 +1540,9 @@ class Ipm {
         }
         a *= 0.5;
       }
-      if (!moved) { zeta *= 10.0; if (zeta > 1e8) return false; continue; }
+      // no damped Gauss-Newton step of any length reduces the violation: a stationary point of it
+      if (!moved) { zeta *= 10.0; if (zeta > 1e8) { resto_stationary_ = true; resto_theta_ = th_cur; return false; } continue; }
+      resto_theta_ = th_cur;
       md_->sweep(x, false);
       eval_derivs_after_sweep();
       double ph = barrier_at(f, x, s, mu);
@@ -1563,8 +1584,13 @@ class Ipm {
     if (check_convergence(e) == Solve_Succeeded) { status = Solve_Succeeded; return; }
     for (int k = 0; k < 7; ++k) ex_->d2d(sv[k], aff[k], sizeof(double) * static_cast<size_t>(sz[k]));
     mu = mu0; tau = tau0;
-    md_->sweep(x, false);
+    // objective, constraint values, derivatives and the reported infeasibilities all refer to the
+    // restored point, not to the abandoned polish iterate
+    eval_fg(x, f, g);
     eval_derivs_after_sweep();
+    e_cached_valid_ = false;
+    acceptable_count = 0;
+    check_convergence(error(0.0));
     status = Solve_Succeeded;
   }
 
@@ -1585,6 +1611,8 @@ class Ipm {
     if (opt.adaptive_fallback) {
       const int strategy0 = opt.mu_strategy;
       const double mu_init0 = opt.mu_init;
+      const int max_iter0 = opt.max_iter;
+      const double max_wall0 = opt.max_wall_time;
       for (int rung = 1; rung <= 2; ++rung) {
         const bool failed = status == Infeasible_Problem_Detected || status == Restoration_Failed ||
                             status == Error_In_Step_Computation || status == Search_Direction_Becomes_Too_Small ||
@@ -1592,6 +1620,11 @@ class Ipm {
         if (!failed) break;
         if (rung == 1 && strategy0 != 1) continue;       // already monotone: straight to rung 2
         const int it_first = iter;
+        // the iteration and wall-clock budgets are the caller's for the whole solve, not per rung
+        if (it_first >= max_iter0) { status = Maximum_Iterations_Exceeded; break; }
+        if (now_sec() - t_all > max_wall0) { status = Maximum_WallTime_Exceeded; break; }
+        opt.max_iter = max_iter0 - it_first;
+        opt.max_wall_time = max_wall0 - (now_sec() - t_all);
         ladder_rung_ = rung;
         opt.mu_strategy = 0;
         if (rung == 2) opt.mu_init = mu_init0 * 10.0 > 1.0 ? mu_init0 * 10.0 : 1.0;
@@ -1605,14 +1638,16 @@ class Ipm {
             if (r != 99) break;
           }
         }
-        iter += it_first;
         if (status == Solve_Succeeded) polish();
+        iter += it_first;
         stats.iterations = iter;
         keep.append(iterlog);
         iterlog = keep;
       }
       opt.mu_strategy = strategy0;
       opt.mu_init = mu_init0;
+      opt.max_iter = max_iter0;
+      opt.max_wall_time = max_wall0;
       ladder_rung_ = 0;
     }
     stats.wall = now_sec() - t_all;
@@ -1646,6 +1681,19 @@ class Ipm {
     }
   }
 
+  // iteration log line + the user's intermediate callback; false = the user asked to stop
+  DNLP_HD bool notify(const Err& e, double dnorm, double dw, double a_du, double a_pr, int ls) {
+    log_iter(e, dnorm, dw, a_du, a_pr, ls);
+#if !DNLP_DEVICE_PASS
+    if constexpr (E::has_host_control) {
+      if (intermediate_cb)
+        return intermediate_cb(ls < 0 ? 1 : 0, iter, f / sf, e.primal, e.dual, mu, dnorm, dw, a_du, a_pr, ls < 0 ? 0 : ls,
+                               intermediate_user) != 0;
+    }
+#endif
+    return true;
+  }
+
   DNLP_HD void log_iter(const Err& e, double dnorm, double dw, double a_du, double a_pr, int ls) {
 #if !DNLP_DEVICE_PASS
     if constexpr (E::has_log) {
@@ -1673,6 +1721,8 @@ class Ipm {
   bool e_cached_valid_ = false;
   int last_nneg_ = 0;               // negative pivots reported by the last factorisation attempt
   int ladder_rung_ = 0;             // 0: first run; 1, 2: rungs of the retry ladder
+  bool resto_stationary_ = false;   // the last restoration ended where no step reduces the violation
+  double resto_theta_ = 0.0;        // violation where the last restoration ended
   int dc_fixed_count_ = 0;          // iterations whose wrong inertia the dual regularisation alone repaired
   bool dc_fixed_last_ = false, always_dc_ = false;
   double *lanV = nullptr, *lanW = nullptr, *lanQ = nullptr, *lanY = nullptr;

@@ -505,6 +505,8 @@ struct BlockedLdlt {
   double last_update_seconds = 0.0;
   double total_update_seconds = 0.0, total_update_flops = 0.0;   // outer (Schur) updates, timed
   i64 total_update_launches = 0;
+  i64 outer_updates_full = 0;              // timed Schur updates of one complete factorisation of this order
+  i64 total_bailed = 0;                    // factorisations abandoned early (wrong inertia already certain)
   std::vector<hipEvent_t> tev0, tev1;      // timing events of the Schur updates of one factorisation
   hipEvent_t evPanel = nullptr, evUpd = nullptr;
   hipStream_t s1 = nullptr;                // stream of the big trailing updates
@@ -654,6 +656,8 @@ struct BlockedLdlt {
       }
     }
     last_update_seconds = upd_ms * 1e-3;
+    if (bailed) ++total_bailed;
+    else { outer_updates_full = 0; for (double f : upd_flops) if (f >= 0.0) ++outer_updates_full; }
     if (bailed) { *nneg = cur.nneg + 1000000; *nzero = cur.nzero; return cur.fail == 0; }
     *nneg = cur.nneg;
     *nzero = cur.nzero;
@@ -701,9 +705,11 @@ inline bool HipExec::ldlt_factor(LdltWork& w, double* A, i64 n, i64 ld, i32* ipi
   w.blocked->padded = w.padded;
   return w.blocked->factor(A, nneg, nzero);
 }
-inline void HipExec::ldlt_stats(LdltWork& w, double* out3) {
-  out3[0] = out3[1] = out3[2] = 0.0;
+inline void HipExec::ldlt_stats(LdltWork& w, double* out3) {   // out3: room for 5 values
+  out3[0] = out3[1] = out3[2] = out3[3] = out3[4] = 0.0;
   if (w.blocked) {
+    out3[3] = static_cast<double>(w.blocked->outer_updates_full);
+    out3[4] = static_cast<double>(w.blocked->total_bailed);
     out3[0] = w.blocked->total_update_seconds;
     out3[1] = w.blocked->total_update_flops;
     out3[2] = static_cast<double>(w.blocked->total_update_launches);

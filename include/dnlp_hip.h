@@ -72,9 +72,22 @@ int dnlp_set_option(dnlp_problem* p, const char* key, const char* val);
  * pointer may be NULL.  Returns the IPOPT ApplicationReturnStatus integer. */
 int dnlp_solve(dnlp_problem* p, double* x_inout, double* obj, double* g, double* mult_g,
                double* mult_x_L, double* mult_x_U, int* iters);
+/* Per-iteration callback: Oracles.intermediate (nlp_solver.py:423-427), which cyipopt invokes once
+ * per iteration with IPOPT's intermediate_callback values (alg_mod 0 regular / 1 restoration).
+ * Called at iteration 0 and after every accepted iterate of dnlp_solve / dnlp_ipm_step, on the
+ * calling thread.  Return non-zero to continue, zero to stop: the solve then ends with status 5
+ * (User_Requested_Stop, ipopt_nlpif.py:31-61), the iterate so far being returned.  NULL removes it.
+ * The batched entry points run entirely on the device and do not call back. */
+typedef int (*dnlp_intermediate_cb)(int alg_mod, int iter_count, double obj_value, double inf_pr,
+                                    double inf_du, double mu, double d_norm,
+                                    double regularization_size, double alpha_du, double alpha_pr,
+                                    int ls_trials, void* user_data);
+int dnlp_set_intermediate_cb(dnlp_problem* p, dnlp_intermediate_cb cb, void* user_data);
 /* Stepwise form of the same loop (used by bench.py to time exactly K iterations):
  * begin() initialises from x0; step() performs up to `max_steps` iterations and returns 99
- * while the loop should continue, otherwise the final status; finish() extracts results. */
+ * while the loop should continue, otherwise the final status; *steps_done counts only iterations
+ * that were carried out (the call that merely detects convergence or a limit adds nothing);
+ * finish() extracts results. */
 int dnlp_ipm_begin(dnlp_problem* p, const double* x0);
 int dnlp_ipm_step(dnlp_problem* p, int max_steps, int* steps_done);
 int dnlp_ipm_finish(dnlp_problem* p, double* x, double* obj, double* g, double* mult_g,
@@ -132,8 +145,15 @@ int dnlp_set_warm_start(dnlp_problem* p, const double* mult_g, const double* mul
  * out[6] = elimination-tree levels (out has room for 8 values).
  * `dnlp_set_option(p, "linear_solver", "dense" | "sparse")` forces a path before the first solve. */
 int dnlp_kkt_info(dnlp_problem* p, int64_t* out8);
-/* Statistics of the last solve: stats[0..15] = iterations, factorizations, wall, t_eval,
- * t_factor, t_solve, mu, inf_pr, inf_du, compl, nlp_error, last_delta_w, ... */
+/* Statistics (n <= 24 values).  Of the last solve: stats[0..12] = iterations, factorizations, wall,
+ * t_eval, t_factor, t_solve, mu, inf_pr, inf_du, compl, nlp_error, last_delta_w, objective scaling;
+ * [13..15] = seconds, flops, launches of the timed outer Schur-complement updates (option
+ * time_kernels=yes).  Over the life of the handle (they survive dnlp_ipm_begin): [16] iterations and
+ * [17] factorizations of all dnlp_ipm_begin / dnlp_ipm_step calls, [18] begin calls, [19] seconds
+ * spent in them, [20] factorizations skipped by the certified regularisation bound (last solve),
+ * [21] outer Schur updates of one complete blocked factorisation, [22] blocked factorisations
+ * abandoned early, [23] 1 when hessian_approximation=limited-memory was requested (the exact tape
+ * Hessian is used all the same). */
 int dnlp_get_stats(dnlp_problem* p, double* stats, int n);
 /* Iteration log of the last solve (IPOPT-style table), NUL terminated; returns bytes needed. */
 size_t dnlp_get_log(dnlp_problem* p, char* buf, size_t cap);

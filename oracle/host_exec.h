@@ -19,13 +19,51 @@
 #include "../dnlp_amd/csrc/fused_obj.h"
 #include "../dnlp_amd/csrc/sparse_ldl.h"
 
+#include <dlfcn.h>
+#include <string>
+
 namespace dnlp {
+
+// Optional LAPACK backend for the dense symmetric-indefinite factorisation of the CPU baseline
+// (bench.py cpu_baseline): DSYTRF / DSYTRS (blocked Bunch-Kaufman, the dense counterpart of the
+// MA27 / MUMPS factorisation IPOPT uses) resolved at run time from the OpenBLAS that ships inside
+// the scipy wheel of this image (Fortran interface, 32-bit integers, symbol prefix scipy_).
+// orc_use_lapack(path) switches every later pivoted ldlt_factor / ldlt_solve of this process to it;
+// the restated DSYTF2 below stays the default so that the parity tests do not depend on a BLAS.
+struct HostLapack {
+  using sytrf_t = void (*)(const char*, const int*, double*, const int*, int*, double*, const int*, int*);
+  using sytrs_t = void (*)(const char*, const int*, const int*, const double*, const int*, const int*, double*,
+                           const int*, int*);
+  sytrf_t sytrf = nullptr;
+  sytrs_t sytrs = nullptr;
+  int (*get_threads)() = nullptr;
+  void (*set_threads)(int) = nullptr;
+  std::vector<double> work;
+  std::vector<int> ipiv;
+  static HostLapack& get() { static HostLapack L; return L; }
+  bool load(const char* path) {
+    void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return false;
+    for (const char* pre : {"scipy_", ""}) {
+      const std::string a = std::string(pre) + "dsytrf_", b = std::string(pre) + "dsytrs_";
+      sytrf = reinterpret_cast<sytrf_t>(dlsym(h, a.c_str()));
+      sytrs = reinterpret_cast<sytrs_t>(dlsym(h, b.c_str()));
+      if (sytrf && sytrs) {
+        get_threads = reinterpret_cast<int (*)()>(dlsym(h, (std::string(pre) + "openblas_get_num_threads").c_str()));
+        set_threads = reinterpret_cast<void (*)(int)>(dlsym(h, (std::string(pre) + "openblas_set_num_threads").c_str()));
+        return true;
+      }
+    }
+    sytrf = nullptr; sytrs = nullptr;
+    return false;
+  }
+};
 
 struct HostExec : HostControlled {
   static constexpr bool is_device = false;
   struct FlatTableT {};
   struct LdltWork { std::vector<double> d; int expect_neg = -1; bool time_updates = false; bool padded = false; };
-  void ldlt_stats(LdltWork&, double* out3) { out3[0] = out3[1] = out3[2] = 0.0; }
+  void ldlt_stats(LdltWork&, double* out5) { for (int k = 0; k < 5; ++k) out5[k] = 0.0; }
   explicit HostExec(int device = 0) { (void)device; }
 
   template <class T> T* alloc(size_t n) {
@@ -156,6 +194,29 @@ struct HostExec : HostControlled {
   // Bunch-Kaufman (DSYTF2, lower) when pivoted; plain right-looking LDL^T otherwise.
   bool ldlt_factor(LdltWork&, double* A, i64 n, i64 ld, i32* ipiv, bool pivoted, int* nneg, int* nzero) {
     *nneg = 0; *nzero = 0;
+    HostLapack& LP = HostLapack::get();
+    if (pivoted && LP.sytrf) {
+      const int nn = static_cast<int>(n), lda = static_cast<int>(ld);
+      int info = 0, lwork = -1;
+      double wq = 0.0;
+      for (i64 j = 0; j < n; ++j) if (!(A[j + j * ld] == A[j + j * ld])) return false;
+      LP.sytrf("L", &nn, A, &lda, ipiv, &wq, &lwork, &info);
+      lwork = static_cast<int>(wq) > nn ? static_cast<int>(wq) : nn;
+      if (static_cast<int>(LP.work.size()) < lwork) LP.work.resize(static_cast<size_t>(lwork));
+      LP.sytrf("L", &nn, A, &lda, ipiv, LP.work.data(), &lwork, &info);
+      if (info < 0) return false;
+      // inertia from D (Sylvester): 1x1 blocks by sign, a 2x2 block has one eigenvalue of each sign
+      for (i64 k = 0; k < n;) {
+        if (ipiv[k] > 0) {
+          const double d = A[k + k * ld];
+          if (!(d == d)) return false;
+          if (d == 0.0) { (*nzero)++; A[k + k * ld] = 1e-20; }
+          else if (d < 0.0) (*nneg)++;
+          k += 1;
+        } else { (*nneg)++; k += 2; }
+      }
+      return true;
+    }
     auto a = [&](i64 i, i64 j) -> double& { return A[i + j * ld]; };
     double amax = 0.0;
     for (i64 j = 0; j < n; ++j) amax = std::fmax(amax, std::fabs(a(j, j)));
@@ -251,6 +312,13 @@ struct HostExec : HostControlled {
   // DSYTRS (lower) / plain L D L^T solve, in place
   void ldlt_solve(LdltWork&, const double* A, i64 n, i64 ld, const i32* ipiv, bool pivoted, double* b) {
     auto a = [&](i64 i, i64 j) -> double { return A[i + j * ld]; };
+    HostLapack& LP = HostLapack::get();
+    if (pivoted && LP.sytrs) {
+      const int nn = static_cast<int>(n), lda = static_cast<int>(ld), one = 1;
+      int info = 0;
+      LP.sytrs("L", &nn, &one, A, &lda, ipiv, b, &nn, &info);
+      return;
+    }
     if (!pivoted) {
       for (i64 k = 0; k < n; ++k) { const double bk = b[k]; if (bk != 0.0) for (i64 i = k + 1; i < n; ++i) b[i] -= a(i, k) * bk; }
       for (i64 k = 0; k < n; ++k) b[k] /= a(k, k);

@@ -30,3 +30,29 @@ def api() -> CApi:
 class OracleProblem(ProblemHandle):
     def __init__(self, blob: bytes):
         super().__init__(api(), blob, 0)
+
+
+def use_lapack(threads: int = 0) -> int:
+    """CPU baseline only: route the pivoted dense KKT factorisation of the host build through LAPACK
+    DSYTRF / DSYTRS of the OpenBLAS inside this image's scipy wheel.  Returns the BLAS thread count
+    (0: no such library here — the restated DSYTF2 stays in use)."""
+    import ctypes
+    import glob
+    import scipy
+    lib = api().lib
+    lib.orc_use_lapack.restype = ctypes.c_int
+    lib.orc_use_lapack.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    base = os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs")
+    for path in sorted(glob.glob(os.path.join(base, "libscipy_openblas*.so"))):
+        n = lib.orc_use_lapack(path.encode(), int(threads))
+        if n > 0:
+            return n
+    return 0
+
+
+def no_lapack():
+    import ctypes
+    lib = api().lib
+    lib.orc_use_lapack.restype = ctypes.c_int
+    lib.orc_use_lapack.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    lib.orc_use_lapack(None, 0)
