@@ -337,8 +337,8 @@ class ProblemHandle:
         status = {0: 0, -1: -1, 3: 3}.get(st, st)
         return {"status": status, "x": x, "obj_val": obj.value, "iterations": iters.value,
                 "evaluations": evals.value, "grad_inf_norm": gn.value, "solve_time": time.time() - t0,
-                "g": np.zeros(self.m), "mult_g": np.zeros(self.m), "mult_x_L": np.zeros(self.n),
-                "mult_x_U": np.zeros(self.n), "stats": np.zeros(N_STATS)}
+                "g": self.eval_g(x) if self.m else np.zeros(0), "mult_g": np.zeros(self.m),
+                "mult_x_L": np.zeros(self.n), "mult_x_U": np.zeros(self.n), "stats": np.zeros(N_STATS)}
 
     def ipm_begin(self, x0):
         x0 = self._x(x0)

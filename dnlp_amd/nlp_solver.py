@@ -17,9 +17,9 @@ Mirror of the reference's `NLPsolver` / `Bounds` / `Oracles`
 """
 from __future__ import annotations
 
-import warnings
-
 import numpy as np
+
+import warnings
 
 from . import settings as s
 from .constraints import (Equality, Inequality, NonPos, lower_equality,
@@ -29,13 +29,16 @@ from .tape import serialize, tape_arrays
 
 
 class Bounds:
-    """reference nlp_solver.py:81-178 (including its two variable orders: bounds and x0
-    follow the pre-lowering problem's variable order, oracles the lowered problem's)."""
+    """reference nlp_solver.py:81-178, with ONE variable order.  The reference builds lb / ub / x0 in
+    the order of `problem.variables()` (:84,116,163) while its oracles — and `InverseData` — walk the
+    problem whose inequalities were rewritten to `rhs - lhs >= 0` (:200), which can list the variables
+    in another order; bounds then land on the wrong variables.  Here everything follows the lowered
+    problem's order, the one the tape and the returned `x` use."""
 
     def __init__(self, problem):
         self.problem = problem
-        self.main_var = problem.variables()
         self.get_constraint_bounds()
+        self.main_var = self.new_problem.variables()
         self.get_variable_bounds()
         self.construct_initial_point()
 
@@ -83,7 +86,7 @@ class Bounds:
     def construct_initial_point(self):
         initial_values = []
         offset = 0
-        for var in self.problem.variables():
+        for var in self.main_var:
             if var.value is not None:
                 initial_values.append(np.atleast_1d(var.value).flatten(order="F"))
             else:
@@ -121,11 +124,7 @@ def build_nlp_data(problem, user_variables=None, fused_spec=None):
     variables of the problem as the user wrote it) enables the reduced-space arrays."""
     bounds = Bounds(problem)
     new_problem = bounds.new_problem
-    variables = new_problem.variables()
-    if [id(v) for v in variables] != [id(v) for v in bounds.main_var]:
-        warnings.warn("Variable order of the lowered constraints differs from the canonical "
-                      "problem's; bounds and x0 follow the reference's ordering quirk "
-                      "(nlp_solver.py:84,116,163 vs :200).")
+    variables = bounds.main_var
     tape = lower_problem(new_problem.objective.expr,
                          [c.args[0] for c in new_problem.constraints], variables)
     inverse_data = InverseData(new_problem)
@@ -258,10 +257,28 @@ class HIPNLP:
             # 0 is silent and 5 prints the IPOPT-style iteration table
             options["print_level"] = 5 if verbose else 0
         handle = data["handle"]
+        if str(options.get("hessian_approximation", "exact")) == "limited-memory":
+            # IPOPT would run a quasi-Newton interior-point method; the tape always has the exact
+            # Hessian, so that is what runs — said out loud, not silently (stats[23] records it too)
+            warnings.warn("hessian_approximation='limited-memory': the exact tape Hessian is used "
+                          "(no quasi-Newton interior-point variant on the device).")
+        intermediate = options.pop("intermediate_callback", None)
         algorithm = options.pop("algorithm", "interior-point")
         device_loop = options.pop("device_loop", "auto")
         for k, v in options.items():
             handle.set_option(k, v)
+        # Oracles.intermediate (nlp_solver.py:423-427): cyipopt calls it once per iteration; so does
+        # the host-driven loop here.  `intermediate_callback=fn` adds a user hook that may return
+        # False to stop the solve (status 5, User_Requested_Stop -> "user_limit").
+        oracles = data["oracles"]
+        data["_intermediate"] = intermediate
+        if intermediate is not None:
+            def _cb(*a):
+                oracles.intermediate(*a)
+                return intermediate(*a)
+            handle.set_intermediate(_cb)
+        else:
+            handle.set_intermediate(None)
         if algorithm in ("lbfgs", "reduced-lbfgs"):
             if not data.get("reducible"):
                 raise ValueError("algorithm='lbfgs' needs an unconstrained smooth problem whose "
@@ -285,9 +302,9 @@ class HIPNLP:
                 if wd is not None and str(options.get("warm_start_init_point", "no")) in ("yes", "True", "1") else None
             raw = handle.solve_batch(row[None, :], want_duals=True, warm=warm)
             info = {"status": int(raw["status"][0]), "x": raw["x"][0], "obj_val": float(raw["obj_val"][0]),
-                    "g": np.zeros(handle.m), "mult_g": raw["mult_g"][0], "mult_x_L": raw["mult_x_L"][0],
+                    "g": handle.eval_g(raw["x"][0]) if handle.m else np.zeros(0), "mult_g": raw["mult_g"][0], "mult_x_L": raw["mult_x_L"][0],
                     "mult_x_U": raw["mult_x_U"][0], "iterations": int(raw["iterations"][0]),
-                    "solve_time": raw["kernel_seconds"], "stats": np.zeros(16), "device_loop": True}
+                    "solve_time": raw["kernel_seconds"], "stats": np.zeros(24), "device_loop": True}
         else:
             info = handle.solve(data["x0"])
         data["oracles"].iterations = info["iterations"]
@@ -297,8 +314,8 @@ class HIPNLP:
     DEVICE_LOOP_MAX_ORDER_SPARSE = 20000  # sparse static-pattern KKT (csrc/sparse_plan.h)
 
     def _use_device_loop(self, data, options, mode) -> bool:
-        if mode in (False, "no", "host"):
-            return False
+        if mode in (False, "no", "host") or data.get("_intermediate") is not None:
+            return False                      # a per-iteration callback needs the host-driven loop
         tape = data["tape"]
         order = len(data["x0"]) + len(data["cl"])
         fits = not tape.dense_blocks and not tape.dense_consts
@@ -324,7 +341,7 @@ class HIPNLP:
         return [{"status": int(raw["status"][k]), "x": raw["x"][k], "obj_val": float(raw["obj_val"][k]),
                  "mult_g": raw["mult_g"][k], "mult_x_L": raw["mult_x_L"][k], "mult_x_U": raw["mult_x_U"][k],
                  "iterations": int(raw["iterations"][k]), "solve_time": raw["kernel_seconds"] / len(rows),
-                 "stats": np.zeros(16)} for k in range(len(rows))]
+                 "stats": np.zeros(24)} for k in range(len(rows))]
 
     def invert(self, solution, inverse_data):
         """reference ipopt_nlpif.py:75-102 (duals are not surfaced there either)."""

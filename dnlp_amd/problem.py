@@ -206,9 +206,14 @@ class Problem:
                                                        solver_opts=kwargs)
             else:
                 solution, inverse_data = batched[run]
-            # the reference ranks runs by the ORIGINAL objective at the unpacked point
-            self.unpack_results(solution, chain, inverse_data, raise_on_error=False)
-            obj_value = self.objective.value
+            # the reference ranks runs by the ORIGINAL objective at the unpacked point.  Only a run
+            # that returned a point can be ranked: a failed run writes no variable values, and the
+            # objective read through the shared Variable state would be some other run's (or the
+            # random start's) — such a run gets +inf and can never win
+            obj_value = None
+            if chain.solver.STATUS_MAP.get(solution["status"]) in s.SOLUTION_PRESENT:
+                self.unpack_results(solution, chain, inverse_data, raise_on_error=False)
+                obj_value = self.objective.value
             if type(self.objective) == Maximize and obj_value is not None:
                 obj_value = -obj_value
             all_objs[run] = np.inf if obj_value is None else obj_value

@@ -15,9 +15,17 @@ def test_standard_form_matches_reference(name):
     assert len(data["cl"]) == int(g["m"])
     sizes = [v.size for v in data["problem"].variables()]
     assert sizes == g["var_sizes"].tolist()
-    np.testing.assert_allclose(data["x0"], g["x0"], rtol=0, atol=0)
-    np.testing.assert_array_equal(data["lb"], g["lb"])
-    np.testing.assert_array_equal(data["ub"], g["ub"])
+    # bounds and x0 are compared PER VARIABLE: the reference lays them out in the pre-lowering
+    # problem's variable order (bounds_var_sizes) while its oracles use the lowered problem's
+    # (var_sizes); bounds_perm maps one to the other.  This build uses the oracle order for both.
+    off = np.concatenate([[0], np.cumsum(g["bounds_var_sizes"])])
+
+    def in_oracle_order(flat):
+        return np.concatenate([flat[off[j]:off[j + 1]] for j in g["bounds_perm"]]) if len(flat) else flat
+
+    np.testing.assert_allclose(data["x0"], in_oracle_order(g["x0"]), rtol=0, atol=0)
+    np.testing.assert_array_equal(data["lb"], in_oracle_order(g["lb"]))
+    np.testing.assert_array_equal(data["ub"], in_oracle_order(g["ub"]))
     np.testing.assert_array_equal(data["cl"], g["cl"])
     np.testing.assert_array_equal(data["cu"], g["cu"])
 
@@ -39,3 +47,28 @@ def test_tape_blob_roundtrip():
     assert set(back) == set(data["tape_arrays"])
     for k, v in data["tape_arrays"].items():
         np.testing.assert_array_equal(back[k], v)
+
+
+def test_bounds_follow_the_lowered_variable_order():
+    """`a <= b` is lowered to `b - a >= 0`, which lists b before a; bounds of `a` must
+    stay on `a` (the reference puts them on the first two entries of whatever comes first)."""
+    import dnlp_amd as cp
+    from dnlp_amd.dnlp2smooth import Dnlp2Smooth
+    from dnlp_amd.nlp_solver import build_nlp_data
+    a = cp.Variable(2, bounds=[0, 1])
+    b = cp.Variable(2)
+    c = cp.Variable()
+    prob = cp.Problem(cp.Minimize(c), [a <= b, c >= cp.sum(b)])
+    smooth, _ = Dnlp2Smooth().apply(prob)
+    data, inv = build_nlp_data(smooth)
+    order = data["problem"].variables()
+    off = 0
+    for v in order:
+        lb, ub = data["lb"][off:off + v.size], data["ub"][off:off + v.size]
+        if v is a:
+            assert np.all(lb == 0.0) and np.all(ub == 1.0)
+        else:
+            assert np.all(np.isneginf(lb)) and np.all(np.isposinf(ub))
+        assert inv.var_offsets[v.id] == off
+        off += v.size
+    assert any(v is a for v in order)

@@ -4,7 +4,7 @@ holds the numbers and their log locations).  north_star: optima within 1e-6 rela
 import numpy as np
 import pytest
 
-from golden_util import build_canonical
+from golden_util import build_canonical, load_golden
 from paper_examples import PAPER, PUBLISHED
 
 REL_TOL = 1e-6
@@ -24,6 +24,19 @@ def test_dimensions_match_published_ipopt_log(name):
         assert len(t.hess_rows) == pub["nnz_hess"]
     if "nnz_jac" in pub:
         assert len(t.jac_rows) == pub["nnz_jac"]
+
+
+def _published_start(name, data):
+    """The start point of the published run.  The reference hands IPOPT `x0` in the variable order
+    of the pre-lowering problem while the oracles use the lowered order (nlp_solver.py:84,163 vs
+    :200); for circle packing the two differ, so the notebook's log belongs to the start the golden
+    record holds verbatim (flat, as cyipopt received it) — not to the user's start, which this
+    build places on the right variables.  Bounds are identical under that permutation."""
+    if name == "nb_circle_packing":
+        g = load_golden(name)
+        assert np.array_equal(g["lb"], data["lb"]) and np.array_equal(g["ub"], data["ub"])
+        return g["x0"]
+    return data["x0"]
 
 
 def _check(name, info):
@@ -53,7 +66,17 @@ def test_cpu_oracle_reaches_published_optimum(name):
     opts.update(PUBLISHED[name].get("options", {}))
     for k, v in opts.items():
         h.set_option(k, v)
-    _check(name, h.solve(data["x0"]))
+    _check(name, h.solve(_published_start(name, data)))
+    if name == "nb_circle_packing":
+        # from the user's own start (correct variable order) the non-convex problem ends at another
+        # KKT point; it must be one (status 0) and feasible
+        h2 = OracleProblem(serialize(data["tape_arrays"]))
+        for k, v in opts.items():
+            h2.set_option(k, v)
+        own = h2.solve(data["x0"])
+        assert own["status"] == 0
+        g = own["g"]
+        assert np.all(g >= data["cl"] - 1e-6) and np.all(g <= data["cu"] + 1e-6)
 
 
 def test_cpu_power_flow_iteration_count_equals_ipopt():
@@ -97,7 +120,7 @@ def test_device_reaches_published_optimum(name, gpu_required):
     opts.update(PUBLISHED[name].get("options", {}))
     for k, v in opts.items():
         dev.set_option(k, v)
-    info = dev.solve(data["x0"])
+    info = dev.solve(_published_start(name, data))
     assert info["status"] == 0, dev.log()
     _check(name, info)
     dev.close()

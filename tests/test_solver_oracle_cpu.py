@@ -233,3 +233,102 @@ def test_reduction_structure_rejects_constrained_problems():
         smooth, _ = Dnlp2Smooth().apply(p)
         data, _ = build_nlp_data(smooth, p.variables())
         assert data["reducible"] is False and "def_var" not in data["tape_arrays"]
+
+
+def test_intermediate_callback_and_user_requested_stop():
+    """Oracles.intermediate (nlp_solver.py:423-427): called at iteration 0 and after every
+    iteration; a False return ends the solve with status 5 (ipopt_nlpif.py:31-61)."""
+    from dnlp_amd.nlp_solver import HIPNLP
+    from dnlp_amd.tape import serialize
+    from oracle.oracle_capi import OracleProblem
+    data, _ = build_canonical("hs071")
+    h = OracleProblem(serialize(data["tape_arrays"]))
+    seen = []
+    h.set_intermediate(lambda *a: seen.append(a) or True)
+    info = h.solve(data["x0"])
+    assert info["status"] == 0
+    assert [a[1] for a in seen] == list(range(info["iterations"] + 1))       # iter_count 0..K
+    assert len(seen[0]) == 11                                                 # cyipopt's eleven values
+    assert abs(seen[-1][2] - info["obj_val"]) <= 1e-12 * abs(info["obj_val"])
+    # stop after the third iteration
+    h.set_intermediate(lambda alg, it, *rest: it < 3)
+    info = h.solve(data["x0"])
+    assert info["status"] == 5 and info["iterations"] == 3
+    assert HIPNLP.STATUS_MAP[5] == "user_limit"
+    h.set_intermediate(None)
+    assert h.solve(data["x0"])["status"] == 0
+
+
+def test_ipm_step_counts_only_iterations_that_were_carried_out():
+    """bench.py's step count: the step() call that merely detects convergence adds nothing, and the
+    cumulative counters survive ipm_begin (stats[16..18])."""
+    from dnlp_amd.tape import serialize
+    from oracle.oracle_capi import OracleProblem
+    data, _ = build_canonical("hs071")
+    h = OracleProblem(serialize(data["tape_arrays"]))
+    total = h.solve(data["x0"])["iterations"]
+    h.ipm_begin(data["x0"])
+    rc, k = h.ipm_step(3)
+    assert (rc, k) == (99, 3)
+    rc, k2 = h.ipm_step(1000)
+    assert rc == 0 and k + k2 == total
+    rc, k3 = h.ipm_step(5)                 # already converged: nothing is carried out, nothing counted
+    assert rc == 0 and k3 == 0
+    st = h.stats()
+    assert st[16] == total and st[18] == 1
+    h.ipm_begin(data["x0"])
+    h.ipm_step(2)
+    st2 = h.stats()
+    assert st2[16] == total + 2 and st2[18] == 2 and st2[17] > st[17]
+    assert st2[0] == 2                     # per-solve statistics were reset by begin
+
+
+def test_convergence_is_tested_before_the_iteration_limit():
+    """A point that converges exactly at max_iter is a success (IPOPT's order of tests)."""
+    from dnlp_amd.tape import serialize
+    from oracle.oracle_capi import OracleProblem
+    data, _ = build_canonical("hs071")
+    h = OracleProblem(serialize(data["tape_arrays"]))
+    n = h.solve(data["x0"])["iterations"]
+    h.set_option("max_iter", n)
+    assert h.solve(data["x0"])["status"] == 0
+    h.set_option("max_iter", n - 1)
+    assert h.solve(data["x0"])["status"] == -1
+
+
+def test_best_of_never_ranks_a_failed_run(monkeypatch):
+    """a SOLVER_ERROR run writes no variable values; it must enter all_objs as +inf and
+    never win, whatever objective the shared Variable state happens to show."""
+    import dnlp_amd as cp
+    from dnlp_amd.nlp_solver import HIPNLP
+    from dnlp_amd.problem import NLPChain
+    x = cp.Variable(2, bounds=[-1, 1])
+    prob = cp.Problem(cp.Minimize(cp.sum_squares(x - 0.25)))
+    chain = NLPChain(False, HIPNLP())
+    objs = [0.5, None, 0.125]              # run 1 fails
+
+    def fake_apply(self, problem, make_handle=True):
+        from dnlp_amd.dnlp2smooth import Dnlp2Smooth
+        from dnlp_amd.nlp_solver import build_nlp_data
+        smooth, _ = Dnlp2Smooth().apply(problem)
+        data, inv = build_nlp_data(smooth)
+        data["_x_offset"] = inv.var_offsets[x.id]
+        return data, inv
+    calls = {"k": 0}
+
+    def fake_solve(self, data, warm_start, verbose, solver_opts=None, solver_cache=None):
+        k = calls["k"]
+        calls["k"] += 1
+        N = len(data["x0"])
+        if objs[k] is None:
+            return {"status": -3, "x": np.full(N, 9.0), "obj_val": -1e9, "iterations": 1}
+        xv = np.zeros(N)
+        xv[data["_x_offset"]:data["_x_offset"] + 2] = 0.25 + np.sqrt(objs[k] / 2.0)
+        return {"status": 0, "x": xv, "obj_val": objs[k], "iterations": 1}
+    monkeypatch.setattr(NLPChain, "apply", fake_apply)
+    monkeypatch.setattr(HIPNLP, "solve_via_data", fake_solve)
+    monkeypatch.setattr(cp.Problem, "_build_chain", lambda self, solver: chain)
+    prob.solve(nlp=True, best_of=3, batch=False)
+    allobjs = prob.solver_stats.extra_stats["all_objs_from_best_of"]
+    assert np.isinf(allobjs[1]) and np.allclose(allobjs[[0, 2]], [0.5, 0.125])
+    assert abs(prob.value - 0.125) < 1e-12

@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(HERE, "..", "tests"))
 
-from ref_import import import_reference, ref_chain_apply  # noqa: E402
+from ref_import import import_reference, ref_reductions  # noqa: E402
 
 K_POINTS = 3
 
@@ -45,7 +45,12 @@ def main():
         if only and name not in only:
             continue
         prob = builder(cp)
-        data, inv, chain = ref_chain_apply(cp, prob)
+        # the reference's chain (problems/problem.py:1220-1243), reduction by reduction, so that the
+        # smooth problem NLPsolver.apply receives (whose variables() order its Bounds use) is at hand
+        smooth = prob
+        for red in ref_reductions(cp, prob)[:-1]:
+            smooth, _ = red.apply(smooth)
+        data, inv = ref_reductions(cp, prob)[-1].apply(smooth)
         o = data["oracles"]
         x0 = np.asarray(data["x0"], dtype=float)
         N, m = x0.size, len(data["cl"])
@@ -60,6 +65,13 @@ def main():
             "var_ndims": np.array([v.ndim for v in data["problem"].variables()], np.int64),
             "is_max": int(type(prob.objective) == cp.Maximize),
         }
+        # The reference lays lb / ub / x0 out in the order of the PRE-lowering problem's variables
+        # (nlp_solver.py:84,116,163) but evaluates its oracles in the lowered problem's order (:200).
+        # bounds_perm[k] = position, in the bounds order, of the k-th variable of the oracle order, so
+        # that the per-variable bounds can be compared whatever flat order an implementation uses.
+        pre_ids = [v.id for v in smooth.variables()]
+        rec["bounds_var_sizes"] = np.array([v.size for v in smooth.variables()], np.int64)
+        rec["bounds_perm"] = np.array([pre_ids.index(v.id) for v in data["problem"].variables()], np.int64)
         rng = np.random.default_rng(0)
         for k in range(K_POINTS):
             x = sample_point(rng, x0, np.asarray(data["lb"]), np.asarray(data["ub"])) if k else x0.copy()

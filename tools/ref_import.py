@@ -29,6 +29,16 @@ def import_reference():
     return cp
 
 
+def ref_reductions(cp, prob):
+    """The reduction list of problem.py:1220-1228 (the last entry is the NLPsolver)."""
+    from cvxpy.reductions.cvx_attr2constr import CvxAttr2Constr
+    from cvxpy.reductions.dnlp2smooth.dnlp2smooth import Dnlp2Smooth
+    from cvxpy.reductions.flip_objective import FlipObjective
+    from cvxpy.reductions.solvers.nlp_solvers.ipopt_nlpif import IPOPT
+    return ([FlipObjective()] if type(prob.objective) == cp.Maximize else []) + \
+        [CvxAttr2Constr(reduce_bounds=False), Dnlp2Smooth(), IPOPT()]
+
+
 def ref_chain_apply(cp, prob):
     """Mirror of problem.py:1220-1243 without the cyipopt call."""
     from cvxpy.reductions.cvx_attr2constr import CvxAttr2Constr
