@@ -128,10 +128,90 @@ def nb_circle_packing(cp):
     return cp.Problem(cp.Minimize(cp.max(cp.norm_inf(centers, axis=1) + radius)), cons)
 
 
+def _nmf_shapes(n=20):
+    """The three basis images of examples/nlp_examples/NMF.ipynb (cell 1): disc, square, triangle."""
+    yy, xx = np.ogrid[-n // 2:n // 2, -n // 2:n // 2]
+    disc = (xx ** 2 + yy ** 2 <= 5 ** 2).astype(float)
+    square = np.zeros((n, n))
+    st = (n - 10) // 2
+    square[st:st + 10, st:st + 10] = 1
+    tri = np.zeros((n, n))
+    for i in range(12):
+        row = n // 2 + i - 6
+        if 0 <= row < n:
+            tri[row, max(0, n // 2 - i // 2):min(n, n // 2 + i // 2)] = 1
+    return [disc, square, tri]
+
+
+def nmf_data(n_samples=100):
+    """Noisy mixtures of the three shapes (NMF.ipynb cells 2-3, seed 0): returns (A_true, A)."""
+    np.random.seed(0)
+    bases = _nmf_shapes()
+    true_images, noises = [], []
+    for _ in range(n_samples):
+        coeffs = 10 * np.random.rand(3)
+        coeffs /= coeffs.sum()
+        img = sum(c * b for c, b in zip(coeffs, bases))
+        noise = 0.2 * np.random.randn(*img.shape)
+        noise[img + noise < 0] = -img[img + noise < 0]
+        true_images.append(img.flatten())
+        noises.append(noise.flatten())
+    A_true = np.array(true_images)
+    return A_true, A_true + np.array(noises)
+
+
+def nb_nmf(cp, n_samples=100):
+    """Nonnegative matrix factorisation, examples/nlp_examples/NMF.ipynb (100 images of 20 x 20,
+    k = 3): min ||A - X Y||_F^2, X, Y >= 0 — the bilinear Var @ Var product.  Canonical form
+    N = 41 500, m = 40 000.  The notebook prints no IPOPT log, so there is no published objective;
+    the checks are KKT optimality and the denoising property (tests/test_paper_examples.py)."""
+    _, A = nmf_data(n_samples)
+    n, m, k = A.shape[0], A.shape[1], 3
+    X = cp.Variable((n, k), bounds=[0, None])
+    Y = cp.Variable((k, m), bounds=[0, None])
+    X.value, Y.value = np.random.rand(n, k), np.random.rand(k, m)
+    return cp.Problem(cp.Minimize(cp.sum(cp.square(A - X @ Y))))
+
+
+def nb_nmf_small(cp):
+    """The same example with 12 images (N = 5 036): the size whose oracle vectors are committed."""
+    return nb_nmf(cp, 12)
+
+
+def sparse_recovery_data(m=80, k=30, n=100, seed=0):
+    """One cell of the sweep of examples/nlp_examples/sparse_recovery.ipynb (n = 100, m in 60..80,
+    k in 30..50; `rng = default_rng(0)` draws the support, x0 and A in that order)."""
+    rng = np.random.default_rng(seed)
+    x0 = np.zeros(n)
+    ind = rng.permutation(n)[:k]
+    x0[ind] = rng.standard_normal(k) * 5
+    A = rng.standard_normal((m, n))
+    return A, A @ x0, x0
+
+
+def nb_sparse_recovery(cp):
+    """Non-convex sparse recovery, sparse_recovery.ipynb: min sum sqrt|x| s.t. Ax = y (m = 80
+    measurements, k = 30 non-zeros of n = 100).  The notebook solves it with Knitro and reports only
+    recovery probabilities; the known answer is the recovery property ||x - x0|| <= 1e-2 ||x0||
+    (RECOVERY_TOL of the notebook), which holds with probability ~1 at this (m, k)."""
+    A, y, _ = sparse_recovery_data()
+    x = cp.Variable((100,))
+    return cp.Problem(cp.Minimize(cp.sum(cp.sqrt(cp.abs(x)))), [A @ x == y])
+
+
 PAPER = {
     "nb_localization": nb_localization,
     "nb_path_planning": nb_path_planning,
     "nb_phase_retrieval": nb_phase_retrieval,
     "nb_power_flow": nb_power_flow,
     "nb_circle_packing": nb_circle_packing,
+    "nb_nmf_small": nb_nmf_small,
+    "nb_sparse_recovery": nb_sparse_recovery,
 }
+
+# notebook-size problems that are solved (not golden-compared oracle by oracle: the vectors would be
+# tens of MB); their oracle arithmetic is covered by the *_small variants above
+PAPER_LARGE = {"nb_nmf": nb_nmf}
+
+# portfolio_construction.ipynb is the eighth example of the paper; its data file (a returns CSV) is
+# not in the reference tree (.MISSING_LARGE_BLOBS), so it cannot be restated here.

@@ -10,7 +10,7 @@ from paper_examples import PAPER, PUBLISHED
 REL_TOL = 1e-6
 
 
-@pytest.mark.parametrize("name", sorted(PAPER))
+@pytest.mark.parametrize("name", sorted(PUBLISHED))
 def test_dimensions_match_published_ipopt_log(name):
     """IPOPT's header counts free variables, equality rows, inequality rows and non-zeros."""
     pub = PUBLISHED[name]
@@ -109,7 +109,7 @@ def test_cpu_power_flow_iteration_count_equals_ipopt():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(set(PAPER) - {"nb_localization"}))
+@pytest.mark.parametrize("name", sorted(set(PUBLISHED) - {"nb_localization"}))
 def test_device_reaches_published_optimum(name, gpu_required):
     from dnlp_amd import _capi
     from dnlp_amd.nlp_solver import HIPNLP
@@ -124,3 +124,68 @@ def test_device_reaches_published_optimum(name, gpu_required):
     assert info["status"] == 0, dev.log()
     _check(name, info)
     dev.close()
+
+
+# ---- examples without a published IPOPT log: NMF.ipynb, sparse_recovery.ipynb ------------------------
+def _check_sparse_recovery(x):
+    """RECOVERY_TOL of the notebook: ||x - x0|| <= 1e-2 ||x0|| (here the recovery is exact)."""
+    from paper_examples import sparse_recovery_data
+    A, y, x0 = sparse_recovery_data()
+    assert np.linalg.norm(x - x0) <= 1e-2 * np.linalg.norm(x0)
+    assert np.linalg.norm(A @ x - y) <= 1e-6 * np.linalg.norm(y)
+
+
+def _check_nmf(prob, X, Y, n_samples):
+    """No published objective exists.  Known properties: a KKT point (status optimal) with X, Y >= 0
+    whose rank-3 reconstruction denoises — it is closer to the noise-free images than the data are,
+    and no rank-3 nonnegative factorisation can beat the unconstrained rank-3 SVD."""
+    from paper_examples import nmf_data
+    A_true, A = nmf_data(n_samples)
+    R = X @ Y
+    assert X.min() >= -1e-8 and Y.min() >= -1e-8
+    assert abs(prob.value - np.sum((A - R) ** 2)) <= 1e-6 * prob.value
+    sv = np.linalg.svd(A, compute_uv=False)
+    assert prob.value >= np.sum(sv[3:] ** 2) * (1 - 1e-9)              # Eckart-Young lower bound
+    assert prob.value <= 1.05 * np.sum((A - A_true) ** 2)             # fits down to the noise level
+    # (12 images determine the three shapes less sharply than the notebook's 100)
+    assert np.linalg.norm(R - A_true) < (0.5 if n_samples >= 100 else 0.8) * np.linalg.norm(A - A_true)
+
+
+def test_cpu_sparse_recovery_and_small_nmf():
+    import dnlp_amd as cp
+    from oracle_frontend import oracle_engine
+    from paper_examples import nb_nmf, nb_sparse_recovery
+    with oracle_engine():
+        p = nb_sparse_recovery(cp)
+        p.solve(nlp=True)
+        assert p.status == cp.OPTIMAL
+        _check_sparse_recovery(p.variables()[0].value)
+        p = nb_nmf(cp, 12)
+        p.solve(nlp=True)
+        assert p.status == cp.OPTIMAL
+        X, Y = (v.value for v in p.variables())
+        _check_nmf(p, X, Y, 12)
+
+
+@pytest.mark.gpu
+def test_device_sparse_recovery(gpu_required):
+    import dnlp_amd as cp
+    from paper_examples import nb_sparse_recovery
+    p = nb_sparse_recovery(cp)
+    p.solve(nlp=True)
+    assert p.status == cp.OPTIMAL
+    _check_sparse_recovery(p.variables()[0].value)
+
+
+@pytest.mark.gpu
+def test_device_nmf_at_notebook_size(gpu_required):
+    """NMF.ipynb at its own size: 100 images of 20 x 20, k = 3 -> N = 41 500, m = 40 000, the bilinear
+    Var @ Var product; sparse static-pattern KKT (6e7 update triples)."""
+    import dnlp_amd as cp
+    from paper_examples import nb_nmf
+    p = nb_nmf(cp, 100)
+    p.solve(nlp=True)
+    assert p.status == cp.OPTIMAL
+    X, Y = (v.value for v in p.variables())
+    assert X.shape == (100, 3) and Y.shape == (3, 400)
+    _check_nmf(p, X, Y, 100)

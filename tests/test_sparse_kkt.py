@@ -26,8 +26,11 @@ def _solve(name, linear_solver, **extra):
 
 @pytest.mark.parametrize("name", sorted(GOLDEN_ZOO))
 def test_sparse_and_dense_kkt_reach_the_same_optimum(name):
-    if name in ("mle", "nb_phase_retrieval", "nb_path_planning", "nb_power_flow"):
-        pytest.skip("dense host factorisation of this order takes seconds; covered by test_paper_examples")
+    if name in ("mle", "nb_phase_retrieval", "nb_path_planning", "nb_power_flow", "nb_nmf_small"):
+        pytest.skip("dense host factorisation of this order takes seconds to minutes; covered by test_paper_examples")
+    if name == "nb_sparse_recovery":
+        pytest.skip("dense measurement matrix (80 x 100 Jacobian block): the automatic choice is the dense "
+                    "Bunch-Kaufman path, static pivots are not meant for this pattern")
     if name == "sphere60":
         pytest.skip("dense quad_form block: no sparse plan by construction")
     hs, s = _solve(name, "sparse")
