@@ -83,6 +83,13 @@ def cpu_baseline(seed, device, sweep=CPU_SWEEP):
     from dnlp_amd.dnlp2smooth import Dnlp2Smooth
     from dnlp_amd.nlp_solver import HIPNLP, build_nlp_data
     blas_threads = use_lapack(0)
+    probe = None
+    if blas_threads:
+        # OpenBLAS's DSYTRF does not scale to every core of a large host (64 threads measured 3x slower
+        # than 16 on the GPU box): take the fastest of a few thread counts, and say which
+        from oracle.oracle_capi import lapack_best_threads
+        cand = sorted({t for t in (4, 8, 16, 32, threads) if t <= threads})
+        blas_threads, probe = lapack_best_threads(cand)
     kind = "LAPACK dsytrf/dsytrs (scipy OpenBLAS, %d threads)" % blas_threads if blas_threads else \
         "restated DSYTF2 (no LAPACK found)"
     table = []
@@ -117,7 +124,8 @@ def cpu_baseline(seed, device, sweep=CPU_SWEEP):
     expo = float(np.polyfit(ln, lt, 1)[0]) if len(table) >= 2 else None
     last = table[-1]
     return {"value": last["iters_per_s"], "unit": "iters/s", "cores": blas_threads or threads, "kind": "port",
-            "n": last["n"], "sweep": table, "factorization_time_exponent": expo,
+            "n": last["n"], "sweep": table, "factorization_time_exponent": expo, "host_cores": threads,
+            "dsytrf_n3000_seconds_by_threads": probe,
             "sample": "host build of the same interior-point algorithm, dense KKT through %s, same generator / "
                       "front-end at n in %s with %s timed iterations; value = iters/s at n=%d; seconds per "
                       "factorisation scale as n^%.2f over the sweep (n^3 asymptotically: n=1e5 is %.3g x the "

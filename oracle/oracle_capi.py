@@ -50,6 +50,22 @@ def use_lapack(threads: int = 0) -> int:
     return 0
 
 
+def lapack_best_threads(candidates, n=3000):
+    """Thread count among `candidates` with the fastest DSYTRF of order n on this host (after
+    use_lapack); leaves the BLAS set to it.  Returns (threads, {threads: seconds})."""
+    import ctypes
+    lib = api().lib
+    lib.orc_lapack_probe.restype = ctypes.c_double
+    lib.orc_lapack_probe.argtypes = [ctypes.c_int, ctypes.c_int]
+    times = {}
+    for t in candidates:
+        lib.orc_lapack_probe(n, t)                       # warm the threads
+        times[t] = lib.orc_lapack_probe(n, t)
+    best = min(times, key=times.get)
+    lib.orc_lapack_probe(64, best)
+    return best, times
+
+
 def no_lapack():
     import ctypes
     lib = api().lib

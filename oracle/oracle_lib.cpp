@@ -16,3 +16,28 @@ extern "C" int orc_use_lapack(const char* path, int threads) {
   if (threads > 0 && L.set_threads) L.set_threads(threads);
   return L.get_threads ? L.get_threads() : 1;
 }
+
+// Seconds of one DSYTRF of a seeded symmetric indefinite matrix of order n with `threads` BLAS
+// threads (bench.py picks the thread count that factors fastest on this box: OpenBLAS's DSYTRF does
+// not scale to every core of a large host).  Negative when no LAPACK is loaded.
+extern "C" double orc_lapack_probe(int n, int threads) {
+  dnlp::HostLapack& L = dnlp::HostLapack::get();
+  if (!L.sytrf) return -1.0;
+  if (threads > 0 && L.set_threads) L.set_threads(threads);
+  std::vector<double> A(static_cast<size_t>(n) * n);
+  uint64_t s = 0x9E3779B97F4A7C15ull;
+  for (int j = 0; j < n; ++j)
+    for (int i = j; i < n; ++i) {
+      s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+      A[static_cast<size_t>(i) + static_cast<size_t>(j) * n] = static_cast<double>(s >> 11) / 9007199254740992.0 - 0.5;
+    }
+  std::vector<int> ipiv(static_cast<size_t>(n));
+  int info = 0, lwork = -1;
+  double wq = 0.0;
+  L.sytrf("L", &n, A.data(), &n, ipiv.data(), &wq, &lwork, &info);
+  lwork = static_cast<int>(wq) > n ? static_cast<int>(wq) : n;
+  std::vector<double> work(static_cast<size_t>(lwork));
+  const double t0 = dnlp::now_sec();
+  L.sytrf("L", &n, A.data(), &n, ipiv.data(), work.data(), &lwork, &info);
+  return dnlp::now_sec() - t0;
+}

@@ -16,6 +16,22 @@ def coo_dense(rows, cols, vals, shape):
     return np.asarray(sp.coo_matrix((np.asarray(vals, float), (rows, cols)), shape=shape).todense())
 
 
+def assert_coo_close(shape, r1, c1, v1, r2, c2, v2, rtol, atol):
+    """|A - B| <= atol + rtol |B| entrywise for two COO matrices (duplicates summed), without
+    densifying: large problems (N in the thousands) would otherwise cost N^2 per comparison."""
+    if shape[0] * shape[1] <= 4_000_000:
+        np.testing.assert_allclose(coo_dense(r1, c1, v1, shape), coo_dense(r2, c2, v2, shape), rtol=rtol, atol=atol)
+        return
+    A = sp.coo_matrix((np.asarray(v1, float), (r1, c1)), shape=shape).tocsr()
+    B = sp.coo_matrix((np.asarray(v2, float), (r2, c2)), shape=shape).tocsr()
+    D = (A - B).tocoo()
+    if D.nnz == 0:
+        return
+    ref = np.asarray(B[D.row, D.col]).ravel()
+    bad = np.abs(D.data) > atol + rtol * np.abs(ref)
+    assert not bad.any(), "max abs diff %g at %d entries" % (np.abs(D.data[bad]).max(), int(bad.sum()))
+
+
 def build_canonical(name):
     """Front-end side: problem -> (flip) -> dnlp2smooth -> Bounds + tape."""
     import dnlp_amd as cp
@@ -48,7 +64,8 @@ def check_oracles_against_golden(g, ev, rtol=1e-12, atol0=1e-12):
         if extra:
             er, ec = np.array(sorted(extra)).T
             for vals in ref_vals:
-                assert np.all(coo_dense(ref_r, ref_c, vals, shape)[er, ec] == 0.0)
+                M = sp.coo_matrix((np.asarray(vals, float), (ref_r, ref_c)), shape=shape).tocsr()
+                assert np.all(np.asarray(M[er, ec]).ravel() == 0.0)
 
     same_pattern(jr, jc, g["jac_rows"], g["jac_cols"],
                  [g["jac_%d" % k] for k in range(K_POINTS)] if m else [], (max(m, 1), N))
@@ -63,9 +80,6 @@ def check_oracles_against_golden(g, ev, rtol=1e-12, atol0=1e-12):
         np.testing.assert_allclose(ev.gradient(x), g["grad_%d" % k], rtol=rtol, atol=atol)
         if m:
             np.testing.assert_allclose(ev.constraints(x), g["g_%d" % k], rtol=rtol, atol=atol)
-            J = coo_dense(jr, jc, ev.jacobian(x), (m, N))
-            Jg = coo_dense(g["jac_rows"], g["jac_cols"], g["jac_%d" % k], (m, N))
-            np.testing.assert_allclose(J, Jg, rtol=rtol, atol=atol)
-        H = coo_dense(hr, hc, ev.hessian(x, lam, sigma), (N, N))
-        Hg = coo_dense(g["hess_rows"], g["hess_cols"], g["hess_%d" % k], (N, N))
-        np.testing.assert_allclose(H, Hg, rtol=rtol, atol=atol)
+            assert_coo_close((m, N), jr, jc, ev.jacobian(x), g["jac_rows"], g["jac_cols"], g["jac_%d" % k], rtol, atol)
+        assert_coo_close((N, N), hr, hc, ev.hessian(x, lam, sigma), g["hess_rows"], g["hess_cols"],
+                         g["hess_%d" % k], rtol, atol)
