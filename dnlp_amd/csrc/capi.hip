@@ -78,7 +78,10 @@ int dnlp_time_fused(dnlp_problem* vp, const double* xfree, int reps, double* sec
     DNLP_HIP_CHECK(hipEventCreate(&e0));
     DNLP_HIP_CHECK(hipEventCreate(&e1));
     DNLP_HIP_CHECK(hipEventRecord(e0, p->ex.stream));
-    for (int r = 0; r < reps; ++r) p->fused.eval(dx, dg);
+    // the generated kernel is launched back to back (no scalar read-back between launches: kernel time,
+    // not host round trips); the interpreter path keeps its evaluation call
+    for (int r = 0; r < reps; ++r)
+      if (!p->ex.fused_generated_launch(p->fused.progs, dx, p->fused.consts, dg, p->fused.nfree)) p->fused.eval(dx, dg);
     DNLP_HIP_CHECK(hipEventRecord(e1, p->ex.stream));
     DNLP_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -87,6 +90,33 @@ int dnlp_time_fused(dnlp_problem* vp, const double* xfree, int reps, double* sec
     p->ex.release(dx); p->ex.release(dg);
     *seconds = 1e-3 * ms / (reps > 0 ? reps : 1);
     return 0;)
+}
+
+// Generated-kernel self check (no GPU needed: hiprtc cross-compiles): parse the fused programs of a
+// tape blob, generate the specialised f + grad f kernel with `elems_per_lane` entries per lane and
+// compile it for gfx950.  0 = compiled, 1 = this objective has no generated form (reason in log),
+// 2 = compiler error (text in log), -11 = the tape carries no fused program.
+int dnlp_fused_codegen_check(const void* blob, size_t len, int elems_per_lane, char* src_out, size_t src_cap, char* log_out,
+                             size_t log_cap) {
+  DNLP_TRY(
+    auto put = [](char* dst, size_t cap, const std::string& t) {
+      if (!dst || !cap) return;
+      const size_t n = t.size() < cap - 1 ? t.size() : cap - 1;
+      std::memcpy(dst, t.data(), n);
+      dst[n] = 0;
+    };
+    TapeBlob tb(blob, len);
+    std::vector<FusedSlotProg> progs;
+    i64 nconst = 0; i64 nfree = 0; double c0 = 0.0;
+    if (!fused_parse_programs(tb, progs, nconst, c0, nfree)) { put(log_out, log_cap, "no fused program in this tape"); return -11; }
+    const FusedCodegenInfo info = fused_codegen_plan(progs, elems_per_lane > 0 ? elems_per_lane : 4);
+    if (!info.ok) { put(log_out, log_cap, info.why); return 1; }
+    const std::string src = fused_codegen_eval_source(progs, info);
+    put(src_out, src_cap, src);
+    std::string log;
+    const std::vector<char> code = rtc_compile(src, log, false);
+    put(log_out, log_cap, log);
+    return code.empty() ? 2 : 0;)
 }
 
 const char* dnlp_version(void) { return "dnlp_amd 0.1.0 (gfx950)"; }

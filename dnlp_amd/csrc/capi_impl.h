@@ -49,6 +49,9 @@ struct ProblemT {
   bool sparse_planned = false, use_sparse = false;
 
   explicit ProblemT(int device) : ex(device) {}
+  // generated kernels exist in the HIP space only
+  template <class X = E> auto set_fused_codegen(bool on) -> decltype(std::declval<X&>().fused_codegen, void()) { ex.fused_codegen = on; }
+  void set_fused_codegen(...) {}
   ~ProblemT() { model.destroy(); }
 
   void create(const void* data, size_t len) {
@@ -170,6 +173,7 @@ struct ProblemT {
     else if (k == "time_kernels") time_kernels = yes();
     else if (k == "lbfgs_history" || k == "limited_memory_max_history") lbfgs_history = static_cast<int>(num());
     else if (k == "fused_objective") use_fused = yes();
+    else if (k == "fused_codegen") set_fused_codegen(yes());
     else if (k == "adaptive_fallback") opt.adaptive_fallback = yes() ? 1 : 0;
     else if (k == "lanczos_inertia_bound") opt.lanczos_inertia_bound = yes() ? 1 : 0;
     else if (k == "lanczos_min_n") opt.lanczos_min_n = static_cast<int>(num());

@@ -18,7 +18,10 @@
 
 #include "atom_math.h"
 #include "exec.h"
+#include <chrono>
 #include "fused_obj.h"
+#include "fused_codegen.h"
+#include "fused_rtc.h"
 #include "sparse_ldl.h"
 
 namespace dnlp {
@@ -1025,6 +1028,54 @@ struct HipExec : HostControlled {
     return f;
   }
   int fused_ne_override = 0;     // DNLP_FUSED_NE = 1 | 2 | 4 (measurement sweeps)
+
+  // ---- generated fused-objective kernel (fused_codegen.h + fused_rtc.h) -------------------------
+  bool fused_codegen = true;     // option fused_codegen=no keeps the interpreter
+  int fused_E = 4;               // grad entries per lane of the generated kernel (DNLP_FUSED_E)
+  RtcKernel fused_rtc;
+  const void* fused_rtc_key = nullptr;
+  bool fused_generated_eval(const std::vector<FusedSlotProg>& progs, const double* x, const double* consts, double* grad,
+                            i64 nfree, double& f) {
+    if (!fused_codegen || progs.empty() || nfree <= 0) return false;
+    if (fused_rtc_key != static_cast<const void*>(&progs)) {
+      fused_rtc_key = &progs;
+      if (const char* v = std::getenv("DNLP_FUSED_E")) { const int e = std::atoi(v); if (e >= 1 && e <= 16) fused_E = e; }
+      const FusedCodegenInfo info = fused_codegen_plan(progs, fused_E);
+      if (info.ok) {
+        const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        fused_rtc.load(fused_codegen_eval_source(progs, info), "dnlp_fused_eval");
+        fused_rtc.compile_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
+      } else {
+        fused_rtc.tried = true;
+        fused_rtc.log = info.why;
+      }
+    }
+    if (!fused_rtc.ok) return false;
+    const i64 nchunks = (nfree + fused_E - 1) / fused_E;
+    i64 blocks = (nchunks + kBlock - 1) / kBlock;
+    if (blocks > kMaxPartials) blocks = kMaxPartials;
+    i64 nf = nfree, nc = nchunks;
+    void* args[] = {&x, &consts, &grad, &d_partial, &nf, &nc};
+    DNLP_HIP_CHECK(hipModuleLaunchKernel(fused_rtc.fn, static_cast<unsigned>(blocks), 1, 1, kBlock, 1, 1, 0, stream, args, nullptr));
+    const i64 np = blocks * (kBlock / 64);
+    DNLP_HIP_CHECK(hipMemcpyAsync(h_partial, d_partial, sizeof(double) * static_cast<size_t>(np), hipMemcpyDeviceToHost, stream));
+    DNLP_HIP_CHECK(hipStreamSynchronize(stream));
+    f = 0.0;
+    for (i64 k = 0; k < np; ++k) f += h_partial[k];
+    return true;
+  }
+  // launch only (timing loops: no read-back)
+  bool fused_generated_launch(const std::vector<FusedSlotProg>& progs, const double* x, const double* consts, double* grad,
+                              i64 nfree) {
+    if (!fused_rtc.ok || fused_rtc_key != static_cast<const void*>(&progs)) return false;
+    const i64 nchunks = (nfree + fused_E - 1) / fused_E;
+    i64 blocks = (nchunks + kBlock - 1) / kBlock;
+    if (blocks > kMaxPartials) blocks = kMaxPartials;
+    i64 nf = nfree, nc = nchunks;
+    void* args[] = {&x, &consts, &grad, &d_partial, &nf, &nc};
+    DNLP_HIP_CHECK(hipModuleLaunchKernel(fused_rtc.fn, static_cast<unsigned>(blocks), 1, 1, kBlock, 1, 1, 0, stream, args, nullptr));
+    return true;
+  }
   void coo_mult(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out, bool trans) {
     if (nnz <= 0) return;
     hipLaunchKernelGGL(coo_mult_kernel, dim3(static_cast<unsigned>((nnz + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,

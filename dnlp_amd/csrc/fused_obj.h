@@ -363,6 +363,47 @@ DNLP_HD inline double fused_elements(const FusedSlotProg& P, i64 i0, i64 estride
   return fsum;
 }
 
+// fz_* arrays of the tape blob -> slot programs (no execution space involved)
+inline bool fused_parse_programs(const TapeBlob& tb, std::vector<FusedSlotProg>& progs, i64& nconst, double& c0, i64& nfree) {
+  if (!tb.has("fz_dims")) return false;
+  const i64* d = tb.i64s("fz_dims");
+  const i64 nprog = d[0], ninstr = d[1];
+  nconst = d[2];
+  nfree = d[3];
+  const i64* ps = tb.i64s("fz_prog_start");
+  const i64* pn = tb.i64s("fz_prog_nelem");
+  for (i64 q = 0; q < nprog; ++q) {
+    FusedProg P;
+    P.n = static_cast<int>(ps[q + 1] - ps[q]);
+    P.nelem = pn[q];
+    if (P.n < 1 || P.n > kFusedMaxInstr || ps[q + 1] > ninstr) throw std::runtime_error("bad fused program");
+    for (int k = 0; k < P.n; ++k) {
+      const i64 s = ps[q] + k;
+      P.op[k] = tb.i32s("fz_op")[s]; P.a[k] = tb.i32s("fz_a")[s]; P.b[k] = tb.i32s("fz_b")[s];
+      P.off[k] = tb.i64s("fz_off")[s]; P.stride[k] = tb.i64s("fz_stride")[s];
+      P.p[k] = tb.f64("fz_p")[s]; P.p2[k] = tb.f64("fz_p2")[s];
+      // every value must have exactly one consumer that comes later (tree programs)
+      if (P.op[k] >= F_UNARY && (P.a[k] < 0 || P.a[k] >= k)) throw std::runtime_error("bad fused operand");
+      if ((P.op[k] == F_ADD || P.op[k] == F_SUB || P.op[k] == F_MUL || P.op[k] == F_DIV) && (P.b[k] < 0 || P.b[k] >= k))
+        throw std::runtime_error("bad fused operand");
+    }
+    {
+      i64 lo = 0, hi = 0;
+      bool unit = true, any = false;
+      for (int k = 0; k < P.n; ++k) {
+        if (P.op[k] != F_LOADV) continue;
+        if (P.stride[k] != 1) unit = false;
+        if (!any) { lo = hi = P.off[k]; any = true; }
+        lo = std::min(lo, P.off[k]); hi = std::max(hi, P.off[k]);
+      }
+      if (any && unit && hi - lo <= 64) { P.win_lo = lo; P.win_extra = static_cast<int>(hi - lo); }
+    }
+    progs.push_back(fused_compile(P));
+  }
+  c0 = tb.f64("fz_c0")[0];
+  return true;
+}
+
 template <class E>
 struct FusedObjective {
   E* ex = nullptr;
@@ -374,48 +415,18 @@ struct FusedObjective {
 
   void load(E* e, const TapeBlob& tb) {
     ex = e;
-    if (!tb.has("fz_dims")) return;
-    const i64* d = tb.i64s("fz_dims");
-    const i64 nprog = d[0], ninstr = d[1], nconst = d[2];
-    nfree = d[3];
-    const i64* ps = tb.i64s("fz_prog_start");
-    const i64* pn = tb.i64s("fz_prog_nelem");
-    for (i64 q = 0; q < nprog; ++q) {
-      FusedProg P;
-      P.n = static_cast<int>(ps[q + 1] - ps[q]);
-      P.nelem = pn[q];
-      if (P.n < 1 || P.n > kFusedMaxInstr || ps[q + 1] > ninstr) throw std::runtime_error("bad fused program");
-      for (int k = 0; k < P.n; ++k) {
-        const i64 s = ps[q] + k;
-        P.op[k] = tb.i32s("fz_op")[s]; P.a[k] = tb.i32s("fz_a")[s]; P.b[k] = tb.i32s("fz_b")[s];
-        P.off[k] = tb.i64s("fz_off")[s]; P.stride[k] = tb.i64s("fz_stride")[s];
-        P.p[k] = tb.f64("fz_p")[s]; P.p2[k] = tb.f64("fz_p2")[s];
-        // every value must have exactly one consumer that comes later (tree programs)
-        if (P.op[k] >= F_UNARY && (P.a[k] < 0 || P.a[k] >= k)) throw std::runtime_error("bad fused operand");
-        if ((P.op[k] == F_ADD || P.op[k] == F_SUB || P.op[k] == F_MUL || P.op[k] == F_DIV) && (P.b[k] < 0 || P.b[k] >= k))
-          throw std::runtime_error("bad fused operand");
-      }
-      {
-        i64 lo = 0, hi = 0;
-        bool unit = true, any = false;
-        for (int k = 0; k < P.n; ++k) {
-          if (P.op[k] != F_LOADV) continue;
-          if (P.stride[k] != 1) unit = false;
-          if (!any) { lo = hi = P.off[k]; any = true; }
-          lo = std::min(lo, P.off[k]); hi = std::max(hi, P.off[k]);
-        }
-        if (any && unit && hi - lo <= 64) { P.win_lo = lo; P.win_extra = static_cast<int>(hi - lo); }
-      }
-      progs.push_back(fused_compile(P));
-    }
+    i64 nconst = 0;
+    if (!fused_parse_programs(tb, progs, nconst, c0, nfree)) return;
     consts = ex->template alloc<double>(static_cast<size_t>(nconst > 0 ? nconst : 1));
     if (nconst > 0) ex->h2d(consts, tb.f64("fz_consts"), sizeof(double) * static_cast<size_t>(nconst));
-    c0 = tb.f64("fz_c0")[0];
     present = true;
   }
 
   // x, grad: exec space, nfree entries.  Returns f.
   double eval(const double* x, double* grad) {
+    // specialised kernel generated from the programs (fused_codegen.h): grad is written, not accumulated
+    double fg = 0.0;
+    if (ex->fused_generated_eval(progs, x, consts, grad, nfree, fg)) return c0 + fg;
     ex->zero(grad, sizeof(double) * static_cast<size_t>(nfree));
     double f = c0;
     for (const FusedSlotProg& P : progs) f += ex->fused_eval(P, x, consts, grad);

@@ -1,0 +1,98 @@
+// Run-time compilation of generated kernels (fused_codegen.h, lbfgs_codegen.h): hiprtc -> code
+// object for gfx950 -> hipModuleLoadData.  Code objects are cached on disk by the hash of their
+// source ($DNLP_KERNEL_CACHE, default /tmp/dnlp_kernel_cache-<uid>), so a problem structure is
+// compiled once per machine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+namespace dnlp {
+
+inline uint64_t rtc_hash(const std::string& s) {
+  uint64_t h = 1469598103934665603ull;
+  for (unsigned char ch : s) { h ^= ch; h *= 1099511628211ull; }
+  return h;
+}
+
+inline std::string rtc_cache_dir() {
+  if (const char* d = std::getenv("DNLP_KERNEL_CACHE")) return d;
+  return "/tmp/dnlp_kernel_cache-" + std::to_string(static_cast<long>(getuid()));
+}
+
+// Compile `src` for gfx950.  Returns the code object (empty on failure, `log` has the compiler text).
+inline std::vector<char> rtc_compile(const std::string& src, std::string& log, bool use_cache = true) {
+  const std::string arch = "--offload-arch=gfx950";
+  char name[64];
+  std::snprintf(name, sizeof name, "%016llx.hsaco", static_cast<unsigned long long>(rtc_hash(src + arch)));
+  const std::string dir = rtc_cache_dir(), path = dir + "/" + name;
+  std::vector<char> code;
+  if (use_cache) {
+    if (FILE* fp = std::fopen(path.c_str(), "rb")) {
+      std::fseek(fp, 0, SEEK_END);
+      const long n = std::ftell(fp);
+      std::fseek(fp, 0, SEEK_SET);
+      code.resize(static_cast<size_t>(n > 0 ? n : 0));
+      const size_t got = code.empty() ? 0 : std::fread(code.data(), 1, code.size(), fp);
+      std::fclose(fp);
+      if (got == code.size() && !code.empty()) return code;
+      code.clear();
+    }
+  }
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, src.c_str(), "dnlp_generated.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+    log = "hiprtcCreateProgram failed";
+    return code;
+  }
+  const char* opts[] = {arch.c_str(), "-O3", "-std=c++17", "-munsafe-fp-atomics"};
+  const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+  size_t ls = 0;
+  hiprtcGetProgramLogSize(prog, &ls);
+  if (ls > 1) { log.resize(ls); hiprtcGetProgramLog(prog, &log[0]); }
+  if (r != HIPRTC_SUCCESS) {
+    if (log.empty()) log = hiprtcGetErrorString(r);
+    hiprtcDestroyProgram(&prog);
+    return code;
+  }
+  size_t cs = 0;
+  hiprtcGetCodeSize(prog, &cs);
+  code.resize(cs);
+  hiprtcGetCode(prog, code.data());
+  hiprtcDestroyProgram(&prog);
+  if (use_cache && !code.empty()) {
+    mkdir(dir.c_str(), 0700);
+    const std::string tmp = path + ".tmp" + std::to_string(static_cast<long>(getpid()));
+    if (FILE* fp = std::fopen(tmp.c_str(), "wb")) {
+      const size_t w = std::fwrite(code.data(), 1, code.size(), fp);
+      std::fclose(fp);
+      if (w == code.size()) std::rename(tmp.c_str(), path.c_str()); else std::remove(tmp.c_str());
+    }
+  }
+  return code;
+}
+
+struct RtcKernel {
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  bool tried = false, ok = false;
+  std::string log;
+  double compile_seconds = 0.0;
+  ~RtcKernel() { if (mod) hipModuleUnload(mod); }
+  bool load(const std::string& src, const char* entry) {
+    tried = true;
+    const std::vector<char> code = rtc_compile(src, log);
+    if (code.empty()) return false;
+    if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { log += " hipModuleLoadData failed"; mod = nullptr; return false; }
+    if (hipModuleGetFunction(&fn, mod, entry) != hipSuccess) { log += " entry point not found"; return false; }
+    ok = true;
+    return true;
+  }
+};
+
+}  // namespace dnlp

@@ -132,6 +132,13 @@ int dnlp_solve_batch_timed(dnlp_problem* p, int batch, const double* data, int64
 int dnlp_eval_fused(dnlp_problem* p, const double* xfree, double* f, double* grad);
 /* Average seconds of one fused evaluation with x resident in HBM (HIP events, `reps` evaluations). */
 int dnlp_time_fused(dnlp_problem* p, const double* xfree, int reps, double* seconds);
+/* The fused objective is evaluated by a kernel GENERATED from the element program at lowering time
+ * (hiprtc, gfx950; option `fused_codegen=no` keeps the interpreter).  This self check parses the fused
+ * programs of a tape blob, generates the kernel text (returned in src_out) and compiles it; it needs no
+ * GPU.  0 = compiled, 1 = no generated form for this objective (reason in log_out), 2 = compiler error
+ * (text in log_out), -11 = the tape has no fused program. */
+int dnlp_fused_codegen_check(const void* tape_blob, size_t len, int elems_per_lane, char* src_out,
+                             size_t src_cap, char* log_out, size_t log_cap);
 /* Dual warm start (IPOPT `warm_start_init_point`; SURVEY.md 8f-4.  The reference accepts
  * `warm_start` and ignores it, ipopt_nlpif.py:126-127): with the option
  * `warm_start_init_point=yes`, the next dnlp_solve / dnlp_ipm_begin starts from x_inout AND these

@@ -129,6 +129,9 @@ struct HostExec : HostControlled {
     return f;
   }
 
+  // (generated kernels exist only in the HIP space)
+  bool fused_generated_eval(const std::vector<FusedSlotProg>&, const double*, const double*, double*, i64, double&) { return false; }
+
   // c = V^T w for k stored vectors; out = sum_q c_q V_q
   void vt_dot(int k, const double* V, i64 N, const double* w, double* c_host) {
     for (int q = 0; q < k; ++q) {
