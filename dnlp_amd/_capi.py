@@ -67,6 +67,7 @@ class CApi:
         f("get_stats", C.c_int, [C.c_void_p, _dbl_p, C.c_int])
         f("get_log", C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t])
         f("set_intermediate_cb", C.c_int, [C.c_void_p, INTERMEDIATE_CB, C.c_void_p])
+        f("reduced_info", C.c_int, [C.c_void_p, _dbl_p, C.c_int])
         if hasattr(self.lib, prefix + "time_fused"):
             f("time_fused", C.c_int, [C.c_void_p, _dbl_p, C.c_int, _dbl_p])
         if hasattr(self.lib, prefix + "solve_batch_timed"):      # product library only (no oracle batch path)
@@ -335,7 +336,11 @@ class ProblemHandle:
         if st == -199:
             raise RuntimeError("solve_reduced failed: %s" % self.api.error())
         status = {0: 0, -1: -1, 3: 3}.get(st, st)
+        ri = np.zeros(6)
+        self.api.reduced_info(self.ptr, _dp(ri), 6)
         return {"status": status, "x": x, "obj_val": obj.value, "iterations": iters.value,
+                "device_loop": bool(ri[0]), "device_loop_seconds": float(ri[1]), "device_loop_slots": int(ri[2]),
+                "fused_objective_used": bool(ri[3]), "library_seconds": float(ri[4]),
                 "evaluations": evals.value, "grad_inf_norm": gn.value, "solve_time": time.time() - t0,
                 "g": self.eval_g(x) if self.m else np.zeros(0), "mult_g": np.zeros(self.m),
                 "mult_x_L": np.zeros(self.n), "mult_x_U": np.zeros(self.n), "stats": np.zeros(N_STATS)}

@@ -119,6 +119,31 @@ int dnlp_fused_codegen_check(const void* blob, size_t len, int elems_per_lane, c
     return code.empty() ? 2 : 0;)
 }
 
+// Same self check for the device-resident L-BFGS translation unit (lbfgs_codegen.h): the four slot
+// kernels around the generated element code.
+int dnlp_lbfgs_codegen_check(const void* blob, size_t len, int elems_per_lane, char* src_out, size_t src_cap, char* log_out,
+                             size_t log_cap) {
+  DNLP_TRY(
+    auto put = [](char* dst, size_t cap, const std::string& t) {
+      if (!dst || !cap) return;
+      const size_t n = t.size() < cap - 1 ? t.size() : cap - 1;
+      std::memcpy(dst, t.data(), n);
+      dst[n] = 0;
+    };
+    TapeBlob tb(blob, len);
+    std::vector<FusedSlotProg> progs;
+    i64 nconst = 0; i64 nfree = 0; double c0 = 0.0;
+    if (!fused_parse_programs(tb, progs, nconst, c0, nfree)) { put(log_out, log_cap, "no fused program in this tape"); return -11; }
+    const FusedCodegenInfo info = fused_codegen_plan(progs, elems_per_lane > 0 ? elems_per_lane : 4);
+    if (!info.ok) { put(log_out, log_cap, info.why); return 1; }
+    const std::string src = lbfgs_codegen_source(progs, info);
+    put(src_out, src_cap, src);
+    std::string log;
+    const std::vector<char> code = rtc_compile(src, log, false);
+    put(log_out, log_cap, log);
+    return code.empty() ? 2 : 0;)
+}
+
 const char* dnlp_version(void) { return "dnlp_amd 0.1.0 (gfx950)"; }
 
 int dnlp_dev_alloc(int device, size_t bytes, void** out) {

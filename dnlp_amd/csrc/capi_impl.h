@@ -29,6 +29,7 @@ struct ProblemT {
   FusedObjective<E> fused;
   std::shared_ptr<void> batch_state;   // exec-space specific batched-solve state (capi.hip)
   bool use_fused = true;
+  bool lbfgs_device_loop = true;            // option lbfgs_device_loop=no keeps the host-driven L-BFGS loop
   bool exact_hessian_substituted = false;   // hessian_approximation=limited-memory was requested
   int lbfgs_history = 10;
   IpmOptions opt;
@@ -174,6 +175,7 @@ struct ProblemT {
     else if (k == "lbfgs_history" || k == "limited_memory_max_history") lbfgs_history = static_cast<int>(num());
     else if (k == "fused_objective") use_fused = yes();
     else if (k == "fused_codegen") set_fused_codegen(yes());
+    else if (k == "lbfgs_device_loop") lbfgs_device_loop = yes();
     else if (k == "adaptive_fallback") opt.adaptive_fallback = yes() ? 1 : 0;
     else if (k == "lanczos_inertia_bound") opt.lanczos_inertia_bound = yes() ? 1 : 0;
     else if (k == "lanczos_min_n") opt.lanczos_min_n = static_cast<int>(num());
@@ -324,11 +326,21 @@ struct ProblemT {
              p->lbfgs->tol = p->opt.tol; p->lbfgs->max_iter = p->opt.max_iter > 3000 ? p->opt.max_iter : 20000; \
              p->lbfgs->history = p->lbfgs_history; p->lbfgs->print_level = p->opt.print_level;         \
              p->lbfgs->fused = &p->fused; p->lbfgs->use_fused = p->use_fused;                        \
+             p->lbfgs->allow_device_loop = p->lbfgs_device_loop;                                     \
              p->swept = false;                                                                       \
              int st = p->lbfgs->solve(x);                                                            \
              p->lbfgs->extract(x, obj);                                                              \
              if (iters) *iters = p->lbfgs->iterations; if (evals) *evals = p->lbfgs->evaluations;    \
              if (gnorm) *gnorm = p->lbfgs->gnorm_final; return st;)                                  \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, reduced_info)(HANDLE* vp, double* out, int n) {                                  \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    double v[6] = {0, 0, 0, 0, 0, 0};                                                                \
+    if (p->lbfgs) { v[0] = p->lbfgs->device_loop_used ? 1.0 : 0.0; v[1] = p->lbfgs->device_seconds;  \
+                    v[2] = p->lbfgs->device_slots; v[3] = p->lbfgs->fused_used ? 1.0 : 0.0;          \
+                    v[4] = p->lbfgs->wall; }                                                         \
+    for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];                                              \
+    return 0;                                                                                        \
   }                                                                                                  \
   int DNLP_CAT(PFX, eval_fused)(HANDLE* vp, const double* xfree, double* f, double* grad) {            \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \

@@ -21,6 +21,7 @@
 #include <chrono>
 #include "fused_obj.h"
 #include "fused_codegen.h"
+#include "lbfgs_codegen.h"
 #include "fused_rtc.h"
 #include "sparse_ldl.h"
 
@@ -1064,6 +1065,89 @@ struct HipExec : HostControlled {
     for (i64 k = 0; k < np; ++k) f += h_partial[k];
     return true;
   }
+  // ---- device-resident L-BFGS over the generated objective (lbfgs_codegen.h) -------------------------
+  struct LbfgsResult { int status = -199, iterations = 0, evaluations = 0, slots = 0; double f = 0.0, gnorm = 0.0, seconds = 0.0; };
+  RtcKernel lb_rtc;
+  hipFunction_t lb_eval = nullptr, lb_accept = nullptr, lb_update = nullptr, lb_control = nullptr;
+  const void* lb_key = nullptr;
+  LbfgsState* lb_state = nullptr;       // device
+  LbfgsState* lb_host = nullptr;        // pinned
+  double *lb_BV = nullptr, *lb_dir = nullptr, *lb_gt = nullptr, *lb_fpart = nullptr, *lb_upart = nullptr;
+  i64 lb_cap_nf = 0;
+  int lb_cap_M = 0, lb_slots_per_batch = 16;
+  // x: exec space, nfree entries, start point in / solution out.  false = no generated form (caller
+  // keeps the host-driven loop).
+  bool lbfgs_generated_solve(const std::vector<FusedSlotProg>& progs, const double* consts, double c0, i64 nfree, double* x,
+                             int M, double tol, int max_iter, LbfgsResult& out) {
+    if (!fused_codegen || progs.empty() || nfree <= 0) return false;
+    if (const char* v = std::getenv("DNLP_LBFGS_DEVICE")) if (std::atoi(v) == 0) return false;
+    if (M < 1) M = 1;
+    if (M > kLbMaxM) M = kLbMaxM;
+    if (lb_key != static_cast<const void*>(&progs)) {
+      lb_key = &progs;
+      if (const char* v = std::getenv("DNLP_FUSED_E")) { const int e = std::atoi(v); if (e >= 1 && e <= 16) fused_E = e; }
+      const FusedCodegenInfo info = fused_codegen_plan(progs, fused_E);
+      if (info.ok && lb_rtc.load(lbfgs_codegen_source(progs, info), "dnlp_lb_eval")) {
+        lb_eval = lb_rtc.fn;
+        lb_accept = lb_rtc.get("dnlp_lb_accept");
+        lb_update = lb_rtc.get("dnlp_lb_update");
+        lb_control = lb_rtc.get("dnlp_lb_control");
+        if (!lb_accept || !lb_update || !lb_control) lb_rtc.ok = false;
+      }
+    }
+    if (!lb_rtc.ok) return false;
+    const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    const i64 nchunks = (nfree + fused_E - 1) / fused_E;
+    i64 blocks = (nchunks + kBlock - 1) / kBlock;
+    if (blocks > 1024) blocks = 1024;
+    const int nb = 2 * M + 1;
+    if (!lb_state) {
+      DNLP_HIP_CHECK(hipMalloc(&lb_state, sizeof(LbfgsState)));
+      DNLP_HIP_CHECK(hipHostMalloc(&lb_host, sizeof(LbfgsState)));
+      DNLP_HIP_CHECK(hipMalloc(&lb_fpart, sizeof(double) * 2 * 1024));
+      DNLP_HIP_CHECK(hipMalloc(&lb_upart, sizeof(double) * (3 * kLbMaxNB + 1) * 1024));
+    }
+    if (nfree > lb_cap_nf || M > lb_cap_M) {
+      if (lb_BV) { hipFree(lb_BV); hipFree(lb_dir); hipFree(lb_gt); }
+      DNLP_HIP_CHECK(hipMalloc(&lb_BV, sizeof(double) * static_cast<size_t>(nb) * static_cast<size_t>(nfree)));
+      DNLP_HIP_CHECK(hipMalloc(&lb_dir, sizeof(double) * static_cast<size_t>(nfree)));
+      DNLP_HIP_CHECK(hipMalloc(&lb_gt, sizeof(double) * static_cast<size_t>(nfree)));
+      lb_cap_nf = nfree; lb_cap_M = M;
+    }
+    DNLP_HIP_CHECK(hipMemsetAsync(lb_BV, 0, sizeof(double) * static_cast<size_t>(nb) * static_cast<size_t>(nfree), stream));
+    std::memset(lb_host, 0, sizeof(LbfgsState));
+    lb_host->tol = tol; lb_host->max_iter = max_iter; lb_host->M = M; lb_host->nblocks = static_cast<int>(blocks);
+    DNLP_HIP_CHECK(hipMemcpyAsync(lb_state, lb_host, sizeof(LbfgsState), hipMemcpyHostToDevice, stream));
+    i64 nf = nfree, nc = nchunks;
+    double c0v = c0;
+    void* a_eval[] = {&lb_state, &x, &lb_BV, &lb_dir, &lb_gt, &consts, &lb_fpart, &nf, &nc};
+    void* a_acc[] = {&lb_state, &lb_fpart, &c0v};
+    void* a_upd[] = {&lb_state, &x, &lb_BV, &lb_dir, &lb_gt, &lb_upart, &nf};
+    void* a_ctl[] = {&lb_state, &lb_upart};
+    auto slot = [&]() {
+      DNLP_HIP_CHECK(hipModuleLaunchKernel(lb_eval, static_cast<unsigned>(blocks), 1, 1, kBlock, 1, 1, 0, stream, a_eval, nullptr));
+      DNLP_HIP_CHECK(hipModuleLaunchKernel(lb_accept, 1, 1, 1, 64, 1, 1, 0, stream, a_acc, nullptr));
+      DNLP_HIP_CHECK(hipModuleLaunchKernel(lb_update, static_cast<unsigned>(blocks), 1, 1, kBlock, 1, 1, 0, stream, a_upd, nullptr));
+      DNLP_HIP_CHECK(hipModuleLaunchKernel(lb_control, 1, 1, 1, 128, 1, 1, 0, stream, a_ctl, nullptr));
+    };
+    int slots = 0;
+    const long max_slots = static_cast<long>(max_iter) * 4 + 256;
+    while (true) {
+      for (int k = 0; k < lb_slots_per_batch; ++k, ++slots) slot();
+      DNLP_HIP_CHECK(hipMemcpyAsync(lb_host, lb_state, sizeof(LbfgsState), hipMemcpyDeviceToHost, stream));
+      DNLP_HIP_CHECK(hipStreamSynchronize(stream));
+      if (lb_host->done != 0 || slots > max_slots) break;
+    }
+    out.slots = slots;
+    out.iterations = lb_host->iter;
+    out.evaluations = lb_host->evals;
+    out.f = lb_host->f;
+    out.gnorm = lb_host->gn;
+    out.status = lb_host->done == 1 ? 0 : lb_host->done == 2 ? 3 : lb_host->done == 4 ? -13 : -1;
+    out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
+    return true;
+  }
+
   // launch only (timing loops: no read-back)
   bool fused_generated_launch(const std::vector<FusedSlotProg>& progs, const double* x, const double* consts, double* grad,
                               i64 nfree) {

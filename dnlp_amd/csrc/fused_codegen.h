@@ -79,20 +79,19 @@ inline std::string fused_codegen_chunk(const std::vector<FusedSlotProg>& progs, 
   std::string s;
   char b[512];
   auto add = [&](const char* fmt, auto... a) { std::snprintf(b, sizeof b, fmt, a...); s += b; };
-  s += "template <bool GUARD>\n__device__ __forceinline__ void dnlp_chunk(const i64 c, const double* __restrict__ x,\n"
-       "    const double* __restrict__ consts, const i64 nfree, double (&g)[DNLP_E], double& facc) {\n";
-  // x window: xr[k] = x[c - W + k]
-  add("  double xr[%d];\n", NX);
-  s += "  if (!GUARD) {\n";
-  // aligned middle part as 16-byte vectors, halo as scalars
-  for (int k = 0; k < W; ++k) add("    xr[%d] = x[c - %d];\n", k, W - k);
-  for (int k = 0; k + 1 < E; k += 2)
-    add("    { const double2 v = *reinterpret_cast<const double2*>(x + c + %d); xr[%d] = v.x; xr[%d] = v.y; }\n", k, W + k, W + k + 1);
-  if (E & 1) add("    xr[%d] = x[c + %d];\n", W + E - 1, E - 1);
-  for (int k = 0; k < W; ++k) add("    xr[%d] = x[c + %d];\n", W + E + k, E + k);
-  s += "  } else {\n";
-  add("    for (int k = 0; k < %d; ++k) { const i64 q = c - %d + k; xr[k] = (q >= 0 && q < nfree) ? x[q] : 0.0; }\n", NX, W);
-  s += "  }\n";
+  // the window xr[k] = x[c - W + k], k < E + 2W, is loaded by dnlp_chunk below; the L-BFGS kernels
+  // (lbfgs_codegen.h) hand in a window they computed themselves (trial point x + step * dir)
+  add("#define DNLP_W %d\n#define DNLP_NX %d\n", W, NX);
+  {
+    i64 min_nelem = progs[0].nelem;
+    for (const auto& P : progs) min_nelem = std::min(min_nelem, P.nelem);
+    // every window entry inside [0, nfree) and every touched element valid in every program
+    add("#define DNLP_INTERIOR(c, nfree) ((c) - DNLP_W >= 0 && (c) + DNLP_E + DNLP_W <= (nfree) && (c) - %lldLL >= 0 && "
+        "(c) + DNLP_E - 1 - %lldLL < %lldLL)\n", static_cast<long long>(hi), static_cast<long long>(lo),
+        static_cast<long long>(min_nelem));
+  }
+  s += "template <bool GUARD>\n__device__ __forceinline__ void dnlp_chunk_w(const i64 c, const double (&xr)[DNLP_NX],\n"
+       "    const double* __restrict__ consts, double (&g)[DNLP_E], double& facc) {\n";
   int pi = 0;
   for (const FusedSlotProg& P : progs) {
     add("  // ---- program %d: %d ops, %d slots, %lld elements\n", pi, P.nops, P.nslots, static_cast<long long>(P.nelem));
@@ -159,6 +158,18 @@ inline std::string fused_codegen_chunk(const std::vector<FusedSlotProg>& progs, 
     ++pi;
   }
   s += "}\n";
+  s += "template <bool GUARD>\n__device__ __forceinline__ void dnlp_chunk(const i64 c, const double* __restrict__ x,\n"
+       "    const double* __restrict__ consts, const i64 nfree, double (&g)[DNLP_E], double& facc) {\n";
+  s += "  double xr[DNLP_NX];\n  if (!GUARD) {\n";
+  // aligned middle part as 16-byte vectors, halo as scalars
+  for (int k = 0; k < W; ++k) add("    xr[%d] = x[c - %d];\n", k, W - k);
+  for (int k = 0; k + 1 < E; k += 2)
+    add("    { const double2 v = *reinterpret_cast<const double2*>(x + c + %d); xr[%d] = v.x; xr[%d] = v.y; }\n", k, W + k, W + k + 1);
+  if (E & 1) add("    xr[%d] = x[c + %d];\n", W + E - 1, E - 1);
+  for (int k = 0; k < W; ++k) add("    xr[%d] = x[c + %d];\n", W + E + k, E + k);
+  s += "  } else {\n";
+  s += "    for (int k = 0; k < DNLP_NX; ++k) { const i64 q = c - DNLP_W + k; xr[k] = (q >= 0 && q < nfree) ? x[q] : 0.0; }\n";
+  s += "  }\n  dnlp_chunk_w<GUARD>(c, xr, consts, g, facc);\n}\n";
   return s;
 }
 
@@ -189,24 +200,19 @@ inline std::string fused_codegen_preamble(int E) {
 //   extern "C" __global__ void dnlp_fused_eval(x, consts, grad, partial, nfree, nchunks)
 inline std::string fused_codegen_eval_source(const std::vector<FusedSlotProg>& progs, const FusedCodegenInfo& info) {
   const int E = info.E;
-  const int W = static_cast<int>(info.hi - info.lo);
   std::string s = fused_codegen_preamble(E);
   s += fused_codegen_chunk(progs, info);
   char b[1024];
-  std::snprintf(b, sizeof b,
-                "extern \"C\" __global__ void __launch_bounds__(256) dnlp_fused_eval(const double* __restrict__ x,\n"
-                "    const double* __restrict__ consts, double* __restrict__ grad, double* __restrict__ partial,\n"
-                "    const i64 nfree, const i64 nchunks) {\n"
-                "  double facc = 0.0;\n"
-                "  for (i64 q = static_cast<i64>(blockIdx.x) * 256 + threadIdx.x; q < nchunks; q += static_cast<i64>(gridDim.x) * 256) {\n"
-                "    const i64 c = q * DNLP_E;\n"
-                "    double g[DNLP_E];\n"
-                "#pragma unroll\n"
-                "    for (int t = 0; t < DNLP_E; ++t) g[t] = 0.0;\n"
-                "    const bool interior = c - %d >= 0 && c + DNLP_E + %d <= nfree && c - %lld >= 0 && c + DNLP_E - 1 - %lld < %lldLL;\n",
-                W, W, static_cast<long long>(info.hi), static_cast<long long>(info.lo),
-                static_cast<long long>([&] { i64 m = progs[0].nelem; for (const auto& P : progs) m = std::min(m, P.nelem); return m; }()));
-  s += b;
+  s += "extern \"C\" __global__ void __launch_bounds__(256) dnlp_fused_eval(const double* __restrict__ x,\n"
+       "    const double* __restrict__ consts, double* __restrict__ grad, double* __restrict__ partial,\n"
+       "    const i64 nfree, const i64 nchunks) {\n"
+       "  double facc = 0.0;\n"
+       "  for (i64 q = static_cast<i64>(blockIdx.x) * 256 + threadIdx.x; q < nchunks; q += static_cast<i64>(gridDim.x) * 256) {\n"
+       "    const i64 c = q * DNLP_E;\n"
+       "    double g[DNLP_E];\n"
+       "#pragma unroll\n"
+       "    for (int t = 0; t < DNLP_E; ++t) g[t] = 0.0;\n"
+       "    const bool interior = DNLP_INTERIOR(c, nfree);\n";
   s += "    if (interior) {\n      dnlp_chunk<false>(c, x, consts, nfree, g, facc);\n";
   // vector stores of the owned entries
   s += "      double* gp = grad + c;\n";

@@ -93,6 +93,12 @@ struct RtcKernel {
     ok = true;
     return true;
   }
+  // further entry points of the same module (nullptr when missing)
+  hipFunction_t get(const char* entry) {
+    hipFunction_t f = nullptr;
+    if (!mod || hipModuleGetFunction(&f, mod, entry) != hipSuccess) return nullptr;
+    return f;
+  }
 };
 
 }  // namespace dnlp

@@ -30,6 +30,10 @@ class ReducedLbfgs {
   FusedObjective<E>* fused = nullptr;
   bool use_fused = true;
   bool fused_used = false;
+  bool allow_device_loop = true;
+  bool device_loop_used = false;      // the device-resident loop (lbfgs_codegen.h) ran the solve
+  double device_seconds = 0.0;
+  int device_slots = 0;
 
   double tol = 1e-7;
   int max_iter = 20000;
@@ -113,6 +117,31 @@ class ReducedLbfgs {
     // reductions of the textbook loop, the recursion runs on 2M+1 coefficients on the host, and the
     // direction is one fused linear combination.  Same mathematics, a handful of host round trips.
     const int M = history < 1 ? 1 : (history > 15 ? 15 : history);
+    // Device-resident form (lbfgs_codegen.h): the same algorithm with every decision taken on the device
+    // over the generated objective kernel; the host only enqueues.  Taken when the objective has a
+    // generated form and no iteration log is asked for.
+    device_loop_used = false;
+    if (allow_device_loop && fused && fused->present && use_fused && print_level < 5) {
+      typename E::LbfgsResult r;
+      if (ex_->lbfgs_generated_solve(fused->progs, fused->consts, fused->c0, nf, xf, M, tol, max_iter, r)) {
+        device_loop_used = true;
+        fused_used = true;
+        iterations = r.iterations;
+        evaluations = r.evaluations;
+        gnorm_final = r.gnorm;
+        device_seconds = r.seconds;
+        device_slots = r.slots;
+        double fl;
+        const bool keep = use_fused;
+        use_fused = false;
+        eval(xf, fl, gf);            // canonical vector (auxiliary variables) consistent with the solution
+        use_fused = keep;
+        --evaluations;
+        f_final = fl;
+        wall = now_sec() - t0;
+        return r.status;
+      }
+    }
     const int nb = 2 * M + 1, GR = 2 * M;              // GR: row of the current gradient
     if (!BV) BV = A<double>(static_cast<i64>(nb) * nf);
     ex_->zero(BV, sizeof(double) * static_cast<size_t>(nb) * static_cast<size_t>(nf));

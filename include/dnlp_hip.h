@@ -99,6 +99,11 @@ int dnlp_ipm_finish(dnlp_problem* p, double* x, double* obj, double* g, double* 
  * failure, -11 when the tape has no reduced-space structure. */
 int dnlp_solve_reduced(dnlp_problem* p, double* x_inout, double* obj, int* iters, int* evals,
                        double* gnorm);
+/* How the last dnlp_solve_reduced ran: out[0] = 1 when the device-resident loop did (every decision on
+ * the device, option lbfgs_device_loop=no turns it off), out[1] = its seconds (enqueue to final state
+ * read-back), out[2] = line-search slots enqueued, out[3] = 1 when the fused objective was used,
+ * out[4] = wall seconds of the whole call (n <= 6 values). */
+int dnlp_reduced_info(dnlp_problem* p, double* out, int n);
 /* Batched variant (SURVEY.md 8b "dnlp_solve_batch"; BASELINE config C5): `batch` independent
  * instances that share the structure of p's tape and differ in data — the role of the
  * reference's serial best_of / re-solve loop (problems/problem.py:1256-1269, which
@@ -138,6 +143,11 @@ int dnlp_time_fused(dnlp_problem* p, const double* xfree, int reps, double* seco
  * GPU.  0 = compiled, 1 = no generated form for this objective (reason in log_out), 2 = compiler error
  * (text in log_out), -11 = the tape has no fused program. */
 int dnlp_fused_codegen_check(const void* tape_blob, size_t len, int elems_per_lane, char* src_out,
+                             size_t src_cap, char* log_out, size_t log_cap);
+/* The same self check for the device-resident L-BFGS kernels generated around that element code
+ * (dnlp_solve_reduced runs them when the objective has a generated form: every line-search and
+ * convergence decision is taken on the device, the host only enqueues). */
+int dnlp_lbfgs_codegen_check(const void* tape_blob, size_t len, int elems_per_lane, char* src_out,
                              size_t src_cap, char* log_out, size_t log_cap);
 /* Dual warm start (IPOPT `warm_start_init_point`; SURVEY.md 8f-4.  The reference accepts
  * `warm_start` and ignores it, ipopt_nlpif.py:126-127): with the option

@@ -221,3 +221,91 @@ def test_device_generated_kernels_for_random_windowed_trees(gpu_required, seed):
     f1, g1 = numpy_eval(ta, z)
     assert abs(f - f1) <= 1e-11 * max(1.0, abs(f1))
     np.testing.assert_allclose(g, g1, rtol=1e-11, atol=1e-11)
+
+
+# ---- device-resident L-BFGS (csrc/lbfgs_codegen.h): the four slot kernels, emulated on the host ----------
+LB_DRIVER = r"""
+#include <vector>
+template <class K, class... A> static void run_grid(unsigned blocks, unsigned threads, K kern, A... a) {
+  gridDim.x = blocks;
+  for (unsigned b = 0; b < blocks; ++b)
+    for (unsigned t = 0; t < threads; ++t) { blockIdx.x = b; threadIdx.x = t; kern(a...); }
+}
+extern "C" int emulate_lbfgs(double* x, const double* consts, double c0, long long nf, int M, double tol, int max_iter,
+                             int blocks, double* out) {
+  LbfgsState S;
+  std::memset(&S, 0, sizeof S);
+  S.tol = tol; S.max_iter = max_iter; S.M = M; S.nblocks = blocks;
+  const int nb = 2 * M + 1;
+  std::vector<double> BV((size_t)nb * nf, 0.0), dir(nf, 0.0), gt(nf, 0.0), fpart(2 * blocks, 0.0), upart((3 * DNLP_MAXNB + 1) * blocks, 0.0);
+  const long long nchunks = (nf + DNLP_E - 1) / DNLP_E;
+  int slots = 0;
+  while (S.done == 0 && slots < 100000) {
+    run_grid(blocks, 256, dnlp_lb_eval, &S, (const double*)x, (const double*)BV.data(), dir.data(), gt.data(), consts, fpart.data(), nf, nchunks);
+    run_grid(1, 64, dnlp_lb_accept, &S, (const double*)fpart.data(), c0);
+    run_grid(blocks, 256, dnlp_lb_update, (const LbfgsState*)&S, x, BV.data(), (const double*)dir.data(), (const double*)gt.data(), upart.data(), nf);
+    run_grid(1, 128, dnlp_lb_control, &S, (const double*)upart.data());
+    ++slots;
+  }
+  out[0] = S.f; out[1] = S.gn; out[2] = S.iter; out[3] = S.evals; out[4] = S.done; out[5] = slots;
+  return S.done;
+}
+"""
+
+
+def _emulate_lbfgs(ta, x0, E, M=10, tol=1e-7, max_iter=20000, blocks=2):
+    blob = bytes(serialize(ta))
+    lib = _lib()
+    lib.dnlp_lbfgs_codegen_check.restype = C.c_int
+    src = C.create_string_buffer(1 << 21)
+    log = C.create_string_buffer(1 << 16)
+    rc = lib.dnlp_lbfgs_codegen_check(blob, C.c_size_t(len(blob)), E, src, C.c_size_t(len(src)), log, C.c_size_t(len(log)))
+    assert rc == 0, log.value.decode()            # also: the translation unit compiles for gfx950
+    with tempfile.TemporaryDirectory() as d:
+        cpp, so = os.path.join(d, "lb.cpp"), os.path.join(d, "lb.so")
+        with open(cpp, "w") as fh:
+            fh.write(SHIM + "#define __shared__ static\n" + src.value.decode() + LB_DRIVER)
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-w", cpp, "-o", so])
+        em = C.CDLL(so)
+        x = np.array(x0, dtype=float)
+        consts = np.ascontiguousarray(ta.get("fz_consts", np.zeros(1)), dtype=float)
+        if consts.size == 0:
+            consts = np.zeros(1)
+        out = np.zeros(8)
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))   # noqa: E731
+        em.emulate_lbfgs.restype = C.c_int
+        done = em.emulate_lbfgs(dp(x), dp(consts), C.c_double(float(ta["fz_c0"][0])), C.c_longlong(x.size), M,
+                                C.c_double(tol), max_iter, blocks, dp(out))
+        return done, x, out
+
+
+@pytest.mark.parametrize("n,E", [(60, 4), (1000, 4), (1000, 2)])
+def test_device_resident_lbfgs_kernels_agree_with_the_host_driven_loop(n, E):
+    """Same algorithm, decisions moved into the slot kernels: the emulated kernels must take the
+    host-driven loop's path (iteration and evaluation counts up to summation-order effects) and reach
+    the analytic optimum x* = 1."""
+    from oracle.oracle_capi import OracleProblem
+    data = _data(rosenbrock_chain(cp, n))
+    ta = data["tape_arrays"]
+    free = np.asarray(ta["free_idx"])
+    x0 = np.asarray(data["x0"])[free]
+    done, x, out = _emulate_lbfgs(ta, x0, E)
+    assert done == 1
+    assert np.max(np.abs(x - 1.0)) <= 1e-5
+    ref = OracleProblem(serialize(ta)).solve_reduced(data["x0"])
+    assert ref["status"] == 0
+    assert abs(int(out[2]) - ref["iterations"]) <= max(3, ref["iterations"] // 10)
+    assert abs(int(out[3]) - ref["evaluations"]) <= max(4, ref["evaluations"] // 10)
+    assert abs(out[0] - ref["obj_val"]) <= 1e-8
+
+
+def test_device_resident_lbfgs_status_paths():
+    data = _data(rosenbrock_chain(cp, 200))
+    ta = data["tape_arrays"]
+    x0 = np.asarray(data["x0"])[np.asarray(ta["free_idx"])]
+    done, x, out = _emulate_lbfgs(ta, x0, 4, max_iter=5)
+    assert done == 3 and int(out[2]) == 5                 # iteration limit -> status -1
+    bad = x0.copy()
+    bad[3] = np.nan
+    done, x, out = _emulate_lbfgs(ta, bad, 4)
+    assert done == 4                                      # invalid number at the start -> status -13

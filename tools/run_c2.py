@@ -27,27 +27,46 @@ from problem_zoo import rosenbrock_chain  # noqa: E402
 warnings.simplefilter("ignore")
 out = {"solves": [], "kernel_sweep": []}
 sizes = [int(a) for a in sys.argv[1:]] or [100000, 1000000, 4000000]
+MODES = {
+    # generated objective kernel + every L-BFGS decision on the device (the default path)
+    "generated+device-loop": {},
+    # generated objective kernel, loop driven from the host (a read-back per scalar)
+    "generated+host-loop": {"lbfgs_device_loop": "no"},
+    # round-1 path: interpreter kernel, host loop
+    "interpreter+host-loop": {"lbfgs_device_loop": "no", "fused_codegen": "no"},
+    # canonical-tape reduced evaluator
+    "tape+host-loop": {"fused_objective": "no"},
+}
 for n in sizes:
-    for fused in ("yes", "no"):
-        p = rosenbrock_chain(cp, n)
-        t0 = time.time()
-        chain = p._build_chain(None)
-        data, inv = chain.apply(p)
-        t_lower = time.time() - t0
-        t0 = time.time()
-        info = chain.solver.solve_via_data(data, True, False, {"algorithm": "lbfgs", "fused_objective": fused})
-        t_solve = time.time() - t0
-        p.unpack_results(info, chain, inv)
-        x = p.variables()[0].value
-        rec = {"n": n, "fused": fused, "N_canonical": len(data["x0"]), "status": p.status,
-               "iterations": info["iterations"], "evaluations": info["evaluations"], "f": info["obj_val"],
-               "max_abs_x_minus_1": float(np.max(np.abs(x - 1))), "lower_sec": t_lower, "solve_sec": t_solve,
-               "ms_per_f_grad_eval": 1e3 * t_solve / max(info["evaluations"], 1),
-               "alg_GBps_16n": 16.0 * n * info["evaluations"] / t_solve / 1e9,
-               "iters_per_sec": info["iterations"] / t_solve}
-        print(json.dumps(rec), flush=True)
-        out["solves"].append(rec)
-        data["handle"].close()
+    for mode, opts in MODES.items():
+        best = None
+        for rep in range(3):                         # first repetition pays the one-off kernel compile / cache load
+            p = rosenbrock_chain(cp, n)
+            t0 = time.time()
+            chain = p._build_chain(None)
+            data, inv = chain.apply(p)
+            t_lower = time.time() - t0
+            o = {"algorithm": "lbfgs"}
+            o.update(opts)
+            t0 = time.time()
+            info = chain.solver.solve_via_data(data, True, False, o)
+            t_solve = time.time() - t0
+            p.unpack_results(info, chain, inv)
+            x = p.variables()[0].value
+            rec = {"n": n, "mode": mode, "rep": rep, "N_canonical": len(data["x0"]), "status": p.status,
+                   "iterations": info["iterations"], "evaluations": info["evaluations"], "f": info["obj_val"],
+                   "max_abs_x_minus_1": float(np.max(np.abs(x - 1))), "lower_sec": t_lower, "solve_sec": t_solve,
+                   "device_loop": info.get("device_loop"), "device_loop_sec": info.get("device_loop_seconds"),
+                   "device_loop_slots": info.get("device_loop_slots"), "library_sec": info.get("library_seconds")}
+            core = rec["device_loop_sec"] if rec["device_loop"] else rec["library_sec"]
+            rec["evals_per_sec"] = info["evaluations"] / core if core else None
+            rec["alg_GBps_16n"] = 16.0 * n * info["evaluations"] / core / 1e9 if core else None
+            rec["iters_per_sec"] = info["iterations"] / core if core else None
+            data["handle"].close()
+            if best is None or rec["solve_sec"] < best["solve_sec"]:
+                best = rec
+        print(json.dumps(best), flush=True)
+        out["solves"].append(best)
 
 # fused kernel alone: re-target the n = 1e5 program
 p = rosenbrock_chain(cp, 100000)
@@ -55,24 +74,30 @@ chain = p._build_chain(None)
 data, _ = chain.apply(p)
 data["handle"].close()
 arrays = dict(data["tape_arrays"])
-base_n = 100000
 for n in (100000, 1000000, 10000000, 100000000):
-    a = dict(arrays)
-    a["fz_prog_nelem"] = np.array([n - 1], dtype=np.int64)
-    dims = a["fz_dims"].copy()
-    dims[3] = n
-    a["fz_dims"] = dims
-    h = _capi.DeviceProblem(serialize(a), data["tape"])
-    x = np.random.default_rng(0).uniform(0.5, 1.5, n)
-    reps = 5 if n >= 10000000 else 20
-    st = np.zeros(3)
-    f, g = h.eval_fused(x)                       # warm-up + correctness
-    fr = np.sum((1 - x[:-1]) ** 2) + 100 * np.sum((x[1:] - x[:-1] ** 2) ** 2)
-    sec = h.time_fused(x, reps)
-    rec = {"n": n, "kernel_ms": 1e3 * sec, "alg_GBps_16n": 16.0 * n / sec / 1e9,
-           "frac_of_8TBps": 16.0 * n / sec / 8e12, "f_rel_err": abs(f - fr) / abs(fr)}
-    print(json.dumps(rec), flush=True)
-    out["kernel_sweep"].append(rec)
-    h.close()
+    for kind, E in (("interpreter", 0), ("generated", 2), ("generated", 4), ("generated", 8)):
+        a = dict(arrays)
+        a["fz_prog_nelem"] = np.array([n - 1], dtype=np.int64)
+        dims = a["fz_dims"].copy()
+        dims[3] = n
+        a["fz_dims"] = dims
+        if E:
+            os.environ["DNLP_FUSED_E"] = str(E)
+        h = _capi.DeviceProblem(serialize(a), data["tape"])
+        h.set_option("fused_codegen", "yes" if E else "no")
+        x = np.random.default_rng(0).uniform(0.5, 1.5, n)
+        reps = 10 if n >= 10000000 else 50
+        f, g = h.eval_fused(x)                       # warm-up + correctness
+        fr = np.sum((1 - x[:-1]) ** 2) + 100 * np.sum((x[1:] - x[:-1] ** 2) ** 2)
+        gr = np.zeros(n)
+        gr[:-1] += -2 * (1 - x[:-1]) - 400 * (x[1:] - x[:-1] ** 2) * x[:-1]
+        gr[1:] += 200 * (x[1:] - x[:-1] ** 2)
+        sec = h.time_fused(x, reps)
+        rec = {"n": n, "kernel": kind, "entries_per_lane": E or None, "kernel_ms": 1e3 * sec,
+               "alg_GBps_16n": 16.0 * n / sec / 1e9, "frac_of_8TBps": 16.0 * n / sec / 8e12,
+               "f_rel_err": abs(f - fr) / abs(fr), "grad_max_abs_err": float(np.max(np.abs(g - gr)))}
+        print(json.dumps(rec), flush=True)
+        out["kernel_sweep"].append(rec)
+        h.close()
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "c2.json"), "w"), indent=1)
