@@ -1100,35 +1100,39 @@ struct HipExec : HostControlled {
     const i64 nchunks = (nfree + fused_E - 1) / fused_E;
     i64 blocks = (nchunks + kBlock - 1) / kBlock;
     if (blocks > 1024) blocks = 1024;
-    const int nb = 2 * M + 1;
+    constexpr int ldp = 1024;                      // leading dimension of the partial-result columns (>= blocks)
     if (!lb_state) {
       DNLP_HIP_CHECK(hipMalloc(&lb_state, sizeof(LbfgsState)));
       DNLP_HIP_CHECK(hipHostMalloc(&lb_host, sizeof(LbfgsState)));
-      DNLP_HIP_CHECK(hipMalloc(&lb_fpart, sizeof(double) * 2 * 1024));
-      DNLP_HIP_CHECK(hipMalloc(&lb_upart, sizeof(double) * (3 * kLbMaxNB + 1) * 1024));
+      DNLP_HIP_CHECK(hipMalloc(&lb_fpart, sizeof(double) * 8 * ldp));
+      DNLP_HIP_CHECK(hipMalloc(&lb_upart, sizeof(double) * (3 * kLbMaxNB + 1) * ldp));
     }
     if (nfree > lb_cap_nf || M > lb_cap_M) {
       if (lb_BV) { hipFree(lb_BV); hipFree(lb_dir); hipFree(lb_gt); }
-      DNLP_HIP_CHECK(hipMalloc(&lb_BV, sizeof(double) * static_cast<size_t>(nb) * static_cast<size_t>(nfree)));
+      DNLP_HIP_CHECK(hipMalloc(&lb_BV, sizeof(double) * static_cast<size_t>(2 * M) * static_cast<size_t>(nfree)));
       DNLP_HIP_CHECK(hipMalloc(&lb_dir, sizeof(double) * static_cast<size_t>(nfree)));
-      DNLP_HIP_CHECK(hipMalloc(&lb_gt, sizeof(double) * static_cast<size_t>(nfree)));
+      DNLP_HIP_CHECK(hipMalloc(&lb_gt, sizeof(double) * 2 * static_cast<size_t>(nfree)));      // two gradient buffers
       lb_cap_nf = nfree; lb_cap_M = M;
     }
-    DNLP_HIP_CHECK(hipMemsetAsync(lb_BV, 0, sizeof(double) * static_cast<size_t>(nb) * static_cast<size_t>(nfree), stream));
+    DNLP_HIP_CHECK(hipMemsetAsync(lb_BV, 0, sizeof(double) * static_cast<size_t>(2 * M) * static_cast<size_t>(nfree), stream));
+    DNLP_HIP_CHECK(hipMemsetAsync(lb_gt, 0, sizeof(double) * 2 * static_cast<size_t>(nfree), stream));
     std::memset(lb_host, 0, sizeof(LbfgsState));
     lb_host->tol = tol; lb_host->max_iter = max_iter; lb_host->M = M; lb_host->nblocks = static_cast<int>(blocks);
     DNLP_HIP_CHECK(hipMemcpyAsync(lb_state, lb_host, sizeof(LbfgsState), hipMemcpyHostToDevice, stream));
     i64 nf = nfree, nc = nchunks;
     double c0v = c0;
-    void* a_eval[] = {&lb_state, &x, &lb_BV, &lb_dir, &lb_gt, &consts, &lb_fpart, &nf, &nc};
-    void* a_acc[] = {&lb_state, &lb_fpart, &c0v};
-    void* a_upd[] = {&lb_state, &x, &lb_BV, &lb_dir, &lb_gt, &lb_upart, &nf};
-    void* a_ctl[] = {&lb_state, &lb_upart};
+    int ldpv = ldp;
+    double* g0 = lb_gt;
+    double* g1 = lb_gt + nfree;
+    void* a_eval[] = {&lb_state, &x, &lb_BV, &g0, &g1, &lb_dir, &consts, &lb_fpart, &nf, &nc, &ldpv};
+    void* a_acc[] = {&lb_state, &lb_fpart, &c0v, &ldpv};
+    void* a_upd[] = {&lb_state, &x, &lb_BV, &g0, &g1, &lb_dir, &lb_upart, &nf, &ldpv};
+    void* a_ctl[] = {&lb_state, &lb_upart, &ldpv};
     auto slot = [&]() {
       DNLP_HIP_CHECK(hipModuleLaunchKernel(lb_eval, static_cast<unsigned>(blocks), 1, 1, kBlock, 1, 1, 0, stream, a_eval, nullptr));
       DNLP_HIP_CHECK(hipModuleLaunchKernel(lb_accept, 1, 1, 1, 64, 1, 1, 0, stream, a_acc, nullptr));
       DNLP_HIP_CHECK(hipModuleLaunchKernel(lb_update, static_cast<unsigned>(blocks), 1, 1, kBlock, 1, 1, 0, stream, a_upd, nullptr));
-      DNLP_HIP_CHECK(hipModuleLaunchKernel(lb_control, 1, 1, 1, 128, 1, 1, 0, stream, a_ctl, nullptr));
+      DNLP_HIP_CHECK(hipModuleLaunchKernel(lb_control, 1, 1, 1, kBlock, 1, 1, 0, stream, a_ctl, nullptr));
     };
     int slots = 0;
     const long max_slots = static_cast<long>(max_iter) * 4 + 256;

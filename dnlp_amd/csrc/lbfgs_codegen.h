@@ -41,7 +41,7 @@ constexpr int kLbMaxNB = 2 * kLbMaxM + 1;
   double f; double fn; double step; double gd; double gn; double tol;                                       \
   double rho[15]; double alpha[15]; double coef[31]; double G[31 * 31];                                      \
   int iter; int evals; int head; int stored; int ls; int phase; int accept; int done; int max_iter; int M;   \
-  int nblocks; int pad;
+  int nblocks; int gcur;
 struct LbfgsState { DNLP_LB_STATE_BODY };
 
 inline std::string lbfgs_codegen_source(const std::vector<FusedSlotProg>& progs, const FusedCodegenInfo& info) {
@@ -50,48 +50,63 @@ inline std::string lbfgs_codegen_source(const std::vector<FusedSlotProg>& progs,
   s += "struct LbfgsState { " DNLP_LB_STR(DNLP_LB_STATE_BODY) " };\n";
   s += R"DNLPLB(
 #define DNLP_MAXNB 31
-// block-wide reduction of `n` per-lane values into dst[0..n): the first n - ntail by sum, the last ntail
-// by max.  (Host emulation runs the lanes one after the other: lane 0 clears, every lane folds in.)
+#define DNLP_NV (3 * DNLP_MAXNB + 1)
+// Partial results travel between the grid kernels and the one-workgroup control kernels as COLUMNS:
+// value k of block b at part[k * ldp + b], so that one wavefront reads 64 blocks' values of one quantity
+// in one coalesced load and folds them with shuffles.
+// (Host emulation, DNLP_EMULATE: the lanes run one after the other, so "reduce over the wavefront and let
+// lane 0 store" becomes "lane 0 clears, every lane folds in", and a column reduction is a serial loop.)
 #ifndef DNLP_EMULATE
 __device__ __forceinline__ double dnlp_wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
   return v;
 }
-template <int N>
-__device__ __forceinline__ void dnlp_block_reduce_store(const double (&v)[N], int ntail, double* __restrict__ dst) {
-  __shared__ double red[4][N];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const double r = (k >= N - ntail) ? dnlp_wave_max(v[k]) : dnlp_wave_sum(v[k]);
-    if (lane == 0) red[wave][k] = r;
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < N; k += 256)
-    dst[k] = (k >= N - ntail) ? fmax(fmax(red[0][k], red[1][k]), fmax(red[2][k], red[3][k]))
-                              : (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+__device__ __forceinline__ void dnlp_wave_store_sum(double* __restrict__ dst, double v) {
+  v = dnlp_wave_sum(v);
+  if ((threadIdx.x & 63) == 0) *dst = v;
+}
+__device__ __forceinline__ void dnlp_wave_store_max(double* __restrict__ dst, double v) {
+  v = dnlp_wave_max(v);
+  if ((threadIdx.x & 63) == 0) *dst = v;
+}
+// reduction of col[0..n) by the calling wavefront; every lane gets the result
+__device__ __forceinline__ double dnlp_col_reduce(const double* __restrict__ col, int n, bool is_max) {
+  const int lane = threadIdx.x & 63;
+  double a = is_max ? -1.0 : 0.0;
+  for (int b = lane; b < n; b += 64) { const double v = col[b]; a = is_max ? fmax(a, v) : a + v; }
+  return is_max ? dnlp_wave_max(a) : dnlp_wave_sum(a);
 }
 #define DNLP_SYNC() __syncthreads()
 #else
-template <int N>
-inline void dnlp_block_reduce_store(const double (&v)[N], int ntail, double* dst) {
-  for (int k = 0; k < N; ++k) {
-    if (threadIdx.x == 0) dst[k] = (k >= N - ntail) ? -1.0 : 0.0;
-    if (k >= N - ntail) dst[k] = fmax(dst[k], v[k]); else dst[k] += v[k];
-  }
+inline void dnlp_wave_store_sum(double* dst, double v) { if ((threadIdx.x & 63) == 0) *dst = 0.0; *dst += v; }
+inline void dnlp_wave_store_max(double* dst, double v) { if ((threadIdx.x & 63) == 0) *dst = -1.0; *dst = fmax(*dst, v); }
+inline double dnlp_col_reduce(const double* col, int n, bool is_max) {
+  double a = is_max ? -1.0 : 0.0;
+  for (int b = 0; b < n; ++b) a = is_max ? fmax(a, col[b]) : a + col[b];
+  return a;
 }
 #define DNLP_SYNC()
 #endif
 
+// Row j of the basis B = [s_0 .. s_{M-1} | y_0 .. y_{M-1} | g]: the current gradient is one of two
+// buffers that swap roles on acceptance (lb_eval writes the trial gradient into the other one), so the
+// update kernel never writes a row another wavefront still reads.
+__device__ __forceinline__ const double* dnlp_row(const double* __restrict__ BV, const double* __restrict__ gcur, int j, int GR, i64 nf) {
+  return j == GR ? gcur : BV + static_cast<i64>(j) * nf;
+}
+
 // ---- trial point: gradient and f partials at x + step * dir -------------------------------------
-extern "C" __global__ void __launch_bounds__(256) dnlp_lb_eval(LbfgsState* __restrict__ S, const double* __restrict__ x,
-    const double* __restrict__ BV, double* __restrict__ dir, double* __restrict__ gt, const double* __restrict__ consts,
-    double* __restrict__ fpart, const i64 nf, const i64 nchunks) {
-  double vals[2] = {0.0, 0.0};                      // f partial, NaN / inf detector of the gradient
+extern "C" __global__ void __launch_bounds__(256) dnlp_lb_eval(const LbfgsState* __restrict__ S, const double* __restrict__ x,
+    const double* __restrict__ BV, double* __restrict__ gbuf0, double* __restrict__ gbuf1, double* __restrict__ dir,
+    const double* __restrict__ consts, double* __restrict__ fpart, const i64 nf, const i64 nchunks, const int ldp) {
+  double facc = 0.0, chk = 0.0;                       // f partial, NaN / inf detector of the gradient
   if (S->done == 0) {
-    const int nb = 2 * S->M + 1;
-    const double step = S->phase == 0 ? 0.0 : S->step;
-    const bool fresh = S->phase != 0 && S->ls == 0;   // first trial of an iteration: dir is not built yet
+    const int GR = 2 * S->M, nb = GR + 1;
+    const double* __restrict__ gcur = S->gcur ? gbuf1 : gbuf0;
+    double* __restrict__ gt = S->gcur ? gbuf0 : gbuf1;
+    const int phase = S->phase;
+    const double step = phase == 0 ? 0.0 : S->step;
+    const bool fresh = phase != 0 && S->ls == 0;      // first trial of an iteration: dir is not built yet
     for (i64 q = static_cast<i64>(blockIdx.x) * 256 + threadIdx.x; q < nchunks; q += static_cast<i64>(gridDim.x) * 256) {
       const i64 c = q * DNLP_E;
       double xr[DNLP_NX], dw[DNLP_NX];
@@ -101,13 +116,13 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_eval(LbfgsState* __res
         for (int j = 0; j < nb; ++j) {
           const double cj = S->coef[j];
           if (cj == 0.0) continue;                   // uniform: rows not yet in the history cost nothing
-          const double* __restrict__ row = BV + static_cast<i64>(j) * nf;
+          const double* __restrict__ row = dnlp_row(BV, gcur, j, GR, nf);
 #pragma unroll
           for (int k = 0; k < DNLP_NX; ++k) { const i64 i = c - DNLP_W + k; if (i >= 0 && i < nf) dw[k] += cj * row[i]; }
         }
 #pragma unroll
         for (int t = 0; t < DNLP_E; ++t) if (c + t < nf) dir[c + t] = dw[DNLP_W + t];
-      } else if (S->phase != 0) {
+      } else if (phase != 0) {
 #pragma unroll
         for (int k = 0; k < DNLP_NX; ++k) { const i64 i = c - DNLP_W + k; if (i >= 0 && i < nf) dw[k] = dir[i]; }
       }
@@ -116,28 +131,27 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_eval(LbfgsState* __res
       double g[DNLP_E];
 #pragma unroll
       for (int t = 0; t < DNLP_E; ++t) g[t] = 0.0;
-      if (DNLP_INTERIOR(c, nf)) dnlp_chunk_w<false>(c, xr, consts, g, vals[0]);
-      else dnlp_chunk_w<true>(c, xr, consts, g, vals[0]);
+      if (DNLP_INTERIOR(c, nf)) dnlp_chunk_w<false>(c, xr, consts, g, facc);
+      else dnlp_chunk_w<true>(c, xr, consts, g, facc);
 #pragma unroll
-      for (int t = 0; t < DNLP_E; ++t) if (c + t < nf) { gt[c + t] = g[t]; vals[1] += g[t] - g[t]; }
+      for (int t = 0; t < DNLP_E; ++t) if (c + t < nf) { gt[c + t] = g[t]; chk += g[t] - g[t]; }
     }
   }
-  dnlp_block_reduce_store<2>(vals, 0, fpart + 2 * static_cast<i64>(blockIdx.x));
+  // one partial per wavefront: column index 4 * block + wave
+  const int col = 4 * blockIdx.x + (threadIdx.x >> 6);
+  dnlp_wave_store_sum(fpart + col, facc);
+  dnlp_wave_store_sum(fpart + static_cast<i64>(ldp) * 4 + col, chk);
 }
 
-// ---- Armijo test (one workgroup of 64) ------------------------------------------------------------
+// ---- Armijo test (one wavefront) --------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(64) dnlp_lb_accept(LbfgsState* __restrict__ S, const double* __restrict__ fpart,
-                                                                const double c0) {
-  __shared__ double red[2][64];
+                                                                const double c0, const int ldp) {
   if (S->done != 0) return;
-  double a = 0.0, b = 0.0;
-  for (int k = threadIdx.x; k < S->nblocks; k += 64) { a += fpart[2 * k]; b += fpart[2 * k + 1]; }
-  red[0][threadIdx.x] = a;
-  red[1][threadIdx.x] = b;
-  DNLP_SYNC();
+  const int ncol = 4 * S->nblocks;
+  const double fsum = dnlp_col_reduce(fpart, ncol, false);
+  const double chk = dnlp_col_reduce(fpart + static_cast<i64>(ldp) * 4, ncol, false);
   if (threadIdx.x != 63) return;                    // (the LAST lane decides: host emulation runs lanes in order)
-  double fn = c0, chk = 0.0;
-  for (int k = 0; k < 64; ++k) { fn += red[0][k]; chk += red[1][k]; }
+  const double fn = c0 + fsum;
   S->evals += 1;
   const bool finite = (fn - fn == 0.0) && chk == 0.0;
   S->fn = fn;
@@ -152,123 +166,173 @@ extern "C" __global__ void __launch_bounds__(64) dnlp_lb_accept(LbfgsState* __re
   if (S->ls >= 60) S->done = 2;                      // line search stuck
 }
 
-// ---- accepted step: x, history rows, partial Gram rows ----------------------------------------------
+// ---- accepted step: x, history rows s and y, partial Gram rows --------------------------------------
+// A block owns a contiguous range of elements; every wavefront holds the range's s, y, g_new in
+// registers (tiles of 1024 elements), wavefront w writes the elements of tile slots t = w (mod 4) and
+// owns the basis rows j = w (mod 4): it streams row j once against the three vectors, so a row's three
+// dots are reduced inside ONE wavefront and stored by its lane 0 — no cross-wavefront reduction, and no
+// row is written that another wavefront still reads (rows head / M + head come from registers, the
+// gradient row is the buffer lb_eval just filled).
+#define DNLP_UT 16
 extern "C" __global__ void __launch_bounds__(256) dnlp_lb_update(const LbfgsState* __restrict__ S, double* __restrict__ x,
-    double* __restrict__ BV, const double* __restrict__ dir, const double* __restrict__ gt, double* __restrict__ upart,
-    const i64 nf) {
-  double acc[3 * DNLP_MAXNB + 1];
+    double* __restrict__ BV, const double* __restrict__ gbuf0, const double* __restrict__ gbuf1,
+    const double* __restrict__ dir, double* __restrict__ upart, const i64 nf, const int ldp) {
+  if (S->done != 0 || S->accept == 0) return;
+  const int M = S->M, nb = 2 * M + 1, GR = 2 * M, head = S->head;
+  const bool run = S->phase != 0;
+  const double step = S->step;
+  const double* __restrict__ gold = S->gcur ? gbuf1 : gbuf0;
+  const double* __restrict__ gnew = S->gcur ? gbuf0 : gbuf1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const i64 per = ((nf + gridDim.x - 1) / gridDim.x + 63) / 64 * 64;
+  const i64 b0 = static_cast<i64>(blockIdx.x) * per, b1 = b0 + per < nf ? b0 + per : nf;
+  double as[8], ay[8], ag[8];                       // dots of this wavefront's rows (at most ceil(31 / 4) = 8)
 #pragma unroll
-  for (int k = 0; k < 3 * DNLP_MAXNB + 1; ++k) acc[k] = 0.0;
-  const bool act = S->done == 0 && S->accept != 0;
-  if (act) {
-    const int M = S->M, nb = 2 * M + 1, GR = 2 * M, head = S->head;
-    const bool run = S->phase != 0;
-    const double step = S->step;
-    for (i64 i = static_cast<i64>(blockIdx.x) * 256 + threadIdx.x; i < nf; i += static_cast<i64>(gridDim.x) * 256) {
-      const double gnew = gt[i];
-      const double sv = run ? step * dir[i] : 0.0;
-      const double yv = run ? gnew - BV[static_cast<i64>(GR) * nf + i] : 0.0;
-      if (run) {
-        x[i] += sv;
-        BV[static_cast<i64>(head) * nf + i] = sv;
-        BV[static_cast<i64>(M + head) * nf + i] = yv;
+  for (int r = 0; r < 8; ++r) as[r] = ay[r] = ag[r] = 0.0;
+  double gmax = 0.0;
+  for (i64 t0 = b0; t0 < b1; t0 += 64 * DNLP_UT) {
+    double sv[DNLP_UT], yv[DNLP_UT], gv[DNLP_UT];
+#pragma unroll
+    for (int t = 0; t < DNLP_UT; ++t) {
+      const i64 i = t0 + lane + 64 * t;
+      const bool in = i < b1;
+      gv[t] = in ? gnew[i] : 0.0;
+      sv[t] = (in && run) ? step * dir[i] : 0.0;
+      yv[t] = (in && run) ? gv[t] - gold[i] : 0.0;
+      gmax = fmax(gmax, fabs(gv[t]));
+      if (in && run && (t & 3) == wave) {
+        x[i] += sv[t];
+        BV[static_cast<i64>(head) * nf + i] = sv[t];
+        BV[static_cast<i64>(M + head) * nf + i] = yv[t];
       }
-      BV[static_cast<i64>(GR) * nf + i] = gnew;
+    }
 #pragma unroll
-      for (int j = 0; j < DNLP_MAXNB; ++j) {
-        if (j < nb) {
-          const double r = (run && j == head) ? sv : (run && j == M + head) ? yv : (j == GR) ? gnew : BV[static_cast<i64>(j) * nf + i];
-          acc[j] += sv * r;
-          acc[DNLP_MAXNB + j] += yv * r;
-          acc[2 * DNLP_MAXNB + j] += gnew * r;
+    for (int r = 0; r < 8; ++r) {
+      const int j = wave + 4 * r;
+      if (j < nb) {
+        const double* __restrict__ row = dnlp_row(BV, gnew, j, GR, nf);
+        const bool is_s = run && j == head, is_y = run && j == M + head, is_g = j == GR;
+#pragma unroll
+        for (int t = 0; t < DNLP_UT; ++t) {
+          const i64 i = t0 + lane + 64 * t;
+          const double v = is_s ? sv[t] : is_y ? yv[t] : is_g ? gv[t] : (i < b1 ? row[i] : 0.0);
+          as[r] += sv[t] * v;
+          ay[r] += yv[t] * v;
+          ag[r] += gv[t] * v;
         }
       }
-      acc[3 * DNLP_MAXNB] = fmax(acc[3 * DNLP_MAXNB], fabs(gnew));
     }
   }
-  dnlp_block_reduce_store<3 * DNLP_MAXNB + 1>(acc, 1, upart + static_cast<i64>(3 * DNLP_MAXNB + 1) * blockIdx.x);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int j = wave + 4 * r;
+    if (j < nb) {
+      dnlp_wave_store_sum(upart + static_cast<i64>(j) * ldp + blockIdx.x, as[r]);
+      dnlp_wave_store_sum(upart + static_cast<i64>(DNLP_MAXNB + j) * ldp + blockIdx.x, ay[r]);
+      dnlp_wave_store_sum(upart + static_cast<i64>(2 * DNLP_MAXNB + j) * ldp + blockIdx.x, ag[r]);
+    }
+  }
+  if (wave == 0) dnlp_wave_store_max(upart + static_cast<i64>(3 * DNLP_MAXNB) * ldp + blockIdx.x, gmax);
 }
 
-// ---- Gram rows, history bookkeeping, convergence, two-loop recursion (one workgroup of 128) -----------
-extern "C" __global__ void __launch_bounds__(128) dnlp_lb_control(LbfgsState* __restrict__ S, const double* __restrict__ upart) {
-  __shared__ double red[3 * DNLP_MAXNB + 1];
+// ---- Gram rows, history bookkeeping, convergence, two-loop recursion (one workgroup of 256) -----------
+// The scalar part runs on ONE lane; everything it touches repeatedly (Gram matrix, coefficients) is staged
+// in LDS first — a dependent chain of global loads costs ~1 us per link, an LDS one ~0.05.
+extern "C" __global__ void __launch_bounds__(256) dnlp_lb_control(LbfgsState* __restrict__ S, const double* __restrict__ upart,
+                                                                  const int ldp) {
+  __shared__ double red[DNLP_NV];
+  __shared__ double Gs[DNLP_MAXNB * DNLP_MAXNB];
+  __shared__ double cf[DNLP_MAXNB], rh[16], al[16];
   if (S->done != 0 || S->accept == 0) return;
-  const int NV = 3 * DNLP_MAXNB + 1;
-  if (static_cast<int>(threadIdx.x) < NV) {
-    const int k = threadIdx.x;
-    double a = (k == NV - 1) ? -1.0 : 0.0;
-    for (int b = 0; b < S->nblocks; ++b) { const double v = upart[static_cast<i64>(NV) * b + k]; a = (k == NV - 1) ? fmax(a, v) : a + v; }
-    red[k] = a;
+  const int nblocks = S->nblocks;
+  {
+    const int M0 = S->M, nb0 = 2 * M0 + 1;
+    for (int k = threadIdx.x >> 6; k < DNLP_NV; k += 4) {
+      const int j = k % DNLP_MAXNB;
+      if (k < 3 * DNLP_MAXNB && j >= nb0) continue;            // rows beyond the basis were never written
+      const double r = dnlp_col_reduce(upart + static_cast<i64>(k) * ldp, nblocks, k == DNLP_NV - 1);
+      if ((threadIdx.x & 63) == 63) red[k] = r;
+    }
   }
+  for (int k = threadIdx.x; k < DNLP_MAXNB * DNLP_MAXNB; k += 256) Gs[k] = S->G[k];
+  if (threadIdx.x < 15) rh[threadIdx.x] = S->rho[threadIdx.x];
   DNLP_SYNC();
-  if (threadIdx.x != 127) return;
+  if (threadIdx.x != 255) return;                    // (the LAST lane: host emulation runs the lanes in order)
+  const int NV = DNLP_NV;
   const int M = S->M, nb = 2 * M + 1, GR = 2 * M;
   const int ld = DNLP_MAXNB;
-  double* G = S->G;
-  int head = S->head, stored = S->stored;
+  int head = S->head, stored = S->stored, iter = S->iter;
   const bool run = S->phase != 0;
+  const double tol = S->tol, fnew = S->fn;
+  const int max_iter = S->max_iter;
+  double* G = S->G;
   if (run) {
-    for (int j = 0; j < nb; ++j) {
-      G[head * ld + j] = G[j * ld + head] = red[j];
-    }
-    for (int j = 0; j < nb; ++j) {
-      G[(M + head) * ld + j] = G[j * ld + (M + head)] = red[DNLP_MAXNB + j];
-    }
+    for (int j = 0; j < nb; ++j) { Gs[head * ld + j] = Gs[j * ld + head] = red[j]; }
+    for (int j = 0; j < nb; ++j) { Gs[(M + head) * ld + j] = Gs[j * ld + (M + head)] = red[DNLP_MAXNB + j]; }
   }
-  for (int j = 0; j < nb; ++j) G[GR * ld + j] = G[j * ld + GR] = red[2 * DNLP_MAXNB + j];
+  for (int j = 0; j < nb; ++j) Gs[GR * ld + j] = Gs[j * ld + GR] = red[2 * DNLP_MAXNB + j];
+  // write the new rows / columns through (in the order above, so that shared entries end up as in LDS)
   if (run) {
-    const double sy = G[head * ld + (M + head)], ss = G[head * ld + head], yy = G[(M + head) * ld + (M + head)];
+    for (int j = 0; j < nb; ++j) { G[head * ld + j] = Gs[head * ld + j]; G[j * ld + head] = Gs[j * ld + head]; }
+    for (int j = 0; j < nb; ++j) { G[(M + head) * ld + j] = Gs[(M + head) * ld + j]; G[j * ld + (M + head)] = Gs[j * ld + (M + head)]; }
+  }
+  for (int j = 0; j < nb; ++j) { G[GR * ld + j] = Gs[GR * ld + j]; G[j * ld + GR] = Gs[j * ld + GR]; }
+  if (run) {
+    const double sy = Gs[head * ld + (M + head)], ss = Gs[head * ld + head], yy = Gs[(M + head) * ld + (M + head)];
     if (sy > 1e-10 * sqrt(ss) * sqrt(yy)) {
-      S->rho[head] = 1.0 / sy;
+      rh[head] = 1.0 / sy;
+      S->rho[head] = rh[head];
       head = (head + 1) % M;
       if (stored < M) ++stored;
     }
-    S->iter += 1;
+    iter += 1;
   }
+  S->iter = iter;
   S->head = head;
-  S->stored = stored;
-  S->f = S->fn;
+  S->f = fnew;
   S->phase = 1;
   S->accept = 0;
   S->ls = 0;
-  const double gn = red[NV - 1], f = S->f;
+  S->gcur ^= 1;                                      // the trial gradient is the current one from here on
+  const double gn = red[NV - 1];
   S->gn = gn;
-  if (gn <= S->tol * fmax(1.0, fabs(f))) { S->done = 1; return; }
-  if (S->iter >= S->max_iter) { S->done = 3; return; }
+  if (gn <= tol * fmax(1.0, fabs(fnew))) { S->stored = stored; S->done = 1; return; }
+  if (iter >= max_iter) { S->stored = stored; S->done = 3; return; }
   // two-loop recursion on the coefficients of q in the basis (lbfgs_core.h)
-  double* coef = S->coef;
-  for (int j = 0; j < nb; ++j) coef[j] = 0.0;
-  coef[GR] = 1.0;
+  for (int j = 0; j < nb; ++j) cf[j] = 0.0;
+  cf[GR] = 1.0;
   for (int j = 0; j < stored; ++j) {
     const int idx = (head - 1 - j + 2 * M) % M;
     double v = 0.0;
-    for (int q = 0; q < nb; ++q) v += coef[q] * G[idx * ld + q];
-    const double a = S->rho[idx] * v;
-    S->alpha[idx] = a;
-    coef[M + idx] -= a;
+    for (int q = 0; q < nb; ++q) v += cf[q] * Gs[idx * ld + q];
+    const double a = rh[idx] * v;
+    al[idx] = a;
+    cf[M + idx] -= a;
   }
   if (stored > 0) {
     const int idx = (head - 1 + M) % M;
-    const double gam = G[idx * ld + (M + idx)] / G[(M + idx) * ld + (M + idx)];
-    for (int j = 0; j < nb; ++j) coef[j] *= gam;
+    const double gam = Gs[idx * ld + (M + idx)] / Gs[(M + idx) * ld + (M + idx)];
+    for (int j = 0; j < nb; ++j) cf[j] *= gam;
   }
   for (int j = stored - 1; j >= 0; --j) {
     const int idx = (head - 1 - j + 2 * M) % M;
     double v = 0.0;
-    for (int q = 0; q < nb; ++q) v += coef[q] * G[(M + idx) * ld + q];
-    coef[idx] += S->alpha[idx] - S->rho[idx] * v;
+    for (int q = 0; q < nb; ++q) v += cf[q] * Gs[(M + idx) * ld + q];
+    cf[idx] += al[idx] - rh[idx] * v;
   }
-  for (int j = 0; j < nb; ++j) coef[j] = -coef[j];
+  for (int j = 0; j < nb; ++j) cf[j] = -cf[j];
   double gd = 0.0;
-  for (int q = 0; q < nb; ++q) gd += coef[q] * G[GR * ld + q];
+  for (int q = 0; q < nb; ++q) gd += cf[q] * Gs[GR * ld + q];
   if (!(gd < 0.0)) {                                 // not a descent direction: steepest descent, history dropped
-    S->stored = stored = 0;
-    for (int j = 0; j < nb; ++j) coef[j] = 0.0;
-    coef[GR] = -1.0;
-    gd = -G[GR * ld + GR];
+    stored = 0;
+    for (int j = 0; j < nb; ++j) cf[j] = 0.0;
+    cf[GR] = -1.0;
+    gd = -Gs[GR * ld + GR];
   }
+  for (int j = 0; j < nb; ++j) S->coef[j] = cf[j];
+  S->stored = stored;
   S->gd = gd;
-  S->step = (S->iter == 0 && stored == 0) ? fmin(1.0, 1.0 / fmax(gn, 1e-300)) : 1.0;
+  S->step = (iter == 0 && stored == 0) ? fmin(1.0, 1.0 / fmax(gn, 1e-300)) : 1.0;
 }
 )DNLPLB";
   return s;

@@ -236,15 +236,15 @@ extern "C" int emulate_lbfgs(double* x, const double* consts, double c0, long lo
   LbfgsState S;
   std::memset(&S, 0, sizeof S);
   S.tol = tol; S.max_iter = max_iter; S.M = M; S.nblocks = blocks;
-  const int nb = 2 * M + 1;
-  std::vector<double> BV((size_t)nb * nf, 0.0), dir(nf, 0.0), gt(nf, 0.0), fpart(2 * blocks, 0.0), upart((3 * DNLP_MAXNB + 1) * blocks, 0.0);
+  const int ldp = 64;
+  std::vector<double> BV((size_t)2 * M * nf, 0.0), dir(nf, 0.0), g0(nf, 0.0), g1(nf, 0.0), fpart(8 * ldp, 0.0), upart(DNLP_NV * ldp, 0.0);
   const long long nchunks = (nf + DNLP_E - 1) / DNLP_E;
   int slots = 0;
   while (S.done == 0 && slots < 100000) {
-    run_grid(blocks, 256, dnlp_lb_eval, &S, (const double*)x, (const double*)BV.data(), dir.data(), gt.data(), consts, fpart.data(), nf, nchunks);
-    run_grid(1, 64, dnlp_lb_accept, &S, (const double*)fpart.data(), c0);
-    run_grid(blocks, 256, dnlp_lb_update, (const LbfgsState*)&S, x, BV.data(), (const double*)dir.data(), (const double*)gt.data(), upart.data(), nf);
-    run_grid(1, 128, dnlp_lb_control, &S, (const double*)upart.data());
+    run_grid(blocks, 256, dnlp_lb_eval, (const LbfgsState*)&S, (const double*)x, (const double*)BV.data(), g0.data(), g1.data(), dir.data(), consts, fpart.data(), nf, nchunks, ldp);
+    run_grid(1, 64, dnlp_lb_accept, &S, (const double*)fpart.data(), c0, ldp);
+    run_grid(blocks, 256, dnlp_lb_update, (const LbfgsState*)&S, x, BV.data(), (const double*)g0.data(), (const double*)g1.data(), (const double*)dir.data(), upart.data(), nf, ldp);
+    run_grid(1, 256, dnlp_lb_control, &S, (const double*)upart.data(), ldp);
     ++slots;
   }
   out[0] = S.f; out[1] = S.gn; out[2] = S.iter; out[3] = S.evals; out[4] = S.done; out[5] = slots;
