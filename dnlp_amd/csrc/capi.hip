@@ -136,7 +136,7 @@ int dnlp_lbfgs_codegen_check(const void* blob, size_t len, int elems_per_lane, c
     if (!fused_parse_programs(tb, progs, nconst, c0, nfree)) { put(log_out, log_cap, "no fused program in this tape"); return -11; }
     const FusedCodegenInfo info = fused_codegen_plan(progs, elems_per_lane > 0 ? elems_per_lane : 4);
     if (!info.ok) { put(log_out, log_cap, info.why); return 1; }
-    const std::string src = lbfgs_codegen_source(progs, info);
+    const std::string src = lbfgs_codegen_source(progs, info, 10);
     put(src_out, src_cap, src);
     std::string log;
     const std::vector<char> code = rtc_compile(src, log, false);

@@ -1070,6 +1070,7 @@ struct HipExec : HostControlled {
   RtcKernel lb_rtc;
   hipFunction_t lb_eval = nullptr, lb_accept = nullptr, lb_update = nullptr, lb_control = nullptr;
   const void* lb_key = nullptr;
+  int lb_key_M = 0;
   LbfgsState* lb_state = nullptr;       // device
   LbfgsState* lb_host = nullptr;        // pinned
   double *lb_BV = nullptr, *lb_dir = nullptr, *lb_gt = nullptr, *lb_fpart = nullptr, *lb_upart = nullptr;
@@ -1083,11 +1084,14 @@ struct HipExec : HostControlled {
     if (const char* v = std::getenv("DNLP_LBFGS_DEVICE")) if (std::atoi(v) == 0) return false;
     if (M < 1) M = 1;
     if (M > kLbMaxM) M = kLbMaxM;
-    if (lb_key != static_cast<const void*>(&progs)) {
+    if (lb_key != static_cast<const void*>(&progs) || lb_key_M != M) {
       lb_key = &progs;
+      lb_key_M = M;
+      if (lb_rtc.mod) { hipModuleUnload(lb_rtc.mod); lb_rtc.mod = nullptr; }
+      lb_rtc.ok = false;
       if (const char* v = std::getenv("DNLP_FUSED_E")) { const int e = std::atoi(v); if (e >= 1 && e <= 16) fused_E = e; }
       const FusedCodegenInfo info = fused_codegen_plan(progs, fused_E);
-      if (info.ok && lb_rtc.load(lbfgs_codegen_source(progs, info), "dnlp_lb_eval")) {
+      if (info.ok && lb_rtc.load(lbfgs_codegen_source(progs, info, M), "dnlp_lb_eval")) {
         lb_eval = lb_rtc.fn;
         lb_accept = lb_rtc.get("dnlp_lb_accept");
         lb_update = lb_rtc.get("dnlp_lb_update");

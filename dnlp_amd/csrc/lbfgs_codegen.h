@@ -44,8 +44,11 @@ constexpr int kLbMaxNB = 2 * kLbMaxM + 1;
   int nblocks; int gcur;
 struct LbfgsState { DNLP_LB_STATE_BODY };
 
-inline std::string lbfgs_codegen_source(const std::vector<FusedSlotProg>& progs, const FusedCodegenInfo& info) {
+// M (history length) is a generation-time constant: the loops over the 2M+1 basis rows unroll, which is
+// what lets the single-lane two-loop recursion of lb_control pipeline its LDS reads.
+inline std::string lbfgs_codegen_source(const std::vector<FusedSlotProg>& progs, const FusedCodegenInfo& info, int M) {
   std::string s = fused_codegen_preamble(info.E);
+  s += "#define DNLP_M " + std::to_string(M) + "\n#define DNLP_NB " + std::to_string(2 * M + 1) + "\n";
   s += fused_codegen_chunk(progs, info);
   s += "struct LbfgsState { " DNLP_LB_STR(DNLP_LB_STATE_BODY) " };\n";
   s += R"DNLPLB(
@@ -69,22 +72,26 @@ __device__ __forceinline__ void dnlp_wave_store_max(double* __restrict__ dst, do
   v = dnlp_wave_max(v);
   if ((threadIdx.x & 63) == 0) *dst = v;
 }
-// reduction of col[0..n) by the calling wavefront; every lane gets the result
-__device__ __forceinline__ double dnlp_col_reduce(const double* __restrict__ col, int n, bool is_max) {
+// reduction of col[0..n) by the calling wavefront in two steps, so that a wavefront can put the loads of
+// MANY columns in flight before it folds any of them (one memory latency instead of one per column):
+// dnlp_col_partial = this lane's share, dnlp_col_finish = fold across the wavefront (every lane gets it)
+__device__ __forceinline__ double dnlp_col_partial(const double* __restrict__ col, int n, bool is_max) {
   const int lane = threadIdx.x & 63;
   double a = is_max ? -1.0 : 0.0;
   for (int b = lane; b < n; b += 64) { const double v = col[b]; a = is_max ? fmax(a, v) : a + v; }
-  return is_max ? dnlp_wave_max(a) : dnlp_wave_sum(a);
+  return a;
 }
+__device__ __forceinline__ double dnlp_col_finish(double a, bool is_max) { return is_max ? dnlp_wave_max(a) : dnlp_wave_sum(a); }
 #define DNLP_SYNC() __syncthreads()
 #else
 inline void dnlp_wave_store_sum(double* dst, double v) { if ((threadIdx.x & 63) == 0) *dst = 0.0; *dst += v; }
 inline void dnlp_wave_store_max(double* dst, double v) { if ((threadIdx.x & 63) == 0) *dst = -1.0; *dst = fmax(*dst, v); }
-inline double dnlp_col_reduce(const double* col, int n, bool is_max) {
+inline double dnlp_col_partial(const double* col, int n, bool is_max) {
   double a = is_max ? -1.0 : 0.0;
   for (int b = 0; b < n; ++b) a = is_max ? fmax(a, col[b]) : a + col[b];
   return a;
 }
+inline double dnlp_col_finish(double a, bool) { return a; }
 #define DNLP_SYNC()
 #endif
 
@@ -101,7 +108,7 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_eval(const LbfgsState*
     const double* __restrict__ consts, double* __restrict__ fpart, const i64 nf, const i64 nchunks, const int ldp) {
   double facc = 0.0, chk = 0.0;                       // f partial, NaN / inf detector of the gradient
   if (S->done == 0) {
-    const int GR = 2 * S->M, nb = GR + 1;
+    constexpr int GR = 2 * DNLP_M, nb = DNLP_NB;
     const double* __restrict__ gcur = S->gcur ? gbuf1 : gbuf0;
     double* __restrict__ gt = S->gcur ? gbuf0 : gbuf1;
     const int phase = S->phase;
@@ -113,6 +120,7 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_eval(const LbfgsState*
 #pragma unroll
       for (int k = 0; k < DNLP_NX; ++k) dw[k] = 0.0;
       if (fresh) {
+#pragma unroll 1
         for (int j = 0; j < nb; ++j) {
           const double cj = S->coef[j];
           if (cj == 0.0) continue;                   // uniform: rows not yet in the history cost nothing
@@ -148,8 +156,9 @@ extern "C" __global__ void __launch_bounds__(64) dnlp_lb_accept(LbfgsState* __re
                                                                 const double c0, const int ldp) {
   if (S->done != 0) return;
   const int ncol = 4 * S->nblocks;
-  const double fsum = dnlp_col_reduce(fpart, ncol, false);
-  const double chk = dnlp_col_reduce(fpart + static_cast<i64>(ldp) * 4, ncol, false);
+  const double p0 = dnlp_col_partial(fpart, ncol, false);
+  const double p1 = dnlp_col_partial(fpart + static_cast<i64>(ldp) * 4, ncol, false);
+  const double fsum = dnlp_col_finish(p0, false), chk = dnlp_col_finish(p1, false);
   if (threadIdx.x != 63) return;                    // (the LAST lane decides: host emulation runs lanes in order)
   const double fn = c0 + fsum;
   S->evals += 1;
@@ -178,7 +187,8 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_update(const LbfgsStat
     double* __restrict__ BV, const double* __restrict__ gbuf0, const double* __restrict__ gbuf1,
     const double* __restrict__ dir, double* __restrict__ upart, const i64 nf, const int ldp) {
   if (S->done != 0 || S->accept == 0) return;
-  const int M = S->M, nb = 2 * M + 1, GR = 2 * M, head = S->head;
+  constexpr int M = DNLP_M, nb = DNLP_NB, GR = 2 * DNLP_M;
+  const int head = S->head;
   const bool run = S->phase != 0;
   const double step = S->step;
   const double* __restrict__ gold = S->gcur ? gbuf1 : gbuf0;
@@ -246,21 +256,33 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_control(LbfgsState* __
   if (S->done != 0 || S->accept == 0) return;
   const int nblocks = S->nblocks;
   {
-    const int M0 = S->M, nb0 = 2 * M0 + 1;
-    for (int k = threadIdx.x >> 6; k < DNLP_NV; k += 4) {
-      const int j = k % DNLP_MAXNB;
-      if (k < 3 * DNLP_MAXNB && j >= nb0) continue;            // rows beyond the basis were never written
-      const double r = dnlp_col_reduce(upart + static_cast<i64>(k) * ldp, nblocks, k == DNLP_NV - 1);
-      if ((threadIdx.x & 63) == 63) red[k] = r;
+    // wavefront w folds the columns k = w (mod 4): all their loads first, then the shuffles
+    constexpr int nb0 = DNLP_NB;
+    const int wave = threadIdx.x >> 6;
+    constexpr int NC = (DNLP_NV + 3) / 4;
+    double part[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int k = wave + 4 * c;
+      const bool used = k < DNLP_NV && (k >= 3 * DNLP_MAXNB || (k % DNLP_MAXNB) < nb0);   // rows beyond the basis were never written
+      part[c] = used ? dnlp_col_partial(upart + static_cast<i64>(k) * ldp, nblocks, k == DNLP_NV - 1) : 0.0;
+    }
+    for (int k = threadIdx.x; k < DNLP_MAXNB * DNLP_MAXNB; k += 256) Gs[k] = S->G[k];
+    if (threadIdx.x < 15) rh[threadIdx.x] = S->rho[threadIdx.x];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int k = wave + 4 * c;
+      if (k < DNLP_NV) {
+        const double r = dnlp_col_finish(part[c], k == DNLP_NV - 1);
+        if ((threadIdx.x & 63) == 63) red[k] = r;
+      }
     }
   }
-  for (int k = threadIdx.x; k < DNLP_MAXNB * DNLP_MAXNB; k += 256) Gs[k] = S->G[k];
-  if (threadIdx.x < 15) rh[threadIdx.x] = S->rho[threadIdx.x];
   DNLP_SYNC();
   if (threadIdx.x != 255) return;                    // (the LAST lane: host emulation runs the lanes in order)
   const int NV = DNLP_NV;
-  const int M = S->M, nb = 2 * M + 1, GR = 2 * M;
-  const int ld = DNLP_MAXNB;
+  constexpr int M = DNLP_M, nb = DNLP_NB, GR = 2 * DNLP_M;
+  constexpr int ld = DNLP_MAXNB;
   int head = S->head, stored = S->stored, iter = S->iter;
   const bool run = S->phase != 0;
   const double tol = S->tol, fnew = S->fn;
@@ -304,6 +326,7 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_control(LbfgsState* __
   for (int j = 0; j < stored; ++j) {
     const int idx = (head - 1 - j + 2 * M) % M;
     double v = 0.0;
+#pragma unroll
     for (int q = 0; q < nb; ++q) v += cf[q] * Gs[idx * ld + q];
     const double a = rh[idx] * v;
     al[idx] = a;
@@ -317,11 +340,13 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_control(LbfgsState* __
   for (int j = stored - 1; j >= 0; --j) {
     const int idx = (head - 1 - j + 2 * M) % M;
     double v = 0.0;
+#pragma unroll
     for (int q = 0; q < nb; ++q) v += cf[q] * Gs[(M + idx) * ld + q];
     cf[idx] += al[idx] - rh[idx] * v;
   }
   for (int j = 0; j < nb; ++j) cf[j] = -cf[j];
   double gd = 0.0;
+#pragma unroll
   for (int q = 0; q < nb; ++q) gd += cf[q] * Gs[GR * ld + q];
   if (!(gd < 0.0)) {                                 // not a descent direction: steepest descent, history dropped
     stored = 0;
