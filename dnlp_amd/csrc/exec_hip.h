@@ -625,6 +625,23 @@ __global__ void __launch_bounds__(kBlock) v_axpy_kernel(int k, const double* __r
   w[i] -= s;
 }
 
+// y = base + M v for CSR matrices with long rows: one wavefront per row, lanes stride over the row's
+// entries (coalesced index / value reads), shuffle reduction
+__global__ void __launch_bounds__(kBlock) spmv_long_kernel(i64 rows, const i64* __restrict__ ptr, const i32* __restrict__ idx,
+                                                           const double* __restrict__ val, const double* __restrict__ v,
+                                                           const double* __restrict__ base, double* __restrict__ y) {
+  const i64 r = static_cast<i64>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  double s0 = 0.0, s1 = 0.0;
+  const i64 b = ptr[r], e = ptr[r + 1];
+  i64 k = b + lane;
+  for (; k + 64 < e; k += 128) { s0 += val[k] * v[idx[k]]; s1 += val[k + 64] * v[idx[k + 64]]; }
+  if (k < e) s0 += val[k] * v[idx[k]];
+  const double s = wave_sum(s0 + s1);
+  if (lane == 0) y[r] = s + (base ? base[r] : 0.0);
+}
+
 // ---- fused element programs (fused_obj.h): the interpreter's register file lives in LDS --------
 // slot[k][lane] (k < P.n, 256 lanes): consecutive lanes hit consecutive banks.  The program sits
 // in the kernel arguments, so opcode dispatch is scalar and uniform.  f: per-lane partial ->
@@ -887,6 +904,12 @@ struct HipExec : HostControlled {
     return r;
   }
 
+  void spmv_long_rows(const Csr& M, const double* v, const double* base, double* y) {
+    const i64 grid = (M.rows + kBlock / 64 - 1) / (kBlock / 64);
+    hipLaunchKernelGGL(spmv_long_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, M.rows, M.ptr, M.idx, M.val,
+                       v, base, y);
+    DNLP_LAUNCH_CHECK();
+  }
   void gemv_sym(i64 n, const double* P, i64 ld, const double* u, double* out) {
     const i64 nrb = (n + 511) / 512, ncb = (n + GEMV_CB - 1) / GEMV_CB;
     const size_t need = static_cast<size_t>(ncb) * static_cast<size_t>(n);

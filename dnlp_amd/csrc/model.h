@@ -61,6 +61,11 @@ struct Model {
 
   // y = base + M v   (base may be null)
   DNLP_HD void spmv(const Csr& M, const double* v, const double* base, double* y) {
+    if constexpr (E::is_device && E::has_host_control) {
+      // long rows (dense constraint blocks: C3's A is 1e3 rows of 1e4 entries): a lane per row would walk
+      // 1e4 entries alone; one wavefront per row reads them coalesced
+      if (M.rows > 0 && M.nnz >= 32 * M.rows) { ex->spmv_long_rows(M, v, base, y); return; }
+    }
     const i64* ptr = M.ptr;
     const i32* idx = M.idx;
     const double* val = M.val;
