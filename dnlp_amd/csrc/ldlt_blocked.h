@@ -159,11 +159,15 @@ __global__ void __launch_bounds__(TB_T) ldlt_topblock_kernel(double* A, i64 ld, 
       while (tr * (tr + 1) / 2 > q) --tr;
       const int tc = q - tr * (tr + 1) / 2;
       double acc[4][4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
       const int ra = tr * 4, ca = tc * 4;
+      // the tile's 16 entries are loaded FIRST (independent loads, one memory round trip): a
+      // read-modify-write per entry would chain 16 dependent round trips behind possibly aliasing stores
+      double* tile = A + (static_cast<i64>(K0) + r0 + ra) + (static_cast<i64>(K0) + r0 + ca) * ld;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          acc[a][b] = (ra + a < nrows && ca + b < nrows && ra + a >= ca + b) ? -tile[a + static_cast<i64>(b) * ld] : 0.0;
 #pragma unroll 8
       for (int k = 0; k < LD_nb; ++k) {
         double w[4], l[4];
@@ -182,8 +186,7 @@ __global__ void __launch_bounds__(TB_T) ldlt_topblock_kernel(double* A, i64 ld, 
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int rr = ra + a, cc = ca + b;
-          if (rr < nrows && cc < nrows && rr >= cc)
-            A[(static_cast<i64>(K0) + r0 + rr) + (static_cast<i64>(K0) + r0 + cc) * ld] -= acc[a][b];
+          if (rr < nrows && cc < nrows && rr >= cc) tile[a + static_cast<i64>(b) * ld] = -acc[a][b];
         }
     }
     __syncthreads();
@@ -195,36 +198,49 @@ __global__ void __launch_bounds__(TB_T) ldlt_topblock_kernel(double* A, i64 ld, 
   }
 }
 
-// rows below a finished KB x KB diagonal block: every row independently, strip by strip — forward
-// substitution against the strip's 32 x 32 block, then the row's remaining panel columns are updated with
-// the strip (A[r, c] -= sum_k x_k L[c, k], L of the block's strip in LDS).  Writes L in place and W = L D
-// into the panel workspace (the operand of the big MFMA update).
+// rows below a finished KB x KB diagonal block: every row independently, strip by strip, LEFT-looking:
+//   x = A[r, strip] - sum_{k < strip} W[r, k] L[strip rows, k]      (W[r, k]: the row's earlier results)
+//   forward substitution against the strip's 32 x 32 block -> W[r, strip] = x, L[r, strip] = x / d
+// so a strip costs one batch of independent loads (the row's 32 entries and its earlier W values) and one
+// batch of stores — a right-looking update would read-modify-write every remaining panel entry of the row
+// once per strip, each a dependent round trip.  The block rows L[strip rows, 0 .. strip) sit in LDS.
+// Writes L in place and W = L D into the panel workspace (the operand of the big MFMA update).
 __global__ void __launch_bounds__(256) ldlt_panel_rows_kernel(double* A, i64 ld, int K0, int KB, int n, double* Wp, i64 ldw) {
   extern __shared__ double pr_smem[];
   double (*Lb)[LD_nb + 1] = reinterpret_cast<double (*)[LD_nb + 1]>(pr_smem);
   double* dv = pr_smem + LD_nb * (LD_nb + 1);
-  double* Lc = dv + LD_nb;                                 // (KB - strip end) x 32, row c: L[c, strip]
+  double* Lr = dv + LD_nb;                                 // Lr[k * 32 + c] = L[strip row c, block column k], k < strip start
   const int tid = threadIdx.x;
   const i64 r = static_cast<i64>(K0) + KB + static_cast<i64>(blockIdx.x) * 256 + tid;
   const bool live = r < n;
   for (int s0 = 0; s0 < KB; s0 += LD_nb) {
     const int j0 = K0 + s0, jb = min(LD_nb, KB - s0);
-    const int c0 = s0 + jb, ncols = KB - c0;              // block columns right of the strip
     __syncthreads();
     for (int e = tid; e < jb * jb; e += 256) {
       const int rr = e % jb, cc = e / jb;
       Lb[rr][cc] = (rr > cc) ? A[(j0 + rr) + static_cast<i64>(j0 + cc) * ld] : 0.0;
     }
     if (tid < jb) dv[tid] = A[(j0 + tid) + static_cast<i64>(j0 + tid) * ld];
-    for (int e = tid; e < ncols * jb; e += 256) {
-      const int cc = e % ncols, k = e / ncols;             // consecutive lanes: consecutive rows of the block (coalesced)
-      Lc[cc * LD_nb + k] = A[(static_cast<i64>(K0) + c0 + cc) + static_cast<i64>(j0 + k) * ld];
+    for (int e = tid; e < s0 * LD_nb; e += 256) {
+      const int c = e % LD_nb, k = e / LD_nb;              // consecutive lanes: consecutive rows of the block (coalesced)
+      Lr[k * LD_nb + c] = (c < jb) ? A[(j0 + c) + static_cast<i64>(K0 + k) * ld] : 0.0;
     }
     __syncthreads();
     if (!live) continue;
     double x[LD_nb];
 #pragma unroll
     for (int c = 0; c < LD_nb; ++c) x[c] = (c < jb) ? A[r + static_cast<i64>(j0 + c) * ld] : 0.0;
+    for (int k0 = 0; k0 < s0; k0 += LD_nb) {
+      double w[LD_nb];
+#pragma unroll
+      for (int k = 0; k < LD_nb; ++k) w[k] = Wp[r + static_cast<i64>(k0 + k) * ldw];
+#pragma unroll
+      for (int k = 0; k < LD_nb; ++k) {
+        const double* lk = Lr + (k0 + k) * LD_nb;
+#pragma unroll
+        for (int c = 0; c < LD_nb; ++c) x[c] -= w[k] * lk[c];
+      }
+    }
 #pragma unroll
     for (int c = 1; c < LD_nb; ++c) {
       if (c < jb) {
@@ -240,48 +256,6 @@ __global__ void __launch_bounds__(256) ldlt_panel_rows_kernel(double* A, i64 ld,
         Wp[r + static_cast<i64>(s0 + c) * ldw] = x[c];
         A[r + static_cast<i64>(j0 + c) * ld] = x[c] / dv[c];
       }
-    }
-    for (int cc = 0; cc < ncols; ++cc) {
-      const double* lrow = Lc + cc * LD_nb;
-      double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-      for (int k = 0; k < LD_nb; k += 2) { a0 += x[k] * lrow[k]; a1 += x[k + 1] * lrow[k + 1]; }
-      A[r + (static_cast<i64>(K0) + c0 + cc) * ld] -= a0 + a1;
-    }
-  }
-}
-
-// ---- panel rows: forward substitution per row ----------------------------------------------
-__global__ void __launch_bounds__(256) ldlt_trsm_kernel(double* A, i64 ld, int j0, int jb, int n,
-                                                        double* Wp, i64 ldw, int wcol0) {
-  __shared__ double Lb[LD_nb][LD_nb + 1];
-  __shared__ double dv[LD_nb];
-  const int tid = threadIdx.x;
-  for (int e = tid; e < jb * jb; e += 256) {
-    const int r = e % jb, c = e / jb;
-    Lb[r][c] = (r > c) ? A[(j0 + r) + static_cast<i64>(j0 + c) * ld] : 0.0;
-  }
-  if (tid < jb) dv[tid] = A[(j0 + tid) + static_cast<i64>(j0 + tid) * ld];
-  __syncthreads();
-  const i64 r = static_cast<i64>(j0) + jb + static_cast<i64>(blockIdx.x) * 256 + tid;
-  if (r >= n) return;
-  double x[LD_nb];
-#pragma unroll
-  for (int c = 0; c < LD_nb; ++c) x[c] = (c < jb) ? A[r + static_cast<i64>(j0 + c) * ld] : 0.0;
-#pragma unroll
-  for (int c = 1; c < LD_nb; ++c) {
-    if (c < jb) {
-      double s = x[c];
-#pragma unroll
-      for (int t = 0; t < c; ++t) s -= x[t] * Lb[c][t];
-      x[c] = s;
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < LD_nb; ++c) {
-    if (c < jb) {
-      Wp[r + static_cast<i64>(wcol0 + c) * ldw] = x[c];
-      A[r + static_cast<i64>(j0 + c) * ld] = x[c] / dv[c];
     }
   }
 }
