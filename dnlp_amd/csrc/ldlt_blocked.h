@@ -260,6 +260,41 @@ __global__ void __launch_bounds__(256) ldlt_panel_rows_kernel(double* A, i64 ld,
   }
 }
 
+// ---- panel rows: forward substitution per row ----------------------------------------------
+__global__ void __launch_bounds__(256) ldlt_trsm_kernel(double* A, i64 ld, int j0, int jb, int n,
+                                                        double* Wp, i64 ldw, int wcol0) {
+  __shared__ double Lb[LD_nb][LD_nb + 1];
+  __shared__ double dv[LD_nb];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < jb * jb; e += 256) {
+    const int r = e % jb, c = e / jb;
+    Lb[r][c] = (r > c) ? A[(j0 + r) + static_cast<i64>(j0 + c) * ld] : 0.0;
+  }
+  if (tid < jb) dv[tid] = A[(j0 + tid) + static_cast<i64>(j0 + tid) * ld];
+  __syncthreads();
+  const i64 r = static_cast<i64>(j0) + jb + static_cast<i64>(blockIdx.x) * 256 + tid;
+  if (r >= n) return;
+  double x[LD_nb];
+#pragma unroll
+  for (int c = 0; c < LD_nb; ++c) x[c] = (c < jb) ? A[r + static_cast<i64>(j0 + c) * ld] : 0.0;
+#pragma unroll
+  for (int c = 1; c < LD_nb; ++c) {
+    if (c < jb) {
+      double s = x[c];
+#pragma unroll
+      for (int t = 0; t < c; ++t) s -= x[t] * Lb[c][t];
+      x[c] = s;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < LD_nb; ++c) {
+    if (c < jb) {
+      Wp[r + static_cast<i64>(wcol0 + c) * ldw] = x[c];
+      A[r + static_cast<i64>(j0 + c) * ld] = x[c] / dv[c];
+    }
+  }
+}
+
 // ---- C -= W L^T on FP64 MFMA ---------------------------------------------------------------
 // Interior tiles (full 128x128, strictly below the diagonal, K a multiple of 16, 16-B aligned
 // operands) take the fast body: the C tile is loaded straight into the MFMA accumulators
