@@ -14,7 +14,7 @@ import numpy as np
 from .error import DeviceUnavailableError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdnlp_hip.so")
+LIB_PATH = os.environ.get("DNLP_HIP_LIB", os.path.join(_HERE, "libdnlp_hip.so"))    # (override: kernel-variant experiments)
 
 _dbl_p = C.POINTER(C.c_double)
 _i32_p = C.POINTER(C.c_int32)

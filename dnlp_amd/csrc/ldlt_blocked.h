@@ -45,10 +45,9 @@ __device__ inline double ldlt_bcast(double v, int srclane) {
   return __hiloint2double(hi, lo);
 }
 
-// the 32 x 32 factorisation by the calling wavefront (lane = threadIdx.x & 63); counts go to the caller
-__device__ inline void ldlt_diag_wave(double* A, i64 ld, int j0, int jb, double tiny, int& nneg_out, int& nzero_out,
-                                      int& fail_out) {
-  const int lane = threadIdx.x & 63;
+__global__ void __launch_bounds__(64) ldlt_diag_kernel(double* A, i64 ld, int j0, int jb, LdltInfo* info,
+                                                       double tiny) {
+  const int lane = threadIdx.x;
   const int row = lane < jb ? lane : jb - 1;            // clamped: loads stay inside the block
   double S[LD_nb];
 #pragma unroll
@@ -78,185 +77,10 @@ __device__ inline void ldlt_diag_wave(double* A, i64 ld, int j0, int jb, double 
     for (int c = 0; c < LD_nb; ++c)
       if (c < jb && lane >= c) A[(j0 + lane) + static_cast<i64>(j0 + c) * ld] = S[c];
   }
-  nneg_out = nneg; nzero_out = nzero; fail_out = fail;
-}
-
-__global__ void __launch_bounds__(64) ldlt_diag_kernel(double* A, i64 ld, int j0, int jb, LdltInfo* info,
-                                                       double tiny) {
-  int nneg = 0, nzero = 0, fail = 0;
-  ldlt_diag_wave(A, ld, j0, jb, tiny, nneg, nzero, fail);
-  if (threadIdx.x == 0 && (nneg | nzero | fail)) {
+  if (lane == 0 && (nneg | nzero | fail)) {
     info->nneg += nneg;
     info->nzero += nzero;
     if (fail) info->fail = 1;
-  }
-}
-
-// ---- mid-size matrices: the whole panel in TWO launches ----------------------------------------------
-// For orders up to a few 1e4 the panel chain (diag -> trsm -> update per 32 columns, ~50 us of launch and
-// latency each) is the critical path of the factorisation, not the MFMA update.  Here the KB x KB diagonal
-// block of a panel (KB <= 256) is factored by ONE workgroup that keeps the current 32-column strip (W = L D
-// and L) in LDS and walks the eight 32-column steps behind workgroup barriers; the rows below the block then
-// need no serial step at all — every row is an independent forward substitution against the finished block
-// (ldlt_panel_rows_kernel: one row per lane, the strip of the block it needs in LDS) — so a panel is two
-// launches instead of ~50.
-constexpr int TB_KB = 256;           // largest diagonal block the single-workgroup kernel takes
-constexpr int TB_T = 1024;           // its workgroup size (16 wavefronts)
-__global__ void __launch_bounds__(TB_T) ldlt_topblock_kernel(double* A, i64 ld, int K0, int KB, LdltInfo* info, double tiny) {
-  extern __shared__ double tb_smem[];
-  double (*Lb)[LD_nb + 1] = reinterpret_cast<double (*)[LD_nb + 1]>(tb_smem);                     // 32 x 33
-  double* dv = tb_smem + LD_nb * (LD_nb + 1);                                                     // 32
-  double* Ws = dv + LD_nb;                                // (rows below the strip) x 33: W = L D of the strip
-  double* Ls = Ws + (TB_KB - LD_nb) * (LD_nb + 1);        // same shape: L of the strip
-  const int tid = threadIdx.x;
-  int nneg = 0, nzero = 0, fail = 0;
-  for (int s0 = 0; s0 < KB; s0 += LD_nb) {
-    const int j0 = K0 + s0, jb = min(LD_nb, KB - s0);
-    if (tid < 64) {
-      int a = 0, b = 0, c = 0;
-      ldlt_diag_wave(A, ld, j0, jb, tiny, a, b, c);
-      nneg += a; nzero += b; fail |= c;
-    }
-    __syncthreads();
-    for (int e = tid; e < jb * jb; e += TB_T) {
-      const int r = e % jb, c = e / jb;
-      Lb[r][c] = (r > c) ? A[(j0 + r) + static_cast<i64>(j0 + c) * ld] : 0.0;
-    }
-    if (tid < jb) dv[tid] = A[(j0 + tid) + static_cast<i64>(j0 + tid) * ld];
-    __syncthreads();
-    const int r0 = s0 + jb, nrows = KB - r0;           // rows of the block below the strip
-    if (nrows <= 0) break;
-    // forward substitution, one row per lane (the body of ldlt_trsm_kernel)
-    if (tid < nrows) {
-      const i64 r = static_cast<i64>(K0) + r0 + tid;
-      double x[LD_nb];
-#pragma unroll
-      for (int c = 0; c < LD_nb; ++c) x[c] = (c < jb) ? A[r + static_cast<i64>(j0 + c) * ld] : 0.0;
-#pragma unroll
-      for (int c = 1; c < LD_nb; ++c) {
-        if (c < jb) {
-          double sacc = x[c];
-#pragma unroll
-          for (int t = 0; t < c; ++t) sacc -= x[t] * Lb[c][t];
-          x[c] = sacc;
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < LD_nb; ++c) {
-        const double l = (c < jb) ? x[c] / dv[c] : 0.0;
-        Ws[tid * (LD_nb + 1) + c] = (c < jb) ? x[c] : 0.0;
-        Ls[tid * (LD_nb + 1) + c] = l;
-        if (c < jb) A[r + static_cast<i64>(j0 + c) * ld] = l;
-      }
-    }
-    __syncthreads();
-    // trailing part of the block, lower triangle: A[r, c] -= sum_k W[r, k] L[c, k]; 4 x 4 micro-tiles
-    const int nt = (nrows + 3) / 4;
-    for (int q = tid; q < nt * (nt + 1) / 2; q += TB_T) {
-      // q -> (tr, tc) with tr >= tc
-      int tr = static_cast<int>((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
-      while ((tr + 1) * (tr + 2) / 2 <= q) ++tr;
-      while (tr * (tr + 1) / 2 > q) --tr;
-      const int tc = q - tr * (tr + 1) / 2;
-      double acc[4][4];
-      const int ra = tr * 4, ca = tc * 4;
-      // the tile's 16 entries are loaded FIRST (independent loads, one memory round trip): a
-      // read-modify-write per entry would chain 16 dependent round trips behind possibly aliasing stores
-      double* tile = A + (static_cast<i64>(K0) + r0 + ra) + (static_cast<i64>(K0) + r0 + ca) * ld;
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-          acc[a][b] = (ra + a < nrows && ca + b < nrows && ra + a >= ca + b) ? -tile[a + static_cast<i64>(b) * ld] : 0.0;
-#pragma unroll 8
-      for (int k = 0; k < LD_nb; ++k) {
-        double w[4], l[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          w[a] = (ra + a < nrows) ? Ws[(ra + a) * (LD_nb + 1) + k] : 0.0;
-          l[a] = (ca + a < nrows) ? Ls[(ca + a) * (LD_nb + 1) + k] : 0.0;
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] += w[a] * l[b];
-      }
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const int rr = ra + a, cc = ca + b;
-          if (rr < nrows && cc < nrows && rr >= cc) tile[a + static_cast<i64>(b) * ld] = -acc[a][b];
-        }
-    }
-    __syncthreads();
-  }
-  if (tid == 0 && (nneg | nzero | fail)) {
-    info->nneg += nneg;
-    info->nzero += nzero;
-    if (fail) info->fail = 1;
-  }
-}
-
-// rows below a finished KB x KB diagonal block: every row independently, strip by strip, LEFT-looking:
-//   x = A[r, strip] - sum_{k < strip} W[r, k] L[strip rows, k]      (W[r, k]: the row's earlier results)
-//   forward substitution against the strip's 32 x 32 block -> W[r, strip] = x, L[r, strip] = x / d
-// so a strip costs one batch of independent loads (the row's 32 entries and its earlier W values) and one
-// batch of stores — a right-looking update would read-modify-write every remaining panel entry of the row
-// once per strip, each a dependent round trip.  The block rows L[strip rows, 0 .. strip) sit in LDS.
-// Writes L in place and W = L D into the panel workspace (the operand of the big MFMA update).
-__global__ void __launch_bounds__(256) ldlt_panel_rows_kernel(double* A, i64 ld, int K0, int KB, int n, double* Wp, i64 ldw) {
-  extern __shared__ double pr_smem[];
-  double (*Lb)[LD_nb + 1] = reinterpret_cast<double (*)[LD_nb + 1]>(pr_smem);
-  double* dv = pr_smem + LD_nb * (LD_nb + 1);
-  double* Lr = dv + LD_nb;                                 // Lr[k * 32 + c] = L[strip row c, block column k], k < strip start
-  const int tid = threadIdx.x;
-  const i64 r = static_cast<i64>(K0) + KB + static_cast<i64>(blockIdx.x) * 256 + tid;
-  const bool live = r < n;
-  for (int s0 = 0; s0 < KB; s0 += LD_nb) {
-    const int j0 = K0 + s0, jb = min(LD_nb, KB - s0);
-    __syncthreads();
-    for (int e = tid; e < jb * jb; e += 256) {
-      const int rr = e % jb, cc = e / jb;
-      Lb[rr][cc] = (rr > cc) ? A[(j0 + rr) + static_cast<i64>(j0 + cc) * ld] : 0.0;
-    }
-    if (tid < jb) dv[tid] = A[(j0 + tid) + static_cast<i64>(j0 + tid) * ld];
-    for (int e = tid; e < s0 * LD_nb; e += 256) {
-      const int c = e % LD_nb, k = e / LD_nb;              // consecutive lanes: consecutive rows of the block (coalesced)
-      Lr[k * LD_nb + c] = (c < jb) ? A[(j0 + c) + static_cast<i64>(K0 + k) * ld] : 0.0;
-    }
-    __syncthreads();
-    if (!live) continue;
-    double x[LD_nb];
-#pragma unroll
-    for (int c = 0; c < LD_nb; ++c) x[c] = (c < jb) ? A[r + static_cast<i64>(j0 + c) * ld] : 0.0;
-    for (int k0 = 0; k0 < s0; k0 += LD_nb) {
-      double w[LD_nb];
-#pragma unroll
-      for (int k = 0; k < LD_nb; ++k) w[k] = Wp[r + static_cast<i64>(k0 + k) * ldw];
-#pragma unroll
-      for (int k = 0; k < LD_nb; ++k) {
-        const double* lk = Lr + (k0 + k) * LD_nb;
-#pragma unroll
-        for (int c = 0; c < LD_nb; ++c) x[c] -= w[k] * lk[c];
-      }
-    }
-#pragma unroll
-    for (int c = 1; c < LD_nb; ++c) {
-      if (c < jb) {
-        double sacc = x[c];
-#pragma unroll
-        for (int t = 0; t < c; ++t) sacc -= x[t] * Lb[c][t];
-        x[c] = sacc;
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < LD_nb; ++c) {
-      if (c < jb) {
-        Wp[r + static_cast<i64>(s0 + c) * ldw] = x[c];
-        A[r + static_cast<i64>(j0 + c) * ld] = x[c] / dv[c];
-      }
-    }
   }
 }
 
@@ -691,8 +515,6 @@ struct BlockedLdlt {
   bool xcd_swizzle = false;    // 8 x 8 super-tiles per XCD: cuts the W-strip re-reads ~5x but measured 1.5-3% slower (MFMA-bound), so off; DNLP_LDLT_XCD=1 enables
   bool padded = false;         // the matrix allocation has >= 128 doubles of slack behind it
   int NB = 512;                // outer panel width (K of the MFMA Schur update)
-  bool two_launch_panels = false;   // orders up to ~5e4: topblock + panel-rows kernels, NB = 256 (see ldlt_topblock_kernel)
-  size_t lds_tb = 0, lds_pr = 0;
   int max_neg = -1;            // >= 0: give up as soon as more negative pivots than this appear
 
   void init(HipExec* e, i64 n_, i64 ld_) {
@@ -701,18 +523,6 @@ struct BlockedLdlt {
     if (const char* ev = std::getenv("DNLP_LDLT_NB")) NB = std::atoi(ev);
     if (const char* ev = std::getenv("DNLP_LDLT_LOOKAHEAD")) lookahead = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_XCD")) xcd_swizzle = std::atoi(ev) != 0;
-    // mid-size orders are bound by the panel chain, not by the update: two launches per panel
-    two_launch_panels = n <= 49152;
-    if (const char* ev = std::getenv("DNLP_LDLT_PANEL2")) two_launch_panels = std::atoi(ev) != 0;
-    if (two_launch_panels) {
-      if (!std::getenv("DNLP_LDLT_NB") || NB > TB_KB) NB = TB_KB;
-      lds_tb = sizeof(double) * (LD_nb * (LD_nb + 1) + LD_nb + 2 * static_cast<size_t>(TB_KB - LD_nb) * (LD_nb + 1));
-      lds_pr = sizeof(double) * (LD_nb * (LD_nb + 1) + LD_nb + static_cast<size_t>(TB_KB - LD_nb) * LD_nb);
-      DNLP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ldlt_topblock_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_tb)));
-      DNLP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ldlt_panel_rows_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_pr)));
-    }
     if (NB < LD_nb) NB = LD_nb;
     if (NB > LD_NB_MAX) NB = LD_NB_MAX;
     NB = NB / LD_nb * LD_nb;
@@ -779,13 +589,6 @@ struct BlockedLdlt {
     for (int K0 = 0; K0 < ni; K0 += NB, ++p) {
       const int KB = std::min(NB, ni - K0);
       double* Wp = Wp2[p & 1];
-      if (two_launch_panels) {
-        hipLaunchKernelGGL(ldlt_topblock_kernel, dim3(1), dim3(TB_T), lds_tb, s0, A, ld, K0, KB, info, tiny);
-        if (K0 + KB < ni)
-          hipLaunchKernelGGL(ldlt_panel_rows_kernel, dim3((ni - K0 - KB + 255) / 256), dim3(256), lds_pr, s0, A, ld, K0, KB, ni,
-                             Wp, ldw);
-        DNLP_LAUNCH_CHECK();
-      } else
       for (int j0 = K0; j0 < K0 + KB; j0 += LD_nb) {
         const int jb = std::min(LD_nb, K0 + KB - j0);
         hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(64), 0, s0, A, ld, j0, jb, info, tiny);
