@@ -179,33 +179,30 @@ class Expression:
 
     @staticmethod
     def broadcast(lh_expr, rh_expr):
-        """Binary-operator broadcasting (reference expression.py:680-715)."""
+        """Operand pair of a binary elementwise operator, brought to a common shape.  Same resulting
+        trees as the reference's rule (expression.py:680-715): a scalar next to a non-scalar is
+        promoted; two matrices are stretched along their unit dimensions by products with vectors of
+        ones (rows first, then columns); operands of different rank or rank >= 3 go through
+        broadcast_to."""
         from . import atoms as at
-        lh_expr = Expression.cast_to_const(lh_expr)
-        rh_expr = Expression.cast_to_const(rh_expr)
-        if lh_expr.is_scalar() and not rh_expr.is_scalar():
-            lh_expr = at.promote(lh_expr, rh_expr.shape)
-        elif rh_expr.is_scalar() and not lh_expr.is_scalar():
-            rh_expr = at.promote(rh_expr, lh_expr.shape)
-        elif lh_expr.is_scalar() and rh_expr.is_scalar():
-            return lh_expr, rh_expr
-        if lh_expr.ndim == 2 and rh_expr.ndim == 2:
-            dims = [max(lh_expr.shape[i], rh_expr.shape[i]) for i in range(2)]
-            if lh_expr.shape[0] == 1 and lh_expr.shape[0] < dims[0]:
-                lh_expr = np.ones((dims[0], 1)) @ lh_expr
-            if rh_expr.shape[0] == 1 and rh_expr.shape[0] < dims[0]:
-                rh_expr = np.ones((dims[0], 1)) @ rh_expr
-            if lh_expr.shape[1] == 1 and lh_expr.shape[1] < dims[1]:
-                lh_expr = lh_expr @ np.ones((1, dims[1]))
-            if rh_expr.shape[1] == 1 and rh_expr.shape[1] < dims[1]:
-                rh_expr = rh_expr @ np.ones((1, dims[1]))
-        elif lh_expr.ndim >= 3 or rh_expr.ndim >= 3 or lh_expr.ndim != rh_expr.ndim:
-            output_shape = np.broadcast_shapes(lh_expr.shape, rh_expr.shape)
-            if lh_expr.shape != output_shape:
-                lh_expr = at.broadcast_to(lh_expr, output_shape)
-            if rh_expr.shape != output_shape:
-                rh_expr = at.broadcast_to(rh_expr, output_shape)
-        return lh_expr, rh_expr
+        pair = [Expression.cast_to_const(lh_expr), Expression.cast_to_const(rh_expr)]
+        scalar = [e.is_scalar() for e in pair]
+        if all(scalar):
+            return pair[0], pair[1]
+        for k in (0, 1):
+            if scalar[k]:
+                pair[k] = at.promote(pair[k], pair[1 - k].shape)
+        if pair[0].ndim == 2 and pair[1].ndim == 2:
+            for axis in (0, 1):
+                full = max(pair[0].shape[axis], pair[1].shape[axis])
+                for k in (0, 1):
+                    if pair[k].shape[axis] == 1 and full > 1:
+                        ones = np.ones((full, 1)) if axis == 0 else np.ones((1, full))
+                        pair[k] = ones @ pair[k] if axis == 0 else pair[k] @ ones
+        elif pair[0].ndim != pair[1].ndim or max(pair[0].ndim, pair[1].ndim) >= 3:
+            target = np.broadcast_shapes(pair[0].shape, pair[1].shape)
+            pair = [e if e.shape == target else at.broadcast_to(e, target) for e in pair]
+        return pair[0], pair[1]
 
     def __getitem__(self, key):
         from . import atoms as at
