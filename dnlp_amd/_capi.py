@@ -56,6 +56,7 @@ class CApi:
         f("eval_h", C.c_int, [C.c_void_p, _dbl_p, C.c_int, C.c_double, _dbl_p, C.c_int, _i32_p,
                               _i32_p, _dbl_p])
         f("set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p])
+        f("reset_options", C.c_int, [C.c_void_p])
         f("solve", C.c_int, [C.c_void_p] + [_dbl_p] * 6 + [C.POINTER(C.c_int)])
         f("solve_reduced", C.c_int, [C.c_void_p, _dbl_p, _dbl_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _dbl_p])
         f("ipm_begin", C.c_int, [C.c_void_p, _dbl_p])
@@ -297,6 +298,9 @@ class ProblemHandle:
         return {"sparse": bool(out[0]), "factor_values": int(out[1]), "pivot_blocks": int(out[2]),
                 "max_struct": int(out[3]), "pairs_2x2": int(out[4]), "update_triples": int(out[5]),
                 "levels": int(out[6])}
+
+    def reset_options(self):
+        self.api.reset_options(self.ptr)
 
     def set_option(self, key, val):
         if isinstance(val, bool):

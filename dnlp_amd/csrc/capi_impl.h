@@ -127,6 +127,21 @@ struct ProblemT {
     ipm->intermediate_cb = intermediate_cb; ipm->intermediate_user = intermediate_user;
   }
 
+  // back to the defaults of a fresh handle (a cached handle is reused by the next solve of the same
+  // problem: options of the previous call must not leak into it).  The linear-solver choice stays: it
+  // is fixed once the KKT object exists.
+  void reset_options() {
+    opt = IpmOptions();
+    pivot_max_n = 2048;
+    optimistic_min_n = static_cast<i64>(1) << 40;
+    use_fused = true;
+    lbfgs_device_loop = true;
+    lbfgs_history = 10;
+    time_kernels = false;
+    exact_hessian_substituted = false;
+    set_fused_codegen(true);
+  }
+
   int set_option(const std::string& k, const std::string& v) {
     auto num = [&]() { return std::strtod(v.c_str(), nullptr); };
     auto yes = [&]() { return v == "yes" || v == "1" || v == "true" || v == "True"; };
@@ -282,6 +297,10 @@ struct ProblemT {
     int rc = p->set_option(k, v);                                                                    \
     if (rc) dnlp::tls_error() = std::string("invalid option ") + k + "=" + v;                        \
     return rc;                                                                                       \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, reset_options)(HANDLE* vp) {                                                     \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    p->reset_options(); return 0;                                                                    \
   }                                                                                                  \
   int DNLP_CAT(PFX, set_intermediate_cb)(HANDLE* vp, dnlp::IntermediateCb cb, void* user) {          \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \

@@ -46,42 +46,40 @@ class Bounds:
         lower, upper, new_constr = [], [], []
         for constraint in self.problem.constraints:
             if isinstance(constraint, Equality):
-                lower.extend([0.0] * constraint.size)
-                upper.extend([0.0] * constraint.size)
+                upper.append(np.zeros(constraint.size))
                 new_constr.append(lower_equality(constraint))
             elif isinstance(constraint, Inequality):
-                lower.extend([0.0] * constraint.size)
-                upper.extend([np.inf] * constraint.size)
+                upper.append(np.full(constraint.size, np.inf))
                 new_constr.append(lower_ineq_to_nonneg(constraint))
             elif isinstance(constraint, NonPos):
-                lower.extend([0.0] * constraint.size)
-                upper.extend([np.inf] * constraint.size)
+                upper.append(np.full(constraint.size, np.inf))
                 new_constr.append(nonpos2nonneg(constraint))
             else:
                 raise ValueError("Constraint type %s is not supported on the NLP path."
                                  % type(constraint).__name__)
+            lower.append(np.zeros(constraint.size))
         self.new_problem = self.problem.copy([self.problem.objective, new_constr])
-        self.cl = np.array(lower, dtype=float)
-        self.cu = np.array(upper, dtype=float)
+        self.cl = np.concatenate(lower) if lower else np.zeros(0)
+        self.cu = np.concatenate(upper) if upper else np.zeros(0)
 
     def get_variable_bounds(self):
-        var_lower, var_upper = [], []
+        lows, ups = [], []
         for var in self.main_var:
             size = var.size
             if var.bounds:
-                lb = var.bounds[0].flatten(order="F")
-                ub = var.bounds[1].flatten(order="F")
+                lb = np.asarray(var.bounds[0], dtype=float).flatten(order="F")
+                ub = np.asarray(var.bounds[1], dtype=float).flatten(order="F")
                 if var.attributes["nonneg"]:
                     lb = np.maximum(lb, 0)
                 if var.attributes["nonpos"]:
                     ub = np.minimum(ub, 0)
-                var_lower.extend(lb)
-                var_upper.extend(ub)
             else:
-                var_lower.extend([0.0] * size if var.is_nonneg() else [-np.inf] * size)
-                var_upper.extend([0.0] * size if var.is_nonpos() else [np.inf] * size)
-        self.lb = np.array(var_lower, dtype=float)
-        self.ub = np.array(var_upper, dtype=float)
+                lb = np.zeros(size) if var.is_nonneg() else np.full(size, -np.inf)
+                ub = np.zeros(size) if var.is_nonpos() else np.full(size, np.inf)
+            lows.append(lb)
+            ups.append(ub)
+        self.lb = np.concatenate(lows) if lows else np.zeros(0)
+        self.ub = np.concatenate(ups) if ups else np.zeros(0)
 
     def construct_initial_point(self):
         initial_values = []
@@ -245,6 +243,29 @@ class HIPNLP:
                   "hessian", "hessianstructure"):
             data[k] = getattr(oracles, k)
         return data, inverse_data
+
+    def reapply(self, problem, cached):
+        """Second and later solves of an unchanged problem: the lowered tape AND the device handle
+        (uploaded tape, sparse plan, generated kernels) of the first solve are reused; only the start
+        point is rebuilt from the variables' current values.  Returns None when anything that shapes the
+        tape differs (then the caller lowers again)."""
+        bounds = Bounds(problem)
+        old = cached["data"]
+        handle = old.get("handle")
+        if handle is None or handle.ptr is None:
+            return None
+        same = (bounds.x0.size == old["x0"].size and np.array_equal(bounds.lb, old["lb"]) and
+                np.array_equal(bounds.ub, old["ub"]) and np.array_equal(bounds.cl, old["cl"]) and
+                np.array_equal(bounds.cu, old["cu"]) and
+                [v.size for v in bounds.main_var] == [v.size for v in old["problem"].variables()])
+        if not same:
+            return None
+        data = dict(old)
+        data["problem"] = bounds.new_problem
+        data["x0"] = bounds.x0
+        data.pop("warm_duals", None)
+        handle.reset_options()
+        return data, InverseData(bounds.new_problem)
 
     def solve_via_data(self, data, warm_start: bool, verbose: bool, solver_opts,
                        solver_cache=None):

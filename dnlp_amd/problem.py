@@ -309,19 +309,42 @@ class NLPChain:
         self.flip = flip
         self.solver = solver
 
+    @staticmethod
+    def _signature(problem):
+        """What the lowered tape depends on besides variable VALUES: the expression objects and the
+        parameter values.  (Constants are taken as immutable, as the reference's own caches do.)"""
+        params = tuple((id(p), None if p.value is None else np.asarray(p.value, dtype=float).tobytes())
+                       for p in problem.parameters())
+        return (id(problem.objective.expr), tuple(id(c) for c in problem._constraints), params)
+
     def apply(self, problem, make_handle=True):
         from .dnlp2smooth import Dnlp2Smooth
+        original = problem
         if self.flip:
             problem = Problem(Minimize(-problem.objective.expr), problem.constraints)
         smooth, _ = Dnlp2Smooth().apply(problem)
-        if make_handle:
-            from .fused import build_fused_spec
-            try:
-                return self.solver.apply(smooth, user_variables=problem.variables(),
-                                         fused_spec=build_fused_spec(problem))
-            except TypeError:      # a solver interface without the fused-objective hook
-                return self.solver.apply(smooth, user_variables=problem.variables())
-        return self.solver.apply(smooth, user_variables=problem.variables(), make_handle=False)
+        if not make_handle:
+            return self.solver.apply(smooth, user_variables=problem.variables(), make_handle=False)
+        # Lowering, tape upload, sparse plan and generated kernels depend on the problem's structure and
+        # constants only: a second solve of the same Problem object (another start, other options, a
+        # warm start) reuses them and rebuilds just the start point.  The reference re-runs its whole
+        # chain on every solve (problem.py:1243-1246, :1256-1269).
+        sig = self._signature(original)
+        cached = getattr(original, "_nlp_cache", None)
+        reapply = getattr(self.solver, "reapply", None)
+        if cached is not None and cached["sig"] == sig and cached["solver"] is type(self.solver) and reapply is not None:
+            hit = reapply(smooth, cached)
+            if hit is not None:
+                return hit
+        from .fused import build_fused_spec
+        try:
+            out = self.solver.apply(smooth, user_variables=problem.variables(), fused_spec=build_fused_spec(problem))
+        except TypeError:      # a solver interface without the fused-objective hook
+            out = self.solver.apply(smooth, user_variables=problem.variables())
+        if cached is not None and cached["data"].get("handle") is not None:
+            cached["data"]["handle"].close()
+        original._nlp_cache = {"sig": sig, "solver": type(self.solver), "data": out[0]}
+        return out
 
     def invert(self, solution, inverse_data):
         sol = self.solver.invert(solution, inverse_data)

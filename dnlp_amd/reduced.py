@@ -48,26 +48,33 @@ def reduction_arrays(new_problem, tape, user_var_ids):
             return None
         def_var[row:row + size] = offsets[id(lhs)] + np.arange(size)
         row += size
-    if np.any(def_var < 0) or np.unique(def_var).size != m:
-        return None
-    free = np.setdiff1d(np.arange(N), def_var)
-    user_idx = np.concatenate([offsets[id(v)] + np.arange(v.size) for v in variables
-                               if id(v) in user_var_ids]) if user_var_ids else np.zeros(0, int)
-    if not np.array_equal(np.sort(user_idx), free):
-        return None
-    # the defining row of t must carry coefficient +1 on t and no other defined variable of the
-    # same row block; nesting depth from the dependency pattern of the Jacobian
-    J = sp.csr_matrix((np.ones(tape.nnzJ), (tape.jac_rows, tape.jac_cols)), shape=(m, N))
-    Gx = sp.csr_matrix(tape.G[:, :N])
-    diag = np.asarray(Gx[np.arange(m), def_var]).reshape(-1)
-    if not np.allclose(diag, 1.0):
+    if np.any(def_var < 0):
         return None
     is_def = np.zeros(N, bool)
     is_def[def_var] = True
+    if int(is_def.sum()) != m:                     # two rows define the same variable
+        return None
+    free = np.nonzero(~is_def)[0]
+    is_user = np.zeros(N, bool)
+    for v in variables:
+        if id(v) in user_var_ids:
+            is_user[offsets[id(v)]:offsets[id(v)] + v.size] = True
+    if not np.array_equal(is_user, ~is_def):
+        return None
+    # the defining row of t must carry coefficient +1 on t; nesting depth from the dependency pattern
+    # of the Jacobian
+    G = tape.G.tocsr()
+    rows_of = np.repeat(np.arange(m), np.diff(G.indptr))
+    on_def = G.indices == def_var[rows_of]
+    diag = np.zeros(m)
+    diag[rows_of[on_def]] = G.data[on_def]
+    if not np.allclose(diag, 1.0):
+        return None
     level = np.zeros(N, dtype=np.int64)
-    Jc = J.tocoo()
-    keep = Jc.col != def_var[Jc.row]
-    dep_rows, dep_cols = def_var[Jc.row[keep]], Jc.col[keep]
+    jr = np.asarray(tape.jac_rows, dtype=np.int64)
+    jc = np.asarray(tape.jac_cols, dtype=np.int64)
+    keep = jc != def_var[jr]
+    dep_rows, dep_cols = def_var[jr[keep]], jc[keep]
     depth = 0
     for _ in range(256):
         new = np.zeros(N, dtype=np.int64)

@@ -68,6 +68,9 @@ int dnlp_eval_h(dnlp_problem* p, const double* x, int new_x, double sigma, const
 /* ---- solver level ------------------------------------------------------------------------ */
 /* nlp.add_option(name, value) (ipopt_nlpif.py:161-168); numeric values are passed as text. */
 int dnlp_set_option(dnlp_problem* p, const char* key, const char* val);
+/* Every option back to its default (a handle kept for the next solve of the same problem starts from
+ * the defaults the reference sets on a fresh cyipopt.Problem, ipopt_nlpif.py:153-160). */
+int dnlp_reset_options(dnlp_problem* p);
 /* nlp.solve(x0) (ipopt_nlpif.py:170).  x_inout: start point in, solution out.  Any output
  * pointer may be NULL.  Returns the IPOPT ApplicationReturnStatus integer. */
 int dnlp_solve(dnlp_problem* p, double* x_inout, double* obj, double* g, double* mult_g,

@@ -332,3 +332,33 @@ def test_best_of_never_ranks_a_failed_run(monkeypatch):
     allobjs = prob.solver_stats.extra_stats["all_objs_from_best_of"]
     assert np.isinf(allobjs[1]) and np.allclose(allobjs[[0, 2]], [0.5, 0.125])
     assert abs(prob.value - 0.125) < 1e-12
+
+
+def test_second_solve_reuses_the_lowered_tape_and_handle():
+    """A Problem solved again (other start, other options) keeps its tape and solver handle: only the
+    start point is rebuilt; options of the previous solve do not leak; a changed Parameter lowers again."""
+    import dnlp_amd as cp
+    from oracle_frontend import oracle_engine
+    from problem_zoo import hs071
+    with oracle_engine():
+        p = hs071(cp)
+        x = p.variables()[0]
+        p.solve(nlp=True, max_iter=2)
+        assert p.status == cp.USER_LIMIT
+        h1 = p._nlp_cache["data"]["handle"]
+        x.value = np.array([1.0, 5.0, 5.0, 1.0])
+        p.solve(nlp=True)                                   # max_iter = 2 must not survive
+        assert p.status == cp.OPTIMAL
+        assert p._nlp_cache["data"]["handle"] is h1
+        assert np.allclose(x.value, [0.75450865, 4.63936861, 3.78856881, 1.88513184])
+        # a parameter value is part of the signature
+        a = cp.Parameter(value=1.0)
+        y = cp.Variable(2)
+        q = cp.Problem(cp.Minimize(cp.sum_squares(y - a)), [cp.sum(y) == 1])
+        q.solve(nlp=True)
+        h2 = q._nlp_cache["data"]["handle"]
+        assert np.allclose(y.value, [0.5, 0.5], atol=1e-6)
+        a.value = 3.0
+        q.solve(nlp=True)
+        assert q._nlp_cache["data"]["handle"] is not h2
+        assert np.allclose(y.value, [0.5, 0.5], atol=1e-6) and abs(q.value - 2 * 2.5 ** 2) < 1e-6
