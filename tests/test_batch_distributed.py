@@ -50,3 +50,31 @@ def test_world_size_2_gloo_matches_serial(tmp_path):
     assert got.shape == ref.shape
     np.testing.assert_array_equal(got[:, 0], np.arange(n_items))
     np.testing.assert_allclose(got[:, 1:], ref[:, 1:], rtol=1e-12, atol=1e-12, equal_nan=True)
+
+
+def test_world_size_2_gloo_parametric_batch_shards(tmp_path):
+    """The product's own sharding + gather (ParametricBatch.solve_sharded) across two ranks: every
+    instance of the gathered result must be the instance's own solution (noise-free localization:
+    objective 0 at the true position, test_nlp_solvers.py:175-189), ordered by instance id."""
+    n_items = 7                       # odd: the last rank's shard is shorter than the others'
+    out = str(tmp_path / "rows_pb.npy")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29573", WORLD_SIZE="2", PYTHONWARNINGS="ignore")
+    procs = []
+    for rank in range(2):
+        e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), out,
+                                       str(n_items), "parametric"], env=e))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = np.load(out)
+    assert got.shape[0] == n_items
+    np.testing.assert_array_equal(got[:, 0], np.arange(n_items))
+    assert np.all(got[:, 2] == 0) and np.all(np.abs(got[:, 1]) < 1e-9)
+    import batch_problems as bp
+    prob, params, sample, xvar = bp.template_localization()
+    from dnlp_amd.batch import ParametricBatch
+    pb = ParametricBatch(prob, params)
+    off = pb.inv.var_offsets[xvar.id]
+    for i in range(n_items):
+        x_true = np.random.default_rng(i).uniform(-3, 3, 2)
+        assert np.allclose(got[i, 4 + off:4 + off + 2], x_true, atol=1e-5)

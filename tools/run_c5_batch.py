@@ -88,7 +88,10 @@ for which in args.which.split(","):
         if rank != 0:
             continue
         assert allrows.shape[0] == args.batch and np.array_equal(allrows[:, 0], np.arange(args.batch))
+        # evidence for the scaling run: did the collective see every rank, over which backend, how many bytes
         print(json.dumps({"problem": which, "n_gpus": world, "batch_total": args.batch,
+                          "collective_backend": ("%s (RCCL)" % dist.get_backend()) if dist.get_backend() == "nccl" else dist.get_backend(),
+                          "collective_ranks": dist.get_world_size(),
                           "problems_per_sec_wall_all_ranks": args.batch / float(tw[0]),
                           "problems_per_sec_kernel_all_ranks": args.batch / float(tw[1]),
                           "gather_sec": t_gather, "gather_bytes": int(allrows.size * 8),
