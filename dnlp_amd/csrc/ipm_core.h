@@ -372,6 +372,7 @@ class Ipm {
     dc_fixed_count_ = 0; dc_fixed_last_ = false; always_dc_ = false;
     lan_warm_ = false; lan_width_ = 0.0;
     resto_stationary_ = false; resto_theta_ = 0.0;
+    tiny_streak_ = 0;
     e_cached_valid_ = false;
     fixed_mode = false;
     n_hist = 0;
@@ -1154,6 +1155,13 @@ class Ipm {
     accept_trial(alpha_used, a_z, f_t);
     ++iter;
     stats.iterations = iter;
+    // Stall guard (deviation, feeds the retry ladder): forty consecutive accepted steps that each keep
+    // less than 1e-3 of the Newton step (the fraction-to-boundary rule pinning the iterate against its
+    // bounds while the direction is huge) make no progress that max_iter could wait for — observed on one
+    // of 8192 circle-packing instances in free-mu mode: alpha_pr = 1e-4, ||d|| ~ 500 for 3000 iterations,
+    // while the monotone rung solves the same instance in 23.  Reported as IPOPT's tiny-step status.
+    tiny_streak_ = alpha_used <= 1e-3 ? tiny_streak_ + 1 : 0;
+    if (tiny_streak_ >= 40) return status = Search_Direction_Becomes_Too_Small;
     Err e = error(0.0);
     e_cached_ = e;
     e_cached_valid_ = true;
@@ -1721,6 +1729,7 @@ class Ipm {
   bool e_cached_valid_ = false;
   int last_nneg_ = 0;               // negative pivots reported by the last factorisation attempt
   int ladder_rung_ = 0;             // 0: first run; 1, 2: rungs of the retry ladder
+  int tiny_streak_ = 0;             // consecutive accepted steps with alpha_pr <= 1e-3 (stall guard)
   bool resto_stationary_ = false;   // the last restoration ended where no step reduces the violation
   double resto_theta_ = 0.0;        // violation where the last restoration ended
   int dc_fixed_count_ = 0;          // iterations whose wrong inertia the dual regularisation alone repaired

@@ -88,3 +88,32 @@ def test_lazy_dense_fallback_keeps_the_sparse_factorisation_in_the_first_run():
     assert "Bunch-Kaufman from here on" in eager.log()
     first_run = lazy.log().split("restarting in monotone mode")[0]
     assert "Bunch-Kaufman from here on" not in first_run
+
+
+def test_stall_guard_hands_a_crawling_run_to_the_monotone_rung():
+    """One of 8192 circle-packing instances (start placed on the right variables) crawls in
+    free-mu mode: alpha_pr = 1e-4 with ||d|| ~ 500 until max_iter (3000 iterations: the tail of the whole
+    batch launch).  Forty consecutive accepted steps below 1e-3 of the Newton step now end the run with the
+    tiny-step status, which the retry ladder answers with the monotone rung (23 iterations)."""
+    import batch_problems as bp
+    from dnlp_amd.batch import ParametricBatch, arrays_with_data
+    from dnlp_amd.nlp_solver import HIPNLP
+    from dnlp_amd.tape import serialize
+    from oracle.oracle_capi import OracleProblem
+    prob, params, sample, _ = bp.template_circle_packing()
+    pb = ParametricBatch(prob, params)
+    a = arrays_with_data(pb.arrays0, pb.data(np.stack([sample(6272)]))[0])
+    opts = dict(HIPNLP.DEFAULT_OPTIONS)
+    opts["lazy_dense_fallback"] = "yes"            # the batch path's setting
+    o = OracleProblem(serialize(a))
+    for k, v in opts.items():
+        o.set_option(k, v)
+    r = o.solve(a["x0"])
+    assert r["status"] == 0 and r["iterations"] < 150
+    # without the ladder the guard's verdict is visible: IPOPT's tiny-step status, long before max_iter
+    o2 = OracleProblem(serialize(a))
+    opts["adaptive_fallback"] = "no"
+    for k, v in opts.items():
+        o2.set_option(k, v)
+    r2 = o2.solve(a["x0"])
+    assert r2["status"] == 3 and r2["iterations"] < 150
