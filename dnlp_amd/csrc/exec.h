@@ -40,6 +40,8 @@ using i32 = int32_t;
 
 constexpr double kInf = std::numeric_limits<double>::infinity();
 struct D2 { double first, second; };     // pair of reduction results (E::min2)
+// several reductions in ONE pass (E::reduce_multi<NM, NS>): NM maxima (NaN -> +inf, as E::max) and NS sums
+struct RMulti { double mx[4]; double sm[4]; };
 
 }  // namespace dnlp
 

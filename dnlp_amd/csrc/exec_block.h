@@ -526,6 +526,39 @@ struct BlockExecT {
   template <class F> __device__ double sum(i64 n, F f) { return reduce<0>(n, f); }
   template <class F> __device__ double max(i64 n, F f) { return reduce<1>(n, f); }
   template <class F> __device__ double min(i64 n, F f) { return reduce<2>(n, f); }
+  // NM maxima and NS sums in one pass over the data
+  template <int NM, int NS, class F> __device__ RMulti reduce_multi(i64 n, F f) {
+    RMulti r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { r.mx[k] = -kInf; r.sm[k] = 0.0; }
+    for (i64 i = threadIdx.x; i < n; i += kBatchThreads) {
+      const RMulti v = f(i);
+#pragma unroll
+      for (int k = 0; k < NM; ++k) r.mx[k] = fmax(r.mx[k], v.mx[k] != v.mx[k] ? kInf : v.mx[k]);
+#pragma unroll
+      for (int k = 0; k < NS; ++k) r.sm[k] += v.sm[k];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int k = 0; k < NM; ++k) r.mx[k] = fmax(r.mx[k], __shfl_xor(r.mx[k], o, 64));
+#pragma unroll
+      for (int k = 0; k < NS; ++k) r.sm[k] += __shfl_xor(r.sm[k], o, 64);
+    }
+    if constexpr (NT == 64) return r;
+    // several wavefronts: one value at a time through the two-slot staging buffer of reduce()
+#pragma unroll
+    for (int k = 0; k < NM + NS; ++k) {
+      double* buf = red + 4 * parity;
+      parity ^= 1;
+      const double mine = k < NM ? r.mx[k] : r.sm[k - NM];
+      if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = mine;
+      __syncthreads();
+      double t = buf[0];
+      for (int w = 1; w < kBatchThreads / 64; ++w) t = k < NM ? fmax(t, buf[w]) : t + buf[w];
+      if (k < NM) r.mx[k] = t; else r.sm[k - NM] = t;
+    }
+    return r;
+  }
   // two minima in one pass (NaN -> -inf, as min)
   template <class F> __device__ D2 min2(i64 n, F f) {
     double a0 = -kInf, a1 = -kInf;                   // min via max of the negatives

@@ -83,6 +83,36 @@ __global__ void __launch_bounds__(kBlock) reduce_kernel(i64 n, F f, double* part
   }
 }
 
+// NM maxima and NS sums in one pass; partial[(NM + NS) b + k]
+template <int NM, int NS, class F>
+__global__ void __launch_bounds__(kBlock) reduce_multi_kernel(i64 n, F f, double* partial) {
+  __shared__ double sm[(NM + NS) * (kBlock / 64)];
+  double am[NM > 0 ? NM : 1], as[NS > 0 ? NS : 1];
+#pragma unroll
+  for (int k = 0; k < NM; ++k) am[k] = -kInf;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) as[k] = 0.0;
+  for (i64 i = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += static_cast<i64>(gridDim.x) * kBlock) {
+    const RMulti v = f(i);
+#pragma unroll
+    for (int k = 0; k < NM; ++k) am[k] = fmax(am[k], v.mx[k] != v.mx[k] ? kInf : v.mx[k]);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) as[k] += v.sm[k];
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NM; ++k) { const double w = wave_max(am[k]); if (lane == 0) sm[wid * (NM + NS) + k] = w; }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) { const double w = wave_sum(as[k]); if (lane == 0) sm[wid * (NM + NS) + NM + k] = w; }
+  __syncthreads();
+  if (threadIdx.x < NM + NS) {
+    const int k = threadIdx.x;
+    double r = sm[k];
+    for (int w = 1; w < kBlock / 64; ++w) r = k < NM ? fmax(r, sm[w * (NM + NS) + k]) : r + sm[w * (NM + NS) + k];
+    partial[(NM + NS) * blockIdx.x + k] = r;
+  }
+}
+
 // two minima in one pass (NaN -> -inf, as mode 2 above); partial[2 b], partial[2 b + 1]
 template <class F>
 __global__ void __launch_bounds__(kBlock) reduce_min2_kernel(i64 n, F f, double* partial) {
@@ -891,6 +921,24 @@ struct HipExec : HostControlled {
   template <class F> double sum(i64 n, F f) { return reduce<0>(n, f); }
   template <class F> double max(i64 n, F f) { return reduce<1>(n, f); }
   template <class F> double min(i64 n, F f) { return reduce<2>(n, f); }
+  // NM maxima and NS sums with ONE launch and ONE read-back (every separate reduction costs a launch and a
+  // stream synchronisation: the optimality error of an iteration was nine of them)
+  template <int NM, int NS, class F> RMulti reduce_multi(i64 n, F f) {
+    RMulti r;
+    for (int k = 0; k < 4; ++k) { r.mx[k] = -kInf; r.sm[k] = 0.0; }
+    if (n <= 0) return r;
+    i64 grid = (n + kBlock - 1) / kBlock;
+    if (grid > kMaxPartials * 4 / (NM + NS)) grid = kMaxPartials * 4 / (NM + NS);
+    hipLaunchKernelGGL((reduce_multi_kernel<NM, NS, F>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, n, f, d_partial);
+    DNLP_LAUNCH_CHECK();
+    DNLP_HIP_CHECK(hipMemcpyAsync(h_partial, d_partial, sizeof(double) * (NM + NS) * grid, hipMemcpyDeviceToHost, stream));
+    DNLP_HIP_CHECK(hipStreamSynchronize(stream));
+    for (i64 b = 0; b < grid; ++b) {
+      for (int k = 0; k < NM; ++k) r.mx[k] = std::fmax(r.mx[k], h_partial[(NM + NS) * b + k]);
+      for (int k = 0; k < NS; ++k) r.sm[k] += h_partial[(NM + NS) * b + NM + k];
+    }
+    return r;
+  }
   template <class F> D2 min2(i64 n, F f) {
     if (n <= 0) return D2{kInf, kInf};
     i64 grid = (n + kBlock - 1) / kBlock;

@@ -193,14 +193,15 @@ class Ipm {
 
   // ---- evaluation helpers (scaled problem) --------------------------------------
   // f~(xp), g~(xp) -> returns false on non-finite values
-  DNLP_HD bool eval_fg(const double* xp, double& fval, double* gout) {
+  DNLP_HD bool eval_fg(const double* xp, double& fval, double* gout, bool check = true) {
     double t0 = now_sec();
     md_->sweep(xp, false);
     fval = sf * md_->eval_f_after_sweep();
     md_->eval_g_after_sweep(gout);
     const double* sgp = sg;
     ex_->map(m, [=] DNLP_HD(i64 i) { gout[i] *= sgp[i]; });
-    double chk = ex_->sum(m, [=] DNLP_HD(i64 i) { return gout[i] - gout[i]; });   // NaN/inf detector
+    // NaN/inf detector (check = false: the caller folds it into its own pass, see measures())
+    double chk = check ? ex_->sum(m, [=] DNLP_HD(i64 i) { return gout[i] - gout[i]; }) : 0.0;
     stats.t_eval += now_sec() - t0;
     return std::isfinite(fval) && chk == 0.0;
   }
@@ -303,6 +304,7 @@ class Ipm {
       const i64 n_eq = m ? static_cast<i64>(ex_->sum(m, [=] DNLP_HD(i64 i) { return eq[i]; })) : 0;
       const i64 n_free = static_cast<i64>(ex_->sum(N, [=] DNLP_HD(i64 j) { return l[j] == u[j] ? 0.0 : 1.0; }));
       if (n_eq > n_free) return status = Not_Enough_Degrees_Of_Freedom;
+      n_eq_ = n_eq;
       kkt_->n_fixed = N - n_free;
     }
     // start point pushed into the bounds; fixed variables (lb == ub) sit on their value, keep no
@@ -503,6 +505,42 @@ class Ipm {
     return fv + muv * (bx + bs);
   }
 
+  // theta, the barrier terms and the NaN / inf detector of g in ONE pass over [variables | constraint rows]
+  // (theta_at + barrier_at + the check of eval_fg are four reductions)
+  struct Measures { double theta, phi, chk; };
+  DNLP_HD Measures measures(double fv, const double* gg, const double* xx, const double* ss, double muv) {
+    const double *l = xL, *u = xU, *sl = sL, *su = sU, *eq = eqmask;
+    const double kd = opt.kappa_d;
+    const i64 NN = N;
+    const RMulti R = ex_->template reduce_multi<0, 3>(N + m, [=] DNLP_HD(i64 k) -> RMulti {
+      RMulti v;
+      v.mx[0] = v.mx[1] = v.mx[2] = v.mx[3] = 0.0;
+      v.sm[0] = v.sm[1] = v.sm[2] = v.sm[3] = 0.0;
+      double bt = 0.0;
+      if (k < NN) {
+        const i64 j = k;
+        const bool hl = l[j] > -kInf, hu = u[j] < kInf;
+        if (hl) bt -= log(xx[j] - l[j]);
+        if (hu) bt -= log(u[j] - xx[j]);
+        if (hl && !hu) bt += kd * (xx[j] - l[j]);
+        if (hu && !hl) bt += kd * (u[j] - xx[j]);
+      } else {
+        const i64 i = k - NN;
+        v.sm[0] = fabs(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]);
+        v.sm[2] = gg[i] - gg[i];
+        if (eq[i] == 0.0) {
+          const bool hl = sl[i] > -kInf, hu = su[i] < kInf;
+          if (hl) bt -= log(ss[i] - sl[i]);
+          if (hu) bt -= log(su[i] - ss[i]);
+          if (hl && !hu) bt += kd * (ss[i] - sl[i]);
+          if (hu && !hl) bt += kd * (su[i] - ss[i]);
+        }
+      }
+      v.sm[1] = bt;
+      return v; });
+    return Measures{R.sm[0], fv + muv * R.sm[1], R.sm[2]};
+  }
+
   // dual residuals rx = grad + J^T y - zL + zU ; rs = -y - vL + vU (inequality rows)
   DNLP_HD void dual_residuals() {
     md_->jac_tmult(jv, y, tN);
@@ -512,34 +550,51 @@ class Ipm {
     ex_->map(m, [=] DNLP_HD(i64 i) { q[i] = (eq[i] == 0.0) ? -yy[i] - c[i] + d[i] : 0.0; });
   }
 
-  struct Err { double dual, primal, cmpl, sd, sc, total; };
+  struct Err { double dual, primal, cmpl, sd, sc, total, primal_unscaled; };
 
   // WB eq. (5): scaled optimality error for barrier parameter muv
   DNLP_HD Err error(double muv) {
     dual_residuals();
     const double *r = rx, *q = rs, *gg = g, *ss = s, *eq = eqmask, *sl = sL, *su = sU, *l = xL, *u = xU,
-                 *xx = x, *a = zL, *b = zU, *c = vL, *d = vU, *yy = y;
+                 *xx = x, *a = zL, *b = zU, *c = vL, *d = vU, *yy = y, *sgp = sg;
+    // every norm of WB eq. (5) in ONE pass over [variables | constraint rows]: maxima = dual residual,
+    // primal residual, complementarity, unscaled primal residual (the convergence test's); sums = |y| + |v|
+    // and |z|.  (Nine separate reductions before: nine launches and read-backs on the host-driven space.)
+    const i64 NN = N;
+    const RMulti R = ex_->template reduce_multi<4, 2>(N + m, [=] DNLP_HD(i64 k) -> RMulti {
+      RMulti v;
+      v.mx[0] = v.mx[1] = v.mx[2] = v.mx[3] = 0.0;
+      v.sm[0] = v.sm[1] = v.sm[2] = v.sm[3] = 0.0;
+      if (k < NN) {
+        const i64 j = k;
+        v.mx[0] = fabs(r[j]);
+        double cv = 0.0;
+        if (l[j] > -kInf) cv = fmax(cv, fabs((xx[j] - l[j]) * a[j] - muv));
+        if (u[j] < kInf) cv = fmax(cv, fabs((u[j] - xx[j]) * b[j] - muv));
+        v.mx[2] = cv;
+        v.sm[1] = fabs(a[j]) + fabs(b[j]);
+      } else {
+        const i64 i = k - NN;
+        v.mx[0] = fabs(q[i]);
+        const double pr = fabs(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]);
+        v.mx[1] = pr;
+        v.mx[3] = pr / sgp[i];
+        double cv = 0.0;
+        if (eq[i] == 0.0) {
+          if (sl[i] > -kInf) cv = fmax(cv, fabs((ss[i] - sl[i]) * c[i] - muv));
+          if (su[i] < kInf) cv = fmax(cv, fabs((su[i] - ss[i]) * d[i] - muv));
+        }
+        v.mx[2] = cv;
+        v.sm[0] = fabs(yy[i]) + fabs(c[i]) + fabs(d[i]);
+      }
+      return v; });
     Err e;
-    e.dual = std::max(ex_->max(N, [=] DNLP_HD(i64 j) { return fabs(r[j]); }),
-                      m ? ex_->max(m, [=] DNLP_HD(i64 i) { return fabs(q[i]); }) : 0.0);
-    e.primal = m ? ex_->max(m, [=] DNLP_HD(i64 i) { return fabs(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]); }) : 0.0;
-    double cx = ex_->max(N, [=] DNLP_HD(i64 j) {
-      double v = 0.0;
-      if (l[j] > -kInf) v = fmax(v, fabs((xx[j] - l[j]) * a[j] - muv));
-      if (u[j] < kInf) v = fmax(v, fabs((u[j] - xx[j]) * b[j] - muv));
-      return v;
-    });
-    double cs = m ? ex_->max(m, [=] DNLP_HD(i64 i) {
-      double v = 0.0;
-      if (eq[i] != 0.0) return v;
-      if (sl[i] > -kInf) v = fmax(v, fabs((ss[i] - sl[i]) * c[i] - muv));
-      if (su[i] < kInf) v = fmax(v, fabs((su[i] - ss[i]) * d[i] - muv));
-      return v;
-    }) : 0.0;
-    e.cmpl = std::max(std::max(cx, cs), 0.0);
+    e.dual = std::max(R.mx[0], 0.0);
+    e.primal = m ? std::max(R.mx[1], 0.0) : 0.0;
+    e.cmpl = std::max(R.mx[2], 0.0);
+    e.primal_unscaled = m ? std::max(R.mx[3], 0.0) : 0.0;
     const double smax = 100.0;
-    double sy = m ? ex_->sum(m, [=] DNLP_HD(i64 i) { return fabs(yy[i]) + fabs(c[i]) + fabs(d[i]); }) : 0.0;
-    double sz = ex_->sum(N, [=] DNLP_HD(i64 j) { return fabs(a[j]) + fabs(b[j]); });
+    const double sy = R.sm[0], sz = R.sm[1];
     i64 nb = n_bound_mults();
     e.sd = std::max(smax, (sy + sz) / std::max<double>(1.0, static_cast<double>(m + nb))) / smax;
     e.sc = std::max(smax, sz / std::max<double>(1.0, static_cast<double>(nb))) / smax;
@@ -872,8 +927,12 @@ class Ipm {
       double* re = res;
       ex_->map(N + m, [=] DNLP_HD(i64 i) { re[i] = rr[i] - re[i]; });
       const double* so = sol;
-      double en = ex_->max(N + m, [=] DNLP_HD(i64 i) { return fabs(re[i]); });
-      double sn = ex_->max(N + m, [=] DNLP_HD(i64 i) { return fabs(so[i]); });
+      const RMulti Rn = ex_->template reduce_multi<2, 0>(N + m, [=] DNLP_HD(i64 i) -> RMulti {
+        RMulti v;
+        v.mx[0] = fabs(re[i]); v.mx[1] = fabs(so[i]); v.mx[2] = v.mx[3] = 0.0;
+        v.sm[0] = v.sm[1] = v.sm[2] = v.sm[3] = 0.0;
+        return v; });
+      double en = Rn.mx[0], sn = Rn.mx[1];
       double ratio = en / (std::max(rn, 1e-300) + sn);
       if (!std::isfinite(en)) { stats.t_solve += now_sec() - t0; return false; }
       last_ratio_ = std::isfinite(ratio) ? ratio : kInf;
@@ -891,8 +950,12 @@ class Ipm {
       kkt_mult(sol, dw, res);
       double* re = res;
       const double* so = sol;
-      double en = ex_->max(N + m, [=] DNLP_HD(i64 i) { return fabs(rr[i] - re[i]); });
-      double sn = ex_->max(N + m, [=] DNLP_HD(i64 i) { return fabs(so[i]); });
+      const RMulti Rn = ex_->template reduce_multi<2, 0>(N + m, [=] DNLP_HD(i64 i) -> RMulti {
+        RMulti v;
+        v.mx[0] = fabs(rr[i] - re[i]); v.mx[1] = fabs(so[i]); v.mx[2] = v.mx[3] = 0.0;
+        v.sm[0] = v.sm[1] = v.sm[2] = v.sm[3] = 0.0;
+        return v; });
+      const double en = Rn.mx[0], sn = Rn.mx[1];
       last_ratio_ = en / (std::max(rn, 1e-300) + sn);
       if (!std::isfinite(last_ratio_)) last_ratio_ = kInf;
     }
@@ -1002,9 +1065,7 @@ class Ipm {
   // ---- convergence tests (IPOPT OptimalityErrorConvergenceCheck) ----------------------
   DNLP_HD int check_convergence(const Err& e0) {
     double unsc_du = e0.dual / sf;
-    const double *gg = g, *ss = s, *eq = eqmask, *sl = sL, *sgp = sg;
-    double unsc_pr = m ? ex_->max(m, [=] DNLP_HD(i64 i) {
-      return fabs(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]) / sgp[i]; }) : 0.0;
+    double unsc_pr = e0.primal_unscaled;          // computed in the same pass as the scaled norms (error())
     double unsc_co = e0.cmpl / sf;
     stats.inf_pr = unsc_pr; stats.inf_du = unsc_du; stats.cmpl = unsc_co; stats.nlp_error = e0.total;
     if (e0.total <= opt.tol && unsc_du <= opt.dual_inf_tol && unsc_pr <= opt.constr_viol_tol &&
@@ -1069,15 +1130,19 @@ class Ipm {
     const D2 steps = max_steps(tau);
     double a_max = steps.first;
     double a_z = steps.second;
-    const double theta_k = theta_at(g, s);
-    const double phi_k = barrier_at(f, x, s, mu);
+    const Measures mk = measures(f, g, x, s, mu);
+    const double theta_k = mk.theta;
+    const double phi_k = mk.phi;
     double gphid;   // directional derivative of the barrier function
     {
       const double *rxx = rx, *jt = tN, *ddx = dx, *q = rs, *yy = y, *dds = ds, *eq = eqmask;
       // rx = grad_x phi + J^T y  and  tN still holds J^T y from barrier_terms
       md_->jac_tmult(jv, y, tN);
-      gphid = ex_->sum(N, [=] DNLP_HD(i64 j) { return (rxx[j] - jt[j]) * ddx[j]; }) +
-              (m ? ex_->sum(m, [=] DNLP_HD(i64 i) { return eq[i] == 0.0 ? (q[i] + yy[i]) * dds[i] : 0.0; }) : 0.0);
+      const i64 NN = N;
+      gphid = ex_->sum(N + m, [=] DNLP_HD(i64 k) {
+        if (k < NN) return (rxx[k] - jt[k]) * ddx[k];
+        const i64 i = k - NN;
+        return eq[i] == 0.0 ? (q[i] + yy[i]) * dds[i] : 0.0; });
     }
     const double g_th = 1e-5, g_ph = 1e-8, dlt = 1.0, s_th = 1.1, s_ph = 2.3, eta = 1e-8, g_al = 0.05;
     double a_min;
@@ -1098,11 +1163,12 @@ class Ipm {
     while (true) {
       ++ls;
       trial_point(alpha);
-      bool fin = eval_fg(xt, f_t, gt);
+      bool fin = eval_fg(xt, f_t, gt, false);
       if (fin) {
-        th_t = theta_at(gt, st);
-        ph_t = barrier_at(f_t, xt, st, mu);
-        fin = std::isfinite(th_t) && std::isfinite(ph_t);
+        const Measures mt = measures(f_t, gt, xt, st, mu);
+        th_t = mt.theta;
+        ph_t = mt.phi;
+        fin = mt.chk == 0.0 && std::isfinite(th_t) && std::isfinite(ph_t);
       }
       if (fin && th_t <= theta_max && filter_ok(th_t, ph_t)) {
         bool sw = gphid < 0.0 && alpha * std::pow(-gphid, s_ph) > dlt * std::pow(theta_k, s_th);
@@ -1248,18 +1314,21 @@ class Ipm {
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *a = zL, *b = zU, *c = vL, *d = vU, *eq = eqmask;
     i64 nb = n_bound_mults();
     if (nb == 0) return 0.0;
-    double cx = ex_->sum(N, [=] DNLP_HD(i64 j) {
+    const i64 NN = N;
+    const double tot = ex_->sum(N + m, [=] DNLP_HD(i64 k) {
       double v = 0.0;
-      if (l[j] > -kInf) v += (xx[j] - l[j]) * a[j];
-      if (u[j] < kInf) v += (u[j] - xx[j]) * b[j];
+      if (k < NN) {
+        const i64 j = k;
+        if (l[j] > -kInf) v += (xx[j] - l[j]) * a[j];
+        if (u[j] < kInf) v += (u[j] - xx[j]) * b[j];
+      } else {
+        const i64 i = k - NN;
+        if (eq[i] != 0.0) return v;
+        if (sl[i] > -kInf) v += (ss[i] - sl[i]) * c[i];
+        if (su[i] < kInf) v += (su[i] - ss[i]) * d[i];
+      }
       return v; });
-    double cs = m ? ex_->sum(m, [=] DNLP_HD(i64 i) {
-      double v = 0.0;
-      if (eq[i] != 0.0) return v;
-      if (sl[i] > -kInf) v += (ss[i] - sl[i]) * c[i];
-      if (su[i] < kInf) v += (su[i] - ss[i]) * d[i];
-      return v; }) : 0.0;
-    return (cx + cs) / static_cast<double>(nb);
+    return tot / static_cast<double>(nb);
   }
 
   DNLP_HD void monotone_update() {
@@ -1337,9 +1406,15 @@ class Ipm {
     const i64 sz[7] = {N, m, m, N, N, m, m};
     barrier_terms(0.0);
     const double *rxx = rx, *rss = rs, *rpp = rp;
-    const double nd2 = ex_->sum(N, [=] DNLP_HD(i64 j) { return rxx[j] * rxx[j]; }) +
-                       (m ? ex_->sum(m, [=] DNLP_HD(i64 i) { return rss[i] * rss[i]; }) : 0.0);
-    const double np2 = m ? ex_->sum(m, [=] DNLP_HD(i64 i) { return rpp[i] * rpp[i]; }) : 0.0;
+    const i64 NN0 = N;
+    const RMulti R2 = ex_->template reduce_multi<0, 2>(N + m, [=] DNLP_HD(i64 k) -> RMulti {
+      RMulti v;
+      v.mx[0] = v.mx[1] = v.mx[2] = v.mx[3] = 0.0;
+      v.sm[0] = v.sm[1] = v.sm[2] = v.sm[3] = 0.0;
+      if (k < NN0) v.sm[0] = rxx[k] * rxx[k];
+      else { const i64 i = k - NN0; v.sm[0] = rss[i] * rss[i]; v.sm[1] = rpp[i] * rpp[i]; }
+      return v; });
+    const double nd2 = R2.sm[0], np2 = m ? R2.sm[1] : 0.0;
     if (!compute_direction(0.0, rp, dw)) return false;
     for (int k = 0; k < 7; ++k) ex_->d2d(aff[k], cur[k], sizeof(double) * static_cast<size_t>(sz[k]));
     {
@@ -1370,7 +1445,7 @@ class Ipm {
     }
     if (!compute_direction(1.0, zeroM, dw, true)) return false;
     for (int k = 0; k < 7; ++k) ex_->d2d(cen[k], cur[k], sizeof(double) * static_cast<size_t>(sz[k]));
-    i64 n_ineq = static_cast<i64>(m - (m ? ex_->sum(m, [=, eq = eqmask] DNLP_HD(i64 i) { return eq[i]; }) : 0.0));
+    const i64 n_ineq = m - n_eq_;                      // (counted once in begin())
     const double n_dual = static_cast<double>(N + n_ineq), n_pri = static_cast<double>(m > 0 ? m : 1);
     const double *ax = aff[0], *as = aff[1], *aa = aff[3], *ab = aff[4], *ac = aff[5], *ad = aff[6];
     const double *cx = cen[0], *cs = cen[1], *ca = cen[3], *cb = cen[4], *cc = cen[5], *cd = cen[6];
@@ -1730,6 +1805,7 @@ class Ipm {
   int last_nneg_ = 0;               // negative pivots reported by the last factorisation attempt
   int ladder_rung_ = 0;             // 0: first run; 1, 2: rungs of the retry ladder
   int tiny_streak_ = 0;             // consecutive accepted steps with alpha_pr <= 1e-3 (stall guard)
+  i64 n_eq_ = 0;                    // equality rows (fixed at begin())
   bool resto_stationary_ = false;   // the last restoration ended where no step reduces the violation
   double resto_theta_ = 0.0;        // violation where the last restoration ended
   int dc_fixed_count_ = 0;          // iterations whose wrong inertia the dual regularisation alone repaired

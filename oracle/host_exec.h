@@ -101,6 +101,16 @@ struct HostExec : HostControlled {
     return nan ? std::nan("") : s;
   }
 
+  template <int NM, int NS, class F> RMulti reduce_multi(i64 n, F f) {
+    RMulti r;
+    for (int k = 0; k < 4; ++k) { r.mx[k] = -kInf; r.sm[k] = 0.0; }
+    for (i64 i = 0; i < n; ++i) {
+      const RMulti v = f(i);
+      for (int k = 0; k < NM; ++k) r.mx[k] = std::fmax(r.mx[k], v.mx[k] != v.mx[k] ? kInf : v.mx[k]);
+      for (int k = 0; k < NS; ++k) r.sm[k] += v.sm[k];
+    }
+    return r;
+  }
   template <class F> D2 min2(i64 n, F f) {
     D2 s{kInf, kInf};
     bool nan = false;
