@@ -13,32 +13,40 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import dnlp_amd as cp  # noqa: E402
-from paper_examples import PAPER, PUBLISHED  # noqa: E402
+from paper_examples import PAPER, PAPER_LARGE, PUBLISHED  # noqa: E402
 
+ALL = dict(PAPER)
+ALL.update(PAPER_LARGE)
 rows = []
-for name in sorted(PAPER):
-    pub = PUBLISHED[name]
+for name in sorted(ALL):
+    pub = PUBLISHED.get(name, {})
     best = None
     for rep in range(2):                       # second pass = warm library / allocator
-        prob = PAPER[name](cp)
+        prob = ALL[name](cp)
         t0 = time.time()
         chain = prob._build_chain(None)
         data, inv = chain.apply(prob)
         t_lower = time.time() - t0
+        if name == "nb_circle_packing":
+            # the published log belongs to the start the reference handed IPOPT (tests/test_paper_examples.py)
+            data["x0"] = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))["x0"]
         t0 = time.time()
         opts = dict(pub.get("options", {}))
         opts["time_kernels"] = "yes"
         info = chain.solver.solve_via_data(data, True, False, opts)
         t_solve = time.time() - t0
-        best = (t_lower, t_solve, info, data)
-    t_lower, t_solve, info, data = best
+        t0 = time.time()
+        chain.apply(prob)                      # the same Problem again: cached tape and handle
+        t_again = time.time() - t0
+        best = (t_lower, t_solve, info, data, t_again)
+    t_lower, t_solve, info, data, t_again = best
     st = info["stats"]
     row = {"example": name, "N": len(data["x0"]), "m": len(data["cl"]), "status": int(info["status"]),
            "iters": int(info["iterations"]), "objective": float(info["obj_val"]),
            "published_objective": pub.get("objective"), "published_iters": pub.get("iters"),
            "rel_diff": (abs(info["obj_val"] - pub["objective"]) / max(abs(pub["objective"]), 1e-300))
            if pub.get("objective") and abs(pub["objective"]) > 1e-6 else None,
-           "lower_sec": t_lower, "solve_sec": t_solve, "factor_sec": float(st[4]),
+           "lower_sec": t_lower, "lower_again_sec": t_again, "solve_sec": t_solve, "factor_sec": float(st[4]),
            "factorizations": int(st[1]),
            "published_ipopt_sec": pub.get("ipopt_s"), "published_oracle_sec": pub.get("oracle_s"),
            "published_total_sec": pub.get("total_s")}
