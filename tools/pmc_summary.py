@@ -2,6 +2,7 @@
 of every counter found under the given directories.
 
     python tools/pmc_summary.py out.json dir1 [dir2 ...] [--kernel substring] [--min-ms X]
+(--min-ms keeps dispatches that ran at least X ms: e.g. the outer Schur-complement updates of bench.py.)
 
 FETCH_SIZE / WRITE_SIZE are reported in bytes with the gfx950 correction of MI355X_MICROARCH.md (HBM
 section): rocprofv3 gives KB; FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads, so it is
@@ -22,7 +23,13 @@ def main():
         i = args.index("--kernel")
         kernel_filter = args[i + 1]
         del args[i:i + 2]
+    min_ms = 0.0
+    if "--min-ms" in args:
+        i = args.index("--min-ms")
+        min_ms = float(args[i + 1])
+        del args[i:i + 2]
     acc = defaultdict(lambda: defaultdict(float))
+    dur = defaultdict(lambda: defaultdict(float))
     cnt = defaultdict(lambda: defaultdict(int))
     for d in args:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -31,7 +38,11 @@ def main():
                 if kernel_filter and kernel_filter not in k:
                     continue
                 c = r.get("Counter_Name")
+                ms = (float(r.get("End_Timestamp", 0)) - float(r.get("Start_Timestamp", 0))) * 1e-6
+                if ms < min_ms:
+                    continue
                 acc[k][c] += float(r.get("Counter_Value", 0.0))
+                dur[k][c] += ms
                 cnt[k][c] += 1
     res = {}
     for k in acc:
@@ -45,6 +56,7 @@ def main():
             else:
                 row[c + "_per_dispatch"] = v / n
             row["dispatches_" + c] = n
+            row["avg_ms_under_" + c] = dur[k][c] / n
         if "SQ_WAVE_CYCLES_per_dispatch" in row:
             wc = row["SQ_WAVE_CYCLES_per_dispatch"]
             for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
