@@ -119,6 +119,212 @@ __global__ void __launch_bounds__(256) ldlt_trsm_kernel(double* A, i64 ld, int j
   }
 }
 
+// ---- 128-column sub-panels --------------------------------------------------------------------
+// The 32-column chain above costs a diag -> trsm -> update round of ~45 us of pure latency per 32
+// columns whatever the row count.  For orders where the panel chain, not the MFMA update, is the
+// critical path (a few thousand to a few ten thousand rows) a panel is taken 128 columns at a
+// time instead:
+//   ldlt_top128_kernel  — ONE workgroup factors the 128 x 128 diagonal block: the lower triangle
+//                         lives in registers as 528 tiles of 4 x 4 (one tile per lane, static
+//                         register indices), a step publishes the pivot column in LDS (two
+//                         buffers: one barrier per column) and every tile right of it takes its
+//                         rank-1 update from 8 LDS words.  It leaves a packed operand copy behind
+//                         (LD_TOP_WS doubles): the 28 strictly-lower 16 x 16 blocks negated, the
+//                         inverses of the 8 unit-lower diagonal 16 x 16 blocks, and 1 / d.
+//   ldlt_rows128_kernel — rows below on FP64 MFMA, 16 rows per wavefront, the row block TRANSPOSED
+//                         in the accumulators: X^T_c = Linv_cc (A^T_c - sum_{p<c} L_cp X^T_p) per
+//                         16-column block c.  In the 16x16x4 layout an accumulator register of
+//                         block p IS the B operand of k-slab s = register index, so the chain needs
+//                         no shuffle, no LDS and no barrier; the A operands are 512-B coalesced reads
+//                         of the packed copy (144 MFMAs per 16 rows).
+constexpr int LD_T = 128;
+constexpr int LD_TB = LD_T / 16;               // 16-column blocks of a sub-panel
+constexpr int LD_TOP_THREADS = 576;            // 528 lower 4 x 4 tiles, whole wavefronts
+constexpr int LD_TOP_NEG = 0;                                          // [pair(c,p)][k][i] = -L[16c+i][16p+k]
+constexpr int LD_TOP_INV = (LD_TB * (LD_TB - 1) / 2) * 256;            // [c][k][i] = inv(L_cc)[i][k]
+constexpr int LD_TOP_DINV = LD_TOP_INV + LD_TB * 256;                  // [col] = 1 / d
+constexpr int LD_TOP_WS = LD_TOP_DINV + LD_T;
+
+// 1 / d to full double precision without the IEEE division sequence (v_rcp_f64 + two Newton steps): the
+// reciprocals of the four pivots of a tile sit back to back on the critical path of the top-block kernel
+__device__ inline double ldlt_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(r, fma(-d, r, 1.0), r);
+  r = fma(r, fma(-d, r, 1.0), r);
+  return r;
+}
+
+__global__ void __launch_bounds__(LD_TOP_THREADS) ldlt_top128_kernel(double* __restrict__ A, i64 ld, int j0,
+                                                                     LdltInfo* info, double tiny,
+                                                                     double* __restrict__ Ltop) {
+  // per tile column (4 matrix columns): the diagonal tile is factored by its lane alone and published
+  // (barrier), the tiles below it finish their four columns from it and publish W = L D and L
+  // (barrier), every tile to the right takes one rank-4 update.  Two barriers per four columns.
+  __shared__ __attribute__((aligned(16))) double Wb[LD_T][4];
+  __shared__ __attribute__((aligned(16))) double Lb[LD_T][4];
+  __shared__ double dgL[4][4];
+  __shared__ double dgI[4];
+  __shared__ double Ld[LD_TB][16][17];          // unit-lower diagonal 16 x 16 blocks, for their inverses
+  const int t = threadIdx.x;
+  // tile columns in order, the tiles of a column top to bottom: finished columns are a thread prefix
+  int tj = 0, rem = t;
+  while (tj < LD_T / 4 && rem >= LD_T / 4 - tj) { rem -= LD_T / 4 - tj; ++tj; }
+  const bool valid = tj < LD_T / 4;
+  const int ti = valid ? tj + rem : 0;
+  if (!valid) tj = -1;                          // never a pivot column, never right of one
+  double T[4][4];
+  {
+    const double* src = A + (j0 + 4 * ti) + static_cast<i64>(j0 + 4 * (valid ? tj : 0)) * ld;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) T[a][b] = src[a + static_cast<i64>(b) * ld];
+  }
+  double dinv[4] = {1.0, 1.0, 1.0, 1.0};
+  int nneg = 0, nzero = 0, fail = 0;
+  for (int kb = 0; kb < LD_T / 4; ++kb) {
+    if (tj == kb && ti == kb) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        // the reciprocal starts on the raw pivot; the (rare) repair of a NaN / tiny pivot redoes it
+        double d = T[kk][kk];
+        double di = ldlt_rcp(d);
+        if (!(fabs(d) > tiny)) {
+          if (!(d == d)) { fail = 1; d = 1.0; }
+          else { nzero += 1; d = (d < 0.0 ? -tiny : tiny); if (d == 0.0) d = 1e-300; }
+          di = ldlt_rcp(d);
+          T[kk][kk] = d;
+        }
+        nneg += d < 0.0 ? 1 : 0;
+        dinv[kk] = di;
+        dgI[kk] = di;
+#pragma unroll
+        for (int a = kk + 1; a < 4; ++a) {
+          const double l = T[a][kk] * di;
+#pragma unroll
+          for (int b = kk + 1; b <= a; ++b) T[a][b] -= l * T[b][kk];
+        }
+#pragma unroll
+        for (int a = kk + 1; a < 4; ++a) {
+          T[a][kk] *= di;
+          dgL[a][kk] = T[a][kk];
+        }
+      }
+    }
+    __syncthreads();
+    if (tj == kb && ti > kb) {
+      double w[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          double v = T[a][kk];
+#pragma unroll
+          for (int q = 0; q < kk; ++q) v -= w[a][q] * dgL[kk][q];
+          w[a][kk] = v;
+          T[a][kk] = v * dgI[kk];
+        }
+        *reinterpret_cast<double2*>(&Wb[4 * ti + a][0]) = double2{w[a][0], w[a][1]};
+        *reinterpret_cast<double2*>(&Wb[4 * ti + a][2]) = double2{w[a][2], w[a][3]};
+        *reinterpret_cast<double2*>(&Lb[4 * ti + a][0]) = double2{T[a][0], T[a][1]};
+        *reinterpret_cast<double2*>(&Lb[4 * ti + a][2]) = double2{T[a][2], T[a][3]};
+      }
+    }
+    __syncthreads();
+    if (tj > kb) {
+      double wi[4][4], lj[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const double2 w0v = *reinterpret_cast<const double2*>(&Wb[4 * ti + a][0]);
+        const double2 w1v = *reinterpret_cast<const double2*>(&Wb[4 * ti + a][2]);
+        const double2 l0v = *reinterpret_cast<const double2*>(&Lb[4 * tj + a][0]);
+        const double2 l1v = *reinterpret_cast<const double2*>(&Lb[4 * tj + a][2]);
+        wi[a][0] = w0v.x; wi[a][1] = w0v.y; wi[a][2] = w1v.x; wi[a][3] = w1v.y;
+        lj[a][0] = l0v.x; lj[a][1] = l0v.y; lj[a][2] = l1v.x; lj[a][3] = l1v.y;
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) T[a][b] -= wi[a][kk] * lj[b][kk];
+    }
+  }
+  if (valid) {
+    const int cb = ti >> 2, pb = tj >> 2;       // 16-blocks of the tile's rows / columns
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int r = 4 * ti + a, c = 4 * tj + b;
+        if (r >= c) A[(j0 + r) + static_cast<i64>(j0 + c) * ld] = T[a][b];
+        if (cb > pb) Ltop[LD_TOP_NEG + ((cb * (cb - 1) / 2 + pb) * 16 + (c & 15)) * 16 + (r & 15)] = -T[a][b];
+        else if (r > c) Ld[cb][r & 15][c & 15] = T[a][b];
+        else if (r == c) Ltop[LD_TOP_DINV + c] = dinv[a];
+      }
+  }
+  __syncthreads();
+  if (t < LD_T) {
+    // column j of the inverse of the unit-lower block c: forward substitution on e_j
+    const int c = t >> 4, j = t & 15;
+    double y[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      double v = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k) v -= Ld[c][i][k] * y[k];
+      y[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Ltop[LD_TOP_INV + (c * 16 + j) * 16 + i] = y[i];
+  }
+  if (nneg) atomicAdd(&info->nneg, nneg);
+  if (nzero) atomicAdd(&info->nzero, nzero);
+  if (fail) atomicExch(&info->fail, 1);
+}
+
+__global__ void __launch_bounds__(256) ldlt_rows128_kernel(double* __restrict__ A, i64 ld, int j0, int n,
+                                                           double* __restrict__ Wp, i64 ldw, int wcol0,
+                                                           const double* __restrict__ Ltop) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const i64 row0 = static_cast<i64>(j0) + LD_T + (static_cast<i64>(blockIdx.x) * 4 + wave) * 16;
+  if (row0 >= n) return;                                  // whole wavefront; the kernel has no barrier
+  const int lr = lane & 15, lq = lane >> 4;
+  const i64 row = row0 + lr;
+  const bool ok = row < n;
+  const i64 rr = ok ? row : static_cast<i64>(n) - 1;      // clamped loads, predicated stores
+  mfma_d4 D[LD_TB];
+#pragma unroll
+  for (int c = 0; c < LD_TB; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) D[c][r] = A[rr + static_cast<i64>(j0 + 16 * c + lq + 4 * r) * ld];
+  const double* opn = Ltop + LD_TOP_NEG + lq * 16 + lr;
+  const double* opi = Ltop + LD_TOP_INV + lq * 16 + lr;
+#pragma unroll
+  for (int c = 0; c < LD_TB; ++c) {
+#pragma unroll
+    for (int p = 0; p < c; ++p)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        D[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(opn[((c * (c - 1) / 2 + p) * 16 + 4 * s) * 16], D[p][s], D[c], 0, 0, 0);
+    mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(opi[(c * 16 + 4 * s) * 16], D[c][s], acc, 0, 0, 0);
+    D[c] = acc;
+  }
+  if (ok) {
+#pragma unroll
+    for (int c = 0; c < LD_TB; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = 16 * c + lq + 4 * r;
+        Wp[row + static_cast<i64>(wcol0 + col) * ldw] = D[c][r];
+        A[row + static_cast<i64>(j0 + col) * ld] = D[c][r] * Ltop[LD_TOP_DINV + col];
+      }
+  }
+}
+
 // ---- C -= W L^T on FP64 MFMA ---------------------------------------------------------------
 // Interior tiles (full 128x128, strictly below the diagonal, K a multiple of 16, 16-B aligned
 // operands) take the fast body: the C tile is loaded straight into the MFMA accumulators
@@ -502,6 +708,8 @@ struct BlockedLdlt {
   double* Wp2[2] = {nullptr, nullptr};     // panel workspaces W = L D (double buffered for look-ahead)
   LdltInfo* info = nullptr;
   double* acc = nullptr;
+  double* Ltop = nullptr;                  // packed operands of the current 128-column sub-panel (ldlt_top128_kernel)
+  bool sub128 = true;                      // panels in 128-column sub-panels (DNLP_LDLT_T128=0: the 32-column chain)
   double last_update_seconds = 0.0;
   double total_update_seconds = 0.0, total_update_flops = 0.0;   // outer (Schur) updates, timed
   i64 total_update_launches = 0;
@@ -523,6 +731,7 @@ struct BlockedLdlt {
     if (const char* ev = std::getenv("DNLP_LDLT_NB")) NB = std::atoi(ev);
     if (const char* ev = std::getenv("DNLP_LDLT_LOOKAHEAD")) lookahead = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_XCD")) xcd_swizzle = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("DNLP_LDLT_T128")) sub128 = std::atoi(ev) != 0;
     if (NB < LD_nb) NB = LD_nb;
     if (NB > LD_NB_MAX) NB = LD_NB_MAX;
     NB = NB / LD_nb * LD_nb;
@@ -530,6 +739,7 @@ struct BlockedLdlt {
     Wp2[1] = lookahead ? ex->alloc<double>(static_cast<size_t>(ldw) * NB + 256) : Wp2[0];
     info = ex->alloc<LdltInfo>(1);
     acc = ex->alloc<double>(SV_B);
+    Ltop = ex->alloc<double>(LD_TOP_WS);
     DNLP_HIP_CHECK(hipEventCreateWithFlags(&evPanel, hipEventDisableTiming));
     DNLP_HIP_CHECK(hipEventCreateWithFlags(&evUpd, hipEventDisableTiming));
     // the trailing updates run on their own (lower-priority) stream so that the next panel's
@@ -590,6 +800,21 @@ struct BlockedLdlt {
       const int KB = std::min(NB, ni - K0);
       double* Wp = Wp2[p & 1];
       for (int j0 = K0; j0 < K0 + KB; j0 += LD_nb) {
+        if (sub128 && K0 + KB - j0 >= LD_T) {
+          // a full 128-column sub-panel: three launches instead of twelve
+          hipLaunchKernelGGL(ldlt_top128_kernel, dim3(1), dim3(LD_TOP_THREADS), 0, s0, A, ld, j0, info, tiny, Ltop);
+          const int r0 = j0 + LD_T, rows = ni - r0;
+          if (rows > 0) {
+            hipLaunchKernelGGL(ldlt_rows128_kernel, dim3((rows + 63) / 64), dim3(256), 0, s0, A, ld, j0, ni, Wp, ldw,
+                               j0 - K0, Ltop);
+            const int nc = K0 + KB - r0;
+            if (nc > 0)
+              gemm(s0, A + r0 + static_cast<i64>(r0) * ld, Wp + r0 + static_cast<i64>(j0 - K0) * ldw,
+                   A + r0 + static_cast<i64>(j0) * ld, ld, rows, nc, LD_T, 1);
+          }
+          j0 += LD_T - LD_nb;
+          continue;
+        }
         const int jb = std::min(LD_nb, K0 + KB - j0);
         hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(64), 0, s0, A, ld, j0, jb, info, tiny);
         const int r0 = j0 + jb;
