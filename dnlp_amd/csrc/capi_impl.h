@@ -182,7 +182,7 @@ struct ProblemT {
     else if (k == "warm_start_bound_push") opt.warm_start_bound_push = num();
     else if (k == "warm_start_bound_frac") opt.warm_start_bound_frac = num();
     else if (k == "warm_start_mult_bound_push") opt.warm_start_mult_bound_push = num();
-    else if (k == "kkt_pivot_max_n") pivot_max_n = static_cast<i64>(num());
+    else if (k == "kkt_pivot_max_n") pivot_max_n = std::min<i64>(static_cast<i64>(num()), 4096);   // the pivoted solve keeps its vector in LDS
     else if (k == "kkt_optimistic_min_n") optimistic_min_n = static_cast<i64>(num());
     else if (k == "lazy_dense_fallback") opt.lazy_dense_fallback = yes() ? 1 : 0;
     else if (k == "restoration") opt.restoration = yes() ? 1 : 0;

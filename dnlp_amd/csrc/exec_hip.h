@@ -256,27 +256,61 @@ struct BkState {
 
 constexpr int BK_T = 1024;
 
+// wave-wide max of a non-negative double / min of an int on DPP row shifts and row broadcasts (no LDS
+// round trips: ds_bpermute shuffles cost ~120 cycles each, a block argmax was 18 of them in sequence)
+template <int CTRL, int ROW_MASK>
+__device__ inline double bk_dpp_max(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return fmax(v, __hiloint2double(hi, lo));
+}
+template <int CTRL, int ROW_MASK>
+__device__ inline int bk_dpp_min(int v) {
+  return min(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false));
+}
+__device__ inline double bk_wave_max(double v) {
+  v = bk_dpp_max<0x111, 0xf>(v);     // row_shr:1
+  v = bk_dpp_max<0x112, 0xf>(v);     // row_shr:2
+  v = bk_dpp_max<0x114, 0xf>(v);     // row_shr:4
+  v = bk_dpp_max<0x118, 0xf>(v);     // row_shr:8   -> lane 15 of every row holds the row's maximum
+  v = bk_dpp_max<0x142, 0xa>(v);     // row_bcast:15 into rows 1, 3
+  v = bk_dpp_max<0x143, 0xc>(v);     // row_bcast:31 into rows 2, 3 -> lane 63 holds the wavefront's maximum
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ inline int bk_wave_min(int v) {
+  v = bk_dpp_min<0x111, 0xf>(v);
+  v = bk_dpp_min<0x112, 0xf>(v);
+  v = bk_dpp_min<0x114, 0xf>(v);
+  v = bk_dpp_min<0x118, 0xf>(v);
+  v = bk_dpp_min<0x142, 0xa>(v);
+  v = bk_dpp_min<0x143, 0xc>(v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// block-wide argmax of v >= 0 (v = -1: the lane has no candidate); the smallest index wins ties, as IDAMAX
 __device__ inline void bk_argmax(double v, int idx, double* sv, int* si, double& outv, int& outi) {
-  // block-wide argmax of |v| (first index wins ties, as IDAMAX)
-  for (int o = 32; o > 0; o >>= 1) {
-    double ov = __shfl_down(v, o, 64);
-    int oi = __shfl_down(idx, o, 64);
-    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-  }
+  const bool has = v >= 0.0;
+  const double m = bk_wave_max(has ? v : 0.0);
+  const int cand = bk_wave_min((has && v == m) ? idx : 0x7fffffff);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (lane == 0) { sv[wid] = v; si[wid] = idx; }
+  if (lane == 0) { sv[wid] = cand == 0x7fffffff ? -1.0 : m; si[wid] = cand; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double bv = sv[0];
-    int bi = si[0];
-    for (int w = 1; w < BK_T / 64; ++w)
-      if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
-    sv[0] = bv;
-    si[0] = bi;
-  }
-  __syncthreads();
-  outv = sv[0];
-  outi = si[0];
+  // sixteen wavefront results: a four-level tree in every lane (a serial scan is fifteen dependent
+  // compare / select rounds of ~100 cycles each)
+  double tv[BK_T / 64];
+  int tix[BK_T / 64];
+#pragma unroll
+  for (int w = 0; w < BK_T / 64; ++w) { tv[w] = sv[w]; tix[w] = si[w]; }
+#pragma unroll
+  for (int span = BK_T / 128; span >= 1; span >>= 1)
+#pragma unroll
+    for (int w = 0; w < span; ++w) {
+      const bool take = tv[w + span] > tv[w] || (tv[w + span] == tv[w] && tix[w + span] < tix[w]);
+      tv[w] = take ? tv[w + span] : tv[w];
+      tix[w] = take ? tix[w + span] : tix[w];
+    }
+  outv = tv[0];
+  outi = tix[0];
   __syncthreads();
 }
 
@@ -355,6 +389,13 @@ __global__ void __launch_bounds__(BK_T) bk_pivot_kernel(double* A, int n, i64 ld
     for (int j = kk + 1 + tid; j < kp; j += BK_T) {
       const double t = A[j + static_cast<i64>(kk) * ld];
       A[j + static_cast<i64>(kk) * ld] = A[kp + static_cast<i64>(j) * ld];
+      A[kp + static_cast<i64>(j) * ld] = t;
+    }
+    // ... and in the columns already factored, so that L ends as ONE unit-lower factor of P A P^T
+    // (the blocked solve below needs no interchange between its column blocks)
+    for (int j = tid; j < k; j += BK_T) {
+      const double t = A[kk + static_cast<i64>(j) * ld];
+      A[kk + static_cast<i64>(j) * ld] = A[kp + static_cast<i64>(j) * ld];
       A[kp + static_cast<i64>(j) * ld] = t;
     }
     __syncthreads();
@@ -436,65 +477,123 @@ __global__ void __launch_bounds__(kBlock) bk_update_kernel(double* A, int n, i64
   }
 }
 
-// DSYTRS (lower) in one workgroup; b in global memory.
-__global__ void __launch_bounds__(BK_T) bk_solve_kernel(const double* A, int n, i64 ld, const int* ipiv, double* b) {
-  __shared__ double red[BK_T / 64];
-  __shared__ double red2[BK_T / 64];
+// After the last pivot: the interchanges as ONE permutation (x = b[perm]) and the pivot structure
+// (0: 1x1, 1 / 2: first / second column of a 2x2 block), both by a sequential pass in LDS.
+constexpr int BK_NMAX = 4096;            // largest order the one-workgroup solve keeps in LDS
+__global__ void __launch_bounds__(BK_T) bk_finish_kernel(const int* __restrict__ ipiv, int n, int* __restrict__ perm,
+                                                         int* __restrict__ dtype) {
+  __shared__ int sp[BK_NMAX], sv[BK_NMAX], st[BK_NMAX];
   const int tid = threadIdx.x;
-  int k = 0;
-  while (k < n) {
-    if (ipiv[k] > 0) {
-      const int kp = ipiv[k] - 1;
-      if (tid == 0 && kp != k) { const double t = b[k]; b[k] = b[kp]; b[kp] = t; }
-      __syncthreads();
-      const double bk = b[k];
-      for (int i = k + 1 + tid; i < n; i += BK_T) b[i] -= A[i + static_cast<i64>(k) * ld] * bk;
-      __syncthreads();
-      if (tid == 0) b[k] = bk / A[k + static_cast<i64>(k) * ld];
-      k += 1;
-    } else {
-      const int kp = -ipiv[k] - 1;
-      if (tid == 0 && kp != k + 1) { const double t = b[k + 1]; b[k + 1] = b[kp]; b[kp] = t; }
-      __syncthreads();
-      const double bk = b[k], bk1 = b[k + 1];
-      for (int i = k + 2 + tid; i < n; i += BK_T)
-        b[i] -= A[i + static_cast<i64>(k) * ld] * bk + A[i + static_cast<i64>(k + 1) * ld] * bk1;
-      __syncthreads();
-      if (tid == 0) {
-        const double akm1k = A[k + 1 + static_cast<i64>(k) * ld];
-        const double akm1 = A[k + static_cast<i64>(k) * ld] / akm1k, ak = A[k + 1 + static_cast<i64>(k + 1) * ld] / akm1k;
-        const double denom = akm1 * ak - 1.0, bkm1 = bk / akm1k, bkk = bk1 / akm1k;
-        b[k] = (ak * bkm1 - bkk) / denom;
-        b[k + 1] = (akm1 * bkk - bkm1) / denom;
+  for (int i = tid; i < n; i += BK_T) { sp[i] = i; sv[i] = ipiv[i]; }
+  __syncthreads();
+  if (tid == 0) {
+    int k = 0;
+    while (k < n) {
+      if (sv[k] > 0) {
+        const int kp = sv[k] - 1;
+        if (kp != k) { const int t = sp[k]; sp[k] = sp[kp]; sp[kp] = t; }
+        st[k] = 0;
+        k += 1;
+      } else {
+        const int kp = -sv[k] - 1;
+        if (kp != k + 1) { const int t = sp[k + 1]; sp[k + 1] = sp[kp]; sp[kp] = t; }
+        st[k] = 1;
+        st[k + 1] = 2;
+        k += 2;
       }
-      k += 2;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += BK_T) { perm[i] = sp[i]; dtype[i] = st[i]; }
+}
+
+// P A P^T = L D L^T solve in one workgroup with the vector in LDS: 32-column blocks, the diagonal block
+// by one wavefront (lane = row, v_readlane broadcasts), the rows below / the columns' dot products by all
+// sixteen; three barriers per block instead of two per column.
+__global__ void __launch_bounds__(BK_T) bk_solve_kernel(const double* __restrict__ A, int n, i64 ld,
+                                                        const int* __restrict__ perm, const int* __restrict__ dtype,
+                                                        double* __restrict__ b) {
+  __shared__ double x[BK_NMAX];
+  __shared__ double Lb[32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < n; i += BK_T) x[i] = b[perm[i]];
+  __syncthreads();
+  auto stage_diag = [&](int j0, int jb) {
+    for (int e = tid; e < jb * jb; e += BK_T) {
+      const int r = e % jb, c = e / jb;
+      double v = (r > c) ? A[(j0 + r) + static_cast<i64>(j0 + c) * ld] : 0.0;
+      if (r == c + 1 && dtype[j0 + c] == 1) v = 0.0;          // the off-diagonal of a 2x2 pivot is D, not L
+      Lb[r][c] = v;
+    }
+  };
+  // forward: L y = P b
+  for (int j0 = 0; j0 < n; j0 += 32) {
+    const int jb = min(32, n - j0);
+    stage_diag(j0, jb);
+    __syncthreads();
+    if (wave == 0) {
+      double y = lane < jb ? x[j0 + lane] : 0.0;
+      for (int c = 0; c < jb; ++c) {
+        const double yc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(y), c),
+                                           __builtin_amdgcn_readlane(__double2loint(y), c));
+        if (lane > c && lane < jb) y -= Lb[lane][c] * yc;
+      }
+      if (lane < jb) x[j0 + lane] = y;
+    }
+    __syncthreads();
+    const int r0 = j0 + jb;
+    const bool straddle = dtype[r0 - 1] == 1;                  // 2x2 pivot across the block boundary
+    for (int r = r0 + tid; r < n; r += BK_T) {
+      double s = 0.0;
+#pragma unroll 8
+      for (int c = 0; c < jb; ++c) s += A[r + static_cast<i64>(j0 + c) * ld] * x[j0 + c];
+      if (straddle && r == r0) s -= A[r + static_cast<i64>(r0 - 1) * ld] * x[r0 - 1];
+      x[r] -= s;
     }
     __syncthreads();
   }
-  k = n - 1;
-  while (k >= 0) {
-    const bool one = ipiv[k] > 0;
-    double s0 = 0.0, s1 = 0.0;
-    for (int i = k + 1 + tid; i < n; i += BK_T) {
-      const double bi = b[i];
-      s0 += A[i + static_cast<i64>(k) * ld] * bi;
-      if (!one) s1 += A[i + static_cast<i64>(k - 1) * ld] * bi;
+  // D z = y
+  for (int k = tid; k < n; k += BK_T) {
+    const int ty = dtype[k];
+    if (ty == 0) {
+      x[k] /= A[k + static_cast<i64>(k) * ld];
+    } else if (ty == 1) {
+      const double akm1k = A[k + 1 + static_cast<i64>(k) * ld];
+      const double akm1 = A[k + static_cast<i64>(k) * ld] / akm1k, ak = A[k + 1 + static_cast<i64>(k + 1) * ld] / akm1k;
+      const double denom = akm1 * ak - 1.0, bkm1 = x[k] / akm1k, bkk = x[k + 1] / akm1k;
+      x[k] = (ak * bkm1 - bkk) / denom;
+      x[k + 1] = (akm1 * bkk - bkm1) / denom;
     }
-    s0 = wave_sum(s0);
-    s1 = wave_sum(s1);
-    if ((tid & 63) == 0) { red[tid >> 6] = s0; red2[tid >> 6] = s1; }
-    __syncthreads();
-    if (tid == 0) {
-      double t0 = 0.0, t1 = 0.0;
-      for (int w = 0; w < BK_T / 64; ++w) { t0 += red[w]; t1 += red2[w]; }
-      b[k] -= t0;
-      if (!one) b[k - 1] -= t1;
-      const int kp = (one ? ipiv[k] : -ipiv[k]) - 1;
-      if (kp != k) { const double t = b[k]; b[k] = b[kp]; b[kp] = t; }
-    }
-    __syncthreads();
-    k -= one ? 1 : 2;
   }
+  __syncthreads();
+  // backward: L^T w = z
+  for (int j0 = (n - 1) / 32 * 32; j0 >= 0; j0 -= 32) {
+    const int jb = min(32, n - j0);
+    const int r0 = j0 + jb;
+    stage_diag(j0, jb);
+    const bool straddle = r0 < n && dtype[r0 - 1] == 1;
+    for (int c = wave; c < jb; c += BK_T / 64) {
+      double s = 0.0;
+      for (int r = r0 + lane; r < n; r += 64) s += A[r + static_cast<i64>(j0 + c) * ld] * x[r];
+      s = wave_sum(s);
+      if (lane == 0) {
+        if (straddle && c == jb - 1) s -= A[r0 + static_cast<i64>(r0 - 1) * ld] * x[r0];
+        x[j0 + c] -= s;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      double w = lane < jb ? x[j0 + lane] : 0.0;
+      for (int c = jb - 1; c >= 0; --c) {
+        const double wc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(w), c),
+                                           __builtin_amdgcn_readlane(__double2loint(w), c));
+        if (lane < c) w -= Lb[c][lane] * wc;
+      }
+      if (lane < jb) x[j0 + lane] = w;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += BK_T) b[perm[i]] = x[i];
 }
 
 // ---- tape sweep over the elementwise-class segments (hand-written form of Model::sweep_flat) ---
@@ -837,6 +936,8 @@ struct HipExec : HostControlled {
 
   struct LdltWork {
     BkState* st = nullptr;
+    i32* bk_perm = nullptr;      // Bunch-Kaufman: the interchanges as one permutation, and the pivot structure
+    i32* bk_dtype = nullptr;
     BlockedLdlt* blocked = nullptr;
     int expect_neg = -1;         // inertia the caller needs (early exit of hopeless attempts)
     bool time_updates = false;
@@ -1278,6 +1379,7 @@ struct HipExec : HostControlled {
       }
     }
     hipLaunchKernelGGL(bk_pivot_kernel, dim3(1), dim3(BK_T), 0, stream, A, ni, ld, ipiv, w.st);
+    hipLaunchKernelGGL(bk_finish_kernel, dim3(1), dim3(BK_T), 0, stream, ipiv, ni, w.bk_perm, w.bk_dtype);
     BkState out;
     DNLP_HIP_CHECK(hipMemcpyAsync(&out, w.st, sizeof out, hipMemcpyDeviceToHost, stream));
     DNLP_HIP_CHECK(hipStreamSynchronize(stream));

@@ -917,7 +917,10 @@ struct BlockedLdlt {
 
 inline void HipExec::ldlt_prepare(LdltWork& w, i64 n, i64 ld, bool pivoted) {
   if (pivoted) {
+    if (n > BK_NMAX) throw std::runtime_error("Bunch-Kaufman path: order above BK_NMAX");
     w.st = alloc<BkState>(1);
+    w.bk_perm = alloc<i32>(static_cast<size_t>(n));
+    w.bk_dtype = alloc<i32>(static_cast<size_t>(n));
   } else {
     w.blocked = new BlockedLdlt();
     w.blocked->init(this, n, ld);
@@ -942,7 +945,8 @@ inline void HipExec::ldlt_stats(LdltWork& w, double* out3) {   // out3: room for
 }
 inline void HipExec::ldlt_solve(LdltWork& w, const double* A, i64 n, i64 ld, const i32* ipiv, bool pivoted, double* b) {
   if (pivoted) {
-    hipLaunchKernelGGL(bk_solve_kernel, dim3(1), dim3(BK_T), 0, stream, A, static_cast<int>(n), ld, ipiv, b);
+    (void)ipiv;
+    hipLaunchKernelGGL(bk_solve_kernel, dim3(1), dim3(BK_T), 0, stream, A, static_cast<int>(n), ld, w.bk_perm, w.bk_dtype, b);
   } else {
     w.blocked->solve(A, b);
   }

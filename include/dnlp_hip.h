@@ -195,7 +195,10 @@ int dnlp_dev_symv(int device, const double* device_A, int64_t n, int64_t ld, con
 /* ---- factorisation kernels exposed for parity tests and benchmarks ----------------------- */
 /* In-place LDL^T of a host column-major symmetric matrix (lower triangle referenced) through
  * the device path: pivoted (Bunch-Kaufman) or blocked unpivoted with the FP64-MFMA trailing
- * update.  Outputs the factored matrix, pivots (LAPACK DSYTF2 convention) and the inertia. */
+ * update.  Outputs the factored matrix, pivots and the inertia.  Pivoted: the pivot choices and ipiv are
+ * DSYTF2's, but every interchange is also applied to the columns already factored, so the matrix
+ * holds ONE unit-lower factor L of P A P^T = L D L^T (P = the interchanges in order), not DSYTRS's
+ * interleaved form. */
 int dnlp_ldlt_host(int device, double* A, int64_t n, int64_t ld, int32_t* ipiv, int pivoted,
                    int* nneg, int* nzero, const double* rhs, double* sol, double* seconds);
 /* Time the blocked FP64-MFMA LDL^T on a device-resident matrix (destroys it).  The allocation

@@ -17,6 +17,8 @@ from paper_examples import PAPER, PAPER_LARGE, PUBLISHED  # noqa: E402
 
 ALL = dict(PAPER)
 ALL.update(PAPER_LARGE)
+if len(sys.argv) > 1:                              # python tools/run_paper_examples.py nb_phase_retrieval ...
+    ALL = {k: v for k, v in ALL.items() if k in sys.argv[1:]}
 rows = []
 for name in sorted(ALL):
     pub = PUBLISHED.get(name, {})
