@@ -47,6 +47,7 @@ struct ProblemT {
   IntermediateCb intermediate_cb = nullptr;   // dnlp_set_intermediate_cb
   void* intermediate_user = nullptr;
   SparsePlanHost sparse_plan;
+  double plan_seconds = 0.0;      // host time of the symbolic analysis (build_sparse_plan)
   bool sparse_planned = false, use_sparse = false;
 
   explicit ProblemT(int device) : ex(device) {}
@@ -99,7 +100,12 @@ struct ProblemT {
       for (double& v : jabs) v = std::isfinite(v) ? std::fabs(v) : 0.0;
       swept = false;
     }
+    const double t_plan0 = now_sec();
     build_sparse_plan(t, sparse_plan, opt.bound_relax_factor > 0.0, &jabs);
+    plan_seconds = now_sec() - t_plan0;
+    if (std::getenv("DNLP_TIME_PLAN"))
+      std::fprintf(stderr, "[dnlp] sparse plan: order %.0f, %zu triples, fill ratio %.4f, %.3f s on the host\n", n,
+                   sparse_plan.tdst.size(), sparse_plan.fill_ratio, plan_seconds);
     // a long update program (dense-ish fill) is walked by one workgroup: it must be clearly cheaper
     // than the chip-wide dense factorisation (n^3/3 flops at MFMA rate; phase retrieval, order
     // 1472 with 3.6e6 triples, stays dense — a 7e5-order chain with 8e5 triples is sparse)

@@ -853,6 +853,7 @@ __global__ void __launch_bounds__(kBlock) sparse_solve_kernel(SparsePlan pl, con
 }
 // Wide levels (large sparse systems: 7e5-order chains have levels of 1e5 independent pivot
 // blocks): one grid-wide kernel per level phase instead of one workgroup walking everything.
+__global__ void sp_info_reset_kernel(SparseInfo* info) { *info = SparseInfo{1, 0, 0, 0}; }
 __global__ void __launch_bounds__(kBlock) sp_pivot_kernel(SparsePlan pl, double* vals, double* dinv, i64 b0, i64 b1, SparseInfo* info) {
   const i64 k = b0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
   if (k >= b1) return;
@@ -956,6 +957,7 @@ struct HipExec : HostControlled {
   }
   ~HipExec() {
     hipSetDevice(device);
+    for (const LevelGraph& g : level_graphs_) hipGraphExecDestroy(g.exec);
     for (void* p : owned_) hipFree(p);
     if (gemv_part) hipFree(gemv_part);
     if (d_partial) hipFree(d_partial);
@@ -1113,25 +1115,66 @@ struct HipExec : HostControlled {
   }
   // Small systems: one workgroup walks all levels (one launch).  Large ones (>= 8192 pivot
   // blocks): one grid-wide kernel per level phase, sized by that level's blocks / rows / triples.
+  // one workgroup walks the whole plan (no launches) below these sizes; above, one kernel per level phase
+  // over the whole chip (a plan with few blocks but a long update program -- dense-ish fronts, 1e6 triples
+  // at order 1e4 in the small NMF example -- is compute-bound on one CU)
   static constexpr i64 kSparseGridMin = 8192;
+  static constexpr i64 kSparseGridMinTriples = 200000;
+  static bool sparse_grid_path(const SparsePlan& pl) {
+    return pl.h_lev_blk && (pl.nblk >= kSparseGridMin || pl.ntrip >= kSparseGridMinTriples);
+  }
+  // The level loops of the static-pattern factorisation / solves are the same launch sequence every time
+  // (a plan with 300 levels is 1 200 + 600 launches of ~2 us kernels: host launch overhead, ~16 us each,
+  // was 80 % of the NMF example).  They are captured ONCE per (plan, buffers) into a HIP graph and replayed.
+  struct LevelGraph { const void* k0; const void* k1; const void* k2; int kind; hipGraphExec_t exec; };
+  std::vector<LevelGraph> level_graphs_;
+  int level_graphs_on_ = -1;
+  template <class F>
+  void replay_levels(int kind, const void* k0, const void* k1, const void* k2, F&& launches) {
+    if (level_graphs_on_ < 0) {
+      const char* ev = std::getenv("DNLP_LEVEL_GRAPHS");
+      level_graphs_on_ = (ev && std::atoi(ev) == 0) ? 0 : 1;
+    }
+    if (!level_graphs_on_) { launches(); return; }
+    for (const LevelGraph& g : level_graphs_)
+      if (g.kind == kind && g.k0 == k0 && g.k1 == k1 && g.k2 == k2) {
+        DNLP_HIP_CHECK(hipGraphLaunch(g.exec, stream));
+        return;
+      }
+    hipGraph_t graph = nullptr;
+    DNLP_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    launches();
+    DNLP_HIP_CHECK(hipStreamEndCapture(stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    DNLP_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    DNLP_HIP_CHECK(hipGraphDestroy(graph));
+    if (level_graphs_.size() >= 24) {              // buffers of retired solver objects: oldest out
+      hipGraphExecDestroy(level_graphs_.front().exec);
+      level_graphs_.erase(level_graphs_.begin());
+    }
+    level_graphs_.push_back(LevelGraph{k0, k1, k2, kind, exec});
+    DNLP_HIP_CHECK(hipGraphLaunch(exec, stream));
+  }
   bool sparse_factor(const SparsePlan& pl, double* vals, double* w, int* nneg, int* nzero) {
     if (!sparse_info) { sparse_info = alloc<SparseInfo>(1); }
     auto grid = [](i64 items) { return dim3(static_cast<unsigned>((items + kBlock - 1) / kBlock)); };
-    if (pl.nblk < kSparseGridMin || !pl.h_lev_blk) {
+    if (!sparse_grid_path(pl)) {
       hipLaunchKernelGGL(sparse_factor_kernel, dim3(1), dim3(kBlock), 0, stream, pl, vals, w, sparse_info);
       DNLP_LAUNCH_CHECK();
     } else {
-      const SparseInfo init{1, 0, 0, 0};
-      DNLP_HIP_CHECK(hipMemcpyAsync(sparse_info, &init, sizeof init, hipMemcpyHostToDevice, stream));
       double* dinv = w + pl.nvals;
-      for (i64 lev = 0; lev < pl.nlev; ++lev) {
-        const i64 b0 = pl.h_lev_blk[lev], b1 = pl.h_lev_blk[lev + 1], r0 = pl.h_lev_row[lev], r1 = pl.h_lev_row[lev + 1];
-        const i64 t0 = pl.h_lev_trip[lev], t1 = pl.h_lev_trip[lev + 1], v0 = pl.h_lev_val[lev], v1 = pl.h_lev_val[lev + 1];
-        hipLaunchKernelGGL(sp_pivot_kernel, grid(b1 - b0), dim3(kBlock), 0, stream, pl, vals, dinv, b0, b1, sparse_info);
-        if (r1 > r0) hipLaunchKernelGGL(sp_scale_kernel, grid(r1 - r0), dim3(kBlock), 0, stream, pl, vals, w, dinv, r0, r1);
-        if (t1 > t0) hipLaunchKernelGGL(sp_update_kernel, grid(t1 - t0), dim3(kBlock), 0, stream, pl, vals, w, t0, t1);
-        if (v1 > v0) hipLaunchKernelGGL(sp_store_kernel, grid(v1 - v0), dim3(kBlock), 0, stream, vals, w, v0, v1);
-      }
+      SparseInfo* info = sparse_info;
+      replay_levels(0, pl.soff, vals, w, [&] {
+        hipLaunchKernelGGL(sp_info_reset_kernel, dim3(1), dim3(1), 0, stream, info);
+        for (i64 lev = 0; lev < pl.nlev; ++lev) {
+          const i64 b0 = pl.h_lev_blk[lev], b1 = pl.h_lev_blk[lev + 1], r0 = pl.h_lev_row[lev], r1 = pl.h_lev_row[lev + 1];
+          const i64 t0 = pl.h_lev_trip[lev], t1 = pl.h_lev_trip[lev + 1], v0 = pl.h_lev_val[lev], v1 = pl.h_lev_val[lev + 1];
+          hipLaunchKernelGGL(sp_pivot_kernel, grid(b1 - b0), dim3(kBlock), 0, stream, pl, vals, dinv, b0, b1, info);
+          if (r1 > r0) hipLaunchKernelGGL(sp_scale_kernel, grid(r1 - r0), dim3(kBlock), 0, stream, pl, vals, w, dinv, r0, r1);
+          if (t1 > t0) hipLaunchKernelGGL(sp_update_kernel, grid(t1 - t0), dim3(kBlock), 0, stream, pl, vals, w, t0, t1);
+          if (v1 > v0) hipLaunchKernelGGL(sp_store_kernel, grid(v1 - v0), dim3(kBlock), 0, stream, vals, w, v0, v1);
+        }
+      });
       DNLP_LAUNCH_CHECK();
     }
     SparseInfo h;
@@ -1143,24 +1186,26 @@ struct HipExec : HostControlled {
   }
   void sparse_solve(const SparsePlan& pl, const double* vals, double* x) {
     auto grid = [](i64 items) { return dim3(static_cast<unsigned>((items + kBlock - 1) / kBlock)); };
-    if (pl.nblk < kSparseGridMin || !pl.h_lev_blk) {
+    if (!sparse_grid_path(pl)) {
       hipLaunchKernelGGL(sparse_solve_kernel, dim3(1), dim3(kBlock), 0, stream, pl, vals, x);
     } else {
-      for (i64 lev = 0; lev < pl.nlev; ++lev) {
-        const i64 r0 = pl.h_lev_row[lev], r1 = pl.h_lev_row[lev + 1];
-        if (r1 > r0) hipLaunchKernelGGL(sp_fwd_kernel, grid(r1 - r0), dim3(kBlock), 0, stream, pl, vals, x, r0, r1);
-      }
-      hipLaunchKernelGGL(sp_dsolve_kernel, grid(pl.nblk), dim3(kBlock), 0, stream, pl, vals, x);
-      for (i64 lev = pl.nlev - 1; lev >= 0; --lev) {
-        const i64 b0 = pl.h_lev_blk[lev], b1 = pl.h_lev_blk[lev + 1];
-        if (pl.h_lev_row[lev + 1] == pl.h_lev_row[lev]) continue;       // root blocks: empty structs
-        // average struct length of the level decides: a wavefront per block only pays for long structs
-        if ((pl.h_lev_row[lev + 1] - pl.h_lev_row[lev]) < 16 * (b1 - b0))
-          hipLaunchKernelGGL(sp_bwd_thread_kernel, grid(b1 - b0), dim3(kBlock), 0, stream, pl, vals, x, b0, b1);
-        else
-          hipLaunchKernelGGL(sp_bwd_kernel, dim3(static_cast<unsigned>((b1 - b0 + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
-                             stream, pl, vals, x, b0, b1);
-      }
+      replay_levels(1, pl.soff, vals, x, [&] {
+        for (i64 lev = 0; lev < pl.nlev; ++lev) {
+          const i64 r0 = pl.h_lev_row[lev], r1 = pl.h_lev_row[lev + 1];
+          if (r1 > r0) hipLaunchKernelGGL(sp_fwd_kernel, grid(r1 - r0), dim3(kBlock), 0, stream, pl, vals, x, r0, r1);
+        }
+        hipLaunchKernelGGL(sp_dsolve_kernel, grid(pl.nblk), dim3(kBlock), 0, stream, pl, vals, x);
+        for (i64 lev = pl.nlev - 1; lev >= 0; --lev) {
+          const i64 b0 = pl.h_lev_blk[lev], b1 = pl.h_lev_blk[lev + 1];
+          if (pl.h_lev_row[lev + 1] == pl.h_lev_row[lev]) continue;       // root blocks: empty structs
+          // average struct length of the level decides: a wavefront per block only pays for long structs
+          if ((pl.h_lev_row[lev + 1] - pl.h_lev_row[lev]) < 16 * (b1 - b0))
+            hipLaunchKernelGGL(sp_bwd_thread_kernel, grid(b1 - b0), dim3(kBlock), 0, stream, pl, vals, x, b0, b1);
+          else
+            hipLaunchKernelGGL(sp_bwd_kernel, dim3(static_cast<unsigned>((b1 - b0 + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
+                               stream, pl, vals, x, b0, b1);
+        }
+      });
     }
     DNLP_LAUNCH_CHECK();
   }

@@ -26,6 +26,9 @@
 // nneg), and the interior-point loop's delta_w / delta_c regularisation (WB Algorithm IC)
 // repairs it, exactly as for the unpivoted blocked dense path.
 #pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -72,6 +75,12 @@ struct SparsePlanHost {
   std::vector<i32> sblk, tblk;
   i64 nnzL = 0, n_delayed = 0, n_pairs = 0;
   double fill_ratio = 0.0;    // factor values / dense lower triangle
+  // analyse() results: what the numeric phase will cost (known before the layout and the update program,
+  // which are the expensive part of the analysis, are generated), and the state layout() continues from
+  i64 pred_triples = 0, pred_levels = 0;
+  std::vector<std::array<i32, 2>> bn_;
+  std::vector<i32> order_;
+  std::vector<std::vector<i32>> bstruct_;
 
   i64 nblk() const { return static_cast<i64>(doff.size()); }
 
@@ -83,12 +92,25 @@ struct SparsePlanHost {
              const std::vector<i32>& jc, const std::vector<char>& zero_diag_var, const std::vector<char>& eq_row,
              const std::vector<double>& jac_const, const std::vector<char>& fixed_var, int relax = 0,
              const std::vector<double>* jac_abs0 = nullptr) {
+    analyse(N_, m_, hr, hc, jr, jc, zero_diag_var, eq_row, jac_const, fixed_var, relax, jac_abs0);
+    layout(hr, hc, jr, jc, fixed_var);
+  }
+
+  // pairing, elimination order, elimination-tree levels
+  void analyse(i64 N_, i64 m_, const std::vector<i32>& hr, const std::vector<i32>& hc, const std::vector<i32>& jr,
+               const std::vector<i32>& jc, const std::vector<char>& zero_diag_var, const std::vector<char>& eq_row,
+               const std::vector<double>& jac_const, const std::vector<char>& fixed_var, int relax = 0,
+               const std::vector<double>* jac_abs0 = nullptr) {
     *this = SparsePlanHost();
     N = N_; m = m_; n = N + m;
     const i64 nn = n;
     // fixed variables (lb == ub) are pinned by the interior-point loop: unit diagonal, all their
     // couplings masked.  They are isolated nodes of the pattern and never pivot partners.
     auto is_fixed = [&](i32 u) { return u < N && fixed_var[static_cast<size_t>(u)] != 0; };
+    const bool tplan = std::getenv("DNLP_TIME_PLAN") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tp0 = tnow();
+    auto tick = [&](const char* what) { if (tplan) { const double t1 = tnow(); std::fprintf(stderr, "[dnlp plan] %-28s %.3f s\n", what, t1 - tp0); tp0 = t1; } };
     // ---- symmetric adjacency (no diagonal) ----
     std::vector<std::vector<i32>> adj(static_cast<size_t>(nn));
     auto edge = [&](i32 a, i32 b) { if (a != b && !is_fixed(a) && !is_fixed(b)) { adj[static_cast<size_t>(a)].push_back(b); adj[static_cast<size_t>(b)].push_back(a); } };
@@ -173,6 +195,7 @@ struct SparsePlanHost {
       for (i64 i = 0; i < m; ++i) if (eq_row[static_cast<size_t>(i)]) { ++tot; if (partner[static_cast<size_t>(N + i)] < 0) { ++un; if (un <= 5) std::fprintf(stderr, "[plan] unmatched eq row %lld\n", (long long)i); } }
       std::fprintf(stderr, "[plan] equality rows %lld, unmatched %lld\n", (long long)tot, (long long)un);
     }
+    tick("adjacency + matching");
     // ---- blocks ----
     std::vector<i32> blk_of(static_cast<size_t>(nn), -1);
     std::vector<std::array<i32, 2>> bn;
@@ -228,26 +251,15 @@ struct SparsePlanHost {
     std::vector<i64> mark(static_cast<size_t>(nb), -1);
     std::vector<i32> cand;
     i64 round = 0;
-    auto eliminate = [&](i32 b) {
-      gone[static_cast<size_t>(b)] = 1;
-      --remaining;
-      order.push_back(b);
-      std::vector<i32>& nb_ = badj[static_cast<size_t>(b)];
-      bstruct[static_cast<size_t>(b)] = nb_;
-      for (i32 c : nb_) {
-        std::vector<i32>& ac = badj[static_cast<size_t>(c)];
-        merged.clear();
-        std::set_union(ac.begin(), ac.end(), nb_.begin(), nb_.end(), std::back_inserter(merged));
-        ac.clear();
-        for (i32 x : merged) if (x != c && x != b) ac.push_back(x);
-        deg[static_cast<size_t>(c)] = degree(c);
-        ready[static_cast<size_t>(c)] = 1;
-        mark[static_cast<size_t>(c)] = round;
-        pq.push({deg[static_cast<size_t>(c)], c});
-      }
-      nb_.clear();
-      nb_.shrink_to_fit();
-    };
+    // One round eliminates an INDEPENDENT set: no eliminated block is a neighbour of another, so the blocks'
+    // structs are their adjacency lists as they stand, and the fill can be applied per surviving neighbour
+    // ONCE per round -- the union of its own list and the lists of all its eliminated neighbours -- instead
+    // of one merge per (eliminated block, neighbour) pair: a variable coupled to 400 paired rows that all
+    // go in the same round (the NMF example) used to be merged 400 times.
+    std::vector<i32> round_elim, touched;
+    std::vector<std::vector<i32>> contrib(static_cast<size_t>(nb));     // eliminated neighbours of a block, this round
+    std::vector<i64> seen(static_cast<size_t>(nb), -1);
+    i64 stamp = 0;
     while (remaining > 0) {
       // drop stale heads
       while (!pq.empty() && (gone[static_cast<size_t>(pq.top().second)] || pq.top().first != deg[static_cast<size_t>(pq.top().second)])) pq.pop();
@@ -266,12 +278,43 @@ struct SparsePlanHost {
         if (gone[static_cast<size_t>(top.second)] || top.first != deg[static_cast<size_t>(top.second)]) continue;
         cand.push_back(top.second);
       }
+      round_elim.clear();
+      touched.clear();
       for (i32 b : cand) {
         if (gone[static_cast<size_t>(b)]) continue;
-        if (mark[static_cast<size_t>(b)] == round) continue;     // a neighbour went this round (it was re-queued by eliminate)
-        eliminate(b);
+        if (mark[static_cast<size_t>(b)] == round) continue;     // a neighbour goes this round
+        gone[static_cast<size_t>(b)] = 1;
+        --remaining;
+        order.push_back(b);
+        round_elim.push_back(b);
+        for (i32 c : badj[static_cast<size_t>(b)]) {
+          if (contrib[static_cast<size_t>(c)].empty()) touched.push_back(c);
+          contrib[static_cast<size_t>(c)].push_back(b);
+          mark[static_cast<size_t>(c)] = round;
+        }
+      }
+      for (i32 c : touched) {
+        ++stamp;
+        merged.clear();
+        seen[static_cast<size_t>(c)] = stamp;
+        for (i32 x : badj[static_cast<size_t>(c)])
+          if (!gone[static_cast<size_t>(x)] && seen[static_cast<size_t>(x)] != stamp) { seen[static_cast<size_t>(x)] = stamp; merged.push_back(x); }
+        for (i32 b : contrib[static_cast<size_t>(c)])
+          for (i32 x : badj[static_cast<size_t>(b)])
+            if (seen[static_cast<size_t>(x)] != stamp) { seen[static_cast<size_t>(x)] = stamp; merged.push_back(x); }
+        std::sort(merged.begin(), merged.end());
+        badj[static_cast<size_t>(c)].assign(merged.begin(), merged.end());
+        contrib[static_cast<size_t>(c)].clear();
+        deg[static_cast<size_t>(c)] = degree(c);
+        ready[static_cast<size_t>(c)] = 1;
+        pq.push({deg[static_cast<size_t>(c)], c});
+      }
+      for (i32 b : round_elim) {
+        bstruct[static_cast<size_t>(b)] = std::move(badj[static_cast<size_t>(b)]);
+        badj[static_cast<size_t>(b)] = std::vector<i32>();
       }
     }
+    tick("elimination");
     // ---- elimination-tree levels: level-major order is a topological order of the same tree ----
     {
       std::vector<i64> pos0(static_cast<size_t>(nb));
@@ -292,6 +335,33 @@ struct SparsePlanHost {
         if (k == nb || level[static_cast<size_t>(order[static_cast<size_t>(k)])] != level[static_cast<size_t>(order[static_cast<size_t>(k - 1)])]) lev_off.push_back(k);
       if (nb == 0) lev_off.assign(1, 0);
     }
+    pred_levels = static_cast<i64>(lev_off.size()) - 1;
+    pred_triples = 0;
+    for (i64 b = 0; b < nb; ++b) {
+      i64 sz = 0;
+      for (i32 c : bstruct[static_cast<size_t>(b)]) sz += bsize(c);
+      pred_triples += sz * (sz + 1) / 2;
+    }
+    bn_ = std::move(bn);
+    order_ = std::move(order);
+    bstruct_ = std::move(bstruct);
+    tick("levels");
+  }
+
+  // value layout, assembly maps and the update program of the analysed order
+  void layout(const std::vector<i32>& hr, const std::vector<i32>& hc, const std::vector<i32>& jr, const std::vector<i32>& jc,
+              const std::vector<char>& fixed_var) {
+    const bool tplan = std::getenv("DNLP_TIME_PLAN") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tp0 = tnow();
+    auto tick = [&](const char* what) { if (tplan) { const double t1 = tnow(); std::fprintf(stderr, "[dnlp plan] %-28s %.3f s\n", what, t1 - tp0); tp0 = t1; } };
+    const i64 nn = n;
+    auto is_fixed = [&](i32 u) { return u < N && fixed_var[static_cast<size_t>(u)] != 0; };
+    const std::vector<std::array<i32, 2>>& bn = bn_;
+    const std::vector<i32>& order = order_;
+    const std::vector<std::vector<i32>>& bstruct = bstruct_;
+    const i64 nb = static_cast<i64>(bn.size());
+    auto bsize = [&](i32 b) { return bn[static_cast<size_t>(b)][1] >= 0 ? 2 : 1; };
     // ---- layout: values = [D blocks | L blocks], in elimination order ----
     std::vector<i64> pos(static_cast<size_t>(nb));          // elimination position of every block
     for (i64 k = 0; k < nb; ++k) pos[static_cast<size_t>(order[static_cast<size_t>(k)])] = k;
@@ -357,6 +427,7 @@ struct SparsePlanHost {
       if (lo >= s1 || sidx[static_cast<size_t>(lo)] != w) return -1;
       return loff[static_cast<size_t>(ku)] + (lo - s0) * bk + ncol[static_cast<size_t>(u)];
     };
+    tick("layout");
     // ---- assembly maps ----
     hpos.resize(hr.size());
     for (size_t p = 0; p < hr.size(); ++p) hpos[p] = static_cast<i32>(addr(hr[p], hc[p]));
@@ -369,21 +440,51 @@ struct SparsePlanHost {
       if (hpos[p] < 0 && !is_fixed(hr[p]) && !is_fixed(hc[p])) throw std::runtime_error("sparse KKT plan: Hessian entry outside the pattern");
     for (size_t p = 0; p < jr.size(); ++p)
       if (jpos[p] < 0 && !is_fixed(jc[p])) throw std::runtime_error("sparse KKT plan: Jacobian entry outside the pattern");
+    tick("assembly maps");
     // ---- update program ----
+    // Every pair (iu >= iv) of a block's struct updates the entry (S[iu], S[iv]).  For a fixed iv the
+    // destinations live in the struct of S[iv]'s block, which is sorted by the same (block position, node)
+    // key as S: one merge scan per iv instead of a binary search per pair (6e7 pairs in the NMF example).
     toff.assign(static_cast<size_t>(nb + 1), 0);
+    {
+      i64 total = 0;
+      for (i64 k = 0; k < nb; ++k) { const i64 sz = soff[static_cast<size_t>(k + 1)] - soff[static_cast<size_t>(k)]; total += sz * (sz + 1) / 2; }
+      tdst.reserve(static_cast<size_t>(total)); tiu.reserve(static_cast<size_t>(total));
+      tiv.reserve(static_cast<size_t>(total)); tblk.reserve(static_cast<size_t>(total));
+    }
+    std::vector<i32> dtmp;
     for (i64 k = 0; k < nb; ++k) {
-      const i64 s0 = soff[static_cast<size_t>(k)], s = soff[static_cast<size_t>(k + 1)] - s0;
-      for (i64 iu = 0; iu < s; ++iu)
+      const i64 s0 = soff[static_cast<size_t>(k)], sz = soff[static_cast<size_t>(k + 1)] - s0;
+      dtmp.assign(static_cast<size_t>(sz * (sz + 1) / 2), -1);
+      for (i64 iv = 0; iv < sz; ++iv) {
+        const i32 w = sidx[static_cast<size_t>(s0 + iv)];
+        const i64 kw = npos[static_cast<size_t>(w)];
+        const i64 w0 = soff[static_cast<size_t>(kw)], w1 = soff[static_cast<size_t>(kw + 1)];
+        const int bk = bnode[static_cast<size_t>(2 * kw + 1)] >= 0 ? 2 : 1;
+        i64 pcur = w0;
+        for (i64 iu = iv; iu < sz; ++iu) {
+          const i32 u = sidx[static_cast<size_t>(s0 + iu)];
+          i64 a;
+          if (npos[static_cast<size_t>(u)] == kw) {
+            a = (u == w) ? doff[static_cast<size_t>(kw)] + (ncol[static_cast<size_t>(u)] == 0 ? 0 : 2) : doff[static_cast<size_t>(kw)] + 1;
+          } else {
+            while (pcur < w1 && sidx[static_cast<size_t>(pcur)] != u) ++pcur;
+            if (pcur >= w1) throw std::runtime_error("sparse KKT plan: fill entry outside the pattern");
+            a = loff[static_cast<size_t>(kw)] + (pcur - w0) * bk + ncol[static_cast<size_t>(w)];
+          }
+          dtmp[static_cast<size_t>(iu * (iu + 1) / 2 + iv)] = static_cast<i32>(a);
+        }
+      }
+      for (i64 iu = 0; iu < sz; ++iu)
         for (i64 iv = 0; iv <= iu; ++iv) {
-          const i64 a = addr(sidx[static_cast<size_t>(s0 + iu)], sidx[static_cast<size_t>(s0 + iv)]);
-          if (a < 0) throw std::runtime_error("sparse KKT plan: fill entry outside the pattern");
-          tdst.push_back(static_cast<i32>(a));
+          tdst.push_back(dtmp[static_cast<size_t>(iu * (iu + 1) / 2 + iv)]);
           tiu.push_back(static_cast<i32>(iu));
           tiv.push_back(static_cast<i32>(iv));
           tblk.push_back(static_cast<i32>(k));
         }
       toff[static_cast<size_t>(k + 1)] = static_cast<i64>(tdst.size());
     }
+    tick("update program");
     lev_row.clear(); lev_trip.clear(); lev_val.clear();
     for (i64 b : lev_off) {
       lev_row.push_back(soff[static_cast<size_t>(b)]);
@@ -391,6 +492,9 @@ struct SparsePlanHost {
       lev_val.push_back(b < nb ? loff[static_cast<size_t>(b)] : nvals);
     }
     if (nvals >= (static_cast<i64>(1) << 31)) throw std::runtime_error("sparse KKT plan: factor too large for 32-bit addresses");
+    bn_.clear(); bn_.shrink_to_fit();
+    order_.clear(); order_.shrink_to_fit();
+    bstruct_.clear(); bstruct_.shrink_to_fit();
   }
 
   template <class E> SparsePlan upload(E* ex) const {
@@ -423,15 +527,18 @@ inline void build_sparse_plan(const Tape<E>& t, SparsePlanHost& plan, bool bound
   for (i64 i = 0; i < t.m; ++i) eq[static_cast<size_t>(i)] = t.h_cl[static_cast<size_t>(i)] == t.h_cu[static_cast<size_t>(i)];
   // two candidate orders: plain minimum degree, and the relaxed multiple elimination that gives
   // shallow trees on chain-like patterns; the relaxed one is kept unless it costs noticeably more
+  // (both are analysed -- pairing, elimination, levels -- and compared on what the numeric phase will
+  // cost; the value layout and the update program, 80 % of the analysis time, are generated once)
   SparsePlanHost strict;
-  strict.build(t.N, t.m, t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, zero_diag, eq, t.h_jac_const, fixed, 0, jac_abs0);
-  plan.build(t.N, t.m, t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, zero_diag, eq, t.h_jac_const, fixed, 1, jac_abs0);
+  strict.analyse(t.N, t.m, t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, zero_diag, eq, t.h_jac_const, fixed, 0, jac_abs0);
+  plan.analyse(t.N, t.m, t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, zero_diag, eq, t.h_jac_const, fixed, 1, jac_abs0);
   // cost model of the level-parallel numeric phase: a level costs a few barriers, a triple a
   // fraction of that per lane — halving the depth is worth up to 3x the update work
-  const double tr = static_cast<double>(plan.tdst.size()), ts = static_cast<double>(strict.tdst.size());
-  const double lr = static_cast<double>(plan.lev_off.size()), ls = static_cast<double>(strict.lev_off.size());
+  const double tr = static_cast<double>(plan.pred_triples), ts = static_cast<double>(strict.pred_triples);
+  const double lr = static_cast<double>(plan.pred_levels + 1), ls = static_cast<double>(strict.pred_levels + 1);
   const bool relaxed_ok = (lr <= 0.5 * ls && tr <= 3.0 * ts + 64.0) || (lr <= ls && tr <= 1.2 * ts + 64.0);
-  if (!relaxed_ok) plan = strict;
+  if (!relaxed_ok) plan = std::move(strict);
+  plan.layout(t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, fixed);
 }
 
 }  // namespace dnlp

@@ -333,6 +333,7 @@ class HIPNLP:
 
     DEVICE_LOOP_MAX_ORDER = 256          # dense KKT: order up to which one wavefront runs the whole solve
     DEVICE_LOOP_MAX_ORDER_SPARSE = 20000  # sparse static-pattern KKT (csrc/sparse_plan.h)
+    DEVICE_LOOP_MAX_TRIPLES = 150000      # ... whose update program one workgroup can walk in ~0.5 ms
 
     def _use_device_loop(self, data, options, mode) -> bool:
         if mode in (False, "no", "host") or data.get("_intermediate") is not None:
@@ -341,7 +342,11 @@ class HIPNLP:
         order = len(data["x0"]) + len(data["cl"])
         fits = not tape.dense_blocks and not tape.dense_consts
         if fits and order > self.DEVICE_LOOP_MAX_ORDER:
-            fits = order <= self.DEVICE_LOOP_MAX_ORDER_SPARSE and data["handle"].kkt_info()["sparse"]
+            info = data["handle"].kkt_info()
+            # one workgroup factors in-kernel: a long update program (dense-ish fronts) belongs to the
+            # host-driven loop, whose level kernels use the whole chip (small NMF: 1.9 s in-kernel, 0.5 s host-driven)
+            fits = order <= self.DEVICE_LOOP_MAX_ORDER_SPARSE and info["sparse"] and \
+                info.get("update_triples", 0) <= self.DEVICE_LOOP_MAX_TRIPLES
         if mode in (True, "yes", "device"):
             if tape.dense_blocks or tape.dense_consts:
                 raise ValueError("device_loop='yes' needs a tape without dense quad_form blocks")
