@@ -22,6 +22,7 @@
 
 #include "atom_math.h"
 #include "exec.h"
+#include "wave_ops.h"
 #include "sparse_ldl.h"
 
 namespace dnlp {
@@ -54,11 +55,7 @@ __device__ bool bk_factor_wave(AP A, int n, int ld, int* piv, int* nneg_out, int
       const int i = lane + 64 * r;
       if (i > k && i < n) { const double a = fabs(Ak[i]); if (a > v) { v = a; idx = i; } }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-      const double ov = __shfl_xor(v, o, 64);
-      const int oi = __shfl_xor(idx, o, 64);
-      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
+    wave_all_argmax(v, idx);
     double colmax = v;
     int imax = idx;
     if (colmax < 0.0) { colmax = 0.0; imax = k; }
@@ -72,7 +69,7 @@ __device__ bool bk_factor_wave(AP A, int n, int ld, int* piv, int* nneg_out, int
       double rv = 0.0;
       for (int j = k + lane; j < imax; j += 64) rv = fmax(rv, fabs(A[imax + j * ld]));
       for (int i = imax + 1 + lane; i < n; i += 64) rv = fmax(rv, fabs(A[i + imax * ld]));
-      for (int o = 32; o > 0; o >>= 1) rv = fmax(rv, __shfl_xor(rv, o, 64));
+      rv = wave_all_max(rv);
       const double rowmax = rv;
       const double aii = fabs(A[imax + imax * ld]);
       if (absakk >= alpha * colmax * (colmax / rowmax)) kp = k;
@@ -402,7 +399,8 @@ __device__ void bk_solve_wave(AP A, int n, int ld, const int* piv, double* v) {
       s0 += Ak[i] * bi;
       if (!one) s1 += Akm[i] * bi;
     }
-    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+    s0 = wave_all_sum(s0);
+    if (!one) s1 = wave_all_sum(s1);
     if (lane == 0) {
       v[k] -= s0;
       if (!one) v[k - 1] -= s1;
@@ -510,10 +508,7 @@ struct BlockExecT {
       else if (MODE == 1) acc = fmax(acc, v != v ? kInf : v);
       else { v = v != v ? -kInf : v; acc = fmax(acc, -v); }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-      const double other = __shfl_xor(acc, o, 64);
-      acc = MODE == 0 ? acc + other : fmax(acc, other);
-    }
+    acc = MODE == 0 ? wave_all_sum(acc) : wave_all_max(acc);
     if constexpr (NT == 64) return MODE == 2 ? -acc : acc;     // the butterfly left the result in every lane
     double* buf = red + 4 * parity;
     parity ^= 1;
@@ -538,12 +533,10 @@ struct BlockExecT {
 #pragma unroll
       for (int k = 0; k < NS; ++k) r.sm[k] += v.sm[k];
     }
-    for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
-      for (int k = 0; k < NM; ++k) r.mx[k] = fmax(r.mx[k], __shfl_xor(r.mx[k], o, 64));
+    for (int k = 0; k < NM; ++k) r.mx[k] = wave_all_max(r.mx[k]);
 #pragma unroll
-      for (int k = 0; k < NS; ++k) r.sm[k] += __shfl_xor(r.sm[k], o, 64);
-    }
+    for (int k = 0; k < NS; ++k) r.sm[k] = wave_all_sum(r.sm[k]);
     if constexpr (NT == 64) return r;
     // several wavefronts: one value at a time through the two-slot staging buffer of reduce()
 #pragma unroll
@@ -567,10 +560,8 @@ struct BlockExecT {
       a0 = fmax(a0, v.first != v.first ? kInf : -v.first);
       a1 = fmax(a1, v.second != v.second ? kInf : -v.second);
     }
-    for (int o = 32; o > 0; o >>= 1) {
-      a0 = fmax(a0, __shfl_xor(a0, o, 64));
-      a1 = fmax(a1, __shfl_xor(a1, o, 64));
-    }
+    a0 = wave_all_max(a0);
+    a1 = wave_all_max(a1);
     if constexpr (NT == 64) return D2{-a0, -a1};
     double* buf = red + 4 * parity;
     parity ^= 1;
@@ -589,11 +580,7 @@ struct BlockExecT {
 
   // block-wide argmax of v (first index wins ties, as IDAMAX); every lane gets the result
   __device__ void argmax(double v, int idx, double& outv, int& outi) {
-    for (int o = 32; o > 0; o >>= 1) {
-      const double ov = __shfl_xor(v, o, 64);
-      const int oi = __shfl_xor(idx, o, 64);
-      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
+    wave_all_argmax(v, idx);
     if constexpr (NT == 64) { outv = v; outi = idx; return; }
     double* bv = red + 4 * parity;
     int* bi = redi + 4 * parity;
@@ -614,7 +601,7 @@ struct BlockExecT {
     __device__ void sync() const { __syncthreads(); }
     __device__ void add(double* p, double v) const { unsafeAtomicAdd(p, v); }
     __device__ double sum(double v) const {
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      v = wave_all_sum(v);
       if constexpr (NT == 64) return v;
       double* buf = ex->red + 4 * ex->parity;
       ex->parity ^= 1;

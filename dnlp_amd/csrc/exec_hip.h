@@ -18,6 +18,7 @@
 
 #include "atom_math.h"
 #include "exec.h"
+#include "wave_ops.h"
 #include <chrono>
 #include "fused_obj.h"
 #include "fused_codegen.h"
@@ -50,14 +51,8 @@ __global__ void __launch_bounds__(kBlock) map_kernel(i64 off, i64 n, F f) {
   if (i < n) f(i);
 }
 
-__device__ inline double wave_sum(double v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
-}
-__device__ inline double wave_max(double v) {
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
-  return v;
-}
+__device__ inline double wave_sum(double v) { return wave_all_sum(v); }
+__device__ inline double wave_max(double v) { return wave_all_max(v); }
 
 // mode 0 sum, 1 max (NaN -> +inf), 2 min (NaN -> -inf)
 template <int MODE, class F>
@@ -256,42 +251,11 @@ struct BkState {
 
 constexpr int BK_T = 1024;
 
-// wave-wide max of a non-negative double / min of an int on DPP row shifts and row broadcasts (no LDS
-// round trips: ds_bpermute shuffles cost ~120 cycles each, a block argmax was 18 of them in sequence)
-template <int CTRL, int ROW_MASK>
-__device__ inline double bk_dpp_max(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
-  return fmax(v, __hiloint2double(hi, lo));
-}
-template <int CTRL, int ROW_MASK>
-__device__ inline int bk_dpp_min(int v) {
-  return min(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false));
-}
-__device__ inline double bk_wave_max(double v) {
-  v = bk_dpp_max<0x111, 0xf>(v);     // row_shr:1
-  v = bk_dpp_max<0x112, 0xf>(v);     // row_shr:2
-  v = bk_dpp_max<0x114, 0xf>(v);     // row_shr:4
-  v = bk_dpp_max<0x118, 0xf>(v);     // row_shr:8   -> lane 15 of every row holds the row's maximum
-  v = bk_dpp_max<0x142, 0xa>(v);     // row_bcast:15 into rows 1, 3
-  v = bk_dpp_max<0x143, 0xc>(v);     // row_bcast:31 into rows 2, 3 -> lane 63 holds the wavefront's maximum
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
-}
-__device__ inline int bk_wave_min(int v) {
-  v = bk_dpp_min<0x111, 0xf>(v);
-  v = bk_dpp_min<0x112, 0xf>(v);
-  v = bk_dpp_min<0x114, 0xf>(v);
-  v = bk_dpp_min<0x118, 0xf>(v);
-  v = bk_dpp_min<0x142, 0xa>(v);
-  v = bk_dpp_min<0x143, 0xc>(v);
-  return __builtin_amdgcn_readlane(v, 63);
-}
-
 // block-wide argmax of v >= 0 (v = -1: the lane has no candidate); the smallest index wins ties, as IDAMAX
 __device__ inline void bk_argmax(double v, int idx, double* sv, int* si, double& outv, int& outi) {
   const bool has = v >= 0.0;
-  const double m = bk_wave_max(has ? v : 0.0);
-  const int cand = bk_wave_min((has && v == m) ? idx : 0x7fffffff);
+  const double m = wave_all_max(has ? v : 0.0);
+  const int cand = wave_all_min((has && v == m) ? idx : 0x7fffffff);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) { sv[wid] = cand == 0x7fffffff ? -1.0 : m; si[wid] = cand; }
   __syncthreads();
