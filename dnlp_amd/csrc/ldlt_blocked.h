@@ -588,8 +588,10 @@ __global__ void __launch_bounds__(SV_B) ldlt_fwd_diag(const double* __restrict__
       const bool mine = t >= s0 && t < s1;
 #pragma unroll
       for (int kk = 0; kk < 32; ++kk) {
-        const double yk = __shfl(v, (s0 + kk) & 63, 64);
-        v -= (mine && s0 + kk < t) ? cur[kk] * yk : 0.0;
+        // the masked multiplier does not depend on v: the chain is v_readlane -> one FMA per step
+        const double ck = (mine && s0 + kk < t) ? -cur[kk] : 0.0;
+        const double yk = ldlt_bcast(v, __builtin_amdgcn_readfirstlane((s0 + kk) & 63));   // uniform lane: v_readlane, not ds_bpermute
+        v = fma(ck, yk, v);
       }
       if (mine) y[t] = v;
     }
@@ -608,25 +610,33 @@ __global__ void __launch_bounds__(SV_B) ldlt_fwd_diag(const double* __restrict__
   }
   if (t < jb) b[j0 + t] = v;
 }
-// rows below the block: b[r] -= sum_t A[r, j0+t] y[t]  (one row per lane, coalesced columns)
+// rows below the block: b[r] -= sum_t A[r, j0+t] y[t].  A workgroup takes 64 rows; its four wavefronts
+// split the block's columns (64 loads per lane instead of 256, four times the workgroups: the kernel is
+// bound by the per-lane load chain, not by bandwidth) and meet in LDS.
 __global__ void __launch_bounds__(256) ldlt_fwd_update(const double* __restrict__ A, i64 ld, int j0, int jb,
                                                        int n, double* __restrict__ b) {
   __shared__ double y[SV_B];
+  __shared__ double part[4][64];
   if (threadIdx.x < jb) y[threadIdx.x] = b[j0 + threadIdx.x];
   __syncthreads();
-  const i64 r = static_cast<i64>(j0) + jb + static_cast<i64>(blockIdx.x) * 256 + threadIdx.x;
-  if (r >= n) return;
-  const double* row = A + r + static_cast<i64>(j0) * ld;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const i64 r = static_cast<i64>(j0) + jb + static_cast<i64>(blockIdx.x) * 64 + lane;
+  const int c0 = w * 64, c1 = (c0 + 64 < jb) ? c0 + 64 : jb;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int t = 0;
-  for (; t + 4 <= jb; t += 4) {
-    s0 += row[static_cast<i64>(t) * ld] * y[t];
-    s1 += row[static_cast<i64>(t + 1) * ld] * y[t + 1];
-    s2 += row[static_cast<i64>(t + 2) * ld] * y[t + 2];
-    s3 += row[static_cast<i64>(t + 3) * ld] * y[t + 3];
+  if (r < n) {
+    const double* row = A + r + static_cast<i64>(j0) * ld;
+    int t = c0;
+    for (; t + 4 <= c1; t += 4) {
+      s0 += row[static_cast<i64>(t) * ld] * y[t];
+      s1 += row[static_cast<i64>(t + 1) * ld] * y[t + 1];
+      s2 += row[static_cast<i64>(t + 2) * ld] * y[t + 2];
+      s3 += row[static_cast<i64>(t + 3) * ld] * y[t + 3];
+    }
+    for (; t < c1; ++t) s0 += row[static_cast<i64>(t) * ld] * y[t];
   }
-  for (; t < jb; ++t) s0 += row[static_cast<i64>(t) * ld] * y[t];
-  b[r] -= (s0 + s1) + (s2 + s3);
+  part[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && r < n) b[r] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 __global__ void __launch_bounds__(256) ldlt_diag_scale(const double* A, i64 ld, int n, double* b) {
   const i64 i = static_cast<i64>(blockIdx.x) * 256 + threadIdx.x;
@@ -681,8 +691,9 @@ __global__ void __launch_bounds__(SV_B) ldlt_bwd_diag(const double* __restrict__
       const bool mine = t >= s0 && t < s1;
 #pragma unroll
       for (int kk = 31; kk >= 0; --kk) {
-        const double xk = __shfl(v, (s0 + kk) & 63, 64);
-        v -= (mine && s0 + kk > t && s0 + kk < s1) ? cur[kk] * xk : 0.0;
+        const double ck = (mine && s0 + kk > t && s0 + kk < s1) ? -cur[kk] : 0.0;
+        const double xk = ldlt_bcast(v, __builtin_amdgcn_readfirstlane((s0 + kk) & 63));
+        v = fma(ck, xk, v);
       }
       if (mine) xs[t] = v;
     }
@@ -896,7 +907,7 @@ struct BlockedLdlt {
       hipLaunchKernelGGL(ldlt_fwd_diag, dim3(1), dim3(SV_B), 0, ex->stream, A, ld, j0, jb, b);
       const int rows = ni - j0 - jb;
       if (rows > 0)
-        hipLaunchKernelGGL(ldlt_fwd_update, dim3((rows + 255) / 256), dim3(256), 0, ex->stream, A, ld, j0, jb, ni, b);
+        hipLaunchKernelGGL(ldlt_fwd_update, dim3((rows + 63) / 64), dim3(256), 0, ex->stream, A, ld, j0, jb, ni, b);
     }
     hipLaunchKernelGGL(ldlt_diag_scale, dim3((ni + 255) / 256), dim3(256), 0, ex->stream, A, ld, ni, b);
     ex->zero(acc, sizeof(double) * SV_B);
