@@ -739,6 +739,10 @@ struct BlockedLdlt {
   void init(HipExec* e, i64 n_, i64 ld_) {
     ex = e; n = n_; ld = ld_;
     ldw = (n + 7) / 8 * 8;
+    // wide outer panels for large orders: the update kernel runs at the same rate for K = 512 / 768 / 1024
+    // (62.3 +- 0.2 TF at n = 1e5) and half the panels means half the exposed panel heads and tails
+    // (n = 1e5: 5.46 -> 5.37 s per factorisation); mid-size orders measured flat between 256 and 768
+    if (n >= 32768) NB = 1024;
     if (const char* ev = std::getenv("DNLP_LDLT_NB")) NB = std::atoi(ev);
     if (const char* ev = std::getenv("DNLP_LDLT_LOOKAHEAD")) lookahead = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_XCD")) xcd_swizzle = std::atoi(ev) != 0;

@@ -120,7 +120,7 @@ def _ldlt(A, pivoted, rhs):
     return sol, nneg.value, nzero.value, sec.value
 
 
-@pytest.mark.parametrize("n", [1, 2, 7, 64, 257, 600])
+@pytest.mark.parametrize("n", [1, 2, 7, 33, 64, 257, 600, 1100])
 def test_pivoted_ldlt_indefinite(n, gpu_required):
     """Bunch-Kaufman path on symmetric indefinite KKT-shaped matrices with a zero (2,2) block:
     solve residual and inertia vs numpy."""
@@ -131,6 +131,12 @@ def test_pivoted_ldlt_indefinite(n, gpu_required):
     J = rng.standard_normal((n - nh, nh))
     A = np.block([[H, J.T], [J, np.zeros((n - nh, n - nh))]]) if n > nh else H
     b = rng.standard_normal(n)
+    if nh > 6:
+        # variables without curvature: their columns can only be eliminated by 2x2 pivots, which then land on
+        # every position relative to the 32-column blocks of the one-workgroup solve
+        H[:nh // 3, :] = 0.0
+        H[:, :nh // 3] = 0.0
+        A = np.block([[H, J.T], [J, np.zeros((n - nh, n - nh))]])
     sol, nneg, nzero, _ = _ldlt(A, True, b)
     ev = np.linalg.eigvalsh(A)
     assert nzero == 0

@@ -158,3 +158,30 @@ def test_c2_canonical_form_through_the_interior_point_loop(gpu_required):
     assert prob.status == "optimal"
     assert np.max(np.abs(prob.variables()[0].value - 1.0)) <= 1e-6
     assert info["iterations"] <= 60
+
+
+@pytest.mark.gpu
+def test_level_graph_replay_is_the_same_computation(gpu_required, monkeypatch):
+    """The host-driven sparse factorisation / solves replay their level loops as HIP graphs
+    (HipExec::replay_levels).  A replay launches the very same kernels with the same arguments, so the solve
+    of a problem large enough for the chip-wide level kernels (small NMF: order 10 836, 9.5e5 update
+    triples) must land on the same point as the direct launches (the update kernels add with FP64 atomics, so
+    the two runs agree to rounding, not bit for bit)."""
+    import dnlp_amd as cp
+    from paper_examples import PAPER
+    runs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DNLP_LEVEL_GRAPHS", flag)
+        prob = PAPER["nb_nmf_small"](cp)
+        chain = prob._build_chain(None)
+        data, inv = chain.apply(prob)
+        info_k = data["handle"].kkt_info()
+        assert info_k["sparse"] and info_k["update_triples"] > 200000      # the level-kernel path, host-driven loop
+        info = chain.solver.solve_via_data(data, True, False, {})
+        assert info.get("device_loop") is not True
+        runs.append(info)
+    a, b = runs
+    assert a["status"] == b["status"] == 0
+    assert abs(a["iterations"] - b["iterations"]) <= 2
+    np.testing.assert_allclose(a["x"], b["x"], rtol=0, atol=1e-6)
+    assert abs(a["obj_val"] - b["obj_val"]) <= 1e-9 * max(1.0, abs(b["obj_val"]))

@@ -6,10 +6,10 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM
   tag=$(echo $C | cut -d' ' -f1)
   timeout 500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/r02g/pmc_bench_$tag -- python3 bench.py --steps 1 --warmup 0 --no-cpu > gpurun_out/r02g/pmc_bench_$tag.log 2>&1 < /dev/null
 done
-python3 tools/pmc_summary.py gpurun_out/r02g/pmc_bench.json gpurun_out/r02g/pmc_bench_FETCH_SIZE gpurun_out/r02g/pmc_bench_WRITE_SIZE gpurun_out/r02g/pmc_bench_SQ_VALU_MFMA_BUSY_CYCLES --kernel gemm_nt_update_fast --min-ms 1.0 | head -40
+python3 tools/pmc_summary.py gpurun_out/r02g/pmc_bench.json gpurun_out/r02g/pmc_bench_FETCH_SIZE gpurun_out/r02g/pmc_bench_WRITE_SIZE gpurun_out/r02g/pmc_bench_SQ_VALU_MFMA_BUSY_CYCLES --kernel gemm_nt_update_fast --update-queue | head -40
 # the XCD-aware 8 x 8 super-tile order (DNLP_LDLT_XCD=1, off by default): traffic and speed of the same command
 DNLP_LDLT_XCD=1 timeout 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/r02g/pmc_bench_xcd_FETCH_SIZE -- python3 bench.py --steps 1 --warmup 0 --no-cpu > gpurun_out/r02g/pmc_bench_xcd_FETCH.log 2>&1 < /dev/null
-python3 tools/pmc_summary.py gpurun_out/r02g/pmc_bench_xcd.json gpurun_out/r02g/pmc_bench_xcd_FETCH_SIZE --kernel gemm_nt_update_fast --min-ms 1.0 | head -20
+python3 tools/pmc_summary.py gpurun_out/r02g/pmc_bench_xcd.json gpurun_out/r02g/pmc_bench_xcd_FETCH_SIZE --kernel gemm_nt_update_fast --update-queue | head -20
 DNLP_LDLT_XCD=1 timeout 300 python3 bench.py --steps 2 --warmup 1 --no-cpu > gpurun_out/r02g/bench_xcd.json 2> gpurun_out/r02g/bench_xcd.err < /dev/null
 timeout 300 python3 bench.py --steps 2 --warmup 1 --no-cpu > gpurun_out/r02g/bench_default.json 2> gpurun_out/r02g/bench_default.err < /dev/null
 python3 -c "

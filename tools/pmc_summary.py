@@ -1,8 +1,10 @@
 """Summarise rocprofv3 --pmc passes (csv output): per kernel, the number of dispatches and the sum / mean
 of every counter found under the given directories.
 
-    python tools/pmc_summary.py out.json dir1 [dir2 ...] [--kernel substring] [--min-ms X]
-(--min-ms keeps dispatches that ran at least X ms: e.g. the outer Schur-complement updates of bench.py.)
+    python tools/pmc_summary.py out.json dir1 [dir2 ...] [--kernel substring] [--min-ms X] [--update-queue]
+(--min-ms keeps dispatches that ran at least X ms.  --update-queue keeps, per file, only the dispatches on
+the queue of the kernel's largest grid: bench.py's outer Schur-complement updates run on their own stream,
+the panel-internal launches of the same kernel on the other one.)
 
 FETCH_SIZE / WRITE_SIZE are reported in bytes with the gfx950 correction of MI355X_MICROARCH.md (HBM
 section): rocprofv3 gives KB; FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads, so it is
@@ -28,14 +30,25 @@ def main():
         i = args.index("--min-ms")
         min_ms = float(args[i + 1])
         del args[i:i + 2]
+    update_queue = "--update-queue" in args
+    if update_queue:
+        args.remove("--update-queue")
     acc = defaultdict(lambda: defaultdict(float))
     dur = defaultdict(lambda: defaultdict(float))
     cnt = defaultdict(lambda: defaultdict(int))
     for d in args:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-            for r in csv.DictReader(open(f)):
+            rows = list(csv.DictReader(open(f)))
+            queue = None
+            if update_queue:
+                sel = [r for r in rows if not kernel_filter or kernel_filter in r.get("Kernel_Name", "")]
+                if sel:
+                    queue = max(sel, key=lambda r: int(r.get("Grid_Size", 0)))["Queue_Id"]
+            for r in rows:
                 k = r.get("Kernel_Name", "")
                 if kernel_filter and kernel_filter not in k:
+                    continue
+                if queue is not None and r.get("Queue_Id") != queue:
                     continue
                 c = r.get("Counter_Name")
                 ms = (float(r.get("End_Timestamp", 0)) - float(r.get("Start_Timestamp", 0))) * 1e-6
