@@ -297,7 +297,7 @@ class ProblemHandle:
             raise RuntimeError("kkt_info failed: %s" % self.api.error())
         return {"sparse": bool(out[0]), "factor_values": int(out[1]), "pivot_blocks": int(out[2]),
                 "max_struct": int(out[3]), "pairs_2x2": int(out[4]), "update_triples": int(out[5]),
-                "levels": int(out[6])}
+                "levels": int(out[6]), "dense_pivoted": bool(out[7])}
 
     def reset_options(self):
         self.api.reset_options(self.ptr)

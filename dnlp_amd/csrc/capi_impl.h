@@ -188,7 +188,7 @@ struct ProblemT {
     else if (k == "warm_start_bound_push") opt.warm_start_bound_push = num();
     else if (k == "warm_start_bound_frac") opt.warm_start_bound_frac = num();
     else if (k == "warm_start_mult_bound_push") opt.warm_start_mult_bound_push = num();
-    else if (k == "kkt_pivot_max_n") pivot_max_n = std::min<i64>(static_cast<i64>(num()), 4096);   // the pivoted solve keeps its vector in LDS
+    else if (k == "kkt_pivot_max_n") pivot_max_n = std::min<i64>(static_cast<i64>(num()), E::kPivotedMaxOrder);
     else if (k == "kkt_optimistic_min_n") optimistic_min_n = static_cast<i64>(num());
     else if (k == "lazy_dense_fallback") opt.lazy_dense_fallback = yes() ? 1 : 0;
     else if (k == "restoration") opt.restoration = yes() ? 1 : 0;
@@ -390,7 +390,8 @@ struct ProblemT {
              out[0] = p->use_sparse ? 1 : 0; out[1] = p->sparse_plan.nnzL; out[2] = p->sparse_plan.nblk(); \
              out[3] = p->sparse_plan.maxs; out[4] = p->sparse_plan.n_pairs;                          \
              out[5] = static_cast<int64_t>(p->sparse_plan.tdst.size());                                 \
-             out[6] = static_cast<int64_t>(p->sparse_plan.lev_off.size()) - 1; return 0;)                    \
+             out[6] = static_cast<int64_t>(p->sparse_plan.lev_off.size()) - 1;                              \
+             out[7] = (!p->use_sparse && p->model.t.N + p->model.t.m <= p->pivot_max_n) ? 1 : 0; return 0;)  \
   }                                                                                                  \
   int DNLP_CAT(PFX, get_stats)(HANDLE* vp, double* s, int n) {                                         \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \

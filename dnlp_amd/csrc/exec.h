@@ -57,6 +57,9 @@ struct HostControlled {
   static constexpr bool has_log = true;
   static constexpr bool has_host_control = true;
   static constexpr int kFilterCap = 1024;
+  // largest order the space's pivoted (Bunch-Kaufman) factorisation accepts; HipExec narrows it (its solve keeps
+  // the vector in LDS), the host space's LAPACK backend has no such limit
+  static constexpr long long kPivotedMaxOrder = 1LL << 40;
   struct Log {
     std::vector<std::string> lines;
     void append(const Log& o) { lines.insert(lines.end(), o.lines.begin(), o.lines.end()); }

@@ -889,6 +889,7 @@ __global__ void __launch_bounds__(kBlock) sp_bwd_thread_kernel(SparsePlan pl, co
 struct BlockedLdlt;   // ldlt_blocked.h
 
 struct HipExec : HostControlled {
+  static constexpr long long kPivotedMaxOrder = 4096;      // = BK_NMAX: bk_solve_kernel / bk_finish_kernel LDS arrays
   static constexpr bool is_device = true;
   using FlatTableT = FlatTable;
   int device = 0;

@@ -162,7 +162,8 @@ int dnlp_set_warm_start(dnlp_problem* p, const double* mult_g, const double* mul
 /* Linear-solver plan of the handle (decided once, from the sparsity pattern of the tape):
  * out[0] = 1 static-pattern sparse LDL^T / 0 dense, out[1] = factor values, out[2] = pivot blocks,
  * out[3] = largest block struct, out[4] = static 2x2 pivot pairs, out[5] = update triples,
- * out[6] = elimination-tree levels (out has room for 8 values).
+ * out[6] = elimination-tree levels, out[7] = 1 when the dense path is the pivoted (Bunch-Kaufman)
+ * factorisation (order <= kkt_pivot_max_n; the device space accepts at most 4096 there) (8 values).
  * `dnlp_set_option(p, "linear_solver", "dense" | "sparse")` forces a path before the first solve. */
 int dnlp_kkt_info(dnlp_problem* p, int64_t* out8);
 /* Statistics (n <= 24 values).  Of the last solve: stats[0..12] = iterations, factorizations, wall,

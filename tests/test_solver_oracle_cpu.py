@@ -362,3 +362,33 @@ def test_second_solve_reuses_the_lowered_tape_and_handle():
         q.solve(nlp=True)
         assert q._nlp_cache["data"]["handle"] is not h2
         assert np.allclose(y.value, [0.5, 0.5], atol=1e-6) and abs(q.value - 2 * 2.5 ** 2) < 1e-6
+
+
+def test_pivoted_order_limit_is_a_property_of_the_execution_space():
+    """`kkt_pivot_max_n` above 4096 is clamped on the device space only (its one-workgroup Bunch-Kaufman solve
+    keeps the vector in LDS).  The host space has no such limit: bench.py's cpu_baseline relies on the pivoted
+    (LAPACK DSYTRF) factorisation at n = 1e4 -- clamped there, it silently fell back to the scalar unpivoted
+    LDL^T and the default bench ran into its time limit."""
+    import dnlp_amd as cp
+    from dnlp_amd.dnlp2smooth import Dnlp2Smooth
+    from dnlp_amd.nlp_solver import build_nlp_data
+    from dnlp_amd.tape import serialize
+    from oracle.oracle_capi import OracleProblem
+    n = 4200
+    rng = np.random.default_rng(0)
+    d = rng.uniform(1.0, 2.0, n)
+    x = cp.Variable(n)
+    x.value = np.ones(n) / np.sqrt(n)
+    Q = np.diag(d)
+    Q[0, 1] = Q[1, 0] = 0.25                           # a dense constant block, not a diagonal the lowering could split
+    prob = cp.Problem(cp.Minimize(-cp.quad_form(x, Q)), [cp.sum_squares(x) == 1])
+    smooth, _ = Dnlp2Smooth().apply(prob)
+    data, _ = build_nlp_data(smooth)
+    orc = OracleProblem(serialize(data["tape_arrays"]))
+    try:
+        assert not orc.kkt_info()["dense_pivoted"]     # default kkt_pivot_max_n = 2048 < order 4201
+        orc.set_option("kkt_pivot_max_n", 10 ** 9)
+        info = orc.kkt_info()
+        assert not info["sparse"] and info["dense_pivoted"]
+    finally:
+        orc.close()

@@ -183,5 +183,5 @@ def test_level_graph_replay_is_the_same_computation(gpu_required, monkeypatch):
     a, b = runs
     assert a["status"] == b["status"] == 0
     assert abs(a["iterations"] - b["iterations"]) <= 2
-    np.testing.assert_allclose(a["x"], b["x"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(a["x"], b["x"], rtol=1e-7, atol=1e-7)
     assert abs(a["obj_val"] - b["obj_val"]) <= 1e-9 * max(1.0, abs(b["obj_val"]))
