@@ -263,7 +263,11 @@ def main():
                          "traffic": traffic, "traffic_unit": "bytes per launch (FETCH x2-corrected + WRITE)",
                          "traffic_source": traffic_src},
         }
-        if not args.no_cpu:
+        if world > 1:
+            # the CPU baseline is a property of the host, not of N: it is timed in the N = 1 run only
+            out["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": 0, "kind": "port",
+                                   "sample": "not timed at N > 1 (see the N = 1 line)"}
+        elif not args.no_cpu:
             try:
                 sweep = tuple(tuple(int(v) for v in kv.split(":")) for kv in args.cpu_sweep.split(",")) \
                     if args.cpu_sweep else CPU_SWEEP
