@@ -936,6 +936,9 @@ inline void HipExec::ldlt_prepare(LdltWork& w, i64 n, i64 ld, bool pivoted) {
     w.st = alloc<BkState>(1);
     w.bk_perm = alloc<i32>(static_cast<size_t>(n));
     w.bk_dtype = alloc<i32>(static_cast<size_t>(n));
+    w.bk_w = alloc<double>(static_cast<size_t>((n + 7) / 8 * 8) * 16);
+    w.bk_swaps = alloc<BkPanelSwaps>(1);
+    if (const char* ev = std::getenv("DNLP_BK_PANELS")) w.bk_panels = std::atoi(ev) != 0;
   } else {
     w.blocked = new BlockedLdlt();
     w.blocked->init(this, n, ld);
