@@ -60,6 +60,8 @@ struct HostControlled {
   // largest order the space's pivoted (Bunch-Kaufman) factorisation accepts; HipExec narrows it (its solve keeps
   // the vector in LDS), the host space's LAPACK backend has no such limit
   static constexpr long long kPivotedMaxOrder = 1LL << 40;
+  // a dense m x m condensed least-squares multiplier start on the space's GEMM (HipExec: FP64 MFMA)
+  static constexpr bool has_condensed_ls = false;
   struct Log {
     std::vector<std::string> lines;
     void append(const Log& o) { lines.insert(lines.end(), o.lines.begin(), o.lines.end()); }

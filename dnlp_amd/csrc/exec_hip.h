@@ -1259,6 +1259,7 @@ struct BlockedLdlt;   // ldlt_blocked.h
 
 struct HipExec : HostControlled {
   static constexpr long long kPivotedMaxOrder = 4096;      // = BK_NMAX: bk_solve_kernel / bk_finish_kernel LDS arrays
+  static constexpr bool has_condensed_ls = true;
   static constexpr bool is_device = true;
   using FlatTableT = FlatTable;
   int device = 0;
@@ -1744,6 +1745,13 @@ struct HipExec : HostControlled {
   void ldlt_prepare(LdltWork& w, i64 n, i64 ld, bool pivoted);
   bool ldlt_factor(LdltWork& w, double* A, i64 n, i64 ld, i32* ipiv, bool pivoted, int* nneg, int* nzero);
   void ldlt_solve(LdltWork& w, const double* A, i64 n, i64 ld, const i32* ipiv, bool pivoted, double* b);
+  // least-squares multipliers of [I J^T; J -D][x; y] = [rx; ry] through the m x m Schur complement
+  // S = -(D + J J^T): one K = N pass of the MFMA update kernel, an order-m LDL^T, one solve (ldlt_blocked.h).
+  // jd_rhs: J rx (m values); y receives the multipliers.  False: not applicable / not definite.
+  struct CondensedLs { BlockedLdlt* ldlt = nullptr; double* Jd = nullptr; double* S = nullptr; i64 N = 0, m = 0, Npad = 0, lds = 0; };
+  CondensedLs cls_;
+  bool condensed_ls(i64 N, i64 m, i64 nnzJ, const i32* jr, const i32* jc, const double* jv, const double* fixmask,
+                    const double* Dd, const double* ry_minus_Jrx, double* y);
 
   // panel-blocked Bunch-Kaufman: ROWS x 1024 rows, NBP-column panels (bk_panel_kernel)
   template <int ROWS, int NBP>

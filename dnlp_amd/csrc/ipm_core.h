@@ -448,6 +448,28 @@ class Ipm {
     double *sx = Sx, *dd = Dd;
     ex_->map(N, [=] DNLP_HD(i64 j) { sx[j] = 1.0; });
     ex_->map(m, [=] DNLP_HD(i64 i) { dd[i] = (eq[i] == 0.0) ? 1.0 : 0.0; });
+    if constexpr (E::has_condensed_ls) if (!kkt_->pivoted && !kkt_->sparse && m > 8 && 4 * m <= N) {
+      // A moderate number of rows on a large dense system (BASELINE C3: m = 1e3, N = 1e4): the identity (1,1)
+      // block condenses the least-squares system to S y = r_y - J r_x with S = -(D + J J^T), one MFMA pass over
+      // J and an order-m factorisation instead of an O((N + m)^3) one.
+      double* r = rhs;
+      const double *gr = grad, *a = zL, *b = zU, *c = vL, *d = vU, *fm = fixmask;
+      const i64 NN = N;
+      ex_->map(N, [=] DNLP_HD(i64 j) { r[j] = fm[j] != 0.0 ? 0.0 : -(gr[j] - a[j] + b[j]); });
+      md_->jac_mult(jv, rhs, sol);                                 // sol[0..m) = J r_x
+      double* t = sol;
+      ex_->map(m, [=] DNLP_HD(i64 i) { t[i] = ((eq[i] == 0.0) ? -(-c[i] + d[i]) : 0.0) - t[i]; });
+      if (ex_->condensed_ls(N, m, md_->t.nnzJ, md_->t.jac_rows, md_->t.jac_cols, jv, fixmask, Dd, sol, sol + m)) {
+        const double* so = sol + m;
+        const double ymax = ex_->max(m, [=] DNLP_HD(i64 i) { return fabs(so[i]); });
+        if (std::isfinite(ymax) && ymax <= opt.constr_mult_init_max) {
+          double* yy = y;
+          ex_->map(m, [=] DNLP_HD(i64 i) { yy[i] = so[i]; });
+        }
+        (void)NN;
+        return;
+      }
+    }
     int nneg = 0, nzero = 0;
     md_->clear_dense_w();
     ex_->zero(md_->Hs, sizeof(double) * static_cast<size_t>(md_->t.nnzH));

@@ -930,6 +930,39 @@ struct BlockedLdlt {
   }
 };
 
+inline bool HipExec::condensed_ls(i64 N, i64 m, i64 nnzJ, const i32* jr, const i32* jc, const double* jv,
+                                  const double* fixmask, const double* Dd, const double* rhs_y, double* y) {
+  const i64 Npad = (N + 15) / 16 * 16;
+  if (m < 2 || (m & 1) || static_cast<double>(m) * static_cast<double>(Npad) * 8.0 > 2.0e9) return false;
+  if (!cls_.ldlt || cls_.N != N || cls_.m != m) {
+    cls_ = CondensedLs();
+    cls_.N = N; cls_.m = m; cls_.Npad = Npad;
+    cls_.lds = (m + 7) / 8 * 8;
+    cls_.Jd = alloc<double>(static_cast<size_t>(m) * static_cast<size_t>(Npad) + 256);      // J, column-major m x Npad
+    cls_.S = alloc<double>(static_cast<size_t>(cls_.lds) * static_cast<size_t>(m) + 256);
+    cls_.ldlt = new BlockedLdlt();
+    cls_.ldlt->init(this, m, cls_.lds);
+    cls_.ldlt->padded = true;
+  }
+  double *Jd = cls_.Jd, *S = cls_.S;
+  const i64 lds = cls_.lds, mm = m;
+  zero(Jd, sizeof(double) * (static_cast<size_t>(m) * static_cast<size_t>(Npad) + 256));
+  zero(S, sizeof(double) * (static_cast<size_t>(lds) * static_cast<size_t>(m) + 256));
+  map(nnzJ, [=] DNLP_HD(i64 p) { if (fixmask[jc[p]] == 0.0) Jd[jr[p] + static_cast<i64>(jc[p]) * mm] = jv[p]; });
+  map(m, [=] DNLP_HD(i64 i) { S[i + i * lds] = -Dd[i]; });
+  // S -= J J^T on the lower tiles: W = L = J (leading dimension m), K = Npad
+  BlockedLdlt& bl = *cls_.ldlt;
+  const i64 keep_ldw = bl.ldw;
+  bl.ldw = m;
+  bl.gemm(stream, S, Jd, Jd, m, static_cast<int>(m), static_cast<int>(m), static_cast<int>(Npad), 1);
+  bl.ldw = keep_ldw;
+  int nneg = 0, nzero = 0;
+  if (!bl.factor(S, &nneg, &nzero) || nzero > 0 || nneg != static_cast<int>(m)) return false;
+  map(m, [=] DNLP_HD(i64 i) { y[i] = rhs_y[i]; });
+  bl.solve(S, y);
+  return true;
+}
+
 inline void HipExec::ldlt_prepare(LdltWork& w, i64 n, i64 ld, bool pivoted) {
   if (pivoted) {
     if (n > BK_NMAX) throw std::runtime_error("Bunch-Kaufman path: order above BK_NMAX");
