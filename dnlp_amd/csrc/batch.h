@@ -296,7 +296,11 @@ struct BatchRunner {
     // LDS reservation for the vectors: tight (the allocator spills to the global slab, which always
     // has room for the whole working set, so an underestimate costs latency on a few arrays only)
     const size_t vdoubles_lds = vdoubles - static_cast<size_t>(have_sparse ? 2 * n : 0);
-    const size_t vbytes_lds = (vdoubles_lds * 8 + 80 * 32 + 63) & ~static_cast<size_t>(63);
+    size_t vbytes_lds = (vdoubles_lds * 8 + 80 * 32 + 63) & ~static_cast<size_t>(63);
+    if (const char* e = std::getenv("DNLP_BATCH_VLDS_KB")) {       // experiment: cap the vectors' LDS share (the rest spills to the global slab)
+      const size_t cap_b = static_cast<size_t>(std::atoi(e)) * 1024;
+      if (cap_b >= 4096 && cap_b < vbytes_lds) vbytes_lds = cap_b & ~static_cast<size_t>(63);
+    }
     // lanes per instance: one wavefront up to order 256 (factorisation and solves are
     // single-wavefront there, vectors are at most a few hundred long), four above
     // sparse instances have no dense matrix to factor, so one wavefront suffices at any order;
@@ -337,6 +341,21 @@ struct BatchRunner {
     if (const char* e = std::getenv("DNLP_BATCH_LDS")) {
       const int want = std::atoi(e);
       if (want >= 0 && want <= 3 && slots(want) > 0) mode = want;
+    }
+    // One more resident instance for the price of the last third of the vectors: the allocator hands out LDS
+    // in allocation order (iterate, directions, residuals first) and spills the tail to the global slab.
+    // Localization, 65 536 instances: 3 per CU with all 41 KB of vectors in LDS 209.8 k problems/s, 4 per CU with
+    // 28 KB 220.0 k, 4 per CU with 24 KB 168.7 k (the hot arrays start to spill) -- so never below two thirds.
+    if ((mode & 2) && wave && !std::getenv("DNLP_BATCH_VLDS_KB")) {
+      const int s_now = slots(mode);
+      if (s_now >= 1 && s_now < slots_max) {
+        const size_t fixed = stage_bytes + (mode & 1 ? kbytes : 0) + fa.sharedSizeBytes + 256 + 3072;   // (+ the plan's solve arrays)
+        const size_t room = (160 * 1024) / static_cast<size_t>(s_now + 1);
+        if (room > fixed) {
+          const size_t want = (room - fixed) & ~static_cast<size_t>(63);
+          if (want < vbytes_lds && 3 * want >= 2 * vbytes_lds) vbytes_lds = want;
+        }
+      }
     }
     a.lds_mode = mode;
     a.lds_stage_bytes = static_cast<unsigned>((stage_bytes + 63) & ~static_cast<size_t>(63));
