@@ -1,0 +1,46 @@
+"""Which instances make the tail of a batch launch: iteration histogram of a localization batch, and the
+interior-point log (host build, print_level 5) of the slowest ones.  python tools/batch_tail.py [batch] [nlogs]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import batch_problems as bp  # noqa: E402
+from dnlp_amd.batch import ParametricBatch, arrays_with_data  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+nlogs = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+prob, params, sample, var = bp.template_localization()
+pb = ParametricBatch(prob, params)
+thetas = np.stack([sample(i) for i in range(B)])
+mat = pb.data(thetas)
+res = pb.solve(thetas)
+it = res.iterations
+wall = res.raw["phase_seconds"][:, 0]
+print("kernel_sec", res.kernel_seconds, "iters mean", it.mean(), "max", it.max())
+edges = [0, 20, 30, 40, 60, 80, 120, 160, 1000]
+h, _ = np.histogram(it, edges)
+print("iteration histogram", dict(zip(["<%d" % e for e in edges[1:]], h.tolist())))
+print("instance wall ms: mean %.3f, p99 %.3f, max %.3f" % (1e3 * wall.mean(), 1e3 * np.quantile(wall, 0.99), 1e3 * wall.max()))
+order = np.argsort(-it)
+print("slowest", [(int(i), int(it[i]), round(1e3 * wall[i], 2), int(res.factorizations[i])) for i in order[:12]])
+from oracle_check import OracleProblem  # noqa: E402
+from dnlp_amd.nlp_solver import HIPNLP  # noqa: E402
+from dnlp_amd.tape import serialize  # noqa: E402
+for i in order[:nlogs]:
+    arrays = arrays_with_data(pb.arrays0, mat[i])
+    orc = OracleProblem(serialize(arrays))
+    for k, v in dict(HIPNLP.DEFAULT_OPTIONS, print_level=5).items():
+        orc.set_option(k, v)
+    info = orc.solve(arrays["x0"])
+    print("=== instance", int(i), "oracle iterations", info["iterations"], "status", info["status"])
+    log = orc.log().splitlines()
+    full = os.environ.get("DNLP_TAIL_FULL_LOG")
+    if full:
+        open(full, "w").write("\n".join(log))
+    print("\n".join(log[:12]))
+    print("   ...")
+    print("\n".join(log[-40:]))
