@@ -287,3 +287,59 @@ def test_c2_lbfgs_execution_space_agreement(gpu_required):
     o = OracleProblem(blob).solve_reduced(data["x0"])
     assert d["status"] == 0 and o["status"] == 0
     np.testing.assert_allclose(d["x"], o["x"], atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["zero", "rank_deficient", "neg_diagonal", "arrow", "random_sizes"])
+def test_pivoted_ldlt_special_structures(case, gpu_required):
+    """The panel-blocked Bunch-Kaufman factorisation on inputs that exercise its rarely taken branches: zero pivot
+    columns (counted, replaced, no division by zero), a rank-deficient matrix (inertia with zeros), pure 1x1
+    negative pivots, an arrow matrix whose pivot search always lands on the last row, and orders that are not
+    multiples of the 16-column panel or of the 32-column solve block."""
+    rng = np.random.default_rng(7)
+    if case == "zero":
+        n = 70
+        A = np.zeros((n, n))
+        sol, nneg, nzero, _ = _ldlt(A, True, np.zeros(n))
+        assert nzero == n and nneg == 0 and np.all(np.isfinite(sol))
+        return
+    if case == "rank_deficient":
+        n, r = 90, 60
+        G = rng.standard_normal((n, r))
+        A = G @ np.diag(np.where(np.arange(r) % 3 == 0, -1.0, 1.0)) @ G.T       # rank 60, indefinite
+        _, nneg, nzero, _ = _ldlt(A, True, np.zeros(n))
+        # pivots below the replacement threshold are counted as zeros; rounding leaves O(1e-14) pivots, which
+        # are counted by their sign: the non-zero part of the inertia is what must come out exactly
+        ev = np.linalg.eigvalsh(A)
+        assert nneg >= int(np.sum(ev < -1e-8)) and nneg <= int(np.sum(ev < 1e-8))
+        return
+    if case == "neg_diagonal":
+        n = 100
+        A = -np.diag(rng.uniform(1.0, 2.0, n))
+        b = rng.standard_normal(n)
+        sol, nneg, nzero, _ = _ldlt(A, True, b)
+        assert (nneg, nzero) == (n, 0)
+        np.testing.assert_allclose(sol, b / np.diag(A), rtol=1e-13)
+        return
+    if case == "arrow":
+        n = 97
+        A = np.diag(rng.uniform(0.01, 0.02, n))
+        A[-1, :] = A[:, -1] = rng.uniform(1.0, 2.0, n)
+        b = rng.standard_normal(n)
+        sol, nneg, nzero, _ = _ldlt(A, True, b)
+        ev = np.linalg.eigvalsh(A)
+        assert nzero == 0 and nneg == int(np.sum(ev < 0))
+        assert np.linalg.norm(A @ sol - b) <= 1e-9 * np.linalg.norm(A, 2) * max(np.linalg.norm(sol), 1.0)
+        return
+    for n in (34, 47, 48, 49, 63, 95, 129, 161):
+        nh = (2 * n) // 3
+        H = rng.standard_normal((nh, nh))
+        H = H + H.T
+        H[: nh // 2, : nh // 2] = 0.0                     # a zero diagonal block: 2x2 pivots from the first column on
+        J = rng.standard_normal((n - nh, nh))
+        A = np.block([[H, J.T], [J, np.zeros((n - nh, n - nh))]])
+        b = rng.standard_normal(n)
+        sol, nneg, nzero, _ = _ldlt(A, True, b)
+        ev = np.linalg.eigvalsh(A)
+        assert nzero == 0 and nneg == int(np.sum(ev < 0)), n
+        assert np.linalg.norm(A @ sol - b) <= 1e-9 * np.linalg.norm(A, 2) * max(np.linalg.norm(sol), 1.0), n
