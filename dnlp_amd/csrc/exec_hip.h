@@ -14,6 +14,7 @@
 
 #include <stdexcept>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "atom_math.h"
@@ -1295,6 +1296,7 @@ struct HipExec : HostControlled {
   }
   ~HipExec() {
     hipSetDevice(device);
+    for (auto& f : at_exit_) f();                 // host objects that hold streams / events on this device
     for (const LevelGraph& g : level_graphs_) hipGraphExecDestroy(g.exec);
     for (void* p : owned_) hipFree(p);
     if (gemv_part) hipFree(gemv_part);
@@ -1465,6 +1467,7 @@ struct HipExec : HostControlled {
   // (a plan with 300 levels is 1 200 + 600 launches of ~2 us kernels: host launch overhead, ~16 us each,
   // was 80 % of the NMF example).  They are captured ONCE per (plan, buffers) into a HIP graph and replayed.
   struct LevelGraph { const void* k0; const void* k1; const void* k2; int kind; hipGraphExec_t exec; };
+  std::vector<std::function<void()>> at_exit_;   // run by the destructor before the device memory goes
   std::vector<LevelGraph> level_graphs_;
   int level_graphs_on_ = -1;
   template <class F>

@@ -736,6 +736,17 @@ struct BlockedLdlt {
   int NB = 512;                // outer panel width (K of the MFMA Schur update)
   int max_neg = -1;            // >= 0: give up as soon as more negative pivots than this appear
 
+  BlockedLdlt() = default;
+  BlockedLdlt(const BlockedLdlt&) = delete;
+  BlockedLdlt& operator=(const BlockedLdlt&) = delete;
+  ~BlockedLdlt() {
+    for (hipEvent_t e : tev0) hipEventDestroy(e);
+    for (hipEvent_t e : tev1) hipEventDestroy(e);
+    if (evPanel) hipEventDestroy(evPanel);
+    if (evUpd) hipEventDestroy(evUpd);
+    if (s1) hipStreamDestroy(s1);
+  }
+
   void init(HipExec* e, i64 n_, i64 ld_) {
     ex = e; n = n_; ld = ld_;
     ldw = (n + 7) / 8 * 8;
@@ -941,6 +952,7 @@ inline bool HipExec::condensed_ls(i64 N, i64 m, i64 nnzJ, const i32* jr, const i
     cls_.Jd = alloc<double>(static_cast<size_t>(m) * static_cast<size_t>(Npad) + 256);      // J, column-major m x Npad
     cls_.S = alloc<double>(static_cast<size_t>(cls_.lds) * static_cast<size_t>(m) + 256);
     cls_.ldlt = new BlockedLdlt();
+    { BlockedLdlt* owned = cls_.ldlt; at_exit_.push_back([owned] { delete owned; }); }
     cls_.ldlt->init(this, m, cls_.lds);
     cls_.ldlt->padded = true;
   }
@@ -974,6 +986,7 @@ inline void HipExec::ldlt_prepare(LdltWork& w, i64 n, i64 ld, bool pivoted) {
     if (const char* ev = std::getenv("DNLP_BK_PANELS")) w.bk_panels = std::atoi(ev) != 0;
   } else {
     w.blocked = new BlockedLdlt();
+    { BlockedLdlt* owned = w.blocked; at_exit_.push_back([owned] { delete owned; }); }
     w.blocked->init(this, n, ld);
   }
 }
