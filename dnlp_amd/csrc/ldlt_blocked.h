@@ -1,19 +1,22 @@
 // Blocked right-looking LDL^T (no pivoting) for large dense KKT matrices on gfx950.
 //
-//   for each outer panel of NB columns:
-//     for each inner block of nb columns inside the panel:
-//       ldlt_diag_kernel   — nb x nb diagonal block factored in LDS by one workgroup
-//       ldlt_trsm_kernel   — rows below: X = A21 L11^-T (= L21 D) by per-row forward
-//                            substitution (one row per lane, coalesced down the columns);
-//                            stores L21 in place and W21 = L21 D in the panel workspace
-//       gemm_nt_update     — rest of the panel:   A[r, c] -= W[r, :] . L[c, :]
-//     gemm_nt_update       — trailing matrix (Schur complement): A22 -= W21 L21^T, lower
-//                            tiles only.  This is the n^3/3 part and the ONLY place MFMA is
-//                            used: v_mfma_f64_16x16x4_f64, 128x128 block tile, 64x64 per
-//                            wave (4x4 MFMA tiles, 128 accumulator VGPRs), operands staged
-//                            global -> registers -> LDS with 16-B lanes, LDS rows padded by
-//                            16 doubles so the two k-rows a 32-lane group reads hit disjoint
-//                            banks.
+//   for each outer panel of NB columns (512; 1024 from order 32768 on):
+//     for each 128-column sub-panel (the 32-column chain below serves what is left of a panel):
+//       ldlt_top128_kernel   — 128 x 128 diagonal block in the registers of one workgroup
+//       ldlt_rows128_kernel  — rows below on FP64 MFMA, the row block transposed in the accumulators;
+//                              stores L21 in place and W21 = L21 D in the panel workspace
+//       gemm_nt_update_fast  — rest of the panel, K = 128
+//     (32-column chain: ldlt_diag_kernel — 32 x 32 block by one wavefront in registers —,
+//      ldlt_trsm_kernel — per-row forward substitution —, gemm_nt_update, K = 32)
+//     gemm_nt_update_fast    — trailing matrix (Schur complement): A22 -= W21 L21^T, lower tiles only, on its
+//                              own stream with one panel of look-ahead.  This is the n^3/3 part:
+//                              v_mfma_f64_16x16x4_f64, 128 x 128 tile per 512-thread workgroup, a wavefront
+//                              owns 64 x 32 (2 x 4 MFMA tiles, 64 accumulator VGPRs, four wavefronts per SIMD,
+//                              two workgroups per CU), operand k-tiles go global -> LDS directly
+//                              (global_load_lds_dwordx4), double buffered, one barrier per 16-deep k-tile,
+//                              LDS rows padded by 16 doubles.  Edge tiles, unaligned operands and K not a
+//                              multiple of 16 take gemm_nt_update: four wavefronts of 64 x 64, operands staged
+//                              through registers.
 //   The MFMA computes D[row=j][col=i] so that lane&15 walks the contiguous (row) direction
 //   of the column-major C tile in the read-modify-write epilogue.
 //
