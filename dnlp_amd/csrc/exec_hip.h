@@ -1482,12 +1482,24 @@ struct HipExec : HostControlled {
         DNLP_HIP_CHECK(hipGraphLaunch(g.exec, stream));
         return;
       }
+    // a runtime that cannot capture or instantiate runs the launches directly from then on
     hipGraph_t graph = nullptr;
-    DNLP_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      (void)hipGetLastError();
+      level_graphs_on_ = 0;
+      launches();
+      return;
+    }
     launches();
     DNLP_HIP_CHECK(hipStreamEndCapture(stream, &graph));
     hipGraphExec_t exec = nullptr;
-    DNLP_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      hipGraphDestroy(graph);
+      level_graphs_on_ = 0;
+      launches();
+      return;
+    }
     DNLP_HIP_CHECK(hipGraphDestroy(graph));
     if (level_graphs_.size() >= 24) {              // buffers of retired solver objects: oldest out
       hipGraphExecDestroy(level_graphs_.front().exec);
