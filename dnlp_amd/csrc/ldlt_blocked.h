@@ -583,7 +583,9 @@ __global__ void __launch_bounds__(SV_B) ldlt_fwd_diag(const double* __restrict__
   for (int kk = 0; kk < 32; ++kk) cur[kk] = row[static_cast<i64>(kk < jb ? kk : jb - 1) * ld];
   for (int s0 = 0; s0 < jb; s0 += 32) {
     const int s1 = (s0 + 32 < jb) ? s0 + 32 : jb;
-    if (s1 < jb) {
+    // rows above a strip hold no entry of it (upper triangle): a wavefront whose 64 rows all lie above skips the
+    // strip — the kernel is bound by the issue rate of these loads on its one CU
+    if (s1 < jb && (t | 63) >= s1) {
 #pragma unroll
       for (int kk = 0; kk < 32; ++kk) nxt[kk] = row[static_cast<i64>(s1 + kk < jb ? s1 + kk : jb - 1) * ld];
     }
@@ -686,7 +688,8 @@ __global__ void __launch_bounds__(SV_B) ldlt_bwd_diag(const double* __restrict__
   }
   for (int sbk = nsb - 1; sbk >= 0; --sbk) {
     const int s0 = sbk * 32, s1 = (s0 + 32 < jb) ? s0 + 32 : jb;
-    if (sbk > 0) {
+    // (columns right of a strip's rows hold no entry of it either)
+    if (sbk > 0 && (t & ~63) < s0) {
 #pragma unroll
       for (int kk = 0; kk < 32; ++kk) nxt[kk] = colt[s0 - 32 + kk];
     }
