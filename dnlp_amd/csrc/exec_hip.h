@@ -1197,6 +1197,23 @@ __global__ void __launch_bounds__(kBlock) sp_pivot_kernel(SparsePlan pl, double*
   if (nzero != 0.0) atomicAdd(&info->nzero, static_cast<int>(nzero));
   if (bad != 0.0) atomicExch(&info->ok, 0);
 }
+// One lane per block, the four phases in sequence: for levels whose blocks have short structs (chain-like
+// patterns: three rows, six triples per block in the Rosenbrock chain) the phases of a block are a handful of
+// operations and the level costs one launch instead of four.
+__global__ void __launch_bounds__(kBlock) sp_level_fused_kernel(SparsePlan pl, double* vals, double* w, double* dinv, i64 b0, i64 b1,
+                                                                SparseInfo* info) {
+  const i64 k = b0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+  if (k >= b1) return;
+  double nneg = 0.0, nzero = 0.0, bad = 0.0;
+  sp_pivot(pl, vals, dinv, k, nneg, nzero, bad);
+  if (nneg != 0.0) atomicAdd(&info->nneg, static_cast<int>(nneg));
+  if (nzero != 0.0) atomicAdd(&info->nzero, static_cast<int>(nzero));
+  if (bad != 0.0) atomicExch(&info->ok, 0);
+  for (i64 r = pl.soff[k]; r < pl.soff[k + 1]; ++r) sp_scale(pl, vals, w, dinv, r);
+  for (i64 q = pl.toff[k]; q < pl.toff[k + 1]; ++q) unsafeAtomicAdd(&vals[pl.tdst[q]], -sp_update(pl, vals, w, q));
+  const i64 v0 = pl.loff[k], v1 = (k + 1 < pl.nblk) ? pl.loff[k + 1] : pl.nvals;
+  for (i64 a = v0; a < v1; ++a) vals[a] = w[a];
+}
 __global__ void __launch_bounds__(kBlock) sp_scale_kernel(SparsePlan pl, const double* vals, double* w, const double* dinv, i64 r0, i64 r1) {
   const i64 r = r0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
   if (r < r1) sp_scale(pl, vals, w, dinv, r);
@@ -1470,6 +1487,7 @@ struct HipExec : HostControlled {
   std::vector<std::function<void()>> at_exit_;   // run by the destructor before the device memory goes
   std::vector<LevelGraph> level_graphs_;
   int level_graphs_on_ = -1;
+  bool level_fusion_ = std::getenv("DNLP_LEVEL_FUSION") == nullptr || std::atoi(std::getenv("DNLP_LEVEL_FUSION")) != 0;
   template <class F>
   void replay_levels(int kind, const void* k0, const void* k1, const void* k2, F&& launches) {
     if (level_graphs_on_ < 0) {
@@ -1522,6 +1540,10 @@ struct HipExec : HostControlled {
         for (i64 lev = 0; lev < pl.nlev; ++lev) {
           const i64 b0 = pl.h_lev_blk[lev], b1 = pl.h_lev_blk[lev + 1], r0 = pl.h_lev_row[lev], r1 = pl.h_lev_row[lev + 1];
           const i64 t0 = pl.h_lev_trip[lev], t1 = pl.h_lev_trip[lev + 1], v0 = pl.h_lev_val[lev], v1 = pl.h_lev_val[lev + 1];
+          if (level_fusion_ && (t1 - t0) <= 40 * (b1 - b0) && (r1 - r0) <= 8 * (b1 - b0)) {
+            hipLaunchKernelGGL(sp_level_fused_kernel, grid(b1 - b0), dim3(kBlock), 0, stream, pl, vals, w, dinv, b0, b1, info);
+            continue;
+          }
           hipLaunchKernelGGL(sp_pivot_kernel, grid(b1 - b0), dim3(kBlock), 0, stream, pl, vals, dinv, b0, b1, info);
           if (r1 > r0) hipLaunchKernelGGL(sp_scale_kernel, grid(r1 - r0), dim3(kBlock), 0, stream, pl, vals, w, dinv, r0, r1);
           if (t1 > t0) hipLaunchKernelGGL(sp_update_kernel, grid(t1 - t0), dim3(kBlock), 0, stream, pl, vals, w, t0, t1);
