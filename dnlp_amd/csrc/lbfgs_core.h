@@ -137,7 +137,9 @@ class ReducedLbfgs {
         eval(xf, fl, gf);            // canonical vector (auxiliary variables) consistent with the solution
         use_fused = keep;
         --evaluations;
-        f_final = fl;
+        // a tape without segments carries the user's variables and a zero objective (the direct path of
+        // algorithm='lbfgs', dnlp_amd/problem.py): the objective lives in the fused program only
+        f_final = (md_->t.nseg == 0 && md_->t.m == 0) ? r.f : fl;
         wall = now_sec() - t0;
         return r.status;
       }
@@ -242,7 +244,7 @@ class ReducedLbfgs {
     use_fused = false;
     eval(xf, fl, gf);
     use_fused = keep;
-    f_final = fl;
+    if (!(md_->t.nseg == 0 && md_->t.m == 0 && fused && fused->present && use_fused)) f_final = fl;
     wall = now_sec() - t0;
     return status;
   }

@@ -221,3 +221,43 @@ def test_device_slot_kernel_on_random_trees_at_scale(gpu_required, seed):
     f1, g1 = numpy_eval(ta, z)
     assert abs(f - f1) <= 1e-10 * max(1.0, abs(f1))
     np.testing.assert_allclose(g, g1, rtol=1e-10, atol=1e-10)
+
+
+def _direct_path_checks(engine_ctx):
+    """algorithm='lbfgs' on an unconstrained elementwise-sum objective never lowers the canonical form: the tape
+    holds the user's variables only (m = 0, no segments) and the objective value comes from the fused program."""
+    with engine_ctx:
+        p = rosenbrock_chain(cp, 60)
+        p.solve(nlp=True, algorithm="lbfgs", tol=1e-9)
+        d = p._nlp_cache["data"]
+        assert p._nlp_cache["sig"][0] == "direct" and d["tape"].N == 60 and d["tape"].m == 0
+        assert p.status == "optimal" and np.max(np.abs(p.variables()[0].value - 1.0)) <= 1e-6 and 0.0 <= p.value <= 1e-10
+        p.variables()[0].value = np.full(60, 0.5)
+        p.solve(nlp=True, algorithm="lbfgs", tol=1e-9)          # cached handle, new start
+        assert p.status == "optimal" and np.max(np.abs(p.variables()[0].value - 1.0)) <= 1e-6
+        # a constant term and a Maximize flip travel with the fused program
+        x = cp.Variable(7)
+        x.value = np.zeros(7)
+        q = cp.Problem(cp.Maximize(-cp.sum(cp.square(x - 2.0)) - 3.0), [])
+        q.solve(nlp=True, algorithm="lbfgs")
+        assert q.status == "optimal" and abs(q.value + 3.0) <= 1e-9 and np.max(np.abs(x.value - 2.0)) <= 1e-6
+        # fused_objective="no" asks for the canonical reduced gradient: the canonical form is lowered
+        p2 = rosenbrock_chain(cp, 60)
+        p2.solve(nlp=True, algorithm="lbfgs", tol=1e-9, fused_objective="no")
+        assert p2._nlp_cache["data"]["tape"].m > 0 and np.max(np.abs(p2.variables()[0].value - 1.0)) <= 1e-6
+        # a constrained problem has no fused form: algorithm='lbfgs' is refused as before
+        y = cp.Variable(3)
+        y.value = np.ones(3)
+        with pytest.raises(ValueError):
+            cp.Problem(cp.Minimize(cp.sum(cp.square(y))), [cp.sum(y) == 1]).solve(nlp=True, algorithm="lbfgs")
+
+
+def test_lbfgs_direct_path_on_the_host_engine():
+    from oracle_frontend import oracle_engine
+    _direct_path_checks(oracle_engine())
+
+
+@pytest.mark.gpu
+def test_lbfgs_direct_path_on_the_device(gpu_required):
+    import contextlib
+    _direct_path_checks(contextlib.nullcontext())
