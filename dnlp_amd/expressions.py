@@ -28,7 +28,12 @@ def get_id() -> int:
 
 
 def size_from_shape(shape) -> int:
-    return int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
+    # (shapes are tuples of at most a few ints: a Python product is 20x cheaper than np.prod, and the
+    # lowering asks for sizes thousands of times)
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return n
 
 
 def unique_list(items):
