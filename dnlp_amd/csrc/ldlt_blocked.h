@@ -740,6 +740,7 @@ struct BlockedLdlt {
   bool xcd_swizzle = false;    // 8 x 8 super-tiles per XCD: cuts the W-strip re-reads ~5x but measured 1.5-3% slower (MFMA-bound), so off; DNLP_LDLT_XCD=1 enables
   bool padded = false;         // the matrix allocation has >= 128 doubles of slack behind it
   int NB = 512;                // outer panel width (K of the MFMA Schur update)
+  int reserve_cus = 0;         // compute units the update stream may not use (look-ahead panel kernels run there)
   int max_neg = -1;            // >= 0: give up as soon as more negative pivots than this appear
 
   BlockedLdlt() = default;
@@ -776,9 +777,30 @@ struct BlockedLdlt {
     DNLP_HIP_CHECK(hipEventCreateWithFlags(&evUpd, hipEventDisableTiming));
     // the trailing updates run on their own (lower-priority) stream so that the next panel's
     // latency-bound factorisation kernels overlap with the previous panel's MFMA update
-    int lo_p = 0, hi_p = 0;
-    DNLP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-    DNLP_HIP_CHECK(hipStreamCreateWithPriority(&s1, hipStreamNonBlocking, lo_p));
+    // Mid-size orders keep `reserve_cus` compute units (one per XCD for 8: mask bit i is XCD i % 8) out of the
+    // update stream's CU mask: a panel kernel of the look-ahead chain otherwise waits for a CU on which BOTH
+    // resident update workgroups have retired (~a tile time per launch, longer than the kernel itself).
+    if (n < 32768) reserve_cus = 8;
+    if (const char* ev = std::getenv("DNLP_LDLT_RESERVE_CUS")) reserve_cus = std::atoi(ev);
+    if (reserve_cus > 0 && lookahead) {
+      int dev = 0, ncu = 0;
+      DNLP_HIP_CHECK(hipGetDevice(&dev));
+      DNLP_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+      if (ncu > 2 * reserve_cus) {
+        std::vector<uint32_t> mask(static_cast<size_t>((ncu + 31) / 32), 0u);
+        for (int i = 0; i < ncu - reserve_cus; ++i) mask[static_cast<size_t>(i >> 5)] |= 1u << (i & 31);
+        if (hipExtStreamCreateWithCUMask(&s1, static_cast<uint32_t>(mask.size()), mask.data()) != hipSuccess) {
+          (void)hipGetLastError();
+          s1 = nullptr;
+        }
+      }
+    }
+    if (!s1) {
+      reserve_cus = 0;
+      int lo_p = 0, hi_p = 0;
+      DNLP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+      DNLP_HIP_CHECK(hipStreamCreateWithPriority(&s1, hipStreamNonBlocking, lo_p));
+    }
   }
 
   void gemm(hipStream_t st, double* C, const double* W, const double* L, i64 ldl, int M, int Nc, int Kd, int lower) {
