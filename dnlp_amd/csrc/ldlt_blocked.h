@@ -561,6 +561,96 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_update(double* __restrict__ C,
   gemm_body_guarded(C, ldc, W, ldw, L, ldl, M, Nc, Kd, lower, tm, tn, vec_ok, smem);
 }
 
+// 64 x 64 tiles, four wavefronts (2 x 2, each 32 x 32 = 2 x 2 MFMA tiles), register-staged operands in two LDS
+// buffers with one barrier per 16-deep k-tile; every access guarded.  For launches whose 128 x 128 tiling gives
+// fewer workgroups than the chip has room for (in-panel updates of mid-size orders: 80-240 tiles for 256 CUs).
+constexpr int GS_B = 64, GS_PAD = 4;
+__global__ void __launch_bounds__(256) gemm_nt_update_small(double* __restrict__ C, i64 ldc,
+                                                            const double* __restrict__ W, i64 ldw,
+                                                            const double* __restrict__ L, i64 ldl, int M, int Nc,
+                                                            int Kd, int lower, int ntm, int vec_ok) {
+  const int tm = blockIdx.x % ntm, tn = blockIdx.x / ntm;
+  if (lower && (tm * GS_B + GS_B - 1 < tn * GS_B)) return;
+  __shared__ __attribute__((aligned(16))) double Ws[2][GM_BK][GS_B + GS_PAD];
+  __shared__ __attribute__((aligned(16))) double Ls[2][GM_BK][GS_B + GS_PAD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int srow = 2 * (tid & 31), sk = tid >> 5;
+  const i64 gi = static_cast<i64>(tm) * GS_B + srow;
+  const i64 gj = static_cast<i64>(tn) * GS_B + srow;
+  double2 rw[2], rl[2];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int k = kt * GM_BK + sk + 8 * q;
+      double2 vw = {0.0, 0.0}, vl = {0.0, 0.0};
+      if (k < Kd) {
+        const double* pw = W + gi + static_cast<i64>(k) * ldw;
+        const double* pl = L + gj + static_cast<i64>(k) * ldl;
+        if (vec_ok && gi + 1 < M) vw = *reinterpret_cast<const double2*>(pw);
+        else { if (gi < M) vw.x = pw[0]; if (gi + 1 < M) vw.y = pw[1]; }
+        if (vec_ok && gj + 1 < Nc) vl = *reinterpret_cast<const double2*>(pl);
+        else { if (gj < Nc) vl.x = pl[0]; if (gj + 1 < Nc) vl.y = pl[1]; }
+      }
+      rw[q] = vw;
+      rl[q] = vl;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      *reinterpret_cast<double2*>(&Ws[buf][sk + 8 * q][srow]) = rw[q];
+      *reinterpret_cast<double2*>(&Ls[buf][sk + 8 * q][srow]) = rl[q];
+    }
+  };
+  const int nkt = (Kd + GM_BK - 1) / GM_BK;
+  load_tile(0);
+  const int i_base = tm * GS_B + wm * 32 + (lane & 15);
+  const int j_base = tn * GS_B + wn * 32 + (lane >> 4);
+  mfma_d4 acc[2][2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i_base + mi * 16, j = j_base + ni * 16 + 4 * r;
+        acc[ni][mi][r] = (i < M && j < Nc && (!lower || i >= j)) ? -C[i + static_cast<i64>(j) * ldc] : 0.0;
+      }
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < GM_BK; kk += 4) {
+      double a[2], b[2];
+      const int kr = kk + (lane >> 4), lc = lane & 15;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = Ls[buf][kr][wn * 32 + t * 16 + lc];
+        b[t] = Ws[buf][kr][wm * 32 + t * 16 + lc];
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ni], b[mi], acc[ni][mi], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i_base + mi * 16, j = j_base + ni * 16 + 4 * r;
+        if (i < M && j < Nc && (!lower || i >= j)) C[i + static_cast<i64>(j) * ldc] = -acc[ni][mi][r];
+      }
+}
+
 // ---- triangular solves with the unit-lower factor ---------------------------------------------
 // Blocks of SV_B = 256 columns: the diagonal block is solved by one workgroup (32-wide
 // wave-shuffle substitutions, no barrier inside a sub-block), the panel below / the panel
@@ -740,6 +830,9 @@ struct BlockedLdlt {
   bool xcd_swizzle = false;    // 8 x 8 super-tiles per XCD: cuts the W-strip re-reads ~5x but measured 1.5-3% slower (MFMA-bound), so off; DNLP_LDLT_XCD=1 enables
   bool padded = false;         // the matrix allocation has >= 128 doubles of slack behind it
   int NB = 512;                // outer panel width (K of the MFMA Schur update)
+  int small_tiles_below = 384; // launches with fewer 128 x 128 tiles than this use the 64 x 64 kernel (DNLP_LDLT_SMALL_TILES)
+  int small_rows_max = 5120;   // ... and only up to this many rows: above, the launch runs beside a big update of the
+                               // look-ahead and the tile with the better MFMA rate wins (DNLP_LDLT_SMALL_ROWS)
   int reserve_cus = 0;         // compute units the update stream may not use (look-ahead panel kernels run there)
   int max_neg = -1;            // >= 0: give up as soon as more negative pivots than this appear
 
@@ -765,6 +858,8 @@ struct BlockedLdlt {
     if (const char* ev = std::getenv("DNLP_LDLT_LOOKAHEAD")) lookahead = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_XCD")) xcd_swizzle = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_T128")) sub128 = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("DNLP_LDLT_SMALL_TILES")) small_tiles_below = std::atoi(ev);
+    if (const char* ev = std::getenv("DNLP_LDLT_SMALL_ROWS")) small_rows_max = std::atoi(ev);
     if (NB < LD_nb) NB = LD_nb;
     if (NB > LD_NB_MAX) NB = LD_NB_MAX;
     NB = NB / LD_nb * LD_nb;
@@ -810,6 +905,15 @@ struct BlockedLdlt {
     const int vec_ok = al(W) && al(L) && (ldw % 2 == 0) && (ldl % 2 == 0);
     // operands may be read up to 127 rows past M / Nc: both allocations carry that padding
     const bool fast_ok = vec_ok && (Kd % GM_BK == 0) && padded;
+    // launches that would not fill the chip with 128 x 128 tiles take four times as many 64 x 64 ones
+    const i64 work_tiles = (lower && M == Nc) ? static_cast<i64>(ntm) * (ntm + 1) / 2 : static_cast<i64>(ntm) * ntn;
+    if (work_tiles < small_tiles_below && M <= small_rows_max) {
+      const int sm = (M + GS_B - 1) / GS_B, sn = (Nc + GS_B - 1) / GS_B;
+      hipLaunchKernelGGL(gemm_nt_update_small, dim3(static_cast<unsigned>(sm) * sn), dim3(256), 0, st, C, ld, W, ldw,
+                         L, ldl, M, Nc, Kd, lower, sm, vec_ok);
+      DNLP_LAUNCH_CHECK();
+      return;
+    }
     if (fast_ok && xcd_swizzle && ntm >= 16 && ntn >= 16) {
       const unsigned nsuper = static_cast<unsigned>((ntm + 7) / 8) * static_cast<unsigned>((ntn + 7) / 8);
       hipLaunchKernelGGL(gemm_nt_update_fast, dim3(((nsuper + 7) / 8) * 8 * 64), dim3(512), 0, st, C, ld, W,
