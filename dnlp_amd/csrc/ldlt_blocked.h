@@ -562,49 +562,56 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_update(double* __restrict__ C,
 }
 
 // 64 x 64 tiles, four wavefronts (2 x 2, each 32 x 32 = 2 x 2 MFMA tiles), register-staged operands in two LDS
-// buffers with one barrier per 16-deep k-tile; every access guarded.  For launches whose 128 x 128 tiling gives
-// fewer workgroups than the chip has room for (in-panel updates of mid-size orders: 80-240 tiles for 256 CUs).
+// buffers with one barrier per 16-deep k-tile.  For launches whose 128 x 128 tiling gives fewer workgroups than the
+// chip has room for (in-panel updates of mid-size orders: 80-240 tiles for 256 CUs).  A workgroup's k-loop is a
+// chain of global round trips (16 MFMAs per wavefront per k-tile against ~1.5 us of latency), so operand tiles are
+// fetched TWO k-tiles ahead into two register sets.  GUARD = edge / diagonal tile or unaligned operands.
 constexpr int GS_B = 64, GS_PAD = 4;
-__global__ void __launch_bounds__(256) gemm_nt_update_small(double* __restrict__ C, i64 ldc,
-                                                            const double* __restrict__ W, i64 ldw,
-                                                            const double* __restrict__ L, i64 ldl, int M, int Nc,
-                                                            int Kd, int lower, int ntm, int vec_ok) {
-  const int tm = blockIdx.x % ntm, tn = blockIdx.x / ntm;
-  if (lower && (tm * GS_B + GS_B - 1 < tn * GS_B)) return;
-  __shared__ __attribute__((aligned(16))) double Ws[2][GM_BK][GS_B + GS_PAD];
-  __shared__ __attribute__((aligned(16))) double Ls[2][GM_BK][GS_B + GS_PAD];
+template <bool GUARD>
+__device__ inline void gemm_body_small(double* __restrict__ C, i64 ldc, const double* __restrict__ W, i64 ldw,
+                                       const double* __restrict__ L, i64 ldl, int M, int Nc, int Kd, int lower,
+                                       int tm, int tn, int vec_ok, double (*Ws)[GM_BK][GS_B + GS_PAD],
+                                       double (*Ls)[GM_BK][GS_B + GS_PAD]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int srow = 2 * (tid & 31), sk = tid >> 5;
   const i64 gi = static_cast<i64>(tm) * GS_B + srow;
   const i64 gj = static_cast<i64>(tn) * GS_B + srow;
-  double2 rw[2], rl[2];
-  auto load_tile = [&](int kt) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int k = kt * GM_BK + sk + 8 * q;
-      double2 vw = {0.0, 0.0}, vl = {0.0, 0.0};
+  const int nkt = (Kd + GM_BK - 1) / GM_BK;
+  // two register sets, named (not indexed, not passed by address) so that they stay in registers
+  double2 rw0a, rw0b, rl0a, rl0b, rw1a, rw1b, rl1a, rl1b;
+  auto load_one = [&](int k, double2& vw, double2& vl) {
+    if (!GUARD) {
+      vw = *reinterpret_cast<const double2*>(W + gi + static_cast<i64>(k) * ldw);
+      vl = *reinterpret_cast<const double2*>(L + gj + static_cast<i64>(k) * ldl);
+    } else {
+      double wx = 0.0, wy = 0.0, lx = 0.0, ly = 0.0;
       if (k < Kd) {
         const double* pw = W + gi + static_cast<i64>(k) * ldw;
         const double* pl = L + gj + static_cast<i64>(k) * ldl;
-        if (vec_ok && gi + 1 < M) vw = *reinterpret_cast<const double2*>(pw);
-        else { if (gi < M) vw.x = pw[0]; if (gi + 1 < M) vw.y = pw[1]; }
-        if (vec_ok && gj + 1 < Nc) vl = *reinterpret_cast<const double2*>(pl);
-        else { if (gj < Nc) vl.x = pl[0]; if (gj + 1 < Nc) vl.y = pl[1]; }
+        if (vec_ok && gi + 1 < M) { const double2 v = *reinterpret_cast<const double2*>(pw); wx = v.x; wy = v.y; }
+        else { if (gi < M) wx = pw[0]; if (gi + 1 < M) wy = pw[1]; }
+        if (vec_ok && gj + 1 < Nc) { const double2 v = *reinterpret_cast<const double2*>(pl); lx = v.x; ly = v.y; }
+        else { if (gj < Nc) lx = pl[0]; if (gj + 1 < Nc) ly = pl[1]; }
       }
-      rw[q] = vw;
-      rl[q] = vl;
+      vw = double2{wx, wy};
+      vl = double2{lx, ly};
     }
   };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      *reinterpret_cast<double2*>(&Ws[buf][sk + 8 * q][srow]) = rw[q];
-      *reinterpret_cast<double2*>(&Ls[buf][sk + 8 * q][srow]) = rl[q];
-    }
-  };
-  const int nkt = (Kd + GM_BK - 1) / GM_BK;
-  load_tile(0);
+#define DNLP_GS_LOAD(kt, S)                                   \
+  do {                                                        \
+    load_one((kt) * GM_BK + sk, rw##S##a, rl##S##a);          \
+    load_one((kt) * GM_BK + sk + 8, rw##S##b, rl##S##b);      \
+  } while (0)
+#define DNLP_GS_STORE(buf, S)                                              \
+  do {                                                                     \
+    *reinterpret_cast<double2*>(&Ws[buf][sk][srow]) = rw##S##a;            \
+    *reinterpret_cast<double2*>(&Ls[buf][sk][srow]) = rl##S##a;            \
+    *reinterpret_cast<double2*>(&Ws[buf][sk + 8][srow]) = rw##S##b;        \
+    *reinterpret_cast<double2*>(&Ls[buf][sk + 8][srow]) = rl##S##b;        \
+  } while (0)
+  DNLP_GS_LOAD(0, 0);
+  DNLP_GS_LOAD(nkt > 1 ? 1 : 0, 1);
   const int i_base = tm * GS_B + wm * 32 + (lane & 15);
   const int j_base = tn * GS_B + wn * 32 + (lane >> 4);
   mfma_d4 acc[2][2];
@@ -615,13 +622,10 @@ __global__ void __launch_bounds__(256) gemm_nt_update_small(double* __restrict__
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = i_base + mi * 16, j = j_base + ni * 16 + 4 * r;
-        acc[ni][mi][r] = (i < M && j < Nc && (!lower || i >= j)) ? -C[i + static_cast<i64>(j) * ldc] : 0.0;
+        if (GUARD) acc[ni][mi][r] = (i < M && j < Nc && (!lower || i >= j)) ? -C[i + static_cast<i64>(j) * ldc] : 0.0;
+        else acc[ni][mi][r] = -C[i + static_cast<i64>(j) * ldc];
       }
-  store_tile(0);
-  __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) load_tile(kt + 1);
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < GM_BK; kk += 4) {
       double a[2], b[2];
@@ -637,9 +641,24 @@ __global__ void __launch_bounds__(256) gemm_nt_update_small(double* __restrict__
         for (int mi = 0; mi < 2; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ni], b[mi], acc[ni][mi], 0, 0, 0);
     }
-    if (kt + 1 < nkt) store_tile(buf ^ 1);
+  };
+  DNLP_GS_STORE(0, 0);
+  __syncthreads();
+  // k-tile kt is computed from LDS buffer kt & 1; tile kt + 1 waits in a register set, tile kt + 2 is in flight
+  for (int kt = 0; kt < nkt; kt += 2) {
+    DNLP_GS_LOAD(kt + 2 < nkt ? kt + 2 : nkt - 1, 0);   // unconditional (clamped): a branch here would make the
+                                                        // compiler wait for every outstanding load at the store
+    compute(0);
+    DNLP_GS_STORE(1, 1);
+    __syncthreads();
+    if (kt + 1 >= nkt) break;
+    DNLP_GS_LOAD(kt + 3 < nkt ? kt + 3 : nkt - 1, 1);
+    compute(1);
+    DNLP_GS_STORE(0, 0);
     __syncthreads();
   }
+#undef DNLP_GS_LOAD
+#undef DNLP_GS_STORE
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -647,8 +666,22 @@ __global__ void __launch_bounds__(256) gemm_nt_update_small(double* __restrict__
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = i_base + mi * 16, j = j_base + ni * 16 + 4 * r;
-        if (i < M && j < Nc && (!lower || i >= j)) C[i + static_cast<i64>(j) * ldc] = -acc[ni][mi][r];
+        if (!GUARD || (i < M && j < Nc && (!lower || i >= j))) C[i + static_cast<i64>(j) * ldc] = -acc[ni][mi][r];
       }
+}
+
+__global__ void __launch_bounds__(256, 3) gemm_nt_update_small(double* __restrict__ C, i64 ldc,
+                                                            const double* __restrict__ W, i64 ldw,
+                                                            const double* __restrict__ L, i64 ldl, int M, int Nc,
+                                                            int Kd, int lower, int ntm, int vec_ok) {
+  const int tm = blockIdx.x % ntm, tn = blockIdx.x / ntm;
+  if (lower && (tm * GS_B + GS_B - 1 < tn * GS_B)) return;
+  __shared__ __attribute__((aligned(16))) double Ws[2][GM_BK][GS_B + GS_PAD];
+  __shared__ __attribute__((aligned(16))) double Ls[2][GM_BK][GS_B + GS_PAD];
+  const bool interior = vec_ok && (Kd % GM_BK == 0) && (tm + 1) * GS_B <= M && (tn + 1) * GS_B <= Nc &&
+                        (!lower || tm * GS_B >= (tn + 1) * GS_B);
+  if (interior) gemm_body_small<false>(C, ldc, W, ldw, L, ldl, M, Nc, Kd, lower, tm, tn, vec_ok, Ws, Ls);
+  else gemm_body_small<true>(C, ldc, W, ldw, L, ldl, M, Nc, Kd, lower, tm, tn, vec_ok, Ws, Ls);
 }
 
 // ---- triangular solves with the unit-lower factor ---------------------------------------------
