@@ -480,7 +480,8 @@ __global__ void __launch_bounds__(BK_PT) bk_panel_kernel(double* A, int n, i64 l
                                                         i64 ldw, BkPanelSwaps* swaps) {
   __shared__ double sv[BK_PT / 64];
   __shared__ int si[BK_PT / 64];
-  __shared__ double vb[2][NBP];            // multipliers L[row, panel columns] of the pivot row / the candidate row
+  __shared__ __attribute__((aligned(16))) double vb[2][NBP];   // multipliers L[row, panel columns] of the pivot row / the candidate row
+  __shared__ double xr[2][NBP + 2];        // W row of the pivot row / the candidate row, zero on both sides
   __shared__ double xw[2][NBP + 2];        // interchange: W rows and the (w, c) entries of rows kk / kp
   __shared__ double dinf[NBP][3];          // 1x1: {1/d} ; first column of a 2x2: {d11, d22, d21}
   __shared__ int dk[NBP];                  // 0: 1x1, 1 / 2: first / second column of a 2x2
@@ -514,23 +515,36 @@ __global__ void __launch_bounds__(BK_PT) bk_panel_kernel(double* A, int n, i64 l
   }
   int nneg = 0, nzero = 0, fail = 0;
   int j = 0;
-  // multipliers of `row` for the panel columns done so far, by the lane that owns the row
-  auto publish_lrow = [&](int row, int slot) {
-    if (tid == row % BK_PT) {
+  // multipliers of `row` for the panel columns done so far, by the WAVEFRONT of the lane that owns the row: the
+  // owner puts its W row into LDS, lane i of the same wavefront turns column i's entry into the multiplier (its
+  // pivot data, the three forms 1x1 / first / second column of a 2x2, 0 for columns not done yet) -- two LDS round
+  // trips in all, where one lane walking the columns paid one dependent round trip and a branch per column
+  auto publish_lrow = [&](int row_in, int slot) {
+    const int row = __builtin_amdgcn_readfirstlane(row_in);
+    const int owner = row % BK_PT, srow = row / BK_PT;
+    if ((tid >> 6) == (owner >> 6)) {
+      const int lane = tid & 63;
+      if (tid == owner) {
 #pragma unroll
-      for (int s = 0; s < ROWS; ++s)
-        if (s == row / BK_PT) {
+        for (int s = 0; s < ROWS; ++s)
+          if (s == srow) {
 #pragma unroll
-          for (int i = 0; i < NBP; ++i)
-            if (i < j) {
-              if (dk[i] == 0) vb[slot][i] = W[s][i] * dinf[i][0];
-              else if (dk[i] == 1 && i + 1 < NBP) {
-                const double d11 = dinf[i][0], d22 = dinf[i][1], d21 = dinf[i][2];
-                vb[slot][i] = d21 * (d11 * W[s][i] - W[s][i + 1]);
-                vb[slot][i + 1] = d21 * (d22 * W[s][i + 1] - W[s][i]);
-              }
-            }
-        }
+            for (int i = 0; i < NBP; ++i) xr[slot][i + 1] = W[s][i];
+          }
+        xr[slot][0] = 0.0;
+        xr[slot][NBP + 1] = 0.0;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): one wavefront's LDS operations complete in order
+      __builtin_amdgcn_wave_barrier();
+      if (lane < NBP) {
+        const int d = dk[lane];
+        const double e0 = dinf[lane][0], e2 = dinf[lane][2];
+        const double mine = xr[slot][lane + 1], up = xr[slot][lane + 2], dn = xr[slot][lane];
+        const double other = d == 1 ? up : dn;
+        const double two = e2 * (e0 * mine - other);
+        const double val = d == 0 ? mine * e0 : two;
+        vb[slot][lane] = lane < j ? val : 0.0;
+      }
     }
   };
   __syncthreads();
@@ -545,12 +559,19 @@ __global__ void __launch_bounds__(BK_PT) bk_panel_kernel(double* A, int n, i64 l
     }
     publish_lrow(k, 0);
     __syncthreads();
+    // four multipliers per LDS round trip (columns not done yet hold 0 in vb and in W)
 #pragma unroll
-    for (int i = 0; i < NBP; ++i)
-      if (i < j) {
-        const double vi = vb[0][i];
+    for (int h = 0; h < NBP; h += 4)
+      if (h < j) {
+        const double2 v01 = *reinterpret_cast<const double2*>(&vb[0][h]);
+        const double2 v23 = *reinterpret_cast<const double2*>(&vb[0][h + 2]);
 #pragma unroll
-        for (int s = 0; s < ROWS; ++s) a[s] -= W[s][i] * vi;
+        for (int s = 0; s < ROWS; ++s) {
+          a[s] -= W[s][h] * v01.x;
+          a[s] -= W[s][h + 1] * v01.y;
+          a[s] -= W[s][h + 2] * v23.x;
+          a[s] -= W[s][h + 3] * v23.y;
+        }
       }
     double v = -1.0;
     int idx = n;
@@ -587,11 +608,17 @@ __global__ void __launch_bounds__(BK_PT) bk_panel_kernel(double* A, int n, i64 l
       __syncthreads();
       double rv = 0.0;
 #pragma unroll
-      for (int i = 0; i < NBP; ++i)
-        if (i < j) {
-          const double vi = vb[1][i];
+      for (int h = 0; h < NBP; h += 4)
+        if (h < j) {
+          const double2 v01 = *reinterpret_cast<const double2*>(&vb[1][h]);
+          const double2 v23 = *reinterpret_cast<const double2*>(&vb[1][h + 2]);
 #pragma unroll
-          for (int s = 0; s < ROWS; ++s) c[s] -= W[s][i] * vi;
+          for (int s = 0; s < ROWS; ++s) {
+            c[s] -= W[s][h] * v01.x;
+            c[s] -= W[s][h + 1] * v01.y;
+            c[s] -= W[s][h + 2] * v23.x;
+            c[s] -= W[s][h + 3] * v23.y;
+          }
         }
 #pragma unroll
       for (int s = 0; s < ROWS; ++s) {
@@ -705,6 +732,7 @@ __global__ void __launch_bounds__(BK_PT) bk_panel_kernel(double* A, int n, i64 l
         dk[j] = 1;
         dk[j + 1] = 2;
         dinf[j][0] = d11; dinf[j][1] = d22; dinf[j][2] = d21;
+        dinf[j + 1][0] = d22; dinf[j + 1][1] = d11; dinf[j + 1][2] = d21;   // the second column's form of the same block
       }
     }
     j += kstep;
