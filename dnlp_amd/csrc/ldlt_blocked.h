@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_update(double* __restrict__ C,
 // chip has room for (in-panel updates of mid-size orders: 80-240 tiles for 256 CUs).  A workgroup's k-loop is a
 // chain of global round trips (16 MFMAs per wavefront per k-tile against ~1.5 us of latency), so operand tiles are
 // fetched TWO k-tiles ahead into two register sets.  GUARD = edge / diagonal tile or unaligned operands.
-constexpr int GS_B = 64, GS_PAD = 4;
+constexpr int GS_B = 64, GS_PAD = 16;   // k-rows 640 B apart: the two k-rows a half-wavefront reads fall on disjoint LDS banks
 template <bool GUARD>
 __device__ inline void gemm_body_small(double* __restrict__ C, i64 ldc, const double* __restrict__ W, i64 ldw,
                                        const double* __restrict__ L, i64 ldl, int M, int Nc, int Kd, int lower,
