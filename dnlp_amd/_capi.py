@@ -45,6 +45,7 @@ class CApi:
         f = self._fn
         f("last_error", C.c_char_p, [])
         f("create", C.c_void_p, [C.c_void_p, C.c_size_t, C.c_int])
+        f("create_arrays", C.c_void_p, [C.c_void_p, C.c_int, C.c_int])
         f("destroy", None, [C.c_void_p])
         f("bind_dense", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64])
         f("dims", C.c_int, [C.c_void_p] + [C.POINTER(C.c_int64)] * 4)
@@ -148,15 +149,36 @@ def current_device() -> int:
     return int(os.environ.get("DNLP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
 
 
+class TapeArrayDesc(C.Structure):
+    """include/dnlp_hip.h: dnlp_tape_array."""
+    _fields_ = [("name", C.c_char_p), ("dtype", C.c_int32), ("reserved", C.c_int32), ("count", C.c_uint64),
+                ("data", C.c_void_p)]
+
+
 class ProblemHandle:
     """A created `<prefix>problem` with numpy-friendly methods (shared by the product binding
     and the test oracle binding)."""
 
-    def __init__(self, api: CApi, blob: bytes, device: int = 0):
+    def __init__(self, api: CApi, blob, device: int = 0):
         self.api = api
-        # the library copies the blob while parsing it; bytes and bytearray are both accepted
-        buf = (C.c_char * len(blob)).from_buffer(blob) if isinstance(blob, bytearray) else blob
-        self.ptr = api.create(buf, len(blob), device)
+        if isinstance(blob, dict):
+            # the tape as named arrays (tape.tape_arrays): handed over in place, nothing serialised
+            # (`<prefix>create_arrays`; the library copies every array into its execution space during the call)
+            from .tape import DTYPE_CODES
+            keep, descs = [], (TapeArrayDesc * len(blob))()
+            for d, (name, arr) in zip(descs, blob.items()):
+                arr = np.ascontiguousarray(arr)
+                if arr.dtype not in DTYPE_CODES:
+                    raise TypeError("array %s has unsupported dtype %s" % (name, arr.dtype))
+                keep.append(arr)
+                d.name, d.dtype, d.reserved, d.count = name.encode(), DTYPE_CODES[arr.dtype], 0, arr.size
+                d.data = arr.ctypes.data if arr.size else None
+            self.ptr = api.create_arrays(descs, len(blob), device)
+            del keep
+        else:
+            # the library parses the blob in place (and copies what it keeps); bytes and bytearray are both accepted
+            buf = (C.c_char * len(blob)).from_buffer(blob) if isinstance(blob, bytearray) else blob
+            self.ptr = api.create(buf, len(blob), device)
         if not self.ptr:
             raise RuntimeError("%screate failed: %s" % (api.prefix, api.error()))
         n, m, nj, nh = (C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64())

@@ -58,8 +58,17 @@ struct ProblemT {
 
   void create(const void* data, size_t len) {
     blob.reset(new TapeBlob(data, len));
+    finish_create();
+  }
+  void create(const TapeArrayDesc* arrays, int n) {
+    blob.reset(new TapeBlob(arrays, n));
+    finish_create();
+  }
+  void finish_create() {
     model.init(&ex, *blob);
     fused.load(&ex, *blob);
+    ex.sync();          // every upload out of the caller's memory has landed
+    blob.reset();       // (a view of the caller's memory: not kept)
     const auto& t = model.t;
     dx = ex.template alloc<double>(static_cast<size_t>(t.N));
     dlam = ex.template alloc<double>(static_cast<size_t>(t.m + 1));
@@ -231,6 +240,13 @@ struct ProblemT {
     try {                                                                                            \
       auto* p = new HANDLE(device);                                                \
       p->create(blob, len);                                                                          \
+      return p;                                                                                      \
+    } catch (const std::exception& e) { dnlp::tls_error() = e.what(); return nullptr; }              \
+  }                                                                                                  \
+  HANDLE* DNLP_CAT(PFX, create_arrays)(const dnlp::TapeArrayDesc* arrays, int n_arrays, int device) { \
+    try {                                                                                            \
+      auto* p = new HANDLE(device);                                                                  \
+      p->create(arrays, n_arrays);                                                                   \
       return p;                                                                                      \
     } catch (const std::exception& e) { dnlp::tls_error() = e.what(); return nullptr; }              \
   }                                                                                                  \

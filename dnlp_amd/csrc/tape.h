@@ -2,6 +2,8 @@
 // Blob layout: dnlp_amd/tape.py.  Normal form: dnlp_amd/lowering.py.
 #pragma once
 #include <cmath>
+#include <cstdint>
+#include <cstring>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -17,33 +19,71 @@ struct BlobArray {
   const void* data = nullptr;
 };
 
+// One named array of a tape handed over without the blob around it (include/dnlp_hip.h: dnlp_tape_array).
+#ifdef DNLP_HIP_H
+using TapeArrayDesc = ::dnlp_tape_array;       // the product library: the public header's struct
+#else
+struct TapeArrayDesc {                         // (same layout; the test oracle library has no public header)
+  const char* name;
+  int32_t dtype;          // 0 f64, 1 i32, 2 i64
+  int32_t reserved;
+  uint64_t count;
+  const void* data;
+};
+#endif
+
+// A VIEW of the caller's memory: everything the model needs is copied into the execution space while the
+// problem is created (Tape::load, FusedObjective::load), so the blob is parsed in place -- a 1.16 GB tape
+// (BASELINE C3) used to be copied once more here -- and the view is dropped when creation is done.  Only a
+// blob that is not 8-byte aligned is copied first.
 class TapeBlob {
  public:
-  TapeBlob(const void* blob, size_t len) : buf_(static_cast<const char*>(blob), static_cast<const char*>(blob) + len) {
-    if (len < 16 || std::memcmp(buf_.data(), "DNLPTAPE", 8) != 0) throw std::runtime_error("not a DNLP tape blob");
+  TapeBlob(const void* blob, size_t len) {
+    const char* base = static_cast<const char*>(blob);
+    if (reinterpret_cast<uintptr_t>(blob) & 7) {
+      buf_.assign(base, base + len);
+      base = buf_.data();
+    }
+    if (len < 16 || std::memcmp(base, "DNLPTAPE", 8) != 0) throw std::runtime_error("not a DNLP tape blob");
     uint32_t version, n;
-    std::memcpy(&version, buf_.data() + 8, 4);
-    std::memcpy(&n, buf_.data() + 12, 4);
+    std::memcpy(&version, base + 8, 4);
+    std::memcpy(&n, base + 12, 4);
     if (version != 1) throw std::runtime_error("unsupported tape version");
     size_t pos = 16;
     for (uint32_t k = 0; k < n; ++k) {
       if (pos + 64 > len) throw std::runtime_error("truncated tape header");
       char name[41];
-      std::memcpy(name, buf_.data() + pos, 40);
+      std::memcpy(name, base + pos, 40);
       name[40] = 0;
       uint32_t dt;
       uint64_t cnt, off;
-      std::memcpy(&dt, buf_.data() + pos + 40, 4);
-      std::memcpy(&cnt, buf_.data() + pos + 48, 8);
-      std::memcpy(&off, buf_.data() + pos + 56, 8);
+      std::memcpy(&dt, base + pos + 40, 4);
+      std::memcpy(&cnt, base + pos + 48, 8);
+      std::memcpy(&off, base + pos + 56, 8);
       pos += 64;
       size_t esz = dt == 1 ? 4 : 8;
       if (off + cnt * esz > len) throw std::runtime_error(std::string("tape array out of range: ") + name);
       BlobArray a;
       a.dtype = static_cast<int>(dt);
       a.count = cnt;
-      a.data = buf_.data() + off;
+      a.data = base + off;
       arrays_[name] = a;
+    }
+  }
+  // the same tape as separate arrays (no blob was built: the arrays stay where the front-end has them)
+  TapeBlob(const TapeArrayDesc* arr, int n) {
+    if (!arr || n <= 0) throw std::runtime_error("empty tape array list");
+    for (int k = 0; k < n; ++k) {
+      if (!arr[k].name) throw std::runtime_error("tape array without a name");
+      if (arr[k].dtype < 0 || arr[k].dtype > 2) throw std::runtime_error(std::string("tape array has an unknown dtype: ") + arr[k].name);
+      if (arr[k].count && !arr[k].data) throw std::runtime_error(std::string("tape array without data: ") + arr[k].name);
+      if (reinterpret_cast<uintptr_t>(arr[k].data) & (arr[k].dtype == 1 ? 3 : 7))
+        throw std::runtime_error(std::string("tape array is not aligned to its element size: ") + arr[k].name);
+      BlobArray a;
+      a.dtype = arr[k].dtype;
+      a.count = arr[k].count;
+      a.data = arr[k].data;
+      arrays_[arr[k].name] = a;
     }
   }
   bool has(const std::string& k) const { return arrays_.count(k) != 0; }

@@ -74,7 +74,19 @@ class LinForm:
     def apply(self, S):
         """Left-multiply by a constant sparse matrix S (out_rows x rows)."""
         S = sp.csr_matrix(S)
-        return LinForm(S @ self.A, S @ self.b)
+        A = self.A
+        if (A.nnz == A.shape[0] == S.shape[1] and S.nnz > 4096 and not self.b.any()
+                and bool(np.all(A.data == 1.0)) and A.indptr[-1] == A.shape[0]
+                and bool(np.all(np.diff(A.indptr) == 1))):
+            # a plain (sub)vector of variables: S @ A is S with its columns renamed -- one gather over S's
+            # indices instead of a sparse product (a dense 1e3 x 1e4 constraint block is 1e7 entries)
+            cols = A.indices.astype(S.indices.dtype, copy=False)[S.indices]
+            R = sp.csr_matrix((S.data, cols, S.indptr), shape=(S.shape[0], A.shape[1]))
+            if not bool(np.all(np.diff(A.indices) > 0)):
+                R.has_sorted_indices = False
+                R.sort_indices()
+            return LinForm(R, np.zeros(S.shape[0]))
+        return LinForm(S @ A, S @ self.b)
 
 
 @dataclass
@@ -256,7 +268,8 @@ class Lowerer:
         A = forms[0].A
         b = forms[0].b.copy()
         for f in forms[1:]:
-            A = A + f.A
+            if f.A.nnz:                      # (a constant term has no coefficients: no sparse sum, no copy)
+                A = A + f.A if A.nnz else f.A
             b = b + f.b
         return LinForm(A, b)
 
@@ -550,7 +563,8 @@ class Lowerer:
 
 
 def _is_symmetric(P: np.ndarray) -> bool:
-    """Exact symmetry test, tile against mirrored tile (cache-sized, no n x n temporary)."""
+    """Exact symmetry test, tile against mirrored tile (cache-sized, no n x n temporary).  (Memory-bound: 0.14 s
+    for BASELINE C3's 1e4 x 1e4 block; a thread pool over the tile rows measured no faster.)"""
     n, b = P.shape[0], 256
     for i in range(0, n, b):
         for j in range(0, i + 1, b):
@@ -595,13 +609,22 @@ def lower_problem(objective_expr: Expression, constraint_exprs: List[Expression]
     N, Z = lw.N, lw.Z
     ncol = N + Z
 
+    def head_cols(A, k):
+        """A[:, :k] as CSR; when no entry lies beyond column k the arrays are shared (no 1e7-entry copy)."""
+        A = sp.csr_matrix(A)
+        if A.shape[1] == k:
+            return A
+        if A.nnz == 0 or int(A.indices.max()) < k:
+            return sp.csr_matrix((A.data, A.indices, A.indptr), shape=(A.shape[0], k))
+        return sp.csr_matrix(A[:, :k])
+
     def trim(A):
-        return sp.csr_matrix(A[:, :ncol]) if A.shape[1] != ncol else sp.csr_matrix(A)
+        return head_cols(A, ncol)
 
     c = np.asarray(trim(fobj.A).todense()).reshape(-1) if fobj.A.nnz else np.zeros(ncol)
     c0 = float(fobj.b[0])
     if forms:
-        G = trim(sp.vstack([f.A for f in forms], format="csr"))
+        G = trim(sp.vstack([f.A for f in forms], format="csr") if len(forms) > 1 else forms[0].A)
         b = np.concatenate([f.b for f in forms])
     else:
         G = sp.csr_matrix((0, ncol))
@@ -616,8 +639,12 @@ def lower_problem(objective_expr: Expression, constraint_exprs: List[Expression]
     nd, nh = drow.size, hrow.size
 
     cz = c[N:]
-    Gx = sp.csr_matrix(G[:, :N])
-    Gz = sp.csr_matrix(G[:, N:])
+    if Z:
+        Gx = head_cols(G, N)
+        Gz = sp.csr_matrix(G[:, N:]) if Gx.nnz != G.nnz else sp.csr_matrix((m, Z))
+    else:                                    # no intermediate values: G is Gx
+        Gx = G
+        Gz = sp.csr_matrix((m, 0))
 
     # gradient map: grad = c_x + Mg @ dvals
     coef = cz[drow] if nd else np.zeros(0)

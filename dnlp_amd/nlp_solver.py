@@ -234,8 +234,13 @@ class HIPNLP:
         data, inverse_data = build_nlp_data(problem, user_variables, fused_spec)
         if not make_handle:          # front-end only: the batched multistart needs just the tape arrays
             return data, inverse_data
-        blob = serialize(data["tape_arrays"])
-        handle = _capi.DeviceProblem(blob, data["tape"])
+        arrays = data["tape_arrays"]
+        if sum(a.nbytes for a in arrays.values()) >= self.LARGE_TAPE_BYTES:
+            # dense constant blocks of hundreds of MB: the arrays go to the library where they are
+            # (dnlp_create_arrays) instead of through one more gigabyte-sized copy
+            handle = _capi.DeviceProblem(arrays, data["tape"])
+        else:
+            handle = _capi.DeviceProblem(serialize(arrays), data["tape"])
         oracles = DeviceOracles(handle, len(data["x0"]), len(data["cl"]))
         data["handle"] = handle
         data["oracles"] = oracles
@@ -331,6 +336,7 @@ class HIPNLP:
         data["oracles"].iterations = info["iterations"]
         return info
 
+    LARGE_TAPE_BYTES = 64 << 20          # tapes above this are created from their arrays in place, not from a blob
     DEVICE_LOOP_MAX_ORDER = 256          # dense KKT: order up to which one wavefront runs the whole solve
     DEVICE_LOOP_MAX_ORDER_SPARSE = 20000  # sparse static-pattern KKT (csrc/sparse_plan.h)
     DEVICE_LOOP_MAX_TRIPLES = 150000      # ... whose update program one workgroup can walk in ~0.5 ms

@@ -28,6 +28,7 @@ from .lowering import Tape
 MAGIC = b"DNLPTAPE"
 VERSION = 1
 _DT = {np.dtype("float64"): 0, np.dtype("int32"): 1, np.dtype("int64"): 2}
+DTYPE_CODES = _DT          # (csrc/tape.h: BlobArray::dtype)
 
 
 def _csr(arrs: Dict[str, np.ndarray], name: str, M):

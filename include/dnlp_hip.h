@@ -39,6 +39,19 @@ const char* dnlp_version(void);
  * of `Oracles(problem, x0, m)` (nlp_solver.py:181-203) + `cyipopt.Problem(n, m, problem_obj,
  * lb, ub, cl, cu)` (ipopt_nlpif.py:143-151).  Returns NULL on failure. */
 dnlp_problem* dnlp_create(const void* tape_blob, size_t len, int device);
+/* The same tape as separate named arrays (name, dtype 0 = f64 / 1 = i32 / 2 = i64, element count, pointer
+ * aligned to the element size): nothing is serialised, each array is read where the caller has it and
+ * copied into HBM during the call -- the arrays need not outlive it.  For tapes whose dense constant
+ * blocks run to gigabytes (BASELINE config C3: 1.16 GB; the reference hands such blocks to its
+ * oracles by reference too: `Constant` values held by the expression tree, atoms/quad_form.py:33-47). */
+typedef struct dnlp_tape_array {
+  const char* name;
+  int32_t dtype;
+  int32_t reserved;
+  uint64_t count;
+  const void* data;
+} dnlp_tape_array;
+dnlp_problem* dnlp_create_arrays(const dnlp_tape_array* arrays, int n_arrays, int device);
 void dnlp_destroy(dnlp_problem* p);
 /* Bind a device-resident dense FP64 column-major matrix (order n, leading dimension ld) as
  * constant `const_id` of the tape (quad_form matrices too large to travel through the host;

@@ -343,3 +343,29 @@ def test_pivoted_ldlt_special_structures(case, gpu_required):
         ev = np.linalg.eigvalsh(A)
         assert nzero == 0 and nneg == int(np.sum(ev < 0)), n
         assert np.linalg.norm(A @ sol - b) <= 1e-9 * np.linalg.norm(A, 2) * max(np.linalg.norm(sol), 1.0), n
+
+
+@pytest.mark.gpu
+def test_create_from_arrays_on_the_device():
+    """dnlp_create_arrays (no blob: the arrays are uploaded from where the front-end has them) gives the same
+    oracles as dnlp_create, and the front-end takes that path for large tapes."""
+    from dnlp_amd import _capi
+    from dnlp_amd.nlp_solver import HIPNLP
+    from dnlp_amd.tape import serialize
+    from test_solver_oracle_cpu import _arrays_problem, _same_oracles
+    data, z, lam = _arrays_problem()
+    arrays = data["tape_arrays"]
+    _same_oracles(_capi.DeviceProblem(serialize(arrays), data["tape"]), _capi.DeviceProblem(arrays, data["tape"]), z, lam)
+    import dnlp_amd as cp
+    from problem_zoo import ZOO
+    ref = ZOO["hs071"](cp)
+    ref.solve(nlp=True)                    # through the blob
+    old = HIPNLP.LARGE_TAPE_BYTES
+    HIPNLP.LARGE_TAPE_BYTES = 0            # every tape counts as large
+    try:
+        prob = ZOO["hs071"](cp)
+        prob.solve(nlp=True)
+        assert prob.status == ref.status == "optimal" and prob.value == ref.value
+        assert np.array_equal(prob.variables()[0].value, ref.variables()[0].value)
+    finally:
+        HIPNLP.LARGE_TAPE_BYTES = old

@@ -392,3 +392,46 @@ def test_pivoted_order_limit_is_a_property_of_the_execution_space():
         assert not info["sparse"] and info["dense_pivoted"]
     finally:
         orc.close()
+
+
+def _arrays_problem():
+    import dnlp_amd as cp
+    rng = np.random.default_rng(3)
+    n, m = 40, 7
+    G = rng.standard_normal((n, n))
+    Q = G.T @ G / n + np.eye(n)
+    A = rng.standard_normal((m, n))
+    x = cp.Variable(n)
+    prob = cp.Problem(cp.Minimize(0.5 * cp.quad_form(x, Q) + rng.standard_normal(n) @ x + cp.sum(cp.exp(x))),
+                      [A @ x == A @ rng.standard_normal(n)])
+    data, _ = prob._build_chain(None).apply(prob, make_handle=False)
+    return data, rng.standard_normal(n), rng.standard_normal(m)
+
+
+def _same_oracles(h1, h2, z, lam):
+    assert (h1.n, h1.m, h1.nnz_jac, h1.nnz_hess) == (h2.n, h2.m, h2.nnz_jac, h2.nnz_hess)
+    assert h1.eval_f(z) == h2.eval_f(z)
+    for a, b in ((h1.eval_grad_f(z), h2.eval_grad_f(z)), (h1.eval_g(z), h2.eval_g(z)),
+                 (h1.eval_jac_g(z), h2.eval_jac_g(z)), (h1.eval_h(z, lam, 1.0), h2.eval_h(z, lam, 1.0))):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    for a, b in zip(h1.jac_structure() + h1.hess_structure(), h2.jac_structure() + h2.hess_structure()):
+        assert np.array_equal(a, b)
+
+
+def test_create_from_arrays_is_create_from_the_blob():
+    """`<prefix>create_arrays` (the tape's arrays handed over in place, for gigabyte-sized tapes) builds the same
+    problem as `<prefix>create` on the serialised blob; bad descriptors are refused with a message."""
+    from dnlp_amd import _capi
+    from dnlp_amd.tape import serialize
+    from oracle.oracle_capi import OracleProblem, api
+    data, z, lam = _arrays_problem()
+    arrays = data["tape_arrays"]
+    _same_oracles(OracleProblem(serialize(arrays)), OracleProblem(arrays), z, lam)
+    a = api()
+    bad = (_capi.TapeArrayDesc * 1)()
+    bad[0].name, bad[0].dtype, bad[0].count, bad[0].data = b"dims", 7, 1, 8
+    assert not a.create_arrays(bad, 1, 0) and "dtype" in a.error()
+    buf = np.zeros(4)
+    bad[0].dtype, bad[0].data = 0, buf.ctypes.data + 4
+    assert not a.create_arrays(bad, 1, 0) and "aligned" in a.error()
+    assert not a.create_arrays(None, 0, 0) and "empty" in a.error()
