@@ -1843,7 +1843,12 @@ struct HipExec : HostControlled {
     DNLP_HIP_CHECK(hipStreamSynchronize(stream));
     const int ni = static_cast<int>(n);
     if (w.bk_panels && ni > 32) {
-      if (ni <= 4 * BK_PT) bk_factor_panels<4, 16>(w, A, ni, ld, ipiv);
+      // rows per lane sized to the order: the register tile W (ROWS x 16 doubles) and the per-column work follow
+      if (ni <= BK_PT) bk_factor_panels<1, 16>(w, A, ni, ld, ipiv);
+      else if (ni <= 2 * BK_PT) bk_factor_panels<2, 16>(w, A, ni, ld, ipiv);
+      else if (ni <= 3 * BK_PT) bk_factor_panels<3, 16>(w, A, ni, ld, ipiv);
+      else if (ni <= 4 * BK_PT) bk_factor_panels<4, 8>(w, A, ni, ld, ipiv);
+      else if (ni <= 6 * BK_PT) bk_factor_panels<6, 8>(w, A, ni, ld, ipiv);
       else bk_factor_panels<8, 8>(w, A, ni, ld, ipiv);
       hipLaunchKernelGGL(bk_finish_kernel, dim3(1), dim3(BK_T), 0, stream, ipiv, ni, w.bk_perm, w.bk_dtype);
       BkState out;
