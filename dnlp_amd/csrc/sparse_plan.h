@@ -37,6 +37,8 @@
 #include <cstdlib>
 #include <queue>
 #include <vector>
+#include <atomic>
+#include <thread>
 
 #include "tape.h"
 
@@ -445,44 +447,64 @@ struct SparsePlanHost {
     // Every pair (iu >= iv) of a block's struct updates the entry (S[iu], S[iv]).  For a fixed iv the
     // destinations live in the struct of S[iv]'s block, which is sorted by the same (block position, node)
     // key as S: one merge scan per iv instead of a binary search per pair (6e7 pairs in the NMF example).
+    // Blocks are independent and their triple ranges are known up front (sz (sz + 1) / 2 each), so the program is
+    // written in place by a few host threads, blocks handed out in chunks from a shared counter.
     toff.assign(static_cast<size_t>(nb + 1), 0);
-    {
-      i64 total = 0;
-      for (i64 k = 0; k < nb; ++k) { const i64 sz = soff[static_cast<size_t>(k + 1)] - soff[static_cast<size_t>(k)]; total += sz * (sz + 1) / 2; }
-      tdst.reserve(static_cast<size_t>(total)); tiu.reserve(static_cast<size_t>(total));
-      tiv.reserve(static_cast<size_t>(total)); tblk.reserve(static_cast<size_t>(total));
-    }
-    std::vector<i32> dtmp;
     for (i64 k = 0; k < nb; ++k) {
-      const i64 s0 = soff[static_cast<size_t>(k)], sz = soff[static_cast<size_t>(k + 1)] - s0;
-      dtmp.assign(static_cast<size_t>(sz * (sz + 1) / 2), -1);
-      for (i64 iv = 0; iv < sz; ++iv) {
-        const i32 w = sidx[static_cast<size_t>(s0 + iv)];
-        const i64 kw = npos[static_cast<size_t>(w)];
-        const i64 w0 = soff[static_cast<size_t>(kw)], w1 = soff[static_cast<size_t>(kw + 1)];
-        const int bk = bnode[static_cast<size_t>(2 * kw + 1)] >= 0 ? 2 : 1;
-        i64 pcur = w0;
-        for (i64 iu = iv; iu < sz; ++iu) {
-          const i32 u = sidx[static_cast<size_t>(s0 + iu)];
-          i64 a;
-          if (npos[static_cast<size_t>(u)] == kw) {
-            a = (u == w) ? doff[static_cast<size_t>(kw)] + (ncol[static_cast<size_t>(u)] == 0 ? 0 : 2) : doff[static_cast<size_t>(kw)] + 1;
-          } else {
-            while (pcur < w1 && sidx[static_cast<size_t>(pcur)] != u) ++pcur;
-            if (pcur >= w1) throw std::runtime_error("sparse KKT plan: fill entry outside the pattern");
-            a = loff[static_cast<size_t>(kw)] + (pcur - w0) * bk + ncol[static_cast<size_t>(w)];
+      const i64 sz = soff[static_cast<size_t>(k + 1)] - soff[static_cast<size_t>(k)];
+      toff[static_cast<size_t>(k + 1)] = toff[static_cast<size_t>(k)] + sz * (sz + 1) / 2;
+    }
+    {
+      const size_t total = static_cast<size_t>(toff[static_cast<size_t>(nb)]);
+      tdst.resize(total); tiu.resize(total); tiv.resize(total); tblk.resize(total);
+      std::atomic<i64> next{0};
+      std::atomic<bool> failed{false};
+      auto work = [&]() {
+        std::vector<i32> dtmp;
+        const i64 chunk = 64;
+        for (;;) {
+          const i64 kb = next.fetch_add(chunk);
+          if (kb >= nb || failed.load()) return;
+          for (i64 k = kb; k < std::min(nb, kb + chunk); ++k) {
+            const i64 s0 = soff[static_cast<size_t>(k)], sz = soff[static_cast<size_t>(k + 1)] - s0;
+            dtmp.assign(static_cast<size_t>(sz * (sz + 1) / 2), -1);
+            for (i64 iv = 0; iv < sz; ++iv) {
+              const i32 w = sidx[static_cast<size_t>(s0 + iv)];
+              const i64 kw = npos[static_cast<size_t>(w)];
+              const i64 w0 = soff[static_cast<size_t>(kw)], w1 = soff[static_cast<size_t>(kw + 1)];
+              const int bk = bnode[static_cast<size_t>(2 * kw + 1)] >= 0 ? 2 : 1;
+              i64 pcur = w0;
+              for (i64 iu = iv; iu < sz; ++iu) {
+                const i32 u = sidx[static_cast<size_t>(s0 + iu)];
+                i64 a;
+                if (npos[static_cast<size_t>(u)] == kw) {
+                  a = (u == w) ? doff[static_cast<size_t>(kw)] + (ncol[static_cast<size_t>(u)] == 0 ? 0 : 2) : doff[static_cast<size_t>(kw)] + 1;
+                } else {
+                  while (pcur < w1 && sidx[static_cast<size_t>(pcur)] != u) ++pcur;
+                  if (pcur >= w1) { failed.store(true); return; }
+                  a = loff[static_cast<size_t>(kw)] + (pcur - w0) * bk + ncol[static_cast<size_t>(w)];
+                }
+                dtmp[static_cast<size_t>(iu * (iu + 1) / 2 + iv)] = static_cast<i32>(a);
+              }
+            }
+            size_t q = static_cast<size_t>(toff[static_cast<size_t>(k)]);
+            for (i64 iu = 0; iu < sz; ++iu)
+              for (i64 iv = 0; iv <= iu; ++iv, ++q) {
+                tdst[q] = dtmp[static_cast<size_t>(iu * (iu + 1) / 2 + iv)];
+                tiu[q] = static_cast<i32>(iu);
+                tiv[q] = static_cast<i32>(iv);
+                tblk[q] = static_cast<i32>(k);
+              }
           }
-          dtmp[static_cast<size_t>(iu * (iu + 1) / 2 + iv)] = static_cast<i32>(a);
         }
-      }
-      for (i64 iu = 0; iu < sz; ++iu)
-        for (i64 iv = 0; iv <= iu; ++iv) {
-          tdst.push_back(dtmp[static_cast<size_t>(iu * (iu + 1) / 2 + iv)]);
-          tiu.push_back(static_cast<i32>(iu));
-          tiv.push_back(static_cast<i32>(iv));
-          tblk.push_back(static_cast<i32>(k));
-        }
-      toff[static_cast<size_t>(k + 1)] = static_cast<i64>(tdst.size());
+      };
+      unsigned nthreads = total > (1u << 20) ? std::min(4u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+      if (const char* ev = std::getenv("DNLP_PLAN_THREADS")) nthreads = static_cast<unsigned>(std::max(1, std::atoi(ev)));
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(work);
+      work();
+      for (std::thread& th : pool) th.join();
+      if (failed.load()) throw std::runtime_error("sparse KKT plan: fill entry outside the pattern");
     }
     tick("update program");
     lev_row.clear(); lev_trip.clear(); lev_val.clear();
