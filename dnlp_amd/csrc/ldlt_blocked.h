@@ -908,7 +908,7 @@ struct BlockedLdlt {
     // Mid-size orders keep `reserve_cus` compute units (one per XCD for 8: mask bit i is XCD i % 8) out of the
     // update stream's CU mask: a panel kernel of the look-ahead chain otherwise waits for a CU on which BOTH
     // resident update workgroups have retired (~a tile time per launch, longer than the kernel itself).
-    if (n < 32768) reserve_cus = 8;
+    if (n < 16384) reserve_cus = 8;      // (order 22 000 loses 3.5 % with the mask, 11 000 gains 1 %, below 6000 neutral)
     if (const char* ev = std::getenv("DNLP_LDLT_RESERVE_CUS")) reserve_cus = std::atoi(ev);
     if (reserve_cus > 0 && lookahead) {
       int dev = 0, ncu = 0;
