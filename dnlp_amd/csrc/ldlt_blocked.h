@@ -886,7 +886,7 @@ struct BlockedLdlt {
     // wide outer panels for large orders: the update kernel runs at the same rate for K = 512 / 768 / 1024
     // (62.3 +- 0.2 TF at n = 1e5) and half the panels means half the exposed panel heads and tails
     // (n = 1e5: 5.46 -> 5.37 s per factorisation); mid-size orders measured flat between 256 and 768
-    if (n >= 32768) NB = 1024;
+    if (n >= 20000) NB = 1024;          // (order 15 000: 512 is 3 % faster; 22 000 and 30 000: 1024 is 2-3 % faster)
     if (const char* ev = std::getenv("DNLP_LDLT_NB")) NB = std::atoi(ev);
     if (const char* ev = std::getenv("DNLP_LDLT_LOOKAHEAD")) lookahead = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_XCD")) xcd_swizzle = std::atoi(ev) != 0;
