@@ -9,7 +9,16 @@ factorisation does not shard without a distributed factorisation, SURVEY.md §8e
 scaling, no data-path collective, one RCCL all_gather of the per-rank results at the end.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 8 --steps 20 --warmup 5          # starts its 8 ranks itself (child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--workload c5 --batch 8192` is BASELINE config C5 by the same command: the batch of parametrised
+paper NLPs is sharded over the N ranks (8 x 1024 at N = 8), one launch per rank, ONE RCCL
+all_gather of {id, objective, status, iterations, x*}; a step is one pass over the whole batch.
+
+With --gpus N > 1 and no WORLD_SIZE in the environment this process touches neither torch nor HIP:
+it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process and
+exits with its code (never an exec of a process that initialised the GPU).
 """
 import argparse
 import json
@@ -135,34 +144,257 @@ def cpu_baseline(seed, device, sweep=CPU_SWEEP):
                          ctypes.util.find_library("ipopt") or "not found")}
 
 
+C5_TRAFFIC_PROFILE = "r03_pmc_batch_8192.json"  # rocprofv3 --pmc passes of `bench.py --workload c5` (per round)
+PEAK_HBM_GBS = 8000.0                           # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def c5_template(which):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))     # problem definitions (paper notebooks), not the oracle
+    import batch_problems as bp
+    return {"localization": bp.template_localization, "circle_packing": bp.template_circle_packing,
+            "circle_packing10": lambda: bp.template_circle_packing(10),
+            "path_planning": bp.template_path_planning, "power_flow": bp.template_power_flow}[which]()
+
+
+def c5_cpu_baseline(pb, thetas, budget_s=12.0):
+    """The CPU oracle (host build of the same algorithm, one core) on a bounded sample of the same
+    instances: as many of the batch's first rows as fit in ~budget_s seconds."""
+    from dnlp_amd.batch import arrays_with_data
+    from dnlp_amd.nlp_solver import HIPNLP
+    from dnlp_amd.tape import serialize
+    from oracle.oracle_capi import OracleProblem
+    mat = pb.data(thetas[:min(len(thetas), 4096)])
+    done, iters, t0 = 0, 0, time.time()
+    for row in mat:
+        a = arrays_with_data(pb.arrays0, row)
+        o = OracleProblem(serialize(a))
+        for k, v in HIPNLP.DEFAULT_OPTIONS.items():
+            o.set_option(k, v)
+        r = o.solve(a["x0"])
+        o.close()
+        done += 1
+        iters += int(r["iterations"])
+        if time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    return {"value": done / dt, "unit": "problems/s", "cores": 1, "kind": "port", "iters_per_s": iters / dt,
+            "sample": "CPU oracle (host build of the same interior-point algorithm, sparse static-pattern LDL^T, "
+                      "one core) on the first %d instances of the same batch, %.1f s; tape creation per instance "
+                      "included (the device path shares one tape)" % (done, dt)}
+
+
+def bench_c5(args):
+    """BASELINE config C5: `--batch` parametrised paper NLPs, contiguous shards of ceil(B/N) instances
+    per rank, one batch_solve launch per rank and step, ONE all_gather of the result rows per step
+    (inside the timed region).  A step = one pass over the whole batch, from parameter rows in host
+    memory to gathered results on every rank."""
+    rank, world, local, dist, tdev, torch = init_ranks(args)
+    from dnlp_amd import _capi
+    _capi.require_device(local)
+    from dnlp_amd.batch import ParametricBatch, shard_bounds
+    prob, params, sample, _ = c5_template(args.which)
+    pb = ParametricBatch(prob, params)
+    B = args.batch
+    lo, hi = shard_bounds(B, rank, world)
+    thetas = np.stack([sample(i) for i in range(B)])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def step():
+        rows, info = pb.solve_sharded(thetas, device=local)
+        return rows, info
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.time()
+    ksec, gbytes = 0.0, 0
+    for _ in range(args.steps):
+        rows, info = step()
+        ksec += info["kernel_seconds"]
+        gbytes += info["gathered_bytes"]
+    barrier()
+    dt = time.time() - t0
+    assert rows.shape[0] == B and np.array_equal(rows[:, 0], np.arange(B)), "gathered rows are not the whole batch"
+    gathered_ranks, backend_name = info["ranks"], info["backend"]
+    if dist is not None:
+        tm = torch.tensor([dt, ksec], device=tdev, dtype=torch.float64)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dt_all, ksec_all = float(tm[0].item()), float(tm[1].item())
+        assert gathered_ranks == args.gpus, "the gather saw %d ranks, --gpus %d" % (gathered_ranks, args.gpus)
+        if args.backend == "nccl":
+            assert backend_name == "nccl", backend_name
+            backend_name = "nccl (RCCL)"
+    else:
+        dt_all, ksec_all = dt, ksec
+        r1, b1, backend_name = single_rank_collective(torch, local, rows[0, :4].tolist())
+    if rank == 0:
+        N, m = int(pb.arrays0["dims"][0]), int(pb.arrays0["dims"][1])
+        h = pb._handle
+        nnzj, nnzh = int(h.nnz_jac), int(h.nnz_hess)
+        iters_total = float(rows[:, 3].sum())
+        # SURVEY 8d: per-iteration oracle bytes f 8N + grad 16N + g (8N+8m) + J (8N+8nnzJ) + H (8N+8m+8nnzH)
+        bytes_iter = 8 * N + 16 * N + (8 * N + 8 * m) + (8 * N + 8 * nnzj) + (8 * N + 8 * m + 8 * nnzh)
+        per_launch_s = ksec_all / args.steps
+        shard = hi - lo
+        alg_bytes_launch = bytes_iter * float(rows[lo:hi, 3].sum())
+        traffic, traffic_src = None, None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", C5_TRAFFIC_PROFILE)))
+            if pj.get("which") == args.which and int(pj.get("batch", 0)) == shard:
+                traffic = pj["traffic_bytes_per_launch"]
+                traffic_src = "profiles/" + C5_TRAFFIC_PROFILE
+        except (OSError, KeyError, ValueError):
+            pass
+        out = {
+            "metric": "problems/sec, batch of %d parametrised paper NLPs (%s), sharded over the GPUs" % (B, args.which),
+            "value": B * args.steps / dt_all, "unit": "problems/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_all / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C5: %d x %d instances of %s (N=%d, m=%d, nnzJ=%d, nnzH=%d), parameters drawn per "
+                                   "instance from default_rng(instance id); one batch_solve launch per rank, one "
+                                   "all_gather of {id, obj, status, iterations, x*} per step"
+                                   % (world, -(-B // world), args.which, N, m, nnzj, nnzh),
+                       "batch_total": B, "shard": [lo, hi],
+                       "optimal": int(np.sum(rows[:, 2] == 0)), "acceptable": int(np.sum(rows[:, 2] == 1)),
+                       "ip_iterations_per_pass": iters_total,
+                       "aggregate_ip_iterations_per_s": iters_total * args.steps / dt_all,
+                       "problems_per_s_kernel_only": B * args.steps / ksec_all if ksec_all > 0 else None,
+                       "gathered_ranks": gathered_ranks, "gathered_bytes": gbytes // max(args.steps, 1),
+                       "collective_backend": backend_name},
+            "roofline": {"bound": "hbm", "kernel": "batch_solve_kernel (whole interior-point loop per wavefront)",
+                         "achieved": alg_bytes_launch / per_launch_s / 1e9 if per_launch_s > 0 else None,
+                         "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": alg_bytes_launch / per_launch_s / 1e9 / PEAK_HBM_GBS if per_launch_s > 0 else None,
+                         "algorithmic_bytes_per_iteration": bytes_iter, "avg_launch_ms": 1e3 * per_launch_s,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "note": "latency-bound: one wavefront per instance runs a dependent chain; neither roof is near "
+                                 "(DESIGN.md 4a)"},
+        }
+        if world > 1 or args.no_cpu:
+            out["cpu_baseline"] = {"value": None, "unit": "problems/s", "cores": 0, "kind": "port",
+                                   "sample": "not timed (N > 1 or --no-cpu; see the N = 1 line)"}
+        else:
+            try:
+                out["cpu_baseline"] = c5_cpu_baseline(pb, thetas)
+            except Exception as e:
+                out["cpu_baseline"] = {"value": None, "unit": "problems/s", "cores": 1, "kind": "port",
+                                       "sample": "failed: %s" % e}
+        print(json.dumps(out))
+    pb.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def self_launch(n_ranks):
+    """--gpus N > 1 without a launcher: start the N ranks as children of this process, which has not
+    imported torch or touched HIP (the reference's counterpart is the serial multistart loop,
+    problems/problem.py:1256-1269).  Rank 0's JSON line reaches stdout through the inherited stream;
+    the exit code is the launcher's (non-zero when any rank fails)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_ranks)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def init_ranks(args):
+    """(rank, world, local device, dist module or None, tensor device, torch).  One process per GPU;
+    a launch with more ranks than visible GPUs fails loudly instead of sharing devices."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench: --gpus %d but the launcher set WORLD_SIZE=%d" % (args.gpus, world))
+    import torch
+    dist, tdev = None, "cpu"
+    if world > 1:
+        import datetime
+        import torch.distributed as dist
+        if args.backend == "nccl":
+            ndev = torch.cuda.device_count()
+            if ndev < world:
+                raise SystemExit("bench: %d ranks but %d GPUs visible (one process per GPU)" % (world, ndev))
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local),
+                                    timeout=datetime.timedelta(seconds=600))
+            tdev = "cuda"
+        else:
+            dist.init_process_group(args.backend)
+            local = local % max(torch.cuda.device_count(), 1)     # gloo debugging runs may share a GPU
+    os.environ["DNLP_DEVICE"] = str(local)
+    return rank, world, local, dist, tdev, torch
+
+
+def single_rank_collective(torch, local, payload):
+    """N = 1: the path's one exchange still runs once over RCCL (a one-rank group: all_reduce +
+    all_gather on device tensors), after the timed region — evidence that the collective the N > 1
+    runs depend on initialises and executes on this box.  Reported, never required."""
+    import datetime
+    import socket
+    try:
+        import torch.distributed as dist
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=120))
+        t = torch.tensor(payload, dtype=torch.float64, device="cuda")
+        mx = t.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        parts = [torch.zeros_like(t)]
+        dist.all_gather(parts, t)
+        torch.cuda.synchronize()
+        ok = bool(torch.equal(parts[0], t) and torch.equal(mx, t))
+        name = dist.get_backend()
+        n = dist.get_world_size()
+        dist.destroy_process_group()
+        if not ok:
+            return 1, 0, "nccl (RCCL): one-rank all_gather returned other data"
+        return n, int(t.numel() * t.element_size()), "%s (RCCL)" % name if name == "nccl" else name
+    except Exception as e:            # pragma: no cover - depends on the box
+        return 1, 0, "unavailable: %s" % str(e)[:200]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 3; 5 for --workload c5)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 1; 2 for --workload c5)")
+    ap.add_argument("--workload", default="c4", choices=("c4", "c5"),
+                    help="c4: dense n=1e5 NLP, iterations/s (the metric's config); c5: sharded batch of paper NLPs")
     ap.add_argument("--order", type=int, default=100000, help="order n of the dense NLP (BASELINE: 1e5)")
+    ap.add_argument("--batch", type=int, default=8192, help="c5: instances in the whole job (BASELINE: 8 x 1024)")
+    ap.add_argument("--which", default="localization",
+                    help="c5 member: localization | circle_packing10 | power_flow | path_planning | circle_packing")
     ap.add_argument("--cpu-sweep", default="", help="CPU baseline orders as n:iters,... (default: 1000:3,2000:3,4000:2,10000:1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench: --gpus must be >= 1")
+    # the launch decision comes before torch / HIP are touched: children, never a re-exec
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    if args.workload == "c5":
+        args.steps = 5 if args.steps is None else args.steps
+        args.warmup = 2 if args.warmup is None else args.warmup
+        return bench_c5(args)
+    args.steps = 3 if args.steps is None else args.steps
+    args.warmup = 1 if args.warmup is None else args.warmup
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
-    ndev = max(torch.cuda.device_count(), 1)
-    local = local % ndev            # one process per GPU; wraps only in single-GPU debugging runs
-    os.environ["DNLP_DEVICE"] = str(local)
-    dist = None
-    tdev = "cpu"
-    if world > 1:
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-            tdev = "cuda"
-        else:
-            dist.init_process_group(args.backend)
+    rank, world, local, dist, tdev, torch = init_ranks(args)
 
     from dnlp_amd import _capi
     _capi.require_device(local)
@@ -206,8 +438,13 @@ def main():
         gathered_ranks = dist.get_world_size()
         gathered_bytes = int(sum(g.numel() * g.element_size() for g in gathered))
         backend_name = "%s (RCCL)" % dist.get_backend() if dist.get_backend() == "nccl" else dist.get_backend()
+        assert gathered_ranks == args.gpus, "the gather saw %d ranks, --gpus %d" % (gathered_ranks, args.gpus)
+        if args.backend == "nccl":
+            assert backend_name == "nccl (RCCL)", backend_name
     else:
         dt_all = dt
+        gathered_ranks, gathered_bytes, backend_name = single_rank_collective(
+            torch, local, [info["obj_val"], float(info["iterations"]), float(info["status"])])
     if rank == 0:
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same
         # command (FETCH_SIZE and WRITE_SIZE cannot share a pass); the committed summary is quoted

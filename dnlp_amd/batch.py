@@ -243,13 +243,15 @@ class ParametricBatch:
             print("[batch.py] data %.4f handle %.4f solve_batch %.4f" % (t1 - t0, t2 - t1, t3 - t2), flush=True)
         return BatchResult(raw, self.inv, self.flip)
 
-    def solve_sharded(self, thetas, device=None, **opts):
+    def solve_sharded(self, thetas, device=None, force_collective=False, **opts):
         """Problem-parallel solve across the ranks of an initialised torch.distributed group (one
         process per GPU): rank r solves the contiguous block shard_bounds(B, r, W) of the
         rows of `thetas` in ONE launch on its own GPU, then ONE all_gather (RCCL over xGMI with the nccl
         backend) gives every rank all rows {id, objective, status, iterations, x*}.  Without a process
-        group it is a plain solve.  Returns (rows ordered by instance id, info) with info = ranks the
-        collective saw, bytes it moved, this rank's kernel seconds."""
+        group it is a plain solve; with a one-rank group the exchange is skipped unless
+        `force_collective` asks for it (the single-GPU test of the RCCL path).  Returns (rows ordered by
+        instance id, info) with info = ranks the collective saw, bytes it moved, this rank's kernel
+        seconds."""
         thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
         B = thetas.shape[0]
         rank, world, backend = 0, 1, None
@@ -268,10 +270,12 @@ class ParametricBatch:
             ksec = res.kernel_seconds
         else:
             local, ksec = np.zeros((0, 4 + int(self.arrays0["dims"][0]))), 0.0
-        rows = gather_rows(local, B)
+        rows = gather_rows(local, B, force=force_collective)
         per = math.ceil(B / world) if world > 0 else B
+        exchanged = backend is not None and (world > 1 or force_collective)
         info = {"ranks": world, "backend": backend, "rank": rank, "shard": (lo, hi), "kernel_seconds": ksec,
-                "gathered_bytes": 0 if world == 1 else int(world * per * rows.shape[1] * 8)}
+                "collective": exchanged,
+                "gathered_bytes": int(world * per * rows.shape[1] * 8) if exchanged else 0}
         return rows, info
 
     def close(self):
@@ -325,20 +329,21 @@ def solve_shard(build: Callable[[int], object], ids: Sequence[int], solver: Call
     return out
 
 
-def gather_rows(local: np.ndarray, n_items: int):
+def gather_rows(local: np.ndarray, n_items: int, force: bool = False):
     """The single exchange of the path: every rank receives all rows, ordered by instance id.
-    Works with any initialised torch.distributed backend; a no-op without a process group."""
+    Works with any initialised torch.distributed backend; a no-op without a process group.  A
+    one-rank group skips the collective unless `force` is set (then the all_reduce + all_gather run
+    on the backend all the same: how the RCCL path is exercised on a single MI355X)."""
     try:
         import torch
         import torch.distributed as dist
     except ImportError:   # pragma: no cover
         return local
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return local[np.argsort(local[:, 0])] if local.size else local
     world = dist.get_world_size()
     per = math.ceil(n_items / world)
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) \
-        if dist.get_backend() == "nccl" else torch.device("cpu")
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     # rows are padded to a common width and a common count so one all_gather suffices
     width = torch.tensor([local.shape[1] if local.size else 0], dtype=torch.int64, device=dev)
     dist.all_reduce(width, op=dist.ReduceOp.MAX)

@@ -207,6 +207,7 @@ struct ProblemT {
     else if (k == "fused_codegen") set_fused_codegen(yes());
     else if (k == "lbfgs_device_loop") lbfgs_device_loop = yes();
     else if (k == "adaptive_fallback") opt.adaptive_fallback = yes() ? 1 : 0;
+    else if (k == "stall_guard") opt.stall_guard = (v == "auto") ? -1 : yes() ? 1 : 0;
     else if (k == "lanczos_inertia_bound") opt.lanczos_inertia_bound = yes() ? 1 : 0;
     else if (k == "lanczos_min_n") opt.lanczos_min_n = static_cast<int>(num());
     else if (k == "linear_solver") {

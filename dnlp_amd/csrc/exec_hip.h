@@ -462,8 +462,12 @@ __global__ void __launch_bounds__(kBlock) bk_update_kernel(double* A, int n, i64
 struct BkPanelSwaps { int count; int pad; int rows[2 * 16]; };
 
 __device__ inline void bk_barrier_lds_only() {
-  __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0) only: outstanding global stores keep draining
+  // workgroup barrier that orders LDS traffic only: release / acquire fences restricted to the local address
+  // space (the compiler may not move LDS accesses across them; they lower to s_waitcnt lgkmcnt(0), so
+  // outstanding global stores keep draining — no vmcnt wait, no hard-coded waitcnt immediate)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // (512 lanes x ROWS rows: 1024 lanes leave 128 VGPRs per lane, and W alone is 64 of them -- the kernel spilled)
@@ -534,8 +538,11 @@ __global__ void __launch_bounds__(BK_PT) bk_panel_kernel(double* A, int n, i64 l
         xr[slot][0] = 0.0;
         xr[slot][NBP + 1] = 0.0;
       }
-      __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): one wavefront's LDS operations complete in order
+      // one wavefront's LDS operations complete in order; the fences keep the compiler from moving the
+      // xr stores below / the dk, dinf, xr loads above this point (lgkmcnt(0) only, no vmcnt wait)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
       if (lane < NBP) {
         const int d = dk[lane];
         const double e0 = dinf[lane][0], e2 = dinf[lane][2];
@@ -1344,6 +1351,14 @@ struct HipExec : HostControlled {
     for (auto& f : at_exit_) f();                 // host objects that hold streams / events on this device
     for (const LevelGraph& g : level_graphs_) hipGraphExecDestroy(g.exec);
     for (void* p : owned_) hipFree(p);
+    // device-resident L-BFGS workspace (lbfgs_generated_solve): (2M + 3) nfree doubles per handle
+    if (lb_state) hipFree(lb_state);
+    if (lb_host) hipHostFree(lb_host);
+    if (lb_fpart) hipFree(lb_fpart);
+    if (lb_upart) hipFree(lb_upart);
+    if (lb_BV) hipFree(lb_BV);
+    if (lb_dir) hipFree(lb_dir);
+    if (lb_gt) hipFree(lb_gt);
     if (gemv_part) hipFree(gemv_part);
     if (d_partial) hipFree(d_partial);
     if (h_partial) hipHostFree(h_partial);

@@ -1,7 +1,10 @@
 // Run-time compilation of generated kernels (fused_codegen.h, lbfgs_codegen.h): hiprtc -> code
 // object for gfx950 -> hipModuleLoadData.  Code objects are cached on disk by the hash of their
-// source ($DNLP_KERNEL_CACHE, default /tmp/dnlp_kernel_cache-<uid>), so a problem structure is
-// compiled once per machine.
+// source and the hiprtc version ($DNLP_KERNEL_CACHE, else $XDG_CACHE_HOME/dnlp_kernel_cache, else
+// /tmp/dnlp_kernel_cache-<uid>), so a problem structure is compiled once per machine.  The cache
+// directory is used only when it is a real directory owned by this user with mode 0700 (code objects
+// are executed: a directory somebody else could have planted is ignored and the kernel is compiled
+// afresh); a cached object that no longer loads is deleted and recompiled.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
@@ -23,15 +26,39 @@ inline uint64_t rtc_hash(const std::string& s) {
 
 inline std::string rtc_cache_dir() {
   if (const char* d = std::getenv("DNLP_KERNEL_CACHE")) return d;
+  if (const char* x = std::getenv("XDG_CACHE_HOME")) if (*x) return std::string(x) + "/dnlp_kernel_cache";
   return "/tmp/dnlp_kernel_cache-" + std::to_string(static_cast<long>(getuid()));
+}
+
+// The cache directory, created if absent; "" when it cannot be trusted (not a directory, a symlink,
+// another owner, or group / world accessible).
+inline std::string rtc_trusted_cache_dir() {
+  const std::string dir = rtc_cache_dir();
+  struct stat st;
+  if (lstat(dir.c_str(), &st) != 0) {
+    if (mkdir(dir.c_str(), 0700) != 0 || lstat(dir.c_str(), &st) != 0) return "";
+  }
+  if (!S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 077) != 0) return "";
+  return dir;
+}
+
+inline std::string rtc_cache_path(const std::string& src, const std::string& arch) {
+  const std::string dir = rtc_trusted_cache_dir();
+  if (dir.empty()) return "";
+  int major = 0, minor = 0;
+  hiprtcVersion(&major, &minor);
+  char name[64];
+  std::snprintf(name, sizeof name, "%016llx.hsaco",
+                static_cast<unsigned long long>(rtc_hash(src + arch + "#hiprtc" + std::to_string(major) + "." +
+                                                         std::to_string(minor))));
+  return dir + "/" + name;
 }
 
 // Compile `src` for gfx950.  Returns the code object (empty on failure, `log` has the compiler text).
 inline std::vector<char> rtc_compile(const std::string& src, std::string& log, bool use_cache = true) {
   const std::string arch = "--offload-arch=gfx950";
-  char name[64];
-  std::snprintf(name, sizeof name, "%016llx.hsaco", static_cast<unsigned long long>(rtc_hash(src + arch)));
-  const std::string dir = rtc_cache_dir(), path = dir + "/" + name;
+  const std::string path = use_cache ? rtc_cache_path(src, arch) : std::string();
+  if (path.empty()) use_cache = false;
   std::vector<char> code;
   if (use_cache) {
     if (FILE* fp = std::fopen(path.c_str(), "rb")) {
@@ -66,7 +93,6 @@ inline std::vector<char> rtc_compile(const std::string& src, std::string& log, b
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
   if (use_cache && !code.empty()) {
-    mkdir(dir.c_str(), 0700);
     const std::string tmp = path + ".tmp" + std::to_string(static_cast<long>(getpid()));
     if (FILE* fp = std::fopen(tmp.c_str(), "wb")) {
       const size_t w = std::fwrite(code.data(), 1, code.size(), fp);
@@ -86,9 +112,18 @@ struct RtcKernel {
   ~RtcKernel() { if (mod) hipModuleUnload(mod); }
   bool load(const std::string& src, const char* entry) {
     tried = true;
-    const std::vector<char> code = rtc_compile(src, log);
+    std::vector<char> code = rtc_compile(src, log);
     if (code.empty()) return false;
-    if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { log += " hipModuleLoadData failed"; mod = nullptr; return false; }
+    if (hipModuleLoadData(&mod, code.data()) != hipSuccess) {
+      // a truncated / stale cached object: drop it and compile afresh, once
+      mod = nullptr;
+      const std::string path = rtc_cache_path(src, "--offload-arch=gfx950");
+      if (!path.empty()) std::remove(path.c_str());
+      code = rtc_compile(src, log, false);
+      if (code.empty() || hipModuleLoadData(&mod, code.data()) != hipSuccess) {
+        log += " hipModuleLoadData failed"; mod = nullptr; return false;
+      }
+    }
     if (hipModuleGetFunction(&fn, mod, entry) != hipSuccess) { log += " entry point not found"; return false; }
     ok = true;
     return true;

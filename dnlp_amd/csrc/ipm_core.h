@@ -51,6 +51,8 @@ struct IpmOptions {
   int max_refine = 10, min_refine = 1;
   int restoration = 1;
   int adaptive_fallback = 1;
+  int stall_guard = -1;              // -1 auto: only inside solve() while a rung of the retry ladder is still ahead
+                                     // (adaptive_fallback on); 1 always; 0 never (IPOPT has no such rule)
   int lazy_dense_fallback = 0;       // 1: a sparse instance switches to Bunch-Kaufman only in the rungs of the retry
                                      // ladder (the first run handles singular static pivots with delta_c alone)
   int lanczos_inertia_bound = 1;
@@ -1269,8 +1271,25 @@ class Ipm {
     // bounds while the direction is huge) make no progress that max_iter could wait for — observed on one
     // of 8192 circle-packing instances in free-mu mode: alpha_pr = 1e-4, ||d|| ~ 500 for 3000 iterations,
     // while the monotone rung solves the same instance in 23.  Reported as IPOPT's tiny-step status.
-    tiny_streak_ = alpha_used <= 1e-3 ? tiny_streak_ + 1 : 0;
-    if (tiny_streak_ >= 40) return status = Search_Direction_Becomes_Too_Small;
+    // IPOPT has no such rule, and long runs of short fraction-to-boundary steps are legitimate on badly
+    // scaled problems: the guard is active only where a rung of the retry ladder can take the run over
+    // (inside solve() with adaptive_fallback on; option stall_guard = yes / no overrides), and a streak
+    // counts only while neither the violation nor the objective moved since it began.
+    const bool guard_on = opt.stall_guard == 1 ||
+                          (opt.stall_guard < 0 && in_solve_ && opt.adaptive_fallback && ladder_rung_ < 2);
+    if (guard_on && alpha_used <= 1e-3) {
+      if (tiny_streak_ == 0) { streak_theta0_ = theta_k; streak_f0_ = f; }
+      ++tiny_streak_;
+      const bool progress = th_t < 0.9 * streak_theta0_ ||
+                            f_t < streak_f0_ - 1e-3 * fmax(1.0, fabs(streak_f0_));
+      if (progress) tiny_streak_ = 0;
+    } else {
+      tiny_streak_ = 0;
+    }
+    if (tiny_streak_ >= 40) {
+      logf("stall guard: 40 accepted steps with alpha_pr <= 1e-3 and no progress in theta or f (iteration %d)", iter);
+      return status = Search_Direction_Becomes_Too_Small;
+    }
     Err e = error(0.0);
     e_cached_ = e;
     e_cached_valid_ = true;
@@ -1723,8 +1742,9 @@ class Ipm {
   // ---- driver -------------------------------------------------------------------------
   DNLP_HD int solve(const double* x0_ctl) {
     const double t_all = now_sec();
+    in_solve_ = true;
     int rc = begin(x0_ctl);
-    if (rc != 0) return rc;
+    if (rc != 0) { in_solve_ = false; return rc; }
     while (true) {
       int r = step();
       if (r != 99) break;
@@ -1776,6 +1796,7 @@ class Ipm {
       opt.max_wall_time = max_wall0;
       ladder_rung_ = 0;
     }
+    in_solve_ = false;
     stats.wall = now_sec() - t_all;
     stats.final_mu = mu;
     return status;
@@ -1848,6 +1869,8 @@ class Ipm {
   int last_nneg_ = 0;               // negative pivots reported by the last factorisation attempt
   int ladder_rung_ = 0;             // 0: first run; 1, 2: rungs of the retry ladder
   int tiny_streak_ = 0;             // consecutive accepted steps with alpha_pr <= 1e-3 (stall guard)
+  double streak_theta0_ = 0.0, streak_f0_ = 0.0;   // violation / objective when the current streak began
+  bool in_solve_ = false;           // inside solve() (the retry ladder exists) as opposed to begin() / step() calls
   i64 n_eq_ = 0;                    // equality rows (fixed at begin())
   bool resto_stationary_ = false;   // the last restoration ended where no step reduces the violation
   double resto_theta_ = 0.0;        // violation where the last restoration ended

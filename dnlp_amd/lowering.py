@@ -81,8 +81,14 @@ class LinForm:
             # a plain (sub)vector of variables: S @ A is S with its columns renamed -- one gather over S's
             # indices instead of a sparse product (a dense 1e3 x 1e4 constraint block is 1e7 entries)
             cols = A.indices.astype(S.indices.dtype, copy=False)[S.indices]
-            R = sp.csr_matrix((S.data, cols, S.indptr), shape=(S.shape[0], A.shape[1]))
-            if not bool(np.all(np.diff(A.indices) > 0)):
+            if bool(np.all(np.diff(A.indices) > 0)):
+                # monotone renaming: S's value / row-pointer arrays are shared, read-only from here on
+                R = sp.csr_matrix((S.data, cols, S.indptr), shape=(S.shape[0], A.shape[1]))
+            else:
+                # x[::-1], x[perm], hstack([y, x]): the rows must be re-sorted, and sort_indices permutes
+                # the value array IN PLACE — S.data may be the caller's own constant (a dense matrix without
+                # zeros is wrapped as a view), so the sort works on a private copy
+                R = sp.csr_matrix((S.data.copy(), cols, S.indptr.copy()), shape=(S.shape[0], A.shape[1]))
                 R.has_sorted_indices = False
                 R.sort_indices()
             return LinForm(R, np.zeros(S.shape[0]))
@@ -629,8 +635,13 @@ def lower_problem(objective_expr: Expression, constraint_exprs: List[Expression]
     else:
         G = sp.csr_matrix((0, ncol))
         b = np.zeros(0)
-    G.sum_duplicates()
-    G.sort_indices()
+    if not G.has_canonical_format:
+        # sum_duplicates / sort_indices rewrite the arrays in place; with a single constraint block and
+        # shared column ranges (head_cols, LinForm.apply) those arrays can still be a constant the user holds
+        if len(forms) == 1 and np.shares_memory(G.data, forms[0].A.data):
+            G = G.copy()
+        G.sum_duplicates()
+        G.sort_indices()
     m = G.shape[0]
 
     cat = lambda lst, dt: (np.concatenate(lst).astype(dt) if lst else np.zeros(0, dt))  # noqa

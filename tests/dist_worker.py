@@ -3,7 +3,11 @@ test_batch_distributed.py with RANK / WORLD_SIZE / MASTER_* set).
 
 mode "shard"      : solve_shard + gather_rows with the CPU oracle as the per-problem solver
 mode "parametric" : ParametricBatch.solve_sharded — the product's sharding + gather code — with the
-                    per-rank launch answered by the CPU oracle (no GPU in this container)"""
+                    per-rank launch answered by the CPU oracle (no GPU in this container)
+mode "device"     : ParametricBatch.solve_sharded on the MI355X of this rank with the backend named by
+                    DNLP_TEST_BACKEND (nccl = RCCL); with WORLD_SIZE=1 the exchange is forced through the
+                    backend all the same (force_collective) so that RCCL init + all_reduce + all_gather on
+                    device tensors run on a single GPU"""
 import os
 import sys
 
@@ -53,9 +57,28 @@ class OracleBatchHandle:
 def main():
     out_path, n_items = sys.argv[1], int(sys.argv[2])
     mode = sys.argv[3] if len(sys.argv) > 3 else "shard"
-    dist.init_process_group("gloo")
+    backend = os.environ.get("DNLP_TEST_BACKEND", "gloo")
+    if backend == "nccl":
+        import torch
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
-    if mode == "parametric":
+    if mode == "device":
+        prob, params, sample, _ = bp.template_localization()
+        pb = batch_mod.ParametricBatch(prob, params)
+        thetas = np.stack([sample(i) for i in range(n_items)])
+        allrows, info = pb.solve_sharded(thetas, force_collective=True)
+        assert info["ranks"] == world and info["backend"] == backend and info["collective"]
+        assert info["gathered_bytes"] == world * -(-n_items // world) * allrows.shape[1] * 8
+        # gather_rows by itself, a second time, on rows it did not produce
+        again = gather_rows(allrows[shard_bounds(n_items, rank, world)[0]:shard_bounds(n_items, rank, world)[1]],
+                            n_items, force=True)
+        assert np.array_equal(again, allrows)
+        pb.close()
+    elif mode == "parametric":
         batch_mod._device_handle = lambda arrays, tape, device, opts: OracleBatchHandle(arrays, tape, device, opts)
         prob, params, sample, _ = bp.template_localization()
         pb = batch_mod.ParametricBatch(prob, params)

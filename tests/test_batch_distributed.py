@@ -6,6 +6,7 @@ import sys
 import warnings
 
 import numpy as np
+import pytest
 
 from batch_problems import build_localization, oracle_solver
 from dnlp_amd.batch import gather_rows, shard_bounds, solve_shard
@@ -78,3 +79,75 @@ def test_world_size_2_gloo_parametric_batch_shards(tmp_path):
     for i in range(n_items):
         x_true = np.random.default_rng(i).uniform(-3, 3, 2)
         assert np.allclose(got[i, 4 + off:4 + off + 2], x_true, atol=1e-5)
+
+
+def _run_ranks(world, args, port, extra_env=None, timeout=600):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
+               PYTHONWARNINGS="ignore", **(extra_env or {}))
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py")] + args,
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=timeout) == 0
+
+
+@pytest.mark.parametrize("mode", ["shard", "parametric"])
+def test_world_size_4_gloo_uneven_and_empty_shard(tmp_path, mode):
+    """Five instances over four ranks: shards [0,2) [2,4) [4,5) and an EMPTY one — the gather pads
+    every rank's block to ceil(B/W) rows, drops the padding and orders by instance id."""
+    n_items = 5
+    assert [shard_bounds(n_items, r, 4) for r in range(4)] == [(0, 2), (2, 4), (4, 5), (5, 5)]
+    out = str(tmp_path / ("rows4_%s.npy" % mode))
+    _run_ranks(4, [out, str(n_items)] + (["parametric"] if mode == "parametric" else []), 29575 + (mode == "shard"))
+    got = np.load(out)
+    assert got.shape[0] == n_items
+    np.testing.assert_array_equal(got[:, 0], np.arange(n_items))
+    assert np.all(got[:, 2] == 0) and np.all(np.abs(got[:, 1]) < 1e-9)
+    if mode == "shard":
+        warnings.simplefilter("ignore")
+        ref = solve_shard(build_localization, list(range(n_items)), solver=oracle_solver, workers=1)
+        np.testing.assert_allclose(got[:, 1:], ref[:, 1:], rtol=1e-12, atol=1e-12, equal_nan=True)
+
+
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher must start two ranks itself (children, decided
+    before torch / HIP are touched) — and on a box with fewer than two GPUs every rank must fail
+    loudly instead of the run printing an n_gpus = 1 line."""
+    from dnlp_amd import _capi
+    if _capi.device_count() >= 2:
+        pytest.skip("two GPUs visible: the run would succeed")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--order", "256", "--no-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert '"n_gpus"' not in r.stdout
+    assert r.stderr.count("one process per GPU") == 2, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_world_size_1_rccl_gather_on_device(tmp_path):
+    """ONE rank, backend nccl (= RCCL): the product's sharded batch solve on the device with its
+    exchange forced through the collective (all_reduce of the row width + all_gather of the rows,
+    device tensors) — so that RCCL has initialised and moved this path's data on an MI355X."""
+    n_items = 64
+    out = str(tmp_path / "rows_rccl.npy")
+    _run_ranks(1, [out, str(n_items), "device"], 29581,
+               extra_env={"DNLP_TEST_BACKEND": "nccl", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    got = np.load(out)
+    assert got.shape[0] == n_items
+    np.testing.assert_array_equal(got[:, 0], np.arange(n_items))
+    assert np.all(got[:, 2] == 0) and np.all(np.abs(got[:, 1]) < 1e-9)
+
+
+@pytest.mark.gpu
+def test_bench_c5_one_command_line(tmp_path):
+    """`python bench.py --workload c5` prints one JSON line for the sharded batch with the gather's
+    evidence (ranks, bytes, backend) and the roofline / cpu_baseline objects."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--batch", "512",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["unit"] == "problems/s" and line["n_gpus"] == 1 and line["value"] > 0
+    assert line["config"]["optimal"] == 512 and line["config"]["batch_total"] == 512
+    assert line["config"]["collective_backend"] == "nccl (RCCL)", line["config"]
+    assert line["roofline"]["bound"] == "hbm" and line["cpu_baseline"]["value"] > 0

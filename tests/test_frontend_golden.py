@@ -72,3 +72,28 @@ def test_bounds_follow_the_lowered_variable_order():
         assert inv.var_offsets[v.id] == off
         off += v.size
     assert any(v is a for v in order)
+
+
+def test_lowering_leaves_the_users_constants_untouched():
+    """A dense constant under a non-monotone vector of variables (x[::-1], a permutation, hstack of two
+    variables in the other order): lowering re-sorts rows of the renamed matrix and must do so on a
+    private copy — the constant the user holds is bit-identical afterwards, and the lowered rows are
+    the permuted matrix."""
+    import dnlp_amd as cp
+    from dnlp_amd.dnlp2smooth import Dnlp2Smooth
+    from dnlp_amd.nlp_solver import build_nlp_data
+    rng = np.random.default_rng(0)
+    n = 70
+    perm = rng.permutation(n)
+    for build in (lambda x, y, A: [A @ x[::-1] == 1],
+                  lambda x, y, A: [A @ x[perm] == 1],
+                  lambda x, y, A: [A @ cp.hstack([y, x])[n // 2:n // 2 + n] == 1]):
+        A = rng.standard_normal((n, n)) + 3.0          # no zero entry: the CSR wrap is a view of A
+        A0 = A.copy()
+        x, y = cp.Variable(n), cp.Variable(n)
+        prob = cp.Problem(cp.Minimize(cp.sum_squares(x) + cp.sum_squares(y)), build(x, y, A))
+        smooth, _ = Dnlp2Smooth().apply(prob)
+        data, _ = build_nlp_data(smooth)
+        assert np.array_equal(A, A0), "lowering permuted the user's constant in place"
+        arr = data["tape_arrays"]
+        assert int(arr["dims"][1]) == n

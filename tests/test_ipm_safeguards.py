@@ -110,10 +110,21 @@ def test_stall_guard_hands_a_crawling_run_to_the_monotone_rung():
         o.set_option(k, v)
     r = o.solve(a["x0"])
     assert r["status"] == 0 and r["iterations"] < 150
-    # without the ladder the guard's verdict is visible: IPOPT's tiny-step status, long before max_iter
+    assert "stall guard" in o.log()
+    # without the ladder but with the guard asked for, its verdict is visible: IPOPT's tiny-step status
     o2 = OracleProblem(serialize(a))
     opts["adaptive_fallback"] = "no"
+    opts["stall_guard"] = "yes"
     for k, v in opts.items():
         o2.set_option(k, v)
     r2 = o2.solve(a["x0"])
     assert r2["status"] == 3 and r2["iterations"] < 150
+    # default for a run that no rung can take over: no guard — IPOPT has no such rule, the run
+    # goes on to the iteration limit as IPOPT's would
+    o3 = OracleProblem(serialize(a))
+    opts["stall_guard"] = "auto"
+    opts["max_iter"] = 300
+    for k, v in opts.items():
+        o3.set_option(k, v)
+    r3 = o3.solve(a["x0"])
+    assert r3["status"] == -1 and r3["iterations"] == 300 and "stall guard" not in o3.log()
