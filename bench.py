@@ -284,10 +284,30 @@ def bench_c5(args):
             except Exception as e:
                 out["cpu_baseline"] = {"value": None, "unit": "problems/s", "cores": 1, "kind": "port",
                                        "sample": "failed: %s" % e}
-        print(json.dumps(out))
+        emit(out)
     pb.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def emit(line):
+    """The ONE JSON line, last on stdout: whatever native libraries left in the C stdio buffers (RCCL
+    prints a version banner through printf, which a pipe holds back until exit) goes out first."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(line) + "\n")
+    sys.stdout.flush()
+
+
+def flush_native_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 def self_launch(n_ranks):
@@ -333,6 +353,9 @@ def init_ranks(args):
             dist.init_process_group(args.backend)
             local = local % max(torch.cuda.device_count(), 1)     # gloo debugging runs may share a GPU
     os.environ["DNLP_DEVICE"] = str(local)
+    if dist is not None:
+        dist.barrier()                 # communicator creation (and RCCL's printf banner) happen here, on every rank
+        flush_native_stdio()           # ... so no rank holds native stdout text back until after rank 0's JSON line
     return rank, world, local, dist, tdev, torch
 
 
@@ -512,7 +535,7 @@ def main():
             except Exception as e:   # the baseline is reported, never required for the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": 1, "kind": "port",
                                        "sample": "failed: %s" % e}
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -78,6 +78,9 @@ class CApi:
             f("batch_warm_start", C.c_int, [C.c_void_p, C.c_int, _dbl_p, _dbl_p, _dbl_p])
             f("solve_batch_timed", C.c_int, [C.c_void_p, C.c_int, _dbl_p, C.c_int64] + [_dbl_p] * 5 +
               [_int_p] * 3 + [_dbl_p, _dbl_p])
+            f("batch_set_affine_map", C.c_int, [C.c_void_p, C.c_int, _dbl_p, _dbl_p, C.POINTER(C.c_int64), _i32_p, _dbl_p])
+            f("solve_batch_theta", C.c_int, [C.c_void_p, C.c_int, _dbl_p, C.c_int] + [_dbl_p] * 5 +
+              [_int_p] * 3 + [_dbl_p, _dbl_p])
 
     def _fn(self, name, restype, argtypes):
         fn = getattr(self.lib, self.prefix + name)
@@ -391,17 +394,46 @@ class ProblemHandle:
                                      C.byref(iters))
         return self._info(status, x, obj, g, mg, zl, zu, iters)
 
-    def solve_batch(self, data, want_duals: bool = False, warm=None):
+    def set_batch_affine_map(self, d0, theta0, D):
+        """Hand the affine parameter -> instance-data map to the device once (`D`: scipy CSR,
+        stride x P): later `solve_batch(thetas=...)` calls move only the parameter rows."""
+        need = int(self.api.batch_stride(self.ptr))
+        d0 = np.ascontiguousarray(d0, dtype=np.float64)
+        theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
+        if d0.size != need or D.shape != (need, theta0.size):
+            raise ValueError("set_batch_affine_map: the map does not match the tape's instance stride")
+        D = D.tocsr()
+        D.sort_indices()
+        indptr = np.ascontiguousarray(D.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(D.indices, dtype=np.int32)
+        vals = np.ascontiguousarray(D.data, dtype=np.float64)
+        rc = self.api.batch_set_affine_map(self.ptr, int(theta0.size), _dp(d0), _dp(theta0 if theta0.size else np.zeros(1)),
+                                           indptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                                           _ip(indices if indices.size else np.zeros(1, np.int32)),
+                                           _dp(vals if vals.size else np.zeros(1)))
+        if rc != 0:
+            raise RuntimeError("batch_set_affine_map failed: %s" % self.api.error())
+        self._affine_P = int(theta0.size)
+
+    def solve_batch(self, data=None, want_duals: bool = False, warm=None, thetas=None):
         """Solve `data.shape[0]` instances that share this handle's tape structure in ONE kernel
         launch (one workgroup per instance, csrc/batch.h).  `data`: (B, stride) float64, rows laid
-        out as dnlp_amd.batch.BATCH_DATA_KEYS.  Returns arrays over the batch."""
-        data = np.ascontiguousarray(data, dtype=np.float64)
-        B, stride = data.shape
-        need = int(self.api.batch_stride(self.ptr))
-        if need < 0:
-            raise RuntimeError("solve_batch: %s" % self.api.error())
-        if stride != need:
-            raise ValueError("solve_batch: rows have %d values, the tape needs %d" % (stride, need))
+        out as dnlp_amd.batch.BATCH_DATA_KEYS — or `thetas`: (B, P) parameter rows after
+        set_batch_affine_map (the instance data is then generated on the device).  Returns arrays over
+        the batch."""
+        if thetas is not None:
+            thetas = np.ascontiguousarray(thetas, dtype=np.float64)
+            B = thetas.shape[0]
+            if getattr(self, "_affine_P", None) != thetas.shape[1]:
+                raise ValueError("solve_batch: parameter rows do not match the affine map of this handle")
+        else:
+            data = np.ascontiguousarray(data, dtype=np.float64)
+            B, stride = data.shape
+            need = int(self.api.batch_stride(self.ptr))
+            if need < 0:
+                raise RuntimeError("solve_batch: %s" % self.api.error())
+            if stride != need:
+                raise ValueError("solve_batch: rows have %d values, the tape needs %d" % (stride, need))
         if warm is not None:
             mg, wl, wu = (np.ascontiguousarray(a, dtype=np.float64) for a in warm)
             if mg.shape != (B, self.m) or wl.shape != (B, self.n) or wu.shape != (B, self.n):
@@ -420,10 +452,12 @@ class ProblemHandle:
         _int_p = C.POINTER(C.c_int)
         ip = lambda a: a.ctypes.data_as(_int_p)
         times = np.zeros((B, 4))
-        rc = self.api.solve_batch_timed(self.ptr, B, _dp(data), stride, _dp(x), _dp(obj),
-                                  _dp(mg) if want_duals else None, _dp(zl) if want_duals else None,
-                                  _dp(zu) if want_duals else None, ip(status), ip(iters), ip(nfact),
-                                        C.cast(C.byref(sec), _dbl_p), _dp(times))
+        outs = (_dp(x), _dp(obj), _dp(mg) if want_duals else None, _dp(zl) if want_duals else None,
+                _dp(zu) if want_duals else None, ip(status), ip(iters), ip(nfact), C.cast(C.byref(sec), _dbl_p), _dp(times))
+        if thetas is not None:
+            rc = self.api.solve_batch_theta(self.ptr, B, _dp(thetas if thetas.size else np.zeros(1)), thetas.shape[1], *outs)
+        else:
+            rc = self.api.solve_batch_timed(self.ptr, B, _dp(data), stride, *outs)
         if rc != 0:
             raise RuntimeError("solve_batch failed: %s" % self.api.error())
         out = {"x": x, "obj_val": obj, "status": status, "iterations": iters, "factorizations": nfact,

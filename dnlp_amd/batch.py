@@ -220,8 +220,6 @@ class ParametricBatch:
         warm_start_init_point; pass mu_init small, e.g. 1e-6, as with IPOPT)."""
         import time as _t
         t0 = _t.time()
-        mat = self.data(thetas)
-        t1 = _t.time()
         if warm_from is not None:
             opts.setdefault("warm_start_init_point", "yes")
         key = (device, tuple(sorted((k, str(v)) for k, v in opts.items())))
@@ -229,6 +227,23 @@ class ParametricBatch:
             self.close()
             self._handle = _device_handle(self.arrays0, self.data0["tape"], device, opts)
             self._handle_key = key
+            self._map_on_device = False
+        # affine templates: the map lives on the device and a call moves only the parameter rows (the
+        # warm-started form patches the rows' x0 block on the host, so it keeps the host-generated rows)
+        if self.affine and warm_from is None and hasattr(self._handle, "set_batch_affine_map"):
+            thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
+            if thetas.shape[1] != self.P:
+                raise ValueError("expected %d parameter values per instance" % self.P)
+            if not self._map_on_device:
+                self._handle.set_batch_affine_map(self.d0, self.theta0, self.D)
+                self._map_on_device = True
+            t1 = _t.time()
+            raw = self._handle.solve_batch(want_duals=want_duals, thetas=thetas)
+            if os.environ.get("DNLP_BATCH_DEBUG"):
+                print("[batch.py] handle/map %.4f solve_batch(thetas) %.4f" % (t1 - t0, _t.time() - t1), flush=True)
+            return BatchResult(raw, self.inv, self.flip)
+        mat = self.data(thetas)
+        t1 = _t.time()
         warm = None
         if warm_from is not None:
             if "mult_g" not in warm_from.raw:

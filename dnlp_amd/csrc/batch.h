@@ -171,6 +171,27 @@ __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
   }
 }
 
+// Instance data from parameter rows, on the device: slab[b][o] = d0[o] + sum_k D[o][k] (theta[b][k] - theta0[k]) with
+// D in CSR over the slab's own layout (the per-segment parameters already gathered to per-flat-row ones).
+// A lane owns one slab entry of one instance; the instance's parameter row (tens of doubles) is read by
+// every lane of the workgroup through the scalar / L1 path.  Rows without entries (infinite bounds,
+// constants) copy d0.  Writes are coalesced along o.
+__global__ void __launch_bounds__(256) batch_affine_expand_kernel(double* __restrict__ slabs, i64 total, int batch, int P,
+                                                                  const double* __restrict__ theta, const double* __restrict__ theta0,
+                                                                  const double* __restrict__ d0, const i64* __restrict__ indptr,
+                                                                  const int* __restrict__ indices, const double* __restrict__ vals) {
+  const i64 o = static_cast<i64>(blockIdx.x) * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (o >= total || b >= batch) return;
+  const double* th = theta + static_cast<i64>(b) * P;
+  double v = d0[o];
+  for (i64 e = indptr[o]; e < indptr[o + 1]; ++e) {
+    const int k = indices[e];
+    v += vals[e] * (th[k] - theta0[k]);
+  }
+  slabs[static_cast<i64>(b) * total + o] = v;
+}
+
 // Host side: tables uploaded once per problem handle, slabs per call.
 struct BatchRunner {
   HipExec* ex = nullptr;
@@ -201,7 +222,58 @@ struct BatchRunner {
   int ncu = 0;
   std::vector<double> slab;
 
+  // affine parameter -> instance-data map (dnlp_batch_set_affine_map), resident on the device, in slab layout
+  int aff_P = -1;
+  double *aff_d0 = nullptr, *aff_theta0 = nullptr, *aff_val = nullptr, *aff_theta = nullptr;
+  i64* aff_indptr = nullptr;
+  int* aff_idx = nullptr;
+  size_t aff_theta_cap = 0;
+  void free_affine() {
+    for (void* q : {static_cast<void*>(aff_d0), static_cast<void*>(aff_theta0), static_cast<void*>(aff_val),
+                    static_cast<void*>(aff_indptr), static_cast<void*>(aff_idx), static_cast<void*>(aff_theta)})
+      if (q) hipFree(q);
+    aff_d0 = aff_theta0 = aff_val = aff_theta = nullptr; aff_indptr = nullptr; aff_idx = nullptr; aff_P = -1; aff_theta_cap = 0;
+  }
+  // d0: in_stride doubles (the base instance, BATCH_DATA_KEYS order); (indptr, indices, vals): CSR of the
+  // in_stride x P sensitivity; theta0: P.  Re-expressed over the slab layout and uploaded once.
+  void set_affine_map(int P, const double* d0, const double* theta0, const i64* indptr, const int* indices, const double* vals) {
+    const Tape<HipExec>& t = *tape;
+    DNLP_HIP_CHECK(hipSetDevice(ex->device));
+    free_affine();
+    const i64 head = 1 + (t.N + t.Z) + t.m + t.nnzJ + t.G.nnz + t.Mg.nnz + t.Mw.nnz + t.MJ.nnz + t.MH.nnz;
+    auto src_row = [&](i64 o) -> i64 {
+      if (o < head) return o;
+      if (o < lay.fp2) return head + t.h_flat_seg[static_cast<size_t>(o - lay.fp)];
+      if (o < lay.x0) return head + t.nseg + t.h_flat_seg[static_cast<size_t>(o - lay.fp2)];
+      return head + 2 * t.nseg + (o - lay.x0);
+    };
+    std::vector<double> h_d0(static_cast<size_t>(lay.total)), h_val;
+    std::vector<i64> h_ptr(static_cast<size_t>(lay.total) + 1, 0);
+    std::vector<int> h_idx;
+    for (i64 o = 0; o < lay.total; ++o) {
+      const i64 j = src_row(o);
+      h_d0[static_cast<size_t>(o)] = d0[j];
+      for (i64 e = indptr[j]; e < indptr[j + 1]; ++e) {
+        if (indices[e] < 0 || indices[e] >= P) throw std::runtime_error("batch affine map: column index out of range");
+        h_idx.push_back(indices[e]); h_val.push_back(vals[e]);
+      }
+      h_ptr[static_cast<size_t>(o) + 1] = static_cast<i64>(h_idx.size());
+    }
+    auto up = [&](auto** dst, const auto* src, size_t n) {
+      using T = std::remove_pointer_t<std::remove_pointer_t<decltype(dst)>>;
+      DNLP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(dst), (n ? n : 1) * sizeof(T)));
+      if (n) DNLP_HIP_CHECK(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    };
+    up(&aff_d0, h_d0.data(), h_d0.size());
+    up(&aff_theta0, theta0, static_cast<size_t>(P));
+    up(&aff_indptr, h_ptr.data(), h_ptr.size());
+    up(&aff_idx, h_idx.data(), h_idx.size());
+    up(&aff_val, h_val.data(), h_val.size());
+    aff_P = P;
+  }
+
   ~BatchRunner() {
+    free_affine();
     for (Buf& b : bufs) if (b.p) hipFree(b.p);
     if (d_segs) hipFree(d_segs);
     if (d_red) hipFree(d_red);
@@ -248,27 +320,29 @@ struct BatchRunner {
              double* multg_out, double* zl_out, double* zu_out, int* status_out, int* iters_out, int* nfact_out,
              double* seconds, double* times_out = nullptr) {
     if (stride != in_stride) throw std::runtime_error("batched solve: instance stride does not match the tape");
+    solve_impl(batch, data, nullptr, opt, x_out, obj_out, multg_out, zl_out, zu_out, status_out, iters_out, nfact_out, seconds,
+               times_out);
+  }
+  // theta: batch x P parameter rows (host); the instance data is generated on the device from the map of
+  // set_affine_map: the call moves batch x P doubles in and the results out.
+  void solve_theta(int batch, const double* theta, int P, const IpmOptions& opt, double* x_out, double* obj_out,
+                   double* multg_out, double* zl_out, double* zu_out, int* status_out, int* iters_out, int* nfact_out,
+                   double* seconds, double* times_out = nullptr) {
+    if (aff_P < 0) throw std::runtime_error("batched solve: no affine parameter map set (dnlp_batch_set_affine_map)");
+    if (P != aff_P) throw std::runtime_error("batched solve: parameter rows do not match the affine map");
+    solve_impl(batch, nullptr, theta, opt, x_out, obj_out, multg_out, zl_out, zu_out, status_out, iters_out, nfact_out, seconds,
+               times_out);
+  }
+
+  void solve_impl(int batch, const double* data, const double* theta, const IpmOptions& opt, double* x_out, double* obj_out,
+                  double* multg_out, double* zl_out, double* zu_out, int* status_out, int* iters_out, int* nfact_out,
+                  double* seconds, double* times_out) {
+    const i64 stride = in_stride;
     const bool dbg = std::getenv("DNLP_BATCH_DEBUG") != nullptr;
     const double tdbg0 = now_sec();
     auto mark = [&](const char* what) { if (dbg) std::fprintf(stderr, "[batch] %-22s %.4f s\n", what, now_sec() - tdbg0); };
     const Tape<HipExec>& t = *tape;
     DNLP_HIP_CHECK(hipSetDevice(ex->device));
-    // host gather: the per-segment parameters become per-flat-row parameters
-    slab.resize(static_cast<size_t>(batch) * static_cast<size_t>(lay.total));
-    const i64 head = 1 + (t.N + t.Z) + t.m + t.nnzJ + t.G.nnz + t.Mg.nnz + t.Mw.nnz + t.MJ.nnz + t.MH.nnz;
-    const i64 tail = 3 * t.N + 2 * t.m;
-    for (int k = 0; k < batch; ++k) {
-      const double* src = data + static_cast<i64>(k) * stride;
-      double* dst = slab.data() + static_cast<i64>(k) * lay.total;
-      std::copy(src, src + head, dst);
-      const double *sp = src + head, *sp2 = sp + t.nseg;
-      for (i64 f = 0; f < t.nflat; ++f) {
-        dst[lay.fp + f] = sp[t.h_flat_seg[static_cast<size_t>(f)]];
-        dst[lay.fp2 + f] = sp2[t.h_flat_seg[static_cast<size_t>(f)]];
-      }
-      std::copy(sp2 + t.nseg, sp2 + t.nseg + tail, dst + lay.x0);
-    }
-    mark("slab built");
     release();
     BatchArgs a;
     a.base = t;           // slice: the view with the shared exec-space index arrays
@@ -277,9 +351,41 @@ struct BatchRunner {
     a.lay = lay;
     a.batch = batch;
     a.opt = opt;
-    a.slabs = dalloc<double>(slab.size());
-    DNLP_HIP_CHECK(hipMemcpy(a.slabs, slab.data(), slab.size() * sizeof(double), hipMemcpyHostToDevice));
-    mark("slab uploaded");
+    a.slabs = dalloc<double>(static_cast<size_t>(batch) * static_cast<size_t>(lay.total));
+    if (theta) {
+      const size_t nth = static_cast<size_t>(batch) * static_cast<size_t>(aff_P);
+      if (nth > aff_theta_cap) {
+        if (aff_theta) DNLP_HIP_CHECK(hipFree(aff_theta));
+        aff_theta = nullptr;
+        DNLP_HIP_CHECK(hipMalloc(&aff_theta, (nth ? nth : 1) * sizeof(double)));
+        aff_theta_cap = nth;
+      }
+      if (nth) DNLP_HIP_CHECK(hipMemcpyAsync(aff_theta, theta, nth * sizeof(double), hipMemcpyHostToDevice, ex->stream));
+      const dim3 grid(static_cast<unsigned>((lay.total + 255) / 256), static_cast<unsigned>(batch));
+      hipLaunchKernelGGL(batch_affine_expand_kernel, grid, dim3(256), 0, ex->stream, a.slabs, lay.total, batch, aff_P, aff_theta,
+                         aff_theta0, aff_d0, aff_indptr, aff_idx, aff_val);
+      DNLP_LAUNCH_CHECK();
+      mark("slab generated on device");
+    } else {
+      // host gather: the per-segment parameters become per-flat-row parameters
+      slab.resize(static_cast<size_t>(batch) * static_cast<size_t>(lay.total));
+      const i64 head = 1 + (t.N + t.Z) + t.m + t.nnzJ + t.G.nnz + t.Mg.nnz + t.Mw.nnz + t.MJ.nnz + t.MH.nnz;
+      const i64 tail = 3 * t.N + 2 * t.m;
+      for (int k = 0; k < batch; ++k) {
+        const double* src = data + static_cast<i64>(k) * stride;
+        double* dst = slab.data() + static_cast<i64>(k) * lay.total;
+        std::copy(src, src + head, dst);
+        const double *sp = src + head, *sp2 = sp + t.nseg;
+        for (i64 f = 0; f < t.nflat; ++f) {
+          dst[lay.fp + f] = sp[t.h_flat_seg[static_cast<size_t>(f)]];
+          dst[lay.fp2 + f] = sp2[t.h_flat_seg[static_cast<size_t>(f)]];
+        }
+        std::copy(sp2 + t.nseg, sp2 + t.nseg + tail, dst + lay.x0);
+      }
+      mark("slab built");
+      DNLP_HIP_CHECK(hipMemcpy(a.slabs, slab.data(), slab.size() * sizeof(double), hipMemcpyHostToDevice));
+      mark("slab uploaded");
+    }
     const i64 n = t.N + t.m, ld = (n + 7) / 8 * 8;
     // KKT matrix in LDS when it fits beside the static reduction scratch (160 KB per workgroup)
     a.use_sparse = have_sparse ? 1 : 0;

@@ -62,6 +62,27 @@ int dnlp_solve_batch_timed(dnlp_problem* vp, int batch, const double* data, int6
     return 0;)
 }
 
+/* Parametrised batches whose instance data is affine in the parameters (dnlp_amd.batch.ParametricBatch): the map is
+   handed over once — d0 = the base instance's data row (dnlp_batch_stride doubles), theta0 = its P parameter values,
+   (indptr, indices, vals) = CSR of the stride x P sensitivity — and stays on the device. */
+int dnlp_batch_set_affine_map(dnlp_problem* vp, int n_params, const double* d0, const double* theta0, const int64_t* indptr,
+                              const int32_t* indices, const double* vals) {
+  dnlp_problem_t* p = vp;
+  DNLP_TRY(batch_runner(p)->set_affine_map(n_params, d0, theta0, reinterpret_cast<const dnlp::i64*>(indptr), indices, vals); return 0;)
+}
+/* dnlp_solve_batch_timed with the instances given as parameter rows (batch x n_params): the instance data is generated
+   on the device, so a call moves the parameter rows in and the results out. */
+int dnlp_solve_batch_theta(dnlp_problem* vp, int batch, const double* theta, int n_params, double* x, double* obj, double* mult_g,
+                           double* mult_x_L, double* mult_x_U, int* status, int* iters, int* factorizations, double* seconds,
+                           double* times) {
+  dnlp_problem_t* p = vp;
+  DNLP_TRY(
+    BatchRunner& r = *batch_runner(p);
+    p->ex.sync();
+    r.solve_theta(batch, theta, n_params, p->opt, x, obj, mult_g, mult_x_L, mult_x_U, status, iters, factorizations, seconds, times);
+    return 0;)
+}
+
 // Average seconds of one fused f + grad f evaluation with x resident in HBM (HIP events around
 // `reps` back-to-back evaluations on the problem's stream): the measurement behind the C2 roofline
 // line (tools/run_c2.py).

@@ -145,6 +145,17 @@ int dnlp_solve_batch_timed(dnlp_problem* p, int batch, const double* data, int64
                            double* obj, double* mult_g, double* mult_x_L, double* mult_x_U,
                            int* status, int* iters, int* factorizations, double* kernel_seconds,
                            double* times);
+/* Parametrised batches (the reference re-canonicalises and re-solves one Problem per parameter value,
+ * problems/problem.py:1256-1269; a Parameter's value reaches the tape data through the lowering).  When the
+ * instance data is an affine function of the P parameter values — dnlp_amd.batch.ParametricBatch recovers and
+ * checks the map — it is handed over ONCE: d0 = data row of the base instance (dnlp_batch_stride doubles),
+ * theta0 = its parameter values (P), (indptr[stride + 1], indices, vals) = CSR of the stride x P sensitivity.
+ * dnlp_solve_batch_theta then takes batch x P parameter rows and generates the instance data on the device. */
+int dnlp_batch_set_affine_map(dnlp_problem* p, int n_params, const double* d0, const double* theta0,
+                              const int64_t* indptr, const int32_t* indices, const double* vals);
+int dnlp_solve_batch_theta(dnlp_problem* p, int batch, const double* theta, int n_params, double* x, double* obj,
+                           double* mult_g, double* mult_x_L, double* mult_x_U, int* status, int* iters,
+                           int* factorizations, double* kernel_seconds, double* times);
 /* f and grad f of the USER's variables from the fused element program of an unconstrained
  * elementwise-sum objective (tape arrays fz_*, dnlp_amd/fused.py; BASELINE config C2): one kernel,
  * x read once, grad accumulated once — eval_f + eval_grad_f of nlp_solver.py:212-235 on the

@@ -85,9 +85,11 @@ def _run_ranks(world, args, port, extra_env=None, timeout=600):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
                PYTHONWARNINGS="ignore", **(extra_env or {}))
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py")] + args,
-                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(world)]
-    for p in procs:
-        assert p.wait(timeout=timeout) == 0
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    for r, p in enumerate(procs):
+        out, _ = p.communicate(timeout=timeout)
+        assert p.returncode == 0, "rank %d exited with %s:\n%s" % (r, p.returncode, out[-3000:])
 
 
 @pytest.mark.parametrize("mode", ["shard", "parametric"])

@@ -250,3 +250,25 @@ def test_batch_status_codes_and_options(gpu_required):
     assert np.all(res2.status == -1) and np.all(res2.iterations == 2)
     res3 = solve_batch([make(3.0)], mu_strategy="monotone")
     assert res3.status[0] == 0 and abs(res3.obj_val[0] - res.obj_val[0]) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_instance_data_generated_on_the_device_equals_host_rows(gpu_required):
+    """Affine templates hand the parameter -> data map to the device once (dnlp_batch_set_affine_map) and a
+    solve moves only the parameter rows (dnlp_solve_batch_theta).  Same instances through the host-generated
+    rows (dnlp_solve_batch): same statuses and iteration counts, solutions equal to rounding of the row
+    generation (d0 + D dtheta summed in another order)."""
+    for tmpl, nb in ((bp.template_localization, 300), (lambda: bp.template_circle_packing(4), 200)):
+        prob, params, sample, var = tmpl()
+        pb = ParametricBatch(prob, params)
+        assert pb.affine
+        thetas = np.stack([sample(i) for i in range(nb)])
+        res_dev = pb.solve(thetas, want_duals=True)
+        assert pb._map_on_device
+        raw = pb._handle.solve_batch(pb.data(thetas), want_duals=True)
+        assert np.array_equal(res_dev.status, raw["status"])
+        assert np.mean(res_dev.iterations == raw["iterations"]) >= 0.97
+        same = res_dev.iterations == raw["iterations"]
+        np.testing.assert_allclose(res_dev.raw["obj_val"][same], raw["obj_val"][same], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(res_dev.x[same], raw["x"][same], rtol=1e-6, atol=1e-7)
+        pb.close()

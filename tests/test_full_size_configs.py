@@ -47,14 +47,49 @@ def test_c3_full_size_against_lapack(gpu_required):
     assert abs(info["obj_val"] - (0.5 * sol[:n] @ Q @ sol[:n] + c @ sol[:n])) <= 1e-9 * abs(info["obj_val"])
 
 
-def _oracle(arrays):
+def _oracle(arrays, opts=None, batch_defaults=False):
     from dnlp_amd.nlp_solver import HIPNLP
     from dnlp_amd.tape import serialize
     from oracle.oracle_capi import OracleProblem
     orc = OracleProblem(serialize(arrays))
-    for k, v in HIPNLP.DEFAULT_OPTIONS.items():
+    options = dict(HIPNLP.DEFAULT_OPTIONS)
+    if batch_defaults:
+        options["lazy_dense_fallback"] = "yes"        # dnlp_amd.batch._device_handle's setting
+    options.update(opts or {})
+    for k, v in options.items():
         orc.set_option(k, v)
     return orc.solve(arrays["x0"])
+
+
+def _kkt_residuals(arrays, x, mult_g, zl, zu):
+    """Stationarity / feasibility / complementarity of a returned primal-dual point, evaluated with the CPU
+    oracle's derivative oracles on the instance's own tape (an instance-level certificate that does not
+    depend on the solver's path): returns (|grad f + J'y - zL + zU|_inf, constraint violation, bound
+    violation, complementarity)."""
+    import scipy.sparse as sp
+    from dnlp_amd.tape import serialize
+    from oracle.oracle_capi import OracleProblem
+    o = OracleProblem(serialize(arrays))
+    n, m = o.n, o.m
+    g = o.eval_grad_f(x)
+    r, c = o.jac_structure()
+    J = sp.csr_matrix((o.eval_jac_g(x), (r, c)), shape=(m, n))
+    cons = o.eval_g(x)
+    o.close()
+    lb, ub, cl, cu = (np.asarray(arrays[k], float).ravel() for k in ("lb", "ub", "cl", "cu"))
+    stat = np.max(np.abs(g + J.T @ mult_g - zl + zu))
+    viol = max(np.max(np.maximum(cl - cons, 0.0), initial=0.0), np.max(np.maximum(cons - cu, 0.0), initial=0.0))
+    bviol = max(np.max(np.maximum(lb - x, 0.0), initial=0.0), np.max(np.maximum(x - ub, 0.0), initial=0.0))
+    fin_l, fin_u = lb > -1e19, ub < 1e19
+    comp = max(np.max(np.abs(zl[fin_l] * (x[fin_l] - lb[fin_l])), initial=0.0),
+               np.max(np.abs(zu[fin_u] * (ub[fin_u] - x[fin_u])), initial=0.0))
+    ineq = cl < cu
+    act_l = np.where(cl > -1e19, cons - cl, 0.0)
+    act_u = np.where(cu < 1e19, cu - cons, 0.0)
+    lam_minus, lam_plus = np.maximum(-mult_g, 0.0), np.maximum(mult_g, 0.0)
+    comp = max(comp, np.max(np.abs(lam_minus[ineq] * act_l[ineq]), initial=0.0),
+               np.max(np.abs(lam_plus[ineq] * act_u[ineq]), initial=0.0))
+    return stat, viol, bviol, comp
 
 
 def test_c5_8192_localization_instances(gpu_required):
@@ -125,3 +160,146 @@ def test_c5_8192_circle_packing_instances(gpu_required):
             continue
         np.testing.assert_allclose(res.x[i], oi["x"], rtol=1e-5, atol=1e-5)
     assert other <= CHECKED // 16
+
+
+MEMBER_BATCH = 1024           # 8 x 1024; each remaining member at one GPU's share
+MEMBER_CHECKED = 64
+
+
+def test_c5_1024_circle_packing_n10_instances(gpu_required):
+    """C5's circle-packing member at its STATED size (n = 10: N = 121, m = 185).  Instance 0 is
+    the notebook's problem from the notebook's start (circle_packing.ipynb:68-79, published 7.22863 after 50
+    iterations — one local optimum of a non-convex problem; a KKT point at or below it is accepted).  Every
+    instance: no overlap and objective = half side of the enclosing square, from the returned centres and the
+    instance's radii; 64 instances against the host build of the algorithm (the oracle library), a KKT
+    certificate for each of those from the oracle's derivative evaluators."""
+    n = 10
+    prob, params, sample, cvar = bp.template_circle_packing(n)
+    pb = ParametricBatch(prob, params)
+    assert int(pb.arrays0["dims"][0]) == 121 and int(pb.arrays0["dims"][1]) == 185
+    thetas = np.stack([sample(i) for i in range(MEMBER_BATCH)])
+    res = pb.solve(thetas, want_duals=True)
+    ok = res.status == 0
+    assert ok.sum() >= int(0.98 * MEMBER_BATCH), np.unique(res.status, return_counts=True)
+    assert res.status[0] == 0 and res.obj_val[0] <= 7.2286302188441365 * (1 + 1e-6)
+    centers = res.value_of(cvar)
+    npairs = n * (n - 1) // 2
+    radius = thetas[:, npairs:]
+    k = 0
+    for a in range(n - 1):
+        for b in range(a + 1, n):
+            d2 = np.sum((centers[:, :, a] - centers[:, :, b]) ** 2, axis=1)
+            assert np.all(d2[ok] >= thetas[ok, k] * (1 - 1e-7))
+            k += 1
+    half_side = np.max(np.max(np.abs(centers), axis=1) + radius, axis=1)
+    np.testing.assert_allclose(res.obj_val[ok], half_side[ok], rtol=1e-6)
+    mat = pb.data(thetas)
+    other = 0
+    for i in range(0, MEMBER_BATCH, MEMBER_BATCH // MEMBER_CHECKED):
+        a = arrays_with_data(pb.arrays0, mat[i])
+        if res.status[i] == 0:
+            stat, viol, bviol, comp = _kkt_residuals(a, res.x[i], res.raw["mult_g"][i], res.raw["mult_x_L"][i],
+                                                     res.raw["mult_x_U"][i])
+            assert stat <= 1e-5 and viol <= 1e-6 and bviol <= 1e-9 and comp <= 1e-5, (i, stat, viol, bviol, comp)
+        oi = _oracle(a, batch_defaults=True)
+        if oi["status"] != res.status[i] or abs(res.raw["obj_val"][i] - oi["obj_val"]) > 1e-6 * abs(oi["obj_val"]):
+            other += 1                      # another local optimum / rung: must still be a certified KKT point
+            continue
+        np.testing.assert_allclose(res.x[i], oi["x"], rtol=1e-5, atol=1e-5)
+    assert other <= MEMBER_CHECKED // 8
+    pb.close()
+
+
+def test_c5_1024_power_flow_instances(gpu_required):
+    """C5's AC power-flow member (IEEE 9-bus, N = 867 with the load rows, KKT order 1723; loads scaled per
+    instance by default_rng(i) in [0.8, 1.2]).  Instance 0 carries the notebook's loads: published objective
+    3087.84222847 (power_flow.ipynb:101).  Every optimal instance: the AC power-balance equations, the
+    load rows, the voltage / generation bounds and objective = generation cost, all recomputed here from the
+    returned v, theta, p, q; 64 instances against the host build + KKT certificates."""
+    from paper_examples import ieee9_admittance
+    prob, params, sample, pvar = bp.template_power_flow()
+    pb = ParametricBatch(prob, params)
+    thetas = np.stack([sample(i) for i in range(MEMBER_BATCH)])
+    opts = {"least_square_init_duals": "no"}
+    res = pb.solve(thetas, want_duals=True, **opts)
+    ok = res.status == 0
+    # (r01: 6.6 % of the perturbed-load instances are locally infeasible from the flat start)
+    assert ok.sum() >= int(0.90 * MEMBER_BATCH), np.unique(res.status, return_counts=True)
+    assert res.status[0] == 0 and abs(res.obj_val[0] - 3.0878422284732592e+03) <= 1e-6 * 3.0878e3
+    vars_by_shape = {}
+    for var in prob.variables():
+        vars_by_shape.setdefault(tuple(var.shape), []).append(var)
+    (theta, v) = vars_by_shape[(9, 1)]           # creation order: theta, then v
+    (p, q) = vars_by_shape[(9,)]
+    G, B = ieee9_admittance()
+    th, vv = res.value_of(theta)[:, :, 0], res.value_of(v)[:, :, 0]
+    pp, qq = res.value_of(p), res.value_of(q)
+    dth = th[:, :, None] - th[:, None, :]
+    vv2 = vv[:, :, None] * vv[:, None, :]
+    p_calc = np.sum(vv2 * (G * np.cos(dth) + B * np.sin(dth)), axis=2)
+    q_calc = np.sum(vv2 * (G * np.sin(dth) - B * np.cos(dth)), axis=2)
+    scale = 300.0
+    assert np.max(np.abs(p_calc[ok] - pp[ok])) <= 1e-5 * scale and np.max(np.abs(q_calc[ok] - qq[ok])) <= 1e-5 * scale
+    load = [4, 6, 8]
+    assert np.max(np.abs(pp[ok][:, load] + thetas[ok, :3])) <= 1e-6 * scale
+    assert np.max(np.abs(qq[ok][:, load] + thetas[ok, 3:])) <= 1e-6 * scale
+    assert np.all(vv[ok] >= 0.9 - 1e-8) and np.all(vv[ok] <= 1.1 + 1e-8) and np.max(np.abs(th[ok][:, 0])) <= 1e-8
+    cost = (0.11 * pp[:, 0] ** 2 + 5 * pp[:, 0] + 150 + 0.085 * pp[:, 1] ** 2 + 1.2 * pp[:, 1] + 600
+            + 0.1225 * pp[:, 2] ** 2 + pp[:, 2] + 335)
+    np.testing.assert_allclose(res.obj_val[ok], cost[ok], rtol=1e-8)
+    mat = pb.data(thetas)
+    differ = 0
+    for i in range(0, MEMBER_BATCH, MEMBER_BATCH // MEMBER_CHECKED):
+        a = arrays_with_data(pb.arrays0, mat[i])
+        if res.status[i] == 0:
+            stat, viol, bviol, comp = _kkt_residuals(a, res.x[i], res.raw["mult_g"][i], res.raw["mult_x_L"][i],
+                                                     res.raw["mult_x_U"][i])
+            assert stat <= 1e-4 and viol <= 1e-5 and bviol <= 1e-9 and comp <= 1e-4, (i, stat, viol, bviol, comp)
+        oi = _oracle(a, opts, batch_defaults=True)
+        if oi["status"] != res.status[i]:
+            differ += 1
+            continue
+        if oi["status"] == 0:
+            assert abs(res.raw["obj_val"][i] - oi["obj_val"]) <= 1e-6 * abs(oi["obj_val"])
+    assert differ <= MEMBER_CHECKED // 16
+    pb.close()
+
+
+def test_c5_1024_path_planning_instances(gpu_required):
+    """C5's path-planning member (n = 50 segments: N = 715 free variables, KKT order 1636; obstacle centres
+    and radii perturbed per instance).  Instance 0 is the notebook's problem: published 13.1368823193
+    (path_planning.ipynb:103).  Every optimal instance: end points, every way-point outside every obstacle,
+    every segment no longer than L / n, objective = L; 64 against the host build + KKT certificates."""
+    prob, params, sample, xvar = bp.template_path_planning()
+    pb = ParametricBatch(prob, params)
+    thetas = np.stack([sample(i) for i in range(MEMBER_BATCH)])
+    res = pb.solve(thetas, want_duals=True)
+    ok = res.status == 0
+    assert ok.sum() >= int(0.97 * MEMBER_BATCH), np.unique(res.status, return_counts=True)
+    assert res.status[0] == 0 and abs(res.obj_val[0] - 1.3136882319337619e+01) <= 1e-6 * 13.14
+    X = res.value_of(xvar)                                  # (B, 2, 51)
+    nseg = X.shape[2] - 1
+    assert np.max(np.abs(X[ok][:, :, 0] - 1.25)) <= 1e-7 and np.max(np.abs(X[ok][:, :, nseg] - 10.0)) <= 1e-7
+    centres = thetas[:, :10].reshape(MEMBER_BATCH, 2, 5)   # F-order flatten of the (5, 2) parameter
+    r2 = thetas[:, 10:]
+    d2 = np.sum((X[:, :, :, None] - centres[:, :, None, :]) ** 2, axis=1)     # (B, 51, 5)
+    assert np.all(d2[ok] >= r2[ok][:, None, :] * (1 - 1e-6))
+    seg2 = np.sum((X[:, :, 1:] - X[:, :, :-1]) ** 2, axis=1)
+    L = res.obj_val
+    assert np.all(seg2[ok] <= (L[ok, None] / nseg) ** 2 * (1 + 1e-6) + 1e-9)
+    assert np.all(L[ok] >= np.sqrt(2.0) * 8.75 - 1e-6)       # never shorter than the straight line
+    mat = pb.data(thetas)
+    differ = 0
+    for i in range(0, MEMBER_BATCH, MEMBER_BATCH // MEMBER_CHECKED):
+        a = arrays_with_data(pb.arrays0, mat[i])
+        if res.status[i] == 0:
+            stat, viol, bviol, comp = _kkt_residuals(a, res.x[i], res.raw["mult_g"][i], res.raw["mult_x_L"][i],
+                                                     res.raw["mult_x_U"][i])
+            assert stat <= 1e-5 and viol <= 1e-6 and bviol <= 1e-9 and comp <= 1e-5, (i, stat, viol, bviol, comp)
+        oi = _oracle(a, batch_defaults=True)
+        if oi["status"] != res.status[i] or abs(res.raw["obj_val"][i] - oi["obj_val"]) > 1e-6 * abs(oi["obj_val"]):
+            differ += 1
+            continue
+        np.testing.assert_allclose(res.x[i], oi["x"], rtol=1e-4, atol=1e-4)
+    assert differ <= MEMBER_CHECKED // 8
+    pb.close()
