@@ -978,7 +978,9 @@ class Ipm {
         v.sm[0] = v.sm[1] = v.sm[2] = v.sm[3] = 0.0;
         return v; });
       double en = Rn.mx[0], sn = Rn.mx[1];
-      double ratio = en / (std::max(rn, 1e-300) + sn);
+      // IPOPT's residual ratio (PDFullSpaceSolver::ComputeResidualRatio): the solution norm counts for at most
+      // 1e6 x the right-hand side's, so that a garbage solution with huge entries cannot excuse its own residual
+      double ratio = en / (std::max(rn, 1e-300) + std::min(sn, 1e6 * rn));
       if (!std::isfinite(en)) { stats.t_solve += now_sec() - t0; return false; }
       last_ratio_ = std::isfinite(ratio) ? ratio : kInf;
       fresh = true;
@@ -1001,10 +1003,11 @@ class Ipm {
         v.sm[0] = v.sm[1] = v.sm[2] = v.sm[3] = 0.0;
         return v; });
       const double en = Rn.mx[0], sn = Rn.mx[1];
-      last_ratio_ = en / (std::max(rn, 1e-300) + sn);
+      last_ratio_ = en / (std::max(rn, 1e-300) + std::min(sn, 1e6 * rn));
       if (!std::isfinite(last_ratio_)) last_ratio_ = kInf;
     }
     stats.t_solve += now_sec() - t0;
+    if (opt.print_level >= 7) logf("   solve: |rhs| %.3e residual ratio %.3e", rn, last_ratio_);
     return true;
   }
 
@@ -1393,9 +1396,21 @@ class Ipm {
     return tot / static_cast<double>(nb);
   }
 
+  // Smallest barrier parameter.  IPOPT's monotone update never goes below min(tol, compl_inf_tol) /
+  // (barrier_tol_factor + 1) (IpMonotoneMuUpdate); its adaptive update uses mu_min — 1e-11 by default, lowered to
+  // half of min(tol, compl_inf_tol) when that is smaller — in the free AND in the fixed mode (IpAdaptiveMuUpdate):
+  // the published logs of the adaptive default end at lg(mu) = -11 (phase_retrieval.ipynb:112-115), which a floor of
+  // tol / 11 cannot reach — rounds 1-2 applied the monotone floor to both, and solutions stopped at an objective
+  // error of (active bounds) x 9e-9 where IPOPT's stop at (active bounds) x 1e-11.
+  DNLP_HD double mu_floor_now() const {
+    const double t = std::min(opt.tol, opt.compl_inf_tol);
+    if (opt.mu_strategy == 0) return std::max(opt.mu_min, t / 11.0);
+    return std::min(opt.mu_min, 0.5 * t);
+  }
+
   DNLP_HD void monotone_update() {
     const double k_eps = 10.0, k_mu = 0.2, th_mu = 1.5;
-    const double mu_floor = std::max(opt.mu_min, std::min(opt.tol, opt.compl_inf_tol) / 11.0);
+    const double mu_floor = mu_floor_now();
     for (int k = 0; k < 50; ++k) {
       Err e = error(mu);
       if (e.total <= k_eps * mu && mu > mu_floor) {
@@ -1429,7 +1444,7 @@ class Ipm {
   DNLP_HD bool update_mu(const Err& e0) {
     if (n_bound_mults() == 0) { tau = 0.99; return false; }   // no barrier terms at all
     if (opt.mu_strategy == 0) { monotone_update(); return false; }
-    const double mu_floor = std::max(opt.mu_min, std::min(opt.tol, opt.compl_inf_tol) / 11.0);
+    const double mu_floor = mu_floor_now();
     double kkt = e0.dual + e0.primal + e0.cmpl;
     if (!fixed_mode) {
       bool ok = n_hist == 0;
@@ -1463,7 +1478,7 @@ class Ipm {
     const double avg = avg_complementarity();
     const i64 nb = n_bound_mults();
     if (!(avg > 0.0) || nb == 0) return false;
-    const double mu_floor = std::max(opt.mu_min, std::min(opt.tol, opt.compl_inf_tol) / 11.0);
+    const double mu_floor = mu_floor_now();
     double* cur[7] = {dx, ds, dy, dzL, dzU, dvL, dvU};
     const i64 sz[7] = {N, m, m, N, N, m, m};
     barrier_terms(0.0);
@@ -1478,6 +1493,10 @@ class Ipm {
       return v; });
     const double nd2 = R2.sm[0], np2 = m ? R2.sm[1] : 0.0;
     if (!compute_direction(0.0, rp, dw)) return false;
+    // a poorly solved affine system must not hide behind a well solved centring system (the step is
+    // aff + mu cen, mu tiny: its accuracy is the affine solve's): the "pretend singular" test that follows
+    // the oracle sees the worse of the two residual ratios
+    const double ratio_aff = last_ratio_;
     for (int k = 0; k < 7; ++k) ex_->d2d(aff[k], cur[k], sizeof(double) * static_cast<size_t>(sz[k]));
     {
       // centering right-hand side: derivative of the barrier terms w.r.t. mu
@@ -1506,6 +1525,7 @@ class Ipm {
       });
     }
     if (!compute_direction(1.0, zeroM, dw, true)) return false;
+    if (ratio_aff > last_ratio_) last_ratio_ = ratio_aff;
     for (int k = 0; k < 7; ++k) ex_->d2d(cen[k], cur[k], sizeof(double) * static_cast<size_t>(sz[k]));
     const i64 n_ineq = m - n_eq_;                      // (counted once in begin())
     const double n_dual = static_cast<double>(N + n_ineq), n_pri = static_cast<double>(m > 0 ? m : 1);

@@ -82,15 +82,25 @@ def template_circle_packing(n=4):
     pairs = [(a, b) for a in range(n - 1) for b in range(a + 1, n)]
     R2 = cp.Parameter(len(pairs), name="R2", value=np.full(len(pairs), 4.0))
     rad = cp.Parameter(n, name="rad", value=np.ones(n))
-    centers = cp.Variable((2, n), name="c")
-    cons = [cp.sum(cp.square(centers[:, a] - centers[:, b])) >= R2[k] for k, (a, b) in enumerate(pairs)]
     rng0 = np.random.default_rng(0)
     if n >= 10:
-        # the notebook's member (circle_packing.ipynb, n = 10): its radii are instance 0's (first draw of
-        # default_rng(0)) and the start is its second draw, so instance 0 IS the published problem
+        # the notebook's member (circle_packing.ipynb, n = 10), in the notebook's own formulation (centres
+        # n x 2, one vector constraint per circle against the circles after it): its radii are instance 0's
+        # (first draw of default_rng(0)) and the start is its second draw, so instance 0 IS the published
+        # problem, canonical form included
         rng0.uniform(1.0, 3.0, n)
-    centers.value = rng0.uniform(-5.0, 5.0, (2, n))
-    prob = cp.Problem(cp.Minimize(cp.max(cp.norm_inf(centers, axis=0) + rad)), cons)
+        centers = cp.Variable((n, 2), name="c")
+        cons, k = [], 0
+        for i in range(n - 1):
+            cons += [cp.sum((centers[i, :] - centers[i + 1:, :]) ** 2, axis=1) >= R2[k:k + n - 1 - i]]
+            k += n - 1 - i
+        centers.value = rng0.uniform(-5.0, 5.0, (2, n)).T
+        prob = cp.Problem(cp.Minimize(cp.max(cp.norm_inf(centers, axis=1) + rad)), cons)
+    else:
+        centers = cp.Variable((2, n), name="c")
+        cons = [cp.sum(cp.square(centers[:, a] - centers[:, b])) >= R2[k] for k, (a, b) in enumerate(pairs)]
+        centers.value = rng0.uniform(-5.0, 5.0, (2, n))
+        prob = cp.Problem(cp.Minimize(cp.max(cp.norm_inf(centers, axis=0) + rad)), cons)
 
     def sample(i):
         rng = np.random.default_rng(i)

@@ -369,3 +369,77 @@ def test_create_from_arrays_on_the_device():
         assert np.array_equal(prob.variables()[0].value, ref.variables()[0].value)
     finally:
         HIPNLP.LARGE_TAPE_BYTES = old
+
+
+def test_device_intermediate_callback_and_user_requested_stop(gpu_required):
+    """Row a10 on the DEVICE library: dnlp_set_intermediate_cb on libdnlp_hip.so (Oracles.intermediate,
+    nlp_solver.py:423-427) — called at iteration 0 and after every iteration with cyipopt's eleven values; a
+    False return ends the solve with status 5 (ipopt_nlpif.py:31-61).  A callback forces the host-driven loop
+    (a problem this small would otherwise run inside one kernel)."""
+    from dnlp_amd.nlp_solver import HIPNLP
+    data, blob, dev = _device_problem("hs071")
+    seen = []
+    dev.set_intermediate(lambda *a: seen.append(a) or True)
+    for k, v in HIPNLP.DEFAULT_OPTIONS.items():
+        dev.set_option(k, v)
+    info = dev.solve(data["x0"])
+    assert info["status"] == 0
+    assert [a[1] for a in seen] == list(range(info["iterations"] + 1))       # iter_count 0..K
+    assert len(seen[0]) == 11
+    assert abs(seen[-1][2] - info["obj_val"]) <= 1e-12 * abs(info["obj_val"])
+    assert all(a[5] > 0 for a in seen)                                       # mu
+    xs = np.array([0.75450865, 4.63936861, 3.78856881, 1.88513184])          # test_nlp_solvers.py:37
+    assert abs(info["obj_val"] - (xs[0] * xs[3] * (xs[0] + xs[1] + xs[2]) + xs[2])) <= 1e-6 * info["obj_val"]
+    # stop after the third iteration
+    dev.set_intermediate(lambda alg, it, *rest: it < 3)
+    info = dev.solve(data["x0"])
+    assert info["status"] == 5 and info["iterations"] == 3
+    assert HIPNLP.STATUS_MAP[5] == "user_limit"
+    dev.set_intermediate(None)
+    assert dev.solve(data["x0"])["status"] == 0
+    dev.close()
+
+
+def test_device_intermediate_callback_through_the_front_end(gpu_required):
+    """Problem.solve(nlp=True, intermediate_callback=fn): the user's hook sees every iteration of the
+    device solve and may stop it (status "user_limit")."""
+    import dnlp_amd as cp
+    from problem_zoo import hs071
+    prob = hs071(cp)
+    calls = []
+    prob.solve(nlp=True, intermediate_callback=lambda *a: calls.append(a[1]) or True)
+    assert prob.status == cp.OPTIMAL
+    assert calls == list(range(prob.solver_stats.num_iters + 1))
+    full = prob.solver_stats.num_iters
+    prob2 = hs071(cp)
+    prob2.solve(nlp=True, intermediate_callback=lambda alg, it, *rest: it < 2)
+    assert prob2.status == "user_limit" and prob2.solver_stats.num_iters == 2 < full
+
+
+def test_device_ipm_step_counts_only_iterations_that_were_carried_out(gpu_required):
+    """The counters bench.py's `value` is made of, on the device library: dnlp_ipm_step counts an iteration
+    only when the iterate advanced (the call that merely detects convergence adds nothing) and the cumulative
+    counters survive dnlp_ipm_begin (stats[16..18])."""
+    from dnlp_amd.nlp_solver import HIPNLP
+    data, blob, dev = _device_problem("hs071")
+    for k, v in HIPNLP.DEFAULT_OPTIONS.items():
+        dev.set_option(k, v)
+    dev.set_intermediate(lambda *a: True)           # host-driven loop, as ipm_begin / ipm_step are
+    total = dev.solve(data["x0"])["iterations"]
+    dev.set_intermediate(None)
+    st0 = dev.stats()
+    dev.ipm_begin(data["x0"])
+    rc, k = dev.ipm_step(3)
+    assert (rc, k) == (99, 3)
+    rc, k2 = dev.ipm_step(1000)
+    assert rc == 0 and k + k2 == total
+    rc, k3 = dev.ipm_step(5)                 # already converged: nothing is carried out, nothing counted
+    assert rc == 0 and k3 == 0
+    st = dev.stats()
+    assert st[16] - st0[16] == total and st[18] - st0[18] == 1
+    dev.ipm_begin(data["x0"])
+    dev.ipm_step(2)
+    st2 = dev.stats()
+    assert st2[16] - st0[16] == total + 2 and st2[18] - st0[18] == 2 and st2[17] > st[17]
+    assert st2[0] == 2                     # per-solve statistics were reset by begin
+    dev.close()

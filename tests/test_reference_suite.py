@@ -14,8 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_TESTS = "/root/reference/cvxpy/tests/NLP_tests"
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF_TESTS), reason="reference tree not present")
 
-# tests that need a solver this image does not have (CLARABEL cross-checks) ...
-NEEDS_OTHER_SOLVER = {
+# tests whose cross-check needs a conic solver this image does not have (CLARABEL): each of them is restated in
+# tests/convex_certificates.py with a duality-gap certificate (or an exact LP / independent SLSQP solve) in the
+# conic solver's place and runs in tests/test_convex_certificates.py on both engines
+CERTIFIED_HERE = {
     "test_Sharpe_ratio.py::TestSharpeRatio::test_formulation_one",
     "test_abs.py::TestAbs::test_lasso_square_small", "test_abs.py::TestAbs::test_lasso_square",
     "test_abs.py::TestAbs::test_lasso_underdetermined", "test_abs.py::TestAbs::test_lasso_overdetermined",
@@ -40,6 +42,6 @@ def test_reference_nlp_suite_passes_on_this_solver():
     m = re.search(r"(\d+) passed", out)
     assert m, out[-2000:]
     passed = int(m.group(1))
-    unexpected = failed - NEEDS_OTHER_SOLVER - KNOWN_GAPS
+    unexpected = failed - CERTIFIED_HERE - KNOWN_GAPS
     assert not unexpected, sorted(unexpected)
     assert passed >= 205, passed
