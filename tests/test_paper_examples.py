@@ -44,8 +44,10 @@ def _check(name, info):
     assert info["status"] == 0
     ref = pub["objective"]
     if name == "nb_phase_retrieval":
-        # exact recovery: the optimum is 0 and the log's 3.9e-9 is the final barrier residue
-        assert abs(info["obj_val"]) <= 1e-5
+        # exact recovery: the optimum is 0 and the log's 3.9e-9 is the final barrier residue — 384 active
+        # inequality rows x the adaptive strategy's barrier floor 1e-11, which this build shares since round 3
+        # (rounds 1-2 floored mu at tol / 11 and stopped at 3.5e-6 = 384 x 9e-9)
+        assert abs(info["obj_val"]) <= 1e-7
     elif name == "nb_circle_packing":
         # non-convex: the log's value is one local optimum; ours must be a KKT point no worse
         assert info["obj_val"] <= ref * (1 + REL_TOL)
@@ -109,7 +111,7 @@ def test_cpu_power_flow_iteration_count_equals_ipopt():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(set(PUBLISHED) - {"nb_localization"}))
+@pytest.mark.parametrize("name", sorted(set(PUBLISHED) - {"nb_localization", "nb_portfolio_construction"}))
 def test_device_reaches_published_optimum(name, gpu_required):
     from dnlp_amd import _capi
     from dnlp_amd.nlp_solver import HIPNLP
@@ -124,6 +126,64 @@ def test_device_reaches_published_optimum(name, gpu_required):
     assert info["status"] == 0, dev.log()
     _check(name, info)
     dev.close()
+
+
+# ---- portfolio_construction.ipynb: published dimensions, synthetic returns ----------------------------------
+def _solve_portfolio(make_handle):
+    """The eighth example of the paper at its published dimensions (1 282 / 959 / 15, nnz 103 995 + 1 306 /
+    51 359: test_dimensions_match_published_ipopt_log) on seeded synthetic returns.  The published objective
+    belongs to the real price file, so the known answers are properties: a KKT point (certificate from the
+    returned multipliers), a fully invested long-only portfolio, t1 = Sigma w and t2 = w'Sigma w at the
+    solution, and every sector's risk contribution within 10 % of its budget (the constraint the example is
+    about; the notebook prints [0.33, 0.225, 0.18, 0.165, 0.1] for b = [0.3, 0.25, 0.2, 0.15, 0.1])."""
+    import dnlp_amd as cp
+    from dnlp_amd.dnlp2smooth import Dnlp2Smooth
+    from dnlp_amd.nlp_solver import HIPNLP, build_nlp_data
+    from dnlp_amd.tape import serialize
+    from paper_examples import nb_portfolio_construction, portfolio_data
+    from test_full_size_configs import _kkt_residuals
+    p = nb_portfolio_construction(cp)
+    pmin = cp.Problem(cp.Minimize(-p.objective.expr), p.constraints)
+    smooth, _ = Dnlp2Smooth().apply(pmin)
+    data, inv = build_nlp_data(smooth, user_variables=p.variables())
+    h = make_handle(serialize(data["tape_arrays"]), data["tape"])
+    for k, v in HIPNLP.DEFAULT_OPTIONS.items():
+        h.set_option(k, v)
+    info = h.solve(data["x0"])
+    assert info["status"] == 0, info["status"]
+    assert info["iterations"] <= 2 * PUBLISHED["nb_portfolio_construction"]["iters"] + 10
+    stat, viol, bviol, comp = _kkt_residuals(data["tape_arrays"], info["x"], info["mult_g"], info["mult_x_L"],
+                                             info["mult_x_U"])
+    assert stat <= 1e-6 and viol <= 1e-8 and bviol <= 1e-12 and comp <= 1e-7, (stat, viol, bviol, comp)
+    Sigma, mu, groups = portfolio_data()
+    n = Sigma.shape[0]
+    by_size = {}
+    for v in p.variables():
+        by_size.setdefault(v.size, []).append(v)
+    w_var, t1_var = by_size[n]                       # creation order: w, then t1
+    t2_var = by_size[1][0]
+    val = lambda v: info["x"][inv.var_offsets[v.id]:inv.var_offsets[v.id] + v.size]
+    w, t1, t2 = val(w_var), val(t1_var), float(val(t2_var)[0])
+    assert abs(np.sum(w) - 1.0) <= 1e-9 and np.min(w) >= -1e-12
+    np.testing.assert_allclose(t1, Sigma @ w, rtol=1e-7, atol=1e-12)
+    assert abs(t2 - w @ Sigma @ w) <= 1e-9 * t2
+    assert abs(-info["obj_val"] - (mu @ w - t2)) <= 1e-10
+    rc = w * (Sigma @ w)
+    rc = np.array([np.sum(rc[g]) for g in groups]) / np.sum(rc)
+    b = np.array([0.3, 0.25, 0.20, 0.15, 0.10])
+    assert np.all(np.abs(rc - b) <= 0.1 * b * (1 + 1e-6)), rc
+    return info
+
+
+def test_cpu_portfolio_construction_at_published_dimensions():
+    from oracle.oracle_capi import OracleProblem
+    _solve_portfolio(lambda blob, tape: OracleProblem(blob))
+
+
+@pytest.mark.gpu
+def test_device_portfolio_construction_at_published_dimensions(gpu_required):
+    from dnlp_amd import _capi
+    _solve_portfolio(lambda blob, tape: _capi.DeviceProblem(blob, tape, device=0))
 
 
 # ---- examples without a published IPOPT log: NMF.ipynb, sparse_recovery.ipynb ------------------------
