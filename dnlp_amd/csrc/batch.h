@@ -49,6 +49,7 @@ struct BatchArgs {
   i64 fallback_max_n = 0;        // sparse instances up to this order may switch to in-kernel Bunch-Kaufman
   const double *ws_g = nullptr, *ws_l = nullptr, *ws_u = nullptr;   // per-instance warm-start multipliers (batch-major) or null
   int* next = nullptr;           // work queue head: instances are claimed dynamically (iteration counts vary 10x)
+  const int* order = nullptr;    // queue position -> instance (longest expected first), or null for 0, 1, 2, ...
 };
 
 // The solver objects of an instance (exec space, model, KKT, interior-point state) live in LDS,
@@ -115,7 +116,10 @@ __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
   __shared__ int s_inst;
   Objs& o = s_objs[threadIdx.x >> 6];
   while (true) {
-    if (threadIdx.x == 0) s_inst = atomicAdd(a.next, 1);
+    if (threadIdx.x == 0) {
+      const int k = atomicAdd(a.next, 1);
+      s_inst = (k < a.batch && a.order) ? a.order[k] : k;
+    }
     __syncthreads();
     const int inst = s_inst;
     __syncthreads();
@@ -217,10 +221,15 @@ struct BatchRunner {
   // device buffers kept across calls (grow-only): a call is then one H2D copy, one launch and the
   // result copies — no allocation on the steady-state path
   struct Buf { void* p = nullptr; size_t cap = 0; };
-  Buf bufs[16];
+  Buf bufs[24];
   int nbuf_used = 0;
   int ncu = 0;
   std::vector<double> slab;
+  // Iteration counts of the previous solve of the same batch size: a re-solve of a parametrised batch (same or
+  // nearby parameter rows, warm or cold) takes its instances longest-first, so the instances that need 150+
+  // iterations start at once instead of being the tail of the launch (mean 31, max 184-198 at 8192 localization
+  // instances: a third of the launch was the tail).  A heuristic only — any order gives the same results.
+  std::vector<int> prev_iters;
 
   // affine parameter -> instance-data map (dnlp_batch_set_affine_map), resident on the device, in slab layout
   int aff_P = -1;
@@ -534,6 +543,15 @@ struct BatchRunner {
     ws_batch = 0;
     a.next = dalloc<int>(1);
     DNLP_HIP_CHECK(hipMemsetAsync(a.next, 0, sizeof(int), ex->stream));
+    if (static_cast<int>(prev_iters.size()) == batch && batch > grid && !std::getenv("DNLP_BATCH_FIFO")) {
+      std::vector<int> ord(static_cast<size_t>(batch));
+      for (int k = 0; k < batch; ++k) ord[static_cast<size_t>(k)] = k;
+      std::stable_sort(ord.begin(), ord.end(), [&](int p, int q) { return prev_iters[static_cast<size_t>(p)] > prev_iters[static_cast<size_t>(q)]; });
+      int* d_ord = dalloc<int>(static_cast<size_t>(batch));
+      DNLP_HIP_CHECK(hipMemcpyAsync(d_ord, ord.data(), sizeof(int) * static_cast<size_t>(batch), hipMemcpyHostToDevice, ex->stream));
+      DNLP_HIP_CHECK(hipStreamSynchronize(ex->stream));     // `ord` is a local
+      a.order = d_ord;
+    }
     mark("plan + buffers");
     hipEvent_t e0, e1;
     DNLP_HIP_CHECK(hipEventCreate(&e0));
@@ -560,6 +578,7 @@ struct BatchRunner {
     down(iters_out, a.iters_out, sizeof(int) * batch);
     down(nfact_out, a.nfact_out, sizeof(int) * batch);
     down(times_out, a.times_out, sizeof(double) * 4 * batch);
+    if (iters_out) prev_iters.assign(iters_out, iters_out + batch);
     release();
     mark("results copied");
   }
