@@ -842,6 +842,288 @@ __global__ void __launch_bounds__(SV_B) ldlt_bwd_diag(const double* __restrict__
   if (t < jb) b[j0 + t] = v;
 }
 
+// ---- triangular solves on inverted diagonal blocks (round 3) ---------------------------------------------------
+// The 256-wide diagonal solves above are chains of dependent substitutions on ONE compute unit (28 us per block,
+// 30 % of a C3 solve).  After a factorisation the unit-lower 128 x 128 diagonal blocks are inverted once
+// (ldlt_inv128_kernel, all blocks in parallel, off the solves' path); a 256-column block step of a solve is then
+// products only — inverse x vector, 128 x 128 coupling block x vector, inverse x vector — and ONE launch per
+// step: workgroup 0 brings the NEXT block's right-hand side up to date and solves it while the other workgroups
+// update the rows (columns, in the transposed sweep) further away with the block that is already final.
+constexpr int SI_B = 256;           // columns per step
+constexpr int SI_H = 128;           // order of an inverted diagonal block
+constexpr int SI_T = 1024;          // threads per workgroup of the step kernels
+
+// inv / invT: per 128-block 128 x 128 doubles, column-major, X = L_bb^-1 and its transpose.  One workgroup of 128
+// lanes per block: each wavefront inverts one 64 x 64 diagonal half with a column per lane in registers (static
+// indices; L is read as LDS broadcasts), then M = -X1 (C X0) for the coupling block C = L[64.., ..64) in two
+// products whose operands a lane holds as a register row / column.  Rows and columns past n are identity.
+__global__ void __launch_bounds__(128) ldlt_inv128_kernel(const double* __restrict__ A, i64 ld, int n,
+                                                          double* __restrict__ inv, double* __restrict__ invT) {
+  extern __shared__ __align__(16) double si_lds[];
+  double* Ls = si_lds;                 // [2][64 * 64]: the two diagonal halves, later their inverses
+  double* Cs = si_lds + 2 * 4096;      // [64 * 64]: C, then T = C X0, then M
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j0 = blockIdx.x * SI_H;
+  {
+    // strictly lower part of diagonal half w (unit diagonal implied), row `lane`
+    double* Lw = Ls + w * 4096;
+    const int gi = j0 + 64 * w + lane;
+    for (int j = 0; j < 64; ++j) {
+      const int gj = j0 + 64 * w + j;
+      Lw[lane * 64 + j] = (j < lane && gi < n) ? A[gi + static_cast<i64>(gj) * ld] : 0.0;
+    }
+    // coupling block: row `lane`, columns 32 w .. 32 w + 32
+    const int ci = j0 + 64 + lane;
+    for (int j = 32 * w; j < 32 * w + 32; ++j)
+      Cs[lane * 64 + j] = (ci < n) ? A[ci + static_cast<i64>(j0 + j) * ld] : 0.0;
+  }
+  __syncthreads();
+  double x[64];
+  {
+    const double* Lw = Ls + w * 4096;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      double sacc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+      for (int j = 0; j < i; ++j) sacc = fma(-Lw[i * 64 + j], x[j], sacc);
+      x[i] = sacc;
+    }
+  }
+  __syncthreads();                      // every lane is done reading L
+  {
+    double* Xw = Ls + w * 4096;         // X_w[i][t] at i * 64 + t
+#pragma unroll
+    for (int i = 0; i < 64; ++i) Xw[i * 64 + lane] = x[i];
+  }
+  // T = C X0: lane owns row `lane` of C (registers) and 32 columns of the result
+#pragma unroll
+  for (int k = 0; k < 64; ++k) x[k] = Cs[lane * 64 + k];
+  __syncthreads();                      // X0, X1 in LDS; every lane holds its row of C
+  {
+    const double* X0 = Ls;
+    for (int j = 32 * w; j < 32 * w + 32; ++j) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) sacc = fma(x[k], X0[k * 64 + j], sacc);   // (X0[k][j] = 0 for k < j)
+      Cs[lane * 64 + j] = sacc;         // row `lane` is this lane pair's own: no other lane reads it before the barrier
+    }
+  }
+  __syncthreads();
+  // M = -X1 T: lane owns column `lane` of T (registers) and 32 rows of the result
+#pragma unroll
+  for (int k = 0; k < 64; ++k) x[k] = Cs[k * 64 + lane];
+  __syncthreads();
+  {
+    const double* X1 = Ls + 4096;
+    for (int i = 32 * w; i < 32 * w + 32; ++i) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) sacc = fma(X1[i * 64 + k], x[k], sacc);   // (X1[i][k] = 0 for k > i)
+      Cs[i * 64 + lane] = -sacc;
+    }
+  }
+  __syncthreads();
+  double* out = inv + static_cast<i64>(blockIdx.x) * (SI_H * SI_H);
+  double* outT = invT + static_cast<i64>(blockIdx.x) * (SI_H * SI_H);
+  auto elem = [&](int r, int c) -> double {
+    if (r < 64) return c < 64 ? Ls[r * 64 + c] : 0.0;
+    return c < 64 ? Cs[(r - 64) * 64 + c] : Ls[4096 + (r - 64) * 64 + (c - 64)];
+  };
+  for (int idx = tid; idx < SI_H * SI_H; idx += 128) {
+    const int lo = idx & (SI_H - 1), hi = idx >> 7;
+    out[idx] = elem(lo, hi);            // column-major X: idx = r + 128 c
+    outT[idx] = elem(hi, lo);           // column-major X^T: idx = c + 128 r
+  }
+}
+
+// 128 x 128 product from global memory by all SI_T lanes: out[i] = sum_c M[i + ldm c] v[c] for i < 128, eight column
+// chunks of 16 meeting in `part` ([8][128]).  Ends with a barrier; `out` may alias nothing the product reads.
+__device__ inline void si_mat128_vec(const double* __restrict__ M, i64 ldm, const double* v, double* part, int tid) {
+  const int i = tid & (SI_H - 1), ch = tid >> 7;
+  const double* col = M + i + static_cast<i64>(16 * ch) * ldm;
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int c = 0; c < 16; c += 2) {
+    s0 = fma(col[static_cast<i64>(c) * ldm], v[16 * ch + c], s0);
+    s1 = fma(col[static_cast<i64>(c + 1) * ldm], v[16 * ch + c + 1], s1);
+  }
+  part[ch * SI_H + i] = s0 + s1;
+  __syncthreads();
+}
+__device__ inline double si_part_sum(const double* part, int i) {
+  double s = 0.0;
+#pragma unroll
+  for (int ch = 0; ch < 8; ++ch) s += part[ch * SI_H + i];
+  return s;
+}
+
+// One step of L y = b.  j0 = block whose y is final in b (j0 < 0: prologue, only block 0 is solved).
+// Workgroup 0: rows of the next block j1 = j0 + 256: b1 -= L[j1.., j0..) y, then y1 = L11^-1 b1 through the two
+// inverted halves.  Workgroups g >= 1: 64 rows from j1 + 256 + 64 (g - 1): b[r] -= L[r, j0..) y.
+__global__ void __launch_bounds__(SI_T) ldlt_fwd_step_kernel(const double* __restrict__ A, i64 ld, int n, int j0,
+                                                             double* __restrict__ b, const double* __restrict__ inv) {
+  __shared__ double y[SI_B];
+  __shared__ double part[SI_T];
+  __shared__ double bn[SI_B];
+  const int tid = threadIdx.x;
+  const int j1 = j0 + SI_B;
+  if (j0 >= 0) {
+    if (tid < SI_B) y[tid] = b[j0 + tid];
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {
+    const int jbn = (n - j1 < SI_B) ? n - j1 : SI_B;
+    if (j0 >= 0) {
+      // 256 x 256 coupling block: lane = row, four column quarters
+      const int r = tid & (SI_B - 1), q = tid >> 8;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      if (r < jbn) {
+        const double* row = A + (j1 + r) + static_cast<i64>(j0 + 64 * q) * ld;
+        const double* yq = y + 64 * q;
+#pragma unroll 4
+        for (int c = 0; c < 64; c += 4) {
+          s0 = fma(row[static_cast<i64>(c) * ld], yq[c], s0);
+          s1 = fma(row[static_cast<i64>(c + 1) * ld], yq[c + 1], s1);
+          s2 = fma(row[static_cast<i64>(c + 2) * ld], yq[c + 2], s2);
+          s3 = fma(row[static_cast<i64>(c + 3) * ld], yq[c + 3], s3);
+        }
+      }
+      part[q * SI_B + r] = (s0 + s1) + (s2 + s3);
+      __syncthreads();
+      if (tid < SI_B)
+        bn[tid] = (tid < jbn) ? b[j1 + tid] - ((part[tid] + part[SI_B + tid]) + (part[2 * SI_B + tid] + part[3 * SI_B + tid])) : 0.0;
+    } else if (tid < SI_B) {
+      bn[tid] = (tid < jbn) ? b[j1 + tid] : 0.0;
+    }
+    __syncthreads();
+    const double* X0 = inv + static_cast<i64>(j1 / SI_H) * (SI_H * SI_H);
+    si_mat128_vec(X0, SI_H, bn, part, tid);
+    if (tid < SI_H) {
+      const double v = si_part_sum(part, tid);
+      bn[tid] = v;
+      if (tid < jbn) b[j1 + tid] = v;
+    }
+    __syncthreads();
+    if (jbn > SI_H) {
+      si_mat128_vec(A + (j1 + SI_H) + static_cast<i64>(j1) * ld, ld, bn, part, tid);      // rows past n: read inside the padded allocation, unused
+      if (tid < SI_H) bn[SI_H + tid] -= (SI_H + tid < jbn) ? si_part_sum(part, tid) : 0.0;
+      __syncthreads();
+      si_mat128_vec(X0 + SI_H * SI_H, SI_H, bn + SI_H, part, tid);
+      if (tid < SI_H && SI_H + tid < jbn) b[j1 + SI_H + tid] = si_part_sum(part, tid);
+    }
+  } else {
+    const int lane = tid & 63, w = tid >> 6;           // sixteen column chunks of 16
+    const i64 r = static_cast<i64>(j1) + SI_B + 64 * static_cast<i64>(blockIdx.x - 1) + lane;
+    double s0 = 0.0, s1 = 0.0;
+    if (r < n) {
+      const double* row = A + r + static_cast<i64>(j0 + 16 * w) * ld;
+      const double* yw = y + 16 * w;
+#pragma unroll
+      for (int c = 0; c < 16; c += 2) {
+        s0 = fma(row[static_cast<i64>(c) * ld], yw[c], s0);
+        s1 = fma(row[static_cast<i64>(c + 1) * ld], yw[c + 1], s1);
+      }
+    }
+    part[w * 64 + lane] = s0 + s1;
+    __syncthreads();
+    if (w == 0 && r < n) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += part[k * 64 + lane];
+      b[r] -= s;
+    }
+  }
+}
+
+// One step of L^T x = b, blocks from the last to the first.  j0 = block whose x is final (j0 >= n: prologue, only the
+// last block is solved).  Workgroup 0: columns of the previous block jp = j0 - 256: bp -= L[j0.., jp..)^T x, then
+// xp = Lpp^-T bp through the two transposed inverses.  Workgroups g >= 1: 64 columns from 64 (g - 1) below jp.
+__global__ void __launch_bounds__(SI_T) ldlt_bwd_step_kernel(const double* __restrict__ A, i64 ld, int n, int j0,
+                                                             double* __restrict__ b, const double* __restrict__ invT) {
+  __shared__ double x[SI_B];
+  __shared__ double part[SI_T];
+  __shared__ double bn[SI_B];
+  const int tid = threadIdx.x;
+  const bool prologue = j0 >= n;
+  const int jb = prologue ? 0 : ((n - j0 < SI_B) ? n - j0 : SI_B);
+  if (!prologue) {
+    if (tid < SI_B) x[tid] = (tid < jb) ? b[j0 + tid] : 0.0;
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {
+    const int jp = prologue ? ((n - 1) / SI_B) * SI_B : j0 - SI_B;
+    const int jbp = (n - jp < SI_B) ? n - jp : SI_B;
+    if (!prologue) {
+      // lane = column of the previous block, four row quarters of 64 contiguous entries each
+      const int c = tid & (SI_B - 1), q = tid >> 8;
+      const double* col = A + (j0 + 64 * q) + static_cast<i64>(jp + c) * ld;
+      const double* xq = x + 64 * q;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      const int rmax = jb - 64 * q;                   // rows of this quarter that exist
+#pragma unroll 4
+      for (int r = 0; r < 64; r += 4) {
+        s0 = fma((r < rmax) ? col[r] : 0.0, xq[r], s0);
+        s1 = fma((r + 1 < rmax) ? col[r + 1] : 0.0, xq[r + 1], s1);
+        s2 = fma((r + 2 < rmax) ? col[r + 2] : 0.0, xq[r + 2], s2);
+        s3 = fma((r + 3 < rmax) ? col[r + 3] : 0.0, xq[r + 3], s3);
+      }
+      part[q * SI_B + c] = (s0 + s1) + (s2 + s3);
+      __syncthreads();
+      if (tid < SI_B)
+        bn[tid] = b[jp + tid] - ((part[tid] + part[SI_B + tid]) + (part[2 * SI_B + tid] + part[3 * SI_B + tid]));
+    } else if (tid < SI_B) {
+      bn[tid] = (tid < jbp) ? b[jp + tid] : 0.0;
+    }
+    __syncthreads();
+    const double* XT0 = invT + static_cast<i64>(jp / SI_H) * (SI_H * SI_H);
+    if (jbp > SI_H) {
+      si_mat128_vec(XT0 + SI_H * SI_H, SI_H, bn + SI_H, part, tid);
+      if (tid < SI_H) {
+        const double v = si_part_sum(part, tid);
+        bn[SI_H + tid] = (SI_H + tid < jbp) ? v : 0.0;
+        if (SI_H + tid < jbp) b[jp + SI_H + tid] = v;
+      }
+      __syncthreads();
+      // bn[0 .. 128) -= L[jp + 128 .., jp ..)^T x_hi: lane = column, eight row chunks of 16 contiguous entries
+      const int c = tid & (SI_H - 1), ch = tid >> 7;
+      const double* col = A + (jp + SI_H + 16 * ch) + static_cast<i64>(jp + c) * ld;
+      const int rmax = jbp - SI_H - 16 * ch;
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        s0 = fma((r < rmax) ? col[r] : 0.0, bn[SI_H + 16 * ch + r], s0);
+        s1 = fma((r + 1 < rmax) ? col[r + 1] : 0.0, bn[SI_H + 16 * ch + r + 1], s1);
+      }
+      part[ch * SI_H + c] = s0 + s1;
+      __syncthreads();
+      if (tid < SI_H) bn[tid] -= si_part_sum(part, tid);
+      __syncthreads();
+    }
+    si_mat128_vec(XT0, SI_H, bn, part, tid);
+    if (tid < SI_H && tid < jbp) b[jp + tid] = si_part_sum(part, tid);
+  } else {
+    const int lane = tid & 63, w = tid >> 6;           // sixteen row chunks of 16
+    const int c = 64 * (blockIdx.x - 1) + lane;        // < j0 - 256 by the launch geometry
+    const double* col = A + (j0 + 16 * w) + static_cast<i64>(c) * ld;
+    const double* xw = x + 16 * w;
+    const int rmax = jb - 16 * w;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      s0 = fma((r < rmax) ? col[r] : 0.0, xw[r], s0);
+      s1 = fma((r + 1 < rmax) ? col[r + 1] : 0.0, xw[r + 1], s1);
+    }
+    part[w * 64 + lane] = s0 + s1;
+    __syncthreads();
+    if (w == 0) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += part[k * 64 + lane];
+      b[c] -= s;
+    }
+  }
+}
+
 struct BlockedLdlt {
   HipExec* ex = nullptr;
   i64 n = 0, ld = 0, ldw = 0;
@@ -868,6 +1150,9 @@ struct BlockedLdlt {
                                // look-ahead and the tile with the better MFMA rate wins (DNLP_LDLT_SMALL_ROWS)
   int reserve_cus = 0;         // compute units the update stream may not use (look-ahead panel kernels run there)
   int max_neg = -1;            // >= 0: give up as soon as more negative pivots than this appear
+  double *Linv = nullptr, *LinvT = nullptr;   // inverted 128 x 128 diagonal blocks of the current factor (and transposes)
+  bool inv_ready = false;      // ... computed by the first solve after a factorisation
+  bool solve_inv = true;       // DNLP_LDLT_SOLVE_INV=0: the substitution-based block solves
 
   BlockedLdlt() = default;
   BlockedLdlt(const BlockedLdlt&) = delete;
@@ -893,6 +1178,7 @@ struct BlockedLdlt {
     if (const char* ev = std::getenv("DNLP_LDLT_T128")) sub128 = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_SMALL_TILES")) small_tiles_below = std::atoi(ev);
     if (const char* ev = std::getenv("DNLP_LDLT_SMALL_ROWS")) small_rows_max = std::atoi(ev);
+    if (const char* ev = std::getenv("DNLP_LDLT_SOLVE_INV")) solve_inv = std::atoi(ev) != 0;
     if (NB < LD_nb) NB = LD_nb;
     if (NB > LD_NB_MAX) NB = LD_NB_MAX;
     NB = NB / LD_nb * LD_nb;
@@ -966,6 +1252,7 @@ struct BlockedLdlt {
   // so the small panel kernels of p+1 run underneath the big MFMA update of p.
   bool factor(double* A, int* nneg, int* nzero) {
     hipStream_t s0 = ex->stream;
+    inv_ready = false;
     LdltInfo z;
     std::memset(&z, 0, sizeof z);
     DNLP_HIP_CHECK(hipMemcpyAsync(info, &z, sizeof z, hipMemcpyHostToDevice, s0));
@@ -1080,7 +1367,41 @@ struct BlockedLdlt {
     return cur.fail == 0;
   }
 
+  // L D L^T x = b on the inverted diagonal blocks: one launch per 256-column step and sweep
+  void solve_on_inverses(const double* A, double* b) {
+    const int ni = static_cast<int>(n);
+    const int nb128 = (ni + SI_H - 1) / SI_H;
+    if (!Linv) {
+      const size_t cnt = static_cast<size_t>(nb128 + 1) * SI_H * SI_H;
+      Linv = ex->alloc<double>(cnt);
+      LinvT = ex->alloc<double>(cnt);
+      DNLP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ldlt_inv128_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 4096 * 8));
+    }
+    if (!inv_ready) {
+      hipLaunchKernelGGL(ldlt_inv128_kernel, dim3(static_cast<unsigned>(nb128)), dim3(128), 3 * 4096 * 8, ex->stream, A, ld, ni,
+                         Linv, LinvT);
+      inv_ready = true;
+    }
+    hipLaunchKernelGGL(ldlt_fwd_step_kernel, dim3(1), dim3(SI_T), 0, ex->stream, A, ld, ni, -SI_B, b, Linv);
+    for (int j0 = 0; j0 + SI_B < ni; j0 += SI_B) {
+      const int below = ni - (j0 + 2 * SI_B);
+      const unsigned grid = 1u + (below > 0 ? static_cast<unsigned>((below + 63) / 64) : 0u);
+      hipLaunchKernelGGL(ldlt_fwd_step_kernel, dim3(grid), dim3(SI_T), 0, ex->stream, A, ld, ni, j0, b, Linv);
+    }
+    hipLaunchKernelGGL(ldlt_diag_scale, dim3((ni + 255) / 256), dim3(256), 0, ex->stream, A, ld, ni, b);
+    const int last = ((ni - 1) / SI_B) * SI_B;
+    hipLaunchKernelGGL(ldlt_bwd_step_kernel, dim3(1), dim3(SI_T), 0, ex->stream, A, ld, ni, last + SI_B >= ni ? ni : ni, b, LinvT);
+    for (int j0 = last; j0 >= SI_B; j0 -= SI_B) {
+      const int before = j0 - SI_B;                       // columns left of the previous block
+      const unsigned grid = 1u + static_cast<unsigned>(before / 64);
+      hipLaunchKernelGGL(ldlt_bwd_step_kernel, dim3(grid), dim3(SI_T), 0, ex->stream, A, ld, ni, j0, b, LinvT);
+    }
+    DNLP_LAUNCH_CHECK();
+  }
+
   void solve(const double* A, double* b) {
+    if (solve_inv && padded) { solve_on_inverses(A, b); return; }
     const int ni = static_cast<int>(n);
     for (int j0 = 0; j0 < ni; j0 += SV_B) {
       const int jb = std::min(SV_B, ni - j0);
