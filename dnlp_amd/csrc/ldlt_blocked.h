@@ -936,18 +936,36 @@ __global__ void __launch_bounds__(128) ldlt_inv128_kernel(const double* __restri
   }
 }
 
-// 128 x 128 product from global memory by all SI_T lanes: out[i] = sum_c M[i + ldm c] v[c] for i < 128, eight column
-// chunks of 16 meeting in `part` ([8][128]).  Ends with a barrier; `out` may alias nothing the product reads.
-__device__ inline void si_mat128_vec(const double* __restrict__ M, i64 ldm, const double* v, double* part, int tid) {
-  const int i = tid & (SI_H - 1), ch = tid >> 7;
-  const double* col = M + i + static_cast<i64>(16 * ch) * ldm;
+// Operands of a 128 x 128 product held by the SI_T lanes: lane (i = tid & 127, ch = tid >> 7) keeps the sixteen
+// entries M[i + ldm (16 ch + c)], c < 16 — fetched at kernel start, long before the vector they multiply exists,
+// so the dependent part of a step is LDS traffic only.
+// Entry `elem` (in doubles) behind a base that is uniform across the wavefront: the load is scalar base + 32-bit lane
+// offset.  (With 64-bit index arithmetic every load of an unrolled group keeps its own 64-bit address pair in VGPRs:
+// 64 registers for 32 loads, and these kernels have 128 per lane.)  Valid while elem * 8 < 2^32: the largest use is
+// 255 columns x ld + 255 rows, i.e. ld < 2^21.
+__device__ inline double si_ld(const double* base, unsigned elem) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + elem * 8u);
+}
+struct SiTile { double v[16]; };
+__device__ inline void si_tile_load(SiTile& t, const double* __restrict__ M, i64 ldm, int tid) {
+  // (the chunk index is the same for a whole wavefront: said so, the column bases live in scalar registers and a
+  //  load is scalar base + lane offset instead of a 64-bit address pair per load)
+  const int ch = __builtin_amdgcn_readfirstlane(tid >> 7);
+  const double* col = M + static_cast<i64>(16 * ch) * ldm;
+  const unsigned i = tid & (SI_H - 1), l32 = static_cast<unsigned>(ldm);
+#pragma unroll
+  for (int c = 0; c < 16; ++c) t.v[c] = si_ld(col, c * l32 + i);
+}
+// part[ch][i] = sum_c tile[c] v[16 ch + c]; ends with a barrier
+__device__ inline void si_tile_vec(const SiTile& t, const double* v, double* part, int tid) {
+  const int ch = __builtin_amdgcn_readfirstlane(tid >> 7);
   double s0 = 0.0, s1 = 0.0;
 #pragma unroll
   for (int c = 0; c < 16; c += 2) {
-    s0 = fma(col[static_cast<i64>(c) * ldm], v[16 * ch + c], s0);
-    s1 = fma(col[static_cast<i64>(c + 1) * ldm], v[16 * ch + c + 1], s1);
+    s0 = fma(t.v[c], v[16 * ch + c], s0);
+    s1 = fma(t.v[c + 1], v[16 * ch + c + 1], s1);
   }
-  part[ch * SI_H + i] = s0 + s1;
+  part[ch * SI_H + (tid & (SI_H - 1))] = s0 + s1;
   __syncthreads();
 }
 __device__ inline double si_part_sum(const double* part, int i) {
@@ -967,37 +985,63 @@ __global__ void __launch_bounds__(SI_T) ldlt_fwd_step_kernel(const double* __res
   __shared__ double bn[SI_B];
   const int tid = threadIdx.x;
   const int j1 = j0 + SI_B;
-  if (j0 >= 0) {
-    if (tid < SI_B) y[tid] = b[j0 + tid];
-    __syncthreads();
-  }
   if (blockIdx.x == 0) {
     const int jbn = (n - j1 < SI_B) ? n - j1 : SI_B;
+    const double* X0 = inv + static_cast<i64>(j1 / SI_H) * (SI_H * SI_H);
+    // One compute unit pulls this workgroup's 896 KB (coupling block 512, three operand tiles 384): more than its
+    // registers and LDS hold, so the coupling block is consumed in two halves and the tiles follow it in issue order
+    SiTile t0, tc, t1;
     if (j0 >= 0) {
       // 256 x 256 coupling block: lane = row, four column quarters
-      const int r = tid & (SI_B - 1), q = tid >> 8;
+      const int r = tid & (SI_B - 1), q = __builtin_amdgcn_readfirstlane(tid >> 8);
+      const double* row = A + static_cast<i64>(j0 + 64 * q) * ld + j1;      // wavefront-uniform base ...
+      const unsigned ro = r < jbn ? r : 0, l32 = static_cast<unsigned>(ld);   // ... plus the lane's row
+      double a[32];
+#pragma unroll
+      for (int c = 0; c < 32; ++c) a[c] = si_ld(row, c * l32 + ro);
+      if (tid < SI_B) y[tid] = b[j0 + tid];
+      __syncthreads();
+      const double* yq = y + 64 * q;
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      if (r < jbn) {
-        const double* row = A + (j1 + r) + static_cast<i64>(j0 + 64 * q) * ld;
-        const double* yq = y + 64 * q;
-#pragma unroll 4
-        for (int c = 0; c < 64; c += 4) {
-          s0 = fma(row[static_cast<i64>(c) * ld], yq[c], s0);
-          s1 = fma(row[static_cast<i64>(c + 1) * ld], yq[c + 1], s1);
-          s2 = fma(row[static_cast<i64>(c + 2) * ld], yq[c + 2], s2);
-          s3 = fma(row[static_cast<i64>(c + 3) * ld], yq[c + 3], s3);
-        }
+#pragma unroll
+      for (int c = 0; c < 32; c += 4) {
+        s0 = fma(a[c], yq[c], s0);
+        s1 = fma(a[c + 1], yq[c + 1], s1);
+        s2 = fma(a[c + 2], yq[c + 2], s2);
+        s3 = fma(a[c + 3], yq[c + 3], s3);
+      }
+      // the second half's loads are issued here — not hoisted above, and the first half's products are done (the sums
+      // are operands of the statement): 128 VGPRs per lane
+      asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3) : : "memory");
+#pragma unroll
+      for (int c = 0; c < 32; ++c) a[c] = si_ld(row, (32 + c) * l32 + ro);
+      si_tile_load(t0, X0, SI_H, tid);
+#pragma unroll
+      for (int c = 0; c < 32; c += 4) {
+        s0 = fma(a[c], yq[32 + c], s0);
+        s1 = fma(a[c + 1], yq[32 + c + 1], s1);
+        s2 = fma(a[c + 2], yq[32 + c + 2], s2);
+        s3 = fma(a[c + 3], yq[32 + c + 3], s3);
+      }
+      asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3) : : "memory");
+      if (jbn > SI_H) {
+        si_tile_load(tc, A + (j1 + SI_H) + static_cast<i64>(j1) * ld, ld, tid);   // (rows past n: inside the padded allocation, unused)
+        si_tile_load(t1, X0 + SI_H * SI_H, SI_H, tid);
       }
       part[q * SI_B + r] = (s0 + s1) + (s2 + s3);
       __syncthreads();
       if (tid < SI_B)
         bn[tid] = (tid < jbn) ? b[j1 + tid] - ((part[tid] + part[SI_B + tid]) + (part[2 * SI_B + tid] + part[3 * SI_B + tid])) : 0.0;
-    } else if (tid < SI_B) {
-      bn[tid] = (tid < jbn) ? b[j1 + tid] : 0.0;
+    } else {
+      si_tile_load(t0, X0, SI_H, tid);
+      if (jbn > SI_H) {
+        si_tile_load(tc, A + (j1 + SI_H) + static_cast<i64>(j1) * ld, ld, tid);
+        si_tile_load(t1, X0 + SI_H * SI_H, SI_H, tid);
+      }
+      if (tid < SI_B) bn[tid] = (tid < jbn) ? b[j1 + tid] : 0.0;
     }
     __syncthreads();
-    const double* X0 = inv + static_cast<i64>(j1 / SI_H) * (SI_H * SI_H);
-    si_mat128_vec(X0, SI_H, bn, part, tid);
+    si_tile_vec(t0, bn, part, tid);
     if (tid < SI_H) {
       const double v = si_part_sum(part, tid);
       bn[tid] = v;
@@ -1005,24 +1049,28 @@ __global__ void __launch_bounds__(SI_T) ldlt_fwd_step_kernel(const double* __res
     }
     __syncthreads();
     if (jbn > SI_H) {
-      si_mat128_vec(A + (j1 + SI_H) + static_cast<i64>(j1) * ld, ld, bn, part, tid);      // rows past n: read inside the padded allocation, unused
+      si_tile_vec(tc, bn, part, tid);
       if (tid < SI_H) bn[SI_H + tid] -= (SI_H + tid < jbn) ? si_part_sum(part, tid) : 0.0;
       __syncthreads();
-      si_mat128_vec(X0 + SI_H * SI_H, SI_H, bn + SI_H, part, tid);
+      si_tile_vec(t1, bn + SI_H, part, tid);
       if (tid < SI_H && SI_H + tid < jbn) b[j1 + SI_H + tid] = si_part_sum(part, tid);
     }
   } else {
-    const int lane = tid & 63, w = tid >> 6;           // sixteen column chunks of 16
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);           // sixteen column chunks of 16
     const i64 r = static_cast<i64>(j1) + SI_B + 64 * static_cast<i64>(blockIdx.x - 1) + lane;
-    double s0 = 0.0, s1 = 0.0;
-    if (r < n) {
-      const double* row = A + r + static_cast<i64>(j0 + 16 * w) * ld;
-      const double* yw = y + 16 * w;
+    double a[16];
+    const double* row = A + static_cast<i64>(j0 + 16 * w) * ld;
+    const unsigned ro = static_cast<unsigned>(r < n ? r : static_cast<i64>(n) - 1), l32 = static_cast<unsigned>(ld);
 #pragma unroll
-      for (int c = 0; c < 16; c += 2) {
-        s0 = fma(row[static_cast<i64>(c) * ld], yw[c], s0);
-        s1 = fma(row[static_cast<i64>(c + 1) * ld], yw[c + 1], s1);
-      }
+    for (int c = 0; c < 16; ++c) a[c] = si_ld(row, c * l32 + ro);
+    if (tid < SI_B) y[tid] = b[j0 + tid];
+    __syncthreads();
+    const double* yw = y + 16 * w;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+      s0 = fma(a[c], yw[c], s0);
+      s1 = fma(a[c + 1], yw[c + 1], s1);
     }
     part[w * 64 + lane] = s0 + s1;
     __syncthreads();
@@ -1038,88 +1086,95 @@ __global__ void __launch_bounds__(SI_T) ldlt_fwd_step_kernel(const double* __res
 // One step of L^T x = b, blocks from the last to the first.  j0 = block whose x is final (j0 >= n: prologue, only the
 // last block is solved).  Workgroup 0: columns of the previous block jp = j0 - 256: bp -= L[j0.., jp..)^T x, then
 // xp = Lpp^-T bp through the two transposed inverses.  Workgroups g >= 1: 64 columns from 64 (g - 1) below jp.
+// Transposed products keep the lanes on the rows (the contiguous direction): a wavefront takes a few columns, four
+// 512-byte loads per column, and sums across its lanes (DPP) — a lane per column reads a cache line per lane and
+// instruction, sixteen times the transactions (53 us per step measured that way, 22 for the forward step).
 __global__ void __launch_bounds__(SI_T) ldlt_bwd_step_kernel(const double* __restrict__ A, i64 ld, int n, int j0,
                                                              double* __restrict__ b, const double* __restrict__ invT) {
-  __shared__ double x[SI_B];
   __shared__ double part[SI_T];
   __shared__ double bn[SI_B];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool prologue = j0 >= n;
   const int jb = prologue ? 0 : ((n - j0 < SI_B) ? n - j0 : SI_B);
-  if (!prologue) {
-    if (tid < SI_B) x[tid] = (tid < jb) ? b[j0 + tid] : 0.0;
-    __syncthreads();
-  }
   if (blockIdx.x == 0) {
     const int jp = prologue ? ((n - 1) / SI_B) * SI_B : j0 - SI_B;
     const int jbp = (n - jp < SI_B) ? n - jp : SI_B;
-    if (!prologue) {
-      // lane = column of the previous block, four row quarters of 64 contiguous entries each
-      const int c = tid & (SI_B - 1), q = tid >> 8;
-      const double* col = A + (j0 + 64 * q) + static_cast<i64>(jp + c) * ld;
-      const double* xq = x + 64 * q;
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      const int rmax = jb - 64 * q;                   // rows of this quarter that exist
-#pragma unroll 4
-      for (int r = 0; r < 64; r += 4) {
-        s0 = fma((r < rmax) ? col[r] : 0.0, xq[r], s0);
-        s1 = fma((r + 1 < rmax) ? col[r + 1] : 0.0, xq[r + 1], s1);
-        s2 = fma((r + 2 < rmax) ? col[r + 2] : 0.0, xq[r + 2], s2);
-        s3 = fma((r + 3 < rmax) ? col[r + 3] : 0.0, xq[r + 3], s3);
+    const double* XT0 = invT + static_cast<i64>(jp / SI_H) * (SI_H * SI_H);
+    SiTile t0, t1;
+    double cpl[16];                                   // coupling block L[jp + 128 .., jp ..): columns 8 w .. 8 w + 8, rows lane, lane + 64
+    if (jbp > SI_H) {
+      si_tile_load(t1, XT0 + SI_H * SI_H, SI_H, tid);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const double* col = A + (jp + SI_H) + static_cast<i64>(jp + 8 * w + k) * ld;
+        cpl[2 * k] = (SI_H + lane < jbp) ? col[lane] : 0.0;
+        cpl[2 * k + 1] = (SI_H + 64 + lane < jbp) ? col[64 + lane] : 0.0;
       }
-      part[q * SI_B + c] = (s0 + s1) + (s2 + s3);
+    }
+    if (!prologue) {
+      // wavefront w: columns 16 w .. 16 w + 16 of the previous block in four groups of four, rows lane + 64 q of block j0
+      double xr[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xr[q] = (64 * q + lane < jb) ? b[j0 + 64 * q + lane] : 0.0;
+#pragma unroll 1
+      for (int g = 0; g < 4; ++g) {
+        double a[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double* col = A + j0 + static_cast<i64>(jp + 16 * w + 4 * g + k) * ld;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a[4 * k + q] = (64 * q + lane < jb) ? col[64 * q + lane] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double sacc = wave_sum(fma(a[4 * k], xr[0], a[4 * k + 1] * xr[1]) + fma(a[4 * k + 2], xr[2], a[4 * k + 3] * xr[3]));
+          if (lane == 0) part[16 * w + 4 * g + k] = sacc;
+        }
+      }
+      si_tile_load(t0, XT0, SI_H, tid);
       __syncthreads();
-      if (tid < SI_B)
-        bn[tid] = b[jp + tid] - ((part[tid] + part[SI_B + tid]) + (part[2 * SI_B + tid] + part[3 * SI_B + tid]));
-    } else if (tid < SI_B) {
-      bn[tid] = (tid < jbp) ? b[jp + tid] : 0.0;
+      if (tid < SI_B) bn[tid] = b[jp + tid] - part[tid];
+    } else {
+      si_tile_load(t0, XT0, SI_H, tid);
+      if (tid < SI_B) bn[tid] = (tid < jbp) ? b[jp + tid] : 0.0;
     }
     __syncthreads();
-    const double* XT0 = invT + static_cast<i64>(jp / SI_H) * (SI_H * SI_H);
     if (jbp > SI_H) {
-      si_mat128_vec(XT0 + SI_H * SI_H, SI_H, bn + SI_H, part, tid);
+      si_tile_vec(t1, bn + SI_H, part, tid);
       if (tid < SI_H) {
         const double v = si_part_sum(part, tid);
         bn[SI_H + tid] = (SI_H + tid < jbp) ? v : 0.0;
         if (SI_H + tid < jbp) b[jp + SI_H + tid] = v;
       }
       __syncthreads();
-      // bn[0 .. 128) -= L[jp + 128 .., jp ..)^T x_hi: lane = column, eight row chunks of 16 contiguous entries
-      const int c = tid & (SI_H - 1), ch = tid >> 7;
-      const double* col = A + (jp + SI_H + 16 * ch) + static_cast<i64>(jp + c) * ld;
-      const int rmax = jbp - SI_H - 16 * ch;
-      double s0 = 0.0, s1 = 0.0;
+      const double x0 = bn[SI_H + lane], x1 = bn[SI_H + 64 + lane];
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        s0 = fma((r < rmax) ? col[r] : 0.0, bn[SI_H + 16 * ch + r], s0);
-        s1 = fma((r + 1 < rmax) ? col[r + 1] : 0.0, bn[SI_H + 16 * ch + r + 1], s1);
+      for (int k = 0; k < 8; ++k) {
+        const double sacc = wave_sum(fma(cpl[2 * k], x0, cpl[2 * k + 1] * x1));
+        if (lane == 0) part[8 * w + k] = sacc;
       }
-      part[ch * SI_H + c] = s0 + s1;
       __syncthreads();
-      if (tid < SI_H) bn[tid] -= si_part_sum(part, tid);
+      if (tid < SI_H) bn[tid] -= part[tid];
       __syncthreads();
     }
-    si_mat128_vec(XT0, SI_H, bn, part, tid);
+    si_tile_vec(t0, bn, part, tid);
     if (tid < SI_H && tid < jbp) b[jp + tid] = si_part_sum(part, tid);
   } else {
-    const int lane = tid & 63, w = tid >> 6;           // sixteen row chunks of 16
-    const int c = 64 * (blockIdx.x - 1) + lane;        // < j0 - 256 by the launch geometry
-    const double* col = A + (j0 + 16 * w) + static_cast<i64>(c) * ld;
-    const double* xw = x + 16 * w;
-    const int rmax = jb - 16 * w;
-    double s0 = 0.0, s1 = 0.0;
+    // wavefront w: columns 4 w .. 4 w + 4 of this workgroup's 64
+    const int c0 = 64 * (blockIdx.x - 1) + 4 * w;      // < j0 - 256 by the launch geometry
+    double a[16], xr[4];
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      s0 = fma((r < rmax) ? col[r] : 0.0, xw[r], s0);
-      s1 = fma((r + 1 < rmax) ? col[r + 1] : 0.0, xw[r + 1], s1);
+    for (int k = 0; k < 4; ++k) {
+      const double* col = A + j0 + static_cast<i64>(c0 + k) * ld;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[4 * k + q] = (64 * q + lane < jb) ? col[64 * q + lane] : 0.0;
     }
-    part[w * 64 + lane] = s0 + s1;
-    __syncthreads();
-    if (w == 0) {
-      double s = 0.0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) s += part[k * 64 + lane];
-      b[c] -= s;
+    for (int q = 0; q < 4; ++q) xr[q] = (64 * q + lane < jb) ? b[j0 + 64 * q + lane] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double sacc = wave_sum(fma(a[4 * k], xr[0], a[4 * k + 1] * xr[1]) + fma(a[4 * k + 2], xr[2], a[4 * k + 3] * xr[3]));
+      if (lane == 0) b[c0 + k] -= sacc;
     }
   }
 }
@@ -1401,7 +1456,7 @@ struct BlockedLdlt {
   }
 
   void solve(const double* A, double* b) {
-    if (solve_inv && padded) { solve_on_inverses(A, b); return; }
+    if (solve_inv && padded && ld < (static_cast<i64>(1) << 21)) { solve_on_inverses(A, b); return; }
     const int ni = static_cast<int>(n);
     for (int j0 = 0; j0 < ni; j0 += SV_B) {
       const int jb = std::min(SV_B, ni - j0);

@@ -144,7 +144,7 @@ def test_pivoted_ldlt_indefinite(n, gpu_required):
     assert np.linalg.norm(A @ sol - b) <= 1e-9 * np.linalg.norm(A, 2) * max(np.linalg.norm(sol), 1.0)
 
 
-@pytest.mark.parametrize("n", [33, 300, 777, 1500])
+@pytest.mark.parametrize("n", [33, 128, 129, 255, 256, 257, 300, 384, 511, 512, 513, 777, 1500, 2600])
 def test_blocked_mfma_ldlt_quasidefinite(n, gpu_required):
     """Blocked unpivoted LDL^T (FP64-MFMA trailing update) on quasi-definite KKT matrices:
     inertia (n1, n2, 0) and solve residual vs numpy; sizes straddle the 128 / 256 tiles."""
