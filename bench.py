@@ -76,29 +76,36 @@ CPU_SWEEP = ((1000, 3), (2000, 3), (4000, 2), (10000, 1))   # (order n, timed it
 
 def cpu_baseline(seed, device, sweep=CPU_SWEEP):
     """IPOPT-class CPU baseline on the box's host cores, same run: the host build of the same
-    interior-point algorithm (oracle/, test infrastructure) with its dense KKT factorisation routed
-    through LAPACK DSYTRF / DSYTRS (blocked Bunch-Kaufman of the OpenBLAS inside the image's scipy
-    wheel — the dense counterpart of the MA27 / MUMPS factorisation IPOPT calls), on the same
-    generator and front-end at the orders of BASELINE.md §3.  n = 1e5 itself is out of reach of any
-    host factorisation in bench time (n^3/3 = 3.3e14 flop per attempt), so the sweep and its fitted
-    scaling law are reported, never an extrapolated figure as if measured."""
+    interior-point algorithm (oracle/, test infrastructure) on the same generator and front-end at the
+    orders of BASELINE.md §3, with its dense KKT factorisation done two ways:
+      * `dsytrf`:  LAPACK DSYTRF / DSYTRS (blocked Bunch-Kaufman of the OpenBLAS inside the image's scipy wheel —
+        the dense counterpart of the MA27 / MUMPS factorisation IPOPT calls) at its fastest thread count;
+      * `blocked`: the device's algorithm on the host's BLAS — unpivoted right-looking blocked LDL^T whose trailing
+        update is DGEMM on ALL cores (DTRSM for the panel rows), with the DGEMM rate of the box beside it.
+    `value` is the better of the two at the largest order.  n = 1e5 itself is out of reach of any host
+    factorisation in bench time (n^3/3 = 3.3e14 flop per attempt), so the sweep and its fitted scaling law are
+    reported, never an extrapolated figure as if measured."""
     import ctypes.util
     threads = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(min(threads, 32)))
     from dnlp_amd.tape import serialize
-    from oracle.oracle_capi import OracleProblem, use_lapack
+    from oracle.oracle_capi import (OracleProblem, dgemm_gflops, lapack_best_threads, set_blas_threads,
+                                    use_blocked_ldlt, use_lapack)
     import dnlp_amd as cp
     from dnlp_amd.device import symmetric_test_matrix
     from dnlp_amd.dnlp2smooth import Dnlp2Smooth
     from dnlp_amd.nlp_solver import HIPNLP, build_nlp_data
     blas_threads = use_lapack(0)
-    probe = None
+    probe, gemm_rate, gemm_threads = None, None, None
     if blas_threads:
         # OpenBLAS's DSYTRF does not scale to every core of a large host (64 threads measured 3x slower
         # than 16 on the GPU box): take the fastest of a few thread counts, and say which
-        from oracle.oracle_capi import lapack_best_threads
         cand = sorted({t for t in (4, 8, 16, 32, threads) if t <= threads})
         blas_threads, probe = lapack_best_threads(cand)
+        # DGEMM does scale: the blocked factorisation runs on every core (or on the count where DGEMM peaks)
+        rates = {t: dgemm_gflops(3000, t) for t in sorted({min(64, threads), min(128, threads), threads})}
+        gemm_threads = max(rates, key=rates.get)
+        gemm_rate = {"gflops_by_threads": rates, "n": 3000}
+    have_blocked = bool(blas_threads) and use_blocked_ldlt(True)
     kind = "LAPACK dsytrf/dsytrs (scipy OpenBLAS, %d threads)" % blas_threads if blas_threads else \
         "restated DSYTF2 (no LAPACK found)"
     table = []
@@ -108,39 +115,54 @@ def cpu_baseline(seed, device, sweep=CPU_SWEEP):
         A.free()
         x = cp.Variable(n_cpu)
         rng = np.random.default_rng(seed)
-        x.value = np.ones(n_cpu) / np.sqrt(n_cpu) + 0.1 * rng.standard_normal(n_cpu) / np.sqrt(n_cpu)
+        x0 = np.ones(n_cpu) / np.sqrt(n_cpu) + 0.1 * rng.standard_normal(n_cpu) / np.sqrt(n_cpu)
+        x.value = x0
         prob = cp.Problem(cp.Minimize(-cp.quad_form(x, Ah)), [cp.sum_squares(x) == 1])
         smooth, _ = Dnlp2Smooth().apply(prob)
         data, _ = build_nlp_data(smooth)
-        orc = OracleProblem(serialize(data["tape_arrays"]))
-        for k, v in HIPNLP.DEFAULT_OPTIONS.items():
-            orc.set_option(k, v)
-        orc.set_option("kkt_pivot_max_n", 10 ** 9)      # pivoted (Bunch-Kaufman) at every order, as IPOPT's solvers are
-        orc.ipm_begin(data["x0"])
-        t0 = time.time()
-        rc, k = orc.ipm_step(steps)
-        dt = time.time() - t0
-        st = orc.stats()
-        nf = max(int(st[1]), 1)
-        table.append({"n": n_cpu, "iterations": k, "factorizations": int(st[1]), "seconds": dt,
-                      "iters_per_s": k / dt if dt > 0 else None,
-                      "s_per_factorization": float(st[4]) / nf,
-                      "factorization_gflops": (n_cpu + 1) ** 3 / 3.0 / (float(st[4]) / nf) / 1e9 if st[4] > 0 else None})
-        orc.close()
-        del Ah, data, smooth, prob
+        blob = serialize(data["tape_arrays"])
+        row = {"n": n_cpu}
+        for column in (("dsytrf", "blocked") if have_blocked else ("dsytrf",)):
+            orc = OracleProblem(blob)
+            for k, v in HIPNLP.DEFAULT_OPTIONS.items():
+                orc.set_option(k, v)
+            if column == "dsytrf":
+                if blas_threads:
+                    set_blas_threads(blas_threads)
+                orc.set_option("kkt_pivot_max_n", 10 ** 9)     # pivoted (Bunch-Kaufman) at every order, as IPOPT's solvers are
+            else:
+                set_blas_threads(gemm_threads)
+                orc.set_option("kkt_pivot_max_n", 0)           # unpivoted blocked LDL^T at every order, as on the device
+            orc.ipm_begin(data["x0"])
+            t0 = time.time()
+            rc, k = orc.ipm_step(steps)
+            dt = time.time() - t0
+            st = orc.stats()
+            nf = max(int(st[1]), 1)
+            row[column] = {"iterations": k, "factorizations": int(st[1]), "seconds": dt,
+                           "iters_per_s": k / dt if dt > 0 else None, "s_per_factorization": float(st[4]) / nf,
+                           "factorization_gflops": (n_cpu + 1) ** 3 / 3.0 / (float(st[4]) / nf) / 1e9 if st[4] > 0 else None}
+            orc.close()
+        table.append(row)
+        del Ah, data, smooth, prob, blob
+    best_col = "dsytrf"
+    if have_blocked and (table[-1]["blocked"]["iters_per_s"] or 0) > (table[-1]["dsytrf"]["iters_per_s"] or 0):
+        best_col = "blocked"
     ln = np.log([r["n"] for r in table])
-    lt = np.log([max(r["s_per_factorization"], 1e-12) for r in table])
+    lt = np.log([max(r[best_col]["s_per_factorization"], 1e-12) for r in table])
     expo = float(np.polyfit(ln, lt, 1)[0]) if len(table) >= 2 else None
     last = table[-1]
-    return {"value": last["iters_per_s"], "unit": "iters/s", "cores": blas_threads or threads, "kind": "port",
-            "n": last["n"], "sweep": table, "factorization_time_exponent": expo, "host_cores": threads,
-            "dsytrf_n3000_seconds_by_threads": probe,
-            "sample": "host build of the same interior-point algorithm, dense KKT through %s, same generator / "
-                      "front-end at n in %s with %s timed iterations; value = iters/s at n=%d; seconds per "
-                      "factorisation scale as n^%.2f over the sweep (n^3 asymptotically: n=1e5 is %.3g x the "
-                      "n=%d flops per factorisation); libipopt on this box: %s"
-                      % (kind, [r["n"] for r in table], [r["iterations"] for r in table], last["n"],
-                         expo if expo is not None else float("nan"), (1e5 / last["n"]) ** 3, last["n"],
+    cores = (gemm_threads if best_col == "blocked" else blas_threads) or threads
+    return {"value": last[best_col]["iters_per_s"], "unit": "iters/s", "cores": cores, "kind": "port",
+            "n": last["n"], "factorization": best_col, "sweep": table, "factorization_time_exponent": expo,
+            "host_cores": threads, "dsytrf_n3000_seconds_by_threads": probe, "dgemm": gemm_rate,
+            "sample": "host build of the same interior-point algorithm on the same generator / front-end at n in %s with %s "
+                      "timed iterations, dense KKT two ways: %s; and the unpivoted blocked LDL^T with its trailing update "
+                      "through DGEMM on %s threads (the device's algorithm on the host's BLAS).  value = iters/s of the "
+                      "faster one (%s) at n=%d; its seconds per factorisation scale as n^%.2f over the sweep (n^3 "
+                      "asymptotically: n=1e5 is %.3g x the n=%d flops per factorisation); libipopt on this box: %s"
+                      % ([r["n"] for r in table], [r["dsytrf"]["iterations"] for r in table], kind, gemm_threads, best_col,
+                         last["n"], expo if expo is not None else float("nan"), (1e5 / last["n"]) ** 3, last["n"],
                          ctypes.util.find_library("ipopt") or "not found")}
 
 

@@ -34,8 +34,16 @@ struct HostLapack {
   using sytrf_t = void (*)(const char*, const int*, double*, const int*, int*, double*, const int*, int*);
   using sytrs_t = void (*)(const char*, const int*, const int*, const double*, const int*, const int*, double*,
                            const int*, int*);
+  using gemm_t = void (*)(const char*, const char*, const int*, const int*, const int*, const double*, const double*,
+                          const int*, const double*, const int*, const double*, double*, const int*);
+  using trsm_t = void (*)(const char*, const char*, const char*, const char*, const int*, const int*, const double*,
+                          const double*, const int*, double*, const int*);
   sytrf_t sytrf = nullptr;
   sytrs_t sytrs = nullptr;
+  gemm_t gemm = nullptr;                 // DGEMM / DTRSM of the same library: the blocked unpivoted LDL^T below
+  trsm_t trsm = nullptr;
+  bool blocked_unpivoted = false;        // orc_use_blocked_ldlt: unpivoted factorisations of order >= 512 go through them
+  std::vector<double> wpanel;
   int (*get_threads)() = nullptr;
   void (*set_threads)(int) = nullptr;
   std::vector<double> work;
@@ -49,6 +57,8 @@ struct HostLapack {
       sytrf = reinterpret_cast<sytrf_t>(dlsym(h, a.c_str()));
       sytrs = reinterpret_cast<sytrs_t>(dlsym(h, b.c_str()));
       if (sytrf && sytrs) {
+        gemm = reinterpret_cast<gemm_t>(dlsym(h, (std::string(pre) + "dgemm_").c_str()));
+        trsm = reinterpret_cast<trsm_t>(dlsym(h, (std::string(pre) + "dtrsm_").c_str()));
         get_threads = reinterpret_cast<int (*)()>(dlsym(h, (std::string(pre) + "openblas_get_num_threads").c_str()));
         set_threads = reinterpret_cast<void (*)(int)>(dlsym(h, (std::string(pre) + "openblas_set_num_threads").c_str()));
         return true;
@@ -237,6 +247,49 @@ struct HostExec : HostControlled {
     double amax = 0.0;
     for (i64 j = 0; j < n; ++j) amax = std::fmax(amax, std::fabs(a(j, j)));
     const double tiny = 1e-14 * std::fmax(amax, 1e-300) * 0 + 1e-300;
+    if (!pivoted && LP.blocked_unpivoted && LP.gemm && LP.trsm && n >= 512) {
+      // CPU baseline (bench.py): the device's algorithm on the host's BLAS — right-looking blocked LDL^T, the panel's
+      // diagonal block unblocked, the rows below by DTRSM (A21 L11^-T = L21 D = W), the trailing matrix
+      // C -= W L21^T by one DGEMM per block column of the lower triangle, all cores.
+      const i64 NB = 256;
+      const double one = 1.0, mone = -1.0;
+      for (i64 K0 = 0; K0 < n; K0 += NB) {
+        const i64 KB = std::min<i64>(NB, n - K0);
+        for (i64 k = K0; k < K0 + KB; ++k) {
+          double d = a(k, k);
+          if (!(d == d)) return false;
+          if (std::fabs(d) <= tiny) { (*nzero)++; d = (d < 0 ? -1.0 : 1.0) * 1e-20; a(k, k) = d; }
+          if (d < 0) (*nneg)++;
+          ipiv[k] = static_cast<i32>(k + 1);
+          const double inv = 1.0 / d;
+          for (i64 j = k + 1; j < K0 + KB; ++j) {
+            const double lj = A[j + k * ld] * inv;
+            if (lj == 0.0) continue;
+            for (i64 i = j; i < K0 + KB; ++i) A[i + j * ld] -= A[i + k * ld] * lj;
+          }
+          for (i64 i = k + 1; i < K0 + KB; ++i) a(i, k) *= inv;
+        }
+        const i64 r1 = K0 + KB, rows = n - r1;
+        if (rows <= 0) break;
+        const int mi = static_cast<int>(rows), ki = static_cast<int>(KB), ldi = static_cast<int>(ld);
+        LP.trsm("R", "L", "T", "U", &mi, &ki, &one, A + K0 + K0 * ld, &ldi, A + r1 + K0 * ld, &ldi);   // A21 <- W = L21 D
+        if (LP.wpanel.size() < static_cast<size_t>(rows * KB)) LP.wpanel.resize(static_cast<size_t>(rows * KB));
+        double* W = LP.wpanel.data();
+#pragma omp parallel for schedule(static)
+        for (i64 c = 0; c < KB; ++c) {
+          const double inv = 1.0 / A[(K0 + c) + (K0 + c) * ld];
+          double* col = A + r1 + (K0 + c) * ld;
+          double* wc = W + c * rows;
+          for (i64 i = 0; i < rows; ++i) { wc[i] = col[i]; col[i] *= inv; }
+        }
+        for (i64 J = 0; J < rows; J += NB) {
+          const int jb = static_cast<int>(std::min<i64>(NB, rows - J)), mr = static_cast<int>(rows - J);
+          LP.gemm("N", "T", &mr, &jb, &ki, &mone, W + J, &mi, A + (r1 + J) + K0 * ld, &ldi, &one,
+                  A + (r1 + J) + (r1 + J) * ld, &ldi);
+        }
+      }
+      return true;
+    }
     if (!pivoted) {
       for (i64 k = 0; k < n; ++k) {
         double d = a(k, k);

@@ -72,3 +72,30 @@ def no_lapack():
     lib.orc_use_lapack.restype = ctypes.c_int
     lib.orc_use_lapack.argtypes = [ctypes.c_char_p, ctypes.c_int]
     lib.orc_use_lapack(None, 0)
+
+
+def use_blocked_ldlt(on: bool = True) -> bool:
+    """CPU baseline only: unpivoted dense factorisations of the host build go through the blocked LDL^T whose
+    trailing update is DGEMM of the library loaded by use_lapack (all its threads)."""
+    import ctypes
+    lib = api().lib
+    lib.orc_use_blocked_ldlt.restype = ctypes.c_int
+    lib.orc_use_blocked_ldlt.argtypes = [ctypes.c_int]
+    return bool(lib.orc_use_blocked_ldlt(1 if on else 0))
+
+
+def set_blas_threads(threads: int) -> int:
+    import ctypes
+    lib = api().lib
+    lib.orc_lapack_probe.restype = ctypes.c_double
+    lib.orc_lapack_probe.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.orc_lapack_probe(8, int(threads))
+    return int(threads)
+
+
+def dgemm_gflops(n: int, threads: int) -> float:
+    import ctypes
+    lib = api().lib
+    lib.orc_dgemm_probe.restype = ctypes.c_double
+    lib.orc_dgemm_probe.argtypes = [ctypes.c_int, ctypes.c_int]
+    return float(lib.orc_dgemm_probe(int(n), int(threads)))

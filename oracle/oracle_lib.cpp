@@ -41,3 +41,24 @@ extern "C" double orc_lapack_probe(int n, int threads) {
   L.sytrf("L", &n, A.data(), &n, ipiv.data(), work.data(), &lwork, &info);
   return dnlp::now_sec() - t0;
 }
+
+// CPU-baseline switch: unpivoted dense factorisations of order >= 512 take the blocked LDL^T whose trailing update is
+// DGEMM (the device's algorithm on the host's BLAS); needs orc_use_lapack first.  Returns 1 when the BLAS has DGEMM / DTRSM.
+extern "C" int orc_use_blocked_ldlt(int on) {
+  dnlp::HostLapack& L = dnlp::HostLapack::get();
+  L.blocked_unpivoted = on != 0 && L.gemm && L.trsm;
+  return L.blocked_unpivoted ? 1 : 0;
+}
+
+// GFLOP/s of one square DGEMM of order n with `threads` BLAS threads: the rate the blocked factorisation can approach.
+extern "C" double orc_dgemm_probe(int n, int threads) {
+  dnlp::HostLapack& L = dnlp::HostLapack::get();
+  if (!L.gemm) return -1.0;
+  if (threads > 0 && L.set_threads) L.set_threads(threads);
+  std::vector<double> A(static_cast<size_t>(n) * n, 0.5), B(static_cast<size_t>(n) * n, 0.25), C(static_cast<size_t>(n) * n, 0.0);
+  const double one = 1.0, zero = 0.0;
+  L.gemm("N", "T", &n, &n, &n, &one, A.data(), &n, B.data(), &n, &zero, C.data(), &n);      // warm the threads
+  const double t0 = dnlp::now_sec();
+  L.gemm("N", "T", &n, &n, &n, &one, A.data(), &n, B.data(), &n, &zero, C.data(), &n);
+  return 2.0 * n * n * n / (dnlp::now_sec() - t0) / 1e9;
+}
