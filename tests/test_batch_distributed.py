@@ -122,7 +122,8 @@ def test_bench_gpus_flag_starts_its_own_ranks():
                         "--order", "256", "--no-cpu"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
     assert '"n_gpus"' not in r.stdout
-    assert r.stderr.count("one process per GPU") == 2, r.stderr[-2000:]
+    # (the launcher ends the other rank as soon as the first one fails: at least one of the two has said why)
+    assert r.stderr.count("one process per GPU") >= 1, r.stderr[-2000:]
 
 
 @pytest.mark.gpu
