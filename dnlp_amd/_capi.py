@@ -94,6 +94,72 @@ class CApi:
         return msg.decode() if msg else ""
 
 
+def lower_maps(N, Z, m, G, c, drow, dcol, hrow, hcol, blocks):
+    """C++ construction of the constant maps of a lowered problem (include/dnlp_hip.h: dnlp_lower_maps; the role of
+    cvxcore's build_matrix).  `G`: scipy CSR m x (N + Z).  Returns a dict of numpy arrays / scipy matrices, or None
+    when the library (or the entry point) is not there — the caller then runs its numpy construction."""
+    import scipy.sparse as sp
+    try:
+        lib = load().lib
+        fn = lib.dnlp_lower_maps
+    except (DeviceUnavailableError, OSError, AttributeError):
+        return None
+    i64p, i32p = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+    fn.restype = C.c_void_p
+    fn.argtypes = [C.c_int64] * 5 + [i64p, i32p, _dbl_p, _dbl_p, i64p, i64p, i64p, i64p, C.c_int, i64p, i64p]
+    lib.dnlp_lowered_free.argtypes = [C.c_void_p]
+    lib.dnlp_lowered_sizes.argtypes = [C.c_void_p, i64p]
+    lib.dnlp_lowered_csr.argtypes = [C.c_void_p, C.c_int, i64p, i32p, _dbl_p]
+    lib.dnlp_lowered_pattern.argtypes = [C.c_void_p, C.c_int, i32p, i32p, _dbl_p]
+    lib.dnlp_lowered_block.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), i64p, i64p]
+    c64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)     # noqa: E731
+    Gp, Gi, Gv = c64(G.indptr), np.ascontiguousarray(G.indices, dtype=np.int32), np.ascontiguousarray(G.data, dtype=np.float64)
+    cc = np.ascontiguousarray(c, dtype=np.float64)
+    drow, dcol, hrow, hcol = c64(drow), c64(dcol), c64(hrow), c64(hcol)
+    bx0, bn = c64([b[0] for b in blocks]), c64([b[1] for b in blocks])
+    p64 = lambda a: a.ctypes.data_as(i64p)                      # noqa: E731
+    p32 = lambda a: a.ctypes.data_as(i32p)                      # noqa: E731
+    h = fn(N, Z, m, drow.size, hrow.size, p64(Gp), p32(Gi), _dp(Gv), _dp(cc), p64(drow), p64(dcol), p64(hrow), p64(hcol),
+           len(blocks), p64(bx0), p64(bn))
+    if not h:
+        raise RuntimeError("dnlp_lower_maps failed: %s" % load().error())
+    try:
+        sz = np.zeros(9, np.int64)
+        lib.dnlp_lowered_sizes(h, p64(sz))
+        changed, nG, nMg, nMw, nMJ, nnzJ, nMH, nnzH, jac_is_G = (int(v) for v in sz)
+
+        def csr(which, rows, nnz, shape):
+            ptr, idx, val = np.zeros(rows + 1, np.int64), np.zeros(nnz, np.int32), np.zeros(nnz, np.float64)
+            lib.dnlp_lowered_csr(h, which, p64(ptr), p32(idx), _dp(val))
+            M = sp.csr_matrix((val, idx, ptr), shape=shape)
+            M.has_sorted_indices = True
+            M.has_canonical_format = True
+            return M
+        nd, nh = int(drow.size), int(hrow.size)
+        out = {"G": csr(0, m, nG, (m, N + Z)) if changed else None,
+               "Mg": csr(1, N, nMg, (N, nd)), "Mw": csr(2, Z, nMw, (Z, 1 + m)),
+               "MJ": csr(3, nnzJ, nMJ, (nnzJ, nd)), "MH": csr(4, nnzH, nMH, (nnzH, nh))}
+        if jac_is_G:
+            # affine rows over x only (BASELINE C3: 1e7 entries): pattern and values are G's own arrays
+            jr = np.repeat(np.arange(m, dtype=np.int32), np.diff(Gp))
+            jc, Jc = Gi, Gv
+        else:
+            jr, jc, Jc = np.zeros(nnzJ, np.int32), np.zeros(nnzJ, np.int32), np.zeros(nnzJ, np.float64)
+            lib.dnlp_lowered_pattern(h, 0, p32(jr), p32(jc), _dp(Jc))
+        hr, hc = np.zeros(nnzH, np.int32), np.zeros(nnzH, np.int32)
+        lib.dnlp_lowered_pattern(h, 1, p32(hr), p32(hc), None)
+        out.update({"jac_rows": jr, "jac_cols": jc, "Jc": Jc, "hess_rows": hr, "hess_cols": hc, "blocks": []})
+        for b in range(len(blocks)):
+            mode, cnt = C.c_int(), C.c_int64()
+            lib.dnlp_lowered_block(h, b, C.byref(mode), C.byref(cnt), None)
+            pos = np.zeros(cnt.value, np.int64)
+            lib.dnlp_lowered_block(h, b, C.byref(mode), C.byref(cnt), p64(pos))
+            out["blocks"].append((mode.value, pos))
+        return out
+    finally:
+        lib.dnlp_lowered_free(h)
+
+
 _api = None
 
 

@@ -6,6 +6,7 @@
 #include "ldlt_blocked.h"
 #include "capi_impl.h"
 #include "batch.h"
+#include "lower_maps.h"
 
 // struct dnlp_problem (the opaque handle of the header) IS the problem object over the HIP space
 DNLP_DEFINE_CAPI(dnlp_, dnlp::HipExec, dnlp_problem)
@@ -203,6 +204,63 @@ int dnlp_dev_symv(int device, const double* A, int64_t n, int64_t ld, const doub
     ex.gemv_sym(n, A, ld, dx, dy);
     ex.d2h(y, dy, sizeof(double) * n);
     return 0;)
+}
+
+// ---- host side of the lowering (lower_maps.h): no device is touched ------------------------------------------------
+struct dnlp_lowered { dnlp::LowerMapsOut out; };
+
+dnlp_lowered* dnlp_lower_maps(int64_t N, int64_t Z, int64_t m, int64_t nd, int64_t nh, const int64_t* G_ptr, const int32_t* G_idx,
+                              const double* G_val, const double* c, const int64_t* drow, const int64_t* dcol, const int64_t* hrow,
+                              const int64_t* hcol, int n_blocks, const int64_t* block_x0, const int64_t* block_n) {
+  try {
+    dnlp::LowerMapsIn in;
+    in.N = N; in.Z = Z; in.m = m; in.nd = nd; in.nh = nh;
+    in.Gp = reinterpret_cast<const dnlp::lm_i64*>(G_ptr); in.Gi = G_idx; in.Gv = G_val; in.c = c;
+    in.drow = reinterpret_cast<const dnlp::lm_i64*>(drow); in.dcol = reinterpret_cast<const dnlp::lm_i64*>(dcol);
+    in.hrow = reinterpret_cast<const dnlp::lm_i64*>(hrow); in.hcol = reinterpret_cast<const dnlp::lm_i64*>(hcol);
+    in.nblk = n_blocks;
+    in.blk_x0 = reinterpret_cast<const dnlp::lm_i64*>(block_x0); in.blk_n = reinterpret_cast<const dnlp::lm_i64*>(block_n);
+    auto* h = new dnlp_lowered();
+    dnlp::lower_maps_build(in, h->out);
+    return h;
+  } catch (const std::exception& e) { dnlp::tls_error() = e.what(); return nullptr; }
+}
+void dnlp_lowered_free(dnlp_lowered* h) { delete h; }
+/* sizes[0..8] = G_changed, nnz(G), nnz(Mg), nnz(Mw), nnz(MJ), nnzJ, nnz(MH), nnzH, jac_is_G */
+int dnlp_lowered_sizes(const dnlp_lowered* h, int64_t* sizes) {
+  const dnlp::LowerMapsOut& o = h->out;
+  sizes[8] = o.jac_is_G;
+  sizes[0] = o.G_changed; sizes[1] = static_cast<int64_t>(o.G.idx.size()); sizes[2] = static_cast<int64_t>(o.Mg.idx.size());
+  sizes[3] = static_cast<int64_t>(o.Mw.idx.size()); sizes[4] = static_cast<int64_t>(o.MJ.idx.size());
+  sizes[5] = static_cast<int64_t>(o.MJ.ptr.empty() ? 0 : o.MJ.ptr.size() - 1); sizes[6] = static_cast<int64_t>(o.MH.idx.size()); sizes[7] = static_cast<int64_t>(o.hr.size());
+  return 0;
+}
+/* which: 0 G (only when G_changed), 1 Mg, 2 Mw, 3 MJ, 4 MH; the caller's arrays have the sizes of dnlp_lowered_sizes */
+int dnlp_lowered_csr(const dnlp_lowered* h, int which, int64_t* ptr, int32_t* idx, double* val) {
+  const dnlp::LowerMapsOut& o = h->out;
+  const dnlp::LmCsr* M = which == 0 ? &o.G : which == 1 ? &o.Mg : which == 2 ? &o.Mw : which == 3 ? &o.MJ : which == 4 ? &o.MH : nullptr;
+  if (!M) { dnlp::tls_error() = "dnlp_lowered_csr: no such map"; return -1; }
+  if (!M->ptr.empty()) std::memcpy(ptr, M->ptr.data(), M->ptr.size() * sizeof(int64_t));
+  if (!M->idx.empty()) { std::memcpy(idx, M->idx.data(), M->idx.size() * sizeof(int32_t)); std::memcpy(val, M->val.data(), M->val.size() * sizeof(double)); }
+  return 0;
+}
+/* which: 0 Jacobian (rows, cols, Jc), 1 Hessian (rows, cols; vals ignored) */
+int dnlp_lowered_pattern(const dnlp_lowered* h, int which, int32_t* rows, int32_t* cols, double* vals) {
+  const dnlp::LowerMapsOut& o = h->out;
+  const std::vector<dnlp::lm_i32>& r = which == 0 ? o.jr : o.hr;
+  const std::vector<dnlp::lm_i32>& c = which == 0 ? o.jc : o.hc;
+  if (!r.empty()) { std::memcpy(rows, r.data(), r.size() * sizeof(int32_t)); std::memcpy(cols, c.data(), c.size() * sizeof(int32_t)); }
+  if (which == 0 && vals && !o.Jc.empty()) std::memcpy(vals, o.Jc.data(), o.Jc.size() * sizeof(double));
+  return 0;
+}
+/* dense block b: *mode = 2 (contiguous run: pos[0] is its first position) or 1 (table); *count = entries of pos */
+int dnlp_lowered_block(const dnlp_lowered* h, int b, int* mode, int64_t* count, int64_t* pos) {
+  const dnlp::LowerMapsOut& o = h->out;
+  if (b < 0 || b >= static_cast<int>(o.blk_mode.size())) { dnlp::tls_error() = "dnlp_lowered_block: no such block"; return -1; }
+  *mode = o.blk_mode[static_cast<size_t>(b)];
+  *count = static_cast<int64_t>(o.blk_pos[static_cast<size_t>(b)].size());
+  if (pos) std::memcpy(pos, o.blk_pos[static_cast<size_t>(b)].data(), o.blk_pos[static_cast<size_t>(b)].size() * sizeof(int64_t));
+  return 0;
 }
 
 int dnlp_ldlt_host(int device, double* A, int64_t n, int64_t ld, int32_t* ipiv, int pivoted, int* nneg, int* nzero,

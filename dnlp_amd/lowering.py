@@ -28,6 +28,8 @@ quad_form matrices stay dense (and may live in HBM only, see `DeviceMatrix`).
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -570,7 +572,8 @@ class Lowerer:
 
 def _is_symmetric(P: np.ndarray) -> bool:
     """Exact symmetry test, tile against mirrored tile (cache-sized, no n x n temporary).  (Memory-bound: 0.14 s
-    for BASELINE C3's 1e4 x 1e4 block; a thread pool over the tile rows measured no faster.)"""
+    for BASELINE C3's 1e4 x 1e4 block; a thread pool over the tile rows measured no faster, and neither did a threaded
+    C++ tile loop on the build host: 0.19-0.25 s.)"""
     n, b = P.shape[0], 256
     for i in range(0, n, b):
         for j in range(0, i + 1, b):
@@ -605,49 +608,24 @@ def _coo_unique(keys, return_first=False):
     return uniq, inv.astype(np.int64)
 
 
-def lower_problem(objective_expr: Expression, constraint_exprs: List[Expression],
-                  variables: List[Variable]) -> Tape:
-    """Flatten objective + constraint expressions (already smooth-canonical, constraints
-    already lowered to `expr == 0` / `expr >= 0` residual form) over `variables`."""
-    lw = Lowerer(variables, [objective_expr] + list(constraint_exprs))
-    fobj = lw.lower(objective_expr)
-    forms = [lw.lower(c) for c in constraint_exprs]
-    N, Z = lw.N, lw.Z
-    ncol = N + Z
+def _maps_numpy(N, Z, m, G, c, drow, dcol, hrow, hcol, listed, single_form=None):
+    """The constant maps of a lowered problem in numpy / scipy: what csrc/lower_maps.h computes (same arrays)."""
+    if not G.has_canonical_format:
+        # sum_duplicates / sort_indices rewrite the arrays in place; with a single constraint block and
+        # shared column ranges (head_cols, LinForm.apply) those arrays can still be a constant the user holds
+        if single_form is not None and np.shares_memory(G.data, single_form.data):
+            G = G.copy()
+        G.sum_duplicates()
+        G.sort_indices()
+    nd, nh = drow.size, hrow.size
 
     def head_cols(A, k):
-        """A[:, :k] as CSR; when no entry lies beyond column k the arrays are shared (no 1e7-entry copy)."""
         A = sp.csr_matrix(A)
         if A.shape[1] == k:
             return A
         if A.nnz == 0 or int(A.indices.max()) < k:
             return sp.csr_matrix((A.data, A.indices, A.indptr), shape=(A.shape[0], k))
         return sp.csr_matrix(A[:, :k])
-
-    def trim(A):
-        return head_cols(A, ncol)
-
-    c = np.asarray(trim(fobj.A).todense()).reshape(-1) if fobj.A.nnz else np.zeros(ncol)
-    c0 = float(fobj.b[0])
-    if forms:
-        G = trim(sp.vstack([f.A for f in forms], format="csr") if len(forms) > 1 else forms[0].A)
-        b = np.concatenate([f.b for f in forms])
-    else:
-        G = sp.csr_matrix((0, ncol))
-        b = np.zeros(0)
-    if not G.has_canonical_format:
-        # sum_duplicates / sort_indices rewrite the arrays in place; with a single constraint block and
-        # shared column ranges (head_cols, LinForm.apply) those arrays can still be a constant the user holds
-        if len(forms) == 1 and np.shares_memory(G.data, forms[0].A.data):
-            G = G.copy()
-        G.sum_duplicates()
-        G.sort_indices()
-    m = G.shape[0]
-
-    cat = lambda lst, dt: (np.concatenate(lst).astype(dt) if lst else np.zeros(0, dt))  # noqa
-    drow, dcol = cat(lw._d[0], np.int64), cat(lw._d[1], np.int64)
-    hrow, hcol, hz = cat(lw._h[0], np.int64), cat(lw._h[1], np.int64), cat(lw._h[2], np.int64)
-    nd, nh = drow.size, hrow.size
 
     cz = c[N:]
     if Z:
@@ -693,14 +671,9 @@ def lower_problem(objective_expr: Expression, constraint_exprs: List[Expression]
     # Hessian: lower-oriented positions, row-major sorted unique
     hkeys = hrow * N + hcol
     dense_pos_keys = []
-    hess_coo_complete = True
-    for blk in lw.dense_blocks:
-        nb = blk["n"]
-        if nb <= DENSE_COO_MAX_N:
-            ii, jj = np.tril_indices(nb)
-            dense_pos_keys.append((blk["x0"] + ii).astype(np.int64) * N + (blk["x0"] + jj))
-        else:
-            hess_coo_complete = False
+    for x0, nb in listed:
+        ii, jj = np.tril_indices(nb)
+        dense_pos_keys.append((x0 + ii).astype(np.int64) * N + (x0 + jj))
     allkeys = np.concatenate([hkeys] + dense_pos_keys) if (nh or dense_pos_keys) else \
         np.zeros(0, np.int64)
     huniq, hinv = _coo_unique(allkeys)
@@ -709,21 +682,82 @@ def lower_problem(objective_expr: Expression, constraint_exprs: List[Expression]
     hess_cols = (huniq % N).astype(np.int32) if N else np.zeros(0, np.int32)
     MH = sp.csr_matrix((np.ones(nh), (hinv[:nh], np.arange(nh))), shape=(nnzH, nh))
     off = nh
+    blocks = []
+    for x0, nb in listed:
+        cnt = nb * (nb + 1) // 2
+        pos = hinv[off:off + cnt]                               # tril_indices order
+        if cnt and int(pos[-1]) - int(pos[0]) == cnt - 1 and bool(np.all(pos[1:] > pos[:-1])):
+            # the block's entries are a contiguous run of the sorted pattern (the usual case: the
+            # quad_form block is the only Hessian contribution of its rows): base + q, no table
+            blocks.append((2, np.array([int(pos[0])], dtype=np.int64)))
+        else:
+            blocks.append((1, pos.astype(np.int64)))
+        off += cnt
+    return {"G": G,
+            "Mg": Mg, "Mw": Mw, "MJ": MJ, "MH": MH, "Jc": Jc, "jac_rows": jac_rows, "jac_cols": jac_cols,
+            "hess_rows": hess_rows, "hess_cols": hess_cols, "blocks": blocks}
+
+
+def lower_problem(objective_expr: Expression, constraint_exprs: List[Expression],
+                  variables: List[Variable]) -> Tape:
+    """Flatten objective + constraint expressions (already smooth-canonical, constraints
+    already lowered to `expr == 0` / `expr >= 0` residual form) over `variables`."""
+    lw = Lowerer(variables, [objective_expr] + list(constraint_exprs))
+    fobj = lw.lower(objective_expr)
+    forms = [lw.lower(c) for c in constraint_exprs]
+    N, Z = lw.N, lw.Z
+    ncol = N + Z
+
+    def head_cols(A, k):
+        """A[:, :k] as CSR; when no entry lies beyond column k the arrays are shared (no 1e7-entry copy)."""
+        A = sp.csr_matrix(A)
+        if A.shape[1] == k:
+            return A
+        if A.nnz == 0 or int(A.indices.max()) < k:
+            return sp.csr_matrix((A.data, A.indices, A.indptr), shape=(A.shape[0], k))
+        return sp.csr_matrix(A[:, :k])
+
+    def trim(A):
+        return head_cols(A, ncol)
+
+    c = np.asarray(trim(fobj.A).todense()).reshape(-1) if fobj.A.nnz else np.zeros(ncol)
+    c0 = float(fobj.b[0])
+    if forms:
+        G = trim(sp.vstack([f.A for f in forms], format="csr") if len(forms) > 1 else forms[0].A)
+        b = np.concatenate([f.b for f in forms])
+    else:
+        G = sp.csr_matrix((0, ncol))
+        b = np.zeros(0)
+    m = G.shape[0]
+    cat = lambda lst, dt: (np.concatenate(lst).astype(dt) if lst else np.zeros(0, dt))  # noqa
+    drow, dcol = cat(lw._d[0], np.int64), cat(lw._d[1], np.int64)
+    hrow, hcol, hz = cat(lw._h[0], np.int64), cat(lw._h[1], np.int64), cat(lw._h[2], np.int64)
+    # The constant maps (canonical G, Mg, Mw, MJ / Jc, MH, the two patterns) are built in C++ behind the C ABI
+    # (csrc/lower_maps.h, dnlp_lower_maps: the role of cvxcore's build_matrix); the numpy / scipy construction
+    # below is the same computation, kept as the fallback where the library is not built and as the checker
+    # (tests/test_lower_maps.py compares every array of the two).  DNLP_LOWER_CXX=0 forces it.
+    listed = [(blk["x0"], blk["n"]) for blk in lw.dense_blocks if blk["n"] <= DENSE_COO_MAX_N]
+    maps = None
+    if os.environ.get("DNLP_LOWER_CXX", "1") != "0":
+        from . import _capi
+        maps = _capi.lower_maps(N, Z, m, G, c, drow, dcol, hrow, hcol, listed)
+    if maps is None:
+        maps = _maps_numpy(N, Z, m, G, c, drow, dcol, hrow, hcol, listed, single_form=forms[0].A if len(forms) == 1 else None)
+    if maps["G"] is not None:
+        G = maps["G"]
+    Mg, Mw, MJ, MH, Jc = maps["Mg"], maps["Mw"], maps["MJ"], maps["MH"], maps["Jc"]
+    jac_rows, jac_cols, hess_rows, hess_cols = maps["jac_rows"], maps["jac_cols"], maps["hess_rows"], maps["hess_cols"]
+    hess_coo_complete = True
+    it = iter(maps["blocks"])
     for blk in lw.dense_blocks:
-        nb = blk["n"]
-        if nb <= DENSE_COO_MAX_N:
-            cnt = nb * (nb + 1) // 2
-            pos = hinv[off:off + cnt]                               # tril_indices order
-            if cnt and int(pos[-1]) - int(pos[0]) == cnt - 1 and bool(np.all(pos[1:] > pos[:-1])):
-                # the block's entries are a contiguous run of the sorted pattern (the usual case: the
-                # quad_form block is the only Hessian contribution of its rows): base + q, no table
-                blk["coo_pos"] = np.array([int(pos[0])], dtype=np.int64)
+        if blk["n"] <= DENSE_COO_MAX_N:
+            mode, pos = next(it)
+            blk["coo_pos"] = np.asarray(pos, dtype=np.int64)
+            if mode == 2:
                 blk["coo_pos_identity"] = True
-            else:
-                blk["coo_pos"] = pos.astype(np.int64)
-            off += cnt
         else:
             blk["coo_pos"] = None
+            hess_coo_complete = False
 
     return Tape(N=N, m=m, Z=Z, segments=lw.segments, dense_consts=lw.dense_consts,
                 sparse_consts=lw.sparse_consts, c0=c0, c=c, G=G, b=b, drow=drow, dcol=dcol,

@@ -217,6 +217,30 @@ int dnlp_gen_symmetric(int device, double* device_A, int64_t n, int64_t ld, uint
 int dnlp_dev_symv(int device, const double* device_A, int64_t n, int64_t ld, const double* x,
                   double* y);
 
+/* ---- host side of the lowering ----------------------------------------------------------------
+ * The role of cvxcore's build_matrix (cvxpy/cvxcore/src/cvxcore.cpp:161-215) and of the reference's per-callback
+ * COO bookkeeping (nlp_solvers/nlp_solver.py:246-276, 337-372): from the constraint rows G over [x; z] (CSR, any
+ * order, duplicates allowed), the objective coefficients c and the derivative triplets (drow, dcol: d z / d x;
+ * hrow, hcol: lower oriented second derivatives) that the front-end's DAG walk emits, build the canonical G, the
+ * constant CSR maps Mg, Mw, MJ, MH, the affine Jacobian part Jc and the sorted unique Jacobian / Hessian patterns
+ * (+ the positions of the listed dense quad_form blocks x0, n), in C++ with a few host threads.  No device is
+ * touched.  Fetch with the accessors below (sizes first), then dnlp_lowered_free. */
+typedef struct dnlp_lowered dnlp_lowered;
+dnlp_lowered* dnlp_lower_maps(int64_t N, int64_t Z, int64_t m, int64_t nd, int64_t nh, const int64_t* G_ptr,
+                              const int32_t* G_idx, const double* G_val, const double* c, const int64_t* drow,
+                              const int64_t* dcol, const int64_t* hrow, const int64_t* hcol, int n_blocks,
+                              const int64_t* block_x0, const int64_t* block_n);
+void dnlp_lowered_free(dnlp_lowered* h);
+/* sizes[0..8] = G_changed, nnz(G), nnz(Mg), nnz(Mw), nnz(MJ), nnzJ, nnz(MH), nnzH, jac_is_G (1: every row is affine
+ * in x alone and G was canonical — the Jacobian pattern and Jc ARE the caller's G arrays, nothing is copied) */
+int dnlp_lowered_sizes(const dnlp_lowered* h, int64_t* sizes);
+/* which: 0 G (only when G_changed), 1 Mg, 2 Mw, 3 MJ, 4 MH */
+int dnlp_lowered_csr(const dnlp_lowered* h, int which, int64_t* ptr, int32_t* idx, double* val);
+/* which: 0 Jacobian (rows, cols, Jc), 1 Hessian (rows, cols) */
+int dnlp_lowered_pattern(const dnlp_lowered* h, int which, int32_t* rows, int32_t* cols, double* vals);
+/* dense block b: *mode = 2 (contiguous run, pos[0] = first position) or 1 (table of *count positions) */
+int dnlp_lowered_block(const dnlp_lowered* h, int b, int* mode, int64_t* count, int64_t* pos);
+
 /* ---- factorisation kernels exposed for parity tests and benchmarks ----------------------- */
 /* In-place LDL^T of a host column-major symmetric matrix (lower triangle referenced) through
  * the device path: pivoted (Bunch-Kaufman) or blocked unpivoted with the FP64-MFMA trailing
