@@ -436,6 +436,7 @@ class ProblemHandle:
         return {"status": status, "x": x, "obj_val": obj.value, "iterations": iters.value,
                 "device_loop": bool(ri[0]), "device_loop_seconds": float(ri[1]), "device_loop_slots": int(ri[2]),
                 "fused_objective_used": bool(ri[3]), "library_seconds": float(ri[4]),
+                "device_loop_persistent": bool(ri[5]),
                 "evaluations": evals.value, "grad_inf_norm": gn.value, "solve_time": time.time() - t0,
                 "g": self.eval_g(x) if self.m else np.zeros(0), "mult_g": np.zeros(self.m),
                 "mult_x_L": np.zeros(self.n), "mult_x_U": np.zeros(self.n), "stats": np.zeros(N_STATS)}

@@ -158,7 +158,14 @@ int dnlp_lbfgs_codegen_check(const void* blob, size_t len, int elems_per_lane, c
     if (!fused_parse_programs(tb, progs, nconst, c0, nfree)) { put(log_out, log_cap, "no fused program in this tape"); return -11; }
     const FusedCodegenInfo info = fused_codegen_plan(progs, elems_per_lane > 0 ? elems_per_lane : 4);
     if (!info.ok) { put(log_out, log_cap, info.why); return 1; }
-    const std::string src = lbfgs_codegen_source(progs, info, 10);
+    // with the persistent single-launch kernel when a slice per compute unit (256 of them) fits its LDS, as the
+    // execution space decides (exec_hip.h: lbfgs_generated_solve)
+    long long per = 0;
+    if (nfree >= 1024 && info.hi - info.lo >= 1) {
+      per = ((nfree + 255) / 256 + info.E - 1) / info.E * info.E;
+      if ((2 * 10 + 5) * (per + 64) * 8 + 12 * 1024 > 150 * 1024) per = 0;
+    }
+    const std::string src = lbfgs_codegen_source(progs, info, 10, per);
     put(src_out, src_cap, src);
     std::string log;
     const std::vector<char> code = rtc_compile(src, log, false);

@@ -380,7 +380,7 @@ struct ProblemT {
     double v[6] = {0, 0, 0, 0, 0, 0};                                                                \
     if (p->lbfgs) { v[0] = p->lbfgs->device_loop_used ? 1.0 : 0.0; v[1] = p->lbfgs->device_seconds;  \
                     v[2] = p->lbfgs->device_slots; v[3] = p->lbfgs->fused_used ? 1.0 : 0.0;          \
-                    v[4] = p->lbfgs->wall; }                                                         \
+                    v[4] = p->lbfgs->wall; v[5] = p->lbfgs->device_persistent ? 1.0 : 0.0; }                \
     for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];                                              \
     return 0;                                                                                        \
   }                                                                                                  \

@@ -1352,7 +1352,10 @@ struct HipExec : HostControlled {
     for (const LevelGraph& g : level_graphs_) hipGraphExecDestroy(g.exec);
     for (void* p : owned_) hipFree(p);
     // device-resident L-BFGS workspace (lbfgs_generated_solve): (2M + 3) nfree doubles per handle
+    lb_graph_reset();
     if (lb_state) hipFree(lb_state);
+    if (lb_ctl) hipFree(lb_ctl);
+    if (lb_halo) hipFree(lb_halo);
     if (lb_host) hipHostFree(lb_host);
     if (lb_fpart) hipFree(lb_fpart);
     if (lb_upart) hipFree(lb_upart);
@@ -1701,11 +1704,20 @@ struct HipExec : HostControlled {
     return true;
   }
   // ---- device-resident L-BFGS over the generated objective (lbfgs_codegen.h) -------------------------
-  struct LbfgsResult { int status = -199, iterations = 0, evaluations = 0, slots = 0; double f = 0.0, gnorm = 0.0, seconds = 0.0; };
+  struct LbfgsResult { int status = -199, iterations = 0, evaluations = 0, slots = 0; double f = 0.0, gnorm = 0.0, seconds = 0.0; bool persistent = false; };
   RtcKernel lb_rtc;
-  hipFunction_t lb_eval = nullptr, lb_accept = nullptr, lb_update = nullptr, lb_control = nullptr;
+  hipFunction_t lb_eval = nullptr, lb_accept = nullptr, lb_update = nullptr, lb_control = nullptr, lb_persist = nullptr;
+  LbPersistCtl* lb_ctl = nullptr;       // control block of the persistent kernel
+  double* lb_halo = nullptr;
+  i64 lb_key_nf = -1, lb_per = 0;
+  int lb_persist_wgs = 0;
   const void* lb_key = nullptr;
-  int lb_key_M = 0;
+  int lb_key_M = 0, lb_key_E = 0;
+  hipGraphExec_t lb_graph_exec = nullptr;      // one batch of slots, captured once per argument set
+  const void* lb_graph_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double lb_graph_c0 = 0.0;
+  int lb_graph_on_ = -1;
+  void lb_graph_reset() { if (lb_graph_exec) { hipGraphExecDestroy(lb_graph_exec); lb_graph_exec = nullptr; } }
   LbfgsState* lb_state = nullptr;       // device
   LbfgsState* lb_host = nullptr;        // pinned
   double *lb_BV = nullptr, *lb_dir = nullptr, *lb_gt = nullptr, *lb_fpart = nullptr, *lb_upart = nullptr;
@@ -1719,15 +1731,40 @@ struct HipExec : HostControlled {
     if (const char* v = std::getenv("DNLP_LBFGS_DEVICE")) if (std::atoi(v) == 0) return false;
     if (M < 1) M = 1;
     if (M > kLbMaxM) M = kLbMaxM;
-    if (lb_key != static_cast<const void*>(&progs) || lb_key_M != M) {
+    // Elements per lane of the L-BFGS kernels = the evaluation kernel's (four).  Fewer per lane were measured at the
+    // stated size of BASELINE C2 (n = 1e5, slot kernels): 4 -> 4.0 ms, 2 -> 4.6 ms, 1 -> 6.3 ms per solve: the slot
+    // kernels are bound by their dependent global loads, not by idle compute units.
+    int lbE = fused_E;
+    if (const char* v = std::getenv("DNLP_LBFGS_E")) { const int e = std::atoi(v); if (e >= 1 && e <= 16) lbE = e; }
+    // Persistent single-launch form (one workgroup per compute unit, slices of x and of the whole history in LDS):
+    // when a slice of ceil(nfree / CUs) variables with its 2M + 5 vectors fits the LDS of a compute unit
+    int ncu = 0;
+    DNLP_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+    i64 per = 0;
+    bool want_persist = true;
+    if (const char* v = std::getenv("DNLP_LBFGS_PERSIST")) want_persist = std::atoi(v) != 0;
+    if (want_persist && ncu >= 2 && nfree >= 4 * static_cast<i64>(ncu)) {
+      per = ((nfree + ncu - 1) / ncu + lbE - 1) / lbE * lbE;
+      const i64 lds_bytes = (2 * static_cast<i64>(M) + 5) * (per + 64) * 8 + 12 * 1024;     // (+ halo, Gram matrix, scratch)
+      if (lds_bytes > 150 * 1024) per = 0;
+    }
+    if (lb_key != static_cast<const void*>(&progs) || lb_key_M != M || lb_key_E != lbE || lb_key_nf != (per ? nfree : -1)) {
       lb_key = &progs;
       lb_key_M = M;
+      lb_key_E = lbE;
+      lb_key_nf = per ? nfree : -1;
+      lb_per = per;
+      lb_persist = nullptr;
+      lb_graph_reset();
       if (lb_rtc.mod) { hipModuleUnload(lb_rtc.mod); lb_rtc.mod = nullptr; }
       lb_rtc.ok = false;
       if (const char* v = std::getenv("DNLP_FUSED_E")) { const int e = std::atoi(v); if (e >= 1 && e <= 16) fused_E = e; }
-      const FusedCodegenInfo info = fused_codegen_plan(progs, fused_E);
-      if (info.ok && lb_rtc.load(lbfgs_codegen_source(progs, info, M), "dnlp_lb_eval")) {
+      const FusedCodegenInfo info = fused_codegen_plan(progs, lbE);
+      if (info.ok && per > 0 && (info.hi - info.lo) < 1) { per = 0; lb_per = 0; }     // (no neighbour coupling: nothing to exchange; the slot kernels do)
+      if (info.ok && lb_rtc.load(lbfgs_codegen_source(progs, info, M, per), "dnlp_lb_eval")) {
         lb_eval = lb_rtc.fn;
+        lb_persist = per > 0 ? lb_rtc.get("dnlp_lb_persist") : nullptr;
+        lb_persist_wgs = per > 0 ? static_cast<int>((nfree + per - 1) / per) : 0;
         lb_accept = lb_rtc.get("dnlp_lb_accept");
         lb_update = lb_rtc.get("dnlp_lb_update");
         lb_control = lb_rtc.get("dnlp_lb_control");
@@ -1736,7 +1773,7 @@ struct HipExec : HostControlled {
     }
     if (!lb_rtc.ok) return false;
     const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    const i64 nchunks = (nfree + fused_E - 1) / fused_E;
+    const i64 nchunks = (nfree + lbE - 1) / lbE;
     i64 blocks = (nchunks + kBlock - 1) / kBlock;
     if (blocks > 1024) blocks = 1024;
     constexpr int ldp = 1024;                      // leading dimension of the partial-result columns (>= blocks)
@@ -1758,6 +1795,30 @@ struct HipExec : HostControlled {
     std::memset(lb_host, 0, sizeof(LbfgsState));
     lb_host->tol = tol; lb_host->max_iter = max_iter; lb_host->M = M; lb_host->nblocks = static_cast<int>(blocks);
     DNLP_HIP_CHECK(hipMemcpyAsync(lb_state, lb_host, sizeof(LbfgsState), hipMemcpyHostToDevice, stream));
+    if (lb_persist && lb_persist_wgs >= 2 && lb_persist_wgs <= ncu) {
+      // ONE launch: the state goes in zeroed, comes back final
+      if (!lb_ctl) {
+        DNLP_HIP_CHECK(hipMalloc(&lb_ctl, sizeof(LbPersistCtl)));
+        DNLP_HIP_CHECK(hipMalloc(&lb_halo, sizeof(double) * 2 * 1024 * 128));
+      }
+      DNLP_HIP_CHECK(hipMemsetAsync(lb_ctl, 0, sizeof(LbPersistCtl), stream));
+      i64 nfp = nfree;
+      double c0p = c0;
+      void* a_p[] = {&lb_state, &x, &consts, &lb_ctl, &lb_halo, &c0p, &nfp};
+      DNLP_HIP_CHECK(hipModuleLaunchKernel(lb_persist, static_cast<unsigned>(lb_persist_wgs), 1, 1, kBlock, 1, 1, 0, stream, a_p, nullptr));
+      DNLP_HIP_CHECK(hipMemcpyAsync(lb_host, lb_state, sizeof(LbfgsState), hipMemcpyDeviceToHost, stream));
+      DNLP_HIP_CHECK(hipStreamSynchronize(stream));
+      if (lb_host->done == 5) throw std::runtime_error("device L-BFGS: a workgroup of the persistent kernel never reached a grid barrier");
+      out.slots = lb_host->evals;
+      out.iterations = lb_host->iter;
+      out.evaluations = lb_host->evals;
+      out.f = lb_host->f;
+      out.gnorm = lb_host->gn;
+      out.status = lb_host->done == 1 ? 0 : lb_host->done == 2 ? 3 : lb_host->done == 4 ? -13 : -1;
+      out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
+      out.persistent = true;
+      return true;
+    }
     i64 nf = nfree, nc = nchunks;
     double c0v = c0;
     int ldpv = ldp;
@@ -1773,10 +1834,37 @@ struct HipExec : HostControlled {
       DNLP_HIP_CHECK(hipModuleLaunchKernel(lb_update, static_cast<unsigned>(blocks), 1, 1, kBlock, 1, 1, 0, stream, a_upd, nullptr));
       DNLP_HIP_CHECK(hipModuleLaunchKernel(lb_control, 1, 1, 1, kBlock, 1, 1, 0, stream, a_ctl, nullptr));
     };
+    // A batch of slots is one graph launch: the 64 kernel nodes are enqueued by the GPU's command processor back to
+    // back (a dependent kernel boundary is ~1.5 us there; 64 eager hipModuleLaunchKernel calls keep a host thread busy
+    // for longer than the kernels run).  The graph is captured once per argument set and replayed.
+    const void* gkey[6] = {x, consts, lb_BV, lb_gt, reinterpret_cast<const void*>(static_cast<uintptr_t>(nfree)),
+                           reinterpret_cast<const void*>(static_cast<uintptr_t>(blocks))};
+    bool use_graph = lb_graph_on_ != 0;
+    if (lb_graph_on_ < 0) { const char* ev = std::getenv("DNLP_LBFGS_GRAPH"); use_graph = !(ev && std::atoi(ev) == 0); lb_graph_on_ = use_graph ? 1 : 0; }
+    if (use_graph && (!lb_graph_exec || std::memcmp(gkey, lb_graph_key, sizeof gkey) != 0 || lb_graph_c0 != c0)) {
+      lb_graph_reset();
+      hipGraph_t graph = nullptr;
+      if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        for (int k = 0; k < lb_slots_per_batch; ++k) slot();
+        if (hipStreamEndCapture(stream, &graph) == hipSuccess && graph &&
+            hipGraphInstantiate(&lb_graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+          std::memcpy(lb_graph_key, gkey, sizeof gkey);
+          lb_graph_c0 = c0;
+        } else {
+          (void)hipGetLastError();
+          lb_graph_exec = nullptr;
+        }
+        if (graph) hipGraphDestroy(graph);
+      } else {
+        (void)hipGetLastError();
+      }
+      if (!lb_graph_exec) { lb_graph_on_ = 0; use_graph = false; }     // a runtime that cannot capture: eager launches
+    }
     int slots = 0;
     const long max_slots = static_cast<long>(max_iter) * 4 + 256;
     while (true) {
-      for (int k = 0; k < lb_slots_per_batch; ++k, ++slots) slot();
+      if (use_graph && lb_graph_exec) { DNLP_HIP_CHECK(hipGraphLaunch(lb_graph_exec, stream)); slots += lb_slots_per_batch; }
+      else for (int k = 0; k < lb_slots_per_batch; ++k, ++slots) slot();
       DNLP_HIP_CHECK(hipMemcpyAsync(lb_host, lb_state, sizeof(LbfgsState), hipMemcpyDeviceToHost, stream));
       DNLP_HIP_CHECK(hipStreamSynchronize(stream));
       if (lb_host->done != 0 || slots > max_slots) break;

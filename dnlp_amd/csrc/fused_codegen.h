@@ -187,8 +187,20 @@ inline std::string fused_codegen_preamble(int E) {
   // (DNLP_EMULATE: tests/test_fused_codegen.py compiles this very text with g++ and runs the lanes one
   // after the other on the host to check the generated arithmetic without a GPU)
   s += "#ifndef DNLP_EMULATE\n"
+       // wavefront sum on DPP row shifts / row broadcasts, result to every lane through lane 63 (wave_ops.h has the
+       // same text for the library's own kernels): a __shfl_xor butterfly is twelve ds_bpermute round trips, ~1 500
+       // cycles; this is ~200
+       "template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dnlp_dpp_f64(double v, double keep) {\n"
+       "  const int lo = __builtin_amdgcn_update_dpp(__double2loint(keep), __double2loint(v), CTRL, ROW_MASK, 0xf, false);\n"
+       "  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(keep), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);\n"
+       "  return __hiloint2double(hi, lo);\n}\n"
+       "__device__ __forceinline__ double dnlp_lane63(double v) {\n"
+       "  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));\n}\n"
        "__device__ __forceinline__ double dnlp_wave_sum(double v) {\n"
-       "  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);\n  return v;\n}\n"
+       "  v += dnlp_dpp_f64<0x111, 0xf>(v, 0.0);\n  v += dnlp_dpp_f64<0x112, 0xf>(v, 0.0);\n"
+       "  v += dnlp_dpp_f64<0x114, 0xf>(v, 0.0);\n  v += dnlp_dpp_f64<0x118, 0xf>(v, 0.0);\n"
+       "  v += dnlp_dpp_f64<0x142, 0xa>(v, 0.0);\n  v += dnlp_dpp_f64<0x143, 0xc>(v, 0.0);\n"
+       "  return dnlp_lane63(v);\n}\n"
        "__device__ __forceinline__ void dnlp_store_f(double facc, double* __restrict__ partial) {\n"
        "  facc = dnlp_wave_sum(facc);\n"
        "  if ((threadIdx.x & 63) == 0) partial[blockIdx.x * 4 + (threadIdx.x >> 6)] = facc;\n}\n"

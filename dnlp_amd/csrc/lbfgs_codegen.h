@@ -46,9 +46,20 @@ struct LbfgsState { DNLP_LB_STATE_BODY };
 
 // M (history length) is a generation-time constant: the loops over the 2M+1 basis rows unroll, which is
 // what lets the single-lane two-loop recursion of lb_control pipeline its LDS reads.
-inline std::string lbfgs_codegen_source(const std::vector<FusedSlotProg>& progs, const FusedCodegenInfo& info, int M) {
+// Control block of the persistent kernel (device memory, zeroed by the host before every launch).
+struct LbPersistCtl {
+  unsigned arrive; unsigned abort; unsigned pad[30];        // barrier counter on a line of its own
+  double acc[3][96 * 16];                                   // rotating accumulators, ONE PER 128-BYTE LINE: f, chk, 3 x 31 inner
+                                                            // products, max |g| (atomics to one line serialise in its L2 channel:
+                                                            // sixteen accumulators per line made a barrier phase 32 us)
+};
+
+// `per` > 0 adds the persistent kernel dnlp_lb_persist for workgroups that own `per` consecutive variables each.
+inline std::string lbfgs_codegen_source(const std::vector<FusedSlotProg>& progs, const FusedCodegenInfo& info, int M,
+                                        long long per = 0) {
   std::string s = fused_codegen_preamble(info.E);
   s += "#define DNLP_M " + std::to_string(M) + "\n#define DNLP_NB " + std::to_string(2 * M + 1) + "\n";
+  if (per > 0) s += "#define DNLP_PER " + std::to_string(per) + "\n";
   s += fused_codegen_chunk(progs, info);
   s += "struct LbfgsState { " DNLP_LB_STR(DNLP_LB_STATE_BODY) " };\n";
   s += R"DNLPLB(
@@ -61,8 +72,13 @@ inline std::string lbfgs_codegen_source(const std::vector<FusedSlotProg>& progs,
 // lane 0 store" becomes "lane 0 clears, every lane folds in", and a column reduction is a serial loop.)
 #ifndef DNLP_EMULATE
 __device__ __forceinline__ double dnlp_wave_max(double v) {
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmax(v, dnlp_dpp_f64<0x111, 0xf>(v, v));
+  v = fmax(v, dnlp_dpp_f64<0x112, 0xf>(v, v));
+  v = fmax(v, dnlp_dpp_f64<0x114, 0xf>(v, v));
+  v = fmax(v, dnlp_dpp_f64<0x118, 0xf>(v, v));
+  v = fmax(v, dnlp_dpp_f64<0x142, 0xa>(v, v));
+  v = fmax(v, dnlp_dpp_f64<0x143, 0xc>(v, v));
+  return dnlp_lane63(v);
 }
 __device__ __forceinline__ void dnlp_wave_store_sum(double* __restrict__ dst, double v) {
   v = dnlp_wave_sum(v);
@@ -279,6 +295,91 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_control(LbfgsState* __
     }
   }
   DNLP_SYNC();
+#ifndef DNLP_EMULATE
+  // The scalar part on ONE WAVEFRONT, lane q owning coefficient q of the 2M+1 basis rows: every inner product of the
+  // two-loop recursion is one DPP reduction instead of a 21-link chain of dependent LDS reads on a single lane
+  // (17 us of the 55 us slot in round 2).  Same arithmetic order as the serial text below is NOT kept (a tree sum
+  // replaces the left-to-right sum): iterates agree to rounding, decisions to the last bit only by luck.
+  if (threadIdx.x >= 64) return;
+  {
+    const int lane = threadIdx.x;
+    constexpr int M = DNLP_M, nb = DNLP_NB, GR = 2 * DNLP_M;
+    constexpr int ld = DNLP_MAXNB;
+    const int NV = DNLP_NV;
+    int head = S->head, stored = S->stored, iter = S->iter;
+    const bool run = S->phase != 0;
+    const double tol = S->tol, fnew = S->fn;
+    const int max_iter = S->max_iter;
+    double* G = S->G;
+    const bool in = lane < nb;
+    if (in) {
+      if (run) {
+        Gs[head * ld + lane] = Gs[lane * ld + head] = red[lane];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (in && run) { Gs[(M + head) * ld + lane] = Gs[lane * ld + (M + head)] = red[DNLP_MAXNB + lane]; }
+    __builtin_amdgcn_wave_barrier();
+    if (in) { Gs[GR * ld + lane] = Gs[lane * ld + GR] = red[2 * DNLP_MAXNB + lane]; }
+    __builtin_amdgcn_wave_barrier();
+    // write the new rows / columns through
+    if (in) {
+      if (run) {
+        G[head * ld + lane] = Gs[head * ld + lane]; G[lane * ld + head] = Gs[lane * ld + head];
+        G[(M + head) * ld + lane] = Gs[(M + head) * ld + lane]; G[lane * ld + (M + head)] = Gs[lane * ld + (M + head)];
+      }
+      G[GR * ld + lane] = Gs[GR * ld + lane]; G[lane * ld + GR] = Gs[lane * ld + GR];
+    }
+    if (run) {
+      const double sy = Gs[head * ld + (M + head)], ss = Gs[head * ld + head], yy = Gs[(M + head) * ld + (M + head)];
+      if (sy > 1e-10 * sqrt(ss) * sqrt(yy)) {
+        if (lane == 0) { rh[head] = 1.0 / sy; S->rho[head] = 1.0 / sy; }
+        head = (head + 1) % M;
+        if (stored < M) ++stored;
+      }
+      iter += 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double gn = red[NV - 1];
+    if (lane == 0) {
+      S->iter = iter; S->head = head; S->f = fnew; S->phase = 1; S->accept = 0; S->ls = 0; S->gcur ^= 1; S->gn = gn;
+    }
+    if (gn <= tol * fmax(1.0, fabs(fnew))) { if (lane == 0) { S->stored = stored; S->done = 1; } return; }
+    if (iter >= max_iter) { if (lane == 0) { S->stored = stored; S->done = 3; } return; }
+    double c = (lane == GR) ? 1.0 : 0.0;
+    double myal = 0.0;                               // alpha of history slot `lane` (lanes 0 .. M-1)
+    for (int j = 0; j < stored; ++j) {
+      const int idx = (head - 1 - j + 2 * M) % M;
+      const double v = dnlp_wave_sum(in ? c * Gs[idx * ld + lane] : 0.0);
+      const double a = rh[idx] * v;
+      if (lane == idx) myal = a;
+      if (lane == M + idx) c -= a;
+    }
+    if (stored > 0) {
+      const int idx = (head - 1 + M) % M;
+      const double gam = Gs[idx * ld + (M + idx)] / Gs[(M + idx) * ld + (M + idx)];
+      c *= gam;
+    }
+    for (int j = stored - 1; j >= 0; --j) {
+      const int idx = (head - 1 - j + 2 * M) % M;
+      const double v = dnlp_wave_sum(in ? c * Gs[(M + idx) * ld + lane] : 0.0);
+      if (lane == idx) c += myal - rh[idx] * v;
+    }
+    c = -c;
+    double gd = dnlp_wave_sum(in ? c * Gs[GR * ld + lane] : 0.0);
+    if (!(gd < 0.0)) {                                 // not a descent direction: steepest descent, history dropped
+      stored = 0;
+      c = (lane == GR) ? -1.0 : 0.0;
+      gd = -Gs[GR * ld + GR];
+    }
+    if (in) S->coef[lane] = c;
+    if (lane == 0) {
+      S->stored = stored;
+      S->gd = gd;
+      S->step = (iter == 0 && stored == 0) ? fmin(1.0, 1.0 / fmax(gn, 1e-300)) : 1.0;
+    }
+  }
+#else
   if (threadIdx.x != 255) return;                    // (the LAST lane: host emulation runs the lanes in order)
   const int NV = DNLP_NV;
   constexpr int M = DNLP_M, nb = DNLP_NB, GR = 2 * DNLP_M;
@@ -358,7 +459,280 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_control(LbfgsState* __
   S->stored = stored;
   S->gd = gd;
   S->step = (iter == 0 && stored == 0) ? fmin(1.0, 1.0 / fmax(gn, 1e-300)) : 1.0;
+#endif
 }
+
+#if defined(DNLP_PER) && !defined(DNLP_EMULATE)
+// ---- the whole solve in ONE launch (BASELINE C2 at its stated size) ---------------------------------------------------
+// One workgroup per compute unit owns DNLP_PER consecutive variables and keeps, in LDS for the whole solve, its slice
+// (plus a halo of DNLP_W on either side) of x, the direction, the gradients and all 2M history rows: a trial point, the
+// direction, the history update and the 3 (2M+1) inner products of the vector-free two-loop recursion never touch
+// HBM.  Workgroups meet twice per iteration (once per rejected trial) at a grid barrier; what crosses it is tiny —
+// f and the inner products through double-precision atomic adds into rotating accumulators, the boundary entries
+// of the trial gradient for the neighbours' halos — and every workgroup then takes the same decisions from the same
+// numbers (Armijo test, curvature test, two-loop recursion on its own LDS copy of the Gram matrix).  The four-kernel
+// slot above spends its time in dependent global loads (state, coefficients, rows): 50 us per slot at n = 1e5.
+#define DNLP_PL (DNLP_PER + 2 * DNLP_W)
+struct LbPersistCtl { unsigned arrive; unsigned abort; unsigned pad[30]; double acc[3][96 * 16]; };
+#define DNLP_ACC(p, k) ((p) + 16 * (k))
+
+__device__ __forceinline__ double dnlp_agent_load(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Counter barrier over the nwg co-resident workgroups (grid <= compute units: every workgroup is resident).  A spin is
+// bounded: a stranded workgroup raises `abort` and everybody leaves instead of hanging the device.
+__device__ __forceinline__ bool dnlp_grid_barrier(LbPersistCtl* ctl, unsigned& epoch, const unsigned nwg, int* s_flag) {
+  ++epoch;                                             // (uniform: every lane counts the barriers)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();                                   // release: this workgroup's stores and atomics before the arrive
+    atomicAdd(&ctl->arrive, 1u);
+    const unsigned target = epoch * nwg;
+    unsigned spins = 0;
+    int ok = 1;
+    while (__hip_atomic_load(&ctl->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 1023u) == 0u) {
+        if (spins > (1u << 22) || __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
+      }
+    }
+    __threadfence();                                   // acquire
+    *s_flag = ok;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
+extern "C" __global__ void __launch_bounds__(256) dnlp_lb_persist(LbfgsState* __restrict__ S, double* __restrict__ x,
+    const double* __restrict__ consts, LbPersistCtl* __restrict__ ctl, double* __restrict__ halo, const double c0, const i64 nf) {
+  constexpr int M = DNLP_M, nb = DNLP_NB, GR = 2 * DNLP_M, W = DNLP_W, PL = DNLP_PL, PER = DNLP_PER;
+  constexpr int ldg = DNLP_MAXNB;
+  __shared__ double xs[PL], ds[PL], xt[PL], gold[PL], gnew[PL];
+  __shared__ double rows[2 * M][PL];                       // s_0 .. s_{M-1}, y_0 .. y_{M-1}
+  __shared__ double Gs[DNLP_MAXNB * DNLP_MAXNB];
+  __shared__ double cf[DNLP_MAXNB], rh[16], red[96], wred[4][4];
+  __shared__ double sc[8];                                  // gd, step, (spare)
+  __shared__ int sci[8];                                    // head, stored, iter, done, flag
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned nwg = gridDim.x;
+  const i64 e0 = static_cast<i64>(blockIdx.x) * PER;       // first owned variable
+  const i64 e1 = e0 + PER < nf ? e0 + PER : nf;
+  const int own = static_cast<int>(e1 > e0 ? e1 - e0 : 0);
+  unsigned epoch = 0;
+  // ---- load the slice, clear the history ----
+  for (int li = tid; li < PL; li += 256) {
+    const i64 i = e0 - W + li;
+    xs[li] = (i >= 0 && i < nf) ? x[i] : 0.0;
+    ds[li] = 0.0; gold[li] = 0.0; gnew[li] = 0.0;
+  }
+  for (int k = tid; k < 2 * M * PL; k += 256) (&rows[0][0])[k] = 0.0;
+  for (int k = tid; k < DNLP_MAXNB * DNLP_MAXNB; k += 256) Gs[k] = 0.0;
+  if (tid < DNLP_MAXNB) cf[tid] = 0.0;
+  if (tid < 16) rh[tid] = 0.0;
+  __syncthreads();
+  // replicated state (every lane of every workgroup holds the same values)
+  double f = 0.0, step = 0.0, gd = 0.0, gn = 0.0;
+  int iter = 0, evals = 0, head = 0, stored = 0, ls = 0, phase = 0, done = 0, slot = 0;
+  bool fresh = false;
+  const double tol = S->tol;
+  const int max_iter = S->max_iter;
+  while (done == 0) {
+    // ---- trial point xt = xs + step ds (phase 0: the start point itself) ----
+    if (fresh) {
+      for (int li = tid; li < PL; li += 256) {
+        double d = cf[GR] * gold[li];
+#pragma unroll
+        for (int j = 0; j < 2 * M; ++j) d = fma(cf[j], rows[j][li], d);
+        ds[li] = d;
+      }
+      __syncthreads();
+    }
+    const double stp = phase == 0 ? 0.0 : step;
+    for (int li = tid; li < PL; li += 256) xt[li] = fma(stp, ds[li], xs[li]);
+    __syncthreads();
+    double facc = 0.0, chk = 0.0;
+    for (int q = tid; q * DNLP_E < own; q += 256) {
+      const i64 c = e0 + static_cast<i64>(q) * DNLP_E;
+      double xr[DNLP_NX];
+#pragma unroll
+      for (int k = 0; k < DNLP_NX; ++k) xr[k] = xt[q * DNLP_E + k];        // xt[li] holds variable e0 - W + li
+      double g[DNLP_E];
+#pragma unroll
+      for (int t = 0; t < DNLP_E; ++t) g[t] = 0.0;
+      if (DNLP_INTERIOR(c, nf)) dnlp_chunk_w<false>(c, xr, consts, g, facc);
+      else dnlp_chunk_w<true>(c, xr, consts, g, facc);
+#pragma unroll
+      for (int t = 0; t < DNLP_E; ++t) if (q * DNLP_E + t < own) { gnew[W + q * DNLP_E + t] = g[t]; chk += g[t] - g[t]; }
+    }
+    // ---- what an ACCEPTED trial needs from the other workgroups travels with f through the same barrier: the inner
+    // products of the would-be history rows s = step d, y = g_new - g_old and of g_new against the whole basis, over the
+    // owned entries (a rejected trial has computed them for nothing: LDS work of a microsecond against a second
+    // grid barrier per iteration)
+    const bool run = phase != 0;
+    double gmax = 0.0;
+    {
+      // wavefront w owns the basis rows j = w (mod 4): three inner products each
+      double as_[8], ay_[8], ag_[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) as_[r] = ay_[r] = ag_[r] = 0.0;
+      __syncthreads();                                  // gnew of the owned entries is complete
+      for (int li = W + lane; li < W + own; li += 64) {
+        const double gv = gnew[li];
+        const double sv = run ? stp * ds[li] : 0.0, yv = run ? gv - gold[li] : 0.0;
+        gmax = fmax(gmax, fabs(gv));
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int j = wave + 4 * r;
+          if (j < nb) {
+            const double v = j == GR ? gv : (run && j == head) ? sv : (run && j == M + head) ? yv : rows[j < 2 * M ? j : 0][li];
+            as_[r] = fma(sv, v, as_[r]);
+            ay_[r] = fma(yv, v, ay_[r]);
+            ag_[r] = fma(gv, v, ag_[r]);
+          }
+        }
+      }
+      double* accd = ctl->acc[slot % 3];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int j = wave + 4 * r;
+        if (j < nb) {
+          const double a = dnlp_wave_sum(as_[r]), b = dnlp_wave_sum(ay_[r]), c = dnlp_wave_sum(ag_[r]);
+          if (lane == 0) {
+            atomicAdd(DNLP_ACC(accd, 2 + j), a);
+            atomicAdd(DNLP_ACC(accd, 2 + DNLP_MAXNB + j), b);
+            atomicAdd(DNLP_ACC(accd, 2 + 2 * DNLP_MAXNB + j), c);
+          }
+        }
+      }
+    }
+    facc = dnlp_wave_sum(facc);
+    chk = dnlp_wave_sum(chk);
+    gmax = dnlp_wave_max(gmax);
+    if (lane == 0) { wred[wave][0] = facc; wred[wave][1] = chk; wred[wave][2] = gmax; }
+    __syncthreads();
+    double* acc = ctl->acc[slot % 3];
+    if (tid == 0) {
+      atomicAdd(DNLP_ACC(acc, 0), (wred[0][0] + wred[1][0]) + (wred[2][0] + wred[3][0]));
+      atomicAdd(DNLP_ACC(acc, 1), (wred[0][1] + wred[1][1]) + (wred[2][1] + wred[3][1]));
+      const double g4 = fmax(fmax(wred[0][2], wred[1][2]), fmax(wred[2][2], wred[3][2]));
+      // max of non-negative doubles = max of their bit patterns as unsigned integers
+      atomicMax(reinterpret_cast<unsigned long long*>(DNLP_ACC(acc, 95)), static_cast<unsigned long long>(__double_as_longlong(g4)));
+    }
+    if (blockIdx.x == 0 && tid < 96) __hip_atomic_store(DNLP_ACC(ctl->acc[(slot + 1) % 3], tid), 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // boundary entries of the trial gradient for the neighbours: halo[parity][wg][0 .. W) = first W, [W .. 2W) = last W
+    double* hb = halo + (static_cast<i64>(slot & 1) * nwg + blockIdx.x) * (2 * W);
+    if (tid < W) {
+      __hip_atomic_store(hb + tid, own > tid ? gnew[W + tid] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(hb + W + tid, own >= W ? gnew[W + own - W + tid] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!dnlp_grid_barrier(ctl, epoch, nwg, &sci[4])) { done = 5; break; }
+    if (tid < 96) red[tid] = dnlp_agent_load(DNLP_ACC(acc, tid));
+    if (tid >= 128 && tid < 128 + W) {
+      // left halo = the last W entries of the left neighbour, right halo = the first W of the right one
+      const int t = tid - 128;
+      const double* hp = halo + static_cast<i64>(slot & 1) * nwg * (2 * W);
+      gnew[t] = blockIdx.x > 0 ? dnlp_agent_load(hp + static_cast<i64>(blockIdx.x - 1) * (2 * W) + W + t) : 0.0;
+      gnew[W + own + t] = (blockIdx.x + 1 < nwg && own == PER) ? dnlp_agent_load(hp + static_cast<i64>(blockIdx.x + 1) * (2 * W) + t) : 0.0;
+    }
+    __syncthreads();
+    const double fn = c0 + red[0];
+    const double chks = red[1];
+    ++slot;
+    ++evals;
+    const bool finite = (fn - fn == 0.0) && chks == 0.0;
+    bool accept;
+    if (phase == 0) { accept = finite; if (!finite) { done = 4; break; } }
+    else accept = finite && fn <= f + 1e-4 * step * gd;
+    if (!accept) {
+      step *= 0.5;
+      ++ls;
+      fresh = false;
+      if (ls >= 60) done = 2;
+      __syncthreads();
+      continue;
+    }
+    // ---- accepted: history rows, x, gradient (own entries and halo: all local) ----
+    for (int li = tid; li < PL; li += 256) {
+      if (run) {
+        const double sv = step * ds[li];
+        rows[head][li] = sv;
+        rows[M + head][li] = gnew[li] - gold[li];
+        xs[li] += sv;
+      }
+      gold[li] = gnew[li];
+    }
+    __syncthreads();
+    // ---- Gram matrix, curvature test, convergence, two-loop recursion: wavefront 0, a coefficient per lane ----
+    if (tid < 64) {
+      const bool in = lane < nb;
+      if (in && run) { Gs[head * ldg + lane] = Gs[lane * ldg + head] = red[2 + lane]; }
+      __builtin_amdgcn_wave_barrier();
+      if (in && run) { Gs[(M + head) * ldg + lane] = Gs[lane * ldg + (M + head)] = red[2 + DNLP_MAXNB + lane]; }
+      __builtin_amdgcn_wave_barrier();
+      if (in) { Gs[GR * ldg + lane] = Gs[lane * ldg + GR] = red[2 + 2 * DNLP_MAXNB + lane]; }
+      __builtin_amdgcn_wave_barrier();
+      int h2 = head, st2 = stored, it2 = iter;
+      if (run) {
+        const double sy = Gs[head * ldg + (M + head)], ss = Gs[head * ldg + head], yy = Gs[(M + head) * ldg + (M + head)];
+        if (sy > 1e-10 * sqrt(ss) * sqrt(yy)) {
+          if (lane == 0) rh[head] = 1.0 / sy;
+          h2 = (head + 1) % M;
+          if (st2 < M) ++st2;
+        }
+        it2 += 1;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const double gn2 = red[95];                     // (the largest bit pattern IS the largest non-negative double)
+      int dn = 0;
+      if (gn2 <= tol * fmax(1.0, fabs(fn))) dn = 1;
+      else if (it2 >= max_iter) dn = 3;
+      double c = (lane == GR) ? 1.0 : 0.0, myal = 0.0, gd2 = 0.0;
+      if (dn == 0) {
+        for (int j = 0; j < st2; ++j) {
+          const int idx = (h2 - 1 - j + 2 * M) % M;
+          const double v = dnlp_wave_sum(in ? c * Gs[idx * ldg + lane] : 0.0);
+          const double a = rh[idx] * v;
+          if (lane == idx) myal = a;
+          if (lane == M + idx) c -= a;
+        }
+        if (st2 > 0) {
+          const int idx = (h2 - 1 + M) % M;
+          c *= Gs[idx * ldg + (M + idx)] / Gs[(M + idx) * ldg + (M + idx)];
+        }
+        for (int j = st2 - 1; j >= 0; --j) {
+          const int idx = (h2 - 1 - j + 2 * M) % M;
+          const double v = dnlp_wave_sum(in ? c * Gs[(M + idx) * ldg + lane] : 0.0);
+          if (lane == idx) c += myal - rh[idx] * v;
+        }
+        c = -c;
+        gd2 = dnlp_wave_sum(in ? c * Gs[GR * ldg + lane] : 0.0);
+        if (!(gd2 < 0.0)) { st2 = 0; c = (lane == GR) ? -1.0 : 0.0; gd2 = -Gs[GR * ldg + GR]; }
+        if (in) cf[lane] = c;
+      }
+      if (lane == 0) {
+        sc[0] = gd2; sc[1] = gn2;
+        sc[2] = (it2 == 0 && st2 == 0) ? fmin(1.0, 1.0 / fmax(gn2, 1e-300)) : 1.0;
+        sci[0] = h2; sci[1] = st2; sci[2] = it2; sci[3] = dn;
+      }
+    }
+    __syncthreads();
+    gd = sc[0]; gn = sc[1]; step = sc[2];
+    head = sci[0]; stored = sci[1]; iter = sci[2]; done = sci[3];
+    f = fn; phase = 1; ls = 0; fresh = true;
+    __syncthreads();
+  }
+  // ---- results: the owned entries of x, the state ----
+  for (int li = W + tid; li < W + own; li += 256) x[e0 + (li - W)] = xs[li];
+  if (blockIdx.x == 0 && tid == 0) {
+    S->f = f; S->fn = f; S->gn = gn; S->iter = iter; S->evals = evals; S->done = done; S->head = head; S->stored = stored;
+    S->step = step; S->gd = gd; S->phase = phase; S->ls = ls;
+  }
+}
+#endif
 )DNLPLB";
   return s;
 }

@@ -34,6 +34,7 @@ class ReducedLbfgs {
   bool device_loop_used = false;      // the device-resident loop (lbfgs_codegen.h) ran the solve
   double device_seconds = 0.0;
   int device_slots = 0;
+  bool device_persistent = false;   // the single-launch persistent kernel ran (lbfgs_codegen.h: dnlp_lb_persist)
 
   double tol = 1e-7;
   int max_iter = 20000;
@@ -131,6 +132,7 @@ class ReducedLbfgs {
         gnorm_final = r.gnorm;
         device_seconds = r.seconds;
         device_slots = r.slots;
+        device_persistent = r.persistent;
         double fl;
         const bool keep = use_fused;
         use_fused = false;

@@ -152,7 +152,7 @@ struct HostExec : HostControlled {
   // (generated kernels exist only in the HIP space)
   bool fused_generated_eval(const std::vector<FusedSlotProg>&, const double*, const double*, double*, i64, double&) { return false; }
 
-  struct LbfgsResult { int status = -199, iterations = 0, evaluations = 0, slots = 0; double f = 0.0, gnorm = 0.0, seconds = 0.0; };
+  struct LbfgsResult { int status = -199, iterations = 0, evaluations = 0, slots = 0; double f = 0.0, gnorm = 0.0, seconds = 0.0; bool persistent = false; };
   bool lbfgs_generated_solve(const std::vector<FusedSlotProg>&, const double*, double, i64, double*, int, double, int, LbfgsResult&) { return false; }
 
   // c = V^T w for k stored vectors; out = sum_q c_q V_q

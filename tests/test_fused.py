@@ -261,3 +261,34 @@ def test_lbfgs_direct_path_on_the_host_engine():
 def test_lbfgs_direct_path_on_the_device(gpu_required):
     import contextlib
     _direct_path_checks(contextlib.nullcontext())
+
+
+@pytest.mark.gpu
+def test_c2_persistent_single_launch_kernel_against_the_slot_kernels(gpu_required, monkeypatch):
+    """BASELINE C2 at its stated size: the whole L-BFGS solve in ONE launch (a slice of x and of the history per
+    compute unit in LDS, one grid barrier per trial point) — the analytic optimum x* = 1, and the same iteration /
+    evaluation counts (up to summation order) as the four-kernel slot sequence it replaces at this size."""
+    from problem_zoo import rosenbrock_chain
+    out = {}
+    for persist in ("1", "0"):
+        monkeypatch.setenv("DNLP_LBFGS_PERSIST", persist)
+        p = rosenbrock_chain(cp, 100000)
+        chain = p._build_chain(None)
+        data, inv = chain.apply(p)
+        info = chain.solver.solve_via_data(data, True, False, {"algorithm": "lbfgs"})
+        assert info["status"] == 0 and info["device_loop"]
+        assert info["device_loop_persistent"] == (persist == "1")
+        p.unpack_results(info, chain, inv)
+        assert np.max(np.abs(p.variables()[0].value - 1.0)) <= 1e-5
+        assert abs(info["obj_val"]) <= 1e-10
+        out[persist] = info
+        data["handle"].close()
+    assert abs(out["1"]["iterations"] - out["0"]["iterations"]) <= 6
+    assert abs(out["1"]["evaluations"] - out["0"]["evaluations"]) <= 8
+    # sizes whose slice does not fit the LDS of a compute unit keep the slot kernels
+    p = rosenbrock_chain(cp, 2000000)
+    chain = p._build_chain(None)
+    data, inv = chain.apply(p)
+    monkeypatch.setenv("DNLP_LBFGS_PERSIST", "1")
+    info = chain.solver.solve_via_data(data, True, False, {"algorithm": "lbfgs"})
+    assert info["status"] == 0 and info["device_loop"] and not info["device_loop_persistent"]

@@ -309,3 +309,18 @@ def test_device_resident_lbfgs_status_paths():
     bad[3] = np.nan
     done, x, out = _emulate_lbfgs(ta, bad, 4)
     assert done == 4                                      # invalid number at the start -> status -13
+
+
+def test_persistent_lbfgs_kernel_compiles_for_gfx950_at_the_stated_size():
+    """BASELINE C2 at n = 1e5: the translation unit with the persistent single-launch kernel (a slice of 392
+    variables and the whole L-BFGS history per workgroup in LDS) is generated and compiles for gfx950."""
+    data = _data(rosenbrock_chain(cp, 100000))
+    blob = bytes(serialize(data["tape_arrays"]))
+    lib = _lib()
+    lib.dnlp_lbfgs_codegen_check.restype = C.c_int
+    src = C.create_string_buffer(1 << 21)
+    log = C.create_string_buffer(1 << 16)
+    rc = lib.dnlp_lbfgs_codegen_check(blob, C.c_size_t(len(blob)), 4, src, C.c_size_t(len(src)), log, C.c_size_t(len(log)))
+    assert rc == 0, log.value.decode()
+    text = src.value.decode()
+    assert "#define DNLP_PER 392" in text and "dnlp_lb_persist" in text
