@@ -1,0 +1,25 @@
+# Round-3 counter passes (separate --pmc passes, kernel trace only): the bench command (C4), the C5 bench command and the
+# C5 batch at 65 536.  Run on the GPU box:  bash tools/pmc_r03.sh
+export TMPDIR=/tmp
+O=gpurun_out/r03pmc
+mkdir -p $O
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  tag=$(echo $C | cut -d' ' -f1)
+  timeout 500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/bench_$tag -- python3 bench.py --steps 1 --warmup 0 --no-cpu > $O/bench_$tag.log 2>&1 < /dev/null
+done
+python3 tools/pmc_summary.py $O/pmc_bench.json $O/bench_FETCH_SIZE $O/bench_WRITE_SIZE $O/bench_SQ_VALU_MFMA_BUSY_CYCLES --kernel gemm_nt_update_fast --update-queue > /dev/null
+for C in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
+  tag=$(echo $C | cut -d' ' -f1)
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/c5_$tag -- python3 bench.py --workload c5 --batch 8192 --steps 3 --warmup 1 --no-cpu > $O/c5_$tag.log 2>&1 < /dev/null
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/c5b_$tag -- python3 tools/run_c5_batch.py --batch 65536 --which localization --check 0 --reps 2 > $O/c5b_$tag.log 2>&1 < /dev/null
+done
+python3 tools/pmc_summary.py $O/pmc_c5_8192.json $O/c5_SQ_WAVE_CYCLES $O/c5_FETCH_SIZE $O/c5_WRITE_SIZE --kernel batch_solve > /dev/null
+python3 tools/pmc_summary.py $O/pmc_c5_65536.json $O/c5b_SQ_WAVE_CYCLES $O/c5b_FETCH_SIZE $O/c5b_WRITE_SIZE --kernel batch_solve > /dev/null
+rm -rf $O/bench_* $O/c5_* $O/c5b_*
+timeout 300 python3 bench.py --workload c5 --batch 8192 --steps 5 --warmup 2 > $O/bench_c5_8192.json 2>/dev/null
+timeout 300 python3 tools/run_c5_batch.py --batch 65536 --which localization --check 0 --reps 3 2>/dev/null | grep "^{" > $O/c5_batch_65536.jsonl
+for W in circle_packing10 power_flow path_planning; do
+  B=1024
+  timeout 300 python3 bench.py --workload c5 --which $W --batch $B --steps 3 --warmup 1 --no-cpu 2>/dev/null | grep "^{" > $O/bench_c5_${W}_$B.json
+done
+ls $O
