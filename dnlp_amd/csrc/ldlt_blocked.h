@@ -1195,6 +1195,12 @@ struct BlockedLdlt {
   std::vector<hipEvent_t> tev0, tev1;      // timing events of the Schur updates of one factorisation
   hipEvent_t evPanel = nullptr, evUpd = nullptr;
   hipStream_t s1 = nullptr;                // stream of the big trailing updates
+  // in-panel overlap: the next sub-panel's diagonal block is brought up to date first (on the chain's stream) and its
+  // one-workgroup factorisation runs while the rest of the in-panel update is still going on s2
+  hipStream_t s2 = nullptr;
+  hipEvent_t evR = nullptr, evB = nullptr, evRest = nullptr;
+  bool sub_overlap = false;                // DNLP_LDLT_SUB_OVERLAP=1 enables it.  Measured (round 3, orders 1500 .. 22 000): 0-6 % SLOWER —
+                                           // the one-workgroup top block then waits for a compute unit the s2 update holds
   bool time_updates = false;
   bool lookahead = true;
   bool xcd_swizzle = false;    // 8 x 8 super-tiles per XCD: cuts the W-strip re-reads ~5x but measured 1.5-3% slower (MFMA-bound), so off; DNLP_LDLT_XCD=1 enables
@@ -1217,7 +1223,9 @@ struct BlockedLdlt {
     for (hipEvent_t e : tev1) hipEventDestroy(e);
     if (evPanel) hipEventDestroy(evPanel);
     if (evUpd) hipEventDestroy(evUpd);
+    for (hipEvent_t e : {evR, evB, evRest}) if (e) hipEventDestroy(e);
     if (s1) hipStreamDestroy(s1);
+    if (s2) hipStreamDestroy(s2);
   }
 
   void init(HipExec* e, i64 n_, i64 ld_) {
@@ -1234,6 +1242,13 @@ struct BlockedLdlt {
     if (const char* ev = std::getenv("DNLP_LDLT_SMALL_TILES")) small_tiles_below = std::atoi(ev);
     if (const char* ev = std::getenv("DNLP_LDLT_SMALL_ROWS")) small_rows_max = std::atoi(ev);
     if (const char* ev = std::getenv("DNLP_LDLT_SOLVE_INV")) solve_inv = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("DNLP_LDLT_SUB_OVERLAP")) sub_overlap = std::atoi(ev) != 0;
+    if (sub_overlap && sub128) {
+      DNLP_HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+      DNLP_HIP_CHECK(hipEventCreateWithFlags(&evR, hipEventDisableTiming));
+      DNLP_HIP_CHECK(hipEventCreateWithFlags(&evB, hipEventDisableTiming));
+      DNLP_HIP_CHECK(hipEventCreateWithFlags(&evRest, hipEventDisableTiming));
+    }
     if (NB < LD_nb) NB = LD_nb;
     if (NB > LD_NB_MAX) NB = LD_NB_MAX;
     NB = NB / LD_nb * LD_nb;
@@ -1332,23 +1347,47 @@ struct BlockedLdlt {
     for (int K0 = 0; K0 < ni; K0 += NB, ++p) {
       const int KB = std::min(NB, ni - K0);
       double* Wp = Wp2[p & 1];
+      bool b_pending = false, rest_pending = false;
       for (int j0 = K0; j0 < K0 + KB; j0 += LD_nb) {
         if (sub128 && K0 + KB - j0 >= LD_T) {
           // a full 128-column sub-panel: three launches instead of twelve
           hipLaunchKernelGGL(ldlt_top128_kernel, dim3(1), dim3(LD_TOP_THREADS), 0, s0, A, ld, j0, info, tiny, Ltop);
           const int r0 = j0 + LD_T, rows = ni - r0;
           if (rows > 0) {
+            if (b_pending) { DNLP_HIP_CHECK(hipStreamWaitEvent(s0, evB, 0)); b_pending = false; }    // this sub-panel's rows, brought up to date on s2
             hipLaunchKernelGGL(ldlt_rows128_kernel, dim3((rows + 63) / 64), dim3(256), 0, s0, A, ld, j0, ni, Wp, ldw,
                                j0 - K0, Ltop);
             const int nc = K0 + KB - r0;
-            if (nc > 0)
+            if (nc > 0 && s2 && rows > LD_T) {
+              // In-panel update in three pieces: D = the next sub-panel's diagonal block (this stream: the next top
+              // block follows at once), B = the rows below it, rest = the panel's later columns (both on s2, under the
+              // next top block: one workgroup for 49 us while this update has the rest of the chip).
+              const int dn = nc < LD_T ? nc : LD_T, rs = r0 + dn;
+              const double* Wj = Wp + static_cast<i64>(j0 - K0) * ldw;
+              DNLP_HIP_CHECK(hipEventRecord(evR, s0));
+              if (rest_pending) { DNLP_HIP_CHECK(hipStreamWaitEvent(s0, evRest, 0)); rest_pending = false; }   // earlier updates of D
+              gemm(s0, A + r0 + static_cast<i64>(r0) * ld, Wj + r0, A + r0 + static_cast<i64>(j0) * ld, ld, dn, dn, LD_T, 1);
+              DNLP_HIP_CHECK(hipStreamWaitEvent(s2, evR, 0));
+              gemm(s2, A + rs + static_cast<i64>(r0) * ld, Wj + rs, A + r0 + static_cast<i64>(j0) * ld, ld, ni - rs, dn, LD_T, 0);
+              DNLP_HIP_CHECK(hipEventRecord(evB, s2));
+              b_pending = true;
+              if (nc > dn) {
+                gemm(s2, A + rs + static_cast<i64>(rs) * ld, Wj + rs, A + rs + static_cast<i64>(j0) * ld, ld, ni - rs, nc - dn, LD_T, 1);
+                DNLP_HIP_CHECK(hipEventRecord(evRest, s2));
+                rest_pending = true;
+              }
+            } else if (nc > 0) {
+              if (rest_pending) { DNLP_HIP_CHECK(hipStreamWaitEvent(s0, evRest, 0)); rest_pending = false; }
               gemm(s0, A + r0 + static_cast<i64>(r0) * ld, Wp + r0 + static_cast<i64>(j0 - K0) * ldw,
                    A + r0 + static_cast<i64>(j0) * ld, ld, rows, nc, LD_T, 1);
+            }
           }
           j0 += LD_T - LD_nb;
           continue;
         }
         const int jb = std::min(LD_nb, K0 + KB - j0);
+        if (b_pending) { DNLP_HIP_CHECK(hipStreamWaitEvent(s0, evB, 0)); b_pending = false; }
+        if (rest_pending) { DNLP_HIP_CHECK(hipStreamWaitEvent(s0, evRest, 0)); rest_pending = false; }
         hipLaunchKernelGGL(ldlt_diag_kernel, dim3(1), dim3(64), 0, s0, A, ld, j0, jb, info, tiny);
         const int r0 = j0 + jb;
         if (r0 >= ni) continue;
@@ -1360,6 +1399,8 @@ struct BlockedLdlt {
           gemm(s0, A + r0 + static_cast<i64>(r0) * ld, Wp + r0 + static_cast<i64>(j0 - K0) * ldw,
                A + r0 + static_cast<i64>(j0) * ld, ld, rows, nc, jb, 1);
       }
+      if (b_pending) DNLP_HIP_CHECK(hipStreamWaitEvent(s0, evB, 0));
+      if (rest_pending) DNLP_HIP_CHECK(hipStreamWaitEvent(s0, evRest, 0));
       const int r1 = K0 + KB;
       if (max_neg >= 0) {
         // wrong inertia is known as soon as too many negative pivots have appeared: the rest
@@ -1397,6 +1438,7 @@ struct BlockedLdlt {
       }
     }
     if (lookahead) DNLP_HIP_CHECK(hipStreamSynchronize(s1));
+    if (s2) DNLP_HIP_CHECK(hipStreamSynchronize(s2));
     if (!bailed) {
       DNLP_HIP_CHECK(hipMemcpyAsync(&cur, info, sizeof cur, hipMemcpyDeviceToHost, s0));
     }
