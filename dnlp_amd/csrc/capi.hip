@@ -7,6 +7,7 @@
 #include "capi_impl.h"
 #include "batch.h"
 #include "lower_maps.h"
+#include "linform.h"
 
 // struct dnlp_problem (the opaque handle of the header) IS the problem object over the HIP space
 DNLP_DEFINE_CAPI(dnlp_, dnlp::HipExec, dnlp_problem)
@@ -213,7 +214,50 @@ int dnlp_dev_symv(int device, const double* A, int64_t n, int64_t ld, const doub
     return 0;)
 }
 
-// ---- host side of the lowering (lower_maps.h): no device is touched ------------------------------------------------
+// ---- host side of the lowering (linform.h, lower_maps.h): no device is touched -------------------------------------
+struct dnlp_linform : dnlp::LinFormH {};
+#define DNLP_LF_TRY(...) try { __VA_ARGS__ } catch (const std::exception& e) { dnlp::tls_error() = e.what(); return nullptr; }
+static dnlp_linform* lf_wrap(dnlp::LinFormH* f) { return static_cast<dnlp_linform*>(f); }
+dnlp_linform* dnlp_lf_const(int64_t ncol, int64_t n, const double* b) { DNLP_LF_TRY(return lf_wrap(dnlp::lf_const(ncol, n, b));) }
+dnlp_linform* dnlp_lf_range(int64_t ncol, int64_t n, int64_t col0) { DNLP_LF_TRY(return lf_wrap(dnlp::lf_range(ncol, n, col0));) }
+dnlp_linform* dnlp_lf_select(const dnlp_linform* a, const int64_t* sel, int64_t n) {
+  DNLP_LF_TRY(return lf_wrap(dnlp::lf_select(*a, reinterpret_cast<const long long*>(sel), n));)
+}
+dnlp_linform* dnlp_lf_add(dnlp_linform* a, dnlp_linform* b) { DNLP_LF_TRY(return lf_wrap(dnlp::lf_add(*a, *b));) }
+/* diag(s) a; s == NULL: -a */
+dnlp_linform* dnlp_lf_scale(const dnlp_linform* a, const double* s) { DNLP_LF_TRY(return lf_wrap(dnlp::lf_scale_rows(*a, s));) }
+/* S a, S a constant CSR matrix with srows rows and a's row count as columns */
+dnlp_linform* dnlp_lf_apply_csr(const dnlp_linform* a, int64_t srows, const int64_t* s_ptr, const int32_t* s_idx, const double* s_val) {
+  DNLP_LF_TRY(return lf_wrap(dnlp::lf_apply_csr(*a, srows, reinterpret_cast<const long long*>(s_ptr), s_idx, s_val));)
+}
+dnlp_linform* dnlp_lf_vstack(dnlp_linform* const* parts, int n) {
+  DNLP_LF_TRY(std::vector<dnlp::LinFormH*> v(parts, parts + n); return lf_wrap(dnlp::lf_vstack(v.data(), n));)
+}
+void dnlp_lf_free(dnlp_linform* a) { delete a; }
+/* info[0..3] = rows, columns, stored coefficients, 1 when the form is a plain selection of columns */
+int dnlp_lf_info(const dnlp_linform* a, int64_t* info) {
+  info[0] = a->rows; info[1] = a->ncol; info[2] = a->nnz(); info[3] = dnlp::lf_is_selection(*a) ? 1 : 0;
+  return 0;
+}
+/* 1 and the column of every row in out[0..rows) when the form is a plain selection of columns below n_cols, else 0 */
+int dnlp_lf_gather(const dnlp_linform* a, int64_t n_cols, int64_t* out) {
+  if (!dnlp::lf_is_selection(*a)) return 0;
+  for (long long r = 0; r < a->rows; ++r) {
+    if (a->idx[static_cast<size_t>(r)] >= n_cols) return 0;
+    out[r] = a->idx[static_cast<size_t>(r)];
+  }
+  return 1;
+}
+/* copies out the CSR arrays (canonical: rows sorted, duplicates summed) and the constants; any pointer may be NULL */
+int dnlp_lf_export(dnlp_linform* a, int64_t* ptr, int32_t* idx, double* val, double* b) {
+  dnlp::lf_canonicalize(*a);
+  if (ptr) std::memcpy(ptr, a->ptr.data(), a->ptr.size() * sizeof(int64_t));
+  if (idx && !a->idx.empty()) std::memcpy(idx, a->idx.data(), a->idx.size() * sizeof(int32_t));
+  if (val && !a->val.empty()) std::memcpy(val, a->val.data(), a->val.size() * sizeof(double));
+  if (b && !a->b.empty()) std::memcpy(b, a->b.data(), a->b.size() * sizeof(double));
+  return 0;
+}
+
 struct dnlp_lowered { dnlp::LowerMapsOut out; };
 
 dnlp_lowered* dnlp_lower_maps(int64_t N, int64_t Z, int64_t m, int64_t nd, int64_t nh, const int64_t* G_ptr, const int32_t* G_idx,

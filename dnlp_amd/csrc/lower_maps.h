@@ -211,31 +211,40 @@ inline void lower_maps_build(const LowerMapsIn& in, LowerMapsOut& out) {
     for (lm_i64 k = 0; k < nd; ++k) Ek[static_cast<size_t>(w[static_cast<size_t>(in.drow[k])]++)] = k;
   }
   struct Cand { lm_i32 col; lm_i32 k; double v; };          // k < 0: an affine (Gx) entry
-  std::vector<lm_i64> jcount(static_cast<size_t>(m) + 1, 0), mjcount(static_cast<size_t>(m) + 1, 0);
-  std::vector<std::vector<Cand>> rowc(static_cast<size_t>(m));
-  lm_par_for(m, 512, [&](lm_i64 lo, lm_i64 hi) {
+  // candidates of every row with derivative entries in ONE flat array (a vector per row is 3e5 allocations for
+  // BASELINE C2's canonical form); affine rows have none: their sorted G entries are the pattern
+  std::vector<lm_i64> jcount(static_cast<size_t>(m) + 1, 0), mjcount(static_cast<size_t>(m) + 1, 0), coff(static_cast<size_t>(m) + 1, 0);
+  lm_par_for(m, 2048, [&](lm_i64 lo, lm_i64 hi) {
     for (lm_i64 i = lo; i < hi; ++i) {
-      auto& r = rowc[static_cast<size_t>(i)];
       lm_i64 extra = 0;
       for (lm_i64 e = zbeg[static_cast<size_t>(i)]; e < Gp[i + 1]; ++e) extra += Ep[static_cast<size_t>(Gi[e] - N) + 1] - Ep[static_cast<size_t>(Gi[e] - N)];
-      if (extra == 0) {                                      // affine row: the sorted G entries are the pattern
+      mjcount[static_cast<size_t>(i) + 1] = extra;
+      coff[static_cast<size_t>(i) + 1] = extra ? (zbeg[static_cast<size_t>(i)] - Gp[i]) + extra : 0;
+    }
+  });
+  for (lm_i64 i = 0; i < m; ++i) coff[static_cast<size_t>(i) + 1] += coff[static_cast<size_t>(i)];
+  std::vector<Cand> cand(static_cast<size_t>(coff[static_cast<size_t>(m)]));
+  lm_par_for(m, 1024, [&](lm_i64 lo, lm_i64 hi) {
+    for (lm_i64 i = lo; i < hi; ++i) {
+      const lm_i64 c0 = coff[static_cast<size_t>(i)], c1 = coff[static_cast<size_t>(i) + 1];
+      if (c1 == c0) {                                        // affine row
         jcount[static_cast<size_t>(i) + 1] = zbeg[static_cast<size_t>(i)] - Gp[i];
         continue;
       }
-      r.reserve(static_cast<size_t>(zbeg[static_cast<size_t>(i)] - Gp[i] + extra));
-      for (lm_i64 e = Gp[i]; e < zbeg[static_cast<size_t>(i)]; ++e) r.push_back({Gi[e], -1, Gv[e]});
+      Cand* r = cand.data() + c0;
+      lm_i64 w = 0;
+      for (lm_i64 e = Gp[i]; e < zbeg[static_cast<size_t>(i)]; ++e) r[w++] = {Gi[e], -1, Gv[e]};
       for (lm_i64 e = zbeg[static_cast<size_t>(i)]; e < Gp[i + 1]; ++e) {
         const lm_i64 z = Gi[e] - N;
         for (lm_i64 q = Ep[static_cast<size_t>(z)]; q < Ep[static_cast<size_t>(z) + 1]; ++q) {
           const lm_i64 k = Ek[static_cast<size_t>(q)];
-          r.push_back({static_cast<lm_i32>(in.dcol[k]), static_cast<lm_i32>(k), Gv[e]});
+          r[w++] = {static_cast<lm_i32>(in.dcol[k]), static_cast<lm_i32>(k), Gv[e]};
         }
       }
-      std::stable_sort(r.begin(), r.end(), [](const Cand& a, const Cand& b) { return a.col < b.col || (a.col == b.col && a.k < b.k); });
+      std::stable_sort(r, r + w, [](const Cand& a, const Cand& b) { return a.col < b.col || (a.col == b.col && a.k < b.k); });
       lm_i64 u = 0;
-      for (size_t q = 0; q < r.size(); ++q) if (q == 0 || r[q].col != r[q - 1].col) ++u;
+      for (lm_i64 q = 0; q < w; ++q) if (q == 0 || r[q].col != r[q - 1].col) ++u;
       jcount[static_cast<size_t>(i) + 1] = u;
-      mjcount[static_cast<size_t>(i) + 1] = extra;
     }
   });
   for (lm_i64 i = 0; i < m; ++i) { jcount[static_cast<size_t>(i) + 1] += jcount[static_cast<size_t>(i)]; mjcount[static_cast<size_t>(i) + 1] += mjcount[static_cast<size_t>(i)]; }
@@ -248,20 +257,21 @@ inline void lower_maps_build(const LowerMapsIn& in, LowerMapsOut& out) {
   out.MJ.ptr.assign(static_cast<size_t>(nnzJ) + 1, 0);
   out.MJ.idx.resize(static_cast<size_t>(mjcount[static_cast<size_t>(m)]));
   out.MJ.val.resize(out.MJ.idx.size());
-  lm_par_for(m, 512, [&](lm_i64 lo, lm_i64 hi) {
+  lm_par_for(m, 1024, [&](lm_i64 lo, lm_i64 hi) {
     for (lm_i64 i = lo; i < hi; ++i) {
       lm_i64 pos = jcount[static_cast<size_t>(i)];
-      const auto& r = rowc[static_cast<size_t>(i)];
-      if (r.empty()) {
+      const lm_i64 c0 = coff[static_cast<size_t>(i)], c1 = coff[static_cast<size_t>(i) + 1];
+      if (c1 == c0) {
         for (lm_i64 e = Gp[i]; e < zbeg[static_cast<size_t>(i)]; ++e, ++pos) {
           out.jr[static_cast<size_t>(pos)] = static_cast<lm_i32>(i); out.jc[static_cast<size_t>(pos)] = Gi[e]; out.Jc[static_cast<size_t>(pos)] = Gv[e];
           out.MJ.ptr[static_cast<size_t>(pos) + 1] = 0;
         }
         continue;
       }
+      const Cand* r = cand.data() + c0;
       lm_i64 mo = mjcount[static_cast<size_t>(i)];
       --pos;
-      for (size_t q = 0; q < r.size(); ++q) {
+      for (lm_i64 q = 0; q < c1 - c0; ++q) {
         if (q == 0 || r[q].col != r[q - 1].col) {
           ++pos;
           out.jr[static_cast<size_t>(pos)] = static_cast<lm_i32>(i); out.jc[static_cast<size_t>(pos)] = r[q].col;
@@ -274,7 +284,6 @@ inline void lower_maps_build(const LowerMapsIn& in, LowerMapsOut& out) {
   });
   for (lm_i64 p = 0; p < nnzJ; ++p) out.MJ.ptr[static_cast<size_t>(p) + 1] += out.MJ.ptr[static_cast<size_t>(p)];
   }
-  rowc.clear(); rowc.shrink_to_fit();
   // ---- Hessian pattern and MH --------------------------------------------------------------------------------------
   lm_i64 nkeys = nh;
   for (int b = 0; b < in.nblk; ++b) nkeys += in.blk_n[b] * (in.blk_n[b] + 1) / 2;

@@ -28,6 +28,7 @@ quad_form matrices stay dense (and may live in HBM only, see `DeviceMatrix`).
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 
 from dataclasses import dataclass, field
@@ -58,7 +59,10 @@ DENSE_EXPAND_MAX_N = 48
 
 
 class LinForm:
-    """rows x (N+Z) sparse coefficient matrix plus constant: value = A @ [x; z] + b."""
+    """rows x (N+Z) sparse coefficient matrix plus constant: value = A @ [x; z] + b.
+
+    scipy.sparse implementation (the fallback when libdnlp_hip.so is not built, and the checker of the C++ one:
+    tests/test_lower_maps.py).  `CLinForm` below has the same interface over handles of the C ABI."""
     __slots__ = ("A", "b")
 
     def __init__(self, A, b):
@@ -69,9 +73,55 @@ class LinForm:
     def rows(self):
         return self.A.shape[0]
 
+    # -- constructors --
+    @classmethod
+    def const(cls, ncol, values):
+        values = np.asarray(values, dtype=float).reshape(-1)
+        return cls(sp.csr_matrix((values.size, ncol)), values)
+
+    @classmethod
+    def range(cls, ncol, n, col0):
+        A = sp.csr_matrix((np.ones(n), (np.arange(n), col0 + np.arange(n))), shape=(n, ncol))
+        return cls(A, np.zeros(n))
+
+    # -- operations --
     def select(self, sel):
         sel = np.asarray(sel, dtype=np.int64).reshape(-1)
         return LinForm(self.A[sel, :], self.b[sel])
+
+    def neg(self):
+        return LinForm(-self.A, -self.b)
+
+    def scale(self, cvals):
+        cvals = np.asarray(cvals, dtype=float).reshape(-1)
+        return LinForm(sp.diags(cvals) @ self.A, cvals * self.b)
+
+    @staticmethod
+    def add(forms):
+        A = forms[0].A
+        b = forms[0].b.copy()
+        for f in forms[1:]:
+            if f.A.nnz:                      # (a constant term has no coefficients: no sparse sum, no copy)
+                A = A + f.A if A.nnz else f.A
+            b = b + f.b
+        return LinForm(A, b)
+
+    @staticmethod
+    def vstack(forms):
+        if len(forms) == 1:
+            return forms[0]
+        return LinForm(sp.vstack([f.A for f in forms], format="csr"), np.concatenate([f.b for f in forms]))
+
+    def gather(self, N):
+        """Column of every row when the form is a plain selection of variables (columns below N), else None."""
+        A = self.A
+        ok = (A.nnz == self.rows and np.all(np.diff(A.indptr) == 1) and np.all(A.data == 1.0)
+              and np.all(self.b == 0.0) and (A.indices.size == 0 or A.indices.max() < N))
+        return A.indices.astype(np.int64) if ok else None
+
+    def csr(self):
+        """(CSR matrix, constants): the canonical form is NOT guaranteed (lower_problem canonicalises)."""
+        return self.A, self.b
 
     def apply(self, S):
         """Left-multiply by a constant sparse matrix S (out_rows x rows)."""
@@ -95,6 +145,128 @@ class LinForm:
                 R.sort_indices()
             return LinForm(R, np.zeros(S.shape[0]))
         return LinForm(S @ A, S @ self.b)
+
+
+class CLinForm:
+    """The same affine form behind the C ABI (include/dnlp_hip.h: dnlp_lf_*, csrc/linform.h): the DAG walk composes
+    handles instead of scipy.sparse objects."""
+    __slots__ = ("h", "rows", "ncol", "__weakref__")
+    _lib = None
+
+    @classmethod
+    def available(cls):
+        if cls._lib is None:
+            try:
+                from . import _capi
+                lib = _capi.load().lib
+                i64p, i32p, dp = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+                for name, args in (("dnlp_lf_const", [C.c_int64, C.c_int64, dp]), ("dnlp_lf_range", [C.c_int64] * 3),
+                                   ("dnlp_lf_select", [C.c_void_p, i64p, C.c_int64]), ("dnlp_lf_add", [C.c_void_p, C.c_void_p]),
+                                   ("dnlp_lf_scale", [C.c_void_p, dp]),
+                                   ("dnlp_lf_apply_csr", [C.c_void_p, C.c_int64, i64p, i32p, dp]),
+                                   ("dnlp_lf_vstack", [C.POINTER(C.c_void_p), C.c_int])):
+                    fn = getattr(lib, name)
+                    fn.restype = C.c_void_p
+                    fn.argtypes = args
+                lib.dnlp_lf_free.argtypes = [C.c_void_p]
+                lib.dnlp_lf_free.restype = None
+                lib.dnlp_lf_info.argtypes = [C.c_void_p, i64p]
+                lib.dnlp_lf_export.argtypes = [C.c_void_p, i64p, i32p, dp, dp]
+                lib.dnlp_lf_gather.argtypes = [C.c_void_p, C.c_int64, i64p]
+                lib.dnlp_last_error.restype = C.c_char_p
+                cls._lib = lib
+            except Exception:
+                cls._lib = False
+        return bool(cls._lib)
+
+    def __init__(self, h, rows, ncol):
+        if not h:
+            raise RuntimeError("linform: %s" % (self._lib.dnlp_last_error() or b"").decode())
+        self.h, self.rows, self.ncol = h, int(rows), int(ncol)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._lib.dnlp_lf_free(self.h)
+        except Exception:
+            pass
+
+    @staticmethod
+    def _p(a, ct):
+        return a.ctypes.data_as(C.POINTER(ct))
+
+    @classmethod
+    def const(cls, ncol, values):
+        v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        return cls(cls._lib.dnlp_lf_const(ncol, v.size, cls._p(v, C.c_double)), v.size, ncol)
+
+    @classmethod
+    def range(cls, ncol, n, col0):
+        return cls(cls._lib.dnlp_lf_range(ncol, n, col0), n, ncol)
+
+    def select(self, sel):
+        sel = np.ascontiguousarray(sel, dtype=np.int64).reshape(-1)
+        return CLinForm(self._lib.dnlp_lf_select(self.h, self._p(sel, C.c_int64), sel.size), sel.size, self.ncol)
+
+    def neg(self):
+        return CLinForm(self._lib.dnlp_lf_scale(self.h, None), self.rows, self.ncol)
+
+    def scale(self, cvals):
+        v = np.ascontiguousarray(cvals, dtype=np.float64).reshape(-1)
+        if v.size != self.rows:
+            raise ValueError("scale: one factor per row")
+        return CLinForm(self._lib.dnlp_lf_scale(self.h, self._p(v, C.c_double)), self.rows, self.ncol)
+
+    @staticmethod
+    def add(forms):
+        out = forms[0]
+        for f in forms[1:]:
+            out = CLinForm(CLinForm._lib.dnlp_lf_add(out.h, f.h), out.rows, out.ncol)
+        return out
+
+    @staticmethod
+    def vstack(forms):
+        if len(forms) == 1:
+            return forms[0]
+        arr = (C.c_void_p * len(forms))(*[f.h for f in forms])
+        return CLinForm(CLinForm._lib.dnlp_lf_vstack(arr, len(forms)), sum(f.rows for f in forms), forms[0].ncol)
+
+    def apply(self, S):
+        S = sp.csr_matrix(S)
+        ptr = np.ascontiguousarray(S.indptr, dtype=np.int64)
+        idx = np.ascontiguousarray(S.indices, dtype=np.int32)
+        val = np.ascontiguousarray(S.data, dtype=np.float64)
+        if S.shape[1] != self.rows:
+            raise ValueError("apply: shape mismatch")
+        return CLinForm(self._lib.dnlp_lf_apply_csr(self.h, S.shape[0], self._p(ptr, C.c_int64), self._p(idx, C.c_int32),
+                                                    self._p(val, C.c_double)), S.shape[0], self.ncol)
+
+    def _info(self):
+        info = np.zeros(4, np.int64)
+        self._lib.dnlp_lf_info(self.h, self._p(info, C.c_int64))
+        return info
+
+    def csr(self):
+        nnz = int(self._info()[2])
+        ptr, idx, val, b = np.zeros(self.rows + 1, np.int64), np.zeros(nnz, np.int32), np.zeros(nnz), np.zeros(self.rows)
+        self._lib.dnlp_lf_export(self.h, self._p(ptr, C.c_int64), self._p(idx, C.c_int32), self._p(val, C.c_double),
+                                 self._p(b, C.c_double))
+        A = sp.csr_matrix((val, idx, ptr), shape=(self.rows, self.ncol))
+        A.has_sorted_indices = True
+        A.has_canonical_format = True
+        return A, b
+
+    def gather(self, N):
+        out = np.zeros(self.rows, np.int64)
+        return out if self._lib.dnlp_lf_gather(self.h, N, self._p(out, C.c_int64)) else None
+
+    @property
+    def A(self):
+        return self.csr()[0]
+
+    @property
+    def b(self):
+        return self.csr()[1]
 
 
 @dataclass
@@ -183,6 +355,8 @@ class Lowerer:
         self.nd = 0
         self.nh = 0
         self._memo = {}
+        # affine forms behind the C ABI (csrc/linform.h) unless the library is not built or DNLP_LOWER_CXX=0
+        self.LF = CLinForm if (os.environ.get("DNLP_LOWER_CXX", "1") != "0" and CLinForm.available()) else LinForm
 
     # -- sizing ---------------------------------------------------------------------
     def _count_outputs(self, exprs):
@@ -213,20 +387,16 @@ class Lowerer:
     # -- leaves ---------------------------------------------------------------------
     def _const_form(self, value, size):
         v = value.toarray() if sp.issparse(value) else np.asarray(value, dtype=float)
-        return LinForm(sp.csr_matrix((size, self.ncol)), v.reshape(-1, order="F"))
+        return self.LF.const(self.ncol, v.reshape(-1, order="F"))
 
     def _var_form(self, v: Variable):
         off = self.var_offsets.get(id(v))
         if off is None:
             raise ValueError("Variable %s is not part of the problem." % v.name())
-        n = v.size
-        A = sp.csr_matrix((np.ones(n), (np.arange(n), off + np.arange(n))), shape=(n, self.ncol))
-        return LinForm(A, np.zeros(n))
+        return self.LF.range(self.ncol, v.size, off)
 
     def _z_form(self, zoff, n):
-        A = sp.csr_matrix((np.ones(n), (np.arange(n), self.N + zoff + np.arange(n))),
-                          shape=(n, self.ncol))
-        return LinForm(A, np.zeros(n))
+        return self.LF.range(self.ncol, n, self.N + zoff)
 
     # -- main recursion ---------------------------------------------------------------
     def lower(self, e: Expression) -> LinForm:
@@ -273,21 +443,13 @@ class Lowerer:
                 sel = np.broadcast_to(self._idx(a), e.shape).reshape(-1, order="F")
                 f = f.select(sel)
             forms.append(f)
-        A = forms[0].A
-        b = forms[0].b.copy()
-        for f in forms[1:]:
-            if f.A.nnz:                      # (a constant term has no coefficients: no sparse sum, no copy)
-                A = A + f.A if A.nnz else f.A
-            b = b + f.b
-        return LinForm(A, b)
+        return self.LF.add(forms)
 
     def _lower_NegExpression(self, e):
-        f = self.lower(e.args[0])
-        return LinForm(-f.A, -f.b)
+        return self.lower(e.args[0]).neg()
 
     def _scale_rows(self, f, cvals):
-        cvals = np.asarray(cvals, dtype=float).reshape(-1)
-        return LinForm(sp.diags(cvals) @ f.A, cvals * f.b)
+        return f.scale(np.asarray(cvals, dtype=float).reshape(-1))
 
     def _bcast_const(self, cexpr, shape):
         v = cexpr.value
@@ -388,9 +550,7 @@ class Lowerer:
             off += a.size
         sel = fn([np.atleast_1d(p) for p in pieces]).reshape(-1, order="F")
         forms = [self.lower(a) for a in e.args]
-        A = sp.vstack([f.A for f in forms], format="csr")
-        b = np.concatenate([f.b for f in forms])
-        return LinForm(A, b).select(sel)
+        return self.LF.vstack(forms).select(sel)
 
     def _lower_Hstack(self, e):
         return self._stack(e, np.hstack)
@@ -403,14 +563,11 @@ class Lowerer:
         """x index of every entry of a nonlinear atom's argument.  After dnlp2smooth the
         argument is a Variable; pure selections of variables (index / reshape / promote of a
         variable) are accepted too."""
-        f = self.lower(arg)
-        A = f.A
-        ok = (A.nnz == f.rows and np.all(np.diff(A.indptr) == 1) and np.all(A.data == 1.0)
-              and np.all(f.b == 0.0) and (A.indices.size == 0 or A.indices.max() < self.N))
-        if not ok:
+        idx = self.lower(arg).gather(self.N)
+        if idx is None:
             raise ValueError("Argument of a nonlinear atom is not a bare variable; run "
                              "dnlp2smooth first (got %s)." % type(arg).__name__)
-        return A.indices.astype(np.int64)
+        return idx
 
     def _new_segment(self, seg: Segment, drow, dcol, hrow, hcol, hz):
         seg.zoff = self.Z
@@ -720,11 +877,15 @@ def lower_problem(objective_expr: Expression, constraint_exprs: List[Expression]
     def trim(A):
         return head_cols(A, ncol)
 
-    c = np.asarray(trim(fobj.A).todense()).reshape(-1) if fobj.A.nnz else np.zeros(ncol)
-    c0 = float(fobj.b[0])
+    fA, fb = fobj.csr()
+    c = np.asarray(trim(fA).todense()).reshape(-1) if fA.nnz else np.zeros(ncol)
+    c0 = float(fb[0])
+    single_A = None
     if forms:
-        G = trim(sp.vstack([f.A for f in forms], format="csr") if len(forms) > 1 else forms[0].A)
-        b = np.concatenate([f.b for f in forms])
+        GA, b = lw.LF.vstack(forms).csr()
+        if len(forms) == 1:
+            single_A = GA
+        G = trim(GA)
     else:
         G = sp.csr_matrix((0, ncol))
         b = np.zeros(0)
@@ -742,7 +903,7 @@ def lower_problem(objective_expr: Expression, constraint_exprs: List[Expression]
         from . import _capi
         maps = _capi.lower_maps(N, Z, m, G, c, drow, dcol, hrow, hcol, listed)
     if maps is None:
-        maps = _maps_numpy(N, Z, m, G, c, drow, dcol, hrow, hcol, listed, single_form=forms[0].A if len(forms) == 1 else None)
+        maps = _maps_numpy(N, Z, m, G, c, drow, dcol, hrow, hcol, listed, single_form=single_A)
     if maps["G"] is not None:
         G = maps["G"]
     Mg, Mw, MJ, MH, Jc = maps["Mg"], maps["Mw"], maps["MJ"], maps["MH"], maps["Jc"]

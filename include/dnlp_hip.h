@@ -225,6 +225,23 @@ int dnlp_dev_symv(int device, const double* device_A, int64_t n, int64_t ld, con
  * constant CSR maps Mg, Mw, MJ, MH, the affine Jacobian part Jc and the sorted unique Jacobian / Hessian patterns
  * (+ the positions of the listed dense quad_form blocks x0, n), in C++ with a few host threads.  No device is
  * touched.  Fetch with the accessors below (sizes first), then dnlp_lowered_free. */
+/* Affine forms value = A [x; z] + b (A: CSR over the problem's columns) as opaque handles: the front-end's DAG walk
+ * composes them with the operations affine atoms need (the role of cvxcore's lin_ops, cvxcore/src/LinOpOperations.cpp).
+ * Every function returns a NEW form (NULL on error, text in dnlp_last_error); dnlp_lf_free releases one. */
+typedef struct dnlp_linform dnlp_linform;
+dnlp_linform* dnlp_lf_const(int64_t ncol, int64_t n, const double* b);                    /* no coefficients, constants b */
+dnlp_linform* dnlp_lf_range(int64_t ncol, int64_t n, int64_t col0);                        /* row r = column col0 + r */
+dnlp_linform* dnlp_lf_select(const dnlp_linform* a, const int64_t* sel, int64_t n);       /* rows sel[0..n) of a */
+dnlp_linform* dnlp_lf_add(dnlp_linform* a, dnlp_linform* b);
+dnlp_linform* dnlp_lf_scale(const dnlp_linform* a, const double* s);                       /* diag(s) a; s == NULL: -a */
+dnlp_linform* dnlp_lf_apply_csr(const dnlp_linform* a, int64_t srows, const int64_t* s_ptr, const int32_t* s_idx,
+                                const double* s_val);                                       /* S a */
+dnlp_linform* dnlp_lf_vstack(dnlp_linform* const* parts, int n);
+void dnlp_lf_free(dnlp_linform* a);
+int dnlp_lf_info(const dnlp_linform* a, int64_t* info);   /* rows, columns, stored coefficients, is-a-plain-selection */
+int dnlp_lf_gather(const dnlp_linform* a, int64_t n_cols, int64_t* out);                 /* plain selection of columns < n_cols? */
+int dnlp_lf_export(dnlp_linform* a, int64_t* ptr, int32_t* idx, double* val, double* b);   /* canonical CSR + constants */
+
 typedef struct dnlp_lowered dnlp_lowered;
 dnlp_lowered* dnlp_lower_maps(int64_t N, int64_t Z, int64_t m, int64_t nd, int64_t nh, const int64_t* G_ptr,
                               const int32_t* G_idx, const double* G_val, const double* c, const int64_t* drow,
