@@ -94,11 +94,57 @@ class CApi:
         return msg.decode() if msg else ""
 
 
+class CsrArrays:
+    """A CSR matrix as its three raw arrays — int64 row pointers, int32 columns, float64 values: the layout of the
+    tape (tape.py) and of the C ABI's views (dnlp_lf_view, dnlp_lowered_csr_view), so a 1e7-entry constraint block
+    travels from the lowering to the device upload without a copy.  `tocsr()` builds the scipy object on demand."""
+    __slots__ = ("indptr", "indices", "data", "shape")
+
+    def __init__(self, indptr, indices, data, shape):
+        self.indptr, self.indices, self.data, self.shape = indptr, indices, data, (int(shape[0]), int(shape[1]))
+
+    @property
+    def nnz(self):
+        return int(self.indices.size)
+
+    def tocsr(self):
+        import scipy.sparse as sp
+        M = sp.csr_matrix((self.data, self.indices, self.indptr), shape=self.shape)
+        M.has_sorted_indices = True
+        return M
+
+    def __matmul__(self, other):
+        return self.tocsr() @ other
+
+
+class _Owner:
+    """Keeps a C-ABI handle alive for as long as a numpy view of its arrays exists."""
+    __slots__ = ("h", "free")
+
+    def __init__(self, h, free):
+        self.h, self.free = h, free
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.free(self.h)
+        except Exception:
+            pass
+
+
+def view_array(addr, n, ctype, dtype, owner):
+    """numpy array over `n` elements at `addr` (memory of a C-ABI handle); `owner` is released with the last view."""
+    if not n or not addr:
+        return np.zeros(0, dtype)
+    buf = (ctype * int(n)).from_address(addr)
+    buf._owner = owner
+    return np.frombuffer(buf, dtype=dtype)
+
+
 def lower_maps(N, Z, m, G, c, drow, dcol, hrow, hcol, blocks):
     """C++ construction of the constant maps of a lowered problem (include/dnlp_hip.h: dnlp_lower_maps; the role of
     cvxcore's build_matrix).  `G`: scipy CSR m x (N + Z).  Returns a dict of numpy arrays / scipy matrices, or None
     when the library (or the entry point) is not there — the caller then runs its numpy construction."""
-    import scipy.sparse as sp
     try:
         lib = load().lib
         fn = lib.dnlp_lower_maps
@@ -109,7 +155,7 @@ def lower_maps(N, Z, m, G, c, drow, dcol, hrow, hcol, blocks):
     fn.argtypes = [C.c_int64] * 5 + [i64p, i32p, _dbl_p, _dbl_p, i64p, i64p, i64p, i64p, C.c_int, i64p, i64p]
     lib.dnlp_lowered_free.argtypes = [C.c_void_p]
     lib.dnlp_lowered_sizes.argtypes = [C.c_void_p, i64p]
-    lib.dnlp_lowered_csr.argtypes = [C.c_void_p, C.c_int, i64p, i32p, _dbl_p]
+    lib.dnlp_lowered_csr_view.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     lib.dnlp_lowered_pattern.argtypes = [C.c_void_p, C.c_int, i32p, i32p, _dbl_p]
     lib.dnlp_lowered_block.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), i64p, i64p]
     c64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)     # noqa: E731
@@ -123,41 +169,37 @@ def lower_maps(N, Z, m, G, c, drow, dcol, hrow, hcol, blocks):
            len(blocks), p64(bx0), p64(bn))
     if not h:
         raise RuntimeError("dnlp_lower_maps failed: %s" % load().error())
-    try:
-        sz = np.zeros(9, np.int64)
-        lib.dnlp_lowered_sizes(h, p64(sz))
-        changed, nG, nMg, nMw, nMJ, nnzJ, nMH, nnzH, jac_is_G = (int(v) for v in sz)
+    owner = _Owner(h, lib.dnlp_lowered_free)          # the maps below are views of the handle's arrays
+    sz = np.zeros(9, np.int64)
+    lib.dnlp_lowered_sizes(h, p64(sz))
+    changed, nG, nMg, nMw, nMJ, nnzJ, nMH, nnzH, jac_is_G = (int(v) for v in sz)
 
-        def csr(which, rows, nnz, shape):
-            ptr, idx, val = np.zeros(rows + 1, np.int64), np.zeros(nnz, np.int32), np.zeros(nnz, np.float64)
-            lib.dnlp_lowered_csr(h, which, p64(ptr), p32(idx), _dp(val))
-            M = sp.csr_matrix((val, idx, ptr), shape=shape)
-            M.has_sorted_indices = True
-            M.has_canonical_format = True
-            return M
-        nd, nh = int(drow.size), int(hrow.size)
-        out = {"G": csr(0, m, nG, (m, N + Z)) if changed else None,
-               "Mg": csr(1, N, nMg, (N, nd)), "Mw": csr(2, Z, nMw, (Z, 1 + m)),
-               "MJ": csr(3, nnzJ, nMJ, (nnzJ, nd)), "MH": csr(4, nnzH, nMH, (nnzH, nh))}
-        if jac_is_G:
-            # affine rows over x only (BASELINE C3: 1e7 entries): pattern and values are G's own arrays
-            jr = np.repeat(np.arange(m, dtype=np.int32), np.diff(Gp))
-            jc, Jc = Gi, Gv
-        else:
-            jr, jc, Jc = np.zeros(nnzJ, np.int32), np.zeros(nnzJ, np.int32), np.zeros(nnzJ, np.float64)
-            lib.dnlp_lowered_pattern(h, 0, p32(jr), p32(jc), _dp(Jc))
-        hr, hc = np.zeros(nnzH, np.int32), np.zeros(nnzH, np.int32)
-        lib.dnlp_lowered_pattern(h, 1, p32(hr), p32(hc), None)
-        out.update({"jac_rows": jr, "jac_cols": jc, "Jc": Jc, "hess_rows": hr, "hess_cols": hc, "blocks": []})
-        for b in range(len(blocks)):
-            mode, cnt = C.c_int(), C.c_int64()
-            lib.dnlp_lowered_block(h, b, C.byref(mode), C.byref(cnt), None)
-            pos = np.zeros(cnt.value, np.int64)
-            lib.dnlp_lowered_block(h, b, C.byref(mode), C.byref(cnt), p64(pos))
-            out["blocks"].append((mode.value, pos))
-        return out
-    finally:
-        lib.dnlp_lowered_free(h)
+    def csr(which, rows, nnz, shape):
+        pp, pi, pv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        lib.dnlp_lowered_csr_view(h, which, C.byref(pp), C.byref(pi), C.byref(pv))
+        return CsrArrays(view_array(pp.value, rows + 1, C.c_int64, np.int64, owner), view_array(pi.value, nnz, C.c_int32, np.int32, owner),
+                         view_array(pv.value, nnz, C.c_double, np.float64, owner), shape)
+    nd, nh = int(drow.size), int(hrow.size)
+    out = {"G": csr(0, m, nG, (m, N + Z)) if changed else None,
+           "Mg": csr(1, N, nMg, (N, nd)), "Mw": csr(2, Z, nMw, (Z, 1 + m)),
+           "MJ": csr(3, nnzJ, nMJ, (nnzJ, nd)), "MH": csr(4, nnzH, nMH, (nnzH, nh))}
+    if jac_is_G:
+        # affine rows over x only (BASELINE C3: 1e7 entries): pattern and values are G's own arrays
+        jr = np.repeat(np.arange(m, dtype=np.int32), np.diff(Gp))
+        jc, Jc = Gi, Gv
+    else:
+        jr, jc, Jc = np.zeros(nnzJ, np.int32), np.zeros(nnzJ, np.int32), np.zeros(nnzJ, np.float64)
+        lib.dnlp_lowered_pattern(h, 0, p32(jr), p32(jc), _dp(Jc))
+    hr, hc = np.zeros(nnzH, np.int32), np.zeros(nnzH, np.int32)
+    lib.dnlp_lowered_pattern(h, 1, p32(hr), p32(hc), None)
+    out.update({"jac_rows": jr, "jac_cols": jc, "Jc": Jc, "hess_rows": hr, "hess_cols": hc, "blocks": []})
+    for b in range(len(blocks)):
+        mode, cnt = C.c_int(), C.c_int64()
+        lib.dnlp_lowered_block(h, b, C.byref(mode), C.byref(cnt), None)
+        pos = np.zeros(cnt.value, np.int64)
+        lib.dnlp_lowered_block(h, b, C.byref(mode), C.byref(cnt), p64(pos))
+        out["blocks"].append((mode.value, pos))
+    return out
 
 
 _api = None

@@ -230,6 +230,10 @@ dnlp_linform* dnlp_lf_scale(const dnlp_linform* a, const double* s) { DNLP_LF_TR
 dnlp_linform* dnlp_lf_apply_csr(const dnlp_linform* a, int64_t srows, const int64_t* s_ptr, const int32_t* s_idx, const double* s_val) {
   DNLP_LF_TRY(return lf_wrap(dnlp::lf_apply_csr(*a, srows, reinterpret_cast<const long long*>(s_ptr), s_idx, s_val));)
 }
+/* S a, S a dense constant (srows x a's row count, row-major); exact zeros of S carry no entry */
+dnlp_linform* dnlp_lf_apply_dense(const dnlp_linform* a, int64_t srows, const double* S) {
+  DNLP_LF_TRY(return lf_wrap(dnlp::lf_apply_dense(*a, srows, S));)
+}
 dnlp_linform* dnlp_lf_vstack(dnlp_linform* const* parts, int n) {
   DNLP_LF_TRY(std::vector<dnlp::LinFormH*> v(parts, parts + n); return lf_wrap(dnlp::lf_vstack(v.data(), n));)
 }
@@ -255,6 +259,13 @@ int dnlp_lf_export(dnlp_linform* a, int64_t* ptr, int32_t* idx, double* val, dou
   if (idx && !a->idx.empty()) std::memcpy(idx, a->idx.data(), a->idx.size() * sizeof(int32_t));
   if (val && !a->val.empty()) std::memcpy(val, a->val.data(), a->val.size() * sizeof(double));
   if (b && !a->b.empty()) std::memcpy(b, a->b.data(), a->b.size() * sizeof(double));
+  return 0;
+}
+/* the same arrays without a copy: pointers into the handle (canonical form), valid until dnlp_lf_free */
+int dnlp_lf_view(dnlp_linform* a, const int64_t** ptr, const int32_t** idx, const double** val, const double** b) {
+  dnlp::lf_canonicalize(*a);
+  static_assert(sizeof(long long) == sizeof(int64_t), "row pointers are exported as int64");
+  *ptr = reinterpret_cast<const int64_t*>(a->ptr.data()); *idx = a->idx.data(); *val = a->val.data(); *b = a->b.data();
   return 0;
 }
 
@@ -293,6 +304,14 @@ int dnlp_lowered_csr(const dnlp_lowered* h, int which, int64_t* ptr, int32_t* id
   if (!M) { dnlp::tls_error() = "dnlp_lowered_csr: no such map"; return -1; }
   if (!M->ptr.empty()) std::memcpy(ptr, M->ptr.data(), M->ptr.size() * sizeof(int64_t));
   if (!M->idx.empty()) { std::memcpy(idx, M->idx.data(), M->idx.size() * sizeof(int32_t)); std::memcpy(val, M->val.data(), M->val.size() * sizeof(double)); }
+  return 0;
+}
+/* the same map without a copy: pointers into the handle, valid until dnlp_lowered_free */
+int dnlp_lowered_csr_view(const dnlp_lowered* h, int which, const int64_t** ptr, const int32_t** idx, const double** val) {
+  const dnlp::LowerMapsOut& o = h->out;
+  const dnlp::LmCsr* M = which == 0 ? &o.G : which == 1 ? &o.Mg : which == 2 ? &o.Mw : which == 3 ? &o.MJ : which == 4 ? &o.MH : nullptr;
+  if (!M) { dnlp::tls_error() = "dnlp_lowered_csr_view: no such map"; return -1; }
+  *ptr = reinterpret_cast<const int64_t*>(M->ptr.data()); *idx = M->idx.data(); *val = M->val.data();
   return 0;
 }
 /* which: 0 Jacobian (rows, cols, Jc), 1 Hessian (rows, cols; vals ignored) */

@@ -8,18 +8,34 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <vector>
 
+#include "lower_maps.h"
+
 namespace dnlp {
 
-struct LinFormH {
-  long long rows = 0, ncol = 0;
+// The matrix part is shared between forms that differ only in their constants (A x - b keeps the arrays of A x: for
+// BASELINE C3's 1e3 x 1e4 dense block that is 120 MB not copied), and exported to the front-end as views.
+struct LfMat {
   std::vector<long long> ptr;      // rows + 1
   std::vector<int32_t> idx;
   std::vector<double> val;
-  std::vector<double> b;           // rows
   bool canonical = true;           // every row sorted by column, no duplicate columns
+};
+struct LinFormH {
+  long long rows = 0, ncol = 0;
+  std::shared_ptr<LfMat> m = std::make_shared<LfMat>();
+  std::vector<long long>& ptr;
+  std::vector<int32_t>& idx;
+  std::vector<double>& val;
+  bool& canonical;
+  std::vector<double> b;           // rows
+  LinFormH() : ptr(m->ptr), idx(m->idx), val(m->val), canonical(m->canonical) {}
+  // a form over the matrix part of another one (the constants are the caller's to fill)
+  explicit LinFormH(const LinFormH& o) : rows(o.rows), ncol(o.ncol), m(o.m), ptr(m->ptr), idx(m->idx), val(m->val), canonical(m->canonical) {}
+  LinFormH& operator=(const LinFormH&) = delete;
   long long nnz() const { return static_cast<long long>(idx.size()); }
 };
 
@@ -101,6 +117,12 @@ inline void lf_canonicalize(LinFormH& f) {
 // a + b (same row count): rows merged by column, coefficients of a common column added
 inline LinFormH* lf_add(LinFormH& a, LinFormH& b) {
   if (a.rows != b.rows) throw std::runtime_error("linform add: row counts differ");
+  if (a.nnz() == 0 || b.nnz() == 0) {
+    auto* f = new LinFormH(a.nnz() == 0 ? b : a);
+    f->b.resize(static_cast<size_t>(a.rows));
+    for (long long r = 0; r < a.rows; ++r) f->b[static_cast<size_t>(r)] = a.b[static_cast<size_t>(r)] + b.b[static_cast<size_t>(r)];
+    return f;
+  }
   lf_canonicalize(a);
   lf_canonicalize(b);
   auto* f = new LinFormH();
@@ -204,6 +226,50 @@ inline LinFormH* lf_apply_csr(const LinFormH& a, long long srows, const long lon
   }
   f->ptr[static_cast<size_t>(srows)] = static_cast<long long>(f->idx.size());
   return f;
+}
+// S a with S a dense constant (srows x a.rows, row-major): exact zeros of S carry no entry (scipy's csr_matrix(dense))
+inline LinFormH* lf_apply_dense(const LinFormH& a, long long srows, const double* S) {
+  const long long k = a.rows;
+  std::vector<long long> sp(static_cast<size_t>(srows) + 1, 0);
+  lm_par_for(srows, 16, [&](lm_i64 lo, lm_i64 hi) {
+    for (lm_i64 r = lo; r < hi; ++r) {
+      long long c = 0;
+      const double* row = S + r * k;
+      for (long long j = 0; j < k; ++j) c += row[j] != 0.0;
+      sp[static_cast<size_t>(r) + 1] = c;
+    }
+  });
+  for (long long r = 0; r < srows; ++r) sp[static_cast<size_t>(r) + 1] += sp[static_cast<size_t>(r)];
+  const long long snnz = sp[static_cast<size_t>(srows)];
+  if (lf_is_selection(a)) {
+    auto* f = new LinFormH();
+    f->rows = srows; f->ncol = a.ncol;
+    f->b.assign(static_cast<size_t>(srows), 0.0);
+    f->idx.resize(static_cast<size_t>(snnz));
+    f->val.resize(static_cast<size_t>(snnz));
+    bool mono = true;
+    for (long long r = 1; r < k && mono; ++r) mono = a.idx[static_cast<size_t>(r)] > a.idx[static_cast<size_t>(r - 1)];
+    lm_par_for(srows, 16, [&](lm_i64 lo, lm_i64 hi) {
+      for (lm_i64 r = lo; r < hi; ++r) {
+        const double* row = S + r * k;
+        long long w = sp[static_cast<size_t>(r)];
+        for (long long j = 0; j < k; ++j) if (row[j] != 0.0) { f->idx[static_cast<size_t>(w)] = a.idx[static_cast<size_t>(j)]; f->val[static_cast<size_t>(w)] = row[j]; ++w; }
+      }
+    });
+    f->ptr.swap(sp);
+    f->canonical = mono;
+    return f;
+  }
+  std::vector<int32_t> si(static_cast<size_t>(snnz));
+  std::vector<double> sv(static_cast<size_t>(snnz));
+  lm_par_for(srows, 16, [&](lm_i64 lo, lm_i64 hi) {
+    for (lm_i64 r = lo; r < hi; ++r) {
+      const double* row = S + r * k;
+      long long w = sp[static_cast<size_t>(r)];
+      for (long long j = 0; j < k; ++j) if (row[j] != 0.0) { si[static_cast<size_t>(w)] = static_cast<int32_t>(j); sv[static_cast<size_t>(w)] = row[j]; ++w; }
+    }
+  });
+  return lf_apply_csr(a, srows, sp.data(), si.data(), sv.data());
 }
 inline LinFormH* lf_vstack(LinFormH* const* parts, int n) {
   auto* f = new LinFormH();

@@ -123,6 +123,10 @@ class LinForm:
         """(CSR matrix, constants): the canonical form is NOT guaranteed (lower_problem canonicalises)."""
         return self.A, self.b
 
+    def apply_dense(self, M):
+        """Left-multiply by a dense constant matrix."""
+        return self.apply(_dense_csr(M))
+
     def apply(self, S):
         """Left-multiply by a constant sparse matrix S (out_rows x rows)."""
         S = sp.csr_matrix(S)
@@ -172,6 +176,9 @@ class CLinForm:
                 lib.dnlp_lf_free.restype = None
                 lib.dnlp_lf_info.argtypes = [C.c_void_p, i64p]
                 lib.dnlp_lf_export.argtypes = [C.c_void_p, i64p, i32p, dp, dp]
+                lib.dnlp_lf_view.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 4
+                lib.dnlp_lf_apply_dense.restype = C.c_void_p
+                lib.dnlp_lf_apply_dense.argtypes = [C.c_void_p, C.c_int64, dp]
                 lib.dnlp_lf_gather.argtypes = [C.c_void_p, C.c_int64, i64p]
                 lib.dnlp_last_error.restype = C.c_char_p
                 cls._lib = lib
@@ -246,15 +253,21 @@ class CLinForm:
         self._lib.dnlp_lf_info(self.h, self._p(info, C.c_int64))
         return info
 
+    def apply_dense(self, M):
+        M = np.ascontiguousarray(M, dtype=np.float64)
+        if M.shape[1] != self.rows:
+            raise ValueError("apply: shape mismatch")
+        return CLinForm(self._lib.dnlp_lf_apply_dense(self.h, M.shape[0], self._p(M, C.c_double)), M.shape[0], self.ncol)
+
     def csr(self):
+        """(A, b) in canonical form as views of the handle's arrays (no copy; the handle lives as long as they do)."""
+        from ._capi import CsrArrays, view_array
+        pp, pi, pv, pb = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._lib.dnlp_lf_view(self.h, C.byref(pp), C.byref(pi), C.byref(pv), C.byref(pb))
         nnz = int(self._info()[2])
-        ptr, idx, val, b = np.zeros(self.rows + 1, np.int64), np.zeros(nnz, np.int32), np.zeros(nnz), np.zeros(self.rows)
-        self._lib.dnlp_lf_export(self.h, self._p(ptr, C.c_int64), self._p(idx, C.c_int32), self._p(val, C.c_double),
-                                 self._p(b, C.c_double))
-        A = sp.csr_matrix((val, idx, ptr), shape=(self.rows, self.ncol))
-        A.has_sorted_indices = True
-        A.has_canonical_format = True
-        return A, b
+        A = CsrArrays(view_array(pp.value, self.rows + 1, C.c_int64, np.int64, self), view_array(pi.value, nnz, C.c_int32, np.int32, self),
+                      view_array(pv.value, nnz, C.c_double, np.float64, self), (self.rows, self.ncol))
+        return A, view_array(pb.value, self.rows, C.c_double, np.float64, self)
 
     def gather(self, N):
         out = np.zeros(self.rows, np.int64)
@@ -262,7 +275,7 @@ class CLinForm:
 
     @property
     def A(self):
-        return self.csr()[0]
+        return self.csr()[0].tocsr()
 
     @property
     def b(self):
@@ -496,6 +509,8 @@ class Lowerer:
         m, k, p = self._matmul_dims(X, Y)
         if X.is_constant():
             C = X.value
+            if p == 1 and not sp.issparse(C):
+                return self.lower(Y).apply_dense(np.asarray(C, dtype=float).reshape(m, k))
             C = sp.csr_matrix(C) if sp.issparse(C) else _dense_csr(np.asarray(C, dtype=float).reshape(m, k))
             S = C if p == 1 else sp.kron(sp.identity(p, format="csr"), C, format="csr")
             return self.lower(Y).apply(S)
@@ -865,20 +880,19 @@ def lower_problem(objective_expr: Expression, constraint_exprs: List[Expression]
     N, Z = lw.N, lw.Z
     ncol = N + Z
 
-    def head_cols(A, k):
-        """A[:, :k] as CSR; when no entry lies beyond column k the arrays are shared (no 1e7-entry copy)."""
-        A = sp.csr_matrix(A)
-        if A.shape[1] == k:
-            return A
-        if A.nnz == 0 or int(A.indices.max()) < k:
-            return sp.csr_matrix((A.data, A.indices, A.indptr), shape=(A.shape[0], k))
-        return sp.csr_matrix(A[:, :k])
-
     def trim(A):
-        return head_cols(A, ncol)
+        """A[:, :ncol] as CSR; when no entry lies beyond column ncol the arrays are shared (no 1e7-entry copy)."""
+        from ._capi import CsrArrays
+        if A.shape[1] == ncol:
+            return A
+        if A.nnz == 0 or int(A.indices.max()) < ncol:
+            if isinstance(A, CsrArrays):
+                return CsrArrays(A.indptr, A.indices, A.data, (A.shape[0], ncol))
+            return sp.csr_matrix((A.data, A.indices, A.indptr), shape=(A.shape[0], ncol))
+        return sp.csr_matrix(A.tocsr()[:, :ncol])
 
     fA, fb = fobj.csr()
-    c = np.asarray(trim(fA).todense()).reshape(-1) if fA.nnz else np.zeros(ncol)
+    c = np.asarray(trim(fA).tocsr().todense()).reshape(-1) if fA.nnz else np.zeros(ncol)
     c0 = float(fb[0])
     single_A = None
     if forms:
@@ -903,7 +917,8 @@ def lower_problem(objective_expr: Expression, constraint_exprs: List[Expression]
         from . import _capi
         maps = _capi.lower_maps(N, Z, m, G, c, drow, dcol, hrow, hcol, listed)
     if maps is None:
-        maps = _maps_numpy(N, Z, m, G, c, drow, dcol, hrow, hcol, listed, single_form=single_A)
+        maps = _maps_numpy(N, Z, m, G.tocsr(), c, drow, dcol, hrow, hcol, listed,
+                           single_form=None if single_A is None else single_A.tocsr())
     if maps["G"] is not None:
         G = maps["G"]
     Mg, Mw, MJ, MH, Jc = maps["Mg"], maps["Mw"], maps["MJ"], maps["MH"], maps["Jc"]

@@ -32,8 +32,10 @@ DTYPE_CODES = _DT          # (csrc/tape.h: BlobArray::dtype)
 
 
 def _csr(arrs: Dict[str, np.ndarray], name: str, M):
-    M = sp.csr_matrix(M)
-    M.sort_indices()
+    from ._capi import CsrArrays
+    if not isinstance(M, CsrArrays):        # (the C ABI's views are canonical already and are taken as they are)
+        M = sp.csr_matrix(M)
+        M.sort_indices()
     arrs[name + "_ptr"] = M.indptr.astype(np.int64, copy=False)
     arrs[name + "_idx"] = M.indices.astype(np.int32, copy=False)
     arrs[name + "_val"] = M.data.astype(np.float64, copy=False)

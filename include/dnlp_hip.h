@@ -236,11 +236,15 @@ dnlp_linform* dnlp_lf_add(dnlp_linform* a, dnlp_linform* b);
 dnlp_linform* dnlp_lf_scale(const dnlp_linform* a, const double* s);                       /* diag(s) a; s == NULL: -a */
 dnlp_linform* dnlp_lf_apply_csr(const dnlp_linform* a, int64_t srows, const int64_t* s_ptr, const int32_t* s_idx,
                                 const double* s_val);                                       /* S a */
+dnlp_linform* dnlp_lf_apply_dense(const dnlp_linform* a, int64_t srows, const double* S); /* S a, S dense row-major */
 dnlp_linform* dnlp_lf_vstack(dnlp_linform* const* parts, int n);
 void dnlp_lf_free(dnlp_linform* a);
 int dnlp_lf_info(const dnlp_linform* a, int64_t* info);   /* rows, columns, stored coefficients, is-a-plain-selection */
 int dnlp_lf_gather(const dnlp_linform* a, int64_t n_cols, int64_t* out);                 /* plain selection of columns < n_cols? */
 int dnlp_lf_export(dnlp_linform* a, int64_t* ptr, int32_t* idx, double* val, double* b);   /* canonical CSR + constants */
+/* the same arrays without a copy: pointers into the handle, valid until dnlp_lf_free (forms that differ only in their
+ * constants share the matrix arrays) */
+int dnlp_lf_view(dnlp_linform* a, const int64_t** ptr, const int32_t** idx, const double** val, const double** b);
 
 typedef struct dnlp_lowered dnlp_lowered;
 dnlp_lowered* dnlp_lower_maps(int64_t N, int64_t Z, int64_t m, int64_t nd, int64_t nh, const int64_t* G_ptr,
@@ -253,6 +257,8 @@ void dnlp_lowered_free(dnlp_lowered* h);
 int dnlp_lowered_sizes(const dnlp_lowered* h, int64_t* sizes);
 /* which: 0 G (only when G_changed), 1 Mg, 2 Mw, 3 MJ, 4 MH */
 int dnlp_lowered_csr(const dnlp_lowered* h, int which, int64_t* ptr, int32_t* idx, double* val);
+/* the same map without a copy: pointers into the handle, valid until dnlp_lowered_free */
+int dnlp_lowered_csr_view(const dnlp_lowered* h, int which, const int64_t** ptr, const int32_t** idx, const double** val);
 /* which: 0 Jacobian (rows, cols, Jc), 1 Hessian (rows, cols) */
 int dnlp_lowered_pattern(const dnlp_lowered* h, int which, int32_t* rows, int32_t* cols, double* vals);
 /* dense block b: *mode = 2 (contiguous run, pos[0] = first position) or 1 (table of *count positions) */
