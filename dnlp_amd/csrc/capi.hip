@@ -60,6 +60,7 @@ int dnlp_solve_batch_timed(dnlp_problem* vp, int batch, const double* data, int6
   DNLP_TRY(
     BatchRunner& r = *batch_runner(p);
     p->ex.sync();
+    p->exact_hessian_substituted = p->opt.hessian_approximation == 1;   // no quasi-Newton mode inside the batch kernel
     r.solve(batch, data, stride, p->opt, x, obj, mult_g, mult_x_L, mult_x_U, status, iters, factorizations, seconds, times);
     return 0;)
 }
@@ -81,6 +82,7 @@ int dnlp_solve_batch_theta(dnlp_problem* vp, int batch, const double* theta, int
   DNLP_TRY(
     BatchRunner& r = *batch_runner(p);
     p->ex.sync();
+    p->exact_hessian_substituted = p->opt.hessian_approximation == 1;
     r.solve_theta(batch, theta, n_params, p->opt, x, obj, mult_g, mult_x_L, mult_x_U, status, iters, factorizations, seconds, times);
     return 0;)
 }

@@ -171,10 +171,12 @@ struct ProblemT {
     else if (k == "bound_push") opt.bound_push = num();
     else if (k == "bound_frac") opt.bound_frac = num();
     else if (k == "hessian_approximation") {
-      // "limited-memory" asks IPOPT to do WITHOUT second derivatives; here the exact tape Hessian is
-      // always available, so it is used — the choice is recorded (get_log, stats[22]) rather than hidden
+      // "limited-memory": IPOPT's quasi-Newton interior-point mode, no second derivatives (ipm_core.h: lm_*)
       if (v != "exact" && v != "limited-memory") return -12;
-      exact_hessian_substituted = (v == "limited-memory");
+      opt.hessian_approximation = (v == "limited-memory") ? 1 : 0;
+      // (the in-kernel solver of the batch / device-loop paths has no quasi-Newton mode: there the exact tape
+      //  Hessian is used and the substitution is recorded — stats[23])
+      exact_hessian_substituted = false;
     }
     else if (k == "derivative_test") { /* accepted, unused: oracles are exact by construction */ }
     else if (k == "least_square_init_duals") opt.least_square_init_duals = yes() ? 1 : 0;
@@ -202,7 +204,9 @@ struct ProblemT {
     else if (k == "lazy_dense_fallback") opt.lazy_dense_fallback = yes() ? 1 : 0;
     else if (k == "restoration") opt.restoration = yes() ? 1 : 0;
     else if (k == "time_kernels") time_kernels = yes();
-    else if (k == "lbfgs_history" || k == "limited_memory_max_history") lbfgs_history = static_cast<int>(num());
+    else if (k == "lbfgs_history") lbfgs_history = static_cast<int>(num());
+    else if (k == "limited_memory_max_history") { lbfgs_history = static_cast<int>(num()); opt.limited_memory_max_history = static_cast<int>(num()); }
+    else if (k == "limited_memory_max_skipping") opt.limited_memory_max_skipping = static_cast<int>(num());
     else if (k == "fused_objective") use_fused = yes();
     else if (k == "fused_codegen") set_fused_codegen(yes());
     else if (k == "lbfgs_device_loop") lbfgs_device_loop = yes();

@@ -59,6 +59,11 @@ struct IpmOptions {
   int lanczos_min_n = 12000;
   // IPOPT's warm start (warm_start_init_point = yes): start from given primal AND dual values,
   // pushed only slightly into the interior
+  // hessian_approximation: 0 exact (the tape's second derivatives), 1 limited-memory (IPOPT's quasi-Newton
+  // interior-point mode: BFGS pairs in compact form, no second derivatives evaluated)
+  int hessian_approximation = 0;
+  int limited_memory_max_history = 6;       // IPOPT default
+  int limited_memory_max_skipping = 2;      // IPOPT default: this many rejected updates in a row drop the history
   int warm_start = 0;
   double warm_start_bound_push = 1e-3, warm_start_bound_frac = 1e-3, warm_start_mult_bound_push = 1e-3;
 };
@@ -117,6 +122,9 @@ class Ipm {
   IntermediateCb intermediate_cb = nullptr;   // host-driven spaces only
   void* intermediate_user = nullptr;
   DNLP_HD Ipm(E* ex, Model<E>* model, K* kkt) : ex_(ex), md_(model), kkt_(kkt) {}
+#if !DNLP_DEVICE_PASS
+  ~Ipm() { delete lm_; }
+#endif
 
   IpmOptions opt;
   IpmStats stats;
@@ -194,6 +202,246 @@ class Ipm {
     filt_th[nfilt] = th; filt_ph[nfilt] = ph; ++nfilt;
   }
 
+
+  // ---- limited-memory quasi-Newton Hessian (hessian_approximation = limited-memory) ---------------------------
+  // The role of IPOPT's LimMemQuasiNewtonUpdater + LowRankAugSystemSolver (the reference passes the option through,
+  // ipopt_nlpif.py:153-168; cvxpy/tests/NLP_tests/test_entropy_related.py:40 uses it).  No second derivatives are
+  // evaluated.  The Hessian of the Lagrangian is replaced by the BFGS matrix of the last k <= max_history pairs
+  //   s = x+ - x,   y = grad_x L(x+, lambda+) - grad_x L(x, lambda+)
+  // in the compact form of Byrd, Nocedal and Schnabel:
+  //   B = sigma I - Psi M^{-1} Psi^T,   Psi = [sigma S, Y],   M = [[sigma S^T S, L], [L^T, -D]],
+  // sigma = s^T y / s^T s of the newest pair (IPOPT's "scalar1"), L the strictly lower part of S^T Y, D its diagonal.
+  // A pair with s^T y <= sqrt(eps) |s| |y| is skipped; max_skipping skips in a row drop the history.  The KKT matrix
+  // is K = K0 - [Psi; 0] M^{-1} [Psi; 0]^T with K0 the matrix of the DIAGONAL Hessian sigma I (+ Sigma + delta_w):
+  // K0 is factorised by the usual path (static-pattern sparse / dense), and a solve is Sherman-Morrison-Woodbury,
+  //   K^{-1} r = K0^{-1} r + Z (M - Psi^T Z_x)^{-1} Psi^T (K0^{-1} r)_x,   Z = K0^{-1} [Psi; 0]   (2k solves per factorisation).
+  // B is positive definite by construction, so K has the inertia (N, m, 0) exactly when K0 has it (both need only J of
+  // full row rank): the inertia test reads the factorisation of K0.  Host-driven spaces only: the batch kernel keeps
+  // the exact Hessian and says so (stats[23]).
+  static constexpr int kLmMaxH = 12;
+  struct LmState {
+    int hist = 6, alloc_hist = 0, k = 0, skipped = 0;
+    int updates = 0, skips_total = 0, resets = 0;
+    int slot[kLmMaxH];                          // chronological position (0 = oldest) -> physical row
+    double sigma = 1.0;
+    double SS[kLmMaxH][kLmMaxH], SY[kLmMaxH][kLmMaxH];    // s_a^T s_b and s_a^T y_b by physical row
+    double *S = nullptr, *Y = nullptr;          // hist x N each (exec space)
+    double *xold = nullptr, *gold = nullptr, *jold = nullptr, *sv = nullptr, *yv = nullptr;
+    double* Z = nullptr;                        // 2 hist x (N + m)
+    double* tmp = nullptr;                      // N + m
+    double Mm[4 * kLmMaxH * kLmMaxH], Mlu[4 * kLmMaxH * kLmMaxH], Clu[4 * kLmMaxH * kLmMaxH];
+    int Mpiv[2 * kLmMaxH], Cpiv[2 * kLmMaxH];
+    bool c_ready = false, c_ok = false, have_old = false;
+  };
+  LmState* lm_ = nullptr;
+  DNLP_HD bool lm_on() const {
+    if constexpr (E::has_host_control) return lm_ != nullptr && opt.hessian_approximation == 1;
+    else return false;
+  }
+  // LU with partial pivoting of a small row-major matrix held by the control thread
+  DNLP_HD static bool lm_lu(double* Am, int n, int* piv) {
+    for (int c = 0; c < n; ++c) {
+      int p = c;
+      for (int r = c + 1; r < n; ++r) if (fabs(Am[r * n + c]) > fabs(Am[p * n + c])) p = r;
+      piv[c] = p;
+      if (!(fabs(Am[p * n + c]) > 0.0)) return false;
+      if (p != c) for (int q = 0; q < n; ++q) { const double t = Am[c * n + q]; Am[c * n + q] = Am[p * n + q]; Am[p * n + q] = t; }
+      for (int r = c + 1; r < n; ++r) {
+        const double l = Am[r * n + c] / Am[c * n + c];
+        Am[r * n + c] = l;
+        for (int q = c + 1; q < n; ++q) Am[r * n + q] -= l * Am[c * n + q];
+      }
+    }
+    return true;
+  }
+  DNLP_HD static void lm_lu_solve(const double* Am, int n, const int* piv, double* b) {
+    for (int c = 0; c < n; ++c) { const double t = b[c]; b[c] = b[piv[c]]; b[piv[c]] = t; }     // (whole rows were swapped: P first)
+    for (int c = 0; c < n; ++c) for (int r = c + 1; r < n; ++r) b[r] -= Am[r * n + c] * b[c];
+    for (int c = n - 1; c >= 0; --c) { for (int q = c + 1; q < n; ++q) b[c] -= Am[c * n + q] * b[q]; b[c] /= Am[c * n + c]; }
+  }
+  DNLP_HD void lm_begin() {
+    if constexpr (E::has_host_control) {
+      if (opt.hessian_approximation != 1) { kkt_->skip_hessian = false; return; }
+      if (!lm_) lm_ = new LmState();
+      LmState& L = *lm_;
+      const int h = opt.limited_memory_max_history < 1 ? 1 : (opt.limited_memory_max_history > kLmMaxH ? kLmMaxH : opt.limited_memory_max_history);
+      if (!L.S || h > L.alloc_hist) {
+        L.S = A<double>(static_cast<i64>(h) * N); L.Y = A<double>(static_cast<i64>(h) * N);
+        L.Z = A<double>(static_cast<i64>(2 * h) * (N + m));
+        if (!L.xold) {
+          L.xold = A<double>(N); L.gold = A<double>(N); L.jold = A<double>(md_->t.nnzJ); L.sv = A<double>(N); L.yv = A<double>(N);
+          L.tmp = A<double>(N + m);
+        }
+        L.alloc_hist = h;
+      }
+      L.hist = h;
+      lm_reset();
+      if (ladder_rung_ == 0) L.updates = L.skips_total = L.resets = 0;
+      kkt_->skip_hessian = true;
+    }
+  }
+  DNLP_HD void lm_reset() {
+    if (!lm_) return;
+    lm_->k = 0; lm_->skipped = 0; lm_->sigma = 1.0; lm_->c_ready = false; lm_->have_old = false;
+  }
+  // column c of Psi: row pointer and scale
+  DNLP_HD const double* lm_col(int c, double& scale) const {
+    const LmState& L = *lm_;
+    if (c < L.k) { scale = L.sigma; return L.S + static_cast<i64>(L.slot[c]) * N; }
+    scale = 1.0;
+    return L.Y + static_cast<i64>(L.slot[c - L.k]) * N;
+  }
+  DNLP_HD void lm_psi_dots(const double* v, double* t) {
+    const int n2 = 2 * lm_->k;
+    for (int c = 0; c < n2; ++c) {
+      double sc;
+      const double* row = lm_col(c, sc);
+      t[c] = sc * ex_->sum(N, [=] DNLP_HD(i64 j) { return row[j] * v[j]; });
+    }
+  }
+  // the point the next pair is measured from: x, grad f and the Jacobian values of the current iterate
+  DNLP_HD void lm_save_point() {
+    LmState& L = *lm_;
+    ex_->d2d(L.xold, x, sizeof(double) * static_cast<size_t>(N));
+    ex_->d2d(L.gold, grad, sizeof(double) * static_cast<size_t>(N));
+    ex_->d2d(L.jold, jv, sizeof(double) * static_cast<size_t>(md_->t.nnzJ));
+    L.have_old = true;
+  }
+  // after an accepted step: the new pair (both gradients of the Lagrangian with the NEW multipliers)
+  DNLP_HD void lm_update() {
+    LmState& L = *lm_;
+    if (!L.have_old) return;
+    L.have_old = false;
+    md_->jac_tmult(jv, y, tN);
+    md_->jac_tmult(L.jold, y, L.tmp);
+    {
+      double *sv = L.sv, *yv = L.yv;
+      const double *xx = x, *xo = L.xold, *gn = grad, *go = L.gold, *jn = tN, *jo = L.tmp, *fm = fixmask;
+      ex_->map(N, [=] DNLP_HD(i64 j) {
+        const bool fx = fm[j] != 0.0;
+        sv[j] = fx ? 0.0 : xx[j] - xo[j];
+        yv[j] = fx ? 0.0 : (gn[j] - go[j]) + (jn[j] - jo[j]);
+      });
+    }
+    const double *sv = L.sv, *yv = L.yv;
+    const double sts = ex_->sum(N, [=] DNLP_HD(i64 j) { return sv[j] * sv[j]; });
+    const double sty = ex_->sum(N, [=] DNLP_HD(i64 j) { return sv[j] * yv[j]; });
+    const double yty = ex_->sum(N, [=] DNLP_HD(i64 j) { return yv[j] * yv[j]; });
+    const double eps = 2.220446049250313e-16;
+    if (!(sty > std::sqrt(eps) * std::sqrt(sts) * std::sqrt(yty)) || !std::isfinite(sty) || !std::isfinite(yty)) {
+      ++L.skips_total;
+      if (++L.skipped >= opt.limited_memory_max_skipping) {
+        logf("   limited-memory: %d updates skipped in a row (s^T y = %.3e): history dropped", L.skipped, sty);
+        lm_reset();
+        ++L.resets;
+      }
+      return;
+    }
+    L.skipped = 0;
+    if (L.k == L.hist) { for (int a = 1; a < L.k; ++a) L.slot[a - 1] = L.slot[a]; --L.k; }
+    int phys = 0;
+    for (;; ++phys) { bool used = false; for (int a = 0; a < L.k; ++a) used = used || L.slot[a] == phys; if (!used) break; }
+    ex_->d2d(L.S + static_cast<i64>(phys) * N, sv, sizeof(double) * static_cast<size_t>(N));
+    ex_->d2d(L.Y + static_cast<i64>(phys) * N, yv, sizeof(double) * static_cast<size_t>(N));
+    for (int a = 0; a < L.k; ++a) {
+      const int pa = L.slot[a];
+      const double *sa = L.S + static_cast<i64>(pa) * N, *ya = L.Y + static_cast<i64>(pa) * N;
+      L.SS[pa][phys] = L.SS[phys][pa] = ex_->sum(N, [=] DNLP_HD(i64 j) { return sa[j] * sv[j]; });
+      L.SY[pa][phys] = ex_->sum(N, [=] DNLP_HD(i64 j) { return sa[j] * yv[j]; });
+      L.SY[phys][pa] = ex_->sum(N, [=] DNLP_HD(i64 j) { return sv[j] * ya[j]; });
+    }
+    L.SS[phys][phys] = sts;
+    L.SY[phys][phys] = sty;
+    L.slot[L.k++] = phys;
+    L.sigma = fmin(fmax(sty / sts, 1e-8), 1e8);
+    ++L.updates;
+    // M = [[sigma S^T S, L], [L^T, -D]] in chronological order
+    const int k = L.k, n2 = 2 * k;
+    for (int a = 0; a < k; ++a)
+      for (int b = 0; b < k; ++b) {
+        const int pa = L.slot[a], pb = L.slot[b];
+        L.Mm[a * n2 + b] = L.sigma * L.SS[pa][pb];
+        const double lab = a > b ? L.SY[pa][pb] : 0.0, lba = b > a ? L.SY[pb][pa] : 0.0;
+        L.Mm[a * n2 + (k + b)] = lab;
+        L.Mm[(k + a) * n2 + b] = lba;
+        L.Mm[(k + a) * n2 + (k + b)] = a == b ? -L.SY[pa][pa] : 0.0;
+      }
+    for (int q = 0; q < n2 * n2; ++q) L.Mlu[q] = L.Mm[q];
+    if (!lm_lu(L.Mlu, n2, L.Mpiv)) {
+      logf("   limited-memory: the middle matrix is singular: history dropped");
+      lm_reset();
+      ++L.resets;
+    }
+    L.c_ready = false;
+  }
+  // out = B v
+  DNLP_HD void lm_hess_mult(const double* v, double* out) {
+    LmState& L = *lm_;
+    const double sg0 = L.sigma;
+    ex_->map(N, [=] DNLP_HD(i64 j) { out[j] = sg0 * v[j]; });
+    if (L.k == 0) return;
+    const int n2 = 2 * L.k;
+    double t[2 * kLmMaxH];
+    lm_psi_dots(v, t);
+    lm_lu_solve(L.Mlu, n2, L.Mpiv, t);
+    for (int c = 0; c < n2; ++c) {
+      double sc;
+      const double* row = lm_col(c, sc);
+      const double u = sc * t[c];
+      ex_->map(N, [=] DNLP_HD(i64 j) { out[j] -= u * row[j]; });
+    }
+  }
+  // Z = K0^{-1} [Psi; 0] and the LU factors of M - Psi^T Z_x, once per factorisation of K0
+  DNLP_HD void lm_prepare() {
+    LmState& L = *lm_;
+    L.c_ready = true;
+    L.c_ok = true;
+    if (L.k == 0) return;
+    const int n2 = 2 * L.k;
+    const i64 NM = N + m, NN = N;
+    for (int c = 0; c < n2; ++c) {
+      double sc;
+      const double* row = lm_col(c, sc);
+      double* tp = L.tmp;
+      ex_->map(NM, [=] DNLP_HD(i64 j) { tp[j] = j < NN ? sc * row[j] : 0.0; });
+      kkt_->solve(L.tmp, L.Z + static_cast<i64>(c) * NM);
+    }
+    for (int a = 0; a < n2; ++a) {
+      double sa;
+      const double* ra = lm_col(a, sa);
+      for (int b = a; b < n2; ++b) {
+        const double* zb = L.Z + static_cast<i64>(b) * NM;
+        const double d = sa * ex_->sum(N, [=] DNLP_HD(i64 j) { return ra[j] * zb[j]; });
+        L.Clu[a * n2 + b] = L.Mm[a * n2 + b] - d;
+        L.Clu[b * n2 + a] = L.Mm[b * n2 + a] - d;
+      }
+    }
+    bool fin = true;
+    for (int q = 0; q < n2 * n2; ++q) fin = fin && std::isfinite(L.Clu[q]);
+    L.c_ok = fin && lm_lu(L.Clu, n2, L.Cpiv);
+    if (!L.c_ok) logf("   limited-memory: the capacitance matrix of the low-rank solve is singular");
+  }
+  // out = K^{-1} r through the factorisation of K0
+  DNLP_HD void kkt_solve(const double* r, double* out) {
+    kkt_->solve(r, out);
+    if constexpr (E::has_host_control) {
+      if (!lm_on() || lm_->k == 0) return;
+      LmState& L = *lm_;
+      if (!L.c_ready) lm_prepare();
+      if (!L.c_ok) return;                 // (the refinement on the true operator reports the bad solve)
+      const int n2 = 2 * L.k;
+      const i64 NM = N + m;
+      double t[2 * kLmMaxH];
+      lm_psi_dots(out, t);
+      lm_lu_solve(L.Clu, n2, L.Cpiv, t);
+      for (int c = 0; c < n2; ++c) {
+        const double u = t[c];
+        const double* zc = L.Z + static_cast<i64>(c) * NM;
+        ex_->map(NM, [=] DNLP_HD(i64 j) { out[j] += u * zc[j]; });
+      }
+    }
+  }
+
   // ---- evaluation helpers (scaled problem) --------------------------------------
   // f~(xp), g~(xp) -> returns false on non-finite values
   DNLP_HD bool eval_fg(const double* xp, double& fval, double* gout, bool check = true) {
@@ -223,6 +471,7 @@ class Ipm {
     stats.t_eval += now_sec() - t0;
   }
   DNLP_HD void eval_hessian() {
+    if (lm_on()) return;                 // limited-memory mode: no second derivatives
     double t0 = now_sec();
     const double* sgp = sg;
     const double* yy = y;
@@ -237,6 +486,7 @@ class Ipm {
   DNLP_HD int begin(const double* x0_ctl) {
     double t_start = now_sec();
     if (!x) allocate();
+    lm_begin();
     const TapeView& T = md_->t;
     const double inf = opt.nlp_inf, brf = opt.bound_relax_factor;
     const bool warm = opt.warm_start != 0 && ws_mult_g != nullptr && ws_mult_xL != nullptr && ws_mult_xU != nullptr;
@@ -841,7 +1091,10 @@ class Ipm {
     const double *sS = Ss, *eq = eqmask;
     ex_->map(m, [=] DNLP_HD(i64 i) { dd[i] = dc + (eq[i] == 0.0 ? 1.0 / fmax(sS[i] + dw, 1e-20) : 0.0); });
     double t0 = now_sec();
-    bool ok = kkt_->assemble_factor(*md_, jv, Sx, Dd, fixmask, dw, &nneg, &nzero);
+    // (limited-memory mode: K0 carries the diagonal sigma I of the BFGS matrix; the low-rank part enters in kkt_solve)
+    double dwx = dw;
+    if constexpr (E::has_host_control) if (lm_on()) { dwx = dw + lm_->sigma; lm_->c_ready = false; }
+    bool ok = kkt_->assemble_factor(*md_, jv, Sx, Dd, fixmask, dwx, &nneg, &nzero);
     stats.t_factor += now_sec() - t0;
     stats.factorizations++;
     last_nneg_ = nneg;
@@ -864,7 +1117,7 @@ class Ipm {
       dw_first = dw_lb > 0.0 ? 1.05 * dw_lb + 0.02 * lbw.second : 0.0;
       have_lb = true;
     };
-    const bool use_lb = opt.lanczos_inertia_bound && !kkt_->pivoted && (N + m) >= opt.lanczos_min_n;
+    const bool use_lb = opt.lanczos_inertia_bound && !kkt_->pivoted && (N + m) >= opt.lanczos_min_n && !lm_on();
     auto attempt = [&](double dw, double dc) -> int {
       if (use_lb && have_lb && dw < dw_lb) { stats.skipped_factorizations++; return 1; }
       double t0 = now_sec();
@@ -950,7 +1203,9 @@ class Ipm {
 
   // K v for the reduced system at the current iterate (for iterative refinement)
   DNLP_HD void kkt_mult(const double* v, double dw, double* out) {
-    md_->hess_mult(v, out);
+    bool quasi = false;
+    if constexpr (E::has_host_control) if (lm_on()) { lm_hess_mult(v, out); quasi = true; }
+    if (!quasi) md_->hess_mult(v, out);
     md_->jac_tmult(jv, v + N, tN);
     md_->jac_mult(jv, v, tM);
     const double *sx = Sx, *jt = tN, *jx = tM, *dd = Dd, *fm = fixmask;
@@ -962,7 +1217,7 @@ class Ipm {
   // solve K sol = rhs with iterative refinement on the unfactored operator
   DNLP_HD bool solve_refined(double dw) {
     double t0 = now_sec();
-    kkt_->solve(rhs, sol);
+    kkt_solve(rhs, sol);
     const double* rr = rhs;
     double rn = ex_->max(N + m, [=] DNLP_HD(i64 i) { return fabs(rr[i]); });
     double best = kInf;
@@ -989,7 +1244,7 @@ class Ipm {
       if (it >= opt.min_refine && ratio <= 1e-10) break;
       if (en >= best * 0.999 && it >= opt.min_refine) break;   // no further progress
       best = std::min(best, en);
-      kkt_->solve(res, cor);
+      kkt_solve(res, cor);
       double* sw = sol;
       const double* co = cor;
       ex_->map(N + m, [=] DNLP_HD(i64 i) { sw[i] += co[i]; });
@@ -1152,6 +1407,7 @@ class Ipm {
     const bool want_oracle = update_mu(e0);
     // Hessian of the Lagrangian at (x, y)
     eval_hessian();
+    if constexpr (E::has_host_control) if (lm_on()) lm_save_point();
     barrier_terms(mu);
     double dw = 0.0, dc = 0.0;
     if (!factor_with_inertia(dw, dc)) return status = Error_In_Step_Computation;
@@ -1247,6 +1503,7 @@ class Ipm {
     if (!accepted) {
       if (opt.restoration && restoration_phase(theta_k)) {
         // restoration produced a new (x, s) acceptable to the filter; multipliers reset
+        if constexpr (E::has_host_control) if (lm_on()) lm_reset();
         ++iter;
         Err e = error(0.0);
         stats.iterations = iter;
@@ -1269,6 +1526,7 @@ class Ipm {
     const double* ddx = dx;
     double dnorm = ex_->max(N, [=] DNLP_HD(i64 j) { return fabs(ddx[j]); });
     accept_trial(alpha_used, a_z, f_t);
+    if constexpr (E::has_host_control) if (lm_on()) lm_update();
     ++iter;
     stats.iterations = iter;
     // Stall guard (deviation, feeds the retry ladder): forty consecutive accepted steps that each keep
@@ -1825,6 +2083,9 @@ class Ipm {
     in_solve_ = false;
     stats.wall = now_sec() - t_all;
     stats.final_mu = mu;
+    if constexpr (E::has_host_control)
+      if (lm_on()) logf("limited-memory quasi-Newton: %d pairs accepted, %d skipped, %d history resets; no second derivatives evaluated",
+                        lm_->updates, lm_->skips_total, lm_->resets);
     return status;
   }
 

@@ -36,6 +36,7 @@ struct DenseKkt {
   typename E::LdltWork lw;
   // sparse mode (sparse_plan.h / sparse_ldl.h): static-pattern LDL^T instead of the dense matrix
   bool sparse = false;
+  bool skip_hessian = false;   // limited-memory quasi-Newton mode (ipm_core.h): the Hessian block is the diagonal the caller passes
   SparsePlan sp;
   double* svals = nullptr;     // plan-layout values: assembled matrix, then (D, L)
   double* swork = nullptr;     // scratch of the numeric phase (sparse_ldl_work_doubles)
@@ -87,7 +88,7 @@ struct DenseKkt {
       const double* hs = md.Hs;
       const i64 NN = N;
       ex->zero(svals, sizeof(double) * static_cast<size_t>(sp.nvals));
-      ex->map(t.nnzH, [=] DNLP_HD(i64 p) {
+      if (!skip_hessian) ex->map(t.nnzH, [=] DNLP_HD(i64 p) {
         if (fixmask[hr[p]] != 0.0 || fixmask[hc[p]] != 0.0 || hp[p] < 0) return;
         V[hp[p]] += hs[p];
       });
@@ -105,14 +106,14 @@ struct DenseKkt {
     double* Kp = K;
     const i64 ldk = ld, NN = N;
     // one dense block covering all of W lets us skip the memset of the n x n part
-    bool full_block = t.nblk == 1 && t.blocks[0].n == N && N > 4096;
+    bool full_block = t.nblk == 1 && t.blocks[0].n == N && N > 4096 && !skip_hessian;
     if (!full_block) {
       ex->zero(K, sizeof(double) * static_cast<size_t>(ld) * static_cast<size_t>(n));
     } else {
       const i64 mm = m, nn = n;
       ex->map(mm * nn, [=] DNLP_HD(i64 q) { Kp[(NN + q % mm) + (q / mm) * ldk] = 0.0; });
     }
-    for (i64 k = 0; k < t.nblk; ++k) {
+    for (i64 k = 0; k < t.nblk && !skip_hessian; ++k) {
       const DenseBlock& B = t.blocks[k];
       const double* P = t.dense_ptr[B.cid];
       const i64 ldp = t.dense_ld[B.cid], nb = B.n, x0 = B.x0;
@@ -121,7 +122,7 @@ struct DenseKkt {
     }
     const i32 *hr = t.hess_rows, *hc = t.hess_cols, *jr = t.jac_rows, *jc = t.jac_cols;
     const double* hs = md.Hs;
-    ex->map(t.nnzH, [=] DNLP_HD(i64 p) {
+    if (!skip_hessian) ex->map(t.nnzH, [=] DNLP_HD(i64 p) {
       const i64 r = hr[p], c = hc[p];
       if (fixmask[r] != 0.0 || fixmask[c] != 0.0) return;
       Kp[r + c * ldk] += hs[p];

@@ -283,11 +283,9 @@ class HIPNLP:
             # 0 is silent and 5 prints the IPOPT-style iteration table
             options["print_level"] = 5 if verbose else 0
         handle = data["handle"]
-        if str(options.get("hessian_approximation", "exact")) == "limited-memory":
-            # IPOPT would run a quasi-Newton interior-point method; the tape always has the exact
-            # Hessian, so that is what runs — said out loud, not silently (stats[23] records it too)
-            warnings.warn("hessian_approximation='limited-memory': the exact tape Hessian is used "
-                          "(no quasi-Newton interior-point variant on the device).")
+        # hessian_approximation='limited-memory' (ipopt_nlpif.py:153-168 passes it to IPOPT): the quasi-Newton
+        # interior-point mode of csrc/ipm_core.h (BFGS pairs in compact form, no second derivatives); it lives in
+        # the host-driven loop, so the in-kernel loop is not taken for such a solve (_use_device_loop)
         intermediate = options.pop("intermediate_callback", None)
         algorithm = options.pop("algorithm", "interior-point")
         device_loop = options.pop("device_loop", "auto")
@@ -344,6 +342,8 @@ class HIPNLP:
     def _use_device_loop(self, data, options, mode) -> bool:
         if mode in (False, "no", "host") or data.get("_intermediate") is not None:
             return False                      # a per-iteration callback needs the host-driven loop
+        if str(options.get("hessian_approximation", "exact")) == "limited-memory":
+            return False                      # the quasi-Newton mode is the host-driven loop's
         tape = data["tape"]
         order = len(data["x0"]) + len(data["cl"])
         fits = not tape.dense_blocks and not tape.dense_consts

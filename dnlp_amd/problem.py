@@ -235,6 +235,8 @@ class Problem:
         solve_rows = getattr(chain.solver, "solve_batch_via_data", None)
         if solve_rows is None:
             return None
+        if str(opts.get("hessian_approximation", "exact")) == "limited-memory":
+            return None          # the quasi-Newton mode belongs to the host-driven loop: the starts run one by one
         from .batch import instance_data, same_structure
         lowered = []
         for run in range(best_of):
