@@ -271,6 +271,10 @@ int dnlp_lf_view(dnlp_linform* a, const int64_t** ptr, const int32_t** idx, cons
   return 0;
 }
 
+/* 1 when the dense n x n matrix (row-major, leading dimension ld) is exactly symmetric, else 0 (threads; the check of
+ * quad_form's constant — 800 MB at BASELINE C3 — was the largest single cost of that problem's lowering in numpy) */
+int dnlp_is_symmetric(const double* P, int64_t n, int64_t ld) { return dnlp::lm_is_symmetric(P, n, ld) ? 1 : 0; }
+
 struct dnlp_lowered { dnlp::LowerMapsOut out; };
 
 dnlp_lowered* dnlp_lower_maps(int64_t N, int64_t Z, int64_t m, int64_t nd, int64_t nh, const int64_t* G_ptr, const int32_t* G_idx,

@@ -13,6 +13,7 @@
 // the fallback and as the checker (tests/test_lower_maps.py compares every array); the results are identical.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <numeric>
@@ -68,6 +69,33 @@ inline void lm_par_for(lm_i64 n, lm_i64 grain, F f) {
   }
   f(static_cast<lm_i64>(0), std::min(n, per));
   for (auto& t : th) t.join();
+}
+
+// exact symmetry of a dense n x n matrix (leading dimension ld): 64 x 64 tiles against their mirrors, tile rows dealt
+// round-robin to the threads (the triangle's rows are not equally long); stops at the first difference
+inline bool lm_is_symmetric(const double* P, lm_i64 n, lm_i64 ld) {
+  const lm_i64 B = 64, nb = (n + B - 1) / B;
+  unsigned T = std::thread::hardware_concurrency();
+  if (T > 32) T = 32;
+  if (T < 1 || n < 512) T = 1;
+  std::atomic<int> bad{0};
+  auto work = [&](unsigned t) {
+    for (lm_i64 bi = t; bi < nb && !bad.load(std::memory_order_relaxed); bi += T) {
+      const lm_i64 i0 = bi * B, i1 = std::min(n, i0 + B);
+      for (lm_i64 bj = 0; bj <= bi; ++bj) {
+        const lm_i64 j0 = bj * B, j1 = std::min(n, j0 + B);
+        for (lm_i64 i = i0; i < i1; ++i) {
+          const double* row = P + i * ld;
+          for (lm_i64 j = j0; j < j1; ++j) if (row[j] != P[j * ld + i]) { bad.store(1, std::memory_order_relaxed); return; }
+        }
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  return bad.load() == 0;
 }
 
 // sorted unique keys of `keys` (int64) and, for every input key, its position among them

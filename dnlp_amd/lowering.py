@@ -743,10 +743,19 @@ class Lowerer:
 
 
 def _is_symmetric(P: np.ndarray) -> bool:
-    """Exact symmetry test, tile against mirrored tile (cache-sized, no n x n temporary).  (Memory-bound: 0.14 s
-    for BASELINE C3's 1e4 x 1e4 block; a thread pool over the tile rows measured no faster, and neither did a threaded
-    C++ tile loop on the build host: 0.19-0.25 s.)"""
+    """Exact symmetry test, tile against mirrored tile (cache-sized, no n x n temporary).  Large constants go to the
+    threaded tile loop behind the C ABI (dnlp_is_symmetric): BASELINE C3's 1e4 x 1e4 block 5-18 ms on the GPU box's
+    host against 62 ms for the numpy loop below (build host: 40 against 130 ms; tools/micro/sym_check_time.py) — it
+    was the largest single cost of that problem's lowering."""
     n, b = P.shape[0], 256
+    if n >= 1024 and P.dtype == np.float64 and P.flags.c_contiguous and os.environ.get("DNLP_LOWER_CXX", "1") != "0":
+        try:
+            from . import _capi
+            fn = _capi.load().lib.dnlp_is_symmetric
+            fn.argtypes = [C.POINTER(C.c_double), C.c_int64, C.c_int64]
+            return bool(fn(P.ctypes.data_as(C.POINTER(C.c_double)), n, n))
+        except Exception:
+            pass
     for i in range(0, n, b):
         for j in range(0, i + 1, b):
             if not np.array_equal(P[i:i + b, j:j + b], P[j:j + b, i:i + b].T):

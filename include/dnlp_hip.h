@@ -246,6 +246,9 @@ int dnlp_lf_export(dnlp_linform* a, int64_t* ptr, int32_t* idx, double* val, dou
  * constants share the matrix arrays) */
 int dnlp_lf_view(dnlp_linform* a, const int64_t** ptr, const int32_t** idx, const double** val, const double** b);
 
+/* exact symmetry of a dense row-major n x n constant (threads): 1 / 0 */
+int dnlp_is_symmetric(const double* P, int64_t n, int64_t ld);
+
 typedef struct dnlp_lowered dnlp_lowered;
 dnlp_lowered* dnlp_lower_maps(int64_t N, int64_t Z, int64_t m, int64_t nd, int64_t nh, const int64_t* G_ptr,
                               const int32_t* G_idx, const double* G_val, const double* c, const int64_t* drow,
