@@ -66,6 +66,7 @@ class CApi:
         f("eval_fused", C.c_int, [C.c_void_p, _dbl_p, _dbl_p, _dbl_p])
         f("set_warm_start", C.c_int, [C.c_void_p, _dbl_p, _dbl_p, _dbl_p])
         f("kkt_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)])
+        f("kkt_mode", C.c_int, [C.c_void_p])
         f("get_stats", C.c_int, [C.c_void_p, _dbl_p, C.c_int])
         f("get_log", C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t])
         f("set_intermediate_cb", C.c_int, [C.c_void_p, INTERMEDIATE_CB, C.c_void_p])
@@ -431,6 +432,14 @@ class ProblemHandle:
         return {"sparse": bool(out[0]), "factor_values": int(out[1]), "pivot_blocks": int(out[2]),
                 "max_struct": int(out[3]), "pairs_2x2": int(out[4]), "update_triples": int(out[5]),
                 "levels": int(out[6]), "dense_pivoted": bool(out[7])}
+
+    KKT_MODES = {-1: None, 0: "sparse", 1: "bunch-kaufman", 2: "unpivoted", 3: "paired", 4: "paired-then-bunch-kaufman"}
+
+    def kkt_mode(self):
+        """The handle's linear solver as it stands after the last solve (csrc/kkt_dense.h): 'sparse', 'bunch-kaufman',
+        'unpivoted' (blocked LDL^T), 'paired' (unpivoted on rotated static pairs), 'paired-then-bunch-kaufman' (the static
+        sequence lost digits on the way and the handle was demoted); None before the first solve."""
+        return self.KKT_MODES[int(self.api.kkt_mode(self.ptr))]
 
     def reset_options(self):
         self.api.reset_options(self.ptr)

@@ -30,6 +30,9 @@ struct ProblemT {
   std::shared_ptr<void> batch_state;   // exec-space specific batched-solve state (capi.hip)
   bool use_fused = true;
   bool lbfgs_device_loop = true;            // option lbfgs_device_loop=no keeps the host-driven L-BFGS loop
+  bool kkt_paired = true;                   // option kkt_paired: rotated static pairs + unpivoted LDL^T for dense patterns
+  i64 paired_min_n = 1024;                  // (below it the one-workgroup-panel Bunch-Kaufman costs 1-5 ms and never loses digits)
+  std::vector<double> plan_jabs;            // |Jacobian| at the start point (steers the static pairing)
   bool exact_hessian_substituted = false;   // hessian_approximation=limited-memory was requested
   int lbfgs_history = 10;
   IpmOptions opt;
@@ -96,11 +99,10 @@ struct ProblemT {
     const auto& t = *model.owner;
     const double n = static_cast<double>(t.N + t.m);
     if (linear_solver == 1 || t.nblk > 0 || t.ndense > 0 || n < 2) return;
-    const double pattern = static_cast<double>(t.nnzH + t.nnzJ) + n;
-    if (linear_solver == 0 && pattern > 0.1 * 0.5 * n * n) return;        // already dense
     // Jacobian magnitudes at the tape's start point steer the static 2x2 pairing away from
     // couplings that vanish there
-    std::vector<double> jabs(static_cast<size_t>(t.nnzJ), 0.0);
+    std::vector<double>& jabs = plan_jabs;
+    jabs.assign(static_cast<size_t>(t.nnzJ), 0.0);
     if (t.nnzJ > 0) {
       ex.h2d(dx, t.h_x0.data(), sizeof(double) * static_cast<size_t>(t.N));
       model.sweep(dx, false);
@@ -109,6 +111,8 @@ struct ProblemT {
       for (double& v : jabs) v = std::isfinite(v) ? std::fabs(v) : 0.0;
       swept = false;
     }
+    const double pattern = static_cast<double>(t.nnzH + t.nnzJ) + n;
+    if (linear_solver == 0 && pattern > 0.1 * 0.5 * n * n) return;        // already dense (the pairing alone: ensure_ipm)
     const double t_plan0 = now_sec();
     build_sparse_plan(t, sparse_plan, opt.bound_relax_factor > 0.0, &jabs);
     plan_seconds = now_sec() - t_plan0;
@@ -132,7 +136,24 @@ struct ProblemT {
         kkt.init_sparse(&ex, model.t.N, model.t.m, sparse_plan.upload(&ex));
         kkt.fallback_max_n = linear_solver == 2 ? 0 : 2048;      // forced sparse never falls back
       }
-      else kkt.init(&ex, model.t.N, model.t.m);
+      else {
+        // dense pattern with a static pairing: the rotated-pair unpivoted factorisation (kkt_dense.h) instead of
+        // Bunch-Kaufman, for orders where the chip-wide / host blocked LDL^T pays (option kkt_paired = no disables)
+        const auto& tp = *model.owner;
+        const i64 nn = tp.N + tp.m;
+        bool done = false;
+        if constexpr (E::has_host_control) {
+          if (kkt_paired && tp.nblk == 0 && tp.ndense == 0 && nn >= paired_min_n && nn <= 16384 && optimistic_min_n > nn) {
+            std::vector<i32> perm, pair_pos;
+            const double t0 = now_sec();
+            static_pivot_order(sparse_plan, nn, perm, pair_pos);
+            if (std::getenv("DNLP_TIME_PLAN"))
+              std::fprintf(stderr, "[dnlp] static pivot order: order %lld, %zu pairs, %.3f s on the host\n", (long long)nn, pair_pos.size(), now_sec() - t0);
+            if (!perm.empty() && !pair_pos.empty()) { kkt.init_paired(&ex, tp.N, tp.m, perm, pair_pos); done = true; }
+          }
+        }
+        if (!done) kkt.init(&ex, model.t.N, model.t.m);
+      }
       kkt_ready = true;
     }
     kkt.lw.time_updates = time_kernels;
@@ -201,6 +222,8 @@ struct ProblemT {
     else if (k == "warm_start_mult_bound_push") opt.warm_start_mult_bound_push = num();
     else if (k == "kkt_pivot_max_n") pivot_max_n = std::min<i64>(static_cast<i64>(num()), E::kPivotedMaxOrder);
     else if (k == "kkt_optimistic_min_n") optimistic_min_n = static_cast<i64>(num());
+    else if (k == "kkt_paired") kkt_paired = yes();
+    else if (k == "kkt_paired_min_n") paired_min_n = static_cast<i64>(num());
     else if (k == "lazy_dense_fallback") opt.lazy_dense_fallback = yes() ? 1 : 0;
     else if (k == "restoration") opt.restoration = yes() ? 1 : 0;
     else if (k == "time_kernels") time_kernels = yes();
@@ -413,6 +436,11 @@ struct ProblemT {
              out[5] = static_cast<int64_t>(p->sparse_plan.tdst.size());                                 \
              out[6] = static_cast<int64_t>(p->sparse_plan.lev_off.size()) - 1;                              \
              out[7] = (!p->use_sparse && p->model.t.N + p->model.t.m <= p->pivot_max_n) ? 1 : 0; return 0;)  \
+  }                                                                                                  \
+  int DNLP_CAT(PFX, kkt_mode)(HANDLE* vp) {                                                            \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    if (!p->kkt_ready) return -1;                                                                    \
+    return p->kkt.sparse ? 0 : p->kkt.paired ? 3 : p->kkt.paired_factorizations > 0 ? 4 : p->kkt.pivoted ? 1 : 2;                           \
   }                                                                                                  \
   int DNLP_CAT(PFX, get_stats)(HANDLE* vp, double* s, int n) {                                         \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \

@@ -33,6 +33,23 @@ struct DenseKkt {
   int optimistic_zero_streak = 0;   // consecutive delta_w = 0 attempts that met a zero pivot
   i64 optimistic_min_n = static_cast<i64>(1) << 40;   // off unless the option kkt_optimistic_min_n lowers it:
                                                       // nonconvex problems can reach another local optimum
+  // Paired mode (host-driven spaces, dense patterns whose static pairing exists; set up by init_paired): the matrix is
+  // assembled in the elimination order of the static analysis (sparse_plan.h: every equality row next to the variable
+  // it was matched with, blocks in an order whose pivots are structurally non-zero), every matched pair is rotated by
+  // Q = [[1, 1], [s, -s]] / sqrt(2) — the block [[w, a], [a, -d]] (zero diagonal for a variable without curvature and an
+  // unregularised row) becomes [[(w-d)/2 + s a, (w+d)/2], [(w+d)/2, (w-d)/2 - s a]], s chosen so that the first
+  // pivot is |w-d|/2 + |a| — and Q^T P K P^T Q is factorised WITHOUT pivoting by the blocked MFMA LDL^T: the same
+  // pivot blocks as the static 2x2 sequence of the sparse path, as two 1x1 steps each (same inertia: Q is orthogonal).
+  // 1.1 ms instead of 8.6 ms for Bunch-Kaufman at order 1472.  Two zero-pivot attempts with delta_w = 0 in a row
+  // switch the handle to Bunch-Kaufman for good, as in optimistic mode.
+  bool paired = false;
+  i64 npairs = 0;
+  int paired_factorizations = 0;
+  double paired_growth = 0.0, paired_growth_max = 1e8;   // largest |L| of the last paired factorisation / the demotion threshold
+  i32* pperm = nullptr;        // KKT index -> position in the permuted matrix
+  i32* ppos = nullptr;         // first position of every pair
+  double* psign = nullptr;     // s of the last factorisation's rotation, per pair
+  double* pvec = nullptr;      // permuted right-hand side / solution
   typename E::LdltWork lw;
   // sparse mode (sparse_plan.h / sparse_ldl.h): static-pattern LDL^T instead of the dense matrix
   bool sparse = false;
@@ -75,6 +92,67 @@ struct DenseKkt {
     }
     lw.padded = true;
     ex->ldlt_prepare(lw, n, ld, pivoted);
+  }
+
+  // perm[k] = position of KKT index k; pair_pos[q] = first position of pair q (host arrays)
+  void init_paired(E* e, i64 N_, i64 m_, const std::vector<i32>& perm, const std::vector<i32>& pair_pos) {
+    const i64 keep = pivot_max_n;
+    pivot_max_n = 0;                            // unpivoted factorisation of the rotated matrix
+    init(e, N_, m_);
+    pivot_max_n = keep;
+    paired = true;
+    optimistic = true;                          // (the zero-pivot streak rule ends the mode)
+    npairs = static_cast<i64>(pair_pos.size());
+    pperm = ex->template alloc<i32>(static_cast<size_t>(n));
+    ppos = ex->template alloc<i32>(static_cast<size_t>(npairs > 0 ? npairs : 1));
+    psign = ex->template alloc<double>(static_cast<size_t>(npairs > 0 ? npairs : 1));
+    pvec = ex->template alloc<double>(static_cast<size_t>(n));
+    ex->h2d(pperm, perm.data(), sizeof(i32) * static_cast<size_t>(n));
+    if (npairs) ex->h2d(ppos, pair_pos.data(), sizeof(i32) * static_cast<size_t>(npairs));
+  }
+
+  // Q^T (P K P^T) Q in place on the lower triangle: the diagonal blocks (and the sign choice), then the rows of every
+  // pair left of its block, then the columns below it — pairs own disjoint rows / columns, so a pass has no conflicts
+  DNLP_HD void rotate_pairs() {
+    double* Kp = K;
+    const i64 ldk = ld, nn = n, np = npairs;
+    const i32* pos = ppos;
+    double* sg = psign;
+    const double r2 = 0.70710678118654752440;
+    ex->map(np, [=] DNLP_HD(i64 q) {
+      const i64 p = pos[q];
+      const double w = Kp[p + p * ldk], a = Kp[(p + 1) + p * ldk], e = Kp[(p + 1) + (p + 1) * ldk];
+      // a diagonal that dominates the coupling is a good 1x1 pivot as it stands (Bunch-Kaufman's test with the
+      // coupling as the only off-diagonal candidate): no rotation — with a large delta_w the rotated block would
+      // compute its second pivot -2|a| as a difference of two numbers of size delta_w / 2
+      if (fabs(w) >= 0.6403882032022076 * fabs(a)) { sg[q] = 0.0; return; }
+      const double sa = a < 0.0 ? -1.0 : 1.0;
+      const double s = (w + e >= 0.0) ? sa : -sa;
+      sg[q] = s;
+      Kp[p + p * ldk] = 0.5 * (w + e) + s * a;
+      Kp[(p + 1) + (p + 1) * ldk] = 0.5 * (w + e) - s * a;
+      Kp[(p + 1) + p * ldk] = 0.5 * (w - e);
+    });
+    // rows p, p + 1 over the columns c < p   (one lane per (pair, column); pairs sit early in the order, p is small on average)
+    ex->map(np * nn, [=] DNLP_HD(i64 t) {
+      const i64 q = t / nn, c = t % nn, p = pos[q];
+      if (c >= p) return;
+      const double s = sg[q];
+      if (s == 0.0) return;
+      const double v1 = Kp[p + c * ldk], v2 = Kp[(p + 1) + c * ldk];
+      Kp[p + c * ldk] = r2 * (v1 + s * v2);
+      Kp[(p + 1) + c * ldk] = r2 * (v1 - s * v2);
+    });
+    // columns p, p + 1 over the rows r > p + 1
+    ex->map(np * nn, [=] DNLP_HD(i64 t) {
+      const i64 q = t / nn, r = t % nn, p = pos[q];
+      if (r <= p + 1) return;
+      const double s = sg[q];
+      if (s == 0.0) return;
+      const double u1 = Kp[r + p * ldk], u2 = Kp[r + (p + 1) * ldk];
+      Kp[r + p * ldk] = r2 * (u1 + s * u2);
+      Kp[r + (p + 1) * ldk] = r2 * (u1 - s * u2);
+    });
   }
 
   // Assemble from the model's current Hessian (Hs + dense blocks) and factor.
@@ -122,6 +200,31 @@ struct DenseKkt {
     }
     const i32 *hr = t.hess_rows, *hc = t.hess_cols, *jr = t.jac_rows, *jc = t.jac_cols;
     const double* hs = md.Hs;
+    bool placed = false;
+    if constexpr (E::has_host_control) if (paired) {
+      placed = true;
+      // the same entries at their permuted positions (lower triangle of P K P^T)
+      const i32* pm = pperm;
+      if (!skip_hessian) ex->map(t.nnzH, [=] DNLP_HD(i64 p) {
+        const i64 r = hr[p], c = hc[p];
+        if (fixmask[r] != 0.0 || fixmask[c] != 0.0) return;
+        const i64 a = pm[r], b = pm[c];
+        Kp[(a > b ? a : b) + (a > b ? b : a) * ldk] += hs[p];
+      });
+      ex->map(t.nnzJ, [=] DNLP_HD(i64 p) {
+        if (fixmask[jc[p]] != 0.0) return;
+        const i64 a = pm[NN + jr[p]], b = pm[jc[p]];
+        Kp[(a > b ? a : b) + (a > b ? b : a) * ldk] = jv[p];
+      });
+      ex->map(N, [=] DNLP_HD(i64 j) {
+        const i64 a = pm[j];
+        if (fixmask[j] != 0.0) Kp[a + a * ldk] = 1.0;
+        else Kp[a + a * ldk] += Sx[j] + dw;
+      });
+      ex->map(m, [=] DNLP_HD(i64 i) { const i64 a = pm[NN + i]; Kp[a + a * ldk] = -D[i]; });
+      rotate_pairs();
+    }
+    if (!placed) {
     if (!skip_hessian) ex->map(t.nnzH, [=] DNLP_HD(i64 p) {
       const i64 r = hr[p], c = hc[p];
       if (fixmask[r] != 0.0 || fixmask[c] != 0.0) return;
@@ -136,6 +239,7 @@ struct DenseKkt {
       else Kp[j + j * ldk] += Sx[j] + dw;
     });
     ex->map(m, [=] DNLP_HD(i64 i) { Kp[(NN + i) + (NN + i) * ldk] = -D[i]; });
+    }
     if (n_fixed > 0 && t.nblk > 0) {
       // fixed variables (lb == ub) inside a dense block: pin them (unit row / column)
       for (i64 kb = 0; kb < t.nblk; ++kb) {
@@ -154,10 +258,33 @@ struct DenseKkt {
       // one such attempt is tolerated (at the start the multipliers are zero and variables that only
       // occur in nonlinear constraints have no curvature yet: delta_w handles that iteration)
       if (optimistic && dw == 0.0) optimistic_zero_streak = (!ok || *nzero > 0) ? optimistic_zero_streak + 1 : 0;
-      if (optimistic && dw == 0.0 && optimistic_zero_streak >= 2) {
+      // paired mode is stricter: its pivots are static, so a zero pivot later than the first two factorisations (where
+      // multipliers are still zero) means a coupling of a pair has vanished at this iterate — Bunch-Kaufman picks
+      // another partner there, a static sequence cannot.  The handle is demoted at once and the attempt repeated.
+      bool demote = false;
+      if (paired) {
+        ++paired_factorizations;
+        if (dw == 0.0 && (!ok || *nzero > 0) && paired_factorizations > 2) demote = true;
+        // element growth: Bunch-Kaufman keeps |L| below 1 / alpha + 1 by choosing its pivots; a static sequence whose
+        // multipliers reach 1e8 has lost half the digits of the Schur complement and its inertia count with them
+        if (ok && !demote) {
+          const double* Kp2 = K;
+          const i64 ldk2 = ld, nn2 = n;
+          const double g = ex->max(nn2 * nn2, [=] DNLP_HD(i64 q) {
+            const i64 r = q % nn2, c = q / nn2;
+            return r > c ? fabs(Kp2[r + c * ldk2]) : 0.0; });
+          paired_growth = g;
+          if (!(g <= paired_growth_max)) demote = true;
+#if !DNLP_DEVICE_PASS
+          if (std::getenv("DNLP_PAIRED_DEBUG")) std::fprintf(stderr, "[paired] factorisation %d delta_w %.2e: nneg %d nzero %d max|L| %.3e%s\n", paired_factorizations, dw, *nneg, *nzero, g, demote ? " -> Bunch-Kaufman from here on" : "");
+#endif
+        }
+      }
+      if (demote || (optimistic && dw == 0.0 && optimistic_zero_streak >= 2)) {
         optimistic = false;
-        pivoted = true;
-        ex->ldlt_prepare(lw, n, ld, true);
+        paired = false;
+        pivoted = n <= pivot_max_n;
+        ex->ldlt_prepare(lw, n, ld, pivoted);
         return assemble_factor(md, jv, Sx, D, fixmask, dw, nneg, nzero);
       }
     }
@@ -167,6 +294,31 @@ struct DenseKkt {
   DNLP_HD void solve(const double* rhs, double* sol) {
     if (sol != rhs) ex->d2d(sol, rhs, sizeof(double) * static_cast<size_t>(n));
     if (sparse) { ex->sparse_solve(sp, svals, sol); return; }
+    if constexpr (E::has_host_control) if (paired) {
+      // b~ = Q^T P b;  K~ y = b~;  x = P^T Q y
+      double* v = pvec;
+      const i32 *pm = pperm, *pos = ppos;
+      const double* sg = psign;
+      const double r2 = 0.70710678118654752440;
+      ex->map(n, [=] DNLP_HD(i64 k) { v[pm[k]] = sol[k]; });
+      ex->map(npairs, [=] DNLP_HD(i64 q) {
+        const i64 p = pos[q];
+        const double s = sg[q], a = v[p], b = v[p + 1];
+        if (s == 0.0) return;
+        v[p] = r2 * (a + s * b);
+        v[p + 1] = r2 * (a - s * b);
+      });
+      ex->ldlt_solve(lw, K, n, ld, ipiv, false, v);
+      ex->map(npairs, [=] DNLP_HD(i64 q) {
+        const i64 p = pos[q];
+        const double s = sg[q], a = v[p], b = v[p + 1];
+        if (s == 0.0) return;
+        v[p] = r2 * (a + b);
+        v[p + 1] = r2 * s * (a - b);
+      });
+      ex->map(n, [=] DNLP_HD(i64 k) { sol[k] = v[pm[k]]; });
+      return;
+    }
     ex->ldlt_solve(lw, K, n, ld, ipiv, pivoted, sol);
   }
 };

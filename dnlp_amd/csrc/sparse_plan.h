@@ -563,4 +563,24 @@ inline void build_sparse_plan(const Tape<E>& t, SparsePlanHost& plan, bool bound
   plan.layout(t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, fixed);
 }
 
+// The pivot blocks of a built plan in elimination order (kkt_dense.h paired mode: a dense matrix assembled in this order
+// has every matched pair adjacent and no structurally zero pivot).  Empty when no plan was built (a pattern that is
+// dense to begin with: its minimum-degree analysis alone would cost more than the factorisations it saves).
+inline void static_pivot_order(const SparsePlanHost& plan, i64 n, std::vector<i32>& perm, std::vector<i32>& pair_pos) {
+  perm.clear();
+  pair_pos.clear();
+  if (plan.nblk() <= 0 || static_cast<i64>(plan.bnode.size()) != 2 * plan.nblk() || plan.n != n) return;
+  perm.assign(static_cast<size_t>(n), -1);
+  i32 pos = 0;
+  for (i64 k = 0; k < plan.nblk(); ++k) {
+    const i32 u0 = plan.bnode[static_cast<size_t>(2 * k)], u1 = plan.bnode[static_cast<size_t>(2 * k + 1)];
+    if (u1 >= 0) pair_pos.push_back(pos);
+    perm[static_cast<size_t>(u0)] = pos++;
+    if (u1 >= 0) perm[static_cast<size_t>(u1)] = pos++;
+  }
+  bool ok = pos == n;
+  for (i64 k = 0; k < n && ok; ++k) ok = perm[static_cast<size_t>(k)] >= 0;
+  if (!ok) { perm.clear(); pair_pos.clear(); }
+}
+
 }  // namespace dnlp

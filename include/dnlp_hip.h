@@ -190,6 +190,10 @@ int dnlp_set_warm_start(dnlp_problem* p, const double* mult_g, const double* mul
  * factorisation (order <= kkt_pivot_max_n; the device space accepts at most 4096 there) (8 values).
  * `dnlp_set_option(p, "linear_solver", "dense" | "sparse")` forces a path before the first solve. */
 int dnlp_kkt_info(dnlp_problem* p, int64_t* out8);
+/* linear solver of the handle as it stands (it can change during a solve): -1 not chosen yet (no solve so far), 0 sparse
+ * static-pattern LDL^T, 1 dense Bunch-Kaufman, 2 dense unpivoted blocked LDL^T, 3 dense unpivoted on rotated static pairs,
+ * 4 started as 3 and was handed to Bunch-Kaufman (element growth / zero pivot of the static sequence) */
+int dnlp_kkt_mode(dnlp_problem* p);
 /* Statistics (n <= 24 values).  Of the last solve: stats[0..12] = iterations, factorizations, wall,
  * t_eval, t_factor, t_solve, mu, inf_pr, inf_du, compl, nlp_error, last_delta_w, objective scaling;
  * [13..15] = seconds, flops, launches of the timed outer Schur-complement updates (option

@@ -17,8 +17,10 @@ from paper_examples import PAPER, PAPER_LARGE, PUBLISHED  # noqa: E402
 
 ALL = dict(PAPER)
 ALL.update(PAPER_LARGE)
-if len(sys.argv) > 1:                              # python tools/run_paper_examples.py nb_phase_retrieval ...
-    ALL = {k: v for k, v in ALL.items() if k in sys.argv[1:]}
+EXTRA = dict(a.split("=", 1) for a in sys.argv[1:] if "=" in a)     # solver options for every example: kkt_paired=no ...
+NAMES = [a for a in sys.argv[1:] if "=" not in a]
+if NAMES:                                          # python tools/run_paper_examples.py nb_phase_retrieval ...
+    ALL = {k: v for k, v in ALL.items() if k in NAMES}
 rows = []
 for name in sorted(ALL):
     pub = PUBLISHED.get(name, {})
@@ -35,6 +37,7 @@ for name in sorted(ALL):
         t0 = time.time()
         opts = dict(pub.get("options", {}))
         opts["time_kernels"] = "yes"
+        opts.update(EXTRA)
         info = chain.solver.solve_via_data(data, True, False, opts)
         t_solve = time.time() - t0
         t0 = time.time()
@@ -55,4 +58,4 @@ for name in sorted(ALL):
     rows.append(row)
     print(json.dumps(row))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "paper_examples.json"), "w"), indent=1)
+json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "paper_examples%s.json" % ("_" + "_".join(sorted(EXTRA.values())) if EXTRA else "")), "w"), indent=1)
