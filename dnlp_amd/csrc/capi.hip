@@ -33,7 +33,20 @@ static BatchRunner* batch_runner(dnlp_problem_t* p) {
     std::shared_ptr<void> hold(r, [](void* q) { delete static_cast<BatchRunner*>(q); });
     r->init(&p->ex, p->model.owner);
     p->plan_linear_solver();
-    if (p->use_sparse) { r->set_sparse_plan(p->sparse_plan); r->force_sparse = p->linear_solver == 2; }
+    if (p->use_sparse) {
+      if (p->sparse_plan.panels_dropped) {
+        // the handle's plan was built for the dense tail of the host-driven loop: its panel blocks carry no tail x tail
+        // triples.  The in-kernel solver needs the whole update program: a second analysis, without the tail.
+        if (!p->batch_plan_full) {
+          p->batch_plan_full.reset(new dnlp::SparsePlanHost());
+          dnlp::build_sparse_plan(*p->model.owner, *p->batch_plan_full, p->opt.bound_relax_factor > 0.0, p->plan_jabs.empty() ? nullptr : &p->plan_jabs, false);
+        }
+        r->set_sparse_plan(*p->batch_plan_full);
+      } else {
+        r->set_sparse_plan(p->sparse_plan);
+      }
+      r->force_sparse = p->linear_solver == 2;
+    }
     p->batch_state = hold;
   }
   return static_cast<BatchRunner*>(p->batch_state.get());

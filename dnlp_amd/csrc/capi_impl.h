@@ -30,8 +30,11 @@ struct ProblemT {
   std::shared_ptr<void> batch_state;   // exec-space specific batched-solve state (capi.hip)
   bool use_fused = true;
   bool lbfgs_device_loop = true;            // option lbfgs_device_loop=no keeps the host-driven L-BFGS loop
+  bool sparse_tail = true;                  // option sparse_dense_tail: the chain of one-block levels over a dense separator
+                                            // is factorised as a dense matrix (sparse_plan.h: choose_tail)
   bool kkt_paired = true;                   // option kkt_paired: rotated static pairs + unpivoted LDL^T for dense patterns
   i64 paired_min_n = 1024;                  // (below it the one-workgroup-panel Bunch-Kaufman costs 1-5 ms and never loses digits)
+  std::unique_ptr<SparsePlanHost> batch_plan_full;   // (capi.hip batch_runner: a full plan when sparse_plan has a dense tail)
   std::vector<double> plan_jabs;            // |Jacobian| at the start point (steers the static pairing)
   bool exact_hessian_substituted = false;   // hessian_approximation=limited-memory was requested
   int lbfgs_history = 10;
@@ -98,7 +101,7 @@ struct ProblemT {
     use_sparse = false;
     const auto& t = *model.owner;
     const double n = static_cast<double>(t.N + t.m);
-    if (linear_solver == 1 || t.nblk > 0 || t.ndense > 0 || n < 2) return;
+    if (t.nblk > 0 || t.ndense > 0 || n < 2) return;
     // Jacobian magnitudes at the tape's start point steer the static 2x2 pairing away from
     // couplings that vanish there
     std::vector<double>& jabs = plan_jabs;
@@ -114,7 +117,7 @@ struct ProblemT {
     const double pattern = static_cast<double>(t.nnzH + t.nnzJ) + n;
     if (linear_solver == 0 && pattern > 0.1 * 0.5 * n * n) return;        // already dense (the pairing alone: ensure_ipm)
     const double t_plan0 = now_sec();
-    build_sparse_plan(t, sparse_plan, opt.bound_relax_factor > 0.0, &jabs);
+    build_sparse_plan(t, sparse_plan, opt.bound_relax_factor > 0.0, &jabs, E::has_host_control && sparse_tail);
     plan_seconds = now_sec() - t_plan0;
     if (std::getenv("DNLP_TIME_PLAN"))
       std::fprintf(stderr, "[dnlp] sparse plan: order %.0f, %zu triples, fill ratio %.4f, %.3f s on the host\n", n,
@@ -125,6 +128,7 @@ struct ProblemT {
     const double triples = static_cast<double>(sparse_plan.tdst.size());
     use_sparse = linear_solver == 2 ||
                  (sparse_plan.fill_ratio <= 0.3 && (triples <= 4e5 || triples * 1000.0 <= n * n * n / 3.0));
+    if (linear_solver == 1) use_sparse = false;      // forced dense (the plan still serves the static pairing of kkt_dense.h)
   }
 
   void ensure_ipm() {
@@ -133,7 +137,7 @@ struct ProblemT {
       kkt.pivot_max_n = pivot_max_n;
       kkt.optimistic_min_n = optimistic_min_n;
       if (use_sparse) {
-        kkt.init_sparse(&ex, model.t.N, model.t.m, sparse_plan.upload(&ex));
+        kkt.init_sparse(&ex, model.t.N, model.t.m, sparse_plan.upload(&ex, sparse_plan.tail_n > 0));
         kkt.fallback_max_n = linear_solver == 2 ? 0 : 2048;      // forced sparse never falls back
       }
       else {
@@ -223,6 +227,7 @@ struct ProblemT {
     else if (k == "kkt_pivot_max_n") pivot_max_n = std::min<i64>(static_cast<i64>(num()), E::kPivotedMaxOrder);
     else if (k == "kkt_optimistic_min_n") optimistic_min_n = static_cast<i64>(num());
     else if (k == "kkt_paired") kkt_paired = yes();
+    else if (k == "sparse_dense_tail") sparse_tail = yes();
     else if (k == "kkt_paired_min_n") paired_min_n = static_cast<i64>(num());
     else if (k == "lazy_dense_fallback") opt.lazy_dense_fallback = yes() ? 1 : 0;
     else if (k == "restoration") opt.restoration = yes() ? 1 : 0;

@@ -1257,6 +1257,14 @@ __global__ void __launch_bounds__(kBlock) sp_update_kernel(SparsePlan pl, double
   const i64 q = t0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
   if (q < t1) unsafeAtomicAdd(&vals[pl.tdst[q]], -sp_update(pl, vals, w, q));
 }
+// tail rows of a level's panel blocks into the two dense panels (l and w = l D^-1)
+__global__ void __launch_bounds__(kBlock) sp_panel_gather_kernel(SparsePlan pl, const double* vals, const double* w, double* Pl, double* Pw,
+                                                                 i64 q0, i64 q1) {
+  const i64 q = q0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+  if (q >= q1) return;
+  Pl[pl.pg_dst[q]] = vals[pl.pg_src[q]];
+  Pw[pl.pg_dst[q]] = w[pl.pg_src[q]];
+}
 __global__ void __launch_bounds__(kBlock) sp_store_kernel(double* vals, const double* w, i64 v0, i64 v1) {
   const i64 a = v0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
   if (a < v1) vals[a] = w[a];
@@ -1269,7 +1277,7 @@ __global__ void __launch_bounds__(kBlock) sp_fwd_kernel(SparsePlan pl, const dou
 }
 __global__ void __launch_bounds__(kBlock) sp_dsolve_kernel(SparsePlan pl, const double* vals, double* x) {
   const i64 k = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
-  if (k < pl.nblk) sp_dsolve(pl, vals, x, k);
+  if (k < pl.nblk_run) sp_dsolve(pl, vals, x, k);
 }
 // backward: one wavefront per block of the level (shuffle reduction over the block's struct)
 __global__ void __launch_bounds__(kBlock) sp_bwd_kernel(SparsePlan pl, const double* vals, double* x, i64 b0, i64 b1) {
@@ -1572,6 +1580,7 @@ struct HipExec : HostControlled {
     level_graphs_.push_back(LevelGraph{k0, k1, k2, kind, exec});
     DNLP_HIP_CHECK(hipGraphLaunch(exec, stream));
   }
+  void sparse_tail_gemm(double* T, i64 ldt, const double* Pl, const double* Pw, int r, int cols);   // ldlt_blocked.h kernels
   bool sparse_factor(const SparsePlan& pl, double* vals, double* w, int* nneg, int* nzero) {
     if (!sparse_info) { sparse_info = alloc<SparseInfo>(1); }
     auto grid = [](i64 items) { return dim3(static_cast<unsigned>((items + kBlock - 1) / kBlock)); };
@@ -1581,9 +1590,13 @@ struct HipExec : HostControlled {
     } else {
       double* dinv = w + pl.nvals;
       SparseInfo* info = sparse_info;
+      double* Tacc = w + sparse_ldl_tail_acc_offset(pl);
+      double* Pl = Tacc + pl.tail_ld * pl.tail_n;
+      double* Pw = Pl + pl.tail_ld * pl.pg_maxcols;
       replay_levels(0, pl.soff, vals, w, [&] {
         hipLaunchKernelGGL(sp_info_reset_kernel, dim3(1), dim3(1), 0, stream, info);
-        for (i64 lev = 0; lev < pl.nlev; ++lev) {
+        if (pl.tail_n > 0) DNLP_HIP_CHECK(hipMemsetAsync(Tacc, 0, sizeof(double) * static_cast<size_t>(pl.tail_ld * pl.tail_n), stream));
+        for (i64 lev = 0; lev < pl.nlev_run; ++lev) {
           const i64 b0 = pl.h_lev_blk[lev], b1 = pl.h_lev_blk[lev + 1], r0 = pl.h_lev_row[lev], r1 = pl.h_lev_row[lev + 1];
           const i64 t0 = pl.h_lev_trip[lev], t1 = pl.h_lev_trip[lev + 1], v0 = pl.h_lev_val[lev], v1 = pl.h_lev_val[lev + 1];
           if (level_fusion_ && (t1 - t0) <= 40 * (b1 - b0) && (r1 - r0) <= 8 * (b1 - b0)) {
@@ -1592,6 +1605,13 @@ struct HipExec : HostControlled {
           }
           hipLaunchKernelGGL(sp_pivot_kernel, grid(b1 - b0), dim3(kBlock), 0, stream, pl, vals, dinv, b0, b1, info);
           if (r1 > r0) hipLaunchKernelGGL(sp_scale_kernel, grid(r1 - r0), dim3(kBlock), 0, stream, pl, vals, w, dinv, r0, r1);
+          if (pl.tail_n > 0 && pl.h_pg_cols[lev] > 0) {
+            // the level's panel blocks: T -= Pl Pw^T on the FP64 MFMA kernel (lower triangle, tail_n x tail_n x cols)
+            const i64 cols = pl.h_pg_cols[lev], q0 = pl.h_pg_off[lev], q1 = pl.h_pg_off[lev + 1];
+            DNLP_HIP_CHECK(hipMemsetAsync(Pl, 0, sizeof(double) * static_cast<size_t>(2 * pl.tail_ld * pl.pg_maxcols), stream));
+            hipLaunchKernelGGL(sp_panel_gather_kernel, grid(q1 - q0), dim3(kBlock), 0, stream, pl, vals, w, Pl, Pw, q0, q1);
+            sparse_tail_gemm(Tacc, pl.tail_ld, Pl, Pw, static_cast<int>(pl.tail_n), static_cast<int>(cols));
+          }
           if (t1 > t0) hipLaunchKernelGGL(sp_update_kernel, grid(t1 - t0), dim3(kBlock), 0, stream, pl, vals, w, t0, t1);
           if (v1 > v0) hipLaunchKernelGGL(sp_store_kernel, grid(v1 - v0), dim3(kBlock), 0, stream, vals, w, v0, v1);
         }
@@ -1610,13 +1630,15 @@ struct HipExec : HostControlled {
     if (!sparse_grid_path(pl)) {
       hipLaunchKernelGGL(sparse_solve_kernel, dim3(1), dim3(kBlock), 0, stream, pl, vals, x);
     } else {
-      replay_levels(1, pl.soff, vals, x, [&] {
-        for (i64 lev = 0; lev < pl.nlev; ++lev) {
-          const i64 r0 = pl.h_lev_row[lev], r1 = pl.h_lev_row[lev + 1];
-          if (r1 > r0) hipLaunchKernelGGL(sp_fwd_kernel, grid(r1 - r0), dim3(kBlock), 0, stream, pl, vals, x, r0, r1);
+      replay_levels(1 + 2 * pl.solve_phase, pl.soff, vals, x, [&] {
+        if (pl.solve_phase != 2) {
+          for (i64 lev = 0; lev < pl.nlev_run; ++lev) {
+            const i64 r0 = pl.h_lev_row[lev], r1 = pl.h_lev_row[lev + 1];
+            if (r1 > r0) hipLaunchKernelGGL(sp_fwd_kernel, grid(r1 - r0), dim3(kBlock), 0, stream, pl, vals, x, r0, r1);
+          }
+          hipLaunchKernelGGL(sp_dsolve_kernel, grid(pl.nblk_run), dim3(kBlock), 0, stream, pl, vals, x);
         }
-        hipLaunchKernelGGL(sp_dsolve_kernel, grid(pl.nblk), dim3(kBlock), 0, stream, pl, vals, x);
-        for (i64 lev = pl.nlev - 1; lev >= 0; --lev) {
+        for (i64 lev = pl.solve_phase == 1 ? -1 : pl.nlev_run - 1; lev >= 0; --lev) {
           const i64 b0 = pl.h_lev_blk[lev], b1 = pl.h_lev_blk[lev + 1];
           if (pl.h_lev_row[lev + 1] == pl.h_lev_row[lev]) continue;       // root blocks: empty structs
           // average struct length of the level decides: a wavefront per block only pays for long structs

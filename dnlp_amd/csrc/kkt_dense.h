@@ -51,6 +51,13 @@ struct DenseKkt {
   double* psign = nullptr;     // s of the last factorisation's rotation, per pair
   double* pvec = nullptr;      // permuted right-hand side / solution
   typename E::LdltWork lw;
+  // dense tail of a sparse plan (init_sparse)
+  double* Kt = nullptr;
+  double* tail_x = nullptr;
+  i32* tail_ipiv = nullptr;
+  i64 tail_ld = 0;
+  bool tail_pivoted = true;
+  typename E::LdltWork tail_lw;
   // sparse mode (sparse_plan.h / sparse_ldl.h): static-pattern LDL^T instead of the dense matrix
   bool sparse = false;
   bool skip_hessian = false;   // limited-memory quasi-Newton mode (ipm_core.h): the Hessian block is the diagonal the caller passes
@@ -76,6 +83,19 @@ struct DenseKkt {
     sp = plan;
     svals = ex->template alloc<double>(static_cast<size_t>(sp.nvals > 0 ? sp.nvals : 1));
     swork = ex->template alloc<double>(static_cast<size_t>(sparse_ldl_work_doubles(sp)));
+    if constexpr (E::has_host_control) {
+      if (sp.tail_n > 0) {
+        // the dense tail of the plan (sparse_plan.h): its own matrix, factorised by the dense path — Bunch-Kaufman
+        // up to pivot_max_n (more robust than the static sequence it replaces), the blocked LDL^T above
+        tail_ld = (sp.tail_n + 7) / 8 * 8;
+        Kt = ex->template alloc<double>(static_cast<size_t>(tail_ld) * static_cast<size_t>(sp.tail_n) + 256);
+        tail_ipiv = ex->template alloc<i32>(static_cast<size_t>(sp.tail_n));
+        tail_x = ex->template alloc<double>(static_cast<size_t>(sp.tail_n));
+        tail_pivoted = sp.tail_n <= pivot_max_n;
+        tail_lw.padded = true;
+        ex->ldlt_prepare(tail_lw, sp.tail_n, tail_ld, tail_pivoted);
+      }
+    }
   }
 
   DNLP_HD void init(E* e, i64 N_, i64 m_) {
@@ -179,7 +199,28 @@ struct DenseKkt {
         else V[dp[j]] += Sx[j] + dw;
       });
       ex->map(m, [=] DNLP_HD(i64 i) { V[dp[NN + i]] = -D[i]; });
-      return ex->sparse_factor(sp, svals, swork, nneg, nzero);
+      bool oks = ex->sparse_factor(sp, svals, swork, nneg, nzero);
+      if constexpr (E::has_host_control) {
+        if (sp.tail_n > 0 && oks) {
+          double* T = Kt;
+          const double* sv = svals;
+          const i32 *src = sp.tg_src, *dst = sp.tg_dst;
+          const i64 r = sp.tail_n, ldt = tail_ld;
+          ex->zero(Kt, sizeof(double) * static_cast<size_t>(ldt) * static_cast<size_t>(r));
+          ex->map(sp.tg_count, [=] DNLP_HD(i64 q) { const i64 d = dst[q]; T[d % r + (d / r) * ldt] = sv[src[q]]; });
+          if (sp.pg_maxcols > 0) {
+            // + what the panel blocks of the levels before the tail contributed (sparse_ldl.h: T -= Pl Pw^T)
+            const double* acc = swork + sparse_ldl_tail_acc_offset(sp);
+            ex->map(r * r, [=] DNLP_HD(i64 e) { const i64 u = e % r, v = e / r; if (u >= v) T[u + v * ldt] += acc[u + v * ldt]; });
+          }
+          int nn2 = 0, nz2 = 0;
+          tail_lw.expect_neg = -1;
+          oks = ex->ldlt_factor(tail_lw, Kt, r, ldt, tail_ipiv, tail_pivoted, &nn2, &nz2);
+          *nneg += nn2;
+          *nzero += nz2;
+        }
+      }
+      return oks;
     }
     double* Kp = K;
     const i64 ldk = ld, NN = N;
@@ -293,7 +334,27 @@ struct DenseKkt {
 
   DNLP_HD void solve(const double* rhs, double* sol) {
     if (sol != rhs) ex->d2d(sol, rhs, sizeof(double) * static_cast<size_t>(n));
-    if (sparse) { ex->sparse_solve(sp, svals, sol); return; }
+    if (sparse) {
+      bool tail_done = false;
+      if constexpr (E::has_host_control) {
+        if (sp.tail_n > 0) {
+          // levels before the tail forward (+ D^-1), the tail by its dense factor, then the same levels backward
+          SparsePlan ph = sp;
+          ph.solve_phase = 1;
+          ex->sparse_solve(ph, svals, sol);
+          double* tx = tail_x;
+          const i32* tn = sp.tnode;
+          ex->map(sp.tail_n, [=] DNLP_HD(i64 j) { tx[j] = sol[tn[j]]; });
+          ex->ldlt_solve(tail_lw, Kt, sp.tail_n, tail_ld, tail_ipiv, tail_pivoted, tail_x);
+          ex->map(sp.tail_n, [=] DNLP_HD(i64 j) { sol[tn[j]] = tx[j]; });
+          ph.solve_phase = 2;
+          ex->sparse_solve(ph, svals, sol);
+          tail_done = true;
+        }
+      }
+      if (!tail_done) ex->sparse_solve(sp, svals, sol);
+      return;
+    }
     if constexpr (E::has_host_control) if (paired) {
       // b~ = Q^T P b;  K~ y = b~;  x = P^T Q y
       double* v = pvec;

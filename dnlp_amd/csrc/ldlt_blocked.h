@@ -1558,6 +1558,18 @@ inline bool HipExec::condensed_ls(i64 N, i64 m, i64 nnzJ, const i32* jr, const i
   return true;
 }
 
+// T (r x r, lower triangle) -= Pl Pw^T with Pl, Pw of r x cols (all with leading dimension ldt): the dense-tail update
+// of a level of the static-pattern sparse factorisation (sparse_plan.h panels) on the 64 x 64-tile FP64 MFMA kernel
+inline void HipExec::sparse_tail_gemm(double* T, i64 ldt, const double* Pl, const double* Pw, int r, int cols) {
+  if (r <= 0 || cols <= 0) return;
+  const int sm = (r + GS_B - 1) / GS_B;
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const int vec_ok = al(Pl) && al(Pw) && (ldt % 2 == 0);
+  hipLaunchKernelGGL(gemm_nt_update_small, dim3(static_cast<unsigned>(sm) * sm), dim3(256), 0, stream, T, ldt, Pl, ldt, Pw, ldt, r, r,
+                     cols, 1, sm, vec_ok);
+  DNLP_LAUNCH_CHECK();
+}
+
 inline void HipExec::ldlt_prepare(LdltWork& w, i64 n, i64 ld, bool pivoted) {
   if (pivoted) {
     if (n > BK_NMAX) throw std::runtime_error("Bunch-Kaufman path: order above BK_NMAX");

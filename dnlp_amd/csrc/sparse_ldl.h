@@ -22,7 +22,12 @@ struct SeqPar {
 };
 
 // work: nvals (w, laid out like the L values) + 3 * nblk (inverse pivot blocks)
-DNLP_HD inline i64 sparse_ldl_work_doubles(const SparsePlan& pl) { return pl.nvals + 3 * pl.nblk + 8; }
+//       (+ with a dense tail: the accumulator T, tail_ld x tail_n, and the two panels, tail_ld x pg_maxcols each)
+DNLP_HD inline i64 sparse_ldl_tail_acc_offset(const SparsePlan& pl) { return (pl.nvals + 3 * pl.nblk + 8 + 7) / 8 * 8; }
+DNLP_HD inline i64 sparse_ldl_work_doubles(const SparsePlan& pl) {
+  if (pl.tail_n <= 0) return pl.nvals + 3 * pl.nblk + 8;
+  return sparse_ldl_tail_acc_offset(pl) + pl.tail_ld * pl.tail_n + 2 * pl.tail_ld * (pl.pg_maxcols > 0 ? pl.pg_maxcols : 1);
+}
 
 // ---- per-item bodies of the level phases (shared by the cooperative routine below and by the
 // grid-wide level kernels of the HIP space) ------------------------------------------------------
@@ -110,7 +115,14 @@ DNLP_HD inline bool sparse_ldl_factor(const SparsePlan& pl, double* vals, double
   double* w = work;
   double* dinv = work + pl.nvals;
   double nneg = 0.0, nzero = 0.0, bad = 0.0;
-  for (i64 lev = 0; lev < pl.nlev; ++lev) {
+  double* Tacc = work + sparse_ldl_tail_acc_offset(pl);
+  double* Pl = Tacc + pl.tail_ld * pl.tail_n;
+  double* Pw = Pl + pl.tail_ld * pl.pg_maxcols;
+  if (pl.tail_n > 0) {
+    for (i64 a = me; a < pl.tail_ld * pl.tail_n; a += L) Tacc[a] = 0.0;
+    par.sync();
+  }
+  for (i64 lev = 0; lev < pl.nlev_run; ++lev) {
     const i64 b0 = pl.lev_off[lev], b1 = pl.lev_off[lev + 1];
     // A: pivot blocks
     for (i64 k = b0 + me; k < b1; k += L) sp_pivot(pl, vals, dinv, k, nneg, nzero, bad);
@@ -119,6 +131,22 @@ DNLP_HD inline bool sparse_ldl_factor(const SparsePlan& pl, double* vals, double
     const i64 r0 = pl.soff[b0], r1 = pl.soff[b1];
     for (i64 r = r0 + me; r < r1; r += L) sp_scale(pl, vals, w, dinv, r);
     par.sync();
+    // C': the level's panel blocks update the dense tail with one product (see SparsePlan)
+    if (pl.tail_n > 0 && pl.pg_cols[lev] > 0) {
+      const i64 cols = pl.pg_cols[lev], ldt = pl.tail_ld, r = pl.tail_n;
+      for (i64 a = me; a < ldt * cols; a += L) { Pl[a] = 0.0; Pw[a] = 0.0; }
+      par.sync();
+      for (i64 q = pl.pg_off[lev] + me; q < pl.pg_off[lev + 1]; q += L) { Pl[pl.pg_dst[q]] = vals[pl.pg_src[q]]; Pw[pl.pg_dst[q]] = w[pl.pg_src[q]]; }
+      par.sync();
+      for (i64 e = me; e < r * r; e += L) {
+        const i64 u = e % r, v = e / r;
+        if (u < v) continue;
+        double acc = 0.0;
+        for (i64 c = 0; c < cols; ++c) acc += Pl[u + c * ldt] * Pw[v + c * ldt];
+        Tacc[u + v * ldt] -= acc;
+      }
+      par.sync();
+    }
     // C: Schur-complement updates of the level
     const i64 t0 = pl.toff[b0], t1 = pl.toff[b1];
     for (i64 q = t0 + me; q < t1; q += L) par.add(&vals[pl.tdst[q]], -sp_update(pl, vals, w, q));
@@ -141,7 +169,9 @@ template <class P>
 DNLP_HD inline void sparse_ldl_solve(const SparsePlan& pl, const double* vals, double* x, P par) {
   const int L = par.lanes(), me = par.lane();
   // forward, level by level: every struct row pushes its contribution into an ancestor entry
-  for (i64 lev = 0; lev < pl.nlev; ++lev) {
+  // (a plan with a dense tail runs the levels before it in two calls: solve_phase 1, the tail's dense solve, then 2)
+  if (pl.solve_phase != 2) {
+  for (i64 lev = 0; lev < pl.nlev_run; ++lev) {
     const i64 b0 = pl.lev_off[lev], b1 = pl.lev_off[lev + 1];
     const i64 r0 = pl.soff[b0], r1 = pl.soff[b1];
     for (i64 r = r0 + me; r < r1; r += L) {
@@ -150,11 +180,13 @@ DNLP_HD inline void sparse_ldl_solve(const SparsePlan& pl, const double* vals, d
     }
     par.sync();
   }
-  for (i64 k = me; k < pl.nblk; k += L) sp_dsolve(pl, vals, x, k);
+  for (i64 k = me; k < pl.nblk_run; k += L) sp_dsolve(pl, vals, x, k);
   par.sync();
+  }
+  if (pl.solve_phase == 1) return;
   // backward, levels descending: a block gathers from its (already final) ancestors.  Wide levels:
   // one lane per block; narrow levels near the root (few blocks, long structs): all lanes per block.
-  for (i64 lev = pl.nlev - 1; lev >= 0; --lev) {
+  for (i64 lev = pl.nlev_run - 1; lev >= 0; --lev) {
     const i64 b0 = pl.lev_off[lev], b1 = pl.lev_off[lev + 1];
     // (a narrow level only pays for the all-lanes-per-block form when its structs are long compared
     // with the number of blocks: a lane-wide reduction per block costs about as much as two serial

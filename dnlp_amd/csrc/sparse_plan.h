@@ -47,6 +47,28 @@ namespace dnlp {
 // exec-space view of the plan (plain pointers)
 struct SparsePlan {
   i64 n = 0, N = 0, m = 0, nblk = 0, nvals = 0, ntrip = 0, maxs = 0, nlev = 0;
+  // Dense tail (host-driven spaces, kkt_dense.h): the last levels of the elimination order of a pattern with a dense
+  // separator are a chain of one-block levels over a dense Schur complement (NMF at notebook size: 301 of 305 levels,
+  // 1 200 dependent launches per factorisation and 600 per solve).  When tail_n > 0 the level loops stop at nlev_run /
+  // nblk_run, the tail's entries are gathered from the plan's storage into a dense tail_n x tail_n matrix
+  // (tg_src -> tg_dst) and that matrix is factorised and solved by the dense path.
+  i64 nlev_run = 0, nblk_run = 0;     // levels / blocks the sparse phases process (= nlev / nblk without a tail)
+  int solve_phase = 0;                // sparse_solve: 0 everything, 1 forward + D^-1, 2 backward
+  i64 tail_n = 0, tg_count = 0;
+  i32* tnode = nullptr;               // tail_n: KKT node of every tail position
+  i32* tg_src = nullptr;              // tg_count: value index in the plan's storage ...
+  i32* tg_dst = nullptr;              // ... and its place r + c * tail_n (r >= c) in the dense tail
+  // Panels: a block before the tail whose struct ends in >= 16 tail nodes (NMF: 1 200 blocks with 300 each, 5.4e7 of
+  // the 5.5e7 update triples) carries NO triples for its tail x tail pairs.  After the level's rows are scaled its tail
+  // rows are gathered into two dense panels (l and w = l D^-1, tail_ld x pg_cols[level]) and the level's whole
+  // contribution to the tail is ONE product  T -= Pl Pw^T  into the accumulator T (tail_ld x tail_n, lower triangle),
+  // which joins the gathered tail before its dense factorisation.
+  i64 tail_ld = 0, pg_maxcols = 0;
+  i64* pg_off = nullptr;              // nlev_run + 1: offsets into pg_src / pg_dst per level
+  i32* pg_src = nullptr;              // value index of a tail row of a panel block's column
+  i32* pg_dst = nullptr;              // its place row + col * tail_ld in the level's panel
+  const i64 *h_pg_off = nullptr, *h_pg_cols = nullptr;   // host copies (level loops of the host-driven space)
+  i64* pg_cols = nullptr;             // nlev_run: panel columns per level (exec space; the in-kernel routine reads it)
   i32* bnode = nullptr;   // 2 per block: pivot nodes (second = -1 for a 1x1 block)
   i64* soff = nullptr;    // nblk + 1: offsets into sidx
   i32* sidx = nullptr;    // struct of every block: node ids (0..N-1 variables, N.. constraint rows)
@@ -75,6 +97,12 @@ struct SparsePlanHost {
   std::vector<i64> soff, doff, loff, toff, lev_off;
   std::vector<i64> lev_row, lev_trip, lev_val;     // per-level boundaries in rows / triples / values
   std::vector<i32> sblk, tblk;
+  // dense tail (see SparsePlan): chosen by layout(), handed to the exec space only by upload(ex, true)
+  i64 tail_lev = -1, tail_n = 0, tail_ld = 0, pg_maxcols = 0;
+  std::vector<i32> tnode, tg_src, tg_dst, pg_src, pg_dst;
+  std::vector<i64> pg_off, pg_cols;
+  bool allow_tail = false;            // build_sparse_plan(..., allow_tail): host-driven spaces only
+  bool panels_dropped = false;        // tail x tail triples of the panel blocks are not in the update program
   i64 nnzL = 0, n_delayed = 0, n_pairs = 0;
   double fill_ratio = 0.0;    // factor values / dense lower triangle
   // analyse() results: what the numeric phase will cost (known before the layout and the update program,
@@ -449,10 +477,45 @@ struct SparsePlanHost {
     // key as S: one merge scan per iv instead of a binary search per pair (6e7 pairs in the NMF example).
     // Blocks are independent and their triple ranges are known up front (sz (sz + 1) / 2 each), so the program is
     // written in place by a few host threads, blocks handed out in chunks from a shared counter.
+    // (dense tail: chosen here, before the program is written, so that the tail x tail pairs of the panel blocks are
+    //  never generated — they are most of the program where a tail exists)
+    std::vector<i64> tcut(static_cast<size_t>(nb));
+    for (i64 k = 0; k < nb; ++k) tcut[static_cast<size_t>(k)] = soff[static_cast<size_t>(k + 1)] - soff[static_cast<size_t>(k)];
+    panels_dropped = false;
+    pg_src.clear(); pg_dst.clear(); pg_off.clear(); pg_cols.clear(); pg_maxcols = 0;
+    tail_lev = -1; tail_n = 0; tail_ld = 0;
+    if (allow_tail) choose_tail();
+    if (tail_n > 0) {
+      tail_ld = (tail_n + 7) / 8 * 8;
+      const i64 tb0 = lev_off[static_cast<size_t>(tail_lev)];
+      std::vector<i32> tpos(static_cast<size_t>(nn), -1);
+      for (i64 j = 0; j < tail_n; ++j) tpos[static_cast<size_t>(tnode[static_cast<size_t>(j)])] = static_cast<i32>(j);
+      pg_off.assign(1, 0);
+      for (i64 lev = 0; lev < tail_lev; ++lev) {
+        i64 cols = 0;
+        for (i64 k = lev_off[static_cast<size_t>(lev)]; k < lev_off[static_cast<size_t>(lev) + 1]; ++k) {
+          const i64 s0 = soff[static_cast<size_t>(k)], sz = soff[static_cast<size_t>(k + 1)] - s0;
+          i64 h = sz;                                   // the struct is sorted by elimination position: tail nodes last
+          while (h > 0 && npos[static_cast<size_t>(sidx[static_cast<size_t>(s0 + h - 1)])] >= tb0) --h;
+          if (sz - h < 16) continue;
+          tcut[static_cast<size_t>(k)] = h;
+          panels_dropped = true;
+          const int bk = bnode[static_cast<size_t>(2 * k + 1)] >= 0 ? 2 : 1;
+          for (int c = 0; c < bk; ++c, ++cols)
+            for (i64 i = h; i < sz; ++i) {
+              pg_src.push_back(static_cast<i32>(loff[static_cast<size_t>(k)] + i * bk + c));
+              pg_dst.push_back(static_cast<i32>(tpos[static_cast<size_t>(sidx[static_cast<size_t>(s0 + i)])] + cols * tail_ld));
+            }
+        }
+        pg_cols.push_back(cols);
+        pg_off.push_back(static_cast<i64>(pg_src.size()));
+        pg_maxcols = std::max(pg_maxcols, cols);
+      }
+    }
     toff.assign(static_cast<size_t>(nb + 1), 0);
     for (i64 k = 0; k < nb; ++k) {
-      const i64 sz = soff[static_cast<size_t>(k + 1)] - soff[static_cast<size_t>(k)];
-      toff[static_cast<size_t>(k + 1)] = toff[static_cast<size_t>(k)] + sz * (sz + 1) / 2;
+      const i64 sz = soff[static_cast<size_t>(k + 1)] - soff[static_cast<size_t>(k)], h = tcut[static_cast<size_t>(k)];
+      toff[static_cast<size_t>(k + 1)] = toff[static_cast<size_t>(k)] + h * sz - h * (h - 1) / 2;      // pairs (iu >= iv) with iv < h
     }
     {
       const size_t total = static_cast<size_t>(toff[static_cast<size_t>(nb)]);
@@ -460,21 +523,20 @@ struct SparsePlanHost {
       std::atomic<i64> next{0};
       std::atomic<bool> failed{false};
       auto work = [&]() {
-        std::vector<i32> dtmp;
         const i64 chunk = 64;
         for (;;) {
           const i64 kb = next.fetch_add(chunk);
           if (kb >= nb || failed.load()) return;
           for (i64 k = kb; k < std::min(nb, kb + chunk); ++k) {
-            const i64 s0 = soff[static_cast<size_t>(k)], sz = soff[static_cast<size_t>(k + 1)] - s0;
-            dtmp.assign(static_cast<size_t>(sz * (sz + 1) / 2), -1);
-            for (i64 iv = 0; iv < sz; ++iv) {
+            const i64 s0 = soff[static_cast<size_t>(k)], sz = soff[static_cast<size_t>(k + 1)] - s0, hcut = tcut[static_cast<size_t>(k)];
+            size_t q = static_cast<size_t>(toff[static_cast<size_t>(k)]);
+            for (i64 iv = 0; iv < hcut; ++iv) {
               const i32 w = sidx[static_cast<size_t>(s0 + iv)];
               const i64 kw = npos[static_cast<size_t>(w)];
               const i64 w0 = soff[static_cast<size_t>(kw)], w1 = soff[static_cast<size_t>(kw + 1)];
               const int bk = bnode[static_cast<size_t>(2 * kw + 1)] >= 0 ? 2 : 1;
               i64 pcur = w0;
-              for (i64 iu = iv; iu < sz; ++iu) {
+              for (i64 iu = iv; iu < sz; ++iu, ++q) {
                 const i32 u = sidx[static_cast<size_t>(s0 + iu)];
                 i64 a;
                 if (npos[static_cast<size_t>(u)] == kw) {
@@ -484,17 +546,12 @@ struct SparsePlanHost {
                   if (pcur >= w1) { failed.store(true); return; }
                   a = loff[static_cast<size_t>(kw)] + (pcur - w0) * bk + ncol[static_cast<size_t>(w)];
                 }
-                dtmp[static_cast<size_t>(iu * (iu + 1) / 2 + iv)] = static_cast<i32>(a);
-              }
-            }
-            size_t q = static_cast<size_t>(toff[static_cast<size_t>(k)]);
-            for (i64 iu = 0; iu < sz; ++iu)
-              for (i64 iv = 0; iv <= iu; ++iv, ++q) {
-                tdst[q] = dtmp[static_cast<size_t>(iu * (iu + 1) / 2 + iv)];
+                tdst[q] = static_cast<i32>(a);
                 tiu[q] = static_cast<i32>(iu);
                 tiv[q] = static_cast<i32>(iv);
                 tblk[q] = static_cast<i32>(k);
               }
+            }
           }
         }
       };
@@ -519,7 +576,45 @@ struct SparsePlanHost {
     bstruct_.clear(); bstruct_.shrink_to_fit();
   }
 
-  template <class E> SparsePlan upload(E* ex) const {
+  // The longest suffix of levels that is a dense chain: 1x1 blocks only, at least 16 levels and 48 nodes, at most
+  // 8192 nodes, at least 60 % of the tail's lower triangle structurally present, and narrow (two blocks per level on
+  // average at most: a wide level is parallel work the level kernels handle well).
+  void choose_tail() {
+    tail_lev = -1; tail_n = 0;
+    tnode.clear(); tg_src.clear(); tg_dst.clear();
+    const i64 nl = static_cast<i64>(lev_off.size()) - 1, nb = nblk();
+    i64 best = -1, rows = 0;
+    for (i64 lev = nl - 1; lev >= 0; --lev) {
+      const i64 b0 = lev_off[static_cast<size_t>(lev)], b1 = lev_off[static_cast<size_t>(lev) + 1];
+      bool single = true;
+      for (i64 k = b0; k < b1 && single; ++k) single = bnode[static_cast<size_t>(2 * k + 1)] < 0;
+      if (!single) break;
+      rows += soff[static_cast<size_t>(b1)] - soff[static_cast<size_t>(b0)];
+      const i64 r = nb - b0, levels = nl - lev;
+      if (r > 8192 || r > 2 * levels) break;
+      if (levels >= 16 && r >= 48 && static_cast<double>(rows) >= 0.6 * 0.5 * static_cast<double>(r) * static_cast<double>(r - 1)) best = lev;
+    }
+    if (best < 0) return;
+    tail_lev = best;
+    const i64 b0 = lev_off[static_cast<size_t>(best)];
+    tail_n = nb - b0;
+    std::vector<i32> tpos(static_cast<size_t>(n), -1);
+    tnode.resize(static_cast<size_t>(tail_n));
+    for (i64 j = 0; j < tail_n; ++j) { tnode[static_cast<size_t>(j)] = bnode[static_cast<size_t>(2 * (b0 + j))]; tpos[static_cast<size_t>(tnode[static_cast<size_t>(j)])] = static_cast<i32>(j); }
+    for (i64 j = 0; j < tail_n; ++j) {
+      const i64 k = b0 + j;
+      tg_src.push_back(static_cast<i32>(doff[static_cast<size_t>(k)]));
+      tg_dst.push_back(static_cast<i32>(j + j * tail_n));
+      for (i64 i = 0; i < soff[static_cast<size_t>(k) + 1] - soff[static_cast<size_t>(k)]; ++i) {
+        const i32 row = tpos[static_cast<size_t>(sidx[static_cast<size_t>(soff[static_cast<size_t>(k)] + i)])];
+        if (row < 0 || row <= j) { tail_lev = -1; tail_n = 0; tnode.clear(); tg_src.clear(); tg_dst.clear(); return; }   // (cannot happen: structs point forward)
+        tg_src.push_back(static_cast<i32>(loff[static_cast<size_t>(k)] + i));
+        tg_dst.push_back(static_cast<i32>(row + j * tail_n));
+      }
+    }
+  }
+
+  template <class E> SparsePlan upload(E* ex, bool with_tail = false) const {
     SparsePlan p;
     p.n = n; p.N = N; p.m = m; p.nblk = nblk(); p.nvals = nvals; p.ntrip = static_cast<i64>(tdst.size()); p.maxs = maxs;
     auto up = [&](auto*& dst, const auto& src) {
@@ -531,6 +626,17 @@ struct SparsePlanHost {
     up(p.tdst, tdst); up(p.tiu, tiu); up(p.tiv, tiv); up(p.hpos, hpos); up(p.jpos, jpos); up(p.dpos, dpos);
     up(p.lev_off, lev_off); up(p.sblk, sblk); up(p.tblk, tblk);
     p.nlev = static_cast<i64>(lev_off.size()) - 1;
+    p.nlev_run = p.nlev; p.nblk_run = p.nblk;
+    if (panels_dropped && !(with_tail && tail_n > 0))
+      throw std::runtime_error("sparse plan: built for the dense tail (its panel blocks carry no tail x tail triples); this space needs a full plan");
+    if (with_tail && tail_n > 0) {
+      p.tail_n = tail_n; p.tg_count = static_cast<i64>(tg_src.size());
+      p.nlev_run = tail_lev; p.nblk_run = lev_off[static_cast<size_t>(tail_lev)];
+      up(p.tnode, tnode); up(p.tg_src, tg_src); up(p.tg_dst, tg_dst);
+      p.tail_ld = tail_ld; p.pg_maxcols = pg_maxcols;
+      up(p.pg_off, pg_off); up(p.pg_src, pg_src); up(p.pg_dst, pg_dst); up(p.pg_cols, pg_cols);
+      p.h_pg_off = pg_off.data(); p.h_pg_cols = pg_cols.data();
+    }
     p.h_lev_blk = lev_off.data(); p.h_lev_row = lev_row.data(); p.h_lev_trip = lev_trip.data(); p.h_lev_val = lev_val.data();
     return p;
   }
@@ -538,7 +644,8 @@ struct SparsePlanHost {
 
 // Plan of a loaded tape: structural information from the host copies.
 template <class E>
-inline void build_sparse_plan(const Tape<E>& t, SparsePlanHost& plan, bool bounds_relaxed, const std::vector<double>* jac_abs0 = nullptr) {
+inline void build_sparse_plan(const Tape<E>& t, SparsePlanHost& plan, bool bounds_relaxed, const std::vector<double>* jac_abs0 = nullptr,
+                              bool allow_tail = false) {
   std::vector<char> zero_diag(static_cast<size_t>(t.N), 1), eq(static_cast<size_t>(t.m), 0), fixed(static_cast<size_t>(t.N), 0);
   if (!bounds_relaxed)
     for (i64 j = 0; j < t.N; ++j) fixed[static_cast<size_t>(j)] = t.h_lb[static_cast<size_t>(j)] == t.h_ub[static_cast<size_t>(j)];
@@ -560,7 +667,18 @@ inline void build_sparse_plan(const Tape<E>& t, SparsePlanHost& plan, bool bound
   const double lr = static_cast<double>(plan.pred_levels + 1), ls = static_cast<double>(strict.pred_levels + 1);
   const bool relaxed_ok = (lr <= 0.5 * ls && tr <= 3.0 * ts + 64.0) || (lr <= ls && tr <= 1.2 * ts + 64.0);
   if (!relaxed_ok) plan = std::move(strict);
+  plan.allow_tail = allow_tail;
   plan.layout(t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, fixed);
+  if (std::getenv("DNLP_PLAN_LEVELS")) {
+    std::fprintf(stderr, "[plan] dense tail: %lld nodes from level %lld on, panel columns per level up to %lld, %zu triples\n", (long long)plan.tail_n,
+                 (long long)plan.tail_lev, (long long)plan.pg_maxcols, plan.tdst.size());
+    const i64 nl = static_cast<i64>(plan.lev_off.size()) - 1;
+    for (i64 l = 0; l < nl; ++l)
+      std::fprintf(stderr, "[plan] level %lld: blocks %lld struct rows %lld triples %lld\n", (long long)l,
+                   (long long)(plan.lev_off[static_cast<size_t>(l) + 1] - plan.lev_off[static_cast<size_t>(l)]),
+                   (long long)(plan.lev_row[static_cast<size_t>(l) + 1] - plan.lev_row[static_cast<size_t>(l)]),
+                   (long long)(plan.lev_trip[static_cast<size_t>(l) + 1] - plan.lev_trip[static_cast<size_t>(l)]));
+  }
 }
 
 // The pivot blocks of a built plan in elimination order (kkt_dense.h paired mode: a dense matrix assembled in this order

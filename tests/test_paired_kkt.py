@@ -47,7 +47,8 @@ def _host(blob, data):
 
 
 def test_phase_retrieval_runs_on_rotated_pairs_host_build():
-    bk, mode_bk, pr, mode_pr = _pair(_host, "nb_phase_retrieval")
+    # (linear_solver = dense: since the dense-tail form of the sparse plan exists this problem would take the sparse path)
+    bk, mode_bk, pr, mode_pr = _pair(_host, "nb_phase_retrieval", linear_solver="dense")
     assert mode_bk == "bunch-kaufman" and mode_pr in ("paired", "paired-then-bunch-kaufman")
     assert bk["status"] == 0 and pr["status"] == 0
     assert abs(pr["obj_val"]) <= 1e-7 and abs(bk["obj_val"]) <= 1e-7            # published: 3.86e-9
@@ -58,7 +59,7 @@ def test_phase_retrieval_runs_on_rotated_pairs_host_build():
 def test_unreliable_static_sequence_is_handed_to_bunch_kaufman_host_build():
     """Sparse recovery (non-convex, delta_w up to 1e7 on its path) at a lowered size threshold: the static sequence's
     multipliers pass 1e8 on the way, the handle ends on Bunch-Kaufman and at the Bunch-Kaufman run's optimum."""
-    bk, mode_bk, pr, mode_pr = _pair(_host, "nb_sparse_recovery", kkt_paired_min_n=384)
+    bk, mode_bk, pr, mode_pr = _pair(_host, "nb_sparse_recovery", kkt_paired_min_n=384, linear_solver="dense")
     assert mode_bk == "bunch-kaufman" and mode_pr == "paired-then-bunch-kaufman"
     assert pr["status"] in (0, 1) and bk["status"] in (0, 1)
     assert abs(pr["obj_val"] - bk["obj_val"]) <= 1e-4 * abs(bk["obj_val"])
@@ -66,7 +67,7 @@ def test_unreliable_static_sequence_is_handed_to_bunch_kaufman_host_build():
 
 def test_small_and_sparse_systems_keep_their_solver():
     from oracle.oracle_capi import OracleProblem
-    for name, want in (("hs071", "bunch-kaufman"), ("nb_sparse_recovery", "bunch-kaufman"), ("nb_power_flow", "sparse")):
+    for name, want in (("hs071", "bunch-kaufman"), ("nb_power_flow", "sparse")):
         data, blob = _lowered(name)
         h = OracleProblem(blob)
         assert h.kkt_mode() is None
@@ -80,7 +81,7 @@ def test_device_phase_retrieval_runs_on_rotated_pairs(gpu_required):
 
     def dev(blob, data):
         return _capi.DeviceProblem(blob, data["tape"], device=0)
-    bk, mode_bk, pr, mode_pr = _pair(dev, "nb_phase_retrieval", time_kernels="yes")
+    bk, mode_bk, pr, mode_pr = _pair(dev, "nb_phase_retrieval", time_kernels="yes", linear_solver="dense")
     assert mode_bk == "bunch-kaufman" and mode_pr in ("paired", "paired-then-bunch-kaufman")
     assert bk["status"] == 0 and pr["status"] == 0
     assert abs(pr["obj_val"]) <= 1e-7 and abs(bk["obj_val"]) <= 1e-7

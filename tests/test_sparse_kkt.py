@@ -62,13 +62,14 @@ def test_plan_is_sparse_for_the_paper_examples():
         data, _ = build_canonical(name)
         h = OracleProblem(serialize(data["tape_arrays"]))
         if name == "nb_phase_retrieval":
-            # dense measurement matrices: the plan exists but its update program (3.6e6 triples) is
-            # past the point where one workgroup beats the chip-wide dense factorisation
-            assert not h.kkt_info()["sparse"]
-            h.set_option("linear_solver", "sparse")
-            h2 = OracleProblem(serialize(data["tape_arrays"]))
-            h2.set_option("linear_solver", "sparse")
-            h = h2
+            # dense measurement matrices: as a chain of triples the update program is 3.6e6 long (past the point where
+            # one workgroup beats the chip-wide dense factorisation: sparse_dense_tail = no keeps the dense path); with
+            # the last 128 nodes as a dense tail and the levels before it as panels it is 4.1e5, and sparse
+            h0 = OracleProblem(serialize(data["tape_arrays"]))
+            h0.set_option("sparse_dense_tail", "no")
+            i0 = h0.kkt_info()
+            assert not i0["sparse"] and i0["update_triples"] > 3000000
+            assert h.kkt_info()["update_triples"] < 500000
         info = h.kkt_info()
         n = len(data["x0"]) + len(data["cl"])
         assert info["sparse"], name
@@ -199,3 +200,60 @@ def test_level_graph_replay_is_the_same_computation(gpu_required, monkeypatch):
     #  the ill-conditioned last steps carry that into the sixth digit of the large multipliers)
     np.testing.assert_allclose(a["x"], b["x"], rtol=1e-5, atol=1e-7)
     assert abs(a["obj_val"] - b["obj_val"]) <= 1e-9 * max(1.0, abs(b["obj_val"]))
+
+
+def _nmf_blob(images):
+    import dnlp_amd as cp
+    from dnlp_amd.dnlp2smooth import Dnlp2Smooth
+    from dnlp_amd.nlp_solver import build_nlp_data
+    from dnlp_amd.tape import serialize
+    from paper_examples import nb_nmf
+    smooth, _ = Dnlp2Smooth().apply(nb_nmf(cp, images))
+    data, _ = build_nlp_data(smooth)
+    return data, serialize(data["tape_arrays"])
+
+
+def _solve_with(make, blob, data, **opts):
+    from dnlp_amd.nlp_solver import HIPNLP
+    h = make(blob, data)
+    for k, v in HIPNLP.DEFAULT_OPTIONS.items():
+        h.set_option(k, v)
+    for k, v in opts.items():
+        h.set_option(k, v)
+    return h.solve(data["x0"]), h.kkt_info()
+
+
+def test_dense_tail_and_panels_are_the_same_factorisation_host_build():
+    """NMF with 20 images (KKT order ~1.7e4): the elimination order ends in a chain of 60 one-block levels over a dense
+    Schur complement, fed by 1 200 blocks whose structs end in those 60 nodes.  With sparse_dense_tail (default) the chain
+    is ONE dense factorisation, the 1 200 blocks update it with one product per level instead of 2.2e6 triples, and the
+    solves run 4 levels + one dense solve instead of 64 levels — the same LDL^T: same iterates, same optimum."""
+    from oracle.oracle_capi import OracleProblem
+    data, blob = _nmf_blob(20)
+
+    def make(b, d):
+        return OracleProblem(b)
+    chain, ki_chain = _solve_with(make, blob, data, sparse_dense_tail="no")
+    tail, ki_tail = _solve_with(make, blob, data)
+    assert ki_chain["sparse"] and ki_tail["sparse"]
+    assert ki_chain["update_triples"] > 2000000 and ki_tail["update_triples"] < 400000
+    assert chain["status"] == 0 and tail["status"] == 0
+    assert chain["iterations"] == tail["iterations"]
+    assert abs(chain["obj_val"] - tail["obj_val"]) <= 1e-9 * abs(chain["obj_val"])
+
+
+@pytest.mark.gpu
+def test_device_dense_tail_against_the_level_chain(gpu_required):
+    """The same on the MI355X (level kernels + FP64 MFMA product for the panels + dense tail): optimum of the level-chain
+    run, and the notebook-size plan (100 images: 5.5e7 triples as a chain) carries under 2e6 triples."""
+    from dnlp_amd import _capi
+    data, blob = _nmf_blob(20)
+
+    def make(b, d):
+        return _capi.DeviceProblem(b, d["tape"], device=0)
+    chain, ki_chain = _solve_with(make, blob, data, sparse_dense_tail="no")
+    tail, ki_tail = _solve_with(make, blob, data)
+    assert chain["status"] == 0 and tail["status"] == 0
+    assert abs(chain["iterations"] - tail["iterations"]) <= 3
+    assert abs(chain["obj_val"] - tail["obj_val"]) <= 1e-7 * abs(chain["obj_val"])
+    assert ki_tail["update_triples"] < 0.2 * ki_chain["update_triples"]
