@@ -576,7 +576,8 @@ struct SparsePlanHost {
     bstruct_.clear(); bstruct_.shrink_to_fit();
   }
 
-  // The longest suffix of levels that is a dense chain: 1x1 blocks only, at least 16 levels and 48 nodes, at most
+  // The longest suffix of levels that is a dense chain: 1x1 blocks only, at least 16 levels and 48 nodes (a tail of 36
+  // nodes — the 12-image NMF — measured 2.6x SLOWER than its chain on the MI355X: 0.87 against 0.33 s), at most
   // 8192 nodes, at least 60 % of the tail's lower triangle structurally present, and narrow (two blocks per level on
   // average at most: a wide level is parallel work the level kernels handle well).
   void choose_tail() {
