@@ -48,7 +48,9 @@ struct LbfgsState { DNLP_LB_STATE_BODY };
 // what lets the single-lane two-loop recursion of lb_control pipeline its LDS reads.
 // Control block of the persistent kernel (device memory, zeroed by the host before every launch).
 struct LbPersistCtl {
-  unsigned arrive; unsigned abort; unsigned pad[30];        // barrier counter on a line of its own
+  unsigned arrive; unsigned abort; unsigned pad[30];        // top barrier counter on a line of its own
+  unsigned grp[8][32];                                      // arrival counter of workgroup group g = blockIdx % 8, a line each
+  unsigned gen[8][32];                                      // generation word the members of group g wait on, a line each
   double acc[3][96 * 16];                                   // rotating accumulators, ONE PER 128-BYTE LINE: f, chk, 3 x 31 inner
                                                             // products, max |g| (atomics to one line serialise in its L2 channel:
                                                             // sixteen accumulators per line made a barrier phase 32 us)
@@ -473,24 +475,33 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_control(LbfgsState* __
 // numbers (Armijo test, curvature test, two-loop recursion on its own LDS copy of the Gram matrix).  The four-kernel
 // slot above spends its time in dependent global loads (state, coefficients, rows): 50 us per slot at n = 1e5.
 #define DNLP_PL (DNLP_PER + 2 * DNLP_W)
-struct LbPersistCtl { unsigned arrive; unsigned abort; unsigned pad[30]; double acc[3][96 * 16]; };
+struct LbPersistCtl { unsigned arrive; unsigned abort; unsigned pad[30]; unsigned grp[8][32]; unsigned gen[8][32]; double acc[3][96 * 16]; };
 #define DNLP_ACC(p, k) ((p) + 16 * (k))
 
 __device__ __forceinline__ double dnlp_agent_load(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Counter barrier over the nwg co-resident workgroups (grid <= compute units: every workgroup is resident).  A spin is
-// bounded: a stranded workgroup raises `abort` and everybody leaves instead of hanging the device.
+// Two-level counter barrier over the nwg co-resident workgroups (grid <= compute units: every workgroup is resident).
+// 256 arrivals on ONE device-scope counter serialise in its memory channel (~12 ns each: 3 us before the last arriver
+// is even counted) and 256 pollers hammer the same line; here a workgroup arrives on the counter of its group
+// g = blockIdx % 8 (32 arrivals per line, the eight lines in parallel), the LAST arriver of a group arrives on the top
+// counter, waits for the eight groups and bumps its group's generation word, which the other members poll.
+// A spin is bounded: a stranded workgroup raises `abort` and everybody leaves instead of hanging the device.
 __device__ __forceinline__ bool dnlp_grid_barrier(LbPersistCtl* ctl, unsigned& epoch, const unsigned nwg, int* s_flag) {
   ++epoch;                                             // (uniform: every lane counts the barriers)
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();                                   // release: this workgroup's stores and atomics before the arrive
-    atomicAdd(&ctl->arrive, 1u);
-    const unsigned target = epoch * nwg;
+    const unsigned g = blockIdx.x & 7u, ngroups = nwg < 8u ? nwg : 8u;
+    const unsigned gsize = (nwg + 7u - g) >> 3;        // workgroups with blockIdx % 8 == g
+    const unsigned mine = atomicAdd(&ctl->grp[g][0], 1u) + 1u;
     unsigned spins = 0;
     int ok = 1;
-    while (__hip_atomic_load(&ctl->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    const bool leader = mine == epoch * gsize;
+    if (leader) atomicAdd(&ctl->arrive, 1u);
+    unsigned* word = leader ? &ctl->arrive : &ctl->gen[g][0];
+    const unsigned target = leader ? epoch * ngroups : epoch;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 1023u) == 0u) {
         if (spins > (1u << 22) || __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
@@ -500,6 +511,7 @@ __device__ __forceinline__ bool dnlp_grid_barrier(LbPersistCtl* ctl, unsigned& e
         }
       }
     }
+    if (leader && ok) __hip_atomic_store(&ctl->gen[g][0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();                                   // acquire
     *s_flag = ok;
   }
