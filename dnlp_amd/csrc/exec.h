@@ -33,6 +33,19 @@
 #define DNLP_FAIL(msg) throw std::runtime_error(msg)
 #endif
 
+// The in-kernel execution space keeps its solver objects (exec space, model, KKT, interior-point state) in LDS, but a
+// member function that is not inlined receives a GENERIC `this`: every field read is then a flat_load (address-space
+// check, both wait counters, ~2x the latency of ds_read) — Ipm::step() alone had 351 of them and not one ds_read.
+// DNLP_THIS_IN_LDS(E) at the top of such a function tells the compiler what the kernel knows (LLVM's InferAddressSpaces
+// takes llvm.assume(is.shared(p)) as proof): field accesses through `this` become LDS instructions.
+#if DNLP_DEVICE_PASS
+#define DNLP_THIS_IN_LDS(E) do { if constexpr (E::objects_in_lds) __builtin_assume(__builtin_amdgcn_is_shared(this)); } while (0)
+#define DNLP_PTR_IN_LDS(E, p) do { if constexpr (E::objects_in_lds) __builtin_assume(__builtin_amdgcn_is_shared(p)); } while (0)
+#else
+#define DNLP_THIS_IN_LDS(E) do { } while (0)
+#define DNLP_PTR_IN_LDS(E, p) do { } while (0)
+#endif
+
 namespace dnlp {
 
 using i64 = int64_t;
@@ -56,6 +69,7 @@ namespace dnlp {
 struct HostControlled {
   static constexpr bool has_log = true;
   static constexpr bool has_host_control = true;
+  static constexpr bool objects_in_lds = false;
   static constexpr int kFilterCap = 1024;
   // largest order the space's pivoted (Bunch-Kaufman) factorisation accepts; HipExec narrows it (its solve keeps
   // the vector in LDS), the host space's LAPACK backend has no such limit

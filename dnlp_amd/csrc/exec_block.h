@@ -419,6 +419,7 @@ struct BlockExecT {
   static constexpr bool is_device = false;          // model.h: generic lambda form of the flat sweep
   static constexpr bool has_log = false;
   static constexpr bool has_host_control = false;
+  static constexpr bool objects_in_lds = true;      // batch.h places every solver object in LDS (DNLP_THIS_IN_LDS)
   static constexpr bool has_condensed_ls = false;
   static constexpr int kFilterCap = 32;
   struct Log { __device__ void append(const Log&) {} };

@@ -116,6 +116,9 @@ typedef int (*IntermediateCb)(int alg_mod, int iter_count, double obj_value, dou
                               double d_norm, double regularization_size, double alpha_du, double alpha_pr,
                               int ls_trials, void* user_data);
 
+// (see exec.h: DNLP_THIS_IN_LDS) — at the top of every member function of the in-kernel instantiation
+#define DNLP_IPM_LDS() do { DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex_); DNLP_PTR_IN_LDS(E, md_); DNLP_PTR_IN_LDS(E, kkt_); } while (0)
+
 template <class E, class K>
 class Ipm {
  public:
@@ -166,6 +169,7 @@ class Ipm {
   template <class T> DNLP_HD T* A(i64 n) { return ex_->template alloc<T>(static_cast<size_t>(n > 0 ? n : 1)); }
 
   DNLP_HD void allocate() {
+    DNLP_IPM_LDS();
     N = md_->N(); m = md_->m();
     x = A<double>(N); s = A<double>(m); y = A<double>(m); zL = A<double>(N); zU = A<double>(N);
     vL = A<double>(m); vU = A<double>(m); xL = A<double>(N); xU = A<double>(N); sL = A<double>(m);
@@ -195,6 +199,7 @@ class Ipm {
   }
   DNLP_HD void filter_clear() { nfilt = 0; }
   DNLP_HD void filter_add(double th, double ph) {
+    DNLP_IPM_LDS();
     if (nfilt == kFilterCap) {
       for (int k = 1; k < nfilt; ++k) { filt_th[k - 1] = filt_th[k]; filt_ph[k - 1] = filt_ph[k]; }
       --nfilt;
@@ -260,6 +265,7 @@ class Ipm {
     for (int c = n - 1; c >= 0; --c) { for (int q = c + 1; q < n; ++q) b[c] -= Am[c * n + q] * b[q]; b[c] /= Am[c * n + c]; }
   }
   DNLP_HD void lm_begin() {
+    DNLP_IPM_LDS();
     if constexpr (E::has_host_control) {
       if (opt.hessian_approximation != 1) { kkt_->skip_hessian = false; return; }
       if (!lm_) lm_ = new LmState();
@@ -281,6 +287,7 @@ class Ipm {
     }
   }
   DNLP_HD void lm_reset() {
+    DNLP_IPM_LDS();
     if (!lm_) return;
     lm_->k = 0; lm_->skipped = 0; lm_->sigma = 1.0; lm_->c_ready = false; lm_->have_old = false;
   }
@@ -292,6 +299,7 @@ class Ipm {
     return L.Y + static_cast<i64>(L.slot[c - L.k]) * N;
   }
   DNLP_HD void lm_psi_dots(const double* v, double* t) {
+    DNLP_IPM_LDS();
     const int n2 = 2 * lm_->k;
     for (int c = 0; c < n2; ++c) {
       double sc;
@@ -301,6 +309,7 @@ class Ipm {
   }
   // the point the next pair is measured from: x, grad f and the Jacobian values of the current iterate
   DNLP_HD void lm_save_point() {
+    DNLP_IPM_LDS();
     LmState& L = *lm_;
     ex_->d2d(L.xold, x, sizeof(double) * static_cast<size_t>(N));
     ex_->d2d(L.gold, grad, sizeof(double) * static_cast<size_t>(N));
@@ -309,6 +318,7 @@ class Ipm {
   }
   // after an accepted step: the new pair (both gradients of the Lagrangian with the NEW multipliers)
   DNLP_HD void lm_update() {
+    DNLP_IPM_LDS();
     LmState& L = *lm_;
     if (!L.have_old) return;
     L.have_old = false;
@@ -376,6 +386,7 @@ class Ipm {
   }
   // out = B v
   DNLP_HD void lm_hess_mult(const double* v, double* out) {
+    DNLP_IPM_LDS();
     LmState& L = *lm_;
     const double sg0 = L.sigma;
     ex_->map(N, [=] DNLP_HD(i64 j) { out[j] = sg0 * v[j]; });
@@ -393,6 +404,7 @@ class Ipm {
   }
   // Z = K0^{-1} [Psi; 0] and the LU factors of M - Psi^T Z_x, once per factorisation of K0
   DNLP_HD void lm_prepare() {
+    DNLP_IPM_LDS();
     LmState& L = *lm_;
     L.c_ready = true;
     L.c_ok = true;
@@ -423,6 +435,7 @@ class Ipm {
   }
   // out = K^{-1} r through the factorisation of K0
   DNLP_HD void kkt_solve(const double* r, double* out) {
+    DNLP_IPM_LDS();
     kkt_->solve(r, out);
     if constexpr (E::has_host_control) {
       if (!lm_on() || lm_->k == 0) return;
@@ -445,6 +458,7 @@ class Ipm {
   // ---- evaluation helpers (scaled problem) --------------------------------------
   // f~(xp), g~(xp) -> returns false on non-finite values
   DNLP_HD bool eval_fg(const double* xp, double& fval, double* gout, bool check = true) {
+    DNLP_IPM_LDS();
     double t0 = now_sec();
     md_->sweep(xp, false);
     fval = sf * md_->eval_f_after_sweep();
@@ -458,6 +472,7 @@ class Ipm {
   }
   // gradient and Jacobian values at the point of the last sweep (scaled)
   DNLP_HD void eval_derivs_after_sweep() {
+    DNLP_IPM_LDS();
     double t0 = now_sec();
     md_->eval_grad_after_sweep(grad);
     md_->eval_jac_after_sweep(jv);
@@ -471,6 +486,7 @@ class Ipm {
     stats.t_eval += now_sec() - t0;
   }
   DNLP_HD void eval_hessian() {
+    DNLP_IPM_LDS();
     if (lm_on()) return;                 // limited-memory mode: no second derivatives
     double t0 = now_sec();
     const double* sgp = sg;
@@ -484,6 +500,7 @@ class Ipm {
   // ---- initialisation (WB section 3.6) -------------------------------------------
   // x0_ctl: control-space pointer (host memory for the host / HIP spaces)
   DNLP_HD int begin(const double* x0_ctl) {
+    DNLP_IPM_LDS();
     double t_start = now_sec();
     if (!x) allocate();
     lm_begin();
@@ -661,6 +678,7 @@ class Ipm {
 
   // least-squares equality multipliers (WB eq. (36)); discarded above constr_mult_init_max
   DNLP_HD void init_multipliers_ls() {
+    DNLP_IPM_LDS();
     const double* eq = eqmask;
     if constexpr (E::has_host_control) if (!kkt_->pivoted && m <= 8) {
       // Few rows on a large system: the (1,1) block of the least-squares system is the identity,
@@ -772,10 +790,12 @@ class Ipm {
   // ---- measures -------------------------------------------------------------------
   // primal residual: g - cl for equalities, g - s for inequalities
   DNLP_HD double theta_at(const double* gg, const double* ss) {
+    DNLP_IPM_LDS();
     const double *eq = eqmask, *sl = sL;
     return ex_->sum(m, [=] DNLP_HD(i64 i) { return fabs(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]); });
   }
   DNLP_HD double barrier_at(double fv, const double* xx, const double* ss, double muv) {
+    DNLP_IPM_LDS();
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *eq = eqmask;
     const double kd = opt.kappa_d;
     double bx = ex_->sum(N, [=] DNLP_HD(i64 j) {
@@ -804,6 +824,7 @@ class Ipm {
   // (theta_at + barrier_at + the check of eval_fg are four reductions)
   struct Measures { double theta, phi, chk; };
   DNLP_HD Measures measures(double fv, const double* gg, const double* xx, const double* ss, double muv) {
+    DNLP_IPM_LDS();
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *eq = eqmask;
     const double kd = opt.kappa_d;
     const i64 NN = N;
@@ -838,6 +859,7 @@ class Ipm {
 
   // dual residuals rx = grad + J^T y - zL + zU ; rs = -y - vL + vU (inequality rows)
   DNLP_HD void dual_residuals() {
+    DNLP_IPM_LDS();
     md_->jac_tmult(jv, y, tN);
     double *r = rx, *q = rs;
     const double *gr = grad, *jt = tN, *a = zL, *b = zU, *c = vL, *d = vU, *yy = y, *eq = eqmask, *fm = fixmask;
@@ -849,6 +871,7 @@ class Ipm {
 
   // WB eq. (5): scaled optimality error for barrier parameter muv
   DNLP_HD Err error(double muv) {
+    DNLP_IPM_LDS();
     dual_residuals();
     const double *r = rx, *q = rs, *gg = g, *ss = s, *eq = eqmask, *sl = sL, *su = sU, *l = xL, *u = xU,
                  *xx = x, *a = zL, *b = zU, *c = vL, *d = vU, *yy = y, *sgp = sg;
@@ -898,6 +921,7 @@ class Ipm {
   }
 
   DNLP_HD i64 n_bound_mults() {
+    DNLP_IPM_LDS();
     if (nb_cache_ >= 0) return nb_cache_;
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *eq = eqmask;
     double c1 = ex_->sum(N, [=] DNLP_HD(i64 j) { return (l[j] > -kInf ? 1.0 : 0.0) + (u[j] < kInf ? 1.0 : 0.0); });
@@ -910,6 +934,7 @@ class Ipm {
   // ---- search direction (WB section 2.2 / 3.1) ---------------------------------------
   // Builds Sigma and the barrier right-hand sides for barrier parameter muv.
   DNLP_HD void barrier_terms(double muv) {
+    DNLP_IPM_LDS();
     md_->jac_tmult(jv, y, tN);
     double *sx = Sx, *sS = Ss, *r = rx, *q = rs, *p = rp;
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *eq = eqmask, *xx = x, *ss = s, *a = zL, *b = zU,
@@ -951,6 +976,7 @@ class Ipm {
   // of H~ itself is certain to fail.  Either way the doomed O(n^3) factorisations are skipped at
   // the price of k Hessian-vector products (k HBM sweeps).  Returns (lower bound, spectral width).
   DNLP_HD D2 lanczos_delta_lower_bound() {
+    DNLP_IPM_LDS();
     if constexpr (!E::has_host_control) {
       return {0.0, 0.0};
     } else {
@@ -1086,6 +1112,7 @@ class Ipm {
 
   // one factorisation attempt: 0 ok, 1 wrong inertia, 2 singular
   DNLP_HD int try_factor(double dw, double dc) {
+    DNLP_IPM_LDS();
     int nneg = 0, nzero = 0;
     double* dd = Dd;
     const double *sS = Ss, *eq = eqmask;
@@ -1104,6 +1131,7 @@ class Ipm {
   }
 
   DNLP_HD bool factor_with_inertia(double& delta_w, double& delta_c) {
+    DNLP_IPM_LDS();
     const double dw_min = 1e-20, dw_0 = 1e-4, dw_max = 1e40, dc_bar = 1e-8, kwp = 8.0, kwpb = 100.0, kwm = 1.0 / 3.0, kc = 0.25;
     delta_w = 0.0; delta_c = 0.0;
     // large unpivoted systems: skip regularisation values that are provably too small
@@ -1203,6 +1231,7 @@ class Ipm {
 
   // K v for the reduced system at the current iterate (for iterative refinement)
   DNLP_HD void kkt_mult(const double* v, double dw, double* out) {
+    DNLP_IPM_LDS();
     bool quasi = false;
     if constexpr (E::has_host_control) if (lm_on()) { lm_hess_mult(v, out); quasi = true; }
     if (!quasi) md_->hess_mult(v, out);
@@ -1216,6 +1245,7 @@ class Ipm {
 
   // solve K sol = rhs with iterative refinement on the unfactored operator
   DNLP_HD bool solve_refined(double dw) {
+    DNLP_IPM_LDS();
     double t0 = now_sec();
     kkt_solve(rhs, sol);
     const double* rr = rhs;
@@ -1270,6 +1300,7 @@ class Ipm {
 
   // direction for barrier parameter muv with primal residual `pres` (rp or the SOC one)
   DNLP_HD bool compute_direction(double muv, const double* pres, double dw, bool centering = false) {
+    DNLP_IPM_LDS();
     double* r = rhs;
     const double *rxx = rx, *q = rs, *sS = Ss, *eq = eqmask;
     const i64 NN = N;
@@ -1301,6 +1332,7 @@ class Ipm {
 
   // fraction-to-boundary step sizes (WB eq. (15))
   DNLP_HD double max_step_primal(double tauv) {
+    DNLP_IPM_LDS();
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *ddx = dx, *dds = ds, *eq = eqmask;
     double ax = ex_->min(N, [=] DNLP_HD(i64 j) {
       double a = 1.0;
@@ -1318,6 +1350,7 @@ class Ipm {
     return std::min(1.0, std::min(ax, as));
   }
   DNLP_HD double max_step_dual(double tauv) {
+    DNLP_IPM_LDS();
     const double *a = zL, *b = zU, *c = vL, *d = vU, *da = dzL, *db = dzU, *dc = dvL, *dd2 = dvU;
     double az = ex_->min(N, [=] DNLP_HD(i64 j) {
       double t = 1.0;
@@ -1336,6 +1369,7 @@ class Ipm {
 
   // both fraction-to-boundary step sizes in one pass over [variables | constraint rows]
   DNLP_HD D2 max_steps(double tauv) {
+    DNLP_IPM_LDS();
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *ddx = dx, *dds = ds, *eq = eqmask;
     const double *a = zL, *b = zU, *c = vL, *d = vU, *da = dzL, *db = dzU, *dc = dvL, *dd2 = dvU;
     const i64 NN = N;
@@ -1369,6 +1403,7 @@ class Ipm {
 
   // ---- convergence tests (IPOPT OptimalityErrorConvergenceCheck) ----------------------
   DNLP_HD int check_convergence(const Err& e0) {
+    DNLP_IPM_LDS();
     double unsc_du = e0.dual / sf;
     double unsc_pr = e0.primal_unscaled;          // computed in the same pass as the scaled norms (error())
     double unsc_co = e0.cmpl / sf;
@@ -1385,6 +1420,7 @@ class Ipm {
 
   // ---- one interior-point iteration; returns IPOPT status or 99 to continue -----------
   DNLP_HD int step() {
+    DNLP_IPM_LDS();
     if (!initialized) return status = Internal_Error;
     // (the optimality error of this point was already computed for the log line that closed the
     // previous iteration: nine reductions saved per iteration)
@@ -1565,6 +1601,7 @@ class Ipm {
   }
 
   DNLP_HD void trial_point(double alpha) {
+    DNLP_IPM_LDS();
     double *a = xt, *b = st;
     const double *xx = x, *ss = s, *ddx = dx, *dds = ds, *eq = eqmask, *sl = sL;
     ex_->map(N, [=] DNLP_HD(i64 j) { a[j] = xx[j] + alpha * ddx[j]; });
@@ -1572,6 +1609,7 @@ class Ipm {
   }
 
   DNLP_HD void accept_trial(double alpha, double a_z, double f_new) {
+    DNLP_IPM_LDS();
     double *xx = x, *ss = s, *yy = y, *a = zL, *b = zU, *c = vL, *d = vU;
     const double *nx = xt, *ns = st, *ddy = dy, *da = dzL, *db = dzU, *dc = dvL, *dd2 = dvU;
     ex_->map(N, [=] DNLP_HD(i64 j) { xx[j] = nx[j]; a[j] += a_z * da[j]; b[j] += a_z * db[j]; });
@@ -1587,6 +1625,7 @@ class Ipm {
 
   // WB eq. (16): keep z within [mu/(kS (x-l)), kS mu/(x-l)]
   DNLP_HD void reset_bound_multipliers() {
+    DNLP_IPM_LDS();
     const double kS = 1e10, muv = mu;
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *eq = eqmask;
     double *a = zL, *b = zU, *c = vL, *d = vU;
@@ -1640,6 +1679,7 @@ class Ipm {
 
   // ---- barrier parameter strategies --------------------------------------------------
   DNLP_HD double avg_complementarity() {
+    DNLP_IPM_LDS();
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *a = zL, *b = zU, *c = vL, *d = vU, *eq = eqmask;
     i64 nb = n_bound_mults();
     if (nb == 0) return 0.0;
@@ -1673,6 +1713,7 @@ class Ipm {
   }
 
   DNLP_HD void monotone_update() {
+    DNLP_IPM_LDS();
     const double k_eps = 10.0, k_mu = 0.2, th_mu = 1.5;
     const double mu_floor = mu_floor_now();
     for (int k = 0; k < 50; ++k) {
@@ -1702,10 +1743,12 @@ class Ipm {
   // started at 0.8 * average complementarity, until it does.
   // Returns true when the free-mode oracle must be run after the factorisation.
   DNLP_HD void hist_push(double v) {
+    DNLP_IPM_LDS();
     if (n_hist == 4) { for (int k = 1; k < 4; ++k) kkt_hist[k - 1] = kkt_hist[k]; --n_hist; }
     kkt_hist[n_hist++] = v;
   }
   DNLP_HD bool update_mu(const Err& e0) {
+    DNLP_IPM_LDS();
     if (n_bound_mults() == 0) { tau = 0.99; return false; }   // no barrier terms at all
     if (opt.mu_strategy == 0) { monotone_update(); return false; }
     const double mu_floor = mu_floor_now();
@@ -1739,6 +1782,7 @@ class Ipm {
   // log(sigma), mu = sigma * average complementarity.  On success the search direction for the
   // chosen mu is already in dx..dvU and rx/rs hold the residuals for that mu.
   DNLP_HD bool quality_function_mu(double dw) {
+    DNLP_IPM_LDS();
     const double avg = avg_complementarity();
     const i64 nb = n_bound_mults();
     if (!(avg > 0.0) || nb == 0) return false;
@@ -1920,6 +1964,7 @@ class Ipm {
   // the iterate strictly inside its bounds, until the point is acceptable to the filter and
   // reduces the violation by the factor 0.9.
   DNLP_HD bool restoration_phase(double theta_k) {
+    DNLP_IPM_LDS();
     const double phi_k = barrier_at(f, x, s, mu);
     filter_add((1.0 - 1e-5) * theta_k, phi_k - 1e-8 * theta_k);
     double th_cur = theta_k;
@@ -1998,6 +2043,7 @@ class Ipm {
   // steps overshoot the tolerance).  A few more iterations toward tol / 1000 make up for that; if they
   // do not get there the better of the two points that satisfies the requested tolerance is kept.
   DNLP_HD void polish() {
+    DNLP_IPM_LDS();
     double* sv[7] = {x, s, y, zL, zU, vL, vU};
     const i64 sz[7] = {N, m, m, N, N, m, m};
     for (int k = 0; k < 7; ++k) ex_->d2d(aff[k], sv[k], sizeof(double) * static_cast<size_t>(sz[k]));   // aff: free in monotone mode
@@ -2025,6 +2071,7 @@ class Ipm {
 
   // ---- driver -------------------------------------------------------------------------
   DNLP_HD int solve(const double* x0_ctl) {
+    DNLP_IPM_LDS();
     const double t_all = now_sec();
     in_solve_ = true;
     int rc = begin(x0_ctl);
@@ -2091,6 +2138,7 @@ class Ipm {
 
   // unscaled results into exec-space arrays (any may be null); `res` / `cor` are free between steps
   DNLP_HD void extract_exec(double* xo, double* mult_g, double* mult_xL, double* mult_xU, double* gout) {
+    DNLP_IPM_LDS();
     const double sff = sf;
     const double *xx = x, *yy = y, *sgp = sg, *a = zL, *b = zU, *gg = g;
     if (xo) ex_->map(N, [=] DNLP_HD(i64 j) { xo[j] = xx[j]; });
@@ -2103,6 +2151,7 @@ class Ipm {
 
   // unscaled results to control-space buffers (any may be null)
   DNLP_HD void extract(double* xo, double* obj, double* mult_g, double* mult_xL, double* mult_xU, double* gout) {
+    DNLP_IPM_LDS();
     if (xo) ex_->d2h(xo, x, sizeof(double) * static_cast<size_t>(N));
     if (obj) *obj = objective_unscaled();
     extract_exec(nullptr, mult_g ? res : nullptr, mult_xL ? cor : nullptr, nullptr, gout ? cor + N : nullptr);
@@ -2117,6 +2166,7 @@ class Ipm {
 
   // iteration log line + the user's intermediate callback; false = the user asked to stop
   DNLP_HD bool notify(const Err& e, double dnorm, double dw, double a_du, double a_pr, int ls) {
+    DNLP_IPM_LDS();
     log_iter(e, dnorm, dw, a_du, a_pr, ls);
 #if !DNLP_DEVICE_PASS
     if constexpr (E::has_host_control) {
@@ -2129,6 +2179,7 @@ class Ipm {
   }
 
   DNLP_HD void log_iter(const Err& e, double dnorm, double dw, double a_du, double a_pr, int ls) {
+    DNLP_IPM_LDS();
 #if !DNLP_DEVICE_PASS
     if constexpr (E::has_log) {
       char rg[16];

@@ -68,6 +68,7 @@ struct DenseKkt {
                                // makes the instance switch to the dense Bunch-Kaufman path
   DNLP_HD bool can_fallback() const { return sparse && n <= fallback_max_n; }
   DNLP_HD void fallback_to_dense() {
+    DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     sparse = false;
     const i64 keep = pivot_max_n;
     if (pivot_max_n < n) pivot_max_n = n;      // the fallback is the pivoted factorisation
@@ -134,6 +135,7 @@ struct DenseKkt {
   // Q^T (P K P^T) Q in place on the lower triangle: the diagonal blocks (and the sign choice), then the rows of every
   // pair left of its block, then the columns below it — pairs own disjoint rows / columns, so a pass has no conflicts
   DNLP_HD void rotate_pairs() {
+    DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     double* Kp = K;
     const i64 ldk = ld, nn = n, np = npairs;
     const i32* pos = ppos;
@@ -342,6 +344,7 @@ struct DenseKkt {
   }
 
   DNLP_HD void solve(const double* rhs, double* sol) {
+    DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     if (sol != rhs) ex->d2d(sol, rhs, sizeof(double) * static_cast<size_t>(n));
     if (sparse) {
       bool tail_done = false;

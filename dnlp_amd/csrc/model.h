@@ -61,6 +61,7 @@ struct Model {
 
   // y = base + M v   (base may be null)
   DNLP_HD void spmv(const Csr& M, const double* v, const double* base, double* y) {
+    DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     if constexpr (E::is_device && E::has_host_control) {
       // long rows (dense constraint blocks: C3's A is 1e3 rows of 1e4 entries): a lane per row would walk
       // 1e4 entries alone; one wavefront per row reads them coalesced
@@ -78,6 +79,7 @@ struct Model {
 
   // flat (elementwise-class) sweep: one work unit per output element
   DNLP_HD void sweep_flat(const double* x, bool with_h) {
+    DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     if (t.flat_units == 0) return;
     if constexpr (E::is_device) {
       // hand-written gfx950 kernel (exec_hip.h); the lambda below is the same arithmetic
@@ -162,6 +164,7 @@ struct Model {
 
   // reduction-class segments: quad_form (dense / sparse), quad_over_lin
   DNLP_HD void sweep_reductions(const double* x, bool with_h) {
+    DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     for (i64 rk = 0; rk < t.nred; ++rk) {
       const SegHost& g = t.segs[t.red_segs[rk]];
       double* z = xz + t.N;
@@ -232,6 +235,7 @@ struct Model {
 
   // values + first-derivative element arrays at x (x: exec space, N)
   DNLP_HD void sweep(const double* x, bool with_h) {
+    DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     set_x(x);
     sweep_flat(xz, with_h);
     sweep_reductions(xz, with_h);
@@ -239,6 +243,7 @@ struct Model {
 
   // ---- reference callback set (all pointers exec space) ------------------------
   DNLP_HD double eval_f_after_sweep() {
+    DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     const double* cc = t.c;
     const double* v = xz;
     return t.c0 + ex->sum(t.N + t.Z, [=] DNLP_HD(i64 i) { return cc[i] * v[i]; });
@@ -249,6 +254,7 @@ struct Model {
 
   // Hessian of sigma f + lambda.g at x; sparse part -> Hs, dense block weights -> dense_w
   DNLP_HD void eval_hess(const double* x, double sigma, const double* lambda) {
+    DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     double* s = sl;
     const i64 mm = t.m;
     ex->map(1 + mm, [=] DNLP_HD(i64 i) { s[i] = (i == 0) ? sigma : lambda[i - 1]; });
@@ -267,6 +273,7 @@ struct Model {
 
   // COO Hessian values (lower triangle, fixed pattern) into `out` (exec space, nnzH)
   DNLP_HD void hess_coo(double* out) {
+    DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     if (!t.coo_complete) DNLP_FAIL("dense quad_form block too large for a COO Hessian; use the solver-level entry points");
     ex->d2d(out, Hs, static_cast<size_t>(t.nnzH) * sizeof(double));
     for (i64 k = 0; k < t.nblk; ++k) {
@@ -290,6 +297,7 @@ struct Model {
 
   // out = W v  (W = current Lagrangian Hessian, symmetric) ; v, out: exec space N
   DNLP_HD void hess_mult(const double* v, double* out) {
+    DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     const i64 NN = t.N;
     ex->zero(out, static_cast<size_t>(NN) * sizeof(double));
     // sparse part: serial-safe scatter through a row-wise pass is not available in COO
@@ -312,10 +320,12 @@ struct Model {
 
   // out(m) = J v ; out(N) = J^T v with COO values jv on the fixed pattern
   DNLP_HD void jac_mult(const double* jv, const double* v, double* out) {
+    DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     ex->zero(out, static_cast<size_t>(t.m) * sizeof(double));
     ex->coo_mult(t.nnzJ, t.jac_rows, t.jac_cols, jv, v, out, false);
   }
   DNLP_HD void jac_tmult(const double* jv, const double* v, double* out) {
+    DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     ex->zero(out, static_cast<size_t>(t.N) * sizeof(double));
     ex->coo_mult(t.nnzJ, t.jac_rows, t.jac_cols, jv, v, out, true);
   }
