@@ -166,7 +166,9 @@ def _solve_portfolio(make_handle):
     w, t1, t2 = val(w_var), val(t1_var), float(val(t2_var)[0])
     assert abs(np.sum(w) - 1.0) <= 1e-9 and np.min(w) >= -1e-12
     np.testing.assert_allclose(t1, Sigma @ w, rtol=1e-7, atol=1e-12)
-    assert abs(t2 - w @ Sigma @ w) <= 1e-9 * t2
+    # (the defining row of t2 is a constraint like any other: satisfied to the solver's tolerance — 1e-12 … 6e-12 on the
+    #  device from run to run — not to a relative 1e-9 of a value of 1.4e-4)
+    assert abs(t2 - w @ Sigma @ w) <= 1e-9 * t2 + 1e-10
     assert abs(-info["obj_val"] - (mu @ w - t2)) <= 1e-10
     rc = w * (Sigma @ w)
     rc = np.array([np.sum(rc[g]) for g in groups]) / np.sum(rc)
