@@ -38,6 +38,7 @@
 #include <queue>
 #include <vector>
 #include <atomic>
+#include <exception>
 #include <thread>
 
 #include "tape.h"
@@ -660,8 +661,21 @@ inline void build_sparse_plan(const Tape<E>& t, SparsePlanHost& plan, bool bound
   // (both are analysed -- pairing, elimination, levels -- and compared on what the numeric phase will
   // cost; the value layout and the update program, 80 % of the analysis time, are generated once)
   SparsePlanHost strict;
-  strict.analyse(t.N, t.m, t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, zero_diag, eq, t.h_jac_const, fixed, 0, jac_abs0);
-  plan.analyse(t.N, t.m, t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, zero_diag, eq, t.h_jac_const, fixed, 1, jac_abs0);
+  if (t.N + t.m >= 20000) {
+    // the two analyses are independent: side by side (NMF at notebook size: 0.2 s each, most of the symbolic phase)
+    std::exception_ptr err;
+    std::thread other([&] {
+      try { strict.analyse(t.N, t.m, t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, zero_diag, eq, t.h_jac_const, fixed, 0, jac_abs0); }
+      catch (...) { err = std::current_exception(); }
+    });
+    try { plan.analyse(t.N, t.m, t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, zero_diag, eq, t.h_jac_const, fixed, 1, jac_abs0); }
+    catch (...) { other.join(); throw; }
+    other.join();
+    if (err) std::rethrow_exception(err);
+  } else {
+    strict.analyse(t.N, t.m, t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, zero_diag, eq, t.h_jac_const, fixed, 0, jac_abs0);
+    plan.analyse(t.N, t.m, t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, zero_diag, eq, t.h_jac_const, fixed, 1, jac_abs0);
+  }
   // cost model of the level-parallel numeric phase: a level costs a few barriers, a triple a
   // fraction of that per lane — halving the depth is worth up to 3x the update work
   const double tr = static_cast<double>(plan.pred_triples), ts = static_cast<double>(strict.pred_triples);
