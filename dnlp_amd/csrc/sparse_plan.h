@@ -512,6 +512,8 @@ struct SparsePlanHost {
         pg_off.push_back(static_cast<i64>(pg_src.size()));
         pg_maxcols = std::max(pg_maxcols, cols);
       }
+      // the tail's own blocks are never walked by the level loops: no triples for them either (r^3 / 6 of them)
+      for (i64 k = tb0; k < nb; ++k) if (tcut[static_cast<size_t>(k)] > 0) { tcut[static_cast<size_t>(k)] = 0; panels_dropped = true; }
     }
     toff.assign(static_cast<size_t>(nb + 1), 0);
     for (i64 k = 0; k < nb; ++k) {

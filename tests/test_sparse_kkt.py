@@ -245,7 +245,7 @@ def test_dense_tail_and_panels_are_the_same_factorisation_host_build():
 @pytest.mark.gpu
 def test_device_dense_tail_against_the_level_chain(gpu_required):
     """The same on the MI355X (level kernels + FP64 MFMA product for the panels + dense tail): optimum of the level-chain
-    run, and the notebook-size plan (100 images: 5.5e7 triples as a chain) carries under 2e6 triples."""
+    run, with a fraction of the update program (the notebook-size plan: 5.5e7 triples as a chain, 1.2e6 with tail and panels)."""
     from dnlp_amd import _capi
     data, blob = _nmf_blob(20)
 
