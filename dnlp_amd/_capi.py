@@ -67,6 +67,7 @@ class CApi:
         f("set_warm_start", C.c_int, [C.c_void_p, _dbl_p, _dbl_p, _dbl_p])
         f("kkt_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)])
         f("kkt_mode", C.c_int, [C.c_void_p])
+        f("kkt_tail_nodes", C.c_int64, [C.c_void_p])
         f("get_stats", C.c_int, [C.c_void_p, _dbl_p, C.c_int])
         f("get_log", C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t])
         f("set_intermediate_cb", C.c_int, [C.c_void_p, INTERMEDIATE_CB, C.c_void_p])
@@ -440,6 +441,10 @@ class ProblemHandle:
         'unpivoted' (blocked LDL^T), 'paired' (unpivoted on rotated static pairs), 'paired-then-bunch-kaufman' (the static
         sequence lost digits on the way and the handle was demoted); None before the first solve."""
         return self.KKT_MODES[int(self.api.kkt_mode(self.ptr))]
+
+    def kkt_tail_nodes(self) -> int:
+        """Nodes of the dense tail of the sparse plan (0: none): such a plan is the host-driven loop's."""
+        return int(self.api.kkt_tail_nodes(self.ptr))
 
     def reset_options(self):
         self.api.reset_options(self.ptr)

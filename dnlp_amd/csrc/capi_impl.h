@@ -442,6 +442,10 @@ struct ProblemT {
              out[6] = static_cast<int64_t>(p->sparse_plan.lev_off.size()) - 1;                              \
              out[7] = (!p->use_sparse && p->model.t.N + p->model.t.m <= p->pivot_max_n) ? 1 : 0; return 0;)  \
   }                                                                                                  \
+  int64_t DNLP_CAT(PFX, kkt_tail_nodes)(HANDLE* vp) {                                                  \
+    auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
+    DNLP_TRY(p->plan_linear_solver(); return p->use_sparse ? static_cast<int64_t>(p->sparse_plan.tail_n) : 0;)     \
+  }                                                                                                  \
   int DNLP_CAT(PFX, kkt_mode)(HANDLE* vp) {                                                            \
     auto* p = static_cast<DNLP_CAT(PFX, problem_t)*>(vp);                                            \
     if (!p->kkt_ready) return -1;                                                                    \

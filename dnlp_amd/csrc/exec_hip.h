@@ -1532,7 +1532,9 @@ struct HipExec : HostControlled {
   static constexpr i64 kSparseGridMin = 8192;
   static constexpr i64 kSparseGridMinTriples = 200000;
   static bool sparse_grid_path(const SparsePlan& pl) {
-    return pl.h_lev_blk && (pl.nblk >= kSparseGridMin || pl.ntrip >= kSparseGridMinTriples);
+    // (a plan with a dense tail always: its panel products are the MFMA kernel's, not one workgroup's loops — phase
+    //  retrieval, 5.7e4 triples left beside a 128-node tail: 7 ms per factorisation in one workgroup, 0.25 ms here)
+    return pl.h_lev_blk && (pl.nblk >= kSparseGridMin || pl.ntrip >= kSparseGridMinTriples || pl.tail_n > 0);
   }
   // The level loops of the static-pattern factorisation / solves are the same launch sequence every time
   // (a plan with 300 levels is 1 200 + 600 launches of ~2 us kernels: host launch overhead, ~16 us each,

@@ -351,8 +351,10 @@ class HIPNLP:
             info = data["handle"].kkt_info()
             # one workgroup factors in-kernel: a long update program (dense-ish fronts) belongs to the
             # host-driven loop, whose level kernels use the whole chip (small NMF: 1.9 s in-kernel, 0.5 s host-driven)
+            # (a plan with a dense tail — NMF, phase retrieval — lists no triples for the tail: the count says nothing
+            #  about what ONE workgroup would have to walk, and the dense tail is the host-driven loop's anyway)
             fits = order <= self.DEVICE_LOOP_MAX_ORDER_SPARSE and info["sparse"] and \
-                info.get("update_triples", 0) <= self.DEVICE_LOOP_MAX_TRIPLES
+                info.get("update_triples", 0) <= self.DEVICE_LOOP_MAX_TRIPLES and data["handle"].kkt_tail_nodes() == 0
         if mode in (True, "yes", "device"):
             if tape.dense_blocks or tape.dense_consts:
                 raise ValueError("device_loop='yes' needs a tape without dense quad_form blocks")

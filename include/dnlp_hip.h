@@ -194,6 +194,9 @@ int dnlp_kkt_info(dnlp_problem* p, int64_t* out8);
  * static-pattern LDL^T, 1 dense Bunch-Kaufman, 2 dense unpivoted blocked LDL^T, 3 dense unpivoted on rotated static pairs,
  * 4 started as 3 and was handed to Bunch-Kaufman (element growth / zero pivot of the static sequence) */
 int dnlp_kkt_mode(dnlp_problem* p);
+/* nodes of the dense tail of the sparse plan (0: none, or a dense KKT path).  A plan with a tail belongs to the host-driven
+ * loop: its update program has no entries for the tail, which the in-kernel solver would need (it gets a second, full plan) */
+int64_t dnlp_kkt_tail_nodes(dnlp_problem* p);
 /* Statistics (n <= 24 values).  Of the last solve: stats[0..12] = iterations, factorizations, wall,
  * t_eval, t_factor, t_solve, mu, inf_pr, inf_du, compl, nlp_error, last_delta_w, objective scaling;
  * [13..15] = seconds, flops, launches of the timed outer Schur-complement updates (option
