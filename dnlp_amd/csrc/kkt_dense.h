@@ -224,6 +224,9 @@ struct DenseKkt {
             nn2 = nz2 = 0;
             oks = ex->ldlt_factor(tail_lw, Kt, r, ldt, tail_ipiv, tail_pivoted, &nn2, &nz2);
             if (tail_pivoted || (oks && nz2 == 0) || r > pivot_max_n) break;
+#if !DNLP_DEVICE_PASS
+            if (std::getenv("DNLP_PAIRED_DEBUG")) std::fprintf(stderr, "[tail] unpivoted attempt: ok %d, %d zero pivots, delta_w %.2e -> Bunch-Kaufman from here on\n", oks ? 1 : 0, nz2, dw);
+#endif
             tail_pivoted = true;
             ex->ldlt_prepare(tail_lw, r, ldt, true);
           }

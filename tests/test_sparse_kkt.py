@@ -277,3 +277,27 @@ def test_device_tail_plans_take_the_host_driven_loop(gpu_required):
     assert info["status"] == 0 and info.get("device_loop") is not True
     assert abs(info["obj_val"]) <= 1e-7
     assert wall < 0.4, wall
+
+
+@pytest.mark.gpu
+def test_device_batch_of_a_tailed_plan_gets_a_full_plan(gpu_required):
+    """best_of on a problem whose handle carries a plan with a dense tail: the batch kernel cannot use that plan (its
+    update program has no entries for the tail), so the C ABI builds a second, full plan for the in-kernel solver."""
+    import dnlp_amd as cp
+    from paper_examples import PAPER
+    prob = PAPER["nb_phase_retrieval"](cp)
+    for v in prob.variables():
+        v.sample_bounds = (-1.0, 1.0)
+    np.random.seed(3)
+    prob.solve(nlp=True, best_of=2)
+    # (random starts of a non-convex problem: a KKT point, not necessarily the global optimum 0 of the default start)
+    assert prob.status == cp.OPTIMAL
+    assert np.isfinite(prob.value) and prob.value >= -1e-9
+    assert data_handle_modes(prob) == "sparse"
+
+
+def data_handle_modes(prob):
+    """kkt mode of the handle behind a solved Problem (the lowered data is cached on the problem)."""
+    chain = prob._build_chain(None)
+    data, _ = chain.apply(prob)
+    return "sparse" if data["handle"].kkt_info()["sparse"] else "dense"
