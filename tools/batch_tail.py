@@ -13,7 +13,8 @@ from dnlp_amd.batch import ParametricBatch, arrays_with_data  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 nlogs = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-prob, params, sample, var = bp.template_localization()
+which = sys.argv[3] if len(sys.argv) > 3 else "localization"          # localization | circle_packing10 | power_flow | path_planning
+prob, params, sample, var = getattr(bp, "template_" + which)()
 pb = ParametricBatch(prob, params)
 thetas = np.stack([sample(i) for i in range(B)])
 mat = pb.data(thetas)
@@ -26,7 +27,9 @@ h, _ = np.histogram(it, edges)
 print("iteration histogram", dict(zip(["<%d" % e for e in edges[1:]], h.tolist())))
 print("instance wall ms: mean %.3f, p99 %.3f, max %.3f" % (1e3 * wall.mean(), 1e3 * np.quantile(wall, 0.99), 1e3 * wall.max()))
 order = np.argsort(-it)
-print("slowest", [(int(i), int(it[i]), round(1e3 * wall[i], 2), int(res.factorizations[i])) for i in order[:12]])
+print("slowest", [(int(i), int(it[i]), round(1e3 * wall[i], 2), int(res.factorizations[i]), int(res.status[i])) for i in order[:12]])
+print("statuses", {int(k): int(v) for k, v in zip(*np.unique(res.status, return_counts=True))})
+print("sum of instance walls %.3f s over %d instances; slowest instance %.3f s" % (wall.sum(), B, wall.max()))
 from oracle_check import OracleProblem  # noqa: E402
 from dnlp_amd.nlp_solver import HIPNLP  # noqa: E402
 from dnlp_amd.tape import serialize  # noqa: E402
