@@ -183,6 +183,76 @@ __global__ void __launch_bounds__(kBlock) gemv_stage2(i64 n, i64 ncb, const doub
   y[r] = s;
 }
 
+// The same product from the LOWER triangle only (A symmetric, stored in full): half the bytes.  A block of 512 rows x
+// GEMV_CB columns on or below the diagonal gives BOTH contributions of its entries: the row sums y_i += a_ij x_j as
+// above, and the column sums y_j += a_ij x_i — per column a DPP wave reduction of the two products a lane holds
+// (the VALU work grows from 2 to ~22 instructions per 1 KiB of matrix, still a third of what the memory rate allows),
+// kept by lane j mod 64, the four wavefronts' sums combined through LDS into part2[rb][column].  Blocks that the
+// diagonal crosses predicate per element (i >= j for the row sum, i > j for the column sum); blocks above it exit.
+// Stage 2 adds, in a fixed order, the row-sum partials of the column blocks left of the diagonal and the column-sum
+// partials of the row blocks below it: bitwise reproducible like the full product.
+__global__ void __launch_bounds__(kBlock) gemv_sym_stage1(i64 n, const double* __restrict__ A, i64 ld,
+                                                          const double* __restrict__ x, double* __restrict__ part,
+                                                          double* __restrict__ part2, i64 nrb) {
+  __shared__ double tl[kBlock / 64][GEMV_CB];
+  const i64 rb = blockIdx.x % nrb, cb = blockIdx.x / nrb;
+  const i64 row0 = rb * 512, c0 = cb * GEMV_CB;
+  if (row0 + 512 <= c0) return;                                   // every row above every column of the block
+  const i64 c1 = c0 + GEMV_CB < n ? c0 + GEMV_CB : n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const i64 r0 = row0 + 2 * static_cast<i64>(threadIdx.x);
+  const bool in0 = r0 < n, in1 = r0 + 1 < n;
+  const double xr0 = in0 ? x[r0] : 0.0, xr1 = in1 ? x[r0 + 1] : 0.0;
+  const bool crossing = row0 < c0 + GEMV_CB;                      // some entries of the block lie above the diagonal
+  double a0 = 0.0, a1 = 0.0;
+  double keep[GEMV_CB / 64];
+#pragma unroll
+  for (int q = 0; q < GEMV_CB / 64; ++q) keep[q] = 0.0;
+  const double* col = A + (in0 ? r0 : 0) + c0 * ld;
+  for (i64 j = c0; j < c1; ++j, col += ld) {
+    double2 v = double2{0.0, 0.0};
+    if (in1) v = *reinterpret_cast<const double2*>(col);          // (every lane of the wavefront stays in the loop: the
+    else if (in0) v.x = col[0];                                   //  reduction below is wave-wide)
+    const double xj = x[j];
+    double t;
+    if (!crossing) {
+      a0 = fma(v.x, xj, a0);
+      a1 = fma(v.y, xj, a1);
+      t = fma(v.x, xr0, v.y * xr1);
+    } else {
+      a0 += (r0 >= j) ? v.x * xj : 0.0;
+      a1 += (r0 + 1 >= j) ? v.y * xj : 0.0;
+      t = ((r0 > j) ? v.x * xr0 : 0.0) + ((r0 + 1 > j) ? v.y * xr1 : 0.0);
+    }
+    const double T = wave_all_sum(t);
+    const int jj = static_cast<int>(j - c0);
+#pragma unroll
+    for (int q = 0; q < GEMV_CB / 64; ++q) if ((jj >> 6) == q && lane == (jj & 63)) keep[q] = T;
+  }
+  if (in0) part[cb * n + r0] = a0;
+  if (in1) part[cb * n + r0 + 1] = a1;
+#pragma unroll
+  for (int q = 0; q < GEMV_CB / 64; ++q) tl[wave][lane + 64 * q] = keep[q];
+  __syncthreads();
+  const i64 jc = c0 + threadIdx.x;
+  if (jc < n) {
+    double sacc = tl[0][threadIdx.x];
+    for (int w2 = 1; w2 < kBlock / 64; ++w2) sacc += tl[w2][threadIdx.x];
+    part2[rb * n + jc] = sacc;
+  }
+}
+__global__ void __launch_bounds__(kBlock) gemv_sym_stage2(i64 n, i64 nrb, const double* __restrict__ part,
+                                                          const double* __restrict__ part2, double* __restrict__ y) {
+  const i64 r = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+  if (r >= n) return;
+  double s = 0.0;
+  const i64 cmax = ((r / 512) * 512 + 511) / GEMV_CB;             // last column block the row's row block touched
+  for (i64 c = 0; c <= cmax && c * GEMV_CB < n; ++c) s += part[c * n + r];
+  const i64 bmin = ((r / GEMV_CB) * GEMV_CB) / 512;               // first row block that touched the column's column block
+  for (i64 b = bmin; b < nrb; ++b) s += part2[b * n + r];
+  y[r] = s;
+}
+
 // K[x0+r, x0+c] (+)= w P[r,c] on r >= c.  grid.x walks 512-row tiles (two rows per lane, 16-B
 // accesses down the column), grid.y strides over columns; tiles above the diagonal exit.
 __global__ void __launch_bounds__(kBlock) dense_block_add_kernel(double* __restrict__ K, i64 ldk, i64 x0,
@@ -1474,11 +1544,21 @@ struct HipExec : HostControlled {
   }
   void gemv_sym(i64 n, const double* P, i64 ld, const double* u, double* out) {
     const i64 nrb = (n + 511) / 512, ncb = (n + GEMV_CB - 1) / GEMV_CB;
-    const size_t need = static_cast<size_t>(ncb) * static_cast<size_t>(n);
+    static const bool lower_only = std::getenv("DNLP_GEMV_FULL") == nullptr;
+    const bool tri = lower_only && n >= 4096 && (ld & 1) == 0 && (reinterpret_cast<uintptr_t>(P) & 15) == 0 && kBlock == 256;
+    const size_t need = (static_cast<size_t>(ncb) + (tri ? static_cast<size_t>(nrb) : 0)) * static_cast<size_t>(n);
     if (need > gemv_part_cap) {
       if (gemv_part) DNLP_HIP_CHECK(hipFree(gemv_part));
       DNLP_HIP_CHECK(hipMalloc(&gemv_part, need * sizeof(double)));
       gemv_part_cap = need;
+    }
+    if (tri) {
+      // the lower triangle only: half the bytes of the full product (A is symmetric and stored in full)
+      double* part2 = gemv_part + static_cast<size_t>(ncb) * static_cast<size_t>(n);
+      hipLaunchKernelGGL(gemv_sym_stage1, dim3(static_cast<unsigned>(nrb * ncb)), dim3(kBlock), 0, stream, n, P, ld, u, gemv_part, part2, nrb);
+      hipLaunchKernelGGL(gemv_sym_stage2, dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, n, nrb, gemv_part, part2, out);
+      DNLP_LAUNCH_CHECK();
+      return;
     }
     hipLaunchKernelGGL(gemv_stage1, dim3(static_cast<unsigned>(nrb * ncb)), dim3(kBlock), 0, stream, n, P, ld, u, gemv_part, nrb);
     hipLaunchKernelGGL(gemv_stage2, dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, n, ncb, gemv_part, out);

@@ -185,6 +185,24 @@ def test_device_matrix_sphere_and_symv(gpu_required):
     assert abs(float(prob._nlp_last["mult_g"][0]) - lam_max) <= 1e-6 * lam_max
 
 
+@pytest.mark.parametrize("n", [4096, 4097, 4611, 6000, 9999])
+def test_device_symmetric_product_from_the_lower_triangle(gpu_required, n):
+    """From order 4096 the symmetric product reads the lower triangle only (gemv_sym_stage1: row sums and, by DPP wave
+    reductions, column sums of every block on or below the diagonal).  Against numpy on the downloaded matrix, at
+    orders that leave ragged last blocks (odd order: a last lane with one row), and against the full-matrix kernels
+    (DNLP_GEMV_FULL is read once per process, so the comparison kernel is the order-1500 path of the test above)."""
+    from dnlp_amd.device import symmetric_test_matrix
+    A = symmetric_test_matrix(n, seed=n, spike_eig=2.0 * np.sqrt(n), device=0)
+    Ah = A.to_host()
+    rng = np.random.default_rng(n)
+    for _ in range(2):
+        xh = rng.standard_normal(n)
+        ref = Ah @ xh
+        got = A.symv(xh)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-10 * np.linalg.norm(ref, np.inf) * np.sqrt(n))
+        assert np.array_equal(got, A.symv(xh))            # fixed summation order: bitwise reproducible
+
+
 def test_dense_eq_qp_blocked_kkt_closed_form(gpu_required):
     """BASELINE C3 shape (dense equality-constrained QP) at n=2400, m=240: KKT order 2640 goes
     through the blocked FP64-MFMA LDL^T; one Newton step must reproduce the closed-form KKT
