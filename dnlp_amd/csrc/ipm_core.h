@@ -119,6 +119,14 @@ typedef int (*IntermediateCb)(int alg_mod, int iter_count, double obj_value, dou
 // (see exec.h: DNLP_THIS_IN_LDS) — at the top of every member function of the in-kernel instantiation
 #define DNLP_IPM_LDS() do { DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex_); DNLP_PTR_IN_LDS(E, md_); DNLP_PTR_IN_LDS(E, kkt_); } while (0)
 
+// (in the in-kernel space step() is inlined into its three call sites: as a called function it saves and restores ~107
+//  callee-saved VGPRs per call — 27 KB per wavefront each way — that its caller never uses)
+#if DNLP_DEVICE_PASS
+#define DNLP_STEP_INLINE __attribute__((always_inline))
+#else
+#define DNLP_STEP_INLINE
+#endif
+
 template <class E, class K>
 class Ipm {
  public:
@@ -1419,7 +1427,7 @@ class Ipm {
   }
 
   // ---- one interior-point iteration; returns IPOPT status or 99 to continue -----------
-  DNLP_HD int step() {
+  DNLP_STEP_INLINE DNLP_HD int step() {
     DNLP_IPM_LDS();
     if (!initialized) return status = Internal_Error;
     // (the optimality error of this point was already computed for the log line that closed the
