@@ -29,6 +29,12 @@ print("instance wall ms: mean %.3f, p99 %.3f, max %.3f" % (1e3 * wall.mean(), 1e
 order = np.argsort(-it)
 print("slowest", [(int(i), int(it[i]), round(1e3 * wall[i], 2), int(res.factorizations[i]), int(res.status[i])) for i in order[:12]])
 print("statuses", {int(k): int(v) for k, v in zip(*np.unique(res.status, return_counts=True))})
+ph = res.raw["phase_seconds"]
+tot_it = float(it.sum())
+print("per iteration (mean over all instances, device clock): wall %.3f ms = tape %.3f + factorisation %.3f + solves %.3f + rest %.3f" % (
+    1e3 * ph[:, 0].sum() / tot_it, 1e3 * ph[:, 1].sum() / tot_it, 1e3 * ph[:, 2].sum() / tot_it, 1e3 * ph[:, 3].sum() / tot_it,
+    1e3 * (ph[:, 0] - ph[:, 1] - ph[:, 2] - ph[:, 3]).sum() / tot_it))
+print("factorisations per iteration %.2f" % (float(res.factorizations.sum()) / tot_it))
 print("sum of instance walls %.3f s over %d instances; slowest instance %.3f s" % (wall.sum(), B, wall.max()))
 from oracle_check import OracleProblem  # noqa: E402
 from dnlp_amd.nlp_solver import HIPNLP  # noqa: E402
