@@ -70,6 +70,8 @@ __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
     alignas(16) char kkt[sizeof(KktT)];
     alignas(16) char ipm[sizeof(IpmT)];
   };
+  // (exec.h DNLP_THIS_IN_LDS: the member functions of these objects ASSUME that they live in LDS — EX::objects_in_lds;
+  //  an instance of BlockExecT / Model / DenseKkt / Ipm over it placed anywhere else would be undefined behaviour)
   __shared__ Objs s_objs[NW];
   __shared__ double s_red[8];
   __shared__ int s_redi[8];
