@@ -92,7 +92,7 @@ struct DenseKkt {
         Kt = ex->template alloc<double>(static_cast<size_t>(tail_ld) * static_cast<size_t>(sp.tail_n) + 256);
         tail_ipiv = ex->template alloc<i32>(static_cast<size_t>(sp.tail_n));
         tail_x = ex->template alloc<double>(static_cast<size_t>(sp.tail_n));
-        tail_pivoted = sp.tail_n <= pivot_max_n && (!E::is_device || sp.tail_n < 64);   // (see assemble_factor)
+        tail_pivoted = sp.tail_n <= pivot_max_n && !E::is_device;   // (device: unpivoted first, see assemble_factor)
         tail_lw.padded = true;
         ex->ldlt_prepare(tail_lw, sp.tail_n, tail_ld, tail_pivoted);
       }

@@ -59,7 +59,7 @@ struct SparsePlan {
   i32* tnode = nullptr;               // tail_n: KKT node of every tail position
   i32* tg_src = nullptr;              // tg_count: value index in the plan's storage ...
   i32* tg_dst = nullptr;              // ... and its place r + c * tail_n (r >= c) in the dense tail
-  // Panels: a block before the tail whose struct ends in >= 16 tail nodes (NMF: 1 200 blocks with 300 each, 5.4e7 of
+  // Panels: a block before the tail whose struct ends in >= 12 tail nodes (NMF: 1 200 blocks with 300 each, 5.4e7 of
   // the 5.5e7 update triples) carries NO triples for its tail x tail pairs.  After the level's rows are scaled its tail
   // rows are gathered into two dense panels (l and w = l D^-1, tail_ld x pg_cols[level]) and the level's whole
   // contribution to the tail is ONE product  T -= Pl Pw^T  into the accumulator T (tail_ld x tail_n, lower triangle),
@@ -498,7 +498,7 @@ struct SparsePlanHost {
           const i64 s0 = soff[static_cast<size_t>(k)], sz = soff[static_cast<size_t>(k + 1)] - s0;
           i64 h = sz;                                   // the struct is sorted by elimination position: tail nodes last
           while (h > 0 && npos[static_cast<size_t>(sidx[static_cast<size_t>(s0 + h - 1)])] >= tb0) --h;
-          if (sz - h < 16) continue;
+          if (sz - h < 12) continue;
           tcut[static_cast<size_t>(k)] = h;
           panels_dropped = true;
           const int bk = bnode[static_cast<size_t>(2 * k + 1)] >= 0 ? 2 : 1;
@@ -579,8 +579,9 @@ struct SparsePlanHost {
     bstruct_.clear(); bstruct_.shrink_to_fit();
   }
 
-  // The longest suffix of levels that is a dense chain: 1x1 blocks only, at least 16 levels and 48 nodes (a tail of 36
-  // nodes — the 12-image NMF — measured 2.6x SLOWER than its chain on the MI355X: 0.87 against 0.33 s), at most
+  // The longest suffix of levels that is a dense chain: 1x1 blocks only, at least 12 levels and 24 nodes (the 36-node
+  // tail of the 12-image NMF: 0.31 -> 0.26 s per solve on the MI355X with the unpivoted dense factor; with Bunch-Kaufman
+  // on that tail it was 2.6x SLOWER than the chain), at most
   // 8192 nodes, at least 60 % of the tail's lower triangle structurally present, and narrow (two blocks per level on
   // average at most: a wide level is parallel work the level kernels handle well).
   void choose_tail() {
@@ -596,7 +597,7 @@ struct SparsePlanHost {
       rows += soff[static_cast<size_t>(b1)] - soff[static_cast<size_t>(b0)];
       const i64 r = nb - b0, levels = nl - lev;
       if (r > 8192 || r > 2 * levels) break;
-      if (levels >= 16 && r >= 48 && static_cast<double>(rows) >= 0.6 * 0.5 * static_cast<double>(r) * static_cast<double>(r - 1)) best = lev;
+      if (levels >= 12 && r >= 24 && static_cast<double>(rows) >= 0.6 * 0.5 * static_cast<double>(r) * static_cast<double>(r - 1)) best = lev;
     }
     if (best < 0) return;
     tail_lev = best;

@@ -189,7 +189,9 @@ def test_level_graph_replay_is_the_same_computation(gpu_required, monkeypatch):
         chain = prob._build_chain(None)
         data, inv = chain.apply(prob)
         info_k = data["handle"].kkt_info()
-        assert info_k["sparse"] and info_k["update_triples"] > 200000      # the level-kernel path, host-driven loop
+        # the level-kernel path, host-driven loop: a long update program, or (since the 36-node chain at the end of this
+        # plan became a dense tail) a plan with a tail, which always takes it
+        assert info_k["sparse"] and (info_k["update_triples"] > 200000 or data["handle"].kkt_tail_nodes() > 0)
         info = chain.solver.solve_via_data(data, True, False, {})
         assert info.get("device_loop") is not True
         runs.append(info)
