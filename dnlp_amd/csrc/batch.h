@@ -466,7 +466,18 @@ struct BatchRunner {
     if ((mode & 2) && wave && !std::getenv("DNLP_BATCH_VLDS_KB")) {
       const int s_now = slots(mode);
       if (s_now >= 1 && s_now < slots_max) {
-        const size_t fixed = stage_bytes + (mode & 1 ? kbytes : 0) + fa.sharedSizeBytes + 256 + 3072;   // (+ the plan's solve arrays)
+        // Room for the LDS copy of the plan's index arrays (2.7 KB) or 2.6 KB more of the vectors?  Measured, localization,
+        // 4 per CU (tools/micro/batch_lds_share_sweep.sh; problems/s, kernel): the plan arrays shorten an instance's
+        // iteration — what a batch of a few instances per slot is made of (8192: 235 k against 218 k) — the vectors raise
+        // the throughput of a long queue (16 384: 242 -> 264 k, 65 536: 246 -> 268 k).  From twelve instances per slot on
+        // the vectors get the room.
+        if (this->ncu == 0) {
+          int v = 0;
+          DNLP_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ex->device));
+          this->ncu = v;
+        }
+        const bool long_queue = static_cast<i64>(batch) >= 12 * static_cast<i64>(this->ncu) * (s_now + 1);
+        const size_t fixed = stage_bytes + (mode & 1 ? kbytes : 0) + fa.sharedSizeBytes + 256 + (long_queue ? 512 : 3072);
         const size_t room = (160 * 1024) / static_cast<size_t>(s_now + 1);
         if (room > fixed) {
           const size_t want = (room - fixed) & ~static_cast<size_t>(63);
