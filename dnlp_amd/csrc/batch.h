@@ -37,6 +37,7 @@ struct BatchArgs {
   unsigned lds_bytes = 0;        // dynamic LDS pool (0: everything in global memory)
   int lds_mode = 0;              // what the pool holds: 0 nothing, 1 KKT matrix, 2 vectors, 3 both
   unsigned lds_stage_bytes = 0;  // front of the pool: staging arrays of the dense wavefront solves
+  unsigned stage_global_bytes = 0;   // ... or, for sparse instances with a dense fallback, the tail of the block's global slab
   unsigned plan_stage_bytes = 0; // then: LDS copy of the sparse plan's solve-phase index arrays (0: read from global)
   int plan_stage_factor = 0;     // ... and of the factor-phase / assembly arrays (update triples, value positions)
   i64 plan_rows = 0;             // struct rows of the plan (length of sidx / sblk)
@@ -126,8 +127,12 @@ __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
     const int inst = s_inst;
     __syncthreads();
     if (inst >= a.batch) break;
-    EX* ex = new (o.ex) EX(a.ws + static_cast<size_t>(blockIdx.x) * a.ws_per_block, a.ws_per_block, lds_dyn + stage + pstage,
-                           a.lds_bytes - stage - pstage, s_red, s_redi, stage ? s_vec : nullptr, stage ? s_piv : nullptr);
+    char* slab = a.ws + static_cast<size_t>(blockIdx.x) * a.ws_per_block;
+    const size_t slab_cap = a.ws_per_block - a.stage_global_bytes;
+    double* g_vec = a.stage_global_bytes ? reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(slab + slab_cap) + 63) & ~static_cast<uintptr_t>(63)) : nullptr;
+    int* g_piv = g_vec ? reinterpret_cast<int*>(g_vec + EX::kWaveSolveMax) : nullptr;
+    EX* ex = new (o.ex) EX(slab, slab_cap, lds_dyn + stage + pstage,
+                           a.lds_bytes - stage - pstage, s_red, s_redi, stage ? s_vec : g_vec, stage ? s_piv : g_piv);
     ex->lds_mode = a.lds_mode;
     double* sl = a.slabs + static_cast<i64>(inst) * a.lay.total;
     TapeView t = a.base;
@@ -437,7 +442,11 @@ struct BatchRunner {
     // per CU.  DNLP_BATCH_LDS=0..3 overrides, for experiments.
     // staging for the dense single-wavefront solves is needed whenever the dense path can run
     const bool dense_possible = !have_sparse || (n <= 512 && !force_sparse);
-    const size_t stage_bytes = dense_possible ? static_cast<size_t>(BlockExecT<64>::kWaveSolveMax) * 12 : 0;
+    // (the staging arrays of the dense wavefront solves live in LDS only where the dense path is THE path; a sparse
+    //  instance that may fall back to it — rarely, and with the lazy fallback only in the retry rungs — gets them at the
+    //  end of its global slab instead: 6 KB of LDS per instance that the vectors and the plan's index arrays use)
+    const size_t stage_bytes = !have_sparse ? static_cast<size_t>(BlockExecT<64>::kWaveSolveMax) * 12 : 0;
+    const size_t stage_global = (have_sparse && dense_possible) ? static_cast<size_t>(BlockExecT<64>::kWaveSolveMax) * 12 + 64 : 0;
     const int slots_max = wave ? 4 : 1;
     auto slots = [&](int md_) {
       const size_t dyn = stage_bytes + (md_ & 1 ? kbytes : 0) + (md_ & 2 ? vbytes_lds : 0);
@@ -466,18 +475,11 @@ struct BatchRunner {
     if ((mode & 2) && wave && !std::getenv("DNLP_BATCH_VLDS_KB")) {
       const int s_now = slots(mode);
       if (s_now >= 1 && s_now < slots_max) {
-        // Room for the LDS copy of the plan's index arrays (2.7 KB) or 2.6 KB more of the vectors?  Measured, localization,
-        // 4 per CU (tools/micro/batch_lds_share_sweep.sh; problems/s, kernel): the plan arrays shorten an instance's
-        // iteration — what a batch of a few instances per slot is made of (8192: 235 k against 218 k) — the vectors raise
-        // the throughput of a long queue (16 384: 242 -> 264 k, 65 536: 246 -> 268 k).  From twelve instances per slot on
-        // the vectors get the room.
-        if (this->ncu == 0) {
-          int v = 0;
-          DNLP_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ex->device));
-          this->ncu = v;
-        }
-        const bool long_queue = static_cast<i64>(batch) >= 12 * static_cast<i64>(this->ncu) * (s_now + 1);
-        const size_t fixed = stage_bytes + (mode & 1 ? kbytes : 0) + fa.sharedSizeBytes + 256 + (long_queue ? 512 : 3072);
+        // (+ room for the LDS copy of the plan's index arrays.  While the 6 KB staging area of the dense fallback still sat
+        //  in LDS this was a choice — plan arrays OR 2.6 KB more of the vectors, the first better for short queues, the
+        //  second for long ones: 65 536 localization instances 246 against 268 k problems/s — with the staging area in the
+        //  global slab both fit: 290 k/s; tools/micro/batch_lds_share_sweep.sh)
+        const size_t fixed = stage_bytes + (mode & 1 ? kbytes : 0) + fa.sharedSizeBytes + 256 + 3072;
         const size_t room = (160 * 1024) / static_cast<size_t>(s_now + 1);
         if (room > fixed) {
           const size_t want = (room - fixed) & ~static_cast<size_t>(63);
@@ -516,7 +518,8 @@ struct BatchRunner {
     const bool fb = have_sparse && n <= 512 && !force_sparse;
     a.fallback_max_n = fb ? 512 : 0;
     const size_t fbbytes = fb ? (((static_cast<size_t>(ld) * n + 256) * 8 + 2 * static_cast<size_t>(n) * 8 + 4096 + 63) & ~static_cast<size_t>(63)) : 0;
-    a.ws_per_block = 256 + vbytes + (mode & 1 ? 0 : kbytes) + fbbytes;
+    a.ws_per_block = 256 + vbytes + (mode & 1 ? 0 : kbytes) + fbbytes + stage_global;
+    a.stage_global_bytes = static_cast<unsigned>(stage_global);
     DNLP_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(a.lds_bytes)));
     int per_cu = 1, ncu = 256;
     if (wave) DNLP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, batch_solve_kernel<64>, nthreads, a.lds_bytes));
