@@ -448,6 +448,17 @@ struct BatchRunner {
     const size_t stage_bytes = !have_sparse ? static_cast<size_t>(BlockExecT<64>::kWaveSolveMax) * 12 : 0;
     const size_t stage_global = (have_sparse && dense_possible) ? static_cast<size_t>(BlockExecT<64>::kWaveSolveMax) * 12 + 64 : 0;
     const int slots_max = wave ? 4 : 1;
+    // One-wavefront sparse instances whose vectors exceed LDS by far (AC power flow: 413 KB) still take the share of a
+    // four-per-CU plan: the allocator hands out LDS in allocation order and spills the rest to the global slab
+    // (1024 power-flow instances 2.24 -> 2.34 k problems/s; path planning unchanged; DNLP_BATCH_PART_LDS=0 disables).
+    if (wave && have_sparse && !(std::getenv("DNLP_BATCH_PART_LDS") && std::atoi(std::getenv("DNLP_BATCH_PART_LDS")) == 0)) {
+      const size_t room = (160 * 1024) / static_cast<size_t>(slots_max);
+      const size_t fixed = stage_bytes + fa.sharedSizeBytes + 256 + 512;
+      if (room > fixed + 4096 && 3 * (room - fixed) < 2 * vbytes_lds) {      // (below two thirds: the trim further down handles the rest)
+        const size_t cap = (room - fixed) & ~static_cast<size_t>(63);
+        if (vbytes_lds > cap) vbytes_lds = cap;
+      }
+    }
     auto slots = [&](int md_) {
       const size_t dyn = stage_bytes + (md_ & 1 ? kbytes : 0) + (md_ & 2 ? vbytes_lds : 0);
       if (dyn > lds_max) return 0;
