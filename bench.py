@@ -166,7 +166,7 @@ def cpu_baseline(seed, device, sweep=CPU_SWEEP):
                          ctypes.util.find_library("ipopt") or "not found")}
 
 
-C5_TRAFFIC_PROFILE = "r03_pmc_batch_8192.json"  # rocprofv3 --pmc passes of `bench.py --workload c5` (per round)
+C5_TRAFFIC_PROFILE = "r03_pmc_batch_8192_final.json"  # rocprofv3 --pmc passes of `bench.py --workload c5` (per round)
 PEAK_HBM_GBS = 8000.0                           # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
