@@ -475,6 +475,17 @@ struct BatchRunner {
       const double sc = slots(cand) / lat[cand];
       if (sc > best * 1.02) { best = sc; mode = cand; }
     }
+    // A batch that mode 3 (factor AND vectors in LDS, fewer instances per CU) gets through in two rounds is made of
+    // iteration latency, not of residency: circle packing n = 10, 1024 instances: 2 per CU with both in LDS 16.9 k
+    // problems/s, 4 per CU with the vectors only 14.7 k (8192 instances keep the 4-per-CU plan: 30.5 k/s)
+    if (wave && have_sparse && sparse_big && mode != 3 && slots(3) >= 1) {
+      if (this->ncu == 0) {
+        int v = 0;
+        DNLP_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ex->device));
+        this->ncu = v;
+      }
+      if (static_cast<i64>(batch) <= 2 * static_cast<i64>(this->ncu) * slots(3)) mode = 3;
+    }
     if (const char* e = std::getenv("DNLP_BATCH_LDS")) {
       const int want = std::atoi(e);
       if (want >= 0 && want <= 3 && slots(want) > 0) mode = want;
