@@ -328,6 +328,10 @@ __global__ void __launch_bounds__(256) ldlt_rows128_kernel(double* __restrict__ 
   }
 }
 
+}  // namespace dnlp
+#include "ldlt_top_mfma.h"
+namespace dnlp {
+
 // ---- C -= W L^T on FP64 MFMA ---------------------------------------------------------------
 // Interior tiles (full 128x128, strictly below the diagonal, K a multiple of 16, 16-B aligned
 // operands) take the fast body: the C tile is loaded straight into the MFMA accumulators
@@ -1234,6 +1238,7 @@ struct BlockedLdlt {
   LdltInfo* info = nullptr;
   double* acc = nullptr;
   double* Ltop = nullptr;                  // packed operands of the current 128-column sub-panel (ldlt_top128_kernel)
+  bool top_mfma = true;                    // the 128 x 128 top block on MFMA blocks (DNLP_LDLT_TOP_MFMA=0: the 4 x 4 tile kernel)
   bool sub128 = true;                      // panels in 128-column sub-panels (DNLP_LDLT_T128=0: the 32-column chain)
   double last_update_seconds = 0.0;
   double total_update_seconds = 0.0, total_update_flops = 0.0;   // outer (Schur) updates, timed
@@ -1287,6 +1292,7 @@ struct BlockedLdlt {
     if (const char* ev = std::getenv("DNLP_LDLT_LOOKAHEAD")) lookahead = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_XCD")) xcd_swizzle = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_T128")) sub128 = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("DNLP_LDLT_TOP_MFMA")) top_mfma = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_SMALL_TILES")) small_tiles_below = std::atoi(ev);
     if (const char* ev = std::getenv("DNLP_LDLT_SMALL_ROWS")) small_rows_max = std::atoi(ev);
     if (const char* ev = std::getenv("DNLP_LDLT_SOLVE_INV")) solve_inv = std::atoi(ev) != 0;
@@ -1399,7 +1405,10 @@ struct BlockedLdlt {
       for (int j0 = K0; j0 < K0 + KB; j0 += LD_nb) {
         if (sub128 && K0 + KB - j0 >= LD_T) {
           // a full 128-column sub-panel: three launches instead of twelve
-          hipLaunchKernelGGL(ldlt_top128_kernel, dim3(1), dim3(LD_TOP_THREADS), 0, s0, A, ld, j0, info, tiny, Ltop);
+          if (top_mfma)
+            hipLaunchKernelGGL(ldlt_top128_mfma_kernel, dim3(1), dim3(LD_TOPM_THREADS), 0, s0, A, ld, j0, info, tiny, Ltop);
+          else
+            hipLaunchKernelGGL(ldlt_top128_kernel, dim3(1), dim3(LD_TOP_THREADS), 0, s0, A, ld, j0, info, tiny, Ltop);
           const int r0 = j0 + LD_T, rows = ni - r0;
           if (rows > 0) {
             if (b_pending) { DNLP_HIP_CHECK(hipStreamWaitEvent(s0, evB, 0)); b_pending = false; }    // this sub-panel's rows, brought up to date on s2

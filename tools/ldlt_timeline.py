@@ -9,7 +9,7 @@ limit = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ev = [(r["Kernel_Name"].split("(")[0].replace("dnlp::", "").replace("void ", ""), int(r["Start_Timestamp"]),
        int(r["End_Timestamp"]), r.get("Queue_Id", "?")) for r in rows]
-first = [i for i, e in enumerate(ev) if e[0] in ("ldlt_top128_kernel", "ldlt_diag_kernel")]
+first = [i for i, e in enumerate(ev) if e[0] in ("ldlt_top128_kernel", "ldlt_top128_mfma_kernel", "ldlt_diag_kernel")]
 # the last factorisation starts at the last panel kernel with j0 == 0: approximate by the largest gap
 starts = [first[0]] + [first[k] for k in range(1, len(first)) if ev[first[k]][1] - ev[first[k - 1]][2] > 2_000_000]
 i0 = starts[-1]
