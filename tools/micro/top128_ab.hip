@@ -7,9 +7,6 @@
 #include <random>
 #include <vector>
 using namespace dnlp;
-#ifndef PROBE
-#define PROBE 0
-#endif
 int main(int argc, char** argv) {
   const int ld = 640, j0 = 128, n = 128;
   const int kind = argc > 1 ? atoi(argv[1]) : 0;     // 0 positive definite, 1 quasi-definite (64 negative), 2 with a zero pivot
@@ -48,7 +45,7 @@ int main(int argc, char** argv) {
       hipDeviceSynchronize();
       hipEventRecord(e0, 0);
       if (v == 0) hipLaunchKernelGGL(ldlt_top128_kernel, dim3(1), dim3(LD_TOP_THREADS), 0, 0, dA, (i64)ld, j0, info, 1e-300, dL);
-      else hipLaunchKernelGGL(ldlt_top128_mfma_probe<PROBE>, dim3(1), dim3(LD_TOPM_THREADS), 0, 0, dA, (i64)ld, j0, info, 1e-300, dL);
+      else hipLaunchKernelGGL(ldlt_top128_mfma_kernel, dim3(1), dim3(LD_TOPM_THREADS), 0, 0, dA, (i64)ld, j0, info, 1e-300, dL);
       hipEventRecord(e1, 0);
       hipEventSynchronize(e1);
       float ms;
