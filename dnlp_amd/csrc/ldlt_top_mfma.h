@@ -66,19 +66,27 @@ __global__ void __launch_bounds__(LD_TOPM_THREADS) ldlt_top128_mfma_kernel(doubl
       for (int c = 0; c < 16; ++c) {
         const int cq = c & 3, cr = c >> 2, src = cq * 16 + c;      // pivot c: register cr of lane src
         double d = ldlt_bcast(D[cr], src);
-        double di = ldlt_rcp(d);                  // starts on the raw pivot; a repair redoes it
+        const bool sel = lq == cq;
+        const double b = (c < 15 && sel && lr > c) ? D[cr] : 0.0;       // w_n, n > c, in k-slot cq
+        // 1/d = r0 (1 + e + e^2), e = 1 - d r0 (|e| <= 4.6e-8: the cube is below double precision) — and the
+        // multipliers are formed from b r0 beside it, so the chain pivot -> update operand is four dependent
+        // operations (reciprocal, e | b r0, e + e^2, operand) instead of six
+        double r0 = __builtin_amdgcn_rcp(d);
+        double e = fma(-d, r0, 1.0), tn = -(b * r0);
+        double pe = fma(e, e, e);
+        double a = fma(tn, pe, tn);                                      // -l_m, m > c
+        double di = fma(r0, pe, r0);
+        asm volatile("" : "+v"(a), "+v"(di));    // (computed before the pivot test's branch, not once on either side of it)
         if (!(fabs(d) > tiny)) {
           if (!(d == d)) { fail = 1; d = 1.0; }
           else { nzero += 1; d = (d < 0.0 ? -tiny : tiny); if (d == 0.0) d = 1e-300; }
           di = ldlt_rcp(d);
+          a = -(b * di);
           if (lane == src) D[cr] = d;
         }
         nneg += d < 0.0 ? 1 : 0;
         mydi = lane == c ? di : mydi;
         if (c < 15) {
-          const bool sel = lq == cq;
-          const double b = (sel && lr > c) ? D[cr] : 0.0;     // w_n, n > c, in k-slot cq
-          const double a = -(b * di);                          // -l_m, m > c
           const double yb = sel ? Y[cr] : 0.0;                // row c of the inverse so far
           // (the inverse's update directly behind the block's: issued ahead of the next pivot's reciprocal it
           //  measured 1.5 us slower — FP64 vector instructions wait for the FP64 matrix pipe)
