@@ -2,6 +2,7 @@
 libdnlp_hip.so; the CPU oracle (oracle/) and the golden vectors captured from the reference
 (tests/golden/) are only the checkers.  Nothing here reads /root/reference."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -159,6 +160,73 @@ def test_blocked_mfma_ldlt_quasidefinite(n, gpu_required):
     assert (nneg, nzero) == (n - n1, 0)
     ref = np.linalg.solve(A, b)
     assert np.linalg.norm(sol - ref) <= 1e-9 * np.linalg.norm(ref) * np.linalg.cond(A)
+
+
+def _ldlt_factor(A, top_mfma):
+    """Factor through the C ABI with the chosen top-block kernel (csrc/ldlt_top_mfma.h / ldlt_top128_kernel); returns
+    the factor as stored (unit-lower L below the diagonal, D on it), the inertia counts and the solution of A x = 1."""
+    from dnlp_amd import _capi
+    api = _capi.require_device(0)
+    n = A.shape[0]
+    old = os.environ.get("DNLP_LDLT_TOP_MFMA")
+    os.environ["DNLP_LDLT_TOP_MFMA"] = "1" if top_mfma else "0"
+    try:
+        Af = np.asfortranarray(A.copy())
+        ipiv = np.zeros(n, np.int32)
+        nneg, nzero, sec = C.c_int(), C.c_int(), C.c_double()
+        sol = np.zeros(n)
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+        rc = api.lib.dnlp_ldlt_host(0, dp(Af), n, n, ipiv.ctypes.data_as(C.POINTER(C.c_int32)), 0, C.byref(nneg),
+                                    C.byref(nzero), dp(np.ones(n)), dp(sol), C.byref(sec))
+    finally:
+        if old is None:
+            del os.environ["DNLP_LDLT_TOP_MFMA"]
+        else:
+            os.environ["DNLP_LDLT_TOP_MFMA"] = old
+    return rc, np.tril(Af), nneg.value, nzero.value, sol
+
+
+@pytest.mark.parametrize("n", [128, 200, 256, 640, 1100])
+def test_top_block_kernels_agree(n, gpu_required):
+    """The 128 x 128 top block of a sub-panel on FP64 MFMA blocks against the 4 x 4 tile kernel it replaces: same
+    factor to rounding, same inertia, and the factor reproduces the matrix (quasi-definite KKT shape, so the
+    unpivoted factorisation exists and is stable)."""
+    rng = np.random.default_rng(100 + n)
+    n1 = (3 * n) // 4
+    G = rng.standard_normal((n1, n1))
+    H = G @ G.T / n1 + np.eye(n1)
+    J = rng.standard_normal((n - n1, n1))
+    A = np.block([[H, J.T], [J, -1e-2 * np.eye(n - n1)]])
+    rc0, F0, neg0, zero0, x0 = _ldlt_factor(A, False)
+    rc1, F1, neg1, zero1, x1 = _ldlt_factor(A, True)
+    assert rc0 == 0 and rc1 == 0
+    assert (neg1, zero1) == (neg0, zero0) == (n - n1, 0)
+    scale = np.abs(F0).max()
+    assert np.abs(F1 - F0).max() <= 1e-10 * scale
+    L = np.tril(F1, -1) + np.eye(n)
+    d = np.diag(F1)
+    assert np.abs((L * d) @ L.T - A).max() <= 1e-11 * np.abs(A).max() * n
+    ref = np.linalg.solve(A, np.ones(n))
+    assert np.linalg.norm(x1 - ref) <= 1e-9 * np.linalg.norm(ref) * np.linalg.cond(A)
+    assert np.linalg.norm(x1 - x0) <= 1e-9 * np.linalg.norm(ref) * np.linalg.cond(A)
+
+
+def test_top_block_kernels_count_a_zero_pivot_alike(gpu_required):
+    """An exactly zero pivot inside a top block (column 37 decoupled from the rest, zero diagonal): both kernels replace it
+    by the tiny pivot, count it once and leave the same inertia; a NaN in the block fails the factorisation in both."""
+    n = 384
+    rng = np.random.default_rng(5)
+    G = rng.standard_normal((n, n))
+    A = G @ G.T / n + np.eye(n)
+    A[37, :] = 0.0
+    A[:, 37] = 0.0
+    out = [_ldlt_factor(A, m) for m in (False, True)]
+    assert out[0][0] == 0 and out[1][0] == 0
+    assert (out[0][2], out[0][3]) == (out[1][2], out[1][3]) == (0, 1)
+    assert np.abs(out[1][1] - out[0][1]).max() <= 1e-10 * np.abs(out[0][1]).max()
+    A[200, 100] = A[100, 200] = np.nan
+    assert _ldlt_factor(A, False)[0] != 0
+    assert _ldlt_factor(A, True)[0] != 0
 
 
 def test_device_matrix_sphere_and_symv(gpu_required):
