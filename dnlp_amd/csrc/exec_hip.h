@@ -1397,6 +1397,7 @@ struct HipExec : HostControlled {
   hipStream_t stream = nullptr;
   double* d_partial = nullptr;
   double* h_partial = nullptr;
+  double* r_partial = nullptr;   // where the reductions' kernels write: the pinned host buffer itself (device view), or d_partial
   double* gemv_part = nullptr;
   struct SparseInfo* sparse_info = nullptr;
   size_t gemv_part_cap = 0;
@@ -1422,6 +1423,15 @@ struct HipExec : HostControlled {
     // (the fused objective kernel writes one partial per wavefront: 4 per workgroup)
     DNLP_HIP_CHECK(hipMalloc(&d_partial, sizeof(double) * kMaxPartials * 4));
     DNLP_HIP_CHECK(hipHostMalloc(&h_partial, sizeof(double) * kMaxPartials * 4));
+    // A reduction's partials (a few doubles per workgroup) are written straight into the pinned host buffer: the
+    // device-to-host copy behind every reduction was a blit kernel of its own (3-4 us and a launch) on the
+    // host-driven loop's ~50 reductions per iteration.  DNLP_REDUCE_COPY=1 restores the copy.
+    r_partial = d_partial;
+    if (!std::getenv("DNLP_REDUCE_COPY") || std::atoi(std::getenv("DNLP_REDUCE_COPY")) == 0) {
+      void* dv = nullptr;
+      if (hipHostGetDevicePointer(&dv, h_partial, 0) == hipSuccess && dv) r_partial = static_cast<double*>(dv);
+      else (void)hipGetLastError();
+    }
     if (const char* v = std::getenv("DNLP_FUSED_NE")) fused_ne_override = std::atoi(v);
   }
   ~HipExec() {
@@ -1490,9 +1500,9 @@ struct HipExec : HostControlled {
     if (n <= 0) return MODE == 0 ? 0.0 : (MODE == 1 ? -kInf : kInf);
     i64 grid = (n + kBlock - 1) / kBlock;
     if (grid > kMaxPartials) grid = kMaxPartials;
-    hipLaunchKernelGGL((reduce_kernel<MODE, F>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, n, f, d_partial);
+    hipLaunchKernelGGL((reduce_kernel<MODE, F>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, n, f, r_partial);
     DNLP_LAUNCH_CHECK();
-    DNLP_HIP_CHECK(hipMemcpyAsync(h_partial, d_partial, sizeof(double) * grid, hipMemcpyDeviceToHost, stream));
+    if (r_partial == d_partial) DNLP_HIP_CHECK(hipMemcpyAsync(h_partial, d_partial, sizeof(double) * grid, hipMemcpyDeviceToHost, stream));
     DNLP_HIP_CHECK(hipStreamSynchronize(stream));
     double r = h_partial[0];
     for (i64 k = 1; k < grid; ++k) {
@@ -1513,9 +1523,9 @@ struct HipExec : HostControlled {
     if (n <= 0) return r;
     i64 grid = (n + kBlock - 1) / kBlock;
     if (grid > kMaxPartials * 4 / (NM + NS)) grid = kMaxPartials * 4 / (NM + NS);
-    hipLaunchKernelGGL((reduce_multi_kernel<NM, NS, F>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, n, f, d_partial);
+    hipLaunchKernelGGL((reduce_multi_kernel<NM, NS, F>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, n, f, r_partial);
     DNLP_LAUNCH_CHECK();
-    DNLP_HIP_CHECK(hipMemcpyAsync(h_partial, d_partial, sizeof(double) * (NM + NS) * grid, hipMemcpyDeviceToHost, stream));
+    if (r_partial == d_partial) DNLP_HIP_CHECK(hipMemcpyAsync(h_partial, d_partial, sizeof(double) * (NM + NS) * grid, hipMemcpyDeviceToHost, stream));
     DNLP_HIP_CHECK(hipStreamSynchronize(stream));
     for (i64 b = 0; b < grid; ++b) {
       for (int k = 0; k < NM; ++k) r.mx[k] = std::fmax(r.mx[k], h_partial[(NM + NS) * b + k]);
@@ -1527,9 +1537,9 @@ struct HipExec : HostControlled {
     if (n <= 0) return D2{kInf, kInf};
     i64 grid = (n + kBlock - 1) / kBlock;
     if (grid > kMaxPartials) grid = kMaxPartials;
-    hipLaunchKernelGGL((reduce_min2_kernel<F>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, n, f, d_partial);
+    hipLaunchKernelGGL((reduce_min2_kernel<F>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, n, f, r_partial);
     DNLP_LAUNCH_CHECK();
-    DNLP_HIP_CHECK(hipMemcpyAsync(h_partial, d_partial, sizeof(double) * 2 * grid, hipMemcpyDeviceToHost, stream));
+    if (r_partial == d_partial) DNLP_HIP_CHECK(hipMemcpyAsync(h_partial, d_partial, sizeof(double) * 2 * grid, hipMemcpyDeviceToHost, stream));
     DNLP_HIP_CHECK(hipStreamSynchronize(stream));
     D2 r{h_partial[0], h_partial[1]};
     for (i64 k = 1; k < grid; ++k) { r.first = std::fmin(r.first, h_partial[2 * k]); r.second = std::fmin(r.second, h_partial[2 * k + 1]); }
