@@ -940,6 +940,10 @@ __global__ void __launch_bounds__(128) ldlt_inv128_kernel(const double* __restri
   }
 }
 
+}  // namespace dnlp
+#include "ldlt_inv_mfma.h"
+namespace dnlp {
+
 // Operands of a 128 x 128 product held by the SI_T lanes: lane (i = tid & 127, ch = tid >> 7) keeps the sixteen
 // entries M[i + ldm (16 ch + c)], c < 16 — fetched at kernel start, long before the vector they multiply exists,
 // so the dependent part of a step is LDS traffic only.
@@ -1238,6 +1242,7 @@ struct BlockedLdlt {
   LdltInfo* info = nullptr;
   double* acc = nullptr;
   double* Ltop = nullptr;                  // packed operands of the current 128-column sub-panel (ldlt_top128_kernel)
+  bool inv_mfma = true;                    // inverses of the diagonal 128-blocks on MFMA blocks (DNLP_LDLT_INV_MFMA=0: the 128-lane kernel)
   bool top_mfma = true;                    // the 128 x 128 top block on MFMA blocks (DNLP_LDLT_TOP_MFMA=0: the 4 x 4 tile kernel)
   bool sub128 = true;                      // panels in 128-column sub-panels (DNLP_LDLT_T128=0: the 32-column chain)
   double last_update_seconds = 0.0;
@@ -1293,6 +1298,7 @@ struct BlockedLdlt {
     if (const char* ev = std::getenv("DNLP_LDLT_XCD")) xcd_swizzle = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_T128")) sub128 = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_TOP_MFMA")) top_mfma = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("DNLP_LDLT_INV_MFMA")) inv_mfma = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_SMALL_TILES")) small_tiles_below = std::atoi(ev);
     if (const char* ev = std::getenv("DNLP_LDLT_SMALL_ROWS")) small_rows_max = std::atoi(ev);
     if (const char* ev = std::getenv("DNLP_LDLT_SOLVE_INV")) solve_inv = std::atoi(ev) != 0;
@@ -1532,10 +1538,16 @@ struct BlockedLdlt {
       LinvT = ex->alloc<double>(cnt);
       DNLP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ldlt_inv128_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 4096 * 8));
+      DNLP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ldlt_inv128_mfma_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, SI_INVM_LDS));
     }
     if (!inv_ready) {
-      hipLaunchKernelGGL(ldlt_inv128_kernel, dim3(static_cast<unsigned>(nb128)), dim3(128), 3 * 4096 * 8, ex->stream, A, ld, ni,
-                         Linv, LinvT);
+      if (inv_mfma)
+        hipLaunchKernelGGL(ldlt_inv128_mfma_kernel, dim3(static_cast<unsigned>(nb128)), dim3(SI_INVM_THREADS), SI_INVM_LDS, ex->stream, A, ld, ni,
+                           Linv, LinvT);
+      else
+        hipLaunchKernelGGL(ldlt_inv128_kernel, dim3(static_cast<unsigned>(nb128)), dim3(128), 3 * 4096 * 8, ex->stream, A, ld, ni,
+                           Linv, LinvT);
       inv_ready = true;
     }
     // (+ the prefetching workgroup of the next step at the first block index past the grid that is a multiple of 8)
