@@ -16,6 +16,8 @@
 #include <string>
 #include <functional>
 #include <vector>
+#include <map>
+#include <tuple>
 
 #include "atom_math.h"
 #include "exec.h"
@@ -311,6 +313,27 @@ __global__ void __launch_bounds__(kBlock) coo_mult_kernel(i64 nnz, const i32* __
     coo_row_add(out, rp, active ? av * v[cp] : 0.0, active);
     if (active && rp != cp) unsafeAtomicAdd(&out[cp], av * v[rp]);
   }
+}
+
+// Order-fixed COO product: the entries that feed one output are a segment of an index built once per pattern
+// (HipExec::coo_index: counting sort by output, storage order inside a segment), sixteen lanes walk a segment in
+// strides and reduce in a fixed tree, ONE lane adds the sum to out[g].  No atomics: the sum of an output is rounded
+// in the same order on every run (with atomics portfolio construction ended after 22 to 72 iterations from run to
+// run, with this after 22 every time: profiles/r03_determinism.txt).
+__global__ void __launch_bounds__(kBlock) coo_rows_kernel(i64 nout, const i64* __restrict__ ptr, const i32* __restrict__ ent,
+                                                          const i32* __restrict__ src, const double* __restrict__ a,
+                                                          const double* __restrict__ v, double* out) {
+  const i64 g = (static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x) >> 4;
+  const int l = threadIdx.x & 15;
+  double s = 0.0;
+  i64 p0 = 0, p1 = 0;
+  if (g < nout) { p0 = ptr[g]; p1 = ptr[g + 1]; }
+  for (i64 p = p0 + l; p < p1; p += 16) s += a[ent[p]] * v[src[p]];
+  s += __shfl_xor(s, 8, 16);
+  s += __shfl_xor(s, 4, 16);
+  s += __shfl_xor(s, 2, 16);
+  s += __shfl_xor(s, 1, 16);
+  if (l == 0 && p1 > p0) out[g] += s;
 }
 
 // ---- Bunch-Kaufman LDL^T (DSYTF2 semantics, lower) ----------------------------------------
@@ -2005,15 +2028,72 @@ struct HipExec : HostControlled {
     DNLP_HIP_CHECK(hipModuleLaunchKernel(fused_rtc.fn, static_cast<unsigned>(blocks), 1, 1, kBlock, 1, 1, 0, stream, args, nullptr));
     return true;
   }
-  void coo_mult(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out, bool trans) {
+  // Index of a COO pattern by output (mode 0: rows, 1: columns, 2: both sides of a lower triangle): ent = entry, src =
+  // index into v, ptr = segment of every output.  Built on the host on a pattern's first product (the patterns of a
+  // handle are fixed), for patterns up to coo_det_max entries (DNLP_COO_DET_MAX; 0 = never): beyond that — the 1e7-entry
+  // dense Jacobian of BASELINE C3 — the first call would pay 0.1 s for it and the atomic kernel stays.
+  struct CooIndex { i32* ent = nullptr; i32* src = nullptr; i64* ptr = nullptr; i64 nout = 0; };
+  std::map<std::tuple<const void*, const void*, i64, int>, CooIndex> coo_index_;
+  i64 coo_det_max = 4000000;
+  const CooIndex* coo_index(i64 nnz, const i32* r, const i32* c, int mode) {
+    static const i64 env_max = [] { const char* e = std::getenv("DNLP_COO_DET_MAX"); return e ? std::atoll(e) : -1; }();
+    if (nnz > (env_max >= 0 ? env_max : coo_det_max)) return nullptr;
+    const auto key = std::make_tuple(static_cast<const void*>(r), static_cast<const void*>(c), nnz, mode);
+    auto it = coo_index_.find(key);
+    if (it != coo_index_.end()) return &it->second;
+    std::vector<i32> hr(static_cast<size_t>(nnz)), hc(static_cast<size_t>(nnz));
+    d2h(hr.data(), r, sizeof(i32) * static_cast<size_t>(nnz));
+    d2h(hc.data(), c, sizeof(i32) * static_cast<size_t>(nnz));
+    i64 nout = 0;
+    for (i64 p = 0; p < nnz; ++p) {
+      const i32 rp = hr[static_cast<size_t>(p)], cp = hc[static_cast<size_t>(p)];
+      if (mode != 1 && rp + 1 > nout) nout = rp + 1;
+      if (mode != 0 && cp + 1 > nout) nout = cp + 1;
+    }
+    std::vector<i64> ptr(static_cast<size_t>(nout) + 1, 0);
+    auto each = [&](auto&& f) {                  // (entry, output, source) in storage order
+      for (i64 p = 0; p < nnz; ++p) {
+        const i32 rp = hr[static_cast<size_t>(p)], cp = hc[static_cast<size_t>(p)];
+        if (mode != 1) f(p, rp, cp);
+        if (mode == 1 || (mode == 2 && rp != cp)) f(p, cp, rp);
+      }
+    };
+    each([&](i64, i32 o, i32) { ++ptr[static_cast<size_t>(o) + 1]; });
+    for (i64 g = 0; g < nout; ++g) ptr[static_cast<size_t>(g) + 1] += ptr[static_cast<size_t>(g)];
+    const i64 total = ptr[static_cast<size_t>(nout)];
+    std::vector<i32> ent(static_cast<size_t>(total)), src(static_cast<size_t>(total));
+    std::vector<i64> fill(ptr.begin(), ptr.end() - 1);
+    each([&](i64 p, i32 o, i32 sidx) {
+      const i64 at = fill[static_cast<size_t>(o)]++;
+      ent[static_cast<size_t>(at)] = static_cast<i32>(p);
+      src[static_cast<size_t>(at)] = sidx;
+    });
+    CooIndex ix;
+    ix.nout = nout;
+    ix.ent = alloc<i32>(static_cast<size_t>(total));
+    ix.src = alloc<i32>(static_cast<size_t>(total));
+    ix.ptr = alloc<i64>(static_cast<size_t>(nout) + 1);
+    h2d(ix.ent, ent.data(), sizeof(i32) * static_cast<size_t>(total));
+    h2d(ix.src, src.data(), sizeof(i32) * static_cast<size_t>(total));
+    h2d(ix.ptr, ptr.data(), sizeof(i64) * (static_cast<size_t>(nout) + 1));
+    return &coo_index_.emplace(key, ix).first->second;
+  }
+  void coo_product(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out, int mode) {
     if (nnz <= 0) return;
+    if (const CooIndex* ix = coo_index(nnz, r, c, mode)) {
+      if (ix->nout > 0)
+        hipLaunchKernelGGL(coo_rows_kernel, dim3(static_cast<unsigned>((ix->nout * 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                           ix->nout, ix->ptr, ix->ent, ix->src, a, v, out);
+      return;
+    }
     hipLaunchKernelGGL(coo_mult_kernel, dim3(static_cast<unsigned>((nnz + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
-                       nnz, r, c, a, v, out, trans ? 1 : 0);
+                       nnz, r, c, a, v, out, mode);
+  }
+  void coo_mult(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out, bool trans) {
+    coo_product(nnz, r, c, a, v, out, trans ? 1 : 0);
   }
   void coo_sym_mult(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out) {
-    if (nnz <= 0) return;
-    hipLaunchKernelGGL(coo_mult_kernel, dim3(static_cast<unsigned>((nnz + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
-                       nnz, r, c, a, v, out, 2);
+    coo_product(nnz, r, c, a, v, out, 2);
   }
   void dense_block_add(double* K, i64 ldk, i64 x0, const double* P, i64 ldp, i64 nb, double w, bool set) {
     const i64 nrb = (nb + 511) / 512;
