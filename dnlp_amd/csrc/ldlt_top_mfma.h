@@ -55,6 +55,8 @@ __global__ void __launch_bounds__(LD_TOPM_THREADS) ldlt_top128_mfma_kernel(doubl
         T[q][r] = ((q > 0 && q <= w) || (q == 0 && lq + 4 * r <= lr)) ? src[static_cast<i64>(4 * r - 16 * q) * ld] : 0.0;
   }
   int nneg = 0, nzero = 0, fail = 0;
+  // high words above this belong to magnitudes above `tiny` whatever the low word is
+  const unsigned tiny_hi = (static_cast<unsigned>(__double2hiint(tiny)) & 0x7fffffffu) + 1u;
 #pragma unroll 1
   for (int k = 0; k < LD_TB; ++k) {
     if (w == k) {
@@ -77,12 +79,17 @@ __global__ void __launch_bounds__(LD_TOPM_THREADS) ldlt_top128_mfma_kernel(doubl
         double a = fma(tn, pe, tn);                                      // -l_m, m > c
         double di = fma(r0, pe, r0);
         asm volatile("" : "+v"(a), "+v"(di));    // (computed before the pivot test's branch, not once on either side of it)
-        if (!(fabs(d) > tiny)) {
-          if (!(d == d)) { fail = 1; d = 1.0; }
-          else { nzero += 1; d = (d < 0.0 ? -tiny : tiny); if (d == 0.0) d = 1e-300; }
-          di = ldlt_rcp(d);
-          a = -(b * di);
-          if (lane == src) D[cr] = d;
+        // the pivot is uniform (two scalar registers): the common case is told apart on the scalar unit from the high
+        // word alone — magnitude well above `tiny` and not NaN / infinity — and only the rest takes the exact test
+        const unsigned dh = static_cast<unsigned>(__double2hiint(d)) & 0x7fffffffu;
+        if (__builtin_expect(dh - tiny_hi >= 0x7ff00000u - tiny_hi, 0)) {
+          if (!(fabs(d) > tiny)) {
+            if (!(d == d)) { fail = 1; d = 1.0; }
+            else { nzero += 1; d = (d < 0.0 ? -tiny : tiny); if (d == 0.0) d = 1e-300; }
+            di = ldlt_rcp(d);
+            a = -(b * di);
+            if (lane == src) D[cr] = d;
+          }
         }
         nneg += d < 0.0 ? 1 : 0;
         mydi = lane == c ? di : mydi;
