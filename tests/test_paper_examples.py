@@ -268,3 +268,29 @@ def test_device_nmf_at_notebook_size(gpu_required):
     X, Y = (v.value for v in p.variables())
     assert X.shape == (100, 3) and Y.shape == (3, 400)
     _check_nmf(p, X, Y, 100)
+
+
+# ---- run-to-run reproducibility of the host-driven loop ---------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["nb_portfolio_construction", "nb_sparse_recovery"])
+def test_device_host_driven_solve_repeats_bit_for_bit(name, gpu_required):
+    """IPOPT on one thread repeats a run bit for bit; so does the host-driven loop since its sparse products
+    (J v, J^T v, H v) accumulate in a fixed order (csrc/exec_hip.h coo_rows_kernel).  With atomic products these two
+    non-convex examples ended after 22 to 72 resp. 66 to 177 iterations from run to run
+    (profiles/r03_determinism.txt).  Two fresh handles, two solves each: same iteration count, same bits."""
+    import dnlp_amd as cp
+    from paper_examples import PAPER, PAPER_LARGE
+    make = dict(PAPER)
+    make.update(PAPER_LARGE)
+    runs = []
+    for fresh in range(2):
+        prob = make[name](cp)
+        chain = prob._build_chain(None)
+        data, _ = chain.apply(prob)
+        for rep in range(2):
+            info = chain.solver.solve_via_data(dict(data), True, False, {})
+            runs.append((int(info["iterations"]), int(info["status"]), float(info["obj_val"]), np.array(info["x"])))
+    assert all(r[1] == 0 for r in runs)
+    assert len({r[0] for r in runs}) == 1, [r[0] for r in runs]
+    assert all(r[2] == runs[0][2] for r in runs), [r[2] for r in runs]
+    assert all(np.array_equal(r[3], runs[0][3]) for r in runs)
