@@ -2031,13 +2031,13 @@ struct HipExec : HostControlled {
   // Index of a COO pattern by output (mode 0: rows, 1: columns, 2: both sides of a lower triangle): ent = entry, src =
   // index into v, ptr = segment of every output.  Built on the host on a pattern's first product (the patterns of a
   // handle are fixed), for patterns up to coo_det_max entries (DNLP_COO_DET_MAX; 0 = never): beyond that — the 1e7-entry
-  // dense Jacobian of BASELINE C3 — the first call would pay 0.1 s for it and the atomic kernel stays.
+  // dense Jacobian of BASELINE C3 — the first call would pay 0.16 s for it (and a product 0.1 ms more: measured with DNLP_COO_DET_MAX=20000000) and the atomic kernel stays.
   struct CooIndex { i32* ent = nullptr; i32* src = nullptr; i64* ptr = nullptr; i64 nout = 0; };
   std::map<std::tuple<const void*, const void*, i64, int>, CooIndex> coo_index_;
   i64 coo_det_max = 4000000;
   const CooIndex* coo_index(i64 nnz, const i32* r, const i32* c, int mode) {
     static const i64 env_max = [] { const char* e = std::getenv("DNLP_COO_DET_MAX"); return e ? std::atoll(e) : -1; }();
-    if (nnz > (env_max >= 0 ? env_max : coo_det_max)) return nullptr;
+    if (nnz > (env_max >= 0 ? env_max : coo_det_max) || nnz > (i64{1} << 30)) return nullptr;   // (entry ids are 32-bit, two per entry in mode 2)
     const auto key = std::make_tuple(static_cast<const void*>(r), static_cast<const void*>(c), nnz, mode);
     auto it = coo_index_.find(key);
     if (it != coo_index_.end()) return &it->second;
