@@ -582,7 +582,7 @@ class ProblemHandle:
         else:
             rc = self.api.solve_batch_timed(self.ptr, B, _dp(data), stride, *outs)
         if rc != 0:
-            raise RuntimeError("solve_batch failed: %s" % self.api.error())
+            raise RuntimeError("solve_batch failed (code %d): %s" % (rc, self.api.error()))
         out = {"x": x, "obj_val": obj, "status": status, "iterations": iters, "factorizations": nfact,
                "kernel_seconds": float(sec.value), "phase_seconds": times}
         if want_duals:

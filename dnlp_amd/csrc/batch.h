@@ -104,9 +104,14 @@ __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
     put(spl.lev_off, spl.nlev + 1);
     put(spl.sblk, a.plan_rows);
     put(spl.sidx, a.plan_rows);
+    put(spl.lev_f, spl.nlev + 1);
+    put(spl.fnode, spl.nfwd);
+    put(spl.foff, spl.nfwd + 1);
+    put(spl.frow, a.plan_rows);
     if (a.plan_stage_factor) {
-      put(spl.toff, spl.nblk + 1);
-      put(spl.tdst, spl.ntrip);
+      put(spl.lev_g, spl.nlev + 1);
+      put(spl.gdst, spl.ngrp);
+      put(spl.goff, spl.ngrp + 1);
       put(spl.tiu, spl.ntrip);
       put(spl.tiv, spl.ntrip);
       put(spl.tblk, spl.ntrip);
@@ -213,6 +218,7 @@ struct BatchRunner {
   BatchLayout lay;
   i64 in_stride = 0;
   int last_grid = 0, last_threads = 0, last_lds_mode = 0, last_per_cu = 0;   // launch plan of the last solve
+  bool last_order_lpt = false;   // the last solve took its instances longest-first (a re-solve of the same rows)
   bool have_sparse = false, force_sparse = false;
   // warm-start multipliers for the NEXT solve (consumed by it)
   std::vector<double> h_ws_g, h_ws_l, h_ws_u;
@@ -232,11 +238,18 @@ struct BatchRunner {
   int nbuf_used = 0;
   int ncu = 0;
   std::vector<double> slab;
-  // Iteration counts of the previous solve of the same batch size: a re-solve of a parametrised batch (same or
-  // nearby parameter rows, warm or cold) takes its instances longest-first, so the instances that need 150+
+  // Iteration counts of the previous solve of the SAME ROWS (prev_key): a re-solve of a parametrised batch (warm or
+  // cold) takes its instances longest-first, so the instances that need 150+
   // iterations start at once instead of being the tail of the launch (mean 31, max 184-198 at 8192 localization
   // instances: a third of the launch was the tail).  A heuristic only — any order gives the same results.
   std::vector<int> prev_iters;
+  uint64_t prev_key = 0;        // hash of the input rows prev_iters belongs to: only a RE-SOLVE OF THE SAME ROWS inherits the order
+  static uint64_t rows_hash(const double* rows, size_t count) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ static_cast<uint64_t>(count);
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(rows);
+    for (size_t i = 0; i < count; ++i) { h ^= w[i]; h *= 0x100000001B3ull; h ^= h >> 29; }
+    return h ? h : 1;
+  }
 
   // affine parameter -> instance-data map (dnlp_batch_set_affine_map), resident on the device, in slab layout
   int aff_P = -1;
@@ -518,11 +531,13 @@ struct BatchRunner {
     if (have_sparse && !std::getenv("DNLP_BATCH_NO_PLAN_LDS")) {
       auto pad8 = [](size_t b) { return (b + 7) & ~static_cast<size_t>(7); };
       const size_t nb = static_cast<size_t>(dev_plan.nblk), nl = static_cast<size_t>(dev_plan.nlev), nr = static_cast<size_t>(plan_rows);
-      const size_t pbytes = (pad8(8 * nb) + pad8(8 * (nb + 1)) + 2 * pad8(8 * nb) + pad8(8 * (nl + 1)) + 2 * pad8(4 * nr) + 63) & ~static_cast<size_t>(63);
+      const size_t nf = static_cast<size_t>(dev_plan.nfwd), ng = static_cast<size_t>(dev_plan.ngrp);
+      const size_t pbytes = (pad8(8 * nb) + pad8(8 * (nb + 1)) + 2 * pad8(8 * nb) + pad8(8 * (nl + 1)) + 2 * pad8(4 * nr) +
+                             pad8(8 * (nl + 1)) + pad8(4 * nf) + pad8(8 * (nf + 1)) + pad8(4 * nr) + 63) & ~static_cast<size_t>(63);
       const size_t per0 = a.lds_bytes + fa.sharedSizeBytes + 256, per1 = per0 + pbytes;
       const size_t cap = 160 * 1024;
       const size_t nt = static_cast<size_t>(dev_plan.ntrip);
-      const size_t fbytes2 = (pad8(8 * (nb + 1)) + 4 * pad8(4 * nt) + pad8(4 * static_cast<size_t>(t.nnzH)) +
+      const size_t fbytes2 = (pad8(8 * (nl + 1)) + pad8(4 * ng) + pad8(8 * (ng + 1)) + 3 * pad8(4 * nt) + pad8(4 * static_cast<size_t>(t.nnzH)) +
                               pad8(4 * static_cast<size_t>(t.nnzJ)) + pad8(4 * static_cast<size_t>(dev_plan.n)) + 63) & ~static_cast<size_t>(63);
       const size_t per2 = per1 + fbytes2;
       const size_t s0 = std::min<size_t>(slots_max, cap / per0);
@@ -581,7 +596,13 @@ struct BatchRunner {
     ws_batch = 0;
     a.next = dalloc<int>(1);
     DNLP_HIP_CHECK(hipMemsetAsync(a.next, 0, sizeof(int), ex->stream));
-    if (static_cast<int>(prev_iters.size()) == batch && batch > grid && !std::getenv("DNLP_BATCH_FIFO")) {
+    // longest-first only for a re-solve of the SAME rows (warm starts, repeated what-if solves): a different batch of
+    // equal size must not inherit an order derived from unrelated iteration counts, and takes its instances first-come
+    const uint64_t key = theta ? rows_hash(theta, static_cast<size_t>(batch) * static_cast<size_t>(aff_P))
+                               : rows_hash(data, static_cast<size_t>(batch) * static_cast<size_t>(stride));
+    last_order_lpt = false;
+    if (static_cast<int>(prev_iters.size()) == batch && key == prev_key && batch > grid && !std::getenv("DNLP_BATCH_FIFO")) {
+      last_order_lpt = true;
       std::vector<int> ord(static_cast<size_t>(batch));
       for (int k = 0; k < batch; ++k) ord[static_cast<size_t>(k)] = k;
       std::stable_sort(ord.begin(), ord.end(), [&](int p, int q) { return prev_iters[static_cast<size_t>(p)] > prev_iters[static_cast<size_t>(q)]; });
@@ -616,7 +637,7 @@ struct BatchRunner {
     down(iters_out, a.iters_out, sizeof(int) * batch);
     down(nfact_out, a.nfact_out, sizeof(int) * batch);
     down(times_out, a.times_out, sizeof(double) * 4 * batch);
-    if (iters_out) prev_iters.assign(iters_out, iters_out + batch);
+    if (iters_out) { prev_iters.assign(iters_out, iters_out + batch); prev_key = key; }
     release();
     mark("results copied");
   }

@@ -51,6 +51,14 @@ static BatchRunner* batch_runner(dnlp_problem_t* p) {
   }
   return static_cast<BatchRunner*>(p->batch_state.get());
 }
+// The in-kernel solver has no quasi-Newton mode.  The reference hands hessian_approximation to IPOPT for every solve
+// (ipopt_nlpif.py:153-168); a batch launch that would silently run the exact Hessian instead is refused with IPOPT's
+// Invalid_Option (-12) — the front-end runs such starts one at a time through the host-driven loop (problem.py).
+static int batch_rejects_limited_memory() {
+  dnlp::tls_error() = "hessian_approximation=limited-memory is not available inside a batch launch (the in-kernel solver "
+                      "evaluates the exact Hessian): solve the instances one at a time, or use hessian_approximation=exact";
+  return -12;
+}
 int64_t dnlp_batch_stride(dnlp_problem* vp) {
   dnlp_problem_t* p = vp;
   DNLP_TRY(return batch_runner(p)->in_stride;)
@@ -73,7 +81,7 @@ int dnlp_solve_batch_timed(dnlp_problem* vp, int batch, const double* data, int6
   DNLP_TRY(
     BatchRunner& r = *batch_runner(p);
     p->ex.sync();
-    p->exact_hessian_substituted = p->opt.hessian_approximation == 1;   // no quasi-Newton mode inside the batch kernel
+    if (p->opt.hessian_approximation == 1) return batch_rejects_limited_memory();
     r.solve(batch, data, stride, p->opt, x, obj, mult_g, mult_x_L, mult_x_U, status, iters, factorizations, seconds, times);
     return 0;)
 }
@@ -95,7 +103,7 @@ int dnlp_solve_batch_theta(dnlp_problem* vp, int batch, const double* theta, int
   DNLP_TRY(
     BatchRunner& r = *batch_runner(p);
     p->ex.sync();
-    p->exact_hessian_substituted = p->opt.hessian_approximation == 1;
+    if (p->opt.hessian_approximation == 1) return batch_rejects_limited_memory();
     r.solve_theta(batch, theta, n_params, p->opt, x, obj, mult_g, mult_x_L, mult_x_U, status, iters, factorizations, seconds, times);
     return 0;)
 }

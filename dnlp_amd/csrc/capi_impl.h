@@ -199,8 +199,8 @@ struct ProblemT {
       // "limited-memory": IPOPT's quasi-Newton interior-point mode, no second derivatives (ipm_core.h: lm_*)
       if (v != "exact" && v != "limited-memory") return -12;
       opt.hessian_approximation = (v == "limited-memory") ? 1 : 0;
-      // (the in-kernel solver of the batch / device-loop paths has no quasi-Newton mode: there the exact tape
-      //  Hessian is used and the substitution is recorded — stats[23])
+      // (the in-kernel solver has no quasi-Newton mode: a batch launch with this option is refused with -12,
+      //  capi.hip; the front-end takes the host-driven loop for a single solve)
       exact_hessian_substituted = false;
     }
     else if (k == "derivative_test") { /* accepted, unused: oracles are exact by construction */ }

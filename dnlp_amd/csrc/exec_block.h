@@ -601,7 +601,6 @@ struct BlockExecT {
     __device__ int lanes() const { return NT; }
     __device__ int lane() const { return static_cast<int>(threadIdx.x); }
     __device__ void sync() const { __syncthreads(); }
-    __device__ void add(double* p, double v) const { unsafeAtomicAdd(p, v); }
     __device__ double sum(double v) const {
       v = wave_all_sum(v);
       if constexpr (NT == 64) return v;
@@ -626,7 +625,19 @@ struct BlockExecT {
   __device__ void dense_block_add(double*, i64, i64, const double*, i64, i64, double, bool) { __builtin_trap(); }
   __device__ void ldlt_prepare(LdltWork&, i64, i64, bool) {}
 
-  // out (+)= J v / J^T v / sym(H) v from COO triplets; `out` was zeroed by the caller
+  // out += J v / J^T v / sym(H) v through the tape's index by output (tape.h CooIdx): a lane owns an output and sums
+  // its segment serially, in storage order — no atomics, the host loops' rounding order
+  __device__ void coo_gather(const CooIdx& ix, const double* a, const double* v, double* out) {
+    const i64* ptr = ix.ptr;
+    const i32 *ent = ix.ent, *src = ix.src;
+    for (i64 g = threadIdx.x; g < ix.nout; g += kBatchThreads) {
+      double s = 0.0;
+      for (i64 p = ptr[g]; p < ptr[g + 1]; ++p) s += a[ent[p]] * v[src[p]];
+      out[g] += s;
+    }
+    __syncthreads();
+  }
+  // scatter form with atomics: only for patterns the tape did not index
   __device__ void coo_mult(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out, bool trans) {
     for (i64 p = threadIdx.x; p < nnz; p += kBatchThreads) {
       if (trans) unsafeAtomicAdd(&out[c[p]], a[p] * v[r[p]]);

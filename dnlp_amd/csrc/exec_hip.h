@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(kBlock) coo_mult_kernel(i64 nnz, const i32* __
 }
 
 // Order-fixed COO product: the entries that feed one output are a segment of an index built once per pattern
-// (HipExec::coo_index: counting sort by output, storage order inside a segment), sixteen lanes walk a segment in
+// (tape.h CooIdx: counting sort by output, storage order inside a segment), sixteen lanes walk a segment in
 // strides and reduce in a fixed tree, ONE lane adds the sum to out[g].  No atomics: the sum of an output is rounded
 // in the same order on every run (with atomics portfolio construction ended after 22 to 72 iterations from run to
 // run, with this after 22 every time: profiles/r03_determinism.txt).
@@ -1291,7 +1291,6 @@ struct WgPar {
   __device__ int lanes() const { return kBlock; }
   __device__ int lane() const { return static_cast<int>(threadIdx.x); }
   __device__ void sync() const { __syncthreads(); }
-  __device__ void add(double* p, double v) const { unsafeAtomicAdd(p, v); }
   __device__ double sum(double v) const {
     v = wave_sum(v);
     __syncthreads();                      // red may still be read from the previous call
@@ -1325,10 +1324,9 @@ __global__ void __launch_bounds__(kBlock) sp_pivot_kernel(SparsePlan pl, double*
   if (nzero != 0.0) atomicAdd(&info->nzero, static_cast<int>(nzero));
   if (bad != 0.0) atomicExch(&info->ok, 0);
 }
-// One lane per block, the four phases in sequence: for levels whose blocks have short structs (chain-like
-// patterns: three rows, six triples per block in the Rosenbrock chain) the phases of a block are a handful of
-// operations and the level costs one launch instead of four.
-__global__ void __launch_bounds__(kBlock) sp_level_fused_kernel(SparsePlan pl, double* vals, double* w, double* dinv, i64 b0, i64 b1,
+// One lane per block, pivot and scaling in sequence: for levels whose blocks have short structs (chain-like
+// patterns: three rows per block in the Rosenbrock chain) the two phases of a block are a handful of operations.
+__global__ void __launch_bounds__(kBlock) sp_pivot_scale_kernel(SparsePlan pl, double* vals, double* w, double* dinv, i64 b0, i64 b1,
                                                                 SparseInfo* info) {
   const i64 k = b0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
   if (k >= b1) return;
@@ -1338,17 +1336,26 @@ __global__ void __launch_bounds__(kBlock) sp_level_fused_kernel(SparsePlan pl, d
   if (nzero != 0.0) atomicAdd(&info->nzero, static_cast<int>(nzero));
   if (bad != 0.0) atomicExch(&info->ok, 0);
   for (i64 r = pl.soff[k]; r < pl.soff[k + 1]; ++r) sp_scale(pl, vals, w, dinv, r);
-  for (i64 q = pl.toff[k]; q < pl.toff[k + 1]; ++q) unsafeAtomicAdd(&vals[pl.tdst[q]], -sp_update(pl, vals, w, q));
-  const i64 v0 = pl.loff[k], v1 = (k + 1 < pl.nblk) ? pl.loff[k + 1] : pl.nvals;
-  for (i64 a = v0; a < v1; ++a) vals[a] = w[a];
 }
 __global__ void __launch_bounds__(kBlock) sp_scale_kernel(SparsePlan pl, const double* vals, double* w, const double* dinv, i64 r0, i64 r1) {
   const i64 r = r0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
   if (r < r1) sp_scale(pl, vals, w, dinv, r);
 }
-__global__ void __launch_bounds__(kBlock) sp_update_kernel(SparsePlan pl, double* vals, const double* w, i64 t0, i64 t1) {
-  const i64 q = t0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
-  if (q < t1) unsafeAtomicAdd(&vals[pl.tdst[q]], -sp_update(pl, vals, w, q));
+// Schur-complement updates of a level, ORDER-FIXED: the level's triples are stored sorted by destination
+// (sparse_plan.h gdst / goff); sixteen lanes walk a destination's triples in strides, a fixed tree reduces them and
+// ONE lane subtracts the sum.  No floating-point atomics (they made power flow take 16 to 18 iterations from run to run).
+__global__ void __launch_bounds__(kBlock) sp_update_gather_kernel(SparsePlan pl, double* vals, const double* w, i64 g0, i64 g1) {
+  const i64 g = g0 + ((static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x) >> 4);
+  const int l = threadIdx.x & 15;
+  double s = 0.0;
+  i64 q0 = 0, q1 = 0;
+  if (g < g1) { q0 = pl.goff[g]; q1 = pl.goff[g + 1]; }
+  for (i64 q = q0 + l; q < q1; q += 16) s += sp_update(pl, vals, w, q);
+  s += __shfl_xor(s, 8, 16);
+  s += __shfl_xor(s, 4, 16);
+  s += __shfl_xor(s, 2, 16);
+  s += __shfl_xor(s, 1, 16);
+  if (l == 0 && q1 > q0) vals[pl.gdst[g]] -= s;
 }
 // tail rows of a level's panel blocks into the two dense panels (l and w = l D^-1)
 __global__ void __launch_bounds__(kBlock) sp_panel_gather_kernel(SparsePlan pl, const double* vals, const double* w, double* Pl, double* Pw,
@@ -1362,11 +1369,19 @@ __global__ void __launch_bounds__(kBlock) sp_store_kernel(double* vals, const do
   const i64 a = v0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
   if (a < v1) vals[a] = w[a];
 }
-__global__ void __launch_bounds__(kBlock) sp_fwd_kernel(SparsePlan pl, const double* vals, double* x, i64 r0, i64 r1) {
-  const i64 r = r0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
-  if (r >= r1) return;
-  const double c = sp_fwd(pl, vals, x, r);
-  if (c != 0.0) unsafeAtomicAdd(&x[pl.sidx[r]], -c);
+// forward substitution in gather form (sparse_plan.h fnode / foff / frow): sixteen lanes per target node, fixed tree
+__global__ void __launch_bounds__(kBlock) sp_fwd_gather_kernel(SparsePlan pl, const double* vals, double* x, i64 h0, i64 h1, i64 rmax) {
+  const i64 h = h0 + ((static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x) >> 4);
+  const int l = threadIdx.x & 15;
+  double s = 0.0;
+  i64 q0 = 0, q1 = 0;
+  if (h < h1) { q0 = pl.foff[h]; q1 = pl.foff[h + 1]; }
+  for (i64 q = q0 + l; q < q1; q += 16) { const i64 r = pl.frow[q]; if (r < rmax) s += sp_fwd(pl, vals, x, r); }
+  s += __shfl_xor(s, 8, 16);
+  s += __shfl_xor(s, 4, 16);
+  s += __shfl_xor(s, 2, 16);
+  s += __shfl_xor(s, 1, 16);
+  if (l == 0 && q1 > q0) x[pl.fnode[h]] -= s;
 }
 __global__ void __launch_bounds__(kBlock) sp_dsolve_kernel(SparsePlan pl, const double* vals, double* x) {
   const i64 k = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
@@ -1713,13 +1728,14 @@ struct HipExec : HostControlled {
         if (pl.tail_n > 0) DNLP_HIP_CHECK(hipMemsetAsync(Tacc, 0, sizeof(double) * static_cast<size_t>(pl.tail_ld * pl.tail_n), stream));
         for (i64 lev = 0; lev < pl.nlev_run; ++lev) {
           const i64 b0 = pl.h_lev_blk[lev], b1 = pl.h_lev_blk[lev + 1], r0 = pl.h_lev_row[lev], r1 = pl.h_lev_row[lev + 1];
-          const i64 t0 = pl.h_lev_trip[lev], t1 = pl.h_lev_trip[lev + 1], v0 = pl.h_lev_val[lev], v1 = pl.h_lev_val[lev + 1];
-          if (level_fusion_ && (t1 - t0) <= 40 * (b1 - b0) && (r1 - r0) <= 8 * (b1 - b0)) {
-            hipLaunchKernelGGL(sp_level_fused_kernel, grid(b1 - b0), dim3(kBlock), 0, stream, pl, vals, w, dinv, b0, b1, info);
-            continue;
+          const i64 v0 = pl.h_lev_val[lev], v1 = pl.h_lev_val[lev + 1];
+          const i64 g0 = pl.h_lev_g[lev], g1 = pl.h_lev_g[lev + 1];
+          if (level_fusion_ && (r1 - r0) <= 8 * (b1 - b0)) {
+            hipLaunchKernelGGL(sp_pivot_scale_kernel, grid(b1 - b0), dim3(kBlock), 0, stream, pl, vals, w, dinv, b0, b1, info);
+          } else {
+            hipLaunchKernelGGL(sp_pivot_kernel, grid(b1 - b0), dim3(kBlock), 0, stream, pl, vals, dinv, b0, b1, info);
+            if (r1 > r0) hipLaunchKernelGGL(sp_scale_kernel, grid(r1 - r0), dim3(kBlock), 0, stream, pl, vals, w, dinv, r0, r1);
           }
-          hipLaunchKernelGGL(sp_pivot_kernel, grid(b1 - b0), dim3(kBlock), 0, stream, pl, vals, dinv, b0, b1, info);
-          if (r1 > r0) hipLaunchKernelGGL(sp_scale_kernel, grid(r1 - r0), dim3(kBlock), 0, stream, pl, vals, w, dinv, r0, r1);
           if (pl.tail_n > 0 && pl.h_pg_cols[lev] > 0) {
             // the level's panel blocks: T -= Pl Pw^T on the FP64 MFMA kernel (lower triangle, tail_n x tail_n x cols)
             const i64 cols = pl.h_pg_cols[lev], q0 = pl.h_pg_off[lev], q1 = pl.h_pg_off[lev + 1];
@@ -1727,7 +1743,7 @@ struct HipExec : HostControlled {
             hipLaunchKernelGGL(sp_panel_gather_kernel, grid(q1 - q0), dim3(kBlock), 0, stream, pl, vals, w, Pl, Pw, q0, q1);
             sparse_tail_gemm(Tacc, pl.tail_ld, Pl, Pw, static_cast<int>(pl.tail_n), static_cast<int>(cols));
           }
-          if (t1 > t0) hipLaunchKernelGGL(sp_update_kernel, grid(t1 - t0), dim3(kBlock), 0, stream, pl, vals, w, t0, t1);
+          if (g1 > g0) hipLaunchKernelGGL(sp_update_gather_kernel, grid(16 * (g1 - g0)), dim3(kBlock), 0, stream, pl, vals, w, g0, g1);
           if (v1 > v0) hipLaunchKernelGGL(sp_store_kernel, grid(v1 - v0), dim3(kBlock), 0, stream, vals, w, v0, v1);
         }
       });
@@ -1747,9 +1763,12 @@ struct HipExec : HostControlled {
     } else {
       replay_levels(1 + 2 * pl.solve_phase, pl.soff, vals, x, [&] {
         if (pl.solve_phase != 2) {
-          for (i64 lev = 0; lev < pl.nlev_run; ++lev) {
-            const i64 r0 = pl.h_lev_row[lev], r1 = pl.h_lev_row[lev + 1];
-            if (r1 > r0) hipLaunchKernelGGL(sp_fwd_kernel, grid(r1 - r0), dim3(kBlock), 0, stream, pl, vals, x, r0, r1);
+          const i64 rmax = pl.h_lev_row[pl.nlev_run];
+          for (i64 lev = 1; lev <= pl.nlev_run; ++lev) {
+            const bool last = lev == pl.nlev_run;
+            if (last && pl.nlev_run == pl.nlev) break;
+            const i64 h0 = pl.h_lev_f[lev], h1 = last ? pl.h_lev_f[pl.nlev] : pl.h_lev_f[lev + 1];
+            if (h1 > h0) hipLaunchKernelGGL(sp_fwd_gather_kernel, grid(16 * (h1 - h0)), dim3(kBlock), 0, stream, pl, vals, x, h0, h1, rmax);
           }
           hipLaunchKernelGGL(sp_dsolve_kernel, grid(pl.nblk_run), dim3(kBlock), 0, stream, pl, vals, x);
         }
@@ -2028,64 +2047,16 @@ struct HipExec : HostControlled {
     DNLP_HIP_CHECK(hipModuleLaunchKernel(fused_rtc.fn, static_cast<unsigned>(blocks), 1, 1, kBlock, 1, 1, 0, stream, args, nullptr));
     return true;
   }
-  // Index of a COO pattern by output (mode 0: rows, 1: columns, 2: both sides of a lower triangle): ent = entry, src =
-  // index into v, ptr = segment of every output.  Built on the host on a pattern's first product (the patterns of a
-  // handle are fixed), for patterns up to coo_det_max entries (DNLP_COO_DET_MAX; 0 = never): beyond that — the 1e7-entry
-  // dense Jacobian of BASELINE C3 — the first call would pay 0.16 s for it (and a product 0.1 ms more: measured with DNLP_COO_DET_MAX=20000000) and the atomic kernel stays.
-  struct CooIndex { i32* ent = nullptr; i32* src = nullptr; i64* ptr = nullptr; i64 nout = 0; };
-  std::map<std::tuple<const void*, const void*, i64, int>, CooIndex> coo_index_;
-  i64 coo_det_max = 4000000;
-  const CooIndex* coo_index(i64 nnz, const i32* r, const i32* c, int mode) {
-    static const i64 env_max = [] { const char* e = std::getenv("DNLP_COO_DET_MAX"); return e ? std::atoll(e) : -1; }();
-    if (nnz > (env_max >= 0 ? env_max : coo_det_max) || nnz > (i64{1} << 30)) return nullptr;   // (entry ids are 32-bit, two per entry in mode 2)
-    const auto key = std::make_tuple(static_cast<const void*>(r), static_cast<const void*>(c), nnz, mode);
-    auto it = coo_index_.find(key);
-    if (it != coo_index_.end()) return &it->second;
-    std::vector<i32> hr(static_cast<size_t>(nnz)), hc(static_cast<size_t>(nnz));
-    d2h(hr.data(), r, sizeof(i32) * static_cast<size_t>(nnz));
-    d2h(hc.data(), c, sizeof(i32) * static_cast<size_t>(nnz));
-    i64 nout = 0;
-    for (i64 p = 0; p < nnz; ++p) {
-      const i32 rp = hr[static_cast<size_t>(p)], cp = hc[static_cast<size_t>(p)];
-      if (mode != 1 && rp + 1 > nout) nout = rp + 1;
-      if (mode != 0 && cp + 1 > nout) nout = cp + 1;
-    }
-    std::vector<i64> ptr(static_cast<size_t>(nout) + 1, 0);
-    auto each = [&](auto&& f) {                  // (entry, output, source) in storage order
-      for (i64 p = 0; p < nnz; ++p) {
-        const i32 rp = hr[static_cast<size_t>(p)], cp = hc[static_cast<size_t>(p)];
-        if (mode != 1) f(p, rp, cp);
-        if (mode == 1 || (mode == 2 && rp != cp)) f(p, cp, rp);
-      }
-    };
-    each([&](i64, i32 o, i32) { ++ptr[static_cast<size_t>(o) + 1]; });
-    for (i64 g = 0; g < nout; ++g) ptr[static_cast<size_t>(g) + 1] += ptr[static_cast<size_t>(g)];
-    const i64 total = ptr[static_cast<size_t>(nout)];
-    std::vector<i32> ent(static_cast<size_t>(total)), src(static_cast<size_t>(total));
-    std::vector<i64> fill(ptr.begin(), ptr.end() - 1);
-    each([&](i64 p, i32 o, i32 sidx) {
-      const i64 at = fill[static_cast<size_t>(o)]++;
-      ent[static_cast<size_t>(at)] = static_cast<i32>(p);
-      src[static_cast<size_t>(at)] = sidx;
-    });
-    CooIndex ix;
-    ix.nout = nout;
-    ix.ent = alloc<i32>(static_cast<size_t>(total));
-    ix.src = alloc<i32>(static_cast<size_t>(total));
-    ix.ptr = alloc<i64>(static_cast<size_t>(nout) + 1);
-    h2d(ix.ent, ent.data(), sizeof(i32) * static_cast<size_t>(total));
-    h2d(ix.src, src.data(), sizeof(i32) * static_cast<size_t>(total));
-    h2d(ix.ptr, ptr.data(), sizeof(i64) * (static_cast<size_t>(nout) + 1));
-    return &coo_index_.emplace(key, ix).first->second;
+  // Order-fixed products through the tape's index by output (tape.h CooIdx, built when the tape is loaded — no lazy
+  // index keyed by device pointers, nothing built inside a product): sixteen lanes per output, fixed reduction tree.
+  void coo_gather(const CooIdx& ix, const double* a, const double* v, double* out) {
+    if (ix.nout <= 0 || ix.total <= 0) return;
+    hipLaunchKernelGGL(coo_rows_kernel, dim3(static_cast<unsigned>((ix.nout * 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                       ix.nout, ix.ptr, ix.ent, ix.src, a, v, out);
   }
+  // scatter products with floating-point atomics: patterns the tape did not index (above Tape::coo_index_max entries)
   void coo_product(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out, int mode) {
     if (nnz <= 0) return;
-    if (const CooIndex* ix = coo_index(nnz, r, c, mode)) {
-      if (ix->nout > 0)
-        hipLaunchKernelGGL(coo_rows_kernel, dim3(static_cast<unsigned>((ix->nout * 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
-                           ix->nout, ix->ptr, ix->ent, ix->src, a, v, out);
-      return;
-    }
     hipLaunchKernelGGL(coo_mult_kernel, dim3(static_cast<unsigned>((nnz + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
                        nnz, r, c, a, v, out, mode);
   }

@@ -300,12 +300,12 @@ struct Model {
     DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     const i64 NN = t.N;
     ex->zero(out, static_cast<size_t>(NN) * sizeof(double));
-    // sparse part: serial-safe scatter through a row-wise pass is not available in COO
-    // order, so accumulate with the exec space's atomic-free two-pass form: lower entries
-    // contribute to both (r,c) and (c,r).
+    // sparse part: lower entries contribute to both (r,c) and (c,r); the tape's index by output (tape.h CooIdx)
+    // makes it an order-fixed gather (scatter with atomics only for patterns too large to index)
     const i32 *hr = t.hess_rows, *hc = t.hess_cols;
     const double* hs = Hs;
-    ex->coo_sym_mult(t.nnzH, hr, hc, hs, v, out);
+    if (t.hess_sym.ptr) ex->coo_gather(t.hess_sym, hs, v, out);
+    else ex->coo_sym_mult(t.nnzH, hr, hc, hs, v, out);
     for (i64 k = 0; k < t.nblk; ++k) {
       const DenseBlock& B = t.blocks[k];
       const double* P = t.dense_ptr[B.cid];
@@ -322,12 +322,14 @@ struct Model {
   DNLP_HD void jac_mult(const double* jv, const double* v, double* out) {
     DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     ex->zero(out, static_cast<size_t>(t.m) * sizeof(double));
-    ex->coo_mult(t.nnzJ, t.jac_rows, t.jac_cols, jv, v, out, false);
+    if (t.jac_by_row.ptr) ex->coo_gather(t.jac_by_row, jv, v, out);
+    else ex->coo_mult(t.nnzJ, t.jac_rows, t.jac_cols, jv, v, out, false);
   }
   DNLP_HD void jac_tmult(const double* jv, const double* v, double* out) {
     DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     ex->zero(out, static_cast<size_t>(t.N) * sizeof(double));
-    ex->coo_mult(t.nnzJ, t.jac_rows, t.jac_cols, jv, v, out, true);
+    if (t.jac_by_col.ptr) ex->coo_gather(t.jac_by_col, jv, v, out);
+    else ex->coo_mult(t.nnzJ, t.jac_rows, t.jac_cols, jv, v, out, true);
   }
 };
 

@@ -18,7 +18,6 @@ struct SeqPar {
   DNLP_HD int lane() const { return 0; }
   DNLP_HD void sync() const {}
   DNLP_HD double sum(double v) const { return v; }
-  DNLP_HD void add(double* p, double v) const { *p += v; }
 };
 
 // work: nvals (w, laid out like the L values) + 3 * nblk (inverse pivot blocks)
@@ -107,8 +106,10 @@ DNLP_HD inline void sp_dsolve(const SparsePlan& pl, const double* vals, double* 
 
 // vals: assembled matrix in plan layout, overwritten by (D, L).  Level by level: the blocks of an
 // elimination-tree level are independent, so their pivots are inverted together, their rows scaled
-// together and their update triples applied together (sums into common ancestors through
-// par.add: an atomic add on the device, a plain add on the host).
+// together and their update triples applied together.  The triples of a level are stored sorted by
+// destination (sparse_plan.h: gdst / goff / lev_g): a destination is summed by ONE lane in storage order —
+// or, on a narrow level with long groups, by all lanes and par.sum's fixed tree — and subtracted once.
+// No floating-point atomics: the same bits on every run.
 template <class P>
 DNLP_HD inline bool sparse_ldl_factor(const SparsePlan& pl, double* vals, double* work, int* nneg_out, int* nzero_out, P par) {
   const int L = par.lanes(), me = par.lane();
@@ -147,9 +148,26 @@ DNLP_HD inline bool sparse_ldl_factor(const SparsePlan& pl, double* vals, double
       }
       par.sync();
     }
-    // C: Schur-complement updates of the level
-    const i64 t0 = pl.toff[b0], t1 = pl.toff[b1];
-    for (i64 q = t0 + me; q < t1; q += L) par.add(&vals[pl.tdst[q]], -sp_update(pl, vals, w, q));
+    // C: Schur-complement updates of the level, one destination at a time
+    {
+      const i64 g0 = pl.lev_g[lev], g1 = pl.lev_g[lev + 1];
+      const i64 ngr = g1 - g0, ntr = pl.goff[g1] - pl.goff[g0];
+      if (ngr * 8 <= L && ntr >= 16 * ngr) {
+        // few destinations, long groups (a separator's diagonal block under many children): all lanes per group
+        for (i64 g = g0; g < g1; ++g) {
+          double acc = 0.0;
+          for (i64 q = pl.goff[g] + me; q < pl.goff[g + 1]; q += L) acc += sp_update(pl, vals, w, q);
+          acc = par.sum(acc);
+          if (me == 0) vals[pl.gdst[g]] -= acc;
+        }
+      } else {
+        for (i64 g = g0 + me; g < g1; g += L) {
+          double acc = 0.0;
+          for (i64 q = pl.goff[g]; q < pl.goff[g + 1]; ++q) acc += sp_update(pl, vals, w, q);
+          vals[pl.gdst[g]] -= acc;
+        }
+      }
+    }
     par.sync();
     // D: keep L = l D^-1
     const i64 v0 = pl.loff[b0], v1 = (b1 < pl.nblk) ? pl.loff[b1] : pl.nvals;
@@ -168,15 +186,31 @@ DNLP_HD inline bool sparse_ldl_factor(const SparsePlan& pl, double* vals, double
 template <class P>
 DNLP_HD inline void sparse_ldl_solve(const SparsePlan& pl, const double* vals, double* x, P par) {
   const int L = par.lanes(), me = par.lane();
-  // forward, level by level: every struct row pushes its contribution into an ancestor entry
-  // (a plan with a dense tail runs the levels before it in two calls: solve_phase 1, the tail's dense solve, then 2)
+  // forward, level by level, in GATHER form: a node of level lev collects the struct rows that point at it (all from
+  // blocks of lower levels, so their x entries are final), in ascending row order, and is final itself afterwards
+  // (a plan with a dense tail runs the levels before it in two calls: solve_phase 1, the tail's dense solve, then 2;
+  //  the tail's nodes then gather only the rows of the blocks before the tail, in one last phase)
   if (pl.solve_phase != 2) {
-  for (i64 lev = 0; lev < pl.nlev_run; ++lev) {
-    const i64 b0 = pl.lev_off[lev], b1 = pl.lev_off[lev + 1];
-    const i64 r0 = pl.soff[b0], r1 = pl.soff[b1];
-    for (i64 r = r0 + me; r < r1; r += L) {
-      const double c = sp_fwd(pl, vals, x, r);
-      if (c != 0.0) par.add(&x[pl.sidx[r]], -c);
+  const i64 rmax = pl.soff[pl.nblk_run];
+  for (i64 lev = 1; lev <= pl.nlev_run; ++lev) {
+    const bool last = lev == pl.nlev_run;
+    if (last && pl.nlev_run == pl.nlev) break;
+    const i64 h0 = pl.lev_f[lev], h1 = last ? pl.lev_f[pl.nlev] : pl.lev_f[lev + 1];
+    if (h1 == h0) continue;
+    const i64 nh = h1 - h0, nrw = pl.foff[h1] - pl.foff[h0];
+    if (nh * 8 <= L && nrw >= 16 * nh) {
+      for (i64 h = h0; h < h1; ++h) {
+        double acc = 0.0;
+        for (i64 q = pl.foff[h] + me; q < pl.foff[h + 1]; q += L) { const i64 r = pl.frow[q]; if (r < rmax) acc += sp_fwd(pl, vals, x, r); }
+        acc = par.sum(acc);
+        if (me == 0) x[pl.fnode[h]] -= acc;
+      }
+    } else {
+      for (i64 h = h0 + me; h < h1; h += L) {
+        double acc = 0.0;
+        for (i64 q = pl.foff[h]; q < pl.foff[h + 1]; ++q) { const i64 r = pl.frow[q]; if (r >= rmax) break; acc += sp_fwd(pl, vals, x, r); }
+        x[pl.fnode[h]] -= acc;
+      }
     }
     par.sync();
   }

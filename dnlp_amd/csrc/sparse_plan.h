@@ -87,6 +87,21 @@ struct SparsePlan {
   i64* lev_off = nullptr; // nlev + 1 offsets into the block order
   i32* sblk = nullptr;    // block of every struct row (soff-indexed)
   i32* tblk = nullptr;    // block of every update triple
+  // ORDER-FIXED ACCUMULATION (no floating-point atomics anywhere in the numeric phase).  The update triples of a level
+  // are stored sorted by destination: group g = one destination value gdst[g] and the triples goff[g] .. goff[g+1];
+  // lev_g[lev] .. lev_g[lev+1] are the groups of level lev.  One lane (or a fixed reduction tree over lanes) sums a
+  // group and subtracts it from its destination once.  Forward substitution likewise gathers: target node fnode[h]
+  // (a node of a block of level lev for h in lev_f[lev] .. lev_f[lev+1]) collects the struct rows frow[foff[h] ..
+  // foff[h+1]) that point at it, ascending (= by source block), so a node is final when its level is reached.
+  i64 ngrp = 0, nfwd = 0;
+  i32* gdst = nullptr;
+  i64* goff = nullptr;
+  i64* lev_g = nullptr;
+  i32* fnode = nullptr;
+  i64* foff = nullptr;
+  i32* frow = nullptr;
+  i64* lev_f = nullptr;
+  const i64 *h_lev_g = nullptr, *h_lev_f = nullptr;
   // host copies of the level boundaries (blocks / struct rows / triples / values), for the space
   // that launches one kernel per level phase; unused inside kernels
   const i64 *h_lev_blk = nullptr, *h_lev_row = nullptr, *h_lev_trip = nullptr, *h_lev_val = nullptr;
@@ -98,6 +113,8 @@ struct SparsePlanHost {
   std::vector<i64> soff, doff, loff, toff, lev_off;
   std::vector<i64> lev_row, lev_trip, lev_val;     // per-level boundaries in rows / triples / values
   std::vector<i32> sblk, tblk;
+  std::vector<i32> gdst, fnode, frow;                // order-fixed accumulation (see SparsePlan)
+  std::vector<i64> goff, lev_g, foff, lev_f;
   // dense tail (see SparsePlan): chosen by layout(), handed to the exec space only by upload(ex, true)
   i64 tail_lev = -1, tail_n = 0, tail_ld = 0, pg_maxcols = 0;
   std::vector<i32> tnode, tg_src, tg_dst, pg_src, pg_dst;
@@ -573,6 +590,62 @@ struct SparsePlanHost {
       lev_trip.push_back(toff[static_cast<size_t>(b)]);
       lev_val.push_back(b < nb ? loff[static_cast<size_t>(b)] : nvals);
     }
+    // ---- order-fixed accumulation: the triples of a level sorted by destination (stable counting sort), one group per
+    // destination; struct rows grouped by the node they point at ----
+    {
+      const i64 nl = static_cast<i64>(lev_off.size()) - 1;
+      gdst.clear(); goff.assign(1, 0); lev_g.assign(1, 0);
+      std::vector<i64> cnt(static_cast<size_t>(nvals), 0);
+      std::vector<i32> touched, t_dst, t_iu, t_iv, t_blk;
+      for (i64 lev = 0; lev < nl; ++lev) {
+        const size_t t0 = static_cast<size_t>(lev_trip[static_cast<size_t>(lev)]), t1 = static_cast<size_t>(lev_trip[static_cast<size_t>(lev) + 1]);
+        touched.clear();
+        for (size_t q = t0; q < t1; ++q) if (cnt[static_cast<size_t>(tdst[q])]++ == 0) touched.push_back(tdst[q]);
+        std::sort(touched.begin(), touched.end());
+        i64 at = static_cast<i64>(t0);
+        for (i32 d : touched) {
+          const i64 c = cnt[static_cast<size_t>(d)];
+          cnt[static_cast<size_t>(d)] = at;              // from here on: next free position of this destination
+          at += c;
+          gdst.push_back(d);
+          goff.push_back(at);
+        }
+        t_dst.assign(tdst.begin() + static_cast<std::ptrdiff_t>(t0), tdst.begin() + static_cast<std::ptrdiff_t>(t1));
+        t_iu.assign(tiu.begin() + static_cast<std::ptrdiff_t>(t0), tiu.begin() + static_cast<std::ptrdiff_t>(t1));
+        t_iv.assign(tiv.begin() + static_cast<std::ptrdiff_t>(t0), tiv.begin() + static_cast<std::ptrdiff_t>(t1));
+        t_blk.assign(tblk.begin() + static_cast<std::ptrdiff_t>(t0), tblk.begin() + static_cast<std::ptrdiff_t>(t1));
+        for (size_t q = 0; q < t1 - t0; ++q) {
+          const size_t to = static_cast<size_t>(cnt[static_cast<size_t>(t_dst[q])]++);
+          tdst[to] = t_dst[q]; tiu[to] = t_iu[q]; tiv[to] = t_iv[q]; tblk[to] = t_blk[q];
+        }
+        for (i32 d : touched) cnt[static_cast<size_t>(d)] = 0;
+        lev_g.push_back(static_cast<i64>(gdst.size()));
+      }
+      // (toff keeps the level boundaries toff[lev_off[l]]; inside a level the triples are no longer grouped by block)
+      fnode.clear(); foff.assign(1, 0); frow.clear(); lev_f.assign(1, 0);
+      std::vector<i64> fcnt(static_cast<size_t>(nn) + 1, 0);
+      for (i32 u : sidx) ++fcnt[static_cast<size_t>(u) + 1];
+      for (i64 u = 0; u < nn; ++u) fcnt[static_cast<size_t>(u) + 1] += fcnt[static_cast<size_t>(u)];
+      std::vector<i32> rows_by_node(sidx.size());
+      {
+        std::vector<i64> fill(fcnt.begin(), fcnt.end() - 1);
+        for (size_t r = 0; r < sidx.size(); ++r) rows_by_node[static_cast<size_t>(fill[static_cast<size_t>(sidx[r])]++)] = static_cast<i32>(r);
+      }
+      for (i64 lev = 0; lev < nl; ++lev) {
+        for (i64 k = lev_off[static_cast<size_t>(lev)]; k < lev_off[static_cast<size_t>(lev) + 1]; ++k)
+          for (int c = 0; c < 2; ++c) {
+            const i32 u = bnode[static_cast<size_t>(2 * k + c)];
+            if (u < 0) continue;
+            const i64 a = fcnt[static_cast<size_t>(u)], b = fcnt[static_cast<size_t>(u) + 1];
+            if (b == a) continue;
+            fnode.push_back(u);
+            frow.insert(frow.end(), rows_by_node.begin() + static_cast<std::ptrdiff_t>(a), rows_by_node.begin() + static_cast<std::ptrdiff_t>(b));
+            foff.push_back(static_cast<i64>(frow.size()));
+          }
+        lev_f.push_back(static_cast<i64>(fnode.size()));
+      }
+    }
+    tick("order-fixed groups");
     if (nvals >= (static_cast<i64>(1) << 31)) throw std::runtime_error("sparse KKT plan: factor too large for 32-bit addresses");
     bn_.clear(); bn_.shrink_to_fit();
     order_.clear(); order_.shrink_to_fit();
@@ -630,6 +703,9 @@ struct SparsePlanHost {
     up(p.bnode, bnode); up(p.soff, soff); up(p.sidx, sidx); up(p.doff, doff); up(p.loff, loff); up(p.toff, toff);
     up(p.tdst, tdst); up(p.tiu, tiu); up(p.tiv, tiv); up(p.hpos, hpos); up(p.jpos, jpos); up(p.dpos, dpos);
     up(p.lev_off, lev_off); up(p.sblk, sblk); up(p.tblk, tblk);
+    up(p.gdst, gdst); up(p.goff, goff); up(p.lev_g, lev_g); up(p.fnode, fnode); up(p.foff, foff); up(p.frow, frow); up(p.lev_f, lev_f);
+    p.ngrp = static_cast<i64>(gdst.size()); p.nfwd = static_cast<i64>(fnode.size());
+    p.h_lev_g = lev_g.data(); p.h_lev_f = lev_f.data();
     p.nlev = static_cast<i64>(lev_off.size()) - 1;
     p.nlev_run = p.nlev; p.nblk_run = p.nblk;
     if (panels_dropped && !(with_tail && tail_n > 0))

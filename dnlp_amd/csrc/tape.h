@@ -3,6 +3,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -132,6 +133,18 @@ struct DenseBlock {
 
 struct SparseConst { Csr P, PT; i64 nh = 0; double* hv = nullptr; };
 
+// Index of a COO pattern BY OUTPUT, built once when the tape is loaded: the entries that feed output g are the
+// segment ptr[g] .. ptr[g+1] of (ent = COO entry, src = index into the multiplied vector), in storage order.
+// A product that walks the segments sums every output in one fixed order: no floating-point atomics, the same
+// bits on every run and in every execution space that sums a segment serially (host loops, the in-kernel solver).
+// ptr == nullptr: no index (pattern above Tape::coo_index_max entries); the exec space falls back to its scatter form.
+struct CooIdx {
+  i64 nout = 0, total = 0;
+  i64* ptr = nullptr;
+  i32* ent = nullptr;
+  i32* src = nullptr;
+};
+
 // Everything the evaluators (model.h) and the interior-point loop (ipm_core.h) read, as plain
 // pointers and counts: the same struct describes a tape loaded by Tape<E>::load below and one
 // instance of a batch inside the batched-solve kernel (exec_block.h).  "exec space" arrays live
@@ -157,6 +170,7 @@ struct TapeView {
   Csr G, Mg, Mw, MJ, MH;
   i32 *jac_rows = nullptr, *jac_cols = nullptr, *hess_rows = nullptr, *hess_cols = nullptr;
   i64* jac_rowptr = nullptr;   // m+1: the Jacobian COO is row-major sorted
+  CooIdx jac_by_row, jac_by_col, hess_sym;   // order-fixed products J v, J^T v, sym(H) v (model.h)
   // control space: reduction-class segments, constants, dense Hessian blocks
   const SegHost* segs = nullptr;
   const i64* red_segs = nullptr;
@@ -198,6 +212,39 @@ struct Tape : TapeView {
     T* d = ex->template alloc<T>(n);
     ex->h2d(d, src, n * sizeof(T));
     return d;
+  }
+  // patterns above this many entries keep the exec space's scatter product (BASELINE C3's dense Jacobian, 1e7 entries:
+  // the column index alone would cost 0.16 s of its first call); DNLP_COO_DET_MAX overrides
+  i64 coo_index_max = 4000000;
+  // mode 0: outputs = rows (src = column), 1: outputs = columns (src = row), 2: both sides of a lower triangle
+  CooIdx build_coo_index(const std::vector<i32>& hr, const std::vector<i32>& hc, i64 nout, int mode) {
+    CooIdx ix;
+    const i64 nnz = static_cast<i64>(hr.size());
+    if (const char* e = std::getenv("DNLP_COO_DET_MAX")) coo_index_max = std::atoll(e);
+    if (nnz > coo_index_max || nnz > (i64{1} << 30)) return ix;      // (entry ids are 32-bit, two per entry in mode 2)
+    std::vector<i64> ptr(static_cast<size_t>(nout) + 1, 0);
+    auto each = [&](auto&& f) {                  // (entry, output, source) in storage order
+      for (i64 p = 0; p < nnz; ++p) {
+        const i32 rp = hr[static_cast<size_t>(p)], cp = hc[static_cast<size_t>(p)];
+        if (mode != 1) f(p, rp, cp);
+        if (mode == 1 || (mode == 2 && rp != cp)) f(p, cp, rp);
+      }
+    };
+    each([&](i64, i32 o, i32) { ++ptr[static_cast<size_t>(o) + 1]; });
+    for (i64 g = 0; g < nout; ++g) ptr[static_cast<size_t>(g) + 1] += ptr[static_cast<size_t>(g)];
+    const i64 total = ptr[static_cast<size_t>(nout)];
+    std::vector<i32> ent(static_cast<size_t>(total)), src(static_cast<size_t>(total));
+    std::vector<i64> fill(ptr.begin(), ptr.end() - 1);
+    each([&](i64 p, i32 o, i32 sidx) {
+      const i64 at = fill[static_cast<size_t>(o)]++;
+      ent[static_cast<size_t>(at)] = static_cast<i32>(p);
+      src[static_cast<size_t>(at)] = sidx;
+    });
+    ix.nout = nout; ix.total = total;
+    ix.ptr = up(ptr.data(), ptr.size());
+    ix.ent = up(ent.data(), ent.size());
+    ix.src = up(src.data(), src.size());
+    return ix;
   }
   Csr up_csr(const TapeBlob& tb, const std::string& name, i64 rows, i64 cols) {
     Csr m;
@@ -291,6 +338,9 @@ struct Tape : TapeView {
     jac_cols = up(h_jac_cols.data(), h_jac_cols.size());
     hess_rows = up(h_hess_rows.data(), h_hess_rows.size());
     hess_cols = up(h_hess_cols.data(), h_hess_cols.size());
+    jac_by_row = build_coo_index(h_jac_rows, h_jac_cols, m, 0);
+    jac_by_col = build_coo_index(h_jac_rows, h_jac_cols, N, 1);
+    hess_sym = build_coo_index(h_hess_rows, h_hess_cols, N, 2);
     dense_n.assign(tb.i64s("dense_n"), tb.i64s("dense_n") + ndense);
     h_dense_ptr.assign(static_cast<size_t>(ndense), nullptr);
     h_dense_ld.assign(static_cast<size_t>(ndense), 0);

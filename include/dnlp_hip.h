@@ -204,8 +204,8 @@ int64_t dnlp_kkt_tail_nodes(dnlp_problem* p);
  * [17] factorizations of all dnlp_ipm_begin / dnlp_ipm_step calls, [18] begin calls, [19] seconds
  * spent in them, [20] factorizations skipped by the certified regularisation bound (last solve),
  * [21] outer Schur updates of one complete blocked factorisation, [22] blocked factorisations
- * abandoned early, [23] 1 when hessian_approximation=limited-memory was requested (the exact tape
- * Hessian is used all the same). */
+ * abandoned early, [23] reserved, 0 (a batch launch with hessian_approximation=limited-memory is refused with
+ * -12 Invalid_Option: the in-kernel solver has no quasi-Newton mode and does not substitute the exact Hessian). */
 int dnlp_get_stats(dnlp_problem* p, double* stats, int n);
 /* Iteration log of the last solve (IPOPT-style table), NUL terminated; returns bytes needed. */
 size_t dnlp_get_log(dnlp_problem* p, char* buf, size_t cap);

@@ -43,7 +43,7 @@ struct HostLapack {
   gemm_t gemm = nullptr;                 // DGEMM / DTRSM of the same library: the blocked unpivoted LDL^T below
   trsm_t trsm = nullptr;
   bool blocked_unpivoted = false;        // orc_use_blocked_ldlt: unpivoted factorisations of order >= 512 go through them
-  std::vector<double> wpanel;
+  std::vector<double> wpanel, wpanel2;
   int (*get_threads)() = nullptr;
   void (*set_threads)(int) = nullptr;
   std::vector<double> work;
@@ -199,6 +199,14 @@ struct HostExec : HostControlled {
       if (trans) out[c[p]] += a[p] * v[r[p]]; else out[r[p]] += a[p] * v[c[p]];
     }
   }
+  // out += (pattern product) through the tape's index by output: every output sums its segment in storage order
+  void coo_gather(const CooIdx& ix, const double* a, const double* v, double* out) {
+    for (i64 g = 0; g < ix.nout; ++g) {
+      double s = 0.0;
+      for (i64 p = ix.ptr[g]; p < ix.ptr[g + 1]; ++p) s += a[ix.ent[p]] * v[ix.src[p]];
+      out[g] += s;
+    }
+  }
   // out += S v for a symmetric matrix given by its lower-triangle COO entries
   void coo_sym_mult(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out) {
     for (i64 p = 0; p < nnz; ++p) {
@@ -255,19 +263,38 @@ struct HostExec : HostControlled {
       const double one = 1.0, mone = -1.0;
       for (i64 K0 = 0; K0 < n; K0 += NB) {
         const i64 KB = std::min<i64>(NB, n - K0);
-        for (i64 k = K0; k < K0 + KB; ++k) {
-          double d = a(k, k);
-          if (!(d == d)) return false;
-          if (std::fabs(d) <= tiny) { (*nzero)++; d = (d < 0 ? -1.0 : 1.0) * 1e-20; a(k, k) = d; }
-          if (d < 0) (*nneg)++;
-          ipiv[k] = static_cast<i32>(k + 1);
-          const double inv = 1.0 / d;
-          for (i64 j = k + 1; j < K0 + KB; ++j) {
-            const double lj = A[j + k * ld] * inv;
-            if (lj == 0.0) continue;
-            for (i64 i = j; i < K0 + KB; ++i) A[i + j * ld] -= A[i + k * ld] * lj;
+        // the panel's diagonal block, itself blocked by 64 columns (unblocked it was 45 Mflop of scalar code per
+        // 512-column panel, more time than the DGEMMs of the whole factorisation on a 256-core host): 64 x 64 diagonal
+        // pieces unblocked, the rows of the block below them by DTRSM, the rest of the block by DGEMM
+        const i64 IB = 64;
+        for (i64 k0 = K0; k0 < K0 + KB; k0 += IB) {
+          const i64 kb = std::min<i64>(IB, K0 + KB - k0), e0 = k0 + kb, er = K0 + KB - e0;
+          for (i64 k = k0; k < e0; ++k) {
+            double d = a(k, k);
+            if (!(d == d)) return false;
+            if (std::fabs(d) <= tiny) { (*nzero)++; d = (d < 0 ? -1.0 : 1.0) * 1e-20; a(k, k) = d; }
+            if (d < 0) (*nneg)++;
+            ipiv[k] = static_cast<i32>(k + 1);
+            const double inv = 1.0 / d;
+            for (i64 j = k + 1; j < e0; ++j) {
+              const double lj = A[j + k * ld] * inv;
+              if (lj == 0.0) continue;
+              for (i64 i = j; i < e0; ++i) A[i + j * ld] -= A[i + k * ld] * lj;
+            }
+            for (i64 i = k + 1; i < e0; ++i) a(i, k) *= inv;
           }
-          for (i64 i = k + 1; i < K0 + KB; ++i) a(i, k) *= inv;
+          if (er <= 0) break;
+          const int mi2 = static_cast<int>(er), ki2 = static_cast<int>(kb), ldi2 = static_cast<int>(ld);
+          LP.trsm("R", "L", "T", "U", &mi2, &ki2, &one, A + k0 + k0 * ld, &ldi2, A + e0 + k0 * ld, &ldi2);   // W = L D
+          if (LP.wpanel2.size() < static_cast<size_t>(er * kb)) LP.wpanel2.resize(static_cast<size_t>(er * kb));
+          double* W2 = LP.wpanel2.data();
+          for (i64 c = 0; c < kb; ++c) {
+            const double inv = 1.0 / A[(k0 + c) + (k0 + c) * ld];
+            double* col = A + e0 + (k0 + c) * ld;
+            double* wc = W2 + c * er;
+            for (i64 i = 0; i < er; ++i) { wc[i] = col[i]; col[i] *= inv; }
+          }
+          LP.gemm("N", "T", &mi2, &mi2, &ki2, &mone, W2, &mi2, A + e0 + k0 * ld, &ldi2, &one, A + e0 + e0 * ld, &ldi2);
         }
         const i64 r1 = K0 + KB, rows = n - r1;
         if (rows <= 0) break;

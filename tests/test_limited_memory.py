@@ -121,3 +121,20 @@ def test_device_front_end_takes_the_quasi_newton_mode(gpu_required):
     assert "no second derivatives evaluated" in data["handle"].log()
     exact = chain.solver.solve_via_data(data, True, False, {})
     assert exact.get("device_loop") is True            # (the default solve of this small problem is the in-kernel loop)
+
+
+@pytest.mark.gpu
+def test_batch_launch_refuses_the_quasi_newton_mode(gpu_required):
+    """The reference hands hessian_approximation to IPOPT for every solve (ipopt_nlpif.py:153-168).  The in-kernel
+    solver of a batch launch has no quasi-Newton mode: it answers with IPOPT's Invalid_Option (-12) instead of
+    silently running the exact Hessian; the same batch with the exact Hessian still solves."""
+    import batch_problems as bp
+    from dnlp_amd.batch import ParametricBatch
+    tprob, params, sample, _ = bp.template_localization()
+    pb = ParametricBatch(tprob, params)
+    thetas = np.stack([sample(i) for i in range(8)])
+    with pytest.raises(RuntimeError, match=r"code -12.*not available inside a batch launch"):
+        pb.solve(thetas, hessian_approximation="limited-memory")
+    res = pb.solve(thetas)
+    assert np.all(res.status == 0)
+    pb.close()
