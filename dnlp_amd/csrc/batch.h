@@ -38,8 +38,9 @@ struct BatchArgs {
   int lds_mode = 0;              // what the pool holds: 0 nothing, 1 KKT matrix, 2 vectors, 3 both
   unsigned lds_stage_bytes = 0;  // front of the pool: staging arrays of the dense wavefront solves
   unsigned stage_global_bytes = 0;   // ... or, for sparse instances with a dense fallback, the tail of the block's global slab
-  unsigned plan_stage_bytes = 0; // then: LDS copy of the sparse plan's solve-phase index arrays (0: read from global)
-  int plan_stage_factor = 0;     // ... and of the factor-phase / assembly arrays (update triples, value positions)
+  unsigned plan_stage_bytes = 0; // then: LDS copies of index arrays that every instance reads (0: all read from global), by
+  int plan_stage_factor = 0;     // this mask: 1 the sparse plan's solve-phase arrays, 2 the tape's product indices (CooIdx),
+                                 // 4 the plan's factor-phase / assembly arrays (update triples, value positions)
   i64 plan_rows = 0;             // struct rows of the plan (length of sidx / sblk)
   IpmOptions opt;
   double *x_out = nullptr, *obj_out = nullptr, *multg_out = nullptr, *zl_out = nullptr, *zu_out = nullptr;
@@ -57,6 +58,10 @@ struct BatchArgs {
 // one private copy per wavefront: every wavefront runs the control flow redundantly, and a field
 // read is an LDS access (~0.1 us) instead of a scratch-memory round trip through L2 (~0.5 us)
 // on the critical path of each of the several hundred maps / reductions of an iteration.
+// (measured in round 4 and not kept: the same kernel held to 256 registers per lane, amdgpu_waves_per_eu(2, 2), eight
+//  instances per compute unit: an iteration takes 0.27 ms instead of 0.155 by the device clock and a launch of 8192 /
+//  65 536 instances 59 / 300 ms instead of 60 / 333 — two wavefronts on a SIMD share the memory pipeline that one
+//  already keeps busy: the kernel is bound by the NUMBER of its memory operations, not by their latency)
 template <int NT>
 __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
   extern __shared__ __align__(64) char lds_dyn[];
@@ -87,6 +92,7 @@ __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
   // for every instance, so the workgroup copies them into LDS once and every instance it solves
   // reads them through a patched view of the plan.
   SparsePlan spl = a.sp;
+  CooIdx cjr = a.base.jac_by_row, cjc = a.base.jac_by_col, chs = a.base.hess_sym;
   const unsigned pstage = a.use_sparse ? a.plan_stage_bytes : 0u;
   if (pstage) {
     char* p = lds_dyn + stage;
@@ -97,24 +103,34 @@ __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
       field = dst;
       p += (static_cast<size_t>(count) * sizeof(T) + 7) & ~static_cast<size_t>(7);
     };
-    put(spl.bnode, 2 * spl.nblk);
-    put(spl.soff, spl.nblk + 1);
-    put(spl.loff, spl.nblk);
-    put(spl.doff, spl.nblk);
-    put(spl.lev_off, spl.nlev + 1);
-    put(spl.sblk, a.plan_rows);
-    put(spl.sidx, a.plan_rows);
-    put(spl.lev_f, spl.nlev + 1);
-    put(spl.fnode, spl.nfwd);
-    put(spl.foff, spl.nfwd + 1);
-    put(spl.frow, a.plan_rows);
-    if (a.plan_stage_factor) {
+    if (a.plan_stage_factor & 1) {
+      put(spl.bnode, 2 * spl.nblk);
+      put(spl.soff, spl.nblk + 1);
+      put(spl.loff, spl.nblk);
+      put(spl.doff, spl.nblk);
+      put(spl.lev_off, spl.nlev + 1);
+      put(spl.sblk, a.plan_rows);
+      put(spl.sidx, a.plan_rows);
+      put(spl.lev_f, spl.nlev + 1);
+      put(spl.fnode, spl.nfwd);
+      put(spl.foff, spl.nfwd + 1);
+      put(spl.fa, a.plan_rows);
+      put(spl.fu0, a.plan_rows);
+      put(spl.fu1, a.plan_rows);
+    }
+    if (a.plan_stage_factor & 2) {
+      auto putc = [&](CooIdx& c) {
+        if (!c.ptr) return;
+        put(c.ptr, c.nout + 1); put(c.ent, c.total); put(c.src, c.total); put(c.heavy, c.nheavy);
+      };
+      putc(cjr); putc(cjc); putc(chs);
+    }
+    if (a.plan_stage_factor & 4) {
       put(spl.lev_g, spl.nlev + 1);
       put(spl.gdst, spl.ngrp);
       put(spl.goff, spl.ngrp + 1);
-      put(spl.tiu, spl.ntrip);
-      put(spl.tiv, spl.ntrip);
-      put(spl.tblk, spl.ntrip);
+      put(spl.tau, spl.ntrip);
+      put(spl.tav, spl.ntrip);
       put(spl.hpos, a.base.nnzH);
       put(spl.jpos, a.base.nnzJ);
       put(spl.dpos, spl.n);
@@ -141,6 +157,7 @@ __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
     ex->lds_mode = a.lds_mode;
     double* sl = a.slabs + static_cast<i64>(inst) * a.lay.total;
     TapeView t = a.base;
+    t.jac_by_row = cjr; t.jac_by_col = cjc; t.hess_sym = chs;
     t.c0 = sl[a.lay.c0];
     t.c = sl + a.lay.c; t.b = sl + a.lay.b; t.Jc = sl + a.lay.Jc;
     t.G.val = sl + a.lay.G; t.Mg.val = sl + a.lay.Mg; t.Mw.val = sl + a.lay.Mw; t.MJ.val = sl + a.lay.MJ;
@@ -319,6 +336,23 @@ struct BatchRunner {
       b.cap = bytes;
     }
     return static_cast<T*>(b.p);
+  }
+
+  // bytes of the LDS copies of the shared index arrays (batch_solve_kernel's `put` order and padding)
+  struct IdxBytes { size_t solve = 0, coo = 0, factor = 0; };
+  IdxBytes index_bytes() const {
+    auto pad8 = [](size_t b) { return (b + 7) & ~static_cast<size_t>(7); };
+    const Tape<HipExec>& t = *tape;
+    const size_t nb = static_cast<size_t>(dev_plan.nblk), nl = static_cast<size_t>(dev_plan.nlev), nr = static_cast<size_t>(plan_rows);
+    const size_t nf = static_cast<size_t>(dev_plan.nfwd), ng = static_cast<size_t>(dev_plan.ngrp), nt = static_cast<size_t>(dev_plan.ntrip);
+    IdxBytes b;
+    b.solve = pad8(8 * nb) + pad8(4 * (nb + 1)) + 2 * pad8(4 * nb) + pad8(4 * (nl + 1)) + 2 * pad8(4 * nr) +
+              pad8(4 * (nl + 1)) + pad8(4 * nf) + pad8(4 * (nf + 1)) + 3 * pad8(4 * nr);
+    for (const CooIdx* c : {&t.jac_by_row, &t.jac_by_col, &t.hess_sym})
+      if (c->ptr) b.coo += pad8(4 * static_cast<size_t>(c->nout + 1)) + 2 * pad8(4 * static_cast<size_t>(c->total)) + pad8(4 * static_cast<size_t>(c->nheavy));
+    b.factor = pad8(4 * (nl + 1)) + pad8(4 * ng) + pad8(4 * (ng + 1)) + 2 * pad8(4 * nt) + pad8(4 * static_cast<size_t>(t.nnzH)) +
+               pad8(4 * static_cast<size_t>(t.nnzJ)) + pad8(4 * static_cast<size_t>(dev_plan.n));
+    return b;
   }
 
   void init(HipExec* e, Tape<HipExec>* t) {
@@ -514,7 +548,14 @@ struct BatchRunner {
         //  in LDS this was a choice — plan arrays OR 2.6 KB more of the vectors, the first better for short queues, the
         //  second for long ones: 65 536 localization instances 246 against 268 k problems/s — with the staging area in the
         //  global slab both fit: 290 k/s; tools/micro/batch_lds_share_sweep.sh)
-        const size_t fixed = stage_bytes + (mode & 1 ? kbytes : 0) + fa.sharedSizeBytes + 256 + 3072;
+        size_t idx_reserve = 3072;
+        if (have_sparse) {
+          const IdxBytes ib = index_bytes();
+          int want = 7;
+          if (const char* e = std::getenv("DNLP_BATCH_IDX_LDS")) want = std::atoi(e) & 7;
+          idx_reserve = (want & 1 ? ib.solve : 0) + (want & 2 ? ib.coo : 0) + (want & 4 ? ib.factor : 0) + 128;
+        }
+        const size_t fixed = stage_bytes + (mode & 1 ? kbytes : 0) + fa.sharedSizeBytes + 256 + idx_reserve;
         const size_t room = (160 * 1024) / static_cast<size_t>(s_now + 1);
         if (room > fixed) {
           const size_t want = (room - fixed) & ~static_cast<size_t>(63);
@@ -525,29 +566,28 @@ struct BatchRunner {
     a.lds_mode = mode;
     a.lds_stage_bytes = static_cast<unsigned>((stage_bytes + 63) & ~static_cast<size_t>(63));
     a.lds_bytes = static_cast<unsigned>(a.lds_stage_bytes + (mode & 1 ? kbytes : 0) + (mode & 2 ? vbytes_lds : 0));
-    // LDS copy of the plan's solve-phase index arrays — when it does not cost a resident instance
+    // LDS copies of the index arrays every instance reads — when they do not cost a resident instance
     a.plan_stage_bytes = 0;
+    a.plan_stage_factor = 0;
     a.plan_rows = plan_rows;
     if (have_sparse && !std::getenv("DNLP_BATCH_NO_PLAN_LDS")) {
-      auto pad8 = [](size_t b) { return (b + 7) & ~static_cast<size_t>(7); };
-      const size_t nb = static_cast<size_t>(dev_plan.nblk), nl = static_cast<size_t>(dev_plan.nlev), nr = static_cast<size_t>(plan_rows);
-      const size_t nf = static_cast<size_t>(dev_plan.nfwd), ng = static_cast<size_t>(dev_plan.ngrp);
-      const size_t pbytes = (pad8(8 * nb) + pad8(8 * (nb + 1)) + 2 * pad8(8 * nb) + pad8(8 * (nl + 1)) + 2 * pad8(4 * nr) +
-                             pad8(8 * (nl + 1)) + pad8(4 * nf) + pad8(8 * (nf + 1)) + pad8(4 * nr) + 63) & ~static_cast<size_t>(63);
-      const size_t per0 = a.lds_bytes + fa.sharedSizeBytes + 256, per1 = per0 + pbytes;
+      const IdxBytes ib = index_bytes();
+      int want = 7;
+      if (const char* e = std::getenv("DNLP_BATCH_IDX_LDS")) want = std::atoi(e) & 7;
+      const size_t per0 = a.lds_bytes + fa.sharedSizeBytes + 256;
       const size_t cap = 160 * 1024;
-      const size_t nt = static_cast<size_t>(dev_plan.ntrip);
-      const size_t fbytes2 = (pad8(8 * (nl + 1)) + pad8(4 * ng) + pad8(8 * (ng + 1)) + 3 * pad8(4 * nt) + pad8(4 * static_cast<size_t>(t.nnzH)) +
-                              pad8(4 * static_cast<size_t>(t.nnzJ)) + pad8(4 * static_cast<size_t>(dev_plan.n)) + 63) & ~static_cast<size_t>(63);
-      const size_t per2 = per1 + fbytes2;
       const size_t s0 = std::min<size_t>(slots_max, cap / per0);
-      a.plan_stage_factor = 0;
-      if (per2 <= cap && std::min<size_t>(slots_max, cap / per2) == s0) {
-        a.plan_stage_bytes = static_cast<unsigned>(pbytes + fbytes2);
-        a.plan_stage_factor = 1;
-        a.lds_bytes += a.plan_stage_bytes;
-      } else if (per1 <= cap && std::min<size_t>(slots_max, cap / per1) == s0) {
-        a.plan_stage_bytes = static_cast<unsigned>(pbytes);
+      // most valuable first: the solves' arrays (~10 level phases per solve, ~10 solves per iteration), the product
+      // indices (~15 products per iteration), the factorisation's arrays (1.3 factorisations per iteration)
+      size_t add = 0;
+      const size_t part[3] = {ib.solve, ib.coo, ib.factor};
+      for (int k = 0; k < 3; ++k) {
+        if (!(want & (1 << k))) continue;
+        const size_t per = per0 + add + part[k] + 64;
+        if (per <= cap && std::min<size_t>(slots_max, cap / per) == s0) { add += part[k]; a.plan_stage_factor |= 1 << k; }
+      }
+      if (a.plan_stage_factor) {
+        a.plan_stage_bytes = static_cast<unsigned>((add + 63) & ~static_cast<size_t>(63));
         a.lds_bytes += a.plan_stage_bytes;
       }
     }

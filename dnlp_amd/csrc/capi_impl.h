@@ -121,11 +121,11 @@ struct ProblemT {
     plan_seconds = now_sec() - t_plan0;
     if (std::getenv("DNLP_TIME_PLAN"))
       std::fprintf(stderr, "[dnlp] sparse plan: order %.0f, %zu triples, fill ratio %.4f, %.3f s on the host\n", n,
-                   sparse_plan.tdst.size(), sparse_plan.fill_ratio, plan_seconds);
+                   static_cast<size_t>(sparse_plan.ntrip), sparse_plan.fill_ratio, plan_seconds);
     // a long update program (dense-ish fill) is walked by one workgroup: it must be clearly cheaper
     // than the chip-wide dense factorisation (n^3/3 flops at MFMA rate; phase retrieval, order
     // 1472 with 3.6e6 triples, stays dense — a 7e5-order chain with 8e5 triples is sparse)
-    const double triples = static_cast<double>(sparse_plan.tdst.size());
+    const double triples = static_cast<double>(static_cast<size_t>(sparse_plan.ntrip));
     use_sparse = linear_solver == 2 ||
                  (sparse_plan.fill_ratio <= 0.3 && (triples <= 4e5 || triples * 1000.0 <= n * n * n / 3.0));
     if (linear_solver == 1) use_sparse = false;      // forced dense (the plan still serves the static pairing of kkt_dense.h)
@@ -438,7 +438,7 @@ struct ProblemT {
     DNLP_TRY(p->plan_linear_solver();                                                                \
              out[0] = p->use_sparse ? 1 : 0; out[1] = p->sparse_plan.nnzL; out[2] = p->sparse_plan.nblk(); \
              out[3] = p->sparse_plan.maxs; out[4] = p->sparse_plan.n_pairs;                          \
-             out[5] = static_cast<int64_t>(p->sparse_plan.tdst.size());                                 \
+             out[5] = static_cast<int64_t>(p->sparse_plan.ntrip);                                 \
              out[6] = static_cast<int64_t>(p->sparse_plan.lev_off.size()) - 1;                              \
              out[7] = (!p->use_sparse && p->model.t.N + p->model.t.m <= p->pivot_max_n) ? 1 : 0; return 0;)  \
   }                                                                                                  \

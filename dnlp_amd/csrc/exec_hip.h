@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(kBlock) coo_mult_kernel(i64 nnz, const i32* __
 // strides and reduce in a fixed tree, ONE lane adds the sum to out[g].  No atomics: the sum of an output is rounded
 // in the same order on every run (with atomics portfolio construction ended after 22 to 72 iterations from run to
 // run, with this after 22 every time: profiles/r03_determinism.txt).
-__global__ void __launch_bounds__(kBlock) coo_rows_kernel(i64 nout, const i64* __restrict__ ptr, const i32* __restrict__ ent,
+__global__ void __launch_bounds__(kBlock) coo_rows_kernel(i64 nout, const i32* __restrict__ ptr, const i32* __restrict__ ent,
                                                           const i32* __restrict__ src, const double* __restrict__ a,
                                                           const double* __restrict__ v, double* out) {
   const i64 g = (static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x) >> 4;
@@ -334,6 +334,45 @@ __global__ void __launch_bounds__(kBlock) coo_rows_kernel(i64 nout, const i64* _
   s += __shfl_xor(s, 2, 16);
   s += __shfl_xor(s, 1, 16);
   if (l == 0 && p1 > p0) out[g] += s;
+}
+
+// Products with a rectangular Jacobian stored row-major (tape.h jac_rect_cols: every row carries the same L columns),
+// order-fixed without an index.  out[r] += sum_k a[r L + k] v[col[k]]: one wavefront per row, coalesced, DPP tree.
+__global__ void __launch_bounds__(kBlock) rect_mult_kernel(i64 rows, i64 L, const i32* __restrict__ col, const double* __restrict__ a,
+                                                           const double* __restrict__ v, double* out) {
+  const i64 r = static_cast<i64>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const double* ar = a + r * L;
+  double s0 = 0.0, s1 = 0.0;
+  i64 k = lane;
+  for (; k + 64 < L; k += 128) { s0 += ar[k] * v[col[k]]; s1 += ar[k + 64] * v[col[k + 64]]; }
+  if (k < L) s0 += ar[k] * v[col[k]];
+  const double s = wave_sum(s0 + s1);
+  if (lane == 0) out[r] += s;
+}
+// out[col[k]] += sum_r a[r L + k] v[r]: a lane owns a column position k (coalesced along k), grid.y walks chunks of
+// rows into partial[chunk][k]; the finish kernel adds the chunks in order.
+__global__ void __launch_bounds__(kBlock) rect_tmult_partial_kernel(i64 rows, i64 L, int rows_per_chunk, const double* __restrict__ a,
+                                                                    const double* __restrict__ v, double* __restrict__ partial) {
+  const i64 k = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+  if (k >= L) return;
+  const i64 r0 = static_cast<i64>(blockIdx.y) * rows_per_chunk;
+  i64 r1 = r0 + rows_per_chunk;
+  if (r1 > rows) r1 = rows;
+  double s0 = 0.0, s1 = 0.0;
+  i64 r = r0;
+  for (; r + 1 < r1; r += 2) { s0 += a[r * L + k] * v[r]; s1 += a[(r + 1) * L + k] * v[r + 1]; }
+  if (r < r1) s0 += a[r * L + k] * v[r];
+  partial[static_cast<i64>(blockIdx.y) * L + k] = s0 + s1;
+}
+__global__ void __launch_bounds__(kBlock) rect_tmult_finish_kernel(i64 L, int nchunks, const i32* __restrict__ col,
+                                                                   const double* __restrict__ partial, double* out) {
+  const i64 k = static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
+  if (k >= L) return;
+  double s = 0.0;
+  for (int c = 0; c < nchunks; ++c) s += partial[static_cast<i64>(c) * L + k];
+  out[col[k]] += s;
 }
 
 // ---- Bunch-Kaufman LDL^T (DSYTF2 semantics, lower) ----------------------------------------
@@ -1337,7 +1376,7 @@ __global__ void __launch_bounds__(kBlock) sp_pivot_scale_kernel(SparsePlan pl, d
   if (bad != 0.0) atomicExch(&info->ok, 0);
   for (i64 r = pl.soff[k]; r < pl.soff[k + 1]; ++r) sp_scale(pl, vals, w, dinv, r);
 }
-__global__ void __launch_bounds__(kBlock) sp_scale_kernel(SparsePlan pl, const double* vals, double* w, const double* dinv, i64 r0, i64 r1) {
+__global__ void __launch_bounds__(kBlock) sp_scale_kernel(SparsePlan pl, double* vals, double* w, const double* dinv, i64 r0, i64 r1) {
   const i64 r = r0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
   if (r < r1) sp_scale(pl, vals, w, dinv, r);
 }
@@ -1362,21 +1401,41 @@ __global__ void __launch_bounds__(kBlock) sp_panel_gather_kernel(SparsePlan pl, 
                                                                  i64 q0, i64 q1) {
   const i64 q = q0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
   if (q >= q1) return;
-  Pl[pl.pg_dst[q]] = vals[pl.pg_src[q]];
-  Pw[pl.pg_dst[q]] = w[pl.pg_src[q]];
+  Pl[pl.pg_dst[q]] = w[pl.pg_src[q]];          // (sp_scale leaves the unscaled l in w and L = l D^-1 in vals)
+  Pw[pl.pg_dst[q]] = vals[pl.pg_src[q]];
 }
-__global__ void __launch_bounds__(kBlock) sp_store_kernel(double* vals, const double* w, i64 v0, i64 v1) {
-  const i64 a = v0 + static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x;
-  if (a < v1) vals[a] = w[a];
+// ... and a whole workgroup per destination for levels whose groups are long (the separator of the NMF example: 300
+// tail nodes under 1 200 blocks each): wavefront sums by DPP, the four partials added in order
+__global__ void __launch_bounds__(kBlock) sp_update_gather_wg_kernel(SparsePlan pl, double* vals, const double* w, i64 g0) {
+  __shared__ double part[kBlock / 64];
+  const i64 g = g0 + blockIdx.x;
+  const i64 q0 = pl.goff[g], q1 = pl.goff[g + 1];
+  double s = 0.0;
+  for (i64 q = q0 + threadIdx.x; q < q1; q += kBlock) s += sp_update(pl, vals, w, q);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = part[0]; for (int k = 1; k < kBlock / 64; ++k) t += part[k]; vals[pl.gdst[g]] -= t; }
+}
+__global__ void __launch_bounds__(kBlock) sp_fwd_gather_wg_kernel(SparsePlan pl, const double* vals, double* x, i64 h0) {
+  __shared__ double part[kBlock / 64];
+  const i64 h = h0 + blockIdx.x;
+  const i64 q0 = pl.foff[h], q1 = pl.fend ? pl.fend[h] : pl.foff[h + 1];
+  double s = 0.0;
+  for (i64 q = q0 + threadIdx.x; q < q1; q += kBlock) s += sp_fwd(pl, vals, x, q);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = part[0]; for (int k = 1; k < kBlock / 64; ++k) t += part[k]; x[pl.fnode[h]] -= t; }
 }
 // forward substitution in gather form (sparse_plan.h fnode / foff / frow): sixteen lanes per target node, fixed tree
-__global__ void __launch_bounds__(kBlock) sp_fwd_gather_kernel(SparsePlan pl, const double* vals, double* x, i64 h0, i64 h1, i64 rmax) {
+__global__ void __launch_bounds__(kBlock) sp_fwd_gather_kernel(SparsePlan pl, const double* vals, double* x, i64 h0, i64 h1) {
   const i64 h = h0 + ((static_cast<i64>(blockIdx.x) * kBlock + threadIdx.x) >> 4);
   const int l = threadIdx.x & 15;
   double s = 0.0;
   i64 q0 = 0, q1 = 0;
-  if (h < h1) { q0 = pl.foff[h]; q1 = pl.foff[h + 1]; }
-  for (i64 q = q0 + l; q < q1; q += 16) { const i64 r = pl.frow[q]; if (r < rmax) s += sp_fwd(pl, vals, x, r); }
+  if (h < h1) { q0 = pl.foff[h]; q1 = pl.fend ? pl.fend[h] : pl.foff[h + 1]; }
+  for (i64 q = q0 + l; q < q1; q += 16) s += sp_fwd(pl, vals, x, q);
   s += __shfl_xor(s, 8, 16);
   s += __shfl_xor(s, 4, 16);
   s += __shfl_xor(s, 2, 16);
@@ -1482,6 +1541,7 @@ struct HipExec : HostControlled {
     if (lb_state) hipFree(lb_state);
     if (lb_ctl) hipFree(lb_ctl);
     if (lb_halo) hipFree(lb_halo);
+    if (lb_xsave) hipFree(lb_xsave);
     if (lb_host) hipHostFree(lb_host);
     if (lb_fpart) hipFree(lb_fpart);
     if (lb_upart) hipFree(lb_upart);
@@ -1728,7 +1788,6 @@ struct HipExec : HostControlled {
         if (pl.tail_n > 0) DNLP_HIP_CHECK(hipMemsetAsync(Tacc, 0, sizeof(double) * static_cast<size_t>(pl.tail_ld * pl.tail_n), stream));
         for (i64 lev = 0; lev < pl.nlev_run; ++lev) {
           const i64 b0 = pl.h_lev_blk[lev], b1 = pl.h_lev_blk[lev + 1], r0 = pl.h_lev_row[lev], r1 = pl.h_lev_row[lev + 1];
-          const i64 v0 = pl.h_lev_val[lev], v1 = pl.h_lev_val[lev + 1];
           const i64 g0 = pl.h_lev_g[lev], g1 = pl.h_lev_g[lev + 1];
           if (level_fusion_ && (r1 - r0) <= 8 * (b1 - b0)) {
             hipLaunchKernelGGL(sp_pivot_scale_kernel, grid(b1 - b0), dim3(kBlock), 0, stream, pl, vals, w, dinv, b0, b1, info);
@@ -1743,8 +1802,12 @@ struct HipExec : HostControlled {
             hipLaunchKernelGGL(sp_panel_gather_kernel, grid(q1 - q0), dim3(kBlock), 0, stream, pl, vals, w, Pl, Pw, q0, q1);
             sparse_tail_gemm(Tacc, pl.tail_ld, Pl, Pw, static_cast<int>(pl.tail_n), static_cast<int>(cols));
           }
-          if (g1 > g0) hipLaunchKernelGGL(sp_update_gather_kernel, grid(16 * (g1 - g0)), dim3(kBlock), 0, stream, pl, vals, w, g0, g1);
-          if (v1 > v0) hipLaunchKernelGGL(sp_store_kernel, grid(v1 - v0), dim3(kBlock), 0, stream, vals, w, v0, v1);
+          if (g1 > g0) {
+            if (pl.h_lev_trip[lev + 1] - pl.h_lev_trip[lev] >= 128 * (g1 - g0))
+              hipLaunchKernelGGL(sp_update_gather_wg_kernel, dim3(static_cast<unsigned>(g1 - g0)), dim3(kBlock), 0, stream, pl, vals, w, g0);
+            else
+              hipLaunchKernelGGL(sp_update_gather_kernel, grid(16 * (g1 - g0)), dim3(kBlock), 0, stream, pl, vals, w, g0, g1);
+          }
         }
       });
       DNLP_LAUNCH_CHECK();
@@ -1763,12 +1826,16 @@ struct HipExec : HostControlled {
     } else {
       replay_levels(1 + 2 * pl.solve_phase, pl.soff, vals, x, [&] {
         if (pl.solve_phase != 2) {
-          const i64 rmax = pl.h_lev_row[pl.nlev_run];
           for (i64 lev = 1; lev <= pl.nlev_run; ++lev) {
             const bool last = lev == pl.nlev_run;
             if (last && pl.nlev_run == pl.nlev) break;
             const i64 h0 = pl.h_lev_f[lev], h1 = last ? pl.h_lev_f[pl.nlev] : pl.h_lev_f[lev + 1];
-            if (h1 > h0) hipLaunchKernelGGL(sp_fwd_gather_kernel, grid(16 * (h1 - h0)), dim3(kBlock), 0, stream, pl, vals, x, h0, h1, rmax);
+            if (h1 > h0) {
+              if (pl.h_fwd_rows[h1] - pl.h_fwd_rows[h0] >= 128 * (h1 - h0))
+                hipLaunchKernelGGL(sp_fwd_gather_wg_kernel, dim3(static_cast<unsigned>(h1 - h0)), dim3(kBlock), 0, stream, pl, vals, x, h0);
+              else
+                hipLaunchKernelGGL(sp_fwd_gather_kernel, grid(16 * (h1 - h0)), dim3(kBlock), 0, stream, pl, vals, x, h0, h1);
+            }
           }
           hipLaunchKernelGGL(sp_dsolve_kernel, grid(pl.nblk_run), dim3(kBlock), 0, stream, pl, vals, x);
         }
@@ -1867,6 +1934,10 @@ struct HipExec : HostControlled {
   double* lb_halo = nullptr;
   i64 lb_key_nf = -1, lb_per = 0;
   int lb_persist_wgs = 0;
+  bool lb_persist_failed_ = false;      // the persistent kernel could not be made co-resident once: slot kernels from then on
+  int lb_persist_fallbacks = 0;
+  double* lb_xsave = nullptr;           // start point of a persistent launch (restored when the launch is given up)
+  i64 lb_xsave_cap = 0;
   const void* lb_key = nullptr;
   int lb_key_M = 0, lb_key_E = 0;
   hipGraphExec_t lb_graph_exec = nullptr;      // one batch of slots, captured once per argument set
@@ -1951,29 +2022,59 @@ struct HipExec : HostControlled {
     std::memset(lb_host, 0, sizeof(LbfgsState));
     lb_host->tol = tol; lb_host->max_iter = max_iter; lb_host->M = M; lb_host->nblocks = static_cast<int>(blocks);
     DNLP_HIP_CHECK(hipMemcpyAsync(lb_state, lb_host, sizeof(LbfgsState), hipMemcpyHostToDevice, stream));
-    if (lb_persist && lb_persist_wgs >= 2 && lb_persist_wgs <= ncu) {
-      // ONE launch: the state goes in zeroed, comes back final
+    if (lb_persist && lb_persist_wgs >= 2 && lb_persist_wgs <= ncu && !lb_persist_failed_) {
+      // ONE launch: the state goes in zeroed, comes back final.  The kernel's grid barrier needs every workgroup
+      // resident at once: the launch is COOPERATIVE (the runtime refuses it when the grid cannot be co-resident with the
+      // ~150 KB of LDS per workgroup — another stream, handle or process holding LDS or compute units), and x is saved
+      // first: a refused launch or a barrier that timed out all the same (done == 5) restores x and takes the slot
+      // kernels below, which need no co-residency.  It never throws and never leaves a half-written x behind.
       if (!lb_ctl) {
         DNLP_HIP_CHECK(hipMalloc(&lb_ctl, sizeof(LbPersistCtl)));
         DNLP_HIP_CHECK(hipMalloc(&lb_halo, sizeof(double) * 2 * 1024 * 128));
       }
+      if (nfree > lb_xsave_cap) {
+        if (lb_xsave) hipFree(lb_xsave);
+        lb_xsave = nullptr;
+        DNLP_HIP_CHECK(hipMalloc(&lb_xsave, sizeof(double) * static_cast<size_t>(nfree)));
+        lb_xsave_cap = nfree;
+      }
+      DNLP_HIP_CHECK(hipMemcpyAsync(lb_xsave, x, sizeof(double) * static_cast<size_t>(nfree), hipMemcpyDeviceToDevice, stream));
       DNLP_HIP_CHECK(hipMemsetAsync(lb_ctl, 0, sizeof(LbPersistCtl), stream));
       i64 nfp = nfree;
       double c0p = c0;
       void* a_p[] = {&lb_state, &x, &consts, &lb_ctl, &lb_halo, &c0p, &nfp};
-      DNLP_HIP_CHECK(hipModuleLaunchKernel(lb_persist, static_cast<unsigned>(lb_persist_wgs), 1, 1, kBlock, 1, 1, 0, stream, a_p, nullptr));
-      DNLP_HIP_CHECK(hipMemcpyAsync(lb_host, lb_state, sizeof(LbfgsState), hipMemcpyDeviceToHost, stream));
-      DNLP_HIP_CHECK(hipStreamSynchronize(stream));
-      if (lb_host->done == 5) throw std::runtime_error("device L-BFGS: a workgroup of the persistent kernel never reached a grid barrier");
-      out.slots = lb_host->evals;
-      out.iterations = lb_host->iter;
-      out.evaluations = lb_host->evals;
-      out.f = lb_host->f;
-      out.gnorm = lb_host->gn;
-      out.status = lb_host->done == 1 ? 0 : lb_host->done == 2 ? 3 : lb_host->done == 4 ? -13 : -1;
-      out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
-      out.persistent = true;
-      return true;
+      bool launched = true;
+      static const bool plain_launch = [] { const char* e = std::getenv("DNLP_LBFGS_COOPERATIVE"); return e && std::atoi(e) == 0; }();
+      if (plain_launch) {
+        DNLP_HIP_CHECK(hipModuleLaunchKernel(lb_persist, static_cast<unsigned>(lb_persist_wgs), 1, 1, kBlock, 1, 1, 0, stream, a_p, nullptr));
+      } else if (hipModuleLaunchCooperativeKernel(lb_persist, static_cast<unsigned>(lb_persist_wgs), 1, 1, kBlock, 1, 1, 0, stream, a_p) != hipSuccess) {
+        (void)hipGetLastError();
+        launched = false;
+      }
+      if (launched) {
+        DNLP_HIP_CHECK(hipMemcpyAsync(lb_host, lb_state, sizeof(LbfgsState), hipMemcpyDeviceToHost, stream));
+        DNLP_HIP_CHECK(hipStreamSynchronize(stream));
+      }
+      if (launched && lb_host->done != 5) {
+        out.slots = lb_host->evals;
+        out.iterations = lb_host->iter;
+        out.evaluations = lb_host->evals;
+        out.f = lb_host->f;
+        out.gnorm = lb_host->gn;
+        out.status = lb_host->done == 1 ? 0 : lb_host->done == 2 ? 3 : lb_host->done == 4 ? -13 : -1;
+        out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
+        out.persistent = true;
+        return true;
+      }
+      // not co-resident: the start point back, a clean state, and the slot kernels from here on for this handle
+      lb_persist_failed_ = true;
+      ++lb_persist_fallbacks;
+      DNLP_HIP_CHECK(hipMemcpyAsync(x, lb_xsave, sizeof(double) * static_cast<size_t>(nfree), hipMemcpyDeviceToDevice, stream));
+      DNLP_HIP_CHECK(hipMemsetAsync(lb_BV, 0, sizeof(double) * static_cast<size_t>(2 * M) * static_cast<size_t>(nfree), stream));
+      DNLP_HIP_CHECK(hipMemsetAsync(lb_gt, 0, sizeof(double) * 2 * static_cast<size_t>(nfree), stream));
+      std::memset(lb_host, 0, sizeof(LbfgsState));
+      lb_host->tol = tol; lb_host->max_iter = max_iter; lb_host->M = M; lb_host->nblocks = static_cast<int>(blocks);
+      DNLP_HIP_CHECK(hipMemcpyAsync(lb_state, lb_host, sizeof(LbfgsState), hipMemcpyHostToDevice, stream));
     }
     i64 nf = nfree, nc = nchunks;
     double c0v = c0;
@@ -2053,6 +2154,25 @@ struct HipExec : HostControlled {
     if (ix.nout <= 0 || ix.total <= 0) return;
     hipLaunchKernelGGL(coo_rows_kernel, dim3(static_cast<unsigned>((ix.nout * 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
                        ix.nout, ix.ptr, ix.ent, ix.src, a, v, out);
+  }
+  // rectangular row-major Jacobian (BASELINE C3's dense constraint block): see rect_mult_kernel
+  double* rect_part = nullptr;
+  size_t rect_part_cap = 0;
+  void rect_mult(i64 rows, i64 L, const i32* col, const double* a, const double* v, double* out) {
+    hipLaunchKernelGGL(rect_mult_kernel, dim3(static_cast<unsigned>((rows + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, stream,
+                       rows, L, col, a, v, out);
+  }
+  void rect_tmult(i64 rows, i64 L, const i32* col, const double* a, const double* v, double* out) {
+    // enough chunks to fill the chip: ceil(L / 256) workgroups per chunk, ~1024 workgroups in all
+    const i64 wg = (L + kBlock - 1) / kBlock;
+    int nchunks = static_cast<int>(std::min<i64>(std::max<i64>(1, 1024 / wg), (rows + 15) / 16));
+    const int per = static_cast<int>((rows + nchunks - 1) / nchunks);
+    nchunks = static_cast<int>((rows + per - 1) / per);
+    const size_t need = static_cast<size_t>(nchunks) * static_cast<size_t>(L);
+    if (need > rect_part_cap) { rect_part = alloc<double>(need); rect_part_cap = need; }     // (grow-only; the old buffer goes with the handle)
+    hipLaunchKernelGGL(rect_tmult_partial_kernel, dim3(static_cast<unsigned>(wg), static_cast<unsigned>(nchunks)), dim3(kBlock), 0, stream,
+                       rows, L, per, a, v, rect_part);
+    hipLaunchKernelGGL(rect_tmult_finish_kernel, dim3(static_cast<unsigned>(wg)), dim3(kBlock), 0, stream, L, nchunks, col, rect_part, out);
   }
   // scatter products with floating-point atomics: patterns the tape did not index (above Tape::coo_index_max entries)
   void coo_product(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out, int mode) {

@@ -322,14 +322,16 @@ struct Model {
   DNLP_HD void jac_mult(const double* jv, const double* v, double* out) {
     DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     ex->zero(out, static_cast<size_t>(t.m) * sizeof(double));
-    if (t.jac_by_row.ptr) ex->coo_gather(t.jac_by_row, jv, v, out);
-    else ex->coo_mult(t.nnzJ, t.jac_rows, t.jac_cols, jv, v, out, false);
+    if (t.jac_by_row.ptr) { ex->coo_gather(t.jac_by_row, jv, v, out); return; }
+    if constexpr (E::is_device && E::has_host_control) if (t.jac_rect_cols > 0) { ex->rect_mult(t.m, t.jac_rect_cols, t.jac_cols, jv, v, out); return; }
+    ex->coo_mult(t.nnzJ, t.jac_rows, t.jac_cols, jv, v, out, false);
   }
   DNLP_HD void jac_tmult(const double* jv, const double* v, double* out) {
     DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     ex->zero(out, static_cast<size_t>(t.N) * sizeof(double));
-    if (t.jac_by_col.ptr) ex->coo_gather(t.jac_by_col, jv, v, out);
-    else ex->coo_mult(t.nnzJ, t.jac_rows, t.jac_cols, jv, v, out, true);
+    if (t.jac_by_col.ptr) { ex->coo_gather(t.jac_by_col, jv, v, out); return; }
+    if constexpr (E::is_device && E::has_host_control) if (t.jac_rect_cols > 0) { ex->rect_tmult(t.m, t.jac_rect_cols, t.jac_cols, jv, v, out); return; }
+    ex->coo_mult(t.nnzJ, t.jac_rows, t.jac_cols, jv, v, out, true);
   }
 };
 

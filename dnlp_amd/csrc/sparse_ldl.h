@@ -60,33 +60,37 @@ DNLP_HD inline void sp_pivot(const SparsePlan& pl, double* vals, double* dinv, i
     di[0] = e / det; di[1] = -c / det; di[2] = a / det;
   }
 }
-// B: w = l D^-1 for struct row r
-DNLP_HD inline void sp_scale(const SparsePlan& pl, const double* vals, double* w, const double* dinv, i64 r) {
+// B: struct row r: L = l D^-1 goes into vals (its final place), the unscaled l into w (the update phase multiplies the
+// two: no separate "keep L" pass over the level's values afterwards)
+DNLP_HD inline void sp_scale(const SparsePlan& pl, double* vals, double* w, const double* dinv, i64 r) {
   const i64 k = pl.sblk[r], i = r - pl.soff[k];
   const double* di = dinv + 3 * k;
   if (pl.bnode[2 * k + 1] < 0) {
     const i64 a = pl.loff[k] + i;
-    w[a] = vals[a] * di[0];
+    const double l1 = vals[a];
+    w[a] = l1;
+    vals[a] = l1 * di[0];
   } else {
     const i64 a = pl.loff[k] + 2 * i;
     const double l1 = vals[a], l2 = vals[a + 1];
-    w[a] = di[0] * l1 + di[1] * l2;
-    w[a + 1] = di[1] * l1 + di[2] * l2;
+    w[a] = l1; w[a + 1] = l2;
+    vals[a] = di[0] * l1 + di[1] * l2;
+    vals[a + 1] = di[1] * l1 + di[2] * l2;
   }
 }
-// C: value of update triple q
+// C: value of update triple q: l_u (unscaled, in w) times (l D^-1)_v (in vals), direct addresses (sparse_plan.h tau / tav)
 DNLP_HD inline double sp_update(const SparsePlan& pl, const double* vals, const double* w, i64 q) {
-  const i64 k = pl.tblk[q], iu = pl.tiu[q], iv = pl.tiv[q];
-  if (pl.bnode[2 * k + 1] < 0) return vals[pl.loff[k] + iu] * w[pl.loff[k] + iv];
-  const i64 au = pl.loff[k] + 2 * iu, av = pl.loff[k] + 2 * iv;
-  return vals[au] * w[av] + vals[au + 1] * w[av + 1];
+  const i32 au = pl.tau[q], av = pl.tav[q];
+  if (av >= 0) return w[au] * vals[av];
+  const i32 bv = ~av;
+  return w[au] * vals[bv] + w[au + 1] * vals[bv + 1];
 }
-// forward substitution: contribution of struct row r
-DNLP_HD inline double sp_fwd(const SparsePlan& pl, const double* vals, const double* x, i64 r) {
-  const i64 k = pl.sblk[r], i = r - pl.soff[k];
-  const i32 u0 = pl.bnode[2 * k], u1 = pl.bnode[2 * k + 1];
-  if (u1 < 0) return vals[pl.loff[k] + i] * x[u0];
-  return vals[pl.loff[k] + 2 * i] * x[u0] + vals[pl.loff[k] + 2 * i + 1] * x[u1];
+// forward substitution: contribution of gathered row q (sparse_plan.h fa / fu0 / fu1)
+DNLP_HD inline double sp_fwd(const SparsePlan& pl, const double* vals, const double* x, i64 q) {
+  const i32 a = pl.fa[q];
+  if (a >= 0) return vals[a] * x[pl.fu0[q]];
+  const i32 b = ~a;
+  return vals[b] * x[pl.fu0[q]] + vals[b + 1] * x[pl.fu1[q]];
 }
 // D^-1 on block k
 DNLP_HD inline void sp_dsolve(const SparsePlan& pl, const double* vals, double* x, i64 k) {
@@ -125,19 +129,28 @@ DNLP_HD inline bool sparse_ldl_factor(const SparsePlan& pl, double* vals, double
   }
   for (i64 lev = 0; lev < pl.nlev_run; ++lev) {
     const i64 b0 = pl.lev_off[lev], b1 = pl.lev_off[lev + 1];
-    // A: pivot blocks
-    for (i64 k = b0 + me; k < b1; k += L) sp_pivot(pl, vals, dinv, k, nneg, nzero, bad);
-    par.sync();
-    // B: w = L D^-1 for every struct row of the level
     const i64 r0 = pl.soff[b0], r1 = pl.soff[b1];
-    for (i64 r = r0 + me; r < r1; r += L) sp_scale(pl, vals, w, dinv, r);
-    par.sync();
+    if (r1 - r0 <= 8 * (b1 - b0)) {
+      // short structs: a lane inverts its block's pivot and scales the block's rows in one phase
+      for (i64 k = b0 + me; k < b1; k += L) {
+        sp_pivot(pl, vals, dinv, k, nneg, nzero, bad);
+        for (i64 r = pl.soff[k]; r < pl.soff[k + 1]; ++r) sp_scale(pl, vals, w, dinv, r);
+      }
+      par.sync();
+    } else {
+      // A: pivot blocks
+      for (i64 k = b0 + me; k < b1; k += L) sp_pivot(pl, vals, dinv, k, nneg, nzero, bad);
+      par.sync();
+      // B: L = l D^-1 for every struct row of the level
+      for (i64 r = r0 + me; r < r1; r += L) sp_scale(pl, vals, w, dinv, r);
+      par.sync();
+    }
     // C': the level's panel blocks update the dense tail with one product (see SparsePlan)
     if (pl.tail_n > 0 && pl.pg_cols[lev] > 0) {
       const i64 cols = pl.pg_cols[lev], ldt = pl.tail_ld, r = pl.tail_n;
       for (i64 a = me; a < ldt * cols; a += L) { Pl[a] = 0.0; Pw[a] = 0.0; }
       par.sync();
-      for (i64 q = pl.pg_off[lev] + me; q < pl.pg_off[lev + 1]; q += L) { Pl[pl.pg_dst[q]] = vals[pl.pg_src[q]]; Pw[pl.pg_dst[q]] = w[pl.pg_src[q]]; }
+      for (i64 q = pl.pg_off[lev] + me; q < pl.pg_off[lev + 1]; q += L) { Pl[pl.pg_dst[q]] = w[pl.pg_src[q]]; Pw[pl.pg_dst[q]] = vals[pl.pg_src[q]]; }
       par.sync();
       for (i64 e = me; e < r * r; e += L) {
         const i64 u = e % r, v = e / r;
@@ -169,10 +182,6 @@ DNLP_HD inline bool sparse_ldl_factor(const SparsePlan& pl, double* vals, double
       }
     }
     par.sync();
-    // D: keep L = l D^-1
-    const i64 v0 = pl.loff[b0], v1 = (b1 < pl.nblk) ? pl.loff[b1] : pl.nvals;
-    for (i64 a = v0 + me; a < v1; a += L) vals[a] = w[a];
-    par.sync();
   }
   nneg = par.sum(nneg);
   nzero = par.sum(nzero);
@@ -191,7 +200,6 @@ DNLP_HD inline void sparse_ldl_solve(const SparsePlan& pl, const double* vals, d
   // (a plan with a dense tail runs the levels before it in two calls: solve_phase 1, the tail's dense solve, then 2;
   //  the tail's nodes then gather only the rows of the blocks before the tail, in one last phase)
   if (pl.solve_phase != 2) {
-  const i64 rmax = pl.soff[pl.nblk_run];
   for (i64 lev = 1; lev <= pl.nlev_run; ++lev) {
     const bool last = lev == pl.nlev_run;
     if (last && pl.nlev_run == pl.nlev) break;
@@ -200,15 +208,17 @@ DNLP_HD inline void sparse_ldl_solve(const SparsePlan& pl, const double* vals, d
     const i64 nh = h1 - h0, nrw = pl.foff[h1] - pl.foff[h0];
     if (nh * 8 <= L && nrw >= 16 * nh) {
       for (i64 h = h0; h < h1; ++h) {
+        const i64 q1 = pl.fend ? pl.fend[h] : pl.foff[h + 1];
         double acc = 0.0;
-        for (i64 q = pl.foff[h] + me; q < pl.foff[h + 1]; q += L) { const i64 r = pl.frow[q]; if (r < rmax) acc += sp_fwd(pl, vals, x, r); }
+        for (i64 q = pl.foff[h] + me; q < q1; q += L) acc += sp_fwd(pl, vals, x, q);
         acc = par.sum(acc);
         if (me == 0) x[pl.fnode[h]] -= acc;
       }
     } else {
       for (i64 h = h0 + me; h < h1; h += L) {
+        const i64 q1 = pl.fend ? pl.fend[h] : pl.foff[h + 1];
         double acc = 0.0;
-        for (i64 q = pl.foff[h]; q < pl.foff[h + 1]; ++q) { const i64 r = pl.frow[q]; if (r >= rmax) break; acc += sp_fwd(pl, vals, x, r); }
+        for (i64 q = pl.foff[h]; q < q1; ++q) acc += sp_fwd(pl, vals, x, q);
         x[pl.fnode[h]] -= acc;
       }
     }

@@ -71,22 +71,23 @@ struct SparsePlan {
   const i64 *h_pg_off = nullptr, *h_pg_cols = nullptr;   // host copies (level loops of the host-driven space)
   i64* pg_cols = nullptr;             // nlev_run: panel columns per level (exec space; the in-kernel routine reads it)
   i32* bnode = nullptr;   // 2 per block: pivot nodes (second = -1 for a 1x1 block)
-  i64* soff = nullptr;    // nblk + 1: offsets into sidx
+  i32* soff = nullptr;    // nblk + 1: offsets into sidx (every offset array of the plan is 32-bit: the in-kernel solver keeps them in LDS)
   i32* sidx = nullptr;    // struct of every block: node ids (0..N-1 variables, N.. constraint rows)
-  i64* doff = nullptr;    // per block: D values (1x1: d ; 2x2: d11, d21, d22)
-  i64* loff = nullptr;    // per block: L values, s_k rows x b_k, row-major
-  i64* toff = nullptr;    // nblk + 1: offsets into the triples
-  i32* tdst = nullptr;    // target value index
-  i32* tiu = nullptr;     // row indices (within the block's struct) of the two factors
-  i32* tiv = nullptr;
+  i32* doff = nullptr;    // per block: D values (1x1: d ; 2x2: d11, d21, d22)
+  i32* loff = nullptr;    // per block: L values, s_k rows x b_k, row-major
+  i32* toff = nullptr;    // nblk + 1: offsets into the triples
+  // update program in DIRECT ADDRESSES: triple q multiplies the unscaled l at value index tau[q] with L = l D^-1 at
+  // tav[q] (a 2x2 pivot block: the pairs tau, tau + 1 and ~tav, ~tav + 1 — the complement marks the block size), into
+  // the destination of q's group (gdst).  No block / row lookups in the numeric phase.
+  i32* tau = nullptr;
+  i32* tav = nullptr;
   i32* hpos = nullptr;    // value index of every Hessian COO entry (lower triangle)
   i32* jpos = nullptr;    // value index of every Jacobian COO entry
   i32* dpos = nullptr;    // value index of the diagonal of every node
   // level schedule: blocks are stored level-major (elimination-tree levels); blocks of one level
   // are independent and are processed together
-  i64* lev_off = nullptr; // nlev + 1 offsets into the block order
+  i32* lev_off = nullptr; // nlev + 1 offsets into the block order
   i32* sblk = nullptr;    // block of every struct row (soff-indexed)
-  i32* tblk = nullptr;    // block of every update triple
   // ORDER-FIXED ACCUMULATION (no floating-point atomics anywhere in the numeric phase).  The update triples of a level
   // are stored sorted by destination: group g = one destination value gdst[g] and the triples goff[g] .. goff[g+1];
   // lev_g[lev] .. lev_g[lev+1] are the groups of level lev.  One lane (or a fixed reduction tree over lanes) sums a
@@ -95,13 +96,18 @@ struct SparsePlan {
   // foff[h+1]) that point at it, ascending (= by source block), so a node is final when its level is reached.
   i64 ngrp = 0, nfwd = 0;
   i32* gdst = nullptr;
-  i64* goff = nullptr;
-  i64* lev_g = nullptr;
+  i32* goff = nullptr;
+  i32* lev_g = nullptr;
   i32* fnode = nullptr;
-  i64* foff = nullptr;
-  i32* frow = nullptr;
-  i64* lev_f = nullptr;
-  const i64 *h_lev_g = nullptr, *h_lev_f = nullptr;
+  i32* foff = nullptr;
+  i32* lev_f = nullptr;
+  // a gathered row in direct addresses: value index fa (complemented for a row of a 2x2 block: two values), source
+  // nodes fu0 / fu1 (fu1 unused for 1x1)
+  i32* fa = nullptr;
+  i32* fu0 = nullptr;
+  i32* fu1 = nullptr;
+  i32* fend = nullptr;    // dense-tail plans only: end of target h's rows that come from blocks before the tail (else null: foff[h + 1])
+  const i32 *h_lev_g = nullptr, *h_lev_f = nullptr, *h_fwd_rows = nullptr;   // (h_fwd_rows = host copy of foff)
   // host copies of the level boundaries (blocks / struct rows / triples / values), for the space
   // that launches one kernel per level phase; unused inside kernels
   const i64 *h_lev_blk = nullptr, *h_lev_row = nullptr, *h_lev_trip = nullptr, *h_lev_val = nullptr;
@@ -109,12 +115,13 @@ struct SparsePlan {
 
 struct SparsePlanHost {
   i64 n = 0, N = 0, m = 0, nvals = 0, maxs = 0;
-  std::vector<i32> bnode, sidx, tdst, tiu, tiv, hpos, jpos, dpos;
-  std::vector<i64> soff, doff, loff, toff, lev_off;
-  std::vector<i64> lev_row, lev_trip, lev_val;     // per-level boundaries in rows / triples / values
+  std::vector<i32> bnode, sidx, tdst, tiu, tiv, tau, tav, hpos, jpos, dpos;   // (tdst / tiu / tiv: scratch of layout(), empty afterwards)
+  std::vector<i32> soff, doff, loff, toff, lev_off;
+  std::vector<i64> lev_blk, lev_row, lev_trip, lev_val;     // per-level boundaries in blocks / rows / triples / values
   std::vector<i32> sblk, tblk;
-  std::vector<i32> gdst, fnode, frow;                // order-fixed accumulation (see SparsePlan)
-  std::vector<i64> goff, lev_g, foff, lev_f;
+  std::vector<i32> gdst, fnode, fa, fu0, fu1, fend;  // order-fixed accumulation (see SparsePlan)
+  i64 ntrip = 0;
+  std::vector<i32> goff, lev_g, foff, lev_f;
   // dense tail (see SparsePlan): chosen by layout(), handed to the exec space only by upload(ex, true)
   i64 tail_lev = -1, tail_n = 0, tail_ld = 0, pg_maxcols = 0;
   std::vector<i32> tnode, tg_src, tg_dst, pg_src, pg_dst;
@@ -380,7 +387,7 @@ struct SparsePlanHost {
       std::stable_sort(order.begin(), order.end(), [&](i32 a, i32 b) { return level[static_cast<size_t>(a)] < level[static_cast<size_t>(b)]; });
       lev_off.assign(1, 0);
       for (i64 k = 1; k <= nb; ++k)
-        if (k == nb || level[static_cast<size_t>(order[static_cast<size_t>(k)])] != level[static_cast<size_t>(order[static_cast<size_t>(k - 1)])]) lev_off.push_back(k);
+        if (k == nb || level[static_cast<size_t>(order[static_cast<size_t>(k)])] != level[static_cast<size_t>(order[static_cast<size_t>(k - 1)])]) lev_off.push_back(static_cast<i32>(k));
       if (nb == 0) lev_off.assign(1, 0);
     }
     pred_levels = static_cast<i64>(lev_off.size()) - 1;
@@ -535,7 +542,9 @@ struct SparsePlanHost {
     toff.assign(static_cast<size_t>(nb + 1), 0);
     for (i64 k = 0; k < nb; ++k) {
       const i64 sz = soff[static_cast<size_t>(k + 1)] - soff[static_cast<size_t>(k)], h = tcut[static_cast<size_t>(k)];
-      toff[static_cast<size_t>(k + 1)] = toff[static_cast<size_t>(k)] + h * sz - h * (h - 1) / 2;      // pairs (iu >= iv) with iv < h
+      const i64 nxt = static_cast<i64>(toff[static_cast<size_t>(k)]) + h * sz - h * (h - 1) / 2;      // pairs (iu >= iv) with iv < h
+      if (nxt >= (static_cast<i64>(1) << 31)) throw std::runtime_error("sparse KKT plan: update program too long for 32-bit offsets");
+      toff[static_cast<size_t>(k + 1)] = static_cast<i32>(nxt);
     }
     {
       const size_t total = static_cast<size_t>(toff[static_cast<size_t>(nb)]);
@@ -584,8 +593,9 @@ struct SparsePlanHost {
       if (failed.load()) throw std::runtime_error("sparse KKT plan: fill entry outside the pattern");
     }
     tick("update program");
-    lev_row.clear(); lev_trip.clear(); lev_val.clear();
+    lev_blk.clear(); lev_row.clear(); lev_trip.clear(); lev_val.clear();
     for (i64 b : lev_off) {
+      lev_blk.push_back(b);
       lev_row.push_back(soff[static_cast<size_t>(b)]);
       lev_trip.push_back(toff[static_cast<size_t>(b)]);
       lev_val.push_back(b < nb ? loff[static_cast<size_t>(b)] : nvals);
@@ -608,7 +618,7 @@ struct SparsePlanHost {
           cnt[static_cast<size_t>(d)] = at;              // from here on: next free position of this destination
           at += c;
           gdst.push_back(d);
-          goff.push_back(at);
+          goff.push_back(static_cast<i32>(at));
         }
         t_dst.assign(tdst.begin() + static_cast<std::ptrdiff_t>(t0), tdst.begin() + static_cast<std::ptrdiff_t>(t1));
         t_iu.assign(tiu.begin() + static_cast<std::ptrdiff_t>(t0), tiu.begin() + static_cast<std::ptrdiff_t>(t1));
@@ -619,10 +629,22 @@ struct SparsePlanHost {
           tdst[to] = t_dst[q]; tiu[to] = t_iu[q]; tiv[to] = t_iv[q]; tblk[to] = t_blk[q];
         }
         for (i32 d : touched) cnt[static_cast<size_t>(d)] = 0;
-        lev_g.push_back(static_cast<i64>(gdst.size()));
+        lev_g.push_back(static_cast<i32>(gdst.size()));
       }
       // (toff keeps the level boundaries toff[lev_off[l]]; inside a level the triples are no longer grouped by block)
-      fnode.clear(); foff.assign(1, 0); frow.clear(); lev_f.assign(1, 0);
+      ntrip = static_cast<i64>(tdst.size());
+      tau.resize(tdst.size()); tav.resize(tdst.size());
+      for (size_t q = 0; q < tdst.size(); ++q) {
+        const i64 k = tblk[q];
+        const bool two = bnode[static_cast<size_t>(2 * k + 1)] >= 0;
+        const i64 au = loff[static_cast<size_t>(k)] + (two ? 2 : 1) * static_cast<i64>(tiu[q]);
+        const i64 av = loff[static_cast<size_t>(k)] + (two ? 2 : 1) * static_cast<i64>(tiv[q]);
+        tau[q] = static_cast<i32>(au);
+        tav[q] = two ? ~static_cast<i32>(av) : static_cast<i32>(av);
+      }
+      std::vector<i32>().swap(tdst); std::vector<i32>().swap(tiu); std::vector<i32>().swap(tiv); std::vector<i32>().swap(tblk);
+      std::vector<i32> frow;
+      fnode.clear(); foff.assign(1, 0); lev_f.assign(1, 0);
       std::vector<i64> fcnt(static_cast<size_t>(nn) + 1, 0);
       for (i32 u : sidx) ++fcnt[static_cast<size_t>(u) + 1];
       for (i64 u = 0; u < nn; ++u) fcnt[static_cast<size_t>(u) + 1] += fcnt[static_cast<size_t>(u)];
@@ -640,9 +662,30 @@ struct SparsePlanHost {
             if (b == a) continue;
             fnode.push_back(u);
             frow.insert(frow.end(), rows_by_node.begin() + static_cast<std::ptrdiff_t>(a), rows_by_node.begin() + static_cast<std::ptrdiff_t>(b));
-            foff.push_back(static_cast<i64>(frow.size()));
+            foff.push_back(static_cast<i32>(frow.size()));
           }
-        lev_f.push_back(static_cast<i64>(fnode.size()));
+        lev_f.push_back(static_cast<i32>(fnode.size()));
+      }
+      fa.resize(frow.size()); fu0.resize(frow.size()); fu1.resize(frow.size());
+      for (size_t q = 0; q < frow.size(); ++q) {
+        const i64 r = frow[q], k = sblk[static_cast<size_t>(r)], i = r - soff[static_cast<size_t>(k)];
+        const i32 u0 = bnode[static_cast<size_t>(2 * k)], u1 = bnode[static_cast<size_t>(2 * k + 1)];
+        const i64 a = loff[static_cast<size_t>(k)] + (u1 >= 0 ? 2 : 1) * i;
+        fa[q] = u1 >= 0 ? ~static_cast<i32>(a) : static_cast<i32>(a);
+        fu0[q] = u0;
+        fu1[q] = u1 >= 0 ? u1 : u0;
+      }
+      fend.clear();
+      if (tail_n > 0) {
+        // rows of a target that come from blocks before the tail (its rows are ascending): the tail's own rows belong to
+        // the dense solve
+        const i64 rmax = soff[static_cast<size_t>(lev_off[static_cast<size_t>(tail_lev)])];
+        fend.resize(fnode.size());
+        for (size_t h = 0; h < fnode.size(); ++h) {
+          i64 e = foff[h];
+          while (e < foff[h + 1] && frow[static_cast<size_t>(e)] < rmax) ++e;
+          fend[h] = static_cast<i32>(e);
+        }
       }
     }
     tick("order-fixed groups");
@@ -694,18 +737,20 @@ struct SparsePlanHost {
 
   template <class E> SparsePlan upload(E* ex, bool with_tail = false) const {
     SparsePlan p;
-    p.n = n; p.N = N; p.m = m; p.nblk = nblk(); p.nvals = nvals; p.ntrip = static_cast<i64>(tdst.size()); p.maxs = maxs;
+    p.n = n; p.N = N; p.m = m; p.nblk = nblk(); p.nvals = nvals; p.ntrip = ntrip; p.maxs = maxs;
     auto up = [&](auto*& dst, const auto& src) {
       using T = std::remove_pointer_t<std::remove_reference_t<decltype(dst)>>;
       dst = ex->template alloc<T>(src.size());
       if (!src.empty()) ex->h2d(dst, src.data(), src.size() * sizeof(T));
     };
     up(p.bnode, bnode); up(p.soff, soff); up(p.sidx, sidx); up(p.doff, doff); up(p.loff, loff); up(p.toff, toff);
-    up(p.tdst, tdst); up(p.tiu, tiu); up(p.tiv, tiv); up(p.hpos, hpos); up(p.jpos, jpos); up(p.dpos, dpos);
-    up(p.lev_off, lev_off); up(p.sblk, sblk); up(p.tblk, tblk);
-    up(p.gdst, gdst); up(p.goff, goff); up(p.lev_g, lev_g); up(p.fnode, fnode); up(p.foff, foff); up(p.frow, frow); up(p.lev_f, lev_f);
+    up(p.tau, tau); up(p.tav, tav); up(p.hpos, hpos); up(p.jpos, jpos); up(p.dpos, dpos);
+    up(p.lev_off, lev_off); up(p.sblk, sblk);
+    up(p.gdst, gdst); up(p.goff, goff); up(p.lev_g, lev_g); up(p.fnode, fnode); up(p.foff, foff); up(p.lev_f, lev_f);
+    up(p.fa, fa); up(p.fu0, fu0); up(p.fu1, fu1);
+    if (with_tail && tail_n > 0) up(p.fend, fend);
     p.ngrp = static_cast<i64>(gdst.size()); p.nfwd = static_cast<i64>(fnode.size());
-    p.h_lev_g = lev_g.data(); p.h_lev_f = lev_f.data();
+    p.h_lev_g = lev_g.data(); p.h_lev_f = lev_f.data(); p.h_fwd_rows = foff.data();
     p.nlev = static_cast<i64>(lev_off.size()) - 1;
     p.nlev_run = p.nlev; p.nblk_run = p.nblk;
     if (panels_dropped && !(with_tail && tail_n > 0))
@@ -718,7 +763,7 @@ struct SparsePlanHost {
       up(p.pg_off, pg_off); up(p.pg_src, pg_src); up(p.pg_dst, pg_dst); up(p.pg_cols, pg_cols);
       p.h_pg_off = pg_off.data(); p.h_pg_cols = pg_cols.data();
     }
-    p.h_lev_blk = lev_off.data(); p.h_lev_row = lev_row.data(); p.h_lev_trip = lev_trip.data(); p.h_lev_val = lev_val.data();
+    p.h_lev_blk = lev_blk.data(); p.h_lev_row = lev_row.data(); p.h_lev_trip = lev_trip.data(); p.h_lev_val = lev_val.data();
     return p;
   }
 };
@@ -765,7 +810,7 @@ inline void build_sparse_plan(const Tape<E>& t, SparsePlanHost& plan, bool bound
   plan.layout(t.h_hess_rows, t.h_hess_cols, t.h_jac_rows, t.h_jac_cols, fixed);
   if (std::getenv("DNLP_PLAN_LEVELS")) {
     std::fprintf(stderr, "[plan] dense tail: %lld nodes from level %lld on, panel columns per level up to %lld, %zu triples\n", (long long)plan.tail_n,
-                 (long long)plan.tail_lev, (long long)plan.pg_maxcols, plan.tdst.size());
+                 (long long)plan.tail_lev, (long long)plan.pg_maxcols, static_cast<size_t>(plan.ntrip));
     const i64 nl = static_cast<i64>(plan.lev_off.size()) - 1;
     for (i64 l = 0; l < nl; ++l)
       std::fprintf(stderr, "[plan] level %lld: blocks %lld struct rows %lld triples %lld\n", (long long)l,

@@ -140,9 +140,14 @@ struct SparseConst { Csr P, PT; i64 nh = 0; double* hv = nullptr; };
 // ptr == nullptr: no index (pattern above Tape::coo_index_max entries); the exec space falls back to its scatter form.
 struct CooIdx {
   i64 nout = 0, total = 0;
-  i64* ptr = nullptr;
+  i32* ptr = nullptr;
   i32* ent = nullptr;
   i32* src = nullptr;
+  // outputs with more than kHeavy entries (a dense column under many rows): the in-kernel solver sums those with all
+  // its lanes and a fixed reduction tree instead of one lane walking the whole segment
+  static constexpr i64 kHeavy = 12;
+  i64 nheavy = 0;
+  i32* heavy = nullptr;
 };
 
 // Everything the evaluators (model.h) and the interior-point loop (ipm_core.h) read, as plain
@@ -171,6 +176,11 @@ struct TapeView {
   i32 *jac_rows = nullptr, *jac_cols = nullptr, *hess_rows = nullptr, *hess_cols = nullptr;
   i64* jac_rowptr = nullptr;   // m+1: the Jacobian COO is row-major sorted
   CooIdx jac_by_row, jac_by_col, hess_sym;   // order-fixed products J v, J^T v, sym(H) v (model.h)
+  // A Jacobian too large to index whose rows all carry the SAME column list (a dense constraint block: BASELINE C3's
+  // A, 1e3 x 1e4) is a rectangular matrix stored row-major: jac_rect_cols = its row length (0: not rectangular), the
+  // columns are jac_cols[0 .. jac_rect_cols).  The host-driven device space multiplies with it in a fixed order
+  // without any index (exec_hip.h rect_mult / rect_tmult).
+  i64 jac_rect_cols = 0;
   // control space: reduction-class segments, constants, dense Hessian blocks
   const SegHost* segs = nullptr;
   const i64* red_segs = nullptr;
@@ -222,7 +232,7 @@ struct Tape : TapeView {
     const i64 nnz = static_cast<i64>(hr.size());
     if (const char* e = std::getenv("DNLP_COO_DET_MAX")) coo_index_max = std::atoll(e);
     if (nnz > coo_index_max || nnz > (i64{1} << 30)) return ix;      // (entry ids are 32-bit, two per entry in mode 2)
-    std::vector<i64> ptr(static_cast<size_t>(nout) + 1, 0);
+    std::vector<i32> ptr(static_cast<size_t>(nout) + 1, 0);
     auto each = [&](auto&& f) {                  // (entry, output, source) in storage order
       for (i64 p = 0; p < nnz; ++p) {
         const i32 rp = hr[static_cast<size_t>(p)], cp = hc[static_cast<size_t>(p)];
@@ -234,13 +244,18 @@ struct Tape : TapeView {
     for (i64 g = 0; g < nout; ++g) ptr[static_cast<size_t>(g) + 1] += ptr[static_cast<size_t>(g)];
     const i64 total = ptr[static_cast<size_t>(nout)];
     std::vector<i32> ent(static_cast<size_t>(total)), src(static_cast<size_t>(total));
-    std::vector<i64> fill(ptr.begin(), ptr.end() - 1);
+    std::vector<i32> fill(ptr.begin(), ptr.end() - 1);
     each([&](i64 p, i32 o, i32 sidx) {
       const i64 at = fill[static_cast<size_t>(o)]++;
       ent[static_cast<size_t>(at)] = static_cast<i32>(p);
       src[static_cast<size_t>(at)] = sidx;
     });
     ix.nout = nout; ix.total = total;
+    std::vector<i32> heavy;
+    for (i64 g = 0; g < nout; ++g)
+      if (ptr[static_cast<size_t>(g) + 1] - ptr[static_cast<size_t>(g)] > CooIdx::kHeavy) heavy.push_back(static_cast<i32>(g));
+    ix.nheavy = static_cast<i64>(heavy.size());
+    ix.heavy = up(heavy.data(), heavy.size());
     ix.ptr = up(ptr.data(), ptr.size());
     ix.ent = up(ent.data(), ent.size());
     ix.src = up(src.data(), src.size());
@@ -341,6 +356,17 @@ struct Tape : TapeView {
     jac_by_row = build_coo_index(h_jac_rows, h_jac_cols, m, 0);
     jac_by_col = build_coo_index(h_jac_rows, h_jac_cols, N, 1);
     hess_sym = build_coo_index(h_hess_rows, h_hess_cols, N, 2);
+    jac_rect_cols = 0;
+    if (!jac_by_col.ptr && m > 0 && nnzJ > 0 && nnzJ % m == 0) {
+      const i64 L = nnzJ / m;
+      bool rect = true;
+      for (i64 i = 0; i < m && rect; ++i) {
+        const i32* row = h_jac_cols.data() + i * L;
+        rect = h_jac_rows[static_cast<size_t>(i * L)] == i && h_jac_rows[static_cast<size_t>(i * L + L - 1)] == i &&
+               (i == 0 || std::memcmp(row, h_jac_cols.data(), sizeof(i32) * static_cast<size_t>(L)) == 0);
+      }
+      if (rect) jac_rect_cols = L;
+    }
     dense_n.assign(tb.i64s("dense_n"), tb.i64s("dense_n") + ndense);
     h_dense_ptr.assign(static_cast<size_t>(ndense), nullptr);
     h_dense_ld.assign(static_cast<size_t>(ndense), 0);

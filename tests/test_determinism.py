@@ -47,20 +47,33 @@ def test_paper_example_is_bitwise_repeatable(gpu_required, name):
     _assert_same(name, _runs(ALL[name]))
 
 
-def test_c3_dense_equality_qp_is_bitwise_repeatable(gpu_required):
+def _c3(cp, n=3000, m=300):
+    rng = np.random.default_rng(0)
+    Gm = rng.standard_normal((n, n))
+    Q = Gm.T @ Gm / n + np.eye(n)
+    c = rng.standard_normal(n)
+    A = rng.standard_normal((m, n))
+    b = A @ rng.standard_normal(n)
+    x = cp.Variable(n)
+    return cp.Problem(cp.Minimize(0.5 * cp.quad_form(x, Q) + c @ x), [A @ x == b])
+
+
+@pytest.mark.parametrize("rect", [False, True])
+def test_c3_dense_equality_qp_is_bitwise_repeatable(gpu_required, monkeypatch, rect):
     """BASELINE C3 at a size the suite affords twice over (n = 3000, m = 300: the blocked MFMA LDL^T, the dense
-    Jacobian's products and the triangular solves on inverted blocks are the kernels of the full size)."""
-    def build(cp):
-        n, m = 3000, 300
-        rng = np.random.default_rng(0)
-        Gm = rng.standard_normal((n, n))
-        Q = Gm.T @ Gm / n + np.eye(n)
-        c = rng.standard_normal(n)
-        A = rng.standard_normal((m, n))
-        b = A @ rng.standard_normal(n)
-        x = cp.Variable(n)
-        return cp.Problem(cp.Minimize(0.5 * cp.quad_form(x, Q) + c @ x), [A @ x == b])
-    _assert_same("c3", _runs(build))
+    Jacobian's products and the triangular solves on inverted blocks are the kernels of the full size).  At the
+    full size the Jacobian (1e7 entries) is above the tape's index limit and takes the rectangular row-major
+    products (exec_hip.h rect_mult / rect_tmult): `rect` forces that path here through the same limit."""
+    if rect:
+        monkeypatch.setenv("DNLP_COO_DET_MAX", "1000")
+    runs = _runs(_c3)
+    _assert_same("c3", runs)
+    if rect:
+        monkeypatch.delenv("DNLP_COO_DET_MAX")
+        ref = _runs(_c3, fresh=1, reps=1)[0]
+        assert runs[0][0] == ref[0] and runs[0][1] == ref[1]
+        np.testing.assert_allclose(runs[0][3], ref[3], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(runs[0][4], ref[4], rtol=1e-8, atol=1e-10)
 
 
 @pytest.mark.parametrize("which", ["localization", "circle_packing10", "power_flow", "path_planning"])
@@ -71,7 +84,8 @@ def test_c5_member_launch_is_bitwise_repeatable(gpu_required, which):
     B = 1024
     res = []
     for fresh in range(2):
-        prob, params, sample, _ = getattr(bp, "template_" + which)()
+        prob, params, sample, _ = (bp.template_circle_packing(10) if which == "circle_packing10"
+                                   else getattr(bp, "template_" + which)())
         pb = ParametricBatch(prob, params)
         thetas = np.stack([sample(i) for i in range(B)])
         for _ in range(2 - fresh):

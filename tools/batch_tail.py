@@ -14,7 +14,7 @@ from dnlp_amd.batch import ParametricBatch, arrays_with_data  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 nlogs = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 which = sys.argv[3] if len(sys.argv) > 3 else "localization"          # localization | circle_packing10 | power_flow | path_planning
-prob, params, sample, var = getattr(bp, "template_" + which)()
+prob, params, sample, var = bp.template_circle_packing(10) if which == "circle_packing10" else getattr(bp, "template_" + which)()
 pb = ParametricBatch(prob, params)
 thetas = np.stack([sample(i) for i in range(B)])
 mat = pb.data(thetas)
