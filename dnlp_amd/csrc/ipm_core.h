@@ -1307,7 +1307,9 @@ class Ipm {
   }
 
   // direction for barrier parameter muv with primal residual `pres` (rp or the SOC one)
-  DNLP_HD bool compute_direction(double muv, const double* pres, double dw, bool centering = false) {
+  // `into`: the seven arrays the direction is written to (null: dx, ds, dy, dzL, dzU, dvL, dvU) — the mu oracle lets its
+  // two solves write straight into aff[] / cen[] instead of copying seven arrays after each
+  DNLP_HD bool compute_direction(double muv, const double* pres, double dw, bool centering = false, double* const* into = nullptr) {
     DNLP_IPM_LDS();
     double* r = rhs;
     const double *rxx = rx, *q = rs, *sS = Ss, *eq = eqmask;
@@ -1316,7 +1318,7 @@ class Ipm {
     ex_->map(m, [=] DNLP_HD(i64 i) { r[NN + i] = -pres[i] - (eq[i] == 0.0 ? q[i] / (sS[i] + dw) : 0.0); });
     if (!solve_refined(dw)) return false;
     const double* so = sol;
-    double *ddx = dx, *dds = ds, *ddy = dy;
+    double *ddx = into ? into[0] : dx, *dds = into ? into[1] : ds, *ddy = into ? into[2] : dy;
     ex_->map(N, [=] DNLP_HD(i64 j) { ddx[j] = so[j]; });
     ex_->map(m, [=] DNLP_HD(i64 i) {
       ddy[i] = so[NN + i];
@@ -1324,7 +1326,7 @@ class Ipm {
     });
     // bound multiplier steps (WB eq. (12))
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *a = zL, *b = zU, *c = vL, *d = vU;
-    double *da = dzL, *db = dzU, *dc = dvL, *dd2 = dvU;
+    double *da = into ? into[3] : dzL, *db = into ? into[4] : dzU, *dc = into ? into[5] : dvL, *dd2 = into ? into[6] : dvU;
     const double keep = centering ? 0.0 : 1.0;   // the centering direction has no "- z" term
     ex_->map(N, [=] DNLP_HD(i64 j) {
       da[j] = (l[j] > -kInf) ? (muv - a[j] * ddx[j]) / (xx[j] - l[j]) - keep * a[j] : 0.0;
@@ -1808,12 +1810,11 @@ class Ipm {
       else { const i64 i = k - NN0; v.sm[0] = rss[i] * rss[i]; v.sm[1] = rpp[i] * rpp[i]; }
       return v; });
     const double nd2 = R2.sm[0], np2 = m ? R2.sm[1] : 0.0;
-    if (!compute_direction(0.0, rp, dw)) return false;
+    if (!compute_direction(0.0, rp, dw, false, aff)) return false;
     // a poorly solved affine system must not hide behind a well solved centring system (the step is
     // aff + mu cen, mu tiny: its accuracy is the affine solve's): the "pretend singular" test that follows
     // the oracle sees the worse of the two residual ratios
     const double ratio_aff = last_ratio_;
-    for (int k = 0; k < 7; ++k) ex_->d2d(aff[k], cur[k], sizeof(double) * static_cast<size_t>(sz[k]));
     {
       // centering right-hand side: derivative of the barrier terms w.r.t. mu
       double *r = rx, *q = rs;
@@ -1840,9 +1841,8 @@ class Ipm {
         q[i] = c;
       });
     }
-    if (!compute_direction(1.0, zeroM, dw, true)) return false;
+    if (!compute_direction(1.0, zeroM, dw, true, cen)) return false;
     if (ratio_aff > last_ratio_) last_ratio_ = ratio_aff;
-    for (int k = 0; k < 7; ++k) ex_->d2d(cen[k], cur[k], sizeof(double) * static_cast<size_t>(sz[k]));
     const i64 n_ineq = m - n_eq_;                      // (counted once in begin())
     const double n_dual = static_cast<double>(N + n_ineq), n_pri = static_cast<double>(m > 0 ? m : 1);
     const double *ax = aff[0], *as = aff[1], *aa = aff[3], *ab = aff[4], *ac = aff[5], *ad = aff[6];
