@@ -114,8 +114,12 @@ def cpu_baseline(seed, device, sweep=CPU_SWEEP):
     reported, never an extrapolated figure as if measured."""
     import ctypes.util
     threads = os.cpu_count() or 1
+    # the host build's own OpenMP loops (vector maps, the W copy of the blocked factorisation): a moderate team — 256
+    # OpenMP threads spinning beside the BLAS's pool cost the blocked column a factor of four on the GPU box's host
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(32, threads)))
+    os.environ.setdefault("DNLP_HOST_LDLT_TIMING", "1")
     from dnlp_amd.tape import serialize
-    from oracle.oracle_capi import (OracleProblem, dgemm_gflops, lapack_best_threads, set_blas_threads,
+    from oracle.oracle_capi import (OracleProblem, blocked_ldlt_phases, dgemm_gflops, lapack_best_threads, set_blas_threads,
                                     use_blocked_ldlt, use_lapack)
     import dnlp_amd as cp
     from dnlp_amd.device import symmetric_test_matrix
@@ -133,6 +137,7 @@ def cpu_baseline(seed, device, sweep=CPU_SWEEP):
         gemm_threads = max(rates, key=rates.get)
         gemm_rate = {"gflops_by_threads": rates, "n": 3000}
     have_blocked = bool(blas_threads) and use_blocked_ldlt(True)
+    blocked_probe = None
     kind = "LAPACK dsytrf/dsytrs (scipy OpenBLAS, %d threads)" % blas_threads if blas_threads else \
         "restated DSYTF2 (no LAPACK found)"
     table = []
@@ -158,14 +163,27 @@ def cpu_baseline(seed, device, sweep=CPU_SWEEP):
                     set_blas_threads(blas_threads)
                 orc.set_option("kkt_pivot_max_n", 10 ** 9)     # pivoted (Bunch-Kaufman) at every order, as IPOPT's solvers are
             else:
-                set_blas_threads(gemm_threads)
                 orc.set_option("kkt_pivot_max_n", 0)           # unpivoted blocked LDL^T at every order, as on the device
+                if blocked_probe is None and n_cpu == sweep[-1][0]:
+                    # the thread count that FACTORS fastest, measured at the largest order of the sweep (the DGEMM probe
+                    # alone misleads: its best count is not the best for the mix of DTRSM, small and large DGEMMs); the
+                    # smaller orders above ran with the DGEMM probe's count
+                    blocked_probe = {}
+                    for tcand in sorted({t for t in (16, 32, 64) if t <= threads} or {threads}):
+                        set_blas_threads(tcand)
+                        orc.ipm_begin(data["x0"])
+                        orc.ipm_step(1)
+                        blocked_probe[tcand] = float(orc.stats()[4]) / max(int(orc.stats()[1]), 1)
+                    gemm_threads = min(blocked_probe, key=blocked_probe.get)
+                set_blas_threads(gemm_threads)
             orc.ipm_begin(data["x0"])
             t0 = time.time()
             rc, k = orc.ipm_step(steps)
             dt = time.time() - t0
             st = orc.stats()
             nf = max(int(st[1]), 1)
+            if column == "blocked":
+                row["blocked_phase_seconds_last_factorization"] = blocked_ldlt_phases()
             row[column] = {"iterations": k, "factorizations": int(st[1]), "seconds": dt,
                            "iters_per_s": k / dt if dt > 0 else None, "s_per_factorization": float(st[4]) / nf,
                            "factorization_gflops": (n_cpu + 1) ** 3 / 3.0 / (float(st[4]) / nf) / 1e9 if st[4] > 0 else None}
@@ -183,6 +201,7 @@ def cpu_baseline(seed, device, sweep=CPU_SWEEP):
     return {"value": last[best_col]["iters_per_s"], "unit": "iters/s", "cores": cores, "kind": "port",
             "n": last["n"], "factorization": best_col, "sweep": table, "factorization_time_exponent": expo,
             "host_cores": threads, "dsytrf_n3000_seconds_by_threads": probe, "dgemm": gemm_rate,
+            "blocked_s_per_factorization_by_threads": blocked_probe, "blocked_threads": gemm_threads,
             "sample": "host build of the same interior-point algorithm on the same generator / front-end at n in %s with %s "
                       "timed iterations, dense KKT two ways: %s; and the unpivoted blocked LDL^T with its trailing update "
                       "through DGEMM on %s threads (the device's algorithm on the host's BLAS).  value = iters/s of the "

@@ -185,11 +185,13 @@ int dnlp_lbfgs_codegen_check(const void* blob, size_t len, int elems_per_lane, c
     // with the persistent single-launch kernel when a slice per compute unit (256 of them) fits its LDS, as the
     // execution space decides (exec_hip.h: lbfgs_generated_solve)
     long long per = 0;
+    int pmode = 0;
     if (nfree >= 1024 && info.hi - info.lo >= 1) {
       per = ((nfree + 255) / 256 + info.E - 1) / info.E * info.E;
-      if ((2 * 10 + 5) * (per + 64) * 8 + 12 * 1024 > 150 * 1024) per = 0;
+      pmode = (2 * 10 + 5) * (per + 64) * 8 + 12 * 1024 <= 150 * 1024 ? 0 : 5 * (per + 64) * 8 + 12 * 1024 <= 150 * 1024 ? 1 : 2;
+      if (const char* v = std::getenv("DNLP_LBFGS_PERSIST_MODE")) { const int w = std::atoi(v); if (w >= pmode && w <= 2) pmode = w; }
     }
-    const std::string src = lbfgs_codegen_source(progs, info, 10, per);
+    const std::string src = lbfgs_codegen_source(progs, info, 10, per, pmode);
     put(src_out, src_cap, src);
     std::string log;
     const std::vector<char> code = rtc_compile(src, log, false);

@@ -1542,6 +1542,7 @@ struct HipExec : HostControlled {
     if (lb_ctl) hipFree(lb_ctl);
     if (lb_halo) hipFree(lb_halo);
     if (lb_xsave) hipFree(lb_xsave);
+    if (lb_strip) hipFree(lb_strip);
     if (lb_host) hipHostFree(lb_host);
     if (lb_fpart) hipFree(lb_fpart);
     if (lb_upart) hipFree(lb_upart);
@@ -1936,6 +1937,9 @@ struct HipExec : HostControlled {
   int lb_persist_wgs = 0;
   bool lb_persist_failed_ = false;      // the persistent kernel could not be made co-resident once: slot kernels from then on
   int lb_persist_fallbacks = 0;
+  double* lb_strip = nullptr;           // per-workgroup slices of the persistent kernel when they exceed LDS (lbfgs_codegen.h mode 1 / 2)
+  size_t lb_strip_cap = 0;
+  int lb_key_mode = 0;
   double* lb_xsave = nullptr;           // start point of a persistent launch (restored when the launch is given up)
   i64 lb_xsave_cap = 0;
   const void* lb_key = nullptr;
@@ -1970,12 +1974,24 @@ struct HipExec : HostControlled {
     i64 per = 0;
     bool want_persist = true;
     if (const char* v = std::getenv("DNLP_LBFGS_PERSIST")) want_persist = std::atoi(v) != 0;
+    int pmode = 0;
     if (want_persist && ncu >= 2 && nfree >= 4 * static_cast<i64>(ncu)) {
       per = ((nfree + ncu - 1) / ncu + lbE - 1) / lbE * lbE;
-      const i64 lds_bytes = (2 * static_cast<i64>(M) + 5) * (per + 64) * 8 + 12 * 1024;     // (+ halo, Gram matrix, scratch)
-      if (lds_bytes > 150 * 1024) per = 0;
+      // where a workgroup's slice lives (lbfgs_codegen.h): everything in LDS, the history in its global strip, or all of it
+      const i64 all_lds = (2 * static_cast<i64>(M) + 5) * (per + 64) * 8 + 12 * 1024;     // (+ halo, Gram matrix, scratch)
+      const i64 work_lds = 5 * (per + 64) * 8 + 12 * 1024;
+      pmode = all_lds <= 150 * 1024 ? 0 : work_lds <= 150 * 1024 ? 1 : 2;
+      // Measured (profiles/r04_c2_n_sweep.jsonl, per trial point): n = 3e5 mode 1 46 us against 70 us of the four-kernel
+      // slots; n = 1e6 mode 2 203 us against 166 us — a workgroup per compute unit streams its strip with 256 lanes, the
+      // slot kernels with the whole chip's — so a slice takes the strip while it is short (<= 2400 variables: n <= 6e5 on
+      // 256 compute units) and the slot kernels beyond; DNLP_LBFGS_PERSIST_MODE = 1 / 2 forces a mode (tests).
+      bool forced = false;
+      if (const char* v = std::getenv("DNLP_LBFGS_PERSIST_MODE")) { const int w = std::atoi(v); if (w >= pmode && w <= 2) { pmode = w; forced = true; } }
+      if (!forced && (pmode == 2 || (pmode == 1 && per > 2400))) per = 0;
+      if (pmode == 2 && per > 65536) per = 0;
     }
-    if (lb_key != static_cast<const void*>(&progs) || lb_key_M != M || lb_key_E != lbE || lb_key_nf != (per ? nfree : -1)) {
+    if (lb_key != static_cast<const void*>(&progs) || lb_key_M != M || lb_key_E != lbE || lb_key_nf != (per ? nfree : -1) || lb_key_mode != pmode) {
+      lb_key_mode = pmode;
       lb_key = &progs;
       lb_key_M = M;
       lb_key_E = lbE;
@@ -1988,7 +2004,7 @@ struct HipExec : HostControlled {
       if (const char* v = std::getenv("DNLP_FUSED_E")) { const int e = std::atoi(v); if (e >= 1 && e <= 16) fused_E = e; }
       const FusedCodegenInfo info = fused_codegen_plan(progs, lbE);
       if (info.ok && per > 0 && (info.hi - info.lo) < 1) { per = 0; lb_per = 0; }     // (no neighbour coupling: nothing to exchange; the slot kernels do)
-      if (info.ok && lb_rtc.load(lbfgs_codegen_source(progs, info, M, per), "dnlp_lb_eval")) {
+      if (info.ok && lb_rtc.load(lbfgs_codegen_source(progs, info, M, per, pmode), "dnlp_lb_eval")) {
         lb_eval = lb_rtc.fn;
         lb_persist = per > 0 ? lb_rtc.get("dnlp_lb_persist") : nullptr;
         lb_persist_wgs = per > 0 ? static_cast<int>((nfree + per - 1) / per) : 0;
@@ -2042,7 +2058,17 @@ struct HipExec : HostControlled {
       DNLP_HIP_CHECK(hipMemsetAsync(lb_ctl, 0, sizeof(LbPersistCtl), stream));
       i64 nfp = nfree;
       double c0p = c0;
-      void* a_p[] = {&lb_state, &x, &consts, &lb_ctl, &lb_halo, &c0p, &nfp};
+      if (lb_key_mode != 0) {
+        // (2M + 5) (per + 2 W) doubles per workgroup; W <= 64 (fused_codegen_plan's halo limit)
+        const size_t need = static_cast<size_t>(lb_persist_wgs) * static_cast<size_t>(2 * M + 5) * static_cast<size_t>(lb_per + 128);
+        if (need > lb_strip_cap) {
+          if (lb_strip) hipFree(lb_strip);
+          lb_strip = nullptr;
+          DNLP_HIP_CHECK(hipMalloc(&lb_strip, need * sizeof(double)));
+          lb_strip_cap = need;
+        }
+      }
+      void* a_p[] = {&lb_state, &x, &consts, &lb_ctl, &lb_halo, &c0p, &nfp, &lb_strip};
       bool launched = true;
       static const bool plain_launch = [] { const char* e = std::getenv("DNLP_LBFGS_COOPERATIVE"); return e && std::atoi(e) == 0; }();
       if (plain_launch) {

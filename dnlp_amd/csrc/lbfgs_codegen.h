@@ -57,11 +57,14 @@ struct LbPersistCtl {
 };
 
 // `per` > 0 adds the persistent kernel dnlp_lb_persist for workgroups that own `per` consecutive variables each.
+// `mode`: where a workgroup keeps its slice — 0 everything in LDS (slices up to ~700 variables at M = 10), 1 the 2M
+// history rows in a per-workgroup strip of global memory (L2 / Infinity-Cache resident: 48 MB at n = 3e5) and the five
+// working vectors in LDS, 2 everything in that strip (slices that exceed LDS altogether: n beyond ~9e5 on 256 CUs).
 inline std::string lbfgs_codegen_source(const std::vector<FusedSlotProg>& progs, const FusedCodegenInfo& info, int M,
-                                        long long per = 0) {
+                                        long long per = 0, int mode = 0) {
   std::string s = fused_codegen_preamble(info.E);
   s += "#define DNLP_M " + std::to_string(M) + "\n#define DNLP_NB " + std::to_string(2 * M + 1) + "\n";
-  if (per > 0) s += "#define DNLP_PER " + std::to_string(per) + "\n";
+  if (per > 0) s += "#define DNLP_PER " + std::to_string(per) + "\n#define DNLP_PMODE " + std::to_string(mode) + "\n";
   s += fused_codegen_chunk(progs, info);
   s += "struct LbfgsState { " DNLP_LB_STR(DNLP_LB_STATE_BODY) " };\n";
   s += R"DNLPLB(
@@ -520,11 +523,28 @@ __device__ __forceinline__ bool dnlp_grid_barrier(LbPersistCtl* ctl, unsigned& e
 }
 
 extern "C" __global__ void __launch_bounds__(256) dnlp_lb_persist(LbfgsState* __restrict__ S, double* __restrict__ x,
-    const double* __restrict__ consts, LbPersistCtl* __restrict__ ctl, double* __restrict__ halo, const double c0, const i64 nf) {
+    const double* __restrict__ consts, LbPersistCtl* __restrict__ ctl, double* __restrict__ halo, const double c0, const i64 nf,
+    double* __restrict__ strip) {
   constexpr int M = DNLP_M, nb = DNLP_NB, GR = 2 * DNLP_M, W = DNLP_W, PL = DNLP_PL, PER = DNLP_PER;
   constexpr int ldg = DNLP_MAXNB;
+  // the slice of this workgroup: in LDS, or (DNLP_PMODE) in its strip of global memory — (2M + 5) PL doubles per
+  // workgroup, read and written by this workgroup only, coalesced; the same indexing either way
+#if DNLP_PMODE == 0
   __shared__ double xs[PL], ds[PL], xt[PL], gold[PL], gnew[PL];
   __shared__ double rows[2 * M][PL];                       // s_0 .. s_{M-1}, y_0 .. y_{M-1}
+#else
+  double* const mine = strip + static_cast<i64>(blockIdx.x) * (2 * M + 5) * PL;
+  double (*rows)[PL] = reinterpret_cast<double (*)[PL]>(mine);
+#if DNLP_PMODE == 1
+  __shared__ double xs[PL], ds[PL], xt[PL], gold[PL], gnew[PL];
+#else
+  double* const xs = mine + static_cast<i64>(2 * M) * PL;
+  double* const ds = xs + PL;
+  double* const xt = ds + PL;
+  double* const gold = xt + PL;
+  double* const gnew = gold + PL;
+#endif
+#endif
   __shared__ double Gs[DNLP_MAXNB * DNLP_MAXNB];
   __shared__ double cf[DNLP_MAXNB], rh[16], red[96], wred[4][4];
   __shared__ double sc[8];                                  // gd, step, (spare)
@@ -555,6 +575,7 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_persist(LbfgsState* __
   while (done == 0) {
     // ---- trial point xt = xs + step ds (phase 0: the start point itself) ----
     if (fresh) {
+#pragma unroll 2
       for (int li = tid; li < PL; li += 256) {
         double d = cf[GR] * gold[li];
 #pragma unroll
@@ -592,6 +613,8 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_persist(LbfgsState* __
 #pragma unroll
       for (int r = 0; r < 8; ++r) as_[r] = ay_[r] = ag_[r] = 0.0;
       __syncthreads();                                  // gnew of the owned entries is complete
+      // (unrolled: with the history in the global strip the loads of four strides are in flight together)
+#pragma unroll 4
       for (int li = W + lane; li < W + own; li += 64) {
         const double gv = gnew[li];
         const double sv = run ? stp * ds[li] : 0.0, yv = run ? gv - gold[li] : 0.0;

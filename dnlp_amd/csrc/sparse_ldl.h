@@ -206,7 +206,10 @@ DNLP_HD inline void sparse_ldl_solve(const SparsePlan& pl, const double* vals, d
     const i64 h0 = pl.lev_f[lev], h1 = last ? pl.lev_f[pl.nlev] : pl.lev_f[lev + 1];
     if (h1 == h0) continue;
     const i64 nh = h1 - h0, nrw = pl.foff[h1] - pl.foff[h0];
-    if (nh * 8 <= L && nrw >= 16 * nh) {
+    if (nh * 8 <= L && nrw > 2 * nh) {
+      // few targets (the one-block levels of a dense separator chain: circle packing's last 21 levels have one node
+      // each, under up to 20 rows): all lanes gather a target's rows and par.sum's fixed tree adds them — one lane
+      // walking the rows is a chain of dependent loads per row
       for (i64 h = h0; h < h1; ++h) {
         const i64 q1 = pl.fend ? pl.fend[h] : pl.foff[h + 1];
         double acc = 0.0;

@@ -9,6 +9,7 @@
 // The dense symmetric-indefinite factorisation below restates LAPACK's DSYTF2/DSYTRS
 // (Bunch-Kaufman partial pivoting, lower storage), the role MUMPS plays for IPOPT.
 #pragma once
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -44,6 +45,7 @@ struct HostLapack {
   trsm_t trsm = nullptr;
   bool blocked_unpivoted = false;        // orc_use_blocked_ldlt: unpivoted factorisations of order >= 512 go through them
   std::vector<double> wpanel, wpanel2;
+  double last_phases[4] = {0.0, 0.0, 0.0, 0.0};   // blocked LDL^T, last factorisation: diagonal blocks, DTRSM, W copy, DGEMM (seconds)
   int (*get_threads)() = nullptr;
   void (*set_threads)(int) = nullptr;
   std::vector<double> work;
@@ -261,7 +263,13 @@ struct HostExec : HostControlled {
       // C -= W L21^T by one DGEMM per block column of the lower triangle, all cores.
       const i64 NB = n >= 4000 ? 512 : 256;
       const double one = 1.0, mone = -1.0;
+      // DNLP_HOST_LDLT_TIMING=1: seconds per phase of this factorisation on stderr (where the host's time goes)
+      static const bool timing = std::getenv("DNLP_HOST_LDLT_TIMING") != nullptr;     // (bench.py sets it: the phase split is part of the baseline's line)
+      auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+      double t_diag = 0.0, t_trsm = 0.0, t_copy = 0.0, t_gemm = 0.0, t_mark = timing ? clk() : 0.0;
+      auto lap = [&](double& acc) { if (timing) { const double t = clk(); acc += t - t_mark; t_mark = t; } };
       for (i64 K0 = 0; K0 < n; K0 += NB) {
+        if (timing) t_mark = clk();
         const i64 KB = std::min<i64>(NB, n - K0);
         // the panel's diagonal block, itself blocked by 64 columns (unblocked it was 45 Mflop of scalar code per
         // 512-column panel, more time than the DGEMMs of the whole factorisation on a 256-core host): 64 x 64 diagonal
@@ -296,10 +304,12 @@ struct HostExec : HostControlled {
           }
           LP.gemm("N", "T", &mi2, &mi2, &ki2, &mone, W2, &mi2, A + e0 + k0 * ld, &ldi2, &one, A + e0 + e0 * ld, &ldi2);
         }
+        lap(t_diag);
         const i64 r1 = K0 + KB, rows = n - r1;
         if (rows <= 0) break;
         const int mi = static_cast<int>(rows), ki = static_cast<int>(KB), ldi = static_cast<int>(ld);
         LP.trsm("R", "L", "T", "U", &mi, &ki, &one, A + K0 + K0 * ld, &ldi, A + r1 + K0 * ld, &ldi);   // A21 <- W = L21 D
+        lap(t_trsm);
         if (LP.wpanel.size() < static_cast<size_t>(rows * KB)) LP.wpanel.resize(static_cast<size_t>(rows * KB));
         double* W = LP.wpanel.data();
 #pragma omp parallel for schedule(static)
@@ -312,13 +322,19 @@ struct HostExec : HostControlled {
         // few, large DGEMMs: block columns of a quarter of the trailing order (a call per 256 columns spends its time in
         // the thread pool's hand-offs on a 256-core host: 82 GFLOP/s at n = 1e4 against 3.2 TFLOP/s of plain DGEMM); the
         // part of a block above the diagonal is computed and ignored (<= 1/8 more flops)
+        lap(t_copy);
         const i64 CB = std::max<i64>(NB, (rows / 4 + NB - 1) / NB * NB);
         for (i64 J = 0; J < rows; J += CB) {
           const int jb = static_cast<int>(std::min<i64>(CB, rows - J)), mr = static_cast<int>(rows - J);
           LP.gemm("N", "T", &mr, &jb, &ki, &mone, W + J, &mi, A + (r1 + J) + K0 * ld, &ldi, &one,
                   A + (r1 + J) + (r1 + J) * ld, &ldi);
         }
+        lap(t_gemm);
       }
+      LP.last_phases[0] = t_diag; LP.last_phases[1] = t_trsm; LP.last_phases[2] = t_copy; LP.last_phases[3] = t_gemm;
+      if (timing && std::getenv("DNLP_HOST_LDLT_TIMING")[0] == '2')
+        std::fprintf(stderr, "[host ldlt] n %lld: diagonal blocks %.3f s, dtrsm %.3f s, W copy %.3f s, dgemm %.3f s\n",
+                     static_cast<long long>(n), t_diag, t_trsm, t_copy, t_gemm);
       return true;
     }
     if (!pivoted) {

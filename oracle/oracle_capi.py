@@ -99,3 +99,12 @@ def dgemm_gflops(n: int, threads: int) -> float:
     lib.orc_dgemm_probe.restype = ctypes.c_double
     lib.orc_dgemm_probe.argtypes = [ctypes.c_int, ctypes.c_int]
     return float(lib.orc_dgemm_probe(int(n), int(threads)))
+
+
+def blocked_ldlt_phases():
+    """Seconds of the last blocked LDL^T's phases (needs DNLP_HOST_LDLT_TIMING in the environment)."""
+    import ctypes
+    lib = api().lib
+    out = (ctypes.c_double * 4)()
+    lib.orc_blocked_ldlt_phases(out)
+    return {"diagonal_blocks": out[0], "dtrsm": out[1], "w_copy": out[2], "dgemm": out[3]}

@@ -62,3 +62,10 @@ extern "C" double orc_dgemm_probe(int n, int threads) {
   L.gemm("N", "T", &n, &n, &n, &one, A.data(), &n, B.data(), &n, &zero, C.data(), &n);
   return 2.0 * n * n * n / (dnlp::now_sec() - t0) / 1e9;
 }
+
+// Seconds of the four phases of the last blocked unpivoted LDL^T (diagonal blocks, DTRSM, W copy, DGEMM); zeros unless
+// DNLP_HOST_LDLT_TIMING is set.
+extern "C" void orc_blocked_ldlt_phases(double* out4) {
+  dnlp::HostLapack& L = dnlp::HostLapack::get();
+  for (int k = 0; k < 4; ++k) out4[k] = L.last_phases[k];
+}

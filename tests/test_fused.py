@@ -285,10 +285,29 @@ def test_c2_persistent_single_launch_kernel_against_the_slot_kernels(gpu_require
         data["handle"].close()
     assert abs(out["1"]["iterations"] - out["0"]["iterations"]) <= 6
     assert abs(out["1"]["evaluations"] - out["0"]["evaluations"]) <= 8
-    # sizes whose slice does not fit the LDS of a compute unit keep the slot kernels
-    p = rosenbrock_chain(cp, 2000000)
-    chain = p._build_chain(None)
-    data, inv = chain.apply(p)
+    # the same solve with the slice's history (mode 1) or the whole slice (mode 2) in the workgroup's strip of global
+    # memory instead of LDS — what sizes beyond n ~ 2e5 take: same optimum, iteration counts within summation order
+    for mode in ("1", "2"):
+        monkeypatch.setenv("DNLP_LBFGS_PERSIST", "1")
+        monkeypatch.setenv("DNLP_LBFGS_PERSIST_MODE", mode)
+        p = rosenbrock_chain(cp, 100000)
+        chain = p._build_chain(None)
+        data, inv = chain.apply(p)
+        info = chain.solver.solve_via_data(data, True, False, {"algorithm": "lbfgs"})
+        assert info["status"] == 0 and info["device_loop"] and info["device_loop_persistent"]
+        p.unpack_results(info, chain, inv)
+        assert np.max(np.abs(p.variables()[0].value - 1.0)) <= 1e-5
+        assert abs(info["iterations"] - out["1"]["iterations"]) <= 6
+        data["handle"].close()
+    monkeypatch.delenv("DNLP_LBFGS_PERSIST_MODE")
+    # n = 3e5: the history no longer fits LDS and lives in the strip (one launch); n = 2e6: the slot kernels
     monkeypatch.setenv("DNLP_LBFGS_PERSIST", "1")
-    info = chain.solver.solve_via_data(data, True, False, {"algorithm": "lbfgs"})
-    assert info["status"] == 0 and info["device_loop"] and not info["device_loop_persistent"]
+    for n, persistent in ((300000, True), (2000000, False)):
+        p = rosenbrock_chain(cp, n)
+        chain = p._build_chain(None)
+        data, inv = chain.apply(p)
+        info = chain.solver.solve_via_data(data, True, False, {"algorithm": "lbfgs"})
+        assert info["status"] == 0 and info["device_loop"] and info["device_loop_persistent"] == persistent
+        p.unpack_results(info, chain, inv)
+        assert np.max(np.abs(p.variables()[0].value - 1.0)) <= 1e-5
+        data["handle"].close()

@@ -324,3 +324,19 @@ def test_persistent_lbfgs_kernel_compiles_for_gfx950_at_the_stated_size():
     assert rc == 0, log.value.decode()
     text = src.value.decode()
     assert "#define DNLP_PER 392" in text and "dnlp_lb_persist" in text
+
+
+@pytest.mark.parametrize("n,mode", [(300000, 1), (1000000, 2)])
+def test_persistent_lbfgs_kernel_beyond_lds_compiles_for_gfx950(n, mode):
+    """Above n ~ 2e5 a workgroup's slice no longer fits LDS with its whole history: the history rows (mode 1) or the
+    whole slice (mode 2) live in a per-workgroup strip of global memory; the same kernel text, compiled for gfx950."""
+    data = _data(rosenbrock_chain(cp, n))
+    blob = bytes(serialize(data["tape_arrays"]))
+    lib = _lib()
+    lib.dnlp_lbfgs_codegen_check.restype = C.c_int
+    src = C.create_string_buffer(1 << 21)
+    log = C.create_string_buffer(1 << 16)
+    rc = lib.dnlp_lbfgs_codegen_check(blob, C.c_size_t(len(blob)), 4, src, C.c_size_t(len(src)), log, C.c_size_t(len(log)))
+    assert rc == 0, log.value.decode()
+    text = src.value.decode()
+    assert ("#define DNLP_PMODE %d" % mode) in text and "dnlp_lb_persist" in text
