@@ -204,6 +204,121 @@ __global__ void __launch_bounds__(NT) batch_solve_kernel(BatchArgs a) {
   }
 }
 
+// PACKED form for small sparse instances (round 4): a workgroup of NW wavefronts, one instance per wavefront, the
+// wavefronts independent of each other after the staging.  The index arrays that every instance reads (sparse plan,
+// product indices: ~10 KB for localization) exist ONCE per compute unit instead of once per instance, which leaves
+// room for EVERY vector of the NW instances in LDS (localization: 4 x 37 KB + 10 KB of 160 KB) — no vector in the
+// global slab, and because that is guaranteed (BlockExecT<64, true>::alloc refuses anything else before
+// freeze_vectors()), the solver's element accesses are compiled as LDS instructions (exec.h VecP, vectors_in_lds)
+// instead of flat ones.  The host takes this kernel when the sizes allow it (BatchRunner::solve_impl) and falls back
+// to batch_solve_kernel when an instance reports that its vectors did not fit.
+struct PackedObjSizes { size_t ex, md, kkt, ipm; };
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) batch_solve_packed_kernel(BatchArgs a, unsigned wave_lds_bytes) {
+  extern __shared__ __align__(64) char lds_dyn[];
+  using EX = BlockExecT<64, true>;
+  using KktT = DenseKkt<EX>;
+  using ModelT = Model<EX>;
+  using IpmT = Ipm<EX, KktT>;
+  struct alignas(16) Objs {
+    alignas(16) char ex[sizeof(EX)];
+    alignas(16) char md[sizeof(ModelT)];
+    alignas(16) char kkt[sizeof(KktT)];
+    alignas(16) char ipm[sizeof(IpmT)];
+  };
+  __shared__ Objs s_objs[NW];
+  __shared__ double s_red[NW][8];
+  __shared__ int s_redi[NW][8];
+  __shared__ int s_inst[NW];
+  const int wave = static_cast<int>(threadIdx.x >> 6), lane = static_cast<int>(threadIdx.x & 63u);
+  SparsePlan spl = a.sp;
+  CooIdx cjr = a.base.jac_by_row, cjc = a.base.jac_by_col, chs = a.base.hess_sym;
+  const unsigned pstage = a.plan_stage_bytes;
+  {
+    // every array the instances share, once per workgroup (the same `put` order as batch_solve_kernel's tiers 1 | 2 | 4)
+    char* p = lds_dyn;
+    auto put = [&](auto*& field, i64 count) {
+      using T = typename std::remove_pointer<typename std::remove_reference<decltype(field)>::type>::type;
+      T* dst = reinterpret_cast<T*>(p);
+      for (i64 i = threadIdx.x; i < count; i += 64 * NW) dst[i] = field[i];
+      field = dst;
+      p += (static_cast<size_t>(count) * sizeof(T) + 7) & ~static_cast<size_t>(7);
+    };
+    put(spl.bnode, 2 * spl.nblk); put(spl.soff, spl.nblk + 1); put(spl.loff, spl.nblk); put(spl.doff, spl.nblk);
+    put(spl.lev_off, spl.nlev + 1); put(spl.sblk, a.plan_rows); put(spl.sidx, a.plan_rows);
+    put(spl.lev_f, spl.nlev + 1); put(spl.fnode, spl.nfwd); put(spl.foff, spl.nfwd + 1);
+    put(spl.fa, a.plan_rows); put(spl.fu0, a.plan_rows); put(spl.fu1, a.plan_rows);
+    auto putc = [&](CooIdx& c) { if (c.ptr) { put(c.ptr, c.nout + 1); put(c.ent, c.total); put(c.src, c.total); put(c.heavy, c.nheavy); } };
+    putc(cjr); putc(cjc); putc(chs);
+    put(spl.lev_g, spl.nlev + 1); put(spl.gdst, spl.ngrp); put(spl.goff, spl.ngrp + 1);
+    put(spl.tau, spl.ntrip); put(spl.tav, spl.ntrip);
+    put(spl.hpos, a.base.nnzH); put(spl.jpos, a.base.nnzJ); put(spl.dpos, spl.n);
+    __syncthreads();                 // the only workgroup barrier of the kernel
+  }
+  Objs& o = s_objs[wave];
+  char* my_lds = lds_dyn + pstage + static_cast<size_t>(wave) * wave_lds_bytes;
+  char* slab = a.ws + (static_cast<size_t>(blockIdx.x) * NW + wave) * a.ws_per_block;
+  const size_t slab_cap = a.ws_per_block - a.stage_global_bytes;
+  double* g_vec = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(slab + slab_cap) + 63) & ~static_cast<uintptr_t>(63));
+  int* g_piv = reinterpret_cast<int*>(g_vec + EX::kWaveSolveMax);
+  while (true) {
+    if (lane == 0) {
+      const int k = atomicAdd(a.next, 1);
+      s_inst[wave] = (k < a.batch && a.order) ? a.order[k] : k;
+    }
+    wave_sync();
+    const int inst = s_inst[wave];
+    wave_sync();
+    if (inst >= a.batch) break;
+    EX* ex = new (o.ex) EX(slab, slab_cap, my_lds, wave_lds_bytes, s_red[wave], s_redi[wave], g_vec, g_piv);
+    ex->lds_mode = 3;
+    double* sl = a.slabs + static_cast<i64>(inst) * a.lay.total;
+    TapeView t = a.base;
+    t.jac_by_row = cjr; t.jac_by_col = cjc; t.hess_sym = chs;
+    t.c0 = sl[a.lay.c0];
+    t.c = sl + a.lay.c; t.b = sl + a.lay.b; t.Jc = sl + a.lay.Jc;
+    t.G.val = sl + a.lay.G; t.Mg.val = sl + a.lay.Mg; t.Mw.val = sl + a.lay.Mw; t.MJ.val = sl + a.lay.MJ;
+    t.MH.val = sl + a.lay.MH; t.flat_p = sl + a.lay.fp; t.flat_p2 = sl + a.lay.fp2;
+    t.d_x0 = sl + a.lay.x0; t.d_lb = sl + a.lay.lb; t.d_ub = sl + a.lay.ub; t.d_cl = sl + a.lay.cl; t.d_cu = sl + a.lay.cu;
+    ModelT* md = new (o.md) ModelT();
+    md->init_view(ex, t);
+    KktT* kkt = new (o.kkt) KktT();
+    kkt->init_sparse(ex, t.N, t.m, spl);
+    kkt->pivot_max_n = static_cast<i64>(1) << 40;
+    kkt->fallback_max_n = a.fallback_max_n;
+    IpmT* ipm = new (o.ipm) IpmT(ex, md, kkt);
+    ipm->opt = a.opt;
+    if (a.ws_g) {
+      ipm->ws_mult_g = a.ws_g + static_cast<i64>(inst) * t.m;
+      ipm->ws_mult_xL = a.ws_l + static_cast<i64>(inst) * t.N;
+      ipm->ws_mult_xU = a.ws_u + static_cast<i64>(inst) * t.N;
+    }
+    ipm->allocate();
+    ex->freeze_vectors();            // (what a dense fallback allocates later — its matrix, pivots, scratch — may live in the slab)
+    int st = Internal_Error;
+    if (!ex->overflow) {
+      st = ipm->solve(t.d_x0);
+      if (ipm->initialized)
+        ipm->extract_exec(a.x_out + static_cast<i64>(inst) * t.N, a.multg_out ? a.multg_out + static_cast<i64>(inst) * t.m : nullptr,
+                          a.zl_out ? a.zl_out + static_cast<i64>(inst) * t.N : nullptr,
+                          a.zu_out ? a.zu_out + static_cast<i64>(inst) * t.N : nullptr, nullptr);
+    } else {
+      st = -198;                     // the vectors did not fit the wavefront's LDS share: the host takes the other kernel
+    }
+    if (lane == 0) {
+      a.status_out[inst] = st;
+      a.iters_out[inst] = ex->overflow ? 0 : ipm->iter;
+      a.obj_out[inst] = (!ex->overflow && ipm->initialized) ? ipm->objective_unscaled() : 0.0;
+      if (a.nfact_out) a.nfact_out[inst] = ipm->stats.factorizations;
+      if (a.times_out) {
+        double* to = a.times_out + 4 * static_cast<i64>(inst);
+        to[0] = ipm->stats.wall; to[1] = ipm->stats.t_eval; to[2] = ipm->stats.t_factor; to[3] = ipm->stats.t_solve;
+      }
+    }
+    wave_sync();
+  }
+}
+
 // Instance data from parameter rows, on the device: slab[b][o] = d0[o] + sum_k D[o][k] (theta[b][k] - theta0[k]) with
 // D in CSR over the slab's own layout (the per-segment parameters already gathered to per-flat-row ones).
 // A lane owns one slab entry of one instance; the instance's parameter row (tens of doubles) is read by
@@ -236,6 +351,8 @@ struct BatchRunner {
   i64 in_stride = 0;
   int last_grid = 0, last_threads = 0, last_lds_mode = 0, last_per_cu = 0;   // launch plan of the last solve
   bool last_order_lpt = false;   // the last solve took its instances longest-first (a re-solve of the same rows)
+  bool last_packed = false;      // the last solve ran batch_solve_packed_kernel
+  bool packed_disabled = false;  // an instance's vectors did not fit the packed kernel's LDS share once
   bool have_sparse = false, force_sparse = false;
   // warm-start multipliers for the NEXT solve (consumed by it)
   std::vector<double> h_ws_g, h_ws_l, h_ws_u;
@@ -353,6 +470,24 @@ struct BatchRunner {
     b.factor = pad8(4 * (nl + 1)) + pad8(4 * ng) + pad8(4 * (ng + 1)) + 2 * pad8(4 * nt) + pad8(4 * static_cast<size_t>(t.nnzH)) +
                pad8(4 * static_cast<size_t>(t.nnzJ)) + pad8(4 * static_cast<size_t>(dev_plan.n));
     return b;
+  }
+
+  // bytes of every vector one instance allocates (BlockExecT::alloc: 64-byte granules), in the order of
+  // Model::init_view, DenseKkt::init_sparse, Ipm::allocate
+  size_t packed_vector_bytes() const {
+    const Tape<HipExec>& t = *tape;
+    const size_t N = static_cast<size_t>(t.N), m = static_cast<size_t>(t.m), Z = static_cast<size_t>(t.Z);
+    size_t total = 0;
+    auto al = [&](size_t n) { total += ((n ? n : 1) * 8 + 15) & ~static_cast<size_t>(15); };      // (BlockExecT<64, true>::alloc: 16-byte granules)
+    al(N + Z); al(static_cast<size_t>(t.nd)); al(static_cast<size_t>(t.nh)); al(Z); al(1 + m); al(static_cast<size_t>(t.nnzH)); al(N);
+    al(static_cast<size_t>(t.nblk));
+    al(static_cast<size_t>(dev_plan.nvals)); al(static_cast<size_t>(dev_plan.nvals + 3 * dev_plan.nblk + 8));
+    for (int k = 0; k < 14; ++k) al(N);                       // x zL zU xL xU grad dx dzL dzU xt Sx rx tN fixmask
+    for (int k = 0; k < 22; ++k) al(m);                       // s y vL vU sL sU eqmask g sg ds dy dvL dvU st gt Dd Ss rs rp tM csoc zeroM
+    al(static_cast<size_t>(t.nnzJ));
+    for (int k = 0; k < 4; ++k) al(N + m);                    // rhs sol res cor
+    for (int k = 0; k < 2; ++k) { for (int q = 0; q < 3; ++q) al(N); for (int q = 0; q < 4; ++q) al(m); }     // aff, cen
+    return total;
   }
 
   void init(HipExec* e, Tape<HipExec>* t) {
@@ -610,11 +745,42 @@ struct BatchRunner {
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     if (const char* e = std::getenv("DNLP_BATCH_PER_CU")) { const int w = std::atoi(e); if (w >= 1 && w <= 8) per_cu = w; }
-    const int grid = std::min(batch, ncu * per_cu);
-    last_grid = grid; last_threads = nthreads; last_lds_mode = mode; last_per_cu = per_cu;
-    if (dbg) std::fprintf(stderr, "[batch] plan: threads %d lds_mode %d static LDS %zu B dynamic %u B (plan arrays %u B) -> %d per CU, grid %d\n", nthreads, mode,
-                          static_cast<size_t>(fa.sharedSizeBytes), a.lds_bytes, a.plan_stage_bytes, per_cu, grid);
-    a.ws = dalloc<char>(static_cast<size_t>(grid) * a.ws_per_block);
+    int grid = std::min(batch, ncu * per_cu);
+    // Packed form (batch_solve_packed_kernel): four instances per workgroup share one LDS copy of the index arrays and
+    // keep ALL their vectors in LDS — taken when that fits a compute unit and the regular plan holds no more instances
+    // per compute unit than four (DNLP_BATCH_PACKED=0 disables; an instance whose vectors did not fit reports -198 and
+    // the handle goes back to the regular kernel for good)
+    constexpr int kPackedWaves = 4;
+    unsigned pk_wave_bytes = 0;
+    bool packed = false;
+    if (wave && have_sparse && !sparse_big && !packed_disabled && per_cu <= kPackedWaves &&
+        !(std::getenv("DNLP_BATCH_PACKED") && std::atoi(std::getenv("DNLP_BATCH_PACKED")) == 0)) {
+      const IdxBytes ib = index_bytes();
+      const size_t idx = (ib.solve + ib.coo + ib.factor + 63) & ~static_cast<size_t>(63);
+      const size_t wv = (packed_vector_bytes() + 64 + 15) & ~static_cast<size_t>(15);
+      hipFuncAttributes fp;
+      DNLP_HIP_CHECK(hipFuncGetAttributes(&fp, reinterpret_cast<const void*>(batch_solve_packed_kernel<kPackedWaves>)));
+      if (idx + kPackedWaves * wv + fp.sharedSizeBytes + 512 <= 160 * 1024) {
+        packed = true;
+        pk_wave_bytes = static_cast<unsigned>(wv);
+        a.plan_stage_bytes = static_cast<unsigned>(idx);
+        a.plan_stage_factor = 7;
+        a.lds_stage_bytes = 0;
+        a.lds_bytes = static_cast<unsigned>(idx + kPackedWaves * wv);
+        a.stage_global_bytes = static_cast<unsigned>(static_cast<size_t>(BlockExecT<64>::kWaveSolveMax) * 12 + 64);
+        a.ws_per_block = 256 + fbbytes + a.stage_global_bytes + 64;       // per WAVEFRONT here: only a dense fallback uses it
+        DNLP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(batch_solve_packed_kernel<kPackedWaves>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(a.lds_bytes)));
+        grid = std::min((batch + kPackedWaves - 1) / kPackedWaves, ncu);
+        per_cu = kPackedWaves;
+        mode = 3;
+      }
+    }
+    last_grid = grid; last_threads = packed ? 64 * kPackedWaves : nthreads; last_lds_mode = mode; last_per_cu = per_cu; last_packed = packed;
+    if (dbg) std::fprintf(stderr, "[batch] plan: %s threads %d lds_mode %d static LDS %zu B dynamic %u B (index arrays %u B, per wavefront %u B) -> %d per CU, grid %d\n",
+                          packed ? "PACKED" : "regular", last_threads, mode, static_cast<size_t>(fa.sharedSizeBytes), a.lds_bytes, a.plan_stage_bytes,
+                          pk_wave_bytes, per_cu, grid);
+    a.ws = dalloc<char>(static_cast<size_t>(grid) * (packed ? kPackedWaves : 1) * a.ws_per_block);
     a.x_out = dalloc<double>(static_cast<size_t>(batch) * t.N);
     a.obj_out = dalloc<double>(static_cast<size_t>(batch));
     a.multg_out = multg_out ? dalloc<double>(static_cast<size_t>(batch) * t.m) : nullptr;
@@ -656,7 +822,9 @@ struct BatchRunner {
     DNLP_HIP_CHECK(hipEventCreate(&e0));
     DNLP_HIP_CHECK(hipEventCreate(&e1));
     DNLP_HIP_CHECK(hipEventRecord(e0, ex->stream));
-    if (wave) hipLaunchKernelGGL(batch_solve_kernel<64>, dim3(static_cast<unsigned>(grid)), dim3(64), a.lds_bytes, ex->stream, a);
+    if (packed) hipLaunchKernelGGL(batch_solve_packed_kernel<kPackedWaves>, dim3(static_cast<unsigned>(grid)), dim3(64 * kPackedWaves), a.lds_bytes,
+                                   ex->stream, a, pk_wave_bytes);
+    else if (wave) hipLaunchKernelGGL(batch_solve_kernel<64>, dim3(static_cast<unsigned>(grid)), dim3(64), a.lds_bytes, ex->stream, a);
     else hipLaunchKernelGGL(batch_solve_kernel<256>, dim3(static_cast<unsigned>(grid)), dim3(256), a.lds_bytes, ex->stream, a);
     DNLP_LAUNCH_CHECK();
     DNLP_HIP_CHECK(hipEventRecord(e1, ex->stream));
@@ -677,6 +845,17 @@ struct BatchRunner {
     down(iters_out, a.iters_out, sizeof(int) * batch);
     down(nfact_out, a.nfact_out, sizeof(int) * batch);
     down(times_out, a.times_out, sizeof(double) * 4 * batch);
+    if (packed && status_out) {
+      bool refused = false;
+      for (int k = 0; k < batch && !refused; ++k) refused = status_out[k] == -198;
+      if (refused) {
+        // the estimate of the vectors' bytes was short for this tape: the regular kernel, from now on
+        packed_disabled = true;
+        release();
+        solve_impl(batch, data, theta, opt, x_out, obj_out, multg_out, zl_out, zu_out, status_out, iters_out, nfact_out, seconds, times_out);
+        return;
+      }
+    }
     if (iters_out) { prev_iters.assign(iters_out, iters_out + batch); prev_key = key; }
     release();
     mark("results copied");

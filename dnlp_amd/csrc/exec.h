@@ -51,6 +51,43 @@ namespace dnlp {
 using i64 = int64_t;
 using i32 = int32_t;
 
+// A vector of the solver (iterate, direction, residual, factor values ...) as the solver objects hold it: a plain
+// double* in every execution space, plus — in a space whose vectors ALL live in LDS (E::vectors_in_lds: the packed batch
+// kernel of batch.h) — the knowledge that it does: every read of the member tells the compiler so, and the element
+// accesses through the copy (`const double* xx = x;` before a lambda, as everywhere in ipm_core.h / model.h) become
+// ds_read / ds_write instead of flat instructions (address-space check, both wait counters, the texture path).
+// The member is STORED as an LDS pointer (32 bits) and converted to a generic one where it is read: LLVM's address-space
+// inference follows a generic pointer that comes out of an addrspacecast from LDS and rewrites the accesses through it.
+// (Measured on a ten-line kernel, tools/micro/lds_infer.hip: a generic -> LDS -> generic round trip of a loaded generic
+//  pointer is folded away and infers nothing; llvm.assume(is.shared(p)) on every read works but crashed this compiler's
+//  loop-deletion pass on Ipm::update_mu, where the reads sit inside loops after inlining.)
+template <class E, bool InLds = E::vectors_in_lds>
+struct VecP {
+  double* p = nullptr;
+  DNLP_HD VecP() {}
+  DNLP_HD VecP(double* q) : p(q) {}
+  DNLP_HD VecP& operator=(double* q) { p = q; return *this; }
+  DNLP_HD operator double*() const { return p; }
+};
+#if defined(__HIPCC__)
+template <class E>
+struct VecP<E, true> {
+  typedef __attribute__((address_space(3))) double lds_t;
+  lds_t* p = nullptr;
+  __device__ VecP() {}
+  __device__ VecP(double* q) : p((lds_t*)q) {}
+  __device__ VecP& operator=(double* q) { p = (lds_t*)q; return *this; }
+  __device__ operator double*() const { return (double*)p; }
+};
+#endif
+// the same statement for a vector that arrives as a function argument (callers pass solver vectors only); used at the
+// top of functions, outside loops
+#if DNLP_DEVICE_PASS
+#define DNLP_VEC_IN_LDS(E, p) do { if constexpr (E::vectors_in_lds) __builtin_assume(__builtin_amdgcn_is_shared(p)); } while (0)
+#else
+#define DNLP_VEC_IN_LDS(E, p) do { } while (0)
+#endif
+
 constexpr double kInf = std::numeric_limits<double>::infinity();
 struct D2 { double first, second; };     // pair of reduction results (E::min2)
 // several reductions in ONE pass (E::reduce_multi<NM, NS>): NM maxima (NaN -> +inf, as E::max) and NS sums
@@ -70,6 +107,7 @@ struct HostControlled {
   static constexpr bool has_log = true;
   static constexpr bool has_host_control = true;
   static constexpr bool objects_in_lds = false;
+  static constexpr bool vectors_in_lds = false;
   static constexpr int kFilterCap = 1024;
   // largest order the space's pivoted (Bunch-Kaufman) factorisation accepts; HipExec narrows it (its solve keeps
   // the vector in LDS), the host space's LAPACK backend has no such limit

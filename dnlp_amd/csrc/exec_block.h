@@ -413,8 +413,19 @@ __device__ void bk_solve_wave(AP A, int n, int ld, const int* piv, double* v) {
 }
 
 // NT lanes work on one instance: 64 (one wavefront; small instances, several per CU) or 256.
-template <int NT>
+// PK (packed, NT = 64 only): the wavefront is one of several in a workgroup, each with its own instance (batch.h
+// batch_solve_packed_kernel: the instances of a compute unit share ONE LDS copy of the index arrays, which leaves room
+// for every vector of all of them): lanes are tid() & 63, a "barrier" orders this wavefront's memory operations
+// only (wavefronts of a workgroup run different instances and never wait for each other), and every vector the solver
+// objects allocate before freeze_vectors() lives in LDS — the execution space says so (vectors_in_lds) and the solver's
+// element accesses become LDS instructions (exec.h VecP).
+template <int NT, bool PK = false>
 struct BlockExecT {
+  static_assert(!PK || NT == 64, "packed instances are one wavefront each");
+  static constexpr bool vectors_in_lds = PK;
+  __device__ static int tid() { return PK ? static_cast<int>(threadIdx.x & 63u) : static_cast<int>(threadIdx.x); }
+  bool vec_frozen = false;          // PK: the solver's vectors are all allocated (in LDS); later allocations may go to the global slab
+  __device__ void freeze_vectors() { vec_frozen = true; }
   static constexpr int kBatchThreads = NT;
   static constexpr bool is_device = false;          // model.h: generic lambda form of the flat sweep
   static constexpr bool has_log = false;
@@ -445,13 +456,21 @@ struct BlockExecT {
   __device__ BlockExecT(char* slab, size_t cap, char* lds, size_t ldscap, double* r, int* ri, double* v, int* pv)
       : ws(slab), ws_cap(cap), lds_pool(lds), lds_cap(ldscap), red(r), redi(ri), vec(v), piv(pv) {}
 
-  __device__ void barrier() { __syncthreads(); }
+  __device__ void barrier() { if constexpr (PK) wave_sync(); else __syncthreads(); }
 
   template <class T> __device__ T* alloc(size_t n) {
-    size_t bytes = ((n ? n : 1) * sizeof(T) + 63) & ~static_cast<size_t>(63);
+    // (PK: 16-byte granules — four instances' vectors have to fit the LDS of a compute unit, and ~80 allocations of
+    //  400-byte vectors lose 2.3 KB per instance to 64-byte granules)
+    constexpr size_t gran = PK ? 16 : 64;
+    size_t bytes = ((n ? n : 1) * sizeof(T) + gran - 1) & ~(gran - 1);
     char* p;
     const bool big = bytes >= 16384;
-    if ((big ? (lds_mode & 1) : (lds_mode & 2)) && lds_off + bytes <= lds_cap) {
+    bool in_lds = (big ? (lds_mode & 1) : (lds_mode & 2)) && lds_off + bytes <= lds_cap;
+    if constexpr (PK) {
+      in_lds = !big && lds_off + bytes <= lds_cap;
+      if (!in_lds && !big && !vec_frozen) { overflow = 1; return reinterpret_cast<T*>(lds_pool); }   // a solver vector outside LDS would break vectors_in_lds
+    }
+    if (in_lds) {
       // LDS first: every map / reduction of the interior-point loop is one dependent memory
       // round trip, ~0.1 us in LDS against ~1 us in L2.  With lds_all the whole working set of
       // a small instance (vectors + KKT matrix) lives in LDS; otherwise only the KKT matrix does.
@@ -463,8 +482,8 @@ struct BlockExecT {
       ws_off += bytes;
     }
     unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
-    for (size_t i = threadIdx.x; i < bytes / 8; i += kBatchThreads) q[i] = 0ull;
-    __syncthreads();
+    for (size_t i = tid(); i < bytes / 8; i += kBatchThreads) q[i] = 0ull;
+    barrier();
     return reinterpret_cast<T*>(p);
   }
   template <class T> __device__ T* ctl_alloc(size_t n) { return alloc<T>(n); }
@@ -473,13 +492,13 @@ struct BlockExecT {
     if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | bytes) & 7) == 0) {
       unsigned long long* d = static_cast<unsigned long long*>(dst);
       const unsigned long long* s = static_cast<const unsigned long long*>(src);
-      for (size_t i = threadIdx.x; i < bytes / 8; i += kBatchThreads) d[i] = s[i];
+      for (size_t i = tid(); i < bytes / 8; i += kBatchThreads) d[i] = s[i];
     } else {
       char* d = static_cast<char*>(dst);
       const char* s = static_cast<const char*>(src);
-      for (size_t i = threadIdx.x; i < bytes; i += kBatchThreads) d[i] = s[i];
+      for (size_t i = tid(); i < bytes; i += kBatchThreads) d[i] = s[i];
     }
-    __syncthreads();
+    barrier();
   }
   __device__ void h2d(void* dst, const void* src, size_t bytes) { copy(dst, src, bytes); }
   __device__ void d2h(void* dst, const void* src, size_t bytes) { copy(dst, src, bytes); }
@@ -487,24 +506,24 @@ struct BlockExecT {
   __device__ void zero(void* p, size_t bytes) {
     if (((reinterpret_cast<uintptr_t>(p) | bytes) & 7) == 0) {
       unsigned long long* d = static_cast<unsigned long long*>(p);
-      for (size_t i = threadIdx.x; i < bytes / 8; i += kBatchThreads) d[i] = 0ull;
+      for (size_t i = tid(); i < bytes / 8; i += kBatchThreads) d[i] = 0ull;
     } else {
       char* d = static_cast<char*>(p);
-      for (size_t i = threadIdx.x; i < bytes; i += kBatchThreads) d[i] = 0;
+      for (size_t i = tid(); i < bytes; i += kBatchThreads) d[i] = 0;
     }
-    __syncthreads();
+    barrier();
   }
   __device__ void sync() {}
 
   template <class F> __device__ void map(i64 n, F f) {
-    for (i64 i = threadIdx.x; i < n; i += kBatchThreads) f(i);
-    __syncthreads();
+    for (i64 i = tid(); i < n; i += kBatchThreads) f(i);
+    barrier();
   }
 
   // mode 0 sum, 1 max (NaN -> +inf), 2 min (NaN -> -inf): same conventions as HipExec::reduce
   template <int MODE, class F> __device__ double reduce(i64 n, F f) {
     double acc = MODE == 0 ? 0.0 : -kInf;
-    for (i64 i = threadIdx.x; i < n; i += kBatchThreads) {
+    for (i64 i = tid(); i < n; i += kBatchThreads) {
       double v = f(i);
       if (MODE == 0) acc += v;
       else if (MODE == 1) acc = fmax(acc, v != v ? kInf : v);
@@ -514,8 +533,8 @@ struct BlockExecT {
     if constexpr (NT == 64) return MODE == 2 ? -acc : acc;     // the butterfly left the result in every lane
     double* buf = red + 4 * parity;
     parity ^= 1;
-    if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = acc;
-    __syncthreads();
+    if ((tid() & 63) == 0) buf[tid() >> 6] = acc;
+    barrier();
     double r = buf[0];
     for (int k = 1; k < kBatchThreads / 64; ++k) r = MODE == 0 ? r + buf[k] : fmax(r, buf[k]);
     return MODE == 2 ? -r : r;
@@ -528,7 +547,7 @@ struct BlockExecT {
     RMulti r;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { r.mx[k] = -kInf; r.sm[k] = 0.0; }
-    for (i64 i = threadIdx.x; i < n; i += kBatchThreads) {
+    for (i64 i = tid(); i < n; i += kBatchThreads) {
       const RMulti v = f(i);
 #pragma unroll
       for (int k = 0; k < NM; ++k) r.mx[k] = fmax(r.mx[k], v.mx[k] != v.mx[k] ? kInf : v.mx[k]);
@@ -546,8 +565,8 @@ struct BlockExecT {
       double* buf = red + 4 * parity;
       parity ^= 1;
       const double mine = k < NM ? r.mx[k] : r.sm[k - NM];
-      if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = mine;
-      __syncthreads();
+      if ((tid() & 63) == 0) buf[tid() >> 6] = mine;
+      barrier();
       double t = buf[0];
       for (int w = 1; w < kBatchThreads / 64; ++w) t = k < NM ? fmax(t, buf[w]) : t + buf[w];
       if (k < NM) r.mx[k] = t; else r.sm[k - NM] = t;
@@ -557,7 +576,7 @@ struct BlockExecT {
   // two minima in one pass (NaN -> -inf, as min)
   template <class F> __device__ D2 min2(i64 n, F f) {
     double a0 = -kInf, a1 = -kInf;                   // min via max of the negatives
-    for (i64 i = threadIdx.x; i < n; i += kBatchThreads) {
+    for (i64 i = tid(); i < n; i += kBatchThreads) {
       const D2 v = f(i);
       a0 = fmax(a0, v.first != v.first ? kInf : -v.first);
       a1 = fmax(a1, v.second != v.second ? kInf : -v.second);
@@ -567,14 +586,14 @@ struct BlockExecT {
     if constexpr (NT == 64) return D2{-a0, -a1};
     double* buf = red + 4 * parity;
     parity ^= 1;
-    if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = a0;
-    __syncthreads();
+    if ((tid() & 63) == 0) buf[tid() >> 6] = a0;
+    barrier();
     double r0 = buf[0];
     for (int k = 1; k < kBatchThreads / 64; ++k) r0 = fmax(r0, buf[k]);
     double* buf1 = red + 4 * parity;
     parity ^= 1;
-    if ((threadIdx.x & 63) == 0) buf1[threadIdx.x >> 6] = a1;
-    __syncthreads();
+    if ((tid() & 63) == 0) buf1[tid() >> 6] = a1;
+    barrier();
     double r1 = buf1[0];
     for (int k = 1; k < kBatchThreads / 64; ++k) r1 = fmax(r1, buf1[k]);
     return D2{-r0, -r1};
@@ -587,8 +606,8 @@ struct BlockExecT {
     double* bv = red + 4 * parity;
     int* bi = redi + 4 * parity;
     parity ^= 1;
-    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = v; bi[threadIdx.x >> 6] = idx; }
-    __syncthreads();
+    if ((tid() & 63) == 0) { bv[tid() >> 6] = v; bi[tid() >> 6] = idx; }
+    barrier();
     outv = bv[0];
     outi = bi[0];
     for (int k = 1; k < kBatchThreads / 64; ++k)
@@ -599,15 +618,17 @@ struct BlockExecT {
   struct Par {
     BlockExecT* ex;
     __device__ int lanes() const { return NT; }
-    __device__ int lane() const { return static_cast<int>(threadIdx.x); }
-    __device__ void sync() const { __syncthreads(); }
+    __device__ int lane() const { return BlockExecT::tid(); }
+    __device__ void sync() const { ex->barrier(); }
+    // (PK: the factor values, the work array and the right-hand side are solver vectors: LDS)
+    template <class T> __device__ T* vec(T* p) const { DNLP_VEC_IN_LDS(BlockExecT, p); return p; }
     __device__ double sum(double v) const {
       v = wave_all_sum(v);
       if constexpr (NT == 64) return v;
       double* buf = ex->red + 4 * ex->parity;
       ex->parity ^= 1;
-      if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
-      __syncthreads();
+      if ((BlockExecT::tid() & 63) == 0) buf[BlockExecT::tid() >> 6] = v;
+      ex->barrier();
       double r = buf[0];
       for (int k = 1; k < NT / 64; ++k) r += buf[k];
       return r;
@@ -630,9 +651,10 @@ struct BlockExecT {
   // coordinates of the localization example sit under all fifty range rows) is summed by ALL lanes and the fixed
   // reduction tree of reduce().  No atomics: the same bits on every run.
   __device__ void coo_gather(const CooIdx& ix, const double* a, const double* v, double* out) {
+    DNLP_VEC_IN_LDS(BlockExecT, a); DNLP_VEC_IN_LDS(BlockExecT, v); DNLP_VEC_IN_LDS(BlockExecT, out);   // (values, operand and result are solver vectors)
     const i32* ptr = ix.ptr;
     const i32 *ent = ix.ent, *src = ix.src;
-    for (i64 g = threadIdx.x; g < ix.nout; g += kBatchThreads) {
+    for (i64 g = tid(); g < ix.nout; g += kBatchThreads) {
       const i64 p0 = ptr[g], p1 = ptr[g + 1];
       if (p1 - p0 > CooIdx::kHeavy) continue;
       double s = 0.0;
@@ -643,32 +665,32 @@ struct BlockExecT {
       const i64 g = ix.heavy[h];
       const i64 p0 = ptr[g];
       const double s = reduce<0>(ptr[g + 1] - p0, [=] __device__(i64 q) { return a[ent[p0 + q]] * v[src[p0 + q]]; });
-      if (threadIdx.x == 0) out[g] += s;
+      if (tid() == 0) out[g] += s;
     }
-    __syncthreads();
+    barrier();
   }
   // scatter form with atomics: only for patterns the tape did not index
   __device__ void coo_mult(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out, bool trans) {
-    for (i64 p = threadIdx.x; p < nnz; p += kBatchThreads) {
+    for (i64 p = tid(); p < nnz; p += kBatchThreads) {
       if (trans) unsafeAtomicAdd(&out[c[p]], a[p] * v[r[p]]);
       else unsafeAtomicAdd(&out[r[p]], a[p] * v[c[p]]);
     }
-    __syncthreads();
+    barrier();
   }
   __device__ void coo_sym_mult(i64 nnz, const i32* r, const i32* c, const double* a, const double* v, double* out) {
-    for (i64 p = threadIdx.x; p < nnz; p += kBatchThreads) {
+    for (i64 p = tid(); p < nnz; p += kBatchThreads) {
       const double av = a[p];
       unsafeAtomicAdd(&out[r[p]], av * v[c[p]]);
       if (r[p] != c[p]) unsafeAtomicAdd(&out[c[p]], av * v[r[p]]);
     }
-    __syncthreads();
+    barrier();
   }
 
   // ---- Bunch-Kaufman LDL^T by one workgroup (DSYTF2 semantics, lower storage) -------------
   // Same pivot rule, interchanges, multipliers and inertia count as bk_pivot_kernel /
   // bk_update_kernel of exec_hip.h and as the DSYTF2 restatement of the test oracle.
   __device__ bool ldlt_factor(LdltWork& lw, double* A, i64 nn, i64 ld, i32* ipiv, bool, int* nneg_out, int* nzero_out) {
-    const int n = static_cast<int>(nn), tid = threadIdx.x;
+    const int n = static_cast<int>(nn), tid = BlockExecT::tid();
     lw.standard = false;
     if (n <= 256) {
       // small instance: one wavefront, no workgroup barrier inside; L comes out in standard form
@@ -689,12 +711,12 @@ struct BlockExecT {
         }
         if (tid == 0) { redi[0] = ok ? 1 : 0; redi[1] = nn_; redi[2] = nz_; }
       }
-      __syncthreads();
+      barrier();
       const bool ok = redi[0] != 0;
       *nneg_out = redi[1];
       *nzero_out = redi[2];
       for (int i = tid; i < n; i += kBatchThreads) ipiv[i] = piv[i];
-      __syncthreads();
+      barrier();
       parity = 0;     // redi[0..2] were used outside the alternating scheme: restart it
       return ok;
     }
@@ -742,20 +764,20 @@ struct BlockExecT {
           Akk[j] = A[kp + static_cast<i64>(j) * ld];
           A[kp + static_cast<i64>(j) * ld] = t;
         }
-        __syncthreads();
+        barrier();
         if (tid == 0) {
           const double t = Akk[kk];
           Akk[kk] = Akp[kp];
           Akp[kp] = t;
           if (kstep == 2) { const double t2 = Ak[k + 1]; Ak[k + 1] = Ak[kp]; Ak[kp] = t2; }
         }
-        __syncthreads();
+        barrier();
       }
       if (zero_piv) {
         // structurally empty column: unit tiny pivot, reported through nzero
         if (tid == 0) { Ak[k] = 1e-20; ipiv[k] = k + 1; }
         ++nzero;
-        __syncthreads();
+        barrier();
         k += 1;
         continue;
       }
@@ -772,9 +794,9 @@ struct BlockExecT {
           double* Aj = A + static_cast<i64>(j) * ld;
           for (int i = j + lane; i < n; i += 64) Aj[i] -= Ak[i] * wj;
         }
-        __syncthreads();
+        barrier();
         for (int i = k + 1 + tid; i < n; i += kBatchThreads) Ak[i] *= inv;
-        __syncthreads();
+        barrier();
       } else {
         double* Ak1 = Ak + ld;
         double d21 = Ak[k + 1];
@@ -789,13 +811,13 @@ struct BlockExecT {
           double* Aj = A + static_cast<i64>(j) * ld;
           for (int i = j + lane; i < n; i += 64) Aj[i] -= Ak[i] * wk + Ak1[i] * wk1;
         }
-        __syncthreads();
+        barrier();
         for (int j = k + 2 + tid; j < n; j += kBatchThreads) {
           const double ajk = Ak[j], ajk1 = Ak1[j];
           Ak[j] = d21 * (d11 * ajk - ajk1);
           Ak1[j] = d21 * (d22 * ajk1 - ajk);
         }
-        __syncthreads();
+        barrier();
       }
       k += kstep;
     }
@@ -814,9 +836,9 @@ struct BlockExecT {
   // pivot vector are staged in LDS, wavefront 0 walks the columns (bk_solve_wave) and the other
   // wavefronts wait at one barrier.
   __device__ void ldlt_solve_wave(const double* A, int n, i64 ld, const i32* ipiv, double* b, bool standard) {
-    const int tid = threadIdx.x;
+    const int tid = BlockExecT::tid();
     for (int i = tid; i < n; i += kBatchThreads) { vec[i] = b[i]; piv[i] = ipiv[i]; }
-    __syncthreads();
+    barrier();
     if (tid < 64) {
       const int ldi = static_cast<int>(ld);
       if (standard) {
@@ -836,14 +858,14 @@ struct BlockExecT {
         bk_solve_wave(A, n, ldi, piv, vec);
       }
     }
-    __syncthreads();
+    barrier();
     for (int i = tid; i < n; i += kBatchThreads) b[i] = vec[i];
-    __syncthreads();
+    barrier();
   }
 
   // DSYTRS (lower) by one workgroup; b in exec-space memory
   __device__ void ldlt_solve(LdltWork& lw, const double* A, i64 nn, i64 ld, const i32* ipiv, bool, double* b) {
-    const int n = static_cast<int>(nn), tid = threadIdx.x;
+    const int n = static_cast<int>(nn), tid = BlockExecT::tid();
     if (n <= kWaveSolveMax) { ldlt_solve_wave(A, n, ld, ipiv, b, lw.standard); return; }
     int k = 0;
     while (k < n) {
@@ -851,20 +873,20 @@ struct BlockExecT {
       if (ipiv[k] > 0) {
         const int kp = ipiv[k] - 1;
         if (tid == 0 && kp != k) { const double t = b[k]; b[k] = b[kp]; b[kp] = t; }
-        __syncthreads();
+        barrier();
         const double bk = b[k];
         for (int i = k + 1 + tid; i < n; i += kBatchThreads) b[i] -= Ak[i] * bk;
-        __syncthreads();
+        barrier();
         if (tid == 0) b[k] = bk / Ak[k];
         k += 1;
       } else {
         const double* Ak1 = Ak + ld;
         const int kp = -ipiv[k] - 1;
         if (tid == 0 && kp != k + 1) { const double t = b[k + 1]; b[k + 1] = b[kp]; b[kp] = t; }
-        __syncthreads();
+        barrier();
         const double bk = b[k], bk1 = b[k + 1];
         for (int i = k + 2 + tid; i < n; i += kBatchThreads) b[i] -= Ak[i] * bk + Ak1[i] * bk1;
-        __syncthreads();
+        barrier();
         if (tid == 0) {
           const double akm1k = Ak[k + 1];
           const double akm1 = Ak[k] / akm1k, ak = Ak1[k + 1] / akm1k;
@@ -874,7 +896,7 @@ struct BlockExecT {
         }
         k += 2;
       }
-      __syncthreads();
+      barrier();
     }
     k = n - 1;
     while (k >= 0) {
@@ -889,7 +911,7 @@ struct BlockExecT {
         const int kp = (one ? ipiv[k] : -ipiv[k]) - 1;
         if (kp != k) { const double t = b[k]; b[k] = b[kp]; b[kp] = t; }
       }
-      __syncthreads();
+      barrier();
       k -= one ? 1 : 2;
     }
   }

@@ -1327,6 +1327,7 @@ fused_eval_kernel(FusedSlotProg P, const double* __restrict__ x, const double* _
 // pivot blocks in order (the update triples of a block are spread over the 256 lanes).
 struct WgPar {
   double* red;
+  template <class T> __device__ T* vec(T* p) const { return p; }
   __device__ int lanes() const { return kBlock; }
   __device__ int lane() const { return static_cast<int>(threadIdx.x); }
   __device__ void sync() const { __syncthreads(); }

@@ -143,16 +143,18 @@ class Ipm {
 
   // ---- problem data / iterate (exec space) ------------------------------------
   i64 N = 0, m = 0;
-  double *x = nullptr, *s = nullptr, *y = nullptr, *zL = nullptr, *zU = nullptr, *vL = nullptr, *vU = nullptr;
-  double *xL = nullptr, *xU = nullptr, *sL = nullptr, *sU = nullptr;   // scaled slack bounds
-  double *eqmask = nullptr;           // 1.0 for equality rows
-  double *grad = nullptr, *g = nullptr, *jv = nullptr, *sg = nullptr;
-  double *dx = nullptr, *ds = nullptr, *dy = nullptr, *dzL = nullptr, *dzU = nullptr, *dvL = nullptr, *dvU = nullptr;
-  double *xt = nullptr, *st = nullptr, *gt = nullptr;
-  double *rhs = nullptr, *sol = nullptr, *res = nullptr, *cor = nullptr, *Sx = nullptr, *Dd = nullptr, *Ss = nullptr;
-  double *rx = nullptr, *rs = nullptr, *rp = nullptr, *tN = nullptr, *tM = nullptr, *csoc = nullptr;
+  using V = VecP<E>;                  // (exec.h: a double* that knows when it is in LDS)
+  V x, s, y, zL, zU, vL, vU;
+  V xL, xU, sL, sU;                   // scaled slack bounds
+  V eqmask;                           // 1.0 for equality rows
+  V grad, g, jv, sg;
+  V dx, ds, dy, dzL, dzU, dvL, dvU;
+  V xt, st, gt;
+  V rhs, sol, res, cor, Sx, Dd, Ss;
+  V rx, rs, rp, tN, tM, csoc;
   double* rowmax_tmp_ = nullptr;      // 64 partial row maxima per constraint row (gradient-based scaling of long rows)
-  double *aff[7] = {nullptr}, *cen[7] = {nullptr}, *zeroM = nullptr;   // mu-oracle directions
+  V aff[7], cen[7];                   // mu-oracle directions
+  V zeroM;
   double sf = 1.0;
   double f = 0.0;                     // scaled objective at x
   double mu = 0.1, tau = 0.99;
@@ -1309,7 +1311,7 @@ class Ipm {
   // direction for barrier parameter muv with primal residual `pres` (rp or the SOC one)
   // `into`: the seven arrays the direction is written to (null: dx, ds, dy, dzL, dzU, dvL, dvU) — the mu oracle lets its
   // two solves write straight into aff[] / cen[] instead of copying seven arrays after each
-  DNLP_HD bool compute_direction(double muv, const double* pres, double dw, bool centering = false, double* const* into = nullptr) {
+  DNLP_HD bool compute_direction(double muv, const double* pres, double dw, bool centering = false, const V* into = nullptr) {
     DNLP_IPM_LDS();
     double* r = rhs;
     const double *rxx = rx, *q = rs, *sS = Ss, *eq = eqmask;
@@ -1318,7 +1320,8 @@ class Ipm {
     ex_->map(m, [=] DNLP_HD(i64 i) { r[NN + i] = -pres[i] - (eq[i] == 0.0 ? q[i] / (sS[i] + dw) : 0.0); });
     if (!solve_refined(dw)) return false;
     const double* so = sol;
-    double *ddx = into ? into[0] : dx, *dds = into ? into[1] : ds, *ddy = into ? into[2] : dy;
+    double *ddx = into ? static_cast<double*>(into[0]) : static_cast<double*>(dx), *dds = into ? static_cast<double*>(into[1]) : static_cast<double*>(ds),
+           *ddy = into ? static_cast<double*>(into[2]) : static_cast<double*>(dy);
     ex_->map(N, [=] DNLP_HD(i64 j) { ddx[j] = so[j]; });
     ex_->map(m, [=] DNLP_HD(i64 i) {
       ddy[i] = so[NN + i];
@@ -1326,7 +1329,8 @@ class Ipm {
     });
     // bound multiplier steps (WB eq. (12))
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *a = zL, *b = zU, *c = vL, *d = vU;
-    double *da = into ? into[3] : dzL, *db = into ? into[4] : dzU, *dc = into ? into[5] : dvL, *dd2 = into ? into[6] : dvU;
+    double *da = into ? static_cast<double*>(into[3]) : static_cast<double*>(dzL), *db = into ? static_cast<double*>(into[4]) : static_cast<double*>(dzU),
+           *dc = into ? static_cast<double*>(into[5]) : static_cast<double*>(dvL), *dd2 = into ? static_cast<double*>(into[6]) : static_cast<double*>(dvU);
     const double keep = centering ? 0.0 : 1.0;   // the centering direction has no "- z" term
     ex_->map(N, [=] DNLP_HD(i64 j) {
       da[j] = (l[j] > -kInf) ? (muv - a[j] * ddx[j]) / (xx[j] - l[j]) - keep * a[j] : 0.0;
@@ -2200,7 +2204,7 @@ class Ipm {
 #endif
   }
 
-  double* fixmask = nullptr;
+  V fixmask;
 
  private:
   E* ex_;

@@ -62,8 +62,8 @@ struct DenseKkt {
   bool sparse = false;
   bool skip_hessian = false;   // limited-memory quasi-Newton mode (ipm_core.h): the Hessian block is the diagonal the caller passes
   SparsePlan sp;
-  double* svals = nullptr;     // plan-layout values: assembled matrix, then (D, L)
-  double* swork = nullptr;     // scratch of the numeric phase (sparse_ldl_work_doubles)
+  VecP<E> svals;               // plan-layout values: assembled matrix, then (D, L)
+  VecP<E> swork;               // scratch of the numeric phase (sparse_ldl_work_doubles)
   i64 fallback_max_n = 0;      // orders up to which a structurally singular static pivot sequence
                                // makes the instance switch to the dense Bunch-Kaufman path
   DNLP_HD bool can_fallback() const { return sparse && n <= fallback_max_n; }

@@ -26,13 +26,13 @@ struct Model {
   TapeView t;                 // what the evaluators read (tape.h)
   Tape<E>* owner = nullptr;   // the loaded tape behind `t` (host / HIP spaces); null inside the batch kernel
   // work arrays (exec space)
-  double* xz = nullptr;     // [x; z]
-  double* dvals = nullptr;
-  double* hvals = nullptr;
-  double* w = nullptr;      // Z
-  double* sl = nullptr;     // [sigma; lambda]
-  double* Hs = nullptr;     // nnzH sparse-part Hessian values
-  double* tmpN = nullptr;   // N scratch (dense quad_form products)
+  VecP<E> xz;               // [x; z]
+  VecP<E> dvals;
+  VecP<E> hvals;
+  VecP<E> w;                // Z
+  VecP<E> sl;               // [sigma; lambda]
+  VecP<E> Hs;               // nnzH sparse-part Hessian values
+  VecP<E> tmpN;             // N scratch (dense quad_form products)
   double* dense_w = nullptr;   // control space: current weight 2*w_z of every dense block
 
   DNLP_HD i64 N() const { return t.N; }
@@ -70,6 +70,7 @@ struct Model {
     const i64* ptr = M.ptr;
     const i32* idx = M.idx;
     const double* val = M.val;
+    DNLP_VEC_IN_LDS(E, v); DNLP_VEC_IN_LDS(E, y);      // (operand and result are solver vectors; `base` and the map's values are tape data)
     ex->map(M.rows, [=] DNLP_HD(i64 r) {
       double s = base ? base[r] : 0.0;
       for (i64 k = ptr[r]; k < ptr[r + 1]; ++k) s += val[k] * v[idx[k]];

@@ -18,6 +18,7 @@ struct SeqPar {
   DNLP_HD int lane() const { return 0; }
   DNLP_HD void sync() const {}
   DNLP_HD double sum(double v) const { return v; }
+  template <class T> DNLP_HD T* vec(T* p) const { return p; }     // (a policy may know in which address space the vectors live)
 };
 
 // work: nvals (w, laid out like the L values) + 3 * nblk (inverse pivot blocks)
@@ -117,6 +118,7 @@ DNLP_HD inline void sp_dsolve(const SparsePlan& pl, const double* vals, double* 
 template <class P>
 DNLP_HD inline bool sparse_ldl_factor(const SparsePlan& pl, double* vals, double* work, int* nneg_out, int* nzero_out, P par) {
   const int L = par.lanes(), me = par.lane();
+  vals = par.vec(vals); work = par.vec(work);
   double* w = work;
   double* dinv = work + pl.nvals;
   double nneg = 0.0, nzero = 0.0, bad = 0.0;
@@ -195,6 +197,7 @@ DNLP_HD inline bool sparse_ldl_factor(const SparsePlan& pl, double* vals, double
 template <class P>
 DNLP_HD inline void sparse_ldl_solve(const SparsePlan& pl, const double* vals, double* x, P par) {
   const int L = par.lanes(), me = par.lane();
+  vals = par.vec(vals); x = par.vec(x);
   // forward, level by level, in GATHER form: a node of level lev collects the struct rows that point at it (all from
   // blocks of lower levels, so their x entries are final), in ascending row order, and is final itself afterwards
   // (a plan with a dense tail runs the levels before it in two calls: solve_phase 1, the tail's dense solve, then 2;
