@@ -646,7 +646,7 @@ struct BlockExecT {
   __device__ void dense_block_add(double*, i64, i64, const double*, i64, i64, double, bool) { __builtin_trap(); }
   __device__ void ldlt_prepare(LdltWork&, i64, i64, bool) {}
 
-  // out += J v / J^T v / sym(H) v through the tape's index by output (tape.h CooIdx): a lane owns an output and sums
+  // out = J v / J^T v / sym(H) v through the tape's index by output (tape.h CooIdx): a lane owns an output and sums
   // its segment serially, in storage order; an output with a long segment (a variable under many rows: both position
   // coordinates of the localization example sit under all fifty range rows) is summed by ALL lanes and the fixed
   // reduction tree of reduce().  No atomics: the same bits on every run.
@@ -659,13 +659,13 @@ struct BlockExecT {
       if (p1 - p0 > CooIdx::kHeavy) continue;
       double s = 0.0;
       for (i64 p = p0; p < p1; ++p) s += a[ent[p]] * v[src[p]];
-      out[g] += s;
+      out[g] = s;                    // (assigned: no zeroing pass before the product)
     }
     for (i64 h = 0; h < ix.nheavy; ++h) {
       const i64 g = ix.heavy[h];
       const i64 p0 = ptr[g];
       const double s = reduce<0>(ptr[g + 1] - p0, [=] __device__(i64 q) { return a[ent[p0 + q]] * v[src[p0 + q]]; });
-      if (tid() == 0) out[g] += s;
+      if (tid() == 0) out[g] = s;
     }
     barrier();
   }

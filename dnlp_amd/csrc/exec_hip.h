@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(kBlock) coo_mult_kernel(i64 nnz, const i32* __
 
 // Order-fixed COO product: the entries that feed one output are a segment of an index built once per pattern
 // (tape.h CooIdx: counting sort by output, storage order inside a segment), sixteen lanes walk a segment in
-// strides and reduce in a fixed tree, ONE lane adds the sum to out[g].  No atomics: the sum of an output is rounded
+// strides and reduce in a fixed tree, ONE lane assigns the sum to out[g].  No atomics: the sum of an output is rounded
 // in the same order on every run (with atomics portfolio construction ended after 22 to 72 iterations from run to
 // run, with this after 22 every time: profiles/r03_determinism.txt).
 __global__ void __launch_bounds__(kBlock) coo_rows_kernel(i64 nout, const i32* __restrict__ ptr, const i32* __restrict__ ent,
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(kBlock) coo_rows_kernel(i64 nout, const i32* _
   s += __shfl_xor(s, 4, 16);
   s += __shfl_xor(s, 2, 16);
   s += __shfl_xor(s, 1, 16);
-  if (l == 0 && p1 > p0) out[g] += s;
+  if (l == 0 && g < nout) out[g] = s;      // assigned (an output without entries becomes 0): no memset before the product
 }
 
 // Products with a rectangular Jacobian stored row-major (tape.h jac_rect_cols: every row carries the same L columns),
@@ -2178,7 +2178,8 @@ struct HipExec : HostControlled {
   // Order-fixed products through the tape's index by output (tape.h CooIdx, built when the tape is loaded — no lazy
   // index keyed by device pointers, nothing built inside a product): sixteen lanes per output, fixed reduction tree.
   void coo_gather(const CooIdx& ix, const double* a, const double* v, double* out) {
-    if (ix.nout <= 0 || ix.total <= 0) return;
+    if (ix.nout <= 0) return;
+    if (ix.total <= 0) { DNLP_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double) * static_cast<size_t>(ix.nout), stream)); return; }   // (the product ASSIGNS)
     hipLaunchKernelGGL(coo_rows_kernel, dim3(static_cast<unsigned>((ix.nout * 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
                        ix.nout, ix.ptr, ix.ent, ix.src, a, v, out);
   }

@@ -483,6 +483,7 @@ class Ipm {
   // gradient and Jacobian values at the point of the last sweep (scaled)
   DNLP_HD void eval_derivs_after_sweep() {
     DNLP_IPM_LDS();
+    jty_valid_ = false;
     double t0 = now_sec();
     md_->eval_grad_after_sweep(grad);
     md_->eval_jac_after_sweep(jv);
@@ -642,6 +643,7 @@ class Ipm {
     (void)NN;
     mu = opt.mu_init;
     tau = std::max(0.99, 1.0 - mu);
+    jty_valid_ = false;
     ex_->zero(y, sizeof(double) * static_cast<size_t>(m));
     if (warm) {
       // given multipliers -> scaled problem: y~ = y sf / sg, z~ = z sf; bound multipliers of the
@@ -689,6 +691,7 @@ class Ipm {
   // least-squares equality multipliers (WB eq. (36)); discarded above constr_mult_init_max
   DNLP_HD void init_multipliers_ls() {
     DNLP_IPM_LDS();
+    jty_valid_ = false;                 // (y is about to change)
     const double* eq = eqmask;
     if constexpr (E::has_host_control) if (!kkt_->pivoted && m <= 8) {
       // Few rows on a large system: the (1,1) block of the least-squares system is the identity,
@@ -867,14 +870,25 @@ class Ipm {
     return Measures{R.sm[0], fv + muv * R.sm[1], R.sm[2]};
   }
 
+  // J^T y of the current (Jacobian values, multipliers), kept in tN: the dual residuals, the three barrier_terms of a
+  // free-mode iteration and the directional derivative of the line search all need it, and it changes only when the
+  // point is accepted (eval_derivs_after_sweep) or the multipliers are reset — one product per iteration instead of
+  // five.  (kkt_residual's own J^T v goes to xt, which is free whenever a system is solved.)
+  DNLP_HD const double* jty() {
+    DNLP_IPM_LDS();
+    if (!jty_valid_) { md_->jac_tmult(jv, y, tN); jty_valid_ = true; }
+    return tN;
+  }
   // dual residuals rx = grad + J^T y - zL + zU ; rs = -y - vL + vU (inequality rows)
   DNLP_HD void dual_residuals() {
     DNLP_IPM_LDS();
-    md_->jac_tmult(jv, y, tN);
+    const double* jt = jty();
     double *r = rx, *q = rs;
-    const double *gr = grad, *jt = tN, *a = zL, *b = zU, *c = vL, *d = vU, *yy = y, *eq = eqmask, *fm = fixmask;
-    ex_->map(N, [=] DNLP_HD(i64 j) { r[j] = fm[j] != 0.0 ? 0.0 : gr[j] + jt[j] - a[j] + b[j]; });
-    ex_->map(m, [=] DNLP_HD(i64 i) { q[i] = (eq[i] == 0.0) ? -yy[i] - c[i] + d[i] : 0.0; });
+    const double *gr = grad, *a = zL, *b = zU, *c = vL, *d = vU, *yy = y, *eq = eqmask, *fm = fixmask;
+    const i64 NN = N;
+    ex_->map(N + m, [=] DNLP_HD(i64 k) {
+      if (k < NN) { const i64 j = k; r[j] = fm[j] != 0.0 ? 0.0 : gr[j] + jt[j] - a[j] + b[j]; }
+      else { const i64 i = k - NN; q[i] = (eq[i] == 0.0) ? -yy[i] - c[i] + d[i] : 0.0; } });
   }
 
   struct Err { double dual, primal, cmpl, sd, sc, total, primal_unscaled; };
@@ -945,12 +959,15 @@ class Ipm {
   // Builds Sigma and the barrier right-hand sides for barrier parameter muv.
   DNLP_HD void barrier_terms(double muv) {
     DNLP_IPM_LDS();
-    md_->jac_tmult(jv, y, tN);
+    const double* jt = jty();
     double *sx = Sx, *sS = Ss, *r = rx, *q = rs, *p = rp;
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *eq = eqmask, *xx = x, *ss = s, *a = zL, *b = zU,
-                 *c = vL, *d = vU, *gr = grad, *jt = tN, *yy = y, *gg = g, *fm = fixmask;
+                 *c = vL, *d = vU, *gr = grad, *yy = y, *gg = g, *fm = fixmask;
     const double kd = opt.kappa_d;
-    ex_->map(N, [=] DNLP_HD(i64 j) {
+    const i64 NN = N;
+    ex_->map(N + m, [=] DNLP_HD(i64 k) {
+      if (k < NN) {
+      const i64 j = k;
       double sig = 0.0, gphi = gr[j];
       const bool hl = l[j] > -kInf, hu = u[j] < kInf;
       if (hl) { sig += a[j] / (xx[j] - l[j]); gphi -= muv / (xx[j] - l[j]); }
@@ -959,8 +976,9 @@ class Ipm {
       if (hu && !hl) gphi -= kd * muv;
       sx[j] = sig;
       r[j] = fm[j] != 0.0 ? 0.0 : gphi + jt[j];             // grad_x phi + J^T y
-    });
-    ex_->map(m, [=] DNLP_HD(i64 i) {
+      return;
+      }
+      const i64 i = k - NN;
       if (eq[i] != 0.0) { sS[i] = 0.0; q[i] = 0.0; p[i] = gg[i] - sl[i]; return; }
       double sig = 0.0, gphi = 0.0;
       const bool hl = sl[i] > -kInf, hu = su[i] < kInf;
@@ -1239,18 +1257,27 @@ class Ipm {
     return false;
   }
 
-  // K v for the reduced system at the current iterate (for iterative refinement)
-  DNLP_HD void kkt_mult(const double* v, double dw, double* out) {
+  // out = rhsv - K v and, in the same pass, max |out| and max |v| (the refinement's residual, its norm and the
+  // solution norm: one pass over [variables | constraint rows] after the three products instead of two maps and a reduction)
+  DNLP_HD RMulti kkt_residual(const double* v, double dw, const double* rhsv, double* out) {
     DNLP_IPM_LDS();
     bool quasi = false;
     if constexpr (E::has_host_control) if (lm_on()) { lm_hess_mult(v, out); quasi = true; }
     if (!quasi) md_->hess_mult(v, out);
-    md_->jac_tmult(jv, v + N, tN);
+    md_->jac_tmult(jv, v + N, xt);
     md_->jac_mult(jv, v, tM);
-    const double *sx = Sx, *jt = tN, *jx = tM, *dd = Dd, *fm = fixmask;
+    const double *sx = Sx, *jt = xt, *jx = tM, *dd = Dd, *fm = fixmask;
     const i64 NN = N;
-    ex_->map(N, [=] DNLP_HD(i64 j) { out[j] = fm[j] != 0.0 ? v[j] : out[j] + (sx[j] + dw) * v[j] + jt[j]; });
-    ex_->map(m, [=] DNLP_HD(i64 i) { out[NN + i] = jx[i] - dd[i] * v[NN + i]; });
+    return ex_->template reduce_multi<2, 0>(N + m, [=] DNLP_HD(i64 k) -> RMulti {
+      double kv;
+      if (k < NN) kv = fm[k] != 0.0 ? v[k] : out[k] + (sx[k] + dw) * v[k] + jt[k];
+      else kv = jx[k - NN] - dd[k - NN] * v[k];
+      const double r = rhsv[k] - kv;
+      out[k] = r;
+      RMulti w;
+      w.mx[0] = fabs(r); w.mx[1] = fabs(v[k]); w.mx[2] = w.mx[3] = 0.0;
+      w.sm[0] = w.sm[1] = w.sm[2] = w.sm[3] = 0.0;
+      return w; });
   }
 
   // solve K sol = rhs with iterative refinement on the unfactored operator
@@ -1263,15 +1290,7 @@ class Ipm {
     double best = kInf;
     bool fresh = false;          // last_ratio_ already belongs to the current sol (loop left right after its residual)
     for (int it = 0; it < opt.max_refine; ++it) {
-      kkt_mult(sol, dw, res);
-      double* re = res;
-      ex_->map(N + m, [=] DNLP_HD(i64 i) { re[i] = rr[i] - re[i]; });
-      const double* so = sol;
-      const RMulti Rn = ex_->template reduce_multi<2, 0>(N + m, [=] DNLP_HD(i64 i) -> RMulti {
-        RMulti v;
-        v.mx[0] = fabs(re[i]); v.mx[1] = fabs(so[i]); v.mx[2] = v.mx[3] = 0.0;
-        v.sm[0] = v.sm[1] = v.sm[2] = v.sm[3] = 0.0;
-        return v; });
+      const RMulti Rn = kkt_residual(sol, dw, rhs, res);
       double en = Rn.mx[0], sn = Rn.mx[1];
       // (IPOPT's ComputeResidualRatio caps the solution norm at 1e6 x the right-hand side's; tried here in round 3:
       //  near a stationary point of the barrier problem the right-hand side is tiny against a legitimate solution,
@@ -1291,14 +1310,7 @@ class Ipm {
       fresh = false;
     }
     if (!fresh) {
-      kkt_mult(sol, dw, res);
-      double* re = res;
-      const double* so = sol;
-      const RMulti Rn = ex_->template reduce_multi<2, 0>(N + m, [=] DNLP_HD(i64 i) -> RMulti {
-        RMulti v;
-        v.mx[0] = fabs(rr[i] - re[i]); v.mx[1] = fabs(so[i]); v.mx[2] = v.mx[3] = 0.0;
-        v.sm[0] = v.sm[1] = v.sm[2] = v.sm[3] = 0.0;
-        return v; });
+      const RMulti Rn = kkt_residual(sol, dw, rhs, res);
       const double en = Rn.mx[0], sn = Rn.mx[1];
       last_ratio_ = en / (std::max(rn, 1e-300) + sn);
       if (!std::isfinite(last_ratio_)) last_ratio_ = kInf;
@@ -1316,31 +1328,34 @@ class Ipm {
     double* r = rhs;
     const double *rxx = rx, *q = rs, *sS = Ss, *eq = eqmask;
     const i64 NN = N;
-    ex_->map(N, [=] DNLP_HD(i64 j) { r[j] = -rxx[j]; });
-    ex_->map(m, [=] DNLP_HD(i64 i) { r[NN + i] = -pres[i] - (eq[i] == 0.0 ? q[i] / (sS[i] + dw) : 0.0); });
+    ex_->map(N + m, [=] DNLP_HD(i64 k) {
+      if (k < NN) r[k] = -rxx[k];
+      else { const i64 i = k - NN; r[k] = -pres[i] - (eq[i] == 0.0 ? q[i] / (sS[i] + dw) : 0.0); } });
     if (!solve_refined(dw)) return false;
     const double* so = sol;
     double *ddx = into ? static_cast<double*>(into[0]) : static_cast<double*>(dx), *dds = into ? static_cast<double*>(into[1]) : static_cast<double*>(ds),
            *ddy = into ? static_cast<double*>(into[2]) : static_cast<double*>(dy);
-    ex_->map(N, [=] DNLP_HD(i64 j) { ddx[j] = so[j]; });
-    ex_->map(m, [=] DNLP_HD(i64 i) {
-      ddy[i] = so[NN + i];
-      dds[i] = (eq[i] == 0.0) ? (so[NN + i] - q[i]) / (sS[i] + dw) : 0.0;
-    });
-    // bound multiplier steps (WB eq. (12))
+    // bound multiplier steps (WB eq. (12)); one pass over [variables | constraint rows]
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *a = zL, *b = zU, *c = vL, *d = vU;
     double *da = into ? static_cast<double*>(into[3]) : static_cast<double*>(dzL), *db = into ? static_cast<double*>(into[4]) : static_cast<double*>(dzU),
            *dc = into ? static_cast<double*>(into[5]) : static_cast<double*>(dvL), *dd2 = into ? static_cast<double*>(into[6]) : static_cast<double*>(dvU);
     const double keep = centering ? 0.0 : 1.0;   // the centering direction has no "- z" term
-    ex_->map(N, [=] DNLP_HD(i64 j) {
-      da[j] = (l[j] > -kInf) ? (muv - a[j] * ddx[j]) / (xx[j] - l[j]) - keep * a[j] : 0.0;
-      db[j] = (u[j] < kInf) ? (muv + b[j] * ddx[j]) / (u[j] - xx[j]) - keep * b[j] : 0.0;
-    });
-    ex_->map(m, [=] DNLP_HD(i64 i) {
-      const bool in = eq[i] == 0.0;
-      dc[i] = (in && sl[i] > -kInf) ? (muv - c[i] * dds[i]) / (ss[i] - sl[i]) - keep * c[i] : 0.0;
-      dd2[i] = (in && su[i] < kInf) ? (muv + d[i] * dds[i]) / (su[i] - ss[i]) - keep * d[i] : 0.0;
-    });
+    ex_->map(N + m, [=] DNLP_HD(i64 k) {
+      if (k < NN) {
+        const i64 j = k;
+        const double dxj = so[j];
+        ddx[j] = dxj;
+        da[j] = (l[j] > -kInf) ? (muv - a[j] * dxj) / (xx[j] - l[j]) - keep * a[j] : 0.0;
+        db[j] = (u[j] < kInf) ? (muv + b[j] * dxj) / (u[j] - xx[j]) - keep * b[j] : 0.0;
+      } else {
+        const i64 i = k - NN;
+        const bool in = eq[i] == 0.0;
+        const double dsi = in ? (so[NN + i] - q[i]) / (sS[i] + dw) : 0.0;
+        ddy[i] = so[NN + i];
+        dds[i] = dsi;
+        dc[i] = (in && sl[i] > -kInf) ? (muv - c[i] * dsi) / (ss[i] - sl[i]) - keep * c[i] : 0.0;
+        dd2[i] = (in && su[i] < kInf) ? (muv + d[i] * dsi) / (su[i] - ss[i]) - keep * d[i] : 0.0;
+      } });
     return true;
   }
 
@@ -1491,9 +1506,9 @@ class Ipm {
     const double phi_k = mk.phi;
     double gphid;   // directional derivative of the barrier function
     {
-      const double *rxx = rx, *jt = tN, *ddx = dx, *q = rs, *yy = y, *dds = ds, *eq = eqmask;
-      // rx = grad_x phi + J^T y  and  tN still holds J^T y from barrier_terms
-      md_->jac_tmult(jv, y, tN);
+      const double *rxx = rx, *ddx = dx, *q = rs, *yy = y, *dds = ds, *eq = eqmask;
+      // rx = grad_x phi + J^T y
+      const double* jt = jty();
       const i64 NN = N;
       gphid = ex_->sum(N + m, [=] DNLP_HD(i64 k) {
         if (k < NN) return (rxx[k] - jt[k]) * ddx[k];
@@ -1618,17 +1633,22 @@ class Ipm {
     DNLP_IPM_LDS();
     double *a = xt, *b = st;
     const double *xx = x, *ss = s, *ddx = dx, *dds = ds, *eq = eqmask, *sl = sL;
-    ex_->map(N, [=] DNLP_HD(i64 j) { a[j] = xx[j] + alpha * ddx[j]; });
-    ex_->map(m, [=] DNLP_HD(i64 i) { b[i] = eq[i] != 0.0 ? sl[i] : ss[i] + alpha * dds[i]; });
+    const i64 NN = N;
+    ex_->map(N + m, [=] DNLP_HD(i64 k) {
+      if (k < NN) a[k] = xx[k] + alpha * ddx[k];
+      else { const i64 i = k - NN; b[i] = eq[i] != 0.0 ? sl[i] : ss[i] + alpha * dds[i]; } });
   }
 
   DNLP_HD void accept_trial(double alpha, double a_z, double f_new) {
     DNLP_IPM_LDS();
     double *xx = x, *ss = s, *yy = y, *a = zL, *b = zU, *c = vL, *d = vU;
     const double *nx = xt, *ns = st, *ddy = dy, *da = dzL, *db = dzU, *dc = dvL, *dd2 = dvU;
-    ex_->map(N, [=] DNLP_HD(i64 j) { xx[j] = nx[j]; a[j] += a_z * da[j]; b[j] += a_z * db[j]; });
-    ex_->map(m, [=] DNLP_HD(i64 i) { ss[i] = ns[i]; yy[i] += alpha * ddy[i]; c[i] += a_z * dc[i]; d[i] += a_z * dd2[i]; });
-    ex_->d2d(g, gt, sizeof(double) * static_cast<size_t>(m));
+    double* gg = g;
+    const double* gn = gt;
+    const i64 NN = N;
+    ex_->map(N + m, [=] DNLP_HD(i64 k) {
+      if (k < NN) { const i64 j = k; xx[j] = nx[j]; a[j] += a_z * da[j]; b[j] += a_z * db[j]; }
+      else { const i64 i = k - NN; ss[i] = ns[i]; yy[i] += alpha * ddy[i]; c[i] += a_z * dc[i]; d[i] += a_z * dd2[i]; gg[i] = gn[i]; } });
     f = f_new;
     // derivatives at the accepted point: the last sweep was the accepted trial only if no
     // later trial was evaluated, so sweep again (cheap relative to the factorisation)
@@ -1643,11 +1663,15 @@ class Ipm {
     const double kS = 1e10, muv = mu;
     const double *l = xL, *u = xU, *sl = sL, *su = sU, *xx = x, *ss = s, *eq = eqmask;
     double *a = zL, *b = zU, *c = vL, *d = vU;
-    ex_->map(N, [=] DNLP_HD(i64 j) {
-      if (l[j] > -kInf) { double t = xx[j] - l[j]; a[j] = fmax(fmin(a[j], kS * muv / t), muv / (kS * t)); }
-      if (u[j] < kInf) { double t = u[j] - xx[j]; b[j] = fmax(fmin(b[j], kS * muv / t), muv / (kS * t)); }
-    });
-    ex_->map(m, [=] DNLP_HD(i64 i) {
+    const i64 NN = N;
+    ex_->map(N + m, [=] DNLP_HD(i64 k) {
+      if (k < NN) {
+        const i64 j = k;
+        if (l[j] > -kInf) { double t = xx[j] - l[j]; a[j] = fmax(fmin(a[j], kS * muv / t), muv / (kS * t)); }
+        if (u[j] < kInf) { double t = u[j] - xx[j]; b[j] = fmax(fmin(b[j], kS * muv / t), muv / (kS * t)); }
+        return;
+      }
+      const i64 i = k - NN;
       if (eq[i] != 0.0) return;
       if (sl[i] > -kInf) { double t = ss[i] - sl[i]; c[i] = fmax(fmin(c[i], kS * muv / t), muv / (kS * t)); }
       if (su[i] < kInf) { double t = su[i] - ss[i]; d[i] = fmax(fmin(d[i], kS * muv / t), muv / (kS * t)); }
@@ -1801,8 +1825,6 @@ class Ipm {
     const i64 nb = n_bound_mults();
     if (!(avg > 0.0) || nb == 0) return false;
     const double mu_floor = mu_floor_now();
-    double* cur[7] = {dx, ds, dy, dzL, dzU, dvL, dvU};
-    const i64 sz[7] = {N, m, m, N, N, m, m};
     barrier_terms(0.0);
     const double *rxx = rx, *rss = rs, *rpp = rp;
     const i64 NN0 = N;
@@ -1824,16 +1846,20 @@ class Ipm {
       double *r = rx, *q = rs;
       const double *l = xL, *u = xU, *sl = sL, *su = sU, *eq = eqmask, *xx = x, *ss = s, *fm = fixmask;
       const double kd = opt.kappa_d;
-      ex_->map(N, [=] DNLP_HD(i64 j) {
-        double c = 0.0;
-        const bool hl = l[j] > -kInf, hu = u[j] < kInf;
-        if (hl) c -= 1.0 / (xx[j] - l[j]);
-        if (hu) c += 1.0 / (u[j] - xx[j]);
-        if (hl && !hu) c += kd;
-        if (hu && !hl) c -= kd;
-        r[j] = fm[j] != 0.0 ? 0.0 : c;
-      });
-      ex_->map(m, [=] DNLP_HD(i64 i) {
+      const i64 NN1 = N;
+      ex_->map(N + m, [=] DNLP_HD(i64 k) {
+        if (k < NN1) {
+          const i64 j = k;
+          double c = 0.0;
+          const bool hl = l[j] > -kInf, hu = u[j] < kInf;
+          if (hl) c -= 1.0 / (xx[j] - l[j]);
+          if (hu) c += 1.0 / (u[j] - xx[j]);
+          if (hl && !hu) c += kd;
+          if (hu && !hl) c -= kd;
+          r[j] = fm[j] != 0.0 ? 0.0 : c;
+          return;
+        }
+        const i64 i = k - NN1;
         double c = 0.0;
         if (eq[i] == 0.0) {
           const bool hl = sl[i] > -kInf, hu = su[i] < kInf;
@@ -1963,10 +1989,18 @@ class Ipm {
     filter_clear();                   // free mode: every iteration is a new barrier problem
     barrier_terms(mu);                // residuals for the chosen mu (line search, SOC)
     const double muv = mu;
-    for (int k = 0; k < 7; ++k) {
-      double* o = cur[k];
-      const double *p1 = aff[k], *p2 = cen[k];
-      ex_->map(sz[k], [=] DNLP_HD(i64 i) { o[i] = p1[i] + muv * p2[i]; });
+    {
+      // direction(mu) = aff + mu cen, all seven arrays in one pass over [variables | constraint rows]
+      double *o0 = dx, *o1 = ds, *o2 = dy, *o3 = dzL, *o4 = dzU, *o5 = dvL, *o6 = dvU;
+      const double *ay = aff[2], *cy = cen[2];
+      const i64 NN2 = N;
+      ex_->map(N + m, [=] DNLP_HD(i64 k) {
+        if (k < NN2) {
+          o0[k] = ax[k] + muv * cx[k]; o3[k] = aa[k] + muv * ca[k]; o4[k] = ab[k] + muv * cb[k];
+        } else {
+          const i64 i = k - NN2;
+          o1[i] = as[i] + muv * cs[i]; o2[i] = ay[i] + muv * cy[i]; o5[i] = ac[i] + muv * cc[i]; o6[i] = ad[i] + muv * cd[i];
+        } });
     }
     return true;
   }
@@ -2035,6 +2069,7 @@ class Ipm {
       if (th_cur <= 0.9 * theta_k && th_cur <= theta_max && filter_ok(th_cur, ph)) {
         // reset multipliers as IPOPT does after restoration
         ex_->zero(y, sizeof(double) * static_cast<size_t>(m));
+        jty_valid_ = false;
         const double zi = 1.0;
         const double *l = xL, *u = xU, *su = sU;
         double *za = zL, *zb = zU, *c = vL, *d = vU;
@@ -2220,6 +2255,7 @@ class Ipm {
   int ladder_rung_ = 0;             // 0: first run; 1, 2: rungs of the retry ladder
   static constexpr double kStallAlpha = 1e-2;   // stall guard: a step that keeps at most this much of the Newton step ...
   static constexpr int kStallSteps = 30;        // ... this many times in a row, without progress (see step())
+  bool jty_valid_ = false;          // tN holds J^T y of the current Jacobian values and multipliers (jty())
   int tiny_streak_ = 0;             // consecutive accepted steps with alpha_pr <= kStallAlpha (stall guard)
   double streak_theta0_ = 0.0, streak_f0_ = 0.0;   // violation / objective when the current streak began
   bool in_solve_ = false;           // inside solve() (the retry ladder exists) as opposed to begin() / step() calls

@@ -1124,6 +1124,104 @@ __global__ void __launch_bounds__(SI_T) ldlt_fwd_step_kernel(const double* __res
   }
 }
 
+// ---- the whole sweep in ONE launch: dataflow over the 128-blocks (round 4) ---------------------------------------
+// The step kernels above are a chain of 43 dependent launches per sweep at order 11 000 (22-25 us each: launch boundary,
+// one compute unit's cold pull of the step's operands).  Here every 128-row block of the right-hand side has its own
+// workgroup, resident for the whole sweep (cooperative launch: at most one workgroup per compute unit, order up to
+// 128 x CUs): workgroup i waits for block k < i to be published (a generation word per block in global memory, polled by
+// one lane), subtracts L[i, k] y_k — the 128 x 128 tile was fetched into registers BEFORE the wait, the next tile is on
+// its way during the product — and, after block i - 1, multiplies with the inverted diagonal block and publishes
+// block i.  The dependent part of a step is: see the flag, read 1 KB of y, two LDS-reduced tile products, a fence and
+// the flag — no launch boundary, nothing cold.  The transposed sweep mirrors it from the last block (tiles read with
+// the lanes on the rows, the contiguous direction; column sums by DPP).
+struct SweepCtl { unsigned gen; unsigned abort; unsigned pad[30]; };
+__device__ inline bool sweep_wait(const unsigned* word, unsigned gen, unsigned* abort_word, int* s_ok, int tid) {
+  if (tid == 0) {
+    unsigned spins = 0;
+    int ok = 1;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 1023u) == 0u && (spins > (1u << 22) || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+        __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    __threadfence();                       // acquire: the published block is visible after the flag
+    *s_ok = ok;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+__global__ void __launch_bounds__(SI_T) ldlt_fwd_sweep_kernel(const double* __restrict__ A, i64 ld, int n, double* __restrict__ b,
+                                                              const double* __restrict__ inv, unsigned* __restrict__ ready,
+                                                              SweepCtl* __restrict__ ctl, unsigned gen) {
+  __shared__ double y[SI_H];
+  __shared__ double acc[SI_H];
+  __shared__ double part[SI_T];
+  __shared__ int s_ok;
+  const int tid = threadIdx.x, i = blockIdx.x, r0 = i * SI_H;
+  if (tid < SI_H) acc[tid] = (r0 + tid < n) ? b[r0 + tid] : 0.0;
+  SiTile cur, nxt, ti;
+  si_tile_load(ti, inv + static_cast<i64>(i) * (SI_H * SI_H), SI_H, tid);
+  if (i > 0) si_tile_load(cur, A + r0, ld, tid);                               // tile (i, 0)   (rows past n: padded allocation)
+  for (int k = 0; k < i; ++k) {
+    if (k + 1 < i) si_tile_load(nxt, A + r0 + static_cast<i64>(k + 1) * SI_H * ld, ld, tid);
+    if (!sweep_wait(ready + k, gen, &ctl->abort, &s_ok, tid)) return;
+    if (tid < SI_H) y[tid] = b[k * SI_H + tid];
+    __syncthreads();
+    si_tile_vec(cur, y, part, tid);
+    if (tid < SI_H) acc[tid] -= si_part_sum(part, tid);
+    __syncthreads();
+    cur = nxt;
+  }
+  si_tile_vec(ti, acc, part, tid);
+  if (tid < SI_H && r0 + tid < n) b[r0 + tid] = si_part_sum(part, tid);
+  __threadfence();                           // release: the block before its flag
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(ready + i, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// L^T x = y.  Workgroup i owns block i and waits for the blocks k > i, last first.  Tile (k, i): rows of block k (the
+// lanes: contiguous), columns of block i — column sums over the 128 rows by two wavefront DPP sums each.
+__global__ void __launch_bounds__(SI_T) ldlt_bwd_sweep_kernel(const double* __restrict__ A, i64 ld, int n, double* __restrict__ b,
+                                                              const double* __restrict__ invT, unsigned* __restrict__ ready,
+                                                              SweepCtl* __restrict__ ctl, unsigned gen, int nblk) {
+  __shared__ double x[SI_H];
+  __shared__ double acc[SI_H];
+  __shared__ double part[SI_T];
+  __shared__ double colp[2][SI_H];
+  __shared__ int s_ok;
+  const int tid = threadIdx.x, i = blockIdx.x, c0 = i * SI_H;
+  const int lane = tid & 63, half = (tid >> 6) & 1, ch = __builtin_amdgcn_readfirstlane(tid >> 7);
+  if (tid < SI_H) acc[tid] = (c0 + tid < n) ? b[c0 + tid] : 0.0;
+  SiTile cur, nxt, ti;
+  si_tile_load(ti, invT + static_cast<i64>(i) * (SI_H * SI_H), SI_H, tid);
+  if (i + 1 < nblk) si_tile_load(cur, A + static_cast<i64>(nblk - 1) * SI_H + static_cast<i64>(c0) * ld, ld, tid);      // tile (nblk - 1, i)
+  for (int k = nblk - 1; k > i; --k) {
+    if (k - 1 > i) si_tile_load(nxt, A + static_cast<i64>(k - 1) * SI_H + static_cast<i64>(c0) * ld, ld, tid);
+    if (!sweep_wait(ready + k, gen, &ctl->abort, &s_ok, tid)) return;
+    if (tid < SI_H) x[tid] = (k * SI_H + tid < n) ? b[k * SI_H + tid] : 0.0;       // (rows past n of the last block: no contribution)
+    __syncthreads();
+    {
+      const double xr = x[tid & (SI_H - 1)];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double sum = wave_all_sum(cur.v[c] * xr);
+        if (lane == c) colp[half][16 * ch + c] = sum;          // (lane c keeps column c's sum: sixteen lanes write, no serial tail)
+      }
+    }
+    __syncthreads();
+    if (tid < SI_H) acc[tid] -= colp[0][tid] + colp[1][tid];
+    __syncthreads();
+    cur = nxt;
+  }
+  si_tile_vec(ti, acc, part, tid);
+  if (tid < SI_H && c0 + tid < n) b[c0 + tid] = si_part_sum(part, tid);
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(ready + i, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // One step of L^T x = b, blocks from the last to the first.  j0 = block whose x is final (j0 >= n: prologue, only the
 // last block is solved).  Workgroup 0: columns of the previous block jp = j0 - 256: bp -= L[j0.., jp..)^T x, then
 // xp = Lpp^-T bp through the two transposed inverses.  Workgroups g >= 1: 64 columns from 64 (g - 1) below jp.
@@ -1527,6 +1625,64 @@ struct BlockedLdlt {
     return cur.fail == 0;
   }
 
+  // The two sweeps as ONE cooperative launch each (ldlt_fwd_sweep_kernel / ldlt_bwd_sweep_kernel).  false: not possible
+  // here (more 128-blocks than compute units, DNLP_LDLT_SWEEP=0, or the runtime refused the cooperative launch once) —
+  // the step kernels run instead.  A sweep that aborted (a workgroup was never scheduled: cannot happen under a
+  // cooperative launch, checked all the same) restores b and reports false.
+  unsigned* sweep_ready = nullptr;
+  SweepCtl* sweep_ctl = nullptr;
+  double* sweep_save = nullptr;
+  unsigned sweep_gen = 0;
+  int sweep_ncu = 0;
+  bool sweep_off = std::getenv("DNLP_LDLT_SWEEP") != nullptr && std::atoi(std::getenv("DNLP_LDLT_SWEEP")) == 0;
+  bool sweep_solve(const double* A, double* b, int nb128) {
+    if (sweep_off) return false;
+    if (!sweep_ncu) DNLP_HIP_CHECK(hipDeviceGetAttribute(&sweep_ncu, hipDeviceAttributeMultiprocessorCount, ex->device));
+    if (nb128 < 2 || nb128 > sweep_ncu) return false;
+    const int ni = static_cast<int>(n);
+    if (!sweep_ready) {
+      sweep_ready = ex->alloc<unsigned>(static_cast<size_t>(nb128) + 64);
+      sweep_ctl = ex->alloc<SweepCtl>(1);
+      sweep_save = ex->alloc<double>(static_cast<size_t>(ni));
+      DNLP_HIP_CHECK(hipMemsetAsync(sweep_ready, 0, sizeof(unsigned) * (static_cast<size_t>(nb128) + 64), ex->stream));
+      DNLP_HIP_CHECK(hipMemsetAsync(sweep_ctl, 0, sizeof(SweepCtl), ex->stream));
+    }
+    DNLP_HIP_CHECK(hipMemcpyAsync(sweep_save, b, sizeof(double) * static_cast<size_t>(ni), hipMemcpyDeviceToDevice, ex->stream));
+    const double* Ap = A;
+    i64 ldp = ld;
+    int np = ni, nbp = nb128;
+    const double *invp = Linv, *invTp = LinvT;
+    unsigned g1 = ++sweep_gen, g2 = ++sweep_gen;
+    void* a_f[] = {&Ap, &ldp, &np, &b, &invp, &sweep_ready, &sweep_ctl, &g1};
+    void* a_b[] = {&Ap, &ldp, &np, &b, &invTp, &sweep_ready, &sweep_ctl, &g2, &nbp};
+    if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(ldlt_fwd_sweep_kernel), dim3(static_cast<unsigned>(nb128)), dim3(SI_T), a_f, 0, ex->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      sweep_off = true;
+      return false;
+    }
+    hipLaunchKernelGGL(ldlt_diag_scale, dim3((ni + 255) / 256), dim3(256), 0, ex->stream, A, ld, ni, b);
+    if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(ldlt_bwd_sweep_kernel), dim3(static_cast<unsigned>(nb128)), dim3(SI_T), a_b, 0, ex->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      sweep_off = true;
+      DNLP_HIP_CHECK(hipMemcpyAsync(b, sweep_save, sizeof(double) * static_cast<size_t>(ni), hipMemcpyDeviceToDevice, ex->stream));
+      return false;
+    }
+    if (sweep_check) {
+      SweepCtl h;
+      DNLP_HIP_CHECK(hipMemcpyAsync(&h, sweep_ctl, sizeof h, hipMemcpyDeviceToHost, ex->stream));
+      DNLP_HIP_CHECK(hipStreamSynchronize(ex->stream));
+      if (h.abort) {
+        sweep_off = true;
+        DNLP_HIP_CHECK(hipMemsetAsync(sweep_ctl, 0, sizeof(SweepCtl), ex->stream));
+        DNLP_HIP_CHECK(hipMemcpyAsync(b, sweep_save, sizeof(double) * static_cast<size_t>(ni), hipMemcpyDeviceToDevice, ex->stream));
+        return false;
+      }
+    }
+    DNLP_LAUNCH_CHECK();
+    return true;
+  }
+  bool sweep_check = true;     // read the abort word back after every solve (one 128-byte copy; the caller synchronises anyway)
+
   // L D L^T x = b on the inverted diagonal blocks: one launch per 256-column step and sweep
   bool solve_prefetch = std::getenv("DNLP_LDLT_SOLVE_PREFETCH") == nullptr || std::atoi(std::getenv("DNLP_LDLT_SOLVE_PREFETCH")) != 0;
   void solve_on_inverses(const double* A, double* b) {
@@ -1550,6 +1706,7 @@ struct BlockedLdlt {
                            Linv, LinvT);
       inv_ready = true;
     }
+    if (sweep_solve(A, b, nb128)) return;
     // (+ the prefetching workgroup of the next step at the first block index past the grid that is a multiple of 8)
     auto with_pf = [&](unsigned grid) { return solve_prefetch ? (grid + 7u) / 8u * 8u + 8u * (SI_PF - 1) + 1u : grid; };
     hipLaunchKernelGGL(ldlt_fwd_step_kernel, dim3(with_pf(1)), dim3(SI_T), 0, ex->stream, A, ld, ni, -SI_B, b, Linv, 1, Linv);

@@ -300,13 +300,13 @@ struct Model {
   DNLP_HD void hess_mult(const double* v, double* out) {
     DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
     const i64 NN = t.N;
-    ex->zero(out, static_cast<size_t>(NN) * sizeof(double));
     // sparse part: lower entries contribute to both (r,c) and (c,r); the tape's index by output (tape.h CooIdx)
-    // makes it an order-fixed gather (scatter with atomics only for patterns too large to index)
+    // makes it an order-fixed gather that ASSIGNS every output (no zeroing pass before it); scatter with atomics
+    // into a zeroed vector only for patterns too large to index
     const i32 *hr = t.hess_rows, *hc = t.hess_cols;
     const double* hs = Hs;
     if (t.hess_sym.ptr) ex->coo_gather(t.hess_sym, hs, v, out);
-    else ex->coo_sym_mult(t.nnzH, hr, hc, hs, v, out);
+    else { ex->zero(out, static_cast<size_t>(NN) * sizeof(double)); ex->coo_sym_mult(t.nnzH, hr, hc, hs, v, out); }
     for (i64 k = 0; k < t.nblk; ++k) {
       const DenseBlock& B = t.blocks[k];
       const double* P = t.dense_ptr[B.cid];
@@ -322,15 +322,15 @@ struct Model {
   // out(m) = J v ; out(N) = J^T v with COO values jv on the fixed pattern
   DNLP_HD void jac_mult(const double* jv, const double* v, double* out) {
     DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
-    ex->zero(out, static_cast<size_t>(t.m) * sizeof(double));
     if (t.jac_by_row.ptr) { ex->coo_gather(t.jac_by_row, jv, v, out); return; }
+    ex->zero(out, static_cast<size_t>(t.m) * sizeof(double));
     if constexpr (E::is_device && E::has_host_control) if (t.jac_rect_cols > 0) { ex->rect_mult(t.m, t.jac_rect_cols, t.jac_cols, jv, v, out); return; }
     ex->coo_mult(t.nnzJ, t.jac_rows, t.jac_cols, jv, v, out, false);
   }
   DNLP_HD void jac_tmult(const double* jv, const double* v, double* out) {
     DNLP_THIS_IN_LDS(E); DNLP_PTR_IN_LDS(E, ex);
-    ex->zero(out, static_cast<size_t>(t.N) * sizeof(double));
     if (t.jac_by_col.ptr) { ex->coo_gather(t.jac_by_col, jv, v, out); return; }
+    ex->zero(out, static_cast<size_t>(t.N) * sizeof(double));
     if constexpr (E::is_device && E::has_host_control) if (t.jac_rect_cols > 0) { ex->rect_tmult(t.m, t.jac_rect_cols, t.jac_cols, jv, v, out); return; }
     ex->coo_mult(t.nnzJ, t.jac_rows, t.jac_cols, jv, v, out, true);
   }

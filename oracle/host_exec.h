@@ -201,12 +201,13 @@ struct HostExec : HostControlled {
       if (trans) out[c[p]] += a[p] * v[r[p]]; else out[r[p]] += a[p] * v[c[p]];
     }
   }
-  // out += (pattern product) through the tape's index by output: every output sums its segment in storage order
+  // out = (pattern product) through the tape's index by output: every output sums its segment in storage order and is
+  // ASSIGNED (an output without entries becomes 0): no zeroing pass before the product
   void coo_gather(const CooIdx& ix, const double* a, const double* v, double* out) {
     for (i64 g = 0; g < ix.nout; ++g) {
       double s = 0.0;
       for (i64 p = ix.ptr[g]; p < ix.ptr[g + 1]; ++p) s += a[ix.ent[p]] * v[ix.src[p]];
-      out[g] += s;
+      out[g] = s;
     }
   }
   // out += S v for a symmetric matrix given by its lower-triangle COO entries
