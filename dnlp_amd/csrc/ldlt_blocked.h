@@ -1127,81 +1127,105 @@ __global__ void __launch_bounds__(SI_T) ldlt_fwd_step_kernel(const double* __res
 // ---- the whole sweep in ONE launch: dataflow over the 128-blocks (round 4) ---------------------------------------
 // The step kernels above are a chain of 43 dependent launches per sweep at order 11 000 (22-25 us each: launch boundary,
 // one compute unit's cold pull of the step's operands).  Here every 128-row block of the right-hand side has its own
-// workgroup, resident for the whole sweep (cooperative launch: at most one workgroup per compute unit, order up to
-// 128 x CUs): workgroup i waits for block k < i to be published (a generation word per block in global memory, polled by
-// one lane), subtracts L[i, k] y_k — the 128 x 128 tile was fetched into registers BEFORE the wait, the next tile is on
-// its way during the product — and, after block i - 1, multiplies with the inverted diagonal block and publishes
-// block i.  The dependent part of a step is: see the flag, read 1 KB of y, two LDS-reduced tile products, a fence and
-// the flag — no launch boundary, nothing cold.  The transposed sweep mirrors it from the last block (tiles read with
-// the lanes on the rows, the contiguous direction; column sums by DPP).
-struct SweepCtl { unsigned gen; unsigned abort; unsigned pad[30]; };
-__device__ inline bool sweep_wait(const unsigned* word, unsigned gen, unsigned* abort_word, int* s_ok, int tid) {
-  if (tid == 0) {
+// workgroup for the whole sweep.  Workgroup j works on the j-th block IN SWEEP ORDER and waits only for blocks of lower
+// workgroup index: workgroups are dispatched in index order, so whatever a resident workgroup waits for is resident or
+// finished — no co-residency requirement, no cooperative launch (which this runtime serialises against graph launches
+// on the same stream in a way that broke the NMF example's solves).  A finished block travels through `xch` (one double
+// per entry, preset to an all-ones bit pattern that no computation produces): the readers' lanes poll THEIR entry —
+// the data is its own flag, one trip through the memory fabric per step instead of flag + fence + data.  Workgroup j
+// subtracts L[j, k] y_k for k < j — the 128 x 128 tile was fetched into registers before the wait, the next one is on
+// its way during the product — multiplies with the inverted diagonal block and publishes.  The transposed sweep mirrors
+// it from the last block (tiles read with the lanes on the rows, the contiguous direction; column sums by DPP).
+constexpr unsigned long long kSweepEmpty = 0xFFFFFFFFFFFFFFFFull;
+struct SweepCtl { unsigned abort; unsigned pad[31]; };
+// a tile whose block has only `nrows` valid rows (the last block of an order that is not a multiple of 128): rows past
+// them are read from the last valid row (what lies below is padding: not numbers anyone set); their products are masked
+// by the caller (forward: not accumulated; transposed: multiplied with x = 0)
+__device__ inline void si_tile_load_rows(SiTile& t, const double* __restrict__ M, i64 ldm, int tid, int nrows) {
+  const int ch = __builtin_amdgcn_readfirstlane(tid >> 7);
+  const double* col = M + static_cast<i64>(16 * ch) * ldm;
+  const int ri = tid & (SI_H - 1);
+  const unsigned i = static_cast<unsigned>(ri < nrows ? ri : nrows - 1), l32 = static_cast<unsigned>(ldm);
+#pragma unroll
+  for (int c = 0; c < 16; ++c) t.v[c] = si_ld(col, c * l32 + i);
+}
+// lanes tid < 128 fetch entry tid of a published block (poll until it is no longer the preset pattern); false = gave up
+__device__ inline bool sweep_fetch(const double* __restrict__ src, double* dst, unsigned* abort_word, int* s_ok, int tid) {
+  if (tid == 0) *s_ok = 1;
+  __syncthreads();
+  if (tid < SI_H) {
+    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(src) + tid;
+    unsigned long long v;
     unsigned spins = 0;
-    int ok = 1;
-    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
+    while ((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kSweepEmpty) {
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 1023u) == 0u && (spins > (1u << 22) || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
         __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
+        *s_ok = 0;
         break;
       }
     }
-    __threadfence();                       // acquire: the published block is visible after the flag
-    *s_ok = ok;
+    dst[tid] = __longlong_as_double(static_cast<long long>(v));
   }
   __syncthreads();
   return *s_ok != 0;
 }
+__device__ inline void sweep_publish(double* __restrict__ dst, double v, int tid) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst) + tid, static_cast<unsigned long long>(__double_as_longlong(v)), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
 __global__ void __launch_bounds__(SI_T) ldlt_fwd_sweep_kernel(const double* __restrict__ A, i64 ld, int n, double* __restrict__ b,
-                                                              const double* __restrict__ inv, unsigned* __restrict__ ready,
-                                                              SweepCtl* __restrict__ ctl, unsigned gen) {
+                                                              const double* __restrict__ inv, double* __restrict__ xch,
+                                                              SweepCtl* __restrict__ ctl) {
   __shared__ double y[SI_H];
   __shared__ double acc[SI_H];
   __shared__ double part[SI_T];
   __shared__ int s_ok;
   const int tid = threadIdx.x, i = blockIdx.x, r0 = i * SI_H;
-  if (tid < SI_H) acc[tid] = (r0 + tid < n) ? b[r0 + tid] : 0.0;
+  const int nrows = (n - r0 < SI_H) ? n - r0 : SI_H;                           // valid rows of this block
+  if (tid < SI_H) acc[tid] = (tid < nrows) ? b[r0 + tid] : 0.0;
   SiTile cur, nxt, ti;
   si_tile_load(ti, inv + static_cast<i64>(i) * (SI_H * SI_H), SI_H, tid);
-  if (i > 0) si_tile_load(cur, A + r0, ld, tid);                               // tile (i, 0)   (rows past n: padded allocation)
+  __syncthreads();                                                             // (acc: block 0 goes straight to the product below)
+  if (i > 0) si_tile_load_rows(cur, A + r0, ld, tid, nrows);                   // tile (i, 0)
   for (int k = 0; k < i; ++k) {
-    if (k + 1 < i) si_tile_load(nxt, A + r0 + static_cast<i64>(k + 1) * SI_H * ld, ld, tid);
-    if (!sweep_wait(ready + k, gen, &ctl->abort, &s_ok, tid)) return;
-    if (tid < SI_H) y[tid] = b[k * SI_H + tid];
-    __syncthreads();
+    if (k + 1 < i) si_tile_load_rows(nxt, A + r0 + static_cast<i64>(k + 1) * SI_H * ld, ld, tid, nrows);
+    if (!sweep_fetch(xch + k * SI_H, y, &ctl->abort, &s_ok, tid)) return;
     si_tile_vec(cur, y, part, tid);
-    if (tid < SI_H) acc[tid] -= si_part_sum(part, tid);
+    if (tid < nrows) acc[tid] -= si_part_sum(part, tid);
     __syncthreads();
     cur = nxt;
   }
   si_tile_vec(ti, acc, part, tid);
-  if (tid < SI_H && r0 + tid < n) b[r0 + tid] = si_part_sum(part, tid);
-  __threadfence();                           // release: the block before its flag
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(ready + i, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < SI_H) {
+    const double v = (tid < nrows) ? si_part_sum(part, tid) : 0.0;
+    sweep_publish(xch + r0, v, tid);           // (entries past n of the last block: zeros — nobody reads that block)
+    if (tid < nrows) b[r0 + tid] = v;
+  }
 }
-// L^T x = y.  Workgroup i owns block i and waits for the blocks k > i, last first.  Tile (k, i): rows of block k (the
-// lanes: contiguous), columns of block i — column sums over the 128 rows by two wavefront DPP sums each.
+// L^T x = y.  Workgroup j owns block i = nblk - 1 - j and waits for the blocks k > i (lower workgroup indices), last
+// first.  Tile (k, i): rows of block k (the lanes: contiguous), columns of block i — column sums over the 128 rows by
+// two wavefront DPP sums each.
 __global__ void __launch_bounds__(SI_T) ldlt_bwd_sweep_kernel(const double* __restrict__ A, i64 ld, int n, double* __restrict__ b,
-                                                              const double* __restrict__ invT, unsigned* __restrict__ ready,
-                                                              SweepCtl* __restrict__ ctl, unsigned gen, int nblk) {
+                                                              const double* __restrict__ invT, double* __restrict__ xch,
+                                                              SweepCtl* __restrict__ ctl, int nblk) {
   __shared__ double x[SI_H];
   __shared__ double acc[SI_H];
   __shared__ double part[SI_T];
   __shared__ double colp[2][SI_H];
   __shared__ int s_ok;
-  const int tid = threadIdx.x, i = blockIdx.x, c0 = i * SI_H;
+  const int tid = threadIdx.x, i = nblk - 1 - static_cast<int>(blockIdx.x), c0 = i * SI_H;
   const int lane = tid & 63, half = (tid >> 6) & 1, ch = __builtin_amdgcn_readfirstlane(tid >> 7);
-  if (tid < SI_H) acc[tid] = (c0 + tid < n) ? b[c0 + tid] : 0.0;
+  const int ncols = (n - c0 < SI_H) ? n - c0 : SI_H;
+  if (tid < SI_H) acc[tid] = (tid < ncols) ? b[c0 + tid] : 0.0;
   SiTile cur, nxt, ti;
   si_tile_load(ti, invT + static_cast<i64>(i) * (SI_H * SI_H), SI_H, tid);
-  if (i + 1 < nblk) si_tile_load(cur, A + static_cast<i64>(nblk - 1) * SI_H + static_cast<i64>(c0) * ld, ld, tid);      // tile (nblk - 1, i)
+  __syncthreads();
+  const int last_rows = n - (nblk - 1) * SI_H;                                  // valid rows of the last block
+  if (i + 1 < nblk) si_tile_load_rows(cur, A + static_cast<i64>(nblk - 1) * SI_H + static_cast<i64>(c0) * ld, ld, tid, last_rows);      // tile (nblk - 1, i)
   for (int k = nblk - 1; k > i; --k) {
     if (k - 1 > i) si_tile_load(nxt, A + static_cast<i64>(k - 1) * SI_H + static_cast<i64>(c0) * ld, ld, tid);
-    if (!sweep_wait(ready + k, gen, &ctl->abort, &s_ok, tid)) return;
-    if (tid < SI_H) x[tid] = (k * SI_H + tid < n) ? b[k * SI_H + tid] : 0.0;       // (rows past n of the last block: no contribution)
-    __syncthreads();
+    if (!sweep_fetch(xch + k * SI_H, x, &ctl->abort, &s_ok, tid)) return;       // (entries past n of the last block were published as zeros)
     {
       const double xr = x[tid & (SI_H - 1)];
 #pragma unroll
@@ -1216,10 +1240,11 @@ __global__ void __launch_bounds__(SI_T) ldlt_bwd_sweep_kernel(const double* __re
     cur = nxt;
   }
   si_tile_vec(ti, acc, part, tid);
-  if (tid < SI_H && c0 + tid < n) b[c0 + tid] = si_part_sum(part, tid);
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(ready + i, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < SI_H) {
+    const double v = (tid < ncols) ? si_part_sum(part, tid) : 0.0;
+    sweep_publish(xch + c0, v, tid);
+    if (tid < ncols) b[c0 + tid] = v;
+  }
 }
 
 // One step of L^T x = b, blocks from the last to the first.  j0 = block whose x is final (j0 >= n: prologue, only the
@@ -1625,63 +1650,42 @@ struct BlockedLdlt {
     return cur.fail == 0;
   }
 
-  // The two sweeps as ONE cooperative launch each (ldlt_fwd_sweep_kernel / ldlt_bwd_sweep_kernel).  false: not possible
-  // here (more 128-blocks than compute units, DNLP_LDLT_SWEEP=0, or the runtime refused the cooperative launch once) —
-  // the step kernels run instead.  A sweep that aborted (a workgroup was never scheduled: cannot happen under a
-  // cooperative launch, checked all the same) restores b and reports false.
-  unsigned* sweep_ready = nullptr;
+  // The two sweeps as ONE launch each (ldlt_fwd_sweep_kernel / ldlt_bwd_sweep_kernel).  false: not taken (fewer than two
+  // 128-blocks, more than kSweepMaxBlocks, DNLP_LDLT_SWEEP=0, or a sweep once gave up waiting) — the step kernels run
+  // instead.  A sweep that gave up restores b and reports false.
+  static constexpr int kSweepMaxBlocks = 256;       // (order 32 768: beyond it a workgroup's serial walk over its row of tiles is the bound)
+  double* sweep_xch = nullptr;      // two exchange vectors (forward / transposed sweep), nb128 x 128 doubles each
   SweepCtl* sweep_ctl = nullptr;
   double* sweep_save = nullptr;
-  unsigned sweep_gen = 0;
-  int sweep_ncu = 0;
   bool sweep_off = std::getenv("DNLP_LDLT_SWEEP") != nullptr && std::atoi(std::getenv("DNLP_LDLT_SWEEP")) == 0;
   bool sweep_solve(const double* A, double* b, int nb128) {
-    if (sweep_off) return false;
-    if (!sweep_ncu) DNLP_HIP_CHECK(hipDeviceGetAttribute(&sweep_ncu, hipDeviceAttributeMultiprocessorCount, ex->device));
-    if (nb128 < 2 || nb128 > sweep_ncu) return false;
+    if (sweep_off || nb128 < 2 || nb128 > kSweepMaxBlocks) return false;
     const int ni = static_cast<int>(n);
-    if (!sweep_ready) {
-      sweep_ready = ex->alloc<unsigned>(static_cast<size_t>(nb128) + 64);
+    const size_t xn = static_cast<size_t>(nb128) * SI_H;
+    if (!sweep_xch) {
+      sweep_xch = ex->alloc<double>(2 * xn);
       sweep_ctl = ex->alloc<SweepCtl>(1);
       sweep_save = ex->alloc<double>(static_cast<size_t>(ni));
-      DNLP_HIP_CHECK(hipMemsetAsync(sweep_ready, 0, sizeof(unsigned) * (static_cast<size_t>(nb128) + 64), ex->stream));
       DNLP_HIP_CHECK(hipMemsetAsync(sweep_ctl, 0, sizeof(SweepCtl), ex->stream));
     }
     DNLP_HIP_CHECK(hipMemcpyAsync(sweep_save, b, sizeof(double) * static_cast<size_t>(ni), hipMemcpyDeviceToDevice, ex->stream));
-    const double* Ap = A;
-    i64 ldp = ld;
-    int np = ni, nbp = nb128;
-    const double *invp = Linv, *invTp = LinvT;
-    unsigned g1 = ++sweep_gen, g2 = ++sweep_gen;
-    void* a_f[] = {&Ap, &ldp, &np, &b, &invp, &sweep_ready, &sweep_ctl, &g1};
-    void* a_b[] = {&Ap, &ldp, &np, &b, &invTp, &sweep_ready, &sweep_ctl, &g2, &nbp};
-    if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(ldlt_fwd_sweep_kernel), dim3(static_cast<unsigned>(nb128)), dim3(SI_T), a_f, 0, ex->stream) != hipSuccess) {
-      (void)hipGetLastError();
-      sweep_off = true;
-      return false;
-    }
+    DNLP_HIP_CHECK(hipMemsetAsync(sweep_xch, 0xFF, sizeof(double) * 2 * xn, ex->stream));          // every entry "not published yet"
+    hipLaunchKernelGGL(ldlt_fwd_sweep_kernel, dim3(static_cast<unsigned>(nb128)), dim3(SI_T), 0, ex->stream, A, ld, ni, b, Linv, sweep_xch, sweep_ctl);
     hipLaunchKernelGGL(ldlt_diag_scale, dim3((ni + 255) / 256), dim3(256), 0, ex->stream, A, ld, ni, b);
-    if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(ldlt_bwd_sweep_kernel), dim3(static_cast<unsigned>(nb128)), dim3(SI_T), a_b, 0, ex->stream) != hipSuccess) {
-      (void)hipGetLastError();
+    hipLaunchKernelGGL(ldlt_bwd_sweep_kernel, dim3(static_cast<unsigned>(nb128)), dim3(SI_T), 0, ex->stream, A, ld, ni, b, LinvT, sweep_xch + xn, sweep_ctl,
+                       nb128);
+    SweepCtl h;
+    DNLP_HIP_CHECK(hipMemcpyAsync(&h, sweep_ctl, sizeof h, hipMemcpyDeviceToHost, ex->stream));
+    DNLP_HIP_CHECK(hipStreamSynchronize(ex->stream));
+    if (h.abort) {
       sweep_off = true;
+      DNLP_HIP_CHECK(hipMemsetAsync(sweep_ctl, 0, sizeof(SweepCtl), ex->stream));
       DNLP_HIP_CHECK(hipMemcpyAsync(b, sweep_save, sizeof(double) * static_cast<size_t>(ni), hipMemcpyDeviceToDevice, ex->stream));
       return false;
-    }
-    if (sweep_check) {
-      SweepCtl h;
-      DNLP_HIP_CHECK(hipMemcpyAsync(&h, sweep_ctl, sizeof h, hipMemcpyDeviceToHost, ex->stream));
-      DNLP_HIP_CHECK(hipStreamSynchronize(ex->stream));
-      if (h.abort) {
-        sweep_off = true;
-        DNLP_HIP_CHECK(hipMemsetAsync(sweep_ctl, 0, sizeof(SweepCtl), ex->stream));
-        DNLP_HIP_CHECK(hipMemcpyAsync(b, sweep_save, sizeof(double) * static_cast<size_t>(ni), hipMemcpyDeviceToDevice, ex->stream));
-        return false;
-      }
     }
     DNLP_LAUNCH_CHECK();
     return true;
   }
-  bool sweep_check = true;     // read the abort word back after every solve (one 128-byte copy; the caller synchronises anyway)
 
   // L D L^T x = b on the inverted diagonal blocks: one launch per 256-column step and sweep
   bool solve_prefetch = std::getenv("DNLP_LDLT_SOLVE_PREFETCH") == nullptr || std::atoi(std::getenv("DNLP_LDLT_SOLVE_PREFETCH")) != 0;
