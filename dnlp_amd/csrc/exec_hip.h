@@ -211,25 +211,37 @@ __global__ void __launch_bounds__(kBlock) gemv_sym_stage1(i64 n, const double* _
 #pragma unroll
   for (int q = 0; q < GEMV_CB / 64; ++q) keep[q] = 0.0;
   const double* col = A + (in0 ? r0 : 0) + c0 * ld;
-  for (i64 j = c0; j < c1; ++j, col += ld) {
-    double2 v = double2{0.0, 0.0};
-    if (in1) v = *reinterpret_cast<const double2*>(col);          // (every lane of the wavefront stays in the loop: the
-    else if (in0) v.x = col[0];                                   //  reduction below is wave-wide)
-    const double xj = x[j];
-    double t;
-    if (!crossing) {
-      a0 = fma(v.x, xj, a0);
-      a1 = fma(v.y, xj, a1);
-      t = fma(v.x, xr0, v.y * xr1);
-    } else {
-      a0 += (r0 >= j) ? v.x * xj : 0.0;
-      a1 += (r0 + 1 >= j) ? v.y * xj : 0.0;
-      t = ((r0 > j) ? v.x * xr0 : 0.0) + ((r0 + 1 > j) ? v.y * xr1 : 0.0);
-    }
-    const double T = wave_all_sum(t);
-    const int jj = static_cast<int>(j - c0);
+  // eight columns per trip, their loads issued together (one 16-byte load per lane and trip in flight drew 2.0 TB/s)
+  constexpr int U = 8;
+  for (i64 j0 = c0; j0 < c1; j0 += U, col += U * ld) {
+    double2 v[U];
+    double xj[U];
 #pragma unroll
-    for (int q = 0; q < GEMV_CB / 64; ++q) if ((jj >> 6) == q && lane == (jj & 63)) keep[q] = T;
+    for (int u = 0; u < U; ++u) {
+      const bool live = j0 + u < c1;
+      v[u] = double2{0.0, 0.0};
+      if (live && in1) v[u] = *reinterpret_cast<const double2*>(col + u * ld);          // (every lane of the wavefront stays in the
+      else if (live && in0) v[u].x = col[u * ld];                                         //  loop: the reduction below is wave-wide)
+      xj[u] = live ? x[j0 + u] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const i64 j = j0 + u;
+      double t;
+      if (!crossing) {
+        a0 = fma(v[u].x, xj[u], a0);
+        a1 = fma(v[u].y, xj[u], a1);
+        t = fma(v[u].x, xr0, v[u].y * xr1);
+      } else {
+        a0 += (r0 >= j) ? v[u].x * xj[u] : 0.0;
+        a1 += (r0 + 1 >= j) ? v[u].y * xj[u] : 0.0;
+        t = ((r0 > j) ? v[u].x * xr0 : 0.0) + ((r0 + 1 > j) ? v[u].y * xr1 : 0.0);
+      }
+      const double T = wave_all_sum(t);
+      const int jj = static_cast<int>(j - c0);
+#pragma unroll
+      for (int q = 0; q < GEMV_CB / 64; ++q) if ((jj >> 6) == q && lane == (jj & 63)) keep[q] = T;
+    }
   }
   if (in0) part[cb * n + r0] = a0;
   if (in1) part[cb * n + r0 + 1] = a1;

@@ -1174,72 +1174,136 @@ __device__ inline void sweep_publish(double* __restrict__ dst, double v, int tid
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst) + tid, static_cast<unsigned long long>(__double_as_longlong(v)), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
 }
+// Sixteen wavefront-wide sums at once: u[c] = this lane's term of column c.  On return lane L holds in u[t], t < 4, the
+// total of column 4 (L >> 4) + t.  Halving exchanges instead of sixteen full reductions (84 instructions against 320, which
+// made the transposed sweep VALU-bound: 329 us against the forward sweep's 138): v_permlane32_swap trades the upper half
+// of u[t] for the lower half of u[t + 8] (one add leaves column t in lanes 0-31, column t + 8 in lanes 32-63), then
+// v_permlane16_swap the same between the 16-lane rows; the four values left are summed over their row by DPP rotations.
+__device__ inline void wave_colsum16(double (&u)[16]) {
+  auto swap_add = [](double a, double b, auto swap) {
+    const auto lo = swap(static_cast<unsigned>(__double2loint(a)), static_cast<unsigned>(__double2loint(b)));
+    const auto hi = swap(static_cast<unsigned>(__double2hiint(a)), static_cast<unsigned>(__double2hiint(b)));
+    return __hiloint2double(static_cast<int>(hi[0]), static_cast<int>(lo[0])) + __hiloint2double(static_cast<int>(hi[1]), static_cast<int>(lo[1]));
+  };
+  auto swap32 = [](unsigned a, unsigned b) { return __builtin_amdgcn_permlane32_swap(a, b, false, false); };
+  auto swap16 = [](unsigned a, unsigned b) { return __builtin_amdgcn_permlane16_swap(a, b, false, false); };
+#pragma unroll
+  for (int t = 0; t < 8; ++t) u[t] = swap_add(u[t], u[t + 8], swap32);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) u[t] = swap_add(u[t], u[t + 4], swap16);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    u[t] += dpp_shift_f64<0x128, 0xf>(u[t], 0.0);       // row_ror:8, 4, 2, 1: every lane of the row ends with the row's total
+    u[t] += dpp_shift_f64<0x124, 0xf>(u[t], 0.0);
+    u[t] += dpp_shift_f64<0x122, 0xf>(u[t], 0.0);
+    u[t] += dpp_shift_f64<0x121, 0xf>(u[t], 0.0);
+  }
+}
+// Each block row is shared by P workgroups (one compute unit draws ~35 GB/s: a row's 128 KB tiles at one per 3.9 us were
+// the sweep's pace, against 1.7 us for the exchange itself — tools/micro/chain_hop.hip): member q of the row at sweep
+// position j takes the tiles at sweep positions s = (j + q) mod P, + P, ...; the LAST member (q = P - 1) has the tile of the
+// block published last, adds the other members' partial sums (exchanged through `pex`, same data-as-flag form) in member
+// order and finishes the block.  Every wait is for a lower workgroup index.
 __global__ void __launch_bounds__(SI_T) ldlt_fwd_sweep_kernel(const double* __restrict__ A, i64 ld, int n, double* __restrict__ b,
                                                               const double* __restrict__ inv, double* __restrict__ xch,
-                                                              SweepCtl* __restrict__ ctl) {
+                                                              double* __restrict__ pex, SweepCtl* __restrict__ ctl, int P) {
   __shared__ double y[SI_H];
   __shared__ double acc[SI_H];
   __shared__ double part[SI_T];
   __shared__ int s_ok;
-  const int tid = threadIdx.x, i = blockIdx.x, r0 = i * SI_H;
+  const int tid = threadIdx.x, i = static_cast<int>(blockIdx.x) / P, q = static_cast<int>(blockIdx.x) % P, r0 = i * SI_H;
+  const bool owner = q == P - 1;
   const int nrows = (n - r0 < SI_H) ? n - r0 : SI_H;                           // valid rows of this block
-  if (tid < SI_H) acc[tid] = (tid < nrows) ? b[r0 + tid] : 0.0;
-  SiTile cur, nxt, ti;
-  si_tile_load(ti, inv + static_cast<i64>(i) * (SI_H * SI_H), SI_H, tid);
+  if (tid < SI_H) acc[tid] = (owner && tid < nrows) ? b[r0 + tid] : 0.0;
+  // two tiles in registers, not three (a third spilled 24 VGPRs to scratch): the owner's inverted diagonal block rides in
+  // the look-ahead slot of its last tile
+  SiTile cur, nxt;
+  const double* invi = inv + static_cast<i64>(i) * (SI_H * SI_H);
   __syncthreads();                                                             // (acc: block 0 goes straight to the product below)
-  if (i > 0) si_tile_load_rows(cur, A + r0, ld, tid, nrows);                   // tile (i, 0)
-  for (int k = 0; k < i; ++k) {
-    if (k + 1 < i) si_tile_load_rows(nxt, A + r0 + static_cast<i64>(k + 1) * SI_H * ld, ld, tid, nrows);
+  int k = (i + q) % P;
+  if (k < i) si_tile_load_rows(cur, A + r0 + static_cast<i64>(k) * SI_H * ld, ld, tid, nrows);
+  else if (owner) si_tile_load(cur, invi, SI_H, tid);
+  for (; k < i; k += P) {
+    if (k + P < i) si_tile_load_rows(nxt, A + r0 + static_cast<i64>(k + P) * SI_H * ld, ld, tid, nrows);
+    else if (owner) si_tile_load(nxt, invi, SI_H, tid);
     if (!sweep_fetch(xch + k * SI_H, y, &ctl->abort, &s_ok, tid)) return;
     si_tile_vec(cur, y, part, tid);
     if (tid < nrows) acc[tid] -= si_part_sum(part, tid);
     __syncthreads();
     cur = nxt;
   }
-  si_tile_vec(ti, acc, part, tid);
+  if (!owner) {
+    if (tid < SI_H) sweep_publish(pex + (static_cast<i64>(i) * P + q) * SI_H, acc[tid], tid);
+    return;
+  }
+  for (int o = 0; o + 1 < P; ++o) {
+    if (!sweep_fetch(pex + (static_cast<i64>(i) * P + o) * SI_H, y, &ctl->abort, &s_ok, tid)) return;
+    if (tid < SI_H) acc[tid] += y[tid];
+    __syncthreads();
+  }
+  si_tile_vec(cur, acc, part, tid);
   if (tid < SI_H) {
     const double v = (tid < nrows) ? si_part_sum(part, tid) : 0.0;
     sweep_publish(xch + r0, v, tid);           // (entries past n of the last block: zeros — nobody reads that block)
     if (tid < nrows) b[r0 + tid] = v;
   }
 }
-// L^T x = y.  Workgroup j owns block i = nblk - 1 - j and waits for the blocks k > i (lower workgroup indices), last
+// L^T x = y.  Sweep position j is block i = nblk - 1 - j; its members wait for the blocks k > i (lower sweep positions), last
 // first.  Tile (k, i): rows of block k (the lanes: contiguous), columns of block i — column sums over the 128 rows by
 // two wavefront DPP sums each.
 __global__ void __launch_bounds__(SI_T) ldlt_bwd_sweep_kernel(const double* __restrict__ A, i64 ld, int n, double* __restrict__ b,
                                                               const double* __restrict__ invT, double* __restrict__ xch,
-                                                              SweepCtl* __restrict__ ctl, int nblk) {
+                                                              double* __restrict__ pex, SweepCtl* __restrict__ ctl, int nblk, int P) {
   __shared__ double x[SI_H];
   __shared__ double acc[SI_H];
   __shared__ double part[SI_T];
   __shared__ double colp[2][SI_H];
   __shared__ int s_ok;
-  const int tid = threadIdx.x, i = nblk - 1 - static_cast<int>(blockIdx.x), c0 = i * SI_H;
+  const int tid = threadIdx.x, j = static_cast<int>(blockIdx.x) / P, q = static_cast<int>(blockIdx.x) % P, i = nblk - 1 - j, c0 = i * SI_H;
+  const bool owner = q == P - 1;
   const int lane = tid & 63, half = (tid >> 6) & 1, ch = __builtin_amdgcn_readfirstlane(tid >> 7);
   const int ncols = (n - c0 < SI_H) ? n - c0 : SI_H;
-  if (tid < SI_H) acc[tid] = (tid < ncols) ? b[c0 + tid] : 0.0;
-  SiTile cur, nxt, ti;
-  si_tile_load(ti, invT + static_cast<i64>(i) * (SI_H * SI_H), SI_H, tid);
+  if (tid < SI_H) acc[tid] = (owner && tid < ncols) ? b[c0 + tid] : 0.0;
+  SiTile cur, nxt;
+  const double* invi = invT + static_cast<i64>(i) * (SI_H * SI_H);
   __syncthreads();
   const int last_rows = n - (nblk - 1) * SI_H;                                  // valid rows of the last block
-  if (i + 1 < nblk) si_tile_load_rows(cur, A + static_cast<i64>(nblk - 1) * SI_H + static_cast<i64>(c0) * ld, ld, tid, last_rows);      // tile (nblk - 1, i)
-  for (int k = nblk - 1; k > i; --k) {
-    if (k - 1 > i) si_tile_load(nxt, A + static_cast<i64>(k - 1) * SI_H + static_cast<i64>(c0) * ld, ld, tid);
-    if (!sweep_fetch(xch + k * SI_H, x, &ctl->abort, &s_ok, tid)) return;       // (entries past n of the last block were published as zeros)
+  auto load = [&](SiTile& t, int s) {                                           // tile at sweep position s: block row k = nblk - 1 - s
+    const int k = nblk - 1 - s;
+    si_tile_load_rows(t, A + static_cast<i64>(k) * SI_H + static_cast<i64>(c0) * ld, ld, tid, s == 0 ? last_rows : SI_H);
+  };
+  int s = (j + q) % P;
+  if (s < j) load(cur, s);
+  else if (owner) si_tile_load(cur, invi, SI_H, tid);
+  for (; s < j; s += P) {
+    if (s + P < j) load(nxt, s + P);
+    else if (owner) si_tile_load(nxt, invi, SI_H, tid);
+    if (!sweep_fetch(xch + (nblk - 1 - s) * SI_H, x, &ctl->abort, &s_ok, tid)) return;       // (entries past n of the last block were published as zeros)
     {
       const double xr = x[tid & (SI_H - 1)];
+      double u[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const double sum = wave_all_sum(cur.v[c] * xr);
-        if (lane == c) colp[half][16 * ch + c] = sum;          // (lane c keeps column c's sum: sixteen lanes write, no serial tail)
-      }
+      for (int c = 0; c < 16; ++c) u[c] = cur.v[c] * xr;
+      wave_colsum16(u);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if ((lane & 15) == t) colp[half][16 * ch + 4 * (lane >> 4) + t] = u[t];
     }
     __syncthreads();
     if (tid < SI_H) acc[tid] -= colp[0][tid] + colp[1][tid];
     __syncthreads();
     cur = nxt;
   }
-  si_tile_vec(ti, acc, part, tid);
+  if (!owner) {
+    if (tid < SI_H) sweep_publish(pex + (static_cast<i64>(j) * P + q) * SI_H, acc[tid], tid);
+    return;
+  }
+  for (int o = 0; o + 1 < P; ++o) {
+    if (!sweep_fetch(pex + (static_cast<i64>(j) * P + o) * SI_H, x, &ctl->abort, &s_ok, tid)) return;
+    if (tid < SI_H) acc[tid] += x[tid];
+    __syncthreads();
+  }
+  si_tile_vec(cur, acc, part, tid);
   if (tid < SI_H) {
     const double v = (tid < ncols) ? si_part_sum(part, tid) : 0.0;
     sweep_publish(xch + c0, v, tid);
@@ -1658,22 +1722,24 @@ struct BlockedLdlt {
   SweepCtl* sweep_ctl = nullptr;
   double* sweep_save = nullptr;
   bool sweep_off = std::getenv("DNLP_LDLT_SWEEP") != nullptr && std::atoi(std::getenv("DNLP_LDLT_SWEEP")) == 0;
+  int sweep_split = std::getenv("DNLP_LDLT_SWEEP_SPLIT") ? std::max(1, std::min(4, std::atoi(std::getenv("DNLP_LDLT_SWEEP_SPLIT")))) : 2;
   bool sweep_solve(const double* A, double* b, int nb128) {
     if (sweep_off || nb128 < 2 || nb128 > kSweepMaxBlocks) return false;
-    const int ni = static_cast<int>(n);
-    const size_t xn = static_cast<size_t>(nb128) * SI_H;
+    const int ni = static_cast<int>(n), P = sweep_split;
+    const size_t xn = static_cast<size_t>(nb128) * SI_H, pn = xn * static_cast<size_t>(P);
     if (!sweep_xch) {
-      sweep_xch = ex->alloc<double>(2 * xn);
+      sweep_xch = ex->alloc<double>(2 * xn + 2 * pn);          // block exchange (forward, transposed), then the members' partial sums
       sweep_ctl = ex->alloc<SweepCtl>(1);
       sweep_save = ex->alloc<double>(static_cast<size_t>(ni));
       DNLP_HIP_CHECK(hipMemsetAsync(sweep_ctl, 0, sizeof(SweepCtl), ex->stream));
     }
     DNLP_HIP_CHECK(hipMemcpyAsync(sweep_save, b, sizeof(double) * static_cast<size_t>(ni), hipMemcpyDeviceToDevice, ex->stream));
-    DNLP_HIP_CHECK(hipMemsetAsync(sweep_xch, 0xFF, sizeof(double) * 2 * xn, ex->stream));          // every entry "not published yet"
-    hipLaunchKernelGGL(ldlt_fwd_sweep_kernel, dim3(static_cast<unsigned>(nb128)), dim3(SI_T), 0, ex->stream, A, ld, ni, b, Linv, sweep_xch, sweep_ctl);
+    DNLP_HIP_CHECK(hipMemsetAsync(sweep_xch, 0xFF, sizeof(double) * (2 * xn + 2 * pn), ex->stream));          // every entry "not published yet"
+    const unsigned grid = static_cast<unsigned>(nb128) * static_cast<unsigned>(P);
+    hipLaunchKernelGGL(ldlt_fwd_sweep_kernel, dim3(grid), dim3(SI_T), 0, ex->stream, A, ld, ni, b, Linv, sweep_xch, sweep_xch + 2 * xn, sweep_ctl, P);
     hipLaunchKernelGGL(ldlt_diag_scale, dim3((ni + 255) / 256), dim3(256), 0, ex->stream, A, ld, ni, b);
-    hipLaunchKernelGGL(ldlt_bwd_sweep_kernel, dim3(static_cast<unsigned>(nb128)), dim3(SI_T), 0, ex->stream, A, ld, ni, b, LinvT, sweep_xch + xn, sweep_ctl,
-                       nb128);
+    hipLaunchKernelGGL(ldlt_bwd_sweep_kernel, dim3(grid), dim3(SI_T), 0, ex->stream, A, ld, ni, b, LinvT, sweep_xch + xn, sweep_xch + 2 * xn + pn,
+                       sweep_ctl, nb128, P);
     SweepCtl h;
     DNLP_HIP_CHECK(hipMemcpyAsync(&h, sweep_ctl, sizeof h, hipMemcpyDeviceToHost, ex->stream));
     DNLP_HIP_CHECK(hipStreamSynchronize(ex->stream));
