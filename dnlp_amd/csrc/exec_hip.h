@@ -2241,7 +2241,7 @@ struct HipExec : HostControlled {
   // least-squares multipliers of [I J^T; J -D][x; y] = [rx; ry] through the m x m Schur complement
   // S = -(D + J J^T): one K = N pass of the MFMA update kernel, an order-m LDL^T, one solve (ldlt_blocked.h).
   // jd_rhs: J rx (m values); y receives the multipliers.  False: not applicable / not definite.
-  struct CondensedLs { BlockedLdlt* ldlt = nullptr; double* Jd = nullptr; double* S = nullptr; i64 N = 0, m = 0, Npad = 0, lds = 0; };
+  struct CondensedLs { BlockedLdlt* ldlt = nullptr; double* Jd = nullptr; double* S = nullptr; double* parts = nullptr; size_t parts_cap = 0; i64 N = 0, m = 0, Npad = 0, lds = 0; };
   CondensedLs cls_;
   bool condensed_ls(i64 N, i64 m, i64 nnzJ, const i32* jr, const i32* jc, const double* jv, const double* fixmask,
                     const double* Dd, const double* ry_minus_Jrx, double* y);

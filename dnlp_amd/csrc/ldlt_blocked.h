@@ -688,6 +688,29 @@ __global__ void __launch_bounds__(256, 3) gemm_nt_update_small(double* __restric
   else gemm_body_small<true>(C, ldc, W, ldw, L, ldl, M, Nc, Kd, lower, tm, tn, vec_ok, Ws, Ls);
 }
 
+// The same tiles with the k range cut into gridDim.y slices, slice y accumulating into its own copy of C (cslice doubles
+// apart; the caller adds the copies in slice order: reproducible, no atomics).  For products with few output tiles and a
+// long inner dimension (J J^T of the least-squares multipliers: 136 tiles x K = 10 000 kept 136 workgroups busy for 0.92 ms).
+__global__ void __launch_bounds__(256, 3) gemm_nt_update_small_splitk(double* __restrict__ C, i64 ldc, i64 cslice,
+                                                                   const double* __restrict__ W, i64 ldw,
+                                                                   const double* __restrict__ L, i64 ldl, int M, int Nc,
+                                                                   int Kd, int kslice, int lower, int ntm, int vec_ok) {
+  const int tm = blockIdx.x % ntm, tn = blockIdx.x / ntm;
+  if (lower && (tm * GS_B + GS_B - 1 < tn * GS_B)) return;
+  const int k0 = static_cast<int>(blockIdx.y) * kslice;
+  if (k0 >= Kd) return;
+  const int kd = (Kd - k0 < kslice) ? Kd - k0 : kslice;
+  C += static_cast<i64>(blockIdx.y) * cslice;
+  W += static_cast<i64>(k0) * ldw;
+  L += static_cast<i64>(k0) * ldl;
+  __shared__ __attribute__((aligned(16))) double Ws[2][GM_BK][GS_B + GS_PAD];
+  __shared__ __attribute__((aligned(16))) double Ls[2][GM_BK][GS_B + GS_PAD];
+  const bool interior = vec_ok && (kd % GM_BK == 0) && (tm + 1) * GS_B <= M && (tn + 1) * GS_B <= Nc &&
+                        (!lower || tm * GS_B >= (tn + 1) * GS_B);
+  if (interior) gemm_body_small<false>(C, ldc, W, ldw, L, ldl, M, Nc, kd, lower, tm, tn, vec_ok, Ws, Ls);
+  else gemm_body_small<true>(C, ldc, W, ldw, L, ldl, M, Nc, kd, lower, tm, tn, vec_ok, Ws, Ls);
+}
+
 // ---- triangular solves with the unit-lower factor ---------------------------------------------
 // Blocks of SV_B = 256 columns: the diagonal block is solved by one workgroup (32-wide
 // wave-shuffle substitutions, no barrier inside a sub-block), the panel below / the panel
@@ -1841,15 +1864,40 @@ inline bool HipExec::condensed_ls(i64 N, i64 m, i64 nnzJ, const i32* jr, const i
   double *Jd = cls_.Jd, *S = cls_.S;
   const i64 lds = cls_.lds, mm = m;
   zero(Jd, sizeof(double) * (static_cast<size_t>(m) * static_cast<size_t>(Npad) + 256));
-  zero(S, sizeof(double) * (static_cast<size_t>(lds) * static_cast<size_t>(m) + 256));
   map(nnzJ, [=] DNLP_HD(i64 p) { if (fixmask[jc[p]] == 0.0) Jd[jr[p] + static_cast<i64>(jc[p]) * mm] = jv[p]; });
-  map(m, [=] DNLP_HD(i64 i) { S[i + i * lds] = -Dd[i]; });
-  // S -= J J^T on the lower tiles: W = L = J (leading dimension m), K = Npad
   BlockedLdlt& bl = *cls_.ldlt;
-  const i64 keep_ldw = bl.ldw;
-  bl.ldw = m;
-  bl.gemm(stream, S, Jd, Jd, m, static_cast<int>(m), static_cast<int>(m), static_cast<int>(Npad), 1);
-  bl.ldw = keep_ldw;
+  // S = -D - J J^T on the lower tiles: W = L = J (leading dimension m), K = Npad.  Few tiles and a long K: the k range is
+  // cut into slices that fill the chip, each into its own copy, the copies added in slice order.
+  const int sm = static_cast<int>((m + GS_B - 1) / GS_B);
+  const i64 tiles = static_cast<i64>(sm) * (sm + 1) / 2, scount = static_cast<i64>(lds) * m;
+  int slices = static_cast<int>(std::min<i64>(16, std::max<i64>(1, 1024 / tiles)));
+  while (slices > 1 && (Npad / slices < 256 || static_cast<double>(slices) * static_cast<double>(scount) * 8.0 > 5.0e8)) --slices;
+  if (slices > 1 && (m & 1) == 0) {
+    if (cls_.parts_cap < static_cast<size_t>(slices) * static_cast<size_t>(scount)) {
+      cls_.parts_cap = static_cast<size_t>(slices) * static_cast<size_t>(scount);
+      cls_.parts = alloc<double>(cls_.parts_cap + 256);
+    }
+    double* parts = cls_.parts;
+    zero(parts, sizeof(double) * static_cast<size_t>(slices) * static_cast<size_t>(scount));
+    const int kslice = static_cast<int>(((Npad + slices - 1) / slices + GM_BK - 1) / GM_BK * GM_BK);
+    hipLaunchKernelGGL(gemm_nt_update_small_splitk, dim3(static_cast<unsigned>(sm) * sm, static_cast<unsigned>(slices)), dim3(256), 0, stream, parts, lds,
+                       scount, Jd, mm, Jd, mm, static_cast<int>(m), static_cast<int>(m), static_cast<int>(Npad), kslice, 1, sm, 1);
+    DNLP_LAUNCH_CHECK();
+    const int ns = slices;
+    map(scount, [=] DNLP_HD(i64 e) {
+      const i64 i = e % lds, j = e / lds;
+      double v = (i == j && i < mm) ? -Dd[i] : 0.0;
+      for (int q = 0; q < ns; ++q) v += parts[static_cast<i64>(q) * scount + e];
+      S[e] = v;
+    });
+  } else {
+    zero(S, sizeof(double) * (static_cast<size_t>(lds) * static_cast<size_t>(m) + 256));
+    map(m, [=] DNLP_HD(i64 i) { S[i + i * lds] = -Dd[i]; });
+    const i64 keep_ldw = bl.ldw;
+    bl.ldw = m;
+    bl.gemm(stream, S, Jd, Jd, m, static_cast<int>(m), static_cast<int>(m), static_cast<int>(Npad), 1);
+    bl.ldw = keep_ldw;
+  }
   int nneg = 0, nzero = 0;
   if (!bl.factor(S, &nneg, &nzero) || nzero > 0 || nneg != static_cast<int>(m)) return false;
   map(m, [=] DNLP_HD(i64 i) { y[i] = rhs_y[i]; });
