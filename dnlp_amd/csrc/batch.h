@@ -595,6 +595,7 @@ struct BatchRunner {
     const size_t kbytes = have_sparse ? (sparse_big ? ((sparse_vals * 8 + 63) & ~static_cast<size_t>(63)) : 0)
                                       : (((static_cast<size_t>(ld) * n + 256) * 8 + 63) & ~static_cast<size_t>(63));
     const size_t vdoubles = static_cast<size_t>(26 * t.N + 36 * t.m + 2 * t.Z + t.nd + t.nh + t.nnzH + t.nnzJ + 2 * n + 64) +
+                            (n > 256 && n <= 2048 ? static_cast<size_t>(18 * n + 128) : 0) +      // (panel-blocked factorisation: W, permutation, pivot types)
                             (have_sparse && !sparse_big ? sparse_vals : 0);
     const size_t vbytes = ((vdoubles * 8 * 21 / 20) + 96 * 64 + 255) & ~static_cast<size_t>(255);
     // LDS reservation for the vectors: tight (the allocator spills to the global slab, which always

@@ -23,6 +23,7 @@
 #include "atom_math.h"
 #include "exec.h"
 #include "wave_ops.h"
+#include "bk_panel.h"
 #include "sparse_ldl.h"
 
 namespace dnlp {
@@ -435,7 +436,13 @@ struct BlockExecT {
   static constexpr int kFilterCap = 32;
   struct Log { __device__ void append(const Log&) {} };
   struct FlatTableT {};
-  struct LdltWork { int expect_neg = -1; bool time_updates = false; bool padded = false; bool standard = false; };
+  struct LdltWork {
+    int expect_neg = -1; bool time_updates = false; bool padded = false; bool standard = false;
+    // orders 257 .. 2048 on four wavefronts: the panel-blocked factorisation of bk_panel.h (see bk_panels below)
+    bool panels = false;
+    BkState* st = nullptr; BkPanelSwaps* swaps = nullptr; double* bk_w = nullptr; i32* bk_perm = nullptr; i32* bk_dtype = nullptr;
+  };
+  static constexpr int kPanelMaxOrder = 2048;
 
   // per-workgroup bump allocators: global slab and (for the KKT matrix) LDS
   char* ws = nullptr;
@@ -644,7 +651,18 @@ struct BlockExecT {
   __device__ void gemv_sym(i64, const double*, i64, const double*, double*) { __builtin_trap(); }
   __device__ void orthogonalize(int, const double*, i64, double*, double*) { __builtin_trap(); }
   __device__ void dense_block_add(double*, i64, i64, const double*, i64, i64, double, bool) { __builtin_trap(); }
-  __device__ void ldlt_prepare(LdltWork&, i64, i64, bool) {}
+  __device__ void ldlt_prepare(LdltWork& lw, i64 n, i64, bool) {
+    if constexpr (NT == 256 && !PK) {
+      if (n > 256 && n <= kPanelMaxOrder) {
+        lw.panels = true;
+        lw.st = alloc<BkState>(1);
+        lw.swaps = alloc<BkPanelSwaps>(1);
+        lw.bk_w = alloc<double>(static_cast<size_t>((n + 7) / 8 * 8) * 16);
+        lw.bk_perm = alloc<i32>(static_cast<size_t>(n));
+        lw.bk_dtype = alloc<i32>(static_cast<size_t>(n));
+      }
+    }
+  }
 
   // out = J v / J^T v / sym(H) v through the tape's index by output (tape.h CooIdx): a lane owns an output and sums
   // its segment serially, in storage order; an output with a long segment (a variable under many rows: both position
@@ -689,9 +707,215 @@ struct BlockExecT {
   // ---- Bunch-Kaufman LDL^T by one workgroup (DSYTF2 semantics, lower storage) -------------
   // Same pivot rule, interchanges, multipliers and inertia count as bk_pivot_kernel /
   // bk_update_kernel of exec_hip.h and as the DSYTF2 restatement of the test oracle.
+  // ---- orders 257 .. 2048, four wavefronts: panel-blocked Bunch-Kaufman (bk_panel.h) ----------------------------
+  // The unblocked loop below touches the whole trailing matrix once per column from one workgroup (36 M global
+  // read-modify-writes at order 600: 0.12 s per factorisation, a 64-start best_of on a dense order-600 problem took twice
+  // as long batched as one by one).  Here the instance's workgroup runs the host-driven path's panel body (W = L D of 16
+  // columns in registers, the DSYTF2 pivot choices) and then the rank-16 trailing update itself: every trailing entry is
+  // touched once per PANEL.  The factor comes out in the fully permuted form (interchanges applied to earlier columns
+  // too); bk_panels_solve below is the matching solve (32-column blocks, the vector in LDS).
+  template <int ROWS, int NBP>
+  __device__ void bk_panels(LdltWork& lw, double* A, int n, i64 ld, i32* ipiv) {
+    __shared__ double Ls[16][NBP + 1];
+    const int tid = BlockExecT::tid();
+    const i64 ldw = (n + 7) / 8 * 8;
+    BkState* st = lw.st;
+    BkPanelSwaps* swaps = lw.swaps;
+    const double* Wg = lw.bk_w;
+    for (;;) {
+      bk_panel_body<ROWS, NBP, NT>(A, n, ld, ipiv, st, lw.bk_w, ldw, swaps);
+      __syncthreads();
+      const int k0 = st->kp, cnt = st->kstep, pending = st->pending, fail = st->fail, knext = st->k, ns = swaps->count;
+      if (!pending || cnt <= 0) break;
+      // the panel's interchanges on the rows of the columns of EARLIER panels (one lane per column, the swaps in order)
+      if (ns > 0)
+        for (int q = tid; q < k0; q += NT) {
+          double* col = A + static_cast<i64>(q) * ld;
+          for (int e = 0; e < ns; ++e) {
+            const int ra = swaps->rows[2 * e], rb = swaps->rows[2 * e + 1];
+            const double t = col[ra];
+            col[ra] = col[rb];
+            col[rb] = t;
+          }
+        }
+      const int j0 = k0 + cnt;
+      if (!fail && j0 < n) {
+        // A22 -= W21 L21^T: a lane keeps the W rows it owns for the whole update, 16-column strips of multipliers in LDS
+        double w[ROWS][NBP];
+#pragma unroll
+        for (int s2 = 0; s2 < ROWS; ++s2) {
+          const int r = tid + s2 * NT;
+#pragma unroll
+          for (int i = 0; i < NBP; ++i) w[s2][i] = (r >= j0 && r < n) ? Wg[r + static_cast<i64>(i) * ldw] : 0.0;
+        }
+        for (int cstart = j0; cstart < n; cstart += 16) {
+          for (int e = tid; e < 16 * NBP; e += NT) {
+            const int cc = e % 16, i = e / 16;
+            Ls[cc][i] = (cstart + cc < n && i < cnt) ? A[(cstart + cc) + static_cast<i64>(k0 + i) * ld] : 0.0;
+          }
+          __syncthreads();
+#pragma unroll
+          for (int s2 = 0; s2 < ROWS; ++s2) {
+            const int r = tid + s2 * NT;
+            if (r >= cstart && r < n) {
+              double* row = A + r + static_cast<i64>(cstart) * ld;
+              double cur[16];
+#pragma unroll
+              for (int cc = 0; cc < 16; ++cc) cur[cc] = (cstart + cc <= r) ? row[static_cast<i64>(cc) * ld] : 0.0;
+#pragma unroll
+              for (int cc = 0; cc < 16; ++cc) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int i = 0; i < NBP; ++i) sacc += w[s2][i] * Ls[cc][i];
+                if (cstart + cc <= r) row[static_cast<i64>(cc) * ld] = cur[cc] - sacc;
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+      __syncthreads();
+      if (fail || knext >= n) break;
+    }
+  }
+  __device__ bool bk_panels_factor(LdltWork& lw, double* A, int n, i64 ld, i32* ipiv, int* nneg_out, int* nzero_out) {
+    __shared__ int sp[kPanelMaxOrder], sdt[kPanelMaxOrder], spv[kPanelMaxOrder];
+    const int tid = BlockExecT::tid();
+    if (tid == 0) {
+      BkState z;
+      z.k = z.kstep = z.kp = z.pending = z.nneg = z.nzero = z.fail = z.pad = 0;
+      z.d11 = z.d22 = z.d21 = 0.0;
+      *lw.st = z;
+      lw.swaps->count = 0;
+    }
+    __syncthreads();
+    // rows per lane sized to the order: the register tile W (ROWS x NBP doubles) and the per-column work follow
+    if (n <= 2 * NT) bk_panels<2, 16>(lw, A, n, ld, ipiv);
+    else if (n <= 3 * NT) bk_panels<3, 16>(lw, A, n, ld, ipiv);
+    else if (n <= 4 * NT) bk_panels<4, 8>(lw, A, n, ld, ipiv);
+    else if (n <= 6 * NT) bk_panels<6, 8>(lw, A, n, ld, ipiv);
+    else bk_panels<8, 8>(lw, A, n, ld, ipiv);
+    __syncthreads();
+    // the interchanges as ONE permutation and the pivot structure (0: 1x1, 1 / 2: first / second column of a 2x2 block)
+    for (int i = tid; i < n; i += NT) { sp[i] = i; spv[i] = ipiv[i]; }
+    __syncthreads();
+    if (tid == 0) {
+      int k = 0;
+      while (k < n) {
+        if (spv[k] > 0) {
+          const int kp = spv[k] - 1;
+          if (kp != k) { const int t = sp[k]; sp[k] = sp[kp]; sp[kp] = t; }
+          sdt[k] = 0;
+          k += 1;
+        } else {
+          const int kp = -spv[k] - 1;
+          if (k + 1 < n && kp != k + 1) { const int t = sp[k + 1]; sp[k + 1] = sp[kp]; sp[kp] = t; }
+          sdt[k] = 1;
+          if (k + 1 < n) sdt[k + 1] = 2;
+          k += 2;
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) { lw.bk_perm[i] = sp[i]; lw.bk_dtype[i] = sdt[i]; }
+    __syncthreads();
+    *nneg_out = lw.st->nneg;
+    *nzero_out = lw.st->nzero;
+    return lw.st->fail == 0;
+  }
+  // P A P^T = L D L^T x = b with the vector in LDS: 32-column blocks, the diagonal block by one wavefront (lane = row,
+  // v_readlane broadcasts), the rows below / the columns' dot products by all four (exec_hip.h bk_solve_kernel's form)
+  __device__ void bk_panels_solve(const LdltWork& lw, const double* A, int n, i64 ld, double* b) {
+    __shared__ double x[kPanelMaxOrder];
+    __shared__ double Lb[32][33];
+    const int tid = BlockExecT::tid(), lane = tid & 63, wave = tid >> 6;
+    const i32 *perm = lw.bk_perm, *dtype = lw.bk_dtype;
+    for (int i = tid; i < n; i += NT) x[i] = b[perm[i]];
+    __syncthreads();
+    auto stage_diag = [&](int j0, int jb) {
+      for (int e = tid; e < jb * jb; e += NT) {
+        const int r = e % jb, c = e / jb;
+        double v = (r > c) ? A[(j0 + r) + static_cast<i64>(j0 + c) * ld] : 0.0;
+        if (r == c + 1 && dtype[j0 + c] == 1) v = 0.0;          // the off-diagonal of a 2x2 pivot is D, not L
+        Lb[r][c] = v;
+      }
+    };
+    for (int j0 = 0; j0 < n; j0 += 32) {                         // forward: L y = P b
+      const int jb = n - j0 < 32 ? n - j0 : 32;
+      stage_diag(j0, jb);
+      __syncthreads();
+      if (wave == 0) {
+        double y = lane < jb ? x[j0 + lane] : 0.0;
+        for (int c = 0; c < jb; ++c) {
+          const double yc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(y), c), __builtin_amdgcn_readlane(__double2loint(y), c));
+          if (lane > c && lane < jb) y -= Lb[lane][c] * yc;
+        }
+        if (lane < jb) x[j0 + lane] = y;
+      }
+      __syncthreads();
+      const int r0 = j0 + jb;
+      const bool straddle = dtype[r0 - 1] == 1;                  // 2x2 pivot across the block boundary
+      for (int r = r0 + tid; r < n; r += NT) {
+        double s = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < jb; ++c) s += A[r + static_cast<i64>(j0 + c) * ld] * x[j0 + c];
+        if (straddle && r == r0) s -= A[r + static_cast<i64>(r0 - 1) * ld] * x[r0 - 1];
+        x[r] -= s;
+      }
+      __syncthreads();
+    }
+    for (int k = tid; k < n; k += NT) {                          // D z = y
+      const int ty = dtype[k];
+      if (ty == 0) {
+        x[k] /= A[k + static_cast<i64>(k) * ld];
+      } else if (ty == 1) {
+        const double akm1k = A[k + 1 + static_cast<i64>(k) * ld];
+        const double akm1 = A[k + static_cast<i64>(k) * ld] / akm1k, ak = A[k + 1 + static_cast<i64>(k + 1) * ld] / akm1k;
+        const double denom = akm1 * ak - 1.0, bkm1 = x[k] / akm1k, bkk = x[k + 1] / akm1k;
+        x[k] = (ak * bkm1 - bkk) / denom;
+        x[k + 1] = (akm1 * bkk - bkm1) / denom;
+      }
+    }
+    __syncthreads();
+    for (int j0 = (n - 1) / 32 * 32; j0 >= 0; j0 -= 32) {       // backward: L^T w = z
+      const int jb = n - j0 < 32 ? n - j0 : 32;
+      const int r0 = j0 + jb;
+      stage_diag(j0, jb);
+      const bool straddle = r0 < n && dtype[r0 - 1] == 1;
+      for (int c = wave; c < jb; c += NT / 64) {
+        double s = 0.0;
+        for (int r = r0 + lane; r < n; r += 64) s += A[r + static_cast<i64>(j0 + c) * ld] * x[r];
+        s = wave_all_sum(s);
+        if (lane == 0) {
+          if (straddle && c == jb - 1) s -= A[r0 + static_cast<i64>(r0 - 1) * ld] * x[r0];
+          x[j0 + c] -= s;
+        }
+      }
+      __syncthreads();
+      if (wave == 0) {
+        double w = lane < jb ? x[j0 + lane] : 0.0;
+        for (int c = jb - 1; c >= 0; --c) {
+          const double wc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(w), c), __builtin_amdgcn_readlane(__double2loint(w), c));
+          if (lane < c) w -= Lb[c][lane] * wc;
+        }
+        if (lane < jb) x[j0 + lane] = w;
+      }
+      __syncthreads();
+    }
+    for (int i = tid; i < n; i += NT) b[perm[i]] = x[i];
+    __syncthreads();
+  }
+
   __device__ bool ldlt_factor(LdltWork& lw, double* A, i64 nn, i64 ld, i32* ipiv, bool, int* nneg_out, int* nzero_out) {
     const int n = static_cast<int>(nn), tid = BlockExecT::tid();
     lw.standard = false;
+    if constexpr (NT == 256 && !PK) {
+      if (lw.panels) {
+        const bool ok = bk_panels_factor(lw, A, n, ld, ipiv, nneg_out, nzero_out);
+        parity = 0;
+        return ok;
+      }
+    }
     if (n <= 256) {
       // small instance: one wavefront, no workgroup barrier inside; L comes out in standard form
       lw.standard = true;
@@ -866,6 +1090,9 @@ struct BlockExecT {
   // DSYTRS (lower) by one workgroup; b in exec-space memory
   __device__ void ldlt_solve(LdltWork& lw, const double* A, i64 nn, i64 ld, const i32* ipiv, bool, double* b) {
     const int n = static_cast<int>(nn), tid = BlockExecT::tid();
+    if constexpr (NT == 256 && !PK) {
+      if (lw.panels) { bk_panels_solve(lw, A, n, ld, b); return; }
+    }
     if (n <= kWaveSolveMax) { ldlt_solve_wave(A, n, ld, ipiv, b, lw.standard); return; }
     int k = 0;
     while (k < n) {

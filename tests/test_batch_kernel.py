@@ -280,3 +280,70 @@ def test_instance_data_generated_on_the_device_equals_host_rows(gpu_required):
         np.testing.assert_allclose(res_dev.raw["obj_val"][same], raw["obj_val"][same], rtol=1e-8, atol=1e-10)
         np.testing.assert_allclose(res_dev.x[same], raw["x"][same], rtol=1e-6, atol=1e-7)
         pb.close()
+
+
+@pytest.mark.gpu
+def test_best_of_64_on_a_dense_kkt_of_order_600_is_one_launch(gpu_required, capsys):
+    """best_of on a mid-size DENSE problem (reference problem.py:1256-1269): 400 variables under 200 dense equality
+    rows — KKT order 600, no sparsity to plan — runs its 64 starts as one batched launch (four wavefronts per
+    instance, the factorisation by the workgroup on the instance's matrix in global memory); objectives per start
+    and the selected optimum equal the serial loop's."""
+    import dnlp_amd as cp
+
+    def build():
+        rng = np.random.default_rng(5)
+        n, m = 400, 200
+        A = rng.standard_normal((m, n))
+        xs = rng.uniform(-1.0, 1.0, n)
+        x = cp.Variable(n, name="x")
+        x.sample_bounds = [-2.0, 2.0]
+        obj = cp.sum(cp.power(x, 4)) - 3.0 * cp.sum(cp.square(x))          # a double well per coordinate
+        return cp.Problem(cp.Minimize(obj), [A @ x == A @ xs]), x
+
+    prob, x = build()
+    np.random.seed(1)
+    prob.solve(nlp=True, best_of=64)
+    objs_b = np.array(prob.solver_stats.extra_stats["all_objs_from_best_of"])
+    assert "Solving 64 NLP starts in one batched launch" in capsys.readouterr().out
+    val_b = prob.value
+    prob, x = build()
+    np.random.seed(1)
+    prob.solve(nlp=True, best_of=64, batch=False)
+    objs_s = np.array(prob.solver_stats.extra_stats["all_objs_from_best_of"])
+    assert len(set(np.round(objs_s, 5))) > 4                 # the starts end in different local minima
+    np.testing.assert_allclose(objs_b, objs_s, rtol=1e-6, atol=1e-7)
+    assert abs(val_b - prob.value) <= 1e-6 * max(1.0, abs(val_b))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nv", [200, 600, 900])
+def test_dense_instances_above_order_256_in_one_launch(nv, gpu_required):
+    """Dense batch instances of KKT order 300 / 900 / 1350 (two, four and six rows per lane of the in-workgroup
+    panel-blocked Bunch-Kaufman, csrc/exec_block.h bk_panels): each instance of a two-start launch ends where the
+    host-driven solve of the same start ends."""
+    import dnlp_amd as cp
+    from dnlp_amd.batch import _device_handle, instance_data
+    rng = np.random.default_rng(nv)
+    m = nv // 2
+    A = rng.standard_normal((m, nv))
+    xs = rng.uniform(-1.0, 1.0, nv)
+    x = cp.Variable(nv, name="x")
+    x.sample_bounds = [-2.0, 2.0]
+    prob = cp.Problem(cp.Minimize(cp.sum(cp.power(x, 4)) - 3.0 * cp.sum(cp.square(x))), [A @ x == A @ xs])
+    chain = prob._build_chain(None)
+    np.random.seed(nv)
+    rows, starts = [], []
+    for run in range(2):
+        prob.set_random_NLP_initial_point(run)
+        starts.append(x.value.copy())
+        data, _ = chain.apply(prob, make_handle=False)
+        rows.append(instance_data(data["tape_arrays"]))
+    h = _device_handle(data["tape_arrays"], data["tape"], None, {"print_level": 0})
+    raw = h.solve_batch(np.stack(rows), want_duals=True)
+    h.close()
+    assert list(raw["status"]) == [0, 0]
+    for k in range(2):
+        x.value = starts[k]
+        prob.solve(nlp=True)
+        assert abs(raw["obj_val"][k] - prob.value) <= 1e-6 * max(1.0, abs(prob.value)), (k, raw["obj_val"][k], prob.value)
+        np.testing.assert_allclose(A @ raw["x"][k][:nv], A @ xs, rtol=0, atol=1e-6)
