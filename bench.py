@@ -31,7 +31,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_PROFILE = "r03_pmc_bench_traffic.json"   # rocprofv3 --pmc passes of this command (refreshed per round)
+TRAFFIC_PROFILE = "r04_pmc_bench_traffic.json"   # rocprofv3 --pmc passes of this command (refreshed per round)
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X datasheet FP64 matrix peak (dense); see DESIGN.md §5
 
 
@@ -212,7 +212,7 @@ def cpu_baseline(seed, device, sweep=CPU_SWEEP):
                          ctypes.util.find_library("ipopt") or "not found")}
 
 
-C5_TRAFFIC_PROFILE = "r03_pmc_batch_8192_final.json"  # rocprofv3 --pmc passes of `bench.py --workload c5` (per round)
+C5_TRAFFIC_PROFILE = "r04_pmc_batch_8192.json"  # rocprofv3 --pmc passes of `bench.py --workload c5` (per round)
 PEAK_HBM_GBS = 8000.0                           # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 

@@ -102,6 +102,13 @@ struct ProblemT {
     const auto& t = *model.owner;
     const double n = static_cast<double>(t.N + t.m);
     if (t.nblk > 0 || t.ndense > 0 || n < 2) return;
+    // a forced-dense handle needs the analysis only for the static pairing of kkt_dense.h (ensure_ipm's conditions):
+    // outside them the Jacobian sweep and the whole update program would be built for nothing
+    if (linear_solver == 1) {
+      const i64 nn = t.N + t.m;
+      const bool pairing = E::has_host_control && kkt_paired && nn >= paired_min_n && nn <= 16384 && optimistic_min_n > nn;
+      if (!pairing) return;
+    }
     // Jacobian magnitudes at the tape's start point steer the static 2x2 pairing away from
     // couplings that vanish there
     std::vector<double>& jabs = plan_jabs;

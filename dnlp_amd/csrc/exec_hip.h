@@ -1136,6 +1136,7 @@ struct HipExec : HostControlled {
 
   struct LdltWork {
     BkState* st = nullptr;
+    i64 bk_n = 0;                // order the Bunch-Kaufman workspace below was sized for
     i32* bk_perm = nullptr;      // Bunch-Kaufman: the interchanges as one permutation, and the pivot structure
     i32* bk_dtype = nullptr;
     double* bk_w = nullptr;      // panel workspace W = L D of bk_panel_kernel (n x 16)

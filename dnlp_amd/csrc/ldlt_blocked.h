@@ -1481,6 +1481,7 @@ struct BlockedLdlt {
   int max_neg = -1;            // >= 0: give up as soon as more negative pivots than this appear
   double *Linv = nullptr, *LinvT = nullptr;   // inverted 128 x 128 diagonal blocks of the current factor (and transposes)
   bool inv_ready = false;      // ... computed by the first solve after a factorisation
+  const double* inv_of = nullptr;   // ... of THIS matrix (a solve on another buffer recomputes them)
   bool solve_inv = true;       // DNLP_LDLT_SOLVE_INV=0: the substitution-based block solves
 
   BlockedLdlt() = default;
@@ -1790,7 +1791,9 @@ struct BlockedLdlt {
       DNLP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ldlt_inv128_mfma_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, SI_INVM_LDS));
     }
+    if (inv_of != A) inv_ready = false;
     if (!inv_ready) {
+      inv_of = A;
       if (inv_mfma)
         hipLaunchKernelGGL(ldlt_inv128_mfma_kernel, dim3(static_cast<unsigned>(nb128)), dim3(SI_INVM_THREADS), SI_INVM_LDS, ex->stream, A, ld, ni,
                            Linv, LinvT);
@@ -1920,6 +1923,8 @@ inline void HipExec::sparse_tail_gemm(double* T, i64 ldt, const double* Pl, cons
 inline void HipExec::ldlt_prepare(LdltWork& w, i64 n, i64 ld, bool pivoted) {
   if (pivoted) {
     if (n > BK_NMAX) throw std::runtime_error("Bunch-Kaufman path: order above BK_NMAX");
+    if (w.st && w.bk_n == n) return;                 // (prepared before for this order: the workspace is kept)
+    w.bk_n = n;
     w.st = alloc<BkState>(1);
     w.bk_perm = alloc<i32>(static_cast<size_t>(n));
     w.bk_dtype = alloc<i32>(static_cast<size_t>(n));
@@ -1927,6 +1932,8 @@ inline void HipExec::ldlt_prepare(LdltWork& w, i64 n, i64 ld, bool pivoted) {
     w.bk_swaps = alloc<BkPanelSwaps>(1);
     if (const char* ev = std::getenv("DNLP_BK_PANELS")) w.bk_panels = std::atoi(ev) != 0;
   } else {
+    // (a handle demoted from paired / optimistic mode prepares again: the workspace of the same order is kept)
+    if (w.blocked && w.blocked->n == n && w.blocked->ld == ld) return;
     w.blocked = new BlockedLdlt();
     { BlockedLdlt* owned = w.blocked; at_exit_.push_back([owned] { delete owned; }); }
     w.blocked->init(this, n, ld);
