@@ -714,9 +714,15 @@ struct BlockExecT {
   // columns in registers, the DSYTF2 pivot choices) and then the rank-16 trailing update itself: every trailing entry is
   // touched once per PANEL.  The factor comes out in the fully permuted form (interchanges applied to earlier columns
   // too); bk_panels_solve below is the matching solve (32-column blocks, the vector in LDS).
+  // (the LDS arrays of the three phases — update strips, permutation pass, solve — are never live together: one pool)
+  static constexpr int kBkPoolDoubles = kPanelMaxOrder + 32 * 33 + 8;
+  __device__ static double* bk_pool() {
+    __shared__ __attribute__((aligned(16))) double pool[kBkPoolDoubles];
+    return pool;
+  }
   template <int ROWS, int NBP>
   __device__ void bk_panels(LdltWork& lw, double* A, int n, i64 ld, i32* ipiv) {
-    __shared__ double Ls[16][NBP + 1];
+    double (*Ls)[NBP + 1] = reinterpret_cast<double (*)[NBP + 1]>(bk_pool());
     const int tid = BlockExecT::tid();
     const i64 ldw = (n + 7) / 8 * 8;
     BkState* st = lw.st;
@@ -779,7 +785,9 @@ struct BlockExecT {
     }
   }
   __device__ bool bk_panels_factor(LdltWork& lw, double* A, int n, i64 ld, i32* ipiv, int* nneg_out, int* nzero_out) {
-    __shared__ int sp[kPanelMaxOrder], sdt[kPanelMaxOrder], spv[kPanelMaxOrder];
+    static_assert(3 * kPanelMaxOrder * sizeof(int) <= kBkPoolDoubles * sizeof(double), "permutation pass does not fit the pool");
+    int* sp = reinterpret_cast<int*>(bk_pool());
+    int *sdt = sp + kPanelMaxOrder, *spv = sdt + kPanelMaxOrder;
     const int tid = BlockExecT::tid();
     if (tid == 0) {
       BkState z;
@@ -826,8 +834,8 @@ struct BlockExecT {
   // P A P^T = L D L^T x = b with the vector in LDS: 32-column blocks, the diagonal block by one wavefront (lane = row,
   // v_readlane broadcasts), the rows below / the columns' dot products by all four (exec_hip.h bk_solve_kernel's form)
   __device__ void bk_panels_solve(const LdltWork& lw, const double* A, int n, i64 ld, double* b) {
-    __shared__ double x[kPanelMaxOrder];
-    __shared__ double Lb[32][33];
+    double* x = bk_pool();
+    double (*Lb)[33] = reinterpret_cast<double (*)[33]>(x + kPanelMaxOrder);
     const int tid = BlockExecT::tid(), lane = tid & 63, wave = tid >> 6;
     const i32 *perm = lw.bk_perm, *dtype = lw.bk_dtype;
     for (int i = tid; i < n; i += NT) x[i] = b[perm[i]];

@@ -1594,10 +1594,7 @@ struct BlockedLdlt {
   bool factor(double* A, int* nneg, int* nzero) {
     hipStream_t s0 = ex->stream;
     inv_ready = false;
-    LdltInfo z;
-    std::memset(&z, 0, sizeof z);
-    DNLP_HIP_CHECK(hipMemcpyAsync(info, &z, sizeof z, hipMemcpyHostToDevice, s0));
-    DNLP_HIP_CHECK(hipStreamSynchronize(s0));
+    DNLP_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(LdltInfo), s0));      // (stream-ordered: no host round trip before the first panel)
     const double tiny = 1e-300;
     const int ni = static_cast<int>(n);
     const int npanels = (ni + NB - 1) / NB;
