@@ -1674,7 +1674,7 @@ struct HipExec : HostControlled {
     std::memset(lb_host, 0, sizeof(LbfgsState));
     lb_host->tol = tol; lb_host->max_iter = max_iter; lb_host->M = M; lb_host->nblocks = static_cast<int>(blocks);
     DNLP_HIP_CHECK(hipMemcpyAsync(lb_state, lb_host, sizeof(LbfgsState), hipMemcpyHostToDevice, stream));
-    if (lb_persist && lb_persist_wgs >= 2 && lb_persist_wgs <= ncu && !lb_persist_failed_) {
+    if (lb_persist && lb_persist_wgs >= 2 && lb_persist_wgs <= ncu && lb_persist_wgs <= kLbPersistMaxWgs && !lb_persist_failed_) {
       // ONE launch: the state goes in zeroed, comes back final.  The kernel's grid barrier needs every workgroup
       // resident at once: the launch is COOPERATIVE (the runtime refuses it when the grid cannot be co-resident with the
       // ~150 KB of LDS per workgroup — another stream, handle or process holding LDS or compute units), and x is saved

@@ -51,10 +51,16 @@ struct LbPersistCtl {
   unsigned arrive; unsigned abort; unsigned pad[30];        // top barrier counter on a line of its own
   unsigned grp[8][32];                                      // arrival counter of workgroup group g = blockIdx % 8, a line each
   unsigned gen[8][32];                                      // generation word the members of group g wait on, a line each
-  double acc[3][96 * 16];                                   // rotating accumulators, ONE PER 128-BYTE LINE: f, chk, 3 x 31 inner
-                                                            // products, max |g| (atomics to one line serialise in its L2 channel:
-                                                            // sixteen accumulators per line made a barrier phase 32 us)
+  double acc[3][96 * 16];                                   // rotating accumulators, one per 128-byte line; since round 4 only
+                                                            // entry 95 is live: max |g| (an atomic max: order-independent)
+  // Order-fixed sums across the workgroups (round 4: the atomic adds that used to land here in arrival order made C2 the
+  // one path whose bits could change from run to run): a workgroup stores its 95 partial sums in its row of `part`, the
+  // LAST arriver of a barrier group adds its group's rows in member order into gsum[parity][group], and after the
+  // barrier every workgroup adds the eight group sums in group order.
+  double gsum[2][8][96];
+  double part[256][96];
 };
+constexpr int kLbPersistMaxWgs = 256;                       // rows of LbPersistCtl::part
 
 // `per` > 0 adds the persistent kernel dnlp_lb_persist for workgroups that own `per` consecutive variables each.
 // `mode`: where a workgroup keeps its slice — 0 everything in LDS (slices up to ~700 variables at M = 10), 1 the 2M
@@ -478,7 +484,8 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_control(LbfgsState* __
 // numbers (Armijo test, curvature test, two-loop recursion on its own LDS copy of the Gram matrix).  The four-kernel
 // slot above spends its time in dependent global loads (state, coefficients, rows): 50 us per slot at n = 1e5.
 #define DNLP_PL (DNLP_PER + 2 * DNLP_W)
-struct LbPersistCtl { unsigned arrive; unsigned abort; unsigned pad[30]; unsigned grp[8][32]; unsigned gen[8][32]; double acc[3][96 * 16]; };
+struct LbPersistCtl { unsigned arrive; unsigned abort; unsigned pad[30]; unsigned grp[8][32]; unsigned gen[8][32]; double acc[3][96 * 16];
+                      double gsum[2][8][96]; double part[256][96]; };
 #define DNLP_ACC(p, k) ((p) + 16 * (k))
 
 __device__ __forceinline__ double dnlp_agent_load(const double* p) {
@@ -522,6 +529,85 @@ __device__ __forceinline__ bool dnlp_grid_barrier(LbPersistCtl* ctl, unsigned& e
   return *s_flag != 0;
 }
 
+// The same barrier carrying the order-fixed sums of the 95 per-workgroup partials in wpart (LDS) into red (LDS):
+// see LbPersistCtl::part / gsum.  scr: 192 doubles of LDS.
+// Everything that crosses workgroups in this kernel travels as device-scope atomic loads / stores (write-through, cache-
+// bypassing): between them only ORDER is needed — all of this wavefront's memory operations complete before the next one
+// issues — not the L2 write-back + invalidate of a device-scope fence (DNLP_LB_FULL_FENCE=1 restores __threadfence()).
+#ifdef DNLP_LB_FULL_FENCE
+#define DNLP_ORDER_FENCE() __threadfence()
+#else
+#define DNLP_ORDER_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+#endif
+__device__ __forceinline__ bool dnlp_grid_barrier_sum(LbPersistCtl* ctl, unsigned& epoch, const unsigned nwg, int* s_flag, int* s_lead,
+                                                      const double* wpart, double* red, double* scr, const int parity) {
+  ++epoch;                                             // (uniform: every lane counts the barriers)
+  const int tid = threadIdx.x;
+  const unsigned g = blockIdx.x & 7u, ngroups = nwg < 8u ? nwg : 8u;
+  const unsigned gsize = (nwg + 7u - g) >> 3;          // workgroups with blockIdx % 8 == g
+  __syncthreads();                                     // wpart is complete
+  if (tid < 95) __hip_atomic_store(&ctl->part[blockIdx.x][tid], wpart[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (tid == 0) {
+    DNLP_ORDER_FENCE();                                   // release: this workgroup's stores before the arrive
+    const unsigned mine = atomicAdd(&ctl->grp[g][0], 1u) + 1u;
+    *s_lead = (mine == epoch * gsize) ? 1 : 0;
+  }
+  __syncthreads();
+  const bool leader = *s_lead != 0;
+  if (leader) {
+    DNLP_ORDER_FENCE();                                   // acquire: the members' rows
+    if (tid < 192) {
+      // two half-sums per value, members in index order, then the halves: the same tree whoever arrives last
+      const int v = tid % 96, c = tid / 96;
+      const unsigned half = (gsize + 1u) >> 1, k0 = c ? half : 0u, k1 = c ? gsize : half;
+      // (the loads of a half issued together, THEN added in member order: a load-add loop is a chain of round trips)
+      double t[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t[q] = (v < 95 && k0 + q < k1) ? dnlp_agent_load(&ctl->part[g + 8u * (k0 + q)][v]) : 0.0;
+      double sacc = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sacc += t[q];
+      scr[c * 96 + v] = sacc;
+    }
+    __syncthreads();
+    if (tid < 95) __hip_atomic_store(&ctl->gsum[parity][g][tid], scr[tid] + scr[96 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    unsigned spins = 0;
+    int ok = 1;
+    if (leader) { DNLP_ORDER_FENCE(); atomicAdd(&ctl->arrive, 1u); }
+    unsigned* word = leader ? &ctl->arrive : &ctl->gen[g][0];
+    const unsigned target = leader ? epoch * ngroups : epoch;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 1023u) == 0u) {
+        if (spins > (1u << 22) || __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
+      }
+    }
+    DNLP_ORDER_FENCE();                                   // acquire what the other groups released; ordered before the release below
+    if (leader && ok) __hip_atomic_store(&ctl->gen[g][0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_flag = ok;
+  }
+  __syncthreads();
+  if (*s_flag == 0) return false;
+  if (tid < 95) {
+    double t[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) t[h] = (static_cast<unsigned>(h) < ngroups) ? dnlp_agent_load(&ctl->gsum[parity][h][tid]) : 0.0;
+    double sacc = 0.0;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) sacc += t[h];
+    red[tid] = sacc;
+  }
+  return true;                                         // (the caller's next __syncthreads publishes red)
+}
+
 extern "C" __global__ void __launch_bounds__(256) dnlp_lb_persist(LbfgsState* __restrict__ S, double* __restrict__ x,
     const double* __restrict__ consts, LbPersistCtl* __restrict__ ctl, double* __restrict__ halo, const double c0, const i64 nf,
     double* __restrict__ strip) {
@@ -546,7 +632,7 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_persist(LbfgsState* __
 #endif
 #endif
   __shared__ double Gs[DNLP_MAXNB * DNLP_MAXNB];
-  __shared__ double cf[DNLP_MAXNB], rh[16], red[96], wred[4][4];
+  __shared__ double cf[DNLP_MAXNB], rh[16], red[96], wred[4][4], wpart[96], scr[192];
   __shared__ double sc[8];                                  // gd, step, (spare)
   __shared__ int sci[8];                                    // head, stored, iter, done, flag
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -565,6 +651,7 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_persist(LbfgsState* __
   for (int k = tid; k < DNLP_MAXNB * DNLP_MAXNB; k += 256) Gs[k] = 0.0;
   if (tid < DNLP_MAXNB) cf[tid] = 0.0;
   if (tid < 16) rh[tid] = 0.0;
+  if (tid < 96) wpart[tid] = 0.0;
   __syncthreads();
   // replicated state (every lane of every workgroup holds the same values)
   double f = 0.0, step = 0.0, gd = 0.0, gn = 0.0;
@@ -630,16 +717,15 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_persist(LbfgsState* __
           }
         }
       }
-      double* accd = ctl->acc[slot % 3];
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int j = wave + 4 * r;
         if (j < nb) {
           const double a = dnlp_wave_sum(as_[r]), b = dnlp_wave_sum(ay_[r]), c = dnlp_wave_sum(ag_[r]);
-          if (lane == 0) {
-            atomicAdd(DNLP_ACC(accd, 2 + j), a);
-            atomicAdd(DNLP_ACC(accd, 2 + DNLP_MAXNB + j), b);
-            atomicAdd(DNLP_ACC(accd, 2 + 2 * DNLP_MAXNB + j), c);
+          if (lane == 0) {                              // (row j belongs to this wavefront alone: plain LDS stores)
+            wpart[2 + j] = a;
+            wpart[2 + DNLP_MAXNB + j] = b;
+            wpart[2 + 2 * DNLP_MAXNB + j] = c;
           }
         }
       }
@@ -651,8 +737,8 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_persist(LbfgsState* __
     __syncthreads();
     double* acc = ctl->acc[slot % 3];
     if (tid == 0) {
-      atomicAdd(DNLP_ACC(acc, 0), (wred[0][0] + wred[1][0]) + (wred[2][0] + wred[3][0]));
-      atomicAdd(DNLP_ACC(acc, 1), (wred[0][1] + wred[1][1]) + (wred[2][1] + wred[3][1]));
+      wpart[0] = (wred[0][0] + wred[1][0]) + (wred[2][0] + wred[3][0]);
+      wpart[1] = (wred[0][1] + wred[1][1]) + (wred[2][1] + wred[3][1]);
       const double g4 = fmax(fmax(wred[0][2], wred[1][2]), fmax(wred[2][2], wred[3][2]));
       // max of non-negative doubles = max of their bit patterns as unsigned integers
       atomicMax(reinterpret_cast<unsigned long long*>(DNLP_ACC(acc, 95)), static_cast<unsigned long long>(__double_as_longlong(g4)));
@@ -664,8 +750,8 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_persist(LbfgsState* __
       __hip_atomic_store(hb + tid, own > tid ? gnew[W + tid] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(hb + W + tid, own >= W ? gnew[W + own - W + tid] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!dnlp_grid_barrier(ctl, epoch, nwg, &sci[4])) { done = 5; break; }
-    if (tid < 96) red[tid] = dnlp_agent_load(DNLP_ACC(acc, tid));
+    if (!dnlp_grid_barrier_sum(ctl, epoch, nwg, &sci[4], &sci[5], wpart, red, scr, slot & 1)) { done = 5; break; }
+    if (tid == 95) red[95] = dnlp_agent_load(DNLP_ACC(acc, 95));
     if (tid >= 128 && tid < 128 + W) {
       // left halo = the last W entries of the left neighbour, right halo = the first W of the right one
       const int t = tid - 128;

@@ -97,3 +97,25 @@ def test_c5_member_launch_is_bitwise_repeatable(gpu_required, which):
         assert np.array_equal(r[1], res[0][1]), (which, "iteration counts differ on", int(np.sum(r[1] != res[0][1])), "instances")
         assert np.array_equal(r[3], res[0][3]), (which, "objective bits differ")
         assert np.array_equal(r[2], res[0][2]), (which, "x bits differ")
+
+
+def test_c2_persistent_lbfgs_is_bitwise_repeatable(gpu_required):
+    """BASELINE C2 at its stated size through the one-launch L-BFGS kernel (csrc/lbfgs_codegen.h): the sums across its
+    workgroups — f, the check sum and the 3 (2M + 1) inner products of every trial point — are added in member /
+    group order inside the grid barrier, not by atomics in arrival order: two fresh handles x three solves end on
+    the same bits after the same number of iterations and evaluations."""
+    import dnlp_amd as cp
+    from problem_zoo import rosenbrock_chain
+    runs = []
+    for _ in range(2):
+        prob = rosenbrock_chain(cp, 100000)
+        chain = prob._build_chain(None)
+        data, _ = chain.apply(prob)
+        for _ in range(3):
+            info = chain.solver.solve_via_data(dict(data), True, False, {"algorithm": "lbfgs"})
+            assert info["status"] == 0 and info["device_loop"] and info["device_loop_persistent"]
+            runs.append((int(info["iterations"]), int(info["evaluations"]), float(info["obj_val"]), np.array(info["x"])))
+    for r in runs[1:]:
+        assert (r[0], r[1]) == (runs[0][0], runs[0][1]), ("iterations / evaluations differ", [(q[0], q[1]) for q in runs])
+        assert r[2] == runs[0][2], ("objective bits differ", r[2], runs[0][2])
+        assert np.array_equal(r[3], runs[0][3]), ("x bits differ", float(np.max(np.abs(r[3] - runs[0][3]))))
