@@ -71,6 +71,8 @@ inline std::string lbfgs_codegen_source(const std::vector<FusedSlotProg>& progs,
   std::string s = fused_codegen_preamble(info.E);
   s += "#define DNLP_M " + std::to_string(M) + "\n#define DNLP_NB " + std::to_string(2 * M + 1) + "\n";
   if (per > 0) s += "#define DNLP_PER " + std::to_string(per) + "\n#define DNLP_PMODE " + std::to_string(mode) + "\n";
+  if (const char* ev = std::getenv("DNLP_LBFGS_FULL_FENCE"); ev && std::atoi(ev) != 0) s += "#define DNLP_LB_FULL_FENCE 1\n";     // (A/B of the barrier's fences)
+  if (const char* ev = std::getenv("DNLP_LBFGS_ATOMIC_SUMS"); ev && std::atoi(ev) != 0) s += "#define DNLP_LB_ATOMIC_SUMS 1\n";   // (the arrival-order sums of rounds 3-4: not reproducible)
   s += fused_codegen_chunk(progs, info);
   s += "struct LbfgsState { " DNLP_LB_STR(DNLP_LB_STATE_BODY) " };\n";
   s += R"DNLPLB(
@@ -491,6 +493,14 @@ struct LbPersistCtl { unsigned arrive; unsigned abort; unsigned pad[30]; unsigne
 __device__ __forceinline__ double dnlp_agent_load(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Everything that crosses workgroups in this kernel travels as device-scope atomic loads / stores (write-through, cache-
+// bypassing): between them only ORDER is needed — all of this wavefront's memory operations complete before the next one
+// issues — not the L2 write-back + invalidate of a device-scope fence (DNLP_LB_FULL_FENCE=1 restores __threadfence()).
+#ifdef DNLP_LB_FULL_FENCE
+#define DNLP_ORDER_FENCE() __threadfence()
+#else
+#define DNLP_ORDER_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+#endif
 // Two-level counter barrier over the nwg co-resident workgroups (grid <= compute units: every workgroup is resident).
 // 256 arrivals on ONE device-scope counter serialise in its memory channel (~12 ns each: 3 us before the last arriver
 // is even counted) and 256 pollers hammer the same line; here a workgroup arrives on the counter of its group
@@ -501,7 +511,7 @@ __device__ __forceinline__ bool dnlp_grid_barrier(LbPersistCtl* ctl, unsigned& e
   ++epoch;                                             // (uniform: every lane counts the barriers)
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence();                                   // release: this workgroup's stores and atomics before the arrive
+    DNLP_ORDER_FENCE();                                   // release: this workgroup's stores and atomics before the arrive
     const unsigned g = blockIdx.x & 7u, ngroups = nwg < 8u ? nwg : 8u;
     const unsigned gsize = (nwg + 7u - g) >> 3;        // workgroups with blockIdx % 8 == g
     const unsigned mine = atomicAdd(&ctl->grp[g][0], 1u) + 1u;
@@ -522,7 +532,7 @@ __device__ __forceinline__ bool dnlp_grid_barrier(LbPersistCtl* ctl, unsigned& e
       }
     }
     if (leader && ok) __hip_atomic_store(&ctl->gen[g][0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();                                   // acquire
+    DNLP_ORDER_FENCE();                                   // acquire
     *s_flag = ok;
   }
   __syncthreads();
@@ -531,15 +541,9 @@ __device__ __forceinline__ bool dnlp_grid_barrier(LbPersistCtl* ctl, unsigned& e
 
 // The same barrier carrying the order-fixed sums of the 95 per-workgroup partials in wpart (LDS) into red (LDS):
 // see LbPersistCtl::part / gsum.  scr: 192 doubles of LDS.
-// Everything that crosses workgroups in this kernel travels as device-scope atomic loads / stores (write-through, cache-
-// bypassing): between them only ORDER is needed — all of this wavefront's memory operations complete before the next one
-// issues — not the L2 write-back + invalidate of a device-scope fence (DNLP_LB_FULL_FENCE=1 restores __threadfence()).
-#ifdef DNLP_LB_FULL_FENCE
-#define DNLP_ORDER_FENCE() __threadfence()
-#else
-#define DNLP_ORDER_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
-#endif
-__device__ __forceinline__ bool dnlp_grid_barrier_sum(LbPersistCtl* ctl, unsigned& epoch, const unsigned nwg, int* s_flag, int* s_lead,
+// The same barrier carrying the order-fixed sums of the 95 per-workgroup partials in wpart (LDS) into red (LDS):
+// see LbPersistCtl::part / gsum.  scr: 192 doubles of LDS.
+__device__ __noinline__ bool dnlp_grid_barrier_sum(LbPersistCtl* ctl, unsigned& epoch, const unsigned nwg, int* s_flag, int* s_lead,
                                                       const double* wpart, double* red, double* scr, const int parity) {
   ++epoch;                                             // (uniform: every lane counts the barriers)
   const int tid = threadIdx.x;
@@ -723,9 +727,16 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_persist(LbfgsState* __
         if (j < nb) {
           const double a = dnlp_wave_sum(as_[r]), b = dnlp_wave_sum(ay_[r]), c = dnlp_wave_sum(ag_[r]);
           if (lane == 0) {                              // (row j belongs to this wavefront alone: plain LDS stores)
+#ifdef DNLP_LB_ATOMIC_SUMS
+            double* accd = ctl->acc[slot % 3];
+            atomicAdd(DNLP_ACC(accd, 2 + j), a);
+            atomicAdd(DNLP_ACC(accd, 2 + DNLP_MAXNB + j), b);
+            atomicAdd(DNLP_ACC(accd, 2 + 2 * DNLP_MAXNB + j), c);
+#else
             wpart[2 + j] = a;
             wpart[2 + DNLP_MAXNB + j] = b;
             wpart[2 + 2 * DNLP_MAXNB + j] = c;
+#endif
           }
         }
       }
@@ -737,8 +748,13 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_persist(LbfgsState* __
     __syncthreads();
     double* acc = ctl->acc[slot % 3];
     if (tid == 0) {
+#ifdef DNLP_LB_ATOMIC_SUMS
+      atomicAdd(DNLP_ACC(acc, 0), (wred[0][0] + wred[1][0]) + (wred[2][0] + wred[3][0]));
+      atomicAdd(DNLP_ACC(acc, 1), (wred[0][1] + wred[1][1]) + (wred[2][1] + wred[3][1]));
+#else
       wpart[0] = (wred[0][0] + wred[1][0]) + (wred[2][0] + wred[3][0]);
       wpart[1] = (wred[0][1] + wred[1][1]) + (wred[2][1] + wred[3][1]);
+#endif
       const double g4 = fmax(fmax(wred[0][2], wred[1][2]), fmax(wred[2][2], wred[3][2]));
       // max of non-negative doubles = max of their bit patterns as unsigned integers
       atomicMax(reinterpret_cast<unsigned long long*>(DNLP_ACC(acc, 95)), static_cast<unsigned long long>(__double_as_longlong(g4)));
@@ -750,8 +766,13 @@ extern "C" __global__ void __launch_bounds__(256) dnlp_lb_persist(LbfgsState* __
       __hip_atomic_store(hb + tid, own > tid ? gnew[W + tid] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(hb + W + tid, own >= W ? gnew[W + own - W + tid] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifdef DNLP_LB_ATOMIC_SUMS
+    if (!dnlp_grid_barrier(ctl, epoch, nwg, &sci[4])) { done = 5; break; }
+    if (tid < 96) red[tid] = dnlp_agent_load(DNLP_ACC(acc, tid));
+#else
     if (!dnlp_grid_barrier_sum(ctl, epoch, nwg, &sci[4], &sci[5], wpart, red, scr, slot & 1)) { done = 5; break; }
     if (tid == 95) red[95] = dnlp_agent_load(DNLP_ACC(acc, 95));
+#endif
     if (tid >= 128 && tid < 128 + W) {
       // left halo = the last W entries of the left neighbour, right halo = the first W of the right one
       const int t = tid - 128;

@@ -365,16 +365,17 @@ class NLPChain:
         from .fused import build_fused_spec
         if getattr(self.solver, "reapply", None) is None:
             return None
-        spec = build_fused_spec(problem)
-        if spec is None:
-            return None
         sig = ("direct",) + self._signature(original)
         cached = getattr(original, "_nlp_cache", None)
         if cached is not None and cached["sig"] == sig and cached["solver"] is type(self.solver):
+            # (a cached direct handle: the fused program need not be emitted again to know that it exists)
             light = cached["light"]
             hit = self.solver.reapply(light, cached)
             if hit is not None:
                 return hit
+        spec = build_fused_spec(problem)
+        if spec is None:
+            return None
         zero = None
         for v in problem.variables():
             term = sum_atom(0.0 * v)
