@@ -1673,9 +1673,11 @@ struct BlockedLdlt {
       if (b_pending) DNLP_HIP_CHECK(hipStreamWaitEvent(s0, evB, 0));
       if (rest_pending) DNLP_HIP_CHECK(hipStreamWaitEvent(s0, evRest, 0));
       const int r1 = K0 + KB;
-      if (max_neg >= 0) {
+      if (max_neg >= 0 && n >= 16384) {
         // wrong inertia is known as soon as too many negative pivots have appeared: the rest
         // of the factorisation would be thrown away by the caller's regularisation loop
+        // (a host round trip per panel: worth it where a factorisation takes tens of milliseconds and more — at order
+        //  11 000 the 22 round trips cost 0.2-0.3 ms of a 13 ms factorisation and an abandoned attempt saves little)
         DNLP_HIP_CHECK(hipMemcpyAsync(&cur, info, sizeof cur, hipMemcpyDeviceToHost, s0));
         DNLP_HIP_CHECK(hipStreamSynchronize(s0));
         if (cur.nneg > max_neg || cur.fail) { bailed = true; break; }
