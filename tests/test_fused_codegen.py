@@ -311,9 +311,13 @@ def test_device_resident_lbfgs_status_paths():
     assert done == 4                                      # invalid number at the start -> status -13
 
 
-def test_persistent_lbfgs_kernel_compiles_for_gfx950_at_the_stated_size():
+@pytest.mark.parametrize("env", [{}, {"DNLP_LBFGS_ATOMIC_SUMS": "1"}, {"DNLP_LBFGS_ATOMIC_SUMS": "1", "DNLP_LBFGS_FULL_FENCE": "1"}])
+def test_persistent_lbfgs_kernel_compiles_for_gfx950_at_the_stated_size(env, monkeypatch):
     """BASELINE C2 at n = 1e5: the translation unit with the persistent single-launch kernel (a slice of 392
-    variables and the whole L-BFGS history per workgroup in LDS) is generated and compiles for gfx950."""
+    variables and the whole L-BFGS history per workgroup in LDS) is generated and compiles for gfx950 — in the shipped
+    form (sums across workgroups in a fixed order, order-only fences) and in the two earlier forms kept for A/B."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     data = _data(rosenbrock_chain(cp, 100000))
     blob = bytes(serialize(data["tape_arrays"]))
     lib = _lib()
@@ -324,6 +328,8 @@ def test_persistent_lbfgs_kernel_compiles_for_gfx950_at_the_stated_size():
     assert rc == 0, log.value.decode()
     text = src.value.decode()
     assert "#define DNLP_PER 392" in text and "dnlp_lb_persist" in text
+    assert ("#define DNLP_LB_ATOMIC_SUMS 1" in text) == ("DNLP_LBFGS_ATOMIC_SUMS" in env)
+    assert "dnlp_grid_barrier_sum" in text
 
 
 @pytest.mark.parametrize("n,mode", [(300000, 1), (1000000, 2)])
