@@ -162,6 +162,29 @@ def test_blocked_mfma_ldlt_quasidefinite(n, gpu_required):
     assert np.linalg.norm(sol - ref) <= 1e-9 * np.linalg.norm(ref) * np.linalg.cond(A)
 
 
+@pytest.mark.parametrize("n", [300, 1100, 2600])
+def test_one_launch_triangular_sweeps_against_the_step_kernels(n, gpu_required, monkeypatch):
+    """csrc/ldlt_blocked.h: the dataflow sweeps (one launch per sweep, 128-blocks exchanged as data-as-flag vectors, two
+    workgroups per block row) and the per-step kernels they replace solve the same factored system: both within the
+    residual bound, agreeing to rounding, and the sweep result identical on a second run (its sums are order-fixed)."""
+    rng = np.random.default_rng(n)
+    n1 = (3 * n) // 4
+    G = rng.standard_normal((n1, n1))
+    H = G @ G.T / n1 + np.eye(n1)
+    J = rng.standard_normal((n - n1, n1))
+    A = np.block([[H, J.T], [J, -1e-2 * np.eye(n - n1)]])
+    b = rng.standard_normal(n)
+    sol_sweep, nneg, nzero, _ = _ldlt(A, False, b)
+    sol_again, _, _, _ = _ldlt(A, False, b)
+    monkeypatch.setenv("DNLP_LDLT_SWEEP", "0")
+    sol_steps, nneg2, nzero2, _ = _ldlt(A, False, b)
+    assert (nneg, nzero) == (nneg2, nzero2) == (n - n1, 0)
+    assert np.array_equal(sol_sweep, sol_again)
+    scale = np.linalg.norm(A, 2) * max(np.linalg.norm(sol_steps), 1.0)
+    assert np.linalg.norm(A @ sol_sweep - b) <= 1e-9 * scale
+    assert np.linalg.norm(sol_sweep - sol_steps) <= 1e-10 * max(np.linalg.norm(sol_steps), 1.0) * np.linalg.cond(A)
+
+
 def _ldlt_factor(A, top_mfma):
     """Factor through the C ABI with the chosen top-block kernel (csrc/ldlt_top_mfma.h / ldlt_top128_kernel); returns
     the factor as stored (unit-lower L below the diagonal, D on it), the inertia counts and the solution of A x = 1."""
