@@ -1740,14 +1740,15 @@ struct BlockedLdlt {
   // The two sweeps as ONE launch each (ldlt_fwd_sweep_kernel / ldlt_bwd_sweep_kernel).  false: not taken (fewer than two
   // 128-blocks, more than kSweepMaxBlocks, DNLP_LDLT_SWEEP=0, or a sweep once gave up waiting) — the step kernels run
   // instead.  A sweep that gave up restores b and reports false.
-  static constexpr int kSweepMaxBlocks = 256;       // (order 32 768: beyond it a workgroup's serial walk over its row of tiles is the bound)
+  static constexpr int kSweepMaxBlocks = 1024;      // (order 131 072; DNLP_LDLT_SWEEP_MAX_BLOCKS lowers it)
+  int sweep_max_blocks = std::getenv("DNLP_LDLT_SWEEP_MAX_BLOCKS") ? std::atoi(std::getenv("DNLP_LDLT_SWEEP_MAX_BLOCKS")) : kSweepMaxBlocks;
   double* sweep_xch = nullptr;      // two exchange vectors (forward / transposed sweep), nb128 x 128 doubles each
   SweepCtl* sweep_ctl = nullptr;
   double* sweep_save = nullptr;
   bool sweep_off = std::getenv("DNLP_LDLT_SWEEP") != nullptr && std::atoi(std::getenv("DNLP_LDLT_SWEEP")) == 0;
   int sweep_split = std::getenv("DNLP_LDLT_SWEEP_SPLIT") ? std::max(1, std::min(4, std::atoi(std::getenv("DNLP_LDLT_SWEEP_SPLIT")))) : 2;
   bool sweep_solve(const double* A, double* b, int nb128) {
-    if (sweep_off || nb128 < 2 || nb128 > kSweepMaxBlocks) return false;
+    if (sweep_off || nb128 < 2 || nb128 > kSweepMaxBlocks || nb128 > sweep_max_blocks) return false;
     const int ni = static_cast<int>(n), P = sweep_split;
     const size_t xn = static_cast<size_t>(nb128) * SI_H, pn = xn * static_cast<size_t>(P);
     if (!sweep_xch) {
