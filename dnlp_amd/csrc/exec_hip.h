@@ -843,9 +843,11 @@ __global__ void __launch_bounds__(kBlock) sweep_flat_kernel(FlatTable t, const d
   }
 }
 
-// out[q] += sum_i V[q*N + i] * w[i] for q < k (k <= 32): all k dot products in one sweep of w
+// part[q * 1024 + block] = this block's share of sum_i V[q*N + i] * w[i] for q < k (k <= 32): all k dot products in one
+// sweep of w; vt_dot_finish_kernel adds the blocks' shares in block order (round 4: an atomic add per block landed in
+// arrival order — the Lanczos bound of C4 and the host-driven L-BFGS's Gram rows could differ in the last bits)
 __global__ void __launch_bounds__(kBlock) vt_dot_kernel(int k, const double* __restrict__ V, i64 N,
-                                                        const double* __restrict__ w, double* out) {
+                                                        const double* __restrict__ w, double* __restrict__ part) {
   __shared__ double red[kBlock / 64][32];
   double acc[32];
 #pragma unroll
@@ -868,8 +870,16 @@ __global__ void __launch_bounds__(kBlock) vt_dot_kernel(int k, const double* __r
   if (threadIdx.x < k) {
     double t = 0.0;
     for (int w2 = 0; w2 < kBlock / 64; ++w2) t += red[w2][threadIdx.x];
-    unsafeAtomicAdd(&out[threadIdx.x], t);
+    part[static_cast<i64>(threadIdx.x) * 1024 + blockIdx.x] = t;
   }
+}
+__global__ void __launch_bounds__(64) vt_dot_finish_kernel(int nblocks, const double* __restrict__ part, double* __restrict__ out) {
+  // one wavefront per dot product: lanes take the blocks round robin, the fixed wavefront tree adds the lanes
+  const double* row = part + static_cast<i64>(blockIdx.x) * 1024;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 64) s += row[b];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 // w[i] -= sum_q c[q] V[q*N + i]
 __global__ void __launch_bounds__(kBlock) v_comb_kernel(int k, const double* __restrict__ V, i64 N,
@@ -1176,6 +1186,7 @@ struct HipExec : HostControlled {
     lb_graph_reset();
     if (lb_state) hipFree(lb_state);
     if (lb_ctl) hipFree(lb_ctl);
+    if (vt_part) hipFree(vt_part);
     if (lb_halo) hipFree(lb_halo);
     if (lb_xsave) hipFree(lb_xsave);
     if (lb_strip) hipFree(lb_strip);
@@ -1314,10 +1325,11 @@ struct HipExec : HostControlled {
   void vt_dot(int k, const double* V, i64 N, const double* w, double* c_host) {
     if (k <= 0) return;
     double* dc = d_partial;
-    DNLP_HIP_CHECK(hipMemsetAsync(dc, 0, sizeof(double) * 32, stream));
     i64 grid = (N + kBlock - 1) / kBlock;
     if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(vt_dot_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, k, V, N, w, dc);
+    if (!vt_part) DNLP_HIP_CHECK(hipMalloc(&vt_part, sizeof(double) * 32 * 1024));
+    hipLaunchKernelGGL(vt_dot_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, k, V, N, w, vt_part);
+    hipLaunchKernelGGL(vt_dot_finish_kernel, dim3(static_cast<unsigned>(k)), dim3(64), 0, stream, static_cast<int>(grid), vt_part, dc);
     DNLP_HIP_CHECK(hipMemcpyAsync(c_host, dc, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
     DNLP_HIP_CHECK(hipStreamSynchronize(stream));
     DNLP_LAUNCH_CHECK();
@@ -1333,10 +1345,11 @@ struct HipExec : HostControlled {
   void orthogonalize(int k, const double* V, i64 N, double* w, double* c_host) {
     if (k <= 0) return;
     double* dc = d_partial;      // k <= 32 doubles of the reduction scratch
-    DNLP_HIP_CHECK(hipMemsetAsync(dc, 0, sizeof(double) * 32, stream));
     i64 grid = (N + kBlock - 1) / kBlock;
     if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(vt_dot_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, k, V, N, w, dc);
+    if (!vt_part) DNLP_HIP_CHECK(hipMalloc(&vt_part, sizeof(double) * 32 * 1024));
+    hipLaunchKernelGGL(vt_dot_kernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, k, V, N, w, vt_part);
+    hipLaunchKernelGGL(vt_dot_finish_kernel, dim3(static_cast<unsigned>(k)), dim3(64), 0, stream, static_cast<int>(grid), vt_part, dc);
     hipLaunchKernelGGL(v_axpy_kernel, dim3(static_cast<unsigned>((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, k, V, N, dc, w);
     DNLP_HIP_CHECK(hipMemcpyAsync(c_host, dc, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
     DNLP_HIP_CHECK(hipStreamSynchronize(stream));
@@ -1568,6 +1581,7 @@ struct HipExec : HostControlled {
   RtcKernel lb_rtc;
   hipFunction_t lb_eval = nullptr, lb_accept = nullptr, lb_update = nullptr, lb_control = nullptr, lb_persist = nullptr;
   LbPersistCtl* lb_ctl = nullptr;       // control block of the persistent kernel
+  double* vt_part = nullptr;            // per-block shares of vt_dot (32 x 1024)
   double* lb_halo = nullptr;
   i64 lb_key_nf = -1, lb_per = 0;
   int lb_persist_wgs = 0;
