@@ -302,6 +302,19 @@ def bench_c5(args):
         pb.solve_sharded(thetas, device=local)
     barrier()
     dt_resolve = (time.time() - t1) / 2.0
+    # secondary figure: TWO batches in flight (ParametricBatch.solve_many) — the same fresh batches (first come)
+    # through two handles on two streams: the next launch's instances take the compute units the tail of the previous
+    # one leaves idle (a launch is as long as its slowest instance; evenly spread the work is ~60 % of it).  What a
+    # caller with a stream of batches gets; one batch at a time stays the headline.
+    dt_two, n_two = None, 0
+    if world == 1 and args.steps >= 2:
+        ks = list(range(args.warmup, n_batches))
+        pb.solve_many([all_thetas[0], all_thetas[0]], device=local, in_flight=2)      # (the second handle's first call)
+        barrier()
+        t2 = time.time()
+        pb.solve_many([all_thetas[k] for k in ks], device=local, in_flight=2)
+        barrier()
+        dt_two, n_two = time.time() - t2, len(ks)
     assert rows.shape[0] == B and np.array_equal(rows[:, 0], np.arange(B)), "gathered rows are not the whole batch"
     gathered_ranks, backend_name = info["ranks"], info["backend"]
     if dist is not None:
@@ -346,6 +359,7 @@ def bench_c5(args):
                        "optimal": optimal_all // max(args.steps, 1), "acceptable": int(np.sum(rows[:, 2] == 1)),
                        "instance_order": "first come (every step is a fresh batch)",
                        "resolve_same_batch_problems_per_s": B / dt_resolve if dt_resolve > 0 else None,
+                       "two_batches_in_flight_problems_per_s": B * n_two / dt_two if dt_two else None,
                        "ip_iterations_per_pass": iters_total,
                        "aggregate_ip_iterations_per_s": iters_total * args.steps / dt_all,
                        "problems_per_s_kernel_only": B * args.steps / ksec_all if ksec_all > 0 else None,

@@ -347,3 +347,21 @@ def test_dense_instances_above_order_256_in_one_launch(nv, gpu_required):
         prob.solve(nlp=True)
         assert abs(raw["obj_val"][k] - prob.value) <= 1e-6 * max(1.0, abs(prob.value)), (k, raw["obj_val"][k], prob.value)
         np.testing.assert_allclose(A @ raw["x"][k][:nv], A @ xs, rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_solve_many_overlaps_launches_and_changes_no_result(gpu_required):
+    """ParametricBatch.solve_many: six batches of 512 localization instances with two launches in flight (two device
+    handles, two streams, two host threads) give, batch by batch, the bits of six solve() calls one after the other."""
+    import batch_problems as bp
+    from dnlp_amd.batch import ParametricBatch
+    prob, params, sample, _ = bp.template_localization()
+    pb = ParametricBatch(prob, params)
+    batches = [np.stack([sample(1000 * k + i) for i in range(512)]) for k in range(6)]
+    one_by_one = [pb.solve(t) for t in batches]
+    overlapped = pb.solve_many(batches, in_flight=2)
+    assert len(overlapped) == 6
+    for a, b in zip(one_by_one, overlapped):
+        assert np.array_equal(a.status, b.status) and np.array_equal(a.iterations, b.iterations)
+        assert np.array_equal(a.obj_val, b.obj_val) and np.array_equal(a.x, b.x)
+    pb.close()
