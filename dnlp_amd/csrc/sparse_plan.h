@@ -605,7 +605,7 @@ struct SparsePlanHost {
     {
       const i64 nl = static_cast<i64>(lev_off.size()) - 1;
       gdst.clear(); goff.assign(1, 0); lev_g.assign(1, 0);
-      std::vector<i64> cnt(static_cast<size_t>(nvals), 0);
+      std::vector<i32> cnt(static_cast<size_t>(nvals), 0);      // (32-bit: the random walk over this array is the phase's cost)
       std::vector<i32> touched, t_dst, t_iu, t_iv, t_blk;
       for (i64 lev = 0; lev < nl; ++lev) {
         const size_t t0 = static_cast<size_t>(lev_trip[static_cast<size_t>(lev)]), t1 = static_cast<size_t>(lev_trip[static_cast<size_t>(lev) + 1]);
@@ -615,7 +615,7 @@ struct SparsePlanHost {
         i64 at = static_cast<i64>(t0);
         for (i32 d : touched) {
           const i64 c = cnt[static_cast<size_t>(d)];
-          cnt[static_cast<size_t>(d)] = at;              // from here on: next free position of this destination
+          cnt[static_cast<size_t>(d)] = static_cast<i32>(at);              // from here on: next free position of this destination
           at += c;
           gdst.push_back(d);
           goff.push_back(static_cast<i32>(at));
