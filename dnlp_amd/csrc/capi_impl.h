@@ -224,6 +224,7 @@ struct ProblemT {
     else if (k == "nlp_scaling_method") opt.nlp_scaling = (v == "none") ? 0 : 1;
     else if (k == "nlp_scaling_max_gradient") opt.nlp_scaling_max_gradient = num();
     else if (k == "max_wall_time" || k == "max_cpu_time") opt.max_wall_time = num();
+    else if (k == "max_hessian_perturbation") opt.max_hessian_perturbation = num();
     else if (k == "max_soc") opt.max_soc = static_cast<int>(num());
     else if (k == "constr_mult_init_max") opt.constr_mult_init_max = num();
     else if (k == "bound_mult_init_val") opt.bound_mult_init_val = num();

@@ -45,6 +45,8 @@ struct IpmOptions {
   double kappa_d = 1e-5;
   double max_wall_time = 1e20;
   double diverging_iterates_tol = 1e20;
+  double max_hessian_perturbation = 1e20;   // IPOPT's option of the same name and default: beyond it the step computation
+                                             // has failed (restoration phase / the mu-strategy ladder) instead of crawling on
   int print_level = 0;
   int max_soc = 4;
   double nlp_inf = 1e19;              // |bound| >= 1e19 means "no bound"
@@ -1160,7 +1162,7 @@ class Ipm {
 
   DNLP_HD bool factor_with_inertia(double& delta_w, double& delta_c) {
     DNLP_IPM_LDS();
-    const double dw_min = 1e-20, dw_0 = 1e-4, dw_max = 1e40, dc_bar = 1e-8, kwp = 8.0, kwpb = 100.0, kwm = 1.0 / 3.0, kc = 0.25;
+    const double dw_min = 1e-20, dw_0 = 1e-4, dw_max = opt.max_hessian_perturbation, dc_bar = 1e-8, kwp = 8.0, kwpb = 100.0, kwm = 1.0 / 3.0, kc = 0.25;
     delta_w = 0.0; delta_c = 0.0;
     // large unpivoted systems: skip regularisation values that are provably too small
     double dw_lb = 0.0, dw_first = 0.0;
@@ -1490,7 +1492,7 @@ class Ipm {
       if (dc == 0.0) dc = 1e-8 * std::pow(mu, 0.25);
       dw = (dw == 0.0) ? ((delta_w_last == 0.0) ? 1e-4 : std::max(1e-20, delta_w_last / 3.0)) : 8.0 * dw;
       int r = try_factor(dw, dc);
-      while (r != 0 && dw < 1e40) { dw *= 8.0; r = try_factor(dw, dc); }
+      while (r != 0 && dw < opt.max_hessian_perturbation) { dw *= 8.0; r = try_factor(dw, dc); }
       if (r != 0) return status = Error_In_Step_Computation;
       delta_w_last = dw;
       stats.last_delta_w = dw;
