@@ -14,11 +14,12 @@ from dnlp_amd.batch import ParametricBatch, arrays_with_data  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 nlogs = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 which = sys.argv[3] if len(sys.argv) > 3 else "localization"          # localization | circle_packing10 | power_flow | path_planning
+OPTS = dict(a.split("=", 1) for a in sys.argv[4:])                       # solver options: ladder_dual_blowup_tol=1e12 ...
 prob, params, sample, var = bp.template_circle_packing(10) if which == "circle_packing10" else getattr(bp, "template_" + which)()
 pb = ParametricBatch(prob, params)
 thetas = np.stack([sample(i) for i in range(B)])
 mat = pb.data(thetas)
-res = pb.solve(thetas)
+res = pb.solve(thetas, **OPTS)
 it = res.iterations
 wall = res.raw["phase_seconds"][:, 0]
 print("kernel_sec", res.kernel_seconds, "iters mean", it.mean(), "max", it.max())
