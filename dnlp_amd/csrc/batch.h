@@ -611,7 +611,12 @@ struct BatchRunner {
     // sparse instances have no dense matrix to factor, so one wavefront suffices at any order;
     // when the batch does not even fill the CUs, large instances get four wavefronts each instead
     // (a one-off solve of order ~2000 is then ~3x faster)
-    const bool wave = n <= 256 || (have_sparse && !(n > 512 && batch <= 256));
+    // Sparse instances of order > 512 get four wavefronts each while the batch is at most 1024 (DNLP_BATCH_WIDE_MAX): such a
+    // launch has every instance resident at once and lasts as long as its slowest one (power flow: 104 iterations against a
+    // mean of 17.7), so the ~3x faster instance wins: 1024 power-flow instances 0.424 -> 0.341 s, path planning 0.306 ->
+    // 0.241 s; at 4096 instances the one-wavefront form is as fast or faster (0.59 / 0.63 s against 0.59 / 0.73 s).
+    static const int wide_max = std::getenv("DNLP_BATCH_WIDE_MAX") ? std::atoi(std::getenv("DNLP_BATCH_WIDE_MAX")) : 1024;
+    const bool wave = n <= 256 || (have_sparse && !(n > 512 && batch <= wide_max));
     const void* kern = wave ? reinterpret_cast<const void*>(batch_solve_kernel<64>)
                             : reinterpret_cast<const void*>(batch_solve_kernel<256>);
     const int nthreads = wave ? 64 : 256;
