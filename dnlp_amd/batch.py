@@ -222,12 +222,7 @@ class ParametricBatch:
         t0 = _t.time()
         if warm_from is not None:
             opts.setdefault("warm_start_init_point", "yes")
-        key = (device, tuple(sorted((k, str(v)) for k, v in opts.items())))
-        if getattr(self, "_handle_key", None) != key:
-            self.close()
-            self._handle = _device_handle(self.arrays0, self.data0["tape"], device, opts)
-            self._handle_key = key
-            self._map_on_device = False
+        self._ensure_handle(device, opts)
         # affine templates: the map lives on the device and a call moves only the parameter rows (the
         # warm-started form patches the rows' x0 block on the host, so it keeps the host-generated rows)
         if self.affine and warm_from is None and hasattr(self._handle, "set_batch_affine_map"):
@@ -258,6 +253,16 @@ class ParametricBatch:
             print("[batch.py] data %.4f handle %.4f solve_batch %.4f" % (t1 - t0, t2 - t1, t3 - t2), flush=True)
         return BatchResult(raw, self.inv, self.flip)
 
+    def _ensure_handle(self, device, opts):
+        """(Re)create THIS object's device handle for (device, options).  Only its own handle is touched — the clones
+        `solve_many` keeps belong to their workers (closing them from here raced with a worker that was launching)."""
+        key = (device, tuple(sorted((k, str(v)) for k, v in opts.items())))
+        if getattr(self, "_handle_key", None) != key:
+            self._close_own()
+            self._handle = _device_handle(self.arrays0, self.data0["tape"], device, opts)
+            self._handle_key = key
+            self._map_on_device = False
+
     def solve_many(self, batches, device=None, in_flight=2, **opts):
         """A stream of batches with `in_flight` launches overlapping: batch i goes to worker i mod in_flight, every
         worker has its own device handle (own HIP stream) and its own host thread.  A launch lasts as long as its
@@ -265,7 +270,8 @@ class ParametricBatch:
         and the workgroups of the next launch take the compute units that the tail of the previous one leaves idle:
         8192 fresh localization instances per batch go from 147 k to 215 k problems/s with two launches in flight
         (profiles/r04_c5_two_in_flight.json).  Results are the ones `solve` returns, batch by batch, in order
-        (the solver is bitwise reproducible, so overlapping changes no result)."""
+        (a launch is bitwise reproducible for its launch plan — the kernel form is chosen from the template and the
+        batch size — so overlapping launches changes no result)."""
         import copy
         import threading
         batches = list(batches)
@@ -282,6 +288,9 @@ class ParametricBatch:
             c._handle, c._handle_key, c._map_on_device, c._clones = None, None, False, []
             clones.append(c)
         workers = [self] + clones[:n_workers - 1]
+        if "warm_start_init_point" not in opts:
+            for w in workers:                         # every handle exists before a thread starts: no worker creates or
+                w._ensure_handle(device, opts)        # closes one while another is launching
         out, errors = [None] * len(batches), []
 
         def run(w, idx):
@@ -335,13 +344,16 @@ class ParametricBatch:
                 "gathered_bytes": int(world * per * rows.shape[1] * 8) if exchanged else 0}
         return rows, info
 
-    def close(self):
-        for c in getattr(self, "_clones", None) or []:
-            c.close()
+    def _close_own(self):
         h = getattr(self, "_handle", None)
         if h is not None:
             h.close()
         self._handle, self._handle_key = None, None
+
+    def close(self):
+        for c in getattr(self, "_clones", None) or []:
+            c.close()
+        self._close_own()
 
     def __del__(self):
         try:

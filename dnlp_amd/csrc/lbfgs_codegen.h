@@ -494,12 +494,20 @@ __device__ __forceinline__ double dnlp_agent_load(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Everything that crosses workgroups in this kernel travels as device-scope atomic loads / stores (write-through, cache-
-// bypassing): between them only ORDER is needed — all of this wavefront's memory operations complete before the next one
-// issues — not the L2 write-back + invalidate of a device-scope fence (DNLP_LB_FULL_FENCE=1 restores __threadfence()).
+// bypassing).  What the barrier's release side needs is COMPLETION of those stores — in EVERY wavefront that issued some,
+// not only in the one that arrives: a workgroup-scope fence lowers to s_waitcnt lgkmcnt(0) alone on gfx950, and
+// `global_store ... sc1; s_barrier; global_atomic_add` then lets the arrive overtake another wavefront's part[] / gsum /
+// halo stores.  DNLP_RELEASE_ALL() is executed by every lane before the __syncthreads that precedes the arrive: an order
+// fence for the compiler + s_waitcnt vmcnt(0) (gfx9 counts stores in vmcnt), i.e. all of this wavefront's write-through
+// stores are acknowledged; it skips only the L2 write-back (buffer_wbl2) of an agent-scope release, which the plain
+// (cached) stores of this kernel do not need because none of them is read by another workgroup.
+// DNLP_LB_FULL_FENCE=1 makes both sides __threadfence().
 #ifdef DNLP_LB_FULL_FENCE
 #define DNLP_ORDER_FENCE() __threadfence()
+#define DNLP_RELEASE_ALL() __threadfence()
 #else
-#define DNLP_ORDER_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+#define DNLP_ORDER_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_s_waitcnt(0x0F70); } while (0)
+#define DNLP_RELEASE_ALL() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0x0F70); } while (0)
 #endif
 // Two-level counter barrier over the nwg co-resident workgroups (grid <= compute units: every workgroup is resident).
 // 256 arrivals on ONE device-scope counter serialise in its memory channel (~12 ns each: 3 us before the last arriver
@@ -509,6 +517,7 @@ __device__ __forceinline__ double dnlp_agent_load(const double* p) {
 // A spin is bounded: a stranded workgroup raises `abort` and everybody leaves instead of hanging the device.
 __device__ __forceinline__ bool dnlp_grid_barrier(LbPersistCtl* ctl, unsigned& epoch, const unsigned nwg, int* s_flag) {
   ++epoch;                                             // (uniform: every lane counts the barriers)
+  DNLP_RELEASE_ALL();                                  // every wavefront: its device-scope stores have completed
   __syncthreads();
   if (threadIdx.x == 0) {
     DNLP_ORDER_FENCE();                                   // release: this workgroup's stores and atomics before the arrive
@@ -549,8 +558,10 @@ __device__ __noinline__ bool dnlp_grid_barrier_sum(LbPersistCtl* ctl, unsigned& 
   const int tid = threadIdx.x;
   const unsigned g = blockIdx.x & 7u, ngroups = nwg < 8u ? nwg : 8u;
   const unsigned gsize = (nwg + 7u - g) >> 3;          // workgroups with blockIdx % 8 == g
+  DNLP_RELEASE_ALL();                                  // (the halo entries any wavefront stored before the call)
   __syncthreads();                                     // wpart is complete
   if (tid < 95) __hip_atomic_store(&ctl->part[blockIdx.x][tid], wpart[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  DNLP_RELEASE_ALL();                                  // BOTH storing wavefronts (tid 0..94): rows and halo entries acknowledged
   __syncthreads();
   if (tid == 0) {
     DNLP_ORDER_FENCE();                                   // release: this workgroup's stores before the arrive
@@ -576,6 +587,7 @@ __device__ __noinline__ bool dnlp_grid_barrier_sum(LbPersistCtl* ctl, unsigned& 
     }
     __syncthreads();
     if (tid < 95) __hip_atomic_store(&ctl->gsum[parity][g][tid], scr[tid] + scr[96 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    DNLP_RELEASE_ALL();
     __syncthreads();
   }
   if (tid == 0) {
