@@ -1,0 +1,1709 @@
+// Template-specialised batch solver, part 2: the interior-point loop of ONE small sparse instance by ONE wavefront.
+//
+// Role: the serial best_of / re-solve loop of the reference (cvxpy/problems/problem.py:1256-1269 -> IPOPT through
+// ipopt_nlpif.py:140-170), for templates that wave_plan.h accepts.  The ALGORITHM is ipm_core.h's (Waechter & Biegler
+// 2006 with IPOPT's defaults; every function below names the Ipm<E, K> member it restates) — same formulas, same
+// decisions, same safeguards and retry ladder; what differs is how it is laid out for a 64-lane wavefront:
+//   * every vector of the instance lives at a fixed place in the wavefront's share of LDS and is read / written through
+//     LDS-typed pointers (ds_read / ds_write; the generic kernel reaches most of them through flat instructions, its
+//     sparse factor through the global slab, and spills 3.3 KB per lane to scratch);
+//   * variables and constraint rows are separate loops (the generic text runs both branch sides of every
+//     [variables | rows] pass in each of its two trips);
+//   * the tape is one table row per work unit and 32-bit CSR maps (wave_plan.h) staged once per workgroup;
+//   * reductions are lane-strided partial sums + the fixed DPP tree of wave_ops.h: the same bits on every run.
+// Single source over a lane policy P (lanes, lane(), sync(), sum / vmax): WaveLanes (wave_batch.h) on the device, one
+// host lane in the test oracle (oracle/oracle_lib.cpp) — where its serial sums reproduce the HostExec build of
+// ipm_core.h, which is how the restatement is pinned on the CPU (tests/test_wave_ipm_cpu.py).
+// What it does not have: the dense Bunch-Kaufman fallback of a structurally singular static pivot sequence — such an
+// instance ends with status kWaveNeedsGeneric and the host hands it to the generic kernel (batch.h).
+#pragma once
+#include "ipm_core.h"
+#include "wave_plan.h"
+
+#if DNLP_DEVICE_PASS
+#define DNLP_WLDS __attribute__((address_space(3)))
+#define DNLP_WGLB __attribute__((address_space(1)))
+#else
+#define DNLP_WLDS
+#define DNLP_WGLB
+#endif
+
+namespace dnlp {
+
+// (device: the phases are real functions over one LDS pointer — the all-inlined generic kernel is a 28 k-instruction body)
+#if DNLP_DEVICE_PASS
+#define DNLP_WFN __attribute__((noinline))
+#else
+#define DNLP_WFN
+#endif
+
+typedef DNLP_WLDS double WD;          // a double of the wavefront's LDS share
+typedef DNLP_WLDS const i32 WI;       // a table entry of the staged plan
+typedef DNLP_WGLB const double WG;    // a double of the instance's data row (global memory)
+
+constexpr int kWaveNeedsGeneric = -197;
+#ifndef DNLP_WAVE_FILTER_CAP
+#define DNLP_WAVE_FILTER_CAP 32        // (BlockExecT::kFilterCap; the test oracle builds with HostExec's 1024)
+#endif
+constexpr int kWaveFilterCap = DNLP_WAVE_FILTER_CAP;
+
+struct WCsr { WI* ptr; WI* idx; i32 rows; i32 val; };       // val: offset of the values in the instance's data row
+struct WCoo { WI* ptr; WI* ent; WI* src; WI* heavy; i32 nout; i32 nheavy; };
+
+// Everything one wavefront knows about the instance it is solving.  Lives in LDS (one per wavefront).
+struct WState {
+  // ---- sizes and tables (set once per kernel: w_layout) ----
+  i32 N, m, Z, nd, nh, nnzJ, nnzH, nunits;
+  WI *u_op, *u_a0, *u_a1, *u_z, *u_d0, *u_d1, *u_h, *u_p, *mm_idx;
+  WCsr G, Mg, MJ, Mw, MH;
+  WI *jac_rows, *jac_cols, *hess_rows, *hess_cols, *jac_rowptr;
+  WCoo jr, jc, hs;
+  i32 nblk, nvals, nlev, ngrp, nfwd;
+  WI *bnode, *soff, *loff, *doff, *lev_off, *sblk, *sidx, *lev_f, *fnode, *foff, *fa, *fu0, *fu1, *lev_g, *gdst, *goff, *upd_u, *upd_v,
+     *hpos, *jpos, *dpos;
+  i32 l_c0, l_c, l_b, l_Jc, l_fp, l_fp2, l_x0, l_lb, l_ub, l_cl, l_cu;
+  // ---- vectors (LDS) ----
+  WD *x, *zL, *zU, *xL, *xU, *grad, *dx, *dzL, *dzU, *xt, *Sx, *rx, *tN, *fixm;
+  WD *s, *y, *vL, *vU, *sL, *sU, *eq, *g, *sg, *ds, *dy, *dvL, *dvU, *st, *gt, *Dd, *Ss, *rs, *rp, *tM, *csoc;
+  WD *dir[3][7];                     // [0] = dx ds dy dzL dzU dvL dvU, [1] = affine-scaling, [2] = centering direction
+  WD *rhs, *sol, *res, *cor;
+  WD *jv, *xz, *dvals, *hvals, *w, *sl, *Hs, *svals, *swork;
+  // ---- the instance (set per instance: w_bind) ----
+  WG* row;                           // its data row (batch.h layout)
+  const double *ws_g, *ws_l, *ws_u;  // warm-start multipliers or null
+  i64 fallback_max_n;
+  // ---- interior-point state (Ipm<E, K> members of the same names) ----
+  IpmOptions opt;
+  double sf, f, mu, tau, delta_w_last, theta_max, theta_min, last_obj, last_ratio, streak_theta0, streak_f0, resto_theta, t_begin;
+  double filt_th[kWaveFilterCap], filt_ph[kWaveFilterCap], kkt_hist[4];
+  double e_dual, e_primal, e_cmpl, e_sd, e_sc, e_total, e_primal_unscaled;      // e_cached_
+  double inf_pr, inf_du, cmpl, nlp_error, wall;
+  i32 nfilt, n_hist, acceptable_count, iter, status, factorizations, nb_cache, n_eq, n_fixed, last_nneg, ladder_rung,
+      sparse_singular_streak, dc_fixed_count, tiny_streak;
+  bool initialized, fixed_mode, e_cached_valid, jty_valid, delta_w_used_last_iter, dc_fixed_last, always_dc, in_solve,
+       resto_stationary, bail;
+};
+
+struct WErr { double dual, primal, cmpl, sd, sc, total, primal_unscaled; };
+struct WMeasures { double theta, phi, chk; };
+
+template <class P>
+struct WaveIpm {
+  // lane-strided loops
+#define W_FOR(i, n) for (int i = P::lane(); i < (n); i += P::lanes)
+
+  // ---- layout: the tables out of the staged block, the vectors out of the wavefront's share ---------------------------
+  DNLP_HD static void layout(DNLP_WLDS WState* S, WI* blk, WD* base) {
+    DNLP_WLDS const WaveHdr* h = (DNLP_WLDS const WaveHdr*)blk;
+    S->N = h->N; S->m = h->m; S->Z = h->Z; S->nd = h->nd; S->nh = h->nh; S->nnzJ = h->nnzJ; S->nnzH = h->nnzH; S->nunits = h->nunits;
+    S->u_op = blk + h->u_op; S->u_a0 = blk + h->u_a0; S->u_a1 = blk + h->u_a1; S->u_z = blk + h->u_z; S->u_d0 = blk + h->u_d0;
+    S->u_d1 = blk + h->u_d1; S->u_h = blk + h->u_h; S->u_p = blk + h->u_p; S->mm_idx = blk + h->mm_idx;
+    S->G = WCsr{blk + h->G_ptr, blk + h->G_idx, h->m, h->l_G};
+    S->Mg = WCsr{blk + h->Mg_ptr, blk + h->Mg_idx, h->N, h->l_Mg};
+    S->MJ = WCsr{blk + h->MJ_ptr, blk + h->MJ_idx, h->nnzJ, h->l_MJ};
+    S->Mw = WCsr{blk + h->Mw_ptr, blk + h->Mw_idx, h->Z, h->l_Mw};
+    S->MH = WCsr{blk + h->MH_ptr, blk + h->MH_idx, h->nnzH, h->l_MH};
+    S->jac_rows = blk + h->jac_rows; S->jac_cols = blk + h->jac_cols; S->hess_rows = blk + h->hess_rows; S->hess_cols = blk + h->hess_cols;
+    S->jac_rowptr = blk + h->jac_rowptr;
+    S->jr = WCoo{blk + h->jr_ptr, blk + h->jr_ent, blk + h->jr_src, blk + h->jr_heavy, h->m, h->jr_nheavy};
+    S->jc = WCoo{blk + h->jc_ptr, blk + h->jc_ent, blk + h->jc_src, blk + h->jc_heavy, h->N, h->jc_nheavy};
+    S->hs = WCoo{blk + h->hs_ptr, blk + h->hs_ent, blk + h->hs_src, blk + h->hs_heavy, h->N, h->hs_nheavy};
+    S->nblk = h->sp_nblk; S->nvals = h->sp_nvals; S->nlev = h->sp_nlev; S->ngrp = h->sp_ngrp; S->nfwd = h->sp_nfwd;
+    S->bnode = blk + h->bnode; S->soff = blk + h->soff; S->loff = blk + h->loff; S->doff = blk + h->doff; S->lev_off = blk + h->lev_off;
+    S->sblk = blk + h->sblk; S->sidx = blk + h->sidx; S->lev_f = blk + h->lev_f; S->fnode = blk + h->fnode; S->foff = blk + h->foff;
+    S->fa = blk + h->fa; S->fu0 = blk + h->fu0; S->fu1 = blk + h->fu1; S->lev_g = blk + h->lev_g; S->gdst = blk + h->gdst;
+    S->goff = blk + h->goff; S->upd_u = blk + h->tau; S->upd_v = blk + h->tav; S->hpos = blk + h->hpos; S->jpos = blk + h->jpos; S->dpos = blk + h->dpos;
+    S->l_c0 = h->l_c0; S->l_c = h->l_c; S->l_b = h->l_b; S->l_Jc = h->l_Jc; S->l_fp = h->l_fp; S->l_fp2 = h->l_fp2;
+    S->l_x0 = h->l_x0; S->l_lb = h->l_lb; S->l_ub = h->l_ub; S->l_cl = h->l_cl; S->l_cu = h->l_cu;
+    // vectors, 16-byte granules (the count per class is wave_plan.h wave_state_doubles)
+    const i32 N = h->N, m = h->m;
+    WD* p = base;
+    auto take = [&](i32 n) { WD* q = p; p += (n + 1) & ~1; return q; };
+    S->x = take(N); S->zL = take(N); S->zU = take(N); S->xL = take(N); S->xU = take(N); S->grad = take(N); S->dx = take(N);
+    S->dzL = take(N); S->dzU = take(N); S->xt = take(N); S->Sx = take(N); S->rx = take(N); S->tN = take(N); S->fixm = take(N);
+    WD* ax = take(N); WD* azL = take(N); WD* azU = take(N); WD* cx = take(N); WD* czL = take(N); WD* czU = take(N);
+    S->s = take(m); S->y = take(m); S->vL = take(m); S->vU = take(m); S->sL = take(m); S->sU = take(m); S->eq = take(m); S->g = take(m);
+    S->sg = take(m); S->ds = take(m); S->dy = take(m); S->dvL = take(m); S->dvU = take(m); S->st = take(m); S->gt = take(m); S->Dd = take(m);
+    S->Ss = take(m); S->rs = take(m); S->rp = take(m); S->tM = take(m); S->csoc = take(m);
+    WD* as = take(m); WD* ay = take(m); WD* avL = take(m); WD* avU = take(m); WD* cs = take(m); WD* cy = take(m); WD* cvL = take(m); WD* cvU = take(m);
+    S->rhs = take(N + m); S->sol = take(N + m); S->res = take(N + m); S->cor = take(N + m);
+    S->jv = take(h->nnzJ); S->xz = take(N + h->Z); S->dvals = take(h->nd); S->hvals = take(h->nh); S->w = take(h->Z); S->sl = take(1 + m);
+    S->Hs = take(h->nnzH); S->svals = take(h->sp_nvals); S->swork = take(h->sp_nvals + 3 * h->sp_nblk + 8);
+    S->dir[0][0] = S->dx; S->dir[0][1] = S->ds; S->dir[0][2] = S->dy; S->dir[0][3] = S->dzL; S->dir[0][4] = S->dzU; S->dir[0][5] = S->dvL; S->dir[0][6] = S->dvU;
+    S->dir[1][0] = ax; S->dir[1][1] = as; S->dir[1][2] = ay; S->dir[1][3] = azL; S->dir[1][4] = azU; S->dir[1][5] = avL; S->dir[1][6] = avU;
+    S->dir[2][0] = cx; S->dir[2][1] = cs; S->dir[2][2] = cy; S->dir[2][3] = czL; S->dir[2][4] = czU; S->dir[2][5] = cvL; S->dir[2][6] = cvU;
+  }
+
+  // ---- lane reductions (NaN conventions of BlockExecT::reduce: max NaN -> +inf, min NaN -> -inf) -------------------------
+  DNLP_HD static double mxin(double acc, double v) { return fmax(acc, v != v ? kInf : v); }
+  DNLP_HD static double mnin(double acc, double v) { v = v != v ? -kInf : v; return fmax(acc, -v); }      // (minimum as a maximum of negatives)
+
+  // ====================================================================================================================
+  // tape evaluation (model.h)
+  // ====================================================================================================================
+  // Model::sweep: xz[0..N) <- src (unless it is xz already), then every flat unit: z, dvals (and hvals with the weights w)
+  DNLP_WFN DNLP_HD static void sweep(DNLP_WLDS WState* S, const WD* src, bool with_h) {
+    const int N = S->N, nu = S->nunits;
+    WD *xz = S->xz, *dv = S->dvals, *hv = S->hvals;
+    const WD* ww = S->w;
+    if (src != xz) { W_FOR(j, N) xz[j] = src[j]; P::sync(); }
+    WI *uop = S->u_op, *ua0 = S->u_a0, *ua1 = S->u_a1, *uz = S->u_z, *ud0 = S->u_d0, *ud1 = S->u_d1, *uh = S->u_h, *up = S->u_p;
+    WG *fp = S->row + S->l_fp, *fp2 = S->row + S->l_fp2;
+    W_FOR(e, nu) {
+      const int op = uop[e];
+      const i32 zi = uz[e];
+      if (op < OP_MUL) {
+        double val, g1, g2;
+        const i32 f = up[e];
+        unary_rules(op, xz[ua0[e]], fp[f], fp2[f], val, g1, g2);
+        xz[N + zi] = val;
+        dv[ud0[e]] = g1;
+        if (with_h) hv[uh[e]] = ww[zi] * g2;
+      } else if (op == OP_MUL) {
+        // bilinear u*v: binary_operators.py:586-591 (Jacobian), :543-546 (cross Hessian)
+        const double u = xz[ua0[e]], v = xz[ua1[e]];
+        xz[N + zi] = u * v;
+        dv[ud0[e]] = v;
+        dv[ud1[e]] = u;
+        if (with_h) hv[uh[e]] = ww[zi];
+      } else if (op == OP_REL_ENTR) {
+        // rel_entr.py:37-40, :129-148, :150-179
+        const double u = xz[ua0[e]], v = xz[ua1[e]];
+        const double lr = log(u / v);
+        xz[N + zi] = u * lr;
+        dv[ud0[e]] = lr + 1.0;
+        dv[ud1[e]] = -u / v;
+        if (with_h) {
+          const double wi = ww[zi];
+          const i32 hb = uh[e], n = up[e];
+          hv[hb] = wi / u;
+          hv[hb + n] = wi * u / (v * v);
+          hv[hb + 2 * n] = -wi / v;
+        }
+      } else {
+        // OP_MATMUL: one output entry of U @ V (model.h sweep_flat)
+        const i32 kk = ua1[e], db0 = ud0[e], db1 = ud1[e], hb = uh[e];
+        WI* mi = S->mm_idx + ua0[e];
+        double acc = 0.0;
+        for (i32 q = 0; q < kk; ++q) {
+          const double u = xz[mi[2 * q]], v = xz[mi[2 * q + 1]];
+          acc += u * v;
+          dv[db0 + q] = v;
+          dv[db1 + q] = u;
+          if (with_h) hv[hb + q] = ww[zi];
+        }
+        xz[N + zi] = acc;
+      }
+    }
+    P::sync();
+  }
+  // Model::spmv: y = (base + M v) [* scale];  scale_kind 0 none, 1 a scalar, 2 sg[r], 3 sg[jac_rows[r]]
+  DNLP_WFN DNLP_HD static void spmv(DNLP_WLDS WState* S, const WCsr M, const WD* v, i32 base_off, WD* y, int scale_kind, double scalar) {
+    WI *ptr = M.ptr, *idx = M.idx;
+    WG* val = S->row + M.val;
+    WG* base = base_off >= 0 ? S->row + base_off : nullptr;
+    const WD* sg = S->sg;
+    WI* jr = S->jac_rows;
+    W_FOR(r, M.rows) {
+      double sacc = base ? base[r] : 0.0;
+      const i32 k1 = ptr[r + 1];
+      for (i32 k = ptr[r]; k < k1; ++k) sacc += val[k] * v[idx[k]];
+      if (scale_kind == 1) sacc *= scalar;
+      else if (scale_kind == 2) sacc *= sg[r];
+      else if (scale_kind == 3) sacc *= sg[jr[r]];
+      y[r] = sacc;
+    }
+    P::sync();
+  }
+  // Ipm::eval_fg (check folded into the callers): f~ and g~ at xp; returns isfinite(f~)
+  DNLP_WFN DNLP_HD static bool eval_fg(DNLP_WLDS WState* S, const WD* xp, double& fval, WD* gout) {
+    sweep(S, xp, false);
+    const int NZ = S->N + S->Z;
+    WG* cc = S->row + S->l_c;
+    const WD* v = S->xz;
+    double acc = 0.0;
+    W_FOR(i, NZ) acc += cc[i] * v[i];
+    fval = S->sf * (S->row[S->l_c0] + P::sum(acc));
+    spmv(S, S->G, S->xz, S->l_b, gout, 2, 0.0);
+    return std::isfinite(fval);
+  }
+  DNLP_HD static double nan_check(DNLP_WLDS WState* S, const WD* gg) {
+    double acc = 0.0;
+    W_FOR(i, S->m) acc += gg[i] - gg[i];
+    return P::sum(acc);
+  }
+  // Ipm::eval_derivs_after_sweep
+  DNLP_HD static void eval_derivs(DNLP_WLDS WState* S) {
+    S->jty_valid = false;
+    spmv(S, S->Mg, S->dvals, S->l_c, S->grad, 1, S->sf);
+    spmv(S, S->MJ, S->dvals, S->l_Jc, S->jv, 3, 0.0);
+  }
+  // Ipm::eval_hessian + Model::eval_hess
+  DNLP_WFN DNLP_HD static void eval_hessian(DNLP_WLDS WState* S) {
+    const int m = S->m;
+    WD* sl = S->sl;
+    const WD *sg = S->sg, *yy = S->y;
+    const double sff = S->sf;
+    if (P::lane() == 0) sl[0] = sff;
+    W_FOR(i, m) sl[1 + i] = sg[i] * yy[i];
+    P::sync();
+    spmv(S, S->Mw, S->sl, -1, S->w, 0, 0.0);
+    sweep(S, S->x, true);
+    spmv(S, S->MH, S->hvals, -1, S->Hs, 0, 0.0);
+  }
+  // BlockExecT::coo_gather through the tape's index by output: out = J v / J^T v / sym(H) v
+  DNLP_WFN DNLP_HD static void coo(DNLP_WLDS WState* S, const WCoo ix, const WD* a, const WD* v, WD* out) {
+    WI *ptr = ix.ptr, *ent = ix.ent, *src = ix.src;
+    W_FOR(gq, ix.nout) {
+      const i32 p0 = ptr[gq], p1 = ptr[gq + 1];
+      if (p1 - p0 > static_cast<i32>(CooIdx::kHeavy)) continue;
+      double sacc = 0.0;
+      for (i32 p = p0; p < p1; ++p) sacc += a[ent[p]] * v[src[p]];
+      out[gq] = sacc;
+    }
+    for (i32 hq = 0; hq < ix.nheavy; ++hq) {
+      const i32 gq = ix.heavy[hq];
+      const i32 p0 = ptr[gq], cnt = ptr[gq + 1] - p0;
+      double sacc = 0.0;
+      W_FOR(q, cnt) sacc += a[ent[p0 + q]] * v[src[p0 + q]];
+      sacc = P::sum(sacc);
+      if (P::lane() == 0) out[gq] = sacc;
+    }
+    P::sync();
+  }
+  DNLP_HD static void hess_mult(DNLP_WLDS WState* S, const WD* v, WD* out) { coo(S, S->hs, S->Hs, v, out); }
+  DNLP_HD static void jac_mult(DNLP_WLDS WState* S, const WD* v, WD* out) { coo(S, S->jr, S->jv, v, out); }
+  DNLP_HD static void jac_tmult(DNLP_WLDS WState* S, const WD* v, WD* out) { coo(S, S->jc, S->jv, v, out); }
+
+  // ====================================================================================================================
+  // KKT system: assembly (kkt_dense.h assemble_factor, sparse branch) and the static-pattern LDL^T (sparse_ldl.h)
+  // ====================================================================================================================
+  DNLP_WFN DNLP_HD static bool assemble_factor(DNLP_WLDS WState* S, const WD* Sx, const WD* D, double dw, bool zero_h, int* nneg_out, int* nzero_out) {
+    const int N = S->N, m = S->m, nnzH = S->nnzH, nnzJ = S->nnzJ, nvals = S->nvals;
+    WD* V = S->svals;
+    const WD *fixm = S->fixm, *hs = S->Hs, *jv = S->jv;
+    WI *hp = S->hpos, *jp = S->jpos, *dp = S->dpos, *hr = S->hess_rows, *hc = S->hess_cols, *jc = S->jac_cols;
+    W_FOR(a, nvals) V[a] = 0.0;
+    P::sync();
+    if (!zero_h) {
+      W_FOR(p, nnzH) {
+        if (fixm[hr[p]] != 0.0 || fixm[hc[p]] != 0.0 || hp[p] < 0) continue;
+        V[hp[p]] += hs[p];
+      }
+    }
+    W_FOR(p, nnzJ) {
+      if (fixm[jc[p]] != 0.0 || jp[p] < 0) continue;
+      V[jp[p]] = jv[p];
+    }
+    P::sync();
+    W_FOR(j, N) {
+      if (fixm[j] != 0.0) V[dp[j]] = 1.0;
+      else V[dp[j]] += Sx[j] + dw;
+    }
+    W_FOR(i, m) V[dp[N + i]] = -D[i];
+    P::sync();
+    S->factorizations++;
+    return ldl_factor(S, nneg_out, nzero_out);
+  }
+  // sparse_ldl.h sp_pivot
+  DNLP_HD static void sp_pivot(DNLP_WLDS WState* S, WD* vals, WD* dinv, int k, double& nneg, double& nzero, double& bad) {
+    WD* Dk = vals + S->doff[k];
+    WD* di = dinv + 3 * k;
+    if (S->bnode[2 * k + 1] < 0) {
+      double d = Dk[0];
+      if (!(d == d)) bad += 1.0;
+      if (fabs(d) < 1e-300) { nzero += 1.0; d = 1e-20; Dk[0] = d; }
+      if (d < 0.0) nneg += 1.0;
+      di[0] = 1.0 / d;
+    } else {
+      const double a = Dk[0], c = Dk[1], e = Dk[2];
+      double det = a * e - c * c;
+      if (!(det == det)) bad += 1.0;
+      if (fabs(det) < 1e-300) { nzero += 1.0; det = -1e-20; }
+      if (det < 0.0) nneg += 1.0;
+      else if (a < 0.0 || (a == 0.0 && e < 0.0)) nneg += 2.0;
+      di[0] = e / det; di[1] = -c / det; di[2] = a / det;
+    }
+  }
+  // sparse_ldl.h sp_scale
+  DNLP_HD static void sp_scale(DNLP_WLDS WState* S, WD* vals, WD* w, const WD* dinv, int r) {
+    const int k = S->sblk[r], i = r - S->soff[k];
+    const WD* di = dinv + 3 * k;
+    if (S->bnode[2 * k + 1] < 0) {
+      const int a = S->loff[k] + i;
+      const double l1 = vals[a];
+      w[a] = l1;
+      vals[a] = l1 * di[0];
+    } else {
+      const int a = S->loff[k] + 2 * i;
+      const double l1 = vals[a], l2 = vals[a + 1];
+      w[a] = l1; w[a + 1] = l2;
+      vals[a] = di[0] * l1 + di[1] * l2;
+      vals[a + 1] = di[1] * l1 + di[2] * l2;
+    }
+  }
+  DNLP_HD static double sp_update(WI* tau, WI* tav, const WD* vals, const WD* w, int q) {
+    const i32 au = tau[q], av = tav[q];
+    if (av >= 0) return w[au] * vals[av];
+    const i32 bv = ~av;
+    return w[au] * vals[bv] + w[au + 1] * vals[bv + 1];
+  }
+  // sparse_ldl.h sparse_ldl_factor (no dense tail)
+  DNLP_WFN DNLP_HD static bool ldl_factor(DNLP_WLDS WState* S, int* nneg_out, int* nzero_out) {
+    const int L = P::lanes, me = P::lane();
+    WD* vals = S->svals;
+    WD* w = S->swork;
+    WD* dinv = S->swork + S->nvals;
+    WI *lev_off = S->lev_off, *soff = S->soff, *lev_g = S->lev_g, *goff = S->goff, *gdst = S->gdst, *tau = S->upd_u, *tav = S->upd_v;
+    double nneg = 0.0, nzero = 0.0, bad = 0.0;
+    const int nlev = S->nlev;
+    for (int lev = 0; lev < nlev; ++lev) {
+      const int b0 = lev_off[lev], b1 = lev_off[lev + 1];
+      const int r0 = soff[b0], r1 = soff[b1];
+      if (r1 - r0 <= 8 * (b1 - b0)) {
+        for (int k = b0 + me; k < b1; k += L) {
+          sp_pivot(S, vals, dinv, k, nneg, nzero, bad);
+          const int re = soff[k + 1];
+          for (int r = soff[k]; r < re; ++r) sp_scale(S, vals, w, dinv, r);
+        }
+        P::sync();
+      } else {
+        for (int k = b0 + me; k < b1; k += L) sp_pivot(S, vals, dinv, k, nneg, nzero, bad);
+        P::sync();
+        for (int r = r0 + me; r < r1; r += L) sp_scale(S, vals, w, dinv, r);
+        P::sync();
+      }
+      const int g0 = lev_g[lev], g1 = lev_g[lev + 1];
+      const int ngr = g1 - g0, ntr = goff[g1] - goff[g0];
+      if (ngr * 8 <= L && ntr >= 16 * ngr) {
+        for (int gq = g0; gq < g1; ++gq) {
+          double acc = 0.0;
+          const int qe = goff[gq + 1];
+          for (int q = goff[gq] + me; q < qe; q += L) acc += sp_update(tau, tav, vals, w, q);
+          acc = P::sum(acc);
+          if (me == 0) vals[gdst[gq]] -= acc;
+        }
+      } else {
+        for (int gq = g0 + me; gq < g1; gq += L) {
+          double acc = 0.0;
+          const int qe = goff[gq + 1];
+          for (int q = goff[gq]; q < qe; ++q) acc += sp_update(tau, tav, vals, w, q);
+          vals[gdst[gq]] -= acc;
+        }
+      }
+      P::sync();
+    }
+    nneg = P::sum(nneg);
+    nzero = P::sum(nzero);
+    bad = P::sum(bad);
+    *nneg_out = static_cast<int>(nneg);
+    *nzero_out = static_cast<int>(nzero);
+    return bad == 0.0;
+  }
+  DNLP_HD static double sp_fwd(DNLP_WLDS WState* S, const WD* vals, const WD* x, int q) {
+    const i32 a = S->fa[q];
+    if (a >= 0) return vals[a] * x[S->fu0[q]];
+    const i32 b = ~a;
+    return vals[b] * x[S->fu0[q]] + vals[b + 1] * x[S->fu1[q]];
+  }
+  // sparse_ldl.h sparse_ldl_solve: x <- K^-1 x
+  DNLP_WFN DNLP_HD static void ldl_solve(DNLP_WLDS WState* S, WD* x) {
+    const int L = P::lanes, me = P::lane();
+    const WD* vals = S->svals;
+    WI *lev_f = S->lev_f, *foff = S->foff, *fnode = S->fnode, *lev_off = S->lev_off, *soff = S->soff, *bnode = S->bnode, *loff = S->loff,
+       *sidx = S->sidx, *doff = S->doff;
+    const int nlev = S->nlev, nblk = S->nblk;
+    for (int lev = 1; lev < nlev; ++lev) {
+      const int h0 = lev_f[lev], h1 = lev_f[lev + 1];
+      if (h1 == h0) continue;
+      const int nh = h1 - h0, nrw = foff[h1] - foff[h0];
+      if (nh * 8 <= L && nrw > 2 * nh) {
+        for (int hq = h0; hq < h1; ++hq) {
+          const int q1 = foff[hq + 1];
+          double acc = 0.0;
+          for (int q = foff[hq] + me; q < q1; q += L) acc += sp_fwd(S, vals, x, q);
+          acc = P::sum(acc);
+          if (me == 0) x[fnode[hq]] -= acc;
+        }
+      } else {
+        for (int hq = h0 + me; hq < h1; hq += L) {
+          const int q1 = foff[hq + 1];
+          double acc = 0.0;
+          for (int q = foff[hq]; q < q1; ++q) acc += sp_fwd(S, vals, x, q);
+          x[fnode[hq]] -= acc;
+        }
+      }
+      P::sync();
+    }
+    for (int k = me; k < nblk; k += L) {
+      const i32 u0 = bnode[2 * k], u1 = bnode[2 * k + 1];
+      const WD* Dk = vals + doff[k];
+      if (u1 < 0) {
+        x[u0] /= Dk[0];
+      } else {
+        const double a = Dk[0], c = Dk[1], e = Dk[2];
+        double det = a * e - c * c;
+        if (fabs(det) < 1e-300) det = -1e-20;
+        const double x0 = x[u0], x1 = x[u1];
+        x[u0] = (e * x0 - c * x1) / det;
+        x[u1] = (a * x1 - c * x0) / det;
+      }
+    }
+    P::sync();
+    for (int lev = nlev - 1; lev >= 0; --lev) {
+      const int b0 = lev_off[lev], b1 = lev_off[lev + 1];
+      const int nbl = b1 - b0, nrw = soff[b1] - soff[b0];
+      if (nbl * 4 >= L || nrw <= 3 * nbl * nbl) {
+        for (int k = b0 + me; k < b1; k += L) {
+          const int s0 = soff[k], sn = soff[k + 1] - s0;
+          const i32 u0 = bnode[2 * k], u1 = bnode[2 * k + 1];
+          const WD* Lk = vals + loff[k];
+          double a0 = 0.0, a1 = 0.0;
+          if (u1 < 0) { for (int i = 0; i < sn; ++i) a0 += Lk[i] * x[sidx[s0 + i]]; x[u0] -= a0; }
+          else {
+            for (int i = 0; i < sn; ++i) { const double xi = x[sidx[s0 + i]]; a0 += Lk[2 * i] * xi; a1 += Lk[2 * i + 1] * xi; }
+            x[u0] -= a0; x[u1] -= a1;
+          }
+        }
+      } else {
+        for (int k = b0; k < b1; ++k) {
+          const int s0 = soff[k], sn = soff[k + 1] - s0;
+          if (sn == 0) continue;
+          const i32 u0 = bnode[2 * k], u1 = bnode[2 * k + 1];
+          const WD* Lk = vals + loff[k];
+          double a0 = 0.0, a1 = 0.0;
+          if (u1 < 0) {
+            for (int i = me; i < sn; i += L) a0 += Lk[i] * x[sidx[s0 + i]];
+            a0 = P::sum(a0);
+            if (me == 0) x[u0] -= a0;
+          } else {
+            for (int i = me; i < sn; i += L) { const double xi = x[sidx[s0 + i]]; a0 += Lk[2 * i] * xi; a1 += Lk[2 * i + 1] * xi; }
+            a0 = P::sum(a0);
+            a1 = P::sum(a1);
+            if (me == 0) { x[u0] -= a0; x[u1] -= a1; }
+          }
+        }
+      }
+      P::sync();
+    }
+  }
+  // DenseKkt::solve (sparse) == Ipm::kkt_solve without the quasi-Newton part
+  DNLP_HD static void kkt_solve(DNLP_WLDS WState* S, const WD* r, WD* out) {
+    const int n = S->N + S->m;
+    if (out != r) { W_FOR(k, n) out[k] = r[k]; P::sync(); }
+    ldl_solve(S, out);
+  }
+
+  // ====================================================================================================================
+  // interior-point loop (ipm_core.h; the member restated is named at each function)
+  // ====================================================================================================================
+  DNLP_HD static void filter_add(DNLP_WLDS WState* S, double th, double ph) {
+    if (S->nfilt == kWaveFilterCap) {
+      for (int k = 1; k < S->nfilt; ++k) { S->filt_th[k - 1] = S->filt_th[k]; S->filt_ph[k - 1] = S->filt_ph[k]; }
+      --S->nfilt;
+    }
+    S->filt_th[S->nfilt] = th; S->filt_ph[S->nfilt] = ph; ++S->nfilt;
+  }
+  DNLP_HD static bool filter_ok(DNLP_WLDS WState* S, double th, double ph) {
+    const double gth = 1e-5, gph = 1e-8;
+    for (int k = 0; k < S->nfilt; ++k)
+      if (!(th <= (1.0 - gth) * S->filt_th[k] || ph <= S->filt_ph[k] - gph * S->filt_th[k])) return false;
+    return true;
+  }
+
+  // Ipm::begin
+  DNLP_WFN DNLP_HD static int begin(DNLP_WLDS WState* S) {
+    const double t_start = now_sec();
+    const int N = S->N, m = S->m;
+    const IpmOptions& opt = S->opt;
+    const double inf = opt.nlp_inf, brf = opt.bound_relax_factor;
+    const bool warm = opt.warm_start != 0 && S->ws_g != nullptr && S->ws_l != nullptr && S->ws_u != nullptr;
+    const double k1 = warm ? opt.warm_start_bound_push : opt.bound_push, k2 = warm ? opt.warm_start_bound_frac : opt.bound_frac;
+    WG *lb = S->row + S->l_lb, *ub = S->row + S->l_ub, *cl = S->row + S->l_cl, *cu = S->row + S->l_cu, *x0 = S->row + S->l_x0;
+    WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *sgp = S->sg, *xx = S->x, *px = S->xt;
+    {
+      double bad = -kInf;
+      W_FOR(j, N) {
+        double a = lb[j], b = ub[j];
+        if (brf > 0) {
+          if (a > -inf) a -= fmin(brf * fmax(1.0, fabs(a)), 1e-3);
+          if (b < inf) b += fmin(brf * fmax(1.0, fabs(b)), 1e-3);
+        }
+        const double lj = a <= -inf ? -kInf : a, uj = b >= inf ? kInf : b;
+        l[j] = lj; u[j] = uj;
+        bad = mxin(bad, lj > uj ? 1.0 : 0.0);
+        xx[j] = x0[j];
+      }
+      W_FOR(i, m) {
+        const double a = cl[i] <= -inf ? -kInf : cl[i], b = cu[i] >= inf ? kInf : cu[i];
+        sl[i] = a; su[i] = b;
+        bad = mxin(bad, a > b ? 1.0 : 0.0);
+        sgp[i] = 1.0;
+      }
+      bad = P::vmax(bad);
+      P::sync();
+      if (bad > 0.0) return S->status = Invalid_Option;
+    }
+    S->sf = 1.0;
+    if (opt.nlp_scaling) {
+      W_FOR(j, N) px[j] = push_into_bounds1(xx[j], l[j], u[j], k1, k2);
+      P::sync();
+      sweep(S, S->xt, false);
+      spmv(S, S->Mg, S->dvals, S->l_c, S->grad, 0, 0.0);
+      spmv(S, S->MJ, S->dvals, S->l_Jc, S->jv, 0, 0.0);
+      const WD* gr = S->grad;
+      double gmax = -kInf;
+      W_FOR(j, N) gmax = mxin(gmax, fabs(gr[j]));
+      gmax = P::vmax(gmax);
+      const double smax = opt.nlp_scaling_max_gradient;
+      if (std::isfinite(gmax) && gmax > smax) S->sf = std::max(smax / gmax, 1e-8);
+      if (m > 0) {
+        WI* rp_ = S->jac_rowptr;
+        const WD* jvv = S->jv;
+        W_FOR(i, m) {
+          double rmax = 0.0;
+          bool fin = true;
+          const i32 pe = rp_[i + 1];
+          for (i32 p = rp_[i]; p < pe; ++p) { const double a = fabs(jvv[p]); if (!(a <= kInf) || a == kInf) fin = false; if (a > rmax) rmax = a; }
+          sgp[i] = (fin && rmax > smax) ? fmax(smax / rmax, 1e-8) : 1.0;
+        }
+        P::sync();
+      }
+    }
+    // scaled constraint bounds, equality mask, counts; start point pushed into the bounds, fixed variables pinned
+    {
+      WD *eq = S->eq, *fm = S->fixm;
+      double neq = 0.0, nfree = 0.0;
+      W_FOR(i, m) {
+        const double e = (sl[i] == su[i]) ? 1.0 : 0.0;
+        eq[i] = e;
+        sl[i] *= sgp[i];
+        su[i] *= sgp[i];
+        neq += e;
+      }
+      W_FOR(j, N) nfree += l[j] == u[j] ? 0.0 : 1.0;
+      const i64 n_eq = m ? static_cast<i64>(P::sum(neq)) : 0;
+      const i64 n_free = static_cast<i64>(P::sum(nfree));
+      if (n_eq > n_free) return S->status = Not_Enough_Degrees_Of_Freedom;
+      S->n_eq = static_cast<i32>(n_eq);
+      S->n_fixed = static_cast<i32>(N - n_free);
+      W_FOR(j, N) {
+        const bool fx = l[j] == u[j];
+        xx[j] = fx ? l[j] : push_into_bounds1(xx[j], l[j], u[j], k1, k2);
+        fm[j] = fx ? 1.0 : 0.0;
+        if (fx) { l[j] = -kInf; u[j] = kInf; }
+      }
+      P::sync();
+    }
+    S->nb_cache = -1;
+    if (!eval_fg(S, S->x, S->f, S->g) || nan_check(S, S->g) != 0.0) return S->status = Invalid_Number_Detected;
+    eval_derivs(S);
+    {
+      WD *ss = S->s, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU, *yy = S->y;
+      const WD *gg = S->g, *eq = S->eq;
+      const double zi = opt.bound_mult_init_val;
+      W_FOR(i, m) {
+        ss[i] = eq[i] != 0.0 ? sl[i] : push_into_bounds1(gg[i], sl[i], su[i], k1, k2);
+        c[i] = (eq[i] == 0.0 && sl[i] > -kInf) ? zi : 0.0;
+        d[i] = (eq[i] == 0.0 && su[i] < kInf) ? zi : 0.0;
+        yy[i] = 0.0;
+      }
+      W_FOR(j, N) { a[j] = (l[j] > -kInf) ? zi : 0.0; b[j] = (u[j] < kInf) ? zi : 0.0; }
+      P::sync();
+    }
+    S->mu = opt.mu_init;
+    S->tau = std::max(0.99, 1.0 - S->mu);
+    S->jty_valid = false;
+    if (warm) {
+      const double sff = S->sf, mp = opt.warm_start_mult_bound_push;
+      const double *wy = S->ws_g, *wl = S->ws_l, *wu = S->ws_u;
+      const WD* eq = S->eq;
+      WD *yy = S->y, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU;
+      W_FOR(i, m) {
+        const double yi = wy[i] * sff / sgp[i];
+        yy[i] = yi;
+        const bool in = eq[i] == 0.0;
+        c[i] = (in && sl[i] > -kInf) ? fmax(-yi, mp) : 0.0;
+        d[i] = (in && su[i] < kInf) ? fmax(yi, mp) : 0.0;
+      }
+      W_FOR(j, N) {
+        a[j] = (l[j] > -kInf) ? fmax(wl[j] * sff, mp) : 0.0;
+        b[j] = (u[j] < kInf) ? fmax(wu[j] * sff, mp) : 0.0;
+      }
+      P::sync();
+    } else if (m > 0 && opt.least_square_init_duals >= 0) {
+      init_multipliers_ls(S);
+    }
+    S->nfilt = 0;
+    const double th0 = theta_at(S, S->g, S->s);
+    S->theta_max = 1e4 * std::max(1.0, th0);
+    S->theta_min = 1e-4 * std::max(1.0, th0);
+    S->iter = 0;
+    S->acceptable_count = 0;
+    S->delta_w_last = 0.0;
+    S->dc_fixed_count = 0; S->dc_fixed_last = false; S->always_dc = false;
+    S->resto_stationary = false; S->resto_theta = 0.0;
+    S->tiny_streak = 0;
+    S->e_cached_valid = false;
+    S->fixed_mode = false;
+    S->n_hist = 0;
+    S->initialized = true;
+    S->status = Internal_Error;
+    S->factorizations = 0;            // (stats = IpmStats())
+    S->inf_pr = S->inf_du = S->cmpl = S->nlp_error = 0.0;
+    S->t_begin = t_start;
+    return 0;
+  }
+
+  // Ipm::init_multipliers_ls (the general path: neither of the host-only condensed forms)
+  DNLP_WFN DNLP_HD static void init_multipliers_ls(DNLP_WLDS WState* S) {
+    const int N = S->N, m = S->m;
+    S->jty_valid = false;
+    const WD* eq = S->eq;
+    WD *sx = S->Sx, *dd = S->Dd;
+    W_FOR(j, N) sx[j] = 1.0;
+    W_FOR(i, m) dd[i] = (eq[i] == 0.0) ? 1.0 : 0.0;
+    {
+      WD* hs = S->Hs;                      // (ex_->zero(md_->Hs): the next eval_hessian refills it)
+      W_FOR(p, S->nnzH) hs[p] = 0.0;
+    }
+    P::sync();
+    int nneg = 0, nzero = 0;
+    bool ok = assemble_factor(S, S->Sx, S->Dd, 0.0, true, &nneg, &nzero);
+    if (!ok || nzero > 0 || nneg != m) {
+      W_FOR(i, m) dd[i] += 1e-8;
+      P::sync();
+      ok = assemble_factor(S, S->Sx, S->Dd, 0.0, true, &nneg, &nzero);
+      if (!ok) return;
+    }
+    WD* r = S->rhs;
+    const WD *gr = S->grad, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU;
+    W_FOR(j, N) r[j] = -(gr[j] - a[j] + b[j]);
+    W_FOR(i, m) r[N + i] = (eq[i] == 0.0) ? -(-c[i] + d[i]) : 0.0;
+    P::sync();
+    kkt_solve(S, S->rhs, S->sol);
+    const WD* so = S->sol;
+    double ymax = -kInf;
+    W_FOR(i, m) ymax = mxin(ymax, fabs(so[N + i]));
+    ymax = P::vmax(ymax);
+    if (std::isfinite(ymax) && ymax <= S->opt.constr_mult_init_max) {
+      WD* yy = S->y;
+      W_FOR(i, m) yy[i] = so[N + i];
+      P::sync();
+    }
+  }
+
+  // Ipm::theta_at
+  DNLP_HD static double theta_at(DNLP_WLDS WState* S, const WD* gg, const WD* ss) {
+    const WD *eq = S->eq, *sl = S->sL;
+    double acc = 0.0;
+    W_FOR(i, S->m) acc += fabs(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]);
+    return P::sum(acc);
+  }
+  DNLP_HD static double bterm(double v, double lo, double hi, double kd) {
+    double bt = 0.0;
+    const bool hl = lo > -kInf, hu = hi < kInf;
+    if (hl) bt -= log(v - lo);
+    if (hu) bt -= log(hi - v);
+    if (hl && !hu) bt += kd * (v - lo);
+    if (hu && !hl) bt += kd * (hi - v);
+    return bt;
+  }
+  // Ipm::barrier_at (two sums: variables, rows)
+  DNLP_WFN DNLP_HD static double barrier_at(DNLP_WLDS WState* S, double fv, const WD* xx, const WD* ss, double muv) {
+    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *eq = S->eq;
+    const double kd = S->opt.kappa_d;
+    double ax = 0.0, as = 0.0;
+    W_FOR(j, S->N) ax += bterm(xx[j], l[j], u[j], kd);
+    W_FOR(i, S->m) as += eq[i] != 0.0 ? 0.0 : bterm(ss[i], sl[i], su[i], kd);
+    const double bx = P::sum(ax), bs = P::sum(as);
+    return fv + muv * (bx + bs);
+  }
+  // Ipm::measures: theta, the barrier function and the NaN detector of g in one pass
+  DNLP_WFN DNLP_HD static WMeasures measures(DNLP_WLDS WState* S, double fv, const WD* gg, const WD* xx, const WD* ss, double muv) {
+    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *eq = S->eq;
+    const double kd = S->opt.kappa_d;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    W_FOR(j, S->N) s1 += bterm(xx[j], l[j], u[j], kd);
+    W_FOR(i, S->m) {
+      s0 += fabs(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]);
+      s2 += gg[i] - gg[i];
+      if (eq[i] == 0.0) s1 += bterm(ss[i], sl[i], su[i], kd);
+    }
+    s0 = P::sum(s0); s1 = P::sum(s1); s2 = P::sum(s2);
+    return WMeasures{s0, fv + muv * s1, s2};
+  }
+  // Ipm::jty
+  DNLP_HD static const WD* jty(DNLP_WLDS WState* S) {
+    if (!S->jty_valid) { jac_tmult(S, S->y, S->tN); S->jty_valid = true; }
+    return S->tN;
+  }
+  // Ipm::error (dual_residuals fused into the same pass)
+  DNLP_WFN DNLP_HD static WErr error(DNLP_WLDS WState* S, double muv) {
+    const int N = S->N, m = S->m;
+    const WD* jt = jty(S);
+    WD *r = S->rx, *q = S->rs;
+    const WD *gr = S->grad, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU, *yy = S->y, *eq = S->eq, *fm = S->fixm, *gg = S->g, *ss = S->s,
+             *sl = S->sL, *su = S->sU, *l = S->xL, *u = S->xU, *xx = S->x, *sgp = S->sg;
+    double m0 = -kInf, m1 = -kInf, m2 = -kInf, m3 = -kInf, sy = 0.0, sz = 0.0;
+    W_FOR(j, N) {
+      const double rj = fm[j] != 0.0 ? 0.0 : gr[j] + jt[j] - a[j] + b[j];
+      r[j] = rj;
+      m0 = mxin(m0, fabs(rj));
+      double cv = 0.0;
+      if (l[j] > -kInf) cv = fmax(cv, fabs((xx[j] - l[j]) * a[j] - muv));
+      if (u[j] < kInf) cv = fmax(cv, fabs((u[j] - xx[j]) * b[j] - muv));
+      m2 = mxin(m2, cv);
+      sz += fabs(a[j]) + fabs(b[j]);
+    }
+    W_FOR(i, m) {
+      const double qi = (eq[i] == 0.0) ? -yy[i] - c[i] + d[i] : 0.0;
+      q[i] = qi;
+      m0 = mxin(m0, fabs(qi));
+      const double pr = fabs(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]);
+      m1 = mxin(m1, pr);
+      m3 = mxin(m3, pr / sgp[i]);
+      double cv = 0.0;
+      if (eq[i] == 0.0) {
+        if (sl[i] > -kInf) cv = fmax(cv, fabs((ss[i] - sl[i]) * c[i] - muv));
+        if (su[i] < kInf) cv = fmax(cv, fabs((su[i] - ss[i]) * d[i] - muv));
+      }
+      m2 = mxin(m2, cv);
+      sy += fabs(yy[i]) + fabs(c[i]) + fabs(d[i]);
+    }
+    m0 = P::vmax(m0); m1 = P::vmax(m1); m2 = P::vmax(m2); m3 = P::vmax(m3); sy = P::sum(sy); sz = P::sum(sz);
+    P::sync();
+    WErr e;
+    e.dual = std::max(m0, 0.0);
+    e.primal = m ? std::max(m1, 0.0) : 0.0;
+    e.cmpl = std::max(m2, 0.0);
+    e.primal_unscaled = m ? std::max(m3, 0.0) : 0.0;
+    const double smax = 100.0;
+    const i64 nb = n_bound_mults(S);
+    e.sd = std::max(smax, (sy + sz) / std::max<double>(1.0, static_cast<double>(m + nb))) / smax;
+    e.sc = std::max(smax, sz / std::max<double>(1.0, static_cast<double>(nb))) / smax;
+    e.total = std::max(std::max(e.dual / e.sd, e.primal), e.cmpl / e.sc);
+    return e;
+  }
+  // Ipm::n_bound_mults
+  DNLP_HD static i64 n_bound_mults(DNLP_WLDS WState* S) {
+    if (S->nb_cache >= 0) return S->nb_cache;
+    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *eq = S->eq;
+    double c1 = 0.0, c2 = 0.0;
+    W_FOR(j, S->N) c1 += (l[j] > -kInf ? 1.0 : 0.0) + (u[j] < kInf ? 1.0 : 0.0);
+    W_FOR(i, S->m) c2 += eq[i] != 0.0 ? 0.0 : (sl[i] > -kInf ? 1.0 : 0.0) + (su[i] < kInf ? 1.0 : 0.0);
+    c1 = P::sum(c1);
+    c2 = S->m ? P::sum(c2) : 0.0;
+    S->nb_cache = static_cast<i32>(c1 + c2);
+    return S->nb_cache;
+  }
+  // Ipm::barrier_terms
+  DNLP_WFN DNLP_HD static void barrier_terms(DNLP_WLDS WState* S, double muv) {
+    const WD* jt = jty(S);
+    WD *sx = S->Sx, *sS = S->Ss, *r = S->rx, *q = S->rs, *p = S->rp;
+    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *eq = S->eq, *xx = S->x, *ss = S->s, *a = S->zL, *b = S->zU, *c = S->vL,
+             *d = S->vU, *gr = S->grad, *yy = S->y, *gg = S->g, *fm = S->fixm;
+    const double kd = S->opt.kappa_d;
+    W_FOR(j, S->N) {
+      double sig = 0.0, gphi = gr[j];
+      const bool hl = l[j] > -kInf, hu = u[j] < kInf;
+      if (hl) { sig += a[j] / (xx[j] - l[j]); gphi -= muv / (xx[j] - l[j]); }
+      if (hu) { sig += b[j] / (u[j] - xx[j]); gphi += muv / (u[j] - xx[j]); }
+      if (hl && !hu) gphi += kd * muv;
+      if (hu && !hl) gphi -= kd * muv;
+      sx[j] = sig;
+      r[j] = fm[j] != 0.0 ? 0.0 : gphi + jt[j];
+    }
+    W_FOR(i, S->m) {
+      if (eq[i] != 0.0) { sS[i] = 0.0; q[i] = 0.0; p[i] = gg[i] - sl[i]; continue; }
+      double sig = 0.0, gphi = 0.0;
+      const bool hl = sl[i] > -kInf, hu = su[i] < kInf;
+      if (hl) { sig += c[i] / (ss[i] - sl[i]); gphi -= muv / (ss[i] - sl[i]); }
+      if (hu) { sig += d[i] / (su[i] - ss[i]); gphi += muv / (su[i] - ss[i]); }
+      if (hl && !hu) gphi += kd * muv;
+      if (hu && !hl) gphi -= kd * muv;
+      sS[i] = sig;
+      q[i] = gphi - yy[i];
+      p[i] = gg[i] - ss[i];
+    }
+    P::sync();
+  }
+  // Ipm::try_factor: 0 ok, 1 wrong inertia, 2 singular
+  DNLP_HD static int try_factor(DNLP_WLDS WState* S, double dw, double dc) {
+    int nneg = 0, nzero = 0;
+    WD* dd = S->Dd;
+    const WD *sS = S->Ss, *eq = S->eq;
+    W_FOR(i, S->m) dd[i] = dc + (eq[i] == 0.0 ? 1.0 / fmax(sS[i] + dw, 1e-20) : 0.0);
+    P::sync();
+    const bool ok = assemble_factor(S, S->Sx, S->Dd, dw, false, &nneg, &nzero);
+    S->last_nneg = nneg;
+    if (!ok) return 2;
+    if (nzero > 0) return 2;
+    return nneg == S->m ? 0 : 1;
+  }
+  // Ipm::factor_with_inertia (WB Algorithm IC; no Lanczos bound: host-driven large dense systems only)
+  DNLP_WFN DNLP_HD static bool factor_with_inertia(DNLP_WLDS WState* S, double& delta_w, double& delta_c) {
+    const double dw_min = 1e-20, dw_0 = 1e-4, dw_max = S->opt.max_hessian_perturbation, dc_bar = 1e-8, kwp = 8.0, kwpb = 100.0, kwm = 1.0 / 3.0, kc = 0.25;
+    delta_w = 0.0; delta_c = 0.0;
+    const double dc_val = dc_bar * std::pow(S->mu, kc);
+    int r = try_factor(S, 0.0, S->always_dc ? dc_val : 0.0);
+    if (S->always_dc) delta_c = dc_val;
+    const bool can_fallback = (S->N + S->m) <= S->fallback_max_n;
+    if (r == 2 && !S->always_dc && can_fallback && (!S->opt.lazy_dense_fallback || S->ladder_rung > 0)) {
+      ++S->sparse_singular_streak;
+      if ((S->N + S->m) <= 512 || (S->iter >= 1 && S->sparse_singular_streak >= 2)) {
+        S->bail = true;                    // the generic kernel's Bunch-Kaufman path takes this instance
+        return false;
+      }
+    } else {
+      S->sparse_singular_streak = 0;
+    }
+    if (r == 0) { S->delta_w_used_last_iter = false; if (!S->always_dc) S->dc_fixed_last = false; return true; }
+    S->delta_w_used_last_iter = true;
+    if (r == 2) delta_c = dc_val;
+    delta_w = (S->delta_w_last == 0.0) ? dw_0 : std::max(dw_min, kwm * S->delta_w_last);
+    if (delta_c == 0.0 ? (r == 2 || (r == 1 && S->dc_fixed_last)) : (r == 2 && !S->always_dc)) {
+      const int r2 = try_factor(S, 0.0, dc_val);
+      if (r2 == 0) { delta_c = dc_val; delta_w = 0.0; if (r == 1) dc_fixed(S); return true; }
+      if (r == 1) S->dc_fixed_last = false;
+    }
+    const double dw_start = delta_w;
+    int wrong_no_dc = 0, nneg_seen = -1;
+    for (int k = 0; k < 100; ++k) {
+      const int r2 = try_factor(S, delta_w, delta_c);
+      if (r2 == 0) { S->delta_w_last = delta_w; if (!S->always_dc) S->dc_fixed_last = false; return true; }
+      if (r2 == 2 && delta_c == 0.0) delta_c = dc_val;
+      if (r2 == 1 && delta_c == 0.0) {
+        if (S->last_nneg < 1000000 && (nneg_seen < 0 || S->last_nneg == nneg_seen)) ++wrong_no_dc; else wrong_no_dc = 0;
+        nneg_seen = S->last_nneg < 1000000 ? S->last_nneg : -1;
+        if (wrong_no_dc >= 3) {
+          int r3 = try_factor(S, 0.0, dc_val);
+          if (r3 == 0) { delta_c = dc_val; delta_w = 0.0; dc_fixed(S); return true; }
+          r3 = try_factor(S, dw_start, dc_val);
+          if (r3 == 0) { delta_c = dc_val; delta_w = S->delta_w_last = dw_start; dc_fixed(S); return true; }
+          delta_c = dc_val;
+        } else if (delta_w > 1e20) {
+          delta_c = dc_val;
+          delta_w = dw_start;
+          continue;
+        }
+      }
+      delta_w = (S->delta_w_last == 0.0) ? kwpb * delta_w : kwp * delta_w;
+      if (delta_w > dw_max) return false;
+    }
+    return false;
+  }
+  DNLP_HD static void dc_fixed(DNLP_WLDS WState* S) {
+    S->dc_fixed_last = true;
+    if (++S->dc_fixed_count >= 3 && !S->always_dc) S->always_dc = true;
+  }
+  // Ipm::kkt_residual: out = rhsv - K v, max |out|, max |v|
+  DNLP_WFN DNLP_HD static void kkt_residual(DNLP_WLDS WState* S, const WD* v, double dw, const WD* rhsv, WD* out, double& en, double& sn) {
+    const int N = S->N, m = S->m;
+    hess_mult(S, v, out);
+    jac_tmult(S, v + N, S->xt);
+    jac_mult(S, v, S->tM);
+    const WD *sx = S->Sx, *jt = S->xt, *jx = S->tM, *dd = S->Dd, *fm = S->fixm;
+    double m0 = -kInf, m1 = -kInf;
+    W_FOR(k, N) {
+      const double kv = fm[k] != 0.0 ? v[k] : out[k] + (sx[k] + dw) * v[k] + jt[k];
+      const double r = rhsv[k] - kv;
+      out[k] = r;
+      m0 = mxin(m0, fabs(r)); m1 = mxin(m1, fabs(v[k]));
+    }
+    W_FOR(i, m) {
+      const int k = N + i;
+      const double kv = jx[i] - dd[i] * v[k];
+      const double r = rhsv[k] - kv;
+      out[k] = r;
+      m0 = mxin(m0, fabs(r)); m1 = mxin(m1, fabs(v[k]));
+    }
+    en = P::vmax(m0); sn = P::vmax(m1);
+    P::sync();
+  }
+  // Ipm::solve_refined
+  DNLP_WFN DNLP_HD static bool solve_refined(DNLP_WLDS WState* S, double dw) {
+    const int n = S->N + S->m;
+    kkt_solve(S, S->rhs, S->sol);
+    const WD* rr = S->rhs;
+    double rn = -kInf;
+    W_FOR(i, n) rn = mxin(rn, fabs(rr[i]));
+    rn = P::vmax(rn);
+    double best = kInf;
+    bool fresh = false;
+    for (int it = 0; it < S->opt.max_refine; ++it) {
+      double en, sn;
+      kkt_residual(S, S->sol, dw, S->rhs, S->res, en, sn);
+      const double ratio = en / (std::max(rn, 1e-300) + sn);
+      if (!std::isfinite(en)) return false;
+      S->last_ratio = std::isfinite(ratio) ? ratio : kInf;
+      fresh = true;
+      if (it >= S->opt.min_refine && ratio <= 1e-10) break;
+      if (en >= best * 0.999 && it >= S->opt.min_refine) break;
+      best = std::min(best, en);
+      kkt_solve(S, S->res, S->cor);
+      WD* sw = S->sol;
+      const WD* co = S->cor;
+      W_FOR(i, n) sw[i] += co[i];
+      P::sync();
+      fresh = false;
+    }
+    if (!fresh) {
+      double en, sn;
+      kkt_residual(S, S->sol, dw, S->rhs, S->res, en, sn);
+      S->last_ratio = en / (std::max(rn, 1e-300) + sn);
+      if (!std::isfinite(S->last_ratio)) S->last_ratio = kInf;
+    }
+    return true;
+  }
+  // Ipm::compute_direction; `set` picks the seven output arrays (0: dx .. dvU, 1: affine-scaling, 2: centering);
+  // pres == nullptr stands for the all-zero primal residual of the centering system
+  DNLP_WFN DNLP_HD static bool compute_direction(DNLP_WLDS WState* S, double muv, const WD* pres, double dw, bool centering, int set) {
+    const int N = S->N, m = S->m;
+    WD* r = S->rhs;
+    const WD *rxx = S->rx, *q = S->rs, *sS = S->Ss, *eq = S->eq;
+    W_FOR(k, N) r[k] = -rxx[k];
+    W_FOR(i, m) r[N + i] = -(pres ? pres[i] : 0.0) - (eq[i] == 0.0 ? q[i] / (sS[i] + dw) : 0.0);
+    P::sync();
+    if (!solve_refined(S, dw)) return false;
+    const WD* so = S->sol;
+    WD *ddx = S->dir[set][0], *dds = S->dir[set][1], *ddy = S->dir[set][2], *da = S->dir[set][3], *db = S->dir[set][4], *dc = S->dir[set][5],
+       *dd2 = S->dir[set][6];
+    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *xx = S->x, *ss = S->s, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU;
+    const double keep = centering ? 0.0 : 1.0;
+    W_FOR(j, N) {
+      const double dxj = so[j];
+      ddx[j] = dxj;
+      da[j] = (l[j] > -kInf) ? (muv - a[j] * dxj) / (xx[j] - l[j]) - keep * a[j] : 0.0;
+      db[j] = (u[j] < kInf) ? (muv + b[j] * dxj) / (u[j] - xx[j]) - keep * b[j] : 0.0;
+    }
+    W_FOR(i, m) {
+      const bool in = eq[i] == 0.0;
+      const double dsi = in ? (so[N + i] - q[i]) / (sS[i] + dw) : 0.0;
+      ddy[i] = so[N + i];
+      dds[i] = dsi;
+      dc[i] = (in && sl[i] > -kInf) ? (muv - c[i] * dsi) / (ss[i] - sl[i]) - keep * c[i] : 0.0;
+      dd2[i] = (in && su[i] < kInf) ? (muv + d[i] * dsi) / (su[i] - ss[i]) - keep * d[i] : 0.0;
+    }
+    P::sync();
+    return true;
+  }
+  // Ipm::max_step_primal
+  DNLP_HD static double max_step_primal(DNLP_WLDS WState* S, double tauv) {
+    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *xx = S->x, *ss = S->s, *ddx = S->dx, *dds = S->ds, *eq = S->eq;
+    double ax = -kInf, as = -kInf;
+    W_FOR(j, S->N) {
+      double a = 1.0;
+      if (l[j] > -kInf && ddx[j] < 0.0) a = fmin(a, -tauv * (xx[j] - l[j]) / ddx[j]);
+      if (u[j] < kInf && ddx[j] > 0.0) a = fmin(a, tauv * (u[j] - xx[j]) / ddx[j]);
+      ax = mnin(ax, a);
+    }
+    W_FOR(i, S->m) {
+      double a = 1.0;
+      if (eq[i] == 0.0) {
+        if (sl[i] > -kInf && dds[i] < 0.0) a = fmin(a, -tauv * (ss[i] - sl[i]) / dds[i]);
+        if (su[i] < kInf && dds[i] > 0.0) a = fmin(a, tauv * (su[i] - ss[i]) / dds[i]);
+      }
+      as = mnin(as, a);
+    }
+    const double rx_ = -P::vmax(ax), rs_ = S->m ? -P::vmax(as) : 1.0;
+    return std::min(1.0, std::min(rx_, rs_));
+  }
+  // Ipm::max_step_dual
+  DNLP_HD static double max_step_dual(DNLP_WLDS WState* S, double tauv) {
+    const WD *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU, *da = S->dzL, *db = S->dzU, *dc = S->dvL, *dd2 = S->dvU;
+    double az = -kInf, av = -kInf;
+    W_FOR(j, S->N) {
+      double t = 1.0;
+      if (da[j] < 0.0) t = fmin(t, -tauv * a[j] / da[j]);
+      if (db[j] < 0.0) t = fmin(t, -tauv * b[j] / db[j]);
+      az = mnin(az, t);
+    }
+    W_FOR(i, S->m) {
+      double t = 1.0;
+      if (dc[i] < 0.0) t = fmin(t, -tauv * c[i] / dc[i]);
+      if (dd2[i] < 0.0) t = fmin(t, -tauv * d[i] / dd2[i]);
+      av = mnin(av, t);
+    }
+    const double rz = -P::vmax(az), rv = S->m ? -P::vmax(av) : 1.0;
+    return std::min(1.0, std::min(rz, rv));
+  }
+  // Ipm::max_steps: both fraction-to-boundary step sizes in one pass
+  DNLP_WFN DNLP_HD static D2 max_steps(DNLP_WLDS WState* S, double tauv) {
+    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *xx = S->x, *ss = S->s, *ddx = S->dx, *dds = S->ds, *eq = S->eq;
+    const WD *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU, *da = S->dzL, *db = S->dzU, *dc = S->dvL, *dd2 = S->dvU;
+    double a0 = -kInf, a1 = -kInf;
+    W_FOR(j, S->N) {
+      double tp = 1.0, td = 1.0;
+      if (l[j] > -kInf && ddx[j] < 0.0) tp = fmin(tp, -tauv * (xx[j] - l[j]) / ddx[j]);
+      if (u[j] < kInf && ddx[j] > 0.0) tp = fmin(tp, tauv * (u[j] - xx[j]) / ddx[j]);
+      if (da[j] < 0.0) td = fmin(td, -tauv * a[j] / da[j]);
+      if (db[j] < 0.0) td = fmin(td, -tauv * b[j] / db[j]);
+      a0 = mnin(a0, tp); a1 = mnin(a1, td);
+    }
+    W_FOR(i, S->m) {
+      double tp = 1.0, td = 1.0;
+      if (eq[i] == 0.0) {
+        if (sl[i] > -kInf && dds[i] < 0.0) tp = fmin(tp, -tauv * (ss[i] - sl[i]) / dds[i]);
+        if (su[i] < kInf && dds[i] > 0.0) tp = fmin(tp, tauv * (su[i] - ss[i]) / dds[i]);
+      }
+      if (dc[i] < 0.0) td = fmin(td, -tauv * c[i] / dc[i]);
+      if (dd2[i] < 0.0) td = fmin(td, -tauv * d[i] / dd2[i]);
+      a0 = mnin(a0, tp); a1 = mnin(a1, td);
+    }
+    a0 = P::vmax(a0); a1 = P::vmax(a1);
+    return D2{std::min(1.0, -a0), std::min(1.0, -a1)};
+  }
+  // Ipm::check_convergence
+  DNLP_HD static int check_convergence(DNLP_WLDS WState* S, const WErr& e0) {
+    const IpmOptions& opt = S->opt;
+    const double unsc_du = e0.dual / S->sf, unsc_pr = e0.primal_unscaled, unsc_co = e0.cmpl / S->sf;
+    S->inf_pr = unsc_pr; S->inf_du = unsc_du; S->cmpl = unsc_co; S->nlp_error = e0.total;
+    if (e0.total <= opt.tol && unsc_du <= opt.dual_inf_tol && unsc_pr <= opt.constr_viol_tol && unsc_co <= opt.compl_inf_tol)
+      return Solve_Succeeded;
+    const bool acc = e0.total <= opt.acceptable_tol && unsc_du <= opt.acceptable_dual_inf_tol &&
+                     unsc_pr <= opt.acceptable_constr_viol_tol && unsc_co <= opt.acceptable_compl_inf_tol;
+    S->acceptable_count = acc ? S->acceptable_count + 1 : 0;
+    if (opt.acceptable_iter > 0 && S->acceptable_count >= opt.acceptable_iter) return Solved_To_Acceptable_Level;
+    return 99;
+  }
+  DNLP_HD static WErr cached_err(DNLP_WLDS WState* S) {
+    return WErr{S->e_dual, S->e_primal, S->e_cmpl, S->e_sd, S->e_sc, S->e_total, S->e_primal_unscaled};
+  }
+  DNLP_HD static void cache_err(DNLP_WLDS WState* S, const WErr& e) {
+    S->e_dual = e.dual; S->e_primal = e.primal; S->e_cmpl = e.cmpl; S->e_sd = e.sd; S->e_sc = e.sc; S->e_total = e.total;
+    S->e_primal_unscaled = e.primal_unscaled;
+    S->e_cached_valid = true;
+  }
+
+  // Ipm::step
+  DNLP_WFN DNLP_HD static int step(DNLP_WLDS WState* S) {
+    const int N = S->N, m = S->m;
+    if (!S->initialized) return S->status = Internal_Error;
+    const WErr e0 = S->e_cached_valid ? cached_err(S) : error(S, 0.0);
+    S->e_cached_valid = false;
+    const int cv = check_convergence(S, e0);
+    if (cv != 99) return S->status = cv;
+    if (S->iter >= S->opt.max_iter) return S->status = Maximum_Iterations_Exceeded;
+    if (now_sec() - S->t_begin > S->opt.max_wall_time) return S->status = Maximum_WallTime_Exceeded;
+    {
+      const WD* xx = S->x;
+      double xm = -kInf;
+      W_FOR(j, N) xm = mxin(xm, fabs(xx[j]));
+      xm = P::vmax(xm);
+      if (!(xm <= S->opt.diverging_iterates_tol)) return S->status = Diverging_Iterates;
+    }
+    const bool want_oracle = update_mu(S, e0);
+    eval_hessian(S);
+    barrier_terms(S, S->mu);
+    double dw = 0.0, dc = 0.0;
+    if (!factor_with_inertia(S, dw, dc)) return S->status = Error_In_Step_Computation;
+    bool have_dir = false;
+    if (want_oracle) have_dir = quality_function_mu(S, dw);
+    if (!have_dir) {
+      barrier_terms(S, S->mu);
+      if (!compute_direction(S, S->mu, S->rp, dw, false, 0)) return S->status = Error_In_Step_Computation;
+    }
+    for (int tries = 0; tries < 6 && S->last_ratio > 1e-5; ++tries) {
+      if (dc == 0.0) dc = 1e-8 * std::pow(S->mu, 0.25);
+      dw = (dw == 0.0) ? ((S->delta_w_last == 0.0) ? 1e-4 : std::max(1e-20, S->delta_w_last / 3.0)) : 8.0 * dw;
+      int r = try_factor(S, dw, dc);
+      while (r != 0 && dw < S->opt.max_hessian_perturbation) { dw *= 8.0; r = try_factor(S, dw, dc); }
+      if (r != 0) return S->status = Error_In_Step_Computation;
+      S->delta_w_last = dw;
+      barrier_terms(S, S->mu);
+      if (!compute_direction(S, S->mu, S->rp, dw, false, 0)) return S->status = Error_In_Step_Computation;
+    }
+    // ---- backtracking filter line search (WB Algorithm A, steps A-5) ----
+    const double mu = S->mu, tau = S->tau;
+    const D2 steps = max_steps(S, tau);
+    const double a_max = steps.first;
+    double a_z = steps.second;
+    const WMeasures mk = measures(S, S->f, S->g, S->x, S->s, mu);
+    const double theta_k = mk.theta, phi_k = mk.phi;
+    double gphid;
+    {
+      const WD *rxx = S->rx, *ddx = S->dx, *q = S->rs, *yy = S->y, *dds = S->ds, *eq = S->eq;
+      const WD* jt = jty(S);
+      double acc = 0.0;
+      W_FOR(k, N) acc += (rxx[k] - jt[k]) * ddx[k];
+      W_FOR(i, m) acc += eq[i] == 0.0 ? (q[i] + yy[i]) * dds[i] : 0.0;
+      gphid = P::sum(acc);
+    }
+    const double g_th = 1e-5, g_ph = 1e-8, dlt = 1.0, s_th = 1.1, s_ph = 2.3, eta = 1e-8, g_al = 0.05;
+    double a_min;
+    if (gphid < 0.0) {
+      a_min = std::min(g_th, g_ph * theta_k / (-gphid));
+      if (theta_k <= S->theta_min) a_min = std::min(a_min, dlt * std::pow(theta_k, s_th) / std::pow(-gphid, s_ph));
+      a_min *= g_al;
+    } else {
+      a_min = g_al * g_th;
+    }
+    const double macheps = 2.220446049250313e-16;
+    auto le = [&](double a, double b, double base) { return a - b <= 10.0 * macheps * std::fabs(base); };
+    double alpha = a_max;
+    bool accepted = false, ftype = false;
+    int ls = 0;
+    bool soc_tried = false;
+    double th_t = 0.0, ph_t = 0.0, f_t = 0.0;
+    while (true) {
+      ++ls;
+      trial_point(S, alpha);
+      bool fin = eval_fg(S, S->xt, f_t, S->gt);
+      if (fin) {
+        const WMeasures mt = measures(S, f_t, S->gt, S->xt, S->st, mu);
+        th_t = mt.theta;
+        ph_t = mt.phi;
+        fin = mt.chk == 0.0 && std::isfinite(th_t) && std::isfinite(ph_t);
+      }
+      if (fin && th_t <= S->theta_max && filter_ok(S, th_t, ph_t)) {
+        const bool sw = gphid < 0.0 && alpha * std::pow(-gphid, s_ph) > dlt * std::pow(theta_k, s_th);
+        if (theta_k <= S->theta_min && sw) {
+          if (le(ph_t, phi_k + eta * alpha * gphid, phi_k)) { accepted = true; ftype = true; }
+        } else {
+          if (le(th_t, (1.0 - g_th) * theta_k, theta_k) || le(ph_t, phi_k - g_ph * theta_k, phi_k)) accepted = true;
+        }
+      }
+      if (accepted) break;
+      if (ls == 1 && !soc_tried && fin && th_t >= theta_k && S->opt.max_soc > 0 && m > 0) {
+        soc_tried = true;
+        if (second_order_correction(S, alpha, dw, theta_k, phi_k, gphid, th_t, ph_t, f_t, ftype)) {
+          accepted = true;
+          a_z = max_step_dual(S, tau);
+          break;
+        }
+        compute_direction(S, mu, S->rp, dw, false, 0);
+      }
+      alpha *= 0.5;
+      if (alpha < a_min || ls > 60) break;
+    }
+    const double alpha_used = alpha;
+    if (!accepted) {
+      if (S->opt.restoration && restoration_phase(S, theta_k)) {
+        ++S->iter;
+        (void)error(S, 0.0);             // (Ipm::step computes it for the log line; it also refreshes rx / rs)
+        return 99;
+      }
+      if (S->bail) return S->status = Error_In_Step_Computation;
+      const WD* ddx = S->dx;
+      double dn = -kInf;
+      W_FOR(j, N) dn = mxin(dn, fabs(ddx[j]));
+      dn = P::vmax(dn);
+      if (dn < 1e-12 && theta_k < S->opt.constr_viol_tol) return S->status = Search_Direction_Becomes_Too_Small;
+      return S->status = (S->resto_stationary && S->resto_theta > S->opt.constr_viol_tol) ? Infeasible_Problem_Detected : Restoration_Failed;
+    }
+    if (!ftype) filter_add(S, (1.0 - g_th) * theta_k, phi_k - g_ph * theta_k);
+    accept_trial(S, alpha_used, a_z, f_t);
+    ++S->iter;
+    const bool guard_on = S->opt.stall_guard == 1 || (S->opt.stall_guard < 0 && S->in_solve && S->opt.adaptive_fallback && S->ladder_rung < 2);
+    const double kStallAlpha = 1e-2;
+    const int kStallSteps = 30;
+    if (guard_on && alpha_used <= kStallAlpha) {
+      if (S->tiny_streak == 0) { S->streak_theta0 = theta_k; S->streak_f0 = S->f; }
+      ++S->tiny_streak;
+      if (S->tiny_streak >= kStallSteps) {
+        const bool progress = th_t < 0.9 * S->streak_theta0 ||
+                              (th_t <= S->streak_theta0 && f_t < S->streak_f0 - 1e-2 * fmax(1.0, fabs(S->streak_f0)));
+        if (progress) S->tiny_streak = 0;
+      }
+    } else {
+      S->tiny_streak = 0;
+    }
+    if (S->tiny_streak >= kStallSteps) return S->status = Search_Direction_Becomes_Too_Small;
+    const WErr e = error(S, 0.0);
+    cache_err(S, e);
+    return 99;
+  }
+
+  // Ipm::trial_point
+  DNLP_HD static void trial_point(DNLP_WLDS WState* S, double alpha) {
+    WD *a = S->xt, *b = S->st;
+    const WD *xx = S->x, *ss = S->s, *ddx = S->dx, *dds = S->ds, *eq = S->eq, *sl = S->sL;
+    W_FOR(k, S->N) a[k] = xx[k] + alpha * ddx[k];
+    W_FOR(i, S->m) b[i] = eq[i] != 0.0 ? sl[i] : ss[i] + alpha * dds[i];
+    P::sync();
+  }
+  // Ipm::accept_trial (+ reset_bound_multipliers, WB eq. (16), after the derivatives as there)
+  DNLP_WFN DNLP_HD static void accept_trial(DNLP_WLDS WState* S, double alpha, double a_z, double f_new) {
+    const int N = S->N, m = S->m;
+    {
+      WD *xx = S->x, *ss = S->s, *yy = S->y, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU, *gg = S->g;
+      const WD *nx = S->xt, *ns = S->st, *ddy = S->dy, *da = S->dzL, *db = S->dzU, *dc = S->dvL, *dd2 = S->dvU, *gn = S->gt;
+      W_FOR(j, N) { xx[j] = nx[j]; a[j] += a_z * da[j]; b[j] += a_z * db[j]; }
+      W_FOR(i, m) { ss[i] = ns[i]; yy[i] += alpha * ddy[i]; c[i] += a_z * dc[i]; d[i] += a_z * dd2[i]; gg[i] = gn[i]; }
+      P::sync();
+    }
+    S->f = f_new;
+    sweep(S, S->x, false);
+    eval_derivs(S);
+    reset_bound_multipliers(S);
+  }
+  DNLP_HD static void reset_bound_multipliers(DNLP_WLDS WState* S) {
+    const double kS = 1e10, muv = S->mu;
+    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *xx = S->x, *ss = S->s, *eq = S->eq;
+    WD *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU;
+    W_FOR(j, S->N) {
+      if (l[j] > -kInf) { const double t = xx[j] - l[j]; a[j] = fmax(fmin(a[j], kS * muv / t), muv / (kS * t)); }
+      if (u[j] < kInf) { const double t = u[j] - xx[j]; b[j] = fmax(fmin(b[j], kS * muv / t), muv / (kS * t)); }
+    }
+    W_FOR(i, S->m) {
+      if (eq[i] != 0.0) continue;
+      if (sl[i] > -kInf) { const double t = ss[i] - sl[i]; c[i] = fmax(fmin(c[i], kS * muv / t), muv / (kS * t)); }
+      if (su[i] < kInf) { const double t = su[i] - ss[i]; d[i] = fmax(fmin(d[i], kS * muv / t), muv / (kS * t)); }
+    }
+    P::sync();
+  }
+  // Ipm::second_order_correction (WB section 2.4)
+  DNLP_WFN DNLP_HD static bool second_order_correction(DNLP_WLDS WState* S, double alpha, double dw, double theta_k, double phi_k, double gphid,
+                                              double& th_t, double& ph_t, double& f_t, bool& ftype) {
+    const double k_soc = 0.99, g_th = 1e-5, g_ph = 1e-8, dlt = 1.0, s_th = 1.1, s_ph = 2.3, eta = 1e-8;
+    const double macheps = 2.220446049250313e-16;
+    auto le = [&](double a, double b, double base) { return a - b <= 10.0 * macheps * std::fabs(base); };
+    const int m = S->m;
+    WD* cs = S->csoc;
+    const WD *p = S->rp, *eq = S->eq, *sl = S->sL;
+    {
+      const WD *gg = S->gt, *ss = S->st;
+      W_FOR(i, m) cs[i] = alpha * p[i] + (eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]);
+      P::sync();
+    }
+    double th_old = th_t;
+    for (int k = 0; k < S->opt.max_soc; ++k) {
+      if (!compute_direction(S, S->mu, S->csoc, dw, false, 0)) return false;
+      const double a_soc = max_step_primal(S, S->tau);
+      trial_point(S, a_soc);
+      double fv;
+      if (!eval_fg(S, S->xt, fv, S->gt) || nan_check(S, S->gt) != 0.0) return false;
+      const double th = theta_at(S, S->gt, S->st), ph = barrier_at(S, fv, S->xt, S->st, S->mu);
+      if (!std::isfinite(th) || !std::isfinite(ph)) return false;
+      if (th <= S->theta_max && filter_ok(S, th, ph)) {
+        const bool sw = gphid < 0.0 && alpha * std::pow(-gphid, s_ph) > dlt * std::pow(theta_k, s_th);
+        bool ok = false;
+        if (theta_k <= S->theta_min && sw) {
+          if (le(ph, phi_k + eta * alpha * gphid, phi_k)) { ok = true; ftype = true; }
+        } else if (le(th, (1.0 - g_th) * theta_k, theta_k) || le(ph, phi_k - g_ph * theta_k, phi_k)) {
+          ok = true;
+        }
+        if (ok) { th_t = th; ph_t = ph; f_t = fv; return true; }
+      }
+      if (th > k_soc * th_old) return false;
+      th_old = th;
+      const WD *gg2 = S->gt, *ss2 = S->st;
+      W_FOR(i, m) cs[i] = a_soc * cs[i] + (eq[i] != 0.0 ? gg2[i] - sl[i] : gg2[i] - ss2[i]);
+      P::sync();
+    }
+    return false;
+  }
+
+  // Ipm::avg_complementarity
+  DNLP_HD static double avg_complementarity(DNLP_WLDS WState* S) {
+    const i64 nb = n_bound_mults(S);
+    if (nb == 0) return 0.0;
+    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *xx = S->x, *ss = S->s, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU, *eq = S->eq;
+    double acc = 0.0;
+    W_FOR(j, S->N) {
+      double v = 0.0;
+      if (l[j] > -kInf) v += (xx[j] - l[j]) * a[j];
+      if (u[j] < kInf) v += (u[j] - xx[j]) * b[j];
+      acc += v;
+    }
+    W_FOR(i, S->m) {
+      double v = 0.0;
+      if (eq[i] == 0.0) {
+        if (sl[i] > -kInf) v += (ss[i] - sl[i]) * c[i];
+        if (su[i] < kInf) v += (su[i] - ss[i]) * d[i];
+      }
+      acc += v;
+    }
+    return P::sum(acc) / static_cast<double>(nb);
+  }
+  DNLP_HD static double mu_floor_now(DNLP_WLDS WState* S) {
+    const double t = std::min(S->opt.tol, S->opt.compl_inf_tol);
+    if (S->opt.mu_strategy == 0) return std::max(S->opt.mu_min, t / 11.0);
+    return std::min(S->opt.mu_min, 0.5 * t);
+  }
+  // Ipm::monotone_update
+  DNLP_WFN DNLP_HD static void monotone_update(DNLP_WLDS WState* S) {
+    const double k_eps = 10.0, k_mu = 0.2, th_mu = 1.5;
+    const double mu_floor = mu_floor_now(S);
+    for (int k = 0; k < 50; ++k) {
+      const WErr e = error(S, S->mu);
+      if (e.total <= k_eps * S->mu && S->mu > mu_floor) {
+        const double nm = std::max(mu_floor, std::min(k_mu * S->mu, std::pow(S->mu, th_mu)));
+        if (nm >= S->mu) break;
+        S->mu = nm;
+        S->tau = std::max(0.99, 1.0 - S->mu);
+        S->nfilt = 0;
+      } else {
+        break;
+      }
+    }
+  }
+  DNLP_HD static void hist_push(DNLP_WLDS WState* S, double v) {
+    if (S->n_hist == 4) { for (int k = 1; k < 4; ++k) S->kkt_hist[k - 1] = S->kkt_hist[k]; --S->n_hist; }
+    S->kkt_hist[S->n_hist++] = v;
+  }
+  // Ipm::update_mu
+  DNLP_HD static bool update_mu(DNLP_WLDS WState* S, const WErr& e0) {
+    if (n_bound_mults(S) == 0) { S->tau = 0.99; return false; }
+    if (S->opt.mu_strategy == 0) { monotone_update(S); return false; }
+    const double mu_floor = mu_floor_now(S);
+    const double kkt = e0.dual + e0.primal + e0.cmpl;
+    if (!S->fixed_mode) {
+      bool ok = S->n_hist == 0;
+      for (int k = 0; k < S->n_hist; ++k) if (kkt <= 0.9999 * S->kkt_hist[k]) ok = true;
+      if (ok) {
+        hist_push(S, kkt);
+      } else {
+        S->fixed_mode = true;
+        S->mu = std::max(mu_floor, std::min(0.8 * avg_complementarity(S), 1e5));
+        S->tau = std::max(0.99, 1.0 - S->mu);
+        S->nfilt = 0;
+      }
+    } else {
+      bool ok = false;
+      for (int k = 0; k < S->n_hist; ++k) if (kkt <= 0.9999 * S->kkt_hist[k]) ok = true;
+      if (ok || S->n_hist == 0) {
+        S->fixed_mode = false;
+        hist_push(S, kkt);
+      }
+    }
+    if (S->fixed_mode) { monotone_update(S); return false; }
+    return true;
+  }
+
+  // one evaluation of the quality function (the lambda qf of Ipm::quality_function_mu)
+  DNLP_WFN DNLP_HD static double quality(DNLP_WLDS WState* S, double sigma, double avg, double nd2, double np2, double n_dual, double n_pri, i64 nb) {
+    const double mus = sigma * avg;
+    const double tv = std::max(0.99, 1.0 - mus);
+    const WD *ax = S->dir[1][0], *as = S->dir[1][1], *aa = S->dir[1][3], *ab = S->dir[1][4], *ac = S->dir[1][5], *ad = S->dir[1][6];
+    const WD *cx = S->dir[2][0], *cs = S->dir[2][1], *ca = S->dir[2][3], *cb = S->dir[2][4], *cc = S->dir[2][5], *cd = S->dir[2][6];
+    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *eq = S->eq, *xx = S->x, *ss = S->s, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU;
+    const int N = S->N, m = S->m;
+    double a0 = -kInf, a1 = -kInf;
+    W_FOR(j, N) {
+      double tp = 1.0, td = 1.0;
+      const double dxx = ax[j] + mus * cx[j];
+      if (l[j] > -kInf && dxx < 0.0) tp = fmin(tp, -tv * (xx[j] - l[j]) / dxx);
+      if (u[j] < kInf && dxx > 0.0) tp = fmin(tp, tv * (u[j] - xx[j]) / dxx);
+      const double da = aa[j] + mus * ca[j], db = ab[j] + mus * cb[j];
+      if (da < 0.0) td = fmin(td, -tv * a[j] / da);
+      if (db < 0.0) td = fmin(td, -tv * b[j] / db);
+      a0 = mnin(a0, tp); a1 = mnin(a1, td);
+    }
+    W_FOR(i, m) {
+      double tp = 1.0, td = 1.0;
+      if (eq[i] == 0.0) {
+        const double dss = as[i] + mus * cs[i];
+        if (sl[i] > -kInf && dss < 0.0) tp = fmin(tp, -tv * (ss[i] - sl[i]) / dss);
+        if (su[i] < kInf && dss > 0.0) tp = fmin(tp, tv * (su[i] - ss[i]) / dss);
+      }
+      const double dc = ac[i] + mus * cc[i], dd2 = ad[i] + mus * cd[i];
+      if (dc < 0.0) td = fmin(td, -tv * c[i] / dc);
+      if (dd2 < 0.0) td = fmin(td, -tv * d[i] / dd2);
+      a0 = mnin(a0, tp); a1 = mnin(a1, td);
+    }
+    a0 = P::vmax(a0); a1 = P::vmax(a1);
+    const double apv = std::min(1.0, -a0), adv = std::min(1.0, -a1);
+    double comp = 0.0;
+    W_FOR(j, N) {
+      double v = 0.0;
+      const double dxx = ax[j] + mus * cx[j];
+      if (l[j] > -kInf) { const double t = (xx[j] - l[j] + apv * dxx) * (a[j] + adv * (aa[j] + mus * ca[j])); v += t * t; }
+      if (u[j] < kInf) { const double t = (u[j] - xx[j] - apv * dxx) * (b[j] + adv * (ab[j] + mus * cb[j])); v += t * t; }
+      comp += v;
+    }
+    W_FOR(i, m) {
+      double v = 0.0;
+      if (eq[i] == 0.0) {
+        const double dss = as[i] + mus * cs[i];
+        if (sl[i] > -kInf) { const double t = (ss[i] - sl[i] + apv * dss) * (c[i] + adv * (ac[i] + mus * cc[i])); v += t * t; }
+        if (su[i] < kInf) { const double t = (su[i] - ss[i] - apv * dss) * (d[i] + adv * (ad[i] + mus * cd[i])); v += t * t; }
+      }
+      comp += v;
+    }
+    comp = P::sum(comp);
+    return (1.0 - adv) * (1.0 - adv) * nd2 / n_dual + (1.0 - apv) * (1.0 - apv) * np2 / n_pri + comp / static_cast<double>(nb);
+  }
+  struct QfArgs { double avg, nd2, np2, n_dual, n_pri; i64 nb; };
+  // golden section in log(sigma) + IPOPT's end-point check (the lambda `section` of Ipm::quality_function_mu)
+  DNLP_WFN DNLP_HD static double section(DNLP_WLDS WState* S, const QfArgs& A, double slo, double sup, double& fsel, bool& endpoint) {
+    auto qf = [&](double sg) { return quality(S, sg, A.avg, A.nd2, A.np2, A.n_dual, A.n_pri, A.nb); };
+    const double gr = 0.5 * (3.0 - std::sqrt(5.0));
+    double la = std::log(slo), lb = std::log(std::max(sup, slo * (1 + 1e-12)));
+    double m1 = la + gr * (lb - la), m2 = lb - gr * (lb - la);
+    double f1 = qf(std::exp(m1)), f2 = qf(std::exp(m2));
+    for (int it = 0; it < 8 && (lb - la) > 1e-2 * std::fabs(lb) + 1e-12; ++it) {
+      if (f1 > f2) { la = m1; m1 = m2; f1 = f2; m2 = lb - gr * (lb - la); f2 = qf(std::exp(m2)); }
+      else { lb = m2; m2 = m1; f2 = f1; m1 = la + gr * (lb - la); f1 = qf(std::exp(m1)); }
+    }
+    double sg = std::exp(f1 < f2 ? m1 : m2);
+    fsel = std::min(f1, f2);
+    const double qlo = qf(slo), qup = qf(sup);
+    endpoint = false;
+    if (qlo < fsel && qlo <= qup) { sg = slo; fsel = qlo; endpoint = true; }
+    else if (qup < fsel) { sg = sup; fsel = qup; endpoint = true; }
+    return sg;
+  }
+  // Ipm::quality_function_mu
+  DNLP_WFN DNLP_HD static bool quality_function_mu(DNLP_WLDS WState* S, double dw) {
+    const int N = S->N, m = S->m;
+    const double avg = avg_complementarity(S);
+    const i64 nb = n_bound_mults(S);
+    if (!(avg > 0.0) || nb == 0) return false;
+    const double mu_floor = mu_floor_now(S);
+    barrier_terms(S, 0.0);
+    double nd2, np2;
+    {
+      const WD *rxx = S->rx, *rss = S->rs, *rpp = S->rp;
+      double s0 = 0.0, s1 = 0.0;
+      W_FOR(k, N) s0 += rxx[k] * rxx[k];
+      W_FOR(i, m) { s0 += rss[i] * rss[i]; s1 += rpp[i] * rpp[i]; }
+      nd2 = P::sum(s0);
+      np2 = m ? P::sum(s1) : 0.0;
+    }
+    if (!compute_direction(S, 0.0, S->rp, dw, false, 1)) return false;
+    const double ratio_aff = S->last_ratio;
+    {
+      WD *r = S->rx, *q = S->rs;
+      const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *eq = S->eq, *xx = S->x, *ss = S->s, *fm = S->fixm;
+      const double kd = S->opt.kappa_d;
+      W_FOR(j, N) {
+        double c = 0.0;
+        const bool hl = l[j] > -kInf, hu = u[j] < kInf;
+        if (hl) c -= 1.0 / (xx[j] - l[j]);
+        if (hu) c += 1.0 / (u[j] - xx[j]);
+        if (hl && !hu) c += kd;
+        if (hu && !hl) c -= kd;
+        r[j] = fm[j] != 0.0 ? 0.0 : c;
+      }
+      W_FOR(i, m) {
+        double c = 0.0;
+        if (eq[i] == 0.0) {
+          const bool hl = sl[i] > -kInf, hu = su[i] < kInf;
+          if (hl) c -= 1.0 / (ss[i] - sl[i]);
+          if (hu) c += 1.0 / (su[i] - ss[i]);
+          if (hl && !hu) c += kd;
+          if (hu && !hl) c -= kd;
+        }
+        q[i] = c;
+      }
+      P::sync();
+    }
+    if (!compute_direction(S, 1.0, nullptr, dw, true, 2)) return false;
+    if (ratio_aff > S->last_ratio) S->last_ratio = ratio_aff;
+    const i64 n_ineq = m - S->n_eq;
+    QfArgs A;
+    A.avg = avg; A.nd2 = nd2; A.np2 = np2; A.nb = nb;
+    A.n_dual = static_cast<double>(N + n_ineq); A.n_pri = static_cast<double>(m > 0 ? m : 1);
+    auto qf = [&](double sg) { return quality(S, sg, A.avg, A.nd2, A.np2, A.n_dual, A.n_pri, A.nb); };
+    const double mu_max = S->opt.mu_max_fact * avg;
+    const double s_lo = std::max(1e-6, mu_floor / avg), s_up = std::min(1e2, mu_max / avg);
+    double sigma;
+    if (s_lo >= s_up) {
+      sigma = s_lo;
+    } else {
+      const double q1 = qf(1.0), s1m = 1.0 - 1e-2, q1m = qf(std::max(s_lo, s1m));
+      double lo, up;
+      if (q1m > q1 && s_up > 1.0) { lo = 1.0; up = s_up; } else { lo = s_lo; up = std::min(std::max(s_lo, s1m), s_up); }
+      double fsel = 0.0;
+      bool endpoint = false;
+      sigma = section(S, A, lo, up, fsel, endpoint);
+      if (endpoint && up > lo * 10.0) {
+        const double grid[6] = {lo, 1e-4, 1e-2, 1e-1, 0.5, up};
+        double gs[6], gq[6];
+        int ng = 0;
+        for (int k = 0; k < 6; ++k) {
+          if (grid[k] < lo || grid[k] > up || (ng > 0 && grid[k] <= gs[ng - 1])) continue;
+          gs[ng] = grid[k]; gq[ng] = qf(grid[k]); ++ng;
+        }
+        int best = 0;
+        for (int k = 1; k < ng; ++k) if (gq[k] < gq[best]) best = k;
+        if (gq[best] < fsel && best > 0 && best + 1 < ng) {
+          const double f0 = fsel, s0 = sigma;
+          sigma = section(S, A, gs[best - 1], gs[best + 1], fsel, endpoint);
+          if (!(fsel < f0)) sigma = s0;
+        }
+      }
+    }
+    const double nm = std::max(mu_floor, std::min(sigma * avg, mu_max));
+    if (!std::isfinite(nm)) return false;
+    S->mu = nm;
+    S->tau = std::max(0.99, 1.0 - S->mu);
+    S->nfilt = 0;
+    barrier_terms(S, S->mu);
+    const double muv = S->mu;
+    {
+      for (int k = 0; k < 7; ++k) {
+        WD* o = S->dir[0][k];
+        const WD *av = S->dir[1][k], *cv = S->dir[2][k];
+        const int n = (k == 0 || k == 3 || k == 4) ? N : m;
+        W_FOR(i, n) o[i] = av[i] + muv * cv[i];
+      }
+      P::sync();
+    }
+    return true;
+  }
+
+  // Ipm::restoration_phase
+  DNLP_WFN DNLP_HD static bool restoration_phase(DNLP_WLDS WState* S, double theta_k) {
+    const int N = S->N, m = S->m;
+    const double phi_k = barrier_at(S, S->f, S->x, S->s, S->mu);
+    filter_add(S, (1.0 - 1e-5) * theta_k, phi_k - 1e-8 * theta_k);
+    double th_cur = theta_k;
+    double zeta = std::sqrt(S->mu);
+    S->resto_stationary = false;
+    S->resto_theta = theta_k;
+    const WD *eq = S->eq, *sl = S->sL;
+    for (int it = 0; it < 100; ++it) {
+      WD *sx = S->Sx, *dd = S->Dd;
+      const double zz = zeta;
+      W_FOR(j, N) sx[j] = zz;
+      W_FOR(i, m) dd[i] = 1.0 + (eq[i] == 0.0 ? 1.0 / zz : 0.0);
+      { WD* hs = S->Hs; W_FOR(p, S->nnzH) hs[p] = 0.0; }
+      P::sync();
+      int nneg = 0, nzero = 0;
+      if (!assemble_factor(S, S->Sx, S->Dd, 0.0, true, &nneg, &nzero)) return false;
+      WD* r = S->rhs;
+      const WD *gg = S->g, *ss = S->s;
+      W_FOR(j, N) r[j] = 0.0;
+      W_FOR(i, m) r[N + i] = -(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]);
+      P::sync();
+      kkt_solve(S, S->rhs, S->sol);
+      const WD* so = S->sol;
+      WD *ddx = S->dx, *dds = S->ds;
+      W_FOR(j, N) ddx[j] = so[j];
+      W_FOR(i, m) dds[i] = eq[i] == 0.0 ? so[N + i] / zz : 0.0;
+      P::sync();
+      double a = max_step_primal(S, S->tau);
+      bool moved = false;
+      for (int bt = 0; bt < 30; ++bt) {
+        trial_point(S, a);
+        double fv;
+        if (eval_fg(S, S->xt, fv, S->gt) && nan_check(S, S->gt) == 0.0) {
+          const double th = theta_at(S, S->gt, S->st);
+          if (std::isfinite(th) && th < (1.0 - 1e-4 * a) * th_cur) {
+            WD *xx = S->x, *sv = S->s, *gv = S->g;
+            const WD *nx = S->xt, *ns = S->st, *gn = S->gt;
+            W_FOR(j, N) xx[j] = nx[j];
+            W_FOR(i, m) { sv[i] = ns[i]; gv[i] = gn[i]; }
+            P::sync();
+            S->f = fv;
+            th_cur = th;
+            moved = true;
+            break;
+          }
+        }
+        a *= 0.5;
+      }
+      if (!moved) { zeta *= 10.0; if (zeta > 1e8) { S->resto_stationary = true; S->resto_theta = th_cur; return false; } continue; }
+      S->resto_theta = th_cur;
+      sweep(S, S->x, false);
+      eval_derivs(S);
+      const double ph = barrier_at(S, S->f, S->x, S->s, S->mu);
+      if (th_cur <= 0.9 * theta_k && th_cur <= S->theta_max && filter_ok(S, th_cur, ph)) {
+        S->jty_valid = false;
+        const double zi = 1.0;
+        const WD *l = S->xL, *u = S->xU, *su = S->sU;
+        WD *za = S->zL, *zb = S->zU, *c = S->vL, *d = S->vU, *yy = S->y;
+        W_FOR(j, N) { za[j] = (l[j] > -kInf) ? zi : 0.0; zb[j] = (u[j] < kInf) ? zi : 0.0; }
+        W_FOR(i, m) {
+          yy[i] = 0.0;
+          c[i] = (eq[i] == 0.0 && sl[i] > -kInf) ? zi : 0.0;
+          d[i] = (eq[i] == 0.0 && su[i] < kInf) ? zi : 0.0;
+        }
+        P::sync();
+        if (m > 0) init_multipliers_ls(S);
+        return true;
+      }
+      if (th_cur < 1e-13) return false;
+    }
+    return false;
+  }
+
+  // Ipm::polish
+  DNLP_WFN DNLP_HD static void polish(DNLP_WLDS WState* S) {
+    const int N = S->N, m = S->m;
+    WD* sv[7] = {S->x, S->s, S->y, S->zL, S->zU, S->vL, S->vU};
+    const int sz[7] = {N, m, m, N, N, m, m};
+    const int slot[7] = {0, 1, 2, 3, 4, 5, 6};
+    for (int k = 0; k < 7; ++k) { WD* dst = S->dir[1][slot[k]]; const WD* src = sv[k]; W_FOR(i, sz[k]) dst[i] = src[i]; }
+    P::sync();
+    const double tol0 = S->opt.tol, mu0 = S->mu, tau0 = S->tau;
+    const int maxit0 = S->opt.max_iter;
+    S->opt.tol = tol0 * 1e-3;
+    S->opt.max_iter = S->iter + 12;
+    while (step(S) == 99) {}
+    S->opt.tol = tol0;
+    S->opt.max_iter = maxit0;
+    if (S->status == Solve_Succeeded) return;
+    if (S->bail) return;
+    {
+      const WErr e = error(S, 0.0);
+      if (check_convergence(S, e) == Solve_Succeeded) { S->status = Solve_Succeeded; return; }
+    }
+    for (int k = 0; k < 7; ++k) { const WD* src = S->dir[1][slot[k]]; WD* dst = sv[k]; W_FOR(i, sz[k]) dst[i] = src[i]; }
+    P::sync();
+    S->mu = mu0; S->tau = tau0;
+    (void)eval_fg(S, S->x, S->f, S->g);
+    eval_derivs(S);
+    S->e_cached_valid = false;
+    S->acceptable_count = 0;
+    (void)check_convergence(S, error(S, 0.0));
+    S->status = Solve_Succeeded;
+  }
+
+  // Ipm::solve (the retry ladder included)
+  DNLP_WFN DNLP_HD static int solve(DNLP_WLDS WState* S) {
+    const double t_all = now_sec();
+    S->in_solve = true;
+    S->bail = false;
+    S->ladder_rung = 0;
+    S->sparse_singular_streak = 0;
+    S->delta_w_used_last_iter = false;
+    S->last_ratio = 0.0;
+    S->initialized = false;
+    S->iter = 0;
+    S->f = 0.0;
+    int rc = begin(S);
+    if (rc != 0) { S->in_solve = false; return rc; }
+    while (step(S) == 99) {}
+    if (S->opt.adaptive_fallback && !S->bail) {
+      const int strategy0 = S->opt.mu_strategy;
+      const double mu_init0 = S->opt.mu_init;
+      const int max_iter0 = S->opt.max_iter;
+      const double max_wall0 = S->opt.max_wall_time;
+      for (int rung = 1; rung <= 2; ++rung) {
+        const int status = S->status;
+        const bool failed = status == Infeasible_Problem_Detected || status == Restoration_Failed || status == Error_In_Step_Computation ||
+                            status == Search_Direction_Becomes_Too_Small || status == Diverging_Iterates;
+        if (!failed || S->bail) break;
+        if (rung == 1 && strategy0 != 1) continue;
+        const int it_first = S->iter;
+        if (it_first >= max_iter0) { S->status = Maximum_Iterations_Exceeded; break; }
+        if (now_sec() - t_all > max_wall0) { S->status = Maximum_WallTime_Exceeded; break; }
+        S->opt.max_iter = max_iter0 - it_first;
+        S->opt.max_wall_time = max_wall0 - (now_sec() - t_all);
+        S->ladder_rung = rung;
+        S->opt.mu_strategy = 0;
+        if (rung == 2) S->opt.mu_init = mu_init0 * 10.0 > 1.0 ? mu_init0 * 10.0 : 1.0;
+        rc = begin(S);
+        if (rc == 0) while (step(S) == 99) {}
+        if (S->status == Solve_Succeeded && !S->bail) polish(S);
+        S->iter += it_first;
+      }
+      S->opt.mu_strategy = strategy0;
+      S->opt.mu_init = mu_init0;
+      S->opt.max_iter = max_iter0;
+      S->opt.max_wall_time = max_wall0;
+      S->ladder_rung = 0;
+    }
+    S->in_solve = false;
+    S->wall = now_sec() - t_all;
+    if (S->bail) S->status = kWaveNeedsGeneric;
+    return S->status;
+  }
+#undef W_FOR
+};
+
+}  // namespace dnlp

@@ -69,3 +69,106 @@ extern "C" void orc_blocked_ldlt_phases(double* out4) {
   dnlp::HostLapack& L = dnlp::HostLapack::get();
   for (int k = 0; k < 4; ++k) out4[k] = L.last_phases[k];
 }
+
+// ---- wavefront batch solver (dnlp_amd/csrc/wave_ipm.h) on ONE host lane ------------------------------------------------
+// The CPU pin of the template-specialised batch kernel: the restated interior-point loop runs over the same plan block
+// and the same instance rows as on the device, with a one-lane policy whose serial sums are the host build's — next to
+// (which = 1) the generic algorithm text (ipm_core.h over HostExec) set up the way the generic batch kernel sets it up
+// (batch.h: one shared tape view patched with the instance's data, the template's static-pattern plan).
+#define DNLP_WAVE_FILTER_CAP 1024      // (HostControlled::kFilterCap: the host build it is compared with)
+#include "../dnlp_amd/csrc/wave_ipm.h"
+
+namespace {
+struct HostLane {
+  static constexpr int lanes = 1;
+  static int lane() { return 0; }
+  static void sync() {}
+  static double sum(double v) { return v; }
+  static double vmax(double v) { return v; }
+};
+}  // namespace
+
+// data: batch x stride rows in BATCH_DATA_KEYS order (dnlp_amd/batch.py).  Outputs batch-major; mult_* may be null.
+extern "C" int orc_wave_solve_batch(orc_problem* vp, int batch, const double* data, int64_t stride, int which, double* x, double* obj,
+                                    int* status, int* iters, int* nfact, double* mult_g, double* mult_x_L, double* mult_x_U) {
+  using namespace dnlp;
+  orc_problem_t* p = vp;
+  DNLP_TRY(
+    p->plan_linear_solver();
+    const Tape<HostExec>& t = *p->model.owner;
+    if (!p->use_sparse) { tls_error() = "no sparse plan for this tape"; return -1; }
+    const char* why = wave_plan_refusal(t, &p->sparse_plan);
+    if (which == 0 && why[0]) { tls_error() = why; return -2; }
+    const WaveLayoutIn lay = wave_layout_of(t);
+    const i64 head = 1 + (t.N + t.Z) + t.m + t.nnzJ + t.G.nnz + t.Mg.nnz + t.Mw.nnz + t.MJ.nnz + t.MH.nnz;
+    const i64 tail = 3 * t.N + 2 * t.m;
+    if (stride != head + 2 * t.nseg + tail) { tls_error() = "instance stride does not match the tape"; return -3; }
+    std::vector<double> row(static_cast<size_t>(lay.total));
+    std::vector<i32> blk;
+    std::vector<double> state;
+    if (which == 0) {
+      blk = build_wave_plan(&p->ex, t, p->sparse_plan, lay);
+      state.assign(static_cast<size_t>(reinterpret_cast<const WaveHdr*>(blk.data())->state_doubles) + 8, 0.0);
+      if (std::getenv("DNLP_WAVE_DEBUG")) {
+        const WaveHdr* hh = reinterpret_cast<const WaveHdr*>(blk.data());
+        std::fprintf(stderr, "[wave] plan block %d ints (%.1f KB), state %d doubles (%.1f KB), WState %zu B; units %d, nvals %d, blocks %d, levels %d, triples %d\n",
+                     hh->total, hh->total * 4 / 1024.0, hh->state_doubles, hh->state_doubles * 8 / 1024.0, sizeof(WState), hh->nunits, hh->sp_nvals, hh->sp_nblk, hh->sp_nlev, hh->sp_ntrip);
+      }
+    }
+    const bool fb = (t.N + t.m) <= 512 && p->linear_solver != 2;
+    for (int k = 0; k < batch; ++k) {
+      const double* src = data + static_cast<i64>(k) * stride;
+      std::copy(src, src + head, row.begin());
+      const double *sp = src + head, *sp2 = sp + t.nseg;
+      for (i64 f = 0; f < t.nflat; ++f) {
+        row[static_cast<size_t>(lay.fp + f)] = sp[t.h_flat_seg[static_cast<size_t>(f)]];
+        row[static_cast<size_t>(lay.fp2 + f)] = sp2[t.h_flat_seg[static_cast<size_t>(f)]];
+      }
+      std::copy(sp2 + t.nseg, sp2 + t.nseg + tail, row.begin() + lay.x0);
+      if (which == 0) {
+        WState S;
+        std::fill(state.begin(), state.end(), 0.0);
+        WaveIpm<HostLane>::layout(&S, blk.data(), state.data());
+        S.row = row.data();
+        S.ws_g = S.ws_l = S.ws_u = nullptr;
+        S.fallback_max_n = fb ? 512 : 0;
+        S.opt = p->opt;
+        const int st = WaveIpm<HostLane>::solve(&S);
+        status[k] = st; iters[k] = S.iter; if (nfact) nfact[k] = S.factorizations;
+        obj[k] = S.initialized ? S.f / S.sf : 0.0;
+        for (i64 j = 0; j < t.N; ++j) {
+          x[static_cast<i64>(k) * t.N + j] = S.x[j];
+          if (mult_x_L) mult_x_L[static_cast<i64>(k) * t.N + j] = S.zL[j] / S.sf;
+          if (mult_x_U) mult_x_U[static_cast<i64>(k) * t.N + j] = S.zU[j] / S.sf;
+        }
+        if (mult_g) for (i64 i = 0; i < t.m; ++i) mult_g[static_cast<i64>(k) * t.m + i] = S.y[i] * S.sg[i] / S.sf;
+      } else {
+        HostExec ex;
+        TapeView v = t;
+        v.c0 = row[static_cast<size_t>(lay.c0)];
+        v.c = row.data() + lay.c; v.b = row.data() + lay.b; v.Jc = row.data() + lay.Jc;
+        v.G.val = row.data() + lay.G; v.Mg.val = row.data() + lay.Mg; v.Mw.val = row.data() + lay.Mw; v.MJ.val = row.data() + lay.MJ;
+        v.MH.val = row.data() + lay.MH;
+        // (the host evaluator reads per-SEGMENT parameters through flat_p / flat_p2 indexed by flat row, as the kernel does)
+        v.flat_p = row.data() + lay.fp; v.flat_p2 = row.data() + lay.fp2;
+        v.d_x0 = row.data() + lay.x0; v.d_lb = row.data() + lay.lb; v.d_ub = row.data() + lay.ub; v.d_cl = row.data() + lay.cl; v.d_cu = row.data() + lay.cu;
+        Model<HostExec> md;
+        md.init_view(&ex, v);
+        DenseKkt<HostExec> kkt;
+        SparsePlan pl = p->sparse_plan.upload(&ex);
+        kkt.init_sparse(&ex, v.N, v.m, pl);
+        kkt.pivot_max_n = static_cast<i64>(1) << 40;
+        kkt.fallback_max_n = fb ? 512 : 0;
+        Ipm<HostExec, DenseKkt<HostExec>> ipm(&ex, &md, &kkt);
+        ipm.opt = p->opt;
+        ipm.allocate();
+        const int st = ipm.solve(v.d_x0);
+        status[k] = st; iters[k] = ipm.iter; if (nfact) nfact[k] = ipm.stats.factorizations;
+        obj[k] = ipm.initialized ? ipm.objective_unscaled() : 0.0;
+        if (ipm.initialized)
+          ipm.extract(x + static_cast<i64>(k) * t.N, nullptr, mult_g ? mult_g + static_cast<i64>(k) * t.m : nullptr,
+                      mult_x_L ? mult_x_L + static_cast<i64>(k) * t.N : nullptr, mult_x_U ? mult_x_U + static_cast<i64>(k) * t.N : nullptr, nullptr);
+      }
+    }
+    return 0;)
+}
