@@ -83,6 +83,8 @@ class CApi:
             f("batch_set_affine_map", C.c_int, [C.c_void_p, C.c_int, _dbl_p, _dbl_p, C.POINTER(C.c_int64), _i32_p, _dbl_p])
             f("solve_batch_theta", C.c_int, [C.c_void_p, C.c_int, _dbl_p, C.c_int] + [_dbl_p] * 5 +
               [_int_p] * 3 + [_dbl_p, _dbl_p])
+            if hasattr(self.lib, prefix + "batch_launch_info"):
+                f("batch_launch_info", C.c_int, [C.c_void_p, _i32_p])
 
     def _fn(self, name, restype, argtypes):
         fn = getattr(self.lib, self.prefix + name)
@@ -585,6 +587,12 @@ class ProblemHandle:
             raise RuntimeError("solve_batch failed (code %d): %s" % (rc, self.api.error()))
         out = {"x": x, "obj_val": obj, "status": status, "iterations": iters, "factorizations": nfact,
                "kernel_seconds": float(sec.value), "phase_seconds": times}
+        if hasattr(self.api, "batch_launch_info"):
+            info = np.zeros(8, dtype=np.int32)
+            if self.api.batch_launch_info(self.ptr, info.ctypes.data_as(_i32_p)) == 0:
+                out["launch"] = {"grid": int(info[0]), "lanes": int(info[1]), "lds_mode": int(info[2]), "per_cu": int(info[3]),
+                                 "packed": bool(info[4]), "longest_first": bool(info[5]), "wave_form": int(info[6]),
+                                 "wave_refused": int(info[7])}
         if want_duals:
             out.update({"mult_g": mg[:, :self.m], "mult_x_L": zl, "mult_x_U": zu})
         return out

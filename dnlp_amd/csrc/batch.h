@@ -19,6 +19,7 @@
 #include "exec_hip.h"
 #include "ipm_core.h"
 #include "kkt_dense.h"
+#include "wave_batch.h"
 
 namespace dnlp {
 
@@ -364,7 +365,33 @@ struct BatchRunner {
   }
   SparsePlan dev_plan;
   i64 plan_rows = 0;
-  void set_sparse_plan(const SparsePlanHost& hp) { dev_plan = hp.upload(ex); have_sparse = true; plan_rows = static_cast<i64>(hp.sidx.size()); }
+  void set_sparse_plan(const SparsePlanHost& hp) { dev_plan = hp.upload(ex); have_sparse = true; plan_rows = static_cast<i64>(hp.sidx.size()); host_plan = &hp; }
+  // ---- the wavefront solver of small sparse templates (wave_plan.h / wave_ipm.h / wave_batch.h) ----
+  const SparsePlanHost* host_plan = nullptr;      // (owned by the problem handle, as the tape is)
+  std::vector<i32> wave_blk;                      // the template's plan block; empty: the template takes the generic kernel
+  i32* d_wave_blk = nullptr;
+  bool wave_checked = false;
+  bool wave_fits16 = false;                       // every table entry of the block fits 16 bits: it can be staged in LDS
+  std::string wave_why;                           // why not, when not
+  int last_wave = 0;                              // the last solve: 0 generic kernel, else 100 * wavefronts per workgroup + 10 * state in LDS + plan in LDS
+  int last_wave_refused = 0;                      // instances of the last solve that the wavefront solver handed to the generic kernel
+  bool wave_prepare() {
+    if (!wave_checked) {
+      wave_checked = true;
+      wave_why = wave_plan_refusal(*tape, have_sparse ? host_plan : nullptr);
+      if (wave_why.empty()) {
+        WaveLayoutIn l;
+        l.c0 = lay.c0; l.c = lay.c; l.b = lay.b; l.Jc = lay.Jc; l.G = lay.G; l.Mg = lay.Mg; l.Mw = lay.Mw; l.MJ = lay.MJ; l.MH = lay.MH;
+        l.fp = lay.fp; l.fp2 = lay.fp2; l.x0 = lay.x0; l.lb = lay.lb; l.ub = lay.ub; l.cl = lay.cl; l.cu = lay.cu; l.total = lay.total;
+        wave_blk = build_wave_plan(ex, *tape, *host_plan, l);
+        wave_fits16 = true;
+        for (size_t k = sizeof(WaveHdr) / 4; k < wave_blk.size() && wave_fits16; ++k) wave_fits16 = wave_blk[k] >= -32768 && wave_blk[k] <= 32767;
+        DNLP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_wave_blk), wave_blk.size() * sizeof(i32)));
+        DNLP_HIP_CHECK(hipMemcpy(d_wave_blk, wave_blk.data(), wave_blk.size() * sizeof(i32), hipMemcpyHostToDevice));
+      }
+    }
+    return !wave_blk.empty();
+  }
   // device buffers kept across calls (grow-only): a call is then one H2D copy, one launch and the
   // result copies — no allocation on the steady-state path
   struct Buf { void* p = nullptr; size_t cap = 0; };
@@ -441,6 +468,7 @@ struct BatchRunner {
     if (d_segs) hipFree(d_segs);
     if (d_red) hipFree(d_red);
     if (d_sparse) hipFree(d_sparse);
+    if (d_wave_blk) hipFree(d_wave_blk);
   }
   void release() { nbuf_used = 0; }
   template <class T> T* dalloc(size_t n) {
@@ -534,7 +562,7 @@ struct BatchRunner {
 
   void solve_impl(int batch, const double* data, const double* theta, const IpmOptions& opt, double* x_out, double* obj_out,
                   double* multg_out, double* zl_out, double* zu_out, int* status_out, int* iters_out, int* nfact_out,
-                  double* seconds, double* times_out) {
+                  double* seconds, double* times_out, bool allow_wave = true) {
     const i64 stride = in_stride;
     const bool dbg = std::getenv("DNLP_BATCH_DEBUG") != nullptr;
     const double tdbg0 = now_sec();
@@ -583,6 +611,12 @@ struct BatchRunner {
       mark("slab built");
       DNLP_HIP_CHECK(hipMemcpy(a.slabs, slab.data(), slab.size() * sizeof(double), hipMemcpyHostToDevice));
       mark("slab uploaded");
+    }
+    last_wave = 0;
+    last_wave_refused = 0;
+    if (allow_wave && !(std::getenv("DNLP_BATCH_WAVE") && std::atoi(std::getenv("DNLP_BATCH_WAVE")) == 0) && wave_prepare()) {
+      solve_wave(a, batch, data, theta, opt, x_out, obj_out, multg_out, zl_out, zu_out, status_out, iters_out, nfact_out, seconds, times_out);
+      return;
     }
     const i64 n = t.N + t.m, ld = (n + 7) / 8 * 8;
     // KKT matrix in LDS when it fits beside the static reduction scratch (160 KB per workgroup)
@@ -866,6 +900,221 @@ struct BatchRunner {
     if (iters_out) { prev_iters.assign(iters_out, iters_out + batch); prev_key = key; }
     release();
     mark("results copied");
+  }
+  // The same launch through the wavefront solver (the caller has generated a.slabs).  Instances it refuses
+  // (kWaveNeedsGeneric: a structurally singular static pivot sequence, the generic kernel's Bunch-Kaufman switch) are
+  // solved by the generic kernel in a second, small launch and their results merged.
+  template <int NW, bool SL, bool PL>
+  void launch_wave(const WaveArgs& w, int grid, unsigned lds, hipStream_t stream) {
+    const void* k = reinterpret_cast<const void*>(wave_batch_kernel<NW, SL, PL>);
+    DNLP_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((wave_batch_kernel<NW, SL, PL>), dim3(static_cast<unsigned>(grid)), dim3(64 * NW), lds, stream, w);
+  }
+  template <int NW, bool SL, bool PL>
+  int wave_occupancy(unsigned lds) {
+    const void* k = reinterpret_cast<const void*>(wave_batch_kernel<NW, SL, PL>);
+    DNLP_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    int v = 1;
+    DNLP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, wave_batch_kernel<NW, SL, PL>, 64 * NW, lds));
+    return v < 1 ? 1 : v;
+  }
+  template <int NW, bool SL, bool PL>
+  size_t wave_static_lds() {
+    hipFuncAttributes fa;
+    DNLP_HIP_CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(wave_batch_kernel<NW, SL, PL>)));
+    return fa.sharedSizeBytes;
+  }
+  void solve_wave(const BatchArgs& a, int batch, const double* data, const double* theta, const IpmOptions& opt, double* x_out, double* obj_out,
+                  double* multg_out, double* zl_out, double* zu_out, int* status_out, int* iters_out, int* nfact_out,
+                  double* seconds, double* times_out) {
+    const Tape<HipExec>& t = *tape;
+    const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(wave_blk.data());
+    if (this->ncu == 0) {
+      int v = 0;
+      DNLP_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ex->device));
+      this->ncu = v;
+    }
+    const size_t plan_b = wave_fits16 ? ((static_cast<size_t>(h.total) * 2 + 15) & ~static_cast<size_t>(15)) : (static_cast<size_t>(1) << 30);
+    const size_t state_b = static_cast<size_t>(h.state_doubles) * 8;
+    const size_t cap = 160 * 1024 - 256;
+    // form: (wavefronts per workgroup, state in LDS, plan in LDS)
+    int nw = 0, sl = 0, pl = 0;
+    if (plan_b + 4 * state_b + wave_static_lds<4, true, true>() <= cap) { nw = 4; sl = 1; pl = 1; }
+    else if (plan_b + 2 * state_b + wave_static_lds<2, true, true>() <= cap) { nw = 2; sl = 1; pl = 1; }
+    else if (plan_b + state_b + wave_static_lds<1, true, true>() <= cap) { nw = 1; sl = 1; pl = 1; }
+    else if (2 * state_b + wave_static_lds<2, true, false>() <= cap) { nw = 2; sl = 1; pl = 0; }
+    else if (state_b + wave_static_lds<1, true, false>() <= cap) { nw = 1; sl = 1; pl = 0; }
+    else { nw = 4; sl = 0; pl = 0; }
+    if (const char* e = std::getenv("DNLP_WAVE_FORM")) {        // experiments: "411", "211", "111", "210", "110", "400"
+      const int f = std::atoi(e);
+      nw = f / 100; sl = (f / 10) % 10; pl = f % 10;
+      if (pl && !wave_fits16) throw std::runtime_error("wavefront solver: this plan does not fit 16-bit tables");
+    }
+    WaveArgs w;
+    w.blk = d_wave_blk; w.blk_ints = h.total;
+    w.rows = a.slabs; w.row_doubles = lay.total;
+    w.batch = batch;
+    w.state_doubles = h.state_doubles;
+    w.opt = opt;
+    const i64 n = t.N + t.m;
+    w.fallback_max_n = (n <= 512 && !force_sparse) ? 512 : 0;
+    int per_cu = 1;
+    const unsigned lds = static_cast<unsigned>((pl ? plan_b : 0) + (sl ? static_cast<size_t>(nw) * state_b : 0));
+    const int form = 100 * nw + 10 * sl + pl;
+    switch (form) {
+      case 411: per_cu = wave_occupancy<4, true, true>(lds); break;
+      case 211: per_cu = wave_occupancy<2, true, true>(lds); break;
+      case 111: per_cu = wave_occupancy<1, true, true>(lds); break;
+      case 210: per_cu = wave_occupancy<2, true, false>(lds); break;
+      case 110: per_cu = wave_occupancy<1, true, false>(lds); break;
+      case 400: per_cu = wave_occupancy<4, false, false>(lds); break;
+      default: throw std::runtime_error("wavefront solver: no such launch form");
+    }
+    if (const char* e = std::getenv("DNLP_WAVE_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 16) per_cu = v; }
+    int grid = std::min((batch + nw - 1) / nw, ncu * per_cu);
+    if (grid < 1) grid = 1;
+    if (!sl) w.state = dalloc<double>(static_cast<size_t>(grid) * static_cast<size_t>(nw) * static_cast<size_t>(h.state_doubles));
+    w.x_out = dalloc<double>(static_cast<size_t>(batch) * t.N);
+    w.obj_out = dalloc<double>(static_cast<size_t>(batch));
+    w.multg_out = multg_out ? dalloc<double>(static_cast<size_t>(batch) * t.m) : nullptr;
+    w.zl_out = zl_out ? dalloc<double>(static_cast<size_t>(batch) * t.N) : nullptr;
+    w.zu_out = zu_out ? dalloc<double>(static_cast<size_t>(batch) * t.N) : nullptr;
+    w.status_out = dalloc<int>(static_cast<size_t>(batch));
+    w.iters_out = dalloc<int>(static_cast<size_t>(batch));
+    w.nfact_out = dalloc<int>(static_cast<size_t>(batch));
+    w.times_out = times_out ? dalloc<double>(4 * static_cast<size_t>(batch)) : nullptr;
+    const bool warm = ws_batch == batch && opt.warm_start;
+    std::vector<double> keep_g, keep_l, keep_u;
+    if (warm) {
+      double* g = dalloc<double>(h_ws_g.size());
+      double* l = dalloc<double>(h_ws_l.size());
+      double* u = dalloc<double>(h_ws_u.size());
+      if (!h_ws_g.empty()) DNLP_HIP_CHECK(hipMemcpy(g, h_ws_g.data(), h_ws_g.size() * 8, hipMemcpyHostToDevice));
+      DNLP_HIP_CHECK(hipMemcpy(l, h_ws_l.data(), h_ws_l.size() * 8, hipMemcpyHostToDevice));
+      DNLP_HIP_CHECK(hipMemcpy(u, h_ws_u.data(), h_ws_u.size() * 8, hipMemcpyHostToDevice));
+      w.ws_g = g; w.ws_l = l; w.ws_u = u;
+      keep_g = h_ws_g; keep_l = h_ws_l; keep_u = h_ws_u;
+    }
+    ws_batch = 0;
+    w.next = dalloc<int>(1);
+    DNLP_HIP_CHECK(hipMemsetAsync(w.next, 0, sizeof(int), ex->stream));
+#ifdef DNLP_WAVE_PROF
+    w.prof = dalloc<unsigned long long>(kWaveProfSlots + 1);
+    DNLP_HIP_CHECK(hipMemsetAsync(w.prof, 0, sizeof(unsigned long long) * (kWaveProfSlots + 1), ex->stream));
+#endif
+    const uint64_t key = theta ? rows_hash(theta, static_cast<size_t>(batch) * static_cast<size_t>(aff_P))
+                               : rows_hash(data, static_cast<size_t>(batch) * static_cast<size_t>(in_stride));
+    last_order_lpt = false;
+    if (static_cast<int>(prev_iters.size()) == batch && key == prev_key && batch > grid * nw && !std::getenv("DNLP_BATCH_FIFO")) {
+      last_order_lpt = true;
+      std::vector<int> ord(static_cast<size_t>(batch));
+      for (int k = 0; k < batch; ++k) ord[static_cast<size_t>(k)] = k;
+      std::stable_sort(ord.begin(), ord.end(), [&](int p, int q) { return prev_iters[static_cast<size_t>(p)] > prev_iters[static_cast<size_t>(q)]; });
+      int* d_ord = dalloc<int>(static_cast<size_t>(batch));
+      DNLP_HIP_CHECK(hipMemcpyAsync(d_ord, ord.data(), sizeof(int) * static_cast<size_t>(batch), hipMemcpyHostToDevice, ex->stream));
+      DNLP_HIP_CHECK(hipStreamSynchronize(ex->stream));
+      w.order = d_ord;
+    }
+    last_grid = grid; last_threads = 64 * nw; last_lds_mode = 2 * sl + pl; last_per_cu = nw * per_cu; last_packed = false;
+    last_wave = 100 * nw + 10 * sl + pl;
+    if (std::getenv("DNLP_BATCH_DEBUG"))
+      std::fprintf(stderr, "[batch] wavefront solver: %d wavefronts per workgroup, state %s (%zu B per instance), plan %s (%zu B), dynamic LDS %u B, grid %d\n",
+                   nw, sl ? "in LDS" : "in global memory", state_b, pl ? "in LDS" : "in global memory", plan_b, lds, grid);
+    hipEvent_t e0, e1;
+    DNLP_HIP_CHECK(hipEventCreate(&e0));
+    DNLP_HIP_CHECK(hipEventCreate(&e1));
+    DNLP_HIP_CHECK(hipEventRecord(e0, ex->stream));
+    switch (form) {
+      case 411: launch_wave<4, true, true>(w, grid, lds, ex->stream); break;
+      case 211: launch_wave<2, true, true>(w, grid, lds, ex->stream); break;
+      case 111: launch_wave<1, true, true>(w, grid, lds, ex->stream); break;
+      case 210: launch_wave<2, true, false>(w, grid, lds, ex->stream); break;
+      case 110: launch_wave<1, true, false>(w, grid, lds, ex->stream); break;
+      case 400: launch_wave<4, false, false>(w, grid, lds, ex->stream); break;
+      default: throw std::runtime_error("wavefront solver: no such launch form");
+    }
+    DNLP_LAUNCH_CHECK();
+    DNLP_HIP_CHECK(hipEventRecord(e1, ex->stream));
+    DNLP_HIP_CHECK(hipStreamSynchronize(ex->stream));
+    float ms = 0.f;
+    DNLP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    double total_sec = 1e-3 * ms;
+    auto down = [&](void* hp, const void* d, size_t bytes) { if (hp && bytes) DNLP_HIP_CHECK(hipMemcpy(hp, d, bytes, hipMemcpyDeviceToHost)); };
+    std::vector<int> st_local;
+    int* st_host = status_out;
+    if (!st_host) { st_local.resize(static_cast<size_t>(batch)); st_host = st_local.data(); }
+    down(x_out, w.x_out, sizeof(double) * static_cast<size_t>(batch) * t.N);
+    down(obj_out, w.obj_out, sizeof(double) * batch);
+    down(multg_out, w.multg_out, sizeof(double) * static_cast<size_t>(batch) * t.m);
+    down(zl_out, w.zl_out, sizeof(double) * static_cast<size_t>(batch) * t.N);
+    down(zu_out, w.zu_out, sizeof(double) * static_cast<size_t>(batch) * t.N);
+    down(st_host, w.status_out, sizeof(int) * batch);
+    down(iters_out, w.iters_out, sizeof(int) * batch);
+    down(nfact_out, w.nfact_out, sizeof(int) * batch);
+    down(times_out, w.times_out, sizeof(double) * 4 * batch);
+#ifdef DNLP_WAVE_PROF
+    {
+      unsigned long long pr[kWaveProfSlots + 1];
+      DNLP_HIP_CHECK(hipMemcpy(pr, w.prof, sizeof pr, hipMemcpyDeviceToHost));
+      const double it = static_cast<double>(pr[kWaveProfSlots] ? pr[kWaveProfSlots] : 1);
+      static const char* nm[kWaveProfSlots] = {"solve (all)", "begin", "error", "eval_hessian", "barrier_terms", "assemble", "ldl_factor", "ldl_solve",
+                                               "coo products", "residual combine", "quality()", "direction loops", "max_steps+measures", "trial point + f,g",
+                                               "accept_trial", "(sweep)", "(spmv)", "mu oracle prologue", "[update_mu]", "[factor_with_inertia]", "[quality_function_mu]",
+                                               "[solve_refined]", "kkt_solve copy", "[line search]"};
+      std::fprintf(stderr, "[wave profile] %llu iterations; cycles per iteration by phase (s_memtime ticks):\n", pr[kWaveProfSlots]);
+      for (int k = 0; k < kWaveProfSlots; ++k) if (pr[k]) std::fprintf(stderr, "[wave profile]   %-22s %10.0f\n", nm[k], static_cast<double>(pr[k]) / it);
+    }
+#endif
+    release();
+    // the refused instances, through the generic kernel
+    std::vector<int> refused;
+    for (int k = 0; k < batch; ++k) if (st_host[k] == kWaveNeedsGeneric) refused.push_back(k);
+    last_wave_refused = static_cast<int>(refused.size());
+    if (!refused.empty()) {
+      const int nb = static_cast<int>(refused.size());
+      const i64 width = theta ? aff_P : in_stride;
+      const double* src = theta ? theta : data;
+      std::vector<double> sub(static_cast<size_t>(nb) * static_cast<size_t>(width));
+      for (int q = 0; q < nb; ++q) std::copy(src + static_cast<i64>(refused[q]) * width, src + static_cast<i64>(refused[q] + 1) * width, sub.begin() + static_cast<i64>(q) * width);
+      const size_t N = static_cast<size_t>(t.N), m = static_cast<size_t>(t.m);
+      std::vector<double> sx(nb * N), sobj(nb), smg(multg_out ? nb * m : 0), szl(zl_out ? nb * N : 0), szu(zu_out ? nb * N : 0), stm(times_out ? 4 * nb : 0);
+      std::vector<int> sst(nb), sit(nb), snf(nb);
+      if (warm) {
+        std::vector<double> g2(nb * m), l2(nb * N), u2(nb * N);
+        for (int q = 0; q < nb; ++q) {
+          std::copy(keep_g.begin() + refused[q] * m, keep_g.begin() + (refused[q] + 1) * m, g2.begin() + q * m);
+          std::copy(keep_l.begin() + refused[q] * N, keep_l.begin() + (refused[q] + 1) * N, l2.begin() + q * N);
+          std::copy(keep_u.begin() + refused[q] * N, keep_u.begin() + (refused[q] + 1) * N, u2.begin() + q * N);
+        }
+        set_warm_start(nb, g2.data(), l2.data(), u2.data());
+      }
+      const std::vector<int> keep_iters = prev_iters;
+      const uint64_t keep_key = prev_key;
+      double sec2 = 0.0;
+      solve_impl(nb, theta ? nullptr : sub.data(), theta ? sub.data() : nullptr, opt, sx.data(), sobj.data(), multg_out ? smg.data() : nullptr,
+                 zl_out ? szl.data() : nullptr, zu_out ? szu.data() : nullptr, sst.data(), sit.data(), snf.data(), &sec2, times_out ? stm.data() : nullptr, false);
+      prev_iters = keep_iters; prev_key = keep_key;
+      total_sec += sec2;
+      const int wave_form = last_wave;
+      for (int q = 0; q < nb; ++q) {
+        const int k = refused[q];
+        if (x_out) std::copy(sx.begin() + q * N, sx.begin() + (q + 1) * N, x_out + static_cast<size_t>(k) * N);
+        if (obj_out) obj_out[k] = sobj[q];
+        if (multg_out) std::copy(smg.begin() + q * m, smg.begin() + (q + 1) * m, multg_out + static_cast<size_t>(k) * m);
+        if (zl_out) std::copy(szl.begin() + q * N, szl.begin() + (q + 1) * N, zl_out + static_cast<size_t>(k) * N);
+        if (zu_out) std::copy(szu.begin() + q * N, szu.begin() + (q + 1) * N, zu_out + static_cast<size_t>(k) * N);
+        st_host[k] = sst[q];
+        if (iters_out) iters_out[k] = sit[q];
+        if (nfact_out) nfact_out[k] = snf[q];
+        if (times_out) std::copy(stm.begin() + 4 * q, stm.begin() + 4 * q + 4, times_out + 4 * static_cast<size_t>(k));
+      }
+      last_wave = wave_form;
+      last_wave_refused = nb;
+    }
+    if (seconds) *seconds = total_sec;
+    if (iters_out) { prev_iters.assign(iters_out, iters_out + batch); prev_key = key; }
   }
 };
 

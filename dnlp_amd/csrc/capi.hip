@@ -108,6 +108,15 @@ int dnlp_solve_batch_theta(dnlp_problem* vp, int batch, const double* theta, int
     return 0;)
 }
 
+int dnlp_batch_launch_info(dnlp_problem* vp, int32_t* out8) {
+  dnlp_problem_t* p = vp;
+  DNLP_TRY(
+    BatchRunner& r = *batch_runner(p);
+    out8[0] = r.last_grid; out8[1] = r.last_threads; out8[2] = r.last_lds_mode; out8[3] = r.last_per_cu; out8[4] = r.last_packed ? 1 : 0;
+    out8[5] = r.last_order_lpt ? 1 : 0; out8[6] = r.last_wave; out8[7] = r.last_wave_refused;
+    return 0;)
+}
+
 // Average seconds of one fused f + grad f evaluation with x resident in HBM (HIP events around
 // `reps` back-to-back evaluations on the problem's stream): the measurement behind the C2 roofline
 // line (tools/run_c2.py).

@@ -1,0 +1,135 @@
+// Template-specialised batch solver, part 3: the kernel.  One wavefront per instance, NW wavefronts per workgroup; the
+// plan block (wave_plan.h) is staged once per workgroup, every wavefront claims instance after instance from the launch's
+// queue and runs wave_ipm.h on it.  Where the instance's vectors and the plan live is a compile-time choice per launch:
+//   <state in LDS, plan in LDS>    small templates (localization: 15 KB of plan + 4 x 33 KB of state per compute unit)
+//   <state in LDS, plan global>    the plan does not fit beside one instance's state (read through L1 / L2)
+//   <state global, plan global>    large templates (power flow: 655 KB of state per instance)
+// The host side (batch.h BatchRunner::solve_wave) picks the richest form that fits 160 KB.
+#pragma once
+#include <type_traits>
+
+#include "exec_block.h"
+#include "wave_ipm.h"
+#include "wave_ops.h"
+
+namespace dnlp {
+
+template <bool STATE_LDS, bool PLAN_LDS>
+struct WaveLanesT {
+  typedef typename std::conditional<STATE_LDS, WLdsD, WGlbD>::type D;
+  typedef typename std::conditional<PLAN_LDS, WLdsI, WGlbI>::type I;
+  static constexpr int lanes = 64;
+  __device__ static int lane() { return static_cast<int>(threadIdx.x & 63u); }
+  __device__ static void sync() { wave_sync(); }
+  __device__ static double sum(double v) { return wave_all_sum(v); }
+  __device__ static double vmax(double v) { return wave_all_max(v); }
+  // per-level bounds (measured on MI355X: keeping the table one entry per lane in a register and reading it back with
+  // v_readlane made the substitutions 17 % SLOWER than these plain uniform LDS loads — 46.1 -> 53.8 k cycles per iteration)
+  __device__ static int tab_load(I*, int) { return 0; }
+  __device__ static int tab_at(I* tab, int, int idx, int) { return static_cast<int>(tab[idx]); }
+};
+
+struct WaveArgs {
+  const i32* blk = nullptr;          // the plan block (device memory)
+  int blk_ints = 0;
+  const double* rows = nullptr;      // batch x row_doubles instance rows (batch.h slab layout)
+  i64 row_doubles = 0;
+  int batch = 0;
+  double* state = nullptr;           // state in global memory: (grid x NW) x state_doubles
+  i64 state_doubles = 0;
+  IpmOptions opt;
+  i64 fallback_max_n = 0;
+  double *x_out = nullptr, *obj_out = nullptr, *multg_out = nullptr, *zl_out = nullptr, *zu_out = nullptr;
+  int *status_out = nullptr, *iters_out = nullptr, *nfact_out = nullptr;
+  double* times_out = nullptr;
+  const double *ws_g = nullptr, *ws_l = nullptr, *ws_u = nullptr;
+  int* next = nullptr;
+  const int* order = nullptr;
+  unsigned long long* prof = nullptr;   // kWaveProfSlots + 1 counters of a -DDNLP_WAVE_PROF build (last: iterations)
+};
+
+template <int NW, bool STATE_LDS, bool PLAN_LDS>
+__global__ void __launch_bounds__(64 * NW) wave_batch_kernel(WaveArgs a) {
+  extern __shared__ __align__(16) char w_lds[];
+  using P = WaveLanesT<STATE_LDS, PLAN_LDS>;
+  using W = WaveIpm<P>;
+  using WState = typename W::WState;
+  using WD = typename P::D;
+  using WI = typename P::I;
+  __shared__ __align__(16) char s_state[NW][(sizeof(WState) + 15) & ~static_cast<size_t>(15)];
+  __shared__ int s_inst[NW];
+  const int wave = static_cast<int>(threadIdx.x >> 6), lane = static_cast<int>(threadIdx.x & 63u);
+  char* pool = w_lds;
+  WI* blk;
+  if constexpr (PLAN_LDS) {
+    // (16-bit copy: the host takes this form only for plans whose entries all fit — BatchRunner::wave_prepare)
+    DNLP_WLDS int16_t* dst = (DNLP_WLDS int16_t*)pool;
+    for (int k = static_cast<int>(threadIdx.x); k < a.blk_ints; k += 64 * NW) dst[k] = static_cast<int16_t>(a.blk[k]);
+    blk = (WI*)dst;
+    pool += (static_cast<size_t>(a.blk_ints) * 2 + 15) & ~static_cast<size_t>(15);
+    __syncthreads();                   // the only workgroup barrier of the kernel
+  } else {
+    blk = (WI*)a.blk;
+  }
+  WD* base;
+  if constexpr (STATE_LDS) base = (WD*)(pool + static_cast<size_t>(wave) * static_cast<size_t>(a.state_doubles) * 8);
+  else base = (WD*)(a.state + (static_cast<size_t>(blockIdx.x) * NW + wave) * static_cast<size_t>(a.state_doubles));
+  typename W::WS* S = (typename W::WS*)s_state[wave];
+  W::layout(S, reinterpret_cast<const WaveHdr*>(a.blk), blk, base);
+  wave_sync();
+  const int N = S->N, m = S->m;
+  while (true) {
+    if (lane == 0) {
+      const int k = atomicAdd(a.next, 1);
+      s_inst[wave] = (k < a.batch && a.order) ? a.order[k] : k;
+    }
+    wave_sync();
+    const int inst = s_inst[wave];
+    wave_sync();
+    if (inst >= a.batch) break;
+    // (the generic spaces hand out zero-filled vectors; nothing below relies on it, but a stale NaN must not travel
+    //  from one instance into the next through an entry that a masked pass skips)
+    for (i64 k = lane; k < a.state_doubles; k += 64) base[k] = 0.0;
+    S->row = (WG*)(a.rows + static_cast<i64>(inst) * a.row_doubles);
+    S->ws_g = a.ws_g ? a.ws_g + static_cast<i64>(inst) * m : nullptr;
+    S->ws_l = a.ws_l ? a.ws_l + static_cast<i64>(inst) * N : nullptr;
+    S->ws_u = a.ws_u ? a.ws_u + static_cast<i64>(inst) * N : nullptr;
+    S->fallback_max_n = a.fallback_max_n;
+    S->opt = a.opt;
+    S->factorizations = 0;
+#ifdef DNLP_WAVE_PROF
+    for (int k = 0; k < kWaveProfSlots; ++k) S->prof[k] = 0ull;
+#endif
+    wave_sync();
+    const int st = W::solve(S);
+    const bool have = S->initialized && st != kWaveNeedsGeneric;
+    const double sf = have ? S->sf : 1.0;
+    {
+      const WD *xx = S->x, *yy = S->y, *sg = S->sg, *zl = S->zL, *zu = S->zU;
+      double* xo = a.x_out + static_cast<i64>(inst) * N;
+      for (int j = lane; j < N; j += 64) {
+        xo[j] = have ? xx[j] : 0.0;
+        if (a.zl_out) a.zl_out[static_cast<i64>(inst) * N + j] = have ? zl[j] / sf : 0.0;
+        if (a.zu_out) a.zu_out[static_cast<i64>(inst) * N + j] = have ? zu[j] / sf : 0.0;
+      }
+      if (a.multg_out)
+        for (int i = lane; i < m; i += 64) a.multg_out[static_cast<i64>(inst) * m + i] = have ? yy[i] * sg[i] / sf : 0.0;
+    }
+    if (lane == 0) {
+#ifdef DNLP_WAVE_PROF
+      if (a.prof) { for (int k = 0; k < kWaveProfSlots; ++k) atomicAdd(a.prof + k, S->prof[k]); atomicAdd(a.prof + kWaveProfSlots, static_cast<unsigned long long>(S->iter)); }
+#endif
+      a.status_out[inst] = st;
+      a.iters_out[inst] = S->iter;
+      a.obj_out[inst] = have ? S->f / sf : 0.0;
+      if (a.nfact_out) a.nfact_out[inst] = S->factorizations;
+      if (a.times_out) {
+        double* to = a.times_out + 4 * static_cast<i64>(inst);
+        to[0] = S->wall; to[1] = 0.0; to[2] = 0.0; to[3] = 0.0;
+      }
+    }
+    wave_sync();
+  }
+}
+
+}  // namespace dnlp

@@ -28,17 +28,35 @@
 #define DNLP_WGLB
 #endif
 
+// Cycle profile of the phases (a -DDNLP_WAVE_PROF build; tools/wave_profile.sh): S->prof[k] accumulates s_memtime ticks per
+// category, the kernel adds them up over the launch (wave_batch.h) and the host prints them (batch.h solve_wave).
+#if defined(DNLP_WAVE_PROF) && DNLP_DEVICE_PASS
+#define W_P0() const unsigned long long wp0_ = __builtin_readcyclecounter()
+#define W_P1(k) S->prof[k] += __builtin_readcyclecounter() - wp0_
+#else
+#define W_P0() do { } while (0)
+#define W_P1(k) do { } while (0)
+#endif
+
 namespace dnlp {
+
+constexpr int kWaveProfSlots = 24;
 
 // (device: the phases are real functions over one LDS pointer — the all-inlined generic kernel is a 28 k-instruction body)
 #if DNLP_DEVICE_PASS
 #define DNLP_WFN __attribute__((noinline))
+#define DNLP_WINL __attribute__((always_inline))
 #else
 #define DNLP_WFN
+#define DNLP_WINL
 #endif
 
-typedef DNLP_WLDS double WD;          // a double of the wavefront's LDS share
-typedef DNLP_WLDS const i32 WI;       // a table entry of the staged plan
+// Where a wavefront's vectors and the staged plan live is part of the lane policy P: P::D (a double of the instance's state)
+// and P::I (a table entry) are LDS-qualified types when they fit the compute unit's LDS, plain (global memory) otherwise.
+typedef DNLP_WLDS double WLdsD;
+typedef DNLP_WLDS const int16_t WLdsI;       // (a plan staged in LDS is narrowed to 16 bits: wave_batch.h)
+typedef DNLP_WGLB double WGlbD;
+typedef DNLP_WGLB const i32 WGlbI;
 typedef DNLP_WGLB const double WG;    // a double of the instance's data row (global memory)
 
 constexpr int kWaveNeedsGeneric = -197;
@@ -47,11 +65,14 @@ constexpr int kWaveNeedsGeneric = -197;
 #endif
 constexpr int kWaveFilterCap = DNLP_WAVE_FILTER_CAP;
 
-struct WCsr { WI* ptr; WI* idx; i32 rows; i32 val; };       // val: offset of the values in the instance's data row
-struct WCoo { WI* ptr; WI* ent; WI* src; WI* heavy; i32 nout; i32 nheavy; };
+template <class WI> struct WCsrT { WI* ptr; WI* idx; i32 rows; i32 val; };       // val: offset of the values in the instance's data row
+template <class WI> struct WCooT { WI* ptr; WI* ent; WI* src; WI* heavy; i32 nout; i32 nheavy; };
 
 // Everything one wavefront knows about the instance it is solving.  Lives in LDS (one per wavefront).
-struct WState {
+template <class WD, class WI>
+struct WStateT {
+  typedef WCsrT<WI> WCsr;
+  typedef WCooT<WI> WCoo;
   // ---- sizes and tables (set once per kernel: w_layout) ----
   i32 N, m, Z, nd, nh, nnzJ, nnzH, nunits;
   WI *u_op, *u_a0, *u_a1, *u_z, *u_d0, *u_d1, *u_h, *u_p, *mm_idx;
@@ -60,14 +81,15 @@ struct WState {
   WCoo jr, jc, hs;
   i32 nblk, nvals, nlev, ngrp, nfwd;
   WI *bnode, *soff, *loff, *doff, *lev_off, *sblk, *sidx, *lev_f, *fnode, *foff, *fa, *fu0, *fu1, *lev_g, *gdst, *goff, *upd_u, *upd_v,
-     *hpos, *jpos, *dpos;
+     *hpos, *jpos, *dpos, *lev_r, *lev_t, *lev_fe;
   i32 l_c0, l_c, l_b, l_Jc, l_fp, l_fp2, l_x0, l_lb, l_ub, l_cl, l_cu;
   // ---- vectors (LDS) ----
   WD *x, *zL, *zU, *xL, *xU, *grad, *dx, *dzL, *dzU, *xt, *Sx, *rx, *tN, *fixm;
   WD *s, *y, *vL, *vU, *sL, *sU, *eq, *g, *sg, *ds, *dy, *dvL, *dvU, *st, *gt, *Dd, *Ss, *rs, *rp, *tM, *csoc;
   WD *dir[3][7];                     // [0] = dx ds dy dzL dzU dvL dvU, [1] = affine-scaling, [2] = centering direction
   WD *rhs, *sol, *res, *cor;
-  WD *jv, *xz, *dvals, *hvals, *w, *sl, *Hs, *svals, *swork;
+  WD *jv, *xz, *dvals, *hvals, *w, *sl, *Hs, *svals, *swork, *scr;
+  WD *up0, *up1, *ucls;               // the two parameters of every sweep unit and its class (bind_params: once per instance)
   // ---- the instance (set per instance: w_bind) ----
   WG* row;                           // its data row (batch.h layout)
   const double *ws_g, *ws_l, *ws_u;  // warm-start multipliers or null
@@ -82,6 +104,9 @@ struct WState {
       sparse_singular_streak, dc_fixed_count, tiny_streak;
   bool initialized, fixed_mode, e_cached_valid, jty_valid, delta_w_used_last_iter, dc_fixed_last, always_dc, in_solve,
        resto_stationary, bail;
+#ifdef DNLP_WAVE_PROF
+  unsigned long long prof[kWaveProfSlots];
+#endif
 };
 
 struct WErr { double dual, primal, cmpl, sd, sc, total, primal_unscaled; };
@@ -89,12 +114,17 @@ struct WMeasures { double theta, phi, chk; };
 
 template <class P>
 struct WaveIpm {
+  typedef typename P::D WD;
+  typedef typename P::I WI;
+  typedef WStateT<WD, WI> WState;
+  typedef DNLP_WLDS WState WS;          // (the state record itself is always in LDS)
+  typedef WCsrT<WI> WCsr;
+  typedef WCooT<WI> WCoo;
   // lane-strided loops
 #define W_FOR(i, n) for (int i = P::lane(); i < (n); i += P::lanes)
 
   // ---- layout: the tables out of the staged block, the vectors out of the wavefront's share ---------------------------
-  DNLP_HD static void layout(DNLP_WLDS WState* S, WI* blk, WD* base) {
-    DNLP_WLDS const WaveHdr* h = (DNLP_WLDS const WaveHdr*)blk;
+  DNLP_HD static void layout(WS* S, const WaveHdr* h, WI* blk, WD* base) {
     S->N = h->N; S->m = h->m; S->Z = h->Z; S->nd = h->nd; S->nh = h->nh; S->nnzJ = h->nnzJ; S->nnzH = h->nnzH; S->nunits = h->nunits;
     S->u_op = blk + h->u_op; S->u_a0 = blk + h->u_a0; S->u_a1 = blk + h->u_a1; S->u_z = blk + h->u_z; S->u_d0 = blk + h->u_d0;
     S->u_d1 = blk + h->u_d1; S->u_h = blk + h->u_h; S->u_p = blk + h->u_p; S->mm_idx = blk + h->mm_idx;
@@ -113,6 +143,7 @@ struct WaveIpm {
     S->sblk = blk + h->sblk; S->sidx = blk + h->sidx; S->lev_f = blk + h->lev_f; S->fnode = blk + h->fnode; S->foff = blk + h->foff;
     S->fa = blk + h->fa; S->fu0 = blk + h->fu0; S->fu1 = blk + h->fu1; S->lev_g = blk + h->lev_g; S->gdst = blk + h->gdst;
     S->goff = blk + h->goff; S->upd_u = blk + h->tau; S->upd_v = blk + h->tav; S->hpos = blk + h->hpos; S->jpos = blk + h->jpos; S->dpos = blk + h->dpos;
+    S->lev_r = blk + h->lev_r; S->lev_t = blk + h->lev_t; S->lev_fe = blk + h->lev_fe;
     S->l_c0 = h->l_c0; S->l_c = h->l_c; S->l_b = h->l_b; S->l_Jc = h->l_Jc; S->l_fp = h->l_fp; S->l_fp2 = h->l_fp2;
     S->l_x0 = h->l_x0; S->l_lb = h->l_lb; S->l_ub = h->l_ub; S->l_cl = h->l_cl; S->l_cu = h->l_cu;
     // vectors, 16-byte granules (the count per class is wave_plan.h wave_state_doubles)
@@ -129,6 +160,8 @@ struct WaveIpm {
     S->rhs = take(N + m); S->sol = take(N + m); S->res = take(N + m); S->cor = take(N + m);
     S->jv = take(h->nnzJ); S->xz = take(N + h->Z); S->dvals = take(h->nd); S->hvals = take(h->nh); S->w = take(h->Z); S->sl = take(1 + m);
     S->Hs = take(h->nnzH); S->svals = take(h->sp_nvals); S->swork = take(h->sp_nvals + 3 * h->sp_nblk + 8);
+    S->scr = take(h->scr_doubles);
+    S->up0 = take(h->nunits); S->up1 = take(h->nunits); S->ucls = take(h->nunits);
     S->dir[0][0] = S->dx; S->dir[0][1] = S->ds; S->dir[0][2] = S->dy; S->dir[0][3] = S->dzL; S->dir[0][4] = S->dzU; S->dir[0][5] = S->dvL; S->dir[0][6] = S->dvU;
     S->dir[1][0] = ax; S->dir[1][1] = as; S->dir[1][2] = ay; S->dir[1][3] = azL; S->dir[1][4] = azU; S->dir[1][5] = avL; S->dir[1][6] = avU;
     S->dir[2][0] = cx; S->dir[2][1] = cs; S->dir[2][2] = cy; S->dir[2][3] = czL; S->dir[2][4] = czU; S->dir[2][5] = cvL; S->dir[2][6] = cvU;
@@ -142,20 +175,29 @@ struct WaveIpm {
   // tape evaluation (model.h)
   // ====================================================================================================================
   // Model::sweep: xz[0..N) <- src (unless it is xz already), then every flat unit: z, dvals (and hvals with the weights w)
-  DNLP_WFN DNLP_HD static void sweep(DNLP_WLDS WState* S, const WD* src, bool with_h) {
+  DNLP_WFN DNLP_HD static void sweep(WS* S, const WD* src, bool with_h) {
+    W_P0();
     const int N = S->N, nu = S->nunits;
     WD *xz = S->xz, *dv = S->dvals, *hv = S->hvals;
     const WD* ww = S->w;
     if (src != xz) { W_FOR(j, N) xz[j] = src[j]; P::sync(); }
     WI *uop = S->u_op, *ua0 = S->u_a0, *ua1 = S->u_a1, *uz = S->u_z, *ud0 = S->u_d0, *ud1 = S->u_d1, *uh = S->u_h, *up = S->u_p;
-    WG *fp = S->row + S->l_fp, *fp2 = S->row + S->l_fp2;
+    const WD *up0 = S->up0, *up1 = S->up1, *ucls = S->ucls;
     W_FOR(e, nu) {
       const int op = uop[e];
       const i32 zi = uz[e];
       if (op < OP_MUL) {
         double val, g1, g2;
-        const i32 f = up[e];
-        unary_rules(op, xz[ua0[e]], fp[f], fp2[f], val, g1, g2);
+        const double u = xz[ua0[e]], cls = ucls[e];
+        if (cls == 1.0) {              // x^2: pow_fast(u, 2) = u u; 2 pow_fast(u, 1) = 2 u; 2 (2 - 1) pow_fast(u, 0) = 2
+          const double pd = up0[e];
+          val = u * u; g1 = pd * u; g2 = pd * (pd - 1.0) * 1.0;
+        } else if (cls == 2.0) {       // sqrt: pow_fast(u, 0.5) = sqrt(u); 0.5 pow_fast(u, -0.5); 0.5 (-0.5) pow_fast(u, -1.5)
+          const double pd = up0[e], sq = sqrt(u);
+          val = sq; g1 = pd * (1.0 / sq); g2 = pd * (pd - 1.0) * (1.0 / (u * sq));
+        } else {
+          unary_rules(op, u, up0[e], up1[e], val, g1, g2);
+        }
         xz[N + zi] = val;
         dv[ud0[e]] = g1;
         if (with_h) hv[uh[e]] = ww[zi] * g2;
@@ -195,10 +237,45 @@ struct WaveIpm {
         xz[N + zi] = acc;
       }
     }
+    W_P1(15);
+    P::sync();
+  }
+  // Sums of products, the pattern of every index-driven piece below (CSR maps, the products by output, the update
+  // program and the substitutions of the LDL^T): a lane that walks "its" output's entries runs a chain of dependent LDS
+  // trips per entry (index -> operands -> add).  Instead the products of ALL entries of the phase are formed side by
+  // side into the scratch array (one entry per lane and trip: the index loads of different entries overlap), and the
+  // owner of an output then adds its run of consecutive scratch entries — in the same order as before, so the sums keep
+  // their bits.
+  DNLP_HD static double run_sum(double acc, const WD* p, int n) {
+    int q = 0;
+    for (; q + 4 <= n; q += 4) {
+      const double t0 = p[q], t1 = p[q + 1], t2 = p[q + 2], t3 = p[q + 3];
+      acc += t0; acc += t1; acc += t2; acc += t3;
+    }
+    for (; q < n; ++q) acc += p[q];
+    return acc;
+  }
+  // the per-segment parameters of the unary atoms, once per instance: out of the data row (global memory) into LDS
+  DNLP_HD static void bind_params(WS* S) {
+    WI *uop = S->u_op, *up = S->u_p;
+    WG *fp = S->row + S->l_fp, *fp2 = S->row + S->l_fp2;
+    WD *up0 = S->up0, *up1 = S->up1, *ucls = S->ucls;
+    W_FOR(e, S->nunits) {
+      const int op = uop[e];
+      const bool unary = op < OP_MUL;
+      const i32 f = unary ? up[e] : 0;
+      const double p = unary ? fp[f] : 0.0, p2 = unary ? fp2[f] : 0.0;
+      up0[e] = p;
+      up1[e] = p2;
+      // the two power atoms every canonical form is full of take their branch of pow_fast directly (atom_math.h: the
+      // same expressions, so the same bits — the chain of comparisons in front of them is what a sweep was made of)
+      ucls[e] = (op == OP_POWER && p == 2.0 && p2 == 2.0) ? 1.0 : (op == OP_POWER && p == 0.5 && p2 == 0.5) ? 2.0 : 0.0;
+    }
     P::sync();
   }
   // Model::spmv: y = (base + M v) [* scale];  scale_kind 0 none, 1 a scalar, 2 sg[r], 3 sg[jac_rows[r]]
-  DNLP_WFN DNLP_HD static void spmv(DNLP_WLDS WState* S, const WCsr M, const WD* v, i32 base_off, WD* y, int scale_kind, double scalar) {
+  DNLP_WFN DNLP_WFN DNLP_HD static void spmv(DNLP_WLDS WState* S, const WCsr M, const WD* v, i32 base_off, WD* y, int scale_kind, double scalar) {
+    W_P0();
     WI *ptr = M.ptr, *idx = M.idx;
     WG* val = S->row + M.val;
     WG* base = base_off >= 0 ? S->row + base_off : nullptr;
@@ -214,9 +291,10 @@ struct WaveIpm {
       y[r] = sacc;
     }
     P::sync();
+    W_P1(16);
   }
   // Ipm::eval_fg (check folded into the callers): f~ and g~ at xp; returns isfinite(f~)
-  DNLP_WFN DNLP_HD static bool eval_fg(DNLP_WLDS WState* S, const WD* xp, double& fval, WD* gout) {
+  DNLP_WFN DNLP_HD static bool eval_fg(WS* S, const WD* xp, double& fval, WD* gout) {
     sweep(S, xp, false);
     const int NZ = S->N + S->Z;
     WG* cc = S->row + S->l_c;
@@ -227,19 +305,20 @@ struct WaveIpm {
     spmv(S, S->G, S->xz, S->l_b, gout, 2, 0.0);
     return std::isfinite(fval);
   }
-  DNLP_HD static double nan_check(DNLP_WLDS WState* S, const WD* gg) {
+  DNLP_HD static double nan_check(WS* S, const WD* gg) {
     double acc = 0.0;
     W_FOR(i, S->m) acc += gg[i] - gg[i];
     return P::sum(acc);
   }
   // Ipm::eval_derivs_after_sweep
-  DNLP_HD static void eval_derivs(DNLP_WLDS WState* S) {
+  DNLP_HD static void eval_derivs(WS* S) {
     S->jty_valid = false;
     spmv(S, S->Mg, S->dvals, S->l_c, S->grad, 1, S->sf);
     spmv(S, S->MJ, S->dvals, S->l_Jc, S->jv, 3, 0.0);
   }
   // Ipm::eval_hessian + Model::eval_hess
-  DNLP_WFN DNLP_HD static void eval_hessian(DNLP_WLDS WState* S) {
+  DNLP_WFN DNLP_HD static void eval_hessian(WS* S) {
+    W_P0();
     const int m = S->m;
     WD* sl = S->sl;
     const WD *sg = S->sg, *yy = S->y;
@@ -250,9 +329,11 @@ struct WaveIpm {
     spmv(S, S->Mw, S->sl, -1, S->w, 0, 0.0);
     sweep(S, S->x, true);
     spmv(S, S->MH, S->hvals, -1, S->Hs, 0, 0.0);
+    W_P1(3);
   }
   // BlockExecT::coo_gather through the tape's index by output: out = J v / J^T v / sym(H) v
-  DNLP_WFN DNLP_HD static void coo(DNLP_WLDS WState* S, const WCoo ix, const WD* a, const WD* v, WD* out) {
+  DNLP_WFN DNLP_WFN DNLP_HD static void coo(DNLP_WLDS WState* S, const WCoo ix, const WD* a, const WD* v, WD* out) {
+    W_P0();
     WI *ptr = ix.ptr, *ent = ix.ent, *src = ix.src;
     W_FOR(gq, ix.nout) {
       const i32 p0 = ptr[gq], p1 = ptr[gq + 1];
@@ -270,16 +351,18 @@ struct WaveIpm {
       if (P::lane() == 0) out[gq] = sacc;
     }
     P::sync();
+    W_P1(8);
   }
-  DNLP_HD static void hess_mult(DNLP_WLDS WState* S, const WD* v, WD* out) { coo(S, S->hs, S->Hs, v, out); }
-  DNLP_HD static void jac_mult(DNLP_WLDS WState* S, const WD* v, WD* out) { coo(S, S->jr, S->jv, v, out); }
-  DNLP_HD static void jac_tmult(DNLP_WLDS WState* S, const WD* v, WD* out) { coo(S, S->jc, S->jv, v, out); }
+  DNLP_HD static void hess_mult(WS* S, const WD* v, WD* out) { coo(S, S->hs, S->Hs, v, out); }
+  DNLP_HD static void jac_mult(WS* S, const WD* v, WD* out) { coo(S, S->jr, S->jv, v, out); }
+  DNLP_HD static void jac_tmult(WS* S, const WD* v, WD* out) { coo(S, S->jc, S->jv, v, out); }
 
   // ====================================================================================================================
   // KKT system: assembly (kkt_dense.h assemble_factor, sparse branch) and the static-pattern LDL^T (sparse_ldl.h)
   // ====================================================================================================================
-  DNLP_WFN DNLP_HD static bool assemble_factor(DNLP_WLDS WState* S, const WD* Sx, const WD* D, double dw, bool zero_h, int* nneg_out, int* nzero_out) {
+  DNLP_WFN DNLP_HD static bool assemble_factor(WS* S, const WD* Sx, const WD* D, double dw, bool zero_h, int* nneg_out, int* nzero_out) {
     const int N = S->N, m = S->m, nnzH = S->nnzH, nnzJ = S->nnzJ, nvals = S->nvals;
+    W_P0();
     WD* V = S->svals;
     const WD *fixm = S->fixm, *hs = S->Hs, *jv = S->jv;
     WI *hp = S->hpos, *jp = S->jpos, *dp = S->dpos, *hr = S->hess_rows, *hc = S->hess_cols, *jc = S->jac_cols;
@@ -303,10 +386,11 @@ struct WaveIpm {
     W_FOR(i, m) V[dp[N + i]] = -D[i];
     P::sync();
     S->factorizations++;
+    W_P1(5);
     return ldl_factor(S, nneg_out, nzero_out);
   }
   // sparse_ldl.h sp_pivot
-  DNLP_HD static void sp_pivot(DNLP_WLDS WState* S, WD* vals, WD* dinv, int k, double& nneg, double& nzero, double& bad) {
+  DNLP_HD static void sp_pivot(WS* S, WD* vals, WD* dinv, int k, double& nneg, double& nzero, double& bad) {
     WD* Dk = vals + S->doff[k];
     WD* di = dinv + 3 * k;
     if (S->bnode[2 * k + 1] < 0) {
@@ -326,7 +410,7 @@ struct WaveIpm {
     }
   }
   // sparse_ldl.h sp_scale
-  DNLP_HD static void sp_scale(DNLP_WLDS WState* S, WD* vals, WD* w, const WD* dinv, int r) {
+  DNLP_HD static void sp_scale(WS* S, WD* vals, WD* w, const WD* dinv, int r) {
     const int k = S->sblk[r], i = r - S->soff[k];
     const WD* di = dinv + 3 * k;
     if (S->bnode[2 * k + 1] < 0) {
@@ -348,47 +432,45 @@ struct WaveIpm {
     const i32 bv = ~av;
     return w[au] * vals[bv] + w[au + 1] * vals[bv + 1];
   }
-  // sparse_ldl.h sparse_ldl_factor (no dense tail)
-  DNLP_WFN DNLP_HD static bool ldl_factor(DNLP_WLDS WState* S, int* nneg_out, int* nzero_out) {
+  // sparse_ldl.h sparse_ldl_factor (no dense tail).  Per level: pivots, row scaling, then the update triples — their
+  // products side by side into the scratch array, each destination's run added in storage order (see run_sum).
+  DNLP_WFN DNLP_HD static bool ldl_factor(WS* S, int* nneg_out, int* nzero_out) {
+    W_P0();
     const int L = P::lanes, me = P::lane();
     WD* vals = S->svals;
     WD* w = S->swork;
     WD* dinv = S->swork + S->nvals;
+    WD* scr = S->scr;
     WI *lev_off = S->lev_off, *soff = S->soff, *lev_g = S->lev_g, *goff = S->goff, *gdst = S->gdst, *tau = S->upd_u, *tav = S->upd_v;
     double nneg = 0.0, nzero = 0.0, bad = 0.0;
-    const int nlev = S->nlev;
+    const int nlev = S->nlev, nt = nlev + 1;
+    // (the per-level bounds: one table entry per lane in a register, read back with v_readlane — two dependent uniform
+    //  LDS trips less in front of every level phase)
+    WI *lev_r = S->lev_r, *lev_t = S->lev_t;
+    const int c_off = P::tab_load(lev_off, nt), c_r = P::tab_load(lev_r, nt), c_g = P::tab_load(lev_g, nt), c_t = P::tab_load(lev_t, nt);
     for (int lev = 0; lev < nlev; ++lev) {
-      const int b0 = lev_off[lev], b1 = lev_off[lev + 1];
-      const int r0 = soff[b0], r1 = soff[b1];
-      if (r1 - r0 <= 8 * (b1 - b0)) {
-        for (int k = b0 + me; k < b1; k += L) {
-          sp_pivot(S, vals, dinv, k, nneg, nzero, bad);
-          const int re = soff[k + 1];
-          for (int r = soff[k]; r < re; ++r) sp_scale(S, vals, w, dinv, r);
-        }
-        P::sync();
-      } else {
-        for (int k = b0 + me; k < b1; k += L) sp_pivot(S, vals, dinv, k, nneg, nzero, bad);
-        P::sync();
-        for (int r = r0 + me; r < r1; r += L) sp_scale(S, vals, w, dinv, r);
-        P::sync();
-      }
-      const int g0 = lev_g[lev], g1 = lev_g[lev + 1];
-      const int ngr = g1 - g0, ntr = goff[g1] - goff[g0];
+      const int b0 = P::tab_at(lev_off, c_off, lev, nt), b1 = P::tab_at(lev_off, c_off, lev + 1, nt);
+      const int r0 = P::tab_at(lev_r, c_r, lev, nt), r1 = P::tab_at(lev_r, c_r, lev + 1, nt);
+      for (int k = b0 + me; k < b1; k += L) sp_pivot(S, vals, dinv, k, nneg, nzero, bad);
+      P::sync();
+      for (int r = r0 + me; r < r1; r += L) sp_scale(S, vals, w, dinv, r);
+      P::sync();
+      const int g0 = P::tab_at(lev_g, c_g, lev, nt), g1 = P::tab_at(lev_g, c_g, lev + 1, nt);
+      const int t0 = P::tab_at(lev_t, c_t, lev, nt), ntr = P::tab_at(lev_t, c_t, lev + 1, nt) - t0, ngr = g1 - g0;
+      for (int q = me; q < ntr; q += L) scr[q] = sp_update(tau, tav, vals, w, t0 + q);
+      P::sync();
       if (ngr * 8 <= L && ntr >= 16 * ngr) {
         for (int gq = g0; gq < g1; ++gq) {
           double acc = 0.0;
-          const int qe = goff[gq + 1];
-          for (int q = goff[gq] + me; q < qe; q += L) acc += sp_update(tau, tav, vals, w, q);
+          const int q0 = goff[gq] - t0, qe = goff[gq + 1] - t0;
+          for (int q = q0 + me; q < qe; q += L) acc += scr[q];
           acc = P::sum(acc);
           if (me == 0) vals[gdst[gq]] -= acc;
         }
       } else {
         for (int gq = g0 + me; gq < g1; gq += L) {
-          double acc = 0.0;
-          const int qe = goff[gq + 1];
-          for (int q = goff[gq]; q < qe; ++q) acc += sp_update(tau, tav, vals, w, q);
-          vals[gdst[gq]] -= acc;
+          const int q0 = goff[gq] - t0;
+          vals[gdst[gq]] -= run_sum(0.0, scr + q0, goff[gq + 1] - t0 - q0);
         }
       }
       P::sync();
@@ -398,30 +480,34 @@ struct WaveIpm {
     bad = P::sum(bad);
     *nneg_out = static_cast<int>(nneg);
     *nzero_out = static_cast<int>(nzero);
+    W_P1(6);
     return bad == 0.0;
   }
-  DNLP_HD static double sp_fwd(DNLP_WLDS WState* S, const WD* vals, const WD* x, int q) {
-    const i32 a = S->fa[q];
-    if (a >= 0) return vals[a] * x[S->fu0[q]];
+  DNLP_HD static double sp_fwd(WI* fa, WI* fu0, WI* fu1, const WD* vals, const WD* x, int q) {
+    const i32 a = fa[q];
+    if (a >= 0) return vals[a] * x[fu0[q]];
     const i32 b = ~a;
-    return vals[b] * x[S->fu0[q]] + vals[b + 1] * x[S->fu1[q]];
+    return vals[b] * x[fu0[q]] + vals[b + 1] * x[fu1[q]];
   }
   // sparse_ldl.h sparse_ldl_solve: x <- K^-1 x
-  DNLP_WFN DNLP_HD static void ldl_solve(DNLP_WLDS WState* S, WD* x) {
+  DNLP_WFN DNLP_WFN DNLP_HD static void ldl_solve(DNLP_WLDS WState* S, WD* x) {
+    W_P0();
     const int L = P::lanes, me = P::lane();
     const WD* vals = S->svals;
     WI *lev_f = S->lev_f, *foff = S->foff, *fnode = S->fnode, *lev_off = S->lev_off, *soff = S->soff, *bnode = S->bnode, *loff = S->loff,
-       *sidx = S->sidx, *doff = S->doff;
-    const int nlev = S->nlev, nblk = S->nblk;
+       *sidx = S->sidx, *doff = S->doff, *fa = S->fa, *fu0 = S->fu0, *fu1 = S->fu1;
+    const int nlev = S->nlev, nblk = S->nblk, nt = nlev + 1;
+    WI *lev_r = S->lev_r, *lev_fe = S->lev_fe;
+    const int c_f = P::tab_load(lev_f, nt), c_fe = P::tab_load(lev_fe, nt), c_off = P::tab_load(lev_off, nt), c_r = P::tab_load(lev_r, nt);
     for (int lev = 1; lev < nlev; ++lev) {
-      const int h0 = lev_f[lev], h1 = lev_f[lev + 1];
+      const int h0 = P::tab_at(lev_f, c_f, lev, nt), h1 = P::tab_at(lev_f, c_f, lev + 1, nt);
       if (h1 == h0) continue;
-      const int nh = h1 - h0, nrw = foff[h1] - foff[h0];
+      const int nh = h1 - h0, nrw = P::tab_at(lev_fe, c_fe, lev + 1, nt) - P::tab_at(lev_fe, c_fe, lev, nt);
       if (nh * 8 <= L && nrw > 2 * nh) {
         for (int hq = h0; hq < h1; ++hq) {
           const int q1 = foff[hq + 1];
           double acc = 0.0;
-          for (int q = foff[hq] + me; q < q1; q += L) acc += sp_fwd(S, vals, x, q);
+          for (int q = foff[hq] + me; q < q1; q += L) acc += sp_fwd(fa, fu0, fu1, vals, x, q);
           acc = P::sum(acc);
           if (me == 0) x[fnode[hq]] -= acc;
         }
@@ -429,7 +515,7 @@ struct WaveIpm {
         for (int hq = h0 + me; hq < h1; hq += L) {
           const int q1 = foff[hq + 1];
           double acc = 0.0;
-          for (int q = foff[hq]; q < q1; ++q) acc += sp_fwd(S, vals, x, q);
+          for (int q = foff[hq]; q < q1; ++q) acc += sp_fwd(fa, fu0, fu1, vals, x, q);
           x[fnode[hq]] -= acc;
         }
       }
@@ -451,8 +537,8 @@ struct WaveIpm {
     }
     P::sync();
     for (int lev = nlev - 1; lev >= 0; --lev) {
-      const int b0 = lev_off[lev], b1 = lev_off[lev + 1];
-      const int nbl = b1 - b0, nrw = soff[b1] - soff[b0];
+      const int b0 = P::tab_at(lev_off, c_off, lev, nt), b1 = P::tab_at(lev_off, c_off, lev + 1, nt);
+      const int nbl = b1 - b0, nrw = P::tab_at(lev_r, c_r, lev + 1, nt) - P::tab_at(lev_r, c_r, lev, nt);
       if (nbl * 4 >= L || nrw <= 3 * nbl * nbl) {
         for (int k = b0 + me; k < b1; k += L) {
           const int s0 = soff[k], sn = soff[k + 1] - s0;
@@ -486,25 +572,26 @@ struct WaveIpm {
       }
       P::sync();
     }
+    W_P1(7);
   }
   // DenseKkt::solve (sparse) == Ipm::kkt_solve without the quasi-Newton part
-  DNLP_HD static void kkt_solve(DNLP_WLDS WState* S, const WD* r, WD* out) {
+  DNLP_HD static void kkt_solve(WS* S, const WD* r, WD* out) {
     const int n = S->N + S->m;
-    if (out != r) { W_FOR(k, n) out[k] = r[k]; P::sync(); }
+    { W_P0(); if (out != r) { W_FOR(k, n) out[k] = r[k]; P::sync(); } W_P1(22); }
     ldl_solve(S, out);
   }
 
   // ====================================================================================================================
   // interior-point loop (ipm_core.h; the member restated is named at each function)
   // ====================================================================================================================
-  DNLP_HD static void filter_add(DNLP_WLDS WState* S, double th, double ph) {
+  DNLP_HD static void filter_add(WS* S, double th, double ph) {
     if (S->nfilt == kWaveFilterCap) {
       for (int k = 1; k < S->nfilt; ++k) { S->filt_th[k - 1] = S->filt_th[k]; S->filt_ph[k - 1] = S->filt_ph[k]; }
       --S->nfilt;
     }
     S->filt_th[S->nfilt] = th; S->filt_ph[S->nfilt] = ph; ++S->nfilt;
   }
-  DNLP_HD static bool filter_ok(DNLP_WLDS WState* S, double th, double ph) {
+  DNLP_HD static bool filter_ok(WS* S, double th, double ph) {
     const double gth = 1e-5, gph = 1e-8;
     for (int k = 0; k < S->nfilt; ++k)
       if (!(th <= (1.0 - gth) * S->filt_th[k] || ph <= S->filt_ph[k] - gph * S->filt_th[k])) return false;
@@ -512,7 +599,8 @@ struct WaveIpm {
   }
 
   // Ipm::begin
-  DNLP_WFN DNLP_HD static int begin(DNLP_WLDS WState* S) {
+  DNLP_WFN DNLP_HD static int begin(WS* S) {
+    W_P0();
     const double t_start = now_sec();
     const int N = S->N, m = S->m;
     const IpmOptions& opt = S->opt;
@@ -652,11 +740,12 @@ struct WaveIpm {
     S->factorizations = 0;            // (stats = IpmStats())
     S->inf_pr = S->inf_du = S->cmpl = S->nlp_error = 0.0;
     S->t_begin = t_start;
+    W_P1(1);
     return 0;
   }
 
   // Ipm::init_multipliers_ls (the general path: neither of the host-only condensed forms)
-  DNLP_WFN DNLP_HD static void init_multipliers_ls(DNLP_WLDS WState* S) {
+  DNLP_WFN DNLP_HD static void init_multipliers_ls(WS* S) {
     const int N = S->N, m = S->m;
     S->jty_valid = false;
     const WD* eq = S->eq;
@@ -694,7 +783,7 @@ struct WaveIpm {
   }
 
   // Ipm::theta_at
-  DNLP_HD static double theta_at(DNLP_WLDS WState* S, const WD* gg, const WD* ss) {
+  DNLP_HD static double theta_at(WS* S, const WD* gg, const WD* ss) {
     const WD *eq = S->eq, *sl = S->sL;
     double acc = 0.0;
     W_FOR(i, S->m) acc += fabs(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]);
@@ -710,7 +799,7 @@ struct WaveIpm {
     return bt;
   }
   // Ipm::barrier_at (two sums: variables, rows)
-  DNLP_WFN DNLP_HD static double barrier_at(DNLP_WLDS WState* S, double fv, const WD* xx, const WD* ss, double muv) {
+  DNLP_WFN DNLP_HD static double barrier_at(WS* S, double fv, const WD* xx, const WD* ss, double muv) {
     const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *eq = S->eq;
     const double kd = S->opt.kappa_d;
     double ax = 0.0, as = 0.0;
@@ -720,9 +809,10 @@ struct WaveIpm {
     return fv + muv * (bx + bs);
   }
   // Ipm::measures: theta, the barrier function and the NaN detector of g in one pass
-  DNLP_WFN DNLP_HD static WMeasures measures(DNLP_WLDS WState* S, double fv, const WD* gg, const WD* xx, const WD* ss, double muv) {
+  DNLP_WFN DNLP_HD static WMeasures measures(WS* S, double fv, const WD* gg, const WD* xx, const WD* ss, double muv) {
     const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *eq = S->eq;
     const double kd = S->opt.kappa_d;
+    W_P0();
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     W_FOR(j, S->N) s1 += bterm(xx[j], l[j], u[j], kd);
     W_FOR(i, S->m) {
@@ -731,17 +821,19 @@ struct WaveIpm {
       if (eq[i] == 0.0) s1 += bterm(ss[i], sl[i], su[i], kd);
     }
     s0 = P::sum(s0); s1 = P::sum(s1); s2 = P::sum(s2);
+    W_P1(12);
     return WMeasures{s0, fv + muv * s1, s2};
   }
   // Ipm::jty
-  DNLP_HD static const WD* jty(DNLP_WLDS WState* S) {
+  DNLP_HD static const WD* jty(WS* S) {
     if (!S->jty_valid) { jac_tmult(S, S->y, S->tN); S->jty_valid = true; }
     return S->tN;
   }
   // Ipm::error (dual_residuals fused into the same pass)
-  DNLP_WFN DNLP_HD static WErr error(DNLP_WLDS WState* S, double muv) {
+  DNLP_WFN DNLP_HD static WErr error(WS* S, double muv) {
     const int N = S->N, m = S->m;
     const WD* jt = jty(S);
+    W_P0();
     WD *r = S->rx, *q = S->rs;
     const WD *gr = S->grad, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU, *yy = S->y, *eq = S->eq, *fm = S->fixm, *gg = S->g, *ss = S->s,
              *sl = S->sL, *su = S->sU, *l = S->xL, *u = S->xU, *xx = S->x, *sgp = S->sg;
@@ -783,10 +875,11 @@ struct WaveIpm {
     e.sd = std::max(smax, (sy + sz) / std::max<double>(1.0, static_cast<double>(m + nb))) / smax;
     e.sc = std::max(smax, sz / std::max<double>(1.0, static_cast<double>(nb))) / smax;
     e.total = std::max(std::max(e.dual / e.sd, e.primal), e.cmpl / e.sc);
+    W_P1(2);
     return e;
   }
   // Ipm::n_bound_mults
-  DNLP_HD static i64 n_bound_mults(DNLP_WLDS WState* S) {
+  DNLP_HD static i64 n_bound_mults(WS* S) {
     if (S->nb_cache >= 0) return S->nb_cache;
     const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *eq = S->eq;
     double c1 = 0.0, c2 = 0.0;
@@ -798,7 +891,8 @@ struct WaveIpm {
     return S->nb_cache;
   }
   // Ipm::barrier_terms
-  DNLP_WFN DNLP_HD static void barrier_terms(DNLP_WLDS WState* S, double muv) {
+  DNLP_WFN DNLP_HD static void barrier_terms(WS* S, double muv) {
+    W_P0();
     const WD* jt = jty(S);
     WD *sx = S->Sx, *sS = S->Ss, *r = S->rx, *q = S->rs, *p = S->rp;
     const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *eq = S->eq, *xx = S->x, *ss = S->s, *a = S->zL, *b = S->zU, *c = S->vL,
@@ -826,10 +920,11 @@ struct WaveIpm {
       q[i] = gphi - yy[i];
       p[i] = gg[i] - ss[i];
     }
+    W_P1(4);
     P::sync();
   }
   // Ipm::try_factor: 0 ok, 1 wrong inertia, 2 singular
-  DNLP_HD static int try_factor(DNLP_WLDS WState* S, double dw, double dc) {
+  DNLP_HD static int try_factor(WS* S, double dw, double dc) {
     int nneg = 0, nzero = 0;
     WD* dd = S->Dd;
     const WD *sS = S->Ss, *eq = S->eq;
@@ -842,7 +937,7 @@ struct WaveIpm {
     return nneg == S->m ? 0 : 1;
   }
   // Ipm::factor_with_inertia (WB Algorithm IC; no Lanczos bound: host-driven large dense systems only)
-  DNLP_WFN DNLP_HD static bool factor_with_inertia(DNLP_WLDS WState* S, double& delta_w, double& delta_c) {
+  DNLP_WFN DNLP_HD static bool factor_with_inertia(WS* S, double& delta_w, double& delta_c) {
     const double dw_min = 1e-20, dw_0 = 1e-4, dw_max = S->opt.max_hessian_perturbation, dc_bar = 1e-8, kwp = 8.0, kwpb = 100.0, kwm = 1.0 / 3.0, kc = 0.25;
     delta_w = 0.0; delta_c = 0.0;
     const double dc_val = dc_bar * std::pow(S->mu, kc);
@@ -893,16 +988,17 @@ struct WaveIpm {
     }
     return false;
   }
-  DNLP_HD static void dc_fixed(DNLP_WLDS WState* S) {
+  DNLP_HD static void dc_fixed(WS* S) {
     S->dc_fixed_last = true;
     if (++S->dc_fixed_count >= 3 && !S->always_dc) S->always_dc = true;
   }
   // Ipm::kkt_residual: out = rhsv - K v, max |out|, max |v|
-  DNLP_WFN DNLP_HD static void kkt_residual(DNLP_WLDS WState* S, const WD* v, double dw, const WD* rhsv, WD* out, double& en, double& sn) {
+  DNLP_WFN DNLP_HD static void kkt_residual(WS* S, const WD* v, double dw, const WD* rhsv, WD* out, double& en, double& sn) {
     const int N = S->N, m = S->m;
     hess_mult(S, v, out);
     jac_tmult(S, v + N, S->xt);
     jac_mult(S, v, S->tM);
+    W_P0();
     const WD *sx = S->Sx, *jt = S->xt, *jx = S->tM, *dd = S->Dd, *fm = S->fixm;
     double m0 = -kInf, m1 = -kInf;
     W_FOR(k, N) {
@@ -920,9 +1016,10 @@ struct WaveIpm {
     }
     en = P::vmax(m0); sn = P::vmax(m1);
     P::sync();
+    W_P1(9);
   }
   // Ipm::solve_refined
-  DNLP_WFN DNLP_HD static bool solve_refined(DNLP_WLDS WState* S, double dw) {
+  DNLP_WFN DNLP_HD static bool solve_refined(WS* S, double dw) {
     const int n = S->N + S->m;
     kkt_solve(S, S->rhs, S->sol);
     const WD* rr = S->rhs;
@@ -958,14 +1055,17 @@ struct WaveIpm {
   }
   // Ipm::compute_direction; `set` picks the seven output arrays (0: dx .. dvU, 1: affine-scaling, 2: centering);
   // pres == nullptr stands for the all-zero primal residual of the centering system
-  DNLP_WFN DNLP_HD static bool compute_direction(DNLP_WLDS WState* S, double muv, const WD* pres, double dw, bool centering, int set) {
+  DNLP_WFN DNLP_HD static bool compute_direction(WS* S, double muv, const WD* pres, double dw, bool centering, int set) {
     const int N = S->N, m = S->m;
     WD* r = S->rhs;
     const WD *rxx = S->rx, *q = S->rs, *sS = S->Ss, *eq = S->eq;
+    { W_P0();
     W_FOR(k, N) r[k] = -rxx[k];
     W_FOR(i, m) r[N + i] = -(pres ? pres[i] : 0.0) - (eq[i] == 0.0 ? q[i] / (sS[i] + dw) : 0.0);
     P::sync();
-    if (!solve_refined(S, dw)) return false;
+    W_P1(11); }
+    { W_P0(); const bool oks = solve_refined(S, dw); W_P1(21); if (!oks) return false; }
+    W_P0();
     const WD* so = S->sol;
     WD *ddx = S->dir[set][0], *dds = S->dir[set][1], *ddy = S->dir[set][2], *da = S->dir[set][3], *db = S->dir[set][4], *dc = S->dir[set][5],
        *dd2 = S->dir[set][6];
@@ -986,10 +1086,11 @@ struct WaveIpm {
       dd2[i] = (in && su[i] < kInf) ? (muv + d[i] * dsi) / (su[i] - ss[i]) - keep * d[i] : 0.0;
     }
     P::sync();
+    W_P1(11);
     return true;
   }
   // Ipm::max_step_primal
-  DNLP_HD static double max_step_primal(DNLP_WLDS WState* S, double tauv) {
+  DNLP_HD static double max_step_primal(WS* S, double tauv) {
     const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *xx = S->x, *ss = S->s, *ddx = S->dx, *dds = S->ds, *eq = S->eq;
     double ax = -kInf, as = -kInf;
     W_FOR(j, S->N) {
@@ -1010,7 +1111,7 @@ struct WaveIpm {
     return std::min(1.0, std::min(rx_, rs_));
   }
   // Ipm::max_step_dual
-  DNLP_HD static double max_step_dual(DNLP_WLDS WState* S, double tauv) {
+  DNLP_HD static double max_step_dual(WS* S, double tauv) {
     const WD *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU, *da = S->dzL, *db = S->dzU, *dc = S->dvL, *dd2 = S->dvU;
     double az = -kInf, av = -kInf;
     W_FOR(j, S->N) {
@@ -1029,9 +1130,10 @@ struct WaveIpm {
     return std::min(1.0, std::min(rz, rv));
   }
   // Ipm::max_steps: both fraction-to-boundary step sizes in one pass
-  DNLP_WFN DNLP_HD static D2 max_steps(DNLP_WLDS WState* S, double tauv) {
+  DNLP_WFN DNLP_HD static D2 max_steps(WS* S, double tauv) {
     const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *xx = S->x, *ss = S->s, *ddx = S->dx, *dds = S->ds, *eq = S->eq;
     const WD *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU, *da = S->dzL, *db = S->dzU, *dc = S->dvL, *dd2 = S->dvU;
+    W_P0();
     double a0 = -kInf, a1 = -kInf;
     W_FOR(j, S->N) {
       double tp = 1.0, td = 1.0;
@@ -1052,10 +1154,11 @@ struct WaveIpm {
       a0 = mnin(a0, tp); a1 = mnin(a1, td);
     }
     a0 = P::vmax(a0); a1 = P::vmax(a1);
+    W_P1(12);
     return D2{std::min(1.0, -a0), std::min(1.0, -a1)};
   }
   // Ipm::check_convergence
-  DNLP_HD static int check_convergence(DNLP_WLDS WState* S, const WErr& e0) {
+  DNLP_HD static int check_convergence(WS* S, const WErr& e0) {
     const IpmOptions& opt = S->opt;
     const double unsc_du = e0.dual / S->sf, unsc_pr = e0.primal_unscaled, unsc_co = e0.cmpl / S->sf;
     S->inf_pr = unsc_pr; S->inf_du = unsc_du; S->cmpl = unsc_co; S->nlp_error = e0.total;
@@ -1067,17 +1170,19 @@ struct WaveIpm {
     if (opt.acceptable_iter > 0 && S->acceptable_count >= opt.acceptable_iter) return Solved_To_Acceptable_Level;
     return 99;
   }
-  DNLP_HD static WErr cached_err(DNLP_WLDS WState* S) {
+  DNLP_HD static WErr cached_err(WS* S) {
     return WErr{S->e_dual, S->e_primal, S->e_cmpl, S->e_sd, S->e_sc, S->e_total, S->e_primal_unscaled};
   }
-  DNLP_HD static void cache_err(DNLP_WLDS WState* S, const WErr& e) {
+  DNLP_HD static void cache_err(WS* S, const WErr& e) {
     S->e_dual = e.dual; S->e_primal = e.primal; S->e_cmpl = e.cmpl; S->e_sd = e.sd; S->e_sc = e.sc; S->e_total = e.total;
     S->e_primal_unscaled = e.primal_unscaled;
     S->e_cached_valid = true;
   }
 
   // Ipm::step
-  DNLP_WFN DNLP_HD static int step(DNLP_WLDS WState* S) {
+  // (inlined into its callers' loops: as a called function it saved and restored ~75 callee-saved VGPRs per iteration —
+  //  150 scratch operations, 22 KB of HBM writes per iteration over the launch)
+  DNLP_WINL DNLP_HD static int step(WS* S) {
     const int N = S->N, m = S->m;
     if (!S->initialized) return S->status = Internal_Error;
     const WErr e0 = S->e_cached_valid ? cached_err(S) : error(S, 0.0);
@@ -1093,13 +1198,14 @@ struct WaveIpm {
       xm = P::vmax(xm);
       if (!(xm <= S->opt.diverging_iterates_tol)) return S->status = Diverging_Iterates;
     }
-    const bool want_oracle = update_mu(S, e0);
+    bool want_oracle;
+    { W_P0(); want_oracle = update_mu(S, e0); W_P1(18); }
     eval_hessian(S);
     barrier_terms(S, S->mu);
     double dw = 0.0, dc = 0.0;
-    if (!factor_with_inertia(S, dw, dc)) return S->status = Error_In_Step_Computation;
+    { W_P0(); const bool okf = factor_with_inertia(S, dw, dc); W_P1(19); if (!okf) return S->status = Error_In_Step_Computation; }
     bool have_dir = false;
-    if (want_oracle) have_dir = quality_function_mu(S, dw);
+    if (want_oracle) { W_P0(); have_dir = quality_function_mu(S, dw); W_P1(20); }
     if (!have_dir) {
       barrier_terms(S, S->mu);
       if (!compute_direction(S, S->mu, S->rp, dw, false, 0)) return S->status = Error_In_Step_Computation;
@@ -1116,6 +1222,7 @@ struct WaveIpm {
     }
     // ---- backtracking filter line search (WB Algorithm A, steps A-5) ----
     const double mu = S->mu, tau = S->tau;
+    W_P0();
     const D2 steps = max_steps(S, tau);
     const double a_max = steps.first;
     double a_z = steps.second;
@@ -1148,8 +1255,11 @@ struct WaveIpm {
     double th_t = 0.0, ph_t = 0.0, f_t = 0.0;
     while (true) {
       ++ls;
+      bool fin;
+      { W_P0();
       trial_point(S, alpha);
-      bool fin = eval_fg(S, S->xt, f_t, S->gt);
+      fin = eval_fg(S, S->xt, f_t, S->gt);
+      W_P1(13); }
       if (fin) {
         const WMeasures mt = measures(S, f_t, S->gt, S->xt, S->st, mu);
         th_t = mt.theta;
@@ -1178,6 +1288,7 @@ struct WaveIpm {
       if (alpha < a_min || ls > 60) break;
     }
     const double alpha_used = alpha;
+    W_P1(23);
     if (!accepted) {
       if (S->opt.restoration && restoration_phase(S, theta_k)) {
         ++S->iter;
@@ -1216,7 +1327,7 @@ struct WaveIpm {
   }
 
   // Ipm::trial_point
-  DNLP_HD static void trial_point(DNLP_WLDS WState* S, double alpha) {
+  DNLP_HD static void trial_point(WS* S, double alpha) {
     WD *a = S->xt, *b = S->st;
     const WD *xx = S->x, *ss = S->s, *ddx = S->dx, *dds = S->ds, *eq = S->eq, *sl = S->sL;
     W_FOR(k, S->N) a[k] = xx[k] + alpha * ddx[k];
@@ -1224,7 +1335,8 @@ struct WaveIpm {
     P::sync();
   }
   // Ipm::accept_trial (+ reset_bound_multipliers, WB eq. (16), after the derivatives as there)
-  DNLP_WFN DNLP_HD static void accept_trial(DNLP_WLDS WState* S, double alpha, double a_z, double f_new) {
+  DNLP_WFN DNLP_HD static void accept_trial(WS* S, double alpha, double a_z, double f_new) {
+    W_P0();
     const int N = S->N, m = S->m;
     {
       WD *xx = S->x, *ss = S->s, *yy = S->y, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU, *gg = S->g;
@@ -1237,8 +1349,9 @@ struct WaveIpm {
     sweep(S, S->x, false);
     eval_derivs(S);
     reset_bound_multipliers(S);
+    W_P1(14);
   }
-  DNLP_HD static void reset_bound_multipliers(DNLP_WLDS WState* S) {
+  DNLP_HD static void reset_bound_multipliers(WS* S) {
     const double kS = 1e10, muv = S->mu;
     const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *xx = S->x, *ss = S->s, *eq = S->eq;
     WD *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU;
@@ -1254,7 +1367,7 @@ struct WaveIpm {
     P::sync();
   }
   // Ipm::second_order_correction (WB section 2.4)
-  DNLP_WFN DNLP_HD static bool second_order_correction(DNLP_WLDS WState* S, double alpha, double dw, double theta_k, double phi_k, double gphid,
+  DNLP_WFN DNLP_HD static bool second_order_correction(WS* S, double alpha, double dw, double theta_k, double phi_k, double gphid,
                                               double& th_t, double& ph_t, double& f_t, bool& ftype) {
     const double k_soc = 0.99, g_th = 1e-5, g_ph = 1e-8, dlt = 1.0, s_th = 1.1, s_ph = 2.3, eta = 1e-8;
     const double macheps = 2.220446049250313e-16;
@@ -1296,7 +1409,7 @@ struct WaveIpm {
   }
 
   // Ipm::avg_complementarity
-  DNLP_HD static double avg_complementarity(DNLP_WLDS WState* S) {
+  DNLP_HD static double avg_complementarity(WS* S) {
     const i64 nb = n_bound_mults(S);
     if (nb == 0) return 0.0;
     const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *xx = S->x, *ss = S->s, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU, *eq = S->eq;
@@ -1317,13 +1430,14 @@ struct WaveIpm {
     }
     return P::sum(acc) / static_cast<double>(nb);
   }
-  DNLP_HD static double mu_floor_now(DNLP_WLDS WState* S) {
-    const double t = std::min(S->opt.tol, S->opt.compl_inf_tol);
-    if (S->opt.mu_strategy == 0) return std::max(S->opt.mu_min, t / 11.0);
-    return std::min(S->opt.mu_min, 0.5 * t);
+  DNLP_HD static double mu_floor_now(WS* S) {
+    const double tol = S->opt.tol, ctol = S->opt.compl_inf_tol, mu_min = S->opt.mu_min;
+    const double t = std::min(tol, ctol);
+    if (S->opt.mu_strategy == 0) return std::max(mu_min, t / 11.0);
+    return std::min(mu_min, 0.5 * t);
   }
   // Ipm::monotone_update
-  DNLP_WFN DNLP_HD static void monotone_update(DNLP_WLDS WState* S) {
+  DNLP_WFN DNLP_HD static void monotone_update(WS* S) {
     const double k_eps = 10.0, k_mu = 0.2, th_mu = 1.5;
     const double mu_floor = mu_floor_now(S);
     for (int k = 0; k < 50; ++k) {
@@ -1339,12 +1453,12 @@ struct WaveIpm {
       }
     }
   }
-  DNLP_HD static void hist_push(DNLP_WLDS WState* S, double v) {
+  DNLP_HD static void hist_push(WS* S, double v) {
     if (S->n_hist == 4) { for (int k = 1; k < 4; ++k) S->kkt_hist[k - 1] = S->kkt_hist[k]; --S->n_hist; }
     S->kkt_hist[S->n_hist++] = v;
   }
   // Ipm::update_mu
-  DNLP_HD static bool update_mu(DNLP_WLDS WState* S, const WErr& e0) {
+  DNLP_HD static bool update_mu(WS* S, const WErr& e0) {
     if (n_bound_mults(S) == 0) { S->tau = 0.99; return false; }
     if (S->opt.mu_strategy == 0) { monotone_update(S); return false; }
     const double mu_floor = mu_floor_now(S);
@@ -1373,7 +1487,8 @@ struct WaveIpm {
   }
 
   // one evaluation of the quality function (the lambda qf of Ipm::quality_function_mu)
-  DNLP_WFN DNLP_HD static double quality(DNLP_WLDS WState* S, double sigma, double avg, double nd2, double np2, double n_dual, double n_pri, i64 nb) {
+  DNLP_WFN DNLP_HD static double quality(WS* S, double sigma, double avg, double nd2, double np2, double n_dual, double n_pri, i64 nb) {
+    W_P0();
     const double mus = sigma * avg;
     const double tv = std::max(0.99, 1.0 - mus);
     const WD *ax = S->dir[1][0], *as = S->dir[1][1], *aa = S->dir[1][3], *ab = S->dir[1][4], *ac = S->dir[1][5], *ad = S->dir[1][6];
@@ -1423,11 +1538,12 @@ struct WaveIpm {
       comp += v;
     }
     comp = P::sum(comp);
+    W_P1(10);
     return (1.0 - adv) * (1.0 - adv) * nd2 / n_dual + (1.0 - apv) * (1.0 - apv) * np2 / n_pri + comp / static_cast<double>(nb);
   }
   struct QfArgs { double avg, nd2, np2, n_dual, n_pri; i64 nb; };
   // golden section in log(sigma) + IPOPT's end-point check (the lambda `section` of Ipm::quality_function_mu)
-  DNLP_WFN DNLP_HD static double section(DNLP_WLDS WState* S, const QfArgs& A, double slo, double sup, double& fsel, bool& endpoint) {
+  DNLP_WFN DNLP_HD static double section(WS* S, const QfArgs& A, double slo, double sup, double& fsel, bool& endpoint) {
     auto qf = [&](double sg) { return quality(S, sg, A.avg, A.nd2, A.np2, A.n_dual, A.n_pri, A.nb); };
     const double gr = 0.5 * (3.0 - std::sqrt(5.0));
     double la = std::log(slo), lb = std::log(std::max(sup, slo * (1 + 1e-12)));
@@ -1446,8 +1562,9 @@ struct WaveIpm {
     return sg;
   }
   // Ipm::quality_function_mu
-  DNLP_WFN DNLP_HD static bool quality_function_mu(DNLP_WLDS WState* S, double dw) {
+  DNLP_WFN DNLP_HD static bool quality_function_mu(WS* S, double dw) {
     const int N = S->N, m = S->m;
+    W_P0();
     const double avg = avg_complementarity(S);
     const i64 nb = n_bound_mults(S);
     if (!(avg > 0.0) || nb == 0) return false;
@@ -1462,6 +1579,7 @@ struct WaveIpm {
       nd2 = P::sum(s0);
       np2 = m ? P::sum(s1) : 0.0;
     }
+    W_P1(17);
     if (!compute_direction(S, 0.0, S->rp, dw, false, 1)) return false;
     const double ratio_aff = S->last_ratio;
     {
@@ -1546,7 +1664,7 @@ struct WaveIpm {
   }
 
   // Ipm::restoration_phase
-  DNLP_WFN DNLP_HD static bool restoration_phase(DNLP_WLDS WState* S, double theta_k) {
+  DNLP_WFN DNLP_HD static bool restoration_phase(WS* S, double theta_k) {
     const int N = S->N, m = S->m;
     const double phi_k = barrier_at(S, S->f, S->x, S->s, S->mu);
     filter_add(S, (1.0 - 1e-5) * theta_k, phi_k - 1e-8 * theta_k);
@@ -1622,7 +1740,7 @@ struct WaveIpm {
   }
 
   // Ipm::polish
-  DNLP_WFN DNLP_HD static void polish(DNLP_WLDS WState* S) {
+  DNLP_WFN DNLP_HD static void polish(WS* S) {
     const int N = S->N, m = S->m;
     WD* sv[7] = {S->x, S->s, S->y, S->zL, S->zU, S->vL, S->vU};
     const int sz[7] = {N, m, m, N, N, m, m};
@@ -1654,7 +1772,8 @@ struct WaveIpm {
   }
 
   // Ipm::solve (the retry ladder included)
-  DNLP_WFN DNLP_HD static int solve(DNLP_WLDS WState* S) {
+  DNLP_WFN DNLP_HD static int solve(WS* S) {
+    W_P0();
     const double t_all = now_sec();
     S->in_solve = true;
     S->bail = false;
@@ -1665,6 +1784,7 @@ struct WaveIpm {
     S->initialized = false;
     S->iter = 0;
     S->f = 0.0;
+    bind_params(S);
     int rc = begin(S);
     if (rc != 0) { S->in_solve = false; return rc; }
     while (step(S) == 99) {}
@@ -1701,6 +1821,7 @@ struct WaveIpm {
     S->in_solve = false;
     S->wall = now_sec() - t_all;
     if (S->bail) S->status = kWaveNeedsGeneric;
+    W_P1(0);
     return S->status;
   }
 #undef W_FOR

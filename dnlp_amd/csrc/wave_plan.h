@@ -37,10 +37,11 @@ struct WaveHdr {
   // static-pattern LDL^T
   i32 sp_nblk, sp_nvals, sp_nlev, sp_ngrp, sp_nfwd, sp_ntrip, sp_rows;
   i32 bnode, soff, loff, doff, lev_off, sblk, sidx, lev_f, fnode, foff, fa, fu0, fu1, lev_g, gdst, goff, tau, tav, hpos, jpos, dpos;
+  i32 lev_r, lev_t, lev_fe, lev_pad;          // per level (nlev + 1 each): first struct row, first update triple, first gathered row
   // data row of an instance (doubles; batch.h BatchLayout)
   i32 l_c0, l_c, l_b, l_Jc, l_G, l_Mg, l_Mw, l_MJ, l_MH, l_fp, l_fp2, l_x0, l_lb, l_ub, l_cl, l_cu, l_total;
-  i32 state_doubles;                          // solver state of one instance (wave_ipm.h w_layout)
-  i32 pad;
+  i32 state_doubles;                          // solver state of one instance (wave_ipm.h layout)
+  i32 scr_doubles;                            // its scratch array: the largest phase of products (wave_ipm.h run_sum)
 };
 static_assert(sizeof(WaveHdr) % 8 == 0, "the tables behind the header start 8-byte aligned");
 
@@ -61,10 +62,10 @@ inline WaveLayoutIn wave_layout_of(const Tape<E>& t) {
 }
 
 // doubles of per-instance solver state (the order of wave_ipm.h w_layout)
-inline i64 wave_state_doubles(i64 N, i64 m, i64 Z, i64 nd, i64 nh, i64 nnzJ, i64 nnzH, i64 nvals, i64 nblk) {
+inline i64 wave_state_doubles(i64 N, i64 m, i64 Z, i64 nd, i64 nh, i64 nnzJ, i64 nnzH, i64 nvals, i64 nblk, i64 scr, i64 nunits) {
   auto ev = [](i64 n) { return (n + 1) & ~static_cast<i64>(1); };      // 16-byte granules
   return 20 * ev(N) + 29 * ev(m) + 4 * ev(N + m) + ev(nnzJ) + ev(N + Z) + ev(nd) + ev(nh) + ev(Z) + ev(1 + m) + ev(nnzH) +
-         ev(nvals) + ev(nvals + 3 * nblk + 8);
+         ev(nvals) + ev(nvals + 3 * nblk + 8) + ev(scr) + 3 * ev(nunits);
 }
 
 // Why a template cannot take the wavefront solver ("" = it can).  The generic kernel stays the solver of everything else.
@@ -159,11 +160,29 @@ inline std::vector<i32> build_wave_plan(E* ex, const Tape<E>& t, const SparsePla
   h.bnode = put(sp.bnode); h.soff = put(sp.soff); h.loff = put(sp.loff); h.doff = put(sp.doff); h.lev_off = put(sp.lev_off);
   h.sblk = put(sp.sblk); h.sidx = put(sp.sidx); h.lev_f = put(sp.lev_f); h.fnode = put(sp.fnode); h.foff = put(sp.foff);
   h.fa = put(sp.fa); h.fu0 = put(sp.fu0); h.fu1 = put(sp.fu1); h.lev_g = put(sp.lev_g); h.gdst = put(sp.gdst); h.goff = put(sp.goff);
+  {
+    const size_t nl = sp.lev_off.size();
+    std::vector<i32> lr(nl), lt(nl), lfe(nl);
+    for (size_t l = 0; l < nl; ++l) {
+      lr[l] = sp.soff[static_cast<size_t>(sp.lev_off[l])];
+      lt[l] = sp.goff[static_cast<size_t>(sp.lev_g[l])];
+      lfe[l] = sp.foff[static_cast<size_t>(sp.lev_f[l])];
+    }
+    h.lev_r = put(lr); h.lev_t = put(lt); h.lev_fe = put(lfe);
+  }
   h.tau = put(sp.tau); h.tav = put(sp.tav); h.hpos = put(sp.hpos); h.jpos = put(sp.jpos); h.dpos = put(sp.dpos);
   h.l_c0 = narrow(lay.c0); h.l_c = narrow(lay.c); h.l_b = narrow(lay.b); h.l_Jc = narrow(lay.Jc); h.l_G = narrow(lay.G); h.l_Mg = narrow(lay.Mg);
   h.l_Mw = narrow(lay.Mw); h.l_MJ = narrow(lay.MJ); h.l_MH = narrow(lay.MH); h.l_fp = narrow(lay.fp); h.l_fp2 = narrow(lay.fp2);
   h.l_x0 = narrow(lay.x0); h.l_lb = narrow(lay.lb); h.l_ub = narrow(lay.ub); h.l_cl = narrow(lay.cl); h.l_cu = narrow(lay.cu); h.l_total = narrow(lay.total);
-  h.state_doubles = narrow(wave_state_doubles(t.N, t.m, t.Z, t.nd, t.nh, t.nnzJ, t.nnzH, sp.nvals, sp.nblk()));
+  {
+    // the largest phase of products: a level's update triples (wave_ipm.h ldl_factor)
+    i64 scr = 1;
+    const size_t nlev = sp.lev_off.size() - 1;
+    for (size_t lev = 0; lev < nlev; ++lev)
+      scr = std::max<i64>(scr, sp.goff[static_cast<size_t>(sp.lev_g[lev + 1])] - sp.goff[static_cast<size_t>(sp.lev_g[lev])]);
+    h.scr_doubles = narrow(scr);
+  }
+  h.state_doubles = narrow(wave_state_doubles(t.N, t.m, t.Z, t.nd, t.nh, t.nnzJ, t.nnzH, sp.nvals, sp.nblk(), h.scr_doubles, h.nunits));
   h.total = narrow(static_cast<i64>(out.size()));
   std::memcpy(out.data(), &h, sizeof h);
   return out;

@@ -156,6 +156,13 @@ int dnlp_batch_set_affine_map(dnlp_problem* p, int n_params, const double* d0, c
 int dnlp_solve_batch_theta(dnlp_problem* p, int batch, const double* theta, int n_params, double* x, double* obj,
                            double* mult_g, double* mult_x_L, double* mult_x_U, int* status, int* iters,
                            int* factorizations, double* kernel_seconds, double* times);
+
+/* What the LAST dnlp_solve_batch* call of this handle launched (diagnostics; the reference has no counterpart —
+ * its loop of problems/problem.py:1256-1269 is serial).  out[0] grid, [1] lanes per workgroup, [2] LDS mode,
+ * [3] instances resident per compute unit, [4] 1 = packed generic kernel, [5] 1 = longest-first order,
+ * [6] wavefront solver form (0: the generic kernel; else 100 x wavefronts per workgroup + 10 x state in LDS +
+ * plan in LDS; csrc/wave_batch.h), [7] instances the wavefront solver handed to the generic kernel. */
+int dnlp_batch_launch_info(dnlp_problem* p, int32_t* out8);
 /* f and grad f of the USER's variables from the fused element program of an unconstrained
  * elementwise-sum objective (tape arrays fz_*, dnlp_amd/fused.py; BASELINE config C2): one kernel,
  * x read once, grad accumulated once — eval_f + eval_grad_f of nlp_solver.py:212-235 on the

@@ -80,11 +80,15 @@ extern "C" void orc_blocked_ldlt_phases(double* out4) {
 
 namespace {
 struct HostLane {
+  typedef double D;
+  typedef const dnlp::i32 I;
   static constexpr int lanes = 1;
   static int lane() { return 0; }
   static void sync() {}
   static double sum(double v) { return v; }
   static double vmax(double v) { return v; }
+  static int tab_load(const dnlp::i32*, int) { return 0; }
+  static int tab_at(const dnlp::i32* tab, int, int idx, int) { return tab[idx]; }
 };
 }  // namespace
 
@@ -112,7 +116,7 @@ extern "C" int orc_wave_solve_batch(orc_problem* vp, int batch, const double* da
       if (std::getenv("DNLP_WAVE_DEBUG")) {
         const WaveHdr* hh = reinterpret_cast<const WaveHdr*>(blk.data());
         std::fprintf(stderr, "[wave] plan block %d ints (%.1f KB), state %d doubles (%.1f KB), WState %zu B; units %d, nvals %d, blocks %d, levels %d, triples %d\n",
-                     hh->total, hh->total * 4 / 1024.0, hh->state_doubles, hh->state_doubles * 8 / 1024.0, sizeof(WState), hh->nunits, hh->sp_nvals, hh->sp_nblk, hh->sp_nlev, hh->sp_ntrip);
+                     hh->total, hh->total * 4 / 1024.0, hh->state_doubles, hh->state_doubles * 8 / 1024.0, sizeof(WaveIpm<HostLane>::WState), hh->nunits, hh->sp_nvals, hh->sp_nblk, hh->sp_nlev, hh->sp_ntrip);
       }
     }
     const bool fb = (t.N + t.m) <= 512 && p->linear_solver != 2;
@@ -126,9 +130,9 @@ extern "C" int orc_wave_solve_batch(orc_problem* vp, int batch, const double* da
       }
       std::copy(sp2 + t.nseg, sp2 + t.nseg + tail, row.begin() + lay.x0);
       if (which == 0) {
-        WState S;
+        WaveIpm<HostLane>::WState S;
         std::fill(state.begin(), state.end(), 0.0);
-        WaveIpm<HostLane>::layout(&S, blk.data(), state.data());
+        WaveIpm<HostLane>::layout(&S, reinterpret_cast<const WaveHdr*>(blk.data()), blk.data(), state.data());
         S.row = row.data();
         S.ws_g = S.ws_l = S.ws_u = nullptr;
         S.fallback_max_n = fb ? 512 : 0;
@@ -171,4 +175,30 @@ extern "C" int orc_wave_solve_batch(orc_problem* vp, int batch, const double* da
       }
     }
     return 0;)
+}
+
+// plan statistics per level (tools / tests: what the wavefront solver's level phases are made of)
+extern "C" int orc_wave_plan_levels(orc_problem* vp, int32_t* out, int cap) {
+  using namespace dnlp;
+  orc_problem_t* p = vp;
+  DNLP_TRY(
+    p->plan_linear_solver();
+    if (!p->use_sparse) return -1;
+    const SparsePlanHost& sp = p->sparse_plan;
+    const int nlev = static_cast<int>(sp.lev_off.size()) - 1;
+    int w = 0;
+    for (int l = 0; l < nlev && w + 8 <= cap; ++l) {
+      const int b0 = sp.lev_off[l], b1 = sp.lev_off[l + 1];
+      int maxs = 0, two = 0;
+      for (int k = b0; k < b1; ++k) { maxs = std::max(maxs, sp.soff[k + 1] - sp.soff[k]); two += sp.bnode[2 * k + 1] >= 0; }
+      const int g0 = sp.lev_g[l], g1 = sp.lev_g[l + 1];
+      int maxg = 0;
+      for (int g = g0; g < g1; ++g) maxg = std::max(maxg, sp.goff[g + 1] - sp.goff[g]);
+      const int h0 = sp.lev_f[l], h1 = sp.lev_f[l + 1];
+      int maxf = 0;
+      for (int h = h0; h < h1; ++h) maxf = std::max(maxf, sp.foff[h + 1] - sp.foff[h]);
+      out[w++] = b1 - b0; out[w++] = two; out[w++] = sp.soff[b1] - sp.soff[b0]; out[w++] = maxs;
+      out[w++] = g1 - g0; out[w++] = sp.goff[g1] - sp.goff[g0]; out[w++] = maxg; out[w++] = (h1 - h0) * 1000 + maxf;
+    }
+    return nlev;)
 }
