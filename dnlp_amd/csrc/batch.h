@@ -614,7 +614,13 @@ struct BatchRunner {
     }
     last_wave = 0;
     last_wave_refused = 0;
-    if (allow_wave && !(std::getenv("DNLP_BATCH_WAVE") && std::atoi(std::getenv("DNLP_BATCH_WAVE")) == 0) && wave_prepare()) {
+    // (templates whose state does not fit LDS keep the generic kernel, which gives such an instance four wavefronts —
+    //  measured at 1024 instances: power flow 5.3 k problems/s against 3.9 k through the one-wavefront global-memory form,
+    //  path planning 4.5 against 4.8; DNLP_BATCH_WAVE=2 takes the wavefront solver for them too, 0 never)
+    const int wave_env = std::getenv("DNLP_BATCH_WAVE") ? std::atoi(std::getenv("DNLP_BATCH_WAVE")) : 1;
+    bool take_wave = allow_wave && wave_env != 0 && wave_prepare();
+    if (take_wave && wave_env != 2) { int nw = 0, sl = 0, pl = 0; wave_form(nw, sl, pl); take_wave = sl != 0; }
+    if (take_wave) {
       solve_wave(a, batch, data, theta, opt, x_out, obj_out, multg_out, zl_out, zu_out, status_out, iters_out, nfact_out, seconds, times_out);
       return;
     }
@@ -904,6 +910,26 @@ struct BatchRunner {
   // The same launch through the wavefront solver (the caller has generated a.slabs).  Instances it refuses
   // (kWaveNeedsGeneric: a structurally singular static pivot sequence, the generic kernel's Bunch-Kaufman switch) are
   // solved by the generic kernel in a second, small launch and their results merged.
+  // launch form of this template: wavefronts per workgroup, state in LDS, plan in LDS — the richest that fits 160 KB
+  void wave_form(int& nw, int& sl, int& pl) {
+    const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(wave_blk.data());
+    const size_t plan_b = wave_fits16 ? ((static_cast<size_t>(h.total) * 2 + 15) & ~static_cast<size_t>(15)) : (static_cast<size_t>(1) << 30);
+    const size_t state_b = static_cast<size_t>(h.state_doubles) * 8;
+    const size_t cap = 160 * 1024 - 256;
+    if (plan_b + 4 * state_b + wave_static_lds<4, true, true>() <= cap) { nw = 4; sl = 1; pl = 1; }
+    else if (plan_b + 2 * state_b + wave_static_lds<2, true, true>() <= cap) { nw = 2; sl = 1; pl = 1; }
+    else if (plan_b + state_b + wave_static_lds<1, true, true>() <= cap) { nw = 1; sl = 1; pl = 1; }
+    else if (2 * state_b + wave_static_lds<2, true, false>() <= cap) { nw = 2; sl = 1; pl = 0; }
+    else if (state_b + wave_static_lds<1, true, false>() <= cap) { nw = 1; sl = 1; pl = 0; }
+    else { nw = 4; sl = 0; pl = 0; }
+    if (const char* e = std::getenv("DNLP_WAVE_FORM")) {        // experiments: "411", "211", "111", "210", "110", "400"
+      const int f = std::atoi(e);
+      if (f > 0) {
+        nw = f / 100; sl = (f / 10) % 10; pl = f % 10;
+        if (pl && !wave_fits16) throw std::runtime_error("wavefront solver: this plan does not fit 16-bit tables");
+      }
+    }
+  }
   template <int NW, bool SL, bool PL>
   void launch_wave(const WaveArgs& w, int grid, unsigned lds, hipStream_t stream) {
     const void* k = reinterpret_cast<const void*>(wave_batch_kernel<NW, SL, PL>);
@@ -934,22 +960,10 @@ struct BatchRunner {
       DNLP_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ex->device));
       this->ncu = v;
     }
-    const size_t plan_b = wave_fits16 ? ((static_cast<size_t>(h.total) * 2 + 15) & ~static_cast<size_t>(15)) : (static_cast<size_t>(1) << 30);
-    const size_t state_b = static_cast<size_t>(h.state_doubles) * 8;
-    const size_t cap = 160 * 1024 - 256;
-    // form: (wavefronts per workgroup, state in LDS, plan in LDS)
     int nw = 0, sl = 0, pl = 0;
-    if (plan_b + 4 * state_b + wave_static_lds<4, true, true>() <= cap) { nw = 4; sl = 1; pl = 1; }
-    else if (plan_b + 2 * state_b + wave_static_lds<2, true, true>() <= cap) { nw = 2; sl = 1; pl = 1; }
-    else if (plan_b + state_b + wave_static_lds<1, true, true>() <= cap) { nw = 1; sl = 1; pl = 1; }
-    else if (2 * state_b + wave_static_lds<2, true, false>() <= cap) { nw = 2; sl = 1; pl = 0; }
-    else if (state_b + wave_static_lds<1, true, false>() <= cap) { nw = 1; sl = 1; pl = 0; }
-    else { nw = 4; sl = 0; pl = 0; }
-    if (const char* e = std::getenv("DNLP_WAVE_FORM")) {        // experiments: "411", "211", "111", "210", "110", "400"
-      const int f = std::atoi(e);
-      nw = f / 100; sl = (f / 10) % 10; pl = f % 10;
-      if (pl && !wave_fits16) throw std::runtime_error("wavefront solver: this plan does not fit 16-bit tables");
-    }
+    wave_form(nw, sl, pl);
+    const size_t plan_b = wave_fits16 ? ((static_cast<size_t>(h.total) * 2 + 15) & ~static_cast<size_t>(15)) : 0;
+    const size_t state_b = static_cast<size_t>(h.state_doubles) * 8;
     WaveArgs w;
     w.blk = d_wave_blk; w.blk_ints = h.total;
     w.rows = a.slabs; w.row_doubles = lay.total;
@@ -1070,7 +1084,10 @@ struct BatchRunner {
     release();
     // the refused instances, through the generic kernel
     std::vector<int> refused;
-    for (int k = 0; k < batch; ++k) if (st_host[k] == kWaveNeedsGeneric) refused.push_back(k);
+    // (DNLP_WAVE_REFUSE_EVERY=k, tests: every k-th instance is treated as refused — the merge path without waiting for a
+    //  structurally singular pivot sequence to come along)
+    const int refuse_every = std::getenv("DNLP_WAVE_REFUSE_EVERY") ? std::atoi(std::getenv("DNLP_WAVE_REFUSE_EVERY")) : 0;
+    for (int k = 0; k < batch; ++k) if (st_host[k] == kWaveNeedsGeneric || (refuse_every > 0 && k % refuse_every == 0)) refused.push_back(k);
     last_wave_refused = static_cast<int>(refused.size());
     if (!refused.empty()) {
       const int nb = static_cast<int>(refused.size());
@@ -1090,6 +1107,7 @@ struct BatchRunner {
         }
         set_warm_start(nb, g2.data(), l2.data(), u2.data());
       }
+      const int wave_form = last_wave;
       const std::vector<int> keep_iters = prev_iters;
       const uint64_t keep_key = prev_key;
       double sec2 = 0.0;
@@ -1097,7 +1115,6 @@ struct BatchRunner {
                  zl_out ? szl.data() : nullptr, zu_out ? szu.data() : nullptr, sst.data(), sit.data(), snf.data(), &sec2, times_out ? stm.data() : nullptr, false);
       prev_iters = keep_iters; prev_key = keep_key;
       total_sec += sec2;
-      const int wave_form = last_wave;
       for (int q = 0; q < nb; ++q) {
         const int k = refused[q];
         if (x_out) std::copy(sx.begin() + q * N, sx.begin() + (q + 1) * N, x_out + static_cast<size_t>(k) * N);

@@ -103,7 +103,8 @@ struct WStateT {
   i32 nfilt, n_hist, acceptable_count, iter, status, factorizations, nb_cache, n_eq, n_fixed, last_nneg, ladder_rung,
       sparse_singular_streak, dc_fixed_count, tiny_streak;
   bool initialized, fixed_mode, e_cached_valid, jty_valid, delta_w_used_last_iter, dc_fixed_last, always_dc, in_solve,
-       resto_stationary, bail;
+       resto_stationary, bail,
+       swept_xt;                    // the tape's z / dvals belong to the point in xt (the last sweep was a trial evaluation)
 #ifdef DNLP_WAVE_PROF
   unsigned long long prof[kWaveProfSlots];
 #endif
@@ -152,11 +153,14 @@ struct WaveIpm {
     auto take = [&](i32 n) { WD* q = p; p += (n + 1) & ~1; return q; };
     S->x = take(N); S->zL = take(N); S->zU = take(N); S->xL = take(N); S->xU = take(N); S->grad = take(N); S->dx = take(N);
     S->dzL = take(N); S->dzU = take(N); S->xt = take(N); S->Sx = take(N); S->rx = take(N); S->tN = take(N); S->fixm = take(N);
-    WD* ax = take(N); WD* azL = take(N); WD* azU = take(N); WD* cx = take(N); WD* czL = take(N); WD* czU = take(N);
+    WD* ax = take(N); WD* azL = take(N); WD* azU = take(N);
     S->s = take(m); S->y = take(m); S->vL = take(m); S->vU = take(m); S->sL = take(m); S->sU = take(m); S->eq = take(m); S->g = take(m);
     S->sg = take(m); S->ds = take(m); S->dy = take(m); S->dvL = take(m); S->dvU = take(m); S->st = take(m); S->gt = take(m); S->Dd = take(m);
     S->Ss = take(m); S->rs = take(m); S->rp = take(m); S->tM = take(m); S->csoc = take(m);
-    WD* as = take(m); WD* ay = take(m); WD* avL = take(m); WD* avU = take(m); WD* cs = take(m); WD* cy = take(m); WD* cvL = take(m); WD* cvU = take(m);
+    WD* as = take(m); WD* ay = take(m); WD* avL = take(m); WD* avU = take(m); WD* cy = take(m);
+    // the centering direction as three [variables | rows] pairs: until its outputs are written they hold the second
+    // right-hand side, solution and residual of the mu oracle's joint solve (quality_function_mu)
+    WD* cx = take(N + m); WD* cs = cx + N; WD* czL = take(N + m); WD* cvL = czL + N; WD* czU = take(N + m); WD* cvU = czU + N;
     S->rhs = take(N + m); S->sol = take(N + m); S->res = take(N + m); S->cor = take(N + m);
     S->jv = take(h->nnzJ); S->xz = take(N + h->Z); S->dvals = take(h->nd); S->hvals = take(h->nh); S->w = take(h->Z); S->sl = take(1 + m);
     S->Hs = take(h->nnzH); S->svals = take(h->sp_nvals); S->swork = take(h->sp_nvals + 3 * h->sp_nblk + 8);
@@ -181,6 +185,7 @@ struct WaveIpm {
     WD *xz = S->xz, *dv = S->dvals, *hv = S->hvals;
     const WD* ww = S->w;
     if (src != xz) { W_FOR(j, N) xz[j] = src[j]; P::sync(); }
+    S->swept_xt = src == S->xt;
     WI *uop = S->u_op, *ua0 = S->u_a0, *ua1 = S->u_a1, *uz = S->u_z, *ud0 = S->u_d0, *ud1 = S->u_d1, *uh = S->u_h, *up = S->u_p;
     const WD *up0 = S->up0, *up1 = S->up1, *ucls = S->ucls;
     W_FOR(e, nu) {
@@ -452,11 +457,13 @@ struct WaveIpm {
       const int b0 = P::tab_at(lev_off, c_off, lev, nt), b1 = P::tab_at(lev_off, c_off, lev + 1, nt);
       const int r0 = P::tab_at(lev_r, c_r, lev, nt), r1 = P::tab_at(lev_r, c_r, lev + 1, nt);
       for (int k = b0 + me; k < b1; k += L) sp_pivot(S, vals, dinv, k, nneg, nzero, bad);
+      if (r1 == r0) continue;          // (a level without struct rows — the last block: nothing to scale, nothing to update)
       P::sync();
       for (int r = r0 + me; r < r1; r += L) sp_scale(S, vals, w, dinv, r);
       P::sync();
       const int g0 = P::tab_at(lev_g, c_g, lev, nt), g1 = P::tab_at(lev_g, c_g, lev + 1, nt);
       const int t0 = P::tab_at(lev_t, c_t, lev, nt), ntr = P::tab_at(lev_t, c_t, lev + 1, nt) - t0, ngr = g1 - g0;
+      if (ntr == 0) continue;
       for (int q = me; q < ntr; q += L) scr[q] = sp_update(tau, tav, vals, w, t0 + q);
       P::sync();
       if (ngr * 8 <= L && ntr >= 16 * ngr) {
@@ -483,14 +490,34 @@ struct WaveIpm {
     W_P1(6);
     return bad == 0.0;
   }
-  DNLP_HD static double sp_fwd(WI* fa, WI* fu0, WI* fu1, const WD* vals, const WD* x, int q) {
-    const i32 a = fa[q];
-    if (a >= 0) return vals[a] * x[fu0[q]];
-    const i32 b = ~a;
-    return vals[b] * x[fu0[q]] + vals[b + 1] * x[fu1[q]];
+  // (measured on MI355X and not kept: forming the terms of four entries of a lane's run side by side so that their index and
+  //  operand loads overlap — the substitutions went from 43.6 to 49.8 k cycles per iteration, the residual pass from 14.3 to
+  //  15.4: at one wavefront per SIMD these loops are bound by the NUMBER of instructions issued, not by the LDS round trips)
+  // sparse_ldl.h sp_dsolve: D^-1 on block k of x (and y)
+  DNLP_HD static void dsolve(const WD* vals, WI* doff, i32 u0, i32 u1, int k, WD* x, WD* y) {
+    const WD* Dk = vals + doff[k];
+    if (u1 < 0) {
+      const double d = Dk[0];
+      x[u0] /= d;
+      if (y) y[u0] /= d;
+    } else {
+      const double a = Dk[0], c = Dk[1], e = Dk[2];
+      double det = a * e - c * c;
+      if (fabs(det) < 1e-300) det = -1e-20;
+      const double x0 = x[u0], x1 = x[u1];
+      x[u0] = (e * x0 - c * x1) / det;
+      x[u1] = (a * x1 - c * x0) / det;
+      if (y) {
+        const double y0 = y[u0], y1 = y[u1];
+        y[u0] = (e * y0 - c * y1) / det;
+        y[u1] = (a * y1 - c * y0) / det;
+      }
+    }
   }
-  // sparse_ldl.h sparse_ldl_solve: x <- K^-1 x
-  DNLP_WFN DNLP_WFN DNLP_HD static void ldl_solve(DNLP_WLDS WState* S, WD* x) {
+  // sparse_ldl.h sparse_ldl_solve: x <- K^-1 x — and y <- K^-1 y in the same level phases when a second right-hand side is
+  // given (the mu oracle's affine-scaling and centering systems share the factor: one walk of the index arrays, one
+  // chain of level barriers for both; each vector sees exactly the operations of a solve of its own)
+  DNLP_WFN DNLP_HD static void ldl_solve(WS* S, WD* x, WD* y) {
     W_P0();
     const int L = P::lanes, me = P::lane();
     const WD* vals = S->svals;
@@ -498,75 +525,102 @@ struct WaveIpm {
        *sidx = S->sidx, *doff = S->doff, *fa = S->fa, *fu0 = S->fu0, *fu1 = S->fu1;
     const int nlev = S->nlev, nblk = S->nblk, nt = nlev + 1;
     WI *lev_r = S->lev_r, *lev_fe = S->lev_fe;
-    const int c_f = P::tab_load(lev_f, nt), c_fe = P::tab_load(lev_fe, nt), c_off = P::tab_load(lev_off, nt), c_r = P::tab_load(lev_r, nt);
+    const bool two = y != nullptr;
     for (int lev = 1; lev < nlev; ++lev) {
-      const int h0 = P::tab_at(lev_f, c_f, lev, nt), h1 = P::tab_at(lev_f, c_f, lev + 1, nt);
+      const int h0 = lev_f[lev], h1 = lev_f[lev + 1];
       if (h1 == h0) continue;
-      const int nh = h1 - h0, nrw = P::tab_at(lev_fe, c_fe, lev + 1, nt) - P::tab_at(lev_fe, c_fe, lev, nt);
+      const int nh = h1 - h0, nrw = lev_fe[lev + 1] - lev_fe[lev];
       if (nh * 8 <= L && nrw > 2 * nh) {
         for (int hq = h0; hq < h1; ++hq) {
           const int q1 = foff[hq + 1];
-          double acc = 0.0;
-          for (int q = foff[hq] + me; q < q1; q += L) acc += sp_fwd(fa, fu0, fu1, vals, x, q);
+          double acc = 0.0, acc2 = 0.0;
+          for (int q = foff[hq] + me; q < q1; q += L) {
+            const i32 a = fa[q], u0 = fu0[q];
+            if (a >= 0) { const double l = vals[a]; acc += l * x[u0]; if (two) acc2 += l * y[u0]; }
+            else {
+              const i32 b = ~a, u1 = fu1[q];
+              const double l0 = vals[b], l1 = vals[b + 1];
+              acc += l0 * x[u0] + l1 * x[u1];
+              if (two) acc2 += l0 * y[u0] + l1 * y[u1];
+            }
+          }
           acc = P::sum(acc);
-          if (me == 0) x[fnode[hq]] -= acc;
+          if (two) acc2 = P::sum(acc2);
+          if (me == 0) { x[fnode[hq]] -= acc; if (two) y[fnode[hq]] -= acc2; }
         }
       } else {
         for (int hq = h0 + me; hq < h1; hq += L) {
           const int q1 = foff[hq + 1];
-          double acc = 0.0;
-          for (int q = foff[hq]; q < q1; ++q) acc += sp_fwd(fa, fu0, fu1, vals, x, q);
-          x[fnode[hq]] -= acc;
+          double acc = 0.0, acc2 = 0.0;
+          for (int q = foff[hq]; q < q1; ++q) {
+            const i32 a = fa[q], u0 = fu0[q];
+            if (a >= 0) { const double l = vals[a]; acc += l * x[u0]; if (two) acc2 += l * y[u0]; }
+            else {
+              const i32 b = ~a, u1 = fu1[q];
+              const double l0 = vals[b], l1 = vals[b + 1];
+              acc += l0 * x[u0] + l1 * x[u1];
+              if (two) acc2 += l0 * y[u0] + l1 * y[u1];
+            }
+          }
+          const i32 u = fnode[hq];
+          x[u] -= acc;
+          if (two) y[u] -= acc2;
         }
       }
       P::sync();
     }
-    for (int k = me; k < nblk; k += L) {
-      const i32 u0 = bnode[2 * k], u1 = bnode[2 * k + 1];
-      const WD* Dk = vals + doff[k];
-      if (u1 < 0) {
-        x[u0] /= Dk[0];
-      } else {
-        const double a = Dk[0], c = Dk[1], e = Dk[2];
-        double det = a * e - c * c;
-        if (fabs(det) < 1e-300) det = -1e-20;
-        const double x0 = x[u0], x1 = x[u1];
-        x[u0] = (e * x0 - c * x1) / det;
-        x[u1] = (a * x1 - c * x0) / det;
-      }
-    }
+    // D^-1, all blocks side by side (measured: folded into the backward pass — one level barrier less — the division
+    // joins each block's dependent chain and the solve gets 8 % slower)
+    for (int k = me; k < nblk; k += L) dsolve(vals, doff, bnode[2 * k], bnode[2 * k + 1], k, x, y);
     P::sync();
     for (int lev = nlev - 1; lev >= 0; --lev) {
-      const int b0 = P::tab_at(lev_off, c_off, lev, nt), b1 = P::tab_at(lev_off, c_off, lev + 1, nt);
-      const int nbl = b1 - b0, nrw = P::tab_at(lev_r, c_r, lev + 1, nt) - P::tab_at(lev_r, c_r, lev, nt);
+      const int b0 = lev_off[lev], b1 = lev_off[lev + 1];
+      const int nbl = b1 - b0, nrw = lev_r[lev + 1] - lev_r[lev];
+      if (nrw == 0) continue;            // (the last block: nothing to gather)
       if (nbl * 4 >= L || nrw <= 3 * nbl * nbl) {
         for (int k = b0 + me; k < b1; k += L) {
           const int s0 = soff[k], sn = soff[k + 1] - s0;
           const i32 u0 = bnode[2 * k], u1 = bnode[2 * k + 1];
           const WD* Lk = vals + loff[k];
-          double a0 = 0.0, a1 = 0.0;
-          if (u1 < 0) { for (int i = 0; i < sn; ++i) a0 += Lk[i] * x[sidx[s0 + i]]; x[u0] -= a0; }
-          else {
-            for (int i = 0; i < sn; ++i) { const double xi = x[sidx[s0 + i]]; a0 += Lk[2 * i] * xi; a1 += Lk[2 * i + 1] * xi; }
+          double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
+          if (u1 < 0) {
+            for (int i = 0; i < sn; ++i) { const i32 u = sidx[s0 + i]; const double l = Lk[i]; a0 += l * x[u]; if (two) c0 += l * y[u]; }
+            x[u0] -= a0;
+            if (two) y[u0] -= c0;
+          } else {
+            for (int i = 0; i < sn; ++i) {
+              const i32 u = sidx[s0 + i];
+              const double l0 = Lk[2 * i], l1 = Lk[2 * i + 1], xi = x[u];
+              a0 += l0 * xi; a1 += l1 * xi;
+              if (two) { const double yi = y[u]; c0 += l0 * yi; c1 += l1 * yi; }
+            }
             x[u0] -= a0; x[u1] -= a1;
+            if (two) { y[u0] -= c0; y[u1] -= c1; }
           }
         }
       } else {
         for (int k = b0; k < b1; ++k) {
           const int s0 = soff[k], sn = soff[k + 1] - s0;
-          if (sn == 0) continue;
           const i32 u0 = bnode[2 * k], u1 = bnode[2 * k + 1];
+          if (sn == 0) continue;
           const WD* Lk = vals + loff[k];
-          double a0 = 0.0, a1 = 0.0;
+          double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
           if (u1 < 0) {
-            for (int i = me; i < sn; i += L) a0 += Lk[i] * x[sidx[s0 + i]];
+            for (int i = me; i < sn; i += L) { const i32 u = sidx[s0 + i]; const double l = Lk[i]; a0 += l * x[u]; if (two) c0 += l * y[u]; }
             a0 = P::sum(a0);
-            if (me == 0) x[u0] -= a0;
+            if (two) c0 = P::sum(c0);
+            if (me == 0) { x[u0] -= a0; if (two) y[u0] -= c0; }
           } else {
-            for (int i = me; i < sn; i += L) { const double xi = x[sidx[s0 + i]]; a0 += Lk[2 * i] * xi; a1 += Lk[2 * i + 1] * xi; }
+            for (int i = me; i < sn; i += L) {
+              const i32 u = sidx[s0 + i];
+              const double l0 = Lk[2 * i], l1 = Lk[2 * i + 1], xi = x[u];
+              a0 += l0 * xi; a1 += l1 * xi;
+              if (two) { const double yi = y[u]; c0 += l0 * yi; c1 += l1 * yi; }
+            }
             a0 = P::sum(a0);
             a1 = P::sum(a1);
-            if (me == 0) { x[u0] -= a0; x[u1] -= a1; }
+            if (two) { c0 = P::sum(c0); c1 = P::sum(c1); }
+            if (me == 0) { x[u0] -= a0; x[u1] -= a1; if (two) { y[u0] -= c0; y[u1] -= c1; } }
           }
         }
       }
@@ -575,10 +629,14 @@ struct WaveIpm {
     W_P1(7);
   }
   // DenseKkt::solve (sparse) == Ipm::kkt_solve without the quasi-Newton part
-  DNLP_HD static void kkt_solve(WS* S, const WD* r, WD* out) {
+  DNLP_HD static void kkt_solve(WS* S, const WD* r, WD* out, const WD* r2 = nullptr, WD* out2 = nullptr) {
     const int n = S->N + S->m;
-    { W_P0(); if (out != r) { W_FOR(k, n) out[k] = r[k]; P::sync(); } W_P1(22); }
-    ldl_solve(S, out);
+    { W_P0();
+      if (out != r) W_FOR(k, n) out[k] = r[k];
+      if (out2 && out2 != r2) W_FOR(k, n) out2[k] = r2[k];
+      P::sync();
+      W_P1(22); }
+    ldl_solve(S, out, out2);
   }
 
   // ====================================================================================================================
@@ -992,24 +1050,53 @@ struct WaveIpm {
     S->dc_fixed_last = true;
     if (++S->dc_fixed_count >= 3 && !S->always_dc) S->always_dc = true;
   }
-  // Ipm::kkt_residual: out = rhsv - K v, max |out|, max |v|
+  // the long outputs of a product by output (more than CooIdx::kHeavy entries), by all lanes: out[g] for those only
+  DNLP_HD static void coo_heavy(const WCoo ix, const WD* a, const WD* v, WD* out) {
+    WI *ptr = ix.ptr, *ent = ix.ent, *src = ix.src;
+    for (i32 hq = 0; hq < ix.nheavy; ++hq) {
+      const i32 gq = ix.heavy[hq];
+      const i32 p0 = ptr[gq], cnt = ptr[gq + 1] - p0;
+      double sacc = 0.0;
+      W_FOR(q, cnt) sacc += a[ent[p0 + q]] * v[src[p0 + q]];
+      sacc = P::sum(sacc);
+      if (P::lane() == 0) out[gq] = sacc;
+    }
+  }
+  // one output of a product by output: its short segment walked here, or the value coo_heavy left in `pre`
+  DNLP_HD static double coo_one(const WCoo& ix, const WD* a, const WD* v, const WD* pre, int gq) {
+    const i32 p0 = ix.ptr[gq], p1 = ix.ptr[gq + 1];
+    if (p1 - p0 > static_cast<i32>(CooIdx::kHeavy)) return pre[gq];
+    double sacc = 0.0;
+    for (i32 p = p0; p < p1; ++p) sacc += a[ix.ent[p]] * v[ix.src[p]];
+    return sacc;
+  }
+  // Ipm::kkt_residual: out = rhsv - K v, max |out|, max |v|.  The three products (sym(H) v, J^T v_y, J v_x) and the
+  // combination are ONE pass: the owner of an output walks its segments of the three indices itself (the sums and their
+  // order are those of the separate products); only the long outputs are formed beforehand by all lanes.
   DNLP_WFN DNLP_HD static void kkt_residual(WS* S, const WD* v, double dw, const WD* rhsv, WD* out, double& en, double& sn) {
-    const int N = S->N, m = S->m;
-    hess_mult(S, v, out);
-    jac_tmult(S, v + N, S->xt);
-    jac_mult(S, v, S->tM);
     W_P0();
-    const WD *sx = S->Sx, *jt = S->xt, *jx = S->tM, *dd = S->Dd, *fm = S->fixm;
+    const int N = S->N, m = S->m;
+    const WCoo hs = S->hs, jc = S->jc, jr = S->jr;
+    const WD *Hs = S->Hs, *jv = S->jv;
+    WD *preH = out, *preJt = S->xt, *preJ = S->tM;
+    if (hs.nheavy | jc.nheavy | jr.nheavy) {
+      coo_heavy(hs, Hs, v, preH);
+      coo_heavy(jc, jv, v + N, preJt);
+      coo_heavy(jr, jv, v, preJ);
+      P::sync();
+    }
+    const WD *sx = S->Sx, *dd = S->Dd, *fm = S->fixm;
     double m0 = -kInf, m1 = -kInf;
     W_FOR(k, N) {
-      const double kv = fm[k] != 0.0 ? v[k] : out[k] + (sx[k] + dw) * v[k] + jt[k];
+      const double hv = coo_one(hs, Hs, v, preH, k), jt = coo_one(jc, jv, v + N, preJt, k);
+      const double kv = fm[k] != 0.0 ? v[k] : hv + (sx[k] + dw) * v[k] + jt;
       const double r = rhsv[k] - kv;
       out[k] = r;
       m0 = mxin(m0, fabs(r)); m1 = mxin(m1, fabs(v[k]));
     }
     W_FOR(i, m) {
       const int k = N + i;
-      const double kv = jx[i] - dd[i] * v[k];
+      const double kv = coo_one(jr, jv, v, preJ, i) - dd[i] * v[k];
       const double r = rhsv[k] - kv;
       out[k] = r;
       m0 = mxin(m0, fabs(r)); m1 = mxin(m1, fabs(v[k]));
@@ -1017,6 +1104,62 @@ struct WaveIpm {
     en = P::vmax(m0); sn = P::vmax(m1);
     P::sync();
     W_P1(9);
+  }
+  // the same for two systems at once (mu oracle): one walk of the three indices; the second system's long outputs in dx / ds
+  struct Res2 { double en, sn, en2, sn2; };
+  DNLP_WFN DNLP_HD static Res2 kkt_residual2(WS* S, double dw, const WD* v, const WD* rhsv, WD* out, const WD* v2, const WD* rhsv2, WD* out2) {
+    W_P0();
+    const int N = S->N, m = S->m;
+    const WCoo hs = S->hs, jc = S->jc, jr = S->jr;
+    const WD *Hs = S->Hs, *jv = S->jv;
+    WD *preH = out, *preJt = S->xt, *preJ = S->tM, *preH2 = out2, *preJt2 = S->dx, *preJ2 = S->ds;
+    if (hs.nheavy | jc.nheavy | jr.nheavy) {
+      coo_heavy(hs, Hs, v, preH); coo_heavy(jc, jv, v + N, preJt); coo_heavy(jr, jv, v, preJ);
+      coo_heavy(hs, Hs, v2, preH2); coo_heavy(jc, jv, v2 + N, preJt2); coo_heavy(jr, jv, v2, preJ2);
+      P::sync();
+    }
+    const WD *sx = S->Sx, *dd = S->Dd, *fm = S->fixm;
+    double m0 = -kInf, m1 = -kInf, n0 = -kInf, n1 = -kInf;
+    W_FOR(k, N) {
+      // both systems' segments in one walk: the entry and source indices are loaded once
+      double hv, jt, hv2, jt2;
+      {
+        const i32 p0 = hs.ptr[k], p1 = hs.ptr[k + 1];
+        if (p1 - p0 > static_cast<i32>(CooIdx::kHeavy)) { hv = preH[k]; hv2 = preH2[k]; }
+        else { double a = 0.0, b = 0.0; for (i32 p = p0; p < p1; ++p) { const double c = Hs[hs.ent[p]]; const i32 u = hs.src[p]; a += c * v[u]; b += c * v2[u]; } hv = a; hv2 = b; }
+      }
+      {
+        const i32 p0 = jc.ptr[k], p1 = jc.ptr[k + 1];
+        if (p1 - p0 > static_cast<i32>(CooIdx::kHeavy)) { jt = preJt[k]; jt2 = preJt2[k]; }
+        else { double a = 0.0, b = 0.0; for (i32 p = p0; p < p1; ++p) { const double c = jv[jc.ent[p]]; const i32 u = N + jc.src[p]; a += c * v[u]; b += c * v2[u]; } jt = a; jt2 = b; }
+      }
+      const bool fx = fm[k] != 0.0;
+      const double sd = sx[k] + dw;
+      const double kv = fx ? v[k] : hv + sd * v[k] + jt, kv2 = fx ? v2[k] : hv2 + sd * v2[k] + jt2;
+      const double r = rhsv[k] - kv, r2 = rhsv2[k] - kv2;
+      out[k] = r; out2[k] = r2;
+      m0 = mxin(m0, fabs(r)); m1 = mxin(m1, fabs(v[k]));
+      n0 = mxin(n0, fabs(r2)); n1 = mxin(n1, fabs(v2[k]));
+    }
+    W_FOR(i, m) {
+      const int k = N + i;
+      double jx, jx2;
+      {
+        const i32 p0 = jr.ptr[i], p1 = jr.ptr[i + 1];
+        if (p1 - p0 > static_cast<i32>(CooIdx::kHeavy)) { jx = preJ[i]; jx2 = preJ2[i]; }
+        else { double a = 0.0, b = 0.0; for (i32 p = p0; p < p1; ++p) { const double c = jv[jr.ent[p]]; const i32 u = jr.src[p]; a += c * v[u]; b += c * v2[u]; } jx = a; jx2 = b; }
+      }
+      const double kv = jx - dd[i] * v[k], kv2 = jx2 - dd[i] * v2[k];
+      const double r = rhsv[k] - kv, r2 = rhsv2[k] - kv2;
+      out[k] = r; out2[k] = r2;
+      m0 = mxin(m0, fabs(r)); m1 = mxin(m1, fabs(v[k]));
+      n0 = mxin(n0, fabs(r2)); n1 = mxin(n1, fabs(v2[k]));
+    }
+    Res2 R;
+    R.en = P::vmax(m0); R.sn = P::vmax(m1); R.en2 = P::vmax(n0); R.sn2 = P::vmax(n1);
+    P::sync();
+    W_P1(9);
+    return R;
   }
   // Ipm::solve_refined
   DNLP_WFN DNLP_HD static bool solve_refined(WS* S, double dw) {
@@ -1053,6 +1196,72 @@ struct WaveIpm {
     }
     return true;
   }
+  // Ipm::solve_refined for the mu oracle's two systems side by side: K sol = rhs (affine scaling) and K sol2 = rhs2
+  // (centering), each refined exactly as solve_refined refines it — the same iterates, the same stopping decisions — but
+  // in joint solves and joint residual passes while both are still going.  0: both fine; 1 / 2: the first / second met a
+  // non-finite residual (what makes solve_refined return false).  ratio / ratio2: their last_ratio_.
+  DNLP_WFN DNLP_HD static int solve_refined2(WS* S, double dw, WD* rhs2, WD* sol2, WD* res2, double& ratio_out, double& ratio2_out) {
+    const int n = S->N + S->m;
+    WD *rhs = S->rhs, *sol = S->sol, *res = S->res, *cor = S->cor;
+    kkt_solve(S, rhs, sol, rhs2, sol2);
+    double rn = -kInf, rn2 = -kInf;
+    W_FOR(i, n) { rn = mxin(rn, fabs(rhs[i])); rn2 = mxin(rn2, fabs(rhs2[i])); }
+    rn = P::vmax(rn); rn2 = P::vmax(rn2);
+    double best = kInf, best2 = kInf, lr = 0.0, lr2 = 0.0;
+    bool fresh = false, fresh2 = false, go = true, go2 = true;      // go: still inside its refinement loop
+    const int max_refine = S->opt.max_refine, min_refine = S->opt.min_refine;
+    for (int it = 0; it < max_refine && (go || go2); ++it) {
+      double en = 0.0, sn = 0.0, en2 = 0.0, sn2 = 0.0;
+      if (go && go2) { const Res2 R = kkt_residual2(S, dw, sol, rhs, res, sol2, rhs2, res2); en = R.en; sn = R.sn; en2 = R.en2; sn2 = R.sn2; }
+      else if (go) kkt_residual(S, sol, dw, rhs, res, en, sn);
+      else kkt_residual(S, sol2, dw, rhs2, res2, en2, sn2);
+      if (go) {
+        const double ratio = en / (std::max(rn, 1e-300) + sn);
+        if (!std::isfinite(en)) return 1;
+        lr = std::isfinite(ratio) ? ratio : kInf;
+        fresh = true;
+        if (it >= min_refine && ratio <= 1e-10) go = false;
+        else if (en >= best * 0.999 && it >= min_refine) go = false;
+        else best = std::min(best, en);
+      }
+      if (go2) {
+        const double ratio = en2 / (std::max(rn2, 1e-300) + sn2);
+        if (!std::isfinite(en2)) return 2;
+        lr2 = std::isfinite(ratio) ? ratio : kInf;
+        fresh2 = true;
+        if (it >= min_refine && ratio <= 1e-10) go2 = false;
+        else if (en2 >= best2 * 0.999 && it >= min_refine) go2 = false;
+        else best2 = std::min(best2, en2);
+      }
+      // correction solves of the systems still going (the second one's correction in place in its residual array)
+      if (go && go2) {
+        kkt_solve(S, res, cor, res2, res2);
+        W_FOR(i, n) { sol[i] += cor[i]; sol2[i] += res2[i]; }
+        P::sync();
+        fresh = fresh2 = false;
+      } else if (go) {
+        kkt_solve(S, res, cor);
+        W_FOR(i, n) sol[i] += cor[i];
+        P::sync();
+        fresh = false;
+      } else if (go2) {
+        kkt_solve(S, res2, res2);
+        W_FOR(i, n) sol2[i] += res2[i];
+        P::sync();
+        fresh2 = false;
+      }
+    }
+    if (!fresh || !fresh2) {
+      double en = 0.0, sn = 0.0, en2 = 0.0, sn2 = 0.0;
+      if (!fresh && !fresh2) { const Res2 R = kkt_residual2(S, dw, sol, rhs, res, sol2, rhs2, res2); en = R.en; sn = R.sn; en2 = R.en2; sn2 = R.sn2; }
+      else if (!fresh) kkt_residual(S, sol, dw, rhs, res, en, sn);
+      else kkt_residual(S, sol2, dw, rhs2, res2, en2, sn2);
+      if (!fresh) { lr = en / (std::max(rn, 1e-300) + sn); if (!std::isfinite(lr)) lr = kInf; }
+      if (!fresh2) { lr2 = en2 / (std::max(rn2, 1e-300) + sn2); if (!std::isfinite(lr2)) lr2 = kInf; }
+    }
+    ratio_out = lr; ratio2_out = lr2;
+    return 0;
+  }
   // Ipm::compute_direction; `set` picks the seven output arrays (0: dx .. dvU, 1: affine-scaling, 2: centering);
   // pres == nullptr stands for the all-zero primal residual of the centering system
   DNLP_WFN DNLP_HD static bool compute_direction(WS* S, double muv, const WD* pres, double dw, bool centering, int set) {
@@ -1065,8 +1274,15 @@ struct WaveIpm {
     P::sync();
     W_P1(11); }
     { W_P0(); const bool oks = solve_refined(S, dw); W_P1(21); if (!oks) return false; }
+    direction_outputs(S, S->sol, S->rs, muv, dw, centering, set);
+    return true;
+  }
+  // the second half of Ipm::compute_direction: the seven arrays of a direction from the solution `so` of its system
+  // (q: the slack residual the system was built with).  so / q may be the output arrays themselves (read before written).
+  DNLP_HD static void direction_outputs(WS* S, const WD* so, const WD* q, double muv, double dw, bool centering, int set) {
     W_P0();
-    const WD* so = S->sol;
+    const int N = S->N, m = S->m;
+    const WD *sS = S->Ss, *eq = S->eq;
     WD *ddx = S->dir[set][0], *dds = S->dir[set][1], *ddy = S->dir[set][2], *da = S->dir[set][3], *db = S->dir[set][4], *dc = S->dir[set][5],
        *dd2 = S->dir[set][6];
     const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *xx = S->x, *ss = S->s, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU;
@@ -1079,15 +1295,15 @@ struct WaveIpm {
     }
     W_FOR(i, m) {
       const bool in = eq[i] == 0.0;
-      const double dsi = in ? (so[N + i] - q[i]) / (sS[i] + dw) : 0.0;
-      ddy[i] = so[N + i];
+      const double soi = so[N + i], qi = q[i];
+      const double dsi = in ? (soi - qi) / (sS[i] + dw) : 0.0;
+      ddy[i] = soi;
       dds[i] = dsi;
       dc[i] = (in && sl[i] > -kInf) ? (muv - c[i] * dsi) / (ss[i] - sl[i]) - keep * c[i] : 0.0;
       dd2[i] = (in && su[i] < kInf) ? (muv + d[i] * dsi) / (su[i] - ss[i]) - keep * d[i] : 0.0;
     }
     P::sync();
     W_P1(11);
-    return true;
   }
   // Ipm::max_step_primal
   DNLP_HD static double max_step_primal(WS* S, double tauv) {
@@ -1346,7 +1562,10 @@ struct WaveIpm {
       P::sync();
     }
     S->f = f_new;
-    sweep(S, S->x, false);
+    // (Ipm::accept_trial sweeps again "in case a later trial was evaluated": the accepted point IS the last one evaluated
+    //  on every path that gets here, and then z / dvals are already those of x — the same values, one sweep less)
+    if (!S->swept_xt) sweep(S, S->x, false);
+    S->swept_xt = false;
     eval_derivs(S);
     reset_bound_multipliers(S);
     W_P1(14);
@@ -1580,22 +1799,30 @@ struct WaveIpm {
       np2 = m ? P::sum(s1) : 0.0;
     }
     W_P1(17);
-    if (!compute_direction(S, 0.0, S->rp, dw, false, 1)) return false;
-    const double ratio_aff = S->last_ratio;
+    // The two systems of the oracle — affine scaling (mu = 0, residuals rx / rs / rp) and centering (unit mu, the
+    // derivative of the barrier terms) — share the factor: both right-hand sides first, ONE refined joint solve
+    // (solve_refined2), then the two directions.  The centering system lives in the arrays of its own direction until
+    // that is written: rhs2 = [czL | cvL], sol2 = [cx | cs], res2 = [czU | cvU], its slack residual in cy.
+    WD *rhs2 = S->dir[2][3], *sol2 = S->dir[2][0], *res2 = S->dir[2][4], *q2 = S->dir[2][2];
     {
-      WD *r = S->rx, *q = S->rs;
-      const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *eq = S->eq, *xx = S->x, *ss = S->s, *fm = S->fixm;
+      W_P0();
+      WD* r = S->rhs;
+      const WD *rxx = S->rx, *q = S->rs, *pres = S->rp, *sS = S->Ss, *eq = S->eq;
+      const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *xx = S->x, *ss = S->s, *fm = S->fixm;
       const double kd = S->opt.kappa_d;
       W_FOR(j, N) {
+        r[j] = -rxx[j];
         double c = 0.0;
         const bool hl = l[j] > -kInf, hu = u[j] < kInf;
         if (hl) c -= 1.0 / (xx[j] - l[j]);
         if (hu) c += 1.0 / (u[j] - xx[j]);
         if (hl && !hu) c += kd;
         if (hu && !hl) c -= kd;
-        r[j] = fm[j] != 0.0 ? 0.0 : c;
+        const double rc = fm[j] != 0.0 ? 0.0 : c;
+        rhs2[j] = -rc;
       }
       W_FOR(i, m) {
+        r[N + i] = -pres[i] - (eq[i] == 0.0 ? q[i] / (sS[i] + dw) : 0.0);
         double c = 0.0;
         if (eq[i] == 0.0) {
           const bool hl = sl[i] > -kInf, hu = su[i] < kInf;
@@ -1604,11 +1831,22 @@ struct WaveIpm {
           if (hl && !hu) c += kd;
           if (hu && !hl) c -= kd;
         }
-        q[i] = c;
+        q2[i] = c;
+        rhs2[N + i] = -0.0 - (eq[i] == 0.0 ? c / (sS[i] + dw) : 0.0);
       }
       P::sync();
+      W_P1(11);
     }
-    if (!compute_direction(S, 1.0, nullptr, dw, true, 2)) return false;
+    double ratio_aff = 0.0, ratio_cen = 0.0;
+    {
+      W_P0();
+      const int rc = solve_refined2(S, dw, rhs2, sol2, res2, ratio_aff, ratio_cen);
+      W_P1(21);
+      if (rc != 0) return false;
+    }
+    direction_outputs(S, S->sol, S->rs, 0.0, dw, false, 1);
+    direction_outputs(S, sol2, q2, 1.0, dw, true, 2);
+    S->last_ratio = ratio_cen;
     if (ratio_aff > S->last_ratio) S->last_ratio = ratio_aff;
     const i64 n_ineq = m - S->n_eq;
     QfArgs A;
