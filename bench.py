@@ -212,7 +212,7 @@ def cpu_baseline(seed, device, sweep=CPU_SWEEP):
                          ctypes.util.find_library("ipopt") or "not found")}
 
 
-C5_TRAFFIC_PROFILE = "r04_pmc_batch_8192.json"  # rocprofv3 --pmc passes of `bench.py --workload c5` (per round)
+C5_TRAFFIC_PROFILE = "r05_pmc_wave_8192.json"  # rocprofv3 --pmc passes of `bench.py --workload c5` (per round)
 PEAK_HBM_GBS = 8000.0                           # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
@@ -224,31 +224,18 @@ def c5_template(which):
             "path_planning": bp.template_path_planning, "power_flow": bp.template_power_flow}[which]()
 
 
-def c5_cpu_baseline(pb, thetas, budget_s=12.0):
-    """The CPU oracle (host build of the same algorithm, one core) on a bounded sample of the same
-    instances: as many of the batch's first rows as fit in ~budget_s seconds."""
-    from dnlp_amd.batch import arrays_with_data
-    from dnlp_amd.nlp_solver import HIPNLP
-    from dnlp_amd.tape import serialize
-    from oracle.oracle_capi import OracleProblem
-    mat = pb.data(thetas[:min(len(thetas), 4096)])
-    done, iters, t0 = 0, 0, time.time()
-    for row in mat:
-        a = arrays_with_data(pb.arrays0, row)
-        o = OracleProblem(serialize(a))
-        for k, v in HIPNLP.DEFAULT_OPTIONS.items():
-            o.set_option(k, v)
-        r = o.solve(a["x0"])
-        o.close()
-        done += 1
-        iters += int(r["iterations"])
-        if time.time() - t0 > budget_s:
-            break
-    dt = time.time() - t0
-    return {"value": done / dt, "unit": "problems/s", "cores": 1, "kind": "port", "iters_per_s": iters / dt,
-            "sample": "CPU oracle (host build of the same interior-point algorithm, sparse static-pattern LDL^T, "
-                      "one core) on the first %d instances of the same batch, %.1f s; tape creation per instance "
-                      "included (the device path shares one tape)" % (done, dt)}
+def c5_cpu_baseline(which, batch, first, budget_s=12.0):
+    """The host build of the same interior-point algorithm on ALL host cores ("across all host cores"): one
+    worker process per core, ONE shared tape + the template's static-pattern plan as on the device, whole passes over the
+    same batch for ~budget_s seconds (tools/c5_cpu_allcores.py; a process tree of its own that never touches the GPU)."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "c5_cpu_allcores.py"), "--which", which, "--batch", str(batch),
+           "--first", str(first), "--budget", str(budget_s)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s * 8 + 240)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if out.returncode != 0 or not lines:
+        raise RuntimeError("c5_cpu_allcores.py failed: %s" % (out.stderr.strip().splitlines() or ["no output"])[-1])
+    return json.loads(lines[-1])
 
 
 def bench_c5(args):
@@ -315,6 +302,19 @@ def bench_c5(args):
         pb.solve_many([all_thetas[k] for k in ks], device=local, in_flight=2)
         barrier()
         dt_two, n_two = time.time() - t2, len(ks)
+    # secondary figure: the per-GPU shard BASELINE's config names (8 x 1024) — 1024 fresh instances per launch, all
+    # resident at once: the launch is its slowest instance
+    dt_1024, it_1024, launch_info = None, None, None
+    if world == 1 and B > 1024:
+        small = [np.stack([sample((n_batches + k) * B + i) for i in range(1024)]) for k in range(4)]
+        pb.solve(small[0], device=local)
+        barrier()
+        t3 = time.time()
+        for k in range(1, 4):
+            r1024 = pb.solve(small[k], device=local)
+        barrier()
+        dt_1024, it_1024 = (time.time() - t3) / 3.0, int(r1024.iterations.max())
+    launch_info = pb.solve(thetas[: min(B, 1024)], device=local).raw.get("launch") if world == 1 else None
     assert rows.shape[0] == B and np.array_equal(rows[:, 0], np.arange(B)), "gathered rows are not the whole batch"
     gathered_ranks, backend_name = info["ranks"], info["backend"]
     if dist is not None:
@@ -360,26 +360,30 @@ def bench_c5(args):
                        "instance_order": "first come (every step is a fresh batch)",
                        "resolve_same_batch_problems_per_s": B / dt_resolve if dt_resolve > 0 else None,
                        "two_batches_in_flight_problems_per_s": B * n_two / dt_two if dt_two else None,
+                       "shard_of_1024_problems_per_s": 1024 / dt_1024 if dt_1024 else None,
+                       "shard_of_1024_slowest_instance_iterations": it_1024,
+                       "kernel_form": launch_info,
                        "ip_iterations_per_pass": iters_total,
                        "aggregate_ip_iterations_per_s": iters_total * args.steps / dt_all,
                        "problems_per_s_kernel_only": B * args.steps / ksec_all if ksec_all > 0 else None,
                        "gathered_ranks": gathered_ranks, "gathered_bytes": gbytes // max(args.steps, 1),
                        "collective_backend": backend_name},
-            "roofline": {"bound": "hbm", "kernel": "batch_solve_kernel (whole interior-point loop per wavefront)",
+            "roofline": {"bound": "hbm", "kernel": ("wave_batch_kernel" if (launch_info or {}).get("wave_form") else "batch_solve_kernel") +
+                         " (whole interior-point loop per wavefront)",
                          "achieved": alg_bytes_launch / per_launch_s / 1e9 if per_launch_s > 0 else None,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": alg_bytes_launch / per_launch_s / 1e9 / PEAK_HBM_GBS if per_launch_s > 0 else None,
                          "algorithmic_bytes_per_iteration": bytes_iter, "avg_launch_ms": 1e3 * per_launch_s,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "note": "latency-bound: one wavefront per instance runs a dependent chain; neither roof is near "
-                                 "(DESIGN.md 4a)"},
+                         "note": "one wavefront per instance runs the interior-point loop out of LDS: bound by the instructions it issues and "
+                                 "its LDS round trips, neither roof is near (DESIGN.md 4a)"},
         }
         if world > 1 or args.no_cpu:
             out["cpu_baseline"] = {"value": None, "unit": "problems/s", "cores": 0, "kind": "port",
                                    "sample": "not timed (N > 1 or --no-cpu; see the N = 1 line)"}
         else:
             try:
-                out["cpu_baseline"] = c5_cpu_baseline(pb, thetas)
+                out["cpu_baseline"] = c5_cpu_baseline(args.which, B, (n_batches - 1) * B)
             except Exception as e:
                 out["cpu_baseline"] = {"value": None, "unit": "problems/s", "cores": 1, "kind": "port",
                                        "sample": "failed: %s" % e}

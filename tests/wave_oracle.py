@@ -32,7 +32,11 @@ class HostBatch:
 
     def solve(self, thetas, which):
         """which = 0: wave_ipm.h on one host lane; 1: ipm_core.h (generic) with the template's plan."""
-        mat = np.ascontiguousarray(self.pb.data(np.atleast_2d(thetas)))
+        return self.solve_rows(self.pb.data(np.atleast_2d(thetas)), which)
+
+    def solve_rows(self, mat, which):
+        """The same for instance data rows (BATCH_DATA_KEYS order)."""
+        mat = np.ascontiguousarray(mat)
         B = mat.shape[0]
         out = {"x": np.zeros((B, self.N)), "obj": np.zeros(B), "status": np.zeros(B, np.int32), "iters": np.zeros(B, np.int32),
                "nfact": np.zeros(B, np.int32), "mult_g": np.zeros((B, max(self.m, 1))), "zl": np.zeros((B, self.N)), "zu": np.zeros((B, self.N))}
