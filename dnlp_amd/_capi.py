@@ -85,6 +85,11 @@ class CApi:
               [_int_p] * 3 + [_dbl_p, _dbl_p])
             if hasattr(self.lib, prefix + "batch_launch_info"):
                 f("batch_launch_info", C.c_int, [C.c_void_p, _i32_p])
+            if hasattr(self.lib, prefix + "batch_stream_create"):
+                f("batch_stream_create", C.c_void_p, [C.c_void_p, C.c_int])
+                f("batch_stream_submit", C.c_int, [C.c_void_p, C.c_int, _dbl_p, C.c_int] + [_dbl_p] * 5 + [_int_p] * 3)
+                f("batch_stream_wait", C.c_int, [C.c_void_p, C.c_int, _dbl_p])
+                f("batch_stream_destroy", None, [C.c_void_p])
 
     def _fn(self, name, restype, argtypes):
         fn = getattr(self.lib, self.prefix + name)
@@ -301,6 +306,10 @@ class ProblemHandle:
         self.n, self.m, self.nnz_jac, self.nnz_hess = n.value, m.value, nj.value, nh.value
 
     def close(self):
+        st = getattr(self, "_bstream", None)
+        if st is not None and self.ptr:
+            self.api.batch_stream_destroy(st[0])
+        self._bstream = None
         if self.ptr:
             self.api.destroy(self.ptr)
             self.ptr = None
@@ -523,6 +532,9 @@ class ProblemHandle:
         """Hand the affine parameter -> instance-data map to the device once (`D`: scipy CSR,
         stride x P): later `solve_batch(thetas=...)` calls move only the parameter rows."""
         need = int(self.api.batch_stride(self.ptr))
+        if getattr(self, "_bstream", None) is not None:          # (its slots carry copies of the previous map)
+            self.api.batch_stream_destroy(self._bstream[0])
+            self._bstream = None
         d0 = np.ascontiguousarray(d0, dtype=np.float64)
         theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
         if d0.size != need or D.shape != (need, theta0.size):
@@ -596,6 +608,62 @@ class ProblemHandle:
         if want_duals:
             out.update({"mult_g": mg[:, :self.m], "mult_x_L": zl, "mult_x_U": zu})
         return out
+
+    def solve_batch_stream(self, batches, slots: int = 2, want_duals: bool = False):
+        """A stream of parameter-row batches with `slots` launches in flight INSIDE the library (include/dnlp_hip.h
+        dnlp_batch_stream_*: own HIP stream, buffers and host thread per slot — no Python threads, one handle).  Returns the
+        solve_batch dicts in order; bit for bit what solve_batch(thetas=...) returns one launch at a time."""
+        batches = [np.ascontiguousarray(t, dtype=np.float64) for t in batches]
+        P = getattr(self, "_affine_P", None)
+        if any(t.ndim != 2 or t.shape[1] != P for t in batches):
+            raise ValueError("solve_batch_stream: parameter rows do not match the affine map of this handle")
+        # (the stream — its slots' device buffers and plan copies — is kept with the handle for the next call)
+        cached = getattr(self, "_bstream", None)
+        if cached is not None and cached[1] != int(slots):
+            self.api.batch_stream_destroy(cached[0])
+            cached = self._bstream = None
+        if cached is None:
+            st = self.api.batch_stream_create(self.ptr, int(slots))
+            if not st:
+                raise RuntimeError("batch_stream_create failed: %s" % self.api.error())
+            self._bstream = (st, int(slots))
+        st = self._bstream[0]
+        _int_p = C.POINTER(C.c_int)
+        ip = lambda a: a.ctypes.data_as(_int_p)      # noqa: E731
+        outs, tickets, res = [], [], [None] * len(batches)
+
+        def collect(k):
+            sec = C.c_double()
+            rc = self.api.batch_stream_wait(st, tickets[k], C.cast(C.byref(sec), _dbl_p))
+            if rc != 0:
+                raise RuntimeError("batch stream: submission %d failed (code %d): %s" % (k, rc, self.api.error()))
+            o = outs[k]
+            res[k] = {"x": o["x"], "obj_val": o["obj"], "status": o["status"], "iterations": o["iters"], "factorizations": o["nfact"],
+                      "kernel_seconds": float(sec.value), "phase_seconds": np.zeros((o["x"].shape[0], 4))}
+            if want_duals:
+                res[k].update({"mult_g": o["mg"][:, :self.m], "mult_x_L": o["zl"], "mult_x_U": o["zu"]})
+        try:
+            for k, th in enumerate(batches):
+                B = th.shape[0]
+                o = {"x": np.empty((B, self.n)), "obj": np.empty(B), "status": np.empty(B, np.int32), "iters": np.empty(B, np.int32),
+                     "nfact": np.empty(B, np.int32), "mg": np.empty((B, max(self.m, 1))) if want_duals else None,
+                     "zl": np.empty((B, self.n)) if want_duals else None, "zu": np.empty((B, self.n)) if want_duals else None}
+                outs.append(o)
+                if k >= slots:
+                    collect(k - slots)
+                t = self.api.batch_stream_submit(st, B, _dp(th if th.size else np.zeros(1)), th.shape[1], _dp(o["x"]), _dp(o["obj"]),
+                                                 _dp(o["mg"]) if want_duals else None, _dp(o["zl"]) if want_duals else None,
+                                                 _dp(o["zu"]) if want_duals else None, ip(o["status"]), ip(o["iters"]), ip(o["nfact"]))
+                if t < 0:
+                    raise RuntimeError("batch_stream_submit failed (code %d): %s" % (t, self.api.error()))
+                tickets.append(t)
+            for k in range(max(0, len(batches) - slots), len(batches)):
+                collect(k)
+        except BaseException:
+            self.api.batch_stream_destroy(st)        # (waits for what is in flight: the output arrays die with this frame)
+            self._bstream = None
+            raise
+        return res
 
     def log(self) -> str:
         need = self.api.get_log(self.ptr, None, 0)

@@ -254,8 +254,7 @@ class ParametricBatch:
         return BatchResult(raw, self.inv, self.flip)
 
     def _ensure_handle(self, device, opts):
-        """(Re)create THIS object's device handle for (device, options).  Only its own handle is touched — the clones
-        `solve_many` keeps belong to their workers (closing them from here raced with a worker that was launching)."""
+        """(Re)create this object's device handle for (device, options)."""
         key = (device, tuple(sorted((k, str(v)) for k, v in opts.items())))
         if getattr(self, "_handle_key", None) != key:
             self._close_own()
@@ -263,51 +262,25 @@ class ParametricBatch:
             self._handle_key = key
             self._map_on_device = False
 
-    def solve_many(self, batches, device=None, in_flight=2, **opts):
-        """A stream of batches with `in_flight` launches overlapping: batch i goes to worker i mod in_flight, every
-        worker has its own device handle (own HIP stream) and its own host thread.  A launch lasts as long as its
-        slowest instance — evenly spread, the work of an 8192-instance localization batch is ~60 % of the launch —
-        and the workgroups of the next launch take the compute units that the tail of the previous one leaves idle:
-        8192 fresh localization instances per batch go from 147 k to 215 k problems/s with two launches in flight
-        (profiles/r04_c5_two_in_flight.json).  Results are the ones `solve` returns, batch by batch, in order
-        (a launch is bitwise reproducible for its launch plan — the kernel form is chosen from the template and the
-        batch size — so overlapping launches changes no result)."""
-        import copy
-        import threading
-        batches = list(batches)
-        n_workers = max(1, min(int(in_flight), len(batches)))
-        if not self.affine:
-            n_workers = 1                             # (per-instance lowering moves the shared Parameter objects: one at a time)
-        if n_workers == 1:
-            return [self.solve(t, device=device, **opts) for t in batches]
-        clones = getattr(self, "_clones", None)
-        if clones is None:
-            clones = self._clones = []
-        while len(clones) < n_workers - 1:
-            c = copy.copy(self)                       # the lowered template and the affine map are shared (read-only)
-            c._handle, c._handle_key, c._map_on_device, c._clones = None, None, False, []
-            clones.append(c)
-        workers = [self] + clones[:n_workers - 1]
-        if "warm_start_init_point" not in opts:
-            for w in workers:                         # every handle exists before a thread starts: no worker creates or
-                w._ensure_handle(device, opts)        # closes one while another is launching
-        out, errors = [None] * len(batches), []
-
-        def run(w, idx):
-            try:
-                for i in idx:
-                    out[i] = w.solve(batches[i], device=device, **opts)
-            except Exception as e:                    # surfaced on the calling thread
-                errors.append(e)
-
-        threads = [threading.Thread(target=run, args=(w, range(k, len(batches), n_workers))) for k, w in enumerate(workers)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
-        return out
+    def solve_many(self, batches, device=None, in_flight=2, want_duals=False, **opts):
+        """A stream of batches with `in_flight` launches overlapping.  A launch lasts as long as its slowest instance —
+        evenly spread, the work of an 8192-instance localization batch is ~70 % of the launch — and the workgroups of the
+        next launch take the compute units that the tail of the previous one leaves idle.  The overlap lives INSIDE the
+        library (include/dnlp_hip.h dnlp_batch_stream_*: every slot its own HIP stream, device buffers and host thread;
+        ONE handle, no Python threads — round 4 did this with a handle and a Python thread per worker).  Results are the
+        ones `solve` returns, batch by batch, in order, bit for bit."""
+        batches = [np.atleast_2d(np.asarray(t, dtype=float)) for t in batches]
+        slots = max(1, min(int(in_flight), len(batches)))
+        if not self.affine or slots == 1:
+            return [self.solve(t, device=device, want_duals=want_duals, **opts) for t in batches]
+        self._ensure_handle(device, opts)
+        if not hasattr(self._handle, "solve_batch_stream") or not hasattr(self._handle.api, "batch_stream_create"):
+            return [self.solve(t, device=device, want_duals=want_duals, **opts) for t in batches]
+        if not self._map_on_device:
+            self._handle.set_batch_affine_map(self.d0, self.theta0, self.D)
+            self._map_on_device = True
+        raws = self._handle.solve_batch_stream(batches, slots=slots, want_duals=want_duals)
+        return [BatchResult(r, self.inv, self.flip) for r in raws]
 
     def solve_sharded(self, thetas, device=None, force_collective=False, **opts):
         """Problem-parallel solve across the ranks of an initialised torch.distributed group (one
@@ -351,8 +324,6 @@ class ParametricBatch:
         self._handle, self._handle_key = None, None
 
     def close(self):
-        for c in getattr(self, "_clones", None) or []:
-            c.close()
         self._close_own()
 
     def __del__(self):

@@ -344,6 +344,8 @@ __global__ void __launch_bounds__(256) batch_affine_expand_kernel(double* __rest
 // Host side: tables uploaded once per problem handle, slabs per call.
 struct BatchRunner {
   HipExec* ex = nullptr;
+  hipStream_t stream = nullptr;   // this runner's launches and copies (the handle's stream; a batch-stream slot has its own)
+  bool own_stream = false;
   Tape<HipExec>* tape = nullptr;
   SegHost* d_segs = nullptr;
   i64* d_red = nullptr;
@@ -414,6 +416,9 @@ struct BatchRunner {
 
   // affine parameter -> instance-data map (dnlp_batch_set_affine_map), resident on the device, in slab layout
   int aff_P = -1;
+  std::vector<double> h_aff_d0, h_aff_theta0, h_aff_vals;      // (host copy of what set_affine_map was given: a batch-stream slot replays it)
+  std::vector<i64> h_aff_indptr;
+  std::vector<int> h_aff_indices;
   double *aff_d0 = nullptr, *aff_theta0 = nullptr, *aff_val = nullptr, *aff_theta = nullptr;
   i64* aff_indptr = nullptr;
   int* aff_idx = nullptr;
@@ -429,6 +434,13 @@ struct BatchRunner {
   void set_affine_map(int P, const double* d0, const double* theta0, const i64* indptr, const int* indices, const double* vals) {
     const Tape<HipExec>& t = *tape;
     DNLP_HIP_CHECK(hipSetDevice(ex->device));
+    {
+      const i64 rows = in_stride, nz = indptr[rows];
+      std::vector<double> a(d0, d0 + rows), b(theta0, theta0 + P), v(vals, vals + nz);
+      std::vector<i64> ip(indptr, indptr + rows + 1);
+      std::vector<int> ix(indices, indices + nz);
+      h_aff_d0.swap(a); h_aff_theta0.swap(b); h_aff_vals.swap(v); h_aff_indptr.swap(ip); h_aff_indices.swap(ix);
+    }
     free_affine();
     const i64 head = 1 + (t.N + t.Z) + t.m + t.nnzJ + t.G.nnz + t.Mg.nnz + t.Mw.nnz + t.MJ.nnz + t.MH.nnz;
     auto src_row = [&](i64 o) -> i64 {
@@ -469,6 +481,7 @@ struct BatchRunner {
     if (d_red) hipFree(d_red);
     if (d_sparse) hipFree(d_sparse);
     if (d_wave_blk) hipFree(d_wave_blk);
+    if (own_stream && stream) hipStreamDestroy(stream);
   }
   void release() { nbuf_used = 0; }
   template <class T> T* dalloc(size_t n) {
@@ -518,8 +531,14 @@ struct BatchRunner {
     return total;
   }
 
-  void init(HipExec* e, Tape<HipExec>* t) {
+  void init(HipExec* e, Tape<HipExec>* t, bool private_stream = false) {
     ex = e; tape = t;
+    stream = e->stream;
+    if (private_stream) {
+      DNLP_HIP_CHECK(hipSetDevice(e->device));
+      DNLP_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+      own_stream = true;
+    }
     if (t->nblk > 0 || t->ndense > 0)
       throw std::runtime_error("batched solve: tapes with dense quad_form blocks are solved one at a time (dnlp_solve)");
     auto up = [&](auto** dst, const auto* src, size_t n) {
@@ -586,9 +605,9 @@ struct BatchRunner {
         DNLP_HIP_CHECK(hipMalloc(&aff_theta, (nth ? nth : 1) * sizeof(double)));
         aff_theta_cap = nth;
       }
-      if (nth) DNLP_HIP_CHECK(hipMemcpyAsync(aff_theta, theta, nth * sizeof(double), hipMemcpyHostToDevice, ex->stream));
+      if (nth) DNLP_HIP_CHECK(hipMemcpyAsync(aff_theta, theta, nth * sizeof(double), hipMemcpyHostToDevice, stream));
       const dim3 grid(static_cast<unsigned>((lay.total + 255) / 256), static_cast<unsigned>(batch));
-      hipLaunchKernelGGL(batch_affine_expand_kernel, grid, dim3(256), 0, ex->stream, a.slabs, lay.total, batch, aff_P, aff_theta,
+      hipLaunchKernelGGL(batch_affine_expand_kernel, grid, dim3(256), 0, stream, a.slabs, lay.total, batch, aff_P, aff_theta,
                          aff_theta0, aff_d0, aff_indptr, aff_idx, aff_val);
       DNLP_LAUNCH_CHECK();
       mark("slab generated on device");
@@ -847,7 +866,7 @@ struct BatchRunner {
     }
     ws_batch = 0;
     a.next = dalloc<int>(1);
-    DNLP_HIP_CHECK(hipMemsetAsync(a.next, 0, sizeof(int), ex->stream));
+    DNLP_HIP_CHECK(hipMemsetAsync(a.next, 0, sizeof(int), stream));
     // longest-first only for a re-solve of the SAME rows (warm starts, repeated what-if solves): a different batch of
     // equal size must not inherit an order derived from unrelated iteration counts, and takes its instances first-come
     const uint64_t key = theta ? rows_hash(theta, static_cast<size_t>(batch) * static_cast<size_t>(aff_P))
@@ -859,22 +878,22 @@ struct BatchRunner {
       for (int k = 0; k < batch; ++k) ord[static_cast<size_t>(k)] = k;
       std::stable_sort(ord.begin(), ord.end(), [&](int p, int q) { return prev_iters[static_cast<size_t>(p)] > prev_iters[static_cast<size_t>(q)]; });
       int* d_ord = dalloc<int>(static_cast<size_t>(batch));
-      DNLP_HIP_CHECK(hipMemcpyAsync(d_ord, ord.data(), sizeof(int) * static_cast<size_t>(batch), hipMemcpyHostToDevice, ex->stream));
-      DNLP_HIP_CHECK(hipStreamSynchronize(ex->stream));     // `ord` is a local
+      DNLP_HIP_CHECK(hipMemcpyAsync(d_ord, ord.data(), sizeof(int) * static_cast<size_t>(batch), hipMemcpyHostToDevice, stream));
+      DNLP_HIP_CHECK(hipStreamSynchronize(stream));     // `ord` is a local
       a.order = d_ord;
     }
     mark("plan + buffers");
     hipEvent_t e0, e1;
     DNLP_HIP_CHECK(hipEventCreate(&e0));
     DNLP_HIP_CHECK(hipEventCreate(&e1));
-    DNLP_HIP_CHECK(hipEventRecord(e0, ex->stream));
+    DNLP_HIP_CHECK(hipEventRecord(e0, stream));
     if (packed) hipLaunchKernelGGL(batch_solve_packed_kernel<kPackedWaves>, dim3(static_cast<unsigned>(grid)), dim3(64 * kPackedWaves), a.lds_bytes,
-                                   ex->stream, a, pk_wave_bytes);
-    else if (wave) hipLaunchKernelGGL(batch_solve_kernel<64>, dim3(static_cast<unsigned>(grid)), dim3(64), a.lds_bytes, ex->stream, a);
-    else hipLaunchKernelGGL(batch_solve_kernel<256>, dim3(static_cast<unsigned>(grid)), dim3(256), a.lds_bytes, ex->stream, a);
+                                   stream, a, pk_wave_bytes);
+    else if (wave) hipLaunchKernelGGL(batch_solve_kernel<64>, dim3(static_cast<unsigned>(grid)), dim3(64), a.lds_bytes, stream, a);
+    else hipLaunchKernelGGL(batch_solve_kernel<256>, dim3(static_cast<unsigned>(grid)), dim3(256), a.lds_bytes, stream, a);
     DNLP_LAUNCH_CHECK();
-    DNLP_HIP_CHECK(hipEventRecord(e1, ex->stream));
-    DNLP_HIP_CHECK(hipStreamSynchronize(ex->stream));
+    DNLP_HIP_CHECK(hipEventRecord(e1, stream));
+    DNLP_HIP_CHECK(hipStreamSynchronize(stream));
     float ms = 0.f;
     DNLP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0);
@@ -1011,10 +1030,10 @@ struct BatchRunner {
     }
     ws_batch = 0;
     w.next = dalloc<int>(1);
-    DNLP_HIP_CHECK(hipMemsetAsync(w.next, 0, sizeof(int), ex->stream));
+    DNLP_HIP_CHECK(hipMemsetAsync(w.next, 0, sizeof(int), stream));
 #ifdef DNLP_WAVE_PROF
     w.prof = dalloc<unsigned long long>(kWaveProfSlots + 1);
-    DNLP_HIP_CHECK(hipMemsetAsync(w.prof, 0, sizeof(unsigned long long) * (kWaveProfSlots + 1), ex->stream));
+    DNLP_HIP_CHECK(hipMemsetAsync(w.prof, 0, sizeof(unsigned long long) * (kWaveProfSlots + 1), stream));
 #endif
     const uint64_t key = theta ? rows_hash(theta, static_cast<size_t>(batch) * static_cast<size_t>(aff_P))
                                : rows_hash(data, static_cast<size_t>(batch) * static_cast<size_t>(in_stride));
@@ -1025,8 +1044,8 @@ struct BatchRunner {
       for (int k = 0; k < batch; ++k) ord[static_cast<size_t>(k)] = k;
       std::stable_sort(ord.begin(), ord.end(), [&](int p, int q) { return prev_iters[static_cast<size_t>(p)] > prev_iters[static_cast<size_t>(q)]; });
       int* d_ord = dalloc<int>(static_cast<size_t>(batch));
-      DNLP_HIP_CHECK(hipMemcpyAsync(d_ord, ord.data(), sizeof(int) * static_cast<size_t>(batch), hipMemcpyHostToDevice, ex->stream));
-      DNLP_HIP_CHECK(hipStreamSynchronize(ex->stream));
+      DNLP_HIP_CHECK(hipMemcpyAsync(d_ord, ord.data(), sizeof(int) * static_cast<size_t>(batch), hipMemcpyHostToDevice, stream));
+      DNLP_HIP_CHECK(hipStreamSynchronize(stream));
       w.order = d_ord;
     }
     last_grid = grid; last_threads = 64 * nw; last_lds_mode = 2 * sl + pl; last_per_cu = nw * per_cu; last_packed = false;
@@ -1037,19 +1056,19 @@ struct BatchRunner {
     hipEvent_t e0, e1;
     DNLP_HIP_CHECK(hipEventCreate(&e0));
     DNLP_HIP_CHECK(hipEventCreate(&e1));
-    DNLP_HIP_CHECK(hipEventRecord(e0, ex->stream));
+    DNLP_HIP_CHECK(hipEventRecord(e0, stream));
     switch (form) {
-      case 411: launch_wave<4, true, true>(w, grid, lds, ex->stream); break;
-      case 211: launch_wave<2, true, true>(w, grid, lds, ex->stream); break;
-      case 111: launch_wave<1, true, true>(w, grid, lds, ex->stream); break;
-      case 210: launch_wave<2, true, false>(w, grid, lds, ex->stream); break;
-      case 110: launch_wave<1, true, false>(w, grid, lds, ex->stream); break;
-      case 400: launch_wave<4, false, false>(w, grid, lds, ex->stream); break;
+      case 411: launch_wave<4, true, true>(w, grid, lds, stream); break;
+      case 211: launch_wave<2, true, true>(w, grid, lds, stream); break;
+      case 111: launch_wave<1, true, true>(w, grid, lds, stream); break;
+      case 210: launch_wave<2, true, false>(w, grid, lds, stream); break;
+      case 110: launch_wave<1, true, false>(w, grid, lds, stream); break;
+      case 400: launch_wave<4, false, false>(w, grid, lds, stream); break;
       default: throw std::runtime_error("wavefront solver: no such launch form");
     }
     DNLP_LAUNCH_CHECK();
-    DNLP_HIP_CHECK(hipEventRecord(e1, ex->stream));
-    DNLP_HIP_CHECK(hipStreamSynchronize(ex->stream));
+    DNLP_HIP_CHECK(hipEventRecord(e1, stream));
+    DNLP_HIP_CHECK(hipStreamSynchronize(stream));
     float ms = 0.f;
     DNLP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0);

@@ -108,6 +108,79 @@ int dnlp_solve_batch_theta(dnlp_problem* vp, int batch, const double* theta, int
     return 0;)
 }
 
+// ---- batches in flight (include/dnlp_hip.h dnlp_batch_stream_*) ----------------------------------------------------------
+}  // extern "C"
+#include <thread>
+struct dnlp_batch_stream {
+  dnlp_problem_t* p = nullptr;
+  struct Slot {
+    BatchRunner runner;
+    std::thread th;
+    int ticket = -1, rc = 0;
+    double seconds = 0.0;
+    std::string err;
+  };
+  std::vector<std::unique_ptr<Slot>> slots;
+  int next_ticket = 0;
+};
+extern "C" {
+dnlp_batch_stream* dnlp_batch_stream_create(dnlp_problem* vp, int nslots) {
+  dnlp_problem_t* p = vp;
+  try {
+    if (nslots < 1 || nslots > 16) throw std::runtime_error("dnlp_batch_stream_create: 1 .. 16 slots");
+    BatchRunner& main = *batch_runner(p);
+    if (main.aff_P < 0) throw std::runtime_error("dnlp_batch_stream_create: set the affine parameter map first (dnlp_batch_set_affine_map)");
+    p->ex.sync();
+    std::unique_ptr<dnlp_batch_stream> s(new dnlp_batch_stream());
+    s->p = p;
+    for (int k = 0; k < nslots; ++k) {
+      // a slot = a runner of its own over the SAME tape and plan: own stream, own device buffers, own copy of the map
+      std::unique_ptr<dnlp_batch_stream::Slot> sl(new dnlp_batch_stream::Slot());
+      sl->runner.init(&p->ex, p->model.owner, true);
+      if (main.have_sparse) { sl->runner.set_sparse_plan(*main.host_plan); sl->runner.force_sparse = main.force_sparse; }
+      sl->runner.set_affine_map(main.aff_P, main.h_aff_d0.data(), main.h_aff_theta0.data(), main.h_aff_indptr.data(), main.h_aff_indices.data(),
+                                main.h_aff_vals.data());
+      sl->runner.wave_prepare();            // (reads the tape's index arrays back through the handle's stream: here, on the caller's thread)
+      s->slots.push_back(std::move(sl));
+    }
+    p->ex.sync();
+    return s.release();
+  } catch (const std::exception& e) { dnlp::tls_error() = e.what(); return nullptr; }
+}
+int dnlp_batch_stream_submit(dnlp_batch_stream* s, int batch, const double* theta, int n_params, double* x, double* obj, double* mult_g,
+                             double* mult_x_L, double* mult_x_U, int* status, int* iters, int* factorizations) {
+  DNLP_TRY(
+    if (s->p->opt.hessian_approximation == 1) return batch_rejects_limited_memory();
+    const int ticket = s->next_ticket++;
+    dnlp_batch_stream::Slot& sl = *s->slots[static_cast<size_t>(ticket) % s->slots.size()];
+    if (sl.th.joinable()) sl.th.join();                // every slot busy: the oldest submission first
+    sl.ticket = ticket; sl.rc = 0; sl.err.clear(); sl.seconds = 0.0;
+    const IpmOptions opt = s->p->opt;
+    dnlp_batch_stream::Slot* q = &sl;
+    sl.th = std::thread([=]() {
+      try {
+        q->runner.solve_theta(batch, theta, n_params, opt, x, obj, mult_g, mult_x_L, mult_x_U, status, iters, factorizations, &q->seconds);
+      } catch (const std::exception& e) { q->rc = -199; q->err = e.what(); }
+      catch (...) { q->rc = -199; q->err = "unknown exception"; }
+    });
+    return ticket;)
+}
+int dnlp_batch_stream_wait(dnlp_batch_stream* s, int ticket, double* kernel_seconds) {
+  DNLP_TRY(
+    if (ticket < 0 || ticket >= s->next_ticket) { dnlp::tls_error() = "dnlp_batch_stream_wait: no such ticket"; return -1; }
+    dnlp_batch_stream::Slot& sl = *s->slots[static_cast<size_t>(ticket) % s->slots.size()];
+    if (sl.ticket != ticket) { dnlp::tls_error() = "dnlp_batch_stream_wait: that ticket's slot has been reused (wait once, in time)"; return -1; }
+    if (sl.th.joinable()) sl.th.join();
+    if (kernel_seconds) *kernel_seconds = sl.seconds;
+    if (sl.rc != 0) dnlp::tls_error() = sl.err;
+    return sl.rc;)
+}
+void dnlp_batch_stream_destroy(dnlp_batch_stream* s) {
+  if (!s) return;
+  for (auto& sl : s->slots) if (sl->th.joinable()) sl->th.join();
+  delete s;
+}
+
 int dnlp_batch_launch_info(dnlp_problem* vp, int32_t* out8) {
   dnlp_problem_t* p = vp;
   DNLP_TRY(

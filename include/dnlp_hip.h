@@ -157,6 +157,25 @@ int dnlp_solve_batch_theta(dnlp_problem* p, int batch, const double* theta, int 
                            double* mult_g, double* mult_x_L, double* mult_x_U, int* status, int* iters,
                            int* factorizations, double* kernel_seconds, double* times);
 
+/* A STREAM of parametrised batches with several launches in flight (the reference's counterpart is the serial loop of
+ * problems/problem.py:1256-1269; dnlp_amd.batch.ParametricBatch.solve_many used Python threads and one handle per worker
+ * for this).  A launch lasts as long as its slowest instance; with `slots` launches in flight — each slot has its own HIP
+ * stream, device buffers and host thread inside the library — the workgroups of the next batch take the compute units
+ * the tail of the previous one leaves idle.  Results are bit for bit those of dnlp_solve_batch_theta on the same rows.
+ *   create   after dnlp_batch_set_affine_map; slots >= 1 (2 is what pays); options are those of `p` at each submit
+ *   submit   batch x n_params parameter rows and the output arrays of dnlp_solve_batch_theta (batch-major, mult_* may be
+ *            NULL); returns a ticket >= 0 at once — unless every slot is busy: then it first waits for the oldest —
+ *            or a negative error code.  The arrays must stay valid until the ticket has been waited for.
+ *   wait     blocks until that submission's outputs are filled; returns its dnlp_solve_batch_theta code; *kernel_seconds
+ *            (may be NULL) = its launch's device time.  A ticket can be waited for once.
+ *   destroy  waits for everything in flight. */
+typedef struct dnlp_batch_stream dnlp_batch_stream;
+dnlp_batch_stream* dnlp_batch_stream_create(dnlp_problem* p, int slots);
+int dnlp_batch_stream_submit(dnlp_batch_stream* s, int batch, const double* theta, int n_params, double* x, double* obj,
+                             double* mult_g, double* mult_x_L, double* mult_x_U, int* status, int* iters, int* factorizations);
+int dnlp_batch_stream_wait(dnlp_batch_stream* s, int ticket, double* kernel_seconds);
+void dnlp_batch_stream_destroy(dnlp_batch_stream* s);
+
 /* What the LAST dnlp_solve_batch* call of this handle launched (diagnostics; the reference has no counterpart —
  * its loop of problems/problem.py:1256-1269 is serial).  out[0] grid, [1] lanes per workgroup, [2] LDS mode,
  * [3] instances resident per compute unit, [4] 1 = packed generic kernel, [5] 1 = longest-first order,

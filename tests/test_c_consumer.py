@@ -90,3 +90,42 @@ def test_c_consumer_drives_the_device_oracles(name, gpu_required):
     binary = _build("consumer")
     vals, obj, iters = _run(binary, name, device=0)
     CASES[name](vals, obj)
+
+
+@pytest.mark.gpu
+def test_c_consumer_streams_batches_through_the_library(gpu_required):
+    """dnlp_batch_stream_* from plain C (include/dnlp_hip.h; the role of the serial loop problems/problem.py:1256-1269):
+    eight fresh batches of 2048 localization instances, two launches in flight inside the library — no Python thread,
+    one handle — give bit for bit the results of dnlp_solve_batch_theta one launch at a time, in clearly less time."""
+    import batch_problems as bp
+    from dnlp_amd.batch import ParametricBatch
+    from dnlp_amd.tape import serialize
+    prob, params, sample, _ = bp.template_localization()
+    pb = ParametricBatch(prob, params)
+    assert pb.affine
+    nb, B = 8, 2048
+    thetas = np.stack([sample(i) for i in range(nb * B)])
+    D = pb.D.tocsr()
+    D.sort_indices()
+    binary = _build("batch_stream")
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "tape.blob"), "wb") as fh:
+            fh.write(serialize(pb.arrays0))
+        with open(os.path.join(td, "map.bin"), "wb") as fh:
+            fh.write(np.array([pb.d0.size, pb.P], np.int64).tobytes())
+            fh.write(np.ascontiguousarray(pb.d0, np.float64).tobytes())
+            fh.write(np.ascontiguousarray(pb.theta0, np.float64).tobytes())
+            fh.write(np.ascontiguousarray(D.indptr, np.int64).tobytes())
+            idx = np.ascontiguousarray(D.indices, np.int32).tobytes()
+            fh.write(idx + b"\0" * (-len(idx) % 8))
+            fh.write(np.ascontiguousarray(D.data, np.float64).tobytes())
+        with open(os.path.join(td, "thetas.bin"), "wb") as fh:
+            fh.write(np.ascontiguousarray(thetas, np.float64).tobytes())
+        out = subprocess.run([binary, os.path.join(td, "tape.blob"), os.path.join(td, "map.bin"), os.path.join(td, "thetas.bin"),
+                              "0", str(nb), str(B), "2"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    t_serial, t_stream, same, optimal = out.stdout.split()
+    assert int(same) == 1
+    assert int(optimal) >= 0.999 * nb * B
+    assert float(t_stream) < 0.8 * float(t_serial), out.stdout
+    print("one at a time %.1f k problems/s, two in flight %.1f k" % (nb * B / float(t_serial) / 1e3, nb * B / float(t_stream) / 1e3))
