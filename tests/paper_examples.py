@@ -12,9 +12,10 @@ the known answers the solver is checked against (SURVEY.md §8c
     power flow 9-bus  power_flow.ipynb:36-119           855 / 850 / 0     15     3.0878422284732592e+03
     circle packing    circle_packing.ipynb:68-79        121 / 90 / 95     50     7.2286302188441365e+00
 
-The localization log was produced with other noise draws than the committed cell generates
-(its iteration-0 infeasibility 7.81 is not the 11.6 of the committed data), so only its
-dimensions are pinned.  Circle packing is non-convex: the log's value is one local optimum.
+The localization log was produced with other noise draws than the committed cell generates, so only its
+dimensions are pinned.  tools/localization_log_check.py shows it with numbers: at iteration 0 the committed data has
+inf_pr 11.6 (the log: 7.81); the minimiser the notebook prints, [2.11285122, -1.6415691], gives the committed data a
+least-squares value of 17.372 — neither the log's 7.660 nor an optimum (this solver's 14.004 at [3.0967, -1.4470] is lower).  Circle packing is non-convex: the log's value is one local optimum.
 """
 import numpy as np
 

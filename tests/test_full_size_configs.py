@@ -230,7 +230,11 @@ def test_c5_1024_power_flow_instances(gpu_required):
     opts = {"least_square_init_duals": "no"}
     res = pb.solve(thetas, want_duals=True, **opts)
     ok = res.status == 0
-    # (r01: 6.6 % of the perturbed-load instances are locally infeasible from the flat start)
+    # 6.6 % of the perturbed-load instances end "locally infeasible" from the flat start.  The launch is bitwise
+    # repeatable (tests/test_determinism.py), so the count is a fixed number of this build's launch plan: 956 optimal +
+    # 68 infeasible at 1024 instances (round 5, four wavefronts per instance); a change of it is a change of the
+    # algorithm or of a summation order and has to be looked at, not absorbed by a percentage
+    assert MEMBER_BATCH != 1024 or (int(ok.sum()), int((res.status == 2).sum())) == (956, 68), np.unique(res.status, return_counts=True)
     assert ok.sum() >= int(0.90 * MEMBER_BATCH), np.unique(res.status, return_counts=True)
     assert res.status[0] == 0 and abs(res.obj_val[0] - 3.0878422284732592e+03) <= 1e-6 * 3.0878e3
     vars_by_shape = {}
@@ -282,6 +286,8 @@ def test_c5_1024_path_planning_instances(gpu_required):
     thetas = np.stack([sample(i) for i in range(MEMBER_BATCH)])
     res = pb.solve(thetas, want_duals=True)
     ok = res.status == 0
+    # (the exact count of this build's launch plan, as for power flow: 1006 optimal + 18 "locally infeasible" at 1024)
+    assert MEMBER_BATCH != 1024 or (int(ok.sum()), int((res.status == 2).sum())) == (1006, 18), np.unique(res.status, return_counts=True)
     assert ok.sum() >= int(0.97 * MEMBER_BATCH), np.unique(res.status, return_counts=True)
     assert res.status[0] == 0 and abs(res.obj_val[0] - 1.3136882319337619e+01) <= 1e-6 * 13.14
     X = res.value_of(xvar)                                  # (B, 2, 51)

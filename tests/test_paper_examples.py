@@ -294,3 +294,18 @@ def test_device_host_driven_solve_repeats_bit_for_bit(name, gpu_required):
     assert len({r[0] for r in runs}) == 1, [r[0] for r in runs]
     assert all(r[2] == runs[0][2] for r in runs), [r[2] for r in runs]
     assert all(np.array_equal(r[3], runs[0][3]) for r in runs)
+
+
+def test_published_localization_log_belongs_to_other_data():
+    """tests/paper_examples.py pins only the dimensions of the localization log; tools/localization_log_check.py is the
+    evidence: with the data the notebook's committed cells generate, the minimiser the notebook prints is not an optimum
+    (17.37 against this solver's 14.00) and the iteration-0 infeasibility is 11.6, not the log's 7.81."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "localization_log_check.py")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "max |c| 1.161e+01" in out.stdout
+    assert "at the log's minimiser 17.37207" in out.stdout and "at this solve's minimiser 14.00431" in out.stdout
+    assert "minimiser is NOT the printed one; objective does not match the log's" in out.stdout
