@@ -98,7 +98,21 @@ def full_solve(chain, data, A, n):
             "iters_per_s_whole_solve": int(sol["iterations"]) / wall if wall > 0 else None}
 
 
-CPU_SWEEP = ((1000, 3), (2000, 3), (4000, 2), (10000, 1))   # (order n, timed iterations) — BASELINE.md §3
+CPU_SWEEP = ((1000, 3), (2000, 3), (4000, 2), (10000, 1), (20000, 1))   # (order n, timed iterations) — BASELINE.md §3; the last order: blocked column only
+CPU_DSYTRF_MAX_N = 10000      # (pivoted Bunch-Kaufman takes ~6 factorisations per iteration without the Lanczos bound: 60 s at 2e4)
+
+
+def usable_cores():
+    """(cores this process tree can use, logical CPUs it sees): the affinity mask capped by the cgroup's CPU quota."""
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    usable = visible
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            usable = max(1, min(visible, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return usable, visible
 
 
 def cpu_baseline(seed, device, sweep=CPU_SWEEP):
@@ -113,9 +127,10 @@ def cpu_baseline(seed, device, sweep=CPU_SWEEP):
     factorisation in bench time (n^3/3 = 3.3e14 flop per attempt), so the sweep and its fitted scaling law are
     reported, never an extrapolated figure as if measured."""
     import ctypes.util
-    threads = os.cpu_count() or 1
-    # the host build's own OpenMP loops (vector maps, the W copy of the blocked factorisation): a moderate team — 256
-    # OpenMP threads spinning beside the BLAS's pool cost the blocked column a factor of four on the GPU box's host
+    # the cores this process may actually use: the GPU boxes show 256 logical CPUs and grant 16 CPUs' worth of time
+    # (cgroup cpu.max) — rounds 1-4 sized the BLAS pools from os.cpu_count(), and 64-256 threads on 16 CPUs is what made
+    # this sweep erratic (DGEMM 1.1-5.1 TF/s "by thread count", n = 4000 at 26.7 GF/s, a fitted exponent of 0.96)
+    threads, visible = usable_cores()
     os.environ.setdefault("OMP_NUM_THREADS", str(min(32, threads)))
     os.environ.setdefault("DNLP_HOST_LDLT_TIMING", "1")
     from dnlp_amd.tape import serialize
@@ -130,10 +145,10 @@ def cpu_baseline(seed, device, sweep=CPU_SWEEP):
     if blas_threads:
         # OpenBLAS's DSYTRF does not scale to every core of a large host (64 threads measured 3x slower
         # than 16 on the GPU box): take the fastest of a few thread counts, and say which
-        cand = sorted({t for t in (4, 8, 16, 32, threads) if t <= threads})
+        cand = sorted({t for t in (4, 8, 16, 32, 64, threads) if t <= threads})
         blas_threads, probe = lapack_best_threads(cand)
         # DGEMM does scale: the blocked factorisation runs on every core (or on the count where DGEMM peaks)
-        rates = {t: dgemm_gflops(3000, t) for t in sorted({min(64, threads), min(128, threads), threads})}
+        rates = {t: dgemm_gflops(3000, t) for t in sorted({max(1, threads // 2), threads})}
         gemm_threads = max(rates, key=rates.get)
         gemm_rate = {"gflops_by_threads": rates, "n": 3000}
     have_blocked = bool(blas_threads) and use_blocked_ldlt(True)
@@ -154,22 +169,30 @@ def cpu_baseline(seed, device, sweep=CPU_SWEEP):
         data, _ = build_nlp_data(smooth)
         blob = serialize(data["tape_arrays"])
         row = {"n": n_cpu}
+        if not have_blocked and n_cpu > CPU_DSYTRF_MAX_N:
+            continue
         for column in (("dsytrf", "blocked") if have_blocked else ("dsytrf",)):
+            if column == "dsytrf" and n_cpu > CPU_DSYTRF_MAX_N:
+                continue
             orc = OracleProblem(blob)
             for k, v in HIPNLP.DEFAULT_OPTIONS.items():
                 orc.set_option(k, v)
+            # the certified Lanczos lower bound on delta_w that the device's solve of the n = 1e5 problem uses (ipm_core.h:
+            # on from order 12 000) at every order of the sweep: a timed iteration is then ~one factorisation on both sides
+            # (round 4: six doomed attempts per iteration at n = 1e4 on the host, one on the device)
+            orc.set_option("lanczos_min_n", 500)
             if column == "dsytrf":
                 if blas_threads:
                     set_blas_threads(blas_threads)
                 orc.set_option("kkt_pivot_max_n", 10 ** 9)     # pivoted (Bunch-Kaufman) at every order, as IPOPT's solvers are
             else:
                 orc.set_option("kkt_pivot_max_n", 0)           # unpivoted blocked LDL^T at every order, as on the device
-                if blocked_probe is None and n_cpu == sweep[-1][0]:
+                if blocked_probe is None and n_cpu == CPU_DSYTRF_MAX_N:
                     # the thread count that FACTORS fastest, measured at the largest order of the sweep (the DGEMM probe
                     # alone misleads: its best count is not the best for the mix of DTRSM, small and large DGEMMs); the
                     # smaller orders above ran with the DGEMM probe's count
                     blocked_probe = {}
-                    for tcand in sorted({t for t in (16, 32, 64) if t <= threads} or {threads}):
+                    for tcand in sorted({t for t in (8, 16, 32, 64) if t <= threads} or {threads}):
                         set_blas_threads(tcand)
                         orc.ipm_begin(data["x0"])
                         orc.ipm_step(1)
@@ -191,23 +214,28 @@ def cpu_baseline(seed, device, sweep=CPU_SWEEP):
         table.append(row)
         del Ah, data, smooth, prob, blob
     best_col = "dsytrf"
-    if have_blocked and (table[-1]["blocked"]["iters_per_s"] or 0) > (table[-1]["dsytrf"]["iters_per_s"] or 0):
+    both = [r for r in table if "dsytrf" in r and "blocked" in r]
+    if have_blocked and both and (both[-1]["blocked"]["iters_per_s"] or 0) > (both[-1]["dsytrf"]["iters_per_s"] or 0):
         best_col = "blocked"
-    ln = np.log([r["n"] for r in table])
-    lt = np.log([max(r[best_col]["s_per_factorization"], 1e-12) for r in table])
-    expo = float(np.polyfit(ln, lt, 1)[0]) if len(table) >= 2 else None
-    last = table[-1]
+    rows_best = [r for r in table if best_col in r]
+    # scaling law of the factorisation from the TWO LARGEST orders of the reported column: the small orders of the sweep
+    # are thread-start and panel overhead (n = 1000 factors at 3-10 GF/s), and a fit over all of them measures that
+    ln = np.log([r["n"] for r in rows_best[-2:]])
+    lt = np.log([max(r[best_col]["s_per_factorization"], 1e-12) for r in rows_best[-2:]])
+    expo = float((lt[1] - lt[0]) / (ln[1] - ln[0])) if len(rows_best) >= 2 else None
+    last = rows_best[-1]
     cores = (gemm_threads if best_col == "blocked" else blas_threads) or threads
     return {"value": last[best_col]["iters_per_s"], "unit": "iters/s", "cores": cores, "kind": "port",
             "n": last["n"], "factorization": best_col, "sweep": table, "factorization_time_exponent": expo,
-            "host_cores": threads, "dsytrf_n3000_seconds_by_threads": probe, "dgemm": gemm_rate,
+            "host_cores": threads, "host_logical_cpus_visible": visible, "dsytrf_n3000_seconds_by_threads": probe, "dgemm": gemm_rate,
             "blocked_s_per_factorization_by_threads": blocked_probe, "blocked_threads": gemm_threads,
             "sample": "host build of the same interior-point algorithm on the same generator / front-end at n in %s with %s "
                       "timed iterations, dense KKT two ways: %s; and the unpivoted blocked LDL^T with its trailing update "
                       "through DGEMM on %s threads (the device's algorithm on the host's BLAS).  value = iters/s of the "
-                      "faster one (%s) at n=%d; its seconds per factorisation scale as n^%.2f over the sweep (n^3 "
-                      "asymptotically: n=1e5 is %.3g x the n=%d flops per factorisation); libipopt on this box: %s"
-                      % ([r["n"] for r in table], [r["dsytrf"]["iterations"] for r in table], kind, gemm_threads, best_col,
+                      "faster one (%s) at n=%d; its seconds per factorisation scale as n^%.2f between the two largest orders (n^3 "
+                      "asymptotically; the blocked column runs with the certified Lanczos bound on delta_w as the device does — one "
+                      "factorisation per iteration on both sides; n=1e5 is %.3g x the n=%d flops per factorisation); libipopt on this box: %s"
+                      % ([r["n"] for r in table], [r.get("dsytrf", r.get("blocked"))["iterations"] for r in table], kind, gemm_threads, best_col,
                          last["n"], expo if expo is not None else float("nan"), (1e5 / last["n"]) ** 3, last["n"],
                          ctypes.util.find_library("ipopt") or "not found")}
 
