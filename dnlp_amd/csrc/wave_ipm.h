@@ -125,7 +125,8 @@ struct WaveIpm {
 #define W_FOR(i, n) for (int i = P::lane(); i < (n); i += P::lanes)
 
   // ---- layout: the tables out of the staged block, the vectors out of the wavefront's share ---------------------------
-  DNLP_HD static void layout(WS* S, const WaveHdr* h, WI* blk, WD* base) {
+  // (returns the doubles of state it laid out: wave_plan.h wave_state_doubles says the same number)
+  DNLP_HD static i32 layout(WS* S, const WaveHdr* h, WI* blk, WD* base) {
     S->N = h->N; S->m = h->m; S->Z = h->Z; S->nd = h->nd; S->nh = h->nh; S->nnzJ = h->nnzJ; S->nnzH = h->nnzH; S->nunits = h->nunits;
     S->u_op = blk + h->u_op; S->u_a0 = blk + h->u_a0; S->u_a1 = blk + h->u_a1; S->u_z = blk + h->u_z; S->u_d0 = blk + h->u_d0;
     S->u_d1 = blk + h->u_d1; S->u_h = blk + h->u_h; S->u_p = blk + h->u_p; S->mm_idx = blk + h->mm_idx;
@@ -151,24 +152,36 @@ struct WaveIpm {
     const i32 N = h->N, m = h->m;
     WD* p = base;
     auto take = [&](i32 n) { WD* q = p; p += (n + 1) & ~1; return q; };
-    S->x = take(N); S->zL = take(N); S->zU = take(N); S->xL = take(N); S->xU = take(N); S->grad = take(N); S->dx = take(N);
-    S->dzL = take(N); S->dzU = take(N); S->xt = take(N); S->Sx = take(N); S->rx = take(N); S->tN = take(N); S->fixm = take(N);
+    S->x = take(N); S->zL = take(N); S->zU = take(N); S->xL = take(N); S->xU = take(N); S->grad = take(N);
+    S->Sx = take(N); S->rx = take(N); S->tN = take(N); S->fixm = take(N);
     WD* ax = take(N); WD* azL = take(N); WD* azU = take(N);
     S->s = take(m); S->y = take(m); S->vL = take(m); S->vU = take(m); S->sL = take(m); S->sU = take(m); S->eq = take(m); S->g = take(m);
-    S->sg = take(m); S->ds = take(m); S->dy = take(m); S->dvL = take(m); S->dvU = take(m); S->st = take(m); S->gt = take(m); S->Dd = take(m);
-    S->Ss = take(m); S->rs = take(m); S->rp = take(m); S->tM = take(m); S->csoc = take(m);
-    WD* as = take(m); WD* ay = take(m); WD* avL = take(m); WD* avU = take(m); WD* cy = take(m);
+    S->sg = take(m); S->Dd = take(m); S->Ss = take(m); S->rs = take(m); S->rp = take(m); S->tM = take(m); S->csoc = take(m);
+    WD* as = take(m); WD* ay = take(m); WD* avL = take(m); WD* avU = take(m);
+    S->jv = take(h->nnzJ); S->xz = take(N + h->Z); S->dvals = take(h->nd); S->hvals = take(h->nh); S->w = take(h->Z); S->sl = take(1 + m);
+    S->Hs = take(h->nnzH); S->svals = take(h->sp_nvals);
+    // One contiguous region of everything that is DEAD while the KKT matrix is being factorised — the step (dx .. dvU), the
+    // trial point (xt, st, gt), the centering direction and the four arrays of a linear solve: the factorisation's work
+    // arrays (the unscaled L, the inverse pivots, the scratch of a level's products) live there for its duration instead
+    // of in 22 KB (circle packing n = 10) of LDS of their own, when they fit (wave_plan.h wave_state_doubles: same rule).
+    WD* dead0 = p;
+    S->dx = take(N); S->dzL = take(N); S->dzU = take(N); S->xt = take(N);
+    S->ds = take(m); S->dy = take(m); S->dvL = take(m); S->dvU = take(m); S->st = take(m); S->gt = take(m);
+    WD* cy = take(m);
     // the centering direction as three [variables | rows] pairs: until its outputs are written they hold the second
     // right-hand side, solution and residual of the mu oracle's joint solve (quality_function_mu)
     WD* cx = take(N + m); WD* cs = cx + N; WD* czL = take(N + m); WD* cvL = czL + N; WD* czU = take(N + m); WD* cvU = czU + N;
     S->rhs = take(N + m); S->sol = take(N + m); S->res = take(N + m); S->cor = take(N + m);
-    S->jv = take(h->nnzJ); S->xz = take(N + h->Z); S->dvals = take(h->nd); S->hvals = take(h->nh); S->w = take(h->Z); S->sl = take(1 + m);
-    S->Hs = take(h->nnzH); S->svals = take(h->sp_nvals); S->swork = take(h->sp_nvals + 3 * h->sp_nblk + 8);
-    S->scr = take(h->scr_doubles);
+    {
+      const i32 nwork = (h->sp_nvals + 3 * h->sp_nblk + 8 + 1) & ~1, nscr = (h->scr_doubles + 1) & ~1;
+      if (nwork + nscr <= static_cast<i32>(p - dead0)) { S->swork = dead0; S->scr = dead0 + nwork; }
+      else { S->swork = take(nwork); S->scr = take(nscr); }
+    }
     S->up0 = take(h->nunits); S->up1 = take(h->nunits); S->ucls = take(h->nunits);
     S->dir[0][0] = S->dx; S->dir[0][1] = S->ds; S->dir[0][2] = S->dy; S->dir[0][3] = S->dzL; S->dir[0][4] = S->dzU; S->dir[0][5] = S->dvL; S->dir[0][6] = S->dvU;
     S->dir[1][0] = ax; S->dir[1][1] = as; S->dir[1][2] = ay; S->dir[1][3] = azL; S->dir[1][4] = azU; S->dir[1][5] = avL; S->dir[1][6] = avU;
     S->dir[2][0] = cx; S->dir[2][1] = cs; S->dir[2][2] = cy; S->dir[2][3] = czL; S->dir[2][4] = czU; S->dir[2][5] = cvL; S->dir[2][6] = cvU;
+    return static_cast<i32>(p - base);
   }
 
   // ---- lane reductions (NaN conventions of BlockExecT::reduce: max NaN -> +inf, min NaN -> -inf) -------------------------

@@ -132,7 +132,8 @@ extern "C" int orc_wave_solve_batch(orc_problem* vp, int batch, const double* da
       if (which == 0) {
         WaveIpm<HostLane>::WState S;
         std::fill(state.begin(), state.end(), 0.0);
-        WaveIpm<HostLane>::layout(&S, reinterpret_cast<const WaveHdr*>(blk.data()), blk.data(), state.data());
+        if (WaveIpm<HostLane>::layout(&S, reinterpret_cast<const WaveHdr*>(blk.data()), blk.data(), state.data()) !=
+            reinterpret_cast<const WaveHdr*>(blk.data())->state_doubles) throw std::runtime_error("wave layout and wave_state_doubles disagree");
         S.row = row.data();
         S.ws_g = S.ws_l = S.ws_u = nullptr;
         S.fallback_max_n = fb ? 512 : 0;
