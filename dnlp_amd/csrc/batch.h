@@ -1095,7 +1095,7 @@ struct BatchRunner {
       static const char* nm[kWaveProfSlots] = {"solve (all)", "begin", "error", "eval_hessian", "barrier_terms", "assemble", "ldl_factor", "ldl_solve",
                                                "coo products", "residual combine", "quality()", "direction loops", "max_steps+measures", "trial point + f,g",
                                                "accept_trial", "(sweep)", "(spmv)", "mu oracle prologue", "[update_mu]", "[factor_with_inertia]", "[quality_function_mu]",
-                                               "[solve_refined]", "kkt_solve copy", "[line search]"};
+                                               "[solve_refined]", "kkt_solve copy", "[line search]", "(tail_factor)", "(tail_forward)", "(tail_backward)", ""};
       std::fprintf(stderr, "[wave profile] %llu iterations; cycles per iteration by phase (s_memtime ticks):\n", pr[kWaveProfSlots]);
       for (int k = 0; k < kWaveProfSlots; ++k) if (pr[k]) std::fprintf(stderr, "[wave profile]   %-22s %10.0f\n", nm[k], static_cast<double>(pr[k]) / it);
     }

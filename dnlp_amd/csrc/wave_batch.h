@@ -27,6 +27,10 @@ struct WaveLanesT {
   // v_readlane made the substitutions 17 % SLOWER than these plain uniform LDS loads — 46.1 -> 53.8 k cycles per iteration)
   __device__ static int tab_load(I*, int) { return 0; }
   __device__ static int tab_at(I* tab, int, int idx, int) { return static_cast<int>(tab[idx]); }
+  // a value every lane holds alike, as a scalar register
+  __device__ static int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+  // the dense tail keeps one row per lane (wave_ipm.h kTailSlots = 1): the entry of row `row` comes through v_readlane
+  template <int SL> __device__ static double row_get(const double (&a)[SL], int row) { return readlane_d(a[0], row); }
 };
 
 struct WaveArgs {

@@ -40,7 +40,7 @@
 
 namespace dnlp {
 
-constexpr int kWaveProfSlots = 24;
+constexpr int kWaveProfSlots = 28;
 
 // (device: the phases are real functions over one LDS pointer — the all-inlined generic kernel is a 28 k-instruction body)
 #if DNLP_DEVICE_PASS
@@ -81,7 +81,8 @@ struct WStateT {
   WCoo jr, jc, hs;
   i32 nblk, nvals, nlev, ngrp, nfwd;
   WI *bnode, *soff, *loff, *doff, *lev_off, *sblk, *sidx, *lev_f, *fnode, *foff, *fa, *fu0, *fu1, *lev_g, *gdst, *goff, *upd_u, *upd_v,
-     *hpos, *jpos, *dpos, *lev_r, *lev_t, *lev_fe;
+     *hpos, *jpos, *dpos, *lev_r, *lev_t, *lev_fe, *t_node, *t_d, *t_l, *t_fq, *t_fp;
+  i32 tail_L, tail_T;                // dense tail (wave_plan.h): first tail level (= nlev without one), its order
   i32 l_c0, l_c, l_b, l_Jc, l_fp, l_fp2, l_x0, l_lb, l_ub, l_cl, l_cu;
   // ---- vectors (LDS) ----
   WD *x, *zL, *zU, *xL, *xU, *grad, *dx, *dzL, *dzU, *xt, *Sx, *rx, *tN, *fixm;
@@ -146,6 +147,8 @@ struct WaveIpm {
     S->fa = blk + h->fa; S->fu0 = blk + h->fu0; S->fu1 = blk + h->fu1; S->lev_g = blk + h->lev_g; S->gdst = blk + h->gdst;
     S->goff = blk + h->goff; S->upd_u = blk + h->tau; S->upd_v = blk + h->tav; S->hpos = blk + h->hpos; S->jpos = blk + h->jpos; S->dpos = blk + h->dpos;
     S->lev_r = blk + h->lev_r; S->lev_t = blk + h->lev_t; S->lev_fe = blk + h->lev_fe;
+    S->t_node = blk + h->t_node; S->t_d = blk + h->t_d; S->t_l = blk + h->t_l; S->t_fq = blk + h->t_fq; S->t_fp = blk + h->t_fp;
+    S->tail_L = h->tail_L; S->tail_T = h->tail_T;
     S->l_c0 = h->l_c0; S->l_c = h->l_c; S->l_b = h->l_b; S->l_Jc = h->l_Jc; S->l_fp = h->l_fp; S->l_fp2 = h->l_fp2;
     S->l_x0 = h->l_x0; S->l_lb = h->l_lb; S->l_ub = h->l_ub; S->l_cl = h->l_cl; S->l_cu = h->l_cu;
     // vectors, 16-byte granules (the count per class is wave_plan.h wave_state_doubles)
@@ -450,6 +453,173 @@ struct WaveIpm {
     const i32 bv = ~av;
     return w[au] * vals[bv] + w[au + 1] * vals[bv + 1];
   }
+  // ---- dense tail (wave_plan.h WaveHdr): the trailing T x T matrix of a chain of one-block levels, ONE ROW PER LANE in
+  // registers.  The operations on every entry are those of the level code (sp_pivot, sp_scale, one update product per
+  // destination and level, subtracted in level order), so a host lane that owns all rows reproduces the generic text's bits;
+  // what goes away is the level machinery — four phases of index walks per block — for what is T^3 / 6 multiply-adds.
+  static constexpr int kTailMax = 32;
+  static constexpr int kTailSlots = (kTailMax + P::lanes - 1) / P::lanes;      // rows of the tail a lane owns (device 1, host 32)
+  DNLP_WFN DNLP_HD static void tail_factor(WS* S, double& nneg_io, double& nzero_io, double& bad_io) {
+    W_P0();
+    const int T = P::uni(S->tail_T), me = P::lane();      // (uniform: a scalar register, so that the unrolled loops below test it on the scalar unit)
+    double nneg = 0.0, nzero = 0.0, bad = 0.0;           // (lane 0 counts; handed back once)
+    WD* vals = S->svals;
+    WI *td = S->t_d, *tl = S->t_l;
+    double A[kTailSlots][kTailMax];
+#pragma clang loop unroll(full)
+    for (int sl = 0; sl < kTailSlots; ++sl) {
+      const int i = me + P::lanes * sl;
+#pragma clang loop unroll(full)
+      for (int j = 0; j < kTailMax; ++j) {
+        double v = 0.0;
+        if (i < T && j <= i) v = vals[j == i ? td[i] : tl[i * T + j]];
+        A[sl][j] = v;
+      }
+    }
+#pragma clang loop unroll(full)
+    for (int k = 0; k < kTailMax; ++k) if (k < T) {
+      double col[kTailSlots];
+#pragma clang loop unroll(full)
+      for (int sl = 0; sl < kTailSlots; ++sl) col[sl] = A[sl][k];
+      // sp_pivot of block k (a 1x1 block): every lane computes it from the same value, lane 0 counts
+      double d = P::row_get(col, k);
+      if (!(d == d) && me == 0) bad += 1.0;
+      bool fixed = false;
+      if (fabs(d) < 1e-300) { if (me == 0) nzero += 1.0; d = 1e-20; fixed = true; }
+      if (d < 0.0 && me == 0) nneg += 1.0;
+      const double dinv = 1.0 / d;
+      // sp_scale: rows i > k keep the unscaled entry for the updates (w) and store L = l / d
+      double wv[kTailSlots], sc[kTailSlots];
+#pragma clang loop unroll(full)
+      for (int sl = 0; sl < kTailSlots; ++sl) {
+        const int i = me + P::lanes * sl;
+        const bool below = i > k && i < T;
+        wv[sl] = below ? col[sl] : 0.0;
+        sc[sl] = below ? col[sl] * dinv : 0.0;
+        if (below) A[sl][k] = sc[sl];
+        if (i == k && fixed) A[sl][k] = d;
+      }
+      // the level's update triples: destination (i, j), i >= j > k, gets  - l_ik (l_jk / d).  No predicate on (i, j): rows
+      // up to k and rows / columns from T on carry wv = 0 or sc = 0, and what the products do to the entries ABOVE the diagonal
+      // is never read — three instructions per pair (two v_readlane, one fma) instead of a mask per pair
+#pragma clang loop unroll(full)
+      for (int j = k + 1; j < kTailMax; ++j) {
+        const double sj = P::row_get(sc, j);
+#pragma clang loop unroll(full)
+        for (int sl = 0; sl < kTailSlots; ++sl) A[sl][j] -= wv[sl] * sj;
+      }
+    }
+#pragma clang loop unroll(full)
+    for (int sl = 0; sl < kTailSlots; ++sl) {
+      const int i = me + P::lanes * sl;
+#pragma clang loop unroll(full)
+      for (int j = 0; j < kTailMax; ++j)
+        if (i < T && j <= i) vals[j == i ? td[i] : tl[i * T + j]] = A[sl][j];
+    }
+    nneg_io += nneg; nzero_io += nzero; bad_io += bad;
+    P::sync();
+    W_P1(24);
+  }
+  // forward substitution through the tail: the gathers of the tail's targets from the blocks before it (products side by
+  // side, runs added in storage order), then row t adds L_tk x_k for k < t as x_k becomes final — the order of the level code
+  DNLP_WFN DNLP_HD static void tail_forward(WS* S, WD* x, WD* y) {
+    W_P0();
+    const int T = P::uni(S->tail_T), me = P::lane();      // (uniform: a scalar register, so that the unrolled loops below test it on the scalar unit)
+    const WD* vals = S->svals;
+    WI *tn = S->t_node, *tl = S->t_l, *tfq = S->t_fq, *tfp = S->t_fp, *fa = S->fa, *fu0 = S->fu0, *fu1 = S->fu1;
+    const bool two = y != nullptr;
+    WD* scr = S->dy;                        // (dy dvL dvU st gt: consecutive and dead during a solve; wave_plan.h keeps t_nf within them)
+    WD* scr2 = scr + tfp[T];
+    const int nf = tfp[T];
+    for (int n = me; n < nf; n += P::lanes) {
+      const int q = tfq[n];
+      const i32 a = fa[q], u0 = fu0[q];
+      if (a >= 0) { const double l = vals[a]; scr[n] = l * x[u0]; if (two) scr2[n] = l * y[u0]; }
+      else {
+        const i32 b = ~a, u1 = fu1[q];
+        const double l0 = vals[b], l1 = vals[b + 1];
+        scr[n] = l0 * x[u0] + l1 * x[u1];
+        if (two) scr2[n] = l0 * y[u0] + l1 * y[u1];
+      }
+    }
+    P::sync();
+    double acc[kTailSlots], acc2[kTailSlots], xr[kTailSlots], yr[kTailSlots], Lr[kTailSlots][kTailMax];
+#pragma clang loop unroll(full)
+    for (int sl = 0; sl < kTailSlots; ++sl) {
+      const int t = me + P::lanes * sl;
+      const bool in = t < T;
+      const int f0 = in ? tfp[t] : 0, cnt = in ? tfp[t + 1] - f0 : 0;
+      acc[sl] = run_sum(0.0, scr + f0, cnt);
+      acc2[sl] = two ? run_sum(0.0, scr2 + f0, cnt) : 0.0;
+      xr[sl] = in ? x[tn[t]] : 0.0;
+      yr[sl] = (in && two) ? y[tn[t]] : 0.0;
+#pragma clang loop unroll(full)
+      for (int k = 0; k < kTailMax; ++k) Lr[sl][k] = (in && k < t) ? vals[tl[t * T + k]] : 0.0;
+    }
+#pragma clang loop unroll(full)
+    for (int k = 0; k < kTailMax; ++k) if (k < T) {
+      double xf[kTailSlots], yf[kTailSlots];
+#pragma clang loop unroll(full)
+      for (int sl = 0; sl < kTailSlots; ++sl) { xf[sl] = xr[sl] - acc[sl]; yf[sl] = yr[sl] - acc2[sl]; }
+      const double xk = P::row_get(xf, k), yk = two ? P::row_get(yf, k) : 0.0;
+#pragma clang loop unroll(full)
+      for (int sl = 0; sl < kTailSlots; ++sl) {
+        const int t = me + P::lanes * sl;
+        if (t == k) { xr[sl] = xk; yr[sl] = yk; }
+        // (no predicate: Lr[.][k] is zero for the rows up to k, whose sums are never looked at again)
+        acc[sl] += Lr[sl][k] * xk;
+        if (two) acc2[sl] += Lr[sl][k] * yk;
+      }
+    }
+#pragma clang loop unroll(full)
+    for (int sl = 0; sl < kTailSlots; ++sl) {
+      const int t = me + P::lanes * sl;
+      if (t < T) { x[tn[t]] = xr[sl]; if (two) y[tn[t]] = yr[sl]; }
+    }
+    P::sync();
+    W_P1(25);
+  }
+  // backward substitution through the tail (after D^-1): x_t -= sum over i > t of L_it x_i, t descending
+  DNLP_WFN DNLP_HD static void tail_backward(WS* S, WD* x, WD* y) {
+    W_P0();
+    const int T = P::uni(S->tail_T), me = P::lane();      // (uniform: a scalar register, so that the unrolled loops below test it on the scalar unit)
+    const WD* vals = S->svals;
+    WI *tn = S->t_node, *tl = S->t_l;
+    const bool two = y != nullptr;
+    double xr[kTailSlots], yr[kTailSlots], Lr[kTailSlots][kTailMax];
+#pragma clang loop unroll(full)
+    for (int sl = 0; sl < kTailSlots; ++sl) {
+      const int i = me + P::lanes * sl;
+      const bool in = i < T;
+      xr[sl] = in ? x[tn[i]] : 0.0;
+      yr[sl] = (in && two) ? y[tn[i]] : 0.0;
+#pragma clang loop unroll(full)
+      for (int k = 0; k < kTailMax; ++k) Lr[sl][k] = (in && k < i) ? vals[tl[i * T + k]] : 0.0;
+    }
+#pragma clang loop unroll(full)
+    for (int t = kTailMax - 1; t >= 0; --t) if (t < T) {
+      double a0 = 0.0, c0 = 0.0;
+#pragma clang loop unroll(full)
+      for (int sl = 0; sl < kTailSlots; ++sl) {
+        a0 += Lr[sl][t] * xr[sl];          // (Lr[.][t] is zero for the rows up to t and beyond the tail)
+        if (two) c0 += Lr[sl][t] * yr[sl];
+      }
+      a0 = P::sum(a0);
+      if (two) c0 = P::sum(c0);
+#pragma clang loop unroll(full)
+      for (int sl = 0; sl < kTailSlots; ++sl) {
+        const int i = me + P::lanes * sl;
+        if (i == t) { xr[sl] -= a0; if (two) yr[sl] -= c0; }
+      }
+    }
+#pragma clang loop unroll(full)
+    for (int sl = 0; sl < kTailSlots; ++sl) {
+      const int i = me + P::lanes * sl;
+      if (i < T) { x[tn[i]] = xr[sl]; if (two) y[tn[i]] = yr[sl]; }
+    }
+    P::sync();
+    W_P1(26);
+  }
   // sparse_ldl.h sparse_ldl_factor (no dense tail).  Per level: pivots, row scaling, then the update triples — their
   // products side by side into the scratch array, each destination's run added in storage order (see run_sum).
   DNLP_WFN DNLP_HD static bool ldl_factor(WS* S, int* nneg_out, int* nzero_out) {
@@ -461,7 +631,7 @@ struct WaveIpm {
     WD* scr = S->scr;
     WI *lev_off = S->lev_off, *soff = S->soff, *lev_g = S->lev_g, *goff = S->goff, *gdst = S->gdst, *tau = S->upd_u, *tav = S->upd_v;
     double nneg = 0.0, nzero = 0.0, bad = 0.0;
-    const int nlev = S->nlev, nt = nlev + 1;
+    const int nlev = S->tail_L, nt = S->nlev + 1;          // (the levels before the dense tail; tail_L = nlev without one)
     // (the per-level bounds: one table entry per lane in a register, read back with v_readlane — two dependent uniform
     //  LDS trips less in front of every level phase)
     WI *lev_r = S->lev_r, *lev_t = S->lev_t;
@@ -495,6 +665,7 @@ struct WaveIpm {
       }
       P::sync();
     }
+    if (S->tail_T > 0) tail_factor(S, nneg, nzero, bad);
     nneg = P::sum(nneg);
     nzero = P::sum(nzero);
     bad = P::sum(bad);
@@ -536,7 +707,7 @@ struct WaveIpm {
     const WD* vals = S->svals;
     WI *lev_f = S->lev_f, *foff = S->foff, *fnode = S->fnode, *lev_off = S->lev_off, *soff = S->soff, *bnode = S->bnode, *loff = S->loff,
        *sidx = S->sidx, *doff = S->doff, *fa = S->fa, *fu0 = S->fu0, *fu1 = S->fu1;
-    const int nlev = S->nlev, nblk = S->nblk, nt = nlev + 1;
+    const int nlev = S->tail_L, nblk = S->nblk, nt = S->nlev + 1;      // (the levels before the dense tail)
     WI *lev_r = S->lev_r, *lev_fe = S->lev_fe;
     const bool two = y != nullptr;
     for (int lev = 1; lev < nlev; ++lev) {
@@ -582,10 +753,12 @@ struct WaveIpm {
       }
       P::sync();
     }
+    if (S->tail_T > 0) tail_forward(S, x, y);
     // D^-1, all blocks side by side (measured: folded into the backward pass — one level barrier less — the division
     // joins each block's dependent chain and the solve gets 8 % slower)
     for (int k = me; k < nblk; k += L) dsolve(vals, doff, bnode[2 * k], bnode[2 * k + 1], k, x, y);
     P::sync();
+    if (S->tail_T > 0) tail_backward(S, x, y);
     for (int lev = nlev - 1; lev >= 0; --lev) {
       const int b0 = lev_off[lev], b1 = lev_off[lev + 1];
       const int nbl = b1 - b0, nrw = lev_r[lev + 1] - lev_r[lev];

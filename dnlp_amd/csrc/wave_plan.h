@@ -38,6 +38,13 @@ struct WaveHdr {
   i32 sp_nblk, sp_nvals, sp_nlev, sp_ngrp, sp_nfwd, sp_ntrip, sp_rows;
   i32 bnode, soff, loff, doff, lev_off, sblk, sidx, lev_f, fnode, foff, fa, fu0, fu1, lev_g, gdst, goff, tau, tav, hpos, jpos, dpos;
   i32 lev_r, lev_t, lev_fe, lev_pad;          // per level (nlev + 1 each): first struct row, first update triple, first gathered row
+  // DENSE TAIL: the last tail_T levels are a chain of one 1x1 block each over a dense trailing matrix (a dense separator:
+  // circle packing n = 10 ends in 21 such levels of 23).  wave_ipm.h factors and solves that matrix in registers — one
+  // row per lane — instead of walking the level machinery once per block.  tail_L = first tail level (= nlev: no tail).
+  i32 tail_L, tail_T;
+  i32 t_node, t_d, t_l;                       // tail position -> KKT node / value index of D; (i, j), i > j -> value index of L_ij (T x T)
+  i32 t_fq, t_fp;                             // forward gathers of the tail targets from blocks BEFORE the tail: entry list, T + 1 offsets into it
+  i32 t_nf;                                   // entries in t_fq
   // data row of an instance (doubles; batch.h BatchLayout)
   i32 l_c0, l_c, l_b, l_Jc, l_G, l_Mg, l_Mw, l_MJ, l_MH, l_fp, l_fp2, l_x0, l_lb, l_ub, l_cl, l_cu, l_total;
   i32 state_doubles;                          // solver state of one instance (wave_ipm.h layout)
@@ -171,6 +178,60 @@ inline std::vector<i32> build_wave_plan(E* ex, const Tape<E>& t, const SparsePla
       lfe[l] = sp.foff[static_cast<size_t>(sp.lev_f[l])];
     }
     h.lev_r = put(lr); h.lev_t = put(lt); h.lev_fe = put(lfe);
+  }
+  {
+    // dense tail (see WaveHdr): the longest chain of one-block 1x1 levels at the end whose trailing matrix is dense
+    const i32 nlev = static_cast<i32>(sp.lev_off.size()) - 1;
+    i32 Ls = nlev;
+    auto one_by_one = [&](i32 lev) { const i32 b = sp.lev_off[static_cast<size_t>(lev)]; return sp.lev_off[static_cast<size_t>(lev) + 1] - b == 1 && sp.bnode[static_cast<size_t>(2 * b + 1)] < 0; };
+    while (Ls > 0 && one_by_one(Ls - 1)) --Ls;
+    i32 T = nlev - Ls;
+    const i32 kTailMax = 32;
+    if (T > kTailMax) { Ls = nlev - kTailMax; T = kTailMax; }
+    std::vector<i32> tnode, td, tl, tfq, tfp;
+    bool ok = T >= 3 && !std::getenv("DNLP_WAVE_NO_TAIL");
+    if (ok) {
+      std::vector<i32> pos(static_cast<size_t>(sp.n), -1);
+      for (i32 t = 0; t < T; ++t) {
+        const i32 b = sp.lev_off[static_cast<size_t>(Ls + t)];
+        tnode.push_back(sp.bnode[static_cast<size_t>(2 * b)]);
+        td.push_back(sp.doff[static_cast<size_t>(b)]);
+        pos[static_cast<size_t>(tnode.back())] = t;
+      }
+      tl.assign(static_cast<size_t>(T) * T, -1);
+      for (i32 t = 0; t < T && ok; ++t) {
+        const i32 b = sp.lev_off[static_cast<size_t>(Ls + t)];
+        i32 prev = t;
+        for (i32 r = sp.soff[static_cast<size_t>(b)]; r < sp.soff[static_cast<size_t>(b) + 1]; ++r) {
+          const i32 i = pos[static_cast<size_t>(sp.sidx[static_cast<size_t>(r)])];
+          if (i <= prev) { ok = false; break; }              // struct rows: later tail nodes, ascending
+          prev = i;
+          tl[static_cast<size_t>(i) * T + t] = sp.loff[static_cast<size_t>(b)] + (r - sp.soff[static_cast<size_t>(b)]);
+        }
+        for (i32 i = t + 1; i < T && ok; ++i) if (tl[static_cast<size_t>(i) * T + t] < 0) ok = false;     // dense
+      }
+      // the forward gathers of the tail targets: one target per tail level; its entries from blocks before the tail come
+      // first (ascending by source block), then the tail's own rows k = 0 .. t - 1 in order
+      tfp.push_back(0);
+      for (i32 t = 0; t < T && ok; ++t) {
+        const i32 h0 = sp.lev_f[static_cast<size_t>(Ls + t)], h1 = sp.lev_f[static_cast<size_t>(Ls + t) + 1];
+        if (Ls + t == 0) { if (h1 != h0) ok = false; tfp.push_back(static_cast<i32>(tfq.size())); continue; }
+        if (h1 - h0 != 1 || sp.fnode[static_cast<size_t>(h0)] != tnode[static_cast<size_t>(t)]) { ok = false; break; }
+        i32 q = sp.foff[static_cast<size_t>(h0)];
+        const i32 q1 = sp.foff[static_cast<size_t>(h0) + 1];
+        for (; q < q1 && pos[static_cast<size_t>(sp.fu0[static_cast<size_t>(q)])] < 0; ++q) tfq.push_back(q);
+        for (i32 k = 0; k < t && ok; ++k, ++q)
+          if (q >= q1 || sp.fa[static_cast<size_t>(q)] != tl[static_cast<size_t>(t) * T + k] || pos[static_cast<size_t>(sp.fu0[static_cast<size_t>(q)])] != k) ok = false;
+        if (q != q1) ok = false;
+        tfp.push_back(static_cast<i32>(tfq.size()));
+      }
+    }
+    // (the tail's forward products use the five consecutive row-sized arrays dy dvL dvU st gt — dead during every solve — as scratch)
+    if (ok && static_cast<i64>(tfq.size()) > 5 * ((static_cast<i64>(t.m) + 1) & ~static_cast<i64>(1))) ok = false;
+    if (!ok) { T = 0; Ls = nlev; tnode.clear(); td.clear(); tl.clear(); tfq.clear(); tfp.assign(1, 0); }
+    h.tail_L = Ls; h.tail_T = T;
+    h.t_node = put(tnode); h.t_d = put(td); h.t_l = put(tl); h.t_fq = put(tfq); h.t_fp = put(tfp);
+    h.t_nf = narrow(static_cast<i64>(tfq.size()));
   }
   h.tau = put(sp.tau); h.tav = put(sp.tav); h.hpos = put(sp.hpos); h.jpos = put(sp.jpos); h.dpos = put(sp.dpos);
   h.l_c0 = narrow(lay.c0); h.l_c = narrow(lay.c); h.l_b = narrow(lay.b); h.l_Jc = narrow(lay.Jc); h.l_G = narrow(lay.G); h.l_Mg = narrow(lay.Mg);

@@ -89,6 +89,8 @@ struct HostLane {
   static double vmax(double v) { return v; }
   static int tab_load(const dnlp::i32*, int) { return 0; }
   static int tab_at(const dnlp::i32* tab, int, int idx, int) { return tab[idx]; }
+  static int uni(int v) { return v; }
+  template <int SL> static double row_get(const double (&a)[SL], int row) { return a[row]; }      // one lane owns every tail row
 };
 }  // namespace
 
@@ -115,8 +117,8 @@ extern "C" int orc_wave_solve_batch(orc_problem* vp, int batch, const double* da
       state.assign(static_cast<size_t>(reinterpret_cast<const WaveHdr*>(blk.data())->state_doubles) + 8, 0.0);
       if (std::getenv("DNLP_WAVE_DEBUG")) {
         const WaveHdr* hh = reinterpret_cast<const WaveHdr*>(blk.data());
-        std::fprintf(stderr, "[wave] plan block %d ints (%.1f KB), state %d doubles (%.1f KB), WState %zu B; units %d, nvals %d, blocks %d, levels %d, triples %d\n",
-                     hh->total, hh->total * 4 / 1024.0, hh->state_doubles, hh->state_doubles * 8 / 1024.0, sizeof(WaveIpm<HostLane>::WState), hh->nunits, hh->sp_nvals, hh->sp_nblk, hh->sp_nlev, hh->sp_ntrip);
+        std::fprintf(stderr, "[wave] plan block %d ints (%.1f KB), state %d doubles (%.1f KB), WState %zu B; units %d, nvals %d, blocks %d, levels %d, triples %d; dense tail of order %d from level %d\n",
+                     hh->total, hh->total * 4 / 1024.0, hh->state_doubles, hh->state_doubles * 8 / 1024.0, sizeof(WaveIpm<HostLane>::WState), hh->nunits, hh->sp_nvals, hh->sp_nblk, hh->sp_nlev, hh->sp_ntrip, hh->tail_T, hh->tail_L);
       }
     }
     const bool fb = (t.N + t.m) <= 512 && p->linear_solver != 2;

@@ -61,3 +61,22 @@ def test_templates_outside_the_wave_solver_are_refused_with_a_reason():
     hb = HostBatch(ParametricBatch(prob, [p]))
     with pytest.raises(RuntimeError, match="reduction-class|no sparse plan"):
         hb.solve(np.ones((2, 3)), 0)
+
+
+def test_dense_tail_in_registers_changes_no_bit(monkeypatch):
+    """circle packing n = 10 ends in a chain of 21 one-block levels over a dense trailing matrix: the wavefront solver
+    factors and solves it one row per lane in registers (wave_ipm.h tail_factor / tail_forward / tail_backward) instead of
+    walking the level code per block.  With and without the tail (DNLP_WAVE_NO_TAIL) the host lane gives the generic text's
+    bits — the tail performs the level code's operations on every entry, in its order."""
+    prob, params, sample, _ = bp.template_circle_packing(10)
+    pb = ParametricBatch(prob, params)
+    thetas = np.stack([sample(i) for i in range(16)])
+    g = HostBatch(pb).solve(thetas, 1)
+    for no_tail in ("", "1"):
+        if no_tail:
+            monkeypatch.setenv("DNLP_WAVE_NO_TAIL", "1")
+        w = HostBatch(pb).solve(thetas, 0)
+        took = w["status"] != NEEDS_GENERIC
+        assert took.sum() >= 12
+        for k in ("x", "obj", "mult_g", "iters", "nfact", "status"):
+            assert np.array_equal(w[k][took], g[k][took]), (no_tail, k)
