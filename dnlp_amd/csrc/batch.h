@@ -930,7 +930,9 @@ struct BatchRunner {
   // (kWaveNeedsGeneric: a structurally singular static pivot sequence, the generic kernel's Bunch-Kaufman switch) are
   // solved by the generic kernel in a second, small launch and their results merged.
   // launch form of this template: wavefronts per workgroup, state in LDS, plan in LDS — the richest that fits 160 KB
+  int wf_nw = 0, wf_sl = 0, wf_pl = 0, wf_per_cu = 0;      // the form of this template, found once (six hipFuncGetAttributes + an occupancy query)
   void wave_form(int& nw, int& sl, int& pl) {
+    if (wf_nw > 0 && !std::getenv("DNLP_WAVE_FORM")) { nw = wf_nw; sl = wf_sl; pl = wf_pl; return; }
     const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(wave_blk.data());
     const size_t plan_b = wave_fits16 ? ((static_cast<size_t>(h.total) * 2 + 15) & ~static_cast<size_t>(15)) : (static_cast<size_t>(1) << 30);
     const size_t state_b = static_cast<size_t>(h.state_doubles) * 8;
@@ -947,7 +949,7 @@ struct BatchRunner {
         nw = f / 100; sl = (f / 10) % 10; pl = f % 10;
         if (pl && !wave_fits16) throw std::runtime_error("wavefront solver: this plan does not fit 16-bit tables");
       }
-    }
+    } else { wf_nw = nw; wf_sl = sl; wf_pl = pl; }
   }
   template <int NW, bool SL, bool PL>
   void launch_wave(const WaveArgs& w, int grid, unsigned lds, hipStream_t stream) {
@@ -994,7 +996,8 @@ struct BatchRunner {
     int per_cu = 1;
     const unsigned lds = static_cast<unsigned>((pl ? plan_b : 0) + (sl ? static_cast<size_t>(nw) * state_b : 0));
     const int form = 100 * nw + 10 * sl + pl;
-    switch (form) {
+    if (wf_per_cu > 0 && form == 100 * wf_nw + 10 * wf_sl + wf_pl) per_cu = wf_per_cu;
+    else switch (form) {
       case 411: per_cu = wave_occupancy<4, true, true>(lds); break;
       case 211: per_cu = wave_occupancy<2, true, true>(lds); break;
       case 111: per_cu = wave_occupancy<1, true, true>(lds); break;
@@ -1003,6 +1006,7 @@ struct BatchRunner {
       case 400: per_cu = wave_occupancy<4, false, false>(lds); break;
       default: throw std::runtime_error("wavefront solver: no such launch form");
     }
+    if (form == 100 * wf_nw + 10 * wf_sl + wf_pl) wf_per_cu = per_cu;
     if (const char* e = std::getenv("DNLP_WAVE_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 16) per_cu = v; }
     int grid = std::min((batch + nw - 1) / nw, ncu * per_cu);
     if (grid < 1) grid = 1;
@@ -1053,6 +1057,9 @@ struct BatchRunner {
     if (std::getenv("DNLP_BATCH_DEBUG"))
       std::fprintf(stderr, "[batch] wavefront solver: %d wavefronts per workgroup, state %s (%zu B per instance), plan %s (%zu B), dynamic LDS %u B, grid %d\n",
                    nw, sl ? "in LDS" : "in global memory", state_b, pl ? "in LDS" : "in global memory", plan_b, lds, grid);
+    const bool dbg = std::getenv("DNLP_BATCH_DEBUG") != nullptr;
+    const double tdbg0 = now_sec();
+    auto mark = [&](const char* what) { if (dbg) std::fprintf(stderr, "[batch] %-22s %.4f s\n", what, now_sec() - tdbg0); };
     hipEvent_t e0, e1;
     DNLP_HIP_CHECK(hipEventCreate(&e0));
     DNLP_HIP_CHECK(hipEventCreate(&e1));
@@ -1074,6 +1081,7 @@ struct BatchRunner {
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     double total_sec = 1e-3 * ms;
+    mark("wave kernel done");
     auto down = [&](void* hp, const void* d, size_t bytes) { if (hp && bytes) DNLP_HIP_CHECK(hipMemcpy(hp, d, bytes, hipMemcpyDeviceToHost)); };
     std::vector<int> st_local;
     int* st_host = status_out;
@@ -1100,6 +1108,7 @@ struct BatchRunner {
       for (int k = 0; k < kWaveProfSlots; ++k) if (pr[k]) std::fprintf(stderr, "[wave profile]   %-22s %10.0f\n", nm[k], static_cast<double>(pr[k]) / it);
     }
 #endif
+    mark("wave results copied");
     release();
     // the refused instances, through the generic kernel
     std::vector<int> refused;

@@ -328,9 +328,266 @@ __global__ void __launch_bounds__(256) ldlt_rows128_kernel(double* __restrict__ 
   }
 }
 
+
+// ---- a whole 512-column panel below its diagonal block in ONE launch (round 5) -------------------------------------
+// Once the 512 x 512 diagonal block of a panel is factored (the sub-panel chain above on its own 512 rows: launches of
+// 1-6 workgroups), every block of 16 rows below it is independent of every other: X^T_C = inv(L_CC) (A^T_C -
+// sum_{P<C} L_CP X^T_P) over the panel's thirty-two 16-column blocks.  The sub-panel chain did that as 4 x (rows128 +
+// in-panel update over ALL rows below) — eight chip-wide launches per panel on the critical path, each waiting for
+// compute units beside the trailing update.  Here a wavefront carries its 16 rows through the four sub-panels alone:
+// the eight accumulator blocks of the current sub-panel first take the products with the earlier sub-panels' W (read
+// back from the panel workspace: the lane that wrote an entry is the lane that reads it — no fence, no barrier), then
+// the chain of ldlt_rows128_kernel.  2112 MFMAs per 16 rows, 128 registers: it shares a compute unit with the
+// trailing update's workgroups instead of waiting for an empty one.
+//   Ltop4: the four packed operand copies ldlt_top128_*_kernel leave behind (LD_TOP_WS doubles apart)
+//   Lpk:   the six off-diagonal 128 x 128 blocks of the diagonal block's L, packed by ldlt_pack512_kernel:
+//          [(j (j - 1) / 2 + i) * 64 + c * 8 + p][k][i'] = -L[128 j + 16 c + i'][128 i + 16 p + k]
+constexpr int LD_P = 512;
+constexpr int LD_PK_WS = 6 * 64 * 256;
+
+__global__ void __launch_bounds__(256) ldlt_pack512_kernel(const double* __restrict__ A, i64 ld, int K0, double* __restrict__ Lpk) {
+  const int pair = blockIdx.x >> 6, c = (blockIdx.x >> 3) & 7, p = blockIdx.x & 7;
+  int j = 1, base = 0;
+  while (base + j <= pair) { base += j; ++j; }
+  const int i = pair - base;
+  const int t = threadIdx.x, ii = t & 15, k = t >> 4;
+  Lpk[static_cast<i64>(blockIdx.x) * 256 + k * 16 + ii] =
+      -A[(K0 + 128 * j + 16 * c + ii) + static_cast<i64>(K0 + 128 * i + 16 * p + k) * ld];
+}
+
+// Sixteen rows (one wavefront) through the sub-panels 0 .. nsub - 1 of a 512-column panel.  PACK: the rows belong to
+// the diagonal block itself (ldlt_diag512_kernel) — their -L blocks also go to `pack` in operand layout.
+struct LdltNoHook { __device__ void operator()(int) const {} };
+// (pre / mid / post: called by the whole workgroup before sub-panel j's products, before its chain, after its stores —
+//  the waits and the diagonal-block update of ldlt_diag512_kernel)
+template <bool PACK, class Pre = LdltNoHook, class Mid = LdltNoHook, class Post = LdltNoHook>
+__device__ __forceinline__ void ldlt_trsm16(double* __restrict__ A, i64 ld, int K0, i64 row, i64 rr, bool ok, double* __restrict__ Wp,
+                                            i64 ldw, const double* __restrict__ Ltop4, const double* __restrict__ Lpk, int nsub,
+                                            double* __restrict__ pack, Pre pre = Pre(), Mid mid = Mid(), Post post = Post()) {
+  const int lane = threadIdx.x & 63;
+  const int lr = lane & 15, lq = lane >> 4;
+  // Operands travel in groups of 32 (one per MFMA of the group), two groups in flight: the loads of the next group are
+  // issued BEFORE the products of the current one (the compiler, left alone, waits for every load right in front of its
+  // MFMA — measured 470 cycles per product that way, 150 with the groups).
+  double a0[32], a1[32], b0[4], b1[4];
+#pragma unroll 1
+  for (int j = 0; j < nsub; ++j) {
+    const int j0 = K0 + LD_T * j;
+    pre(j);
+    mfma_d4 D[LD_TB];
+#pragma unroll
+    for (int c = 0; c < LD_TB; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) D[c][r] = A[rr + static_cast<i64>(j0 + 16 * c + lq + 4 * r) * ld];
+    // the earlier sub-panels' share: D_c += (-L_(j,c),(i,p)) W^T_(i,p), step t = 8 i + p
+    const double* pkj = Lpk + static_cast<i64>(j * (j - 1) / 2) * 64 * 256 + lq * 16 + lr;
+    const double* wsrc = Wp + rr + static_cast<i64>(lq) * ldw;
+    auto fetch = [&](double (&a)[32], double (&b)[4], int t) {
+      const double* pk = pkj + static_cast<i64>(t >> 3) * 64 * 256 + (t & 7) * 256;
+#pragma unroll
+      for (int c = 0; c < LD_TB; ++c)
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) a[4 * c + sidx] = pk[c * 8 * 256 + 64 * sidx];
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx) b[sidx] = wsrc[static_cast<i64>(16 * t + 4 * sidx) * ldw];
+    };
+    auto products = [&](const double (&a)[32], const double (&b)[4]) {
+#pragma unroll
+      for (int c = 0; c < LD_TB; ++c)
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) D[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * c + sidx], b[sidx], D[c], 0, 0, 0);
+    };
+    const int nt = LD_TB * j;
+    if (nt > 0) fetch(a0, b0, 0);
+#pragma unroll 1
+    for (int t = 0; t < nt; t += 2) {
+      fetch(a1, b1, t + 1);
+      asm volatile("" ::: "memory");
+      products(a0, b0);
+      if (t + 2 < nt) fetch(a0, b0, t + 2);
+      asm volatile("" ::: "memory");
+      products(a1, b1);
+    }
+    mid(j);
+    // the sub-panel's own chain (ldlt_rows128_kernel), block c's operands fetched under block c - 1's products
+    const double* top = Ltop4 + static_cast<i64>(j) * LD_TOP_WS;
+    const double* opn = top + LD_TOP_NEG + lq * 16 + lr;
+    const double* opi = top + LD_TOP_INV + lq * 16 + lr;
+    auto fetch_c = [&](double (&a)[32], int c) {
+#pragma unroll
+      for (int p = 0; p < LD_TB - 1; ++p)
+        if (p < c) {
+#pragma unroll
+          for (int sidx = 0; sidx < 4; ++sidx) a[4 * p + sidx] = opn[((c * (c - 1) / 2 + p) * 16 + 4 * sidx) * 16];
+        }
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx) a[28 + sidx] = opi[(c * 16 + 4 * sidx) * 16];
+    };
+    fetch_c(a0, 0);
+#pragma unroll
+    for (int c = 0; c < LD_TB; ++c) {
+      double (&cur)[32] = (c & 1) ? a1 : a0;
+      double (&nxt)[32] = (c & 1) ? a0 : a1;
+      if (c + 1 < LD_TB) fetch_c(nxt, c + 1);
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int p = 0; p < c; ++p)
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) D[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[4 * p + sidx], D[p][sidx], D[c], 0, 0, 0);
+      mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[28 + sidx], D[c][sidx], acc, 0, 0, 0);
+      D[c] = acc;
+    }
+    if (ok) {
+#pragma unroll
+      for (int c = 0; c < LD_TB; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = 16 * c + lq + 4 * r;
+          const double l = D[c][r] * top[LD_TOP_DINV + col];
+          Wp[row + static_cast<i64>(LD_T * j + col) * ldw] = D[c][r];
+          A[row + static_cast<i64>(j0 + col) * ld] = l;
+          if (PACK) pack[static_cast<i64>(j) * 64 * 256 + c * 256 + 64 * r + lane] = -l;
+        }
+    }
+    post(j);
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) ldlt_rows512_kernel(double* __restrict__ A, i64 ld, int K0, int n, double* __restrict__ Wp,
+                                                              i64 ldw, const double* __restrict__ Ltop4, const double* __restrict__ Lpk) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const i64 row0 = static_cast<i64>(K0) + LD_P + (static_cast<i64>(blockIdx.x) * 4 + wave) * 16;
+  if (row0 >= n) return;                                  // whole wavefront; the kernel has no barrier
+  const i64 row = row0 + (lane & 15);
+  const bool ok = row < n;
+  const i64 rr = ok ? row : static_cast<i64>(n) - 1;      // clamped loads, predicated stores
+  ldlt_trsm16<false>(A, ld, K0, row, rr, ok, Wp, ldw, Ltop4, Lpk, LD_P / LD_T, nullptr);
+}
+
 }  // namespace dnlp
 #include "ldlt_top_mfma.h"
 namespace dnlp {
+
+// ---- the 512 x 512 diagonal block of a panel in ONE launch of four workgroups (round 5) ------------------------------
+// Left-looking over its four 128-column sub-panels: workgroup j (eight wavefronts, wavefront w = its block row w) owns
+// block row j.  For every sub-panel i < j:
+//   1. its 16 rows through sub-panel i (ldlt_trsm16): the products with the sub-panels left of i as soon as workgroup i
+//      has published ITS rows' packed -L (pk_done[i]), the chain as soon as workgroup i has factored its diagonal block
+//      (top_done[i]); W to the panel workspace, L to the matrix, -L packed for ldlt_rows512_kernel and for step 2;
+//   2. barrier; its block row of the 128 x 128 diagonal block takes A_(w,w-q)^T += (-L_(w-q),(i,p)) W_(w),(i,p)^T — the
+//      B operands its own W read back, the A operands the packed copies the other wavefronts just wrote;
+// then the block factorisation of ldlt_top128_mfma_kernel on the registers that hold the block row.  Behind the last
+// top block of the chain there are only one chain (144 MFMAs), one update (32 (w + 1)) and the next top block; everything
+// else runs under the top blocks of the workgroups above.  A workgroup waits only for LOWER workgroup indices (dispatch
+// order: no co-residency assumption).  One workgroup for the whole block was measured first: 45 MFLOP on one compute
+// unit's four FP64 matrix pipes (64 cycles per 16 x 16 x 4 on this part) — 460 us, the ten-launch chain 315.
+struct PanelCtl { unsigned top_done[4]; unsigned pk_done[4]; unsigned abort; unsigned pad[23]; };
+
+// all threads; false = gave up (a publisher that never came: the launch reports `fail` instead of hanging)
+__device__ inline bool panel_wait(unsigned* flag, unsigned epoch, PanelCtl* ctl, int* s_ok) {
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    int good = 1;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 1023u) == 0u && (spins > (1u << 22) || __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch)) {
+        __hip_atomic_store(&ctl->abort, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        good = 0;
+        break;
+      }
+    }
+    *s_ok = good;
+  }
+  __syncthreads();
+  __threadfence();          // (acquire side: what the publisher wrote before its flag)
+  return *s_ok != 0;
+}
+__device__ inline void panel_publish(unsigned* flag, unsigned epoch) {
+  __threadfence();          // every storing thread: its stores are out of this XCD's caches before the flag
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(LD_TOPM_THREADS) ldlt_diag512_kernel(double* __restrict__ A, i64 ld, int K0, LdltInfo* info, double tiny,
+                                                                      double* __restrict__ Ltop4, double* __restrict__ Lpk,
+                                                                      double* __restrict__ Wp, i64 ldw, PanelCtl* ctl, unsigned epoch) {
+  __shared__ __attribute__((aligned(16))) double negL[LD_TB][256];
+  __shared__ double invS[16 * 17];
+  __shared__ double dinvS[16];
+  __shared__ int s_ok;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = static_cast<int>(blockIdx.x);
+  const int j0 = K0 + LD_T * j;
+  int nneg = 0, nzero = 0, fail = 0;
+  bool alive = true;
+  mfma_d4 T[LD_TB];
+  if (j > 0) {
+    const i64 row = static_cast<i64>(j0) + 16 * w + (lane & 15);
+    double* pack = Lpk + (static_cast<i64>(j * (j - 1) / 2) * 64 + w * 8) * 256;
+    const double* pkj = Lpk + static_cast<i64>(j * (j - 1) / 2) * 64 * 256 + lane;
+    const double* wsrc = Wp + row + static_cast<i64>(lane >> 4) * ldw;
+    double* tdst = A + (j0 + 16 * w + (lane & 15)) + static_cast<i64>(j0 + 16 * w + (lane >> 4)) * ld;
+    auto pre = [&](int i) { if (i > 0 && alive) alive = panel_wait(&ctl->pk_done[i], epoch, ctl, &s_ok); };
+    auto mid = [&](int i) { if (alive) alive = panel_wait(&ctl->top_done[i], epoch, ctl, &s_ok); };
+    auto post = [&](int i) {
+      // the packed -L of (j, i) is complete: later workgroups may take their products with it; this one its diagonal block
+      if (i == j - 1) panel_publish(&ctl->pk_done[j], epoch);
+      else __syncthreads();
+      ldlt_top128_load(T, A, ld, j0);
+      double a0[16], a1[16], bb[32];
+#pragma unroll
+      for (int pp = 0; pp < LD_TB; ++pp)
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) bb[4 * pp + sidx] = wsrc[static_cast<i64>(LD_T * i + 16 * pp + 4 * sidx) * ldw];
+      // half a group (four column blocks of one q) in flight beside the half being multiplied
+      auto fetchg = [&](double (&a)[16], int q, int h) {
+        const double* pk = pkj + (static_cast<i64>(i) * 64 + (w - q) * 8 + 4 * h) * 256;
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+          for (int sidx = 0; sidx < 4; ++sidx) a[4 * pp + sidx] = pk[pp * 256 + 64 * sidx];
+      };
+      fetchg(a0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < LD_TB; ++q)
+        if (q <= w) {
+          fetchg(a1, q, 1);
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int e = 0; e < 16; ++e) T[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], bb[e], T[q], 0, 0, 0);
+          if (q + 1 < LD_TB && q + 1 <= w) fetchg(a0, q + 1, 0);
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int e = 0; e < 16; ++e) T[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], bb[16 + e], T[q], 0, 0, 0);
+        }
+      if (i < j - 1) {
+        // back to the matrix until the next sub-panel's turn (the lane that stores an entry is the lane that reloads it)
+#pragma unroll
+        for (int q = 0; q < LD_TB; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if ((q > 0 && q <= w) || (q == 0 && (lane >> 4) + 4 * r <= (lane & 15))) tdst[static_cast<i64>(4 * r - 16 * q) * ld] = T[q][r];
+      }
+    };
+    ldlt_trsm16<true>(A, ld, K0, row, row, true, Wp, ldw, Ltop4, Lpk, j, pack, pre, mid, post);
+    // (the products filled the whole of T[0]; the factorisation wants zeros above its diagonal)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[0][r] = ((lane >> 4) + 4 * r <= (lane & 15)) ? T[0][r] : 0.0;
+  } else {
+    ldlt_top128_load(T, A, ld, j0);
+  }
+  ldlt_top128_body(T, A, ld, j0, tiny, Ltop4 + static_cast<i64>(j) * LD_TOP_WS, nneg, nzero, fail, negL, invS, dinvS);
+  panel_publish(&ctl->top_done[j], epoch);
+  if (!alive) fail = 1;
+  if (lane == 0) {
+    if (nneg) atomicAdd(&info->nneg, nneg);
+    if (nzero) atomicAdd(&info->nzero, nzero);
+    if (fail) atomicExch(&info->fail, 1);
+  }
+}
 
 // ---- C -= W L^T on FP64 MFMA ---------------------------------------------------------------
 // Interior tiles (full 128x128, strictly below the diagonal, K a multiple of 16, 16-B aligned
@@ -1455,6 +1712,17 @@ struct BlockedLdlt {
   bool inv_mfma = true;                    // inverses of the diagonal 128-blocks on MFMA blocks (DNLP_LDLT_INV_MFMA=0: the 128-lane kernel)
   bool top_mfma = true;                    // the 128 x 128 top block on MFMA blocks (DNLP_LDLT_TOP_MFMA=0: the 4 x 4 tile kernel)
   bool sub128 = true;                      // panels in 128-column sub-panels (DNLP_LDLT_T128=0: the 32-column chain)
+  // A full 512-column panel as diagonal block first, then ldlt_rows512_kernel (DNLP_LDLT_FUSED_ROWS=1).  OFF: measured on the
+  // MI355X (round 5, tools/ldlt_fused_ab.sh) it reproduces the chain's factor bit for bit and is SLOWER at every order —
+  // 11 000: 13.1 ms chain, 14.2 fused rows + ten-launch diagonal block, 15.3 with the four-workgroup diagonal block
+  // (335 us per launch against 315 for the ten launches), 17.3 with a one-workgroup diagonal block (460 us: 45 MFLOP on one
+  // compute unit's FP64 matrix pipes, 64 cycles per 16 x 16 x 4 on this part); ldlt_rows512_kernel 132-146 us per panel
+  // (56 us of MFMA issue per wavefront).  The panel's critical path is the diagonal block, not the rows below it.
+  bool fused_rows = false;
+  double* Lpk = nullptr;                   // ... the packed off-diagonal blocks of that diagonal block (ldlt_pack512_kernel)
+  bool diag512 = true;                     // ... the diagonal block in one launch (DNLP_LDLT_DIAG512=0: the sub-panel chain on its 512 rows)
+  PanelCtl* pctl = nullptr;                // ... its flags, compared against a launch counter (never reset)
+  unsigned panel_epoch = 0;
   double last_update_seconds = 0.0;
   double total_update_seconds = 0.0, total_update_flops = 0.0;   // outer (Schur) updates, timed
   i64 total_update_launches = 0;
@@ -1508,6 +1776,8 @@ struct BlockedLdlt {
     if (const char* ev = std::getenv("DNLP_LDLT_LOOKAHEAD")) lookahead = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_XCD")) xcd_swizzle = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_T128")) sub128 = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("DNLP_LDLT_FUSED_ROWS")) fused_rows = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("DNLP_LDLT_DIAG512")) diag512 = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_TOP_MFMA")) top_mfma = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_INV_MFMA")) inv_mfma = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("DNLP_LDLT_SMALL_TILES")) small_tiles_below = std::atoi(ev);
@@ -1527,7 +1797,10 @@ struct BlockedLdlt {
     Wp2[1] = lookahead ? ex->alloc<double>(static_cast<size_t>(ldw) * NB + 256) : Wp2[0];
     info = ex->alloc<LdltInfo>(1);
     acc = ex->alloc<double>(SV_B);
-    Ltop = ex->alloc<double>(LD_TOP_WS);
+    Ltop = ex->alloc<double>(4 * LD_TOP_WS);
+    Lpk = ex->alloc<double>(LD_PK_WS);
+    pctl = ex->alloc<PanelCtl>(1);
+    DNLP_HIP_CHECK(hipMemset(pctl, 0, sizeof(PanelCtl)));
     DNLP_HIP_CHECK(hipEventCreateWithFlags(&evPanel, hipEventDisableTiming));
     DNLP_HIP_CHECK(hipEventCreateWithFlags(&evUpd, hipEventDisableTiming));
     // the trailing updates run on their own (lower-priority) stream so that the next panel's
@@ -1616,6 +1889,28 @@ struct BlockedLdlt {
       const int KB = std::min(NB, ni - K0);
       double* Wp = Wp2[p & 1];
       bool b_pending = false, rest_pending = false;
+      if (fused_rows && sub128 && top_mfma && !s2 && KB == LD_P && ni - (K0 + KB) > 0) {
+        // the diagonal block on its own 512 rows, then every 16 rows below in one launch (ldlt_rows512_kernel)
+        const int nb = K0 + KB;
+        if (diag512)
+          hipLaunchKernelGGL(ldlt_diag512_kernel, dim3(LD_P / LD_T), dim3(LD_TOPM_THREADS), 0, s0, A, ld, K0, info, tiny, Ltop, Lpk, Wp, ldw, pctl,
+                             ++panel_epoch);
+        else {
+          for (int q = 0; q < LD_P / LD_T; ++q) {
+            const int j0 = K0 + LD_T * q, r0 = j0 + LD_T, rows = nb - r0;
+            double* top = Ltop + static_cast<i64>(q) * LD_TOP_WS;
+            hipLaunchKernelGGL(ldlt_top128_mfma_kernel, dim3(1), dim3(LD_TOPM_THREADS), 0, s0, A, ld, j0, info, tiny, top);
+            if (rows > 0) {
+              hipLaunchKernelGGL(ldlt_rows128_kernel, dim3((rows + 63) / 64), dim3(256), 0, s0, A, ld, j0, nb, Wp, ldw, j0 - K0, top);
+              gemm(s0, A + r0 + static_cast<i64>(r0) * ld, Wp + r0 + static_cast<i64>(j0 - K0) * ldw, A + r0 + static_cast<i64>(j0) * ld, ld,
+                   rows, rows, LD_T, 1);
+            }
+          }
+          hipLaunchKernelGGL(ldlt_pack512_kernel, dim3(6 * 64), dim3(256), 0, s0, A, ld, K0, Lpk);
+        }
+        hipLaunchKernelGGL(ldlt_rows512_kernel, dim3((ni - nb + 63) / 64), dim3(256), 0, s0, A, ld, K0, ni, Wp, ldw, Ltop, Lpk);
+        DNLP_LAUNCH_CHECK();
+      } else
       for (int j0 = K0; j0 < K0 + KB; j0 += LD_nb) {
         if (sub128 && K0 + KB - j0 >= LD_T) {
           // a full 128-column sub-panel: three launches instead of twelve

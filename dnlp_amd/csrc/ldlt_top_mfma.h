@@ -35,26 +35,14 @@ __device__ inline void ldlt_barrier_lds_only() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-__global__ void __launch_bounds__(LD_TOPM_THREADS) ldlt_top128_mfma_kernel(double* __restrict__ A, i64 ld, int j0,
-                                                                          LdltInfo* info, double tiny,
-                                                                          double* __restrict__ Ltop) {
-  __shared__ __attribute__((aligned(16))) double negL[LD_TB][256];   // -L_jk of the current block column
-  __shared__ double invS[16 * 17];                                   // inv(L_kk) row-major, rows padded
-  __shared__ double dinvS[16];
+// The factorisation proper, on the block row T every wavefront already holds (T[q] = block (w, w - q) transposed, zero
+// above the diagonal of T[0] and for q > w): shared by the one-block kernel below and by ldlt_diag512_kernel.
+__device__ __forceinline__ void ldlt_top128_body(mfma_d4 (&T)[LD_TB], double* __restrict__ A, i64 ld, int j0, double tiny,
+                                                 double* __restrict__ Ltop, int& nneg, int& nzero, int& fail,
+                                                 double (*negL)[256], double* invS, double* dinvS) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lq = lane >> 4, lr = lane & 15;
-  // T[q] = block (w, w - q): q = 0 the wavefront's own diagonal block, q = w - k the block of column k
-  mfma_d4 T[LD_TB];
-  {
-    const double* src = A + (j0 + 16 * w + lr) + static_cast<i64>(j0 + 16 * w + lq) * ld;
-#pragma unroll
-    for (int q = 0; q < LD_TB; ++q)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        T[q][r] = ((q > 0 && q <= w) || (q == 0 && lq + 4 * r <= lr)) ? src[static_cast<i64>(4 * r - 16 * q) * ld] : 0.0;
-  }
-  int nneg = 0, nzero = 0, fail = 0;
   // high words above this belong to magnitudes above `tiny` whatever the low word is
   const unsigned tiny_hi = (static_cast<unsigned>(__double2hiint(tiny)) & 0x7fffffffu) + 1u;
 #pragma unroll 1
@@ -159,7 +147,32 @@ __global__ void __launch_bounds__(LD_TOPM_THREADS) ldlt_top128_mfma_kernel(doubl
         }
     }
   }
-  if (lane == 0) {
+}
+
+__device__ __forceinline__ void ldlt_top128_load(mfma_d4 (&T)[LD_TB], const double* __restrict__ A, i64 ld, int j0) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lq = lane >> 4, lr = lane & 15;
+  // T[q] = block (w, w - q): q = 0 the wavefront's own diagonal block, q = w - k the block of column k
+  const double* src = A + (j0 + 16 * w + lr) + static_cast<i64>(j0 + 16 * w + lq) * ld;
+#pragma unroll
+  for (int q = 0; q < LD_TB; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      T[q][r] = ((q > 0 && q <= w) || (q == 0 && lq + 4 * r <= lr)) ? src[static_cast<i64>(4 * r - 16 * q) * ld] : 0.0;
+}
+
+__global__ void __launch_bounds__(LD_TOPM_THREADS) ldlt_top128_mfma_kernel(double* __restrict__ A, i64 ld, int j0,
+                                                                          LdltInfo* info, double tiny,
+                                                                          double* __restrict__ Ltop) {
+  __shared__ __attribute__((aligned(16))) double negL[LD_TB][256];   // -L_jk of the current block column
+  __shared__ double invS[16 * 17];                                   // inv(L_kk) row-major, rows padded
+  __shared__ double dinvS[16];
+  mfma_d4 T[LD_TB];
+  ldlt_top128_load(T, A, ld, j0);
+  int nneg = 0, nzero = 0, fail = 0;
+  ldlt_top128_body(T, A, ld, j0, tiny, Ltop, nneg, nzero, fail, negL, invS, dinvS);
+  if ((threadIdx.x & 63) == 0) {
     if (nneg) atomicAdd(&info->nneg, nneg);
     if (nzero) atomicAdd(&info->nzero, nzero);
     if (fail) atomicExch(&info->fail, 1);

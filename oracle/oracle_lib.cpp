@@ -119,6 +119,7 @@ extern "C" int orc_wave_solve_batch(orc_problem* vp, int batch, const double* da
         const WaveHdr* hh = reinterpret_cast<const WaveHdr*>(blk.data());
         std::fprintf(stderr, "[wave] plan block %d ints (%.1f KB), state %d doubles (%.1f KB), WState %zu B; units %d, nvals %d, blocks %d, levels %d, triples %d; dense tail of order %d from level %d\n",
                      hh->total, hh->total * 4 / 1024.0, hh->state_doubles, hh->state_doubles * 8 / 1024.0, sizeof(WaveIpm<HostLane>::WState), hh->nunits, hh->sp_nvals, hh->sp_nblk, hh->sp_nlev, hh->sp_ntrip, hh->tail_T, hh->tail_L);
+        std::fprintf(stderr, "[wave] N %d m %d Z %d nd %d nh %d nnzJ %d nnzH %d scr %d\n", hh->N, hh->m, hh->Z, hh->nd, hh->nh, hh->nnzJ, hh->nnzH, hh->scr_doubles);
       }
     }
     const bool fb = (t.N + t.m) <= 512 && p->linear_solver != 2;

@@ -185,14 +185,17 @@ def test_one_launch_triangular_sweeps_against_the_step_kernels(n, gpu_required, 
     assert np.linalg.norm(sol_sweep - sol_steps) <= 1e-10 * max(np.linalg.norm(sol_steps), 1.0) * np.linalg.cond(A)
 
 
-def _ldlt_factor(A, top_mfma):
+def _ldlt_factor(A, top_mfma, env=None):
     """Factor through the C ABI with the chosen top-block kernel (csrc/ldlt_top_mfma.h / ldlt_top128_kernel); returns
-    the factor as stored (unit-lower L below the diagonal, D on it), the inertia counts and the solution of A x = 1."""
+    the factor as stored (unit-lower L below the diagonal, D on it), the inertia counts and the solution of A x = 1.
+    `env`: further DNLP_LDLT_* switches for this one factorisation."""
     from dnlp_amd import _capi
     api = _capi.require_device(0)
     n = A.shape[0]
     old = os.environ.get("DNLP_LDLT_TOP_MFMA")
     os.environ["DNLP_LDLT_TOP_MFMA"] = "1" if top_mfma else "0"
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
     try:
         Af = np.asfortranarray(A.copy())
         ipiv = np.zeros(n, np.int32)
@@ -206,7 +209,32 @@ def _ldlt_factor(A, top_mfma):
             del os.environ["DNLP_LDLT_TOP_MFMA"]
         else:
             os.environ["DNLP_LDLT_TOP_MFMA"] = old
+        for k, v in saved.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     return rc, np.tril(Af), nneg.value, nzero.value, sol
+
+
+@pytest.mark.parametrize("n", [1100, 2700])
+def test_fused_panel_forms_reproduce_the_sub_panel_chain(n, gpu_required):
+    """A full 512-column panel three ways (csrc/ldlt_blocked.h, round 5): the sub-panel chain (default); the diagonal
+    block on its own rows followed by ldlt_rows512_kernel; the same with the diagonal block in one four-workgroup launch
+    (ldlt_diag512_kernel, flags between workgroups).  Same products in the same order: the factors are equal bit for bit."""
+    rng = np.random.default_rng(7 + n)
+    n1 = (3 * n) // 4
+    G = rng.standard_normal((n1, n1))
+    H = G @ G.T / n1 + np.eye(n1)
+    J = rng.standard_normal((n - n1, n1))
+    A = np.block([[H, J.T], [J, -1e-2 * np.eye(n - n1)]])
+    rc0, F0, neg0, zero0, x0 = _ldlt_factor(A, True, {"DNLP_LDLT_FUSED_ROWS": "0"})
+    assert rc0 == 0 and (neg0, zero0) == (n - n1, 0)
+    for diag in ("0", "1"):
+        rc1, F1, neg1, zero1, x1 = _ldlt_factor(A, True, {"DNLP_LDLT_FUSED_ROWS": "1", "DNLP_LDLT_DIAG512": diag})
+        assert rc1 == 0 and (neg1, zero1) == (neg0, zero0)
+        assert np.array_equal(F1, F0), (diag, np.abs(F1 - F0).max())
+        assert np.array_equal(x1, x0)
 
 
 @pytest.mark.parametrize("n", [128, 200, 256, 640, 1100])
