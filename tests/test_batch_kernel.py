@@ -45,7 +45,9 @@ def test_non_affine_parameter_use_falls_back_to_lowering():
     np.testing.assert_allclose(mat[1][np.isfinite(mat[1])], instance_data(a)[np.isfinite(mat[1])])
 
 
-def _oracle(arrays, opts=None):
+def _oracle(arrays, opts=None, check_point=None):
+    """The host build's solve of one instance; with `check_point` also the instance's constraint functions at that
+    point (key "g_at_point": how far another optimum of the same objective value is checked for feasibility)."""
     from dnlp_amd.nlp_solver import HIPNLP
     from dnlp_amd.tape import serialize
     from oracle.oracle_capi import OracleProblem
@@ -54,7 +56,10 @@ def _oracle(arrays, opts=None):
     o.update(opts or {})
     for k, v in o.items():
         orc.set_option(k, v)
-    return orc.solve(arrays["x0"])
+    info = orc.solve(arrays["x0"])
+    if check_point is not None:
+        info["g_at_point"] = np.array(orc.eval_g(np.asarray(check_point, dtype=float)))
+    return info
 
 
 @pytest.mark.gpu
@@ -87,8 +92,14 @@ def test_batch_kernel_execution_space_agreement_per_instance(name, batch, gpu_re
         assert abs(res.raw["obj_val"][i] - oi["obj_val"]) <= 1e-6 * max(1.0, abs(oi["obj_val"]))
         if name == "circle_packing" and not np.allclose(res.x[i], oi["x"], rtol=1e-5, atol=1e-6):
             # a circle that touches nothing can slide: the optimum is a face, and with the barrier going down
-            # to IPOPT's 1e-11 the two builds' rounding picks different points of it (same objective, above)
-            assert np.max(np.abs(res.x[i] - oi["x"])) <= 1e-2
+            # to IPOPT's 1e-11 the two builds' rounding picks different points of it.  Same objective (above) and
+            # feasible for the instance's own constraint functions and bounds = another point of the same optimal face
+            # (how far it slid is not a property of the solver: 0.0085 .. 0.066 seen across builds).
+            a = arrays_with_data(pb.arrays0, mat[i])
+            g = _oracle(a, check_point=res.x[i])["g_at_point"]
+            assert np.all(g >= a["cl"] - 1e-6) and np.all(g <= a["cu"] + 1e-6)
+            assert np.all(res.x[i] >= a["lb"] - 1e-8) and np.all(res.x[i] <= a["ub"] + 1e-8)
+            assert np.max(np.abs(res.x[i] - oi["x"])) <= 0.25
             loose_circle += 1
             same_iters += int(res.iterations[i] == oi["iterations"])
             continue
