@@ -583,6 +583,13 @@ struct BatchRunner {
                   double* multg_out, double* zl_out, double* zu_out, int* status_out, int* iters_out, int* nfact_out,
                   double* seconds, double* times_out, bool allow_wave = true) {
     const i64 stride = in_stride;
+    if (batch < 0) throw std::runtime_error("batch solve: negative instance count");
+    if (batch == 0) {                 // an empty launch (an empty shard of a sharded batch) is a launch of nothing
+      if (seconds) *seconds = 0.0;
+      ws_batch = 0;
+      last_grid = 0; last_wave = 0; last_wave_refused = 0;
+      return;
+    }
     const bool dbg = std::getenv("DNLP_BATCH_DEBUG") != nullptr;
     const double tdbg0 = now_sec();
     auto mark = [&](const char* what) { if (dbg) std::fprintf(stderr, "[batch] %-22s %.4f s\n", what, now_sec() - tdbg0); };

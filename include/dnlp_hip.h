@@ -150,7 +150,9 @@ int dnlp_solve_batch_timed(dnlp_problem* p, int batch, const double* data, int64
  * instance data is an affine function of the P parameter values — dnlp_amd.batch.ParametricBatch recovers and
  * checks the map — it is handed over ONCE: d0 = data row of the base instance (dnlp_batch_stride doubles),
  * theta0 = its parameter values (P), (indptr[stride + 1], indices, vals) = CSR of the stride x P sensitivity.
- * dnlp_solve_batch_theta then takes batch x P parameter rows and generates the instance data on the device. */
+ * dnlp_solve_batch_theta then takes batch x P parameter rows and generates the instance data on the device.
+ * batch = 0 (an empty shard) is a launch of nothing: returns 0, writes nothing; batch < 0 is an error.  Same for
+ * dnlp_solve_batch / _timed and a stream's submit. */
 int dnlp_batch_set_affine_map(dnlp_problem* p, int n_params, const double* d0, const double* theta0,
                               const int64_t* indptr, const int32_t* indices, const double* vals);
 int dnlp_solve_batch_theta(dnlp_problem* p, int batch, const double* theta, int n_params, double* x, double* obj,
