@@ -362,8 +362,9 @@ def test_dense_instances_above_order_256_in_one_launch(nv, gpu_required):
 
 @pytest.mark.gpu
 def test_solve_many_overlaps_launches_and_changes_no_result(gpu_required):
-    """ParametricBatch.solve_many: six batches of 512 localization instances with two launches in flight (two device
-    handles, two streams, two host threads) give, batch by batch, the bits of six solve() calls one after the other."""
+    """ParametricBatch.solve_many: six batches of 512 localization instances with two launches in flight (one handle,
+    dnlp_batch_stream_* with two slots inside the library) give, batch by batch, the bits of six solve() calls one after
+    the other."""
     import batch_problems as bp
     from dnlp_amd.batch import ParametricBatch
     prob, params, sample, _ = bp.template_localization()
@@ -376,3 +377,59 @@ def test_solve_many_overlaps_launches_and_changes_no_result(gpu_required):
         assert np.array_equal(a.status, b.status) and np.array_equal(a.iterations, b.iterations)
         assert np.array_equal(a.obj_val, b.obj_val) and np.array_equal(a.x, b.x)
     pb.close()
+
+
+@pytest.mark.gpu
+def test_batch_stream_tickets_and_refusals(gpu_required):
+    """dnlp_batch_stream_* at its edges (include/dnlp_hip.h): more submissions than slots (the oldest is waited for),
+    batches of different sizes incl. an empty one through the same stream, a ticket that was never issued, a ticket
+    whose slot has been reused, parameter rows of the wrong width (refused at wait, the stream stays usable), and a
+    stream on a handle without an affine map (refused at create)."""
+    import ctypes as C
+    import batch_problems as bp
+    from dnlp_amd import _capi
+    from dnlp_amd.batch import ParametricBatch
+    prob, params, sample, _ = bp.template_localization()
+    pb = ParametricBatch(prob, params)
+    sizes = [64, 0, 7, 300, 1]
+    batches = [np.stack([sample(50 * k + i) for i in range(n)]).reshape(n, -1) if n else np.zeros((0, 22)) for k, n in enumerate(sizes)]
+    P = batches[0].shape[1]
+    batches[1] = np.zeros((0, P))
+    ref = [pb.solve(t) for t in batches]
+    many = pb.solve_many(batches, in_flight=2)
+    for a, b in zip(ref, many):
+        assert a.x.shape == b.x.shape and np.array_equal(a.x, b.x) and np.array_equal(a.status, b.status)
+    # the raw entry points
+    h = pb._handle
+    api = h.api
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))       # noqa: E731
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))          # noqa: E731
+    st = api.batch_stream_create(h.ptr, 2)
+    assert st
+    n = 16
+    th = np.ascontiguousarray(batches[0][:n])
+    outs = [dict(x=np.zeros((n, h.n)), obj=np.zeros(n), st=np.zeros(n, np.int32), it=np.zeros(n, np.int32), nf=np.zeros(n, np.int32)) for _ in range(3)]
+
+    def submit(o, theta, width):
+        return api.batch_stream_submit(st, n, dp(theta), width, dp(o["x"]), dp(o["obj"]), None, None, None, ip(o["st"]), ip(o["it"]), ip(o["nf"]))
+
+    sec = C.c_double()
+    secp = C.cast(C.byref(sec), C.POINTER(C.c_double))
+    t0, t1, t2 = submit(outs[0], th, P), submit(outs[1], th, P), submit(outs[2], th, P)
+    assert (t0, t1, t2) == (0, 1, 2)
+    assert api.batch_stream_wait(st, 7, secp) == -1 and "no such ticket" in api.error()
+    assert api.batch_stream_wait(st, t0, secp) == -1 and "reused" in api.error()        # (slot 0 now belongs to ticket 2)
+    assert api.batch_stream_wait(st, t1, secp) == 0 and api.batch_stream_wait(st, t2, secp) == 0
+    assert np.array_equal(outs[1]["x"], ref[0].x[:n]) and np.array_equal(outs[2]["x"], ref[0].x[:n])
+    assert np.array_equal(outs[0]["x"], ref[0].x[:n])          # (ticket 0 ran to completion before its slot was reused)
+    bad = np.zeros((n, P + 1))
+    t3 = submit(outs[0], bad, P + 1)
+    assert t3 == 3 and api.batch_stream_wait(st, t3, secp) != 0 and api.error()
+    t4 = submit(outs[0], th, P)
+    assert api.batch_stream_wait(st, t4, secp) == 0 and np.array_equal(outs[0]["x"], ref[0].x[:n])
+    api.batch_stream_destroy(st)
+    pb.close()
+    from dnlp_amd.tape import serialize
+    bare = _capi.DeviceProblem(serialize(pb.arrays0), None, device=0)
+    assert not api.batch_stream_create(bare.ptr, 2) and "affine" in api.error()
+    bare.close()
