@@ -85,6 +85,9 @@ class CApi:
               [_int_p] * 3 + [_dbl_p, _dbl_p])
             if hasattr(self.lib, prefix + "batch_launch_info"):
                 f("batch_launch_info", C.c_int, [C.c_void_p, _i32_p])
+            if hasattr(self.lib, prefix + "batch_result_rows"):
+                f("batch_keep_result_rows", C.c_int, [C.c_void_p, C.c_int])
+                f("batch_result_rows", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
             if hasattr(self.lib, prefix + "batch_stream_create"):
                 f("batch_stream_create", C.c_void_p, [C.c_void_p, C.c_int])
                 f("batch_stream_submit", C.c_int, [C.c_void_p, C.c_int, _dbl_p, C.c_int] + [_dbl_p] * 5 + [_int_p] * 3)
@@ -608,6 +611,22 @@ class ProblemHandle:
         if want_duals:
             out.update({"mult_g": mg[:, :self.m], "mult_x_L": zl, "mult_x_U": zu})
         return out
+
+    def keep_batch_result_rows(self, on: bool = True):
+        """dnlp_batch_keep_result_rows: the launches that follow also leave their result rows packed on the device."""
+        if not hasattr(self.api, "batch_keep_result_rows"):
+            return False
+        if self.api.batch_keep_result_rows(self.ptr, 1 if on else 0) != 0:
+            raise RuntimeError("batch_keep_result_rows failed: %s" % self.api.error())
+        return True
+
+    def batch_result_rows(self):
+        """dnlp_batch_result_rows: (device pointer, rows, width) of the last launch's packed rows {index, objective,
+        status, iterations, x*}; the memory belongs to the handle and is valid until its next launch."""
+        ptr, rows, width = C.c_void_p(), C.c_int64(), C.c_int64()
+        if self.api.batch_result_rows(self.ptr, C.byref(ptr), C.byref(rows), C.byref(width)) != 0:
+            raise RuntimeError("batch_result_rows failed: %s" % self.api.error())
+        return (ptr.value or 0), int(rows.value), int(width.value)
 
     def solve_batch_stream(self, batches, slots: int = 2, want_duals: bool = False):
         """A stream of parameter-row batches with `slots` launches in flight INSIDE the library (include/dnlp_hip.h

@@ -301,19 +301,30 @@ class ParametricBatch:
         except ImportError:       # pragma: no cover
             pass
         lo, hi = shard_bounds(B, rank, world)
+        exchanging = backend is not None and (world > 1 or force_collective)
+        # with RCCL the shard's rows go into the collective straight from the device buffer the launch packed them in
+        # (dnlp_batch_result_rows); the flip of a maximisation's objective is applied on the device tensor
+        from_device = exchanging and backend == "nccl" and hi > lo
+        if from_device:
+            self._ensure_handle(device, opts)
+            from_device = self._handle.keep_batch_result_rows(True)
+        local_dev = None
         if hi > lo:
             res = self.solve(thetas[lo:hi], device=device, **opts)
             local = np.concatenate([np.arange(lo, hi, dtype=float)[:, None], res.obj_val[:, None],
                                     res.status[:, None].astype(float), res.iterations[:, None].astype(float), res.x],
                                    axis=1)
             ksec = res.kernel_seconds
+            if from_device:
+                local_dev = _device_rows(self._handle, lo, -1.0 if self.flip else 1.0)
+                self._handle.keep_batch_result_rows(False)
         else:
             local, ksec = np.zeros((0, 4 + int(self.arrays0["dims"][0]))), 0.0
-        rows = gather_rows(local, B, force=force_collective)
+        rows = gather_rows(local, B, force=force_collective, local_dev=local_dev)
         per = math.ceil(B / world) if world > 0 else B
-        exchanged = backend is not None and (world > 1 or force_collective)
+        exchanged = exchanging
         info = {"ranks": world, "backend": backend, "rank": rank, "shard": (lo, hi), "kernel_seconds": ksec,
-                "collective": exchanged,
+                "collective": exchanged, "rows_from_device": local_dev is not None,
                 "gathered_bytes": int(world * per * rows.shape[1] * 8) if exchanged else 0}
         return rows, info
 
@@ -371,11 +382,35 @@ def solve_shard(build: Callable[[int], object], ids: Sequence[int], solver: Call
     return out
 
 
-def gather_rows(local: np.ndarray, n_items: int, force: bool = False):
+class _DeviceRows:
+    """A library-owned device buffer of doubles as an object torch can wrap without a copy."""
+
+    def __init__(self, ptr, rows, width):
+        self.__cuda_array_interface__ = {"shape": (rows, width), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def _device_rows(handle, id0, obj_sign):
+    """The last launch's rows {index, objective, status, iterations, x*} as a device tensor (dnlp_batch_result_rows):
+    a copy on the device with the shard's first instance id added to column 0 — the library's buffer lives until the
+    handle's next launch only."""
+    import torch
+    ptr, rows, width = handle.batch_result_rows()
+    if rows == 0:
+        return None
+    t = torch.as_tensor(_DeviceRows(ptr, rows, width), device=torch.device("cuda", handle.device)).clone()
+    t[:, 0] += float(id0)
+    if obj_sign != 1.0:
+        t[:, 1] *= obj_sign
+    return t
+
+
+def gather_rows(local: np.ndarray, n_items: int, force: bool = False, local_dev=None):
     """The single exchange of the path: every rank receives all rows, ordered by instance id.
     Works with any initialised torch.distributed backend; a no-op without a process group.  A
     one-rank group skips the collective unless `force` is set (then the all_reduce + all_gather run
-    on the backend all the same: how the RCCL path is exercised on a single MI355X)."""
+    on the backend all the same: how the RCCL path is exercised on a single MI355X).
+    `local_dev`: this rank's rows as a device tensor (the launch's own buffer, _device_rows) — then nothing of this
+    rank's contribution passes through host memory on its way into the collective."""
     try:
         import torch
         import torch.distributed as dist
@@ -391,7 +426,9 @@ def gather_rows(local: np.ndarray, n_items: int, force: bool = False):
     dist.all_reduce(width, op=dist.ReduceOp.MAX)
     w = int(width.item())
     buf = torch.full((per, w), float("nan"), dtype=torch.float64, device=dev)
-    if local.size:
+    if local_dev is not None and dev.type == "cuda":
+        buf[:local_dev.shape[0], :local_dev.shape[1]] = local_dev
+    elif local.size:
         buf[:local.shape[0], :local.shape[1]] = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
     parts = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(parts, buf)

@@ -342,6 +342,19 @@ __global__ void __launch_bounds__(256) batch_affine_expand_kernel(double* __rest
 }
 
 // Host side: tables uploaded once per problem handle, slabs per call.
+// Result rows {index in the launch, objective, status, iterations, x*} of a launch, packed on the device: what a rank
+// hands to the path's one collective (dnlp_amd/batch.py gather_rows) without a trip through host memory.
+__global__ void __launch_bounds__(256) batch_pack_rows_kernel(double* __restrict__ rows, int width, int batch, int N, const double* __restrict__ x,
+                                                              const double* __restrict__ obj, const int* __restrict__ status,
+                                                              const int* __restrict__ iters) {
+  const i64 total = static_cast<i64>(batch) * width;
+  for (i64 e = static_cast<i64>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<i64>(gridDim.x) * 256) {
+    const int i = static_cast<int>(e / width), c = static_cast<int>(e % width);
+    rows[e] = c == 0 ? static_cast<double>(i) : c == 1 ? obj[i] : c == 2 ? static_cast<double>(status[i]) : c == 3 ? static_cast<double>(iters[i])
+                                                                                                                  : x[static_cast<i64>(i) * N + (c - 4)];
+  }
+}
+
 struct BatchRunner {
   HipExec* ex = nullptr;
   hipStream_t stream = nullptr;   // this runner's launches and copies (the handle's stream; a batch-stream slot has its own)
@@ -481,9 +494,39 @@ struct BatchRunner {
     if (d_red) hipFree(d_red);
     if (d_sparse) hipFree(d_sparse);
     if (d_wave_blk) hipFree(d_wave_blk);
+    if (d_rows) hipFree(d_rows);
     if (own_stream && stream) hipStreamDestroy(stream);
   }
   void release() { nbuf_used = 0; }
+  // result rows of the last launch on the device (dnlp_batch_result_rows): {index, objective, status, iterations, x*}
+  double* d_rows = nullptr;
+  size_t d_rows_cap = 0;
+  int rows_batch = 0, rows_width = 0;
+  bool rows_wanted = false, rows_nested = false;
+  void pack_rows(int batch, const double* x, const double* obj, const int* status, const int* iters) {
+    if (!rows_wanted || rows_nested) return;
+    const int width = 4 + static_cast<int>(tape->N);
+    const size_t need = static_cast<size_t>(batch) * static_cast<size_t>(width) * sizeof(double);
+    if (need > d_rows_cap) {
+      if (d_rows) DNLP_HIP_CHECK(hipFree(d_rows));
+      d_rows = nullptr;
+      DNLP_HIP_CHECK(hipMalloc(&d_rows, need));
+      d_rows_cap = need;
+    }
+    const unsigned grid = static_cast<unsigned>(std::min<i64>((static_cast<i64>(batch) * width + 255) / 256, 1024));
+    hipLaunchKernelGGL(batch_pack_rows_kernel, dim3(grid), dim3(256), 0, stream, d_rows, width, batch, static_cast<int>(tape->N), x, obj, status, iters);
+    DNLP_LAUNCH_CHECK();
+    DNLP_HIP_CHECK(hipStreamSynchronize(stream));
+    rows_batch = batch; rows_width = width;
+  }
+  // (an instance the wavefront solver refused was re-solved and merged on the host: its row follows)
+  void patch_row(int k, double obj, int status, int iters, const double* x) {
+    if (!rows_wanted || rows_nested || !d_rows || k >= rows_batch) return;
+    std::vector<double> row(static_cast<size_t>(rows_width));
+    row[0] = k; row[1] = obj; row[2] = status; row[3] = iters;
+    std::copy(x, x + tape->N, row.begin() + 4);
+    DNLP_HIP_CHECK(hipMemcpy(d_rows + static_cast<size_t>(k) * rows_width, row.data(), row.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   template <class T> T* dalloc(size_t n) {
     Buf& b = bufs[nbuf_used++];
     const size_t bytes = (n ? n : 1) * sizeof(T);
@@ -588,6 +631,7 @@ struct BatchRunner {
       if (seconds) *seconds = 0.0;
       ws_batch = 0;
       last_grid = 0; last_wave = 0; last_wave_refused = 0;
+      if (!rows_nested) { rows_batch = 0; rows_width = 4 + static_cast<int>(tape->N); }
       return;
     }
     const bool dbg = std::getenv("DNLP_BATCH_DEBUG") != nullptr;
@@ -930,6 +974,7 @@ struct BatchRunner {
       }
     }
     if (iters_out) { prev_iters.assign(iters_out, iters_out + batch); prev_key = key; }
+    pack_rows(batch, a.x_out, a.obj_out, a.status_out, a.iters_out);
     release();
     mark("results copied");
   }
@@ -1116,6 +1161,7 @@ struct BatchRunner {
     }
 #endif
     mark("wave results copied");
+    pack_rows(batch, w.x_out, w.obj_out, w.status_out, w.iters_out);
     release();
     // the refused instances, through the generic kernel
     std::vector<int> refused;
@@ -1146,8 +1192,13 @@ struct BatchRunner {
       const std::vector<int> keep_iters = prev_iters;
       const uint64_t keep_key = prev_key;
       double sec2 = 0.0;
-      solve_impl(nb, theta ? nullptr : sub.data(), theta ? sub.data() : nullptr, opt, sx.data(), sobj.data(), multg_out ? smg.data() : nullptr,
-                 zl_out ? szl.data() : nullptr, zu_out ? szu.data() : nullptr, sst.data(), sit.data(), snf.data(), &sec2, times_out ? stm.data() : nullptr, false);
+      const bool nested_before = rows_nested;
+      rows_nested = true;
+      try {
+        solve_impl(nb, theta ? nullptr : sub.data(), theta ? sub.data() : nullptr, opt, sx.data(), sobj.data(), multg_out ? smg.data() : nullptr,
+                   zl_out ? szl.data() : nullptr, zu_out ? szu.data() : nullptr, sst.data(), sit.data(), snf.data(), &sec2, times_out ? stm.data() : nullptr, false);
+      } catch (...) { rows_nested = nested_before; throw; }
+      rows_nested = nested_before;
       prev_iters = keep_iters; prev_key = keep_key;
       total_sec += sec2;
       for (int q = 0; q < nb; ++q) {
@@ -1161,6 +1212,7 @@ struct BatchRunner {
         if (iters_out) iters_out[k] = sit[q];
         if (nfact_out) nfact_out[k] = snf[q];
         if (times_out) std::copy(stm.begin() + 4 * q, stm.begin() + 4 * q + 4, times_out + 4 * static_cast<size_t>(k));
+        patch_row(k, sobj[q], sst[q], sit[q], sx.data() + q * N);
       }
       last_wave = wave_form;
       last_wave_refused = nb;

@@ -181,6 +181,24 @@ void dnlp_batch_stream_destroy(dnlp_batch_stream* s) {
   delete s;
 }
 
+int dnlp_batch_keep_result_rows(dnlp_problem* vp, int on) {
+  dnlp_problem_t* p = vp;
+  DNLP_TRY(
+    batch_runner(p)->rows_wanted = on != 0;
+    return 0;)
+}
+int dnlp_batch_result_rows(dnlp_problem* vp, const double** rows, int64_t* n_rows, int64_t* width) {
+  dnlp_problem_t* p = vp;
+  DNLP_TRY(
+    BatchRunner& r = *batch_runner(p);
+    if (!r.rows_wanted) { dnlp::tls_error() = "dnlp_batch_result_rows: ask for them first (dnlp_batch_keep_result_rows)"; return -1; }
+    if (r.rows_width == 0) { dnlp::tls_error() = "dnlp_batch_result_rows: no launch yet"; return -1; }
+    *rows = r.rows_batch > 0 ? r.d_rows : nullptr;
+    *n_rows = r.rows_batch;
+    *width = r.rows_width;
+    return 0;)
+}
+
 int dnlp_batch_launch_info(dnlp_problem* vp, int32_t* out8) {
   dnlp_problem_t* p = vp;
   DNLP_TRY(

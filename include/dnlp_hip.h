@@ -178,6 +178,15 @@ int dnlp_batch_stream_submit(dnlp_batch_stream* s, int batch, const double* thet
 int dnlp_batch_stream_wait(dnlp_batch_stream* s, int ticket, double* kernel_seconds);
 void dnlp_batch_stream_destroy(dnlp_batch_stream* s);
 
+/* The result rows of the last dnlp_solve_batch* launch of this handle, PACKED ON THE DEVICE: n_rows x width doubles,
+ * row i = {i, objective, status, iterations, x*[0 .. N)} (width = 4 + N), valid until the handle's next launch.  It is
+ * what a rank contributes to the path's one exchange (the reference's counterpart is the serial loop of
+ * problems/problem.py:1256-1269 appending to one Python list) without a trip through host memory: dnlp_amd.batch wraps
+ * the pointer as a device tensor and hands it to the RCCL all_gather.  Off by default (one more small kernel per launch):
+ * dnlp_batch_keep_result_rows(p, 1) turns it on for the launches that follow.  An empty launch has n_rows = 0, rows NULL. */
+int dnlp_batch_keep_result_rows(dnlp_problem* p, int on);
+int dnlp_batch_result_rows(dnlp_problem* p, const double** rows, int64_t* n_rows, int64_t* width);
+
 /* What the LAST dnlp_solve_batch* call of this handle launched (diagnostics; the reference has no counterpart —
  * its loop of problems/problem.py:1256-1269 is serial).  out[0] grid, [1] lanes per workgroup, [2] LDS mode,
  * [3] instances resident per compute unit, [4] 1 = packed generic kernel, [5] 1 = longest-first order,

@@ -73,6 +73,14 @@ def main():
         allrows, info = pb.solve_sharded(thetas, force_collective=True)
         assert info["ranks"] == world and info["backend"] == backend and info["collective"]
         assert info["gathered_bytes"] == world * -(-n_items // world) * allrows.shape[1] * 8
+        if backend == "nccl":
+            # the rows went into the collective from the launch's own device buffer (dnlp_batch_result_rows) and are the
+            # rows a plain solve of the same instances returns through host memory
+            assert info["rows_from_device"]
+            res = pb.solve(thetas)
+            host = np.concatenate([np.arange(n_items, dtype=float)[:, None], res.obj_val[:, None], res.status[:, None].astype(float),
+                                   res.iterations[:, None].astype(float), res.x], axis=1)
+            assert np.array_equal(allrows, host)
         # gather_rows by itself, a second time, on rows it did not produce
         again = gather_rows(allrows[shard_bounds(n_items, rank, world)[0]:shard_bounds(n_items, rank, world)[1]],
                             n_items, force=True)
