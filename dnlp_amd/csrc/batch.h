@@ -721,11 +721,19 @@ struct BatchRunner {
     // sparse instances have no dense matrix to factor, so one wavefront suffices at any order;
     // when the batch does not even fill the CUs, large instances get four wavefronts each instead
     // (a one-off solve of order ~2000 is then ~3x faster)
-    // Sparse instances of order > 512 get four wavefronts each while the batch is at most 1024 (DNLP_BATCH_WIDE_MAX): such a
-    // launch has every instance resident at once and lasts as long as its slowest one (power flow: 104 iterations against a
-    // mean of 17.7), so the ~3x faster instance wins: 1024 power-flow instances 0.424 -> 0.341 s, path planning 0.306 ->
-    // 0.241 s; at 4096 instances the one-wavefront form is as fast or faster (0.59 / 0.63 s against 0.59 / 0.73 s).
-    static const int wide_max = std::getenv("DNLP_BATCH_WIDE_MAX") ? std::atoi(std::getenv("DNLP_BATCH_WIDE_MAX")) : 1024;
+    // Sparse instances of order > 512 get four wavefronts each while the batch is at most four instances per compute unit
+    // (1024 on the MI355X; DNLP_BATCH_WIDE_MAX): such a launch is a few rounds of its slowest instances (power flow: 104
+    // iterations against a mean of 17.7; one to three instances resident per compute unit), so the ~3x faster instance wins:
+    // 1024 power-flow instances 0.424 -> 0.341 s, path planning 0.306 -> 0.241 s; at 4096 instances the one-wavefront form
+    // is as fast or faster (0.59 / 0.63 s against 0.59 / 0.73 s).  The kernel — and with it the order of the sums, the
+    // last bits of a result — therefore depends on the launch's size for these templates: results repeat bit for bit for
+    // the same launch plan, not across shard sizes.
+    if (this->ncu == 0) {
+      int v = 0;
+      DNLP_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ex->device));
+      this->ncu = v;
+    }
+    const int wide_max = std::getenv("DNLP_BATCH_WIDE_MAX") ? std::atoi(std::getenv("DNLP_BATCH_WIDE_MAX")) : 4 * this->ncu;
     const bool wave = n <= 256 || (have_sparse && !(n > 512 && batch <= wide_max));
     const void* kern = wave ? reinterpret_cast<const void*>(batch_solve_kernel<64>)
                             : reinterpret_cast<const void*>(batch_solve_kernel<256>);
@@ -874,9 +882,11 @@ struct BatchRunner {
       const IdxBytes ib = index_bytes();
       const size_t idx = (ib.solve + ib.coo + ib.factor + 63) & ~static_cast<size_t>(63);
       const size_t wv = (packed_vector_bytes() + 64 + 15) & ~static_cast<size_t>(15);
+      // (a single vector of 16 KB or more is never placed in LDS by the packed kernel's allocator: not a packed template)
+      const size_t widest = 8 * static_cast<size_t>(std::max<i64>(std::max<i64>(t.N + t.Z, t.N + t.m), std::max<i64>(dev_plan.nvals + 3 * dev_plan.nblk + 8, std::max<i64>(t.nnzJ, t.nnzH))));
       hipFuncAttributes fp;
       DNLP_HIP_CHECK(hipFuncGetAttributes(&fp, reinterpret_cast<const void*>(batch_solve_packed_kernel<kPackedWaves>)));
-      if (idx + kPackedWaves * wv + fp.sharedSizeBytes + 512 <= 160 * 1024) {
+      if (widest < 16384 && idx + kPackedWaves * wv + fp.sharedSizeBytes + 512 <= 160 * 1024) {
         packed = true;
         pk_wave_bytes = static_cast<unsigned>(wv);
         a.plan_stage_bytes = static_cast<unsigned>(idx);
@@ -961,9 +971,12 @@ struct BatchRunner {
     down(iters_out, a.iters_out, sizeof(int) * batch);
     down(nfact_out, a.nfact_out, sizeof(int) * batch);
     down(times_out, a.times_out, sizeof(double) * 4 * batch);
-    if (packed && status_out) {
+    if (packed) {
+      std::vector<int> st_local;
+      const int* st_host = status_out;
+      if (!st_host) { st_local.resize(static_cast<size_t>(batch)); down(st_local.data(), a.status_out, sizeof(int) * batch); st_host = st_local.data(); }
       bool refused = false;
-      for (int k = 0; k < batch && !refused; ++k) refused = status_out[k] == -198;
+      for (int k = 0; k < batch && !refused; ++k) refused = st_host[k] == -198;
       if (refused) {
         // the estimate of the vectors' bytes was short for this tape: the regular kernel, from now on
         packed_disabled = true;

@@ -475,7 +475,9 @@ struct BlockExecT {
     bool in_lds = (big ? (lds_mode & 1) : (lds_mode & 2)) && lds_off + bytes <= lds_cap;
     if constexpr (PK) {
       in_lds = !big && lds_off + bytes <= lds_cap;
-      if (!in_lds && !big && !vec_frozen) { overflow = 1; return reinterpret_cast<T*>(lds_pool); }   // a solver vector outside LDS would break vectors_in_lds
+      // a solver vector outside LDS — too large for the pool or one of the 'big' ones that go to the slab — would break
+      // vectors_in_lds (32-bit LDS pointers): the launch reports -198 and the host takes the regular kernel
+      if (!in_lds && !vec_frozen) { overflow = 1; return reinterpret_cast<T*>(lds_pool); }
     }
     if (in_lds) {
       // LDS first: every map / reduction of the interior-point loop is one dependent memory
