@@ -457,9 +457,12 @@ struct WaveIpm {
   // registers.  The operations on every entry are those of the level code (sp_pivot, sp_scale, one update product per
   // destination and level, subtracted in level order), so a host lane that owns all rows reproduces the generic text's bits;
   // what goes away is the level machinery — four phases of index walks per block — for what is T^3 / 6 multiply-adds.
+  // (three widths of the unrolled loops — 12, 24, 32 rows — so that a tail of 9 or 21 rows does not pay for 32: the
+  //  padding columns cost products, loads and skipped steps; circle packing n = 4 has T = 9, n = 10 T = 21)
   static constexpr int kTailMax = 32;
-  static constexpr int kTailSlots = (kTailMax + P::lanes - 1) / P::lanes;      // rows of the tail a lane owns (device 1, host 32)
-  DNLP_WFN DNLP_HD static void tail_factor(WS* S, double& nneg_io, double& nzero_io, double& bad_io) {
+  template <int kTailMax>
+  DNLP_WFN DNLP_HD static void tail_factor_n(WS* S, double& nneg_io, double& nzero_io, double& bad_io) {
+    constexpr int kTailSlots = (kTailMax + P::lanes - 1) / P::lanes;      // rows of the tail a lane owns (device 1, host: all)
     W_P0();
     const int T = P::uni(S->tail_T), me = P::lane();      // (uniform: a scalar register, so that the unrolled loops below test it on the scalar unit)
     double nneg = 0.0, nzero = 0.0, bad = 0.0;           // (lane 0 counts; handed back once)
@@ -522,7 +525,9 @@ struct WaveIpm {
   }
   // forward substitution through the tail: the gathers of the tail's targets from the blocks before it (products side by
   // side, runs added in storage order), then row t adds L_tk x_k for k < t as x_k becomes final — the order of the level code
-  DNLP_WFN DNLP_HD static void tail_forward(WS* S, WD* x, WD* y) {
+  template <int kTailMax>
+  DNLP_WFN DNLP_HD static void tail_forward_n(WS* S, WD* x, WD* y) {
+    constexpr int kTailSlots = (kTailMax + P::lanes - 1) / P::lanes;      // rows of the tail a lane owns (device 1, host: all)
     W_P0();
     const int T = P::uni(S->tail_T), me = P::lane();      // (uniform: a scalar register, so that the unrolled loops below test it on the scalar unit)
     const WD* vals = S->svals;
@@ -580,7 +585,9 @@ struct WaveIpm {
     W_P1(25);
   }
   // backward substitution through the tail (after D^-1): x_t -= sum over i > t of L_it x_i, t descending
-  DNLP_WFN DNLP_HD static void tail_backward(WS* S, WD* x, WD* y) {
+  template <int kTailMax>
+  DNLP_WFN DNLP_HD static void tail_backward_n(WS* S, WD* x, WD* y) {
+    constexpr int kTailSlots = (kTailMax + P::lanes - 1) / P::lanes;      // rows of the tail a lane owns (device 1, host: all)
     W_P0();
     const int T = P::uni(S->tail_T), me = P::lane();      // (uniform: a scalar register, so that the unrolled loops below test it on the scalar unit)
     const WD* vals = S->svals;
@@ -619,6 +626,24 @@ struct WaveIpm {
     }
     P::sync();
     W_P1(26);
+  }
+  DNLP_HD static void tail_factor(WS* S, double& nneg_io, double& nzero_io, double& bad_io) {
+    const int T = P::uni(S->tail_T);
+    if (T <= 12) tail_factor_n<12>(S, nneg_io, nzero_io, bad_io);
+    else if (T <= 24) tail_factor_n<24>(S, nneg_io, nzero_io, bad_io);
+    else tail_factor_n<32>(S, nneg_io, nzero_io, bad_io);
+  }
+  DNLP_HD static void tail_forward(WS* S, WD* x, WD* y) {
+    const int T = P::uni(S->tail_T);
+    if (T <= 12) tail_forward_n<12>(S, x, y);
+    else if (T <= 24) tail_forward_n<24>(S, x, y);
+    else tail_forward_n<32>(S, x, y);
+  }
+  DNLP_HD static void tail_backward(WS* S, WD* x, WD* y) {
+    const int T = P::uni(S->tail_T);
+    if (T <= 12) tail_backward_n<12>(S, x, y);
+    else if (T <= 24) tail_backward_n<24>(S, x, y);
+    else tail_backward_n<32>(S, x, y);
   }
   // sparse_ldl.h sparse_ldl_factor (no dense tail).  Per level: pivots, row scaling, then the update triples — their
   // products side by side into the scratch array, each destination's run added in storage order (see run_sum).
