@@ -332,7 +332,7 @@ def bench_c5(args):
         dt_two, n_two = time.time() - t2, len(ks)
     # secondary figure: the per-GPU shard BASELINE's config names (8 x 1024) — 1024 fresh instances per launch, all
     # resident at once: the launch is its slowest instance
-    dt_1024, it_1024, launch_info = None, None, None
+    dt_1024, it_1024, launch_info, dt_1024_stream = None, None, None, None
     if world == 1 and B > 1024:
         small = [np.stack([sample((n_batches + k) * B + i) for i in range(1024)]) for k in range(4)]
         pb.solve(small[0], device=local)
@@ -342,6 +342,15 @@ def bench_c5(args):
             r1024 = pb.solve(small[k], device=local)
         barrier()
         dt_1024, it_1024 = (time.time() - t3) / 3.0, int(r1024.iterations.max())
+        # ... and a STREAM of such shards with four launches in flight (dnlp_batch_stream_*): what a rank that is handed
+        # one 1024-instance shard after another gets
+        more = [np.stack([sample((n_batches + 4 + k) * B + i) for i in range(1024)]) for k in range(12)]
+        pb.solve_many(more[:4], device=local, in_flight=4)
+        barrier()
+        t4 = time.time()
+        pb.solve_many(more, device=local, in_flight=4)
+        barrier()
+        dt_1024_stream = (time.time() - t4) / len(more)
     launch_info = pb.solve(thetas[: min(B, 1024)], device=local).raw.get("launch") if world == 1 else None
     assert rows.shape[0] == B and np.array_equal(rows[:, 0], np.arange(B)), "gathered rows are not the whole batch"
     gathered_ranks, backend_name = info["ranks"], info["backend"]
@@ -389,6 +398,7 @@ def bench_c5(args):
                        "resolve_same_batch_problems_per_s": B / dt_resolve if dt_resolve > 0 else None,
                        "two_batches_in_flight_problems_per_s": B * n_two / dt_two if dt_two else None,
                        "shard_of_1024_problems_per_s": 1024 / dt_1024 if dt_1024 else None,
+                       "shards_of_1024_four_in_flight_problems_per_s": 1024 / dt_1024_stream if dt_1024_stream else None,
                        "shard_of_1024_slowest_instance_iterations": it_1024,
                        "kernel_form": launch_info,
                        "ip_iterations_per_pass": iters_total,
