@@ -167,25 +167,54 @@ struct SparsePlanHost {
     double tp0 = tnow();
     auto tick = [&](const char* what) { if (tplan) { const double t1 = tnow(); std::fprintf(stderr, "[dnlp plan] %-28s %.3f s\n", what, t1 - tp0); tp0 = t1; } };
     // ---- symmetric adjacency (no diagonal) ----
-    std::vector<std::vector<i32>> adj(static_cast<size_t>(nn));
-    auto edge = [&](i32 a, i32 b) { if (a != b && !is_fixed(a) && !is_fixed(b)) { adj[static_cast<size_t>(a)].push_back(b); adj[static_cast<size_t>(b)].push_back(a); } };
-    for (size_t p = 0; p < hr.size(); ++p) edge(hr[p], hc[p]);
-    for (size_t p = 0; p < jr.size(); ++p) edge(static_cast<i32>(N + jr[p]), jc[p]);
-    for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+    // (flat: two counting passes instead of 700 000 little vectors for the canonical Rosenbrock chain — the lists are
+    //  only read afterwards; node u's sorted, duplicate-free neighbours are aidx[aptr[u] .. aptr[u] + alen[u]))
+    std::vector<i64> aptr(static_cast<size_t>(nn) + 1, 0);
+    std::vector<i32> aidx, alen(static_cast<size_t>(nn), 0);
+    {
+      auto keep = [&](i32 a, i32 b) { return a != b && !is_fixed(a) && !is_fixed(b); };
+      for (size_t p = 0; p < hr.size(); ++p) if (keep(hr[p], hc[p])) { ++aptr[static_cast<size_t>(hr[p]) + 1]; ++aptr[static_cast<size_t>(hc[p]) + 1]; }
+      for (size_t p = 0; p < jr.size(); ++p) if (keep(static_cast<i32>(N + jr[p]), jc[p])) { ++aptr[static_cast<size_t>(N + jr[p]) + 1]; ++aptr[static_cast<size_t>(jc[p]) + 1]; }
+      for (i64 u = 0; u < nn; ++u) aptr[static_cast<size_t>(u) + 1] += aptr[static_cast<size_t>(u)];
+      aidx.resize(static_cast<size_t>(aptr[static_cast<size_t>(nn)]));
+      std::vector<i64> fill(aptr.begin(), aptr.end() - 1);
+      auto put = [&](i32 a, i32 b) { aidx[static_cast<size_t>(fill[static_cast<size_t>(a)]++)] = b; aidx[static_cast<size_t>(fill[static_cast<size_t>(b)]++)] = a; };
+      for (size_t p = 0; p < hr.size(); ++p) if (keep(hr[p], hc[p])) put(hr[p], hc[p]);
+      for (size_t p = 0; p < jr.size(); ++p) if (keep(static_cast<i32>(N + jr[p]), jc[p])) put(static_cast<i32>(N + jr[p]), jc[p]);
+      for (i64 u = 0; u < nn; ++u) {
+        i32* b0 = aidx.data() + aptr[static_cast<size_t>(u)];
+        i32* b1 = aidx.data() + aptr[static_cast<size_t>(u) + 1];
+        std::sort(b0, b1);
+        alen[static_cast<size_t>(u)] = static_cast<i32>(std::unique(b0, b1) - b0);
+      }
+    }
     // ---- static 2x2 blocks: equality row <-> one adjacent variable ----
     std::vector<i32> partner(static_cast<size_t>(nn), -1);
     {
       // best coefficient per (row, var): from the Jacobian COO
       // candidate weight: > 1 constant coefficient, (0, 1] varying coefficient that is non-zero at the
       // start point, 0 varying coefficient that vanishes there
-      std::vector<std::vector<std::pair<i32, double>>> rowvars(static_cast<size_t>(m));
-      for (size_t p = 0; p < jr.size(); ++p) {
-        if (is_fixed(jc[p])) continue;
-        double wgt;
-        if (jac_const[p] > 0.0) wgt = 1.0 + std::min(jac_const[p], 1.0);
-        else if (jac_abs0) wgt = std::min((*jac_abs0)[p], 1.0) * 0.999;
-        else wgt = 0.5;
-        rowvars[static_cast<size_t>(jr[p])].push_back({jc[p], wgt});
+      // (flat as well: row i's candidates in the order of the Jacobian's entries)
+      struct RowVars {
+        std::vector<i64> ptr;
+        std::vector<std::pair<i32, double>> ent;
+        struct Range { const std::pair<i32, double>*b, *e; const std::pair<i32, double>* begin() const { return b; } const std::pair<i32, double>* end() const { return e; } size_t size() const { return static_cast<size_t>(e - b); } };
+        Range operator[](size_t i) const { return Range{ent.data() + ptr[i], ent.data() + ptr[i + 1]}; }
+      } rowvars;
+      rowvars.ptr.assign(static_cast<size_t>(m) + 1, 0);
+      for (size_t p = 0; p < jr.size(); ++p) if (!is_fixed(jc[p])) ++rowvars.ptr[static_cast<size_t>(jr[p]) + 1];
+      for (i64 i = 0; i < m; ++i) rowvars.ptr[static_cast<size_t>(i) + 1] += rowvars.ptr[static_cast<size_t>(i)];
+      rowvars.ent.resize(static_cast<size_t>(rowvars.ptr[static_cast<size_t>(m)]));
+      {
+        std::vector<i64> fill(rowvars.ptr.begin(), rowvars.ptr.end() - 1);
+        for (size_t p = 0; p < jr.size(); ++p) {
+          if (is_fixed(jc[p])) continue;
+          double wgt;
+          if (jac_const[p] > 0.0) wgt = 1.0 + std::min(jac_const[p], 1.0);
+          else if (jac_abs0) wgt = std::min((*jac_abs0)[p], 1.0) * 0.999;
+          else wgt = 0.5;
+          rowvars.ent[static_cast<size_t>(fill[static_cast<size_t>(jr[p])]++)] = {jc[p], wgt};
+        }
       }
       // rows with the fewest candidates first (they have the least choice)
       std::vector<i32> rows;
@@ -194,12 +223,12 @@ struct SparsePlanHost {
       for (i32 i : rows) {
         i32 best = -1;
         double best_score = -1.0;
-        for (auto& vc : rowvars[static_cast<size_t>(i)]) {
+        for (const auto& vc : rowvars[static_cast<size_t>(i)]) {
           const i32 v = vc.first;
           if (partner[static_cast<size_t>(v)] >= 0 || !(vc.second > 0.0)) continue;
           // constant coefficient > large coefficient > structurally zero diagonal > low degree
           double score = 4.0 * vc.second + (zero_diag_var[static_cast<size_t>(v)] ? 2.0 : 0.0) +
-                         1.0 / (1.0 + static_cast<double>(adj[static_cast<size_t>(v)].size()));
+                         1.0 / (1.0 + static_cast<double>(alen[static_cast<size_t>(v)]));
           if (score > best_score) { best_score = score; best = v; }
         }
         if (best >= 0) { partner[static_cast<size_t>(best)] = static_cast<i32>(N + i); partner[static_cast<size_t>(N + i)] = best; }
@@ -220,7 +249,7 @@ struct SparsePlanHost {
           i32 end_var = -1;
           for (size_t qh = 0; qh < queue.size() && end_var < 0; ++qh) {
             const i32 r = queue[qh];
-            for (auto& vc : rowvars[static_cast<size_t>(r)]) {
+            for (const auto& vc : rowvars[static_cast<size_t>(r)]) {
               const i32 v = vc.first;
               if (pass == 0 && !(vc.second > 1.0)) continue;       // constant coefficients only
               if (pass == 1 && !(vc.second > 0.0)) continue;       // non-zero at the start point
@@ -268,8 +297,10 @@ struct SparsePlanHost {
     // block adjacency
     std::vector<std::vector<i32>> badj(static_cast<size_t>(nb));
     for (i64 u = 0; u < nn; ++u)
-      for (i32 v : adj[static_cast<size_t>(u)])
+      for (i64 q = aptr[static_cast<size_t>(u)], q1 = q + alen[static_cast<size_t>(u)]; q < q1; ++q) {
+        const i32 v = aidx[static_cast<size_t>(q)];
         if (blk_of[static_cast<size_t>(u)] != blk_of[static_cast<size_t>(v)]) badj[static_cast<size_t>(blk_of[static_cast<size_t>(u)])].push_back(blk_of[static_cast<size_t>(v)]);
+      }
     for (auto& a : badj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
     // ---- minimum (external) degree elimination of the blocks, explicit fill ----
     // A 1x1 block whose diagonal is structurally zero (unpaired equality row, unpaired linear
@@ -315,6 +346,7 @@ struct SparsePlanHost {
     std::vector<std::vector<i32>> contrib(static_cast<size_t>(nb));     // eliminated neighbours of a block, this round
     std::vector<i64> seen(static_cast<size_t>(nb), -1);
     i64 stamp = 0;
+    double t_merge = 0.0; i64 n_touched = 0;
     while (remaining > 0) {
       // drop stale heads
       while (!pq.empty() && (gone[static_cast<size_t>(pq.top().second)] || pq.top().first != deg[static_cast<size_t>(pq.top().second)])) pq.pop();
@@ -348,6 +380,7 @@ struct SparsePlanHost {
           mark[static_cast<size_t>(c)] = round;
         }
       }
+      const double tm0 = tplan ? tnow() : 0.0;
       for (i32 c : touched) {
         ++stamp;
         merged.clear();
@@ -357,18 +390,22 @@ struct SparsePlanHost {
         for (i32 b : contrib[static_cast<size_t>(c)])
           for (i32 x : badj[static_cast<size_t>(b)])
             if (seen[static_cast<size_t>(x)] != stamp) { seen[static_cast<size_t>(x)] = stamp; merged.push_back(x); }
-        std::sort(merged.begin(), merged.end());
+        // (unsorted: the list is a set until its block is eliminated — nothing below looks at the order of a LIVE list;
+        //  it is sorted once, when it becomes the block's struct.  Sorting every merge was 0.1 s of the NMF plan's 0.35)
         badj[static_cast<size_t>(c)].assign(merged.begin(), merged.end());
         contrib[static_cast<size_t>(c)].clear();
         deg[static_cast<size_t>(c)] = degree(c);
         ready[static_cast<size_t>(c)] = 1;
         pq.push({deg[static_cast<size_t>(c)], c});
       }
+      if (tplan) { t_merge += tnow() - tm0; n_touched += static_cast<i64>(touched.size()); }
       for (i32 b : round_elim) {
+        std::sort(badj[static_cast<size_t>(b)].begin(), badj[static_cast<size_t>(b)].end());
         bstruct[static_cast<size_t>(b)] = std::move(badj[static_cast<size_t>(b)]);
         badj[static_cast<size_t>(b)] = std::vector<i32>();
       }
     }
+    if (tplan) std::fprintf(stderr, "[dnlp plan]   rounds %lld, touched %lld, merge phase %.3f s\n", (long long)round, (long long)n_touched, t_merge);
     tick("elimination");
     // ---- elimination-tree levels: level-major order is a topological order of the same tree ----
     {
