@@ -334,7 +334,8 @@ class HIPNLP:
         data["oracles"].iterations = info["iterations"]
         return info
 
-    LARGE_TAPE_BYTES = 64 << 20          # tapes above this are created from their arrays in place, not from a blob
+    LARGE_TAPE_BYTES = 1 << 20           # tapes above this are created from their arrays in place (dnlp_create_arrays), not from a blob:
+                                         # one copy less (the canonical Rosenbrock chain at n = 1e5 is a 60 MB tape: 0.05 s of serialising)
     DEVICE_LOOP_MAX_ORDER = 256          # dense KKT: order up to which one wavefront runs the whole solve
     DEVICE_LOOP_MAX_ORDER_SPARSE = 20000  # sparse static-pattern KKT (csrc/sparse_plan.h)
     DEVICE_LOOP_MAX_TRIPLES = 150000      # ... whose update program one workgroup can walk in ~0.5 ms
