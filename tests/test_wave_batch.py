@@ -48,18 +48,33 @@ def test_wave_kernel_agrees_with_the_generic_kernel(gpu_required, name, tmpl, B,
     pb.close()
 
 
-def test_wave_kernel_agrees_with_its_own_text_on_one_host_lane(gpu_required):
+@pytest.mark.parametrize("opts", [{}, {"mu_strategy": "monotone", "tol": 1e-6}, {"least_square_init_duals": "yes", "max_iter": 25}],
+                         ids=["defaults", "monotone", "ls-duals-capped"])
+def test_wave_kernel_agrees_with_its_own_text_on_one_host_lane(gpu_required, opts):
+    """The MI355X kernel against the same text on one host lane (tests/wave_oracle.py; the host lane itself is pinned bit
+    for bit on the generic text by tests/test_wave_ipm_cpu.py) — under the default options, the monotone barrier strategy
+    with a loose tolerance, and least-squares multiplier starts with an iteration cap that stops most instances early
+    (status -1 on both sides)."""
     from wave_oracle import HostBatch
     prob, params, sample, _ = bp.template_localization()
     pb = ParametricBatch(prob, params)
     thetas = np.stack([sample(i) for i in range(96)])
-    w = _solve(pb, thetas, True)
-    h = HostBatch(pb).solve(thetas, 0)
+    w = _solve(pb, thetas, True, **opts)
+    assert w.raw["launch"]["wave_form"] == 411
+    h = HostBatch(pb, opts).solve(thetas, 0)
     assert np.array_equal(w.status, h["status"])
     assert np.mean(w.iterations == h["iters"]) >= 0.95
     same = w.iterations == h["iters"]
-    np.testing.assert_allclose(w.raw["obj_val"][same], h["obj"][same], rtol=1e-9, atol=1e-10)
-    np.testing.assert_allclose(w.x[same], h["x"][same], rtol=1e-6, atol=1e-7)
+    done = same & (w.status == 0)                  # converged: the optimum itself
+    np.testing.assert_allclose(w.raw["obj_val"][done], h["obj"][done], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(w.x[done], h["x"][done], rtol=1e-6, atol=1e-7)
+    cut = same & (w.status != 0)                   # stopped on the way (max_iter): the same iterate up to the path's sensitivity
+    if cut.any():
+        np.testing.assert_allclose(w.raw["obj_val"][cut], h["obj"][cut], rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(w.x[cut], h["x"][cut], rtol=1e-4, atol=1e-5)
+    assert done.sum() + cut.sum() >= 0.95 * len(thetas)
+    if opts.get("max_iter"):
+        assert cut.sum() >= 0.3 * len(thetas)      # (the cap did stop a good part of the batch early)
     pb.close()
 
 
