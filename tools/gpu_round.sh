@@ -15,6 +15,8 @@
 #   misc       first-call breakdown, C2 end to end + by n, the nine paper examples
 #   pmc_mix    instruction mix / LDS / address-path counters of the batch kernel (tools/pmc_wave.sh)
 #   ab_c2_barrier, ab_c4_sweep   the two A/B measurements of round 4 (C2 grid barrier three ways; C4 sweeps vs step kernels)
+#   ab_ldlt_fused                the round-5 A/B of the 512-column panel forms of the blocked LDL^T (tools/ldlt_fused_ab.sh)
+#   pmc_icache, launch_breakdown instruction-fetch / LDS-wait counters of the wavefront kernel; where a batch launch's wall time goes
 cd "${GRAFT_REPO_ROOT:-$(git rev-parse --show-toplevel)}"
 export TMPDIR=/tmp
 TAG=${1:?tag}; shift
@@ -87,6 +89,12 @@ ab_c4_sweep)
 import json,sys
 d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['roofline']['achieved'])"
   done | tee $O/c4_sweep_ab.txt ;;
+ab_ldlt_fused)
+  bash tools/ldlt_fused_ab.sh 2>&1 | tee $O/ldlt_fused_ab.txt ;;
+pmc_icache)
+  bash tools/pmc_icache.sh > /dev/null 2>&1; cp gpurun_out/pmc_icache/icache.json $O/pmc_wave_icache.json; head -c 600 $O/pmc_wave_icache.json ;;
+launch_breakdown)
+  for b in 1024 8192; do python tools/c5_launch_breakdown.py localization $b 2>&1 | tail -7; done | tee $O/c5_launch_breakdown.txt ;;
 *) echo "unknown part $PART" ;;
 esac
 done
