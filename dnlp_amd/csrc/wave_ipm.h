@@ -90,7 +90,6 @@ struct WStateT {
   WD *dir[3][7];                     // [0] = dx ds dy dzL dzU dvL dvU, [1] = affine-scaling, [2] = centering direction
   WD *rhs, *sol, *res, *cor;
   WD *jv, *xz, *dvals, *hvals, *w, *sl, *Hs, *svals, *swork, *scr;
-  WD *up0, *up1, *ucls;               // the two parameters of every sweep unit and its class (bind_params: once per instance)
   // ---- the instance (set per instance: w_bind) ----
   WG* row;                           // its data row (batch.h layout)
   const double *ws_g, *ws_l, *ws_u;  // warm-start multipliers or null
@@ -159,7 +158,7 @@ struct WaveIpm {
     S->Sx = take(N); S->rx = take(N); S->tN = take(N); S->fixm = take(N);
     WD* ax = take(N); WD* azL = take(N); WD* azU = take(N);
     S->s = take(m); S->y = take(m); S->vL = take(m); S->vU = take(m); S->sL = take(m); S->sU = take(m); S->eq = take(m); S->g = take(m);
-    S->sg = take(m); S->Dd = take(m); S->Ss = take(m); S->rs = take(m); S->rp = take(m); S->tM = take(m); S->csoc = take(m);
+    S->sg = take(m); S->Dd = take(m); S->Ss = take(m); S->rs = take(m); S->rp = take(m); S->tM = take(m);
     WD* as = take(m); WD* ay = take(m); WD* avL = take(m); WD* avU = take(m);
     S->jv = take(h->nnzJ); S->xz = take(N + h->Z); S->dvals = take(h->nd); S->hvals = take(h->nh); S->w = take(h->Z); S->sl = take(1 + m);
     S->Hs = take(h->nnzH); S->svals = take(h->sp_nvals);
@@ -180,8 +179,11 @@ struct WaveIpm {
       if (nwork + nscr <= static_cast<i32>(p - dead0)) { S->swork = dead0; S->scr = dead0 + nwork; }
       else { S->swork = take(nwork); S->scr = take(nscr); }
     }
-    S->up0 = take(h->nunits); S->up1 = take(h->nunits); S->ucls = take(h->nunits);
     S->dir[0][0] = S->dx; S->dir[0][1] = S->ds; S->dir[0][2] = S->dy; S->dir[0][3] = S->dzL; S->dir[0][4] = S->dzU; S->dir[0][5] = S->dvL; S->dir[0][6] = S->dvU;
+    // (the second-order correction's right-hand side lives in the CENTERING direction's slack part: that direction is dead
+    //  once the barrier parameter is chosen, the correction runs inside the line search that follows and factors nothing —
+    //  the affine-scaling arrays are not free for this: polish() parks the iterate there)
+    S->csoc = cs;
     S->dir[1][0] = ax; S->dir[1][1] = as; S->dir[1][2] = ay; S->dir[1][3] = azL; S->dir[1][4] = azU; S->dir[1][5] = avL; S->dir[1][6] = avU;
     S->dir[2][0] = cx; S->dir[2][1] = cs; S->dir[2][2] = cy; S->dir[2][3] = czL; S->dir[2][4] = czU; S->dir[2][5] = cvL; S->dir[2][6] = cvU;
     return static_cast<i32>(p - base);
@@ -203,21 +205,27 @@ struct WaveIpm {
     if (src != xz) { W_FOR(j, N) xz[j] = src[j]; P::sync(); }
     S->swept_xt = src == S->xt;
     WI *uop = S->u_op, *ua0 = S->u_a0, *ua1 = S->u_a1, *uz = S->u_z, *ud0 = S->u_d0, *ud1 = S->u_d1, *uh = S->u_h, *up = S->u_p;
-    const WD *up0 = S->up0, *up1 = S->up1, *ucls = S->ucls;
+    // the per-segment parameters of the unary atoms come straight out of the instance's data row (global memory, read-only,
+    // two loads per unit and sweep that travel beside the LDS loads): copies of them in LDS were 3 x nunits doubles of state,
+    // and state is what decides how many wavefronts a compute unit holds (batch.h wave_form)
+    WG *fp = S->row + S->l_fp, *fp2 = S->row + S->l_fp2;
     W_FOR(e, nu) {
       const int op = uop[e];
       const i32 zi = uz[e];
       if (op < OP_MUL) {
         double val, g1, g2;
-        const double u = xz[ua0[e]], cls = ucls[e];
-        if (cls == 1.0) {              // x^2: pow_fast(u, 2) = u u; 2 pow_fast(u, 1) = 2 u; 2 (2 - 1) pow_fast(u, 0) = 2
-          const double pd = up0[e];
+        const i32 f = up[e];
+        const double pd = fp[f], p2 = fp2[f];
+        const double u = xz[ua0[e]];
+        // the two power atoms every canonical form is full of take their branch of pow_fast directly (atom_math.h: the
+        // same expressions, so the same bits — the chain of comparisons in front of them is what a sweep was made of)
+        if (op == OP_POWER && pd == 2.0 && p2 == 2.0) {           // x^2: pow_fast(u, 2) = u u; 2 pow_fast(u, 1) = 2 u; 2 (2 - 1) pow_fast(u, 0) = 2
           val = u * u; g1 = pd * u; g2 = pd * (pd - 1.0) * 1.0;
-        } else if (cls == 2.0) {       // sqrt: pow_fast(u, 0.5) = sqrt(u); 0.5 pow_fast(u, -0.5); 0.5 (-0.5) pow_fast(u, -1.5)
-          const double pd = up0[e], sq = sqrt(u);
+        } else if (op == OP_POWER && pd == 0.5 && p2 == 0.5) {    // sqrt: pow_fast(u, 0.5) = sqrt(u); 0.5 pow_fast(u, -0.5); 0.5 (-0.5) pow_fast(u, -1.5)
+          const double sq = sqrt(u);
           val = sq; g1 = pd * (1.0 / sq); g2 = pd * (pd - 1.0) * (1.0 / (u * sq));
         } else {
-          unary_rules(op, u, up0[e], up1[e], val, g1, g2);
+          unary_rules(op, u, pd, p2, val, g1, g2);
         }
         xz[N + zi] = val;
         dv[ud0[e]] = g1;
@@ -275,24 +283,6 @@ struct WaveIpm {
     }
     for (; q < n; ++q) acc += p[q];
     return acc;
-  }
-  // the per-segment parameters of the unary atoms, once per instance: out of the data row (global memory) into LDS
-  DNLP_HD static void bind_params(WS* S) {
-    WI *uop = S->u_op, *up = S->u_p;
-    WG *fp = S->row + S->l_fp, *fp2 = S->row + S->l_fp2;
-    WD *up0 = S->up0, *up1 = S->up1, *ucls = S->ucls;
-    W_FOR(e, S->nunits) {
-      const int op = uop[e];
-      const bool unary = op < OP_MUL;
-      const i32 f = unary ? up[e] : 0;
-      const double p = unary ? fp[f] : 0.0, p2 = unary ? fp2[f] : 0.0;
-      up0[e] = p;
-      up1[e] = p2;
-      // the two power atoms every canonical form is full of take their branch of pow_fast directly (atom_math.h: the
-      // same expressions, so the same bits — the chain of comparisons in front of them is what a sweep was made of)
-      ucls[e] = (op == OP_POWER && p == 2.0 && p2 == 2.0) ? 1.0 : (op == OP_POWER && p == 0.5 && p2 == 0.5) ? 2.0 : 0.0;
-    }
-    P::sync();
   }
   // Model::spmv: y = (base + M v) [* scale];  scale_kind 0 none, 1 a scalar, 2 sg[r], 3 sg[jac_rows[r]]
   DNLP_WFN DNLP_WFN DNLP_HD static void spmv(DNLP_WLDS WState* S, const WCsr M, const WD* v, i32 base_off, WD* y, int scale_kind, double scalar) {
@@ -2233,7 +2223,6 @@ struct WaveIpm {
     S->initialized = false;
     S->iter = 0;
     S->f = 0.0;
-    bind_params(S);
     int rc = begin(S);
     if (rc != 0) { S->in_solve = false; return rc; }
     while (step(S) == 99) {}
