@@ -14,7 +14,11 @@
 
 namespace dnlp {
 
-template <bool STATE_LDS, bool PLAN_LDS>
+// (TWO_PER_SIMD only tells the instantiations apart: the functions of wave_ipm.h called from a launch with more than four
+//  wavefronts per workgroup have 256 registers and spill to scratch memory; those of a launch with up to four have 512
+//  and spill to the accumulation registers — compiled once for both, the tighter budget would apply to all: measured 81.8
+//  -> 84.8 us per iteration for the four-wavefront form)
+template <bool STATE_LDS, bool PLAN_LDS, bool TWO_PER_SIMD = false>
 struct WaveLanesT {
   typedef typename std::conditional<STATE_LDS, WLdsD, WGlbD>::type D;
   typedef typename std::conditional<PLAN_LDS, WLdsI, WGlbI>::type I;
@@ -55,7 +59,7 @@ struct WaveArgs {
 template <int NW, bool STATE_LDS, bool PLAN_LDS>
 __global__ void __launch_bounds__(64 * NW) wave_batch_kernel(WaveArgs a) {
   extern __shared__ __align__(16) char w_lds[];
-  using P = WaveLanesT<STATE_LDS, PLAN_LDS>;
+  using P = WaveLanesT<STATE_LDS, PLAN_LDS, (NW > 4)>;
   using W = WaveIpm<P>;
   using WState = typename W::WState;
   using WD = typename P::D;

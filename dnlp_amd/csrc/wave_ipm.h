@@ -215,17 +215,24 @@ struct WaveIpm {
       if (op < OP_MUL) {
         double val, g1, g2;
         const i32 f = up[e];
-        const double pd = fp[f], p2 = fp2[f];
         const double u = xz[ua0[e]];
         // the two power atoms every canonical form is full of take their branch of pow_fast directly (atom_math.h: the
-        // same expressions, so the same bits — the chain of comparisons in front of them is what a sweep was made of)
-        if (op == OP_POWER && pd == 2.0 && p2 == 2.0) {           // x^2: pow_fast(u, 2) = u u; 2 pow_fast(u, 1) = 2 u; 2 (2 - 1) pow_fast(u, 0) = 2
+        // same expressions, so the same bits — the chain of comparisons in front of them is what a sweep was made of).
+        // (the parameters are loaded where they are used: live across the general rule's code they cost the function 32
+        //  more saved registers per call)
+        int cls = 0;
+        if (op == OP_POWER) {
+          const double pd = fp[f], p2 = fp2[f];
+          cls = (pd == 2.0 && p2 == 2.0) ? 1 : (pd == 0.5 && p2 == 0.5) ? 2 : 0;
+        }
+        if (cls == 1) {                // x^2: pow_fast(u, 2) = u u; 2 pow_fast(u, 1) = 2 u; 2 (2 - 1) pow_fast(u, 0) = 2
+          const double pd = 2.0;
           val = u * u; g1 = pd * u; g2 = pd * (pd - 1.0) * 1.0;
-        } else if (op == OP_POWER && pd == 0.5 && p2 == 0.5) {    // sqrt: pow_fast(u, 0.5) = sqrt(u); 0.5 pow_fast(u, -0.5); 0.5 (-0.5) pow_fast(u, -1.5)
-          const double sq = sqrt(u);
+        } else if (cls == 2) {         // sqrt: pow_fast(u, 0.5) = sqrt(u); 0.5 pow_fast(u, -0.5); 0.5 (-0.5) pow_fast(u, -1.5)
+          const double pd = 0.5, sq = sqrt(u);
           val = sq; g1 = pd * (1.0 / sq); g2 = pd * (pd - 1.0) * (1.0 / (u * sq));
         } else {
-          unary_rules(op, u, pd, p2, val, g1, g2);
+          unary_rules(op, u, fp[f], fp2[f], val, g1, g2);
         }
         xz[N + zi] = val;
         dv[ud0[e]] = g1;
