@@ -173,7 +173,8 @@ struct WaveIpm {
     // the centering direction as three [variables | rows] pairs: until its outputs are written they hold the second
     // right-hand side, solution and residual of the mu oracle's joint solve (quality_function_mu)
     WD* cx = take(N + m); WD* cs = cx + N; WD* czL = take(N + m); WD* cvL = czL + N; WD* czU = take(N + m); WD* cvU = czU + N;
-    S->rhs = take(N + m); S->sol = take(N + m); S->res = take(N + m); S->cor = take(N + m);
+    S->rhs = take(N + m); S->sol = take(N + m); S->res = take(N + m);
+    S->cor = S->res;      // (a refinement step's correction is solved IN PLACE in the residual's array: kkt_solve(res, cor) copies nothing)
     {
       const i32 nwork = (h->sp_nvals + 3 * h->sp_nblk + 8 + 1) & ~1, nscr = (h->scr_doubles + 1) & ~1;
       if (nwork + nscr <= static_cast<i32>(p - dead0)) { S->swork = dead0; S->scr = dead0 + nwork; }

@@ -72,7 +72,7 @@ inline WaveLayoutIn wave_layout_of(const Tape<E>& t) {
 inline i64 wave_state_doubles(i64 N, i64 m, i64 Z, i64 nd, i64 nh, i64 nnzJ, i64 nnzH, i64 nvals, i64 nblk, i64 scr, i64 nunits) {
   auto ev = [](i64 n) { return (n + 1) & ~static_cast<i64>(1); };      // 16-byte granules
   // (wave_ipm.h layout: the factorisation's work arrays share the region of what is dead while it runs, when they fit)
-  const i64 dead = 4 * ev(N) + 7 * ev(m) + 7 * ev(N + m), work = ev(nvals + 3 * nblk + 8) + ev(scr);
+  const i64 dead = 4 * ev(N) + 7 * ev(m) + 6 * ev(N + m), work = ev(nvals + 3 * nblk + 8) + ev(scr);
   (void)nunits;
   return 13 * ev(N) + 18 * ev(m) + ev(nnzJ) + ev(N + Z) + ev(nd) + ev(nh) + ev(Z) + ev(1 + m) + ev(nnzH) + ev(nvals) + dead +
          (work <= dead ? 0 : work);
