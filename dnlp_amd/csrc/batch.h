@@ -999,6 +999,7 @@ struct BatchRunner {
   //  MI355X, circle packing n = 4 at 16 384 instances: four wavefronts per compute unit 382 k problems/s, six 518 k, and an
   //  instance's own wall time only 5 % longer — a second wavefront on a SIMD fills the cycles the first one waits for LDS)
   int wf_nw = 0, wf_sl = 0, wf_pl = 0;      // the form of this template, found once (hipFuncGetAttributes per candidate)
+  int wf_nw_glb = 0;                         // wavefronts per workgroup that fit with the plan in global memory (up to four)
   int wf_per_cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // ... and the occupancy of <nw, LDS, LDS> / of the fallback form at [0]
   size_t wave_static_full(int nw) {
     switch (nw) {
@@ -1021,9 +1022,16 @@ struct BatchRunner {
     nw = 0;
     for (int k = 8; k >= 1 && nw == 0; --k)
       if (plan_b + static_cast<size_t>(k) * state_b + wave_static_full(k) <= cap) { nw = k; sl = 1; pl = 1; }
+    // with the plan left in global memory (read through L1 / L2: measured +23 % per iteration on circle packing n = 10) more
+    // wavefronts may fit — worth it when a launch has the instances for them (solve_wave decides per launch)
+    wf_nw_glb = 0;
+    for (int k = 4; k >= 1 && wf_nw_glb == 0; --k) {
+      const size_t st = k == 4 ? wave_static_lds<4, true, false>() : k == 3 ? wave_static_lds<3, true, false>() : k == 2 ? wave_static_lds<2, true, false>()
+                                                                                                                  : wave_static_lds<1, true, false>();
+      if (static_cast<size_t>(k) * state_b + st <= cap) wf_nw_glb = k;
+    }
     if (nw > 0) {}
-    else if (2 * state_b + wave_static_lds<2, true, false>() <= cap) { nw = 2; sl = 1; pl = 0; }
-    else if (state_b + wave_static_lds<1, true, false>() <= cap) { nw = 1; sl = 1; pl = 0; }
+    else if (wf_nw_glb > 0) { nw = wf_nw_glb; sl = 1; pl = 0; }
     else { nw = 4; sl = 0; pl = 0; }
     if (const char* e = std::getenv("DNLP_WAVE_FORM")) {        // experiments: "811" .. "111", "210", "110", "400"
       const int f = std::atoi(e);
@@ -1077,11 +1085,16 @@ struct BatchRunner {
     w.fallback_max_n = (n <= 512 && !force_sparse) ? 512 : 0;
     // a launch that does not fill the chip spreads out: no more wavefronts per compute unit than instances per compute unit
     // (1024 instances on 256 units: four each, whatever would fit — a lone wavefront on its SIMD is the fastest instance)
-    if (sl && pl && !std::getenv("DNLP_WAVE_FORM")) nw = std::max(1, std::min(nw, (batch + this->ncu - 1) / this->ncu));
+    if (sl && !std::getenv("DNLP_WAVE_FORM")) {
+      const int want = std::max(1, (batch + this->ncu - 1) / this->ncu);
+      if (pl && want > nw && wf_nw_glb > nw) { nw = std::min(want, wf_nw_glb); pl = 0; }      // more instances than fit beside the plan
+      else nw = std::min(nw, want);
+    }
     int per_cu = 1;
     const unsigned lds = static_cast<unsigned>((pl ? plan_b : 0) + (sl ? static_cast<size_t>(nw) * state_b : 0));
     const int form = 100 * nw + 10 * sl + pl;
-    int& cached = wf_per_cu[(sl && pl) ? nw : 0];
+    int cached_none = 0;
+    int& cached = (sl && pl) ? wf_per_cu[nw] : cached_none;
     if (cached > 0 && !std::getenv("DNLP_WAVE_FORM")) per_cu = cached;
     else switch (form) {
       case 811: per_cu = wave_occupancy<8, true, true>(lds); break;
@@ -1092,6 +1105,8 @@ struct BatchRunner {
       case 311: per_cu = wave_occupancy<3, true, true>(lds); break;
       case 211: per_cu = wave_occupancy<2, true, true>(lds); break;
       case 111: per_cu = wave_occupancy<1, true, true>(lds); break;
+      case 410: per_cu = wave_occupancy<4, true, false>(lds); break;
+      case 310: per_cu = wave_occupancy<3, true, false>(lds); break;
       case 210: per_cu = wave_occupancy<2, true, false>(lds); break;
       case 110: per_cu = wave_occupancy<1, true, false>(lds); break;
       case 400: per_cu = wave_occupancy<4, false, false>(lds); break;
@@ -1102,6 +1117,8 @@ struct BatchRunner {
     int grid = std::min((batch + nw - 1) / nw, ncu * per_cu);
     if (grid < 1) grid = 1;
     if (!sl) w.state = dalloc<double>(static_cast<size_t>(grid) * static_cast<size_t>(nw) * static_cast<size_t>(h.state_doubles));
+    w.park_doubles = wave_park_doubles(t.N, t.m);
+    w.park = dalloc<double>(static_cast<size_t>(grid) * static_cast<size_t>(nw) * static_cast<size_t>(w.park_doubles));
     w.x_out = dalloc<double>(static_cast<size_t>(batch) * t.N);
     w.obj_out = dalloc<double>(static_cast<size_t>(batch));
     w.multg_out = multg_out ? dalloc<double>(static_cast<size_t>(batch) * t.m) : nullptr;
@@ -1164,6 +1181,8 @@ struct BatchRunner {
       case 311: launch_wave<3, true, true>(w, grid, lds, stream); break;
       case 211: launch_wave<2, true, true>(w, grid, lds, stream); break;
       case 111: launch_wave<1, true, true>(w, grid, lds, stream); break;
+      case 410: launch_wave<4, true, false>(w, grid, lds, stream); break;
+      case 310: launch_wave<3, true, false>(w, grid, lds, stream); break;
       case 210: launch_wave<2, true, false>(w, grid, lds, stream); break;
       case 110: launch_wave<1, true, false>(w, grid, lds, stream); break;
       case 400: launch_wave<4, false, false>(w, grid, lds, stream); break;

@@ -44,6 +44,8 @@ struct WaveArgs {
   i64 row_doubles = 0;
   int batch = 0;
   double* state = nullptr;           // state in global memory: (grid x NW) x state_doubles
+  double* park = nullptr;            // (grid x NW) x park_doubles: polish()'s parking place (wave_plan.h wave_park_doubles)
+  i64 park_doubles = 0;
   i64 state_doubles = 0;
   IpmOptions opt;
   i64 fallback_max_n = 0;
@@ -99,6 +101,7 @@ __global__ void __launch_bounds__(64 * NW) wave_batch_kernel(WaveArgs a) {
     //  from one instance into the next through an entry that a masked pass skips)
     for (i64 k = lane; k < a.state_doubles; k += 64) base[k] = 0.0;
     S->row = (WG*)(a.rows + static_cast<i64>(inst) * a.row_doubles);
+    S->park = a.park + (static_cast<i64>(blockIdx.x) * NW + wave) * a.park_doubles;
     S->ws_g = a.ws_g ? a.ws_g + static_cast<i64>(inst) * m : nullptr;
     S->ws_l = a.ws_l ? a.ws_l + static_cast<i64>(inst) * N : nullptr;
     S->ws_u = a.ws_u ? a.ws_u + static_cast<i64>(inst) * N : nullptr;

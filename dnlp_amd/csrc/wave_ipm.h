@@ -92,6 +92,7 @@ struct WStateT {
   WD *jv, *xz, *dvals, *hvals, *w, *sl, *Hs, *svals, *swork, *scr;
   // ---- the instance (set per instance: w_bind) ----
   WG* row;                           // its data row (batch.h layout)
+  double* park;                      // 3 N + 4 m doubles of global memory: where polish() keeps the iterate it may have to come back to
   const double *ws_g, *ws_l, *ws_u;  // warm-start multipliers or null
   i64 fallback_max_n;
   // ---- interior-point state (Ipm<E, K> members of the same names) ----
@@ -156,11 +157,15 @@ struct WaveIpm {
     auto take = [&](i32 n) { WD* q = p; p += (n + 1) & ~1; return q; };
     S->x = take(N); S->zL = take(N); S->zU = take(N); S->xL = take(N); S->xU = take(N); S->grad = take(N);
     S->Sx = take(N); S->rx = take(N); S->tN = take(N); S->fixm = take(N);
-    WD* ax = take(N); WD* azL = take(N); WD* azU = take(N);
     S->s = take(m); S->y = take(m); S->vL = take(m); S->vU = take(m); S->sL = take(m); S->sU = take(m); S->eq = take(m); S->g = take(m);
-    S->sg = take(m); S->Dd = take(m); S->Ss = take(m); S->rs = take(m); S->rp = take(m); S->tM = take(m);
-    WD* as = take(m); WD* ay = take(m); WD* avL = take(m); WD* avU = take(m);
-    S->jv = take(h->nnzJ); S->xz = take(N + h->Z); S->dvals = take(h->nd); S->hvals = take(h->nh); S->w = take(h->Z); S->sl = take(1 + m);
+    S->sg = take(m); S->Dd = take(m); S->Ss = take(m); S->rs = take(m); S->rp = take(m);
+    // (xz: the units' values z only — an argument index below N reads the point the sweep is at, x or the trial point, where it
+    //  lies: no copy of it in front of z)
+    S->jv = take(h->nnzJ); S->xz = take(h->Z); S->dvals = take(h->nd);
+    // what only lives inside eval_hessian — the scaled multipliers sl, the unit weights w, the units' second derivatives hvals
+    // (sl -> w -> hvals -> Hs) — borrows the three arrays of a linear solve, which are idle then, when it fits them
+    const bool hess_borrows = h->nh <= N + m && h->Z <= N + m;
+    if (!hess_borrows) { S->hvals = take(h->nh); S->w = take(h->Z); S->sl = take(1 + m); }
     S->Hs = take(h->nnzH); S->svals = take(h->sp_nvals);
     // One contiguous region of everything that is DEAD while the KKT matrix is being factorised — the step (dx .. dvU), the
     // trial point (xt, st, gt), the centering direction and the four arrays of a linear solve: the factorisation's work
@@ -169,11 +174,14 @@ struct WaveIpm {
     WD* dead0 = p;
     S->dx = take(N); S->dzL = take(N); S->dzU = take(N); S->xt = take(N);
     S->ds = take(m); S->dy = take(m); S->dvL = take(m); S->dvU = take(m); S->st = take(m); S->gt = take(m);
+    S->tM = S->gt;        // (the residual passes' scratch: the trial point's constraint values are dead inside a linear solve — the
+                          //  dense end's scratch has always counted on that)
     WD* cy = take(m);
     // the centering direction as three [variables | rows] pairs: until its outputs are written they hold the second
     // right-hand side, solution and residual of the mu oracle's joint solve (quality_function_mu)
     WD* cx = take(N + m); WD* cs = cx + N; WD* czL = take(N + m); WD* cvL = czL + N; WD* czU = take(N + m); WD* cvU = czU + N;
     S->rhs = take(N + m); S->sol = take(N + m); S->res = take(N + m);
+    if (hess_borrows) { S->hvals = S->rhs; S->w = S->sol; S->sl = S->res; }
     S->cor = S->res;      // (a refinement step's correction is solved IN PLACE in the residual's array: kkt_solve(res, cor) copies nothing)
     {
       const i32 nwork = (h->sp_nvals + 3 * h->sp_nblk + 8 + 1) & ~1, nscr = (h->scr_doubles + 1) & ~1;
@@ -185,7 +193,10 @@ struct WaveIpm {
     //  once the barrier parameter is chosen, the correction runs inside the line search that follows and factors nothing —
     //  the affine-scaling arrays are not free for this: polish() parks the iterate there)
     S->csoc = cs;
-    S->dir[1][0] = ax; S->dir[1][1] = as; S->dir[1][2] = ay; S->dir[1][3] = azL; S->dir[1][4] = azU; S->dir[1][5] = avL; S->dir[1][6] = avU;
+    // The affine-scaling direction lives in the STEP's arrays: it is written after the mu oracle's joint solve (until then
+    // those arrays are scratch, as they always were), read by the quality function, and the step itself — affine + mu x
+    // centering — is formed in place.  3 N + 4 m doubles of state less: LDS decides how many wavefronts a compute unit holds.
+    for (int k = 0; k < 7; ++k) S->dir[1][k] = S->dir[0][k];
     S->dir[2][0] = cx; S->dir[2][1] = cs; S->dir[2][2] = cy; S->dir[2][3] = czL; S->dir[2][4] = czU; S->dir[2][5] = cvL; S->dir[2][6] = cvU;
     return static_cast<i32>(p - base);
   }
@@ -201,9 +212,11 @@ struct WaveIpm {
   DNLP_WFN DNLP_HD static void sweep(WS* S, const WD* src, bool with_h) {
     W_P0();
     const int N = S->N, nu = S->nunits;
-    WD *xz = S->xz, *dv = S->dvals, *hv = S->hvals;
+    WD *dv = S->dvals, *hv = S->hvals;
+    WD* zz = S->xz;
     const WD* ww = S->w;
-    if (src != xz) { W_FOR(j, N) xz[j] = src[j]; P::sync(); }
+    const WD* zlo = S->xz - N;          // argument index u: u < N -> src[u], else zlo[u] = z[u - N]
+    auto at = [&](i32 u) -> double { return (u < N ? src : zlo)[u]; };
     S->swept_xt = src == S->xt;
     WI *uop = S->u_op, *ua0 = S->u_a0, *ua1 = S->u_a1, *uz = S->u_z, *ud0 = S->u_d0, *ud1 = S->u_d1, *uh = S->u_h, *up = S->u_p;
     // the per-segment parameters of the unary atoms come straight out of the instance's data row (global memory, read-only,
@@ -216,7 +229,7 @@ struct WaveIpm {
       if (op < OP_MUL) {
         double val, g1, g2;
         const i32 f = up[e];
-        const double u = xz[ua0[e]];
+        const double u = at(ua0[e]);
         // the two power atoms every canonical form is full of take their branch of pow_fast directly (atom_math.h: the
         // same expressions, so the same bits — the chain of comparisons in front of them is what a sweep was made of).
         // (the parameters are loaded where they are used: live across the general rule's code they cost the function 32
@@ -235,21 +248,21 @@ struct WaveIpm {
         } else {
           unary_rules(op, u, fp[f], fp2[f], val, g1, g2);
         }
-        xz[N + zi] = val;
+        zz[zi] = val;
         dv[ud0[e]] = g1;
         if (with_h) hv[uh[e]] = ww[zi] * g2;
       } else if (op == OP_MUL) {
         // bilinear u*v: binary_operators.py:586-591 (Jacobian), :543-546 (cross Hessian)
-        const double u = xz[ua0[e]], v = xz[ua1[e]];
-        xz[N + zi] = u * v;
+        const double u = at(ua0[e]), v = at(ua1[e]);
+        zz[zi] = u * v;
         dv[ud0[e]] = v;
         dv[ud1[e]] = u;
         if (with_h) hv[uh[e]] = ww[zi];
       } else if (op == OP_REL_ENTR) {
         // rel_entr.py:37-40, :129-148, :150-179
-        const double u = xz[ua0[e]], v = xz[ua1[e]];
+        const double u = at(ua0[e]), v = at(ua1[e]);
         const double lr = log(u / v);
-        xz[N + zi] = u * lr;
+        zz[zi] = u * lr;
         dv[ud0[e]] = lr + 1.0;
         dv[ud1[e]] = -u / v;
         if (with_h) {
@@ -265,13 +278,13 @@ struct WaveIpm {
         WI* mi = S->mm_idx + ua0[e];
         double acc = 0.0;
         for (i32 q = 0; q < kk; ++q) {
-          const double u = xz[mi[2 * q]], v = xz[mi[2 * q + 1]];
+          const double u = at(mi[2 * q]), v = at(mi[2 * q + 1]);
           acc += u * v;
           dv[db0 + q] = v;
           dv[db1 + q] = u;
           if (with_h) hv[hb + q] = ww[zi];
         }
-        xz[N + zi] = acc;
+        zz[zi] = acc;
       }
     }
     W_P1(15);
@@ -293,7 +306,10 @@ struct WaveIpm {
     return acc;
   }
   // Model::spmv: y = (base + M v) [* scale];  scale_kind 0 none, 1 a scalar, 2 sg[r], 3 sg[jac_rows[r]]
-  DNLP_WFN DNLP_WFN DNLP_HD static void spmv(DNLP_WLDS WState* S, const WCsr M, const WD* v, i32 base_off, WD* y, int scale_kind, double scalar) {
+  // (SPLIT: v is the vector [x | z] in two places — column c < split reads v[c], the others vhi[c]: the sweep's point and S->xz - N)
+  template <bool SPLIT = false>
+  DNLP_WFN DNLP_HD static void spmv(DNLP_WLDS WState* S, const WCsr M, const WD* v, i32 base_off, WD* y, int scale_kind, double scalar,
+                                    const WD* vhi = nullptr, i32 split = 0) {
     W_P0();
     WI *ptr = M.ptr, *idx = M.idx;
     WG* val = S->row + M.val;
@@ -303,7 +319,10 @@ struct WaveIpm {
     W_FOR(r, M.rows) {
       double sacc = base ? base[r] : 0.0;
       const i32 k1 = ptr[r + 1];
-      for (i32 k = ptr[r]; k < k1; ++k) sacc += val[k] * v[idx[k]];
+      for (i32 k = ptr[r]; k < k1; ++k) {
+        const i32 c = idx[k];
+        sacc += val[k] * ((SPLIT && c >= split) ? vhi : v)[c];
+      }
       if (scale_kind == 1) sacc *= scalar;
       else if (scale_kind == 2) sacc *= sg[r];
       else if (scale_kind == 3) sacc *= sg[jr[r]];
@@ -317,11 +336,12 @@ struct WaveIpm {
     sweep(S, xp, false);
     const int NZ = S->N + S->Z;
     WG* cc = S->row + S->l_c;
-    const WD* v = S->xz;
+    const int N = S->N;
+    const WD* zlo = S->xz - N;
     double acc = 0.0;
-    W_FOR(i, NZ) acc += cc[i] * v[i];
+    W_FOR(i, NZ) acc += cc[i] * (i < N ? xp : zlo)[i];
     fval = S->sf * (S->row[S->l_c0] + P::sum(acc));
-    spmv(S, S->G, S->xz, S->l_b, gout, 2, 0.0);
+    spmv<true>(S, S->G, xp, S->l_b, gout, 2, 0.0, zlo, N);
     return std::isfinite(fval);
   }
   DNLP_HD static double nan_check(WS* S, const WD* gg) {
@@ -2192,7 +2212,11 @@ struct WaveIpm {
     WD* sv[7] = {S->x, S->s, S->y, S->zL, S->zU, S->vL, S->vU};
     const int sz[7] = {N, m, m, N, N, m, m};
     const int slot[7] = {0, 1, 2, 3, 4, 5, 6};
-    for (int k = 0; k < 7; ++k) { WD* dst = S->dir[1][slot[k]]; const WD* src = sv[k]; W_FOR(i, sz[k]) dst[i] = src[i]; }
+    int poff[8];
+    poff[0] = 0;
+    for (int k = 0; k < 7; ++k) poff[k + 1] = poff[k] + ((sz[k] + 1) & ~1);
+    (void)slot;
+    for (int k = 0; k < 7; ++k) { double* dst = S->park + poff[k]; const WD* src = sv[k]; W_FOR(i, sz[k]) dst[i] = src[i]; }
     P::sync();
     const double tol0 = S->opt.tol, mu0 = S->mu, tau0 = S->tau;
     const int maxit0 = S->opt.max_iter;
@@ -2207,7 +2231,7 @@ struct WaveIpm {
       const WErr e = error(S, 0.0);
       if (check_convergence(S, e) == Solve_Succeeded) { S->status = Solve_Succeeded; return; }
     }
-    for (int k = 0; k < 7; ++k) { const WD* src = S->dir[1][slot[k]]; WD* dst = sv[k]; W_FOR(i, sz[k]) dst[i] = src[i]; }
+    for (int k = 0; k < 7; ++k) { const double* src = S->park + poff[k]; WD* dst = sv[k]; W_FOR(i, sz[k]) dst[i] = src[i]; }
     P::sync();
     S->mu = mu0; S->tau = tau0;
     (void)eval_fg(S, S->x, S->f, S->g);

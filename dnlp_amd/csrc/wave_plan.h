@@ -74,9 +74,13 @@ inline i64 wave_state_doubles(i64 N, i64 m, i64 Z, i64 nd, i64 nh, i64 nnzJ, i64
   // (wave_ipm.h layout: the factorisation's work arrays share the region of what is dead while it runs, when they fit)
   const i64 dead = 4 * ev(N) + 7 * ev(m) + 6 * ev(N + m), work = ev(nvals + 3 * nblk + 8) + ev(scr);
   (void)nunits;
-  return 13 * ev(N) + 18 * ev(m) + ev(nnzJ) + ev(N + Z) + ev(nd) + ev(nh) + ev(Z) + ev(1 + m) + ev(nnzH) + ev(nvals) + dead +
+  const i64 hess = (nh <= N + m && Z <= N + m) ? 0 : ev(nh) + ev(Z) + ev(1 + m);      // (eval_hessian's transients borrow rhs / sol / res)
+  return 10 * ev(N) + 13 * ev(m) + ev(nnzJ) + ev(Z) + ev(nd) + hess + ev(nnzH) + ev(nvals) + dead +
          (work <= dead ? 0 : work);
 }
+
+// doubles of global memory a wavefront parks an iterate in (wave_ipm.h polish)
+inline i64 wave_park_doubles(i64 N, i64 m) { auto ev = [](i64 n) { return (n + 1) & ~static_cast<i64>(1); }; return 3 * ev(N) + 4 * ev(m); }
 
 // Why a template cannot take the wavefront solver ("" = it can).  The generic kernel stays the solver of everything else.
 template <class E>

@@ -137,7 +137,9 @@ extern "C" int orc_wave_solve_batch(orc_problem* vp, int batch, const double* da
         std::fill(state.begin(), state.end(), 0.0);
         if (WaveIpm<HostLane>::layout(&S, reinterpret_cast<const WaveHdr*>(blk.data()), blk.data(), state.data()) !=
             reinterpret_cast<const WaveHdr*>(blk.data())->state_doubles) throw std::runtime_error("wave layout and wave_state_doubles disagree");
+        std::vector<double> park(static_cast<size_t>(wave_park_doubles(t.N, t.m)) + 8, 0.0);
         S.row = row.data();
+        S.park = park.data();
         S.ws_g = S.ws_l = S.ws_u = nullptr;
         S.fallback_max_n = fb ? 512 : 0;
         S.opt = p->opt;
