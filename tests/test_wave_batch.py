@@ -54,20 +54,32 @@ def test_wave_kernel_agrees_with_the_generic_kernel(gpu_required, name, tmpl, B,
     pb.close()
 
 
+@pytest.mark.parametrize("template", ["localization", "circle_packing"])
 @pytest.mark.parametrize("opts", [{}, {"mu_strategy": "monotone", "tol": 1e-6}, {"least_square_init_duals": "yes", "max_iter": 25}],
                          ids=["defaults", "monotone", "ls-duals-capped"])
-def test_wave_kernel_agrees_with_its_own_text_on_one_host_lane(gpu_required, opts):
+def test_wave_kernel_agrees_with_its_own_text_on_one_host_lane(gpu_required, opts, template):
     """The MI355X kernel against the same text on one host lane (tests/wave_oracle.py; the host lane itself is pinned bit
     for bit on the generic text by tests/test_wave_ipm_cpu.py) — under the default options, the monotone barrier strategy
     with a loose tolerance, and least-squares multiplier starts with an iteration cap that stops most instances early
     (status -1 on both sides)."""
     from wave_oracle import HostBatch
-    prob, params, sample, _ = bp.template_localization()
+    prob, params, sample, _ = bp.template_localization() if template == "localization" else bp.template_circle_packing()
     pb = ParametricBatch(prob, params)
     thetas = np.stack([sample(i) for i in range(96)])
     w = _solve(pb, thetas, True, **opts)
     assert _in_lds(w.raw["launch"]["wave_form"], 1)            # (96 instances: one wavefront per compute unit)
     h = HostBatch(pb, opts).solve(thetas, 0)
+    took = h["status"] != NEEDS_GENERIC        # (circle packing: exact zero pivots on the host lane go to the generic kernel there)
+    if template == "circle_packing":
+        # non-convex, several optima: fused multiply-adds on the device may tip an instance onto another path — status and
+        # iteration count of most instances agree, and where they do, so does the optimum found
+        assert np.mean(w.status[took] == h["status"][took]) >= 0.9
+        same = took & (w.status == h["status"]) & (w.iterations == h["iters"])
+        assert same.mean() >= 0.6
+        done = same & (w.status == 0)
+        np.testing.assert_allclose(w.raw["obj_val"][done], h["obj"][done], rtol=1e-7, atol=1e-9)
+        pb.close()
+        return
     assert np.array_equal(w.status, h["status"])
     assert np.mean(w.iterations == h["iters"]) >= 0.95
     same = w.iterations == h["iters"]
