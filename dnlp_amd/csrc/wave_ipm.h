@@ -106,6 +106,16 @@ struct WStateT {
   bool initialized, fixed_mode, e_cached_valid, jty_valid, delta_w_used_last_iter, dc_fixed_last, always_dc, in_solve,
        resto_stationary, bail,
        swept_xt;                    // the tape's z / dvals belong to the point in xt (the last sweep was a trial evaluation)
+  // the quality function's constants and the golden section's two results: here, not on the stack (a struct passed by
+  // reference and two reference outputs were private-memory traffic in every evaluation)
+  // output slots of the phase functions: a function that is CALLED hands its scalar results back through these (the caller's
+  // wrapper copies them out at once) — a reference parameter makes the caller's variable a private-memory variable, a
+  // scratch store before and a scratch load after every call
+  double o_d[10];
+  i32 o_i[4];
+  double qf_avg, qf_nd2, qf_np2, qf_n_dual, qf_n_pri, qf_fsel;
+  i64 qf_nb;
+  i32 qf_endpoint;
 #ifdef DNLP_WAVE_PROF
   unsigned long long prof[kWaveProfSlots];
 #endif
@@ -208,6 +218,15 @@ struct WaveIpm {
   // ====================================================================================================================
   // tape evaluation (model.h)
   // ====================================================================================================================
+  // the general rule table (atom_math.h unary_rules: pow / exp / log / trigonometric ... a few thousand instructions inline) as a
+  // function of its own: inside the sweep it cost the sweep 34 saved registers per call in the 256-register forms, whether
+  // or not a unit ever took it
+  struct U3 { double v, g1, g2; };
+  DNLP_WFN DNLP_HD static U3 unary_slow(int op, double u, double p, double p2) {
+    U3 r;
+    unary_rules(op, u, p, p2, r.v, r.g1, r.g2);
+    return r;
+  }
   // Model::sweep: xz[0..N) <- src (unless it is xz already), then every flat unit: z, dvals (and hvals with the weights w)
   DNLP_WFN DNLP_HD static void sweep(WS* S, const WD* src, bool with_h) {
     W_P0();
@@ -246,7 +265,8 @@ struct WaveIpm {
           const double pd = 0.5, sq = sqrt(u);
           val = sq; g1 = pd * (1.0 / sq); g2 = pd * (pd - 1.0) * (1.0 / (u * sq));
         } else {
-          unary_rules(op, u, fp[f], fp2[f], val, g1, g2);
+          const U3 r = unary_slow(op, u, fp[f], fp2[f]);
+          val = r.v; g1 = r.g1; g2 = r.g2;
         }
         zz[zi] = val;
         dv[ud0[e]] = g1;
@@ -332,7 +352,20 @@ struct WaveIpm {
     W_P1(16);
   }
   // Ipm::eval_fg (check folded into the callers): f~ and g~ at xp; returns isfinite(f~)
-  DNLP_WFN DNLP_HD static bool eval_fg(WS* S, const WD* xp, double& fval, WD* gout) {
+  DNLP_HD static bool eval_fg(WS* S, const WD* xp, double& fval, WD* gout) {
+    const bool ok = eval_fg_impl(S, xp, gout);
+    fval = S->o_d[0];
+    return ok;
+  }
+#if DNLP_DEVICE_PASS
+  DNLP_HD static bool eval_fg(WS* S, const WD* xp, DNLP_WLDS double& fval, WD* gout) {      // (a field of the state record as the destination)
+    const bool ok = eval_fg_impl(S, xp, gout);
+    fval = S->o_d[0];
+    return ok;
+  }
+#endif
+  DNLP_WFN DNLP_HD static bool eval_fg_impl(WS* S, const WD* xp, WD* gout) {
+    auto& fval = S->o_d[0];
     sweep(S, xp, false);
     const int NZ = S->N + S->Z;
     WG* cc = S->row + S->l_c;
@@ -399,7 +432,12 @@ struct WaveIpm {
   // ====================================================================================================================
   // KKT system: assembly (kkt_dense.h assemble_factor, sparse branch) and the static-pattern LDL^T (sparse_ldl.h)
   // ====================================================================================================================
-  DNLP_WFN DNLP_HD static bool assemble_factor(WS* S, const WD* Sx, const WD* D, double dw, bool zero_h, int* nneg_out, int* nzero_out) {
+  DNLP_HD static bool assemble_factor(WS* S, const WD* Sx, const WD* D, double dw, bool zero_h, int* nneg_out, int* nzero_out) {
+    const bool ok = assemble_factor_impl(S, Sx, D, dw, zero_h);
+    *nneg_out = S->o_i[1]; *nzero_out = S->o_i[2];
+    return ok;
+  }
+  DNLP_WFN DNLP_HD static bool assemble_factor_impl(WS* S, const WD* Sx, const WD* D, double dw, bool zero_h) {
     const int N = S->N, m = S->m, nnzH = S->nnzH, nnzJ = S->nnzJ, nvals = S->nvals;
     W_P0();
     WD* V = S->svals;
@@ -426,7 +464,7 @@ struct WaveIpm {
     P::sync();
     S->factorizations++;
     W_P1(5);
-    return ldl_factor(S, nneg_out, nzero_out);
+    return ldl_factor_impl(S);
   }
   // sparse_ldl.h sp_pivot
   DNLP_HD static void sp_pivot(WS* S, WD* vals, WD* dinv, int k, double& nneg, double& nzero, double& bad) {
@@ -478,8 +516,9 @@ struct WaveIpm {
   // (three widths of the unrolled loops — 12, 24, 32 rows — so that a tail of 9 or 21 rows does not pay for 32: the
   //  padding columns cost products, loads and skipped steps; circle packing n = 4 has T = 9, n = 10 T = 21)
   static constexpr int kTailMax = 32;
+  struct T3 { double nneg, nzero, bad; };      // (lane-local counts — lane 0 counts — handed back in registers)
   template <int kTailMax>
-  DNLP_WFN DNLP_HD static void tail_factor_n(WS* S, double& nneg_io, double& nzero_io, double& bad_io) {
+  DNLP_WFN DNLP_HD static T3 tail_factor_n(WS* S) {
     constexpr int kTailSlots = (kTailMax + P::lanes - 1) / P::lanes;      // rows of the tail a lane owns (device 1, host: all)
     W_P0();
     const int T = P::uni(S->tail_T), me = P::lane();      // (uniform: a scalar register, so that the unrolled loops below test it on the scalar unit)
@@ -537,9 +576,11 @@ struct WaveIpm {
       for (int j = 0; j < kTailMax; ++j)
         if (i < T && j <= i) vals[j == i ? td[i] : tl[i * T + j]] = A[sl][j];
     }
-    nneg_io += nneg; nzero_io += nzero; bad_io += bad;
     P::sync();
     W_P1(24);
+    T3 r;
+    r.nneg = nneg; r.nzero = nzero; r.bad = bad;
+    return r;
   }
   // forward substitution through the tail: the gathers of the tail's targets from the blocks before it (products side by
   // side, runs added in storage order), then row t adds L_tk x_k for k < t as x_k becomes final — the order of the level code
@@ -647,9 +688,8 @@ struct WaveIpm {
   }
   DNLP_HD static void tail_factor(WS* S, double& nneg_io, double& nzero_io, double& bad_io) {
     const int T = P::uni(S->tail_T);
-    if (T <= 12) tail_factor_n<12>(S, nneg_io, nzero_io, bad_io);
-    else if (T <= 24) tail_factor_n<24>(S, nneg_io, nzero_io, bad_io);
-    else tail_factor_n<32>(S, nneg_io, nzero_io, bad_io);
+    const T3 r = T <= 12 ? tail_factor_n<12>(S) : T <= 24 ? tail_factor_n<24>(S) : tail_factor_n<32>(S);
+    nneg_io += r.nneg; nzero_io += r.nzero; bad_io += r.bad;
   }
   DNLP_HD static void tail_forward(WS* S, WD* x, WD* y) {
     const int T = P::uni(S->tail_T);
@@ -665,7 +705,9 @@ struct WaveIpm {
   }
   // sparse_ldl.h sparse_ldl_factor (no dense tail).  Per level: pivots, row scaling, then the update triples — their
   // products side by side into the scratch array, each destination's run added in storage order (see run_sum).
-  DNLP_WFN DNLP_HD static bool ldl_factor(WS* S, int* nneg_out, int* nzero_out) {
+  DNLP_WFN DNLP_HD static bool ldl_factor_impl(WS* S) {
+    auto* nneg_out = &S->o_i[1];
+    auto* nzero_out = &S->o_i[2];
     W_P0();
     const int L = P::lanes, me = P::lane();
     WD* vals = S->svals;
@@ -1224,7 +1266,14 @@ struct WaveIpm {
     return nneg == S->m ? 0 : 1;
   }
   // Ipm::factor_with_inertia (WB Algorithm IC; no Lanczos bound: host-driven large dense systems only)
-  DNLP_WFN DNLP_HD static bool factor_with_inertia(WS* S, double& delta_w, double& delta_c) {
+  DNLP_HD static bool factor_with_inertia(WS* S, double& delta_w, double& delta_c) {
+    const bool ok = factor_with_inertia_impl(S);
+    delta_w = S->o_d[5]; delta_c = S->o_d[6];
+    return ok;
+  }
+  DNLP_WFN DNLP_HD static bool factor_with_inertia_impl(WS* S) {
+    auto& delta_w = S->o_d[5];
+    auto& delta_c = S->o_d[6];
     const double dw_min = 1e-20, dw_0 = 1e-4, dw_max = S->opt.max_hessian_perturbation, dc_bar = 1e-8, kwp = 8.0, kwpb = 100.0, kwm = 1.0 / 3.0, kc = 0.25;
     delta_w = 0.0; delta_c = 0.0;
     const double dc_val = dc_bar * std::pow(S->mu, kc);
@@ -1302,7 +1351,13 @@ struct WaveIpm {
   // Ipm::kkt_residual: out = rhsv - K v, max |out|, max |v|.  The three products (sym(H) v, J^T v_y, J v_x) and the
   // combination are ONE pass: the owner of an output walks its segments of the three indices itself (the sums and their
   // order are those of the separate products); only the long outputs are formed beforehand by all lanes.
-  DNLP_WFN DNLP_HD static void kkt_residual(WS* S, const WD* v, double dw, const WD* rhsv, WD* out, double& en, double& sn) {
+  DNLP_HD static void kkt_residual(WS* S, const WD* v, double dw, const WD* rhsv, WD* out, double& en, double& sn) {
+    kkt_residual_impl(S, v, dw, rhsv, out);
+    en = S->o_d[1]; sn = S->o_d[2];
+  }
+  DNLP_WFN DNLP_HD static void kkt_residual_impl(WS* S, const WD* v, double dw, const WD* rhsv, WD* out) {
+    auto& en = S->o_d[1];
+    auto& sn = S->o_d[2];
     W_P0();
     const int N = S->N, m = S->m;
     const WCoo hs = S->hs, jc = S->jc, jr = S->jr;
@@ -1429,7 +1484,14 @@ struct WaveIpm {
   // (centering), each refined exactly as solve_refined refines it — the same iterates, the same stopping decisions — but
   // in joint solves and joint residual passes while both are still going.  0: both fine; 1 / 2: the first / second met a
   // non-finite residual (what makes solve_refined return false).  ratio / ratio2: their last_ratio_.
-  DNLP_WFN DNLP_HD static int solve_refined2(WS* S, double dw, WD* rhs2, WD* sol2, WD* res2, double& ratio_out, double& ratio2_out) {
+  DNLP_HD static int solve_refined2(WS* S, double dw, WD* rhs2, WD* sol2, WD* res2, double& ratio_out, double& ratio2_out) {
+    const int rc = solve_refined2_impl(S, dw, rhs2, sol2, res2);
+    ratio_out = S->o_d[3]; ratio2_out = S->o_d[4];
+    return rc;
+  }
+  DNLP_WFN DNLP_HD static int solve_refined2_impl(WS* S, double dw, WD* rhs2, WD* sol2, WD* res2) {
+    auto& ratio_out = S->o_d[3];
+    auto& ratio2_out = S->o_d[4];
     const int n = S->N + S->m;
     WD *rhs = S->rhs, *sol = S->sol, *res = S->res, *cor = S->cor;
     kkt_solve(S, rhs, sol, rhs2, sol2);
@@ -1815,8 +1877,18 @@ struct WaveIpm {
     P::sync();
   }
   // Ipm::second_order_correction (WB section 2.4)
-  DNLP_WFN DNLP_HD static bool second_order_correction(WS* S, double alpha, double dw, double theta_k, double phi_k, double gphid,
+  DNLP_HD static bool second_order_correction(WS* S, double alpha, double dw, double theta_k, double phi_k, double gphid,
                                               double& th_t, double& ph_t, double& f_t, bool& ftype) {
+    S->o_d[7] = th_t; S->o_d[8] = ph_t; S->o_d[9] = f_t; S->o_i[0] = ftype ? 1 : 0;
+    const bool ok = second_order_correction_impl(S, alpha, dw, theta_k, phi_k, gphid);
+    th_t = S->o_d[7]; ph_t = S->o_d[8]; f_t = S->o_d[9]; ftype = S->o_i[0] != 0;
+    return ok;
+  }
+  DNLP_WFN DNLP_HD static bool second_order_correction_impl(WS* S, double alpha, double dw, double theta_k, double phi_k, double gphid) {
+    auto& th_t = S->o_d[7];
+    auto& ph_t = S->o_d[8];
+    auto& f_t = S->o_d[9];
+    auto& ftype_i = S->o_i[0];
     const double k_soc = 0.99, g_th = 1e-5, g_ph = 1e-8, dlt = 1.0, s_th = 1.1, s_ph = 2.3, eta = 1e-8;
     const double macheps = 2.220446049250313e-16;
     auto le = [&](double a, double b, double base) { return a - b <= 10.0 * macheps * std::fabs(base); };
@@ -1841,7 +1913,7 @@ struct WaveIpm {
         const bool sw = gphid < 0.0 && alpha * std::pow(-gphid, s_ph) > dlt * std::pow(theta_k, s_th);
         bool ok = false;
         if (theta_k <= S->theta_min && sw) {
-          if (le(ph, phi_k + eta * alpha * gphid, phi_k)) { ok = true; ftype = true; }
+          if (le(ph, phi_k + eta * alpha * gphid, phi_k)) { ok = true; ftype_i = 1; }
         } else if (le(th, (1.0 - g_th) * theta_k, theta_k) || le(ph, phi_k - g_ph * theta_k, phi_k)) {
           ok = true;
         }
@@ -1989,10 +2061,9 @@ struct WaveIpm {
     W_P1(10);
     return (1.0 - adv) * (1.0 - adv) * nd2 / n_dual + (1.0 - apv) * (1.0 - apv) * np2 / n_pri + comp / static_cast<double>(nb);
   }
-  struct QfArgs { double avg, nd2, np2, n_dual, n_pri; i64 nb; };
   // golden section in log(sigma) + IPOPT's end-point check (the lambda `section` of Ipm::quality_function_mu)
-  DNLP_WFN DNLP_HD static double section(WS* S, const QfArgs& A, double slo, double sup, double& fsel, bool& endpoint) {
-    auto qf = [&](double sg) { return quality(S, sg, A.avg, A.nd2, A.np2, A.n_dual, A.n_pri, A.nb); };
+  DNLP_WFN DNLP_HD static double section(WS* S, double slo, double sup) {
+    auto qf = [&](double sg) { return quality(S, sg, S->qf_avg, S->qf_nd2, S->qf_np2, S->qf_n_dual, S->qf_n_pri, S->qf_nb); };
     const double gr = 0.5 * (3.0 - std::sqrt(5.0));
     double la = std::log(slo), lb = std::log(std::max(sup, slo * (1 + 1e-12)));
     double m1 = la + gr * (lb - la), m2 = lb - gr * (lb - la);
@@ -2002,11 +2073,13 @@ struct WaveIpm {
       else { lb = m2; m2 = m1; f2 = f1; m1 = la + gr * (lb - la); f1 = qf(std::exp(m1)); }
     }
     double sg = std::exp(f1 < f2 ? m1 : m2);
-    fsel = std::min(f1, f2);
+    double fsel = std::min(f1, f2);
     const double qlo = qf(slo), qup = qf(sup);
-    endpoint = false;
+    bool endpoint = false;
     if (qlo < fsel && qlo <= qup) { sg = slo; fsel = qlo; endpoint = true; }
     else if (qup < fsel) { sg = sup; fsel = qup; endpoint = true; }
+    S->qf_fsel = fsel;
+    S->qf_endpoint = endpoint ? 1 : 0;
     return sg;
   }
   // Ipm::quality_function_mu
@@ -2078,10 +2151,9 @@ struct WaveIpm {
     S->last_ratio = ratio_cen;
     if (ratio_aff > S->last_ratio) S->last_ratio = ratio_aff;
     const i64 n_ineq = m - S->n_eq;
-    QfArgs A;
-    A.avg = avg; A.nd2 = nd2; A.np2 = np2; A.nb = nb;
-    A.n_dual = static_cast<double>(N + n_ineq); A.n_pri = static_cast<double>(m > 0 ? m : 1);
-    auto qf = [&](double sg) { return quality(S, sg, A.avg, A.nd2, A.np2, A.n_dual, A.n_pri, A.nb); };
+    S->qf_avg = avg; S->qf_nd2 = nd2; S->qf_np2 = np2; S->qf_nb = nb;
+    S->qf_n_dual = static_cast<double>(N + n_ineq); S->qf_n_pri = static_cast<double>(m > 0 ? m : 1);
+    auto qf = [&](double sg) { return quality(S, sg, S->qf_avg, S->qf_nd2, S->qf_np2, S->qf_n_dual, S->qf_n_pri, S->qf_nb); };
     const double mu_max = S->opt.mu_max_fact * avg;
     const double s_lo = std::max(1e-6, mu_floor / avg), s_up = std::min(1e2, mu_max / avg);
     double sigma;
@@ -2091,10 +2163,9 @@ struct WaveIpm {
       const double q1 = qf(1.0), s1m = 1.0 - 1e-2, q1m = qf(std::max(s_lo, s1m));
       double lo, up;
       if (q1m > q1 && s_up > 1.0) { lo = 1.0; up = s_up; } else { lo = s_lo; up = std::min(std::max(s_lo, s1m), s_up); }
-      double fsel = 0.0;
-      bool endpoint = false;
-      sigma = section(S, A, lo, up, fsel, endpoint);
-      if (endpoint && up > lo * 10.0) {
+      sigma = section(S, lo, up);
+      double fsel = S->qf_fsel;
+      if (S->qf_endpoint != 0 && up > lo * 10.0) {
         const double grid[6] = {lo, 1e-4, 1e-2, 1e-1, 0.5, up};
         double gs[6], gq[6];
         int ng = 0;
@@ -2106,7 +2177,8 @@ struct WaveIpm {
         for (int k = 1; k < ng; ++k) if (gq[k] < gq[best]) best = k;
         if (gq[best] < fsel && best > 0 && best + 1 < ng) {
           const double f0 = fsel, s0 = sigma;
-          sigma = section(S, A, gs[best - 1], gs[best + 1], fsel, endpoint);
+          sigma = section(S, gs[best - 1], gs[best + 1]);
+          fsel = S->qf_fsel;
           if (!(fsel < f0)) sigma = s0;
         }
       }
