@@ -385,6 +385,7 @@ struct BatchRunner {
   const SparsePlanHost* host_plan = nullptr;      // (owned by the problem handle, as the tape is)
   std::vector<i32> wave_blk;                      // the template's plan block; empty: the template takes the generic kernel
   i32* d_wave_blk = nullptr;
+  int16_t* d_wave_blk16 = nullptr;                // the same block narrowed to 16 bits (forms with the state in LDS and the plan in global memory)
   bool wave_checked = false;
   bool wave_fits16 = false;                       // every table entry of the block fits 16 bits: it can be staged in LDS
   std::string wave_why;                           // why not, when not
@@ -403,6 +404,12 @@ struct BatchRunner {
         for (size_t k = sizeof(WaveHdr) / 4; k < wave_blk.size() && wave_fits16; ++k) wave_fits16 = wave_blk[k] >= -32768 && wave_blk[k] <= 32767;
         DNLP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_wave_blk), wave_blk.size() * sizeof(i32)));
         DNLP_HIP_CHECK(hipMemcpy(d_wave_blk, wave_blk.data(), wave_blk.size() * sizeof(i32), hipMemcpyHostToDevice));
+        if (wave_fits16) {
+          std::vector<int16_t> narrow16(wave_blk.size());
+          for (size_t k = 0; k < wave_blk.size(); ++k) narrow16[k] = static_cast<int16_t>(wave_blk[k]);
+          DNLP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_wave_blk16), narrow16.size() * sizeof(int16_t)));
+          DNLP_HIP_CHECK(hipMemcpy(d_wave_blk16, narrow16.data(), narrow16.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+        }
       }
     }
     return !wave_blk.empty();
@@ -494,6 +501,7 @@ struct BatchRunner {
     if (d_red) hipFree(d_red);
     if (d_sparse) hipFree(d_sparse);
     if (d_wave_blk) hipFree(d_wave_blk);
+    if (d_wave_blk16) hipFree(d_wave_blk16);
     if (d_rows) hipFree(d_rows);
     if (own_stream && stream) hipStreamDestroy(stream);
   }
@@ -1028,7 +1036,7 @@ struct BatchRunner {
     for (int k = 4; k >= 1 && wf_nw_glb == 0; --k) {
       const size_t st = k == 4 ? wave_static_lds<4, true, false>() : k == 3 ? wave_static_lds<3, true, false>() : k == 2 ? wave_static_lds<2, true, false>()
                                                                                                                   : wave_static_lds<1, true, false>();
-      if (static_cast<size_t>(k) * state_b + st <= cap) wf_nw_glb = k;
+      if (wave_fits16 && static_cast<size_t>(k) * state_b + st <= cap) wf_nw_glb = k;      // (state in LDS: the 16-bit copy of the plan)
     }
     if (nw > 0) {}
     else if (wf_nw_glb > 0) { nw = wf_nw_glb; sl = 1; pl = 0; }
@@ -1037,7 +1045,7 @@ struct BatchRunner {
       const int f = std::atoi(e);
       if (f > 0) {
         nw = f / 100; sl = (f / 10) % 10; pl = f % 10;
-        if (pl && !wave_fits16) throw std::runtime_error("wavefront solver: this plan does not fit 16-bit tables");
+        if ((pl || sl) && !wave_fits16) throw std::runtime_error("wavefront solver: this plan does not fit 16-bit tables");
       }
     } else { wf_nw = nw; wf_sl = sl; wf_pl = pl; }
   }
@@ -1076,7 +1084,7 @@ struct BatchRunner {
     const size_t plan_b = wave_fits16 ? ((static_cast<size_t>(h.total) * 2 + 15) & ~static_cast<size_t>(15)) : 0;
     const size_t state_b = static_cast<size_t>(h.state_doubles) * 8;
     WaveArgs w;
-    w.blk = d_wave_blk; w.blk_ints = h.total;
+    w.blk = d_wave_blk; w.blk16 = d_wave_blk16; w.blk_ints = h.total;
     w.rows = a.slabs; w.row_doubles = lay.total;
     w.batch = batch;
     w.state_doubles = h.state_doubles;

@@ -21,7 +21,9 @@ namespace dnlp {
 template <bool STATE_LDS, bool PLAN_LDS, bool TWO_PER_SIMD = false>
 struct WaveLanesT {
   typedef typename std::conditional<STATE_LDS, WLdsD, WGlbD>::type D;
-  typedef typename std::conditional<PLAN_LDS, WLdsI, WGlbI>::type I;
+  // (a plan left in global memory beside a state in LDS is read from its 16-bit copy: a state that fits LDS has no table
+  //  entry beyond 16 bits, and half the bytes is half the L1 / L2 traffic of the index loads)
+  typedef typename std::conditional<PLAN_LDS, WLdsI, typename std::conditional<STATE_LDS, WGlbI16, WGlbI>::type>::type I;
   static constexpr int lanes = 64;
   __device__ static int lane() { return static_cast<int>(threadIdx.x & 63u); }
   __device__ static void sync() { wave_sync(); }
@@ -39,6 +41,7 @@ struct WaveLanesT {
 
 struct WaveArgs {
   const i32* blk = nullptr;          // the plan block (device memory)
+  const int16_t* blk16 = nullptr;    // ... narrowed to 16 bits (null when an entry does not fit)
   int blk_ints = 0;
   const double* rows = nullptr;      // batch x row_doubles instance rows (batch.h slab layout)
   i64 row_doubles = 0;
@@ -78,6 +81,8 @@ __global__ void __launch_bounds__(64 * NW) wave_batch_kernel(WaveArgs a) {
     blk = (WI*)dst;
     pool += (static_cast<size_t>(a.blk_ints) * 2 + 15) & ~static_cast<size_t>(15);
     __syncthreads();                   // the only workgroup barrier of the kernel
+  } else if constexpr (STATE_LDS) {
+    blk = (WI*)a.blk16;
   } else {
     blk = (WI*)a.blk;
   }

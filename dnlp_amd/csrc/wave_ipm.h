@@ -57,6 +57,7 @@ typedef DNLP_WLDS double WLdsD;
 typedef DNLP_WLDS const int16_t WLdsI;       // (a plan staged in LDS is narrowed to 16 bits: wave_batch.h)
 typedef DNLP_WGLB double WGlbD;
 typedef DNLP_WGLB const i32 WGlbI;
+typedef DNLP_WGLB const int16_t WGlbI16;
 typedef DNLP_WGLB const double WG;    // a double of the instance's data row (global memory)
 
 constexpr int kWaveNeedsGeneric = -197;
