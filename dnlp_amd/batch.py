@@ -311,9 +311,12 @@ class ParametricBatch:
         local_dev = None
         if hi > lo:
             res = self.solve(thetas[lo:hi], device=device, **opts)
-            local = np.concatenate([np.arange(lo, hi, dtype=float)[:, None], res.obj_val[:, None],
-                                    res.status[:, None].astype(float), res.iterations[:, None].astype(float), res.x],
-                                   axis=1)
+            local = np.empty((hi - lo, 4 + res.x.shape[1]))           # (filled in place: no temporaries of the 65 536 x 56 rows)
+            local[:, 0] = np.arange(lo, hi)
+            local[:, 1] = res.obj_val
+            local[:, 2] = res.status
+            local[:, 3] = res.iterations
+            local[:, 4:] = res.x
             ksec = res.kernel_seconds
             if from_device:
                 local_dev = _device_rows(self._handle, lo, -1.0 if self.flip else 1.0)
