@@ -620,8 +620,12 @@ def main():
             if int(pj["n"]) == n:
                 traffic = pj["avg_traffic_bytes_per_launch"]
                 traffic_src = "profiles/" + TRAFFIC_PROFILE + " (" + pj["command"] + ")"
-        except (OSError, KeyError, ValueError):
+        except OSError:
             pass
+        except (KeyError, ValueError) as e:
+            # (round 5 shipped a file in another schema and the line silently lost its traffic figure)
+            sys.stderr.write("bench: profiles/%s exists but cannot be read as a traffic profile (%r): roofline.traffic is null\n"
+                             % (TRAFFIC_PROFILE, e))
         upd_s, upd_f, upd_l = st1[13] - st0[13], st1[14] - st0[14], st1[15] - st0[15]
         achieved = upd_f / upd_s / 1e12 if upd_s > 0 else None
         # counters that survive restarts (stats[16..19]); every one is a delta over the timed region

@@ -253,6 +253,17 @@ class ParametricBatch:
             print("[batch.py] data %.4f handle %.4f solve_batch %.4f" % (t1 - t0, t2 - t1, t3 - t2), flush=True)
         return BatchResult(raw, self.inv, self.flip)
 
+    @staticmethod
+    def _solver_options(opts):
+        """Solver options of a call, as `solve` sees them: its own named arguments (want_duals, warm_from) taken out, the
+        warm-start default applied — the key a handle is cached under must not depend on which entry point was used."""
+        o = dict(opts)
+        want_duals = bool(o.pop("want_duals", False))
+        warm_from = o.pop("warm_from", None)
+        if warm_from is not None:
+            o.setdefault("warm_start_init_point", "yes")
+        return o, want_duals, warm_from
+
     def _ensure_handle(self, device, opts):
         """(Re)create this object's device handle for (device, options)."""
         key = (device, tuple(sorted((k, str(v)) for k, v in opts.items())))
@@ -271,8 +282,9 @@ class ParametricBatch:
         ones `solve` returns, batch by batch, in order, bit for bit."""
         batches = [np.atleast_2d(np.asarray(t, dtype=float)) for t in batches]
         slots = max(1, min(int(in_flight), len(batches)))
-        if not self.affine or slots == 1:
+        if not self.affine or slots == 1 or opts.get("warm_from") is not None:
             return [self.solve(t, device=device, want_duals=want_duals, **opts) for t in batches]
+        opts, _, _ = self._solver_options(opts)
         self._ensure_handle(device, opts)
         if not hasattr(self._handle, "solve_batch_stream") or not hasattr(self._handle.api, "batch_stream_create"):
             return [self.solve(t, device=device, want_duals=want_duals, **opts) for t in batches]
@@ -306,21 +318,26 @@ class ParametricBatch:
         # (dnlp_batch_result_rows); the flip of a maximisation's objective is applied on the device tensor
         from_device = exchanging and backend == "nccl" and hi > lo
         if from_device:
-            self._ensure_handle(device, opts)
+            # (the handle key is computed from the solver options alone, as solve() computes it: want_duals / warm_from in
+            #  `opts` must not make this a different handle from the one the launch below uses)
+            self._ensure_handle(device, self._solver_options(opts)[0])
             from_device = self._handle.keep_batch_result_rows(True)
         local_dev = None
         if hi > lo:
-            res = self.solve(thetas[lo:hi], device=device, **opts)
-            local = np.empty((hi - lo, 4 + res.x.shape[1]))           # (filled in place: no temporaries of the 65 536 x 56 rows)
-            local[:, 0] = np.arange(lo, hi)
-            local[:, 1] = res.obj_val
-            local[:, 2] = res.status
-            local[:, 3] = res.iterations
-            local[:, 4:] = res.x
-            ksec = res.kernel_seconds
-            if from_device:
-                local_dev = _device_rows(self._handle, lo, -1.0 if self.flip else 1.0)
-                self._handle.keep_batch_result_rows(False)
+            try:
+                res = self.solve(thetas[lo:hi], device=device, **opts)
+                local = np.empty((hi - lo, 4 + res.x.shape[1]))           # (filled in place: no temporaries of the 65 536 x 56 rows)
+                local[:, 0] = np.arange(lo, hi)
+                local[:, 1] = res.obj_val
+                local[:, 2] = res.status
+                local[:, 3] = res.iterations
+                local[:, 4:] = res.x
+                ksec = res.kernel_seconds
+                if from_device:
+                    local_dev = _device_rows(self._handle, lo, -1.0 if self.flip else 1.0)
+            finally:
+                if from_device:
+                    self._handle.keep_batch_result_rows(False)
         else:
             local, ksec = np.zeros((0, 4 + int(self.arrays0["dims"][0]))), 0.0
         rows = gather_rows(local, B, force=force_collective, local_dev=local_dev)

@@ -990,7 +990,7 @@ struct BatchRunner {
         packed_disabled = true;
         if (a.ws_g) ws_batch = batch;      // (a warm-started batch stays warm in the retry: h_ws_* still hold its multipliers)
         release();
-        solve_impl(batch, data, theta, opt, x_out, obj_out, multg_out, zl_out, zu_out, status_out, iters_out, nfact_out, seconds, times_out);
+        solve_impl(batch, data, theta, opt, x_out, obj_out, multg_out, zl_out, zu_out, status_out, iters_out, nfact_out, seconds, times_out, allow_wave);
         return;
       }
     }

@@ -502,7 +502,10 @@ __device__ inline bool panel_wait(unsigned* flag, unsigned epoch, PanelCtl* ctl,
   }
   __syncthreads();
   __threadfence();          // (acquire side: what the publisher wrote before its flag)
-  return *s_ok != 0;
+  const bool ok = *s_ok != 0;
+  __syncthreads();          // (every thread has read s_ok before thread 0 of the NEXT wait may write it: a slow wavefront must
+                            //  not see a later give-up as the answer of this wait and leave the workgroup's barriers uneven)
+  return ok;
 }
 __device__ inline void panel_publish(unsigned* flag, unsigned epoch) {
   __threadfence();          // every storing thread: its stores are out of this XCD's caches before the flag

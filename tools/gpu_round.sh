@@ -17,7 +17,8 @@
 #   ab_c2_barrier, ab_c4_sweep   the two A/B measurements of round 4 (C2 grid barrier three ways; C4 sweeps vs step kernels)
 #   ab_ldlt_fused                the round-5 A/B of the 512-column panel forms of the blocked LDL^T (tools/ldlt_fused_ab.sh)
 #   pmc_icache, launch_breakdown instruction-fetch / LDS-wait counters of the wavefront kernel; where a batch launch's wall time goes
-cd "${GRAFT_REPO_ROOT:-$(git rev-parse --show-toplevel)}"
+ROOT=${GRAFT_REPO_ROOT:-$(git rev-parse --show-toplevel)}
+cd "$ROOT"
 export TMPDIR=/tmp
 TAG=${1:?tag}; shift
 O=gpurun_out/$TAG
@@ -35,7 +36,8 @@ pmc_c4)
     t=$(echo $C | cut -d' ' -f1)
     timeout 500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/bench_$t -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-full-solve > $O/bench_$t.log 2>&1 < /dev/null
   done
-  python3 tools/pmc_summary.py $O/pmc_bench_traffic.json $O/bench_FETCH_SIZE $O/bench_WRITE_SIZE $O/bench_SQ_VALU_MFMA_BUSY_CYCLES --kernel gemm_nt_update_fast --update-queue > /dev/null
+  python3 tools/pmc_summary.py $O/pmc_bench_traffic_raw.json $O/bench_FETCH_SIZE $O/bench_WRITE_SIZE $O/bench_SQ_VALU_MFMA_BUSY_CYCLES --kernel gemm_nt_update_fast --update-queue > /dev/null
+  python3 tools/pmc_c4_post.py $O/pmc_bench_traffic_raw.json $O/pmc_bench_traffic.json 100000 > /dev/null      # (the schema bench.py reads)
   rm -rf $O/bench_FETCH_SIZE $O/bench_WRITE_SIZE $O/bench_SQ_VALU_MFMA_BUSY_CYCLES; head -c 1500 $O/pmc_bench_traffic.json ;;
 c5)
   timeout 600 python3 bench.py --workload c5 --batch 8192 --steps 5 --warmup 2 2>/dev/null | tail -1 > $O/c5_bench_8192.json; tail -c 2500 $O/c5_bench_8192.json
@@ -45,7 +47,7 @@ c5)
 members)
   : > $O/c5_members.jsonl
   for W in circle_packing circle_packing10 path_planning power_flow; do
-    timeout 400 python3 bench.py --workload c5 --which $W --batch 1024 --steps 4 --warmup 1 --no-cpu 2>/dev/null | grep "^{" | tail -1 >> $O/c5_members.jsonl
+    timeout 600 python3 bench.py --workload c5 --which $W --batch 1024 --steps 4 --warmup 1 2>/dev/null | grep "^{" | tail -1 >> $O/c5_members.jsonl
   done
   python3 -c "
 import json
@@ -64,7 +66,7 @@ stream)
   timeout 600 python tools/c5_in_flight.py 2048 2>/dev/null | tail -1 >> $O/c5_in_flight.json; cat $O/c5_in_flight.json ;;
 c3)
   timeout 200 python3 tools/c3_repeat.py > $O/c3_repeat.log 2>&1; tail -c 900 $O/c3_repeat.log; cp gpurun_out/c3_repeat.json $O/c3_repeat.json
-  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_c3 -- python3 $GRAFT_REPO_ROOT/tools/c3_repeat.py > $GRAFT_REPO_ROOT/$O/prof_c3.log 2>&1 )
+  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/prof_c3 -- python3 $ROOT/tools/c3_repeat.py > $ROOT/$O/prof_c3.log 2>&1 )
   python3 tools/kstats.py $O/prof_c3 30 > $O/c3_kernel_stats.txt; head -12 $O/c3_kernel_stats.txt
   T=$(ls $O/prof_c3/*/*_kernel_trace.csv | tail -1)
   python3 tools/kernel_order.py $T 19 > $O/c3_kernel_order.txt 2>/dev/null; python3 tools/ldlt_timeline.py $T 400 > $O/c3_timeline.txt 2>/dev/null; rm -rf $O/prof_c3

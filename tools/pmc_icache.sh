@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "${GRAFT_REPO_ROOT}"
+cd "${GRAFT_REPO_ROOT:-$(git rev-parse --show-toplevel)}"
 export TMPDIR=/tmp
 O=gpurun_out/pmc_icache; mkdir -p $O
 i=0
