@@ -605,9 +605,11 @@ class ProblemHandle:
         if hasattr(self.api, "batch_launch_info"):
             info = np.zeros(8, dtype=np.int32)
             if self.api.batch_launch_info(self.ptr, info.ctypes.data_as(_i32_p)) == 0:
-                out["launch"] = {"grid": int(info[0]), "lanes": int(info[1]), "lds_mode": int(info[2]), "per_cu": int(info[3]),
+                # (lds_mode of a wavefront-solver launch: 2 x state in LDS + plan in LDS, + 4 when the kernel was the one
+                #  compiled for this template at run time — csrc/wave_codegen.h)
+                out["launch"] = {"grid": int(info[0]), "lanes": int(info[1]), "lds_mode": int(info[2]) & 3, "per_cu": int(info[3]),
                                  "packed": bool(info[4]), "longest_first": bool(info[5]), "wave_form": int(info[6]),
-                                 "wave_refused": int(info[7])}
+                                 "wave_refused": int(info[7]), "wave_spec": bool(int(info[6]) and (int(info[2]) & 4))}
         if want_duals:
             out.update({"mult_g": mg[:, :self.m], "mult_x_L": zl, "mult_x_U": zu})
         return out

@@ -20,6 +20,7 @@
 #include "ipm_core.h"
 #include "kkt_dense.h"
 #include "wave_batch.h"
+#include "wave_codegen.h"
 
 namespace dnlp {
 
@@ -391,6 +392,34 @@ struct BatchRunner {
   std::string wave_why;                           // why not, when not
   int last_wave = 0;                              // the last solve: 0 generic kernel, else 100 * wavefronts per workgroup + 10 * state in LDS + plan in LDS
   int last_wave_refused = 0;                      // instances of the last solve that the wavefront solver handed to the generic kernel
+  // the per-template kernel (wave_codegen.h): compiled by hiprtc at the template's first large launch, cached on disk
+  RtcKernel wave_spec;
+  int wave_spec_nw = 0;                           // wavefronts per workgroup it was compiled for (its static LDS holds that many shares)
+  bool last_wave_spec = false;                    // the last solve ran it
+  double wave_spec_compile_seconds = 0.0;
+  // DNLP_WAVE_SPEC: 0 never, 1 for every launch of a template whose state and plan fit LDS, unset: launches of at least
+  // kWaveSpecMinBatch instances (a compilation costs seconds once per template and machine; a 1024-instance launch 10 ms)
+  static constexpr int kWaveSpecMinBatch = 1024;
+  bool wave_spec_prepare(int batch) {
+    const char* e = std::getenv("DNLP_WAVE_SPEC");
+    const int mode = e ? std::atoi(e) : -1;
+    if (mode == 0) return false;
+    if (mode < 0 && batch < kWaveSpecMinBatch && !wave_spec.ok) return false;
+    if (wave_spec.tried) return wave_spec.ok;
+    const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(wave_blk.data());
+    const int fit = wave_fits16 ? wave_spec_max_waves(h) : 0;
+    if (fit < 1) { wave_spec.tried = true; return false; }
+    const double t0 = now_sec();
+    const std::string src = wave_spec_source(wave_blk, fit);
+    if (!wave_spec.load(src, "dnlp_wave_spec_kernel")) {
+      std::fprintf(stderr, "[dnlp] per-template batch kernel not available (the library's own kernel is used): %s\n", wave_spec.log.substr(0, 2000).c_str());
+      return false;
+    }
+    wave_spec_nw = fit;
+    wave_spec_compile_seconds = now_sec() - t0;
+    if (std::getenv("DNLP_BATCH_DEBUG")) std::fprintf(stderr, "[batch] per-template kernel: %d wavefronts per workgroup, %.2f s to compile / load\n", fit, wave_spec_compile_seconds);
+    return true;
+  }
   bool wave_prepare() {
     if (!wave_checked) {
       wave_checked = true;
@@ -1098,12 +1127,17 @@ struct BatchRunner {
       if (pl && want > nw && wf_nw_glb > nw) { nw = std::min(want, wf_nw_glb); pl = 0; }      // more instances than fit beside the plan
       else nw = std::min(nw, want);
     }
+    // the per-template kernel when the template has one: its static LDS (plan + wave_spec_nw shares) fills the compute
+    // unit, a launch puts as many wavefronts into a workgroup as it has instances per compute unit
+    const bool spec = sl && pl && !std::getenv("DNLP_WAVE_FORM") && wave_spec_prepare(batch);
+    if (spec) nw = std::min(wave_spec_nw, std::max(1, (batch + this->ncu - 1) / this->ncu));
     int per_cu = 1;
     const unsigned lds = static_cast<unsigned>((pl ? plan_b : 0) + (sl ? static_cast<size_t>(nw) * state_b : 0));
     const int form = 100 * nw + 10 * sl + pl;
     int cached_none = 0;
     int& cached = (sl && pl) ? wf_per_cu[nw] : cached_none;
-    if (cached > 0 && !std::getenv("DNLP_WAVE_FORM")) per_cu = cached;
+    if (spec) per_cu = 1;
+    else if (cached > 0 && !std::getenv("DNLP_WAVE_FORM")) per_cu = cached;
     else switch (form) {
       case 811: per_cu = wave_occupancy<8, true, true>(lds); break;
       case 711: per_cu = wave_occupancy<7, true, true>(lds); break;
@@ -1120,13 +1154,13 @@ struct BatchRunner {
       case 400: per_cu = wave_occupancy<4, false, false>(lds); break;
       default: throw std::runtime_error("wavefront solver: no such launch form");
     }
-    if (!std::getenv("DNLP_WAVE_FORM")) cached = per_cu;
+    if (!std::getenv("DNLP_WAVE_FORM") && !spec) cached = per_cu;
     if (const char* e = std::getenv("DNLP_WAVE_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 16) per_cu = v; }
     int grid = std::min((batch + nw - 1) / nw, ncu * per_cu);
     if (grid < 1) grid = 1;
     if (!sl) w.state = dalloc<double>(static_cast<size_t>(grid) * static_cast<size_t>(nw) * static_cast<size_t>(h.state_doubles));
     w.park_doubles = wave_park_doubles(t.N, t.m);
-    w.park = dalloc<double>(static_cast<size_t>(grid) * static_cast<size_t>(nw) * static_cast<size_t>(w.park_doubles));
+    w.park = dalloc<double>(static_cast<size_t>(grid) * static_cast<size_t>(spec ? wave_spec_nw : nw) * static_cast<size_t>(w.park_doubles));
     w.x_out = dalloc<double>(static_cast<size_t>(batch) * t.N);
     w.obj_out = dalloc<double>(static_cast<size_t>(batch));
     w.multg_out = multg_out ? dalloc<double>(static_cast<size_t>(batch) * t.m) : nullptr;
@@ -1168,8 +1202,9 @@ struct BatchRunner {
       DNLP_HIP_CHECK(hipStreamSynchronize(stream));
       w.order = d_ord;
     }
-    last_grid = grid; last_threads = 64 * nw; last_lds_mode = 2 * sl + pl; last_per_cu = nw * per_cu; last_packed = false;
+    last_grid = grid; last_threads = 64 * nw; last_lds_mode = 2 * sl + pl + (spec ? 4 : 0); last_per_cu = nw * per_cu; last_packed = false;
     last_wave = 100 * nw + 10 * sl + pl;
+    last_wave_spec = spec;
     if (std::getenv("DNLP_BATCH_DEBUG"))
       std::fprintf(stderr, "[batch] wavefront solver: %d wavefronts per workgroup, state %s (%zu B per instance), plan %s (%zu B), dynamic LDS %u B, grid %d\n",
                    nw, sl ? "in LDS" : "in global memory", state_b, pl ? "in LDS" : "in global memory", plan_b, lds, grid);
@@ -1180,7 +1215,10 @@ struct BatchRunner {
     DNLP_HIP_CHECK(hipEventCreate(&e0));
     DNLP_HIP_CHECK(hipEventCreate(&e1));
     DNLP_HIP_CHECK(hipEventRecord(e0, stream));
-    switch (form) {
+    if (spec) {
+      void* kargs[] = {&w};
+      DNLP_HIP_CHECK(hipModuleLaunchKernel(wave_spec.fn, static_cast<unsigned>(grid), 1, 1, static_cast<unsigned>(64 * nw), 1, 1, 0, stream, kargs, nullptr));
+    } else switch (form) {
       case 811: launch_wave<8, true, true>(w, grid, lds, stream); break;
       case 711: launch_wave<7, true, true>(w, grid, lds, stream); break;
       case 611: launch_wave<6, true, true>(w, grid, lds, stream); break;

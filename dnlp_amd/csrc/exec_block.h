@@ -33,10 +33,6 @@ namespace dnlp {
 // the instance sits in LDS
 typedef __attribute__((address_space(3))) double lds_double;
 
-__device__ inline void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 
 // Bunch-Kaufman LDL^T (DSYTF2 semantics, lower) by ONE wavefront, no workgroup barrier: the
 // pivot column is cached in registers (R rows per lane, n <= 64 R), the trailing update walks
@@ -225,12 +221,6 @@ __device__ bool bk_factor_wave(AP A, int n, int ld, int* piv, int* nneg_out, int
 }
 
 // ---- solves with a standard-form factor (bk_factor_wave), right-hand side in registers -------
-__device__ inline double readlane_d(double v, int l) {
-  l = __builtin_amdgcn_readfirstlane(l);
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-  return __hiloint2double(hi, lo);
-}
 template <int R> __device__ inline double lane_get(const double (&x)[R], int idx) {
   double o = 0.0;
 #pragma unroll

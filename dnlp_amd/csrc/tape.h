@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "exec.h"
+#include "wave_hdr.h"      // (kCooHeavy)
 
 namespace dnlp {
 
@@ -145,7 +146,7 @@ struct CooIdx {
   i32* src = nullptr;
   // outputs with more than kHeavy entries (a dense column under many rows): the in-kernel solver sums those with all
   // its lanes and a fixed reduction tree instead of one lane walking the whole segment
-  static constexpr i64 kHeavy = 12;
+  static constexpr i64 kHeavy = kCooHeavy;
   i64 nheavy = 0;
   i32* heavy = nullptr;
 };

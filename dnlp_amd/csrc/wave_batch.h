@@ -9,6 +9,7 @@
 #include <type_traits>
 
 #include "exec_block.h"
+#include "wave_args.h"
 #include "wave_ipm.h"
 #include "wave_ops.h"
 
@@ -37,28 +38,6 @@ struct WaveLanesT {
   __device__ static int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
   // the dense tail keeps one row per lane (wave_ipm.h kTailSlots = 1): the entry of row `row` comes through v_readlane
   template <int SL> __device__ static double row_get(const double (&a)[SL], int row) { return readlane_d(a[0], row); }
-};
-
-struct WaveArgs {
-  const i32* blk = nullptr;          // the plan block (device memory)
-  const int16_t* blk16 = nullptr;    // ... narrowed to 16 bits (null when an entry does not fit)
-  int blk_ints = 0;
-  const double* rows = nullptr;      // batch x row_doubles instance rows (batch.h slab layout)
-  i64 row_doubles = 0;
-  int batch = 0;
-  double* state = nullptr;           // state in global memory: (grid x NW) x state_doubles
-  double* park = nullptr;            // (grid x NW) x park_doubles: polish()'s parking place (wave_plan.h wave_park_doubles)
-  i64 park_doubles = 0;
-  i64 state_doubles = 0;
-  IpmOptions opt;
-  i64 fallback_max_n = 0;
-  double *x_out = nullptr, *obj_out = nullptr, *multg_out = nullptr, *zl_out = nullptr, *zu_out = nullptr;
-  int *status_out = nullptr, *iters_out = nullptr, *nfact_out = nullptr;
-  double* times_out = nullptr;
-  const double *ws_g = nullptr, *ws_l = nullptr, *ws_u = nullptr;
-  int* next = nullptr;
-  const int* order = nullptr;
-  unsigned long long* prof = nullptr;   // kWaveProfSlots + 1 counters of a -DDNLP_WAVE_PROF build (last: iterations)
 };
 
 template <int NW, bool STATE_LDS, bool PLAN_LDS>

@@ -1,0 +1,168 @@
+// Template-specialised batch solver, part 5: the per-template kernel as TEXT.
+//
+// wave_batch.h's kernels serve every template: what a template fixes — sizes, where each table of the plan block and each
+// vector of an instance lies — they read from the wavefront's state record in LDS, a pointer load and an address
+// computation in front of every loop, loop bounds in registers.  For the templates a rank solves by the thousand (the C5
+// members of BASELINE.json; reference role: the serial loop cvxpy/problems/problem.py:1256-1269 into IPOPT,
+// ipopt_nlpif.py:140-170) the library compiles ONE kernel per template at run time (hiprtc, cached on disk by source
+// hash: fused_rtc.h) from
+//     a prelude                 what the embedded headers expect from exec.h / <cmath> / <algorithm>, hiprtc-clean
+//     atom_math.h               the unary atom rules            }
+//     ipm_options.h             options, status codes           }  the very text the library's own kernels and the
+//     wave_hdr.h, wave_args.h   plan header, launch arguments   }  host lane of the test oracle are compiled from
+//     namespace wspec           THE TEMPLATE: every size, table offset and vector place as a literal (this file)
+//     wave_ops.h, wave_ipm.h    reductions, the interior-point loop (its WK / WT / WV accessors resolve to wspec::)
+//     wave_spec_kernel.h        static LDS for plan + shares, the lane policy, the kernel
+// The algorithm text is not forked: the same wave_ipm.h is pinned bit for bit on the CPU (tests/test_wave_ipm_cpu.py) and
+// the per-template kernel is compared with the library's own on the device (tests/test_wave_spec.py).
+//
+// This header is plain host C++ (no HIP): the test oracle prints the same text (oracle_lib.cpp orc_wave_spec_source) so
+// that a CPU test can hand it to hiprtc without a GPU.
+#pragma once
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "wave_ipm.h"
+
+namespace dnlp {
+
+// host stand-in for a lane policy: only its types matter (WaveIpm<P>::layout is run once on the host to learn the offsets)
+struct WaveProbeLanes {
+  typedef double D;
+  typedef const i32 I;
+  static constexpr int lanes = 1;
+  static int lane() { return 0; }
+  static void sync() {}
+  static double sum(double v) { return v; }
+  static double vmax(double v) { return v; }
+  static int tab_load(const i32*, int) { return 0; }
+  static int tab_at(const i32* tab, int, int idx, int) { return tab[idx]; }
+  static int uni(int v) { return v; }
+  template <int SL> static double row_get(const double (&a)[SL], int row) { return a[row]; }
+};
+
+constexpr int kWaveSpecRecBytesMax = 2048;      // (what the host sizes a launch with; the kernel asserts its record fits)
+
+// the largest number of wavefronts per workgroup whose shares fit a compute unit's LDS beside the 16-bit plan (0: none)
+inline int wave_spec_max_waves(const WaveHdr& h) {
+  const size_t cap = 160 * 1024 - 512;
+  const size_t plan_b = ((static_cast<size_t>(h.total) + 7) & ~static_cast<size_t>(7)) * 2;
+  const size_t share_b = kWaveSpecRecBytesMax + static_cast<size_t>(h.state_doubles) * 8 + 16;
+  if (plan_b + share_b > cap) return 0;
+  const size_t k = (cap - plan_b) / share_b;
+  return static_cast<int>(k > 8 ? 8 : k);
+}
+
+// namespace wspec of a template: the literals behind WK / WT / WV / WDIR / WCSR / WCOO (wave_ipm.h)
+inline std::string wave_spec_constants(const std::vector<i32>& blk, int nw) {
+  const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(blk.data());
+  typedef WaveIpm<WaveProbeLanes> W;
+  W::WState S;
+  std::vector<double> vecs(static_cast<size_t>(h.state_doubles) + 8, 0.0);
+  const i32 laid = W::layout((W::WS*)&S, &h, blk.data(), vecs.data());      // (the cast matters only to the device pass, where WS is LDS-qualified)
+  if (laid != h.state_doubles) throw std::runtime_error("wave codegen: layout and wave_state_doubles disagree");
+  std::string s = "namespace wspec {\n";
+  char b[256];
+  auto put = [&](const char* pre, const char* name, long long v) { std::snprintf(b, sizeof b, "constexpr int %s%s = %lld;\n", pre, name, v); s += b; };
+#define W_PUT_K(f) put("k_", #f, static_cast<long long>(S.f));
+#define W_PUT_T(f) put("t_", #f, static_cast<long long>(S.f - blk.data()));
+#define W_PUT_V(f) put("v_", #f, static_cast<long long>(S.f - vecs.data()));
+  WAVE_SIZE_FIELDS(W_PUT_K)
+  WAVE_TAB_FIELDS(W_PUT_T)
+  WAVE_VEC_FIELDS(W_PUT_V)
+#undef W_PUT_K
+#undef W_PUT_T
+#undef W_PUT_V
+  s += "constexpr int v_dir[3][7] = {";
+  for (int a = 0; a < 3; ++a) {
+    s += a ? ", {" : "{";
+    for (int k = 0; k < 7; ++k) { std::snprintf(b, sizeof b, "%s%lld", k ? ", " : "", static_cast<long long>(S.dir[a][k] - vecs.data())); s += b; }
+    s += "}";
+  }
+  s += "};\n";
+  auto csr = [&](const char* name, const W::WCsr& M) {
+    std::snprintf(b, sizeof b, "constexpr int t_%s_ptr = %lld, t_%s_idx = %lld, k_%s_rows = %d, k_%s_val = %d;\n", name,
+                  static_cast<long long>(M.ptr - blk.data()), name, static_cast<long long>(M.idx - blk.data()), name, M.rows, name, M.val);
+    s += b;
+  };
+  csr("G", S.G); csr("Mg", S.Mg); csr("MJ", S.MJ); csr("Mw", S.Mw); csr("MH", S.MH);
+  auto coo = [&](const char* name, const W::WCoo& M) {
+    std::snprintf(b, sizeof b, "constexpr int t_%s_ptr = %lld, t_%s_ent = %lld, t_%s_src = %lld, t_%s_heavy = %lld, k_%s_nout = %d, k_%s_nheavy = %d;\n", name,
+                  static_cast<long long>(M.ptr - blk.data()), name, static_cast<long long>(M.ent - blk.data()), name, static_cast<long long>(M.src - blk.data()),
+                  name, static_cast<long long>(M.heavy - blk.data()), name, M.nout, name, M.nheavy);
+    s += b;
+  };
+  coo("jr", S.jr); coo("jc", S.jc); coo("hs", S.hs);
+  put("", "kStateDoubles", h.state_doubles);
+  put("", "kPlanInts", h.total);
+  put("", "kNW", nw);
+  put("", "kRecBytesMax", kWaveSpecRecBytesMax);
+  s += "}  // namespace wspec\n";
+  return s;
+}
+
+// what the embedded headers expect around them, without a standard library (hiprtc)
+inline const char* wave_spec_prelude() {
+  return
+      "#define DNLP_RTC 1\n"
+      "#define DNLP_WAVE_SPEC 1\n"
+      "#define DNLP_HD __device__\n"
+      "#define DNLP_DEVICE_PASS 1\n"
+      "typedef __INT16_TYPE__ int16_t;\ntypedef __INT32_TYPE__ int32_t;\ntypedef __INT64_TYPE__ int64_t;\ntypedef __UINT64_TYPE__ uint64_t;\n"
+      "namespace dnlp {\n"
+      "using i64 = int64_t;\nusing i32 = int32_t;\n"
+      "constexpr double kInf = __builtin_inf();\n"
+      "struct D2 { double first, second; };\n"
+      "}  // namespace dnlp\n"
+      // <algorithm> / <cmath> as far as wave_ipm.h uses them (std::max / std::min: libstdc++'s definitions — the second
+      // argument wins only when it compares greater / less, NaN conventions included)
+      "namespace dnlp_std {\n"
+      "template <class T> __device__ constexpr const T& max(const T& a, const T& b) { return (a < b) ? b : a; }\n"
+      "template <class T> __device__ constexpr const T& min(const T& a, const T& b) { return (b < a) ? b : a; }\n"
+      "__device__ inline bool isfinite(double v) { return __builtin_isfinite(v); }\n"
+      "__device__ inline double pow(double a, double b) { return ::pow(a, b); }\n"
+      "__device__ inline double sqrt(double a) { return ::sqrt(a); }\n"
+      "__device__ inline double log(double a) { return ::log(a); }\n"
+      "__device__ inline double exp(double a) { return ::exp(a); }\n"
+      "__device__ inline double fabs(double a) { return ::fabs(a); }\n"
+      "}  // namespace dnlp_std\n"
+      "#define std dnlp_std\n";
+}
+
+// the translation unit of a template's kernel (entry point: dnlp_wave_spec_kernel)
+inline std::string wave_spec_source(const std::vector<i32>& blk, int nw) {
+  static const char* atom_math_text =
+#include "atom_math_src.inc"
+      ;
+  static const char* ipm_options_text =
+#include "ipm_options_src.inc"
+      ;
+  static const char* wave_hdr_text =
+#include "wave_hdr_src.inc"
+      ;
+  static const char* wave_args_text =
+#include "wave_args_src.inc"
+      ;
+  static const char* wave_ops_text =
+#include "wave_ops_src.inc"
+      ;
+  static const char* wave_ipm_text =
+#include "wave_ipm_src.inc"
+      ;
+  static const char* wave_spec_kernel_text =
+#include "wave_spec_kernel_src.inc"
+      ;
+  std::string s = wave_spec_prelude();
+  s += atom_math_text;
+  s += ipm_options_text;
+  s += wave_hdr_text;
+  s += wave_args_text;
+  s += wave_spec_constants(blk, nw);
+  s += wave_ops_text;
+  s += wave_ipm_text;
+  s += wave_spec_kernel_text;
+  return s;
+}
+
+}  // namespace dnlp

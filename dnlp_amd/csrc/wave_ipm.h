@@ -17,8 +17,10 @@
 // What it does not have: the dense Bunch-Kaufman fallback of a structurally singular static pivot sequence — such an
 // instance ends with status kWaveNeedsGeneric and the host hands it to the generic kernel (batch.h).
 #pragma once
+#ifndef DNLP_RTC
 #include "ipm_core.h"
 #include "wave_plan.h"
+#endif
 
 #if DNLP_DEVICE_PASS
 #define DNLP_WLDS __attribute__((address_space(3)))
@@ -36,6 +38,28 @@
 #else
 #define W_P0() do { } while (0)
 #define W_P1(k) do { } while (0)
+#endif
+
+// How the algorithm text reaches what never changes between the instances of a template — sizes, tables of the plan
+// block, the places of an instance's vectors.  The library's own kernels and the host lane read them from the state
+// record (set once per kernel by layout()).  A kernel compiled PER TEMPLATE at run time (wave_codegen.h, -DDNLP_WAVE_SPEC)
+// knows them as constants: a size is a literal (a lane-strided loop over N <= 64 entries is one predicated trip), a vector
+// is the wavefront's LDS share plus an immediate offset (no pointer load from the state record in front of every loop),
+// a table is a fixed LDS address.
+#ifdef DNLP_WAVE_SPEC
+#define WK(f) (wspec::k_##f)
+#define WV(f) (P::vec(S, wspec::v_##f))
+#define WT(f) (P::tab(wspec::t_##f))
+#define WDIR(set, k) (P::vec(S, wspec::v_dir[set][k]))
+#define WCSR(f) (WCsr{P::tab(wspec::t_##f##_ptr), P::tab(wspec::t_##f##_idx), wspec::k_##f##_rows, wspec::k_##f##_val})
+#define WCOO(f) (WCoo{P::tab(wspec::t_##f##_ptr), P::tab(wspec::t_##f##_ent), P::tab(wspec::t_##f##_src), P::tab(wspec::t_##f##_heavy), wspec::k_##f##_nout, wspec::k_##f##_nheavy})
+#else
+#define WK(f) (S->f)
+#define WV(f) (S->f)
+#define WT(f) (S->f)
+#define WDIR(set, k) (S->dir[set][k])
+#define WCSR(f) (S->f)
+#define WCOO(f) (S->f)
 #endif
 
 namespace dnlp {
@@ -69,28 +93,40 @@ constexpr int kWaveFilterCap = DNLP_WAVE_FILTER_CAP;
 template <class WI> struct WCsrT { WI* ptr; WI* idx; i32 rows; i32 val; };       // val: offset of the values in the instance's data row
 template <class WI> struct WCooT { WI* ptr; WI* ent; WI* src; WI* heavy; i32 nout; i32 nheavy; };
 
+// the fields of the state record that layout() sets once per kernel (X-macro lists: the record's declaration below, and
+// wave_codegen.h, which prints them as the constants of a per-template kernel)
+//   sizes (tail_L / tail_T: the dense tail of wave_plan.h — first tail level (= nlev without one), its order)
+#define WAVE_SIZE_FIELDS(X) X(N) X(m) X(Z) X(nd) X(nh) X(nnzJ) X(nnzH) X(nunits) X(nblk) X(nvals) X(nlev) X(ngrp) X(nfwd) X(tail_L) X(tail_T) \
+  X(l_c0) X(l_c) X(l_b) X(l_Jc) X(l_fp) X(l_fp2) X(l_x0) X(l_lb) X(l_ub) X(l_cl) X(l_cu)
+//   tables of the plan block
+#define WAVE_TAB_FIELDS(X) X(u_op) X(u_a0) X(u_a1) X(u_z) X(u_d0) X(u_d1) X(u_h) X(u_p) X(mm_idx) X(jac_rows) X(jac_cols) X(hess_rows) X(hess_cols) \
+  X(jac_rowptr) X(bnode) X(soff) X(loff) X(doff) X(lev_off) X(sblk) X(sidx) X(lev_f) X(fnode) X(foff) X(fa) X(fu0) X(fu1) X(lev_g) X(gdst) X(goff) \
+  X(upd_u) X(upd_v) X(hpos) X(jpos) X(dpos) X(lev_r) X(lev_t) X(lev_fe) X(t_node) X(t_d) X(t_l) X(t_fq) X(t_fp)
+//   vectors of the instance
+#define WAVE_VEC_FIELDS(X) X(x) X(zL) X(zU) X(xL) X(xU) X(grad) X(dx) X(dzL) X(dzU) X(xt) X(Sx) X(rx) X(tN) X(fixm) \
+  X(s) X(y) X(vL) X(vU) X(sL) X(sU) X(eq) X(g) X(sg) X(ds) X(dy) X(dvL) X(dvU) X(st) X(gt) X(Dd) X(Ss) X(rs) X(rp) X(tM) X(csoc) \
+  X(rhs) X(sol) X(res) X(cor) X(jv) X(xz) X(dvals) X(hvals) X(w) X(sl) X(Hs) X(svals) X(swork) X(scr)
+
 // Everything one wavefront knows about the instance it is solving.  Lives in LDS (one per wavefront).
 template <class WD, class WI>
 struct WStateT {
   typedef WCsrT<WI> WCsr;
   typedef WCooT<WI> WCoo;
-  // ---- sizes and tables (set once per kernel: w_layout) ----
-  i32 N, m, Z, nd, nh, nnzJ, nnzH, nunits;
-  WI *u_op, *u_a0, *u_a1, *u_z, *u_d0, *u_d1, *u_h, *u_p, *mm_idx;
+  // ---- sizes, tables, vectors (set once per kernel by layout(); a per-template kernel knows them as constants: WK / WT / WV) ----
+#ifndef DNLP_WAVE_SPEC
+#define W_DECL_K(f) i32 f;
+#define W_DECL_T(f) WI* f;
+#define W_DECL_V(f) WD* f;
+  WAVE_SIZE_FIELDS(W_DECL_K)
+  WAVE_TAB_FIELDS(W_DECL_T)
   WCsr G, Mg, MJ, Mw, MH;
-  WI *jac_rows, *jac_cols, *hess_rows, *hess_cols, *jac_rowptr;
   WCoo jr, jc, hs;
-  i32 nblk, nvals, nlev, ngrp, nfwd;
-  WI *bnode, *soff, *loff, *doff, *lev_off, *sblk, *sidx, *lev_f, *fnode, *foff, *fa, *fu0, *fu1, *lev_g, *gdst, *goff, *upd_u, *upd_v,
-     *hpos, *jpos, *dpos, *lev_r, *lev_t, *lev_fe, *t_node, *t_d, *t_l, *t_fq, *t_fp;
-  i32 tail_L, tail_T;                // dense tail (wave_plan.h): first tail level (= nlev without one), its order
-  i32 l_c0, l_c, l_b, l_Jc, l_fp, l_fp2, l_x0, l_lb, l_ub, l_cl, l_cu;
-  // ---- vectors (LDS) ----
-  WD *x, *zL, *zU, *xL, *xU, *grad, *dx, *dzL, *dzU, *xt, *Sx, *rx, *tN, *fixm;
-  WD *s, *y, *vL, *vU, *sL, *sU, *eq, *g, *sg, *ds, *dy, *dvL, *dvU, *st, *gt, *Dd, *Ss, *rs, *rp, *tM, *csoc;
+  WAVE_VEC_FIELDS(W_DECL_V)
   WD *dir[3][7];                     // [0] = dx ds dy dzL dzU dvL dvU, [1] = affine-scaling, [2] = centering direction
-  WD *rhs, *sol, *res, *cor;
-  WD *jv, *xz, *dvals, *hvals, *w, *sl, *Hs, *svals, *swork, *scr;
+#undef W_DECL_K
+#undef W_DECL_T
+#undef W_DECL_V
+#endif
   // ---- the instance (set per instance: w_bind) ----
   WG* row;                           // its data row (batch.h layout)
   double* park;                      // 3 N + 4 m doubles of global memory: where polish() keeps the iterate it may have to come back to
@@ -136,6 +172,7 @@ struct WaveIpm {
   // lane-strided loops
 #define W_FOR(i, n) for (int i = P::lane(); i < (n); i += P::lanes)
 
+#ifndef DNLP_WAVE_SPEC
   // ---- layout: the tables out of the staged block, the vectors out of the wavefront's share ---------------------------
   // (returns the doubles of state it laid out: wave_plan.h wave_state_doubles says the same number)
   DNLP_HD static i32 layout(WS* S, const WaveHdr* h, WI* blk, WD* base) {
@@ -211,6 +248,7 @@ struct WaveIpm {
     S->dir[2][0] = cx; S->dir[2][1] = cs; S->dir[2][2] = cy; S->dir[2][3] = czL; S->dir[2][4] = czU; S->dir[2][5] = cvL; S->dir[2][6] = cvU;
     return static_cast<i32>(p - base);
   }
+#endif
 
   // ---- lane reductions (NaN conventions of BlockExecT::reduce: max NaN -> +inf, min NaN -> -inf) -------------------------
   DNLP_HD static double mxin(double acc, double v) { return fmax(acc, v != v ? kInf : v); }
@@ -231,18 +269,18 @@ struct WaveIpm {
   // Model::sweep: xz[0..N) <- src (unless it is xz already), then every flat unit: z, dvals (and hvals with the weights w)
   DNLP_WFN DNLP_HD static void sweep(WS* S, const WD* src, bool with_h) {
     W_P0();
-    const int N = S->N, nu = S->nunits;
-    WD *dv = S->dvals, *hv = S->hvals;
-    WD* zz = S->xz;
-    const WD* ww = S->w;
-    const WD* zlo = S->xz - N;          // argument index u: u < N -> src[u], else zlo[u] = z[u - N]
+    const int N = WK(N), nu = WK(nunits);
+    WD *dv = WV(dvals), *hv = WV(hvals);
+    WD* zz = WV(xz);
+    const WD* ww = WV(w);
+    const WD* zlo = WV(xz) - N;          // argument index u: u < N -> src[u], else zlo[u] = z[u - N]
     auto at = [&](i32 u) -> double { return (u < N ? src : zlo)[u]; };
-    S->swept_xt = src == S->xt;
-    WI *uop = S->u_op, *ua0 = S->u_a0, *ua1 = S->u_a1, *uz = S->u_z, *ud0 = S->u_d0, *ud1 = S->u_d1, *uh = S->u_h, *up = S->u_p;
+    S->swept_xt = src == WV(xt);
+    WI *uop = WT(u_op), *ua0 = WT(u_a0), *ua1 = WT(u_a1), *uz = WT(u_z), *ud0 = WT(u_d0), *ud1 = WT(u_d1), *uh = WT(u_h), *up = WT(u_p);
     // the per-segment parameters of the unary atoms come straight out of the instance's data row (global memory, read-only,
     // two loads per unit and sweep that travel beside the LDS loads): copies of them in LDS were 3 x nunits doubles of state,
     // and state is what decides how many wavefronts a compute unit holds (batch.h wave_form)
-    WG *fp = S->row + S->l_fp, *fp2 = S->row + S->l_fp2;
+    WG *fp = S->row + WK(l_fp), *fp2 = S->row + WK(l_fp2);
     W_FOR(e, nu) {
       const int op = uop[e];
       const i32 zi = uz[e];
@@ -296,7 +334,7 @@ struct WaveIpm {
       } else {
         // OP_MATMUL: one output entry of U @ V (model.h sweep_flat)
         const i32 kk = ua1[e], db0 = ud0[e], db1 = ud1[e], hb = uh[e];
-        WI* mi = S->mm_idx + ua0[e];
+        WI* mi = WT(mm_idx) + ua0[e];
         double acc = 0.0;
         for (i32 q = 0; q < kk; ++q) {
           const double u = at(mi[2 * q]), v = at(mi[2 * q + 1]);
@@ -327,7 +365,7 @@ struct WaveIpm {
     return acc;
   }
   // Model::spmv: y = (base + M v) [* scale];  scale_kind 0 none, 1 a scalar, 2 sg[r], 3 sg[jac_rows[r]]
-  // (SPLIT: v is the vector [x | z] in two places — column c < split reads v[c], the others vhi[c]: the sweep's point and S->xz - N)
+  // (SPLIT: v is the vector [x | z] in two places — column c < split reads v[c], the others vhi[c]: the sweep's point and WV(xz) - N)
   template <bool SPLIT = false>
   DNLP_WFN DNLP_HD static void spmv(DNLP_WLDS WState* S, const WCsr M, const WD* v, i32 base_off, WD* y, int scale_kind, double scalar,
                                     const WD* vhi = nullptr, i32 split = 0) {
@@ -335,8 +373,8 @@ struct WaveIpm {
     WI *ptr = M.ptr, *idx = M.idx;
     WG* val = S->row + M.val;
     WG* base = base_off >= 0 ? S->row + base_off : nullptr;
-    const WD* sg = S->sg;
-    WI* jr = S->jac_rows;
+    const WD* sg = WV(sg);
+    WI* jr = WT(jac_rows);
     W_FOR(r, M.rows) {
       double sacc = base ? base[r] : 0.0;
       const i32 k1 = ptr[r + 1];
@@ -368,40 +406,40 @@ struct WaveIpm {
   DNLP_WFN DNLP_HD static bool eval_fg_impl(WS* S, const WD* xp, WD* gout) {
     auto& fval = S->o_d[0];
     sweep(S, xp, false);
-    const int NZ = S->N + S->Z;
-    WG* cc = S->row + S->l_c;
-    const int N = S->N;
-    const WD* zlo = S->xz - N;
+    const int NZ = WK(N) + WK(Z);
+    WG* cc = S->row + WK(l_c);
+    const int N = WK(N);
+    const WD* zlo = WV(xz) - N;
     double acc = 0.0;
     W_FOR(i, NZ) acc += cc[i] * (i < N ? xp : zlo)[i];
-    fval = S->sf * (S->row[S->l_c0] + P::sum(acc));
-    spmv<true>(S, S->G, xp, S->l_b, gout, 2, 0.0, zlo, N);
+    fval = S->sf * (S->row[WK(l_c0)] + P::sum(acc));
+    spmv<true>(S, WCSR(G), xp, WK(l_b), gout, 2, 0.0, zlo, N);
     return std::isfinite(fval);
   }
   DNLP_HD static double nan_check(WS* S, const WD* gg) {
     double acc = 0.0;
-    W_FOR(i, S->m) acc += gg[i] - gg[i];
+    W_FOR(i, WK(m)) acc += gg[i] - gg[i];
     return P::sum(acc);
   }
   // Ipm::eval_derivs_after_sweep
   DNLP_HD static void eval_derivs(WS* S) {
     S->jty_valid = false;
-    spmv(S, S->Mg, S->dvals, S->l_c, S->grad, 1, S->sf);
-    spmv(S, S->MJ, S->dvals, S->l_Jc, S->jv, 3, 0.0);
+    spmv(S, WCSR(Mg), WV(dvals), WK(l_c), WV(grad), 1, S->sf);
+    spmv(S, WCSR(MJ), WV(dvals), WK(l_Jc), WV(jv), 3, 0.0);
   }
   // Ipm::eval_hessian + Model::eval_hess
   DNLP_WFN DNLP_HD static void eval_hessian(WS* S) {
     W_P0();
-    const int m = S->m;
-    WD* sl = S->sl;
-    const WD *sg = S->sg, *yy = S->y;
+    const int m = WK(m);
+    WD* sl = WV(sl);
+    const WD *sg = WV(sg), *yy = WV(y);
     const double sff = S->sf;
     if (P::lane() == 0) sl[0] = sff;
     W_FOR(i, m) sl[1 + i] = sg[i] * yy[i];
     P::sync();
-    spmv(S, S->Mw, S->sl, -1, S->w, 0, 0.0);
-    sweep(S, S->x, true);
-    spmv(S, S->MH, S->hvals, -1, S->Hs, 0, 0.0);
+    spmv(S, WCSR(Mw), WV(sl), -1, WV(w), 0, 0.0);
+    sweep(S, WV(x), true);
+    spmv(S, WCSR(MH), WV(hvals), -1, WV(Hs), 0, 0.0);
     W_P1(3);
   }
   // BlockExecT::coo_gather through the tape's index by output: out = J v / J^T v / sym(H) v
@@ -410,7 +448,7 @@ struct WaveIpm {
     WI *ptr = ix.ptr, *ent = ix.ent, *src = ix.src;
     W_FOR(gq, ix.nout) {
       const i32 p0 = ptr[gq], p1 = ptr[gq + 1];
-      if (p1 - p0 > static_cast<i32>(CooIdx::kHeavy)) continue;
+      if (p1 - p0 > static_cast<i32>(kCooHeavy)) continue;
       double sacc = 0.0;
       for (i32 p = p0; p < p1; ++p) sacc += a[ent[p]] * v[src[p]];
       out[gq] = sacc;
@@ -426,9 +464,9 @@ struct WaveIpm {
     P::sync();
     W_P1(8);
   }
-  DNLP_HD static void hess_mult(WS* S, const WD* v, WD* out) { coo(S, S->hs, S->Hs, v, out); }
-  DNLP_HD static void jac_mult(WS* S, const WD* v, WD* out) { coo(S, S->jr, S->jv, v, out); }
-  DNLP_HD static void jac_tmult(WS* S, const WD* v, WD* out) { coo(S, S->jc, S->jv, v, out); }
+  DNLP_HD static void hess_mult(WS* S, const WD* v, WD* out) { coo(S, WCOO(hs), WV(Hs), v, out); }
+  DNLP_HD static void jac_mult(WS* S, const WD* v, WD* out) { coo(S, WCOO(jr), WV(jv), v, out); }
+  DNLP_HD static void jac_tmult(WS* S, const WD* v, WD* out) { coo(S, WCOO(jc), WV(jv), v, out); }
 
   // ====================================================================================================================
   // KKT system: assembly (kkt_dense.h assemble_factor, sparse branch) and the static-pattern LDL^T (sparse_ldl.h)
@@ -439,11 +477,11 @@ struct WaveIpm {
     return ok;
   }
   DNLP_WFN DNLP_HD static bool assemble_factor_impl(WS* S, const WD* Sx, const WD* D, double dw, bool zero_h) {
-    const int N = S->N, m = S->m, nnzH = S->nnzH, nnzJ = S->nnzJ, nvals = S->nvals;
+    const int N = WK(N), m = WK(m), nnzH = WK(nnzH), nnzJ = WK(nnzJ), nvals = WK(nvals);
     W_P0();
-    WD* V = S->svals;
-    const WD *fixm = S->fixm, *hs = S->Hs, *jv = S->jv;
-    WI *hp = S->hpos, *jp = S->jpos, *dp = S->dpos, *hr = S->hess_rows, *hc = S->hess_cols, *jc = S->jac_cols;
+    WD* V = WV(svals);
+    const WD *fixm = WV(fixm), *hs = WV(Hs), *jv = WV(jv);
+    WI *hp = WT(hpos), *jp = WT(jpos), *dp = WT(dpos), *hr = WT(hess_rows), *hc = WT(hess_cols), *jc = WT(jac_cols);
     W_FOR(a, nvals) V[a] = 0.0;
     P::sync();
     if (!zero_h) {
@@ -469,9 +507,9 @@ struct WaveIpm {
   }
   // sparse_ldl.h sp_pivot
   DNLP_HD static void sp_pivot(WS* S, WD* vals, WD* dinv, int k, double& nneg, double& nzero, double& bad) {
-    WD* Dk = vals + S->doff[k];
+    WD* Dk = vals + WT(doff)[k];
     WD* di = dinv + 3 * k;
-    if (S->bnode[2 * k + 1] < 0) {
+    if (WT(bnode)[2 * k + 1] < 0) {
       double d = Dk[0];
       if (!(d == d)) bad += 1.0;
       if (fabs(d) < 1e-300) { nzero += 1.0; d = 1e-20; Dk[0] = d; }
@@ -489,15 +527,15 @@ struct WaveIpm {
   }
   // sparse_ldl.h sp_scale
   DNLP_HD static void sp_scale(WS* S, WD* vals, WD* w, const WD* dinv, int r) {
-    const int k = S->sblk[r], i = r - S->soff[k];
+    const int k = WT(sblk)[r], i = r - WT(soff)[k];
     const WD* di = dinv + 3 * k;
-    if (S->bnode[2 * k + 1] < 0) {
-      const int a = S->loff[k] + i;
+    if (WT(bnode)[2 * k + 1] < 0) {
+      const int a = WT(loff)[k] + i;
       const double l1 = vals[a];
       w[a] = l1;
       vals[a] = l1 * di[0];
     } else {
-      const int a = S->loff[k] + 2 * i;
+      const int a = WT(loff)[k] + 2 * i;
       const double l1 = vals[a], l2 = vals[a + 1];
       w[a] = l1; w[a + 1] = l2;
       vals[a] = di[0] * l1 + di[1] * l2;
@@ -522,10 +560,10 @@ struct WaveIpm {
   DNLP_WFN DNLP_HD static T3 tail_factor_n(WS* S) {
     constexpr int kTailSlots = (kTailMax + P::lanes - 1) / P::lanes;      // rows of the tail a lane owns (device 1, host: all)
     W_P0();
-    const int T = P::uni(S->tail_T), me = P::lane();      // (uniform: a scalar register, so that the unrolled loops below test it on the scalar unit)
+    const int T = P::uni(WK(tail_T)), me = P::lane();      // (uniform: a scalar register, so that the unrolled loops below test it on the scalar unit)
     double nneg = 0.0, nzero = 0.0, bad = 0.0;           // (lane 0 counts; handed back once)
-    WD* vals = S->svals;
-    WI *td = S->t_d, *tl = S->t_l;
+    WD* vals = WV(svals);
+    WI *td = WT(t_d), *tl = WT(t_l);
     double A[kTailSlots][kTailMax];
 #pragma clang loop unroll(full)
     for (int sl = 0; sl < kTailSlots; ++sl) {
@@ -589,11 +627,11 @@ struct WaveIpm {
   DNLP_WFN DNLP_HD static void tail_forward_n(WS* S, WD* x, WD* y) {
     constexpr int kTailSlots = (kTailMax + P::lanes - 1) / P::lanes;      // rows of the tail a lane owns (device 1, host: all)
     W_P0();
-    const int T = P::uni(S->tail_T), me = P::lane();      // (uniform: a scalar register, so that the unrolled loops below test it on the scalar unit)
-    const WD* vals = S->svals;
-    WI *tn = S->t_node, *tl = S->t_l, *tfq = S->t_fq, *tfp = S->t_fp, *fa = S->fa, *fu0 = S->fu0, *fu1 = S->fu1;
+    const int T = P::uni(WK(tail_T)), me = P::lane();      // (uniform: a scalar register, so that the unrolled loops below test it on the scalar unit)
+    const WD* vals = WV(svals);
+    WI *tn = WT(t_node), *tl = WT(t_l), *tfq = WT(t_fq), *tfp = WT(t_fp), *fa = WT(fa), *fu0 = WT(fu0), *fu1 = WT(fu1);
     const bool two = y != nullptr;
-    WD* scr = S->dy;                        // (dy dvL dvU st gt: consecutive and dead during a solve; wave_plan.h keeps t_nf within them)
+    WD* scr = WV(dy);                        // (dy dvL dvU st gt: consecutive and dead during a solve; wave_plan.h keeps t_nf within them)
     WD* scr2 = scr + tfp[T];
     const int nf = tfp[T];
     for (int n = me; n < nf; n += P::lanes) {
@@ -649,9 +687,9 @@ struct WaveIpm {
   DNLP_WFN DNLP_HD static void tail_backward_n(WS* S, WD* x, WD* y) {
     constexpr int kTailSlots = (kTailMax + P::lanes - 1) / P::lanes;      // rows of the tail a lane owns (device 1, host: all)
     W_P0();
-    const int T = P::uni(S->tail_T), me = P::lane();      // (uniform: a scalar register, so that the unrolled loops below test it on the scalar unit)
-    const WD* vals = S->svals;
-    WI *tn = S->t_node, *tl = S->t_l;
+    const int T = P::uni(WK(tail_T)), me = P::lane();      // (uniform: a scalar register, so that the unrolled loops below test it on the scalar unit)
+    const WD* vals = WV(svals);
+    WI *tn = WT(t_node), *tl = WT(t_l);
     const bool two = y != nullptr;
     double xr[kTailSlots], yr[kTailSlots], Lr[kTailSlots][kTailMax];
 #pragma clang loop unroll(full)
@@ -688,18 +726,18 @@ struct WaveIpm {
     W_P1(26);
   }
   DNLP_HD static void tail_factor(WS* S, double& nneg_io, double& nzero_io, double& bad_io) {
-    const int T = P::uni(S->tail_T);
+    const int T = P::uni(WK(tail_T));
     const T3 r = T <= 12 ? tail_factor_n<12>(S) : T <= 24 ? tail_factor_n<24>(S) : tail_factor_n<32>(S);
     nneg_io += r.nneg; nzero_io += r.nzero; bad_io += r.bad;
   }
   DNLP_HD static void tail_forward(WS* S, WD* x, WD* y) {
-    const int T = P::uni(S->tail_T);
+    const int T = P::uni(WK(tail_T));
     if (T <= 12) tail_forward_n<12>(S, x, y);
     else if (T <= 24) tail_forward_n<24>(S, x, y);
     else tail_forward_n<32>(S, x, y);
   }
   DNLP_HD static void tail_backward(WS* S, WD* x, WD* y) {
-    const int T = P::uni(S->tail_T);
+    const int T = P::uni(WK(tail_T));
     if (T <= 12) tail_backward_n<12>(S, x, y);
     else if (T <= 24) tail_backward_n<24>(S, x, y);
     else tail_backward_n<32>(S, x, y);
@@ -711,16 +749,16 @@ struct WaveIpm {
     auto* nzero_out = &S->o_i[2];
     W_P0();
     const int L = P::lanes, me = P::lane();
-    WD* vals = S->svals;
-    WD* w = S->swork;
-    WD* dinv = S->swork + S->nvals;
-    WD* scr = S->scr;
-    WI *lev_off = S->lev_off, *soff = S->soff, *lev_g = S->lev_g, *goff = S->goff, *gdst = S->gdst, *tau = S->upd_u, *tav = S->upd_v;
+    WD* vals = WV(svals);
+    WD* w = WV(swork);
+    WD* dinv = WV(swork) + WK(nvals);
+    WD* scr = WV(scr);
+    WI *lev_off = WT(lev_off), *soff = WT(soff), *lev_g = WT(lev_g), *goff = WT(goff), *gdst = WT(gdst), *tau = WT(upd_u), *tav = WT(upd_v);
     double nneg = 0.0, nzero = 0.0, bad = 0.0;
-    const int nlev = S->tail_L, nt = S->nlev + 1;          // (the levels before the dense tail; tail_L = nlev without one)
+    const int nlev = WK(tail_L), nt = WK(nlev) + 1;          // (the levels before the dense tail; tail_L = nlev without one)
     // (the per-level bounds: one table entry per lane in a register, read back with v_readlane — two dependent uniform
     //  LDS trips less in front of every level phase)
-    WI *lev_r = S->lev_r, *lev_t = S->lev_t;
+    WI *lev_r = WT(lev_r), *lev_t = WT(lev_t);
     const int c_off = P::tab_load(lev_off, nt), c_r = P::tab_load(lev_r, nt), c_g = P::tab_load(lev_g, nt), c_t = P::tab_load(lev_t, nt);
     for (int lev = 0; lev < nlev; ++lev) {
       const int b0 = P::tab_at(lev_off, c_off, lev, nt), b1 = P::tab_at(lev_off, c_off, lev + 1, nt);
@@ -751,7 +789,7 @@ struct WaveIpm {
       }
       P::sync();
     }
-    if (S->tail_T > 0) tail_factor(S, nneg, nzero, bad);
+    if (WK(tail_T) > 0) tail_factor(S, nneg, nzero, bad);
     nneg = P::sum(nneg);
     nzero = P::sum(nzero);
     bad = P::sum(bad);
@@ -790,11 +828,11 @@ struct WaveIpm {
   DNLP_WFN DNLP_HD static void ldl_solve(WS* S, WD* x, WD* y) {
     W_P0();
     const int L = P::lanes, me = P::lane();
-    const WD* vals = S->svals;
-    WI *lev_f = S->lev_f, *foff = S->foff, *fnode = S->fnode, *lev_off = S->lev_off, *soff = S->soff, *bnode = S->bnode, *loff = S->loff,
-       *sidx = S->sidx, *doff = S->doff, *fa = S->fa, *fu0 = S->fu0, *fu1 = S->fu1;
-    const int nlev = S->tail_L, nblk = S->nblk, nt = S->nlev + 1;      // (the levels before the dense tail)
-    WI *lev_r = S->lev_r, *lev_fe = S->lev_fe;
+    const WD* vals = WV(svals);
+    WI *lev_f = WT(lev_f), *foff = WT(foff), *fnode = WT(fnode), *lev_off = WT(lev_off), *soff = WT(soff), *bnode = WT(bnode), *loff = WT(loff),
+       *sidx = WT(sidx), *doff = WT(doff), *fa = WT(fa), *fu0 = WT(fu0), *fu1 = WT(fu1);
+    const int nlev = WK(tail_L), nblk = WK(nblk), nt = WK(nlev) + 1;      // (the levels before the dense tail)
+    WI *lev_r = WT(lev_r), *lev_fe = WT(lev_fe);
     const bool two = y != nullptr;
     for (int lev = 1; lev < nlev; ++lev) {
       const int h0 = lev_f[lev], h1 = lev_f[lev + 1];
@@ -839,12 +877,12 @@ struct WaveIpm {
       }
       P::sync();
     }
-    if (S->tail_T > 0) tail_forward(S, x, y);
+    if (WK(tail_T) > 0) tail_forward(S, x, y);
     // D^-1, all blocks side by side (measured: folded into the backward pass — one level barrier less — the division
     // joins each block's dependent chain and the solve gets 8 % slower)
     for (int k = me; k < nblk; k += L) dsolve(vals, doff, bnode[2 * k], bnode[2 * k + 1], k, x, y);
     P::sync();
-    if (S->tail_T > 0) tail_backward(S, x, y);
+    if (WK(tail_T) > 0) tail_backward(S, x, y);
     for (int lev = nlev - 1; lev >= 0; --lev) {
       const int b0 = lev_off[lev], b1 = lev_off[lev + 1];
       const int nbl = b1 - b0, nrw = lev_r[lev + 1] - lev_r[lev];
@@ -902,7 +940,7 @@ struct WaveIpm {
   }
   // DenseKkt::solve (sparse) == Ipm::kkt_solve without the quasi-Newton part
   DNLP_HD static void kkt_solve(WS* S, const WD* r, WD* out, const WD* r2 = nullptr, WD* out2 = nullptr) {
-    const int n = S->N + S->m;
+    const int n = WK(N) + WK(m);
     { W_P0();
       if (out != r) W_FOR(k, n) out[k] = r[k];
       if (out2 && out2 != r2) W_FOR(k, n) out2[k] = r2[k];
@@ -932,13 +970,13 @@ struct WaveIpm {
   DNLP_WFN DNLP_HD static int begin(WS* S) {
     W_P0();
     const double t_start = now_sec();
-    const int N = S->N, m = S->m;
+    const int N = WK(N), m = WK(m);
     const IpmOptions& opt = S->opt;
     const double inf = opt.nlp_inf, brf = opt.bound_relax_factor;
     const bool warm = opt.warm_start != 0 && S->ws_g != nullptr && S->ws_l != nullptr && S->ws_u != nullptr;
     const double k1 = warm ? opt.warm_start_bound_push : opt.bound_push, k2 = warm ? opt.warm_start_bound_frac : opt.bound_frac;
-    WG *lb = S->row + S->l_lb, *ub = S->row + S->l_ub, *cl = S->row + S->l_cl, *cu = S->row + S->l_cu, *x0 = S->row + S->l_x0;
-    WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *sgp = S->sg, *xx = S->x, *px = S->xt;
+    WG *lb = S->row + WK(l_lb), *ub = S->row + WK(l_ub), *cl = S->row + WK(l_cl), *cu = S->row + WK(l_cu), *x0 = S->row + WK(l_x0);
+    WD *l = WV(xL), *u = WV(xU), *sl = WV(sL), *su = WV(sU), *sgp = WV(sg), *xx = WV(x), *px = WV(xt);
     {
       double bad = -kInf;
       W_FOR(j, N) {
@@ -966,18 +1004,18 @@ struct WaveIpm {
     if (opt.nlp_scaling) {
       W_FOR(j, N) px[j] = push_into_bounds1(xx[j], l[j], u[j], k1, k2);
       P::sync();
-      sweep(S, S->xt, false);
-      spmv(S, S->Mg, S->dvals, S->l_c, S->grad, 0, 0.0);
-      spmv(S, S->MJ, S->dvals, S->l_Jc, S->jv, 0, 0.0);
-      const WD* gr = S->grad;
+      sweep(S, WV(xt), false);
+      spmv(S, WCSR(Mg), WV(dvals), WK(l_c), WV(grad), 0, 0.0);
+      spmv(S, WCSR(MJ), WV(dvals), WK(l_Jc), WV(jv), 0, 0.0);
+      const WD* gr = WV(grad);
       double gmax = -kInf;
       W_FOR(j, N) gmax = mxin(gmax, fabs(gr[j]));
       gmax = P::vmax(gmax);
       const double smax = opt.nlp_scaling_max_gradient;
       if (std::isfinite(gmax) && gmax > smax) S->sf = std::max(smax / gmax, 1e-8);
       if (m > 0) {
-        WI* rp_ = S->jac_rowptr;
-        const WD* jvv = S->jv;
+        WI* rp_ = WT(jac_rowptr);
+        const WD* jvv = WV(jv);
         W_FOR(i, m) {
           double rmax = 0.0;
           bool fin = true;
@@ -990,7 +1028,7 @@ struct WaveIpm {
     }
     // scaled constraint bounds, equality mask, counts; start point pushed into the bounds, fixed variables pinned
     {
-      WD *eq = S->eq, *fm = S->fixm;
+      WD *eq = WV(eq), *fm = WV(fixm);
       double neq = 0.0, nfree = 0.0;
       W_FOR(i, m) {
         const double e = (sl[i] == su[i]) ? 1.0 : 0.0;
@@ -1014,11 +1052,11 @@ struct WaveIpm {
       P::sync();
     }
     S->nb_cache = -1;
-    if (!eval_fg(S, S->x, S->f, S->g) || nan_check(S, S->g) != 0.0) return S->status = Invalid_Number_Detected;
+    if (!eval_fg(S, WV(x), S->f, WV(g)) || nan_check(S, WV(g)) != 0.0) return S->status = Invalid_Number_Detected;
     eval_derivs(S);
     {
-      WD *ss = S->s, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU, *yy = S->y;
-      const WD *gg = S->g, *eq = S->eq;
+      WD *ss = WV(s), *a = WV(zL), *b = WV(zU), *c = WV(vL), *d = WV(vU), *yy = WV(y);
+      const WD *gg = WV(g), *eq = WV(eq);
       const double zi = opt.bound_mult_init_val;
       W_FOR(i, m) {
         ss[i] = eq[i] != 0.0 ? sl[i] : push_into_bounds1(gg[i], sl[i], su[i], k1, k2);
@@ -1035,8 +1073,8 @@ struct WaveIpm {
     if (warm) {
       const double sff = S->sf, mp = opt.warm_start_mult_bound_push;
       const double *wy = S->ws_g, *wl = S->ws_l, *wu = S->ws_u;
-      const WD* eq = S->eq;
-      WD *yy = S->y, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU;
+      const WD* eq = WV(eq);
+      WD *yy = WV(y), *a = WV(zL), *b = WV(zU), *c = WV(vL), *d = WV(vU);
       W_FOR(i, m) {
         const double yi = wy[i] * sff / sgp[i];
         yy[i] = yi;
@@ -1053,7 +1091,7 @@ struct WaveIpm {
       init_multipliers_ls(S);
     }
     S->nfilt = 0;
-    const double th0 = theta_at(S, S->g, S->s);
+    const double th0 = theta_at(S, WV(g), WV(s));
     S->theta_max = 1e4 * std::max(1.0, th0);
     S->theta_min = 1e-4 * std::max(1.0, th0);
     S->iter = 0;
@@ -1076,37 +1114,37 @@ struct WaveIpm {
 
   // Ipm::init_multipliers_ls (the general path: neither of the host-only condensed forms)
   DNLP_WFN DNLP_HD static void init_multipliers_ls(WS* S) {
-    const int N = S->N, m = S->m;
+    const int N = WK(N), m = WK(m);
     S->jty_valid = false;
-    const WD* eq = S->eq;
-    WD *sx = S->Sx, *dd = S->Dd;
+    const WD* eq = WV(eq);
+    WD *sx = WV(Sx), *dd = WV(Dd);
     W_FOR(j, N) sx[j] = 1.0;
     W_FOR(i, m) dd[i] = (eq[i] == 0.0) ? 1.0 : 0.0;
     {
-      WD* hs = S->Hs;                      // (ex_->zero(md_->Hs): the next eval_hessian refills it)
-      W_FOR(p, S->nnzH) hs[p] = 0.0;
+      WD* hs = WV(Hs);                      // (ex_->zero(md_->Hs): the next eval_hessian refills it)
+      W_FOR(p, WK(nnzH)) hs[p] = 0.0;
     }
     P::sync();
     int nneg = 0, nzero = 0;
-    bool ok = assemble_factor(S, S->Sx, S->Dd, 0.0, true, &nneg, &nzero);
+    bool ok = assemble_factor(S, WV(Sx), WV(Dd), 0.0, true, &nneg, &nzero);
     if (!ok || nzero > 0 || nneg != m) {
       W_FOR(i, m) dd[i] += 1e-8;
       P::sync();
-      ok = assemble_factor(S, S->Sx, S->Dd, 0.0, true, &nneg, &nzero);
+      ok = assemble_factor(S, WV(Sx), WV(Dd), 0.0, true, &nneg, &nzero);
       if (!ok) return;
     }
-    WD* r = S->rhs;
-    const WD *gr = S->grad, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU;
+    WD* r = WV(rhs);
+    const WD *gr = WV(grad), *a = WV(zL), *b = WV(zU), *c = WV(vL), *d = WV(vU);
     W_FOR(j, N) r[j] = -(gr[j] - a[j] + b[j]);
     W_FOR(i, m) r[N + i] = (eq[i] == 0.0) ? -(-c[i] + d[i]) : 0.0;
     P::sync();
-    kkt_solve(S, S->rhs, S->sol);
-    const WD* so = S->sol;
+    kkt_solve(S, WV(rhs), WV(sol));
+    const WD* so = WV(sol);
     double ymax = -kInf;
     W_FOR(i, m) ymax = mxin(ymax, fabs(so[N + i]));
     ymax = P::vmax(ymax);
     if (std::isfinite(ymax) && ymax <= S->opt.constr_mult_init_max) {
-      WD* yy = S->y;
+      WD* yy = WV(y);
       W_FOR(i, m) yy[i] = so[N + i];
       P::sync();
     }
@@ -1114,9 +1152,9 @@ struct WaveIpm {
 
   // Ipm::theta_at
   DNLP_HD static double theta_at(WS* S, const WD* gg, const WD* ss) {
-    const WD *eq = S->eq, *sl = S->sL;
+    const WD *eq = WV(eq), *sl = WV(sL);
     double acc = 0.0;
-    W_FOR(i, S->m) acc += fabs(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]);
+    W_FOR(i, WK(m)) acc += fabs(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]);
     return P::sum(acc);
   }
   DNLP_HD static double bterm(double v, double lo, double hi, double kd) {
@@ -1130,22 +1168,22 @@ struct WaveIpm {
   }
   // Ipm::barrier_at (two sums: variables, rows)
   DNLP_WFN DNLP_HD static double barrier_at(WS* S, double fv, const WD* xx, const WD* ss, double muv) {
-    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *eq = S->eq;
+    const WD *l = WV(xL), *u = WV(xU), *sl = WV(sL), *su = WV(sU), *eq = WV(eq);
     const double kd = S->opt.kappa_d;
     double ax = 0.0, as = 0.0;
-    W_FOR(j, S->N) ax += bterm(xx[j], l[j], u[j], kd);
-    W_FOR(i, S->m) as += eq[i] != 0.0 ? 0.0 : bterm(ss[i], sl[i], su[i], kd);
+    W_FOR(j, WK(N)) ax += bterm(xx[j], l[j], u[j], kd);
+    W_FOR(i, WK(m)) as += eq[i] != 0.0 ? 0.0 : bterm(ss[i], sl[i], su[i], kd);
     const double bx = P::sum(ax), bs = P::sum(as);
     return fv + muv * (bx + bs);
   }
   // Ipm::measures: theta, the barrier function and the NaN detector of g in one pass
   DNLP_WFN DNLP_HD static WMeasures measures(WS* S, double fv, const WD* gg, const WD* xx, const WD* ss, double muv) {
-    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *eq = S->eq;
+    const WD *l = WV(xL), *u = WV(xU), *sl = WV(sL), *su = WV(sU), *eq = WV(eq);
     const double kd = S->opt.kappa_d;
     W_P0();
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    W_FOR(j, S->N) s1 += bterm(xx[j], l[j], u[j], kd);
-    W_FOR(i, S->m) {
+    W_FOR(j, WK(N)) s1 += bterm(xx[j], l[j], u[j], kd);
+    W_FOR(i, WK(m)) {
       s0 += fabs(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]);
       s2 += gg[i] - gg[i];
       if (eq[i] == 0.0) s1 += bterm(ss[i], sl[i], su[i], kd);
@@ -1156,17 +1194,17 @@ struct WaveIpm {
   }
   // Ipm::jty
   DNLP_HD static const WD* jty(WS* S) {
-    if (!S->jty_valid) { jac_tmult(S, S->y, S->tN); S->jty_valid = true; }
-    return S->tN;
+    if (!S->jty_valid) { jac_tmult(S, WV(y), WV(tN)); S->jty_valid = true; }
+    return WV(tN);
   }
   // Ipm::error (dual_residuals fused into the same pass)
   DNLP_WFN DNLP_HD static WErr error(WS* S, double muv) {
-    const int N = S->N, m = S->m;
+    const int N = WK(N), m = WK(m);
     const WD* jt = jty(S);
     W_P0();
-    WD *r = S->rx, *q = S->rs;
-    const WD *gr = S->grad, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU, *yy = S->y, *eq = S->eq, *fm = S->fixm, *gg = S->g, *ss = S->s,
-             *sl = S->sL, *su = S->sU, *l = S->xL, *u = S->xU, *xx = S->x, *sgp = S->sg;
+    WD *r = WV(rx), *q = WV(rs);
+    const WD *gr = WV(grad), *a = WV(zL), *b = WV(zU), *c = WV(vL), *d = WV(vU), *yy = WV(y), *eq = WV(eq), *fm = WV(fixm), *gg = WV(g), *ss = WV(s),
+             *sl = WV(sL), *su = WV(sU), *l = WV(xL), *u = WV(xU), *xx = WV(x), *sgp = WV(sg);
     double m0 = -kInf, m1 = -kInf, m2 = -kInf, m3 = -kInf, sy = 0.0, sz = 0.0;
     W_FOR(j, N) {
       const double rj = fm[j] != 0.0 ? 0.0 : gr[j] + jt[j] - a[j] + b[j];
@@ -1211,12 +1249,12 @@ struct WaveIpm {
   // Ipm::n_bound_mults
   DNLP_HD static i64 n_bound_mults(WS* S) {
     if (S->nb_cache >= 0) return S->nb_cache;
-    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *eq = S->eq;
+    const WD *l = WV(xL), *u = WV(xU), *sl = WV(sL), *su = WV(sU), *eq = WV(eq);
     double c1 = 0.0, c2 = 0.0;
-    W_FOR(j, S->N) c1 += (l[j] > -kInf ? 1.0 : 0.0) + (u[j] < kInf ? 1.0 : 0.0);
-    W_FOR(i, S->m) c2 += eq[i] != 0.0 ? 0.0 : (sl[i] > -kInf ? 1.0 : 0.0) + (su[i] < kInf ? 1.0 : 0.0);
+    W_FOR(j, WK(N)) c1 += (l[j] > -kInf ? 1.0 : 0.0) + (u[j] < kInf ? 1.0 : 0.0);
+    W_FOR(i, WK(m)) c2 += eq[i] != 0.0 ? 0.0 : (sl[i] > -kInf ? 1.0 : 0.0) + (su[i] < kInf ? 1.0 : 0.0);
     c1 = P::sum(c1);
-    c2 = S->m ? P::sum(c2) : 0.0;
+    c2 = WK(m) ? P::sum(c2) : 0.0;
     S->nb_cache = static_cast<i32>(c1 + c2);
     return S->nb_cache;
   }
@@ -1224,11 +1262,11 @@ struct WaveIpm {
   DNLP_WFN DNLP_HD static void barrier_terms(WS* S, double muv) {
     W_P0();
     const WD* jt = jty(S);
-    WD *sx = S->Sx, *sS = S->Ss, *r = S->rx, *q = S->rs, *p = S->rp;
-    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *eq = S->eq, *xx = S->x, *ss = S->s, *a = S->zL, *b = S->zU, *c = S->vL,
-             *d = S->vU, *gr = S->grad, *yy = S->y, *gg = S->g, *fm = S->fixm;
+    WD *sx = WV(Sx), *sS = WV(Ss), *r = WV(rx), *q = WV(rs), *p = WV(rp);
+    const WD *l = WV(xL), *u = WV(xU), *sl = WV(sL), *su = WV(sU), *eq = WV(eq), *xx = WV(x), *ss = WV(s), *a = WV(zL), *b = WV(zU), *c = WV(vL),
+             *d = WV(vU), *gr = WV(grad), *yy = WV(y), *gg = WV(g), *fm = WV(fixm);
     const double kd = S->opt.kappa_d;
-    W_FOR(j, S->N) {
+    W_FOR(j, WK(N)) {
       double sig = 0.0, gphi = gr[j];
       const bool hl = l[j] > -kInf, hu = u[j] < kInf;
       if (hl) { sig += a[j] / (xx[j] - l[j]); gphi -= muv / (xx[j] - l[j]); }
@@ -1238,7 +1276,7 @@ struct WaveIpm {
       sx[j] = sig;
       r[j] = fm[j] != 0.0 ? 0.0 : gphi + jt[j];
     }
-    W_FOR(i, S->m) {
+    W_FOR(i, WK(m)) {
       if (eq[i] != 0.0) { sS[i] = 0.0; q[i] = 0.0; p[i] = gg[i] - sl[i]; continue; }
       double sig = 0.0, gphi = 0.0;
       const bool hl = sl[i] > -kInf, hu = su[i] < kInf;
@@ -1256,15 +1294,15 @@ struct WaveIpm {
   // Ipm::try_factor: 0 ok, 1 wrong inertia, 2 singular
   DNLP_HD static int try_factor(WS* S, double dw, double dc) {
     int nneg = 0, nzero = 0;
-    WD* dd = S->Dd;
-    const WD *sS = S->Ss, *eq = S->eq;
-    W_FOR(i, S->m) dd[i] = dc + (eq[i] == 0.0 ? 1.0 / fmax(sS[i] + dw, 1e-20) : 0.0);
+    WD* dd = WV(Dd);
+    const WD *sS = WV(Ss), *eq = WV(eq);
+    W_FOR(i, WK(m)) dd[i] = dc + (eq[i] == 0.0 ? 1.0 / fmax(sS[i] + dw, 1e-20) : 0.0);
     P::sync();
-    const bool ok = assemble_factor(S, S->Sx, S->Dd, dw, false, &nneg, &nzero);
+    const bool ok = assemble_factor(S, WV(Sx), WV(Dd), dw, false, &nneg, &nzero);
     S->last_nneg = nneg;
     if (!ok) return 2;
     if (nzero > 0) return 2;
-    return nneg == S->m ? 0 : 1;
+    return nneg == WK(m) ? 0 : 1;
   }
   // Ipm::factor_with_inertia (WB Algorithm IC; no Lanczos bound: host-driven large dense systems only)
   DNLP_HD static bool factor_with_inertia(WS* S, double& delta_w, double& delta_c) {
@@ -1280,10 +1318,10 @@ struct WaveIpm {
     const double dc_val = dc_bar * std::pow(S->mu, kc);
     int r = try_factor(S, 0.0, S->always_dc ? dc_val : 0.0);
     if (S->always_dc) delta_c = dc_val;
-    const bool can_fallback = (S->N + S->m) <= S->fallback_max_n;
+    const bool can_fallback = (WK(N) + WK(m)) <= S->fallback_max_n;
     if (r == 2 && !S->always_dc && can_fallback && (!S->opt.lazy_dense_fallback || S->ladder_rung > 0)) {
       ++S->sparse_singular_streak;
-      if ((S->N + S->m) <= 512 || (S->iter >= 1 && S->sparse_singular_streak >= 2)) {
+      if ((WK(N) + WK(m)) <= 512 || (S->iter >= 1 && S->sparse_singular_streak >= 2)) {
         S->bail = true;                    // the generic kernel's Bunch-Kaufman path takes this instance
         return false;
       }
@@ -1329,7 +1367,7 @@ struct WaveIpm {
     S->dc_fixed_last = true;
     if (++S->dc_fixed_count >= 3 && !S->always_dc) S->always_dc = true;
   }
-  // the long outputs of a product by output (more than CooIdx::kHeavy entries), by all lanes: out[g] for those only
+  // the long outputs of a product by output (more than kCooHeavy entries), by all lanes: out[g] for those only
   DNLP_HD static void coo_heavy(const WCoo ix, const WD* a, const WD* v, WD* out) {
     WI *ptr = ix.ptr, *ent = ix.ent, *src = ix.src;
     for (i32 hq = 0; hq < ix.nheavy; ++hq) {
@@ -1344,7 +1382,7 @@ struct WaveIpm {
   // one output of a product by output: its short segment walked here, or the value coo_heavy left in `pre`
   DNLP_HD static double coo_one(const WCoo& ix, const WD* a, const WD* v, const WD* pre, int gq) {
     const i32 p0 = ix.ptr[gq], p1 = ix.ptr[gq + 1];
-    if (p1 - p0 > static_cast<i32>(CooIdx::kHeavy)) return pre[gq];
+    if (p1 - p0 > static_cast<i32>(kCooHeavy)) return pre[gq];
     double sacc = 0.0;
     for (i32 p = p0; p < p1; ++p) sacc += a[ix.ent[p]] * v[ix.src[p]];
     return sacc;
@@ -1360,17 +1398,17 @@ struct WaveIpm {
     auto& en = S->o_d[1];
     auto& sn = S->o_d[2];
     W_P0();
-    const int N = S->N, m = S->m;
-    const WCoo hs = S->hs, jc = S->jc, jr = S->jr;
-    const WD *Hs = S->Hs, *jv = S->jv;
-    WD *preH = out, *preJt = S->xt, *preJ = S->tM;
+    const int N = WK(N), m = WK(m);
+    const WCoo hs = WCOO(hs), jc = WCOO(jc), jr = WCOO(jr);
+    const WD *Hs = WV(Hs), *jv = WV(jv);
+    WD *preH = out, *preJt = WV(xt), *preJ = WV(tM);
     if (hs.nheavy | jc.nheavy | jr.nheavy) {
       coo_heavy(hs, Hs, v, preH);
       coo_heavy(jc, jv, v + N, preJt);
       coo_heavy(jr, jv, v, preJ);
       P::sync();
     }
-    const WD *sx = S->Sx, *dd = S->Dd, *fm = S->fixm;
+    const WD *sx = WV(Sx), *dd = WV(Dd), *fm = WV(fixm);
     double m0 = -kInf, m1 = -kInf;
     W_FOR(k, N) {
       const double hv = coo_one(hs, Hs, v, preH, k), jt = coo_one(jc, jv, v + N, preJt, k);
@@ -1394,28 +1432,28 @@ struct WaveIpm {
   struct Res2 { double en, sn, en2, sn2; };
   DNLP_WFN DNLP_HD static Res2 kkt_residual2(WS* S, double dw, const WD* v, const WD* rhsv, WD* out, const WD* v2, const WD* rhsv2, WD* out2) {
     W_P0();
-    const int N = S->N, m = S->m;
-    const WCoo hs = S->hs, jc = S->jc, jr = S->jr;
-    const WD *Hs = S->Hs, *jv = S->jv;
-    WD *preH = out, *preJt = S->xt, *preJ = S->tM, *preH2 = out2, *preJt2 = S->dx, *preJ2 = S->ds;
+    const int N = WK(N), m = WK(m);
+    const WCoo hs = WCOO(hs), jc = WCOO(jc), jr = WCOO(jr);
+    const WD *Hs = WV(Hs), *jv = WV(jv);
+    WD *preH = out, *preJt = WV(xt), *preJ = WV(tM), *preH2 = out2, *preJt2 = WV(dx), *preJ2 = WV(ds);
     if (hs.nheavy | jc.nheavy | jr.nheavy) {
       coo_heavy(hs, Hs, v, preH); coo_heavy(jc, jv, v + N, preJt); coo_heavy(jr, jv, v, preJ);
       coo_heavy(hs, Hs, v2, preH2); coo_heavy(jc, jv, v2 + N, preJt2); coo_heavy(jr, jv, v2, preJ2);
       P::sync();
     }
-    const WD *sx = S->Sx, *dd = S->Dd, *fm = S->fixm;
+    const WD *sx = WV(Sx), *dd = WV(Dd), *fm = WV(fixm);
     double m0 = -kInf, m1 = -kInf, n0 = -kInf, n1 = -kInf;
     W_FOR(k, N) {
       // both systems' segments in one walk: the entry and source indices are loaded once
       double hv, jt, hv2, jt2;
       {
         const i32 p0 = hs.ptr[k], p1 = hs.ptr[k + 1];
-        if (p1 - p0 > static_cast<i32>(CooIdx::kHeavy)) { hv = preH[k]; hv2 = preH2[k]; }
+        if (p1 - p0 > static_cast<i32>(kCooHeavy)) { hv = preH[k]; hv2 = preH2[k]; }
         else { double a = 0.0, b = 0.0; for (i32 p = p0; p < p1; ++p) { const double c = Hs[hs.ent[p]]; const i32 u = hs.src[p]; a += c * v[u]; b += c * v2[u]; } hv = a; hv2 = b; }
       }
       {
         const i32 p0 = jc.ptr[k], p1 = jc.ptr[k + 1];
-        if (p1 - p0 > static_cast<i32>(CooIdx::kHeavy)) { jt = preJt[k]; jt2 = preJt2[k]; }
+        if (p1 - p0 > static_cast<i32>(kCooHeavy)) { jt = preJt[k]; jt2 = preJt2[k]; }
         else { double a = 0.0, b = 0.0; for (i32 p = p0; p < p1; ++p) { const double c = jv[jc.ent[p]]; const i32 u = N + jc.src[p]; a += c * v[u]; b += c * v2[u]; } jt = a; jt2 = b; }
       }
       const bool fx = fm[k] != 0.0;
@@ -1431,7 +1469,7 @@ struct WaveIpm {
       double jx, jx2;
       {
         const i32 p0 = jr.ptr[i], p1 = jr.ptr[i + 1];
-        if (p1 - p0 > static_cast<i32>(CooIdx::kHeavy)) { jx = preJ[i]; jx2 = preJ2[i]; }
+        if (p1 - p0 > static_cast<i32>(kCooHeavy)) { jx = preJ[i]; jx2 = preJ2[i]; }
         else { double a = 0.0, b = 0.0; for (i32 p = p0; p < p1; ++p) { const double c = jv[jr.ent[p]]; const i32 u = jr.src[p]; a += c * v[u]; b += c * v2[u]; } jx = a; jx2 = b; }
       }
       const double kv = jx - dd[i] * v[k], kv2 = jx2 - dd[i] * v2[k];
@@ -1448,9 +1486,9 @@ struct WaveIpm {
   }
   // Ipm::solve_refined
   DNLP_WFN DNLP_HD static bool solve_refined(WS* S, double dw) {
-    const int n = S->N + S->m;
-    kkt_solve(S, S->rhs, S->sol);
-    const WD* rr = S->rhs;
+    const int n = WK(N) + WK(m);
+    kkt_solve(S, WV(rhs), WV(sol));
+    const WD* rr = WV(rhs);
     double rn = -kInf;
     W_FOR(i, n) rn = mxin(rn, fabs(rr[i]));
     rn = P::vmax(rn);
@@ -1458,7 +1496,7 @@ struct WaveIpm {
     bool fresh = false;
     for (int it = 0; it < S->opt.max_refine; ++it) {
       double en, sn;
-      kkt_residual(S, S->sol, dw, S->rhs, S->res, en, sn);
+      kkt_residual(S, WV(sol), dw, WV(rhs), WV(res), en, sn);
       const double ratio = en / (std::max(rn, 1e-300) + sn);
       if (!std::isfinite(en)) return false;
       S->last_ratio = std::isfinite(ratio) ? ratio : kInf;
@@ -1466,16 +1504,16 @@ struct WaveIpm {
       if (it >= S->opt.min_refine && ratio <= 1e-10) break;
       if (en >= best * 0.999 && it >= S->opt.min_refine) break;
       best = std::min(best, en);
-      kkt_solve(S, S->res, S->cor);
-      WD* sw = S->sol;
-      const WD* co = S->cor;
+      kkt_solve(S, WV(res), WV(cor));
+      WD* sw = WV(sol);
+      const WD* co = WV(cor);
       W_FOR(i, n) sw[i] += co[i];
       P::sync();
       fresh = false;
     }
     if (!fresh) {
       double en, sn;
-      kkt_residual(S, S->sol, dw, S->rhs, S->res, en, sn);
+      kkt_residual(S, WV(sol), dw, WV(rhs), WV(res), en, sn);
       S->last_ratio = en / (std::max(rn, 1e-300) + sn);
       if (!std::isfinite(S->last_ratio)) S->last_ratio = kInf;
     }
@@ -1493,8 +1531,8 @@ struct WaveIpm {
   DNLP_WFN DNLP_HD static int solve_refined2_impl(WS* S, double dw, WD* rhs2, WD* sol2, WD* res2) {
     auto& ratio_out = S->o_d[3];
     auto& ratio2_out = S->o_d[4];
-    const int n = S->N + S->m;
-    WD *rhs = S->rhs, *sol = S->sol, *res = S->res, *cor = S->cor;
+    const int n = WK(N) + WK(m);
+    WD *rhs = WV(rhs), *sol = WV(sol), *res = WV(res), *cor = WV(cor);
     kkt_solve(S, rhs, sol, rhs2, sol2);
     double rn = -kInf, rn2 = -kInf;
     W_FOR(i, n) { rn = mxin(rn, fabs(rhs[i])); rn2 = mxin(rn2, fabs(rhs2[i])); }
@@ -1557,27 +1595,27 @@ struct WaveIpm {
   // Ipm::compute_direction; `set` picks the seven output arrays (0: dx .. dvU, 1: affine-scaling, 2: centering);
   // pres == nullptr stands for the all-zero primal residual of the centering system
   DNLP_WFN DNLP_HD static bool compute_direction(WS* S, double muv, const WD* pres, double dw, bool centering, int set) {
-    const int N = S->N, m = S->m;
-    WD* r = S->rhs;
-    const WD *rxx = S->rx, *q = S->rs, *sS = S->Ss, *eq = S->eq;
+    const int N = WK(N), m = WK(m);
+    WD* r = WV(rhs);
+    const WD *rxx = WV(rx), *q = WV(rs), *sS = WV(Ss), *eq = WV(eq);
     { W_P0();
     W_FOR(k, N) r[k] = -rxx[k];
     W_FOR(i, m) r[N + i] = -(pres ? pres[i] : 0.0) - (eq[i] == 0.0 ? q[i] / (sS[i] + dw) : 0.0);
     P::sync();
     W_P1(11); }
     { W_P0(); const bool oks = solve_refined(S, dw); W_P1(21); if (!oks) return false; }
-    direction_outputs(S, S->sol, S->rs, muv, dw, centering, set);
+    direction_outputs(S, WV(sol), WV(rs), muv, dw, centering, set);
     return true;
   }
   // the second half of Ipm::compute_direction: the seven arrays of a direction from the solution `so` of its system
   // (q: the slack residual the system was built with).  so / q may be the output arrays themselves (read before written).
   DNLP_HD static void direction_outputs(WS* S, const WD* so, const WD* q, double muv, double dw, bool centering, int set) {
     W_P0();
-    const int N = S->N, m = S->m;
-    const WD *sS = S->Ss, *eq = S->eq;
-    WD *ddx = S->dir[set][0], *dds = S->dir[set][1], *ddy = S->dir[set][2], *da = S->dir[set][3], *db = S->dir[set][4], *dc = S->dir[set][5],
-       *dd2 = S->dir[set][6];
-    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *xx = S->x, *ss = S->s, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU;
+    const int N = WK(N), m = WK(m);
+    const WD *sS = WV(Ss), *eq = WV(eq);
+    WD *ddx = WDIR(set, 0), *dds = WDIR(set, 1), *ddy = WDIR(set, 2), *da = WDIR(set, 3), *db = WDIR(set, 4), *dc = WDIR(set, 5),
+       *dd2 = WDIR(set, 6);
+    const WD *l = WV(xL), *u = WV(xU), *sl = WV(sL), *su = WV(sU), *xx = WV(x), *ss = WV(s), *a = WV(zL), *b = WV(zU), *c = WV(vL), *d = WV(vU);
     const double keep = centering ? 0.0 : 1.0;
     W_FOR(j, N) {
       const double dxj = so[j];
@@ -1599,15 +1637,15 @@ struct WaveIpm {
   }
   // Ipm::max_step_primal
   DNLP_HD static double max_step_primal(WS* S, double tauv) {
-    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *xx = S->x, *ss = S->s, *ddx = S->dx, *dds = S->ds, *eq = S->eq;
+    const WD *l = WV(xL), *u = WV(xU), *sl = WV(sL), *su = WV(sU), *xx = WV(x), *ss = WV(s), *ddx = WV(dx), *dds = WV(ds), *eq = WV(eq);
     double ax = -kInf, as = -kInf;
-    W_FOR(j, S->N) {
+    W_FOR(j, WK(N)) {
       double a = 1.0;
       if (l[j] > -kInf && ddx[j] < 0.0) a = fmin(a, -tauv * (xx[j] - l[j]) / ddx[j]);
       if (u[j] < kInf && ddx[j] > 0.0) a = fmin(a, tauv * (u[j] - xx[j]) / ddx[j]);
       ax = mnin(ax, a);
     }
-    W_FOR(i, S->m) {
+    W_FOR(i, WK(m)) {
       double a = 1.0;
       if (eq[i] == 0.0) {
         if (sl[i] > -kInf && dds[i] < 0.0) a = fmin(a, -tauv * (ss[i] - sl[i]) / dds[i]);
@@ -1615,35 +1653,35 @@ struct WaveIpm {
       }
       as = mnin(as, a);
     }
-    const double rx_ = -P::vmax(ax), rs_ = S->m ? -P::vmax(as) : 1.0;
+    const double rx_ = -P::vmax(ax), rs_ = WK(m) ? -P::vmax(as) : 1.0;
     return std::min(1.0, std::min(rx_, rs_));
   }
   // Ipm::max_step_dual
   DNLP_HD static double max_step_dual(WS* S, double tauv) {
-    const WD *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU, *da = S->dzL, *db = S->dzU, *dc = S->dvL, *dd2 = S->dvU;
+    const WD *a = WV(zL), *b = WV(zU), *c = WV(vL), *d = WV(vU), *da = WV(dzL), *db = WV(dzU), *dc = WV(dvL), *dd2 = WV(dvU);
     double az = -kInf, av = -kInf;
-    W_FOR(j, S->N) {
+    W_FOR(j, WK(N)) {
       double t = 1.0;
       if (da[j] < 0.0) t = fmin(t, -tauv * a[j] / da[j]);
       if (db[j] < 0.0) t = fmin(t, -tauv * b[j] / db[j]);
       az = mnin(az, t);
     }
-    W_FOR(i, S->m) {
+    W_FOR(i, WK(m)) {
       double t = 1.0;
       if (dc[i] < 0.0) t = fmin(t, -tauv * c[i] / dc[i]);
       if (dd2[i] < 0.0) t = fmin(t, -tauv * d[i] / dd2[i]);
       av = mnin(av, t);
     }
-    const double rz = -P::vmax(az), rv = S->m ? -P::vmax(av) : 1.0;
+    const double rz = -P::vmax(az), rv = WK(m) ? -P::vmax(av) : 1.0;
     return std::min(1.0, std::min(rz, rv));
   }
   // Ipm::max_steps: both fraction-to-boundary step sizes in one pass
   DNLP_WFN DNLP_HD static D2 max_steps(WS* S, double tauv) {
-    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *xx = S->x, *ss = S->s, *ddx = S->dx, *dds = S->ds, *eq = S->eq;
-    const WD *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU, *da = S->dzL, *db = S->dzU, *dc = S->dvL, *dd2 = S->dvU;
+    const WD *l = WV(xL), *u = WV(xU), *sl = WV(sL), *su = WV(sU), *xx = WV(x), *ss = WV(s), *ddx = WV(dx), *dds = WV(ds), *eq = WV(eq);
+    const WD *a = WV(zL), *b = WV(zU), *c = WV(vL), *d = WV(vU), *da = WV(dzL), *db = WV(dzU), *dc = WV(dvL), *dd2 = WV(dvU);
     W_P0();
     double a0 = -kInf, a1 = -kInf;
-    W_FOR(j, S->N) {
+    W_FOR(j, WK(N)) {
       double tp = 1.0, td = 1.0;
       if (l[j] > -kInf && ddx[j] < 0.0) tp = fmin(tp, -tauv * (xx[j] - l[j]) / ddx[j]);
       if (u[j] < kInf && ddx[j] > 0.0) tp = fmin(tp, tauv * (u[j] - xx[j]) / ddx[j]);
@@ -1651,7 +1689,7 @@ struct WaveIpm {
       if (db[j] < 0.0) td = fmin(td, -tauv * b[j] / db[j]);
       a0 = mnin(a0, tp); a1 = mnin(a1, td);
     }
-    W_FOR(i, S->m) {
+    W_FOR(i, WK(m)) {
       double tp = 1.0, td = 1.0;
       if (eq[i] == 0.0) {
         if (sl[i] > -kInf && dds[i] < 0.0) tp = fmin(tp, -tauv * (ss[i] - sl[i]) / dds[i]);
@@ -1691,7 +1729,7 @@ struct WaveIpm {
   // (inlined into its callers' loops: as a called function it saved and restored ~75 callee-saved VGPRs per iteration —
   //  150 scratch operations, 22 KB of HBM writes per iteration over the launch)
   DNLP_WINL DNLP_HD static int step(WS* S) {
-    const int N = S->N, m = S->m;
+    const int N = WK(N), m = WK(m);
     if (!S->initialized) return S->status = Internal_Error;
     const WErr e0 = S->e_cached_valid ? cached_err(S) : error(S, 0.0);
     S->e_cached_valid = false;
@@ -1700,7 +1738,7 @@ struct WaveIpm {
     if (S->iter >= S->opt.max_iter) return S->status = Maximum_Iterations_Exceeded;
     if (now_sec() - S->t_begin > S->opt.max_wall_time) return S->status = Maximum_WallTime_Exceeded;
     {
-      const WD* xx = S->x;
+      const WD* xx = WV(x);
       double xm = -kInf;
       W_FOR(j, N) xm = mxin(xm, fabs(xx[j]));
       xm = P::vmax(xm);
@@ -1716,7 +1754,7 @@ struct WaveIpm {
     if (want_oracle) { W_P0(); have_dir = quality_function_mu(S, dw); W_P1(20); }
     if (!have_dir) {
       barrier_terms(S, S->mu);
-      if (!compute_direction(S, S->mu, S->rp, dw, false, 0)) return S->status = Error_In_Step_Computation;
+      if (!compute_direction(S, S->mu, WV(rp), dw, false, 0)) return S->status = Error_In_Step_Computation;
     }
     for (int tries = 0; tries < 6 && S->last_ratio > 1e-5; ++tries) {
       if (dc == 0.0) dc = 1e-8 * std::pow(S->mu, 0.25);
@@ -1726,7 +1764,7 @@ struct WaveIpm {
       if (r != 0) return S->status = Error_In_Step_Computation;
       S->delta_w_last = dw;
       barrier_terms(S, S->mu);
-      if (!compute_direction(S, S->mu, S->rp, dw, false, 0)) return S->status = Error_In_Step_Computation;
+      if (!compute_direction(S, S->mu, WV(rp), dw, false, 0)) return S->status = Error_In_Step_Computation;
     }
     // ---- backtracking filter line search (WB Algorithm A, steps A-5) ----
     const double mu = S->mu, tau = S->tau;
@@ -1734,11 +1772,11 @@ struct WaveIpm {
     const D2 steps = max_steps(S, tau);
     const double a_max = steps.first;
     double a_z = steps.second;
-    const WMeasures mk = measures(S, S->f, S->g, S->x, S->s, mu);
+    const WMeasures mk = measures(S, S->f, WV(g), WV(x), WV(s), mu);
     const double theta_k = mk.theta, phi_k = mk.phi;
     double gphid;
     {
-      const WD *rxx = S->rx, *ddx = S->dx, *q = S->rs, *yy = S->y, *dds = S->ds, *eq = S->eq;
+      const WD *rxx = WV(rx), *ddx = WV(dx), *q = WV(rs), *yy = WV(y), *dds = WV(ds), *eq = WV(eq);
       const WD* jt = jty(S);
       double acc = 0.0;
       W_FOR(k, N) acc += (rxx[k] - jt[k]) * ddx[k];
@@ -1766,10 +1804,10 @@ struct WaveIpm {
       bool fin;
       { W_P0();
       trial_point(S, alpha);
-      fin = eval_fg(S, S->xt, f_t, S->gt);
+      fin = eval_fg(S, WV(xt), f_t, WV(gt));
       W_P1(13); }
       if (fin) {
-        const WMeasures mt = measures(S, f_t, S->gt, S->xt, S->st, mu);
+        const WMeasures mt = measures(S, f_t, WV(gt), WV(xt), WV(st), mu);
         th_t = mt.theta;
         ph_t = mt.phi;
         fin = mt.chk == 0.0 && std::isfinite(th_t) && std::isfinite(ph_t);
@@ -1790,7 +1828,7 @@ struct WaveIpm {
           a_z = max_step_dual(S, tau);
           break;
         }
-        compute_direction(S, mu, S->rp, dw, false, 0);
+        compute_direction(S, mu, WV(rp), dw, false, 0);
       }
       alpha *= 0.5;
       if (alpha < a_min || ls > 60) break;
@@ -1804,7 +1842,7 @@ struct WaveIpm {
         return 99;
       }
       if (S->bail) return S->status = Error_In_Step_Computation;
-      const WD* ddx = S->dx;
+      const WD* ddx = WV(dx);
       double dn = -kInf;
       W_FOR(j, N) dn = mxin(dn, fabs(ddx[j]));
       dn = P::vmax(dn);
@@ -1836,19 +1874,19 @@ struct WaveIpm {
 
   // Ipm::trial_point
   DNLP_HD static void trial_point(WS* S, double alpha) {
-    WD *a = S->xt, *b = S->st;
-    const WD *xx = S->x, *ss = S->s, *ddx = S->dx, *dds = S->ds, *eq = S->eq, *sl = S->sL;
-    W_FOR(k, S->N) a[k] = xx[k] + alpha * ddx[k];
-    W_FOR(i, S->m) b[i] = eq[i] != 0.0 ? sl[i] : ss[i] + alpha * dds[i];
+    WD *a = WV(xt), *b = WV(st);
+    const WD *xx = WV(x), *ss = WV(s), *ddx = WV(dx), *dds = WV(ds), *eq = WV(eq), *sl = WV(sL);
+    W_FOR(k, WK(N)) a[k] = xx[k] + alpha * ddx[k];
+    W_FOR(i, WK(m)) b[i] = eq[i] != 0.0 ? sl[i] : ss[i] + alpha * dds[i];
     P::sync();
   }
   // Ipm::accept_trial (+ reset_bound_multipliers, WB eq. (16), after the derivatives as there)
   DNLP_WFN DNLP_HD static void accept_trial(WS* S, double alpha, double a_z, double f_new) {
     W_P0();
-    const int N = S->N, m = S->m;
+    const int N = WK(N), m = WK(m);
     {
-      WD *xx = S->x, *ss = S->s, *yy = S->y, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU, *gg = S->g;
-      const WD *nx = S->xt, *ns = S->st, *ddy = S->dy, *da = S->dzL, *db = S->dzU, *dc = S->dvL, *dd2 = S->dvU, *gn = S->gt;
+      WD *xx = WV(x), *ss = WV(s), *yy = WV(y), *a = WV(zL), *b = WV(zU), *c = WV(vL), *d = WV(vU), *gg = WV(g);
+      const WD *nx = WV(xt), *ns = WV(st), *ddy = WV(dy), *da = WV(dzL), *db = WV(dzU), *dc = WV(dvL), *dd2 = WV(dvU), *gn = WV(gt);
       W_FOR(j, N) { xx[j] = nx[j]; a[j] += a_z * da[j]; b[j] += a_z * db[j]; }
       W_FOR(i, m) { ss[i] = ns[i]; yy[i] += alpha * ddy[i]; c[i] += a_z * dc[i]; d[i] += a_z * dd2[i]; gg[i] = gn[i]; }
       P::sync();
@@ -1856,7 +1894,7 @@ struct WaveIpm {
     S->f = f_new;
     // (Ipm::accept_trial sweeps again "in case a later trial was evaluated": the accepted point IS the last one evaluated
     //  on every path that gets here, and then z / dvals are already those of x — the same values, one sweep less)
-    if (!S->swept_xt) sweep(S, S->x, false);
+    if (!S->swept_xt) sweep(S, WV(x), false);
     S->swept_xt = false;
     eval_derivs(S);
     reset_bound_multipliers(S);
@@ -1864,13 +1902,13 @@ struct WaveIpm {
   }
   DNLP_HD static void reset_bound_multipliers(WS* S) {
     const double kS = 1e10, muv = S->mu;
-    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *xx = S->x, *ss = S->s, *eq = S->eq;
-    WD *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU;
-    W_FOR(j, S->N) {
+    const WD *l = WV(xL), *u = WV(xU), *sl = WV(sL), *su = WV(sU), *xx = WV(x), *ss = WV(s), *eq = WV(eq);
+    WD *a = WV(zL), *b = WV(zU), *c = WV(vL), *d = WV(vU);
+    W_FOR(j, WK(N)) {
       if (l[j] > -kInf) { const double t = xx[j] - l[j]; a[j] = fmax(fmin(a[j], kS * muv / t), muv / (kS * t)); }
       if (u[j] < kInf) { const double t = u[j] - xx[j]; b[j] = fmax(fmin(b[j], kS * muv / t), muv / (kS * t)); }
     }
-    W_FOR(i, S->m) {
+    W_FOR(i, WK(m)) {
       if (eq[i] != 0.0) continue;
       if (sl[i] > -kInf) { const double t = ss[i] - sl[i]; c[i] = fmax(fmin(c[i], kS * muv / t), muv / (kS * t)); }
       if (su[i] < kInf) { const double t = su[i] - ss[i]; d[i] = fmax(fmin(d[i], kS * muv / t), muv / (kS * t)); }
@@ -1893,22 +1931,22 @@ struct WaveIpm {
     const double k_soc = 0.99, g_th = 1e-5, g_ph = 1e-8, dlt = 1.0, s_th = 1.1, s_ph = 2.3, eta = 1e-8;
     const double macheps = 2.220446049250313e-16;
     auto le = [&](double a, double b, double base) { return a - b <= 10.0 * macheps * std::fabs(base); };
-    const int m = S->m;
-    WD* cs = S->csoc;
-    const WD *p = S->rp, *eq = S->eq, *sl = S->sL;
+    const int m = WK(m);
+    WD* cs = WV(csoc);
+    const WD *p = WV(rp), *eq = WV(eq), *sl = WV(sL);
     {
-      const WD *gg = S->gt, *ss = S->st;
+      const WD *gg = WV(gt), *ss = WV(st);
       W_FOR(i, m) cs[i] = alpha * p[i] + (eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]);
       P::sync();
     }
     double th_old = th_t;
     for (int k = 0; k < S->opt.max_soc; ++k) {
-      if (!compute_direction(S, S->mu, S->csoc, dw, false, 0)) return false;
+      if (!compute_direction(S, S->mu, WV(csoc), dw, false, 0)) return false;
       const double a_soc = max_step_primal(S, S->tau);
       trial_point(S, a_soc);
       double fv;
-      if (!eval_fg(S, S->xt, fv, S->gt) || nan_check(S, S->gt) != 0.0) return false;
-      const double th = theta_at(S, S->gt, S->st), ph = barrier_at(S, fv, S->xt, S->st, S->mu);
+      if (!eval_fg(S, WV(xt), fv, WV(gt)) || nan_check(S, WV(gt)) != 0.0) return false;
+      const double th = theta_at(S, WV(gt), WV(st)), ph = barrier_at(S, fv, WV(xt), WV(st), S->mu);
       if (!std::isfinite(th) || !std::isfinite(ph)) return false;
       if (th <= S->theta_max && filter_ok(S, th, ph)) {
         const bool sw = gphid < 0.0 && alpha * std::pow(-gphid, s_ph) > dlt * std::pow(theta_k, s_th);
@@ -1922,7 +1960,7 @@ struct WaveIpm {
       }
       if (th > k_soc * th_old) return false;
       th_old = th;
-      const WD *gg2 = S->gt, *ss2 = S->st;
+      const WD *gg2 = WV(gt), *ss2 = WV(st);
       W_FOR(i, m) cs[i] = a_soc * cs[i] + (eq[i] != 0.0 ? gg2[i] - sl[i] : gg2[i] - ss2[i]);
       P::sync();
     }
@@ -1933,15 +1971,15 @@ struct WaveIpm {
   DNLP_HD static double avg_complementarity(WS* S) {
     const i64 nb = n_bound_mults(S);
     if (nb == 0) return 0.0;
-    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *xx = S->x, *ss = S->s, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU, *eq = S->eq;
+    const WD *l = WV(xL), *u = WV(xU), *sl = WV(sL), *su = WV(sU), *xx = WV(x), *ss = WV(s), *a = WV(zL), *b = WV(zU), *c = WV(vL), *d = WV(vU), *eq = WV(eq);
     double acc = 0.0;
-    W_FOR(j, S->N) {
+    W_FOR(j, WK(N)) {
       double v = 0.0;
       if (l[j] > -kInf) v += (xx[j] - l[j]) * a[j];
       if (u[j] < kInf) v += (u[j] - xx[j]) * b[j];
       acc += v;
     }
-    W_FOR(i, S->m) {
+    W_FOR(i, WK(m)) {
       double v = 0.0;
       if (eq[i] == 0.0) {
         if (sl[i] > -kInf) v += (ss[i] - sl[i]) * c[i];
@@ -2012,10 +2050,10 @@ struct WaveIpm {
     W_P0();
     const double mus = sigma * avg;
     const double tv = std::max(0.99, 1.0 - mus);
-    const WD *ax = S->dir[1][0], *as = S->dir[1][1], *aa = S->dir[1][3], *ab = S->dir[1][4], *ac = S->dir[1][5], *ad = S->dir[1][6];
-    const WD *cx = S->dir[2][0], *cs = S->dir[2][1], *ca = S->dir[2][3], *cb = S->dir[2][4], *cc = S->dir[2][5], *cd = S->dir[2][6];
-    const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *eq = S->eq, *xx = S->x, *ss = S->s, *a = S->zL, *b = S->zU, *c = S->vL, *d = S->vU;
-    const int N = S->N, m = S->m;
+    const WD *ax = WDIR(1, 0), *as = WDIR(1, 1), *aa = WDIR(1, 3), *ab = WDIR(1, 4), *ac = WDIR(1, 5), *ad = WDIR(1, 6);
+    const WD *cx = WDIR(2, 0), *cs = WDIR(2, 1), *ca = WDIR(2, 3), *cb = WDIR(2, 4), *cc = WDIR(2, 5), *cd = WDIR(2, 6);
+    const WD *l = WV(xL), *u = WV(xU), *sl = WV(sL), *su = WV(sU), *eq = WV(eq), *xx = WV(x), *ss = WV(s), *a = WV(zL), *b = WV(zU), *c = WV(vL), *d = WV(vU);
+    const int N = WK(N), m = WK(m);
     double a0 = -kInf, a1 = -kInf;
     W_FOR(j, N) {
       double tp = 1.0, td = 1.0;
@@ -2085,7 +2123,7 @@ struct WaveIpm {
   }
   // Ipm::quality_function_mu
   DNLP_WFN DNLP_HD static bool quality_function_mu(WS* S, double dw) {
-    const int N = S->N, m = S->m;
+    const int N = WK(N), m = WK(m);
     W_P0();
     const double avg = avg_complementarity(S);
     const i64 nb = n_bound_mults(S);
@@ -2094,7 +2132,7 @@ struct WaveIpm {
     barrier_terms(S, 0.0);
     double nd2, np2;
     {
-      const WD *rxx = S->rx, *rss = S->rs, *rpp = S->rp;
+      const WD *rxx = WV(rx), *rss = WV(rs), *rpp = WV(rp);
       double s0 = 0.0, s1 = 0.0;
       W_FOR(k, N) s0 += rxx[k] * rxx[k];
       W_FOR(i, m) { s0 += rss[i] * rss[i]; s1 += rpp[i] * rpp[i]; }
@@ -2106,12 +2144,12 @@ struct WaveIpm {
     // derivative of the barrier terms) — share the factor: both right-hand sides first, ONE refined joint solve
     // (solve_refined2), then the two directions.  The centering system lives in the arrays of its own direction until
     // that is written: rhs2 = [czL | cvL], sol2 = [cx | cs], res2 = [czU | cvU], its slack residual in cy.
-    WD *rhs2 = S->dir[2][3], *sol2 = S->dir[2][0], *res2 = S->dir[2][4], *q2 = S->dir[2][2];
+    WD *rhs2 = WDIR(2, 3), *sol2 = WDIR(2, 0), *res2 = WDIR(2, 4), *q2 = WDIR(2, 2);
     {
       W_P0();
-      WD* r = S->rhs;
-      const WD *rxx = S->rx, *q = S->rs, *pres = S->rp, *sS = S->Ss, *eq = S->eq;
-      const WD *l = S->xL, *u = S->xU, *sl = S->sL, *su = S->sU, *xx = S->x, *ss = S->s, *fm = S->fixm;
+      WD* r = WV(rhs);
+      const WD *rxx = WV(rx), *q = WV(rs), *pres = WV(rp), *sS = WV(Ss), *eq = WV(eq);
+      const WD *l = WV(xL), *u = WV(xU), *sl = WV(sL), *su = WV(sU), *xx = WV(x), *ss = WV(s), *fm = WV(fixm);
       const double kd = S->opt.kappa_d;
       W_FOR(j, N) {
         r[j] = -rxx[j];
@@ -2147,7 +2185,7 @@ struct WaveIpm {
       W_P1(21);
       if (rc != 0) return false;
     }
-    direction_outputs(S, S->sol, S->rs, 0.0, dw, false, 1);
+    direction_outputs(S, WV(sol), WV(rs), 0.0, dw, false, 1);
     direction_outputs(S, sol2, q2, 1.0, dw, true, 2);
     S->last_ratio = ratio_cen;
     if (ratio_aff > S->last_ratio) S->last_ratio = ratio_aff;
@@ -2193,8 +2231,8 @@ struct WaveIpm {
     const double muv = S->mu;
     {
       for (int k = 0; k < 7; ++k) {
-        WD* o = S->dir[0][k];
-        const WD *av = S->dir[1][k], *cv = S->dir[2][k];
+        WD* o = WDIR(0, k);
+        const WD *av = WDIR(1, k), *cv = WDIR(2, k);
         const int n = (k == 0 || k == 3 || k == 4) ? N : m;
         W_FOR(i, n) o[i] = av[i] + muv * cv[i];
       }
@@ -2205,31 +2243,31 @@ struct WaveIpm {
 
   // Ipm::restoration_phase
   DNLP_WFN DNLP_HD static bool restoration_phase(WS* S, double theta_k) {
-    const int N = S->N, m = S->m;
-    const double phi_k = barrier_at(S, S->f, S->x, S->s, S->mu);
+    const int N = WK(N), m = WK(m);
+    const double phi_k = barrier_at(S, S->f, WV(x), WV(s), S->mu);
     filter_add(S, (1.0 - 1e-5) * theta_k, phi_k - 1e-8 * theta_k);
     double th_cur = theta_k;
     double zeta = std::sqrt(S->mu);
     S->resto_stationary = false;
     S->resto_theta = theta_k;
-    const WD *eq = S->eq, *sl = S->sL;
+    const WD *eq = WV(eq), *sl = WV(sL);
     for (int it = 0; it < 100; ++it) {
-      WD *sx = S->Sx, *dd = S->Dd;
+      WD *sx = WV(Sx), *dd = WV(Dd);
       const double zz = zeta;
       W_FOR(j, N) sx[j] = zz;
       W_FOR(i, m) dd[i] = 1.0 + (eq[i] == 0.0 ? 1.0 / zz : 0.0);
-      { WD* hs = S->Hs; W_FOR(p, S->nnzH) hs[p] = 0.0; }
+      { WD* hs = WV(Hs); W_FOR(p, WK(nnzH)) hs[p] = 0.0; }
       P::sync();
       int nneg = 0, nzero = 0;
-      if (!assemble_factor(S, S->Sx, S->Dd, 0.0, true, &nneg, &nzero)) return false;
-      WD* r = S->rhs;
-      const WD *gg = S->g, *ss = S->s;
+      if (!assemble_factor(S, WV(Sx), WV(Dd), 0.0, true, &nneg, &nzero)) return false;
+      WD* r = WV(rhs);
+      const WD *gg = WV(g), *ss = WV(s);
       W_FOR(j, N) r[j] = 0.0;
       W_FOR(i, m) r[N + i] = -(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]);
       P::sync();
-      kkt_solve(S, S->rhs, S->sol);
-      const WD* so = S->sol;
-      WD *ddx = S->dx, *dds = S->ds;
+      kkt_solve(S, WV(rhs), WV(sol));
+      const WD* so = WV(sol);
+      WD *ddx = WV(dx), *dds = WV(ds);
       W_FOR(j, N) ddx[j] = so[j];
       W_FOR(i, m) dds[i] = eq[i] == 0.0 ? so[N + i] / zz : 0.0;
       P::sync();
@@ -2238,11 +2276,11 @@ struct WaveIpm {
       for (int bt = 0; bt < 30; ++bt) {
         trial_point(S, a);
         double fv;
-        if (eval_fg(S, S->xt, fv, S->gt) && nan_check(S, S->gt) == 0.0) {
-          const double th = theta_at(S, S->gt, S->st);
+        if (eval_fg(S, WV(xt), fv, WV(gt)) && nan_check(S, WV(gt)) == 0.0) {
+          const double th = theta_at(S, WV(gt), WV(st));
           if (std::isfinite(th) && th < (1.0 - 1e-4 * a) * th_cur) {
-            WD *xx = S->x, *sv = S->s, *gv = S->g;
-            const WD *nx = S->xt, *ns = S->st, *gn = S->gt;
+            WD *xx = WV(x), *sv = WV(s), *gv = WV(g);
+            const WD *nx = WV(xt), *ns = WV(st), *gn = WV(gt);
             W_FOR(j, N) xx[j] = nx[j];
             W_FOR(i, m) { sv[i] = ns[i]; gv[i] = gn[i]; }
             P::sync();
@@ -2256,14 +2294,14 @@ struct WaveIpm {
       }
       if (!moved) { zeta *= 10.0; if (zeta > 1e8) { S->resto_stationary = true; S->resto_theta = th_cur; return false; } continue; }
       S->resto_theta = th_cur;
-      sweep(S, S->x, false);
+      sweep(S, WV(x), false);
       eval_derivs(S);
-      const double ph = barrier_at(S, S->f, S->x, S->s, S->mu);
+      const double ph = barrier_at(S, S->f, WV(x), WV(s), S->mu);
       if (th_cur <= 0.9 * theta_k && th_cur <= S->theta_max && filter_ok(S, th_cur, ph)) {
         S->jty_valid = false;
         const double zi = 1.0;
-        const WD *l = S->xL, *u = S->xU, *su = S->sU;
-        WD *za = S->zL, *zb = S->zU, *c = S->vL, *d = S->vU, *yy = S->y;
+        const WD *l = WV(xL), *u = WV(xU), *su = WV(sU);
+        WD *za = WV(zL), *zb = WV(zU), *c = WV(vL), *d = WV(vU), *yy = WV(y);
         W_FOR(j, N) { za[j] = (l[j] > -kInf) ? zi : 0.0; zb[j] = (u[j] < kInf) ? zi : 0.0; }
         W_FOR(i, m) {
           yy[i] = 0.0;
@@ -2281,8 +2319,8 @@ struct WaveIpm {
 
   // Ipm::polish
   DNLP_WFN DNLP_HD static void polish(WS* S) {
-    const int N = S->N, m = S->m;
-    WD* sv[7] = {S->x, S->s, S->y, S->zL, S->zU, S->vL, S->vU};
+    const int N = WK(N), m = WK(m);
+    WD* sv[7] = {WV(x), WV(s), WV(y), WV(zL), WV(zU), WV(vL), WV(vU)};
     const int sz[7] = {N, m, m, N, N, m, m};
     const int slot[7] = {0, 1, 2, 3, 4, 5, 6};
     int poff[8];
@@ -2307,7 +2345,7 @@ struct WaveIpm {
     for (int k = 0; k < 7; ++k) { const double* src = S->park + poff[k]; WD* dst = sv[k]; W_FOR(i, sz[k]) dst[i] = src[i]; }
     P::sync();
     S->mu = mu0; S->tau = tau0;
-    (void)eval_fg(S, S->x, S->f, S->g);
+    (void)eval_fg(S, WV(x), S->f, WV(g));
     eval_derivs(S);
     S->e_cached_valid = false;
     S->acceptable_count = 0;

@@ -5,10 +5,26 @@
 // reduction, each a dependent ~100-cycle trip through the LDS crossbar (~1 500 cycles per reduction; the
 // in-kernel interior-point loop did ~70 of them per iteration).  A DPP step is two v_mov_b32_dpp and the
 // operation: ~200 cycles for the whole reduction.  All 64 lanes must be active at the call.
+//
+// Free of standard-library includes: the text also travels inside the library (wave_ops_src.inc) into the per-template
+// kernels of wave_codegen.h.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace dnlp {
+
+// barrier of ONE wavefront: its LDS stores are visible to its own lanes afterwards (no workgroup barrier)
+__device__ inline void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+// lane l's value of v (l uniform), to every lane
+__device__ inline double readlane_d(double v, int l) {
+  l = __builtin_amdgcn_readfirstlane(l);
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
 
 // lane i <- lane (i - shift) of its row, or `keep` where there is no such lane / the row is masked off
 template <int CTRL, int ROW_MASK>

@@ -183,6 +183,28 @@ extern "C" int orc_wave_solve_batch(orc_problem* vp, int batch, const double* da
     return 0;)
 }
 
+// The text of a template's per-template kernel (dnlp_amd/csrc/wave_codegen.h), as the product library would hand it to
+// hiprtc: tests compile it for gfx950 without a GPU.  Returns the length of the text (0-terminated copy in buf when it fits),
+// a negative code when the template is not the wavefront solver's.
+#include "../dnlp_amd/csrc/wave_codegen.h"
+extern "C" long long orc_wave_spec_source(orc_problem* vp, int nw, char* buf, long long cap) {
+  using namespace dnlp;
+  orc_problem_t* p = vp;
+  DNLP_TRY(
+    p->plan_linear_solver();
+    const Tape<HostExec>& t = *p->model.owner;
+    if (!p->use_sparse) { tls_error() = "no sparse plan for this tape"; return -1; }
+    const char* why = wave_plan_refusal(t, &p->sparse_plan);
+    if (why[0]) { tls_error() = why; return -2; }
+    const std::vector<i32> blk = build_wave_plan(&p->ex, t, p->sparse_plan, wave_layout_of(t));
+    const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(blk.data());
+    const int fit = wave_spec_max_waves(h);
+    if (fit < 1) { tls_error() = "the template's state does not fit a compute unit's LDS"; return -3; }
+    const std::string src = wave_spec_source(blk, nw > 0 ? std::min(nw, fit) : fit);
+    if (buf && cap > static_cast<long long>(src.size())) { std::memcpy(buf, src.data(), src.size()); buf[src.size()] = 0; }
+    return static_cast<long long>(src.size());)
+}
+
 // plan statistics per level (tools / tests: what the wavefront solver's level phases are made of)
 extern "C" int orc_wave_plan_levels(orc_problem* vp, int32_t* out, int cap) {
   using namespace dnlp;

@@ -1,0 +1,115 @@
+"""The per-template batch kernel (dnlp_amd/csrc/wave_codegen.h): the wavefront solver's own algorithm text (wave_ipm.h)
+compiled at run time with every size, table offset and vector place of ONE template as a literal.  Role in the reference:
+the serial re-solve loop cvxpy/problems/problem.py:1256-1269 -> ipopt_nlpif.py:140-170.
+
+Without a GPU: the generated translation unit compiles for gfx950 (hiprtc is part of the image) and its constants are those
+of the host lane's layout.  On the MI355X: the same launches through the per-template kernel and through the library's own
+kernel take the same path (statuses, iteration counts; results to 1e-8), and the per-template kernel repeats its own bits
+from launch to launch and from a ragged launch to a full one."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import batch_problems as bp
+from dnlp_amd.batch import ParametricBatch
+from hiprtc_util import compile_for_gfx950
+from wave_oracle import HostBatch
+
+TEMPLATES = {"localization": bp.template_localization, "circle_packing": bp.template_circle_packing,
+             "circle_packing10": lambda: bp.template_circle_packing(10)}
+
+
+def _source(name, nw=0):
+    prob, params, sample, _ = TEMPLATES[name]()
+    hb = HostBatch(ParametricBatch(prob, params))
+    f = hb.lib.orc_wave_spec_source
+    f.restype = C.c_longlong
+    f.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_longlong]
+    buf = C.create_string_buffer(1 << 22)
+    n = f(hb.handle.ptr, nw, buf, len(buf))
+    assert 0 < n < len(buf), (n, hb.lib.orc_last_error())
+    return buf.value.decode()
+
+
+@pytest.mark.parametrize("name", sorted(TEMPLATES))
+def test_per_template_kernel_text_compiles_for_gfx950(name):
+    src = _source(name)
+    ok, log, seconds, code = compile_for_gfx950(src)
+    assert ok, log[:4000]
+    assert len(code) > 10000
+    # the template is in the text as literals
+    consts = dict(re.findall(r"constexpr int (\w+) = (-?\d+);", src))
+    prob, params, sample, _ = TEMPLATES[name]()
+    pb = ParametricBatch(prob, params)
+    assert int(consts["k_N"]) == int(pb.arrays0["dims"][0]) and int(consts["k_m"]) == int(pb.arrays0["dims"][1])
+    assert 1 <= int(consts["kNW"]) <= 8
+    # plan (16 bit) + kNW shares (record + vectors) fit a compute unit's LDS
+    lds = 2 * int(consts["kPlanInts"]) + int(consts["kNW"]) * (int(consts["kRecBytesMax"]) + 8 * int(consts["kStateDoubles"]))
+    assert lds <= 160 * 1024
+
+
+def test_templates_the_wavefront_solver_refuses_have_no_per_template_kernel():
+    prob, params, sample, _ = bp.template_power_flow()
+    hb = HostBatch(ParametricBatch(prob, params))
+    f = hb.lib.orc_wave_spec_source
+    f.restype = C.c_longlong
+    f.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_longlong]
+    assert f(hb.handle.ptr, 0, None, 0) == -3          # (its state, 655 KB, does not fit LDS)
+
+
+def _both(pb, thetas, **kw):
+    out = []
+    for mode in ("1", "0"):
+        old = os.environ.get("DNLP_WAVE_SPEC")
+        os.environ["DNLP_WAVE_SPEC"] = mode
+        try:
+            out.append(pb.solve(thetas, want_duals=True, **kw))
+        finally:
+            if old is None:
+                os.environ.pop("DNLP_WAVE_SPEC", None)
+            else:
+                os.environ["DNLP_WAVE_SPEC"] = old
+    return out
+
+
+def _same_path(s, o, frac=0.98):
+    """Two compilations of one algorithm text: the compiler contracts / orders a few sums differently (last-bit differences),
+    the path is the same — statuses, (almost always) iteration counts, and the results of the instances that took the same
+    number of iterations to 1e-8."""
+    assert np.array_equal(s.status, o.status)
+    same = s.iterations == o.iterations
+    assert same.mean() >= frac, same.mean()
+    np.testing.assert_allclose(s.obj_val[same], o.obj_val[same], rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B", [("localization", 1024), ("circle_packing", 512), ("circle_packing10", 256)])
+def test_per_template_kernel_follows_the_library_kernel(gpu_required, name, B):
+    prob, params, sample, _ = TEMPLATES[name]()
+    pb = ParametricBatch(prob, params)
+    thetas = np.stack([sample(i) for i in range(B)])
+    s, o = _both(pb, thetas)
+    assert s.raw["launch"]["wave_spec"] and not o.raw["launch"]["wave_spec"]
+    assert s.raw["launch"]["wave_form"] % 100 == 11
+    _same_path(s, o)
+    assert (s.status == 0).mean() >= 0.9
+    pb.close()
+
+
+@pytest.mark.gpu
+def test_per_template_kernel_under_other_options_and_ragged_launches(gpu_required):
+    prob, params, sample, _ = bp.template_localization()
+    pb = ParametricBatch(prob, params)
+    thetas = np.stack([sample(i) for i in range(300)])
+    for opts in ({"mu_strategy": "monotone", "tol": 1e-6}, {"max_soc": 0, "max_iter": 25}):
+        s, o = _both(pb, thetas, **opts)
+        assert s.raw["launch"]["wave_spec"]
+        _same_path(s, o)
+    full, _ = _both(pb, thetas)
+    for n in (1, 3, 65, 257):
+        part, _ = _both(pb, thetas[:n])
+        assert np.array_equal(part.x, full.x[:n]) and np.array_equal(part.iterations, full.iterations[:n]), n
+    pb.close()
