@@ -395,6 +395,9 @@ struct BatchRunner {
   // the per-template kernel (wave_codegen.h): compiled by hiprtc at the template's first large launch, cached on disk
   RtcKernel wave_spec;
   int wave_spec_nw = 0;                           // wavefronts per workgroup it was compiled for (its static LDS holds that many shares)
+  unsigned* d_wave_gen = nullptr;                 // work tables of its generated LDL^T phases (wave_gen.h)
+  int wave_gen_words = 0;
+  bool wave_spec_prof = false;
   bool last_wave_spec = false;                    // the last solve ran it
   double wave_spec_compile_seconds = 0.0;
   // DNLP_WAVE_SPEC: 0 never, 1 for every launch of a template whose state and plan fit LDS, unset: launches of at least
@@ -407,14 +410,26 @@ struct BatchRunner {
     if (mode < 0 && batch < kWaveSpecMinBatch && !wave_spec.ok) return false;
     if (wave_spec.tried) return wave_spec.ok;
     const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(wave_blk.data());
-    const int fit = wave_fits16 ? wave_spec_max_waves(h) : 0;
-    if (fit < 1) { wave_spec.tried = true; return false; }
+    wave_spec.tried = true;
+    if (wave_gen_refusal(h)[0]) return false;
+    // (the kernel stages the first keep_gen ints of the block, narrowed to 16 bits, and the generated phases' work tables)
+    bool fits = true;
+    for (size_t k = sizeof(WaveHdr) / 4; k < static_cast<size_t>(h.keep_gen) && fits; ++k) fits = wave_blk[k] >= -32768 && wave_blk[k] <= 32767;
+    if (!fits) return false;
     const double t0 = now_sec();
-    const std::string src = wave_spec_source(wave_blk, fit);
+    const WaveGen gen = wave_generate(wave_blk);
+    const int fit = wave_spec_max_waves(h, gen.G.size());
+    if (fit < 1) return false;
+    // (DNLP_WAVE_SPEC_PROF: the kernel is compiled with the cycle counters of wave_ipm.h W_P0 / W_P1 and the host prints them)
+    wave_spec_prof = std::getenv("DNLP_WAVE_SPEC_PROF") != nullptr;
+    const std::string src = (wave_spec_prof ? std::string("#define DNLP_WAVE_PROF 1\n") : std::string()) + wave_spec_source(wave_blk, fit, gen);
     if (!wave_spec.load(src, "dnlp_wave_spec_kernel")) {
       std::fprintf(stderr, "[dnlp] per-template batch kernel not available (the library's own kernel is used): %s\n", wave_spec.log.substr(0, 2000).c_str());
       return false;
     }
+    wave_gen_words = static_cast<int>(gen.G.size());
+    DNLP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_wave_gen), (gen.G.size() + 4) * sizeof(unsigned)));
+    if (!gen.G.empty()) DNLP_HIP_CHECK(hipMemcpy(d_wave_gen, gen.G.data(), gen.G.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     wave_spec_nw = fit;
     wave_spec_compile_seconds = now_sec() - t0;
     if (std::getenv("DNLP_BATCH_DEBUG")) std::fprintf(stderr, "[batch] per-template kernel: %d wavefronts per workgroup, %.2f s to compile / load\n", fit, wave_spec_compile_seconds);
@@ -531,6 +546,7 @@ struct BatchRunner {
     if (d_sparse) hipFree(d_sparse);
     if (d_wave_blk) hipFree(d_wave_blk);
     if (d_wave_blk16) hipFree(d_wave_blk16);
+    if (d_wave_gen) hipFree(d_wave_gen);
     if (d_rows) hipFree(d_rows);
     if (own_stream && stream) hipStreamDestroy(stream);
   }
@@ -1114,6 +1130,7 @@ struct BatchRunner {
     const size_t state_b = static_cast<size_t>(h.state_doubles) * 8;
     WaveArgs w;
     w.blk = d_wave_blk; w.blk16 = d_wave_blk16; w.blk_ints = h.total;
+    w.gen = d_wave_gen; w.gen_words = wave_gen_words;
     w.rows = a.slabs; w.row_doubles = lay.total;
     w.batch = batch;
     w.state_doubles = h.state_doubles;
@@ -1122,15 +1139,21 @@ struct BatchRunner {
     w.fallback_max_n = (n <= 512 && !force_sparse) ? 512 : 0;
     // a launch that does not fill the chip spreads out: no more wavefronts per compute unit than instances per compute unit
     // (1024 instances on 256 units: four each, whatever would fit — a lone wavefront on its SIMD is the fastest instance)
+    bool spec = false;
     if (sl && !std::getenv("DNLP_WAVE_FORM")) {
       const int want = std::max(1, (batch + this->ncu - 1) / this->ncu);
       if (pl && want > nw && wf_nw_glb > nw) { nw = std::min(want, wf_nw_glb); pl = 0; }      // more instances than fit beside the plan
       else nw = std::min(nw, want);
+      // the per-template kernel when the template has one and it holds as many wavefronts per compute unit as the library's
+      // own form would run (it stages less: the level machinery's tables are generated code): its static LDS (plan prefix +
+      // work tables + wave_spec_nw shares) fills the compute unit, a launch puts as many wavefronts into a workgroup as it
+      // has instances per compute unit
+      if (wave_spec_prepare(batch) && std::min(wave_spec_nw, want) >= nw) {
+        spec = true;
+        nw = std::min(wave_spec_nw, want); pl = 1;
+        w.gen = d_wave_gen; w.gen_words = wave_gen_words;
+      }
     }
-    // the per-template kernel when the template has one: its static LDS (plan + wave_spec_nw shares) fills the compute
-    // unit, a launch puts as many wavefronts into a workgroup as it has instances per compute unit
-    const bool spec = sl && pl && !std::getenv("DNLP_WAVE_FORM") && wave_spec_prepare(batch);
-    if (spec) nw = std::min(wave_spec_nw, std::max(1, (batch + this->ncu - 1) / this->ncu));
     int per_cu = 1;
     const unsigned lds = static_cast<unsigned>((pl ? plan_b : 0) + (sl ? static_cast<size_t>(nw) * state_b : 0));
     const int form = 100 * nw + 10 * sl + pl;
@@ -1186,9 +1209,14 @@ struct BatchRunner {
     w.next = dalloc<int>(1);
     DNLP_HIP_CHECK(hipMemsetAsync(w.next, 0, sizeof(int), stream));
 #ifdef DNLP_WAVE_PROF
-    w.prof = dalloc<unsigned long long>(kWaveProfSlots + 1);
-    DNLP_HIP_CHECK(hipMemsetAsync(w.prof, 0, sizeof(unsigned long long) * (kWaveProfSlots + 1), stream));
+    const bool want_prof = true;
+#else
+    const bool want_prof = spec && wave_spec_prof;
 #endif
+    if (want_prof) {
+      w.prof = dalloc<unsigned long long>(kWaveProfSlots + 1);
+      DNLP_HIP_CHECK(hipMemsetAsync(w.prof, 0, sizeof(unsigned long long) * (kWaveProfSlots + 1), stream));
+    }
     const uint64_t key = theta ? rows_hash(theta, static_cast<size_t>(batch) * static_cast<size_t>(aff_P))
                                : rows_hash(data, static_cast<size_t>(batch) * static_cast<size_t>(in_stride));
     last_order_lpt = false;
@@ -1256,8 +1284,7 @@ struct BatchRunner {
     down(iters_out, w.iters_out, sizeof(int) * batch);
     down(nfact_out, w.nfact_out, sizeof(int) * batch);
     down(times_out, w.times_out, sizeof(double) * 4 * batch);
-#ifdef DNLP_WAVE_PROF
-    {
+    if (w.prof) {
       unsigned long long pr[kWaveProfSlots + 1];
       DNLP_HIP_CHECK(hipMemcpy(pr, w.prof, sizeof pr, hipMemcpyDeviceToHost));
       const double it = static_cast<double>(pr[kWaveProfSlots] ? pr[kWaveProfSlots] : 1);
@@ -1268,7 +1295,6 @@ struct BatchRunner {
       std::fprintf(stderr, "[wave profile] %llu iterations; cycles per iteration by phase (s_memtime ticks):\n", pr[kWaveProfSlots]);
       for (int k = 0; k < kWaveProfSlots; ++k) if (pr[k]) std::fprintf(stderr, "[wave profile]   %-22s %10.0f\n", nm[k], static_cast<double>(pr[k]) / it);
     }
-#endif
     mark("wave results copied");
     pack_rows(batch, w.x_out, w.obj_out, w.status_out, w.iters_out);
     release();

@@ -10,6 +10,8 @@ struct WaveArgs {
   const i32* blk = nullptr;          // the plan block (device memory)
   const int16_t* blk16 = nullptr;    // ... narrowed to 16 bits (null when an entry does not fit)
   int blk_ints = 0;
+  const unsigned* gen = nullptr;     // work tables of the generated LDL^T phases (wave_gen.h; per-template kernels only)
+  int gen_words = 0;
   const double* rows = nullptr;      // batch x row_doubles instance rows (batch.h slab layout)
   i64 row_doubles = 0;
   int batch = 0;

@@ -12,7 +12,9 @@
 //     wave_hdr.h, wave_args.h   plan header, launch arguments   }  host lane of the test oracle are compiled from
 //     namespace wspec           THE TEMPLATE: every size, table offset and vector place as a literal (this file)
 //     wave_ops.h, wave_ipm.h    reductions, the interior-point loop (its WK / WT / WV accessors resolve to wspec::)
-//     wave_spec_kernel.h        static LDS for plan + shares, the lane policy, the kernel
+//     wave_spec_kernel.h        static LDS for plan + work tables + shares, the lane policy, the kernel
+//     wave_gen_rt.h + generated the static-pattern LDL^T (factorisation, both substitutions) as straight-line phases for
+//                               THIS template's levels (wave_gen.h), in place of the walk over the plan's level tables
 // The algorithm text is not forked: the same wave_ipm.h is pinned bit for bit on the CPU (tests/test_wave_ipm_cpu.py) and
 // the per-template kernel is compared with the library's own on the device (tests/test_wave_spec.py).
 //
@@ -20,9 +22,11 @@
 // that a CPU test can hand it to hiprtc without a GPU.
 #pragma once
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
+#include "wave_gen.h"
 #include "wave_ipm.h"
 
 namespace dnlp {
@@ -42,12 +46,13 @@ struct WaveProbeLanes {
   template <int SL> static double row_get(const double (&a)[SL], int row) { return a[row]; }
 };
 
-constexpr int kWaveSpecRecBytesMax = 2048;      // (what the host sizes a launch with; the kernel asserts its record fits)
+constexpr int kWaveSpecRecBytesMax = 1792;      // (what the host sizes a launch with; the kernel asserts its record — 1334 B today, 1558 B with the
+                                                //  cycle counters of a profile build — fits)
 
 // the largest number of wavefronts per workgroup whose shares fit a compute unit's LDS beside the 16-bit plan (0: none)
-inline int wave_spec_max_waves(const WaveHdr& h) {
+inline int wave_spec_max_waves(const WaveHdr& h, size_t gen_words) {
   const size_t cap = 160 * 1024 - 512;
-  const size_t plan_b = ((static_cast<size_t>(h.total) + 7) & ~static_cast<size_t>(7)) * 2;
+  const size_t plan_b = ((static_cast<size_t>(h.keep_gen) + 7) & ~static_cast<size_t>(7)) * 2 + ((gen_words + 3) & ~static_cast<size_t>(3)) * 4;
   const size_t share_b = kWaveSpecRecBytesMax + static_cast<size_t>(h.state_doubles) * 8 + 16;
   if (plan_b + share_b > cap) return 0;
   const size_t k = (cap - plan_b) / share_b;
@@ -55,7 +60,7 @@ inline int wave_spec_max_waves(const WaveHdr& h) {
 }
 
 // namespace wspec of a template: the literals behind WK / WT / WV / WDIR / WCSR / WCOO (wave_ipm.h)
-inline std::string wave_spec_constants(const std::vector<i32>& blk, int nw) {
+inline std::string wave_spec_constants(const std::vector<i32>& blk, int nw, size_t gen_words = 0) {
   const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(blk.data());
   typedef WaveIpm<WaveProbeLanes> W;
   W::WState S;
@@ -95,7 +100,8 @@ inline std::string wave_spec_constants(const std::vector<i32>& blk, int nw) {
   };
   coo("jr", S.jr); coo("jc", S.jc); coo("hs", S.hs);
   put("", "kStateDoubles", h.state_doubles);
-  put("", "kPlanInts", h.total);
+  put("", "kPlanInts", h.keep_gen);      // (what a kernel with generated LDL^T phases stages of the block)
+  put("", "kGenWords", static_cast<long long>(gen_words));
   put("", "kNW", nw);
   put("", "kRecBytesMax", kWaveSpecRecBytesMax);
   s += "}  // namespace wspec\n";
@@ -107,6 +113,7 @@ inline const char* wave_spec_prelude() {
   return
       "#define DNLP_RTC 1\n"
       "#define DNLP_WAVE_SPEC 1\n"
+      "#define DNLP_WAVE_GEN 1\n"
       "#define DNLP_HD __device__\n"
       "#define DNLP_DEVICE_PASS 1\n"
       "typedef __INT16_TYPE__ int16_t;\ntypedef __INT32_TYPE__ int32_t;\ntypedef __INT64_TYPE__ int64_t;\ntypedef __UINT64_TYPE__ uint64_t;\n"
@@ -130,8 +137,29 @@ inline const char* wave_spec_prelude() {
       "#define std dnlp_std\n";
 }
 
+// development aid: with DNLP_WAVE_SRC_DIR set, a header's text is read from <dir>/<name> (stripped of its #pragma once and
+// #include lines, as the build does for the embedded copy) instead of taken from the library — the kernel text can then be
+// edited without rebuilding the library
+inline std::string wave_spec_text(const char* name, const char* embedded) {
+  const char* dir = std::getenv("DNLP_WAVE_SRC_DIR");
+  if (!dir || !*dir) return embedded;
+  FILE* fp = std::fopen((std::string(dir) + "/" + name).c_str(), "r");
+  if (!fp) return embedded;
+  std::string out, line;
+  char buf[4096];
+  while (std::fgets(buf, sizeof buf, fp)) {
+    line = buf;
+    size_t k = 0;
+    while (k < line.size() && (line[k] == ' ' || line[k] == '\t')) ++k;
+    if (line.compare(0, 12, "#pragma once") == 0 || line.compare(k, 8, "#include") == 0) continue;
+    out += line;
+  }
+  std::fclose(fp);
+  return out;
+}
+
 // the translation unit of a template's kernel (entry point: dnlp_wave_spec_kernel)
-inline std::string wave_spec_source(const std::vector<i32>& blk, int nw) {
+inline std::string wave_spec_source(const std::vector<i32>& blk, int nw, const WaveGen& gen) {
   static const char* atom_math_text =
 #include "atom_math_src.inc"
       ;
@@ -150,18 +178,23 @@ inline std::string wave_spec_source(const std::vector<i32>& blk, int nw) {
   static const char* wave_ipm_text =
 #include "wave_ipm_src.inc"
       ;
+  static const char* wave_gen_rt_text =
+#include "wave_gen_rt_src.inc"
+      ;
   static const char* wave_spec_kernel_text =
 #include "wave_spec_kernel_src.inc"
       ;
   std::string s = wave_spec_prelude();
-  s += atom_math_text;
-  s += ipm_options_text;
-  s += wave_hdr_text;
-  s += wave_args_text;
-  s += wave_spec_constants(blk, nw);
-  s += wave_ops_text;
-  s += wave_ipm_text;
-  s += wave_spec_kernel_text;
+  s += wave_spec_text("atom_math.h", atom_math_text);
+  s += wave_spec_text("ipm_options.h", ipm_options_text);
+  s += wave_spec_text("wave_hdr.h", wave_hdr_text);
+  s += wave_spec_text("wave_args.h", wave_args_text);
+  s += wave_spec_constants(blk, nw, gen.G.size());
+  s += wave_spec_text("wave_ops.h", wave_ops_text);
+  s += wave_spec_text("wave_ipm.h", wave_ipm_text);
+  s += wave_spec_text("wave_spec_kernel.h", wave_spec_kernel_text);      // (the lane policy P: the generated functions below are templates over it)
+  s += wave_spec_text("wave_gen_rt.h", wave_gen_rt_text);
+  s += gen.code;
   return s;
 }
 

@@ -1,0 +1,339 @@
+// Template-specialised batch solver, part 6: the PHASES of the static-pattern LDL^T as straight-line code.
+//
+// wave_ipm.h's ldl_factor_impl / ldl_solve walk the plan's index tables: per level a handful of uniform bound loads, per
+// entry an index load, a dependent operand load and loop control — 9.7 k cycles for one solve of an order-102 factor.  In a
+// kernel compiled per template (wave_codegen.h) the level structure is known when the text is written: wave_gen.h lays the
+// work of every level phase out as ONE TASK PER LANE (descriptor words G[base + lane], entry words G[base + e * lanes_active
+// + lane], both 32-bit, staged in LDS next to the plan) and emits, per phase, one call of a helper below with every bound,
+// base and count as a template argument.  After inlining that is straight-line code: ds_read with immediate offsets for
+// the descriptors, unrolled entry loops, no level tables, no scalar loop control.
+//
+// The ARITHMETIC is that of wave_ipm.h / sparse_ldl.h, entry by entry and in the same order: every destination (a forward
+// target, a block's backward sum, an update group) is summed by ONE lane in storage order — what the host lane of the
+// interpreted text does — so the generated phases reproduce its bits on the CPU (tests/test_wave_gen_cpu.py runs this text
+// with 64 virtual lanes against the interpreted host lane) and the device runs the same sums.  A padded entry multiplies
+// two selected zeros: adding +0.0 to a sum that started at +0.0 never changes it.
+//
+// Free of standard-library includes (the text travels into hiprtc as wave_gen_rt_src.inc).
+#pragma once
+
+// a phase: every lane of the wavefront runs the body once; on the host one thread plays the 64 lanes one after the other
+// (phases have no cross-lane dependence inside: that is what makes them phases)
+#if DNLP_DEVICE_PASS
+#define WG_BEGIN { const int lane = P::lane();
+#define WG_END } P::sync();
+#define WG_INLINE __attribute__((always_inline)) __device__ inline
+#else
+#define WG_BEGIN for (int lane = 0; lane < 64; ++lane) {
+#define WG_END }
+#define WG_INLINE inline
+#endif
+
+namespace dnlp {
+namespace wgrt {
+
+typedef unsigned int u32;
+
+// ---- forward substitution: target node `node` collects its rows (wave_ipm.h ldl_solve, first half) -------------------
+// descriptor (1 word): node | rows << 16.  entry e (2 words, [2e][lane], [2e + 1][lane]): a | u0 << 16, u1 | kind << 16
+// (kind 1: a row of a 1x1 block, value index a; 2: of a 2x2 block, values a, a + 1, sources u0, u1).
+// KINDS: 1 / 2 = every real entry of the phase is of that kind, 3 = mixed.  RAGGED: lanes differ in their number of rows.
+template <bool TWO, int D0, int E0, int NACT, int MAXC, int KINDS, bool RAGGED, class GP, class VP>
+WG_INLINE void fwd(int lane, GP G, const VP vals, VP x, VP y) {
+  if (lane < NACT) {
+    const u32 d = G[D0 + lane];
+    const int node = static_cast<int>(d & 0xffffu), cnt = static_cast<int>(d >> 16);
+    double acc = 0.0, acc2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < MAXC; ++e) {
+      const u32 w0 = G[E0 + (2 * e) * NACT + lane], w1 = G[E0 + (2 * e + 1) * NACT + lane];
+      const int a = static_cast<int>(w0 & 0xffffu), u0 = static_cast<int>(w0 >> 16), u1 = static_cast<int>(w1 & 0xffffu);
+      const bool on = !RAGGED || e < cnt;
+      const bool two = KINDS == 2 || (KINDS == 3 && (w1 >> 16) == 2u);
+      if (KINDS == 1) {
+        const double l = on ? vals[a] : 0.0, xv = on ? x[u0] : 0.0;
+        acc += l * xv;
+        if (TWO) { const double yv = on ? y[u0] : 0.0; acc2 += l * yv; }
+      } else if (KINDS == 2) {
+        const double l0 = on ? vals[a] : 0.0, l1 = on ? vals[a + 1] : 0.0, x0 = on ? x[u0] : 0.0, x1 = on ? x[u1] : 0.0;
+        acc += l0 * x0 + l1 * x1;
+        if (TWO) { const double y0 = on ? y[u0] : 0.0, y1 = on ? y[u1] : 0.0; acc2 += l0 * y0 + l1 * y1; }
+      } else {
+        // mixed: the loads side by side, the two forms of the sum under the lane's own kind
+        const double l0 = on ? vals[a] : 0.0, l1 = (on && two) ? vals[a + 1] : 0.0, x0 = on ? x[u0] : 0.0, x1 = (on && two) ? x[u1] : 0.0;
+        double y0 = 0.0, y1 = 0.0;
+        if (TWO) { y0 = on ? y[u0] : 0.0; y1 = (on && two) ? y[u1] : 0.0; }
+        if (two) { acc += l0 * x0 + l1 * x1; if (TWO) acc2 += l0 * y0 + l1 * y1; }
+        else { acc += l0 * x0; if (TWO) acc2 += l0 * y0; }
+      }
+    }
+    x[node] -= acc;
+    if (TWO) y[node] -= acc2;
+  }
+}
+
+// ---- forward substitution, WIDE form: ONE target whose many rows lie across the lanes ------------------------------------------
+// (the last levels of a plan with a dense row — localization's two position variables meet all twenty range rows: one lane
+//  walking twenty entries issues 160 LDS loads by itself.)  Lane e forms the product of row e; the products are then added
+// IN ROW ORDER — on the device every lane adds the same v_readlane broadcasts, on the host the lanes are played in that order
+// anyway — which is the serial sum of the interpreted text.  entry e (2 words): as in fwd.  The caller chains the slots of a
+// target with more than 64 rows through acc / acc2 and subtracts once (fwdw_fin).
+template <class P, bool TWO, int E0, int CNT, int KINDS, class GP, class VP>
+WG_INLINE void fwdw(GP G, const VP vals, const VP x, const VP y, double& acc, double& acc2) {
+#if DNLP_DEVICE_PASS
+  const int lane = P::lane();
+  double p = 0.0, p2 = 0.0;
+  if (lane < CNT) {
+#else
+  for (int lane = 0; lane < CNT; ++lane) {
+    double p = 0.0, p2 = 0.0;
+#endif
+    const u32 w0 = G[E0 + lane], w1 = G[E0 + CNT + lane];
+    const int a = static_cast<int>(w0 & 0xffffu), u0 = static_cast<int>(w0 >> 16), u1 = static_cast<int>(w1 & 0xffffu);
+    const bool two = KINDS == 2 || (KINDS == 3 && (w1 >> 16) == 2u);
+    if (two) {
+      const double l0 = vals[a], l1 = vals[a + 1];
+      p = l0 * x[u0] + l1 * x[u1];
+      if (TWO) p2 = l0 * y[u0] + l1 * y[u1];
+    } else {
+      const double l = vals[a];
+      p = l * x[u0];
+      if (TWO) p2 = l * y[u0];
+    }
+#if DNLP_DEVICE_PASS
+  }
+#pragma unroll
+  for (int e = 0; e < CNT; ++e) {
+    acc += readlane_d(p, e);
+    if (TWO) acc2 += readlane_d(p2, e);
+  }
+#else
+    acc += p;
+    if (TWO) acc2 += p2;
+  }
+#endif
+}
+template <class P, bool TWO, int NODE, class VP>
+WG_INLINE void fwdw_fin(VP x, VP y, double acc, double acc2) {
+#if DNLP_DEVICE_PASS
+  if (P::lane() == 0) {
+#else
+  {
+#endif
+    x[NODE] -= acc;
+    if (TWO) y[NODE] -= acc2;
+  }
+  P::sync();
+}
+
+// ---- backward substitution, WIDE form: ONE block whose many struct rows lie across the lanes -------------------------------
+// entry i (1 word): source node u.  ONE: a 1x1 block (values LOF + i), else a 2x2 block (LOF + 2 i, LOF + 2 i + 1).
+template <class P, bool TWO, bool ONE, int E0, int CNT, int LOF, int I0, class GP, class VP>
+WG_INLINE void bwdw(GP G, const VP vals, const VP x, const VP y, double& a0, double& a1, double& c0, double& c1) {
+#if DNLP_DEVICE_PASS
+  const int lane = P::lane();
+  double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;
+  if (lane < CNT) {
+#else
+  for (int lane = 0; lane < CNT; ++lane) {
+    double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;
+#endif
+    const int u = static_cast<int>(G[E0 + lane]);
+    const int i = I0 + lane;
+    const double xi = x[u];
+    double yi = 0.0;
+    if (TWO) yi = y[u];
+    if (ONE) {
+      const double l = vals[LOF + i];
+      p0 = l * xi;
+      if (TWO) q0 = l * yi;
+    } else {
+      const double l0 = vals[LOF + 2 * i], l1 = vals[LOF + 2 * i + 1];
+      p0 = l0 * xi; p1 = l1 * xi;
+      if (TWO) { q0 = l0 * yi; q1 = l1 * yi; }
+    }
+#if DNLP_DEVICE_PASS
+  }
+#pragma unroll
+  for (int e = 0; e < CNT; ++e) {
+    a0 += readlane_d(p0, e);
+    if (!ONE) a1 += readlane_d(p1, e);
+    if (TWO) { c0 += readlane_d(q0, e); if (!ONE) c1 += readlane_d(q1, e); }
+  }
+#else
+    a0 += p0;
+    if (!ONE) a1 += p1;
+    if (TWO) { c0 += q0; if (!ONE) c1 += q1; }
+  }
+#endif
+}
+template <class P, bool TWO, bool ONE, int U0, int U1, class VP>
+WG_INLINE void bwdw_fin(VP x, VP y, double a0, double a1, double c0, double c1) {
+#if DNLP_DEVICE_PASS
+  if (P::lane() == 0) {
+#else
+  {
+#endif
+    x[U0] -= a0;
+    if (TWO) y[U0] -= c0;
+    if (!ONE) {
+      x[U1] -= a1;
+      if (TWO) y[U1] -= c1;
+    }
+  }
+  P::sync();
+}
+
+// ---- D^-1 on every block (wave_ipm.h dsolve) -------------------------------------------------------------------------
+// descriptor (2 words): u0 | u1 << 16 (u1 = 0xffff: a 1x1 block), doff
+template <bool TWO, int D0, int NACT, int KINDS, class GP, class VP>
+WG_INLINE void dsol(int lane, GP G, const VP vals, VP x, VP y) {
+  if (lane < NACT) {
+    const u32 w0 = G[D0 + lane], w1 = G[D0 + NACT + lane];
+    const int u0 = static_cast<int>(w0 & 0xffffu), u1r = static_cast<int>(w0 >> 16), dof = static_cast<int>(w1);
+    const bool one = KINDS == 1 || (KINDS == 3 && u1r == 0xffff);
+    if (one) {
+      const double d = vals[dof];
+      x[u0] /= d;
+      if (TWO) y[u0] /= d;
+    } else {
+      const int u1 = u1r;
+      const double a = vals[dof], c = vals[dof + 1], e = vals[dof + 2];
+      double det = a * e - c * c;
+      if (fabs(det) < 1e-300) det = -1e-20;
+      const double x0 = x[u0], x1 = x[u1];
+      x[u0] = (e * x0 - c * x1) / det;
+      x[u1] = (a * x1 - c * x0) / det;
+      if (TWO) {
+        const double y0 = y[u0], y1 = y[u1];
+        y[u0] = (e * y0 - c * y1) / det;
+        y[u1] = (a * y1 - c * y0) / det;
+      }
+    }
+  }
+}
+
+// ---- backward substitution: a block subtracts its struct rows' share (wave_ipm.h ldl_solve, second half) ---------------
+// descriptor (2 words): u0 | u1 << 16 (0xffff: 1x1), loff | rows << 16.  entries: source node u, two per word
+// ([e / 2][lane], low half first).
+template <bool TWO, int D0, int E0, int NACT, int MAXC, int KINDS, bool RAGGED, class GP, class VP>
+WG_INLINE void bwd(int lane, GP G, const VP vals, VP x, VP y) {
+  if (lane < NACT) {
+    const u32 w0 = G[D0 + lane], w1 = G[D0 + NACT + lane];
+    const int u0 = static_cast<int>(w0 & 0xffffu), u1r = static_cast<int>(w0 >> 16);
+    const int lof = static_cast<int>(w1 & 0xffffu), sn = static_cast<int>(w1 >> 16);
+    const bool one = KINDS == 1 || (KINDS == 3 && u1r == 0xffff);
+    double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const u32 w = G[E0 + (i >> 1) * NACT + lane];
+      const int u = static_cast<int>((i & 1) ? (w >> 16) : (w & 0xffffu));
+      const bool on = !RAGGED || i < sn;
+      if (KINDS == 1) {
+        const double l = on ? vals[lof + i] : 0.0, xi = on ? x[u] : 0.0;
+        a0 += l * xi;
+        if (TWO) { const double yi = on ? y[u] : 0.0; c0 += l * yi; }
+      } else if (KINDS == 2) {
+        const double l0 = on ? vals[lof + 2 * i] : 0.0, l1 = on ? vals[lof + 2 * i + 1] : 0.0, xi = on ? x[u] : 0.0;
+        a0 += l0 * xi; a1 += l1 * xi;
+        if (TWO) { const double yi = on ? y[u] : 0.0; c0 += l0 * yi; c1 += l1 * yi; }
+      } else {
+        const int p0 = one ? lof + i : lof + 2 * i;
+        const double l0 = on ? vals[p0] : 0.0, l1 = (on && !one) ? vals[p0 + 1] : 0.0, xi = on ? x[u] : 0.0;
+        a0 += l0 * xi;
+        if (!one) a1 += l1 * xi;
+        if (TWO) { const double yi = on ? y[u] : 0.0; c0 += l0 * yi; if (!one) c1 += l1 * yi; }
+      }
+    }
+    x[u0] -= a0;
+    if (TWO) y[u0] -= c0;
+    if (!one) {
+      x[u1r] -= a1;
+      if (TWO) y[u1r] -= c1;
+    }
+  }
+}
+
+// ---- factorisation: pivots of a level (sparse_ldl.h sp_pivot) -----------------------------------------------------------
+// descriptor (2 words): doff | kind << 16 (1: 1x1, 2: 2x2), 3 k (where the block's inverse goes in dinv)
+template <int D0, int NACT, int KINDS, class GP, class VP>
+WG_INLINE void piv(int lane, GP G, VP vals, VP dinv, double& nneg, double& nzero, double& bad) {
+  if (lane < NACT) {
+    const u32 w0 = G[D0 + lane], w1 = G[D0 + NACT + lane];
+    const int dof = static_cast<int>(w0 & 0xffffu), k3 = static_cast<int>(w1);
+    const bool one = KINDS == 1 || (KINDS == 3 && (w0 >> 16) == 1u);
+    if (one) {
+      double d = vals[dof];
+      if (!(d == d)) bad += 1.0;
+      if (fabs(d) < 1e-300) { nzero += 1.0; d = 1e-20; vals[dof] = d; }
+      if (d < 0.0) nneg += 1.0;
+      dinv[k3] = 1.0 / d;
+    } else {
+      const double a = vals[dof], c = vals[dof + 1], e = vals[dof + 2];
+      double det = a * e - c * c;
+      if (!(det == det)) bad += 1.0;
+      if (fabs(det) < 1e-300) { nzero += 1.0; det = -1e-20; }
+      if (det < 0.0) nneg += 1.0;
+      else if (a < 0.0 || (a == 0.0 && e < 0.0)) nneg += 2.0;
+      dinv[k3] = e / det; dinv[k3 + 1] = -c / det; dinv[k3 + 2] = a / det;
+    }
+  }
+}
+
+// ---- factorisation: struct rows of a level scaled by their block's inverse pivot (sp_scale) ---------------------------------
+// descriptor (2 words): a | kind << 16, 3 k
+template <int D0, int NACT, int KINDS, class GP, class VP>
+WG_INLINE void scl(int lane, GP G, VP vals, VP w, const VP dinv) {
+  if (lane < NACT) {
+    const u32 w0 = G[D0 + lane], w1 = G[D0 + NACT + lane];
+    const int a = static_cast<int>(w0 & 0xffffu), k3 = static_cast<int>(w1);
+    const bool one = KINDS == 1 || (KINDS == 3 && (w0 >> 16) == 1u);
+    if (one) {
+      const double l1 = vals[a];
+      w[a] = l1;
+      vals[a] = l1 * dinv[k3];
+    } else {
+      const double l1 = vals[a], l2 = vals[a + 1];
+      const double d0 = dinv[k3], d1 = dinv[k3 + 1], d2 = dinv[k3 + 2];
+      w[a] = l1; w[a + 1] = l2;
+      vals[a] = d0 * l1 + d1 * l2;
+      vals[a + 1] = d1 * l1 + d2 * l2;
+    }
+  }
+}
+
+// ---- factorisation: the products of a level's update triples, side by side into the scratch array (sp_update) -------------
+// one word per triple: au | av << 16 | (2x2 pivot block) << 31; the triple's place in the scratch array is Q0 + lane
+template <int D0, int NACT, int Q0, int KINDS, class GP, class VP>
+WG_INLINE void upd(int lane, GP G, const VP vals, const VP w, VP scr) {
+  if (lane < NACT) {
+    const u32 t = G[D0 + lane];
+    const int au = static_cast<int>(t & 0xffffu), av = static_cast<int>((t >> 16) & 0x7fffu);
+    const bool two = KINDS == 2 || (KINDS == 3 && (t >> 31) != 0u);
+    double p;
+    if (two) p = w[au] * vals[av] + w[au + 1] * vals[av + 1];
+    else p = w[au] * vals[av];
+    scr[Q0 + lane] = p;
+  }
+}
+
+// ---- factorisation: every destination subtracts its run of products, added in storage order (run_sum) --------------------
+// descriptor (2 words): dst | count << 16, start of the run in the scratch array
+template <int D0, int NACT, int MAXC, bool RAGGED, class GP, class VP>
+WG_INLINE void gsum(int lane, GP G, VP vals, const VP scr) {
+  if (lane < NACT) {
+    const u32 w0 = G[D0 + lane], w1 = G[D0 + NACT + lane];
+    const int dst = static_cast<int>(w0 & 0xffffu), cnt = static_cast<int>(w0 >> 16), q0 = static_cast<int>(w1);
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < MAXC; ++e) {
+      const bool on = !RAGGED || e < cnt;
+      const double t = scr[on ? q0 + e : q0];
+      acc += on ? t : 0.0;
+    }
+    vals[dst] -= acc;
+  }
+}
+
+}  // namespace wgrt
+}  // namespace dnlp

@@ -14,7 +14,9 @@ struct WaveHdr {
   i32 total;                                  // ints in the block
   i32 N, m, Z, nd, nh, nnzJ, nnzH, nunits;
   i32 u_op, u_a0, u_a1, u_z, u_d0, u_d1, u_h, u_p;          // per sweep unit (see build_wave_plan)
-  i32 mm_idx, mm_pad;                         // matmul units: (U entry, V entry) index pairs of every inner product
+  i32 mm_idx;                                 // matmul units: (U entry, V entry) index pairs of every inner product
+  i32 keep_gen;                               // ints of the block a kernel with generated LDL^T phases (wave_gen.h) still reads: the tables
+                                              // of the level machinery come last and are not staged (a template without dense tail also drops fa / fu0 / fu1)
   i32 G_ptr, G_idx, Mg_ptr, Mg_idx, MJ_ptr, MJ_idx, Mw_ptr, Mw_idx, MH_ptr, MH_idx;
   i32 jac_rows, jac_cols, hess_rows, hess_cols, jac_rowptr;
   // products by output: J v (rows), J^T v (columns), sym(H) v
@@ -24,7 +26,7 @@ struct WaveHdr {
   // static-pattern LDL^T
   i32 sp_nblk, sp_nvals, sp_nlev, sp_ngrp, sp_nfwd, sp_ntrip, sp_rows;
   i32 bnode, soff, loff, doff, lev_off, sblk, sidx, lev_f, fnode, foff, fa, fu0, fu1, lev_g, gdst, goff, tau, tav, hpos, jpos, dpos;
-  i32 lev_r, lev_t, lev_fe, lev_pad;          // per level (nlev + 1 each): first struct row, first update triple, first gathered row
+  i32 lev_r, lev_t, lev_fe, keep_pad;          // per level (nlev + 1 each): first struct row, first update triple, first gathered row
   // DENSE TAIL: the last tail_T levels are a chain of one 1x1 block each over a dense trailing matrix (a dense separator:
   // circle packing n = 10 ends in 21 such levels of 23).  wave_ipm.h factors and solves that matrix in registers — one
   // row per lane — instead of walking the level machinery once per block.  tail_L = first tail level (= nlev: no tail).

@@ -161,6 +161,15 @@ struct WStateT {
 struct WErr { double dual, primal, cmpl, sd, sc, total, primal_unscaled; };
 struct WMeasures { double theta, phi, chk; };
 
+#ifdef DNLP_WAVE_GEN
+// the phases of the static-pattern LDL^T as per-template straight-line code (wave_gen.h writes them, wave_gen_rt.h holds their
+// building blocks); defined behind this header in the same translation unit
+namespace wgen {
+template <class P, class WS> DNLP_HD bool ldl_factor(WS* S);
+template <class P, bool TWO, class WS, class WD> DNLP_HD void ldl_solve(WS* S, WD* x, WD* y);
+}  // namespace wgen
+#endif
+
 template <class P>
 struct WaveIpm {
   typedef typename P::D WD;
@@ -745,6 +754,9 @@ struct WaveIpm {
   // sparse_ldl.h sparse_ldl_factor (no dense tail).  Per level: pivots, row scaling, then the update triples — their
   // products side by side into the scratch array, each destination's run added in storage order (see run_sum).
   DNLP_WFN DNLP_HD static bool ldl_factor_impl(WS* S) {
+#ifdef DNLP_WAVE_GEN
+    { W_P0(); const bool okg = wgen::ldl_factor<P>(S); W_P1(6); return okg; }
+#endif
     auto* nneg_out = &S->o_i[1];
     auto* nzero_out = &S->o_i[2];
     W_P0();
@@ -826,6 +838,9 @@ struct WaveIpm {
   // given (the mu oracle's affine-scaling and centering systems share the factor: one walk of the index arrays, one
   // chain of level barriers for both; each vector sees exactly the operations of a solve of its own)
   DNLP_WFN DNLP_HD static void ldl_solve(WS* S, WD* x, WD* y) {
+#ifdef DNLP_WAVE_GEN
+    { W_P0(); if (y) wgen::ldl_solve<P, true>(S, x, y); else wgen::ldl_solve<P, false>(S, x, y); W_P1(7); return; }
+#endif
     W_P0();
     const int L = P::lanes, me = P::lane();
     const WD* vals = WV(svals);

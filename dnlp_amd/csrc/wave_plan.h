@@ -142,19 +142,6 @@ inline std::vector<i32> build_wave_plan(E* ex, const Tape<E>& t, const SparsePla
   h.sp_nblk = narrow(sp.nblk()); h.sp_nvals = narrow(sp.nvals); h.sp_nlev = narrow(static_cast<i64>(sp.lev_off.size()) - 1);
   h.sp_ngrp = narrow(static_cast<i64>(sp.gdst.size())); h.sp_nfwd = narrow(static_cast<i64>(sp.fnode.size())); h.sp_ntrip = narrow(sp.ntrip);
   h.sp_rows = narrow(static_cast<i64>(sp.sidx.size()));
-  h.bnode = put(sp.bnode); h.soff = put(sp.soff); h.loff = put(sp.loff); h.doff = put(sp.doff); h.lev_off = put(sp.lev_off);
-  h.sblk = put(sp.sblk); h.sidx = put(sp.sidx); h.lev_f = put(sp.lev_f); h.fnode = put(sp.fnode); h.foff = put(sp.foff);
-  h.fa = put(sp.fa); h.fu0 = put(sp.fu0); h.fu1 = put(sp.fu1); h.lev_g = put(sp.lev_g); h.gdst = put(sp.gdst); h.goff = put(sp.goff);
-  {
-    const size_t nl = sp.lev_off.size();
-    std::vector<i32> lr(nl), lt(nl), lfe(nl);
-    for (size_t l = 0; l < nl; ++l) {
-      lr[l] = sp.soff[static_cast<size_t>(sp.lev_off[l])];
-      lt[l] = sp.goff[static_cast<size_t>(sp.lev_g[l])];
-      lfe[l] = sp.foff[static_cast<size_t>(sp.lev_f[l])];
-    }
-    h.lev_r = put(lr); h.lev_t = put(lt); h.lev_fe = put(lfe);
-  }
   {
     // dense tail (see WaveHdr): the longest chain of one-block 1x1 levels at the end whose trailing matrix is dense
     const i32 nlev = static_cast<i32>(sp.lev_off.size()) - 1;
@@ -205,11 +192,31 @@ inline std::vector<i32> build_wave_plan(E* ex, const Tape<E>& t, const SparsePla
     // (the tail's forward products use the five consecutive row-sized arrays dy dvL dvU st gt — dead during every solve — as scratch)
     if (ok && static_cast<i64>(tfq.size()) > 5 * ((static_cast<i64>(t.m) + 1) & ~static_cast<i64>(1))) ok = false;
     if (!ok) { T = 0; Ls = nlev; tnode.clear(); td.clear(); tl.clear(); tfq.clear(); tfp.assign(1, 0); }
+    // Order of the static-pattern LDL^T's tables in the block: what every kernel reads first (assembly positions, the dense
+    // tail's tables, the forward rows the tail gathers through), the level machinery last — a kernel whose LDL^T phases are
+    // generated per template (wave_gen.h) stages only the first keep_gen ints in LDS.
     h.tail_L = Ls; h.tail_T = T;
+    h.hpos = put(sp.hpos); h.jpos = put(sp.jpos); h.dpos = put(sp.dpos);
     h.t_node = put(tnode); h.t_d = put(td); h.t_l = put(tl); h.t_fq = put(tfq); h.t_fp = put(tfp);
     h.t_nf = narrow(static_cast<i64>(tfq.size()));
+    if (T == 0) h.keep_gen = narrow(static_cast<i64>(out.size()));
+    h.fa = put(sp.fa); h.fu0 = put(sp.fu0); h.fu1 = put(sp.fu1);
+    if (T > 0) h.keep_gen = narrow(static_cast<i64>(out.size()));
   }
-  h.tau = put(sp.tau); h.tav = put(sp.tav); h.hpos = put(sp.hpos); h.jpos = put(sp.jpos); h.dpos = put(sp.dpos);
+  h.bnode = put(sp.bnode); h.soff = put(sp.soff); h.loff = put(sp.loff); h.doff = put(sp.doff); h.lev_off = put(sp.lev_off);
+  h.sblk = put(sp.sblk); h.sidx = put(sp.sidx); h.lev_f = put(sp.lev_f); h.fnode = put(sp.fnode); h.foff = put(sp.foff);
+  h.lev_g = put(sp.lev_g); h.gdst = put(sp.gdst); h.goff = put(sp.goff);
+  {
+    const size_t nl = sp.lev_off.size();
+    std::vector<i32> lr(nl), lt(nl), lfe(nl);
+    for (size_t l = 0; l < nl; ++l) {
+      lr[l] = sp.soff[static_cast<size_t>(sp.lev_off[l])];
+      lt[l] = sp.goff[static_cast<size_t>(sp.lev_g[l])];
+      lfe[l] = sp.foff[static_cast<size_t>(sp.lev_f[l])];
+    }
+    h.lev_r = put(lr); h.lev_t = put(lt); h.lev_fe = put(lfe);
+  }
+  h.tau = put(sp.tau); h.tav = put(sp.tav);
   h.l_c0 = narrow(lay.c0); h.l_c = narrow(lay.c); h.l_b = narrow(lay.b); h.l_Jc = narrow(lay.Jc); h.l_G = narrow(lay.G); h.l_Mg = narrow(lay.Mg);
   h.l_Mw = narrow(lay.Mw); h.l_MJ = narrow(lay.MJ); h.l_MH = narrow(lay.MH); h.l_fp = narrow(lay.fp); h.l_fp2 = narrow(lay.fp2);
   h.l_x0 = narrow(lay.x0); h.l_lb = narrow(lay.lb); h.l_ub = narrow(lay.ub); h.l_cl = narrow(lay.cl); h.l_cu = narrow(lay.cu); h.l_total = narrow(lay.total);

@@ -19,14 +19,17 @@ struct __attribute__((aligned(16))) WaveSpecShare {
   double vec[wspec::kStateDoubles];             // its vectors (wave_ipm.h layout: wspec::v_* are offsets into this array)
 };
 
-// the plan block narrowed to 16 bits (staged once per workgroup) and the wavefronts' shares: static LDS, fixed addresses
+// the part of the plan block the kernel still reads (WaveHdr::keep_gen ints: the level machinery's tables are replaced by
+// generated phases), narrowed to 16 bits and staged once per workgroup, and the wavefronts' shares: static LDS, fixed addresses
 __shared__ __attribute__((aligned(16))) int16_t g_wspec_plan[(wspec::kPlanInts + 7) & ~7];
+__shared__ __attribute__((aligned(16))) unsigned g_wspec_gen[(wspec::kGenWords + 3) & ~3];      // work tables of the generated LDL^T phases (wave_gen.h)
 __shared__ WaveSpecShare g_wspec_share[wspec::kNW];
 __shared__ int g_wspec_inst[wspec::kNW];
 
 struct WaveLanesSpec {
   typedef WLdsD D;
   typedef WLdsI I;
+  typedef DNLP_WLDS const unsigned* G;
   static constexpr int lanes = 64;
   __device__ static int lane() { return static_cast<int>(threadIdx.x & 63u); }
   __device__ static void sync() { wave_sync(); }
@@ -42,6 +45,7 @@ struct WaveLanesSpec {
   }
   // a table of the plan block
   __device__ static I* tab(int off) { return (I*)g_wspec_plan + off; }
+  __device__ static G gtab() { return (G)g_wspec_gen; }
 };
 
 }  // namespace dnlp
@@ -53,6 +57,7 @@ extern "C" __global__ void __launch_bounds__(64 * wspec::kNW) dnlp_wave_spec_ker
   using WD = typename P::D;
   const int wave = static_cast<int>(threadIdx.x >> 6), lane = static_cast<int>(threadIdx.x & 63u);
   for (int k = static_cast<int>(threadIdx.x); k < wspec::kPlanInts; k += static_cast<int>(blockDim.x)) g_wspec_plan[k] = static_cast<int16_t>(a.blk[k]);
+  for (int k = static_cast<int>(threadIdx.x); k < wspec::kGenWords; k += static_cast<int>(blockDim.x)) g_wspec_gen[k] = a.gen[k];
   __syncthreads();                     // the only workgroup barrier of the kernel
   typename W::WS* S = (typename W::WS*)g_wspec_share[wave].rec;
   WD* base = (WD*)g_wspec_share[wave].vec;
@@ -75,6 +80,9 @@ extern "C" __global__ void __launch_bounds__(64 * wspec::kNW) dnlp_wave_spec_ker
     S->fallback_max_n = a.fallback_max_n;
     S->opt = a.opt;
     S->factorizations = 0;
+#ifdef DNLP_WAVE_PROF
+    for (int k = 0; k < kWaveProfSlots; ++k) S->prof[k] = 0ull;
+#endif
     wave_sync();
     const int st = W::solve(S);
     const bool have = S->initialized && st != kWaveNeedsGeneric;
@@ -91,6 +99,9 @@ extern "C" __global__ void __launch_bounds__(64 * wspec::kNW) dnlp_wave_spec_ker
         for (int i = lane; i < m; i += 64) a.multg_out[static_cast<i64>(inst) * m + i] = have ? yy[i] * sg[i] / sf : 0.0;
     }
     if (lane == 0) {
+#ifdef DNLP_WAVE_PROF
+      if (a.prof) { for (int k = 0; k < kWaveProfSlots; ++k) atomicAdd(a.prof + k, S->prof[k]); atomicAdd(a.prof + kWaveProfSlots, static_cast<unsigned long long>(S->iter)); }
+#endif
       a.status_out[inst] = st;
       a.iters_out[inst] = S->iter;
       a.obj_out[inst] = have ? S->f / sf : 0.0;

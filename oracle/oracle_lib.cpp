@@ -198,11 +198,135 @@ extern "C" long long orc_wave_spec_source(orc_problem* vp, int nw, char* buf, lo
     if (why[0]) { tls_error() = why; return -2; }
     const std::vector<i32> blk = build_wave_plan(&p->ex, t, p->sparse_plan, wave_layout_of(t));
     const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(blk.data());
-    const int fit = wave_spec_max_waves(h);
+    if (wave_gen_refusal(h)[0]) { tls_error() = wave_gen_refusal(h); return -4; }
+    const WaveGen gen = wave_generate(blk);
+    const int fit = wave_spec_max_waves(h, gen.G.size());
     if (fit < 1) { tls_error() = "the template's state does not fit a compute unit's LDS"; return -3; }
-    const std::string src = wave_spec_source(blk, nw > 0 ? std::min(nw, fit) : fit);
+    const std::string src = wave_spec_source(blk, nw > 0 ? std::min(nw, fit) : fit, gen);
     if (buf && cap > static_cast<long long>(src.size())) { std::memcpy(buf, src.data(), src.size()); buf[src.size()] = 0; }
     return static_cast<long long>(src.size());)
+}
+
+// ---- the per-template straight-line LDL^T phases (dnlp_amd/csrc/wave_gen.h) on the host ---------------------------------
+// orc_wave_gen_host_source: a self-contained translation unit for g++ — the template's constants (namespace wspec), its
+// plan block and work tables as arrays, wave_ipm.h compiled with -DDNLP_WAVE_SPEC -DDNLP_WAVE_GEN over a one-thread lane
+// policy (the generated phases play 64 lanes one after the other), and a driver `wgen_host_solve`.  tests/test_wave_gen_cpu.py
+// builds it and compares its bits with orc_wave_solve_batch (the interpreted text on one host lane).
+#include "../dnlp_amd/csrc/wave_gen.h"
+extern "C" long long orc_wave_gen_host_source(orc_problem* vp, char* buf, long long cap) {
+  using namespace dnlp;
+  orc_problem_t* p = vp;
+  DNLP_TRY(
+    p->plan_linear_solver();
+    const Tape<HostExec>& t = *p->model.owner;
+    if (!p->use_sparse) { tls_error() = "no sparse plan for this tape"; return -1; }
+    const char* why = wave_plan_refusal(t, &p->sparse_plan);
+    if (why[0]) { tls_error() = why; return -2; }
+    const std::vector<i32> blk = build_wave_plan(&p->ex, t, p->sparse_plan, wave_layout_of(t));
+    const WaveGen gen = wave_generate(blk);
+    std::string s;
+    s += "#include \"ipm_core.h\"\n#include \"wave_plan.h\"\n";
+    s += wave_spec_constants(blk, 1);
+    s += "#define DNLP_WAVE_SPEC 1\n#define DNLP_WAVE_GEN 1\n#define DNLP_WAVE_FILTER_CAP 1024\n#include \"wave_ipm.h\"\n#include \"wave_gen_rt.h\"\n";
+    char b[64];
+    s += "static const int32_t k_blk[] = {";
+    for (size_t k = 0; k < blk.size(); ++k) { std::snprintf(b, sizeof b, "%s%d", k ? "," : "", blk[k]); s += b; if ((k & 31) == 31) s += "\n"; }
+    s += "};\nstatic const uint32_t k_gen[] = {";
+    for (size_t k = 0; k < gen.G.size(); ++k) { std::snprintf(b, sizeof b, "%s%uu", k ? "," : "", gen.G[k]); s += b; if ((k & 31) == 31) s += "\n"; }
+    if (gen.G.empty()) s += "0u";
+    s += "};\n";
+    s += R"WGH(
+namespace {
+double* g_vec = nullptr;
+struct HostSpecLane {
+  typedef double D;
+  typedef const dnlp::i32 I;
+  typedef const uint32_t* G;
+  static constexpr int lanes = 1;
+  static int lane() { return 0; }
+  static void sync() {}
+  static double sum(double v) { return v; }
+  static double vmax(double v) { return v; }
+  static int tab_load(const dnlp::i32*, int) { return 0; }
+  static int tab_at(const dnlp::i32* tab, int, int idx, int) { return tab[idx]; }
+  static int uni(int v) { return v; }
+  template <int SL> static double row_get(const double (&a)[SL], int row) { return a[row]; }
+  template <class WS> static D* vec(WS*, int off) { return g_vec + off; }
+  static I* tab(int off) { return k_blk + off; }
+  static G gtab() { return k_gen; }
+};
+}  // namespace
+)WGH";
+    s += gen.code;
+    s += R"WGH(
+// rows: batch x wspec::k_l_total expanded instance rows (orc_wave_expand_rows); opt: the oracle handle's IpmOptions bytes
+extern "C" int wgen_host_solve(int batch, const double* rows, long long row_doubles, const void* opt_bytes, long long opt_size, int fallback_512,
+                               double* x, double* obj, int* status, int* iters, int* nfact, double* mult_g, double* zl, double* zu) {
+  using namespace dnlp;
+  typedef HostSpecLane P;
+  typedef WaveIpm<P> W;
+  if (opt_size != static_cast<long long>(sizeof(IpmOptions))) return -1;
+  std::vector<double> state(static_cast<size_t>(wspec::kStateDoubles) + 64, 0.0);
+  std::vector<double> park(static_cast<size_t>(wave_park_doubles(wspec::k_N, wspec::k_m)) + 8, 0.0);
+  g_vec = state.data();
+  for (int k = 0; k < batch; ++k) {
+    W::WState st;
+    W::WState* S = &st;
+    std::fill(state.begin(), state.end(), 0.0);
+    S->row = rows + static_cast<long long>(k) * row_doubles;
+    S->park = park.data();
+    S->ws_g = S->ws_l = S->ws_u = nullptr;
+    S->fallback_max_n = fallback_512 ? 512 : 0;
+    std::memcpy(&S->opt, opt_bytes, sizeof(IpmOptions));
+    S->factorizations = 0;
+    const int rc = W::solve(S);
+    status[k] = rc; iters[k] = S->iter; nfact[k] = S->factorizations;
+    obj[k] = S->initialized ? S->f / S->sf : 0.0;
+    const double *xx = WV(x), *a = WV(zL), *b = WV(zU), *yy = WV(y), *sg = WV(sg);
+    for (int j = 0; j < wspec::k_N; ++j) {
+      x[static_cast<long long>(k) * wspec::k_N + j] = xx[j];
+      zl[static_cast<long long>(k) * wspec::k_N + j] = a[j] / S->sf;
+      zu[static_cast<long long>(k) * wspec::k_N + j] = b[j] / S->sf;
+    }
+    for (int i = 0; i < wspec::k_m; ++i) mult_g[static_cast<long long>(k) * wspec::k_m + i] = yy[i] * sg[i] / S->sf;
+  }
+  return 0;
+}
+)WGH";
+    if (buf && cap > static_cast<long long>(s.size())) { std::memcpy(buf, s.data(), s.size()); buf[s.size()] = 0; }
+    return static_cast<long long>(s.size());)
+}
+
+extern "C" long long orc_sizeof_ipm_options() { return static_cast<long long>(sizeof(dnlp::IpmOptions)); }
+
+// the instance rows as the wavefront solver reads them (batch.h layout: per-segment parameters expanded per flat row), and the
+// handle's options as bytes — inputs of wgen_host_solve.  Returns the doubles per row (out may be null to ask for it).
+extern "C" long long orc_wave_expand_rows(orc_problem* vp, int batch, const double* data, int64_t stride, double* out, void* opt_out, long long opt_cap,
+                                          int* fallback_512) {
+  using namespace dnlp;
+  orc_problem_t* p = vp;
+  DNLP_TRY(
+    p->plan_linear_solver();
+    const Tape<HostExec>& t = *p->model.owner;
+    const WaveLayoutIn lay = wave_layout_of(t);
+    if (opt_out && opt_cap >= static_cast<long long>(sizeof(IpmOptions))) std::memcpy(opt_out, &p->opt, sizeof(IpmOptions));
+    if (fallback_512) *fallback_512 = ((t.N + t.m) <= 512 && p->linear_solver != 2) ? 1 : 0;
+    if (!out) return lay.total;
+    const i64 head = 1 + (t.N + t.Z) + t.m + t.nnzJ + t.G.nnz + t.Mg.nnz + t.Mw.nnz + t.MJ.nnz + t.MH.nnz;
+    const i64 tail = 3 * t.N + 2 * t.m;
+    if (stride != head + 2 * t.nseg + tail) { tls_error() = "instance stride does not match the tape"; return -3; }
+    for (int k = 0; k < batch; ++k) {
+      const double* src = data + static_cast<i64>(k) * stride;
+      double* row = out + static_cast<i64>(k) * lay.total;
+      std::copy(src, src + head, row);
+      const double *sp = src + head, *sp2 = sp + t.nseg;
+      for (i64 f = 0; f < t.nflat; ++f) {
+        row[lay.fp + f] = sp[t.h_flat_seg[static_cast<size_t>(f)]];
+        row[lay.fp2 + f] = sp2[t.h_flat_seg[static_cast<size_t>(f)]];
+      }
+      std::copy(sp2 + t.nseg, sp2 + t.nseg + tail, row + lay.x0);
+    }
+    return lay.total;)
 }
 
 // plan statistics per level (tools / tests: what the wavefront solver's level phases are made of)
