@@ -1221,30 +1221,36 @@ struct WaveIpm {
     const WD *gr = WV(grad), *a = WV(zL), *b = WV(zU), *c = WV(vL), *d = WV(vU), *yy = WV(y), *eq = WV(eq), *fm = WV(fixm), *gg = WV(g), *ss = WV(s),
              *sl = WV(sL), *su = WV(sU), *l = WV(xL), *u = WV(xU), *xx = WV(x), *sgp = WV(sg);
     double m0 = -kInf, m1 = -kInf, m2 = -kInf, m3 = -kInf, sy = 0.0, sz = 0.0;
+    // (operands first, selects instead of branches: see quality())
     W_FOR(j, N) {
-      const double rj = fm[j] != 0.0 ? 0.0 : gr[j] + jt[j] - a[j] + b[j];
+      const double fmj = fm[j], aj = a[j], bj = b[j], lj = l[j], uj = u[j], xj = xx[j];
+      const double rfree = gr[j] + jt[j] - aj + bj;
+      const double rj = fmj != 0.0 ? 0.0 : rfree;
       r[j] = rj;
       m0 = mxin(m0, fabs(rj));
+      const double cl_ = fabs((xj - lj) * aj - muv), cu_ = fabs((uj - xj) * bj - muv);
       double cv = 0.0;
-      if (l[j] > -kInf) cv = fmax(cv, fabs((xx[j] - l[j]) * a[j] - muv));
-      if (u[j] < kInf) cv = fmax(cv, fabs((u[j] - xx[j]) * b[j] - muv));
+      cv = lj > -kInf ? fmax(cv, cl_) : cv;
+      cv = uj < kInf ? fmax(cv, cu_) : cv;
       m2 = mxin(m2, cv);
-      sz += fabs(a[j]) + fabs(b[j]);
+      sz += fabs(aj) + fabs(bj);
     }
     W_FOR(i, m) {
-      const double qi = (eq[i] == 0.0) ? -yy[i] - c[i] + d[i] : 0.0;
+      const double eqi = eq[i], yi = yy[i], ci = c[i], di = d[i], gi = gg[i], li = sl[i], ui = su[i], si = ss[i], sgi = sgp[i];
+      const bool in = eqi == 0.0;
+      const double qfree = -yi - ci + di;
+      const double qi = in ? qfree : 0.0;
       q[i] = qi;
       m0 = mxin(m0, fabs(qi));
-      const double pr = fabs(eq[i] != 0.0 ? gg[i] - sl[i] : gg[i] - ss[i]);
+      const double pr = fabs(eqi != 0.0 ? gi - li : gi - si);
       m1 = mxin(m1, pr);
-      m3 = mxin(m3, pr / sgp[i]);
+      m3 = mxin(m3, pr / sgi);
+      const double cl_ = fabs((si - li) * ci - muv), cu_ = fabs((ui - si) * di - muv);
       double cv = 0.0;
-      if (eq[i] == 0.0) {
-        if (sl[i] > -kInf) cv = fmax(cv, fabs((ss[i] - sl[i]) * c[i] - muv));
-        if (su[i] < kInf) cv = fmax(cv, fabs((su[i] - ss[i]) * d[i] - muv));
-      }
+      cv = (in && li > -kInf) ? fmax(cv, cl_) : cv;
+      cv = (in && ui < kInf) ? fmax(cv, cu_) : cv;
       m2 = mxin(m2, cv);
-      sy += fabs(yy[i]) + fabs(c[i]) + fabs(d[i]);
+      sy += fabs(yi) + fabs(ci) + fabs(di);
     }
     m0 = P::vmax(m0); m1 = P::vmax(m1); m2 = P::vmax(m2); m3 = P::vmax(m3); sy = P::sum(sy); sz = P::sum(sz);
     P::sync();

@@ -13,7 +13,7 @@ if [ "$4" = "quick" ]; then
     i=$((i+1))
     timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/p$i -- python3 tools/wave_check.py --which $W --batch $B --reps 1 --skip-generic --out pmc_wave_runs.jsonl > $O/p$i.log 2>&1 < /dev/null
   done
-  python3 tools/pmc_summary.py $O/wave_quick.json $O/p1 $O/p2 $O/p3 --kernel wave_batch > /dev/null
+  python3 tools/pmc_summary.py $O/wave_quick.json $O/p1 $O/p2 $O/p3 --kernel ${KERNEL_FILTER:-wave_} > /dev/null
   rm -rf $O/p?
   python3 -c "
 import json,sys
@@ -33,6 +33,6 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
   timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/p$i -- python3 tools/wave_check.py --which $W --batch $B --reps 1 --skip-generic --out pmc_wave_runs.jsonl > $O/p$i.log 2>&1 < /dev/null
   tail -1 $O/p$i.log | cut -c1-160
 done
-python3 tools/pmc_summary.py $O/wave_mix.json $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 $O/p6 $O/p7 --kernel wave_batch > /dev/null
+python3 tools/pmc_summary.py $O/wave_mix.json $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 $O/p6 $O/p7 --kernel ${KERNEL_FILTER:-wave_} > /dev/null
 rm -rf $O/p?
 cat $O/wave_mix.json
