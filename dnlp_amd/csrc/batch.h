@@ -418,11 +418,11 @@ struct BatchRunner {
     if (!fits) return false;
     const double t0 = now_sec();
     const WaveGen gen = wave_generate(wave_blk);
-    const int fit = wave_spec_max_waves(h, gen.G.size());
-    if (fit < 1) return false;
     // (DNLP_WAVE_SPEC_PROF: the kernel is compiled with the cycle counters of wave_ipm.h W_P0 / W_P1 and the host prints them)
     wave_spec_prof = std::getenv("DNLP_WAVE_SPEC_PROF") != nullptr;
-    const std::string src = (wave_spec_prof ? std::string("#define DNLP_WAVE_PROF 1\n") : std::string()) + wave_spec_source(wave_blk, fit, gen);
+    const int fit = wave_spec_max_waves(h, gen.G.size(), wave_spec_prof);
+    if (fit < 1) return false;
+    const std::string src = wave_spec_source(wave_blk, fit, gen, wave_spec_prof);
     if (!wave_spec.load(src, "dnlp_wave_spec_kernel")) {
       std::fprintf(stderr, "[dnlp] per-template batch kernel not available (the library's own kernel is used): %s\n", wave_spec.log.substr(0, 2000).c_str());
       return false;
@@ -1148,7 +1148,8 @@ struct BatchRunner {
       // own form would run (it stages less: the level machinery's tables are generated code): its static LDS (plan prefix +
       // work tables + wave_spec_nw shares) fills the compute unit, a launch puts as many wavefronts into a workgroup as it
       // has instances per compute unit
-      if (wave_spec_prepare(batch) && std::min(wave_spec_nw, want) >= nw) {
+      const bool spec_forced = std::getenv("DNLP_WAVE_SPEC") && std::atoi(std::getenv("DNLP_WAVE_SPEC")) == 1;
+      if (wave_spec_prepare(batch) && (spec_forced || std::min(wave_spec_nw, want) >= nw)) {
         spec = true;
         nw = std::min(wave_spec_nw, want); pl = 1;
         w.gen = d_wave_gen; w.gen_words = wave_gen_words;

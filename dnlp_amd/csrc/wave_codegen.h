@@ -46,21 +46,22 @@ struct WaveProbeLanes {
   template <int SL> static double row_get(const double (&a)[SL], int row) { return a[row]; }
 };
 
-constexpr int kWaveSpecRecBytesMax = 1792;      // (what the host sizes a launch with; the kernel asserts its record — 1334 B today, 1558 B with the
-                                                //  cycle counters of a profile build — fits)
+constexpr int kWaveSpecRecBytesMax = 1344;      // (what the host sizes a launch with; the kernel asserts its record — 1334 B today — fits;
+                                                //  a profile build's record carries 224 B of cycle counters more: kWaveSpecRecBytesProf)
+constexpr int kWaveSpecRecBytesProf = 1568;
 
 // the largest number of wavefronts per workgroup whose shares fit a compute unit's LDS beside the 16-bit plan (0: none)
-inline int wave_spec_max_waves(const WaveHdr& h, size_t gen_words) {
+inline int wave_spec_max_waves(const WaveHdr& h, size_t gen_words, bool prof = false) {
   const size_t cap = 160 * 1024 - 512;
   const size_t plan_b = ((static_cast<size_t>(h.keep_gen) + 7) & ~static_cast<size_t>(7)) * 2 + ((gen_words + 3) & ~static_cast<size_t>(3)) * 4;
-  const size_t share_b = kWaveSpecRecBytesMax + static_cast<size_t>(h.state_doubles) * 8 + 16;
+  const size_t share_b = (prof ? kWaveSpecRecBytesProf : kWaveSpecRecBytesMax) + static_cast<size_t>(h.state_doubles) * 8 + 16;
   if (plan_b + share_b > cap) return 0;
   const size_t k = (cap - plan_b) / share_b;
   return static_cast<int>(k > 8 ? 8 : k);
 }
 
 // namespace wspec of a template: the literals behind WK / WT / WV / WDIR / WCSR / WCOO (wave_ipm.h)
-inline std::string wave_spec_constants(const std::vector<i32>& blk, int nw, size_t gen_words = 0) {
+inline std::string wave_spec_constants(const std::vector<i32>& blk, int nw, size_t gen_words = 0, bool prof = false) {
   const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(blk.data());
   typedef WaveIpm<WaveProbeLanes> W;
   W::WState S;
@@ -92,6 +93,7 @@ inline std::string wave_spec_constants(const std::vector<i32>& blk, int nw, size
     s += b;
   };
   csr("G", S.G); csr("Mg", S.Mg); csr("MJ", S.MJ); csr("Mw", S.Mw); csr("MH", S.MH);
+  s += "constexpr int k_G_id = 0, k_Mg_id = 1, k_MJ_id = 2, k_Mw_id = 3, k_MH_id = 4;\n";
   auto coo = [&](const char* name, const W::WCoo& M) {
     std::snprintf(b, sizeof b, "constexpr int t_%s_ptr = %lld, t_%s_ent = %lld, t_%s_src = %lld, t_%s_heavy = %lld, k_%s_nout = %d, k_%s_nheavy = %d;\n", name,
                   static_cast<long long>(M.ptr - blk.data()), name, static_cast<long long>(M.ent - blk.data()), name, static_cast<long long>(M.src - blk.data()),
@@ -103,7 +105,7 @@ inline std::string wave_spec_constants(const std::vector<i32>& blk, int nw, size
   put("", "kPlanInts", h.keep_gen);      // (what a kernel with generated LDL^T phases stages of the block)
   put("", "kGenWords", static_cast<long long>(gen_words));
   put("", "kNW", nw);
-  put("", "kRecBytesMax", kWaveSpecRecBytesMax);
+  put("", "kRecBytesMax", prof ? kWaveSpecRecBytesProf : kWaveSpecRecBytesMax);
   s += "}  // namespace wspec\n";
   return s;
 }
@@ -159,7 +161,7 @@ inline std::string wave_spec_text(const char* name, const char* embedded) {
 }
 
 // the translation unit of a template's kernel (entry point: dnlp_wave_spec_kernel)
-inline std::string wave_spec_source(const std::vector<i32>& blk, int nw, const WaveGen& gen) {
+inline std::string wave_spec_source(const std::vector<i32>& blk, int nw, const WaveGen& gen, bool prof = false) {
   static const char* atom_math_text =
 #include "atom_math_src.inc"
       ;
@@ -184,12 +186,13 @@ inline std::string wave_spec_source(const std::vector<i32>& blk, int nw, const W
   static const char* wave_spec_kernel_text =
 #include "wave_spec_kernel_src.inc"
       ;
-  std::string s = wave_spec_prelude();
+  std::string s = prof ? "#define DNLP_WAVE_PROF 1\n" : "";
+  s += wave_spec_prelude();
   s += wave_spec_text("atom_math.h", atom_math_text);
   s += wave_spec_text("ipm_options.h", ipm_options_text);
   s += wave_spec_text("wave_hdr.h", wave_hdr_text);
   s += wave_spec_text("wave_args.h", wave_args_text);
-  s += wave_spec_constants(blk, nw, gen.G.size());
+  s += wave_spec_constants(blk, nw, gen.G.size(), prof);
   s += wave_spec_text("wave_ops.h", wave_ops_text);
   s += wave_spec_text("wave_ipm.h", wave_ipm_text);
   s += wave_spec_text("wave_spec_kernel.h", wave_spec_kernel_text);      // (the lane policy P: the generated functions below are templates over it)

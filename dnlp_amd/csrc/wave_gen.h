@@ -55,7 +55,7 @@ inline uint32_t lo16(int v) {
 
 // can the phases of this plan be generated?  ("" = yes)
 inline const char* wave_gen_refusal(const WaveHdr& h) {
-  if (h.sp_nvals >= 32768 || h.N + h.m >= 65535 || 3 * h.sp_nblk + 8 >= (1 << 30)) return "plan beyond the generated tables' 16-bit fields";
+  if (h.sp_nvals >= 32768 || h.N + h.m >= 65535 || h.sp_nblk >= 16384) return "plan beyond the generated tables' 16-bit fields";
   return "";
 }
 
@@ -90,13 +90,12 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
     // pivots
     for (int s0 = b0; s0 < b1; s0 += 64) {
       const int nact = std::min(64, b1 - s0);
-      const int at = E.reserve(2 * static_cast<size_t>(nact));
+      const int at = E.reserve(static_cast<size_t>(nact));
       int kinds = 0;
       for (int j = 0; j < nact; ++j) {
         const int k = s0 + j, kind = bnode[2 * k + 1] < 0 ? 1 : 2;
         kinds |= kind;
-        out.G[static_cast<size_t>(at + j)] = lo16(doff[k]) | (static_cast<uint32_t>(kind) << 16);
-        out.G[static_cast<size_t>(at + nact + j)] = static_cast<uint32_t>(3 * k);
+        out.G[static_cast<size_t>(at + j)] = lo16(doff[k]) | (static_cast<uint32_t>(k) << 16) | (static_cast<uint32_t>(kind) << 30);
       }
       E.line("  WG_BEGIN wgrt::piv<%d, %d, %d>(lane, G, vals, dinv, nneg, nzero, bad); WG_END\n", at, nact, kinds);
       ++out.phases_factor;
@@ -105,15 +104,14 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
     // row scaling
     for (int s0 = r0; s0 < r1; s0 += 64) {
       const int nact = std::min(64, r1 - s0);
-      const int at = E.reserve(2 * static_cast<size_t>(nact));
+      const int at = E.reserve(static_cast<size_t>(nact));
       int kinds = 0;
       for (int j = 0; j < nact; ++j) {
         const int r = s0 + j, k = sblk[r], i = r - soff[k];
         const bool one = bnode[2 * k + 1] < 0;
         kinds |= one ? 1 : 2;
         const int a = one ? loff[k] + i : loff[k] + 2 * i;
-        out.G[static_cast<size_t>(at + j)] = lo16(a) | (static_cast<uint32_t>(one ? 1 : 2) << 16);
-        out.G[static_cast<size_t>(at + nact + j)] = static_cast<uint32_t>(3 * k);
+        out.G[static_cast<size_t>(at + j)] = lo16(a) | (static_cast<uint32_t>(k) << 16) | (static_cast<uint32_t>(one ? 1 : 2) << 30);
       }
       E.line("  WG_BEGIN wgrt::scl<%d, %d, %d>(lane, G, vals, w, dinv); WG_END\n", at, nact, kinds);
       ++out.phases_factor;
@@ -269,7 +267,122 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
       ++out.phases_solve;
     }
   }
-  E.line("}\n\n}  // namespace wgen\n}  // namespace dnlp\n");
+  E.line("}\n\n");
+  // ================================================================ KKT residual (products by output fused with the combination)
+  {
+    const i32 *hsp = T(h.hs_ptr), *hse = T(h.hs_ent), *hss = T(h.hs_src), *jcp = T(h.jc_ptr), *jce = T(h.jc_ent), *jcs = T(h.jc_src),
+              *jrp = T(h.jr_ptr), *jre = T(h.jr_ent), *jrs = T(h.jr_src);
+    const int N = h.N, m = h.m;
+    E.line("// wave_ipm.h kkt_residual_impl / kkt_residual2 for THIS template: out = rhs - K v (and the same for a second system)\n");
+    E.line("template <class P, bool TWO, class WS, class WD> DNLP_WINL DNLP_HD void kkt_residual(WS* S, double dw, const WD* v, const WD* rhsv, WD* out,\n"
+           "    const WD* v2, const WD* rhsv2, WD* out2, double& en, double& sn, double& en2, double& sn2) {\n"
+           "  const WD *Hs = WV(Hs), *jv = WV(jv), *sx = WV(Sx), *dd = WV(Dd), *fm = WV(fixm);\n"
+           "  WD *preH = out, *preJt = WV(xt), *preJ = WV(tM), *preH2 = out2, *preJt2 = WV(dx), *preJ2 = WV(ds);\n"
+           "  typename P::G G = P::gtab();\n");
+    // long outputs first, by all lanes
+    bool any_heavy = false;
+    std::string jt_heavy, jt_light;          // the same tables drive J^T y alone (jac_tmult below)
+    auto heavy = [&](const i32* ptr, const i32* ent, const i32* src, int nout, const char* a, const char* vv, const char* v2, const char* pre, const char* pre2, bool is_jc) {
+      for (int g = 0; g < nout; ++g) {
+        const int c = ptr[g + 1] - ptr[g];
+        if (c <= kCooHeavy) continue;
+        any_heavy = true;
+        E.line("  { double acc = 0.0, acc2 = 0.0;\n");
+        if (is_jc) jt_heavy += "  { double acc = 0.0, acc2 = 0.0;\n";
+        char b[256];
+        for (int e0 = 0; e0 < c; e0 += 64) {
+          const int cnt = std::min(64, c - e0);
+          const int ea = E.reserve(static_cast<size_t>(cnt));
+          for (int j = 0; j < cnt; ++j) out.G[static_cast<size_t>(ea + j)] = lo16(ent[ptr[g] + e0 + j]) | (lo16(src[ptr[g] + e0 + j]) << 16);
+          E.line("    wgrt::wdot<P, TWO, %d, %d>(G, %s, %s, %s, acc, acc2);\n", ea, cnt, a, vv, v2);
+          if (is_jc) { std::snprintf(b, sizeof b, "    wgrt::wdot<P, false, %d, %d>(G, jv, v, v, acc, acc2);\n", ea, cnt); jt_heavy += b; }
+        }
+        E.line("    wgrt::wdot_fin<P, TWO, %d>(%s, %s, acc, acc2); }\n", g, pre, pre2);
+        if (is_jc) { std::snprintf(b, sizeof b, "    wgrt::wdot_fin<P, false, %d>(out, out, acc, acc2); }\n", g); jt_heavy += b; }
+      }
+    };
+    heavy(hsp, hse, hss, N, "Hs", "v", "v2", "preH", "preH2", false);
+    {
+      char vb[64], v2b[64];
+      std::snprintf(vb, sizeof vb, "v + %d", N); std::snprintf(v2b, sizeof v2b, "v2 + %d", N);
+      heavy(jcp, jce, jcs, N, "jv", vb, v2b, "preJt", "preJt2", true);
+    }
+    heavy(jrp, jre, jrs, m, "jv", "v", "v2", "preJ", "preJ2", false);
+    if (any_heavy) E.line("  P::sync();\n");
+    E.line("  double m0 = -kInf, m1 = -kInf, n0 = -kInf, n1 = -kInf;\n");
+    for (int k0 = 0; k0 < N; k0 += 64) {
+      const int nact = std::min(64, N - k0);
+      int maxh = 0, maxj = 0;
+      for (int j = 0; j < nact; ++j) {
+        const int k = k0 + j, ch = hsp[k + 1] - hsp[k], cj = jcp[k + 1] - jcp[k];
+        if (ch <= kCooHeavy) maxh = std::max(maxh, ch);
+        if (cj <= kCooHeavy) maxj = std::max(maxj, cj);
+      }
+      const int at = E.reserve(static_cast<size_t>(nact)), ea = E.reserve(static_cast<size_t>(maxh + maxj) * static_cast<size_t>(nact));
+      for (int j = 0; j < nact; ++j) {
+        const int k = k0 + j, ch = hsp[k + 1] - hsp[k], cj = jcp[k + 1] - jcp[k];
+        const bool hh = ch > kCooHeavy, hj = cj > kCooHeavy;
+        out.G[static_cast<size_t>(at + j)] = static_cast<uint32_t>(hh ? 0 : ch) | (static_cast<uint32_t>(hj ? 0 : cj) << 8) | (hh ? 0x10000u : 0u) | (hj ? 0x20000u : 0u);
+        if (!hh) for (int e = 0; e < ch; ++e) out.G[static_cast<size_t>(ea + e * nact + j)] = lo16(hse[hsp[k] + e]) | (lo16(hss[hsp[k] + e]) << 16);
+        if (!hj) for (int e = 0; e < cj; ++e) out.G[static_cast<size_t>(ea + (maxh + e) * nact + j)] = lo16(jce[jcp[k] + e]) | (lo16(N + jcs[jcp[k] + e]) << 16);
+      }
+      E.line("  WG_BEGIN wgrt::kres_var<TWO, %d, %d, %d, %d, %d, %d>(lane, G, Hs, jv, sx, fm, dw, v, rhsv, out, (const WD*)preH, (const WD*)preJt, v2, rhsv2, out2, (const WD*)preH2, (const WD*)preJt2, m0, m1, n0, n1); WG_END\n",
+             at, ea, nact, k0, maxh, maxj);
+      { char b[256]; std::snprintf(b, sizeof b, "  WG_BEGIN wgrt::cojt<%d, %d, %d, %d, %d, %d>(lane, G, jv, v - %d, out); WG_END\n", at, ea, nact, k0, maxh, maxj, N); jt_light += b; }
+    }
+    for (int i0 = 0; i0 < m; i0 += 64) {
+      const int nact = std::min(64, m - i0);
+      int maxj = 0;
+      for (int j = 0; j < nact; ++j) { const int c = jrp[i0 + j + 1] - jrp[i0 + j]; if (c <= kCooHeavy) maxj = std::max(maxj, c); }
+      const int at = E.reserve(static_cast<size_t>(nact)), ea = E.reserve(static_cast<size_t>(maxj) * static_cast<size_t>(nact));
+      for (int j = 0; j < nact; ++j) {
+        const int i = i0 + j, c = jrp[i + 1] - jrp[i];
+        const bool hv = c > kCooHeavy;
+        out.G[static_cast<size_t>(at + j)] = static_cast<uint32_t>(hv ? 0 : c) | (hv ? 0x10000u : 0u);
+        if (!hv) for (int e = 0; e < c; ++e) out.G[static_cast<size_t>(ea + e * nact + j)] = lo16(jre[jrp[i] + e]) | (lo16(jrs[jrp[i] + e]) << 16);
+      }
+      E.line("  WG_BEGIN wgrt::kres_row<TWO, %d, %d, %d, %d, %d, %d>(lane, G, jv, dd, v, rhsv, out, (const WD*)preJ, v2, rhsv2, out2, (const WD*)preJ2, m0, m1, n0, n1); WG_END\n",
+             at, ea, nact, i0, N, maxj);
+    }
+    E.line("  en = P::vmax(m0); sn = P::vmax(m1);\n  if (TWO) { en2 = P::vmax(n0); sn2 = P::vmax(n1); }\n  P::sync();\n}\n\n");
+    E.line("// wave_ipm.h jac_tmult (the product by output J^T v of the tape's index jc) out of the same tables\n");
+    E.line("template <class P, class WS, class WD> DNLP_WINL DNLP_HD void jac_tmult(WS* S, const WD* v, WD* out) {\n"
+           "  const WD* jv = WV(jv);\n  typename P::G G = P::gtab();\n");
+    out.code += jt_light;
+    out.code += jt_heavy;
+    E.line("  P::sync();\n}\n\n");
+  }
+  // ================================================================ the five constant CSR maps
+  {
+    struct M { const char* name; i32 ptr, idx, rows, val; };
+    const M mats[5] = {{"G", h.G_ptr, h.G_idx, h.m, h.l_G}, {"Mg", h.Mg_ptr, h.Mg_idx, h.N, h.l_Mg}, {"MJ", h.MJ_ptr, h.MJ_idx, h.nnzJ, h.l_MJ},
+                       {"Mw", h.Mw_ptr, h.Mw_idx, h.Z, h.l_Mw}, {"MH", h.MH_ptr, h.MH_idx, h.nnzH, h.l_MH}};
+    E.line("// wave_ipm.h spmv for THIS template's constant maps (id: 0 G, 1 Mg, 2 MJ, 3 Mw, 4 MH)\n");
+    E.line("template <class P, bool SPLIT, class WS, class WD> DNLP_WINL DNLP_HD void spmv(WS* S, int id, const WD* v, i32 base_off, WD* y, int scale_kind, double scalar,\n"
+           "    const WD* vhi, i32 split) {\n"
+           "  typename P::G G = P::gtab();\n  const WD* sg = WV(sg);\n  typename P::I* jr = WT(jac_rows);\n"
+           "  WG* base = base_off >= 0 ? S->row + base_off : nullptr;\n");
+    for (int q = 0; q < 5; ++q) {
+      const M& mt = mats[q];
+      const i32 *ptr = T(mt.ptr), *idx = T(mt.idx);
+      E.line("  %sif (id == %d) {      // %s: %d rows\n    WG* val = S->row + %d;\n", q ? "else " : "", q, mt.name, mt.rows, mt.val);
+      for (int r0 = 0; r0 < mt.rows; r0 += 64) {
+        const int nact = std::min(64, mt.rows - r0);
+        int maxc = 0;
+        for (int j = 0; j < nact; ++j) maxc = std::max(maxc, ptr[r0 + j + 1] - ptr[r0 + j]);
+        const int at = E.reserve(static_cast<size_t>(nact)), ea = E.reserve(static_cast<size_t>((maxc + 1) / 2) * static_cast<size_t>(nact));
+        for (int j = 0; j < nact; ++j) {
+          const int r = r0 + j, c = ptr[r + 1] - ptr[r];
+          out.G[static_cast<size_t>(at + j)] = lo16(ptr[r]) | (lo16(c) << 16);
+          for (int e = 0; e < c; ++e) out.G[static_cast<size_t>(ea + (e >> 1) * nact + j)] |= lo16(idx[ptr[r] + e]) << ((e & 1) ? 16 : 0);
+        }
+        E.line("    WG_BEGIN wgrt::spmv<SPLIT, %d, %d, %d, %d, %d>(lane, G, val, base, v, vhi, split, y, scale_kind, scalar, sg, jr); WG_END\n", at, ea, nact, r0, maxc);
+      }
+      E.line("  }\n");
+    }
+    E.line("}\n\n");
+  }
+  E.line("}  // namespace wgen\n}  // namespace dnlp\n");
   return out;
 }
 

@@ -50,19 +50,24 @@ WG_INLINE void fwd(int lane, GP G, const VP vals, VP x, VP y) {
       const int a = static_cast<int>(w0 & 0xffffu), u0 = static_cast<int>(w0 >> 16), u1 = static_cast<int>(w1 & 0xffffu);
       const bool on = !RAGGED || e < cnt;
       const bool two = KINDS == 2 || (KINDS == 3 && (w1 >> 16) == 2u);
+      // (every operand is LOADED unconditionally — a padded entry's indices are zeros, valid places — and SELECTED afterwards:
+      //  a load under a condition is a branch, and a branch per entry is an LDS round trip per entry)
       if (KINDS == 1) {
-        const double l = on ? vals[a] : 0.0, xv = on ? x[u0] : 0.0;
+        const double lr = vals[a], xr = x[u0];
+        const double l = on ? lr : 0.0, xv = on ? xr : 0.0;
         acc += l * xv;
-        if (TWO) { const double yv = on ? y[u0] : 0.0; acc2 += l * yv; }
+        if (TWO) { const double yr = y[u0]; const double yv = on ? yr : 0.0; acc2 += l * yv; }
       } else if (KINDS == 2) {
-        const double l0 = on ? vals[a] : 0.0, l1 = on ? vals[a + 1] : 0.0, x0 = on ? x[u0] : 0.0, x1 = on ? x[u1] : 0.0;
+        const double lr0 = vals[a], lr1 = vals[a + 1], xr0 = x[u0], xr1 = x[u1];
+        const double l0 = on ? lr0 : 0.0, l1 = on ? lr1 : 0.0, x0 = on ? xr0 : 0.0, x1 = on ? xr1 : 0.0;
         acc += l0 * x0 + l1 * x1;
-        if (TWO) { const double y0 = on ? y[u0] : 0.0, y1 = on ? y[u1] : 0.0; acc2 += l0 * y0 + l1 * y1; }
+        if (TWO) { const double yr0 = y[u0], yr1 = y[u1]; const double y0 = on ? yr0 : 0.0, y1 = on ? yr1 : 0.0; acc2 += l0 * y0 + l1 * y1; }
       } else {
         // mixed: the loads side by side, the two forms of the sum under the lane's own kind
-        const double l0 = on ? vals[a] : 0.0, l1 = (on && two) ? vals[a + 1] : 0.0, x0 = on ? x[u0] : 0.0, x1 = (on && two) ? x[u1] : 0.0;
+        const double lr0 = vals[a], lr1 = vals[a + 1], xr0 = x[u0], xr1 = x[u1];
+        const double l0 = on ? lr0 : 0.0, l1 = (on && two) ? lr1 : 0.0, x0 = on ? xr0 : 0.0, x1 = (on && two) ? xr1 : 0.0;
         double y0 = 0.0, y1 = 0.0;
-        if (TWO) { y0 = on ? y[u0] : 0.0; y1 = (on && two) ? y[u1] : 0.0; }
+        if (TWO) { const double yr0 = y[u0], yr1 = y[u1]; y0 = on ? yr0 : 0.0; y1 = (on && two) ? yr1 : 0.0; }
         if (two) { acc += l0 * x0 + l1 * x1; if (TWO) acc2 += l0 * y0 + l1 * y1; }
         else { acc += l0 * x0; if (TWO) acc2 += l0 * y0; }
       }
@@ -229,20 +234,25 @@ WG_INLINE void bwd(int lane, GP G, const VP vals, VP x, VP y) {
       const u32 w = G[E0 + (i >> 1) * NACT + lane];
       const int u = static_cast<int>((i & 1) ? (w >> 16) : (w & 0xffffu));
       const bool on = !RAGGED || i < sn;
+      // (loads unconditional, selected afterwards: see fwd.  A padded row reads within the level's values: i < MAXC)
       if (KINDS == 1) {
-        const double l = on ? vals[lof + i] : 0.0, xi = on ? x[u] : 0.0;
+        const double lr = vals[on ? lof + i : lof], xr = x[u];
+        const double l = on ? lr : 0.0, xi = on ? xr : 0.0;
         a0 += l * xi;
-        if (TWO) { const double yi = on ? y[u] : 0.0; c0 += l * yi; }
+        if (TWO) { const double yr = y[u]; const double yi = on ? yr : 0.0; c0 += l * yi; }
       } else if (KINDS == 2) {
-        const double l0 = on ? vals[lof + 2 * i] : 0.0, l1 = on ? vals[lof + 2 * i + 1] : 0.0, xi = on ? x[u] : 0.0;
+        const int p0 = on ? lof + 2 * i : lof;
+        const double lr0 = vals[p0], lr1 = vals[p0 + 1], xr = x[u];
+        const double l0 = on ? lr0 : 0.0, l1 = on ? lr1 : 0.0, xi = on ? xr : 0.0;
         a0 += l0 * xi; a1 += l1 * xi;
-        if (TWO) { const double yi = on ? y[u] : 0.0; c0 += l0 * yi; c1 += l1 * yi; }
+        if (TWO) { const double yr = y[u]; const double yi = on ? yr : 0.0; c0 += l0 * yi; c1 += l1 * yi; }
       } else {
-        const int p0 = one ? lof + i : lof + 2 * i;
-        const double l0 = on ? vals[p0] : 0.0, l1 = (on && !one) ? vals[p0 + 1] : 0.0, xi = on ? x[u] : 0.0;
+        const int p0 = on ? (one ? lof + i : lof + 2 * i) : lof;
+        const double lr0 = vals[p0], lr1 = vals[p0 + 1], xr = x[u];
+        const double l0 = on ? lr0 : 0.0, l1 = (on && !one) ? lr1 : 0.0, xi = on ? xr : 0.0;
         a0 += l0 * xi;
         if (!one) a1 += l1 * xi;
-        if (TWO) { const double yi = on ? y[u] : 0.0; c0 += l0 * yi; if (!one) c1 += l1 * yi; }
+        if (TWO) { const double yr = y[u]; const double yi = on ? yr : 0.0; c0 += l0 * yi; if (!one) c1 += l1 * yi; }
       }
     }
     x[u0] -= a0;
@@ -255,13 +265,13 @@ WG_INLINE void bwd(int lane, GP G, const VP vals, VP x, VP y) {
 }
 
 // ---- factorisation: pivots of a level (sparse_ldl.h sp_pivot) -----------------------------------------------------------
-// descriptor (2 words): doff | kind << 16 (1: 1x1, 2: 2x2), 3 k (where the block's inverse goes in dinv)
+// descriptor (1 word): doff | k << 16 | kind << 30 (kind 1: 1x1, 2: 2x2; the block's inverse goes to dinv[3 k ..])
 template <int D0, int NACT, int KINDS, class GP, class VP>
 WG_INLINE void piv(int lane, GP G, VP vals, VP dinv, double& nneg, double& nzero, double& bad) {
   if (lane < NACT) {
-    const u32 w0 = G[D0 + lane], w1 = G[D0 + NACT + lane];
-    const int dof = static_cast<int>(w0 & 0xffffu), k3 = static_cast<int>(w1);
-    const bool one = KINDS == 1 || (KINDS == 3 && (w0 >> 16) == 1u);
+    const u32 w0 = G[D0 + lane];
+    const int dof = static_cast<int>(w0 & 0xffffu), k3 = 3 * static_cast<int>((w0 >> 16) & 0x3fffu);
+    const bool one = KINDS == 1 || (KINDS == 3 && (w0 >> 30) == 1u);
     if (one) {
       double d = vals[dof];
       if (!(d == d)) bad += 1.0;
@@ -281,13 +291,13 @@ WG_INLINE void piv(int lane, GP G, VP vals, VP dinv, double& nneg, double& nzero
 }
 
 // ---- factorisation: struct rows of a level scaled by their block's inverse pivot (sp_scale) ---------------------------------
-// descriptor (2 words): a | kind << 16, 3 k
+// descriptor (1 word): a | k << 16 | kind << 30
 template <int D0, int NACT, int KINDS, class GP, class VP>
 WG_INLINE void scl(int lane, GP G, VP vals, VP w, const VP dinv) {
   if (lane < NACT) {
-    const u32 w0 = G[D0 + lane], w1 = G[D0 + NACT + lane];
-    const int a = static_cast<int>(w0 & 0xffffu), k3 = static_cast<int>(w1);
-    const bool one = KINDS == 1 || (KINDS == 3 && (w0 >> 16) == 1u);
+    const u32 w0 = G[D0 + lane];
+    const int a = static_cast<int>(w0 & 0xffffu), k3 = 3 * static_cast<int>((w0 >> 16) & 0x3fffu);
+    const bool one = KINDS == 1 || (KINDS == 3 && (w0 >> 30) == 1u);
     if (one) {
       const double l1 = vals[a];
       w[a] = l1;
@@ -332,6 +342,187 @@ WG_INLINE void gsum(int lane, GP G, VP vals, const VP scr) {
       acc += on ? t : 0.0;
     }
     vals[dst] -= acc;
+  }
+}
+
+// =====================================================================================================================
+// products by output (the tape's indices hs / jc / jr: wave_ipm.h coo, kkt_residual) and the constant CSR maps (spmv)
+// =====================================================================================================================
+// NaN conventions of the reductions (wave_ipm.h mxin)
+WG_INLINE double mxin(double acc, double v) { return fmax(acc, v != v ? __builtin_inf() : v); }
+
+// ---- ONE long output by all lanes: sum over its entries of a[ent] v[src] (+ the same with v2), entries across the lanes,
+// added in entry order (the interpreted text's coo_heavy on the host lane).  entry (1 word): ent | src << 16.
+template <class P, bool TWO, int E0, int CNT, class GP, class CP>
+WG_INLINE void wdot(GP G, CP a, CP v, CP v2, double& acc, double& acc2) {
+#if DNLP_DEVICE_PASS
+  const int lane = P::lane();
+  double p = 0.0, p2 = 0.0;
+  if (lane < CNT) {
+#else
+  for (int lane = 0; lane < CNT; ++lane) {
+    double p = 0.0, p2 = 0.0;
+#endif
+    const u32 w = G[E0 + lane];
+    const double c = a[w & 0xffffu];
+    p = c * v[w >> 16];
+    if (TWO) p2 = c * v2[w >> 16];
+#if DNLP_DEVICE_PASS
+  }
+#pragma unroll
+  for (int e = 0; e < CNT; ++e) {
+    acc += readlane_d(p, e);
+    if (TWO) acc2 += readlane_d(p2, e);
+  }
+#else
+    acc += p;
+    if (TWO) acc2 += p2;
+  }
+#endif
+}
+template <class P, bool TWO, int OUT, class VP>
+WG_INLINE void wdot_fin(VP pre, VP pre2, double acc, double acc2) {
+#if DNLP_DEVICE_PASS
+  if (P::lane() == 0) {
+#else
+  {
+#endif
+    pre[OUT] = acc;
+    if (TWO) pre2[OUT] = acc2;
+  }
+}
+
+// ---- KKT residual, variable part: out[k] = rhs[k] - (sym(H) v + (Sx + dw) v + J^T v_y)[k], k = K0 + lane (kkt_residual) --------
+// descriptor (1 word): nh | nj << 8 | (H output long) << 16 | (J^T output long) << 17.  entries (1 word each, [e][lane]):
+// first MAXH of H (ent | src << 16), then MAXJ of J^T (ent | (N + src) << 16).  A long output was summed beforehand into pre*.
+template <bool TWO, int D0, int E0, int NACT, int K0, int MAXH, int MAXJ, class GP, class CP, class VP>
+WG_INLINE void kres_var(int lane, GP G, CP Hs, CP jv, CP sx, CP fm, double dw, CP v, CP rhsv, VP out,
+                        CP preH, CP preJt, CP v2, CP rhsv2, VP out2, CP preH2, CP preJt2,
+                        double& m0, double& m1, double& n0, double& n1) {
+  if (lane < NACT) {
+    const int k = K0 + lane;
+    const u32 d = G[D0 + lane];
+    const int nh = static_cast<int>(d & 0xffu), nj = static_cast<int>((d >> 8) & 0xffu);
+    double hv = 0.0, jt = 0.0, hv2 = 0.0, jt2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < MAXH; ++e) {
+      const u32 w = G[E0 + e * NACT + lane];
+      const bool on = e < nh;
+      const double cr = Hs[w & 0xffffu], vr = v[w >> 16];      // (loads unconditional, selected afterwards: see fwd)
+      const double c = on ? cr : 0.0;
+      hv += c * (on ? vr : 0.0);
+      if (TWO) { const double vr2 = v2[w >> 16]; hv2 += c * (on ? vr2 : 0.0); }
+    }
+#pragma unroll
+    for (int e = 0; e < MAXJ; ++e) {
+      const u32 w = G[E0 + (MAXH + e) * NACT + lane];
+      const bool on = e < nj;
+      const double cr = jv[w & 0xffffu], vr = v[w >> 16];
+      const double c = on ? cr : 0.0;
+      jt += c * (on ? vr : 0.0);
+      if (TWO) { const double vr2 = v2[w >> 16]; jt2 += c * (on ? vr2 : 0.0); }
+    }
+    {
+      const double ph = preH[k], pj = preJt[k];
+      hv = (d & 0x10000u) ? ph : hv;
+      jt = (d & 0x20000u) ? pj : jt;
+      if (TWO) { const double ph2 = preH2[k], pj2 = preJt2[k]; hv2 = (d & 0x10000u) ? ph2 : hv2; jt2 = (d & 0x20000u) ? pj2 : jt2; }
+    }
+    const bool fx = fm[k] != 0.0;
+    const double sd = sx[k] + dw, vk = v[k];
+    const double kv = fx ? vk : hv + sd * vk + jt;
+    const double r = rhsv[k] - kv;
+    out[k] = r;
+    m0 = mxin(m0, fabs(r)); m1 = mxin(m1, fabs(vk));
+    if (TWO) {
+      const double vk2 = v2[k];
+      const double kv2 = fx ? vk2 : hv2 + sd * vk2 + jt2;
+      const double r2 = rhsv2[k] - kv2;
+      out2[k] = r2;
+      n0 = mxin(n0, fabs(r2)); n1 = mxin(n1, fabs(vk2));
+    }
+  }
+}
+// ---- J^T y alone (wave_ipm.h jac_tmult) out of the variable part's tables: the J^T entries carry N + src, so the caller
+// passes y - N.  A long output is written by the wdot pass around this call.
+template <int D0, int E0, int NACT, int K0, int MAXH, int MAXJ, class GP, class CP, class VP>
+WG_INLINE void cojt(int lane, GP G, CP jv, CP vsh, VP out) {
+  if (lane < NACT) {
+    const u32 d = G[D0 + lane];
+    const int nj = static_cast<int>((d >> 8) & 0xffu);
+    double jt = 0.0;
+#pragma unroll
+    for (int e = 0; e < MAXJ; ++e) {
+      const u32 w = G[E0 + (MAXH + e) * NACT + lane];
+      const bool on = e < nj;
+      const double cr = jv[w & 0xffffu], vr = vsh[w >> 16];
+      jt += (on ? cr : 0.0) * (on ? vr : 0.0);
+    }
+    if (!(d & 0x20000u)) out[K0 + lane] = jt;
+  }
+}
+
+// ---- ... row part: out[N + i] = rhs[N + i] - (J v_x - D v_y)[i], i = I0 + lane.  descriptor: nj | (long) << 16 ------------------
+template <bool TWO, int D0, int E0, int NACT, int I0, int NV, int MAXJ, class GP, class CP, class VP>
+WG_INLINE void kres_row(int lane, GP G, CP jv, CP dd, CP v, CP rhsv, VP out, CP preJ,
+                        CP v2, CP rhsv2, VP out2, CP preJ2, double& m0, double& m1, double& n0, double& n1) {
+  if (lane < NACT) {
+    const int i = I0 + lane, k = NV + i;
+    const u32 d = G[D0 + lane];
+    const int nj = static_cast<int>(d & 0xffu);
+    double jx = 0.0, jx2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < MAXJ; ++e) {
+      const u32 w = G[E0 + e * NACT + lane];
+      const bool on = e < nj;
+      const double cr = jv[w & 0xffffu], vr = v[w >> 16];
+      const double c = on ? cr : 0.0;
+      jx += c * (on ? vr : 0.0);
+      if (TWO) { const double vr2 = v2[w >> 16]; jx2 += c * (on ? vr2 : 0.0); }
+    }
+    {
+      const double pj = preJ[i];
+      jx = (d & 0x10000u) ? pj : jx;
+      if (TWO) { const double pj2 = preJ2[i]; jx2 = (d & 0x10000u) ? pj2 : jx2; }
+    }
+    const double di = dd[i], vk = v[k];
+    const double kv = jx - di * vk;
+    const double r = rhsv[k] - kv;
+    out[k] = r;
+    m0 = mxin(m0, fabs(r)); m1 = mxin(m1, fabs(vk));
+    if (TWO) {
+      const double vk2 = v2[k];
+      const double kv2 = jx2 - di * vk2;
+      const double r2 = rhsv2[k] - kv2;
+      out2[k] = r2;
+      n0 = mxin(n0, fabs(r2)); n1 = mxin(n1, fabs(vk2));
+    }
+  }
+}
+
+// ---- a constant CSR map applied to a vector: y[r] = (base[r] + sum_k val[k] v[idx[k]]) [x scale], r = R0 + lane (spmv) ------
+// descriptor (1 word): first value index | entries << 16.  entries: column, two per word ([e / 2][lane], low half first).
+// SPLIT: column c >= split reads vhi[c] (the vector [x | z] in two places).  val / base: the instance's data row (global memory).
+template <bool SPLIT, int D0, int E0, int NACT, int R0, int MAXC, class GP, class CP, class VP, class RP, class IP>
+WG_INLINE void spmv(int lane, GP G, RP val, RP base, CP v, CP vhi, int split, VP y, int scale_kind, double scalar, CP sg, IP jr) {
+  if (lane < NACT) {
+    const int r = R0 + lane;
+    const u32 w0 = G[D0 + lane];
+    const int k0 = static_cast<int>(w0 & 0xffffu), cnt = static_cast<int>(w0 >> 16);
+    double sacc = base ? base[r] : 0.0;
+#pragma unroll
+    for (int e = 0; e < MAXC; ++e) {
+      const u32 w = G[E0 + (e >> 1) * NACT + lane];
+      const int c = static_cast<int>((e & 1) ? (w >> 16) : (w & 0xffffu));
+      const double a = val[k0 + e];
+      const double vv = ((SPLIT && c >= split) ? vhi : v)[c];
+      // (no padding by zeros here: the sum starts at base[r], which may be -0.0)
+      sacc = e < cnt ? sacc + a * vv : sacc;
+    }
+    if (scale_kind == 1) sacc *= scalar;
+    else if (scale_kind == 2) sacc *= sg[r];
+    else if (scale_kind == 3) sacc *= sg[jr[r]];
+    y[r] = sacc;
   }
 }
 

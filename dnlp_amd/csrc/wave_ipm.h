@@ -51,7 +51,7 @@
 #define WV(f) (P::vec(S, wspec::v_##f))
 #define WT(f) (P::tab(wspec::t_##f))
 #define WDIR(set, k) (P::vec(S, wspec::v_dir[set][k]))
-#define WCSR(f) (WCsr{P::tab(wspec::t_##f##_ptr), P::tab(wspec::t_##f##_idx), wspec::k_##f##_rows, wspec::k_##f##_val})
+#define WCSR(f) (WCsr{P::tab(wspec::t_##f##_ptr), P::tab(wspec::t_##f##_idx), wspec::k_##f##_rows, wspec::k_##f##_val, wspec::k_##f##_id})
 #define WCOO(f) (WCoo{P::tab(wspec::t_##f##_ptr), P::tab(wspec::t_##f##_ent), P::tab(wspec::t_##f##_src), P::tab(wspec::t_##f##_heavy), wspec::k_##f##_nout, wspec::k_##f##_nheavy})
 #else
 #define WK(f) (S->f)
@@ -90,7 +90,7 @@ constexpr int kWaveNeedsGeneric = -197;
 #endif
 constexpr int kWaveFilterCap = DNLP_WAVE_FILTER_CAP;
 
-template <class WI> struct WCsrT { WI* ptr; WI* idx; i32 rows; i32 val; };       // val: offset of the values in the instance's data row
+template <class WI> struct WCsrT { WI* ptr; WI* idx; i32 rows; i32 val; i32 id; };       // val: offset of the values in the instance's data row; id: 0 G, 1 Mg, 2 MJ, 3 Mw, 4 MH
 template <class WI> struct WCooT { WI* ptr; WI* ent; WI* src; WI* heavy; i32 nout; i32 nheavy; };
 
 // the fields of the state record that layout() sets once per kernel (X-macro lists: the record's declaration below, and
@@ -167,6 +167,10 @@ struct WMeasures { double theta, phi, chk; };
 namespace wgen {
 template <class P, class WS> DNLP_HD bool ldl_factor(WS* S);
 template <class P, bool TWO, class WS, class WD> DNLP_HD void ldl_solve(WS* S, WD* x, WD* y);
+template <class P, bool TWO, class WS, class WD> DNLP_HD void kkt_residual(WS* S, double dw, const WD* v, const WD* rhsv, WD* out, const WD* v2, const WD* rhsv2, WD* out2,
+                                                                        double& en, double& sn, double& en2, double& sn2);
+template <class P, class WS, class WD> DNLP_HD void jac_tmult(WS* S, const WD* v, WD* out);
+template <class P, bool SPLIT, class WS, class WD> DNLP_HD void spmv(WS* S, int id, const WD* v, i32 base_off, WD* y, int scale_kind, double scalar, const WD* vhi, i32 split);
 }  // namespace wgen
 #endif
 
@@ -188,11 +192,11 @@ struct WaveIpm {
     S->N = h->N; S->m = h->m; S->Z = h->Z; S->nd = h->nd; S->nh = h->nh; S->nnzJ = h->nnzJ; S->nnzH = h->nnzH; S->nunits = h->nunits;
     S->u_op = blk + h->u_op; S->u_a0 = blk + h->u_a0; S->u_a1 = blk + h->u_a1; S->u_z = blk + h->u_z; S->u_d0 = blk + h->u_d0;
     S->u_d1 = blk + h->u_d1; S->u_h = blk + h->u_h; S->u_p = blk + h->u_p; S->mm_idx = blk + h->mm_idx;
-    S->G = WCsr{blk + h->G_ptr, blk + h->G_idx, h->m, h->l_G};
-    S->Mg = WCsr{blk + h->Mg_ptr, blk + h->Mg_idx, h->N, h->l_Mg};
-    S->MJ = WCsr{blk + h->MJ_ptr, blk + h->MJ_idx, h->nnzJ, h->l_MJ};
-    S->Mw = WCsr{blk + h->Mw_ptr, blk + h->Mw_idx, h->Z, h->l_Mw};
-    S->MH = WCsr{blk + h->MH_ptr, blk + h->MH_idx, h->nnzH, h->l_MH};
+    S->G = WCsr{blk + h->G_ptr, blk + h->G_idx, h->m, h->l_G, 0};
+    S->Mg = WCsr{blk + h->Mg_ptr, blk + h->Mg_idx, h->N, h->l_Mg, 1};
+    S->MJ = WCsr{blk + h->MJ_ptr, blk + h->MJ_idx, h->nnzJ, h->l_MJ, 2};
+    S->Mw = WCsr{blk + h->Mw_ptr, blk + h->Mw_idx, h->Z, h->l_Mw, 3};
+    S->MH = WCsr{blk + h->MH_ptr, blk + h->MH_idx, h->nnzH, h->l_MH, 4};
     S->jac_rows = blk + h->jac_rows; S->jac_cols = blk + h->jac_cols; S->hess_rows = blk + h->hess_rows; S->hess_cols = blk + h->hess_cols;
     S->jac_rowptr = blk + h->jac_rowptr;
     S->jr = WCoo{blk + h->jr_ptr, blk + h->jr_ent, blk + h->jr_src, blk + h->jr_heavy, h->m, h->jr_nheavy};
@@ -378,6 +382,9 @@ struct WaveIpm {
   template <bool SPLIT = false>
   DNLP_WFN DNLP_HD static void spmv(DNLP_WLDS WState* S, const WCsr M, const WD* v, i32 base_off, WD* y, int scale_kind, double scalar,
                                     const WD* vhi = nullptr, i32 split = 0) {
+#ifdef DNLP_WAVE_GEN
+    { W_P0(); wgen::spmv<P, SPLIT>(S, M.id, v, base_off, y, scale_kind, scalar, vhi, split); W_P1(16); return; }
+#endif
     W_P0();
     WI *ptr = M.ptr, *idx = M.idx;
     WG* val = S->row + M.val;
@@ -475,7 +482,11 @@ struct WaveIpm {
   }
   DNLP_HD static void hess_mult(WS* S, const WD* v, WD* out) { coo(S, WCOO(hs), WV(Hs), v, out); }
   DNLP_HD static void jac_mult(WS* S, const WD* v, WD* out) { coo(S, WCOO(jr), WV(jv), v, out); }
+#ifdef DNLP_WAVE_GEN
+  DNLP_WFN DNLP_HD static void jac_tmult(WS* S, const WD* v, WD* out) { W_P0(); wgen::jac_tmult<P>(S, v, out); W_P1(8); }
+#else
   DNLP_HD static void jac_tmult(WS* S, const WD* v, WD* out) { coo(S, WCOO(jc), WV(jv), v, out); }
+#endif
 
   // ====================================================================================================================
   // KKT system: assembly (kkt_dense.h assemble_factor, sparse branch) and the static-pattern LDL^T (sparse_ldl.h)
@@ -1416,6 +1427,9 @@ struct WaveIpm {
     en = S->o_d[1]; sn = S->o_d[2];
   }
   DNLP_WFN DNLP_HD static void kkt_residual_impl(WS* S, const WD* v, double dw, const WD* rhsv, WD* out) {
+#ifdef DNLP_WAVE_GEN
+    { W_P0(); double e1, s1, e2, s2; wgen::kkt_residual<P, false>(S, dw, v, rhsv, out, v, rhsv, out, e1, s1, e2, s2); S->o_d[1] = e1; S->o_d[2] = s1; W_P1(9); return; }
+#endif
     auto& en = S->o_d[1];
     auto& sn = S->o_d[2];
     W_P0();
@@ -1452,6 +1466,9 @@ struct WaveIpm {
   // the same for two systems at once (mu oracle): one walk of the three indices; the second system's long outputs in dx / ds
   struct Res2 { double en, sn, en2, sn2; };
   DNLP_WFN DNLP_HD static Res2 kkt_residual2(WS* S, double dw, const WD* v, const WD* rhsv, WD* out, const WD* v2, const WD* rhsv2, WD* out2) {
+#ifdef DNLP_WAVE_GEN
+    { W_P0(); Res2 Rg; wgen::kkt_residual<P, true>(S, dw, v, rhsv, out, v2, rhsv2, out2, Rg.en, Rg.sn, Rg.en2, Rg.sn2); W_P1(9); return Rg; }
+#endif
     W_P0();
     const int N = WK(N), m = WK(m);
     const WCoo hs = WCOO(hs), jc = WCOO(jc), jr = WCOO(jr);

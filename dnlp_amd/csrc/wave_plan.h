@@ -129,16 +129,8 @@ inline std::vector<i32> build_wave_plan(E* ex, const Tape<E>& t, const SparsePla
     h.nunits = narrow(static_cast<i64>(op.size()));
     h.u_op = put(op); h.u_a0 = put(a0); h.u_a1 = put(a1); h.u_z = put(z); h.u_d0 = put(d0); h.u_d1 = put(d1); h.u_h = put(hh); h.u_p = put(pp);
   }
-  auto csr = [&](const Csr& M, i32& optr, i32& oidx) { optr = put(down64(M.ptr, M.rows + 1)); oidx = put(down32(M.idx, M.nnz)); };
-  csr(t.G, h.G_ptr, h.G_idx); csr(t.Mg, h.Mg_ptr, h.Mg_idx); csr(t.MJ, h.MJ_ptr, h.MJ_idx); csr(t.Mw, h.Mw_ptr, h.Mw_idx); csr(t.MH, h.MH_ptr, h.MH_idx);
   h.jac_rows = put(t.h_jac_rows); h.jac_cols = put(t.h_jac_cols); h.hess_rows = put(t.h_hess_rows); h.hess_cols = put(t.h_hess_cols);
   h.jac_rowptr = put(down64(t.jac_rowptr, t.m + 1));
-  auto coo = [&](const CooIdx& c, i32& p, i32& e, i32& s, i32& hv, i32& nh) {
-    p = put(down32(c.ptr, c.nout + 1)); e = put(down32(c.ent, c.total)); s = put(down32(c.src, c.total)); hv = put(down32(c.heavy, c.nheavy)); nh = narrow(c.nheavy);
-  };
-  coo(t.jac_by_row, h.jr_ptr, h.jr_ent, h.jr_src, h.jr_heavy, h.jr_nheavy);
-  coo(t.jac_by_col, h.jc_ptr, h.jc_ent, h.jc_src, h.jc_heavy, h.jc_nheavy);
-  coo(t.hess_sym, h.hs_ptr, h.hs_ent, h.hs_src, h.hs_heavy, h.hs_nheavy);
   h.sp_nblk = narrow(sp.nblk()); h.sp_nvals = narrow(sp.nvals); h.sp_nlev = narrow(static_cast<i64>(sp.lev_off.size()) - 1);
   h.sp_ngrp = narrow(static_cast<i64>(sp.gdst.size())); h.sp_nfwd = narrow(static_cast<i64>(sp.fnode.size())); h.sp_ntrip = narrow(sp.ntrip);
   h.sp_rows = narrow(static_cast<i64>(sp.sidx.size()));
@@ -193,8 +185,9 @@ inline std::vector<i32> build_wave_plan(E* ex, const Tape<E>& t, const SparsePla
     if (ok && static_cast<i64>(tfq.size()) > 5 * ((static_cast<i64>(t.m) + 1) & ~static_cast<i64>(1))) ok = false;
     if (!ok) { T = 0; Ls = nlev; tnode.clear(); td.clear(); tl.clear(); tfq.clear(); tfp.assign(1, 0); }
     // Order of the static-pattern LDL^T's tables in the block: what every kernel reads first (assembly positions, the dense
-    // tail's tables, the forward rows the tail gathers through), the level machinery last — a kernel whose LDL^T phases are
-    // generated per template (wave_gen.h) stages only the first keep_gen ints in LDS.
+    // tail's tables, the forward rows the tail gathers through), then what a kernel with generated phases (wave_gen.h) no
+    // longer reads — the constant CSR maps, the products by output, the level machinery: such a kernel stages only the first
+    // keep_gen ints in LDS.
     h.tail_L = Ls; h.tail_T = T;
     h.hpos = put(sp.hpos); h.jpos = put(sp.jpos); h.dpos = put(sp.dpos);
     h.t_node = put(tnode); h.t_d = put(td); h.t_l = put(tl); h.t_fq = put(tfq); h.t_fp = put(tfp);
@@ -203,6 +196,15 @@ inline std::vector<i32> build_wave_plan(E* ex, const Tape<E>& t, const SparsePla
     h.fa = put(sp.fa); h.fu0 = put(sp.fu0); h.fu1 = put(sp.fu1);
     if (T > 0) h.keep_gen = narrow(static_cast<i64>(out.size()));
   }
+  // (... and the constant CSR maps and the products by output, which such a kernel also runs as generated phases)
+  auto csr = [&](const Csr& M, i32& optr, i32& oidx) { optr = put(down64(M.ptr, M.rows + 1)); oidx = put(down32(M.idx, M.nnz)); };
+  csr(t.G, h.G_ptr, h.G_idx); csr(t.Mg, h.Mg_ptr, h.Mg_idx); csr(t.MJ, h.MJ_ptr, h.MJ_idx); csr(t.Mw, h.Mw_ptr, h.Mw_idx); csr(t.MH, h.MH_ptr, h.MH_idx);
+  auto coo = [&](const CooIdx& c, i32& p, i32& e, i32& s, i32& hv, i32& nh) {
+    p = put(down32(c.ptr, c.nout + 1)); e = put(down32(c.ent, c.total)); s = put(down32(c.src, c.total)); hv = put(down32(c.heavy, c.nheavy)); nh = narrow(c.nheavy);
+  };
+  coo(t.jac_by_row, h.jr_ptr, h.jr_ent, h.jr_src, h.jr_heavy, h.jr_nheavy);
+  coo(t.jac_by_col, h.jc_ptr, h.jc_ent, h.jc_src, h.jc_heavy, h.jc_nheavy);
+  coo(t.hess_sym, h.hs_ptr, h.hs_ent, h.hs_src, h.hs_heavy, h.hs_nheavy);
   h.bnode = put(sp.bnode); h.soff = put(sp.soff); h.loff = put(sp.loff); h.doff = put(sp.doff); h.lev_off = put(sp.lev_off);
   h.sblk = put(sp.sblk); h.sidx = put(sp.sidx); h.lev_f = put(sp.lev_f); h.fnode = put(sp.fnode); h.foff = put(sp.foff);
   h.lev_g = put(sp.lev_g); h.gdst = put(sp.gdst); h.goff = put(sp.goff);
