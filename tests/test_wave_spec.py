@@ -77,24 +77,28 @@ def _both(pb, thetas, **kw):
 
 def _same_path(s, o, frac=0.98):
     """Two compilations of one algorithm text: the compiler contracts / orders a few sums differently (last-bit differences),
-    the path is the same — statuses, (almost always) iteration counts, and the results of the instances that took the same
+    the path is the same — statuses, (almost always) iteration counts, and the optima of the instances that took the same
     number of iterations to 1e-8."""
     assert np.array_equal(s.status, o.status)
     same = s.iterations == o.iterations
     assert same.mean() >= frac, same.mean()
+    same &= s.status == 0                     # (a run stopped by an iteration cap is not at a point worth comparing to 1e-8)
     np.testing.assert_allclose(s.obj_val[same], o.obj_val[same], rtol=1e-8, atol=1e-9)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,B", [("localization", 1024), ("circle_packing", 512), ("circle_packing10", 256)])
-def test_per_template_kernel_follows_the_library_kernel(gpu_required, name, B):
+@pytest.mark.parametrize("name,B,frac", [("localization", 1024, 0.98), ("circle_packing", 512, 0.95), ("circle_packing10", 256, 0.85)])
+def test_per_template_kernel_follows_the_library_kernel(gpu_required, name, B, frac):
+    """(circle packing has several optima and a flat face: a last-bit difference — the generated phases add every sum in
+    storage order, the library kernel's long sums go through a reduction tree — sends some instances through a few more or
+    fewer iterations; tests/test_wave_batch.py accepts the same of the library kernel against its host lane)"""
     prob, params, sample, _ = TEMPLATES[name]()
     pb = ParametricBatch(prob, params)
     thetas = np.stack([sample(i) for i in range(B)])
     s, o = _both(pb, thetas)
     assert s.raw["launch"]["wave_spec"] and not o.raw["launch"]["wave_spec"]
     assert s.raw["launch"]["wave_form"] % 100 == 11
-    _same_path(s, o)
+    _same_path(s, o, frac)
     assert (s.status == 0).mean() >= 0.9
     pb.close()
 
