@@ -435,6 +435,46 @@ struct BatchRunner {
     if (std::getenv("DNLP_BATCH_DEBUG")) std::fprintf(stderr, "[batch] per-template kernel: %d wavefronts per workgroup, %.2f s to compile / load\n", fit, wave_spec_compile_seconds);
     return true;
   }
+  // the WORKGROUP-per-instance kernel of templates whose state exceeds LDS (wave_wg_kernel.h; same switches as the
+  // per-template kernel above: DNLP_WAVE_SPEC 0 / 1 / unset, DNLP_WAVE_WG_WAVES = wavefronts per workgroup, default 4)
+  RtcKernel wave_wg;
+  int wave_wg_nw = 0, wave_wg_per_cu = 1, wave_wg_gen_words = 0;
+  unsigned* d_wave_wg_gen = nullptr;
+  bool wave_wg_prof = false;
+  bool wave_wg_prepare(int batch) {
+    const char* e = std::getenv("DNLP_WAVE_SPEC");
+    const int mode = e ? std::atoi(e) : -1;
+    if (mode == 0) return false;
+    if (mode < 0 && batch < kWaveSpecMinBatch && !wave_wg.ok) return false;
+    if (wave_wg.tried) return wave_wg.ok;
+    wave_wg.tried = true;
+    const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(wave_blk.data());
+    if (wave_gen_refusal(h)[0]) return false;
+    int nwg = std::getenv("DNLP_WAVE_WG_WAVES") ? std::atoi(std::getenv("DNLP_WAVE_WG_WAVES")) : 4;
+    if (nwg < 1 || nwg > 8) nwg = 4;
+    const double t0 = now_sec();
+    const WaveGen gen = wave_generate(wave_blk, 64 * nwg);
+    wave_wg_prof = std::getenv("DNLP_WAVE_SPEC_PROF") != nullptr;
+    // (DNLP_WAVE_WG_BOUND: threads the register budget is sized for — 512 with four wavefronts: two workgroups per compute unit)
+    const int bound = std::getenv("DNLP_WAVE_WG_BOUND") ? std::atoi(std::getenv("DNLP_WAVE_WG_BOUND")) : 512;
+    const std::string src = wave_wg_source(wave_blk, nwg, gen, wave_wg_prof, bound);
+    if (!wave_wg.load(src, "dnlp_wave_wg_kernel")) {
+      std::fprintf(stderr, "[dnlp] workgroup-per-instance batch kernel not available (the library's own kernel is used): %s\n", wave_wg.log.substr(0, 2000).c_str());
+      return false;
+    }
+    wave_wg_gen_words = static_cast<int>(gen.G.size());
+    DNLP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_wave_wg_gen), (gen.G.size() + 4) * sizeof(unsigned)));
+    if (!gen.G.empty()) DNLP_HIP_CHECK(hipMemcpy(d_wave_wg_gen, gen.G.data(), gen.G.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    wave_wg_nw = nwg;
+    int occ = 1;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, wave_wg.fn, 64 * nwg, 0) != hipSuccess || occ < 1) occ = 1;
+    wave_wg_per_cu = occ;
+    if (const char* pc = std::getenv("DNLP_WAVE_WG_PER_CU")) { const int v = std::atoi(pc); if (v >= 1 && v <= 8) wave_wg_per_cu = v; }
+    if (std::getenv("DNLP_BATCH_DEBUG"))
+      std::fprintf(stderr, "[batch] workgroup-per-instance kernel: %d wavefronts per instance, %d workgroups per compute unit, %d table words, %.2f s to generate / compile / load\n",
+                   nwg, wave_wg_per_cu, wave_wg_gen_words, now_sec() - t0);
+    return true;
+  }
   bool wave_prepare() {
     if (!wave_checked) {
       wave_checked = true;
@@ -547,6 +587,7 @@ struct BatchRunner {
     if (d_wave_blk) hipFree(d_wave_blk);
     if (d_wave_blk16) hipFree(d_wave_blk16);
     if (d_wave_gen) hipFree(d_wave_gen);
+    if (d_wave_wg_gen) hipFree(d_wave_wg_gen);
     if (d_rows) hipFree(d_rows);
     if (own_stream && stream) hipStreamDestroy(stream);
   }
@@ -742,7 +783,7 @@ struct BatchRunner {
     //  path planning 4.5 against 4.8; DNLP_BATCH_WAVE=2 takes the wavefront solver for them too, 0 never)
     const int wave_env = std::getenv("DNLP_BATCH_WAVE") ? std::atoi(std::getenv("DNLP_BATCH_WAVE")) : 1;
     bool take_wave = allow_wave && wave_env != 0 && wave_prepare();
-    if (take_wave && wave_env != 2) { int nw = 0, sl = 0, pl = 0; wave_form(nw, sl, pl); take_wave = sl != 0; }
+    if (take_wave && wave_env != 2) { int nw = 0, sl = 0, pl = 0; wave_form(nw, sl, pl); take_wave = sl != 0 || wave_wg_prepare(batch); }
     if (take_wave) {
       solve_wave(a, batch, data, theta, opt, x_out, obj_out, multg_out, zl_out, zu_out, status_out, iters_out, nfact_out, seconds, times_out);
       return;
@@ -1155,12 +1196,16 @@ struct BatchRunner {
         w.gen = d_wave_gen; w.gen_words = wave_gen_words;
       }
     }
+    // a template whose state exceeds LDS: a workgroup per instance through the generated phases when the kernel is there
+    const bool wg = !sl && !std::getenv("DNLP_WAVE_FORM") && wave_wg_prepare(batch);
+    if (wg) { nw = wave_wg_nw; w.gen = d_wave_wg_gen; w.gen_words = wave_wg_gen_words; }
     int per_cu = 1;
     const unsigned lds = static_cast<unsigned>((pl ? plan_b : 0) + (sl ? static_cast<size_t>(nw) * state_b : 0));
     const int form = 100 * nw + 10 * sl + pl;
     int cached_none = 0;
     int& cached = (sl && pl) ? wf_per_cu[nw] : cached_none;
     if (spec) per_cu = 1;
+    else if (wg) per_cu = wave_wg_per_cu;
     else if (cached > 0 && !std::getenv("DNLP_WAVE_FORM")) per_cu = cached;
     else switch (form) {
       case 811: per_cu = wave_occupancy<8, true, true>(lds); break;
@@ -1178,13 +1223,14 @@ struct BatchRunner {
       case 400: per_cu = wave_occupancy<4, false, false>(lds); break;
       default: throw std::runtime_error("wavefront solver: no such launch form");
     }
-    if (!std::getenv("DNLP_WAVE_FORM") && !spec) cached = per_cu;
+    if (!std::getenv("DNLP_WAVE_FORM") && !spec && !wg) cached = per_cu;
     if (const char* e = std::getenv("DNLP_WAVE_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 16) per_cu = v; }
-    int grid = std::min((batch + nw - 1) / nw, ncu * per_cu);
+    int grid = wg ? std::min(batch, ncu * per_cu) : std::min((batch + nw - 1) / nw, ncu * per_cu);
     if (grid < 1) grid = 1;
-    if (!sl) w.state = dalloc<double>(static_cast<size_t>(grid) * static_cast<size_t>(nw) * static_cast<size_t>(h.state_doubles));
+    if (wg) w.state = dalloc<double>(static_cast<size_t>(grid) * static_cast<size_t>(h.state_doubles));
+    else if (!sl) w.state = dalloc<double>(static_cast<size_t>(grid) * static_cast<size_t>(nw) * static_cast<size_t>(h.state_doubles));
     w.park_doubles = wave_park_doubles(t.N, t.m);
-    w.park = dalloc<double>(static_cast<size_t>(grid) * static_cast<size_t>(spec ? wave_spec_nw : nw) * static_cast<size_t>(w.park_doubles));
+    w.park = dalloc<double>(static_cast<size_t>(grid) * static_cast<size_t>(wg ? 1 : spec ? wave_spec_nw : nw) * static_cast<size_t>(w.park_doubles));
     w.x_out = dalloc<double>(static_cast<size_t>(batch) * t.N);
     w.obj_out = dalloc<double>(static_cast<size_t>(batch));
     w.multg_out = multg_out ? dalloc<double>(static_cast<size_t>(batch) * t.m) : nullptr;
@@ -1212,7 +1258,7 @@ struct BatchRunner {
 #ifdef DNLP_WAVE_PROF
     const bool want_prof = true;
 #else
-    const bool want_prof = spec && wave_spec_prof;
+    const bool want_prof = (spec && wave_spec_prof) || (wg && wave_wg_prof);
 #endif
     if (want_prof) {
       w.prof = dalloc<unsigned long long>(kWaveProfSlots + 1);
@@ -1221,7 +1267,7 @@ struct BatchRunner {
     const uint64_t key = theta ? rows_hash(theta, static_cast<size_t>(batch) * static_cast<size_t>(aff_P))
                                : rows_hash(data, static_cast<size_t>(batch) * static_cast<size_t>(in_stride));
     last_order_lpt = false;
-    if (static_cast<int>(prev_iters.size()) == batch && key == prev_key && batch > grid * nw && !std::getenv("DNLP_BATCH_FIFO")) {
+    if (static_cast<int>(prev_iters.size()) == batch && key == prev_key && batch > grid * (wg ? 1 : nw) && !std::getenv("DNLP_BATCH_FIFO")) {
       last_order_lpt = true;
       std::vector<int> ord(static_cast<size_t>(batch));
       for (int k = 0; k < batch; ++k) ord[static_cast<size_t>(k)] = k;
@@ -1231,7 +1277,7 @@ struct BatchRunner {
       DNLP_HIP_CHECK(hipStreamSynchronize(stream));
       w.order = d_ord;
     }
-    last_grid = grid; last_threads = 64 * nw; last_lds_mode = 2 * sl + pl + (spec ? 4 : 0); last_per_cu = nw * per_cu; last_packed = false;
+    last_grid = grid; last_threads = 64 * nw; last_lds_mode = 2 * sl + pl + ((spec || wg) ? 4 : 0); last_per_cu = wg ? per_cu : nw * per_cu; last_packed = false;
     last_wave = 100 * nw + 10 * sl + pl;
     last_wave_spec = spec;
     if (std::getenv("DNLP_BATCH_DEBUG"))
@@ -1244,7 +1290,10 @@ struct BatchRunner {
     DNLP_HIP_CHECK(hipEventCreate(&e0));
     DNLP_HIP_CHECK(hipEventCreate(&e1));
     DNLP_HIP_CHECK(hipEventRecord(e0, stream));
-    if (spec) {
+    if (wg) {
+      void* kargs[] = {&w};
+      DNLP_HIP_CHECK(hipModuleLaunchKernel(wave_wg.fn, static_cast<unsigned>(grid), 1, 1, static_cast<unsigned>(64 * nw), 1, 1, 0, stream, kargs, nullptr));
+    } else if (spec) {
       void* kargs[] = {&w};
       DNLP_HIP_CHECK(hipModuleLaunchKernel(wave_spec.fn, static_cast<unsigned>(grid), 1, 1, static_cast<unsigned>(64 * nw), 1, 1, 0, stream, kargs, nullptr));
     } else switch (form) {

@@ -26,10 +26,12 @@ struct WaveLanesT {
   //  entry beyond 16 bits, and half the bytes is half the L1 / L2 traffic of the index loads)
   typedef typename std::conditional<PLAN_LDS, WLdsI, typename std::conditional<STATE_LDS, WGlbI16, WGlbI>::type>::type I;
   static constexpr int lanes = 64;
+  static constexpr bool hoist = false;        // (wave_ipm.h quality(): which form of the elementwise loops)
   __device__ static int lane() { return static_cast<int>(threadIdx.x & 63u); }
   __device__ static void sync() { wave_sync(); }
   __device__ static double sum(double v) { return wave_all_sum(v); }
   __device__ static double vmax(double v) { return wave_all_max(v); }
+  __device__ static double now() { return now_sec(); }
   // per-level bounds (measured on MI355X: keeping the table one entry per lane in a register and reading it back with
   // v_readlane made the substitutions 17 % SLOWER than these plain uniform LDS loads — 46.1 -> 53.8 k cycles per iteration)
   __device__ static int tab_load(I*, int) { return 0; }

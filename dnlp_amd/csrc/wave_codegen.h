@@ -36,10 +36,12 @@ struct WaveProbeLanes {
   typedef double D;
   typedef const i32 I;
   static constexpr int lanes = 1;
+  static constexpr bool hoist = false;
   static int lane() { return 0; }
   static void sync() {}
   static double sum(double v) { return v; }
   static double vmax(double v) { return v; }
+  static double now() { return dnlp::now_sec(); }
   static int tab_load(const i32*, int) { return 0; }
   static int tab_at(const i32* tab, int, int idx, int) { return tab[idx]; }
   static int uni(int v) { return v; }
@@ -196,6 +198,49 @@ inline std::string wave_spec_source(const std::vector<i32>& blk, int nw, const W
   s += wave_spec_text("wave_ops.h", wave_ops_text);
   s += wave_spec_text("wave_ipm.h", wave_ipm_text);
   s += wave_spec_text("wave_spec_kernel.h", wave_spec_kernel_text);      // (the lane policy P: the generated functions below are templates over it)
+  s += wave_spec_text("wave_gen_rt.h", wave_gen_rt_text);
+  s += gen.code;
+  return s;
+}
+
+// the translation unit of a template's WORKGROUP-per-instance kernel (wave_wg_kernel.h; entry point: dnlp_wave_wg_kernel):
+// `gen` must have been generated for 64 x nwg lanes per phase
+inline std::string wave_wg_source(const std::vector<i32>& blk, int nwg, const WaveGen& gen, bool prof = false, int bound_threads = 0) {
+  static const char* atom_math_text =
+#include "atom_math_src.inc"
+      ;
+  static const char* ipm_options_text =
+#include "ipm_options_src.inc"
+      ;
+  static const char* wave_hdr_text =
+#include "wave_hdr_src.inc"
+      ;
+  static const char* wave_args_text =
+#include "wave_args_src.inc"
+      ;
+  static const char* wave_ops_text =
+#include "wave_ops_src.inc"
+      ;
+  static const char* wave_ipm_text =
+#include "wave_ipm_src.inc"
+      ;
+  static const char* wave_gen_rt_text =
+#include "wave_gen_rt_src.inc"
+      ;
+  static const char* wave_wg_kernel_text =
+#include "wave_wg_kernel_src.inc"
+      ;
+  std::string s = prof ? "#define DNLP_WAVE_PROF 1\n" : "";
+  s += wave_spec_prelude();
+  s += wave_spec_text("atom_math.h", atom_math_text);
+  s += wave_spec_text("ipm_options.h", ipm_options_text);
+  s += wave_spec_text("wave_hdr.h", wave_hdr_text);
+  s += wave_spec_text("wave_args.h", wave_args_text);
+  s += wave_spec_constants(blk, nwg, gen.G.size(), prof);
+  s += "namespace wspec { constexpr int kWgBound = " + std::to_string(bound_threads > 64 * nwg ? bound_threads : 64 * nwg) + "; }\n";
+  s += wave_spec_text("wave_ops.h", wave_ops_text);
+  s += wave_spec_text("wave_ipm.h", wave_ipm_text);
+  s += wave_spec_text("wave_wg_kernel.h", wave_wg_kernel_text);
   s += wave_spec_text("wave_gen_rt.h", wave_gen_rt_text);
   s += gen.code;
   return s;

@@ -63,7 +63,8 @@ inline const char* wave_gen_refusal(const WaveHdr& h) {
 // across the lanes (wave_gen_rt.h fwdw / bwdw) instead of a task per lane
 constexpr int kWideMaxTasks = 4, kWideMinEntries = 8;
 
-inline WaveGen wave_generate(const std::vector<i32>& blk) {
+// LW: lanes that share a phase (64: one wavefront per instance; 64 x wavefronts of a workgroup per instance)
+inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
   using namespace wgen_detail;
   const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(blk.data());
   if (wave_gen_refusal(h)[0]) throw std::runtime_error(wave_gen_refusal(h));
@@ -75,7 +76,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
   const int nblk = h.sp_nblk;
   WaveGen out;
   Emit E(out.G, out.code);
-  E.line("namespace dnlp {\nnamespace wgen {\n");
+  E.line("#define WG_LANES %d\nnamespace dnlp {\nnamespace wgen {\n", LW);
   // ================================================================ factorisation
   E.line("// wave_ipm.h ldl_factor_impl for THIS template: %d levels before the dense tail (order %d), %d blocks, %d values, %d update triples\n",
          nlev, h.tail_T, nblk, h.sp_nvals, h.sp_ntrip);
@@ -88,8 +89,9 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
     const int b0 = lev_off[lev], b1 = lev_off[lev + 1], r0 = lev_r[lev], r1 = lev_r[lev + 1];
     E.line("  // level %d: %d blocks, %d struct rows\n", lev, b1 - b0, r1 - r0);
     // pivots
-    for (int s0 = b0; s0 < b1; s0 += 64) {
-      const int nact = std::min(64, b1 - s0);
+    E.line("  WG_BEGIN\n");
+    for (int s0 = b0; s0 < b1; s0 += LW) {
+      const int nact = std::min(LW, b1 - s0);
       const int at = E.reserve(static_cast<size_t>(nact));
       int kinds = 0;
       for (int j = 0; j < nact; ++j) {
@@ -97,13 +99,15 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
         kinds |= kind;
         out.G[static_cast<size_t>(at + j)] = lo16(doff[k]) | (static_cast<uint32_t>(k) << 16) | (static_cast<uint32_t>(kind) << 30);
       }
-      E.line("  WG_BEGIN wgrt::piv<%d, %d, %d>(lane, G, vals, dinv, nneg, nzero, bad); WG_END\n", at, nact, kinds);
+      E.line("    wgrt::piv<%d, %d, %d>(lane, G, vals, dinv, nneg, nzero, bad);\n", at, nact, kinds);
       ++out.phases_factor;
     }
+    E.line("  WG_END\n");
     if (r1 == r0) continue;
     // row scaling
-    for (int s0 = r0; s0 < r1; s0 += 64) {
-      const int nact = std::min(64, r1 - s0);
+    E.line("  WG_BEGIN\n");
+    for (int s0 = r0; s0 < r1; s0 += LW) {
+      const int nact = std::min(LW, r1 - s0);
       const int at = E.reserve(static_cast<size_t>(nact));
       int kinds = 0;
       for (int j = 0; j < nact; ++j) {
@@ -113,14 +117,16 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
         const int a = one ? loff[k] + i : loff[k] + 2 * i;
         out.G[static_cast<size_t>(at + j)] = lo16(a) | (static_cast<uint32_t>(k) << 16) | (static_cast<uint32_t>(one ? 1 : 2) << 30);
       }
-      E.line("  WG_BEGIN wgrt::scl<%d, %d, %d>(lane, G, vals, w, dinv); WG_END\n", at, nact, kinds);
+      E.line("    wgrt::scl<%d, %d, %d>(lane, G, vals, w, dinv);\n", at, nact, kinds);
       ++out.phases_factor;
     }
+    E.line("  WG_END\n");
     const int g0 = lev_g[lev], g1 = lev_g[lev + 1], t0 = lev_t[lev], ntr = lev_t[lev + 1] - t0;
     if (ntr == 0) continue;
     // products of the update triples, side by side
-    for (int q0 = 0; q0 < ntr; q0 += 64) {
-      const int nact = std::min(64, ntr - q0);
+    E.line("  WG_BEGIN\n");
+    for (int q0 = 0; q0 < ntr; q0 += LW) {
+      const int nact = std::min(LW, ntr - q0);
       const int at = E.reserve(static_cast<size_t>(nact));
       int kinds = 0;
       for (int j = 0; j < nact; ++j) {
@@ -131,12 +137,14 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
         if (bv > 0x7fff) throw std::runtime_error("wave gen: a value index does not fit 15 bits");
         out.G[static_cast<size_t>(at + j)] = lo16(au) | (static_cast<uint32_t>(bv) << 16) | (two ? 0x80000000u : 0u);
       }
-      E.line("  WG_BEGIN wgrt::upd<%d, %d, %d, %d>(lane, G, vals, w, scr); WG_END\n", at, nact, q0, kinds);
+      E.line("    wgrt::upd<%d, %d, %d, %d>(lane, G, vals, w, scr);\n", at, nact, q0, kinds);
       ++out.phases_factor;
     }
+    E.line("  WG_END\n");
     // every destination's run, added in storage order
-    for (int s0 = g0; s0 < g1; s0 += 64) {
-      const int nact = std::min(64, g1 - s0);
+    E.line("  WG_BEGIN\n");
+    for (int s0 = g0; s0 < g1; s0 += LW) {
+      const int nact = std::min(LW, g1 - s0);
       const int at = E.reserve(2 * static_cast<size_t>(nact));
       int maxc = 0, minc = 1 << 30;
       for (int j = 0; j < nact; ++j) {
@@ -145,9 +153,10 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
         out.G[static_cast<size_t>(at + j)] = lo16(gdst[gq]) | (lo16(cnt) << 16);
         out.G[static_cast<size_t>(at + nact + j)] = static_cast<uint32_t>(goff[gq] - t0);
       }
-      E.line("  WG_BEGIN wgrt::gsum<%d, %d, %d, %s>(lane, G, vals, scr); WG_END\n", at, nact, maxc, maxc != minc ? "true" : "false");
+      E.line("    wgrt::gsum<%d, %d, %d, %s>(lane, G, vals, scr);\n", at, nact, maxc, maxc != minc ? "true" : "false");
       ++out.phases_factor;
     }
+    E.line("  WG_END\n");
   }
   E.line("  if (wspec::k_tail_T > 0) W::tail_factor(S, nneg, nzero, bad);\n"
          "  nneg = P::sum(nneg); nzero = P::sum(nzero); bad = P::sum(bad);\n"
@@ -186,8 +195,9 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
       }
       continue;
     }
-    for (int s0 = h0; s0 < h1; s0 += 64) {
-      const int nact = std::min(64, h1 - s0);
+    E.line("  WG_BEGIN\n");
+    for (int s0 = h0; s0 < h1; s0 += LW) {
+      const int nact = std::min(LW, h1 - s0);
       int maxc = 0, minc = 1 << 30, kinds = 0;
       for (int j = 0; j < nact; ++j) { const int c = foff[s0 + j + 1] - foff[s0 + j]; maxc = std::max(maxc, c); minc = std::min(minc, c); }
       const int at = E.reserve(static_cast<size_t>(nact)), ea = E.reserve(2 * static_cast<size_t>(maxc) * static_cast<size_t>(nact));
@@ -202,15 +212,17 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
           out.G[static_cast<size_t>(ea + (2 * e + 1) * nact + j)] = lo16(two ? fu1[q] : fu0[q]) | (static_cast<uint32_t>(two ? 2 : 1) << 16);
         }
       }
-      E.line("  WG_BEGIN wgrt::fwd<TWO, %d, %d, %d, %d, %d, %s>(lane, G, vals, x, y); WG_END\n", at, ea, nact, maxc, kinds, maxc != minc ? "true" : "false");
+      E.line("    wgrt::fwd<TWO, %d, %d, %d, %d, %d, %s>(lane, G, vals, x, y);\n", at, ea, nact, maxc, kinds, maxc != minc ? "true" : "false");
       ++out.phases_solve;
     }
+    E.line("  WG_END\n");
   }
   E.line("  if (wspec::k_tail_T > 0) W::tail_forward(S, x, y);\n");
   // D^-1: every block (the tail's included), side by side
   E.line("  // D^-1, %d blocks\n", nblk);
-  for (int s0 = 0; s0 < nblk; s0 += 64) {
-    const int nact = std::min(64, nblk - s0);
+  E.line("  WG_BEGIN\n");
+  for (int s0 = 0; s0 < nblk; s0 += LW) {
+    const int nact = std::min(LW, nblk - s0);
     const int at = E.reserve(2 * static_cast<size_t>(nact));
     int kinds = 0;
     for (int j = 0; j < nact; ++j) {
@@ -219,9 +231,10 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
       out.G[static_cast<size_t>(at + j)] = lo16(bnode[2 * k]) | ((u1 < 0 ? 0xffffu : lo16(u1)) << 16);
       out.G[static_cast<size_t>(at + nact + j)] = static_cast<uint32_t>(doff[k]);
     }
-    E.line("  WG_BEGIN wgrt::dsol<TWO, %d, %d, %d>(lane, G, vals, x, y); WG_END\n", at, nact, kinds);
+    E.line("    wgrt::dsol<TWO, %d, %d, %d>(lane, G, vals, x, y);\n", at, nact, kinds);
     ++out.phases_solve;
   }
+  E.line("  WG_END\n");
   E.line("  if (wspec::k_tail_T > 0) W::tail_backward(S, x, y);\n");
   // backward: levels descending, a block per lane (blocks without struct rows subtract nothing)
   for (int lev = nlev - 1; lev >= 0; --lev) {
@@ -247,8 +260,9 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
       }
       continue;
     }
-    for (size_t s0 = 0; s0 < blocks.size(); s0 += 64) {
-      const int nact = static_cast<int>(std::min<size_t>(64, blocks.size() - s0));
+    E.line("  WG_BEGIN\n");
+    for (size_t s0 = 0; s0 < blocks.size(); s0 += LW) {
+      const int nact = static_cast<int>(std::min<size_t>(static_cast<size_t>(LW), blocks.size() - s0));
       int maxc = 0, minc = 1 << 30, kinds = 0;
       for (int j = 0; j < nact; ++j) { const int k = blocks[s0 + static_cast<size_t>(j)], c = soff[k + 1] - soff[k]; maxc = std::max(maxc, c); minc = std::min(minc, c); }
       const int ew = (maxc + 1) / 2;
@@ -263,9 +277,10 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
           wd |= lo16(sidx[soff[k] + i]) << ((i & 1) ? 16 : 0);
         }
       }
-      E.line("  WG_BEGIN wgrt::bwd<TWO, %d, %d, %d, %d, %d, %s>(lane, G, vals, x, y); WG_END\n", at, ea, nact, maxc, kinds, maxc != minc ? "true" : "false");
+      E.line("    wgrt::bwd<TWO, %d, %d, %d, %d, %d, %s>(lane, G, vals, x, y);\n", at, ea, nact, maxc, kinds, maxc != minc ? "true" : "false");
       ++out.phases_solve;
     }
+    E.line("  WG_END\n");
   }
   E.line("}\n\n");
   // ================================================================ KKT residual (products by output fused with the combination)
@@ -310,8 +325,9 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
     heavy(jrp, jre, jrs, m, "jv", "v", "v2", "preJ", "preJ2", false);
     if (any_heavy) E.line("  P::sync();\n");
     E.line("  double m0 = -kInf, m1 = -kInf, n0 = -kInf, n1 = -kInf;\n");
-    for (int k0 = 0; k0 < N; k0 += 64) {
-      const int nact = std::min(64, N - k0);
+    E.line("  WG_BEGIN\n");
+    for (int k0 = 0; k0 < N; k0 += LW) {
+      const int nact = std::min(LW, N - k0);
       int maxh = 0, maxj = 0;
       for (int j = 0; j < nact; ++j) {
         const int k = k0 + j, ch = hsp[k + 1] - hsp[k], cj = jcp[k + 1] - jcp[k];
@@ -326,12 +342,14 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
         if (!hh) for (int e = 0; e < ch; ++e) out.G[static_cast<size_t>(ea + e * nact + j)] = lo16(hse[hsp[k] + e]) | (lo16(hss[hsp[k] + e]) << 16);
         if (!hj) for (int e = 0; e < cj; ++e) out.G[static_cast<size_t>(ea + (maxh + e) * nact + j)] = lo16(jce[jcp[k] + e]) | (lo16(N + jcs[jcp[k] + e]) << 16);
       }
-      E.line("  WG_BEGIN wgrt::kres_var<TWO, %d, %d, %d, %d, %d, %d>(lane, G, Hs, jv, sx, fm, dw, v, rhsv, out, (const WD*)preH, (const WD*)preJt, v2, rhsv2, out2, (const WD*)preH2, (const WD*)preJt2, m0, m1, n0, n1); WG_END\n",
+      E.line("    wgrt::kres_var<TWO, %d, %d, %d, %d, %d, %d>(lane, G, Hs, jv, sx, fm, dw, v, rhsv, out, (const WD*)preH, (const WD*)preJt, v2, rhsv2, out2, (const WD*)preH2, (const WD*)preJt2, m0, m1, n0, n1);\n",
              at, ea, nact, k0, maxh, maxj);
-      { char b[256]; std::snprintf(b, sizeof b, "  WG_BEGIN wgrt::cojt<%d, %d, %d, %d, %d, %d>(lane, G, jv, v - %d, out); WG_END\n", at, ea, nact, k0, maxh, maxj, N); jt_light += b; }
+      { char b[256]; std::snprintf(b, sizeof b, "    wgrt::cojt<%d, %d, %d, %d, %d, %d>(lane, G, jv, v - %d, out);\n", at, ea, nact, k0, maxh, maxj, N); jt_light += b; }
     }
-    for (int i0 = 0; i0 < m; i0 += 64) {
-      const int nact = std::min(64, m - i0);
+    E.line("  WG_END\n");
+    E.line("  WG_BEGIN\n");
+    for (int i0 = 0; i0 < m; i0 += LW) {
+      const int nact = std::min(LW, m - i0);
       int maxj = 0;
       for (int j = 0; j < nact; ++j) { const int c = jrp[i0 + j + 1] - jrp[i0 + j]; if (c <= kCooHeavy) maxj = std::max(maxj, c); }
       const int at = E.reserve(static_cast<size_t>(nact)), ea = E.reserve(static_cast<size_t>(maxj) * static_cast<size_t>(nact));
@@ -341,14 +359,15 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
         out.G[static_cast<size_t>(at + j)] = static_cast<uint32_t>(hv ? 0 : c) | (hv ? 0x10000u : 0u);
         if (!hv) for (int e = 0; e < c; ++e) out.G[static_cast<size_t>(ea + e * nact + j)] = lo16(jre[jrp[i] + e]) | (lo16(jrs[jrp[i] + e]) << 16);
       }
-      E.line("  WG_BEGIN wgrt::kres_row<TWO, %d, %d, %d, %d, %d, %d>(lane, G, jv, dd, v, rhsv, out, (const WD*)preJ, v2, rhsv2, out2, (const WD*)preJ2, m0, m1, n0, n1); WG_END\n",
+      E.line("    wgrt::kres_row<TWO, %d, %d, %d, %d, %d, %d>(lane, G, jv, dd, v, rhsv, out, (const WD*)preJ, v2, rhsv2, out2, (const WD*)preJ2, m0, m1, n0, n1);\n",
              at, ea, nact, i0, N, maxj);
     }
+    E.line("  WG_END\n");
     E.line("  en = P::vmax(m0); sn = P::vmax(m1);\n  if (TWO) { en2 = P::vmax(n0); sn2 = P::vmax(n1); }\n  P::sync();\n}\n\n");
     E.line("// wave_ipm.h jac_tmult (the product by output J^T v of the tape's index jc) out of the same tables\n");
     E.line("template <class P, class WS, class WD> DNLP_WINL DNLP_HD void jac_tmult(WS* S, const WD* v, WD* out) {\n"
            "  const WD* jv = WV(jv);\n  typename P::G G = P::gtab();\n");
-    out.code += jt_light;
+    out.code += "  WG_BEGIN\n" + jt_light + "  WG_END\n";
     out.code += jt_heavy;
     E.line("  P::sync();\n}\n\n");
   }
@@ -366,8 +385,9 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
       const M& mt = mats[q];
       const i32 *ptr = T(mt.ptr), *idx = T(mt.idx);
       E.line("  %sif (id == %d) {      // %s: %d rows\n    WG* val = S->row + %d;\n", q ? "else " : "", q, mt.name, mt.rows, mt.val);
-      for (int r0 = 0; r0 < mt.rows; r0 += 64) {
-        const int nact = std::min(64, mt.rows - r0);
+      E.line("    WG_BEGIN\n");
+      for (int r0 = 0; r0 < mt.rows; r0 += LW) {
+        const int nact = std::min(LW, mt.rows - r0);
         int maxc = 0;
         for (int j = 0; j < nact; ++j) maxc = std::max(maxc, ptr[r0 + j + 1] - ptr[r0 + j]);
         const int at = E.reserve(static_cast<size_t>(nact)), ea = E.reserve(static_cast<size_t>((maxc + 1) / 2) * static_cast<size_t>(nact));
@@ -376,8 +396,9 @@ inline WaveGen wave_generate(const std::vector<i32>& blk) {
           out.G[static_cast<size_t>(at + j)] = lo16(ptr[r]) | (lo16(c) << 16);
           for (int e = 0; e < c; ++e) out.G[static_cast<size_t>(ea + (e >> 1) * nact + j)] |= lo16(idx[ptr[r] + e]) << ((e & 1) ? 16 : 0);
         }
-        E.line("    WG_BEGIN wgrt::spmv<SPLIT, %d, %d, %d, %d, %d>(lane, G, val, base, v, vhi, split, y, scale_kind, scalar, sg, jr); WG_END\n", at, ea, nact, r0, maxc);
+        E.line("      wgrt::spmv<SPLIT, %d, %d, %d, %d, %d>(lane, G, val, base, v, vhi, split, y, scale_kind, scalar, sg, jr);\n", at, ea, nact, r0, maxc);
       }
+      E.line("    WG_END\n");
       E.line("  }\n");
     }
     E.line("}\n\n");

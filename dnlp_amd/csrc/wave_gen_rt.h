@@ -11,7 +11,7 @@
 // The ARITHMETIC is that of wave_ipm.h / sparse_ldl.h, entry by entry and in the same order: every destination (a forward
 // target, a block's backward sum, an update group) is summed by ONE lane in storage order — what the host lane of the
 // interpreted text does — so the generated phases reproduce its bits on the CPU (tests/test_wave_gen_cpu.py runs this text
-// with 64 virtual lanes against the interpreted host lane) and the device runs the same sums.  A padded entry multiplies
+// with its lanes played one after the other against the interpreted host lane) and the device runs the same sums.  A padded entry multiplies
 // two selected zeros: adding +0.0 to a sum that started at +0.0 never changes it.
 //
 // Free of standard-library includes (the text travels into hiprtc as wave_gen_rt_src.inc).
@@ -24,7 +24,7 @@
 #define WG_END } P::sync();
 #define WG_INLINE __attribute__((always_inline)) __device__ inline
 #else
-#define WG_BEGIN for (int lane = 0; lane < 64; ++lane) {
+#define WG_BEGIN for (int lane = 0; lane < WG_LANES; ++lane) {      // (WG_LANES: the generated text says how many lanes share a phase)
 #define WG_END }
 #define WG_INLINE inline
 #endif

@@ -11,7 +11,7 @@
 //     [variables | rows] pass in each of its two trips);
 //   * the tape is one table row per work unit and 32-bit CSR maps (wave_plan.h) staged once per workgroup;
 //   * reductions are lane-strided partial sums + the fixed DPP tree of wave_ops.h: the same bits on every run.
-// Single source over a lane policy P (lanes, lane(), sync(), sum / vmax): WaveLanes (wave_batch.h) on the device, one
+// Single source over a lane policy P (lanes, lane(), sync(), sum / vmax, now()): WaveLanes (wave_batch.h) on the device, one
 // host lane in the test oracle (oracle/oracle_lib.cpp) — where its serial sums reproduce the HostExec build of
 // ipm_core.h, which is how the restatement is pinned on the CPU (tests/test_wave_ipm_cpu.py).
 // What it does not have: the dense Bunch-Kaufman fallback of a structurally singular static pivot sequence — such an
@@ -995,7 +995,7 @@ struct WaveIpm {
   // Ipm::begin
   DNLP_WFN DNLP_HD static int begin(WS* S) {
     W_P0();
-    const double t_start = now_sec();
+    const double t_start = P::now();
     const int N = WK(N), m = WK(m);
     const IpmOptions& opt = S->opt;
     const double inf = opt.nlp_inf, brf = opt.bound_relax_factor;
@@ -1298,27 +1298,58 @@ struct WaveIpm {
     const WD *l = WV(xL), *u = WV(xU), *sl = WV(sL), *su = WV(sU), *eq = WV(eq), *xx = WV(x), *ss = WV(s), *a = WV(zL), *b = WV(zU), *c = WV(vL),
              *d = WV(vU), *gr = WV(grad), *yy = WV(y), *gg = WV(g), *fm = WV(fixm);
     const double kd = S->opt.kappa_d;
-    W_FOR(j, WK(N)) {
-      double sig = 0.0, gphi = gr[j];
-      const bool hl = l[j] > -kInf, hu = u[j] < kInf;
-      if (hl) { sig += a[j] / (xx[j] - l[j]); gphi -= muv / (xx[j] - l[j]); }
-      if (hu) { sig += b[j] / (u[j] - xx[j]); gphi += muv / (u[j] - xx[j]); }
-      if (hl && !hu) gphi += kd * muv;
-      if (hu && !hl) gphi -= kd * muv;
-      sx[j] = sig;
-      r[j] = fm[j] != 0.0 ? 0.0 : gphi + jt[j];
-    }
-    W_FOR(i, WK(m)) {
-      if (eq[i] != 0.0) { sS[i] = 0.0; q[i] = 0.0; p[i] = gg[i] - sl[i]; continue; }
-      double sig = 0.0, gphi = 0.0;
-      const bool hl = sl[i] > -kInf, hu = su[i] < kInf;
-      if (hl) { sig += c[i] / (ss[i] - sl[i]); gphi -= muv / (ss[i] - sl[i]); }
-      if (hu) { sig += d[i] / (su[i] - ss[i]); gphi += muv / (su[i] - ss[i]); }
-      if (hl && !hu) gphi += kd * muv;
-      if (hu && !hl) gphi -= kd * muv;
-      sS[i] = sig;
-      q[i] = gphi - yy[i];
-      p[i] = gg[i] - ss[i];
+    if (P::hoist) {        // (operands first, selects instead of branches: see quality())
+      W_FOR(j, WK(N)) {
+        const double lj = l[j], uj = u[j], xj = xx[j], aj = a[j], bj = b[j], fmj = fm[j], jtj = jt[j];
+        double sig = 0.0, gphi = gr[j];
+        const bool hl = lj > -kInf, hu = uj < kInf;
+        const double dl = xj - lj, du = uj - xj;
+        const double sl_ = aj / dl, ml_ = muv / dl, su_ = bj / du, mu_ = muv / du;
+        sig = hl ? sig + sl_ : sig; gphi = hl ? gphi - ml_ : gphi;
+        sig = hu ? sig + su_ : sig; gphi = hu ? gphi + mu_ : gphi;
+        gphi = (hl && !hu) ? gphi + kd * muv : gphi;
+        gphi = (hu && !hl) ? gphi - kd * muv : gphi;
+        sx[j] = sig;
+        r[j] = fmj != 0.0 ? 0.0 : gphi + jtj;
+      }
+      W_FOR(i, WK(m)) {
+        const double li = sl[i], ui = su[i], si = ss[i], ci = c[i], di = d[i], eqi = eq[i], yi = yy[i], gi = gg[i];
+        const bool in = eqi == 0.0;
+        double sig = 0.0, gphi = 0.0;
+        const bool hl = li > -kInf, hu = ui < kInf;
+        const double dl = si - li, du = ui - si;
+        const double sl_ = ci / dl, ml_ = muv / dl, su_ = di / du, mu_ = muv / du;
+        sig = hl ? sig + sl_ : sig; gphi = hl ? gphi - ml_ : gphi;
+        sig = hu ? sig + su_ : sig; gphi = hu ? gphi + mu_ : gphi;
+        gphi = (hl && !hu) ? gphi + kd * muv : gphi;
+        gphi = (hu && !hl) ? gphi - kd * muv : gphi;
+        sS[i] = in ? sig : 0.0;
+        q[i] = in ? gphi - yi : 0.0;
+        p[i] = in ? gi - si : gi - li;
+      }
+    } else {
+      W_FOR(j, WK(N)) {
+        double sig = 0.0, gphi = gr[j];
+        const bool hl = l[j] > -kInf, hu = u[j] < kInf;
+        if (hl) { sig += a[j] / (xx[j] - l[j]); gphi -= muv / (xx[j] - l[j]); }
+        if (hu) { sig += b[j] / (u[j] - xx[j]); gphi += muv / (u[j] - xx[j]); }
+        if (hl && !hu) gphi += kd * muv;
+        if (hu && !hl) gphi -= kd * muv;
+        sx[j] = sig;
+        r[j] = fm[j] != 0.0 ? 0.0 : gphi + jt[j];
+      }
+      W_FOR(i, WK(m)) {
+        if (eq[i] != 0.0) { sS[i] = 0.0; q[i] = 0.0; p[i] = gg[i] - sl[i]; continue; }
+        double sig = 0.0, gphi = 0.0;
+        const bool hl = sl[i] > -kInf, hu = su[i] < kInf;
+        if (hl) { sig += c[i] / (ss[i] - sl[i]); gphi -= muv / (ss[i] - sl[i]); }
+        if (hu) { sig += d[i] / (su[i] - ss[i]); gphi += muv / (su[i] - ss[i]); }
+        if (hl && !hu) gphi += kd * muv;
+        if (hu && !hl) gphi -= kd * muv;
+        sS[i] = sig;
+        q[i] = gphi - yy[i];
+        p[i] = gg[i] - ss[i];
+      }
     }
     W_P1(4);
     P::sync();
@@ -1655,20 +1686,41 @@ struct WaveIpm {
        *dd2 = WDIR(set, 6);
     const WD *l = WV(xL), *u = WV(xU), *sl = WV(sL), *su = WV(sU), *xx = WV(x), *ss = WV(s), *a = WV(zL), *b = WV(zU), *c = WV(vL), *d = WV(vU);
     const double keep = centering ? 0.0 : 1.0;
-    W_FOR(j, N) {
-      const double dxj = so[j];
-      ddx[j] = dxj;
-      da[j] = (l[j] > -kInf) ? (muv - a[j] * dxj) / (xx[j] - l[j]) - keep * a[j] : 0.0;
-      db[j] = (u[j] < kInf) ? (muv + b[j] * dxj) / (u[j] - xx[j]) - keep * b[j] : 0.0;
-    }
-    W_FOR(i, m) {
-      const bool in = eq[i] == 0.0;
-      const double soi = so[N + i], qi = q[i];
-      const double dsi = in ? (soi - qi) / (sS[i] + dw) : 0.0;
-      ddy[i] = soi;
-      dds[i] = dsi;
-      dc[i] = (in && sl[i] > -kInf) ? (muv - c[i] * dsi) / (ss[i] - sl[i]) - keep * c[i] : 0.0;
-      dd2[i] = (in && su[i] < kInf) ? (muv + d[i] * dsi) / (su[i] - ss[i]) - keep * d[i] : 0.0;
+    if (P::hoist) {        // (operands first, selects instead of branches: see quality())
+      W_FOR(j, N) {
+        const double dxj = so[j], lj = l[j], uj = u[j], xj = xx[j], aj = a[j], bj = b[j];
+        const double va = (muv - aj * dxj) / (xj - lj) - keep * aj, vb = (muv + bj * dxj) / (uj - xj) - keep * bj;
+        ddx[j] = dxj;
+        da[j] = (lj > -kInf) ? va : 0.0;
+        db[j] = (uj < kInf) ? vb : 0.0;
+      }
+      W_FOR(i, m) {
+        const double soi = so[N + i], qi = q[i], li = sl[i], ui = su[i], si = ss[i], ci = c[i], di = d[i];
+        const bool in = eq[i] == 0.0;
+        const double dfree = (soi - qi) / (sS[i] + dw);
+        const double dsi = in ? dfree : 0.0;
+        const double vc = (muv - ci * dsi) / (si - li) - keep * ci, vd = (muv + di * dsi) / (ui - si) - keep * di;
+        ddy[i] = soi;
+        dds[i] = dsi;
+        dc[i] = (in && li > -kInf) ? vc : 0.0;
+        dd2[i] = (in && ui < kInf) ? vd : 0.0;
+      }
+    } else {
+      W_FOR(j, N) {
+        const double dxj = so[j];
+        ddx[j] = dxj;
+        da[j] = (l[j] > -kInf) ? (muv - a[j] * dxj) / (xx[j] - l[j]) - keep * a[j] : 0.0;
+        db[j] = (u[j] < kInf) ? (muv + b[j] * dxj) / (u[j] - xx[j]) - keep * b[j] : 0.0;
+      }
+      W_FOR(i, m) {
+        const bool in = eq[i] == 0.0;
+        const double soi = so[N + i], qi = q[i];
+        const double dsi = in ? (soi - qi) / (sS[i] + dw) : 0.0;
+        ddy[i] = soi;
+        dds[i] = dsi;
+        dc[i] = (in && sl[i] > -kInf) ? (muv - c[i] * dsi) / (ss[i] - sl[i]) - keep * c[i] : 0.0;
+        dd2[i] = (in && su[i] < kInf) ? (muv + d[i] * dsi) / (su[i] - ss[i]) - keep * d[i] : 0.0;
+      }
     }
     P::sync();
     W_P1(11);
@@ -1719,26 +1771,52 @@ struct WaveIpm {
     const WD *a = WV(zL), *b = WV(zU), *c = WV(vL), *d = WV(vU), *da = WV(dzL), *db = WV(dzU), *dc = WV(dvL), *dd2 = WV(dvU);
     W_P0();
     double a0 = -kInf, a1 = -kInf;
-    W_FOR(j, WK(N)) {
-      double tp = 1.0, td = 1.0;
-      if (l[j] > -kInf && ddx[j] < 0.0) tp = fmin(tp, -tauv * (xx[j] - l[j]) / ddx[j]);
-      if (u[j] < kInf && ddx[j] > 0.0) tp = fmin(tp, tauv * (u[j] - xx[j]) / ddx[j]);
-      if (da[j] < 0.0) td = fmin(td, -tauv * a[j] / da[j]);
-      if (db[j] < 0.0) td = fmin(td, -tauv * b[j] / db[j]);
-      a0 = mnin(a0, tp); a1 = mnin(a1, td);
-    }
-    W_FOR(i, WK(m)) {
-      double tp = 1.0, td = 1.0;
-      if (eq[i] == 0.0) {
-        if (sl[i] > -kInf && dds[i] < 0.0) tp = fmin(tp, -tauv * (ss[i] - sl[i]) / dds[i]);
-        if (su[i] < kInf && dds[i] > 0.0) tp = fmin(tp, tauv * (su[i] - ss[i]) / dds[i]);
+    if (P::hoist) {        // (operands first, selects instead of branches: see quality())
+      W_FOR(j, WK(N)) {
+        const double lj = l[j], uj = u[j], xj = xx[j], dxx = ddx[j], aj = a[j], bj = b[j], daj = da[j], dbj = db[j];
+        const bool lo = lj > -kInf && dxx < 0.0, up = uj < kInf && dxx > 0.0;
+        const double qp = (lo ? -tauv * (xj - lj) : tauv * (uj - xj)) / dxx, qa = -tauv * aj / daj, qb = -tauv * bj / dbj;
+        double tp = 1.0, td = 1.0;
+        tp = (lo || up) ? fmin(tp, qp) : tp;
+        td = daj < 0.0 ? fmin(td, qa) : td;
+        td = dbj < 0.0 ? fmin(td, qb) : td;
+        a0 = mnin(a0, tp); a1 = mnin(a1, td);
       }
-      if (dc[i] < 0.0) td = fmin(td, -tauv * c[i] / dc[i]);
-      if (dd2[i] < 0.0) td = fmin(td, -tauv * d[i] / dd2[i]);
-      a0 = mnin(a0, tp); a1 = mnin(a1, td);
+      W_FOR(i, WK(m)) {
+        const double li = sl[i], ui = su[i], si = ss[i], dss = dds[i], ci = c[i], di = d[i], dci = dc[i], ddi = dd2[i];
+        const bool in = eq[i] == 0.0;
+        const bool lo = in && li > -kInf && dss < 0.0, up = in && ui < kInf && dss > 0.0;
+        const double qp = (lo ? -tauv * (si - li) : tauv * (ui - si)) / dss, qc = -tauv * ci / dci, qd = -tauv * di / ddi;
+        double tp = 1.0, td = 1.0;
+        tp = (lo || up) ? fmin(tp, qp) : tp;
+        td = dci < 0.0 ? fmin(td, qc) : td;
+        td = ddi < 0.0 ? fmin(td, qd) : td;
+        a0 = mnin(a0, tp); a1 = mnin(a1, td);
+      }
+      a0 = P::vmax(a0); a1 = P::vmax(a1);
+      W_P1(12);
+    } else {
+      W_FOR(j, WK(N)) {
+        double tp = 1.0, td = 1.0;
+        if (l[j] > -kInf && ddx[j] < 0.0) tp = fmin(tp, -tauv * (xx[j] - l[j]) / ddx[j]);
+        if (u[j] < kInf && ddx[j] > 0.0) tp = fmin(tp, tauv * (u[j] - xx[j]) / ddx[j]);
+        if (da[j] < 0.0) td = fmin(td, -tauv * a[j] / da[j]);
+        if (db[j] < 0.0) td = fmin(td, -tauv * b[j] / db[j]);
+        a0 = mnin(a0, tp); a1 = mnin(a1, td);
+      }
+      W_FOR(i, WK(m)) {
+        double tp = 1.0, td = 1.0;
+        if (eq[i] == 0.0) {
+          if (sl[i] > -kInf && dds[i] < 0.0) tp = fmin(tp, -tauv * (ss[i] - sl[i]) / dds[i]);
+          if (su[i] < kInf && dds[i] > 0.0) tp = fmin(tp, tauv * (su[i] - ss[i]) / dds[i]);
+        }
+        if (dc[i] < 0.0) td = fmin(td, -tauv * c[i] / dc[i]);
+        if (dd2[i] < 0.0) td = fmin(td, -tauv * d[i] / dd2[i]);
+        a0 = mnin(a0, tp); a1 = mnin(a1, td);
+      }
+      a0 = P::vmax(a0); a1 = P::vmax(a1);
+      W_P1(12);
     }
-    a0 = P::vmax(a0); a1 = P::vmax(a1);
-    W_P1(12);
     return D2{std::min(1.0, -a0), std::min(1.0, -a1)};
   }
   // Ipm::check_convergence
@@ -1774,7 +1852,7 @@ struct WaveIpm {
     const int cv = check_convergence(S, e0);
     if (cv != 99) return S->status = cv;
     if (S->iter >= S->opt.max_iter) return S->status = Maximum_Iterations_Exceeded;
-    if (now_sec() - S->t_begin > S->opt.max_wall_time) return S->status = Maximum_WallTime_Exceeded;
+    if (P::now() - S->t_begin > S->opt.max_wall_time) return S->status = Maximum_WallTime_Exceeded;
     {
       const WD* xx = WV(x);
       double xm = -kInf;
@@ -1942,14 +2020,32 @@ struct WaveIpm {
     const double kS = 1e10, muv = S->mu;
     const WD *l = WV(xL), *u = WV(xU), *sl = WV(sL), *su = WV(sU), *xx = WV(x), *ss = WV(s), *eq = WV(eq);
     WD *a = WV(zL), *b = WV(zU), *c = WV(vL), *d = WV(vU);
-    W_FOR(j, WK(N)) {
-      if (l[j] > -kInf) { const double t = xx[j] - l[j]; a[j] = fmax(fmin(a[j], kS * muv / t), muv / (kS * t)); }
-      if (u[j] < kInf) { const double t = u[j] - xx[j]; b[j] = fmax(fmin(b[j], kS * muv / t), muv / (kS * t)); }
-    }
-    W_FOR(i, WK(m)) {
-      if (eq[i] != 0.0) continue;
-      if (sl[i] > -kInf) { const double t = ss[i] - sl[i]; c[i] = fmax(fmin(c[i], kS * muv / t), muv / (kS * t)); }
-      if (su[i] < kInf) { const double t = su[i] - ss[i]; d[i] = fmax(fmin(d[i], kS * muv / t), muv / (kS * t)); }
+    if (P::hoist) {        // (operands first, selects instead of branches: see quality())
+      W_FOR(j, WK(N)) {
+        const double lj = l[j], uj = u[j], xj = xx[j], aj = a[j], bj = b[j];
+        const double tl = xj - lj, tu = uj - xj;
+        const double na = fmax(fmin(aj, kS * muv / tl), muv / (kS * tl)), nb = fmax(fmin(bj, kS * muv / tu), muv / (kS * tu));
+        a[j] = lj > -kInf ? na : aj;
+        b[j] = uj < kInf ? nb : bj;
+      }
+      W_FOR(i, WK(m)) {
+        const double li = sl[i], ui = su[i], si = ss[i], ci = c[i], di = d[i];
+        const bool in = eq[i] == 0.0;
+        const double tl = si - li, tu = ui - si;
+        const double nc = fmax(fmin(ci, kS * muv / tl), muv / (kS * tl)), nd = fmax(fmin(di, kS * muv / tu), muv / (kS * tu));
+        c[i] = (in && li > -kInf) ? nc : ci;
+        d[i] = (in && ui < kInf) ? nd : di;
+      }
+    } else {
+      W_FOR(j, WK(N)) {
+        if (l[j] > -kInf) { const double t = xx[j] - l[j]; a[j] = fmax(fmin(a[j], kS * muv / t), muv / (kS * t)); }
+        if (u[j] < kInf) { const double t = u[j] - xx[j]; b[j] = fmax(fmin(b[j], kS * muv / t), muv / (kS * t)); }
+      }
+      W_FOR(i, WK(m)) {
+        if (eq[i] != 0.0) continue;
+        if (sl[i] > -kInf) { const double t = ss[i] - sl[i]; c[i] = fmax(fmin(c[i], kS * muv / t), muv / (kS * t)); }
+        if (su[i] < kInf) { const double t = su[i] - ss[i]; d[i] = fmax(fmin(d[i], kS * muv / t), muv / (kS * t)); }
+      }
     }
     P::sync();
   }
@@ -2092,47 +2188,105 @@ struct WaveIpm {
     const WD *cx = WDIR(2, 0), *cs = WDIR(2, 1), *ca = WDIR(2, 3), *cb = WDIR(2, 4), *cc = WDIR(2, 5), *cd = WDIR(2, 6);
     const WD *l = WV(xL), *u = WV(xU), *sl = WV(sL), *su = WV(sU), *eq = WV(eq), *xx = WV(x), *ss = WV(s), *a = WV(zL), *b = WV(zU), *c = WV(vL), *d = WV(vU);
     const int N = WK(N), m = WK(m);
+    // Two forms of the same values.  P::hoist (a policy whose vectors live in GLOBAL memory: the workgroup-per-instance
+    // kernel): every operand is loaded before the first use and every "if" is a select, so that the loads of a lane leave
+    // together and a trip waits for memory ONCE — the compiler does not move a load across a branch, and a branch per
+    // bound is a chain of a dozen memory round trips per evaluation (12 evaluations per iteration: 240 k of 1 860 k cycles
+    // per iteration of path planning); a select picks what the branch would have computed, the two primal bounds of an
+    // entry share one division (d < 0 can only meet the lower bound, d > 0 only the upper).  With the vectors in LDS the
+    // branches win: a round trip is short, a branch skips its division for the whole wavefront where no lane has the
+    // bound (measured on localization: 9.4 k cycles per iteration with branches, 11.5 k with selects).
     double a0 = -kInf, a1 = -kInf;
-    W_FOR(j, N) {
-      double tp = 1.0, td = 1.0;
-      const double dxx = ax[j] + mus * cx[j];
-      if (l[j] > -kInf && dxx < 0.0) tp = fmin(tp, -tv * (xx[j] - l[j]) / dxx);
-      if (u[j] < kInf && dxx > 0.0) tp = fmin(tp, tv * (u[j] - xx[j]) / dxx);
-      const double da = aa[j] + mus * ca[j], db = ab[j] + mus * cb[j];
-      if (da < 0.0) td = fmin(td, -tv * a[j] / da);
-      if (db < 0.0) td = fmin(td, -tv * b[j] / db);
-      a0 = mnin(a0, tp); a1 = mnin(a1, td);
-    }
-    W_FOR(i, m) {
-      double tp = 1.0, td = 1.0;
-      if (eq[i] == 0.0) {
-        const double dss = as[i] + mus * cs[i];
-        if (sl[i] > -kInf && dss < 0.0) tp = fmin(tp, -tv * (ss[i] - sl[i]) / dss);
-        if (su[i] < kInf && dss > 0.0) tp = fmin(tp, tv * (su[i] - ss[i]) / dss);
+    double comp = 0.0;
+    if (P::hoist) {
+      W_FOR(j, N) {
+        const double lj = l[j], uj = u[j], xj = xx[j], aj = a[j], bj = b[j];
+        const double dxx = ax[j] + mus * cx[j], da = aa[j] + mus * ca[j], db = ab[j] + mus * cb[j];
+        const bool lo = lj > -kInf && dxx < 0.0, up = uj < kInf && dxx > 0.0;
+        const double qp = (lo ? -tv * (xj - lj) : tv * (uj - xj)) / dxx, qa = -tv * aj / da, qb = -tv * bj / db;
+        double tp = 1.0, td = 1.0;
+        tp = (lo || up) ? fmin(tp, qp) : tp;
+        td = da < 0.0 ? fmin(td, qa) : td;
+        td = db < 0.0 ? fmin(td, qb) : td;
+        a0 = mnin(a0, tp); a1 = mnin(a1, td);
       }
-      const double dc = ac[i] + mus * cc[i], dd2 = ad[i] + mus * cd[i];
-      if (dc < 0.0) td = fmin(td, -tv * c[i] / dc);
-      if (dd2 < 0.0) td = fmin(td, -tv * d[i] / dd2);
-      a0 = mnin(a0, tp); a1 = mnin(a1, td);
+      W_FOR(i, m) {
+        const double li = sl[i], ui = su[i], si = ss[i], ci = c[i], di = d[i];
+        const bool in = eq[i] == 0.0;
+        const double dss = as[i] + mus * cs[i], dc = ac[i] + mus * cc[i], dd2 = ad[i] + mus * cd[i];
+        const bool lo = in && li > -kInf && dss < 0.0, up = in && ui < kInf && dss > 0.0;
+        const double qp = (lo ? -tv * (si - li) : tv * (ui - si)) / dss, qc = -tv * ci / dc, qd = -tv * di / dd2;
+        double tp = 1.0, td = 1.0;
+        tp = (lo || up) ? fmin(tp, qp) : tp;
+        td = dc < 0.0 ? fmin(td, qc) : td;
+        td = dd2 < 0.0 ? fmin(td, qd) : td;
+        a0 = mnin(a0, tp); a1 = mnin(a1, td);
+      }
+    } else {
+      W_FOR(j, N) {
+        double tp = 1.0, td = 1.0;
+        const double dxx = ax[j] + mus * cx[j];
+        if (l[j] > -kInf && dxx < 0.0) tp = fmin(tp, -tv * (xx[j] - l[j]) / dxx);
+        if (u[j] < kInf && dxx > 0.0) tp = fmin(tp, tv * (u[j] - xx[j]) / dxx);
+        const double da = aa[j] + mus * ca[j], db = ab[j] + mus * cb[j];
+        if (da < 0.0) td = fmin(td, -tv * a[j] / da);
+        if (db < 0.0) td = fmin(td, -tv * b[j] / db);
+        a0 = mnin(a0, tp); a1 = mnin(a1, td);
+      }
+      W_FOR(i, m) {
+        double tp = 1.0, td = 1.0;
+        if (eq[i] == 0.0) {
+          const double dss = as[i] + mus * cs[i];
+          if (sl[i] > -kInf && dss < 0.0) tp = fmin(tp, -tv * (ss[i] - sl[i]) / dss);
+          if (su[i] < kInf && dss > 0.0) tp = fmin(tp, tv * (su[i] - ss[i]) / dss);
+        }
+        const double dc = ac[i] + mus * cc[i], dd2 = ad[i] + mus * cd[i];
+        if (dc < 0.0) td = fmin(td, -tv * c[i] / dc);
+        if (dd2 < 0.0) td = fmin(td, -tv * d[i] / dd2);
+        a0 = mnin(a0, tp); a1 = mnin(a1, td);
+      }
     }
     a0 = P::vmax(a0); a1 = P::vmax(a1);
     const double apv = std::min(1.0, -a0), adv = std::min(1.0, -a1);
-    double comp = 0.0;
-    W_FOR(j, N) {
-      double v = 0.0;
-      const double dxx = ax[j] + mus * cx[j];
-      if (l[j] > -kInf) { const double t = (xx[j] - l[j] + apv * dxx) * (a[j] + adv * (aa[j] + mus * ca[j])); v += t * t; }
-      if (u[j] < kInf) { const double t = (u[j] - xx[j] - apv * dxx) * (b[j] + adv * (ab[j] + mus * cb[j])); v += t * t; }
-      comp += v;
-    }
-    W_FOR(i, m) {
-      double v = 0.0;
-      if (eq[i] == 0.0) {
-        const double dss = as[i] + mus * cs[i];
-        if (sl[i] > -kInf) { const double t = (ss[i] - sl[i] + apv * dss) * (c[i] + adv * (ac[i] + mus * cc[i])); v += t * t; }
-        if (su[i] < kInf) { const double t = (su[i] - ss[i] - apv * dss) * (d[i] + adv * (ad[i] + mus * cd[i])); v += t * t; }
+    if (P::hoist) {
+      W_FOR(j, N) {
+        const double lj = l[j], uj = u[j], xj = xx[j];
+        const double dxx = ax[j] + mus * cx[j];
+        const double t1 = (xj - lj + apv * dxx) * (a[j] + adv * (aa[j] + mus * ca[j]));
+        const double t2 = (uj - xj - apv * dxx) * (b[j] + adv * (ab[j] + mus * cb[j]));
+        double v = 0.0;
+        v = lj > -kInf ? v + t1 * t1 : v;
+        v = uj < kInf ? v + t2 * t2 : v;
+        comp += v;
       }
-      comp += v;
+      W_FOR(i, m) {
+        const double li = sl[i], ui = su[i], si = ss[i];
+        const bool in = eq[i] == 0.0;
+        const double dss = as[i] + mus * cs[i];
+        const double t1 = (si - li + apv * dss) * (c[i] + adv * (ac[i] + mus * cc[i]));
+        const double t2 = (ui - si - apv * dss) * (d[i] + adv * (ad[i] + mus * cd[i]));
+        double v = 0.0;
+        v = (in && li > -kInf) ? v + t1 * t1 : v;
+        v = (in && ui < kInf) ? v + t2 * t2 : v;
+        comp += v;
+      }
+    } else {
+      W_FOR(j, N) {
+        double v = 0.0;
+        const double dxx = ax[j] + mus * cx[j];
+        if (l[j] > -kInf) { const double t = (xx[j] - l[j] + apv * dxx) * (a[j] + adv * (aa[j] + mus * ca[j])); v += t * t; }
+        if (u[j] < kInf) { const double t = (u[j] - xx[j] - apv * dxx) * (b[j] + adv * (ab[j] + mus * cb[j])); v += t * t; }
+        comp += v;
+      }
+      W_FOR(i, m) {
+        double v = 0.0;
+        if (eq[i] == 0.0) {
+          const double dss = as[i] + mus * cs[i];
+          if (sl[i] > -kInf) { const double t = (ss[i] - sl[i] + apv * dss) * (c[i] + adv * (ac[i] + mus * cc[i])); v += t * t; }
+          if (su[i] < kInf) { const double t = (su[i] - ss[i] - apv * dss) * (d[i] + adv * (ad[i] + mus * cd[i])); v += t * t; }
+        }
+        comp += v;
+      }
     }
     comp = P::sum(comp);
     W_P1(10);
@@ -2394,7 +2548,7 @@ struct WaveIpm {
   // Ipm::solve (the retry ladder included)
   DNLP_WFN DNLP_HD static int solve(WS* S) {
     W_P0();
-    const double t_all = now_sec();
+    const double t_all = P::now();
     S->in_solve = true;
     S->bail = false;
     S->ladder_rung = 0;
@@ -2420,9 +2574,9 @@ struct WaveIpm {
         if (rung == 1 && strategy0 != 1) continue;
         const int it_first = S->iter;
         if (it_first >= max_iter0) { S->status = Maximum_Iterations_Exceeded; break; }
-        if (now_sec() - t_all > max_wall0) { S->status = Maximum_WallTime_Exceeded; break; }
+        if (P::now() - t_all > max_wall0) { S->status = Maximum_WallTime_Exceeded; break; }
         S->opt.max_iter = max_iter0 - it_first;
-        S->opt.max_wall_time = max_wall0 - (now_sec() - t_all);
+        S->opt.max_wall_time = max_wall0 - (P::now() - t_all);
         S->ladder_rung = rung;
         S->opt.mu_strategy = 0;
         if (rung == 2) S->opt.mu_init = mu_init0 * 10.0 > 1.0 ? mu_init0 * 10.0 : 1.0;
@@ -2438,7 +2592,7 @@ struct WaveIpm {
       S->ladder_rung = 0;
     }
     S->in_solve = false;
-    S->wall = now_sec() - t_all;
+    S->wall = P::now() - t_all;
     if (S->bail) S->status = kWaveNeedsGeneric;
     W_P1(0);
     return S->status;

@@ -31,10 +31,12 @@ struct WaveLanesSpec {
   typedef WLdsI I;
   typedef DNLP_WLDS const unsigned* G;
   static constexpr int lanes = 64;
+  static constexpr bool hoist = false;
   __device__ static int lane() { return static_cast<int>(threadIdx.x & 63u); }
   __device__ static void sync() { wave_sync(); }
   __device__ static double sum(double v) { return wave_all_sum(v); }
   __device__ static double vmax(double v) { return wave_all_max(v); }
+  __device__ static double now() { return now_sec(); }
   __device__ static int tab_load(I*, int) { return 0; }
   __device__ static int tab_at(I* tab, int, int idx, int) { return static_cast<int>(tab[idx]); }
   __device__ static int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -1,0 +1,144 @@
+// Template-specialised batch solver, part 8: ONE WORKGROUP per instance, for templates whose state exceeds a compute
+// unit's LDS (power flow: 617 KB, path planning: 377 KB of vectors — KKT order ~1 700).  Compiled per template at run time
+// like wave_spec_kernel.h (this text is never included by the library's own translation unit; it travels as
+// wave_wg_kernel_src.inc), from the same algorithm text and the same generated phases, over a lane policy of
+// wspec::kNW x 64 lanes:
+//   * the instance's vectors live in the workgroup's slab of global memory (L2 / Infinity Cache), the plan prefix and the
+//     generated phases' work tables in global memory too (read-only, shared by every workgroup);
+//   * every wavefront keeps its OWN state record in LDS and runs the scalar control flow redundantly — the wavefronts
+//     agree on every decision because every reduction (sum / vmax: DPP inside a wavefront, a fixed-order sum of the
+//     wavefronts' partials through LDS) and the clock hand all of them the same value;
+//   * a phase of the generated LDL^T / residual / CSR code is one task per lane across ALL wavefronts (wave_gen.h with
+//     256 lanes per slot) between two workgroup barriers; the wide forms and the dense tail run on the first wavefront.
+// The generic batch kernel (batch.h) gives such an instance four wavefronts as well, but interprets: 1.8 ms per interior-point
+// iteration of power flow on MI355X.  Reference role: cvxpy/problems/problem.py:1256-1269 -> ipopt_nlpif.py:140-170 for
+// examples/nlp_examples/power_flow.ipynb, path_planning.ipynb.
+#pragma once
+
+namespace dnlp {
+
+constexpr int kWaveWgRecBytes = (static_cast<int>(sizeof(WStateT<WGlbD, WGlbI>)) + 15) & ~15;
+
+struct __attribute__((aligned(16))) WaveWgRec { char rec[kWaveWgRecBytes]; };
+
+__shared__ WaveWgRec g_wg_rec[wspec::kNW];                 // a state record per wavefront
+__shared__ WGlbD* g_wg_vbase;                              // the workgroup's slab: the instance's vectors (wspec::v_* offsets)
+__shared__ WGlbI* g_wg_plan;                               // the plan block (32-bit, global memory)
+__shared__ DNLP_WGLB const unsigned* g_wg_gen;             // work tables of the generated phases
+__shared__ double g_wg_red[wspec::kNW];                    // the wavefronts' partials of a reduction
+__shared__ double g_wg_clock;
+__shared__ int g_wg_inst;
+
+struct WaveLanesWG {
+  typedef WGlbD D;
+  typedef WGlbI I;
+  typedef DNLP_WGLB const unsigned* G;
+  static constexpr int lanes = 64 * wspec::kNW;
+  static constexpr bool hoist = true;         // (vectors in global memory: wave_ipm.h quality())
+  __device__ static int lane() { return static_cast<int>(threadIdx.x); }
+  __device__ static void sync() { __syncthreads(); }
+  // every wavefront gets the same bits: its own DPP total, then the wavefronts' totals added in wavefront order
+  __device__ static double sum(double v) {
+    const double t = wave_all_sum(v);
+    if ((threadIdx.x & 63u) == 0u) g_wg_red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    double r = g_wg_red[0];
+#pragma unroll
+    for (int k = 1; k < wspec::kNW; ++k) r += g_wg_red[k];
+    __syncthreads();
+    return r;
+  }
+  __device__ static double vmax(double v) {
+    const double t = wave_all_max(v);
+    if ((threadIdx.x & 63u) == 0u) g_wg_red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    double r = g_wg_red[0];
+#pragma unroll
+    for (int k = 1; k < wspec::kNW; ++k) r = fmax(r, g_wg_red[k]);
+    __syncthreads();
+    return r;
+  }
+  // one clock for the workgroup (a time limit must stop every wavefront in the same iteration)
+  __device__ static double now() {
+    if (threadIdx.x == 0) g_wg_clock = now_sec();
+    __syncthreads();
+    const double t = g_wg_clock;
+    __syncthreads();
+    return t;
+  }
+  __device__ static int tab_load(I*, int) { return 0; }
+  __device__ static int tab_at(I* tab, int, int idx, int) { return static_cast<int>(tab[idx]); }
+  __device__ static int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+  template <int SL> __device__ static double row_get(const double (&a)[SL], int row) { return readlane_d(a[0], row); }
+  template <class WS> __device__ static D* vec(WS*, int off) { return g_wg_vbase + off; }
+  __device__ static I* tab(int off) { return g_wg_plan + off; }
+  __device__ static G gtab() { return g_wg_gen; }
+};
+
+}  // namespace dnlp
+
+// (kWgBound: the register budget — a bound of 512 threads holds the kernel and its functions to 256 registers per lane, so that
+//  two workgroups of four wavefronts share a compute unit: these instances wait for memory, and a second workgroup fills the wait)
+extern "C" __global__ void __launch_bounds__(wspec::kWgBound) dnlp_wave_wg_kernel(dnlp::WaveArgs a) {
+  using namespace dnlp;
+  using P = WaveLanesWG;
+  using W = WaveIpm<P>;
+  using WD = typename P::D;
+  const int wave = static_cast<int>(threadIdx.x >> 6), tid = static_cast<int>(threadIdx.x);
+  WD* base = (WD*)(a.state + static_cast<size_t>(blockIdx.x) * static_cast<size_t>(wspec::kStateDoubles));
+  if (tid == 0) { g_wg_vbase = base; g_wg_plan = (WGlbI*)a.blk; g_wg_gen = (DNLP_WGLB const unsigned*)a.gen; }
+  __syncthreads();
+  typename W::WS* S = (typename W::WS*)g_wg_rec[wave].rec;
+  constexpr int N = wspec::k_N, m = wspec::k_m;
+  while (true) {
+    if (tid == 0) {
+      const int k = atomicAdd(a.next, 1);
+      g_wg_inst = (k < a.batch && a.order) ? a.order[k] : k;
+    }
+    __syncthreads();
+    const int inst = g_wg_inst;
+    __syncthreads();
+    if (inst >= a.batch) break;
+    for (int k = tid; k < wspec::kStateDoubles; k += P::lanes) base[k] = 0.0;
+    S->row = (WG*)(a.rows + static_cast<i64>(inst) * a.row_doubles);
+    S->park = a.park + static_cast<i64>(blockIdx.x) * a.park_doubles;
+    S->ws_g = a.ws_g ? a.ws_g + static_cast<i64>(inst) * m : nullptr;
+    S->ws_l = a.ws_l ? a.ws_l + static_cast<i64>(inst) * N : nullptr;
+    S->ws_u = a.ws_u ? a.ws_u + static_cast<i64>(inst) * N : nullptr;
+    S->fallback_max_n = a.fallback_max_n;
+    S->opt = a.opt;
+    S->factorizations = 0;
+#ifdef DNLP_WAVE_PROF
+    for (int k = 0; k < kWaveProfSlots; ++k) S->prof[k] = 0ull;
+#endif
+    __syncthreads();
+    const int st = W::solve(S);
+    const bool have = S->initialized && st != kWaveNeedsGeneric;
+    const double sf = have ? S->sf : 1.0;
+    {
+      const WD *xx = WV(x), *yy = WV(y), *sg = WV(sg), *zl = WV(zL), *zu = WV(zU);
+      double* xo = a.x_out + static_cast<i64>(inst) * N;
+      for (int j = tid; j < N; j += P::lanes) {
+        xo[j] = have ? xx[j] : 0.0;
+        if (a.zl_out) a.zl_out[static_cast<i64>(inst) * N + j] = have ? zl[j] / sf : 0.0;
+        if (a.zu_out) a.zu_out[static_cast<i64>(inst) * N + j] = have ? zu[j] / sf : 0.0;
+      }
+      if (a.multg_out)
+        for (int i = tid; i < m; i += P::lanes) a.multg_out[static_cast<i64>(inst) * m + i] = have ? yy[i] * sg[i] / sf : 0.0;
+    }
+    if (tid == 0) {
+#ifdef DNLP_WAVE_PROF
+      if (a.prof) { for (int k = 0; k < kWaveProfSlots; ++k) atomicAdd(a.prof + k, S->prof[k]); atomicAdd(a.prof + kWaveProfSlots, static_cast<unsigned long long>(S->iter)); }
+#endif
+      a.status_out[inst] = st;
+      a.iters_out[inst] = S->iter;
+      a.obj_out[inst] = have ? S->f / sf : 0.0;
+      if (a.nfact_out) a.nfact_out[inst] = S->factorizations;
+      if (a.times_out) {
+        double* to = a.times_out + 4 * static_cast<i64>(inst);
+        to[0] = S->wall; to[1] = 0.0; to[2] = 0.0; to[3] = 0.0;
+      }
+    }
+    __syncthreads();
+  }
+}

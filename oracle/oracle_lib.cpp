@@ -83,10 +83,12 @@ struct HostLane {
   typedef double D;
   typedef const dnlp::i32 I;
   static constexpr int lanes = 1;
+  static constexpr bool hoist = false;
   static int lane() { return 0; }
   static void sync() {}
   static double sum(double v) { return v; }
   static double vmax(double v) { return v; }
+  static double now() { return dnlp::now_sec(); }
   static int tab_load(const dnlp::i32*, int) { return 0; }
   static int tab_at(const dnlp::i32* tab, int, int idx, int) { return tab[idx]; }
   static int uni(int v) { return v; }
@@ -207,13 +209,8 @@ extern "C" long long orc_wave_spec_source(orc_problem* vp, int nw, char* buf, lo
     return static_cast<long long>(src.size());)
 }
 
-// ---- the per-template straight-line LDL^T phases (dnlp_amd/csrc/wave_gen.h) on the host ---------------------------------
-// orc_wave_gen_host_source: a self-contained translation unit for g++ — the template's constants (namespace wspec), its
-// plan block and work tables as arrays, wave_ipm.h compiled with -DDNLP_WAVE_SPEC -DDNLP_WAVE_GEN over a one-thread lane
-// policy (the generated phases play 64 lanes one after the other), and a driver `wgen_host_solve`.  tests/test_wave_gen_cpu.py
-// builds it and compares its bits with orc_wave_solve_batch (the interpreted text on one host lane).
-#include "../dnlp_amd/csrc/wave_gen.h"
-extern "C" long long orc_wave_gen_host_source(orc_problem* vp, char* buf, long long cap) {
+// The text of a template's workgroup-per-instance kernel (wave_codegen.h wave_wg_source: templates whose state exceeds LDS).
+extern "C" long long orc_wave_wg_source(orc_problem* vp, int nwg, char* buf, long long cap) {
   using namespace dnlp;
   orc_problem_t* p = vp;
   DNLP_TRY(
@@ -223,11 +220,37 @@ extern "C" long long orc_wave_gen_host_source(orc_problem* vp, char* buf, long l
     const char* why = wave_plan_refusal(t, &p->sparse_plan);
     if (why[0]) { tls_error() = why; return -2; }
     const std::vector<i32> blk = build_wave_plan(&p->ex, t, p->sparse_plan, wave_layout_of(t));
-    const WaveGen gen = wave_generate(blk);
+    const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(blk.data());
+    if (wave_gen_refusal(h)[0]) { tls_error() = wave_gen_refusal(h); return -4; }
+    if (nwg < 1 || nwg > 8) { tls_error() = "1 .. 8 wavefronts per workgroup"; return -5; }
+    const WaveGen gen = wave_generate(blk, 64 * nwg);
+    const std::string src = wave_wg_source(blk, nwg, gen);
+    if (buf && cap > static_cast<long long>(src.size())) { std::memcpy(buf, src.data(), src.size()); buf[src.size()] = 0; }
+    return static_cast<long long>(src.size());)
+}
+
+// ---- the per-template straight-line LDL^T phases (dnlp_amd/csrc/wave_gen.h) on the host ---------------------------------
+// orc_wave_gen_host_source: a self-contained translation unit for g++ — the template's constants (namespace wspec), its
+// plan block and work tables as arrays, wave_ipm.h compiled with -DDNLP_WAVE_SPEC -DDNLP_WAVE_GEN over a one-thread lane
+// policy (the generated phases play 64 lanes one after the other), and a driver `wgen_host_solve`.  tests/test_wave_gen_cpu.py
+// builds it and compares its bits with orc_wave_solve_batch (the interpreted text on one host lane).
+#include "../dnlp_amd/csrc/wave_gen.h"
+extern "C" long long orc_wave_gen_host_source(orc_problem* vp, int lanes, char* buf, long long cap) {
+  using namespace dnlp;
+  orc_problem_t* p = vp;
+  DNLP_TRY(
+    p->plan_linear_solver();
+    const Tape<HostExec>& t = *p->model.owner;
+    if (!p->use_sparse) { tls_error() = "no sparse plan for this tape"; return -1; }
+    const char* why = wave_plan_refusal(t, &p->sparse_plan);
+    if (why[0]) { tls_error() = why; return -2; }
+    const std::vector<i32> blk = build_wave_plan(&p->ex, t, p->sparse_plan, wave_layout_of(t));
+    const WaveGen gen = wave_generate(blk, lanes > 0 ? lanes : 64);
     std::string s;
     s += "#include \"ipm_core.h\"\n#include \"wave_plan.h\"\n";
     s += wave_spec_constants(blk, 1);
     s += "#define DNLP_WAVE_SPEC 1\n#define DNLP_WAVE_GEN 1\n#define DNLP_WAVE_FILTER_CAP 1024\n#include \"wave_ipm.h\"\n#include \"wave_gen_rt.h\"\n";
+    s += lanes > 64 ? "#define WGEN_HOST_HOIST true\n" : "#define WGEN_HOST_HOIST false\n";
     char b[64];
     s += "static const int32_t k_blk[] = {";
     for (size_t k = 0; k < blk.size(); ++k) { std::snprintf(b, sizeof b, "%s%d", k ? "," : "", blk[k]); s += b; if ((k & 31) == 31) s += "\n"; }
@@ -243,10 +266,12 @@ struct HostSpecLane {
   typedef const dnlp::i32 I;
   typedef const uint32_t* G;
   static constexpr int lanes = 1;
+  static constexpr bool hoist = WGEN_HOST_HOIST;      // (the elementwise loops' form of the workgroup kernel when its lanes are asked for)
   static int lane() { return 0; }
   static void sync() {}
   static double sum(double v) { return v; }
   static double vmax(double v) { return v; }
+  static double now() { return dnlp::now_sec(); }
   static int tab_load(const dnlp::i32*, int) { return 0; }
   static int tab_at(const dnlp::i32* tab, int, int idx, int) { return tab[idx]; }
   static int uni(int v) { return v; }

@@ -35,6 +35,20 @@ def test_generated_phases_repeat_the_interpreted_host_lane_bit_for_bit(name):
     assert (g["status"] == 0).mean() >= 0.8
 
 
+@pytest.mark.parametrize("name", ["path_planning", "power_flow"])
+def test_generated_phases_for_a_workgroup_of_four_wavefronts(name):
+    """The same generator with 256 lanes sharing a phase — the form of the workgroup-per-instance kernel for templates whose
+    state exceeds a compute unit's LDS (wave_wg_kernel.h): wider slots, the same sums in the same order, the same bits."""
+    tmpl, B = TEMPLATES[name]
+    prob, params, sample, _ = tmpl()
+    hb = GenHostBatch(ParametricBatch(prob, params), lanes=256)
+    thetas = np.stack([sample(i) for i in range(B)])
+    g, w = hb.solve_gen(thetas), hb.solve(thetas, 0)
+    for k in KEYS:
+        assert np.array_equal(g[k], w[k]), k
+    assert "#define WG_LANES 256" in hb.source
+
+
 def test_generated_phases_follow_the_options_too():
     prob, params, sample, _ = bp.template_localization()
     pb = ParametricBatch(prob, params)

@@ -19,16 +19,16 @@ _ip = C.POINTER(C.c_int)
 
 
 class GenHostBatch(HostBatch):
-    def __init__(self, pb, opts=None, build_dir=None):
+    def __init__(self, pb, opts=None, build_dir=None, lanes=64):
         super().__init__(pb, opts)
         f = self.lib.orc_wave_gen_host_source
         f.restype = C.c_longlong
-        f.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
-        n = f(self.handle.ptr, None, 0)
+        f.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_longlong]
+        n = f(self.handle.ptr, lanes, None, 0)
         if n <= 0:
             raise RuntimeError("orc_wave_gen_host_source: %d %s" % (n, self.lib.orc_last_error().decode()))
         buf = C.create_string_buffer(n + 16)
-        f(self.handle.ptr, buf, len(buf))
+        f(self.handle.ptr, lanes, buf, len(buf))
         self.source = buf.value.decode()
         d = build_dir or os.path.join(tempfile.gettempdir(), "dnlp_wave_gen_host-%d" % os.getuid())
         os.makedirs(d, exist_ok=True)
