@@ -450,14 +450,15 @@ struct BatchRunner {
     wave_wg.tried = true;
     const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(wave_blk.data());
     if (wave_gen_refusal(h)[0]) return false;
-    int nwg = std::getenv("DNLP_WAVE_WG_WAVES") ? std::atoi(std::getenv("DNLP_WAVE_WG_WAVES")) : 4;
-    if (nwg < 1 || nwg > 8) nwg = 4;
+    int nwg = std::getenv("DNLP_WAVE_WG_WAVES") ? std::atoi(std::getenv("DNLP_WAVE_WG_WAVES")) : 8;
+    if (nwg < 1 || nwg > 8) nwg = 8;
     const double t0 = now_sec();
     const WaveGen gen = wave_generate(wave_blk, 64 * nwg);
     wave_wg_prof = std::getenv("DNLP_WAVE_SPEC_PROF") != nullptr;
     // (DNLP_WAVE_WG_BOUND: threads the register budget is sized for — 512 with four wavefronts: two workgroups per compute unit)
     const int bound = std::getenv("DNLP_WAVE_WG_BOUND") ? std::atoi(std::getenv("DNLP_WAVE_WG_BOUND")) : 512;
-    const std::string src = wave_wg_source(wave_blk, nwg, gen, wave_wg_prof, bound);
+    const bool lds_vec = !(std::getenv("DNLP_WAVE_WG_LDS") && std::atoi(std::getenv("DNLP_WAVE_WG_LDS")) == 0);
+    const std::string src = wave_wg_source(wave_blk, nwg, gen, wave_wg_prof, bound, lds_vec);
     if (!wave_wg.load(src, "dnlp_wave_wg_kernel")) {
       std::fprintf(stderr, "[dnlp] workgroup-per-instance batch kernel not available (the library's own kernel is used): %s\n", wave_wg.log.substr(0, 2000).c_str());
       return false;

@@ -205,7 +205,34 @@ inline std::string wave_spec_source(const std::vector<i32>& blk, int nw, const W
 
 // the translation unit of a template's WORKGROUP-per-instance kernel (wave_wg_kernel.h; entry point: dnlp_wave_wg_kernel):
 // `gen` must have been generated for 64 x nwg lanes per phase
-inline std::string wave_wg_source(const std::vector<i32>& blk, int nwg, const WaveGen& gen, bool prof = false, int bound_threads = 0) {
+// Which vectors of an instance the workgroup-per-instance kernel keeps in LDS (the rest: the workgroup's slab of global
+// memory): by priority the three arrays a single linear solve runs on (rhs sol res), the factor's values (svals), the three
+// arrays of the mu oracle's second system in front of them (the centering direction's cx czL czU: contiguous with rhs sol res
+// in wave_ipm.h layout) — as far as 160 KB minus the wavefronts' records hold them.  Two ranges of offsets.
+inline std::string wave_wg_lds_ranges(const std::vector<i32>& blk, int nwg, bool enable) {
+  const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(blk.data());
+  typedef WaveIpm<WaveProbeLanes> W;
+  W::WState S;
+  std::vector<double> vecs(static_cast<size_t>(h.state_doubles) + 8, 0.0);
+  W::layout((W::WS*)&S, &h, blk.data(), vecs.data());
+  auto ev = [](long long n) { return (n + 1) & ~1LL; };
+  const long long cap = (160 * 1024 - 2048 - static_cast<long long>(nwg) * 1600) / 8;
+  const long long nm = ev(h.N + h.m), a0 = S.svals - vecs.data(), a1 = a0 + ev(h.sp_nvals);
+  const long long c0 = S.rhs - vecs.data(), c1 = (S.res - vecs.data()) + nm, b0 = S.dir[2][0] - vecs.data();
+  long long r0a = 0, r0b = 0, r1a = 0, r1b = 0;
+  if (enable) {
+    const bool six = b0 + 3 * nm == c0;          // (cx czL czU rhs sol res one block)
+    if (six && (a1 - a0) + (c1 - b0) <= cap) { r0a = a0; r0b = a1; r1a = b0; r1b = c1; }
+    else if ((a1 - a0) + (c1 - c0) <= cap) { r0a = a0; r0b = a1; r1a = c0; r1b = c1; }
+    else if (c1 - c0 <= cap) { r0a = c0; r0b = c1; }
+  }
+  char b[256];
+  std::snprintf(b, sizeof b, "namespace wspec { constexpr int kLds0a = %lld, kLds0b = %lld, kLds1a = %lld, kLds1b = %lld, kLdsDoubles = %lld; }\n", r0a, r0b, r1a, r1b,
+                (r0b - r0a) + (r1b - r1a));
+  return b;
+}
+
+inline std::string wave_wg_source(const std::vector<i32>& blk, int nwg, const WaveGen& gen, bool prof = false, int bound_threads = 0, bool lds_vectors = true) {
   static const char* atom_math_text =
 #include "atom_math_src.inc"
       ;
@@ -238,6 +265,7 @@ inline std::string wave_wg_source(const std::vector<i32>& blk, int nwg, const Wa
   s += wave_spec_text("wave_args.h", wave_args_text);
   s += wave_spec_constants(blk, nwg, gen.G.size(), prof);
   s += "namespace wspec { constexpr int kWgBound = " + std::to_string(bound_threads > 64 * nwg ? bound_threads : 64 * nwg) + "; }\n";
+  s += wave_wg_lds_ranges(blk, nwg, lds_vectors);
   s += wave_spec_text("wave_ops.h", wave_ops_text);
   s += wave_spec_text("wave_ipm.h", wave_ipm_text);
   s += wave_spec_text("wave_wg_kernel.h", wave_wg_kernel_text);

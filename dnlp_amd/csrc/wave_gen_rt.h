@@ -80,8 +80,8 @@ WG_INLINE void fwd(int lane, GP G, const VP vals, VP x, VP y) {
 // ---- forward substitution, WIDE form: ONE target whose many rows lie across the lanes ------------------------------------------
 // (the last levels of a plan with a dense row — localization's two position variables meet all twenty range rows: one lane
 //  walking twenty entries issues 160 LDS loads by itself.)  Lane e forms the product of row e; the products are then added
-// IN ROW ORDER — on the device every lane adds the same v_readlane broadcasts, on the host the lanes are played in that order
-// anyway — which is the serial sum of the interpreted text.  entry e (2 words): as in fwd.  The caller chains the slots of a
+//  — on the host in row order (the lanes are played in that order: the serial sum of the interpreted text), on the device by
+//  the wavefront's fixed reduction tree.  entry e (2 words): as in fwd.  The caller chains the slots of a
 // target with more than 64 rows through acc / acc2 and subtracts once (fwdw_fin).
 template <class P, bool TWO, int E0, int CNT, int KINDS, class GP, class VP>
 WG_INLINE void fwdw(GP G, const VP vals, const VP x, const VP y, double& acc, double& acc2) {
@@ -107,11 +107,11 @@ WG_INLINE void fwdw(GP G, const VP vals, const VP x, const VP y, double& acc, do
     }
 #if DNLP_DEVICE_PASS
   }
-#pragma unroll
-  for (int e = 0; e < CNT; ++e) {
-    acc += readlane_d(p, e);
-    if (TWO) acc2 += readlane_d(p2, e);
-  }
+  // (the wavefront's fixed DPP tree — wave_ops.h — instead of CNT dependent additions through v_readlane: a 47-row target
+  //  of power flow's dense end spent 1 000 cycles in that chain, twice per right-hand side and level.  The same bits on
+  //  every run; the order differs from the host lane's serial sum, as every P::sum of the interpreted text does)
+  acc += wave_all_sum(p);
+  if (TWO) acc2 += wave_all_sum(p2);
 #else
     acc += p;
     if (TWO) acc2 += p2;
@@ -159,12 +159,9 @@ WG_INLINE void bwdw(GP G, const VP vals, const VP x, const VP y, double& a0, dou
     }
 #if DNLP_DEVICE_PASS
   }
-#pragma unroll
-  for (int e = 0; e < CNT; ++e) {
-    a0 += readlane_d(p0, e);
-    if (!ONE) a1 += readlane_d(p1, e);
-    if (TWO) { c0 += readlane_d(q0, e); if (!ONE) c1 += readlane_d(q1, e); }
-  }
+  a0 += wave_all_sum(p0);
+  if (!ONE) a1 += wave_all_sum(p1);
+  if (TWO) { c0 += wave_all_sum(q0); if (!ONE) c1 += wave_all_sum(q1); }
 #else
     a0 += p0;
     if (!ONE) a1 += p1;
@@ -352,7 +349,7 @@ WG_INLINE void gsum(int lane, GP G, VP vals, const VP scr) {
 WG_INLINE double mxin(double acc, double v) { return fmax(acc, v != v ? __builtin_inf() : v); }
 
 // ---- ONE long output by all lanes: sum over its entries of a[ent] v[src] (+ the same with v2), entries across the lanes,
-// added in entry order (the interpreted text's coo_heavy on the host lane).  entry (1 word): ent | src << 16.
+// added in entry order on the host (the interpreted text's coo_heavy on the host lane), by the fixed reduction tree on the device.  entry (1 word): ent | src << 16.
 template <class P, bool TWO, int E0, int CNT, class GP, class CP>
 WG_INLINE void wdot(GP G, CP a, CP v, CP v2, double& acc, double& acc2) {
 #if DNLP_DEVICE_PASS
@@ -369,11 +366,8 @@ WG_INLINE void wdot(GP G, CP a, CP v, CP v2, double& acc, double& acc2) {
     if (TWO) p2 = c * v2[w >> 16];
 #if DNLP_DEVICE_PASS
   }
-#pragma unroll
-  for (int e = 0; e < CNT; ++e) {
-    acc += readlane_d(p, e);
-    if (TWO) acc2 += readlane_d(p2, e);
-  }
+  acc += wave_all_sum(p);
+  if (TWO) acc2 += wave_all_sum(p2);
 #else
     acc += p;
     if (TWO) acc2 += p2;

@@ -3,8 +3,10 @@
 // like wave_spec_kernel.h (this text is never included by the library's own translation unit; it travels as
 // wave_wg_kernel_src.inc), from the same algorithm text and the same generated phases, over a lane policy of
 // wspec::kNW x 64 lanes:
-//   * the instance's vectors live in the workgroup's slab of global memory (L2 / Infinity Cache), the plan prefix and the
-//     generated phases' work tables in global memory too (read-only, shared by every workgroup);
+//   * the instance's vectors live in the workgroup's slab of global memory (L2 / Infinity Cache) — except the hottest, which
+//     the host maps into the compute unit's LDS as far as they fit (wspec::kLds*: the factor's values and the arrays every
+//     linear solve runs on; vectors are reached through generic pointers, the compiler types an access whose place is a
+//     literal) — the plan prefix and the generated phases' work tables in global memory (read-only, shared by every workgroup);
 //   * every wavefront keeps its OWN state record in LDS and runs the scalar control flow redundantly — the wavefronts
 //     agree on every decision because every reduction (sum / vmax: DPP inside a wavefront, a fixed-order sum of the
 //     wavefronts' partials through LDS) and the clock hand all of them the same value;
@@ -17,12 +19,13 @@
 
 namespace dnlp {
 
-constexpr int kWaveWgRecBytes = (static_cast<int>(sizeof(WStateT<WGlbD, WGlbI>)) + 15) & ~15;
+constexpr int kWaveWgRecBytes = (static_cast<int>(sizeof(WStateT<double, WGlbI>)) + 15) & ~15;
 
 struct __attribute__((aligned(16))) WaveWgRec { char rec[kWaveWgRecBytes]; };
 
 __shared__ WaveWgRec g_wg_rec[wspec::kNW];                 // a state record per wavefront
 __shared__ WGlbD* g_wg_vbase;                              // the workgroup's slab: the instance's vectors (wspec::v_* offsets)
+__shared__ __attribute__((aligned(16))) double g_wg_lds[wspec::kLdsDoubles > 0 ? wspec::kLdsDoubles : 2];      // ... the ranges [kLds0a, kLds0b) and [kLds1a, kLds1b) of them
 __shared__ WGlbI* g_wg_plan;                               // the plan block (32-bit, global memory)
 __shared__ DNLP_WGLB const unsigned* g_wg_gen;             // work tables of the generated phases
 __shared__ double g_wg_red[wspec::kNW];                    // the wavefronts' partials of a reduction
@@ -30,7 +33,7 @@ __shared__ double g_wg_clock;
 __shared__ int g_wg_inst;
 
 struct WaveLanesWG {
-  typedef WGlbD D;
+  typedef double D;                  // (generic: a vector is in the slab or in LDS)
   typedef WGlbI I;
   typedef DNLP_WGLB const unsigned* G;
   static constexpr int lanes = 64 * wspec::kNW;
@@ -70,7 +73,11 @@ struct WaveLanesWG {
   __device__ static int tab_at(I* tab, int, int idx, int) { return static_cast<int>(tab[idx]); }
   __device__ static int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
   template <int SL> __device__ static double row_get(const double (&a)[SL], int row) { return readlane_d(a[0], row); }
-  template <class WS> __device__ static D* vec(WS*, int off) { return g_wg_vbase + off; }
+  template <class WS> __device__ static D* vec(WS*, int off) {
+    if (off >= wspec::kLds0a && off < wspec::kLds0b) return (D*)(g_wg_lds + (off - wspec::kLds0a));
+    if (off >= wspec::kLds1a && off < wspec::kLds1b) return (D*)(g_wg_lds + (wspec::kLds0b - wspec::kLds0a) + (off - wspec::kLds1a));
+    return (D*)(g_wg_vbase + off);
+  }
   __device__ static I* tab(int off) { return g_wg_plan + off; }
   __device__ static G gtab() { return g_wg_gen; }
 };
@@ -85,7 +92,7 @@ extern "C" __global__ void __launch_bounds__(wspec::kWgBound) dnlp_wave_wg_kerne
   using W = WaveIpm<P>;
   using WD = typename P::D;
   const int wave = static_cast<int>(threadIdx.x >> 6), tid = static_cast<int>(threadIdx.x);
-  WD* base = (WD*)(a.state + static_cast<size_t>(blockIdx.x) * static_cast<size_t>(wspec::kStateDoubles));
+  WGlbD* base = (WGlbD*)(a.state + static_cast<size_t>(blockIdx.x) * static_cast<size_t>(wspec::kStateDoubles));
   if (tid == 0) { g_wg_vbase = base; g_wg_plan = (WGlbI*)a.blk; g_wg_gen = (DNLP_WGLB const unsigned*)a.gen; }
   __syncthreads();
   typename W::WS* S = (typename W::WS*)g_wg_rec[wave].rec;
@@ -100,6 +107,7 @@ extern "C" __global__ void __launch_bounds__(wspec::kWgBound) dnlp_wave_wg_kerne
     __syncthreads();
     if (inst >= a.batch) break;
     for (int k = tid; k < wspec::kStateDoubles; k += P::lanes) base[k] = 0.0;
+    for (int k = tid; k < wspec::kLdsDoubles; k += P::lanes) g_wg_lds[k] = 0.0;
     S->row = (WG*)(a.rows + static_cast<i64>(inst) * a.row_doubles);
     S->park = a.park + static_cast<i64>(blockIdx.x) * a.park_doubles;
     S->ws_g = a.ws_g ? a.ws_g + static_cast<i64>(inst) * m : nullptr;
