@@ -240,7 +240,7 @@ def cpu_baseline(seed, device, sweep=CPU_SWEEP):
                          ctypes.util.find_library("ipopt") or "not found")}
 
 
-C5_TRAFFIC_PROFILE = "r05_pmc_wave_8192.json"  # rocprofv3 --pmc passes of `bench.py --workload c5` (per round)
+C5_TRAFFIC_PROFILE = "r06_pmc_wave_8192.json"  # rocprofv3 --pmc passes of `bench.py --workload c5` (per round)
 PEAK_HBM_GBS = 8000.0                           # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
@@ -351,7 +351,8 @@ def bench_c5(args):
         pb.solve_many(more, device=local, in_flight=4)
         barrier()
         dt_1024_stream = (time.time() - t4) / len(more)
-    launch_info = pb.solve(thetas[: min(B, 1024)], device=local).raw.get("launch") if world == 1 else None
+    launch_info = info.get("launch")                 # the HEADLINE launch's form (the last timed step of this rank)
+    launch_1024 = pb.solve(thetas[: min(B, 1024)], device=local).raw.get("launch") if world == 1 else None
     assert rows.shape[0] == B and np.array_equal(rows[:, 0], np.arange(B)), "gathered rows are not the whole batch"
     gathered_ranks, backend_name = info["ranks"], info["backend"]
     if dist is not None:
@@ -375,14 +376,26 @@ def bench_c5(args):
         per_launch_s = ksec_all / args.steps
         shard = hi - lo
         alg_bytes_launch = bytes_iter * iters_total * (shard / float(B))
-        traffic, traffic_src = None, None
+        traffic, traffic_src, issue = None, None, None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", C5_TRAFFIC_PROFILE)))
             if pj.get("which") == args.which and int(pj.get("batch", 0)) == shard:
                 traffic = pj["traffic_bytes_per_launch"]
                 traffic_src = "profiles/" + C5_TRAFFIC_PROFILE
-        except (OSError, KeyError, ValueError):
+                # the bound that binds: how much of a wavefront's time issues instructions, and how many it issues per
+                # interior-point iteration (counter passes of this command; per launch / this run's iterations per launch)
+                ins = pj.get("instructions_per_launch") or {}
+                per_it = {k: v / max(iters_total, 1.0) for k, v in ins.items() if v is not None}
+                issue = {"wave_cycles_issuing": pj.get("wave_cycles_issuing"), "wave_cycles_waiting": pj.get("wave_cycles_waiting"),
+                         "wave_cycles_waiting_for_instructions": pj.get("wave_cycles_issue_stalled"),
+                         "wavefronts_per_simd": (launch_info or {}).get("per_cu", 0) / 4.0 if launch_info else None,
+                         "instructions_per_iteration": per_it,
+                         "instructions_per_iteration_total": sum(per_it.values()) if per_it else None,
+                         "source": "profiles/" + C5_TRAFFIC_PROFILE}
+        except OSError:
             pass
+        except (KeyError, ValueError) as e:
+            sys.stderr.write("bench: profiles/%s exists but cannot be read as a C5 counter profile (%r)\n" % (C5_TRAFFIC_PROFILE, e))
         out = {
             "metric": "problems/sec, batch of %d parametrised paper NLPs (%s), sharded over the GPUs" % (B, args.which),
             "value": B * args.steps / dt_all, "unit": "problems/s",
@@ -400,21 +413,24 @@ def bench_c5(args):
                        "shard_of_1024_problems_per_s": 1024 / dt_1024 if dt_1024 else None,
                        "shards_of_1024_four_in_flight_problems_per_s": 1024 / dt_1024_stream if dt_1024_stream else None,
                        "shard_of_1024_slowest_instance_iterations": it_1024,
-                       "kernel_form": launch_info,
+                       "kernel_form": launch_info, "kernel_form_shard_of_1024": launch_1024,
                        "ip_iterations_per_pass": iters_total,
                        "aggregate_ip_iterations_per_s": iters_total * args.steps / dt_all,
                        "problems_per_s_kernel_only": B * args.steps / ksec_all if ksec_all > 0 else None,
                        "gathered_ranks": gathered_ranks, "gathered_bytes": gbytes // max(args.steps, 1),
                        "collective_backend": backend_name},
-            "roofline": {"bound": "hbm", "kernel": ("wave_batch_kernel" if (launch_info or {}).get("wave_form") else "batch_solve_kernel") +
+            "roofline": {"bound": "hbm", "kernel": (("dnlp_wave_wg_kernel (per-template, a workgroup per instance)" if (launch_info or {}).get("lds_mode", 3) == 0 else
+                                                      "dnlp_wave_spec_kernel (per-template: generated LDL^T / residual / CSR phases)")
+                                                     if (launch_info or {}).get("wave_spec") else
+                                                     "wave_batch_kernel" if (launch_info or {}).get("wave_form") else "batch_solve_kernel") +
                          " (whole interior-point loop per wavefront)",
                          "achieved": alg_bytes_launch / per_launch_s / 1e9 if per_launch_s > 0 else None,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": alg_bytes_launch / per_launch_s / 1e9 / PEAK_HBM_GBS if per_launch_s > 0 else None,
                          "algorithmic_bytes_per_iteration": bytes_iter, "avg_launch_ms": 1e3 * per_launch_s,
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_source": traffic_src, "issue": issue,
                          "note": "one wavefront per instance runs the interior-point loop out of LDS: bound by the instructions it issues and "
-                                 "its LDS round trips, neither roof is near (DESIGN.md 4a)"},
+                                 "its LDS round trips (`issue`), neither the HBM nor the MFMA roof is near (DESIGN.md 4d / 4e)"},
         }
         if world > 1 or args.no_cpu:
             out["cpu_baseline"] = {"value": None, "unit": "problems/s", "cores": 0, "kind": "port",

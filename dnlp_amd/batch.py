@@ -333,19 +333,21 @@ class ParametricBatch:
                 local[:, 3] = res.iterations
                 local[:, 4:] = res.x
                 ksec = res.kernel_seconds
+                launch = res.raw.get("launch")
                 if from_device:
                     local_dev = _device_rows(self._handle, lo, -1.0 if self.flip else 1.0)
             finally:
                 if from_device:
                     self._handle.keep_batch_result_rows(False)
         else:
-            local, ksec = np.zeros((0, 4 + int(self.arrays0["dims"][0]))), 0.0
+            local, ksec, launch = np.zeros((0, 4 + int(self.arrays0["dims"][0]))), 0.0, None
         rows = gather_rows(local, B, force=force_collective, local_dev=local_dev)
         per = math.ceil(B / world) if world > 0 else B
         exchanged = exchanging
         info = {"ranks": world, "backend": backend, "rank": rank, "shard": (lo, hi), "kernel_seconds": ksec,
                 "collective": exchanged, "rows_from_device": local_dev is not None,
-                "gathered_bytes": int(world * per * rows.shape[1] * 8) if exchanged else 0}
+                "gathered_bytes": int(world * per * rows.shape[1] * 8) if exchanged else 0,
+                "launch": launch}        # (this rank's launch form: dnlp_batch_launch_info)
         return rows, info
 
     def _close_own(self):

@@ -110,18 +110,60 @@ int dnlp_solve_batch_theta(dnlp_problem* vp, int batch, const double* theta, int
 
 // ---- batches in flight (include/dnlp_hip.h dnlp_batch_stream_*) ----------------------------------------------------------
 }  // extern "C"
+#include <condition_variable>
+#include <map>
+#include <mutex>
+#include <set>
 #include <thread>
+// A stream = nslots runners over the same tape and plan, each with ONE worker thread for its lifetime (round 5 started a
+// thread per submission and always took the round-robin slot).  A submission goes to whichever slot is idle — the caller
+// waits only when all are busy, and then for the first to finish; a result stays on record until it is waited for (a ticket
+// can be waited for once: afterwards, and for a ticket that was never handed out, the call says which of the two it is).
 struct dnlp_batch_stream {
   dnlp_problem_t* p = nullptr;
+  struct Job {
+    int ticket = -1, batch = 0, n_params = 0;
+    const double* theta = nullptr;
+    double *x = nullptr, *obj = nullptr, *mult_g = nullptr, *mult_x_L = nullptr, *mult_x_U = nullptr;
+    int *status = nullptr, *iters = nullptr, *factorizations = nullptr;
+    IpmOptions opt;
+  };
+  struct Result { int rc = 0; double seconds = 0.0; std::string err; };
   struct Slot {
     BatchRunner runner;
     std::thread th;
-    int ticket = -1, rc = 0;
-    double seconds = 0.0;
-    std::string err;
+    std::condition_variable cv;        // work for this slot (or stop)
+    bool busy = false, has_job = false;
+    Job job;
   };
+  std::mutex mu;
+  std::condition_variable cv_done;     // a slot became idle / a result was recorded
   std::vector<std::unique_ptr<Slot>> slots;
+  std::map<int, Result> done;          // finished, not yet waited for
+  std::set<int> inflight;
   int next_ticket = 0;
+  bool stop = false;
+
+  void worker(Slot* sl) {
+    std::unique_lock<std::mutex> lk(mu);
+    while (true) {
+      sl->cv.wait(lk, [&] { return sl->has_job || stop; });
+      if (!sl->has_job) return;          // (stop with nothing queued)
+      const Job j = sl->job;
+      sl->has_job = false;
+      lk.unlock();
+      Result r;
+      try {
+        sl->runner.solve_theta(j.batch, j.theta, j.n_params, j.opt, j.x, j.obj, j.mult_g, j.mult_x_L, j.mult_x_U, j.status, j.iters, j.factorizations, &r.seconds);
+      } catch (const std::exception& e) { r.rc = -199; r.err = e.what(); }
+      catch (...) { r.rc = -199; r.err = "unknown exception"; }
+      lk.lock();
+      done[j.ticket] = r;
+      inflight.erase(j.ticket);
+      sl->busy = false;
+      cv_done.notify_all();
+    }
+  }
 };
 extern "C" {
 dnlp_batch_stream* dnlp_batch_stream_create(dnlp_problem* vp, int nslots) {
@@ -144,6 +186,8 @@ dnlp_batch_stream* dnlp_batch_stream_create(dnlp_problem* vp, int nslots) {
       s->slots.push_back(std::move(sl));
     }
     p->ex.sync();
+    dnlp_batch_stream* raw = s.get();
+    for (auto& sl : s->slots) { dnlp_batch_stream::Slot* q = sl.get(); q->th = std::thread([raw, q] { raw->worker(q); }); }
     return s.release();
   } catch (const std::exception& e) { dnlp::tls_error() = e.what(); return nullptr; }
 }
@@ -151,32 +195,44 @@ int dnlp_batch_stream_submit(dnlp_batch_stream* s, int batch, const double* thet
                              double* mult_x_L, double* mult_x_U, int* status, int* iters, int* factorizations) {
   DNLP_TRY(
     if (s->p->opt.hessian_approximation == 1) return batch_rejects_limited_memory();
-    const int ticket = s->next_ticket++;
-    dnlp_batch_stream::Slot& sl = *s->slots[static_cast<size_t>(ticket) % s->slots.size()];
-    if (sl.th.joinable()) sl.th.join();                // every slot busy: the oldest submission first
-    sl.ticket = ticket; sl.rc = 0; sl.err.clear(); sl.seconds = 0.0;
-    const IpmOptions opt = s->p->opt;
-    dnlp_batch_stream::Slot* q = &sl;
-    sl.th = std::thread([=]() {
-      try {
-        q->runner.solve_theta(batch, theta, n_params, opt, x, obj, mult_g, mult_x_L, mult_x_U, status, iters, factorizations, &q->seconds);
-      } catch (const std::exception& e) { q->rc = -199; q->err = e.what(); }
-      catch (...) { q->rc = -199; q->err = "unknown exception"; }
-    });
-    return ticket;)
+    std::unique_lock<std::mutex> lk(s->mu);
+    dnlp_batch_stream::Slot* sl = nullptr;
+    auto idle = [&] { for (auto& q : s->slots) if (!q->busy) { sl = q.get(); return true; } return false; };
+    s->cv_done.wait(lk, idle);                          // every slot busy: whichever finishes first
+    dnlp_batch_stream::Job& j = sl->job;
+    j.ticket = s->next_ticket++;
+    j.batch = batch; j.theta = theta; j.n_params = n_params;
+    j.x = x; j.obj = obj; j.mult_g = mult_g; j.mult_x_L = mult_x_L; j.mult_x_U = mult_x_U;
+    j.status = status; j.iters = iters; j.factorizations = factorizations;
+    j.opt = s->p->opt;
+    sl->busy = true; sl->has_job = true;
+    s->inflight.insert(j.ticket);
+    sl->cv.notify_one();
+    return j.ticket;)
 }
 int dnlp_batch_stream_wait(dnlp_batch_stream* s, int ticket, double* kernel_seconds) {
   DNLP_TRY(
+    std::unique_lock<std::mutex> lk(s->mu);
     if (ticket < 0 || ticket >= s->next_ticket) { dnlp::tls_error() = "dnlp_batch_stream_wait: no such ticket"; return -1; }
-    dnlp_batch_stream::Slot& sl = *s->slots[static_cast<size_t>(ticket) % s->slots.size()];
-    if (sl.ticket != ticket) { dnlp::tls_error() = "dnlp_batch_stream_wait: that ticket's slot has been reused (wait once, in time)"; return -1; }
-    if (sl.th.joinable()) sl.th.join();
-    if (kernel_seconds) *kernel_seconds = sl.seconds;
-    if (sl.rc != 0) dnlp::tls_error() = sl.err;
-    return sl.rc;)
+    if (!s->done.count(ticket) && !s->inflight.count(ticket)) {
+      dnlp::tls_error() = "dnlp_batch_stream_wait: that ticket has been waited for already (a result is handed out once)";
+      return -2;
+    }
+    s->cv_done.wait(lk, [&] { return s->done.count(ticket) != 0; });
+    const dnlp_batch_stream::Result r = s->done[ticket];
+    s->done.erase(ticket);
+    if (kernel_seconds) *kernel_seconds = r.seconds;
+    if (r.rc != 0) dnlp::tls_error() = r.err;
+    return r.rc;)
 }
 void dnlp_batch_stream_destroy(dnlp_batch_stream* s) {
   if (!s) return;
+  {
+    std::unique_lock<std::mutex> lk(s->mu);
+    s->cv_done.wait(lk, [&] { return s->inflight.empty(); });      // (what was submitted is finished: the caller's arrays are being written)
+    s->stop = true;
+    for (auto& sl : s->slots) sl->cv.notify_one();
+  }
   for (auto& sl : s->slots) if (sl->th.joinable()) sl->th.join();
   delete s;
 }

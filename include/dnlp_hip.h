@@ -166,10 +166,13 @@ int dnlp_solve_batch_theta(dnlp_problem* p, int batch, const double* theta, int 
  * the tail of the previous one leaves idle.  Results are bit for bit those of dnlp_solve_batch_theta on the same rows.
  *   create   after dnlp_batch_set_affine_map; slots >= 1 (2 is what pays); options are those of `p` at each submit
  *   submit   batch x n_params parameter rows and the output arrays of dnlp_solve_batch_theta (batch-major, mult_* may be
- *            NULL); returns a ticket >= 0 at once — unless every slot is busy: then it first waits for the oldest —
- *            or a negative error code.  The arrays must stay valid until the ticket has been waited for.
+ *            NULL); goes to whichever slot is idle and returns a ticket >= 0 at once — unless every slot is busy: then it
+ *            first waits for the FIRST of them to finish — or a negative error code.  The arrays must stay valid until the
+ *            ticket has been waited for.  (Every slot has one worker thread for the stream's lifetime.)
  *   wait     blocks until that submission's outputs are filled; returns its dnlp_solve_batch_theta code; *kernel_seconds
- *            (may be NULL) = its launch's device time.  A ticket can be waited for once.
+ *            (may be NULL) = its launch's device time.  A result stays on record until it is waited for, however many
+ *            submissions follow; it is handed out once: a second wait for the ticket returns -2, a ticket that was never
+ *            handed out -1 (dnlp_last_error says which).
  *   destroy  waits for everything in flight. */
 typedef struct dnlp_batch_stream dnlp_batch_stream;
 dnlp_batch_stream* dnlp_batch_stream_create(dnlp_problem* p, int slots);

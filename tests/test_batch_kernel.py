@@ -381,10 +381,10 @@ def test_solve_many_overlaps_launches_and_changes_no_result(gpu_required):
 
 @pytest.mark.gpu
 def test_batch_stream_tickets_and_refusals(gpu_required):
-    """dnlp_batch_stream_* at its edges (include/dnlp_hip.h): more submissions than slots (the oldest is waited for),
-    batches of different sizes incl. an empty one through the same stream, a ticket that was never issued, a ticket
-    whose slot has been reused, parameter rows of the wrong width (refused at wait, the stream stays usable), and a
-    stream on a handle without an affine map (refused at create)."""
+    """dnlp_batch_stream_* at its edges (include/dnlp_hip.h): more submissions than slots (the first slot to finish takes the
+    next), batches of different sizes incl. an empty one through the same stream, a ticket that was never issued, results
+    waited for out of order and a ticket waited for twice, parameter rows of the wrong width (refused at wait, the stream
+    stays usable), and a stream on a handle without an affine map (refused at create)."""
     import ctypes as C
     import batch_problems as bp
     from dnlp_amd import _capi
@@ -418,10 +418,12 @@ def test_batch_stream_tickets_and_refusals(gpu_required):
     t0, t1, t2 = submit(outs[0], th, P), submit(outs[1], th, P), submit(outs[2], th, P)
     assert (t0, t1, t2) == (0, 1, 2)
     assert api.batch_stream_wait(st, 7, secp) == -1 and "no such ticket" in api.error()
-    assert api.batch_stream_wait(st, t0, secp) == -1 and "reused" in api.error()        # (slot 0 now belongs to ticket 2)
-    assert api.batch_stream_wait(st, t1, secp) == 0 and api.batch_stream_wait(st, t2, secp) == 0
+    # three submissions through two slots: the third took whichever slot finished first; every result is on record until it
+    # is waited for — in any order, however many submissions came after it — and is handed out once
+    assert api.batch_stream_wait(st, t2, secp) == 0 and api.batch_stream_wait(st, t0, secp) == 0 and api.batch_stream_wait(st, t1, secp) == 0
     assert np.array_equal(outs[1]["x"], ref[0].x[:n]) and np.array_equal(outs[2]["x"], ref[0].x[:n])
-    assert np.array_equal(outs[0]["x"], ref[0].x[:n])          # (ticket 0 ran to completion before its slot was reused)
+    assert np.array_equal(outs[0]["x"], ref[0].x[:n])
+    assert api.batch_stream_wait(st, t0, secp) == -2 and "waited for already" in api.error()
     bad = np.zeros((n, P + 1))
     t3 = submit(outs[0], bad, P + 1)
     assert t3 == 3 and api.batch_stream_wait(st, t3, secp) != 0 and api.error()
