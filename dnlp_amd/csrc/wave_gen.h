@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -62,6 +63,8 @@ inline const char* wave_gen_refusal(const WaveHdr& h) {
 // a level of at most kWideMaxTasks tasks with at least kWideMinEntries entries each is run task by task with the entries
 // across the lanes (wave_gen_rt.h fwdw / bwdw) instead of a task per lane
 constexpr int kWideMaxTasks = 4, kWideMinEntries = 8;
+// lines of 32 words of the FOLLOWING table that a narrow phase touches ahead (work tables in global memory: see wave_generate)
+constexpr int kTouchLines = 16;
 
 // LW: lanes that share a phase (64: one wavefront per instance; 64 x wavefronts of a workgroup per instance)
 inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
@@ -76,6 +79,37 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
   const int nblk = h.sp_nblk;
   WaveGen out;
   Emit E(out.G, out.code);
+  // NARROW phases (at most 64 tasks: one slot of one wavefront) are run by the FIRST wavefront alone, with a wavefront-level
+  // barrier behind them; the other wavefronts of a workgroup-per-instance kernel run ahead and wait at the next phase that
+  // needs them (WG_NCLOSE: path planning's 49 two-block levels are 196 dependent narrow phases per factorisation — a
+  // workgroup barrier each was most of their time).  With one wavefront per instance every phase of up to 64 tasks is
+  // narrow and the two kinds of barrier are the same instruction.
+  bool region_open = false;
+  // (work tables in global memory — a workgroup-per-instance kernel, LW > 64: a narrow phase starts by TOUCHING the lines
+  //  of the table that follows its own — the next phase's — so that the next phase finds them in the compute unit's L1:
+  //  such a phase is a table word from L2 / Infinity Cache, then LDS work; 800 of its ~900 cycles were the table word)
+  // MEASURED ON MI355X AND OFF: path planning 14.1 -> 13.3 k problems/s, its factorisation 293 -> 351 k cycles per iteration —
+  // a factor phase is TWO dependent global round trips (table word, then the unscaled rows / inverse pivots / products, which
+  // stay in the slab: they do not fit LDS beside the values and the solves' arrays), and the touched lines did not shorten
+  // the first; DNLP_WAVE_TOUCH=1 turns it on
+  const bool touch = LW > 64 && std::getenv("DNLP_WAVE_TOUCH") && std::atoi(std::getenv("DNLP_WAVE_TOUCH")) == 1;
+  auto patch_touch = [&] {
+    const size_t at = out.code.rfind("@@@");
+    if (at != std::string::npos) out.code.replace(at, 3, std::to_string(out.G.size()));
+  };
+  auto begin_phase = [&](int tasks) {
+    const bool narrow = tasks <= 64;
+    if (!narrow && region_open) { E.line("  WG_NCLOSE\n"); region_open = false; }
+    E.line(narrow ? "  WG_NBEGIN\n" : "  WG_BEGIN\n");
+    if (narrow && touch) E.line("    const unsigned pf_ = wgrt::touch<%d>(lane, G, @@@);\n", kTouchLines);
+    return narrow;
+  };
+  auto end_phase = [&](bool narrow) {
+    if (narrow && touch) { patch_touch(); E.line("    WG_TOUCH_USE(pf_);\n"); }
+    E.line(narrow ? "  WG_NEND\n" : "  WG_END\n");
+    if (narrow) region_open = true;
+  };
+  auto close_region = [&] { if (region_open) { E.line("  WG_NCLOSE\n"); region_open = false; } };
   E.line("#define WG_LANES %d\nnamespace dnlp {\nnamespace wgen {\n", LW);
   // ================================================================ factorisation
   E.line("// wave_ipm.h ldl_factor_impl for THIS template: %d levels before the dense tail (order %d), %d blocks, %d values, %d update triples\n",
@@ -89,7 +123,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
     const int b0 = lev_off[lev], b1 = lev_off[lev + 1], r0 = lev_r[lev], r1 = lev_r[lev + 1];
     E.line("  // level %d: %d blocks, %d struct rows\n", lev, b1 - b0, r1 - r0);
     // pivots
-    E.line("  WG_BEGIN\n");
+    const bool nb_piv = begin_phase(b1 - b0);
     for (int s0 = b0; s0 < b1; s0 += LW) {
       const int nact = std::min(LW, b1 - s0);
       const int at = E.reserve(static_cast<size_t>(nact));
@@ -102,10 +136,10 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
       E.line("    wgrt::piv<%d, %d, %d>(lane, G, vals, dinv, nneg, nzero, bad);\n", at, nact, kinds);
       ++out.phases_factor;
     }
-    E.line("  WG_END\n");
+    end_phase(nb_piv);
     if (r1 == r0) continue;
     // row scaling
-    E.line("  WG_BEGIN\n");
+    const bool nb_scl = begin_phase(r1 - r0);
     for (int s0 = r0; s0 < r1; s0 += LW) {
       const int nact = std::min(LW, r1 - s0);
       const int at = E.reserve(static_cast<size_t>(nact));
@@ -120,11 +154,11 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
       E.line("    wgrt::scl<%d, %d, %d>(lane, G, vals, w, dinv);\n", at, nact, kinds);
       ++out.phases_factor;
     }
-    E.line("  WG_END\n");
+    end_phase(nb_scl);
     const int g0 = lev_g[lev], g1 = lev_g[lev + 1], t0 = lev_t[lev], ntr = lev_t[lev + 1] - t0;
     if (ntr == 0) continue;
     // products of the update triples, side by side
-    E.line("  WG_BEGIN\n");
+    const bool nb_upd = begin_phase(ntr);
     for (int q0 = 0; q0 < ntr; q0 += LW) {
       const int nact = std::min(LW, ntr - q0);
       const int at = E.reserve(static_cast<size_t>(nact));
@@ -140,9 +174,9 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
       E.line("    wgrt::upd<%d, %d, %d, %d>(lane, G, vals, w, scr);\n", at, nact, q0, kinds);
       ++out.phases_factor;
     }
-    E.line("  WG_END\n");
+    end_phase(nb_upd);
     // every destination's run, added in storage order
-    E.line("  WG_BEGIN\n");
+    const bool nb_gs = begin_phase(g1 - g0);
     for (int s0 = g0; s0 < g1; s0 += LW) {
       const int nact = std::min(LW, g1 - s0);
       const int at = E.reserve(2 * static_cast<size_t>(nact));
@@ -156,8 +190,9 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
       E.line("    wgrt::gsum<%d, %d, %d, %s>(lane, G, vals, scr);\n", at, nact, maxc, maxc != minc ? "true" : "false");
       ++out.phases_factor;
     }
-    E.line("  WG_END\n");
+    end_phase(nb_gs);
   }
+  close_region();
   E.line("  if (wspec::k_tail_T > 0) W::tail_factor(S, nneg, nzero, bad);\n"
          "  nneg = P::sum(nneg); nzero = P::sum(nzero); bad = P::sum(bad);\n"
          "  S->o_i[1] = static_cast<int>(nneg);\n  S->o_i[2] = static_cast<int>(nzero);\n  return bad == 0.0;\n}\n\n");
@@ -176,7 +211,8 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
     if (wide) {
       for (int hq = h0; hq < h1; ++hq) {
         const int c = foff[hq + 1] - foff[hq];
-        E.line("  { double acc = 0.0, acc2 = 0.0;\n");
+        E.line("  WG_WBEGIN { double acc = 0.0, acc2 = 0.0;\n");
+        if (touch) E.line("    const unsigned pf_ = wgrt::touch<%d>(P::lane(), G, @@@);\n", kTouchLines);
         for (int e0 = 0; e0 < c; e0 += 64) {
           const int cnt = std::min(64, c - e0);
           const int ea = E.reserve(2 * static_cast<size_t>(cnt));
@@ -190,12 +226,14 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
           }
           E.line("    wgrt::fwdw<P, TWO, %d, %d, %d>(G, vals, x, y, acc, acc2);\n", ea, cnt, kinds);
         }
-        E.line("    wgrt::fwdw_fin<P, TWO, %d>(x, y, acc, acc2); }\n", fnode[hq]);
+        if (touch) { patch_touch(); E.line("    WG_TOUCH_USE(pf_);\n"); }
+        E.line("    wgrt::fwdw_fin<P, TWO, %d>(x, y, acc, acc2); } WG_WEND\n", fnode[hq]);
+        region_open = true;
         ++out.phases_solve;
       }
       continue;
     }
-    E.line("  WG_BEGIN\n");
+    const bool nb_fwd = begin_phase(h1 - h0);
     for (int s0 = h0; s0 < h1; s0 += LW) {
       const int nact = std::min(LW, h1 - s0);
       int maxc = 0, minc = 1 << 30, kinds = 0;
@@ -215,12 +253,13 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
       E.line("    wgrt::fwd<TWO, %d, %d, %d, %d, %d, %s>(lane, G, vals, x, y);\n", at, ea, nact, maxc, kinds, maxc != minc ? "true" : "false");
       ++out.phases_solve;
     }
-    E.line("  WG_END\n");
+    end_phase(nb_fwd);
   }
+  close_region();
   E.line("  if (wspec::k_tail_T > 0) W::tail_forward(S, x, y);\n");
   // D^-1: every block (the tail's included), side by side
   E.line("  // D^-1, %d blocks\n", nblk);
-  E.line("  WG_BEGIN\n");
+  const bool nb_ds = begin_phase(nblk);
   for (int s0 = 0; s0 < nblk; s0 += LW) {
     const int nact = std::min(LW, nblk - s0);
     const int at = E.reserve(2 * static_cast<size_t>(nact));
@@ -234,7 +273,8 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
     E.line("    wgrt::dsol<TWO, %d, %d, %d>(lane, G, vals, x, y);\n", at, nact, kinds);
     ++out.phases_solve;
   }
-  E.line("  WG_END\n");
+  end_phase(nb_ds);
+  close_region();
   E.line("  if (wspec::k_tail_T > 0) W::tail_backward(S, x, y);\n");
   // backward: levels descending, a block per lane (blocks without struct rows subtract nothing)
   for (int lev = nlev - 1; lev >= 0; --lev) {
@@ -248,19 +288,22 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
     if (wide) {
       for (size_t j = 0; j < blocks.size(); ++j) {
         const int k = blocks[j], sn = soff[k + 1] - soff[k], u1 = bnode[2 * k + 1];
-        E.line("  { double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;\n");
+        E.line("  WG_WBEGIN { double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;\n");
+        if (touch) E.line("    const unsigned pf_ = wgrt::touch<%d>(P::lane(), G, @@@);\n", kTouchLines);
         for (int i0 = 0; i0 < sn; i0 += 64) {
           const int cnt = std::min(64, sn - i0);
           const int ea = E.reserve(static_cast<size_t>(cnt));
           for (int i = 0; i < cnt; ++i) out.G[static_cast<size_t>(ea + i)] = lo16(sidx[soff[k] + i0 + i]);
           E.line("    wgrt::bwdw<P, TWO, %s, %d, %d, %d, %d>(G, vals, x, y, a0, a1, c0, c1);\n", u1 < 0 ? "true" : "false", ea, cnt, loff[k], i0);
         }
-        E.line("    wgrt::bwdw_fin<P, TWO, %s, %d, %d>(x, y, a0, a1, c0, c1); }\n", u1 < 0 ? "true" : "false", bnode[2 * k], u1 < 0 ? 0 : u1);
+        if (touch) { patch_touch(); E.line("    WG_TOUCH_USE(pf_);\n"); }
+        E.line("    wgrt::bwdw_fin<P, TWO, %s, %d, %d>(x, y, a0, a1, c0, c1); } WG_WEND\n", u1 < 0 ? "true" : "false", bnode[2 * k], u1 < 0 ? 0 : u1);
+        region_open = true;
         ++out.phases_solve;
       }
       continue;
     }
-    E.line("  WG_BEGIN\n");
+    const bool nb_bwd = begin_phase(static_cast<int>(blocks.size()));
     for (size_t s0 = 0; s0 < blocks.size(); s0 += LW) {
       const int nact = static_cast<int>(std::min<size_t>(static_cast<size_t>(LW), blocks.size() - s0));
       int maxc = 0, minc = 1 << 30, kinds = 0;
@@ -280,8 +323,9 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
       E.line("    wgrt::bwd<TWO, %d, %d, %d, %d, %d, %s>(lane, G, vals, x, y);\n", at, ea, nact, maxc, kinds, maxc != minc ? "true" : "false");
       ++out.phases_solve;
     }
-    E.line("  WG_END\n");
+    end_phase(nb_bwd);
   }
+  close_region();
   E.line("}\n\n");
   // ================================================================ KKT residual (products by output fused with the combination)
   {
@@ -404,6 +448,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
     E.line("}\n\n");
   }
   E.line("}  // namespace wgen\n}  // namespace dnlp\n");
+  out.G.resize(out.G.size() + 32 * static_cast<size_t>(kTouchLines) + 32, 0u);      // (the last phases touch past their own tables)
   return out;
 }
 

@@ -19,13 +19,27 @@
 
 // a phase: every lane of the wavefront runs the body once; on the host one thread plays the 64 lanes one after the other
 // (phases have no cross-lane dependence inside: that is what makes them phases)
+// A NARROW phase (at most 64 tasks) and the wide forms below are run by the first wavefront alone (WG_NBEGIN / WG_WBEGIN),
+// with a wavefront-level barrier behind them; the other wavefronts of a workgroup-per-instance kernel run ahead and wait at
+// WG_NCLOSE, which the generator puts in front of the next thing that needs them.  With one wavefront per instance the first
+// wavefront is the only one and the barriers coincide.
 #if DNLP_DEVICE_PASS
 #define WG_BEGIN { const int lane = P::lane();
 #define WG_END } P::sync();
+#define WG_NBEGIN if (P::lane() < 64) { const int lane = P::lane();
+#define WG_NEND wave_sync(); }
+#define WG_WBEGIN if (P::lane() < 64) {
+#define WG_WEND wave_sync(); }
+#define WG_NCLOSE P::sync();
 #define WG_INLINE __attribute__((always_inline)) __device__ inline
 #else
 #define WG_BEGIN for (int lane = 0; lane < WG_LANES; ++lane) {      // (WG_LANES: the generated text says how many lanes share a phase)
 #define WG_END }
+#define WG_NBEGIN for (int lane = 0; lane < 64; ++lane) {
+#define WG_NEND }
+#define WG_WBEGIN {
+#define WG_WEND }
+#define WG_NCLOSE
 #define WG_INLINE inline
 #endif
 
@@ -33,6 +47,16 @@ namespace dnlp {
 namespace wgrt {
 
 typedef unsigned int u32;
+
+// one word out of each of LINES consecutive 128-byte lines from G[base] on: brings a table that a later phase reads into the
+// compute unit's L1 (work tables in global memory); WG_TOUCH_USE keeps the loads alive until the phase's end
+template <int LINES, class GP>
+WG_INLINE u32 touch(int lane, GP G, int base) { return lane < LINES ? G[base + 32 * lane] : 0u; }
+#if DNLP_DEVICE_PASS
+#define WG_TOUCH_USE(t) asm volatile("" : : "v"(t))
+#else
+#define WG_TOUCH_USE(t) (void)(t)
+#endif
 
 // ---- forward substitution: target node `node` collects its rows (wave_ipm.h ldl_solve, first half) -------------------
 // descriptor (1 word): node | rows << 16.  entry e (2 words, [2e][lane], [2e + 1][lane]): a | u0 << 16, u1 | kind << 16
@@ -128,7 +152,6 @@ WG_INLINE void fwdw_fin(VP x, VP y, double acc, double acc2) {
     x[NODE] -= acc;
     if (TWO) y[NODE] -= acc2;
   }
-  P::sync();
 }
 
 // ---- backward substitution, WIDE form: ONE block whose many struct rows lie across the lanes -------------------------------
@@ -183,7 +206,6 @@ WG_INLINE void bwdw_fin(VP x, VP y, double a0, double a1, double c0, double c1) 
       if (TWO) y[U1] -= c1;
     }
   }
-  P::sync();
 }
 
 // ---- D^-1 on every block (wave_ipm.h dsolve) -------------------------------------------------------------------------

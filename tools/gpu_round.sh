@@ -17,6 +17,7 @@
 #   ab_c2_barrier, ab_c4_sweep   the two A/B measurements of round 4 (C2 grid barrier three ways; C4 sweeps vs step kernels)
 #   ab_ldlt_fused                the round-5 A/B of the 512-column panel forms of the blocked LDL^T (tools/ldlt_fused_ab.sh)
 #   pmc_icache, launch_breakdown instruction-fetch / LDS-wait counters of the wavefront kernel; where a batch launch's wall time goes
+#   spec, spec_prof, wg, pmc_wg  round 6: the per-template kernels against the library's own (tools/wave_spec_check.py, wave_wg_check.py), their phase profiles and counters
 ROOT=${GRAFT_REPO_ROOT:-$(git rev-parse --show-toplevel)}
 cd "$ROOT"
 export TMPDIR=/tmp
@@ -97,6 +98,35 @@ pmc_icache)
   bash tools/pmc_icache.sh > /dev/null 2>&1; cp gpurun_out/pmc_icache/icache.json $O/pmc_wave_icache.json; head -c 600 $O/pmc_wave_icache.json ;;
 launch_breakdown)
   for b in 1024 8192; do python tools/c5_launch_breakdown.py localization $b 2>&1 | tail -7; done | tee $O/c5_launch_breakdown.txt ;;
+spec)
+  # per-template kernel (csrc/wave_codegen.h) against the library's own wavefront kernel: bits / path, kernel time, us per iteration
+  rm -f gpurun_out/wave_spec_check.jsonl
+  timeout 600 python tools/wave_spec_check.py --which localization,circle_packing,circle_packing10 --batch 1024,8192 --reps 3 > /dev/null 2>&1
+  timeout 300 python tools/wave_spec_check.py --which localization --batch 65536 --reps 2 > /dev/null 2>&1
+  cp gpurun_out/wave_spec_check.jsonl $O/wave_spec_check.jsonl
+  python3 -c "
+import json
+for l in open('$O/wave_spec_check.jsonl'):
+    d = json.loads(l); print(d['problem'], d['batch'], 'spec ms %.2f own ms %.2f | us/it %.1f vs %.1f | k/s %.1f vs %.1f | same iterations %d of %d' % (d['spec_kernel_ms_best'], d['own_kernel_ms_best'], d['spec_instance_us_per_iter'], d['own_instance_us_per_iter'], d['spec_problems_per_s_kernel']/1e3, d['own_problems_per_s_kernel']/1e3, d['same_iterations'], d['batch']), d['spec_launch']['wave_form'], d['spec_launch']['wave_spec'])" ;;
+spec_prof)
+  # cycle profile of the per-template kernels' phases (DNLP_WAVE_SPEC_PROF: the kernel is compiled with the counters of wave_ipm.h)
+  DNLP_WAVE_SPEC=1 DNLP_WAVE_SPEC_PROF=1 timeout 300 python tools/wave_check.py --which localization --batch 8192 --reps 2 --skip-generic --out prof_spec.jsonl 2>&1 | grep "wave profile" > $O/wave_phase_profile_spec_localization_8192.txt
+  for W in path_planning power_flow; do
+    DNLP_WAVE_SPEC=1 DNLP_WAVE_SPEC_PROF=1 timeout 300 python tools/wave_wg_check.py --which $W --batch 256 --reps 1 --skip-generic --out prof_wg.jsonl 2>&1 | grep "wave profile" > $O/wave_phase_profile_wg_${W}_256.txt
+  done
+  head -30 $O/wave_phase_profile_spec_localization_8192.txt ;;
+wg)
+  # workgroup-per-instance kernel (csrc/wave_wg_kernel.h) against the generic batch kernel: path planning, power flow
+  rm -f gpurun_out/wave_wg_check.jsonl
+  timeout 900 python tools/wave_wg_check.py --which path_planning,power_flow --batch 1024 --reps 2 > /dev/null 2>&1
+  cp gpurun_out/wave_wg_check.jsonl $O/wave_wg_check.jsonl
+  python3 -c "
+import json
+for l in open('$O/wave_wg_check.jsonl'):
+    d = json.loads(l); print(d['problem'], 'wg k/s %.2f (%.3f ms/it) generic k/s %.2f (%.3f ms/it) same status %d same iterations %d' % (d['wg_problems_per_s_kernel']/1e3, d['wg_instance_ms_per_iter'], d['generic_problems_per_s_kernel']/1e3, d['generic_instance_ms_per_iter'], d['same_status'], d['same_iterations']), d['wg_status_hist'], d['generic_status_hist'])"
+  timeout 300 python tools/pf_status_hist.py > $O/power_flow_status_hist.txt 2>/dev/null; cat $O/power_flow_status_hist.txt ;;
+pmc_wg)
+  for W in path_planning power_flow; do bash tools/pmc_wg.sh $W 1024 $TAG/pmc_wg_$W 2>&1 | tail -2; cp gpurun_out/$TAG/pmc_wg_$W/wg_counters.json $O/pmc_wg_$W.json; done ;;
 *) echo "unknown part $PART" ;;
 esac
 done
