@@ -31,7 +31,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_PROFILE = "r05_pmc_bench_traffic.json"   # rocprofv3 --pmc passes of this command (refreshed per round)
+TRAFFIC_PROFILE = "r06_pmc_bench_traffic.json"   # rocprofv3 --pmc passes of this command (refreshed per round)
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X datasheet FP64 matrix peak (dense); see DESIGN.md §5
 
 

@@ -11,6 +11,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -93,7 +94,9 @@ inline std::vector<char> rtc_compile(const std::string& src, std::string& log, b
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
   if (use_cache && !code.empty()) {
-    const std::string tmp = path + ".tmp" + std::to_string(static_cast<long>(getpid()));
+    // (unique per writer: the slots of a batch stream compile the same source on their own threads at the same time)
+    static std::atomic<unsigned> writer{0};
+    const std::string tmp = path + ".tmp" + std::to_string(static_cast<long>(getpid())) + "." + std::to_string(writer.fetch_add(1));
     if (FILE* fp = std::fopen(tmp.c_str(), "wb")) {
       const size_t w = std::fwrite(code.data(), 1, code.size(), fp);
       std::fclose(fp);

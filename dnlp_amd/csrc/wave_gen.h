@@ -448,7 +448,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
     E.line("}\n\n");
   }
   E.line("}  // namespace wgen\n}  // namespace dnlp\n");
-  out.G.resize(out.G.size() + 32 * static_cast<size_t>(kTouchLines) + 32, 0u);      // (the last phases touch past their own tables)
+  if (touch) out.G.resize(out.G.size() + 32 * static_cast<size_t>(kTouchLines) + 32, 0u);      // (the last phases touch past their own tables)
   return out;
 }
 
