@@ -398,6 +398,7 @@ struct BatchRunner {
   unsigned* d_wave_gen = nullptr;                 // work tables of its generated LDL^T phases (wave_gen.h)
   int wave_gen_words = 0;
   bool wave_spec_prof = false;
+  bool wave_spec_tables_global = false;           // its tables stay in global memory (more wavefronts per compute unit)
   bool last_wave_spec = false;                    // the last solve ran it
   double wave_spec_compile_seconds = 0.0;
   // DNLP_WAVE_SPEC: 0 never, 1 for every launch of a template whose state and plan fit LDS, unset: launches of at least
@@ -420,9 +421,16 @@ struct BatchRunner {
     const WaveGen gen = wave_generate(wave_blk);
     // (DNLP_WAVE_SPEC_PROF: the kernel is compiled with the cycle counters of wave_ipm.h W_P0 / W_P1 and the host prints them)
     wave_spec_prof = std::getenv("DNLP_WAVE_SPEC_PROF") != nullptr;
-    const int fit = wave_spec_max_waves(h, gen.G.size(), wave_spec_prof);
+    // tables in LDS, or — when the shares leave no room for them — in global memory with more wavefronts per compute unit
+    // (a table word through L1 / L2 costs an iteration ~20 %: worth it from 1.2 x the wavefronts on)
+    const int fit_l = wave_spec_max_waves(h, gen.G.size(), wave_spec_prof, false);
+    const int fit_g = (wave_fits16 && d_wave_blk16) ? wave_spec_max_waves(h, gen.G.size(), wave_spec_prof, true) : 0;
+    bool tabg = 5 * fit_g > 6 * fit_l;
+    if (const char* tg = std::getenv("DNLP_WAVE_SPEC_TABLES")) tabg = std::atoi(tg) == 1 ? fit_g > 0 : false;      // (1 global, 0 LDS)
+    const int fit = tabg ? fit_g : fit_l;
     if (fit < 1) return false;
-    const std::string src = wave_spec_source(wave_blk, fit, gen, wave_spec_prof);
+    wave_spec_tables_global = tabg;
+    const std::string src = wave_spec_source(wave_blk, fit, gen, wave_spec_prof, tabg);
     if (!wave_spec.load(src, "dnlp_wave_spec_kernel")) {
       std::fprintf(stderr, "[dnlp] per-template batch kernel not available (the library's own kernel is used): %s\n", wave_spec.log.substr(0, 2000).c_str());
       return false;
@@ -432,7 +440,7 @@ struct BatchRunner {
     if (!gen.G.empty()) DNLP_HIP_CHECK(hipMemcpy(d_wave_gen, gen.G.data(), gen.G.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     wave_spec_nw = fit;
     wave_spec_compile_seconds = now_sec() - t0;
-    if (std::getenv("DNLP_BATCH_DEBUG")) std::fprintf(stderr, "[batch] per-template kernel: %d wavefronts per workgroup, %.2f s to compile / load\n", fit, wave_spec_compile_seconds);
+    if (std::getenv("DNLP_BATCH_DEBUG")) std::fprintf(stderr, "[batch] per-template kernel: %d wavefronts per workgroup, tables in %s, %.2f s to compile / load\n", fit, tabg ? "global memory" : "LDS", wave_spec_compile_seconds);
     return true;
   }
   // the WORKGROUP-per-instance kernel of templates whose state exceeds LDS (wave_wg_kernel.h; same switches as the
@@ -1195,7 +1203,7 @@ struct BatchRunner {
       //  taken as long as it holds at least three quarters of the wavefronts per compute unit the library's form would run)
       if (wave_spec_prepare(batch) && (spec_forced || 4 * std::min(wave_spec_nw, want) >= 3 * nw)) {
         spec = true;
-        nw = std::min(wave_spec_nw, want); pl = 1;
+        nw = std::min(wave_spec_nw, want); pl = wave_spec_tables_global ? 0 : 1;
         w.gen = d_wave_gen; w.gen_words = wave_gen_words;
       }
     }

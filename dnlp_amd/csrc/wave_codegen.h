@@ -53,9 +53,10 @@ constexpr int kWaveSpecRecBytesMax = 1344;      // (what the host sizes a launch
 constexpr int kWaveSpecRecBytesProf = 1568;
 
 // the largest number of wavefronts per workgroup whose shares fit a compute unit's LDS beside the 16-bit plan (0: none)
-inline int wave_spec_max_waves(const WaveHdr& h, size_t gen_words, bool prof = false) {
+// (tables_global: the plan prefix and the work tables stay in global memory — wave_spec_kernel.h kTabGlobal)
+inline int wave_spec_max_waves(const WaveHdr& h, size_t gen_words, bool prof = false, bool tables_global = false) {
   const size_t cap = 160 * 1024 - 512;
-  const size_t plan_b = ((static_cast<size_t>(h.keep_gen) + 7) & ~static_cast<size_t>(7)) * 2 + ((gen_words + 3) & ~static_cast<size_t>(3)) * 4;
+  const size_t plan_b = tables_global ? 64 : ((static_cast<size_t>(h.keep_gen) + 7) & ~static_cast<size_t>(7)) * 2 + ((gen_words + 3) & ~static_cast<size_t>(3)) * 4;
   const size_t share_b = (prof ? kWaveSpecRecBytesProf : kWaveSpecRecBytesMax) + static_cast<size_t>(h.state_doubles) * 8 + 16;
   if (plan_b + share_b > cap) return 0;
   const size_t k = (cap - plan_b) / share_b;
@@ -63,7 +64,7 @@ inline int wave_spec_max_waves(const WaveHdr& h, size_t gen_words, bool prof = f
 }
 
 // namespace wspec of a template: the literals behind WK / WT / WV / WDIR / WCSR / WCOO (wave_ipm.h)
-inline std::string wave_spec_constants(const std::vector<i32>& blk, int nw, size_t gen_words = 0, bool prof = false) {
+inline std::string wave_spec_constants(const std::vector<i32>& blk, int nw, size_t gen_words = 0, bool prof = false, bool tables_global = false) {
   const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(blk.data());
   typedef WaveIpm<WaveProbeLanes> W;
   W::WState S;
@@ -107,6 +108,7 @@ inline std::string wave_spec_constants(const std::vector<i32>& blk, int nw, size
   put("", "kPlanInts", h.keep_gen);      // (what a kernel with generated LDL^T phases stages of the block)
   put("", "kGenWords", static_cast<long long>(gen_words));
   put("", "kNW", nw);
+  s += tables_global ? "constexpr bool kTabGlobal = true;\n" : "constexpr bool kTabGlobal = false;\n";
   put("", "kRecBytesMax", prof ? kWaveSpecRecBytesProf : kWaveSpecRecBytesMax);
   s += "}  // namespace wspec\n";
   return s;
@@ -163,7 +165,7 @@ inline std::string wave_spec_text(const char* name, const char* embedded) {
 }
 
 // the translation unit of a template's kernel (entry point: dnlp_wave_spec_kernel)
-inline std::string wave_spec_source(const std::vector<i32>& blk, int nw, const WaveGen& gen, bool prof = false) {
+inline std::string wave_spec_source(const std::vector<i32>& blk, int nw, const WaveGen& gen, bool prof = false, bool tables_global = false) {
   static const char* atom_math_text =
 #include "atom_math_src.inc"
       ;
@@ -194,7 +196,7 @@ inline std::string wave_spec_source(const std::vector<i32>& blk, int nw, const W
   s += wave_spec_text("ipm_options.h", ipm_options_text);
   s += wave_spec_text("wave_hdr.h", wave_hdr_text);
   s += wave_spec_text("wave_args.h", wave_args_text);
-  s += wave_spec_constants(blk, nw, gen.G.size(), prof);
+  s += wave_spec_constants(blk, nw, gen.G.size(), prof, tables_global);
   s += wave_spec_text("wave_ops.h", wave_ops_text);
   s += wave_spec_text("wave_ipm.h", wave_ipm_text);
   s += wave_spec_text("wave_spec_kernel.h", wave_spec_kernel_text);      // (the lane policy P: the generated functions below are templates over it)

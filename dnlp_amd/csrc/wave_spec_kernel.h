@@ -20,16 +20,24 @@ struct __attribute__((aligned(16))) WaveSpecShare {
 };
 
 // the part of the plan block the kernel still reads (WaveHdr::keep_gen ints: the level machinery's tables are replaced by
-// generated phases), narrowed to 16 bits and staged once per workgroup, and the wavefronts' shares: static LDS, fixed addresses
-__shared__ __attribute__((aligned(16))) int16_t g_wspec_plan[(wspec::kPlanInts + 7) & ~7];
-__shared__ __attribute__((aligned(16))) unsigned g_wspec_gen[(wspec::kGenWords + 3) & ~3];      // work tables of the generated LDL^T phases (wave_gen.h)
+// generated phases), narrowed to 16 bits and staged once per workgroup, and the wavefronts' shares: static LDS, fixed addresses.
+// wspec::kTabGlobal: the tables stay in GLOBAL memory (the block's 16-bit copy, the work tables as uploaded) — the form of a
+// template whose shares leave no room for them (circle packing n = 10: two shares of 74 KB; its tables are 44 KB): a table
+// word then comes through L1 / L2, and a compute unit holds twice the instances.
+__shared__ __attribute__((aligned(16))) int16_t g_wspec_plan[wspec::kTabGlobal ? 8 : ((wspec::kPlanInts + 7) & ~7)];
+__shared__ __attribute__((aligned(16))) unsigned g_wspec_gen[wspec::kTabGlobal ? 4 : ((wspec::kGenWords + 3) & ~3)];      // work tables of the generated phases (wave_gen.h)
+__shared__ WGlbI16* g_wspec_plan_g;
+__shared__ DNLP_WGLB const unsigned* g_wspec_gen_g;
 __shared__ WaveSpecShare g_wspec_share[wspec::kNW];
 __shared__ int g_wspec_inst[wspec::kNW];
 
+template <bool B, class X, class Y> struct WSel { typedef X type; };
+template <class X, class Y> struct WSel<false, X, Y> { typedef Y type; };
+
 struct WaveLanesSpec {
   typedef WLdsD D;
-  typedef WLdsI I;
-  typedef DNLP_WLDS const unsigned* G;
+  typedef typename WSel<wspec::kTabGlobal, WGlbI16, WLdsI>::type I;
+  typedef typename WSel<wspec::kTabGlobal, DNLP_WGLB const unsigned*, DNLP_WLDS const unsigned*>::type G;
   static constexpr int lanes = 64;
   static constexpr bool hoist = false;
   __device__ static int lane() { return static_cast<int>(threadIdx.x & 63u); }
@@ -46,8 +54,14 @@ struct WaveLanesSpec {
     return (D*)((DNLP_WLDS char*)S + kWaveSpecRecBytes) + off;
   }
   // a table of the plan block
-  __device__ static I* tab(int off) { return (I*)g_wspec_plan + off; }
-  __device__ static G gtab() { return (G)g_wspec_gen; }
+  __device__ static I* tab(int off) {
+    if constexpr (wspec::kTabGlobal) return (I*)g_wspec_plan_g + off;
+    else return (I*)g_wspec_plan + off;
+  }
+  __device__ static G gtab() {
+    if constexpr (wspec::kTabGlobal) return (G)g_wspec_gen_g;
+    else return (G)g_wspec_gen;
+  }
 };
 
 }  // namespace dnlp
@@ -58,8 +72,12 @@ extern "C" __global__ void __launch_bounds__(64 * wspec::kNW) dnlp_wave_spec_ker
   using W = WaveIpm<P>;
   using WD = typename P::D;
   const int wave = static_cast<int>(threadIdx.x >> 6), lane = static_cast<int>(threadIdx.x & 63u);
-  for (int k = static_cast<int>(threadIdx.x); k < wspec::kPlanInts; k += static_cast<int>(blockDim.x)) g_wspec_plan[k] = static_cast<int16_t>(a.blk[k]);
-  for (int k = static_cast<int>(threadIdx.x); k < wspec::kGenWords; k += static_cast<int>(blockDim.x)) g_wspec_gen[k] = a.gen[k];
+  if constexpr (wspec::kTabGlobal) {
+    if (threadIdx.x == 0) { g_wspec_plan_g = (WGlbI16*)a.blk16; g_wspec_gen_g = (DNLP_WGLB const unsigned*)a.gen; }
+  } else {
+    for (int k = static_cast<int>(threadIdx.x); k < wspec::kPlanInts; k += static_cast<int>(blockDim.x)) g_wspec_plan[k] = static_cast<int16_t>(a.blk[k]);
+    for (int k = static_cast<int>(threadIdx.x); k < wspec::kGenWords; k += static_cast<int>(blockDim.x)) g_wspec_gen[k] = a.gen[k];
+  }
   __syncthreads();                     // the only workgroup barrier of the kernel
   typename W::WS* S = (typename W::WS*)g_wspec_share[wave].rec;
   WD* base = (WD*)g_wspec_share[wave].vec;

@@ -97,7 +97,8 @@ def test_per_template_kernel_follows_the_library_kernel(gpu_required, name, B, f
     thetas = np.stack([sample(i) for i in range(B)])
     s, o = _both(pb, thetas)
     assert s.raw["launch"]["wave_spec"] and not o.raw["launch"]["wave_spec"]
-    assert s.raw["launch"]["wave_form"] % 100 == 11
+    # (state in LDS; the tables in LDS too, or — circle packing n = 10, whose two shares leave no room for them — in global memory)
+    assert s.raw["launch"]["wave_form"] % 100 == (10 if name == "circle_packing10" else 11)
     _same_path(s, o, frac)
     assert (s.status == 0).mean() >= 0.9
     pb.close()
