@@ -28,7 +28,8 @@ __shared__ WGlbD* g_wg_vbase;                              // the workgroup's sl
 __shared__ __attribute__((aligned(16))) double g_wg_lds[wspec::kLdsDoubles > 0 ? wspec::kLdsDoubles : 2];      // ... the ranges [kLds0a, kLds0b) and [kLds1a, kLds1b) of them
 __shared__ WGlbI* g_wg_plan;                               // the plan block (32-bit, global memory)
 __shared__ DNLP_WGLB const unsigned* g_wg_gen;             // work tables of the generated phases
-__shared__ double g_wg_red[wspec::kNW];                    // the wavefronts' partials of a reduction
+__shared__ double g_wg_red[2][wspec::kNW];                 // the wavefronts' partials of a reduction, two sets used in turn (one barrier per reduction)
+__shared__ unsigned g_wg_turn[wspec::kNW];                 // ... which set a wavefront's next reduction writes (every wavefront counts alike)
 __shared__ double g_wg_clock;
 __shared__ int g_wg_inst;
 
@@ -41,24 +42,33 @@ struct WaveLanesWG {
   __device__ static int lane() { return static_cast<int>(threadIdx.x); }
   __device__ static void sync() { __syncthreads(); }
   // every wavefront gets the same bits: its own DPP total, then the wavefronts' totals added in wavefront order
+  // (the partials go to one of two sets in turn: a wavefront that has passed the barrier of reduction k may already write
+  //  the set of reduction k + 1 while a slower one still reads set k — and nobody writes set k again before everybody has
+  //  passed barrier k + 1)
+  __device__ static unsigned turn() {
+    const unsigned w = threadIdx.x >> 6;
+    const unsigned t = g_wg_turn[w];
+    if ((threadIdx.x & 63u) == 0u) g_wg_turn[w] = t ^ 1u;
+    return t & 1u;
+  }
   __device__ static double sum(double v) {
     const double t = wave_all_sum(v);
-    if ((threadIdx.x & 63u) == 0u) g_wg_red[threadIdx.x >> 6] = t;
+    const unsigned s = turn();
+    if ((threadIdx.x & 63u) == 0u) g_wg_red[s][threadIdx.x >> 6] = t;
     __syncthreads();
-    double r = g_wg_red[0];
+    double r = g_wg_red[s][0];
 #pragma unroll
-    for (int k = 1; k < wspec::kNW; ++k) r += g_wg_red[k];
-    __syncthreads();
+    for (int k = 1; k < wspec::kNW; ++k) r += g_wg_red[s][k];
     return r;
   }
   __device__ static double vmax(double v) {
     const double t = wave_all_max(v);
-    if ((threadIdx.x & 63u) == 0u) g_wg_red[threadIdx.x >> 6] = t;
+    const unsigned s = turn();
+    if ((threadIdx.x & 63u) == 0u) g_wg_red[s][threadIdx.x >> 6] = t;
     __syncthreads();
-    double r = g_wg_red[0];
+    double r = g_wg_red[s][0];
 #pragma unroll
-    for (int k = 1; k < wspec::kNW; ++k) r = fmax(r, g_wg_red[k]);
-    __syncthreads();
+    for (int k = 1; k < wspec::kNW; ++k) r = fmax(r, g_wg_red[s][k]);
     return r;
   }
   // one clock for the workgroup (a time limit must stop every wavefront in the same iteration)
@@ -94,6 +104,7 @@ extern "C" __global__ void __launch_bounds__(wspec::kWgBound) dnlp_wave_wg_kerne
   const int wave = static_cast<int>(threadIdx.x >> 6), tid = static_cast<int>(threadIdx.x);
   WGlbD* base = (WGlbD*)(a.state + static_cast<size_t>(blockIdx.x) * static_cast<size_t>(wspec::kStateDoubles));
   if (tid == 0) { g_wg_vbase = base; g_wg_plan = (WGlbI*)a.blk; g_wg_gen = (DNLP_WGLB const unsigned*)a.gen; }
+  if ((tid & 63) == 0) g_wg_turn[wave] = 0u;
   __syncthreads();
   typename W::WS* S = (typename W::WS*)g_wg_rec[wave].rec;
   constexpr int N = wspec::k_N, m = wspec::k_m;

@@ -6,7 +6,10 @@ import time
 
 def compile_for_gfx950(src: str, opts=("-O3", "-std=c++17", "-munsafe-fp-atomics")):
     """-> (ok, log, seconds, code bytes)."""
-    rtc = C.CDLL("libhiprtc.so")
+    try:
+        rtc = C.CDLL("libhiprtc.so")
+    except OSError:
+        rtc = C.CDLL("/opt/rocm/lib/libhiprtc.so")
     prog = C.c_void_p()
     rtc.hiprtcCreateProgram.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]
     rc = rtc.hiprtcCreateProgram(C.byref(prog), src.encode(), b"dnlp_generated.hip", 0, None, None)
