@@ -31,6 +31,9 @@ struct WaveLanesT {
   __device__ static void sync() { wave_sync(); }
   __device__ static double sum(double v) { return wave_all_sum(v); }
   __device__ static double vmax(double v) { return wave_all_max(v); }
+  // several reductions side by side (wave_ops.h: the chains fill each other's wait states; the same bits as one by one)
+  template <int N> __device__ static void sum_n(double (&v)[N]) { wave_all_sum_n<N>(v); }
+  template <int N> __device__ static void vmax_n(double (&v)[N]) { wave_all_max_n<N>(v); }
   __device__ static double now() { return now_sec(); }
   // per-level bounds (measured on MI355X: keeping the table one entry per lane in a register and reading it back with
   // v_readlane made the substitutions 17 % SLOWER than these plain uniform LDS loads — 46.1 -> 53.8 k cycles per iteration)

@@ -41,6 +41,8 @@ struct WaveProbeLanes {
   static void sync() {}
   static double sum(double v) { return v; }
   static double vmax(double v) { return v; }
+  template <int N> static void sum_n(double (&)[N]) {}
+  template <int N> static void vmax_n(double (&)[N]) {}
   static double now() { return dnlp::now_sec(); }
   static int tab_load(const i32*, int) { return 0; }
   static int tab_at(const i32* tab, int, int idx, int) { return tab[idx]; }

@@ -194,7 +194,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
   }
   close_region();
   E.line("  if (wspec::k_tail_T > 0) W::tail_factor(S, nneg, nzero, bad);\n"
-         "  nneg = P::sum(nneg); nzero = P::sum(nzero); bad = P::sum(bad);\n"
+         "  { double r3[3] = {nneg, nzero, bad}; P::sum_n(r3); nneg = r3[0]; nzero = r3[1]; bad = r3[2]; }\n"
          "  S->o_i[1] = static_cast<int>(nneg);\n  S->o_i[2] = static_cast<int>(nzero);\n  return bad == 0.0;\n}\n\n");
   // ================================================================ solve
   E.line("// wave_ipm.h ldl_solve for THIS template (TWO: a second right-hand side through the same phases)\n");
@@ -407,7 +407,8 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
              at, ea, nact, i0, N, maxj);
     }
     E.line("  WG_END\n");
-    E.line("  en = P::vmax(m0); sn = P::vmax(m1);\n  if (TWO) { en2 = P::vmax(n0); sn2 = P::vmax(n1); }\n  P::sync();\n}\n\n");
+    E.line("  if (TWO) { double r4[4] = {m0, m1, n0, n1}; P::vmax_n(r4); en = r4[0]; sn = r4[1]; en2 = r4[2]; sn2 = r4[3]; }\n"
+           "  else { double r2[2] = {m0, m1}; P::vmax_n(r2); en = r2[0]; sn = r2[1]; }\n  P::sync();\n}\n\n");
     E.line("// wave_ipm.h jac_tmult (the product by output J^T v of the tape's index jc) out of the same tables\n");
     E.line("template <class P, class WS, class WD> DNLP_WINL DNLP_HD void jac_tmult(WS* S, const WD* v, WD* out) {\n"
            "  const WD* jv = WV(jv);\n  typename P::G G = P::gtab();\n");

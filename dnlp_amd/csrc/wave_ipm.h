@@ -813,9 +813,7 @@ struct WaveIpm {
       P::sync();
     }
     if (WK(tail_T) > 0) tail_factor(S, nneg, nzero, bad);
-    nneg = P::sum(nneg);
-    nzero = P::sum(nzero);
-    bad = P::sum(bad);
+    { double r3[3] = {nneg, nzero, bad}; P::sum_n(r3); nneg = r3[0]; nzero = r3[1]; bad = r3[2]; }
     *nneg_out = static_cast<int>(nneg);
     *nzero_out = static_cast<int>(nzero);
     W_P1(6);
@@ -1199,7 +1197,9 @@ struct WaveIpm {
     double ax = 0.0, as = 0.0;
     W_FOR(j, WK(N)) ax += bterm(xx[j], l[j], u[j], kd);
     W_FOR(i, WK(m)) as += eq[i] != 0.0 ? 0.0 : bterm(ss[i], sl[i], su[i], kd);
-    const double bx = P::sum(ax), bs = P::sum(as);
+    double r2[2] = {ax, as};
+    P::sum_n(r2);
+    const double bx = r2[0], bs = r2[1];
     return fv + muv * (bx + bs);
   }
   // Ipm::measures: theta, the barrier function and the NaN detector of g in one pass
@@ -1214,7 +1214,7 @@ struct WaveIpm {
       s2 += gg[i] - gg[i];
       if (eq[i] == 0.0) s1 += bterm(ss[i], sl[i], su[i], kd);
     }
-    s0 = P::sum(s0); s1 = P::sum(s1); s2 = P::sum(s2);
+    { double r3[3] = {s0, s1, s2}; P::sum_n(r3); s0 = r3[0]; s1 = r3[1]; s2 = r3[2]; }
     W_P1(12);
     return WMeasures{s0, fv + muv * s1, s2};
   }
@@ -1263,7 +1263,8 @@ struct WaveIpm {
       m2 = mxin(m2, cv);
       sy += fabs(yi) + fabs(ci) + fabs(di);
     }
-    m0 = P::vmax(m0); m1 = P::vmax(m1); m2 = P::vmax(m2); m3 = P::vmax(m3); sy = P::sum(sy); sz = P::sum(sz);
+    { double r4[4] = {m0, m1, m2, m3}; P::vmax_n(r4); m0 = r4[0]; m1 = r4[1]; m2 = r4[2]; m3 = r4[3]; }
+    { double r2[2] = {sy, sz}; P::sum_n(r2); sy = r2[0]; sz = r2[1]; }
     P::sync();
     WErr e;
     e.dual = std::max(m0, 0.0);
@@ -1490,7 +1491,7 @@ struct WaveIpm {
       out[k] = r;
       m0 = mxin(m0, fabs(r)); m1 = mxin(m1, fabs(v[k]));
     }
-    en = P::vmax(m0); sn = P::vmax(m1);
+    { double r2[2] = {m0, m1}; P::vmax_n(r2); en = r2[0]; sn = r2[1]; }
     P::sync();
     W_P1(9);
   }
@@ -1548,7 +1549,7 @@ struct WaveIpm {
       n0 = mxin(n0, fabs(r2)); n1 = mxin(n1, fabs(v2[k]));
     }
     Res2 R;
-    R.en = P::vmax(m0); R.sn = P::vmax(m1); R.en2 = P::vmax(n0); R.sn2 = P::vmax(n1);
+    { double r4[4] = {m0, m1, n0, n1}; P::vmax_n(r4); R.en = r4[0]; R.sn = r4[1]; R.en2 = r4[2]; R.sn2 = r4[3]; }
     P::sync();
     W_P1(9);
     return R;
@@ -1605,7 +1606,7 @@ struct WaveIpm {
     kkt_solve(S, rhs, sol, rhs2, sol2);
     double rn = -kInf, rn2 = -kInf;
     W_FOR(i, n) { rn = mxin(rn, fabs(rhs[i])); rn2 = mxin(rn2, fabs(rhs2[i])); }
-    rn = P::vmax(rn); rn2 = P::vmax(rn2);
+    { double r2[2] = {rn, rn2}; P::vmax_n(r2); rn = r2[0]; rn2 = r2[1]; }
     double best = kInf, best2 = kInf, lr = 0.0, lr2 = 0.0;
     bool fresh = false, fresh2 = false, go = true, go2 = true;      // go: still inside its refinement loop
     const int max_refine = S->opt.max_refine, min_refine = S->opt.min_refine;
@@ -1793,7 +1794,7 @@ struct WaveIpm {
         td = ddi < 0.0 ? fmin(td, qd) : td;
         a0 = mnin(a0, tp); a1 = mnin(a1, td);
       }
-      a0 = P::vmax(a0); a1 = P::vmax(a1);
+      { double r2[2] = {a0, a1}; P::vmax_n(r2); a0 = r2[0]; a1 = r2[1]; }
       W_P1(12);
     } else {
       W_FOR(j, WK(N)) {
@@ -1814,7 +1815,7 @@ struct WaveIpm {
         if (dd2[i] < 0.0) td = fmin(td, -tauv * d[i] / dd2[i]);
         a0 = mnin(a0, tp); a1 = mnin(a1, td);
       }
-      a0 = P::vmax(a0); a1 = P::vmax(a1);
+      { double r2[2] = {a0, a1}; P::vmax_n(r2); a0 = r2[0]; a1 = r2[1]; }
       W_P1(12);
     }
     return D2{std::min(1.0, -a0), std::min(1.0, -a1)};
@@ -2246,7 +2247,7 @@ struct WaveIpm {
         a0 = mnin(a0, tp); a1 = mnin(a1, td);
       }
     }
-    a0 = P::vmax(a0); a1 = P::vmax(a1);
+    { double r2[2] = {a0, a1}; P::vmax_n(r2); a0 = r2[0]; a1 = r2[1]; }
     const double apv = std::min(1.0, -a0), adv = std::min(1.0, -a1);
     if (P::hoist) {
       W_FOR(j, N) {
@@ -2328,8 +2329,10 @@ struct WaveIpm {
       double s0 = 0.0, s1 = 0.0;
       W_FOR(k, N) s0 += rxx[k] * rxx[k];
       W_FOR(i, m) { s0 += rss[i] * rss[i]; s1 += rpp[i] * rpp[i]; }
-      nd2 = P::sum(s0);
-      np2 = m ? P::sum(s1) : 0.0;
+      double r2[2] = {s0, s1};
+      P::sum_n(r2);
+      nd2 = r2[0];
+      np2 = m ? r2[1] : 0.0;
     }
     W_P1(17);
     // The two systems of the oracle — affine scaling (mu = 0, residuals rx / rs / rp) and centering (unit mu, the

@@ -57,6 +57,44 @@ __device__ inline double wave_all_max(double v) {
   v = fmax(v, dpp_shift_f64<0x143, 0xc>(v, v));
   return wave_lane63(v);
 }
+// N reductions side by side, step by step: one reduction is a chain of six dependent DPP steps (each two v_mov_b32_dpp, the
+// operation and the wait states between them: ~180 cycles of which a wavefront alone on its SIMD spends most waiting);
+// N independent chains interleaved fill each other's wait states.  Every value goes through the same tree as in
+// wave_all_sum / wave_all_max: the same bits.
+template <int N>
+__device__ inline void wave_all_sum_n(double (&v)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_shift_f64<0x111, 0xf>(v[k], 0.0);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_shift_f64<0x112, 0xf>(v[k], 0.0);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_shift_f64<0x114, 0xf>(v[k], 0.0);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_shift_f64<0x118, 0xf>(v[k], 0.0);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_shift_f64<0x142, 0xa>(v[k], 0.0);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] += dpp_shift_f64<0x143, 0xc>(v[k], 0.0);
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = wave_lane63(v[k]);
+}
+template <int N>
+__device__ inline void wave_all_max_n(double (&v)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = fmax(v[k], dpp_shift_f64<0x111, 0xf>(v[k], v[k]));
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = fmax(v[k], dpp_shift_f64<0x112, 0xf>(v[k], v[k]));
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = fmax(v[k], dpp_shift_f64<0x114, 0xf>(v[k], v[k]));
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = fmax(v[k], dpp_shift_f64<0x118, 0xf>(v[k], v[k]));
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = fmax(v[k], dpp_shift_f64<0x142, 0xa>(v[k], v[k]));
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = fmax(v[k], dpp_shift_f64<0x143, 0xc>(v[k], v[k]));
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = wave_lane63(v[k]);
+}
 template <int CTRL, int ROW_MASK>
 __device__ inline int dpp_min_i32(int v) {
   return min(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false));

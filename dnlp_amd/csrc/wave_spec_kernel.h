@@ -44,6 +44,9 @@ struct WaveLanesSpec {
   __device__ static void sync() { wave_sync(); }
   __device__ static double sum(double v) { return wave_all_sum(v); }
   __device__ static double vmax(double v) { return wave_all_max(v); }
+  // several reductions side by side (wave_ops.h: the chains fill each other's wait states; the same bits as one by one)
+  template <int N> __device__ static void sum_n(double (&v)[N]) { wave_all_sum_n<N>(v); }
+  template <int N> __device__ static void vmax_n(double (&v)[N]) { wave_all_max_n<N>(v); }
   __device__ static double now() { return now_sec(); }
   __device__ static int tab_load(I*, int) { return 0; }
   __device__ static int tab_at(I* tab, int, int idx, int) { return static_cast<int>(tab[idx]); }

@@ -29,6 +29,7 @@ __shared__ __attribute__((aligned(16))) double g_wg_lds[wspec::kLdsDoubles > 0 ?
 __shared__ WGlbI* g_wg_plan;                               // the plan block (32-bit, global memory)
 __shared__ DNLP_WGLB const unsigned* g_wg_gen;             // work tables of the generated phases
 __shared__ double g_wg_red[2][wspec::kNW];                 // the wavefronts' partials of a reduction, two sets used in turn (one barrier per reduction)
+__shared__ double g_wg_redn[2][4][wspec::kNW];             // ... of up to four reductions side by side (sum_n / vmax_n)
 __shared__ unsigned g_wg_turn[wspec::kNW];                 // ... which set a wavefront's next reduction writes (every wavefront counts alike)
 __shared__ double g_wg_clock;
 __shared__ int g_wg_inst;
@@ -70,6 +71,39 @@ struct WaveLanesWG {
 #pragma unroll
     for (int k = 1; k < wspec::kNW; ++k) r = fmax(r, g_wg_red[s][k]);
     return r;
+  }
+  // several reductions with ONE barrier (the DPP chains side by side: wave_ops.h)
+  template <int N> __device__ static void sum_n(double (&v)[N]) {
+    wave_all_sum_n<N>(v);
+    const unsigned s = turn();
+    if ((threadIdx.x & 63u) == 0u) {
+#pragma unroll
+      for (int q = 0; q < N; ++q) g_wg_redn[s][q][threadIdx.x >> 6] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      double r = g_wg_redn[s][q][0];
+#pragma unroll
+      for (int k = 1; k < wspec::kNW; ++k) r += g_wg_redn[s][q][k];
+      v[q] = r;
+    }
+  }
+  template <int N> __device__ static void vmax_n(double (&v)[N]) {
+    wave_all_max_n<N>(v);
+    const unsigned s = turn();
+    if ((threadIdx.x & 63u) == 0u) {
+#pragma unroll
+      for (int q = 0; q < N; ++q) g_wg_redn[s][q][threadIdx.x >> 6] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      double r = g_wg_redn[s][q][0];
+#pragma unroll
+      for (int k = 1; k < wspec::kNW; ++k) r = fmax(r, g_wg_redn[s][q][k]);
+      v[q] = r;
+    }
   }
   // one clock for the workgroup (a time limit must stop every wavefront in the same iteration)
   __device__ static double now() {

@@ -88,6 +88,8 @@ struct HostLane {
   static void sync() {}
   static double sum(double v) { return v; }
   static double vmax(double v) { return v; }
+  template <int N> static void sum_n(double (&)[N]) {}
+  template <int N> static void vmax_n(double (&)[N]) {}
   static double now() { return dnlp::now_sec(); }
   static int tab_load(const dnlp::i32*, int) { return 0; }
   static int tab_at(const dnlp::i32* tab, int, int idx, int) { return tab[idx]; }
@@ -271,6 +273,8 @@ struct HostSpecLane {
   static void sync() {}
   static double sum(double v) { return v; }
   static double vmax(double v) { return v; }
+  template <int N> static void sum_n(double (&)[N]) {}
+  template <int N> static void vmax_n(double (&)[N]) {}
   static double now() { return dnlp::now_sec(); }
   static int tab_load(const dnlp::i32*, int) { return 0; }
   static int tab_at(const dnlp::i32* tab, int, int idx, int) { return tab[idx]; }
