@@ -448,6 +448,8 @@ struct BatchRunner {
   RtcKernel wave_wg;
   int wave_wg_nw = 0, wave_wg_per_cu = 1, wave_wg_gen_words = 0;
   unsigned* d_wave_wg_gen = nullptr;
+  std::vector<i32> wave_wg_blk;                   // its plan block (no dense tail in registers)
+  i32* d_wave_wg_blk = nullptr;
   bool wave_wg_prof = false;
   bool wave_wg_prepare(int batch) {
     const char* e = std::getenv("DNLP_WAVE_SPEC");
@@ -461,12 +463,24 @@ struct BatchRunner {
     int nwg = std::getenv("DNLP_WAVE_WG_WAVES") ? std::atoi(std::getenv("DNLP_WAVE_WG_WAVES")) : 8;
     if (nwg < 1 || nwg > 8) nwg = 8;
     const double t0 = now_sec();
-    const WaveGen gen = wave_generate(wave_blk, 64 * nwg);
+    // the kernel's own plan block: WITHOUT the dense tail in registers (one-wavefront code; the chain's few levels run as
+    // narrow generated phases instead — power flow: tail_forward alone was 59 k of 1 590 k cycles per iteration)
+    {
+      WaveLayoutIn l;
+      l.c0 = lay.c0; l.c = lay.c; l.b = lay.b; l.Jc = lay.Jc; l.G = lay.G; l.Mg = lay.Mg; l.Mw = lay.Mw; l.MJ = lay.MJ; l.MH = lay.MH;
+      l.fp = lay.fp; l.fp2 = lay.fp2; l.x0 = lay.x0; l.lb = lay.lb; l.ub = lay.ub; l.cl = lay.cl; l.cu = lay.cu; l.total = lay.total;
+      const bool tail = std::getenv("DNLP_WAVE_WG_TAIL") && std::atoi(std::getenv("DNLP_WAVE_WG_TAIL")) == 1;
+      wave_wg_blk = build_wave_plan(ex, *tape, *host_plan, l, tail);
+      if (reinterpret_cast<const WaveHdr*>(wave_wg_blk.data())->state_doubles != h.state_doubles) return false;
+      DNLP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_wave_wg_blk), wave_wg_blk.size() * sizeof(i32)));
+      DNLP_HIP_CHECK(hipMemcpy(d_wave_wg_blk, wave_wg_blk.data(), wave_wg_blk.size() * sizeof(i32), hipMemcpyHostToDevice));
+    }
+    const WaveGen gen = wave_generate(wave_wg_blk, 64 * nwg);
     wave_wg_prof = std::getenv("DNLP_WAVE_SPEC_PROF") != nullptr;
     // (DNLP_WAVE_WG_BOUND: threads the register budget is sized for — 512 with four wavefronts: two workgroups per compute unit)
     const int bound = std::getenv("DNLP_WAVE_WG_BOUND") ? std::atoi(std::getenv("DNLP_WAVE_WG_BOUND")) : 512;
     const bool lds_vec = !(std::getenv("DNLP_WAVE_WG_LDS") && std::atoi(std::getenv("DNLP_WAVE_WG_LDS")) == 0);
-    const std::string src = wave_wg_source(wave_blk, nwg, gen, wave_wg_prof, bound, lds_vec);
+    const std::string src = wave_wg_source(wave_wg_blk, nwg, gen, wave_wg_prof, bound, lds_vec);
     if (!wave_wg.load(src, "dnlp_wave_wg_kernel")) {
       std::fprintf(stderr, "[dnlp] workgroup-per-instance batch kernel not available (the library's own kernel is used): %s\n", wave_wg.log.substr(0, 2000).c_str());
       return false;
@@ -597,6 +611,7 @@ struct BatchRunner {
     if (d_wave_blk16) hipFree(d_wave_blk16);
     if (d_wave_gen) hipFree(d_wave_gen);
     if (d_wave_wg_gen) hipFree(d_wave_wg_gen);
+    if (d_wave_wg_blk) hipFree(d_wave_wg_blk);
     if (d_rows) hipFree(d_rows);
     if (own_stream && stream) hipStreamDestroy(stream);
   }
@@ -1209,7 +1224,7 @@ struct BatchRunner {
     }
     // a template whose state exceeds LDS: a workgroup per instance through the generated phases when the kernel is there
     const bool wg = !sl && !std::getenv("DNLP_WAVE_FORM") && wave_wg_prepare(batch);
-    if (wg) { nw = wave_wg_nw; w.gen = d_wave_wg_gen; w.gen_words = wave_wg_gen_words; }
+    if (wg) { nw = wave_wg_nw; w.gen = d_wave_wg_gen; w.gen_words = wave_wg_gen_words; w.blk = d_wave_wg_blk; w.blk_ints = static_cast<int>(wave_wg_blk.size()); }
     int per_cu = 1;
     const unsigned lds = static_cast<unsigned>((pl ? plan_b : 0) + (sl ? static_cast<size_t>(nw) * state_b : 0));
     const int form = 100 * nw + 10 * sl + pl;

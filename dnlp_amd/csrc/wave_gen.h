@@ -340,24 +340,26 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
            "  typename P::G G = P::gtab();\n");
     // long outputs first, by all lanes
     bool any_heavy = false;
+    int n_heavy = 0;
     std::string jt_heavy, jt_light;          // the same tables drive J^T y alone (jac_tmult below)
     auto heavy = [&](const i32* ptr, const i32* ent, const i32* src, int nout, const char* a, const char* vv, const char* v2, const char* pre, const char* pre2, bool is_jc) {
       for (int g = 0; g < nout; ++g) {
         const int c = ptr[g + 1] - ptr[g];
         if (c <= kCooHeavy) continue;
         any_heavy = true;
-        E.line("  { double acc = 0.0, acc2 = 0.0;\n");
-        if (is_jc) jt_heavy += "  { double acc = 0.0, acc2 = 0.0;\n";
+        const int wv = n_heavy++ % (LW / 64);          // (dealt out to the wavefronts of the workgroup)
+        E.line("  WG_WAVE(%d) { double acc = 0.0, acc2 = 0.0;\n", wv);
         char b[256];
+        if (is_jc) { std::snprintf(b, sizeof b, "  WG_WAVE(%d) { double acc = 0.0, acc2 = 0.0;\n", wv); jt_heavy += b; }
         for (int e0 = 0; e0 < c; e0 += 64) {
           const int cnt = std::min(64, c - e0);
           const int ea = E.reserve(static_cast<size_t>(cnt));
           for (int j = 0; j < cnt; ++j) out.G[static_cast<size_t>(ea + j)] = lo16(ent[ptr[g] + e0 + j]) | (lo16(src[ptr[g] + e0 + j]) << 16);
-          E.line("    wgrt::wdot<P, TWO, %d, %d>(G, %s, %s, %s, acc, acc2);\n", ea, cnt, a, vv, v2);
-          if (is_jc) { std::snprintf(b, sizeof b, "    wgrt::wdot<P, false, %d, %d>(G, jv, v, v, acc, acc2);\n", ea, cnt); jt_heavy += b; }
+          E.line("    wgrt::wdot<P, TWO, %d, %d, %d>(G, %s, %s, %s, acc, acc2);\n", wv, ea, cnt, a, vv, v2);
+          if (is_jc) { std::snprintf(b, sizeof b, "    wgrt::wdot<P, false, %d, %d, %d>(G, jv, v, v, acc, acc2);\n", wv, ea, cnt); jt_heavy += b; }
         }
-        E.line("    wgrt::wdot_fin<P, TWO, %d>(%s, %s, acc, acc2); }\n", g, pre, pre2);
-        if (is_jc) { std::snprintf(b, sizeof b, "    wgrt::wdot_fin<P, false, %d>(out, out, acc, acc2); }\n", g); jt_heavy += b; }
+        E.line("    wgrt::wdot_fin<P, TWO, %d, %d>(%s, %s, acc, acc2); }\n", wv, g, pre, pre2);
+        if (is_jc) { std::snprintf(b, sizeof b, "    wgrt::wdot_fin<P, false, %d, %d>(out, out, acc, acc2); }\n", wv, g); jt_heavy += b; }
       }
     };
     heavy(hsp, hse, hss, N, "Hs", "v", "v2", "preH", "preH2", false);

@@ -31,6 +31,7 @@
 #define WG_WBEGIN if (P::lane() < 64) {
 #define WG_WEND wave_sync(); }
 #define WG_NCLOSE P::sync();
+#define WG_WAVE(w) if ((P::lane() >> 6) == (w))
 #define WG_INLINE __attribute__((always_inline)) __device__ inline
 #else
 #define WG_BEGIN for (int lane = 0; lane < WG_LANES; ++lane) {      // (WG_LANES: the generated text says how many lanes share a phase)
@@ -40,6 +41,7 @@
 #define WG_WBEGIN {
 #define WG_WEND }
 #define WG_NCLOSE
+#define WG_WAVE(w) if (true)
 #define WG_INLINE inline
 #endif
 
@@ -372,10 +374,12 @@ WG_INLINE double mxin(double acc, double v) { return fmax(acc, v != v ? __builti
 
 // ---- ONE long output by all lanes: sum over its entries of a[ent] v[src] (+ the same with v2), entries across the lanes,
 // added in entry order on the host (the interpreted text's coo_heavy on the host lane), by the fixed reduction tree on the device.  entry (1 word): ent | src << 16.
-template <class P, bool TWO, int E0, int CNT, class GP, class CP>
+// W: the wavefront of the workgroup that runs this output (the generator deals the long outputs out to the wavefronts: power
+// flow has 46 of them per residual, and one wavefront took them one after the other; WG_WAVE(W) keeps the others out)
+template <class P, bool TWO, int W, int E0, int CNT, class GP, class CP>
 WG_INLINE void wdot(GP G, CP a, CP v, CP v2, double& acc, double& acc2) {
 #if DNLP_DEVICE_PASS
-  const int lane = P::lane();
+  const int lane = P::lane() - 64 * W;
   double p = 0.0, p2 = 0.0;
   if (lane < CNT) {
 #else
@@ -396,10 +400,10 @@ WG_INLINE void wdot(GP G, CP a, CP v, CP v2, double& acc, double& acc2) {
   }
 #endif
 }
-template <class P, bool TWO, int OUT, class VP>
+template <class P, bool TWO, int W, int OUT, class VP>
 WG_INLINE void wdot_fin(VP pre, VP pre2, double acc, double acc2) {
 #if DNLP_DEVICE_PASS
-  if (P::lane() == 0) {
+  if (P::lane() == 64 * W) {
 #else
   {
 #endif

@@ -69,7 +69,9 @@ inline const char* wave_plan_refusal(const Tape<E>& t, const SparsePlanHost* sp)
 
 // The block.  E is the execution space the tape was loaded into (its CSR index arrays live there: copied back once).
 template <class E>
-inline std::vector<i32> build_wave_plan(E* ex, const Tape<E>& t, const SparsePlanHost& sp, const WaveLayoutIn& lay) {
+// (allow_tail = false: no dense tail in registers — the workgroup-per-instance kernel runs a short chain of one-block levels
+//  as narrow generated phases instead: the register code was written for one wavefront)
+inline std::vector<i32> build_wave_plan(E* ex, const Tape<E>& t, const SparsePlanHost& sp, const WaveLayoutIn& lay, bool allow_tail = true) {
   WaveHdr h;
   std::memset(&h, 0, sizeof h);
   std::vector<i32> out(sizeof(WaveHdr) / 4, 0);
@@ -144,7 +146,7 @@ inline std::vector<i32> build_wave_plan(E* ex, const Tape<E>& t, const SparsePla
     const i32 kTailMax = 32;
     if (T > kTailMax) { Ls = nlev - kTailMax; T = kTailMax; }
     std::vector<i32> tnode, td, tl, tfq, tfp;
-    bool ok = T >= 3 && !std::getenv("DNLP_WAVE_NO_TAIL");
+    bool ok = allow_tail && T >= 3 && !std::getenv("DNLP_WAVE_NO_TAIL");
     if (ok) {
       std::vector<i32> pos(static_cast<size_t>(sp.n), -1);
       for (i32 t = 0; t < T; ++t) {

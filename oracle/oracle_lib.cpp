@@ -221,7 +221,7 @@ extern "C" long long orc_wave_wg_source(orc_problem* vp, int nwg, char* buf, lon
     if (!p->use_sparse) { tls_error() = "no sparse plan for this tape"; return -1; }
     const char* why = wave_plan_refusal(t, &p->sparse_plan);
     if (why[0]) { tls_error() = why; return -2; }
-    const std::vector<i32> blk = build_wave_plan(&p->ex, t, p->sparse_plan, wave_layout_of(t));
+    const std::vector<i32> blk = build_wave_plan(&p->ex, t, p->sparse_plan, wave_layout_of(t), false);      // (no register tail: batch.h wave_wg_prepare)
     const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(blk.data());
     if (wave_gen_refusal(h)[0]) { tls_error() = wave_gen_refusal(h); return -4; }
     if (nwg < 1 || nwg > 8) { tls_error() = "1 .. 8 wavefronts per workgroup"; return -5; }

@@ -49,6 +49,21 @@ def test_generated_phases_for_a_workgroup_of_four_wavefronts(name):
     assert "#define WG_LANES 256" in hb.source
 
 
+def test_generated_phases_without_the_register_tail(monkeypatch):
+    """The workgroup kernel's plan has no dense tail in registers (one-wavefront code): the chain's last levels run as narrow
+    generated phases.  With the tail switched off in both texts the bits still agree (and tests/test_wave_ipm_cpu.py shows
+    that the tail changes no bit of the interpreted text)."""
+    monkeypatch.setenv("DNLP_WAVE_NO_TAIL", "1")
+    tmpl, B = TEMPLATES["path_planning"]
+    prob, params, sample, _ = tmpl()
+    hb = GenHostBatch(ParametricBatch(prob, params), lanes=512)
+    thetas = np.stack([sample(i) for i in range(B)])
+    g, w = hb.solve_gen(thetas), hb.solve(thetas, 0)
+    for k in KEYS:
+        assert np.array_equal(g[k], w[k]), k
+    assert "constexpr int k_tail_T = 0;" in hb.source and "#define WG_LANES 512" in hb.source
+
+
 def test_generated_phases_follow_the_options_too():
     prob, params, sample, _ = bp.template_localization()
     pb = ParametricBatch(prob, params)
