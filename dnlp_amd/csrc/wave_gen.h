@@ -116,14 +116,15 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
          nlev, h.tail_T, nblk, h.sp_nvals, h.sp_ntrip);
   E.line("template <class P, class WS> DNLP_HD bool ldl_factor(WS* S) {\n"
          "  typedef typename P::D WD;\n  typedef WaveIpm<P> W;\n"
-         "  WD* vals = WV(svals);\n  WD* w = WV(swork);\n  WD* dinv = WV(swork) + wspec::k_nvals;\n  WD* scr = WV(scr);\n"
+         "  WD* vals = WV(svals);\n  WD* w = WV(swork);\n  WD* scr = WV(scr);\n"
          "  typename P::G G = P::gtab();\n"
          "  double nneg = 0.0, nzero = 0.0, bad = 0.0;\n");
   for (int lev = 0; lev < nlev; ++lev) {
     const int b0 = lev_off[lev], b1 = lev_off[lev + 1], r0 = lev_r[lev], r1 = lev_r[lev + 1];
     E.line("  // level %d: %d blocks, %d struct rows\n", lev, b1 - b0, r1 - r0);
-    // pivots
-    const bool nb_piv = begin_phase(b1 - b0);
+    // pivots (inertia, tiny 1x1 pivots fixed in place) and — in the SAME phase — the struct rows scaled by the inverse pivot that
+    // every row's lane recomputes from its block's D entries (wave_gen_rt.h scl2): no inverse is stored, the rows do not wait
+    const bool nb_ps = begin_phase(std::max(b1 - b0, r1 - r0));
     for (int s0 = b0; s0 < b1; s0 += LW) {
       const int nact = std::min(LW, b1 - s0);
       const int at = E.reserve(static_cast<size_t>(nact));
@@ -131,15 +132,11 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
       for (int j = 0; j < nact; ++j) {
         const int k = s0 + j, kind = bnode[2 * k + 1] < 0 ? 1 : 2;
         kinds |= kind;
-        out.G[static_cast<size_t>(at + j)] = lo16(doff[k]) | (static_cast<uint32_t>(k) << 16) | (static_cast<uint32_t>(kind) << 30);
+        out.G[static_cast<size_t>(at + j)] = lo16(doff[k]) | (static_cast<uint32_t>(kind) << 30);
       }
-      E.line("    wgrt::piv<%d, %d, %d>(lane, G, vals, dinv, nneg, nzero, bad);\n", at, nact, kinds);
+      E.line("    wgrt::piv2<%d, %d, %d>(lane, G, vals, nneg, nzero, bad);\n", at, nact, kinds);
       ++out.phases_factor;
     }
-    end_phase(nb_piv);
-    if (r1 == r0) continue;
-    // row scaling
-    const bool nb_scl = begin_phase(r1 - r0);
     for (int s0 = r0; s0 < r1; s0 += LW) {
       const int nact = std::min(LW, r1 - s0);
       const int at = E.reserve(static_cast<size_t>(nact));
@@ -148,13 +145,14 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
         const int r = s0 + j, k = sblk[r], i = r - soff[k];
         const bool one = bnode[2 * k + 1] < 0;
         kinds |= one ? 1 : 2;
-        const int a = one ? loff[k] + i : loff[k] + 2 * i;
-        out.G[static_cast<size_t>(at + j)] = lo16(a) | (static_cast<uint32_t>(k) << 16) | (static_cast<uint32_t>(one ? 1 : 2) << 30);
+        const int aa = one ? loff[k] + i : loff[k] + 2 * i;
+        if (aa > 0x7fff || doff[k] > 0x7fff) throw std::runtime_error("wave gen: a value index does not fit 15 bits");
+        out.G[static_cast<size_t>(at + j)] = static_cast<uint32_t>(aa) | (static_cast<uint32_t>(doff[k]) << 15) | (static_cast<uint32_t>(one ? 1 : 2) << 30);
       }
-      E.line("    wgrt::scl<%d, %d, %d>(lane, G, vals, w, dinv);\n", at, nact, kinds);
-      ++out.phases_factor;
+      E.line("    wgrt::scl2<%d, %d, %d>(lane, G, vals, w);\n", at, nact, kinds);
     }
-    end_phase(nb_scl);
+    end_phase(nb_ps);
+    if (r1 == r0) continue;
     const int g0 = lev_g[lev], g1 = lev_g[lev + 1], t0 = lev_t[lev], ntr = lev_t[lev + 1] - t0;
     if (ntr == 0) continue;
     // products of the update triples, side by side
@@ -211,6 +209,27 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
     if (wide) {
       for (int hq = h0; hq < h1; ++hq) {
         const int c = foff[hq + 1] - foff[hq];
+        // two targets of at most 32 rows each share ONE phase, a half of the wavefront each (path planning's 49 chain levels
+        // have two targets of 19 rows: a phase there is a table word from global memory, then little — one phase less per
+        // level and solve)
+        if (hq + 1 < h1 && c <= 32 && foff[hq + 2] - foff[hq + 1] <= 32) {
+          const int cb = foff[hq + 2] - foff[hq + 1];
+          const int ea = E.reserve(128);
+          int kinds = 0;
+          for (int half = 0; half < 2; ++half)
+            for (int j = 0; j < (half ? cb : c); ++j) {
+              const int q = foff[hq + half] + j, a = fa[q];
+              const bool two = a < 0;
+              kinds |= two ? 2 : 1;
+              out.G[static_cast<size_t>(ea + 32 * half + j)] = lo16(two ? ~a : a) | (lo16(fu0[q]) << 16);
+              out.G[static_cast<size_t>(ea + 64 + 32 * half + j)] = lo16(two ? fu1[q] : fu0[q]) | (static_cast<uint32_t>(two ? 2 : 1) << 16);
+            }
+          E.line("  WG_WBEGIN wgrt::fwdw2<P, TWO, %d, %d, %d, %d, %d, %d>(G, vals, x, y); WG_WEND\n", ea, c, cb, kinds, fnode[hq], fnode[hq + 1]);
+          region_open = true;
+          ++out.phases_solve;
+          ++hq;
+          continue;
+        }
         E.line("  WG_WBEGIN { double acc = 0.0, acc2 = 0.0;\n");
         if (touch) E.line("    const unsigned pf_ = wgrt::touch<%d>(P::lane(), G, @@@);\n", kTouchLines);
         for (int e0 = 0; e0 < c; e0 += 64) {

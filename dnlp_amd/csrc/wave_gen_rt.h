@@ -156,6 +156,57 @@ WG_INLINE void fwdw_fin(VP x, VP y, double acc, double acc2) {
   }
 }
 
+// ---- ... TWO targets of at most 32 rows in one phase: target A on lanes 0 .. 31, target B on lanes 32 .. 63 (table: 64 + 64 words,
+// zero where a half has fewer rows).  Each target's products are added in row order on the host, by the wavefront's reduction
+// tree on the device (the other half contributes zeros).
+template <class P, bool TWO, int E0, int CNT_A, int CNT_B, int KINDS, int NODE_A, int NODE_B, class GP, class VP>
+WG_INLINE void fwdw2(GP G, const VP vals, VP x, VP y) {
+  double accA = 0.0, accB = 0.0, acc2A = 0.0, acc2B = 0.0;
+#if DNLP_DEVICE_PASS
+  const int lane = P::lane();
+  double p = 0.0, p2 = 0.0;
+  if (lane < CNT_A || (lane >= 32 && lane < 32 + CNT_B)) {
+#else
+  for (int lane = 0; lane < 64; ++lane) {
+    if (!(lane < CNT_A || (lane >= 32 && lane < 32 + CNT_B))) continue;
+    double p = 0.0, p2 = 0.0;
+#endif
+    const u32 w0 = G[E0 + lane], w1 = G[E0 + 64 + lane];
+    const int a = static_cast<int>(w0 & 0xffffu), u0 = static_cast<int>(w0 >> 16), u1 = static_cast<int>(w1 & 0xffffu);
+    const bool two = KINDS == 2 || (KINDS == 3 && (w1 >> 16) == 2u);
+    if (two) {
+      const double l0 = vals[a], l1 = vals[a + 1];
+      p = l0 * x[u0] + l1 * x[u1];
+      if (TWO) p2 = l0 * y[u0] + l1 * y[u1];
+    } else {
+      const double l = vals[a];
+      p = l * x[u0];
+      if (TWO) p2 = l * y[u0];
+    }
+#if DNLP_DEVICE_PASS
+  }
+  {
+    double r[2] = {lane < 32 ? p : 0.0, lane < 32 ? 0.0 : p};
+    wave_all_sum_n<2>(r);
+    accA += r[0]; accB += r[1];
+    if (TWO) {
+      double r2[2] = {lane < 32 ? p2 : 0.0, lane < 32 ? 0.0 : p2};
+      wave_all_sum_n<2>(r2);
+      acc2A += r2[0]; acc2B += r2[1];
+    }
+  }
+  if (lane == 0) {
+#else
+    if (lane < 32) { accA += p; if (TWO) acc2A += p2; }
+    else { accB += p; if (TWO) acc2B += p2; }
+  }
+  {
+#endif
+    x[NODE_A] -= accA; x[NODE_B] -= accB;
+    if (TWO) { y[NODE_A] -= acc2A; y[NODE_B] -= acc2B; }
+  }
+}
+
 // ---- backward substitution, WIDE form: ONE block whose many struct rows lie across the lanes -------------------------------
 // entry i (1 word): source node u.  ONE: a 1x1 block (values LOF + i), else a 2x2 block (LOF + 2 i, LOF + 2 i + 1).
 template <class P, bool TWO, bool ONE, int E0, int CNT, int LOF, int I0, class GP, class VP>
@@ -329,6 +380,57 @@ WG_INLINE void scl(int lane, GP G, VP vals, VP w, const VP dinv) {
       w[a] = l1; w[a + 1] = l2;
       vals[a] = d0 * l1 + d1 * l2;
       vals[a + 1] = d1 * l1 + d2 * l2;
+    }
+  }
+}
+
+// ---- ... the same, with the inverse pivot RECOMPUTED from the block's D entries by every row's lane (the expressions of
+// sp_pivot, the tiny-pivot substitutions included): the rows no longer wait for the pivots' phase — pivots (which still count
+// the inertia and fix a tiny 1x1 pivot in place) and row scaling are ONE phase, a dependent round trip less per level.
+// descriptor (1 word): a | doff << 15 | kind << 30
+template <int D0, int NACT, int KINDS, class GP, class VP>
+WG_INLINE void scl2(int lane, GP G, VP vals, VP w) {
+  if (lane < NACT) {
+    const u32 w0 = G[D0 + lane];
+    const int a = static_cast<int>(w0 & 0x7fffu), dof = static_cast<int>((w0 >> 15) & 0x7fffu);
+    const bool one = KINDS == 1 || (KINDS == 3 && (w0 >> 30) == 1u);
+    if (one) {
+      double d = vals[dof];
+      if (fabs(d) < 1e-300) d = 1e-20;
+      const double l1 = vals[a];
+      w[a] = l1;
+      vals[a] = l1 * (1.0 / d);
+    } else {
+      const double pa = vals[dof], pc = vals[dof + 1], pe = vals[dof + 2];
+      double det = pa * pe - pc * pc;
+      if (fabs(det) < 1e-300) det = -1e-20;
+      const double d0 = pe / det, d1 = -pc / det, d2 = pa / det;
+      const double l1 = vals[a], l2 = vals[a + 1];
+      w[a] = l1; w[a + 1] = l2;
+      vals[a] = d0 * l1 + d1 * l2;
+      vals[a + 1] = d1 * l1 + d2 * l2;
+    }
+  }
+}
+// the pivots' part of that phase: inertia counts and the in-place fix of a tiny 1x1 pivot (descriptor as piv; no inverse stored)
+template <int D0, int NACT, int KINDS, class GP, class VP>
+WG_INLINE void piv2(int lane, GP G, VP vals, double& nneg, double& nzero, double& bad) {
+  if (lane < NACT) {
+    const u32 w0 = G[D0 + lane];
+    const int dof = static_cast<int>(w0 & 0xffffu);
+    const bool one = KINDS == 1 || (KINDS == 3 && (w0 >> 30) == 1u);
+    if (one) {
+      double d = vals[dof];
+      if (!(d == d)) bad += 1.0;
+      if (fabs(d) < 1e-300) { nzero += 1.0; d = 1e-20; vals[dof] = d; }
+      if (d < 0.0) nneg += 1.0;
+    } else {
+      const double a = vals[dof], c = vals[dof + 1], e = vals[dof + 2];
+      double det = a * e - c * c;
+      if (!(det == det)) bad += 1.0;
+      if (fabs(det) < 1e-300) { nzero += 1.0; det = -1e-20; }
+      if (det < 0.0) nneg += 1.0;
+      else if (a < 0.0 || (a == 0.0 && e < 0.0)) nneg += 2.0;
     }
   }
 }

@@ -81,9 +81,10 @@ def test_generated_text_is_calls_with_literal_arguments():
     src = hb.source
     assert "template <class P, class WS> DNLP_HD bool ldl_factor(WS* S)" in src
     assert "template <class P, bool TWO, class WS, class WD> DNLP_HD void ldl_solve(WS* S, WD* x, WD* y)" in src
-    # five levels: pivots + scaling + products + sums for the first four, pivots only for the last; forward levels 1..4,
+    # five levels: pivots + scaling (one phase) + products + sums for the first four, pivots only for the last; forward levels 1..4,
     # D^-1 (all 52 blocks in one phase), backward levels 3..0; level 0 has 80 struct rows: two 64-lane slots of scaling
-    assert src.count("wgrt::piv<") == 5 and src.count("wgrt::scl<") == 5 and src.count("wgrt::fwd<TWO") == 2
+    # (pivots and row scaling share a phase: the rows' lanes recompute the inverse pivot)
+    assert src.count("wgrt::piv2<") == 5 and src.count("wgrt::scl2<") == 5 and src.count("wgrt::fwd<TWO") == 2
     # (forward levels 3 and 4: ONE target each — a position variable — with 20 / 21 rows: rows across the lanes, added in order)
     assert src.count("wgrt::fwdw<P, TWO") == 2 and src.count("wgrt::fwdw_fin<P, TWO") == 2
     assert src.count("wgrt::dsol<TWO") == 1 and src.count("wgrt::bwd<TWO") == 4
