@@ -207,6 +207,31 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
     bool wide = h1 - h0 <= kWideMaxTasks;
     for (int hq = h0; hq < h1 && wide; ++hq) wide = foff[hq + 1] - foff[hq] >= kWideMinEntries;
     if (wide) {
+      // several targets too long to share a wavefront (power flow: two of ~40 rows per chain level), work tables in global
+      // memory: a wavefront each, side by side, between two workgroup barriers (a phase there is a table word from L2, then
+      // little: two in a row cost more than two barriers)
+      bool deal = LW > 64 && h1 - h0 >= 2 && h1 - h0 <= LW / 64;
+      for (int hq = h0; hq < h1 && deal; ++hq) deal = foff[hq + 1] - foff[hq] > 32 && foff[hq + 1] - foff[hq] <= 64;
+      if (deal) {
+        close_region();
+        for (int hq = h0; hq < h1; ++hq) {
+          const int c = foff[hq + 1] - foff[hq], wv = hq - h0;
+          const int ea = E.reserve(2 * static_cast<size_t>(c));
+          int kinds = 0;
+          for (int j = 0; j < c; ++j) {
+            const int q = foff[hq] + j, a = fa[q];
+            const bool two = a < 0;
+            kinds |= two ? 2 : 1;
+            out.G[static_cast<size_t>(ea + j)] = lo16(two ? ~a : a) | (lo16(fu0[q]) << 16);
+            out.G[static_cast<size_t>(ea + c + j)] = lo16(two ? fu1[q] : fu0[q]) | (static_cast<uint32_t>(two ? 2 : 1) << 16);
+          }
+          E.line("  WG_WAVE(%d) { double acc = 0.0, acc2 = 0.0; wgrt::fwdw<P, TWO, %d, %d, %d, %d>(G, vals, x, y, acc, acc2); wgrt::fwdw_fin<P, TWO, %d, %d>(x, y, acc, acc2); }\n",
+                 wv, ea, c, kinds, wv, fnode[hq], wv);
+          ++out.phases_solve;
+        }
+        E.line("  P::sync();\n");
+        continue;
+      }
       for (int hq = h0; hq < h1; ++hq) {
         const int c = foff[hq + 1] - foff[hq];
         // two targets of at most 32 rows each share ONE phase, a half of the wavefront each (path planning's 49 chain levels

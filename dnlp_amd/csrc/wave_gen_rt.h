@@ -109,10 +109,11 @@ WG_INLINE void fwd(int lane, GP G, const VP vals, VP x, VP y) {
 //  — on the host in row order (the lanes are played in that order: the serial sum of the interpreted text), on the device by
 //  the wavefront's fixed reduction tree.  entry e (2 words): as in fwd.  The caller chains the slots of a
 // target with more than 64 rows through acc / acc2 and subtracts once (fwdw_fin).
-template <class P, bool TWO, int E0, int CNT, int KINDS, class GP, class VP>
+// (W: the wavefront of the workgroup that runs this target — 0 unless the generator deals a level's targets out: WG_WAVE(W))
+template <class P, bool TWO, int E0, int CNT, int KINDS, int W = 0, class GP, class VP>
 WG_INLINE void fwdw(GP G, const VP vals, const VP x, const VP y, double& acc, double& acc2) {
 #if DNLP_DEVICE_PASS
-  const int lane = P::lane();
+  const int lane = P::lane() - 64 * W;
   double p = 0.0, p2 = 0.0;
   if (lane < CNT) {
 #else
@@ -144,10 +145,10 @@ WG_INLINE void fwdw(GP G, const VP vals, const VP x, const VP y, double& acc, do
   }
 #endif
 }
-template <class P, bool TWO, int NODE, class VP>
+template <class P, bool TWO, int NODE, int W = 0, class VP>
 WG_INLINE void fwdw_fin(VP x, VP y, double acc, double acc2) {
 #if DNLP_DEVICE_PASS
-  if (P::lane() == 0) {
+  if (P::lane() == 64 * W) {
 #else
   {
 #endif
