@@ -182,3 +182,34 @@ def test_workgroup_per_instance_kernel_follows_the_generic_kernel(gpu_required, 
     w2, _ = _wg_and_generic(pb, thetas)
     assert np.array_equal(w.iterations, w2.iterations) and np.array_equal(w.x, w2.x) and np.array_equal(w.raw["mult_g"], w2.raw["mult_g"])
     pb.close()
+
+
+@pytest.mark.gpu
+def test_per_template_kernel_takes_a_warm_start(gpu_required):
+    """IPOPT's warm_start_init_point through the per-template kernel: 1024 localization instances re-solved for slightly moved
+    ranges from the previous result's primal point and multipliers — fewer iterations than cold, the same optima (where the cold
+    start stays in the basin), and the same
+    statuses as the library's own kernel gives for the warm launch."""
+    prob, params, sample, _ = bp.template_localization()
+    pb = ParametricBatch(prob, params)
+    th0 = np.stack([sample(i) for i in range(1024)])
+    th1 = th0.copy()
+    th1[:, 20:] *= 1.0 + 0.01 * np.sin(np.arange(th1.shape[0]))[:, None]          # ranges moved by up to 1 %
+    os.environ["DNLP_WAVE_SPEC"] = "1"
+    try:
+        first = pb.solve(th0, want_duals=True)
+        cold = pb.solve(th1, want_duals=True)
+        warm = pb.solve(th1, warm_from=first, mu_init=1e-6, want_duals=True)
+        assert warm.raw["launch"]["wave_spec"] and cold.raw["launch"]["wave_spec"]
+        os.environ["DNLP_WAVE_SPEC"] = "0"
+        warm_own = pb.solve(th1, warm_from=first, mu_init=1e-6, want_duals=True)
+    finally:
+        os.environ.pop("DNLP_WAVE_SPEC", None)
+    ok = (warm.status == 0) & (cold.status == 0)
+    assert ok.mean() >= 0.95
+    assert warm.iterations[ok].mean() < 0.7 * cold.iterations[ok].mean()
+    # (a non-convex problem: a cold start may leave the basin of the previous solution — tests/test_warm_start.py)
+    same = ok & (np.abs(warm.obj_val - cold.obj_val) <= 1e-5 * np.maximum(1.0, np.abs(cold.obj_val)))
+    assert same.sum() >= 0.97 * ok.sum()
+    assert np.mean(warm.status == warm_own.status) >= 0.99
+    pb.close()
