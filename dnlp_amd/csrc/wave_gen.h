@@ -1,12 +1,19 @@
-// Template-specialised batch solver, part 7: the generator of the per-template LDL^T phases.
+// Template-specialised batch solver, part 7: the generator of the per-template phases.
 //
 // From a template's plan block (wave_plan.h) this writes (a) the 32-bit work tables G — one task per lane and phase, see
 // wave_gen_rt.h for the word formats — and (b) the TEXT of
-//     wgen::ldl_factor<P>(S)          = wave_ipm.h ldl_factor_impl
-//     wgen::ldl_solve<P, TWO>(S, x, y) = wave_ipm.h ldl_solve
-// as a sequence of wgrt:: helper calls whose template arguments are the literals of this template: table bases, active
+//     wgen::ldl_factor<P>(S)                 = wave_ipm.h ldl_factor_impl   (pivots + row scaling in ONE phase per level)
+//     wgen::ldl_solve<P, TWO>(S, x, y)        = wave_ipm.h ldl_solve
+//     wgen::kkt_residual<P, TWO>(S, ...)      = wave_ipm.h kkt_residual_impl / kkt_residual2 (one or two systems)
+//     wgen::jac_tmult<P>(S, v, out)           = wave_ipm.h jac_tmult (out of the residual's tables)
+//     wgen::spmv<P, SPLIT>(S, id, ...)        = wave_ipm.h spmv for the five constant CSR maps
+// as sequences of wgrt:: helper calls whose template arguments are the literals of this template: table bases, active
 // lanes, entry counts, block kinds.  wave_ipm.h calls them when it is compiled with -DDNLP_WAVE_GEN (wave_codegen.h does
-// that for the per-template kernel; tests do it for the host lane and compare bits with the interpreted text).
+// that for the per-template kernels; tests do it for the host lane and compare bits with the interpreted text).
+// LW = lanes that share a phase: 64 (one wavefront per instance) or 64 x the wavefronts of a workgroup per instance — then a
+// phase of more than 64 tasks spreads over the wavefronts between two workgroup barriers, a NARROW one (and the wide forms)
+// runs on the first wavefront alone, and what is independent inside a level (long forward targets, long outputs of the
+// residual) is dealt out to the wavefronts.
 // Role in the reference: what MUMPS does behind ipopt_nlpif.py:170 for one small KKT system, once per iteration and solve.
 //
 // Plain host C++ (no HIP).

@@ -1,18 +1,24 @@
-// Template-specialised batch solver, part 6: the PHASES of the static-pattern LDL^T as straight-line code.
+// Template-specialised batch solver, part 6: the PHASES of the static-pattern LDL^T, of the KKT residual and of the constant
+// CSR maps as straight-line code.
 //
-// wave_ipm.h's ldl_factor_impl / ldl_solve walk the plan's index tables: per level a handful of uniform bound loads, per
-// entry an index load, a dependent operand load and loop control — 9.7 k cycles for one solve of an order-102 factor.  In a
-// kernel compiled per template (wave_codegen.h) the level structure is known when the text is written: wave_gen.h lays the
-// work of every level phase out as ONE TASK PER LANE (descriptor words G[base + lane], entry words G[base + e * lanes_active
-// + lane], both 32-bit, staged in LDS next to the plan) and emits, per phase, one call of a helper below with every bound,
-// base and count as a template argument.  After inlining that is straight-line code: ds_read with immediate offsets for
-// the descriptors, unrolled entry loops, no level tables, no scalar loop control.
+// wave_ipm.h's ldl_factor_impl / ldl_solve / kkt_residual / spmv walk the plan's index tables: per level a handful of uniform
+// bound loads, per entry an index load, a dependent operand load and loop control — 9.7 k cycles for one solve of an
+// order-102 factor.  In a kernel compiled per template (wave_codegen.h) the structure is known when the text is written:
+// wave_gen.h lays the work of every phase out as ONE TASK PER LANE (descriptor words G[base + lane], entry words
+// G[base + e * lanes_active + lane], 32-bit; staged in LDS next to the plan, or read from global memory by the kernels whose
+// shares fill LDS) and emits, per phase slot, one call of a helper below with every base, count and block kind as a template
+// argument.  After inlining that is straight-line code: loads with immediate offsets for the descriptors, unrolled entry
+// loops, no level tables, no scalar loop control.  Every operand is LOADED unconditionally and SELECTED afterwards: a load
+// under a condition is a branch, and a branch per padded entry a memory round trip.
 //
-// The ARITHMETIC is that of wave_ipm.h / sparse_ldl.h, entry by entry and in the same order: every destination (a forward
-// target, a block's backward sum, an update group) is summed by ONE lane in storage order — what the host lane of the
-// interpreted text does — so the generated phases reproduce its bits on the CPU (tests/test_wave_gen_cpu.py runs this text
-// with its lanes played one after the other against the interpreted host lane) and the device runs the same sums.  A padded entry multiplies
-// two selected zeros: adding +0.0 to a sum that started at +0.0 never changes it.
+// The ARITHMETIC is that of wave_ipm.h / sparse_ldl.h, entry by entry: every destination (a forward target, a block's
+// backward sum, an update group, an output of a product) is summed in storage order by one lane — what the host lane of the
+// interpreted text does — so the generated phases reproduce its bits on the CPU (tests/test_wave_gen_cpu.py builds this text
+// for the host, its lanes played one after the other, against the interpreted host lane).  A padded entry multiplies two
+// selected zeros: adding +0.0 to a sum that started at +0.0 never changes it.  The device runs the same sums, with ONE
+// exception: the wide forms (fwdw / fwdw2 / bwdw / wdot: the rows of one long target across the lanes) add their products
+// through the wavefront's fixed DPP tree instead of a chain of CNT dependent additions — the same bits on every run, another
+// order than the host's, as every P::sum of the interpreted text.
 //
 // Free of standard-library includes (the text travels into hiprtc as wave_gen_rt_src.inc).
 #pragma once
