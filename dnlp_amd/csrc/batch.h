@@ -435,6 +435,12 @@ struct BatchRunner {
       std::fprintf(stderr, "[dnlp] per-template batch kernel not available (the library's own kernel is used): %s\n", wave_spec.log.substr(0, 2000).c_str());
       return false;
     }
+    if (!wave_spec.fits(fit)) {
+      wave_spec.ok = false;
+      rtc_cache_drop(src);
+      std::fprintf(stderr, "[dnlp] per-template batch kernel: its register allocation does not fit %d wavefronts per workgroup (the library's own kernel is used)\n", fit);
+      return false;
+    }
     wave_gen_words = static_cast<int>(gen.G.size());
     DNLP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_wave_gen), (gen.G.size() + 4) * sizeof(unsigned)));
     if (!gen.G.empty()) DNLP_HIP_CHECK(hipMemcpy(d_wave_gen, gen.G.data(), gen.G.size() * sizeof(unsigned), hipMemcpyHostToDevice));
@@ -451,6 +457,22 @@ struct BatchRunner {
   std::vector<i32> wave_wg_blk;                   // its plan block (no dense tail in registers)
   i32* d_wave_wg_blk = nullptr;
   bool wave_wg_prof = false;
+  // the workgroup kernel's own plan block: WITHOUT the dense tail in registers (one-wavefront code; the chain's few levels run as
+  // narrow generated phases instead — power flow: tail_forward alone was 59 k of 1 590 k cycles per iteration).  Built where
+  // wave_prepare() builds the library's block — on the caller's thread: build_wave_plan reads the tape's index arrays back
+  // through the handle's stream, which the worker threads of a batch stream's slots must not share.
+  bool wave_wg_plan() {
+    const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(wave_blk.data());
+    WaveLayoutIn l;
+    l.c0 = lay.c0; l.c = lay.c; l.b = lay.b; l.Jc = lay.Jc; l.G = lay.G; l.Mg = lay.Mg; l.Mw = lay.Mw; l.MJ = lay.MJ; l.MH = lay.MH;
+    l.fp = lay.fp; l.fp2 = lay.fp2; l.x0 = lay.x0; l.lb = lay.lb; l.ub = lay.ub; l.cl = lay.cl; l.cu = lay.cu; l.total = lay.total;
+    const bool tail = std::getenv("DNLP_WAVE_WG_TAIL") && std::atoi(std::getenv("DNLP_WAVE_WG_TAIL")) == 1;
+    wave_wg_blk = build_wave_plan(ex, *tape, *host_plan, l, tail);
+    if (reinterpret_cast<const WaveHdr*>(wave_wg_blk.data())->state_doubles != h.state_doubles) { wave_wg_blk.assign(1, 0); return false; }
+    DNLP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_wave_wg_blk), wave_wg_blk.size() * sizeof(i32)));
+    DNLP_HIP_CHECK(hipMemcpy(d_wave_wg_blk, wave_wg_blk.data(), wave_wg_blk.size() * sizeof(i32), hipMemcpyHostToDevice));
+    return true;
+  }
   bool wave_wg_prepare(int batch) {
     const char* e = std::getenv("DNLP_WAVE_SPEC");
     const int mode = e ? std::atoi(e) : -1;
@@ -463,18 +485,8 @@ struct BatchRunner {
     int nwg = std::getenv("DNLP_WAVE_WG_WAVES") ? std::atoi(std::getenv("DNLP_WAVE_WG_WAVES")) : 8;
     if (nwg < 1 || nwg > 8) nwg = 8;
     const double t0 = now_sec();
-    // the kernel's own plan block: WITHOUT the dense tail in registers (one-wavefront code; the chain's few levels run as
-    // narrow generated phases instead — power flow: tail_forward alone was 59 k of 1 590 k cycles per iteration)
-    {
-      WaveLayoutIn l;
-      l.c0 = lay.c0; l.c = lay.c; l.b = lay.b; l.Jc = lay.Jc; l.G = lay.G; l.Mg = lay.Mg; l.Mw = lay.Mw; l.MJ = lay.MJ; l.MH = lay.MH;
-      l.fp = lay.fp; l.fp2 = lay.fp2; l.x0 = lay.x0; l.lb = lay.lb; l.ub = lay.ub; l.cl = lay.cl; l.cu = lay.cu; l.total = lay.total;
-      const bool tail = std::getenv("DNLP_WAVE_WG_TAIL") && std::atoi(std::getenv("DNLP_WAVE_WG_TAIL")) == 1;
-      wave_wg_blk = build_wave_plan(ex, *tape, *host_plan, l, tail);
-      if (reinterpret_cast<const WaveHdr*>(wave_wg_blk.data())->state_doubles != h.state_doubles) return false;
-      DNLP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_wave_wg_blk), wave_wg_blk.size() * sizeof(i32)));
-      DNLP_HIP_CHECK(hipMemcpy(d_wave_wg_blk, wave_wg_blk.data(), wave_wg_blk.size() * sizeof(i32), hipMemcpyHostToDevice));
-    }
+    if (wave_wg_blk.empty() && !wave_wg_plan()) return false;
+    if (wave_wg_blk.size() < sizeof(WaveHdr) / 4) return false;
     const WaveGen gen = wave_generate(wave_wg_blk, 64 * nwg);
     wave_wg_prof = std::getenv("DNLP_WAVE_SPEC_PROF") != nullptr;
     // (DNLP_WAVE_WG_BOUND: threads the register budget is sized for — 512 with four wavefronts: two workgroups per compute unit)
@@ -483,6 +495,12 @@ struct BatchRunner {
     const std::string src = wave_wg_source(wave_wg_blk, nwg, gen, wave_wg_prof, bound, lds_vec);
     if (!wave_wg.load(src, "dnlp_wave_wg_kernel")) {
       std::fprintf(stderr, "[dnlp] workgroup-per-instance batch kernel not available (the library's own kernel is used): %s\n", wave_wg.log.substr(0, 2000).c_str());
+      return false;
+    }
+    if (!wave_wg.fits(nwg)) {
+      wave_wg.ok = false;
+      rtc_cache_drop(src);
+      std::fprintf(stderr, "[dnlp] workgroup-per-instance batch kernel: its register allocation does not fit %d wavefronts per workgroup (the library's own kernel is used)\n", nwg);
       return false;
     }
     wave_wg_gen_words = static_cast<int>(gen.G.size());
@@ -517,6 +535,8 @@ struct BatchRunner {
           DNLP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_wave_blk16), narrow16.size() * sizeof(int16_t)));
           DNLP_HIP_CHECK(hipMemcpy(d_wave_blk16, narrow16.data(), narrow16.size() * sizeof(int16_t), hipMemcpyHostToDevice));
         }
+        // a template whose state exceeds LDS goes through the workgroup-per-instance kernel: its plan block now, too
+        { int nw = 0, sl = 0, pl = 0; wave_form(nw, sl, pl); if (!sl && !wave_gen_refusal(*reinterpret_cast<const WaveHdr*>(wave_blk.data()))[0]) wave_wg_plan(); }
       }
     }
     return !wave_blk.empty();

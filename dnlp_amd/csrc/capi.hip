@@ -355,6 +355,17 @@ int dnlp_lbfgs_codegen_check(const void* blob, size_t len, int elems_per_lane, c
     return code.empty() ? 2 : 0;)
 }
 
+int dnlp_rtc_compiler(char* out, size_t cap) {
+  DNLP_TRY(
+    const RtcChoice c = rtc_choice();
+    if (out && cap) {
+      const size_t n = c.identity.size() < cap - 1 ? c.identity.size() : cap - 1;
+      std::memcpy(out, c.identity.data(), n);
+      out[n] = 0;
+    }
+    return c.clang.empty() ? 0 : 1;)
+}
+
 const char* dnlp_version(void) { return "dnlp_amd 0.1.0 (gfx950)"; }
 
 int dnlp_dev_alloc(int device, size_t bytes, void** out) {

@@ -130,8 +130,17 @@ struct WaveLanesWG {
 
 // (kWgBound: the register budget — a bound of 512 threads holds the kernel and its functions to 256 registers per lane, so that
 //  two workgroups of four wavefronts share a compute unit: these instances wait for memory, and a second workgroup fills the wait)
-extern "C" __global__ void __launch_bounds__(wspec::kWgBound) dnlp_wave_wg_kernel(dnlp::WaveArgs a) {
+//
+// The body is a function of its own, not inlined into the entry point, which only stages the arguments in LDS and calls it.
+// Reason: the compiler of ROCm 7.0 (the one a process that imported PyTorch compiles with: torch ships its own libhiprtc /
+// libamd_comgr) gives the functions of this module half the budget as accumulation registers (128 + 128) but let an entry
+// point with a body of its own take 140 ordinary ones on top: a 268-register kernel under a bound of 256, whose first launch
+// aborts the queue (INVALID_ISA).  An entry point that only copies and calls has next to nothing to allocate.
+__shared__ __attribute__((aligned(16))) unsigned g_wg_args[sizeof(dnlp::WaveArgs) / 4];      // (raw words: WaveArgs has member initialisers)
+
+__device__ __attribute__((noinline)) static void dnlp_wave_wg_main() {
   using namespace dnlp;
+  const DNLP_WLDS WaveArgs& a = *(const DNLP_WLDS WaveArgs*)g_wg_args;
   using P = WaveLanesWG;
   using W = WaveIpm<P>;
   using WD = typename P::D;
@@ -194,4 +203,11 @@ extern "C" __global__ void __launch_bounds__(wspec::kWgBound) dnlp_wave_wg_kerne
     }
     __syncthreads();
   }
+}
+
+extern "C" __global__ void __launch_bounds__(wspec::kWgBound) dnlp_wave_wg_kernel(dnlp::WaveArgs a) {
+  static_assert(sizeof(dnlp::WaveArgs) % 4 == 0, "copied word by word");
+  for (unsigned k = threadIdx.x; k < sizeof(dnlp::WaveArgs) / 4; k += blockDim.x) g_wg_args[k] = ((const unsigned*)&a)[k];
+  __syncthreads();
+  dnlp_wave_wg_main();
 }

@@ -216,6 +216,13 @@ int dnlp_fused_codegen_check(const void* tape_blob, size_t len, int elems_per_la
  * convergence decision is taken on the device, the host only enqueues). */
 int dnlp_lbfgs_codegen_check(const void* tape_blob, size_t len, int elems_per_lane, char* src_out,
                              size_t src_cap, char* log_out, size_t log_cap);
+/* Which compiler the generated kernels of this process go through (dnlp_amd/csrc/fused_rtc.h): 0 = hiprtc in
+ * process — whatever libhiprtc / libamd_comgr the loader bound first: the pair PyTorch ships when torch was
+ * imported before this library, else the ROCm install's — 1 = the ROCm install's clang++ run as a child
+ * process ($DNLP_RTC_COMPILER=clang: the same code objects whichever hiprtc is bound).  `out` receives the
+ * compiler's file, size and time: the identity the kernel cache is keyed by, so that the two never share
+ * entries.  No counterpart in the reference (it compiles nothing at run time). */
+int dnlp_rtc_compiler(char* out, size_t cap);
 /* Dual warm start (IPOPT `warm_start_init_point`; SURVEY.md 8f-4.  The reference accepts
  * `warm_start` and ignores it, ipopt_nlpif.py:126-127): with the option
  * `warm_start_init_point=yes`, the next dnlp_solve / dnlp_ipm_begin starts from x_inout AND these

@@ -37,3 +37,26 @@ def compile_for_gfx950(src: str, opts=("-O3", "-std=c++17", "-munsafe-fp-atomics
     rtc.hiprtcDestroyProgram.argtypes = [C.POINTER(C.c_void_p)]
     rtc.hiprtcDestroyProgram(C.byref(prog))
     return rc == 0, log.value.decode(errors="replace"), dt, code
+
+
+def registers_of(code: bytes):
+    """-> (vgpr_count, agpr_count, max_flat_workgroup_size) of the first kernel in a code object (its metadata note)."""
+    import os
+    import re
+    import subprocess
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".hsaco", delete=False) as f:
+        f.write(code)
+    try:
+        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f.name], capture_output=True, text=True).stdout
+    finally:
+        os.unlink(f.name)
+    g = lambda key: int(re.search(r"\.%s:\s*(\d+)" % key, out).group(1))
+    return g("vgpr_count"), g("agpr_count"), g("max_flat_workgroup_size")
+
+
+def fits_register_file(code: bytes, waves: int) -> bool:
+    """gfx950: 512 unified registers per lane and SIMD, four SIMDs per compute unit — ceil(waves / 4) wavefronts of a workgroup
+    share one (the rule of csrc/fused_rtc.h RtcKernel::fits)."""
+    v, a, bound = registers_of(code)
+    return v * ((waves + 3) // 4) <= 512

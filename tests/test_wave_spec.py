@@ -143,6 +143,70 @@ def test_workgroup_per_instance_kernel_text_compiles_for_gfx950():
     assert ok, log[:4000]
 
 
+_FITS_CHILD = r"""
+import sys
+if sys.argv[1] == "torch":
+    import torch                                  # binds torch/lib/libhiprtc.so + libamd_comgr.so (ROCm 7.0) under the soname
+sys.path.insert(0, sys.argv[2]); sys.path.insert(0, sys.argv[2] + "/tests")
+import hiprtc_util as h
+import test_wave_spec as t
+for name in ("path_planning", "power_flow"):
+    ok, log, seconds, code = h.compile_for_gfx950(t._wg_source(name, 8))
+    assert ok, log[:2000]
+    print("FITS", name, h.registers_of(code), h.fits_register_file(code, 8), flush=True)
+maps = open("/proc/self/maps").read()
+print("COMPILER", "torch" if "torch/lib/libamd_comgr" in maps else "rocm", flush=True)
+"""
+
+
+@pytest.mark.parametrize("compiler", ["rocm", "torch"])
+def test_workgroup_kernel_fits_its_launch_under_both_compilers_of_the_image(compiler):
+    """A process that imported PyTorch compiles with the hiprtc / comgr torch ships (ROCm 7.0), any other with the ROCm install's
+    (7.2).  The 7.0 compiler splits this module's budget into 128 ordinary + 128 accumulation registers and let an entry point
+    with a body take 140 on top: 268 registers under __launch_bounds__(512), INVALID_ISA at the first launch (bench.py and
+    pytest run under torch; the tools do not).  wave_wg_kernel.h's entry point therefore only calls the body: both compilers
+    must stay inside 256 registers for the eight-wavefront launch."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _FITS_CHILD, compiler, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("FITS")]
+    assert len(lines) == 2 and all(l.endswith("True") for l in lines), r.stdout
+    if compiler == "rocm":
+        assert "COMPILER rocm" in r.stdout, r.stdout
+
+
+_CHOICE_CHILD = r"""
+import sys, ctypes as C
+if sys.argv[1] == "torch":
+    import torch
+lib = C.CDLL(sys.argv[2] + "/dnlp_amd/libdnlp_hip.so")
+buf = C.create_string_buffer(1024)
+rc = lib.dnlp_rtc_compiler(buf, C.c_size_t(1024))
+print("CHOICE", rc, buf.value.decode(), flush=True)
+"""
+
+
+@pytest.mark.parametrize("first,env,want,where", [("rocm", None, 0, "/lib/libhiprtc.so"), ("torch", None, 0, "torch/lib/libhiprtc.so"),
+                                                  ("torch", "clang", 1, "/lib/llvm/bin/clang++"), ("rocm", "clang", 1, "/lib/llvm/bin/clang++")])
+def test_the_kernel_cache_is_keyed_by_the_compiler_this_process_compiles_with(first, env, want, where):
+    """include/dnlp_hip.h dnlp_rtc_compiler / csrc/fused_rtc.h: a process that imported PyTorch first compiles with the hiprtc
+    torch ships, any other with the ROCm install's — different compilers behind the same hiprtcVersion, so the identity of the
+    bound library is part of the cache key; $DNLP_RTC_COMPILER=clang takes the install's clang++ (a child process) in both."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.pop("DNLP_RTC_COMPILER", None)
+    if env:
+        e["DNLP_RTC_COMPILER"] = env
+    r = subprocess.run([sys.executable, "-c", _CHOICE_CHILD, first, root], capture_output=True, text=True, timeout=300, env=e)
+    assert r.returncode == 0, r.stderr[-2000:]
+    row = [l.split(None, 2) for l in r.stdout.splitlines() if l.startswith("CHOICE")][0]
+    assert int(row[1]) == want and where in row[2], r.stdout
+
+
 def _wg_and_generic(pb, thetas, **kw):
     out = []
     for mode in ("1", "0"):
