@@ -2293,6 +2293,152 @@ struct WaveIpm {
     W_P1(10);
     return (1.0 - adv) * (1.0 - adv) * nd2 / n_dual + (1.0 - apv) * (1.0 - apv) * np2 / n_pri + comp / static_cast<double>(nb);
   }
+#ifdef DNLP_WAVE_SPEC
+  // ---- the quality function over operands held in REGISTERS (P::hoist: the workgroup-per-instance kernel) --------------------
+  // The mu oracle evaluates quality() 10 to 30 times per iteration on the same 23 vectors (only sigma changes), and with the
+  // vectors in global memory every evaluation waits for them twice (a round trip is 1 us: 10 k cycles per evaluation, 122 k of
+  // 1 070 k per iteration on path planning).  A lane's share is ceil(N / lanes) + ceil(m / lanes) entries — two and two at 512
+  // lanes: 46 doubles — so the oracle loads them ONCE (qf_load) and every evaluation (quality_regs: the same expressions in the
+  // same order as quality()'s P::hoist form, hence the same bits) is arithmetic and two block reductions.  The golden section
+  // has ONE evaluation site here (section_regs: the order of evaluations of section(), written as a loop) so that the inlined
+  // evaluation is not repeated six times in the code.
+  static constexpr int kQfTN = (wspec::k_N + P::lanes - 1) / P::lanes > 0 ? (wspec::k_N + P::lanes - 1) / P::lanes : 1;
+  static constexpr int kQfTM = (wspec::k_m + P::lanes - 1) / P::lanes > 0 ? (wspec::k_m + P::lanes - 1) / P::lanes : 1;
+  struct QfRegs {
+    double l[kQfTN], u[kQfTN], x[kQfTN], a[kQfTN], b[kQfTN], ax[kQfTN], cx[kQfTN], aa[kQfTN], ca[kQfTN], ab[kQfTN], cb[kQfTN];
+    double sl[kQfTM], su[kQfTM], s[kQfTM], c[kQfTM], d[kQfTM], eq[kQfTM], as[kQfTM], cs[kQfTM], ac[kQfTM], cc[kQfTM], ad[kQfTM], cd[kQfTM];
+  };
+  DNLP_WINL DNLP_HD static void qf_load(WS* S, QfRegs& R) {
+    const WD *ax = WDIR(1, 0), *as = WDIR(1, 1), *aa = WDIR(1, 3), *ab = WDIR(1, 4), *ac = WDIR(1, 5), *ad = WDIR(1, 6);
+    const WD *cx = WDIR(2, 0), *cs = WDIR(2, 1), *ca = WDIR(2, 3), *cb = WDIR(2, 4), *cc = WDIR(2, 5), *cd = WDIR(2, 6);
+    const WD *l = WV(xL), *u = WV(xU), *sl = WV(sL), *su = WV(sU), *eq = WV(eq), *xx = WV(x), *ss = WV(s), *a = WV(zL), *b = WV(zU), *c = WV(vL), *d = WV(vU);
+    constexpr int N = WK(N), m = WK(m);
+#pragma unroll
+    for (int t = 0; t < kQfTN; ++t) {
+      const int j0 = P::lane() + t * P::lanes, j = j0 < N ? j0 : 0;      // (an entry past the end reads entry 0: never used)
+      if (N > 0) {
+        R.l[t] = l[j]; R.u[t] = u[j]; R.x[t] = xx[j]; R.a[t] = a[j]; R.b[t] = b[j];
+        R.ax[t] = ax[j]; R.cx[t] = cx[j]; R.aa[t] = aa[j]; R.ca[t] = ca[j]; R.ab[t] = ab[j]; R.cb[t] = cb[j];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kQfTM; ++t) {
+      const int i0 = P::lane() + t * P::lanes, i = i0 < m ? i0 : 0;
+      if (m > 0) {
+        R.sl[t] = sl[i]; R.su[t] = su[i]; R.s[t] = ss[i]; R.c[t] = c[i]; R.d[t] = d[i]; R.eq[t] = eq[i];
+        R.as[t] = as[i]; R.cs[t] = cs[i]; R.ac[t] = ac[i]; R.cc[t] = cc[i]; R.ad[t] = ad[i]; R.cd[t] = cd[i];
+      }
+    }
+  }
+  DNLP_WINL DNLP_HD static double quality_regs(WS* S, const QfRegs& R, double sigma) {
+    W_P0();
+    const double avg = S->qf_avg, nd2 = S->qf_nd2, np2 = S->qf_np2, n_dual = S->qf_n_dual, n_pri = S->qf_n_pri;
+    const i64 nb = S->qf_nb;
+    const double mus = sigma * avg;
+    const double tv = std::max(0.99, 1.0 - mus);
+    constexpr int N = WK(N), m = WK(m);
+    double a0 = -kInf, a1 = -kInf;
+    double comp = 0.0;
+#pragma unroll
+    for (int t = 0; t < kQfTN; ++t) {
+      if (P::lane() + t * P::lanes < N) {
+        const double lj = R.l[t], uj = R.u[t], xj = R.x[t], aj = R.a[t], bj = R.b[t];
+        const double dxx = R.ax[t] + mus * R.cx[t], da = R.aa[t] + mus * R.ca[t], db = R.ab[t] + mus * R.cb[t];
+        const bool lo = lj > -kInf && dxx < 0.0, up = uj < kInf && dxx > 0.0;
+        const double qp = (lo ? -tv * (xj - lj) : tv * (uj - xj)) / dxx, qa = -tv * aj / da, qb = -tv * bj / db;
+        double tp = 1.0, td = 1.0;
+        tp = (lo || up) ? fmin(tp, qp) : tp;
+        td = da < 0.0 ? fmin(td, qa) : td;
+        td = db < 0.0 ? fmin(td, qb) : td;
+        a0 = mnin(a0, tp); a1 = mnin(a1, td);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kQfTM; ++t) {
+      if (P::lane() + t * P::lanes < m) {
+        const double li = R.sl[t], ui = R.su[t], si = R.s[t], ci = R.c[t], di = R.d[t];
+        const bool in = R.eq[t] == 0.0;
+        const double dss = R.as[t] + mus * R.cs[t], dc = R.ac[t] + mus * R.cc[t], dd2 = R.ad[t] + mus * R.cd[t];
+        const bool lo = in && li > -kInf && dss < 0.0, up = in && ui < kInf && dss > 0.0;
+        const double qp = (lo ? -tv * (si - li) : tv * (ui - si)) / dss, qc = -tv * ci / dc, qd = -tv * di / dd2;
+        double tp = 1.0, td = 1.0;
+        tp = (lo || up) ? fmin(tp, qp) : tp;
+        td = dc < 0.0 ? fmin(td, qc) : td;
+        td = dd2 < 0.0 ? fmin(td, qd) : td;
+        a0 = mnin(a0, tp); a1 = mnin(a1, td);
+      }
+    }
+    { double r2[2] = {a0, a1}; P::vmax_n(r2); a0 = r2[0]; a1 = r2[1]; }
+    const double apv = std::min(1.0, -a0), adv = std::min(1.0, -a1);
+#pragma unroll
+    for (int t = 0; t < kQfTN; ++t) {
+      if (P::lane() + t * P::lanes < N) {
+        const double lj = R.l[t], uj = R.u[t], xj = R.x[t];
+        const double dxx = R.ax[t] + mus * R.cx[t];
+        const double t1 = (xj - lj + apv * dxx) * (R.a[t] + adv * (R.aa[t] + mus * R.ca[t]));
+        const double t2 = (uj - xj - apv * dxx) * (R.b[t] + adv * (R.ab[t] + mus * R.cb[t]));
+        double v = 0.0;
+        v = lj > -kInf ? v + t1 * t1 : v;
+        v = uj < kInf ? v + t2 * t2 : v;
+        comp += v;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kQfTM; ++t) {
+      if (P::lane() + t * P::lanes < m) {
+        const double li = R.sl[t], ui = R.su[t], si = R.s[t];
+        const bool in = R.eq[t] == 0.0;
+        const double dss = R.as[t] + mus * R.cs[t];
+        const double t1 = (si - li + apv * dss) * (R.c[t] + adv * (R.ac[t] + mus * R.cc[t]));
+        const double t2 = (ui - si - apv * dss) * (R.d[t] + adv * (R.ad[t] + mus * R.cd[t]));
+        double v = 0.0;
+        v = (in && li > -kInf) ? v + t1 * t1 : v;
+        v = (in && ui < kInf) ? v + t2 * t2 : v;
+        comp += v;
+      }
+    }
+    comp = P::sum(comp);
+    W_P1(10);
+    return (1.0 - adv) * (1.0 - adv) * nd2 / n_dual + (1.0 - apv) * (1.0 - apv) * np2 / n_pri + comp / static_cast<double>(nb);
+  }
+  // section() with one evaluation site: the same points in the same order (m1, m2, one new point per step, slo, sup)
+  DNLP_WINL DNLP_HD static double section_regs(WS* S, const QfRegs& R, double slo, double sup) {
+    const double gr = 0.5 * (3.0 - std::sqrt(5.0));
+    double la = std::log(slo), lb = std::log(std::max(sup, slo * (1 + 1e-12)));
+    double m1 = la + gr * (lb - la), m2 = lb - gr * (lb - la);
+    double f1 = 0.0, f2 = 0.0, qlo = 0.0, qup = 0.0, sg = 0.0, fsel = 0.0;
+    int it = 0, stage = 0;          // 0: f1 at m1, 1: f2 at m2, 2: the steps, 3: qlo, 4: qup
+    bool second = false;            // a step's new value is f2 (else f1)
+    while (true) {
+      double at;
+      if (stage == 0) at = std::exp(m1);
+      else if (stage == 1) at = std::exp(m2);
+      else if (stage == 2) {
+        if (it < 8 && (lb - la) > 1e-2 * std::fabs(lb) + 1e-12) {
+          ++it;
+          if (f1 > f2) { la = m1; m1 = m2; f1 = f2; m2 = lb - gr * (lb - la); second = true; at = std::exp(m2); }
+          else { lb = m2; m2 = m1; f2 = f1; m1 = la + gr * (lb - la); second = false; at = std::exp(m1); }
+        } else {
+          sg = std::exp(f1 < f2 ? m1 : m2);
+          fsel = std::min(f1, f2);
+          stage = 3; at = slo;
+        }
+      } else at = sup;
+      const double f = quality_regs(S, R, at);
+      if (stage == 0) { f1 = f; stage = 1; }
+      else if (stage == 1) { f2 = f; stage = 2; }
+      else if (stage == 2) { if (second) f2 = f; else f1 = f; }
+      else if (stage == 3) { qlo = f; stage = 4; }
+      else { qup = f; break; }
+    }
+    bool endpoint = false;
+    if (qlo < fsel && qlo <= qup) { sg = slo; fsel = qlo; endpoint = true; }
+    else if (qup < fsel) { sg = sup; fsel = qup; endpoint = true; }
+    S->qf_fsel = fsel;
+    S->qf_endpoint = endpoint ? 1 : 0;
+    return sg;
+  }
+#endif
   // golden section in log(sigma) + IPOPT's end-point check (the lambda `section` of Ipm::quality_function_mu)
   DNLP_WFN DNLP_HD static double section(WS* S, double slo, double sup) {
     auto qf = [&](double sg) { return quality(S, sg, S->qf_avg, S->qf_nd2, S->qf_np2, S->qf_n_dual, S->qf_n_pri, S->qf_nb); };
@@ -2313,6 +2459,38 @@ struct WaveIpm {
     S->qf_fsel = fsel;
     S->qf_endpoint = endpoint ? 1 : 0;
     return sg;
+  }
+  // the oracle's search for sigma (Ipm::quality_function_mu): qf = one evaluation, sec = the golden section between two bounds
+  template <class QF, class SEC>
+  DNLP_WINL DNLP_HD static double sigma_search(WS* S, double s_lo, double s_up, QF qf, SEC sec) {
+    double sigma;
+    if (s_lo >= s_up) {
+      sigma = s_lo;
+    } else {
+      const double q1 = qf(1.0), s1m = 1.0 - 1e-2, q1m = qf(std::max(s_lo, s1m));
+      double lo, up;
+      if (q1m > q1 && s_up > 1.0) { lo = 1.0; up = s_up; } else { lo = s_lo; up = std::min(std::max(s_lo, s1m), s_up); }
+      sigma = sec(lo, up);
+      double fsel = S->qf_fsel;
+      if (S->qf_endpoint != 0 && up > lo * 10.0) {
+        const double grid[6] = {lo, 1e-4, 1e-2, 1e-1, 0.5, up};
+        double gs[6], gq[6];
+        int ng = 0;
+        for (int k = 0; k < 6; ++k) {
+          if (grid[k] < lo || grid[k] > up || (ng > 0 && grid[k] <= gs[ng - 1])) continue;
+          gs[ng] = grid[k]; gq[ng] = qf(grid[k]); ++ng;
+        }
+        int best = 0;
+        for (int k = 1; k < ng; ++k) if (gq[k] < gq[best]) best = k;
+        if (gq[best] < fsel && best > 0 && best + 1 < ng) {
+          const double f0 = fsel, s0 = sigma;
+          sigma = sec(gs[best - 1], gs[best + 1]);
+          fsel = S->qf_fsel;
+          if (!(fsel < f0)) sigma = s0;
+        }
+      }
+    }
+    return sigma;
   }
   // Ipm::quality_function_mu
   DNLP_WFN DNLP_HD static bool quality_function_mu(WS* S, double dw) {
@@ -2387,36 +2565,19 @@ struct WaveIpm {
     const i64 n_ineq = m - S->n_eq;
     S->qf_avg = avg; S->qf_nd2 = nd2; S->qf_np2 = np2; S->qf_nb = nb;
     S->qf_n_dual = static_cast<double>(N + n_ineq); S->qf_n_pri = static_cast<double>(m > 0 ? m : 1);
-    auto qf = [&](double sg) { return quality(S, sg, S->qf_avg, S->qf_nd2, S->qf_np2, S->qf_n_dual, S->qf_n_pri, S->qf_nb); };
     const double mu_max = S->opt.mu_max_fact * avg;
     const double s_lo = std::max(1e-6, mu_floor / avg), s_up = std::min(1e2, mu_max / avg);
     double sigma;
-    if (s_lo >= s_up) {
-      sigma = s_lo;
-    } else {
-      const double q1 = qf(1.0), s1m = 1.0 - 1e-2, q1m = qf(std::max(s_lo, s1m));
-      double lo, up;
-      if (q1m > q1 && s_up > 1.0) { lo = 1.0; up = s_up; } else { lo = s_lo; up = std::min(std::max(s_lo, s1m), s_up); }
-      sigma = section(S, lo, up);
-      double fsel = S->qf_fsel;
-      if (S->qf_endpoint != 0 && up > lo * 10.0) {
-        const double grid[6] = {lo, 1e-4, 1e-2, 1e-1, 0.5, up};
-        double gs[6], gq[6];
-        int ng = 0;
-        for (int k = 0; k < 6; ++k) {
-          if (grid[k] < lo || grid[k] > up || (ng > 0 && grid[k] <= gs[ng - 1])) continue;
-          gs[ng] = grid[k]; gq[ng] = qf(grid[k]); ++ng;
-        }
-        int best = 0;
-        for (int k = 1; k < ng; ++k) if (gq[k] < gq[best]) best = k;
-        if (gq[best] < fsel && best > 0 && best + 1 < ng) {
-          const double f0 = fsel, s0 = sigma;
-          sigma = section(S, gs[best - 1], gs[best + 1]);
-          fsel = S->qf_fsel;
-          if (!(fsel < f0)) sigma = s0;
-        }
-      }
-    }
+#ifdef DNLP_WAVE_SPEC
+    if constexpr (P::hoist) {
+      QfRegs R;
+      qf_load(S, R);
+      sigma = sigma_search(S, s_lo, s_up, [&](double sg) DNLP_WINL { return quality_regs(S, R, sg); },
+                           [&](double lo, double up) DNLP_WINL { return section_regs(S, R, lo, up); });
+    } else
+#endif
+    sigma = sigma_search(S, s_lo, s_up, [&](double sg) { return quality(S, sg, S->qf_avg, S->qf_nd2, S->qf_np2, S->qf_n_dual, S->qf_n_pri, S->qf_nb); },
+                         [&](double lo, double up) { return section(S, lo, up); });
     const double nm = std::max(mu_floor, std::min(sigma * avg, mu_max));
     if (!std::isfinite(nm)) return false;
     S->mu = nm;

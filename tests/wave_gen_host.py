@@ -32,7 +32,13 @@ class GenHostBatch(HostBatch):
         self.source = buf.value.decode()
         d = build_dir or os.path.join(tempfile.gettempdir(), "dnlp_wave_gen_host-%d" % os.getuid())
         os.makedirs(d, exist_ok=True)
-        tag = hashlib.sha1(self.source.encode()).hexdigest()[:16]
+        # (the unit includes csrc headers by name: their text is part of what is built, so it is part of the tag)
+        h = hashlib.sha1(self.source.encode())
+        for name in sorted(os.listdir(CSRC)):
+            if name.endswith(".h"):
+                with open(os.path.join(CSRC, name), "rb") as fh:
+                    h.update(name.encode() + b"\0" + fh.read())
+        tag = h.hexdigest()[:16]
         so = os.path.join(d, "wgen_%s.so" % tag)
         if not os.path.exists(so):
             cpp = os.path.join(d, "wgen_%s.cpp" % tag)
