@@ -213,14 +213,15 @@ inline std::string wave_spec_source(const std::vector<i32>& blk, int nw, const W
 // memory): by priority the three arrays a single linear solve runs on (rhs sol res), the factor's values (svals), the three
 // arrays of the mu oracle's second system in front of them (the centering direction's cx czL czU: contiguous with rhs sol res
 // in wave_ipm.h layout) — as far as 160 KB minus the wavefronts' records hold them.  Two ranges of offsets.
-inline std::string wave_wg_lds_ranges(const std::vector<i32>& blk, int nwg, bool enable) {
+inline std::string wave_wg_lds_ranges(const std::vector<i32>& blk, int nwg, bool enable, int stage_words = 0) {
   const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(blk.data());
   typedef WaveIpm<WaveProbeLanes> W;
   W::WState S;
   std::vector<double> vecs(static_cast<size_t>(h.state_doubles) + 8, 0.0);
   W::layout((W::WS*)&S, &h, blk.data(), vecs.data());
   auto ev = [](long long n) { return (n + 1) & ~1LL; };
-  const long long cap = (160 * 1024 - 2048 - static_cast<long long>(nwg) * 1600) / 8;
+  // (beside them: the wavefronts' records, the staged kernel arguments and reduction partials, the narrow phases' staging buffer)
+  const long long cap = (160 * 1024 - 2048 - static_cast<long long>(nwg) * 1600 - 1024 - 4LL * stage_words) / 8;
   const long long nm = ev(h.N + h.m), a0 = S.svals - vecs.data(), a1 = a0 + ev(h.sp_nvals);
   const long long c0 = S.rhs - vecs.data(), c1 = (S.res - vecs.data()) + nm, b0 = S.dir[2][0] - vecs.data();
   long long r0a = 0, r0b = 0, r1a = 0, r1b = 0;
@@ -269,7 +270,8 @@ inline std::string wave_wg_source(const std::vector<i32>& blk, int nwg, const Wa
   s += wave_spec_text("wave_args.h", wave_args_text);
   s += wave_spec_constants(blk, nwg, gen.G.size(), prof);
   s += "namespace wspec { constexpr int kWgBound = " + std::to_string(bound_threads > 64 * nwg ? bound_threads : 64 * nwg) + "; }\n";
-  s += wave_wg_lds_ranges(blk, nwg, lds_vectors);
+  s += "namespace wspec { constexpr int kStageWords = " + std::to_string(gen.stage_words) + "; }\n";
+  s += wave_wg_lds_ranges(blk, nwg, lds_vectors, gen.stage_words);
   s += wave_spec_text("wave_ops.h", wave_ops_text);
   s += wave_spec_text("wave_ipm.h", wave_ipm_text);
   s += wave_spec_text("wave_wg_kernel.h", wave_wg_kernel_text);

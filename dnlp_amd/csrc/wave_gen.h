@@ -35,6 +35,7 @@ struct WaveGen {
   std::vector<uint32_t> G;        // work tables of all phases
   std::string code;               // namespace dnlp::wgen { ... } (function templates)
   int phases_factor = 0, phases_solve = 0;
+  int stage_words = 0;            // LDS words of the staging buffer the narrow phases read their tables from (0: none)
 };
 
 namespace wgen_detail {
@@ -70,8 +71,8 @@ inline const char* wave_gen_refusal(const WaveHdr& h) {
 // a level of at most kWideMaxTasks tasks with at least kWideMinEntries entries each is run task by task with the entries
 // across the lanes (wave_gen_rt.h fwdw / bwdw) instead of a task per lane
 constexpr int kWideMaxTasks = 4, kWideMinEntries = 8;
-// lines of 32 words of the FOLLOWING table that a narrow phase touches ahead (work tables in global memory: see wave_generate)
-constexpr int kTouchLines = 16;
+// the largest table a narrow phase reads from the LDS staging buffer (work tables in global memory: see wave_generate)
+constexpr int kStageMaxWords = 2048;
 
 // LW: lanes that share a phase (64: one wavefront per instance; 64 x wavefronts of a workgroup per instance)
 inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
@@ -92,31 +93,52 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
   // workgroup barrier each was most of their time).  With one wavefront per instance every phase of up to 64 tasks is
   // narrow and the two kinds of barrier are the same instruction.
   bool region_open = false;
-  // (work tables in global memory — a workgroup-per-instance kernel, LW > 64: a narrow phase starts by TOUCHING the lines
-  //  of the table that follows its own — the next phase's — so that the next phase finds them in the compute unit's L1:
-  //  such a phase is a table word from L2 / Infinity Cache, then LDS work; 800 of its ~900 cycles were the table word)
-  // MEASURED ON MI355X AND OFF: path planning 14.1 -> 13.3 k problems/s, its factorisation 293 -> 351 k cycles per iteration —
-  // a factor phase is TWO dependent global round trips (table word, then the unscaled rows / inverse pivots / products, which
-  // stay in the slab: they do not fit LDS beside the values and the solves' arrays), and the touched lines did not shorten
-  // the first; DNLP_WAVE_TOUCH=1 turns it on
-  const bool touch = LW > 64 && std::getenv("DNLP_WAVE_TOUCH") && std::atoi(std::getenv("DNLP_WAVE_TOUCH")) == 1;
-  auto patch_touch = [&] {
-    const size_t at = out.code.rfind("@@@");
-    if (at != std::string::npos) out.code.replace(at, 3, std::to_string(out.G.size()));
+  // STAGING (work tables in global memory — a workgroup-per-instance kernel, LW > 64).  A narrow phase is a table word from
+  // L2 (300-500 cycles), then a little LDS work: path planning's solve is ~120 such phases in a row, ~670 cycles each.  The
+  // phases of a region are run by ONE wavefront in program order, so each one first issues the loads of the NEXT narrow
+  // phase's table into registers (WG_STAGE_NEXT), does its own work, and puts the registers into an LDS buffer at its end
+  // (WG_STAGE_PUT: by then they have arrived); the next phase reads its table from that buffer (sg0_ = where its table
+  // starts in G: WG_SO rebases the offsets, WG_SG is the buffer).  The first narrow phase of a region and a phase whose
+  // table exceeds kStageMaxWords read G as before.  One buffer: a wavefront's LDS operations keep their order.
+  // ($DNLP_WAVE_STAGE=0 turns it off.  Tried before and dropped: touching the next table's lines at a phase's start so
+  //  that L1 holds them — loads return in order, the phase's own table word then waits behind the touch: 14.1 -> 13.3 k
+  //  problems/s on path planning.)
+  const bool stage = LW > 64 && !(std::getenv("DNLP_WAVE_STAGE") && std::atoi(std::getenv("DNLP_WAVE_STAGE")) == 0);
+  int tok = 0, prev_tok = -1, cur_tok = -1, cur_g0 = 0;
+  auto put = [&](const std::string& token, const std::string& val) {
+    const size_t at = out.code.rfind(token);
+    if (at != std::string::npos) out.code.replace(at, token.size(), val);
+  };
+  auto drop_pending = [&] { if (prev_tok >= 0) { put("@@N" + std::to_string(prev_tok) + "@@", "0, 0"); prev_tok = -1; } };
+  auto narrow_open = [&] {          // (behind WG_NBEGIN / WG_WBEGIN)
+    if (!stage) { E.line("    constexpr int sg0_ = -1;\n"); return; }
+    cur_tok = tok++;
+    cur_g0 = static_cast<int>(out.G.size());
+    E.line("    WG_STAGE_NEXT(@@N%d@@)\n    constexpr int sg0_ = @@S%d@@;\n", cur_tok, cur_tok);
+  };
+  auto narrow_close = [&] {         // (in front of WG_NEND / WG_WEND)
+    if (!stage) return;
+    E.line("    WG_STAGE_PUT\n");
+    const int words = static_cast<int>(out.G.size()) - cur_g0;
+    const bool staged = prev_tok >= 0 && words > 0 && words <= kStageMaxWords;
+    put("@@S" + std::to_string(cur_tok) + "@@", staged ? std::to_string(cur_g0) : std::string("-1"));
+    if (prev_tok >= 0) put("@@N" + std::to_string(prev_tok) + "@@", staged ? std::to_string(cur_g0) + ", " + std::to_string(words) : std::string("0, 0"));
+    if (staged) out.stage_words = std::max(out.stage_words, (words + 63) & ~63);
+    prev_tok = cur_tok;
   };
   auto begin_phase = [&](int tasks) {
     const bool narrow = tasks <= 64;
-    if (!narrow && region_open) { E.line("  WG_NCLOSE\n"); region_open = false; }
+    if (!narrow && region_open) { drop_pending(); E.line("  WG_NCLOSE\n"); region_open = false; }
     E.line(narrow ? "  WG_NBEGIN\n" : "  WG_BEGIN\n");
-    if (narrow && touch) E.line("    const unsigned pf_ = wgrt::touch<%d>(lane, G, @@@);\n", kTouchLines);
+    if (narrow) narrow_open(); else E.line("    constexpr int sg0_ = -1;\n");
     return narrow;
   };
   auto end_phase = [&](bool narrow) {
-    if (narrow && touch) { patch_touch(); E.line("    WG_TOUCH_USE(pf_);\n"); }
+    if (narrow) narrow_close();
     E.line(narrow ? "  WG_NEND\n" : "  WG_END\n");
     if (narrow) region_open = true;
   };
-  auto close_region = [&] { if (region_open) { E.line("  WG_NCLOSE\n"); region_open = false; } };
+  auto close_region = [&] { drop_pending(); if (region_open) { E.line("  WG_NCLOSE\n"); region_open = false; } };
   E.line("#define WG_LANES %d\nnamespace dnlp {\nnamespace wgen {\n", LW);
   // ================================================================ factorisation
   E.line("// wave_ipm.h ldl_factor_impl for THIS template: %d levels before the dense tail (order %d), %d blocks, %d values, %d update triples\n",
@@ -141,7 +163,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
         kinds |= kind;
         out.G[static_cast<size_t>(at + j)] = lo16(doff[k]) | (static_cast<uint32_t>(kind) << 30);
       }
-      E.line("    wgrt::piv2<%d, %d, %d>(lane, G, vals, nneg, nzero, bad);\n", at, nact, kinds);
+      E.line("    wgrt::piv2<WG_SO(%d), %d, %d>(lane, WG_SG, vals, nneg, nzero, bad);\n", at, nact, kinds);
       ++out.phases_factor;
     }
     for (int s0 = r0; s0 < r1; s0 += LW) {
@@ -156,7 +178,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
         if (aa > 0x7fff || doff[k] > 0x7fff) throw std::runtime_error("wave gen: a value index does not fit 15 bits");
         out.G[static_cast<size_t>(at + j)] = static_cast<uint32_t>(aa) | (static_cast<uint32_t>(doff[k]) << 15) | (static_cast<uint32_t>(one ? 1 : 2) << 30);
       }
-      E.line("    wgrt::scl2<%d, %d, %d>(lane, G, vals, w);\n", at, nact, kinds);
+      E.line("    wgrt::scl2<WG_SO(%d), %d, %d>(lane, WG_SG, vals, w);\n", at, nact, kinds);
     }
     end_phase(nb_ps);
     if (r1 == r0) continue;
@@ -176,7 +198,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
         if (bv > 0x7fff) throw std::runtime_error("wave gen: a value index does not fit 15 bits");
         out.G[static_cast<size_t>(at + j)] = lo16(au) | (static_cast<uint32_t>(bv) << 16) | (two ? 0x80000000u : 0u);
       }
-      E.line("    wgrt::upd<%d, %d, %d, %d>(lane, G, vals, w, scr);\n", at, nact, q0, kinds);
+      E.line("    wgrt::upd<WG_SO(%d), %d, %d, %d>(lane, WG_SG, vals, w, scr);\n", at, nact, q0, kinds);
       ++out.phases_factor;
     }
     end_phase(nb_upd);
@@ -192,7 +214,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
         out.G[static_cast<size_t>(at + j)] = lo16(gdst[gq]) | (lo16(cnt) << 16);
         out.G[static_cast<size_t>(at + nact + j)] = static_cast<uint32_t>(goff[gq] - t0);
       }
-      E.line("    wgrt::gsum<%d, %d, %d, %s>(lane, G, vals, scr);\n", at, nact, maxc, maxc != minc ? "true" : "false");
+      E.line("    wgrt::gsum<WG_SO(%d), %d, %d, %s>(lane, WG_SG, vals, scr);\n", at, nact, maxc, maxc != minc ? "true" : "false");
       ++out.phases_factor;
     }
     end_phase(nb_gs);
@@ -246,6 +268,8 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
         // level and solve)
         if (hq + 1 < h1 && c <= 32 && foff[hq + 2] - foff[hq + 1] <= 32) {
           const int cb = foff[hq + 2] - foff[hq + 1];
+          E.line("  WG_WBEGIN\n");
+          narrow_open();
           const int ea = E.reserve(128);
           int kinds = 0;
           for (int half = 0; half < 2; ++half)
@@ -256,14 +280,17 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
               out.G[static_cast<size_t>(ea + 32 * half + j)] = lo16(two ? ~a : a) | (lo16(fu0[q]) << 16);
               out.G[static_cast<size_t>(ea + 64 + 32 * half + j)] = lo16(two ? fu1[q] : fu0[q]) | (static_cast<uint32_t>(two ? 2 : 1) << 16);
             }
-          E.line("  WG_WBEGIN wgrt::fwdw2<P, TWO, %d, %d, %d, %d, %d, %d>(G, vals, x, y); WG_WEND\n", ea, c, cb, kinds, fnode[hq], fnode[hq + 1]);
+          E.line("    wgrt::fwdw2<P, TWO, WG_SO(%d), %d, %d, %d, %d, %d>(WG_SG, vals, x, y);\n", ea, c, cb, kinds, fnode[hq], fnode[hq + 1]);
+          narrow_close();
+          E.line("  WG_WEND\n");
           region_open = true;
           ++out.phases_solve;
           ++hq;
           continue;
         }
-        E.line("  WG_WBEGIN { double acc = 0.0, acc2 = 0.0;\n");
-        if (touch) E.line("    const unsigned pf_ = wgrt::touch<%d>(P::lane(), G, @@@);\n", kTouchLines);
+        E.line("  WG_WBEGIN\n");
+        narrow_open();
+        E.line("    { double acc = 0.0, acc2 = 0.0;\n");
         for (int e0 = 0; e0 < c; e0 += 64) {
           const int cnt = std::min(64, c - e0);
           const int ea = E.reserve(2 * static_cast<size_t>(cnt));
@@ -275,10 +302,11 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
             out.G[static_cast<size_t>(ea + j)] = lo16(two ? ~a : a) | (lo16(fu0[q]) << 16);
             out.G[static_cast<size_t>(ea + cnt + j)] = lo16(two ? fu1[q] : fu0[q]) | (static_cast<uint32_t>(two ? 2 : 1) << 16);
           }
-          E.line("    wgrt::fwdw<P, TWO, %d, %d, %d>(G, vals, x, y, acc, acc2);\n", ea, cnt, kinds);
+          E.line("    wgrt::fwdw<P, TWO, WG_SO(%d), %d, %d>(WG_SG, vals, x, y, acc, acc2);\n", ea, cnt, kinds);
         }
-        if (touch) { patch_touch(); E.line("    WG_TOUCH_USE(pf_);\n"); }
-        E.line("    wgrt::fwdw_fin<P, TWO, %d>(x, y, acc, acc2); } WG_WEND\n", fnode[hq]);
+        E.line("    wgrt::fwdw_fin<P, TWO, %d>(x, y, acc, acc2); }\n", fnode[hq]);
+        narrow_close();
+        E.line("  WG_WEND\n");
         region_open = true;
         ++out.phases_solve;
       }
@@ -301,7 +329,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
           out.G[static_cast<size_t>(ea + (2 * e + 1) * nact + j)] = lo16(two ? fu1[q] : fu0[q]) | (static_cast<uint32_t>(two ? 2 : 1) << 16);
         }
       }
-      E.line("    wgrt::fwd<TWO, %d, %d, %d, %d, %d, %s>(lane, G, vals, x, y);\n", at, ea, nact, maxc, kinds, maxc != minc ? "true" : "false");
+      E.line("    wgrt::fwd<TWO, WG_SO(%d), WG_SO(%d), %d, %d, %d, %s>(lane, WG_SG, vals, x, y);\n", at, ea, nact, maxc, kinds, maxc != minc ? "true" : "false");
       ++out.phases_solve;
     }
     end_phase(nb_fwd);
@@ -321,7 +349,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
       out.G[static_cast<size_t>(at + j)] = lo16(bnode[2 * k]) | ((u1 < 0 ? 0xffffu : lo16(u1)) << 16);
       out.G[static_cast<size_t>(at + nact + j)] = static_cast<uint32_t>(doff[k]);
     }
-    E.line("    wgrt::dsol<TWO, %d, %d, %d>(lane, G, vals, x, y);\n", at, nact, kinds);
+    E.line("    wgrt::dsol<TWO, WG_SO(%d), %d, %d>(lane, WG_SG, vals, x, y);\n", at, nact, kinds);
     ++out.phases_solve;
   }
   end_phase(nb_ds);
@@ -339,16 +367,18 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
     if (wide) {
       for (size_t j = 0; j < blocks.size(); ++j) {
         const int k = blocks[j], sn = soff[k + 1] - soff[k], u1 = bnode[2 * k + 1];
-        E.line("  WG_WBEGIN { double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;\n");
-        if (touch) E.line("    const unsigned pf_ = wgrt::touch<%d>(P::lane(), G, @@@);\n", kTouchLines);
+        E.line("  WG_WBEGIN\n");
+        narrow_open();
+        E.line("    { double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;\n");
         for (int i0 = 0; i0 < sn; i0 += 64) {
           const int cnt = std::min(64, sn - i0);
           const int ea = E.reserve(static_cast<size_t>(cnt));
           for (int i = 0; i < cnt; ++i) out.G[static_cast<size_t>(ea + i)] = lo16(sidx[soff[k] + i0 + i]);
-          E.line("    wgrt::bwdw<P, TWO, %s, %d, %d, %d, %d>(G, vals, x, y, a0, a1, c0, c1);\n", u1 < 0 ? "true" : "false", ea, cnt, loff[k], i0);
+          E.line("    wgrt::bwdw<P, TWO, %s, WG_SO(%d), %d, %d, %d>(WG_SG, vals, x, y, a0, a1, c0, c1);\n", u1 < 0 ? "true" : "false", ea, cnt, loff[k], i0);
         }
-        if (touch) { patch_touch(); E.line("    WG_TOUCH_USE(pf_);\n"); }
-        E.line("    wgrt::bwdw_fin<P, TWO, %s, %d, %d>(x, y, a0, a1, c0, c1); } WG_WEND\n", u1 < 0 ? "true" : "false", bnode[2 * k], u1 < 0 ? 0 : u1);
+        E.line("    wgrt::bwdw_fin<P, TWO, %s, %d, %d>(x, y, a0, a1, c0, c1); }\n", u1 < 0 ? "true" : "false", bnode[2 * k], u1 < 0 ? 0 : u1);
+        narrow_close();
+        E.line("  WG_WEND\n");
         region_open = true;
         ++out.phases_solve;
       }
@@ -371,7 +401,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
           wd |= lo16(sidx[soff[k] + i]) << ((i & 1) ? 16 : 0);
         }
       }
-      E.line("    wgrt::bwd<TWO, %d, %d, %d, %d, %d, %s>(lane, G, vals, x, y);\n", at, ea, nact, maxc, kinds, maxc != minc ? "true" : "false");
+      E.line("    wgrt::bwd<TWO, WG_SO(%d), WG_SO(%d), %d, %d, %d, %s>(lane, WG_SG, vals, x, y);\n", at, ea, nact, maxc, kinds, maxc != minc ? "true" : "false");
       ++out.phases_solve;
     }
     end_phase(nb_bwd);
@@ -502,7 +532,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
     E.line("}\n\n");
   }
   E.line("}  // namespace wgen\n}  // namespace dnlp\n");
-  if (touch) out.G.resize(out.G.size() + 32 * static_cast<size_t>(kTouchLines) + 32, 0u);      // (the last phases touch past their own tables)
+  if (stage) out.G.resize(out.G.size() + 64, 0u);      // (WG_STAGE_NEXT reads whole 64-word rows: up to 63 words past a table)
   return out;
 }
 

@@ -56,14 +56,24 @@ namespace wgrt {
 
 typedef unsigned int u32;
 
-// one word out of each of LINES consecutive 128-byte lines from G[base] on: brings a table that a later phase reads into the
-// compute unit's L1 (work tables in global memory); WG_TOUCH_USE keeps the loads alive until the phase's end
-template <int LINES, class GP>
-WG_INLINE u32 touch(int lane, GP G, int base) { return lane < LINES ? G[base + 32 * lane] : 0u; }
+// STAGING of a narrow phase's table (wave_gen.h: work tables in global memory): WG_STAGE_NEXT issues the loads of the NEXT
+// narrow phase's table (whole 64-word rows from G[g0n] on) into registers, WG_STAGE_PUT stores them to the policy's LDS
+// buffer P::stage() at the phase's end; a phase whose table was staged (sg0_ >= 0: where the table starts in G) reads the
+// buffer (WG_SG) at offsets from its start (WG_SO).  On the host the lanes are played one after the other from G itself.
 #if DNLP_DEVICE_PASS
-#define WG_TOUCH_USE(t) asm volatile("" : : "v"(t))
+template <bool ST, class P, class GP>
+WG_INLINE auto gsel(GP G) { if constexpr (ST) return P::stage(); else return G; }
+#define WG_SO(a) ((sg0_) >= 0 ? (a) - (sg0_) : (a))
+#define WG_SG wgrt::gsel<(sg0_ >= 0), P>(G)
+#define WG_STAGE_NEXT_(g0n, nw) constexpr int sn_ = ((nw) + 63) / 64; unsigned st_[sn_ > 0 ? sn_ : 1]; \
+  _Pragma("unroll") for (int i_ = 0; i_ < sn_; ++i_) st_[i_] = G[(g0n) + 64 * i_ + static_cast<int>(P::lane())];
+#define WG_STAGE_NEXT(...) WG_STAGE_NEXT_(__VA_ARGS__)
+#define WG_STAGE_PUT _Pragma("unroll") for (int i_ = 0; i_ < sn_; ++i_) P::stage()[64 * i_ + static_cast<int>(P::lane())] = st_[i_];
 #else
-#define WG_TOUCH_USE(t) (void)(t)
+#define WG_SO(a) (a)
+#define WG_SG G
+#define WG_STAGE_NEXT(...)
+#define WG_STAGE_PUT
 #endif
 
 // ---- forward substitution: target node `node` collects its rows (wave_ipm.h ldl_solve, first half) -------------------

@@ -31,6 +31,7 @@ __shared__ DNLP_WGLB const unsigned* g_wg_gen;             // work tables of the
 __shared__ double g_wg_red[2][wspec::kNW];                 // the wavefronts' partials of a reduction, two sets used in turn (one barrier per reduction)
 __shared__ double g_wg_redn[2][4][wspec::kNW];             // ... of up to four reductions side by side (sum_n / vmax_n)
 __shared__ unsigned g_wg_turn[wspec::kNW];                 // ... which set a wavefront's next reduction writes (every wavefront counts alike)
+__shared__ __attribute__((aligned(16))) unsigned g_wg_stage[wspec::kStageWords > 0 ? wspec::kStageWords : 4];      // the table the next narrow phase reads (wave_gen.h: staging)
 __shared__ double g_wg_clock;
 __shared__ int g_wg_inst;
 
@@ -123,6 +124,7 @@ struct WaveLanesWG {
     return (D*)(g_wg_vbase + off);
   }
   __device__ static I* tab(int off) { return g_wg_plan + off; }
+  __device__ static DNLP_WLDS unsigned* stage() { return (DNLP_WLDS unsigned*)g_wg_stage; }      // (wave_gen_rt.h WG_STAGE_PUT / WG_SG)
   __device__ static G gtab() { return g_wg_gen; }
 };
 
