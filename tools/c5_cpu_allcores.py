@@ -12,6 +12,13 @@ import os
 import sys
 import time
 
+# one thread per worker process, BEFORE numpy loads its BLAS: a GPU box shows 256 logical CPUs and grants 16 — every worker's
+# BLAS / OpenMP pool of 256 spinning threads is charged to that quota, and the cgroup then throttles the whole tree (measured
+# there: the same power-flow sample at 868, 8, 39 and 411 problems/s in four runs in a row, 1 000-2 000 thread-seconds
+# throttled per ten seconds of wall time)
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+    os.environ[_v] = "1"
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
