@@ -277,3 +277,41 @@ def test_per_template_kernel_takes_a_warm_start(gpu_required):
     assert same.sum() >= 0.97 * ok.sum()
     assert np.mean(warm.status == warm_own.status) >= 0.99
     pb.close()
+
+
+_TORCH_FIRST_CHILD = r"""
+import sys
+import torch                                  # FIRST: the process then compiles with the hiprtc / comgr torch ships
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import os
+import numpy as np
+import batch_problems as bp
+from dnlp_amd.batch import ParametricBatch
+os.environ["DNLP_WAVE_SPEC"] = "1"
+os.environ["DNLP_KERNEL_CACHE"] = sys.argv[2]          # (a cache of its own: the kernel is compiled here, by this compiler)
+prob, params, sample, _ = bp.template_path_planning()
+pb = ParametricBatch(prob, params)
+r = pb.solve(np.stack([sample(i) for i in range(256)]))
+print("RESULT", int(r.raw["launch"]["wave_spec"]), int(r.raw["launch"]["wave_form"]), int((r.status == 0).sum()), int(r.iterations.max()), flush=True)
+pb.close()
+"""
+
+
+@pytest.mark.gpu
+def test_workgroup_kernel_runs_in_a_process_that_imported_torch_first(gpu_required, tmp_path):
+    """bench.py and pytest import torch before this library: the generated kernels are then compiled by the ROCm 7.0 hiprtc
+    torch ships.  Its code object of the workgroup kernel once took 268 registers under a bound of 256 and aborted the queue at
+    its first launch (INVALID_ISA) — only there, the tools compile with the ROCm install's compiler.  The kernel compiled by
+    THAT compiler, from an empty cache, must run and solve what the library's other kernels solve."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cache = tmp_path / "kc"
+    cache.mkdir(mode=0o700)
+    e = dict(os.environ)
+    e.pop("DNLP_RTC_COMPILER", None)
+    r = subprocess.run([sys.executable, "-c", _TORCH_FIRST_CHILD, root, str(cache)], capture_output=True, text=True, timeout=600, env=e)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    row = [l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")][0]
+    assert row[1] == "1" and row[2] == "800", row                  # the per-template workgroup kernel, eight wavefronts per instance
+    assert int(row[3]) >= 245, row                                   # (250 of the first 256 instances are optimal under every kernel)
