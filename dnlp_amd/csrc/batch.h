@@ -487,7 +487,8 @@ struct BatchRunner {
     const double t0 = now_sec();
     if (wave_wg_blk.empty() && !wave_wg_plan()) return false;
     if (wave_wg_blk.size() < sizeof(WaveHdr) / 4) return false;
-    const WaveGen gen = wave_generate(wave_wg_blk, 64 * nwg);
+    const bool lds_vec_gen = !(std::getenv("DNLP_WAVE_WG_LDS") && std::atoi(std::getenv("DNLP_WAVE_WG_LDS")) == 0);
+    const WaveGen gen = wave_wg_generate(wave_wg_blk, nwg, lds_vec_gen);
     wave_wg_prof = std::getenv("DNLP_WAVE_SPEC_PROF") != nullptr;
     // (DNLP_WAVE_WG_BOUND: threads the register budget is sized for — 512 with four wavefronts: two workgroups per compute unit)
     const int bound = std::getenv("DNLP_WAVE_WG_BOUND") ? std::atoi(std::getenv("DNLP_WAVE_WG_BOUND")) : 512;

@@ -199,6 +199,7 @@ inline std::string wave_spec_source(const std::vector<i32>& blk, int nw, const W
   s += wave_spec_text("wave_hdr.h", wave_hdr_text);
   s += wave_spec_text("wave_args.h", wave_args_text);
   s += wave_spec_constants(blk, nw, gen.G.size(), prof, tables_global);
+  s += "namespace wspec { constexpr bool kSolve2Lds = false; }\n";      // (a workgroup-kernel matter: wave_wg_lds_ranges)
   s += wave_spec_text("wave_ops.h", wave_ops_text);
   s += wave_spec_text("wave_ipm.h", wave_ipm_text);
   s += wave_spec_text("wave_spec_kernel.h", wave_spec_kernel_text);      // (the lane policy P: the generated functions below are templates over it)
@@ -213,7 +214,8 @@ inline std::string wave_spec_source(const std::vector<i32>& blk, int nw, const W
 // memory): by priority the three arrays a single linear solve runs on (rhs sol res), the factor's values (svals), the three
 // arrays of the mu oracle's second system in front of them (the centering direction's cx czL czU: contiguous with rhs sol res
 // in wave_ipm.h layout) — as far as 160 KB minus the wavefronts' records hold them.  Two ranges of offsets.
-inline std::string wave_wg_lds_ranges(const std::vector<i32>& blk, int nwg, bool enable, int stage_words = 0) {
+// (window_doubles: the factorisation's LDS windows — wave_gen.h; free_doubles: what the chosen ranges leave)
+inline std::string wave_wg_lds_ranges(const std::vector<i32>& blk, int nwg, bool enable, int stage_words = 0, int window_doubles = 0, long long* free_doubles = nullptr) {
   const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(blk.data());
   typedef WaveIpm<WaveProbeLanes> W;
   W::WState S;
@@ -221,7 +223,7 @@ inline std::string wave_wg_lds_ranges(const std::vector<i32>& blk, int nwg, bool
   W::layout((W::WS*)&S, &h, blk.data(), vecs.data());
   auto ev = [](long long n) { return (n + 1) & ~1LL; };
   // (beside them: the wavefronts' records, the staged kernel arguments and reduction partials, the narrow phases' staging buffer)
-  const long long cap = (160 * 1024 - 2048 - static_cast<long long>(nwg) * 1600 - 1024 - 4LL * stage_words) / 8;
+  const long long cap = (160 * 1024 - 2048 - static_cast<long long>(nwg) * 1600 - 1024 - 4LL * stage_words) / 8 - window_doubles;
   const long long nm = ev(h.N + h.m), a0 = S.svals - vecs.data(), a1 = a0 + ev(h.sp_nvals);
   const long long c0 = S.rhs - vecs.data(), c1 = (S.res - vecs.data()) + nm, b0 = S.dir[2][0] - vecs.data();
   long long r0a = 0, r0b = 0, r1a = 0, r1b = 0;
@@ -231,10 +233,28 @@ inline std::string wave_wg_lds_ranges(const std::vector<i32>& blk, int nwg, bool
     else if ((a1 - a0) + (c1 - c0) <= cap) { r0a = a0; r0b = a1; r1a = c0; r1b = c1; }
     else if (c1 - c0 <= cap) { r0a = c0; r0b = c1; }
   }
+  if (free_doubles) *free_doubles = cap - ((r0b - r0a) + (r1b - r1a));
   char b[256];
   std::snprintf(b, sizeof b, "namespace wspec { constexpr int kLds0a = %lld, kLds0b = %lld, kLds1a = %lld, kLds1b = %lld, kLdsDoubles = %lld; }\n", r0a, r0b, r1a, r1b,
                 (r0b - r0a) + (r1b - r1a));
-  return b;
+  // (kSolve2Lds: BOTH systems' solve arrays are in LDS — then every right-hand side of ldl_solve is: wave_ipm.h)
+  const bool solve2 = r1b > r1a && r1a == b0 && r1b == c1;
+  return std::string(b) + (solve2 ? "namespace wspec { constexpr bool kSolve2Lds = true; }\n" : "namespace wspec { constexpr bool kSolve2Lds = false; }\n");
+}
+
+// the generated phases of a template's workgroup kernel: 64 x nwg lanes per phase, the factorisation's windows as large as the LDS
+// that the vectors' ranges leave (half each, at most 2048 doubles)
+inline WaveGen wave_wg_generate(const std::vector<i32>& blk, int nwg, bool lds_vectors = true) {
+  const bool on = !(std::getenv("DNLP_WAVE_WG_WINDOWS") && std::atoi(std::getenv("DNLP_WAVE_WG_WINDOWS")) == 0);
+  WaveGen plain = wave_generate(blk, 64 * nwg);          // (what the staging buffer takes is known only from a generation)
+  if (!on) return plain;
+  long long free_d = 0;
+  (void)wave_wg_lds_ranges(blk, nwg, lds_vectors, plain.stage_words, 0, &free_d);
+  // the rows' window first (a level's span is short), the products' window gets the rest
+  const int ww = static_cast<int>(std::max(0LL, std::min(free_d / 4, 2048LL))) & ~1;
+  const int sw = static_cast<int>(std::max(0LL, std::min(free_d - ww, 2048LL))) & ~1;
+  if (ww < 16) return plain;
+  return wave_generate(blk, 64 * nwg, ww, sw);
 }
 
 inline std::string wave_wg_source(const std::vector<i32>& blk, int nwg, const WaveGen& gen, bool prof = false, int bound_threads = 0, bool lds_vectors = true) {
@@ -270,8 +290,9 @@ inline std::string wave_wg_source(const std::vector<i32>& blk, int nwg, const Wa
   s += wave_spec_text("wave_args.h", wave_args_text);
   s += wave_spec_constants(blk, nwg, gen.G.size(), prof);
   s += "namespace wspec { constexpr int kWgBound = " + std::to_string(bound_threads > 64 * nwg ? bound_threads : 64 * nwg) + "; }\n";
-  s += "namespace wspec { constexpr int kStageWords = " + std::to_string(gen.stage_words) + "; }\n";
-  s += wave_wg_lds_ranges(blk, nwg, lds_vectors, gen.stage_words);
+  s += "namespace wspec { constexpr int kStageWords = " + std::to_string(gen.stage_words) + ", kWwin = " + std::to_string(gen.wwin_doubles) +
+       ", kSwin = " + std::to_string(gen.swin_doubles) + "; }\n";
+  s += wave_wg_lds_ranges(blk, nwg, lds_vectors, gen.stage_words, gen.wwin_doubles + gen.swin_doubles);
   s += wave_spec_text("wave_ops.h", wave_ops_text);
   s += wave_spec_text("wave_ipm.h", wave_ipm_text);
   s += wave_spec_text("wave_wg_kernel.h", wave_wg_kernel_text);

@@ -36,6 +36,7 @@ struct WaveGen {
   std::string code;               // namespace dnlp::wgen { ... } (function templates)
   int phases_factor = 0, phases_solve = 0;
   int stage_words = 0;            // LDS words of the staging buffer the narrow phases read their tables from (0: none)
+  int wwin_doubles = 0, swin_doubles = 0;      // LDS windows of the factorisation's unscaled rows / products (0: none)
 };
 
 namespace wgen_detail {
@@ -75,7 +76,8 @@ constexpr int kWideMaxTasks = 4, kWideMinEntries = 8;
 constexpr int kStageMaxWords = 2048;
 
 // LW: lanes that share a phase (64: one wavefront per instance; 64 x wavefronts of a workgroup per instance)
-inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
+// (ww_cap / sw_cap: doubles of LDS the caller can give the factorisation's two windows — see the level loop)
+inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64, int ww_cap = 0, int sw_cap = 0) {
   using namespace wgen_detail;
   const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(blk.data());
   if (wave_gen_refusal(h)[0]) throw std::runtime_error(wave_gen_refusal(h));
@@ -150,6 +152,26 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
          "  double nneg = 0.0, nzero = 0.0, bad = 0.0;\n");
   for (int lev = 0; lev < nlev; ++lev) {
     const int b0 = lev_off[lev], b1 = lev_off[lev + 1], r0 = lev_r[lev], r1 = lev_r[lev + 1];
+    // WINDOWS.  A level's struct rows are copied unscaled into w (scl2) for the products of its update triples (upd), which go
+    // into scr for the destinations' sums (gsum): w is as long as the factor and scr as the largest level's triples — they live
+    // in the slab when the vectors do (workgroup kernel), two dependent global round trips per level.  But a level touches only
+    // ITS rows' span of w and its own triples: when those fit the LDS windows the caller has room for, the level's phases get
+    // window pointers instead (WG_WW(lo): the window rebased to the span's first value; WG_SW) — path planning's 49 chain
+    // levels are 76 values and a few dozen triples each.
+    int wlo = 1 << 30, whi = 0;
+    for (int r = r0; r < r1; ++r) {
+      const int k = sblk[r], i = r - soff[k];
+      const bool one = bnode[2 * k + 1] < 0;
+      const int aa = one ? loff[k] + i : loff[k] + 2 * i;
+      wlo = std::min(wlo, aa); whi = std::max(whi, aa + (one ? 1 : 2));
+    }
+    const int lev_ntr = lev_t[lev + 1] - lev_t[lev];
+    const bool use_ww = r1 > r0 && whi - wlo <= ww_cap, use_sw = lev_ntr > 0 && lev_ntr <= sw_cap;
+    if (use_ww) out.wwin_doubles = std::max(out.wwin_doubles, (whi - wlo + 1) & ~1);
+    if (use_sw) out.swin_doubles = std::max(out.swin_doubles, (lev_ntr + 1) & ~1);
+    char wexp[48], sexp[16];
+    if (use_ww) std::snprintf(wexp, sizeof wexp, "WG_WW(%d)", wlo); else std::snprintf(wexp, sizeof wexp, "w");
+    std::snprintf(sexp, sizeof sexp, use_sw ? "WG_SW" : "scr");
     E.line("  // level %d: %d blocks, %d struct rows\n", lev, b1 - b0, r1 - r0);
     // pivots (inertia, tiny 1x1 pivots fixed in place) and — in the SAME phase — the struct rows scaled by the inverse pivot that
     // every row's lane recomputes from its block's D entries (wave_gen_rt.h scl2): no inverse is stored, the rows do not wait
@@ -178,7 +200,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
         if (aa > 0x7fff || doff[k] > 0x7fff) throw std::runtime_error("wave gen: a value index does not fit 15 bits");
         out.G[static_cast<size_t>(at + j)] = static_cast<uint32_t>(aa) | (static_cast<uint32_t>(doff[k]) << 15) | (static_cast<uint32_t>(one ? 1 : 2) << 30);
       }
-      E.line("    wgrt::scl2<WG_SO(%d), %d, %d>(lane, WG_SG, vals, w);\n", at, nact, kinds);
+      E.line("    wgrt::scl2<WG_SO(%d), %d, %d>(lane, WG_SG, vals, %s);\n", at, nact, kinds, wexp);
     }
     end_phase(nb_ps);
     if (r1 == r0) continue;
@@ -198,7 +220,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
         if (bv > 0x7fff) throw std::runtime_error("wave gen: a value index does not fit 15 bits");
         out.G[static_cast<size_t>(at + j)] = lo16(au) | (static_cast<uint32_t>(bv) << 16) | (two ? 0x80000000u : 0u);
       }
-      E.line("    wgrt::upd<WG_SO(%d), %d, %d, %d>(lane, WG_SG, vals, w, scr);\n", at, nact, q0, kinds);
+      E.line("    wgrt::upd<WG_SO(%d), %d, %d, %d>(lane, WG_SG, vals, %s, %s);\n", at, nact, q0, kinds, wexp, sexp);
       ++out.phases_factor;
     }
     end_phase(nb_upd);
@@ -214,7 +236,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
         out.G[static_cast<size_t>(at + j)] = lo16(gdst[gq]) | (lo16(cnt) << 16);
         out.G[static_cast<size_t>(at + nact + j)] = static_cast<uint32_t>(goff[gq] - t0);
       }
-      E.line("    wgrt::gsum<WG_SO(%d), %d, %d, %s>(lane, WG_SG, vals, scr);\n", at, nact, maxc, maxc != minc ? "true" : "false");
+      E.line("    wgrt::gsum<WG_SO(%d), %d, %d, %s>(lane, WG_SG, vals, %s);\n", at, nact, maxc, maxc != minc ? "true" : "false", sexp);
       ++out.phases_factor;
     }
     end_phase(nb_gs);
@@ -225,8 +247,10 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
          "  S->o_i[1] = static_cast<int>(nneg);\n  S->o_i[2] = static_cast<int>(nzero);\n  return bad == 0.0;\n}\n\n");
   // ================================================================ solve
   E.line("// wave_ipm.h ldl_solve for THIS template (TWO: a second right-hand side through the same phases)\n");
-  E.line("template <class P, bool TWO, class WS, class WD> DNLP_HD void ldl_solve(WS* S, WD* x, WD* y) {\n"
-         "  typedef WaveIpm<P> W;\n  WD* vals = WV(svals);\n  typename P::G G = P::gtab();\n");
+  // (XP / YP: the right-hand sides' pointer types — the workgroup kernel hands them over typed by where they live, LDS or the
+  //  slab: wave_ipm.h ldl_solve)
+  E.line("template <class P, bool TWO, class WS, class XP, class YP> DNLP_HD void ldl_solve(WS* S, XP x, YP y) {\n"
+         "  typedef WaveIpm<P> W;\n  typedef typename P::D WD;\n  const auto vals = wgrt::tvec<P, wspec::v_svals>(S);\n  typename P::G G = P::gtab();\n");
   // forward: level by level, a target per lane
   for (int lev = 1; lev < nlev; ++lev) {
     const int h0 = lev_f[lev], h1 = lev_f[lev + 1];
@@ -335,7 +359,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
     end_phase(nb_fwd);
   }
   close_region();
-  E.line("  if (wspec::k_tail_T > 0) W::tail_forward(S, x, y);\n");
+  E.line("  if (wspec::k_tail_T > 0) W::tail_forward(S, (WD*)x, (WD*)y);\n");
   // D^-1: every block (the tail's included), side by side
   E.line("  // D^-1, %d blocks\n", nblk);
   const bool nb_ds = begin_phase(nblk);
@@ -354,7 +378,7 @@ inline WaveGen wave_generate(const std::vector<i32>& blk, int LW = 64) {
   }
   end_phase(nb_ds);
   close_region();
-  E.line("  if (wspec::k_tail_T > 0) W::tail_backward(S, x, y);\n");
+  E.line("  if (wspec::k_tail_T > 0) W::tail_backward(S, (WD*)x, (WD*)y);\n");
   // backward: levels descending, a block per lane (blocks without struct rows subtract nothing)
   for (int lev = nlev - 1; lev >= 0; --lev) {
     const int b0 = lev_off[lev], b1 = lev_off[lev + 1];

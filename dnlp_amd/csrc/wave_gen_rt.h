@@ -60,6 +60,15 @@ typedef unsigned int u32;
 // narrow phase's table (whole 64-word rows from G[g0n] on) into registers, WG_STAGE_PUT stores them to the policy's LDS
 // buffer P::stage() at the phase's end; a phase whose table was staged (sg0_ >= 0: where the table starts in G) reads the
 // buffer (WG_SG) at offsets from its start (WG_SO).  On the host the lanes are played one after the other from G itself.
+// a vector of the instance by its LITERAL place, typed by where it lives when the policy's vectors are generic pointers (the
+// workgroup kernel: LDS or the slab — wave_ipm.h ldl_solve): the factor's values are read in every solve phase
+#if DNLP_DEVICE_PASS
+template <class P, int OFF, class WS>
+WG_INLINE auto tvec(WS* S) { if constexpr (P::lds_generic) return P::template vec_typed<OFF>(); else return P::vec(S, OFF); }
+#else
+template <class P, int OFF, class WS>
+WG_INLINE auto tvec(WS* S) { return P::vec(S, OFF); }
+#endif
 #if DNLP_DEVICE_PASS
 template <bool ST, class P, class GP>
 WG_INLINE auto gsel(GP G) { if constexpr (ST) return P::stage(); else return G; }
@@ -68,10 +77,14 @@ WG_INLINE auto gsel(GP G) { if constexpr (ST) return P::stage(); else return G; 
 #define WG_STAGE_NEXT_(g0n, nw) constexpr int sn_ = ((nw) + 63) / 64; unsigned st_[sn_ > 0 ? sn_ : 1]; \
   _Pragma("unroll") for (int i_ = 0; i_ < sn_; ++i_) st_[i_] = G[(g0n) + 64 * i_ + static_cast<int>(P::lane())];
 #define WG_STAGE_NEXT(...) WG_STAGE_NEXT_(__VA_ARGS__)
+#define WG_WW(lo) (P::wwin() - (lo))
+#define WG_SW (P::swin())
 #define WG_STAGE_PUT _Pragma("unroll") for (int i_ = 0; i_ < sn_; ++i_) P::stage()[64 * i_ + static_cast<int>(P::lane())] = st_[i_];
 #else
 #define WG_SO(a) (a)
 #define WG_SG G
+#define WG_WW(lo) w
+#define WG_SW scr
 #define WG_STAGE_NEXT(...)
 #define WG_STAGE_PUT
 #endif
@@ -80,8 +93,8 @@ WG_INLINE auto gsel(GP G) { if constexpr (ST) return P::stage(); else return G; 
 // descriptor (1 word): node | rows << 16.  entry e (2 words, [2e][lane], [2e + 1][lane]): a | u0 << 16, u1 | kind << 16
 // (kind 1: a row of a 1x1 block, value index a; 2: of a 2x2 block, values a, a + 1, sources u0, u1).
 // KINDS: 1 / 2 = every real entry of the phase is of that kind, 3 = mixed.  RAGGED: lanes differ in their number of rows.
-template <bool TWO, int D0, int E0, int NACT, int MAXC, int KINDS, bool RAGGED, class GP, class VP>
-WG_INLINE void fwd(int lane, GP G, const VP vals, VP x, VP y) {
+template <bool TWO, int D0, int E0, int NACT, int MAXC, int KINDS, bool RAGGED, class GP, class AP, class XP, class YP>
+WG_INLINE void fwd(int lane, GP G, const AP vals, XP x, YP y) {
   if (lane < NACT) {
     const u32 d = G[D0 + lane];
     const int node = static_cast<int>(d & 0xffffu), cnt = static_cast<int>(d >> 16);
@@ -126,8 +139,8 @@ WG_INLINE void fwd(int lane, GP G, const VP vals, VP x, VP y) {
 //  the wavefront's fixed reduction tree.  entry e (2 words): as in fwd.  The caller chains the slots of a
 // target with more than 64 rows through acc / acc2 and subtracts once (fwdw_fin).
 // (W: the wavefront of the workgroup that runs this target — 0 unless the generator deals a level's targets out: WG_WAVE(W))
-template <class P, bool TWO, int E0, int CNT, int KINDS, int W = 0, class GP, class VP>
-WG_INLINE void fwdw(GP G, const VP vals, const VP x, const VP y, double& acc, double& acc2) {
+template <class P, bool TWO, int E0, int CNT, int KINDS, int W = 0, class GP, class AP, class XP, class YP>
+WG_INLINE void fwdw(GP G, const AP vals, const XP x, const YP y, double& acc, double& acc2) {
 #if DNLP_DEVICE_PASS
   const int lane = P::lane() - 64 * W;
   double p = 0.0, p2 = 0.0;
@@ -161,8 +174,8 @@ WG_INLINE void fwdw(GP G, const VP vals, const VP x, const VP y, double& acc, do
   }
 #endif
 }
-template <class P, bool TWO, int NODE, int W = 0, class VP>
-WG_INLINE void fwdw_fin(VP x, VP y, double acc, double acc2) {
+template <class P, bool TWO, int NODE, int W = 0, class XP, class YP>
+WG_INLINE void fwdw_fin(XP x, YP y, double acc, double acc2) {
 #if DNLP_DEVICE_PASS
   if (P::lane() == 64 * W) {
 #else
@@ -176,8 +189,8 @@ WG_INLINE void fwdw_fin(VP x, VP y, double acc, double acc2) {
 // ---- ... TWO targets of at most 32 rows in one phase: target A on lanes 0 .. 31, target B on lanes 32 .. 63 (table: 64 + 64 words,
 // zero where a half has fewer rows).  Each target's products are added in row order on the host, by the wavefront's reduction
 // tree on the device (the other half contributes zeros).
-template <class P, bool TWO, int E0, int CNT_A, int CNT_B, int KINDS, int NODE_A, int NODE_B, class GP, class VP>
-WG_INLINE void fwdw2(GP G, const VP vals, VP x, VP y) {
+template <class P, bool TWO, int E0, int CNT_A, int CNT_B, int KINDS, int NODE_A, int NODE_B, class GP, class AP, class XP, class YP>
+WG_INLINE void fwdw2(GP G, const AP vals, XP x, YP y) {
   double accA = 0.0, accB = 0.0, acc2A = 0.0, acc2B = 0.0;
 #if DNLP_DEVICE_PASS
   const int lane = P::lane();
@@ -226,8 +239,8 @@ WG_INLINE void fwdw2(GP G, const VP vals, VP x, VP y) {
 
 // ---- backward substitution, WIDE form: ONE block whose many struct rows lie across the lanes -------------------------------
 // entry i (1 word): source node u.  ONE: a 1x1 block (values LOF + i), else a 2x2 block (LOF + 2 i, LOF + 2 i + 1).
-template <class P, bool TWO, bool ONE, int E0, int CNT, int LOF, int I0, class GP, class VP>
-WG_INLINE void bwdw(GP G, const VP vals, const VP x, const VP y, double& a0, double& a1, double& c0, double& c1) {
+template <class P, bool TWO, bool ONE, int E0, int CNT, int LOF, int I0, class GP, class AP, class XP, class YP>
+WG_INLINE void bwdw(GP G, const AP vals, const XP x, const YP y, double& a0, double& a1, double& c0, double& c1) {
 #if DNLP_DEVICE_PASS
   const int lane = P::lane();
   double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;
@@ -262,8 +275,8 @@ WG_INLINE void bwdw(GP G, const VP vals, const VP x, const VP y, double& a0, dou
   }
 #endif
 }
-template <class P, bool TWO, bool ONE, int U0, int U1, class VP>
-WG_INLINE void bwdw_fin(VP x, VP y, double a0, double a1, double c0, double c1) {
+template <class P, bool TWO, bool ONE, int U0, int U1, class XP, class YP>
+WG_INLINE void bwdw_fin(XP x, YP y, double a0, double a1, double c0, double c1) {
 #if DNLP_DEVICE_PASS
   if (P::lane() == 0) {
 #else
@@ -280,8 +293,8 @@ WG_INLINE void bwdw_fin(VP x, VP y, double a0, double a1, double c0, double c1) 
 
 // ---- D^-1 on every block (wave_ipm.h dsolve) -------------------------------------------------------------------------
 // descriptor (2 words): u0 | u1 << 16 (u1 = 0xffff: a 1x1 block), doff
-template <bool TWO, int D0, int NACT, int KINDS, class GP, class VP>
-WG_INLINE void dsol(int lane, GP G, const VP vals, VP x, VP y) {
+template <bool TWO, int D0, int NACT, int KINDS, class GP, class AP, class XP, class YP>
+WG_INLINE void dsol(int lane, GP G, const AP vals, XP x, YP y) {
   if (lane < NACT) {
     const u32 w0 = G[D0 + lane], w1 = G[D0 + NACT + lane];
     const int u0 = static_cast<int>(w0 & 0xffffu), u1r = static_cast<int>(w0 >> 16), dof = static_cast<int>(w1);
@@ -310,8 +323,8 @@ WG_INLINE void dsol(int lane, GP G, const VP vals, VP x, VP y) {
 // ---- backward substitution: a block subtracts its struct rows' share (wave_ipm.h ldl_solve, second half) ---------------
 // descriptor (2 words): u0 | u1 << 16 (0xffff: 1x1), loff | rows << 16.  entries: source node u, two per word
 // ([e / 2][lane], low half first).
-template <bool TWO, int D0, int E0, int NACT, int MAXC, int KINDS, bool RAGGED, class GP, class VP>
-WG_INLINE void bwd(int lane, GP G, const VP vals, VP x, VP y) {
+template <bool TWO, int D0, int E0, int NACT, int MAXC, int KINDS, bool RAGGED, class GP, class AP, class XP, class YP>
+WG_INLINE void bwd(int lane, GP G, const AP vals, XP x, YP y) {
   if (lane < NACT) {
     const u32 w0 = G[D0 + lane], w1 = G[D0 + NACT + lane];
     const int u0 = static_cast<int>(w0 & 0xffffu), u1r = static_cast<int>(w0 >> 16);
@@ -405,8 +418,8 @@ WG_INLINE void scl(int lane, GP G, VP vals, VP w, const VP dinv) {
 // sp_pivot, the tiny-pivot substitutions included): the rows no longer wait for the pivots' phase — pivots (which still count
 // the inertia and fix a tiny 1x1 pivot in place) and row scaling are ONE phase, a dependent round trip less per level.
 // descriptor (1 word): a | doff << 15 | kind << 30
-template <int D0, int NACT, int KINDS, class GP, class VP>
-WG_INLINE void scl2(int lane, GP G, VP vals, VP w) {
+template <int D0, int NACT, int KINDS, class GP, class VP, class WP>
+WG_INLINE void scl2(int lane, GP G, VP vals, WP w) {
   if (lane < NACT) {
     const u32 w0 = G[D0 + lane];
     const int a = static_cast<int>(w0 & 0x7fffu), dof = static_cast<int>((w0 >> 15) & 0x7fffu);
@@ -454,8 +467,8 @@ WG_INLINE void piv2(int lane, GP G, VP vals, double& nneg, double& nzero, double
 
 // ---- factorisation: the products of a level's update triples, side by side into the scratch array (sp_update) -------------
 // one word per triple: au | av << 16 | (2x2 pivot block) << 31; the triple's place in the scratch array is Q0 + lane
-template <int D0, int NACT, int Q0, int KINDS, class GP, class VP>
-WG_INLINE void upd(int lane, GP G, const VP vals, const VP w, VP scr) {
+template <int D0, int NACT, int Q0, int KINDS, class GP, class VP, class WP, class SP>
+WG_INLINE void upd(int lane, GP G, const VP vals, const WP w, SP scr) {
   if (lane < NACT) {
     const u32 t = G[D0 + lane];
     const int au = static_cast<int>(t & 0xffffu), av = static_cast<int>((t >> 16) & 0x7fffu);
@@ -469,8 +482,8 @@ WG_INLINE void upd(int lane, GP G, const VP vals, const VP w, VP scr) {
 
 // ---- factorisation: every destination subtracts its run of products, added in storage order (run_sum) --------------------
 // descriptor (2 words): dst | count << 16, start of the run in the scratch array
-template <int D0, int NACT, int MAXC, bool RAGGED, class GP, class VP>
-WG_INLINE void gsum(int lane, GP G, VP vals, const VP scr) {
+template <int D0, int NACT, int MAXC, bool RAGGED, class GP, class VP, class SP>
+WG_INLINE void gsum(int lane, GP G, VP vals, const SP scr) {
   if (lane < NACT) {
     const u32 w0 = G[D0 + lane], w1 = G[D0 + NACT + lane];
     const int dst = static_cast<int>(w0 & 0xffffu), cnt = static_cast<int>(w0 >> 16), q0 = static_cast<int>(w1);

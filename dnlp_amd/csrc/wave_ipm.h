@@ -166,7 +166,7 @@ struct WMeasures { double theta, phi, chk; };
 // building blocks); defined behind this header in the same translation unit
 namespace wgen {
 template <class P, class WS> DNLP_HD bool ldl_factor(WS* S);
-template <class P, bool TWO, class WS, class WD> DNLP_HD void ldl_solve(WS* S, WD* x, WD* y);
+template <class P, bool TWO, class WS, class XP, class YP> DNLP_HD void ldl_solve(WS* S, XP x, YP y);
 template <class P, bool TWO, class WS, class WD> DNLP_HD void kkt_residual(WS* S, double dw, const WD* v, const WD* rhsv, WD* out, const WD* v2, const WD* rhsv2, WD* out2,
                                                                         double& en, double& sn, double& en2, double& sn2);
 template <class P, class WS, class WD> DNLP_HD void jac_tmult(WS* S, const WD* v, WD* out);
@@ -848,7 +848,30 @@ struct WaveIpm {
   // chain of level barriers for both; each vector sees exactly the operations of a solve of its own)
   DNLP_WFN DNLP_HD static void ldl_solve(WS* S, WD* x, WD* y) {
 #ifdef DNLP_WAVE_GEN
-    { W_P0(); if (y) wgen::ldl_solve<P, true>(S, x, y); else wgen::ldl_solve<P, false>(S, x, y); W_P1(7); return; }
+    {
+      W_P0();
+#if DNLP_DEVICE_PASS
+      // a policy whose vectors are GENERIC pointers (the workgroup kernel: the solves' arrays in LDS, the rest in the slab) hands
+      // the right-hand sides over typed by where they live: through a generic pointer every access is a FLAT instruction —
+      // 1 576 of them in path planning's solve — whose wait is for global memory AND LDS, so an LDS operand also waited for the
+      // table words the phase had just sent for.  (wspec::kSolve2Lds: the second system's arrays are in LDS too — then no
+      // right-hand side is ever in the slab; else x may be the second system's residual, y always is.)
+      if constexpr (P::lds_generic) {
+        typedef DNLP_WLDS double* LP;
+        typedef DNLP_WGLB double* QP;
+        if constexpr (wspec::kSolve2Lds) {
+          if (y) wgen::ldl_solve<P, true>(S, (LP)x, (LP)y); else wgen::ldl_solve<P, false>(S, (LP)x, (LP)nullptr);
+        } else if (__builtin_amdgcn_is_shared(x)) {
+          if (y) wgen::ldl_solve<P, true>(S, (LP)x, (QP)y); else wgen::ldl_solve<P, false>(S, (LP)x, (LP)nullptr);
+        } else {
+          if (y) wgen::ldl_solve<P, true>(S, (QP)x, (QP)y); else wgen::ldl_solve<P, false>(S, (QP)x, (QP)nullptr);
+        }
+      } else
+#endif
+      if (y) wgen::ldl_solve<P, true>(S, x, y); else wgen::ldl_solve<P, false>(S, x, y);
+      W_P1(7);
+      return;
+    }
 #endif
     W_P0();
     const int L = P::lanes, me = P::lane();

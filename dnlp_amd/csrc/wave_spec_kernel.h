@@ -40,6 +40,7 @@ struct WaveLanesSpec {
   typedef typename WSel<wspec::kTabGlobal, DNLP_WGLB const unsigned*, DNLP_WLDS const unsigned*>::type G;
   static constexpr int lanes = 64;
   static constexpr bool hoist = false;
+  static constexpr bool lds_generic = false;      // (vectors are LDS-typed pointers: wave_ipm.h ldl_solve)
   __device__ static int lane() { return static_cast<int>(threadIdx.x & 63u); }
   __device__ static void sync() { wave_sync(); }
   __device__ static double sum(double v) { return wave_all_sum(v); }

@@ -32,6 +32,8 @@ __shared__ double g_wg_red[2][wspec::kNW];                 // the wavefronts' pa
 __shared__ double g_wg_redn[2][4][wspec::kNW];             // ... of up to four reductions side by side (sum_n / vmax_n)
 __shared__ unsigned g_wg_turn[wspec::kNW];                 // ... which set a wavefront's next reduction writes (every wavefront counts alike)
 __shared__ __attribute__((aligned(16))) unsigned g_wg_stage[wspec::kStageWords > 0 ? wspec::kStageWords : 4];      // the table the next narrow phase reads (wave_gen.h: staging)
+__shared__ __attribute__((aligned(16))) double g_wg_wwin[wspec::kWwin > 0 ? wspec::kWwin : 2];      // a level's unscaled rows / its products (wave_gen.h: windows)
+__shared__ __attribute__((aligned(16))) double g_wg_swin[wspec::kSwin > 0 ? wspec::kSwin : 2];
 __shared__ double g_wg_clock;
 __shared__ int g_wg_inst;
 
@@ -41,6 +43,7 @@ struct WaveLanesWG {
   typedef DNLP_WGLB const unsigned* G;
   static constexpr int lanes = 64 * wspec::kNW;
   static constexpr bool hoist = true;         // (vectors in global memory: wave_ipm.h quality())
+  static constexpr bool lds_generic = true;   // (vectors are generic pointers into LDS or the slab: wave_ipm.h ldl_solve types the solve's right-hand sides)
   __device__ static int lane() { return static_cast<int>(threadIdx.x); }
   __device__ static void sync() { __syncthreads(); }
   // every wavefront gets the same bits: its own DPP total, then the wavefronts' totals added in wavefront order
@@ -123,7 +126,15 @@ struct WaveLanesWG {
     if (off >= wspec::kLds1a && off < wspec::kLds1b) return (D*)(g_wg_lds + (wspec::kLds0b - wspec::kLds0a) + (off - wspec::kLds1a));
     return (D*)(g_wg_vbase + off);
   }
+  // ... with its address space in the type (a literal place: wave_gen_rt.h tvec)
+  template <int OFF> __device__ static auto vec_typed() {
+    if constexpr (OFF >= wspec::kLds0a && OFF < wspec::kLds0b) return (DNLP_WLDS double*)(g_wg_lds + (OFF - wspec::kLds0a));
+    else if constexpr (OFF >= wspec::kLds1a && OFF < wspec::kLds1b) return (DNLP_WLDS double*)(g_wg_lds + (wspec::kLds0b - wspec::kLds0a) + (OFF - wspec::kLds1a));
+    else return (WGlbD*)(g_wg_vbase + OFF);
+  }
   __device__ static I* tab(int off) { return g_wg_plan + off; }
+  __device__ static DNLP_WLDS double* wwin() { return (DNLP_WLDS double*)g_wg_wwin; }
+  __device__ static DNLP_WLDS double* swin() { return (DNLP_WLDS double*)g_wg_swin; }
   __device__ static DNLP_WLDS unsigned* stage() { return (DNLP_WLDS unsigned*)g_wg_stage; }      // (wave_gen_rt.h WG_STAGE_PUT / WG_SG)
   __device__ static G gtab() { return g_wg_gen; }
 };

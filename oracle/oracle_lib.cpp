@@ -225,7 +225,7 @@ extern "C" long long orc_wave_wg_source(orc_problem* vp, int nwg, char* buf, lon
     const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(blk.data());
     if (wave_gen_refusal(h)[0]) { tls_error() = wave_gen_refusal(h); return -4; }
     if (nwg < 1 || nwg > 8) { tls_error() = "1 .. 8 wavefronts per workgroup"; return -5; }
-    const WaveGen gen = wave_generate(blk, 64 * nwg);
+    const WaveGen gen = wave_wg_generate(blk, nwg);
     const std::string src = wave_wg_source(blk, nwg, gen);
     if (buf && cap > static_cast<long long>(src.size())) { std::memcpy(buf, src.data(), src.size()); buf[src.size()] = 0; }
     return static_cast<long long>(src.size());)
@@ -247,7 +247,9 @@ extern "C" long long orc_wave_gen_host_source(orc_problem* vp, int lanes, char* 
     const char* why = wave_plan_refusal(t, &p->sparse_plan);
     if (why[0]) { tls_error() = why; return -2; }
     const std::vector<i32> blk = build_wave_plan(&p->ex, t, p->sparse_plan, wave_layout_of(t));
-    const WaveGen gen = wave_generate(blk, lanes > 0 ? lanes : 64);
+    // (more than 64 lanes: the workgroup kernel's forms — staging and the factorisation's windows are in the text; on the host
+    //  their macros name the arrays themselves)
+    const WaveGen gen = wave_generate(blk, lanes > 0 ? lanes : 64, lanes > 64 ? 2048 : 0, lanes > 64 ? 2048 : 0);
     std::string s;
     s += "#include \"ipm_core.h\"\n#include \"wave_plan.h\"\n";
     s += wave_spec_constants(blk, 1);

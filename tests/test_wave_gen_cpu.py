@@ -80,7 +80,7 @@ def test_generated_text_is_calls_with_literal_arguments():
     hb = GenHostBatch(ParametricBatch(prob, params))
     src = hb.source
     assert "template <class P, class WS> DNLP_HD bool ldl_factor(WS* S)" in src
-    assert "template <class P, bool TWO, class WS, class WD> DNLP_HD void ldl_solve(WS* S, WD* x, WD* y)" in src
+    assert "template <class P, bool TWO, class WS, class XP, class YP> DNLP_HD void ldl_solve(WS* S, XP x, YP y)" in src
     # five levels: pivots + scaling (one phase) + products + sums for the first four, pivots only for the last; forward levels 1..4,
     # D^-1 (all 52 blocks in one phase), backward levels 3..0; level 0 has 80 struct rows: two 64-lane slots of scaling
     # (pivots and row scaling share a phase: the rows' lanes recompute the inverse pivot)
