@@ -419,7 +419,7 @@ def bench_c5(args):
                        "problems_per_s_kernel_only": B * args.steps / ksec_all if ksec_all > 0 else None,
                        "gathered_ranks": gathered_ranks, "gathered_bytes": gbytes // max(args.steps, 1),
                        "collective_backend": backend_name},
-            "roofline": {"bound": "hbm", "kernel": (("dnlp_wave_wg_kernel (per-template, a workgroup per instance)" if (launch_info or {}).get("lds_mode", 3) == 0 else
+            "roofline": {"bound": "hbm", "kernel": (("dnlp_wave_wg_kernel (per-template, a workgroup per instance)" if ((launch_info or {}).get("wave_wg") or (launch_info or {}).get("lds_mode", 3) == 0) else
                                                       "dnlp_wave_spec_kernel (per-template: generated LDL^T / residual / CSR phases)")
                                                      if (launch_info or {}).get("wave_spec") else
                                                      "wave_batch_kernel" if (launch_info or {}).get("wave_form") else "batch_solve_kernel") +

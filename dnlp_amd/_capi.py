@@ -606,10 +606,12 @@ class ProblemHandle:
             info = np.zeros(8, dtype=np.int32)
             if self.api.batch_launch_info(self.ptr, info.ctypes.data_as(_i32_p)) == 0:
                 # (lds_mode of a wavefront-solver launch: 2 x state in LDS + plan in LDS, + 4 when the kernel was the one
-                #  compiled for this template at run time — csrc/wave_codegen.h)
+                #  compiled for this template at run time — csrc/wave_codegen.h — + 8 when that was the workgroup-per-instance
+                #  kernel: `lanes` / 64 wavefronts per instance, `per_cu` workgroups per compute unit)
                 out["launch"] = {"grid": int(info[0]), "lanes": int(info[1]), "lds_mode": int(info[2]) & 3, "per_cu": int(info[3]),
                                  "packed": bool(info[4]), "longest_first": bool(info[5]), "wave_form": int(info[6]),
-                                 "wave_refused": int(info[7]), "wave_spec": bool(int(info[6]) and (int(info[2]) & 4))}
+                                 "wave_refused": int(info[7]), "wave_spec": bool(int(info[6]) and (int(info[2]) & 4)),
+                                 "wave_wg": bool(int(info[6]) and (int(info[2]) & 8))}
         if want_duals:
             out.update({"mult_g": mg[:, :self.m], "mult_x_L": zl, "mult_x_U": zu})
         return out

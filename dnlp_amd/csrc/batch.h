@@ -482,18 +482,28 @@ struct BatchRunner {
     wave_wg.tried = true;
     const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(wave_blk.data());
     if (wave_gen_refusal(h)[0]) return false;
-    int nwg = std::getenv("DNLP_WAVE_WG_WAVES") ? std::atoi(std::getenv("DNLP_WAVE_WG_WAVES")) : 8;
-    if (nwg < 1 || nwg > 8) nwg = 8;
+    // A template whose state EXCEEDS LDS: eight wavefronts per instance, the compute unit to itself.  A template whose state
+    // fits but leaves room for only one or two wavefronts per compute unit in the one-wavefront kernels (circle packing n = 10:
+    // 74 KB per instance) can take this kernel too — TWO wavefronts per instance, FOUR workgroups per compute unit with a
+    // quarter of the LDS each (hot arrays there, the rest in the slab): eight wavefronts per unit instead of two, 173 us per
+    // iteration instead of 138 — 102 k problems/s at 8192 instances against 71 k (solve_wave takes it from 8 instances per
+    // compute unit on; at 1024 the one-wavefront kernel is as fast: 39 k).
+    int sl_form = 0;
+    { int nw0 = 0, pl0 = 0; wave_form(nw0, sl_form, pl0); }
+    int nwg = std::getenv("DNLP_WAVE_WG_WAVES") ? std::atoi(std::getenv("DNLP_WAVE_WG_WAVES")) : (sl_form ? 2 : 8);
+    if (nwg < 1 || nwg > 8) nwg = sl_form ? 2 : 8;
+    int share = std::getenv("DNLP_WAVE_WG_SHARE") ? std::atoi(std::getenv("DNLP_WAVE_WG_SHARE")) : (sl_form ? 4 : 1);
+    if (share < 1 || share > 8) share = 1;
     const double t0 = now_sec();
     if (wave_wg_blk.empty() && !wave_wg_plan()) return false;
     if (wave_wg_blk.size() < sizeof(WaveHdr) / 4) return false;
     const bool lds_vec_gen = !(std::getenv("DNLP_WAVE_WG_LDS") && std::atoi(std::getenv("DNLP_WAVE_WG_LDS")) == 0);
-    const WaveGen gen = wave_wg_generate(wave_wg_blk, nwg, lds_vec_gen);
+    const WaveGen gen = wave_wg_generate(wave_wg_blk, nwg, lds_vec_gen, share);
     wave_wg_prof = std::getenv("DNLP_WAVE_SPEC_PROF") != nullptr;
     // (DNLP_WAVE_WG_BOUND: threads the register budget is sized for — 512 with four wavefronts: two workgroups per compute unit)
     const int bound = std::getenv("DNLP_WAVE_WG_BOUND") ? std::atoi(std::getenv("DNLP_WAVE_WG_BOUND")) : 512;
     const bool lds_vec = !(std::getenv("DNLP_WAVE_WG_LDS") && std::atoi(std::getenv("DNLP_WAVE_WG_LDS")) == 0);
-    const std::string src = wave_wg_source(wave_wg_blk, nwg, gen, wave_wg_prof, bound, lds_vec);
+    const std::string src = wave_wg_source(wave_wg_blk, nwg, gen, wave_wg_prof, bound, lds_vec, share);
     if (!wave_wg.load(src, "dnlp_wave_wg_kernel")) {
       std::fprintf(stderr, "[dnlp] workgroup-per-instance batch kernel not available (the library's own kernel is used): %s\n", wave_wg.log.substr(0, 2000).c_str());
       return false;
@@ -537,7 +547,8 @@ struct BatchRunner {
           DNLP_HIP_CHECK(hipMemcpy(d_wave_blk16, narrow16.data(), narrow16.size() * sizeof(int16_t), hipMemcpyHostToDevice));
         }
         // a template whose state exceeds LDS goes through the workgroup-per-instance kernel: its plan block now, too
-        { int nw = 0, sl = 0, pl = 0; wave_form(nw, sl, pl); if (!sl && !wave_gen_refusal(*reinterpret_cast<const WaveHdr*>(wave_blk.data()))[0]) wave_wg_plan(); }
+        // (... and one whose state fits only once or twice per compute unit: wave_wg_prepare's second form)
+        { int nw = 0, sl = 0, pl = 0; wave_form(nw, sl, pl); if ((!sl || nw <= 2) && !wave_gen_refusal(*reinterpret_cast<const WaveHdr*>(wave_blk.data()))[0]) wave_wg_plan(); }
       }
     }
     return !wave_blk.empty();
@@ -1244,7 +1255,18 @@ struct BatchRunner {
       }
     }
     // a template whose state exceeds LDS: a workgroup per instance through the generated phases when the kernel is there
-    const bool wg = !sl && !std::getenv("DNLP_WAVE_FORM") && wave_wg_prepare(batch);
+    // ... and a template whose state fits, but only once or twice per compute unit: from eight instances per compute unit on
+    // (wave_wg_prepare: two wavefronts per instance, four workgroups per unit).  DNLP_WAVE_WG_SMALL=0 never, =1 at any size.
+    bool wg_small = false;
+    if (sl && !std::getenv("DNLP_WAVE_FORM")) {
+      const int per_unit = spec ? wave_spec_nw : nw;                    // (wavefronts = instances per compute unit of the kernel above)
+      const char* ws = std::getenv("DNLP_WAVE_WG_SMALL");
+      const int wsm = ws ? std::atoi(ws) : -1;
+      wg_small = wsm != 0 && per_unit <= 2 && (wsm == 1 || batch >= 8 * this->ncu);
+    }
+    const bool wg = (!sl || wg_small) && !std::getenv("DNLP_WAVE_FORM") && wave_wg_prepare(batch);
+    if (wg) spec = false;
+    if (wg) { sl = 0; pl = 0; }      // (the kernel has its own static LDS; the form reported is 100 x wavefronts per instance)
     if (wg) { nw = wave_wg_nw; w.gen = d_wave_wg_gen; w.gen_words = wave_wg_gen_words; w.blk = d_wave_wg_blk; w.blk_ints = static_cast<int>(wave_wg_blk.size()); }
     int per_cu = 1;
     const unsigned lds = static_cast<unsigned>((pl ? plan_b : 0) + (sl ? static_cast<size_t>(nw) * state_b : 0));
@@ -1324,7 +1346,7 @@ struct BatchRunner {
       DNLP_HIP_CHECK(hipStreamSynchronize(stream));
       w.order = d_ord;
     }
-    last_grid = grid; last_threads = 64 * nw; last_lds_mode = 2 * sl + pl + ((spec || wg) ? 4 : 0); last_per_cu = wg ? per_cu : nw * per_cu; last_packed = false;
+    last_grid = grid; last_threads = 64 * nw; last_lds_mode = (wg ? 0 : 2 * sl + pl) + ((spec || wg) ? 4 : 0) + (wg ? 8 : 0) /* + 8: the workgroup-per-instance kernel */; last_per_cu = wg ? per_cu : nw * per_cu; last_packed = false;
     last_wave = 100 * nw + 10 * sl + pl;
     last_wave_spec = spec;
     if (std::getenv("DNLP_BATCH_DEBUG"))

@@ -215,7 +215,9 @@ inline std::string wave_spec_source(const std::vector<i32>& blk, int nw, const W
 // arrays of the mu oracle's second system in front of them (the centering direction's cx czL czU: contiguous with rhs sol res
 // in wave_ipm.h layout) — as far as 160 KB minus the wavefronts' records hold them.  Two ranges of offsets.
 // (window_doubles: the factorisation's LDS windows — wave_gen.h; free_doubles: what the chosen ranges leave)
-inline std::string wave_wg_lds_ranges(const std::vector<i32>& blk, int nwg, bool enable, int stage_words = 0, int window_doubles = 0, long long* free_doubles = nullptr) {
+// (share: workgroups meant to share a compute unit — each gets 160 KB / share)
+inline std::string wave_wg_lds_ranges(const std::vector<i32>& blk, int nwg, bool enable, int stage_words = 0, int window_doubles = 0, long long* free_doubles = nullptr,
+                                      int share = 1) {
   const WaveHdr& h = *reinterpret_cast<const WaveHdr*>(blk.data());
   typedef WaveIpm<WaveProbeLanes> W;
   W::WState S;
@@ -223,7 +225,7 @@ inline std::string wave_wg_lds_ranges(const std::vector<i32>& blk, int nwg, bool
   W::layout((W::WS*)&S, &h, blk.data(), vecs.data());
   auto ev = [](long long n) { return (n + 1) & ~1LL; };
   // (beside them: the wavefronts' records, the staged kernel arguments and reduction partials, the narrow phases' staging buffer)
-  const long long cap = (160 * 1024 - 2048 - static_cast<long long>(nwg) * 1600 - 1024 - 4LL * stage_words) / 8 - window_doubles;
+  const long long cap = (160 * 1024 / (share > 0 ? share : 1) - 2048 - static_cast<long long>(nwg) * 1600 - 1024 - 4LL * stage_words) / 8 - window_doubles;
   const long long nm = ev(h.N + h.m), a0 = S.svals - vecs.data(), a1 = a0 + ev(h.sp_nvals);
   const long long c0 = S.rhs - vecs.data(), c1 = (S.res - vecs.data()) + nm, b0 = S.dir[2][0] - vecs.data();
   long long r0a = 0, r0b = 0, r1a = 0, r1b = 0;
@@ -244,12 +246,12 @@ inline std::string wave_wg_lds_ranges(const std::vector<i32>& blk, int nwg, bool
 
 // the generated phases of a template's workgroup kernel: 64 x nwg lanes per phase, the factorisation's windows as large as the LDS
 // that the vectors' ranges leave (half each, at most 2048 doubles)
-inline WaveGen wave_wg_generate(const std::vector<i32>& blk, int nwg, bool lds_vectors = true) {
+inline WaveGen wave_wg_generate(const std::vector<i32>& blk, int nwg, bool lds_vectors = true, int share = 1) {
   const bool on = !(std::getenv("DNLP_WAVE_WG_WINDOWS") && std::atoi(std::getenv("DNLP_WAVE_WG_WINDOWS")) == 0);
   WaveGen plain = wave_generate(blk, 64 * nwg);          // (what the staging buffer takes is known only from a generation)
   if (!on) return plain;
   long long free_d = 0;
-  (void)wave_wg_lds_ranges(blk, nwg, lds_vectors, plain.stage_words, 0, &free_d);
+  (void)wave_wg_lds_ranges(blk, nwg, lds_vectors, plain.stage_words, 0, &free_d, share);
   // the rows' window first (a level's span is short), the products' window gets the rest
   const int ww = static_cast<int>(std::max(0LL, std::min(free_d / 4, 2048LL))) & ~1;
   const int sw = static_cast<int>(std::max(0LL, std::min(free_d - ww, 2048LL))) & ~1;
@@ -257,7 +259,7 @@ inline WaveGen wave_wg_generate(const std::vector<i32>& blk, int nwg, bool lds_v
   return wave_generate(blk, 64 * nwg, ww, sw);
 }
 
-inline std::string wave_wg_source(const std::vector<i32>& blk, int nwg, const WaveGen& gen, bool prof = false, int bound_threads = 0, bool lds_vectors = true) {
+inline std::string wave_wg_source(const std::vector<i32>& blk, int nwg, const WaveGen& gen, bool prof = false, int bound_threads = 0, bool lds_vectors = true, int share = 1) {
   static const char* atom_math_text =
 #include "atom_math_src.inc"
       ;
@@ -292,7 +294,7 @@ inline std::string wave_wg_source(const std::vector<i32>& blk, int nwg, const Wa
   s += "namespace wspec { constexpr int kWgBound = " + std::to_string(bound_threads > 64 * nwg ? bound_threads : 64 * nwg) + "; }\n";
   s += "namespace wspec { constexpr int kStageWords = " + std::to_string(gen.stage_words) + ", kWwin = " + std::to_string(gen.wwin_doubles) +
        ", kSwin = " + std::to_string(gen.swin_doubles) + "; }\n";
-  s += wave_wg_lds_ranges(blk, nwg, lds_vectors, gen.stage_words, gen.wwin_doubles + gen.swin_doubles);
+  s += wave_wg_lds_ranges(blk, nwg, lds_vectors, gen.stage_words, gen.wwin_doubles + gen.swin_doubles, nullptr, share);
   s += wave_spec_text("wave_ops.h", wave_ops_text);
   s += wave_spec_text("wave_ipm.h", wave_ipm_text);
   s += wave_spec_text("wave_wg_kernel.h", wave_wg_kernel_text);

@@ -191,7 +191,9 @@ int dnlp_batch_keep_result_rows(dnlp_problem* p, int on);
 int dnlp_batch_result_rows(dnlp_problem* p, const double** rows, int64_t* n_rows, int64_t* width);
 
 /* What the LAST dnlp_solve_batch* call of this handle launched (diagnostics; the reference has no counterpart —
- * its loop of problems/problem.py:1256-1269 is serial).  out[0] grid, [1] lanes per workgroup, [2] LDS mode,
+ * its loop of problems/problem.py:1256-1269 is serial).  out[0] grid, [1] lanes per workgroup, [2] LDS mode
+ * (wavefront solver: 2 x state in LDS + plan in LDS, + 4 when the kernel was compiled for this template at run time,
+ * + 8 when that was the workgroup-per-instance kernel: [1] / 64 wavefronts per instance, [3] workgroups per unit),
  * [3] instances resident per compute unit, [4] 1 = packed generic kernel, [5] 1 = longest-first order,
  * [6] wavefront solver form (0: the generic kernel; else 100 x wavefronts per workgroup + 10 x state in LDS +
  * plan in LDS; csrc/wave_batch.h), [7] instances the wavefront solver handed to the generic kernel. */

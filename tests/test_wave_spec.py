@@ -315,3 +315,33 @@ def test_workgroup_kernel_runs_in_a_process_that_imported_torch_first(gpu_requir
     row = [l.split() for l in r.stdout.splitlines() if l.startswith("RESULT")][0]
     assert row[1] == "1" and row[2] == "800", row                  # the per-template workgroup kernel, eight wavefronts per instance
     assert int(row[3]) >= 245, row                                   # (250 of the first 256 instances are optimal under every kernel)
+
+
+@pytest.mark.gpu
+def test_small_template_with_a_large_state_takes_the_workgroup_kernel_from_eight_instances_per_unit(gpu_required):
+    """circle packing n = 10 (74 KB of state: two wavefronts per compute unit in the one-wavefront kernels): from 2048 instances
+    on a launch takes the workgroup-per-instance kernel in its second form — two wavefronts per instance, four workgroups per
+    compute unit, hot arrays in a quarter of the LDS each (csrc/batch.h wave_wg_prepare) — and solves what the one-wavefront
+    kernel solves; DNLP_WAVE_WG_SMALL=0 keeps the one-wavefront kernel."""
+    prob, params, sample, _ = bp.template_circle_packing(10)
+    pb = ParametricBatch(prob, params)
+    th = np.stack([sample(i) for i in range(2048)])
+    try:
+        a = pb.solve(th)
+        os.environ["DNLP_WAVE_WG_SMALL"] = "0"
+        b = pb.solve(th)
+    finally:
+        os.environ.pop("DNLP_WAVE_WG_SMALL", None)
+    la, lb = a.raw["launch"], b.raw["launch"]
+    assert la["wave_wg"] and la["lanes"] == 128 and la["per_cu"] == 4 and la["wave_form"] == 200, la
+    assert lb["wave_spec"] and not lb["wave_wg"] and lb["wave_form"] == 210, lb
+    assert (a.status == 0).all() and (b.status == 0).all()
+    # (a non-convex problem and two summation orders: the same optimum on nearly every instance, another local one on a few)
+    rel = np.abs(a.obj_val - b.obj_val) / np.maximum(1.0, np.abs(b.obj_val))
+    print("same optimum on", float((rel <= 1e-6).mean()), "mean iterations", float(a.iterations.mean()), float(b.iterations.mean()))
+    assert (rel <= 1e-6).mean() >= 0.9
+    assert abs(a.iterations.mean() - b.iterations.mean()) <= 0.05 * b.iterations.mean()
+    # a launch below eight instances per compute unit keeps the one-wavefront kernel
+    c = pb.solve(th[:1024])
+    assert not c.raw["launch"]["wave_wg"] and c.raw["launch"]["wave_spec"]
+    pb.close()
