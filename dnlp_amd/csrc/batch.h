@@ -493,7 +493,7 @@ struct BatchRunner {
     int nwg = std::getenv("DNLP_WAVE_WG_WAVES") ? std::atoi(std::getenv("DNLP_WAVE_WG_WAVES")) : (sl_form ? 2 : 8);
     if (nwg < 1 || nwg > 8) nwg = sl_form ? 2 : 8;
     int share = std::getenv("DNLP_WAVE_WG_SHARE") ? std::atoi(std::getenv("DNLP_WAVE_WG_SHARE")) : (sl_form ? 4 : 1);
-    if (share < 1 || share > 8) share = 1;
+    if (share < 1 || share > 16) share = 1;
     const double t0 = now_sec();
     if (wave_wg_blk.empty() && !wave_wg_plan()) return false;
     if (wave_wg_blk.size() < sizeof(WaveHdr) / 4) return false;
@@ -1262,7 +1262,7 @@ struct BatchRunner {
       const int per_unit = spec ? wave_spec_nw : nw;                    // (wavefronts = instances per compute unit of the kernel above)
       const char* ws = std::getenv("DNLP_WAVE_WG_SMALL");
       const int wsm = ws ? std::atoi(ws) : -1;
-      wg_small = wsm != 0 && per_unit <= 2 && (wsm == 1 || batch >= 8 * this->ncu);
+      wg_small = wsm == 2 || (wsm != 0 && per_unit <= 2 && (wsm == 1 || batch >= 8 * this->ncu));      // (2: whatever the template — experiments)
     }
     const bool wg = (!sl || wg_small) && !std::getenv("DNLP_WAVE_FORM") && wave_wg_prepare(batch);
     if (wg) spec = false;
