@@ -247,8 +247,20 @@ def load() -> CApi:
     lib.dnlp_ldlt_device.restype = C.c_int
     lib.dnlp_ldlt_device.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64,
                                      C.POINTER(C.c_int), C.POINTER(C.c_int), _dbl_p, _dbl_p]
+    lib.dnlp_rtc_compiler.restype = C.c_int
+    lib.dnlp_rtc_compiler.argtypes = [C.c_char_p, C.c_size_t]
     _api = api
     return api
+
+
+def rtc_compiler():
+    """(kind, identity) of the compiler the generated kernels of this process go through (include/dnlp_hip.h
+    dnlp_rtc_compiler): kind "hiprtc" — in process, whichever libhiprtc the loader bound first: the one PyTorch ships when
+    torch was imported before this library — or "clang" (DNLP_RTC_COMPILER=clang: the ROCm install's clang++ as a child
+    process); identity = file, size and time: what the kernel cache is keyed by."""
+    buf = C.create_string_buffer(2048)
+    rc = load().lib.dnlp_rtc_compiler(buf, C.c_size_t(len(buf)))
+    return ("clang" if rc == 1 else "hiprtc"), buf.value.decode()
 
 
 def device_count() -> int:
