@@ -859,11 +859,17 @@ struct WaveIpm {
       if constexpr (P::lds_generic) {
         typedef DNLP_WLDS double* LP;
         typedef DNLP_WGLB double* QP;
+        // (a right-hand side somewhere these cases do not name would be read through the wrong address space: stop the kernel
+        //  instead — the launch then fails with a HIP error)
+        const bool xs = __builtin_amdgcn_is_shared(x), ys = y && __builtin_amdgcn_is_shared(y);
         if constexpr (wspec::kSolve2Lds) {
+          if (!xs || (y && !ys)) __builtin_trap();
           if (y) wgen::ldl_solve<P, true>(S, (LP)x, (LP)y); else wgen::ldl_solve<P, false>(S, (LP)x, (LP)nullptr);
-        } else if (__builtin_amdgcn_is_shared(x)) {
+        } else if (xs) {
+          if (ys) __builtin_trap();
           if (y) wgen::ldl_solve<P, true>(S, (LP)x, (QP)y); else wgen::ldl_solve<P, false>(S, (LP)x, (LP)nullptr);
         } else {
+          if (ys) __builtin_trap();
           if (y) wgen::ldl_solve<P, true>(S, (QP)x, (QP)y); else wgen::ldl_solve<P, false>(S, (QP)x, (QP)nullptr);
         }
       } else
