@@ -139,6 +139,11 @@ def test_workgroup_per_instance_kernel_text_compiles_for_gfx950():
     block-wide reductions, every vector in global memory."""
     src = _wg_source("path_planning")
     assert "#define WG_LANES 256" in src and "dnlp_wave_wg_kernel" in src
+    # the narrow phases stage the next phase's table, the chain levels' rows and products go through the LDS windows; every
+    # placeholder of the generator has been resolved
+    assert "@@" not in src and src.count("WG_STAGE_NEXT(") > 100 and src.count("WG_WW(") > 50 and src.count("WG_SW") > 50
+    consts = dict(re.findall(r"constexpr int (\w+) = (-?\d+)[,;]", src))
+    assert 0 < int(consts["kStageWords"]) <= 2048
     ok, log, seconds, code = compile_for_gfx950(src)
     assert ok, log[:4000]
 
