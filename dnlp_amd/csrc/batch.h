@@ -486,7 +486,7 @@ struct BatchRunner {
     // fits but leaves room for only one or two wavefronts per compute unit in the one-wavefront kernels (circle packing n = 10:
     // 74 KB per instance) can take this kernel too — TWO wavefronts per instance, FOUR workgroups per compute unit with a
     // quarter of the LDS each (hot arrays there, the rest in the slab): eight wavefronts per unit instead of two, 173 us per
-    // iteration instead of 138 — 102 k problems/s at 8192 instances against 71 k (solve_wave takes it from 8 instances per
+    // iteration instead of 138 — 102 k problems/s at 8192 instances against 71 k (solve_wave takes it from 6 instances per
     // compute unit on; at 1024 the one-wavefront kernel is as fast: 39 k).
     int sl_form = 0;
     { int nw0 = 0, pl0 = 0; wave_form(nw0, sl_form, pl0); }
@@ -1255,14 +1255,15 @@ struct BatchRunner {
       }
     }
     // a template whose state exceeds LDS: a workgroup per instance through the generated phases when the kernel is there
-    // ... and a template whose state fits, but only once or twice per compute unit: from eight instances per compute unit on
+    // ... and a template whose state fits, but only once or twice per compute unit: from six instances per compute unit on (measured
+    // on circle packing n = 10: 1280 instances 47.2 k problems/s through the one-wavefront kernel / 46.4 k through this one, 1536: 50.2 / 55.1 k)
     // (wave_wg_prepare: two wavefronts per instance, four workgroups per unit).  DNLP_WAVE_WG_SMALL=0 never, =1 at any size.
     bool wg_small = false;
     if (sl && !std::getenv("DNLP_WAVE_FORM")) {
       const int per_unit = spec ? wave_spec_nw : nw;                    // (wavefronts = instances per compute unit of the kernel above)
       const char* ws = std::getenv("DNLP_WAVE_WG_SMALL");
       const int wsm = ws ? std::atoi(ws) : -1;
-      wg_small = wsm == 2 || (wsm != 0 && per_unit <= 2 && (wsm == 1 || batch >= 8 * this->ncu));      // (2: whatever the template — experiments)
+      wg_small = wsm == 2 || (wsm != 0 && per_unit <= 2 && (wsm == 1 || batch >= 6 * this->ncu));      // (2: whatever the template — experiments)
     }
     const bool wg = (!sl || wg_small) && !std::getenv("DNLP_WAVE_FORM") && wave_wg_prepare(batch);
     if (wg) spec = false;

@@ -323,8 +323,8 @@ def test_workgroup_kernel_runs_in_a_process_that_imported_torch_first(gpu_requir
 
 
 @pytest.mark.gpu
-def test_small_template_with_a_large_state_takes_the_workgroup_kernel_from_eight_instances_per_unit(gpu_required):
-    """circle packing n = 10 (74 KB of state: two wavefronts per compute unit in the one-wavefront kernels): from 2048 instances
+def test_small_template_with_a_large_state_takes_the_workgroup_kernel_from_six_instances_per_unit(gpu_required):
+    """circle packing n = 10 (74 KB of state: two wavefronts per compute unit in the one-wavefront kernels): from 1536 instances
     on a launch takes the workgroup-per-instance kernel in its second form — two wavefronts per instance, four workgroups per
     compute unit, hot arrays in a quarter of the LDS each (csrc/batch.h wave_wg_prepare) — and solves what the one-wavefront
     kernel solves; DNLP_WAVE_WG_SMALL=0 keeps the one-wavefront kernel."""
@@ -346,7 +346,7 @@ def test_small_template_with_a_large_state_takes_the_workgroup_kernel_from_eight
     print("same optimum on", float((rel <= 1e-6).mean()), "mean iterations", float(a.iterations.mean()), float(b.iterations.mean()))
     assert (rel <= 1e-6).mean() >= 0.9
     assert abs(a.iterations.mean() - b.iterations.mean()) <= 0.05 * b.iterations.mean()
-    # a launch below eight instances per compute unit keeps the one-wavefront kernel
+    # a launch below six instances per compute unit keeps the one-wavefront kernel
     c = pb.solve(th[:1024])
     assert not c.raw["launch"]["wave_wg"] and c.raw["launch"]["wave_spec"]
     pb.close()

@@ -50,7 +50,7 @@ members)
   for W in circle_packing circle_packing10 path_planning power_flow; do
     timeout 600 python3 bench.py --workload c5 --which $W --batch 1024 --steps 4 --warmup 1 2>/dev/null | grep "^{" | tail -1 >> $O/c5_members.jsonl
   done
-  # (circle packing n = 10 again at 8192 instances: from 2048 on it runs the workgroup kernel's second form — two wavefronts per
+  # (circle packing n = 10 again at 8192 instances: from 1536 on it runs the workgroup kernel's second form — two wavefronts per
   #  instance, four workgroups per compute unit)
   timeout 600 python3 bench.py --workload c5 --which circle_packing10 --batch 8192 --steps 3 --warmup 1 --no-cpu 2>/dev/null | grep "^{" | tail -1 >> $O/c5_members.jsonl
   python3 -c "
